@@ -1,0 +1,1162 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.  Never linked, imported or executed by the product path
+// (lasso_amd/); only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it.
+//
+// Serial CPU restatement of the reference's Lasso prover and verifier (a16z/Lasso @ /root/reference),
+// written to follow the reference function by function; every block cites the file:line it follows.
+// Parity status: the reference holds NO golden vectors for commitments, proofs or
+// transcripts and cannot be built here (no Rust toolchain), so byte-level parity with the reference
+// binary is UNPINNED.  What IS pinned (tests/): field arithmetic vs Python big ints; every
+// small-integer KAT the reference's own unit tests hold (dense_mlpoly.rs:435-458 -> 28,
+// unipoly.rs:128-189, grand_product.rs:269-283 -> 24, sumcheck.rs:458-513 scripted r=[3,1,3],
+// table KATs and MLE parity for and/or/xor/lt/range_check); Merlin vs its published vector; and the
+// reference's own acceptance criterion, prove -> verify == Ok, for the four e2e_test.rs configurations.
+#pragma once
+#include "ff.hpp"
+#include "ed25519.hpp"
+#include "hashes.hpp"
+#include <vector>
+#include <functional>
+#include <stdexcept>
+#include <string>
+#include <algorithm>
+
+namespace orc {
+
+#define ORC_ASSERT(c) do { if (!(c)) throw std::runtime_error(std::string("oracle assert failed: ") + #c + " @" + std::to_string(__LINE__)); } while (0)
+
+// ---------------------------------------------------------------- utils/math.rs:1-36
+inline size_t pow2(size_t k) { return (size_t)1 << k; }
+inline bool is_pow2(size_t n) { return n != 0 && (n & (n - 1)) == 0; }
+inline size_t next_pow2(size_t n) { size_t p = 1; while (p < n) p <<= 1; return p; }
+inline size_t log_2(size_t n) {  // utils/math.rs:27-35: exact for powers of two, else ceil
+  ORC_ASSERT(n != 0);
+  size_t fl = 63 - __builtin_clzll((unsigned long long)n);
+  return is_pow2(n) ? fl : fl + 1;
+}
+inline size_t ark_log2(size_t x) {  // ark_std::log2 = ceil(log2 x), log2(0)=log2(1)=0
+  if (x <= 1) return 0;
+  return 64 - __builtin_clzll((unsigned long long)(x - 1));
+}
+
+// ---------------------------------------------------------------- utils/transcript.rs:6-72
+struct ProofTranscript {
+  virtual ~ProofTranscript() {}
+  virtual void append_message(const char* label, const uint8_t* msg, size_t n) = 0;
+  virtual void challenge_bytes(const char* label, uint8_t* out, size_t n) = 0;
+  virtual Fr challenge_scalar(const char* label) {  // :61-65
+    uint8_t buf[64]; challenge_bytes(label, buf, 64);
+    return Fr::from_le_bytes_mod_order(buf, 64);
+  }
+  virtual std::vector<Fr> challenge_vector(const char* label, size_t len) {  // :67-71
+    std::vector<Fr> v; for (size_t i = 0; i < len; i++) v.push_back(challenge_scalar(label)); return v;
+  }
+  void append_message(const char* label, const char* msg) { append_message(label, (const uint8_t*)msg, strlen(msg)); }
+  void append_u64(const char* label, uint64_t x) { uint8_t b[8]; for (int i = 0; i < 8; i++) b[i] = (uint8_t)(x >> (8 * i)); append_message(label, b, 8); }
+  void append_protocol_name(const char* name) { append_message("protocol-name", name); }  // :29-31
+  void append_scalar(const char* label, const Fr& s) { uint8_t b[32]; s.to_bytes_le(b); append_message(label, b, 32); }  // :33-37
+  void append_scalars(const char* label, const std::vector<Fr>& v) {  // :39-45
+    append_message(label, "begin_append_vector");
+    for (auto& s : v) append_scalar(label, s);
+    append_message(label, "end_append_vector");
+  }
+  void append_point(const char* label, const Point& p) { uint8_t b[32]; p.compress(b); append_message(label, b, 32); }  // :47-51
+};
+struct MerlinTranscript : ProofTranscript {
+  Transcript t;
+  explicit MerlinTranscript(const char* label) : t(label) {}
+  using ProofTranscript::append_message;
+  void append_message(const char* label, const uint8_t* msg, size_t n) override { t.append_message(label, msg, n); }
+  void challenge_bytes(const char* label, uint8_t* out, size_t n) override { t.challenge_bytes(label, out, n); }
+};
+// utils/test.rs:35-128 TestTranscript: scripted challenges, appends still feed a real Merlin transcript
+struct ScriptedTranscript : MerlinTranscript {
+  std::vector<Fr> scalars; size_t scalar_index = 0;
+  std::vector<std::vector<Fr>> vecs; size_t vec_index = 0;
+  ScriptedTranscript(std::vector<Fr> s, std::vector<std::vector<Fr>> v) : MerlinTranscript("transcript"), scalars(std::move(s)), vecs(std::move(v)) {}
+  Fr challenge_scalar(const char*) override { ORC_ASSERT(scalar_index < scalars.size()); return scalars[scalar_index++]; }
+  std::vector<Fr> challenge_vector(const char*, size_t len) override { ORC_ASSERT(vec_index < vecs.size()); auto r = vecs[vec_index++]; ORC_ASSERT(r.size() == len); return r; }
+};
+
+// ark-ff `Fp::rand` (UniformRand): 4 x next_u64 taken directly as the Montgomery representation,
+// top bits masked, rejection-sampled below the modulus.  (third-party; restated, unpinned)
+template <class F, class P>
+inline F field_rand(ChaChaRng& rng) {
+  for (;;) {
+    u64 l[4]; for (int i = 0; i < 4; i++) l[i] = rng.next_u64();
+    l[3] &= (~(u64)0) >> (256 - P::MODULUS_BITS);
+    if (!F::geq_p(l)) return F::from_raw(l);
+  }
+}
+inline Fr fr_rand(ChaChaRng& rng) { return field_rand<Fr, FrParams>(rng); }
+inline Fq fq_rand(ChaChaRng& rng) { return field_rand<Fq, FqParams>(rng); }
+
+// ark-ec TE `Projective::rand`: y <- Fq::rand, greatest <- bool, point from y, times cofactor 8
+inline Point point_rand(ChaChaRng& rng) {
+  for (;;) {
+    Fq y = fq_rand(rng);
+    bool greatest = ((int32_t)rng.next_u32()) < 0;
+    Fq xs, xl;
+    if (ed_xs_from_y(y, xs, xl)) { Point p = Point::from_affine(greatest ? xl : xs, y); return p.dbl().dbl().dbl(); }
+  }
+}
+
+// ---------------------------------------------------------------- utils/random.rs:9-39
+struct RandomTape {
+  MerlinTranscript tape;
+  explicit RandomTape(const char* name) : tape(name) {
+    ChaChaRng prng = test_rng();
+    tape.append_scalar("init_randomness", fr_rand(prng));
+  }
+  Fr random_scalar(const char* label) { return tape.challenge_scalar(label); }
+  std::vector<Fr> random_vector(const char* label, size_t len) { return tape.challenge_vector(label, len); }
+};
+
+// ---------------------------------------------------------------- poly/commitments.rs:15-94
+struct MultiCommitGens {
+  size_t n; std::vector<Point> G; Point h;
+  MultiCommitGens() : n(0) {}
+  static MultiCommitGens create(size_t n, const char* label) {  // :22-44
+    Shake256 shake;
+    shake.absorb((const uint8_t*)label, strlen(label));
+    uint8_t buf[32]; Point::generator().compress(buf);
+    shake.absorb(buf, 32);
+    uint8_t seed[32]; shake.squeeze(seed, 32);
+    ChaChaRng rng(seed, 20);
+    std::vector<Point> gens; for (size_t i = 0; i < n + 1; i++) gens.push_back(point_rand(rng));
+    MultiCommitGens g; g.n = n; g.G.assign(gens.begin(), gens.begin() + n); g.h = gens[n]; return g;
+  }
+  std::pair<MultiCommitGens, MultiCommitGens> split_at(size_t mid) const {  // :54-69
+    MultiCommitGens a, b; a.n = mid; a.G.assign(G.begin(), G.begin() + mid); a.h = h;
+    b.n = G.size() - mid; b.G.assign(G.begin() + mid, G.end()); b.h = h; return {a, b};
+  }
+};
+
+// ---------------------------------------------------------------- msm/mod.rs:91-164, :277-325
+inline size_t ln_without_floats(size_t a) { return ark_log2(a) * 69 / 100; }  // :322-325
+inline std::vector<int64_t> make_digits(const u64* scalar, size_t w, size_t num_bits) {  // :277-316
+  u64 radix = (u64)1 << w, window_mask = radix - 1, carry = 0;
+  size_t digits_count = (num_bits + w - 1) / w;
+  std::vector<int64_t> digits(digits_count, 0);
+  for (size_t i = 0; i < digits_count; i++) {
+    size_t bit_offset = i * w, u64_idx = bit_offset / 64, bit_idx = bit_offset % 64;
+    u64 bit_buf;
+    if (bit_idx < 64 - w || u64_idx == 3) bit_buf = scalar[u64_idx] >> bit_idx;
+    else bit_buf = (scalar[u64_idx] >> bit_idx) | (scalar[1 + u64_idx] << (64 - bit_idx));
+    u64 coef = carry + (bit_buf & window_mask);
+    carry = (coef + radix / 2) >> w;
+    digits[i] = (int64_t)coef - (int64_t)(carry << w);
+  }
+  digits[digits_count - 1] += (int64_t)(carry << w);
+  return digits;
+}
+// `VariableBaseMSM::msm` -> msm_bigint_wnaf (TE groups have NEGATION_IS_CHEAP) with the small-scalar
+// early-exit hack :95-106
+inline Point msm(const std::vector<Point>& bases, const std::vector<Fr>& scalars) {
+  ORC_ASSERT(bases.size() == scalars.size());  // msm() :36-40 returns Err on mismatch; callers unwrap
+  size_t size = bases.size();
+  if (size == 0) return Point::identity();
+  std::vector<std::array<u64, 4>> bigints(size);
+  for (size_t i = 0; i < size; i++) scalars[i].to_canonical(bigints[i].data());
+  size_t max_num_bits = 1;
+  for (auto& b : bigints) {
+    size_t nb = 0; for (int i = 3; i >= 0; i--) if (b[i]) { nb = 64 * i + (64 - __builtin_clzll(b[i])); break; }
+    if (nb > max_num_bits) max_num_bits = nb;
+    if (max_num_bits > 60) { max_num_bits = FrParams::MODULUS_BITS; break; }
+  }
+  size_t c = size < 32 ? 3 : ln_without_floats(size) + 2;
+  size_t num_bits = max_num_bits, digits_count = (num_bits + c - 1) / c;
+  std::vector<int64_t> scalar_digits; scalar_digits.reserve(size * digits_count);
+  for (auto& b : bigints) { auto d = make_digits(b.data(), c, num_bits); scalar_digits.insert(scalar_digits.end(), d.begin(), d.end()); }
+  std::vector<Point> window_sums(digits_count);
+  for (size_t i = 0; i < digits_count; i++) {
+    std::vector<Point> buckets((size_t)1 << c, Point::identity());
+    for (size_t k = 0; k < size; k++) {
+      int64_t s = scalar_digits[k * digits_count + i];
+      if (s > 0) buckets[(size_t)(s - 1)] += bases[k];
+      else if (s < 0) buckets[(size_t)(-s - 1)] += bases[k].neg();
+    }
+    Point running = Point::identity(), res = Point::identity();
+    for (size_t b = buckets.size(); b-- > 0;) { running += buckets[b]; res += running; }
+    window_sums[i] = res;
+  }
+  Point total = Point::identity();
+  for (size_t i = digits_count; i-- > 1;) { total += window_sums[i]; for (size_t k = 0; k < c; k++) total = total.dbl(); }
+  return window_sums[0] + total;
+}
+// commitments.rs:77-93
+inline Point commit_scalar(const Fr& v, const Fr& blind, const MultiCommitGens& gens_n) { ORC_ASSERT(gens_n.n == 1); return gens_n.G[0] * v + gens_n.h * blind; }
+inline Point batch_commit(const Fr* inputs, size_t n, const Fr& blind, const MultiCommitGens& gens_n) {
+  ORC_ASSERT(gens_n.n == n);
+  std::vector<Point> bases(gens_n.G); bases.push_back(gens_n.h);
+  std::vector<Fr> scalars(inputs, inputs + n); scalars.push_back(blind);
+  return msm(bases, scalars);
+}
+
+// ---------------------------------------------------------------- poly/eq_poly.rs:9-53
+struct EqPolynomial {
+  std::vector<Fr> r;
+  explicit EqPolynomial(std::vector<Fr> r_) : r(std::move(r_)) {}
+  Fr evaluate(const std::vector<Fr>& rx) const {  // :14-19
+    ORC_ASSERT(r.size() == rx.size());
+    Fr p = Fr::one();
+    for (size_t i = 0; i < rx.size(); i++) p = p * (r[i] * rx[i] + (Fr::one() - r[i]) * (Fr::one() - rx[i]));
+    return p;
+  }
+  std::vector<Fr> evals() const {  // :22-38
+    size_t ell = r.size();
+    std::vector<Fr> ev(pow2(ell), Fr::one());
+    size_t size = 1;
+    for (size_t j = 0; j < ell; j++) {
+      size *= 2;
+      for (size_t i = size; i-- > 0;) {
+        if (i % 2 == 0) continue;  // (0..size).rev().step_by(2): i = size-1, size-3, ..., 1
+        Fr scalar = ev[i / 2];
+        ev[i] = scalar * r[j];
+        ev[i - 1] = scalar - ev[i];
+      }
+    }
+    return ev;
+  }
+  static std::pair<size_t, size_t> compute_factored_lens(size_t ell) { return {ell / 2, ell - ell / 2}; }  // :40-42
+  std::pair<std::vector<Fr>, std::vector<Fr>> compute_factored_evals() const {  // :44-52
+    size_t ell = r.size(), left = ell / 2;
+    return {EqPolynomial(std::vector<Fr>(r.begin(), r.begin() + left)).evals(), EqPolynomial(std::vector<Fr>(r.begin() + left, r.end())).evals()};
+  }
+};
+
+// ---------------------------------------------------------------- subprotocols/dot_product.rs:139-150, poly/dense_mlpoly.rs:34-45
+struct DotProductProofGens {
+  size_t n; MultiCommitGens gens_n, gens_1;
+  static DotProductProofGens create(size_t n, const char* label) {
+    auto pr = MultiCommitGens::create(n + 1, label).split_at(n);
+    DotProductProofGens g; g.n = n; g.gens_n = pr.first; g.gens_1 = pr.second; return g;
+  }
+};
+struct PolyCommitmentGens {
+  DotProductProofGens gens;
+  static PolyCommitmentGens create(size_t num_vars, const char* label) {
+    size_t right = EqPolynomial::compute_factored_lens(num_vars).second;
+    PolyCommitmentGens g; g.gens = DotProductProofGens::create(pow2(right), label); return g;
+  }
+};
+typedef std::vector<Point> PolyCommitment;  // dense_mlpoly.rs:51-54 { C: Vec<G> }
+
+// ---------------------------------------------------------------- utils/mod.rs:64-73
+inline Fr compute_dotproduct(const Fr* a, const Fr* b, size_t n) { Fr s = Fr::zero(); for (size_t i = 0; i < n; i++) s += a[i] * b[i]; return s; }
+
+// ---------------------------------------------------------------- poly/dense_mlpoly.rs:28-279
+struct DensePolynomial {
+  size_t num_vars, len; std::vector<Fr> Z;
+  DensePolynomial() : num_vars(0), len(0) {}
+  explicit DensePolynomial(std::vector<Fr> z) : Z(std::move(z)) {  // new :62-73
+    ORC_ASSERT(is_pow2(Z.size()));
+    num_vars = log_2(Z.size()); len = Z.size();
+  }
+  static DensePolynomial new_padded(std::vector<Fr> ev) {  // :75-87
+    while (!is_pow2(ev.size())) ev.push_back(Fr::zero());
+    return DensePolynomial(std::move(ev));
+  }
+  DensePolynomial clone() const { return DensePolynomial(std::vector<Fr>(Z.begin(), Z.begin() + len)); }  // :97-99
+  std::pair<DensePolynomial, DensePolynomial> split(size_t idx) const {  // :101-107
+    ORC_ASSERT(idx < len);
+    return {DensePolynomial(std::vector<Fr>(Z.begin(), Z.begin() + idx)), DensePolynomial(std::vector<Fr>(Z.begin() + idx, Z.begin() + 2 * idx))};
+  }
+  const Fr& operator[](size_t i) const { return Z[i]; }
+  PolyCommitment commit(const PolyCommitmentGens& gens) const {  // commit :153-181 with random_tape=None (blinds = 0); commit_inner :110-150
+    size_t n = Z.size(), ell = num_vars;
+    ORC_ASSERT(n == pow2(ell));
+    auto lr = EqPolynomial::compute_factored_lens(ell);
+    size_t L_size = pow2(lr.first), R_size = pow2(lr.second);
+    ORC_ASSERT(L_size * R_size == n);
+    PolyCommitment C;
+    for (size_t i = 0; i < L_size; i++) C.push_back(batch_commit(&Z[R_size * i], R_size, Fr::zero(), gens.gens.gens_n));
+    return C;
+  }
+  std::vector<Fr> bound(const std::vector<Fr>& L) const {  // :184-207
+    auto lr = EqPolynomial::compute_factored_lens(num_vars);
+    size_t L_size = pow2(lr.first), R_size = pow2(lr.second);
+    std::vector<Fr> out(R_size, Fr::zero());
+    for (size_t i = 0; i < R_size; i++) { Fr s = Fr::zero(); for (size_t j = 0; j < L_size; j++) s += L[j] * Z[j * R_size + i]; out[i] = s; }
+    return out;
+  }
+  void bound_poly_var_top(const Fr& r) {  // :209-216
+    size_t n = len / 2;
+    for (size_t i = 0; i < n; i++) Z[i] = Z[i] + r * (Z[i + n] - Z[i]);
+    num_vars -= 1; len = n;
+  }
+  void bound_poly_var_bot(const Fr& r) {  // :218-225
+    size_t n = len / 2;
+    for (size_t i = 0; i < n; i++) Z[i] = Z[2 * i] + r * (Z[2 * i + 1] - Z[2 * i]);
+    num_vars -= 1; len = n;
+  }
+  Fr evaluate(const std::vector<Fr>& r) const {  // :229-235
+    ORC_ASSERT(r.size() == num_vars);
+    auto chis = EqPolynomial(r).evals();
+    ORC_ASSERT(chis.size() == Z.size());
+    return compute_dotproduct(Z.data(), chis.data(), Z.size());
+  }
+  static DensePolynomial merge(const std::vector<DensePolynomial>& polys) {  // :251-261
+    std::vector<Fr> Z;
+    for (auto& p : polys) Z.insert(Z.end(), p.Z.begin(), p.Z.end());
+    Z.resize(next_pow2(Z.size()), Fr::zero());
+    return DensePolynomial(std::move(Z));
+  }
+  static DensePolynomial from_usize(const std::vector<size_t>& v) {  // :263-269
+    std::vector<Fr> Z; Z.reserve(v.size());
+    for (size_t x : v) Z.push_back(Fr::from_u64((u64)x));
+    return DensePolynomial(std::move(Z));
+  }
+};
+inline void append_poly_commitment(ProofTranscript& t, const char* label, const PolyCommitment& C) {  // :281-289
+  t.append_message(label, "poly_commitment_begin");
+  for (auto& p : C) t.append_point("poly_commitment_share", p);
+  t.append_message(label, "poly_commitment_end");
+}
+
+// ---------------------------------------------------------------- utils/gaussian_elimination.rs:9-63
+inline std::vector<Fr> gaussian_elimination(std::vector<std::vector<Fr>>& m) {
+  size_t size = m.size();
+  ORC_ASSERT(size == m[0].size() - 1);
+  for (size_t i = 0; i + 1 < size; i++)
+    for (size_t j = i; j + 1 < size; j++) {  // echelon(matrix, i, j) :39-50
+      if (!m[i][i].is_zero()) {
+        Fr factor = m[j + 1][i] / m[i][i];
+        for (size_t k = i; k < size + 1; k++) { Fr tmp = m[i][k]; m[j + 1][k] -= factor * tmp; }
+      }
+    }
+  for (size_t i = size - 1; i >= 1; i--) {  // eliminate(matrix, i) :52-63
+    if (!m[i][i].is_zero()) {
+      for (size_t j = i; j >= 1; j--) {
+        Fr factor = m[j - 1][i] / m[i][i];
+        for (size_t k = size + 1; k-- > 0;) { Fr tmp = m[i][k]; m[j - 1][k] -= factor * tmp; }
+      }
+    }
+  }
+  std::vector<Fr> result(size);
+  for (size_t i = 0; i < size; i++) result[i] = m[i][size] / m[i][i];
+  return result;
+}
+
+// ---------------------------------------------------------------- poly/unipoly.rs:13-120
+struct CompressedUniPoly { std::vector<Fr> coeffs_except_linear_term; };
+struct UniPoly {
+  std::vector<Fr> coeffs;
+  static UniPoly from_evals(const std::vector<Fr>& evals) {  // :30-54
+    size_t n = evals.size();
+    std::vector<std::vector<Fr>> vand;
+    for (size_t i = 0; i < n; i++) {
+      std::vector<Fr> row; Fr x = Fr::from_u64(i);
+      row.push_back(Fr::one()); row.push_back(x);
+      for (size_t j = 2; j < n; j++) row.push_back(row[j - 1] * x);
+      row.push_back(evals[i]);
+      vand.push_back(row);
+    }
+    UniPoly p; p.coeffs = gaussian_elimination(vand); return p;
+  }
+  size_t degree() const { return coeffs.size() - 1; }
+  Fr eval_at_zero() const { return coeffs[0]; }
+  Fr eval_at_one() const { Fr s = Fr::zero(); for (auto& c : coeffs) s += c; return s; }
+  Fr evaluate(const Fr& r) const {  // :72-80
+    Fr eval = coeffs[0], power = r;
+    for (size_t i = 1; i < coeffs.size(); i++) { eval += power * coeffs[i]; power *= r; }
+    return eval;
+  }
+  CompressedUniPoly compress() const {  // :82-88
+    CompressedUniPoly c; c.coeffs_except_linear_term.push_back(coeffs[0]);
+    c.coeffs_except_linear_term.insert(c.coeffs_except_linear_term.end(), coeffs.begin() + 2, coeffs.end());
+    return c;
+  }
+  void append_to_transcript(ProofTranscript& t, const char* label) const {  // :112-120
+    t.append_message(label, "UniPoly_begin");
+    for (auto& c : coeffs) t.append_scalar("coeff", c);
+    t.append_message(label, "UniPoly_end");
+  }
+};
+inline UniPoly decompress(const CompressedUniPoly& c, const Fr& hint) {  // :96-109
+  auto& v = c.coeffs_except_linear_term;
+  Fr linear = hint - v[0] - v[0];
+  for (size_t i = 1; i < v.size(); i++) linear -= v[i];
+  UniPoly p; p.coeffs.push_back(v[0]); p.coeffs.push_back(linear);
+  p.coeffs.insert(p.coeffs.end(), v.begin() + 1, v.end());
+  return p;
+}
+
+// ---------------------------------------------------------------- subprotocols/sumcheck.rs:25-329
+struct SumcheckInstanceProof { std::vector<CompressedUniPoly> compressed_polys; };
+
+struct CubicClaims { std::vector<Fr> a, b; Fr c; };
+// prove_cubic_batched :27-135 with comb_func = A*B*C (grand_product.rs:126-128)
+inline SumcheckInstanceProof prove_cubic_batched(const Fr& claim, size_t num_rounds, std::vector<DensePolynomial*>& A, std::vector<DensePolynomial*>& B,
+                                                 DensePolynomial& C, const std::vector<Fr>& coeffs, ProofTranscript& t, std::vector<Fr>& r_out, CubicClaims& claims) {
+  Fr e = claim;
+  SumcheckInstanceProof proof;
+  for (size_t j = 0; j < num_rounds; j++) {
+    std::vector<Fr> e0(A.size()), e2(A.size()), e3(A.size());
+    for (size_t c = 0; c < A.size(); c++) {
+      const DensePolynomial& pa = *A[c]; const DensePolynomial& pb = *B[c];
+      Fr p0 = Fr::zero(), p2 = Fr::zero(), p3 = Fr::zero();
+      size_t len = pa.len / 2;
+      for (size_t i = 0; i < len; i++) {
+        p0 += pa[i] * pb[i] * C[i];
+        Fr a2 = pa[len + i] + pa[len + i] - pa[i], b2 = pb[len + i] + pb[len + i] - pb[i], c2 = C[len + i] + C[len + i] - C[i];
+        p2 += a2 * b2 * c2;
+        Fr a3 = a2 + pa[len + i] - pa[i], b3 = b2 + pb[len + i] - pb[i], c3 = c2 + C[len + i] - C[i];
+        p3 += a3 * b3 * c3;
+      }
+      e0[c] = p0; e2[c] = p2; e3[c] = p3;
+    }
+    Fr c0 = Fr::zero(), c2 = Fr::zero(), c3 = Fr::zero();
+    for (size_t i = 0; i < A.size(); i++) { c0 += e0[i] * coeffs[i]; c2 += e2[i] * coeffs[i]; c3 += e3[i] * coeffs[i]; }
+    UniPoly poly = UniPoly::from_evals({c0, e - c0, c2, c3});
+    poly.append_to_transcript(t, "poly");
+    Fr r_j = t.challenge_scalar("challenge_nextround");
+    r_out.push_back(r_j);
+    for (size_t c = 0; c < A.size(); c++) { A[c]->bound_poly_var_top(r_j); B[c]->bound_poly_var_top(r_j); }
+    C.bound_poly_var_top(r_j);
+    e = poly.evaluate(r_j);
+    proof.compressed_polys.push_back(poly.compress());
+  }
+  claims.a.clear(); claims.b.clear();
+  for (size_t c = 0; c < A.size(); c++) { claims.a.push_back((*A[c])[0]); claims.b.push_back((*B[c])[0]); }
+  claims.c = C[0];
+  return proof;
+}
+// prove_arbitrary :150-260
+inline SumcheckInstanceProof prove_arbitrary(size_t num_rounds, std::vector<DensePolynomial>& polys, const std::function<Fr(const Fr*)>& comb_func,
+                                             size_t combined_degree, ProofTranscript& t, std::vector<Fr>& r_out, std::vector<Fr>& final_evals) {
+  SumcheckInstanceProof proof;
+  size_t alpha = polys.size();
+  for (size_t round = 0; round < num_rounds; round++) {
+    std::vector<Fr> eval_points(combined_degree + 1, Fr::zero());
+    size_t mle_half = polys[0].len / 2;
+    std::vector<Fr> lo(alpha), hi(alpha), cur(alpha);
+    for (size_t i = 0; i < mle_half; i++) {
+      for (size_t j = 0; j < alpha; j++) { lo[j] = polys[j][i]; hi[j] = polys[j][mle_half + i]; }
+      eval_points[0] += comb_func(lo.data());
+      eval_points[1] += comb_func(hi.data());
+      cur = hi;
+      for (size_t k = 2; k <= combined_degree; k++) {
+        for (size_t j = 0; j < alpha; j++) cur[j] = cur[j] + hi[j] - lo[j];
+        eval_points[k] += comb_func(cur.data());
+      }
+    }
+    UniPoly up = UniPoly::from_evals(eval_points);
+    up.append_to_transcript(t, "poly");
+    Fr r_j = t.challenge_scalar("challenge_nextround");
+    r_out.push_back(r_j);
+    for (auto& p : polys) p.bound_poly_var_top(r_j);
+    proof.compressed_polys.push_back(up.compress());
+  }
+  final_evals.clear();
+  for (auto& p : polys) final_evals.push_back(p[0]);
+  return proof;
+}
+// verify :286-328
+inline bool sumcheck_verify(const SumcheckInstanceProof& proof, const Fr& claim, size_t num_rounds, size_t degree_bound, ProofTranscript& t, Fr& e_out, std::vector<Fr>& r_out) {
+  Fr e = claim; r_out.clear();
+  ORC_ASSERT(proof.compressed_polys.size() == num_rounds);
+  for (size_t i = 0; i < num_rounds; i++) {
+    UniPoly poly = decompress(proof.compressed_polys[i], e);
+    if (poly.degree() != degree_bound) return false;
+    ORC_ASSERT(poly.eval_at_zero() + poly.eval_at_one() == e);
+    poly.append_to_transcript(t, "poly");
+    Fr r_i = t.challenge_scalar("challenge_nextround");
+    r_out.push_back(r_i);
+    e = poly.evaluate(r_i);
+  }
+  e_out = e; return true;
+}
+
+// ---------------------------------------------------------------- subprotocols/grand_product.rs:14-262
+struct GrandProductCircuit {
+  std::vector<DensePolynomial> left_vec, right_vec;
+  explicit GrandProductCircuit(const DensePolynomial& poly) {  // new :38-58
+    size_t num_layers = log_2(poly.len);
+    auto sp = poly.split(poly.len / 2);
+    left_vec.push_back(sp.first); right_vec.push_back(sp.second);
+    for (size_t i = 0; i + 1 < num_layers; i++) {  // compute_layer :20-36
+      const DensePolynomial& L = left_vec[i]; const DensePolynomial& R = right_vec[i];
+      size_t len = L.len + R.len;
+      std::vector<Fr> ol, orr;
+      for (size_t k = 0; k < len / 4; k++) ol.push_back(L[k] * R[k]);
+      for (size_t k = len / 4; k < len / 2; k++) orr.push_back(L[k] * R[k]);
+      left_vec.push_back(DensePolynomial(ol)); right_vec.push_back(DensePolynomial(orr));
+    }
+  }
+  Fr evaluate() const {  // :60-65
+    size_t len = left_vec.size();
+    ORC_ASSERT(left_vec[len - 1].num_vars == 0 && right_vec[len - 1].num_vars == 0);
+    return left_vec[len - 1][0] * right_vec[len - 1][0];
+  }
+};
+struct LayerProofBatched { SumcheckInstanceProof proof; std::vector<Fr> claims_prod_left, claims_prod_right; };
+struct BatchedGrandProductArgument { std::vector<LayerProofBatched> proof; };
+
+inline BatchedGrandProductArgument bgpa_prove(std::vector<GrandProductCircuit*>& circuits, ProofTranscript& t, std::vector<Fr>& rand_out) {  // :101-201
+  ORC_ASSERT(!circuits.empty());
+  BatchedGrandProductArgument out;
+  size_t num_layers = circuits[0]->left_vec.size();
+  std::vector<Fr> claims_to_verify; for (auto* c : circuits) claims_to_verify.push_back(c->evaluate());
+  std::vector<Fr> rand;
+  for (size_t layer_id = num_layers; layer_id-- > 0;) {
+    size_t len = circuits[0]->left_vec[layer_id].len + circuits[0]->right_vec[layer_id].len;
+    DensePolynomial poly_C(EqPolynomial(rand).evals());
+    ORC_ASSERT(poly_C.len == len / 2);
+    size_t num_rounds_prod = log_2(poly_C.len);
+    std::vector<DensePolynomial*> A, B;
+    for (auto* c : circuits) { A.push_back(&c->left_vec[layer_id]); B.push_back(&c->right_vec[layer_id]); }
+    std::vector<Fr> coeff_vec = t.challenge_vector("rand_coeffs_next_layer", claims_to_verify.size());
+    Fr claim = Fr::zero(); for (size_t i = 0; i < claims_to_verify.size(); i++) claim += claims_to_verify[i] * coeff_vec[i];
+    std::vector<Fr> rand_prod; CubicClaims cl;
+    LayerProofBatched lp;
+    lp.proof = prove_cubic_batched(claim, num_rounds_prod, A, B, poly_C, coeff_vec, t, rand_prod, cl);
+    lp.claims_prod_left = cl.a; lp.claims_prod_right = cl.b;
+    for (size_t i = 0; i < circuits.size(); i++) { t.append_scalar("claim_prod_left", cl.a[i]); t.append_scalar("claim_prod_right", cl.b[i]); }
+    Fr r_layer = t.challenge_scalar("challenge_r_layer");
+    claims_to_verify.clear();
+    for (size_t i = 0; i < circuits.size(); i++) claims_to_verify.push_back(cl.a[i] + r_layer * (cl.b[i] - cl.a[i]));
+    std::vector<Fr> ext{r_layer}; ext.insert(ext.end(), rand_prod.begin(), rand_prod.end()); rand = ext;
+    out.proof.push_back(lp);
+  }
+  rand_out = rand; return out;
+}
+inline void bgpa_verify(const BatchedGrandProductArgument& p, const std::vector<Fr>& claims_prod_vec, size_t len, ProofTranscript& t, std::vector<Fr>& claims_out, std::vector<Fr>& rand_out) {  // :203-261
+  size_t num_layers = log_2(len);
+  std::vector<Fr> rand;
+  ORC_ASSERT(p.proof.size() == num_layers);
+  std::vector<Fr> claims_to_verify = claims_prod_vec;
+  for (size_t i = 0; i < num_layers; i++) {
+    size_t num_rounds = i;
+    std::vector<Fr> coeff_vec = t.challenge_vector("rand_coeffs_next_layer", claims_to_verify.size());
+    Fr claim = Fr::zero(); for (size_t k = 0; k < claims_to_verify.size(); k++) claim += claims_to_verify[k] * coeff_vec[k];
+    Fr claim_last; std::vector<Fr> rand_prod;
+    ORC_ASSERT(sumcheck_verify(p.proof[i].proof, claim, num_rounds, 3, t, claim_last, rand_prod));
+    auto& cl = p.proof[i].claims_prod_left; auto& cr = p.proof[i].claims_prod_right;
+    ORC_ASSERT(cl.size() == claims_prod_vec.size() && cr.size() == claims_prod_vec.size());
+    for (size_t k = 0; k < claims_prod_vec.size(); k++) { t.append_scalar("claim_prod_left", cl[k]); t.append_scalar("claim_prod_right", cr[k]); }
+    ORC_ASSERT(rand.size() == rand_prod.size());
+    Fr eq = Fr::one();
+    for (size_t k = 0; k < rand.size(); k++) eq *= rand[k] * rand_prod[k] + (Fr::one() - rand[k]) * (Fr::one() - rand_prod[k]);
+    Fr claim_expected = Fr::zero();
+    for (size_t k = 0; k < claims_prod_vec.size(); k++) claim_expected += coeff_vec[k] * (cl[k] * cr[k] * eq);
+    ORC_ASSERT(claim_expected == claim_last);
+    Fr r_layer = t.challenge_scalar("challenge_r_layer");
+    claims_to_verify.clear();
+    for (size_t k = 0; k < cl.size(); k++) claims_to_verify.push_back(cl[k] + r_layer * (cr[k] - cl[k]));
+    std::vector<Fr> ext{r_layer}; ext.insert(ext.end(), rand_prod.begin(), rand_prod.end()); rand = ext;
+  }
+  claims_out = claims_to_verify; rand_out = rand;
+}
+
+// ---------------------------------------------------------------- subprotocols/bullet.rs:23-275
+struct BulletReductionProof { std::vector<Point> L_vec, R_vec; };
+inline Fr inner_product(const Fr* a, const Fr* b, size_t n) { Fr o = Fr::zero(); for (size_t i = 0; i < n; i++) o += a[i] * b[i]; return o; }
+struct BulletOut { BulletReductionProof proof; Point Gamma_hat; Fr a_hat, b_hat; Point g_hat; Fr blind_fin; };
+inline BulletOut bullet_prove(ProofTranscript& t, const Point& Q, const std::vector<Point>& G_vec, const Point& H, const std::vector<Fr>& a_vec,
+                              const std::vector<Fr>& b_vec, const Fr& blind, const std::vector<std::pair<Fr, Fr>>& blinds_vec) {  // prove :40-154
+  std::vector<Point> G = G_vec; std::vector<Fr> a = a_vec, b = b_vec;
+  size_t n = G.size();
+  ORC_ASSERT(is_pow2(n));
+  size_t lg_n = log_2(n);
+  ORC_ASSERT(a.size() == n && b.size() == n && blinds_vec.size() == 2 * lg_n);
+  BulletOut out; Fr blind_fin = blind; size_t bi = 0;
+  while (n != 1) {
+    n /= 2;
+    Fr c_L = inner_product(&a[0], &b[n], n), c_R = inner_product(&a[n], &b[0], n);
+    const Fr& blind_L = blinds_vec[bi].first; const Fr& blind_R = blinds_vec[bi].second; bi++;
+    std::vector<Fr> sc(a.begin(), a.begin() + n); sc.push_back(c_L); sc.push_back(blind_L);
+    std::vector<Point> bs(G.begin() + n, G.begin() + 2 * n); bs.push_back(Q); bs.push_back(H);
+    Point L = msm(bs, sc);
+    sc.assign(a.begin() + n, a.begin() + 2 * n); sc.push_back(c_R); sc.push_back(blind_R);
+    bs.assign(G.begin(), G.begin() + n); bs.push_back(Q); bs.push_back(H);
+    Point R = msm(bs, sc);
+    t.append_point("L", L); t.append_point("R", R);
+    Fr u = t.challenge_scalar("u"), u_inv = u.inverse();
+    for (size_t i = 0; i < n; i++) {
+      a[i] = a[i] * u + u_inv * a[n + i];
+      b[i] = b[i] * u_inv + u * b[n + i];
+      G[i] = G[i] * u_inv + G[n + i] * u;
+    }
+    blind_fin = blind_fin + blind_L * u * u + blind_R * u_inv * u_inv;
+    out.proof.L_vec.push_back(L); out.proof.R_vec.push_back(R);
+  }
+  out.Gamma_hat = G[0] * a[0] + Q * (a[0] * b[0]) + H * blind_fin;
+  out.a_hat = a[0]; out.b_hat = b[0]; out.g_hat = G[0]; out.blind_fin = blind_fin;
+  return out;
+}
+inline bool bullet_verify(const BulletReductionProof& p, size_t n, const std::vector<Fr>& a, ProofTranscript& t, const Point& Gamma, const std::vector<Point>& G,
+                          Point& G_hat, Point& Gamma_hat, Fr& a_hat) {  // verification_scalars :158-214 + verify :220-257
+  size_t lg_n = p.L_vec.size();
+  if (lg_n >= 32 || n != ((size_t)1 << lg_n)) return false;
+  std::vector<Fr> ch;
+  for (size_t i = 0; i < lg_n; i++) { t.append_point("L", p.L_vec[i]); t.append_point("R", p.R_vec[i]); ch.push_back(t.challenge_scalar("u")); }
+  std::vector<Fr> ch_inv; for (auto& c : ch) ch_inv.push_back(c.inverse());
+  Fr all_inv = Fr::one(); for (auto& c : ch_inv) all_inv *= c;
+  for (size_t i = 0; i < lg_n; i++) { ch[i] = ch[i].square(); ch_inv[i] = ch_inv[i].square(); }
+  std::vector<Fr> s{all_inv};
+  for (size_t i = 1; i < n; i++) {
+    size_t lg_i = 31 - __builtin_clz((uint32_t)i), k = (size_t)1 << lg_i;
+    s.push_back(s[i - k] * ch[(lg_n - 1) - lg_i]);
+  }
+  G_hat = msm(G, s);
+  a_hat = inner_product(a.data(), s.data(), n);
+  std::vector<Point> bases(p.L_vec); bases.insert(bases.end(), p.R_vec.begin(), p.R_vec.end()); bases.push_back(Gamma);
+  std::vector<Fr> scalars(ch); scalars.insert(scalars.end(), ch_inv.begin(), ch_inv.end()); scalars.push_back(Fr::one());
+  Gamma_hat = msm(bases, scalars);
+  return true;
+}
+
+// ---------------------------------------------------------------- subprotocols/dot_product.rs:152-297
+struct DotProductProofLog { BulletReductionProof bullet_reduction_proof; Point delta, beta; Fr z1, z2; };
+inline DotProductProofLog dot_product_log_prove(const DotProductProofGens& gens, ProofTranscript& t, RandomTape& tape, const std::vector<Fr>& x_vec, const Fr& blind_x,
+                                                const std::vector<Fr>& a_vec, const Fr& y, const Fr& blind_y, Point* Cx_out = nullptr, Point* Cy_out = nullptr) {  // prove :167-249
+  t.append_protocol_name("dot product proof (log)");
+  size_t n = x_vec.size();
+  ORC_ASSERT(a_vec.size() == n && gens.n == n);
+  Fr d = tape.random_scalar("d");
+  Fr r_delta = tape.random_scalar("r_delta");
+  Fr r_beta = tape.random_scalar("r_delta");  // sic: dot_product.rs:189 draws r_beta with label b"r_delta"
+  std::vector<std::pair<Fr, Fr>> blinds_vec;
+  {
+    auto v1 = tape.random_vector("blinds_vec_1", 2 * log_2(n));
+    auto v2 = tape.random_vector("blinds_vec_2", 2 * log_2(n));
+    for (size_t i = 0; i < v1.size(); i++) blinds_vec.push_back({v1[i], v2[i]});
+  }
+  Point Cx = batch_commit(x_vec.data(), n, blind_x, gens.gens_n);
+  t.append_point("Cx", Cx);
+  Point Cy = commit_scalar(y, blind_y, gens.gens_1);
+  t.append_point("Cy", Cy);
+  t.append_scalars("a", a_vec);
+  Fr blind_Gamma = blind_x + blind_y;
+  BulletOut bo = bullet_prove(t, gens.gens_1.G[0], gens.gens_n.G, gens.gens_n.h, x_vec, a_vec, blind_Gamma, blinds_vec);
+  Fr y_hat = bo.a_hat * bo.b_hat;
+  Point delta = bo.g_hat * d + gens.gens_1.h * r_delta;  // d.commit(&r_delta, &gens_hat) :218-226
+  t.append_point("delta", delta);
+  Point beta = commit_scalar(d, r_beta, gens.gens_1);
+  t.append_point("beta", beta);
+  Fr c = t.challenge_scalar("c");
+  DotProductProofLog p; p.bullet_reduction_proof = bo.proof; p.delta = delta; p.beta = beta;
+  p.z1 = d + c * y_hat;
+  p.z2 = bo.b_hat * (c * bo.blind_fin + r_beta) + r_delta;
+  if (Cx_out) *Cx_out = Cx; if (Cy_out) *Cy_out = Cy;
+  return p;
+}
+inline bool dot_product_log_verify(const DotProductProofLog& p, size_t n, const DotProductProofGens& gens, ProofTranscript& t, const std::vector<Fr>& a, const Point& Cx, const Point& Cy) {  // verify :251-296
+  ORC_ASSERT(gens.n == n && a.size() == n);
+  t.append_protocol_name("dot product proof (log)");
+  t.append_point("Cx", Cx); t.append_point("Cy", Cy);
+  t.append_scalars("a", a);
+  Point Gamma = Cx + Cy, g_hat, Gamma_hat; Fr a_hat;
+  if (!bullet_verify(p.bullet_reduction_proof, n, a, t, Gamma, gens.gens_n.G, g_hat, Gamma_hat, a_hat)) return false;
+  t.append_point("delta", p.delta); t.append_point("beta", p.beta);
+  Fr c = t.challenge_scalar("c");
+  Point lhs = (Gamma_hat * c + p.beta) * a_hat + p.delta;
+  Point rhs = (g_hat + gens.gens_1.G[0] * a_hat) * p.z1 + gens.gens_1.h * p.z2;
+  return lhs == rhs;
+}
+
+// ---------------------------------------------------------------- poly/dense_mlpoly.rs:291-401
+struct PolyEvalProof { DotProductProofLog proof; };
+inline PolyEvalProof poly_eval_prove(const DensePolynomial& poly, const std::vector<Fr>& r, const Fr& Zr, const PolyCommitmentGens& gens, ProofTranscript& t, RandomTape& tape) {  // prove :302-359 with blinds None
+  t.append_protocol_name("polynomial evaluation proof");
+  ORC_ASSERT(poly.num_vars == r.size());
+  auto LR = EqPolynomial(r).compute_factored_evals();
+  std::vector<Fr> LZ = poly.bound(LR.first);
+  Fr LZ_blind = Fr::zero();  // blinds are all zero :325-344
+  PolyEvalProof p; p.proof = dot_product_log_prove(gens.gens, t, tape, LZ, LZ_blind, LR.second, Zr, Fr::zero());
+  return p;
+}
+inline bool poly_eval_verify_plain(const PolyEvalProof& p, const PolyCommitmentGens& gens, ProofTranscript& t, const std::vector<Fr>& r, const Fr& Zr, const PolyCommitment& comm) {  // verify_plain :388-400 + verify :361-386
+  Point C_Zr = commit_scalar(Zr, Fr::zero(), gens.gens.gens_1);
+  t.append_protocol_name("polynomial evaluation proof");
+  auto LR = EqPolynomial(r).compute_factored_evals();
+  Point C_LZ = msm(comm, LR.first);
+  return dot_product_log_verify(p.proof, LR.second.size(), gens.gens, t, LR.second, C_LZ, C_Zr);
+}
+
+// ---------------------------------------------------------------- subtables/{mod,and,or,xor,lt,range_check}.rs
+inline std::pair<size_t, size_t> split_bits(size_t item, size_t num_bits) {  // utils/mod.rs:82-89
+  size_t max_value = ((size_t)1 << num_bits) - 1;
+  return {(item >> num_bits) & max_value, item & max_value};
+}
+enum StrategyKind { STRAT_AND = 0, STRAT_OR = 1, STRAT_XOR = 2, STRAT_LT = 3, STRAT_RANGE = 4 };
+struct Strategy {  // trait SubtableStrategy<F, C, M> subtables/mod.rs:31-93, made runtime-parametric
+  StrategyKind kind; size_t C, M, LOG_R;
+  size_t num_subtables() const { return kind == STRAT_LT ? 2 : kind == STRAT_RANGE ? 3 : 1; }
+  size_t num_memories() const { return kind == STRAT_LT ? 2 * C : C; }
+  size_t g_poly_degree() const { return kind == STRAT_LT ? C : 1; }
+  size_t sumcheck_poly_degree() const { return g_poly_degree() + 1; }  // mod.rs:60-62
+  size_t memory_to_subtable_index(size_t i) const {
+    if (kind == STRAT_RANGE) {  // range_check.rs:62-69
+      size_t log_m = ark_log2(M);
+      if (i * log_m > LOG_R) return 2;
+      return ((i + 1) * log_m > LOG_R) ? 1 : 0;
+    }
+    ORC_ASSERT(num_subtables() * C == num_memories() && i < num_memories());  // mod.rs:64-68
+    return i % num_subtables();
+  }
+  size_t memory_to_dimension_index(size_t i) const {
+    if (kind == STRAT_RANGE) return i;  // range_check.rs:71-73
+    ORC_ASSERT(i < num_memories());
+    return i / num_subtables();  // mod.rs:70-74
+  }
+  std::vector<std::vector<Fr>> materialize_subtables() const {
+    size_t bits = ark_log2(M) / 2;
+    std::vector<std::vector<Fr>> out;
+    switch (kind) {
+      case STRAT_AND: case STRAT_OR: case STRAT_XOR: {  // and.rs:16-28, or.rs:16-27, xor.rs:16-27
+        std::vector<Fr> t;
+        for (size_t idx = 0; idx < M; idx++) {
+          auto lr = split_bits(idx, bits);
+          size_t v = kind == STRAT_AND ? (lr.first & lr.second) : kind == STRAT_OR ? (lr.first | lr.second) : (lr.first ^ lr.second);
+          t.push_back(Fr::from_u64(v));
+        }
+        out.push_back(t); break;
+      }
+      case STRAT_LT: {  // lt.rs:16-31
+        std::vector<Fr> lt, eq;
+        for (size_t idx = 0; idx < M; idx++) { auto lr = split_bits(idx, bits); lt.push_back(Fr::from_u64(lr.first < lr.second)); eq.push_back(Fr::from_u64(lr.first == lr.second)); }
+        out.push_back(lt); out.push_back(eq); break;
+      }
+      case STRAT_RANGE: {  // range_check.rs:15-35
+        ORC_ASSERT(is_pow2(M));
+        std::vector<Fr> full, rem, zeros(M, Fr::zero());
+        size_t cutoff = (size_t)1 << (LOG_R % ark_log2(M));
+        for (size_t i = 0; i < M; i++) { full.push_back(Fr::from_u64(i)); rem.push_back(i < cutoff ? Fr::from_u64(i) : Fr::zero()); }
+        out.push_back(full); out.push_back(rem); out.push_back(zeros); break;
+      }
+    }
+    return out;
+  }
+  Fr evaluate_subtable_mle(size_t subtable_index, const std::vector<Fr>& point) const {
+    Fr one = Fr::one();
+    switch (kind) {
+      case STRAT_AND: case STRAT_OR: case STRAT_XOR: {  // and.rs:30-40, or.rs:29-43, xor.rs:29-43
+        size_t b = point.size() / 2; Fr result = Fr::zero();
+        for (size_t i = 0; i < b; i++) {
+          Fr x = point[b - i - 1], y = point[b + b - i - 1], term;
+          if (kind == STRAT_AND) term = x * y;
+          else if (kind == STRAT_OR) term = one - (one - x) * (one - y);
+          else term = (one - x) * y + x * (one - y);
+          result += Fr::from_u64((u64)1 << i) * term;
+        }
+        return result;
+      }
+      case STRAT_LT: {  // lt.rs:34-57
+        size_t b = point.size() / 2; const Fr* x = &point[0]; const Fr* y = &point[b];
+        Fr eq_term = one;
+        if (subtable_index % 2 == 0) {
+          Fr result = Fr::zero();
+          for (size_t i = 0; i < b; i++) { result += (one - x[i]) * y[i] * eq_term; eq_term *= one - x[i] - y[i] + Fr::from_u64(2) * x[i] * y[i]; }
+          return result;
+        }
+        for (size_t i = 0; i < b; i++) eq_term *= one - x[i] - y[i] + Fr::from_u64(2) * x[i] * y[i];
+        return eq_term;
+      }
+      case STRAT_RANGE: {  // range_check.rs:37-60
+        size_t b = point.size();
+        if (subtable_index == 0) { Fr r = Fr::zero(); for (size_t i = 0; i < b; i++) r += Fr::from_u64((u64)1 << i) * point[b - i - 1]; return r; }
+        if (subtable_index == 1) {
+          size_t cutoff = LOG_R % ark_log2(M); Fr r = Fr::zero();
+          for (size_t i = 0; i < b; i++) { if (i < cutoff) r += Fr::from_u64((u64)1 << i) * point[b - i - 1]; else r *= one - point[b - i - 1]; }
+          return r;
+        }
+        ORC_ASSERT(subtable_index == 2); return Fr::zero();
+      }
+    }
+    return Fr::zero();
+  }
+  Fr combine_lookups(const Fr* vals) const {
+    switch (kind) {
+      case STRAT_AND: case STRAT_OR: case STRAT_XOR: {  // and.rs:45-53
+        size_t inc = ark_log2(M) / 2; Fr sum = Fr::zero();
+        for (size_t i = 0; i < C; i++) sum += Fr::from_u64((u64)1 << (i * inc)) * vals[i];
+        return sum;
+      }
+      case STRAT_LT: {  // lt.rs:62-71
+        Fr sum = Fr::zero(), eq_prod = Fr::one();
+        for (size_t i = 0; i < C; i++) { sum += vals[2 * i] * eq_prod; eq_prod *= vals[2 * i + 1]; }
+        return sum;
+      }
+      case STRAT_RANGE: {  // range_check.rs:78-86
+        size_t log_m = ark_log2(M); Fr sum = Fr::zero();
+        for (size_t i = 0; i < C; i++) sum += Fr::from_u64((u64)1 << (i * log_m)) * vals[i];
+        return sum;
+      }
+    }
+    return Fr::zero();
+  }
+  Fr combine_lookups_eq(const Fr* vals) const { return combine_lookups(vals) * vals[num_memories()]; }  // mod.rs:53-57
+};
+
+// ---------------------------------------------------------------- lasso/surge.rs:25-59
+struct SparsePolyCommitmentGens {
+  PolyCommitmentGens gens_combined_l_variate, gens_combined_log_m_variate, gens_derefs;
+  static SparsePolyCommitmentGens create(const char* label, size_t c, size_t s, size_t num_memories, size_t log_m) {
+    SparsePolyCommitmentGens g;
+    g.gens_combined_l_variate = PolyCommitmentGens::create(log_2(next_pow2(2 * c * s)), label);
+    g.gens_combined_log_m_variate = PolyCommitmentGens::create(log_2(next_pow2(c)) + log_m, label);
+    g.gens_derefs = PolyCommitmentGens::create(log_2(next_pow2(num_memories * s)), label);
+    return g;
+  }
+};
+struct SparsePolynomialCommitment { PolyCommitment l_variate_polys_commitment, log_m_variate_polys_commitment; size_t s, log_m, m; };  // surge.rs:61-68
+
+// ---------------------------------------------------------------- lasso/densified.rs:8-97
+struct DensifiedRepresentation {
+  std::vector<std::vector<size_t>> dim_usize;
+  std::vector<DensePolynomial> dim, read, final_;
+  DensePolynomial combined_l_variate_polys, combined_log_m_variate_polys;
+  size_t s, log_m, m, C;
+  static DensifiedRepresentation from_lookup_indices(const std::vector<std::vector<size_t>>& indices /* [lookup][C] */, size_t C, size_t log_m) {  // :22-75
+    DensifiedRepresentation d; d.C = C;
+    d.s = next_pow2(indices.size()); d.log_m = log_m; d.m = pow2(log_m);
+    for (size_t i = 0; i < C; i++) {
+      std::vector<size_t> access; for (auto& idx : indices) access.push_back(idx[i]);
+      access.resize(d.s, 0);
+      std::vector<size_t> final_ts(d.m, 0), read_ts(d.s, 0);
+      for (size_t k = 0; k < d.s; k++) { size_t a = access[k]; ORC_ASSERT(a < d.m); size_t ts = final_ts[a]; read_ts[k] = ts; final_ts[a] = ts + 1; }
+      d.dim.push_back(DensePolynomial::from_usize(access));
+      d.read.push_back(DensePolynomial::from_usize(read_ts));
+      d.final_.push_back(DensePolynomial::from_usize(final_ts));
+      d.dim_usize.push_back(access);
+    }
+    std::vector<DensePolynomial> l = d.dim; l.insert(l.end(), d.read.begin(), d.read.end());
+    d.combined_l_variate_polys = DensePolynomial::merge(l);
+    d.combined_log_m_variate_polys = DensePolynomial::merge(d.final_);
+    return d;
+  }
+  SparsePolynomialCommitment commit(const SparsePolyCommitmentGens& gens) const {  // :78-96
+    SparsePolynomialCommitment c;
+    c.l_variate_polys_commitment = combined_l_variate_polys.commit(gens.gens_combined_l_variate);
+    c.log_m_variate_polys_commitment = combined_log_m_variate_polys.commit(gens.gens_combined_log_m_variate);
+    c.s = s; c.log_m = log_m; c.m = m; return c;
+  }
+};
+
+// ---------------------------------------------------------------- lasso/memory_checking.rs:150-311
+struct GrandProducts {
+  GrandProductCircuit init, read, write, final_;
+  static void build_grand_product_inputs(const std::vector<Fr>& eval_table, const DensePolynomial& dim_i, const std::vector<size_t>& dim_i_usize, const DensePolynomial& read_i,
+                                         const DensePolynomial& final_i, const Fr& gamma, const Fr& tau, DensePolynomial& gi, DensePolynomial& gr, DensePolynomial& gw, DensePolynomial& gf) {  // :236-310
+    Fr g2 = gamma.square();
+    auto hash_func = [&](const Fr& a, const Fr& v, const Fr& t) { return t * g2 + v * gamma + a - tau; };  // :252
+    ORC_ASSERT(eval_table.size() == final_i.len);
+    size_t cells = eval_table.size();
+    std::vector<Fr> vi, vf, vr, vw;
+    for (size_t i = 0; i < cells; i++) vi.push_back(hash_func(Fr::from_u64(i), eval_table[i], Fr::zero()));
+    for (size_t i = 0; i < cells; i++) vf.push_back(hash_func(Fr::from_u64(i), eval_table[i], final_i[i]));
+    ORC_ASSERT(dim_i.len == read_i.len);
+    for (size_t i = 0; i < dim_i.len; i++) vr.push_back(hash_func(dim_i[i], eval_table[dim_i_usize[i]], read_i[i]));
+    for (size_t i = 0; i < dim_i.len; i++) vw.push_back(hash_func(dim_i[i], eval_table[dim_i_usize[i]], read_i[i] + Fr::one()));
+    gi = DensePolynomial(vi); gr = DensePolynomial(vr); gw = DensePolynomial(vw); gf = DensePolynomial(vf);
+  }
+  GrandProducts(const DensePolynomial& gi, const DensePolynomial& gr, const DensePolynomial& gw, const DensePolynomial& gf) : init(gi), read(gr), write(gw), final_(gf) {}
+};
+
+// ---------------------------------------------------------------- subtables/mod.rs:95-217
+struct Subtables {
+  Strategy S; std::vector<std::vector<Fr>> subtable_entries; std::vector<DensePolynomial> lookup_polys; DensePolynomial combined_poly;
+  Subtables(const Strategy& strat, const std::vector<std::vector<size_t>>& nz, size_t s) : S(strat) {  // new :116-129, to_lookup_polys :78-92
+    for (auto& d : nz) ORC_ASSERT(d.size() == s);
+    subtable_entries = S.materialize_subtables();
+    for (size_t i = 0; i < S.num_memories(); i++) {
+      std::vector<Fr> lookups; lookups.reserve(s);
+      const auto& sub = subtable_entries[S.memory_to_subtable_index(i)];
+      const auto& idx = nz[S.memory_to_dimension_index(i)];
+      for (size_t j = 0; j < s; j++) lookups.push_back(sub[idx[j]]);
+      lookup_polys.push_back(DensePolynomial(lookups));
+    }
+    combined_poly = DensePolynomial::merge(lookup_polys);
+  }
+  std::vector<GrandProducts> to_grand_products(const DensifiedRepresentation& dense, const Fr& gamma, const Fr& tau) const {  // :134-175
+    std::vector<GrandProducts> out;
+    for (size_t i = 0; i < S.num_memories(); i++) {
+      const auto& sub = subtable_entries[S.memory_to_subtable_index(i)];
+      size_t j = S.memory_to_dimension_index(i);
+      DensePolynomial gi, gr, gw, gf;
+      GrandProducts::build_grand_product_inputs(sub, dense.dim[j], dense.dim_usize[j], dense.read[j], dense.final_[j], gamma, tau, gi, gr, gw, gf);
+      out.emplace_back(gi, gr, gw, gf);
+    }
+    return out;
+  }
+  PolyCommitment commit(const PolyCommitmentGens& gens) const { return combined_poly.commit(gens); }  // :178-184
+  Fr compute_sumcheck_claim(const EqPolynomial& eq) const {  // :187-216
+    size_t hyper = lookup_polys[0].len;
+    for (auto& p : lookup_polys) ORC_ASSERT(p.len == hyper);
+    auto eq_evals = eq.evals();
+    Fr claim = Fr::zero(); std::vector<Fr> ops(S.num_memories());
+    for (size_t k = 0; k < hyper; k++) { for (size_t j = 0; j < ops.size(); j++) ops[j] = lookup_polys[j][k]; claim += eq_evals[k] * S.combine_lookups(ops.data()); }
+    return claim;
+  }
+};
+inline void append_combined_table_commitment(ProofTranscript& t, const char* label, const PolyCommitment& c) {  // :382-393
+  t.append_message("subtable_evals_commitment", "begin_subtable_evals_commitment");
+  append_poly_commitment(t, label, c);
+  t.append_message("subtable_evals_commitment", "end_subtable_evals_commitment");
+}
+// CombinedTableEvalProof :225-380
+inline PolyEvalProof combined_table_eval_prove(const DensePolynomial& combined_poly, const std::vector<Fr>& eval_ops_val_vec, const std::vector<Fr>& r, const PolyCommitmentGens& gens,
+                                               ProofTranscript& t, RandomTape& tape) {  // prove :285-313 + prove_single :230-281
+  t.append_protocol_name("Lasso CombinedTableEvalProof");
+  std::vector<Fr> evals = eval_ops_val_vec; evals.resize(next_pow2(evals.size()), Fr::zero());
+  ORC_ASSERT(combined_poly.num_vars == r.size() + log_2(evals.size()));
+  t.append_scalars("evals_ops_val", evals);
+  std::vector<Fr> challenges = t.challenge_vector("challenge_combine_n_to_one", log_2(evals.size()));
+  DensePolynomial poly_evals(evals);
+  for (size_t i = challenges.size(); i-- > 0;) poly_evals.bound_poly_var_bot(challenges[i]);
+  ORC_ASSERT(poly_evals.len == 1);
+  Fr joint = poly_evals[0];
+  std::vector<Fr> r_joint = challenges; r_joint.insert(r_joint.end(), r.begin(), r.end());
+  t.append_scalar("joint_claim_eval", joint);
+  return poly_eval_prove(combined_poly, r_joint, joint, gens, t, tape);
+}
+inline bool combined_table_eval_verify(const PolyEvalProof& proof, const std::vector<Fr>& r, const std::vector<Fr>& evals_in, const PolyCommitmentGens& gens, const PolyCommitment& comm, ProofTranscript& t) {  // verify :352-375 + verify_single :315-349
+  t.append_protocol_name("Lasso CombinedTableEvalProof");
+  std::vector<Fr> evals = evals_in; evals.resize(next_pow2(evals.size()), Fr::zero());
+  t.append_scalars("evals_ops_val", evals);
+  std::vector<Fr> challenges = t.challenge_vector("challenge_combine_n_to_one", log_2(evals.size()));
+  DensePolynomial poly_evals(evals);
+  for (size_t i = challenges.size(); i-- > 0;) poly_evals.bound_poly_var_bot(challenges[i]);
+  Fr joint = poly_evals[0];
+  std::vector<Fr> r_joint = challenges; r_joint.insert(r_joint.end(), r.begin(), r.end());
+  t.append_scalar("joint_claim_eval", joint);
+  return poly_eval_verify_plain(proof, gens, t, r_joint, joint, comm);
+}
+
+// ---------------------------------------------------------------- lasso/memory_checking.rs:313-786
+struct HashLayerProof { std::vector<Fr> eval_dim, eval_read, eval_final, eval_derefs; PolyEvalProof proof_ops, proof_mem, proof_derefs; };
+struct GPEvals { Fr init, read, write, final_; };
+struct ProductLayerProof { std::vector<GPEvals> grand_product_evals; BatchedGrandProductArgument proof_mem, proof_ops; };
+struct MemoryCheckingProof { ProductLayerProof proof_prod_layer; HashLayerProof proof_hash_layer; };
+
+inline ProductLayerProof product_layer_prove(std::vector<GrandProducts>& gps, ProofTranscript& t, std::vector<Fr>& rand_mem, std::vector<Fr>& rand_ops) {  // :674-731
+  t.append_protocol_name("Lasso ProductLayerProof");
+  ProductLayerProof p;
+  for (auto& g : gps) {
+    GPEvals e{g.init.evaluate(), g.read.evaluate(), g.write.evaluate(), g.final_.evaluate()};
+    ORC_ASSERT(e.init * e.write == e.read * e.final_);  // :689
+    t.append_scalar("claim_hash_init", e.init); t.append_scalar("claim_hash_read", e.read);
+    t.append_scalar("claim_hash_write", e.write); t.append_scalar("claim_hash_final", e.final_);
+    p.grand_product_evals.push_back(e);
+  }
+  std::vector<GrandProductCircuit*> rw; for (auto& g : gps) { rw.push_back(&g.read); rw.push_back(&g.write); }
+  p.proof_ops = bgpa_prove(rw, t, rand_ops);
+  std::vector<GrandProductCircuit*> inf; for (auto& g : gps) { inf.push_back(&g.init); inf.push_back(&g.final_); }
+  p.proof_mem = bgpa_prove(inf, t, rand_mem);
+  return p;
+}
+inline HashLayerProof hash_layer_prove(const std::vector<Fr>& rand_mem, const std::vector<Fr>& rand_ops, const DensifiedRepresentation& dense, const Subtables& subtables,
+                                       const SparsePolyCommitmentGens& gens, ProofTranscript& t, RandomTape& tape) {  // :338-460
+  t.append_protocol_name("Lasso HashLayerProof");
+  HashLayerProof h; size_t C = dense.C;
+  for (auto& p : subtables.lookup_polys) h.eval_derefs.push_back(p.evaluate(rand_ops));
+  h.proof_derefs = combined_table_eval_prove(subtables.combined_poly, h.eval_derefs, rand_ops, gens.gens_derefs, t, tape);
+  for (size_t i = 0; i < C; i++) h.eval_dim.push_back(dense.dim[i].evaluate(rand_ops));
+  for (size_t i = 0; i < C; i++) h.eval_read.push_back(dense.read[i].evaluate(rand_ops));
+  for (size_t i = 0; i < C; i++) h.eval_final.push_back(dense.final_[i].evaluate(rand_mem));
+  std::vector<Fr> evals_ops = h.eval_dim; evals_ops.insert(evals_ops.end(), h.eval_read.begin(), h.eval_read.end());
+  evals_ops.resize(next_pow2(evals_ops.size()), Fr::zero());
+  t.append_scalars("claim_evals_ops", evals_ops);
+  std::vector<Fr> ch_ops = t.challenge_vector("challenge_combine_n_to_one", log_2(evals_ops.size()));
+  DensePolynomial pe(evals_ops);
+  for (size_t i = ch_ops.size(); i-- > 0;) pe.bound_poly_var_bot(ch_ops[i]);
+  ORC_ASSERT(pe.len == 1);
+  Fr joint_ops = pe[0];
+  std::vector<Fr> r_joint_ops = ch_ops; r_joint_ops.insert(r_joint_ops.end(), rand_ops.begin(), rand_ops.end());
+  t.append_scalar("joint_claim_eval_ops", joint_ops);
+  h.proof_ops = poly_eval_prove(dense.combined_l_variate_polys, r_joint_ops, joint_ops, gens.gens_combined_l_variate, t, tape);
+  t.append_scalars("claim_evals_mem", h.eval_final);
+  std::vector<Fr> ch_mem = t.challenge_vector("challenge_combine_two_to_one", log_2(h.eval_final.size()));
+  DensePolynomial pm = DensePolynomial::new_padded(h.eval_final);
+  for (size_t i = ch_mem.size(); i-- > 0;) pm.bound_poly_var_bot(ch_mem[i]);
+  ORC_ASSERT(pm.len == 1);
+  Fr joint_mem = pm[0];
+  std::vector<Fr> r_joint_mem = ch_mem; r_joint_mem.insert(r_joint_mem.end(), rand_mem.begin(), rand_mem.end());
+  t.append_scalar("joint_claim_eval_mem", joint_mem);
+  h.proof_mem = poly_eval_prove(dense.combined_log_m_variate_polys, r_joint_mem, joint_mem, gens.gens_combined_log_m_variate, t, tape);
+  return h;
+}
+inline MemoryCheckingProof memory_checking_prove(const DensifiedRepresentation& dense, const Fr& gamma, const Fr& tau, const Subtables& subtables, const SparsePolyCommitmentGens& gens,
+                                                 ProofTranscript& t, RandomTape& tape) {  // :56-83
+  t.append_protocol_name("Lasso MemoryCheckingProof");
+  auto gps = subtables.to_grand_products(dense, gamma, tau);
+  MemoryCheckingProof m; std::vector<Fr> rand_mem, rand_ops;
+  m.proof_prod_layer = product_layer_prove(gps, t, rand_mem, rand_ops);
+  m.proof_hash_layer = hash_layer_prove(rand_mem, rand_ops, dense, subtables, gens, t, tape);
+  return m;
+}
+
+// ---------------------------------------------------------------- lasso/surge.rs:84-276
+struct PrimarySumcheck { SumcheckInstanceProof proof; Fr claimed_evaluation; std::vector<Fr> eval_derefs; PolyEvalProof proof_derefs; };
+struct SparsePolynomialEvaluationProof { PolyCommitment comm_derefs; PrimarySumcheck primary_sumcheck; MemoryCheckingProof memory_check; };
+
+inline SparsePolynomialEvaluationProof surge_prove(const Strategy& S, DensifiedRepresentation& dense, const std::vector<Fr>& r, const SparsePolyCommitmentGens& gens,
+                                                   ProofTranscript& t, RandomTape& tape) {  // prove :119-211
+  t.append_protocol_name("Lasso SparsePolynomialEvaluationProof");
+  ORC_ASSERT(r.size() == ark_log2(dense.s));
+  Subtables subtables(S, dense.dim_usize, dense.s);
+  SparsePolynomialEvaluationProof P;
+  P.comm_derefs = subtables.commit(gens.gens_derefs);
+  append_combined_table_commitment(t, "comm_poly_row_col_ops_val", P.comm_derefs);
+  EqPolynomial eq(r);
+  Fr claimed_eval = subtables.compute_sumcheck_claim(eq);
+  t.append_scalar("claim_eval_scalar_product", claimed_eval);
+  std::vector<DensePolynomial> polys;
+  for (size_t i = 0; i < S.num_memories(); i++) polys.push_back(subtables.lookup_polys[i].clone());
+  polys.push_back(DensePolynomial(eq.evals()));
+  std::vector<Fr> r_z, final_evals;
+  P.primary_sumcheck.proof = prove_arbitrary(log_2(dense.s), polys, [&](const Fr* v) { return S.combine_lookups_eq(v); }, S.sumcheck_poly_degree(), t, r_z, final_evals);
+  P.primary_sumcheck.claimed_evaluation = claimed_eval;
+  for (size_t i = 0; i < S.num_memories(); i++) P.primary_sumcheck.eval_derefs.push_back(subtables.lookup_polys[i].evaluate(r_z));
+  P.primary_sumcheck.proof_derefs = combined_table_eval_prove(subtables.combined_poly, P.primary_sumcheck.eval_derefs, r_z, gens.gens_derefs, t, tape);
+  std::vector<Fr> r_hash = t.challenge_vector("challenge_r_hash", 2);
+  P.memory_check = memory_checking_prove(dense, r_hash[0], r_hash[1], subtables, gens, t, tape);
+  return P;
+}
+
+inline Fr identity_poly_evaluate(const std::vector<Fr>& r) {  // poly/identity_poly.rs:14-20
+  size_t len = r.size(); Fr s = Fr::zero();
+  for (size_t i = 0; i < len; i++) s += Fr::from_u64((u64)pow2(len - i - 1)) * r[i];
+  return s;
+}
+
+// verify: surge.rs:214-271, memory_checking.rs:96-143, :525-648, :733-785.  Returns false (or throws on an
+// assert_eq! the reference would panic on) when the proof does not verify.
+inline bool surge_verify(const Strategy& S, const SparsePolynomialEvaluationProof& P, const SparsePolynomialCommitment& commitment, const std::vector<Fr>& eq_randomness,
+                         const SparsePolyCommitmentGens& gens, ProofTranscript& t) {
+  t.append_protocol_name("Lasso SparsePolynomialEvaluationProof");
+  append_combined_table_commitment(t, "comm_poly_row_col_ops_val", P.comm_derefs);
+  t.append_scalar("claim_eval_scalar_product", P.primary_sumcheck.claimed_evaluation);
+  Fr claim_last; std::vector<Fr> r_z;
+  if (!sumcheck_verify(P.primary_sumcheck.proof, P.primary_sumcheck.claimed_evaluation, log_2(commitment.s), S.sumcheck_poly_degree(), t, claim_last, r_z)) return false;
+  Fr eq_eval = EqPolynomial(eq_randomness).evaluate(r_z);
+  ORC_ASSERT(P.primary_sumcheck.eval_derefs.size() == S.num_memories());
+  if (!(eq_eval * S.combine_lookups(P.primary_sumcheck.eval_derefs.data()) == claim_last)) return false;  // :245-249
+  if (!combined_table_eval_verify(P.primary_sumcheck.proof_derefs, r_z, P.primary_sumcheck.eval_derefs, gens.gens_derefs, P.comm_derefs, t)) return false;
+  std::vector<Fr> r_mem_check = t.challenge_vector("challenge_r_hash", 2);
+  const Fr& gamma = r_mem_check[0]; const Fr& tau = r_mem_check[1];
+  // MemoryCheckingProof::verify :96-143
+  t.append_protocol_name("Lasso MemoryCheckingProof");
+  size_t num_ops = next_pow2(commitment.s), num_cells = commitment.m;
+  // ProductLayerProof::verify :733-785
+  const ProductLayerProof& pl = P.memory_check.proof_prod_layer;
+  t.append_protocol_name("Lasso ProductLayerProof");
+  if (pl.grand_product_evals.size() != S.num_memories()) return false;
+  for (auto& e : pl.grand_product_evals) {
+    if (!(e.init * e.write == e.read * e.final_)) return false;
+    t.append_scalar("claim_hash_init", e.init); t.append_scalar("claim_hash_read", e.read);
+    t.append_scalar("claim_hash_write", e.write); t.append_scalar("claim_hash_final", e.final_);
+  }
+  std::vector<Fr> rw_claims, if_claims;
+  for (auto& e : pl.grand_product_evals) { rw_claims.push_back(e.read); rw_claims.push_back(e.write); if_claims.push_back(e.init); if_claims.push_back(e.final_); }
+  std::vector<Fr> claims_ops, rand_ops, claims_mem, rand_mem;
+  bgpa_verify(pl.proof_ops, rw_claims, num_ops, t, claims_ops, rand_ops);
+  bgpa_verify(pl.proof_mem, if_claims, num_cells, t, claims_mem, rand_mem);
+  // HashLayerProof::verify :525-648
+  const HashLayerProof& h = P.memory_check.proof_hash_layer;
+  t.append_protocol_name("Lasso HashLayerProof");
+  if (!combined_table_eval_verify(h.proof_derefs, rand_ops, h.eval_derefs, gens.gens_derefs, P.comm_derefs, t)) return false;
+  std::vector<Fr> evals_ops = h.eval_dim; evals_ops.insert(evals_ops.end(), h.eval_read.begin(), h.eval_read.end());
+  evals_ops.resize(next_pow2(evals_ops.size()), Fr::zero());
+  t.append_scalars("claim_evals_ops", evals_ops);
+  std::vector<Fr> ch_ops = t.challenge_vector("challenge_combine_n_to_one", log_2(evals_ops.size()));
+  DensePolynomial pe(evals_ops);
+  for (size_t i = ch_ops.size(); i-- > 0;) pe.bound_poly_var_bot(ch_ops[i]);
+  Fr joint_ops = pe[0];
+  std::vector<Fr> r_joint_ops = ch_ops; r_joint_ops.insert(r_joint_ops.end(), rand_ops.begin(), rand_ops.end());
+  t.append_scalar("joint_claim_eval_ops", joint_ops);
+  if (!poly_eval_verify_plain(h.proof_ops, gens.gens_combined_l_variate, t, r_joint_ops, joint_ops, commitment.l_variate_polys_commitment)) return false;
+  t.append_scalars("claim_evals_mem", h.eval_final);
+  std::vector<Fr> ch_mem = t.challenge_vector("challenge_combine_two_to_one", log_2(h.eval_final.size()));
+  DensePolynomial pm = DensePolynomial::new_padded(h.eval_final);
+  for (size_t i = ch_mem.size(); i-- > 0;) pm.bound_poly_var_bot(ch_mem[i]);
+  Fr joint_mem = pm[0];
+  std::vector<Fr> r_joint_mem = ch_mem; r_joint_mem.insert(r_joint_mem.end(), rand_mem.begin(), rand_mem.end());
+  t.append_scalar("joint_claim_eval_mem", joint_mem);
+  if (!poly_eval_verify_plain(h.proof_mem, gens.gens_combined_log_m_variate, t, r_joint_mem, joint_mem, commitment.log_m_variate_polys_commitment)) return false;
+  Fr init_addr = identity_poly_evaluate(rand_mem);
+  Fr g2 = gamma.square();
+  auto hash_func = [&](const Fr& a, const Fr& v, const Fr& ts) { return ts * g2 + v * gamma + a - tau; };
+  for (size_t i = 0; i < S.num_memories(); i++) {
+    size_t j = S.memory_to_dimension_index(i), k = S.memory_to_subtable_index(i);
+    Fr init_memory = S.evaluate_subtable_mle(k, rand_mem);
+    // claims = (claims_mem[2i] init, claims_ops[2i] read, claims_ops[2i+1] write, claims_mem[2i+1] final) :116-128
+    if (!(hash_func(init_addr, init_memory, Fr::zero()) == claims_mem[2 * i])) return false;
+    if (!(hash_func(h.eval_dim[j], h.eval_derefs[i], h.eval_read[j]) == claims_ops[2 * i])) return false;
+    if (!(hash_func(h.eval_dim[j], h.eval_derefs[i], h.eval_read[j] + Fr::one()) == claims_ops[2 * i + 1])) return false;
+    if (!(hash_func(init_addr, init_memory, h.eval_final[j]) == claims_mem[2 * i + 1])) return false;
+  }
+  return true;
+}
+
+// ---------------------------------------------------------------- ark-serialize CanonicalSerialize (compressed) of the proof
+struct ByteWriter {
+  std::vector<uint8_t> b;
+  void u64le(uint64_t x) { for (int i = 0; i < 8; i++) b.push_back((uint8_t)(x >> (8 * i))); }
+  void fr(const Fr& x) { uint8_t t[32]; x.to_bytes_le(t); b.insert(b.end(), t, t + 32); }
+  void pt(const Point& p) { uint8_t t[32]; p.compress(t); b.insert(b.end(), t, t + 32); }
+  void frs_vec(const std::vector<Fr>& v) { u64le(v.size()); for (auto& x : v) fr(x); }
+  void frs_arr(const std::vector<Fr>& v) { for (auto& x : v) fr(x); }
+  void pts_vec(const std::vector<Point>& v) { u64le(v.size()); for (auto& x : v) pt(x); }
+  void sumcheck(const SumcheckInstanceProof& s) { u64le(s.compressed_polys.size()); for (auto& c : s.compressed_polys) frs_vec(c.coeffs_except_linear_term); }
+  void dpl(const DotProductProofLog& d) { pts_vec(d.bullet_reduction_proof.L_vec); pts_vec(d.bullet_reduction_proof.R_vec); pt(d.delta); pt(d.beta); fr(d.z1); fr(d.z2); }
+  void bgpa(const BatchedGrandProductArgument& g) { u64le(g.proof.size()); for (auto& l : g.proof) { sumcheck(l.proof); frs_vec(l.claims_prod_left); frs_vec(l.claims_prod_right); } }
+};
+inline std::vector<uint8_t> serialize_proof(const SparsePolynomialEvaluationProof& P) {
+  ByteWriter w;
+  w.pts_vec(P.comm_derefs);                                  // surge.rs:101 comm_derefs
+  w.sumcheck(P.primary_sumcheck.proof);                      // surge.rs:85-90 PrimarySumcheck
+  w.fr(P.primary_sumcheck.claimed_evaluation);
+  w.frs_arr(P.primary_sumcheck.eval_derefs);
+  w.dpl(P.primary_sumcheck.proof_derefs.proof);
+  const ProductLayerProof& pl = P.memory_check.proof_prod_layer;  // memory_checking.rs:656-660
+  for (auto& e : pl.grand_product_evals) { w.fr(e.init); w.fr(e.read); w.fr(e.write); w.fr(e.final_); }
+  w.bgpa(pl.proof_mem); w.bgpa(pl.proof_ops);
+  const HashLayerProof& h = P.memory_check.proof_hash_layer;       // memory_checking.rs:314-329
+  w.frs_arr(h.eval_dim); w.frs_arr(h.eval_read); w.frs_arr(h.eval_final); w.frs_arr(h.eval_derefs);
+  w.dpl(h.proof_ops.proof); w.dpl(h.proof_mem.proof); w.dpl(h.proof_derefs.proof);
+  return w.b;
+}
+struct ByteReader {
+  const uint8_t* p; size_t n, pos = 0; bool ok = true;
+  ByteReader(const uint8_t* p_, size_t n_) : p(p_), n(n_) {}
+  uint64_t u64le() { if (pos + 8 > n) { ok = false; return 0; } uint64_t x = 0; for (int i = 0; i < 8; i++) x |= (uint64_t)p[pos + i] << (8 * i); pos += 8; return x; }
+  Fr fr() { if (pos + 32 > n) { ok = false; return Fr::zero(); } u64 c[4] = {0, 0, 0, 0}; for (int i = 0; i < 32; i++) c[i / 8] |= (u64)p[pos + i] << (8 * (i % 8)); pos += 32; if (Fr::geq_p(c)) ok = false; return Fr::from_canonical(c); }
+  Point pt() { Point q = Point::identity(); if (pos + 32 > n) { ok = false; return q; } if (!ed_decompress(p + pos, q)) ok = false; pos += 32; return q; }
+  std::vector<Fr> frs_vec() { uint64_t k = u64le(); std::vector<Fr> v; if (k > n) { ok = false; return v; } for (uint64_t i = 0; i < k && ok; i++) v.push_back(fr()); return v; }
+  std::vector<Fr> frs_arr(size_t k) { std::vector<Fr> v; for (size_t i = 0; i < k && ok; i++) v.push_back(fr()); return v; }
+  std::vector<Point> pts_vec() { uint64_t k = u64le(); std::vector<Point> v; if (k > n) { ok = false; return v; } for (uint64_t i = 0; i < k && ok; i++) v.push_back(pt()); return v; }
+  SumcheckInstanceProof sumcheck() { SumcheckInstanceProof s; uint64_t k = u64le(); if (k > n) { ok = false; return s; } for (uint64_t i = 0; i < k && ok; i++) { CompressedUniPoly c; c.coeffs_except_linear_term = frs_vec(); s.compressed_polys.push_back(c); } return s; }
+  DotProductProofLog dpl() { DotProductProofLog d; d.bullet_reduction_proof.L_vec = pts_vec(); d.bullet_reduction_proof.R_vec = pts_vec(); d.delta = pt(); d.beta = pt(); d.z1 = fr(); d.z2 = fr(); return d; }
+  BatchedGrandProductArgument bgpa() { BatchedGrandProductArgument g; uint64_t k = u64le(); if (k > n) { ok = false; return g; } for (uint64_t i = 0; i < k && ok; i++) { LayerProofBatched l; l.proof = sumcheck(); l.claims_prod_left = frs_vec(); l.claims_prod_right = frs_vec(); g.proof.push_back(l); } return g; }
+};
+inline bool deserialize_proof(const Strategy& S, const uint8_t* bytes, size_t n, SparsePolynomialEvaluationProof& P) {
+  ByteReader r(bytes, n);
+  P.comm_derefs = r.pts_vec();
+  P.primary_sumcheck.proof = r.sumcheck();
+  P.primary_sumcheck.claimed_evaluation = r.fr();
+  P.primary_sumcheck.eval_derefs = r.frs_arr(S.num_memories());
+  P.primary_sumcheck.proof_derefs.proof = r.dpl();
+  ProductLayerProof& pl = P.memory_check.proof_prod_layer;
+  for (size_t i = 0; i < S.num_memories(); i++) { GPEvals e; e.init = r.fr(); e.read = r.fr(); e.write = r.fr(); e.final_ = r.fr(); pl.grand_product_evals.push_back(e); }
+  pl.proof_mem = r.bgpa(); pl.proof_ops = r.bgpa();
+  HashLayerProof& h = P.memory_check.proof_hash_layer;
+  h.eval_dim = r.frs_arr(S.C); h.eval_read = r.frs_arr(S.C); h.eval_final = r.frs_arr(S.C); h.eval_derefs = r.frs_arr(S.num_memories());
+  h.proof_ops.proof = r.dpl(); h.proof_mem.proof = r.dpl(); h.proof_derefs.proof = r.dpl();
+  return r.ok && r.pos == n;
+}
+
+// ---------------------------------------------------------------- benches/bench.rs:13-34 / utils/test.rs:15-32 harness inputs
+inline std::vector<std::vector<size_t>> gen_indices(size_t C, size_t sparsity, size_t memory_size) {
+  ChaChaRng rng = test_rng();
+  std::vector<std::vector<size_t>> all;
+  for (size_t i = 0; i < sparsity; i++) { size_t v = (size_t)(rng.next_u64() % memory_size); all.push_back(std::vector<size_t>(C, v)); }  // [x; C]: one draw, replicated
+  return all;
+}
+inline std::vector<Fr> gen_random_point(size_t memory_bits) {
+  ChaChaRng rng = test_rng();
+  std::vector<Fr> r; for (size_t i = 0; i < memory_bits; i++) r.push_back(fr_rand(rng)); return r;
+}
+
+}  // namespace orc

@@ -1,0 +1,159 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see lasso_oracle.hpp header).
+// C-ABI surface of the CPU oracle for ctypes-driven tests, smoke() and bench.py's cpu_baseline leg.
+#include "lasso_oracle.hpp"
+#include <chrono>
+#include <memory>
+#include <map>
+
+using namespace orc;
+
+static thread_local std::string g_err;
+#define GUARD(body) try { body } catch (const std::exception& e) { g_err = e.what(); return -1; }
+
+static Strategy mk_strategy(int kind, size_t C, size_t M, size_t log_r) { Strategy s; s.kind = (StrategyKind)kind; s.C = C; s.M = M; s.LOG_R = log_r; return s; }
+
+extern "C" {
+
+const char* orc_last_error() { return g_err.c_str(); }
+
+// ---- field (Montgomery limbs in/out, ark-ff in-memory form); which: 0 = Fr, 1 = Fq
+void orc_f_mul(int which, const u64* a, const u64* b, u64* o) { if (which) { Fq r = Fq::from_raw(a) * Fq::from_raw(b); memcpy(o, r.v, 32); } else { Fr r = Fr::from_raw(a) * Fr::from_raw(b); memcpy(o, r.v, 32); } }
+void orc_f_add(int which, const u64* a, const u64* b, u64* o) { if (which) { Fq r = Fq::from_raw(a) + Fq::from_raw(b); memcpy(o, r.v, 32); } else { Fr r = Fr::from_raw(a) + Fr::from_raw(b); memcpy(o, r.v, 32); } }
+void orc_f_sub(int which, const u64* a, const u64* b, u64* o) { if (which) { Fq r = Fq::from_raw(a) - Fq::from_raw(b); memcpy(o, r.v, 32); } else { Fr r = Fr::from_raw(a) - Fr::from_raw(b); memcpy(o, r.v, 32); } }
+void orc_f_inv(int which, const u64* a, u64* o) { if (which) { Fq r = Fq::from_raw(a).inverse(); memcpy(o, r.v, 32); } else { Fr r = Fr::from_raw(a).inverse(); memcpy(o, r.v, 32); } }
+void orc_f_from_canonical(int which, const u64* a, u64* o) { if (which) { Fq r = Fq::from_canonical(a); memcpy(o, r.v, 32); } else { Fr r = Fr::from_canonical(a); memcpy(o, r.v, 32); } }
+void orc_f_to_canonical(int which, const u64* a, u64* o) { if (which) Fq::from_raw(a).to_canonical(o); else Fr::from_raw(a).to_canonical(o); }
+void orc_fr_from_le_bytes_mod_order(const uint8_t* b, size_t n, u64* o) { Fr r = Fr::from_le_bytes_mod_order(b, n); memcpy(o, r.v, 32); }
+
+// ---- curve: affine canonical coordinates in/out (4 limbs each), for Python big-int cross checks
+static Point pt_from_canon(const u64* xy) { return Point::from_affine(Fq::from_canonical(xy), Fq::from_canonical(xy + 4)); }
+static void pt_to_canon(const Point& p, u64* xy) { Fq x, y; p.to_affine(x, y); x.to_canonical(xy); y.to_canonical(xy + 4); }
+void orc_pt_generator(u64* xy) { pt_to_canon(Point::generator(), xy); }
+void orc_pt_add(const u64* a, const u64* b, u64* o) { pt_to_canon(pt_from_canon(a) + pt_from_canon(b), o); }
+void orc_pt_dbl(const u64* a, u64* o) { pt_to_canon(pt_from_canon(a).dbl(), o); }
+void orc_pt_mul(const u64* a, const u64* scalar_canon, u64* o) { pt_to_canon(pt_from_canon(a).mul_limbs(scalar_canon), o); }
+void orc_pt_compress(const u64* a, uint8_t* out32) { pt_from_canon(a).compress(out32); }
+int orc_pt_decompress(const uint8_t* in32, u64* o) { Point p; if (!ed_decompress(in32, p)) return -1; pt_to_canon(p, o); return 0; }
+// MSM over affine canonical bases and Montgomery Fr scalars (oracle of msm/mod.rs:36-40)
+void orc_msm(const u64* bases_xy, const u64* scalars_mont, size_t n, u64* out_xy) {
+  std::vector<Point> b; std::vector<Fr> s;
+  for (size_t i = 0; i < n; i++) { b.push_back(pt_from_canon(bases_xy + 8 * i)); s.push_back(Fr::from_raw(scalars_mont + 4 * i)); }
+  pt_to_canon(msm(b, s), out_xy);
+}
+
+// ---- hashes
+void orc_shake256(const uint8_t* in, size_t n, uint8_t* out, size_t m) { Shake256 s; s.absorb(in, n); s.squeeze(out, m); }
+void orc_keccak_f1600(uint64_t* st) { keccak_f1600(st); }
+void orc_chacha_block(const uint8_t* key32, uint64_t counter, int rounds, uint32_t* out16) { ChaChaRng r(key32, rounds); ChaChaRng::block(r.key, counter, rounds, out16); }
+// Merlin: transcript(label); append(msg_label, msg); challenge(ch_label) -> n bytes
+void orc_merlin_simple(const char* label, const char* msg_label, const uint8_t* msg, size_t msg_n, const char* ch_label, uint8_t* out, size_t n) {
+  Transcript t(label); t.append_message(msg_label, msg, msg_n); t.challenge_bytes(ch_label, out, n);
+}
+// test_rng stream: first n u64 draws
+void orc_test_rng_u64(uint64_t* out, size_t n) { ChaChaRng r = test_rng(); for (size_t i = 0; i < n; i++) out[i] = r.next_u64(); }
+
+// ---- generators (poly/commitments.rs:22-44): n+1 points, affine canonical; last is h
+int orc_gens(const char* label, size_t n, u64* out_xy) { GUARD(
+  MultiCommitGens g = MultiCommitGens::create(n, label);
+  for (size_t i = 0; i < n; i++) pt_to_canon(g.G[i], out_xy + 8 * i);
+  pt_to_canon(g.h, out_xy + 8 * n); return 0; ) }
+
+// ---- harness inputs (benches/bench.rs:13-34)
+void orc_gen_indices(size_t sparsity, size_t memory_size, uint64_t* out) { auto v = gen_indices(1, sparsity, memory_size); for (size_t i = 0; i < sparsity; i++) out[i] = v[i][0]; }
+void orc_gen_random_point(size_t bits, u64* out_mont) { auto r = gen_random_point(bits); for (size_t i = 0; i < bits; i++) memcpy(out_mont + 4 * i, r[i].v, 32); }
+void orc_random_tape_init_scalar(u64* out_mont) { ChaChaRng p = test_rng(); Fr f = fr_rand(p); memcpy(out_mont, f.v, 32); }
+
+// ---- strategy helpers
+int orc_strategy_info(int kind, size_t C, size_t M, size_t log_r, size_t* num_subtables, size_t* num_memories, size_t* degree) { GUARD(
+  Strategy S = mk_strategy(kind, C, M, log_r); *num_subtables = S.num_subtables(); *num_memories = S.num_memories(); *degree = S.g_poly_degree(); return 0; ) }
+// materialised subtable k as canonical u64 (all tables hold small integers)
+int orc_subtable(int kind, size_t C, size_t M, size_t log_r, size_t k, uint64_t* out) { GUARD(
+  Strategy S = mk_strategy(kind, C, M, log_r); auto t = S.materialize_subtables(); ORC_ASSERT(k < t.size());
+  for (size_t i = 0; i < M; i++) { u64 c[4]; t[k][i].to_canonical(c); ORC_ASSERT(!c[1] && !c[2] && !c[3]); out[i] = c[0]; } return 0; ) }
+int orc_subtable_mle(int kind, size_t C, size_t M, size_t log_r, size_t k, const u64* point_mont, size_t n, u64* out_mont) { GUARD(
+  Strategy S = mk_strategy(kind, C, M, log_r); std::vector<Fr> p; for (size_t i = 0; i < n; i++) p.push_back(Fr::from_raw(point_mont + 4 * i));
+  Fr r = S.evaluate_subtable_mle(k, p); memcpy(out_mont, r.v, 32); return 0; ) }
+int orc_combine_lookups(int kind, size_t C, size_t M, size_t log_r, const u64* vals_mont, u64* out_mont) { GUARD(
+  Strategy S = mk_strategy(kind, C, M, log_r); std::vector<Fr> v; for (size_t i = 0; i < S.num_memories(); i++) v.push_back(Fr::from_raw(vals_mont + 4 * i));
+  Fr r = S.combine_lookups(v.data()); memcpy(out_mont, r.v, 32); return 0; ) }
+
+// ---- session: dense representation + gens + commitment for one (strategy, indices) instance
+struct Session {
+  Strategy S; DensifiedRepresentation dense; SparsePolyCommitmentGens gens; SparsePolynomialCommitment commitment; bool committed = false;
+  std::vector<Fr> r;
+};
+static std::map<std::string, SparsePolyCommitmentGens> g_gens_cache;
+static const SparsePolyCommitmentGens& cached_gens(size_t c, size_t s, size_t nm, size_t log_m) {
+  std::string key = std::to_string(c) + "/" + std::to_string(s) + "/" + std::to_string(nm) + "/" + std::to_string(log_m);
+  auto it = g_gens_cache.find(key);
+  if (it == g_gens_cache.end()) it = g_gens_cache.emplace(key, SparsePolyCommitmentGens::create("gens_sparse_poly", c, s, nm, log_m)).first;
+  return it->second;
+}
+// indices: n_lookups x C (row-major); r: log2(s) Montgomery scalars
+void* orc_session_new(int kind, size_t C, size_t M, size_t log_r, const uint64_t* indices, size_t n_lookups, const u64* r_mont) {
+  try {
+    auto* se = new Session(); se->S = mk_strategy(kind, C, M, log_r);
+    std::vector<std::vector<size_t>> idx(n_lookups, std::vector<size_t>(C));
+    for (size_t i = 0; i < n_lookups; i++) for (size_t j = 0; j < C; j++) idx[i][j] = (size_t)indices[i * C + j];
+    se->dense = DensifiedRepresentation::from_lookup_indices(idx, C, ark_log2(M));
+    se->gens = cached_gens(C, se->dense.s, se->S.num_memories(), ark_log2(M));
+    for (size_t i = 0; i < ark_log2(se->dense.s); i++) se->r.push_back(Fr::from_raw(r_mont + 4 * i));
+    return se;
+  } catch (const std::exception& e) { g_err = e.what(); return nullptr; }
+}
+void orc_session_free(void* s) { delete (Session*)s; }
+// commitment bytes: [u64 n1][n1 x 32B compressed][u64 n2][n2 x 32B]
+int orc_session_commit(void* sv, uint8_t* out, size_t cap, size_t* len) { GUARD(
+  Session* se = (Session*)sv;
+  if (!se->committed) { se->commitment = se->dense.commit(se->gens); se->committed = true; }
+  ByteWriter w; w.pts_vec(se->commitment.l_variate_polys_commitment); w.pts_vec(se->commitment.log_m_variate_polys_commitment);
+  *len = w.b.size(); if (w.b.size() > cap) return -2; memcpy(out, w.b.data(), w.b.size()); return 0; ) }
+int orc_session_prove(void* sv, uint8_t* out, size_t cap, size_t* len) { GUARD(
+  Session* se = (Session*)sv;
+  RandomTape tape("proof"); MerlinTranscript t("example");
+  auto P = surge_prove(se->S, se->dense, se->r, se->gens, t, tape);
+  auto b = serialize_proof(P);
+  *len = b.size(); if (b.size() > cap) return -2; memcpy(out, b.data(), b.size()); return 0; ) }
+// returns 1 = verified, 0 = rejected, <0 = error
+int orc_session_verify(void* sv, const uint8_t* proof, size_t n) { GUARD(
+  Session* se = (Session*)sv;
+  if (!se->committed) { se->commitment = se->dense.commit(se->gens); se->committed = true; }
+  SparsePolynomialEvaluationProof P;
+  if (!deserialize_proof(se->S, proof, n, P)) { g_err = "deserialize failed"; return 0; }
+  MerlinTranscript t("example");
+  bool ok = surge_verify(se->S, P, se->commitment, se->r, se->gens, t);
+  return ok ? 1 : 0; ) }
+// verify against an externally produced commitment (same byte layout as orc_session_commit)
+int orc_session_verify_with_commitment(void* sv, const uint8_t* proof, size_t n, const uint8_t* comm, size_t cn) { GUARD(
+  Session* se = (Session*)sv;
+  ByteReader cr(comm, cn); SparsePolynomialCommitment c; c.l_variate_polys_commitment = cr.pts_vec(); c.log_m_variate_polys_commitment = cr.pts_vec();
+  if (!cr.ok || cr.pos != cn) { g_err = "bad commitment bytes"; return 0; }
+  c.s = se->dense.s; c.log_m = se->dense.log_m; c.m = se->dense.m;
+  SparsePolynomialEvaluationProof P;
+  if (!deserialize_proof(se->S, proof, n, P)) { g_err = "deserialize failed"; return 0; }
+  MerlinTranscript t("example");
+  return surge_verify(se->S, P, c, se->r, se->gens, t) ? 1 : 0; ) }
+
+// ---- timing leg for bench.py cpu_baseline ("port"): harness inputs, serial single-thread
+int orc_bench(int kind, size_t C, size_t M, size_t log_r, size_t s, double* t_densify, double* t_commit, double* t_prove, int do_verify) { GUARD(
+  using clk = std::chrono::steady_clock;
+  Strategy S = mk_strategy(kind, C, M, log_r);
+  size_t log_m = ark_log2(M);
+  auto r = gen_random_point(ark_log2(s));
+  auto nz = gen_indices(C, s, M);
+  const auto& gens = cached_gens(C, s, S.num_memories(), log_m);
+  auto t0 = clk::now();
+  auto dense = DensifiedRepresentation::from_lookup_indices(nz, C, log_m);
+  auto t1 = clk::now();
+  auto commitment = dense.commit(gens);
+  auto t2 = clk::now();
+  RandomTape tape("proof"); MerlinTranscript t("example");
+  auto P = surge_prove(S, dense, r, gens, t, tape);
+  auto t3 = clk::now();
+  *t_densify = std::chrono::duration<double>(t1 - t0).count();
+  *t_commit = std::chrono::duration<double>(t2 - t1).count();
+  *t_prove = std::chrono::duration<double>(t3 - t2).count();
+  if (do_verify) { MerlinTranscript tv("example"); if (!surge_verify(S, P, commitment, r, gens, tv)) { g_err = "verify failed"; return -3; } }
+  return 0; ) }
+
+}  // extern "C"

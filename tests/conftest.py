@@ -1,0 +1,35 @@
+"""Shared fixtures. GPU tests are marked @pytest.mark.gpu; everything else runs on CPU.
+
+The oracle (oracle/) is test infrastructure: it is built here on demand and used only as the checker.
+"""
+import ctypes
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+def _build_oracle():
+    so = os.path.join(ROOT, "oracle", "liblasso_oracle.so")
+    srcs = [os.path.join(ROOT, "oracle", f) for f in ("oracle_capi.cpp", "kats.cpp", "lasso_oracle.hpp", "ff.hpp", "ed25519.hpp", "hashes.hpp")]
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "liblasso_oracle.so"])
+    return so
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    lib = ctypes.CDLL(_build_oracle())
+    lib.orc_kat_names.restype = ctypes.c_char_p
+    lib.orc_last_error.restype = ctypes.c_char_p
+    lib.orc_session_new.restype = ctypes.c_void_p
+    return lib

@@ -1,0 +1,118 @@
+"""Pin the oracle's Montgomery arithmetic (oracle/ff.hpp) and curve (oracle/ed25519.hpp) against Python big ints."""
+import ctypes
+
+import pytest
+
+from fieldref import D, GX, GY, L, Q, ed_add, ed_mul, from_mont, limbs, rng, to_mont, unlimbs
+
+U4 = ctypes.c_uint64 * 4
+U8 = ctypes.c_uint64 * 8
+
+
+def _edge_values(p):
+    return [0, 1, 2, p - 1, p - 2, (p - 1) // 2, (p + 1) // 2, 2**64 - 1, 2**64, 2**128 - 1, 2**192 + 5, 2**252 % p]
+
+
+@pytest.mark.parametrize("which,p", [(0, L), (1, Q)])
+def test_field_ops_vs_bigint(oracle, which, p):
+    r = rng(1234 + which)
+    vals = _edge_values(p) + [r.randrange(p) for _ in range(200)]
+    for i in range(0, len(vals) - 1):
+        a, b = vals[i], vals[(i * 7 + 3) % len(vals)]
+        am, bm = U4(*limbs(to_mont(a, p))), U4(*limbs(to_mont(b, p)))
+        o = U4()
+        oracle.orc_f_mul(which, am, bm, o)
+        assert from_mont(unlimbs(o), p) == a * b % p
+        oracle.orc_f_add(which, am, bm, o)
+        assert from_mont(unlimbs(o), p) == (a + b) % p
+        oracle.orc_f_sub(which, am, bm, o)
+        assert from_mont(unlimbs(o), p) == (a - b) % p
+        if a:
+            oracle.orc_f_inv(which, am, o)
+            assert from_mont(unlimbs(o), p) == pow(a, -1, p)
+        oracle.orc_f_from_canonical(which, U4(*limbs(a)), o)
+        assert unlimbs(o) == to_mont(a, p)
+        oracle.orc_f_to_canonical(which, am, o)
+        assert unlimbs(o) == a
+
+
+def test_from_le_bytes_mod_order(oracle):
+    r = rng(5)
+    for n in (1, 31, 32, 33, 64):
+        for _ in range(20):
+            b = bytes(r.randrange(256) for _ in range(n))
+            o = U4()
+            oracle.orc_fr_from_le_bytes_mod_order(b, ctypes.c_size_t(n), o)
+            assert from_mont(unlimbs(o), L) == int.from_bytes(b, "little") % L
+    b = b"\xff" * 64
+    o = U4()
+    oracle.orc_fr_from_le_bytes_mod_order(b, ctypes.c_size_t(64), o)
+    assert from_mont(unlimbs(o), L) == (2**512 - 1) % L
+
+
+def _pt(xy):
+    return U8(*(limbs(xy[0]) + limbs(xy[1])))
+
+
+def _unpt(v):
+    return (unlimbs(v[0:4]), unlimbs(v[4:8]))
+
+
+def test_curve_vs_bigint(oracle):
+    g = U8()
+    oracle.orc_pt_generator(g)
+    assert _unpt(g) == (GX, GY)
+    assert (-GX * GX + GY * GY) % Q == (1 + D * GX * GX * GY * GY) % Q
+    r = rng(77)
+    pts = [(GX, GY)]
+    for _ in range(8):
+        pts.append(ed_mul((GX, GY), r.randrange(1, L)))
+    o = U8()
+    for i, P in enumerate(pts):
+        P2 = pts[(i * 3 + 1) % len(pts)]
+        oracle.orc_pt_add(_pt(P), _pt(P2), o)
+        assert _unpt(o) == ed_add(P, P2)
+        oracle.orc_pt_add(_pt(P), _pt(P), o)       # unified formula must also double
+        assert _unpt(o) == ed_add(P, P)
+        oracle.orc_pt_dbl(_pt(P), o)
+        assert _unpt(o) == ed_add(P, P)
+        oracle.orc_pt_add(_pt(P), _pt((0, 1)), o)   # identity
+        assert _unpt(o) == P
+        k = r.randrange(L)
+        oracle.orc_pt_mul(_pt(P), U4(*limbs(k)), o)
+        assert _unpt(o) == ed_mul(P, k)
+    # group order: L * G = identity
+    oracle.orc_pt_mul(_pt((GX, GY)), U4(*limbs(L)), o)
+    assert _unpt(o) == (0, 1)
+
+
+def test_compress_roundtrip_and_sign(oracle):
+    r = rng(9)
+    buf = (ctypes.c_uint8 * 32)()
+    o = U8()
+    for _ in range(16):
+        P = ed_mul((GX, GY), r.randrange(1, L))
+        oracle.orc_pt_compress(_pt(P), buf)
+        b = bytes(buf)
+        y = int.from_bytes(b, "little") & (2**255 - 1)
+        assert y == P[1]
+        # ark-ec TEFlags: "negative" iff x > -x as canonical integers
+        assert (b[31] >> 7) == (1 if P[0] > (Q - P[0]) % Q else 0)
+        assert oracle.orc_pt_decompress(buf, o) == 0
+        assert _unpt(o) == P
+
+
+def test_msm_matches_naive(oracle):
+    r = rng(31)
+    for n, small in ((1, False), (5, True), (40, True), (40, False), (33, False)):
+        bases = [ed_mul((GX, GY), r.randrange(1, L)) for _ in range(n)]
+        scalars = [r.randrange(2**16) if small else r.randrange(L) for _ in range(n)]
+        scalars[0] = 0 if n > 1 else scalars[0]
+        B = (ctypes.c_uint64 * (8 * n))(*[w for P in bases for w in limbs(P[0]) + limbs(P[1])])
+        S = (ctypes.c_uint64 * (4 * n))(*[w for s in scalars for w in limbs(to_mont(s, L))])
+        o = U8()
+        oracle.orc_msm(B, S, ctypes.c_size_t(n), o)
+        acc = (0, 1)
+        for P, s in zip(bases, scalars):
+            acc = ed_add(acc, ed_mul(P, s))
+        assert _unpt(o) == acc
