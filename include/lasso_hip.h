@@ -1,0 +1,126 @@
+/* lasso_hip.h — C ABI of the MI355X (gfx950) device library `liblasso_hip.so`.
+ *
+ * This is the drop-in boundary for the hot path of a16z/Lasso's SparsePolynomialEvaluationProof
+ * (SURVEY.md §8b): every O(n) loop of the reference prover is one entry point here; the host
+ * (Rust in the reference, the C++ mirror in lasso_amd/host/ in this repo) keeps the protocol,
+ * the Merlin transcript and all O(log n) scalar work.  Each entry point names the reference
+ * code it replaces (paths relative to /root/reference).
+ *
+ * Conventions
+ *  - lasso_fr     = ark-ff `Fp256<MontBackend<FrConfig,4>>` in-memory form: 4 x u64 little-endian limbs
+ *                   holding a*2^256 mod p, p = 2^252 + 27742317777372353535851937790883648493
+ *                   (`ark_curve25519::Fr`).  Passed through unchanged; device arrays of lasso_fr are
+ *                   byte-identical to a Rust `Vec<Fr>`.
+ *  - lasso_affine = ark-ec `twisted_edwards::Affine<EdwardsConfig>` {x, y}, Fq limbs in Montgomery form.
+ *  - lasso_point  = ark-ec `twisted_edwards::Projective<EdwardsConfig>` {x, y, t, z}, Montgomery form; any
+ *                   valid projective representative is returned (the transcript only ever sees the
+ *                   compressed affine form, src/utils/transcript.rs:47-51).
+ *  - `d_` parameters are DEVICE pointers obtained from lasso_alloc (or any hipMalloc'd memory on the
+ *    context's device, e.g. a torch tensor's data_ptr); all other pointers are HOST memory owned by the
+ *    caller for the duration of the call only.
+ *  - Every function returns 0 on success and a negative lasso_status otherwise; lasso_last_error()
+ *    gives the message.  Nothing unwinds across the ABI.  The reference prover panics on contract
+ *    violations (assert!); a host binding turns non-zero into panic!.
+ *  - A context is entered from one thread at a time; it owns one HIP stream.  Functions that return
+ *    results to host memory synchronise that stream before returning; all others are asynchronous.
+ */
+#ifndef LASSO_HIP_H
+#define LASSO_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct lasso_ctx lasso_ctx;
+typedef struct lasso_bases lasso_bases;
+typedef struct { uint64_t l[4]; } lasso_fr;
+typedef struct { uint64_t x[4], y[4]; } lasso_affine;
+typedef struct { uint64_t x[4], y[4], t[4], z[4]; } lasso_point;
+
+enum lasso_status { LASSO_OK = 0, LASSO_ERR_INVALID = -1, LASSO_ERR_OOM = -2, LASSO_ERR_HIP = -3, LASSO_ERR_UNSUPPORTED = -4 };
+
+/* src/subtables/{and,or,xor,lt,range_check}.rs — the table plug-in (`SubtableStrategy`) as a runtime descriptor */
+enum lasso_strategy_kind { LASSO_AND = 0, LASSO_OR = 1, LASSO_XOR = 2, LASSO_LT = 3, LASSO_RANGE = 4 };
+typedef struct {
+  int32_t kind;      /* lasso_strategy_kind */
+  uint32_t c;        /* const generic C */
+  uint32_t log_m;    /* log2 of const generic M */
+  uint32_t log_r;    /* RangeCheckSubtableStrategy<LOG_R> only */
+} lasso_strategy;
+
+/* ---- context, memory ---------------------------------------------------------------------- */
+int32_t lasso_ctx_create(int32_t device, lasso_ctx** out);
+void lasso_ctx_destroy(lasso_ctx* ctx);
+const char* lasso_last_error(lasso_ctx* ctx);          /* ctx may be NULL: last error of a failed create */
+int32_t lasso_alloc(lasso_ctx* ctx, size_t bytes, void** d_out);
+int32_t lasso_free(lasso_ctx* ctx, void* d_ptr);
+int32_t lasso_upload(lasso_ctx* ctx, void* d_dst, const void* src, size_t bytes);     /* synchronous */
+int32_t lasso_download(lasso_ctx* ctx, void* dst, const void* d_src, size_t bytes);   /* synchronous */
+int32_t lasso_copy(lasso_ctx* ctx, void* d_dst, const void* d_src, size_t bytes);     /* DensePolynomial::clone / merge: src/poly/dense_mlpoly.rs:97-99,:251-261 */
+int32_t lasso_zero(lasso_ctx* ctx, void* d_dst, size_t bytes);                        /* merge's zero padding :258 */
+int32_t lasso_sync(lasso_ctx* ctx);
+void* lasso_stream(lasso_ctx* ctx);                    /* the context's hipStream_t */
+
+/* ---- per-kernel timing (HIP events on the context's stream), for bench.py's roofline ------- */
+enum lasso_kernel_id { LASSO_K_BIND = 0, LASSO_K_CUBIC = 1, LASSO_K_COMBINE = 2, LASSO_K_EQ = 3, LASSO_K_GP = 4, LASSO_K_FINGERPRINT = 5,
+                       LASSO_K_DOT = 6, LASSO_K_MATVEC = 7, LASSO_K_MSM = 8, LASSO_K_MISC = 9, LASSO_K_COUNT = 10 };
+int32_t lasso_prof_enable(lasso_ctx* ctx, int32_t on);
+int32_t lasso_prof_reset(lasso_ctx* ctx);
+/* launches, total milliseconds and algorithmic bytes (SURVEY.md §8d definitions) recorded for one kernel family */
+int32_t lasso_prof_get(lasso_ctx* ctx, int32_t kernel_id, uint64_t* launches, double* total_ms, double* alg_bytes);
+
+/* ---- polynomial kernels -------------------------------------------------------------------- */
+/* DensePolynomial::from_usize (src/poly/dense_mlpoly.rs:263-269): d_dst[i] = Fr::from(d_src[i]) */
+int32_t lasso_fr_from_u32(lasso_ctx* ctx, const uint32_t* d_src, size_t n, lasso_fr* d_dst);
+/* SubtableStrategy::to_lookup_polys (src/subtables/mod.rs:78-92): d_out[j] = d_table[d_idx[j]] */
+int32_t lasso_gather(lasso_ctx* ctx, const lasso_fr* d_table, const uint32_t* d_idx, size_t n, lasso_fr* d_out);
+/* EqPolynomial::evals (src/poly/eq_poly.rs:22-38): d_out[x] = prod_j (x_j ? r_j : 1-r_j), r[0] <-> top bit */
+int32_t lasso_eq_evals(lasso_ctx* ctx, const lasso_fr* r, uint32_t ell, lasso_fr* d_out);
+/* DensePolynomial::bound_poly_var_top (src/poly/dense_mlpoly.rs:209-216) on `npolys` polynomials of current
+ * length n: Z[i] <- Z[i] + r*(Z[i+n/2] - Z[i]) for i < n/2, in place.  `d_polys` is a HOST array of device pointers. */
+int32_t lasso_bind_top(lasso_ctx* ctx, lasso_fr* const* d_polys, uint32_t npolys, size_t n, const lasso_fr* r);
+/* One round of SumcheckInstanceProof::prove_cubic_batched (src/subprotocols/sumcheck.rs:49-93): for each circuit c,
+ * out[3c+0..3c+2] = sum_i comb(A,B,C) at x = 0, 2, 3 with comb = A*B*C (grand_product.rs:126-128).  n = current length. */
+int32_t lasso_sumcheck_cubic_round(lasso_ctx* ctx, const lasso_fr* const* d_A, const lasso_fr* const* d_B, uint32_t ncirc,
+                                   const lasso_fr* d_C, size_t n, lasso_fr* out);
+/* One round of SumcheckInstanceProof::prove_arbitrary (src/subprotocols/sumcheck.rs:165-237) with
+ * comb_func = S::combine_lookups_eq (src/subtables/mod.rs:53-57): out[x] = sum_i g(E_1..E_alpha)(x) * eq(x), x = 0..degree.
+ * d_polys holds alpha = NUM_MEMORIES device pointers; d_eq is the eq polynomial. */
+int32_t lasso_sumcheck_combine_round(lasso_ctx* ctx, const lasso_strategy* s, const lasso_fr* const* d_polys, const lasso_fr* d_eq,
+                                     size_t n, uint32_t degree, lasso_fr* out);
+/* Subtables::compute_sumcheck_claim (src/subtables/mod.rs:187-216): out = sum_k eq[k] * g(E_1[k],...,E_alpha[k]) */
+int32_t lasso_combine_claim(lasso_ctx* ctx, const lasso_strategy* s, const lasso_fr* const* d_polys, const lasso_fr* d_eq, size_t n, lasso_fr* out);
+/* compute_dotproduct for k polynomials against one weight vector (src/utils/mod.rs:64-73 via DensePolynomial::evaluate
+ * src/poly/dense_mlpoly.rs:229-235): out[p] = sum_i d_polys[p][i] * d_w[i] */
+int32_t lasso_multi_dot(lasso_ctx* ctx, const lasso_fr* const* d_polys, uint32_t k, const lasso_fr* d_w, size_t n, lasso_fr* out);
+/* GrandProductCircuit::new (src/subprotocols/grand_product.rs:38-58).  d_tree holds 2n-2 elements: layer 0 (the n
+ * inputs, left half | right half) at [0,n) must be filled by the caller; layer k (n/2^k elements) follows layer k-1
+ * and is computed here as layer_k[i] = left_{k-1}[i] * right_{k-1}[i]. */
+int32_t lasso_gp_build(lasso_ctx* ctx, lasso_fr* d_tree, size_t n);
+/* GrandProducts::build_grand_product_inputs, read/write sets (src/lasso/memory_checking.rs:277-302):
+ * d_read_out[i]  = d_read[i]*gamma^2 + d_table[d_dim[i]]*gamma + d_dim[i] - tau,  d_write_out[i] = d_read_out[i] + gamma^2 */
+int32_t lasso_fingerprint_ops(lasso_ctx* ctx, const lasso_fr* d_table, const uint32_t* d_dim, const lasso_fr* d_read, size_t s,
+                              const lasso_fr* gamma, const lasso_fr* tau, lasso_fr* d_read_out, lasso_fr* d_write_out);
+/* init/final sets (memory_checking.rs:254-273): d_init_out[i] = d_table[i]*gamma + i - tau, d_final_out[i] = d_init_out[i] + d_final[i]*gamma^2 */
+int32_t lasso_fingerprint_mem(lasso_ctx* ctx, const lasso_fr* d_table, const lasso_fr* d_final, size_t m,
+                              const lasso_fr* gamma, const lasso_fr* tau, lasso_fr* d_init_out, lasso_fr* d_final_out);
+/* DensePolynomial::bound (src/poly/dense_mlpoly.rs:184-207): out[i] = sum_j L[j] * d_Z[j*r_size + i], i < r_size */
+int32_t lasso_matvec_left(lasso_ctx* ctx, const lasso_fr* d_Z, const lasso_fr* L, size_t l_size, size_t r_size, lasso_fr* out);
+
+/* ---- curve kernels (Hyrax commitment, src/poly/commitments.rs + src/msm/mod.rs) ------------- */
+/* Upload a generator vector once (MultiCommitGens: G[0..n) then any extra points such as gens_1.G[0] and h) and
+ * precompute the per-window multiples used by both MSM entry points. */
+int32_t lasso_bases_create(lasso_ctx* ctx, const lasso_affine* points, size_t n, lasso_bases** out);
+void lasso_bases_destroy(lasso_ctx* ctx, lasso_bases* b);
+/* DensePolynomial::commit / commit_inner with zero blinds (src/poly/dense_mlpoly.rs:109-181): for each of l_size rows,
+ * out[row] = sum_{j < r_size} d_Z[row*r_size + j] * bases[j]   (Commitments::batch_commit, src/poly/commitments.rs:84-93) */
+int32_t lasso_hyrax_commit(lasso_ctx* ctx, const lasso_fr* d_Z, size_t l_size, size_t r_size, const lasso_bases* bases, lasso_point* out);
+/* VariableBaseMSM::msm (src/msm/mod.rs:36-40): out = sum_{j < n} scalars[j] * bases[j]; n <= number of bases.  Zero scalars cost nothing. */
+int32_t lasso_msm(lasso_ctx* ctx, const lasso_bases* bases, const lasso_fr* scalars, size_t n, lasso_point* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

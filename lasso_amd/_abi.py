@@ -1,0 +1,61 @@
+"""ctypes prototypes for include/lasso_hip.h (shared by the real device library and, in tests, the oracle's mock)."""
+import ctypes as C
+
+u64 = C.c_uint64
+u32 = C.c_uint32
+i32 = C.c_int32
+sz = C.c_size_t
+vp = C.c_void_p
+
+
+class Strategy(C.Structure):
+    _fields_ = [("kind", i32), ("c", u32), ("log_m", u32), ("log_r", u32)]
+
+
+KINDS = {"and": 0, "or": 1, "xor": 2, "lt": 3, "range": 4}
+K_BIND, K_CUBIC, K_COMBINE, K_EQ, K_GP, K_FINGERPRINT, K_DOT, K_MATVEC, K_MSM, K_MISC, K_COUNT = range(11)
+KERNEL_NAMES = ["bind_top", "sumcheck_cubic_round", "sumcheck_combine", "eq_evals", "gp_build", "fingerprint", "multi_dot", "matvec_left", "msm", "misc"]
+
+
+def declare(lib):
+    P = C.POINTER
+    sig = {
+        "lasso_ctx_create": (i32, [i32, P(vp)]),
+        "lasso_ctx_destroy": (None, [vp]),
+        "lasso_last_error": (C.c_char_p, [vp]),
+        "lasso_alloc": (i32, [vp, sz, P(vp)]),
+        "lasso_free": (i32, [vp, vp]),
+        "lasso_upload": (i32, [vp, vp, vp, sz]),
+        "lasso_download": (i32, [vp, vp, vp, sz]),
+        "lasso_copy": (i32, [vp, vp, vp, sz]),
+        "lasso_zero": (i32, [vp, vp, sz]),
+        "lasso_sync": (i32, [vp]),
+        "lasso_stream": (vp, [vp]),
+        "lasso_prof_enable": (i32, [vp, i32]),
+        "lasso_prof_reset": (i32, [vp]),
+        "lasso_prof_get": (i32, [vp, i32, P(u64), P(C.c_double), P(C.c_double)]),
+        "lasso_fr_from_u32": (i32, [vp, vp, sz, vp]),
+        "lasso_gather": (i32, [vp, vp, vp, sz, vp]),
+        "lasso_eq_evals": (i32, [vp, vp, u32, vp]),
+        "lasso_bind_top": (i32, [vp, P(vp), u32, sz, vp]),
+        "lasso_sumcheck_cubic_round": (i32, [vp, P(vp), P(vp), u32, vp, sz, vp]),
+        "lasso_sumcheck_combine_round": (i32, [vp, P(Strategy), P(vp), vp, sz, u32, vp]),
+        "lasso_combine_claim": (i32, [vp, P(Strategy), P(vp), vp, sz, vp]),
+        "lasso_multi_dot": (i32, [vp, P(vp), u32, vp, sz, vp]),
+        "lasso_gp_build": (i32, [vp, vp, sz]),
+        "lasso_fingerprint_ops": (i32, [vp, vp, vp, vp, sz, vp, vp, vp, vp]),
+        "lasso_fingerprint_mem": (i32, [vp, vp, vp, sz, vp, vp, vp, vp]),
+        "lasso_matvec_left": (i32, [vp, vp, vp, sz, sz, vp]),
+        "lasso_bases_create": (i32, [vp, vp, sz, P(vp)]),
+        "lasso_bases_destroy": (None, [vp, vp]),
+        "lasso_hyrax_commit": (i32, [vp, vp, sz, sz, vp, vp]),
+        "lasso_msm": (i32, [vp, vp, vp, sz, vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)   # AttributeError here = the library does not export what the header declares
+        fn.restype = res
+        fn.argtypes = args
+    return sorted(sig)
+
+
+HEADER_SYMBOLS = None

@@ -1,0 +1,358 @@
+// liblasso_hip.so — implementation of include/lasso_hip.h for MI355X (gfx950).
+// One context = one device + one HIP stream + scratch.  See the header for the contract of each entry point.
+#include <hip/hip_runtime.h>
+#include <string>
+#include <vector>
+#include <cstring>
+#include <cstdio>
+#include "../../include/lasso_hip.h"
+#include "poly_kernels.cuh"
+#include "msm_kernels.cuh"
+
+static_assert(sizeof(lasso_fr) == 32 && sizeof(fr_t) == 32, "Fr layout");
+static_assert(sizeof(lasso_affine) == 64 && sizeof(lasso_point) == 128 && sizeof(ed_point) == 128 && sizeof(ed_niels) == 96, "curve layouts");
+
+struct EventPair { hipEvent_t a, b; int kid; double bytes; };
+struct lasso_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  void* d_scratch = nullptr; size_t scratch_cap = 0;      // reduction partials / converted scalars
+  fr_t* d_small = nullptr;                                // small device result buffer
+  fr_t* h_small = nullptr;                                // pinned mirror
+  size_t small_cap = 0;
+  uint32_t* d_flags = nullptr;
+  bool prof = false;
+  std::vector<EventPair> events; size_t events_used = 0;
+  uint64_t prof_launches[LASSO_K_COUNT] = {0}; double prof_ms[LASSO_K_COUNT] = {0}; double prof_bytes[LASSO_K_COUNT] = {0};
+};
+struct lasso_bases { size_t n = 0; ed_niels* d_table = nullptr; };
+
+static thread_local std::string g_create_err;
+
+static int32_t fail(lasso_ctx* c, int32_t code, const std::string& msg) { if (c) c->err = msg; else g_create_err = msg; return code; }
+#define HIPCHK(c, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail((c), e_ == hipErrorOutOfMemory ? LASSO_ERR_OOM : LASSO_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
+#define REQUIRE(c, cond) do { if (!(cond)) return fail((c), LASSO_ERR_INVALID, std::string("invalid argument: ") + #cond); } while (0)
+
+static int32_t ensure_scratch(lasso_ctx* c, size_t bytes) {
+  if (bytes <= c->scratch_cap) return 0;
+  if (c->d_scratch) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(c->d_scratch)); c->d_scratch = nullptr; c->scratch_cap = 0; }
+  size_t cap = bytes < ((size_t)1 << 22) ? ((size_t)1 << 22) : bytes;
+  HIPCHK(c, hipMalloc(&c->d_scratch, cap)); c->scratch_cap = cap; return 0;
+}
+static int32_t ensure_small(lasso_ctx* c, size_t count) {
+  if (count <= c->small_cap) return 0;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->d_small) (void)hipFree(c->d_small);
+  if (c->h_small) (void)hipHostFree(c->h_small);
+  size_t cap = count < 4096 ? 4096 : count;
+  HIPCHK(c, hipMalloc((void**)&c->d_small, cap * sizeof(fr_t)));
+  HIPCHK(c, hipHostMalloc((void**)&c->h_small, cap * sizeof(fr_t), hipHostMallocDefault));
+  c->small_cap = cap; return 0;
+}
+// profiling: bracket a launch with an event pair on the context's stream
+struct ProfScope {
+  lasso_ctx* c; int idx = -1;
+  ProfScope(lasso_ctx* c_, int kid, double bytes) : c(c_) {
+    if (!c->prof) return;
+    if (c->events_used == c->events.size()) { EventPair p; if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return; c->events.push_back(p); }
+    idx = (int)c->events_used++;
+    c->events[idx].kid = kid; c->events[idx].bytes = bytes;
+    (void)hipEventRecord(c->events[idx].a, c->stream);
+  }
+  ~ProfScope() { if (idx >= 0) (void)hipEventRecord(c->events[idx].b, c->stream); }
+};
+static void prof_flush(lasso_ctx* c) {
+  if (!c->events_used) return;
+  (void)hipStreamSynchronize(c->stream);
+  for (size_t i = 0; i < c->events_used; i++) {
+    float ms = 0; if (hipEventElapsedTime(&ms, c->events[i].a, c->events[i].b) != hipSuccess) continue;
+    int k = c->events[i].kid; c->prof_launches[k]++; c->prof_ms[k] += ms; c->prof_bytes[k] += c->events[i].bytes;
+  }
+  c->events_used = 0;
+}
+static inline unsigned grid_for(size_t n, unsigned cap = 2048) { size_t g = (n + LASSO_BLOCK - 1) / LASSO_BLOCK; if (g < 1) g = 1; if (g > cap) g = cap; return (unsigned)g; }
+static inline fr_t to_fr(const lasso_fr* p) { fr_t r; memcpy(r.v, p, 32); return r; }
+static int32_t fetch_small(lasso_ctx* c, size_t count, lasso_fr* out) {
+  HIPCHK(c, hipMemcpyAsync(c->h_small, c->d_small, count * sizeof(fr_t), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  memcpy(out, c->h_small, count * sizeof(fr_t));
+  return 0;
+}
+
+extern "C" {
+
+int32_t lasso_ctx_create(int32_t device, lasso_ctx** out) {
+  if (!out) return fail(nullptr, LASSO_ERR_INVALID, "out is NULL");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n == 0) return fail(nullptr, LASSO_ERR_HIP, std::string("no HIP device: ") + hipGetErrorString(e));
+  if (device < 0 || device >= n) return fail(nullptr, LASSO_ERR_INVALID, "device index out of range");
+  lasso_ctx* c = new lasso_ctx(); c->device = device;
+  if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
+    std::string m = hipGetErrorString(e); delete c; return fail(nullptr, LASSO_ERR_HIP, m);
+  }
+  if (hipMalloc((void**)&c->d_flags, 64) != hipSuccess) { delete c; return fail(nullptr, LASSO_ERR_OOM, "flags alloc"); }
+  int32_t rc = ensure_small(c, 4096); if (rc) { g_create_err = c->err; delete c; return rc; }
+  rc = ensure_scratch(c, (size_t)1 << 22); if (rc) { g_create_err = c->err; delete c; return rc; }
+  *out = c; return 0;
+}
+void lasso_ctx_destroy(lasso_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  for (auto& p : c->events) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+  if (c->d_scratch) (void)hipFree(c->d_scratch);
+  if (c->d_small) (void)hipFree(c->d_small);
+  if (c->h_small) (void)hipHostFree(c->h_small);
+  if (c->d_flags) (void)hipFree(c->d_flags);
+  (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+const char* lasso_last_error(lasso_ctx* c) { return c ? c->err.c_str() : g_create_err.c_str(); }
+void* lasso_stream(lasso_ctx* c) { return c ? (void*)c->stream : nullptr; }
+int32_t lasso_alloc(lasso_ctx* c, size_t bytes, void** d_out) { REQUIRE(c, d_out); HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipMalloc(d_out, bytes ? bytes : 1)); return 0; }
+int32_t lasso_free(lasso_ctx* c, void* p) { if (!p) return 0; HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(p)); return 0; }
+int32_t lasso_upload(lasso_ctx* c, void* d, const void* s, size_t n) { REQUIRE(c, d && s); HIPCHK(c, hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); return 0; }
+int32_t lasso_download(lasso_ctx* c, void* d, const void* s, size_t n) { REQUIRE(c, d && s); HIPCHK(c, hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); return 0; }
+int32_t lasso_copy(lasso_ctx* c, void* d, const void* s, size_t n) { REQUIRE(c, d && s); ProfScope ps(c, LASSO_K_MISC, 2.0 * n); HIPCHK(c, hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, c->stream)); return 0; }
+int32_t lasso_zero(lasso_ctx* c, void* d, size_t n) { REQUIRE(c, d); HIPCHK(c, hipMemsetAsync(d, 0, n, c->stream)); return 0; }
+int32_t lasso_sync(lasso_ctx* c) { HIPCHK(c, hipStreamSynchronize(c->stream)); return 0; }
+
+int32_t lasso_prof_enable(lasso_ctx* c, int32_t on) { prof_flush(c); c->prof = on != 0; return 0; }
+int32_t lasso_prof_reset(lasso_ctx* c) { prof_flush(c); for (int i = 0; i < LASSO_K_COUNT; i++) { c->prof_launches[i] = 0; c->prof_ms[i] = 0; c->prof_bytes[i] = 0; } return 0; }
+int32_t lasso_prof_get(lasso_ctx* c, int32_t k, uint64_t* launches, double* ms, double* bytes) {
+  REQUIRE(c, k >= 0 && k < LASSO_K_COUNT); prof_flush(c);
+  if (launches) *launches = c->prof_launches[k]; if (ms) *ms = c->prof_ms[k]; if (bytes) *bytes = c->prof_bytes[k]; return 0;
+}
+
+// ------------------------------------------------------------------ polynomial entry points
+int32_t lasso_fr_from_u32(lasso_ctx* c, const uint32_t* d_src, size_t n, lasso_fr* d_dst) {
+  REQUIRE(c, d_src && d_dst); if (!n) return 0;
+  ProfScope ps(c, LASSO_K_MISC, 36.0 * n);
+  hipLaunchKernelGGL(k_from_u32, dim3(grid_for(n)), dim3(LASSO_BLOCK), 0, c->stream, d_src, n, (fr_t*)d_dst);
+  HIPCHK(c, hipGetLastError()); return 0;
+}
+int32_t lasso_gather(lasso_ctx* c, const lasso_fr* d_table, const uint32_t* d_idx, size_t n, lasso_fr* d_out) {
+  REQUIRE(c, d_table && d_idx && d_out); if (!n) return 0;
+  ProfScope ps(c, LASSO_K_MISC, 68.0 * n);
+  hipLaunchKernelGGL(k_gather, dim3(grid_for(n)), dim3(LASSO_BLOCK), 0, c->stream, (const fr_t*)d_table, d_idx, n, (fr_t*)d_out);
+  HIPCHK(c, hipGetLastError()); return 0;
+}
+int32_t lasso_eq_evals(lasso_ctx* c, const lasso_fr* r, uint32_t ell, lasso_fr* d_out) {
+  REQUIRE(c, d_out && ell <= 40 && (r || ell == 0));
+  const size_t n = (size_t)1 << ell;
+  ProfScope ps(c, LASSO_K_EQ, 32.0 * n);
+  if (ell <= 12) {
+    RTable R; for (uint32_t j = 0; j < ell; j++) R.r[j] = to_fr(r + j);
+    hipLaunchKernelGGL(k_eq_small, dim3(grid_for(n)), dim3(LASSO_BLOCK), 0, c->stream, R, ell, (fr_t*)d_out);
+  } else {
+    // out[x] = hi[x >> lo_bits] * lo[x & mask]: two small tables (the factored evals of eq_poly.rs:44-52) then one outer-product pass
+    const uint32_t lo_bits = ell / 2, hi_bits = ell - lo_bits;
+    int32_t rc = ensure_scratch(c, (((size_t)1 << hi_bits) + ((size_t)1 << lo_bits)) * sizeof(fr_t)); if (rc) return rc;
+    fr_t* hi = (fr_t*)c->d_scratch; fr_t* lo = hi + ((size_t)1 << hi_bits);
+    RTable Rh, Rl; for (uint32_t j = 0; j < hi_bits; j++) Rh.r[j] = to_fr(r + j); for (uint32_t j = 0; j < lo_bits; j++) Rl.r[j] = to_fr(r + hi_bits + j);
+    hipLaunchKernelGGL(k_eq_small, dim3(grid_for((size_t)1 << hi_bits)), dim3(LASSO_BLOCK), 0, c->stream, Rh, hi_bits, hi);
+    hipLaunchKernelGGL(k_eq_small, dim3(grid_for((size_t)1 << lo_bits)), dim3(LASSO_BLOCK), 0, c->stream, Rl, lo_bits, lo);
+    hipLaunchKernelGGL(k_eq_outer, dim3(grid_for(n, 4096)), dim3(LASSO_BLOCK), 0, c->stream, (const fr_t*)hi, (const fr_t*)lo, lo_bits, n, (fr_t*)d_out);
+  }
+  HIPCHK(c, hipGetLastError()); return 0;
+}
+int32_t lasso_bind_top(lasso_ctx* c, lasso_fr* const* d_polys, uint32_t npolys, size_t n, const lasso_fr* r) {
+  REQUIRE(c, d_polys && r && npolys >= 1 && npolys <= LASSO_MAX_PTRS && n >= 2 && (n & (n - 1)) == 0);
+  MutPtrTable T; for (uint32_t i = 0; i < npolys; i++) { REQUIRE(c, d_polys[i]); T.p[i] = (fr_t*)d_polys[i]; }
+  const size_t half = n / 2;
+  ProfScope ps(c, LASSO_K_BIND, 48.0 * n * npolys);   // read 32n + write 16n per polynomial
+  hipLaunchKernelGGL(k_bind_top, dim3(grid_for(half, 4096), npolys), dim3(LASSO_BLOCK), 0, c->stream, T, half, to_fr(r));
+  HIPCHK(c, hipGetLastError()); return 0;
+}
+int32_t lasso_sumcheck_cubic_round(lasso_ctx* c, const lasso_fr* const* d_A, const lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_C, size_t n, lasso_fr* out) {
+  REQUIRE(c, d_A && d_B && d_C && out && ncirc >= 1 && ncirc <= LASSO_MAX_PTRS && n >= 2 && (n & (n - 1)) == 0);
+  PtrTable A, B; for (uint32_t i = 0; i < ncirc; i++) { REQUIRE(c, d_A[i] && d_B[i]); A.p[i] = (const fr_t*)d_A[i]; B.p[i] = (const fr_t*)d_B[i]; }
+  const size_t half = n / 2; const unsigned nx = grid_for(half, 512);
+  int32_t rc = ensure_scratch(c, (size_t)nx * ncirc * 3 * sizeof(fr_t)); if (rc) return rc;
+  rc = ensure_small(c, (size_t)ncirc * 3); if (rc) return rc;
+  {
+    ProfScope ps(c, LASSO_K_CUBIC, 32.0 * n * (2.0 * ncirc + 1.0));
+    hipLaunchKernelGGL(k_cubic_round, dim3(nx, ncirc), dim3(LASSO_BLOCK), 0, c->stream, A, B, (const fr_t*)d_C, half, (fr_t*)c->d_scratch);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(ncirc), dim3(LASSO_BLOCK), 0, c->stream, (const fr_t*)c->d_scratch, nx, 3u, c->d_small);
+  }
+  HIPCHK(c, hipGetLastError());
+  return fetch_small(c, (size_t)ncirc * 3, out);
+}
+static int32_t make_strategy(lasso_ctx* c, const lasso_strategy* s, StrategyDev& S, WeightTable& W) {
+  REQUIRE(c, s && s->kind >= LASSO_AND && s->kind <= LASSO_RANGE && s->c >= 1);
+  S.kind = s->kind; S.c = s->c; S.log_m = s->log_m; S.log_r = s->log_r;
+  S.alpha = s->kind == LASSO_LT ? 2 * s->c : s->c;
+  REQUIRE(c, S.alpha <= LASSO_MAX_ALPHA);
+  for (uint32_t i = 0; i < LASSO_MAX_ALPHA; i++) W.w[i] = fr_zero();
+  if (s->kind != LASSO_LT) {
+    const uint32_t inc = s->kind == LASSO_RANGE ? s->log_m : s->log_m / 2;  // and.rs:46 / range_check.rs:79
+    for (uint32_t i = 0; i < S.alpha; i++) { REQUIRE(c, i * inc < 64); W.w[i] = fr_from_u64((uint64_t)1 << (i * inc)); }  // `1u64 << ...` in the reference overflows beyond 63
+  }
+  return 0;
+}
+#define DISPATCH_A(alpha, FN) do { if ((alpha) <= 2) { FN(2, 2); } else if ((alpha) <= 4) { FN(4, 3); } else if ((alpha) <= 8) { FN(8, 5); } else if ((alpha) <= 16) { FN(16, 9); } else { FN(32, 17); } } while (0)
+int32_t lasso_sumcheck_combine_round(lasso_ctx* c, const lasso_strategy* s, const lasso_fr* const* d_polys, const lasso_fr* d_eq, size_t n, uint32_t degree, lasso_fr* out) {
+  StrategyDev S; WeightTable W; int32_t rc = make_strategy(c, s, S, W); if (rc) return rc;
+  REQUIRE(c, d_polys && d_eq && out && n >= 2 && (n & (n - 1)) == 0);
+  REQUIRE(c, degree == (s->kind == LASSO_LT ? s->c + 1 : 2));   // sumcheck_poly_degree(): subtables/mod.rs:60-62
+  PtrTable P; for (uint32_t i = 0; i < S.alpha; i++) { REQUIRE(c, d_polys[i]); P.p[i] = (const fr_t*)d_polys[i]; }
+  const size_t half = n / 2; const unsigned nx = grid_for(half, 1024); const uint32_t K = degree + 1;
+  rc = ensure_scratch(c, (size_t)nx * K * sizeof(fr_t)); if (rc) return rc;
+  rc = ensure_small(c, K); if (rc) return rc;
+  {
+    ProfScope ps(c, LASSO_K_COMBINE, 32.0 * n * (S.alpha + 1.0));
+#define LAUNCH_COMBINE(A_, D_) hipLaunchKernelGGL((k_combine_round<A_, D_>), dim3(nx), dim3(LASSO_BLOCK), 0, c->stream, S, P, (const fr_t*)d_eq, W, half, degree, (fr_t*)c->d_scratch)
+    DISPATCH_A(S.alpha, LAUNCH_COMBINE);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(LASSO_BLOCK), 0, c->stream, (const fr_t*)c->d_scratch, nx, K, c->d_small);
+  }
+  HIPCHK(c, hipGetLastError());
+  return fetch_small(c, K, out);
+}
+int32_t lasso_combine_claim(lasso_ctx* c, const lasso_strategy* s, const lasso_fr* const* d_polys, const lasso_fr* d_eq, size_t n, lasso_fr* out) {
+  StrategyDev S; WeightTable W; int32_t rc = make_strategy(c, s, S, W); if (rc) return rc;
+  REQUIRE(c, d_polys && d_eq && out && n >= 1);
+  PtrTable P; for (uint32_t i = 0; i < S.alpha; i++) { REQUIRE(c, d_polys[i]); P.p[i] = (const fr_t*)d_polys[i]; }
+  const unsigned nx = grid_for(n, 1024);
+  rc = ensure_scratch(c, (size_t)nx * sizeof(fr_t)); if (rc) return rc;
+  {
+    ProfScope ps(c, LASSO_K_COMBINE, 32.0 * n * (S.alpha + 1.0));
+#define LAUNCH_CLAIM(A_, D_) hipLaunchKernelGGL((k_combine_claim<A_>), dim3(nx), dim3(LASSO_BLOCK), 0, c->stream, S, P, (const fr_t*)d_eq, W, n, (fr_t*)c->d_scratch)
+    DISPATCH_A(S.alpha, LAUNCH_CLAIM);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(LASSO_BLOCK), 0, c->stream, (const fr_t*)c->d_scratch, nx, 1u, c->d_small);
+  }
+  HIPCHK(c, hipGetLastError());
+  return fetch_small(c, 1, out);
+}
+int32_t lasso_multi_dot(lasso_ctx* c, const lasso_fr* const* d_polys, uint32_t k, const lasso_fr* d_w, size_t n, lasso_fr* out) {
+  REQUIRE(c, d_polys && d_w && out && k >= 1 && k <= LASSO_MAX_PTRS && n >= 1);
+  PtrTable P; for (uint32_t i = 0; i < k; i++) { REQUIRE(c, d_polys[i]); P.p[i] = (const fr_t*)d_polys[i]; }
+  const unsigned nx = grid_for(n, 512);
+  int32_t rc = ensure_scratch(c, (size_t)nx * k * sizeof(fr_t)); if (rc) return rc;
+  rc = ensure_small(c, k); if (rc) return rc;
+  {
+    ProfScope ps(c, LASSO_K_DOT, 32.0 * n * (k + 1.0));
+    hipLaunchKernelGGL(k_multi_dot, dim3(nx, k), dim3(LASSO_BLOCK), 0, c->stream, P, (const fr_t*)d_w, n, (fr_t*)c->d_scratch);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(k), dim3(LASSO_BLOCK), 0, c->stream, (const fr_t*)c->d_scratch, nx, 1u, c->d_small);
+  }
+  HIPCHK(c, hipGetLastError());
+  return fetch_small(c, k, out);
+}
+int32_t lasso_gp_build(lasso_ctx* c, lasso_fr* d_tree, size_t n) {
+  REQUIRE(c, d_tree && n >= 2 && (n & (n - 1)) == 0);
+  fr_t* in = (fr_t*)d_tree; size_t len = n;
+  ProfScope ps(c, LASSO_K_GP, 48.0 * n * 2.0);
+  while (len > 2 * LASSO_BLOCK) {
+    size_t half = len / 2;
+    hipLaunchKernelGGL(k_gp_layer, dim3(grid_for(half, 4096)), dim3(LASSO_BLOCK), 0, c->stream, (const fr_t*)in, half, in + len);
+    in += len; len = half;
+  }
+  if (len > 2) hipLaunchKernelGGL(k_gp_tail, dim3(1), dim3(LASSO_BLOCK), 0, c->stream, in, len);
+  HIPCHK(c, hipGetLastError()); return 0;
+}
+int32_t lasso_fingerprint_ops(lasso_ctx* c, const lasso_fr* d_table, const uint32_t* d_dim, const lasso_fr* d_read, size_t s, const lasso_fr* gamma, const lasso_fr* tau,
+                              lasso_fr* d_read_out, lasso_fr* d_write_out) {
+  REQUIRE(c, d_table && d_dim && d_read && gamma && tau && d_read_out && d_write_out); if (!s) return 0;
+  fr_t g = to_fr(gamma), g2 = fr_sqr(g), t = to_fr(tau);
+  ProfScope ps(c, LASSO_K_FINGERPRINT, (32.0 * 3 + 64.0) * s);
+  hipLaunchKernelGGL(k_fingerprint_ops, dim3(grid_for(s, 4096)), dim3(LASSO_BLOCK), 0, c->stream, (const fr_t*)d_table, d_dim, (const fr_t*)d_read, s, g, g2, t, (fr_t*)d_read_out, (fr_t*)d_write_out);
+  HIPCHK(c, hipGetLastError()); return 0;
+}
+int32_t lasso_fingerprint_mem(lasso_ctx* c, const lasso_fr* d_table, const lasso_fr* d_final, size_t m, const lasso_fr* gamma, const lasso_fr* tau, lasso_fr* d_init_out, lasso_fr* d_final_out) {
+  REQUIRE(c, d_table && d_final && gamma && tau && d_init_out && d_final_out); if (!m) return 0;
+  fr_t g = to_fr(gamma), g2 = fr_sqr(g), t = to_fr(tau);
+  ProfScope ps(c, LASSO_K_FINGERPRINT, (64.0 + 64.0) * m);
+  hipLaunchKernelGGL(k_fingerprint_mem, dim3(grid_for(m, 4096)), dim3(LASSO_BLOCK), 0, c->stream, (const fr_t*)d_table, (const fr_t*)d_final, m, g, g2, t, (fr_t*)d_init_out, (fr_t*)d_final_out);
+  HIPCHK(c, hipGetLastError()); return 0;
+}
+int32_t lasso_matvec_left(lasso_ctx* c, const lasso_fr* d_Z, const lasso_fr* L, size_t l_size, size_t r_size, lasso_fr* out) {
+  REQUIRE(c, d_Z && L && out && l_size >= 1 && r_size >= 1);
+  // enough row chunks to fill the chip: ~1024 workgroups
+  size_t col_blocks = (r_size + LASSO_BLOCK - 1) / LASSO_BLOCK;
+  size_t nchunks = (1024 + col_blocks - 1) / col_blocks; if (nchunks > l_size) nchunks = l_size; if (nchunks < 1) nchunks = 1;
+  size_t rows_per_chunk = (l_size + nchunks - 1) / nchunks; nchunks = (l_size + rows_per_chunk - 1) / rows_per_chunk;
+  int32_t rc = ensure_scratch(c, (l_size + nchunks * r_size) * sizeof(fr_t)); if (rc) return rc;
+  rc = ensure_small(c, r_size); if (rc) return rc;
+  fr_t* dL = (fr_t*)c->d_scratch; fr_t* partials = dL + l_size;
+  HIPCHK(c, hipMemcpyAsync(dL, L, l_size * sizeof(fr_t), hipMemcpyHostToDevice, c->stream));
+  {
+    ProfScope ps(c, LASSO_K_MATVEC, 32.0 * l_size * r_size);
+    hipLaunchKernelGGL(k_matvec_left, dim3((unsigned)col_blocks, (unsigned)nchunks), dim3(LASSO_BLOCK), 0, c->stream, (const fr_t*)d_Z, (const fr_t*)dL, l_size, r_size, rows_per_chunk, partials);
+    hipLaunchKernelGGL(k_matvec_reduce, dim3((unsigned)col_blocks), dim3(LASSO_BLOCK), 0, c->stream, (const fr_t*)partials, nchunks, r_size, c->d_small);
+  }
+  HIPCHK(c, hipGetLastError());
+  return fetch_small(c, r_size, out);
+}
+
+// ------------------------------------------------------------------ curve entry points
+int32_t lasso_bases_create(lasso_ctx* c, const lasso_affine* points, size_t n, lasso_bases** out) {
+  REQUIRE(c, points && out && n >= 1 && n * MSM_WINDOWS < ((size_t)1 << 32));
+  lasso_bases* b = new lasso_bases(); b->n = n;
+  void* d_aff = nullptr;
+  if (hipMalloc(&d_aff, n * sizeof(lasso_affine)) != hipSuccess || hipMalloc((void**)&b->d_table, n * MSM_WINDOWS * sizeof(ed_niels)) != hipSuccess) {
+    if (d_aff) (void)hipFree(d_aff); delete b; return fail(c, LASSO_ERR_OOM, "bases alloc");
+  }
+  hipError_t e = hipMemcpyAsync(d_aff, points, n * sizeof(lasso_affine), hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) { hipLaunchKernelGGL(k_precompute_table, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream, (const fq_t*)d_aff, n, b->d_table); e = hipGetLastError(); }
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(d_aff);
+  if (e != hipSuccess) { (void)hipFree(b->d_table); delete b; return fail(c, LASSO_ERR_HIP, hipGetErrorString(e)); }
+  *out = b; return 0;
+}
+void lasso_bases_destroy(lasso_ctx* c, lasso_bases* b) { if (!b) return; if (c) (void)hipStreamSynchronize(c->stream); if (b->d_table) (void)hipFree(b->d_table); delete b; }
+
+// chunks per row: aim for >= 1024 workgroups but keep >= ~16 pairs per bucket
+static size_t msm_chunks(size_t rows, size_t n_cols, uint32_t W) {
+  size_t pairs = n_cols * W, K = 1;
+  if (rows < 1024) { K = (1024 + rows - 1) / rows; size_t kmax = (pairs + 4095) / 4096; if (kmax < 1) kmax = 1; if (K > kmax) K = kmax; if (K > 256) K = 256; }
+  size_t cols_per_chunk = (n_cols + K - 1) / K;
+  return (n_cols + cols_per_chunk - 1) / cols_per_chunk;
+}
+// shared tail: bucket kernel over `rows` rows of `n_cols` scalars, then per-row sum of the chunk partials, then D2H
+static int32_t run_msm(lasso_ctx* c, const uint8_t* d_scal, uint32_t bps, uint32_t W, size_t row_stride, size_t rows, size_t n_cols, const lasso_bases* b, uint8_t* scratch_after, lasso_point* out) {
+  const size_t K = msm_chunks(rows, n_cols, W);
+  const size_t cols_per_chunk = (n_cols + K - 1) / K;
+  ed_point* d_partial = (ed_point*)scratch_after; ed_point* d_final = d_partial + rows * K;
+  {
+    ProfScope ps(c, LASSO_K_MSM, (double)rows * n_cols * bps);
+    hipLaunchKernelGGL(k_msm_buckets, dim3((unsigned)K, (unsigned)rows), dim3(MSM_THREADS), 0, c->stream, d_scal, bps, W, row_stride, n_cols, cols_per_chunk, (const ed_niels*)b->d_table, b->n, d_partial);
+    hipLaunchKernelGGL(k_points_sum, dim3((unsigned)rows), dim3(MSM_THREADS), 0, c->stream, (const ed_point*)d_partial, (uint32_t)K, d_final);
+  }
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(out, d_final, rows * sizeof(ed_point), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+int32_t lasso_hyrax_commit(lasso_ctx* c, const lasso_fr* d_Z, size_t l_size, size_t r_size, const lasso_bases* b, lasso_point* out) {
+  REQUIRE(c, d_Z && b && out && l_size >= 1 && r_size >= 1 && r_size <= b->n && l_size < ((size_t)1 << 31));
+  const size_t n = l_size * r_size;
+  const size_t pts_bytes = (l_size * msm_chunks(l_size, r_size, 32) + l_size) * sizeof(ed_point) + 256;
+  int32_t rc = ensure_scratch(c, n * 32 + pts_bytes); if (rc) return rc;
+  uint8_t* d_scal = (uint8_t*)c->d_scratch;
+  HIPCHK(c, hipMemsetAsync(c->d_flags, 0, 8, c->stream));
+  {
+    ProfScope ps(c, LASSO_K_MISC, 36.0 * n);
+    hipLaunchKernelGGL(k_fr_to_u32, dim3(grid_for(n, 4096)), dim3(256), 0, c->stream, (const fr_t*)d_Z, n, (uint32_t*)d_scal, c->d_flags);
+  }
+  uint32_t flags[2];
+  HIPCHK(c, hipMemcpyAsync(flags, c->d_flags, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (!flags[1]) {  // every scalar < 2^32: the reference's small-scalar regime (msm/mod.rs:95-106)
+    uint32_t bits = 0; while (bits < 32 && (flags[0] >> bits)) bits++;
+    uint32_t W = (bits + 7) / 8; if (W == 0) W = 1;
+    return run_msm(c, d_scal, 4, W, r_size * 4, l_size, r_size, b, d_scal + ((n * 4 + 255) & ~(size_t)255), out);
+  }
+  hipLaunchKernelGGL(k_fr_to_canonical, dim3(grid_for(n, 4096)), dim3(256), 0, c->stream, (const fr_t*)d_Z, n, (fr_t*)d_scal);
+  return run_msm(c, d_scal, 32, 32, r_size * 32, l_size, r_size, b, d_scal + n * 32, out);
+}
+int32_t lasso_msm(lasso_ctx* c, const lasso_bases* b, const lasso_fr* scalars, size_t n, lasso_point* out) {
+  REQUIRE(c, b && scalars && out && n >= 1 && n <= b->n);
+  int32_t rc = ensure_scratch(c, n * 64 + 258 * sizeof(ed_point)); if (rc) return rc;
+  fr_t* d_in = (fr_t*)c->d_scratch; fr_t* d_can = d_in + n;
+  HIPCHK(c, hipMemcpyAsync(d_in, scalars, n * 32, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_fr_to_canonical, dim3(grid_for(n)), dim3(256), 0, c->stream, (const fr_t*)d_in, n, d_can);
+  return run_msm(c, (const uint8_t*)d_can, 32, 32, n * 32, 1, n, b, (uint8_t*)(d_can + n), out);
+}
+
+}  // extern "C"

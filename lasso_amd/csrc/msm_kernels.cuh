@@ -1,0 +1,135 @@
+// Pippenger-style MSM kernels for the Hyrax commitment (gfx950).
+//
+// Design (MI355X-first, not the reference's serial window loop src/msm/mod.rs:91-164):
+//  * the generators are fixed for the lifetime of a gens object, so every window multiple 2^(8w)*G_j is
+//    precomputed once (table[w][j], affine "Niels" form, 96 B) — all windows of a scalar then fall into ONE
+//    bucket set, with no per-window bucket reduction and no doubling chain at all;
+//  * 8-bit unsigned digits = the bytes of the canonical little-endian scalar; zero digits are skipped, so
+//    the reference's small-scalar shortcut (msm/mod.rs:95-106) is automatic: a 16-bit scalar costs 2 adds;
+//  * one 256-thread workgroup owns one bucket set: (digit, table-index) pairs are counting-sorted in LDS in
+//    batches of 4096, then thread t accumulates bucket t in registers with 7-multiplication mixed adds;
+//  * bucket reduction sum_t t*B_t: each lane scales its own bucket (8 doublings + adds), LDS tree sums them.
+// Results are group elements, so any accumulation order is bit-identical after compression.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "fq.cuh"
+
+#define MSM_THREADS 256
+#define MSM_BATCH 4096
+#define MSM_WINDOWS 32
+
+// curve25519 inversion chain: a^(p-2), 254 squarings + 11 multiplications
+LHD fq_t fq_inv_chain(const fq_t& z) {
+  fq_t z2 = fq_sqr(z);
+  fq_t z8 = fq_sqr(fq_sqr(z2));
+  fq_t z9 = fq_mul(z8, z);
+  fq_t z11 = fq_mul(z9, z2);
+  fq_t z22 = fq_sqr(z11);
+  fq_t z_5_0 = fq_mul(z22, z9);                       // 2^5 - 1
+  fq_t t = z_5_0; for (int i = 0; i < 5; i++) t = fq_sqr(t);
+  fq_t z_10_0 = fq_mul(t, z_5_0);                     // 2^10 - 1
+  t = z_10_0; for (int i = 0; i < 10; i++) t = fq_sqr(t);
+  fq_t z_20_0 = fq_mul(t, z_10_0);
+  t = z_20_0; for (int i = 0; i < 20; i++) t = fq_sqr(t);
+  t = fq_mul(t, z_20_0);                              // 2^40 - 1
+  for (int i = 0; i < 10; i++) t = fq_sqr(t);
+  fq_t z_50_0 = fq_mul(t, z_10_0);
+  t = z_50_0; for (int i = 0; i < 50; i++) t = fq_sqr(t);
+  fq_t z_100_0 = fq_mul(t, z_50_0);
+  t = z_100_0; for (int i = 0; i < 100; i++) t = fq_sqr(t);
+  t = fq_mul(t, z_100_0);                             // 2^200 - 1
+  for (int i = 0; i < 50; i++) t = fq_sqr(t);
+  t = fq_mul(t, z_50_0);                              // 2^250 - 1
+  for (int i = 0; i < 5; i++) t = fq_sqr(t);
+  return fq_mul(t, z11);                              // 2^255 - 21
+}
+
+// table[w*n + j] = Niels(2^(8w) * G_j).  One thread per generator.  `aff` = ark Affine {x,y} Montgomery limbs.
+__global__ void k_precompute_table(const fq_t* __restrict__ aff, size_t n, ed_niels* __restrict__ table) {
+  size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  fq_t x = fq_from_mont(aff[2 * j]), y = fq_from_mont(aff[2 * j + 1]);
+  table[j] = ed_to_niels_affine(x, y);
+  ed_point P = ed_from_affine(x, y);
+  for (int w = 1; w < MSM_WINDOWS; w++) {
+    for (int k = 0; k < 8; k++) P = ed_dbl(P);
+    fq_t zi = fq_inv_chain(P.Z);
+    table[(size_t)w * n + j] = ed_to_niels_affine(fq_mul(P.X, zi), fq_mul(P.Y, zi));
+  }
+}
+
+// Montgomery Fr -> low 32 bits of the canonical value; flags[0] = max low word seen, flags[1] |= 1 if any value >= 2^32
+__global__ void __launch_bounds__(256) k_fr_to_u32(const fr_t* __restrict__ src, size_t n, uint32_t* __restrict__ dst, uint32_t* __restrict__ flags) {
+  uint32_t mx = 0, big = 0;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    fr_t c = fr_to_canonical(src[i]);
+    dst[i] = c.v[0];
+    mx = max(mx, c.v[0]);
+    big |= c.v[1] | c.v[2] | c.v[3] | c.v[4] | c.v[5] | c.v[6] | c.v[7];
+  }
+  for (int off = 32; off > 0; off >>= 1) { mx = max(mx, (uint32_t)__shfl_down(mx, off, 64)); big |= (uint32_t)__shfl_down(big, off, 64); }
+  if ((threadIdx.x & 63) == 0) { atomicMax(&flags[0], mx); if (big) atomicOr(&flags[1], 1u); }
+}
+// Montgomery Fr -> canonical 32-byte little-endian integers
+__global__ void __launch_bounds__(256) k_fr_to_canonical(const fr_t* __restrict__ src, size_t n, fr_t* __restrict__ dst) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = fr_to_canonical(src[i]);
+}
+
+// grid = (chunks per row K, rows).  scal: canonical little-endian scalars, `bps` bytes each (4 or 32), row r at
+// scal + r*row_stride (bytes).  Windows 0..W-1 (byte w of each scalar).  out[row*K + chunk] = partial sum (extended, plain Fq).
+__global__ void __launch_bounds__(MSM_THREADS) k_msm_buckets(const uint8_t* __restrict__ scal, uint32_t bps, uint32_t W, size_t row_stride, size_t n_cols, size_t cols_per_chunk,
+                                                              const ed_niels* __restrict__ table, size_t table_stride, ed_point* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) uint8_t raw[MSM_THREADS * sizeof(ed_point)];  // sorted[] (16 KB) during accumulation, points (32 KB) during the tree
+  __shared__ uint32_t counts[MSM_THREADS], start[MSM_THREADS], cursor[MSM_THREADS];
+  uint32_t* sorted = reinterpret_cast<uint32_t*>(raw);
+  ed_point* pts = reinterpret_cast<ed_point*>(raw);
+  const uint32_t t = threadIdx.x;
+  const uint8_t* row = scal + (size_t)blockIdx.y * row_stride;
+  const size_t c0 = (size_t)blockIdx.x * cols_per_chunk;
+  size_t c1 = c0 + cols_per_chunk; if (c1 > n_cols) c1 = n_cols;
+  const uint32_t scalars_per_batch = MSM_BATCH / W;
+  ed_point B = ed_identity();
+  for (size_t b0 = c0; b0 < c1; b0 += scalars_per_batch) {
+    size_t b1 = b0 + scalars_per_batch; if (b1 > c1) b1 = c1;
+    counts[t] = 0;
+    __syncthreads();
+    for (size_t c = b0 + t; c < b1; c += MSM_THREADS) {
+      const uint8_t* s = row + c * bps;
+      if (bps == 4) { uint32_t v = *reinterpret_cast<const uint32_t*>(s); for (uint32_t w = 0; w < W; w++) { uint32_t d = (v >> (8 * w)) & 255u; if (d) atomicAdd(&counts[d], 1u); } }
+      else { for (uint32_t w4 = 0; w4 < W; w4 += 4) { uint32_t v = *reinterpret_cast<const uint32_t*>(s + w4); for (uint32_t w = w4; w < w4 + 4 && w < W; w++) { uint32_t d = (v >> (8 * (w - w4))) & 255u; if (d) atomicAdd(&counts[d], 1u); } } }
+    }
+    __syncthreads();
+    start[t] = counts[t];
+    __syncthreads();
+    for (uint32_t off = 1; off < MSM_THREADS; off <<= 1) { uint32_t v = t >= off ? start[t - off] : 0; __syncthreads(); start[t] += v; __syncthreads(); }
+    const uint32_t my_start = start[t] - counts[t];
+    cursor[t] = my_start;
+    __syncthreads();
+    for (size_t c = b0 + t; c < b1; c += MSM_THREADS) {
+      const uint8_t* s = row + c * bps;
+      if (bps == 4) { uint32_t v = *reinterpret_cast<const uint32_t*>(s); for (uint32_t w = 0; w < W; w++) { uint32_t d = (v >> (8 * w)) & 255u; if (d) sorted[atomicAdd(&cursor[d], 1u)] = (uint32_t)(w * table_stride + c); } }
+      else { for (uint32_t w4 = 0; w4 < W; w4 += 4) { uint32_t v = *reinterpret_cast<const uint32_t*>(s + w4); for (uint32_t w = w4; w < w4 + 4 && w < W; w++) { uint32_t d = (v >> (8 * (w - w4))) & 255u; if (d) sorted[atomicAdd(&cursor[d], 1u)] = (uint32_t)(w * table_stride + c); } } }
+    }
+    __syncthreads();
+    const uint32_t cnt = counts[t];
+    if (t) for (uint32_t k = 0; k < cnt; k++) B = ed_madd(B, table[sorted[my_start + k]]);
+    __syncthreads();
+  }
+  // sum_t t * B_t
+  ed_point acc = ed_identity();
+  for (int bit = 7; bit >= 0; bit--) { acc = ed_dbl(acc); if ((t >> bit) & 1u) acc = ed_add(acc, B); }
+  pts[t] = acc;
+  __syncthreads();
+  for (uint32_t s = MSM_THREADS / 2; s > 0; s >>= 1) { if (t < s) pts[t] = ed_add(pts[t], pts[t + s]); __syncthreads(); }
+  if (t == 0) out[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = pts[0];
+}
+
+// out[row] = sum_k partial[row*K + k], converted to ark's Montgomery limbs.  One workgroup per row, K <= 256.
+__global__ void __launch_bounds__(MSM_THREADS) k_points_sum(const ed_point* __restrict__ partial, uint32_t K, ed_point* __restrict__ out_mont) {
+  __shared__ ed_point pts[MSM_THREADS];
+  const uint32_t t = threadIdx.x;
+  pts[t] = t < K ? partial[(size_t)blockIdx.x * K + t] : ed_identity();
+  __syncthreads();
+  for (uint32_t s = MSM_THREADS / 2; s > 0; s >>= 1) { if (t < s && t + s < K) pts[t] = ed_add(pts[t], pts[t + s]); __syncthreads(); }
+  if (t == 0) { ed_point p = pts[0], o; o.X = fq_to_mont(p.X); o.Y = fq_to_mont(p.Y); o.T = fq_to_mont(p.T); o.Z = fq_to_mont(p.Z); out_mont[blockIdx.x] = o; }
+}

@@ -1,0 +1,168 @@
+"""Thin ctypes wrapper over liblasso_hip.so (include/lasso_hip.h).  numpy arrays carry field elements as (n, 4) uint64
+Montgomery limbs — the same bytes as ark-ff's Fp256 — and device buffers are raw device pointers."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _abi
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class LassoError(RuntimeError):
+    pass
+
+
+def load_device_library(path=None):
+    path = path or os.path.join(HERE, "liblasso_hip.so")
+    if not os.path.exists(path):
+        raise LassoError(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` (no CPU fallback exists)")
+    lib = C.CDLL(path)
+    _abi.declare(lib)
+    return lib
+
+
+def _vp(a):
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data_as(C.c_void_p)
+    return C.c_void_p(a)
+
+
+class Device:
+    """One lasso_ctx.  `lib` may be injected (tests inject the oracle's mock ABI); the default is the HIP library."""
+
+    def __init__(self, device=0, lib=None):
+        self.lib = lib or load_device_library()
+        ctx = C.c_void_p()
+        rc = self.lib.lasso_ctx_create(device, C.byref(ctx))
+        if rc != 0:
+            raise LassoError(f"lasso_ctx_create failed ({rc}): {self.lib.lasso_last_error(None).decode()}")
+        self.ctx = ctx
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.lasso_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise LassoError(f"lasso error {rc}: {self.lib.lasso_last_error(self.ctx).decode()}")
+
+    # ---- memory
+    def alloc(self, nbytes):
+        p = C.c_void_p()
+        self._chk(self.lib.lasso_alloc(self.ctx, nbytes, C.byref(p)))
+        return p.value
+
+    def free(self, ptr):
+        self._chk(self.lib.lasso_free(self.ctx, C.c_void_p(ptr)))
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        p = self.alloc(arr.nbytes)
+        self._chk(self.lib.lasso_upload(self.ctx, C.c_void_p(p), _vp(arr), arr.nbytes))
+        return p
+
+    def download(self, ptr, shape, dtype=np.uint64):
+        out = np.empty(shape, dtype=dtype)
+        self._chk(self.lib.lasso_download(self.ctx, _vp(out), C.c_void_p(ptr), out.nbytes))
+        return out
+
+    def sync(self):
+        self._chk(self.lib.lasso_sync(self.ctx))
+
+    def _ptrs(self, ptrs):
+        return (C.c_void_p * len(ptrs))(*ptrs)
+
+    # ---- kernels (argument meaning: include/lasso_hip.h)
+    def fr_from_u32(self, d_src, n, d_dst):
+        self._chk(self.lib.lasso_fr_from_u32(self.ctx, C.c_void_p(d_src), n, C.c_void_p(d_dst)))
+
+    def gather(self, d_table, d_idx, n, d_out):
+        self._chk(self.lib.lasso_gather(self.ctx, C.c_void_p(d_table), C.c_void_p(d_idx), n, C.c_void_p(d_out)))
+
+    def eq_evals(self, r, d_out):
+        r = np.ascontiguousarray(r, dtype=np.uint64).reshape(-1, 4)
+        self._chk(self.lib.lasso_eq_evals(self.ctx, _vp(r), r.shape[0], C.c_void_p(d_out)))
+
+    def bind_top(self, ptrs, n, r):
+        r = np.ascontiguousarray(r, dtype=np.uint64)
+        self._chk(self.lib.lasso_bind_top(self.ctx, self._ptrs(ptrs), len(ptrs), n, _vp(r)))
+
+    def sumcheck_cubic_round(self, a_ptrs, b_ptrs, d_c, n):
+        out = np.empty((len(a_ptrs) * 3, 4), dtype=np.uint64)
+        self._chk(self.lib.lasso_sumcheck_cubic_round(self.ctx, self._ptrs(a_ptrs), self._ptrs(b_ptrs), len(a_ptrs), C.c_void_p(d_c), n, _vp(out)))
+        return out
+
+    def sumcheck_combine_round(self, strategy, ptrs, d_eq, n, degree):
+        out = np.empty((degree + 1, 4), dtype=np.uint64)
+        self._chk(self.lib.lasso_sumcheck_combine_round(self.ctx, C.byref(strategy), self._ptrs(ptrs), C.c_void_p(d_eq), n, degree, _vp(out)))
+        return out
+
+    def combine_claim(self, strategy, ptrs, d_eq, n):
+        out = np.empty((1, 4), dtype=np.uint64)
+        self._chk(self.lib.lasso_combine_claim(self.ctx, C.byref(strategy), self._ptrs(ptrs), C.c_void_p(d_eq), n, _vp(out)))
+        return out
+
+    def multi_dot(self, ptrs, d_w, n):
+        out = np.empty((len(ptrs), 4), dtype=np.uint64)
+        self._chk(self.lib.lasso_multi_dot(self.ctx, self._ptrs(ptrs), len(ptrs), C.c_void_p(d_w), n, _vp(out)))
+        return out
+
+    def gp_build(self, d_tree, n):
+        self._chk(self.lib.lasso_gp_build(self.ctx, C.c_void_p(d_tree), n))
+
+    def fingerprint_ops(self, d_table, d_dim, d_read, s, gamma, tau, d_ro, d_wo):
+        g = np.ascontiguousarray(gamma, dtype=np.uint64); t = np.ascontiguousarray(tau, dtype=np.uint64)
+        self._chk(self.lib.lasso_fingerprint_ops(self.ctx, C.c_void_p(d_table), C.c_void_p(d_dim), C.c_void_p(d_read), s, _vp(g), _vp(t), C.c_void_p(d_ro), C.c_void_p(d_wo)))
+
+    def fingerprint_mem(self, d_table, d_final, m, gamma, tau, d_io, d_fo):
+        g = np.ascontiguousarray(gamma, dtype=np.uint64); t = np.ascontiguousarray(tau, dtype=np.uint64)
+        self._chk(self.lib.lasso_fingerprint_mem(self.ctx, C.c_void_p(d_table), C.c_void_p(d_final), m, _vp(g), _vp(t), C.c_void_p(d_io), C.c_void_p(d_fo)))
+
+    def matvec_left(self, d_z, L, l_size, r_size):
+        L = np.ascontiguousarray(L, dtype=np.uint64)
+        out = np.empty((r_size, 4), dtype=np.uint64)
+        self._chk(self.lib.lasso_matvec_left(self.ctx, C.c_void_p(d_z), _vp(L), l_size, r_size, _vp(out)))
+        return out
+
+    def bases_create(self, affine):
+        affine = np.ascontiguousarray(affine, dtype=np.uint64).reshape(-1, 8)
+        b = C.c_void_p()
+        self._chk(self.lib.lasso_bases_create(self.ctx, _vp(affine), affine.shape[0], C.byref(b)))
+        return b.value
+
+    def bases_destroy(self, b):
+        self.lib.lasso_bases_destroy(self.ctx, C.c_void_p(b))
+
+    def hyrax_commit(self, d_z, l_size, r_size, bases):
+        out = np.empty((l_size, 16), dtype=np.uint64)
+        self._chk(self.lib.lasso_hyrax_commit(self.ctx, C.c_void_p(d_z), l_size, r_size, C.c_void_p(bases), _vp(out)))
+        return out
+
+    def msm(self, bases, scalars):
+        scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+        out = np.empty((1, 16), dtype=np.uint64)
+        self._chk(self.lib.lasso_msm(self.ctx, C.c_void_p(bases), _vp(scalars), scalars.shape[0], _vp(out)))
+        return out
+
+    # ---- profiling
+    def prof_enable(self, on=True):
+        self._chk(self.lib.lasso_prof_enable(self.ctx, 1 if on else 0))
+
+    def prof_reset(self):
+        self._chk(self.lib.lasso_prof_reset(self.ctx))
+
+    def prof_get(self, kid):
+        n = C.c_uint64(); ms = C.c_double(); b = C.c_double()
+        self._chk(self.lib.lasso_prof_get(self.ctx, kid, C.byref(n), C.byref(ms), C.byref(b)))
+        return n.value, ms.value, b.value

@@ -1,0 +1,151 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.  Never linked, imported or executed by the product path.
+//
+// CPU implementation of include/lasso_hip.h on top of the oracle's arithmetic ("device" pointers are host
+// pointers).  Two uses, both in tests/:
+//   * the expected value for every entry point of the real liblasso_hip.so in the `-m gpu` parity tests;
+//   * a fake backend so the C++ host prover (lasso_amd/host/) can be exercised end-to-end on a machine
+//     without a GPU (`-m "not gpu"`: transcript schedule, proof bytes == oracle proof bytes).
+// Each function restates the reference loop it stands for, serially, exactly as cited in lasso_hip.h.
+#include "lasso_oracle.hpp"
+#include "../include/lasso_hip.h"
+#include <cstdlib>
+
+using namespace orc;
+
+struct lasso_ctx { std::string err; };
+struct lasso_bases { std::vector<Point> pts; };
+
+static int32_t fail(lasso_ctx* c, const char* m) { if (c) c->err = m; return LASSO_ERR_INVALID; }
+#define REQ(c, cond) do { if (!(cond)) return fail((c), "invalid argument: " #cond); } while (0)
+static inline const Fr* F(const lasso_fr* p) { return reinterpret_cast<const Fr*>(p); }
+static inline Fr* F(lasso_fr* p) { return reinterpret_cast<Fr*>(p); }
+static Strategy mk(const lasso_strategy* s) { Strategy S; S.kind = (StrategyKind)s->kind; S.C = s->c; S.M = (size_t)1 << s->log_m; S.LOG_R = s->log_r; return S; }
+static void put_point(const Point& p, lasso_point* o) { memcpy(o->x, p.X.v, 32); memcpy(o->y, p.Y.v, 32); memcpy(o->t, p.T.v, 32); memcpy(o->z, p.Z.v, 32); }
+
+extern "C" {
+int32_t lasso_ctx_create(int32_t, lasso_ctx** out) { *out = new lasso_ctx(); return 0; }
+void lasso_ctx_destroy(lasso_ctx* c) { delete c; }
+const char* lasso_last_error(lasso_ctx* c) { return c ? c->err.c_str() : ""; }
+void* lasso_stream(lasso_ctx*) { return nullptr; }
+int32_t lasso_alloc(lasso_ctx* c, size_t bytes, void** d) { REQ(c, d); *d = malloc(bytes ? bytes : 1); return *d ? 0 : LASSO_ERR_OOM; }
+int32_t lasso_free(lasso_ctx*, void* p) { free(p); return 0; }
+int32_t lasso_upload(lasso_ctx*, void* d, const void* s, size_t n) { memcpy(d, s, n); return 0; }
+int32_t lasso_download(lasso_ctx*, void* d, const void* s, size_t n) { memcpy(d, s, n); return 0; }
+int32_t lasso_copy(lasso_ctx*, void* d, const void* s, size_t n) { memmove(d, s, n); return 0; }
+int32_t lasso_zero(lasso_ctx*, void* d, size_t n) { memset(d, 0, n); return 0; }
+int32_t lasso_sync(lasso_ctx*) { return 0; }
+int32_t lasso_prof_enable(lasso_ctx*, int32_t) { return 0; }
+int32_t lasso_prof_reset(lasso_ctx*) { return 0; }
+int32_t lasso_prof_get(lasso_ctx*, int32_t, uint64_t* l, double* ms, double* b) { if (l) *l = 0; if (ms) *ms = 0; if (b) *b = 0; return 0; }
+
+int32_t lasso_fr_from_u32(lasso_ctx*, const uint32_t* s, size_t n, lasso_fr* d) { for (size_t i = 0; i < n; i++) F(d)[i] = Fr::from_u64(s[i]); return 0; }
+int32_t lasso_gather(lasso_ctx*, const lasso_fr* t, const uint32_t* idx, size_t n, lasso_fr* o) { for (size_t i = 0; i < n; i++) o[i] = t[idx[i]]; return 0; }
+int32_t lasso_eq_evals(lasso_ctx*, const lasso_fr* r, uint32_t ell, lasso_fr* o) {
+  std::vector<Fr> rr(F(r), F(r) + ell); auto ev = EqPolynomial(rr).evals(); memcpy(o, ev.data(), ev.size() * 32); return 0;
+}
+int32_t lasso_bind_top(lasso_ctx* c, lasso_fr* const* polys, uint32_t np, size_t n, const lasso_fr* r) {
+  REQ(c, n >= 2 && (n & (n - 1)) == 0);
+  for (uint32_t p = 0; p < np; p++) { Fr* Z = F(polys[p]); size_t h = n / 2; for (size_t i = 0; i < h; i++) Z[i] = Z[i] + *F(r) * (Z[i + h] - Z[i]); }  // dense_mlpoly.rs:209-216
+  return 0;
+}
+int32_t lasso_sumcheck_cubic_round(lasso_ctx* c, const lasso_fr* const* A, const lasso_fr* const* B, uint32_t nc, const lasso_fr* C, size_t n, lasso_fr* out) {
+  REQ(c, n >= 2 && (n & (n - 1)) == 0);
+  size_t len = n / 2; const Fr* pc = F(C);
+  for (uint32_t k = 0; k < nc; k++) {  // sumcheck.rs:56-93
+    const Fr* pa = F(A[k]); const Fr* pb = F(B[k]);
+    Fr p0 = Fr::zero(), p2 = Fr::zero(), p3 = Fr::zero();
+    for (size_t i = 0; i < len; i++) {
+      p0 += pa[i] * pb[i] * pc[i];
+      Fr a2 = pa[len + i] + pa[len + i] - pa[i], b2 = pb[len + i] + pb[len + i] - pb[i], c2 = pc[len + i] + pc[len + i] - pc[i];
+      p2 += a2 * b2 * c2;
+      Fr a3 = a2 + pa[len + i] - pa[i], b3 = b2 + pb[len + i] - pb[i], c3 = c2 + pc[len + i] - pc[i];
+      p3 += a3 * b3 * c3;
+    }
+    F(out)[3 * k] = p0; F(out)[3 * k + 1] = p2; F(out)[3 * k + 2] = p3;
+  }
+  return 0;
+}
+int32_t lasso_sumcheck_combine_round(lasso_ctx* c, const lasso_strategy* s, const lasso_fr* const* polys, const lasso_fr* eq, size_t n, uint32_t degree, lasso_fr* out) {
+  REQ(c, n >= 2 && (n & (n - 1)) == 0);
+  Strategy S = mk(s); size_t alpha = S.num_memories(), half = n / 2;
+  REQ(c, degree == S.sumcheck_poly_degree());
+  std::vector<Fr> ev(degree + 1, Fr::zero()), lo(alpha + 1), hi(alpha + 1), cur(alpha + 1);
+  for (size_t i = 0; i < half; i++) {  // sumcheck.rs:179-218
+    for (size_t j = 0; j < alpha; j++) { lo[j] = F(polys[j])[i]; hi[j] = F(polys[j])[half + i]; }
+    lo[alpha] = F(eq)[i]; hi[alpha] = F(eq)[half + i];
+    ev[0] += S.combine_lookups_eq(lo.data()); ev[1] += S.combine_lookups_eq(hi.data());
+    cur = hi;
+    for (uint32_t k = 2; k <= degree; k++) { for (size_t j = 0; j <= alpha; j++) cur[j] = cur[j] + hi[j] - lo[j]; ev[k] += S.combine_lookups_eq(cur.data()); }
+  }
+  memcpy(out, ev.data(), ev.size() * 32); return 0;
+}
+int32_t lasso_combine_claim(lasso_ctx*, const lasso_strategy* s, const lasso_fr* const* polys, const lasso_fr* eq, size_t n, lasso_fr* out) {
+  Strategy S = mk(s); size_t alpha = S.num_memories(); std::vector<Fr> v(alpha); Fr claim = Fr::zero();
+  for (size_t k = 0; k < n; k++) { for (size_t j = 0; j < alpha; j++) v[j] = F(polys[j])[k]; claim += F(eq)[k] * S.combine_lookups(v.data()); }  // subtables/mod.rs:197-213
+  *F(out) = claim; return 0;
+}
+int32_t lasso_multi_dot(lasso_ctx*, const lasso_fr* const* polys, uint32_t k, const lasso_fr* w, size_t n, lasso_fr* out) {
+  for (uint32_t p = 0; p < k; p++) F(out)[p] = compute_dotproduct(F(polys[p]), F(w), n); return 0;
+}
+int32_t lasso_gp_build(lasso_ctx* c, lasso_fr* tree, size_t n) {
+  REQ(c, n >= 2 && (n & (n - 1)) == 0);
+  Fr* in = F(tree); size_t len = n;
+  while (len > 2) { size_t h = len / 2; Fr* o = in + len; for (size_t i = 0; i < h; i++) o[i] = in[i] * in[i + h]; in = o; len = h; }  // grand_product.rs:20-58
+  return 0;
+}
+int32_t lasso_fingerprint_ops(lasso_ctx*, const lasso_fr* table, const uint32_t* dim, const lasso_fr* read, size_t s, const lasso_fr* gamma, const lasso_fr* tau, lasso_fr* ro, lasso_fr* wo) {
+  Fr g = *F(gamma), g2 = g.square(), t = *F(tau);
+  for (size_t i = 0; i < s; i++) {  // memory_checking.rs:252, :284-301
+    Fr a = Fr::from_u64(dim[i]), v = F(table)[dim[i]];
+    F(ro)[i] = F(read)[i] * g2 + v * g + a - t;
+    F(wo)[i] = (F(read)[i] + Fr::one()) * g2 + v * g + a - t;
+  }
+  return 0;
+}
+int32_t lasso_fingerprint_mem(lasso_ctx*, const lasso_fr* table, const lasso_fr* fin, size_t m, const lasso_fr* gamma, const lasso_fr* tau, lasso_fr* io, lasso_fr* fo) {
+  Fr g = *F(gamma), g2 = g.square(), t = *F(tau);
+  for (size_t i = 0; i < m; i++) {  // memory_checking.rs:257-273
+    F(io)[i] = Fr::zero() * g2 + F(table)[i] * g + Fr::from_u64(i) - t;
+    F(fo)[i] = F(fin)[i] * g2 + F(table)[i] * g + Fr::from_u64(i) - t;
+  }
+  return 0;
+}
+int32_t lasso_matvec_left(lasso_ctx*, const lasso_fr* Z, const lasso_fr* L, size_t ls, size_t rs, lasso_fr* out) {
+  for (size_t i = 0; i < rs; i++) { Fr s = Fr::zero(); for (size_t j = 0; j < ls; j++) s += F(L)[j] * F(Z)[j * rs + i]; F(out)[i] = s; }  // dense_mlpoly.rs:184-207
+  return 0;
+}
+int32_t lasso_bases_create(lasso_ctx*, const lasso_affine* pts, size_t n, lasso_bases** out) {
+  auto* b = new lasso_bases();
+  for (size_t i = 0; i < n; i++) b->pts.push_back(Point::from_affine(Fq::from_raw(pts[i].x), Fq::from_raw(pts[i].y)));
+  *out = b; return 0;
+}
+void lasso_bases_destroy(lasso_ctx*, lasso_bases* b) { delete b; }
+int32_t lasso_hyrax_commit(lasso_ctx* c, const lasso_fr* Z, size_t ls, size_t rs, const lasso_bases* b, lasso_point* out) {
+  REQ(c, rs <= b->pts.size());
+  std::vector<Point> bases(b->pts.begin(), b->pts.begin() + rs);
+  for (size_t i = 0; i < ls; i++) { std::vector<Fr> sc(F(Z) + i * rs, F(Z) + (i + 1) * rs); put_point(msm(bases, sc), out + i); }  // dense_mlpoly.rs:118-127, commitments.rs:84-93 with blind = 0
+  return 0;
+}
+int32_t lasso_msm(lasso_ctx* c, const lasso_bases* b, const lasso_fr* scalars, size_t n, lasso_point* out) {
+  REQ(c, n <= b->pts.size());
+  std::vector<Point> bases(b->pts.begin(), b->pts.begin() + n); std::vector<Fr> sc(F(scalars), F(scalars) + n);
+  put_point(msm(bases, sc), out); return 0;
+}
+
+// ---- test helpers (not part of lasso_hip.h): compare projective points produced by two implementations
+void mock_point_compress(const lasso_point* p, uint8_t* out32) {
+  Point q; memcpy(q.X.v, p->x, 32); memcpy(q.Y.v, p->y, 32); memcpy(q.T.v, p->t, 32); memcpy(q.Z.v, p->z, 32); q.compress(out32);
+}
+int mock_point_on_curve(const lasso_point* p) {  // -x^2 + y^2 = 1 + d x^2 y^2 and T*Z = X*Y
+  Point q; memcpy(q.X.v, p->x, 32); memcpy(q.Y.v, p->y, 32); memcpy(q.T.v, p->t, 32); memcpy(q.Z.v, p->z, 32);
+  if (q.Z.is_zero()) return 0;
+  Fq x, y; q.to_affine(x, y);
+  bool on = (y.square() - x.square()) == (Fq::one() + EdConsts::d() * x.square() * y.square());
+  return on && (q.T * q.Z == q.X * q.Y);
+}
+// n+1 generators from the reference's derivation (commitments.rs:22-44), as lasso_affine (Montgomery limbs); last = h
+void mock_gens(const char* label, size_t n, lasso_affine* out) {
+  MultiCommitGens g = MultiCommitGens::create(n, label);
+  for (size_t i = 0; i <= n; i++) { const Point& p = i < n ? g.G[i] : g.h; Fq x, y; p.to_affine(x, y); memcpy(out[i].x, x.v, 32); memcpy(out[i].y, y.v, 32); }
+}
+}  // extern "C"

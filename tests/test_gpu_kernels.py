@@ -1,0 +1,266 @@
+"""-m gpu: every entry point of liblasso_hip.so (include/lasso_hip.h) against the oracle's CPU statement of the same
+call (oracle/mock_hip.cpp), bit-exact, on seeded inputs incl. the edge sizes the reference exercises (n = 2, ragged grids)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from fieldref import L as FR_P, limbs
+from gpuutil import compress_points, gens, load_mock, rand_fr, small_fr
+from lasso_amd import _abi
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def devs():
+    from lasso_amd import Device
+    real = Device(0)                  # raises loudly if the HIP library / GPU is missing
+    mock = Device(0, lib=load_mock())
+    yield real, mock
+    real.close(); mock.close()
+
+
+def both(devs, fn):
+    return fn(devs[0]), fn(devs[1])
+
+
+@pytest.mark.parametrize("n", [2, 4, 64, 1 << 10, 1 << 12, 1 << 17])
+@pytest.mark.parametrize("npolys", [1, 3])
+def test_bind_top(devs, n, npolys):
+    rng = np.random.default_rng(n * 7 + npolys)
+    data = [rand_fr(rng, n) for _ in range(npolys)]
+    r = rand_fr(rng, 1, edge=False)[0]
+
+    def run(d):
+        ptrs = [d.upload(x) for x in data]
+        d.bind_top(ptrs, n, r)
+        out = [d.download(p, (n, 4)) for p in ptrs]
+        for p in ptrs:
+            d.free(p)
+        return out
+    a, b = both(devs, run)
+    for x, y in zip(a, b):
+        assert np.array_equal(x[: n // 2], y[: n // 2])
+        assert np.array_equal(x[n // 2:], y[n // 2:])   # upper half untouched
+
+
+def test_bind_top_chain_to_scalar(devs):
+    """bind every variable: the last element standing is the MLE evaluation (dense_mlpoly.rs:435-458 style)."""
+    rng = np.random.default_rng(5)
+    n = 1 << 9
+    z = rand_fr(rng, n)
+    rs = rand_fr(rng, 9, edge=False)
+
+    def run(d):
+        p = d.upload(z)
+        m = n
+        for r in rs:
+            d.bind_top([p], m, r)
+            m //= 2
+        out = d.download(p, (1, 4))
+        d.free(p)
+        return out
+    a, b = both(devs, run)
+    assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("ell", [0, 1, 5, 12, 13, 17])
+def test_eq_evals(devs, ell):
+    rng = np.random.default_rng(ell)
+    r = rand_fr(rng, max(ell, 1), edge=False)[:ell]
+
+    def run(d):
+        p = d.alloc(32 << ell)
+        d.eq_evals(r, p)
+        out = d.download(p, (1 << ell, 4))
+        d.free(p)
+        return out
+    a, b = both(devs, run)
+    assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("n,ncirc", [(2, 1), (4, 2), (1 << 9, 2), (1 << 13, 8), (1 << 16, 3)])
+def test_sumcheck_cubic_round(devs, n, ncirc):
+    rng = np.random.default_rng(n + ncirc)
+    A = [rand_fr(rng, n) for _ in range(ncirc)]
+    B = [rand_fr(rng, n) for _ in range(ncirc)]
+    Cp = rand_fr(rng, n)
+
+    def run(d):
+        pa = [d.upload(x) for x in A]; pb = [d.upload(x) for x in B]; pc = d.upload(Cp)
+        out = d.sumcheck_cubic_round(pa, pb, pc, n)
+        for p in pa + pb + [pc]:
+            d.free(p)
+        return out
+    a, b = both(devs, run)
+    assert np.array_equal(a, b)
+
+
+CONFIGS = [("and", 1, 16, 0), ("and", 4, 16, 0), ("xor", 8, 16, 0), ("or", 2, 4, 0), ("lt", 1, 4, 0), ("lt", 2, 4, 0), ("lt", 4, 4, 0), ("range", 3, 8, 40), ("range", 4, 16, 40)]
+
+
+@pytest.mark.parametrize("kind,c,log_m,log_r", CONFIGS)
+@pytest.mark.parametrize("n", [2, 1 << 11])
+def test_sumcheck_combine_round_and_claim(devs, kind, c, log_m, log_r, n):
+    rng = np.random.default_rng(abs(hash((kind, c, n))) % 2**32)
+    S = _abi.Strategy(_abi.KINDS[kind], c, log_m, log_r)
+    alpha = 2 * c if kind == "lt" else c
+    degree = c + 1 if kind == "lt" else 2
+    polys = [rand_fr(rng, n) for _ in range(alpha)]
+    eq = rand_fr(rng, n)
+
+    def run(d):
+        pp = [d.upload(x) for x in polys]; pe = d.upload(eq)
+        o1 = d.sumcheck_combine_round(S, pp, pe, n, degree)
+        o2 = d.combine_claim(S, pp, pe, n)
+        for p in pp + [pe]:
+            d.free(p)
+        return o1, o2
+    (a1, a2), (b1, b2) = both(devs, run)
+    assert np.array_equal(a1, b1)
+    assert np.array_equal(a2, b2)
+
+
+@pytest.mark.parametrize("n,k", [(1, 1), (7, 2), (1 << 12, 5), (1 << 16, 1)])
+def test_multi_dot(devs, n, k):
+    rng = np.random.default_rng(n * 3 + k)
+    polys = [rand_fr(rng, n) for _ in range(k)]
+    w = rand_fr(rng, n)
+
+    def run(d):
+        pp = [d.upload(x) for x in polys]; pw = d.upload(w)
+        out = d.multi_dot(pp, pw, n)
+        for p in pp + [pw]:
+            d.free(p)
+        return out
+    a, b = both(devs, run)
+    assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("n", [2, 4, 8, 512, 1024, 1 << 13])
+def test_gp_build(devs, n):
+    rng = np.random.default_rng(n)
+    leaves = rand_fr(rng, n)
+
+    def run(d):
+        tree = np.zeros((2 * n, 4), dtype=np.uint64); tree[:n] = leaves
+        p = d.upload(tree)
+        d.gp_build(p, n)
+        out = d.download(p, (2 * n - 2, 4))
+        d.free(p)
+        return out
+    a, b = both(devs, run)
+    assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("s,log_m", [(16, 4), (1 << 12, 8), (1 << 14, 16)])
+def test_fingerprints_gather_from_u32(devs, s, log_m):
+    rng = np.random.default_rng(s)
+    m = 1 << log_m
+    table_u32 = rng.integers(0, 1 << 16, size=m, dtype=np.uint32)
+    dim = rng.integers(0, m, size=s, dtype=np.uint32)
+    read_u32 = rng.integers(0, 1000, size=s, dtype=np.uint32)
+    final_u32 = rng.integers(0, 1000, size=m, dtype=np.uint32)
+    table_u32[0] = 0xFFFFFFFF                      # from_u32 edge
+    gamma, tau = rand_fr(rng, 2, edge=False)
+
+    def run(d):
+        pt32 = d.upload(table_u32); pdim = d.upload(dim); pr32 = d.upload(read_u32); pf32 = d.upload(final_u32)
+        pt = d.alloc(32 * m); pr = d.alloc(32 * s); pf = d.alloc(32 * m); pe = d.alloc(32 * s)
+        d.fr_from_u32(pt32, m, pt); d.fr_from_u32(pr32, s, pr); d.fr_from_u32(pf32, m, pf)
+        d.gather(pt, pdim, s, pe)
+        ro = d.alloc(32 * s); wo = d.alloc(32 * s); io = d.alloc(32 * m); fo = d.alloc(32 * m)
+        d.fingerprint_ops(pt, pdim, pr, s, gamma, tau, ro, wo)
+        d.fingerprint_mem(pt, pf, m, gamma, tau, io, fo)
+        outs = [d.download(pt, (m, 4)), d.download(pe, (s, 4)), d.download(ro, (s, 4)), d.download(wo, (s, 4)), d.download(io, (m, 4)), d.download(fo, (m, 4))]
+        for p in (pt32, pdim, pr32, pf32, pt, pr, pf, pe, ro, wo, io, fo):
+            d.free(p)
+        return outs
+    a, b = both(devs, run)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("ls,rs", [(1, 1), (2, 4), (32, 64), (64, 300), (512, 1024)])
+def test_matvec_left(devs, ls, rs):
+    rng = np.random.default_rng(ls * 1000 + rs)
+    Z = rand_fr(rng, ls * rs)
+    Lv = rand_fr(rng, ls, edge=False)
+
+    def run(d):
+        p = d.upload(Z)
+        out = d.matvec_left(p, Lv, ls, rs)
+        d.free(p)
+        return out
+    a, b = both(devs, run)
+    assert np.array_equal(a, b)
+
+
+@pytest.fixture(scope="module")
+def gens_300(devs):
+    return gens(devs[1].lib, b"gens_sparse_poly", 300)
+
+
+@pytest.mark.parametrize("ls,rs,maxv", [(1, 1, 5), (4, 8, 256), (16, 256, 1 << 16), (8, 300, 1 << 24), (3, 100, 1 << 32), (2, 64, None)])
+def test_hyrax_commit(devs, gens_300, ls, rs, maxv):
+    rng = np.random.default_rng(ls * 31 + rs)
+    if maxv is None:
+        Z = rand_fr(rng, ls * rs)                      # full-width scalars: the general path
+    else:
+        vals = rng.integers(0, maxv, size=ls * rs, dtype=np.uint64)
+        vals[0] = 0; vals[-1] = maxv - 1
+        Z = small_fr(vals)
+
+    def run(d):
+        b = d.bases_create(gens_300)
+        p = d.upload(Z)
+        out = d.hyrax_commit(p, ls, rs, b)
+        d.free(p); d.bases_destroy(b)
+        return out
+    a, b = both(devs, run)
+    mock_lib = devs[1].lib
+    assert compress_points(mock_lib, a) == compress_points(mock_lib, b)
+
+
+@pytest.mark.parametrize("n", [1, 2, 33, 301])
+def test_msm_full_width(devs, gens_300, n):
+    rng = np.random.default_rng(n)
+    sc = rand_fr(rng, n)
+    if n > 2:
+        sc[n // 2] = 0                                 # zero scalars are free and must not disturb the sum
+
+    def run(d):
+        b = d.bases_create(gens_300)
+        out = d.msm(b, sc)
+        d.bases_destroy(b)
+        return out
+    a, b = both(devs, run)
+    mock_lib = devs[1].lib
+    assert compress_points(mock_lib, a) == compress_points(mock_lib, b)
+
+
+def test_msm_linearity_large(devs, oracle):
+    """size-independent property at a size the CPU oracle would not finish quickly: msm(a) + msm(b) == msm(a+b) over 2^13
+    generators; only the three resulting points go through the oracle."""
+    real, mock = devs
+    mock_lib = mock.lib
+    n = 1 << 13
+    g = gens(mock_lib, b"gens_sparse_poly", n)
+    rng = np.random.default_rng(99)
+    a = rand_fr(rng, n, edge=False); b2 = rand_fr(rng, n, edge=False)
+    s = np.empty_like(a)
+    for i in range(n):   # Montgomery form is linear: add the limb values mod p
+        x = (sum(int(a[i, k]) << (64 * k) for k in range(4)) + sum(int(b2[i, k]) << (64 * k) for k in range(4))) % FR_P
+        s[i] = limbs(x)
+    bases = real.bases_create(g)
+    pa, pb, ps = real.msm(bases, a), real.msm(bases, b2), real.msm(bases, s)
+    real.bases_destroy(bases)
+    ca, cb, cs = compress_points(mock_lib, pa)[0], compress_points(mock_lib, pb)[0], compress_points(mock_lib, ps)[0]
+    U8 = C.c_uint64 * 8
+    xa, xb, xo = U8(), U8(), U8()
+    assert oracle.orc_pt_decompress(ca, xa) == 0 and oracle.orc_pt_decompress(cb, xb) == 0
+    oracle.orc_pt_add(xa, xb, xo)
+    buf = (C.c_uint8 * 32)()
+    oracle.orc_pt_compress(xo, buf)
+    assert bytes(buf) == cs

@@ -1,0 +1,197 @@
+// Micro-benchmarks that decide the kernel design on MI355X (run on the GPU box via gpurun):
+//   1. issue rate of the integer-multiply instructions the 256-bit field arithmetic can be built from
+//   2. Montgomery / pseudo-Mersenne multiplier throughput as compiled from fr.cuh / fq.cuh
+//   3. bind_top achieved bandwidth next to pure-copy ceilings with the same access pattern
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/microbench tools/microbench.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "../lasso_amd/csrc/poly_kernels.cuh"
+#include "../lasso_amd/csrc/msm_kernels.cuh"
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
+
+// ---- 1. instruction issue rates: 8 independent chains per lane, ITER iterations
+#define ITER 4096
+#define DEF_RATE_KERNEL(NAME, BODY)                                                         \
+  __global__ void NAME(uint32_t* out, uint32_t seed) {                                       \
+    uint32_t a0 = seed + threadIdx.x, a1 = a0 * 3 + 1, a2 = a0 * 5 + 2, a3 = a0 * 7 + 3;     \
+    uint32_t a4 = a0 * 11 + 4, a5 = a0 * 13 + 5, a6 = a0 * 17 + 6, a7 = a0 * 19 + 7;         \
+    uint64_t q0 = a0, q1 = a1, q2 = a2, q3 = a3, q4 = a4, q5 = a5, q6 = a6, q7 = a7;         \
+    double d0 = a0, d1 = a1, d2 = a2, d3 = a3, d4 = a4, d5 = a5, d6 = a6, d7 = a7;           \
+    uint32_t m = seed | 1u;                                                                  \
+    for (int i = 0; i < ITER; i++) { BODY }                                                  \
+    uint32_t r = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7 ^ (uint32_t)(q0 ^ q1 ^ q2 ^ q3 ^ q4 ^ q5 ^ q6 ^ q7) ^ (uint32_t)(d0 + d1 + d2 + d3 + d4 + d5 + d6 + d7); \
+    if (r == 0x12345678u) out[0] = r;                                                        \
+  }
+#define X8(OP) OP(0) OP(1) OP(2) OP(3) OP(4) OP(5) OP(6) OP(7)
+#define OP_MAD64(k) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(q##k) : "v"(a##k), "v"(m) : "vcc");
+#define OP_MULLO(k) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a##k) : "v"(m));
+#define OP_MULHI(k) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(a##k) : "v"(m));
+#define OP_MAD24(k) asm volatile("v_mad_u32_u24 %0, %0, %1, %0" : "+v"(a##k) : "v"(m));
+#define OP_MULHI24(k) asm volatile("v_mul_hi_u32_u24 %0, %0, %1" : "+v"(a##k) : "v"(m));
+#define OP_ADD32(k) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a##k) : "v"(m));
+#define OP_ADD3(k) asm volatile("v_add3_u32 %0, %0, %1, %1" : "+v"(a##k) : "v"(m));
+#define OP_LSHLADD64(k) asm volatile("v_lshl_add_u64 %0, %0, 1, %0" : "+v"(q##k));
+#define OP_FMA64(k) asm volatile("v_fma_f64 %0, %0, %0, %0" : "+v"(d##k));
+#define OP_ADDC(k) asm volatile("v_add_co_u32 %0, vcc, %0, %1\n v_addc_co_u32 %0, vcc, %0, %1, vcc" : "+v"(a##k) : "v"(m) : "vcc");
+#define OP_MOV(k) asm volatile("v_mov_b32 %0, %1" : "=v"(a##k) : "v"(a##k));
+DEF_RATE_KERNEL(k_rate_mad64, X8(OP_MAD64))
+DEF_RATE_KERNEL(k_rate_mullo, X8(OP_MULLO))
+DEF_RATE_KERNEL(k_rate_mulhi, X8(OP_MULHI))
+DEF_RATE_KERNEL(k_rate_mad24, X8(OP_MAD24))
+DEF_RATE_KERNEL(k_rate_mulhi24, X8(OP_MULHI24))
+DEF_RATE_KERNEL(k_rate_add32, X8(OP_ADD32))
+DEF_RATE_KERNEL(k_rate_add3, X8(OP_ADD3))
+DEF_RATE_KERNEL(k_rate_lshladd64, X8(OP_LSHLADD64))
+DEF_RATE_KERNEL(k_rate_fma64, X8(OP_FMA64))
+DEF_RATE_KERNEL(k_rate_addc, X8(OP_ADDC))
+DEF_RATE_KERNEL(k_rate_mov, X8(OP_MOV))
+
+template <class K>
+static double time_kernel(K launch, int reps = 5) {
+  hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+  launch(); CK(hipDeviceSynchronize());
+  float best = 1e30f;
+  for (int i = 0; i < reps; i++) { CK(hipEventRecord(a)); launch(); CK(hipEventRecord(b)); CK(hipEventSynchronize(b)); float ms; CK(hipEventElapsedTime(&ms, a, b)); if (ms < best) best = ms; }
+  CK(hipGetLastError());
+  return best;
+}
+
+// ---- 2. multiplier throughput: 4 independent chains per lane
+__global__ void k_tp_frmul(fr_t* io, int iters) {
+  fr_t a = io[threadIdx.x & 63], b = io[64 + (threadIdx.x & 63)], c = fr_add(a, b), d = fr_sub(a, b);
+  for (int i = 0; i < iters; i++) { a = fr_mul(a, b); b = fr_mul(b, c); c = fr_mul(c, d); d = fr_mul(d, a); }
+  fr_t r = fr_add(fr_add(a, b), fr_add(c, d));
+  if (r.v[0] == 0x12345678u && r.v[1] == 0x9abcdef0u) io[blockIdx.x] = r;
+}
+__global__ void k_tp_fqmul(fq_t* io, int iters) {
+  fq_t a = io[threadIdx.x & 63], b = io[64 + (threadIdx.x & 63)], c = fq_add(a, b), d = fq_sub(a, b);
+  for (int i = 0; i < iters; i++) { a = fq_mul(a, b); b = fq_mul(b, c); c = fq_mul(c, d); d = fq_mul(d, a); }
+  fq_t r = fq_add(fq_add(a, b), fq_add(c, d));
+  if (r.v[0] == 0x12345678u && r.v[1] == 0x9abcdef0u) io[blockIdx.x] = r;
+}
+__global__ void k_tp_madd(ed_point* io, const ed_niels* nb, int iters) {
+  ed_point p = io[threadIdx.x & 63]; ed_niels n0 = nb[threadIdx.x & 63];
+  for (int i = 0; i < iters; i++) p = ed_madd(p, n0);
+  if (p.X.v[0] == 0x12345678u && p.Y.v[1] == 0x9abcdef0u) io[blockIdx.x] = p;
+}
+
+// ---- 3. bandwidth kernels
+__global__ void __launch_bounds__(256) k_copy16(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+// same traffic as bind_top (read lo+hi, write lo) without arithmetic
+__global__ void __launch_bounds__(256) k_bind_traffic(fr_t* __restrict__ z, size_t half) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x) {
+    fr_t lo = z[i], hi = z[i + half];
+#pragma unroll
+    for (int k = 0; k < 8; k++) lo.v[k] ^= hi.v[k];
+    z[i] = lo;
+  }
+}
+// bind with a lane pair per two elements: every 16-byte load is part of a fully contiguous 1 KiB wave access
+__global__ void __launch_bounds__(256) k_bind_pairs(fr_t* __restrict__ z, size_t half, fr_t r) {
+  // thread t handles element e = 2*(t/2) + (t&1) of its wave's 64-element tile, but loads halves so that lane l reads 16 B at byte 16*l
+  uint4* z4 = reinterpret_cast<uint4*>(z);
+  const size_t tid = blockIdx.x * (size_t)blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t base = (tid & ~(size_t)63); base < half; base += stride) {
+    const int lane = threadIdx.x & 63;
+    // tile of 64 elements = 128 uint4: pass 0 covers elements base..base+31, pass 1 covers base+32..base+63
+    uint4 l0 = z4[2 * base + lane], l1 = z4[2 * base + 64 + lane];
+    uint4 h0 = z4[2 * (base + half) + lane], h1 = z4[2 * (base + half) + 64 + lane];
+    // lane pair (2j, 2j+1): lane 2j takes element j of pass 0, lane 2j+1 takes element j of pass 1
+    uint4 pl0, pl1, ph0, ph1;
+#define SWZ(dst, src) dst.x = __shfl_xor((int)src.x, 1, 64); dst.y = __shfl_xor((int)src.y, 1, 64); dst.z = __shfl_xor((int)src.z, 1, 64); dst.w = __shfl_xor((int)src.w, 1, 64);
+    SWZ(pl0, l0) SWZ(pl1, l1) SWZ(ph0, h0) SWZ(ph1, h1)
+    const bool odd = lane & 1;
+    fr_t lo, hi;
+    uint4 loA = odd ? pl1 : l0, loB = odd ? l1 : pl0, hiA = odd ? ph1 : h0, hiB = odd ? h1 : ph0;
+    lo.v[0] = loA.x; lo.v[1] = loA.y; lo.v[2] = loA.z; lo.v[3] = loA.w; lo.v[4] = loB.x; lo.v[5] = loB.y; lo.v[6] = loB.z; lo.v[7] = loB.w;
+    hi.v[0] = hiA.x; hi.v[1] = hiA.y; hi.v[2] = hiA.z; hi.v[3] = hiA.w; hi.v[4] = hiB.x; hi.v[5] = hiB.y; hi.v[6] = hiB.z; hi.v[7] = hiB.w;
+    fr_t o = fr_add(lo, fr_mul(r, fr_sub(hi, lo)));
+    // write back: lane 2j holds element j (pass 0), lane 2j+1 holds element 32+j (pass 1)
+    uint4 oA = make_uint4(o.v[0], o.v[1], o.v[2], o.v[3]), oB = make_uint4(o.v[4], o.v[5], o.v[6], o.v[7]), xA, xB;
+    SWZ(xA, oA) SWZ(xB, oB)
+    uint4 w0 = odd ? xB : oA;   // pass 0, position lane: even lane -> low half of its own element; odd lane -> high half of partner's (even lane's) element
+    uint4 w1 = odd ? oB : xA;   // pass 1: even lane -> low half of partner's element; odd lane -> high half of own
+    z4[2 * base + lane] = w0; z4[2 * base + 64 + lane] = w1;
+  }
+}
+
+int main(int argc, char** argv) {
+  hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
+  printf("device: %s  CUs=%d  clock=%d MHz  memclk=%d MHz  L2=%d MB\n", prop.name, prop.multiProcessorCount, prop.clockRate / 1000, prop.memoryClockRate / 1000, prop.l2CacheSize >> 20);
+  const int CU = prop.multiProcessorCount;
+  uint32_t* d_out; CK(hipMalloc(&d_out, 4096));
+
+  printf("\n== 1. instruction issue (wave-instructions per cycle per CU at 2.4 GHz nominal; 8 waves/SIMD resident)\n");
+  struct { const char* name; void (*k)(uint32_t*, uint32_t); int per_op; } rates[] = {
+      {"v_mad_u64_u32", k_rate_mad64, 1}, {"v_mul_lo_u32", k_rate_mullo, 1}, {"v_mul_hi_u32", k_rate_mulhi, 1}, {"v_mad_u32_u24", k_rate_mad24, 1},
+      {"v_mul_hi_u32_u24", k_rate_mulhi24, 1}, {"v_add_u32", k_rate_add32, 1}, {"v_add3_u32", k_rate_add3, 1}, {"v_lshl_add_u64", k_rate_lshladd64, 1},
+      {"v_fma_f64", k_rate_fma64, 1}, {"v_add_co+v_addc_co", k_rate_addc, 2}, {"v_mov_b32", k_rate_mov, 1}};
+  for (auto& r : rates) {
+    const int blocks = CU * 8, threads = 256;  // 8 blocks of 4 waves per CU = 8 waves per SIMD
+    double ms = time_kernel([&] { hipLaunchKernelGGL(r.k, dim3(blocks), dim3(threads), 0, 0, d_out, 12345u); });
+    double wave_instr = (double)blocks * (threads / 64) * ITER * 8 * r.per_op;
+    double per_s = wave_instr / (ms * 1e-3);
+    printf("  %-22s %8.3f ms  %8.2f G wave-instr/s  => %.2f cycles per wave-instr per SIMD (@2.4GHz)  lane-ops %.1f T/s\n", r.name, ms, per_s * 1e-9, (double)CU * 4 * 2.4e9 / per_s, per_s * 64e-12);
+  }
+
+  printf("\n== 2. multiplier throughput (G mult/s, whole chip)\n");
+  {
+    std::vector<fr_t> h(256); for (size_t i = 0; i < h.size(); i++) { h[i] = fr_from_u64(0x9e3779b97f4a7c15ull * (i + 1)); }
+    fr_t* d; CK(hipMalloc(&d, 65536 * sizeof(fr_t))); CK(hipMemcpy(d, h.data(), h.size() * sizeof(fr_t), hipMemcpyHostToDevice));
+    for (int wpb : {4, 8}) {
+      const int blocks = CU * wpb * 4 / 4, threads = 256, iters = 256;
+      double ms = time_kernel([&] { hipLaunchKernelGGL(k_tp_frmul, dim3(blocks), dim3(threads), 0, 0, d, iters); });
+      printf("  fr_mul (Montgomery 8x32 CIOS)   blocks/CU=%d: %8.3f ms  %7.1f G/s\n", wpb, ms, (double)blocks * threads * iters * 4 / (ms * 1e-3) * 1e-9);
+      ms = time_kernel([&] { hipLaunchKernelGGL(k_tp_fqmul, dim3(blocks), dim3(threads), 0, 0, (fq_t*)d, iters); });
+      printf("  fq_mul (2^255-19 fold)          blocks/CU=%d: %8.3f ms  %7.1f G/s\n", wpb, ms, (double)blocks * threads * iters * 4 / (ms * 1e-3) * 1e-9);
+    }
+    std::vector<ed_point> hp(64); std::vector<ed_niels> hn(64);
+    for (int i = 0; i < 64; i++) { fq_t x = fq_zero(), y = fq_one(); hp[i] = ed_from_affine(x, y); fq_t a = fq_zero(); a.v[0] = 5 + i; hn[i].ypx = a; hn[i].ymx = fq_one(); hn[i].t2d = a; }
+    ed_point* dp; ed_niels* dn; CK(hipMalloc(&dp, 65536 * sizeof(ed_point))); CK(hipMalloc(&dn, 64 * sizeof(ed_niels)));
+    CK(hipMemcpy(dp, hp.data(), 64 * sizeof(ed_point), hipMemcpyHostToDevice)); CK(hipMemcpy(dn, hn.data(), 64 * sizeof(ed_niels), hipMemcpyHostToDevice));
+    const int blocks = CU * 4, threads = 256, iters = 256;
+    double ms = time_kernel([&] { hipLaunchKernelGGL(k_tp_madd, dim3(blocks), dim3(threads), 0, 0, dp, dn, iters); });
+    printf("  ed_madd (7 fq_mul)              blocks/CU=4: %8.3f ms  %7.1f G madd/s\n", ms, (double)blocks * threads * iters / (ms * 1e-3) * 1e-9);
+    CK(hipFree(d)); CK(hipFree(dp)); CK(hipFree(dn));
+  }
+
+  printf("\n== 3. bandwidth (GB/s); bind_top algorithmic bytes = 48*n (read 32n + write 16n)\n");
+  for (int logn : {22, 24, 26}) {
+    const size_t n = (size_t)1 << logn, half = n / 2;
+    fr_t* z; CK(hipMalloc(&z, n * sizeof(fr_t))); CK(hipMemset(z, 0x11, n * sizeof(fr_t)));
+    uint4* dst; CK(hipMalloc(&dst, n * sizeof(fr_t)));
+    fr_t r = fr_from_u64(0x123456789abcdefull);
+    MutPtrTable T; T.p[0] = z;
+    double ms = time_kernel([&] { hipLaunchKernelGGL(k_copy16, dim3(CU * 8), dim3(256), 0, 0, (const uint4*)z, dst, n * 2); });
+    printf("  n=2^%d copy16 (r+w %zu MB): %7.3f ms  %7.1f GB/s\n", logn, (n * 64) >> 20, ms, n * 64.0 / (ms * 1e-3) * 1e-9);
+    for (int cap : {CU * 4, CU * 8, CU * 16, CU * 32}) {
+      size_t g = (half + 255) / 256; if (g > (size_t)cap) g = cap;
+      ms = time_kernel([&] { hipLaunchKernelGGL(k_bind_traffic, dim3((unsigned)g), dim3(256), 0, 0, z, half); });
+      double t1 = n * 48.0 / (ms * 1e-3) * 1e-9;
+      ms = time_kernel([&] { hipLaunchKernelGGL(k_bind_top, dim3((unsigned)g, 1), dim3(256), 0, 0, T, half, r); });
+      double t2 = n * 48.0 / (ms * 1e-3) * 1e-9;
+      ms = time_kernel([&] { hipLaunchKernelGGL(k_bind_pairs, dim3((unsigned)g), dim3(256), 0, 0, z, half, r); });
+      double t3 = n * 48.0 / (ms * 1e-3) * 1e-9;
+      printf("  n=2^%d grid=%5zu: traffic-only %7.1f GB/s | bind_top %7.1f GB/s (%.3f ms) | bind_pairs %7.1f GB/s\n", logn, g, t1, t2, n * 48.0 / t2 * 1e-6, t3);
+    }
+    // cubic round with 2 circuits
+    if (logn <= 24) {
+      fr_t *a0, *b0, *a1, *b1, *part; CK(hipMalloc(&a0, n * 32)); CK(hipMalloc(&b0, n * 32)); CK(hipMalloc(&a1, n * 32)); CK(hipMalloc(&b1, n * 32)); CK(hipMalloc(&part, 4096 * 6 * 32));
+      CK(hipMemset(a0, 0x07, n * 32)); CK(hipMemset(b0, 0x05, n * 32)); CK(hipMemset(a1, 0x03, n * 32)); CK(hipMemset(b1, 0x02, n * 32));
+      PtrTable A, B; A.p[0] = a0; A.p[1] = a1; B.p[0] = b0; B.p[1] = b1;
+      for (int nx : {512, 2048}) {
+        ms = time_kernel([&] { hipLaunchKernelGGL(k_cubic_round, dim3(nx, 2), dim3(256), 0, 0, A, B, (const fr_t*)z, half, part); });
+        printf("  n=2^%d cubic round k=2 nx=%d: %7.3f ms  alg %7.1f GB/s  (%.1f G montmul/s)\n", logn, nx, ms, n * 32.0 * 5 / (ms * 1e-3) * 1e-9, half * 2 * 6.0 / (ms * 1e-3) * 1e-9);
+      }
+      CK(hipFree(a0)); CK(hipFree(b0)); CK(hipFree(a1)); CK(hipFree(b1)); CK(hipFree(part));
+    }
+    CK(hipFree(z)); CK(hipFree(dst));
+  }
+  printf("\ndone\n");
+  return 0;
+}
