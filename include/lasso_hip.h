@@ -95,6 +95,9 @@ int32_t lasso_combine_claim(lasso_ctx* ctx, const lasso_strategy* s, const lasso
 /* compute_dotproduct for k polynomials against one weight vector (src/utils/mod.rs:64-73 via DensePolynomial::evaluate
  * src/poly/dense_mlpoly.rs:229-235): out[p] = sum_i d_polys[p][i] * d_w[i] */
 int32_t lasso_multi_dot(lasso_ctx* ctx, const lasso_fr* const* d_polys, uint32_t k, const lasso_fr* d_w, size_t n, lasso_fr* out);
+/* out[p] = d_polys[p][0] for k polynomials — the final claims a sumcheck hands back after the last bind
+ * (src/subprotocols/sumcheck.rs:126-132 `poly_A_vec_par[i][0]`, :257 `poly[0]`) in one transfer. */
+int32_t lasso_read_heads(lasso_ctx* ctx, const lasso_fr* const* d_polys, uint32_t k, lasso_fr* out);
 /* GrandProductCircuit::new (src/subprotocols/grand_product.rs:38-58).  d_tree holds 2n-2 elements: layer 0 (the n
  * inputs, left half | right half) at [0,n) must be filled by the caller; layer k (n/2^k elements) follows layer k-1
  * and is computed here as layer_k[i] = left_{k-1}[i] * right_{k-1}[i]. */

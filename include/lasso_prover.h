@@ -1,0 +1,49 @@
+/* lasso_prover.h — C ABI of `liblasso_prover.so`, the C++ mirror of the reference's Rust host for the north-star path.
+ *
+ * In the reference the host is Rust and these are methods (src/lasso/densified.rs, src/lasso/surge.rs); with no Rust
+ * toolchain in this image the same surface is offered to Python (tests/, bench.py) through this header:
+ *   lasso_host_densify  = DensifiedRepresentation::<F,C>::from_lookup_indices(&indices, log_m)      densified.rs:22
+ *   lasso_host_gens_new = SparsePolyCommitmentGens::<G>::new(label, c, s, num_memories, log_m)      surge.rs:32
+ *   lasso_host_commit   = DensifiedRepresentation::commit(&gens)                                     densified.rs:78
+ *   lasso_host_prove    = SparsePolynomialEvaluationProof::<G,C,M,S>::prove(&mut dense, &r, &gens,
+ *                             &mut Transcript::new(transcript_label), &mut RandomTape::new(tape_label))   surge.rs:119
+ * Proofs and commitments are returned in ark-serialize's compressed wire format (CanonicalSerialize), the artefact the
+ * unmodified Rust `verify` (surge.rs:214) would consume.  All device work goes through include/lasso_hip.h.
+ * Every function returns 0 on success, negative on error (message: lasso_host_last_error); -2 = output buffer too small
+ * (the needed size is written to *len).
+ */
+#ifndef LASSO_PROVER_H
+#define LASSO_PROVER_H
+#include <stddef.h>
+#include <stdint.h>
+#include "lasso_hip.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+typedef struct lasso_host lasso_host;
+typedef struct lasso_host_gens lasso_host_gens;
+typedef struct lasso_host_dense lasso_host_dense;
+
+const char* lasso_host_last_error(void);
+int32_t lasso_host_create(int32_t device, lasso_host** out);
+void lasso_host_destroy(lasso_host* h);
+lasso_ctx* lasso_host_ctx(lasso_host* h);   /* the device context, e.g. for lasso_prof_* */
+
+int32_t lasso_host_gens_new(lasso_host* h, const char* label, size_t c, size_t s, size_t num_memories, size_t log_m, lasso_host_gens** out);
+void lasso_host_gens_free(lasso_host_gens* g);
+/* indices: n_lookups x c, row-major (Vec<[usize; C]>) */
+int32_t lasso_host_densify(lasso_host* h, const uint64_t* indices, size_t n_lookups, size_t c, size_t log_m, lasso_host_dense** out);
+void lasso_host_dense_free(lasso_host_dense* d);
+/* out = [u64 L1][L1 x 32 B][u64 L2][L2 x 32 B]: l_variate_polys_commitment.C then log_m_variate_polys_commitment.C */
+int32_t lasso_host_commit(lasso_host_dense* d, lasso_host_gens* g, uint8_t* out, size_t cap, size_t* len);
+int32_t lasso_host_prove(lasso_host* h, lasso_host_dense* d, lasso_host_gens* g, const lasso_strategy* strategy, const lasso_fr* r, size_t r_len,
+                         const char* transcript_label, const char* tape_label, uint8_t* out, size_t cap, size_t* len);
+
+/* the bench harness's inputs (src/benches/bench.rs:13-34): one `next_u64() % memory_size` per lookup from ark_std::test_rng(),
+ * and log2(s) field elements from a fresh test_rng() */
+void lasso_host_gen_indices(size_t sparsity, size_t memory_size, uint64_t* out);
+void lasso_host_gen_random_point(size_t bits, lasso_fr* out);
+#ifdef __cplusplus
+}
+#endif
+#endif

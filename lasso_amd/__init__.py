@@ -7,3 +7,4 @@ This package is a thin ctypes binding used by tests/ and bench.py.  There is NO 
 layer on a machine without the built extension or without a GPU raises.
 """
 from .device import Device, LassoError, load_device_library  # noqa: F401
+from .prover import HostProver, load_prover_library  # noqa: F401,E402

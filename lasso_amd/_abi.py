@@ -42,6 +42,7 @@ def declare(lib):
         "lasso_sumcheck_combine_round": (i32, [vp, P(Strategy), P(vp), vp, sz, u32, vp]),
         "lasso_combine_claim": (i32, [vp, P(Strategy), P(vp), vp, sz, vp]),
         "lasso_multi_dot": (i32, [vp, P(vp), u32, vp, sz, vp]),
+        "lasso_read_heads": (i32, [vp, P(vp), u32, vp]),
         "lasso_gp_build": (i32, [vp, vp, sz]),
         "lasso_fingerprint_ops": (i32, [vp, vp, vp, vp, sz, vp, vp, vp, vp]),
         "lasso_fingerprint_mem": (i32, [vp, vp, vp, sz, vp, vp, vp, vp]),

@@ -43,7 +43,7 @@ def build_host(force=False, verbose=False):
         return None
     dev = build_device(force=False, verbose=verbose)
     if force or _stale(target, sources + [dev]):
-        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function", "-o", target,
+        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas", "-o", target,
                os.path.join(hdir, "prover_capi.cpp"), "-L" + HERE, "-llasso_hip", "-Wl,-rpath,$ORIGIN"]
         if verbose:
             print(" ".join(cmd))

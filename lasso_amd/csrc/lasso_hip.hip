@@ -239,6 +239,14 @@ int32_t lasso_multi_dot(lasso_ctx* c, const lasso_fr* const* d_polys, uint32_t k
   HIPCHK(c, hipGetLastError());
   return fetch_small(c, k, out);
 }
+int32_t lasso_read_heads(lasso_ctx* c, const lasso_fr* const* d_polys, uint32_t k, lasso_fr* out) {
+  REQUIRE(c, d_polys && out && k >= 1 && k <= LASSO_MAX_PTRS);
+  PtrTable P; for (uint32_t i = 0; i < k; i++) { REQUIRE(c, d_polys[i]); P.p[i] = (const fr_t*)d_polys[i]; }
+  int32_t rc = ensure_small(c, k); if (rc) return rc;
+  hipLaunchKernelGGL(k_read_heads, dim3(1), dim3(LASSO_BLOCK), 0, c->stream, P, k, c->d_small);
+  HIPCHK(c, hipGetLastError());
+  return fetch_small(c, k, out);
+}
 int32_t lasso_gp_build(lasso_ctx* c, lasso_fr* d_tree, size_t n) {
   REQUIRE(c, d_tree && n >= 2 && (n & (n - 1)) == 0);
   fr_t* in = (fr_t*)d_tree; size_t len = n;

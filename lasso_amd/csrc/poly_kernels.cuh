@@ -218,6 +218,11 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_gather(const fr_t* __restrict__
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = table[idx[i]];
 }
 
+__global__ void k_read_heads(PtrTable polys, uint32_t k, fr_t* __restrict__ out) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < k) out[i] = polys.p[i][0];
+}
+
 // ------------------------------------------------------------------ K11: L*Z mat-vec (dense_mlpoly.rs:184-207)
 // grid = (column blocks, row chunks); partials[chunk*R + col] = sum_{j in chunk} L[j] * Z[j*R + col]
 __global__ void __launch_bounds__(LASSO_BLOCK) k_matvec_left(const fr_t* __restrict__ Z, const fr_t* __restrict__ Lv, size_t l_size, size_t r_size, size_t rows_per_chunk,

@@ -118,6 +118,11 @@ class Device:
         self._chk(self.lib.lasso_multi_dot(self.ctx, self._ptrs(ptrs), len(ptrs), C.c_void_p(d_w), n, _vp(out)))
         return out
 
+    def read_heads(self, ptrs):
+        out = np.empty((len(ptrs), 4), dtype=np.uint64)
+        self._chk(self.lib.lasso_read_heads(self.ctx, self._ptrs(ptrs), len(ptrs), _vp(out)))
+        return out
+
     def gp_build(self, d_tree, n):
         self._chk(self.lib.lasso_gp_build(self.ctx, C.c_void_p(d_tree), n))
 

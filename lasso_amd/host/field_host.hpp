@@ -1,0 +1,90 @@
+// Host-side scalar / point helpers for the O(log n) tails of the prover.  Same arithmetic headers as the device
+// (lasso_amd/csrc/fr.cuh, fq.cuh are __host__ __device__), so there is exactly one field implementation in the product.
+#pragma once
+#include <cstring>
+#include <vector>
+#include <stdexcept>
+#include "../csrc/fq.cuh"
+#include "../../include/lasso_hip.h"
+
+namespace lasso {
+
+struct Sc {  // element of Fr in ark-ff's Montgomery form (bytes == lasso_fr)
+  fr_t v;
+  static Sc zero() { Sc s; s.v = fr_zero(); return s; }
+  static Sc one() { Sc s; s.v = fr_one(); return s; }
+  static Sc from_u64(uint64_t x) { Sc s; s.v = fr_from_u64(x); return s; }
+  static Sc from_abi(const lasso_fr& f) { Sc s; memcpy(s.v.v, f.l, 32); return s; }
+  lasso_fr abi() const { lasso_fr f; memcpy(f.l, v.v, 32); return f; }
+  Sc operator+(const Sc& o) const { Sc s; s.v = fr_add(v, o.v); return s; }
+  Sc operator-(const Sc& o) const { Sc s; s.v = fr_sub(v, o.v); return s; }
+  Sc operator*(const Sc& o) const { Sc s; s.v = fr_mul(v, o.v); return s; }
+  Sc operator-() const { Sc s; s.v = fr_neg(v); return s; }
+  Sc& operator+=(const Sc& o) { v = fr_add(v, o.v); return *this; }
+  Sc& operator-=(const Sc& o) { v = fr_sub(v, o.v); return *this; }
+  Sc& operator*=(const Sc& o) { v = fr_mul(v, o.v); return *this; }
+  bool operator==(const Sc& o) const { return fr_eq(v, o.v); }
+  bool is_zero() const { return fr_is_zero(v); }
+  Sc square() const { Sc s; s.v = fr_sqr(v); return s; }
+  Sc inverse() const { Sc s; s.v = fr_inv(v); return s; }
+  void to_bytes(uint8_t out[32]) const { fr_t c = fr_to_canonical(v); memcpy(out, c.v, 32); }  // ark-serialize: canonical, little endian
+  void canonical_limbs(uint32_t out[8]) const { fr_t c = fr_to_canonical(v); memcpy(out, c.v, 32); }
+  // ark-ff from_le_bytes_mod_order on 64 bytes (utils/transcript.rs:61-65): (lo + hi*2^256) mod p
+  static Sc from_wide_bytes(const uint8_t b[64]) {
+    fr_t lo, hi; memcpy(lo.v, b, 32); memcpy(hi.v, b + 32, 32);
+    fr_t r3; const uint32_t R3[8] = {0x7b83a2dbu, 0x2a9e4968u, 0xaef7f3ecu, 0x278324e6u, 0x04ec5b65u, 0x8065dc6cu, 0x3599cec7u, 0x0e530b77u};  // 2^768 mod p
+    memcpy(r3.v, R3, 32);
+    Sc s; s.v = fr_add(fr_mul(lo, fr_r2()), fr_mul(hi, r3)); return s;  // Montgomery products accept any 256-bit left operand
+  }
+};
+typedef std::vector<Sc> ScVec;
+
+struct Pt {  // group element, extended coordinates over plain (non-Montgomery) Fq
+  ed_point p;
+  static Pt identity() { Pt r; r.p = ed_identity(); return r; }
+  static Pt from_abi(const lasso_point& q) {
+    Pt r; fq_t t;
+    memcpy(t.v, q.x, 32); r.p.X = fq_from_mont(t); memcpy(t.v, q.y, 32); r.p.Y = fq_from_mont(t);
+    memcpy(t.v, q.t, 32); r.p.T = fq_from_mont(t); memcpy(t.v, q.z, 32); r.p.Z = fq_from_mont(t); return r;
+  }
+  static Pt from_affine_plain(const fq_t& x, const fq_t& y) { Pt r; r.p = ed_from_affine(x, y); return r; }
+  Pt operator+(const Pt& o) const { Pt r; r.p = ed_add(p, o.p); return r; }
+  Pt dbl() const { Pt r; r.p = ed_dbl(p); return r; }
+  Pt operator*(const Sc& s) const {  // 4-bit fixed window
+    uint32_t e[8]; s.canonical_limbs(e);
+    ed_point tbl[16]; tbl[0] = ed_identity(); tbl[1] = p;
+    for (int i = 2; i < 16; i++) tbl[i] = ed_add(tbl[i - 1], p);
+    ed_point acc = ed_identity();
+    for (int nib = 63; nib >= 0; nib--) {
+      for (int k = 0; k < 4; k++) acc = ed_dbl(acc);
+      uint32_t d = (e[nib / 8] >> (4 * (nib % 8))) & 15u;
+      if (d) acc = ed_add(acc, tbl[d]);
+    }
+    Pt r; r.p = acc; return r;
+  }
+};
+
+// ark-serialize compressed TE point: y (LE) with bit 7 of the last byte = "x is negative" (x > -x as canonical integers)
+inline void compress_affine(const fq_t& x, const fq_t& y, uint8_t out[32]) {
+  fq_t yc = fq_canonical(y), xc = fq_canonical(x), nx = fq_canonical(fq_neg(x));
+  memcpy(out, yc.v, 32);
+  bool neg = false;
+  for (int i = 7; i >= 0; i--) if (xc.v[i] != nx.v[i]) { neg = xc.v[i] > nx.v[i]; break; }
+  if (neg) out[31] |= 0x80;
+}
+// normalize_batch + serialize_compressed for many points with ONE inversion (Montgomery's trick)
+inline void compress_batch(const std::vector<Pt>& pts, std::vector<uint8_t>& out) {
+  size_t n = pts.size(); out.resize(32 * n);
+  if (!n) return;
+  std::vector<fq_t> pre(n);
+  fq_t acc = fq_one();
+  for (size_t i = 0; i < n; i++) { pre[i] = acc; acc = fq_mul(acc, pts[i].p.Z); }
+  fq_t inv = fq_inv(acc);
+  for (size_t i = n; i-- > 0;) {
+    fq_t zi = fq_mul(inv, pre[i]); inv = fq_mul(inv, pts[i].p.Z);
+    compress_affine(fq_mul(pts[i].p.X, zi), fq_mul(pts[i].p.Y, zi), &out[32 * i]);
+  }
+}
+inline void compress_one(const Pt& p, uint8_t out[32]) { fq_t zi = fq_inv(p.p.Z); compress_affine(fq_mul(p.p.X, zi), fq_mul(p.p.Y, zi), out); }
+
+}  // namespace lasso

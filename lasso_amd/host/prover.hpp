@@ -1,0 +1,617 @@
+// C++ mirror of the reference's Rust host for the north-star path: the protocol, the Merlin transcript and every
+// O(log n) scalar step stay here; every O(n) loop is a call into the device C ABI (include/lasso_hip.h).
+// Names, argument meaning and transcript schedule follow the reference so the parity tests read like its own:
+//   DensifiedRepresentation::{from_lookup_indices, commit}        src/lasso/densified.rs:22-96
+//   SparsePolyCommitmentGens::new                                  src/lasso/surge.rs:32-58
+//   SparsePolynomialEvaluationProof::prove                         src/lasso/surge.rs:119-211
+//   MemoryCheckingProof / ProductLayerProof / HashLayerProof       src/lasso/memory_checking.rs:56-83, :674-731, :338-460
+//   BatchedGrandProductArgument::prove, prove_cubic_batched        src/subprotocols/grand_product.rs:101-201, sumcheck.rs:27-135
+//   prove_arbitrary                                                src/subprotocols/sumcheck.rs:150-260
+//   CombinedTableEvalProof / PolyEvalProof / DotProductProofLog / BulletReductionProof
+//                                                                  src/subtables/mod.rs:230-313, src/poly/dense_mlpoly.rs:302-359,
+//                                                                  src/subprotocols/dot_product.rs:167-249, bullet.rs:40-154
+// There is no CPU fallback: a failing device call throws (the reference panics).
+#pragma once
+#include <array>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+#include "field_host.hpp"
+#include "hashes.hpp"
+
+namespace lasso {
+
+struct Error : std::runtime_error { using std::runtime_error::runtime_error; };
+#define LASSO_REQUIRE(c) do { if (!(c)) throw Error(std::string("lasso prover: requirement failed: ") + #c); } while (0)
+
+inline size_t next_pow2(size_t n) { size_t p = 1; while (p < n) p <<= 1; return p; }
+inline bool is_pow2(size_t n) { return n && !(n & (n - 1)); }
+inline size_t ceil_log2(size_t n) { size_t k = 0; while (((size_t)1 << k) < n) k++; return k; }  // == Math::log_2 (utils/math.rs:27-35) and ark_std::log2
+
+// ------------------------------------------------------------------ device handle (RAII over the C ABI)
+class Dev {
+ public:
+  lasso_ctx* ctx = nullptr;
+  explicit Dev(int device) { if (lasso_ctx_create(device, &ctx) != 0) throw Error(std::string("lasso_ctx_create: ") + lasso_last_error(nullptr)); }
+  ~Dev() { if (ctx) lasso_ctx_destroy(ctx); }
+  Dev(const Dev&) = delete; Dev& operator=(const Dev&) = delete;
+  void chk(int32_t rc, const char* what) const { if (rc != 0) throw Error(std::string(what) + " failed (" + std::to_string(rc) + "): " + lasso_last_error(ctx)); }
+  lasso_fr* alloc_fr(size_t n) const { void* p = nullptr; chk(lasso_alloc(ctx, n * sizeof(lasso_fr), &p), "lasso_alloc"); return (lasso_fr*)p; }
+  uint32_t* alloc_u32(size_t n) const { void* p = nullptr; chk(lasso_alloc(ctx, n * 4, &p), "lasso_alloc"); return (uint32_t*)p; }
+  void free(void* p) const { if (p) chk(lasso_free(ctx, p), "lasso_free"); }
+};
+// owning device buffer of field elements
+struct DBuf {
+  const Dev* dev = nullptr; lasso_fr* p = nullptr; size_t n = 0;
+  DBuf() {}
+  DBuf(const Dev& d, size_t n_) : dev(&d), p(d.alloc_fr(n_)), n(n_) {}
+  DBuf(DBuf&& o) noexcept : dev(o.dev), p(o.p), n(o.n) { o.p = nullptr; }
+  DBuf& operator=(DBuf&& o) noexcept { if (this != &o) { reset(); dev = o.dev; p = o.p; n = o.n; o.p = nullptr; } return *this; }
+  DBuf(const DBuf&) = delete; DBuf& operator=(const DBuf&) = delete;
+  void reset() { if (p && dev) dev->free(p); p = nullptr; n = 0; }
+  ~DBuf() { try { reset(); } catch (...) {} }
+};
+struct DBufU32 {
+  const Dev* dev = nullptr; uint32_t* p = nullptr; size_t n = 0;
+  DBufU32() {}
+  DBufU32(const Dev& d, const std::vector<uint32_t>& h) : dev(&d), p(d.alloc_u32(h.size() ? h.size() : 1)), n(h.size()) { if (n) d.chk(lasso_upload(d.ctx, p, h.data(), n * 4), "lasso_upload"); }
+  DBufU32(DBufU32&& o) noexcept : dev(o.dev), p(o.p), n(o.n) { o.p = nullptr; }
+  DBufU32& operator=(DBufU32&& o) noexcept { if (this != &o) { if (p && dev) dev->free(p); dev = o.dev; p = o.p; n = o.n; o.p = nullptr; } return *this; }
+  DBufU32(const DBufU32&) = delete; DBufU32& operator=(const DBufU32&) = delete;
+  ~DBufU32() { try { if (p && dev) dev->free(p); } catch (...) {} }
+};
+
+// ------------------------------------------------------------------ transcript (utils/transcript.rs:6-72)
+class ProofTranscript {
+  Merlin m;
+
+ public:
+  explicit ProofTranscript(const char* label) : m(label) {}
+  void append_message(const char* label, const char* msg) { m.append_str(label, msg); }
+  void append_protocol_name(const char* name) { m.append_str("protocol-name", name); }
+  void append_u64(const char* label, uint64_t x) { m.append_u64(label, x); }
+  void append_scalar(const char* label, const Sc& s) { uint8_t b[32]; s.to_bytes(b); m.append_message(label, b, 32); }
+  void append_scalars(const char* label, const ScVec& v) { m.append_str(label, "begin_append_vector"); for (auto& s : v) append_scalar(label, s); m.append_str(label, "end_append_vector"); }
+  void append_point_bytes(const char* label, const uint8_t b[32]) { m.append_message(label, b, 32); }
+  Sc challenge_scalar(const char* label) { uint8_t b[64]; m.challenge_bytes(label, b, 64); return Sc::from_wide_bytes(b); }
+  ScVec challenge_vector(const char* label, size_t n) { ScVec v; for (size_t i = 0; i < n; i++) v.push_back(challenge_scalar(label)); return v; }
+};
+// ark-ff Fp::rand on the test RNG (first draw): limbs taken as the Montgomery representation, top 3 bits masked, rejection
+inline Sc fr_rand(ChaChaRng& rng) {
+  for (;;) {
+    uint64_t l[4]; for (int i = 0; i < 4; i++) l[i] = rng.next_u64();
+    l[3] &= (~(uint64_t)0) >> 3;
+    fr_t t; memcpy(t.v, l, 32);
+    if (!fr_geq_p(t.v)) { Sc s; s.v = t; return s; }
+  }
+}
+class RandomTape {  // utils/random.rs:9-39
+  ProofTranscript tape;
+
+ public:
+  explicit RandomTape(const char* name) : tape(name) { ChaChaRng prng = ChaChaRng::test_rng(); tape.append_scalar("init_randomness", fr_rand(prng)); }
+  Sc random_scalar(const char* label) { return tape.challenge_scalar(label); }
+  ScVec random_vector(const char* label, size_t n) { return tape.challenge_vector(label, n); }
+};
+
+// ------------------------------------------------------------------ generators (poly/commitments.rs:22-44, dot_product.rs:139-150, dense_mlpoly.rs:34-45)
+inline bool fq_sqrt(const fq_t& a, fq_t& out) {  // p = 5 (mod 8)
+  const uint32_t e[8] = {0xfffffffeu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0x0fffffffu};  // (p+3)/8
+  fq_t r = fq_pow(a, e);
+  if (fq_eq(fq_sqr(r), a)) { out = r; return true; }
+  const fq_t sqrtm1 = fq_from_limbs(0x4a0ea0b0u, 0xc4ee1b27u, 0xad2fe478u, 0x2f431806u, 0x3dfbd7a7u, 0x2b4d0099u, 0x4fc1df0bu, 0x2b832480u);
+  r = fq_mul(r, sqrtm1);
+  if (fq_eq(fq_sqr(r), a)) { out = r; return true; }
+  return false;
+}
+inline bool canonical_less(const fq_t& a, const fq_t& b) { fq_t x = fq_canonical(a), y = fq_canonical(b); for (int i = 7; i >= 0; i--) if (x.v[i] != y.v[i]) return x.v[i] < y.v[i]; return false; }
+// ark-ec `Projective::rand` for a twisted Edwards curve: y <- Fq::rand, bool, x from y (smaller or larger root), times the cofactor
+inline Pt point_rand(ChaChaRng& rng) {
+  for (;;) {
+    uint64_t l[4]; for (int i = 0; i < 4; i++) l[i] = rng.next_u64();
+    l[3] &= (~(uint64_t)0) >> 1;
+    fq_t ym; memcpy(ym.v, l, 32);
+    {  // rejection: limbs (Montgomery representation) must be < p
+      const uint32_t P[8] = {0xffffffedu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0x7fffffffu};
+      bool lt = false; for (int i = 7; i >= 0; i--) if (ym.v[i] != P[i]) { lt = ym.v[i] < P[i]; break; }
+      if (!lt) continue;
+    }
+    bool greatest = ((int32_t)rng.next_u32()) < 0;
+    fq_t y = fq_from_mont(ym), y2 = fq_sqr(y);
+    fq_t den = fq_sub(fq_neg(fq_one()), fq_mul(fq_d(), y2));   // a - d*y^2, a = -1
+    if (fq_is_zero(den)) continue;
+    fq_t x2 = fq_mul(fq_sub(fq_one(), y2), fq_inv(den)), x;
+    if (!fq_sqrt(x2, x)) continue;
+    fq_t nx = fq_neg(x), xs, xl;
+    if (canonical_less(nx, x)) { xs = nx; xl = x; } else { xs = x; xl = nx; }
+    Pt p = Pt::from_affine_plain(greatest ? xl : xs, y);
+    return p.dbl().dbl().dbl();
+  }
+}
+inline void compress_generator(uint8_t out[32]) {
+  fq_t gx = fq_from_limbs(0x8f25d51au, 0xc9562d60u, 0x9525a7b2u, 0x692cc760u, 0xfdd6dc5cu, 0xc0a4e231u, 0xcd6e53feu, 0x216936d3u);
+  fq_t gy = fq_from_limbs(0x66666658u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u);
+  compress_affine(gx, gy, out);
+}
+// The generator stream for one label: MultiCommitGens::new(n, label) = first n points as G, point n as h.
+struct GenStream {
+  std::vector<Pt> pts;
+  GenStream(const char* label, size_t count) {
+    Shake256 sh; sh.update(label, strlen(label));
+    uint8_t buf[32]; compress_generator(buf); sh.update(buf, 32);
+    uint8_t seed[32]; sh.read(seed, 32);
+    ChaChaRng rng(seed, 20);
+    for (size_t i = 0; i < count; i++) pts.push_back(point_rand(rng));
+  }
+};
+// PolyCommitmentGens for one polynomial size: gens_n = {G[0..n), h}, gens_1 = {G[n], h} with h = stream[n+1]  (DotProductProofGens::new(n) =
+// MultiCommitGens::new(n+1).split_at(n)); the device table holds [G_0..G_{n-1}, Q = G_n, h] so one MSM covers G, Q and h.
+struct PolyCommitmentGens {
+  size_t n = 0; Pt Q, h; std::vector<lasso_affine> affine; lasso_bases* bases = nullptr; const Dev* dev = nullptr;
+  PolyCommitmentGens() {}
+  PolyCommitmentGens(const Dev& d, const GenStream& gs, size_t num_vars) : dev(&d) {
+    n = (size_t)1 << (num_vars - num_vars / 2);   // right = ell - ell/2 (eq_poly.rs:40-42)
+    LASSO_REQUIRE(gs.pts.size() >= n + 2);
+    Q = gs.pts[n]; h = gs.pts[n + 1];
+    // affine Montgomery limbs for the ABI, one batch inversion
+    std::vector<fq_t> pre(n + 2); fq_t acc = fq_one();
+    for (size_t i = 0; i < n + 2; i++) { pre[i] = acc; acc = fq_mul(acc, gs.pts[i].p.Z); }
+    fq_t inv = fq_inv(acc); affine.resize(n + 2);
+    for (size_t i = n + 2; i-- > 0;) {
+      fq_t zi = fq_mul(inv, pre[i]); inv = fq_mul(inv, gs.pts[i].p.Z);
+      fq_t x = fq_to_mont(fq_mul(gs.pts[i].p.X, zi)), y = fq_to_mont(fq_mul(gs.pts[i].p.Y, zi));
+      memcpy(affine[i].x, x.v, 32); memcpy(affine[i].y, y.v, 32);
+    }
+    d.chk(lasso_bases_create(d.ctx, affine.data(), n + 2, &bases), "lasso_bases_create");
+  }
+  PolyCommitmentGens(PolyCommitmentGens&& o) noexcept { *this = std::move(o); }
+  PolyCommitmentGens& operator=(PolyCommitmentGens&& o) noexcept { std::swap(n, o.n); std::swap(Q, o.Q); std::swap(h, o.h); affine.swap(o.affine); std::swap(bases, o.bases); std::swap(dev, o.dev); return *this; }
+  ~PolyCommitmentGens() { if (bases && dev) lasso_bases_destroy(dev->ctx, bases); }
+};
+struct SparsePolyCommitmentGens {  // surge.rs:25-59
+  PolyCommitmentGens gens_combined_l_variate, gens_combined_log_m_variate, gens_derefs;
+  SparsePolyCommitmentGens(const Dev& d, const char* label, size_t c, size_t s, size_t num_memories, size_t log_m) {
+    size_t nv_l = ceil_log2(next_pow2(2 * c * s)), nv_m = ceil_log2(next_pow2(c)) + log_m, nv_d = ceil_log2(next_pow2(num_memories * s));
+    size_t mx = std::max(nv_l, std::max(nv_m, nv_d));
+    GenStream gs(label, ((size_t)1 << (mx - mx / 2)) + 2);   // the three sets share one label => one stream, three prefixes
+    gens_combined_l_variate = PolyCommitmentGens(d, gs, nv_l);
+    gens_combined_log_m_variate = PolyCommitmentGens(d, gs, nv_m);
+    gens_derefs = PolyCommitmentGens(d, gs, nv_d);
+  }
+};
+
+// ------------------------------------------------------------------ strategies (host side of subtables/*.rs)
+struct Strategy {
+  lasso_strategy abi;
+  Strategy(int kind, uint32_t c, uint32_t log_m, uint32_t log_r) { abi.kind = kind; abi.c = c; abi.log_m = log_m; abi.log_r = log_r; }
+  size_t C() const { return abi.c; }
+  size_t M() const { return (size_t)1 << abi.log_m; }
+  size_t num_subtables() const { return abi.kind == LASSO_LT ? 2 : abi.kind == LASSO_RANGE ? 3 : 1; }
+  size_t num_memories() const { return abi.kind == LASSO_LT ? 2 * C() : C(); }
+  size_t sumcheck_poly_degree() const { return (abi.kind == LASSO_LT ? C() : 1) + 1; }
+  size_t memory_to_subtable_index(size_t i) const {
+    if (abi.kind == LASSO_RANGE) { size_t lm = abi.log_m; if (i * lm > abi.log_r) return 2; return ((i + 1) * lm > abi.log_r) ? 1 : 0; }  // range_check.rs:62-69
+    return i % num_subtables();                                                                                                        // subtables/mod.rs:64-68
+  }
+  size_t memory_to_dimension_index(size_t i) const { return abi.kind == LASSO_RANGE ? i : i / num_subtables(); }                       // mod.rs:70-74, range_check.rs:71-73
+  // materialize_subtables: every table of the reference holds small integers, so the host builds u32 and the device lifts to Fr
+  std::vector<std::vector<uint32_t>> materialize_subtables() const {
+    size_t m = M(), bits = abi.log_m / 2; std::vector<std::vector<uint32_t>> out;
+    auto split = [&](size_t idx, size_t& l, size_t& r) { size_t mask = ((size_t)1 << bits) - 1; r = idx & mask; l = (idx >> bits) & mask; };   // utils/mod.rs:82-89
+    if (abi.kind == LASSO_AND || abi.kind == LASSO_OR || abi.kind == LASSO_XOR) {
+      std::vector<uint32_t> t(m);
+      for (size_t i = 0; i < m; i++) { size_t l, r; split(i, l, r); t[i] = (uint32_t)(abi.kind == LASSO_AND ? (l & r) : abi.kind == LASSO_OR ? (l | r) : (l ^ r)); }
+      out.push_back(t);
+    } else if (abi.kind == LASSO_LT) {
+      std::vector<uint32_t> lt(m), eq(m);
+      for (size_t i = 0; i < m; i++) { size_t l, r; split(i, l, r); lt[i] = l < r; eq[i] = l == r; }
+      out.push_back(lt); out.push_back(eq);
+    } else {
+      std::vector<uint32_t> full(m), rem(m), zeros(m, 0);
+      size_t cutoff = (size_t)1 << (abi.log_r % abi.log_m);
+      for (size_t i = 0; i < m; i++) { full[i] = (uint32_t)i; rem[i] = i < cutoff ? (uint32_t)i : 0; }
+      out.push_back(full); out.push_back(rem); out.push_back(zeros);
+    }
+    return out;
+  }
+};
+
+// ------------------------------------------------------------------ UniPoly (poly/unipoly.rs:13-120)
+// from_evals solves the same Vandermonde system as the reference's Gaussian elimination; the solution is unique and the
+// arithmetic exact, so the inverse matrix is computed once per degree and applied as a mat-vec.
+struct UniPoly {
+  ScVec coeffs;
+  static const std::vector<ScVec>& inv_vandermonde(size_t n) {
+    static std::map<size_t, std::vector<ScVec>> cache;
+    auto it = cache.find(n); if (it != cache.end()) return it->second;
+    std::vector<ScVec> a(n, ScVec(2 * n, Sc::zero()));
+    for (size_t i = 0; i < n; i++) { Sc x = Sc::from_u64(i), pw = Sc::one(); for (size_t j = 0; j < n; j++) { a[i][j] = pw; pw *= x; } a[i][n + i] = Sc::one(); }
+    for (size_t col = 0; col < n; col++) {   // Gauss-Jordan; leading minors of a Vandermonde matrix on distinct nodes are non-singular
+      size_t piv = col; while (a[piv][col].is_zero()) piv++;
+      std::swap(a[piv], a[col]);
+      Sc inv = a[col][col].inverse(); for (auto& v : a[col]) v *= inv;
+      for (size_t r = 0; r < n; r++) if (r != col && !a[r][col].is_zero()) { Sc f = a[r][col]; for (size_t k = 0; k < 2 * n; k++) a[r][k] -= f * a[col][k]; }
+    }
+    std::vector<ScVec> inv(n, ScVec(n)); for (size_t i = 0; i < n; i++) for (size_t j = 0; j < n; j++) inv[i][j] = a[i][n + j];
+    return cache.emplace(n, inv).first->second;
+  }
+  static UniPoly from_evals(const ScVec& evals) {
+    const auto& V = inv_vandermonde(evals.size()); UniPoly p; p.coeffs.assign(evals.size(), Sc::zero());
+    for (size_t i = 0; i < evals.size(); i++) for (size_t j = 0; j < evals.size(); j++) p.coeffs[i] += V[i][j] * evals[j];
+    return p;
+  }
+  Sc evaluate(const Sc& r) const { Sc e = coeffs[0], pw = r; for (size_t i = 1; i < coeffs.size(); i++) { e += pw * coeffs[i]; pw *= r; } return e; }
+  ScVec compress() const { ScVec c; c.push_back(coeffs[0]); c.insert(c.end(), coeffs.begin() + 2, coeffs.end()); return c; }   // drops the linear term :82-88
+  void append_to_transcript(ProofTranscript& t, const char* label) const {   // :112-120
+    t.append_message(label, "UniPoly_begin"); for (auto& c : coeffs) t.append_scalar("coeff", c); t.append_message(label, "UniPoly_end");
+  }
+};
+// EqPolynomial::evals on the host, for the sqrt(n)-sized L and R vectors (eq_poly.rs:22-52)
+inline ScVec eq_evals_host(const Sc* r, size_t ell) {
+  ScVec ev((size_t)1 << ell, Sc::one()); size_t size = 1;
+  for (size_t j = 0; j < ell; j++) { size *= 2; for (size_t i = size; i-- > 0;) { if (!(i & 1)) continue; Sc sc = ev[i / 2]; ev[i] = sc * r[j]; ev[i - 1] = sc - ev[i]; } }
+  return ev;
+}
+
+// ------------------------------------------------------------------ proof container = ark-serialize (compressed) byte stream
+struct ProofWriter {
+  std::vector<uint8_t> b;
+  void u64le(uint64_t x) { for (int i = 0; i < 8; i++) b.push_back((uint8_t)(x >> (8 * i))); }
+  void sc(const Sc& s) { uint8_t t[32]; s.to_bytes(t); b.insert(b.end(), t, t + 32); }
+  void sc_vec(const ScVec& v) { u64le(v.size()); for (auto& s : v) sc(s); }
+  void sc_arr(const ScVec& v) { for (auto& s : v) sc(s); }
+  void pt_bytes(const uint8_t p[32]) { b.insert(b.end(), p, p + 32); }
+  void pts_vec(const std::vector<uint8_t>& compressed) { u64le(compressed.size() / 32); b.insert(b.end(), compressed.begin(), compressed.end()); }
+};
+struct SumcheckProof { std::vector<ScVec> compressed_polys; void write(ProofWriter& w) const { w.u64le(compressed_polys.size()); for (auto& c : compressed_polys) w.sc_vec(c); } };
+struct DotProductProofLog {
+  std::vector<uint8_t> L_vec, R_vec; uint8_t delta[32], beta[32]; Sc z1, z2;
+  void write(ProofWriter& w) const { w.pts_vec(L_vec); w.pts_vec(R_vec); w.pt_bytes(delta); w.pt_bytes(beta); w.sc(z1); w.sc(z2); }
+};
+struct LayerProofBatched { SumcheckProof proof; ScVec claims_prod_left, claims_prod_right; };
+struct BatchedGrandProductArgument { std::vector<LayerProofBatched> proof; void write(ProofWriter& w) const { w.u64le(proof.size()); for (auto& l : proof) { l.proof.write(w); w.sc_vec(l.claims_prod_left); w.sc_vec(l.claims_prod_right); } } };
+
+// ------------------------------------------------------------------ Hyrax commitment of a device polynomial (dense_mlpoly.rs:109-181)
+struct PolyCommitment { std::vector<uint8_t> compressed; size_t rows = 0; };   // C: Vec<G>, kept in wire form
+inline PolyCommitment hyrax_commit(const Dev& d, const lasso_fr* d_Z, size_t num_vars, const PolyCommitmentGens& gens) {
+  size_t l_size = (size_t)1 << (num_vars / 2), r_size = (size_t)1 << (num_vars - num_vars / 2);
+  LASSO_REQUIRE(r_size == gens.n);
+  std::vector<lasso_point> rows(l_size);
+  d.chk(lasso_hyrax_commit(d.ctx, d_Z, l_size, r_size, gens.bases, rows.data()), "lasso_hyrax_commit");
+  std::vector<Pt> pts(l_size); for (size_t i = 0; i < l_size; i++) pts[i] = Pt::from_abi(rows[i]);
+  PolyCommitment c; c.rows = l_size; compress_batch(pts, c.compressed); return c;
+}
+inline void append_poly_commitment(ProofTranscript& t, const char* label, const PolyCommitment& c) {  // dense_mlpoly.rs:281-289
+  t.append_message(label, "poly_commitment_begin");
+  for (size_t i = 0; i < c.rows; i++) t.append_point_bytes("poly_commitment_share", &c.compressed[32 * i]);
+  t.append_message(label, "poly_commitment_end");
+}
+
+// ------------------------------------------------------------------ DensifiedRepresentation (densified.rs:8-97)
+struct SparsePolynomialCommitment { PolyCommitment l_variate_polys_commitment, log_m_variate_polys_commitment; size_t s, log_m, m; };
+struct DensifiedRepresentation {
+  const Dev* dev; size_t C, s, log_m, m;
+  std::vector<DBufU32> dim_u32;                       // dim_usize, on device
+  DBuf combined_l_variate_polys, combined_log_m_variate_polys;   // [dim_1..dim_C, read_1..read_C | 0...], [final_1..final_C | 0...]
+  size_t nv_l, nv_m;
+  const lasso_fr* dim(size_t i) const { return combined_l_variate_polys.p + i * s; }
+  const lasso_fr* read(size_t i) const { return combined_l_variate_polys.p + (C + i) * s; }
+  const lasso_fr* final_(size_t i) const { return combined_log_m_variate_polys.p + i * m; }
+
+  // indices: n_lookups x C, row-major (the reference's Vec<[usize; C]>)
+  static std::unique_ptr<DensifiedRepresentation> from_lookup_indices(const Dev& d, const uint64_t* indices, size_t n_lookups, size_t C, size_t log_m) {
+    auto D = std::make_unique<DensifiedRepresentation>();
+    D->dev = &d; D->C = C; D->s = next_pow2(n_lookups); D->log_m = log_m; D->m = (size_t)1 << log_m;
+    const size_t s = D->s, m = D->m;
+    size_t n_l = next_pow2(2 * C * s), n_m = next_pow2(C) * m;
+    D->nv_l = ceil_log2(n_l); D->nv_m = ceil_log2(n_m);
+    D->combined_l_variate_polys = DBuf(d, n_l); D->combined_log_m_variate_polys = DBuf(d, n_m);
+    d.chk(lasso_zero(d.ctx, D->combined_l_variate_polys.p, n_l * sizeof(lasso_fr)), "lasso_zero");
+    d.chk(lasso_zero(d.ctx, D->combined_log_m_variate_polys.p, n_m * sizeof(lasso_fr)), "lasso_zero");
+    for (size_t i = 0; i < C; i++) {   // densified.rs:32-57: per-dimension timestamp counting (serial in the reference, TODO(#29))
+      std::vector<uint32_t> access(s, 0), read_ts(s, 0), final_ts(m, 0);
+      for (size_t k = 0; k < n_lookups; k++) { uint64_t a = indices[k * C + i]; LASSO_REQUIRE(a < m); access[k] = (uint32_t)a; }
+      for (size_t k = 0; k < s; k++) { uint32_t a = access[k]; uint32_t ts = final_ts[a]; read_ts[k] = ts; final_ts[a] = ts + 1; }
+      DBufU32 d_access(d, access), d_read(d, read_ts), d_final(d, final_ts);
+      d.chk(lasso_fr_from_u32(d.ctx, d_access.p, s, D->combined_l_variate_polys.p + i * s), "lasso_fr_from_u32");
+      d.chk(lasso_fr_from_u32(d.ctx, d_read.p, s, D->combined_l_variate_polys.p + (C + i) * s), "lasso_fr_from_u32");
+      d.chk(lasso_fr_from_u32(d.ctx, d_final.p, m, D->combined_log_m_variate_polys.p + i * m), "lasso_fr_from_u32");
+      d.chk(lasso_sync(d.ctx), "lasso_sync");
+      D->dim_u32.push_back(std::move(d_access));
+    }
+    return D;
+  }
+  SparsePolynomialCommitment commit(const SparsePolyCommitmentGens& gens) const {  // densified.rs:78-96
+    SparsePolynomialCommitment c;
+    c.l_variate_polys_commitment = hyrax_commit(*dev, combined_l_variate_polys.p, nv_l, gens.gens_combined_l_variate);
+    c.log_m_variate_polys_commitment = hyrax_commit(*dev, combined_log_m_variate_polys.p, nv_m, gens.gens_combined_log_m_variate);
+    c.s = s; c.log_m = log_m; c.m = m; return c;
+  }
+};
+
+// ------------------------------------------------------------------ the prover
+class Prover {
+  const Dev& d; const Strategy S; DensifiedRepresentation& dense; const SparsePolyCommitmentGens& gens; ProofTranscript& t; RandomTape& tape;
+  size_t alpha, s, m, nv_derefs;
+  std::vector<DBuf> tables;          // subtable_entries, lifted to Fr
+  DBuf combined_E;                   // Subtables::combined_poly = merge(lookup_polys); E_i = slice i
+  const lasso_fr* E(size_t i) const { return combined_E.p + i * s; }
+
+ public:
+  std::vector<uint8_t> proof_bytes;
+  Prover(const Dev& d_, const Strategy& S_, DensifiedRepresentation& dense_, const SparsePolyCommitmentGens& gens_, ProofTranscript& t_, RandomTape& tape_)
+      : d(d_), S(S_), dense(dense_), gens(gens_), t(t_), tape(tape_) { alpha = S.num_memories(); s = dense.s; m = dense.m; LASSO_REQUIRE(S.C() == dense.C && S.M() == dense.m); }
+
+  // ---- SumcheckInstanceProof::prove_arbitrary (sumcheck.rs:150-260); polys[0..alpha) = E clones, polys[alpha] = eq
+  SumcheckProof prove_arbitrary(size_t num_rounds, std::vector<lasso_fr*>& polys, size_t combined_degree, ScVec& r_out) {
+    SumcheckProof proof; size_t len = (size_t)1 << num_rounds;
+    std::vector<const lasso_fr*> cp(polys.begin(), polys.begin() + alpha);
+    for (size_t round = 0; round < num_rounds; round++) {
+      std::vector<lasso_fr> ev(combined_degree + 1);
+      d.chk(lasso_sumcheck_combine_round(d.ctx, &S.abi, cp.data(), polys[alpha], len, (uint32_t)combined_degree, ev.data()), "lasso_sumcheck_combine_round");
+      ScVec evals; for (auto& e : ev) evals.push_back(Sc::from_abi(e));
+      UniPoly up = UniPoly::from_evals(evals);
+      up.append_to_transcript(t, "poly");
+      Sc r_j = t.challenge_scalar("challenge_nextround"); r_out.push_back(r_j);
+      lasso_fr rj = r_j.abi();
+      d.chk(lasso_bind_top(d.ctx, polys.data(), (uint32_t)polys.size(), len, &rj), "lasso_bind_top");
+      len /= 2;
+      proof.compressed_polys.push_back(up.compress());
+    }
+    return proof;
+  }
+  // ---- SumcheckInstanceProof::prove_cubic_batched (sumcheck.rs:27-135), comb = A*B*C
+  SumcheckProof prove_cubic_batched(const Sc& claim, size_t num_rounds, std::vector<lasso_fr*>& A, std::vector<lasso_fr*>& B, lasso_fr* Cp, const ScVec& coeffs, ScVec& r_out,
+                                    ScVec& claims_a, ScVec& claims_b) {
+    SumcheckProof proof; Sc e = claim; size_t len = (size_t)1 << num_rounds; const size_t k = A.size();
+    std::vector<lasso_fr*> all(A); all.insert(all.end(), B.begin(), B.end()); all.push_back(Cp);
+    for (size_t j = 0; j < num_rounds; j++) {
+      std::vector<lasso_fr> ev(3 * k);
+      d.chk(lasso_sumcheck_cubic_round(d.ctx, (const lasso_fr* const*)A.data(), (const lasso_fr* const*)B.data(), (uint32_t)k, Cp, len, ev.data()), "lasso_sumcheck_cubic_round");
+      Sc c0 = Sc::zero(), c2 = Sc::zero(), c3 = Sc::zero();
+      for (size_t i = 0; i < k; i++) { c0 += Sc::from_abi(ev[3 * i]) * coeffs[i]; c2 += Sc::from_abi(ev[3 * i + 1]) * coeffs[i]; c3 += Sc::from_abi(ev[3 * i + 2]) * coeffs[i]; }
+      UniPoly poly = UniPoly::from_evals({c0, e - c0, c2, c3});
+      poly.append_to_transcript(t, "poly");
+      Sc r_j = t.challenge_scalar("challenge_nextround"); r_out.push_back(r_j);
+      lasso_fr rj = r_j.abi();
+      d.chk(lasso_bind_top(d.ctx, all.data(), (uint32_t)all.size(), len, &rj), "lasso_bind_top");
+      len /= 2;
+      e = poly.evaluate(r_j);
+      proof.compressed_polys.push_back(poly.compress());
+    }
+    std::vector<lasso_fr> heads(2 * k);
+    d.chk(lasso_read_heads(d.ctx, (const lasso_fr* const*)all.data(), (uint32_t)(2 * k), heads.data()), "lasso_read_heads");
+    claims_a.clear(); claims_b.clear();
+    for (size_t i = 0; i < k; i++) { claims_a.push_back(Sc::from_abi(heads[i])); claims_b.push_back(Sc::from_abi(heads[k + i])); }
+    return proof;
+  }
+  // ---- BatchedGrandProductArgument::prove (grand_product.rs:101-201).  trees[c]: 2n-2 elements, layer k at offset n*(2 - 2^(1-k))
+  BatchedGrandProductArgument bgpa_prove(std::vector<lasso_fr*>& trees, size_t n, const ScVec& roots, ScVec& rand_out) {
+    BatchedGrandProductArgument out; const size_t k = trees.size(), num_layers = ceil_log2(n);
+    ScVec claims_to_verify = roots, rand;
+    DBuf eq(d, n / 2 ? n / 2 : 1);
+    for (size_t layer_id = num_layers; layer_id-- > 0;) {
+      size_t len = n >> layer_id, off = 2 * n - 2 * len;    // layer `layer_id` has n/2^layer_id elements
+      std::vector<lasso_fr> rr; for (auto& x : rand) rr.push_back(x.abi());
+      d.chk(lasso_eq_evals(d.ctx, rr.data(), (uint32_t)rr.size(), eq.p), "lasso_eq_evals");   // poly_C_par :122
+      LASSO_REQUIRE(((size_t)1 << rand.size()) == len / 2);
+      size_t num_rounds_prod = ceil_log2(len / 2);
+      std::vector<lasso_fr*> A, B; for (auto* tr : trees) { A.push_back(tr + off); B.push_back(tr + off + len / 2); }
+      ScVec coeff_vec = t.challenge_vector("rand_coeffs_next_layer", claims_to_verify.size());
+      Sc claim = Sc::zero(); for (size_t i = 0; i < claims_to_verify.size(); i++) claim += claims_to_verify[i] * coeff_vec[i];
+      LayerProofBatched lp; ScVec rand_prod;
+      lp.proof = prove_cubic_batched(claim, num_rounds_prod, A, B, eq.p, coeff_vec, rand_prod, lp.claims_prod_left, lp.claims_prod_right);
+      for (size_t i = 0; i < k; i++) { t.append_scalar("claim_prod_left", lp.claims_prod_left[i]); t.append_scalar("claim_prod_right", lp.claims_prod_right[i]); }
+      Sc r_layer = t.challenge_scalar("challenge_r_layer");
+      claims_to_verify.clear();
+      for (size_t i = 0; i < k; i++) claims_to_verify.push_back(lp.claims_prod_left[i] + r_layer * (lp.claims_prod_right[i] - lp.claims_prod_left[i]));
+      ScVec ext{r_layer}; ext.insert(ext.end(), rand_prod.begin(), rand_prod.end()); rand = ext;
+      out.proof.push_back(std::move(lp));
+    }
+    rand_out = rand; return out;
+  }
+
+  // ---- BulletReductionProof::prove + DotProductProofLog::prove (bullet.rs:40-154, dot_product.rs:167-249), blinds of x and y are zero on this path.
+  // The generator vector is never folded: G^(k)_i = sum_b w_b G_{b*n_k+i} with w the running tensor of u^{+-1}, so every L_k / R_k / g_hat is one
+  // MSM over the ORIGINAL (precomputed) generators with scalars a (x) w — same group elements as the reference's fold-then-MSM.
+  Pt msm(const PolyCommitmentGens& g, const ScVec& scalars) {
+    std::vector<lasso_fr> sc(scalars.size()); for (size_t i = 0; i < sc.size(); i++) sc[i] = scalars[i].abi();
+    lasso_point out; d.chk(lasso_msm(d.ctx, g.bases, sc.data(), sc.size(), &out), "lasso_msm");
+    return Pt::from_abi(out);
+  }
+  DotProductProofLog dot_product_log_prove(const PolyCommitmentGens& g, const ScVec& x_vec, const ScVec& a_vec, const Sc& y) {
+    t.append_protocol_name("dot product proof (log)");
+    const size_t n = x_vec.size(); LASSO_REQUIRE(a_vec.size() == n && g.n == n);
+    const size_t lg_n = ceil_log2(n);
+    Sc dd = tape.random_scalar("d"), r_delta = tape.random_scalar("r_delta"), r_beta = tape.random_scalar("r_delta");   // sic: dot_product.rs:189
+    ScVec v1 = tape.random_vector("blinds_vec_1", 2 * lg_n), v2 = tape.random_vector("blinds_vec_2", 2 * lg_n);
+    DotProductProofLog P; uint8_t buf[32];
+    ScVec full(n + 2, Sc::zero());
+    for (size_t i = 0; i < n; i++) full[i] = x_vec[i];                      // Cx = <x, G> + 0*h   (commitments.rs:84-93)
+    compress_one(msm(g, full), buf); t.append_point_bytes("Cx", buf);
+    compress_one(g.Q * y, buf); t.append_point_bytes("Cy", buf);            // Cy = y*G_1[0] + 0*h (commitments.rs:78-82)
+    t.append_scalars("a", a_vec);
+    // bullet reduction, blind = blind_x + blind_y = 0
+    ScVec a = x_vec, b = a_vec, w{Sc::one()};
+    Sc blind_fin = Sc::zero(); size_t nk = n, round = 0;
+    while (nk != 1) {
+      size_t half = nk / 2;
+      Sc c_L = Sc::zero(), c_R = Sc::zero();
+      for (size_t i = 0; i < half; i++) { c_L += a[i] * b[half + i]; c_R += a[half + i] * b[i]; }
+      const Sc& blind_L = v1[round]; const Sc& blind_R = v2[round];
+      ScVec SL(n + 2, Sc::zero()), SR(n + 2, Sc::zero());
+      for (size_t blk = 0; blk < w.size(); blk++)
+        for (size_t i = 0; i < half; i++) { SL[blk * nk + half + i] = w[blk] * a[i]; SR[blk * nk + i] = w[blk] * a[half + i]; }   // <a_L, G_R>, <a_R, G_L>
+      SL[n] = c_L; SL[n + 1] = blind_L; SR[n] = c_R; SR[n + 1] = blind_R;
+      uint8_t Lb[32], Rb[32];
+      compress_one(msm(g, SL), Lb); compress_one(msm(g, SR), Rb);
+      t.append_point_bytes("L", Lb); t.append_point_bytes("R", Rb);
+      Sc u = t.challenge_scalar("u"), u_inv = u.inverse();
+      for (size_t i = 0; i < half; i++) { a[i] = a[i] * u + u_inv * a[half + i]; b[i] = b[i] * u_inv + u * b[half + i]; }
+      a.resize(half); b.resize(half);
+      ScVec w2(2 * w.size()); for (size_t blk = 0; blk < w.size(); blk++) { w2[2 * blk] = w[blk] * u_inv; w2[2 * blk + 1] = w[blk] * u; }   // G_L*u_inv + G_R*u (bullet.rs:131)
+      w.swap(w2);
+      blind_fin = blind_fin + blind_L * u * u + blind_R * u_inv * u_inv;
+      P.L_vec.insert(P.L_vec.end(), Lb, Lb + 32); P.R_vec.insert(P.R_vec.end(), Rb, Rb + 32);
+      nk = half; round++;
+    }
+    Sc x_hat = a[0], a_hat = b[0], y_hat = x_hat * a_hat;
+    ScVec sg(n + 2, Sc::zero()); for (size_t i = 0; i < n; i++) sg[i] = w[i];
+    Pt g_hat = msm(g, sg);
+    compress_one(g_hat * dd + g.h * r_delta, P.delta); t.append_point_bytes("delta", P.delta);
+    compress_one(g.Q * dd + g.h * r_beta, P.beta); t.append_point_bytes("beta", P.beta);
+    Sc c = t.challenge_scalar("c");
+    P.z1 = dd + c * y_hat;
+    P.z2 = a_hat * (c * blind_fin + r_beta) + r_delta;
+    return P;
+  }
+  // ---- PolyEvalProof::prove (dense_mlpoly.rs:302-359), blinds None
+  DotProductProofLog poly_eval_prove(const lasso_fr* d_poly, size_t num_vars, const ScVec& r, const Sc& Zr, const PolyCommitmentGens& g) {
+    t.append_protocol_name("polynomial evaluation proof");
+    LASSO_REQUIRE(r.size() == num_vars);
+    size_t left = num_vars / 2, right = num_vars - left;
+    ScVec L = eq_evals_host(r.data(), left), R = eq_evals_host(r.data() + left, right);
+    std::vector<lasso_fr> Lh(L.size()), LZh(R.size()); for (size_t i = 0; i < L.size(); i++) Lh[i] = L[i].abi();
+    d.chk(lasso_matvec_left(d.ctx, d_poly, Lh.data(), L.size(), R.size(), LZh.data()), "lasso_matvec_left");
+    ScVec LZ; for (auto& x : LZh) LZ.push_back(Sc::from_abi(x));
+    return dot_product_log_prove(g, LZ, R, Zr);
+  }
+  // ---- CombinedTableEvalProof::prove (subtables/mod.rs:285-313) / the two n-to-1 reductions of HashLayerProof (memory_checking.rs:370-449)
+  DotProductProofLog joint_open(const char* evals_label, const char* challenge_label, const char* joint_label, ScVec evals, bool pad_before_append,
+                                const lasso_fr* d_poly, size_t num_vars, const ScVec& r, const PolyCommitmentGens& g) {
+    if (pad_before_append) evals.resize(next_pow2(evals.size()), Sc::zero());
+    t.append_scalars(evals_label, evals);
+    ScVec ch = t.challenge_vector(challenge_label, ceil_log2(evals.size()));
+    evals.resize(next_pow2(evals.size()), Sc::zero());     // DensePolynomial::new_padded for the unpadded case (:420)
+    size_t len = evals.size();
+    for (size_t i = ch.size(); i-- > 0;) { len /= 2; for (size_t k = 0; k < len; k++) evals[k] = evals[2 * k] + ch[i] * (evals[2 * k + 1] - evals[2 * k]); }   // bound_poly_var_bot
+    LASSO_REQUIRE(len == 1);
+    Sc joint = evals[0];
+    ScVec r_joint = ch; r_joint.insert(r_joint.end(), r.begin(), r.end());
+    t.append_scalar(joint_label, joint);
+    return poly_eval_prove(d_poly, num_vars, r_joint, joint, g);
+  }
+
+  // ---- SparsePolynomialEvaluationProof::prove (surge.rs:119-211)
+  void prove(const ScVec& r) {
+    t.append_protocol_name("Lasso SparsePolynomialEvaluationProof");
+    LASSO_REQUIRE(r.size() == ceil_log2(s));
+    // Subtables::new (subtables/mod.rs:116-129)
+    auto host_tables = S.materialize_subtables();
+    for (auto& ht : host_tables) { DBufU32 tmp(d, ht); DBuf tb(d, m); d.chk(lasso_fr_from_u32(d.ctx, tmp.p, m, tb.p), "lasso_fr_from_u32"); d.chk(lasso_sync(d.ctx), "lasso_sync"); tables.push_back(std::move(tb)); }
+    size_t n_E = next_pow2(alpha * s); nv_derefs = ceil_log2(n_E);
+    combined_E = DBuf(d, n_E);
+    if (n_E > alpha * s) d.chk(lasso_zero(d.ctx, combined_E.p + alpha * s, (n_E - alpha * s) * sizeof(lasso_fr)), "lasso_zero");
+    for (size_t i = 0; i < alpha; i++)
+      d.chk(lasso_gather(d.ctx, tables[S.memory_to_subtable_index(i)].p, dense.dim_u32[S.memory_to_dimension_index(i)].p, s, combined_E.p + i * s), "lasso_gather");
+    ProofWriter W;
+    // comm_derefs
+    PolyCommitment comm_derefs = hyrax_commit(d, combined_E.p, nv_derefs, gens.gens_derefs);
+    t.append_message("subtable_evals_commitment", "begin_subtable_evals_commitment");
+    append_poly_commitment(t, "comm_poly_row_col_ops_val", comm_derefs);
+    t.append_message("subtable_evals_commitment", "end_subtable_evals_commitment");
+    W.pts_vec(comm_derefs.compressed);
+    // claim
+    DBuf eq(d, s);
+    { std::vector<lasso_fr> rr; for (auto& x : r) rr.push_back(x.abi()); d.chk(lasso_eq_evals(d.ctx, rr.data(), (uint32_t)rr.size(), eq.p), "lasso_eq_evals"); }
+    std::vector<const lasso_fr*> Eptr; for (size_t i = 0; i < alpha; i++) Eptr.push_back(E(i));
+    lasso_fr claim_abi; d.chk(lasso_combine_claim(d.ctx, &S.abi, Eptr.data(), eq.p, s, &claim_abi), "lasso_combine_claim");
+    Sc claimed_eval = Sc::from_abi(claim_abi);
+    t.append_scalar("claim_eval_scalar_product", claimed_eval);
+    // primary sumcheck on clones of E_i and the eq polynomial (surge.rs:151-172)
+    ScVec r_z;
+    {
+      DBuf work(d, alpha * s);
+      d.chk(lasso_copy(d.ctx, work.p, combined_E.p, alpha * s * sizeof(lasso_fr)), "lasso_copy");
+      std::vector<lasso_fr*> polys; for (size_t i = 0; i < alpha; i++) polys.push_back(work.p + i * s); polys.push_back(eq.p);
+      SumcheckProof sp = prove_arbitrary(ceil_log2(s), polys, S.sumcheck_poly_degree(), r_z);
+      sp.write(W);
+    }
+    W.sc(claimed_eval);
+    // eval_derefs = E_i(r_z) (surge.rs:175-176)
+    DBuf chis(d, s);
+    auto evaluate_at = [&](const std::vector<const lasso_fr*>& polys, const ScVec& point, size_t n, DBuf& chi) {
+      std::vector<lasso_fr> rr; for (auto& x : point) rr.push_back(x.abi());
+      d.chk(lasso_eq_evals(d.ctx, rr.data(), (uint32_t)rr.size(), chi.p), "lasso_eq_evals");
+      std::vector<lasso_fr> out(polys.size());
+      d.chk(lasso_multi_dot(d.ctx, polys.data(), (uint32_t)polys.size(), chi.p, n, out.data()), "lasso_multi_dot");
+      ScVec v; for (auto& o : out) v.push_back(Sc::from_abi(o)); return v;
+    };
+    ScVec eval_derefs = evaluate_at(Eptr, r_z, s, chis);
+    W.sc_arr(eval_derefs);
+    t.append_protocol_name("Lasso CombinedTableEvalProof");
+    joint_open("evals_ops_val", "challenge_combine_n_to_one", "joint_claim_eval", eval_derefs, true, combined_E.p, nv_derefs, r_z, gens.gens_derefs).write(W);
+    // memory checking (surge.rs:186-199)
+    ScVec r_hash = t.challenge_vector("challenge_r_hash", 2);
+    memory_checking_prove(r_hash[0], r_hash[1], Eptr, chis, W);
+    proof_bytes.swap(W.b);
+  }
+
+  void memory_checking_prove(const Sc& gamma, const Sc& tau, const std::vector<const lasso_fr*>& Eptr, DBuf& chis, ProofWriter& W) {
+    t.append_protocol_name("Lasso MemoryCheckingProof");
+    // Subtables::to_grand_products -> GrandProducts::new (subtables/mod.rs:134-175, memory_checking.rs:175-217)
+    lasso_fr g = gamma.abi(), ta = tau.abi();
+    std::vector<DBuf> t_init, t_read, t_write, t_final;
+    for (size_t i = 0; i < alpha; i++) {
+      size_t j = S.memory_to_dimension_index(i); const lasso_fr* table = tables[S.memory_to_subtable_index(i)].p;
+      DBuf ti(d, 2 * m), tf(d, 2 * m), tr(d, 2 * s), tw(d, 2 * s);
+      d.chk(lasso_fingerprint_mem(d.ctx, table, dense.final_(j), m, &g, &ta, ti.p, tf.p), "lasso_fingerprint_mem");
+      d.chk(lasso_fingerprint_ops(d.ctx, table, dense.dim_u32[j].p, dense.read(j), s, &g, &ta, tr.p, tw.p), "lasso_fingerprint_ops");
+      d.chk(lasso_gp_build(d.ctx, ti.p, m), "lasso_gp_build"); d.chk(lasso_gp_build(d.ctx, tf.p, m), "lasso_gp_build");
+      d.chk(lasso_gp_build(d.ctx, tr.p, s), "lasso_gp_build"); d.chk(lasso_gp_build(d.ctx, tw.p, s), "lasso_gp_build");
+      t_init.push_back(std::move(ti)); t_final.push_back(std::move(tf)); t_read.push_back(std::move(tr)); t_write.push_back(std::move(tw));
+    }
+    // ProductLayerProof::prove (memory_checking.rs:674-731)
+    t.append_protocol_name("Lasso ProductLayerProof");
+    auto root = [&](const DBuf& tree, size_t n) { lasso_fr two[2]; d.chk(lasso_download(d.ctx, two, tree.p + (2 * n - 4), sizeof(two)), "lasso_download"); return Sc::from_abi(two[0]) * Sc::from_abi(two[1]); };   // GrandProductCircuit::evaluate
+    ScVec roots_rw, roots_if;
+    for (size_t i = 0; i < alpha; i++) {
+      Sc hi = root(t_init[i], m), hr = root(t_read[i], s), hw = root(t_write[i], s), hf = root(t_final[i], m);
+      if (!(hi * hw == hr * hf)) throw Error("memory checking: hash_init * hash_write != hash_read * hash_final (memory_checking.rs:689)");
+      t.append_scalar("claim_hash_init", hi); t.append_scalar("claim_hash_read", hr); t.append_scalar("claim_hash_write", hw); t.append_scalar("claim_hash_final", hf);
+      W.sc(hi); W.sc(hr); W.sc(hw); W.sc(hf);
+      roots_rw.push_back(hr); roots_rw.push_back(hw); roots_if.push_back(hi); roots_if.push_back(hf);
+    }
+    std::vector<lasso_fr*> rw, inf;
+    for (size_t i = 0; i < alpha; i++) { rw.push_back(t_read[i].p); rw.push_back(t_write[i].p); inf.push_back(t_init[i].p); inf.push_back(t_final[i].p); }
+    ScVec rand_ops, rand_mem;
+    BatchedGrandProductArgument proof_ops = bgpa_prove(rw, s, roots_rw, rand_ops);
+    t_read.clear(); t_write.clear();
+    BatchedGrandProductArgument proof_mem = bgpa_prove(inf, m, roots_if, rand_mem);
+    t_init.clear(); t_final.clear();
+    proof_mem.write(W); proof_ops.write(W);    // field order of ProductLayerProof: grand_product_evals, proof_mem, proof_ops (:656-660)
+    // HashLayerProof::prove (memory_checking.rs:338-460)
+    t.append_protocol_name("Lasso HashLayerProof");
+    const size_t C = S.C();
+    std::vector<const lasso_fr*> at_ops(Eptr); for (size_t i = 0; i < C; i++) at_ops.push_back(dense.dim(i)); for (size_t i = 0; i < C; i++) at_ops.push_back(dense.read(i));
+    ScVec ev_ops;
+    {
+      std::vector<lasso_fr> rr; for (auto& x : rand_ops) rr.push_back(x.abi());
+      d.chk(lasso_eq_evals(d.ctx, rr.data(), (uint32_t)rr.size(), chis.p), "lasso_eq_evals");
+      std::vector<lasso_fr> out(at_ops.size());
+      d.chk(lasso_multi_dot(d.ctx, at_ops.data(), (uint32_t)at_ops.size(), chis.p, s, out.data()), "lasso_multi_dot");
+      for (auto& o : out) ev_ops.push_back(Sc::from_abi(o));
+    }
+    ScVec eval_derefs(ev_ops.begin(), ev_ops.begin() + alpha), eval_dim(ev_ops.begin() + alpha, ev_ops.begin() + alpha + C), eval_read(ev_ops.begin() + alpha + C, ev_ops.end());
+    t.append_protocol_name("Lasso CombinedTableEvalProof");
+    DotProductProofLog proof_derefs = joint_open("evals_ops_val", "challenge_combine_n_to_one", "joint_claim_eval", eval_derefs, true, combined_E.p, nv_derefs, rand_ops, gens.gens_derefs);
+    ScVec eval_final;
+    {
+      DBuf chim(d, m);
+      std::vector<lasso_fr> rr; for (auto& x : rand_mem) rr.push_back(x.abi());
+      d.chk(lasso_eq_evals(d.ctx, rr.data(), (uint32_t)rr.size(), chim.p), "lasso_eq_evals");
+      std::vector<const lasso_fr*> fin; for (size_t i = 0; i < C; i++) fin.push_back(dense.final_(i));
+      std::vector<lasso_fr> out(C);
+      d.chk(lasso_multi_dot(d.ctx, fin.data(), (uint32_t)C, chim.p, m, out.data()), "lasso_multi_dot");
+      for (auto& o : out) eval_final.push_back(Sc::from_abi(o));
+    }
+    ScVec evals_ops = eval_dim; evals_ops.insert(evals_ops.end(), eval_read.begin(), eval_read.end());
+    DotProductProofLog proof_ops_open = joint_open("claim_evals_ops", "challenge_combine_n_to_one", "joint_claim_eval_ops", evals_ops, true, dense.combined_l_variate_polys.p, dense.nv_l, rand_ops, gens.gens_combined_l_variate);
+    DotProductProofLog proof_mem_open = joint_open("claim_evals_mem", "challenge_combine_two_to_one", "joint_claim_eval_mem", eval_final, false, dense.combined_log_m_variate_polys.p, dense.nv_m, rand_mem, gens.gens_combined_log_m_variate);
+    W.sc_arr(eval_dim); W.sc_arr(eval_read); W.sc_arr(eval_final); W.sc_arr(eval_derefs);     // HashLayerProof field order (:314-329)
+    proof_ops_open.write(W); proof_mem_open.write(W); proof_derefs.write(W);
+  }
+};
+
+}  // namespace lasso

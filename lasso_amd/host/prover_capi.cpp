@@ -1,0 +1,41 @@
+// liblasso_prover.so — include/lasso_prover.h over lasso_amd/host/prover.hpp.  Nothing unwinds across the ABI.
+#include "prover.hpp"
+#include "../../include/lasso_prover.h"
+
+using namespace lasso;
+
+struct lasso_host { Dev dev; explicit lasso_host(int device) : dev(device) {} };
+struct lasso_host_gens { SparsePolyCommitmentGens g; lasso_host_gens(const Dev& d, const char* label, size_t c, size_t s, size_t nm, size_t log_m) : g(d, label, c, s, nm, log_m) {} };
+struct lasso_host_dense { std::unique_ptr<DensifiedRepresentation> d; };
+
+static thread_local std::string g_err;
+#define GUARD(body) try { body } catch (const std::exception& e) { g_err = e.what(); return -1; } catch (...) { g_err = "unknown error"; return -1; }
+static int32_t emit(const std::vector<uint8_t>& b, uint8_t* out, size_t cap, size_t* len) { if (len) *len = b.size(); if (!out || b.size() > cap) { g_err = "output buffer too small"; return -2; } memcpy(out, b.data(), b.size()); return 0; }
+
+extern "C" {
+const char* lasso_host_last_error(void) { return g_err.c_str(); }
+int32_t lasso_host_create(int32_t device, lasso_host** out) { GUARD(*out = new lasso_host(device); return 0;) }
+void lasso_host_destroy(lasso_host* h) { delete h; }
+lasso_ctx* lasso_host_ctx(lasso_host* h) { return h ? h->dev.ctx : nullptr; }
+int32_t lasso_host_gens_new(lasso_host* h, const char* label, size_t c, size_t s, size_t nm, size_t log_m, lasso_host_gens** out) { GUARD(*out = new lasso_host_gens(h->dev, label, c, s, nm, log_m); return 0;) }
+void lasso_host_gens_free(lasso_host_gens* g) { delete g; }
+int32_t lasso_host_densify(lasso_host* h, const uint64_t* indices, size_t n, size_t c, size_t log_m, lasso_host_dense** out) {
+  GUARD(auto* d = new lasso_host_dense(); d->d = DensifiedRepresentation::from_lookup_indices(h->dev, indices, n, c, log_m); *out = d; return 0;)
+}
+void lasso_host_dense_free(lasso_host_dense* d) { delete d; }
+int32_t lasso_host_commit(lasso_host_dense* d, lasso_host_gens* g, uint8_t* out, size_t cap, size_t* len) {
+  GUARD(SparsePolynomialCommitment c = d->d->commit(g->g); ProofWriter w; w.pts_vec(c.l_variate_polys_commitment.compressed); w.pts_vec(c.log_m_variate_polys_commitment.compressed); return emit(w.b, out, cap, len);)
+}
+int32_t lasso_host_prove(lasso_host* h, lasso_host_dense* d, lasso_host_gens* g, const lasso_strategy* st, const lasso_fr* r, size_t r_len, const char* tl, const char* pl,
+                         uint8_t* out, size_t cap, size_t* len) {
+  GUARD(
+    Strategy S(st->kind, st->c, st->log_m, st->log_r);
+    ProofTranscript t(tl); RandomTape tape(pl);
+    ScVec rv; for (size_t i = 0; i < r_len; i++) rv.push_back(Sc::from_abi(r[i]));
+    Prover P(h->dev, S, *d->d, g->g, t, tape);
+    P.prove(rv);
+    return emit(P.proof_bytes, out, cap, len);)
+}
+void lasso_host_gen_indices(size_t sparsity, size_t memory_size, uint64_t* out) { ChaChaRng rng = ChaChaRng::test_rng(); for (size_t i = 0; i < sparsity; i++) out[i] = rng.next_u64() % memory_size; }
+void lasso_host_gen_random_point(size_t bits, lasso_fr* out) { ChaChaRng rng = ChaChaRng::test_rng(); for (size_t i = 0; i < bits; i++) out[i] = fr_rand(rng).abi(); }
+}

@@ -1,0 +1,106 @@
+"""Python view of the host prover (include/lasso_prover.h): the reference's three calls — DensifiedRepresentation::from_lookup_indices,
+DensifiedRepresentation::commit, SparsePolynomialEvaluationProof::prove (src/benches/bench.rs:54-66) — over liblasso_prover.so.
+No CPU fallback: the default library is the HIP-backed one and loading fails loudly if it is missing."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _abi
+from .device import LassoError
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def load_prover_library(path=None):
+    path = path or os.path.join(HERE, "liblasso_prover.so")
+    if not os.path.exists(path):
+        raise LassoError(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` (no CPU fallback exists)")
+    return C.CDLL(path)
+
+
+def declare_prover(lib):
+    vp, sz, i32 = C.c_void_p, C.c_size_t, C.c_int32
+    lib.lasso_host_last_error.restype = C.c_char_p
+    lib.lasso_host_create.argtypes = [i32, C.POINTER(vp)]
+    lib.lasso_host_destroy.argtypes = [vp]
+    lib.lasso_host_ctx.argtypes = [vp]; lib.lasso_host_ctx.restype = vp
+    lib.lasso_host_gens_new.argtypes = [vp, C.c_char_p, sz, sz, sz, sz, C.POINTER(vp)]
+    lib.lasso_host_gens_free.argtypes = [vp]
+    lib.lasso_host_densify.argtypes = [vp, vp, sz, sz, sz, C.POINTER(vp)]
+    lib.lasso_host_dense_free.argtypes = [vp]
+    lib.lasso_host_commit.argtypes = [vp, vp, vp, sz, C.POINTER(sz)]
+    lib.lasso_host_prove.argtypes = [vp, vp, vp, C.POINTER(_abi.Strategy), vp, sz, C.c_char_p, C.c_char_p, vp, sz, C.POINTER(sz)]
+    lib.lasso_host_gen_indices.argtypes = [sz, sz, vp]
+    lib.lasso_host_gen_random_point.argtypes = [sz, vp]
+    return lib
+
+
+class HostProver:
+    """One lasso_host (device context + host prover). `lib` defaults to the product library; tests may inject the mock-backed build."""
+
+    def __init__(self, lib=None, device=0):
+        self.lib = declare_prover(lib or load_prover_library())
+        h = C.c_void_p()
+        if self.lib.lasso_host_create(device, C.byref(h)) != 0:
+            raise LassoError("lasso_host_create: " + self.lib.lasso_host_last_error().decode())
+        self.h = h
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise LassoError(f"lasso_host error {rc}: " + self.lib.lasso_host_last_error().decode())
+
+    def gen_indices(self, s, m, c):
+        one = np.empty(s, dtype=np.uint64)
+        self.lib.lasso_host_gen_indices(s, m, one.ctypes.data_as(C.c_void_p))
+        return np.repeat(one[:, None], c, axis=1).copy()     # `[x; C]`: one draw per lookup, replicated (benches/bench.rs:17)
+
+    def gen_random_point(self, bits):
+        r = np.empty((max(bits, 1), 4), dtype=np.uint64)
+        self.lib.lasso_host_gen_random_point(bits, r.ctypes.data_as(C.c_void_p))
+        return r[:bits]
+
+    def gens(self, c, s, num_memories, log_m, label=b"gens_sparse_poly"):
+        g = C.c_void_p()
+        self._chk(self.lib.lasso_host_gens_new(self.h, label, c, s, num_memories, log_m, C.byref(g)))
+        return g
+
+    def densify(self, indices, log_m):
+        indices = np.ascontiguousarray(indices, dtype=np.uint64)
+        d = C.c_void_p()
+        self._chk(self.lib.lasso_host_densify(self.h, indices.ctypes.data_as(C.c_void_p), indices.shape[0], indices.shape[1], log_m, C.byref(d)))
+        return d
+
+    def _bytes_call(self, fn, *args, cap=1 << 20):
+        while True:
+            buf = (C.c_uint8 * cap)()
+            n = C.c_size_t()
+            rc = fn(*args, buf, cap, C.byref(n))
+            if rc == -2 and n.value > cap:
+                cap = n.value
+                continue
+            self._chk(rc)
+            return bytes(buf[: n.value])
+
+    def commit(self, dense, gens):
+        return self._bytes_call(self.lib.lasso_host_commit, dense, gens)
+
+    def prove(self, dense, gens, strategy, r, transcript=b"example", tape=b"proof"):
+        r = np.ascontiguousarray(r, dtype=np.uint64).reshape(-1, 4)
+        return self._bytes_call(self.lib.lasso_host_prove, self.h, dense, gens, C.byref(strategy), r.ctypes.data_as(C.c_void_p), r.shape[0], transcript, tape)
+
+    def free(self, dense=None, gens=None):
+        if dense:
+            self.lib.lasso_host_dense_free(dense)
+        if gens:
+            self.lib.lasso_host_gens_free(gens)
+
+    def close(self):
+        if self.h:
+            self.lib.lasso_host_destroy(self.h)
+            self.h = None
+
+
+
+    def ctx(self):
+        return self.lib.lasso_host_ctx(self.h)

@@ -87,6 +87,7 @@ int32_t lasso_combine_claim(lasso_ctx*, const lasso_strategy* s, const lasso_fr*
 int32_t lasso_multi_dot(lasso_ctx*, const lasso_fr* const* polys, uint32_t k, const lasso_fr* w, size_t n, lasso_fr* out) {
   for (uint32_t p = 0; p < k; p++) F(out)[p] = compute_dotproduct(F(polys[p]), F(w), n); return 0;
 }
+int32_t lasso_read_heads(lasso_ctx*, const lasso_fr* const* polys, uint32_t k, lasso_fr* out) { for (uint32_t p = 0; p < k; p++) out[p] = polys[p][0]; return 0; }
 int32_t lasso_gp_build(lasso_ctx* c, lasso_fr* tree, size_t n) {
   REQ(c, n >= 2 && (n & (n - 1)) == 0);
   Fr* in = F(tree); size_t len = n;
