@@ -1,0 +1,162 @@
+#!/usr/bin/env python3
+"""bench.py — prover lookups/s for SparsePolynomialEvaluationProof on MI355X (BASELINE.json metric).
+
+A "step" = one SparsePolynomialEvaluationProof::prove over one batch of s synthetic lookups whose densified representation
+is already resident in HBM (the reference's `SparsePoly.prove` span; generator construction, densify, commit and verify are
+outside the timed region exactly as in the reference's published logs).  Default workload = the configuration the metric
+is quoted on: AND table, C=1, M=2^16, s=2^24 (src/benches/bench.rs `halo2_comparison_benchmarks`, src/benches/*.log).
+
+N > 1 (torch.distributed / RCCL, one process per GPU): each rank proves an independent batch of s lookups — the path
+partitions by proof, there is no data-path collective — so value = N*s*K / max-over-ranks time and scaling is "weak".
+
+One JSON line on rank 0.  Extra objects: roofline (dominant streaming kernel, HIP events on the library's stream),
+kernels (every kernel family: launches, ms, algorithmic GB/s), cpu_baseline (oracle port timed on host cores, rank 0, N=1).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec peak
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=3)
+    p.add_argument("--warmup", type=int, default=1)
+    p.add_argument("--log-s", type=int, default=24, help="log2 of lookups per proof (default 24 = the headline metric)")
+    p.add_argument("--c", type=int, default=1)
+    p.add_argument("--kind", default="and", choices=["and", "or", "xor", "lt", "range"])
+    p.add_argument("--log-m", type=int, default=16)
+    p.add_argument("--log-r", type=int, default=40)
+    p.add_argument("--cpu-log-s", type=int, default=16, help="log2 lookups of the bounded CPU-baseline sample")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-prof", action="store_true")
+    return p.parse_args()
+
+
+def cpu_baseline(kind_id, c, log_m, log_r, log_s):
+    """Oracle ("port") prover, serial, on this box's host cores; a bounded sample of the same workload shape."""
+    import subprocess
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "liblasso_oracle.so"])
+    orc = C.CDLL(os.path.join(ROOT, "oracle", "liblasso_oracle.so"))
+    td, tc, tp = C.c_double(), C.c_double(), C.c_double()
+    rc = orc.orc_bench(kind_id, C.c_size_t(c), C.c_size_t(1 << log_m), C.c_size_t(log_r), C.c_size_t(1 << log_s), C.byref(td), C.byref(tc), C.byref(tp), 0)
+    if rc != 0:
+        return None
+    return {"value": (1 << log_s) / tp.value, "unit": "lookups/s", "cores": 1, "kind": "port",
+            "sample": f"oracle (serial C++ restatement) prove, {kind_id=} C={c} M=2^{log_m} s=2^{log_s}: {tp.value:.2f}s (densify {td.value:.3f}s, commit {tc.value:.2f}s)"}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group(backend="nccl", init_method="env://")
+
+    from lasso_amd import HostProver, _abi
+    hp = HostProver(device=local if world > 1 else 0)
+    lib = hp.lib
+    dev_lib = C.CDLL(os.path.join(ROOT, "lasso_amd", "liblasso_hip.so"))
+    _abi.declare(dev_lib)
+    ctx = hp.ctx()
+
+    kind_id = _abi.KINDS[a.kind]
+    c, log_m, s = a.c, a.log_m, 1 << a.log_s
+    alpha = 2 * c if a.kind == "lt" else c
+    S = _abi.Strategy(kind_id, c, log_m, a.log_r if a.kind == "range" else 0)
+
+    t0 = time.time()
+    idx = hp.gen_indices(s, 1 << log_m, c)                  # benches/bench.rs:13-21
+    r = hp.gen_random_point(a.log_s)                        # benches/bench.rs:27-34
+    gens = hp.gens(c, s, alpha, log_m)                      # SparsePolyCommitmentGens::new(b"gens_sparse_poly", C, S, C, log_m)
+    t_setup = time.time() - t0
+    t0 = time.time(); dense = hp.densify(idx, log_m); dev_lib.lasso_sync(ctx); t_densify = time.time() - t0
+    t0 = time.time(); comm = hp.commit(dense, gens); t_commit = time.time() - t0
+
+    def barrier():
+        dev_lib.lasso_sync(ctx)
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    proof = None
+    for _ in range(a.warmup):
+        proof = hp.prove(dense, gens, S, r)
+    if not a.no_prof:
+        dev_lib.lasso_prof_reset(ctx); dev_lib.lasso_prof_enable(ctx, 1)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        proof = hp.prove(dense, gens, S, r)
+    dev_lib.lasso_sync(ctx)
+    if dist is not None:
+        import torch
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    barrier()
+    kernels = []
+    if not a.no_prof:
+        dev_lib.lasso_prof_enable(ctx, 0)
+        for kid, name in enumerate(_abi.KERNEL_NAMES):
+            n = C.c_uint64(); ms = C.c_double(); b = C.c_double()
+            dev_lib.lasso_prof_get(ctx, kid, C.byref(n), C.byref(ms), C.byref(b))
+            if n.value:
+                kernels.append({"kernel": name, "launches": n.value, "ms": round(ms.value, 3), "alg_GB": round(b.value / 1e9, 3),
+                                "alg_GBps": round(b.value / (ms.value * 1e-3) / 1e9, 1) if ms.value > 0 else None})
+    if dist is not None:
+        import torch
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / a.steps * 1e3
+        value = world * s * a.steps / elapsed
+        out = {"metric": "prover lookups/sec for SparsePolynomialEvaluationProof, 2^24 AND lookups" if (a.kind, a.log_s, c) == ("and", 24, 1) else f"prover lookups/sec for SparsePolynomialEvaluationProof, 2^{a.log_s} {a.kind.upper()} lookups",
+               "value": value, "unit": "lookups/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u256 (Montgomery Fr / ed25519 Fq integers)", "data": "synthetic",
+               "config": {"workload": f"{a.kind.upper()} subtable, C={c}, M=2^{log_m}, s=2^{a.log_s} lookups per proof, G=curve25519 (ark_curve25519), harness inputs of src/benches/bench.rs; "
+                                      f"timed = SparsePolynomialEvaluationProof::prove with the densified representation resident in HBM",
+                          "per_rank": "one independent proof per rank" if world > 1 else "single proof",
+                          "proof_bytes": len(proof), "densify_s": round(t_densify, 3), "commit_s": round(t_commit, 3), "gens_setup_s": round(t_setup, 3),
+                          "whole_bench_lookups_per_s": s / (t_densify + t_commit + ms_per_step / 1e3)}}
+        if kernels:
+            out["kernels"] = kernels
+            bind = next((k for k in kernels if k["kernel"] == "bind_top"), None)
+            stream_families = [k for k in kernels if k["kernel"] in ("bind_top", "sumcheck_cubic_round", "sumcheck_combine", "multi_dot", "matvec_left", "gp_build", "fingerprint", "eq_evals")]
+            dom = max(stream_families, key=lambda k: k["ms"]) if stream_families else None
+            def roof(k):
+                ach = k["alg_GB"] / (k["ms"] * 1e-3) if k["ms"] > 0 else 0.0
+                return {"kernel": k["kernel"], "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                        "traffic": None, "launches": k["launches"], "avg_launch_us": round(k["ms"] * 1e3 / k["launches"], 2)}
+            if dom:
+                out["roofline"] = roof(dom)
+            if bind:
+                out["roofline_bind_top"] = roof(bind)     # the kernel BASELINE.json's north_star names (bound_poly_var)
+        if world == 1 and not a.no_cpu_baseline:
+            cb = cpu_baseline(kind_id, c, log_m, S.log_r, min(a.cpu_log_s, a.log_s))
+            if cb:
+                out["cpu_baseline"] = cb
+        print(json.dumps(out))
+    hp.free(dense, gens)
+    hp.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
