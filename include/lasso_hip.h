@@ -66,7 +66,7 @@ void* lasso_stream(lasso_ctx* ctx);                    /* the context's hipStrea
 /* ---- per-kernel timing (HIP events on the context's stream), for bench.py's roofline ------- */
 enum lasso_kernel_id { LASSO_K_BIND = 0, LASSO_K_CUBIC = 1, LASSO_K_COMBINE = 2, LASSO_K_EQ = 3, LASSO_K_GP = 4, LASSO_K_FINGERPRINT = 5,
                        LASSO_K_DOT = 6, LASSO_K_MATVEC = 7, LASSO_K_MSM = 8, LASSO_K_MISC = 9, LASSO_K_COUNT = 10 };
-int32_t lasso_prof_enable(lasso_ctx* ctx, int32_t on);
+int32_t lasso_prof_enable(lasso_ctx* ctx, int32_t family_mask);   /* bit k = bracket launches of lasso_kernel_id k; 0 = off */
 int32_t lasso_prof_reset(lasso_ctx* ctx);
 /* launches, total milliseconds and algorithmic bytes (SURVEY.md §8d definitions) recorded for one kernel family */
 int32_t lasso_prof_get(lasso_ctx* ctx, int32_t kernel_id, uint64_t* launches, double* total_ms, double* alg_bytes);
@@ -122,6 +122,22 @@ void lasso_bases_destroy(lasso_ctx* ctx, lasso_bases* b);
 int32_t lasso_hyrax_commit(lasso_ctx* ctx, const lasso_fr* d_Z, size_t l_size, size_t r_size, const lasso_bases* bases, lasso_point* out);
 /* VariableBaseMSM::msm (src/msm/mod.rs:36-40): out = sum_{j < n} scalars[j] * bases[j]; n <= number of bases.  Zero scalars cost nothing. */
 int32_t lasso_msm(lasso_ctx* ctx, const lasso_bases* bases, const lasso_fr* scalars, size_t n, lasso_point* out);
+
+/* Same as lasso_msm with the scalars already resident on the device (Montgomery form). */
+int32_t lasso_msm_dev(lasso_ctx* ctx, const lasso_bases* bases, const lasso_fr* d_scalars, size_t n, lasso_point* out);
+
+/* ---- Hyrax opening tail: BulletReductionProof::prove (src/subprotocols/bullet.rs:40-154) with the vectors resident on
+ * the device.  State kept by the caller: d_a, d_b (current length nk, folded in place), d_w (n/nk tensor weights, see below).
+ * The generator vector is never folded: after k rounds G^(k)_i = sum_blk w_blk * G_{blk*nk + i}, so every L / R is one MSM
+ * over the original (precomputed) generators — the same group elements as the reference's fold-then-MSM. */
+/* out[0] = c_L = <a_L, b_R>, out[1] = c_R = <a_R, b_L>   (bullet.rs:79-80), halves of the current length nk */
+int32_t lasso_inner_products_lr(lasso_ctx* ctx, const lasso_fr* d_a, const lasso_fr* d_b, size_t nk, lasso_fr* out);
+/* bullet.rs:84-118: out[0] = L = <a_L, G_R> + c_L*Q + blind_L*H, out[1] = R = <a_R, G_L> + c_R*Q + blind_R*H, where G is the
+ * current (virtually folded) generator vector, `bases` holds [G_0..G_{n-1}, Q, H] and tail = {c_L, blind_L, c_R, blind_R}. */
+int32_t lasso_bullet_lr(lasso_ctx* ctx, const lasso_bases* bases, size_t n, const lasso_fr* d_a, size_t nk, const lasso_fr* d_w, const lasso_fr* tail, lasso_point* out);
+/* bullet.rs:127-132: a[i] <- a_L[i]*u + u_inv*a_R[i], b[i] <- b_L[i]*u_inv + u*b_R[i] for i < nk/2 (in place), and the
+ * generator fold G[i] <- G_L[i]*u_inv + G_R[i]*u recorded as weights: d_w_out[2*blk] = d_w[blk]*u_inv, d_w_out[2*blk+1] = d_w[blk]*u. */
+int32_t lasso_bullet_fold(lasso_ctx* ctx, lasso_fr* d_a, lasso_fr* d_b, size_t nk, const lasso_fr* d_w, size_t nw, lasso_fr* d_w_out, const lasso_fr* u, const lasso_fr* u_inv);
 
 #ifdef __cplusplus
 }

@@ -51,6 +51,10 @@ def declare(lib):
         "lasso_bases_destroy": (None, [vp, vp]),
         "lasso_hyrax_commit": (i32, [vp, vp, sz, sz, vp, vp]),
         "lasso_msm": (i32, [vp, vp, vp, sz, vp]),
+        "lasso_msm_dev": (i32, [vp, vp, vp, sz, vp]),
+        "lasso_inner_products_lr": (i32, [vp, vp, vp, sz, vp]),
+        "lasso_bullet_lr": (i32, [vp, vp, sz, vp, sz, vp, vp, vp]),
+        "lasso_bullet_fold": (i32, [vp, vp, vp, sz, vp, sz, vp, vp, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)   # AttributeError here = the library does not export what the header declares

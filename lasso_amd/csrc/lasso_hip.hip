@@ -9,6 +9,17 @@
 #include "poly_kernels.cuh"
 #include "msm_kernels.cuh"
 
+__global__ void __launch_bounds__(256) k_inner_lr(const fr_t* __restrict__ a, const fr_t* __restrict__ b, size_t half, fr_t* __restrict__ partials) {
+  __shared__ fr_t smem[4];
+  fr_t cl = fr_zero(), cr = fr_zero();
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x) {
+    cl = fr_add(cl, fr_mul(a[i], b[half + i]));
+    cr = fr_add(cr, fr_mul(a[half + i], b[i]));
+  }
+  cl = block_reduce_fr(cl, smem); cr = block_reduce_fr(cr, smem);
+  if (threadIdx.x == 0) { partials[2 * (size_t)blockIdx.x] = cl; partials[2 * (size_t)blockIdx.x + 1] = cr; }
+}
+
 static_assert(sizeof(lasso_fr) == 32 && sizeof(fr_t) == 32, "Fr layout");
 static_assert(sizeof(lasso_affine) == 64 && sizeof(lasso_point) == 128 && sizeof(ed_point) == 128 && sizeof(ed_niels) == 96, "curve layouts");
 
@@ -22,7 +33,7 @@ struct lasso_ctx {
   fr_t* h_small = nullptr;                                // pinned mirror
   size_t small_cap = 0;
   uint32_t* d_flags = nullptr;
-  bool prof = false;
+  uint32_t prof_mask = 0;   // bit k set = kernel family k is bracketed with events
   std::vector<EventPair> events; size_t events_used = 0;
   uint64_t prof_launches[LASSO_K_COUNT] = {0}; double prof_ms[LASSO_K_COUNT] = {0}; double prof_bytes[LASSO_K_COUNT] = {0};
 };
@@ -54,7 +65,7 @@ static int32_t ensure_small(lasso_ctx* c, size_t count) {
 struct ProfScope {
   lasso_ctx* c; int idx = -1;
   ProfScope(lasso_ctx* c_, int kid, double bytes) : c(c_) {
-    if (!c->prof) return;
+    if (!((c->prof_mask >> kid) & 1u)) return;
     if (c->events_used == c->events.size()) { EventPair p; if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return; c->events.push_back(p); }
     idx = (int)c->events_used++;
     c->events[idx].kid = kid; c->events[idx].bytes = bytes;
@@ -119,7 +130,7 @@ int32_t lasso_copy(lasso_ctx* c, void* d, const void* s, size_t n) { REQUIRE(c, 
 int32_t lasso_zero(lasso_ctx* c, void* d, size_t n) { REQUIRE(c, d); HIPCHK(c, hipMemsetAsync(d, 0, n, c->stream)); return 0; }
 int32_t lasso_sync(lasso_ctx* c) { HIPCHK(c, hipStreamSynchronize(c->stream)); return 0; }
 
-int32_t lasso_prof_enable(lasso_ctx* c, int32_t on) { prof_flush(c); c->prof = on != 0; return 0; }
+int32_t lasso_prof_enable(lasso_ctx* c, int32_t mask) { prof_flush(c); c->prof_mask = (uint32_t)mask; return 0; }
 int32_t lasso_prof_reset(lasso_ctx* c) { prof_flush(c); for (int i = 0; i < LASSO_K_COUNT; i++) { c->prof_launches[i] = 0; c->prof_ms[i] = 0; c->prof_bytes[i] = 0; } return 0; }
 int32_t lasso_prof_get(lasso_ctx* c, int32_t k, uint64_t* launches, double* ms, double* bytes) {
   REQUIRE(c, k >= 0 && k < LASSO_K_COUNT); prof_flush(c);
@@ -335,7 +346,7 @@ static int32_t run_msm(lasso_ctx* c, const uint8_t* d_scal, uint32_t bps, uint32
 int32_t lasso_hyrax_commit(lasso_ctx* c, const lasso_fr* d_Z, size_t l_size, size_t r_size, const lasso_bases* b, lasso_point* out) {
   REQUIRE(c, d_Z && b && out && l_size >= 1 && r_size >= 1 && r_size <= b->n && l_size < ((size_t)1 << 31));
   const size_t n = l_size * r_size;
-  const size_t pts_bytes = (l_size * msm_chunks(l_size, r_size, 32) + l_size) * sizeof(ed_point) + 256;
+  const size_t pts_bytes = (l_size * msm_chunks(l_size, r_size, MSM_WINDOWS) + l_size) * sizeof(ed_point) + 256;
   int32_t rc = ensure_scratch(c, n * 32 + pts_bytes); if (rc) return rc;
   uint8_t* d_scal = (uint8_t*)c->d_scratch;
   HIPCHK(c, hipMemsetAsync(c->d_flags, 0, 8, c->stream));
@@ -348,11 +359,11 @@ int32_t lasso_hyrax_commit(lasso_ctx* c, const lasso_fr* d_Z, size_t l_size, siz
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (!flags[1]) {  // every scalar < 2^32: the reference's small-scalar regime (msm/mod.rs:95-106)
     uint32_t bits = 0; while (bits < 32 && (flags[0] >> bits)) bits++;
-    uint32_t W = (bits + 7) / 8; if (W == 0) W = 1;
+    uint32_t W = (bits + 3) / 4; if (W == 0) W = 1;   // 4-bit windows actually populated
     return run_msm(c, d_scal, 4, W, r_size * 4, l_size, r_size, b, d_scal + ((n * 4 + 255) & ~(size_t)255), out);
   }
   hipLaunchKernelGGL(k_fr_to_canonical, dim3(grid_for(n, 4096)), dim3(256), 0, c->stream, (const fr_t*)d_Z, n, (fr_t*)d_scal);
-  return run_msm(c, d_scal, 32, 32, r_size * 32, l_size, r_size, b, d_scal + n * 32, out);
+  return run_msm(c, d_scal, 32, MSM_WINDOWS, r_size * 32, l_size, r_size, b, d_scal + n * 32, out);
 }
 int32_t lasso_msm(lasso_ctx* c, const lasso_bases* b, const lasso_fr* scalars, size_t n, lasso_point* out) {
   REQUIRE(c, b && scalars && out && n >= 1 && n <= b->n);
@@ -360,7 +371,42 @@ int32_t lasso_msm(lasso_ctx* c, const lasso_bases* b, const lasso_fr* scalars, s
   fr_t* d_in = (fr_t*)c->d_scratch; fr_t* d_can = d_in + n;
   HIPCHK(c, hipMemcpyAsync(d_in, scalars, n * 32, hipMemcpyHostToDevice, c->stream));
   hipLaunchKernelGGL(k_fr_to_canonical, dim3(grid_for(n)), dim3(256), 0, c->stream, (const fr_t*)d_in, n, d_can);
-  return run_msm(c, (const uint8_t*)d_can, 32, 32, n * 32, 1, n, b, (uint8_t*)(d_can + n), out);
+  return run_msm(c, (const uint8_t*)d_can, 32, MSM_WINDOWS, n * 32, 1, n, b, (uint8_t*)(d_can + n), out);
+}
+
+int32_t lasso_msm_dev(lasso_ctx* c, const lasso_bases* b, const lasso_fr* d_scalars, size_t n, lasso_point* out) {
+  REQUIRE(c, b && d_scalars && out && n >= 1 && n <= b->n);
+  int32_t rc = ensure_scratch(c, n * 32 + 258 * sizeof(ed_point)); if (rc) return rc;
+  fr_t* d_can = (fr_t*)c->d_scratch;
+  hipLaunchKernelGGL(k_fr_to_canonical, dim3(grid_for(n)), dim3(256), 0, c->stream, (const fr_t*)d_scalars, n, d_can);
+  return run_msm(c, (const uint8_t*)d_can, 32, MSM_WINDOWS, n * 32, 1, n, b, (uint8_t*)(d_can + n), out);
+}
+int32_t lasso_inner_products_lr(lasso_ctx* c, const lasso_fr* d_a, const lasso_fr* d_b, size_t nk, lasso_fr* out) {
+  REQUIRE(c, d_a && d_b && out && nk >= 2 && (nk & (nk - 1)) == 0);
+  const size_t half = nk / 2; const unsigned nx = grid_for(half, 256);
+  int32_t rc = ensure_scratch(c, (size_t)nx * 2 * sizeof(fr_t)); if (rc) return rc;
+  {
+    ProfScope ps(c, LASSO_K_DOT, 64.0 * nk);
+    hipLaunchKernelGGL(k_inner_lr, dim3(nx), dim3(256), 0, c->stream, (const fr_t*)d_a, (const fr_t*)d_b, half, (fr_t*)c->d_scratch);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(LASSO_BLOCK), 0, c->stream, (const fr_t*)c->d_scratch, nx, 2u, c->d_small);
+  }
+  HIPCHK(c, hipGetLastError());
+  return fetch_small(c, 2, out);
+}
+int32_t lasso_bullet_lr(lasso_ctx* c, const lasso_bases* b, size_t n, const lasso_fr* d_a, size_t nk, const lasso_fr* d_w, const lasso_fr* tail, lasso_point* out) {
+  REQUIRE(c, b && d_a && d_w && tail && out && n >= 2 && (n & (n - 1)) == 0 && nk >= 2 && nk <= n && (nk & (nk - 1)) == 0 && n + 2 <= b->n);
+  const size_t row = n + 2;
+  int32_t rc = ensure_scratch(c, 2 * row * 32 + (2 * 256 + 2) * sizeof(ed_point) + 256); if (rc) return rc;
+  fr_t* SL = (fr_t*)c->d_scratch; fr_t* SR = SL + row;
+  hipLaunchKernelGGL(k_bullet_expand, dim3(grid_for(n)), dim3(256), 0, c->stream, (const fr_t*)d_a, nk, (const fr_t*)d_w, n, to_fr(tail), to_fr(tail + 1), to_fr(tail + 2), to_fr(tail + 3), SL, SR);
+  return run_msm(c, (const uint8_t*)SL, 32, MSM_WINDOWS, row * 32, 2, row, b, (uint8_t*)(SR + row), out);
+}
+int32_t lasso_bullet_fold(lasso_ctx* c, lasso_fr* d_a, lasso_fr* d_b, size_t nk, const lasso_fr* d_w, size_t nw, lasso_fr* d_w_out, const lasso_fr* u, const lasso_fr* u_inv) {
+  REQUIRE(c, d_a && d_b && d_w && d_w_out && u && u_inv && nk >= 2 && (nk & (nk - 1)) == 0 && nw >= 1 && d_w != d_w_out);
+  const size_t half = nk / 2;
+  ProfScope ps(c, LASSO_K_MISC, 96.0 * nk + 96.0 * nw);
+  hipLaunchKernelGGL(k_bullet_fold, dim3(grid_for(half > nw ? half : nw)), dim3(256), 0, c->stream, (fr_t*)d_a, (fr_t*)d_b, half, (const fr_t*)d_w, nw, (fr_t*)d_w_out, to_fr(u), to_fr(u_inv));
+  HIPCHK(c, hipGetLastError()); return 0;
 }
 
 }  // extern "C"

@@ -1,14 +1,17 @@
 // Pippenger-style MSM kernels for the Hyrax commitment (gfx950).
 //
 // Design (MI355X-first, not the reference's serial window loop src/msm/mod.rs:91-164):
-//  * the generators are fixed for the lifetime of a gens object, so every window multiple 2^(8w)*G_j is
+//  * the generators are fixed for the lifetime of a gens object, so every window multiple 2^(4w)*G_j is
 //    precomputed once (table[w][j], affine "Niels" form, 96 B) — all windows of a scalar then fall into ONE
 //    bucket set, with no per-window bucket reduction and no doubling chain at all;
-//  * 8-bit unsigned digits = the bytes of the canonical little-endian scalar; zero digits are skipped, so
-//    the reference's small-scalar shortcut (msm/mod.rs:95-106) is automatic: a 16-bit scalar costs 2 adds;
-//  * one 256-thread workgroup owns one bucket set: (digit, table-index) pairs are counting-sorted in LDS in
-//    batches of 4096, then thread t accumulates bucket t in registers with 7-multiplication mixed adds;
-//  * bucket reduction sum_t t*B_t: each lane scales its own bucket (8 doublings + adds), LDS tree sums them.
+//  * 4-bit unsigned digits = the nibbles of the canonical little-endian scalar; zero digits are skipped, so
+//    the reference's small-scalar shortcut (msm/mod.rs:95-106) is automatic: a 16-bit scalar costs <= 4 adds;
+//  * one 256-thread workgroup owns one bucket set, split into 16 column slices x 16 digits = 256 bins, one per
+//    thread: real Lasso scalars are heavily skewed (timestamp high nibbles, popcount-skewed AND values) and a
+//    single thread per digit would serialise half a row; the slice split bounds the imbalance to ~3x;
+//  * (bin, table-index) pairs are counting-sorted in LDS in batches of 4096, then thread t accumulates bin t in
+//    registers with 7-multiplication mixed adds;
+//  * reduction: LDS tree over the 16 slices, each digit lane scales its bucket (4 doublings + adds), tree over digits.
 // Results are group elements, so any accumulation order is bit-identical after compression.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -16,7 +19,7 @@
 
 #define MSM_THREADS 256
 #define MSM_BATCH 4096
-#define MSM_WINDOWS 32
+#define MSM_WINDOWS 64   // 4-bit windows over 256-bit scalars
 
 // curve25519 inversion chain: a^(p-2), 254 squarings + 11 multiplications
 LHD fq_t fq_inv_chain(const fq_t& z) {
@@ -44,7 +47,7 @@ LHD fq_t fq_inv_chain(const fq_t& z) {
   return fq_mul(t, z11);                              // 2^255 - 21
 }
 
-// table[w*n + j] = Niels(2^(8w) * G_j).  One thread per generator.  `aff` = ark Affine {x,y} Montgomery limbs.
+// table[w*n + j] = Niels(2^(4w) * G_j).  One thread per generator.  `aff` = ark Affine {x,y} Montgomery limbs.
 __global__ void k_precompute_table(const fq_t* __restrict__ aff, size_t n, ed_niels* __restrict__ table) {
   size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (j >= n) return;
@@ -52,7 +55,7 @@ __global__ void k_precompute_table(const fq_t* __restrict__ aff, size_t n, ed_ni
   table[j] = ed_to_niels_affine(x, y);
   ed_point P = ed_from_affine(x, y);
   for (int w = 1; w < MSM_WINDOWS; w++) {
-    for (int k = 0; k < 8; k++) P = ed_dbl(P);
+    for (int k = 0; k < 4; k++) P = ed_dbl(P);
     fq_t zi = fq_inv_chain(P.Z);
     table[(size_t)w * n + j] = ed_to_niels_affine(fq_mul(P.X, zi), fq_mul(P.Y, zi));
   }
@@ -76,7 +79,8 @@ __global__ void __launch_bounds__(256) k_fr_to_canonical(const fr_t* __restrict_
 }
 
 // grid = (chunks per row K, rows).  scal: canonical little-endian scalars, `bps` bytes each (4 or 32), row r at
-// scal + r*row_stride (bytes).  Windows 0..W-1 (byte w of each scalar).  out[row*K + chunk] = partial sum (extended, plain Fq).
+// scal + r*row_stride (bytes).  Windows 0..W-1 = nibble w of each scalar.  out[row*K + chunk] = partial sum (extended, plain Fq).
+__device__ __forceinline__ uint32_t msm_nibble(const uint8_t* s, uint32_t w) { return (reinterpret_cast<const uint32_t*>(s)[w >> 3] >> (4 * (w & 7))) & 15u; }
 __global__ void __launch_bounds__(MSM_THREADS) k_msm_buckets(const uint8_t* __restrict__ scal, uint32_t bps, uint32_t W, size_t row_stride, size_t n_cols, size_t cols_per_chunk,
                                                               const ed_niels* __restrict__ table, size_t table_stride, ed_point* __restrict__ out) {
   __shared__ __attribute__((aligned(16))) uint8_t raw[MSM_THREADS * sizeof(ed_point)];  // sorted[] (16 KB) during accumulation, points (32 KB) during the tree
@@ -94,9 +98,8 @@ __global__ void __launch_bounds__(MSM_THREADS) k_msm_buckets(const uint8_t* __re
     counts[t] = 0;
     __syncthreads();
     for (size_t c = b0 + t; c < b1; c += MSM_THREADS) {
-      const uint8_t* s = row + c * bps;
-      if (bps == 4) { uint32_t v = *reinterpret_cast<const uint32_t*>(s); for (uint32_t w = 0; w < W; w++) { uint32_t d = (v >> (8 * w)) & 255u; if (d) atomicAdd(&counts[d], 1u); } }
-      else { for (uint32_t w4 = 0; w4 < W; w4 += 4) { uint32_t v = *reinterpret_cast<const uint32_t*>(s + w4); for (uint32_t w = w4; w < w4 + 4 && w < W; w++) { uint32_t d = (v >> (8 * (w - w4))) & 255u; if (d) atomicAdd(&counts[d], 1u); } } }
+      const uint8_t* s = row + c * bps; const uint32_t slice = ((uint32_t)c & 15u) << 4;
+      for (uint32_t w = 0; w < W; w++) { uint32_t d = msm_nibble(s, w); if (d) atomicAdd(&counts[slice | d], 1u); }
     }
     __syncthreads();
     start[t] = counts[t];
@@ -106,21 +109,26 @@ __global__ void __launch_bounds__(MSM_THREADS) k_msm_buckets(const uint8_t* __re
     cursor[t] = my_start;
     __syncthreads();
     for (size_t c = b0 + t; c < b1; c += MSM_THREADS) {
-      const uint8_t* s = row + c * bps;
-      if (bps == 4) { uint32_t v = *reinterpret_cast<const uint32_t*>(s); for (uint32_t w = 0; w < W; w++) { uint32_t d = (v >> (8 * w)) & 255u; if (d) sorted[atomicAdd(&cursor[d], 1u)] = (uint32_t)(w * table_stride + c); } }
-      else { for (uint32_t w4 = 0; w4 < W; w4 += 4) { uint32_t v = *reinterpret_cast<const uint32_t*>(s + w4); for (uint32_t w = w4; w < w4 + 4 && w < W; w++) { uint32_t d = (v >> (8 * (w - w4))) & 255u; if (d) sorted[atomicAdd(&cursor[d], 1u)] = (uint32_t)(w * table_stride + c); } } }
+      const uint8_t* s = row + c * bps; const uint32_t slice = ((uint32_t)c & 15u) << 4;
+      for (uint32_t w = 0; w < W; w++) { uint32_t d = msm_nibble(s, w); if (d) sorted[atomicAdd(&cursor[slice | d], 1u)] = (uint32_t)(w * table_stride + c); }
     }
     __syncthreads();
     const uint32_t cnt = counts[t];
-    if (t) for (uint32_t k = 0; k < cnt; k++) B = ed_madd(B, table[sorted[my_start + k]]);
+    for (uint32_t k = 0; k < cnt; k++) B = ed_madd(B, table[sorted[my_start + k]]);
     __syncthreads();
   }
-  // sum_t t * B_t
-  ed_point acc = ed_identity();
-  for (int bit = 7; bit >= 0; bit--) { acc = ed_dbl(acc); if ((t >> bit) & 1u) acc = ed_add(acc, B); }
-  pts[t] = acc;
+  // bins -> buckets: tree over the 16 column slices (bin t = slice*16 + digit)
+  pts[t] = B;
   __syncthreads();
-  for (uint32_t s = MSM_THREADS / 2; s > 0; s >>= 1) { if (t < s) pts[t] = ed_add(pts[t], pts[t + s]); __syncthreads(); }
+  for (uint32_t s = 8; s > 0; s >>= 1) { if ((t >> 4) < s) pts[t] = ed_add(pts[t], pts[t + 16 * s]); __syncthreads(); }
+  // sum_d d * B_d over the 15 non-zero digits
+  if (t < 16) {
+    ed_point Bd = pts[t], acc = ed_identity();
+    for (int bit = 3; bit >= 0; bit--) { acc = ed_dbl(acc); if ((t >> bit) & 1u) acc = ed_add(acc, Bd); }
+    pts[t] = acc;
+  }
+  __syncthreads();
+  for (uint32_t s = 8; s > 0; s >>= 1) { if (t < s) pts[t] = ed_add(pts[t], pts[t + s]); __syncthreads(); }
   if (t == 0) out[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = pts[0];
 }
 
@@ -132,4 +140,29 @@ __global__ void __launch_bounds__(MSM_THREADS) k_points_sum(const ed_point* __re
   __syncthreads();
   for (uint32_t s = MSM_THREADS / 2; s > 0; s >>= 1) { if (t < s && t + s < K) pts[t] = ed_add(pts[t], pts[t + s]); __syncthreads(); }
   if (t == 0) { ed_point p = pts[0], o; o.X = fq_to_mont(p.X); o.Y = fq_to_mont(p.Y); o.T = fq_to_mont(p.T); o.Z = fq_to_mont(p.Z); out_mont[blockIdx.x] = o; }
+}
+
+// ------------------------------------------------------------------ Hyrax opening tail (bullet.rs:40-154), vectors resident on the device
+// partials[bx*2 + {0,1}] = partial <a_L, b_R>, <a_R, b_L>
+__global__ void __launch_bounds__(256) k_inner_lr(const fr_t* __restrict__ a, const fr_t* __restrict__ b, size_t half, fr_t* __restrict__ partials);
+// canonical scalars of the two MSMs of one round over the ORIGINAL generators: rows SL, SR of n+2 entries each
+__global__ void __launch_bounds__(256) k_bullet_expand(const fr_t* __restrict__ a, size_t nk, const fr_t* __restrict__ w, size_t n, fr_t cL, fr_t bL, fr_t cR, fr_t bR, fr_t* __restrict__ SL,
+                                                        fr_t* __restrict__ SR) {
+  const size_t half = nk / 2;
+  for (size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x; j < n; j += (size_t)gridDim.x * blockDim.x) {
+    const size_t blk = j / nk, pos = j % nk;
+    const fr_t wb = w[blk];
+    if (pos >= half) { SL[j] = fr_to_canonical(fr_mul(wb, a[pos - half])); SR[j] = fr_zero(); }
+    else { SL[j] = fr_zero(); SR[j] = fr_to_canonical(fr_mul(wb, a[pos + half])); }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) { SL[n] = fr_to_canonical(cL); SL[n + 1] = fr_to_canonical(bL); SR[n] = fr_to_canonical(cR); SR[n + 1] = fr_to_canonical(bR); }
+}
+__global__ void __launch_bounds__(256) k_bullet_fold(fr_t* __restrict__ a, fr_t* __restrict__ b, size_t half, const fr_t* __restrict__ w, size_t nw, fr_t* __restrict__ w_out, fr_t u, fr_t u_inv) {
+  const size_t tid = blockIdx.x * (size_t)blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = tid; i < half; i += stride) {
+    fr_t al = a[i], ar = a[i + half], bl = b[i], br = b[i + half];
+    a[i] = fr_add(fr_mul(al, u), fr_mul(u_inv, ar));
+    b[i] = fr_add(fr_mul(bl, u_inv), fr_mul(u, br));
+  }
+  for (size_t k = tid; k < nw; k += stride) { fr_t x = w[k]; w_out[2 * k] = fr_mul(x, u_inv); w_out[2 * k + 1] = fr_mul(x, u); }
 }

@@ -160,9 +160,29 @@ class Device:
         self._chk(self.lib.lasso_msm(self.ctx, C.c_void_p(bases), _vp(scalars), scalars.shape[0], _vp(out)))
         return out
 
+    def msm_dev(self, bases, d_scalars, n):
+        out = np.empty((1, 16), dtype=np.uint64)
+        self._chk(self.lib.lasso_msm_dev(self.ctx, C.c_void_p(bases), C.c_void_p(d_scalars), n, _vp(out)))
+        return out
+
+    def inner_products_lr(self, d_a, d_b, nk):
+        out = np.empty((2, 4), dtype=np.uint64)
+        self._chk(self.lib.lasso_inner_products_lr(self.ctx, C.c_void_p(d_a), C.c_void_p(d_b), nk, _vp(out)))
+        return out
+
+    def bullet_lr(self, bases, n, d_a, nk, d_w, tail):
+        tail = np.ascontiguousarray(tail, dtype=np.uint64).reshape(4, 4)
+        out = np.empty((2, 16), dtype=np.uint64)
+        self._chk(self.lib.lasso_bullet_lr(self.ctx, C.c_void_p(bases), n, C.c_void_p(d_a), nk, C.c_void_p(d_w), _vp(tail), _vp(out)))
+        return out
+
+    def bullet_fold(self, d_a, d_b, nk, d_w, nw, d_w_out, u, u_inv):
+        u = np.ascontiguousarray(u, dtype=np.uint64); ui = np.ascontiguousarray(u_inv, dtype=np.uint64)
+        self._chk(self.lib.lasso_bullet_fold(self.ctx, C.c_void_p(d_a), C.c_void_p(d_b), nk, C.c_void_p(d_w), nw, C.c_void_p(d_w_out), _vp(u), _vp(ui)))
+
     # ---- profiling
-    def prof_enable(self, on=True):
-        self._chk(self.lib.lasso_prof_enable(self.ctx, 1 if on else 0))
+    def prof_enable(self, mask=0x3FF):
+        self._chk(self.lib.lasso_prof_enable(self.ctx, int(mask)))
 
     def prof_reset(self):
         self._chk(self.lib.lasso_prof_reset(self.ctx))

@@ -20,7 +20,20 @@
 #include "field_host.hpp"
 #include "hashes.hpp"
 
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+
 namespace lasso {
+
+// Wall-clock spans with the reference's `tracing` span names, printed when LASSO_TRACE=1 — so a run can be
+// laid next to src/benches/*.log line by line.  Device work is asynchronous: a span closes after a stream sync only when tracing.
+struct Trace {
+  static bool on() { static const bool v = [] { const char* e = getenv("LASSO_TRACE"); return e && e[0] == '1'; }(); return v; }
+  const char* name; lasso_ctx* ctx; std::chrono::steady_clock::time_point t0; static int& depth() { static int d = 0; return d; }
+  Trace(const char* n, lasso_ctx* c) : name(n), ctx(c) { if (on()) { t0 = std::chrono::steady_clock::now(); depth()++; } }
+  ~Trace() { if (on()) { if (ctx) lasso_sync(ctx); depth()--; double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); fprintf(stderr, "[trace] %*s%s: time.busy=%.3fms\n", 2 * depth(), "", name, ms); } }
+};
 
 struct Error : std::runtime_error { using std::runtime_error::runtime_error; };
 #define LASSO_REQUIRE(c) do { if (!(c)) throw Error(std::string("lasso prover: requirement failed: ") + #c); } while (0)
@@ -388,6 +401,7 @@ class Prover {
   }
   // ---- BatchedGrandProductArgument::prove (grand_product.rs:101-201).  trees[c]: 2n-2 elements, layer k at offset n*(2 - 2^(1-k))
   BatchedGrandProductArgument bgpa_prove(std::vector<lasso_fr*>& trees, size_t n, const ScVec& roots, ScVec& rand_out) {
+    Trace tr("BatchedGrandProductArgument.prove", d.ctx);
     BatchedGrandProductArgument out; const size_t k = trees.size(), num_layers = ceil_log2(n);
     ScVec claims_to_verify = roots, rand;
     DBuf eq(d, n / 2 ? n / 2 : 1);
@@ -415,50 +429,49 @@ class Prover {
   // ---- BulletReductionProof::prove + DotProductProofLog::prove (bullet.rs:40-154, dot_product.rs:167-249), blinds of x and y are zero on this path.
   // The generator vector is never folded: G^(k)_i = sum_b w_b G_{b*n_k+i} with w the running tensor of u^{+-1}, so every L_k / R_k / g_hat is one
   // MSM over the ORIGINAL (precomputed) generators with scalars a (x) w — same group elements as the reference's fold-then-MSM.
-  Pt msm(const PolyCommitmentGens& g, const ScVec& scalars) {
-    std::vector<lasso_fr> sc(scalars.size()); for (size_t i = 0; i < sc.size(); i++) sc[i] = scalars[i].abi();
-    lasso_point out; d.chk(lasso_msm(d.ctx, g.bases, sc.data(), sc.size(), &out), "lasso_msm");
+  Pt msm_dev(const PolyCommitmentGens& g, const lasso_fr* d_scalars, size_t n) {
+    lasso_point out; d.chk(lasso_msm_dev(d.ctx, g.bases, d_scalars, n, &out), "lasso_msm_dev");
     return Pt::from_abi(out);
   }
   DotProductProofLog dot_product_log_prove(const PolyCommitmentGens& g, const ScVec& x_vec, const ScVec& a_vec, const Sc& y) {
+    static_assert(sizeof(Sc) == sizeof(lasso_fr), "ScVec is uploaded as an array of lasso_fr");
+    Trace tr("DotProductProofLog.prove", d.ctx);
     t.append_protocol_name("dot product proof (log)");
     const size_t n = x_vec.size(); LASSO_REQUIRE(a_vec.size() == n && g.n == n);
     const size_t lg_n = ceil_log2(n);
     Sc dd = tape.random_scalar("d"), r_delta = tape.random_scalar("r_delta"), r_beta = tape.random_scalar("r_delta");   // sic: dot_product.rs:189
     ScVec v1 = tape.random_vector("blinds_vec_1", 2 * lg_n), v2 = tape.random_vector("blinds_vec_2", 2 * lg_n);
     DotProductProofLog P; uint8_t buf[32];
-    ScVec full(n + 2, Sc::zero());
-    for (size_t i = 0; i < n; i++) full[i] = x_vec[i];                      // Cx = <x, G> + 0*h   (commitments.rs:84-93)
-    compress_one(msm(g, full), buf); t.append_point_bytes("Cx", buf);
-    compress_one(g.Q * y, buf); t.append_point_bytes("Cy", buf);            // Cy = y*G_1[0] + 0*h (commitments.rs:78-82)
+    // a, b and the generator-fold weights live on the device for the whole reduction
+    DBuf d_a(d, n), d_b(d, n), d_w0(d, n), d_w1(d, n);
+    d.chk(lasso_upload(d.ctx, d_a.p, x_vec.data(), n * sizeof(lasso_fr)), "lasso_upload");
+    d.chk(lasso_upload(d.ctx, d_b.p, a_vec.data(), n * sizeof(lasso_fr)), "lasso_upload");
+    { Sc one = Sc::one(); d.chk(lasso_upload(d.ctx, d_w0.p, &one, sizeof(lasso_fr)), "lasso_upload"); }
+    compress_one(msm_dev(g, d_a.p, n), buf); t.append_point_bytes("Cx", buf);   // Cx = <x, G> + 0*h   (commitments.rs:84-93)
+    compress_one(g.Q * y, buf); t.append_point_bytes("Cy", buf);                // Cy = y*G_1[0] + 0*h (commitments.rs:78-82)
     t.append_scalars("a", a_vec);
-    // bullet reduction, blind = blind_x + blind_y = 0
-    ScVec a = x_vec, b = a_vec, w{Sc::one()};
-    Sc blind_fin = Sc::zero(); size_t nk = n, round = 0;
+    // bullet reduction (bullet.rs:40-154), blind = blind_x + blind_y = 0
+    lasso_fr* w_cur = d_w0.p; lasso_fr* w_nxt = d_w1.p;
+    Sc blind_fin = Sc::zero(); size_t nk = n, nw = 1, round = 0;
     while (nk != 1) {
-      size_t half = nk / 2;
-      Sc c_L = Sc::zero(), c_R = Sc::zero();
-      for (size_t i = 0; i < half; i++) { c_L += a[i] * b[half + i]; c_R += a[half + i] * b[i]; }
+      lasso_fr cc[2]; d.chk(lasso_inner_products_lr(d.ctx, d_a.p, d_b.p, nk, cc), "lasso_inner_products_lr");
       const Sc& blind_L = v1[round]; const Sc& blind_R = v2[round];
-      ScVec SL(n + 2, Sc::zero()), SR(n + 2, Sc::zero());
-      for (size_t blk = 0; blk < w.size(); blk++)
-        for (size_t i = 0; i < half; i++) { SL[blk * nk + half + i] = w[blk] * a[i]; SR[blk * nk + i] = w[blk] * a[half + i]; }   // <a_L, G_R>, <a_R, G_L>
-      SL[n] = c_L; SL[n + 1] = blind_L; SR[n] = c_R; SR[n + 1] = blind_R;
-      uint8_t Lb[32], Rb[32];
-      compress_one(msm(g, SL), Lb); compress_one(msm(g, SR), Rb);
-      t.append_point_bytes("L", Lb); t.append_point_bytes("R", Rb);
+      lasso_fr tail[4] = {cc[0], blind_L.abi(), cc[1], blind_R.abi()};
+      lasso_point LR[2]; d.chk(lasso_bullet_lr(d.ctx, g.bases, n, d_a.p, nk, w_cur, tail, LR), "lasso_bullet_lr");
+      std::vector<Pt> two{Pt::from_abi(LR[0]), Pt::from_abi(LR[1])}; std::vector<uint8_t> cb; compress_batch(two, cb);
+      t.append_point_bytes("L", &cb[0]); t.append_point_bytes("R", &cb[32]);
       Sc u = t.challenge_scalar("u"), u_inv = u.inverse();
-      for (size_t i = 0; i < half; i++) { a[i] = a[i] * u + u_inv * a[half + i]; b[i] = b[i] * u_inv + u * b[half + i]; }
-      a.resize(half); b.resize(half);
-      ScVec w2(2 * w.size()); for (size_t blk = 0; blk < w.size(); blk++) { w2[2 * blk] = w[blk] * u_inv; w2[2 * blk + 1] = w[blk] * u; }   // G_L*u_inv + G_R*u (bullet.rs:131)
-      w.swap(w2);
+      lasso_fr ua = u.abi(), uia = u_inv.abi();
+      d.chk(lasso_bullet_fold(d.ctx, d_a.p, d_b.p, nk, w_cur, nw, w_nxt, &ua, &uia), "lasso_bullet_fold");
+      std::swap(w_cur, w_nxt);
       blind_fin = blind_fin + blind_L * u * u + blind_R * u_inv * u_inv;
-      P.L_vec.insert(P.L_vec.end(), Lb, Lb + 32); P.R_vec.insert(P.R_vec.end(), Rb, Rb + 32);
-      nk = half; round++;
+      P.L_vec.insert(P.L_vec.end(), cb.begin(), cb.begin() + 32); P.R_vec.insert(P.R_vec.end(), cb.begin() + 32, cb.end());
+      nk /= 2; nw *= 2; round++;
     }
-    Sc x_hat = a[0], a_hat = b[0], y_hat = x_hat * a_hat;
-    ScVec sg(n + 2, Sc::zero()); for (size_t i = 0; i < n; i++) sg[i] = w[i];
-    Pt g_hat = msm(g, sg);
+    lasso_fr heads[2]; const lasso_fr* hp[2] = {d_a.p, d_b.p};
+    d.chk(lasso_read_heads(d.ctx, hp, 2, heads), "lasso_read_heads");
+    Sc x_hat = Sc::from_abi(heads[0]), a_hat = Sc::from_abi(heads[1]), y_hat = x_hat * a_hat;
+    Pt g_hat = msm_dev(g, w_cur, n);                                             // G[0] after all folds = sum_j w_j G_j
     compress_one(g_hat * dd + g.h * r_delta, P.delta); t.append_point_bytes("delta", P.delta);
     compress_one(g.Q * dd + g.h * r_beta, P.beta); t.append_point_bytes("beta", P.beta);
     Sc c = t.challenge_scalar("c");
@@ -468,6 +481,7 @@ class Prover {
   }
   // ---- PolyEvalProof::prove (dense_mlpoly.rs:302-359), blinds None
   DotProductProofLog poly_eval_prove(const lasso_fr* d_poly, size_t num_vars, const ScVec& r, const Sc& Zr, const PolyCommitmentGens& g) {
+    Trace tr("DensePolyEval.prove", d.ctx);
     t.append_protocol_name("polynomial evaluation proof");
     LASSO_REQUIRE(r.size() == num_vars);
     size_t left = num_vars / 2, right = num_vars - left;
@@ -495,9 +509,11 @@ class Prover {
 
   // ---- SparsePolynomialEvaluationProof::prove (surge.rs:119-211)
   void prove(const ScVec& r) {
+    Trace tr_all("SparsePoly.prove", d.ctx);
     t.append_protocol_name("Lasso SparsePolynomialEvaluationProof");
     LASSO_REQUIRE(r.size() == ceil_log2(s));
     // Subtables::new (subtables/mod.rs:116-129)
+    std::unique_ptr<Trace> sp(new Trace("Subtables.new", d.ctx));
     auto host_tables = S.materialize_subtables();
     for (auto& ht : host_tables) { DBufU32 tmp(d, ht); DBuf tb(d, m); d.chk(lasso_fr_from_u32(d.ctx, tmp.p, m, tb.p), "lasso_fr_from_u32"); d.chk(lasso_sync(d.ctx), "lasso_sync"); tables.push_back(std::move(tb)); }
     size_t n_E = next_pow2(alpha * s); nv_derefs = ceil_log2(n_E);
@@ -507,12 +523,14 @@ class Prover {
       d.chk(lasso_gather(d.ctx, tables[S.memory_to_subtable_index(i)].p, dense.dim_u32[S.memory_to_dimension_index(i)].p, s, combined_E.p + i * s), "lasso_gather");
     ProofWriter W;
     // comm_derefs
+    sp.reset(new Trace("Subtables.commit", d.ctx));
     PolyCommitment comm_derefs = hyrax_commit(d, combined_E.p, nv_derefs, gens.gens_derefs);
     t.append_message("subtable_evals_commitment", "begin_subtable_evals_commitment");
     append_poly_commitment(t, "comm_poly_row_col_ops_val", comm_derefs);
     t.append_message("subtable_evals_commitment", "end_subtable_evals_commitment");
     W.pts_vec(comm_derefs.compressed);
     // claim
+    sp.reset(new Trace("Subtables.compute_sumcheck_claim", d.ctx));
     DBuf eq(d, s);
     { std::vector<lasso_fr> rr; for (auto& x : r) rr.push_back(x.abi()); d.chk(lasso_eq_evals(d.ctx, rr.data(), (uint32_t)rr.size(), eq.p), "lasso_eq_evals"); }
     std::vector<const lasso_fr*> Eptr; for (size_t i = 0; i < alpha; i++) Eptr.push_back(E(i));
@@ -521,6 +539,7 @@ class Prover {
     t.append_scalar("claim_eval_scalar_product", claimed_eval);
     // primary sumcheck on clones of E_i and the eq polynomial (surge.rs:151-172)
     ScVec r_z;
+    sp.reset(new Trace("Sumcheck.prove", d.ctx));
     {
       DBuf work(d, alpha * s);
       d.chk(lasso_copy(d.ctx, work.p, combined_E.p, alpha * s * sizeof(lasso_fr)), "lasso_copy");
@@ -530,6 +549,7 @@ class Prover {
     }
     W.sc(claimed_eval);
     // eval_derefs = E_i(r_z) (surge.rs:175-176)
+    sp.reset(new Trace("CombinedEval.prove", d.ctx));
     DBuf chis(d, s);
     auto evaluate_at = [&](const std::vector<const lasso_fr*>& polys, const ScVec& point, size_t n, DBuf& chi) {
       std::vector<lasso_fr> rr; for (auto& x : point) rr.push_back(x.abi());
@@ -543,8 +563,10 @@ class Prover {
     t.append_protocol_name("Lasso CombinedTableEvalProof");
     joint_open("evals_ops_val", "challenge_combine_n_to_one", "joint_claim_eval", eval_derefs, true, combined_E.p, nv_derefs, r_z, gens.gens_derefs).write(W);
     // memory checking (surge.rs:186-199)
+    sp.reset(new Trace("MemoryChecking.prove", d.ctx));
     ScVec r_hash = t.challenge_vector("challenge_r_hash", 2);
     memory_checking_prove(r_hash[0], r_hash[1], Eptr, chis, W);
+    sp.reset();
     proof_bytes.swap(W.b);
   }
 
@@ -552,6 +574,7 @@ class Prover {
     t.append_protocol_name("Lasso MemoryCheckingProof");
     // Subtables::to_grand_products -> GrandProducts::new (subtables/mod.rs:134-175, memory_checking.rs:175-217)
     lasso_fr g = gamma.abi(), ta = tau.abi();
+    std::unique_ptr<Trace> sp(new Trace("Subtables.to_grand_products", d.ctx));
     std::vector<DBuf> t_init, t_read, t_write, t_final;
     for (size_t i = 0; i < alpha; i++) {
       size_t j = S.memory_to_dimension_index(i); const lasso_fr* table = tables[S.memory_to_subtable_index(i)].p;
@@ -563,6 +586,7 @@ class Prover {
       t_init.push_back(std::move(ti)); t_final.push_back(std::move(tf)); t_read.push_back(std::move(tr)); t_write.push_back(std::move(tw));
     }
     // ProductLayerProof::prove (memory_checking.rs:674-731)
+    sp.reset(new Trace("ProductLayer.prove", d.ctx));
     t.append_protocol_name("Lasso ProductLayerProof");
     auto root = [&](const DBuf& tree, size_t n) { lasso_fr two[2]; d.chk(lasso_download(d.ctx, two, tree.p + (2 * n - 4), sizeof(two)), "lasso_download"); return Sc::from_abi(two[0]) * Sc::from_abi(two[1]); };   // GrandProductCircuit::evaluate
     ScVec roots_rw, roots_if;
@@ -582,6 +606,7 @@ class Prover {
     t_init.clear(); t_final.clear();
     proof_mem.write(W); proof_ops.write(W);    // field order of ProductLayerProof: grand_product_evals, proof_mem, proof_ops (:656-660)
     // HashLayerProof::prove (memory_checking.rs:338-460)
+    sp.reset(new Trace("HashLayer.prove", d.ctx));
     t.append_protocol_name("Lasso HashLayerProof");
     const size_t C = S.C();
     std::vector<const lasso_fr*> at_ops(Eptr); for (size_t i = 0; i < C; i++) at_ops.push_back(dense.dim(i)); for (size_t i = 0; i < C; i++) at_ops.push_back(dense.read(i));

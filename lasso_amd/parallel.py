@@ -1,0 +1,81 @@
+"""Multi-GPU plumbing (one process per GPU, torch.distributed; backend "nccl" = RCCL over xGMI on ROCm, "gloo" in CPU tests).
+
+The north-star path shards by PROOF: each rank owns an independent batch of lookups (its own DensifiedRepresentation,
+transcript and proof) — independent objects, so there is no data-path collective.  torch.distributed
+is only used for the barrier / max-over-ranks timing contract of bench.py and to gather proof digests."""
+import hashlib
+import os
+
+
+class Group:
+    def __init__(self, backend=None):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.dist = None
+        self.backend = None
+        if self.world > 1:
+            import torch
+            import torch.distributed as dist
+            self.backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+            if self.backend == "nccl":
+                torch.cuda.set_device(self.local_rank)
+            dist.init_process_group(backend=self.backend, init_method="env://")
+            self.dist = dist
+            self.torch = torch
+
+    @property
+    def device_index(self):
+        return self.local_rank if self.world > 1 else 0
+
+    def _tensor(self, values, dtype):
+        dev = "cuda" if self.backend == "nccl" else "cpu"
+        return self.torch.tensor(values, dtype=dtype, device=dev)
+
+    def barrier(self):
+        if self.dist is not None:
+            if self.backend == "nccl":
+                self.torch.cuda.synchronize()
+            self.dist.barrier()
+
+    def max_over_ranks(self, x):
+        if self.dist is None:
+            return float(x)
+        t = self._tensor([float(x)], self.torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def sum_over_ranks(self, x):
+        if self.dist is None:
+            return float(x)
+        t = self._tensor([float(x)], self.torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return float(t.item())
+
+    def gather_digests(self, payload: bytes):
+        """sha256 of each rank's proof, gathered on every rank (32 bytes per rank — the only bytes that cross ranks)."""
+        h = hashlib.sha256(payload).digest()
+        if self.dist is None:
+            return [h]
+        t = self._tensor(list(h), self.torch.uint8)
+        out = [self.torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(out, t)
+        return [bytes(o.cpu().tolist()) for o in out]
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.destroy_process_group()
+
+
+def shard_seed(rank):
+    """each rank's batch of lookups is drawn from its own stream (rank 0 = the reference harness's stream)"""
+    return rank
+
+
+def shard_indices(hp, s, m, c, rank):
+    """rank 0 reproduces benches/bench.rs gen_indices exactly; rank r > 0 rotates every index by r (a different, equally
+    distributed batch) so the proofs of different ranks differ."""
+    idx = hp.gen_indices(s, m, c)
+    if rank:
+        idx = (idx + rank) % m
+    return idx

@@ -133,6 +133,32 @@ int32_t lasso_msm(lasso_ctx* c, const lasso_bases* b, const lasso_fr* scalars, s
   put_point(msm(bases, sc), out); return 0;
 }
 
+int32_t lasso_msm_dev(lasso_ctx* c, const lasso_bases* b, const lasso_fr* scalars, size_t n, lasso_point* out) { return lasso_msm(c, b, scalars, n, out); }
+int32_t lasso_inner_products_lr(lasso_ctx*, const lasso_fr* a, const lasso_fr* b, size_t nk, lasso_fr* out) {
+  size_t h = nk / 2; F(out)[0] = inner_product(F(a), F(b) + h, h); F(out)[1] = inner_product(F(a) + h, F(b), h); return 0;   // bullet.rs:79-80
+}
+// bullet.rs:84-118 on the virtually folded generators G^(k)_i = sum_blk w_blk G_{blk*nk+i}: fold G explicitly (as the reference does) then MSM
+int32_t lasso_bullet_lr(lasso_ctx* c, const lasso_bases* b, size_t n, const lasso_fr* a, size_t nk, const lasso_fr* w, const lasso_fr* tail, lasso_point* out) {
+  REQ(c, n + 2 <= b->pts.size() && nk >= 2 && nk <= n);
+  size_t nw = n / nk, h = nk / 2;
+  std::vector<Point> G(nk, Point::identity());
+  for (size_t i = 0; i < nk; i++) for (size_t blk = 0; blk < nw; blk++) G[i] += b->pts[blk * nk + i] * F(w)[blk];
+  const Point& Q = b->pts[n]; const Point& H = b->pts[n + 1];
+  std::vector<Point> bs(G.begin() + h, G.end()); bs.push_back(Q); bs.push_back(H);
+  std::vector<Fr> sc(F(a), F(a) + h); sc.push_back(F(tail)[0]); sc.push_back(F(tail)[1]);
+  put_point(msm(bs, sc), out);
+  bs.assign(G.begin(), G.begin() + h); bs.push_back(Q); bs.push_back(H);
+  sc.assign(F(a) + h, F(a) + nk); sc.push_back(F(tail)[2]); sc.push_back(F(tail)[3]);
+  put_point(msm(bs, sc), out + 1);
+  return 0;
+}
+int32_t lasso_bullet_fold(lasso_ctx*, lasso_fr* a, lasso_fr* b, size_t nk, const lasso_fr* w, size_t nw, lasso_fr* w_out, const lasso_fr* u, const lasso_fr* u_inv) {
+  size_t h = nk / 2; Fr uu = *F(u), ui = *F(u_inv);
+  for (size_t i = 0; i < h; i++) { F(a)[i] = F(a)[i] * uu + ui * F(a)[h + i]; F(b)[i] = F(b)[i] * ui + uu * F(b)[h + i]; }   // bullet.rs:127-130
+  for (size_t k = 0; k < nw; k++) { F(w_out)[2 * k] = F(w)[k] * ui; F(w_out)[2 * k + 1] = F(w)[k] * uu; }                   // bullet.rs:131 as weights
+  return 0;
+}
+
 // ---- test helpers (not part of lasso_hip.h): compare projective points produced by two implementations
 void mock_point_compress(const lasso_point* p, uint8_t* out32) {
   Point q; memcpy(q.X.v, p->x, 32); memcpy(q.Y.v, p->y, 32); memcpy(q.T.v, p->t, 32); memcpy(q.Z.v, p->z, 32); q.compress(out32);

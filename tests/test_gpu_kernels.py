@@ -264,3 +264,47 @@ def test_msm_linearity_large(devs, oracle):
     buf = (C.c_uint8 * 32)()
     oracle.orc_pt_compress(xo, buf)
     assert bytes(buf) == cs
+
+
+@pytest.mark.parametrize("nk", [2, 8, 256, 1 << 12])
+def test_inner_products_lr(devs, nk):
+    rng = np.random.default_rng(nk + 1)
+    a = rand_fr(rng, nk); b = rand_fr(rng, nk)
+
+    def run(d):
+        pa = d.upload(a); pb = d.upload(b)
+        out = d.inner_products_lr(pa, pb, nk)
+        d.free(pa); d.free(pb)
+        return out
+    x, y = both(devs, run)
+    assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("n,nk", [(2, 2), (8, 8), (8, 2), (64, 16), (256, 256), (256, 4)])
+def test_bullet_lr_and_fold(devs, n, nk):
+    """one bullet-reduction round on the virtually folded generators vs the oracle folding G explicitly (bullet.rs:84-132)"""
+    rng = np.random.default_rng(n * 100 + nk)
+    mock_lib = devs[1].lib
+    g = gens(mock_lib, b"gens_sparse_poly", n + 1)       # n + 2 points: G_0..G_{n-1}, Q, H
+    nw = n // nk
+    a = rand_fr(rng, nk, edge=False); b = rand_fr(rng, nk, edge=False); w = rand_fr(rng, nw, edge=False)
+    tail = rand_fr(rng, 4, edge=False)
+    u, ui = rand_fr(rng, 2, edge=False)
+
+    def run(d):
+        bases = d.bases_create(g)
+        pa = d.upload(a); pb = d.upload(b); pw = d.upload(w); pw2 = d.alloc(32 * 2 * nw)
+        lr = d.bullet_lr(bases, n, pa, nk, pw, tail)
+        d.bullet_fold(pa, pb, nk, pw, nw, pw2, u, ui)
+        outs = (lr, d.download(pa, (nk // 2, 4)), d.download(pb, (nk // 2, 4)), d.download(pw2, (2 * nw, 4)))
+        wsum = d.msm_dev(bases, pw2, 2 * nw) if 2 * nw <= n else None
+        for p in (pa, pb, pw, pw2):
+            d.free(p)
+        d.bases_destroy(bases)
+        return outs, wsum
+    (ra, wa), (rb, wb) = both(devs, run)
+    assert compress_points(mock_lib, ra[0]) == compress_points(mock_lib, rb[0])
+    for x, y in zip(ra[1:], rb[1:]):
+        assert np.array_equal(x, y)
+    if wa is not None:
+        assert compress_points(mock_lib, wa) == compress_points(mock_lib, wb)
