@@ -1,0 +1,144 @@
+// Fq = 2^255 - 19 in nine signed 29-bit limbs (value = sum v[k] * 2^(29k), lazily reduced mod p), the representation
+// the MSM kernels keep points and tables in.  Why: on gfx950 `v_mad_i64_i32` issues at ~5 cycles per wave and accumulates a
+// 64-bit column in place, so a schoolbook product in a radix with headroom needs NO carry handling between partial
+// products — the 8x32-bit version in fq.cuh spends three quarters of its instructions on `v_mov`/`v_lshl_add_u64` moving
+// carries around (profiles/r01_microbench_initial.txt).  2^261 = 64 * 2^255 = 1216 (mod p), so high columns fold back with a
+// small constant.  Signed limbs make subtraction a plain limb-wise `v_sub`.
+//
+// Bounds (|.| per limb):  "reduced"  <= 2^29 + 2^15   (outputs of fe_mul / fe_weak)
+//                         "loose"    <= 2^30 + 2^16   (one add/sub of reduced values)
+// fe_mul(a, b) requires a loose, b reduced: 9 products of <= 2^59.01 stay below 2^63.
+#pragma once
+#include <stdint.h>
+#include "fq.cuh"
+
+struct fe29 { int32_t v[9]; };
+#define FE29_MASK 0x1fffffff
+
+LHD fe29 fe_zero() { fe29 r; for (int i = 0; i < 9; i++) r.v[i] = 0; return r; }
+LHD fe29 fe_one() { fe29 r = fe_zero(); r.v[0] = 1; return r; }
+LHD fe29 fe_add(const fe29& a, const fe29& b) { fe29 r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.v[i] = a.v[i] + b.v[i]; return r; }
+LHD fe29 fe_sub(const fe29& a, const fe29& b) { fe29 r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.v[i] = a.v[i] - b.v[i]; return r; }
+LHD fe29 fe_neg(const fe29& a) { fe29 r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.v[i] = -a.v[i]; return r; }
+LHD fe29 fe_dbl(const fe29& a) { fe29 r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.v[i] = a.v[i] * 2; return r; }
+
+// carry pass on 32-bit limbs: |in| < 2^31  ->  reduced
+LHD fe29 fe_weak(const fe29& a) {
+  fe29 r; int32_t c = 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++) { int32_t x = a.v[i] + c; c = x >> 29; r.v[i] = x & FE29_MASK; }
+  r.v[0] += c * 1216;   // |c| <= 4: limb 0 leaves [0, 2^29) by at most 4864
+  return r;
+}
+
+// a loose, b reduced -> reduced.  81 + 9 multiply-accumulates.
+LHD fe29 fe_mul(const fe29& a, const fe29& b) {
+  int64_t h[18];
+#pragma unroll
+  for (int k = 0; k < 18; k++) h[k] = 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++)
+#pragma unroll
+    for (int j = 0; j < 9; j++) h[i + j] += (int64_t)a.v[i] * b.v[j];
+  // normalise columns 9..16 to 29 bits (carry into 17), then fold 2^(29(k+9)) = 1216 * 2^(29k)
+  int32_t hi[9];
+#pragma unroll
+  for (int k = 9; k < 17; k++) { int64_t c = h[k] >> 29; hi[k - 9] = (int32_t)h[k] & FE29_MASK; h[k + 1] += c; }
+  hi[8] = (int32_t)h[17];   // |h17| < 2^31
+#pragma unroll
+  for (int k = 0; k < 9; k++) h[k] += (int64_t)hi[k] * 1216;
+  fe29 r; int64_t c = 0;
+#pragma unroll
+  for (int k = 0; k < 9; k++) { int64_t x = h[k] + c; c = x >> 29; r.v[k] = (int32_t)x & FE29_MASK; }
+  // carry out of limb 8 (|c| < 2^34) has weight 2^261 = 1216
+  int64_t x0 = (int64_t)r.v[0] + c * 1216;
+  r.v[0] = (int32_t)x0 & FE29_MASK;
+  r.v[1] += (int32_t)(x0 >> 29);   // < 2^16 in magnitude
+  return r;
+}
+LHD fe29 fe_sqr(const fe29& a) { return fe_mul(a, a); }   // a must be reduced
+
+// ------------------------------------------------------------------ conversions (table build / result hand-back only)
+LHD fe29 fe_from_fq(const fq_t& x) {   // any lazy fq_t (< 2^256)
+  fq_t c = fq_canonical(x);
+  fe29 r;
+#pragma unroll
+  for (int k = 0; k < 9; k++) {
+    int bit = 29 * k, w = bit >> 5, s = bit & 31;
+    uint64_t two = (uint64_t)c.v[w] | ((w + 1 < 8) ? ((uint64_t)c.v[w + 1] << 32) : 0);
+    r.v[k] = (int32_t)((two >> s) & FE29_MASK);
+  }
+  return r;
+}
+LHD fq_t fe_to_fq(const fe29& a) {   // loose input ok; returns a lazy fq_t congruent to a
+  fe29 t = fe_weak(a);               // limbs 1..8 in [0, 2^29), limb 0 in [-4864, 2^29 + 4864]
+  // V = value(t) + (2^261 - 1216) = value(t) + 64p  >= 0: limb 0 -= 1216, limb 9 = 1, then an exact carry pass
+  int64_t l[10];
+#pragma unroll
+  for (int k = 0; k < 9; k++) l[k] = t.v[k];
+  l[0] -= 1216; l[9] = 1;
+  int64_t c = 0;
+#pragma unroll
+  for (int k = 0; k < 10; k++) { int64_t x = l[k] + c; c = x >> 29; l[k] = x & FE29_MASK; }
+  // pack the ten 29-bit limbs (V < 2^262) into nine 32-bit words
+  uint32_t w[10];
+#pragma unroll
+  for (int i = 0; i < 10; i++) w[i] = 0;
+#pragma unroll
+  for (int k = 0; k < 10; k++) {
+    const int bit = 29 * k, wi = bit >> 5, sh = bit & 31;
+    const uint64_t v = (uint64_t)l[k] << sh;
+    w[wi] |= (uint32_t)v;
+    if (wi + 1 < 10) w[wi + 1] |= (uint32_t)(v >> 32);
+  }
+  // V = lo256 + w[8] * 2^256 and 2^256 = 38 (mod p); w[8] < 2^6, w[9] == 0
+  fq_t lo; for (int i = 0; i < 8; i++) lo.v[i] = w[i];
+  fq_t hi = fq_zero(); hi.v[0] = 38u * w[8];
+  return fq_add(lo, hi);
+}
+
+// ------------------------------------------------------------------ group law on fe29 coordinates
+struct pt29 { fe29 X, Y, T, Z; };            // extended coordinates, all reduced
+struct alignas(16) niels29 { fe29 ypx, ymx, t2d; int32_t pad; };   // 112 bytes: 7 x dwordx4
+
+LHD pt29 pt_identity() { pt29 p; p.X = fe_zero(); p.Y = fe_one(); p.T = fe_zero(); p.Z = fe_one(); return p; }
+LHD fe29 fe_d2() {   // 2d mod p
+  fe29 r; r.v[0] = 112390489; r.v[1] = 515169441; r.v[2] = 15488442; r.v[3] = 2700549; r.v[4] = 487784462; r.v[5] = 7960441; r.v[6] = 329016890; r.v[7] = 462085119; r.v[8] = 2361049; return r;
+}
+// mixed add (7 multiplications): p + n
+LHD pt29 pt_madd(const pt29& p, const niels29& n) {
+  fe29 A = fe_mul(fe_sub(p.Y, p.X), n.ymx);
+  fe29 B = fe_mul(fe_add(p.Y, p.X), n.ypx);
+  fe29 C = fe_mul(p.T, n.t2d);
+  fe29 D = fe_dbl(p.Z);
+  fe29 E = fe_sub(B, A), F = fe_weak(fe_sub(D, C)), G = fe_weak(fe_add(D, C)), H = fe_weak(fe_add(B, A));
+  pt29 r; r.X = fe_mul(E, F); r.Y = fe_mul(H, G); r.T = fe_mul(E, H); r.Z = fe_mul(F, G); return r;
+}
+// full add (9 multiplications), unified / complete
+LHD pt29 pt_add(const pt29& p, const pt29& q, const fe29& d2) {
+  fe29 A = fe_mul(fe_sub(p.Y, p.X), fe_weak(fe_sub(q.Y, q.X)));
+  fe29 B = fe_mul(fe_add(p.Y, p.X), fe_weak(fe_add(q.Y, q.X)));
+  fe29 C = fe_mul(fe_mul(p.T, d2), q.T);
+  fe29 D = fe_dbl(fe_mul(p.Z, q.Z));
+  fe29 E = fe_sub(B, A), F = fe_weak(fe_sub(D, C)), G = fe_weak(fe_add(D, C)), H = fe_weak(fe_add(B, A));
+  pt29 r; r.X = fe_mul(E, F); r.Y = fe_mul(H, G); r.T = fe_mul(E, H); r.Z = fe_mul(F, G); return r;
+}
+LHD pt29 pt_dbl(const pt29& p) {
+  fe29 A = fe_sqr(p.X), B = fe_sqr(p.Y), C = fe_dbl(fe_sqr(p.Z));
+  fe29 E = fe_dbl(fe_mul(p.X, p.Y));                       // (X+Y)^2 - A - B = 2XY
+  fe29 G = fe_sub(B, A), F = fe_weak(fe_sub(G, C)), H = fe_weak(fe_neg(fe_add(A, B)));   // D = -A
+  pt29 r; r.X = fe_mul(E, F); r.Y = fe_mul(G, H); r.T = fe_mul(E, H); r.Z = fe_mul(G, F); return r;
+}
+LHD niels29 niels_from_affine(const fq_t& x, const fq_t& y) {
+  niels29 n; n.ypx = fe_from_fq(fq_add(y, x)); n.ymx = fe_from_fq(fq_sub(y, x)); n.t2d = fe_from_fq(fq_mul(fq_mul(x, y), fq_d2())); n.pad = 0; return n;
+}
+LHD pt29 pt_from_ed(const ed_point& e) { pt29 p; p.X = fe_from_fq(e.X); p.Y = fe_from_fq(e.Y); p.T = fe_from_fq(e.T); p.Z = fe_from_fq(e.Z); return p; }
+LHD ed_point pt_to_ed(const pt29& p) { ed_point e; e.X = fe_to_fq(p.X); e.Y = fe_to_fq(p.Y); e.T = fe_to_fq(p.T); e.Z = fe_to_fq(p.Z); return e; }

@@ -21,7 +21,7 @@ __global__ void __launch_bounds__(256) k_inner_lr(const fr_t* __restrict__ a, co
 }
 
 static_assert(sizeof(lasso_fr) == 32 && sizeof(fr_t) == 32, "Fr layout");
-static_assert(sizeof(lasso_affine) == 64 && sizeof(lasso_point) == 128 && sizeof(ed_point) == 128 && sizeof(ed_niels) == 96, "curve layouts");
+static_assert(sizeof(lasso_affine) == 64 && sizeof(lasso_point) == 128 && sizeof(ed_point) == 128 && sizeof(niels29) == 112 && sizeof(pt29) == 144, "curve layouts");
 
 struct EventPair { hipEvent_t a, b; int kid; double bytes; };
 struct lasso_ctx {
@@ -37,7 +37,7 @@ struct lasso_ctx {
   std::vector<EventPair> events; size_t events_used = 0;
   uint64_t prof_launches[LASSO_K_COUNT] = {0}; double prof_ms[LASSO_K_COUNT] = {0}; double prof_bytes[LASSO_K_COUNT] = {0};
 };
-struct lasso_bases { size_t n = 0; ed_niels* d_table = nullptr; };
+struct lasso_bases { size_t n = 0; niels29* d_table = nullptr; };
 
 static thread_local std::string g_create_err;
 
@@ -309,7 +309,7 @@ int32_t lasso_bases_create(lasso_ctx* c, const lasso_affine* points, size_t n, l
   REQUIRE(c, points && out && n >= 1 && n * MSM_WINDOWS < ((size_t)1 << 32));
   lasso_bases* b = new lasso_bases(); b->n = n;
   void* d_aff = nullptr;
-  if (hipMalloc(&d_aff, n * sizeof(lasso_affine)) != hipSuccess || hipMalloc((void**)&b->d_table, n * MSM_WINDOWS * sizeof(ed_niels)) != hipSuccess) {
+  if (hipMalloc(&d_aff, n * sizeof(lasso_affine)) != hipSuccess || hipMalloc((void**)&b->d_table, n * MSM_WINDOWS * sizeof(niels29)) != hipSuccess) {
     if (d_aff) (void)hipFree(d_aff); delete b; return fail(c, LASSO_ERR_OOM, "bases alloc");
   }
   hipError_t e = hipMemcpyAsync(d_aff, points, n * sizeof(lasso_affine), hipMemcpyHostToDevice, c->stream);
@@ -332,11 +332,11 @@ static size_t msm_chunks(size_t rows, size_t n_cols, uint32_t W) {
 static int32_t run_msm(lasso_ctx* c, const uint8_t* d_scal, uint32_t bps, uint32_t W, size_t row_stride, size_t rows, size_t n_cols, const lasso_bases* b, uint8_t* scratch_after, lasso_point* out) {
   const size_t K = msm_chunks(rows, n_cols, W);
   const size_t cols_per_chunk = (n_cols + K - 1) / K;
-  ed_point* d_partial = (ed_point*)scratch_after; ed_point* d_final = d_partial + rows * K;
+  pt29* d_partial = (pt29*)scratch_after; ed_point* d_final = (ed_point*)(((uintptr_t)(d_partial + rows * K) + 15) & ~(uintptr_t)15);
   {
     ProfScope ps(c, LASSO_K_MSM, (double)rows * n_cols * bps);
-    hipLaunchKernelGGL(k_msm_buckets, dim3((unsigned)K, (unsigned)rows), dim3(MSM_THREADS), 0, c->stream, d_scal, bps, W, row_stride, n_cols, cols_per_chunk, (const ed_niels*)b->d_table, b->n, d_partial);
-    hipLaunchKernelGGL(k_points_sum, dim3((unsigned)rows), dim3(MSM_THREADS), 0, c->stream, (const ed_point*)d_partial, (uint32_t)K, d_final);
+    hipLaunchKernelGGL(k_msm_buckets, dim3((unsigned)K, (unsigned)rows), dim3(MSM_THREADS), 0, c->stream, d_scal, bps, W, row_stride, n_cols, cols_per_chunk, (const niels29*)b->d_table, b->n, d_partial);
+    hipLaunchKernelGGL(k_points_sum, dim3((unsigned)rows), dim3(MSM_THREADS), 0, c->stream, (const pt29*)d_partial, (uint32_t)K, d_final);
   }
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipMemcpyAsync(out, d_final, rows * sizeof(ed_point), hipMemcpyDeviceToHost, c->stream));
@@ -346,7 +346,7 @@ static int32_t run_msm(lasso_ctx* c, const uint8_t* d_scal, uint32_t bps, uint32
 int32_t lasso_hyrax_commit(lasso_ctx* c, const lasso_fr* d_Z, size_t l_size, size_t r_size, const lasso_bases* b, lasso_point* out) {
   REQUIRE(c, d_Z && b && out && l_size >= 1 && r_size >= 1 && r_size <= b->n && l_size < ((size_t)1 << 31));
   const size_t n = l_size * r_size;
-  const size_t pts_bytes = (l_size * msm_chunks(l_size, r_size, MSM_WINDOWS) + l_size) * sizeof(ed_point) + 256;
+  const size_t pts_bytes = (l_size * msm_chunks(l_size, r_size, MSM_WINDOWS) + l_size) * sizeof(pt29) + 512;
   int32_t rc = ensure_scratch(c, n * 32 + pts_bytes); if (rc) return rc;
   uint8_t* d_scal = (uint8_t*)c->d_scratch;
   HIPCHK(c, hipMemsetAsync(c->d_flags, 0, 8, c->stream));
@@ -367,7 +367,7 @@ int32_t lasso_hyrax_commit(lasso_ctx* c, const lasso_fr* d_Z, size_t l_size, siz
 }
 int32_t lasso_msm(lasso_ctx* c, const lasso_bases* b, const lasso_fr* scalars, size_t n, lasso_point* out) {
   REQUIRE(c, b && scalars && out && n >= 1 && n <= b->n);
-  int32_t rc = ensure_scratch(c, n * 64 + 258 * sizeof(ed_point)); if (rc) return rc;
+  int32_t rc = ensure_scratch(c, n * 64 + 260 * sizeof(pt29)); if (rc) return rc;
   fr_t* d_in = (fr_t*)c->d_scratch; fr_t* d_can = d_in + n;
   HIPCHK(c, hipMemcpyAsync(d_in, scalars, n * 32, hipMemcpyHostToDevice, c->stream));
   hipLaunchKernelGGL(k_fr_to_canonical, dim3(grid_for(n)), dim3(256), 0, c->stream, (const fr_t*)d_in, n, d_can);
@@ -376,7 +376,7 @@ int32_t lasso_msm(lasso_ctx* c, const lasso_bases* b, const lasso_fr* scalars, s
 
 int32_t lasso_msm_dev(lasso_ctx* c, const lasso_bases* b, const lasso_fr* d_scalars, size_t n, lasso_point* out) {
   REQUIRE(c, b && d_scalars && out && n >= 1 && n <= b->n);
-  int32_t rc = ensure_scratch(c, n * 32 + 258 * sizeof(ed_point)); if (rc) return rc;
+  int32_t rc = ensure_scratch(c, n * 32 + 260 * sizeof(pt29)); if (rc) return rc;
   fr_t* d_can = (fr_t*)c->d_scratch;
   hipLaunchKernelGGL(k_fr_to_canonical, dim3(grid_for(n)), dim3(256), 0, c->stream, (const fr_t*)d_scalars, n, d_can);
   return run_msm(c, (const uint8_t*)d_can, 32, MSM_WINDOWS, n * 32, 1, n, b, (uint8_t*)(d_can + n), out);
@@ -396,7 +396,7 @@ int32_t lasso_inner_products_lr(lasso_ctx* c, const lasso_fr* d_a, const lasso_f
 int32_t lasso_bullet_lr(lasso_ctx* c, const lasso_bases* b, size_t n, const lasso_fr* d_a, size_t nk, const lasso_fr* d_w, const lasso_fr* tail, lasso_point* out) {
   REQUIRE(c, b && d_a && d_w && tail && out && n >= 2 && (n & (n - 1)) == 0 && nk >= 2 && nk <= n && (nk & (nk - 1)) == 0 && n + 2 <= b->n);
   const size_t row = n + 2;
-  int32_t rc = ensure_scratch(c, 2 * row * 32 + (2 * 256 + 2) * sizeof(ed_point) + 256); if (rc) return rc;
+  int32_t rc = ensure_scratch(c, 2 * row * 32 + (2 * 256 + 4) * sizeof(pt29) + 512); if (rc) return rc;
   fr_t* SL = (fr_t*)c->d_scratch; fr_t* SR = SL + row;
   hipLaunchKernelGGL(k_bullet_expand, dim3(grid_for(n)), dim3(256), 0, c->stream, (const fr_t*)d_a, nk, (const fr_t*)d_w, n, to_fr(tail), to_fr(tail + 1), to_fr(tail + 2), to_fr(tail + 3), SL, SR);
   return run_msm(c, (const uint8_t*)SL, 32, MSM_WINDOWS, row * 32, 2, row, b, (uint8_t*)(SR + row), out);

@@ -16,6 +16,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "fq.cuh"
+#include "fe29.cuh"
 
 #define MSM_THREADS 256
 #define MSM_BATCH 4096
@@ -47,17 +48,18 @@ LHD fq_t fq_inv_chain(const fq_t& z) {
   return fq_mul(t, z11);                              // 2^255 - 21
 }
 
-// table[w*n + j] = Niels(2^(4w) * G_j).  One thread per generator.  `aff` = ark Affine {x,y} Montgomery limbs.
-__global__ void k_precompute_table(const fq_t* __restrict__ aff, size_t n, ed_niels* __restrict__ table) {
+// table[w*n + j] = Niels(2^(4w) * G_j) in 29-bit-limb form (fe29.cuh).  One thread per generator; built once per gens object
+// with the 8x32 arithmetic (needs an inversion per entry), then converted.  `aff` = ark Affine {x,y} Montgomery limbs.
+__global__ void k_precompute_table(const fq_t* __restrict__ aff, size_t n, niels29* __restrict__ table) {
   size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (j >= n) return;
   fq_t x = fq_from_mont(aff[2 * j]), y = fq_from_mont(aff[2 * j + 1]);
-  table[j] = ed_to_niels_affine(x, y);
+  table[j] = niels_from_affine(x, y);
   ed_point P = ed_from_affine(x, y);
   for (int w = 1; w < MSM_WINDOWS; w++) {
     for (int k = 0; k < 4; k++) P = ed_dbl(P);
     fq_t zi = fq_inv_chain(P.Z);
-    table[(size_t)w * n + j] = ed_to_niels_affine(fq_mul(P.X, zi), fq_mul(P.Y, zi));
+    table[(size_t)w * n + j] = niels_from_affine(fq_mul(P.X, zi), fq_mul(P.Y, zi));
   }
 }
 
@@ -82,17 +84,18 @@ __global__ void __launch_bounds__(256) k_fr_to_canonical(const fr_t* __restrict_
 // scal + r*row_stride (bytes).  Windows 0..W-1 = nibble w of each scalar.  out[row*K + chunk] = partial sum (extended, plain Fq).
 __device__ __forceinline__ uint32_t msm_nibble(const uint8_t* s, uint32_t w) { return (reinterpret_cast<const uint32_t*>(s)[w >> 3] >> (4 * (w & 7))) & 15u; }
 __global__ void __launch_bounds__(MSM_THREADS) k_msm_buckets(const uint8_t* __restrict__ scal, uint32_t bps, uint32_t W, size_t row_stride, size_t n_cols, size_t cols_per_chunk,
-                                                              const ed_niels* __restrict__ table, size_t table_stride, ed_point* __restrict__ out) {
-  __shared__ __attribute__((aligned(16))) uint8_t raw[MSM_THREADS * sizeof(ed_point)];  // sorted[] (16 KB) during accumulation, points (32 KB) during the tree
+                                                              const niels29* __restrict__ table, size_t table_stride, pt29* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) uint8_t raw[MSM_THREADS * sizeof(pt29)];  // sorted[] (16 KB) during accumulation, points (36 KB) during the tree
   __shared__ uint32_t counts[MSM_THREADS], start[MSM_THREADS], cursor[MSM_THREADS];
   uint32_t* sorted = reinterpret_cast<uint32_t*>(raw);
-  ed_point* pts = reinterpret_cast<ed_point*>(raw);
+  pt29* pts = reinterpret_cast<pt29*>(raw);
+  const fe29 d2 = fe_d2();
   const uint32_t t = threadIdx.x;
   const uint8_t* row = scal + (size_t)blockIdx.y * row_stride;
   const size_t c0 = (size_t)blockIdx.x * cols_per_chunk;
   size_t c1 = c0 + cols_per_chunk; if (c1 > n_cols) c1 = n_cols;
   const uint32_t scalars_per_batch = MSM_BATCH / W;
-  ed_point B = ed_identity();
+  pt29 B = pt_identity();
   for (size_t b0 = c0; b0 < c1; b0 += scalars_per_batch) {
     size_t b1 = b0 + scalars_per_batch; if (b1 > c1) b1 = c1;
     counts[t] = 0;
@@ -114,32 +117,33 @@ __global__ void __launch_bounds__(MSM_THREADS) k_msm_buckets(const uint8_t* __re
     }
     __syncthreads();
     const uint32_t cnt = counts[t];
-    for (uint32_t k = 0; k < cnt; k++) B = ed_madd(B, table[sorted[my_start + k]]);
+    for (uint32_t k = 0; k < cnt; k++) B = pt_madd(B, table[sorted[my_start + k]]);
     __syncthreads();
   }
   // bins -> buckets: tree over the 16 column slices (bin t = slice*16 + digit)
   pts[t] = B;
   __syncthreads();
-  for (uint32_t s = 8; s > 0; s >>= 1) { if ((t >> 4) < s) pts[t] = ed_add(pts[t], pts[t + 16 * s]); __syncthreads(); }
+  for (uint32_t s = 8; s > 0; s >>= 1) { if ((t >> 4) < s) pts[t] = pt_add(pts[t], pts[t + 16 * s], d2); __syncthreads(); }
   // sum_d d * B_d over the 15 non-zero digits
   if (t < 16) {
-    ed_point Bd = pts[t], acc = ed_identity();
-    for (int bit = 3; bit >= 0; bit--) { acc = ed_dbl(acc); if ((t >> bit) & 1u) acc = ed_add(acc, Bd); }
+    pt29 Bd = pts[t], acc = pt_identity();
+    for (int bit = 3; bit >= 0; bit--) { acc = pt_dbl(acc); if ((t >> bit) & 1u) acc = pt_add(acc, Bd, d2); }
     pts[t] = acc;
   }
   __syncthreads();
-  for (uint32_t s = 8; s > 0; s >>= 1) { if (t < s) pts[t] = ed_add(pts[t], pts[t + s]); __syncthreads(); }
+  for (uint32_t s = 8; s > 0; s >>= 1) { if (t < s) pts[t] = pt_add(pts[t], pts[t + s], d2); __syncthreads(); }
   if (t == 0) out[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = pts[0];
 }
 
 // out[row] = sum_k partial[row*K + k], converted to ark's Montgomery limbs.  One workgroup per row, K <= 256.
-__global__ void __launch_bounds__(MSM_THREADS) k_points_sum(const ed_point* __restrict__ partial, uint32_t K, ed_point* __restrict__ out_mont) {
-  __shared__ ed_point pts[MSM_THREADS];
+__global__ void __launch_bounds__(MSM_THREADS) k_points_sum(const pt29* __restrict__ partial, uint32_t K, ed_point* __restrict__ out_mont) {
+  __shared__ pt29 pts[MSM_THREADS];
+  const fe29 d2 = fe_d2();
   const uint32_t t = threadIdx.x;
-  pts[t] = t < K ? partial[(size_t)blockIdx.x * K + t] : ed_identity();
+  pts[t] = t < K ? partial[(size_t)blockIdx.x * K + t] : pt_identity();
   __syncthreads();
-  for (uint32_t s = MSM_THREADS / 2; s > 0; s >>= 1) { if (t < s && t + s < K) pts[t] = ed_add(pts[t], pts[t + s]); __syncthreads(); }
-  if (t == 0) { ed_point p = pts[0], o; o.X = fq_to_mont(p.X); o.Y = fq_to_mont(p.Y); o.T = fq_to_mont(p.T); o.Z = fq_to_mont(p.Z); out_mont[blockIdx.x] = o; }
+  for (uint32_t s = MSM_THREADS / 2; s > 0; s >>= 1) { if (t < s && t + s < K) pts[t] = pt_add(pts[t], pts[t + s], d2); __syncthreads(); }
+  if (t == 0) { ed_point p = pt_to_ed(pts[0]), o; o.X = fq_to_mont(p.X); o.Y = fq_to_mont(p.Y); o.T = fq_to_mont(p.T); o.Z = fq_to_mont(p.Z); out_mont[blockIdx.x] = o; }
 }
 
 // ------------------------------------------------------------------ Hyrax opening tail (bullet.rs:40-154), vectors resident on the device
