@@ -33,6 +33,7 @@ struct lasso_ctx {
   fr_t* h_small = nullptr;                                // pinned mirror
   size_t small_cap = 0;
   uint32_t* d_flags = nullptr;
+  uint32_t* d_counters = nullptr;                         // arrival tickets of the in-launch reductions (zero between launches)
   uint32_t prof_mask = 0;   // bit k set = kernel family k is bracketed with events
   std::vector<EventPair> events; size_t events_used = 0;
   uint64_t prof_launches[LASSO_K_COUNT] = {0}; double prof_ms[LASSO_K_COUNT] = {0}; double prof_bytes[LASSO_K_COUNT] = {0};
@@ -104,6 +105,7 @@ int32_t lasso_ctx_create(int32_t device, lasso_ctx** out) {
     std::string m = hipGetErrorString(e); delete c; return fail(nullptr, LASSO_ERR_HIP, m);
   }
   if (hipMalloc((void**)&c->d_flags, 64) != hipSuccess) { delete c; return fail(nullptr, LASSO_ERR_OOM, "flags alloc"); }
+  if (hipMalloc((void**)&c->d_counters, LASSO_MAX_PTRS * 4) != hipSuccess || hipMemset(c->d_counters, 0, LASSO_MAX_PTRS * 4) != hipSuccess) { delete c; return fail(nullptr, LASSO_ERR_OOM, "counters alloc"); }
   int32_t rc = ensure_small(c, 4096); if (rc) { g_create_err = c->err; delete c; return rc; }
   rc = ensure_scratch(c, (size_t)1 << 22); if (rc) { g_create_err = c->err; delete c; return rc; }
   *out = c; return 0;
@@ -117,6 +119,7 @@ void lasso_ctx_destroy(lasso_ctx* c) {
   if (c->d_small) (void)hipFree(c->d_small);
   if (c->h_small) (void)hipHostFree(c->h_small);
   if (c->d_flags) (void)hipFree(c->d_flags);
+  if (c->d_counters) (void)hipFree(c->d_counters);
   (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -185,8 +188,22 @@ int32_t lasso_sumcheck_cubic_round(lasso_ctx* c, const lasso_fr* const* d_A, con
   rc = ensure_small(c, (size_t)ncirc * 3); if (rc) return rc;
   {
     ProfScope ps(c, LASSO_K_CUBIC, 32.0 * n * (2.0 * ncirc + 1.0));
-    hipLaunchKernelGGL(k_cubic_round, dim3(nx, ncirc), dim3(LASSO_BLOCK), 0, c->stream, A, B, (const fr_t*)d_C, half, (fr_t*)c->d_scratch);
-    hipLaunchKernelGGL(k_reduce_partials, dim3(ncirc), dim3(LASSO_BLOCK), 0, c->stream, (const fr_t*)c->d_scratch, nx, 3u, c->d_small);
+    hipLaunchKernelGGL(k_cubic_round_lb, dim3(nx, ncirc), dim3(LASSO_BLOCK), 0, c->stream, A, B, (const fr_t*)d_C, half, (fr_t*)c->d_scratch, c->d_counters, c->d_small);
+  }
+  HIPCHK(c, hipGetLastError());
+  return fetch_small(c, (size_t)ncirc * 3, out);
+}
+int32_t lasso_sumcheck_cubic_round_fused(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_C_in, lasso_fr* d_C_out, size_t n,
+                                         const lasso_fr* r, lasso_fr* out) {
+  REQUIRE(c, d_A && d_B && d_C_in && d_C_out && d_C_in != d_C_out && r && out && ncirc >= 1 && ncirc <= LASSO_MAX_PTRS && n >= 4 && (n & (n - 1)) == 0);
+  MutPtrTable A, B; for (uint32_t i = 0; i < ncirc; i++) { REQUIRE(c, d_A[i] && d_B[i]); A.p[i] = (fr_t*)d_A[i]; B.p[i] = (fr_t*)d_B[i]; }
+  const size_t q = n / 4; const unsigned nx = grid_for(q, 512);
+  int32_t rc = ensure_scratch(c, (size_t)nx * ncirc * 3 * sizeof(fr_t)); if (rc) return rc;
+  rc = ensure_small(c, (size_t)ncirc * 3); if (rc) return rc;
+  {
+    // bind: read 32n + write 16n per polynomial (2*ncirc + 1 of them); the evaluation of the next round rides on the same pass
+    ProfScope ps(c, LASSO_K_BIND, 48.0 * n * (2.0 * ncirc + 1.0));
+    hipLaunchKernelGGL(k_cubic_fused, dim3(nx, ncirc), dim3(LASSO_BLOCK), 0, c->stream, A, B, (const fr_t*)d_C_in, (fr_t*)d_C_out, q, to_fr(r), (fr_t*)c->d_scratch, c->d_counters, c->d_small);
   }
   HIPCHK(c, hipGetLastError());
   return fetch_small(c, (size_t)ncirc * 3, out);

@@ -81,6 +81,82 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_round(PtrTable A, PtrTabl
   }
 }
 
+// ------------------------------------------------------------------ in-launch second-stage reduction (no extra kernel per round)
+// Block `bx` of row `y` has written its K partial sums (thread 0).  The last block to arrive for that row sums all nx partials
+// and writes out[y*K + k].  Hand-off follows cdna_hip_programming.md §6 G16: plain stores -> agent-scope release -> drained
+// vmcnt -> relaxed agent atomic ticket; the last arriver does ONE agent-scope acquire, then the workgroup reads plain.
+__device__ __forceinline__ void last_block_reduce(const fr_t* partials, uint32_t nx, uint32_t K, uint32_t y, uint32_t* counters, fr_t* __restrict__ out, fr_t* smem) {
+  __shared__ uint32_t is_last;
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    uint32_t ticket = __hip_atomic_fetch_add(&counters[y], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t last = (ticket == nx - 1) ? 1u : 0u;
+    if (last) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); counters[y] = 0; }   // reset for the next launch (ordered by the kernel boundary)
+    is_last = last;
+  }
+  __syncthreads();
+  if (!is_last) return;
+  for (uint32_t k = 0; k < K; k++) {
+    fr_t acc = fr_zero();
+    for (uint32_t x = threadIdx.x; x < nx; x += blockDim.x) acc = fr_add(acc, partials[((size_t)y * nx + x) * K + k]);
+    acc = block_reduce_fr(acc, smem);
+    if (threadIdx.x == 0) out[(size_t)y * K + k] = acc;
+  }
+}
+
+// K4 fused with K1: bind every polynomial of the round with r (length n = 4q -> 2q), then evaluate the NEXT round on the bound
+// values while they are still in registers (80 -> 48 bytes per element per round, one launch per round).
+// A, B are bound in place (each element is owned by exactly one thread); the shared eq polynomial C is read from C_in and written
+// to C_out by the row-0 workgroups only, because every circuit row re-reads it.
+__global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_fused(MutPtrTable A, MutPtrTable B, const fr_t* __restrict__ C_in, fr_t* __restrict__ C_out, size_t q, fr_t r,
+                                                              fr_t* __restrict__ partials, uint32_t* counters, fr_t* __restrict__ out) {
+  __shared__ fr_t smem[4];
+  fr_t* __restrict__ a = A.p[blockIdx.y];
+  fr_t* __restrict__ b = B.p[blockIdx.y];
+  fr_t e0 = fr_zero(), e2 = fr_zero(), e3 = fr_zero();
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < q; i += (size_t)gridDim.x * blockDim.x) {
+    fr_t x0 = a[i], x1 = a[i + q], x2 = a[i + 2 * q], x3 = a[i + 3 * q];
+    fr_t a0 = fr_add(x0, fr_mul(r, fr_sub(x2, x0))), a1 = fr_add(x1, fr_mul(r, fr_sub(x3, x1)));
+    a[i] = a0; a[i + q] = a1;
+    x0 = b[i]; x1 = b[i + q]; x2 = b[i + 2 * q]; x3 = b[i + 3 * q];
+    fr_t b0 = fr_add(x0, fr_mul(r, fr_sub(x2, x0))), b1 = fr_add(x1, fr_mul(r, fr_sub(x3, x1)));
+    b[i] = b0; b[i + q] = b1;
+    x0 = C_in[i]; x1 = C_in[i + q]; x2 = C_in[i + 2 * q]; x3 = C_in[i + 3 * q];
+    fr_t c0 = fr_add(x0, fr_mul(r, fr_sub(x2, x0))), c1 = fr_add(x1, fr_mul(r, fr_sub(x3, x1)));
+    if (blockIdx.y == 0) { C_out[i] = c0; C_out[i + q] = c1; }
+    e0 = fr_add(e0, fr_mul(fr_mul(a0, b0), c0));
+    fr_t da = fr_sub(a1, a0), db = fr_sub(b1, b0), dc = fr_sub(c1, c0);
+    fr_t a2 = fr_add(a1, da), b2 = fr_add(b1, db), c2 = fr_add(c1, dc);
+    e2 = fr_add(e2, fr_mul(fr_mul(a2, b2), c2));
+    fr_t a3 = fr_add(a2, da), b3 = fr_add(b2, db), c3 = fr_add(c2, dc);
+    e3 = fr_add(e3, fr_mul(fr_mul(a3, b3), c3));
+  }
+  e0 = block_reduce_fr(e0, smem); e2 = block_reduce_fr(e2, smem); e3 = block_reduce_fr(e3, smem);
+  if (threadIdx.x == 0) { fr_t* o = partials + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 3; o[0] = e0; o[1] = e2; o[2] = e3; }
+  last_block_reduce(partials, gridDim.x, 3, blockIdx.y, counters, out, smem);
+}
+// first round of a layer: evaluation only, with the in-launch second stage
+__global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_round_lb(PtrTable A, PtrTable B, const fr_t* __restrict__ C, size_t half, fr_t* __restrict__ partials, uint32_t* counters,
+                                                                 fr_t* __restrict__ out) {
+  __shared__ fr_t smem[4];
+  const fr_t* __restrict__ a = A.p[blockIdx.y];
+  const fr_t* __restrict__ b = B.p[blockIdx.y];
+  fr_t e0 = fr_zero(), e2 = fr_zero(), e3 = fr_zero();
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x) {
+    fr_t a0 = a[i], a1 = a[i + half], b0 = b[i], b1 = b[i + half], c0 = C[i], c1 = C[i + half];
+    e0 = fr_add(e0, fr_mul(fr_mul(a0, b0), c0));
+    fr_t da = fr_sub(a1, a0), db = fr_sub(b1, b0), dc = fr_sub(c1, c0);
+    fr_t a2 = fr_add(a1, da), b2 = fr_add(b1, db), c2 = fr_add(c1, dc);
+    e2 = fr_add(e2, fr_mul(fr_mul(a2, b2), c2));
+    fr_t a3 = fr_add(a2, da), b3 = fr_add(b2, db), c3 = fr_add(c2, dc);
+    e3 = fr_add(e3, fr_mul(fr_mul(a3, b3), c3));
+  }
+  e0 = block_reduce_fr(e0, smem); e2 = block_reduce_fr(e2, smem); e3 = block_reduce_fr(e3, smem);
+  if (threadIdx.x == 0) { fr_t* o = partials + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 3; o[0] = e0; o[1] = e2; o[2] = e3; }
+  last_block_reduce(partials, gridDim.x, 3, blockIdx.y, counters, out, smem);
+}
+
 // ------------------------------------------------------------------ g = S::combine_lookups (subtables/*.rs)
 #define LASSO_MAX_ALPHA 32
 // A = compile-time bound on NUM_MEMORIES so `vals` stays in registers (all indexing static after unrolling)

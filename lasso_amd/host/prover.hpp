@@ -43,16 +43,30 @@ inline bool is_pow2(size_t n) { return n && !(n & (n - 1)); }
 inline size_t ceil_log2(size_t n) { size_t k = 0; while (((size_t)1 << k) < n) k++; return k; }  // == Math::log_2 (utils/math.rs:27-35) and ark_std::log2
 
 // ------------------------------------------------------------------ device handle (RAII over the C ABI)
+// Device buffers are recycled through a size-keyed pool: a proof allocates the same ~40 buffers every time and hipFree is a
+// device-wide synchronisation (the reference pays Vec allocations inside prove as well; the pool only removes the driver calls).
 class Dev {
+  mutable std::multimap<size_t, void*> pool_;
+  mutable std::map<void*, size_t> live_;
+
  public:
   lasso_ctx* ctx = nullptr;
   explicit Dev(int device) { if (lasso_ctx_create(device, &ctx) != 0) throw Error(std::string("lasso_ctx_create: ") + lasso_last_error(nullptr)); }
-  ~Dev() { if (ctx) lasso_ctx_destroy(ctx); }
+  ~Dev() { if (ctx) { for (auto& kv : pool_) lasso_free(ctx, kv.second); for (auto& kv : live_) lasso_free(ctx, kv.first); lasso_ctx_destroy(ctx); } }
   Dev(const Dev&) = delete; Dev& operator=(const Dev&) = delete;
   void chk(int32_t rc, const char* what) const { if (rc != 0) throw Error(std::string(what) + " failed (" + std::to_string(rc) + "): " + lasso_last_error(ctx)); }
-  lasso_fr* alloc_fr(size_t n) const { void* p = nullptr; chk(lasso_alloc(ctx, n * sizeof(lasso_fr), &p), "lasso_alloc"); return (lasso_fr*)p; }
-  uint32_t* alloc_u32(size_t n) const { void* p = nullptr; chk(lasso_alloc(ctx, n * 4, &p), "lasso_alloc"); return (uint32_t*)p; }
-  void free(void* p) const { if (p) chk(lasso_free(ctx, p), "lasso_free"); }
+  void* alloc_bytes(size_t bytes) const {
+    if (!bytes) bytes = 1;
+    auto it = pool_.find(bytes);
+    void* p = nullptr;
+    if (it != pool_.end()) { p = it->second; pool_.erase(it); }
+    else chk(lasso_alloc(ctx, bytes, &p), "lasso_alloc");
+    live_[p] = bytes; return p;
+  }
+  lasso_fr* alloc_fr(size_t n) const { return (lasso_fr*)alloc_bytes(n * sizeof(lasso_fr)); }
+  uint32_t* alloc_u32(size_t n) const { return (uint32_t*)alloc_bytes(n * 4); }
+  // stream-ordered reuse: every kernel of this context runs on one stream, so a recycled buffer cannot be overtaken
+  void free(void* p) const { if (!p) return; auto it = live_.find(p); if (it == live_.end()) return; pool_.emplace(it->second, p); live_.erase(it); }
 };
 // owning device buffer of field elements
 struct DBuf {
@@ -374,27 +388,40 @@ class Prover {
     }
     return proof;
   }
-  // ---- SumcheckInstanceProof::prove_cubic_batched (sumcheck.rs:27-135), comb = A*B*C
-  SumcheckProof prove_cubic_batched(const Sc& claim, size_t num_rounds, std::vector<lasso_fr*>& A, std::vector<lasso_fr*>& B, lasso_fr* Cp, const ScVec& coeffs, ScVec& r_out,
+  // ---- SumcheckInstanceProof::prove_cubic_batched (sumcheck.rs:27-135), comb = A*B*C.
+  // Round j's bind (sumcheck.rs:116-120) is executed by the same kernel that evaluates round j+1, so a round is ONE launch;
+  // the eq polynomial ping-pongs between Cp and Cq (see lasso_sumcheck_cubic_round_fused).  Values and order of everything that
+  // reaches the transcript are unchanged.
+  SumcheckProof prove_cubic_batched(const Sc& claim, size_t num_rounds, std::vector<lasso_fr*>& A, std::vector<lasso_fr*>& B, lasso_fr* Cp, lasso_fr* Cq, const ScVec& coeffs, ScVec& r_out,
                                     ScVec& claims_a, ScVec& claims_b) {
     SumcheckProof proof; Sc e = claim; size_t len = (size_t)1 << num_rounds; const size_t k = A.size();
-    std::vector<lasso_fr*> all(A); all.insert(all.end(), B.begin(), B.end()); all.push_back(Cp);
+    lasso_fr* c_cur = Cp; lasso_fr* c_nxt = Cq;
+    Sc r_prev = Sc::zero();
     for (size_t j = 0; j < num_rounds; j++) {
       std::vector<lasso_fr> ev(3 * k);
-      d.chk(lasso_sumcheck_cubic_round(d.ctx, (const lasso_fr* const*)A.data(), (const lasso_fr* const*)B.data(), (uint32_t)k, Cp, len, ev.data()), "lasso_sumcheck_cubic_round");
+      if (j == 0) {
+        d.chk(lasso_sumcheck_cubic_round(d.ctx, (const lasso_fr* const*)A.data(), (const lasso_fr* const*)B.data(), (uint32_t)k, c_cur, len, ev.data()), "lasso_sumcheck_cubic_round");
+      } else {
+        lasso_fr rp = r_prev.abi();
+        d.chk(lasso_sumcheck_cubic_round_fused(d.ctx, A.data(), B.data(), (uint32_t)k, c_cur, c_nxt, len, &rp, ev.data()), "lasso_sumcheck_cubic_round_fused");
+        std::swap(c_cur, c_nxt); len /= 2;
+      }
       Sc c0 = Sc::zero(), c2 = Sc::zero(), c3 = Sc::zero();
       for (size_t i = 0; i < k; i++) { c0 += Sc::from_abi(ev[3 * i]) * coeffs[i]; c2 += Sc::from_abi(ev[3 * i + 1]) * coeffs[i]; c3 += Sc::from_abi(ev[3 * i + 2]) * coeffs[i]; }
       UniPoly poly = UniPoly::from_evals({c0, e - c0, c2, c3});
       poly.append_to_transcript(t, "poly");
       Sc r_j = t.challenge_scalar("challenge_nextround"); r_out.push_back(r_j);
-      lasso_fr rj = r_j.abi();
-      d.chk(lasso_bind_top(d.ctx, all.data(), (uint32_t)all.size(), len, &rj), "lasso_bind_top");
-      len /= 2;
+      r_prev = r_j;
       e = poly.evaluate(r_j);
       proof.compressed_polys.push_back(poly.compress());
     }
+    std::vector<lasso_fr*> ab(A); ab.insert(ab.end(), B.begin(), B.end());
+    if (num_rounds) {   // the last challenge still has to be bound (len == 2 here); the eq polynomial's final value is not used
+      lasso_fr rp = r_prev.abi();
+      d.chk(lasso_bind_top(d.ctx, ab.data(), (uint32_t)ab.size(), len, &rp), "lasso_bind_top");
+    }
     std::vector<lasso_fr> heads(2 * k);
-    d.chk(lasso_read_heads(d.ctx, (const lasso_fr* const*)all.data(), (uint32_t)(2 * k), heads.data()), "lasso_read_heads");
+    d.chk(lasso_read_heads(d.ctx, (const lasso_fr* const*)ab.data(), (uint32_t)(2 * k), heads.data()), "lasso_read_heads");
     claims_a.clear(); claims_b.clear();
     for (size_t i = 0; i < k; i++) { claims_a.push_back(Sc::from_abi(heads[i])); claims_b.push_back(Sc::from_abi(heads[k + i])); }
     return proof;
@@ -404,7 +431,7 @@ class Prover {
     Trace tr("BatchedGrandProductArgument.prove", d.ctx);
     BatchedGrandProductArgument out; const size_t k = trees.size(), num_layers = ceil_log2(n);
     ScVec claims_to_verify = roots, rand;
-    DBuf eq(d, n / 2 ? n / 2 : 1);
+    DBuf eq(d, n / 2 ? n / 2 : 1), eq2(d, n / 4 ? n / 4 : 1);
     for (size_t layer_id = num_layers; layer_id-- > 0;) {
       size_t len = n >> layer_id, off = 2 * n - 2 * len;    // layer `layer_id` has n/2^layer_id elements
       std::vector<lasso_fr> rr; for (auto& x : rand) rr.push_back(x.abi());
@@ -415,7 +442,7 @@ class Prover {
       ScVec coeff_vec = t.challenge_vector("rand_coeffs_next_layer", claims_to_verify.size());
       Sc claim = Sc::zero(); for (size_t i = 0; i < claims_to_verify.size(); i++) claim += claims_to_verify[i] * coeff_vec[i];
       LayerProofBatched lp; ScVec rand_prod;
-      lp.proof = prove_cubic_batched(claim, num_rounds_prod, A, B, eq.p, coeff_vec, rand_prod, lp.claims_prod_left, lp.claims_prod_right);
+      lp.proof = prove_cubic_batched(claim, num_rounds_prod, A, B, eq.p, eq2.p, coeff_vec, rand_prod, lp.claims_prod_left, lp.claims_prod_right);
       for (size_t i = 0; i < k; i++) { t.append_scalar("claim_prod_left", lp.claims_prod_left[i]); t.append_scalar("claim_prod_right", lp.claims_prod_right[i]); }
       Sc r_layer = t.challenge_scalar("challenge_r_layer");
       claims_to_verify.clear();

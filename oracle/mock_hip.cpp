@@ -65,6 +65,13 @@ int32_t lasso_sumcheck_cubic_round(lasso_ctx* c, const lasso_fr* const* A, const
   }
   return 0;
 }
+int32_t lasso_sumcheck_cubic_round_fused(lasso_ctx* c, lasso_fr* const* A, lasso_fr* const* B, uint32_t nc, const lasso_fr* Cin, lasso_fr* Cout, size_t n, const lasso_fr* r, lasso_fr* out) {
+  REQ(c, n >= 4 && (n & (n - 1)) == 0);
+  size_t h = n / 2;   // sumcheck.rs:116-120 then :56-93 on the bound polynomials
+  for (uint32_t k = 0; k < nc; k++) { Fr* pa = F(A[k]); Fr* pb = F(B[k]); for (size_t i = 0; i < h; i++) { pa[i] = pa[i] + *F(r) * (pa[i + h] - pa[i]); pb[i] = pb[i] + *F(r) * (pb[i + h] - pb[i]); } }
+  for (size_t i = 0; i < h; i++) F(Cout)[i] = F(Cin)[i] + *F(r) * (F(Cin)[i + h] - F(Cin)[i]);
+  return lasso_sumcheck_cubic_round(c, A, B, nc, Cout, h, out);
+}
 int32_t lasso_sumcheck_combine_round(lasso_ctx* c, const lasso_strategy* s, const lasso_fr* const* polys, const lasso_fr* eq, size_t n, uint32_t degree, lasso_fr* out) {
   REQ(c, n >= 2 && (n & (n - 1)) == 0);
   Strategy S = mk(s); size_t alpha = S.num_memories(), half = n / 2;

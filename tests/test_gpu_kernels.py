@@ -308,3 +308,26 @@ def test_bullet_lr_and_fold(devs, n, nk):
         assert np.array_equal(x, y)
     if wa is not None:
         assert compress_points(mock_lib, wa) == compress_points(mock_lib, wb)
+
+
+@pytest.mark.parametrize("n,ncirc", [(4, 1), (8, 2), (1 << 10, 2), (1 << 14, 8), (1 << 17, 3)])
+def test_sumcheck_cubic_round_fused(devs, n, ncirc):
+    """bind with r then evaluate the next round in one pass == bind_top followed by the plain round (sumcheck.rs:49-120)"""
+    rng = np.random.default_rng(n * 5 + ncirc)
+    A = [rand_fr(rng, n) for _ in range(ncirc)]
+    B = [rand_fr(rng, n) for _ in range(ncirc)]
+    Cp = rand_fr(rng, n)
+    r = rand_fr(rng, 1, edge=False)[0]
+
+    def run(d):
+        pa = [d.upload(x) for x in A]; pb = [d.upload(x) for x in B]; pc = d.upload(Cp); pc2 = d.alloc(32 * (n // 2))
+        out = d.sumcheck_cubic_round_fused(pa, pb, pc, pc2, n, r)
+        again = d.sumcheck_cubic_round(pa, pb, pc2, n // 2)          # the bound arrays must equal a separate bind
+        res = (out, again, [d.download(p, (n // 2, 4)) for p in pa + pb + [pc2]])
+        for p in pa + pb + [pc, pc2]:
+            d.free(p)
+        return res
+    a, b = both(devs, run)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[0], a[1])
+    for x, y in zip(a[2], b[2]):
+        assert np.array_equal(x, y)
