@@ -50,6 +50,24 @@ LHD fq_t fq_sub(const fq_t& a, const fq_t& b) {
 LHD fq_t fq_neg(const fq_t& a) { return fq_sub(fq_zero(), a); }
 LHD fq_t fq_dbl(const fq_t& a) { return fq_add(a, a); }
 
+#if !defined(__HIPCC__) && defined(__SIZEOF_INT128__) && !defined(LASSO_HOST_LIMBS32)   /* LASSO_HOST_LIMBS32: tests force the device form on the host */
+// Host build (g++): 4 x 64-bit schoolbook with 128-bit products, then the same 2^256 = 38 fold.
+inline fq_t fq_mul(const fq_t& a, const fq_t& b) {
+  typedef unsigned __int128 u128;
+  uint64_t x[4], y[4], t[8] = {0, 0, 0, 0, 0, 0, 0, 0}; __builtin_memcpy(x, a.v, 32); __builtin_memcpy(y, b.v, 32);
+  for (int i = 0; i < 4; i++) {
+    u128 c = 0;
+    for (int j = 0; j < 4; j++) { c += (u128)x[j] * y[i] + t[i + j]; t[i + j] = (uint64_t)c; c >>= 64; }
+    t[i + 4] = (uint64_t)c;
+  }
+  uint64_t r[4]; u128 c = 0;
+  for (int i = 0; i < 4; i++) { c += (u128)t[i + 4] * 38u + t[i]; r[i] = (uint64_t)c; c >>= 64; }
+  c *= 38u;   // c <= 38: fold, then at most one more wrap
+  for (int i = 0; i < 4; i++) { c += r[i]; r[i] = (uint64_t)c; c >>= 64; }
+  r[0] += 38u * (uint64_t)c;
+  fq_t o; __builtin_memcpy(o.v, r, 32); return o;
+}
+#else
 LHD fq_t fq_mul(const fq_t& a, const fq_t& b) {
   uint32_t t[16];
 #pragma unroll
@@ -72,6 +90,7 @@ LHD fq_t fq_mul(const fq_t& a, const fq_t& b) {
   r.v[0] += 38u * (uint32_t)c;
   return r;
 }
+#endif
 LHD fq_t fq_sqr(const fq_t& a) { return fq_mul(a, a); }
 
 // unique representative in [0, p)
@@ -99,10 +118,33 @@ LHD fq_t fq_pow(const fq_t& a, const uint32_t* e) {
   for (int i = 255; i >= 0; i--) { r = fq_sqr(r); if ((e[i / 32] >> (i % 32)) & 1) r = fq_mul(r, a); }
   return r;
 }
-LHD fq_t fq_inv(const fq_t& a) {
-  const uint32_t e[8] = {0xffffffebu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0x7fffffffu};
-  return fq_pow(a, e);
+// curve25519 inversion chain: a^(p-2), 254 squarings + 11 multiplications
+LHD fq_t fq_inv_chain(const fq_t& z) {
+  fq_t z2 = fq_sqr(z);
+  fq_t z8 = fq_sqr(fq_sqr(z2));
+  fq_t z9 = fq_mul(z8, z);
+  fq_t z11 = fq_mul(z9, z2);
+  fq_t z22 = fq_sqr(z11);
+  fq_t z_5_0 = fq_mul(z22, z9);                       // 2^5 - 1
+  fq_t t = z_5_0; for (int i = 0; i < 5; i++) t = fq_sqr(t);
+  fq_t z_10_0 = fq_mul(t, z_5_0);                     // 2^10 - 1
+  t = z_10_0; for (int i = 0; i < 10; i++) t = fq_sqr(t);
+  fq_t z_20_0 = fq_mul(t, z_10_0);
+  t = z_20_0; for (int i = 0; i < 20; i++) t = fq_sqr(t);
+  t = fq_mul(t, z_20_0);                              // 2^40 - 1
+  for (int i = 0; i < 10; i++) t = fq_sqr(t);
+  fq_t z_50_0 = fq_mul(t, z_10_0);
+  t = z_50_0; for (int i = 0; i < 50; i++) t = fq_sqr(t);
+  fq_t z_100_0 = fq_mul(t, z_50_0);
+  t = z_100_0; for (int i = 0; i < 100; i++) t = fq_sqr(t);
+  t = fq_mul(t, z_100_0);                             // 2^200 - 1
+  for (int i = 0; i < 50; i++) t = fq_sqr(t);
+  t = fq_mul(t, z_50_0);                              // 2^250 - 1
+  for (int i = 0; i < 5; i++) t = fq_sqr(t);
+  return fq_mul(t, z11);                              // 2^255 - 21
 }
+
+LHD fq_t fq_inv(const fq_t& a) { return fq_inv_chain(a); }   // inverse(0) = 0
 // ABI conversions (ark-ff Montgomery, R = 2^256 = 38 mod p)
 LHD fq_t fq_from_mont(const fq_t& m) { return fq_mul(m, fq_inv38()); }
 LHD fq_t fq_to_mont(const fq_t& a) {  // canonical Montgomery limbs, as ark-ff stores them

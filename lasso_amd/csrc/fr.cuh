@@ -83,7 +83,33 @@ LHD fr_t fr_sub(const fr_t& a, const fr_t& b) {
 LHD fr_t fr_neg(const fr_t& a) { return fr_sub(fr_zero(), a); }
 LHD fr_t fr_dbl(const fr_t& a) { return fr_add(a, a); }
 
-// Montgomery product a*b*R^-1 mod p, CIOS over 32-bit limbs.
+// Montgomery product a*b*R^-1 mod p.
+#if !defined(__HIPCC__) && defined(__SIZEOF_INT128__) && !defined(LASSO_HOST_LIMBS32)   /* LASSO_HOST_LIMBS32: tests force the device form on the host */
+// Host build (g++, the O(log n) tails of the prover): CIOS over 64-bit limbs with 128-bit products — same function, ~6x faster on x86-64
+// than the 32-bit form.  fr_t's bytes are the 4 x u64 little-endian limbs on a little-endian host.
+inline fr_t fr_mul(const fr_t& a, const fr_t& b) {
+  typedef unsigned __int128 u128;
+  const uint64_t P0 = 0x5812631a5cf5d3edull, P1 = 0x14def9dea2f79cd6ull, P3 = 0x1000000000000000ull, INV = 0xd2b51da312547e1bull;  // -p^-1 mod 2^64
+  uint64_t x[4], y[4]; __builtin_memcpy(x, a.v, 32); __builtin_memcpy(y, b.v, 32);
+  uint64_t t[6] = {0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < 4; i++) {
+    u128 c = 0;
+    for (int j = 0; j < 4; j++) { c += (u128)x[j] * y[i] + t[j]; t[j] = (uint64_t)c; c >>= 64; }
+    c += t[4]; t[4] = (uint64_t)c; t[5] = (uint64_t)(c >> 64);
+    const uint64_t m = t[0] * INV;
+    c = (u128)m * P0 + t[0]; c >>= 64;
+    c += (u128)m * P1 + t[1]; t[0] = (uint64_t)c; c >>= 64;
+    c += t[2]; t[1] = (uint64_t)c; c >>= 64;
+    c += (u128)m * P3 + t[3]; t[2] = (uint64_t)c; c >>= 64;
+    c += t[4]; t[3] = (uint64_t)c; c >>= 64;
+    t[4] = t[5] + (uint64_t)c;
+  }
+  fr_t r; __builtin_memcpy(r.v, t, 32);
+  fr_cond_sub_p(r.v);
+  return r;
+}
+#else
+// CIOS over 32-bit limbs (device form; also the host form inside hipcc translation units).
 LHD fr_t fr_mul(const fr_t& a, const fr_t& b) {
   uint32_t t[10];
 #pragma unroll
@@ -114,6 +140,7 @@ LHD fr_t fr_mul(const fr_t& a, const fr_t& b) {
   fr_cond_sub_p(r.v);
   return r;
 }
+#endif
 LHD fr_t fr_sqr(const fr_t& a) { return fr_mul(a, a); }
 
 // small integer -> Montgomery form (dense_mlpoly.rs:263-269 `F::from(Z[i] as u64)`)

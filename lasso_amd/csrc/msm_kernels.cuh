@@ -22,32 +22,6 @@
 #define MSM_BATCH 4096
 #define MSM_WINDOWS 64   // 4-bit windows over 256-bit scalars
 
-// curve25519 inversion chain: a^(p-2), 254 squarings + 11 multiplications
-LHD fq_t fq_inv_chain(const fq_t& z) {
-  fq_t z2 = fq_sqr(z);
-  fq_t z8 = fq_sqr(fq_sqr(z2));
-  fq_t z9 = fq_mul(z8, z);
-  fq_t z11 = fq_mul(z9, z2);
-  fq_t z22 = fq_sqr(z11);
-  fq_t z_5_0 = fq_mul(z22, z9);                       // 2^5 - 1
-  fq_t t = z_5_0; for (int i = 0; i < 5; i++) t = fq_sqr(t);
-  fq_t z_10_0 = fq_mul(t, z_5_0);                     // 2^10 - 1
-  t = z_10_0; for (int i = 0; i < 10; i++) t = fq_sqr(t);
-  fq_t z_20_0 = fq_mul(t, z_10_0);
-  t = z_20_0; for (int i = 0; i < 20; i++) t = fq_sqr(t);
-  t = fq_mul(t, z_20_0);                              // 2^40 - 1
-  for (int i = 0; i < 10; i++) t = fq_sqr(t);
-  fq_t z_50_0 = fq_mul(t, z_10_0);
-  t = z_50_0; for (int i = 0; i < 50; i++) t = fq_sqr(t);
-  fq_t z_100_0 = fq_mul(t, z_50_0);
-  t = z_100_0; for (int i = 0; i < 100; i++) t = fq_sqr(t);
-  t = fq_mul(t, z_100_0);                             // 2^200 - 1
-  for (int i = 0; i < 50; i++) t = fq_sqr(t);
-  t = fq_mul(t, z_50_0);                              // 2^250 - 1
-  for (int i = 0; i < 5; i++) t = fq_sqr(t);
-  return fq_mul(t, z11);                              // 2^255 - 21
-}
-
 // table[w*n + j] = Niels(2^(4w) * G_j) in 29-bit-limb form (fe29.cuh).  One thread per generator; built once per gens object
 // with the 8x32 arithmetic (needs an inversion per entry), then converted.  `aff` = ark Affine {x,y} Montgomery limbs.
 __global__ void k_precompute_table(const fq_t* __restrict__ aff, size_t n, niels29* __restrict__ table) {

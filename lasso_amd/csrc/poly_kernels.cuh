@@ -85,7 +85,8 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_round(PtrTable A, PtrTabl
 // Block `bx` of row `y` has written its K partial sums (thread 0).  The last block to arrive for that row sums all nx partials
 // and writes out[y*K + k].  Hand-off follows cdna_hip_programming.md §6 G16: plain stores -> agent-scope release -> drained
 // vmcnt -> relaxed agent atomic ticket; the last arriver does ONE agent-scope acquire, then the workgroup reads plain.
-__device__ __forceinline__ void last_block_reduce(const fr_t* partials, uint32_t nx, uint32_t K, uint32_t y, uint32_t* counters, fr_t* __restrict__ out, fr_t* smem) {
+__device__ __forceinline__ void last_block_reduce(const fr_t* partials, uint32_t nx, uint32_t K, uint32_t y, uint32_t nrows, uint32_t* counters, fr_t* __restrict__ out, fr_t* smem,
+                                                  uint32_t* flag, uint32_t seq) {
   __shared__ uint32_t is_last;
   if (threadIdx.x == 0) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -103,6 +104,13 @@ __device__ __forceinline__ void last_block_reduce(const fr_t* partials, uint32_t
     acc = block_reduce_fr(acc, smem);
     if (threadIdx.x == 0) out[(size_t)y * K + k] = acc;
   }
+  // `out` is host-mapped memory.  The row that finishes last raises the host's sequence flag: every row's stores are released at
+  // system scope before its ticket, so the flag store (system-scope release) is ordered after all of them.
+  if (threadIdx.x == 0 && flag) {
+    __threadfence_system();
+    uint32_t t2 = __hip_atomic_fetch_add(&counters[LASSO_MAX_PTRS], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (t2 == nrows - 1) { counters[LASSO_MAX_PTRS] = 0; __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+  }
 }
 
 // K4 fused with K1: bind every polynomial of the round with r (length n = 4q -> 2q), then evaluate the NEXT round on the bound
@@ -110,7 +118,7 @@ __device__ __forceinline__ void last_block_reduce(const fr_t* partials, uint32_t
 // A, B are bound in place (each element is owned by exactly one thread); the shared eq polynomial C is read from C_in and written
 // to C_out by the row-0 workgroups only, because every circuit row re-reads it.
 __global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_fused(MutPtrTable A, MutPtrTable B, const fr_t* __restrict__ C_in, fr_t* __restrict__ C_out, size_t q, fr_t r,
-                                                              fr_t* __restrict__ partials, uint32_t* counters, fr_t* __restrict__ out) {
+                                                              fr_t* __restrict__ partials, uint32_t* counters, fr_t* __restrict__ out, uint32_t* flag, uint32_t seq) {
   __shared__ fr_t smem[4];
   fr_t* __restrict__ a = A.p[blockIdx.y];
   fr_t* __restrict__ b = B.p[blockIdx.y];
@@ -134,11 +142,11 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_fused(MutPtrTable A, MutP
   }
   e0 = block_reduce_fr(e0, smem); e2 = block_reduce_fr(e2, smem); e3 = block_reduce_fr(e3, smem);
   if (threadIdx.x == 0) { fr_t* o = partials + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 3; o[0] = e0; o[1] = e2; o[2] = e3; }
-  last_block_reduce(partials, gridDim.x, 3, blockIdx.y, counters, out, smem);
+  last_block_reduce(partials, gridDim.x, 3, blockIdx.y, gridDim.y, counters, out, smem, flag, seq);
 }
 // first round of a layer: evaluation only, with the in-launch second stage
 __global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_round_lb(PtrTable A, PtrTable B, const fr_t* __restrict__ C, size_t half, fr_t* __restrict__ partials, uint32_t* counters,
-                                                                 fr_t* __restrict__ out) {
+                                                                 fr_t* __restrict__ out, uint32_t* flag, uint32_t seq) {
   __shared__ fr_t smem[4];
   const fr_t* __restrict__ a = A.p[blockIdx.y];
   const fr_t* __restrict__ b = B.p[blockIdx.y];
@@ -154,7 +162,7 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_round_lb(PtrTable A, PtrT
   }
   e0 = block_reduce_fr(e0, smem); e2 = block_reduce_fr(e2, smem); e3 = block_reduce_fr(e3, smem);
   if (threadIdx.x == 0) { fr_t* o = partials + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 3; o[0] = e0; o[1] = e2; o[2] = e3; }
-  last_block_reduce(partials, gridDim.x, 3, blockIdx.y, counters, out, smem);
+  last_block_reduce(partials, gridDim.x, 3, blockIdx.y, gridDim.y, counters, out, smem, flag, seq);
 }
 
 // ------------------------------------------------------------------ g = S::combine_lookups (subtables/*.rs)

@@ -1,0 +1,24 @@
+"""The product's __host__ __device__ arithmetic headers (lasso_amd/csrc/fr.cuh, fq.cuh, fe29.cuh) checked on the CPU against the
+oracle's independent 64-bit arithmetic (tests/cpp/*.cpp).  Both host forms are covered: the 64-bit-limb form g++ builds for the
+host prover, and (-DLASSO_HOST_LIMBS32) the 32-bit-limb form the device executes."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("name", ["test_arith_host", "test_fe29_host", "test_fr29_host"])
+@pytest.mark.parametrize("flags", [[], ["-DLASSO_HOST_LIMBS32"]], ids=["limbs64", "limbs32"])
+def test_cpp_arith(name, flags):
+    src = os.path.join(ROOT, "tests", "cpp", name + ".cpp")
+    if not os.path.exists(src):
+        pytest.skip(f"{name}.cpp not present")
+    out_dir = os.path.join(ROOT, "tests", "_build")
+    os.makedirs(out_dir, exist_ok=True)
+    exe = os.path.join(out_dir, name + ("_32" if flags else "_64"))
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wno-unknown-pragmas", *flags, "-o", exe, src])
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    assert "OK" in res.stdout
