@@ -140,6 +140,16 @@ int32_t lasso_inner_products_lr(lasso_ctx* ctx, const lasso_fr* d_a, const lasso
 /* bullet.rs:84-118: out[0] = L = <a_L, G_R> + c_L*Q + blind_L*H, out[1] = R = <a_R, G_L> + c_R*Q + blind_R*H, where G is the
  * current (virtually folded) generator vector, `bases` holds [G_0..G_{n-1}, Q, H] and tail = {c_L, blind_L, c_R, blind_R}. */
 int32_t lasso_bullet_lr(lasso_ctx* ctx, const lasso_bases* bases, size_t n, const lasso_fr* d_a, size_t nk, const lasso_fr* d_w, const lasso_fr* tail, lasso_point* out);
+/* One whole round of BulletReductionProof::prove (bullet.rs:66-132) in a single call — the form the host prover uses.
+ * If u != NULL the previous round's fold is applied on the way in: (d_a_in, d_b_in) of length 2*nk and the n/(2*nk) weights d_w_in are
+ * read, (d_a_out, d_b_out) of length nk and the n/nk weights d_w_out are written (ping-pong buffers, must not alias the inputs):
+ *   a'[i] = a_L[i]*u + u_inv*a_R[i], b'[i] = b_L[i]*u_inv + u*b_R[i], w'[2k] = w[k]*u_inv, w'[2k+1] = w[k]*u   (:127-132).
+ * If u == NULL the inputs (length nk, n/nk weights) are the state itself and the *_out pointers are ignored.
+ * Then, for the state of length nk: c_L = <a_L, b_R>, c_R = <a_R, b_L> (:79-80) stay on the device and
+ *   out[0] = L = <a_L, G_R> + c_L*Q + blinds[0]*H,  out[1] = R = <a_R, G_L> + c_R*Q + blinds[1]*H   (:84-118)
+ * with G the virtually folded generators as in lasso_bullet_lr. */
+int32_t lasso_bullet_round(lasso_ctx* ctx, const lasso_bases* bases, size_t n, const lasso_fr* d_a_in, const lasso_fr* d_b_in, const lasso_fr* d_w_in,
+                           lasso_fr* d_a_out, lasso_fr* d_b_out, lasso_fr* d_w_out, size_t nk, const lasso_fr* u, const lasso_fr* u_inv, const lasso_fr* blinds, lasso_point* out);
 /* bullet.rs:127-132: a[i] <- a_L[i]*u + u_inv*a_R[i], b[i] <- b_L[i]*u_inv + u*b_R[i] for i < nk/2 (in place), and the
  * generator fold G[i] <- G_L[i]*u_inv + G_R[i]*u recorded as weights: d_w_out[2*blk] = d_w[blk]*u_inv, d_w_out[2*blk+1] = d_w[blk]*u. */
 int32_t lasso_bullet_fold(lasso_ctx* ctx, lasso_fr* d_a, lasso_fr* d_b, size_t nk, const lasso_fr* d_w, size_t nw, lasso_fr* d_w_out, const lasso_fr* u, const lasso_fr* u_inv);

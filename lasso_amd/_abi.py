@@ -55,6 +55,7 @@ def declare(lib):
         "lasso_msm_dev": (i32, [vp, vp, vp, sz, vp]),
         "lasso_inner_products_lr": (i32, [vp, vp, vp, sz, vp]),
         "lasso_bullet_lr": (i32, [vp, vp, sz, vp, sz, vp, vp, vp]),
+        "lasso_bullet_round": (i32, [vp, vp, sz, vp, vp, vp, vp, vp, vp, sz, vp, vp, vp, vp]),
         "lasso_bullet_fold": (i32, [vp, vp, vp, sz, vp, sz, vp, vp, vp]),
     }
     for name, (res, args) in sig.items():

@@ -381,24 +381,32 @@ int32_t lasso_bases_create(lasso_ctx* c, const lasso_affine* points, size_t n, l
 }
 void lasso_bases_destroy(lasso_ctx* c, lasso_bases* b) { if (!b) return; if (c) (void)hipStreamSynchronize(c->stream); if (b->d_table) (void)hipFree(b->d_table); delete b; }
 
-// chunks per row: aim for >= 1024 workgroups but keep >= ~16 pairs per bucket
+// chunks per row: aim for >= 1024 workgroups but keep >= 4096 (digit, base) pairs per chunk.  Measured on MI355X (profiles/): the
+// kernel is VALU-issue-bound even at one wave per SIMD (the 81 independent multiply-adds of a field product pipeline back to back), so
+// smaller chunks only multiply the fixed per-workgroup reduction tree: 2 x 482 chunks of 1024 pairs ran 310 us, 2 x 129 of 4096 ran 180 us.
 static size_t msm_chunks(size_t rows, size_t n_cols, uint32_t W) {
   size_t pairs = n_cols * W, K = 1;
   if (rows < 1024) { K = (1024 + rows - 1) / rows; size_t kmax = (pairs + 4095) / 4096; if (kmax < 1) kmax = 1; if (K > kmax) K = kmax; if (K > 256) K = 256; }
   size_t cols_per_chunk = (n_cols + K - 1) / K;
   return (n_cols + cols_per_chunk - 1) / cols_per_chunk;
 }
-// shared tail: bucket kernel over `rows` rows of `n_cols` scalars, then per-row sum of the chunk partials, then D2H
+#define MSM_SMALL_ROWS 16   // results of up to this many rows return through the mapped buffer + flag (no memcpy, no stream sync)
+// shared tail: bucket kernel over `rows` rows of `n_cols` scalars, then per-row sum of the chunk partials, then hand the points to the host
 static int32_t run_msm(lasso_ctx* c, const uint8_t* d_scal, uint32_t bps, uint32_t W, size_t row_stride, size_t rows, size_t n_cols, const lasso_bases* b, uint8_t* scratch_after, lasso_point* out) {
   const size_t K = msm_chunks(rows, n_cols, W);
   const size_t cols_per_chunk = (n_cols + K - 1) / K;
-  pt29* d_partial = (pt29*)scratch_after; ed_point* d_final = (ed_point*)(((uintptr_t)(d_partial + rows * K) + 15) & ~(uintptr_t)15);
+  pt29* d_partial = (pt29*)scratch_after;
+  const bool small = rows <= MSM_SMALL_ROWS;
+  ed_point* d_final = small ? (ed_point*)c->d_small : (ed_point*)(((uintptr_t)(d_partial + rows * K) + 15) & ~(uintptr_t)15);
+  const uint32_t seq = small ? ++c->seq : 0;
   {
     ProfScope ps(c, LASSO_K_MSM, (double)rows * n_cols * bps);
     hipLaunchKernelGGL(k_msm_buckets, dim3((unsigned)K, (unsigned)rows), dim3(MSM_THREADS), 0, c->stream, d_scal, bps, W, row_stride, n_cols, cols_per_chunk, (const niels29*)b->d_table, b->n, d_partial);
-    hipLaunchKernelGGL(k_points_sum, dim3((unsigned)rows), dim3(MSM_THREADS), 0, c->stream, (const pt29*)d_partial, (uint32_t)K, d_final);
+    hipLaunchKernelGGL(k_points_sum, dim3((unsigned)rows), dim3(MSM_THREADS), 0, c->stream, (const pt29*)d_partial, (uint32_t)K, d_final, c->d_counters + LASSO_MAX_PTRS + 1,
+                       small ? c->d_flag : (uint32_t*)nullptr, seq);
   }
   HIPCHK(c, hipGetLastError());
+  if (small) return wait_flag(c, seq, rows * (sizeof(ed_point) / sizeof(fr_t)), (lasso_fr*)out);
   HIPCHK(c, hipMemcpyAsync(out, d_final, rows * sizeof(ed_point), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return 0;
@@ -460,6 +468,27 @@ int32_t lasso_bullet_lr(lasso_ctx* c, const lasso_bases* b, size_t n, const lass
   fr_t* SL = (fr_t*)c->d_scratch; fr_t* SR = SL + row;
   hipLaunchKernelGGL(k_bullet_expand, dim3(grid_for(n)), dim3(256), 0, c->stream, (const fr_t*)d_a, nk, (const fr_t*)d_w, n, to_fr(tail), to_fr(tail + 1), to_fr(tail + 2), to_fr(tail + 3), SL, SR);
   return run_msm(c, (const uint8_t*)SL, 32, MSM_WINDOWS, row * 32, 2, row, b, (uint8_t*)(SR + row), out);
+}
+int32_t lasso_bullet_round(lasso_ctx* c, const lasso_bases* b, size_t n, const lasso_fr* d_a_in, const lasso_fr* d_b_in, const lasso_fr* d_w_in, lasso_fr* d_a_out, lasso_fr* d_b_out,
+                           lasso_fr* d_w_out, size_t nk, const lasso_fr* u, const lasso_fr* u_inv, const lasso_fr* blinds, lasso_point* out) {
+  REQUIRE(c, b && d_a_in && d_b_in && d_w_in && blinds && out && n >= 2 && (n & (n - 1)) == 0 && nk >= 2 && nk <= n && (nk & (nk - 1)) == 0 && n + 2 <= b->n);
+  const bool fold = u != nullptr;
+  if (fold) REQUIRE(c, u_inv && d_a_out && d_b_out && d_w_out && 2 * nk <= n && d_a_out != d_a_in && d_b_out != d_b_in && d_w_out != d_w_in);
+  const size_t row = n + 2;
+  const unsigned nx = grid_for(n / 2, 64);
+  const size_t K = msm_chunks(2, row, MSM_WINDOWS);
+  int32_t rc = ensure_scratch(c, 2 * row * 32 + (size_t)nx * 2 * sizeof(fr_t) + (2 * K + 4) * sizeof(pt29) + 512); if (rc) return rc;
+  fr_t* SL = (fr_t*)c->d_scratch; fr_t* SR = SL + row; fr_t* partials = SR + row;
+  {
+    ProfScope ps(c, LASSO_K_MISC, 64.0 * row + (fold ? 96.0 * 2 * nk : 64.0 * nk));
+    const fr_t z = fr_zero();
+    if (fold) hipLaunchKernelGGL((k_bullet_step<true>), dim3(nx), dim3(256), 0, c->stream, (const fr_t*)d_a_in, (const fr_t*)d_b_in, (const fr_t*)d_w_in, (fr_t*)d_a_out, (fr_t*)d_b_out, (fr_t*)d_w_out, nk, n,
+                                 to_fr(u), to_fr(u_inv), to_fr(blinds), to_fr(blinds + 1), SL, SR, partials, c->d_counters + LASSO_MAX_PTRS + 2);
+    else hipLaunchKernelGGL((k_bullet_step<false>), dim3(nx), dim3(256), 0, c->stream, (const fr_t*)d_a_in, (const fr_t*)d_b_in, (const fr_t*)d_w_in, (fr_t*)nullptr, (fr_t*)nullptr, (fr_t*)nullptr, nk, n,
+                            z, z, to_fr(blinds), to_fr(blinds + 1), SL, SR, partials, c->d_counters + LASSO_MAX_PTRS + 2);
+  }
+  HIPCHK(c, hipGetLastError());
+  return run_msm(c, (const uint8_t*)SL, 32, MSM_WINDOWS, row * 32, 2, row, b, (uint8_t*)(partials + (size_t)nx * 2), out);
 }
 int32_t lasso_bullet_fold(lasso_ctx* c, lasso_fr* d_a, lasso_fr* d_b, size_t nk, const lasso_fr* d_w, size_t nw, lasso_fr* d_w_out, const lasso_fr* u, const lasso_fr* u_inv) {
   REQUIRE(c, d_a && d_b && d_w && d_w_out && u && u_inv && nk >= 2 && (nk & (nk - 1)) == 0 && nw >= 1 && d_w != d_w_out);

@@ -17,9 +17,10 @@
 #include <hip/hip_runtime.h>
 #include "fq.cuh"
 #include "fe29.cuh"
+#include "poly_kernels.cuh"   // block_reduce_fr
 
 #define MSM_THREADS 256
-#define MSM_BATCH 4096
+#define MSM_BATCH 8192   // (bin, index) pairs sorted per pass: 32 KB of the 36 KB LDS buffer the reduction tree reuses
 #define MSM_WINDOWS 64   // 4-bit windows over 256-bit scalars
 
 // table[w*n + j] = Niels(2^(4w) * G_j) in 29-bit-limb form (fe29.cuh).  One thread per generator; built once per gens object
@@ -109,15 +110,27 @@ __global__ void __launch_bounds__(MSM_THREADS) k_msm_buckets(const uint8_t* __re
   if (t == 0) out[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = pts[0];
 }
 
-// out[row] = sum_k partial[row*K + k], converted to ark's Montgomery limbs.  One workgroup per row, K <= 256.
-__global__ void __launch_bounds__(MSM_THREADS) k_points_sum(const pt29* __restrict__ partial, uint32_t K, ed_point* __restrict__ out_mont) {
+// out[row] = sum_k partial[row*K + k], converted to ark's Montgomery limbs.  One workgroup per row; thread t first adds partials
+// t, t+256, ... serially, then an LDS tree.  `out_mont` may be host-mapped memory: when `flag` is set, the row that finishes last
+// raises the host's sequence flag (same hand-off as last_block_reduce in poly_kernels.cuh).
+__global__ void __launch_bounds__(MSM_THREADS) k_points_sum(const pt29* __restrict__ partial, uint32_t K, ed_point* __restrict__ out_mont, uint32_t* counters, uint32_t* flag, uint32_t seq) {
   __shared__ pt29 pts[MSM_THREADS];
   const fe29 d2 = fe_d2();
   const uint32_t t = threadIdx.x;
-  pts[t] = t < K ? partial[(size_t)blockIdx.x * K + t] : pt_identity();
+  pt29 acc = t < K ? partial[(size_t)blockIdx.x * K + t] : pt_identity();
+  for (uint32_t k = t + MSM_THREADS; k < K; k += MSM_THREADS) acc = pt_add(acc, partial[(size_t)blockIdx.x * K + k], d2);
+  pts[t] = acc;
   __syncthreads();
-  for (uint32_t s = MSM_THREADS / 2; s > 0; s >>= 1) { if (t < s && t + s < K) pts[t] = pt_add(pts[t], pts[t + s], d2); __syncthreads(); }
-  if (t == 0) { ed_point p = pt_to_ed(pts[0]), o; o.X = fq_to_mont(p.X); o.Y = fq_to_mont(p.Y); o.T = fq_to_mont(p.T); o.Z = fq_to_mont(p.Z); out_mont[blockIdx.x] = o; }
+  const uint32_t live = K < MSM_THREADS ? K : MSM_THREADS;
+  for (uint32_t s = MSM_THREADS / 2; s > 0; s >>= 1) { if (t < s && t + s < live) pts[t] = pt_add(pts[t], pts[t + s], d2); __syncthreads(); }
+  if (t == 0) {
+    ed_point p = pt_to_ed(pts[0]), o; o.X = fq_to_mont(p.X); o.Y = fq_to_mont(p.Y); o.T = fq_to_mont(p.T); o.Z = fq_to_mont(p.Z); out_mont[blockIdx.x] = o;
+    if (flag) {
+      __threadfence_system();
+      uint32_t t2 = __hip_atomic_fetch_add(counters, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      if (t2 == gridDim.x - 1) { *counters = 0; __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+    }
+  }
 }
 
 // ------------------------------------------------------------------ Hyrax opening tail (bullet.rs:40-154), vectors resident on the device
@@ -143,4 +156,58 @@ __global__ void __launch_bounds__(256) k_bullet_fold(fr_t* __restrict__ a, fr_t*
     b[i] = fr_add(fr_mul(bl, u_inv), fr_mul(u, br));
   }
   for (size_t k = tid; k < nw; k += stride) { fr_t x = w[k]; w_out[2 * k] = fr_mul(x, u_inv); w_out[2 * k + 1] = fr_mul(x, u); }
+}
+
+// ------------------------------------------------------------------ one bullet round in one pass (bullet.rs:66-132)
+// FOLD: apply the previous challenge first (a' = a_L*u + u_inv*a_R, b' = b_L*u_inv + u*b_R, w'[2k] = w[k]*u_inv, w'[2k+1] = w[k]*u), reading the
+// ping-pong inputs of length 2*nk and writing the outputs of length nk; then, on the state of length nk: c_L = <a_L, b_R>, c_R = <a_R, b_L>
+// (last-block reduction) and the canonical scalar rows SL, SR (n + 2 entries each) of the two MSMs over the ORIGINAL generators.
+// One thread per (i < nk/2, blk < n/nk): n/2 threads whatever the round, so late rounds are as parallel as early ones.
+template <bool FOLD>
+__global__ void __launch_bounds__(256) k_bullet_step(const fr_t* __restrict__ a_in, const fr_t* __restrict__ b_in, const fr_t* __restrict__ w_in, fr_t* __restrict__ a_out, fr_t* __restrict__ b_out,
+                                                      fr_t* __restrict__ w_out, size_t nk, size_t n, fr_t u, fr_t u_inv, fr_t blind_l, fr_t blind_r, fr_t* __restrict__ SL, fr_t* __restrict__ SR,
+                                                      fr_t* __restrict__ partials, uint32_t* counters) {
+  __shared__ fr_t smem[4];
+  __shared__ uint32_t is_last;
+  const size_t half = nk / 2, total = n / 2;
+  fr_t cl = fr_zero(), cr = fr_zero();
+  for (size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+    const size_t i = g % half, blk = g / half;
+    fr_t a0, a1, wv;
+    if (FOLD) {
+      a0 = fr_add(fr_mul(a_in[i], u), fr_mul(u_inv, a_in[i + nk]));
+      a1 = fr_add(fr_mul(a_in[i + half], u), fr_mul(u_inv, a_in[i + half + nk]));
+      wv = fr_mul(w_in[blk >> 1], (blk & 1) ? u : u_inv);
+      if (i == 0) w_out[blk] = wv;
+    } else { a0 = a_in[i]; a1 = a_in[i + half]; wv = w_in[blk]; }
+    if (blk == 0) {
+      fr_t b0, b1;
+      if (FOLD) {
+        b0 = fr_add(fr_mul(b_in[i], u_inv), fr_mul(u, b_in[i + nk]));
+        b1 = fr_add(fr_mul(b_in[i + half], u_inv), fr_mul(u, b_in[i + half + nk]));
+        a_out[i] = a0; a_out[i + half] = a1; b_out[i] = b0; b_out[i + half] = b1;
+      } else { b0 = b_in[i]; b1 = b_in[i + half]; }
+      cl = fr_add(cl, fr_mul(a0, b1));
+      cr = fr_add(cr, fr_mul(a1, b0));
+    }
+    const size_t base = blk * nk + i;
+    SL[base] = fr_zero(); SL[base + half] = fr_to_canonical(fr_mul(wv, a0));
+    SR[base] = fr_to_canonical(fr_mul(wv, a1)); SR[base + half] = fr_zero();
+  }
+  cl = block_reduce_fr(cl, smem); cr = block_reduce_fr(cr, smem);
+  if (threadIdx.x == 0) {
+    partials[2 * (size_t)blockIdx.x] = cl; partials[2 * (size_t)blockIdx.x + 1] = cr;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    uint32_t ticket = __hip_atomic_fetch_add(counters, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t last = (ticket == gridDim.x - 1) ? 1u : 0u;
+    if (last) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); *counters = 0; }
+    is_last = last;
+  }
+  __syncthreads();
+  if (!is_last) return;
+  fr_t sl = fr_zero(), sr = fr_zero();
+  for (uint32_t x = threadIdx.x; x < gridDim.x; x += blockDim.x) { sl = fr_add(sl, partials[2 * (size_t)x]); sr = fr_add(sr, partials[2 * (size_t)x + 1]); }
+  sl = block_reduce_fr(sl, smem); sr = block_reduce_fr(sr, smem);
+  if (threadIdx.x == 0) { SL[n] = fr_to_canonical(sl); SL[n + 1] = fr_to_canonical(blind_l); SR[n] = fr_to_canonical(sr); SR[n + 1] = fr_to_canonical(blind_r); }
 }

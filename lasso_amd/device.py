@@ -182,6 +182,18 @@ class Device:
         self._chk(self.lib.lasso_bullet_lr(self.ctx, C.c_void_p(bases), n, C.c_void_p(d_a), nk, C.c_void_p(d_w), _vp(tail), _vp(out)))
         return out
 
+    def bullet_round(self, bases, n, d_a_in, d_b_in, d_w_in, d_a_out, d_b_out, d_w_out, nk, u, u_inv, blinds):
+        blinds = np.ascontiguousarray(blinds, dtype=np.uint64).reshape(2, 4)
+        out = np.empty((2, 16), dtype=np.uint64)
+        if u is None:
+            pu = pui = None
+        else:
+            u = np.ascontiguousarray(u, dtype=np.uint64); ui = np.ascontiguousarray(u_inv, dtype=np.uint64)
+            pu, pui = _vp(u), _vp(ui)
+        self._chk(self.lib.lasso_bullet_round(self.ctx, C.c_void_p(bases), n, C.c_void_p(d_a_in), C.c_void_p(d_b_in), C.c_void_p(d_w_in), C.c_void_p(d_a_out), C.c_void_p(d_b_out),
+                                              C.c_void_p(d_w_out), nk, pu, pui, _vp(blinds), _vp(out)))
+        return out
+
     def bullet_fold(self, d_a, d_b, nk, d_w, nw, d_w_out, u, u_inv):
         u = np.ascontiguousarray(u, dtype=np.uint64); ui = np.ascontiguousarray(u_inv, dtype=np.uint64)
         self._chk(self.lib.lasso_bullet_fold(self.ctx, C.c_void_p(d_a), C.c_void_p(d_b), nk, C.c_void_p(d_w), nw, C.c_void_p(d_w_out), _vp(u), _vp(ui)))

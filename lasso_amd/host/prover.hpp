@@ -469,33 +469,43 @@ class Prover {
     Sc dd = tape.random_scalar("d"), r_delta = tape.random_scalar("r_delta"), r_beta = tape.random_scalar("r_delta");   // sic: dot_product.rs:189
     ScVec v1 = tape.random_vector("blinds_vec_1", 2 * lg_n), v2 = tape.random_vector("blinds_vec_2", 2 * lg_n);
     DotProductProofLog P; uint8_t buf[32];
-    // a, b and the generator-fold weights live on the device for the whole reduction
-    DBuf d_a(d, n), d_b(d, n), d_w0(d, n), d_w1(d, n);
-    d.chk(lasso_upload(d.ctx, d_a.p, x_vec.data(), n * sizeof(lasso_fr)), "lasso_upload");
-    d.chk(lasso_upload(d.ctx, d_b.p, a_vec.data(), n * sizeof(lasso_fr)), "lasso_upload");
+    // a, b and the generator-fold weights live on the device for the whole reduction, in ping-pong pairs: round k's fold (bullet.rs:127-132)
+    // is applied by the same call that computes round k+1's c_L, c_R, L, R (lasso_bullet_round) — one host round trip per round.
+    DBuf d_a0(d, n), d_b0(d, n), d_a1(d, n / 2 ? n / 2 : 1), d_b1(d, n / 2 ? n / 2 : 1), d_w0(d, n), d_w1(d, n);
+    d.chk(lasso_upload(d.ctx, d_a0.p, x_vec.data(), n * sizeof(lasso_fr)), "lasso_upload");
+    d.chk(lasso_upload(d.ctx, d_b0.p, a_vec.data(), n * sizeof(lasso_fr)), "lasso_upload");
     { Sc one = Sc::one(); d.chk(lasso_upload(d.ctx, d_w0.p, &one, sizeof(lasso_fr)), "lasso_upload"); }
-    compress_one(msm_dev(g, d_a.p, n), buf); t.append_point_bytes("Cx", buf);   // Cx = <x, G> + 0*h   (commitments.rs:84-93)
+    compress_one(msm_dev(g, d_a0.p, n), buf); t.append_point_bytes("Cx", buf);  // Cx = <x, G> + 0*h   (commitments.rs:84-93)
     compress_one(g.Q * y, buf); t.append_point_bytes("Cy", buf);                // Cy = y*G_1[0] + 0*h (commitments.rs:78-82)
     t.append_scalars("a", a_vec);
     // bullet reduction (bullet.rs:40-154), blind = blind_x + blind_y = 0
-    lasso_fr* w_cur = d_w0.p; lasso_fr* w_nxt = d_w1.p;
+    lasso_fr *a_cur = d_a0.p, *a_nxt = d_a1.p, *b_cur = d_b0.p, *b_nxt = d_b1.p, *w_cur = d_w0.p, *w_nxt = d_w1.p;
     Sc blind_fin = Sc::zero(); size_t nk = n, nw = 1, round = 0;
+    bool have_u = false; lasso_fr ua, uia;
     while (nk != 1) {
-      lasso_fr cc[2]; d.chk(lasso_inner_products_lr(d.ctx, d_a.p, d_b.p, nk, cc), "lasso_inner_products_lr");
       const Sc& blind_L = v1[round]; const Sc& blind_R = v2[round];
-      lasso_fr tail[4] = {cc[0], blind_L.abi(), cc[1], blind_R.abi()};
-      lasso_point LR[2]; d.chk(lasso_bullet_lr(d.ctx, g.bases, n, d_a.p, nk, w_cur, tail, LR), "lasso_bullet_lr");
+      lasso_fr blinds[2] = {blind_L.abi(), blind_R.abi()};
+      lasso_point LR[2];
+      if (have_u) {   // fold with the previous challenge (length 2nk -> nk), then this round's L, R
+        d.chk(lasso_bullet_round(d.ctx, g.bases, n, a_cur, b_cur, w_cur, a_nxt, b_nxt, w_nxt, nk, &ua, &uia, blinds, LR), "lasso_bullet_round");
+        std::swap(a_cur, a_nxt); std::swap(b_cur, b_nxt); std::swap(w_cur, w_nxt);
+      } else {
+        d.chk(lasso_bullet_round(d.ctx, g.bases, n, a_cur, b_cur, w_cur, nullptr, nullptr, nullptr, nk, nullptr, nullptr, blinds, LR), "lasso_bullet_round");
+      }
       std::vector<Pt> two{Pt::from_abi(LR[0]), Pt::from_abi(LR[1])}; std::vector<uint8_t> cb; compress_batch(two, cb);
       t.append_point_bytes("L", &cb[0]); t.append_point_bytes("R", &cb[32]);
       Sc u = t.challenge_scalar("u"), u_inv = u.inverse();
-      lasso_fr ua = u.abi(), uia = u_inv.abi();
-      d.chk(lasso_bullet_fold(d.ctx, d_a.p, d_b.p, nk, w_cur, nw, w_nxt, &ua, &uia), "lasso_bullet_fold");
-      std::swap(w_cur, w_nxt);
+      ua = u.abi(); uia = u_inv.abi(); have_u = true;
       blind_fin = blind_fin + blind_L * u * u + blind_R * u_inv * u_inv;
       P.L_vec.insert(P.L_vec.end(), cb.begin(), cb.begin() + 32); P.R_vec.insert(P.R_vec.end(), cb.begin() + 32, cb.end());
       nk /= 2; nw *= 2; round++;
     }
-    lasso_fr heads[2]; const lasso_fr* hp[2] = {d_a.p, d_b.p};
+    if (have_u) {   // the last challenge still folds a, b (length 2 -> 1) and the weights
+      d.chk(lasso_bullet_fold(d.ctx, a_cur, b_cur, 2, w_cur, nw / 2, w_nxt, &ua, &uia), "lasso_bullet_fold");
+      std::swap(w_cur, w_nxt);
+    }
+    DBuf& d_a = d_a0; DBuf& d_b = d_b0; (void)d_a; (void)d_b;
+    lasso_fr heads[2]; const lasso_fr* hp[2] = {a_cur, b_cur};
     d.chk(lasso_read_heads(d.ctx, hp, 2, heads), "lasso_read_heads");
     Sc x_hat = Sc::from_abi(heads[0]), a_hat = Sc::from_abi(heads[1]), y_hat = x_hat * a_hat;
     Pt g_hat = msm_dev(g, w_cur, n);                                             // G[0] after all folds = sum_j w_j G_j

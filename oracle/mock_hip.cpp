@@ -159,6 +159,23 @@ int32_t lasso_bullet_lr(lasso_ctx* c, const lasso_bases* b, size_t n, const lass
   put_point(msm(bs, sc), out + 1);
   return 0;
 }
+// the fused round = (optional) fold of the previous challenge, then inner products + L/R on the folded state, restated with the pieces above
+int32_t lasso_bullet_fold(lasso_ctx*, lasso_fr* a, lasso_fr* b, size_t nk, const lasso_fr* w, size_t nw, lasso_fr* w_out, const lasso_fr* u, const lasso_fr* u_inv);
+int32_t lasso_bullet_round(lasso_ctx* c, const lasso_bases* bs, size_t n, const lasso_fr* a_in, const lasso_fr* b_in, const lasso_fr* w_in, lasso_fr* a_out, lasso_fr* b_out, lasso_fr* w_out, size_t nk,
+                           const lasso_fr* u, const lasso_fr* u_inv, const lasso_fr* blinds, lasso_point* out) {
+  const lasso_fr *a = a_in, *b = b_in, *w = w_in;
+  std::vector<lasso_fr> ta, tb;
+  if (u) {
+    REQ(c, u_inv && a_out && b_out && w_out && 2 * nk <= n);
+    ta.assign(a_in, a_in + 2 * nk); tb.assign(b_in, b_in + 2 * nk);
+    lasso_bullet_fold(c, ta.data(), tb.data(), 2 * nk, w_in, n / (2 * nk), w_out, u, u_inv);
+    memcpy(a_out, ta.data(), nk * sizeof(lasso_fr)); memcpy(b_out, tb.data(), nk * sizeof(lasso_fr));
+    a = a_out; b = b_out; w = w_out;
+  }
+  lasso_fr cc[2]; lasso_inner_products_lr(c, a, b, nk, cc);
+  lasso_fr tail[4] = {cc[0], blinds[0], cc[1], blinds[1]};
+  return lasso_bullet_lr(c, bs, n, a, nk, w, tail, out);
+}
 int32_t lasso_bullet_fold(lasso_ctx*, lasso_fr* a, lasso_fr* b, size_t nk, const lasso_fr* w, size_t nw, lasso_fr* w_out, const lasso_fr* u, const lasso_fr* u_inv) {
   size_t h = nk / 2; Fr uu = *F(u), ui = *F(u_inv);
   for (size_t i = 0; i < h; i++) { F(a)[i] = F(a)[i] * uu + ui * F(a)[h + i]; F(b)[i] = F(b)[i] * ui + uu * F(b)[h + i]; }   // bullet.rs:127-130

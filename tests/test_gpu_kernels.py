@@ -310,6 +310,38 @@ def test_bullet_lr_and_fold(devs, n, nk):
         assert compress_points(mock_lib, wa) == compress_points(mock_lib, wb)
 
 
+@pytest.mark.parametrize("n,nk,fold", [(2, 2, False), (8, 8, False), (8, 2, True), (8, 4, True), (64, 16, True), (256, 256, False), (256, 128, True), (256, 2, True), (1 << 12, 1 << 11, True), (1 << 12, 4, True)])
+def test_bullet_round_fused(devs, n, nk, fold):
+    """the one-call round (fold of the previous challenge + c_L, c_R + L, R) vs the oracle's explicit fold-then-MSM (bullet.rs:66-132)"""
+    rng = np.random.default_rng(n * 1000 + nk + int(fold))
+    mock_lib = devs[1].lib
+    g = gens(mock_lib, b"gens_sparse_poly", n + 1)
+    len_in = 2 * nk if fold else nk
+    nw_in = n // len_in
+    a = rand_fr(rng, len_in, edge=False); b = rand_fr(rng, len_in, edge=False); w = rand_fr(rng, nw_in, edge=False)
+    blinds = rand_fr(rng, 2, edge=False)
+    u, ui = rand_fr(rng, 2, edge=False)
+
+    def run(d):
+        bases = d.bases_create(g)
+        pa = d.upload(a); pb = d.upload(b); pw = d.upload(w)
+        pa2 = d.alloc(32 * nk); pb2 = d.alloc(32 * nk); pw2 = d.alloc(32 * 2 * nw_in)
+        if fold:
+            lr = d.bullet_round(bases, n, pa, pb, pw, pa2, pb2, pw2, nk, u, ui, blinds)
+            state = (d.download(pa2, (nk, 4)), d.download(pb2, (nk, 4)), d.download(pw2, (2 * nw_in, 4)))
+        else:
+            lr = d.bullet_round(bases, n, pa, pb, pw, 0, 0, 0, nk, None, None, blinds)
+            state = ()
+        for p in (pa, pb, pw, pa2, pb2, pw2):
+            d.free(p)
+        d.bases_destroy(bases)
+        return lr, state
+    (la, sa), (lb, sb) = both(devs, run)
+    assert compress_points(mock_lib, la) == compress_points(mock_lib, lb)
+    for x, y in zip(sa, sb):
+        assert np.array_equal(x, y)
+
+
 @pytest.mark.parametrize("n,ncirc", [(4, 1), (8, 2), (1 << 10, 2), (1 << 14, 8), (1 << 17, 3)])
 def test_sumcheck_cubic_round_fused(devs, n, ncirc):
     """bind with r then evaluate the next round in one pass == bind_top followed by the plain round (sumcheck.rs:49-120)"""
