@@ -10,14 +10,14 @@
 #include "msm_kernels.cuh"
 
 __global__ void __launch_bounds__(256) k_inner_lr(const fr_t* __restrict__ a, const fr_t* __restrict__ b, size_t half, fr_t* __restrict__ partials) {
-  __shared__ fr_t smem[4];
-  fr_t cl = fr_zero(), cr = fr_zero();
+  __shared__ RedScratch S;
+  fr29 acc[3] = {fr29_zero(), fr29_zero(), fr29_zero()}; uint32_t cnt = 0;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x) {
-    cl = fr_add(cl, fr_mul(a[i], b[half + i]));
-    cr = fr_add(cr, fr_mul(a[half + i], b[i]));
+    acc[0] = fr29_weak(fr29_add(acc[0], fr29_mul(fr29_unpack_u(a[i]), fr29_unpack_s(b[half + i]))));
+    acc[1] = fr29_weak(fr29_add(acc[1], fr29_mul(fr29_unpack_u(a[half + i]), fr29_unpack_s(b[i]))));
+    if ((++cnt & 127u) == 0) { acc[0] = fr29_mul(acc[0], fr29_one_s()); acc[1] = fr29_mul(acc[1], fr29_one_s()); }
   }
-  cl = block_reduce_fr(cl, smem); cr = block_reduce_fr(cr, smem);
-  if (threadIdx.x == 0) { partials[2 * (size_t)blockIdx.x] = cl; partials[2 * (size_t)blockIdx.x + 1] = cr; }
+  store_block_partials<3>(acc, 2, partials + 2 * (size_t)blockIdx.x, fr29_one_s(), S);
 }
 
 static_assert(sizeof(lasso_fr) == 32 && sizeof(fr_t) == 32, "Fr layout");
@@ -271,8 +271,11 @@ int32_t lasso_sumcheck_combine_round(lasso_ctx* c, const lasso_strategy* s, cons
   rc = ensure_small(c, K); if (rc) return rc;
   {
     ProfScope ps(c, LASSO_K_COMBINE, 32.0 * n * (S.alpha + 1.0));
-#define LAUNCH_COMBINE(A_, D_) hipLaunchKernelGGL((k_combine_round<A_, D_>), dim3(nx), dim3(LASSO_BLOCK), 0, c->stream, S, P, (const fr_t*)d_eq, W, half, degree, (fr_t*)c->d_scratch)
-    DISPATCH_A(S.alpha, LAUNCH_COMBINE);
+    if (s->kind != LASSO_LT) hipLaunchKernelGGL(k_combine_round_linear, dim3(nx), dim3(LASSO_BLOCK), 0, c->stream, S, P, (const fr_t*)d_eq, W, half, (fr_t*)c->d_scratch);
+    else {
+#define LAUNCH_COMBINE(A_, D_) hipLaunchKernelGGL((k_combine_round_lt<A_, D_>), dim3(nx), dim3(LASSO_BLOCK), 0, c->stream, S, P, (const fr_t*)d_eq, half, degree, (fr_t*)c->d_scratch)
+      DISPATCH_A(S.alpha, LAUNCH_COMBINE);
+    }
     hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(LASSO_BLOCK), 0, c->stream, (const fr_t*)c->d_scratch, nx, K, c->d_small);
   }
   HIPCHK(c, hipGetLastError());

@@ -42,7 +42,7 @@ __global__ void k_precompute_table(const fq_t* __restrict__ aff, size_t n, niels
 __global__ void __launch_bounds__(256) k_fr_to_u32(const fr_t* __restrict__ src, size_t n, uint32_t* __restrict__ dst, uint32_t* __restrict__ flags) {
   uint32_t mx = 0, big = 0;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    fr_t c = fr_to_canonical(src[i]);
+    fr_t c = fr29_to_integer(fr29_unpack_u(src[i]));
     dst[i] = c.v[0];
     mx = max(mx, c.v[0]);
     big |= c.v[1] | c.v[2] | c.v[3] | c.v[4] | c.v[5] | c.v[6] | c.v[7];
@@ -52,7 +52,7 @@ __global__ void __launch_bounds__(256) k_fr_to_u32(const fr_t* __restrict__ src,
 }
 // Montgomery Fr -> canonical 32-byte little-endian integers
 __global__ void __launch_bounds__(256) k_fr_to_canonical(const fr_t* __restrict__ src, size_t n, fr_t* __restrict__ dst) {
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = fr_to_canonical(src[i]);
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = fr29_to_integer(fr29_unpack_u(src[i]));
 }
 
 // grid = (chunks per row K, rows).  scal: canonical little-endian scalars, `bps` bytes each (4 or 32), row r at
@@ -142,20 +142,23 @@ __global__ void __launch_bounds__(256) k_bullet_expand(const fr_t* __restrict__ 
   const size_t half = nk / 2;
   for (size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x; j < n; j += (size_t)gridDim.x * blockDim.x) {
     const size_t blk = j / nk, pos = j % nk;
-    const fr_t wb = w[blk];
-    if (pos >= half) { SL[j] = fr_to_canonical(fr_mul(wb, a[pos - half])); SR[j] = fr_zero(); }
-    else { SL[j] = fr_zero(); SR[j] = fr_to_canonical(fr_mul(wb, a[pos + half])); }
+    const fr29 ws = fr29_unpack_s(w[blk]);
+    if (pos >= half) { SL[j] = fr29_to_integer(fr29_mul(fr29_unpack_u(a[pos - half]), ws)); SR[j] = fr_zero(); }
+    else { SL[j] = fr_zero(); SR[j] = fr29_to_integer(fr29_mul(fr29_unpack_u(a[pos + half]), ws)); }
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) { SL[n] = fr_to_canonical(cL); SL[n + 1] = fr_to_canonical(bL); SR[n] = fr_to_canonical(cR); SR[n + 1] = fr_to_canonical(bR); }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    SL[n] = fr29_to_integer(fr29_unpack_u(cL)); SL[n + 1] = fr29_to_integer(fr29_unpack_u(bL)); SR[n] = fr29_to_integer(fr29_unpack_u(cR)); SR[n + 1] = fr29_to_integer(fr29_unpack_u(bR));
+  }
 }
 __global__ void __launch_bounds__(256) k_bullet_fold(fr_t* __restrict__ a, fr_t* __restrict__ b, size_t half, const fr_t* __restrict__ w, size_t nw, fr_t* __restrict__ w_out, fr_t u, fr_t u_inv) {
   const size_t tid = blockIdx.x * (size_t)blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+  const fr29 us = fr29_unpack_s(u), uis = fr29_unpack_s(u_inv);
   for (size_t i = tid; i < half; i += stride) {
-    fr_t al = a[i], ar = a[i + half], bl = b[i], br = b[i + half];
-    a[i] = fr_add(fr_mul(al, u), fr_mul(u_inv, ar));
-    b[i] = fr_add(fr_mul(bl, u_inv), fr_mul(u, br));
+    const fr29 al = fr29_unpack_u(a[i]), ar = fr29_unpack_u(a[i + half]), bl = fr29_unpack_u(b[i]), br = fr29_unpack_u(b[i + half]);
+    a[i] = fr29_store(fr29_add(fr29_mul(al, us), fr29_mul(ar, uis)));
+    b[i] = fr29_store(fr29_add(fr29_mul(bl, uis), fr29_mul(br, us)));
   }
-  for (size_t k = tid; k < nw; k += stride) { fr_t x = w[k]; w_out[2 * k] = fr_mul(x, u_inv); w_out[2 * k + 1] = fr_mul(x, u); }
+  for (size_t k = tid; k < nw; k += stride) { const fr29 x = fr29_unpack_u(w[k]); w_out[2 * k] = fr29_store(fr29_mul(x, uis)); w_out[2 * k + 1] = fr29_store(fr29_mul(x, us)); }
 }
 
 // ------------------------------------------------------------------ one bullet round in one pass (bullet.rs:66-132)
@@ -167,36 +170,39 @@ template <bool FOLD>
 __global__ void __launch_bounds__(256) k_bullet_step(const fr_t* __restrict__ a_in, const fr_t* __restrict__ b_in, const fr_t* __restrict__ w_in, fr_t* __restrict__ a_out, fr_t* __restrict__ b_out,
                                                       fr_t* __restrict__ w_out, size_t nk, size_t n, fr_t u, fr_t u_inv, fr_t blind_l, fr_t blind_r, fr_t* __restrict__ SL, fr_t* __restrict__ SR,
                                                       fr_t* __restrict__ partials, uint32_t* counters) {
-  __shared__ fr_t smem[4];
+  __shared__ RedScratch S;
   __shared__ uint32_t is_last;
   const size_t half = nk / 2, total = n / 2;
-  fr_t cl = fr_zero(), cr = fr_zero();
+  const fr29 us = fr29_unpack_s(u), uis = fr29_unpack_s(u_inv);
+  fr29 acc[3] = {fr29_zero(), fr29_zero(), fr29_zero()}; uint32_t cnt = 0;   // acc[0] = c_L, acc[1] = c_R partial sums
   for (size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
     const size_t i = g % half, blk = g / half;
-    fr_t a0, a1, wv;
+    fr29 a0, a1, wv;   // canonical u-form
     if (FOLD) {
-      a0 = fr_add(fr_mul(a_in[i], u), fr_mul(u_inv, a_in[i + nk]));
-      a1 = fr_add(fr_mul(a_in[i + half], u), fr_mul(u_inv, a_in[i + half + nk]));
-      wv = fr_mul(w_in[blk >> 1], (blk & 1) ? u : u_inv);
-      if (i == 0) w_out[blk] = wv;
-    } else { a0 = a_in[i]; a1 = a_in[i + half]; wv = w_in[blk]; }
+      a0 = fr29_canonical(fr29_add(fr29_mul(fr29_unpack_u(a_in[i]), us), fr29_mul(fr29_unpack_u(a_in[i + nk]), uis)));
+      a1 = fr29_canonical(fr29_add(fr29_mul(fr29_unpack_u(a_in[i + half]), us), fr29_mul(fr29_unpack_u(a_in[i + half + nk]), uis)));
+      wv = fr29_canonical(fr29_mul(fr29_unpack_u(w_in[blk >> 1]), (blk & 1) ? us : uis));
+      if (i == 0) w_out[blk] = fr29_pack(wv);
+    } else { a0 = fr29_unpack_u(a_in[i]); a1 = fr29_unpack_u(a_in[i + half]); wv = fr29_unpack_u(w_in[blk]); }
     if (blk == 0) {
-      fr_t b0, b1;
+      fr29 b0, b1;
       if (FOLD) {
-        b0 = fr_add(fr_mul(b_in[i], u_inv), fr_mul(u, b_in[i + nk]));
-        b1 = fr_add(fr_mul(b_in[i + half], u_inv), fr_mul(u, b_in[i + half + nk]));
-        a_out[i] = a0; a_out[i + half] = a1; b_out[i] = b0; b_out[i + half] = b1;
-      } else { b0 = b_in[i]; b1 = b_in[i + half]; }
-      cl = fr_add(cl, fr_mul(a0, b1));
-      cr = fr_add(cr, fr_mul(a1, b0));
+        b0 = fr29_canonical(fr29_add(fr29_mul(fr29_unpack_u(b_in[i]), uis), fr29_mul(fr29_unpack_u(b_in[i + nk]), us)));
+        b1 = fr29_canonical(fr29_add(fr29_mul(fr29_unpack_u(b_in[i + half]), uis), fr29_mul(fr29_unpack_u(b_in[i + half + nk]), us)));
+        a_out[i] = fr29_pack(a0); a_out[i + half] = fr29_pack(a1); b_out[i] = fr29_pack(b0); b_out[i + half] = fr29_pack(b1);
+      } else { b0 = fr29_unpack_u(b_in[i]); b1 = fr29_unpack_u(b_in[i + half]); }
+      // u * u products are 2^5 short: corrected with K5 when the block partial is written
+      acc[0] = fr29_weak(fr29_add(acc[0], fr29_mul(a0, b1)));
+      acc[1] = fr29_weak(fr29_add(acc[1], fr29_mul(a1, b0)));
+      if ((++cnt & 127u) == 0) { acc[0] = fr29_mul(acc[0], fr29_one_s()); acc[1] = fr29_mul(acc[1], fr29_one_s()); }
     }
+    // MSM scalars are canonical integers: mul(u, u) = wv*a*2^251, one more Montgomery step with the integer 2^10 gives wv*a itself
     const size_t base = blk * nk + i;
-    SL[base] = fr_zero(); SL[base + half] = fr_to_canonical(fr_mul(wv, a0));
-    SR[base] = fr_to_canonical(fr_mul(wv, a1)); SR[base + half] = fr_zero();
+    SL[base] = fr_zero(); SL[base + half] = fr29_store(fr29_mul(fr29_mul(wv, a0), fr29_int_from_uu()));
+    SR[base] = fr29_store(fr29_mul(fr29_mul(wv, a1), fr29_int_from_uu())); SR[base + half] = fr_zero();
   }
-  cl = block_reduce_fr(cl, smem); cr = block_reduce_fr(cr, smem);
+  store_block_partials<3>(acc, 2, partials + 2 * (size_t)blockIdx.x, fr29_k5(), S);
   if (threadIdx.x == 0) {
-    partials[2 * (size_t)blockIdx.x] = cl; partials[2 * (size_t)blockIdx.x + 1] = cr;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     uint32_t ticket = __hip_atomic_fetch_add(counters, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -206,8 +212,14 @@ __global__ void __launch_bounds__(256) k_bullet_step(const fr_t* __restrict__ a_
   }
   __syncthreads();
   if (!is_last) return;
-  fr_t sl = fr_zero(), sr = fr_zero();
-  for (uint32_t x = threadIdx.x; x < gridDim.x; x += blockDim.x) { sl = fr_add(sl, partials[2 * (size_t)x]); sr = fr_add(sr, partials[2 * (size_t)x + 1]); }
-  sl = block_reduce_fr(sl, smem); sr = block_reduce_fr(sr, smem);
-  if (threadIdx.x == 0) { SL[n] = fr_to_canonical(sl); SL[n + 1] = fr_to_canonical(blind_l); SR[n] = fr_to_canonical(sr); SR[n + 1] = fr_to_canonical(blind_r); }
+  fr29 tot[3] = {fr29_zero(), fr29_zero(), fr29_zero()};
+  for (uint32_t x = threadIdx.x; x < gridDim.x; x += blockDim.x) { tot[0] = fr29_weak(fr29_add(tot[0], fr29_unpack_u(partials[2 * (size_t)x]))); tot[1] = fr29_weak(fr29_add(tot[1], fr29_unpack_u(partials[2 * (size_t)x + 1]))); }
+  block_columns<3>(tot, S);
+  if (threadIdx.x < 2) {
+    int64_t c[9];
+    for (int k = 0; k < 9; k++) c[k] = S.cols[threadIdx.x * 9 + k];
+    fr29 k32 = fr29_zero(); k32.v[0] = 32;
+    const fr_t v = fr29_store(fr29_mul(fr29_from_columns(c), k32));   // u-form sum -> canonical integer
+    if (threadIdx.x == 0) { SL[n] = v; SL[n + 1] = fr29_to_integer(fr29_unpack_u(blind_l)); } else { SR[n] = v; SR[n + 1] = fr29_to_integer(fr29_unpack_u(blind_r)); }
+  }
 }

@@ -1,94 +1,106 @@
 // HIP kernels for the polynomial half of the Lasso hot path (gfx950, wave64).
-// Each kernel streams 32-byte Fr elements (two dwordx4 per lane) and is HBM-bound by design except the
-// sumcheck round evaluators, which are integer-ALU-bound (6 Montgomery products per 128 B).  Reductions are
-// exact field sums, so any tree order gives bit-identical results to the reference's serial/rayon loops.
+// Memory holds 32-byte Fr elements exactly as a Rust Vec<Fr> (two dwordx4 per lane); arithmetic runs in the carry-free 29-bit-limb
+// form of fr29.cuh (unpack on load, canonicalise + pack on store).  Streaming kernels are HBM-bound by design; the sumcheck round
+// evaluators are integer-ALU-bound.  Sums are exact field sums, so any reduction order is bit-identical to the reference's loops.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "fr.cuh"
+#include "fr29.cuh"
 
 #define LASSO_MAX_PTRS 136   // 2 * (2 * 33 memories) + slack; pointer tables travel by value in the kernarg segment
 #define LASSO_BLOCK 256
+#define LASSO_MAX_ALPHA 32
 
 struct PtrTable { const fr_t* p[LASSO_MAX_PTRS]; };
 struct MutPtrTable { fr_t* p[LASSO_MAX_PTRS]; };
-
 struct StrategyDev { int kind; uint32_t c, log_m, log_r, alpha; };
+struct WeightTable { fr_t w[LASSO_MAX_ALPHA]; };
 
 // ------------------------------------------------------------------ reductions
-__device__ __forceinline__ fr_t shfl_down_fr(const fr_t& a, int off) {
-  fr_t r;
+// Block-wide sum of up to 3 field values per thread WITHOUT carries: every thread parks its 27 limbs in LDS, 216 threads add 32-row
+// strips of one limb column each into 64-bit sums, 27 threads finish the columns.  (256 limbs of < 2^30 fit a 64-bit column with room to
+// spare — the point of the 29-bit form.)  cols[v*9 + k] is valid for all threads after the call; fr29_from_columns turns nine columns
+// back into a field value.  Input limbs must be reduced (fr29_weak) with |limb 8| < 2^30.  Requires blockDim.x == 256.
+struct RedScratch { int32_t rows[LASSO_BLOCK * 27]; int64_t strips[8 * 27]; int64_t cols[27]; };
+template <int NV>
+__device__ __forceinline__ void block_columns(const fr29* vals, RedScratch& S) {
+  const uint32_t t = threadIdx.x;
+  __syncthreads();   // any previous use of S is over
 #pragma unroll
-  for (int i = 0; i < 8; i++) r.v[i] = __shfl_down(a.v[i], off, 64);
-  return r;
-}
-__device__ __forceinline__ fr_t wave_reduce_fr(fr_t v) {
+  for (int v = 0; v < NV; v++)
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = fr_add(v, shfl_down_fr(v, off));
-  return v;  // lane 0 holds the wave total
-}
-// sum over the 256-thread block; result valid in thread 0.  smem: 4 fr_t
-__device__ __forceinline__ fr_t block_reduce_fr(fr_t v, fr_t* smem) {
-  v = wave_reduce_fr(v);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int k = 0; k < 9; k++) S.rows[t * 27 + v * 9 + k] = vals[v].v[k];
   __syncthreads();
-  if (lane == 0) smem[wave] = v;
+  if (t < 8 * 27) {
+    const uint32_t j = t % 27, g = t / 27;
+    int64_t s = 0;
+    if (j < NV * 9) {
+#pragma unroll 8
+      for (uint32_t r = 0; r < 32; r++) s += S.rows[(g * 32 + r) * 27 + j];
+    }
+    S.strips[g * 27 + j] = s;
+  }
   __syncthreads();
-  if (threadIdx.x == 0) { v = smem[0]; for (int w = 1; w < (int)(blockDim.x >> 6); w++) v = fr_add(v, smem[w]); }
-  return v;
+  if (t < 27) {
+    int64_t s = 0;
+#pragma unroll
+    for (int g = 0; g < 8; g++) s += S.strips[g * 27 + t];
+    S.cols[t] = s;
+  }
+  __syncthreads();
 }
-// second stage: out[y*K + k] = sum_x partials[(y*nx + x)*K + k]
-__global__ void k_reduce_partials(const fr_t* __restrict__ partials, uint32_t nx, uint32_t K, fr_t* __restrict__ out) {
-  __shared__ fr_t smem[4];
-  const uint32_t y = blockIdx.x;
-  for (uint32_t k = 0; k < K; k++) {
-    fr_t acc = fr_zero();
-    for (uint32_t x = threadIdx.x; x < nx; x += blockDim.x) acc = fr_add(acc, partials[((size_t)y * nx + x) * K + k]);
-    acc = block_reduce_fr(acc, smem);
-    if (threadIdx.x == 0) out[(size_t)y * K + k] = acc;
+// value of column group v after block_columns, multiplied by `fix` (ONE_S to only reduce, K5/K10 to also correct the radix), as memory words
+__device__ __forceinline__ fr_t columns_to_fr(const RedScratch& S, int v, const fr29& fix) {
+  int64_t c[9];
+#pragma unroll
+  for (int k = 0; k < 9; k++) c[k] = S.cols[v * 9 + k];
+  return fr29_store(fr29_mul(fr29_from_columns(c), fix));
+}
+// per-thread accumulator step: acc += t, kept reduced; every 128 terms the magnitude is folded back (limb 8 must stay below 2^30)
+__device__ __forceinline__ void acc_add(fr29& acc, const fr29& t, uint32_t& count) {
+  acc = fr29_weak(fr29_add(acc, t));
+  if ((++count & 127u) == 0) acc = fr29_mul(acc, fr29_one_s());
+}
+// block partials of up to KMAX accumulators (groups of 3) -> dst[k], k < K; `fix` also corrects the radix of the accumulated products
+template <int KMAX>
+__device__ __forceinline__ void store_block_partials(const fr29* acc, uint32_t K, fr_t* __restrict__ dst, const fr29& fix, RedScratch& S) {
+#pragma unroll
+  for (int k0 = 0; k0 < KMAX; k0 += 3) if ((uint32_t)k0 < K) {
+    fr29 grp[3];
+#pragma unroll
+    for (int v = 0; v < 3; v++) grp[v] = (k0 + v < KMAX) ? acc[(k0 + v < KMAX) ? k0 + v : 0] : fr29_zero();
+    block_columns<3>(grp, S);
+    if (threadIdx.x < 3 && k0 + threadIdx.x < K) dst[k0 + threadIdx.x] = columns_to_fr(S, threadIdx.x, fix);
   }
 }
 
-// ------------------------------------------------------------------ K1: bound_poly_var_top (dense_mlpoly.rs:209-216)
-// grid = (blocks over i, polys).  Z[i] <- Z[i] + r*(Z[i+half] - Z[i])
-__global__ void __launch_bounds__(LASSO_BLOCK) k_bind_top(MutPtrTable polys, size_t half, fr_t r) {
-  fr_t* __restrict__ z = polys.p[blockIdx.y];
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x) {
-    fr_t lo = z[i], hi = z[i + half];
-    z[i] = fr_add(lo, fr_mul(r, fr_sub(hi, lo)));
+// second stage: out[y*K + k] = sum_x partials[(y*nx + x)*K + k]   (partials are canonical memory words)
+__device__ __forceinline__ void reduce_partials_row(const fr_t* __restrict__ partials, uint32_t nx, uint32_t K, uint32_t y, fr_t* __restrict__ out, RedScratch& S) {
+  for (uint32_t k0 = 0; k0 < K; k0 += 3) {
+    fr29 acc[3];
+#pragma unroll
+    for (int v = 0; v < 3; v++) {
+      acc[v] = fr29_zero();
+      if (k0 + v < K) for (uint32_t x = threadIdx.x; x < nx; x += blockDim.x) acc[v] = fr29_weak(fr29_add(acc[v], fr29_unpack_u(partials[((size_t)y * nx + x) * K + k0 + v])));
+    }
+    block_columns<3>(acc, S);
+    if (threadIdx.x < 3 && k0 + threadIdx.x < K) out[(size_t)y * K + k0 + threadIdx.x] = columns_to_fr(S, threadIdx.x, fr29_one_s());
   }
 }
-
-// ------------------------------------------------------------------ K4: cubic round (sumcheck.rs:49-93)
-// grid = (blocks over i, circuits); partials[(c*nx + bx)*3 + {0,1,2}] = evals at x = 0, 2, 3
-__global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_round(PtrTable A, PtrTable B, const fr_t* __restrict__ C, size_t half, fr_t* __restrict__ partials) {
-  __shared__ fr_t smem[4];
-  const fr_t* __restrict__ a = A.p[blockIdx.y];
-  const fr_t* __restrict__ b = B.p[blockIdx.y];
-  fr_t e0 = fr_zero(), e2 = fr_zero(), e3 = fr_zero();
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x) {
-    fr_t a0 = a[i], a1 = a[i + half], b0 = b[i], b1 = b[i + half], c0 = C[i], c1 = C[i + half];
-    e0 = fr_add(e0, fr_mul(fr_mul(a0, b0), c0));
-    fr_t da = fr_sub(a1, a0), db = fr_sub(b1, b0), dc = fr_sub(c1, c0);
-    fr_t a2 = fr_add(a1, da), b2 = fr_add(b1, db), c2 = fr_add(c1, dc);   // 2*hi - lo
-    e2 = fr_add(e2, fr_mul(fr_mul(a2, b2), c2));
-    fr_t a3 = fr_add(a2, da), b3 = fr_add(b2, db), c3 = fr_add(c2, dc);   // 3*hi - 2*lo
-    e3 = fr_add(e3, fr_mul(fr_mul(a3, b3), c3));
-  }
-  e0 = block_reduce_fr(e0, smem); e2 = block_reduce_fr(e2, smem); e3 = block_reduce_fr(e3, smem);
-  if (threadIdx.x == 0) {
-    fr_t* o = partials + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 3;
-    o[0] = e0; o[1] = e2; o[2] = e3;
-  }
+__global__ void __launch_bounds__(LASSO_BLOCK) k_reduce_partials(const fr_t* __restrict__ partials, uint32_t nx, uint32_t K, fr_t* __restrict__ out) {
+  __shared__ RedScratch S;
+  reduce_partials_row(partials, nx, K, blockIdx.x, out, S);
 }
 
-// ------------------------------------------------------------------ in-launch second-stage reduction (no extra kernel per round)
-// Block `bx` of row `y` has written its K partial sums (thread 0).  The last block to arrive for that row sums all nx partials
-// and writes out[y*K + k].  Hand-off follows cdna_hip_programming.md §6 G16: plain stores -> agent-scope release -> drained
-// vmcnt -> relaxed agent atomic ticket; the last arriver does ONE agent-scope acquire, then the workgroup reads plain.
-__device__ __forceinline__ void last_block_reduce(const fr_t* partials, uint32_t nx, uint32_t K, uint32_t y, uint32_t nrows, uint32_t* counters, fr_t* __restrict__ out, fr_t* smem,
+// In-launch second stage (no extra kernel per round).  Block `bx` of row `y` has written its K partial sums (threads 0..2, one wave).
+// The last block to arrive for that row sums all nx partials and writes out[y*K + k].  Hand-off follows cdna_hip_programming.md §6 G16:
+// plain stores -> agent-scope release -> drained vmcnt -> relaxed agent atomic ticket; the last arriver does ONE agent-scope acquire,
+// then reads plain.  `out` is host-mapped memory.  The row that finishes last raises the host's sequence flag: every row's stores are
+// released at system scope before its ticket, so the flag store (system-scope release) is ordered after all of them.
+__device__ __forceinline__ void last_block_reduce(const fr_t* partials, uint32_t nx, uint32_t K, uint32_t y, uint32_t nrows, uint32_t* counters, fr_t* __restrict__ out, RedScratch& S,
                                                   uint32_t* flag, uint32_t seq) {
   __shared__ uint32_t is_last;
-  if (threadIdx.x == 0) {
+  if (threadIdx.x == 0) {   // wave 0 holds the partial stores; fence and vmcnt are wave-wide
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     uint32_t ticket = __hip_atomic_fetch_add(&counters[y], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -98,148 +110,182 @@ __device__ __forceinline__ void last_block_reduce(const fr_t* partials, uint32_t
   }
   __syncthreads();
   if (!is_last) return;
-  for (uint32_t k = 0; k < K; k++) {
-    fr_t acc = fr_zero();
-    for (uint32_t x = threadIdx.x; x < nx; x += blockDim.x) acc = fr_add(acc, partials[((size_t)y * nx + x) * K + k]);
-    acc = block_reduce_fr(acc, smem);
-    if (threadIdx.x == 0) out[(size_t)y * K + k] = acc;
-  }
-  // `out` is host-mapped memory.  The row that finishes last raises the host's sequence flag: every row's stores are released at
-  // system scope before its ticket, so the flag store (system-scope release) is ordered after all of them.
-  if (threadIdx.x == 0 && flag) {
+  reduce_partials_row(partials, nx, K, y, out, S);
+  if (threadIdx.x == 0 && flag) {   // the <= 3 result stores were issued by this wave
     __threadfence_system();
     uint32_t t2 = __hip_atomic_fetch_add(&counters[LASSO_MAX_PTRS], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
     if (t2 == nrows - 1) { counters[LASSO_MAX_PTRS] = 0; __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
   }
 }
 
+// ------------------------------------------------------------------ K1: bound_poly_var_top (dense_mlpoly.rs:209-216)
+// grid = (blocks over i, polys).  Z[i] <- Z[i] + r*(Z[i+half] - Z[i]);  r in s-form makes the product come out in memory form.
+__global__ void __launch_bounds__(LASSO_BLOCK) k_bind_top(MutPtrTable polys, size_t half, fr_t r) {
+  fr_t* __restrict__ z = polys.p[blockIdx.y];
+  const fr29 rs = fr29_unpack_s(r);
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x) {
+    const fr29 lo = fr29_unpack_u(z[i]), hi = fr29_unpack_u(z[i + half]);
+    z[i] = fr29_store(fr29_add(lo, fr29_mul(fr29_sub(hi, lo), rs)));
+  }
+}
+
+// ------------------------------------------------------------------ K4: cubic round (sumcheck.rs:49-93)
+// One index of one circuit: the products A*B*C at x = 0, 2, 3 from the values at x = 0 (a0..) and x = 1 (a1..), all reduced u-form.
+// Each product of three u-form values comes out 2^10 short; the block result is corrected once with K10.
+__device__ __forceinline__ void cubic_terms(const fr29& a0, const fr29& a1, const fr29& b0, const fr29& b1, const fr29& c0, const fr29& c1, fr29& t0, fr29& t2, fr29& t3) {
+  t0 = fr29_mul(c0, fr29_mul(a0, b0));
+  const fr29 da = fr29_sub(a1, a0), db = fr29_sub(b1, b0), dc = fr29_sub(c1, c0);
+  const fr29 a2 = fr29_weak(fr29_add(a1, da)), b2 = fr29_weak(fr29_add(b1, db)), c2 = fr29_weak(fr29_add(c1, dc));   // 2*hi - lo
+  t2 = fr29_mul(c2, fr29_mul(a2, b2));
+  const fr29 a3 = fr29_add(a2, da), b3 = fr29_weak(fr29_add(b2, db)), c3 = fr29_add(c2, dc);                          // 3*hi - 2*lo
+  t3 = fr29_mul(c3, fr29_mul(a3, b3));
+}
+#define CUBIC_ACCUMULATE(e, t0, t2, t3, cnt)                                                                                          \
+  do {                                                                                                                                \
+    e[0] = fr29_weak(fr29_add(e[0], t0)); e[1] = fr29_weak(fr29_add(e[1], t2)); e[2] = fr29_weak(fr29_add(e[2], t3));                    \
+    if ((++cnt & 127u) == 0) { e[0] = fr29_mul(e[0], fr29_one_s()); e[1] = fr29_mul(e[1], fr29_one_s()); e[2] = fr29_mul(e[2], fr29_one_s()); } \
+  } while (0)
+// block partials -> memory (K10 also supplies the missing 2^10), then the in-launch second stage
+__device__ __forceinline__ void cubic_epilogue(const fr29* e, fr_t* __restrict__ partials, uint32_t* counters, fr_t* __restrict__ out, uint32_t* flag, uint32_t seq, RedScratch& S) {
+  store_block_partials<3>(e, 3, partials + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 3, fr29_k10(), S);
+  last_block_reduce(partials, gridDim.x, 3, blockIdx.y, gridDim.y, counters, out, S, flag, seq);
+}
+// grid = (blocks over i, circuits); out[c*3 + {0,1,2}] = evals at x = 0, 2, 3.  First round of a layer: evaluation only.
+__global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_round_lb(PtrTable A, PtrTable B, const fr_t* __restrict__ C, size_t half, fr_t* __restrict__ partials, uint32_t* counters,
+                                                                 fr_t* __restrict__ out, uint32_t* flag, uint32_t seq) {
+  __shared__ RedScratch S;
+  const fr_t* __restrict__ a = A.p[blockIdx.y];
+  const fr_t* __restrict__ b = B.p[blockIdx.y];
+  fr29 e[3] = {fr29_zero(), fr29_zero(), fr29_zero()}; uint32_t cnt = 0;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x) {
+    fr29 t0, t2, t3;
+    cubic_terms(fr29_unpack_u(a[i]), fr29_unpack_u(a[i + half]), fr29_unpack_u(b[i]), fr29_unpack_u(b[i + half]), fr29_unpack_u(C[i]), fr29_unpack_u(C[i + half]), t0, t2, t3);
+    CUBIC_ACCUMULATE(e, t0, t2, t3, cnt);
+  }
+  cubic_epilogue(e, partials, counters, out, flag, seq, S);
+}
 // K4 fused with K1: bind every polynomial of the round with r (length n = 4q -> 2q), then evaluate the NEXT round on the bound
 // values while they are still in registers (80 -> 48 bytes per element per round, one launch per round).
 // A, B are bound in place (each element is owned by exactly one thread); the shared eq polynomial C is read from C_in and written
 // to C_out by the row-0 workgroups only, because every circuit row re-reads it.
+__device__ __forceinline__ fr29 bind29(const fr_t& lo, const fr_t& hi, const fr29& rs) {
+  const fr29 l = fr29_unpack_u(lo);
+  return fr29_canonical(fr29_add(l, fr29_mul(fr29_sub(fr29_unpack_u(hi), l), rs)));   // canonical: stored as is, and a reduced operand below
+}
 __global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_fused(MutPtrTable A, MutPtrTable B, const fr_t* __restrict__ C_in, fr_t* __restrict__ C_out, size_t q, fr_t r,
                                                               fr_t* __restrict__ partials, uint32_t* counters, fr_t* __restrict__ out, uint32_t* flag, uint32_t seq) {
-  __shared__ fr_t smem[4];
+  __shared__ RedScratch S;
   fr_t* __restrict__ a = A.p[blockIdx.y];
   fr_t* __restrict__ b = B.p[blockIdx.y];
-  fr_t e0 = fr_zero(), e2 = fr_zero(), e3 = fr_zero();
+  const fr29 rs = fr29_unpack_s(r);
+  fr29 e[3] = {fr29_zero(), fr29_zero(), fr29_zero()}; uint32_t cnt = 0;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < q; i += (size_t)gridDim.x * blockDim.x) {
-    fr_t x0 = a[i], x1 = a[i + q], x2 = a[i + 2 * q], x3 = a[i + 3 * q];
-    fr_t a0 = fr_add(x0, fr_mul(r, fr_sub(x2, x0))), a1 = fr_add(x1, fr_mul(r, fr_sub(x3, x1)));
-    a[i] = a0; a[i + q] = a1;
-    x0 = b[i]; x1 = b[i + q]; x2 = b[i + 2 * q]; x3 = b[i + 3 * q];
-    fr_t b0 = fr_add(x0, fr_mul(r, fr_sub(x2, x0))), b1 = fr_add(x1, fr_mul(r, fr_sub(x3, x1)));
-    b[i] = b0; b[i + q] = b1;
-    x0 = C_in[i]; x1 = C_in[i + q]; x2 = C_in[i + 2 * q]; x3 = C_in[i + 3 * q];
-    fr_t c0 = fr_add(x0, fr_mul(r, fr_sub(x2, x0))), c1 = fr_add(x1, fr_mul(r, fr_sub(x3, x1)));
-    if (blockIdx.y == 0) { C_out[i] = c0; C_out[i + q] = c1; }
-    e0 = fr_add(e0, fr_mul(fr_mul(a0, b0), c0));
-    fr_t da = fr_sub(a1, a0), db = fr_sub(b1, b0), dc = fr_sub(c1, c0);
-    fr_t a2 = fr_add(a1, da), b2 = fr_add(b1, db), c2 = fr_add(c1, dc);
-    e2 = fr_add(e2, fr_mul(fr_mul(a2, b2), c2));
-    fr_t a3 = fr_add(a2, da), b3 = fr_add(b2, db), c3 = fr_add(c2, dc);
-    e3 = fr_add(e3, fr_mul(fr_mul(a3, b3), c3));
+    const fr29 a0 = bind29(a[i], a[i + 2 * q], rs), a1 = bind29(a[i + q], a[i + 3 * q], rs);
+    a[i] = fr29_pack(a0); a[i + q] = fr29_pack(a1);
+    const fr29 b0 = bind29(b[i], b[i + 2 * q], rs), b1 = bind29(b[i + q], b[i + 3 * q], rs);
+    b[i] = fr29_pack(b0); b[i + q] = fr29_pack(b1);
+    const fr29 c0 = bind29(C_in[i], C_in[i + 2 * q], rs), c1 = bind29(C_in[i + q], C_in[i + 3 * q], rs);
+    if (blockIdx.y == 0) { C_out[i] = fr29_pack(c0); C_out[i + q] = fr29_pack(c1); }
+    fr29 t0, t2, t3;
+    cubic_terms(a0, a1, b0, b1, c0, c1, t0, t2, t3);
+    CUBIC_ACCUMULATE(e, t0, t2, t3, cnt);
   }
-  e0 = block_reduce_fr(e0, smem); e2 = block_reduce_fr(e2, smem); e3 = block_reduce_fr(e3, smem);
-  if (threadIdx.x == 0) { fr_t* o = partials + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 3; o[0] = e0; o[1] = e2; o[2] = e3; }
-  last_block_reduce(partials, gridDim.x, 3, blockIdx.y, gridDim.y, counters, out, smem, flag, seq);
-}
-// first round of a layer: evaluation only, with the in-launch second stage
-__global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_round_lb(PtrTable A, PtrTable B, const fr_t* __restrict__ C, size_t half, fr_t* __restrict__ partials, uint32_t* counters,
-                                                                 fr_t* __restrict__ out, uint32_t* flag, uint32_t seq) {
-  __shared__ fr_t smem[4];
-  const fr_t* __restrict__ a = A.p[blockIdx.y];
-  const fr_t* __restrict__ b = B.p[blockIdx.y];
-  fr_t e0 = fr_zero(), e2 = fr_zero(), e3 = fr_zero();
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x) {
-    fr_t a0 = a[i], a1 = a[i + half], b0 = b[i], b1 = b[i + half], c0 = C[i], c1 = C[i + half];
-    e0 = fr_add(e0, fr_mul(fr_mul(a0, b0), c0));
-    fr_t da = fr_sub(a1, a0), db = fr_sub(b1, b0), dc = fr_sub(c1, c0);
-    fr_t a2 = fr_add(a1, da), b2 = fr_add(b1, db), c2 = fr_add(c1, dc);
-    e2 = fr_add(e2, fr_mul(fr_mul(a2, b2), c2));
-    fr_t a3 = fr_add(a2, da), b3 = fr_add(b2, db), c3 = fr_add(c2, dc);
-    e3 = fr_add(e3, fr_mul(fr_mul(a3, b3), c3));
-  }
-  e0 = block_reduce_fr(e0, smem); e2 = block_reduce_fr(e2, smem); e3 = block_reduce_fr(e3, smem);
-  if (threadIdx.x == 0) { fr_t* o = partials + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 3; o[0] = e0; o[1] = e2; o[2] = e3; }
-  last_block_reduce(partials, gridDim.x, 3, blockIdx.y, gridDim.y, counters, out, smem, flag, seq);
+  cubic_epilogue(e, partials, counters, out, flag, seq, S);
 }
 
 // ------------------------------------------------------------------ g = S::combine_lookups (subtables/*.rs)
-#define LASSO_MAX_ALPHA 32
-// A = compile-time bound on NUM_MEMORIES so `vals` stays in registers (all indexing static after unrolling)
+// AND/OR/XOR (and.rs:45-53) and RangeCheck (range_check.rs:78-86): g = sum_i 2^(i*inc) * vals[i] is LINEAR, so along the line
+// lo + x*(hi - lo) it is g(lo) + x*(g(hi) - g(lo)): two weighted sums per index, whatever the number of evaluation points.
+// ws[i] = weights in s-form (LDS).  Returns a reduced u-form value.
+__device__ __forceinline__ fr29 weighted_sum(const PtrTable& polys, size_t idx, uint32_t alpha, const fr29* ws) {
+  fr29 s = fr29_zero();
+  for (uint32_t j = 0; j < alpha; j++) s = fr29_weak(fr29_add(s, fr29_mul(fr29_unpack_u(polys.p[j][idx]), ws[j])));
+  return s;
+}
+// LT (lt.rs:62-71): sum_i LT[i] * prod_{j<i} EQ[j], values in s-form so that products of any degree stay in s-form
 template <int A>
-__device__ __forceinline__ fr_t combine_lookups_dev(const StrategyDev& S, const fr_t* vals, const fr_t* weights) {
-  if (S.kind == 3) {  // LT: lt.rs:62-71  sum_i LT[i] * prod_{j<i} EQ[j]
-    fr_t sum = fr_zero(), eq_prod = fr_one();
+__device__ __forceinline__ fr29 combine_lt(const fr29* vals, uint32_t c) {
+  fr29 sum = fr29_zero(), eq_prod = fr29_one_s();
 #pragma unroll
-    for (int i = 0; i < A / 2; i++) if ((uint32_t)i < S.c) { sum = fr_add(sum, fr_mul(vals[2 * i], eq_prod)); eq_prod = fr_mul(eq_prod, vals[2 * i + 1]); }
-    return sum;
-  }
-  // AND/OR/XOR (and.rs:45-53) and RangeCheck (range_check.rs:78-86): sum_i 2^(i*inc) * vals[i]; weights precomputed in Montgomery form
-  fr_t sum = fr_zero();
-#pragma unroll
-  for (int i = 0; i < A; i++) if ((uint32_t)i < S.alpha) sum = fr_add(sum, fr_mul(weights[i], vals[i]));
+  for (int i = 0; i < A / 2; i++) if ((uint32_t)i < c) { sum = fr29_weak(fr29_add(sum, fr29_mul(vals[2 * i], eq_prod))); eq_prod = fr29_mul(vals[2 * i + 1], eq_prod); }
   return sum;
 }
-struct WeightTable { fr_t w[LASSO_MAX_ALPHA]; };
-
-// K3: prove_arbitrary round (sumcheck.rs:165-237).  partials[bx*(degree+1) + x];  D = compile-time bound on degree
-template <int A, int D>
-__global__ void __launch_bounds__(LASSO_BLOCK) k_combine_round(StrategyDev S, PtrTable polys, const fr_t* __restrict__ eq, WeightTable W, size_t half, uint32_t degree,
-                                                                fr_t* __restrict__ partials) {
-  __shared__ fr_t smem[4];
-  __shared__ fr_t wsm[LASSO_MAX_ALPHA];
-  if (threadIdx.x < S.alpha) wsm[threadIdx.x] = W.w[threadIdx.x];
+__device__ __forceinline__ void load_weights(const StrategyDev& S, const WeightTable& W, fr29* ws) {
+  if (threadIdx.x < S.alpha) ws[threadIdx.x] = fr29_unpack_s(W.w[threadIdx.x]);
   __syncthreads();
-  fr_t acc[D + 1];
-#pragma unroll
-  for (int x = 0; x <= D; x++) acc[x] = fr_zero();
+}
+
+// K3: prove_arbitrary round (sumcheck.rs:165-237), linear strategies: partials[bx*3 + x], x = 0, 1, 2 (sumcheck degree 2)
+__global__ void __launch_bounds__(LASSO_BLOCK) k_combine_round_linear(StrategyDev S, PtrTable polys, const fr_t* __restrict__ eq, WeightTable W, size_t half, fr_t* __restrict__ partials) {
+  __shared__ RedScratch R;
+  __shared__ fr29 ws[LASSO_MAX_ALPHA];
+  load_weights(S, W, ws);
+  fr29 acc[3] = {fr29_zero(), fr29_zero(), fr29_zero()}; uint32_t cnt = 0;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x) {
-    fr_t cur[A], dif[A];
+    const fr29 g0 = weighted_sum(polys, i, S.alpha, ws), g1 = weighted_sum(polys, i + half, S.alpha, ws);
+    const fr29 e0 = fr29_unpack_u(eq[i]), e1 = fr29_unpack_u(eq[i + half]);
+    const fr29 g2 = fr29_weak(fr29_add(g1, fr29_sub(g1, g0))), e2 = fr29_weak(fr29_add(e1, fr29_sub(e1, e0)));
+    acc[0] = fr29_weak(fr29_add(acc[0], fr29_mul(g0, e0)));
+    acc[1] = fr29_weak(fr29_add(acc[1], fr29_mul(g1, e1)));
+    acc[2] = fr29_weak(fr29_add(acc[2], fr29_mul(g2, e2)));
+    if ((++cnt & 63u) == 0) { acc[0] = fr29_mul(acc[0], fr29_one_s()); acc[1] = fr29_mul(acc[1], fr29_one_s()); acc[2] = fr29_mul(acc[2], fr29_one_s()); }
+  }
+  store_block_partials<3>(acc, 3, partials + (size_t)blockIdx.x * 3, fr29_k5(), R);   // (u * s) * u: 2^5 short
+}
+// K3 for LT: degree = C + 1.  A = compile-time bound on NUM_MEMORIES = 2C, D = bound on the degree
+template <int A, int D>
+__global__ void __launch_bounds__(LASSO_BLOCK) k_combine_round_lt(StrategyDev S, PtrTable polys, const fr_t* __restrict__ eq, size_t half, uint32_t degree, fr_t* __restrict__ partials) {
+  __shared__ RedScratch R;
+  fr29 acc[D + 1]; uint32_t cnt = 0;
 #pragma unroll
-    for (int j = 0; j < A; j++) if ((uint32_t)j < S.alpha) { fr_t lo = polys.p[j][i], hi = polys.p[j][i + half]; cur[j] = lo; dif[j] = fr_sub(hi, lo); }
-    fr_t elo = eq[i], ehi = eq[i + half], ecur = elo, edif = fr_sub(ehi, elo);
+  for (int x = 0; x <= D; x++) acc[x] = fr29_zero();
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x) {
+    fr29 cur[A], dif[A];
+#pragma unroll
+    for (int j = 0; j < A; j++) if ((uint32_t)j < S.alpha) { cur[j] = fr29_unpack_s(polys.p[j][i]); dif[j] = fr29_sub(fr29_unpack_s(polys.p[j][i + half]), cur[j]); }
+    fr29 ecur = fr29_unpack_u(eq[i]); const fr29 edif = fr29_sub(fr29_unpack_u(eq[i + half]), ecur);
 #pragma unroll
     for (int x = 0; x <= D; x++) if ((uint32_t)x <= degree) {
-      acc[x] = fr_add(acc[x], fr_mul(combine_lookups_dev<A>(S, cur, wsm), ecur));
+      acc[x] = fr29_weak(fr29_add(acc[x], fr29_mul(combine_lt<A>(cur, S.c), ecur)));   // s * u = u
 #pragma unroll
-      for (int j = 0; j < A; j++) if ((uint32_t)j < S.alpha) cur[j] = fr_add(cur[j], dif[j]);
-      ecur = fr_add(ecur, edif);
+      for (int j = 0; j < A; j++) if ((uint32_t)j < S.alpha) cur[j] = fr29_weak(fr29_add(cur[j], dif[j]));
+      ecur = fr29_weak(fr29_add(ecur, edif));
+    }
+    if ((++cnt & 63u) == 0) {
+#pragma unroll
+      for (int x = 0; x <= D; x++) acc[x] = fr29_mul(acc[x], fr29_one_s());
     }
   }
-#pragma unroll
-  for (int x = 0; x <= D; x++) if ((uint32_t)x <= degree) {
-    fr_t v = block_reduce_fr(acc[x], smem);
-    if (threadIdx.x == 0) partials[(size_t)blockIdx.x * (degree + 1) + x] = v;
-  }
+  store_block_partials<D + 1>(acc, degree + 1, partials + (size_t)blockIdx.x * (degree + 1), fr29_one_s(), R);
 }
 // K10: claim = sum_k eq[k] * g(E(k))  (subtables/mod.rs:187-216)
 template <int A>
 __global__ void __launch_bounds__(LASSO_BLOCK) k_combine_claim(StrategyDev S, PtrTable polys, const fr_t* __restrict__ eq, WeightTable W, size_t n, fr_t* __restrict__ partials) {
-  __shared__ fr_t smem[4];
-  __shared__ fr_t wsm[LASSO_MAX_ALPHA];
-  if (threadIdx.x < S.alpha) wsm[threadIdx.x] = W.w[threadIdx.x];
-  __syncthreads();
-  fr_t acc = fr_zero();
+  __shared__ RedScratch R;
+  __shared__ fr29 ws[LASSO_MAX_ALPHA];
+  load_weights(S, W, ws);
+  const bool lt = S.kind == 3;
+  fr29 acc[1] = {fr29_zero()}; uint32_t cnt = 0;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    fr_t vals[A];
+    fr29 g;
+    if (lt) {
+      fr29 vals[A];
 #pragma unroll
-    for (int j = 0; j < A; j++) if ((uint32_t)j < S.alpha) vals[j] = polys.p[j][i];
-    acc = fr_add(acc, fr_mul(combine_lookups_dev<A>(S, vals, wsm), eq[i]));
+      for (int j = 0; j < A; j++) if ((uint32_t)j < S.alpha) vals[j] = fr29_unpack_s(polys.p[j][i]);
+      g = combine_lt<A>(vals, S.c);
+    } else g = weighted_sum(polys, i, S.alpha, ws);
+    acc_add(acc[0], fr29_mul(g, fr29_unpack_u(eq[i])), cnt);
   }
-  acc = block_reduce_fr(acc, smem);
-  if (threadIdx.x == 0) partials[blockIdx.x] = acc;
+  store_block_partials<1>(acc, 1, partials + blockIdx.x, lt ? fr29_one_s() : fr29_k5(), R);
 }
 
 // K12: out[p] = sum_i polys[p][i] * w[i]; grid = (blocks, polys); partials[p*nx + bx]
 __global__ void __launch_bounds__(LASSO_BLOCK) k_multi_dot(PtrTable polys, const fr_t* __restrict__ w, size_t n, fr_t* __restrict__ partials) {
-  __shared__ fr_t smem[4];
+  __shared__ RedScratch R;
   const fr_t* __restrict__ z = polys.p[blockIdx.y];
-  fr_t acc = fr_zero();
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) acc = fr_add(acc, fr_mul(z[i], w[i]));
-  acc = block_reduce_fr(acc, smem);
-  if (threadIdx.x == 0) partials[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = acc;
+  fr29 acc[1] = {fr29_zero()}; uint32_t cnt = 0;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) acc_add(acc[0], fr29_mul(fr29_unpack_u(z[i]), fr29_unpack_s(w[i])), cnt);
+  store_block_partials<1>(acc, 1, partials + (size_t)blockIdx.y * gridDim.x + blockIdx.x, fr29_one_s(), R);
 }
 
 // ------------------------------------------------------------------ K6: eq evals (eq_poly.rs:22-38)
@@ -248,26 +294,27 @@ struct RTable { fr_t r[32]; };
 __global__ void k_eq_small(RTable R, uint32_t ell, fr_t* __restrict__ out) {
   size_t x = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (x >= ((size_t)1 << ell)) return;
-  fr_t p = fr_one(), one = fr_one();
-  for (uint32_t j = 0; j < ell; j++) { bool bit = (x >> (ell - 1 - j)) & 1; p = fr_mul(p, bit ? R.r[j] : fr_sub(one, R.r[j])); }
-  out[x] = p;
+  fr29 p = fr29_unpack_u(fr_one());
+  const fr29 one_s = fr29_one_s();
+  for (uint32_t j = 0; j < ell; j++) { const bool bit = (x >> (ell - 1 - j)) & 1; const fr29 rs = fr29_unpack_s(R.r[j]); p = fr29_mul(bit ? rs : fr29_sub(one_s, rs), p); }
+  out[x] = fr29_store(p);
 }
 // out[x] = hi[x >> lo_bits] * lo[x & mask]
 __global__ void __launch_bounds__(LASSO_BLOCK) k_eq_outer(const fr_t* __restrict__ hi, const fr_t* __restrict__ lo, uint32_t lo_bits, size_t n, fr_t* __restrict__ out) {
   const size_t mask = ((size_t)1 << lo_bits) - 1;
-  for (size_t x = blockIdx.x * (size_t)blockDim.x + threadIdx.x; x < n; x += (size_t)gridDim.x * blockDim.x) out[x] = fr_mul(hi[x >> lo_bits], lo[x & mask]);
+  for (size_t x = blockIdx.x * (size_t)blockDim.x + threadIdx.x; x < n; x += (size_t)gridDim.x * blockDim.x) out[x] = fr29_store(fr29_mul(fr29_unpack_u(hi[x >> lo_bits]), fr29_unpack_s(lo[x & mask])));
 }
 
 // ------------------------------------------------------------------ K7: product tree layer (grand_product.rs:20-36)
 __global__ void __launch_bounds__(LASSO_BLOCK) k_gp_layer(const fr_t* __restrict__ in, size_t half, fr_t* __restrict__ out) {
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x) out[i] = fr_mul(in[i], in[i + half]);
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x) out[i] = fr29_store(fr29_mul(fr29_unpack_u(in[i]), fr29_unpack_s(in[i + half])));
 }
 // the remaining small layers in one workgroup: in has `len` elements (len <= 2*blockDim.x), layers are laid out back to back
 __global__ void k_gp_tail(fr_t* __restrict__ tree, size_t len) {
   fr_t* in = tree;
   while (len > 2) {
     size_t half = len / 2; fr_t* out = in + len;
-    for (size_t i = threadIdx.x; i < half; i += blockDim.x) out[i] = fr_mul(in[i], in[i + half]);
+    for (size_t i = threadIdx.x; i < half; i += blockDim.x) out[i] = fr29_store(fr29_mul(fr29_unpack_u(in[i]), fr29_unpack_s(in[i + half])));
     __threadfence_block();
     __syncthreads();
     in = out; len = half;
@@ -275,37 +322,42 @@ __global__ void k_gp_tail(fr_t* __restrict__ tree, size_t len) {
 }
 
 // ------------------------------------------------------------------ K8: Reed-Solomon fingerprints (memory_checking.rs:236-310)
+// h(a, v, t) = t*gamma^2 + v*gamma + a - tau
 __global__ void __launch_bounds__(LASSO_BLOCK) k_fingerprint_ops(const fr_t* __restrict__ table, const uint32_t* __restrict__ dim, const fr_t* __restrict__ read, size_t s,
                                                                   fr_t gamma, fr_t gamma2, fr_t tau, fr_t* __restrict__ out_r, fr_t* __restrict__ out_w) {
+  const fr29 gs = fr29_unpack_s(gamma), g2s = fr29_unpack_s(gamma2), g2u = fr29_unpack_u(gamma2), tu = fr29_unpack_u(tau), r2s = fr29_r2s();
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < s; i += (size_t)gridDim.x * blockDim.x) {
-    uint32_t a = dim[i];
-    fr_t h = fr_add(fr_mul(read[i], gamma2), fr_mul(table[a], gamma));
-    h = fr_sub(fr_add(h, fr_from_u64(a)), tau);
-    out_r[i] = h;
-    out_w[i] = fr_add(h, gamma2);   // ts+1: (t+1)*gamma^2 = t*gamma^2 + gamma^2
+    const uint32_t a = dim[i];
+    fr29 h = fr29_add(fr29_mul(fr29_unpack_u(read[i]), g2s), fr29_mul(fr29_unpack_u(table[a]), gs));
+    h = fr29_canonical(fr29_sub(fr29_add(h, fr29_mul(fr29_from_u64_int(a), r2s)), tu));
+    out_r[i] = fr29_pack(h);
+    out_w[i] = fr29_store(fr29_add(h, g2u));   // ts+1: (t+1)*gamma^2 = t*gamma^2 + gamma^2
   }
 }
 __global__ void __launch_bounds__(LASSO_BLOCK) k_fingerprint_mem(const fr_t* __restrict__ table, const fr_t* __restrict__ fin, size_t m, fr_t gamma, fr_t gamma2, fr_t tau,
                                                                   fr_t* __restrict__ out_i, fr_t* __restrict__ out_f) {
+  const fr29 gs = fr29_unpack_s(gamma), g2s = fr29_unpack_s(gamma2), tu = fr29_unpack_u(tau), r2s = fr29_r2s();
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < m; i += (size_t)gridDim.x * blockDim.x) {
-    fr_t h = fr_sub(fr_add(fr_mul(table[i], gamma), fr_from_u64(i)), tau);
-    out_i[i] = h;
-    out_f[i] = fr_add(h, fr_mul(fin[i], gamma2));
+    const fr29 h = fr29_canonical(fr29_sub(fr29_add(fr29_mul(fr29_unpack_u(table[i]), gs), fr29_mul(fr29_from_u64_int(i), r2s)), tu));
+    out_i[i] = fr29_pack(h);
+    out_f[i] = fr29_store(fr29_add(h, fr29_mul(fr29_unpack_u(fin[i]), g2s)));
   }
 }
 
 // ------------------------------------------------------------------ small conversions / gathers
 __global__ void __launch_bounds__(LASSO_BLOCK) k_from_u32(const uint32_t* __restrict__ src, size_t n, fr_t* __restrict__ dst) {
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = fr_from_u64(src[i]);
+  const fr29 r2s = fr29_r2s();
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = fr29_store(fr29_mul(fr29_from_u64_int(src[i]), r2s));
 }
 __global__ void __launch_bounds__(LASSO_BLOCK) k_gather(const fr_t* __restrict__ table, const uint32_t* __restrict__ idx, size_t n, fr_t* __restrict__ out) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = table[idx[i]];
 }
-
 __global__ void k_read_heads(PtrTable polys, uint32_t k, fr_t* __restrict__ out) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < k) out[i] = polys.p[i][0];
 }
+// Montgomery memory form -> the canonical integer (ark-ff into_bigint): x*2^256 * 2^5 / 2^261 = x
+__device__ __forceinline__ fr_t fr29_to_integer(const fr29& u) { fr29 k32 = fr29_zero(); k32.v[0] = 32; return fr29_store(fr29_mul(u, k32)); }
 
 // ------------------------------------------------------------------ K11: L*Z mat-vec (dense_mlpoly.rs:184-207)
 // grid = (column blocks, row chunks); partials[chunk*R + col] = sum_{j in chunk} L[j] * Z[j*R + col]
@@ -314,14 +366,14 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_matvec_left(const fr_t* __restr
   size_t col = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (col >= r_size) return;
   size_t j0 = (size_t)blockIdx.y * rows_per_chunk, j1 = j0 + rows_per_chunk; if (j1 > l_size) j1 = l_size;
-  fr_t acc = fr_zero();
-  for (size_t j = j0; j < j1; j++) acc = fr_add(acc, fr_mul(Lv[j], Z[j * r_size + col]));
-  partials[(size_t)blockIdx.y * r_size + col] = acc;
+  fr29 acc = fr29_zero(); uint32_t cnt = 0;
+  for (size_t j = j0; j < j1; j++) acc_add(acc, fr29_mul(fr29_unpack_u(Z[j * r_size + col]), fr29_unpack_s(Lv[j])), cnt);
+  partials[(size_t)blockIdx.y * r_size + col] = fr29_store(fr29_mul(acc, fr29_one_s()));
 }
 __global__ void __launch_bounds__(LASSO_BLOCK) k_matvec_reduce(const fr_t* __restrict__ partials, size_t nchunks, size_t r_size, fr_t* __restrict__ out) {
   size_t col = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (col >= r_size) return;
-  fr_t acc = fr_zero();
-  for (size_t c = 0; c < nchunks; c++) acc = fr_add(acc, partials[c * r_size + col]);
-  out[col] = acc;
+  fr29 acc = fr29_zero(); uint32_t cnt = 0;
+  for (size_t c = 0; c < nchunks; c++) acc_add(acc, fr29_unpack_u(partials[c * r_size + col]), cnt);
+  out[col] = fr29_store(fr29_mul(acc, fr29_one_s()));
 }

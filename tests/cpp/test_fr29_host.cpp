@@ -1,0 +1,74 @@
+// CPU check of lasso_amd/csrc/fr29.cuh (the 29-bit-limb Fr form the polynomial kernels compute in) against fr.cuh's Montgomery
+// arithmetic, which tests/cpp/test_arith_host.cpp pins to the oracle.  Exercises the bounds the kernels rely on (loose operands,
+// negative values, sums of thousands of terms through the column form).
+#include "../../lasso_amd/csrc/fr29.cuh"
+#include <random>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+static std::mt19937_64 rng(4242);
+static fr_t rand_fr() { for (;;) { uint64_t l[4]; for (int i = 0; i < 4; i++) l[i] = rng(); l[3] &= (~0ull) >> 3; fr_t t; memcpy(t.v, l, 32); if (!fr_geq_p(t.v)) return t; } }
+static bool same(const fr_t& a, const fr_t& b) { return memcmp(a.v, b.v, 32) == 0; }
+#define CHECK(c) do { if (!(c)) { printf("FAIL %s line %d\n", #c, __LINE__); return 1; } } while (0)
+
+int main() {
+  std::vector<fr_t> xs{fr_zero(), fr_one(), fr_neg(fr_one()), fr_from_u64(2), fr_from_u64(~0ull)};
+  { fr_t pm1; const uint32_t e[8] = {FR_P0 - 1u, FR_P1, FR_P2, FR_P3, 0, 0, 0, FR_P7}; memcpy(pm1.v, e, 32); xs.push_back(pm1); }   // memory integer p-1
+  for (int i = 0; i < 400; i++) xs.push_back(rand_fr());
+  const size_t N = xs.size();
+  for (size_t i = 0; i < N; i++) {
+    const fr_t &a = xs[i], &b = xs[(i * 7 + 3) % N], &c = xs[(i * 11 + 5) % N];
+    fr29 au = fr29_unpack_u(a), bu = fr29_unpack_u(b), cu = fr29_unpack_u(c), as = fr29_unpack_s(a), bs = fr29_unpack_s(b);
+    CHECK(same(fr29_pack(au), a));                                   // unpack/pack round trip
+    CHECK(same(fr29_store(au), a));
+    CHECK(same(fr29_store(fr29_mul(au, bs)), fr_mul(a, b)));         // mul(u, s) = u-form of the product
+    CHECK(same(fr29_store(fr29_mul(as, bu)), fr_mul(a, b)));
+    CHECK(same(fr29_store(fr29_mul(au, fr29_one_s())), a));          // ONE_S is the multiplicative identity of the radix
+    // bind: lo + r*(hi - lo) with a negative difference
+    CHECK(same(fr29_store(fr29_add(au, fr29_mul(fr29_sub(bu, au), fr29_unpack_s(c)))), fr_add(a, fr_mul(c, fr_sub(b, a)))));
+    // cubic term at x = 3: (3hi - 2lo) products, deficient by 2^10, corrected once with K10
+    {
+      fr29 da = fr29_sub(bu, au), a2 = fr29_weak(fr29_add(bu, da)), a3 = fr29_add(a2, da);          // a3 loose
+      fr29 dc = fr29_sub(au, cu), c2 = fr29_weak(fr29_add(au, dc)), c3 = fr29_weak(fr29_add(c2, dc));
+      fr29 t = fr29_mul(fr29_mul(a3, c3), a3);
+      fr_t a3r = fr_add(fr_add(b, fr_sub(b, a)), fr_sub(b, a)), c3r = fr_add(fr_add(a, fr_sub(a, c)), fr_sub(a, c));
+      CHECK(same(fr29_store(fr29_mul(t, fr29_k10())), fr_mul(fr_mul(a3r, c3r), a3r)));
+    }
+    CHECK(same(fr29_store(fr29_mul(fr29_mul(fr29_mul(au, bs), cu), fr29_k5())), fr_mul(fr_mul(a, b), c)));   // one 2^5 short -> K5
+    // canonical over the whole allowed range (-4p, 4p)
+    CHECK(same(fr29_store(fr29_sub(fr29_sub(au, bu), fr29_add(cu, bu))), fr_sub(fr_sub(a, b), fr_add(c, b))));
+    CHECK(same(fr29_store(fr29_add(fr29_add(au, bu), fr29_add(cu, au))), fr_add(fr_add(a, b), fr_add(c, a))));
+    CHECK(same(fr29_store(fr29_sub(fr29_zero(), au)), fr_neg(a)));
+    // from_u64 via R2S
+    uint64_t x = rng() >> (i % 64);
+    CHECK(same(fr29_store(fr29_mul(fr29_from_u64_int(x), fr29_r2s())), fr_from_u64(x)));
+    // to canonical integer: mul by the integer 2^5 (as limbs) = x*2^256*2^5/2^261 = x
+    { fr29 k32 = fr29_zero(); k32.v[0] = 32; CHECK(same(fr29_store(fr29_mul(au, k32)), fr_to_canonical(a))); }
+  }
+  // long accumulations through 64-bit columns: sum of T products, T up to 2^16, vs the reference sum
+  for (int T : {1, 2, 255, 4096, 65536}) {
+    int64_t col[9] = {0}; fr_t ref = fr_zero();
+    for (int i = 0; i < T; i++) {
+      const fr_t &a = xs[(size_t)i % N], &b = xs[((size_t)i * 13 + 1) % N];
+      fr29 t = fr29_mul(fr29_unpack_u(a), fr29_unpack_s(b));
+      for (int k = 0; k < 9; k++) col[k] += t.v[k];
+      ref = fr_add(ref, fr_mul(a, b));
+    }
+    fr29 s = fr29_from_columns(col);
+    CHECK(same(fr29_store(fr29_mul(s, fr29_one_s())), ref));
+  }
+  // per-thread style accumulation: weak after every add, fold with ONE_S every 128 terms
+  {
+    fr29 e = fr29_zero(); fr_t ref = fr_zero();
+    for (int i = 0; i < 1000; i++) {
+      const fr_t &a = xs[(size_t)i % N], &b = xs[((size_t)i * 5 + 2) % N];
+      e = fr29_weak(fr29_add(e, fr29_mul(fr29_unpack_u(a), fr29_unpack_s(b))));
+      if ((i & 127) == 127) e = fr29_mul(e, fr29_one_s());
+      ref = fr_add(ref, fr_mul(a, b));
+    }
+    CHECK(same(fr29_store(fr29_mul(e, fr29_one_s())), ref));
+  }
+  printf("OK\n");
+  return 0;
+}
