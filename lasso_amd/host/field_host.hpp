@@ -64,6 +64,27 @@ struct Pt {  // group element, extended coordinates over plain (non-Montgomery) 
   }
 };
 
+// Fixed-base scalar multiplication for the two generators every opening multiplies by fresh scalars (gens_1.G[0] = Q and h:
+// dot_product.rs:198-231 computes Cy, delta, beta from them): 64 windows x 15 multiples built once per generator set, then 64 additions.
+struct FixedBase {
+  std::vector<ed_point> tbl;   // tbl[w*16 + d] = d * 16^w * P
+  FixedBase() {}
+  explicit FixedBase(const Pt& P) : tbl(64 * 16) {
+    ed_point base = P.p;
+    for (int w = 0; w < 64; w++) {
+      tbl[w * 16] = ed_identity(); tbl[w * 16 + 1] = base;
+      for (int d = 2; d < 16; d++) tbl[w * 16 + d] = ed_add(tbl[w * 16 + d - 1], base);
+      base = ed_dbl(ed_dbl(ed_dbl(ed_dbl(base))));
+    }
+  }
+  Pt mul(const Sc& s) const {
+    uint32_t e[8]; s.canonical_limbs(e);
+    ed_point acc = ed_identity();
+    for (int w = 0; w < 64; w++) { uint32_t d = (e[w / 8] >> (4 * (w % 8))) & 15u; if (d) acc = ed_add(acc, tbl[w * 16 + d]); }
+    Pt r; r.p = acc; return r;
+  }
+};
+
 // ark-serialize compressed TE point: y (LE) with bit 7 of the last byte = "x is negative" (x > -x as canonical integers)
 inline void compress_affine(const fq_t& x, const fq_t& y, uint8_t out[32]) {
   fq_t yc = fq_canonical(y), xc = fq_canonical(x), nx = fq_canonical(fq_neg(x));

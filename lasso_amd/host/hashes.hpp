@@ -10,33 +10,32 @@
 
 namespace lasso {
 
+// State kept as 25 little-endian 64-bit lanes (x86-64 host: the byte view aliases them); the round function is fully unrolled —
+// the 4096-scalar vector appends of the opening proofs (dot_product.rs:196) push ~1 MB through STROBE per proof.
 class Keccak1600 {
+  static inline uint64_t rol(uint64_t v, int r) { return (v << r) | (v >> (64 - r)); }
+
  public:
-  uint8_t bytes[200];
+  union { uint64_t A[25]; uint8_t bytes[200]; };
   Keccak1600() { memset(bytes, 0, sizeof(bytes)); }
   void permute() {
-    uint64_t A[25];
-    for (int i = 0; i < 25; i++) { uint64_t w = 0; for (int b = 7; b >= 0; b--) w = (w << 8) | bytes[8 * i + b]; A[i] = w; }
+    static_assert(__BYTE_ORDER__ == __ORDER_LITTLE_ENDIAN__, "lane/byte aliasing assumes a little-endian host");
     static const uint64_t RC[24] = {0x1ULL, 0x8082ULL, 0x800000000000808aULL, 0x8000000080008000ULL, 0x808bULL, 0x80000001ULL, 0x8000000080008081ULL,
                                     0x8000000000008009ULL, 0x8aULL, 0x88ULL, 0x80008009ULL, 0x8000000aULL, 0x8000808bULL, 0x800000000000008bULL,
                                     0x8000000000008089ULL, 0x8000000000008003ULL, 0x8000000000008002ULL, 0x8000000000000080ULL, 0x800aULL,
                                     0x800000008000000aULL, 0x8000000080008081ULL, 0x8000000000008080ULL, 0x80000001ULL, 0x8000000080008008ULL};
-    static const int RHO[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
     for (int rnd = 0; rnd < 24; rnd++) {
-      uint64_t Cc[5], D[5], Bm[25];
-      for (int x = 0; x < 5; x++) Cc[x] = A[x] ^ A[x + 5] ^ A[x + 10] ^ A[x + 15] ^ A[x + 20];
-      for (int x = 0; x < 5; x++) { uint64_t n = Cc[(x + 1) % 5]; D[x] = Cc[(x + 4) % 5] ^ ((n << 1) | (n >> 63)); }
-      for (int i = 0; i < 25; i++) A[i] ^= D[i % 5];
-      for (int x = 0; x < 5; x++)
-        for (int y = 0; y < 5; y++) {  // rho + pi: B[y][2x+3y] = rot(A[x][y], r[x][y]); index = x + 5y
-          int src = x + 5 * y, dst = y + 5 * ((2 * x + 3 * y) % 5), r = RHO[src];
-          Bm[dst] = r ? ((A[src] << r) | (A[src] >> (64 - r))) : A[src];
-        }
-      for (int y = 0; y < 5; y++)
-        for (int x = 0; x < 5; x++) A[x + 5 * y] = Bm[x + 5 * y] ^ (~Bm[(x + 1) % 5 + 5 * y] & Bm[(x + 2) % 5 + 5 * y]);
+      // theta, rho + pi (B[y][2x+3y] = rot(A[x][y] ^ D[x], r[x][y]), index = x + 5y), chi, iota
+      const uint64_t C0 = A[0] ^ A[5] ^ A[10] ^ A[15] ^ A[20], C1 = A[1] ^ A[6] ^ A[11] ^ A[16] ^ A[21], C2 = A[2] ^ A[7] ^ A[12] ^ A[17] ^ A[22], C3 = A[3] ^ A[8] ^ A[13] ^ A[18] ^ A[23], C4 = A[4] ^ A[9] ^ A[14] ^ A[19] ^ A[24];
+      const uint64_t D0 = C4 ^ rol(C1, 1), D1 = C0 ^ rol(C2, 1), D2 = C1 ^ rol(C3, 1), D3 = C2 ^ rol(C4, 1), D4 = C3 ^ rol(C0, 1);
+      const uint64_t B0 = (A[0] ^ D0), B1 = rol((A[6] ^ D1), 44), B2 = rol((A[12] ^ D2), 43), B3 = rol((A[18] ^ D3), 21), B4 = rol((A[24] ^ D4), 14), B5 = rol((A[3] ^ D3), 28), B6 = rol((A[9] ^ D4), 20), B7 = rol((A[10] ^ D0), 3), B8 = rol((A[16] ^ D1), 45), B9 = rol((A[22] ^ D2), 61), B10 = rol((A[1] ^ D1), 1), B11 = rol((A[7] ^ D2), 6), B12 = rol((A[13] ^ D3), 25), B13 = rol((A[19] ^ D4), 8), B14 = rol((A[20] ^ D0), 18), B15 = rol((A[4] ^ D4), 27), B16 = rol((A[5] ^ D0), 36), B17 = rol((A[11] ^ D1), 10), B18 = rol((A[17] ^ D2), 15), B19 = rol((A[23] ^ D3), 56), B20 = rol((A[2] ^ D2), 62), B21 = rol((A[8] ^ D3), 55), B22 = rol((A[14] ^ D4), 39), B23 = rol((A[15] ^ D0), 41), B24 = rol((A[21] ^ D1), 2);
+      A[0] = B0 ^ (~B1 & B2); A[1] = B1 ^ (~B2 & B3); A[2] = B2 ^ (~B3 & B4); A[3] = B3 ^ (~B4 & B0); A[4] = B4 ^ (~B0 & B1);
+      A[5] = B5 ^ (~B6 & B7); A[6] = B6 ^ (~B7 & B8); A[7] = B7 ^ (~B8 & B9); A[8] = B8 ^ (~B9 & B5); A[9] = B9 ^ (~B5 & B6);
+      A[10] = B10 ^ (~B11 & B12); A[11] = B11 ^ (~B12 & B13); A[12] = B12 ^ (~B13 & B14); A[13] = B13 ^ (~B14 & B10); A[14] = B14 ^ (~B10 & B11);
+      A[15] = B15 ^ (~B16 & B17); A[16] = B16 ^ (~B17 & B18); A[17] = B17 ^ (~B18 & B19); A[18] = B18 ^ (~B19 & B15); A[19] = B19 ^ (~B15 & B16);
+      A[20] = B20 ^ (~B21 & B22); A[21] = B21 ^ (~B22 & B23); A[22] = B22 ^ (~B23 & B24); A[23] = B23 ^ (~B24 & B20); A[24] = B24 ^ (~B20 & B21);
       A[0] ^= RC[rnd];
     }
-    for (int i = 0; i < 25; i++) for (int b = 0; b < 8; b++) bytes[8 * i + b] = (uint8_t)(A[i] >> (8 * b));
   }
 };
 

@@ -175,12 +175,12 @@ struct GenStream {
 // PolyCommitmentGens for one polynomial size: gens_n = {G[0..n), h}, gens_1 = {G[n], h} with h = stream[n+1]  (DotProductProofGens::new(n) =
 // MultiCommitGens::new(n+1).split_at(n)); the device table holds [G_0..G_{n-1}, Q = G_n, h] so one MSM covers G, Q and h.
 struct PolyCommitmentGens {
-  size_t n = 0; Pt Q, h; std::vector<lasso_affine> affine; lasso_bases* bases = nullptr; const Dev* dev = nullptr;
+  size_t n = 0; Pt Q, h; FixedBase Qmul, hmul; std::vector<lasso_affine> affine; lasso_bases* bases = nullptr; const Dev* dev = nullptr;
   PolyCommitmentGens() {}
   PolyCommitmentGens(const Dev& d, const GenStream& gs, size_t num_vars) : dev(&d) {
     n = (size_t)1 << (num_vars - num_vars / 2);   // right = ell - ell/2 (eq_poly.rs:40-42)
     LASSO_REQUIRE(gs.pts.size() >= n + 2);
-    Q = gs.pts[n]; h = gs.pts[n + 1];
+    Q = gs.pts[n]; h = gs.pts[n + 1]; Qmul = FixedBase(Q); hmul = FixedBase(h);
     // affine Montgomery limbs for the ABI, one batch inversion
     std::vector<fq_t> pre(n + 2); fq_t acc = fq_one();
     for (size_t i = 0; i < n + 2; i++) { pre[i] = acc; acc = fq_mul(acc, gs.pts[i].p.Z); }
@@ -193,7 +193,7 @@ struct PolyCommitmentGens {
     d.chk(lasso_bases_create(d.ctx, affine.data(), n + 2, &bases), "lasso_bases_create");
   }
   PolyCommitmentGens(PolyCommitmentGens&& o) noexcept { *this = std::move(o); }
-  PolyCommitmentGens& operator=(PolyCommitmentGens&& o) noexcept { std::swap(n, o.n); std::swap(Q, o.Q); std::swap(h, o.h); affine.swap(o.affine); std::swap(bases, o.bases); std::swap(dev, o.dev); return *this; }
+  PolyCommitmentGens& operator=(PolyCommitmentGens&& o) noexcept { std::swap(n, o.n); std::swap(Q, o.Q); std::swap(h, o.h); std::swap(Qmul, o.Qmul); std::swap(hmul, o.hmul); affine.swap(o.affine); std::swap(bases, o.bases); std::swap(dev, o.dev); return *this; }
   ~PolyCommitmentGens() { if (bases && dev) lasso_bases_destroy(dev->ctx, bases); }
 };
 struct SparsePolyCommitmentGens {  // surge.rs:25-59
@@ -476,7 +476,7 @@ class Prover {
     d.chk(lasso_upload(d.ctx, d_b0.p, a_vec.data(), n * sizeof(lasso_fr)), "lasso_upload");
     { Sc one = Sc::one(); d.chk(lasso_upload(d.ctx, d_w0.p, &one, sizeof(lasso_fr)), "lasso_upload"); }
     compress_one(msm_dev(g, d_a0.p, n), buf); t.append_point_bytes("Cx", buf);  // Cx = <x, G> + 0*h   (commitments.rs:84-93)
-    compress_one(g.Q * y, buf); t.append_point_bytes("Cy", buf);                // Cy = y*G_1[0] + 0*h (commitments.rs:78-82)
+    compress_one(g.Qmul.mul(y), buf); t.append_point_bytes("Cy", buf);                // Cy = y*G_1[0] + 0*h (commitments.rs:78-82)
     t.append_scalars("a", a_vec);
     // bullet reduction (bullet.rs:40-154), blind = blind_x + blind_y = 0
     lasso_fr *a_cur = d_a0.p, *a_nxt = d_a1.p, *b_cur = d_b0.p, *b_nxt = d_b1.p, *w_cur = d_w0.p, *w_nxt = d_w1.p;
@@ -509,8 +509,8 @@ class Prover {
     d.chk(lasso_read_heads(d.ctx, hp, 2, heads), "lasso_read_heads");
     Sc x_hat = Sc::from_abi(heads[0]), a_hat = Sc::from_abi(heads[1]), y_hat = x_hat * a_hat;
     Pt g_hat = msm_dev(g, w_cur, n);                                             // G[0] after all folds = sum_j w_j G_j
-    compress_one(g_hat * dd + g.h * r_delta, P.delta); t.append_point_bytes("delta", P.delta);
-    compress_one(g.Q * dd + g.h * r_beta, P.beta); t.append_point_bytes("beta", P.beta);
+    compress_one(g_hat * dd + g.hmul.mul(r_delta), P.delta); t.append_point_bytes("delta", P.delta);
+    compress_one(g.Qmul.mul(dd) + g.hmul.mul(r_beta), P.beta); t.append_point_bytes("beta", P.beta);
     Sc c = t.challenge_scalar("c");
     P.z1 = dd + c * y_hat;
     P.z2 = a_hat * (c * blind_fin + r_beta) + r_delta;
