@@ -5,6 +5,7 @@
 #include <vector>
 #include <cstring>
 #include <cstdio>
+#include <cstdlib>
 #include "../../include/lasso_hip.h"
 #include "poly_kernels.cuh"
 #include "msm_kernels.cuh"
@@ -384,12 +385,12 @@ int32_t lasso_bases_create(lasso_ctx* c, const lasso_affine* points, size_t n, l
 }
 void lasso_bases_destroy(lasso_ctx* c, lasso_bases* b) { if (!b) return; if (c) (void)hipStreamSynchronize(c->stream); if (b->d_table) (void)hipFree(b->d_table); delete b; }
 
-// chunks per row: aim for >= 1024 workgroups but keep >= 4096 (digit, base) pairs per chunk.  Measured on MI355X (profiles/): the
-// kernel is VALU-issue-bound even at one wave per SIMD (the 81 independent multiply-adds of a field product pipeline back to back), so
-// smaller chunks only multiply the fixed per-workgroup reduction tree: 2 x 482 chunks of 1024 pairs ran 310 us, 2 x 129 of 4096 ran 180 us.
+// chunks per row.  Measured on MI355X (profiles/): the bucket kernel is VALU-issue-bound even at one wave per SIMD (the 81 independent
+// multiply-adds of a field product pipeline back to back), so extra workgroups beyond one per CU only multiply the fixed per-workgroup
+// reduction tree (2 rows x 482 chunks ran 310 us, 2 x 129 ran 180 us).  Aim for rows*K = 256 workgroups, never below 1024 pairs a chunk.
 static size_t msm_chunks(size_t rows, size_t n_cols, uint32_t W) {
   size_t pairs = n_cols * W, K = 1;
-  if (rows < 1024) { K = (1024 + rows - 1) / rows; size_t kmax = (pairs + 4095) / 4096; if (kmax < 1) kmax = 1; if (K > kmax) K = kmax; if (K > 256) K = 256; }
+  if (rows < 256) { K = 256 / rows; size_t kmax = (pairs + 1023) / 1024; if (kmax < 1) kmax = 1; if (K > kmax) K = kmax; }
   size_t cols_per_chunk = (n_cols + K - 1) / K;
   return (n_cols + cols_per_chunk - 1) / cols_per_chunk;
 }

@@ -6,12 +6,10 @@
 //    bucket set, with no per-window bucket reduction and no doubling chain at all;
 //  * 4-bit unsigned digits = the nibbles of the canonical little-endian scalar; zero digits are skipped, so
 //    the reference's small-scalar shortcut (msm/mod.rs:95-106) is automatic: a 16-bit scalar costs <= 4 adds;
-//  * one 256-thread workgroup owns one bucket set, split into 16 column slices x 16 digits = 256 bins, one per
-//    thread: real Lasso scalars are heavily skewed (timestamp high nibbles, popcount-skewed AND values) and a
-//    single thread per digit would serialise half a row; the slice split bounds the imbalance to ~3x;
-//  * (bin, table-index) pairs are counting-sorted in LDS in batches of 4096, then thread t accumulates bin t in
-//    registers with 7-multiplication mixed adds;
-//  * reduction: LDS tree over the 16 slices, each digit lane scales its bucket (4 doublings + adds), tree over digits.
+//  * one 256-thread workgroup owns one bucket set (15 non-zero digits) for a chunk of columns; its threads are shared out over the
+//    digits in proportion to the digits' pair counts (see k_msm_buckets), so skewed scalars do not serialise on the busiest digit;
+//  * (digit, table-index) pairs are counting-sorted in LDS in batches of 8192, accumulated in registers with 7-multiplication mixed adds;
+//  * reduction: segmented LDS tree per digit, four bit-plane sums, one Horner chain of doublings.
 // Results are group elements, so any accumulation order is bit-identical after compression.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -56,12 +54,20 @@ __global__ void __launch_bounds__(256) k_fr_to_canonical(const fr_t* __restrict_
 }
 
 // grid = (chunks per row K, rows).  scal: canonical little-endian scalars, `bps` bytes each (4 or 32), row r at
-// scal + r*row_stride (bytes).  Windows 0..W-1 = nibble w of each scalar.  out[row*K + chunk] = partial sum (extended, plain Fq).
+// scal + r*row_stride (bytes).  Windows 0..W-1 = nibble w of each scalar.  out[row*K + chunk] = partial sum (extended, fe29 limbs).
+//
+// Work split inside the workgroup: (digit, base) pairs are counting-sorted by digit in LDS (16 column-slice sub-bins per digit keep the
+// LDS atomics apart), then the 256 threads are shared out over the 15 digits IN PROPORTION TO THEIR PAIR COUNTS — real Lasso scalars are
+// heavily skewed (timestamp high nibbles, popcount-skewed AND values: a one-thread-per-bin layout leaves the busiest bin 2-3x the
+// average) — every thread accumulates a strided share of its digit's pairs in registers (7-multiplication mixed adds, next table entry
+// fetched while the current one is added), a segmented LDS tree joins the threads of each digit, and sum_d d*B_d is taken through the four
+// bit planes S_b = sum_{d: bit b} B_d (three tree levels on 32 lanes) and one Horner chain 2(2(2 S_3 + S_2) + S_1) + S_0.
 __device__ __forceinline__ uint32_t msm_nibble(const uint8_t* s, uint32_t w) { return (reinterpret_cast<const uint32_t*>(s)[w >> 3] >> (4 * (w & 7))) & 15u; }
 __global__ void __launch_bounds__(MSM_THREADS) k_msm_buckets(const uint8_t* __restrict__ scal, uint32_t bps, uint32_t W, size_t row_stride, size_t n_cols, size_t cols_per_chunk,
                                                               const niels29* __restrict__ table, size_t table_stride, pt29* __restrict__ out) {
-  __shared__ __attribute__((aligned(16))) uint8_t raw[MSM_THREADS * sizeof(pt29)];  // sorted[] (16 KB) during accumulation, points (36 KB) during the tree
+  __shared__ __attribute__((aligned(16))) uint8_t raw[MSM_THREADS * sizeof(pt29)];  // sorted[] (32 KB) during accumulation, points (36 KB) during the trees
   __shared__ uint32_t counts[MSM_THREADS], start[MSM_THREADS], cursor[MSM_THREADS];
+  __shared__ uint32_t toff[17], tree_top;
   uint32_t* sorted = reinterpret_cast<uint32_t*>(raw);
   pt29* pts = reinterpret_cast<pt29*>(raw);
   const fe29 d2 = fe_d2();
@@ -71,43 +77,88 @@ __global__ void __launch_bounds__(MSM_THREADS) k_msm_buckets(const uint8_t* __re
   size_t c1 = c0 + cols_per_chunk; if (c1 > n_cols) c1 = n_cols;
   const uint32_t scalars_per_batch = MSM_BATCH / W;
   pt29 B = pt_identity();
+  uint32_t my_d = 0, my_j = 0, my_T = 0;   // this thread's digit, its rank among the digit's threads, and how many threads share the digit
   for (size_t b0 = c0; b0 < c1; b0 += scalars_per_batch) {
     size_t b1 = b0 + scalars_per_batch; if (b1 > c1) b1 = c1;
+    const uint32_t items = (uint32_t)(b1 - b0) * W;   // one item = one (scalar, window)
     counts[t] = 0;
     __syncthreads();
-    for (size_t c = b0 + t; c < b1; c += MSM_THREADS) {
-      const uint8_t* s = row + c * bps; const uint32_t slice = ((uint32_t)c & 15u) << 4;
-      for (uint32_t w = 0; w < W; w++) { uint32_t d = msm_nibble(s, w); if (d) atomicAdd(&counts[slice | d], 1u); }
+    for (uint32_t it = t; it < items; it += MSM_THREADS) {
+      const uint32_t ci = it / W, w = it - ci * W; const size_t c = b0 + ci;
+      const uint32_t d = msm_nibble(row + c * bps, w);
+      if (d) atomicAdd(&counts[(d << 4) | ((uint32_t)c & 15u)], 1u);
     }
     __syncthreads();
     start[t] = counts[t];
     __syncthreads();
-    for (uint32_t off = 1; off < MSM_THREADS; off <<= 1) { uint32_t v = t >= off ? start[t - off] : 0; __syncthreads(); start[t] += v; __syncthreads(); }
-    const uint32_t my_start = start[t] - counts[t];
-    cursor[t] = my_start;
+    for (uint32_t off = 1; off < MSM_THREADS; off <<= 1) { uint32_t v = t >= off ? start[t - off] : 0; __syncthreads(); start[t] += v; __syncthreads(); }   // inclusive scan
+    cursor[t] = start[t] - counts[t];
     __syncthreads();
-    for (size_t c = b0 + t; c < b1; c += MSM_THREADS) {
-      const uint8_t* s = row + c * bps; const uint32_t slice = ((uint32_t)c & 15u) << 4;
-      for (uint32_t w = 0; w < W; w++) { uint32_t d = msm_nibble(s, w); if (d) sorted[atomicAdd(&cursor[slice | d], 1u)] = (uint32_t)(w * table_stride + c); }
+    for (uint32_t it = t; it < items; it += MSM_THREADS) {
+      const uint32_t ci = it / W, w = it - ci * W; const size_t c = b0 + ci;
+      const uint32_t d = msm_nibble(row + c * bps, w);
+      if (d) sorted[atomicAdd(&cursor[(d << 4) | ((uint32_t)c & 15u)], 1u)] = (uint32_t)(w * table_stride + c);
+    }
+    if (b0 == c0) {
+      // share the threads out over digits 1..15 from the first batch's histogram (later batches of the same row have the same statistics);
+      // every digit keeps at least one thread, so no pair of a later batch can be orphaned
+      if (t == 0) {
+        const uint32_t total = start[MSM_THREADS - 1];
+        uint32_t acc = 0, top = 1; toff[0] = 0; toff[1] = 0;
+        for (uint32_t d = 1; d < 16; d++) {
+          const uint32_t cnt = start[d * 16 + 15] - (start[d * 16] - counts[d * 16]);
+          const uint32_t T = 1 + (total ? (uint32_t)(((uint64_t)cnt * (MSM_THREADS - 15)) / total) : 0);
+          acc += T; toff[d + 1] = acc; if (T > top) top = T;
+        }
+        uint32_t p2 = 1; while (p2 < top) p2 <<= 1;
+        tree_top = p2 >> 1;
+      }
+      __syncthreads();
+      for (uint32_t d = 1; d < 16; d++) if (t >= toff[d] && t < toff[d + 1]) { my_d = d; my_j = t - toff[d]; my_T = toff[d + 1] - toff[d]; }
     }
     __syncthreads();
-    const uint32_t cnt = counts[t];
-    for (uint32_t k = 0; k < cnt; k++) B = pt_madd(B, table[sorted[my_start + k]]);
+    if (my_T) {
+      const uint32_t lo = start[my_d * 16] - counts[my_d * 16], hi = start[my_d * 16 + 15];
+      uint32_t pos = lo + my_j;
+      if (pos < hi) {
+        niels29 cur = table[sorted[pos]];
+        for (pos += my_T; pos < hi; pos += my_T) { const niels29 nxt = table[sorted[pos]]; B = pt_madd(B, cur); cur = nxt; }
+        B = pt_madd(B, cur);
+      }
+    }
     __syncthreads();
   }
-  // bins -> buckets: tree over the 16 column slices (bin t = slice*16 + digit)
+  // segmented tree: the threads of one digit are contiguous; pts[toff[d]] ends up holding B_d
   pts[t] = B;
   __syncthreads();
-  for (uint32_t s = 8; s > 0; s >>= 1) { if ((t >> 4) < s) pts[t] = pt_add(pts[t], pts[t + 16 * s], d2); __syncthreads(); }
-  // sum_d d * B_d over the 15 non-zero digits
-  if (t < 16) {
-    pt29 Bd = pts[t], acc = pt_identity();
-    for (int bit = 3; bit >= 0; bit--) { acc = pt_dbl(acc); if ((t >> bit) & 1u) acc = pt_add(acc, Bd, d2); }
-    pts[t] = acc;
+  for (uint32_t s = tree_top; s > 0; s >>= 1) {
+    pt29 sum;
+    const bool act = my_j < s && my_j + s < my_T;
+    if (act) sum = pt_add(pts[t], pts[t + s], d2);
+    __syncthreads();
+    if (act) pts[t] = sum;
+    __syncthreads();
   }
+  // bit planes: lane (b, i), i < 8, takes the i-th digit that has bit b set
+  pt29 P;
+  const uint32_t b = t >> 3, i = t & 7;
+  if (t < 32) { const uint32_t d = ((i >> b) << (b + 1)) | (1u << b) | (i & ((1u << b) - 1)); P = pts[toff[d]]; }
   __syncthreads();
-  for (uint32_t s = 8; s > 0; s >>= 1) { if (t < s) pts[t] = pt_add(pts[t], pts[t + s], d2); __syncthreads(); }
-  if (t == 0) out[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = pts[0];
+  if (t < 32) pts[t] = P;
+  __syncthreads();
+  for (uint32_t s = 4; s > 0; s >>= 1) {
+    if (t < 32 && i < s) P = pt_add(P, pts[t + s], d2);
+    __syncthreads();
+    if (t < 32 && i < s) pts[t] = P;
+    __syncthreads();
+  }
+  if (t == 0) {
+    pt29 acc = pts[24];                                   // S_3
+    acc = pt_add(pt_dbl(acc), pts[16], d2);               // 2 S_3 + S_2
+    acc = pt_add(pt_dbl(acc), pts[8], d2);
+    acc = pt_add(pt_dbl(acc), pts[0], d2);
+    out[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = acc;
+  }
 }
 
 // out[row] = sum_k partial[row*K + k], converted to ark's Montgomery limbs.  One workgroup per row; thread t first adds partials
