@@ -71,6 +71,9 @@ int32_t lasso_prof_reset(lasso_ctx* ctx);
 /* launches, total milliseconds and algorithmic bytes (SURVEY.md §8d definitions) recorded for one kernel family */
 int32_t lasso_prof_get(lasso_ctx* ctx, int32_t kernel_id, uint64_t* launches, double* total_ms, double* alg_bytes);
 
+/* Host-side latency accounting: number of device->host result hand-offs (flag waits) and the host time spent spinning on them since the last reset. */
+int32_t lasso_wait_stats(lasso_ctx* ctx, uint64_t* waits, double* wait_us, int32_t reset);
+
 /* ---- polynomial kernels -------------------------------------------------------------------- */
 /* DensePolynomial::from_usize (src/poly/dense_mlpoly.rs:263-269): d_dst[i] = Fr::from(d_src[i]) */
 int32_t lasso_fr_from_u32(lasso_ctx* ctx, const uint32_t* d_src, size_t n, lasso_fr* d_dst);

@@ -34,6 +34,7 @@ def declare(lib):
         "lasso_prof_enable": (i32, [vp, i32]),
         "lasso_prof_reset": (i32, [vp]),
         "lasso_prof_get": (i32, [vp, i32, P(u64), P(C.c_double), P(C.c_double)]),
+        "lasso_wait_stats": (i32, [vp, P(u64), P(C.c_double), i32]),
         "lasso_fr_from_u32": (i32, [vp, vp, sz, vp]),
         "lasso_gather": (i32, [vp, vp, vp, sz, vp]),
         "lasso_eq_evals": (i32, [vp, vp, u32, vp]),

@@ -6,6 +6,7 @@
 #include <cstring>
 #include <cstdio>
 #include <cstdlib>
+#include <ctime>
 #include "../../include/lasso_hip.h"
 #include "poly_kernels.cuh"
 #include "msm_kernels.cuh"
@@ -38,6 +39,7 @@ struct lasso_ctx {
   size_t small_cap = 0;
   uint32_t* h_flag = nullptr; uint32_t* d_flag = nullptr; // sequence flag (mapped), device alias
   uint32_t seq = 0;
+  uint64_t stat_waits = 0; double stat_wait_us = 0;        // host time spent spinning on the flag (lasso_wait_stats)
   fr_t* d_big = nullptr; fr_t* h_big = nullptr; size_t big_cap = 0;   // large results (matvec rows): device buffer + pinned mirror, hipMemcpyAsync
   uint32_t* d_flags = nullptr;
   uint32_t* d_counters = nullptr;                         // arrival tickets of the in-launch reductions (zero between launches)
@@ -105,8 +107,10 @@ static inline unsigned grid_for(size_t n, unsigned cap = 2048) { size_t g = (n +
 static inline fr_t to_fr(const lasso_fr* p) { fr_t r; memcpy(r.v, p, 32); return r; }
 // Wait until the device has stored sequence number `seq` to the mapped flag, then copy `count` results out of the mapped buffer.
 // The producer's stores to h_small are ordered before the flag by a system-scope release on the device (k_publish / publish_flag).
+static inline double now_us() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; }
 static int32_t wait_flag(lasso_ctx* c, uint32_t seq, size_t count, lasso_fr* out) {
   uint64_t spins = 0;
+  const double t0 = now_us();
   while (__atomic_load_n(c->h_flag, __ATOMIC_ACQUIRE) != seq) {
     if ((++spins & 0xffff) == 0) {   // a faulted or finished stream can never raise the flag: stop spinning
       hipError_t q = hipStreamQuery(c->stream);
@@ -115,6 +119,7 @@ static int32_t wait_flag(lasso_ctx* c, uint32_t seq, size_t count, lasso_fr* out
     }
     __builtin_ia32_pause();
   }
+  c->stat_waits++; c->stat_wait_us += now_us() - t0;
   memcpy(out, c->h_small, count * sizeof(fr_t));
   return 0;
 }
@@ -172,6 +177,7 @@ int32_t lasso_copy(lasso_ctx* c, void* d, const void* s, size_t n) { REQUIRE(c, 
 int32_t lasso_zero(lasso_ctx* c, void* d, size_t n) { REQUIRE(c, d); HIPCHK(c, hipMemsetAsync(d, 0, n, c->stream)); return 0; }
 int32_t lasso_sync(lasso_ctx* c) { HIPCHK(c, hipStreamSynchronize(c->stream)); return 0; }
 
+int32_t lasso_wait_stats(lasso_ctx* c, uint64_t* waits, double* wait_us, int32_t reset) { REQUIRE(c, waits && wait_us); *waits = c->stat_waits; *wait_us = c->stat_wait_us; if (reset) { c->stat_waits = 0; c->stat_wait_us = 0; } return 0; }
 int32_t lasso_prof_enable(lasso_ctx* c, int32_t mask) { prof_flush(c); c->prof_mask = (uint32_t)mask; return 0; }
 int32_t lasso_prof_reset(lasso_ctx* c) { prof_flush(c); for (int i = 0; i < LASSO_K_COUNT; i++) { c->prof_launches[i] = 0; c->prof_ms[i] = 0; c->prof_bytes[i] = 0; } return 0; }
 int32_t lasso_prof_get(lasso_ctx* c, int32_t k, uint64_t* launches, double* ms, double* bytes) {
@@ -219,14 +225,20 @@ int32_t lasso_bind_top(lasso_ctx* c, lasso_fr* const* d_polys, uint32_t npolys, 
   hipLaunchKernelGGL(k_bind_top, dim3(grid_for(half, 4096), npolys), dim3(LASSO_BLOCK), 0, c->stream, T, half, to_fr(r));
   HIPCHK(c, hipGetLastError()); return 0;
 }
+#define CUBIC_SMALL_Q 64   // rounds with at most this many indices per circuit take the latency-shaped kernel
 int32_t lasso_sumcheck_cubic_round(lasso_ctx* c, const lasso_fr* const* d_A, const lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_C, size_t n, lasso_fr* out) {
   REQUIRE(c, d_A && d_B && d_C && out && ncirc >= 1 && ncirc <= LASSO_MAX_PTRS && n >= 2 && (n & (n - 1)) == 0);
-  PtrTable A, B; for (uint32_t i = 0; i < ncirc; i++) { REQUIRE(c, d_A[i] && d_B[i]); A.p[i] = (const fr_t*)d_A[i]; B.p[i] = (const fr_t*)d_B[i]; }
-  const size_t half = n / 2; const unsigned nx = grid_for(half, 512);
-  int32_t rc = ensure_scratch(c, (size_t)nx * ncirc * 3 * sizeof(fr_t)); if (rc) return rc;
-  rc = ensure_small(c, (size_t)ncirc * 3); if (rc) return rc;
+  const size_t half = n / 2;
+  int32_t rc = ensure_small(c, (size_t)ncirc * 3); if (rc) return rc;
   const uint32_t seq = ++c->seq;
-  {
+  if (half <= CUBIC_SMALL_Q) {
+    MutPtrTable A, B; for (uint32_t i = 0; i < ncirc; i++) { REQUIRE(c, d_A[i] && d_B[i]); A.p[i] = (fr_t*)d_A[i]; B.p[i] = (fr_t*)d_B[i]; }   // read-only in this mode
+    ProfScope ps(c, LASSO_K_CUBIC, 32.0 * n * (2.0 * ncirc + 1.0));
+    hipLaunchKernelGGL((k_cubic_small<false>), dim3(ncirc), dim3(LASSO_BLOCK), 0, c->stream, A, B, (const fr_t*)d_C, (fr_t*)nullptr, (uint32_t)half, fr_zero(), c->d_counters, c->d_small, c->d_flag, seq);
+  } else {
+    PtrTable A, B; for (uint32_t i = 0; i < ncirc; i++) { REQUIRE(c, d_A[i] && d_B[i]); A.p[i] = (const fr_t*)d_A[i]; B.p[i] = (const fr_t*)d_B[i]; }
+    const unsigned nx = grid_for(half, 512);
+    rc = ensure_scratch(c, (size_t)nx * ncirc * 3 * sizeof(fr_t)); if (rc) return rc;
     ProfScope ps(c, LASSO_K_CUBIC, 32.0 * n * (2.0 * ncirc + 1.0));
     hipLaunchKernelGGL(k_cubic_round_lb, dim3(nx, ncirc), dim3(LASSO_BLOCK), 0, c->stream, A, B, (const fr_t*)d_C, half, (fr_t*)c->d_scratch, c->d_counters, c->d_small, c->d_flag, seq);
   }
@@ -237,14 +249,19 @@ int32_t lasso_sumcheck_cubic_round_fused(lasso_ctx* c, lasso_fr* const* d_A, las
                                          const lasso_fr* r, lasso_fr* out) {
   REQUIRE(c, d_A && d_B && d_C_in && d_C_out && d_C_in != d_C_out && r && out && ncirc >= 1 && ncirc <= LASSO_MAX_PTRS && n >= 4 && (n & (n - 1)) == 0);
   MutPtrTable A, B; for (uint32_t i = 0; i < ncirc; i++) { REQUIRE(c, d_A[i] && d_B[i]); A.p[i] = (fr_t*)d_A[i]; B.p[i] = (fr_t*)d_B[i]; }
-  const size_t q = n / 4; const unsigned nx = grid_for(q, 512);
-  int32_t rc = ensure_scratch(c, (size_t)nx * ncirc * 3 * sizeof(fr_t)); if (rc) return rc;
-  rc = ensure_small(c, (size_t)ncirc * 3); if (rc) return rc;
+  const size_t q = n / 4;
+  int32_t rc = ensure_small(c, (size_t)ncirc * 3); if (rc) return rc;
   const uint32_t seq = ++c->seq;
   {
     // bind: read 32n + write 16n per polynomial (2*ncirc + 1 of them); the evaluation of the next round rides on the same pass
     ProfScope ps(c, LASSO_K_BIND, 48.0 * n * (2.0 * ncirc + 1.0));
-    hipLaunchKernelGGL(k_cubic_fused, dim3(nx, ncirc), dim3(LASSO_BLOCK), 0, c->stream, A, B, (const fr_t*)d_C_in, (fr_t*)d_C_out, q, to_fr(r), (fr_t*)c->d_scratch, c->d_counters, c->d_small, c->d_flag, seq);
+    if (q <= CUBIC_SMALL_Q) {
+      hipLaunchKernelGGL((k_cubic_small<true>), dim3(ncirc), dim3(LASSO_BLOCK), 0, c->stream, A, B, (const fr_t*)d_C_in, (fr_t*)d_C_out, (uint32_t)q, to_fr(r), c->d_counters, c->d_small, c->d_flag, seq);
+    } else {
+      const unsigned nx = grid_for(q, 512);
+      rc = ensure_scratch(c, (size_t)nx * ncirc * 3 * sizeof(fr_t)); if (rc) return rc;
+      hipLaunchKernelGGL(k_cubic_fused, dim3(nx, ncirc), dim3(LASSO_BLOCK), 0, c->stream, A, B, (const fr_t*)d_C_in, (fr_t*)d_C_out, q, to_fr(r), (fr_t*)c->d_scratch, c->d_counters, c->d_small, c->d_flag, seq);
+    }
   }
   HIPCHK(c, hipGetLastError());
   return wait_flag(c, seq, (size_t)ncirc * 3, out);

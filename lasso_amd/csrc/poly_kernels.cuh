@@ -97,6 +97,7 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_reduce_partials(const fr_t* __r
 // plain stores -> agent-scope release -> drained vmcnt -> relaxed agent atomic ticket; the last arriver does ONE agent-scope acquire,
 // then reads plain.  `out` is host-mapped memory.  The row that finishes last raises the host's sequence flag: every row's stores are
 // released at system scope before its ticket, so the flag store (system-scope release) is ordered after all of them.
+__device__ __forceinline__ void row_done(uint32_t nrows, uint32_t* counters, uint32_t* flag, uint32_t seq);
 __device__ __forceinline__ void last_block_reduce(const fr_t* partials, uint32_t nx, uint32_t K, uint32_t y, uint32_t nrows, uint32_t* counters, fr_t* __restrict__ out, RedScratch& S,
                                                   uint32_t* flag, uint32_t seq) {
   __shared__ uint32_t is_last;
@@ -111,11 +112,7 @@ __device__ __forceinline__ void last_block_reduce(const fr_t* partials, uint32_t
   __syncthreads();
   if (!is_last) return;
   reduce_partials_row(partials, nx, K, y, out, S);
-  if (threadIdx.x == 0 && flag) {   // the <= 3 result stores were issued by this wave
-    __threadfence_system();
-    uint32_t t2 = __hip_atomic_fetch_add(&counters[LASSO_MAX_PTRS], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    if (t2 == nrows - 1) { counters[LASSO_MAX_PTRS] = 0; __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
-  }
+  row_done(nrows, counters, flag, seq);   // the <= 3 result stores were issued by wave 0
 }
 
 // ------------------------------------------------------------------ K1: bound_poly_var_top (dense_mlpoly.rs:209-216)
@@ -145,8 +142,21 @@ __device__ __forceinline__ void cubic_terms(const fr29& a0, const fr29& a1, cons
     e[0] = fr29_weak(fr29_add(e[0], t0)); e[1] = fr29_weak(fr29_add(e[1], t2)); e[2] = fr29_weak(fr29_add(e[2], t3));                    \
     if ((++cnt & 127u) == 0) { e[0] = fr29_mul(e[0], fr29_one_s()); e[1] = fr29_mul(e[1], fr29_one_s()); e[2] = fr29_mul(e[2], fr29_one_s()); } \
   } while (0)
-// block partials -> memory (K10 also supplies the missing 2^10), then the in-launch second stage
+// raise the host flag once every row (circuit) has stored its results: called by the workgroup that finished row y, stores issued by wave 0
+__device__ __forceinline__ void row_done(uint32_t nrows, uint32_t* counters, uint32_t* flag, uint32_t seq) {
+  if (threadIdx.x == 0 && flag) {
+    __threadfence_system();
+    uint32_t t2 = __hip_atomic_fetch_add(&counters[LASSO_MAX_PTRS], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (t2 == nrows - 1) { counters[LASSO_MAX_PTRS] = 0; __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+  }
+}
+// block partials -> memory (K10 also supplies the missing 2^10), then the in-launch second stage; a single-block row writes its result directly
 __device__ __forceinline__ void cubic_epilogue(const fr29* e, fr_t* __restrict__ partials, uint32_t* counters, fr_t* __restrict__ out, uint32_t* flag, uint32_t seq, RedScratch& S) {
+  if (gridDim.x == 1) {
+    store_block_partials<3>(e, 3, out + (size_t)blockIdx.y * 3, fr29_k10(), S);
+    row_done(gridDim.y, counters, flag, seq);
+    return;
+  }
   store_block_partials<3>(e, 3, partials + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 3, fr29_k10(), S);
   last_block_reduce(partials, gridDim.x, 3, blockIdx.y, gridDim.y, counters, out, S, flag, seq);
 }
@@ -191,6 +201,61 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_fused(MutPtrTable A, MutP
     CUBIC_ACCUMULATE(e, t0, t2, t3, cnt);
   }
   cubic_epilogue(e, partials, counters, out, flag, seq, S);
+}
+
+// Late rounds (q <= 64 indices per circuit): the same round, laid out for LATENCY instead of throughput.  One workgroup per circuit;
+// phase 1 gives every bind its own lane (6q products side by side instead of 6 in a row per thread), the bound values go to LDS; phase 2
+// gives every (index, evaluation point) its own lane, one wave per point; the three sums are 64-row column sums.  BIND = false is the
+// first round of a layer (no challenge yet): phase 1 only unpacks.  n_in = current length of A/B/C_in: 4q when BIND, 2q otherwise.
+template <bool BIND>
+__global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_small(MutPtrTable A, MutPtrTable B, const fr_t* __restrict__ C_in, fr_t* __restrict__ C_out, uint32_t q, fr_t r, uint32_t* counters,
+                                                              fr_t* __restrict__ out, uint32_t* flag, uint32_t seq) {
+  __shared__ fr29 bound[3][128];
+  __shared__ int32_t rows[192 * 9];
+  __shared__ int64_t cols[27];
+  const uint32_t t = threadIdx.x, y = blockIdx.x, m = 2 * q;   // m = length after the bind
+  const fr29 rs = fr29_unpack_s(r);
+  for (uint32_t item = t; item < 3 * m; item += LASSO_BLOCK) {
+    const uint32_t p = item / m, i = item - p * m;
+    fr_t* dst = p == 0 ? A.p[y] : p == 1 ? B.p[y] : C_out;
+    const fr_t* src = p == 2 ? C_in : dst;
+    fr29 v;
+    if (BIND) { v = bind29(src[i], src[i + m], rs); if (p < 2 || y == 0) dst[i] = fr29_pack(v); }
+    else v = fr29_unpack_u(src[i]);
+    bound[p][i] = v;
+  }
+  __syncthreads();
+  const uint32_t x = t >> 6, i = t & 63;   // wave x evaluates point {0, 2, 3}[x]
+  if (x < 3) {
+    fr29 term = fr29_zero();
+    if (i < q) {
+      const fr29 a0 = bound[0][i], a1 = bound[0][i + q], b0 = bound[1][i], b1 = bound[1][i + q], c0 = bound[2][i], c1 = bound[2][i + q];
+      if (x == 0) term = fr29_mul(c0, fr29_mul(a0, b0));
+      else {
+        const fr29 da = fr29_sub(a1, a0), db = fr29_sub(b1, b0), dc = fr29_sub(c1, c0);
+        const fr29 a2 = fr29_weak(fr29_add(a1, da)), b2 = fr29_weak(fr29_add(b1, db)), c2 = fr29_weak(fr29_add(c1, dc));
+        if (x == 1) term = fr29_mul(c2, fr29_mul(a2, b2));
+        else term = fr29_mul(fr29_add(c2, dc), fr29_mul(fr29_add(a2, da), fr29_weak(fr29_add(b2, db))));
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 9; k++) rows[t * 9 + k] = term.v[k];
+  }
+  __syncthreads();
+  if (t < 27) {
+    const uint32_t v = t / 9, k = t - v * 9;
+    int64_t sum = 0;
+    for (uint32_t j = 0; j < 64; j++) sum += rows[(v * 64 + j) * 9 + k];
+    cols[t] = sum;
+  }
+  __syncthreads();
+  if (t < 3) {
+    int64_t c[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) c[k] = cols[t * 9 + k];
+    out[(size_t)y * 3 + t] = fr29_store(fr29_mul(fr29_from_columns(c), fr29_k10()));
+  }
+  row_done(gridDim.x, counters, flag, seq);
 }
 
 // ------------------------------------------------------------------ g = S::combine_lookups (subtables/*.rs)

@@ -31,8 +31,16 @@ namespace lasso {
 struct Trace {
   static bool on() { static const bool v = [] { const char* e = getenv("LASSO_TRACE"); return e && e[0] == '1'; }(); return v; }
   const char* name; lasso_ctx* ctx; std::chrono::steady_clock::time_point t0; static int& depth() { static int d = 0; return d; }
-  Trace(const char* n, lasso_ctx* c) : name(n), ctx(c) { if (on()) { t0 = std::chrono::steady_clock::now(); depth()++; } }
-  ~Trace() { if (on()) { if (ctx) lasso_sync(ctx); depth()--; double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); fprintf(stderr, "[trace] %*s%s: time.busy=%.3fms\n", 2 * depth(), "", name, ms); } }
+  uint64_t w0 = 0; double wus0 = 0;
+  Trace(const char* n, lasso_ctx* c) : name(n), ctx(c) { if (on()) { t0 = std::chrono::steady_clock::now(); depth()++; if (ctx) lasso_wait_stats(ctx, &w0, &wus0, 0); } }
+  ~Trace() {
+    if (!on()) return;
+    if (ctx) lasso_sync(ctx);
+    depth()--;
+    double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    uint64_t w1 = 0; double wus1 = 0; if (ctx) lasso_wait_stats(ctx, &w1, &wus1, 0);
+    fprintf(stderr, "[trace] %*s%s: time.busy=%.3fms (device hand-offs %llu, host spinning %.3fms)\n", 2 * depth(), "", name, ms, (unsigned long long)(w1 - w0), (wus1 - wus0) * 1e-3);
+  }
 };
 
 struct Error : std::runtime_error { using std::runtime_error::runtime_error; };

@@ -80,7 +80,7 @@ def test_eq_evals(devs, ell):
     assert np.array_equal(a, b)
 
 
-@pytest.mark.parametrize("n,ncirc", [(2, 1), (4, 2), (1 << 9, 2), (1 << 13, 8), (1 << 16, 3)])
+@pytest.mark.parametrize("n,ncirc", [(2, 1), (4, 2), (16, 33), (128, 5), (256, 2), (1 << 9, 2), (1 << 13, 8), (1 << 16, 3)])   # n <= 128: latency-shaped kernel
 def test_sumcheck_cubic_round(devs, n, ncirc):
     rng = np.random.default_rng(n + ncirc)
     A = [rand_fr(rng, n) for _ in range(ncirc)]
@@ -342,7 +342,7 @@ def test_bullet_round_fused(devs, n, nk, fold):
         assert np.array_equal(x, y)
 
 
-@pytest.mark.parametrize("n,ncirc", [(4, 1), (8, 2), (1 << 10, 2), (1 << 14, 8), (1 << 17, 3)])
+@pytest.mark.parametrize("n,ncirc", [(4, 1), (8, 2), (32, 33), (256, 5), (512, 2), (1 << 10, 2), (1 << 14, 8), (1 << 17, 3)])   # n <= 256: latency-shaped kernel
 def test_sumcheck_cubic_round_fused(devs, n, ncirc):
     """bind with r then evaluate the next round in one pass == bind_top followed by the plain round (sumcheck.rs:49-120)"""
     rng = np.random.default_rng(n * 5 + ncirc)
