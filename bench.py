@@ -56,6 +56,17 @@ def cpu_baseline(kind_id, c, log_m, log_r, log_s):
             "sample": f"oracle (serial C++ restatement) prove, {kind_id=} C={c} M=2^{log_m} s=2^{log_s}: {tp.value:.2f}s (densify {td.value:.3f}s, commit {tc.value:.2f}s)"}
 
 
+def pmc_traffic():
+    """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (profiles/r01_pmc/bench_traffic.json, written by
+    tools/pmc_summary.py: FETCH_SIZE x2 per MI355X_MICROARCH.md's gfx950 correction + WRITE_SIZE, large launches only).  {} when absent."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc", "bench_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f)
+    except Exception:
+        return {}
+
+
 def main():
     a = parse()
     from lasso_amd import HostProver, _abi
@@ -88,10 +99,13 @@ def main():
     proof = None
     for _ in range(a.warmup):
         proof = hp.prove(dense, gens, S, r)
-    # HIP events bracket only the roofline kernel (bind_top = the north star's bound_poly_var) inside the timed region: bracketing
-    # all ~1500 launches of a proof costs ~25% wall time.  The full per-family table comes from one extra, untimed, profiled step.
+    # Roofline numbers are measured live, inside the timed region, with HIP events on the library's stream — but only around the launches
+    # in the HBM-bound regime (>= 256 MiB of algorithmic bytes, past the Infinity Cache: ~20 per proof), so the brackets cost nothing.
+    # Bracketing all ~950 launches of a proof adds ~8% wall time; that full per-family table comes from one extra, untimed, profiled step.
+    STREAM = [_abi.K_BIND, _abi.K_CUBIC, _abi.K_COMBINE, _abi.K_EQ, _abi.K_GP, _abi.K_FINGERPRINT, _abi.K_DOT, _abi.K_MATVEC]
+    LARGE_ONLY = 0x40000000
     if not a.no_prof:
-        dev_lib.lasso_prof_reset(ctx); dev_lib.lasso_prof_enable(ctx, 1 << _abi.K_BIND)
+        dev_lib.lasso_prof_reset(ctx); dev_lib.lasso_prof_enable(ctx, sum(1 << k for k in STREAM) | LARGE_ONLY)
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -99,22 +113,22 @@ def main():
     dev_lib.lasso_sync(ctx)
     elapsed = time.perf_counter() - t0
     barrier()
-    kernels = []
-    bind_timed = None
+
+    def family(kid, large):
+        n = C.c_uint64(); ms = C.c_double(); b = C.c_double()
+        (dev_lib.lasso_prof_get_large if large else dev_lib.lasso_prof_get)(ctx, kid, C.byref(n), C.byref(ms), C.byref(b))
+        if not n.value:
+            return None
+        return {"kernel": _abi.KERNEL_NAMES[kid], "launches": n.value, "ms": round(ms.value, 3), "alg_GB": round(b.value / 1e9, 3),
+                "alg_GBps": round(b.value / (ms.value * 1e-3) / 1e9, 1) if ms.value > 0 else None, "avg_launch_us": round(ms.value * 1e3 / n.value, 2)}
+    kernels, timed_large = [], {}
     if not a.no_prof:
         dev_lib.lasso_prof_enable(ctx, 0)
-        n = C.c_uint64(); ms = C.c_double(); b = C.c_double()
-        dev_lib.lasso_prof_get(ctx, _abi.K_BIND, C.byref(n), C.byref(ms), C.byref(b))
-        bind_timed = {"kernel": "bind_top", "launches": n.value, "ms": round(ms.value, 3), "alg_GB": round(b.value / 1e9, 3)}
+        timed_large = {k: family(k, True) for k in STREAM}
         dev_lib.lasso_prof_reset(ctx); dev_lib.lasso_prof_enable(ctx, (1 << _abi.K_COUNT) - 1)
-        hp.prove(dense, gens, S, r)                      # extra untimed step, every family bracketed
+        hp.prove(dense, gens, S, r)                      # extra untimed step, every launch of every family bracketed
         dev_lib.lasso_prof_enable(ctx, 0)
-        for kid, name in enumerate(_abi.KERNEL_NAMES):
-            n = C.c_uint64(); ms = C.c_double(); b = C.c_double()
-            dev_lib.lasso_prof_get(ctx, kid, C.byref(n), C.byref(ms), C.byref(b))
-            if n.value:
-                kernels.append({"kernel": name, "launches": n.value, "ms": round(ms.value, 3), "alg_GB": round(b.value / 1e9, 3),
-                                "alg_GBps": round(b.value / (ms.value * 1e-3) / 1e9, 1) if ms.value > 0 else None})
+        kernels = [f for f in (family(k, False) for k in range(_abi.K_COUNT)) if f]
     elapsed = grp.max_over_ranks(elapsed)
     digests = grp.gather_digests(proof)
 
@@ -131,17 +145,27 @@ def main():
                           "whole_bench_lookups_per_s": s / (t_densify + t_commit + ms_per_step / 1e3)}}
         if kernels:
             out["kernels_one_profiled_step"] = kernels
-            bind = bind_timed
-            stream_families = [k for k in kernels if k["kernel"] in ("bind_top", "sumcheck_cubic_round", "sumcheck_combine", "multi_dot", "matvec_left", "gp_build", "fingerprint", "eq_evals")]
-            dom = max(stream_families, key=lambda k: k["ms"]) if stream_families else None
-            def roof(k):
-                ach = k["alg_GB"] / (k["ms"] * 1e-3) if k["ms"] > 0 else 0.0
+            out["large_launches_timed"] = {v["kernel"]: {"per_step": v["launches"] // a.steps, "alg_bytes_per_launch": round(v["alg_GB"] * 1e9 / v["launches"])} for v in timed_large.values() if v}
+            traffic = pmc_traffic()
+            def roof(kid):
+                """HBM roofline of one kernel family from the launches bracketed inside the timed region (the HBM-bound regime)."""
+                k = timed_large.get(kid)
+                if not k:
+                    return None
+                ach = k["alg_GB"] / (k["ms"] * 1e-3)
+                allk = next((x for x in kernels if x["kernel"] == k["kernel"]), None)
+                tr = traffic.get(k["kernel"])
                 return {"kernel": k["kernel"], "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                        "traffic": None, "launches": k["launches"], "avg_launch_us": round(k["ms"] * 1e3 / k["launches"], 2)}
+                        "traffic": tr["bytes_per_launch"] if tr else None, "alg_bytes_per_launch": round(k["alg_GB"] * 1e9 / k["launches"]),
+                        "launches": k["launches"], "avg_launch_us": k["avg_launch_us"],
+                        "scope": "launches with >= 256 MiB algorithmic bytes, HIP events inside the timed region",
+                        "traffic_source": tr["source"] if tr else None,
+                        "all_launches_one_profiled_step": {"achieved": allk["alg_GBps"], "launches": allk["launches"], "avg_launch_us": allk["avg_launch_us"]} if allk else None}
+            stream = [k for k in kernels if k["kernel"] in [_abi.KERNEL_NAMES[i] for i in STREAM]]
+            dom = max(stream, key=lambda k: k["ms"]) if stream else None                      # dominant streaming kernel family by total time
             if dom:
-                out["roofline"] = roof(dom)
-            if bind:
-                out["roofline_bind_top"] = roof(bind)     # the kernel BASELINE.json's north_star names (bound_poly_var)
+                out["roofline"] = roof(_abi.KERNEL_NAMES.index(dom["kernel"]))
+            out["roofline_bind_top"] = roof(_abi.K_BIND)                                        # the kernel BASELINE.json's north_star names (bound_poly_var)
         if world == 1 and not a.no_cpu_baseline:
             cb = cpu_baseline(kind_id, c, log_m, S.log_r, min(a.cpu_log_s, a.log_s))
             if cb:

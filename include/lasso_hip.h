@@ -66,10 +66,14 @@ void* lasso_stream(lasso_ctx* ctx);                    /* the context's hipStrea
 /* ---- per-kernel timing (HIP events on the context's stream), for bench.py's roofline ------- */
 enum lasso_kernel_id { LASSO_K_BIND = 0, LASSO_K_CUBIC = 1, LASSO_K_COMBINE = 2, LASSO_K_EQ = 3, LASSO_K_GP = 4, LASSO_K_FINGERPRINT = 5,
                        LASSO_K_DOT = 6, LASSO_K_MATVEC = 7, LASSO_K_MSM = 8, LASSO_K_MISC = 9, LASSO_K_COUNT = 10 };
+#define LASSO_PROF_LARGE_ONLY 0x40000000   /* OR into the mask: bracket only launches of at least LASSO_PROF_LARGE_BYTES (a handful per proof: no measurable overhead) */
 int32_t lasso_prof_enable(lasso_ctx* ctx, int32_t family_mask);   /* bit k = bracket launches of lasso_kernel_id k; 0 = off */
 int32_t lasso_prof_reset(lasso_ctx* ctx);
 /* launches, total milliseconds and algorithmic bytes (SURVEY.md §8d definitions) recorded for one kernel family */
 int32_t lasso_prof_get(lasso_ctx* ctx, int32_t kernel_id, uint64_t* launches, double* total_ms, double* alg_bytes);
+/* the same, restricted to launches with at least LASSO_PROF_LARGE_BYTES algorithmic bytes (past the 256 MiB Infinity Cache: the HBM-bound regime) */
+#define LASSO_PROF_LARGE_BYTES 268435456.0
+int32_t lasso_prof_get_large(lasso_ctx* ctx, int32_t kernel_id, uint64_t* launches, double* total_ms, double* alg_bytes);
 
 /* Host-side latency accounting: number of device->host result hand-offs (flag waits) and the host time spent spinning on them since the last reset. */
 int32_t lasso_wait_stats(lasso_ctx* ctx, uint64_t* waits, double* wait_us, int32_t reset);

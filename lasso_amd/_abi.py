@@ -14,7 +14,7 @@ class Strategy(C.Structure):
 
 KINDS = {"and": 0, "or": 1, "xor": 2, "lt": 3, "range": 4}
 K_BIND, K_CUBIC, K_COMBINE, K_EQ, K_GP, K_FINGERPRINT, K_DOT, K_MATVEC, K_MSM, K_MISC, K_COUNT = range(11)
-KERNEL_NAMES = ["bind_top", "sumcheck_cubic_round", "sumcheck_combine", "eq_evals", "gp_build", "fingerprint", "multi_dot", "matvec_left", "msm", "misc"]
+KERNEL_NAMES = ["bind_top", "sumcheck_cubic_round(+fused bind)", "sumcheck_combine", "eq_evals", "gp_build", "fingerprint", "multi_dot", "matvec_left", "msm", "misc"]
 
 
 def declare(lib):
@@ -34,6 +34,7 @@ def declare(lib):
         "lasso_prof_enable": (i32, [vp, i32]),
         "lasso_prof_reset": (i32, [vp]),
         "lasso_prof_get": (i32, [vp, i32, P(u64), P(C.c_double), P(C.c_double)]),
+        "lasso_prof_get_large": (i32, [vp, i32, P(u64), P(C.c_double), P(C.c_double)]),
         "lasso_wait_stats": (i32, [vp, P(u64), P(C.c_double), i32]),
         "lasso_fr_from_u32": (i32, [vp, vp, sz, vp]),
         "lasso_gather": (i32, [vp, vp, vp, sz, vp]),

@@ -46,6 +46,8 @@ struct lasso_ctx {
   uint32_t prof_mask = 0;   // bit k set = kernel family k is bracketed with events
   std::vector<EventPair> events; size_t events_used = 0;
   uint64_t prof_launches[LASSO_K_COUNT] = {0}; double prof_ms[LASSO_K_COUNT] = {0}; double prof_bytes[LASSO_K_COUNT] = {0};
+  // the same, restricted to launches whose algorithmic bytes exceed LASSO_PROF_LARGE_BYTES (past the 256 MiB Infinity Cache: the HBM-bound regime)
+  uint64_t big_launches[LASSO_K_COUNT] = {0}; double big_ms[LASSO_K_COUNT] = {0}; double big_bytes[LASSO_K_COUNT] = {0};
 };
 struct lasso_bases { size_t n = 0; niels29* d_table = nullptr; };
 
@@ -87,6 +89,7 @@ struct ProfScope {
   lasso_ctx* c; int idx = -1;
   ProfScope(lasso_ctx* c_, int kid, double bytes) : c(c_) {
     if (!((c->prof_mask >> kid) & 1u)) return;
+    if ((c->prof_mask & 0x40000000u) && bytes < LASSO_PROF_LARGE_BYTES) return;   // LASSO_PROF_LARGE_ONLY: leave the latency-bound launches unbracketed
     if (c->events_used == c->events.size()) { EventPair p; if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return; c->events.push_back(p); }
     idx = (int)c->events_used++;
     c->events[idx].kid = kid; c->events[idx].bytes = bytes;
@@ -100,6 +103,7 @@ static void prof_flush(lasso_ctx* c) {
   for (size_t i = 0; i < c->events_used; i++) {
     float ms = 0; if (hipEventElapsedTime(&ms, c->events[i].a, c->events[i].b) != hipSuccess) continue;
     int k = c->events[i].kid; c->prof_launches[k]++; c->prof_ms[k] += ms; c->prof_bytes[k] += c->events[i].bytes;
+    if (c->events[i].bytes >= LASSO_PROF_LARGE_BYTES) { c->big_launches[k]++; c->big_ms[k] += ms; c->big_bytes[k] += c->events[i].bytes; }
   }
   c->events_used = 0;
 }
@@ -177,9 +181,13 @@ int32_t lasso_copy(lasso_ctx* c, void* d, const void* s, size_t n) { REQUIRE(c, 
 int32_t lasso_zero(lasso_ctx* c, void* d, size_t n) { REQUIRE(c, d); HIPCHK(c, hipMemsetAsync(d, 0, n, c->stream)); return 0; }
 int32_t lasso_sync(lasso_ctx* c) { HIPCHK(c, hipStreamSynchronize(c->stream)); return 0; }
 
+int32_t lasso_prof_get_large(lasso_ctx* c, int32_t k, uint64_t* launches, double* ms, double* bytes) {
+  REQUIRE(c, k >= 0 && k < LASSO_K_COUNT); prof_flush(c);
+  if (launches) *launches = c->big_launches[k]; if (ms) *ms = c->big_ms[k]; if (bytes) *bytes = c->big_bytes[k]; return 0;
+}
 int32_t lasso_wait_stats(lasso_ctx* c, uint64_t* waits, double* wait_us, int32_t reset) { REQUIRE(c, waits && wait_us); *waits = c->stat_waits; *wait_us = c->stat_wait_us; if (reset) { c->stat_waits = 0; c->stat_wait_us = 0; } return 0; }
 int32_t lasso_prof_enable(lasso_ctx* c, int32_t mask) { prof_flush(c); c->prof_mask = (uint32_t)mask; return 0; }
-int32_t lasso_prof_reset(lasso_ctx* c) { prof_flush(c); for (int i = 0; i < LASSO_K_COUNT; i++) { c->prof_launches[i] = 0; c->prof_ms[i] = 0; c->prof_bytes[i] = 0; } return 0; }
+int32_t lasso_prof_reset(lasso_ctx* c) { prof_flush(c); for (int i = 0; i < LASSO_K_COUNT; i++) { c->prof_launches[i] = 0; c->prof_ms[i] = 0; c->prof_bytes[i] = 0; c->big_launches[i] = 0; c->big_ms[i] = 0; c->big_bytes[i] = 0; } return 0; }
 int32_t lasso_prof_get(lasso_ctx* c, int32_t k, uint64_t* launches, double* ms, double* bytes) {
   REQUIRE(c, k >= 0 && k < LASSO_K_COUNT); prof_flush(c);
   if (launches) *launches = c->prof_launches[k]; if (ms) *ms = c->prof_ms[k]; if (bytes) *bytes = c->prof_bytes[k]; return 0;
@@ -225,6 +233,9 @@ int32_t lasso_bind_top(lasso_ctx* c, lasso_fr* const* d_polys, uint32_t npolys, 
   hipLaunchKernelGGL(k_bind_top, dim3(grid_for(half, 4096), npolys), dim3(LASSO_BLOCK), 0, c->stream, T, half, to_fr(r));
   HIPCHK(c, hipGetLastError()); return 0;
 }
+// x-extent of the cubic-round grids: ~512 workgroups over the whole grid (measured: 128..512 equal within noise, 64 and >= 1024 slower; the kernels are VALU-bound
+// and every extra workgroup adds a reduction epilogue), LASSO_CUBIC_NX overrides for experiments
+static unsigned cubic_nx_cap(unsigned ny) { static const long e = [] { const char* v = getenv("LASSO_CUBIC_NX"); return v ? atol(v) : 0L; }(); if (e > 0) return (unsigned)e; unsigned c = 512 / (ny ? ny : 1); return c < 64 ? 64 : c; }
 #define CUBIC_SMALL_Q 64   // rounds with at most this many indices per circuit take the latency-shaped kernel
 int32_t lasso_sumcheck_cubic_round(lasso_ctx* c, const lasso_fr* const* d_A, const lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_C, size_t n, lasso_fr* out) {
   REQUIRE(c, d_A && d_B && d_C && out && ncirc >= 1 && ncirc <= LASSO_MAX_PTRS && n >= 2 && (n & (n - 1)) == 0);
@@ -237,10 +248,10 @@ int32_t lasso_sumcheck_cubic_round(lasso_ctx* c, const lasso_fr* const* d_A, con
     hipLaunchKernelGGL((k_cubic_small<false>), dim3(ncirc), dim3(LASSO_BLOCK), 0, c->stream, A, B, (const fr_t*)d_C, (fr_t*)nullptr, (uint32_t)half, fr_zero(), c->d_counters, c->d_small, c->d_flag, seq);
   } else {
     PtrTable A, B; for (uint32_t i = 0; i < ncirc; i++) { REQUIRE(c, d_A[i] && d_B[i]); A.p[i] = (const fr_t*)d_A[i]; B.p[i] = (const fr_t*)d_B[i]; }
-    const unsigned nx = grid_for(half, 512);
-    rc = ensure_scratch(c, (size_t)nx * ncirc * 3 * sizeof(fr_t)); if (rc) return rc;
+    const unsigned ny = ncirc, nx = grid_for(half, cubic_nx_cap(ny));
+    rc = ensure_scratch(c, (size_t)nx * ny * 3 * sizeof(fr_t)); if (rc) return rc;
     ProfScope ps(c, LASSO_K_CUBIC, 32.0 * n * (2.0 * ncirc + 1.0));
-    hipLaunchKernelGGL(k_cubic_round_lb, dim3(nx, ncirc), dim3(LASSO_BLOCK), 0, c->stream, A, B, (const fr_t*)d_C, half, (fr_t*)c->d_scratch, c->d_counters, c->d_small, c->d_flag, seq);
+    hipLaunchKernelGGL(k_cubic_round_lb, dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, A, B, nx, ny, (const fr_t*)d_C, half, (fr_t*)c->d_scratch, c->d_counters, c->d_small, c->d_flag, seq);
   }
   HIPCHK(c, hipGetLastError());
   return wait_flag(c, seq, (size_t)ncirc * 3, out);
@@ -254,13 +265,13 @@ int32_t lasso_sumcheck_cubic_round_fused(lasso_ctx* c, lasso_fr* const* d_A, las
   const uint32_t seq = ++c->seq;
   {
     // bind: read 32n + write 16n per polynomial (2*ncirc + 1 of them); the evaluation of the next round rides on the same pass
-    ProfScope ps(c, LASSO_K_BIND, 48.0 * n * (2.0 * ncirc + 1.0));
+    ProfScope ps(c, LASSO_K_CUBIC, 48.0 * n * (2.0 * ncirc + 1.0));
     if (q <= CUBIC_SMALL_Q) {
       hipLaunchKernelGGL((k_cubic_small<true>), dim3(ncirc), dim3(LASSO_BLOCK), 0, c->stream, A, B, (const fr_t*)d_C_in, (fr_t*)d_C_out, (uint32_t)q, to_fr(r), c->d_counters, c->d_small, c->d_flag, seq);
     } else {
-      const unsigned nx = grid_for(q, 512);
-      rc = ensure_scratch(c, (size_t)nx * ncirc * 3 * sizeof(fr_t)); if (rc) return rc;
-      hipLaunchKernelGGL(k_cubic_fused, dim3(nx, ncirc), dim3(LASSO_BLOCK), 0, c->stream, A, B, (const fr_t*)d_C_in, (fr_t*)d_C_out, q, to_fr(r), (fr_t*)c->d_scratch, c->d_counters, c->d_small, c->d_flag, seq);
+      const unsigned ny = ncirc, nx = grid_for(q, cubic_nx_cap(ny));
+      rc = ensure_scratch(c, (size_t)nx * ny * 3 * sizeof(fr_t)); if (rc) return rc;
+      hipLaunchKernelGGL(k_cubic_fused, dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, A, B, nx, ny, (const fr_t*)d_C_in, (fr_t*)d_C_out, q, to_fr(r), (fr_t*)c->d_scratch, c->d_counters, c->d_small, c->d_flag, seq);
     }
   }
   HIPCHK(c, hipGetLastError());

@@ -75,16 +75,18 @@ __device__ __forceinline__ void store_block_partials(const fr29* acc, uint32_t K
 }
 
 // second stage: out[y*K + k] = sum_x partials[(y*nx + x)*K + k]   (partials are canonical memory words)
-__device__ __forceinline__ void reduce_partials_row(const fr_t* __restrict__ partials, uint32_t nx, uint32_t K, uint32_t y, fr_t* __restrict__ out, RedScratch& S) {
-  for (uint32_t k0 = 0; k0 < K; k0 += 3) {
+// K = row stride of partials/out, Kv <= K = number of valid values in this row
+__device__ __forceinline__ void reduce_partials_row(const fr_t* __restrict__ partials, uint32_t nx, uint32_t K, uint32_t y, fr_t* __restrict__ out, RedScratch& S, uint32_t Kv = 0xffffffffu) {
+  if (Kv > K) Kv = K;
+  for (uint32_t k0 = 0; k0 < Kv; k0 += 3) {
     fr29 acc[3];
 #pragma unroll
     for (int v = 0; v < 3; v++) {
       acc[v] = fr29_zero();
-      if (k0 + v < K) for (uint32_t x = threadIdx.x; x < nx; x += blockDim.x) acc[v] = fr29_weak(fr29_add(acc[v], fr29_unpack_u(partials[((size_t)y * nx + x) * K + k0 + v])));
+      if (k0 + v < Kv) for (uint32_t x = threadIdx.x; x < nx; x += blockDim.x) acc[v] = fr29_weak(fr29_add(acc[v], fr29_unpack_u(partials[((size_t)y * nx + x) * K + k0 + v])));
     }
     block_columns<3>(acc, S);
-    if (threadIdx.x < 3 && k0 + threadIdx.x < K) out[(size_t)y * K + k0 + threadIdx.x] = columns_to_fr(S, threadIdx.x, fr29_one_s());
+    if (threadIdx.x < 3 && k0 + threadIdx.x < Kv) out[(size_t)y * K + k0 + threadIdx.x] = columns_to_fr(S, threadIdx.x, fr29_one_s());
   }
 }
 __global__ void __launch_bounds__(LASSO_BLOCK) k_reduce_partials(const fr_t* __restrict__ partials, uint32_t nx, uint32_t K, fr_t* __restrict__ out) {
@@ -99,7 +101,7 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_reduce_partials(const fr_t* __r
 // released at system scope before its ticket, so the flag store (system-scope release) is ordered after all of them.
 __device__ __forceinline__ void row_done(uint32_t nrows, uint32_t* counters, uint32_t* flag, uint32_t seq);
 __device__ __forceinline__ void last_block_reduce(const fr_t* partials, uint32_t nx, uint32_t K, uint32_t y, uint32_t nrows, uint32_t* counters, fr_t* __restrict__ out, RedScratch& S,
-                                                  uint32_t* flag, uint32_t seq) {
+                                                  uint32_t* flag, uint32_t seq, uint32_t Kv = 0xffffffffu) {
   __shared__ uint32_t is_last;
   if (threadIdx.x == 0) {   // wave 0 holds the partial stores; fence and vmcnt are wave-wide
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -111,7 +113,7 @@ __device__ __forceinline__ void last_block_reduce(const fr_t* partials, uint32_t
   }
   __syncthreads();
   if (!is_last) return;
-  reduce_partials_row(partials, nx, K, y, out, S);
+  reduce_partials_row(partials, nx, K, y, out, S, Kv);
   row_done(nrows, counters, flag, seq);   // the <= 3 result stores were issued by wave 0
 }
 
@@ -137,12 +139,20 @@ __device__ __forceinline__ void cubic_terms(const fr29& a0, const fr29& a1, cons
   const fr29 a3 = fr29_add(a2, da), b3 = fr29_weak(fr29_add(b2, db)), c3 = fr29_add(c2, dc);                          // 3*hi - 2*lo
   t3 = fr29_mul(c3, fr29_mul(a3, b3));
 }
-#define CUBIC_ACCUMULATE(e, t0, t2, t3, cnt)                                                                                          \
-  do {                                                                                                                                \
-    e[0] = fr29_weak(fr29_add(e[0], t0)); e[1] = fr29_weak(fr29_add(e[1], t2)); e[2] = fr29_weak(fr29_add(e[2], t3));                    \
-    if ((++cnt & 127u) == 0) { e[0] = fr29_mul(e[0], fr29_one_s()); e[1] = fr29_mul(e[1], fr29_one_s()); e[2] = fr29_mul(e[2], fr29_one_s()); } \
-  } while (0)
-// raise the host flag once every row (circuit) has stored its results: called by the workgroup that finished row y, stores issued by wave 0
+// Grid shape of the cubic kernels: one workgroup row per circuit (the kernels are VALU-bound: two circuits per thread cost a third of the
+// occupancy and ran 5% slower), laid out so that the workgroups of the SAME index range and different circuits land on the same XCD a few
+// dispatch slots apart — they read the same slice of the shared eq polynomial C, and the second read should hit that XCD's L2 instead of
+// HBM (the first PMC pass showed 1.2x the algorithmic read traffic at k = 2 with a plain (x, circuit) grid).  Workgroup ids go round-robin
+// over the 8 XCDs, so ids b and b + 8 share an XCD: id = (x / 8) * 8 * ny + circuit * 8 + (x % 8).
+struct CubicGrid { uint32_t bx, by, nx, ny; };
+__device__ __forceinline__ CubicGrid cubic_grid(uint32_t nx, uint32_t ny) {
+  CubicGrid g; g.nx = nx; g.ny = ny;
+  const uint32_t b = blockIdx.x;
+  if ((nx & 7u) == 0) { const uint32_t grp = b / (8 * ny), r = b - grp * 8 * ny; g.by = r >> 3; g.bx = grp * 8 + (r & 7u); }
+  else { g.bx = b % nx; g.by = b / nx; }
+  return g;
+}
+// raise the host flag once every grid row has stored its results: called by the workgroup that finished row y, stores issued by wave 0
 __device__ __forceinline__ void row_done(uint32_t nrows, uint32_t* counters, uint32_t* flag, uint32_t seq) {
   if (threadIdx.x == 0 && flag) {
     __threadfence_system();
@@ -150,29 +160,35 @@ __device__ __forceinline__ void row_done(uint32_t nrows, uint32_t* counters, uin
     if (t2 == nrows - 1) { counters[LASSO_MAX_PTRS] = 0; __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
   }
 }
-// block partials -> memory (K10 also supplies the missing 2^10), then the in-launch second stage; a single-block row writes its result directly
-__device__ __forceinline__ void cubic_epilogue(const fr29* e, fr_t* __restrict__ partials, uint32_t* counters, fr_t* __restrict__ out, uint32_t* flag, uint32_t seq, RedScratch& S) {
-  if (gridDim.x == 1) {
-    store_block_partials<3>(e, 3, out + (size_t)blockIdx.y * 3, fr29_k10(), S);
-    row_done(gridDim.y, counters, flag, seq);
+// block partials -> memory (K10 also supplies the missing 2^10), then the in-launch second stage; a single-block row writes its result directly.
+__device__ __forceinline__ void cubic_epilogue(const fr29* e, const CubicGrid& g, fr_t* __restrict__ partials, uint32_t* counters, fr_t* __restrict__ out, uint32_t* flag, uint32_t seq, RedScratch& S) {
+  if (g.nx == 1) {
+    store_block_partials<3>(e, 3, out + (size_t)g.by * 3, fr29_k10(), S);
+    row_done(g.ny, counters, flag, seq);
     return;
   }
-  store_block_partials<3>(e, 3, partials + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 3, fr29_k10(), S);
-  last_block_reduce(partials, gridDim.x, 3, blockIdx.y, gridDim.y, counters, out, S, flag, seq);
+  store_block_partials<3>(e, 3, partials + ((size_t)g.by * g.nx + g.bx) * 3, fr29_k10(), S);
+  last_block_reduce(partials, g.nx, 3, g.by, g.ny, counters, out, S, flag, seq);
 }
-// grid = (blocks over i, circuits); out[c*3 + {0,1,2}] = evals at x = 0, 2, 3.  First round of a layer: evaluation only.
-__global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_round_lb(PtrTable A, PtrTable B, const fr_t* __restrict__ C, size_t half, fr_t* __restrict__ partials, uint32_t* counters,
+#define CUBIC_ACCUMULATE(e, t0, t2, t3, cnt)                                                                                          \
+  do {                                                                                                                                \
+    e[0] = fr29_weak(fr29_add(e[0], t0)); e[1] = fr29_weak(fr29_add(e[1], t2)); e[2] = fr29_weak(fr29_add(e[2], t3));                    \
+    if ((++cnt & 127u) == 0) { e[0] = fr29_mul(e[0], fr29_one_s()); e[1] = fr29_mul(e[1], fr29_one_s()); e[2] = fr29_mul(e[2], fr29_one_s()); } \
+  } while (0)
+// out[c*3 + {0,1,2}] = evals at x = 0, 2, 3.  First round of a layer: evaluation only.  1-D grid of nx*ny workgroups (cubic_grid).
+__global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_round_lb(PtrTable A, PtrTable B, uint32_t nx, uint32_t ny, const fr_t* __restrict__ C, size_t half, fr_t* __restrict__ partials, uint32_t* counters,
                                                                  fr_t* __restrict__ out, uint32_t* flag, uint32_t seq) {
   __shared__ RedScratch S;
-  const fr_t* __restrict__ a = A.p[blockIdx.y];
-  const fr_t* __restrict__ b = B.p[blockIdx.y];
+  const CubicGrid g = cubic_grid(nx, ny);
+  const fr_t* __restrict__ a = A.p[g.by];
+  const fr_t* __restrict__ b = B.p[g.by];
   fr29 e[3] = {fr29_zero(), fr29_zero(), fr29_zero()}; uint32_t cnt = 0;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x) {
+  for (size_t i = g.bx * (size_t)blockDim.x + threadIdx.x; i < half; i += (size_t)nx * blockDim.x) {
     fr29 t0, t2, t3;
     cubic_terms(fr29_unpack_u(a[i]), fr29_unpack_u(a[i + half]), fr29_unpack_u(b[i]), fr29_unpack_u(b[i + half]), fr29_unpack_u(C[i]), fr29_unpack_u(C[i + half]), t0, t2, t3);
     CUBIC_ACCUMULATE(e, t0, t2, t3, cnt);
   }
-  cubic_epilogue(e, partials, counters, out, flag, seq, S);
+  cubic_epilogue(e, g, partials, counters, out, flag, seq, S);
 }
 // K4 fused with K1: bind every polynomial of the round with r (length n = 4q -> 2q), then evaluate the NEXT round on the bound
 // values while they are still in registers (80 -> 48 bytes per element per round, one launch per round).
@@ -182,25 +198,26 @@ __device__ __forceinline__ fr29 bind29(const fr_t& lo, const fr_t& hi, const fr2
   const fr29 l = fr29_unpack_u(lo);
   return fr29_canonical(fr29_add(l, fr29_mul(fr29_sub(fr29_unpack_u(hi), l), rs)));   // canonical: stored as is, and a reduced operand below
 }
-__global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_fused(MutPtrTable A, MutPtrTable B, const fr_t* __restrict__ C_in, fr_t* __restrict__ C_out, size_t q, fr_t r,
+__global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_fused(MutPtrTable A, MutPtrTable B, uint32_t nx, uint32_t ny, const fr_t* __restrict__ C_in, fr_t* __restrict__ C_out, size_t q, fr_t r,
                                                               fr_t* __restrict__ partials, uint32_t* counters, fr_t* __restrict__ out, uint32_t* flag, uint32_t seq) {
   __shared__ RedScratch S;
-  fr_t* __restrict__ a = A.p[blockIdx.y];
-  fr_t* __restrict__ b = B.p[blockIdx.y];
+  const CubicGrid g = cubic_grid(nx, ny);
+  fr_t* __restrict__ a = A.p[g.by];
+  fr_t* __restrict__ b = B.p[g.by];
   const fr29 rs = fr29_unpack_s(r);
   fr29 e[3] = {fr29_zero(), fr29_zero(), fr29_zero()}; uint32_t cnt = 0;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < q; i += (size_t)gridDim.x * blockDim.x) {
+  for (size_t i = g.bx * (size_t)blockDim.x + threadIdx.x; i < q; i += (size_t)nx * blockDim.x) {
     const fr29 a0 = bind29(a[i], a[i + 2 * q], rs), a1 = bind29(a[i + q], a[i + 3 * q], rs);
     a[i] = fr29_pack(a0); a[i + q] = fr29_pack(a1);
     const fr29 b0 = bind29(b[i], b[i + 2 * q], rs), b1 = bind29(b[i + q], b[i + 3 * q], rs);
     b[i] = fr29_pack(b0); b[i + q] = fr29_pack(b1);
     const fr29 c0 = bind29(C_in[i], C_in[i + 2 * q], rs), c1 = bind29(C_in[i + q], C_in[i + 3 * q], rs);
-    if (blockIdx.y == 0) { C_out[i] = fr29_pack(c0); C_out[i + q] = fr29_pack(c1); }
+    if (g.by == 0) { C_out[i] = fr29_pack(c0); C_out[i + q] = fr29_pack(c1); }
     fr29 t0, t2, t3;
     cubic_terms(a0, a1, b0, b1, c0, c1, t0, t2, t3);
     CUBIC_ACCUMULATE(e, t0, t2, t3, cnt);
   }
-  cubic_epilogue(e, partials, counters, out, flag, seq, S);
+  cubic_epilogue(e, g, partials, counters, out, flag, seq, S);
 }
 
 // Late rounds (q <= 64 indices per circuit): the same round, laid out for LATENCY instead of throughput.  One workgroup per circuit;

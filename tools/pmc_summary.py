@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Summarise the rocprofv3 PMC passes of bench.py (tools/gpu_pmc.sh) into profiles/r01_pmc/bench_traffic.json.
+
+Per kernel family: HBM bytes per launch = 2 x FETCH_SIZE (gfx950 counts a wide coalesced stream at half its bytes:
+MI355X_MICROARCH.md §HBM, re-confirmed by profiles/r01_pmc/README.md's copy kernel) + WRITE_SIZE (1:1), both reported in KB,
+averaged over the launches of the HBM-bound regime only: the `top` largest dispatches of each kernel in the LAST proof of the run,
+which are the same launches bench.py brackets with HIP events (algorithmic bytes >= 256 MiB)."""
+import csv
+import json
+import sys
+from collections import defaultdict
+
+FAMILIES = {   # bench.py family name -> kernel-name prefixes
+    "bind_top": ("k_bind_top",),
+    "sumcheck_cubic_round(+fused bind)": ("k_cubic_fused", "k_cubic_round_lb"),
+    "sumcheck_combine": ("k_combine_round_linear", "void k_combine_claim"),
+    "multi_dot": ("k_multi_dot",),
+    "matvec_left": ("k_matvec_left",),
+    "fingerprint": ("k_fingerprint_ops",),
+}
+
+
+def load(path):
+    rows = []
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            rows.append((int(r["Dispatch_Id"]), r["Kernel_Name"], float(r["Counter_Value"])))
+    rows.sort()
+    return rows
+
+
+def last_proof(rows):
+    starts = [i for i, r in enumerate(rows) if r[1].startswith("k_gather")]
+    return rows[starts[-1]:] if starts else rows
+
+
+def main(fetch_csv, write_csv, bench_json, out_json, source):
+    """bench_json: the JSON line bench.py printed under the FETCH_SIZE pass; its `large_launches_timed` gives, per family, how many launches
+    per proof fall in the bracketed class — the PMC average is taken over the same number of largest dispatches."""
+    fetch, write = last_proof(load(fetch_csv)), last_proof(load(write_csv))
+    with open(bench_json) as f:
+        large = json.loads(f.read().strip().splitlines()[-1]).get("large_launches_timed", {})
+    out = {}
+    for fam, prefixes in FAMILIES.items():
+        top = large.get(fam, {}).get("per_step", 0)
+        if not top:
+            continue
+        f = sorted((v for _, n, v in fetch if n.startswith(prefixes)), reverse=True)[:top]
+        w = sorted((v for _, n, v in write if n.startswith(prefixes)), reverse=True)[:top]
+        if not f or not w:
+            continue
+        fb = 2.0 * 1024.0 * sum(f) / len(f)
+        wb = 1024.0 * sum(w) / len(w)
+        out[fam] = {"bytes_per_launch": round(fb + wb), "read_bytes_per_launch": round(fb), "write_bytes_per_launch": round(wb), "launches": len(f),
+                    "alg_bytes_per_launch": large[fam]["alg_bytes_per_launch"], "traffic_over_algorithmic": round((fb + wb) / large[fam]["alg_bytes_per_launch"], 3), "source": source}
+    with open(out_json, "w") as fo:
+        json.dump(out, fo, indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:6])
