@@ -134,6 +134,21 @@ int orc_session_verify_with_commitment(void* sv, const uint8_t* proof, size_t n,
   MerlinTranscript t("example");
   return surge_verify(se->S, P, c, se->r, se->gens, t) ? 1 : 0; ) }
 
+// Verifier only (surge.rs:214-271): needs the strategy, the sizes, the generators, the point, the commitment and the proof — NOT the lookups.
+// Lets the -m gpu tests check proofs at BASELINE.json's full sizes (2^20 .. 2^24 lookups) without building a CPU-side dense representation.
+int orc_verify_only(int kind, size_t C, size_t M, size_t log_r, size_t s, const u64* r_mont, const uint8_t* proof, size_t n, const uint8_t* comm, size_t cn) { GUARD(
+  Strategy S = mk_strategy(kind, C, M, log_r);
+  const size_t log_m = ark_log2(M);
+  const auto& gens = cached_gens(C, s, S.num_memories(), log_m);
+  std::vector<Fr> r; for (size_t i = 0; i < ark_log2(s); i++) r.push_back(Fr::from_raw(r_mont + 4 * i));
+  ByteReader cr(comm, cn); SparsePolynomialCommitment c; c.l_variate_polys_commitment = cr.pts_vec(); c.log_m_variate_polys_commitment = cr.pts_vec();
+  if (!cr.ok || cr.pos != cn) { g_err = "bad commitment bytes"; return 0; }
+  c.s = s; c.log_m = log_m; c.m = M;
+  SparsePolynomialEvaluationProof P;
+  if (!deserialize_proof(S, proof, n, P)) { g_err = "deserialize failed"; return 0; }
+  MerlinTranscript t("example");
+  return surge_verify(S, P, c, r, gens, t) ? 1 : 0; ) }
+
 // ---- timing leg for bench.py cpu_baseline ("port"): harness inputs, serial single-thread
 int orc_bench(int kind, size_t C, size_t M, size_t log_r, size_t s, double* t_densify, double* t_commit, double* t_prove, int do_verify) { GUARD(
   using clk = std::chrono::steady_clock;
