@@ -124,6 +124,15 @@ int32_t lasso_fingerprint_mem(lasso_ctx* ctx, const lasso_fr* d_table, const las
 /* DensePolynomial::bound (src/poly/dense_mlpoly.rs:184-207): out[i] = sum_j L[j] * d_Z[j*r_size + i], i < r_size */
 int32_t lasso_matvec_left(lasso_ctx* ctx, const lasso_fr* d_Z, const lasso_fr* L, size_t l_size, size_t r_size, lasso_fr* out);
 
+/* ---- densify ------------------------------------------------------------------------------- */
+/* DensifiedRepresentation::from_lookup_indices for ONE dimension (src/lasso/densified.rs:32-57; serial in the reference, TODO(#29)).
+ * d_indices: the reference's `Vec<[usize; C]>` uploaded as is (n_lookups x C u64, row-major).  For k < s (s = n_lookups.next_power_of_two()):
+ * access[k] = indices[k][dim] (0 for the padded tail), read_ts[k] = #{j < k : access[j] == access[k]}, final_ts[a] = #{k : access[k] == a}.
+ * Outputs: d_dim_u32[s] (dim_usize), d_dim[s], d_read[s], d_final[2^log_m] as Fr (DensePolynomial::from_usize).  Fails with
+ * LASSO_ERR_INVALID if an index is >= 2^log_m (the reference panics on the out-of-bounds `final_timestamps[memory_address]`). Synchronous. */
+int32_t lasso_densify_dim(lasso_ctx* ctx, const uint64_t* d_indices, size_t n_lookups, size_t C, size_t dim, size_t s, uint32_t log_m,
+                          uint32_t* d_dim_u32, lasso_fr* d_dim, lasso_fr* d_read, lasso_fr* d_final);
+
 /* ---- curve kernels (Hyrax commitment, src/poly/commitments.rs + src/msm/mod.rs) ------------- */
 /* Upload a generator vector once (MultiCommitGens: G[0..n) then any extra points such as gens_1.G[0] and h) and
  * precompute the per-window multiples used by both MSM entry points. */

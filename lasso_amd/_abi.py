@@ -49,6 +49,7 @@ def declare(lib):
         "lasso_gp_build": (i32, [vp, vp, sz]),
         "lasso_fingerprint_ops": (i32, [vp, vp, vp, vp, sz, vp, vp, vp, vp]),
         "lasso_fingerprint_mem": (i32, [vp, vp, vp, sz, vp, vp, vp, vp]),
+        "lasso_densify_dim": (i32, [vp, vp, sz, sz, sz, sz, u32, vp, vp, vp, vp]),
         "lasso_matvec_left": (i32, [vp, vp, vp, sz, sz, vp]),
         "lasso_bases_create": (i32, [vp, vp, sz, P(vp)]),
         "lasso_bases_destroy": (None, [vp, vp]),

@@ -10,6 +10,7 @@
 #include "../../include/lasso_hip.h"
 #include "poly_kernels.cuh"
 #include "msm_kernels.cuh"
+#include "densify_kernels.cuh"
 
 __global__ void __launch_bounds__(256) k_inner_lr(const fr_t* __restrict__ a, const fr_t* __restrict__ b, size_t half, fr_t* __restrict__ partials) {
   __shared__ RedScratch S;
@@ -393,6 +394,41 @@ int32_t lasso_matvec_left(lasso_ctx* c, const lasso_fr* d_Z, const lasso_fr* L, 
   HIPCHK(c, hipMemcpyAsync(c->h_big, c->d_big, r_size * sizeof(fr_t), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   memcpy(out, c->h_big, r_size * sizeof(fr_t));
+  return 0;
+}
+
+// ------------------------------------------------------------------ densify (densified.rs:22-75)
+int32_t lasso_densify_dim(lasso_ctx* c, const uint64_t* d_indices, size_t n_lookups, size_t C, size_t dim, size_t s, uint32_t log_m, uint32_t* d_dim_u32, lasso_fr* d_dim, lasso_fr* d_read,
+                          lasso_fr* d_final) {
+  REQUIRE(c, d_indices && d_dim_u32 && d_dim && d_read && d_final && C >= 1 && dim < C && s >= 1 && (s & (s - 1)) == 0 && n_lookups <= s && s < ((size_t)1 << 32) && log_m <= 32);
+  const size_t m = (size_t)1 << log_m;
+  const uint32_t ntiles = (uint32_t)((s + RADIX_TILE - 1) / RADIX_TILE);
+  const size_t nh = (size_t)256 * ntiles, nb = (nh + 4095) / 4096;
+  const size_t words = 4 * s + nh + nb + 2 * m + 64;
+  int32_t rc = ensure_scratch(c, words * 4); if (rc) return rc;
+  uint32_t* kA = (uint32_t*)c->d_scratch; uint32_t* vA = kA + s; uint32_t* kB = vA + s; uint32_t* vB = kB + s;
+  uint32_t* hist = vB + s; uint32_t* sums = hist + nh; uint32_t* run_start = sums + nb; uint32_t* run_end = run_start + m;
+  HIPCHK(c, hipMemsetAsync(c->d_flags, 0, 8, c->stream));
+  HIPCHK(c, hipMemsetAsync(run_start, 0, 2 * m * 4, c->stream));
+  ProfScope ps(c, LASSO_K_MISC, 8.0 * n_lookups + (32.0 * 2 + 4.0) * s + 32.0 * m);
+  hipLaunchKernelGGL(k_densify_extract, dim3(grid_for(s, 4096)), dim3(256), 0, c->stream, d_indices, n_lookups, C, dim, s, (uint64_t)m, kA, vA, d_dim_u32, (fr_t*)d_dim, c->d_flags);
+  const uint32_t npass = log_m == 0 ? 1 : (log_m + 7) / 8;
+  for (uint32_t p = 0; p < npass; p++) {
+    hipLaunchKernelGGL(k_radix_hist, dim3(ntiles), dim3(RADIX_THREADS), 0, c->stream, (const uint32_t*)kA, s, 8 * p, hist, ntiles);
+    hipLaunchKernelGGL(k_scan_block_sums, dim3((unsigned)nb), dim3(256), 0, c->stream, (const uint32_t*)hist, nh, sums);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, c->stream, sums, nb);
+    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(256), 0, c->stream, hist, nh, (const uint32_t*)sums);
+    hipLaunchKernelGGL(k_radix_scatter, dim3(ntiles), dim3(RADIX_THREADS), 0, c->stream, (const uint32_t*)kA, (const uint32_t*)vA, s, 8 * p, (const uint32_t*)hist, ntiles, kB, vB);
+    std::swap(kA, kB); std::swap(vA, vB);
+  }
+  hipLaunchKernelGGL(k_densify_runs, dim3(grid_for(s, 4096)), dim3(256), 0, c->stream, (const uint32_t*)kA, s, run_start, run_end);
+  hipLaunchKernelGGL(k_densify_read, dim3(grid_for(s, 4096)), dim3(256), 0, c->stream, (const uint32_t*)kA, (const uint32_t*)vA, s, (const uint32_t*)run_start, (fr_t*)d_read);
+  hipLaunchKernelGGL(k_densify_final, dim3(grid_for(m, 4096)), dim3(256), 0, c->stream, (const uint32_t*)run_start, (const uint32_t*)run_end, m, (fr_t*)d_final);
+  HIPCHK(c, hipGetLastError());
+  uint32_t flags[2];
+  HIPCHK(c, hipMemcpyAsync(flags, c->d_flags, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (flags[0]) return fail(c, LASSO_ERR_INVALID, "lookup index out of range (memory_address >= M, densified.rs:46)");
   return 0;
 }
 

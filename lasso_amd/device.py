@@ -182,6 +182,9 @@ class Device:
         self._chk(self.lib.lasso_bullet_lr(self.ctx, C.c_void_p(bases), n, C.c_void_p(d_a), nk, C.c_void_p(d_w), _vp(tail), _vp(out)))
         return out
 
+    def densify_dim(self, d_indices, n_lookups, c, dim, s, log_m, d_dim_u32, d_dim, d_read, d_final):
+        self._chk(self.lib.lasso_densify_dim(self.ctx, C.c_void_p(d_indices), n_lookups, c, dim, s, log_m, C.c_void_p(d_dim_u32), C.c_void_p(d_dim), C.c_void_p(d_read), C.c_void_p(d_final)))
+
     def bullet_round(self, bases, n, d_a_in, d_b_in, d_w_in, d_a_out, d_b_out, d_w_out, nk, u, u_inv, blinds):
         blinds = np.ascontiguousarray(blinds, dtype=np.uint64).reshape(2, 4)
         out = np.empty((2, 16), dtype=np.uint64)

@@ -87,9 +87,16 @@ struct DBuf {
   void reset() { if (p && dev) dev->free(p); p = nullptr; n = 0; }
   ~DBuf() { try { reset(); } catch (...) {} }
 };
+struct DBufU64 {   // read-only upload of a host u64 array
+  const Dev* dev = nullptr; uint64_t* p = nullptr; size_t n = 0;
+  DBufU64(const Dev& d, const uint64_t* h, size_t n_) : dev(&d), p((uint64_t*)d.alloc_bytes((n_ ? n_ : 1) * 8)), n(n_) { if (n) d.chk(lasso_upload(d.ctx, p, h, n * 8), "lasso_upload"); }
+  DBufU64(const DBufU64&) = delete; DBufU64& operator=(const DBufU64&) = delete;
+  ~DBufU64() { try { if (p && dev) dev->free(p); } catch (...) {} }
+};
 struct DBufU32 {
   const Dev* dev = nullptr; uint32_t* p = nullptr; size_t n = 0;
   DBufU32() {}
+  DBufU32(const Dev& d, size_t n_) : dev(&d), p(d.alloc_u32(n_ ? n_ : 1)), n(n_) {}
   DBufU32(const Dev& d, const std::vector<uint32_t>& h) : dev(&d), p(d.alloc_u32(h.size() ? h.size() : 1)), n(h.size()) { if (n) d.chk(lasso_upload(d.ctx, p, h.data(), n * 4), "lasso_upload"); }
   DBufU32(DBufU32&& o) noexcept : dev(o.dev), p(o.p), n(o.n) { o.p = nullptr; }
   DBufU32& operator=(DBufU32&& o) noexcept { if (this != &o) { if (p && dev) dev->free(p); dev = o.dev; p = o.p; n = o.n; o.p = nullptr; } return *this; }
@@ -342,17 +349,16 @@ struct DensifiedRepresentation {
     size_t n_l = next_pow2(2 * C * s), n_m = next_pow2(C) * m;
     D->nv_l = ceil_log2(n_l); D->nv_m = ceil_log2(n_m);
     D->combined_l_variate_polys = DBuf(d, n_l); D->combined_log_m_variate_polys = DBuf(d, n_m);
-    d.chk(lasso_zero(d.ctx, D->combined_l_variate_polys.p, n_l * sizeof(lasso_fr)), "lasso_zero");
-    d.chk(lasso_zero(d.ctx, D->combined_log_m_variate_polys.p, n_m * sizeof(lasso_fr)), "lasso_zero");
-    for (size_t i = 0; i < C; i++) {   // densified.rs:32-57: per-dimension timestamp counting (serial in the reference, TODO(#29))
-      std::vector<uint32_t> access(s, 0), read_ts(s, 0), final_ts(m, 0);
-      for (size_t k = 0; k < n_lookups; k++) { uint64_t a = indices[k * C + i]; LASSO_REQUIRE(a < m); access[k] = (uint32_t)a; }
-      for (size_t k = 0; k < s; k++) { uint32_t a = access[k]; uint32_t ts = final_ts[a]; read_ts[k] = ts; final_ts[a] = ts + 1; }
-      DBufU32 d_access(d, access), d_read(d, read_ts), d_final(d, final_ts);
-      d.chk(lasso_fr_from_u32(d.ctx, d_access.p, s, D->combined_l_variate_polys.p + i * s), "lasso_fr_from_u32");
-      d.chk(lasso_fr_from_u32(d.ctx, d_read.p, s, D->combined_l_variate_polys.p + (C + i) * s), "lasso_fr_from_u32");
-      d.chk(lasso_fr_from_u32(d.ctx, d_final.p, m, D->combined_log_m_variate_polys.p + i * m), "lasso_fr_from_u32");
-      d.chk(lasso_sync(d.ctx), "lasso_sync");
+    // DensePolynomial::merge pads with zeros up to the next power of two (dense_mlpoly.rs:251-261)
+    if (n_l > 2 * C * s) d.chk(lasso_zero(d.ctx, D->combined_l_variate_polys.p + 2 * C * s, (n_l - 2 * C * s) * sizeof(lasso_fr)), "lasso_zero");
+    if (n_m > C * m) d.chk(lasso_zero(d.ctx, D->combined_log_m_variate_polys.p + C * m, (n_m - C * m) * sizeof(lasso_fr)), "lasso_zero");
+    // densified.rs:32-57 on the device: the index array is uploaded once as the reference holds it (Vec<[usize; C]>), each dimension is one
+    // lasso_densify_dim call (stable radix sort by address -> read/final timestamps), the polynomials are written straight into the merged buffers
+    DBufU64 d_idx(d, indices, n_lookups * C);
+    for (size_t i = 0; i < C; i++) {
+      DBufU32 d_access(d, s);
+      d.chk(lasso_densify_dim(d.ctx, d_idx.p, n_lookups, C, i, s, (uint32_t)log_m, d_access.p, D->combined_l_variate_polys.p + i * s, D->combined_l_variate_polys.p + (C + i) * s,
+                              D->combined_log_m_variate_polys.p + i * m), "lasso_densify_dim");
       D->dim_u32.push_back(std::move(d_access));
     }
     return D;

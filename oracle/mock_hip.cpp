@@ -124,6 +124,17 @@ int32_t lasso_matvec_left(lasso_ctx*, const lasso_fr* Z, const lasso_fr* L, size
   for (size_t i = 0; i < rs; i++) { Fr s = Fr::zero(); for (size_t j = 0; j < ls; j++) s += F(L)[j] * F(Z)[j * rs + i]; F(out)[i] = s; }  // dense_mlpoly.rs:184-207
   return 0;
 }
+// densified.rs:32-57, the reference's serial loop for one dimension
+int32_t lasso_densify_dim(lasso_ctx* c, const uint64_t* idx, size_t n_lookups, size_t C, size_t dim, size_t s, uint32_t log_m, uint32_t* dim_u32, lasso_fr* d_dim, lasso_fr* d_read, lasso_fr* d_final) {
+  REQ(c, dim < C && n_lookups <= s);
+  const size_t m = (size_t)1 << log_m;
+  std::vector<size_t> access(s, 0), final_ts(m, 0), read_ts(s, 0);
+  for (size_t k = 0; k < n_lookups; k++) { access[k] = (size_t)idx[k * C + dim]; REQ(c, access[k] < m); }
+  for (size_t k = 0; k < s; k++) { size_t a = access[k]; size_t ts = final_ts[a]; read_ts[k] = ts; final_ts[a] = ts + 1; }
+  for (size_t k = 0; k < s; k++) { dim_u32[k] = (uint32_t)access[k]; F(d_dim)[k] = Fr::from_u64(access[k]); F(d_read)[k] = Fr::from_u64(read_ts[k]); }
+  for (size_t a = 0; a < m; a++) F(d_final)[a] = Fr::from_u64(final_ts[a]);
+  return 0;
+}
 int32_t lasso_bases_create(lasso_ctx*, const lasso_affine* pts, size_t n, lasso_bases** out) {
   auto* b = new lasso_bases();
   for (size_t i = 0; i < n; i++) b->pts.push_back(Point::from_affine(Fq::from_raw(pts[i].x), Fq::from_raw(pts[i].y)));
