@@ -40,6 +40,8 @@ def parse():
     p.add_argument("--cpu-log-s", type=int, default=16, help="log2 lookups of the bounded CPU-baseline sample")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-prof", action="store_true")
+    p.add_argument("--shard-proof", action="store_true", help="N > 1: ONE proof of s lookups sharded over the N GPUs by low index bits (slab mode, strong scaling) "
+                                                                "instead of one independent proof per GPU (the default, weak scaling)")
     return p.parse_args()
 
 
@@ -74,6 +76,9 @@ def main():
     grp = Group()                      # torch.distributed (nccl = RCCL) only when WORLD_SIZE > 1
     rank, world = grp.rank, grp.world
     hp = HostProver(device=grp.device_index)
+    slab = a.shard_proof and world > 1
+    if slab:
+        hp.set_comm(grp)             # slab mode: every polynomial split by low index bits, RCCL all_gather of per-round sums / row commitments
     lib = hp.lib
     dev_lib = C.CDLL(os.path.join(ROOT, "lasso_amd", "liblasso_hip.so"))
     _abi.declare(dev_lib)
@@ -85,7 +90,7 @@ def main():
     S = _abi.Strategy(kind_id, c, log_m, a.log_r if a.kind == "range" else 0)
 
     t0 = time.time()
-    idx = shard_indices(hp, s, 1 << log_m, c, rank)         # benches/bench.rs:13-21 (rank 0 exactly; other ranks: their own batch)
+    idx = shard_indices(hp, s, 1 << log_m, c, 0 if slab else rank)   # benches/bench.rs:13-21 (rank 0 exactly; other ranks: their own batch, or the same lookups in slab mode)
     r = hp.gen_random_point(a.log_s)                        # benches/bench.rs:27-34
     gens = hp.gens(c, s, alpha, log_m)                      # SparsePolyCommitmentGens::new(b"gens_sparse_poly", C, S, C, log_m)
     t_setup = time.time() - t0
@@ -134,13 +139,13 @@ def main():
 
     if rank == 0:
         ms_per_step = elapsed / a.steps * 1e3
-        value = world * s * a.steps / elapsed
+        value = (1 if slab else world) * s * a.steps / elapsed
         out = {"metric": "prover lookups/sec for SparsePolynomialEvaluationProof, 2^24 AND lookups" if (a.kind, a.log_s, c) == ("and", 24, 1) else f"prover lookups/sec for SparsePolynomialEvaluationProof, 2^{a.log_s} {a.kind.upper()} lookups",
                "value": value, "unit": "lookups/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u256 (Montgomery Fr / ed25519 Fq integers)", "data": "synthetic",
+               "higher_is_better": True, "scaling": "strong" if slab else "weak", "vs_baseline": None, "dtype": "u256 (Montgomery Fr / ed25519 Fq integers)", "data": "synthetic",
                "config": {"workload": f"{a.kind.upper()} subtable, C={c}, M=2^{log_m}, s=2^{a.log_s} lookups per proof, G=curve25519 (ark_curve25519), harness inputs of src/benches/bench.rs; "
                                       f"timed = SparsePolynomialEvaluationProof::prove with the densified representation resident in HBM",
-                          "per_rank": "one independent proof per rank" if world > 1 else "single proof",
+                          "per_rank": ("one proof sharded over the ranks by low index bits (slab mode)" if slab else "one independent proof per rank") if world > 1 else "single proof",
                           "proof_bytes": len(proof), "distinct_proofs": len(set(digests)), "densify_s": round(t_densify, 3), "commit_s": round(t_commit, 3), "gens_setup_s": round(t_setup, 3),
                           "whole_bench_lookups_per_s": s / (t_densify + t_commit + ms_per_step / 1e3)}}
         if kernels:

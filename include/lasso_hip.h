@@ -85,6 +85,9 @@ int32_t lasso_fr_from_u32(lasso_ctx* ctx, const uint32_t* d_src, size_t n, lasso
 int32_t lasso_gather(lasso_ctx* ctx, const lasso_fr* d_table, const uint32_t* d_idx, size_t n, lasso_fr* d_out);
 /* EqPolynomial::evals (src/poly/eq_poly.rs:22-38): d_out[x] = prod_j (x_j ? r_j : 1-r_j), r[0] <-> top bit */
 int32_t lasso_eq_evals(lasso_ctx* ctx, const lasso_fr* r, uint32_t ell, lasso_fr* d_out);
+/* the same table multiplied by *scale (NULL = 1): in slab mode a rank's share of eq(r, .) is eq over the high variables times the eq factor of
+ * the rank's low index bits */
+int32_t lasso_eq_evals_scaled(lasso_ctx* ctx, const lasso_fr* r, uint32_t ell, const lasso_fr* scale, lasso_fr* d_out);
 /* DensePolynomial::bound_poly_var_top (src/poly/dense_mlpoly.rs:209-216) on `npolys` polynomials of current
  * length n: Z[i] <- Z[i] + r*(Z[i+n/2] - Z[i]) for i < n/2, in place.  `d_polys` is a HOST array of device pointers. */
 int32_t lasso_bind_top(lasso_ctx* ctx, lasso_fr* const* d_polys, uint32_t npolys, size_t n, const lasso_fr* r);
@@ -121,6 +124,10 @@ int32_t lasso_fingerprint_ops(lasso_ctx* ctx, const lasso_fr* d_table, const uin
 /* init/final sets (memory_checking.rs:254-273): d_init_out[i] = d_table[i]*gamma + i - tau, d_final_out[i] = d_init_out[i] + d_final[i]*gamma^2 */
 int32_t lasso_fingerprint_mem(lasso_ctx* ctx, const lasso_fr* d_table, const lasso_fr* d_final, size_t m,
                               const lasso_fr* gamma, const lasso_fr* tau, lasso_fr* d_init_out, lasso_fr* d_final_out);
+/* Slab mode of the same (one proof sharded over `world` GPUs by low index bits): local index i stands for address i*world + rank; d_table is the whole
+ * subtable, d_final and the outputs hold the rank's m local entries. */
+int32_t lasso_fingerprint_mem_slab(lasso_ctx* ctx, const lasso_fr* d_table, const lasso_fr* d_final, size_t m, uint32_t world, uint32_t rank,
+                                   const lasso_fr* gamma, const lasso_fr* tau, lasso_fr* d_init_out, lasso_fr* d_final_out);
 /* DensePolynomial::bound (src/poly/dense_mlpoly.rs:184-207): out[i] = sum_j L[j] * d_Z[j*r_size + i], i < r_size */
 int32_t lasso_matvec_left(lasso_ctx* ctx, const lasso_fr* d_Z, const lasso_fr* L, size_t l_size, size_t r_size, lasso_fr* out);
 
@@ -132,6 +139,12 @@ int32_t lasso_matvec_left(lasso_ctx* ctx, const lasso_fr* d_Z, const lasso_fr* L
  * LASSO_ERR_INVALID if an index is >= 2^log_m (the reference panics on the out-of-bounds `final_timestamps[memory_address]`). Synchronous. */
 int32_t lasso_densify_dim(lasso_ctx* ctx, const uint64_t* d_indices, size_t n_lookups, size_t C, size_t dim, size_t s, uint32_t log_m,
                           uint32_t* d_dim_u32, lasso_fr* d_dim, lasso_fr* d_read, lasso_fr* d_final);
+
+/* Slab mode: every rank sorts the whole access sequence (timestamps are a property of the whole sequence) but writes only its residue class:
+ * global index k (address a) with k mod world == rank (a mod world == rank) lands at local index k / world (a / world).  Outputs have s/world
+ * (2^log_m / world) entries. */
+int32_t lasso_densify_dim_slab(lasso_ctx* ctx, const uint64_t* d_indices, size_t n_lookups, size_t C, size_t dim, size_t s, uint32_t log_m, uint32_t world, uint32_t rank,
+                               uint32_t* d_dim_u32, lasso_fr* d_dim, lasso_fr* d_read, lasso_fr* d_final);
 
 /* ---- curve kernels (Hyrax commitment, src/poly/commitments.rs + src/msm/mod.rs) ------------- */
 /* Upload a generator vector once (MultiCommitGens: G[0..n) then any extra points such as gens_1.G[0] and h) and

@@ -29,6 +29,14 @@ int32_t lasso_host_create(int32_t device, lasso_host** out);
 void lasso_host_destroy(lasso_host* h);
 lasso_ctx* lasso_host_ctx(lasso_host* h);   /* the device context, e.g. for lasso_prof_* */
 
+/* Slab mode: ONE proof sharded over `world` GPUs (world a power of two, one lasso_host per rank, every rank given the SAME lookups and point).
+ * Every polynomial is split by low index bits (rank g holds the indices = g mod world), the transcript is replicated, and `allgather` is the only
+ * collective: it must gather `bytes` bytes from every rank into recv (rank order) and return 0 — RCCL/gloo all_gather in lasso_amd/parallel.py.
+ * Must be called before lasso_host_gens_new / lasso_host_densify.  All ranks return the same commitment and proof bytes (the bytes a single GPU
+ * produces).  world = 1 restores the single-GPU path. */
+typedef int32_t (*lasso_host_allgather_fn)(void* user, const void* send, void* recv, size_t bytes);
+int32_t lasso_host_set_comm(lasso_host* h, int32_t rank, int32_t world, lasso_host_allgather_fn allgather, void* user);
+
 int32_t lasso_host_gens_new(lasso_host* h, const char* label, size_t c, size_t s, size_t num_memories, size_t log_m, lasso_host_gens** out);
 void lasso_host_gens_free(lasso_host_gens* g);
 /* indices: n_lookups x c, row-major (Vec<[usize; C]>) */

@@ -39,6 +39,7 @@ def declare(lib):
         "lasso_fr_from_u32": (i32, [vp, vp, sz, vp]),
         "lasso_gather": (i32, [vp, vp, vp, sz, vp]),
         "lasso_eq_evals": (i32, [vp, vp, u32, vp]),
+        "lasso_eq_evals_scaled": (i32, [vp, vp, u32, vp, vp]),
         "lasso_bind_top": (i32, [vp, P(vp), u32, sz, vp]),
         "lasso_sumcheck_cubic_round": (i32, [vp, P(vp), P(vp), u32, vp, sz, vp]),
         "lasso_sumcheck_cubic_round_fused": (i32, [vp, P(vp), P(vp), u32, vp, vp, sz, vp, vp]),
@@ -49,6 +50,8 @@ def declare(lib):
         "lasso_gp_build": (i32, [vp, vp, sz]),
         "lasso_fingerprint_ops": (i32, [vp, vp, vp, vp, sz, vp, vp, vp, vp]),
         "lasso_fingerprint_mem": (i32, [vp, vp, vp, sz, vp, vp, vp, vp]),
+        "lasso_fingerprint_mem_slab": (i32, [vp, vp, vp, sz, u32, u32, vp, vp, vp, vp]),
+        "lasso_densify_dim_slab": (i32, [vp, vp, sz, sz, sz, sz, u32, u32, u32, vp, vp, vp, vp]),
         "lasso_densify_dim": (i32, [vp, vp, sz, sz, sz, sz, u32, vp, vp, vp, vp]),
         "lasso_matvec_left": (i32, [vp, vp, vp, sz, sz, vp]),
         "lasso_bases_create": (i32, [vp, vp, sz, P(vp)]),

@@ -20,14 +20,16 @@
 #define RADIX_TILE 4096
 #define RADIX_THREADS 256
 
-__global__ void __launch_bounds__(256) k_densify_extract(const uint64_t* __restrict__ idx, size_t n_lookups, size_t C, size_t col, size_t s, uint64_t m, uint32_t* __restrict__ keys,
-                                                          uint32_t* __restrict__ vals, uint32_t* __restrict__ dim_u32, fr_t* __restrict__ dim_fr, uint32_t* __restrict__ bad) {
+// Slab mode (world = P > 1, one proof sharded over P GPUs): every rank sorts the WHOLE sequence (timestamps are a global property of it)
+// but materialises only its residue class: global index k with k mod P == rank lands at local index k / P.
+__global__ void __launch_bounds__(256) k_densify_extract(const uint64_t* __restrict__ idx, size_t n_lookups, size_t C, size_t col, size_t s, uint64_t m, uint32_t world, uint32_t rank,
+                                                          uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t* __restrict__ dim_u32, fr_t* __restrict__ dim_fr, uint32_t* __restrict__ bad) {
   const fr29 r2s = fr29_r2s();
   for (size_t k = blockIdx.x * (size_t)blockDim.x + threadIdx.x; k < s; k += (size_t)gridDim.x * blockDim.x) {
     const uint64_t a = k < n_lookups ? idx[k * C + col] : 0;   // access_sequence.resize(s, 0)  densified.rs:38
     if (a >= m) { atomicOr(bad, 1u); }                           // debug_assert!(memory_address < m)  :46
-    keys[k] = (uint32_t)a; vals[k] = (uint32_t)k; dim_u32[k] = (uint32_t)a;
-    dim_fr[k] = fr29_store(fr29_mul(fr29_from_u64_int(a), r2s));
+    keys[k] = (uint32_t)a; vals[k] = (uint32_t)k;
+    if (k % world == rank) { dim_u32[k / world] = (uint32_t)a; dim_fr[k / world] = fr29_store(fr29_mul(fr29_from_u64_int(a), r2s)); }
   }
 }
 
@@ -123,15 +125,18 @@ __global__ void __launch_bounds__(256) k_densify_runs(const uint32_t* __restrict
   }
 }
 // read_ts[pos] = rank of pos among the positions of its address (densified.rs:44-50), written as Fr
-__global__ void __launch_bounds__(256) k_densify_read(const uint32_t* __restrict__ skeys, const uint32_t* __restrict__ svals, size_t s, const uint32_t* __restrict__ run_start, fr_t* __restrict__ read_fr) {
+__global__ void __launch_bounds__(256) k_densify_read(const uint32_t* __restrict__ skeys, const uint32_t* __restrict__ svals, size_t s, const uint32_t* __restrict__ run_start, uint32_t world,
+                                                       uint32_t rank, fr_t* __restrict__ read_fr) {
   const fr29 r2s = fr29_r2s();
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < s; i += (size_t)gridDim.x * blockDim.x) {
+    const uint32_t pos = svals[i];
+    if (pos % world != rank) continue;
     const uint32_t ts = (uint32_t)i - run_start[skeys[i]];
-    read_fr[svals[i]] = fr29_store(fr29_mul(fr29_from_u64_int(ts), r2s));
+    read_fr[pos / world] = fr29_store(fr29_mul(fr29_from_u64_int(ts), r2s));
   }
 }
-__global__ void __launch_bounds__(256) k_densify_final(const uint32_t* __restrict__ run_start, const uint32_t* __restrict__ run_end, size_t m, fr_t* __restrict__ final_fr) {
+__global__ void __launch_bounds__(256) k_densify_final(const uint32_t* __restrict__ run_start, const uint32_t* __restrict__ run_end, size_t m, uint32_t world, uint32_t rank, fr_t* __restrict__ final_fr) {
   const fr29 r2s = fr29_r2s();
-  for (size_t a = blockIdx.x * (size_t)blockDim.x + threadIdx.x; a < m; a += (size_t)gridDim.x * blockDim.x)
-    final_fr[a] = fr29_store(fr29_mul(fr29_from_u64_int(run_end[a] - run_start[a]), r2s));
+  for (size_t a = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) * world + rank; a < m; a += (size_t)gridDim.x * blockDim.x * world)
+    final_fr[a / world] = fr29_store(fr29_mul(fr29_from_u64_int(run_end[a] - run_start[a]), r2s));
 }

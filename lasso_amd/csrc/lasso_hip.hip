@@ -207,21 +207,23 @@ int32_t lasso_gather(lasso_ctx* c, const lasso_fr* d_table, const uint32_t* d_id
   hipLaunchKernelGGL(k_gather, dim3(grid_for(n)), dim3(LASSO_BLOCK), 0, c->stream, (const fr_t*)d_table, d_idx, n, (fr_t*)d_out);
   HIPCHK(c, hipGetLastError()); return 0;
 }
-int32_t lasso_eq_evals(lasso_ctx* c, const lasso_fr* r, uint32_t ell, lasso_fr* d_out) {
+int32_t lasso_eq_evals(lasso_ctx* c, const lasso_fr* r, uint32_t ell, lasso_fr* d_out) { return lasso_eq_evals_scaled(c, r, ell, nullptr, d_out); }
+int32_t lasso_eq_evals_scaled(lasso_ctx* c, const lasso_fr* r, uint32_t ell, const lasso_fr* scale, lasso_fr* d_out) {
   REQUIRE(c, d_out && ell <= 40 && (r || ell == 0));
+  const fr_t sc = scale ? to_fr(scale) : fr_one();
   const size_t n = (size_t)1 << ell;
   ProfScope ps(c, LASSO_K_EQ, 32.0 * n);
   if (ell <= 12) {
     RTable R; for (uint32_t j = 0; j < ell; j++) R.r[j] = to_fr(r + j);
-    hipLaunchKernelGGL(k_eq_small, dim3(grid_for(n)), dim3(LASSO_BLOCK), 0, c->stream, R, ell, (fr_t*)d_out);
+    hipLaunchKernelGGL(k_eq_small, dim3(grid_for(n)), dim3(LASSO_BLOCK), 0, c->stream, R, ell, sc, (fr_t*)d_out);
   } else {
     // out[x] = hi[x >> lo_bits] * lo[x & mask]: two small tables (the factored evals of eq_poly.rs:44-52) then one outer-product pass
     const uint32_t lo_bits = ell / 2, hi_bits = ell - lo_bits;
     int32_t rc = ensure_scratch(c, (((size_t)1 << hi_bits) + ((size_t)1 << lo_bits)) * sizeof(fr_t)); if (rc) return rc;
     fr_t* hi = (fr_t*)c->d_scratch; fr_t* lo = hi + ((size_t)1 << hi_bits);
     RTable Rh, Rl; for (uint32_t j = 0; j < hi_bits; j++) Rh.r[j] = to_fr(r + j); for (uint32_t j = 0; j < lo_bits; j++) Rl.r[j] = to_fr(r + hi_bits + j);
-    hipLaunchKernelGGL(k_eq_small, dim3(grid_for((size_t)1 << hi_bits)), dim3(LASSO_BLOCK), 0, c->stream, Rh, hi_bits, hi);
-    hipLaunchKernelGGL(k_eq_small, dim3(grid_for((size_t)1 << lo_bits)), dim3(LASSO_BLOCK), 0, c->stream, Rl, lo_bits, lo);
+    hipLaunchKernelGGL(k_eq_small, dim3(grid_for((size_t)1 << hi_bits)), dim3(LASSO_BLOCK), 0, c->stream, Rh, hi_bits, sc, hi);
+    hipLaunchKernelGGL(k_eq_small, dim3(grid_for((size_t)1 << lo_bits)), dim3(LASSO_BLOCK), 0, c->stream, Rl, lo_bits, fr_one(), lo);
     hipLaunchKernelGGL(k_eq_outer, dim3(grid_for(n, 4096)), dim3(LASSO_BLOCK), 0, c->stream, (const fr_t*)hi, (const fr_t*)lo, lo_bits, n, (fr_t*)d_out);
   }
   HIPCHK(c, hipGetLastError()); return 0;
@@ -369,10 +371,14 @@ int32_t lasso_fingerprint_ops(lasso_ctx* c, const lasso_fr* d_table, const uint3
   HIPCHK(c, hipGetLastError()); return 0;
 }
 int32_t lasso_fingerprint_mem(lasso_ctx* c, const lasso_fr* d_table, const lasso_fr* d_final, size_t m, const lasso_fr* gamma, const lasso_fr* tau, lasso_fr* d_init_out, lasso_fr* d_final_out) {
-  REQUIRE(c, d_table && d_final && gamma && tau && d_init_out && d_final_out); if (!m) return 0;
+  return lasso_fingerprint_mem_slab(c, d_table, d_final, m, 1, 0, gamma, tau, d_init_out, d_final_out);
+}
+int32_t lasso_fingerprint_mem_slab(lasso_ctx* c, const lasso_fr* d_table, const lasso_fr* d_final, size_t m, uint32_t world, uint32_t rank, const lasso_fr* gamma, const lasso_fr* tau,
+                                   lasso_fr* d_init_out, lasso_fr* d_final_out) {
+  REQUIRE(c, d_table && d_final && gamma && tau && d_init_out && d_final_out && world >= 1 && rank < world); if (!m) return 0;
   fr_t g = to_fr(gamma), g2 = fr_sqr(g), t = to_fr(tau);
   ProfScope ps(c, LASSO_K_FINGERPRINT, (64.0 + 64.0) * m);
-  hipLaunchKernelGGL(k_fingerprint_mem, dim3(grid_for(m, 4096)), dim3(LASSO_BLOCK), 0, c->stream, (const fr_t*)d_table, (const fr_t*)d_final, m, g, g2, t, (fr_t*)d_init_out, (fr_t*)d_final_out);
+  hipLaunchKernelGGL(k_fingerprint_mem, dim3(grid_for(m, 4096)), dim3(LASSO_BLOCK), 0, c->stream, (const fr_t*)d_table, (const fr_t*)d_final, m, world, rank, g, g2, t, (fr_t*)d_init_out, (fr_t*)d_final_out);
   HIPCHK(c, hipGetLastError()); return 0;
 }
 int32_t lasso_matvec_left(lasso_ctx* c, const lasso_fr* d_Z, const lasso_fr* L, size_t l_size, size_t r_size, lasso_fr* out) {
@@ -400,7 +406,12 @@ int32_t lasso_matvec_left(lasso_ctx* c, const lasso_fr* d_Z, const lasso_fr* L, 
 // ------------------------------------------------------------------ densify (densified.rs:22-75)
 int32_t lasso_densify_dim(lasso_ctx* c, const uint64_t* d_indices, size_t n_lookups, size_t C, size_t dim, size_t s, uint32_t log_m, uint32_t* d_dim_u32, lasso_fr* d_dim, lasso_fr* d_read,
                           lasso_fr* d_final) {
+  return lasso_densify_dim_slab(c, d_indices, n_lookups, C, dim, s, log_m, 1, 0, d_dim_u32, d_dim, d_read, d_final);
+}
+int32_t lasso_densify_dim_slab(lasso_ctx* c, const uint64_t* d_indices, size_t n_lookups, size_t C, size_t dim, size_t s, uint32_t log_m, uint32_t world, uint32_t rank, uint32_t* d_dim_u32,
+                               lasso_fr* d_dim, lasso_fr* d_read, lasso_fr* d_final) {
   REQUIRE(c, d_indices && d_dim_u32 && d_dim && d_read && d_final && C >= 1 && dim < C && s >= 1 && (s & (s - 1)) == 0 && n_lookups <= s && s < ((size_t)1 << 32) && log_m <= 32);
+  REQUIRE(c, world >= 1 && (world & (world - 1)) == 0 && rank < world && world <= s && world <= ((size_t)1 << log_m));
   const size_t m = (size_t)1 << log_m;
   const uint32_t ntiles = (uint32_t)((s + RADIX_TILE - 1) / RADIX_TILE);
   const size_t nh = (size_t)256 * ntiles, nb = (nh + 4095) / 4096;
@@ -411,7 +422,7 @@ int32_t lasso_densify_dim(lasso_ctx* c, const uint64_t* d_indices, size_t n_look
   HIPCHK(c, hipMemsetAsync(c->d_flags, 0, 8, c->stream));
   HIPCHK(c, hipMemsetAsync(run_start, 0, 2 * m * 4, c->stream));
   ProfScope ps(c, LASSO_K_MISC, 8.0 * n_lookups + (32.0 * 2 + 4.0) * s + 32.0 * m);
-  hipLaunchKernelGGL(k_densify_extract, dim3(grid_for(s, 4096)), dim3(256), 0, c->stream, d_indices, n_lookups, C, dim, s, (uint64_t)m, kA, vA, d_dim_u32, (fr_t*)d_dim, c->d_flags);
+  hipLaunchKernelGGL(k_densify_extract, dim3(grid_for(s, 4096)), dim3(256), 0, c->stream, d_indices, n_lookups, C, dim, s, (uint64_t)m, world, rank, kA, vA, d_dim_u32, (fr_t*)d_dim, c->d_flags);
   const uint32_t npass = log_m == 0 ? 1 : (log_m + 7) / 8;
   for (uint32_t p = 0; p < npass; p++) {
     hipLaunchKernelGGL(k_radix_hist, dim3(ntiles), dim3(RADIX_THREADS), 0, c->stream, (const uint32_t*)kA, s, 8 * p, hist, ntiles);
@@ -422,8 +433,8 @@ int32_t lasso_densify_dim(lasso_ctx* c, const uint64_t* d_indices, size_t n_look
     std::swap(kA, kB); std::swap(vA, vB);
   }
   hipLaunchKernelGGL(k_densify_runs, dim3(grid_for(s, 4096)), dim3(256), 0, c->stream, (const uint32_t*)kA, s, run_start, run_end);
-  hipLaunchKernelGGL(k_densify_read, dim3(grid_for(s, 4096)), dim3(256), 0, c->stream, (const uint32_t*)kA, (const uint32_t*)vA, s, (const uint32_t*)run_start, (fr_t*)d_read);
-  hipLaunchKernelGGL(k_densify_final, dim3(grid_for(m, 4096)), dim3(256), 0, c->stream, (const uint32_t*)run_start, (const uint32_t*)run_end, m, (fr_t*)d_final);
+  hipLaunchKernelGGL(k_densify_read, dim3(grid_for(s, 4096)), dim3(256), 0, c->stream, (const uint32_t*)kA, (const uint32_t*)vA, s, (const uint32_t*)run_start, world, rank, (fr_t*)d_read);
+  hipLaunchKernelGGL(k_densify_final, dim3(grid_for(m / world, 4096)), dim3(256), 0, c->stream, (const uint32_t*)run_start, (const uint32_t*)run_end, m, world, rank, (fr_t*)d_final);
   HIPCHK(c, hipGetLastError());
   uint32_t flags[2];
   HIPCHK(c, hipMemcpyAsync(flags, c->d_flags, 8, hipMemcpyDeviceToHost, c->stream));

@@ -373,10 +373,10 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_multi_dot(PtrTable polys, const
 // ------------------------------------------------------------------ K6: eq evals (eq_poly.rs:22-38)
 // small table: out[x] = prod_j (bit_j(x) ? r[j] : 1 - r[j]), bit 0 of the product order = most significant bit of x
 struct RTable { fr_t r[32]; };
-__global__ void k_eq_small(RTable R, uint32_t ell, fr_t* __restrict__ out) {
+__global__ void k_eq_small(RTable R, uint32_t ell, fr_t scale, fr_t* __restrict__ out) {
   size_t x = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (x >= ((size_t)1 << ell)) return;
-  fr29 p = fr29_unpack_u(fr_one());
+  fr29 p = fr29_unpack_u(scale);   // 1 normally; in slab mode the eq factor of the rank's low index bits
   const fr29 one_s = fr29_one_s();
   for (uint32_t j = 0; j < ell; j++) { const bool bit = (x >> (ell - 1 - j)) & 1; const fr29 rs = fr29_unpack_s(R.r[j]); p = fr29_mul(bit ? rs : fr29_sub(one_s, rs), p); }
   out[x] = fr29_store(p);
@@ -416,11 +416,13 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_fingerprint_ops(const fr_t* __r
     out_w[i] = fr29_store(fr29_add(h, g2u));   // ts+1: (t+1)*gamma^2 = t*gamma^2 + gamma^2
   }
 }
-__global__ void __launch_bounds__(LASSO_BLOCK) k_fingerprint_mem(const fr_t* __restrict__ table, const fr_t* __restrict__ fin, size_t m, fr_t gamma, fr_t gamma2, fr_t tau,
+// slab mode: local index i stands for global address a = i*world + rank; `table` is the whole subtable, `fin` and the outputs are local (m = local length)
+__global__ void __launch_bounds__(LASSO_BLOCK) k_fingerprint_mem(const fr_t* __restrict__ table, const fr_t* __restrict__ fin, size_t m, uint32_t world, uint32_t rank, fr_t gamma, fr_t gamma2, fr_t tau,
                                                                   fr_t* __restrict__ out_i, fr_t* __restrict__ out_f) {
   const fr29 gs = fr29_unpack_s(gamma), g2s = fr29_unpack_s(gamma2), tu = fr29_unpack_u(tau), r2s = fr29_r2s();
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < m; i += (size_t)gridDim.x * blockDim.x) {
-    const fr29 h = fr29_canonical(fr29_sub(fr29_add(fr29_mul(fr29_unpack_u(table[i]), gs), fr29_mul(fr29_from_u64_int(i), r2s)), tu));
+    const size_t a = i * world + rank;
+    const fr29 h = fr29_canonical(fr29_sub(fr29_add(fr29_mul(fr29_unpack_u(table[a]), gs), fr29_mul(fr29_from_u64_int(a), r2s)), tu));
     out_i[i] = fr29_pack(h);
     out_f[i] = fr29_store(fr29_add(h, fr29_mul(fr29_unpack_u(fin[i]), g2s)));
   }

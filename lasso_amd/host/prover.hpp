@@ -50,6 +50,39 @@ inline size_t next_pow2(size_t n) { size_t p = 1; while (p < n) p <<= 1; return 
 inline bool is_pow2(size_t n) { return n && !(n & (n - 1)); }
 inline size_t ceil_log2(size_t n) { size_t k = 0; while (((size_t)1 << k) < n) k++; return k; }  // == Math::log_2 (utils/math.rs:27-35) and ark_std::log2
 
+// ------------------------------------------------------------------ slab sharding of ONE proof over P GPUs
+// Every length-n array is split by LOW index bits: rank g of P holds {i : i mod P == g} as a contiguous local array (local j <-> global j*P + g).
+// bound_poly_var_top pairs i with i + n/2 and product-tree layers pair i with i + len/2; n/2 is a multiple of P while n/2 >= P, so both members of
+// every pair live on the same rank and every kernel runs UNCHANGED on the local array (it is the polynomial restricted to the rank's low bits, which
+// are the LAST variables bound).  What crosses ranks: per-round partial sums (a few field elements: all-gather + local sum), the partial row
+// commitments of the Hyrax matrices (every rank holds the columns = g mod P of every row: all-gather of points, summed per row), the L*Z vectors of
+// the openings, and P-element "tails" when a local array is down to one element and the remaining log2 P variables are bound on replicated copies.
+// The transcript is replicated: every rank sees the same sums, derives the same challenges and emits the same proof bytes.
+// The collective is a callback (host buffers, `bytes` per rank, rank order): torch.distributed all_gather (RCCL = "nccl", or gloo in CPU tests).
+typedef int32_t (*lasso_allgather_fn)(void* user, const void* send, void* recv, size_t bytes);
+struct Comm {
+  size_t rank = 0, world = 1; lasso_allgather_fn fn = nullptr; void* user = nullptr;
+  bool sharded() const { return world > 1; }
+  size_t log_world() const { size_t k = 0; while (((size_t)1 << k) < world) k++; return k; }
+  void allgather(const void* send, void* recv, size_t bytes) const {
+    if (world == 1) { memcpy(recv, send, bytes); return; }
+    if (!fn || fn(user, send, recv, bytes) != 0) throw std::runtime_error("lasso prover: all-gather failed");
+  }
+  // every rank contributes v.size() partial sums; all ranks get the element-wise totals (added in rank order everywhere)
+  void sum(std::vector<lasso_fr>& v) const {
+    if (world == 1 || v.empty()) return;
+    std::vector<lasso_fr> all(v.size() * world);
+    allgather(v.data(), all.data(), v.size() * sizeof(lasso_fr));
+    for (size_t i = 0; i < v.size(); i++) { Sc acc = Sc::zero(); for (size_t g = 0; g < world; g++) acc += Sc::from_abi(all[g * v.size() + i]); v[i] = acc.abi(); }
+  }
+  // eq factor of this rank's low index bits: the last log2(world) variables of `point` (r[0] is the top bit, eq_poly.rs:22-38)
+  Sc eq_low(const ScVec& point) const {
+    const size_t p = log_world(); Sc f = Sc::one();
+    for (size_t b = 0; b < p; b++) { const Sc& rv = point[point.size() - 1 - b]; f *= ((rank >> b) & 1) ? rv : (Sc::one() - rv); }
+    return f;
+  }
+};
+
 // ------------------------------------------------------------------ device handle (RAII over the C ABI)
 // Device buffers are recycled through a size-keyed pool: a proof allocates the same ~40 buffers every time and hipFree is a
 // device-wide synchronisation (the reference pays Vec allocations inside prove as well; the pool only removes the driver calls).
@@ -59,6 +92,7 @@ class Dev {
 
  public:
   lasso_ctx* ctx = nullptr;
+  Comm comm;
   explicit Dev(int device) { if (lasso_ctx_create(device, &ctx) != 0) throw Error(std::string("lasso_ctx_create: ") + lasso_last_error(nullptr)); }
   ~Dev() { if (ctx) { for (auto& kv : pool_) lasso_free(ctx, kv.second); for (auto& kv : live_) lasso_free(ctx, kv.first); lasso_ctx_destroy(ctx); } }
   Dev(const Dev&) = delete; Dev& operator=(const Dev&) = delete;
@@ -191,6 +225,7 @@ struct GenStream {
 // MultiCommitGens::new(n+1).split_at(n)); the device table holds [G_0..G_{n-1}, Q = G_n, h] so one MSM covers G, Q and h.
 struct PolyCommitmentGens {
   size_t n = 0; Pt Q, h; FixedBase Qmul, hmul; std::vector<lasso_affine> affine; lasso_bases* bases = nullptr; const Dev* dev = nullptr;
+  lasso_bases* bases_slab = nullptr;   // slab mode: the generators G_{j*P + rank}, j < n/P (this rank's columns of every Hyrax row)
   PolyCommitmentGens() {}
   PolyCommitmentGens(const Dev& d, const GenStream& gs, size_t num_vars) : dev(&d) {
     n = (size_t)1 << (num_vars - num_vars / 2);   // right = ell - ell/2 (eq_poly.rs:40-42)
@@ -206,10 +241,15 @@ struct PolyCommitmentGens {
       memcpy(affine[i].x, x.v, 32); memcpy(affine[i].y, y.v, 32);
     }
     d.chk(lasso_bases_create(d.ctx, affine.data(), n + 2, &bases), "lasso_bases_create");
+    if (d.comm.sharded()) {
+      const size_t P = d.comm.world; LASSO_REQUIRE(n >= P);
+      std::vector<lasso_affine> sub(n / P); for (size_t j = 0; j < n / P; j++) sub[j] = affine[j * P + d.comm.rank];
+      d.chk(lasso_bases_create(d.ctx, sub.data(), sub.size(), &bases_slab), "lasso_bases_create");
+    }
   }
   PolyCommitmentGens(PolyCommitmentGens&& o) noexcept { *this = std::move(o); }
-  PolyCommitmentGens& operator=(PolyCommitmentGens&& o) noexcept { std::swap(n, o.n); std::swap(Q, o.Q); std::swap(h, o.h); std::swap(Qmul, o.Qmul); std::swap(hmul, o.hmul); affine.swap(o.affine); std::swap(bases, o.bases); std::swap(dev, o.dev); return *this; }
-  ~PolyCommitmentGens() { if (bases && dev) lasso_bases_destroy(dev->ctx, bases); }
+  PolyCommitmentGens& operator=(PolyCommitmentGens&& o) noexcept { std::swap(n, o.n); std::swap(Q, o.Q); std::swap(h, o.h); std::swap(Qmul, o.Qmul); std::swap(hmul, o.hmul); affine.swap(o.affine); std::swap(bases, o.bases); std::swap(bases_slab, o.bases_slab); std::swap(dev, o.dev); return *this; }
+  ~PolyCommitmentGens() { if (bases && dev) lasso_bases_destroy(dev->ctx, bases); if (bases_slab && dev) lasso_bases_destroy(dev->ctx, bases_slab); }
 };
 struct SparsePolyCommitmentGens {  // surge.rs:25-59
   PolyCommitmentGens gens_combined_l_variate, gens_combined_log_m_variate, gens_derefs;
@@ -316,12 +356,23 @@ struct BatchedGrandProductArgument { std::vector<LayerProofBatched> proof; void 
 
 // ------------------------------------------------------------------ Hyrax commitment of a device polynomial (dense_mlpoly.rs:109-181)
 struct PolyCommitment { std::vector<uint8_t> compressed; size_t rows = 0; };   // C: Vec<G>, kept in wire form
+// d_Z: the whole polynomial, or in slab mode the rank's local array (row-major L x R/P: its columns of every row)
 inline PolyCommitment hyrax_commit(const Dev& d, const lasso_fr* d_Z, size_t num_vars, const PolyCommitmentGens& gens) {
   size_t l_size = (size_t)1 << (num_vars / 2), r_size = (size_t)1 << (num_vars - num_vars / 2);
   LASSO_REQUIRE(r_size == gens.n);
   std::vector<lasso_point> rows(l_size);
-  d.chk(lasso_hyrax_commit(d.ctx, d_Z, l_size, r_size, gens.bases, rows.data()), "lasso_hyrax_commit");
-  std::vector<Pt> pts(l_size); for (size_t i = 0; i < l_size; i++) pts[i] = Pt::from_abi(rows[i]);
+  std::vector<Pt> pts(l_size);
+  if (!d.comm.sharded()) {
+    d.chk(lasso_hyrax_commit(d.ctx, d_Z, l_size, r_size, gens.bases, rows.data()), "lasso_hyrax_commit");
+    for (size_t i = 0; i < l_size; i++) pts[i] = Pt::from_abi(rows[i]);
+  } else {
+    // partial row commitments over this rank's columns, then the exchange step of the path: all-gather the points, add per row
+    const size_t P = d.comm.world; LASSO_REQUIRE(gens.bases_slab && r_size >= P);
+    d.chk(lasso_hyrax_commit(d.ctx, d_Z, l_size, r_size / P, gens.bases_slab, rows.data()), "lasso_hyrax_commit");
+    std::vector<lasso_point> all(l_size * P);
+    d.comm.allgather(rows.data(), all.data(), l_size * sizeof(lasso_point));
+    for (size_t i = 0; i < l_size; i++) { Pt acc = Pt::from_abi(all[i]); for (size_t g = 1; g < P; g++) acc = acc + Pt::from_abi(all[g * l_size + i]); pts[i] = acc; }
+  }
   PolyCommitment c; c.rows = l_size; compress_batch(pts, c.compressed); return c;
 }
 inline void append_poly_commitment(ProofTranscript& t, const char* label, const PolyCommitment& c) {  // dense_mlpoly.rs:281-289
@@ -333,32 +384,37 @@ inline void append_poly_commitment(ProofTranscript& t, const char* label, const 
 // ------------------------------------------------------------------ DensifiedRepresentation (densified.rs:8-97)
 struct SparsePolynomialCommitment { PolyCommitment l_variate_polys_commitment, log_m_variate_polys_commitment; size_t s, log_m, m; };
 struct DensifiedRepresentation {
-  const Dev* dev; size_t C, s, log_m, m;
-  std::vector<DBufU32> dim_u32;                       // dim_usize, on device
-  DBuf combined_l_variate_polys, combined_log_m_variate_polys;   // [dim_1..dim_C, read_1..read_C | 0...], [final_1..final_C | 0...]
-  size_t nv_l, nv_m;
-  const lasso_fr* dim(size_t i) const { return combined_l_variate_polys.p + i * s; }
-  const lasso_fr* read(size_t i) const { return combined_l_variate_polys.p + (C + i) * s; }
-  const lasso_fr* final_(size_t i) const { return combined_log_m_variate_polys.p + i * m; }
+  const Dev* dev; size_t C, s, log_m, m;               // global sizes
+  size_t s_loc, m_loc;                                  // this rank's share (== s, m when not sharded)
+  std::vector<DBufU32> dim_u32;                       // dim_usize, on device (local)
+  DBuf combined_l_variate_polys, combined_log_m_variate_polys;   // [dim_1..dim_C, read_1..read_C | 0...], [final_1..final_C | 0...] (local slabs)
+  size_t nv_l, nv_m;                                    // global numbers of variables of the two merged polynomials
+  const lasso_fr* dim(size_t i) const { return combined_l_variate_polys.p + i * s_loc; }
+  const lasso_fr* read(size_t i) const { return combined_l_variate_polys.p + (C + i) * s_loc; }
+  const lasso_fr* final_(size_t i) const { return combined_log_m_variate_polys.p + i * m_loc; }
 
   // indices: n_lookups x C, row-major (the reference's Vec<[usize; C]>)
   static std::unique_ptr<DensifiedRepresentation> from_lookup_indices(const Dev& d, const uint64_t* indices, size_t n_lookups, size_t C, size_t log_m) {
     auto D = std::make_unique<DensifiedRepresentation>();
     D->dev = &d; D->C = C; D->s = next_pow2(n_lookups); D->log_m = log_m; D->m = (size_t)1 << log_m;
-    const size_t s = D->s, m = D->m;
+    const size_t s = D->s, m = D->m, P = d.comm.world;
+    if (d.comm.sharded() && (s < 2 * P || m < 2 * P)) throw Error("slab sharding needs at least 2 lookups and 2 table entries per rank");
+    D->s_loc = s / P; D->m_loc = m / P;
     size_t n_l = next_pow2(2 * C * s), n_m = next_pow2(C) * m;
     D->nv_l = ceil_log2(n_l); D->nv_m = ceil_log2(n_m);
-    D->combined_l_variate_polys = DBuf(d, n_l); D->combined_log_m_variate_polys = DBuf(d, n_m);
+    if (d.comm.sharded() && (((size_t)1 << (D->nv_m - D->nv_m / 2)) < P || ((size_t)1 << (D->nv_l - D->nv_l / 2)) < P)) throw Error("slab sharding needs every Hyrax matrix to have at least one column per rank");
+    D->combined_l_variate_polys = DBuf(d, n_l / P); D->combined_log_m_variate_polys = DBuf(d, n_m / P);
     // DensePolynomial::merge pads with zeros up to the next power of two (dense_mlpoly.rs:251-261)
-    if (n_l > 2 * C * s) d.chk(lasso_zero(d.ctx, D->combined_l_variate_polys.p + 2 * C * s, (n_l - 2 * C * s) * sizeof(lasso_fr)), "lasso_zero");
-    if (n_m > C * m) d.chk(lasso_zero(d.ctx, D->combined_log_m_variate_polys.p + C * m, (n_m - C * m) * sizeof(lasso_fr)), "lasso_zero");
+    if (n_l > 2 * C * s) d.chk(lasso_zero(d.ctx, D->combined_l_variate_polys.p + 2 * C * D->s_loc, (n_l - 2 * C * s) / P * sizeof(lasso_fr)), "lasso_zero");
+    if (n_m > C * m) d.chk(lasso_zero(d.ctx, D->combined_log_m_variate_polys.p + C * D->m_loc, (n_m - C * m) / P * sizeof(lasso_fr)), "lasso_zero");
     // densified.rs:32-57 on the device: the index array is uploaded once as the reference holds it (Vec<[usize; C]>), each dimension is one
-    // lasso_densify_dim call (stable radix sort by address -> read/final timestamps), the polynomials are written straight into the merged buffers
+    // lasso_densify_dim call (stable radix sort by address -> read/final timestamps), the polynomials are written straight into the merged buffers.
+    // Slab mode: every rank sorts the whole sequence (timestamps are a property of the whole sequence) and keeps its residue class.
     DBufU64 d_idx(d, indices, n_lookups * C);
     for (size_t i = 0; i < C; i++) {
-      DBufU32 d_access(d, s);
-      d.chk(lasso_densify_dim(d.ctx, d_idx.p, n_lookups, C, i, s, (uint32_t)log_m, d_access.p, D->combined_l_variate_polys.p + i * s, D->combined_l_variate_polys.p + (C + i) * s,
-                              D->combined_log_m_variate_polys.p + i * m), "lasso_densify_dim");
+      DBufU32 d_access(d, D->s_loc);
+      d.chk(lasso_densify_dim_slab(d.ctx, d_idx.p, n_lookups, C, i, s, (uint32_t)log_m, (uint32_t)P, (uint32_t)d.comm.rank, d_access.p, D->combined_l_variate_polys.p + i * D->s_loc,
+                                   D->combined_l_variate_polys.p + (C + i) * D->s_loc, D->combined_log_m_variate_polys.p + i * D->m_loc), "lasso_densify_dim");
       D->dim_u32.push_back(std::move(d_access));
     }
     return D;
@@ -375,22 +431,53 @@ struct DensifiedRepresentation {
 class Prover {
   const Dev& d; const Strategy S; DensifiedRepresentation& dense; const SparsePolyCommitmentGens& gens; ProofTranscript& t; RandomTape& tape;
   size_t alpha, s, m, nv_derefs;
-  std::vector<DBuf> tables;          // subtable_entries, lifted to Fr
-  DBuf combined_E;                   // Subtables::combined_poly = merge(lookup_polys); E_i = slice i
-  const lasso_fr* E(size_t i) const { return combined_E.p + i * s; }
+  size_t P, lgP, s_loc, m_loc;       // slab mode: world size, its log2, local lengths (P = 1: s_loc = s, m_loc = m)
+  std::vector<DBuf> tables;          // subtable_entries, lifted to Fr (whole tables on every rank)
+  DBuf combined_E;                   // Subtables::combined_poly = merge(lookup_polys); E_i = slice i (local slab)
+  const lasso_fr* E(size_t i) const { return combined_E.p + i * s_loc; }
+  std::vector<DBuf> tail_bufs;       // P-element replicated arrays of the current sumcheck's tail
 
  public:
   std::vector<uint8_t> proof_bytes;
   Prover(const Dev& d_, const Strategy& S_, DensifiedRepresentation& dense_, const SparsePolyCommitmentGens& gens_, ProofTranscript& t_, RandomTape& tape_)
-      : d(d_), S(S_), dense(dense_), gens(gens_), t(t_), tape(tape_) { alpha = S.num_memories(); s = dense.s; m = dense.m; LASSO_REQUIRE(S.C() == dense.C && S.M() == dense.m); }
+      : d(d_), S(S_), dense(dense_), gens(gens_), t(t_), tape(tape_) {
+    alpha = S.num_memories(); s = dense.s; m = dense.m; LASSO_REQUIRE(S.C() == dense.C && S.M() == dense.m);
+    P = d.comm.world; lgP = d.comm.log_world(); s_loc = dense.s_loc; m_loc = dense.m_loc;
+  }
 
-  // ---- SumcheckInstanceProof::prove_arbitrary (sumcheck.rs:150-260); polys[0..alpha) = E clones, polys[alpha] = eq
-  SumcheckProof prove_arbitrary(size_t num_rounds, std::vector<lasso_fr*>& polys, size_t combined_degree, ScVec& r_out) {
-    SumcheckProof proof; size_t len = (size_t)1 << num_rounds;
+  // ---- slab helpers
+  // this rank's share of EqPolynomial(point).evals(): table over the high variables times the eq factor of the rank's low bits (needs 2^|point| >= P)
+  void eq_evals_local(const ScVec& point, lasso_fr* d_out) {
+    LASSO_REQUIRE(point.size() >= lgP);
+    std::vector<lasso_fr> rr; for (size_t i = 0; i + lgP < point.size(); i++) rr.push_back(point[i].abi());
+    if (P == 1) { d.chk(lasso_eq_evals(d.ctx, rr.data(), (uint32_t)rr.size(), d_out), "lasso_eq_evals"); return; }
+    lasso_fr sc = d.comm.eq_low(point).abi();
+    d.chk(lasso_eq_evals_scaled(d.ctx, rr.data(), (uint32_t)rr.size(), &sc, d_out), "lasso_eq_evals_scaled");
+  }
+  // local arrays are down to ONE element each: all-gather them into P-element replicated arrays (index = rank = the remaining low variables)
+  std::vector<lasso_fr*> gather_tail(const std::vector<lasso_fr*>& polys) {
+    const size_t k = polys.size();
+    std::vector<lasso_fr> mine(k), all(k * P), col(P);
+    d.chk(lasso_read_heads(d.ctx, (const lasso_fr* const*)polys.data(), (uint32_t)k, mine.data()), "lasso_read_heads");
+    d.comm.allgather(mine.data(), all.data(), k * sizeof(lasso_fr));
+    std::vector<lasso_fr*> out;
+    for (size_t i = 0; i < k; i++) {
+      for (size_t g = 0; g < P; g++) col[g] = all[g * k + i];
+      tail_bufs.emplace_back(d, P);
+      d.chk(lasso_upload(d.ctx, tail_bufs.back().p, col.data(), P * sizeof(lasso_fr)), "lasso_upload");
+      out.push_back(tail_bufs.back().p);
+    }
+    return out;
+  }
+
+  // ---- SumcheckInstanceProof::prove_arbitrary (sumcheck.rs:150-260); polys[0..alpha) = E clones, polys[alpha] = eq.
+  // One phase = `rounds` rounds on arrays of current length len; `reduce` = the arrays are slabs, per-round sums are all-gathered and added.
+  void arbitrary_rounds(size_t rounds, size_t len, std::vector<lasso_fr*>& polys, size_t combined_degree, bool reduce, SumcheckProof& proof, ScVec& r_out) {
     std::vector<const lasso_fr*> cp(polys.begin(), polys.begin() + alpha);
-    for (size_t round = 0; round < num_rounds; round++) {
+    for (size_t round = 0; round < rounds; round++) {
       std::vector<lasso_fr> ev(combined_degree + 1);
       d.chk(lasso_sumcheck_combine_round(d.ctx, &S.abi, cp.data(), polys[alpha], len, (uint32_t)combined_degree, ev.data()), "lasso_sumcheck_combine_round");
+      if (reduce) d.comm.sum(ev);
       ScVec evals; for (auto& e : ev) evals.push_back(Sc::from_abi(e));
       UniPoly up = UniPoly::from_evals(evals);
       up.append_to_transcript(t, "poly");
@@ -400,18 +487,29 @@ class Prover {
       len /= 2;
       proof.compressed_polys.push_back(up.compress());
     }
+  }
+  // polys: local arrays of length len_loc (global length len_loc * P)
+  SumcheckProof prove_arbitrary(size_t num_rounds, size_t len_loc, std::vector<lasso_fr*>& polys, size_t combined_degree, ScVec& r_out) {
+    SumcheckProof proof;
+    if (P == 1) { arbitrary_rounds(num_rounds, len_loc, polys, combined_degree, false, proof, r_out); return proof; }
+    LASSO_REQUIRE(num_rounds >= lgP && ((size_t)1 << (num_rounds - lgP)) == len_loc);
+    arbitrary_rounds(num_rounds - lgP, len_loc, polys, combined_degree, true, proof, r_out);
+    std::vector<lasso_fr*> tail = gather_tail(polys);
+    arbitrary_rounds(lgP, P, tail, combined_degree, false, proof, r_out);
+    tail_bufs.clear();
     return proof;
   }
   // ---- SumcheckInstanceProof::prove_cubic_batched (sumcheck.rs:27-135), comb = A*B*C.
   // Round j's bind (sumcheck.rs:116-120) is executed by the same kernel that evaluates round j+1, so a round is ONE launch;
   // the eq polynomial ping-pongs between Cp and Cq (see lasso_sumcheck_cubic_round_fused).  Values and order of everything that
-  // reaches the transcript are unchanged.
-  SumcheckProof prove_cubic_batched(const Sc& claim, size_t num_rounds, std::vector<lasso_fr*>& A, std::vector<lasso_fr*>& B, lasso_fr* Cp, lasso_fr* Cq, const ScVec& coeffs, ScVec& r_out,
-                                    ScVec& claims_a, ScVec& claims_b) {
-    SumcheckProof proof; Sc e = claim; size_t len = (size_t)1 << num_rounds; const size_t k = A.size();
+  // reaches the transcript are unchanged.  One phase = `rounds` rounds on arrays of length len (>= 2 when rounds > 0), ending with all
+  // polynomials (eq included when `bind_c`) bound by the last challenge; returns where the bound eq polynomial lives.
+  lasso_fr* cubic_rounds(size_t rounds, size_t len, std::vector<lasso_fr*>& A, std::vector<lasso_fr*>& B, lasso_fr* Cp, lasso_fr* Cq, const ScVec& coeffs, bool reduce, bool bind_c, Sc& e,
+                         SumcheckProof& proof, ScVec& r_out) {
+    const size_t k = A.size();
     lasso_fr* c_cur = Cp; lasso_fr* c_nxt = Cq;
     Sc r_prev = Sc::zero();
-    for (size_t j = 0; j < num_rounds; j++) {
+    for (size_t j = 0; j < rounds; j++) {
       std::vector<lasso_fr> ev(3 * k);
       if (j == 0) {
         d.chk(lasso_sumcheck_cubic_round(d.ctx, (const lasso_fr* const*)A.data(), (const lasso_fr* const*)B.data(), (uint32_t)k, c_cur, len, ev.data()), "lasso_sumcheck_cubic_round");
@@ -420,6 +518,7 @@ class Prover {
         d.chk(lasso_sumcheck_cubic_round_fused(d.ctx, A.data(), B.data(), (uint32_t)k, c_cur, c_nxt, len, &rp, ev.data()), "lasso_sumcheck_cubic_round_fused");
         std::swap(c_cur, c_nxt); len /= 2;
       }
+      if (reduce) d.comm.sum(ev);
       Sc c0 = Sc::zero(), c2 = Sc::zero(), c3 = Sc::zero();
       for (size_t i = 0; i < k; i++) { c0 += Sc::from_abi(ev[3 * i]) * coeffs[i]; c2 += Sc::from_abi(ev[3 * i + 1]) * coeffs[i]; c3 += Sc::from_abi(ev[3 * i + 2]) * coeffs[i]; }
       UniPoly poly = UniPoly::from_evals({c0, e - c0, c2, c3});
@@ -429,34 +528,66 @@ class Prover {
       e = poly.evaluate(r_j);
       proof.compressed_polys.push_back(poly.compress());
     }
-    std::vector<lasso_fr*> ab(A); ab.insert(ab.end(), B.begin(), B.end());
-    if (num_rounds) {   // the last challenge still has to be bound (len == 2 here); the eq polynomial's final value is not used
+    if (rounds) {   // the last challenge of the phase still has to be bound (len == 2 here)
+      std::vector<lasso_fr*> ab(A); ab.insert(ab.end(), B.begin(), B.end()); if (bind_c) ab.push_back(c_cur);
       lasso_fr rp = r_prev.abi();
       d.chk(lasso_bind_top(d.ctx, ab.data(), (uint32_t)ab.size(), len, &rp), "lasso_bind_top");
     }
+    return c_cur;
+  }
+  // A, B: local arrays of length len_loc = 2^num_rounds / P (slab mode) or the whole arrays; Cp = eq table of the same length, Cq = scratch of half of it
+  SumcheckProof prove_cubic_batched(const Sc& claim, size_t num_rounds, bool slab, std::vector<lasso_fr*>& A, std::vector<lasso_fr*>& B, lasso_fr* Cp, lasso_fr* Cq, const ScVec& coeffs, ScVec& r_out,
+                                    ScVec& claims_a, ScVec& claims_b) {
+    SumcheckProof proof; Sc e = claim; const size_t k = A.size();
+    std::vector<lasso_fr*> fa(A), fb(B);   // where the final values end up
+    if (!slab) {
+      cubic_rounds(num_rounds, (size_t)1 << num_rounds, fa, fb, Cp, Cq, coeffs, false, false, e, proof, r_out);   // the eq polynomial's final value is not used
+    } else {
+      LASSO_REQUIRE(num_rounds >= lgP);
+      lasso_fr* c_fin = cubic_rounds(num_rounds - lgP, (size_t)1 << (num_rounds - lgP), fa, fb, Cp, Cq, coeffs, true, true, e, proof, r_out);
+      std::vector<lasso_fr*> heads(fa); heads.insert(heads.end(), fb.begin(), fb.end()); heads.push_back(c_fin);
+      std::vector<lasso_fr*> tail = gather_tail(heads);
+      fa.assign(tail.begin(), tail.begin() + k); fb.assign(tail.begin() + k, tail.begin() + 2 * k);
+      tail_bufs.emplace_back(d, P);   // ping-pong partner of the tail's eq array
+      cubic_rounds(lgP, P, fa, fb, tail[2 * k], tail_bufs.back().p, coeffs, false, false, e, proof, r_out);
+    }
+    std::vector<lasso_fr*> ab(fa); ab.insert(ab.end(), fb.begin(), fb.end());
     std::vector<lasso_fr> heads(2 * k);
     d.chk(lasso_read_heads(d.ctx, (const lasso_fr* const*)ab.data(), (uint32_t)(2 * k), heads.data()), "lasso_read_heads");
     claims_a.clear(); claims_b.clear();
     for (size_t i = 0; i < k; i++) { claims_a.push_back(Sc::from_abi(heads[i])); claims_b.push_back(Sc::from_abi(heads[k + i])); }
+    tail_bufs.clear();
     return proof;
   }
-  // ---- BatchedGrandProductArgument::prove (grand_product.rs:101-201).  trees[c]: 2n-2 elements, layer k at offset n*(2 - 2^(1-k))
-  BatchedGrandProductArgument bgpa_prove(std::vector<lasso_fr*>& trees, size_t n, const ScVec& roots, ScVec& rand_out) {
+  // ---- BatchedGrandProductArgument::prove (grand_product.rs:101-201).
+  // trees[c]: product tree of n_loc leaves (2*n_loc - 2 elements: layer k at offset n_loc*(2 - 2^(1-k))); in slab mode n_loc = n / P and the tree is the
+  // rank's residue class of the global tree down to the global layer of 2P elements; the global layers of P, P/2, .., 2 elements are replicated in tops[c]
+  // (P elements = the ranks' local roots, then their product tree).
+  BatchedGrandProductArgument bgpa_prove(std::vector<lasso_fr*>& trees, std::vector<lasso_fr*>& tops, size_t n, const ScVec& roots, ScVec& rand_out) {
     Trace tr("BatchedGrandProductArgument.prove", d.ctx);
-    BatchedGrandProductArgument out; const size_t k = trees.size(), num_layers = ceil_log2(n);
+    BatchedGrandProductArgument out; const size_t k = trees.size(), num_layers = ceil_log2(n), n_loc = n / P;
     ScVec claims_to_verify = roots, rand;
-    DBuf eq(d, n / 2 ? n / 2 : 1), eq2(d, n / 4 ? n / 4 : 1);
+    DBuf eq(d, std::max(n_loc / 2, P)), eq2(d, std::max(n_loc / 4, P));   // slab layers use n_loc/2 entries; replicated top layers at most P/2
     for (size_t layer_id = num_layers; layer_id-- > 0;) {
-      size_t len = n >> layer_id, off = 2 * n - 2 * len;    // layer `layer_id` has n/2^layer_id elements
-      std::vector<lasso_fr> rr; for (auto& x : rand) rr.push_back(x.abi());
-      d.chk(lasso_eq_evals(d.ctx, rr.data(), (uint32_t)rr.size(), eq.p), "lasso_eq_evals");   // poly_C_par :122
+      const size_t len = n >> layer_id;                     // global layer `layer_id` has n/2^layer_id elements
       LASSO_REQUIRE(((size_t)1 << rand.size()) == len / 2);
-      size_t num_rounds_prod = ceil_log2(len / 2);
-      std::vector<lasso_fr*> A, B; for (auto* tr : trees) { A.push_back(tr + off); B.push_back(tr + off + len / 2); }
+      const size_t num_rounds_prod = ceil_log2(len / 2);
+      const bool slab = P > 1 && len >= 2 * P;              // this layer lives in the local trees; smaller ones in the replicated tops
+      std::vector<lasso_fr*> A, B;
+      if (slab || P == 1) {
+        const size_t len_l = len / P, off = 2 * n_loc - 2 * len_l;
+        for (auto* tr : trees) { A.push_back(tr + off); B.push_back(tr + off + len_l / 2); }
+        eq_evals_local(rand, eq.p);                                                             // poly_C_par :122
+      } else {
+        const size_t off = 2 * P - 2 * len;
+        for (auto* tp : tops) { A.push_back(tp + off); B.push_back(tp + off + len / 2); }
+        std::vector<lasso_fr> rr; for (auto& x : rand) rr.push_back(x.abi());
+        d.chk(lasso_eq_evals(d.ctx, rr.data(), (uint32_t)rr.size(), eq.p), "lasso_eq_evals");
+      }
       ScVec coeff_vec = t.challenge_vector("rand_coeffs_next_layer", claims_to_verify.size());
       Sc claim = Sc::zero(); for (size_t i = 0; i < claims_to_verify.size(); i++) claim += claims_to_verify[i] * coeff_vec[i];
       LayerProofBatched lp; ScVec rand_prod;
-      lp.proof = prove_cubic_batched(claim, num_rounds_prod, A, B, eq.p, eq2.p, coeff_vec, rand_prod, lp.claims_prod_left, lp.claims_prod_right);
+      lp.proof = prove_cubic_batched(claim, num_rounds_prod, slab, A, B, eq.p, eq2.p, coeff_vec, rand_prod, lp.claims_prod_left, lp.claims_prod_right);
       for (size_t i = 0; i < k; i++) { t.append_scalar("claim_prod_left", lp.claims_prod_left[i]); t.append_scalar("claim_prod_right", lp.claims_prod_right[i]); }
       Sc r_layer = t.challenge_scalar("challenge_r_layer");
       claims_to_verify.clear();
@@ -538,7 +669,17 @@ class Prover {
     size_t left = num_vars / 2, right = num_vars - left;
     ScVec L = eq_evals_host(r.data(), left), R = eq_evals_host(r.data() + left, right);
     std::vector<lasso_fr> Lh(L.size()), LZh(R.size()); for (size_t i = 0; i < L.size(); i++) Lh[i] = L[i].abi();
-    d.chk(lasso_matvec_left(d.ctx, d_poly, Lh.data(), L.size(), R.size(), LZh.data()), "lasso_matvec_left");
+    if (this->P == 1) {
+      d.chk(lasso_matvec_left(d.ctx, d_poly, Lh.data(), L.size(), R.size(), LZh.data()), "lasso_matvec_left");
+    } else {
+      // slab mode: d_poly holds this rank's columns (= rank mod P) of every row, so the rank computes its entries of L*Z in full; the vector is
+      // all-gathered and the opening's bullet reduction (latency-bound, sqrt(n)-sized) runs replicated on every rank with the same transcript
+      const size_t Pw = this->P, r_loc = R.size() / Pw; LASSO_REQUIRE(R.size() >= Pw);
+      std::vector<lasso_fr> mine(r_loc), all(R.size());
+      d.chk(lasso_matvec_left(d.ctx, d_poly, Lh.data(), L.size(), r_loc, mine.data()), "lasso_matvec_left");
+      d.comm.allgather(mine.data(), all.data(), r_loc * sizeof(lasso_fr));
+      for (size_t g = 0; g < Pw; g++) for (size_t j = 0; j < r_loc; j++) LZh[j * Pw + g] = all[g * r_loc + j];
+    }
     ScVec LZ; for (auto& x : LZh) LZ.push_back(Sc::from_abi(x));
     return dot_product_log_prove(g, LZ, R, Zr);
   }
@@ -568,10 +709,10 @@ class Prover {
     auto host_tables = S.materialize_subtables();
     for (auto& ht : host_tables) { DBufU32 tmp(d, ht); DBuf tb(d, m); d.chk(lasso_fr_from_u32(d.ctx, tmp.p, m, tb.p), "lasso_fr_from_u32"); d.chk(lasso_sync(d.ctx), "lasso_sync"); tables.push_back(std::move(tb)); }
     size_t n_E = next_pow2(alpha * s); nv_derefs = ceil_log2(n_E);
-    combined_E = DBuf(d, n_E);
-    if (n_E > alpha * s) d.chk(lasso_zero(d.ctx, combined_E.p + alpha * s, (n_E - alpha * s) * sizeof(lasso_fr)), "lasso_zero");
+    combined_E = DBuf(d, n_E / P);
+    if (n_E > alpha * s) d.chk(lasso_zero(d.ctx, combined_E.p + alpha * s_loc, (n_E - alpha * s) / P * sizeof(lasso_fr)), "lasso_zero");
     for (size_t i = 0; i < alpha; i++)
-      d.chk(lasso_gather(d.ctx, tables[S.memory_to_subtable_index(i)].p, dense.dim_u32[S.memory_to_dimension_index(i)].p, s, combined_E.p + i * s), "lasso_gather");
+      d.chk(lasso_gather(d.ctx, tables[S.memory_to_subtable_index(i)].p, dense.dim_u32[S.memory_to_dimension_index(i)].p, s_loc, combined_E.p + i * s_loc), "lasso_gather");
     ProofWriter W;
     // comm_derefs
     sp.reset(new Trace("Subtables.commit", d.ctx));
@@ -582,34 +723,35 @@ class Prover {
     W.pts_vec(comm_derefs.compressed);
     // claim
     sp.reset(new Trace("Subtables.compute_sumcheck_claim", d.ctx));
-    DBuf eq(d, s);
-    { std::vector<lasso_fr> rr; for (auto& x : r) rr.push_back(x.abi()); d.chk(lasso_eq_evals(d.ctx, rr.data(), (uint32_t)rr.size(), eq.p), "lasso_eq_evals"); }
+    DBuf eq(d, s_loc);
+    eq_evals_local(r, eq.p);
     std::vector<const lasso_fr*> Eptr; for (size_t i = 0; i < alpha; i++) Eptr.push_back(E(i));
-    lasso_fr claim_abi; d.chk(lasso_combine_claim(d.ctx, &S.abi, Eptr.data(), eq.p, s, &claim_abi), "lasso_combine_claim");
-    Sc claimed_eval = Sc::from_abi(claim_abi);
+    std::vector<lasso_fr> claim_abi(1); d.chk(lasso_combine_claim(d.ctx, &S.abi, Eptr.data(), eq.p, s_loc, claim_abi.data()), "lasso_combine_claim");
+    d.comm.sum(claim_abi);
+    Sc claimed_eval = Sc::from_abi(claim_abi[0]);
     t.append_scalar("claim_eval_scalar_product", claimed_eval);
     // primary sumcheck on clones of E_i and the eq polynomial (surge.rs:151-172)
     ScVec r_z;
     sp.reset(new Trace("Sumcheck.prove", d.ctx));
     {
-      DBuf work(d, alpha * s);
-      d.chk(lasso_copy(d.ctx, work.p, combined_E.p, alpha * s * sizeof(lasso_fr)), "lasso_copy");
-      std::vector<lasso_fr*> polys; for (size_t i = 0; i < alpha; i++) polys.push_back(work.p + i * s); polys.push_back(eq.p);
-      SumcheckProof sp = prove_arbitrary(ceil_log2(s), polys, S.sumcheck_poly_degree(), r_z);
+      DBuf work(d, alpha * s_loc);
+      d.chk(lasso_copy(d.ctx, work.p, combined_E.p, alpha * s_loc * sizeof(lasso_fr)), "lasso_copy");
+      std::vector<lasso_fr*> polys; for (size_t i = 0; i < alpha; i++) polys.push_back(work.p + i * s_loc); polys.push_back(eq.p);
+      SumcheckProof sp = prove_arbitrary(ceil_log2(s), s_loc, polys, S.sumcheck_poly_degree(), r_z);
       sp.write(W);
     }
     W.sc(claimed_eval);
     // eval_derefs = E_i(r_z) (surge.rs:175-176)
     sp.reset(new Trace("CombinedEval.prove", d.ctx));
-    DBuf chis(d, s);
-    auto evaluate_at = [&](const std::vector<const lasso_fr*>& polys, const ScVec& point, size_t n, DBuf& chi) {
-      std::vector<lasso_fr> rr; for (auto& x : point) rr.push_back(x.abi());
-      d.chk(lasso_eq_evals(d.ctx, rr.data(), (uint32_t)rr.size(), chi.p), "lasso_eq_evals");
+    DBuf chis(d, s_loc);
+    auto evaluate_at = [&](const std::vector<const lasso_fr*>& polys, const ScVec& point, size_t n_loc, DBuf& chi) {
+      eq_evals_local(point, chi.p);
       std::vector<lasso_fr> out(polys.size());
-      d.chk(lasso_multi_dot(d.ctx, polys.data(), (uint32_t)polys.size(), chi.p, n, out.data()), "lasso_multi_dot");
+      d.chk(lasso_multi_dot(d.ctx, polys.data(), (uint32_t)polys.size(), chi.p, n_loc, out.data()), "lasso_multi_dot");
+      d.comm.sum(out);
       ScVec v; for (auto& o : out) v.push_back(Sc::from_abi(o)); return v;
     };
-    ScVec eval_derefs = evaluate_at(Eptr, r_z, s, chis);
+    ScVec eval_derefs = evaluate_at(Eptr, r_z, s_loc, chis);
     W.sc_arr(eval_derefs);
     t.append_protocol_name("Lasso CombinedTableEvalProof");
     joint_open("evals_ops_val", "challenge_combine_n_to_one", "joint_claim_eval", eval_derefs, true, combined_E.p, nv_derefs, r_z, gens.gens_derefs).write(W);
@@ -629,32 +771,50 @@ class Prover {
     std::vector<DBuf> t_init, t_read, t_write, t_final;
     for (size_t i = 0; i < alpha; i++) {
       size_t j = S.memory_to_dimension_index(i); const lasso_fr* table = tables[S.memory_to_subtable_index(i)].p;
-      DBuf ti(d, 2 * m), tf(d, 2 * m), tr(d, 2 * s), tw(d, 2 * s);
-      d.chk(lasso_fingerprint_mem(d.ctx, table, dense.final_(j), m, &g, &ta, ti.p, tf.p), "lasso_fingerprint_mem");
-      d.chk(lasso_fingerprint_ops(d.ctx, table, dense.dim_u32[j].p, dense.read(j), s, &g, &ta, tr.p, tw.p), "lasso_fingerprint_ops");
-      d.chk(lasso_gp_build(d.ctx, ti.p, m), "lasso_gp_build"); d.chk(lasso_gp_build(d.ctx, tf.p, m), "lasso_gp_build");
-      d.chk(lasso_gp_build(d.ctx, tr.p, s), "lasso_gp_build"); d.chk(lasso_gp_build(d.ctx, tw.p, s), "lasso_gp_build");
+      DBuf ti(d, 2 * m_loc), tf(d, 2 * m_loc), tr(d, 2 * s_loc), tw(d, 2 * s_loc);
+      d.chk(lasso_fingerprint_mem_slab(d.ctx, table, dense.final_(j), m_loc, (uint32_t)P, (uint32_t)d.comm.rank, &g, &ta, ti.p, tf.p), "lasso_fingerprint_mem");
+      d.chk(lasso_fingerprint_ops(d.ctx, table, dense.dim_u32[j].p, dense.read(j), s_loc, &g, &ta, tr.p, tw.p), "lasso_fingerprint_ops");
+      d.chk(lasso_gp_build(d.ctx, ti.p, m_loc), "lasso_gp_build"); d.chk(lasso_gp_build(d.ctx, tf.p, m_loc), "lasso_gp_build");
+      d.chk(lasso_gp_build(d.ctx, tr.p, s_loc), "lasso_gp_build"); d.chk(lasso_gp_build(d.ctx, tw.p, s_loc), "lasso_gp_build");
       t_init.push_back(std::move(ti)); t_final.push_back(std::move(tf)); t_read.push_back(std::move(tr)); t_write.push_back(std::move(tw));
     }
     // ProductLayerProof::prove (memory_checking.rs:674-731)
     sp.reset(new Trace("ProductLayer.prove", d.ctx));
     t.append_protocol_name("Lasso ProductLayerProof");
-    auto root = [&](const DBuf& tree, size_t n) { lasso_fr two[2]; d.chk(lasso_download(d.ctx, two, tree.p + (2 * n - 4), sizeof(two)), "lasso_download"); return Sc::from_abi(two[0]) * Sc::from_abi(two[1]); };   // GrandProductCircuit::evaluate
+    // GrandProductCircuit::evaluate = product of the last layer's two elements; in slab mode that is the rank's LOCAL root, i.e. element `rank` of the
+    // global layer of P elements: the roots are all-gathered, the global layers P, P/2, .., 2 are built from them (replicated) and the hash is the top product
+    std::vector<DBuf> tops_store;
+    auto root_and_top = [&](const DBuf& tree, size_t n_loc, lasso_fr*& top_out) {
+      lasso_fr two[2]; d.chk(lasso_download(d.ctx, two, tree.p + (2 * n_loc - 4), sizeof(two)), "lasso_download");
+      Sc local = Sc::from_abi(two[0]) * Sc::from_abi(two[1]);
+      top_out = nullptr;
+      if (P == 1) return local;
+      std::vector<lasso_fr> mine{local.abi()}, all(P);
+      d.comm.allgather(mine.data(), all.data(), sizeof(lasso_fr));
+      tops_store.emplace_back(d, 2 * P);
+      d.chk(lasso_upload(d.ctx, tops_store.back().p, all.data(), P * sizeof(lasso_fr)), "lasso_upload");
+      if (P > 2) d.chk(lasso_gp_build(d.ctx, tops_store.back().p, P), "lasso_gp_build");
+      top_out = tops_store.back().p;
+      Sc prod = Sc::one(); for (auto& x : all) prod *= Sc::from_abi(x);
+      return prod;
+    };
     ScVec roots_rw, roots_if;
+    std::vector<lasso_fr*> rw, inf, rw_top, inf_top;
     for (size_t i = 0; i < alpha; i++) {
-      Sc hi = root(t_init[i], m), hr = root(t_read[i], s), hw = root(t_write[i], s), hf = root(t_final[i], m);
+      lasso_fr *ti_top, *tr_top, *tw_top, *tf_top;
+      Sc hi = root_and_top(t_init[i], m_loc, ti_top), hr = root_and_top(t_read[i], s_loc, tr_top), hw = root_and_top(t_write[i], s_loc, tw_top), hf = root_and_top(t_final[i], m_loc, tf_top);
       if (!(hi * hw == hr * hf)) throw Error("memory checking: hash_init * hash_write != hash_read * hash_final (memory_checking.rs:689)");
       t.append_scalar("claim_hash_init", hi); t.append_scalar("claim_hash_read", hr); t.append_scalar("claim_hash_write", hw); t.append_scalar("claim_hash_final", hf);
       W.sc(hi); W.sc(hr); W.sc(hw); W.sc(hf);
       roots_rw.push_back(hr); roots_rw.push_back(hw); roots_if.push_back(hi); roots_if.push_back(hf);
+      rw.push_back(t_read[i].p); rw.push_back(t_write[i].p); inf.push_back(t_init[i].p); inf.push_back(t_final[i].p);
+      rw_top.push_back(tr_top); rw_top.push_back(tw_top); inf_top.push_back(ti_top); inf_top.push_back(tf_top);
     }
-    std::vector<lasso_fr*> rw, inf;
-    for (size_t i = 0; i < alpha; i++) { rw.push_back(t_read[i].p); rw.push_back(t_write[i].p); inf.push_back(t_init[i].p); inf.push_back(t_final[i].p); }
     ScVec rand_ops, rand_mem;
-    BatchedGrandProductArgument proof_ops = bgpa_prove(rw, s, roots_rw, rand_ops);
+    BatchedGrandProductArgument proof_ops = bgpa_prove(rw, rw_top, s, roots_rw, rand_ops);
     t_read.clear(); t_write.clear();
-    BatchedGrandProductArgument proof_mem = bgpa_prove(inf, m, roots_if, rand_mem);
-    t_init.clear(); t_final.clear();
+    BatchedGrandProductArgument proof_mem = bgpa_prove(inf, inf_top, m, roots_if, rand_mem);
+    t_init.clear(); t_final.clear(); tops_store.clear();
     proof_mem.write(W); proof_ops.write(W);    // field order of ProductLayerProof: grand_product_evals, proof_mem, proof_ops (:656-660)
     // HashLayerProof::prove (memory_checking.rs:338-460)
     sp.reset(new Trace("HashLayer.prove", d.ctx));
@@ -663,10 +823,10 @@ class Prover {
     std::vector<const lasso_fr*> at_ops(Eptr); for (size_t i = 0; i < C; i++) at_ops.push_back(dense.dim(i)); for (size_t i = 0; i < C; i++) at_ops.push_back(dense.read(i));
     ScVec ev_ops;
     {
-      std::vector<lasso_fr> rr; for (auto& x : rand_ops) rr.push_back(x.abi());
-      d.chk(lasso_eq_evals(d.ctx, rr.data(), (uint32_t)rr.size(), chis.p), "lasso_eq_evals");
+      eq_evals_local(rand_ops, chis.p);
       std::vector<lasso_fr> out(at_ops.size());
-      d.chk(lasso_multi_dot(d.ctx, at_ops.data(), (uint32_t)at_ops.size(), chis.p, s, out.data()), "lasso_multi_dot");
+      d.chk(lasso_multi_dot(d.ctx, at_ops.data(), (uint32_t)at_ops.size(), chis.p, s_loc, out.data()), "lasso_multi_dot");
+      d.comm.sum(out);
       for (auto& o : out) ev_ops.push_back(Sc::from_abi(o));
     }
     ScVec eval_derefs(ev_ops.begin(), ev_ops.begin() + alpha), eval_dim(ev_ops.begin() + alpha, ev_ops.begin() + alpha + C), eval_read(ev_ops.begin() + alpha + C, ev_ops.end());
@@ -674,12 +834,12 @@ class Prover {
     DotProductProofLog proof_derefs = joint_open("evals_ops_val", "challenge_combine_n_to_one", "joint_claim_eval", eval_derefs, true, combined_E.p, nv_derefs, rand_ops, gens.gens_derefs);
     ScVec eval_final;
     {
-      DBuf chim(d, m);
-      std::vector<lasso_fr> rr; for (auto& x : rand_mem) rr.push_back(x.abi());
-      d.chk(lasso_eq_evals(d.ctx, rr.data(), (uint32_t)rr.size(), chim.p), "lasso_eq_evals");
+      DBuf chim(d, m_loc);
+      eq_evals_local(rand_mem, chim.p);
       std::vector<const lasso_fr*> fin; for (size_t i = 0; i < C; i++) fin.push_back(dense.final_(i));
       std::vector<lasso_fr> out(C);
-      d.chk(lasso_multi_dot(d.ctx, fin.data(), (uint32_t)C, chim.p, m, out.data()), "lasso_multi_dot");
+      d.chk(lasso_multi_dot(d.ctx, fin.data(), (uint32_t)C, chim.p, m_loc, out.data()), "lasso_multi_dot");
+      d.comm.sum(out);
       for (auto& o : out) eval_final.push_back(Sc::from_abi(o));
     }
     ScVec evals_ops = eval_dim; evals_ops.insert(evals_ops.end(), eval_read.begin(), eval_read.end());

@@ -17,6 +17,11 @@ const char* lasso_host_last_error(void) { return g_err.c_str(); }
 int32_t lasso_host_create(int32_t device, lasso_host** out) { GUARD(*out = new lasso_host(device); return 0;) }
 void lasso_host_destroy(lasso_host* h) { delete h; }
 lasso_ctx* lasso_host_ctx(lasso_host* h) { return h ? h->dev.ctx : nullptr; }
+int32_t lasso_host_set_comm(lasso_host* h, int32_t rank, int32_t world, lasso_host_allgather_fn fn, void* user) {
+  GUARD(
+    if (!h || world < 1 || (world & (world - 1)) || rank < 0 || rank >= world || (world > 1 && !fn)) throw Error("lasso_host_set_comm: world must be a power of two, 0 <= rank < world, and a collective is needed when world > 1");
+    h->dev.comm.rank = (size_t)rank; h->dev.comm.world = (size_t)world; h->dev.comm.fn = fn; h->dev.comm.user = user; return 0;)
+}
 int32_t lasso_host_gens_new(lasso_host* h, const char* label, size_t c, size_t s, size_t nm, size_t log_m, lasso_host_gens** out) { GUARD(*out = new lasso_host_gens(h->dev, label, c, s, nm, log_m); return 0;) }
 void lasso_host_gens_free(lasso_host_gens* g) { delete g; }
 int32_t lasso_host_densify(lasso_host* h, const uint64_t* indices, size_t n, size_t c, size_t log_m, lasso_host_dense** out) {

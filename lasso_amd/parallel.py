@@ -62,6 +62,32 @@ class Group:
         self.dist.all_gather(out, t)
         return [bytes(o.cpu().tolist()) for o in out]
 
+    def allgather_callback(self):
+        """The collective of slab mode (include/lasso_prover.h lasso_host_set_comm): gathers `nbytes` from every rank's host buffer `send` into `recv`
+        in rank order.  RCCL over xGMI when the backend is "nccl" (staged through device tensors), gloo in the CPU tests."""
+        import ctypes as C
+        import numpy as np
+
+        def cb(_user, send, recv, nbytes):
+            try:
+                if self.dist is None:
+                    C.memmove(recv, send, nbytes)
+                    return 0
+                torch = self.torch
+                src = np.ctypeslib.as_array(C.cast(send, C.POINTER(C.c_uint8)), shape=(nbytes,))
+                dst = np.ctypeslib.as_array(C.cast(recv, C.POINTER(C.c_uint8)), shape=(nbytes * self.world,))
+                dev = "cuda" if self.backend == "nccl" else "cpu"
+                t_in = torch.from_numpy(src.copy()).to(dev)
+                t_out = torch.empty(nbytes * self.world, dtype=torch.uint8, device=dev)
+                self.dist.all_gather_into_tensor(t_out, t_in)
+                dst[:] = t_out.cpu().numpy()
+                return 0
+            except Exception as e:      # never unwind into C
+                import sys
+                print("all-gather callback failed:", repr(e), file=sys.stderr)
+                return -1
+        return cb
+
     def close(self):
         if self.dist is not None:
             self.dist.destroy_process_group()

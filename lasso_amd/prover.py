@@ -19,12 +19,16 @@ def load_prover_library(path=None):
     return C.CDLL(path)
 
 
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)   # (user, send, recv, bytes per rank) -> 0
+
+
 def declare_prover(lib):
     vp, sz, i32 = C.c_void_p, C.c_size_t, C.c_int32
     lib.lasso_host_last_error.restype = C.c_char_p
     lib.lasso_host_create.argtypes = [i32, C.POINTER(vp)]
     lib.lasso_host_destroy.argtypes = [vp]
     lib.lasso_host_ctx.argtypes = [vp]; lib.lasso_host_ctx.restype = vp
+    lib.lasso_host_set_comm.argtypes = [vp, i32, i32, ALLGATHER_FN, vp]
     lib.lasso_host_gens_new.argtypes = [vp, C.c_char_p, sz, sz, sz, sz, C.POINTER(vp)]
     lib.lasso_host_gens_free.argtypes = [vp]
     lib.lasso_host_densify.argtypes = [vp, vp, sz, sz, sz, C.POINTER(vp)]
@@ -45,6 +49,11 @@ class HostProver:
         if self.lib.lasso_host_create(device, C.byref(h)) != 0:
             raise LassoError("lasso_host_create: " + self.lib.lasso_host_last_error().decode())
         self.h = h
+
+    def set_comm(self, group):
+        """Slab mode (one proof sharded over the ranks of `group`, lasso_amd.parallel.Group): must precede gens()/densify()."""
+        self._allgather = ALLGATHER_FN(group.allgather_callback())       # keep the callback object alive
+        self._chk(self.lib.lasso_host_set_comm(self.h, group.rank, group.world, self._allgather, None))
 
     def _chk(self, rc):
         if rc != 0:

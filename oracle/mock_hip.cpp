@@ -45,6 +45,11 @@ int32_t lasso_gather(lasso_ctx*, const lasso_fr* t, const uint32_t* idx, size_t 
 int32_t lasso_eq_evals(lasso_ctx*, const lasso_fr* r, uint32_t ell, lasso_fr* o) {
   std::vector<Fr> rr(F(r), F(r) + ell); auto ev = EqPolynomial(rr).evals(); memcpy(o, ev.data(), ev.size() * 32); return 0;
 }
+int32_t lasso_eq_evals_scaled(lasso_ctx* c, const lasso_fr* r, uint32_t ell, const lasso_fr* scale, lasso_fr* o) {
+  lasso_eq_evals(c, r, ell, o);
+  if (scale) for (size_t i = 0; i < ((size_t)1 << ell); i++) F(o)[i] = F(o)[i] * *F(scale);
+  return 0;
+}
 int32_t lasso_bind_top(lasso_ctx* c, lasso_fr* const* polys, uint32_t np, size_t n, const lasso_fr* r) {
   REQ(c, n >= 2 && (n & (n - 1)) == 0);
   for (uint32_t p = 0; p < np; p++) { Fr* Z = F(polys[p]); size_t h = n / 2; for (size_t i = 0; i < h; i++) Z[i] = Z[i] + *F(r) * (Z[i + h] - Z[i]); }  // dense_mlpoly.rs:209-216
@@ -120,6 +125,16 @@ int32_t lasso_fingerprint_mem(lasso_ctx*, const lasso_fr* table, const lasso_fr*
   }
   return 0;
 }
+// slab mode: local index i stands for the global address i*world + rank (table is the whole subtable; fin and the outputs are local)
+int32_t lasso_fingerprint_mem_slab(lasso_ctx*, const lasso_fr* table, const lasso_fr* fin, size_t m, uint32_t world, uint32_t rank, const lasso_fr* gamma, const lasso_fr* tau, lasso_fr* io, lasso_fr* fo) {
+  Fr g = *F(gamma), g2 = g.square(), t = *F(tau);
+  for (size_t i = 0; i < m; i++) {
+    const size_t a = i * world + rank;
+    F(io)[i] = F(table)[a] * g + Fr::from_u64(a) - t;
+    F(fo)[i] = F(fin)[i] * g2 + F(table)[a] * g + Fr::from_u64(a) - t;
+  }
+  return 0;
+}
 int32_t lasso_matvec_left(lasso_ctx*, const lasso_fr* Z, const lasso_fr* L, size_t ls, size_t rs, lasso_fr* out) {
   for (size_t i = 0; i < rs; i++) { Fr s = Fr::zero(); for (size_t j = 0; j < ls; j++) s += F(L)[j] * F(Z)[j * rs + i]; F(out)[i] = s; }  // dense_mlpoly.rs:184-207
   return 0;
@@ -133,6 +148,17 @@ int32_t lasso_densify_dim(lasso_ctx* c, const uint64_t* idx, size_t n_lookups, s
   for (size_t k = 0; k < s; k++) { size_t a = access[k]; size_t ts = final_ts[a]; read_ts[k] = ts; final_ts[a] = ts + 1; }
   for (size_t k = 0; k < s; k++) { dim_u32[k] = (uint32_t)access[k]; F(d_dim)[k] = Fr::from_u64(access[k]); F(d_read)[k] = Fr::from_u64(read_ts[k]); }
   for (size_t a = 0; a < m; a++) F(d_final)[a] = Fr::from_u64(final_ts[a]);
+  return 0;
+}
+// slab mode: the same global timestamps, only the rank's residue class kept (global k -> local k / world)
+int32_t lasso_densify_dim_slab(lasso_ctx* c, const uint64_t* idx, size_t n_lookups, size_t C, size_t dim, size_t s, uint32_t log_m, uint32_t world, uint32_t rank, uint32_t* dim_u32, lasso_fr* d_dim,
+                               lasso_fr* d_read, lasso_fr* d_final) {
+  const size_t m = (size_t)1 << log_m;
+  REQ(c, world >= 1 && rank < world && s % world == 0 && m % world == 0);
+  std::vector<uint32_t> u(s); std::vector<lasso_fr> fd(s), fr(s), ff(m);
+  int32_t rc = lasso_densify_dim(c, idx, n_lookups, C, dim, s, log_m, u.data(), fd.data(), fr.data(), ff.data()); if (rc) return rc;
+  for (size_t k = rank; k < s; k += world) { dim_u32[k / world] = u[k]; d_dim[k / world] = fd[k]; d_read[k / world] = fr[k]; }
+  for (size_t a = rank; a < m; a += world) d_final[a / world] = ff[a];
   return 0;
 }
 int32_t lasso_bases_create(lasso_ctx*, const lasso_affine* pts, size_t n, lasso_bases** out) {

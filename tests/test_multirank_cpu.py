@@ -39,6 +39,54 @@ WORKER = textwrap.dedent('''
 ''')
 
 
+SLAB_WORKER = textwrap.dedent('''
+    import ctypes as C, os, sys
+    sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+    import numpy as np
+    from lasso_amd import _abi
+    from lasso_amd.parallel import Group
+    from lasso_amd.prover import HostProver
+    from proverutil import OracleSession, build_mock_prover
+    grp = Group(backend="gloo")
+    assert grp.world == 2
+    hp = HostProver(C.CDLL(build_mock_prover()))
+    hp.set_comm(grp)                                   # ONE proof over both ranks: torch.distributed all_gather is the only collective
+    c, log_m, lookups = 2, 6, 100
+    s = 128
+    idx = np.random.default_rng(5).integers(0, 1 << log_m, size=(lookups, c), dtype=np.uint64)     # the SAME lookups on every rank
+    r = hp.gen_random_point(7)
+    S = _abi.Strategy(_abi.KINDS["xor"], c, log_m, 0)
+    gens = hp.gens(c, s, c, log_m); dense = hp.densify(idx, log_m)
+    comm = hp.commit(dense, gens)
+    proof = hp.prove(dense, gens, S, r)
+    digests = grp.gather_digests(proof)
+    assert digests[0] == digests[1]                    # replicated transcript -> identical proof bytes on every rank
+    orc = C.CDLL(os.path.join(%(root)r, "oracle", "liblasso_oracle.so")); orc.orc_last_error.restype = C.c_char_p; orc.orc_session_new.restype = C.c_void_p
+    o = OracleSession(orc, _abi.KINDS["xor"], c, log_m, 0, idx, r)
+    assert comm == o.commit() and proof == o.prove() and o.verify(proof, comm) == 1
+    o.close(); hp.free(dense, gens); hp.close(); grp.close()
+    print("rank", grp.rank, "ok")
+''')
+
+
+def _run_two(tmp_path, body, port):
+    from proverutil import build_mock_prover
+    build_mock_prover()
+    script = tmp_path / "worker.py"
+    script.write_text(body % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(rk), LOCAL_RANK=str(rk)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for rk in range(2)]
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    for rk, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert f"rank {rk} ok" in o
+
+
+def test_one_proof_over_two_ranks_gloo(tmp_path, oracle):
+    """slab mode through the real collective plumbing (lasso_amd.parallel.Group.allgather_callback over gloo): proof == oracle proof on both ranks"""
+    _run_two(tmp_path, SLAB_WORKER, 29519)
+
+
 def test_two_ranks_gloo(tmp_path, oracle):
     from proverutil import build_mock_prover
     build_mock_prover()

@@ -1,0 +1,75 @@
+"""CPU: ONE proof sharded over P ranks (slab mode): every polynomial split by low index bits, partial sums all-gathered each round,
+partial Hyrax row commitments exchanged and added, replicated transcript.  The ranks run as threads against the oracle's mock of the device ABI
+(tests/cpp/slab_threads.cpp); the commitment and the proof must be byte-identical to the single-rank prover's AND to the oracle prover's, for
+P = 2, 4, 8 and every strategy.  The torch.distributed (gloo) collective itself is covered by tests/test_multirank_cpu.py."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from lasso_amd import _abi
+from proverutil import HostProver, OracleSession, build_mock_prover
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def build_slab_lib():
+    out_dir = os.path.join(ROOT, "tests", "_build")
+    os.makedirs(out_dir, exist_ok=True)
+    so = os.path.join(out_dir, "libslab_threads.so")
+    srcs = [os.path.join(ROOT, "tests", "cpp", "slab_threads.cpp"), os.path.join(ROOT, "lasso_amd", "host", "prover_capi.cpp"), os.path.join(ROOT, "oracle", "mock_hip.cpp")]
+    deps = srcs + [os.path.join(ROOT, "lasso_amd", "host", f) for f in ("prover.hpp", "field_host.hpp", "hashes.hpp")] + [os.path.join(ROOT, "oracle", "lasso_oracle.hpp")]
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wno-unknown-pragmas", "-o", so] + srcs)
+    return C.CDLL(so)
+
+
+@pytest.fixture(scope="module")
+def slab():
+    return build_slab_lib()
+
+
+@pytest.fixture(scope="module")
+def host():
+    hp = HostProver(C.CDLL(build_mock_prover()))
+    yield hp
+    hp.close()
+
+
+def slab_prove(lib, world, S, num_memories, idx, r):
+    idx = np.ascontiguousarray(idx, dtype=np.uint64); r = np.ascontiguousarray(r, dtype=np.uint64).reshape(-1, 4)
+    comm = (C.c_uint8 * (1 << 20))(); proof = (C.c_uint8 * (1 << 22))(); cl = C.c_size_t(); pl = C.c_size_t(); nc = C.c_size_t(); nb = C.c_size_t(); err = C.create_string_buffer(512)
+    rc = lib.slab_prove_threads(world, C.byref(S), C.c_size_t(num_memories), idx.ctypes.data_as(C.c_void_p), C.c_size_t(idx.shape[0]), r.ctypes.data_as(C.c_void_p), C.c_size_t(r.shape[0]),
+                                comm, C.c_size_t(len(comm)), C.byref(cl), proof, C.c_size_t(len(proof)), C.byref(pl), C.byref(nc), C.byref(nb), err, C.c_size_t(512))
+    assert rc == 0, err.value.decode()
+    return bytes(comm[: cl.value]), bytes(proof[: pl.value]), nc.value, nb.value
+
+
+# (kind, C, log_m, log_r, lookups): every strategy; ragged lookups; sizes where late layers are smaller than the world (replicated tops)
+CASES = [("and", 1, 4, 0, 64), ("and", 2, 4, 0, 32), ("xor", 3, 4, 0, 50), ("or", 2, 6, 0, 16), ("lt", 2, 6, 0, 32), ("range", 3, 8, 40, 16), ("and", 1, 8, 0, 1 << 9), ("xor", 4, 6, 0, 100)]
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+@pytest.mark.parametrize("kind,c,log_m,log_r,lookups", CASES)
+def test_slab_proof_equals_single_rank_and_oracle(slab, host, oracle, world, kind, c, log_m, log_r, lookups):
+    s = 1 << (lookups - 1).bit_length()
+    nv_m = (c - 1).bit_length() + log_m
+    if s < 2 * world or (1 << log_m) < 2 * world or (1 << (nv_m - nv_m // 2)) < world:
+        pytest.skip("fewer than 2 elements, or less than one Hyrax column, per rank")
+    alpha = 2 * c if kind == "lt" else c
+    idx = np.random.default_rng(world * 1000 + lookups + c).integers(0, 1 << log_m, size=(lookups, c), dtype=np.uint64)
+    r = host.gen_random_point(s.bit_length() - 1)
+    S = _abi.Strategy(_abi.KINDS[kind], c, log_m, log_r)
+    comm_p, proof_p, ncoll, nbytes = slab_prove(slab, world, S, alpha, idx, r)
+    gens = host.gens(c, s, alpha, log_m); dense = host.densify(idx, log_m)
+    comm_1 = host.commit(dense, gens); proof_1 = host.prove(dense, gens, S, r)
+    host.free(dense, gens)
+    assert comm_p == comm_1 and proof_p == proof_1
+    assert ncoll > 0 and nbytes / ncoll < 1 << 20          # many small collectives (per-round sums), never a polynomial
+    orc = OracleSession(oracle, _abi.KINDS[kind], c, log_m, log_r, idx, r)
+    try:
+        assert comm_p == orc.commit() and proof_p == orc.prove() and orc.verify(proof_p, comm_p) == 1
+    finally:
+        orc.close()
