@@ -103,3 +103,44 @@ def test_baseline_config_full_size(host, oracle, kind, c, log_m, log_r, log_s):
     assert ok == 1, oracle.orc_last_error()
     bad = bytearray(proof); bad[len(bad) // 2] ^= 0x04
     assert oracle.orc_verify_only(_abi.KINDS[kind], c, 1 << log_m, log_r, s, rr.ctypes.data_as(C.c_void_p), bytes(bad), len(bad), comm, len(comm)) != 1
+
+
+# Slab mode on the real device: ONE proof sharded over P ranks (include/lasso_prover.h lasso_host_set_comm).  The GPU box has one MI355X, so the P ranks
+# are P contexts (own stream, own buffers) on the same device driven by P threads, with a shared-memory all-gather (tests/cpp/slab_threads.cpp) — the
+# kernels, the slab variants (densify / fingerprints / scaled eq tables), the row-commitment exchange and the tails are the ones an N-GPU run executes.
+def _build_slab_hip():
+    import ctypes as C
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out_dir = os.path.join(root, "tests", "_build"); os.makedirs(out_dir, exist_ok=True)
+    so = os.path.join(out_dir, "libslab_threads_hip.so")
+    srcs = [os.path.join(root, "tests", "cpp", "slab_threads.cpp"), os.path.join(root, "lasso_amd", "host", "prover_capi.cpp")]
+    lib_dir = os.path.join(root, "lasso_amd")
+    if not os.path.exists(so) or any(os.path.getmtime(x) > os.path.getmtime(so) for x in srcs + [os.path.join(lib_dir, "liblasso_hip.so"), os.path.join(lib_dir, "host", "prover.hpp")]):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wno-unknown-pragmas", "-o", so] + srcs + ["-L" + lib_dir, "-llasso_hip", "-Wl,-rpath," + lib_dir])
+    return C.CDLL(so)
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+@pytest.mark.parametrize("kind,c,log_m,log_r,lookups", [("and", 1, 8, 0, 1 << 10), ("xor", 3, 6, 0, 500), ("lt", 2, 6, 0, 64), ("range", 3, 8, 40, 100), ("and", 2, 16, 0, 1 << 13)])
+def test_gpu_slab_proof_bit_exact(host, oracle, world, kind, c, log_m, log_r, lookups):
+    import ctypes as C
+    lib = _build_slab_hip()
+    s = 1 << (lookups - 1).bit_length()
+    alpha = 2 * c if kind == "lt" else c
+    idx = np.ascontiguousarray(np.random.default_rng(world * 77 + lookups).integers(0, 1 << log_m, size=(lookups, c), dtype=np.uint64))
+    r = np.ascontiguousarray(host.gen_random_point(s.bit_length() - 1), dtype=np.uint64)
+    S = _abi.Strategy(_abi.KINDS[kind], c, log_m, log_r)
+    comm = (C.c_uint8 * (1 << 22))(); proof = (C.c_uint8 * (1 << 22))(); cl = C.c_size_t(); pl = C.c_size_t(); nc = C.c_size_t(); nb = C.c_size_t(); err = C.create_string_buffer(512)
+    rc = lib.slab_prove_threads(world, C.byref(S), C.c_size_t(alpha), idx.ctypes.data_as(C.c_void_p), C.c_size_t(lookups), r.ctypes.data_as(C.c_void_p), C.c_size_t(r.shape[0]),
+                                comm, C.c_size_t(len(comm)), C.byref(cl), proof, C.c_size_t(len(proof)), C.byref(pl), C.byref(nc), C.byref(nb), err, C.c_size_t(512))
+    assert rc == 0, err.value.decode()
+    comm_p, proof_p = bytes(comm[: cl.value]), bytes(proof[: pl.value])
+    orc = OracleSession(oracle, _abi.KINDS[kind], c, log_m, log_r, idx, r)
+    try:
+        assert comm_p == orc.commit()
+        assert proof_p == orc.prove()
+        assert orc.verify(proof_p, comm_p) == 1
+    finally:
+        orc.close()
