@@ -154,6 +154,9 @@ void lasso_bases_destroy(lasso_ctx* ctx, lasso_bases* b);
 /* DensePolynomial::commit / commit_inner with zero blinds (src/poly/dense_mlpoly.rs:109-181): for each of l_size rows,
  * out[row] = sum_{j < r_size} d_Z[row*r_size + j] * bases[j]   (Commitments::batch_commit, src/poly/commitments.rs:84-93) */
 int32_t lasso_hyrax_commit(lasso_ctx* ctx, const lasso_fr* d_Z, size_t l_size, size_t r_size, const lasso_bases* bases, lasso_point* out);
+/* the same with the rows returned in wire form: out32[32*row..] = serialize_compressed(normalised row commitment) — what the transcript absorbs
+ * (src/poly/dense_mlpoly.rs:281-289 -> utils/transcript.rs:47-51) and what the proof stores; normalisation (one inversion per row) runs on the device */
+int32_t lasso_hyrax_commit_compressed(lasso_ctx* ctx, const lasso_fr* d_Z, size_t l_size, size_t r_size, const lasso_bases* bases, uint8_t* out32);
 /* VariableBaseMSM::msm (src/msm/mod.rs:36-40): out = sum_{j < n} scalars[j] * bases[j]; n <= number of bases.  Zero scalars cost nothing. */
 int32_t lasso_msm(lasso_ctx* ctx, const lasso_bases* bases, const lasso_fr* scalars, size_t n, lasso_point* out);
 

@@ -57,6 +57,7 @@ def declare(lib):
         "lasso_bases_create": (i32, [vp, vp, sz, P(vp)]),
         "lasso_bases_destroy": (None, [vp, vp]),
         "lasso_hyrax_commit": (i32, [vp, vp, sz, sz, vp, vp]),
+        "lasso_hyrax_commit_compressed": (i32, [vp, vp, sz, sz, vp, vp]),
         "lasso_msm": (i32, [vp, vp, vp, sz, vp]),
         "lasso_msm_dev": (i32, [vp, vp, vp, sz, vp]),
         "lasso_inner_products_lr": (i32, [vp, vp, vp, sz, vp]),

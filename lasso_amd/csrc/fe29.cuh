@@ -66,6 +66,32 @@ LHD fe29 fe_mul(const fe29& a, const fe29& b) {
 }
 LHD fe29 fe_sqr(const fe29& a) { return fe_mul(a, a); }   // a must be reduced
 
+// a^(p-2) by the curve25519 addition chain (254 squarings + 11 multiplications); a reduced
+LHD fe29 fe_inv_chain(const fe29& z) {
+  fe29 z2 = fe_sqr(z);
+  fe29 z8 = fe_sqr(fe_sqr(z2));
+  fe29 z9 = fe_mul(z8, z);
+  fe29 z11 = fe_mul(z9, z2);
+  fe29 z22 = fe_sqr(z11);
+  fe29 z_5_0 = fe_mul(z22, z9);
+  fe29 t = z_5_0; for (int i = 0; i < 5; i++) t = fe_sqr(t);
+  fe29 z_10_0 = fe_mul(t, z_5_0);
+  t = z_10_0; for (int i = 0; i < 10; i++) t = fe_sqr(t);
+  fe29 z_20_0 = fe_mul(t, z_10_0);
+  t = z_20_0; for (int i = 0; i < 20; i++) t = fe_sqr(t);
+  t = fe_mul(t, z_20_0);
+  for (int i = 0; i < 10; i++) t = fe_sqr(t);
+  fe29 z_50_0 = fe_mul(t, z_10_0);
+  t = z_50_0; for (int i = 0; i < 50; i++) t = fe_sqr(t);
+  fe29 z_100_0 = fe_mul(t, z_50_0);
+  t = z_100_0; for (int i = 0; i < 100; i++) t = fe_sqr(t);
+  t = fe_mul(t, z_100_0);
+  for (int i = 0; i < 50; i++) t = fe_sqr(t);
+  t = fe_mul(t, z_50_0);
+  for (int i = 0; i < 5; i++) t = fe_sqr(t);
+  return fe_mul(t, z11);
+}
+
 // ------------------------------------------------------------------ conversions (table build / result hand-back only)
 LHD fe29 fe_from_fq(const fq_t& x) {   // any lazy fq_t (< 2^256)
   fq_t c = fq_canonical(x);
@@ -141,4 +167,14 @@ LHD niels29 niels_from_affine(const fq_t& x, const fq_t& y) {
   niels29 n; n.ypx = fe_from_fq(fq_add(y, x)); n.ymx = fe_from_fq(fq_sub(y, x)); n.t2d = fe_from_fq(fq_mul(fq_mul(x, y), fq_d2())); n.pad = 0; return n;
 }
 LHD pt29 pt_from_ed(const ed_point& e) { pt29 p; p.X = fe_from_fq(e.X); p.Y = fe_from_fq(e.Y); p.T = fe_from_fq(e.T); p.Z = fe_from_fq(e.Z); return p; }
+// ark-serialize's compressed twisted-Edwards point (serialize_compressed of the normalised point, utils/transcript.rs:47-51): canonical y,
+// little endian, with bit 7 of the last byte set iff x is "negative", i.e. x > -x as canonical integers.  out = 8 little-endian words.
+LHD void pt_compress(const pt29& p, uint32_t* out) {
+  const fe29 zi = fe_inv_chain(p.Z);
+  const fq_t x = fq_canonical(fe_to_fq(fe_mul(p.X, zi))), y = fq_canonical(fe_to_fq(fe_mul(p.Y, zi))), nx = fq_canonical(fq_neg(x));
+  bool neg = false;
+  for (int i = 7; i >= 0; i--) if (x.v[i] != nx.v[i]) { neg = x.v[i] > nx.v[i]; break; }
+  for (int i = 0; i < 8; i++) out[i] = y.v[i];
+  if (neg) out[7] |= 0x80000000u;
+}
 LHD ed_point pt_to_ed(const pt29& p) { ed_point e; e.X = fe_to_fq(p.X); e.Y = fe_to_fq(p.Y); e.T = fe_to_fq(p.T); e.Z = fe_to_fq(p.Z); return e; }

@@ -471,27 +471,36 @@ static size_t msm_chunks(size_t rows, size_t n_cols, uint32_t W) {
 }
 #define MSM_SMALL_ROWS 16   // results of up to this many rows return through the mapped buffer + flag (no memcpy, no stream sync)
 // shared tail: bucket kernel over `rows` rows of `n_cols` scalars, then per-row sum of the chunk partials, then hand the points to the host
-static int32_t run_msm(lasso_ctx* c, const uint8_t* d_scal, uint32_t bps, uint32_t W, size_t row_stride, size_t rows, size_t n_cols, const lasso_bases* b, uint8_t* scratch_after, lasso_point* out) {
+static int32_t run_msm(lasso_ctx* c, const uint8_t* d_scal, uint32_t bps, uint32_t W, size_t row_stride, size_t rows, size_t n_cols, const lasso_bases* b, uint8_t* scratch_after, lasso_point* out,
+                       uint8_t* out_compressed = nullptr) {
   const size_t K = msm_chunks(rows, n_cols, W);
   const size_t cols_per_chunk = (n_cols + K - 1) / K;
   pt29* d_partial = (pt29*)scratch_after;
-  const bool small = rows <= MSM_SMALL_ROWS;
+  const bool small = rows <= MSM_SMALL_ROWS && !out_compressed;
   ed_point* d_final = small ? (ed_point*)c->d_small : (ed_point*)(((uintptr_t)(d_partial + rows * K) + 15) & ~(uintptr_t)15);
   const uint32_t seq = small ? ++c->seq : 0;
   {
     ProfScope ps(c, LASSO_K_MSM, (double)rows * n_cols * bps);
     hipLaunchKernelGGL(k_msm_buckets, dim3((unsigned)K, (unsigned)rows), dim3(MSM_THREADS), 0, c->stream, d_scal, bps, W, row_stride, n_cols, cols_per_chunk, (const niels29*)b->d_table, b->n, d_partial);
-    hipLaunchKernelGGL(k_points_sum, dim3((unsigned)rows), dim3(MSM_THREADS), 0, c->stream, (const pt29*)d_partial, (uint32_t)K, d_final, c->d_counters + LASSO_MAX_PTRS + 1,
-                       small ? c->d_flag : (uint32_t*)nullptr, seq);
+    hipLaunchKernelGGL(k_points_sum, dim3((unsigned)rows), dim3(MSM_THREADS), 0, c->stream, (const pt29*)d_partial, (uint32_t)K, d_final, out_compressed ? (uint32_t*)d_final : (uint32_t*)nullptr,
+                       c->d_counters + LASSO_MAX_PTRS + 1, small ? c->d_flag : (uint32_t*)nullptr, seq);
   }
   HIPCHK(c, hipGetLastError());
+  if (out_compressed) {   // 32 bytes per row (the scratch behind the partials is large enough for 128)
+    HIPCHK(c, hipMemcpyAsync(out_compressed, d_final, rows * 32, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+  }
   if (small) return wait_flag(c, seq, rows * (sizeof(ed_point) / sizeof(fr_t)), (lasso_fr*)out);
   HIPCHK(c, hipMemcpyAsync(out, d_final, rows * sizeof(ed_point), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return 0;
 }
-int32_t lasso_hyrax_commit(lasso_ctx* c, const lasso_fr* d_Z, size_t l_size, size_t r_size, const lasso_bases* b, lasso_point* out) {
-  REQUIRE(c, d_Z && b && out && l_size >= 1 && r_size >= 1 && r_size <= b->n && l_size < ((size_t)1 << 31));
+static int32_t hyrax_commit_impl(lasso_ctx* c, const lasso_fr* d_Z, size_t l_size, size_t r_size, const lasso_bases* b, lasso_point* out, uint8_t* out_compressed);
+int32_t lasso_hyrax_commit(lasso_ctx* c, const lasso_fr* d_Z, size_t l_size, size_t r_size, const lasso_bases* b, lasso_point* out) { REQUIRE(c, out); return hyrax_commit_impl(c, d_Z, l_size, r_size, b, out, nullptr); }
+int32_t lasso_hyrax_commit_compressed(lasso_ctx* c, const lasso_fr* d_Z, size_t l_size, size_t r_size, const lasso_bases* b, uint8_t* out32) { REQUIRE(c, out32); return hyrax_commit_impl(c, d_Z, l_size, r_size, b, nullptr, out32); }
+static int32_t hyrax_commit_impl(lasso_ctx* c, const lasso_fr* d_Z, size_t l_size, size_t r_size, const lasso_bases* b, lasso_point* out, uint8_t* out_compressed) {
+  REQUIRE(c, d_Z && b && l_size >= 1 && r_size >= 1 && r_size <= b->n && l_size < ((size_t)1 << 31));
   const size_t n = l_size * r_size;
   const size_t pts_bytes = (l_size * msm_chunks(l_size, r_size, MSM_WINDOWS) + l_size) * sizeof(pt29) + 512;
   int32_t rc = ensure_scratch(c, n * 32 + pts_bytes); if (rc) return rc;
@@ -507,10 +516,10 @@ int32_t lasso_hyrax_commit(lasso_ctx* c, const lasso_fr* d_Z, size_t l_size, siz
   if (!flags[1]) {  // every scalar < 2^32: the reference's small-scalar regime (msm/mod.rs:95-106)
     uint32_t bits = 0; while (bits < 32 && (flags[0] >> bits)) bits++;
     uint32_t W = (bits + 3) / 4; if (W == 0) W = 1;   // 4-bit windows actually populated
-    return run_msm(c, d_scal, 4, W, r_size * 4, l_size, r_size, b, d_scal + ((n * 4 + 255) & ~(size_t)255), out);
+    return run_msm(c, d_scal, 4, W, r_size * 4, l_size, r_size, b, d_scal + ((n * 4 + 255) & ~(size_t)255), out, out_compressed);
   }
   hipLaunchKernelGGL(k_fr_to_canonical, dim3(grid_for(n, 4096)), dim3(256), 0, c->stream, (const fr_t*)d_Z, n, (fr_t*)d_scal);
-  return run_msm(c, d_scal, 32, MSM_WINDOWS, r_size * 32, l_size, r_size, b, d_scal + n * 32, out);
+  return run_msm(c, d_scal, 32, MSM_WINDOWS, r_size * 32, l_size, r_size, b, d_scal + n * 32, out, out_compressed);
 }
 int32_t lasso_msm(lasso_ctx* c, const lasso_bases* b, const lasso_fr* scalars, size_t n, lasso_point* out) {
   REQUIRE(c, b && scalars && out && n >= 1 && n <= b->n);

@@ -161,10 +161,11 @@ __global__ void __launch_bounds__(MSM_THREADS) k_msm_buckets(const uint8_t* __re
   }
 }
 
-// out[row] = sum_k partial[row*K + k], converted to ark's Montgomery limbs.  One workgroup per row; thread t first adds partials
+// out[row] = sum_k partial[row*K + k], converted to ark's Montgomery limbs (out_mont) or, when out_compressed is given, to the 32-byte wire form.  One workgroup per row; thread t first adds partials
 // t, t+256, ... serially, then an LDS tree.  `out_mont` may be host-mapped memory: when `flag` is set, the row that finishes last
 // raises the host's sequence flag (same hand-off as last_block_reduce in poly_kernels.cuh).
-__global__ void __launch_bounds__(MSM_THREADS) k_points_sum(const pt29* __restrict__ partial, uint32_t K, ed_point* __restrict__ out_mont, uint32_t* counters, uint32_t* flag, uint32_t seq) {
+__global__ void __launch_bounds__(MSM_THREADS) k_points_sum(const pt29* __restrict__ partial, uint32_t K, ed_point* __restrict__ out_mont, uint32_t* __restrict__ out_compressed, uint32_t* counters,
+                                                             uint32_t* flag, uint32_t seq) {
   __shared__ pt29 pts[MSM_THREADS];
   const fe29 d2 = fe_d2();
   const uint32_t t = threadIdx.x;
@@ -174,7 +175,8 @@ __global__ void __launch_bounds__(MSM_THREADS) k_points_sum(const pt29* __restri
   __syncthreads();
   const uint32_t live = K < MSM_THREADS ? K : MSM_THREADS;
   for (uint32_t s = MSM_THREADS / 2; s > 0; s >>= 1) { if (t < s && t + s < live) pts[t] = pt_add(pts[t], pts[t + s], d2); __syncthreads(); }
-  if (t == 0) {
+  if (t == 0 && out_compressed) pt_compress(pts[0], out_compressed + 8 * (size_t)blockIdx.x);   // wire form straight from the device (normalize_batch + serialize_compressed)
+  if (t == 0 && !out_compressed) {
     ed_point p = pt_to_ed(pts[0]), o; o.X = fq_to_mont(p.X); o.Y = fq_to_mont(p.Y); o.T = fq_to_mont(p.T); o.Z = fq_to_mont(p.Z); out_mont[blockIdx.x] = o;
     if (flag) {
       __threadfence_system();

@@ -160,6 +160,11 @@ class Device:
         self._chk(self.lib.lasso_hyrax_commit(self.ctx, C.c_void_p(d_z), l_size, r_size, C.c_void_p(bases), _vp(out)))
         return out
 
+    def hyrax_commit_compressed(self, d_z, l_size, r_size, bases):
+        out = np.empty((l_size, 32), dtype=np.uint8)
+        self._chk(self.lib.lasso_hyrax_commit_compressed(self.ctx, C.c_void_p(d_z), l_size, r_size, C.c_void_p(bases), _vp(out)))
+        return out
+
     def msm(self, bases, scalars):
         scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
         out = np.empty((1, 16), dtype=np.uint64)

@@ -360,12 +360,14 @@ struct PolyCommitment { std::vector<uint8_t> compressed; size_t rows = 0; };   /
 inline PolyCommitment hyrax_commit(const Dev& d, const lasso_fr* d_Z, size_t num_vars, const PolyCommitmentGens& gens) {
   size_t l_size = (size_t)1 << (num_vars / 2), r_size = (size_t)1 << (num_vars - num_vars / 2);
   LASSO_REQUIRE(r_size == gens.n);
+  if (!d.comm.sharded()) {   // rows come back in wire form: the normalisation (one inversion per row) runs on the device
+    PolyCommitment c; c.rows = l_size; c.compressed.resize(32 * l_size);
+    d.chk(lasso_hyrax_commit_compressed(d.ctx, d_Z, l_size, r_size, gens.bases, c.compressed.data()), "lasso_hyrax_commit_compressed");
+    return c;
+  }
   std::vector<lasso_point> rows(l_size);
   std::vector<Pt> pts(l_size);
-  if (!d.comm.sharded()) {
-    d.chk(lasso_hyrax_commit(d.ctx, d_Z, l_size, r_size, gens.bases, rows.data()), "lasso_hyrax_commit");
-    for (size_t i = 0; i < l_size; i++) pts[i] = Pt::from_abi(rows[i]);
-  } else {
+  {
     // partial row commitments over this rank's columns, then the exchange step of the path: all-gather the points, add per row
     const size_t P = d.comm.world; LASSO_REQUIRE(gens.bases_slab && r_size >= P);
     d.chk(lasso_hyrax_commit(d.ctx, d_Z, l_size, r_size / P, gens.bases_slab, rows.data()), "lasso_hyrax_commit");

@@ -173,6 +173,12 @@ int32_t lasso_hyrax_commit(lasso_ctx* c, const lasso_fr* Z, size_t ls, size_t rs
   for (size_t i = 0; i < ls; i++) { std::vector<Fr> sc(F(Z) + i * rs, F(Z) + (i + 1) * rs); put_point(msm(bases, sc), out + i); }  // dense_mlpoly.rs:118-127, commitments.rs:84-93 with blind = 0
   return 0;
 }
+int32_t lasso_hyrax_commit_compressed(lasso_ctx* c, const lasso_fr* Z, size_t ls, size_t rs, const lasso_bases* b, uint8_t* out32) {
+  REQ(c, rs <= b->pts.size());
+  std::vector<Point> bases(b->pts.begin(), b->pts.begin() + rs);
+  for (size_t i = 0; i < ls; i++) { std::vector<Fr> sc(F(Z) + i * rs, F(Z) + (i + 1) * rs); msm(bases, sc).compress(out32 + 32 * i); }
+  return 0;
+}
 int32_t lasso_msm(lasso_ctx* c, const lasso_bases* b, const lasso_fr* scalars, size_t n, lasso_point* out) {
   REQ(c, n <= b->pts.size());
   std::vector<Point> bases(b->pts.begin(), b->pts.begin() + n); std::vector<Fr> sc(F(scalars), F(scalars) + n);

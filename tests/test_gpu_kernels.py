@@ -216,11 +216,14 @@ def test_hyrax_commit(devs, gens_300, ls, rs, maxv):
         b = d.bases_create(gens_300)
         p = d.upload(Z)
         out = d.hyrax_commit(p, ls, rs, b)
+        wire = d.hyrax_commit_compressed(p, ls, rs, b)
         d.free(p); d.bases_destroy(b)
-        return out
-    a, b = both(devs, run)
+        return out, wire
+    (a, wa), (b, wb) = both(devs, run)
     mock_lib = devs[1].lib
     assert compress_points(mock_lib, a) == compress_points(mock_lib, b)
+    # rows normalised + serialised on the device == the oracle's serialize_compressed of the same rows
+    assert np.array_equal(wa, wb) and [bytes(x) for x in wa] == compress_points(mock_lib, b)
 
 
 @pytest.mark.parametrize("n", [1, 2, 33, 301])
