@@ -131,6 +131,12 @@ int32_t lasso_fingerprint_mem_slab(lasso_ctx* ctx, const lasso_fr* d_table, cons
 /* DensePolynomial::bound (src/poly/dense_mlpoly.rs:184-207): out[i] = sum_j L[j] * d_Z[j*r_size + i], i < r_size */
 int32_t lasso_matvec_left(lasso_ctx* ctx, const lasso_fr* d_Z, const lasso_fr* L, size_t l_size, size_t r_size, lasso_fr* out);
 
+/* lasso_matvec_left with L already on the device and the result left on the device (asynchronous): the opening keeps L*Z resident */
+int32_t lasso_matvec_left_dev(lasso_ctx* ctx, const lasso_fr* d_Z, const lasso_fr* d_L, size_t l_size, size_t r_size, lasso_fr* d_out);
+/* CanonicalSerialize of n device field elements: out[32*i..] = the canonical integer, little endian (what ProofTranscript::append_scalar absorbs,
+ * src/utils/transcript.rs:33-45) */
+int32_t lasso_fr_to_bytes(lasso_ctx* ctx, const lasso_fr* d_src, size_t n, uint8_t* out);
+
 /* ---- densify ------------------------------------------------------------------------------- */
 /* DensifiedRepresentation::from_lookup_indices for ONE dimension (src/lasso/densified.rs:32-57; serial in the reference, TODO(#29)).
  * d_indices: the reference's `Vec<[usize; C]>` uploaded as is (n_lookups x C u64, row-major).  For k < s (s = n_lookups.next_power_of_two()):
@@ -162,6 +168,10 @@ int32_t lasso_msm(lasso_ctx* ctx, const lasso_bases* bases, const lasso_fr* scal
 
 /* Same as lasso_msm with the scalars already resident on the device (Montgomery form). */
 int32_t lasso_msm_dev(lasso_ctx* ctx, const lasso_bases* bases, const lasso_fr* d_scalars, size_t n, lasso_point* out);
+
+/* out = sum_{j<n} (scale * d_scalars[j]) * bases[j] + tail[0]*bases[n] + tail[1]*bases[n+1] — e.g. delta = d*g_hat + r_delta*h of
+ * DotProductProofLog::prove (src/subprotocols/dot_product.rs:219-224) in one MSM over the resident fold weights (bases = [G.., Q, h]) */
+int32_t lasso_msm_dev_scaled(lasso_ctx* ctx, const lasso_bases* bases, const lasso_fr* d_scalars, size_t n, const lasso_fr* scale, const lasso_fr* tail, lasso_point* out);
 
 /* ---- Hyrax opening tail: BulletReductionProof::prove (src/subprotocols/bullet.rs:40-154) with the vectors resident on
  * the device.  State kept by the caller: d_a, d_b (current length nk, folded in place), d_w (n/nk tensor weights, see below).

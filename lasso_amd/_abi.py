@@ -52,6 +52,9 @@ def declare(lib):
         "lasso_fingerprint_mem": (i32, [vp, vp, vp, sz, vp, vp, vp, vp]),
         "lasso_fingerprint_mem_slab": (i32, [vp, vp, vp, sz, u32, u32, vp, vp, vp, vp]),
         "lasso_densify_dim_slab": (i32, [vp, vp, sz, sz, sz, sz, u32, u32, u32, vp, vp, vp, vp]),
+        "lasso_matvec_left_dev": (i32, [vp, vp, vp, sz, sz, vp]),
+        "lasso_fr_to_bytes": (i32, [vp, vp, sz, vp]),
+        "lasso_msm_dev_scaled": (i32, [vp, vp, vp, sz, vp, vp, vp]),
         "lasso_densify_dim": (i32, [vp, vp, sz, sz, sz, sz, u32, vp, vp, vp, vp]),
         "lasso_matvec_left": (i32, [vp, vp, vp, sz, sz, vp]),
         "lasso_bases_create": (i32, [vp, vp, sz, P(vp)]),

@@ -91,22 +91,33 @@ inline fr_t fr_mul(const fr_t& a, const fr_t& b) {
   typedef unsigned __int128 u128;
   const uint64_t P0 = 0x5812631a5cf5d3edull, P1 = 0x14def9dea2f79cd6ull, P3 = 0x1000000000000000ull, INV = 0xd2b51da312547e1bull;  // -p^-1 mod 2^64
   uint64_t x[4], y[4]; __builtin_memcpy(x, a.v, 32); __builtin_memcpy(y, b.v, 32);
-  uint64_t t[6] = {0, 0, 0, 0, 0, 0};
-  for (int i = 0; i < 4; i++) {
-    u128 c = 0;
-    for (int j = 0; j < 4; j++) { c += (u128)x[j] * y[i] + t[j]; t[j] = (uint64_t)c; c >>= 64; }
-    c += t[4]; t[4] = (uint64_t)c; t[5] = (uint64_t)(c >> 64);
-    const uint64_t m = t[0] * INV;
-    c = (u128)m * P0 + t[0]; c >>= 64;
-    c += (u128)m * P1 + t[1]; t[0] = (uint64_t)c; c >>= 64;
-    c += t[2]; t[1] = (uint64_t)c; c >>= 64;
-    c += (u128)m * P3 + t[3]; t[2] = (uint64_t)c; c >>= 64;
-    c += t[4]; t[3] = (uint64_t)c; c >>= 64;
-    t[4] = t[5] + (uint64_t)c;
+  uint64_t t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+#define FR64_ROW(yi)                                                                                   \
+  {                                                                                                    \
+    u128 c = (u128)x[0] * (yi) + t0; t0 = (uint64_t)c; c >>= 64;                                        \
+    c += (u128)x[1] * (yi) + t1; t1 = (uint64_t)c; c >>= 64;                                            \
+    c += (u128)x[2] * (yi) + t2; t2 = (uint64_t)c; c >>= 64;                                            \
+    c += (u128)x[3] * (yi) + t3; t3 = (uint64_t)c; c >>= 64;                                            \
+    c += t4; t4 = (uint64_t)c; const uint64_t t5 = (uint64_t)(c >> 64);                                 \
+    const uint64_t m = t0 * INV;                                                                       \
+    c = (u128)m * P0 + t0; c >>= 64;                                                                    \
+    c += (u128)m * P1 + t1; t0 = (uint64_t)c; c >>= 64;                                                 \
+    c += t2; t1 = (uint64_t)c; c >>= 64;                                                                \
+    c += (u128)m * P3 + t3; t2 = (uint64_t)c; c >>= 64;                                                 \
+    c += t4; t3 = (uint64_t)c; c >>= 64;                                                                \
+    t4 = t5 + (uint64_t)c;                                                                              \
   }
-  fr_t r; __builtin_memcpy(r.v, t, 32);
-  fr_cond_sub_p(r.v);
-  return r;
+  FR64_ROW(y[0]) FR64_ROW(y[1]) FR64_ROW(y[2]) FR64_ROW(y[3])
+#undef FR64_ROW
+  // result < 2p < 2^254: conditional subtraction of p on 64-bit limbs
+  u128 d = (u128)t0 - P0; const uint64_t s0 = (uint64_t)d; uint64_t bw = (uint64_t)(d >> 64) & 1;
+  d = (u128)t1 - P1 - bw; const uint64_t s1 = (uint64_t)d; bw = (uint64_t)(d >> 64) & 1;
+  d = (u128)t2 - bw; const uint64_t s2 = (uint64_t)d; bw = (uint64_t)(d >> 64) & 1;
+  d = (u128)t3 - P3 - bw; const uint64_t s3 = (uint64_t)d; bw = (uint64_t)(d >> 64) & 1;
+  const uint64_t keep = (uint64_t)0 - bw;   // borrow: the value was < p
+  uint64_t r[4] = {(t0 & keep) | (s0 & ~keep), (t1 & keep) | (s1 & ~keep), (t2 & keep) | (s2 & ~keep), (t3 & keep) | (s3 & ~keep)};
+  fr_t o; __builtin_memcpy(o.v, r, 32);
+  return o;
 }
 #else
 // CIOS over 32-bit limbs (device form; also the host form inside hipcc translation units).

@@ -403,6 +403,30 @@ int32_t lasso_matvec_left(lasso_ctx* c, const lasso_fr* d_Z, const lasso_fr* L, 
   return 0;
 }
 
+// device-resident forms used by the opening: L already on the device, L*Z left on the device (no host round trip)
+int32_t lasso_matvec_left_dev(lasso_ctx* c, const lasso_fr* d_Z, const lasso_fr* d_L, size_t l_size, size_t r_size, lasso_fr* d_out) {
+  REQUIRE(c, d_Z && d_L && d_out && l_size >= 1 && r_size >= 1);
+  size_t col_blocks = (r_size + LASSO_BLOCK - 1) / LASSO_BLOCK;
+  size_t nchunks = (1024 + col_blocks - 1) / col_blocks; if (nchunks > l_size) nchunks = l_size; if (nchunks < 1) nchunks = 1;
+  size_t rows_per_chunk = (l_size + nchunks - 1) / nchunks; nchunks = (l_size + rows_per_chunk - 1) / rows_per_chunk;
+  int32_t rc = ensure_scratch(c, nchunks * r_size * sizeof(fr_t)); if (rc) return rc;
+  fr_t* partials = (fr_t*)c->d_scratch;
+  ProfScope ps(c, LASSO_K_MATVEC, 32.0 * l_size * r_size);
+  hipLaunchKernelGGL(k_matvec_left, dim3((unsigned)col_blocks, (unsigned)nchunks), dim3(LASSO_BLOCK), 0, c->stream, (const fr_t*)d_Z, (const fr_t*)d_L, l_size, r_size, rows_per_chunk, partials);
+  hipLaunchKernelGGL(k_matvec_reduce, dim3((unsigned)col_blocks), dim3(LASSO_BLOCK), 0, c->stream, (const fr_t*)partials, nchunks, r_size, (fr_t*)d_out);
+  HIPCHK(c, hipGetLastError()); return 0;
+}
+// ark-serialize of n field elements (canonical integers, 32 little-endian bytes each) — what append_scalar feeds the transcript (utils/transcript.rs:33-45)
+int32_t lasso_fr_to_bytes(lasso_ctx* c, const lasso_fr* d_src, size_t n, uint8_t* out) {
+  REQUIRE(c, d_src && out && n >= 1);
+  int32_t rc = ensure_scratch(c, n * sizeof(fr_t)); if (rc) return rc;
+  hipLaunchKernelGGL(k_fr_to_canonical, dim3(grid_for(n)), dim3(256), 0, c->stream, (const fr_t*)d_src, n, (fr_t*)c->d_scratch);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(out, c->d_scratch, n * 32, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
 // ------------------------------------------------------------------ densify (densified.rs:22-75)
 int32_t lasso_densify_dim(lasso_ctx* c, const uint64_t* d_indices, size_t n_lookups, size_t C, size_t dim, size_t s, uint32_t log_m, uint32_t* d_dim_u32, lasso_fr* d_dim, lasso_fr* d_read,
                           lasso_fr* d_final) {
@@ -536,6 +560,19 @@ int32_t lasso_msm_dev(lasso_ctx* c, const lasso_bases* b, const lasso_fr* d_scal
   fr_t* d_can = (fr_t*)c->d_scratch;
   hipLaunchKernelGGL(k_fr_to_canonical, dim3(grid_for(n)), dim3(256), 0, c->stream, (const fr_t*)d_scalars, n, d_can);
   return run_msm(c, (const uint8_t*)d_can, 32, MSM_WINDOWS, n * 32, 1, n, b, (uint8_t*)(d_can + n), out);
+}
+__global__ void __launch_bounds__(256) k_scale_to_integers(const fr_t* __restrict__ src, size_t n, fr_t scale, fr_t t0, fr_t t1, fr_t* __restrict__ dst) {
+  const fr29 ss = fr29_unpack_s(scale); fr29 k32 = fr29_zero(); k32.v[0] = 32;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = fr29_store(fr29_mul(fr29_mul(fr29_unpack_u(src[i]), ss), k32));   // (u * s) = u-form, then -> integer
+  if (blockIdx.x == 0 && threadIdx.x == 0) { dst[n] = fr29_to_integer(fr29_unpack_u(t0)); dst[n + 1] = fr29_to_integer(fr29_unpack_u(t1)); }
+}
+int32_t lasso_msm_dev_scaled(lasso_ctx* c, const lasso_bases* b, const lasso_fr* d_scalars, size_t n, const lasso_fr* scale, const lasso_fr* tail, lasso_point* out) {
+  REQUIRE(c, b && d_scalars && scale && tail && out && n >= 1 && n + 2 <= b->n);
+  const size_t row = n + 2;
+  int32_t rc = ensure_scratch(c, row * 32 + 260 * sizeof(pt29)); if (rc) return rc;
+  fr_t* d_can = (fr_t*)c->d_scratch;
+  hipLaunchKernelGGL(k_scale_to_integers, dim3(grid_for(n)), dim3(256), 0, c->stream, (const fr_t*)d_scalars, n, to_fr(scale), to_fr(tail), to_fr(tail + 1), d_can);
+  return run_msm(c, (const uint8_t*)d_can, 32, MSM_WINDOWS, row * 32, 1, row, b, (uint8_t*)(d_can + row), out);
 }
 int32_t lasso_inner_products_lr(lasso_ctx* c, const lasso_fr* d_a, const lasso_fr* d_b, size_t nk, lasso_fr* out) {
   REQUIRE(c, d_a && d_b && out && nk >= 2 && (nk & (nk - 1)) == 0);

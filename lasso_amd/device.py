@@ -176,6 +176,20 @@ class Device:
         self._chk(self.lib.lasso_msm_dev(self.ctx, C.c_void_p(bases), C.c_void_p(d_scalars), n, _vp(out)))
         return out
 
+    def matvec_left_dev(self, d_z, d_l, l_size, r_size, d_out):
+        self._chk(self.lib.lasso_matvec_left_dev(self.ctx, C.c_void_p(d_z), C.c_void_p(d_l), l_size, r_size, C.c_void_p(d_out)))
+
+    def fr_to_bytes(self, d_src, n):
+        out = np.empty((n, 32), dtype=np.uint8)
+        self._chk(self.lib.lasso_fr_to_bytes(self.ctx, C.c_void_p(d_src), n, _vp(out)))
+        return out
+
+    def msm_dev_scaled(self, bases, d_scalars, n, scale, tail):
+        scale = np.ascontiguousarray(scale, dtype=np.uint64); tail = np.ascontiguousarray(tail, dtype=np.uint64).reshape(2, 4)
+        out = np.empty((1, 16), dtype=np.uint64)
+        self._chk(self.lib.lasso_msm_dev_scaled(self.ctx, C.c_void_p(bases), C.c_void_p(d_scalars), n, _vp(scale), _vp(tail), _vp(out)))
+        return out
+
     def inner_products_lr(self, d_a, d_b, nk):
         out = np.empty((2, 4), dtype=np.uint64)
         self._chk(self.lib.lasso_inner_products_lr(self.ctx, C.c_void_p(d_a), C.c_void_p(d_b), nk, _vp(out)))

@@ -60,8 +60,26 @@ class Strobe {
   static constexpr uint8_t RATE = 166;
   enum : uint8_t { I = 1, A = 2, C = 4, T = 8, M = 16, K = 32 };
   void run_f() { k.bytes[pos] ^= pos_begin; k.bytes[pos + 1] ^= 0x04; k.bytes[RATE + 1] ^= 0x80; k.permute(); pos = 0; pos_begin = 0; }
-  void absorb(const uint8_t* d, size_t n) { for (size_t i = 0; i < n; i++) { k.bytes[pos++] ^= d[i]; if (pos == RATE) run_f(); } }
-  void squeeze(uint8_t* d, size_t n) { for (size_t i = 0; i < n; i++) { d[i] = k.bytes[pos]; k.bytes[pos++] = 0; if (pos == RATE) run_f(); } }
+  // bulk forms: whole runs up to the end of the rate block at a time (the openings push ~1 MB of scalars through here per proof)
+  void absorb(const uint8_t* d, size_t n) {
+    while (n) {
+      size_t chunk = RATE - pos; if (chunk > n) chunk = n;
+      uint8_t* dst = k.bytes + pos;
+      size_t i = 0;
+      for (; i + 8 <= chunk; i += 8) { uint64_t a, b; memcpy(&a, dst + i, 8); memcpy(&b, d + i, 8); a ^= b; memcpy(dst + i, &a, 8); }
+      for (; i < chunk; i++) dst[i] ^= d[i];
+      pos = (uint8_t)(pos + chunk); d += chunk; n -= chunk;
+      if (pos == RATE) run_f();
+    }
+  }
+  void squeeze(uint8_t* d, size_t n) {
+    while (n) {
+      size_t chunk = RATE - pos; if (chunk > n) chunk = n;
+      memcpy(d, k.bytes + pos, chunk); memset(k.bytes + pos, 0, chunk);
+      pos = (uint8_t)(pos + chunk); d += chunk; n -= chunk;
+      if (pos == RATE) run_f();
+    }
+  }
   void begin(uint8_t flags, bool more) {
     if (more) { if (cur != flags) throw std::logic_error("strobe: continued op with different flags"); return; }
     uint8_t hdr[2] = {pos_begin, flags};

@@ -43,6 +43,15 @@ struct Trace {
   }
 };
 
+// LASSO_TRACE=2: host-side time buckets (where the host spends its share of a proof), printed with the SparsePoly.prove span
+struct HostClock {
+  static bool on() { static const bool v = [] { const char* e = getenv("LASSO_TRACE"); return e && e[0] == '2'; }(); return v; }
+  static std::map<std::string, double>& buckets() { static std::map<std::string, double> b; return b; }
+  const char* name; std::chrono::steady_clock::time_point t0;
+  explicit HostClock(const char* n) : name(n) { if (on()) t0 = std::chrono::steady_clock::now(); }
+  ~HostClock() { if (on()) buckets()[name] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+  static void dump() { if (!on()) return; for (auto& kv : buckets()) fprintf(stderr, "[host] %-28s %.3f ms\n", kv.first.c_str(), kv.second); buckets().clear(); }
+};
 struct Error : std::runtime_error { using std::runtime_error::runtime_error; };
 #define LASSO_REQUIRE(c) do { if (!(c)) throw Error(std::string("lasso prover: requirement failed: ") + #c); } while (0)
 
@@ -148,6 +157,8 @@ class ProofTranscript {
   void append_protocol_name(const char* name) { m.append_str("protocol-name", name); }
   void append_u64(const char* label, uint64_t x) { m.append_u64(label, x); }
   void append_scalar(const char* label, const Sc& s) { uint8_t b[32]; s.to_bytes(b); m.append_message(label, b, 32); }
+  // the same with the scalars already serialised (32 canonical bytes each, e.g. by lasso_fr_to_bytes)
+  void append_scalars_bytes(const char* label, const std::vector<uint8_t>& b) { m.append_str(label, "begin_append_vector"); for (size_t i = 0; i + 32 <= b.size(); i += 32) m.append_message(label, &b[i], 32); m.append_str(label, "end_append_vector"); }
   void append_scalars(const char* label, const ScVec& v) { m.append_str(label, "begin_append_vector"); for (auto& s : v) append_scalar(label, s); m.append_str(label, "end_append_vector"); }
   void append_point_bytes(const char* label, const uint8_t b[32]) { m.append_message(label, b, 32); }
   Sc challenge_scalar(const char* label) { uint8_t b[64]; m.challenge_bytes(label, b, 64); return Sc::from_wide_bytes(b); }
@@ -521,6 +532,7 @@ class Prover {
         std::swap(c_cur, c_nxt); len /= 2;
       }
       if (reduce) d.comm.sum(ev);
+      HostClock hc("cubic round host work");
       Sc c0 = Sc::zero(), c2 = Sc::zero(), c3 = Sc::zero();
       for (size_t i = 0; i < k; i++) { c0 += Sc::from_abi(ev[3 * i]) * coeffs[i]; c2 += Sc::from_abi(ev[3 * i + 1]) * coeffs[i]; c3 += Sc::from_abi(ev[3 * i + 2]) * coeffs[i]; }
       UniPoly poly = UniPoly::from_evals({c0, e - c0, c2, c3});
@@ -607,24 +619,27 @@ class Prover {
     lasso_point out; d.chk(lasso_msm_dev(d.ctx, g.bases, d_scalars, n, &out), "lasso_msm_dev");
     return Pt::from_abi(out);
   }
-  DotProductProofLog dot_product_log_prove(const PolyCommitmentGens& g, const ScVec& x_vec, const ScVec& a_vec, const Sc& y) {
+  // d_a0 = x (here L*Z), d_b0 = a (here the R half of the eq table), both of length n and resident on the device; a_bytes = serialize(a)
+  DotProductProofLog dot_product_log_prove(const PolyCommitmentGens& g, DBuf& d_a0, DBuf& d_b0, const std::vector<uint8_t>& a_bytes, const Sc& y) {
     static_assert(sizeof(Sc) == sizeof(lasso_fr), "ScVec is uploaded as an array of lasso_fr");
     Trace tr("DotProductProofLog.prove", d.ctx);
     t.append_protocol_name("dot product proof (log)");
-    const size_t n = x_vec.size(); LASSO_REQUIRE(a_vec.size() == n && g.n == n);
+    const size_t n = g.n; LASSO_REQUIRE(d_a0.n == n && d_b0.n == n && a_bytes.size() == 32 * n);
     const size_t lg_n = ceil_log2(n);
-    Sc dd = tape.random_scalar("d"), r_delta = tape.random_scalar("r_delta"), r_beta = tape.random_scalar("r_delta");   // sic: dot_product.rs:189
-    ScVec v1 = tape.random_vector("blinds_vec_1", 2 * lg_n), v2 = tape.random_vector("blinds_vec_2", 2 * lg_n);
+    Sc dd, r_delta, r_beta; ScVec v1, v2;
+    {
+      HostClock hc("opening: random tape");
+      dd = tape.random_scalar("d"); r_delta = tape.random_scalar("r_delta"); r_beta = tape.random_scalar("r_delta");   // sic: dot_product.rs:189
+      v1 = tape.random_vector("blinds_vec_1", 2 * lg_n); v2 = tape.random_vector("blinds_vec_2", 2 * lg_n);
+    }
     DotProductProofLog P; uint8_t buf[32];
     // a, b and the generator-fold weights live on the device for the whole reduction, in ping-pong pairs: round k's fold (bullet.rs:127-132)
     // is applied by the same call that computes round k+1's c_L, c_R, L, R (lasso_bullet_round) — one host round trip per round.
-    DBuf d_a0(d, n), d_b0(d, n), d_a1(d, n / 2 ? n / 2 : 1), d_b1(d, n / 2 ? n / 2 : 1), d_w0(d, n), d_w1(d, n);
-    d.chk(lasso_upload(d.ctx, d_a0.p, x_vec.data(), n * sizeof(lasso_fr)), "lasso_upload");
-    d.chk(lasso_upload(d.ctx, d_b0.p, a_vec.data(), n * sizeof(lasso_fr)), "lasso_upload");
+    DBuf d_a1(d, n / 2 ? n / 2 : 1), d_b1(d, n / 2 ? n / 2 : 1), d_w0(d, n), d_w1(d, n);
     { Sc one = Sc::one(); d.chk(lasso_upload(d.ctx, d_w0.p, &one, sizeof(lasso_fr)), "lasso_upload"); }
     compress_one(msm_dev(g, d_a0.p, n), buf); t.append_point_bytes("Cx", buf);  // Cx = <x, G> + 0*h   (commitments.rs:84-93)
     compress_one(g.Qmul.mul(y), buf); t.append_point_bytes("Cy", buf);                // Cy = y*G_1[0] + 0*h (commitments.rs:78-82)
-    t.append_scalars("a", a_vec);
+    { HostClock hc("opening: append a_vec"); t.append_scalars_bytes("a", a_bytes); }
     // bullet reduction (bullet.rs:40-154), blind = blind_x + blind_y = 0
     lasso_fr *a_cur = d_a0.p, *a_nxt = d_a1.p, *b_cur = d_b0.p, *b_nxt = d_b1.p, *w_cur = d_w0.p, *w_nxt = d_w1.p;
     Sc blind_fin = Sc::zero(); size_t nk = n, nw = 1, round = 0;
@@ -639,9 +654,13 @@ class Prover {
       } else {
         d.chk(lasso_bullet_round(d.ctx, g.bases, n, a_cur, b_cur, w_cur, nullptr, nullptr, nullptr, nk, nullptr, nullptr, blinds, LR), "lasso_bullet_round");
       }
-      std::vector<Pt> two{Pt::from_abi(LR[0]), Pt::from_abi(LR[1])}; std::vector<uint8_t> cb; compress_batch(two, cb);
-      t.append_point_bytes("L", &cb[0]); t.append_point_bytes("R", &cb[32]);
-      Sc u = t.challenge_scalar("u"), u_inv = u.inverse();
+      std::vector<uint8_t> cb; Sc u, u_inv;
+      {
+        HostClock hc("opening: round host work");
+        std::vector<Pt> two{Pt::from_abi(LR[0]), Pt::from_abi(LR[1])}; compress_batch(two, cb);
+        t.append_point_bytes("L", &cb[0]); t.append_point_bytes("R", &cb[32]);
+        u = t.challenge_scalar("u"); u_inv = u.inverse();
+      }
       ua = u.abi(); uia = u_inv.abi(); have_u = true;
       blind_fin = blind_fin + blind_L * u * u + blind_R * u_inv * u_inv;
       P.L_vec.insert(P.L_vec.end(), cb.begin(), cb.begin() + 32); P.R_vec.insert(P.R_vec.end(), cb.begin() + 32, cb.end());
@@ -655,9 +674,13 @@ class Prover {
     lasso_fr heads[2]; const lasso_fr* hp[2] = {a_cur, b_cur};
     d.chk(lasso_read_heads(d.ctx, hp, 2, heads), "lasso_read_heads");
     Sc x_hat = Sc::from_abi(heads[0]), a_hat = Sc::from_abi(heads[1]), y_hat = x_hat * a_hat;
-    Pt g_hat = msm_dev(g, w_cur, n);                                             // G[0] after all folds = sum_j w_j G_j
-    compress_one(g_hat * dd + g.hmul.mul(r_delta), P.delta); t.append_point_bytes("delta", P.delta);
-    compress_one(g.Qmul.mul(dd) + g.hmul.mul(r_beta), P.beta); t.append_point_bytes("beta", P.beta);
+    // delta = d*g_hat + r_delta*h with g_hat = G[0] after all folds = sum_j w_j G_j: one MSM over the resident weights scaled by d, plus the h term
+    lasso_point dl; { lasso_fr sc = dd.abi(); lasso_fr tl[2] = {Sc::zero().abi(), r_delta.abi()}; d.chk(lasso_msm_dev_scaled(d.ctx, g.bases, w_cur, n, &sc, tl, &dl), "lasso_msm_dev_scaled"); }
+    {
+      HostClock hc("opening: delta/beta scalar mults");
+      compress_one(Pt::from_abi(dl), P.delta); t.append_point_bytes("delta", P.delta);
+      compress_one(g.Qmul.mul(dd) + g.hmul.mul(r_beta), P.beta); t.append_point_bytes("beta", P.beta);
+    }
     Sc c = t.challenge_scalar("c");
     P.z1 = dd + c * y_hat;
     P.z2 = a_hat * (c * blind_fin + r_beta) + r_delta;
@@ -669,21 +692,32 @@ class Prover {
     t.append_protocol_name("polynomial evaluation proof");
     LASSO_REQUIRE(r.size() == num_vars);
     size_t left = num_vars / 2, right = num_vars - left;
-    ScVec L = eq_evals_host(r.data(), left), R = eq_evals_host(r.data() + left, right);
-    std::vector<lasso_fr> Lh(L.size()), LZh(R.size()); for (size_t i = 0; i < L.size(); i++) Lh[i] = L[i].abi();
+    const size_t Ln = (size_t)1 << left, Rn = (size_t)1 << right;
+    DBuf d_LZ(d, Rn), d_R(d, Rn);
+    std::vector<uint8_t> a_bytes(32 * Rn);
+    std::vector<lasso_fr> rl, rr; for (size_t i = 0; i < left; i++) rl.push_back(r[i].abi()); for (size_t i = left; i < num_vars; i++) rr.push_back(r[i].abi());
     if (this->P == 1) {
-      d.chk(lasso_matvec_left(d.ctx, d_poly, Lh.data(), L.size(), R.size(), LZh.data()), "lasso_matvec_left");
+      // everything stays on the device: the two halves of the eq table (eq_poly.rs:44-52), L*Z (dense_mlpoly.rs:184-207); only serialize(R) comes back
+      DBuf d_L(d, Ln);
+      d.chk(lasso_eq_evals(d.ctx, rl.data(), (uint32_t)left, d_L.p), "lasso_eq_evals");
+      d.chk(lasso_eq_evals(d.ctx, rr.data(), (uint32_t)right, d_R.p), "lasso_eq_evals");
+      d.chk(lasso_matvec_left_dev(d.ctx, d_poly, d_L.p, Ln, Rn, d_LZ.p), "lasso_matvec_left_dev");
+      d.chk(lasso_fr_to_bytes(d.ctx, d_R.p, Rn, a_bytes.data()), "lasso_fr_to_bytes");
     } else {
       // slab mode: d_poly holds this rank's columns (= rank mod P) of every row, so the rank computes its entries of L*Z in full; the vector is
       // all-gathered and the opening's bullet reduction (latency-bound, sqrt(n)-sized) runs replicated on every rank with the same transcript
-      const size_t Pw = this->P, r_loc = R.size() / Pw; LASSO_REQUIRE(R.size() >= Pw);
-      std::vector<lasso_fr> mine(r_loc), all(R.size());
-      d.chk(lasso_matvec_left(d.ctx, d_poly, Lh.data(), L.size(), r_loc, mine.data()), "lasso_matvec_left");
+      ScVec L = eq_evals_host(r.data(), left);
+      std::vector<lasso_fr> Lh(Ln), LZh(Rn); for (size_t i = 0; i < Ln; i++) Lh[i] = L[i].abi();
+      const size_t Pw = this->P, r_loc = Rn / Pw; LASSO_REQUIRE(Rn >= Pw);
+      std::vector<lasso_fr> mine(r_loc), all(Rn);
+      d.chk(lasso_matvec_left(d.ctx, d_poly, Lh.data(), Ln, r_loc, mine.data()), "lasso_matvec_left");
       d.comm.allgather(mine.data(), all.data(), r_loc * sizeof(lasso_fr));
-      for (size_t g = 0; g < Pw; g++) for (size_t j = 0; j < r_loc; j++) LZh[j * Pw + g] = all[g * r_loc + j];
+      for (size_t g2 = 0; g2 < Pw; g2++) for (size_t j = 0; j < r_loc; j++) LZh[j * Pw + g2] = all[g2 * r_loc + j];
+      d.chk(lasso_upload(d.ctx, d_LZ.p, LZh.data(), Rn * sizeof(lasso_fr)), "lasso_upload");
+      d.chk(lasso_eq_evals(d.ctx, rr.data(), (uint32_t)right, d_R.p), "lasso_eq_evals");
+      d.chk(lasso_fr_to_bytes(d.ctx, d_R.p, Rn, a_bytes.data()), "lasso_fr_to_bytes");
     }
-    ScVec LZ; for (auto& x : LZh) LZ.push_back(Sc::from_abi(x));
-    return dot_product_log_prove(g, LZ, R, Zr);
+    return dot_product_log_prove(g, d_LZ, d_R, a_bytes, Zr);
   }
   // ---- CombinedTableEvalProof::prove (subtables/mod.rs:285-313) / the two n-to-1 reductions of HashLayerProof (memory_checking.rs:370-449)
   DotProductProofLog joint_open(const char* evals_label, const char* challenge_label, const char* joint_label, ScVec evals, bool pad_before_append,
@@ -763,6 +797,7 @@ class Prover {
     memory_checking_prove(r_hash[0], r_hash[1], Eptr, chis, W);
     sp.reset();
     proof_bytes.swap(W.b);
+    HostClock::dump();
   }
 
   void memory_checking_prove(const Sc& gamma, const Sc& tau, const std::vector<const lasso_fr*>& Eptr, DBuf& chis, ProofWriter& W) {

@@ -186,6 +186,15 @@ int32_t lasso_msm(lasso_ctx* c, const lasso_bases* b, const lasso_fr* scalars, s
 }
 
 int32_t lasso_msm_dev(lasso_ctx* c, const lasso_bases* b, const lasso_fr* scalars, size_t n, lasso_point* out) { return lasso_msm(c, b, scalars, n, out); }
+int32_t lasso_matvec_left_dev(lasso_ctx* c, const lasso_fr* Z, const lasso_fr* L, size_t ls, size_t rs, lasso_fr* out) { return lasso_matvec_left(c, Z, L, ls, rs, out); }
+int32_t lasso_fr_to_bytes(lasso_ctx*, const lasso_fr* src, size_t n, uint8_t* out) { for (size_t i = 0; i < n; i++) { u64 cc[4]; F(src)[i].to_canonical(cc); memcpy(out + 32 * i, cc, 32); } return 0; }
+int32_t lasso_msm_dev_scaled(lasso_ctx* c, const lasso_bases* b, const lasso_fr* sc, size_t n, const lasso_fr* scale, const lasso_fr* tail, lasso_point* out) {
+  REQ(c, n + 2 <= b->pts.size());
+  std::vector<Point> bases(b->pts.begin(), b->pts.begin() + n + 2); std::vector<Fr> s;
+  for (size_t i = 0; i < n; i++) s.push_back(F(sc)[i] * *F(scale));
+  s.push_back(F(tail)[0]); s.push_back(F(tail)[1]);
+  put_point(msm(bases, s), out); return 0;
+}
 int32_t lasso_inner_products_lr(lasso_ctx*, const lasso_fr* a, const lasso_fr* b, size_t nk, lasso_fr* out) {
   size_t h = nk / 2; F(out)[0] = inner_product(F(a), F(b) + h, h); F(out)[1] = inner_product(F(a) + h, F(b), h); return 0;   // bullet.rs:79-80
 }

@@ -411,3 +411,41 @@ def test_densify_rejects_out_of_range(devs):
         d.densify_dim(p_idx, 2, 1, 0, 2, 4, p_u32, p_dim, p_read, p_fin)
     for p in (p_idx, p_u32, p_dim, p_read, p_fin):
         d.free(p)
+
+
+@pytest.mark.parametrize("ls,rs", [(1, 1), (4, 8), (64, 300), (512, 1024)])
+def test_matvec_left_dev_and_to_bytes(devs, ls, rs):
+    """device-resident forms of the opening's mat-vec and of CanonicalSerialize: equal to the host-result forms / to the canonical integers"""
+    rng = np.random.default_rng(ls * 13 + rs)
+    Z = rand_fr(rng, ls * rs); L = rand_fr(rng, ls)
+
+    def run(d):
+        pz = d.upload(Z); pl = d.upload(L); po = d.alloc(32 * rs)
+        d.matvec_left_dev(pz, pl, ls, rs, po)
+        out = d.download(po, (rs, 4)); ref = d.matvec_left(pz, L, ls, rs); by = d.fr_to_bytes(po, rs)
+        for p in (pz, pl, po):
+            d.free(p)
+        return out, ref, by
+    (a, ra, ba), (b, rb, bb) = both(devs, run)
+    assert np.array_equal(a, b) and np.array_equal(a, ra) and np.array_equal(b, rb) and np.array_equal(ba, bb)
+    # bytes = the canonical integer of each element, little endian
+    Rinv = pow(1 << 256, -1, FR_P)
+    for i in range(min(rs, 5)):
+        mont = int.from_bytes(a[i].tobytes(), "little")
+        assert int.from_bytes(ba[i].tobytes(), "little") == mont * Rinv % FR_P
+
+
+@pytest.mark.parametrize("n", [1, 2, 64, 298])
+def test_msm_dev_scaled(devs, gens_300, n):
+    """sum_j (scale*s_j) G_j + t0*Q + t1*H in one MSM (delta of dot_product.rs:219-224) vs the oracle"""
+    rng = np.random.default_rng(n + 99)
+    sc = rand_fr(rng, n, edge=False); scale = rand_fr(rng, 1, edge=False)[0]; tail = rand_fr(rng, 2, edge=False)
+
+    def run(d):
+        b = d.bases_create(gens_300[: n + 2])
+        p = d.upload(sc)
+        out = d.msm_dev_scaled(b, p, n, scale, tail)
+        d.free(p); d.bases_destroy(b)
+        return out
+    a, b = both(devs, run)
+    assert compress_points(devs[1].lib, a) == compress_points(devs[1].lib, b)

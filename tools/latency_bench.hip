@@ -11,6 +11,12 @@ __global__ void k_flag(volatile uint32_t* out, volatile uint32_t* flag, uint32_t
   __syncthreads();
   if (threadIdx.x == 0) { __threadfence_system(); *flag = v; }
 }
+struct Big { const void* p[272]; };   // 2176 bytes of kernel arguments: the two 136-pointer tables of a cubic round
+__global__ void k_flag_big(Big b, volatile uint32_t* out, volatile uint32_t* flag, uint32_t v) {
+  if (threadIdx.x < 24) out[threadIdx.x] = v + threadIdx.x + (uint32_t)(uintptr_t)b.p[threadIdx.x & 1];
+  __syncthreads();
+  if (threadIdx.x == 0) { __threadfence_system(); *flag = v; }
+}
 static double now() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 int main() {
   hipStream_t s; CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
@@ -36,6 +42,16 @@ int main() {
     // two dependent launches then sync (eval kernel + reduce kernel)
     for (int i = 0; i < N; i++) { hipLaunchKernelGGL(k_small, dim3(1), dim3(64), 0, s, d, i); hipLaunchKernelGGL(k_small, dim3(1), dim3(64), 0, s, d, i); CK(hipMemcpyAsync(h, d, 96, hipMemcpyDeviceToHost, s)); CK(hipStreamSynchronize(s)); }
     double t5 = now();
+    Big big; for (int i = 0; i < 272; i++) big.p[i] = nullptr;
+    *hf = 0xffffffffu;
+    double t6 = now();
+    for (int i = 0; i < N; i++) {
+      hipLaunchKernelGGL(k_flag_big, dim3(1), dim3(64), 0, s, big, dm, df, (uint32_t)i);
+      long spins = 0; while (*(volatile uint32_t*)hf != (uint32_t)i) { if (++spins > 200000000L) { printf("flag timeout\n"); return 2; } }
+    }
+    CK(hipStreamSynchronize(s));
+    double t7 = now();
+    if (rep) printf("launch with 2176 B of kernel arguments + host-flag spin %.1f us\n", (t7 - t6) / N);
     if (rep) printf("per round trip (us): launch+sync %.1f | launch+memcpyD2H+sync %.1f | launch(mapped host store)+sync %.1f | launch+host-flag spin %.1f | 2 launches+memcpy+sync %.1f\n",
                     (t1 - t0) / N, (t2 - t1) / N, (t3 - t2) / N, (t4 - t3) / N, (t5 - t4) / N);
   }
