@@ -95,11 +95,18 @@ int32_t lasso_bind_top(lasso_ctx* ctx, lasso_fr* const* d_polys, uint32_t npolys
  * out[3c+0..3c+2] = sum_i comb(A,B,C) at x = 0, 2, 3 with comb = A*B*C (grand_product.rs:126-128).  n = current length. */
 int32_t lasso_sumcheck_cubic_round(lasso_ctx* ctx, const lasso_fr* const* d_A, const lasso_fr* const* d_B, uint32_t ncirc,
                                    const lasso_fr* d_C, size_t n, lasso_fr* out);
-/* Rounds j >= 1 of prove_cubic_batched in one pass: first bind every polynomial with the previous challenge r
- * (sumcheck.rs:116-120; A, B in place, the shared eq polynomial from d_C_in into d_C_out, n = length BEFORE the bind, n >= 4),
- * then evaluate the next round (sumcheck.rs:49-93) on the bound values: out as lasso_sumcheck_cubic_round for length n/2. */
-int32_t lasso_sumcheck_cubic_round_fused(lasso_ctx* ctx, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_C_in, lasso_fr* d_C_out,
-                                         size_t n, const lasso_fr* r, lasso_fr* out);
+/* The same round in EQ-WEIGHTED form — what the prover calls.  In prove_cubic_batched the third polynomial is always EqPolynomial(rand).evals()
+ * (grand_product.rs:122-128); after binding its top j variables it equals  s_j * eq1(rand_j, x_top) * T_j  with T_j = eq(rand[j+1..]), and T_j is
+ * the prefix of the ORIGINAL table d_E up to the scalar prod_{t<=j}(1 - rand_t).  So the device never binds or stores C: for the current length n
+ * of A and B it returns  out[3c+{0,1,2}] = sum_{i < n/2} A_c(x)[i] * B_c(x)[i] * d_E[i]  at x = 0, 2, 3 (A_c(x) = the line through A_c[i], A_c[i+n/2]),
+ * and the host multiplies by  s_j * eq1(rand_j, x) / prod_{t<=j}(1 - rand_t)  to obtain sumcheck.rs:56-93's evaluations — the same field elements.
+ * d_E: device table with at least n/2 entries (the layer's eq table, or in the degenerate case rand_t = 1 a table proportional to T_j). */
+int32_t lasso_sumcheck_cubic_eqw_round(lasso_ctx* ctx, const lasso_fr* const* d_A, const lasso_fr* const* d_B, uint32_t ncirc,
+                                       const lasso_fr* d_E, size_t n, lasso_fr* out);
+/* Rounds j >= 1 in one pass: first bind A and B with the previous challenge r (sumcheck.rs:116-120, in place, n = length BEFORE the bind, n >= 4),
+ * then the eq-weighted sums of the next round on the bound values: out as lasso_sumcheck_cubic_eqw_round for length n/2 (sums over i < n/4). */
+int32_t lasso_sumcheck_cubic_eqw_round_fused(lasso_ctx* ctx, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n,
+                                             const lasso_fr* r, lasso_fr* out);
 /* One round of SumcheckInstanceProof::prove_arbitrary (src/subprotocols/sumcheck.rs:165-237) with
  * comb_func = S::combine_lookups_eq (src/subtables/mod.rs:53-57): out[x] = sum_i g(E_1..E_alpha)(x) * eq(x), x = 0..degree.
  * d_polys holds alpha = NUM_MEMORIES device pointers; d_eq is the eq polynomial. */

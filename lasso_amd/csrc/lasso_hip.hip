@@ -240,41 +240,58 @@ int32_t lasso_bind_top(lasso_ctx* c, lasso_fr* const* d_polys, uint32_t npolys, 
 // and every extra workgroup adds a reduction epilogue), LASSO_CUBIC_NX overrides for experiments
 static unsigned cubic_nx_cap(unsigned ny) { static const long e = [] { const char* v = getenv("LASSO_CUBIC_NX"); return v ? atol(v) : 0L; }(); if (e > 0) return (unsigned)e; unsigned c = 512 / (ny ? ny : 1); return c < 64 ? 64 : c; }
 #define CUBIC_SMALL_Q 64   // rounds with at most this many indices per circuit take the latency-shaped kernel
+// the reference's loop with an explicit third polynomial (any C): kept as the literal counterpart of sumcheck.rs:49-93
 int32_t lasso_sumcheck_cubic_round(lasso_ctx* c, const lasso_fr* const* d_A, const lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_C, size_t n, lasso_fr* out) {
   REQUIRE(c, d_A && d_B && d_C && out && ncirc >= 1 && ncirc <= LASSO_MAX_PTRS && n >= 2 && (n & (n - 1)) == 0);
   const size_t half = n / 2;
   int32_t rc = ensure_small(c, (size_t)ncirc * 3); if (rc) return rc;
   const uint32_t seq = ++c->seq;
-  if (half <= CUBIC_SMALL_Q) {
-    MutPtrTable A, B; for (uint32_t i = 0; i < ncirc; i++) { REQUIRE(c, d_A[i] && d_B[i]); A.p[i] = (fr_t*)d_A[i]; B.p[i] = (fr_t*)d_B[i]; }   // read-only in this mode
-    ProfScope ps(c, LASSO_K_CUBIC, 32.0 * n * (2.0 * ncirc + 1.0));
-    hipLaunchKernelGGL((k_cubic_small<false>), dim3(ncirc), dim3(LASSO_BLOCK), 0, c->stream, A, B, (const fr_t*)d_C, (fr_t*)nullptr, (uint32_t)half, fr_zero(), c->d_counters, c->d_small, c->d_flag, seq);
-  } else {
-    PtrTable A, B; for (uint32_t i = 0; i < ncirc; i++) { REQUIRE(c, d_A[i] && d_B[i]); A.p[i] = (const fr_t*)d_A[i]; B.p[i] = (const fr_t*)d_B[i]; }
-    const unsigned ny = ncirc, nx = grid_for(half, cubic_nx_cap(ny));
-    rc = ensure_scratch(c, (size_t)nx * ny * 3 * sizeof(fr_t)); if (rc) return rc;
+  PtrTable A, B; for (uint32_t i = 0; i < ncirc; i++) { REQUIRE(c, d_A[i] && d_B[i]); A.p[i] = (const fr_t*)d_A[i]; B.p[i] = (const fr_t*)d_B[i]; }
+  const unsigned ny = ncirc, nx = grid_for(half, cubic_nx_cap(ny));
+  rc = ensure_scratch(c, (size_t)nx * ny * 3 * sizeof(fr_t)); if (rc) return rc;
+  {
     ProfScope ps(c, LASSO_K_CUBIC, 32.0 * n * (2.0 * ncirc + 1.0));
     hipLaunchKernelGGL(k_cubic_round_lb, dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, A, B, nx, ny, (const fr_t*)d_C, half, (fr_t*)c->d_scratch, c->d_counters, c->d_small, c->d_flag, seq);
   }
   HIPCHK(c, hipGetLastError());
   return wait_flag(c, seq, (size_t)ncirc * 3, out);
 }
-int32_t lasso_sumcheck_cubic_round_fused(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_C_in, lasso_fr* d_C_out, size_t n,
-                                         const lasso_fr* r, lasso_fr* out) {
-  REQUIRE(c, d_A && d_B && d_C_in && d_C_out && d_C_in != d_C_out && r && out && ncirc >= 1 && ncirc <= LASSO_MAX_PTRS && n >= 4 && (n & (n - 1)) == 0);
+// eq-weighted forms (see k_cubic_eqw_* in poly_kernels.cuh): what the prover calls.  Algorithmic bytes are SURVEY.md §8d's for the reference's round
+// (2k+1 polynomials), although the kernels read only the 2k of A and B plus n/4 .. n/2 table entries.
+int32_t lasso_sumcheck_cubic_eqw_round(lasso_ctx* c, const lasso_fr* const* d_A, const lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n, lasso_fr* out) {
+  REQUIRE(c, d_A && d_B && d_E && out && ncirc >= 1 && ncirc <= LASSO_MAX_PTRS && n >= 2 && (n & (n - 1)) == 0);
+  const size_t half = n / 2;
+  int32_t rc = ensure_small(c, (size_t)ncirc * 3); if (rc) return rc;
+  const uint32_t seq = ++c->seq;
+  if (half <= CUBIC_SMALL_Q) {
+    MutPtrTable A, B; for (uint32_t i = 0; i < ncirc; i++) { REQUIRE(c, d_A[i] && d_B[i]); A.p[i] = (fr_t*)d_A[i]; B.p[i] = (fr_t*)d_B[i]; }   // read-only in this mode
+    ProfScope ps(c, LASSO_K_CUBIC, 32.0 * n * (2.0 * ncirc + 1.0));
+    hipLaunchKernelGGL((k_cubic_eqw_small<false>), dim3(ncirc), dim3(LASSO_BLOCK), 0, c->stream, A, B, (const fr_t*)d_E, (uint32_t)half, fr_zero(), c->d_counters, c->d_small, c->d_flag, seq);
+  } else {
+    PtrTable A, B; for (uint32_t i = 0; i < ncirc; i++) { REQUIRE(c, d_A[i] && d_B[i]); A.p[i] = (const fr_t*)d_A[i]; B.p[i] = (const fr_t*)d_B[i]; }
+    const unsigned ny = ncirc, nx = grid_for(half, cubic_nx_cap(ny));
+    rc = ensure_scratch(c, (size_t)nx * ny * 3 * sizeof(fr_t)); if (rc) return rc;
+    ProfScope ps(c, LASSO_K_CUBIC, 32.0 * n * (2.0 * ncirc + 1.0));
+    hipLaunchKernelGGL(k_cubic_eqw_lb, dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, A, B, nx, ny, (const fr_t*)d_E, half, (fr_t*)c->d_scratch, c->d_counters, c->d_small, c->d_flag, seq);
+  }
+  HIPCHK(c, hipGetLastError());
+  return wait_flag(c, seq, (size_t)ncirc * 3, out);
+}
+int32_t lasso_sumcheck_cubic_eqw_round_fused(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n, const lasso_fr* r, lasso_fr* out) {
+  REQUIRE(c, d_A && d_B && d_E && r && out && ncirc >= 1 && ncirc <= LASSO_MAX_PTRS && n >= 4 && (n & (n - 1)) == 0);
   MutPtrTable A, B; for (uint32_t i = 0; i < ncirc; i++) { REQUIRE(c, d_A[i] && d_B[i]); A.p[i] = (fr_t*)d_A[i]; B.p[i] = (fr_t*)d_B[i]; }
   const size_t q = n / 4;
   int32_t rc = ensure_small(c, (size_t)ncirc * 3); if (rc) return rc;
   const uint32_t seq = ++c->seq;
   {
-    // bind: read 32n + write 16n per polynomial (2*ncirc + 1 of them); the evaluation of the next round rides on the same pass
+    // bind: read 32n + write 16n per polynomial (SURVEY.md §8d's "fused bind+next-eval" over the reference's 2*ncirc + 1 polynomials)
     ProfScope ps(c, LASSO_K_CUBIC, 48.0 * n * (2.0 * ncirc + 1.0));
     if (q <= CUBIC_SMALL_Q) {
-      hipLaunchKernelGGL((k_cubic_small<true>), dim3(ncirc), dim3(LASSO_BLOCK), 0, c->stream, A, B, (const fr_t*)d_C_in, (fr_t*)d_C_out, (uint32_t)q, to_fr(r), c->d_counters, c->d_small, c->d_flag, seq);
+      hipLaunchKernelGGL((k_cubic_eqw_small<true>), dim3(ncirc), dim3(LASSO_BLOCK), 0, c->stream, A, B, (const fr_t*)d_E, (uint32_t)q, to_fr(r), c->d_counters, c->d_small, c->d_flag, seq);
     } else {
       const unsigned ny = ncirc, nx = grid_for(q, cubic_nx_cap(ny));
       rc = ensure_scratch(c, (size_t)nx * ny * 3 * sizeof(fr_t)); if (rc) return rc;
-      hipLaunchKernelGGL(k_cubic_fused, dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, A, B, nx, ny, (const fr_t*)d_C_in, (fr_t*)d_C_out, q, to_fr(r), (fr_t*)c->d_scratch, c->d_counters, c->d_small, c->d_flag, seq);
+      hipLaunchKernelGGL(k_cubic_eqw_fused, dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, A, B, nx, ny, (const fr_t*)d_E, q, to_fr(r), (fr_t*)c->d_scratch, c->d_counters, c->d_small, c->d_flag, seq);
     }
   }
   HIPCHK(c, hipGetLastError());

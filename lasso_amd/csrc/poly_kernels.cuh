@@ -161,13 +161,14 @@ __device__ __forceinline__ void row_done(uint32_t nrows, uint32_t* counters, uin
   }
 }
 // block partials -> memory (K10 also supplies the missing 2^10), then the in-launch second stage; a single-block row writes its result directly.
-__device__ __forceinline__ void cubic_epilogue(const fr29* e, const CubicGrid& g, fr_t* __restrict__ partials, uint32_t* counters, fr_t* __restrict__ out, uint32_t* flag, uint32_t seq, RedScratch& S) {
+__device__ __forceinline__ void cubic_epilogue(const fr29* e, const CubicGrid& g, fr_t* __restrict__ partials, uint32_t* counters, fr_t* __restrict__ out, uint32_t* flag, uint32_t seq, RedScratch& S,
+                                               const fr29& fix) {
   if (g.nx == 1) {
-    store_block_partials<3>(e, 3, out + (size_t)g.by * 3, fr29_k10(), S);
+    store_block_partials<3>(e, 3, out + (size_t)g.by * 3, fix, S);
     row_done(g.ny, counters, flag, seq);
     return;
   }
-  store_block_partials<3>(e, 3, partials + ((size_t)g.by * g.nx + g.bx) * 3, fr29_k10(), S);
+  store_block_partials<3>(e, 3, partials + ((size_t)g.by * g.nx + g.bx) * 3, fix, S);
   last_block_reduce(partials, g.nx, 3, g.by, g.ny, counters, out, S, flag, seq);
 }
 #define CUBIC_ACCUMULATE(e, t0, t2, t3, cnt)                                                                                          \
@@ -188,18 +189,48 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_round_lb(PtrTable A, PtrT
     cubic_terms(fr29_unpack_u(a[i]), fr29_unpack_u(a[i + half]), fr29_unpack_u(b[i]), fr29_unpack_u(b[i + half]), fr29_unpack_u(C[i]), fr29_unpack_u(C[i + half]), t0, t2, t3);
     CUBIC_ACCUMULATE(e, t0, t2, t3, cnt);
   }
-  cubic_epilogue(e, g, partials, counters, out, flag, seq, S);
+  cubic_epilogue(e, g, partials, counters, out, flag, seq, S, fr29_k10());
 }
-// K4 fused with K1: bind every polynomial of the round with r (length n = 4q -> 2q), then evaluate the NEXT round on the bound
-// values while they are still in registers (80 -> 48 bytes per element per round, one launch per round).
-// A, B are bound in place (each element is owned by exactly one thread); the shared eq polynomial C is read from C_in and written
-// to C_out by the row-0 workgroups only, because every circuit row re-reads it.
 __device__ __forceinline__ fr29 bind29(const fr_t& lo, const fr_t& hi, const fr29& rs) {
   const fr29 l = fr29_unpack_u(lo);
   return fr29_canonical(fr29_add(l, fr29_mul(fr29_sub(fr29_unpack_u(hi), l), rs)));   // canonical: stored as is, and a reduced operand below
 }
-__global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_fused(MutPtrTable A, MutPtrTable B, uint32_t nx, uint32_t ny, const fr_t* __restrict__ C_in, fr_t* __restrict__ C_out, size_t q, fr_t r,
-                                                              fr_t* __restrict__ partials, uint32_t* counters, fr_t* __restrict__ out, uint32_t* flag, uint32_t seq) {
+
+// ------------------------------------------------------------------ K4 in eq-weighted form (the form the prover uses)
+// In prove_cubic_batched (grand_product.rs:126-128 -> sumcheck.rs:49-124) the third polynomial C is ALWAYS EqPolynomial(rand).evals().  After
+// binding its top j variables with challenges rho it is  C_j[i] = s_j * eq1(rand_j, x_top) * T_j[i_low]  with T_j = eq(rand[j+1..]) and
+// s_j = prod_{t<j} eq1(rand_t, rho_t); and T_j is the PREFIX of the original table up to a scalar: E[i] = prod_{t<=j}(1 - rand_t) * T_j[i]
+// for i < 2^(l-1-j).  So the round's sums are  e(x) = [s_j * eq1(rand_j, x) / prod_{t<=j}(1 - rand_t)] * sum_i a(x) b(x) E[i]:
+// the device never binds or stores C — it reads the prefix of the one table built for the layer — and the bracket is three host scalars.
+// Per index and circuit: 2 products for aE(x) = a(x) E[i] (linear in x), 3 for b(x) aE(x): 5 instead of 6, and the fused kernel binds
+// 4 values instead of 6 (9 products per index against 12).  Exact field arithmetic: the round polynomials are the same field elements.
+__device__ __forceinline__ void cubic_eqw_terms(const fr29& a0, const fr29& a1, const fr29& b0, const fr29& b1, const fr29& es, fr29& t0, fr29& t2, fr29& t3) {
+  const fr29 g0 = fr29_mul(a0, es), g1 = fr29_mul(a1, es);          // u * s = u-form, reduced
+  t0 = fr29_mul(b0, g0);
+  const fr29 dg = fr29_sub(g1, g0), db = fr29_sub(b1, b0);
+  const fr29 g2 = fr29_weak(fr29_add(g1, dg)), b2 = fr29_weak(fr29_add(b1, db));   // 2*hi - lo
+  t2 = fr29_mul(b2, g2);
+  t3 = fr29_mul(fr29_add(b2, db), fr29_weak(fr29_add(g2, dg)));                     // 3*hi - 2*lo; u * u: 2^5 short, fixed once per block with K5
+}
+// out[c*3 + {0,1,2}] = sum_{i < half} A_c(x)[i] B_c(x)[i] E[i] at x = 0, 2, 3.  1-D grid of nx*ny workgroups (cubic_grid).
+__global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_eqw_lb(PtrTable A, PtrTable B, uint32_t nx, uint32_t ny, const fr_t* __restrict__ E, size_t half, fr_t* __restrict__ partials, uint32_t* counters,
+                                                               fr_t* __restrict__ out, uint32_t* flag, uint32_t seq) {
+  __shared__ RedScratch S;
+  const CubicGrid g = cubic_grid(nx, ny);
+  const fr_t* __restrict__ a = A.p[g.by];
+  const fr_t* __restrict__ b = B.p[g.by];
+  fr29 e[3] = {fr29_zero(), fr29_zero(), fr29_zero()}; uint32_t cnt = 0;
+  for (size_t i = g.bx * (size_t)blockDim.x + threadIdx.x; i < half; i += (size_t)nx * blockDim.x) {
+    fr29 t0, t2, t3;
+    cubic_eqw_terms(fr29_unpack_u(a[i]), fr29_unpack_u(a[i + half]), fr29_unpack_u(b[i]), fr29_unpack_u(b[i + half]), fr29_unpack_s(E[i]), t0, t2, t3);
+    CUBIC_ACCUMULATE(e, t0, t2, t3, cnt);
+  }
+  cubic_epilogue(e, g, partials, counters, out, flag, seq, S, fr29_k5());
+}
+// fused with K1: bind A and B with r (length n = 4q -> 2q, in place: each element is owned by exactly one thread), then the sums of the NEXT round
+// on the bound values while they are still in registers — one launch per round, 48 bytes per element of A and B plus 32 per index of E.
+__global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_eqw_fused(MutPtrTable A, MutPtrTable B, uint32_t nx, uint32_t ny, const fr_t* __restrict__ E, size_t q, fr_t r,
+                                                                  fr_t* __restrict__ partials, uint32_t* counters, fr_t* __restrict__ out, uint32_t* flag, uint32_t seq) {
   __shared__ RedScratch S;
   const CubicGrid g = cubic_grid(nx, ny);
   fr_t* __restrict__ a = A.p[g.by];
@@ -211,48 +242,45 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_fused(MutPtrTable A, MutP
     a[i] = fr29_pack(a0); a[i + q] = fr29_pack(a1);
     const fr29 b0 = bind29(b[i], b[i + 2 * q], rs), b1 = bind29(b[i + q], b[i + 3 * q], rs);
     b[i] = fr29_pack(b0); b[i + q] = fr29_pack(b1);
-    const fr29 c0 = bind29(C_in[i], C_in[i + 2 * q], rs), c1 = bind29(C_in[i + q], C_in[i + 3 * q], rs);
-    if (g.by == 0) { C_out[i] = fr29_pack(c0); C_out[i + q] = fr29_pack(c1); }
     fr29 t0, t2, t3;
-    cubic_terms(a0, a1, b0, b1, c0, c1, t0, t2, t3);
+    cubic_eqw_terms(a0, a1, b0, b1, fr29_unpack_s(E[i]), t0, t2, t3);
     CUBIC_ACCUMULATE(e, t0, t2, t3, cnt);
   }
-  cubic_epilogue(e, g, partials, counters, out, flag, seq, S);
+  cubic_epilogue(e, g, partials, counters, out, flag, seq, S, fr29_k5());
 }
-
 // Late rounds (q <= 64 indices per circuit): the same round, laid out for LATENCY instead of throughput.  One workgroup per circuit;
-// phase 1 gives every bind its own lane (6q products side by side instead of 6 in a row per thread), the bound values go to LDS; phase 2
-// gives every (index, evaluation point) its own lane, one wave per point; the three sums are 64-row column sums.  BIND = false is the
-// first round of a layer (no challenge yet): phase 1 only unpacks.  n_in = current length of A/B/C_in: 4q when BIND, 2q otherwise.
+// phase 1 gives every bind its own lane (4q products side by side instead of 4 in a row per thread), phase 2 every weighted value a'[i] E[i mod q],
+// phase 3 every (index, evaluation point), one wave per point; the three sums are 64-row column sums.  BIND = false is the first round of a
+// layer (no challenge yet): phase 1 only unpacks.  Lengths: A, B hold 4q elements when BIND, 2q otherwise.
 template <bool BIND>
-__global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_small(MutPtrTable A, MutPtrTable B, const fr_t* __restrict__ C_in, fr_t* __restrict__ C_out, uint32_t q, fr_t r, uint32_t* counters,
-                                                              fr_t* __restrict__ out, uint32_t* flag, uint32_t seq) {
-  __shared__ fr29 bound[3][128];
+__global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_eqw_small(MutPtrTable A, MutPtrTable B, const fr_t* __restrict__ E, uint32_t q, fr_t r, uint32_t* counters, fr_t* __restrict__ out,
+                                                                  uint32_t* flag, uint32_t seq) {
+  __shared__ fr29 bound[2][128];   // A', B' (2q values each)
+  __shared__ fr29 ge[128];         // A'[i] * E[i mod q]
   __shared__ int32_t rows[192 * 9];
   __shared__ int64_t cols[27];
-  const uint32_t t = threadIdx.x, y = blockIdx.x, m = 2 * q;   // m = length after the bind
+  const uint32_t t = threadIdx.x, y = blockIdx.x, m = 2 * q;
   const fr29 rs = fr29_unpack_s(r);
-  for (uint32_t item = t; item < 3 * m; item += LASSO_BLOCK) {
+  for (uint32_t item = t; item < 2 * m; item += LASSO_BLOCK) {
     const uint32_t p = item / m, i = item - p * m;
-    fr_t* dst = p == 0 ? A.p[y] : p == 1 ? B.p[y] : C_out;
-    const fr_t* src = p == 2 ? C_in : dst;
+    fr_t* dst = p == 0 ? A.p[y] : B.p[y];
     fr29 v;
-    if (BIND) { v = bind29(src[i], src[i + m], rs); if (p < 2 || y == 0) dst[i] = fr29_pack(v); }
-    else v = fr29_unpack_u(src[i]);
+    if (BIND) { v = bind29(dst[i], dst[i + m], rs); dst[i] = fr29_pack(v); } else v = fr29_unpack_u(dst[i]);
     bound[p][i] = v;
   }
+  __syncthreads();
+  if (t < m) ge[t] = fr29_mul(bound[0][t], fr29_unpack_s(E[t < q ? t : t - q]));
   __syncthreads();
   const uint32_t x = t >> 6, i = t & 63;   // wave x evaluates point {0, 2, 3}[x]
   if (x < 3) {
     fr29 term = fr29_zero();
     if (i < q) {
-      const fr29 a0 = bound[0][i], a1 = bound[0][i + q], b0 = bound[1][i], b1 = bound[1][i + q], c0 = bound[2][i], c1 = bound[2][i + q];
-      if (x == 0) term = fr29_mul(c0, fr29_mul(a0, b0));
+      const fr29 g0 = ge[i], g1 = ge[i + q], b0 = bound[1][i], b1 = bound[1][i + q];
+      if (x == 0) term = fr29_mul(b0, g0);
       else {
-        const fr29 da = fr29_sub(a1, a0), db = fr29_sub(b1, b0), dc = fr29_sub(c1, c0);
-        const fr29 a2 = fr29_weak(fr29_add(a1, da)), b2 = fr29_weak(fr29_add(b1, db)), c2 = fr29_weak(fr29_add(c1, dc));
-        if (x == 1) term = fr29_mul(c2, fr29_mul(a2, b2));
-        else term = fr29_mul(fr29_add(c2, dc), fr29_mul(fr29_add(a2, da), fr29_weak(fr29_add(b2, db))));
+        const fr29 dg = fr29_sub(g1, g0), db = fr29_sub(b1, b0);
+        const fr29 g2 = fr29_weak(fr29_add(g1, dg)), b2 = fr29_weak(fr29_add(b1, db));
+        term = x == 1 ? fr29_mul(b2, g2) : fr29_mul(fr29_add(b2, db), fr29_weak(fr29_add(g2, dg)));
       }
     }
 #pragma unroll
@@ -270,7 +298,7 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_small(MutPtrTable A, MutP
     int64_t c[9];
 #pragma unroll
     for (int k = 0; k < 9; k++) c[k] = cols[t * 9 + k];
-    out[(size_t)y * 3 + t] = fr29_store(fr29_mul(fr29_from_columns(c), fr29_k10()));
+    out[(size_t)y * 3 + t] = fr29_store(fr29_mul(fr29_from_columns(c), fr29_k5()));
   }
   row_done(gridDim.x, counters, flag, seq);
 }

@@ -103,10 +103,15 @@ class Device:
         self._chk(self.lib.lasso_sumcheck_cubic_round(self.ctx, self._ptrs(a_ptrs), self._ptrs(b_ptrs), len(a_ptrs), C.c_void_p(d_c), n, _vp(out)))
         return out
 
-    def sumcheck_cubic_round_fused(self, a_ptrs, b_ptrs, d_c_in, d_c_out, n, r):
+    def sumcheck_cubic_eqw_round(self, a_ptrs, b_ptrs, d_e, n):
+        out = np.empty((3 * len(a_ptrs), 4), dtype=np.uint64)
+        self._chk(self.lib.lasso_sumcheck_cubic_eqw_round(self.ctx, self._ptrs(a_ptrs), self._ptrs(b_ptrs), len(a_ptrs), C.c_void_p(d_e), n, _vp(out)))
+        return out
+
+    def sumcheck_cubic_eqw_round_fused(self, a_ptrs, b_ptrs, d_e, n, r):
         r = np.ascontiguousarray(r, dtype=np.uint64)
-        out = np.empty((len(a_ptrs) * 3, 4), dtype=np.uint64)
-        self._chk(self.lib.lasso_sumcheck_cubic_round_fused(self.ctx, self._ptrs(a_ptrs), self._ptrs(b_ptrs), len(a_ptrs), C.c_void_p(d_c_in), C.c_void_p(d_c_out), n, _vp(r), _vp(out)))
+        out = np.empty((3 * len(a_ptrs), 4), dtype=np.uint64)
+        self._chk(self.lib.lasso_sumcheck_cubic_eqw_round_fused(self.ctx, self._ptrs(a_ptrs), self._ptrs(b_ptrs), len(a_ptrs), C.c_void_p(d_e), n, _vp(r), _vp(out)))
         return out
 
     def sumcheck_combine_round(self, strategy, ptrs, d_eq, n, degree):

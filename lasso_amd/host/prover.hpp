@@ -512,58 +512,84 @@ class Prover {
     tail_bufs.clear();
     return proof;
   }
-  // ---- SumcheckInstanceProof::prove_cubic_batched (sumcheck.rs:27-135), comb = A*B*C.
-  // Round j's bind (sumcheck.rs:116-120) is executed by the same kernel that evaluates round j+1, so a round is ONE launch;
-  // the eq polynomial ping-pongs between Cp and Cq (see lasso_sumcheck_cubic_round_fused).  Values and order of everything that
-  // reaches the transcript are unchanged.  One phase = `rounds` rounds on arrays of length len (>= 2 when rounds > 0), ending with all
-  // polynomials (eq included when `bind_c`) bound by the last challenge; returns where the bound eq polynomial lives.
-  lasso_fr* cubic_rounds(size_t rounds, size_t len, std::vector<lasso_fr*>& A, std::vector<lasso_fr*>& B, lasso_fr* Cp, lasso_fr* Cq, const ScVec& coeffs, bool reduce, bool bind_c, Sc& e,
-                         SumcheckProof& proof, ScVec& r_out) {
+  // ---- SumcheckInstanceProof::prove_cubic_batched (sumcheck.rs:27-135), comb = A*B*C with C = EqPolynomial(rand).evals() (grand_product.rs:122-128).
+  // Round j's bind (sumcheck.rs:116-120) is executed by the same kernel that evaluates round j+1, so a round is ONE launch.  The eq polynomial is
+  // never bound or stored: after j binds it is  s_j * eq1(rand_j, x_top) * T_j  with T_j a scalar multiple of the PREFIX of the layer's table
+  // (lasso_sumcheck_cubic_eqw_round), so the device returns eq-weighted sums and the three scalars below turn them into sumcheck.rs:56-93's
+  // evaluations — the same field elements, so the transcript is unchanged.
+  // One phase = `rounds` rounds on arrays of length len (>= 2 when rounds > 0) over the variables rand[v0 .. v0+rounds), ending with A and B bound by
+  // the last challenge.  d_E: table whose first len/2^(j+1) entries are prod_{t<=j}(1 - rand[v0+t]) * T_j (the phase's eq table); s = running
+  // prod eq1(rand_t, rho_t) over all rounds so far (all phases).
+  void cubic_rounds(size_t rounds, size_t len, std::vector<lasso_fr*>& A, std::vector<lasso_fr*>& B, const lasso_fr* d_E, const ScVec& rand, size_t v0, const ScVec& coeffs, bool reduce, Sc& s_run,
+                    Sc& e, SumcheckProof& proof, ScVec& r_out) {
     const size_t k = A.size();
-    lasso_fr* c_cur = Cp; lasso_fr* c_nxt = Cq;
+    if (!rounds) return;
+    // 1 / prod_{t<=j}(1 - rand[v0+t]) for every round of the phase with one inversion; a zero factor (rand_t = 1) takes the explicit-table path
+    ScVec inv(rounds); bool degenerate = false;
+    {
+      Sc prod = Sc::one(); ScVec pre(rounds);
+      for (size_t j = 0; j < rounds; j++) { Sc om = Sc::one() - rand[v0 + j]; if (om.is_zero()) degenerate = true; prod *= om; pre[j] = prod; }
+      if (!degenerate) { Sc pi = prod.inverse(); for (size_t j = rounds; j-- > 0;) { inv[j] = pi; pi *= Sc::one() - rand[v0 + j]; } }
+    }
+    DBuf tj; if (degenerate) tj = DBuf(d, len / 2);
     Sc r_prev = Sc::zero();
     for (size_t j = 0; j < rounds; j++) {
+      const lasso_fr* table = d_E; Sc scale = degenerate ? Sc::one() : inv[j];
+      if (degenerate) {   // T_j = eq(rand[v0+j+1 .. v0+rounds)) built explicitly (size len / 2^(j+1) at this point), times the slab factor hidden in d_E[0] / eq-prefix
+        std::vector<lasso_fr> rr; for (size_t t2 = v0 + j + 1; t2 < v0 + rounds; t2++) rr.push_back(rand[t2].abi());
+        lasso_fr sc = (reduce ? d.comm.eq_low(rand) : Sc::one()).abi();
+        d.chk(lasso_eq_evals_scaled(d.ctx, rr.data(), (uint32_t)rr.size(), &sc, tj.p), "lasso_eq_evals_scaled");
+        table = tj.p;
+      }
       std::vector<lasso_fr> ev(3 * k);
       if (j == 0) {
-        d.chk(lasso_sumcheck_cubic_round(d.ctx, (const lasso_fr* const*)A.data(), (const lasso_fr* const*)B.data(), (uint32_t)k, c_cur, len, ev.data()), "lasso_sumcheck_cubic_round");
+        d.chk(lasso_sumcheck_cubic_eqw_round(d.ctx, (const lasso_fr* const*)A.data(), (const lasso_fr* const*)B.data(), (uint32_t)k, table, len, ev.data()), "lasso_sumcheck_cubic_eqw_round");
       } else {
         lasso_fr rp = r_prev.abi();
-        d.chk(lasso_sumcheck_cubic_round_fused(d.ctx, A.data(), B.data(), (uint32_t)k, c_cur, c_nxt, len, &rp, ev.data()), "lasso_sumcheck_cubic_round_fused");
-        std::swap(c_cur, c_nxt); len /= 2;
+        d.chk(lasso_sumcheck_cubic_eqw_round_fused(d.ctx, A.data(), B.data(), (uint32_t)k, table, len, &rp, ev.data()), "lasso_sumcheck_cubic_eqw_round_fused");
+        len /= 2;
       }
       if (reduce) d.comm.sum(ev);
       HostClock hc("cubic round host work");
+      // e(x) = s * eq1(rand_j, x) * scale * sum:  eq1(r, x) = (1 - r)(1 - x) + r x  at x = 0, 2, 3
+      const Sc& rj = rand[v0 + j]; const Sc base = s_run * scale, om = Sc::one() - rj;
+      const Sc f0 = base * om, f2 = base * (rj + rj - om), f3 = base * (rj + rj + rj - om - om);
       Sc c0 = Sc::zero(), c2 = Sc::zero(), c3 = Sc::zero();
       for (size_t i = 0; i < k; i++) { c0 += Sc::from_abi(ev[3 * i]) * coeffs[i]; c2 += Sc::from_abi(ev[3 * i + 1]) * coeffs[i]; c3 += Sc::from_abi(ev[3 * i + 2]) * coeffs[i]; }
+      c0 *= f0; c2 *= f2; c3 *= f3;
       UniPoly poly = UniPoly::from_evals({c0, e - c0, c2, c3});
       poly.append_to_transcript(t, "poly");
       Sc r_j = t.challenge_scalar("challenge_nextround"); r_out.push_back(r_j);
       r_prev = r_j;
       e = poly.evaluate(r_j);
+      s_run *= om * (Sc::one() - r_j) + rj * r_j;   // eq1(rand_j, rho_j)
       proof.compressed_polys.push_back(poly.compress());
     }
-    if (rounds) {   // the last challenge of the phase still has to be bound (len == 2 here)
-      std::vector<lasso_fr*> ab(A); ab.insert(ab.end(), B.begin(), B.end()); if (bind_c) ab.push_back(c_cur);
-      lasso_fr rp = r_prev.abi();
-      d.chk(lasso_bind_top(d.ctx, ab.data(), (uint32_t)ab.size(), len, &rp), "lasso_bind_top");
-    }
-    return c_cur;
+    // the last challenge of the phase still has to be bound (len == 2 here)
+    std::vector<lasso_fr*> ab(A); ab.insert(ab.end(), B.begin(), B.end());
+    lasso_fr rp = r_prev.abi();
+    d.chk(lasso_bind_top(d.ctx, ab.data(), (uint32_t)ab.size(), len, &rp), "lasso_bind_top");
   }
-  // A, B: local arrays of length len_loc = 2^num_rounds / P (slab mode) or the whole arrays; Cp = eq table of the same length, Cq = scratch of half of it
-  SumcheckProof prove_cubic_batched(const Sc& claim, size_t num_rounds, bool slab, std::vector<lasso_fr*>& A, std::vector<lasso_fr*>& B, lasso_fr* Cp, lasso_fr* Cq, const ScVec& coeffs, ScVec& r_out,
-                                    ScVec& claims_a, ScVec& claims_b) {
-    SumcheckProof proof; Sc e = claim; const size_t k = A.size();
+  // A, B: local arrays of length 2^num_rounds / P (slab mode) or the whole arrays; d_E = the layer's eq table over `rand` (local share in slab mode)
+  SumcheckProof prove_cubic_batched(const Sc& claim, size_t num_rounds, bool slab, std::vector<lasso_fr*>& A, std::vector<lasso_fr*>& B, const lasso_fr* d_E, const ScVec& rand, const ScVec& coeffs,
+                                    ScVec& r_out, ScVec& claims_a, ScVec& claims_b) {
+    SumcheckProof proof; Sc e = claim, s_run = Sc::one(); const size_t k = A.size();
+    LASSO_REQUIRE(rand.size() == num_rounds);
     std::vector<lasso_fr*> fa(A), fb(B);   // where the final values end up
     if (!slab) {
-      cubic_rounds(num_rounds, (size_t)1 << num_rounds, fa, fb, Cp, Cq, coeffs, false, false, e, proof, r_out);   // the eq polynomial's final value is not used
+      cubic_rounds(num_rounds, (size_t)1 << num_rounds, fa, fb, d_E, rand, 0, coeffs, false, s_run, e, proof, r_out);
     } else {
       LASSO_REQUIRE(num_rounds >= lgP);
-      lasso_fr* c_fin = cubic_rounds(num_rounds - lgP, (size_t)1 << (num_rounds - lgP), fa, fb, Cp, Cq, coeffs, true, true, e, proof, r_out);
-      std::vector<lasso_fr*> heads(fa); heads.insert(heads.end(), fb.begin(), fb.end()); heads.push_back(c_fin);
+      const size_t local_rounds = num_rounds - lgP;
+      cubic_rounds(local_rounds, (size_t)1 << local_rounds, fa, fb, d_E, rand, 0, coeffs, true, s_run, e, proof, r_out);
+      std::vector<lasso_fr*> heads(fa); heads.insert(heads.end(), fb.begin(), fb.end());
       std::vector<lasso_fr*> tail = gather_tail(heads);
       fa.assign(tail.begin(), tail.begin() + k); fb.assign(tail.begin() + k, tail.begin() + 2 * k);
-      tail_bufs.emplace_back(d, P);   // ping-pong partner of the tail's eq array
-      cubic_rounds(lgP, P, fa, fb, tail[2 * k], tail_bufs.back().p, coeffs, false, false, e, proof, r_out);
+      // the remaining log2 P variables: replicated P-element arrays and the (whole) eq table over rand[local_rounds..]
+      tail_bufs.emplace_back(d, P);
+      std::vector<lasso_fr> rr; for (size_t i = local_rounds; i < num_rounds; i++) rr.push_back(rand[i].abi());
+      d.chk(lasso_eq_evals(d.ctx, rr.data(), (uint32_t)rr.size(), tail_bufs.back().p), "lasso_eq_evals");
+      cubic_rounds(lgP, P, fa, fb, tail_bufs.back().p, rand, local_rounds, coeffs, false, s_run, e, proof, r_out);
     }
     std::vector<lasso_fr*> ab(fa); ab.insert(ab.end(), fb.begin(), fb.end());
     std::vector<lasso_fr> heads(2 * k);
@@ -581,7 +607,7 @@ class Prover {
     Trace tr("BatchedGrandProductArgument.prove", d.ctx);
     BatchedGrandProductArgument out; const size_t k = trees.size(), num_layers = ceil_log2(n), n_loc = n / P;
     ScVec claims_to_verify = roots, rand;
-    DBuf eq(d, std::max(n_loc / 2, P)), eq2(d, std::max(n_loc / 4, P));   // slab layers use n_loc/2 entries; replicated top layers at most P/2
+    DBuf eq(d, std::max(n_loc / 2, P));   // the layer's eq table: slab layers use n_loc/2 entries, replicated top layers at most P/2
     for (size_t layer_id = num_layers; layer_id-- > 0;) {
       const size_t len = n >> layer_id;                     // global layer `layer_id` has n/2^layer_id elements
       LASSO_REQUIRE(((size_t)1 << rand.size()) == len / 2);
@@ -601,7 +627,7 @@ class Prover {
       ScVec coeff_vec = t.challenge_vector("rand_coeffs_next_layer", claims_to_verify.size());
       Sc claim = Sc::zero(); for (size_t i = 0; i < claims_to_verify.size(); i++) claim += claims_to_verify[i] * coeff_vec[i];
       LayerProofBatched lp; ScVec rand_prod;
-      lp.proof = prove_cubic_batched(claim, num_rounds_prod, slab, A, B, eq.p, eq2.p, coeff_vec, rand_prod, lp.claims_prod_left, lp.claims_prod_right);
+      lp.proof = prove_cubic_batched(claim, num_rounds_prod, slab, A, B, eq.p, rand, coeff_vec, rand_prod, lp.claims_prod_left, lp.claims_prod_right);
       for (size_t i = 0; i < k; i++) { t.append_scalar("claim_prod_left", lp.claims_prod_left[i]); t.append_scalar("claim_prod_right", lp.claims_prod_right[i]); }
       Sc r_layer = t.challenge_scalar("challenge_r_layer");
       claims_to_verify.clear();

@@ -72,12 +72,29 @@ int32_t lasso_sumcheck_cubic_round(lasso_ctx* c, const lasso_fr* const* A, const
   }
   return 0;
 }
-int32_t lasso_sumcheck_cubic_round_fused(lasso_ctx* c, lasso_fr* const* A, lasso_fr* const* B, uint32_t nc, const lasso_fr* Cin, lasso_fr* Cout, size_t n, const lasso_fr* r, lasso_fr* out) {
+// eq-weighted form: sum_i A(x)[i] B(x)[i] E[i] at x = 0, 2, 3 (the host turns these into sumcheck.rs:56-93's evaluations with three scalars)
+int32_t lasso_sumcheck_cubic_eqw_round(lasso_ctx* c, const lasso_fr* const* A, const lasso_fr* const* B, uint32_t nc, const lasso_fr* E, size_t n, lasso_fr* out) {
+  REQ(c, n >= 2 && (n & (n - 1)) == 0);
+  size_t len = n / 2; const Fr* pe = F(E);
+  for (uint32_t k = 0; k < nc; k++) {
+    const Fr* pa = F(A[k]); const Fr* pb = F(B[k]);
+    Fr p0 = Fr::zero(), p2 = Fr::zero(), p3 = Fr::zero();
+    for (size_t i = 0; i < len; i++) {
+      p0 += pa[i] * pb[i] * pe[i];
+      Fr a2 = pa[len + i] + pa[len + i] - pa[i], b2 = pb[len + i] + pb[len + i] - pb[i];
+      p2 += a2 * b2 * pe[i];
+      Fr a3 = a2 + pa[len + i] - pa[i], b3 = b2 + pb[len + i] - pb[i];
+      p3 += a3 * b3 * pe[i];
+    }
+    F(out)[3 * k] = p0; F(out)[3 * k + 1] = p2; F(out)[3 * k + 2] = p3;
+  }
+  return 0;
+}
+int32_t lasso_sumcheck_cubic_eqw_round_fused(lasso_ctx* c, lasso_fr* const* A, lasso_fr* const* B, uint32_t nc, const lasso_fr* E, size_t n, const lasso_fr* r, lasso_fr* out) {
   REQ(c, n >= 4 && (n & (n - 1)) == 0);
-  size_t h = n / 2;   // sumcheck.rs:116-120 then :56-93 on the bound polynomials
-  for (uint32_t k = 0; k < nc; k++) { Fr* pa = F(A[k]); Fr* pb = F(B[k]); for (size_t i = 0; i < h; i++) { pa[i] = pa[i] + *F(r) * (pa[i + h] - pa[i]); pb[i] = pb[i] + *F(r) * (pb[i + h] - pb[i]); } }
-  for (size_t i = 0; i < h; i++) F(Cout)[i] = F(Cin)[i] + *F(r) * (F(Cin)[i + h] - F(Cin)[i]);
-  return lasso_sumcheck_cubic_round(c, A, B, nc, Cout, h, out);
+  size_t h = n / 2;
+  for (uint32_t k = 0; k < nc; k++) for (size_t i = 0; i < h; i++) { F(A[k])[i] = F(A[k])[i] + *F(r) * (F(A[k])[i + h] - F(A[k])[i]); F(B[k])[i] = F(B[k])[i] + *F(r) * (F(B[k])[i + h] - F(B[k])[i]); }
+  return lasso_sumcheck_cubic_eqw_round(c, A, B, nc, E, h, out);
 }
 int32_t lasso_sumcheck_combine_round(lasso_ctx* c, const lasso_strategy* s, const lasso_fr* const* polys, const lasso_fr* eq, size_t n, uint32_t degree, lasso_fr* out) {
   REQ(c, n >= 2 && (n & (n - 1)) == 0);

@@ -345,27 +345,49 @@ def test_bullet_round_fused(devs, n, nk, fold):
         assert np.array_equal(x, y)
 
 
+@pytest.mark.parametrize("n,ncirc", [(2, 1), (4, 2), (16, 33), (128, 5), (256, 2), (1 << 9, 2), (1 << 13, 8), (1 << 16, 3)])   # n <= 128: latency-shaped kernel
+def test_sumcheck_cubic_eqw_round(devs, n, ncirc):
+    """eq-weighted round sums: sum_i A(x)[i] B(x)[i] E[i] at x = 0, 2, 3, vs the oracle's loop"""
+    rng = np.random.default_rng(n * 3 + ncirc)
+    A = [rand_fr(rng, n) for _ in range(ncirc)]; B = [rand_fr(rng, n) for _ in range(ncirc)]; E = rand_fr(rng, n // 2)
+
+    def run(d):
+        pa = [d.upload(x) for x in A]; pb = [d.upload(x) for x in B]; pe = d.upload(E)
+        out = d.sumcheck_cubic_eqw_round(pa, pb, pe, n)
+        for p in pa + pb + [pe]:
+            d.free(p)
+        return out
+    a, b = both(devs, run)
+    assert np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("n,ncirc", [(4, 1), (8, 2), (32, 33), (256, 5), (512, 2), (1 << 10, 2), (1 << 14, 8), (1 << 17, 3)])   # n <= 256: latency-shaped kernel
-def test_sumcheck_cubic_round_fused(devs, n, ncirc):
-    """bind with r then evaluate the next round in one pass == bind_top followed by the plain round (sumcheck.rs:49-120)"""
+def test_sumcheck_cubic_eqw_round_fused(devs, n, ncirc):
+    """bind A, B with r then the eq-weighted sums of the next round in one pass == bind_top followed by the plain eq-weighted round (sumcheck.rs:49-120)"""
     rng = np.random.default_rng(n * 5 + ncirc)
     A = [rand_fr(rng, n) for _ in range(ncirc)]
     B = [rand_fr(rng, n) for _ in range(ncirc)]
-    Cp = rand_fr(rng, n)
+    E = rand_fr(rng, n // 4)
     r = rand_fr(rng, 1, edge=False)[0]
 
     def run(d):
-        pa = [d.upload(x) for x in A]; pb = [d.upload(x) for x in B]; pc = d.upload(Cp); pc2 = d.alloc(32 * (n // 2))
-        out = d.sumcheck_cubic_round_fused(pa, pb, pc, pc2, n, r)
-        again = d.sumcheck_cubic_round(pa, pb, pc2, n // 2)          # the bound arrays must equal a separate bind
-        res = (out, again, [d.download(p, (n // 2, 4)) for p in pa + pb + [pc2]])
-        for p in pa + pb + [pc, pc2]:
+        pa = [d.upload(x) for x in A]; pb = [d.upload(x) for x in B]; pe = d.upload(E)
+        out = d.sumcheck_cubic_eqw_round_fused(pa, pb, pe, n, r)
+        again = d.sumcheck_cubic_eqw_round(pa, pb, pe, n // 2)        # the bound arrays must equal a separate bind
+        res = (out, again, [d.download(p, (n // 2, 4)) for p in pa + pb])
+        for p in pa + pb + [pe]:
             d.free(p)
         return res
     a, b = both(devs, run)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[0], a[1])
     for x, y in zip(a[2], b[2]):
         assert np.array_equal(x, y)
+    # the bound arrays are bind_top's
+    def bound(d):
+        pa = [d.upload(x) for x in A[:1]]
+        d.bind_top(pa, n, r)
+        out = d.download(pa[0], (n // 2, 4)); d.free(pa[0]); return out
+    assert np.array_equal(bound(devs[0]), a[2][0])
 
 
 @pytest.mark.parametrize("n_lookups,c,log_m,mode", [(1, 1, 0, "rand"), (2, 1, 1, "rand"), (5, 2, 4, "rand"), (1000, 3, 8, "rand"), (4096, 1, 16, "rand"), (5000, 2, 12, "rand"),
