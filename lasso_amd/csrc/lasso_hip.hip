@@ -527,8 +527,11 @@ static int32_t run_msm(lasso_ctx* c, const uint8_t* d_scal, uint32_t bps, uint32
                        c->d_counters + LASSO_MAX_PTRS + 1, small ? c->d_flag : (uint32_t*)nullptr, seq);
   }
   HIPCHK(c, hipGetLastError());
-  if (out_compressed) {   // 32 bytes per row (the scratch behind the partials is large enough for 128)
-    HIPCHK(c, hipMemcpyAsync(out_compressed, d_final, rows * 32, hipMemcpyDeviceToHost, c->stream));
+  if (out_compressed) {   // d_final holds the row sums as pt29 (144 B per row: the scratch is sized for it, see hyrax_commit_impl); 32 wire bytes per row go out
+    uint32_t* d_wire = (uint32_t*)(((uintptr_t)((pt29*)d_final + rows) + 15) & ~(uintptr_t)15);
+    hipLaunchKernelGGL(k_points_compress, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, c->stream, (const pt29*)d_final, rows, d_wire);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(out_compressed, d_wire, rows * 32, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
   }
@@ -543,7 +546,7 @@ int32_t lasso_hyrax_commit_compressed(lasso_ctx* c, const lasso_fr* d_Z, size_t 
 static int32_t hyrax_commit_impl(lasso_ctx* c, const lasso_fr* d_Z, size_t l_size, size_t r_size, const lasso_bases* b, lasso_point* out, uint8_t* out_compressed) {
   REQUIRE(c, d_Z && b && l_size >= 1 && r_size >= 1 && r_size <= b->n && l_size < ((size_t)1 << 31));
   const size_t n = l_size * r_size;
-  const size_t pts_bytes = (l_size * msm_chunks(l_size, r_size, MSM_WINDOWS) + l_size) * sizeof(pt29) + 512;
+  const size_t pts_bytes = (l_size * msm_chunks(l_size, r_size, MSM_WINDOWS) + 2 * l_size) * sizeof(pt29) + 512;   // chunk partials + row sums (pt29 or ed_point) + wire bytes
   int32_t rc = ensure_scratch(c, n * 32 + pts_bytes); if (rc) return rc;
   uint8_t* d_scal = (uint8_t*)c->d_scratch;
   HIPCHK(c, hipMemsetAsync(c->d_flags, 0, 8, c->stream));

@@ -175,7 +175,7 @@ __global__ void __launch_bounds__(MSM_THREADS) k_points_sum(const pt29* __restri
   __syncthreads();
   const uint32_t live = K < MSM_THREADS ? K : MSM_THREADS;
   for (uint32_t s = MSM_THREADS / 2; s > 0; s >>= 1) { if (t < s && t + s < live) pts[t] = pt_add(pts[t], pts[t + s], d2); __syncthreads(); }
-  if (t == 0 && out_compressed) pt_compress(pts[0], out_compressed + 8 * (size_t)blockIdx.x);   // wire form straight from the device (normalize_batch + serialize_compressed)
+  if (t == 0 && out_compressed) reinterpret_cast<pt29*>(out_compressed)[blockIdx.x] = pts[0];   // compressed mode: hand the row sum to k_points_compress (one lane per row)
   if (t == 0 && !out_compressed) {
     ed_point p = pt_to_ed(pts[0]), o; o.X = fq_to_mont(p.X); o.Y = fq_to_mont(p.Y); o.T = fq_to_mont(p.T); o.Z = fq_to_mont(p.Z); out_mont[blockIdx.x] = o;
     if (flag) {
@@ -184,6 +184,12 @@ __global__ void __launch_bounds__(MSM_THREADS) k_points_sum(const pt29* __restri
       if (t2 == gridDim.x - 1) { *counters = 0; __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
     }
   }
+}
+
+// wire form of many points at once: one lane per point (normalize_batch + serialize_compressed on the device; the inversion chain is 265 products)
+__global__ void __launch_bounds__(256) k_points_compress(const pt29* __restrict__ pts, size_t n, uint32_t* __restrict__ out32) {
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i < n) pt_compress(pts[i], out32 + 8 * i);
 }
 
 // ------------------------------------------------------------------ Hyrax opening tail (bullet.rs:40-154), vectors resident on the device

@@ -12,7 +12,7 @@ from collections import defaultdict
 
 FAMILIES = {   # bench.py family name -> kernel-name prefixes
     "bind_top": ("k_bind_top",),
-    "sumcheck_cubic_round(+fused bind)": ("k_cubic_fused", "k_cubic_round_lb"),
+    "sumcheck_cubic_round(+fused bind)": ("k_cubic_eqw_fused", "k_cubic_eqw_lb", "k_cubic_round_lb"),
     "sumcheck_combine": ("k_combine_round_linear", "void k_combine_claim"),
     "multi_dot": ("k_multi_dot",),
     "matvec_left": ("k_matvec_left",),
