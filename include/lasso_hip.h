@@ -112,6 +112,13 @@ int32_t lasso_sumcheck_cubic_eqw_round_fused(lasso_ctx* ctx, lasso_fr* const* d_
  * d_polys holds alpha = NUM_MEMORIES device pointers; d_eq is the eq polynomial. */
 int32_t lasso_sumcheck_combine_round(lasso_ctx* ctx, const lasso_strategy* s, const lasso_fr* const* d_polys, const lasso_fr* d_eq,
                                      size_t n, uint32_t degree, lasso_fr* out);
+/* The same round in EQ-WEIGHTED form for the LINEAR strategies (AND / OR / XOR / RangeCheck: g = sum_k w_k E_k, src/subtables/and.rs:45-53) — what the
+ * prover calls.  The eq polynomial is factored exactly as in lasso_sumcheck_cubic_eqw_round (prefix of the original table d_E + host scalars), and by
+ * linearity of g a round needs per polynomial only  out[3k] = sum_{i<n/2} E_k[i] d_E[i]  and  out[3k+1] = sum_{i<n/2} E_k[i+n/2] d_E[i]  (out[3k+2] unused):
+ * the host forms G(x) = sum_k w_k (out[3k] + x (out[3k+1] - out[3k])) and e(x) = s_j eq1(r_j, x) / prod_{t<=j}(1 - r_t) G(x), x = 0, 1, 2. */
+int32_t lasso_sumcheck_linear_eqw_round(lasso_ctx* ctx, const lasso_fr* const* d_polys, uint32_t alpha, const lasso_fr* d_E, size_t n, lasso_fr* out);
+/* bind the alpha polynomials with the previous challenge r (in place, n = length before the bind, n >= 4), then the sums of the next round (length n/2) */
+int32_t lasso_sumcheck_linear_eqw_round_fused(lasso_ctx* ctx, lasso_fr* const* d_polys, uint32_t alpha, const lasso_fr* d_E, size_t n, const lasso_fr* r, lasso_fr* out);
 /* Subtables::compute_sumcheck_claim (src/subtables/mod.rs:187-216): out = sum_k eq[k] * g(E_1[k],...,E_alpha[k]) */
 int32_t lasso_combine_claim(lasso_ctx* ctx, const lasso_strategy* s, const lasso_fr* const* d_polys, const lasso_fr* d_eq, size_t n, lasso_fr* out);
 /* compute_dotproduct for k polynomials against one weight vector (src/utils/mod.rs:64-73 via DensePolynomial::evaluate

@@ -303,6 +303,44 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_eqw_small(MutPtrTable A, 
   row_done(gridDim.x, counters, flag, seq);
 }
 
+// ------------------------------------------------------------------ K3 in eq-weighted form for the linear strategies (AND / OR / XOR / RangeCheck)
+// prove_arbitrary's comb_func is g(E_1..E_alpha) * eq with g = sum_k w_k E_k LINEAR (and.rs:45-53, range_check.rs:78-86) and eq = EqPolynomial(r).evals()
+// (surge.rs:156-172).  With the eq polynomial factored as in the cubic rounds (prefix of the one table + host scalars) a round needs, per polynomial k,
+// only two dot products against the table prefix:  S0_k = sum_{i<half} E_k[i] eq[i],  S1_k = sum_{i<half} E_k[i+half] eq[i];  the host forms
+// G(x) = sum_k w_k (S0_k + x (S1_k - S0_k)) and e(x) = s_j * eq1(r_j, x) / prod_{t<=j}(1 - r_t) * G(x) at x = 0, 1, 2.  No weight products, no eq
+// binding, and the bind of the previous challenge rides in the same launch.  out[3k + {0,1}] = S0_k, S1_k (slot 2 unused).  Grid = cubic_grid(nx, alpha).
+__global__ void __launch_bounds__(LASSO_BLOCK) k_dot_eqw_lb(PtrTable polys, uint32_t nx, uint32_t ny, const fr_t* __restrict__ E, size_t half, fr_t* __restrict__ partials, uint32_t* counters,
+                                                             fr_t* __restrict__ out, uint32_t* flag, uint32_t seq) {
+  __shared__ RedScratch S;
+  const CubicGrid g = cubic_grid(nx, ny);
+  const fr_t* __restrict__ z = polys.p[g.by];
+  fr29 e[3] = {fr29_zero(), fr29_zero(), fr29_zero()}; uint32_t cnt = 0;
+  for (size_t i = g.bx * (size_t)blockDim.x + threadIdx.x; i < half; i += (size_t)nx * blockDim.x) {
+    const fr29 es = fr29_unpack_s(E[i]);
+    e[0] = fr29_weak(fr29_add(e[0], fr29_mul(fr29_unpack_u(z[i]), es)));
+    e[1] = fr29_weak(fr29_add(e[1], fr29_mul(fr29_unpack_u(z[i + half]), es)));
+    if ((++cnt & 127u) == 0) { e[0] = fr29_mul(e[0], fr29_one_s()); e[1] = fr29_mul(e[1], fr29_one_s()); }
+  }
+  cubic_epilogue(e, g, partials, counters, out, flag, seq, S, fr29_one_s());
+}
+__global__ void __launch_bounds__(LASSO_BLOCK) k_dot_eqw_fused(MutPtrTable polys, uint32_t nx, uint32_t ny, const fr_t* __restrict__ E, size_t q, fr_t r, fr_t* __restrict__ partials, uint32_t* counters,
+                                                                fr_t* __restrict__ out, uint32_t* flag, uint32_t seq) {
+  __shared__ RedScratch S;
+  const CubicGrid g = cubic_grid(nx, ny);
+  fr_t* __restrict__ z = polys.p[g.by];
+  const fr29 rs = fr29_unpack_s(r);
+  fr29 e[3] = {fr29_zero(), fr29_zero(), fr29_zero()}; uint32_t cnt = 0;
+  for (size_t i = g.bx * (size_t)blockDim.x + threadIdx.x; i < q; i += (size_t)nx * blockDim.x) {
+    const fr29 z0 = bind29(z[i], z[i + 2 * q], rs), z1 = bind29(z[i + q], z[i + 3 * q], rs);
+    z[i] = fr29_pack(z0); z[i + q] = fr29_pack(z1);
+    const fr29 es = fr29_unpack_s(E[i]);
+    e[0] = fr29_weak(fr29_add(e[0], fr29_mul(z0, es)));
+    e[1] = fr29_weak(fr29_add(e[1], fr29_mul(z1, es)));
+    if ((++cnt & 127u) == 0) { e[0] = fr29_mul(e[0], fr29_one_s()); e[1] = fr29_mul(e[1], fr29_one_s()); }
+  }
+  cubic_epilogue(e, g, partials, counters, out, flag, seq, S, fr29_one_s());
+}
+
 // ------------------------------------------------------------------ g = S::combine_lookups (subtables/*.rs)
 // AND/OR/XOR (and.rs:45-53) and RangeCheck (range_check.rs:78-86): g = sum_i 2^(i*inc) * vals[i] is LINEAR, so along the line
 // lo + x*(hi - lo) it is g(lo) + x*(g(hi) - g(lo)): two weighted sums per index, whatever the number of evaluation points.

@@ -103,6 +103,17 @@ class Device:
         self._chk(self.lib.lasso_sumcheck_cubic_round(self.ctx, self._ptrs(a_ptrs), self._ptrs(b_ptrs), len(a_ptrs), C.c_void_p(d_c), n, _vp(out)))
         return out
 
+    def sumcheck_linear_eqw_round(self, ptrs, d_e, n):
+        out = np.empty((3 * len(ptrs), 4), dtype=np.uint64)
+        self._chk(self.lib.lasso_sumcheck_linear_eqw_round(self.ctx, self._ptrs(ptrs), len(ptrs), C.c_void_p(d_e), n, _vp(out)))
+        return out.reshape(len(ptrs), 3, 4)[:, :2].copy()
+
+    def sumcheck_linear_eqw_round_fused(self, ptrs, d_e, n, r):
+        r = np.ascontiguousarray(r, dtype=np.uint64)
+        out = np.empty((3 * len(ptrs), 4), dtype=np.uint64)
+        self._chk(self.lib.lasso_sumcheck_linear_eqw_round_fused(self.ctx, self._ptrs(ptrs), len(ptrs), C.c_void_p(d_e), n, _vp(r), _vp(out)))
+        return out.reshape(len(ptrs), 3, 4)[:, :2].copy()
+
     def sumcheck_cubic_eqw_round(self, a_ptrs, b_ptrs, d_e, n):
         out = np.empty((3 * len(a_ptrs), 4), dtype=np.uint64)
         self._chk(self.lib.lasso_sumcheck_cubic_eqw_round(self.ctx, self._ptrs(a_ptrs), self._ptrs(b_ptrs), len(a_ptrs), C.c_void_p(d_e), n, _vp(out)))

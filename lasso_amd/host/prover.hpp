@@ -282,6 +282,8 @@ struct Strategy {
   size_t M() const { return (size_t)1 << abi.log_m; }
   size_t num_subtables() const { return abi.kind == LASSO_LT ? 2 : abi.kind == LASSO_RANGE ? 3 : 1; }
   size_t num_memories() const { return abi.kind == LASSO_LT ? 2 * C() : C(); }
+  bool linear() const { return abi.kind != LASSO_LT; }   // g = sum_k 2^(k*inc) E_k: and.rs:45-53, range_check.rs:78-86
+  ScVec weights() const { ScVec w; size_t inc = abi.kind == LASSO_RANGE ? abi.log_m : abi.log_m / 2; for (size_t i = 0; i < num_memories(); i++) { LASSO_REQUIRE(i * inc < 64); w.push_back(Sc::from_u64((uint64_t)1 << (i * inc))); } return w; }
   size_t sumcheck_poly_degree() const { return (abi.kind == LASSO_LT ? C() : 1) + 1; }
   size_t memory_to_subtable_index(size_t i) const {
     if (abi.kind == LASSO_RANGE) { size_t lm = abi.log_m; if (i * lm > abi.log_r) return 2; return ((i + 1) * lm > abi.log_r) ? 1 : 0; }  // range_check.rs:62-69
@@ -501,9 +503,63 @@ class Prover {
       proof.compressed_polys.push_back(up.compress());
     }
   }
-  // polys: local arrays of length len_loc (global length len_loc * P)
-  SumcheckProof prove_arbitrary(size_t num_rounds, size_t len_loc, std::vector<lasso_fr*>& polys, size_t combined_degree, ScVec& r_out) {
+  // The same sumcheck for the LINEAR strategies in eq-weighted form (lasso_sumcheck_linear_eqw_round): the eq polynomial is never bound (prefix of
+  // d_E + host scalars), a round is one launch (bind of the previous challenge + two dot products per polynomial), the weights 2^(k*inc) are applied
+  // here.  One phase = `rounds` rounds over point[v0 .. v0+rounds) on arrays of length len; polys = the alpha E clones only.
+  void linear_rounds(size_t rounds, size_t len, std::vector<lasso_fr*>& polys, const lasso_fr* d_E, const ScVec& point, size_t v0, bool reduce, Sc& s_run, SumcheckProof& proof, ScVec& r_out) {
+    if (!rounds) return;
+    const ScVec w = S.weights();
+    ScVec inv(rounds); bool degenerate = false;
+    {
+      Sc prod = Sc::one();
+      for (size_t j = 0; j < rounds; j++) { Sc om = Sc::one() - point[v0 + j]; if (om.is_zero()) degenerate = true; prod *= om; }
+      if (!degenerate) { Sc pi = prod.inverse(); for (size_t j = rounds; j-- > 0;) { inv[j] = pi; pi *= Sc::one() - point[v0 + j]; } }
+    }
+    DBuf tj; if (degenerate) tj = DBuf(d, len / 2);
+    Sc r_prev = Sc::zero();
+    for (size_t j = 0; j < rounds; j++) {
+      const lasso_fr* table = d_E; Sc scale = degenerate ? Sc::one() : inv[j];
+      if (degenerate) {
+        std::vector<lasso_fr> rr; for (size_t t2 = v0 + j + 1; t2 < v0 + rounds; t2++) rr.push_back(point[t2].abi());
+        lasso_fr sc = (reduce ? d.comm.eq_low(point) : Sc::one()).abi();
+        d.chk(lasso_eq_evals_scaled(d.ctx, rr.data(), (uint32_t)rr.size(), &sc, tj.p), "lasso_eq_evals_scaled");
+        table = tj.p;
+      }
+      std::vector<lasso_fr> ev(3 * alpha);
+      if (j == 0) d.chk(lasso_sumcheck_linear_eqw_round(d.ctx, (const lasso_fr* const*)polys.data(), (uint32_t)alpha, table, len, ev.data()), "lasso_sumcheck_linear_eqw_round");
+      else { lasso_fr rp = r_prev.abi(); d.chk(lasso_sumcheck_linear_eqw_round_fused(d.ctx, polys.data(), (uint32_t)alpha, table, len, &rp, ev.data()), "lasso_sumcheck_linear_eqw_round_fused"); len /= 2; }
+      if (reduce) d.comm.sum(ev);
+      Sc G0 = Sc::zero(), G1 = Sc::zero();
+      for (size_t k2 = 0; k2 < alpha; k2++) { G0 += w[k2] * Sc::from_abi(ev[3 * k2]); G1 += w[k2] * Sc::from_abi(ev[3 * k2 + 1]); }
+      const Sc& rj = point[v0 + j]; const Sc base = s_run * scale, om = Sc::one() - rj;
+      ScVec evals{base * om * G0, base * rj * G1, base * (rj + rj - om) * (G1 + G1 - G0)};   // x = 0, 1, 2: eq1(r_j, x) * G(x)
+      UniPoly up = UniPoly::from_evals(evals);
+      up.append_to_transcript(t, "poly");
+      Sc r_j = t.challenge_scalar("challenge_nextround"); r_out.push_back(r_j);
+      r_prev = r_j;
+      s_run *= om * (Sc::one() - r_j) + rj * r_j;
+      proof.compressed_polys.push_back(up.compress());
+    }
+    lasso_fr rp = r_prev.abi();   // the last challenge of the phase (len == 2 here)
+    d.chk(lasso_bind_top(d.ctx, polys.data(), (uint32_t)polys.size(), len, &rp), "lasso_bind_top");
+  }
+  // polys: local arrays of length len_loc (global length len_loc * P); polys[alpha] = the eq table of `point` (local share in slab mode)
+  SumcheckProof prove_arbitrary(size_t num_rounds, size_t len_loc, std::vector<lasso_fr*>& polys, size_t combined_degree, const ScVec& point, ScVec& r_out) {
     SumcheckProof proof;
+    if (S.linear()) {
+      std::vector<lasso_fr*> ep(polys.begin(), polys.begin() + alpha); Sc s_run = Sc::one();
+      if (P == 1) { linear_rounds(num_rounds, len_loc, ep, polys[alpha], point, 0, false, s_run, proof, r_out); return proof; }
+      LASSO_REQUIRE(num_rounds >= lgP && ((size_t)1 << (num_rounds - lgP)) == len_loc);
+      const size_t local_rounds = num_rounds - lgP;
+      linear_rounds(local_rounds, len_loc, ep, polys[alpha], point, 0, true, s_run, proof, r_out);
+      std::vector<lasso_fr*> tail = gather_tail(ep);
+      tail_bufs.emplace_back(d, P);
+      std::vector<lasso_fr> rr; for (size_t i = local_rounds; i < num_rounds; i++) rr.push_back(point[i].abi());
+      d.chk(lasso_eq_evals(d.ctx, rr.data(), (uint32_t)rr.size(), tail_bufs.back().p), "lasso_eq_evals");
+      linear_rounds(lgP, P, tail, tail_bufs.back().p, point, local_rounds, false, s_run, proof, r_out);
+      tail_bufs.clear();
+      return proof;
+    }
     if (P == 1) { arbitrary_rounds(num_rounds, len_loc, polys, combined_degree, false, proof, r_out); return proof; }
     LASSO_REQUIRE(num_rounds >= lgP && ((size_t)1 << (num_rounds - lgP)) == len_loc);
     arbitrary_rounds(num_rounds - lgP, len_loc, polys, combined_degree, true, proof, r_out);
@@ -799,7 +855,7 @@ class Prover {
       DBuf work(d, alpha * s_loc);
       d.chk(lasso_copy(d.ctx, work.p, combined_E.p, alpha * s_loc * sizeof(lasso_fr)), "lasso_copy");
       std::vector<lasso_fr*> polys; for (size_t i = 0; i < alpha; i++) polys.push_back(work.p + i * s_loc); polys.push_back(eq.p);
-      SumcheckProof sp = prove_arbitrary(ceil_log2(s), s_loc, polys, S.sumcheck_poly_degree(), r_z);
+      SumcheckProof sp = prove_arbitrary(ceil_log2(s), s_loc, polys, S.sumcheck_poly_degree(), r, r_z);
       sp.write(W);
     }
     W.sc(claimed_eval);

@@ -471,3 +471,29 @@ def test_msm_dev_scaled(devs, gens_300, n):
         return out
     a, b = both(devs, run)
     assert compress_points(devs[1].lib, a) == compress_points(devs[1].lib, b)
+
+
+@pytest.mark.parametrize("n,alpha", [(2, 1), (4, 3), (64, 8), (1 << 10, 2), (1 << 14, 16), (1 << 17, 1)])
+def test_sumcheck_linear_eqw_rounds(devs, n, alpha):
+    """eq-weighted primary-sumcheck rounds for linear strategies: two dot products per polynomial against the table prefix; fused = bind_top + plain"""
+    rng = np.random.default_rng(n * 7 + alpha)
+    Ps = [rand_fr(rng, n) for _ in range(alpha)]; E = rand_fr(rng, n // 2)
+    r = rand_fr(rng, 1, edge=False)[0]
+
+    def run(d):
+        pp = [d.upload(x) for x in Ps]; pe = d.upload(E)
+        first = d.sumcheck_linear_eqw_round(pp, pe, n)
+        res = [first]
+        if n >= 4:
+            fused = d.sumcheck_linear_eqw_round_fused(pp, pe, n, r)
+            again = d.sumcheck_linear_eqw_round(pp, pe, n // 2)
+            res += [fused, again, [d.download(p, (n // 2, 4)) for p in pp]]
+        for p in pp + [pe]:
+            d.free(p)
+        return res
+    a, b = both(devs, run)
+    assert np.array_equal(a[0], b[0])
+    if n >= 4:
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[1], a[2])
+        for x, y in zip(a[3], b[3]):
+            assert np.array_equal(x, y)
