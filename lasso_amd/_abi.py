@@ -14,7 +14,7 @@ class Strategy(C.Structure):
 
 KINDS = {"and": 0, "or": 1, "xor": 2, "lt": 3, "range": 4}
 K_BIND, K_CUBIC, K_COMBINE, K_EQ, K_GP, K_FINGERPRINT, K_DOT, K_MATVEC, K_MSM, K_MISC, K_COUNT = range(11)
-KERNEL_NAMES = ["bind_top", "sumcheck_cubic_round(+fused bind)", "sumcheck_combine", "eq_evals", "gp_build", "fingerprint", "multi_dot", "matvec_left", "msm", "misc"]
+KERNEL_NAMES = ["bind_top(+fused linear round)", "sumcheck_cubic_round(+fused bind)", "sumcheck_combine", "eq_evals", "gp_build", "fingerprint", "multi_dot", "matvec_left", "msm", "misc"]
 
 
 def declare(lib):

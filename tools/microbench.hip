@@ -66,6 +66,12 @@ __global__ void k_tp_frmul(fr_t* io, int iters) {
   fr_t r = fr_add(fr_add(a, b), fr_add(c, d));
   if (r.v[0] == 0x12345678u && r.v[1] == 0x9abcdef0u) io[blockIdx.x] = r;
 }
+__global__ void k_tp_fr29mul(fr_t* io, int iters) {
+  fr29 a = fr29_unpack_u(io[threadIdx.x & 63]), b = fr29_unpack_s(io[64 + (threadIdx.x & 63)]), c = fr29_weak(fr29_add(a, b)), d = fr29_weak(fr29_sub(a, b));
+  for (int i = 0; i < iters; i++) { a = fr29_mul(a, b); b = fr29_mul(b, c); c = fr29_mul(c, d); d = fr29_mul(d, a); }
+  fr_t r = fr29_store(fr29_mul(fr29_add(fr29_add(a, b), fr29_add(c, d)), fr29_one_s()));
+  if (r.v[0] == 0x12345678u && r.v[1] == 0x9abcdef0u) io[blockIdx.x] = r;
+}
 __global__ void k_tp_fqmul(fq_t* io, int iters) {
   fq_t a = io[threadIdx.x & 63], b = io[64 + (threadIdx.x & 63)], c = fq_add(a, b), d = fq_sub(a, b);
   for (int i = 0; i < iters; i++) { a = fq_mul(a, b); b = fq_mul(b, c); c = fq_mul(c, d); d = fq_mul(d, a); }
@@ -147,6 +153,8 @@ int main(int argc, char** argv) {
       const int blocks = CU * wpb * 4 / 4, threads = 256, iters = 256;
       double ms = time_kernel([&] { hipLaunchKernelGGL(k_tp_frmul, dim3(blocks), dim3(threads), 0, 0, d, iters); });
       printf("  fr_mul (Montgomery 8x32 CIOS)   blocks/CU=%d: %8.3f ms  %7.1f G/s\n", wpb, ms, (double)blocks * threads * iters * 4 / (ms * 1e-3) * 1e-9);
+      ms = time_kernel([&] { hipLaunchKernelGGL(k_tp_fr29mul, dim3(blocks), dim3(threads), 0, 0, d, iters); });
+      printf("  fr29_mul (Montgomery 9x29, radix 2^261) blocks/CU=%d: %8.3f ms  %7.1f G/s\n", wpb, ms, (double)blocks * threads * iters * 4 / (ms * 1e-3) * 1e-9);
       ms = time_kernel([&] { hipLaunchKernelGGL(k_tp_fqmul, dim3(blocks), dim3(threads), 0, 0, (fq_t*)d, iters); });
       printf("  fq_mul (2^255-19 fold)          blocks/CU=%d: %8.3f ms  %7.1f G/s\n", wpb, ms, (double)blocks * threads * iters * 4 / (ms * 1e-3) * 1e-9);
     }
@@ -179,16 +187,17 @@ int main(int argc, char** argv) {
       double t3 = n * 48.0 / (ms * 1e-3) * 1e-9;
       printf("  n=2^%d grid=%5zu: traffic-only %7.1f GB/s | bind_top %7.1f GB/s (%.3f ms) | bind_pairs %7.1f GB/s\n", logn, g, t1, t2, n * 48.0 / t2 * 1e-6, t3);
     }
-    // cubic round with 2 circuits
+    // fused bind + eq-weighted cubic round with 2 circuits (the dominant streaming kernel of a proof)
     if (logn <= 24) {
-      fr_t *a0, *b0, *a1, *b1, *part; CK(hipMalloc(&a0, n * 32)); CK(hipMalloc(&b0, n * 32)); CK(hipMalloc(&a1, n * 32)); CK(hipMalloc(&b1, n * 32)); CK(hipMalloc(&part, 4096 * 6 * 32));
+      fr_t *a0, *b0, *a1, *b1, *part, *small; uint32_t* counters;
+      CK(hipMalloc(&a0, n * 32)); CK(hipMalloc(&b0, n * 32)); CK(hipMalloc(&a1, n * 32)); CK(hipMalloc(&b1, n * 32)); CK(hipMalloc(&part, 4096 * 6 * 32)); CK(hipMalloc(&small, 4096)); CK(hipMalloc(&counters, 4096)); CK(hipMemset(counters, 0, 4096));
       CK(hipMemset(a0, 0x07, n * 32)); CK(hipMemset(b0, 0x05, n * 32)); CK(hipMemset(a1, 0x03, n * 32)); CK(hipMemset(b1, 0x02, n * 32));
-      PtrTable A, B; A.p[0] = a0; A.p[1] = a1; B.p[0] = b0; B.p[1] = b1;
-      for (int nx : {512, 2048}) {
-        ms = time_kernel([&] { hipLaunchKernelGGL(k_cubic_round, dim3(nx, 2), dim3(256), 0, 0, A, B, (const fr_t*)z, half, part); });
-        printf("  n=2^%d cubic round k=2 nx=%d: %7.3f ms  alg %7.1f GB/s  (%.1f G montmul/s)\n", logn, nx, ms, n * 32.0 * 5 / (ms * 1e-3) * 1e-9, half * 2 * 6.0 / (ms * 1e-3) * 1e-9);
+      MutPtrTable A, B; A.p[0] = a0; A.p[1] = a1; B.p[0] = b0; B.p[1] = b1;
+      for (unsigned nx : {128u, 256u, 512u}) {
+        ms = time_kernel([&] { hipLaunchKernelGGL(k_cubic_eqw_fused, dim3(nx * 2), dim3(256), 0, 0, A, B, nx, 2u, (const fr_t*)z, n / 4, r, part, counters, small, (uint32_t*)nullptr, 0u); });
+        printf("  n=2^%d fused bind + eq-weighted cubic round, k=2, nx=%u: %7.3f ms  alg (48 n (2k+1)) %7.1f GB/s  (%.1f G montmul/s)\n", logn, nx, ms, n * 48.0 * 5 / (ms * 1e-3) * 1e-9, (n / 4) * 2 * 9.0 / (ms * 1e-3) * 1e-9);
       }
-      CK(hipFree(a0)); CK(hipFree(b0)); CK(hipFree(a1)); CK(hipFree(b1)); CK(hipFree(part));
+      CK(hipFree(a0)); CK(hipFree(b0)); CK(hipFree(a1)); CK(hipFree(b1)); CK(hipFree(part)); CK(hipFree(small)); CK(hipFree(counters));
     }
     CK(hipFree(z)); CK(hipFree(dst));
   }

@@ -11,9 +11,9 @@ import sys
 from collections import defaultdict
 
 FAMILIES = {   # bench.py family name -> kernel-name prefixes
-    "bind_top": ("k_bind_top",),
+    "bind_top(+fused linear round)": ("k_dot_eqw_fused", "k_bind_top"),
     "sumcheck_cubic_round(+fused bind)": ("k_cubic_eqw_fused", "k_cubic_eqw_lb", "k_cubic_round_lb"),
-    "sumcheck_combine": ("k_combine_round_linear", "void k_combine_claim"),
+    "sumcheck_combine": ("k_dot_eqw_lb", "k_combine_round_linear", "void k_combine_claim"),
     "multi_dot": ("k_multi_dot",),
     "matvec_left": ("k_matvec_left",),
     "fingerprint": ("k_fingerprint_ops",),
