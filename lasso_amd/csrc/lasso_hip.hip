@@ -383,7 +383,7 @@ int32_t lasso_multi_dot(lasso_ctx* c, const lasso_fr* const* d_polys, uint32_t k
   rc = ensure_small(c, k); if (rc) return rc;
   {
     ProfScope ps(c, LASSO_K_DOT, 32.0 * n * (k + 1.0));
-    hipLaunchKernelGGL(k_multi_dot, dim3(nx, k), dim3(LASSO_BLOCK), 0, c->stream, P, (const fr_t*)d_w, n, (fr_t*)c->d_scratch);
+    hipLaunchKernelGGL(k_multi_dot, dim3(nx * k), dim3(LASSO_BLOCK), 0, c->stream, P, nx, k, (const fr_t*)d_w, n, (fr_t*)c->d_scratch);
     hipLaunchKernelGGL(k_reduce_partials, dim3(k), dim3(LASSO_BLOCK), 0, c->stream, (const fr_t*)c->d_scratch, nx, 1u, c->d_small);
   }
   HIPCHK(c, hipGetLastError());
