@@ -37,7 +37,7 @@ def parse():
     p.add_argument("--kind", default="and", choices=["and", "or", "xor", "lt", "range"])
     p.add_argument("--log-m", type=int, default=16)
     p.add_argument("--log-r", type=int, default=40)
-    p.add_argument("--cpu-log-s", type=int, default=20, help="log2 lookups of the bounded CPU-baseline sample (2^20: ~12 s of one host core)")
+    p.add_argument("--cpu-log-s", type=int, default=22, help="log2 lookups of the bounded CPU-baseline sample (2^22: ~20 s of one host core)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-prof", action="store_true")
     p.add_argument("--shard-proof", action="store_true", help="N > 1: ONE proof of s lookups sharded over the N GPUs by low index bits (slab mode, strong scaling) "
