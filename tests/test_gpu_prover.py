@@ -12,6 +12,7 @@ pytestmark = pytest.mark.gpu
 
 CASES = [("lt", 4, 4, 0, 16), ("lt", 4, 4, 0, 128), ("and", 4, 4, 0, 16), ("range", 3, 8, 40, 16),   # e2e_test.rs:64-99
          ("and", 1, 4, 0, 2), ("xor", 3, 4, 0, 11), ("or", 2, 4, 0, 8), ("and", 1, 16, 0, 1 << 10),   # BASELINE config 1 shape
+         ("and", 1, 2, 0, 3), ("or", 1, 6, 0, 7), ("lt", 1, 4, 0, 4), ("range", 2, 4, 6, 9), ("and", 3, 2, 0, 4),
          ("and", 4, 16, 0, 1 << 12), ("xor", 8, 8, 0, 1 << 10), ("range", 4, 16, 40, 1 << 10), ("lt", 2, 8, 0, 1 << 9), ("and", 1, 16, 0, 1 << 14)]
 
 
