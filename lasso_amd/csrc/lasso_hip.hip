@@ -577,7 +577,9 @@ static int32_t hyrax_commit_impl(lasso_ctx* c, const lasso_fr* d_Z, size_t l_siz
   REQUIRE(c, d_Z && b && l_size >= 1 && r_size >= 1 && r_size <= b->n && l_size < ((size_t)1 << 31));
   const size_t n = l_size * r_size;
   const size_t pts_bytes = (l_size * msm_chunks(l_size, r_size, MSM_WINDOWS) + 2 * l_size) * sizeof(pt29) + 512;   // chunk partials + row sums (pt29 or ed_point) + wire bytes
-  int32_t rc = ensure_scratch(c, n * 32 + pts_bytes); if (rc) return rc;
+  // small-scalar regime first (4 bytes per scalar); the 32-byte form is only allocated if some scalar needs it — a 2^25-element polynomial of
+  // table indices / timestamps then needs 128 MiB of scratch instead of 1 GiB (and no hipMalloc at all after densify)
+  int32_t rc = ensure_scratch(c, n * 4 + 256 + pts_bytes); if (rc) return rc;
   uint8_t* d_scal = (uint8_t*)c->d_scratch;
   HIPCHK(c, hipMemsetAsync(c->d_flags, 0, 8, c->stream));
   {
@@ -592,6 +594,8 @@ static int32_t hyrax_commit_impl(lasso_ctx* c, const lasso_fr* d_Z, size_t l_siz
     uint32_t W = (bits + 3) / 4; if (W == 0) W = 1;   // 4-bit windows actually populated
     return run_msm(c, d_scal, 4, W, r_size * 4, l_size, r_size, b, d_scal + ((n * 4 + 255) & ~(size_t)255), out, out_compressed);
   }
+  rc = ensure_scratch(c, n * 32 + pts_bytes); if (rc) return rc;
+  d_scal = (uint8_t*)c->d_scratch;
   hipLaunchKernelGGL(k_fr_to_canonical, dim3(grid_for(n, 4096)), dim3(256), 0, c->stream, (const fr_t*)d_Z, n, (fr_t*)d_scal);
   return run_msm(c, d_scal, 32, MSM_WINDOWS, r_size * 32, l_size, r_size, b, d_scal + n * 32, out, out_compressed);
 }
