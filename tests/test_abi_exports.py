@@ -23,6 +23,17 @@ def test_device_library_exports_every_symbol():
     assert declared == header_functions("lasso_hip.h")
 
 
+def test_prover_library_exports_every_symbol():
+    """include/lasso_prover.h (the host prover's C ABI): every declared function is exported by liblasso_prover.so"""
+    import __graft_entry__ as g
+    g.build()
+    lib = ctypes.CDLL(os.path.join(ROOT, "lasso_amd", "liblasso_prover.so"))
+    names = [n for n in header_functions("lasso_prover.h") if n.startswith("lasso_host_")]
+    assert len(names) >= 12
+    for n in names:
+        getattr(lib, n)          # AttributeError = declared but not exported
+
+
 def test_mock_exports_same_abi():
     from gpuutil import load_mock
     load_mock()
