@@ -40,6 +40,8 @@ def parse():
     p.add_argument("--cpu-log-s", type=int, default=22, help="log2 lookups of the bounded CPU-baseline sample (2^22: ~20 s of one host core)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-prof", action="store_true")
+    p.add_argument("--concurrent", type=int, default=4, help="extra leg at N=1: this many independent proofs proved concurrently on the one GPU (own context, stream and host "
+                                                              "thread each); reported beside the headline, never as `value`.  0 = skip")
     p.add_argument("--shard-proof", action="store_true", help="N > 1: ONE proof of s lookups sharded over the N GPUs by low index bits (slab mode, strong scaling) "
                                                                 "instead of one independent proof per GPU (the default, weak scaling)")
     return p.parse_args()
@@ -67,6 +69,40 @@ def pmc_traffic():
             return json.load(f)
     except Exception:
         return {}
+
+
+def concurrent_leg(HostProver, _abi, streams, steps, S, c, log_m, log_s):
+    """T independent proofs at a time on one GPU.  One proof is latency-bound by its ~470 sequential transcript rounds (the device idles ~25% of the time
+    at 2^24 lookups); independent proofs on their own streams fill the gaps.  Serving-style throughput, reported separately from the one-proof-at-a-time metric."""
+    import threading
+    s = 1 << log_s
+    alpha = 2 * c if S.kind == _abi.KINDS["lt"] else c
+    workers = []
+    for t in range(streams):
+        hp = HostProver()
+        idx = (hp.gen_indices(s, 1 << log_m, c) + t) % (1 << log_m)
+        r = hp.gen_random_point(log_s)
+        gens = hp.gens(c, s, alpha, log_m); dense = hp.densify(idx, log_m)
+        hp.prove(dense, gens, S, r)      # warm-up
+        workers.append((hp, dense, gens, r))
+    bar = threading.Barrier(streams + 1)
+
+    def run(w):
+        hp, dense, gens, r = w
+        bar.wait()
+        for _ in range(steps):
+            hp.prove(dense, gens, S, r)
+        bar.wait()
+    ths = [threading.Thread(target=run, args=(w,)) for w in workers]
+    for th in ths:
+        th.start()
+    bar.wait(); t0 = time.perf_counter(); bar.wait(); el = time.perf_counter() - t0
+    for th in ths:
+        th.join()
+    for hp, dense, gens, r in workers:
+        hp.free(dense, gens); hp.close()
+    return {"streams": streams, "proofs": streams * steps, "value": streams * steps * s / el, "unit": "lookups/s", "ms_per_round_of_proofs": el / steps * 1e3,
+            "note": "independent proofs proved concurrently on one GPU (one context, stream and host thread each); not the headline metric"}
 
 
 def main():
@@ -172,6 +208,8 @@ def main():
             if dom:
                 out["roofline"] = roof(_abi.KERNEL_NAMES.index(dom["kernel"]))
             out["roofline_bind_top"] = roof(_abi.K_BIND)                                        # the kernel BASELINE.json's north_star names (bound_poly_var)
+        if world == 1 and a.concurrent > 1 and a.concurrent * s * alpha * 450 < 150e9:   # ~400 bytes of HBM per lookup and memory per resident proof
+            out["concurrent_proofs"] = concurrent_leg(HostProver, _abi, a.concurrent, max(2, a.steps), S, c, log_m, a.log_s)
         if world == 1 and not a.no_cpu_baseline:
             cb = cpu_baseline(kind_id, c, log_m, S.log_r, min(a.cpu_log_s, a.log_s))
             if cb:
