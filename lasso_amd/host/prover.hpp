@@ -752,7 +752,6 @@ class Prover {
       d.chk(lasso_bullet_fold(d.ctx, a_cur, b_cur, 2, w_cur, nw / 2, w_nxt, &ua, &uia), "lasso_bullet_fold");
       std::swap(w_cur, w_nxt);
     }
-    DBuf& d_a = d_a0; DBuf& d_b = d_b0; (void)d_a; (void)d_b;
     lasso_fr heads[2]; const lasso_fr* hp[2] = {a_cur, b_cur};
     d.chk(lasso_read_heads(d.ctx, hp, 2, heads), "lasso_read_heads");
     Sc x_hat = Sc::from_abi(heads[0]), a_hat = Sc::from_abi(heads[1]), y_hat = x_hat * a_hat;
