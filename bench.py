@@ -25,6 +25,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec peak
+# the only published number for this exact metric — 2^24 AND lookups, C=1, `SparsePoly.prove` span, rayon on an Apple M1 16 GB:
+# 35.3 s (src/benches/m1_16gb_parallel_benches.log:439) = 2^24 / 35.3 lookups/s.  Other hardware: a reference point, not a like-for-like comparison.
+PUBLISHED_LOOKUPS_PER_S = (1 << 24) / 35.3
 
 
 def parse():
@@ -179,9 +182,11 @@ def main():
         value = (1 if slab else world) * s * a.steps / elapsed
         out = {"metric": "prover lookups/sec for SparsePolynomialEvaluationProof, 2^24 AND lookups" if (a.kind, a.log_s, c) == ("and", 24, 1) else f"prover lookups/sec for SparsePolynomialEvaluationProof, 2^{a.log_s} {a.kind.upper()} lookups",
                "value": value, "unit": "lookups/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
-               "higher_is_better": True, "scaling": "strong" if slab else "weak", "vs_baseline": None, "dtype": "u256 (Montgomery Fr / ed25519 Fq integers)", "data": "synthetic",
+               "higher_is_better": True, "scaling": "strong" if slab else "weak",
+               "vs_baseline": (value / PUBLISHED_LOOKUPS_PER_S) if (a.kind, a.log_s, c, world) == ("and", 24, 1, 1) else None, "dtype": "u256 (Montgomery Fr / ed25519 Fq integers)", "data": "synthetic",
                "config": {"workload": f"{a.kind.upper()} subtable, C={c}, M=2^{log_m}, s=2^{a.log_s} lookups per proof, G=curve25519 (ark_curve25519), harness inputs of src/benches/bench.rs; "
                                       f"timed = SparsePolynomialEvaluationProof::prove with the densified representation resident in HBM",
+                          "vs_baseline_reference": "2^24 AND lookups, C=1, SparsePoly.prove 35.3 s with rayon on an Apple M1 16 GB (reference's src/benches/m1_16gb_parallel_benches.log:439; BASELINE.md §1)",
                           "per_rank": ("one proof sharded over the ranks by low index bits (slab mode)" if slab else "one independent proof per rank") if world > 1 else "single proof",
                           "proof_bytes": len(proof), "distinct_proofs": len(set(digests)), "densify_s": round(t_densify, 3), "commit_s": round(t_commit, 3), "commit_warm_s": round(t_commit_warm, 3), "gens_setup_s": round(t_setup, 3),
                           "whole_bench_lookups_per_s": s / (t_densify + t_commit + ms_per_step / 1e3)}}
