@@ -236,9 +236,10 @@ int32_t lasso_bind_top(lasso_ctx* c, lasso_fr* const* d_polys, uint32_t npolys, 
   hipLaunchKernelGGL(k_bind_top, dim3(grid_for(half, 4096), npolys), dim3(LASSO_BLOCK), 0, c->stream, T, half, to_fr(r));
   HIPCHK(c, hipGetLastError()); return 0;
 }
-// x-extent of the cubic-round grids: ~1024 workgroups over the whole grid (profiles/r01_microbench_v2.txt: 512 x 2 beats 256 x 2 by 6% and 128 x 2 by 40% at n = 2^24; the kernels are VALU-bound
+// x-extent of the cubic-round grids: ~512 workgroups over the whole grid.  Inside a proof (random data, tools/gpu_sweep_roofline.sh) 512 total beats 1024 by 3-10% and 256 by 10%
+// for both the cubic (ny = 2) and the linear (ny = 1) rounds, although in isolation on constant data 1024 is 6% faster (profiles/r01_microbench_v2.txt); the kernels are VALU-bound
 // and every extra workgroup adds a reduction epilogue), LASSO_CUBIC_NX overrides for experiments
-static unsigned cubic_nx_cap(unsigned ny) { static const long e = [] { const char* v = getenv("LASSO_CUBIC_NX"); return v ? atol(v) : 0L; }(); if (e > 0) return (unsigned)e; unsigned c = 1024 / (ny ? ny : 1); return c < 64 ? 64 : c; }
+static unsigned cubic_nx_cap(unsigned ny) { static const long e = [] { const char* v = getenv("LASSO_CUBIC_NX"); return v ? atol(v) : 0L; }(); if (e > 0) return (unsigned)e; unsigned c = 512 / (ny ? ny : 1); return c < 64 ? 64 : c; }
 #define CUBIC_SMALL_Q 64   // rounds with at most this many indices per circuit take the latency-shaped kernel
 // the reference's loop with an explicit third polynomial (any C): kept as the literal counterpart of sumcheck.rs:49-93
 int32_t lasso_sumcheck_cubic_round(lasso_ctx* c, const lasso_fr* const* d_A, const lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_C, size_t n, lasso_fr* out) {
