@@ -45,6 +45,8 @@ def parse():
     p.add_argument("--no-prof", action="store_true")
     p.add_argument("--concurrent", type=int, default=4, help="extra leg at N=1: this many independent proofs proved concurrently on the one GPU (own context, stream and host "
                                                               "thread each); reported beside the headline, never as `value`.  0 = skip")
+    p.add_argument("--backend", default=None, choices=["nccl", "gloo"], help="torch.distributed backend for N > 1 (default: nccl = RCCL when a GPU is visible).  gloo lets the N > 1 "
+                                                                              "code path be exercised on a box with fewer GPUs than ranks (ranks share devices)")
     p.add_argument("--shard-proof", action="store_true", help="N > 1: ONE proof of s lookups sharded over the N GPUs by low index bits (slab mode, strong scaling) "
                                                                 "instead of one independent proof per GPU (the default, weak scaling)")
     return p.parse_args()
@@ -112,7 +114,7 @@ def main():
     a = parse()
     from lasso_amd import HostProver, _abi
     from lasso_amd.parallel import Group, shard_indices
-    grp = Group()                      # torch.distributed (nccl = RCCL) only when WORLD_SIZE > 1
+    grp = Group(backend=a.backend)     # torch.distributed (nccl = RCCL) only when WORLD_SIZE > 1
     rank, world = grp.rank, grp.world
     hp = HostProver(device=grp.device_index)
     slab = a.shard_proof and world > 1

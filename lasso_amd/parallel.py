@@ -26,7 +26,17 @@ class Group:
 
     @property
     def device_index(self):
-        return self.local_rank if self.world > 1 else 0
+        """One GPU per rank; with the gloo backend on a box with fewer GPUs than ranks (tests), ranks share devices."""
+        if self.world == 1:
+            return 0
+        if self.backend == "gloo":
+            try:
+                import torch
+                n = torch.cuda.device_count()
+                return self.local_rank % n if n else 0
+            except Exception:
+                return 0
+        return self.local_rank
 
     def _tensor(self, values, dtype):
         dev = "cuda" if self.backend == "nccl" else "cpu"
