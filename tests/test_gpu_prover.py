@@ -80,7 +80,7 @@ def test_gpu_proof_verifies_at_scale(host, oracle, kind, c, log_m, log_r, log_s)
 # reach these sizes in seconds, so parity rests on the size-independent property the reference itself uses as its acceptance test
 # (src/e2e_test.rs:54-59): prove -> verify, here through the oracle's verifier (a restatement of surge.rs:214-271) fed the GPU's commitment,
 # plus rejection of a tampered proof and determinism of the proof bytes.
-FULL = [("and", 4, 16, 0, 20), ("and", 1, 16, 0, 24), ("xor", 8, 16, 0, 24), ("range", 4, 16, 40, 26)]   # configs[1], the metric, configs[2], configs[3] (on one GPU: ~75 GiB)
+FULL = [("and", 4, 16, 0, 20), ("and", 1, 16, 0, 24), ("xor", 8, 16, 0, 24), ("range", 4, 16, 40, 26), ("and", 1, 16, 0, 28)]   # configs[1], the metric, configs[2], configs[3] (on one GPU: ~75 GiB), and the largest lookup count of BASELINE.json (2^28, ~75 GiB) with the AND table
 
 
 @pytest.mark.parametrize("kind,c,log_m,log_r,log_s", FULL)
