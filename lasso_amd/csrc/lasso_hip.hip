@@ -50,7 +50,7 @@ struct lasso_ctx {
   // the same, restricted to launches whose algorithmic bytes exceed LASSO_PROF_LARGE_BYTES (past the 256 MiB Infinity Cache: the HBM-bound regime)
   uint64_t big_launches[LASSO_K_COUNT] = {0}; double big_ms[LASSO_K_COUNT] = {0}; double big_bytes[LASSO_K_COUNT] = {0};
 };
-struct lasso_bases { size_t n = 0; niels29* d_table = nullptr; };
+struct lasso_bases { size_t n = 0; niels29* d_table = nullptr; niels29* d_mult = nullptr; };   // d_mult: signed digit multiples for the latency-shaped MSM (k_msm_direct), optional
 
 static thread_local std::string g_create_err;
 
@@ -150,7 +150,7 @@ int32_t lasso_ctx_create(int32_t device, lasso_ctx** out) {
     std::string m = hipGetErrorString(e); delete c; return fail(nullptr, LASSO_ERR_HIP, m);
   }
   if (hipMalloc((void**)&c->d_flags, 64) != hipSuccess) { delete c; return fail(nullptr, LASSO_ERR_OOM, "flags alloc"); }
-  if (hipMalloc((void**)&c->d_counters, (LASSO_MAX_PTRS + 8) * 4) != hipSuccess || hipMemset(c->d_counters, 0, (LASSO_MAX_PTRS + 8) * 4) != hipSuccess) { delete c; return fail(nullptr, LASSO_ERR_OOM, "counters alloc"); }
+  if (hipMalloc((void**)&c->d_counters, (LASSO_MAX_PTRS + 40) * 4) != hipSuccess || hipMemset(c->d_counters, 0, (LASSO_MAX_PTRS + 40) * 4) != hipSuccess) { delete c; return fail(nullptr, LASSO_ERR_OOM, "counters alloc"); }
   if (hipHostMalloc((void**)&c->h_flag, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess || hipHostGetDevicePointer((void**)&c->d_flag, c->h_flag, 0) != hipSuccess) { delete c; return fail(nullptr, LASSO_ERR_OOM, "mapped flag alloc"); }
   *c->h_flag = 0;
   int32_t rc = ensure_small(c, 4096); if (rc) { g_create_err = c->err; delete c; return rc; }
@@ -528,9 +528,19 @@ int32_t lasso_bases_create(lasso_ctx* c, const lasso_affine* points, size_t n, l
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
   (void)hipFree(d_aff);
   if (e != hipSuccess) { (void)hipFree(b->d_table); delete b; return fail(c, LASSO_ERR_HIP, hipGetErrorString(e)); }
+  // digit multiples for the few-row full-width MSMs of the opening tail: 8 x the window table (57 KB per generator).  Optional: if the
+  // allocation fails or the generator set is larger than LASSO_MSM_DIRECT_MAX_N the bucket kernel serves those MSMs too.
+  static const size_t direct_max = [] { const char* v = getenv("LASSO_MSM_DIRECT_MAX_N"); return v ? (size_t)atoll(v) : (((size_t)1 << 17) + 64); }();
+  if (n <= direct_max) {
+    if (hipMalloc((void**)&b->d_mult, n * MSM_WINDOWS * MSM_MULTS * sizeof(niels29)) == hipSuccess) {
+      hipLaunchKernelGGL(k_precompute_multiples, dim3((unsigned)((n * MSM_WINDOWS + 63) / 64)), dim3(64), 0, c->stream, (const niels29*)b->d_table, n, b->d_mult);
+      e = hipGetLastError(); if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+      if (e != hipSuccess) { (void)hipFree(b->d_mult); (void)hipFree(b->d_table); delete b; return fail(c, LASSO_ERR_HIP, hipGetErrorString(e)); }
+    } else { (void)hipGetLastError(); b->d_mult = nullptr; }
+  }
   *out = b; return 0;
 }
-void lasso_bases_destroy(lasso_ctx* c, lasso_bases* b) { if (!b) return; if (c) (void)hipStreamSynchronize(c->stream); if (b->d_table) (void)hipFree(b->d_table); delete b; }
+void lasso_bases_destroy(lasso_ctx* c, lasso_bases* b) { if (!b) return; if (c) (void)hipStreamSynchronize(c->stream); if (b->d_table) (void)hipFree(b->d_table); if (b->d_mult) (void)hipFree(b->d_mult); delete b; }
 
 // chunks per row.  Measured on MI355X (profiles/): the bucket kernel is VALU-issue-bound even at one wave per SIMD (the 81 independent
 // multiply-adds of a field product pipeline back to back), so extra workgroups beyond one per CU only multiply the fixed per-workgroup
@@ -541,10 +551,39 @@ static size_t msm_chunks(size_t rows, size_t n_cols, uint32_t W) {
   size_t cols_per_chunk = (n_cols + K - 1) / K;
   return (n_cols + cols_per_chunk - 1) / cols_per_chunk;
 }
-#define MSM_SMALL_ROWS 16   // results of up to this many rows return through the mapped buffer + flag (no memcpy, no stream sync)
 // shared tail: bucket kernel over `rows` rows of `n_cols` scalars, then per-row sum of the chunk partials, then hand the points to the host
+#define MSM_SMALL_ROWS 16   // results of up to this many rows return through the mapped buffer + flag (no memcpy, no stream sync)
+// latency-shaped path (k_msm_direct): rows <= MSM_SMALL_ROWS of full-width canonical scalars, results through the mapped buffer + flag.
+// Chunking: one workgroup per CU over all rows, whole multiples of 256 items per workgroup (every thread the same number of mixed adds),
+// at most 8192 items (128 columns of LDS-staged scalars).  Scratch after the scalars: rows * K partial points.
+static bool msm_direct_enabled() { static const bool on = [] { const char* v = getenv("LASSO_MSM_DIRECT"); return !(v && v[0] == '0'); }(); return on; }
+static size_t msm_direct_chunks(size_t rows, size_t n_cols, uint32_t* items_per_chunk) {
+  const size_t total = n_cols * MSM_WINDOWS;
+  size_t K = 256 / rows; if (K < 1) K = 1;
+  size_t ipc = ((total + K - 1) / K + 255) / 256 * 256;
+  if (ipc > 8192) ipc = 8192;
+  *items_per_chunk = (uint32_t)ipc;
+  return (total + ipc - 1) / ipc;
+}
+// bytes of point scratch an MSM of `rows` x `n_cols` may need after its scalars (whichever kernel serves it)
+static size_t msm_pts_bytes(size_t rows, size_t n_cols) {
+  uint32_t ipc; const size_t kd = rows <= MSM_SMALL_ROWS ? msm_direct_chunks(rows, n_cols, &ipc) : 0, kb = msm_chunks(rows, n_cols, MSM_WINDOWS);
+  return (rows * (kd > kb ? kd : kb) + 2 * rows + 4) * sizeof(pt29) + 512;
+}
+static int32_t run_msm_direct(lasso_ctx* c, const uint8_t* d_scal, size_t row_stride, size_t rows, size_t n_cols, const MsmColMap& cm, const lasso_bases* b, uint8_t* scratch_after, lasso_point* out) {
+  uint32_t ipc = 0; const size_t K = msm_direct_chunks(rows, n_cols, &ipc);
+  const uint32_t seq = ++c->seq;
+  {
+    ProfScope ps(c, LASSO_K_MSM, (double)rows * n_cols * 32);
+    hipLaunchKernelGGL(k_msm_direct, dim3((unsigned)K, (unsigned)rows), dim3(MSM_THREADS), 0, c->stream, (const uint32_t*)d_scal, row_stride / 4, (uint32_t)n_cols, ipc, cm, (const niels29*)b->d_mult, b->n,
+                       (pt29*)scratch_after, (ed_point*)c->d_small, c->d_counters + LASSO_MAX_PTRS + 8, c->d_flag, seq);
+  }
+  HIPCHK(c, hipGetLastError());
+  return wait_flag(c, seq, rows * (sizeof(ed_point) / sizeof(fr_t)), (lasso_fr*)out);
+}
 static int32_t run_msm(lasso_ctx* c, const uint8_t* d_scal, uint32_t bps, uint32_t W, size_t row_stride, size_t rows, size_t n_cols, const lasso_bases* b, uint8_t* scratch_after, lasso_point* out,
                        uint8_t* out_compressed = nullptr) {
+  if (bps == 32 && rows <= MSM_SMALL_ROWS && !out_compressed && b->d_mult && msm_direct_enabled()) { const MsmColMap id = {0, 0, 0, 0}; return run_msm_direct(c, d_scal, row_stride, rows, n_cols, id, b, scratch_after, out); }
   const size_t K = msm_chunks(rows, n_cols, W);
   const size_t cols_per_chunk = (n_cols + K - 1) / K;
   pt29* d_partial = (pt29*)scratch_after;
@@ -577,7 +616,7 @@ int32_t lasso_hyrax_commit_compressed(lasso_ctx* c, const lasso_fr* d_Z, size_t 
 static int32_t hyrax_commit_impl(lasso_ctx* c, const lasso_fr* d_Z, size_t l_size, size_t r_size, const lasso_bases* b, lasso_point* out, uint8_t* out_compressed) {
   REQUIRE(c, d_Z && b && l_size >= 1 && r_size >= 1 && r_size <= b->n && l_size < ((size_t)1 << 31));
   const size_t n = l_size * r_size;
-  const size_t pts_bytes = (l_size * msm_chunks(l_size, r_size, MSM_WINDOWS) + 2 * l_size) * sizeof(pt29) + 512;   // chunk partials + row sums (pt29 or ed_point) + wire bytes
+  const size_t pts_bytes = msm_pts_bytes(l_size, r_size);   // chunk partials + row sums (pt29 or ed_point) + wire bytes
   // small-scalar regime first (4 bytes per scalar); the 32-byte form is only allocated if some scalar needs it — a 2^25-element polynomial of
   // table indices / timestamps then needs 128 MiB of scratch instead of 1 GiB (and no hipMalloc at all after densify)
   int32_t rc = ensure_scratch(c, n * 4 + 256 + pts_bytes); if (rc) return rc;
@@ -602,7 +641,7 @@ static int32_t hyrax_commit_impl(lasso_ctx* c, const lasso_fr* d_Z, size_t l_siz
 }
 int32_t lasso_msm(lasso_ctx* c, const lasso_bases* b, const lasso_fr* scalars, size_t n, lasso_point* out) {
   REQUIRE(c, b && scalars && out && n >= 1 && n <= b->n);
-  int32_t rc = ensure_scratch(c, n * 64 + 260 * sizeof(pt29)); if (rc) return rc;
+  int32_t rc = ensure_scratch(c, n * 64 + msm_pts_bytes(1, n)); if (rc) return rc;
   fr_t* d_in = (fr_t*)c->d_scratch; fr_t* d_can = d_in + n;
   HIPCHK(c, hipMemcpyAsync(d_in, scalars, n * 32, hipMemcpyHostToDevice, c->stream));
   hipLaunchKernelGGL(k_fr_to_canonical, dim3(grid_for(n)), dim3(256), 0, c->stream, (const fr_t*)d_in, n, d_can);
@@ -611,7 +650,7 @@ int32_t lasso_msm(lasso_ctx* c, const lasso_bases* b, const lasso_fr* scalars, s
 
 int32_t lasso_msm_dev(lasso_ctx* c, const lasso_bases* b, const lasso_fr* d_scalars, size_t n, lasso_point* out) {
   REQUIRE(c, b && d_scalars && out && n >= 1 && n <= b->n);
-  int32_t rc = ensure_scratch(c, n * 32 + 260 * sizeof(pt29)); if (rc) return rc;
+  int32_t rc = ensure_scratch(c, n * 32 + msm_pts_bytes(1, n)); if (rc) return rc;
   fr_t* d_can = (fr_t*)c->d_scratch;
   hipLaunchKernelGGL(k_fr_to_canonical, dim3(grid_for(n)), dim3(256), 0, c->stream, (const fr_t*)d_scalars, n, d_can);
   return run_msm(c, (const uint8_t*)d_can, 32, MSM_WINDOWS, n * 32, 1, n, b, (uint8_t*)(d_can + n), out);
@@ -624,7 +663,7 @@ __global__ void __launch_bounds__(256) k_scale_to_integers(const fr_t* __restric
 int32_t lasso_msm_dev_scaled(lasso_ctx* c, const lasso_bases* b, const lasso_fr* d_scalars, size_t n, const lasso_fr* scale, const lasso_fr* tail, lasso_point* out) {
   REQUIRE(c, b && d_scalars && scale && tail && out && n >= 1 && n + 2 <= b->n);
   const size_t row = n + 2;
-  int32_t rc = ensure_scratch(c, row * 32 + 260 * sizeof(pt29)); if (rc) return rc;
+  int32_t rc = ensure_scratch(c, row * 32 + msm_pts_bytes(1, row)); if (rc) return rc;
   fr_t* d_can = (fr_t*)c->d_scratch;
   hipLaunchKernelGGL(k_scale_to_integers, dim3(grid_for(n)), dim3(256), 0, c->stream, (const fr_t*)d_scalars, n, to_fr(scale), to_fr(tail), to_fr(tail + 1), d_can);
   return run_msm(c, (const uint8_t*)d_can, 32, MSM_WINDOWS, row * 32, 1, row, b, (uint8_t*)(d_can + row), out);
@@ -644,7 +683,7 @@ int32_t lasso_inner_products_lr(lasso_ctx* c, const lasso_fr* d_a, const lasso_f
 int32_t lasso_bullet_lr(lasso_ctx* c, const lasso_bases* b, size_t n, const lasso_fr* d_a, size_t nk, const lasso_fr* d_w, const lasso_fr* tail, lasso_point* out) {
   REQUIRE(c, b && d_a && d_w && tail && out && n >= 2 && (n & (n - 1)) == 0 && nk >= 2 && nk <= n && (nk & (nk - 1)) == 0 && n + 2 <= b->n);
   const size_t row = n + 2;
-  int32_t rc = ensure_scratch(c, 2 * row * 32 + (2 * 256 + 4) * sizeof(pt29) + 512); if (rc) return rc;
+  int32_t rc = ensure_scratch(c, 2 * row * 32 + msm_pts_bytes(2, row)); if (rc) return rc;
   fr_t* SL = (fr_t*)c->d_scratch; fr_t* SR = SL + row;
   hipLaunchKernelGGL(k_bullet_expand, dim3(grid_for(n)), dim3(256), 0, c->stream, (const fr_t*)d_a, nk, (const fr_t*)d_w, n, to_fr(tail), to_fr(tail + 1), to_fr(tail + 2), to_fr(tail + 3), SL, SR);
   return run_msm(c, (const uint8_t*)SL, 32, MSM_WINDOWS, row * 32, 2, row, b, (uint8_t*)(SR + row), out);
@@ -654,20 +693,21 @@ int32_t lasso_bullet_round(lasso_ctx* c, const lasso_bases* b, size_t n, const l
   REQUIRE(c, b && d_a_in && d_b_in && d_w_in && blinds && out && n >= 2 && (n & (n - 1)) == 0 && nk >= 2 && nk <= n && (nk & (nk - 1)) == 0 && n + 2 <= b->n);
   const bool fold = u != nullptr;
   if (fold) REQUIRE(c, u_inv && d_a_out && d_b_out && d_w_out && 2 * nk <= n && d_a_out != d_a_in && d_b_out != d_b_in && d_w_out != d_w_in);
-  const size_t row = n + 2;
+  const bool direct = b->d_mult && msm_direct_enabled();
+  const size_t row = direct ? n / 2 + 2 : n + 2;   // compact rows for k_msm_direct: only the non-zero half
   const unsigned nx = grid_for(n / 2, 64);
-  const size_t K = msm_chunks(2, row, MSM_WINDOWS);
-  int32_t rc = ensure_scratch(c, 2 * row * 32 + (size_t)nx * 2 * sizeof(fr_t) + (2 * K + 4) * sizeof(pt29) + 512); if (rc) return rc;
+  int32_t rc = ensure_scratch(c, 2 * row * 32 + (size_t)nx * 2 * sizeof(fr_t) + msm_pts_bytes(2, row)); if (rc) return rc;
   fr_t* SL = (fr_t*)c->d_scratch; fr_t* SR = SL + row; fr_t* partials = SR + row;
   {
     ProfScope ps(c, LASSO_K_MISC, 64.0 * row + (fold ? 96.0 * 2 * nk : 64.0 * nk));
     const fr_t z = fr_zero();
     if (fold) hipLaunchKernelGGL((k_bullet_step<true>), dim3(nx), dim3(256), 0, c->stream, (const fr_t*)d_a_in, (const fr_t*)d_b_in, (const fr_t*)d_w_in, (fr_t*)d_a_out, (fr_t*)d_b_out, (fr_t*)d_w_out, nk, n,
-                                 to_fr(u), to_fr(u_inv), to_fr(blinds), to_fr(blinds + 1), SL, SR, partials, c->d_counters + LASSO_MAX_PTRS + 2);
+                                 to_fr(u), to_fr(u_inv), to_fr(blinds), to_fr(blinds + 1), SL, SR, partials, c->d_counters + LASSO_MAX_PTRS + 2, direct ? 1u : 0u);
     else hipLaunchKernelGGL((k_bullet_step<false>), dim3(nx), dim3(256), 0, c->stream, (const fr_t*)d_a_in, (const fr_t*)d_b_in, (const fr_t*)d_w_in, (fr_t*)nullptr, (fr_t*)nullptr, (fr_t*)nullptr, nk, n,
-                            z, z, to_fr(blinds), to_fr(blinds + 1), SL, SR, partials, c->d_counters + LASSO_MAX_PTRS + 2);
+                            z, z, to_fr(blinds), to_fr(blinds + 1), SL, SR, partials, c->d_counters + LASSO_MAX_PTRS + 2, direct ? 1u : 0u);
   }
   HIPCHK(c, hipGetLastError());
+  if (direct) { const MsmColMap cm = {(uint32_t)nk, (uint32_t)(nk / 2), (uint32_t)(n / 2), (uint32_t)n}; return run_msm_direct(c, (const uint8_t*)SL, row * 32, 2, row, cm, b, (uint8_t*)(partials + (size_t)nx * 2), out); }
   return run_msm(c, (const uint8_t*)SL, 32, MSM_WINDOWS, row * 32, 2, row, b, (uint8_t*)(partials + (size_t)nx * 2), out);
 }
 int32_t lasso_bullet_fold(lasso_ctx* c, lasso_fr* d_a, lasso_fr* d_b, size_t nk, const lasso_fr* d_w, size_t nw, lasso_fr* d_w_out, const lasso_fr* u, const lasso_fr* u_inv) {

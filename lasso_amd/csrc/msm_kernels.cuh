@@ -62,6 +62,13 @@ __global__ void __launch_bounds__(256) k_fr_to_canonical(const fr_t* __restrict_
 // average) — every thread accumulates a strided share of its digit's pairs in registers (7-multiplication mixed adds, next table entry
 // fetched while the current one is added), a segmented LDS tree joins the threads of each digit, and sum_d d*B_d is taken through the four
 // bit planes S_b = sum_{d: bit b} B_d (three tree levels on 32 lanes) and one Horner chain 2(2(2 S_3 + S_2) + S_1) + S_0.
+// phase timing for tools/msm_phase_bench.hip only (compiled out of the library): workgroup (0,0) stamps the 100 MHz wall clock at phase boundaries
+#ifdef MSM_PHASE_CLOCK
+__device__ uint64_t msm_phase_clock[32];
+#define MSM_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) msm_phase_clock[k] = wall_clock64(); } while (0)
+#else
+#define MSM_STAMP(k) do { } while (0)
+#endif
 __device__ __forceinline__ uint32_t msm_nibble(const uint8_t* s, uint32_t w) { return (reinterpret_cast<const uint32_t*>(s)[w >> 3] >> (4 * (w & 7))) & 15u; }
 __global__ void __launch_bounds__(MSM_THREADS) k_msm_buckets(const uint8_t* __restrict__ scal, uint32_t bps, uint32_t W, size_t row_stride, size_t n_cols, size_t cols_per_chunk,
                                                               const niels29* __restrict__ table, size_t table_stride, pt29* __restrict__ out) {
@@ -77,6 +84,7 @@ __global__ void __launch_bounds__(MSM_THREADS) k_msm_buckets(const uint8_t* __re
   size_t c1 = c0 + cols_per_chunk; if (c1 > n_cols) c1 = n_cols;
   const uint32_t scalars_per_batch = MSM_BATCH / W;
   pt29 B = pt_identity();
+  MSM_STAMP(0);
   uint32_t my_d = 0, my_j = 0, my_T = 0;   // this thread's digit, its rank among the digit's threads, and how many threads share the digit
   for (size_t b0 = c0; b0 < c1; b0 += scalars_per_batch) {
     size_t b1 = b0 + scalars_per_batch; if (b1 > c1) b1 = c1;
@@ -117,6 +125,7 @@ __global__ void __launch_bounds__(MSM_THREADS) k_msm_buckets(const uint8_t* __re
       for (uint32_t d = 1; d < 16; d++) if (t >= toff[d] && t < toff[d + 1]) { my_d = d; my_j = t - toff[d]; my_T = toff[d + 1] - toff[d]; }
     }
     __syncthreads();
+    MSM_STAMP(1);
     if (my_T) {
       const uint32_t lo = start[my_d * 16] - counts[my_d * 16], hi = start[my_d * 16 + 15];
       uint32_t pos = lo + my_j;
@@ -129,6 +138,7 @@ __global__ void __launch_bounds__(MSM_THREADS) k_msm_buckets(const uint8_t* __re
     __syncthreads();
   }
   // segmented tree: the threads of one digit are contiguous; pts[toff[d]] ends up holding B_d
+  MSM_STAMP(2);
   pts[t] = B;
   __syncthreads();
   for (uint32_t s = tree_top; s > 0; s >>= 1) {
@@ -140,6 +150,7 @@ __global__ void __launch_bounds__(MSM_THREADS) k_msm_buckets(const uint8_t* __re
     __syncthreads();
   }
   // bit planes: lane (b, i), i < 8, takes the i-th digit that has bit b set
+  MSM_STAMP(3);
   pt29 P;
   const uint32_t b = t >> 3, i = t & 7;
   if (t < 32) { const uint32_t d = ((i >> b) << (b + 1)) | (1u << b) | (i & ((1u << b) - 1)); P = pts[toff[d]]; }
@@ -152,6 +163,7 @@ __global__ void __launch_bounds__(MSM_THREADS) k_msm_buckets(const uint8_t* __re
     if (t < 32 && i < s) pts[t] = P;
     __syncthreads();
   }
+  MSM_STAMP(4);
   if (t == 0) {
     pt29 acc = pts[24];                                   // S_3
     acc = pt_add(pt_dbl(acc), pts[16], d2);               // 2 S_3 + S_2
@@ -159,6 +171,177 @@ __global__ void __launch_bounds__(MSM_THREADS) k_msm_buckets(const uint8_t* __re
     acc = pt_add(pt_dbl(acc), pts[0], d2);
     out[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = acc;
   }
+  MSM_STAMP(5);
+}
+
+// ------------------------------------------------------------------ latency-shaped MSM for a few rows of full-width scalars (the opening tail)
+// A bullet round (bullet.rs:98-121) is two MSMs of n/2 + 2 full-width scalars and the host waits for the result before it can draw the next
+// challenge, so what matters is the LENGTH OF THE DEPENDENT CHAIN, not the operation count.  With buckets that chain is: digit sort,
+// accumulate, segmented tree, three bit-plane levels and a six-operation Horner tail run by ONE lane (36 us on MI355X, tools/msm_phase_bench.hip),
+// then the cross-chunk tree.  Here the generators' table holds every signed digit multiple m * 16^w * G_j, m = 1..8 (affine Niels form,
+// 8 x 64 entries per generator), so the MSM is a plain sum of one table entry per non-zero digit: no sort, no buckets, no bit planes, no
+// Horner — per thread a handful of mixed adds, then one binary tree (in the workgroup, then across workgroups in the last one to arrive).
+//   signed digits: s + 0x88..8 has nibbles e_w, and s = sum (e_w - 8) 16^w with e_w - 8 in [-8, 7]; s < 2^253 so the top nibble cannot overflow.
+//   negation of a Niels entry is free (swap y+x and y-x, negate 2dxy).
+#define MSM_MULTS 8
+// mult[(w*8 + m-1)*n + j] = m * 16^w * G_j from table[w*n + j] = 16^w * G_j.  One thread per (w, j): 4 doublings + 3 mixed adds, then the
+// seven results share ONE inversion (Montgomery's trick) on their way to affine Niels form.
+__global__ void __launch_bounds__(64) k_precompute_multiples(const niels29* __restrict__ table, size_t n, niels29* __restrict__ mult) {
+  const size_t id = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (id >= n * MSM_WINDOWS) return;
+  const size_t w = id / n, j = id - w * n;
+  const niels29 b = table[id];
+  const fe29 d2 = fe_d2();
+  pt29 m[7];   // 2P .. 8P
+  const pt29 P1 = pt_madd(pt_identity(), b);
+  m[0] = pt_dbl(P1); m[1] = pt_madd(m[0], b); m[2] = pt_dbl(m[0]); m[3] = pt_madd(m[2], b); m[4] = pt_dbl(m[1]); m[5] = pt_madd(m[4], b); m[6] = pt_dbl(m[2]);
+  fe29 pre[7]; pre[0] = m[0].Z;
+  for (int k = 1; k < 7; k++) pre[k] = fe_mul(pre[k - 1], m[k].Z);
+  fe29 inv = fe_inv_chain(pre[6]);
+  niels29* dst = mult + (w * MSM_MULTS) * n + j;
+  dst[0] = b;
+  for (int k = 6; k >= 0; k--) {
+    const fe29 zi = k ? fe_mul(inv, pre[k - 1]) : inv;
+    if (k) inv = fe_mul(inv, m[k].Z);
+    const fe29 x = fe_mul(m[k].X, zi), y = fe_mul(m[k].Y, zi);
+    niels29 e; e.ypx = fe_weak(fe_add(y, x)); e.ymx = fe_weak(fe_sub(y, x)); e.t2d = fe_mul(fe_mul(x, y), d2); e.pad = 0;
+    dst[(size_t)(k + 1) * n] = e;
+  }
+}
+// Logical column j of row `row` -> generator index.  nk = 0: identity.  Bullet rows (nk > 0) are stored compactly: the n/2 non-zero scalars
+// of L sit on the RIGHT halves of the nk-blocks of the generator vector, those of R on the LEFT halves (bullet.rs:98-121 with the folds kept
+// as weights on the original generators); the two trailing columns (Q and the blinding base) follow the n main generators.
+struct MsmColMap { uint32_t nk, half, n_main, phys_main; };
+__device__ __forceinline__ uint32_t msm_phys_col(const MsmColMap& m, uint32_t row, uint32_t j) {
+  if (!m.nk) return j;
+  if (j >= m.n_main) return m.phys_main + (j - m.n_main);
+  const uint32_t blk = j / m.half, i = j - blk * m.half;
+  return blk * m.nk + i + (row == 0 ? m.half : 0u);
+}
+// Binary tree over points in LDS with FOUR lanes per addition.  A lone lane runs the nine field products of a unified add back to back
+// (3.1 us per tree level on MI355X: one wave per SIMD issues a product's ~150 instructions at the multiply-add rate, and a tree level has
+// nothing else to overlap).  Here lane role c of a quad computes ONE product per stage — stage 1: A, B, C, D of add-2008-hwcd-3 (role 2's
+// C = (T1*2d)*T2 takes two, so every role issues two: the instruction stream stays uniform), stage 2: X3, Y3, T3, Z3 — through an LDS
+// exchange buffer, so a level costs three product times instead of nine.  Role selection is by data (sign / coordinate index), never by branch.
+// pts[0..live) -> pts[0].  st: exchange buffer for 64 additions.  All MSM_THREADS threads must call.
+__device__ __forceinline__ void msm_coop_tree(pt29* pts, fe29 (*st)[4], uint32_t live, const fe29& d2) {
+  const uint32_t t = threadIdx.x, c = t & 3u, g = t >> 2;
+  uint32_t p2 = 1; while (p2 < live) p2 <<= 1;
+  // roles 0/1 use (Y -/+ X), role 2 T, role 3 Z:  first = coordinate index {1,1,2,3} (X,Y,T,Z = 0..3), second = X with sign {-1,+1,0,0}
+  const uint32_t ci = c < 2 ? 1u : c;
+  const int32_t sg = c == 0 ? -1 : (c == 1 ? 1 : 0);
+  fe29 k1 = fe_one();   // first-stage constant: 2d for role 2, 1 otherwise
+#pragma unroll
+  for (int k = 0; k < 9; k++) k1.v[k] = c == 2 ? d2.v[k] : k1.v[k];
+  for (uint32_t s = p2 >> 1; s > 0; s >>= 1) {
+    for (uint32_t i0 = 0; i0 < s; i0 += MSM_THREADS / 4) {
+      const uint32_t i = i0 + g;
+      const bool act = i < s && i + s < live;
+      if (act) {
+        const fe29* pc = reinterpret_cast<const fe29*>(&pts[i]);
+        const fe29* qc = reinterpret_cast<const fe29*>(&pts[i + s]);
+        const fe29 p1 = pc[ci], px = pc[0], q1 = qc[ci], qx = qc[0];
+        fe29 a, b;
+#pragma unroll
+        for (int k = 0; k < 9; k++) { a.v[k] = p1.v[k] + sg * px.v[k]; b.v[k] = q1.v[k] + sg * qx.v[k]; }
+        fe29 v = fe_mul(fe_mul(a, k1), fe_weak(b));
+        if (c == 3) v = fe_dbl(v);
+        st[g][c] = v;
+      }
+      __syncthreads();
+      if (act) {
+        const fe29 A = st[g][0], Bv = st[g][1], C = st[g][2], D = st[g][3];
+        // role 0: E*F, role 1: H*G, role 2: E*H, role 3: F*G   with E = B-A, F = D-C, G = D+C, H = B+A
+        fe29 u, w;
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+          const int32_t E = Bv.v[k] - A.v[k], F = D.v[k] - C.v[k], G = D.v[k] + C.v[k], H = Bv.v[k] + A.v[k];
+          u.v[k] = c == 0 ? E : (c == 1 ? H : (c == 2 ? E : F));
+          w.v[k] = c == 0 ? F : (c == 1 ? G : (c == 2 ? H : G));
+        }
+        reinterpret_cast<fe29*>(&pts[i])[c] = fe_mul(fe_weak(u), fe_weak(w));   // pt29 = {X, Y, T, Z}: role c owns coordinate c
+      }
+      __syncthreads();
+    }
+  }
+}
+#define MSM_DIRECT_MAX_COLS 160   // columns a workgroup may touch (items_per_chunk <= 64 * (MSM_DIRECT_MAX_COLS - 1))
+// grid = (K chunks, rows).  scal: canonical little-endian scalars, 8 words each, row r at scal + r*row_words.  One item = one (column, window);
+// chunk k owns items [k*items_per_chunk, ...).  out_mont[row] (host-mapped) = the row's sum in ark's Montgomery limbs; the workgroup that
+// completes the last row raises the host's sequence flag.  counters[0..rows) = per-row arrival tickets, counters[16] = finished rows.
+__global__ void __launch_bounds__(MSM_THREADS) k_msm_direct(const uint32_t* __restrict__ scal, size_t row_words, uint32_t n_cols, uint32_t items_per_chunk, MsmColMap cm,
+                                                             const niels29* __restrict__ mult, size_t tn, pt29* __restrict__ partial, ed_point* __restrict__ out_mont, uint32_t* counters,
+                                                             uint32_t* flag, uint32_t seq) {
+  __shared__ pt29 pts[MSM_THREADS];
+  __shared__ fe29 st[MSM_THREADS / 4][4];
+  __shared__ uint32_t sb[MSM_DIRECT_MAX_COLS * 8];
+  __shared__ uint32_t is_last;
+  const fe29 d2 = fe_d2();
+  const uint32_t t = threadIdx.x, row = blockIdx.y, K = gridDim.x;
+  const uint32_t total = n_cols * MSM_WINDOWS;
+  const uint32_t it0 = blockIdx.x * items_per_chunk;
+  uint32_t it1 = it0 + items_per_chunk; if (it1 > total) it1 = total;
+  const uint32_t col0 = it0 >> 6, col1 = (it1 + 63) >> 6;
+  MSM_STAMP(0);
+  for (uint32_t c = t; c < col1 - col0; c += MSM_THREADS) {   // e = s + 0x88..8
+    const uint32_t* s = scal + (size_t)row * row_words + (size_t)(col0 + c) * 8;
+    uint64_t carry = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) { const uint64_t x = (uint64_t)s[k] + 0x88888888ull + carry; sb[c * 8 + k] = (uint32_t)x; carry = x >> 32; }
+  }
+  __syncthreads();
+  MSM_STAMP(1);
+  pt29 B = pt_identity();
+  niels29 cur; bool have = false;
+  for (uint32_t base = it0; base < it1; base += MSM_THREADS) {
+    const uint32_t it = base + t;
+    bool valid = it < it1; int32_t d = 0; uint32_t c = 0, w = 0;
+    if (valid) { c = it >> 6; w = it & 63u; d = (int32_t)((sb[(c - col0) * 8 + (w >> 3)] >> (4 * (w & 7u))) & 15u) - 8; valid = d != 0; }
+    // the fetch is unconditional (entry 0 for a skipped item) so that it is issued BEFORE the mixed add below and waited for after it
+    const uint32_t m = d < 0 ? (uint32_t)(-d) : (uint32_t)d;
+    const size_t idx = valid ? ((size_t)w * MSM_MULTS + (m - 1)) * tn + msm_phys_col(cm, row, c) : 0;
+    const niels29 nxt = mult[idx];
+    if (have) B = pt_madd(B, cur);
+    const bool neg = d < 0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) { cur.ypx.v[k] = neg ? nxt.ymx.v[k] : nxt.ypx.v[k]; cur.ymx.v[k] = neg ? nxt.ypx.v[k] : nxt.ymx.v[k]; cur.t2d.v[k] = neg ? -nxt.t2d.v[k] : nxt.t2d.v[k]; }
+    have = valid;
+  }
+  if (have) B = pt_madd(B, cur);
+  MSM_STAMP(2);
+  pts[t] = B;
+  __syncthreads();
+  msm_coop_tree(pts, st, MSM_THREADS, d2);
+  MSM_STAMP(3);
+  if (K > 1) {
+    if (t == 0) {
+      partial[(size_t)row * K + blockIdx.x] = pts[0];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const uint32_t ticket = __hip_atomic_fetch_add(&counters[row], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint32_t last = ticket == K - 1 ? 1u : 0u;
+      if (last) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); counters[row] = 0; }
+      is_last = last;
+    }
+    __syncthreads();
+    if (!is_last) return;
+    pt29 acc = t < K ? partial[(size_t)row * K + t] : pt_identity();
+    for (uint32_t k = t + MSM_THREADS; k < K; k += MSM_THREADS) acc = pt_add(acc, partial[(size_t)row * K + k], d2);
+    __syncthreads();
+    pts[t] = acc;
+    __syncthreads();
+    msm_coop_tree(pts, st, K < MSM_THREADS ? K : MSM_THREADS, d2);
+  }
+  MSM_STAMP(4);
+  if (t == 0) {
+    ed_point p = pt_to_ed(pts[0]), o; o.X = fq_to_mont(p.X); o.Y = fq_to_mont(p.Y); o.T = fq_to_mont(p.T); o.Z = fq_to_mont(p.Z); out_mont[row] = o;
+    if (flag) {
+      __threadfence_system();
+      const uint32_t t2 = __hip_atomic_fetch_add(&counters[16], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      if (t2 == gridDim.y - 1) { counters[16] = 0; __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+    }
+  }
+  MSM_STAMP(5);
 }
 
 // out[row] = sum_k partial[row*K + k], converted to ark's Montgomery limbs (out_mont) or, when out_compressed is given, to the 32-byte wire form.  One workgroup per row; thread t first adds partials
@@ -169,12 +352,14 @@ __global__ void __launch_bounds__(MSM_THREADS) k_points_sum(const pt29* __restri
   __shared__ pt29 pts[MSM_THREADS];
   const fe29 d2 = fe_d2();
   const uint32_t t = threadIdx.x;
+  MSM_STAMP(8);
   pt29 acc = t < K ? partial[(size_t)blockIdx.x * K + t] : pt_identity();
   for (uint32_t k = t + MSM_THREADS; k < K; k += MSM_THREADS) acc = pt_add(acc, partial[(size_t)blockIdx.x * K + k], d2);
   pts[t] = acc;
   __syncthreads();
   const uint32_t live = K < MSM_THREADS ? K : MSM_THREADS;
   for (uint32_t s = MSM_THREADS / 2; s > 0; s >>= 1) { if (t < s && t + s < live) pts[t] = pt_add(pts[t], pts[t + s], d2); __syncthreads(); }
+  MSM_STAMP(9);
   if (t == 0 && out_compressed) reinterpret_cast<pt29*>(out_compressed)[blockIdx.x] = pts[0];   // compressed mode: hand the row sum to k_points_compress (one lane per row)
   if (t == 0 && !out_compressed) {
     ed_point p = pt_to_ed(pts[0]), o; o.X = fq_to_mont(p.X); o.Y = fq_to_mont(p.Y); o.T = fq_to_mont(p.T); o.Z = fq_to_mont(p.Z); out_mont[blockIdx.x] = o;
@@ -184,6 +369,7 @@ __global__ void __launch_bounds__(MSM_THREADS) k_points_sum(const pt29* __restri
       if (t2 == gridDim.x - 1) { *counters = 0; __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
     }
   }
+  MSM_STAMP(10);
 }
 
 // wire form of many points at once: one lane per point (normalize_batch + serialize_compressed on the device; the inversion chain is 265 products)
@@ -223,12 +409,13 @@ __global__ void __launch_bounds__(256) k_bullet_fold(fr_t* __restrict__ a, fr_t*
 // ------------------------------------------------------------------ one bullet round in one pass (bullet.rs:66-132)
 // FOLD: apply the previous challenge first (a' = a_L*u + u_inv*a_R, b' = b_L*u_inv + u*b_R, w'[2k] = w[k]*u_inv, w'[2k+1] = w[k]*u), reading the
 // ping-pong inputs of length 2*nk and writing the outputs of length nk; then, on the state of length nk: c_L = <a_L, b_R>, c_R = <a_R, b_L>
-// (last-block reduction) and the canonical scalar rows SL, SR (n + 2 entries each) of the two MSMs over the ORIGINAL generators.
+// (last-block reduction) and the canonical scalar rows SL, SR of the two MSMs over the ORIGINAL generators (n + 2 entries each, half of them
+// zero; or, `compact`, only the n/2 + 2 non-zero ones).
 // One thread per (i < nk/2, blk < n/nk): n/2 threads whatever the round, so late rounds are as parallel as early ones.
 template <bool FOLD>
 __global__ void __launch_bounds__(256) k_bullet_step(const fr_t* __restrict__ a_in, const fr_t* __restrict__ b_in, const fr_t* __restrict__ w_in, fr_t* __restrict__ a_out, fr_t* __restrict__ b_out,
                                                       fr_t* __restrict__ w_out, size_t nk, size_t n, fr_t u, fr_t u_inv, fr_t blind_l, fr_t blind_r, fr_t* __restrict__ SL, fr_t* __restrict__ SR,
-                                                      fr_t* __restrict__ partials, uint32_t* counters) {
+                                                      fr_t* __restrict__ partials, uint32_t* counters, uint32_t compact) {
   __shared__ RedScratch S;
   __shared__ uint32_t is_last;
   const size_t half = nk / 2, total = n / 2;
@@ -256,9 +443,10 @@ __global__ void __launch_bounds__(256) k_bullet_step(const fr_t* __restrict__ a_
       if ((++cnt & 127u) == 0) { acc[0] = fr29_mul(acc[0], fr29_one_s()); acc[1] = fr29_mul(acc[1], fr29_one_s()); }
     }
     // MSM scalars are canonical integers: mul(u, u) = wv*a*2^251, one more Montgomery step with the integer 2^10 gives wv*a itself
-    const size_t base = blk * nk + i;
-    SL[base] = fr_zero(); SL[base + half] = fr29_store(fr29_mul(fr29_mul(wv, a0), fr29_int_from_uu()));
-    SR[base] = fr29_store(fr29_mul(fr29_mul(wv, a1), fr29_int_from_uu())); SR[base + half] = fr_zero();
+    // compact rows (k_msm_direct with the bullet column map): entry g of L belongs to generator blk*nk + half + i, entry g of R to blk*nk + i
+    const fr_t sl = fr29_store(fr29_mul(fr29_mul(wv, a0), fr29_int_from_uu())), sr = fr29_store(fr29_mul(fr29_mul(wv, a1), fr29_int_from_uu()));
+    if (compact) { SL[g] = sl; SR[g] = sr; }
+    else { const size_t base = blk * nk + i; SL[base] = fr_zero(); SL[base + half] = sl; SR[base] = sr; SR[base + half] = fr_zero(); }
   }
   store_block_partials<3>(acc, 2, partials + 2 * (size_t)blockIdx.x, fr29_k5(), S);
   if (threadIdx.x == 0) {
@@ -279,6 +467,7 @@ __global__ void __launch_bounds__(256) k_bullet_step(const fr_t* __restrict__ a_
     for (int k = 0; k < 9; k++) c[k] = S.cols[threadIdx.x * 9 + k];
     fr29 k32 = fr29_zero(); k32.v[0] = 32;
     const fr_t v = fr29_store(fr29_mul(fr29_from_columns(c), k32));   // u-form sum -> canonical integer
-    if (threadIdx.x == 0) { SL[n] = v; SL[n + 1] = fr29_to_integer(fr29_unpack_u(blind_l)); } else { SR[n] = v; SR[n + 1] = fr29_to_integer(fr29_unpack_u(blind_r)); }
+    const size_t tail = compact ? n / 2 : n;
+    if (threadIdx.x == 0) { SL[tail] = v; SL[tail + 1] = fr29_to_integer(fr29_unpack_u(blind_l)); } else { SR[tail] = v; SR[tail + 1] = fr29_to_integer(fr29_unpack_u(blind_r)); }
   }
 }

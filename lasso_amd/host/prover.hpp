@@ -469,6 +469,16 @@ class Prover {
     lasso_fr sc = d.comm.eq_low(point).abi();
     d.chk(lasso_eq_evals_scaled(d.ctx, rr.data(), (uint32_t)rr.size(), &sc, d_out), "lasso_eq_evals_scaled");
   }
+  // The eq-weighted cubic rounds only ever read the first HALF of a layer's eq table (x_0 = 0; cubic_rounds below), and that half is
+  // (1 - point[0]) * eq(point[1..]): build just that (half the field multiplications and HBM writes of EqPolynomial::evals, eq_poly.rs:29-42).
+  void eq_half_local(const ScVec& point, lasso_fr* d_out) {
+    LASSO_REQUIRE(point.size() >= lgP);
+    if (point.size() == lgP) return;   // no local round reads a table
+    std::vector<lasso_fr> rr; for (size_t i = 1; i + lgP < point.size(); i++) rr.push_back(point[i].abi());
+    Sc scale = Sc::one() - point[0]; if (P > 1) scale *= d.comm.eq_low(point);
+    lasso_fr sc = scale.abi();
+    d.chk(lasso_eq_evals_scaled(d.ctx, rr.data(), (uint32_t)rr.size(), &sc, d_out), "lasso_eq_evals_scaled");
+  }
   // local arrays are down to ONE element each: all-gather them into P-element replicated arrays (index = rank = the remaining low variables)
   std::vector<lasso_fr*> gather_tail(const std::vector<lasso_fr*>& polys) {
     const size_t k = polys.size();
@@ -663,7 +673,7 @@ class Prover {
     Trace tr("BatchedGrandProductArgument.prove", d.ctx);
     BatchedGrandProductArgument out; const size_t k = trees.size(), num_layers = ceil_log2(n), n_loc = n / P;
     ScVec claims_to_verify = roots, rand;
-    DBuf eq(d, std::max(n_loc / 2, P));   // the layer's eq table: slab layers use n_loc/2 entries, replicated top layers at most P/2
+    DBuf eq(d, std::max(n_loc / 4, P));   // the layer's (half) eq table: slab layers use n_loc/4 entries, replicated top layers at most P/2
     for (size_t layer_id = num_layers; layer_id-- > 0;) {
       const size_t len = n >> layer_id;                     // global layer `layer_id` has n/2^layer_id elements
       LASSO_REQUIRE(((size_t)1 << rand.size()) == len / 2);
@@ -673,7 +683,7 @@ class Prover {
       if (slab || P == 1) {
         const size_t len_l = len / P, off = 2 * n_loc - 2 * len_l;
         for (auto* tr : trees) { A.push_back(tr + off); B.push_back(tr + off + len_l / 2); }
-        eq_evals_local(rand, eq.p);                                                             // poly_C_par :122
+        eq_half_local(rand, eq.p);                                                              // poly_C_par :122 (the half the rounds read)
       } else {
         const size_t off = 2 * P - 2 * len;
         for (auto* tp : tops) { A.push_back(tp + off); B.push_back(tp + off + len / 2); }

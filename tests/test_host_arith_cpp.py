@@ -9,7 +9,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("name", ["test_arith_host", "test_fe29_host", "test_fr29_host"])
+@pytest.mark.parametrize("name", ["test_arith_host", "test_fe29_host", "test_fr29_host", "test_modinv_host"])
 @pytest.mark.parametrize("flags", [[], ["-DLASSO_HOST_LIMBS32"]], ids=["limbs64", "limbs32"])
 def test_cpp_arith(name, flags):
     src = os.path.join(ROOT, "tests", "cpp", name + ".cpp")
