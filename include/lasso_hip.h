@@ -107,6 +107,16 @@ int32_t lasso_sumcheck_cubic_eqw_round(lasso_ctx* ctx, const lasso_fr* const* d_
  * then the eq-weighted sums of the next round on the bound values: out as lasso_sumcheck_cubic_eqw_round for length n/2 (sums over i < n/4). */
 int32_t lasso_sumcheck_cubic_eqw_round_fused(lasso_ctx* ctx, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n,
                                              const lasso_fr* r, lasso_fr* out);
+/* The eq-weighted round with TWO sums per circuit, split into launch and wait.  q_c(x) = sum_i A_c(x)[i] B_c(x)[i] d_E[i] is quadratic in x and the
+ * round's claim already fixes q(0) + (a known multiple of) q(1) (sumcheck.rs:99-104 derives the evaluation at 1 from it the same way), so
+ * (q_c(0), q_c,inf) with q_c,inf = sum_i (A_c[i+n/2] - A_c[i]) (B_c[i+n/2] - B_c[i]) d_E[i], the leading coefficient, determine the round
+ * polynomial: one product per index and circuit less than the three-sum form, and the host's per-round inversion overlaps the kernel.
+ * r == NULL: first round of a layer (length n, n >= 2, evaluation only); otherwise bind the previous challenge first (n = length before the
+ * bind, n >= 4) exactly as lasso_sumcheck_cubic_eqw_round_fused.  Returns after the launch; lasso_result_wait(ctx, out, 2*ncirc) then yields
+ * out[2c] = q_c(0), out[2c+1] = q_c,inf.  No other call may be made on the context between the two. */
+int32_t lasso_sumcheck_cubic_eqw2_begin(lasso_ctx* ctx, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n,
+                                        const lasso_fr* r);
+int32_t lasso_result_wait(lasso_ctx* ctx, lasso_fr* out, size_t count);
 /* One round of SumcheckInstanceProof::prove_arbitrary (src/subprotocols/sumcheck.rs:165-237) with
  * comb_func = S::combine_lookups_eq (src/subtables/mod.rs:53-57): out[x] = sum_i g(E_1..E_alpha)(x) * eq(x), x = 0..degree.
  * d_polys holds alpha = NUM_MEMORIES device pointers; d_eq is the eq polynomial. */

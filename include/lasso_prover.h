@@ -51,6 +51,13 @@ int32_t lasso_host_prove(lasso_host* h, lasso_host_dense* d, lasso_host_gens* g,
  * and log2(s) field elements from a fresh test_rng() */
 void lasso_host_gen_indices(size_t sparsity, size_t memory_size, uint64_t* out);
 void lasso_host_gen_random_point(size_t bits, lasso_fr* out);
+/* Test support (not part of the reference's surface): prove_cubic_batched (sumcheck.rs:27-135, C = EqPolynomial(rand).evals()) on caller-supplied
+ * arrays with a scripted eq point, for the degenerate points (rand_t = 0 or 1) no transcript produces.  A, B: k contiguous arrays of 2^ell elements.
+ * out = 3 compressed coefficients per round, the ell challenges, the k final claims of A, the k of B (32-byte canonical scalars). */
+int32_t lasso_host_debug_cubic_batched(lasso_host* h, lasso_host_dense* dense, lasso_host_gens* gens, const lasso_strategy* strategy, size_t k, size_t ell,
+                                       const lasso_fr* A, const lasso_fr* B, const lasso_fr* rand, const lasso_fr* coeffs, const lasso_fr* claim,
+                                       const char* transcript_label, uint8_t* out, size_t cap, size_t* len);
+
 #ifdef __cplusplus
 }
 #endif

@@ -44,6 +44,7 @@ struct lasso_ctx {
   fr_t* d_big = nullptr; fr_t* h_big = nullptr; size_t big_cap = 0;   // large results (matvec rows): device buffer + pinned mirror, hipMemcpyAsync
   uint32_t* d_flags = nullptr;
   uint32_t* d_counters = nullptr;                         // arrival tickets of the in-launch reductions (zero between launches)
+  bool pending = false; uint32_t pending_seq = 0; size_t pending_count = 0;   // a *_begin result not yet collected by lasso_result_wait
   uint32_t prof_mask = 0;   // bit k set = kernel family k is bracketed with events
   std::vector<EventPair> events; size_t events_used = 0;
   uint64_t prof_launches[LASSO_K_COUNT] = {0}; double prof_ms[LASSO_K_COUNT] = {0}; double prof_bytes[LASSO_K_COUNT] = {0};
@@ -259,44 +260,65 @@ int32_t lasso_sumcheck_cubic_round(lasso_ctx* c, const lasso_fr* const* d_A, con
 }
 // eq-weighted forms (see k_cubic_eqw_* in poly_kernels.cuh): what the prover calls.  Algorithmic bytes are SURVEY.md §8d's for the reference's round
 // (2k+1 polynomials), although the kernels read only the 2k of A and B plus n/4 .. n/2 table entries.
-int32_t lasso_sumcheck_cubic_eqw_round(lasso_ctx* c, const lasso_fr* const* d_A, const lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n, lasso_fr* out) {
-  REQUIRE(c, d_A && d_B && d_E && out && ncirc >= 1 && ncirc <= LASSO_MAX_PTRS && n >= 2 && (n & (n - 1)) == 0);
-  const size_t half = n / 2;
+// One eq-weighted cubic round, enqueued only: r == nullptr is the first round of a layer (arrays of length n, evaluation only), otherwise the
+// previous challenge is bound first (length n -> n/2) and the sums are those of the next round.  NT sums per circuit land in the mapped
+// result buffer under sequence number *seq_out.
+static int32_t cubic_eqw_launch(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n, const lasso_fr* r, int NT, uint32_t* seq_out) {
+  MutPtrTable A, B; for (uint32_t i = 0; i < ncirc; i++) { REQUIRE(c, d_A[i] && d_B[i]); A.p[i] = (fr_t*)d_A[i]; B.p[i] = (fr_t*)d_B[i]; }
   int32_t rc = ensure_small(c, (size_t)ncirc * 3); if (rc) return rc;
-  const uint32_t seq = ++c->seq;
-  if (half <= CUBIC_SMALL_Q) {
-    MutPtrTable A, B; for (uint32_t i = 0; i < ncirc; i++) { REQUIRE(c, d_A[i] && d_B[i]); A.p[i] = (fr_t*)d_A[i]; B.p[i] = (fr_t*)d_B[i]; }   // read-only in this mode
+  const uint32_t seq = ++c->seq; *seq_out = seq;
+  if (!r) {
+    const size_t half = n / 2;
     ProfScope ps(c, LASSO_K_CUBIC, 32.0 * n * (2.0 * ncirc + 1.0));
-    hipLaunchKernelGGL((k_cubic_eqw_small<false>), dim3(ncirc), dim3(LASSO_BLOCK), 0, c->stream, A, B, (const fr_t*)d_E, (uint32_t)half, fr_zero(), c->d_counters, c->d_small, c->d_flag, seq);
+    if (half <= CUBIC_SMALL_Q) {   // arrays are read-only in this mode
+      if (NT == 3) hipLaunchKernelGGL((k_cubic_eqw_small<false, 3>), dim3(ncirc), dim3(LASSO_BLOCK), 0, c->stream, A, B, (const fr_t*)d_E, (uint32_t)half, fr_zero(), c->d_counters, c->d_small, c->d_flag, seq);
+      else hipLaunchKernelGGL((k_cubic_eqw_small<false, 2>), dim3(ncirc), dim3(LASSO_BLOCK), 0, c->stream, A, B, (const fr_t*)d_E, (uint32_t)half, fr_zero(), c->d_counters, c->d_small, c->d_flag, seq);
+    } else {
+      PtrTable Ac, Bc; for (uint32_t i = 0; i < ncirc; i++) { Ac.p[i] = A.p[i]; Bc.p[i] = B.p[i]; }
+      const unsigned ny = ncirc, nx = grid_for(half, cubic_nx_cap(ny));
+      rc = ensure_scratch(c, (size_t)nx * ny * 3 * sizeof(fr_t)); if (rc) return rc;
+      if (NT == 3) hipLaunchKernelGGL(k_cubic_eqw_lb<3>, dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, Ac, Bc, nx, ny, (const fr_t*)d_E, half, (fr_t*)c->d_scratch, c->d_counters, c->d_small, c->d_flag, seq);
+      else hipLaunchKernelGGL(k_cubic_eqw_lb<2>, dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, Ac, Bc, nx, ny, (const fr_t*)d_E, half, (fr_t*)c->d_scratch, c->d_counters, c->d_small, c->d_flag, seq);
+    }
   } else {
-    PtrTable A, B; for (uint32_t i = 0; i < ncirc; i++) { REQUIRE(c, d_A[i] && d_B[i]); A.p[i] = (const fr_t*)d_A[i]; B.p[i] = (const fr_t*)d_B[i]; }
-    const unsigned ny = ncirc, nx = grid_for(half, cubic_nx_cap(ny));
-    rc = ensure_scratch(c, (size_t)nx * ny * 3 * sizeof(fr_t)); if (rc) return rc;
-    ProfScope ps(c, LASSO_K_CUBIC, 32.0 * n * (2.0 * ncirc + 1.0));
-    hipLaunchKernelGGL(k_cubic_eqw_lb, dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, A, B, nx, ny, (const fr_t*)d_E, half, (fr_t*)c->d_scratch, c->d_counters, c->d_small, c->d_flag, seq);
+    const size_t q = n / 4;
+    // bind: read 32n + write 16n per polynomial (SURVEY.md §8d's "fused bind+next-eval" over the reference's 2*ncirc + 1 polynomials)
+    ProfScope ps(c, LASSO_K_CUBIC, 48.0 * n * (2.0 * ncirc + 1.0));
+    if (q <= CUBIC_SMALL_Q) {
+      if (NT == 3) hipLaunchKernelGGL((k_cubic_eqw_small<true, 3>), dim3(ncirc), dim3(LASSO_BLOCK), 0, c->stream, A, B, (const fr_t*)d_E, (uint32_t)q, to_fr(r), c->d_counters, c->d_small, c->d_flag, seq);
+      else hipLaunchKernelGGL((k_cubic_eqw_small<true, 2>), dim3(ncirc), dim3(LASSO_BLOCK), 0, c->stream, A, B, (const fr_t*)d_E, (uint32_t)q, to_fr(r), c->d_counters, c->d_small, c->d_flag, seq);
+    } else {
+      const unsigned ny = ncirc, nx = grid_for(q, cubic_nx_cap(ny));
+      rc = ensure_scratch(c, (size_t)nx * ny * 3 * sizeof(fr_t)); if (rc) return rc;
+      if (NT == 3) hipLaunchKernelGGL(k_cubic_eqw_fused<3>, dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, A, B, nx, ny, (const fr_t*)d_E, q, to_fr(r), (fr_t*)c->d_scratch, c->d_counters, c->d_small, c->d_flag, seq);
+      else hipLaunchKernelGGL(k_cubic_eqw_fused<2>, dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, A, B, nx, ny, (const fr_t*)d_E, q, to_fr(r), (fr_t*)c->d_scratch, c->d_counters, c->d_small, c->d_flag, seq);
+    }
   }
   HIPCHK(c, hipGetLastError());
+  return 0;
+}
+int32_t lasso_sumcheck_cubic_eqw_round(lasso_ctx* c, const lasso_fr* const* d_A, const lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n, lasso_fr* out) {
+  REQUIRE(c, d_A && d_B && d_E && out && ncirc >= 1 && ncirc <= LASSO_MAX_PTRS && n >= 2 && (n & (n - 1)) == 0);
+  uint32_t seq; int32_t rc = cubic_eqw_launch(c, (lasso_fr* const*)d_A, (lasso_fr* const*)d_B, ncirc, d_E, n, nullptr, 3, &seq); if (rc) return rc;
   return wait_flag(c, seq, (size_t)ncirc * 3, out);
 }
 int32_t lasso_sumcheck_cubic_eqw_round_fused(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n, const lasso_fr* r, lasso_fr* out) {
   REQUIRE(c, d_A && d_B && d_E && r && out && ncirc >= 1 && ncirc <= LASSO_MAX_PTRS && n >= 4 && (n & (n - 1)) == 0);
-  MutPtrTable A, B; for (uint32_t i = 0; i < ncirc; i++) { REQUIRE(c, d_A[i] && d_B[i]); A.p[i] = (fr_t*)d_A[i]; B.p[i] = (fr_t*)d_B[i]; }
-  const size_t q = n / 4;
-  int32_t rc = ensure_small(c, (size_t)ncirc * 3); if (rc) return rc;
-  const uint32_t seq = ++c->seq;
-  {
-    // bind: read 32n + write 16n per polynomial (SURVEY.md §8d's "fused bind+next-eval" over the reference's 2*ncirc + 1 polynomials)
-    ProfScope ps(c, LASSO_K_CUBIC, 48.0 * n * (2.0 * ncirc + 1.0));
-    if (q <= CUBIC_SMALL_Q) {
-      hipLaunchKernelGGL((k_cubic_eqw_small<true>), dim3(ncirc), dim3(LASSO_BLOCK), 0, c->stream, A, B, (const fr_t*)d_E, (uint32_t)q, to_fr(r), c->d_counters, c->d_small, c->d_flag, seq);
-    } else {
-      const unsigned ny = ncirc, nx = grid_for(q, cubic_nx_cap(ny));
-      rc = ensure_scratch(c, (size_t)nx * ny * 3 * sizeof(fr_t)); if (rc) return rc;
-      hipLaunchKernelGGL(k_cubic_eqw_fused, dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, A, B, nx, ny, (const fr_t*)d_E, q, to_fr(r), (fr_t*)c->d_scratch, c->d_counters, c->d_small, c->d_flag, seq);
-    }
-  }
-  HIPCHK(c, hipGetLastError());
+  uint32_t seq; int32_t rc = cubic_eqw_launch(c, d_A, d_B, ncirc, d_E, n, r, 3, &seq); if (rc) return rc;
   return wait_flag(c, seq, (size_t)ncirc * 3, out);
+}
+// Two-sum form, split into launch and wait so that the host can prepare the round's scalars (one field inversion) while the kernel runs.
+// out (lasso_result_wait) = ncirc pairs (q(0), q_inf) — see cubic_eqw_terms2 in poly_kernels.cuh.  One result may be pending per context.
+int32_t lasso_sumcheck_cubic_eqw2_begin(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n, const lasso_fr* r) {
+  REQUIRE(c, d_A && d_B && d_E && ncirc >= 1 && ncirc <= LASSO_MAX_PTRS && n >= (r ? 4u : 2u) && (n & (n - 1)) == 0 && !c->pending);
+  uint32_t seq; int32_t rc = cubic_eqw_launch(c, d_A, d_B, ncirc, d_E, n, r, 2, &seq); if (rc) return rc;
+  c->pending = true; c->pending_seq = seq; c->pending_count = (size_t)ncirc * 2;
+  return 0;
+}
+int32_t lasso_result_wait(lasso_ctx* c, lasso_fr* out, size_t count) {
+  REQUIRE(c, out && c->pending && count == c->pending_count);
+  c->pending = false;
+  return wait_flag(c, c->pending_seq, count, out);
 }
 // eq-weighted rounds of prove_arbitrary for the linear strategies (k_dot_eqw_* in poly_kernels.cuh)
 int32_t lasso_sumcheck_linear_eqw_round(lasso_ctx* c, const lasso_fr* const* d_polys, uint32_t alpha, const lasso_fr* d_E, size_t n, lasso_fr* out) {

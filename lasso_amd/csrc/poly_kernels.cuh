@@ -162,14 +162,14 @@ __device__ __forceinline__ void row_done(uint32_t nrows, uint32_t* counters, uin
 }
 // block partials -> memory (K10 also supplies the missing 2^10), then the in-launch second stage; a single-block row writes its result directly.
 __device__ __forceinline__ void cubic_epilogue(const fr29* e, const CubicGrid& g, fr_t* __restrict__ partials, uint32_t* counters, fr_t* __restrict__ out, uint32_t* flag, uint32_t seq, RedScratch& S,
-                                               const fr29& fix) {
+                                               const fr29& fix, uint32_t K = 3) {   // K <= 3 results per row
   if (g.nx == 1) {
-    store_block_partials<3>(e, 3, out + (size_t)g.by * 3, fix, S);
+    store_block_partials<3>(e, K, out + (size_t)g.by * K, fix, S);
     row_done(g.ny, counters, flag, seq);
     return;
   }
-  store_block_partials<3>(e, 3, partials + ((size_t)g.by * g.nx + g.bx) * 3, fix, S);
-  last_block_reduce(partials, g.nx, 3, g.by, g.ny, counters, out, S, flag, seq);
+  store_block_partials<3>(e, K, partials + ((size_t)g.by * g.nx + g.bx) * K, fix, S);
+  last_block_reduce(partials, g.nx, K, g.by, g.ny, counters, out, S, flag, seq);
 }
 #define CUBIC_ACCUMULATE(e, t0, t2, t3, cnt)                                                                                          \
   do {                                                                                                                                \
@@ -212,7 +212,23 @@ __device__ __forceinline__ void cubic_eqw_terms(const fr29& a0, const fr29& a1, 
   t2 = fr29_mul(b2, g2);
   t3 = fr29_mul(fr29_add(b2, db), fr29_weak(fr29_add(g2, dg)));                     // 3*hi - 2*lo; u * u: 2^5 short, fixed once per block with K5
 }
-// out[c*3 + {0,1,2}] = sum_{i < half} A_c(x)[i] B_c(x)[i] E[i] at x = 0, 2, 3.  1-D grid of nx*ny workgroups (cubic_grid).
+// Two sums instead of three.  q(x) = sum_i a(x) b(x) E[i] is QUADRATIC in x, and the round's claim already fixes one linear condition on it
+// (e = cubic(0) + cubic(1), sumcheck.rs:99-104 uses it to derive the evaluation at 1), so two numbers per circuit determine the round polynomial:
+// q(0) = sum a0 b0 E  and the leading coefficient  q_inf = sum (a1 - a0)(b1 - b0) E.   The host recovers q(1) from the claim and the evaluations at
+// 2, 3 by extrapolation (prover.hpp cubic_rounds) — the same field elements.  8 products per index and circuit in the fused kernel instead of 9,
+// two accumulators instead of three.   NT = 3: sums at x = 0, 2, 3;  NT = 2: (q(0), q_inf).
+__device__ __forceinline__ void cubic_eqw_terms2(const fr29& a0, const fr29& a1, const fr29& b0, const fr29& b1, const fr29& es, fr29& t0, fr29& tinf) {
+  const fr29 g0 = fr29_mul(a0, es), g1 = fr29_mul(a1, es);
+  t0 = fr29_mul(b0, g0);
+  tinf = fr29_mul(fr29_sub(g1, g0), fr29_sub(b1, b0));   // b0, b1 canonical: the difference keeps |limb| < 2^29
+}
+#define CUBIC_ACCUMULATE2(e, t0, t1, cnt)                                                                         \
+  do {                                                                                                            \
+    e[0] = fr29_weak(fr29_add(e[0], t0)); e[1] = fr29_weak(fr29_add(e[1], t1));                                     \
+    if ((++cnt & 127u) == 0) { e[0] = fr29_mul(e[0], fr29_one_s()); e[1] = fr29_mul(e[1], fr29_one_s()); }          \
+  } while (0)
+// out[c*NT + ..] = the NT sums over i < half of circuit c.  1-D grid of nx*ny workgroups (cubic_grid).
+template <int NT>
 __global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_eqw_lb(PtrTable A, PtrTable B, uint32_t nx, uint32_t ny, const fr_t* __restrict__ E, size_t half, fr_t* __restrict__ partials, uint32_t* counters,
                                                                fr_t* __restrict__ out, uint32_t* flag, uint32_t seq) {
   __shared__ RedScratch S;
@@ -222,13 +238,14 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_eqw_lb(PtrTable A, PtrTab
   fr29 e[3] = {fr29_zero(), fr29_zero(), fr29_zero()}; uint32_t cnt = 0;
   for (size_t i = g.bx * (size_t)blockDim.x + threadIdx.x; i < half; i += (size_t)nx * blockDim.x) {
     fr29 t0, t2, t3;
-    cubic_eqw_terms(fr29_unpack_u(a[i]), fr29_unpack_u(a[i + half]), fr29_unpack_u(b[i]), fr29_unpack_u(b[i + half]), fr29_unpack_s(E[i]), t0, t2, t3);
-    CUBIC_ACCUMULATE(e, t0, t2, t3, cnt);
+    if (NT == 3) { cubic_eqw_terms(fr29_unpack_u(a[i]), fr29_unpack_u(a[i + half]), fr29_unpack_u(b[i]), fr29_unpack_u(b[i + half]), fr29_unpack_s(E[i]), t0, t2, t3); CUBIC_ACCUMULATE(e, t0, t2, t3, cnt); }
+    else { cubic_eqw_terms2(fr29_unpack_u(a[i]), fr29_unpack_u(a[i + half]), fr29_unpack_u(b[i]), fr29_unpack_u(b[i + half]), fr29_unpack_s(E[i]), t0, t2); CUBIC_ACCUMULATE2(e, t0, t2, cnt); }
   }
-  cubic_epilogue(e, g, partials, counters, out, flag, seq, S, fr29_k5());
+  cubic_epilogue(e, g, partials, counters, out, flag, seq, S, fr29_k5(), NT);
 }
 // fused with K1: bind A and B with r (length n = 4q -> 2q, in place: each element is owned by exactly one thread), then the sums of the NEXT round
 // on the bound values while they are still in registers — one launch per round, 48 bytes per element of A and B plus 32 per index of E.
+template <int NT>
 __global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_eqw_fused(MutPtrTable A, MutPtrTable B, uint32_t nx, uint32_t ny, const fr_t* __restrict__ E, size_t q, fr_t r,
                                                                   fr_t* __restrict__ partials, uint32_t* counters, fr_t* __restrict__ out, uint32_t* flag, uint32_t seq) {
   __shared__ RedScratch S;
@@ -243,16 +260,16 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_eqw_fused(MutPtrTable A, 
     const fr29 b0 = bind29(b[i], b[i + 2 * q], rs), b1 = bind29(b[i + q], b[i + 3 * q], rs);
     b[i] = fr29_pack(b0); b[i + q] = fr29_pack(b1);
     fr29 t0, t2, t3;
-    cubic_eqw_terms(a0, a1, b0, b1, fr29_unpack_s(E[i]), t0, t2, t3);
-    CUBIC_ACCUMULATE(e, t0, t2, t3, cnt);
+    if (NT == 3) { cubic_eqw_terms(a0, a1, b0, b1, fr29_unpack_s(E[i]), t0, t2, t3); CUBIC_ACCUMULATE(e, t0, t2, t3, cnt); }
+    else { cubic_eqw_terms2(a0, a1, b0, b1, fr29_unpack_s(E[i]), t0, t2); CUBIC_ACCUMULATE2(e, t0, t2, cnt); }
   }
-  cubic_epilogue(e, g, partials, counters, out, flag, seq, S, fr29_k5());
+  cubic_epilogue(e, g, partials, counters, out, flag, seq, S, fr29_k5(), NT);
 }
 // Late rounds (q <= 64 indices per circuit): the same round, laid out for LATENCY instead of throughput.  One workgroup per circuit;
 // phase 1 gives every bind its own lane (4q products side by side instead of 4 in a row per thread), phase 2 every weighted value a'[i] E[i mod q],
 // phase 3 every (index, evaluation point), one wave per point; the three sums are 64-row column sums.  BIND = false is the first round of a
 // layer (no challenge yet): phase 1 only unpacks.  Lengths: A, B hold 4q elements when BIND, 2q otherwise.
-template <bool BIND>
+template <bool BIND, int NT>
 __global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_eqw_small(MutPtrTable A, MutPtrTable B, const fr_t* __restrict__ E, uint32_t q, fr_t r, uint32_t* counters, fr_t* __restrict__ out,
                                                                   uint32_t* flag, uint32_t seq) {
   __shared__ fr29 bound[2][128];   // A', B' (2q values each)
@@ -271,12 +288,13 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_eqw_small(MutPtrTable A, 
   __syncthreads();
   if (t < m) ge[t] = fr29_mul(bound[0][t], fr29_unpack_s(E[t < q ? t : t - q]));
   __syncthreads();
-  const uint32_t x = t >> 6, i = t & 63;   // wave x evaluates point {0, 2, 3}[x]
-  if (x < 3) {
+  const uint32_t x = t >> 6, i = t & 63;   // wave x evaluates point {0, 2, 3}[x]  (NT = 2: q(0) and the leading coefficient)
+  if (x < NT) {
     fr29 term = fr29_zero();
     if (i < q) {
       const fr29 g0 = ge[i], g1 = ge[i + q], b0 = bound[1][i], b1 = bound[1][i + q];
       if (x == 0) term = fr29_mul(b0, g0);
+      else if (NT == 2) term = fr29_mul(fr29_sub(g1, g0), fr29_sub(b1, b0));
       else {
         const fr29 dg = fr29_sub(g1, g0), db = fr29_sub(b1, b0);
         const fr29 g2 = fr29_weak(fr29_add(g1, dg)), b2 = fr29_weak(fr29_add(b1, db));
@@ -287,18 +305,18 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_eqw_small(MutPtrTable A, 
     for (int k = 0; k < 9; k++) rows[t * 9 + k] = term.v[k];
   }
   __syncthreads();
-  if (t < 27) {
+  if (t < 9 * NT) {
     const uint32_t v = t / 9, k = t - v * 9;
     int64_t sum = 0;
     for (uint32_t j = 0; j < 64; j++) sum += rows[(v * 64 + j) * 9 + k];
     cols[t] = sum;
   }
   __syncthreads();
-  if (t < 3) {
+  if (t < NT) {
     int64_t c[9];
 #pragma unroll
     for (int k = 0; k < 9; k++) c[k] = cols[t * 9 + k];
-    out[(size_t)y * 3 + t] = fr29_store(fr29_mul(fr29_from_columns(c), fr29_k5()));
+    out[(size_t)y * NT + t] = fr29_store(fr29_mul(fr29_from_columns(c), fr29_k5()));
   }
   row_done(gridDim.x, counters, flag, seq);
 }

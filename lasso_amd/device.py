@@ -125,6 +125,14 @@ class Device:
         self._chk(self.lib.lasso_sumcheck_cubic_eqw_round_fused(self.ctx, self._ptrs(a_ptrs), self._ptrs(b_ptrs), len(a_ptrs), C.c_void_p(d_e), n, _vp(r), _vp(out)))
         return out
 
+    def sumcheck_cubic_eqw2(self, a_ptrs, b_ptrs, d_e, n, r=None):
+        """two-sum eq-weighted round (lasso_sumcheck_cubic_eqw2_begin + lasso_result_wait): rows (q(0), q_inf) per circuit"""
+        rp = None if r is None else _vp(np.ascontiguousarray(r, dtype=np.uint64))
+        out = np.empty((2 * len(a_ptrs), 4), dtype=np.uint64)
+        self._chk(self.lib.lasso_sumcheck_cubic_eqw2_begin(self.ctx, self._ptrs(a_ptrs), self._ptrs(b_ptrs), len(a_ptrs), C.c_void_p(d_e), n, rp))
+        self._chk(self.lib.lasso_result_wait(self.ctx, _vp(out), 2 * len(a_ptrs)))
+        return out
+
     def sumcheck_combine_round(self, strategy, ptrs, d_eq, n, degree):
         out = np.empty((degree + 1, 4), dtype=np.uint64)
         self._chk(self.lib.lasso_sumcheck_combine_round(self.ctx, C.byref(strategy), self._ptrs(ptrs), C.c_void_p(d_eq), n, degree, _vp(out)))

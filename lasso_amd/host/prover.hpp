@@ -607,22 +607,43 @@ class Prover {
         d.chk(lasso_eq_evals_scaled(d.ctx, rr.data(), (uint32_t)rr.size(), &sc, tj.p), "lasso_eq_evals_scaled");
         table = tj.p;
       }
-      std::vector<lasso_fr> ev(3 * k);
-      if (j == 0) {
-        d.chk(lasso_sumcheck_cubic_eqw_round(d.ctx, (const lasso_fr* const*)A.data(), (const lasso_fr* const*)B.data(), (uint32_t)k, table, len, ev.data()), "lasso_sumcheck_cubic_eqw_round");
-      } else {
-        lasso_fr rp = r_prev.abi();
-        d.chk(lasso_sumcheck_cubic_eqw_round_fused(d.ctx, A.data(), B.data(), (uint32_t)k, table, len, &rp, ev.data()), "lasso_sumcheck_cubic_eqw_round_fused");
-        len /= 2;
-      }
-      if (reduce) d.comm.sum(ev);
-      HostClock hc("cubic round host work");
-      // e(x) = s * eq1(rand_j, x) * scale * sum:  eq1(r, x) = (1 - r)(1 - x) + r x  at x = 0, 2, 3
+      // e(x) = f(x) * q(x) with f(x) = s * scale * eq1(rand_j, x), eq1(r, x) = (1 - r)(1 - x) + r x, and q(x) = sum_c coeffs_c q_c(x) quadratic
       const Sc& rj = rand[v0 + j]; const Sc base = s_run * scale, om = Sc::one() - rj;
-      const Sc f0 = base * om, f2 = base * (rj + rj - om), f3 = base * (rj + rj + rj - om - om);
-      Sc c0 = Sc::zero(), c2 = Sc::zero(), c3 = Sc::zero();
-      for (size_t i = 0; i < k; i++) { c0 += Sc::from_abi(ev[3 * i]) * coeffs[i]; c2 += Sc::from_abi(ev[3 * i + 1]) * coeffs[i]; c3 += Sc::from_abi(ev[3 * i + 2]) * coeffs[i]; }
-      c0 *= f0; c2 *= f2; c3 *= f3;
+      const Sc f0 = base * om, f1 = base * rj, f2 = base * (rj + rj - om), f3 = base * (rj + rj + rj - om - om);
+      Sc c0, c2, c3;
+      static const bool three_sums = [] { const char* v = getenv("LASSO_CUBIC_THREE_SUMS"); return v && v[0] == '1'; }();   // A/B switch for measurements
+      if (!f1.is_zero() && !three_sums) {
+        // two sums per circuit, q_c(0) and the leading coefficient; q(1) follows from the claim e = e(0) + e(1) (sumcheck.rs:99-104 derives e(1)
+        // the same way) and q(2), q(3) by extrapolation.  The inversion of f(1) overlaps the kernel.
+        lasso_fr rp = r_prev.abi();
+        d.chk(lasso_sumcheck_cubic_eqw2_begin(d.ctx, A.data(), B.data(), (uint32_t)k, table, len, j == 0 ? nullptr : &rp), "lasso_sumcheck_cubic_eqw2_begin");
+        if (j) len /= 2;
+        const Sc f1_inv = f1.inverse();
+        std::vector<lasso_fr> ev(2 * k);
+        d.chk(lasso_result_wait(d.ctx, ev.data(), 2 * k), "lasso_result_wait");
+        if (reduce) d.comm.sum(ev);
+        HostClock hc("cubic round host work");
+        Sc q0 = Sc::zero(), qi = Sc::zero();
+        for (size_t i = 0; i < k; i++) { q0 += Sc::from_abi(ev[2 * i]) * coeffs[i]; qi += Sc::from_abi(ev[2 * i + 1]) * coeffs[i]; }
+        c0 = f0 * q0;
+        const Sc q1 = (e - c0) * f1_inv, qi2 = qi + qi;
+        const Sc q2 = q1 + q1 - q0 + qi2, q3 = q2 + q1 - q0 + qi2 + qi2;   // q(2) = 2 q(1) - q(0) + 2 q_inf,  q(3) = 3 q(1) - 2 q(0) + 6 q_inf
+        c2 = f2 * q2; c3 = f3 * q3;
+      } else {   // rand_j = 0 (or a zero running factor): the claim says nothing about q(1); three sums from the device
+        std::vector<lasso_fr> ev(3 * k);
+        if (j == 0) {
+          d.chk(lasso_sumcheck_cubic_eqw_round(d.ctx, (const lasso_fr* const*)A.data(), (const lasso_fr* const*)B.data(), (uint32_t)k, table, len, ev.data()), "lasso_sumcheck_cubic_eqw_round");
+        } else {
+          lasso_fr rp = r_prev.abi();
+          d.chk(lasso_sumcheck_cubic_eqw_round_fused(d.ctx, A.data(), B.data(), (uint32_t)k, table, len, &rp, ev.data()), "lasso_sumcheck_cubic_eqw_round_fused");
+          len /= 2;
+        }
+        if (reduce) d.comm.sum(ev);
+        c0 = Sc::zero(); c2 = Sc::zero(); c3 = Sc::zero();
+        for (size_t i = 0; i < k; i++) { c0 += Sc::from_abi(ev[3 * i]) * coeffs[i]; c2 += Sc::from_abi(ev[3 * i + 1]) * coeffs[i]; c3 += Sc::from_abi(ev[3 * i + 2]) * coeffs[i]; }
+        c0 *= f0; c2 *= f2; c3 *= f3;
+      }
+      HostClock hc2("cubic round host work");
       UniPoly poly = UniPoly::from_evals({c0, e - c0, c2, c3});
       poly.append_to_transcript(t, "poly");
       Sc r_j = t.challenge_scalar("challenge_nextround"); r_out.push_back(r_j);

@@ -41,6 +41,34 @@ int32_t lasso_host_prove(lasso_host* h, lasso_host_dense* d, lasso_host_gens* g,
     P.prove(rv);
     return emit(P.proof_bytes, out, cap, len);)
 }
+// Test support: Prover::prove_cubic_batched (sumcheck.rs:27-135 with C = EqPolynomial(rand).evals(), grand_product.rs:122-128) on caller-supplied
+// arrays with a SCRIPTED eq point, so that the eq points a transcript never produces (rand_t = 0: the claim-derived evaluation is unavailable;
+// rand_t = 1: the table prefix vanishes) can be driven through the device path.  A, B: k arrays of 2^ell elements each, contiguous.
+// out = per round the three compressed coefficients, then the ell challenges, then the k final claims of A and the k of B (32-byte scalars).
+int32_t lasso_host_debug_cubic_batched(lasso_host* h, lasso_host_dense* dn, lasso_host_gens* g, const lasso_strategy* st, size_t k, size_t ell, const lasso_fr* A, const lasso_fr* B,
+                                       const lasso_fr* rand, const lasso_fr* coeffs, const lasso_fr* claim, const char* tl, uint8_t* out, size_t cap, size_t* len) {
+  try {
+    Strategy S(st->kind, st->c, st->log_m, st->log_r);
+    ProofTranscript t(tl); RandomTape tape("unused");
+    Prover P(h->dev, S, *dn->d, g->g, t, tape);
+    const size_t n = (size_t)1 << ell;
+    std::vector<DBuf> bufs; std::vector<lasso_fr*> pa, pb;
+    for (size_t c = 0; c < 2 * k; c++) {
+      bufs.emplace_back(h->dev, n);
+      h->dev.chk(lasso_upload(h->dev.ctx, bufs.back().p, (c < k ? A + c * n : B + (c - k) * n), n * sizeof(lasso_fr)), "lasso_upload");
+      (c < k ? pa : pb).push_back(bufs.back().p);
+    }
+    ScVec rv, cv; for (size_t i = 0; i < ell; i++) rv.push_back(Sc::from_abi(rand[i])); for (size_t i = 0; i < k; i++) cv.push_back(Sc::from_abi(coeffs[i]));
+    DBuf eq(h->dev, n / 2 ? n / 2 : 1);
+    P.eq_half_local(rv, eq.p);
+    ScVec r_out, ca, cb;
+    SumcheckProof sp = P.prove_cubic_batched(Sc::from_abi(*claim), ell, false, pa, pb, eq.p, rv, cv, r_out, ca, cb);
+    ProofWriter w;
+    for (auto& c : sp.compressed_polys) w.sc_arr(c);
+    w.sc_arr(r_out); w.sc_arr(ca); w.sc_arr(cb);
+    return emit(w.b, out, cap, len);
+  } catch (const std::exception& e) { g_err = e.what(); return -1; } catch (...) { g_err = "unknown error"; return -1; }
+}
 void lasso_host_gen_indices(size_t sparsity, size_t memory_size, uint64_t* out) { ChaChaRng rng = ChaChaRng::test_rng(); for (size_t i = 0; i < sparsity; i++) out[i] = rng.next_u64() % memory_size; }
 void lasso_host_gen_random_point(size_t bits, lasso_fr* out) { ChaChaRng rng = ChaChaRng::test_rng(); for (size_t i = 0; i < bits; i++) out[i] = fr_rand(rng).abi(); }
 }

@@ -35,6 +35,7 @@ def declare_prover(lib):
     lib.lasso_host_dense_free.argtypes = [vp]
     lib.lasso_host_commit.argtypes = [vp, vp, vp, sz, C.POINTER(sz)]
     lib.lasso_host_prove.argtypes = [vp, vp, vp, C.POINTER(_abi.Strategy), vp, sz, C.c_char_p, C.c_char_p, vp, sz, C.POINTER(sz)]
+    lib.lasso_host_debug_cubic_batched.argtypes = [vp, vp, vp, C.POINTER(_abi.Strategy), sz, sz, vp, vp, vp, vp, vp, C.c_char_p, vp, sz, C.POINTER(sz)]
     lib.lasso_host_gen_indices.argtypes = [sz, sz, vp]
     lib.lasso_host_gen_random_point.argtypes = [sz, vp]
     return lib
@@ -97,6 +98,16 @@ class HostProver:
     def prove(self, dense, gens, strategy, r, transcript=b"example", tape=b"proof"):
         r = np.ascontiguousarray(r, dtype=np.uint64).reshape(-1, 4)
         return self._bytes_call(self.lib.lasso_host_prove, self.h, dense, gens, C.byref(strategy), r.ctypes.data_as(C.c_void_p), r.shape[0], transcript, tape)
+
+    def debug_cubic_batched(self, dense, gens, strategy, A, B, rand, coeffs, claim, transcript=b"test"):
+        """test support: prove_cubic_batched on caller arrays with a scripted eq point (lasso_host_debug_cubic_batched)"""
+        A = np.ascontiguousarray(A, dtype=np.uint64); B = np.ascontiguousarray(B, dtype=np.uint64)     # (k, 2^ell, 4)
+        k, n = A.shape[0], A.shape[1]; ell = n.bit_length() - 1
+        rand = np.ascontiguousarray(rand, dtype=np.uint64).reshape(-1, 4); coeffs = np.ascontiguousarray(coeffs, dtype=np.uint64).reshape(-1, 4)
+        claim = np.ascontiguousarray(claim, dtype=np.uint64).reshape(4)
+        assert rand.shape[0] == ell and coeffs.shape[0] == k and B.shape == A.shape
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        return self._bytes_call(self.lib.lasso_host_debug_cubic_batched, self.h, dense, gens, C.byref(strategy), k, ell, vp(A), vp(B), vp(rand), vp(coeffs), vp(claim), transcript)
 
     def free(self, dense=None, gens=None):
         if dense:

@@ -113,6 +113,31 @@ int32_t lasso_sumcheck_cubic_eqw_round_fused(lasso_ctx* c, lasso_fr* const* A, l
   for (uint32_t k = 0; k < nc; k++) for (size_t i = 0; i < h; i++) { F(A[k])[i] = F(A[k])[i] + *F(r) * (F(A[k])[i + h] - F(A[k])[i]); F(B[k])[i] = F(B[k])[i] + *F(r) * (F(B[k])[i + h] - F(B[k])[i]); }
   return lasso_sumcheck_cubic_eqw_round(c, A, B, nc, E, h, out);
 }
+// two-sum form: the CPU mock computes at "begin" and hands the result over at "wait"
+static thread_local std::vector<Fr> g_pending;
+int32_t lasso_sumcheck_cubic_eqw2_begin(lasso_ctx* c, lasso_fr* const* A, lasso_fr* const* B, uint32_t nc, const lasso_fr* E, size_t n, const lasso_fr* r) {
+  REQ(c, n >= (r ? 4u : 2u) && (n & (n - 1)) == 0);
+  if (r) {
+    size_t h = n / 2;
+    for (uint32_t k = 0; k < nc; k++) for (size_t i = 0; i < h; i++) { F(A[k])[i] = F(A[k])[i] + *F(r) * (F(A[k])[i + h] - F(A[k])[i]); F(B[k])[i] = F(B[k])[i] + *F(r) * (F(B[k])[i + h] - F(B[k])[i]); }
+    n = h;
+  }
+  const size_t len = n / 2; const Fr* pe = F(E);
+  g_pending.assign(2 * (size_t)nc, Fr::zero());
+  for (uint32_t k = 0; k < nc; k++) {
+    const Fr* pa = F(A[k]); const Fr* pb = F(B[k]);
+    Fr q0 = Fr::zero(), qi = Fr::zero();
+    for (size_t i = 0; i < len; i++) { q0 += pa[i] * pb[i] * pe[i]; qi += (pa[len + i] - pa[i]) * (pb[len + i] - pb[i]) * pe[i]; }
+    g_pending[2 * k] = q0; g_pending[2 * k + 1] = qi;
+  }
+  return 0;
+}
+int32_t lasso_result_wait(lasso_ctx* c, lasso_fr* out, size_t count) {
+  REQ(c, out && count == g_pending.size());
+  for (size_t i = 0; i < count; i++) F(out)[i] = g_pending[i];
+  g_pending.clear();
+  return 0;
+}
 int32_t lasso_sumcheck_combine_round(lasso_ctx* c, const lasso_strategy* s, const lasso_fr* const* polys, const lasso_fr* eq, size_t n, uint32_t degree, lasso_fr* out) {
   REQ(c, n >= 2 && (n & (n - 1)) == 0);
   Strategy S = mk(s); size_t alpha = S.num_memories(), half = n / 2;

@@ -114,6 +114,27 @@ int orc_session_prove(void* sv, uint8_t* out, size_t cap, size_t* len) { GUARD(
   auto P = surge_prove(se->S, se->dense, se->r, se->gens, t, tape);
   auto b = serialize_proof(P);
   *len = b.size(); if (b.size() > cap) return -2; memcpy(out, b.data(), b.size()); return 0; ) }
+// prove_cubic_batched (sumcheck.rs:27-135) on caller-supplied arrays with C = EqPolynomial(rand).evals() (grand_product.rs:122-128) and a scripted
+// eq point: the literal three-polynomial loop.  A, B: k contiguous arrays of 2^ell Montgomery elements.  out = the honest claim, then (same
+// layout as lasso_host_debug_cubic_batched) 3 compressed coefficients per round, the challenges, the final claims of A and of B.
+int orc_cubic_batched(size_t k, size_t ell, const uint64_t* A, const uint64_t* B, const uint64_t* rand, const uint64_t* coeffs, const char* tl, uint8_t* out, size_t cap, size_t* len) { try {
+  const size_t n = (size_t)1 << ell;
+  auto fr_at = [](const uint64_t* p, size_t i) { Fr x; memcpy(&x, p + 4 * i, 32); return x; };
+  std::vector<DensePolynomial> pa, pb;
+  for (size_t c = 0; c < k; c++) { std::vector<Fr> a(n), b(n); for (size_t i = 0; i < n; i++) { a[i] = fr_at(A, c * n + i); b[i] = fr_at(B, c * n + i); } pa.emplace_back(a); pb.emplace_back(b); }
+  std::vector<Fr> rv(ell), cv(k); for (size_t i = 0; i < ell; i++) rv[i] = fr_at(rand, i); for (size_t i = 0; i < k; i++) cv[i] = fr_at(coeffs, i);
+  DensePolynomial pc(EqPolynomial(rv).evals());
+  Fr claim = Fr::zero();
+  for (size_t c = 0; c < k; c++) { Fr sum = Fr::zero(); for (size_t i = 0; i < n; i++) sum += pa[c][i] * pb[c][i] * pc[i]; claim += sum * cv[c]; }
+  std::vector<DensePolynomial*> ap, bp; for (size_t c = 0; c < k; c++) { ap.push_back(&pa[c]); bp.push_back(&pb[c]); }
+  MerlinTranscript t(tl);
+  std::vector<Fr> r_out; CubicClaims cl;
+  SumcheckInstanceProof sp = prove_cubic_batched(claim, ell, ap, bp, pc, cv, t, r_out, cl);
+  ByteWriter w; w.fr(claim);
+  for (auto& c : sp.compressed_polys) w.frs_arr(c.coeffs_except_linear_term);
+  w.frs_arr(r_out); w.frs_arr(cl.a); w.frs_arr(cl.b);
+  *len = w.b.size(); if (w.b.size() > cap) return -2; memcpy(out, w.b.data(), w.b.size()); return 0;
+  } catch (const std::exception& e) { g_err = e.what(); return -1; } }
 // returns 1 = verified, 0 = rejected, <0 = error
 int orc_session_verify(void* sv, const uint8_t* proof, size_t n) { GUARD(
   Session* se = (Session*)sv;

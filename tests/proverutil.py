@@ -61,3 +61,37 @@ class OracleSession:
     def close(self):
         if self.s:
             self.o.orc_session_free(C.c_void_p(self.s)); self.s = None
+
+
+def cubic_batched_case(host, oracle, k, ell, special, seed):
+    """prove_cubic_batched with a scripted eq point: the host prover's eq-weighted two-sum rounds (device ABI) against the oracle's literal
+    three-polynomial loop (sumcheck.rs:27-135).  `special` maps round -> 0 or 1: rand_t = 0 disables the claim-derived evaluation (three-sum
+    fallback), rand_t = 1 makes the eq table's prefix vanish (explicit tables)."""
+    from gpuutil import rand_fr
+    from fieldref import L as FR_P, limbs, to_mont
+    rng = np.random.default_rng(seed)
+    n = 1 << ell
+    A = np.stack([rand_fr(rng, n) for _ in range(k)]); B = np.stack([rand_fr(rng, n) for _ in range(k)])
+    rand = rand_fr(rng, max(ell, 1), edge=False)[:ell]
+    for t, v in special.items():
+        if t < ell:
+            rand[t] = np.array(limbs(to_mont(v, FR_P)), dtype=np.uint64)
+    coeffs = rand_fr(rng, k, edge=False)
+    oracle.orc_cubic_batched.argtypes = [C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    cap = 1 << 16; buf = (C.c_uint8 * cap)(); ln = C.c_size_t()
+    vp = lambda a: np.ascontiguousarray(a).ctypes.data_as(C.c_void_p)
+    Ac, Bc, rc_, cc = (np.ascontiguousarray(x) for x in (A, B, rand, coeffs))
+    rc = oracle.orc_cubic_batched(k, ell, vp(Ac), vp(Bc), vp(rc_), vp(cc), b"test", buf, cap, C.byref(ln))
+    assert rc == 0, oracle.orc_last_error().decode()
+    want = bytes(buf[: ln.value])
+    from fieldref import to_mont as tm
+    claim_int = int.from_bytes(want[:32], "little")
+    claim = np.array(limbs(tm(claim_int, FR_P)), dtype=np.uint64)
+    S = _abi.Strategy(_abi.KINDS["and"], 1, 4, 0)
+    gens = host.gens(1, 4, 1, 4)
+    dense = host.densify(np.zeros((4, 1), dtype=np.uint64), 4)
+    try:
+        got = host.debug_cubic_batched(dense, gens, S, A, B, rand, coeffs, claim)
+    finally:
+        host.free(dense, gens)
+    assert got == want[32:]

@@ -390,6 +390,43 @@ def test_sumcheck_cubic_eqw_round_fused(devs, n, ncirc):
     assert np.array_equal(bound(devs[0]), a[2][0])
 
 
+@pytest.mark.parametrize("n,ncirc", [(2, 1), (4, 1), (8, 2), (32, 33), (256, 5), (512, 2), (1 << 10, 2), (1 << 14, 8), (1 << 17, 3)])
+def test_sumcheck_cubic_eqw2(devs, n, ncirc):
+    """two-sum form of the eq-weighted round (begin + wait): (q(0), q_inf) per circuit, with and without the fused bind; q(0) must equal the
+    three-sum form's value at 0 and q_inf must reproduce its values at 2 and 3 through q(x) = q(0) + (q(1) - q(0) - q_inf) x + q_inf x^2"""
+    rng = np.random.default_rng(n * 11 + ncirc)
+    A = [rand_fr(rng, n) for _ in range(ncirc)]
+    B = [rand_fr(rng, n) for _ in range(ncirc)]
+    E = rand_fr(rng, max(n // 2, 1))
+    r = rand_fr(rng, 1, edge=False)[0]
+
+    def run(d):
+        pa = [d.upload(x) for x in A]; pb = [d.upload(x) for x in B]; pe = d.upload(E)
+        first = d.sumcheck_cubic_eqw2(pa, pb, pe, n)
+        three = d.sumcheck_cubic_eqw_round(pa, pb, pe, n)
+        res = [first, three]
+        if n >= 4:
+            res.append(d.sumcheck_cubic_eqw2(pa, pb, pe, n, r))
+            res.append(d.sumcheck_cubic_eqw_round(pa, pb, pe, n // 2))
+            res.append(np.stack([d.download(p, (n // 2, 4)) for p in pa + pb]))
+        for p in pa + pb + [pe]:
+            d.free(p)
+        return res
+    a, b = both(devs, run)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    # consistency with the three-sum form, in exact arithmetic on the host
+    from fieldref import from_mont, unlimbs
+    def ints(rows): return [from_mont(unlimbs(row), FR_P) for row in rows]
+    for two, three in ([(a[0], a[1])] + ([(a[2], a[3])] if n >= 4 else [])):
+        t2, t3 = ints(two), ints(three)
+        for c in range(ncirc):
+            q0, qi = t2[2 * c], t2[2 * c + 1]
+            assert q0 == t3[3 * c]
+            # q(2) = q0 + 2 l + 4 qi, q(3) = q0 + 3 l + 9 qi  =>  eliminate the linear coefficient l: 3 q(2) - 2 q(3) = q0 - 6 qi
+            assert (3 * t3[3 * c + 1] - 2 * t3[3 * c + 2] - q0 + 6 * qi) % FR_P == 0
+
+
 @pytest.mark.parametrize("n_lookups,c,log_m,mode", [(1, 1, 0, "rand"), (2, 1, 1, "rand"), (5, 2, 4, "rand"), (1000, 3, 8, "rand"), (4096, 1, 16, "rand"), (5000, 2, 12, "rand"),
                                                      (1 << 16, 1, 16, "rand"), (70000, 1, 17, "rand"), (9000, 1, 16, "same"), (1 << 15, 2, 3, "rand"), (12345, 1, 9, "sorted")])
 def test_densify_dim(devs, n_lookups, c, log_m, mode):

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from lasso_amd import _abi
-from proverutil import OracleSession
+from proverutil import OracleSession, cubic_batched_case
 
 pytestmark = pytest.mark.gpu
 
@@ -145,3 +145,11 @@ def test_gpu_slab_proof_bit_exact(host, oracle, world, kind, c, log_m, log_r, lo
         assert orc.verify(proof_p, comm_p) == 1
     finally:
         orc.close()
+
+
+@pytest.mark.parametrize("k,ell,special", [(1, 1, {}), (2, 3, {}), (3, 5, {0: 0}), (2, 5, {2: 0}), (2, 5, {1: 1}), (1, 6, {0: 0, 1: 1, 2: 0, 5: 1}), (2, 8, {7: 0}), (33, 2, {1: 0}),
+                                          (2, 12, {}), (2, 12, {0: 1, 3: 0, 11: 0}), (4, 14, {5: 0})])
+def test_gpu_cubic_batched_scripted_eq_points(host, oracle, k, ell, special):
+    """the two-sum rounds, the three-sum fallback (rand_t = 0) and the explicit-table path (rand_t = 1) on the device kernels, all sizes
+    (latency-shaped and streaming kernels), against the oracle's literal loop"""
+    cubic_batched_case(host, oracle, k, ell, special, seed=k * 100 + ell)

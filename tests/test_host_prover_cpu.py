@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from lasso_amd import _abi
-from proverutil import HostProver, OracleSession, build_mock_prover
+from proverutil import HostProver, OracleSession, build_mock_prover, cubic_batched_case
 
 # (kind, C, log_m, log_r, lookups) — the reference's e2e_test.rs configurations first
 CASES = [("lt", 4, 4, 0, 16), ("lt", 4, 4, 0, 128), ("and", 4, 4, 0, 16), ("range", 3, 8, 40, 16),
@@ -60,3 +60,9 @@ def test_proof_bytes_equal_oracle_and_verify(host, oracle, kind, c, log_m, log_r
             pass
     finally:
         orc.close()
+
+
+@pytest.mark.parametrize("k,ell,special", [(1, 1, {}), (2, 3, {}), (3, 5, {0: 0}), (2, 5, {2: 0}), (2, 4, {3: 0}), (2, 5, {1: 1}), (1, 6, {0: 0, 1: 1, 2: 0, 5: 1}), (2, 8, {7: 0}),
+                                          (33, 2, {1: 0}), (2, 9, {}), (2, 9, {0: 1, 8: 0})])
+def test_cubic_batched_scripted_eq_points(host, oracle, k, ell, special):
+    cubic_batched_case(host, oracle, k, ell, special, seed=k * 100 + ell)
