@@ -120,6 +120,49 @@ LHD fr29 fr29_mul(const fr29& a, const fr29& b) {
   return r;
 }
 
+// ---- sums of products without a reduction per product.  acc is the 17-column double-width value (29-bit columns, signed 64-bit);
+// fr29_mul_acc adds a*b into it with the same 81 multiply-adds fr29_mul starts with and nothing else.  One product adds < 9 * 2^58 to a column
+// when |a.v|, |b.v| <= 2^29, so up to THREE products may be added between two fr29_acc_carry passes (which bring columns 0..15 back to
+// [0, 2^29) and let column 16 absorb the carries).  fr29_acc_reduce finishes with the Montgomery reduction: the sum / 2^261 (mod p), reduced,
+// correct for sums of up to 2^20 products.
+LHD fr29 fr29_from_columns(const int64_t* col);
+struct fr29_acc { int64_t h[17]; };
+LHD fr29_acc fr29_acc_zero() { fr29_acc r;
+#pragma unroll
+  for (int k = 0; k < 17; k++) r.h[k] = 0; return r; }
+LHD void fr29_mul_acc(fr29_acc& acc, const fr29& a, const fr29& b) {
+#pragma unroll
+  for (int i = 0; i < 9; i++)
+#pragma unroll
+    for (int j = 0; j < 9; j++) acc.h[i + j] += (int64_t)a.v[i] * b.v[j];
+}
+LHD void fr29_acc_carry(fr29_acc& acc) {
+#pragma unroll
+  for (int k = 0; k < 16; k++) { acc.h[k + 1] += acc.h[k] >> 29; acc.h[k] &= FR29_MASK; }
+}
+LHD fr29 fr29_acc_reduce(const fr29_acc& acc) {
+  int64_t h[17];
+#pragma unroll
+  for (int k = 0; k < 17; k++) h[k] = acc.h[k];
+#pragma unroll
+  for (int k = 0; k < 9; k++) {
+    const int32_t m = (int32_t)(((uint32_t)h[k] * FR29_PINV) & FR29_MASK);
+    h[k] += (int64_t)m * FR29_P0;
+    h[k + 1] += (int64_t)m * FR29_P1;
+    h[k + 2] += (int64_t)m * FR29_P2;
+    h[k + 3] += (int64_t)m * FR29_P3;
+    h[k + 4] += (int64_t)m * FR29_P4;
+    h[k + 8] += (int64_t)m << 20;
+    h[k + 1] += h[k] >> 29;          // exact
+  }
+  // columns 9..16 hold the quotient as eight 64-bit columns (column 16 carries the accumulated magnitude): fold through 2^261 = ONE_S
+  int64_t col[9];
+#pragma unroll
+  for (int k = 0; k < 8; k++) col[k] = h[9 + k];
+  col[8] = 0;
+  return fr29_from_columns(col);
+}
+
 // |value| < 4p (any limbs with |.| < 2^31) -> the canonical representative in [0, p), limbs in [0, 2^29)
 LHD fr29 fr29_canonical(const fr29& a) {
   const int32_t P[9] = {FR29_P0, FR29_P1, FR29_P2, FR29_P3, FR29_P4, 0, 0, 0, 1 << 20};

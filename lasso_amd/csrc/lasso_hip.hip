@@ -241,6 +241,7 @@ int32_t lasso_bind_top(lasso_ctx* c, lasso_fr* const* d_polys, uint32_t npolys, 
 // for both the cubic (ny = 2) and the linear (ny = 1) rounds, although in isolation on constant data 1024 is 6% faster (profiles/r01_microbench_v2.txt); the kernels are VALU-bound
 // and every extra workgroup adds a reduction epilogue), LASSO_CUBIC_NX overrides for experiments
 static unsigned cubic_nx_cap(unsigned ny) { static const long e = [] { const char* v = getenv("LASSO_CUBIC_NX"); return v ? atol(v) : 0L; }(); if (e > 0) return (unsigned)e; unsigned c = 512 / (ny ? ny : 1); return c < 64 ? 64 : c; }
+static bool cubic_wide() { static const bool on = [] { const char* v = getenv("LASSO_CUBIC_WIDE"); return !(v && v[0] == '0'); }(); return on; }   // double-width accumulators in the two-sum fused round (A/B switch)
 #define CUBIC_SMALL_Q 64   // rounds with at most this many indices per circuit take the latency-shaped kernel
 // the reference's loop with an explicit third polynomial (any C): kept as the literal counterpart of sumcheck.rs:49-93
 int32_t lasso_sumcheck_cubic_round(lasso_ctx* c, const lasso_fr* const* d_A, const lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_C, size_t n, lasso_fr* out) {
@@ -291,7 +292,8 @@ static int32_t cubic_eqw_launch(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* co
       const unsigned ny = ncirc, nx = grid_for(q, cubic_nx_cap(ny));
       rc = ensure_scratch(c, (size_t)nx * ny * 3 * sizeof(fr_t)); if (rc) return rc;
       if (NT == 3) hipLaunchKernelGGL(k_cubic_eqw_fused<3>, dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, A, B, nx, ny, (const fr_t*)d_E, q, to_fr(r), (fr_t*)c->d_scratch, c->d_counters, c->d_small, c->d_flag, seq);
-      else hipLaunchKernelGGL(k_cubic_eqw_fused<2>, dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, A, B, nx, ny, (const fr_t*)d_E, q, to_fr(r), (fr_t*)c->d_scratch, c->d_counters, c->d_small, c->d_flag, seq);
+      else if (cubic_wide()) hipLaunchKernelGGL((k_cubic_eqw_fused<2, true>), dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, A, B, nx, ny, (const fr_t*)d_E, q, to_fr(r), (fr_t*)c->d_scratch, c->d_counters, c->d_small, c->d_flag, seq);
+      else hipLaunchKernelGGL((k_cubic_eqw_fused<2, false>), dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, A, B, nx, ny, (const fr_t*)d_E, q, to_fr(r), (fr_t*)c->d_scratch, c->d_counters, c->d_small, c->d_flag, seq);
     }
   }
   HIPCHK(c, hipGetLastError());

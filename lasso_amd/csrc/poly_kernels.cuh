@@ -236,16 +236,23 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_eqw_lb(PtrTable A, PtrTab
   const fr_t* __restrict__ a = A.p[g.by];
   const fr_t* __restrict__ b = B.p[g.by];
   fr29 e[3] = {fr29_zero(), fr29_zero(), fr29_zero()}; uint32_t cnt = 0;
+  fr29_acc w0 = fr29_acc_zero(), w1 = fr29_acc_zero();
   for (size_t i = g.bx * (size_t)blockDim.x + threadIdx.x; i < half; i += (size_t)nx * blockDim.x) {
     fr29 t0, t2, t3;
     if (NT == 3) { cubic_eqw_terms(fr29_unpack_u(a[i]), fr29_unpack_u(a[i + half]), fr29_unpack_u(b[i]), fr29_unpack_u(b[i + half]), fr29_unpack_s(E[i]), t0, t2, t3); CUBIC_ACCUMULATE(e, t0, t2, t3, cnt); }
-    else { cubic_eqw_terms2(fr29_unpack_u(a[i]), fr29_unpack_u(a[i + half]), fr29_unpack_u(b[i]), fr29_unpack_u(b[i + half]), fr29_unpack_s(E[i]), t0, t2); CUBIC_ACCUMULATE2(e, t0, t2, cnt); }
+    else {
+      const fr29 es = fr29_unpack_s(E[i]), b0 = fr29_unpack_u(b[i]), b1 = fr29_unpack_u(b[i + half]);
+      const fr29 g0 = fr29_mul(fr29_unpack_u(a[i]), es), g1 = fr29_mul(fr29_unpack_u(a[i + half]), es);
+      fr29_mul_acc(w0, b0, g0); fr29_mul_acc(w1, fr29_sub(g1, g0), fr29_sub(b1, b0));
+      if (++cnt == 3) { fr29_acc_carry(w0); fr29_acc_carry(w1); cnt = 0; }
+    }
   }
+  if (NT == 2) { fr29_acc_carry(w0); fr29_acc_carry(w1); e[0] = fr29_acc_reduce(w0); e[1] = fr29_acc_reduce(w1); }
   cubic_epilogue(e, g, partials, counters, out, flag, seq, S, fr29_k5(), NT);
 }
 // fused with K1: bind A and B with r (length n = 4q -> 2q, in place: each element is owned by exactly one thread), then the sums of the NEXT round
 // on the bound values while they are still in registers — one launch per round, 48 bytes per element of A and B plus 32 per index of E.
-template <int NT>
+template <int NT, bool WIDE = false>
 __global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_eqw_fused(MutPtrTable A, MutPtrTable B, uint32_t nx, uint32_t ny, const fr_t* __restrict__ E, size_t q, fr_t r,
                                                                   fr_t* __restrict__ partials, uint32_t* counters, fr_t* __restrict__ out, uint32_t* flag, uint32_t seq) {
   __shared__ RedScratch S;
@@ -254,6 +261,7 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_eqw_fused(MutPtrTable A, 
   fr_t* __restrict__ b = B.p[g.by];
   const fr29 rs = fr29_unpack_s(r);
   fr29 e[3] = {fr29_zero(), fr29_zero(), fr29_zero()}; uint32_t cnt = 0;
+  fr29_acc w0 = fr29_acc_zero(), w1 = fr29_acc_zero();
   for (size_t i = g.bx * (size_t)blockDim.x + threadIdx.x; i < q; i += (size_t)nx * blockDim.x) {
     const fr29 a0 = bind29(a[i], a[i + 2 * q], rs), a1 = bind29(a[i + q], a[i + 3 * q], rs);
     a[i] = fr29_pack(a0); a[i + q] = fr29_pack(a1);
@@ -261,8 +269,16 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_eqw_fused(MutPtrTable A, 
     b[i] = fr29_pack(b0); b[i + q] = fr29_pack(b1);
     fr29 t0, t2, t3;
     if (NT == 3) { cubic_eqw_terms(a0, a1, b0, b1, fr29_unpack_s(E[i]), t0, t2, t3); CUBIC_ACCUMULATE(e, t0, t2, t3, cnt); }
-    else { cubic_eqw_terms2(a0, a1, b0, b1, fr29_unpack_s(E[i]), t0, t2); CUBIC_ACCUMULATE2(e, t0, t2, cnt); }
+    else if (!WIDE) { cubic_eqw_terms2(a0, a1, b0, b1, fr29_unpack_s(E[i]), t0, t2); CUBIC_ACCUMULATE2(e, t0, t2, cnt); }
+    else {
+      // the two sums are sums of PRODUCTS: add the double-width products and reduce once per thread (fr29_mul_acc)
+      const fr29 es = fr29_unpack_s(E[i]);
+      const fr29 g0 = fr29_mul(a0, es), g1 = fr29_mul(a1, es);
+      fr29_mul_acc(w0, b0, g0); fr29_mul_acc(w1, fr29_sub(g1, g0), fr29_sub(b1, b0));
+      if (++cnt == 3) { fr29_acc_carry(w0); fr29_acc_carry(w1); cnt = 0; }
+    }
   }
+  if (WIDE && NT == 2) { fr29_acc_carry(w0); fr29_acc_carry(w1); e[0] = fr29_acc_reduce(w0); e[1] = fr29_acc_reduce(w1); }
   cubic_epilogue(e, g, partials, counters, out, flag, seq, S, fr29_k5(), NT);
 }
 // Late rounds (q <= 64 indices per circuit): the same round, laid out for LATENCY instead of throughput.  One workgroup per circuit;
@@ -332,13 +348,15 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_dot_eqw_lb(PtrTable polys, uint
   __shared__ RedScratch S;
   const CubicGrid g = cubic_grid(nx, ny);
   const fr_t* __restrict__ z = polys.p[g.by];
-  fr29 e[3] = {fr29_zero(), fr29_zero(), fr29_zero()}; uint32_t cnt = 0;
+  fr29_acc w0 = fr29_acc_zero(), w1 = fr29_acc_zero(); uint32_t cnt = 0;   // two dot products: double-width accumulation (fr29_mul_acc)
   for (size_t i = g.bx * (size_t)blockDim.x + threadIdx.x; i < half; i += (size_t)nx * blockDim.x) {
     const fr29 es = fr29_unpack_s(E[i]);
-    e[0] = fr29_weak(fr29_add(e[0], fr29_mul(fr29_unpack_u(z[i]), es)));
-    e[1] = fr29_weak(fr29_add(e[1], fr29_mul(fr29_unpack_u(z[i + half]), es)));
-    if ((++cnt & 127u) == 0) { e[0] = fr29_mul(e[0], fr29_one_s()); e[1] = fr29_mul(e[1], fr29_one_s()); }
+    fr29_mul_acc(w0, fr29_unpack_u(z[i]), es);
+    fr29_mul_acc(w1, fr29_unpack_u(z[i + half]), es);
+    if (++cnt == 3) { fr29_acc_carry(w0); fr29_acc_carry(w1); cnt = 0; }
   }
+  fr29_acc_carry(w0); fr29_acc_carry(w1);
+  fr29 e[3] = {fr29_acc_reduce(w0), fr29_acc_reduce(w1), fr29_zero()};
   cubic_epilogue(e, g, partials, counters, out, flag, seq, S, fr29_one_s());
 }
 __global__ void __launch_bounds__(LASSO_BLOCK) k_dot_eqw_fused(MutPtrTable polys, uint32_t nx, uint32_t ny, const fr_t* __restrict__ E, size_t q, fr_t r, fr_t* __restrict__ partials, uint32_t* counters,
@@ -347,15 +365,17 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_dot_eqw_fused(MutPtrTable polys
   const CubicGrid g = cubic_grid(nx, ny);
   fr_t* __restrict__ z = polys.p[g.by];
   const fr29 rs = fr29_unpack_s(r);
-  fr29 e[3] = {fr29_zero(), fr29_zero(), fr29_zero()}; uint32_t cnt = 0;
+  fr29_acc w0 = fr29_acc_zero(), w1 = fr29_acc_zero(); uint32_t cnt = 0;
   for (size_t i = g.bx * (size_t)blockDim.x + threadIdx.x; i < q; i += (size_t)nx * blockDim.x) {
     const fr29 z0 = bind29(z[i], z[i + 2 * q], rs), z1 = bind29(z[i + q], z[i + 3 * q], rs);
     z[i] = fr29_pack(z0); z[i + q] = fr29_pack(z1);
     const fr29 es = fr29_unpack_s(E[i]);
-    e[0] = fr29_weak(fr29_add(e[0], fr29_mul(z0, es)));
-    e[1] = fr29_weak(fr29_add(e[1], fr29_mul(z1, es)));
-    if ((++cnt & 127u) == 0) { e[0] = fr29_mul(e[0], fr29_one_s()); e[1] = fr29_mul(e[1], fr29_one_s()); }
+    fr29_mul_acc(w0, z0, es);
+    fr29_mul_acc(w1, z1, es);
+    if (++cnt == 3) { fr29_acc_carry(w0); fr29_acc_carry(w1); cnt = 0; }
   }
+  fr29_acc_carry(w0); fr29_acc_carry(w1);
+  fr29 e[3] = {fr29_acc_reduce(w0), fr29_acc_reduce(w1), fr29_zero()};
   cubic_epilogue(e, g, partials, counters, out, flag, seq, S, fr29_one_s());
 }
 
@@ -452,8 +472,14 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_multi_dot(PtrTable polys, uint3
   __shared__ RedScratch R;
   const CubicGrid g = cubic_grid(nx, ny);
   const fr_t* __restrict__ z = polys.p[g.by];
-  fr29 acc[1] = {fr29_zero()}; uint32_t cnt = 0;
-  for (size_t i = g.bx * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)nx * blockDim.x) acc_add(acc[0], fr29_mul(fr29_unpack_u(z[i]), fr29_unpack_s(w[i])), cnt);
+  // a sum of products: double-width accumulation, one Montgomery reduction per thread (fr29_mul_acc)
+  fr29_acc wa = fr29_acc_zero(); uint32_t cnt = 0;
+  for (size_t i = g.bx * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)nx * blockDim.x) {
+    fr29_mul_acc(wa, fr29_unpack_u(z[i]), fr29_unpack_s(w[i]));
+    if (++cnt == 3) { fr29_acc_carry(wa); cnt = 0; }
+  }
+  fr29_acc_carry(wa);
+  fr29 acc[1] = {fr29_acc_reduce(wa)};
   store_block_partials<1>(acc, 1, partials + (size_t)g.by * nx + g.bx, fr29_one_s(), R);
 }
 
@@ -537,9 +563,13 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_matvec_left(const fr_t* __restr
   size_t col = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (col >= r_size) return;
   size_t j0 = (size_t)blockIdx.y * rows_per_chunk, j1 = j0 + rows_per_chunk; if (j1 > l_size) j1 = l_size;
-  fr29 acc = fr29_zero(); uint32_t cnt = 0;
-  for (size_t j = j0; j < j1; j++) acc_add(acc, fr29_mul(fr29_unpack_u(Z[j * r_size + col]), fr29_unpack_s(Lv[j])), cnt);
-  partials[(size_t)blockIdx.y * r_size + col] = fr29_store(fr29_mul(acc, fr29_one_s()));
+  fr29_acc wa = fr29_acc_zero(); uint32_t cnt = 0;   // sum of products: reduce once (fr29_mul_acc)
+  for (size_t j = j0; j < j1; j++) {
+    fr29_mul_acc(wa, fr29_unpack_u(Z[j * r_size + col]), fr29_unpack_s(Lv[j]));
+    if (++cnt == 3) { fr29_acc_carry(wa); cnt = 0; }
+  }
+  fr29_acc_carry(wa);
+  partials[(size_t)blockIdx.y * r_size + col] = fr29_store(fr29_mul(fr29_acc_reduce(wa), fr29_one_s()));
 }
 __global__ void __launch_bounds__(LASSO_BLOCK) k_matvec_reduce(const fr_t* __restrict__ partials, size_t nchunks, size_t r_size, fr_t* __restrict__ out) {
   size_t col = blockIdx.x * (size_t)blockDim.x + threadIdx.x;

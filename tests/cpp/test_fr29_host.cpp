@@ -69,6 +69,24 @@ int main() {
     }
     CHECK(same(fr29_store(fr29_mul(e, fr29_one_s())), ref));
   }
+  // sums of products through the double-width accumulator (fr29_mul_acc / fr29_acc_carry / fr29_acc_reduce): carry pass every third product,
+  // signed differences as operands (the cubic rounds' leading-coefficient term), T up to 2^16, vs the reference sum of Montgomery products
+  for (int T : {1, 2, 3, 4, 255, 4096, 65536}) {
+    fr29_acc w = fr29_acc_zero(), wd = fr29_acc_zero(); fr_t ref = fr_zero(), refd = fr_zero(); int pend = 0;
+    for (int i = 0; i < T; i++) {
+      const fr_t &a = xs[(size_t)i % N], &b = xs[((size_t)i * 13 + 1) % N], &c = xs[((size_t)i * 5 + 2) % N], &d = xs[((size_t)i * 3 + 4) % N];
+      const fr29 au = fr29_unpack_u(a), bu = fr29_unpack_u(b), cu = fr29_unpack_u(c), du = fr29_unpack_u(d);
+      fr29_mul_acc(w, au, fr29_mul(bu, fr29_unpack_s(c)));                  // canonical x reduced product
+      fr29_mul_acc(wd, fr29_sub(au, bu), fr29_sub(cu, du));                 // differences: |limb| < 2^29, both signs
+      if (++pend == 3) { fr29_acc_carry(w); fr29_acc_carry(wd); pend = 0; }
+      ref = fr_add(ref, fr_mul(a, fr_mul(b, c)));
+      refd = fr_add(refd, fr_mul(fr_sub(a, b), fr_sub(c, d)));
+    }
+    fr29_acc_carry(w); fr29_acc_carry(wd);
+    // u * u products are 2^5 short of memory form: K5 restores it (as the kernels do once per block)
+    CHECK(same(fr29_store(fr29_mul(fr29_acc_reduce(w), fr29_k5())), ref));
+    CHECK(same(fr29_store(fr29_mul(fr29_acc_reduce(wd), fr29_k5())), refd));
+  }
   printf("OK\n");
   return 0;
 }

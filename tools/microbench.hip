@@ -194,8 +194,12 @@ int main(int argc, char** argv) {
       CK(hipMemset(a0, 0x07, n * 32)); CK(hipMemset(b0, 0x05, n * 32)); CK(hipMemset(a1, 0x03, n * 32)); CK(hipMemset(b1, 0x02, n * 32));
       MutPtrTable A, B; A.p[0] = a0; A.p[1] = a1; B.p[0] = b0; B.p[1] = b1;
       for (unsigned nx : {128u, 256u, 512u}) {
-        ms = time_kernel([&] { hipLaunchKernelGGL(k_cubic_eqw_fused, dim3(nx * 2), dim3(256), 0, 0, A, B, nx, 2u, (const fr_t*)z, n / 4, r, part, counters, small, (uint32_t*)nullptr, 0u); });
-        printf("  n=2^%d fused bind + eq-weighted cubic round, k=2, nx=%u: %7.3f ms  alg (48 n (2k+1)) %7.1f GB/s  (%.1f G montmul/s)\n", logn, nx, ms, n * 48.0 * 5 / (ms * 1e-3) * 1e-9, (n / 4) * 2 * 9.0 / (ms * 1e-3) * 1e-9);
+        ms = time_kernel([&] { hipLaunchKernelGGL((k_cubic_eqw_fused<3, false>), dim3(nx * 2), dim3(256), 0, 0, A, B, nx, 2u, (const fr_t*)z, n / 4, r, part, counters, small, (uint32_t*)nullptr, 0u); });
+        printf("  n=2^%d fused bind + eq-weighted cubic round (3 sums), k=2, nx=%u: %7.3f ms  alg (48 n (2k+1)) %7.1f GB/s\n", logn, nx, ms, n * 48.0 * 5 / (ms * 1e-3) * 1e-9);
+        ms = time_kernel([&] { hipLaunchKernelGGL((k_cubic_eqw_fused<2, false>), dim3(nx * 2), dim3(256), 0, 0, A, B, nx, 2u, (const fr_t*)z, n / 4, r, part, counters, small, (uint32_t*)nullptr, 0u); });
+        printf("  n=2^%d fused bind + eq-weighted cubic round (2 sums), k=2, nx=%u: %7.3f ms  alg (48 n (2k+1)) %7.1f GB/s\n", logn, nx, ms, n * 48.0 * 5 / (ms * 1e-3) * 1e-9);
+        ms = time_kernel([&] { hipLaunchKernelGGL((k_cubic_eqw_fused<2, true>), dim3(nx * 2), dim3(256), 0, 0, A, B, nx, 2u, (const fr_t*)z, n / 4, r, part, counters, small, (uint32_t*)nullptr, 0u); });
+        printf("  n=2^%d fused bind + eq-weighted cubic round (2 sums, double-width accumulators), k=2, nx=%u: %7.3f ms  alg (48 n (2k+1)) %7.1f GB/s\n", logn, nx, ms, n * 48.0 * 5 / (ms * 1e-3) * 1e-9);
       }
       CK(hipFree(a0)); CK(hipFree(b0)); CK(hipFree(a1)); CK(hipFree(b1)); CK(hipFree(part)); CK(hipFree(small)); CK(hipFree(counters));
     }
