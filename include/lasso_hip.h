@@ -117,6 +117,12 @@ int32_t lasso_sumcheck_cubic_eqw_round_fused(lasso_ctx* ctx, lasso_fr* const* d_
 int32_t lasso_sumcheck_cubic_eqw2_begin(lasso_ctx* ctx, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n,
                                         const lasso_fr* r);
 int32_t lasso_result_wait(lasso_ctx* ctx, lasso_fr* out, size_t count);
+/* Launch/wait split for any call whose result comes back through the mapped result buffer (sumcheck rounds, MSMs of up to 16 rows,
+ * lasso_bullet_round, lasso_read_heads ...): after lasso_defer_next the NEXT such call returns right after its launch, ignoring its `out`
+ * argument; lasso_result_wait(ctx, out, count) then delivers the values (count in field-element units; a lasso_point is 4).  The prover uses it
+ * to absorb the opening's a-vector into the transcript (dot_product.rs:196) while the first bullet round runs.  If the next call turns out not to
+ * use the mapped buffer it completes synchronously and lasso_result_wait fails with LASSO_ERR_INVALID (the flag is cleared by either). */
+int32_t lasso_defer_next(lasso_ctx* ctx);
 /* One round of SumcheckInstanceProof::prove_arbitrary (src/subprotocols/sumcheck.rs:165-237) with
  * comb_func = S::combine_lookups_eq (src/subtables/mod.rs:53-57): out[x] = sum_i g(E_1..E_alpha)(x) * eq(x), x = 0..degree.
  * d_polys holds alpha = NUM_MEMORIES device pointers; d_eq is the eq polynomial. */

@@ -44,7 +44,7 @@ struct lasso_ctx {
   fr_t* d_big = nullptr; fr_t* h_big = nullptr; size_t big_cap = 0;   // large results (matvec rows): device buffer + pinned mirror, hipMemcpyAsync
   uint32_t* d_flags = nullptr;
   uint32_t* d_counters = nullptr;                         // arrival tickets of the in-launch reductions (zero between launches)
-  bool pending = false; uint32_t pending_seq = 0; size_t pending_count = 0;   // a *_begin result not yet collected by lasso_result_wait
+  bool pending = false, defer_next = false; uint32_t pending_seq = 0; size_t pending_count = 0;   // a deferred result not yet collected by lasso_result_wait
   uint32_t prof_mask = 0;   // bit k set = kernel family k is bracketed with events
   std::vector<EventPair> events; size_t events_used = 0;
   uint64_t prof_launches[LASSO_K_COUNT] = {0}; double prof_ms[LASSO_K_COUNT] = {0}; double prof_bytes[LASSO_K_COUNT] = {0};
@@ -115,6 +115,7 @@ static inline fr_t to_fr(const lasso_fr* p) { fr_t r; memcpy(r.v, p, 32); return
 // The producer's stores to h_small are ordered before the flag by a system-scope release on the device (k_publish / publish_flag).
 static inline double now_us() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; }
 static int32_t wait_flag(lasso_ctx* c, uint32_t seq, size_t count, lasso_fr* out) {
+  if (c->defer_next) { c->defer_next = false; c->pending = true; c->pending_seq = seq; c->pending_count = count; return 0; }   // lasso_defer_next: collected by lasso_result_wait
   uint64_t spins = 0;
   const double t0 = now_us();
   while (__atomic_load_n(c->h_flag, __ATOMIC_ACQUIRE) != seq) {
@@ -317,6 +318,10 @@ int32_t lasso_sumcheck_cubic_eqw2_begin(lasso_ctx* c, lasso_fr* const* d_A, lass
   c->pending = true; c->pending_seq = seq; c->pending_count = (size_t)ncirc * 2;
   return 0;
 }
+// The next entry point that hands its result over through the mapped buffer (the sumcheck rounds, the few-row MSMs, lasso_bullet_round ...)
+// returns right after its launch; its `out` argument is ignored and lasso_result_wait(ctx, out, count) delivers the same values
+// (count in field-element units: a point is 4).  Lets the host absorb transcript data or do scalar work while the device computes.
+int32_t lasso_defer_next(lasso_ctx* c) { REQUIRE(c, !c->pending && !c->defer_next); c->defer_next = true; return 0; }
 int32_t lasso_result_wait(lasso_ctx* c, lasso_fr* out, size_t count) {
   REQUIRE(c, out && c->pending && count == c->pending_count);
   c->pending = false;

@@ -750,9 +750,15 @@ class Prover {
     // is applied by the same call that computes round k+1's c_L, c_R, L, R (lasso_bullet_round) — one host round trip per round.
     DBuf d_a1(d, n / 2 ? n / 2 : 1), d_b1(d, n / 2 ? n / 2 : 1), d_w0(d, n), d_w1(d, n);
     { Sc one = Sc::one(); d.chk(lasso_upload(d.ctx, d_w0.p, &one, sizeof(lasso_fr)), "lasso_upload"); }
-    compress_one(msm_dev(g, d_a0.p, n), buf); t.append_point_bytes("Cx", buf);  // Cx = <x, G> + 0*h   (commitments.rs:84-93)
-    compress_one(g.Qmul.mul(y), buf); t.append_point_bytes("Cy", buf);                // Cy = y*G_1[0] + 0*h (commitments.rs:78-82)
-    { HostClock hc("opening: append a_vec"); t.append_scalars_bytes("a", a_bytes); }
+    {   // Cx = <x, G> + 0*h (commitments.rs:84-93) on the device while the host computes Cy = y*G_1[0] + 0*h (commitments.rs:78-82)
+      lasso_point cx;
+      d.chk(lasso_defer_next(d.ctx), "lasso_defer_next");
+      d.chk(lasso_msm_dev(d.ctx, g.bases, d_a0.p, n, &cx), "lasso_msm_dev");
+      uint8_t cy[32]; compress_one(g.Qmul.mul(y), cy);
+      d.chk(lasso_result_wait(d.ctx, (lasso_fr*)&cx, 4), "lasso_result_wait");
+      compress_one(Pt::from_abi(cx), buf); t.append_point_bytes("Cx", buf);
+      t.append_point_bytes("Cy", cy);
+    }
     // bullet reduction (bullet.rs:40-154), blind = blind_x + blind_y = 0
     lasso_fr *a_cur = d_a0.p, *a_nxt = d_a1.p, *b_cur = d_b0.p, *b_nxt = d_b1.p, *w_cur = d_w0.p, *w_nxt = d_w1.p;
     Sc blind_fin = Sc::zero(); size_t nk = n, nw = 1, round = 0;
@@ -765,7 +771,11 @@ class Prover {
         d.chk(lasso_bullet_round(d.ctx, g.bases, n, a_cur, b_cur, w_cur, a_nxt, b_nxt, w_nxt, nk, &ua, &uia, blinds, LR), "lasso_bullet_round");
         std::swap(a_cur, a_nxt); std::swap(b_cur, b_nxt); std::swap(w_cur, w_nxt);
       } else {
+        // round 0 needs no challenge: it runs on the device while the host absorbs the a-vector (dot_product.rs:196), the longest message of the opening
+        d.chk(lasso_defer_next(d.ctx), "lasso_defer_next");
         d.chk(lasso_bullet_round(d.ctx, g.bases, n, a_cur, b_cur, w_cur, nullptr, nullptr, nullptr, nk, nullptr, nullptr, blinds, LR), "lasso_bullet_round");
+        { HostClock hc("opening: append a_vec"); t.append_scalars_bytes("a", a_bytes); }
+        d.chk(lasso_result_wait(d.ctx, (lasso_fr*)LR, 8), "lasso_result_wait");
       }
       std::vector<uint8_t> cb; Sc u, u_inv;
       {
@@ -779,6 +789,7 @@ class Prover {
       P.L_vec.insert(P.L_vec.end(), cb.begin(), cb.begin() + 32); P.R_vec.insert(P.R_vec.end(), cb.begin() + 32, cb.end());
       nk /= 2; nw *= 2; round++;
     }
+    if (!have_u) { HostClock hc("opening: append a_vec"); t.append_scalars_bytes("a", a_bytes); }   // n = 1: no round absorbed it
     if (have_u) {   // the last challenge still folds a, b (length 2 -> 1) and the weights
       d.chk(lasso_bullet_fold(d.ctx, a_cur, b_cur, 2, w_cur, nw / 2, w_nxt, &ua, &uia), "lasso_bullet_fold");
       std::swap(w_cur, w_nxt);

@@ -19,6 +19,7 @@ static int32_t fail(lasso_ctx* c, const char* m) { if (c) c->err = m; return LAS
 #define REQ(c, cond) do { if (!(cond)) return fail((c), "invalid argument: " #cond); } while (0)
 static inline const Fr* F(const lasso_fr* p) { return reinterpret_cast<const Fr*>(p); }
 static inline Fr* F(lasso_fr* p) { return reinterpret_cast<Fr*>(p); }
+static thread_local std::vector<Fr> g_pending;   // result of a deferred / *_begin call, handed over by lasso_result_wait
 static Strategy mk(const lasso_strategy* s) { Strategy S; S.kind = (StrategyKind)s->kind; S.C = s->c; S.M = (size_t)1 << s->log_m; S.LOG_R = s->log_r; return S; }
 static void put_point(const Point& p, lasso_point* o) { memcpy(o->x, p.X.v, 32); memcpy(o->y, p.Y.v, 32); memcpy(o->t, p.T.v, 32); memcpy(o->z, p.Z.v, 32); }
 
@@ -114,7 +115,6 @@ int32_t lasso_sumcheck_cubic_eqw_round_fused(lasso_ctx* c, lasso_fr* const* A, l
   return lasso_sumcheck_cubic_eqw_round(c, A, B, nc, E, h, out);
 }
 // two-sum form: the CPU mock computes at "begin" and hands the result over at "wait"
-static thread_local std::vector<Fr> g_pending;
 int32_t lasso_sumcheck_cubic_eqw2_begin(lasso_ctx* c, lasso_fr* const* A, lasso_fr* const* B, uint32_t nc, const lasso_fr* E, size_t n, const lasso_fr* r) {
   REQ(c, n >= (r ? 4u : 2u) && (n & (n - 1)) == 0);
   if (r) {
@@ -244,7 +244,17 @@ int32_t lasso_msm(lasso_ctx* c, const lasso_bases* b, const lasso_fr* scalars, s
   put_point(msm(bases, sc), out); return 0;
 }
 
-int32_t lasso_msm_dev(lasso_ctx* c, const lasso_bases* b, const lasso_fr* scalars, size_t n, lasso_point* out) { return lasso_msm(c, b, scalars, n, out); }
+// lasso_defer_next in the mock: the deferred call computes at once and parks its result for lasso_result_wait (points as 4 field elements each)
+static thread_local bool g_defer = false;
+int32_t lasso_defer_next(lasso_ctx* c) { REQ(c, !g_defer && g_pending.empty()); g_defer = true; return 0; }
+static int32_t deliver_points(const lasso_point* pts, size_t n, lasso_point* out) {
+  if (g_defer) { g_defer = false; g_pending.resize(4 * n); memcpy((void*)g_pending.data(), pts, n * sizeof(lasso_point)); return 0; }
+  memcpy(out, pts, n * sizeof(lasso_point)); return 0;
+}
+int32_t lasso_msm_dev(lasso_ctx* c, const lasso_bases* b, const lasso_fr* scalars, size_t n, lasso_point* out) {
+  lasso_point tmp; int32_t rc = lasso_msm(c, b, scalars, n, &tmp); if (rc) return rc;
+  return deliver_points(&tmp, 1, out);
+}
 int32_t lasso_matvec_left_dev(lasso_ctx* c, const lasso_fr* Z, const lasso_fr* L, size_t ls, size_t rs, lasso_fr* out) { return lasso_matvec_left(c, Z, L, ls, rs, out); }
 int32_t lasso_fr_to_bytes(lasso_ctx*, const lasso_fr* src, size_t n, uint8_t* out) { for (size_t i = 0; i < n; i++) { u64 cc[4]; F(src)[i].to_canonical(cc); memcpy(out + 32 * i, cc, 32); } return 0; }
 int32_t lasso_msm_dev_scaled(lasso_ctx* c, const lasso_bases* b, const lasso_fr* sc, size_t n, const lasso_fr* scale, const lasso_fr* tail, lasso_point* out) {
@@ -287,7 +297,8 @@ int32_t lasso_bullet_round(lasso_ctx* c, const lasso_bases* bs, size_t n, const 
   }
   lasso_fr cc[2]; lasso_inner_products_lr(c, a, b, nk, cc);
   lasso_fr tail[4] = {cc[0], blinds[0], cc[1], blinds[1]};
-  return lasso_bullet_lr(c, bs, n, a, nk, w, tail, out);
+  lasso_point lr[2]; int32_t rc = lasso_bullet_lr(c, bs, n, a, nk, w, tail, lr); if (rc) return rc;
+  return deliver_points(lr, 2, out);
 }
 int32_t lasso_bullet_fold(lasso_ctx*, lasso_fr* a, lasso_fr* b, size_t nk, const lasso_fr* w, size_t nw, lasso_fr* w_out, const lasso_fr* u, const lasso_fr* u_inv) {
   size_t h = nk / 2; Fr uu = *F(u), ui = *F(u_inv);
