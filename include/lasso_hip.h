@@ -123,6 +123,18 @@ int32_t lasso_result_wait(lasso_ctx* ctx, lasso_fr* out, size_t count);
  * to absorb the opening's a-vector into the transcript (dot_product.rs:196) while the first bullet round runs.  If the next call turns out not to
  * use the mapped buffer it completes synchronously and lasso_result_wait fails with LASSO_ERR_INVALID (the flag is cleared by either). */
 int32_t lasso_defer_next(lasso_ctx* ctx);
+/* The tail of prove_cubic_batched (sumcheck.rs:49-133) in one resident kernel: once a layer is down to q <= 256 indices per circuit, the remaining
+ * log2(2q) rounds and the final bind are served without a launch per round — the host posts each challenge into a host-mapped mailbox, the kernel
+ * answers through the mapped result buffer (2.5 us per turn against 6.5 us for a launch, tools/pingpong_bench.hip).
+ *   begin: r == NULL: first round of a layer, arrays of length n = 2q; otherwise bind r first (n = 4q, as lasso_sumcheck_cubic_eqw2_begin).
+ *          Afterwards the first round's sums are pending: lasso_result_wait(ctx, out, 2*ncirc) -> out[2c] = q_c(0), out[2c+1] = q_c,inf.
+ *   next:  posts the round's challenge; pending afterwards: the next round's sums, or — after log2(2q) calls — the bound heads
+ *          out[c] = A_c[0], out[ncirc + c] = B_c[0] (the final claims, sumcheck.rs:126-133).
+ * The arrays in device memory are left as they were (stale): nothing reads a layer's arrays after its sumcheck.  No other call may be made on the
+ * context until the heads have been collected.  A host that stops answering cannot hang the device: every wait in the kernel gives up after 5 s. */
+int32_t lasso_sumcheck_cubic_tail_begin(lasso_ctx* ctx, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n,
+                                        const lasso_fr* r);
+int32_t lasso_sumcheck_cubic_tail_next(lasso_ctx* ctx, const lasso_fr* r);
 /* One round of SumcheckInstanceProof::prove_arbitrary (src/subprotocols/sumcheck.rs:165-237) with
  * comb_func = S::combine_lookups_eq (src/subtables/mod.rs:53-57): out[x] = sum_i g(E_1..E_alpha)(x) * eq(x), x = 0..degree.
  * d_polys holds alpha = NUM_MEMORIES device pointers; d_eq is the eq polynomial. */

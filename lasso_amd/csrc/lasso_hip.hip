@@ -1,6 +1,7 @@
 // liblasso_hip.so — implementation of include/lasso_hip.h for MI355X (gfx950).
 // One context = one device + one HIP stream + scratch.  See the header for the contract of each entry point.
 #include <hip/hip_runtime.h>
+#include <emmintrin.h>
 #include <string>
 #include <vector>
 #include <cstring>
@@ -45,6 +46,7 @@ struct lasso_ctx {
   uint32_t* d_flags = nullptr;
   uint32_t* d_counters = nullptr;                         // arrival tickets of the in-launch reductions (zero between launches)
   bool pending = false, defer_next = false; uint32_t pending_seq = 0; size_t pending_count = 0;   // a deferred result not yet collected by lasso_result_wait
+  bool tail_active = false; uint32_t tail_seq0 = 0, tail_turn = 0, tail_turns = 0, tail_ncirc = 0;   // resident sumcheck-tail kernel (k_cubic_tail); its mailbox = h_flag + 32 (bytes 128..163)
   uint32_t prof_mask = 0;   // bit k set = kernel family k is bracketed with events
   std::vector<EventPair> events; size_t events_used = 0;
   uint64_t prof_launches[LASSO_K_COUNT] = {0}; double prof_ms[LASSO_K_COUNT] = {0}; double prof_bytes[LASSO_K_COUNT] = {0};
@@ -153,7 +155,7 @@ int32_t lasso_ctx_create(int32_t device, lasso_ctx** out) {
   }
   if (hipMalloc((void**)&c->d_flags, 64) != hipSuccess) { delete c; return fail(nullptr, LASSO_ERR_OOM, "flags alloc"); }
   if (hipMalloc((void**)&c->d_counters, (LASSO_MAX_PTRS + 40) * 4) != hipSuccess || hipMemset(c->d_counters, 0, (LASSO_MAX_PTRS + 40) * 4) != hipSuccess) { delete c; return fail(nullptr, LASSO_ERR_OOM, "counters alloc"); }
-  if (hipHostMalloc((void**)&c->h_flag, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess || hipHostGetDevicePointer((void**)&c->d_flag, c->h_flag, 0) != hipSuccess) { delete c; return fail(nullptr, LASSO_ERR_OOM, "mapped flag alloc"); }
+  if (hipHostMalloc((void**)&c->h_flag, 256, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess || hipHostGetDevicePointer((void**)&c->d_flag, c->h_flag, 0) != hipSuccess) { delete c; return fail(nullptr, LASSO_ERR_OOM, "mapped flag alloc"); }
   *c->h_flag = 0;
   int32_t rc = ensure_small(c, 4096); if (rc) { g_create_err = c->err; delete c; return rc; }
   rc = ensure_scratch(c, (size_t)1 << 22); if (rc) { g_create_err = c->err; delete c; return rc; }
@@ -321,6 +323,44 @@ int32_t lasso_sumcheck_cubic_eqw2_begin(lasso_ctx* c, lasso_fr* const* d_A, lass
 // The next entry point that hands its result over through the mapped buffer (the sumcheck rounds, the few-row MSMs, lasso_bullet_round ...)
 // returns right after its launch; its `out` argument is ignored and lasso_result_wait(ctx, out, count) delivers the same values
 // (count in field-element units: a point is 4).  Lets the host absorb transcript data or do scalar work while the device computes.
+// The tail of a layer's sumcheck in ONE resident kernel (k_cubic_tail): from q <= 64 indices per circuit on, the remaining rounds are served
+// without a launch per round — the host posts each challenge into a host-mapped mailbox and the kernel answers through the result buffer.
+// begin: r == NULL starts at the first round of a layer (arrays of length n = 2q), otherwise the challenge r is bound first (n = 4q).  The
+// result of the first of the log2(2q) rounds is pending afterwards (lasso_result_wait, 2*ncirc values: (q(0), q_inf) per circuit).
+// next: posts a challenge; pending: the next round's sums, or after the last round the 2*ncirc bound heads (A_0.., B_0..).
+// The arrays in device memory are NOT updated (nothing reads a layer's arrays after its sumcheck).
+int32_t lasso_sumcheck_cubic_tail_begin(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n, const lasso_fr* r) {
+  REQUIRE(c, d_A && d_B && d_E && ncirc >= 1 && ncirc <= LASSO_MAX_PTRS && n >= (r ? 4u : 2u) && (n & (n - 1)) == 0 && !c->pending && !c->tail_active && !c->defer_next);
+  const size_t q = r ? n / 4 : n / 2;
+  REQUIRE(c, q >= 1 && q <= CUBIC_TAIL_Q);
+  MutPtrTable A, B; for (uint32_t i = 0; i < ncirc; i++) { REQUIRE(c, d_A[i] && d_B[i]); A.p[i] = (fr_t*)d_A[i]; B.p[i] = (fr_t*)d_B[i]; }
+  int32_t rc = ensure_small(c, (size_t)ncirc * 3); if (rc) return rc;
+  uint32_t turns = 0; while (((size_t)1 << turns) < 2 * q) turns++;   // rounds of sums; one more publication carries the heads
+  volatile uint32_t* mail = c->h_flag + 32;
+  mail[0] = 0; mail[4] = 0; mail[8] = 0; __atomic_thread_fence(__ATOMIC_SEQ_CST);
+  const uint32_t seq0 = c->seq + 1; c->seq += turns + 1;
+  if (r) hipLaunchKernelGGL((k_cubic_tail<true>), dim3(ncirc), dim3(LASSO_BLOCK), 0, c->stream, A, B, (const fr_t*)d_E, (uint32_t)q, to_fr(r), (const uint32_t*)(c->d_flag + 32), c->d_counters, c->d_small, c->d_flag, seq0);
+  else hipLaunchKernelGGL((k_cubic_tail<false>), dim3(ncirc), dim3(LASSO_BLOCK), 0, c->stream, A, B, (const fr_t*)d_E, (uint32_t)q, fr_zero(), (const uint32_t*)(c->d_flag + 32), c->d_counters, c->d_small, c->d_flag, seq0);
+  HIPCHK(c, hipGetLastError());
+  c->tail_active = true; c->tail_seq0 = seq0; c->tail_turn = 0; c->tail_turns = turns; c->tail_ncirc = ncirc;
+  c->pending = true; c->pending_seq = seq0; c->pending_count = (size_t)ncirc * 2;
+  return 0;
+}
+int32_t lasso_sumcheck_cubic_tail_next(lasso_ctx* c, const lasso_fr* r) {
+  REQUIRE(c, r && c->tail_active && !c->pending);
+  uint32_t* mail = c->h_flag + 32;   // 128-byte offset: 16-byte aligned chunks
+  const fr_t rr = to_fr(r);
+  c->tail_turn++;
+  const uint32_t tn = c->tail_turn;
+  // three self-validating chunks, each ONE aligned 16-byte store (atomic on every x86 with AVX), see k_cubic_tail
+  _mm_store_si128((__m128i*)(mail + 0), _mm_set_epi32((int)rr.v[2], (int)rr.v[1], (int)rr.v[0], (int)tn));
+  _mm_store_si128((__m128i*)(mail + 4), _mm_set_epi32((int)rr.v[5], (int)rr.v[4], (int)rr.v[3], (int)tn));
+  _mm_store_si128((__m128i*)(mail + 8), _mm_set_epi32(0, (int)rr.v[7], (int)rr.v[6], (int)tn));
+  __atomic_thread_fence(__ATOMIC_RELEASE);
+  c->pending = true; c->pending_seq = c->tail_seq0 + c->tail_turn; c->pending_count = (size_t)c->tail_ncirc * 2;
+  if (c->tail_turn == c->tail_turns) c->tail_active = false;
+  return 0;
+}
 int32_t lasso_defer_next(lasso_ctx* c) { REQUIRE(c, !c->pending && !c->defer_next); c->defer_next = true; return 0; }
 int32_t lasso_result_wait(lasso_ctx* c, lasso_fr* out, size_t count) {
   REQUIRE(c, out && c->pending && count == c->pending_count);

@@ -337,6 +337,110 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_eqw_small(MutPtrTable A, 
   row_done(gridDim.x, counters, flag, seq);
 }
 
+// The whole TAIL of a layer's sumcheck in one resident kernel.  Once a layer is down to q <= CUBIC_TAIL_Q indices per circuit its remaining log2(q) + 1
+// rounds move a few KB each; a launch per round costs 6.5 us of round trip (tools/latency_bench.hip) against 2.5 us for a resident kernel that
+// waits for the host's next challenge in a host-mapped mailbox (tools/pingpong_bench.hip).  So: bind (or load) into LDS once, then per round
+// publish the two sums (q(0), q_inf) through the mapped result buffer + flag, spin on the mailbox, bind in LDS, ... and finally publish the
+// bound heads A[0], B[0] (sumcheck.rs:126-133) — the arrays never go back to HBM (nothing reads a layer's bound arrays after its sumcheck).
+// One workgroup per circuit.  mailbox (host-mapped): three 16-byte chunks [turn, w0, w1, w2] [turn, w3, w4, w5] [turn, w6, w7, 0], w = the challenge;
+// turn k's results carry sequence number seq0 + k.  Every spin has a wall-clock bail-out: a host that never answers cannot hang the device.
+// out (2 * ncirc elements per turn): sums turns: out[2c], out[2c+1];  final turn: out[c] = A_c head, out[ncirc + c] = B_c head.
+#define CUBIC_TAIL_Q 256   // the resident kernel takes over at <= this many indices per circuit (arrays of <= 512 elements in LDS)
+template <bool BIND>
+__global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_tail(MutPtrTable A, MutPtrTable B, const fr_t* __restrict__ E, uint32_t q, fr_t r0, const uint32_t* mailbox, uint32_t* counters,
+                                                             fr_t* __restrict__ out, uint32_t* flag, uint32_t seq0) {
+  __shared__ fr29 bound[2][2 * CUBIC_TAIL_Q];   // A', B' (m values each)
+  __shared__ fr29 ge[2 * CUBIC_TAIL_Q];         // A'[i] * E[i mod h]
+  __shared__ int32_t rows[2 * CUBIC_TAIL_Q * 9];
+  __shared__ int64_t strips[8 * 18];
+  __shared__ int64_t cols[18];
+  __shared__ fr_t chal;
+  __shared__ uint32_t alive;
+  const uint32_t t = threadIdx.x, y = blockIdx.x, ncirc = gridDim.x;
+  const uint64_t t_end = wall_clock64() + 500000000ull;   // 5 s at 100 MHz
+  uint32_t m = 2 * q;
+  {
+    const fr29 rs = fr29_unpack_s(r0);
+    for (uint32_t item = t; item < 2 * m; item += LASSO_BLOCK) {
+      const uint32_t p = item / m, i = item - p * m;
+      const fr_t* src = p == 0 ? A.p[y] : B.p[y];
+      bound[p][i] = BIND ? bind29(src[i], src[i + m], rs) : fr29_unpack_u(src[i]);
+    }
+  }
+  __syncthreads();
+  for (uint32_t turn = 0;; turn++) {
+    const uint32_t h = m / 2;      // pairs this round
+    for (uint32_t i = t; i < m; i += LASSO_BLOCK) ge[i] = fr29_mul(bound[0][i], fr29_unpack_s(E[i < h ? i : i - h]));
+    __syncthreads();
+    // 2h terms: u < h the q(0) terms, u >= h the leading-coefficient terms; row u of `rows`
+    for (uint32_t u = t; u < 2 * h; u += LASSO_BLOCK) {
+      const uint32_t v = u >= h ? 1u : 0u, i = u - v * h;
+      const fr29 g0 = ge[i], g1 = ge[i + h], b0 = bound[1][i], b1 = bound[1][i + h];
+      const fr29 term = v == 0 ? fr29_mul(b0, g0) : fr29_mul(fr29_sub(g1, g0), fr29_sub(b1, b0));
+#pragma unroll
+      for (int k = 0; k < 9; k++) rows[u * 9 + k] = term.v[k];
+    }
+    __syncthreads();
+    if (t < 8 * 18) {   // eight strips of rows per (sum, limb) column
+      const uint32_t col = t % 18, strip = t / 18, v = col / 9, k = col - v * 9;
+      const uint32_t per = (h + 7) / 8, i0 = strip * per, i1 = i0 + per < h ? i0 + per : h;
+      int64_t sum = 0;
+      for (uint32_t i = i0; i < i1; i++) sum += rows[(v * h + i) * 9 + k];
+      strips[strip * 18 + col] = sum;
+    }
+    __syncthreads();
+    if (t < 18) { int64_t sum = 0; for (int g = 0; g < 8; g++) sum += strips[g * 18 + t]; cols[t] = sum; }
+    __syncthreads();
+    if (t < 2) {
+      int64_t c[9];
+#pragma unroll
+      for (int k = 0; k < 9; k++) c[k] = cols[t * 9 + k];
+      out[(size_t)y * 2 + t] = fr29_store(fr29_mul(fr29_from_columns(c), fr29_k5()));
+    }
+    row_done(ncirc, counters, flag, seq0 + turn);
+    // the host's answer: the round's challenge
+    if (t == 0) {
+      // three self-validating 16-byte chunks [turn, w, w, w]: the host writes each with one aligned 16-byte store and a PCIe read of an aligned
+      // 16 bytes is one transaction, so when all three carry this turn's number the eight challenge words are this turn's — ONE read round trip
+      // per poll (eight dependent 4-byte reads of host memory cost 12 us)
+      typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+      const u32x4* m4 = reinterpret_cast<const u32x4*>(mailbox);
+      uint32_t ok = 1; u32x4 c0, c1, c2; uint32_t spins = 0;
+      for (;;) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");   // nothing cached from the previous poll
+        c0 = __builtin_nontemporal_load(m4); c1 = __builtin_nontemporal_load(m4 + 1); c2 = __builtin_nontemporal_load(m4 + 2);   // three 16-byte reads in flight together
+        if (c0.x == turn + 1 && c1.x == turn + 1 && c2.x == turn + 1) break;
+        if ((++spins & 63u) == 0 && wall_clock64() > t_end) { ok = 0; break; }
+      }
+      if (ok) { chal.v[0] = c0.y; chal.v[1] = c0.z; chal.v[2] = c0.w; chal.v[3] = c1.y; chal.v[4] = c1.z; chal.v[5] = c1.w; chal.v[6] = c2.y; chal.v[7] = c2.z; }
+      alive = ok;
+    }
+    __syncthreads();
+    if (!alive) return;
+    const fr29 rs = fr29_unpack_s(chal);
+    // bind in LDS: 2h lane tasks (array p, index j); results first, stores after the barrier (task (p, j) reads j and j + h of array p)
+    fr29 nb[2]; 
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+      const uint32_t u = t + pass * LASSO_BLOCK;
+      if (u < 2 * h) { const uint32_t p = u >= h ? 1u : 0u, jx = u - p * h; nb[pass] = fr29_canonical(fr29_add(bound[p][jx], fr29_mul(fr29_sub(bound[p][jx + h], bound[p][jx]), rs))); }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+      const uint32_t u = t + pass * LASSO_BLOCK;
+      if (u < 2 * h) { const uint32_t p = u >= h ? 1u : 0u, jx = u - p * h; bound[p][jx] = nb[pass]; }
+    }
+    __syncthreads();
+    m = h;
+    if (m == 1) {
+      if (t < 2) out[(size_t)t * ncirc + y] = fr29_pack(bound[t][0]);
+      row_done(ncirc, counters, flag, seq0 + turn + 1);
+      return;
+    }
+  }
+}
+
 // ------------------------------------------------------------------ K3 in eq-weighted form for the linear strategies (AND / OR / XOR / RangeCheck)
 // prove_arbitrary's comb_func is g(E_1..E_alpha) * eq with g = sum_k w_k E_k LINEAR (and.rs:45-53, range_check.rs:78-86) and eq = EqPolynomial(r).evals()
 // (surge.rs:156-172).  With the eq polynomial factored as in the cubic rounds (prefix of the one table + host scalars) a round needs, per polynomial k,

@@ -133,6 +133,19 @@ class Device:
         self._chk(self.lib.lasso_result_wait(self.ctx, _vp(out), 2 * len(a_ptrs)))
         return out
 
+    def sumcheck_cubic_tail(self, a_ptrs, b_ptrs, d_e, n, r, challenges):
+        """resident tail kernel (lasso_sumcheck_cubic_tail_begin / _next): returns the list of per-round (2k, 4) results, the last entry being the heads"""
+        k = len(a_ptrs)
+        rp = None if r is None else _vp(np.ascontiguousarray(r, dtype=np.uint64))
+        outs = []
+        self._chk(self.lib.lasso_sumcheck_cubic_tail_begin(self.ctx, self._ptrs(a_ptrs), self._ptrs(b_ptrs), k, C.c_void_p(d_e), n, rp))
+        out = np.empty((2 * k, 4), dtype=np.uint64); self._chk(self.lib.lasso_result_wait(self.ctx, _vp(out), 2 * k)); outs.append(out)
+        for ch in challenges:
+            ch = np.ascontiguousarray(ch, dtype=np.uint64)
+            self._chk(self.lib.lasso_sumcheck_cubic_tail_next(self.ctx, _vp(ch)))
+            out = np.empty((2 * k, 4), dtype=np.uint64); self._chk(self.lib.lasso_result_wait(self.ctx, _vp(out), 2 * k)); outs.append(out)
+        return outs
+
     def sumcheck_combine_round(self, strategy, ptrs, d_eq, n, degree):
         out = np.empty((degree + 1, 4), dtype=np.uint64)
         self._chk(self.lib.lasso_sumcheck_combine_round(self.ctx, C.byref(strategy), self._ptrs(ptrs), C.c_void_p(d_eq), n, degree, _vp(out)))

@@ -587,8 +587,9 @@ class Prover {
   // the last challenge.  d_E: table whose first len/2^(j+1) entries are prod_{t<=j}(1 - rand[v0+t]) * T_j (the phase's eq table); s = running
   // prod eq1(rand_t, rho_t) over all rounds so far (all phases).
   void cubic_rounds(size_t rounds, size_t len, std::vector<lasso_fr*>& A, std::vector<lasso_fr*>& B, const lasso_fr* d_E, const ScVec& rand, size_t v0, const ScVec& coeffs, bool reduce, Sc& s_run,
-                    Sc& e, SumcheckProof& proof, ScVec& r_out) {
+                    Sc& e, SumcheckProof& proof, ScVec& r_out, std::vector<lasso_fr>* heads_out = nullptr) {
     const size_t k = A.size();
+    if (heads_out) heads_out->clear();
     if (!rounds) return;
     // 1 / prod_{t<=j}(1 - rand[v0+t]) for every round of the phase with one inversion; a zero factor (rand_t = 1) takes the explicit-table path
     ScVec inv(rounds); bool degenerate = false;
@@ -599,6 +600,19 @@ class Prover {
     }
     DBuf tj; if (degenerate) tj = DBuf(d, len / 2);
     Sc r_prev = Sc::zero();
+    // The last rounds of the phase (<= 256 indices per circuit) are served by ONE resident kernel (lasso_sumcheck_cubic_tail_*): no launch per
+    // round, the bound arrays stay on chip, and the final bind + heads come back from it.  Not when a collective sits between the rounds
+    // (slab-local phase), nor when one of the remaining eq coordinates is 0 or 1 (the per-round paths handle those).
+    static const bool tail_off = [] { const char* v = getenv("LASSO_CUBIC_TAIL"); return v && v[0] == '0'; }();
+    size_t tail_from = rounds;   // first round served by the resident kernel
+    if (heads_out && !reduce && !degenerate && !tail_off) {
+      size_t j0 = 0; size_t l = len;   // l = array length before round j's bind
+      while (j0 < rounds && (j0 == 0 ? l / 2 : l / 4) > 256) { if (j0) l /= 2; j0++; }   // 256 = the kernel's CUBIC_TAIL_Q
+      bool plain = j0 < rounds;
+      for (size_t j = j0; j < rounds && plain; j++) if (rand[v0 + j].is_zero()) plain = false;
+      if (plain) tail_from = j0;
+    }
+    bool in_tail = false;
     for (size_t j = 0; j < rounds; j++) {
       const lasso_fr* table = d_E; Sc scale = degenerate ? Sc::one() : inv[j];
       if (degenerate) {   // T_j = eq(rand[v0+j+1 .. v0+rounds)) built explicitly (size len / 2^(j+1) at this point), times the slab factor hidden in d_E[0] / eq-prefix
@@ -612,13 +626,16 @@ class Prover {
       const Sc f0 = base * om, f1 = base * rj, f2 = base * (rj + rj - om), f3 = base * (rj + rj + rj - om - om);
       Sc c0, c2, c3;
       static const bool three_sums = [] { const char* v = getenv("LASSO_CUBIC_THREE_SUMS"); return v && v[0] == '1'; }();   // A/B switch for measurements
-      if (!f1.is_zero() && !three_sums) {
+      if (j >= tail_from || (!f1.is_zero() && !three_sums)) {
         // two sums per circuit, q_c(0) and the leading coefficient; q(1) follows from the claim e = e(0) + e(1) (sumcheck.rs:99-104 derives e(1)
         // the same way) and q(2), q(3) by extrapolation.  The inversion of f(1) overlaps the kernel.
         lasso_fr rp = r_prev.abi();
-        d.chk(lasso_sumcheck_cubic_eqw2_begin(d.ctx, A.data(), B.data(), (uint32_t)k, table, len, j == 0 ? nullptr : &rp), "lasso_sumcheck_cubic_eqw2_begin");
+        if (j < tail_from) d.chk(lasso_sumcheck_cubic_eqw2_begin(d.ctx, A.data(), B.data(), (uint32_t)k, table, len, j == 0 ? nullptr : &rp), "lasso_sumcheck_cubic_eqw2_begin");
+        else if (!in_tail) { d.chk(lasso_sumcheck_cubic_tail_begin(d.ctx, A.data(), B.data(), (uint32_t)k, table, len, j == 0 ? nullptr : &rp), "lasso_sumcheck_cubic_tail_begin"); in_tail = true; }
+        else d.chk(lasso_sumcheck_cubic_tail_next(d.ctx, &rp), "lasso_sumcheck_cubic_tail_next");
         if (j) len /= 2;
-        const Sc f1_inv = f1.inverse();
+        // f(1) = 0 inside the tail can only come from a vanished running factor s (probability 2^-252): then f = 0 identically and q is irrelevant
+        const Sc f1_inv = f1.is_zero() ? Sc::zero() : f1.inverse();
         std::vector<lasso_fr> ev(2 * k);
         d.chk(lasso_result_wait(d.ctx, ev.data(), 2 * k), "lasso_result_wait");
         if (reduce) d.comm.sum(ev);
@@ -652,9 +669,15 @@ class Prover {
       s_run *= om * (Sc::one() - r_j) + rj * r_j;   // eq1(rand_j, rho_j)
       proof.compressed_polys.push_back(poly.compress());
     }
+    lasso_fr rp = r_prev.abi();
+    if (in_tail) {   // the resident kernel binds the last challenge itself and hands back the heads A_c[0], B_c[0]
+      d.chk(lasso_sumcheck_cubic_tail_next(d.ctx, &rp), "lasso_sumcheck_cubic_tail_next");
+      heads_out->resize(2 * k);
+      d.chk(lasso_result_wait(d.ctx, heads_out->data(), 2 * k), "lasso_result_wait");
+      return;
+    }
     // the last challenge of the phase still has to be bound (len == 2 here)
     std::vector<lasso_fr*> ab(A); ab.insert(ab.end(), B.begin(), B.end());
-    lasso_fr rp = r_prev.abi();
     d.chk(lasso_bind_top(d.ctx, ab.data(), (uint32_t)ab.size(), len, &rp), "lasso_bind_top");
   }
   // A, B: local arrays of length 2^num_rounds / P (slab mode) or the whole arrays; d_E = the layer's eq table over `rand` (local share in slab mode)
@@ -663,24 +686,27 @@ class Prover {
     SumcheckProof proof; Sc e = claim, s_run = Sc::one(); const size_t k = A.size();
     LASSO_REQUIRE(rand.size() == num_rounds);
     std::vector<lasso_fr*> fa(A), fb(B);   // where the final values end up
+    std::vector<lasso_fr> heads;            // ... unless the resident tail kernel hands them back directly
     if (!slab) {
-      cubic_rounds(num_rounds, (size_t)1 << num_rounds, fa, fb, d_E, rand, 0, coeffs, false, s_run, e, proof, r_out);
+      cubic_rounds(num_rounds, (size_t)1 << num_rounds, fa, fb, d_E, rand, 0, coeffs, false, s_run, e, proof, r_out, &heads);
     } else {
       LASSO_REQUIRE(num_rounds >= lgP);
       const size_t local_rounds = num_rounds - lgP;
       cubic_rounds(local_rounds, (size_t)1 << local_rounds, fa, fb, d_E, rand, 0, coeffs, true, s_run, e, proof, r_out);
-      std::vector<lasso_fr*> heads(fa); heads.insert(heads.end(), fb.begin(), fb.end());
-      std::vector<lasso_fr*> tail = gather_tail(heads);
+      std::vector<lasso_fr*> local_heads(fa); local_heads.insert(local_heads.end(), fb.begin(), fb.end());
+      std::vector<lasso_fr*> tail = gather_tail(local_heads);
       fa.assign(tail.begin(), tail.begin() + k); fb.assign(tail.begin() + k, tail.begin() + 2 * k);
       // the remaining log2 P variables: replicated P-element arrays and the (whole) eq table over rand[local_rounds..]
       tail_bufs.emplace_back(d, P);
       std::vector<lasso_fr> rr; for (size_t i = local_rounds; i < num_rounds; i++) rr.push_back(rand[i].abi());
       d.chk(lasso_eq_evals(d.ctx, rr.data(), (uint32_t)rr.size(), tail_bufs.back().p), "lasso_eq_evals");
-      cubic_rounds(lgP, P, fa, fb, tail_bufs.back().p, rand, local_rounds, coeffs, false, s_run, e, proof, r_out);
+      cubic_rounds(lgP, P, fa, fb, tail_bufs.back().p, rand, local_rounds, coeffs, false, s_run, e, proof, r_out, &heads);
     }
-    std::vector<lasso_fr*> ab(fa); ab.insert(ab.end(), fb.begin(), fb.end());
-    std::vector<lasso_fr> heads(2 * k);
-    d.chk(lasso_read_heads(d.ctx, (const lasso_fr* const*)ab.data(), (uint32_t)(2 * k), heads.data()), "lasso_read_heads");
+    if (heads.empty()) {
+      std::vector<lasso_fr*> ab(fa); ab.insert(ab.end(), fb.begin(), fb.end());
+      heads.resize(2 * k);
+      d.chk(lasso_read_heads(d.ctx, (const lasso_fr* const*)ab.data(), (uint32_t)(2 * k), heads.data()), "lasso_read_heads");
+    }
     claims_a.clear(); claims_b.clear();
     for (size_t i = 0; i < k; i++) { claims_a.push_back(Sc::from_abi(heads[i])); claims_b.push_back(Sc::from_abi(heads[k + i])); }
     tail_bufs.clear();

@@ -138,6 +138,39 @@ int32_t lasso_result_wait(lasso_ctx* c, lasso_fr* out, size_t count) {
   g_pending.clear();
   return 0;
 }
+// resident tail: the mock keeps private copies of the arrays (the device kernel keeps them in LDS and never writes them back either)
+static thread_local std::vector<std::vector<Fr>> g_tail_a, g_tail_b;
+static thread_local std::vector<Fr> g_tail_e;
+static void tail_publish() {
+  const size_t k = g_tail_a.size(), m = g_tail_a[0].size();
+  g_pending.assign(2 * k, Fr::zero());
+  if (m == 1) { for (size_t c = 0; c < k; c++) { g_pending[c] = g_tail_a[c][0]; g_pending[k + c] = g_tail_b[c][0]; } g_tail_a.clear(); g_tail_b.clear(); return; }
+  const size_t h = m / 2;
+  for (size_t c = 0; c < k; c++) {
+    Fr q0 = Fr::zero(), qi = Fr::zero();
+    for (size_t i = 0; i < h; i++) { q0 += g_tail_a[c][i] * g_tail_b[c][i] * g_tail_e[i]; qi += (g_tail_a[c][h + i] - g_tail_a[c][i]) * (g_tail_b[c][h + i] - g_tail_b[c][i]) * g_tail_e[i]; }
+    g_pending[2 * c] = q0; g_pending[2 * c + 1] = qi;
+  }
+}
+static void tail_bind(const Fr& r) {
+  for (auto* arrs : {&g_tail_a, &g_tail_b}) for (auto& v : *arrs) { const size_t h = v.size() / 2; for (size_t i = 0; i < h; i++) v[i] = v[i] + r * (v[i + h] - v[i]); v.resize(h); }
+}
+int32_t lasso_sumcheck_cubic_tail_begin(lasso_ctx* c, lasso_fr* const* A, lasso_fr* const* B, uint32_t nc, const lasso_fr* E, size_t n, const lasso_fr* r) {
+  REQ(c, n >= (r ? 4u : 2u) && (n & (n - 1)) == 0 && g_tail_a.empty() && g_pending.empty());
+  const size_t q = r ? n / 4 : n / 2; REQ(c, q >= 1 && q <= 256);
+  g_tail_a.clear(); g_tail_b.clear();
+  for (uint32_t k = 0; k < nc; k++) { g_tail_a.emplace_back(F(A[k]), F(A[k]) + n); g_tail_b.emplace_back(F(B[k]), F(B[k]) + n); }
+  g_tail_e.assign(F(E), F(E) + q);
+  if (r) tail_bind(*F(r));
+  tail_publish();
+  return 0;
+}
+int32_t lasso_sumcheck_cubic_tail_next(lasso_ctx* c, const lasso_fr* r) {
+  REQ(c, r && !g_tail_a.empty() && g_pending.empty());
+  tail_bind(*F(r));
+  tail_publish();
+  return 0;
+}
 int32_t lasso_sumcheck_combine_round(lasso_ctx* c, const lasso_strategy* s, const lasso_fr* const* polys, const lasso_fr* eq, size_t n, uint32_t degree, lasso_fr* out) {
   REQ(c, n >= 2 && (n & (n - 1)) == 0);
   Strategy S = mk(s); size_t alpha = S.num_memories(), half = n / 2;

@@ -427,6 +427,47 @@ def test_sumcheck_cubic_eqw2(devs, n, ncirc):
             assert (3 * t3[3 * c + 1] - 2 * t3[3 * c + 2] - q0 + 6 * qi) % FR_P == 0
 
 
+@pytest.mark.parametrize("n,ncirc,bind", [(2, 1, False), (4, 1, True), (4, 2, False), (8, 2, True), (64, 3, False), (128, 33, False), (256, 2, True), (256, 66, True), (16, 5, True), (512, 2, False), (1024, 3, True), (512, 40, True)])
+def test_sumcheck_cubic_tail(devs, n, ncirc, bind):
+    """the resident tail kernel (all remaining rounds of a layer + the final bind in one launch, challenges through the mailbox) against the
+    per-round two-sum calls: same sums every round, same heads"""
+    rng = np.random.default_rng(n * 13 + ncirc)
+    A = [rand_fr(rng, n) for _ in range(ncirc)]
+    B = [rand_fr(rng, n) for _ in range(ncirc)]
+    q = n // 4 if bind else n // 2
+    E = rand_fr(rng, q)
+    r0 = rand_fr(rng, 1, edge=False)[0] if bind else None
+    turns = (2 * q).bit_length() - 1
+    chal = rand_fr(rng, turns, edge=False)
+
+    def run(d):
+        pa = [d.upload(x) for x in A]; pb = [d.upload(x) for x in B]; pe = d.upload(E)
+        outs = d.sumcheck_cubic_tail(pa, pb, pe, n, r0, chal)
+        for p in pa + pb + [pe]:
+            d.free(p)
+        return outs
+
+    def per_round(d):
+        pa = [d.upload(x) for x in A]; pb = [d.upload(x) for x in B]; pe = d.upload(E)
+        outs = [d.sumcheck_cubic_eqw2(pa, pb, pe, n, r0)]
+        length = n // 2 if bind else n
+        for t in range(turns - 1):
+            outs.append(d.sumcheck_cubic_eqw2(pa, pb, pe, length, chal[t])); length //= 2
+        d.bind_top(pa + pb, length, chal[turns - 1])
+        heads = np.stack([d.download(p, (1, 4))[0] for p in pa + pb])
+        outs.append(heads)
+        for p in pa + pb + [pe]:
+            d.free(p)
+        return outs
+    a, b = both(devs, run)
+    assert len(a) == turns + 1
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    ref = per_round(devs[0])
+    for x, y in zip(a, ref):
+        assert np.array_equal(x, y)
+
+
 @pytest.mark.parametrize("n_lookups,c,log_m,mode", [(1, 1, 0, "rand"), (2, 1, 1, "rand"), (5, 2, 4, "rand"), (1000, 3, 8, "rand"), (4096, 1, 16, "rand"), (5000, 2, 12, "rand"),
                                                      (1 << 16, 1, 16, "rand"), (70000, 1, 17, "rand"), (9000, 1, 16, "same"), (1 << 15, 2, 3, "rand"), (12345, 1, 9, "sorted")])
 def test_densify_dim(devs, n_lookups, c, log_m, mode):
