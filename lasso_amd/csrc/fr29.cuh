@@ -163,7 +163,23 @@ LHD fr29 fr29_acc_reduce(const fr29_acc& acc) {
   return fr29_from_columns(col);
 }
 
-// |value| < 4p (any limbs with |.| < 2^31) -> the canonical representative in [0, p), limbs in [0, 2^29)
+// Lazily reduced memory form for arrays that only kernels read (the bound arrays of a sumcheck between two rounds): any limbs with
+// |.| < 2^31 and |value| < 2^255 -> digits (limbs in [0, 2^29), limb 8 <= 2^22) of SOME representative in (0, 2^254 + 2^130) of the same
+// residue.  One fused pass: floor(value / 2^252) is estimated from the two top limbs (off by at most 1 either way: the carries of the lower
+// limbs it ignores), and with f = estimate - 2 the value - f p lies in [2^252, 4 * 2^252) up to |f| c (c = p - 2^252 ~ 2^125).  48 instructions
+// against 115 for fr29_canonical; fr29_pack / fr29_unpack_u carry such a value through memory unchanged, and every reader (fr29_mul
+// operands, fr29_canonical) accepts it.
+LHD fr29 fr29_semi(const fr29& a) {
+  const int32_t P[9] = {FR29_P0, FR29_P1, FR29_P2, FR29_P3, FR29_P4, 0, 0, 0, 1 << 20};
+  const int32_t f = ((a.v[8] + (a.v[7] >> 29)) >> 20) - 2;
+  fr29 r; int64_t c = 0;
+#pragma unroll
+  for (int k = 0; k < 9; k++) { int64_t x = (int64_t)a.v[k] - (int64_t)f * P[k] + c; if (k < 8) { r.v[k] = (int32_t)x & FR29_MASK; c = x >> 29; } else r.v[8] = (int32_t)x; }
+  return r;
+}
+
+// any limbs with |.| < 2^31 and |value| < 2^255 -> the canonical representative in [0, p), limbs in [0, 2^29)
+// (f below is floor(value / 2^252), |f| <= 8: the remainder r stays within 8c of [0, 2^252), which the second stage absorbs)
 LHD fr29 fr29_canonical(const fr29& a) {
   const int32_t P[9] = {FR29_P0, FR29_P1, FR29_P2, FR29_P3, FR29_P4, 0, 0, 0, 1 << 20};
   fr29 w = fr29_weak(a);

@@ -191,6 +191,13 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_round_lb(PtrTable A, PtrT
   }
   cubic_epilogue(e, g, partials, counters, out, flag, seq, S, fr29_k10());
 }
+// bind for arrays only kernels read until the layer's final bind: the stored value is lazily reduced (fr29_semi: same residue, < 2^254 + 2^130,
+// 48 instructions against 115) — the next round's loads, the resident tail kernel and k_bind_top all accept it, and what leaves the device
+// (the heads after the last bind) is canonical again.  Used by the two-sum fused rounds (the dominant kernel of a proof).
+__device__ __forceinline__ fr29 bind29_semi(const fr_t& lo, const fr_t& hi, const fr29& rs) {
+  const fr29 l = fr29_unpack_u(lo);
+  return fr29_semi(fr29_add(l, fr29_mul(fr29_sub(fr29_unpack_u(hi), l), rs)));
+}
 __device__ __forceinline__ fr29 bind29(const fr_t& lo, const fr_t& hi, const fr29& rs) {
   const fr29 l = fr29_unpack_u(lo);
   return fr29_canonical(fr29_add(l, fr29_mul(fr29_sub(fr29_unpack_u(hi), l), rs)));   // canonical: stored as is, and a reduced operand below
@@ -263,9 +270,9 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_eqw_fused(MutPtrTable A, 
   fr29 e[3] = {fr29_zero(), fr29_zero(), fr29_zero()}; uint32_t cnt = 0;
   fr29_acc w0 = fr29_acc_zero(), w1 = fr29_acc_zero();
   for (size_t i = g.bx * (size_t)blockDim.x + threadIdx.x; i < q; i += (size_t)nx * blockDim.x) {
-    const fr29 a0 = bind29(a[i], a[i + 2 * q], rs), a1 = bind29(a[i + q], a[i + 3 * q], rs);
+    const fr29 a0 = NT == 2 ? bind29_semi(a[i], a[i + 2 * q], rs) : bind29(a[i], a[i + 2 * q], rs), a1 = NT == 2 ? bind29_semi(a[i + q], a[i + 3 * q], rs) : bind29(a[i + q], a[i + 3 * q], rs);
     a[i] = fr29_pack(a0); a[i + q] = fr29_pack(a1);
-    const fr29 b0 = bind29(b[i], b[i + 2 * q], rs), b1 = bind29(b[i + q], b[i + 3 * q], rs);
+    const fr29 b0 = NT == 2 ? bind29_semi(b[i], b[i + 2 * q], rs) : bind29(b[i], b[i + 2 * q], rs), b1 = NT == 2 ? bind29_semi(b[i + q], b[i + 3 * q], rs) : bind29(b[i + q], b[i + 3 * q], rs);
     b[i] = fr29_pack(b0); b[i + q] = fr29_pack(b1);
     fr29 t0, t2, t3;
     if (NT == 3) { cubic_eqw_terms(a0, a1, b0, b1, fr29_unpack_s(E[i]), t0, t2, t3); CUBIC_ACCUMULATE(e, t0, t2, t3, cnt); }

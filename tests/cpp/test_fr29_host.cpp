@@ -69,6 +69,28 @@ int main() {
     }
     CHECK(same(fr29_store(fr29_mul(e, fr29_one_s())), ref));
   }
+  // lazily reduced memory form (fr29_semi): same residue, digits in range, survives pack/unpack, accepted by fr29_canonical and as a product
+  // operand; inputs over the whole allowed range |value| < 2^255 (sums and differences of up to eight elements, loose limbs)
+  for (size_t i = 0; i < N; i++) {
+    const fr_t &a = xs[i], &b = xs[(i * 7 + 3) % N], &c = xs[(i * 11 + 5) % N];
+    const fr29 au = fr29_unpack_u(a), bu = fr29_unpack_u(b), cu = fr29_unpack_u(c);
+    const fr29 cases[6] = {au, fr29_add(au, bu), fr29_sub(au, bu), fr29_sub(fr29_sub(fr29_zero(), au), fr29_add(bu, cu)),
+                           fr29_add(fr29_add(fr29_add(au, bu), fr29_add(cu, au)), fr29_add(fr29_add(bu, bu), fr29_add(cu, cu))),
+                           fr29_sub(fr29_zero(), fr29_add(fr29_add(fr29_add(au, bu), fr29_add(cu, au)), fr29_add(fr29_add(bu, bu), fr29_add(cu, cu))))};
+    for (const fr29& x : cases) {
+      const fr29 sm = fr29_semi(x);
+      for (int k = 0; k < 8; k++) CHECK(sm.v[k] >= 0 && sm.v[k] < (1 << 29));
+      CHECK(sm.v[8] >= 0 && sm.v[8] <= (1 << 22));
+      CHECK(same(fr29_store(sm), fr29_store(x)));                         // same residue
+      const fr_t mem = fr29_pack(sm); const fr29 back = fr29_unpack_u(mem);
+      for (int k = 0; k < 9; k++) CHECK(back.v[k] == sm.v[k]);             // memory round trip keeps the digits
+      CHECK(same(fr29_store(fr29_mul(sm, fr29_unpack_s(c))), fr_mul(fr29_store(x), c)));   // a valid product operand
+      // a bind on lazily reduced inputs stays in range: lo + r (hi - lo), then semi again
+      const fr29 sm2 = fr29_semi(fr29_add(sm, fr29_mul(fr29_sub(fr29_unpack_u(fr29_pack(fr29_semi(cu))), sm), fr29_unpack_s(b))));
+      CHECK(sm2.v[8] >= 0 && sm2.v[8] <= (1 << 22));
+      CHECK(same(fr29_store(sm2), fr_add(fr29_store(x), fr_mul(b, fr_sub(c, fr29_store(x))))));
+    }
+  }
   // sums of products through the double-width accumulator (fr29_mul_acc / fr29_acc_carry / fr29_acc_reduce): carry pass every third product,
   // signed differences as operands (the cubic rounds' leading-coefficient term), T up to 2^16, vs the reference sum of Montgomery products
   for (int T : {1, 2, 3, 4, 255, 4096, 65536}) {
