@@ -13,7 +13,7 @@ from collections import defaultdict
 FAMILIES = {   # bench.py family name -> kernel-name prefixes
     "bind_top(+fused linear round)": ("k_dot_eqw_fused", "k_bind_top"),
     "sumcheck_cubic_round(+fused bind)": ("k_cubic_eqw_fused", "k_cubic_eqw_lb", "k_cubic_round_lb"),
-    "sumcheck_combine": ("k_dot_eqw_lb", "k_combine_round_linear", "void k_combine_claim"),
+    "sumcheck_combine": ("k_dot_eqw_lb", "k_combine_round_linear", "k_combine_claim"),
     "multi_dot": ("k_multi_dot",),
     "matvec_left": ("k_matvec_left",),
     "fingerprint": ("k_fingerprint_ops",),
@@ -24,7 +24,8 @@ def load(path):
     rows = []
     with open(path) as f:
         for r in csv.DictReader(f):
-            rows.append((int(r["Dispatch_Id"]), r["Kernel_Name"], float(r["Counter_Value"])))
+            name = r["Kernel_Name"]
+            rows.append((int(r["Dispatch_Id"]), name[5:] if name.startswith("void ") else name, float(r["Counter_Value"])))   # templated kernels print as "void k<..>(..)"
     rows.sort()
     return rows
 
