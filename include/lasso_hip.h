@@ -205,6 +205,13 @@ int32_t lasso_hyrax_commit(lasso_ctx* ctx, const lasso_fr* d_Z, size_t l_size, s
 /* the same with the rows returned in wire form: out32[32*row..] = serialize_compressed(normalised row commitment) — what the transcript absorbs
  * (src/poly/dense_mlpoly.rs:281-289 -> utils/transcript.rs:47-51) and what the proof stores; normalisation (one inversion per row) runs on the device */
 int32_t lasso_hyrax_commit_compressed(lasso_ctx* ctx, const lasso_fr* d_Z, size_t l_size, size_t r_size, const lasso_bases* bases, uint8_t* out32);
+/* The same commitment for a polynomial whose canonical values the caller already holds as 32-bit integers, Z[i] = F::from(d_u32[i]) — the lookup
+ * polynomials E_i = T[dim_i] of a small-valued subtable (subtables/mod.rs:116-129), dim, the timestamps.  Skips the pass that converts the
+ * 32-byte elements to integers and its max-bit readback (msm/mod.rs:95-106 finds the same bound by scanning).  max_value >= every d_u32[i]. */
+int32_t lasso_hyrax_commit_compressed_u32(lasso_ctx* ctx, const uint32_t* d_u32, uint32_t max_value, size_t l_size, size_t r_size,
+                                          const lasso_bases* bases, uint8_t* out32);
+/* d_out[i] = d_table[d_idx[i]] on 32-bit integers (the integer twin of lasso_gather, feeding lasso_hyrax_commit_compressed_u32) */
+int32_t lasso_gather_u32(lasso_ctx* ctx, const uint32_t* d_table, const uint32_t* d_idx, size_t n, uint32_t* d_out);
 /* VariableBaseMSM::msm (src/msm/mod.rs:36-40): out = sum_{j < n} scalars[j] * bases[j]; n <= number of bases.  Zero scalars cost nothing. */
 int32_t lasso_msm(lasso_ctx* ctx, const lasso_bases* bases, const lasso_fr* scalars, size_t n, lasso_point* out);
 

@@ -708,6 +708,24 @@ static int32_t hyrax_commit_impl(lasso_ctx* c, const lasso_fr* d_Z, size_t l_siz
   hipLaunchKernelGGL(k_fr_to_canonical, dim3(grid_for(n, 4096)), dim3(256), 0, c->stream, (const fr_t*)d_Z, n, (fr_t*)d_scal);
   return run_msm(c, d_scal, 32, MSM_WINDOWS, r_size * 32, l_size, r_size, b, d_scal + n * 32, out, out_compressed);
 }
+// The commitment of a polynomial whose canonical values the caller already holds as u32 (Z[i] = F::from(d_u32[i]), e.g. E = T[dim] with a small
+// table T, or the dim / timestamp polynomials): no conversion pass over the 32-byte elements and no max-bit readback.  max_value bounds the values.
+int32_t lasso_hyrax_commit_compressed_u32(lasso_ctx* c, const uint32_t* d_u32, uint32_t max_value, size_t l_size, size_t r_size, const lasso_bases* b, uint8_t* out32) {
+  REQUIRE(c, d_u32 && out32 && b && l_size >= 1 && r_size >= 1 && r_size <= b->n && l_size < ((size_t)1 << 31));
+  int32_t rc = ensure_scratch(c, msm_pts_bytes(l_size, r_size) + 256); if (rc) return rc;
+  uint32_t bits = 0; while (bits < 32 && (max_value >> bits)) bits++;
+  uint32_t W = (bits + 3) / 4; if (W == 0) W = 1;
+  return run_msm(c, (const uint8_t*)d_u32, 4, W, r_size * 4, l_size, r_size, b, (uint8_t*)c->d_scratch, nullptr, out32);
+}
+__global__ void __launch_bounds__(256) k_gather_u32(const uint32_t* __restrict__ table, const uint32_t* __restrict__ idx, size_t n, uint32_t* __restrict__ out) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = table[idx[i]];
+}
+int32_t lasso_gather_u32(lasso_ctx* c, const uint32_t* d_table, const uint32_t* d_idx, size_t n, uint32_t* d_out) {
+  REQUIRE(c, d_table && d_idx && d_out); if (!n) return 0;
+  ProfScope ps(c, LASSO_K_MISC, 12.0 * n);
+  hipLaunchKernelGGL(k_gather_u32, dim3(grid_for(n)), dim3(256), 0, c->stream, d_table, d_idx, n, d_out);
+  HIPCHK(c, hipGetLastError()); return 0;
+}
 int32_t lasso_msm(lasso_ctx* c, const lasso_bases* b, const lasso_fr* scalars, size_t n, lasso_point* out) {
   REQUIRE(c, b && scalars && out && n >= 1 && n <= b->n);
   int32_t rc = ensure_scratch(c, n * 64 + msm_pts_bytes(1, n)); if (rc) return rc;

@@ -202,6 +202,14 @@ class Device:
         self._chk(self.lib.lasso_hyrax_commit_compressed(self.ctx, C.c_void_p(d_z), l_size, r_size, C.c_void_p(bases), _vp(out)))
         return out
 
+    def hyrax_commit_compressed_u32(self, d_u32, max_value, l_size, r_size, bases):
+        out = np.empty((l_size, 32), dtype=np.uint8)
+        self._chk(self.lib.lasso_hyrax_commit_compressed_u32(self.ctx, C.c_void_p(d_u32), max_value, l_size, r_size, C.c_void_p(bases), _vp(out)))
+        return out
+
+    def gather_u32(self, d_table, d_idx, n, d_out):
+        self._chk(self.lib.lasso_gather_u32(self.ctx, C.c_void_p(d_table), C.c_void_p(d_idx), n, C.c_void_p(d_out)))
+
     def msm(self, bases, scalars):
         scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
         out = np.empty((1, 16), dtype=np.uint64)

@@ -370,12 +370,14 @@ struct BatchedGrandProductArgument { std::vector<LayerProofBatched> proof; void 
 // ------------------------------------------------------------------ Hyrax commitment of a device polynomial (dense_mlpoly.rs:109-181)
 struct PolyCommitment { std::vector<uint8_t> compressed; size_t rows = 0; };   // C: Vec<G>, kept in wire form
 // d_Z: the whole polynomial, or in slab mode the rank's local array (row-major L x R/P: its columns of every row)
-inline PolyCommitment hyrax_commit(const Dev& d, const lasso_fr* d_Z, size_t num_vars, const PolyCommitmentGens& gens) {
+// d_u32 (optional): the polynomial's canonical values as 32-bit integers, all <= max_u32, when the caller has them anyway
+inline PolyCommitment hyrax_commit(const Dev& d, const lasso_fr* d_Z, size_t num_vars, const PolyCommitmentGens& gens, const uint32_t* d_u32 = nullptr, uint32_t max_u32 = 0) {
   size_t l_size = (size_t)1 << (num_vars / 2), r_size = (size_t)1 << (num_vars - num_vars / 2);
   LASSO_REQUIRE(r_size == gens.n);
   if (!d.comm.sharded()) {   // rows come back in wire form: the normalisation (one inversion per row) runs on the device
     PolyCommitment c; c.rows = l_size; c.compressed.resize(32 * l_size);
-    d.chk(lasso_hyrax_commit_compressed(d.ctx, d_Z, l_size, r_size, gens.bases, c.compressed.data()), "lasso_hyrax_commit_compressed");
+    if (d_u32) d.chk(lasso_hyrax_commit_compressed_u32(d.ctx, d_u32, max_u32, l_size, r_size, gens.bases, c.compressed.data()), "lasso_hyrax_commit_compressed_u32");
+    else d.chk(lasso_hyrax_commit_compressed(d.ctx, d_Z, l_size, r_size, gens.bases, c.compressed.data()), "lasso_hyrax_commit_compressed");
     return c;
   }
   std::vector<lasso_point> rows(l_size);
@@ -892,7 +894,13 @@ class Prover {
     // Subtables::new (subtables/mod.rs:116-129)
     std::unique_ptr<Trace> sp(new Trace("Subtables.new", d.ctx));
     auto host_tables = S.materialize_subtables();
-    for (auto& ht : host_tables) { DBufU32 tmp(d, ht); DBuf tb(d, m); d.chk(lasso_fr_from_u32(d.ctx, tmp.p, m, tb.p), "lasso_fr_from_u32"); d.chk(lasso_sync(d.ctx), "lasso_sync"); tables.push_back(std::move(tb)); }
+    std::vector<DBufU32> tables_u32; uint32_t table_max = 0;   // the integer tables stay until E is committed (the commitment's scalars are T[dim] as integers)
+    for (auto& ht : host_tables) {
+      for (uint32_t v : ht) table_max = std::max(table_max, v);
+      tables_u32.emplace_back(d, ht); DBuf tb(d, m);
+      d.chk(lasso_fr_from_u32(d.ctx, tables_u32.back().p, m, tb.p), "lasso_fr_from_u32");
+      tables.push_back(std::move(tb));
+    }
     size_t n_E = next_pow2(alpha * s); nv_derefs = ceil_log2(n_E);
     combined_E = DBuf(d, n_E / P);
     if (n_E > alpha * s) d.chk(lasso_zero(d.ctx, combined_E.p + alpha * s_loc, (n_E - alpha * s) / P * sizeof(lasso_fr)), "lasso_zero");
@@ -901,17 +909,30 @@ class Prover {
     ProofWriter W;
     // comm_derefs
     sp.reset(new Trace("Subtables.commit", d.ctx));
-    PolyCommitment comm_derefs = hyrax_commit(d, combined_E.p, nv_derefs, gens.gens_derefs);
+    PolyCommitment comm_derefs;
+    if (P == 1) {   // E as integers: one 4-byte gather per lookup instead of converting the 32-byte elements back
+      DBufU32 E_u32(d, n_E);
+      if (n_E > alpha * s) d.chk(lasso_zero(d.ctx, E_u32.p + alpha * s, (n_E - alpha * s) * sizeof(uint32_t)), "lasso_zero");
+      for (size_t i = 0; i < alpha; i++)
+        d.chk(lasso_gather_u32(d.ctx, tables_u32[S.memory_to_subtable_index(i)].p, dense.dim_u32[S.memory_to_dimension_index(i)].p, s, E_u32.p + i * s), "lasso_gather_u32");
+      comm_derefs = hyrax_commit(d, combined_E.p, nv_derefs, gens.gens_derefs, E_u32.p, table_max);
+    } else comm_derefs = hyrax_commit(d, combined_E.p, nv_derefs, gens.gens_derefs);
+    tables_u32.clear();
+    // The claim (subtables/mod.rs:187-216) depends on r and E only, not on the transcript: its kernels run while the host absorbs the
+    // commitment (4096 compressed rows at 2^24: 0.4 ms of Keccak during which the device would otherwise idle)
+    DBuf eq(d, s_loc);
+    eq_evals_local(r, eq.p);
+    std::vector<const lasso_fr*> Eptr; for (size_t i = 0; i < alpha; i++) Eptr.push_back(E(i));
+    std::vector<lasso_fr> claim_abi(1);
+    d.chk(lasso_defer_next(d.ctx), "lasso_defer_next");
+    d.chk(lasso_combine_claim(d.ctx, &S.abi, Eptr.data(), eq.p, s_loc, claim_abi.data()), "lasso_combine_claim");
     t.append_message("subtable_evals_commitment", "begin_subtable_evals_commitment");
     append_poly_commitment(t, "comm_poly_row_col_ops_val", comm_derefs);
     t.append_message("subtable_evals_commitment", "end_subtable_evals_commitment");
     W.pts_vec(comm_derefs.compressed);
     // claim
     sp.reset(new Trace("Subtables.compute_sumcheck_claim", d.ctx));
-    DBuf eq(d, s_loc);
-    eq_evals_local(r, eq.p);
-    std::vector<const lasso_fr*> Eptr; for (size_t i = 0; i < alpha; i++) Eptr.push_back(E(i));
-    std::vector<lasso_fr> claim_abi(1); d.chk(lasso_combine_claim(d.ctx, &S.abi, Eptr.data(), eq.p, s_loc, claim_abi.data()), "lasso_combine_claim");
+    d.chk(lasso_result_wait(d.ctx, claim_abi.data(), 1), "lasso_result_wait");
     d.comm.sum(claim_abi);
     Sc claimed_eval = Sc::from_abi(claim_abi[0]);
     t.append_scalar("claim_eval_scalar_product", claimed_eval);

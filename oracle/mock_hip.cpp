@@ -20,6 +20,7 @@ static int32_t fail(lasso_ctx* c, const char* m) { if (c) c->err = m; return LAS
 static inline const Fr* F(const lasso_fr* p) { return reinterpret_cast<const Fr*>(p); }
 static inline Fr* F(lasso_fr* p) { return reinterpret_cast<Fr*>(p); }
 static thread_local std::vector<Fr> g_pending;   // result of a deferred / *_begin call, handed over by lasso_result_wait
+static thread_local bool g_defer = false;       // lasso_defer_next: the next supporting call parks its result in g_pending
 static Strategy mk(const lasso_strategy* s) { Strategy S; S.kind = (StrategyKind)s->kind; S.C = s->c; S.M = (size_t)1 << s->log_m; S.LOG_R = s->log_r; return S; }
 static void put_point(const Point& p, lasso_point* o) { memcpy(o->x, p.X.v, 32); memcpy(o->y, p.Y.v, 32); memcpy(o->t, p.T.v, 32); memcpy(o->z, p.Z.v, 32); }
 
@@ -188,6 +189,7 @@ int32_t lasso_sumcheck_combine_round(lasso_ctx* c, const lasso_strategy* s, cons
 int32_t lasso_combine_claim(lasso_ctx*, const lasso_strategy* s, const lasso_fr* const* polys, const lasso_fr* eq, size_t n, lasso_fr* out) {
   Strategy S = mk(s); size_t alpha = S.num_memories(); std::vector<Fr> v(alpha); Fr claim = Fr::zero();
   for (size_t k = 0; k < n; k++) { for (size_t j = 0; j < alpha; j++) v[j] = F(polys[j])[k]; claim += F(eq)[k] * S.combine_lookups(v.data()); }  // subtables/mod.rs:197-213
+  if (g_defer) { g_defer = false; g_pending.assign(1, claim); return 0; }   // lasso_defer_next
   *F(out) = claim; return 0;
 }
 int32_t lasso_multi_dot(lasso_ctx*, const lasso_fr* const* polys, uint32_t k, const lasso_fr* w, size_t n, lasso_fr* out) {
@@ -271,6 +273,13 @@ int32_t lasso_hyrax_commit_compressed(lasso_ctx* c, const lasso_fr* Z, size_t ls
   for (size_t i = 0; i < ls; i++) { std::vector<Fr> sc(F(Z) + i * rs, F(Z) + (i + 1) * rs); msm(bases, sc).compress(out32 + 32 * i); }
   return 0;
 }
+int32_t lasso_hyrax_commit_compressed_u32(lasso_ctx* c, const uint32_t* Z, uint32_t max_value, size_t ls, size_t rs, const lasso_bases* b, uint8_t* out32) {
+  REQ(c, rs <= b->pts.size());
+  std::vector<Point> bases(b->pts.begin(), b->pts.begin() + rs);
+  for (size_t i = 0; i < ls; i++) { std::vector<Fr> sc(rs); for (size_t j = 0; j < rs; j++) { REQ(c, Z[i * rs + j] <= max_value); sc[j] = Fr::from_u64(Z[i * rs + j]); } msm(bases, sc).compress(out32 + 32 * i); }
+  return 0;
+}
+int32_t lasso_gather_u32(lasso_ctx*, const uint32_t* t, const uint32_t* idx, size_t n, uint32_t* o) { for (size_t i = 0; i < n; i++) o[i] = t[idx[i]]; return 0; }
 int32_t lasso_msm(lasso_ctx* c, const lasso_bases* b, const lasso_fr* scalars, size_t n, lasso_point* out) {
   REQ(c, n <= b->pts.size());
   std::vector<Point> bases(b->pts.begin(), b->pts.begin() + n); std::vector<Fr> sc(F(scalars), F(scalars) + n);
@@ -278,7 +287,6 @@ int32_t lasso_msm(lasso_ctx* c, const lasso_bases* b, const lasso_fr* scalars, s
 }
 
 // lasso_defer_next in the mock: the deferred call computes at once and parks its result for lasso_result_wait (points as 4 field elements each)
-static thread_local bool g_defer = false;
 int32_t lasso_defer_next(lasso_ctx* c) { REQ(c, !g_defer && g_pending.empty()); g_defer = true; return 0; }
 static int32_t deliver_points(const lasso_point* pts, size_t n, lasso_point* out) {
   if (g_defer) { g_defer = false; g_pending.resize(4 * n); memcpy((void*)g_pending.data(), pts, n * sizeof(lasso_point)); return 0; }

@@ -236,6 +236,32 @@ def test_hyrax_commit(devs, gens_300, ls, rs, maxv):
     assert np.array_equal(wa, wb) and [bytes(x) for x in wa] == compress_points(mock_lib, b)
 
 
+@pytest.mark.parametrize("ls,rs,tbits", [(1, 1, 1), (4, 8, 8), (16, 256, 16), (8, 300, 24), (3, 100, 32)])
+def test_hyrax_commit_u32(devs, gens_300, ls, rs, tbits):
+    """commitment from the integer values (gathered from an integer table, as for E = T[dim]) == commitment of the same polynomial as field elements"""
+    rng = np.random.default_rng(ls * 17 + rs)
+    m = 64
+    table = rng.integers(0, 1 << tbits, size=m, dtype=np.uint64).astype(np.uint32)
+    table[0] = 0; table[-1] = (1 << tbits) - 1
+    idx = rng.integers(0, m, size=ls * rs, dtype=np.uint64).astype(np.uint32)
+    idx[0] = m - 1
+    Z = small_fr(table[idx].astype(np.uint64))
+
+    def run(d):
+        b = d.bases_create(gens_300)
+        pt = d.upload(table); pi = d.upload(idx); pu = d.alloc(4 * ls * rs)
+        d.gather_u32(pt, pi, ls * rs, pu)
+        wire = d.hyrax_commit_compressed_u32(pu, int(table.max()), ls, rs, b)
+        pz = d.upload(Z)
+        ref = d.hyrax_commit_compressed(pz, ls, rs, b)
+        for p in (pt, pi, pu, pz):
+            d.free(p)
+        d.bases_destroy(b)
+        return wire, ref
+    (wa, ra), (wb, rb) = both(devs, run)
+    assert np.array_equal(wa, wb) and np.array_equal(wa, ra) and np.array_equal(ra, rb)
+
+
 @pytest.mark.parametrize("n", [1, 2, 33, 301])
 def test_msm_full_width(devs, gens_300, n):
     rng = np.random.default_rng(n)
