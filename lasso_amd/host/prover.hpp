@@ -98,12 +98,19 @@ struct Comm {
 class Dev {
   mutable std::multimap<size_t, void*> pool_;
   mutable std::map<void*, size_t> live_;
+  int device_ = 0;
+  mutable lasso_ctx* side_ = nullptr;
 
  public:
   lasso_ctx* ctx = nullptr;
   Comm comm;
-  explicit Dev(int device) { if (lasso_ctx_create(device, &ctx) != 0) throw Error(std::string("lasso_ctx_create: ") + lasso_last_error(nullptr)); }
-  ~Dev() { if (ctx) { for (auto& kv : pool_) lasso_free(ctx, kv.second); for (auto& kv : live_) lasso_free(ctx, kv.first); lasso_ctx_destroy(ctx); } }
+  explicit Dev(int device) : device_(device) { if (lasso_ctx_create(device, &ctx) != 0) throw Error(std::string("lasso_ctx_create: ") + lasso_last_error(nullptr)); }
+  ~Dev() { if (side_) lasso_ctx_destroy(side_); if (ctx) { for (auto& kv : pool_) lasso_free(ctx, kv.second); for (auto& kv : live_) lasso_free(ctx, kv.first); lasso_ctx_destroy(ctx); } }
+  // A second context on the same device (own stream, scratch and result buffer): streaming work that does not depend on the transcript is
+  // issued there while the main context is inside a latency-bound phase (Prover::prep_open).  Buffers it touches must outlive its work:
+  // the pool's stream-ordered reuse argument below holds per context, so lasso_sync(side()) precedes their release.
+  lasso_ctx* side() const { if (!side_ && lasso_ctx_create(device_, &side_) != 0) throw Error(std::string("lasso_ctx_create (side): ") + lasso_last_error(nullptr)); return side_; }
+  void chk_side(int32_t rc, const char* what) const { if (rc != 0) throw Error(std::string(what) + " failed on the side context (" + std::to_string(rc) + "): " + lasso_last_error(side_)); }
   Dev(const Dev&) = delete; Dev& operator=(const Dev&) = delete;
   void chk(int32_t rc, const char* what) const { if (rc != 0) throw Error(std::string(what) + " failed (" + std::to_string(rc) + "): " + lasso_last_error(ctx)); }
   void* alloc_bytes(size_t bytes) const {
@@ -453,6 +460,8 @@ class Prover {
   DBuf combined_E;                   // Subtables::combined_poly = merge(lookup_polys); E_i = slice i (local slab)
   const lasso_fr* E(size_t i) const { return combined_E.p + i * s_loc; }
   std::vector<DBuf> tail_bufs;       // P-element replicated arrays of the current sumcheck's tail
+  std::vector<DBuf> side_keep;       // inputs of work in flight on the side context (released after lasso_sync(side))
+  static bool side_off() { static const bool v = [] { const char* e = getenv("LASSO_SIDE_STREAM"); return e && e[0] == '0'; }(); return v; }
 
  public:
   std::vector<uint8_t> proof_bytes;
@@ -870,9 +879,50 @@ class Prover {
     }
     return dot_product_log_prove(g, d_LZ, d_R, a_bytes, Zr);
   }
+  // ---- openings prepared ahead of the transcript.  joint_open's point is (ch, r): k challenges ch drawn when the opening starts, r known earlier
+  // (the grand-product argument's random point).  The L*Z of PolyEvalProof::prove (dense_mlpoly.rs:184-207, :336-340) factors through ch:
+  //   L = eq(ch) (x) eq(r[0 .. left-k))   =>   L*Z = sum_b eq(ch)[b] * M_b,   M_b = eq(r[0 .. left-k)) * Z_b   (Z_b = block b of 2^(left-k) rows),
+  // so the pass over the whole polynomial (the M_b) and the right-half table depend on r only.  They are computed on the side context (own
+  // stream) while the main context sits in a latency-bound phase — the second grand-product argument, or the previous opening's bullet rounds —
+  // and at opening time a 2^k-row mat-vec combines them.
+  struct OpenPrep { DBuf M, R; size_t k = 0, left = 0, right = 0; bool ready = false; };
+  OpenPrep prep_open(const lasso_fr* d_poly, size_t k, const ScVec& r) {
+    OpenPrep pr; const size_t nv = k + r.size();
+    pr.k = k; pr.left = nv / 2; pr.right = nv - pr.left;
+    if (P != 1 || pr.left < k || side_off()) return pr;
+    lasso_ctx* sc = d.side();
+    const size_t lrows = (size_t)1 << (pr.left - k), Rn = (size_t)1 << pr.right, nb = (size_t)1 << k;
+    pr.M = DBuf(d, nb * Rn); pr.R = DBuf(d, Rn);
+    DBuf Lp(d, lrows);
+    std::vector<lasso_fr> rl, rr; for (size_t i = 0; i + k < pr.left; i++) rl.push_back(r[i].abi()); for (size_t i = pr.left - k; i < r.size(); i++) rr.push_back(r[i].abi());
+    d.chk_side(lasso_eq_evals(sc, rl.data(), (uint32_t)rl.size(), Lp.p), "lasso_eq_evals");
+    d.chk_side(lasso_eq_evals(sc, rr.data(), (uint32_t)rr.size(), pr.R.p), "lasso_eq_evals");
+    for (size_t b = 0; b < nb; b++) d.chk_side(lasso_matvec_left_dev(sc, d_poly + b * lrows * Rn, Lp.p, lrows, Rn, pr.M.p + b * Rn), "lasso_matvec_left_dev");
+    side_keep.push_back(std::move(Lp));
+    pr.ready = true; return pr;
+  }
+  void side_sync() { if (!side_keep.empty() || true) { d.chk_side(lasso_sync(d.side()), "lasso_sync"); side_keep.clear(); } }
+  DotProductProofLog poly_eval_prove_prepped(OpenPrep& pr, const ScVec& ch, const Sc& Zr, const PolyCommitmentGens& g) {
+    Trace tr("DensePolyEval.prove", d.ctx);
+    t.append_protocol_name("polynomial evaluation proof");
+    LASSO_REQUIRE(pr.ready && ch.size() == pr.k);
+    side_sync();
+    const size_t Rn = (size_t)1 << pr.right, nb = (size_t)1 << pr.k;
+    DBuf d_LZ;
+    if (pr.k == 0) d_LZ = std::move(pr.M);
+    else {
+      DBuf w(d, nb); d_LZ = DBuf(d, Rn);
+      std::vector<lasso_fr> cc; for (auto& c : ch) cc.push_back(c.abi());
+      d.chk(lasso_eq_evals(d.ctx, cc.data(), (uint32_t)cc.size(), w.p), "lasso_eq_evals");
+      d.chk(lasso_matvec_left_dev(d.ctx, pr.M.p, w.p, nb, Rn, d_LZ.p), "lasso_matvec_left_dev");
+    }
+    std::vector<uint8_t> a_bytes(32 * Rn);
+    d.chk(lasso_fr_to_bytes(d.ctx, pr.R.p, Rn, a_bytes.data()), "lasso_fr_to_bytes");
+    return dot_product_log_prove(g, d_LZ, pr.R, a_bytes, Zr);
+  }
   // ---- CombinedTableEvalProof::prove (subtables/mod.rs:285-313) / the two n-to-1 reductions of HashLayerProof (memory_checking.rs:370-449)
   DotProductProofLog joint_open(const char* evals_label, const char* challenge_label, const char* joint_label, ScVec evals, bool pad_before_append,
-                                const lasso_fr* d_poly, size_t num_vars, const ScVec& r, const PolyCommitmentGens& g) {
+                                const lasso_fr* d_poly, size_t num_vars, const ScVec& r, const PolyCommitmentGens& g, OpenPrep* prep = nullptr) {
     if (pad_before_append) evals.resize(next_pow2(evals.size()), Sc::zero());
     t.append_scalars(evals_label, evals);
     ScVec ch = t.challenge_vector(challenge_label, ceil_log2(evals.size()));
@@ -883,6 +933,7 @@ class Prover {
     Sc joint = evals[0];
     ScVec r_joint = ch; r_joint.insert(r_joint.end(), r.begin(), r.end());
     t.append_scalar(joint_label, joint);
+    if (prep && prep->ready) { LASSO_REQUIRE(prep->k == ch.size() && prep->k + r.size() == num_vars); return poly_eval_prove_prepped(*prep, ch, joint, g); }
     return poly_eval_prove(d_poly, num_vars, r_joint, joint, g);
   }
 
@@ -1020,38 +1071,69 @@ class Prover {
     ScVec rand_ops, rand_mem;
     BatchedGrandProductArgument proof_ops = bgpa_prove(rw, rw_top, s, roots_rw, rand_ops);
     t_read.clear(); t_write.clear();
+    // Everything HashLayerProof needs at rand_ops that does not depend on the transcript — the evaluations of E / dim / read (one pass over all of
+    // them) and the big mat-vecs of the two openings at rand_ops — starts now on the side context and runs under the second grand-product
+    // argument, which is latency-bound (two 2^16-leaf circuits per memory) and leaves the device mostly idle.
+    const size_t C = S.C();
+    const size_t k_derefs = ceil_log2(next_pow2(alpha)), k_ops = ceil_log2(next_pow2(2 * C)), k_mem = ceil_log2(next_pow2(C));
+    std::vector<const lasso_fr*> at_ops(Eptr); for (size_t i = 0; i < C; i++) at_ops.push_back(dense.dim(i)); for (size_t i = 0; i < C; i++) at_ops.push_back(dense.read(i));
+    OpenPrep prep_derefs, prep_ops, prep_mem;
+    const bool side = P == 1 && !side_off();
+    if (side) {
+      lasso_ctx* sc = d.side();
+      std::vector<lasso_fr> rr; for (auto& x : rand_ops) rr.push_back(x.abi());
+      d.chk_side(lasso_eq_evals(sc, rr.data(), (uint32_t)rr.size(), chis.p), "lasso_eq_evals");
+      d.chk_side(lasso_defer_next(sc), "lasso_defer_next");
+      std::vector<lasso_fr> dummy(at_ops.size());
+      d.chk_side(lasso_multi_dot(sc, at_ops.data(), (uint32_t)at_ops.size(), chis.p, s_loc, dummy.data()), "lasso_multi_dot");
+      prep_derefs = prep_open(combined_E.p, k_derefs, rand_ops);
+      prep_ops = prep_open(dense.combined_l_variate_polys.p, k_ops, rand_ops);
+    }
     BatchedGrandProductArgument proof_mem = bgpa_prove(inf, inf_top, m, roots_if, rand_mem);
     t_init.clear(); t_final.clear(); tops_store.clear();
     proof_mem.write(W); proof_ops.write(W);    // field order of ProductLayerProof: grand_product_evals, proof_mem, proof_ops (:656-660)
     // HashLayerProof::prove (memory_checking.rs:338-460)
     sp.reset(new Trace("HashLayer.prove", d.ctx));
     t.append_protocol_name("Lasso HashLayerProof");
-    const size_t C = S.C();
-    std::vector<const lasso_fr*> at_ops(Eptr); for (size_t i = 0; i < C; i++) at_ops.push_back(dense.dim(i)); for (size_t i = 0; i < C; i++) at_ops.push_back(dense.read(i));
     ScVec ev_ops;
+    DBuf chim(d, m_loc);
+    std::vector<const lasso_fr*> fin; for (size_t i = 0; i < C; i++) fin.push_back(dense.final_(i));
     {
-      eq_evals_local(rand_ops, chis.p);
       std::vector<lasso_fr> out(at_ops.size());
-      d.chk(lasso_multi_dot(d.ctx, at_ops.data(), (uint32_t)at_ops.size(), chis.p, s_loc, out.data()), "lasso_multi_dot");
-      d.comm.sum(out);
+      if (side) {
+        d.chk_side(lasso_result_wait(d.side(), out.data(), out.size()), "lasso_result_wait");
+        // the same for rand_mem (known now): the evaluations of final and the mat-vec of the last opening run under the first opening's bullet rounds
+        std::vector<lasso_fr> rr; for (auto& x : rand_mem) rr.push_back(x.abi());
+        d.chk_side(lasso_eq_evals(d.side(), rr.data(), (uint32_t)rr.size(), chim.p), "lasso_eq_evals");
+        d.chk_side(lasso_defer_next(d.side()), "lasso_defer_next");
+        std::vector<lasso_fr> dummy(C);
+        d.chk_side(lasso_multi_dot(d.side(), fin.data(), (uint32_t)C, chim.p, m_loc, dummy.data()), "lasso_multi_dot");
+        prep_mem = prep_open(dense.combined_log_m_variate_polys.p, k_mem, rand_mem);
+      } else {
+        eq_evals_local(rand_ops, chis.p);
+        d.chk(lasso_multi_dot(d.ctx, at_ops.data(), (uint32_t)at_ops.size(), chis.p, s_loc, out.data()), "lasso_multi_dot");
+        d.comm.sum(out);
+      }
       for (auto& o : out) ev_ops.push_back(Sc::from_abi(o));
     }
     ScVec eval_derefs(ev_ops.begin(), ev_ops.begin() + alpha), eval_dim(ev_ops.begin() + alpha, ev_ops.begin() + alpha + C), eval_read(ev_ops.begin() + alpha + C, ev_ops.end());
     t.append_protocol_name("Lasso CombinedTableEvalProof");
-    DotProductProofLog proof_derefs = joint_open("evals_ops_val", "challenge_combine_n_to_one", "joint_claim_eval", eval_derefs, true, combined_E.p, nv_derefs, rand_ops, gens.gens_derefs);
+    DotProductProofLog proof_derefs = joint_open("evals_ops_val", "challenge_combine_n_to_one", "joint_claim_eval", eval_derefs, true, combined_E.p, nv_derefs, rand_ops, gens.gens_derefs, &prep_derefs);
     ScVec eval_final;
     {
-      DBuf chim(d, m_loc);
-      eq_evals_local(rand_mem, chim.p);
-      std::vector<const lasso_fr*> fin; for (size_t i = 0; i < C; i++) fin.push_back(dense.final_(i));
       std::vector<lasso_fr> out(C);
-      d.chk(lasso_multi_dot(d.ctx, fin.data(), (uint32_t)C, chim.p, m_loc, out.data()), "lasso_multi_dot");
-      d.comm.sum(out);
+      if (side) d.chk_side(lasso_result_wait(d.side(), out.data(), C), "lasso_result_wait");
+      else {
+        eq_evals_local(rand_mem, chim.p);
+        d.chk(lasso_multi_dot(d.ctx, fin.data(), (uint32_t)C, chim.p, m_loc, out.data()), "lasso_multi_dot");
+        d.comm.sum(out);
+      }
       for (auto& o : out) eval_final.push_back(Sc::from_abi(o));
     }
     ScVec evals_ops = eval_dim; evals_ops.insert(evals_ops.end(), eval_read.begin(), eval_read.end());
-    DotProductProofLog proof_ops_open = joint_open("claim_evals_ops", "challenge_combine_n_to_one", "joint_claim_eval_ops", evals_ops, true, dense.combined_l_variate_polys.p, dense.nv_l, rand_ops, gens.gens_combined_l_variate);
-    DotProductProofLog proof_mem_open = joint_open("claim_evals_mem", "challenge_combine_two_to_one", "joint_claim_eval_mem", eval_final, false, dense.combined_log_m_variate_polys.p, dense.nv_m, rand_mem, gens.gens_combined_log_m_variate);
+    DotProductProofLog proof_ops_open = joint_open("claim_evals_ops", "challenge_combine_n_to_one", "joint_claim_eval_ops", evals_ops, true, dense.combined_l_variate_polys.p, dense.nv_l, rand_ops, gens.gens_combined_l_variate, &prep_ops);
+    DotProductProofLog proof_mem_open = joint_open("claim_evals_mem", "challenge_combine_two_to_one", "joint_claim_eval_mem", eval_final, false, dense.combined_log_m_variate_polys.p, dense.nv_m, rand_mem, gens.gens_combined_log_m_variate, &prep_mem);
+    if (side) side_sync();
     W.sc_arr(eval_dim); W.sc_arr(eval_read); W.sc_arr(eval_final); W.sc_arr(eval_derefs);     // HashLayerProof field order (:314-329)
     proof_ops_open.write(W); proof_mem_open.write(W); proof_derefs.write(W);
   }

@@ -12,15 +12,18 @@
 
 using namespace orc;
 
-struct lasso_ctx { std::string err; };
+struct lasso_ctx {
+  std::string err;
+  // launch/wait split (per context, as on the device): the result of a deferred / *_begin call, handed over by lasso_result_wait
+  std::vector<Fr> pending; bool defer = false;
+  std::vector<std::vector<Fr>> tail_a, tail_b; std::vector<Fr> tail_e;   // resident tail: private copies of the arrays
+};
 struct lasso_bases { std::vector<Point> pts; };
 
 static int32_t fail(lasso_ctx* c, const char* m) { if (c) c->err = m; return LASSO_ERR_INVALID; }
 #define REQ(c, cond) do { if (!(cond)) return fail((c), "invalid argument: " #cond); } while (0)
 static inline const Fr* F(const lasso_fr* p) { return reinterpret_cast<const Fr*>(p); }
 static inline Fr* F(lasso_fr* p) { return reinterpret_cast<Fr*>(p); }
-static thread_local std::vector<Fr> g_pending;   // result of a deferred / *_begin call, handed over by lasso_result_wait
-static thread_local bool g_defer = false;       // lasso_defer_next: the next supporting call parks its result in g_pending
 static Strategy mk(const lasso_strategy* s) { Strategy S; S.kind = (StrategyKind)s->kind; S.C = s->c; S.M = (size_t)1 << s->log_m; S.LOG_R = s->log_r; return S; }
 static void put_point(const Point& p, lasso_point* o) { memcpy(o->x, p.X.v, 32); memcpy(o->y, p.Y.v, 32); memcpy(o->t, p.T.v, 32); memcpy(o->z, p.Z.v, 32); }
 
@@ -124,52 +127,51 @@ int32_t lasso_sumcheck_cubic_eqw2_begin(lasso_ctx* c, lasso_fr* const* A, lasso_
     n = h;
   }
   const size_t len = n / 2; const Fr* pe = F(E);
-  g_pending.assign(2 * (size_t)nc, Fr::zero());
+  c->pending.assign(2 * (size_t)nc, Fr::zero());
   for (uint32_t k = 0; k < nc; k++) {
     const Fr* pa = F(A[k]); const Fr* pb = F(B[k]);
     Fr q0 = Fr::zero(), qi = Fr::zero();
     for (size_t i = 0; i < len; i++) { q0 += pa[i] * pb[i] * pe[i]; qi += (pa[len + i] - pa[i]) * (pb[len + i] - pb[i]) * pe[i]; }
-    g_pending[2 * k] = q0; g_pending[2 * k + 1] = qi;
+    c->pending[2 * k] = q0; c->pending[2 * k + 1] = qi;
   }
   return 0;
 }
 int32_t lasso_result_wait(lasso_ctx* c, lasso_fr* out, size_t count) {
-  REQ(c, out && count == g_pending.size());
-  for (size_t i = 0; i < count; i++) F(out)[i] = g_pending[i];
-  g_pending.clear();
+  REQ(c, out && count == c->pending.size());
+  for (size_t i = 0; i < count; i++) F(out)[i] = c->pending[i];
+  c->pending.clear();
   return 0;
 }
 // resident tail: the mock keeps private copies of the arrays (the device kernel keeps them in LDS and never writes them back either)
-static thread_local std::vector<std::vector<Fr>> g_tail_a, g_tail_b;
-static thread_local std::vector<Fr> g_tail_e;
-static void tail_publish() {
-  const size_t k = g_tail_a.size(), m = g_tail_a[0].size();
-  g_pending.assign(2 * k, Fr::zero());
-  if (m == 1) { for (size_t c = 0; c < k; c++) { g_pending[c] = g_tail_a[c][0]; g_pending[k + c] = g_tail_b[c][0]; } g_tail_a.clear(); g_tail_b.clear(); return; }
+static void tail_publish(lasso_ctx* ctx) {
+  auto& ta = ctx->tail_a; auto& tb = ctx->tail_b; auto& te = ctx->tail_e; auto& pend = ctx->pending;
+  const size_t k = ta.size(), m = ta[0].size();
+  pend.assign(2 * k, Fr::zero());
+  if (m == 1) { for (size_t c = 0; c < k; c++) { pend[c] = ta[c][0]; pend[k + c] = tb[c][0]; } ta.clear(); tb.clear(); return; }
   const size_t h = m / 2;
   for (size_t c = 0; c < k; c++) {
     Fr q0 = Fr::zero(), qi = Fr::zero();
-    for (size_t i = 0; i < h; i++) { q0 += g_tail_a[c][i] * g_tail_b[c][i] * g_tail_e[i]; qi += (g_tail_a[c][h + i] - g_tail_a[c][i]) * (g_tail_b[c][h + i] - g_tail_b[c][i]) * g_tail_e[i]; }
-    g_pending[2 * c] = q0; g_pending[2 * c + 1] = qi;
+    for (size_t i = 0; i < h; i++) { q0 += ta[c][i] * tb[c][i] * te[i]; qi += (ta[c][h + i] - ta[c][i]) * (tb[c][h + i] - tb[c][i]) * te[i]; }
+    pend[2 * c] = q0; pend[2 * c + 1] = qi;
   }
 }
-static void tail_bind(const Fr& r) {
-  for (auto* arrs : {&g_tail_a, &g_tail_b}) for (auto& v : *arrs) { const size_t h = v.size() / 2; for (size_t i = 0; i < h; i++) v[i] = v[i] + r * (v[i + h] - v[i]); v.resize(h); }
+static void tail_bind(lasso_ctx* c, const Fr& r) {
+  for (auto* arrs : {&c->tail_a, &c->tail_b}) for (auto& v : *arrs) { const size_t h = v.size() / 2; for (size_t i = 0; i < h; i++) v[i] = v[i] + r * (v[i + h] - v[i]); v.resize(h); }
 }
 int32_t lasso_sumcheck_cubic_tail_begin(lasso_ctx* c, lasso_fr* const* A, lasso_fr* const* B, uint32_t nc, const lasso_fr* E, size_t n, const lasso_fr* r) {
-  REQ(c, n >= (r ? 4u : 2u) && (n & (n - 1)) == 0 && g_tail_a.empty() && g_pending.empty());
+  REQ(c, n >= (r ? 4u : 2u) && (n & (n - 1)) == 0 && c->tail_a.empty() && c->pending.empty());
   const size_t q = r ? n / 4 : n / 2; REQ(c, q >= 1 && q <= 256);
-  g_tail_a.clear(); g_tail_b.clear();
-  for (uint32_t k = 0; k < nc; k++) { g_tail_a.emplace_back(F(A[k]), F(A[k]) + n); g_tail_b.emplace_back(F(B[k]), F(B[k]) + n); }
-  g_tail_e.assign(F(E), F(E) + q);
-  if (r) tail_bind(*F(r));
-  tail_publish();
+  c->tail_a.clear(); c->tail_b.clear();
+  for (uint32_t k = 0; k < nc; k++) { c->tail_a.emplace_back(F(A[k]), F(A[k]) + n); c->tail_b.emplace_back(F(B[k]), F(B[k]) + n); }
+  c->tail_e.assign(F(E), F(E) + q);
+  if (r) tail_bind(c, *F(r));
+  tail_publish(c);
   return 0;
 }
 int32_t lasso_sumcheck_cubic_tail_next(lasso_ctx* c, const lasso_fr* r) {
-  REQ(c, r && !g_tail_a.empty() && g_pending.empty());
-  tail_bind(*F(r));
-  tail_publish();
+  REQ(c, r && !c->tail_a.empty() && c->pending.empty());
+  tail_bind(c, *F(r));
+  tail_publish(c);
   return 0;
 }
 int32_t lasso_sumcheck_combine_round(lasso_ctx* c, const lasso_strategy* s, const lasso_fr* const* polys, const lasso_fr* eq, size_t n, uint32_t degree, lasso_fr* out) {
@@ -186,13 +188,14 @@ int32_t lasso_sumcheck_combine_round(lasso_ctx* c, const lasso_strategy* s, cons
   }
   memcpy(out, ev.data(), ev.size() * 32); return 0;
 }
-int32_t lasso_combine_claim(lasso_ctx*, const lasso_strategy* s, const lasso_fr* const* polys, const lasso_fr* eq, size_t n, lasso_fr* out) {
+int32_t lasso_combine_claim(lasso_ctx* c, const lasso_strategy* s, const lasso_fr* const* polys, const lasso_fr* eq, size_t n, lasso_fr* out) {
   Strategy S = mk(s); size_t alpha = S.num_memories(); std::vector<Fr> v(alpha); Fr claim = Fr::zero();
   for (size_t k = 0; k < n; k++) { for (size_t j = 0; j < alpha; j++) v[j] = F(polys[j])[k]; claim += F(eq)[k] * S.combine_lookups(v.data()); }  // subtables/mod.rs:197-213
-  if (g_defer) { g_defer = false; g_pending.assign(1, claim); return 0; }   // lasso_defer_next
+  if (c->defer) { c->defer = false; c->pending.assign(1, claim); return 0; }   // lasso_defer_next
   *F(out) = claim; return 0;
 }
-int32_t lasso_multi_dot(lasso_ctx*, const lasso_fr* const* polys, uint32_t k, const lasso_fr* w, size_t n, lasso_fr* out) {
+int32_t lasso_multi_dot(lasso_ctx* c, const lasso_fr* const* polys, uint32_t k, const lasso_fr* w, size_t n, lasso_fr* out) {
+  if (c->defer) { c->defer = false; c->pending.resize(k); for (uint32_t p = 0; p < k; p++) c->pending[p] = compute_dotproduct(F(polys[p]), F(w), n); return 0; }   // lasso_defer_next
   for (uint32_t p = 0; p < k; p++) F(out)[p] = compute_dotproduct(F(polys[p]), F(w), n); return 0;
 }
 int32_t lasso_read_heads(lasso_ctx*, const lasso_fr* const* polys, uint32_t k, lasso_fr* out) { for (uint32_t p = 0; p < k; p++) out[p] = polys[p][0]; return 0; }
@@ -287,14 +290,14 @@ int32_t lasso_msm(lasso_ctx* c, const lasso_bases* b, const lasso_fr* scalars, s
 }
 
 // lasso_defer_next in the mock: the deferred call computes at once and parks its result for lasso_result_wait (points as 4 field elements each)
-int32_t lasso_defer_next(lasso_ctx* c) { REQ(c, !g_defer && g_pending.empty()); g_defer = true; return 0; }
-static int32_t deliver_points(const lasso_point* pts, size_t n, lasso_point* out) {
-  if (g_defer) { g_defer = false; g_pending.resize(4 * n); memcpy((void*)g_pending.data(), pts, n * sizeof(lasso_point)); return 0; }
+int32_t lasso_defer_next(lasso_ctx* c) { REQ(c, !c->defer && c->pending.empty()); c->defer = true; return 0; }
+static int32_t deliver_points(lasso_ctx* c, const lasso_point* pts, size_t n, lasso_point* out) {
+  if (c->defer) { c->defer = false; c->pending.resize(4 * n); memcpy((void*)c->pending.data(), pts, n * sizeof(lasso_point)); return 0; }
   memcpy(out, pts, n * sizeof(lasso_point)); return 0;
 }
 int32_t lasso_msm_dev(lasso_ctx* c, const lasso_bases* b, const lasso_fr* scalars, size_t n, lasso_point* out) {
   lasso_point tmp; int32_t rc = lasso_msm(c, b, scalars, n, &tmp); if (rc) return rc;
-  return deliver_points(&tmp, 1, out);
+  return deliver_points(c, &tmp, 1, out);
 }
 int32_t lasso_matvec_left_dev(lasso_ctx* c, const lasso_fr* Z, const lasso_fr* L, size_t ls, size_t rs, lasso_fr* out) { return lasso_matvec_left(c, Z, L, ls, rs, out); }
 int32_t lasso_fr_to_bytes(lasso_ctx*, const lasso_fr* src, size_t n, uint8_t* out) { for (size_t i = 0; i < n; i++) { u64 cc[4]; F(src)[i].to_canonical(cc); memcpy(out + 32 * i, cc, 32); } return 0; }
@@ -339,7 +342,7 @@ int32_t lasso_bullet_round(lasso_ctx* c, const lasso_bases* bs, size_t n, const 
   lasso_fr cc[2]; lasso_inner_products_lr(c, a, b, nk, cc);
   lasso_fr tail[4] = {cc[0], blinds[0], cc[1], blinds[1]};
   lasso_point lr[2]; int32_t rc = lasso_bullet_lr(c, bs, n, a, nk, w, tail, lr); if (rc) return rc;
-  return deliver_points(lr, 2, out);
+  return deliver_points(c, lr, 2, out);
 }
 int32_t lasso_bullet_fold(lasso_ctx*, lasso_fr* a, lasso_fr* b, size_t nk, const lasso_fr* w, size_t nw, lasso_fr* w_out, const lasso_fr* u, const lasso_fr* u_inv) {
   size_t h = nk / 2; Fr uu = *F(u), ui = *F(u_inv);
