@@ -147,6 +147,10 @@ int32_t lasso_sumcheck_combine_round(lasso_ctx* ctx, const lasso_strategy* s, co
 int32_t lasso_sumcheck_linear_eqw_round(lasso_ctx* ctx, const lasso_fr* const* d_polys, uint32_t alpha, const lasso_fr* d_E, size_t n, lasso_fr* out);
 /* bind the alpha polynomials with the previous challenge r (in place, n = length before the bind, n >= 4), then the sums of the next round (length n/2) */
 int32_t lasso_sumcheck_linear_eqw_round_fused(lasso_ctx* ctx, lasso_fr* const* d_polys, uint32_t alpha, const lasso_fr* d_E, size_t n, const lasso_fr* r, lasso_fr* out);
+/* The same with separate source arrays: reads d_src[k] (length n), writes the bound arrays (length n/2) to d_polys[k]; d_src[k] == d_polys[k] is the
+ * in-place call above.  The prover's first bind takes the lookup polynomials E_k themselves as source, so surge.rs:151's clones are never made. */
+int32_t lasso_sumcheck_linear_eqw_round_fused_from(lasso_ctx* ctx, const lasso_fr* const* d_src, lasso_fr* const* d_polys, uint32_t alpha, const lasso_fr* d_E,
+                                                   size_t n, const lasso_fr* r, lasso_fr* out);
 /* Subtables::compute_sumcheck_claim (src/subtables/mod.rs:187-216): out = sum_k eq[k] * g(E_1[k],...,E_alpha[k]) */
 int32_t lasso_combine_claim(lasso_ctx* ctx, const lasso_strategy* s, const lasso_fr* const* d_polys, const lasso_fr* d_eq, size_t n, lasso_fr* out);
 /* compute_dotproduct for k polynomials against one weight vector (src/utils/mod.rs:64-73 via DensePolynomial::evaluate

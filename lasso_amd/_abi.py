@@ -52,6 +52,7 @@ def declare(lib):
         "lasso_sumcheck_combine_round": (i32, [vp, P(Strategy), P(vp), vp, sz, u32, vp]),
         "lasso_sumcheck_linear_eqw_round": (i32, [vp, P(vp), u32, vp, sz, vp]),
         "lasso_sumcheck_linear_eqw_round_fused": (i32, [vp, P(vp), u32, vp, sz, vp, vp]),
+        "lasso_sumcheck_linear_eqw_round_fused_from": (i32, [vp, P(vp), P(vp), u32, vp, sz, vp, vp]),
         "lasso_combine_claim": (i32, [vp, P(Strategy), P(vp), vp, sz, vp]),
         "lasso_multi_dot": (i32, [vp, P(vp), u32, vp, sz, vp]),
         "lasso_read_heads": (i32, [vp, P(vp), u32, vp]),

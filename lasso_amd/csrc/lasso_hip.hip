@@ -383,8 +383,11 @@ int32_t lasso_sumcheck_linear_eqw_round(lasso_ctx* c, const lasso_fr* const* d_p
   return wait_flag(c, seq, (size_t)alpha * 3, out);
 }
 int32_t lasso_sumcheck_linear_eqw_round_fused(lasso_ctx* c, lasso_fr* const* d_polys, uint32_t alpha, const lasso_fr* d_E, size_t n, const lasso_fr* r, lasso_fr* out) {
-  REQUIRE(c, d_polys && d_E && r && out && alpha >= 1 && alpha <= LASSO_MAX_PTRS && n >= 4 && (n & (n - 1)) == 0);
-  MutPtrTable P; for (uint32_t i = 0; i < alpha; i++) { REQUIRE(c, d_polys[i]); P.p[i] = (fr_t*)d_polys[i]; }
+  return lasso_sumcheck_linear_eqw_round_fused_from(c, (const lasso_fr* const*)d_polys, d_polys, alpha, d_E, n, r, out);
+}
+int32_t lasso_sumcheck_linear_eqw_round_fused_from(lasso_ctx* c, const lasso_fr* const* d_src, lasso_fr* const* d_polys, uint32_t alpha, const lasso_fr* d_E, size_t n, const lasso_fr* r, lasso_fr* out) {
+  REQUIRE(c, d_src && d_polys && d_E && r && out && alpha >= 1 && alpha <= LASSO_MAX_PTRS && n >= 4 && (n & (n - 1)) == 0);
+  MutPtrTable P; PtrTable Src; for (uint32_t i = 0; i < alpha; i++) { REQUIRE(c, d_polys[i] && d_src[i]); P.p[i] = (fr_t*)d_polys[i]; Src.p[i] = (const fr_t*)d_src[i]; }
   const size_t q = n / 4; const unsigned ny = alpha, nx = grid_for(q, cubic_nx_cap(ny));
   int32_t rc = ensure_small(c, (size_t)alpha * 3); if (rc) return rc;
   rc = ensure_scratch(c, (size_t)nx * ny * 3 * sizeof(fr_t)); if (rc) return rc;
@@ -392,7 +395,7 @@ int32_t lasso_sumcheck_linear_eqw_round_fused(lasso_ctx* c, lasso_fr* const* d_p
   {
     // bind (48 n per polynomial, the reference's alpha + 1 of them) with the next round's sums riding on the same pass
     ProfScope ps(c, LASSO_K_BIND, 48.0 * n * (alpha + 1.0));
-    hipLaunchKernelGGL(k_dot_eqw_fused, dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, P, nx, ny, (const fr_t*)d_E, q, to_fr(r), (fr_t*)c->d_scratch, c->d_counters, c->d_small, c->d_flag, seq);
+    hipLaunchKernelGGL(k_dot_eqw_fused, dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, Src, P, nx, ny, (const fr_t*)d_E, q, to_fr(r), (fr_t*)c->d_scratch, c->d_counters, c->d_small, c->d_flag, seq);
   }
   HIPCHK(c, hipGetLastError());
   return wait_flag(c, seq, (size_t)alpha * 3, out);

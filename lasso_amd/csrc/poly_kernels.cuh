@@ -470,16 +470,19 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_dot_eqw_lb(PtrTable polys, uint
   fr29 e[3] = {fr29_acc_reduce(w0), fr29_acc_reduce(w1), fr29_zero()};
   cubic_epilogue(e, g, partials, counters, out, flag, seq, S, fr29_one_s());
 }
-__global__ void __launch_bounds__(LASSO_BLOCK) k_dot_eqw_fused(MutPtrTable polys, uint32_t nx, uint32_t ny, const fr_t* __restrict__ E, size_t q, fr_t r, fr_t* __restrict__ partials, uint32_t* counters,
+// src != polys: the bind reads src (length 4q) and writes the bound halves to polys — the first bind of the primary sumcheck takes E itself as
+// src, so surge.rs:151's clone of the lookup polynomials never happens (the sumcheck must not modify E, which the later openings read)
+__global__ void __launch_bounds__(LASSO_BLOCK) k_dot_eqw_fused(PtrTable src, MutPtrTable polys, uint32_t nx, uint32_t ny, const fr_t* __restrict__ E, size_t q, fr_t r, fr_t* __restrict__ partials, uint32_t* counters,
                                                                 fr_t* __restrict__ out, uint32_t* flag, uint32_t seq) {
   __shared__ RedScratch S;
   const CubicGrid g = cubic_grid(nx, ny);
-  fr_t* __restrict__ z = polys.p[g.by];
+  fr_t* zd = polys.p[g.by];          // may alias z (in-place call): every thread reads its four elements before it writes its two
+  const fr_t* z = src.p[g.by];
   const fr29 rs = fr29_unpack_s(r);
   fr29_acc w0 = fr29_acc_zero(), w1 = fr29_acc_zero(); uint32_t cnt = 0;
   for (size_t i = g.bx * (size_t)blockDim.x + threadIdx.x; i < q; i += (size_t)nx * blockDim.x) {
     const fr29 z0 = bind29(z[i], z[i + 2 * q], rs), z1 = bind29(z[i + q], z[i + 3 * q], rs);
-    z[i] = fr29_pack(z0); z[i + q] = fr29_pack(z1);
+    zd[i] = fr29_pack(z0); zd[i + q] = fr29_pack(z1);
     const fr29 es = fr29_unpack_s(E[i]);
     fr29_mul_acc(w0, z0, es);
     fr29_mul_acc(w1, z1, es);

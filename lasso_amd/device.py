@@ -114,6 +114,12 @@ class Device:
         self._chk(self.lib.lasso_sumcheck_linear_eqw_round_fused(self.ctx, self._ptrs(ptrs), len(ptrs), C.c_void_p(d_e), n, _vp(r), _vp(out)))
         return out.reshape(len(ptrs), 3, 4)[:, :2].copy()
 
+    def sumcheck_linear_eqw_round_fused_from(self, src_ptrs, dst_ptrs, d_e, n, r):
+        r = np.ascontiguousarray(r, dtype=np.uint64)
+        out = np.empty((3 * len(dst_ptrs), 4), dtype=np.uint64)
+        self._chk(self.lib.lasso_sumcheck_linear_eqw_round_fused_from(self.ctx, self._ptrs(src_ptrs), self._ptrs(dst_ptrs), len(dst_ptrs), C.c_void_p(d_e), n, _vp(r), _vp(out)))
+        return out.reshape(len(dst_ptrs), 3, 4)[:, :2].copy()
+
     def sumcheck_cubic_eqw_round(self, a_ptrs, b_ptrs, d_e, n):
         out = np.empty((3 * len(a_ptrs), 4), dtype=np.uint64)
         self._chk(self.lib.lasso_sumcheck_cubic_eqw_round(self.ctx, self._ptrs(a_ptrs), self._ptrs(b_ptrs), len(a_ptrs), C.c_void_p(d_e), n, _vp(out)))

@@ -527,8 +527,14 @@ class Prover {
   // The same sumcheck for the LINEAR strategies in eq-weighted form (lasso_sumcheck_linear_eqw_round): the eq polynomial is never bound (prefix of
   // d_E + host scalars), a round is one launch (bind of the previous challenge + two dot products per polynomial), the weights 2^(k*inc) are applied
   // here.  One phase = `rounds` rounds over point[v0 .. v0+rounds) on arrays of length len; polys = the alpha E clones only.
-  void linear_rounds(size_t rounds, size_t len, std::vector<lasso_fr*>& polys, const lasso_fr* d_E, const ScVec& point, size_t v0, bool reduce, Sc& s_run, SumcheckProof& proof, ScVec& r_out) {
+  // src (optional): read-only arrays holding the polynomials; the bound arrays go to `polys` (half the length) — no clone of the inputs
+  void linear_rounds(size_t rounds, size_t len, std::vector<lasso_fr*>& polys, const lasso_fr* d_E, const ScVec& point, size_t v0, bool reduce, Sc& s_run, SumcheckProof& proof, ScVec& r_out,
+                     const std::vector<const lasso_fr*>* src = nullptr) {
     if (!rounds) return;
+    if (src && rounds < 2) {   // too short for a fused bind to move the data: a one-element copy per polynomial, then in place
+      for (size_t i = 0; i < polys.size(); i++) d.chk(lasso_copy(d.ctx, polys[i], (*src)[i], len * sizeof(lasso_fr)), "lasso_copy");
+      src = nullptr;
+    }
     const ScVec w = S.weights();
     ScVec inv(rounds); bool degenerate = false;
     {
@@ -547,8 +553,13 @@ class Prover {
         table = tj.p;
       }
       std::vector<lasso_fr> ev(3 * alpha);
-      if (j == 0) d.chk(lasso_sumcheck_linear_eqw_round(d.ctx, (const lasso_fr* const*)polys.data(), (uint32_t)alpha, table, len, ev.data()), "lasso_sumcheck_linear_eqw_round");
-      else { lasso_fr rp = r_prev.abi(); d.chk(lasso_sumcheck_linear_eqw_round_fused(d.ctx, polys.data(), (uint32_t)alpha, table, len, &rp, ev.data()), "lasso_sumcheck_linear_eqw_round_fused"); len /= 2; }
+      if (j == 0) d.chk(lasso_sumcheck_linear_eqw_round(d.ctx, src ? src->data() : (const lasso_fr* const*)polys.data(), (uint32_t)alpha, table, len, ev.data()), "lasso_sumcheck_linear_eqw_round");
+      else {
+        lasso_fr rp = r_prev.abi();
+        if (j == 1 && src) d.chk(lasso_sumcheck_linear_eqw_round_fused_from(d.ctx, src->data(), polys.data(), (uint32_t)alpha, table, len, &rp, ev.data()), "lasso_sumcheck_linear_eqw_round_fused_from");
+        else d.chk(lasso_sumcheck_linear_eqw_round_fused(d.ctx, polys.data(), (uint32_t)alpha, table, len, &rp, ev.data()), "lasso_sumcheck_linear_eqw_round_fused");
+        len /= 2;
+      }
       if (reduce) d.comm.sum(ev);
       Sc G0 = Sc::zero(), G1 = Sc::zero();
       for (size_t k2 = 0; k2 < alpha; k2++) { G0 += w[k2] * Sc::from_abi(ev[3 * k2]); G1 += w[k2] * Sc::from_abi(ev[3 * k2 + 1]); }
@@ -565,27 +576,40 @@ class Prover {
     d.chk(lasso_bind_top(d.ctx, polys.data(), (uint32_t)polys.size(), len, &rp), "lasso_bind_top");
   }
   // polys: local arrays of length len_loc (global length len_loc * P); polys[alpha] = the eq table of `point` (local share in slab mode)
-  SumcheckProof prove_arbitrary(size_t num_rounds, size_t len_loc, std::vector<lasso_fr*>& polys, size_t combined_degree, const ScVec& point, ScVec& r_out) {
+  // heads_out (optional): the final values E_i(r_out) of the first alpha polynomials — the sumcheck's last bind leaves exactly
+  // E_i.evaluate(r_z) (surge.rs:175-176) in element 0 of every array, so the prover reads them instead of evaluating E_i again
+  // src (optional, linear strategies): the first alpha polynomials are read from src and never modified; polys[i < alpha] then only need len_loc / 2 elements
+  SumcheckProof prove_arbitrary(size_t num_rounds, size_t len_loc, std::vector<lasso_fr*>& polys, size_t combined_degree, const ScVec& point, ScVec& r_out, ScVec* heads_out = nullptr,
+                                const std::vector<const lasso_fr*>* src = nullptr) {
     SumcheckProof proof;
+    auto read_heads = [&](const std::vector<lasso_fr*>& arrs) {
+      if (!heads_out) return;
+      std::vector<lasso_fr> h(alpha);
+      d.chk(lasso_read_heads(d.ctx, (const lasso_fr* const*)arrs.data(), (uint32_t)alpha, h.data()), "lasso_read_heads");
+      heads_out->clear(); for (auto& x : h) heads_out->push_back(Sc::from_abi(x));
+    };
     if (S.linear()) {
       std::vector<lasso_fr*> ep(polys.begin(), polys.begin() + alpha); Sc s_run = Sc::one();
-      if (P == 1) { linear_rounds(num_rounds, len_loc, ep, polys[alpha], point, 0, false, s_run, proof, r_out); return proof; }
+      if (P == 1) { linear_rounds(num_rounds, len_loc, ep, polys[alpha], point, 0, false, s_run, proof, r_out, src); read_heads(ep); return proof; }
       LASSO_REQUIRE(num_rounds >= lgP && ((size_t)1 << (num_rounds - lgP)) == len_loc);
       const size_t local_rounds = num_rounds - lgP;
-      linear_rounds(local_rounds, len_loc, ep, polys[alpha], point, 0, true, s_run, proof, r_out);
+      if (src && local_rounds == 0) { for (size_t i = 0; i < alpha; i++) d.chk(lasso_copy(d.ctx, ep[i], (*src)[i], len_loc * sizeof(lasso_fr)), "lasso_copy"); }
+      linear_rounds(local_rounds, len_loc, ep, polys[alpha], point, 0, true, s_run, proof, r_out, src);
       std::vector<lasso_fr*> tail = gather_tail(ep);
       tail_bufs.emplace_back(d, P);
       std::vector<lasso_fr> rr; for (size_t i = local_rounds; i < num_rounds; i++) rr.push_back(point[i].abi());
       d.chk(lasso_eq_evals(d.ctx, rr.data(), (uint32_t)rr.size(), tail_bufs.back().p), "lasso_eq_evals");
       linear_rounds(lgP, P, tail, tail_bufs.back().p, point, local_rounds, false, s_run, proof, r_out);
+      read_heads(tail);
       tail_bufs.clear();
       return proof;
     }
-    if (P == 1) { arbitrary_rounds(num_rounds, len_loc, polys, combined_degree, false, proof, r_out); return proof; }
+    if (P == 1) { arbitrary_rounds(num_rounds, len_loc, polys, combined_degree, false, proof, r_out); read_heads(polys); return proof; }
     LASSO_REQUIRE(num_rounds >= lgP && ((size_t)1 << (num_rounds - lgP)) == len_loc);
     arbitrary_rounds(num_rounds - lgP, len_loc, polys, combined_degree, true, proof, r_out);
     std::vector<lasso_fr*> tail = gather_tail(polys);
     arbitrary_rounds(lgP, P, tail, combined_degree, false, proof, r_out);
+    read_heads(tail);
     tail_bufs.clear();
     return proof;
   }
@@ -990,11 +1014,16 @@ class Prover {
     // primary sumcheck on clones of E_i and the eq polynomial (surge.rs:151-172)
     ScVec r_z;
     sp.reset(new Trace("Sumcheck.prove", d.ctx));
+    ScVec sumcheck_heads;
     {
-      DBuf work(d, alpha * s_loc);
-      d.chk(lasso_copy(d.ctx, work.p, combined_E.p, alpha * s_loc * sizeof(lasso_fr)), "lasso_copy");
-      std::vector<lasso_fr*> polys; for (size_t i = 0; i < alpha; i++) polys.push_back(work.p + i * s_loc); polys.push_back(eq.p);
-      SumcheckProof sp = prove_arbitrary(ceil_log2(s), s_loc, polys, S.sumcheck_poly_degree(), r, r_z);
+      // the sumcheck binds its polynomials; E itself must survive (the openings read it).  Linear strategies: the first bind reads E and writes the
+      // half-length work arrays (no clone, surge.rs:151); LT (every polynomial enters the combine kernel and is bound in place): a clone
+      const bool no_clone = S.linear();
+      const size_t wl = no_clone && s_loc >= 4 ? s_loc / 2 : s_loc;   // fewer than two local rounds: linear_rounds copies the (tiny) arrays instead
+      DBuf work(d, alpha * wl);
+      if (!no_clone) d.chk(lasso_copy(d.ctx, work.p, combined_E.p, alpha * s_loc * sizeof(lasso_fr)), "lasso_copy");
+      std::vector<lasso_fr*> polys; for (size_t i = 0; i < alpha; i++) polys.push_back(work.p + i * wl); polys.push_back(eq.p);
+      SumcheckProof sp = prove_arbitrary(ceil_log2(s), s_loc, polys, S.sumcheck_poly_degree(), r, r_z, &sumcheck_heads, no_clone ? &Eptr : nullptr);
       sp.write(W);
     }
     W.sc(claimed_eval);
@@ -1008,7 +1037,8 @@ class Prover {
       d.comm.sum(out);
       ScVec v; for (auto& o : out) v.push_back(Sc::from_abi(o)); return v;
     };
-    ScVec eval_derefs = evaluate_at(Eptr, r_z, s_loc, chis);
+    // E_i(r_z): the value the sumcheck's last bind left behind (same field element as DensePolynomial::evaluate, without another pass over E_i)
+    ScVec eval_derefs = sumcheck_heads.size() == alpha && ceil_log2(s) > 0 ? sumcheck_heads : evaluate_at(Eptr, r_z, s_loc, chis);
     W.sc_arr(eval_derefs);
     t.append_protocol_name("Lasso CombinedTableEvalProof");
     joint_open("evals_ops_val", "challenge_combine_n_to_one", "joint_claim_eval", eval_derefs, true, combined_E.p, nv_derefs, r_z, gens.gens_derefs).write(W);

@@ -88,11 +88,14 @@ int32_t lasso_sumcheck_linear_eqw_round(lasso_ctx* c, const lasso_fr* const* pol
   }
   return 0;
 }
-int32_t lasso_sumcheck_linear_eqw_round_fused(lasso_ctx* c, lasso_fr* const* polys, uint32_t alpha, const lasso_fr* E, size_t n, const lasso_fr* r, lasso_fr* out) {
+int32_t lasso_sumcheck_linear_eqw_round_fused_from(lasso_ctx* c, const lasso_fr* const* src, lasso_fr* const* polys, uint32_t alpha, const lasso_fr* E, size_t n, const lasso_fr* r, lasso_fr* out) {
   REQ(c, n >= 4 && (n & (n - 1)) == 0);
   size_t h = n / 2;
-  for (uint32_t k = 0; k < alpha; k++) for (size_t i = 0; i < h; i++) F(polys[k])[i] = F(polys[k])[i] + *F(r) * (F(polys[k])[i + h] - F(polys[k])[i]);
+  for (uint32_t k = 0; k < alpha; k++) for (size_t i = 0; i < h; i++) F(polys[k])[i] = F(src[k])[i] + *F(r) * (F(src[k])[i + h] - F(src[k])[i]);
   return lasso_sumcheck_linear_eqw_round(c, polys, alpha, E, h, out);
+}
+int32_t lasso_sumcheck_linear_eqw_round_fused(lasso_ctx* c, lasso_fr* const* polys, uint32_t alpha, const lasso_fr* E, size_t n, const lasso_fr* r, lasso_fr* out) {
+  return lasso_sumcheck_linear_eqw_round_fused_from(c, polys, polys, alpha, E, n, r, out);
 }
 // eq-weighted form: sum_i A(x)[i] B(x)[i] E[i] at x = 0, 2, 3 (the host turns these into sumcheck.rs:56-93's evaluations with three scalars)
 int32_t lasso_sumcheck_cubic_eqw_round(lasso_ctx* c, const lasso_fr* const* A, const lasso_fr* const* B, uint32_t nc, const lasso_fr* E, size_t n, lasso_fr* out) {

@@ -602,6 +602,13 @@ def test_sumcheck_linear_eqw_rounds(devs, n, alpha):
             fused = d.sumcheck_linear_eqw_round_fused(pp, pe, n, r)
             again = d.sumcheck_linear_eqw_round(pp, pe, n // 2)
             res += [fused, again, [d.download(p, (n // 2, 4)) for p in pp]]
+            # separate source arrays: same sums, same bound arrays, sources untouched
+            ps = [d.upload(x) for x in Ps]; pd = [d.alloc(32 * (n // 2)) for _ in Ps]
+            res.append(d.sumcheck_linear_eqw_round_fused_from(ps, pd, pe, n, r))
+            res.append([d.download(p, (n // 2, 4)) for p in pd])
+            res.append([d.download(p, (n, 4)) for p in ps])
+            for p in ps + pd:
+                d.free(p)
         for p in pp + [pe]:
             d.free(p)
         return res
@@ -610,4 +617,9 @@ def test_sumcheck_linear_eqw_rounds(devs, n, alpha):
     if n >= 4:
         assert np.array_equal(a[1], b[1]) and np.array_equal(a[1], a[2])
         for x, y in zip(a[3], b[3]):
+            assert np.array_equal(x, y)
+        assert np.array_equal(a[4], a[1]) and np.array_equal(b[4], a[1])
+        for x, y, z in zip(a[5], a[3], b[5]):
+            assert np.array_equal(x, y) and np.array_equal(z, y)
+        for x, y in zip(a[6], Ps):
             assert np.array_equal(x, y)
