@@ -157,7 +157,7 @@ int32_t lasso_ctx_create(int32_t device, lasso_ctx** out) {
   if (hipMalloc((void**)&c->d_counters, (LASSO_MAX_PTRS + 40) * 4) != hipSuccess || hipMemset(c->d_counters, 0, (LASSO_MAX_PTRS + 40) * 4) != hipSuccess) { delete c; return fail(nullptr, LASSO_ERR_OOM, "counters alloc"); }
   if (hipHostMalloc((void**)&c->h_flag, 256, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess || hipHostGetDevicePointer((void**)&c->d_flag, c->h_flag, 0) != hipSuccess) { delete c; return fail(nullptr, LASSO_ERR_OOM, "mapped flag alloc"); }
   *c->h_flag = 0;
-  int32_t rc = ensure_small(c, 4096); if (rc) { g_create_err = c->err; delete c; return rc; }
+  int32_t rc = ensure_small(c, (size_t)1 << 16); if (rc) { g_create_err = c->err; delete c; return rc; }   // 2 MiB of mapped result buffer: the largest a-vector / row-commitment hand-off without a reallocation
   rc = ensure_scratch(c, (size_t)1 << 22); if (rc) { g_create_err = c->err; delete c; return rc; }
   *out = c; return 0;
 }
@@ -539,6 +539,14 @@ int32_t lasso_matvec_left_dev(lasso_ctx* c, const lasso_fr* d_Z, const lasso_fr*
 // ark-serialize of n field elements (canonical integers, 32 little-endian bytes each) — what append_scalar feeds the transcript (utils/transcript.rs:33-45)
 int32_t lasso_fr_to_bytes(lasso_ctx* c, const lasso_fr* d_src, size_t n, uint8_t* out) {
   REQUIRE(c, d_src && out && n >= 1);
+  // up to 2^16 elements (the a-vector of an opening: 128-256 KiB) go straight into the host-mapped result buffer and come back behind the
+  // sequence flag: a hipMemcpy to pageable memory plus a stream synchronisation cost 100 us of idle device per opening
+  if (n <= ((size_t)1 << 16)) {
+    int32_t rc = ensure_small(c, n); if (rc) return rc;
+    hipLaunchKernelGGL(k_fr_to_canonical, dim3(grid_for(n)), dim3(256), 0, c->stream, (const fr_t*)d_src, n, c->d_small);
+    HIPCHK(c, hipGetLastError());
+    return fetch_small(c, n, (lasso_fr*)out);
+  }
   int32_t rc = ensure_scratch(c, n * sizeof(fr_t)); if (rc) return rc;
   hipLaunchKernelGGL(k_fr_to_canonical, dim3(grid_for(n)), dim3(256), 0, c->stream, (const fr_t*)d_src, n, (fr_t*)c->d_scratch);
   HIPCHK(c, hipGetLastError());
@@ -670,6 +678,12 @@ static int32_t run_msm(lasso_ctx* c, const uint8_t* d_scal, uint32_t bps, uint32
   }
   HIPCHK(c, hipGetLastError());
   if (out_compressed) {   // d_final holds the row sums as pt29 (144 B per row: the scratch is sized for it, see hyrax_commit_impl); 32 wire bytes per row go out
+    if (rows <= ((size_t)1 << 16)) {   // wire bytes straight into the host-mapped result buffer, handed over behind the sequence flag
+      int32_t rc = ensure_small(c, rows); if (rc) return rc;
+      hipLaunchKernelGGL(k_points_compress, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, c->stream, (const pt29*)d_final, rows, (uint32_t*)c->d_small);
+      HIPCHK(c, hipGetLastError());
+      return fetch_small(c, rows, (lasso_fr*)out_compressed);
+    }
     uint32_t* d_wire = (uint32_t*)(((uintptr_t)((pt29*)d_final + rows) + 15) & ~(uintptr_t)15);
     hipLaunchKernelGGL(k_points_compress, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, c->stream, (const pt29*)d_final, rows, d_wire);
     HIPCHK(c, hipGetLastError());

@@ -1073,7 +1073,8 @@ class Prover {
     // global layer of P elements: the roots are all-gathered, the global layers P, P/2, .., 2 are built from them (replicated) and the hash is the top product
     std::vector<DBuf> tops_store;
     auto root_and_top = [&](const DBuf& tree, size_t n_loc, lasso_fr*& top_out) {
-      lasso_fr two[2]; d.chk(lasso_download(d.ctx, two, tree.p + (2 * n_loc - 4), sizeof(two)), "lasso_download");
+      lasso_fr two[2]; const lasso_fr* last[2] = {tree.p + (2 * n_loc - 4), tree.p + (2 * n_loc - 3)};
+      d.chk(lasso_read_heads(d.ctx, last, 2, two), "lasso_read_heads");   // through the mapped result buffer: no memcpy, no stream synchronisation
       Sc local = Sc::from_abi(two[0]) * Sc::from_abi(two[1]);
       top_out = nullptr;
       if (P == 1) return local;
