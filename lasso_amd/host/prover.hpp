@@ -104,7 +104,11 @@ class Dev {
  public:
   lasso_ctx* ctx = nullptr;
   Comm comm;
-  explicit Dev(int device) : device_(device) { if (lasso_ctx_create(device, &ctx) != 0) throw Error(std::string("lasso_ctx_create: ") + lasso_last_error(nullptr)); }
+  explicit Dev(int device) : device_(device) {
+    if (lasso_ctx_create(device, &ctx) != 0) throw Error(std::string("lasso_ctx_create: ") + lasso_last_error(nullptr));
+    const char* e = getenv("LASSO_SIDE_STREAM");
+    if (!(e && e[0] == '0')) (void)side();   // created up front: a context costs ~9 ms, which must not land inside the first proof
+  }
   ~Dev() { if (side_) lasso_ctx_destroy(side_); if (ctx) { for (auto& kv : pool_) lasso_free(ctx, kv.second); for (auto& kv : live_) lasso_free(ctx, kv.first); lasso_ctx_destroy(ctx); } }
   // A second context on the same device (own stream, scratch and result buffer): streaming work that does not depend on the transcript is
   // issued there while the main context is inside a latency-bound phase (Prover::prep_open).  Buffers it touches must outlive its work:

@@ -8,7 +8,7 @@ timeout 900 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo
 tail -3 $OUT/pytest_gpu.log
 timeout 600 python bench.py --steps 5 --warmup 2 > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"
 cat $OUT/bench.json
-LASSO_TRACE=1 timeout 300 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-prof > $OUT/bench_trace.json 2> $OUT/bench_trace.err
+LASSO_TRACE=1 timeout 300 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-prof --concurrent 0 > $OUT/bench_trace.json 2> $OUT/bench_trace.err
 tail -60 $OUT/bench_trace.err
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --concurrent 0 > $GRAFT_REPO_ROOT/$OUT/bench_under_rocprof.json 2> $GRAFT_REPO_ROOT/$OUT/rocprof.err)
 find /tmp/prof_$TAG -name '*kernel_stats*.csv' -exec cp {} $OUT/ \;
