@@ -113,7 +113,11 @@ int32_t lasso_sumcheck_cubic_eqw_round_fused(lasso_ctx* ctx, lasso_fr* const* d_
  * polynomial: one product per index and circuit less than the three-sum form, and the host's per-round inversion overlaps the kernel.
  * r == NULL: first round of a layer (length n, n >= 2, evaluation only); otherwise bind the previous challenge first (n = length before the
  * bind, n >= 4) exactly as lasso_sumcheck_cubic_eqw_round_fused.  Returns after the launch; lasso_result_wait(ctx, out, 2*ncirc) then yields
- * out[2c] = q_c(0), out[2c+1] = q_c,inf.  No other call may be made on the context between the two. */
+ * out[2c] = q_c(0), out[2c+1] = q_c,inf.  No other call may be made on the context between the two.
+ * Memory form of the bound arrays: between rounds only kernels read them, so this call leaves them LAZILY REDUCED — each element is some 256-bit
+ * representative (< 2^254 + 2^130) of the right residue, not necessarily the canonical one.  Every entry point of this library accepts such
+ * input; lasso_bind_top (the last bind of a layer), the resident tail and lasso_sumcheck_cubic_eqw_round_fused write canonical elements again, and
+ * nothing lazily reduced ever reaches the host (the heads are read after the last bind). */
 int32_t lasso_sumcheck_cubic_eqw2_begin(lasso_ctx* ctx, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n,
                                         const lasso_fr* r);
 int32_t lasso_result_wait(lasso_ctx* ctx, lasso_fr* out, size_t count);

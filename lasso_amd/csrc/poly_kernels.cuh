@@ -209,8 +209,10 @@ __device__ __forceinline__ fr29 bind29(const fr_t& lo, const fr_t& hi, const fr2
 // s_j = prod_{t<j} eq1(rand_t, rho_t); and T_j is the PREFIX of the original table up to a scalar: E[i] = prod_{t<=j}(1 - rand_t) * T_j[i]
 // for i < 2^(l-1-j).  So the round's sums are  e(x) = [s_j * eq1(rand_j, x) / prod_{t<=j}(1 - rand_t)] * sum_i a(x) b(x) E[i]:
 // the device never binds or stores C — it reads the prefix of the one table built for the layer — and the bracket is three host scalars.
-// Per index and circuit: 2 products for aE(x) = a(x) E[i] (linear in x), 3 for b(x) aE(x): 5 instead of 6, and the fused kernel binds
-// 4 values instead of 6 (9 products per index against 12).  Exact field arithmetic: the round polynomials are the same field elements.
+// Per index and circuit (three-sum form): 2 products for aE(x) = a(x) E[i] (linear in x), 3 for b(x) aE(x): 5 instead of 6, and the fused kernel
+// binds 4 values instead of 6 (9 products per index against 12).  Exact field arithmetic: the round polynomials are the same field elements.
+// The prover's path is the two-sum form below (cubic_eqw_terms2: 8 products, two of them accumulated double-width); the three-sum kernels serve
+// the rounds whose eq coordinate is 0 (no claim-derived evaluation) and the literal API.
 __device__ __forceinline__ void cubic_eqw_terms(const fr29& a0, const fr29& a1, const fr29& b0, const fr29& b1, const fr29& es, fr29& t0, fr29& t2, fr29& t3) {
   const fr29 g0 = fr29_mul(a0, es), g1 = fr29_mul(a1, es);          // u * s = u-form, reduced
   t0 = fr29_mul(b0, g0);
