@@ -63,6 +63,6 @@ def test_proof_bytes_equal_oracle_and_verify(host, oracle, kind, c, log_m, log_r
 
 
 @pytest.mark.parametrize("k,ell,special", [(1, 1, {}), (2, 3, {}), (3, 5, {0: 0}), (2, 5, {2: 0}), (2, 4, {3: 0}), (2, 5, {1: 1}), (1, 6, {0: 0, 1: 1, 2: 0, 5: 1}), (2, 8, {7: 0}),
-                                          (33, 2, {1: 0}), (2, 9, {}), (2, 9, {0: 1, 8: 0})])
+                                          (33, 2, {1: 0}), (2, 9, {}), (2, 9, {0: 1, 8: 0}), (2, 12, {}), (3, 12, {2: 0}), (2, 13, {1: 1, 5: 0})])   # ell >= 11: streaming rounds before the resident tail
 def test_cubic_batched_scripted_eq_points(host, oracle, k, ell, special):
     cubic_batched_case(host, oracle, k, ell, special, seed=k * 100 + ell)
