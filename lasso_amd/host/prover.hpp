@@ -633,8 +633,8 @@ class Prover {
     // 1 / prod_{t<=j}(1 - rand[v0+t]) for every round of the phase with one inversion; a zero factor (rand_t = 1) takes the explicit-table path
     ScVec inv(rounds); bool degenerate = false;
     {
-      Sc prod = Sc::one(); ScVec pre(rounds);
-      for (size_t j = 0; j < rounds; j++) { Sc om = Sc::one() - rand[v0 + j]; if (om.is_zero()) degenerate = true; prod *= om; pre[j] = prod; }
+      Sc prod = Sc::one();
+      for (size_t j = 0; j < rounds; j++) { Sc om = Sc::one() - rand[v0 + j]; if (om.is_zero()) degenerate = true; prod *= om; }
       if (!degenerate) { Sc pi = prod.inverse(); for (size_t j = rounds; j-- > 0;) { inv[j] = pi; pi *= Sc::one() - rand[v0 + j]; } }
     }
     DBuf tj; if (degenerate) tj = DBuf(d, len / 2);

@@ -504,6 +504,33 @@ def test_sumcheck_cubic_tail(devs, n, ncirc, bind):
         assert np.array_equal(x, y)
 
 
+def test_launch_wait_protocol_errors(devs):
+    """misuse of the launch/wait split is reported as an error code, never a hang or a wrong result: waiting with nothing pending, a wrong count,
+    a second deferral, a tail challenge without a tail; and a deferred call still delivers the right values afterwards"""
+    rng = np.random.default_rng(77)
+    A = rand_fr(rng, 64); W = rand_fr(rng, 64)
+    for d in devs:
+        lib, ctx = d.lib, d.ctx
+        out = np.empty((4, 4), dtype=np.uint64)
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        assert lib.lasso_result_wait(ctx, vp(out), 1) != 0                      # nothing pending
+        r = np.ascontiguousarray(A[0])
+        assert lib.lasso_sumcheck_cubic_tail_next(ctx, vp(r)) != 0              # no tail running
+        pa = d.upload(A); pw = d.upload(W)
+        want = d.multi_dot([pa], pw, 64)
+        assert lib.lasso_defer_next(ctx) == 0
+        assert lib.lasso_defer_next(ctx) != 0                                   # one deferral at a time
+        dummy = np.empty((1, 4), dtype=np.uint64)
+        ptrs = (C.c_void_p * 1)(pa)
+        assert lib.lasso_multi_dot(ctx, ptrs, 1, C.c_void_p(pw), 64, vp(dummy)) == 0
+        assert lib.lasso_result_wait(ctx, vp(out), 3) != 0                      # wrong count: still pending
+        got = np.empty((1, 4), dtype=np.uint64)
+        assert lib.lasso_result_wait(ctx, vp(got), 1) == 0
+        assert np.array_equal(got, want)
+        assert lib.lasso_result_wait(ctx, vp(out), 1) != 0                      # collected already
+        d.free(pa); d.free(pw)
+
+
 @pytest.mark.parametrize("n_lookups,c,log_m,mode", [(1, 1, 0, "rand"), (2, 1, 1, "rand"), (5, 2, 4, "rand"), (1000, 3, 8, "rand"), (4096, 1, 16, "rand"), (5000, 2, 12, "rand"),
                                                      (1 << 16, 1, 16, "rand"), (70000, 1, 17, "rand"), (9000, 1, 16, "same"), (1 << 15, 2, 3, "rand"), (12345, 1, 9, "sorted")])
 def test_densify_dim(devs, n_lookups, c, log_m, mode):
