@@ -974,33 +974,46 @@ class Prover {
     std::unique_ptr<Trace> sp(new Trace("Subtables.new", d.ctx));
     auto host_tables = S.materialize_subtables();
     std::vector<DBufU32> tables_u32; uint32_t table_max = 0;   // the integer tables stay until E is committed (the commitment's scalars are T[dim] as integers)
-    for (auto& ht : host_tables) {
-      for (uint32_t v : ht) table_max = std::max(table_max, v);
-      tables_u32.emplace_back(d, ht); DBuf tb(d, m);
-      d.chk(lasso_fr_from_u32(d.ctx, tables_u32.back().p, m, tb.p), "lasso_fr_from_u32");
-      tables.push_back(std::move(tb));
-    }
+    for (auto& ht : host_tables) { for (uint32_t v : ht) table_max = std::max(table_max, v); tables_u32.emplace_back(d, ht); tables.emplace_back(d, m); }
     size_t n_E = next_pow2(alpha * s); nv_derefs = ceil_log2(n_E);
     combined_E = DBuf(d, n_E / P);
-    if (n_E > alpha * s) d.chk(lasso_zero(d.ctx, combined_E.p + alpha * s_loc, (n_E - alpha * s) / P * sizeof(lasso_fr)), "lasso_zero");
-    for (size_t i = 0; i < alpha; i++)
-      d.chk(lasso_gather(d.ctx, tables[S.memory_to_subtable_index(i)].p, dense.dim_u32[S.memory_to_dimension_index(i)].p, s_loc, combined_E.p + i * s_loc), "lasso_gather");
+    DBuf eq(d, s_loc);
+    // The commitment of E needs only E's INTEGER values (a 4-byte gather per lookup), so on one GPU the field-element side of Subtables::new — the
+    // tables lifted to Fr, E = T[dim] as 32-byte elements — and the eq table of r run on the side context UNDER the commitment's MSM (VALU-bound;
+    // these are HBM-bound) instead of in front of it.
+    const bool side_new = P == 1 && !side_off();
+    lasso_ctx* fc = side_new ? d.side() : d.ctx;
+    auto fchk = [&](int32_t rc, const char* what) { if (side_new) d.chk_side(rc, what); else d.chk(rc, what); };
+    auto field_side = [&] {
+      for (size_t i = 0; i < tables.size(); i++) fchk(lasso_fr_from_u32(fc, tables_u32[i].p, m, tables[i].p), "lasso_fr_from_u32");
+      if (n_E > alpha * s) fchk(lasso_zero(fc, combined_E.p + alpha * s_loc, (n_E - alpha * s) / P * sizeof(lasso_fr)), "lasso_zero");
+      for (size_t i = 0; i < alpha; i++)
+        fchk(lasso_gather(fc, tables[S.memory_to_subtable_index(i)].p, dense.dim_u32[S.memory_to_dimension_index(i)].p, s_loc, combined_E.p + i * s_loc), "lasso_gather");
+    };
     ProofWriter W;
-    // comm_derefs
-    sp.reset(new Trace("Subtables.commit", d.ctx));
     PolyCommitment comm_derefs;
     if (P == 1) {   // E as integers: one 4-byte gather per lookup instead of converting the 32-byte elements back
       DBufU32 E_u32(d, n_E);
       if (n_E > alpha * s) d.chk(lasso_zero(d.ctx, E_u32.p + alpha * s, (n_E - alpha * s) * sizeof(uint32_t)), "lasso_zero");
       for (size_t i = 0; i < alpha; i++)
         d.chk(lasso_gather_u32(d.ctx, tables_u32[S.memory_to_subtable_index(i)].p, dense.dim_u32[S.memory_to_dimension_index(i)].p, s, E_u32.p + i * s), "lasso_gather_u32");
+      if (side_new) {
+        field_side();
+        std::vector<lasso_fr> rr; for (auto& x : r) rr.push_back(x.abi());
+        d.chk_side(lasso_eq_evals(fc, rr.data(), (uint32_t)rr.size(), eq.p), "lasso_eq_evals");
+      } else field_side();
+      sp.reset(new Trace("Subtables.commit", d.ctx));
       comm_derefs = hyrax_commit(d, combined_E.p, nv_derefs, gens.gens_derefs, E_u32.p, table_max);
-    } else comm_derefs = hyrax_commit(d, combined_E.p, nv_derefs, gens.gens_derefs);
+      if (side_new) side_sync();
+    } else {
+      field_side();
+      sp.reset(new Trace("Subtables.commit", d.ctx));
+      comm_derefs = hyrax_commit(d, combined_E.p, nv_derefs, gens.gens_derefs);
+    }
     tables_u32.clear();
     // The claim (subtables/mod.rs:187-216) depends on r and E only, not on the transcript: its kernels run while the host absorbs the
     // commitment (4096 compressed rows at 2^24: 0.4 ms of Keccak during which the device would otherwise idle)
-    DBuf eq(d, s_loc);
-    eq_evals_local(r, eq.p);
+    if (!side_new) eq_evals_local(r, eq.p);
     std::vector<const lasso_fr*> Eptr; for (size_t i = 0; i < alpha; i++) Eptr.push_back(E(i));
     std::vector<lasso_fr> claim_abi(1);
     d.chk(lasso_defer_next(d.ctx), "lasso_defer_next");
