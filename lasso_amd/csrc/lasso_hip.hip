@@ -21,7 +21,7 @@ __global__ void __launch_bounds__(256) k_inner_lr(const fr_t* __restrict__ a, co
     acc[1] = fr29_weak(fr29_add(acc[1], fr29_mul(fr29_unpack_u(a[half + i]), fr29_unpack_s(b[i]))));
     if ((++cnt & 127u) == 0) { acc[0] = fr29_mul(acc[0], fr29_one_s()); acc[1] = fr29_mul(acc[1], fr29_one_s()); }
   }
-  store_block_partials<3>(acc, 2, partials + 2 * (size_t)blockIdx.x, fr29_one_s(), S);
+  store_block_partials<3>(acc, 2, partials + 2 * (size_t)blockIdx.x, 0, S);
 }
 
 static_assert(sizeof(lasso_fr) == 32 && sizeof(fr_t) == 32, "Fr layout");

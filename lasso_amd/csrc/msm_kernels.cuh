@@ -448,7 +448,7 @@ __global__ void __launch_bounds__(256) k_bullet_step(const fr_t* __restrict__ a_
     if (compact) { SL[g] = sl; SR[g] = sr; }
     else { const size_t base = blk * nk + i; SL[base] = fr_zero(); SL[base + half] = sl; SR[base] = sr; SR[base + half] = fr_zero(); }
   }
-  store_block_partials<3>(acc, 2, partials + 2 * (size_t)blockIdx.x, fr29_k5(), S);
+  store_block_partials<3>(acc, 2, partials + 2 * (size_t)blockIdx.x, 5, S);
   if (threadIdx.x == 0) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

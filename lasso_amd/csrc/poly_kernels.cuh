@@ -49,28 +49,29 @@ __device__ __forceinline__ void block_columns(const fr29* vals, RedScratch& S) {
   }
   __syncthreads();
 }
-// value of column group v after block_columns, multiplied by `fix` (ONE_S to only reduce, K5/K10 to also correct the radix), as memory words
-__device__ __forceinline__ fr_t columns_to_fr(const RedScratch& S, int v, const fr29& fix) {
+// value of column group v after block_columns, times 2^shift (0 to only reduce; 5 / 10 also correct the radix of sums of u*u / u*u*u products:
+// what a Montgomery product with K5 = 2^266 / K10 = 2^271 would do), as memory words
+__device__ __forceinline__ fr_t columns_to_fr(const RedScratch& S, int v, int shift) {
   int64_t c[9];
 #pragma unroll
   for (int k = 0; k < 9; k++) c[k] = S.cols[v * 9 + k];
-  return fr29_store(fr29_mul(fr29_from_columns(c), fix));
+  return fr29_pack(fr29_reduce_columns(c, shift));
 }
 // per-thread accumulator step: acc += t, kept reduced; every 128 terms the magnitude is folded back (limb 8 must stay below 2^30)
 __device__ __forceinline__ void acc_add(fr29& acc, const fr29& t, uint32_t& count) {
   acc = fr29_weak(fr29_add(acc, t));
   if ((++count & 127u) == 0) acc = fr29_mul(acc, fr29_one_s());
 }
-// block partials of up to KMAX accumulators (groups of 3) -> dst[k], k < K; `fix` also corrects the radix of the accumulated products
+// block partials of up to KMAX accumulators (groups of 3) -> dst[k], k < K; `shift` also corrects the radix of the accumulated products
 template <int KMAX>
-__device__ __forceinline__ void store_block_partials(const fr29* acc, uint32_t K, fr_t* __restrict__ dst, const fr29& fix, RedScratch& S) {
+__device__ __forceinline__ void store_block_partials(const fr29* acc, uint32_t K, fr_t* __restrict__ dst, int shift, RedScratch& S) {
 #pragma unroll
   for (int k0 = 0; k0 < KMAX; k0 += 3) if ((uint32_t)k0 < K) {
     fr29 grp[3];
 #pragma unroll
     for (int v = 0; v < 3; v++) grp[v] = (k0 + v < KMAX) ? acc[(k0 + v < KMAX) ? k0 + v : 0] : fr29_zero();
     block_columns<3>(grp, S);
-    if (threadIdx.x < 3 && k0 + threadIdx.x < K) dst[k0 + threadIdx.x] = columns_to_fr(S, threadIdx.x, fix);
+    if (threadIdx.x < 3 && k0 + threadIdx.x < K) dst[k0 + threadIdx.x] = columns_to_fr(S, threadIdx.x, shift);
   }
 }
 
@@ -86,7 +87,7 @@ __device__ __forceinline__ void reduce_partials_row(const fr_t* __restrict__ par
       if (k0 + v < Kv) for (uint32_t x = threadIdx.x; x < nx; x += blockDim.x) acc[v] = fr29_weak(fr29_add(acc[v], fr29_unpack_u(partials[((size_t)y * nx + x) * K + k0 + v])));
     }
     block_columns<3>(acc, S);
-    if (threadIdx.x < 3 && k0 + threadIdx.x < Kv) out[(size_t)y * K + k0 + threadIdx.x] = columns_to_fr(S, threadIdx.x, fr29_one_s());
+    if (threadIdx.x < 3 && k0 + threadIdx.x < Kv) out[(size_t)y * K + k0 + threadIdx.x] = columns_to_fr(S, threadIdx.x, 0);
   }
 }
 __global__ void __launch_bounds__(LASSO_BLOCK) k_reduce_partials(const fr_t* __restrict__ partials, uint32_t nx, uint32_t K, fr_t* __restrict__ out) {
@@ -160,15 +161,15 @@ __device__ __forceinline__ void row_done(uint32_t nrows, uint32_t* counters, uin
     if (t2 == nrows - 1) { counters[LASSO_MAX_PTRS] = 0; __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
   }
 }
-// block partials -> memory (K10 also supplies the missing 2^10), then the in-launch second stage; a single-block row writes its result directly.
+// block partials -> memory (shift 10 / 5 also supplies the missing 2^10 / 2^5), then the in-launch second stage; a single-block row writes its result directly.
 __device__ __forceinline__ void cubic_epilogue(const fr29* e, const CubicGrid& g, fr_t* __restrict__ partials, uint32_t* counters, fr_t* __restrict__ out, uint32_t* flag, uint32_t seq, RedScratch& S,
-                                               const fr29& fix, uint32_t K = 3) {   // K <= 3 results per row
+                                               int shift, uint32_t K = 3) {   // K <= 3 results per row
   if (g.nx == 1) {
-    store_block_partials<3>(e, K, out + (size_t)g.by * K, fix, S);
+    store_block_partials<3>(e, K, out + (size_t)g.by * K, shift, S);
     row_done(g.ny, counters, flag, seq);
     return;
   }
-  store_block_partials<3>(e, K, partials + ((size_t)g.by * g.nx + g.bx) * K, fix, S);
+  store_block_partials<3>(e, K, partials + ((size_t)g.by * g.nx + g.bx) * K, shift, S);
   last_block_reduce(partials, g.nx, K, g.by, g.ny, counters, out, S, flag, seq);
 }
 #define CUBIC_ACCUMULATE(e, t0, t2, t3, cnt)                                                                                          \
@@ -189,7 +190,7 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_round_lb(PtrTable A, PtrT
     cubic_terms(fr29_unpack_u(a[i]), fr29_unpack_u(a[i + half]), fr29_unpack_u(b[i]), fr29_unpack_u(b[i + half]), fr29_unpack_u(C[i]), fr29_unpack_u(C[i + half]), t0, t2, t3);
     CUBIC_ACCUMULATE(e, t0, t2, t3, cnt);
   }
-  cubic_epilogue(e, g, partials, counters, out, flag, seq, S, fr29_k10());
+  cubic_epilogue(e, g, partials, counters, out, flag, seq, S, 10);
 }
 // bind for arrays only kernels read until the layer's final bind: the stored value is lazily reduced (fr29_semi: same residue, < 2^254 + 2^130,
 // 48 instructions against 115) — the next round's loads, the resident tail kernel and k_bind_top all accept it, and what leaves the device
@@ -257,7 +258,7 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_eqw_lb(PtrTable A, PtrTab
     }
   }
   if (NT == 2) { fr29_acc_carry(w0); fr29_acc_carry(w1); e[0] = fr29_acc_reduce(w0); e[1] = fr29_acc_reduce(w1); }
-  cubic_epilogue(e, g, partials, counters, out, flag, seq, S, fr29_k5(), NT);
+  cubic_epilogue(e, g, partials, counters, out, flag, seq, S, 5, NT);
 }
 // fused with K1: bind A and B with r (length n = 4q -> 2q, in place: each element is owned by exactly one thread), then the sums of the NEXT round
 // on the bound values while they are still in registers — one launch per round, 48 bytes per element of A and B plus 32 per index of E.
@@ -288,7 +289,7 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_eqw_fused(MutPtrTable A, 
     }
   }
   if (WIDE && NT == 2) { fr29_acc_carry(w0); fr29_acc_carry(w1); e[0] = fr29_acc_reduce(w0); e[1] = fr29_acc_reduce(w1); }
-  cubic_epilogue(e, g, partials, counters, out, flag, seq, S, fr29_k5(), NT);
+  cubic_epilogue(e, g, partials, counters, out, flag, seq, S, 5, NT);
 }
 // Late rounds (q <= 64 indices per circuit): the same round, laid out for LATENCY instead of throughput.  One workgroup per circuit;
 // phase 1 gives every bind its own lane (4q products side by side instead of 4 in a row per thread), phase 2 every weighted value a'[i] E[i mod q],
@@ -341,7 +342,7 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_eqw_small(MutPtrTable A, 
     int64_t c[9];
 #pragma unroll
     for (int k = 0; k < 9; k++) c[k] = cols[t * 9 + k];
-    out[(size_t)y * NT + t] = fr29_store(fr29_mul(fr29_from_columns(c), fr29_k5()));
+    out[(size_t)y * NT + t] = fr29_pack(fr29_reduce_columns(c, 5));
   }
   row_done(gridDim.x, counters, flag, seq);
 }
@@ -404,7 +405,7 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_tail(MutPtrTable A, MutPt
       int64_t c[9];
 #pragma unroll
       for (int k = 0; k < 9; k++) c[k] = cols[t * 9 + k];
-      out[(size_t)y * 2 + t] = fr29_store(fr29_mul(fr29_from_columns(c), fr29_k5()));
+      out[(size_t)y * 2 + t] = fr29_pack(fr29_reduce_columns(c, 5));
     }
     row_done(ncirc, counters, flag, seq0 + turn);
     // the host's answer: the round's challenge
@@ -470,7 +471,7 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_dot_eqw_lb(PtrTable polys, uint
   }
   fr29_acc_carry(w0); fr29_acc_carry(w1);
   fr29 e[3] = {fr29_acc_reduce(w0), fr29_acc_reduce(w1), fr29_zero()};
-  cubic_epilogue(e, g, partials, counters, out, flag, seq, S, fr29_one_s());
+  cubic_epilogue(e, g, partials, counters, out, flag, seq, S, 0);
 }
 // src != polys: the bind reads src (length 4q) and writes the bound halves to polys — the first bind of the primary sumcheck takes E itself as
 // src, so surge.rs:151's clone of the lookup polynomials never happens (the sumcheck must not modify E, which the later openings read)
@@ -492,7 +493,7 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_dot_eqw_fused(PtrTable src, Mut
   }
   fr29_acc_carry(w0); fr29_acc_carry(w1);
   fr29 e[3] = {fr29_acc_reduce(w0), fr29_acc_reduce(w1), fr29_zero()};
-  cubic_epilogue(e, g, partials, counters, out, flag, seq, S, fr29_one_s());
+  cubic_epilogue(e, g, partials, counters, out, flag, seq, S, 0);
 }
 
 // ------------------------------------------------------------------ g = S::combine_lookups (subtables/*.rs)
@@ -532,7 +533,7 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_combine_round_linear(StrategyDe
     acc[2] = fr29_weak(fr29_add(acc[2], fr29_mul(g2, e2)));
     if ((++cnt & 63u) == 0) { acc[0] = fr29_mul(acc[0], fr29_one_s()); acc[1] = fr29_mul(acc[1], fr29_one_s()); acc[2] = fr29_mul(acc[2], fr29_one_s()); }
   }
-  store_block_partials<3>(acc, 3, partials + (size_t)blockIdx.x * 3, fr29_k5(), R);   // (u * s) * u: 2^5 short
+  store_block_partials<3>(acc, 3, partials + (size_t)blockIdx.x * 3, 5, R);   // (u * s) * u: 2^5 short
 }
 // K3 for LT: degree = C + 1.  A = compile-time bound on NUM_MEMORIES = 2C, D = bound on the degree
 template <int A, int D>
@@ -558,7 +559,7 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_combine_round_lt(StrategyDev S,
       for (int x = 0; x <= D; x++) acc[x] = fr29_mul(acc[x], fr29_one_s());
     }
   }
-  store_block_partials<D + 1>(acc, degree + 1, partials + (size_t)blockIdx.x * (degree + 1), fr29_one_s(), R);
+  store_block_partials<D + 1>(acc, degree + 1, partials + (size_t)blockIdx.x * (degree + 1), 0, R);
 }
 // K10: claim = sum_k eq[k] * g(E(k))  (subtables/mod.rs:187-216)
 template <int A>
@@ -578,7 +579,7 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_combine_claim(StrategyDev S, Pt
     } else g = weighted_sum(polys, i, S.alpha, ws);
     acc_add(acc[0], fr29_mul(g, fr29_unpack_u(eq[i])), cnt);
   }
-  store_block_partials<1>(acc, 1, partials + blockIdx.x, lt ? fr29_one_s() : fr29_k5(), R);
+  store_block_partials<1>(acc, 1, partials + blockIdx.x, lt ? 0 : 5, R);
 }
 
 // K12: out[p] = sum_i polys[p][i] * w[i]; 1-D grid of nx*ny workgroups in cubic_grid order (the workgroups of one index range and different polynomials
@@ -596,7 +597,7 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_multi_dot(PtrTable polys, uint3
   }
   fr29_acc_carry(wa);
   fr29 acc[1] = {fr29_acc_reduce(wa)};
-  store_block_partials<1>(acc, 1, partials + (size_t)g.by * nx + g.bx, fr29_one_s(), R);
+  store_block_partials<1>(acc, 1, partials + (size_t)g.by * nx + g.bx, 0, R);
 }
 
 // ------------------------------------------------------------------ K6: eq evals (eq_poly.rs:22-38)

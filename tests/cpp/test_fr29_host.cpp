@@ -91,6 +91,23 @@ int main() {
       CHECK(same(fr29_store(sm2), fr_add(fr29_store(x), fr_mul(b, fr_sub(c, fr29_store(x))))));
     }
   }
+  // block sums: column values times 2^shift reduced without a product (fr29_reduce_columns) == the old from_columns + product with 2^(261+shift)
+  for (int T : {1, 2, 255, 4096, 65536, 1 << 20}) {
+    int64_t col[9] = {0}, ncol[9] = {0};
+    for (int i = 0; i < T; i++) {
+      const fr_t &a = xs[(size_t)i % N], &b = xs[((size_t)i * 13 + 1) % N];
+      fr29 t = fr29_mul(fr29_unpack_u(a), fr29_unpack_s(b));
+      if (i % 5 == 4) t = fr29_add(t, fr29_add(t, t));                    // limbs up to 3 * 2^29, limb 8 grows
+      for (int k = 0; k < 9; k++) { col[k] += t.v[k]; ncol[k] -= t.v[k]; }
+    }
+    const fr29 fixes[3] = {fr29_one_s(), fr29_k5(), fr29_k10()}; const int shifts[3] = {0, 5, 10};
+    for (int v = 0; v < 3; v++) {
+      if (T > 65536 && v) continue;                                          // the old path's bounds end there
+      const fr_t want = T <= 65536 ? fr29_store(fr29_mul(fr29_from_columns(col), fixes[v])) : fr29_store(fr29_mul(fr29_mul(fr29_from_columns(col), fr29_one_s()), fixes[v]));
+      CHECK(same(fr29_pack(fr29_reduce_columns(col, shifts[v])), want));
+      CHECK(same(fr29_pack(fr29_reduce_columns(ncol, shifts[v])), fr_neg(want)));
+    }
+  }
   // sums of products through the double-width accumulator (fr29_mul_acc / fr29_acc_carry / fr29_acc_reduce): carry pass every third product,
   // signed differences as operands (the cubic rounds' leading-coefficient term), T up to 2^16, vs the reference sum of Montgomery products
   for (int T : {1, 2, 3, 4, 255, 4096, 65536}) {
