@@ -370,18 +370,19 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_tail(MutPtrTable A, MutPt
   const uint64_t t_end = wall_clock64() + 500000000ull;   // 5 s at 100 MHz
   uint32_t m = 2 * q;
   {
+    // every lane task (array p, index i) loads / binds its element and, for A, weights it with the eq table right away (no separate pass)
     const fr29 rs = fr29_unpack_s(r0);
     for (uint32_t item = t; item < 2 * m; item += LASSO_BLOCK) {
       const uint32_t p = item / m, i = item - p * m;
       const fr_t* src = p == 0 ? A.p[y] : B.p[y];
-      bound[p][i] = BIND ? bind29(src[i], src[i + m], rs) : fr29_unpack_u(src[i]);
+      const fr29 v = BIND ? bind29(src[i], src[i + m], rs) : fr29_unpack_u(src[i]);
+      bound[p][i] = v;
+      if (p == 0) ge[i] = fr29_mul(v, fr29_unpack_s(E[i < q ? i : i - q]));
     }
   }
   __syncthreads();
   for (uint32_t turn = 0;; turn++) {
     const uint32_t h = m / 2;      // pairs this round
-    for (uint32_t i = t; i < m; i += LASSO_BLOCK) ge[i] = fr29_mul(bound[0][i], fr29_unpack_s(E[i < h ? i : i - h]));
-    __syncthreads();
     // 2h terms: u < h the q(0) terms, u >= h the leading-coefficient terms; row u of `rows`
     for (uint32_t u = t; u < 2 * h; u += LASSO_BLOCK) {
       const uint32_t v = u >= h ? 1u : 0u, i = u - v * h;
@@ -391,15 +392,22 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_tail(MutPtrTable A, MutPt
       for (int k = 0; k < 9; k++) rows[u * 9 + k] = term.v[k];
     }
     __syncthreads();
-    if (t < 8 * 18) {   // eight strips of rows per (sum, limb) column
-      const uint32_t col = t % 18, strip = t / 18, v = col / 9, k = col - v * 9;
-      const uint32_t per = (h + 7) / 8, i0 = strip * per, i1 = i0 + per < h ? i0 + per : h;
+    if (h > 16) {   // eight strips of rows per (sum, limb) column, then the strips
+      if (t < 8 * 18) {
+        const uint32_t col = t % 18, strip = t / 18, v = col / 9, k = col - v * 9;
+        const uint32_t per = (h + 7) / 8, i0 = strip * per, i1 = i0 + per < h ? i0 + per : h;
+        int64_t sum = 0;
+        for (uint32_t i = i0; i < i1; i++) sum += rows[(v * h + i) * 9 + k];
+        strips[strip * 18 + col] = sum;
+      }
+      __syncthreads();
+      if (t < 18) { int64_t sum = 0; for (int g = 0; g < 8; g++) sum += strips[g * 18 + t]; cols[t] = sum; }
+    } else if (t < 18) {   // a handful of rows: one pass
+      const uint32_t v = t / 9, k = t - v * 9;
       int64_t sum = 0;
-      for (uint32_t i = i0; i < i1; i++) sum += rows[(v * h + i) * 9 + k];
-      strips[strip * 18 + col] = sum;
+      for (uint32_t i = 0; i < h; i++) sum += rows[(v * h + i) * 9 + k];
+      cols[t] = sum;
     }
-    __syncthreads();
-    if (t < 18) { int64_t sum = 0; for (int g = 0; g < 8; g++) sum += strips[g * 18 + t]; cols[t] = sum; }
     __syncthreads();
     if (t < 2) {
       int64_t c[9];
@@ -428,18 +436,24 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_tail(MutPtrTable A, MutPt
     __syncthreads();
     if (!alive) return;
     const fr29 rs = fr29_unpack_s(chal);
-    // bind in LDS: 2h lane tasks (array p, index j); results first, stores after the barrier (task (p, j) reads j and j + h of array p)
-    fr29 nb[2]; 
+    // bind in LDS: 2h lane tasks (array p, index j); the A tasks also produce the next round's weighted value.  Results first, stores after
+    // the barrier (task (p, j) reads j and j + h of array p)
+    const uint32_t hn = h / 2;     // pairs of the NEXT round
+    fr29 nb[2], ng[2];
 #pragma unroll
     for (int pass = 0; pass < 2; pass++) {
       const uint32_t u = t + pass * LASSO_BLOCK;
-      if (u < 2 * h) { const uint32_t p = u >= h ? 1u : 0u, jx = u - p * h; nb[pass] = fr29_canonical(fr29_add(bound[p][jx], fr29_mul(fr29_sub(bound[p][jx + h], bound[p][jx]), rs))); }
+      if (u < 2 * h) {
+        const uint32_t p = u >= h ? 1u : 0u, jx = u - p * h;
+        nb[pass] = fr29_canonical(fr29_add(bound[p][jx], fr29_mul(fr29_sub(bound[p][jx + h], bound[p][jx]), rs)));
+        if (p == 0 && h > 1) ng[pass] = fr29_mul(nb[pass], fr29_unpack_s(E[jx < hn ? jx : jx - hn]));
+      }
     }
     __syncthreads();
 #pragma unroll
     for (int pass = 0; pass < 2; pass++) {
       const uint32_t u = t + pass * LASSO_BLOCK;
-      if (u < 2 * h) { const uint32_t p = u >= h ? 1u : 0u, jx = u - p * h; bound[p][jx] = nb[pass]; }
+      if (u < 2 * h) { const uint32_t p = u >= h ? 1u : 0u, jx = u - p * h; bound[p][jx] = nb[pass]; if (p == 0 && h > 1) ge[jx] = ng[pass]; }
     }
     __syncthreads();
     m = h;
