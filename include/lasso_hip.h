@@ -52,6 +52,9 @@ typedef struct {
 
 /* ---- context, memory ---------------------------------------------------------------------- */
 int32_t lasso_ctx_create(int32_t device, lasso_ctx** out);
+/* The same with a stream priority: background != 0 gives the context's stream the lowest priority of the device (bulk work issued beside a
+ * latency-bound context, see lasso_amd/host/prover.hpp Dev::side), 0 the highest (what lasso_ctx_create does). */
+int32_t lasso_ctx_create_background(int32_t device, int32_t background, lasso_ctx** out);
 void lasso_ctx_destroy(lasso_ctx* ctx);
 const char* lasso_last_error(lasso_ctx* ctx);          /* ctx may be NULL: last error of a failed create */
 int32_t lasso_alloc(lasso_ctx* ctx, size_t bytes, void** d_out);

@@ -21,6 +21,7 @@ def declare(lib):
     P = C.POINTER
     sig = {
         "lasso_ctx_create": (i32, [i32, P(vp)]),
+        "lasso_ctx_create_background": (i32, [i32, i32, P(vp)]),
         "lasso_ctx_destroy": (None, [vp]),
         "lasso_last_error": (C.c_char_p, [vp]),
         "lasso_alloc": (i32, [vp, sz, P(vp)]),

@@ -143,14 +143,19 @@ static int32_t fetch_small(lasso_ctx* c, size_t count, lasso_fr* out) {
 
 extern "C" {
 
-int32_t lasso_ctx_create(int32_t device, lasso_ctx** out) {
+int32_t lasso_ctx_create(int32_t device, lasso_ctx** out) { return lasso_ctx_create_background(device, 0, out); }
+// background != 0: the context's stream gets the LOWEST priority the device offers (the prover's side context: bulk work that must not delay
+// the latency-bound kernels of the main context); otherwise the highest.
+int32_t lasso_ctx_create_background(int32_t device, int32_t background, lasso_ctx** out) {
   if (!out) return fail(nullptr, LASSO_ERR_INVALID, "out is NULL");
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
   if (e != hipSuccess || n == 0) return fail(nullptr, LASSO_ERR_HIP, std::string("no HIP device: ") + hipGetErrorString(e));
   if (device < 0 || device >= n) return fail(nullptr, LASSO_ERR_INVALID, "device index out of range");
   lasso_ctx* c = new lasso_ctx(); c->device = device;
-  if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
+  int prio_lo = 0, prio_hi = 0;   // numerically lower = higher priority
+  if ((e = hipSetDevice(device)) == hipSuccess) (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+  if (e != hipSuccess || (e = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, background ? prio_lo : prio_hi)) != hipSuccess) {
     std::string m = hipGetErrorString(e); delete c; return fail(nullptr, LASSO_ERR_HIP, m);
   }
   if (hipMalloc((void**)&c->d_flags, 64) != hipSuccess) { delete c; return fail(nullptr, LASSO_ERR_OOM, "flags alloc"); }

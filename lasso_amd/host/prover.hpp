@@ -113,7 +113,7 @@ class Dev {
   // A second context on the same device (own stream, scratch and result buffer): streaming work that does not depend on the transcript is
   // issued there while the main context is inside a latency-bound phase (Prover::prep_open).  Buffers it touches must outlive its work:
   // the pool's stream-ordered reuse argument below holds per context, so lasso_sync(side()) precedes their release.
-  lasso_ctx* side() const { if (!side_ && lasso_ctx_create(device_, &side_) != 0) throw Error(std::string("lasso_ctx_create (side): ") + lasso_last_error(nullptr)); return side_; }
+  lasso_ctx* side() const { if (!side_ && lasso_ctx_create_background(device_, 1, &side_) != 0) throw Error(std::string("lasso_ctx_create (side): ") + lasso_last_error(nullptr)); return side_; }
   void chk_side(int32_t rc, const char* what) const { if (rc != 0) throw Error(std::string(what) + " failed on the side context (" + std::to_string(rc) + "): " + lasso_last_error(side_)); }
   Dev(const Dev&) = delete; Dev& operator=(const Dev&) = delete;
   void chk(int32_t rc, const char* what) const { if (rc != 0) throw Error(std::string(what) + " failed (" + std::to_string(rc) + "): " + lasso_last_error(ctx)); }

@@ -29,6 +29,7 @@ static void put_point(const Point& p, lasso_point* o) { memcpy(o->x, p.X.v, 32);
 
 extern "C" {
 int32_t lasso_ctx_create(int32_t, lasso_ctx** out) { *out = new lasso_ctx(); return 0; }
+int32_t lasso_ctx_create_background(int32_t, int32_t, lasso_ctx** out) { *out = new lasso_ctx(); return 0; }
 void lasso_ctx_destroy(lasso_ctx* c) { delete c; }
 const char* lasso_last_error(lasso_ctx* c) { return c ? c->err.c_str() : ""; }
 void* lasso_stream(lasso_ctx*) { return nullptr; }
