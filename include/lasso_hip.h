@@ -221,6 +221,9 @@ int32_t lasso_hyrax_commit_compressed(lasso_ctx* ctx, const lasso_fr* d_Z, size_
  * 32-byte elements to integers and its max-bit readback (msm/mod.rs:95-106 finds the same bound by scanning).  max_value >= every d_u32[i]. */
 int32_t lasso_hyrax_commit_compressed_u32(lasso_ctx* ctx, const uint32_t* d_u32, uint32_t max_value, size_t l_size, size_t r_size,
                                           const lasso_bases* bases, uint8_t* out32);
+/* Subtable `sub` of the strategy as 32-bit integers, 2^log_m entries (SubtableStrategy::materialize_subtables: and.rs:16-28, or.rs, xor.rs,
+ * lt.rs:17-44 (0 = LT, 1 = EQ), range_check.rs:19-51 (0 = full, 1 = remainder below 2^(LOG_R mod log_m), 2 = zeros)), written by the device. */
+int32_t lasso_materialize_subtable_u32(lasso_ctx* ctx, const lasso_strategy* strategy, uint32_t sub, uint32_t* d_out);
 /* d_out[i] = d_table[d_idx[i]] on 32-bit integers (the integer twin of lasso_gather, feeding lasso_hyrax_commit_compressed_u32) */
 int32_t lasso_gather_u32(lasso_ctx* ctx, const uint32_t* d_table, const uint32_t* d_idx, size_t n, uint32_t* d_out);
 /* VariableBaseMSM::msm (src/msm/mod.rs:36-40): out = sum_{j < n} scalars[j] * bases[j]; n <= number of bases.  Zero scalars cost nothing. */

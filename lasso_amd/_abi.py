@@ -73,6 +73,7 @@ def declare(lib):
         "lasso_hyrax_commit_compressed": (i32, [vp, vp, sz, sz, vp, vp]),
         "lasso_hyrax_commit_compressed_u32": (i32, [vp, vp, u32, sz, sz, vp, vp]),
         "lasso_gather_u32": (i32, [vp, vp, vp, sz, vp]),
+        "lasso_materialize_subtable_u32": (i32, [vp, P(Strategy), u32, vp]),
         "lasso_msm": (i32, [vp, vp, vp, sz, vp]),
         "lasso_msm_dev": (i32, [vp, vp, vp, sz, vp]),
         "lasso_inner_products_lr": (i32, [vp, vp, vp, sz, vp]),

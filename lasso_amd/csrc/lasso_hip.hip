@@ -210,6 +210,29 @@ int32_t lasso_fr_from_u32(lasso_ctx* c, const uint32_t* d_src, size_t n, lasso_f
   hipLaunchKernelGGL(k_from_u32, dim3(grid_for(n)), dim3(LASSO_BLOCK), 0, c->stream, d_src, n, (fr_t*)d_dst);
   HIPCHK(c, hipGetLastError()); return 0;
 }
+// SubtableStrategy::materialize_subtables (and.rs:16-28, or.rs, xor.rs, lt.rs:17-44, range_check.rs:19-51) as integers, on the device: entry i of
+// subtable `sub` from the two halves (l, r) of the index (utils/mod.rs:82-89 split_bits).  64 K entries: built where they are used instead of on
+// the host and uploaded.
+__global__ void __launch_bounds__(256) k_subtable_u32(int32_t kind, uint32_t sub, uint32_t log_m, uint32_t log_r, uint32_t* __restrict__ out) {
+  const size_t m = (size_t)1 << log_m; const uint32_t bits = log_m / 2, mask = (1u << bits) - 1u;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < m; i += (size_t)gridDim.x * blockDim.x) {
+    const uint32_t r = (uint32_t)i & mask, l = (uint32_t)(i >> bits) & mask;
+    uint32_t v;
+    if (kind == LASSO_AND) v = l & r;
+    else if (kind == LASSO_OR) v = l | r;
+    else if (kind == LASSO_XOR) v = l ^ r;
+    else if (kind == LASSO_LT) v = sub == 0 ? (l < r ? 1u : 0u) : (l == r ? 1u : 0u);
+    else { const size_t cutoff = (size_t)1 << (log_r % log_m); v = sub == 0 ? (uint32_t)i : (sub == 1 ? (i < cutoff ? (uint32_t)i : 0u) : 0u); }
+    out[i] = v;
+  }
+}
+int32_t lasso_materialize_subtable_u32(lasso_ctx* c, const lasso_strategy* s, uint32_t sub, uint32_t* d_out) {
+  REQUIRE(c, s && d_out && s->kind >= LASSO_AND && s->kind <= LASSO_RANGE && s->log_m >= 1 && s->log_m <= 31);
+  const uint32_t nsub = s->kind == LASSO_LT ? 2u : (s->kind == LASSO_RANGE ? 3u : 1u);
+  REQUIRE(c, sub < nsub);
+  hipLaunchKernelGGL(k_subtable_u32, dim3(grid_for((size_t)1 << s->log_m)), dim3(256), 0, c->stream, s->kind, sub, s->log_m, s->log_r, d_out);
+  HIPCHK(c, hipGetLastError()); return 0;
+}
 int32_t lasso_gather(lasso_ctx* c, const lasso_fr* d_table, const uint32_t* d_idx, size_t n, lasso_fr* d_out) {
   REQUIRE(c, d_table && d_idx && d_out); if (!n) return 0;
   ProfScope ps(c, LASSO_K_MISC, 68.0 * n);

@@ -213,6 +213,14 @@ class Device:
         self._chk(self.lib.lasso_hyrax_commit_compressed_u32(self.ctx, C.c_void_p(d_u32), max_value, l_size, r_size, C.c_void_p(bases), _vp(out)))
         return out
 
+    def materialize_subtable_u32(self, strategy, sub):
+        m = 1 << strategy.log_m
+        p = self.alloc(4 * m)
+        self._chk(self.lib.lasso_materialize_subtable_u32(self.ctx, C.byref(strategy), sub, C.c_void_p(p)))
+        out = self.download(p, (m,), dtype=np.uint32)
+        self.free(p)
+        return out
+
     def gather_u32(self, d_table, d_idx, n, d_out):
         self._chk(self.lib.lasso_gather_u32(self.ctx, C.c_void_p(d_table), C.c_void_p(d_idx), n, C.c_void_p(d_out)))
 

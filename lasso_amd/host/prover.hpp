@@ -302,6 +302,12 @@ struct Strategy {
   }
   size_t memory_to_dimension_index(size_t i) const { return abi.kind == LASSO_RANGE ? i : i / num_subtables(); }                       // mod.rs:70-74, range_check.rs:71-73
   // materialize_subtables: every table of the reference holds small integers, so the host builds u32 and the device lifts to Fr
+  // largest entry of any subtable (bounds the scalars of E's commitment): l op r < 2^(log_m / 2); LT / EQ are bits; range tables hold indices
+  uint32_t max_table_value() const {
+    if (abi.kind == LASSO_LT) return 1;
+    if (abi.kind == LASSO_RANGE) return (uint32_t)(M() - 1);
+    return (uint32_t)(((size_t)1 << (abi.log_m / 2)) - 1);
+  }
   std::vector<std::vector<uint32_t>> materialize_subtables() const {
     size_t m = M(), bits = abi.log_m / 2; std::vector<std::vector<uint32_t>> out;
     auto split = [&](size_t idx, size_t& l, size_t& r) { size_t mask = ((size_t)1 << bits) - 1; r = idx & mask; l = (idx >> bits) & mask; };   // utils/mod.rs:82-89
@@ -972,9 +978,14 @@ class Prover {
     LASSO_REQUIRE(r.size() == ceil_log2(s));
     // Subtables::new (subtables/mod.rs:116-129)
     std::unique_ptr<Trace> sp(new Trace("Subtables.new", d.ctx));
-    auto host_tables = S.materialize_subtables();
-    std::vector<DBufU32> tables_u32; uint32_t table_max = 0;   // the integer tables stay until E is committed (the commitment's scalars are T[dim] as integers)
-    for (auto& ht : host_tables) { for (uint32_t v : ht) table_max = std::max(table_max, v); tables_u32.emplace_back(d, ht); tables.emplace_back(d, m); }
+    // the subtables as integers, written by the device (64 K entries each: nothing to compute on the host and upload); they stay until E is
+    // committed (the commitment's scalars are T[dim] as integers)
+    std::vector<DBufU32> tables_u32; const uint32_t table_max = S.max_table_value();
+    for (size_t i = 0; i < S.num_subtables(); i++) {
+      tables_u32.emplace_back(d, m); tables.emplace_back(d, m);
+      d.chk(lasso_materialize_subtable_u32(d.ctx, &S.abi, (uint32_t)i, tables_u32.back().p), "lasso_materialize_subtable_u32");
+    }
+    if (side_off() || P != 1) {} else d.chk(lasso_sync(d.ctx), "lasso_sync");   // the side context reads them
     size_t n_E = next_pow2(alpha * s); nv_derefs = ceil_log2(n_E);
     combined_E = DBuf(d, n_E / P);
     DBuf eq(d, s_loc);

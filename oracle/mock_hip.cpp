@@ -286,6 +286,12 @@ int32_t lasso_hyrax_commit_compressed_u32(lasso_ctx* c, const uint32_t* Z, uint3
   for (size_t i = 0; i < ls; i++) { std::vector<Fr> sc(rs); for (size_t j = 0; j < rs; j++) { REQ(c, Z[i * rs + j] <= max_value); sc[j] = Fr::from_u64(Z[i * rs + j]); } msm(bases, sc).compress(out32 + 32 * i); }
   return 0;
 }
+int32_t lasso_materialize_subtable_u32(lasso_ctx* c, const lasso_strategy* s, uint32_t sub, uint32_t* o) {
+  Strategy S = mk(s); auto tabs = S.materialize_subtables();   // the oracle's restatement of and.rs / or.rs / xor.rs / lt.rs / range_check.rs
+  REQ(c, sub < tabs.size());
+  for (size_t i = 0; i < tabs[sub].size(); i++) { u64 cc[4]; tabs[sub][i].to_canonical(cc); REQ(c, cc[1] == 0 && cc[2] == 0 && cc[3] == 0 && cc[0] < ((u64)1 << 32)); o[i] = (uint32_t)cc[0]; }
+  return 0;
+}
 int32_t lasso_gather_u32(lasso_ctx*, const uint32_t* t, const uint32_t* idx, size_t n, uint32_t* o) { for (size_t i = 0; i < n; i++) o[i] = t[idx[i]]; return 0; }
 int32_t lasso_msm(lasso_ctx* c, const lasso_bases* b, const lasso_fr* scalars, size_t n, lasso_point* out) {
   REQ(c, n <= b->pts.size());

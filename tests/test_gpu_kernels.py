@@ -504,6 +504,19 @@ def test_sumcheck_cubic_tail(devs, n, ncirc, bind):
         assert np.array_equal(x, y)
 
 
+@pytest.mark.parametrize("kind,log_m,log_r,nsub", [("and", 16, 0, 1), ("or", 8, 0, 1), ("xor", 4, 0, 1), ("lt", 8, 0, 2), ("lt", 4, 0, 2), ("range", 16, 40, 3), ("range", 8, 13, 3), ("and", 2, 0, 1)])
+def test_materialize_subtable_u32(devs, kind, log_m, log_r, nsub):
+    """subtables written by the device == the oracle's restatement of and.rs / or.rs / xor.rs / lt.rs / range_check.rs (whose KATs oracle/kats.cpp pins)"""
+    S = _abi.Strategy(_abi.KINDS[kind], 1, log_m, log_r)
+    for sub in range(nsub):
+        a, b = both(devs, lambda d: d.materialize_subtable_u32(S, sub))
+        assert np.array_equal(a, b)
+    bits = log_m // 2; i = np.arange(1 << log_m, dtype=np.uint64); l = (i >> bits) & ((1 << bits) - 1); r = i & ((1 << bits) - 1)
+    t0 = devs[0].materialize_subtable_u32(S, 0)
+    want = {"and": l & r, "or": l | r, "xor": l ^ r, "lt": (l < r).astype(np.uint64), "range": i}[kind]
+    assert np.array_equal(t0.astype(np.uint64), want)
+
+
 def test_launch_wait_protocol_errors(devs):
     """misuse of the launch/wait split is reported as an error code, never a hang or a wrong result: waiting with nothing pending, a wrong count,
     a second deferral, a tail challenge without a tail; and a deferred call still delivers the right values afterwards"""
