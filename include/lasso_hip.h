@@ -142,6 +142,10 @@ int32_t lasso_defer_next(lasso_ctx* ctx);
 int32_t lasso_sumcheck_cubic_tail_begin(lasso_ctx* ctx, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n,
                                         const lasso_fr* r);
 int32_t lasso_sumcheck_cubic_tail_next(lasso_ctx* ctx, const lasso_fr* r);
+/* The resident tail of the primary sumcheck for the linear strategies (the rounds lasso_sumcheck_linear_eqw_round[_fused] serve one launch at a time):
+ * begin as above on the alpha polynomials d_src (only read); per round 2*alpha values out[2k] = S0_k, out[2k+1] = S1_k; challenges through
+ * lasso_sumcheck_cubic_tail_next; after log2(2q) of them the pending result is the alpha heads out[k] = E_k(r_z) (surge.rs:175-176). */
+int32_t lasso_sumcheck_linear_tail_begin(lasso_ctx* ctx, const lasso_fr* const* d_src, uint32_t alpha, const lasso_fr* d_E, size_t n, const lasso_fr* r);
 /* One round of SumcheckInstanceProof::prove_arbitrary (src/subprotocols/sumcheck.rs:165-237) with
  * comb_func = S::combine_lookups_eq (src/subtables/mod.rs:53-57): out[x] = sum_i g(E_1..E_alpha)(x) * eq(x), x = 0..degree.
  * d_polys holds alpha = NUM_MEMORIES device pointers; d_eq is the eq polynomial. */

@@ -46,7 +46,7 @@ struct lasso_ctx {
   uint32_t* d_flags = nullptr;
   uint32_t* d_counters = nullptr;                         // arrival tickets of the in-launch reductions (zero between launches)
   bool pending = false, defer_next = false; uint32_t pending_seq = 0; size_t pending_count = 0;   // a deferred result not yet collected by lasso_result_wait
-  bool tail_active = false; uint32_t tail_seq0 = 0, tail_turn = 0, tail_turns = 0, tail_ncirc = 0;   // resident sumcheck-tail kernel (k_cubic_tail); its mailbox = h_flag + 32 (bytes 128..163)
+  bool tail_active = false; uint32_t tail_seq0 = 0, tail_turn = 0, tail_turns = 0; size_t tail_count = 0, tail_final = 0;   // resident sumcheck-tail kernel (k_cubic_tail); its mailbox = h_flag + 32 (bytes 128..163)
   uint32_t prof_mask = 0;   // bit k set = kernel family k is bracketed with events
   std::vector<EventPair> events; size_t events_used = 0;
   uint64_t prof_launches[LASSO_K_COUNT] = {0}; double prof_ms[LASSO_K_COUNT] = {0}; double prof_bytes[LASSO_K_COUNT] = {0};
@@ -370,8 +370,28 @@ int32_t lasso_sumcheck_cubic_tail_begin(lasso_ctx* c, lasso_fr* const* d_A, lass
   if (r) hipLaunchKernelGGL((k_cubic_tail<true>), dim3(ncirc), dim3(LASSO_BLOCK), 0, c->stream, A, B, (const fr_t*)d_E, (uint32_t)q, to_fr(r), (const uint32_t*)(c->d_flag + 32), c->d_counters, c->d_small, c->d_flag, seq0);
   else hipLaunchKernelGGL((k_cubic_tail<false>), dim3(ncirc), dim3(LASSO_BLOCK), 0, c->stream, A, B, (const fr_t*)d_E, (uint32_t)q, fr_zero(), (const uint32_t*)(c->d_flag + 32), c->d_counters, c->d_small, c->d_flag, seq0);
   HIPCHK(c, hipGetLastError());
-  c->tail_active = true; c->tail_seq0 = seq0; c->tail_turn = 0; c->tail_turns = turns; c->tail_ncirc = ncirc;
-  c->pending = true; c->pending_seq = seq0; c->pending_count = (size_t)ncirc * 2;
+  c->tail_active = true; c->tail_seq0 = seq0; c->tail_turn = 0; c->tail_turns = turns; c->tail_count = (size_t)ncirc * 2; c->tail_final = (size_t)ncirc * 2;
+  c->pending = true; c->pending_seq = seq0; c->pending_count = c->tail_count;
+  return 0;
+}
+// The same for the primary sumcheck of a linear strategy (k_linear_tail): per round two dot products per polynomial, out[2k] = S0_k, out[2k+1] = S1_k
+// (as lasso_sumcheck_linear_eqw_round, without the unused third slot); after the last challenge the heads out[k] = polys_k[0] (alpha values).
+// d_src is only read (r == NULL: arrays of length n = 2q; otherwise bound with r first, n = 4q).  Challenges go through lasso_sumcheck_cubic_tail_next.
+int32_t lasso_sumcheck_linear_tail_begin(lasso_ctx* c, const lasso_fr* const* d_src, uint32_t alpha, const lasso_fr* d_E, size_t n, const lasso_fr* r) {
+  REQUIRE(c, d_src && d_E && alpha >= 1 && alpha <= LASSO_MAX_PTRS && n >= (r ? 4u : 2u) && (n & (n - 1)) == 0 && !c->pending && !c->tail_active && !c->defer_next);
+  const size_t q = r ? n / 4 : n / 2;
+  REQUIRE(c, q >= 1 && q <= CUBIC_TAIL_Q);
+  PtrTable Src; for (uint32_t i = 0; i < alpha; i++) { REQUIRE(c, d_src[i]); Src.p[i] = (const fr_t*)d_src[i]; }
+  int32_t rc = ensure_small(c, (size_t)alpha * 3); if (rc) return rc;
+  uint32_t turns = 0; while (((size_t)1 << turns) < 2 * q) turns++;
+  volatile uint32_t* mail = c->h_flag + 32;
+  mail[0] = 0; mail[4] = 0; mail[8] = 0; __atomic_thread_fence(__ATOMIC_SEQ_CST);
+  const uint32_t seq0 = c->seq + 1; c->seq += turns + 1;
+  if (r) hipLaunchKernelGGL((k_linear_tail<true>), dim3(alpha), dim3(LASSO_BLOCK), 0, c->stream, Src, (const fr_t*)d_E, (uint32_t)q, to_fr(r), (const uint32_t*)(c->d_flag + 32), c->d_counters, c->d_small, c->d_flag, seq0);
+  else hipLaunchKernelGGL((k_linear_tail<false>), dim3(alpha), dim3(LASSO_BLOCK), 0, c->stream, Src, (const fr_t*)d_E, (uint32_t)q, fr_zero(), (const uint32_t*)(c->d_flag + 32), c->d_counters, c->d_small, c->d_flag, seq0);
+  HIPCHK(c, hipGetLastError());
+  c->tail_active = true; c->tail_seq0 = seq0; c->tail_turn = 0; c->tail_turns = turns; c->tail_count = (size_t)alpha * 2; c->tail_final = alpha;
+  c->pending = true; c->pending_seq = seq0; c->pending_count = c->tail_count;
   return 0;
 }
 int32_t lasso_sumcheck_cubic_tail_next(lasso_ctx* c, const lasso_fr* r) {
@@ -385,7 +405,7 @@ int32_t lasso_sumcheck_cubic_tail_next(lasso_ctx* c, const lasso_fr* r) {
   _mm_store_si128((__m128i*)(mail + 4), _mm_set_epi32((int)rr.v[5], (int)rr.v[4], (int)rr.v[3], (int)tn));
   _mm_store_si128((__m128i*)(mail + 8), _mm_set_epi32(0, (int)rr.v[7], (int)rr.v[6], (int)tn));
   __atomic_thread_fence(__ATOMIC_RELEASE);
-  c->pending = true; c->pending_seq = c->tail_seq0 + c->tail_turn; c->pending_count = (size_t)c->tail_ncirc * 2;
+  c->pending = true; c->pending_seq = c->tail_seq0 + c->tail_turn; c->pending_count = c->tail_turn == c->tail_turns ? c->tail_final : c->tail_count;
   if (c->tail_turn == c->tail_turns) c->tail_active = false;
   return 0;
 }

@@ -509,6 +509,90 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_dot_eqw_fused(PtrTable src, Mut
   fr29 e[3] = {fr29_acc_reduce(w0), fr29_acc_reduce(w1), fr29_zero()};
   cubic_epilogue(e, g, partials, counters, out, flag, seq, S, 0);
 }
+// The tail of the primary sumcheck for a linear strategy, resident like k_cubic_tail: from q <= CUBIC_TAIL_Q indices per polynomial on, the
+// remaining rounds' two dot products per polynomial (S0_k = sum_{i<h} z[i] E[i], S1_k = sum_{i<h} z[i+h] E[i]) and the binds run out of LDS,
+// challenges arrive through the host mailbox, and the last publication is the heads z_k[0] = E_k(r_z).  One workgroup per polynomial; src is
+// only read.  out: sums turns out[2k], out[2k+1]; final turn out[k].
+template <bool BIND>
+__global__ void __launch_bounds__(LASSO_BLOCK) k_linear_tail(PtrTable src, const fr_t* __restrict__ E, uint32_t q, fr_t r0, const uint32_t* mailbox, uint32_t* counters,
+                                                              fr_t* __restrict__ out, uint32_t* flag, uint32_t seq0) {
+  __shared__ fr29 z[2 * CUBIC_TAIL_Q];
+  __shared__ int32_t rows[2 * CUBIC_TAIL_Q * 9];
+  __shared__ int64_t strips[8 * 18];
+  __shared__ int64_t cols[18];
+  __shared__ fr_t chal;
+  __shared__ uint32_t alive;
+  const uint32_t t = threadIdx.x, y = blockIdx.x, npoly = gridDim.x;
+  const uint64_t t_end = wall_clock64() + 500000000ull;   // 5 s at 100 MHz
+  uint32_t m = 2 * q;
+  {
+    const fr29 rs = fr29_unpack_s(r0);
+    const fr_t* p = src.p[y];
+    for (uint32_t i = t; i < m; i += LASSO_BLOCK) z[i] = BIND ? bind29(p[i], p[i + m], rs) : fr29_unpack_u(p[i]);
+  }
+  __syncthreads();
+  for (uint32_t turn = 0;; turn++) {
+    const uint32_t h = m / 2;
+    for (uint32_t u = t; u < m; u += LASSO_BLOCK) {   // rows 0..h-1: S0 terms, h..2h-1: S1 terms
+      const fr29 term = fr29_mul(z[u], fr29_unpack_s(E[u < h ? u : u - h]));
+#pragma unroll
+      for (int k = 0; k < 9; k++) rows[u * 9 + k] = term.v[k];
+    }
+    __syncthreads();
+    if (h > 16) {
+      if (t < 8 * 18) {
+        const uint32_t col = t % 18, strip = t / 18, v = col / 9, k = col - v * 9;
+        const uint32_t per = (h + 7) / 8, i0 = strip * per, i1 = i0 + per < h ? i0 + per : h;
+        int64_t sum = 0;
+        for (uint32_t i = i0; i < i1; i++) sum += rows[(v * h + i) * 9 + k];
+        strips[strip * 18 + col] = sum;
+      }
+      __syncthreads();
+      if (t < 18) { int64_t sum = 0; for (int g = 0; g < 8; g++) sum += strips[g * 18 + t]; cols[t] = sum; }
+    } else if (t < 18) {
+      const uint32_t v = t / 9, k = t - v * 9;
+      int64_t sum = 0;
+      for (uint32_t i = 0; i < h; i++) sum += rows[(v * h + i) * 9 + k];
+      cols[t] = sum;
+    }
+    __syncthreads();
+    if (t < 2) {
+      int64_t c[9];
+#pragma unroll
+      for (int k = 0; k < 9; k++) c[k] = cols[t * 9 + k];
+      out[(size_t)y * 2 + t] = fr29_pack(fr29_reduce_columns(c, 0));   // u * s products: memory form already
+    }
+    row_done(npoly, counters, flag, seq0 + turn);
+    if (t == 0) {   // the round's challenge (three self-validating 16-byte chunks, see k_cubic_tail)
+      typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+      const u32x4* m4 = reinterpret_cast<const u32x4*>(mailbox);
+      uint32_t ok = 1; u32x4 c0, c1, c2; uint32_t spins = 0;
+      for (;;) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+        c0 = __builtin_nontemporal_load(m4); c1 = __builtin_nontemporal_load(m4 + 1); c2 = __builtin_nontemporal_load(m4 + 2);
+        if (c0.x == turn + 1 && c1.x == turn + 1 && c2.x == turn + 1) break;
+        if ((++spins & 63u) == 0 && wall_clock64() > t_end) { ok = 0; break; }
+      }
+      if (ok) { chal.v[0] = c0.y; chal.v[1] = c0.z; chal.v[2] = c0.w; chal.v[3] = c1.y; chal.v[4] = c1.z; chal.v[5] = c1.w; chal.v[6] = c2.y; chal.v[7] = c2.z; }
+      alive = ok;
+    }
+    __syncthreads();
+    if (!alive) return;
+    const fr29 rs = fr29_unpack_s(chal);
+    fr29 nb;
+    if (t < h) nb = fr29_canonical(fr29_add(z[t], fr29_mul(fr29_sub(z[t + h], z[t]), rs)));
+    __syncthreads();
+    if (t < h) z[t] = nb;
+    __syncthreads();
+    m = h;
+    if (m == 1) {
+      if (t == 0) out[y] = fr29_pack(z[0]);
+      row_done(npoly, counters, flag, seq0 + turn + 1);
+      return;
+    }
+  }
+}
+
 
 // ------------------------------------------------------------------ g = S::combine_lookups (subtables/*.rs)
 // AND/OR/XOR (and.rs:45-53) and RangeCheck (range_check.rs:78-86): g = sum_i 2^(i*inc) * vals[i] is LINEAR, so along the line

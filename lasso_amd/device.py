@@ -152,6 +152,21 @@ class Device:
             out = np.empty((2 * k, 4), dtype=np.uint64); self._chk(self.lib.lasso_result_wait(self.ctx, _vp(out), 2 * k)); outs.append(out)
         return outs
 
+    def sumcheck_linear_tail(self, ptrs, d_e, n, r, challenges):
+        """resident tail of the primary sumcheck (lasso_sumcheck_linear_tail_begin + lasso_sumcheck_cubic_tail_next): per-round (alpha, 2, 4) sums, then the (alpha, 4) heads"""
+        k = len(ptrs)
+        rp = None if r is None else _vp(np.ascontiguousarray(r, dtype=np.uint64))
+        outs = []
+        self._chk(self.lib.lasso_sumcheck_linear_tail_begin(self.ctx, self._ptrs(ptrs), k, C.c_void_p(d_e), n, rp))
+        out = np.empty((2 * k, 4), dtype=np.uint64); self._chk(self.lib.lasso_result_wait(self.ctx, _vp(out), 2 * k)); outs.append(out.reshape(k, 2, 4))
+        for t, ch in enumerate(challenges):
+            ch = np.ascontiguousarray(ch, dtype=np.uint64)
+            self._chk(self.lib.lasso_sumcheck_cubic_tail_next(self.ctx, _vp(ch)))
+            last = t == len(challenges) - 1
+            out = np.empty(((1 if last else 2) * k, 4), dtype=np.uint64); self._chk(self.lib.lasso_result_wait(self.ctx, _vp(out), out.shape[0]))
+            outs.append(out if last else out.reshape(k, 2, 4))
+        return outs
+
     def sumcheck_combine_round(self, strategy, ptrs, d_eq, n, degree):
         out = np.empty((degree + 1, 4), dtype=np.uint64)
         self._chk(self.lib.lasso_sumcheck_combine_round(self.ctx, C.byref(strategy), self._ptrs(ptrs), C.c_void_p(d_eq), n, degree, _vp(out)))

@@ -538,8 +538,10 @@ class Prover {
   // d_E + host scalars), a round is one launch (bind of the previous challenge + two dot products per polynomial), the weights 2^(k*inc) are applied
   // here.  One phase = `rounds` rounds over point[v0 .. v0+rounds) on arrays of length len; polys = the alpha E clones only.
   // src (optional): read-only arrays holding the polynomials; the bound arrays go to `polys` (half the length) — no clone of the inputs
+  // tail_heads (optional): filled with the alpha final values when the phase ended in the resident tail kernel (then the arrays hold stale data)
   void linear_rounds(size_t rounds, size_t len, std::vector<lasso_fr*>& polys, const lasso_fr* d_E, const ScVec& point, size_t v0, bool reduce, Sc& s_run, SumcheckProof& proof, ScVec& r_out,
-                     const std::vector<const lasso_fr*>* src = nullptr) {
+                     const std::vector<const lasso_fr*>* src = nullptr, std::vector<lasso_fr>* tail_heads = nullptr) {
+    if (tail_heads) tail_heads->clear();
     if (!rounds) return;
     if (src && rounds < 2) {   // too short for a fused bind to move the data: a one-element copy per polynomial, then in place
       for (size_t i = 0; i < polys.size(); i++) d.chk(lasso_copy(d.ctx, polys[i], (*src)[i], len * sizeof(lasso_fr)), "lasso_copy");
@@ -554,6 +556,15 @@ class Prover {
     }
     DBuf tj; if (degenerate) tj = DBuf(d, len / 2);
     Sc r_prev = Sc::zero();
+    // the last rounds (<= 256 indices per polynomial) in one resident kernel, as in cubic_rounds
+    static const bool tail_off = [] { const char* v = getenv("LASSO_LINEAR_TAIL"); return v && v[0] == '0'; }();
+    size_t tail_from = rounds;
+    if (tail_heads && !reduce && !degenerate && !tail_off) {
+      size_t j0 = 0, l = len;
+      while (j0 < rounds && (j0 == 0 ? l / 2 : l / 4) > 256) { if (j0) l /= 2; j0++; }
+      if (j0 < rounds) tail_from = j0;
+    }
+    bool in_tail = false;
     for (size_t j = 0; j < rounds; j++) {
       const lasso_fr* table = d_E; Sc scale = degenerate ? Sc::one() : inv[j];
       if (degenerate) {
@@ -563,7 +574,18 @@ class Prover {
         table = tj.p;
       }
       std::vector<lasso_fr> ev(3 * alpha);
-      if (j == 0) d.chk(lasso_sumcheck_linear_eqw_round(d.ctx, src ? src->data() : (const lasso_fr* const*)polys.data(), (uint32_t)alpha, table, len, ev.data()), "lasso_sumcheck_linear_eqw_round");
+      if (j >= tail_from) {
+        lasso_fr rp = r_prev.abi();
+        if (!in_tail) {   // the data is still in src if no bind has moved it yet
+          const bool from_src = src && j <= 1;
+          d.chk(lasso_sumcheck_linear_tail_begin(d.ctx, from_src ? src->data() : (const lasso_fr* const*)polys.data(), (uint32_t)alpha, table, len, j == 0 ? nullptr : &rp), "lasso_sumcheck_linear_tail_begin");
+          in_tail = true;
+        } else d.chk(lasso_sumcheck_cubic_tail_next(d.ctx, &rp), "lasso_sumcheck_cubic_tail_next");
+        if (j) len /= 2;
+        std::vector<lasso_fr> e2(2 * alpha);
+        d.chk(lasso_result_wait(d.ctx, e2.data(), 2 * alpha), "lasso_result_wait");
+        for (size_t k2 = 0; k2 < alpha; k2++) { ev[3 * k2] = e2[2 * k2]; ev[3 * k2 + 1] = e2[2 * k2 + 1]; }
+      } else if (j == 0) d.chk(lasso_sumcheck_linear_eqw_round(d.ctx, src ? src->data() : (const lasso_fr* const*)polys.data(), (uint32_t)alpha, table, len, ev.data()), "lasso_sumcheck_linear_eqw_round");
       else {
         lasso_fr rp = r_prev.abi();
         if (j == 1 && src) d.chk(lasso_sumcheck_linear_eqw_round_fused_from(d.ctx, src->data(), polys.data(), (uint32_t)alpha, table, len, &rp, ev.data()), "lasso_sumcheck_linear_eqw_round_fused_from");
@@ -583,6 +605,12 @@ class Prover {
       proof.compressed_polys.push_back(up.compress());
     }
     lasso_fr rp = r_prev.abi();   // the last challenge of the phase (len == 2 here)
+    if (in_tail) {
+      d.chk(lasso_sumcheck_cubic_tail_next(d.ctx, &rp), "lasso_sumcheck_cubic_tail_next");
+      tail_heads->resize(alpha);
+      d.chk(lasso_result_wait(d.ctx, tail_heads->data(), alpha), "lasso_result_wait");
+      return;
+    }
     d.chk(lasso_bind_top(d.ctx, polys.data(), (uint32_t)polys.size(), len, &rp), "lasso_bind_top");
   }
   // polys: local arrays of length len_loc (global length len_loc * P); polys[alpha] = the eq table of `point` (local share in slab mode)
@@ -600,7 +628,12 @@ class Prover {
     };
     if (S.linear()) {
       std::vector<lasso_fr*> ep(polys.begin(), polys.begin() + alpha); Sc s_run = Sc::one();
-      if (P == 1) { linear_rounds(num_rounds, len_loc, ep, polys[alpha], point, 0, false, s_run, proof, r_out, src); read_heads(ep); return proof; }
+      std::vector<lasso_fr> th;
+      auto finish = [&](const std::vector<lasso_fr*>& arrs) {
+        if (th.empty()) { read_heads(arrs); return; }
+        if (heads_out) { heads_out->clear(); for (auto& x : th) heads_out->push_back(Sc::from_abi(x)); }
+      };
+      if (P == 1) { linear_rounds(num_rounds, len_loc, ep, polys[alpha], point, 0, false, s_run, proof, r_out, src, heads_out ? &th : nullptr); finish(ep); return proof; }
       LASSO_REQUIRE(num_rounds >= lgP && ((size_t)1 << (num_rounds - lgP)) == len_loc);
       const size_t local_rounds = num_rounds - lgP;
       if (src && local_rounds == 0) { for (size_t i = 0; i < alpha; i++) d.chk(lasso_copy(d.ctx, ep[i], (*src)[i], len_loc * sizeof(lasso_fr)), "lasso_copy"); }
@@ -609,8 +642,8 @@ class Prover {
       tail_bufs.emplace_back(d, P);
       std::vector<lasso_fr> rr; for (size_t i = local_rounds; i < num_rounds; i++) rr.push_back(point[i].abi());
       d.chk(lasso_eq_evals(d.ctx, rr.data(), (uint32_t)rr.size(), tail_bufs.back().p), "lasso_eq_evals");
-      linear_rounds(lgP, P, tail, tail_bufs.back().p, point, local_rounds, false, s_run, proof, r_out);
-      read_heads(tail);
+      linear_rounds(lgP, P, tail, tail_bufs.back().p, point, local_rounds, false, s_run, proof, r_out, nullptr, heads_out ? &th : nullptr);
+      finish(tail);
       tail_bufs.clear();
       return proof;
     }

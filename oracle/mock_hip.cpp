@@ -17,6 +17,7 @@ struct lasso_ctx {
   // launch/wait split (per context, as on the device): the result of a deferred / *_begin call, handed over by lasso_result_wait
   std::vector<Fr> pending; bool defer = false;
   std::vector<std::vector<Fr>> tail_a, tail_b; std::vector<Fr> tail_e;   // resident tail: private copies of the arrays
+  bool tail_linear = false;   // k_linear_tail: tail_a holds the alpha polynomials, tail_b is unused
 };
 struct lasso_bases { std::vector<Point> pts; };
 
@@ -150,6 +151,13 @@ int32_t lasso_result_wait(lasso_ctx* c, lasso_fr* out, size_t count) {
 static void tail_publish(lasso_ctx* ctx) {
   auto& ta = ctx->tail_a; auto& tb = ctx->tail_b; auto& te = ctx->tail_e; auto& pend = ctx->pending;
   const size_t k = ta.size(), m = ta[0].size();
+  if (ctx->tail_linear) {
+    if (m == 1) { pend.assign(k, Fr::zero()); for (size_t c = 0; c < k; c++) pend[c] = ta[c][0]; ta.clear(); ctx->tail_linear = false; return; }
+    pend.assign(2 * k, Fr::zero());
+    const size_t h = m / 2;
+    for (size_t c = 0; c < k; c++) { Fr s0 = Fr::zero(), s1 = Fr::zero(); for (size_t i = 0; i < h; i++) { s0 += ta[c][i] * te[i]; s1 += ta[c][h + i] * te[i]; } pend[2 * c] = s0; pend[2 * c + 1] = s1; }
+    return;
+  }
   pend.assign(2 * k, Fr::zero());
   if (m == 1) { for (size_t c = 0; c < k; c++) { pend[c] = ta[c][0]; pend[k + c] = tb[c][0]; } ta.clear(); tb.clear(); return; }
   const size_t h = m / 2;
@@ -167,6 +175,16 @@ int32_t lasso_sumcheck_cubic_tail_begin(lasso_ctx* c, lasso_fr* const* A, lasso_
   const size_t q = r ? n / 4 : n / 2; REQ(c, q >= 1 && q <= 256);
   c->tail_a.clear(); c->tail_b.clear();
   for (uint32_t k = 0; k < nc; k++) { c->tail_a.emplace_back(F(A[k]), F(A[k]) + n); c->tail_b.emplace_back(F(B[k]), F(B[k]) + n); }
+  c->tail_e.assign(F(E), F(E) + q);
+  if (r) tail_bind(c, *F(r));
+  tail_publish(c);
+  return 0;
+}
+int32_t lasso_sumcheck_linear_tail_begin(lasso_ctx* c, const lasso_fr* const* src, uint32_t alpha, const lasso_fr* E, size_t n, const lasso_fr* r) {
+  REQ(c, n >= (r ? 4u : 2u) && (n & (n - 1)) == 0 && c->tail_a.empty() && c->pending.empty());
+  const size_t q = r ? n / 4 : n / 2; REQ(c, q >= 1 && q <= 256);
+  c->tail_a.clear(); c->tail_b.clear(); c->tail_linear = true;
+  for (uint32_t k = 0; k < alpha; k++) c->tail_a.emplace_back(F(src[k]), F(src[k]) + n);
   c->tail_e.assign(F(E), F(E) + q);
   if (r) tail_bind(c, *F(r));
   tail_publish(c);

@@ -504,6 +504,48 @@ def test_sumcheck_cubic_tail(devs, n, ncirc, bind):
         assert np.array_equal(x, y)
 
 
+@pytest.mark.parametrize("n,alpha,bind", [(2, 1, False), (4, 1, True), (8, 3, False), (64, 2, True), (512, 1, False), (1024, 2, True), (256, 33, True), (16, 8, False)])
+def test_sumcheck_linear_tail(devs, n, alpha, bind):
+    """resident tail of the primary sumcheck (linear strategies) against the per-round eq-weighted calls: same dot products every round, same heads,
+    and the source arrays are left untouched"""
+    rng = np.random.default_rng(n * 17 + alpha)
+    Ps = [rand_fr(rng, n) for _ in range(alpha)]
+    q = n // 4 if bind else n // 2
+    E = rand_fr(rng, q)
+    r0 = rand_fr(rng, 1, edge=False)[0] if bind else None
+    turns = (2 * q).bit_length() - 1
+    chal = rand_fr(rng, turns, edge=False)
+
+    def run(d):
+        pp = [d.upload(x) for x in Ps]; pe = d.upload(E)
+        outs = d.sumcheck_linear_tail(pp, pe, n, r0, chal)
+        after = [d.download(p, (n, 4)) for p in pp]
+        for p in pp + [pe]:
+            d.free(p)
+        return outs, after
+
+    def per_round(d):
+        pp = [d.upload(x) for x in Ps]; pe = d.upload(E)
+        outs = [d.sumcheck_linear_eqw_round_fused(pp, pe, n, r0) if bind else d.sumcheck_linear_eqw_round(pp, pe, n)]
+        length = n // 2 if bind else n
+        for t in range(turns - 1):
+            outs.append(d.sumcheck_linear_eqw_round_fused(pp, pe, length, chal[t])); length //= 2
+        d.bind_top(pp, length, chal[turns - 1])
+        outs.append(np.stack([d.download(p, (1, 4))[0] for p in pp]))
+        for p in pp + [pe]:
+            d.free(p)
+        return outs
+    (a, a_after), (b, b_after) = both(devs, run)
+    assert len(a) == turns + 1
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    for x, y in zip(a_after, Ps):
+        assert np.array_equal(x, y)
+    ref = per_round(devs[0])
+    for x, y in zip(a, ref):
+        assert np.array_equal(x, y)
+
+
 @pytest.mark.parametrize("kind,log_m,log_r,nsub", [("and", 16, 0, 1), ("or", 8, 0, 1), ("xor", 4, 0, 1), ("lt", 8, 0, 2), ("lt", 4, 0, 2), ("range", 16, 40, 3), ("range", 8, 13, 3), ("and", 2, 0, 1)])
 def test_materialize_subtable_u32(devs, kind, log_m, log_r, nsub):
     """subtables written by the device == the oracle's restatement of and.rs / or.rs / xor.rs / lt.rs / range_check.rs (whose KATs oracle/kats.cpp pins)"""
