@@ -18,6 +18,7 @@ struct lasso_ctx {
   std::vector<Fr> pending; bool defer = false;
   std::vector<std::vector<Fr>> tail_a, tail_b; std::vector<Fr> tail_e;   // resident tail: private copies of the arrays
   bool tail_linear = false;   // k_linear_tail: tail_a holds the alpha polynomials, tail_b is unused
+  std::vector<lasso_fr*> mid_a, mid_b;   // k_cubic_mid: where the bound arrays go back when 2*256 elements are left
 };
 struct lasso_bases { std::vector<Point> pts; };
 
@@ -151,6 +152,10 @@ int32_t lasso_result_wait(lasso_ctx* c, lasso_fr* out, size_t count) {
 static void tail_publish(lasso_ctx* ctx) {
   auto& ta = ctx->tail_a; auto& tb = ctx->tail_b; auto& te = ctx->tail_e; auto& pend = ctx->pending;
   const size_t k = ta.size(), m = ta[0].size();
+  if (!ctx->mid_a.empty() && m <= 512) {   // k_cubic_mid hands over: write back, no result
+    for (size_t c = 0; c < k; c++) for (size_t i = 0; i < m; i++) { F(ctx->mid_a[c])[i] = ta[c][i]; F(ctx->mid_b[c])[i] = tb[c][i]; }
+    ta.clear(); tb.clear(); ctx->mid_a.clear(); ctx->mid_b.clear(); pend.clear(); return;
+  }
   if (ctx->tail_linear) {
     if (m == 1) { pend.assign(k, Fr::zero()); for (size_t c = 0; c < k; c++) pend[c] = ta[c][0]; ta.clear(); ctx->tail_linear = false; return; }
     pend.assign(2 * k, Fr::zero());
@@ -174,6 +179,16 @@ int32_t lasso_sumcheck_cubic_tail_begin(lasso_ctx* c, lasso_fr* const* A, lasso_
   REQ(c, n >= (r ? 4u : 2u) && (n & (n - 1)) == 0 && c->tail_a.empty() && c->pending.empty());
   const size_t q = r ? n / 4 : n / 2; REQ(c, q >= 1 && q <= 256);
   c->tail_a.clear(); c->tail_b.clear();
+  for (uint32_t k = 0; k < nc; k++) { c->tail_a.emplace_back(F(A[k]), F(A[k]) + n); c->tail_b.emplace_back(F(B[k]), F(B[k]) + n); }
+  c->tail_e.assign(F(E), F(E) + q);
+  if (r) tail_bind(c, *F(r));
+  tail_publish(c);
+  return 0;
+}
+int32_t lasso_sumcheck_cubic_mid_begin(lasso_ctx* c, lasso_fr* const* A, lasso_fr* const* B, uint32_t nc, const lasso_fr* E, size_t n, const lasso_fr* r) {
+  REQ(c, n >= (r ? 4u : 2u) && (n & (n - 1)) == 0 && c->tail_a.empty() && c->pending.empty() && nc * 16 <= 256);
+  const size_t q = r ? n / 4 : n / 2; REQ(c, q > 256 && q <= 4096);
+  c->tail_a.clear(); c->tail_b.clear(); c->mid_a.assign(A, A + nc); c->mid_b.assign(B, B + nc);
   for (uint32_t k = 0; k < nc; k++) { c->tail_a.emplace_back(F(A[k]), F(A[k]) + n); c->tail_b.emplace_back(F(B[k]), F(B[k]) + n); }
   c->tail_e.assign(F(E), F(E) + q);
   if (r) tail_bind(c, *F(r));
