@@ -111,4 +111,6 @@ inline bool ed_decompress(const uint8_t* in, Point& out) {
   return true;
 }
 
+inline bool curve_decompress(const uint8_t* in, Point& out) { return ed_decompress(in, out); }   // the name both curve headers share
+
 }  // namespace orc

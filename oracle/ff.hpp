@@ -8,6 +8,7 @@
 //   Fr = curve25519 scalar field, p = 2^252 + 27742317777372353535851937790883648493
 //        (`ark_curve25519::Fr`, src/benches/bench.rs:6, src/e2e_test.rs:1)
 //   Fq = curve25519 base field,   p = 2^255 - 19
+// With -DORC_BN254 the same two names stand for ark-bn254's Fr / Fq (configs[1] of BASELINE.json names G = BN254).
 // Parity status: arithmetic is pinned against Python big integers (tests/test_oracle_field.py)
 // and against the reference's own small-integer KATs.
 #pragma once
@@ -134,6 +135,23 @@ struct Fp {
   }
 };
 
+#ifdef ORC_BN254
+// BN254 (ark-bn254 ^0.4): Fr = the order of G1, Fq = its base field; both 254 bits (see bn254.hpp)
+struct FrParams {
+  static constexpr u64 P[4] = {0x43e1f593f0000001ULL, 0x2833e84879b97091ULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL};
+  static constexpr u64 R1[4] = {0xac96341c4ffffffbULL, 0x36fc76959f60cd29ULL, 0x666ea36f7879462eULL, 0x0e0a77c19a07df2fULL};
+  static constexpr u64 R2[4] = {0x1bb8e645ae216da7ULL, 0x53fe3ab1e35c59e3ULL, 0x8c49833d53bb8085ULL, 0x0216d0b17f4e44a5ULL};
+  static constexpr u64 INV = 0xc2e1f593efffffffULL;
+  static constexpr int MODULUS_BITS = 254;
+};
+struct FqParams {
+  static constexpr u64 P[4] = {0x3c208c16d87cfd47ULL, 0x97816a916871ca8dULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL};
+  static constexpr u64 R1[4] = {0xd35d438dc58f0d9dULL, 0x0a78eb28f5c70b3dULL, 0x666ea36f7879462cULL, 0x0e0a77c19a07df2fULL};
+  static constexpr u64 R2[4] = {0xf32cfc5b538afa89ULL, 0xb5e71911d44501fbULL, 0x47ab1eff0a417ff6ULL, 0x06d89f71cab8351fULL};
+  static constexpr u64 INV = 0x87d20782e4866389ULL;
+  static constexpr int MODULUS_BITS = 254;
+};
+#else
 struct FrParams {
   static constexpr u64 P[4] = {0x5812631a5cf5d3edULL, 0x14def9dea2f79cd6ULL, 0x0ULL, 0x1000000000000000ULL};
   static constexpr u64 R1[4] = {0xd6ec31748d98951dULL, 0xc6ef5bf4737dcf70ULL, 0xfffffffffffffffeULL, 0x0fffffffffffffffULL};
@@ -148,6 +166,7 @@ struct FqParams {
   static constexpr u64 INV = 0x86bca1af286bca1bULL;
   static constexpr int MODULUS_BITS = 255;
 };
+#endif
 typedef Fp<FrParams> Fr;
 typedef Fp<FqParams> Fq;
 

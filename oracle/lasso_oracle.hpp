@@ -12,7 +12,11 @@
 // reference's own acceptance criterion, prove -> verify == Ok, for the four e2e_test.rs configurations.
 #pragma once
 #include "ff.hpp"
+#ifdef ORC_BN254
+#include "bn254.hpp"
+#else
 #include "ed25519.hpp"
+#endif
 #include "hashes.hpp"
 #include <vector>
 #include <functional>
@@ -90,6 +94,17 @@ inline F field_rand(ChaChaRng& rng) {
 inline Fr fr_rand(ChaChaRng& rng) { return field_rand<Fr, FrParams>(rng); }
 inline Fq fq_rand(ChaChaRng& rng) { return field_rand<Fq, FqParams>(rng); }
 
+#ifdef ORC_BN254
+// ark-ec SW `Projective::rand`: x <- Fq::rand, greatest <- bool, point from x (cofactor 1)
+inline Point point_rand(ChaChaRng& rng) {
+  for (;;) {
+    Fq x = fq_rand(rng);
+    bool greatest = ((int32_t)rng.next_u32()) < 0;
+    Fq ys, yl;
+    if (sw_ys_from_x(x, ys, yl)) return Point::from_affine(x, greatest ? yl : ys);
+  }
+}
+#else
 // ark-ec TE `Projective::rand`: y <- Fq::rand, greatest <- bool, point from y, times cofactor 8
 inline Point point_rand(ChaChaRng& rng) {
   for (;;) {
@@ -99,6 +114,7 @@ inline Point point_rand(ChaChaRng& rng) {
     if (ed_xs_from_y(y, xs, xl)) { Point p = Point::from_affine(greatest ? xl : xs, y); return p.dbl().dbl().dbl(); }
   }
 }
+#endif
 
 // ---------------------------------------------------------------- utils/random.rs:9-39
 struct RandomTape {
@@ -1123,7 +1139,7 @@ struct ByteReader {
   ByteReader(const uint8_t* p_, size_t n_) : p(p_), n(n_) {}
   uint64_t u64le() { if (pos + 8 > n) { ok = false; return 0; } uint64_t x = 0; for (int i = 0; i < 8; i++) x |= (uint64_t)p[pos + i] << (8 * i); pos += 8; return x; }
   Fr fr() { if (pos + 32 > n) { ok = false; return Fr::zero(); } u64 c[4] = {0, 0, 0, 0}; for (int i = 0; i < 32; i++) c[i / 8] |= (u64)p[pos + i] << (8 * (i % 8)); pos += 32; if (Fr::geq_p(c)) ok = false; return Fr::from_canonical(c); }
-  Point pt() { Point q = Point::identity(); if (pos + 32 > n) { ok = false; return q; } if (!ed_decompress(p + pos, q)) ok = false; pos += 32; return q; }
+  Point pt() { Point q = Point::identity(); if (pos + 32 > n) { ok = false; return q; } if (!curve_decompress(p + pos, q)) ok = false; pos += 32; return q; }
   std::vector<Fr> frs_vec() { uint64_t k = u64le(); std::vector<Fr> v; if (k > n) { ok = false; return v; } for (uint64_t i = 0; i < k && ok; i++) v.push_back(fr()); return v; }
   std::vector<Fr> frs_arr(size_t k) { std::vector<Fr> v; for (size_t i = 0; i < k && ok; i++) v.push_back(fr()); return v; }
   std::vector<Point> pts_vec() { uint64_t k = u64le(); std::vector<Point> v; if (k > n) { ok = false; return v; } for (uint64_t i = 0; i < k && ok; i++) v.push_back(pt()); return v; }

@@ -25,6 +25,14 @@ void orc_f_from_canonical(int which, const u64* a, u64* o) { if (which) { Fq r =
 void orc_f_to_canonical(int which, const u64* a, u64* o) { if (which) Fq::from_raw(a).to_canonical(o); else Fr::from_raw(a).to_canonical(o); }
 void orc_fr_from_le_bytes_mod_order(const uint8_t* b, size_t n, u64* o) { Fr r = Fr::from_le_bytes_mod_order(b, n); memcpy(o, r.v, 32); }
 
+// which group this build restates: 0 = curve25519 (the reference's own instantiation), 1 = BN254 G1 (-DORC_BN254)
+int orc_curve_id() {
+#ifdef ORC_BN254
+  return 1;
+#else
+  return 0;
+#endif
+}
 // ---- curve: affine canonical coordinates in/out (4 limbs each), for Python big-int cross checks
 static Point pt_from_canon(const u64* xy) { return Point::from_affine(Fq::from_canonical(xy), Fq::from_canonical(xy + 4)); }
 static void pt_to_canon(const Point& p, u64* xy) { Fq x, y; p.to_affine(x, y); x.to_canonical(xy); y.to_canonical(xy + 4); }
@@ -33,7 +41,7 @@ void orc_pt_add(const u64* a, const u64* b, u64* o) { pt_to_canon(pt_from_canon(
 void orc_pt_dbl(const u64* a, u64* o) { pt_to_canon(pt_from_canon(a).dbl(), o); }
 void orc_pt_mul(const u64* a, const u64* scalar_canon, u64* o) { pt_to_canon(pt_from_canon(a).mul_limbs(scalar_canon), o); }
 void orc_pt_compress(const u64* a, uint8_t* out32) { pt_from_canon(a).compress(out32); }
-int orc_pt_decompress(const uint8_t* in32, u64* o) { Point p; if (!ed_decompress(in32, p)) return -1; pt_to_canon(p, o); return 0; }
+int orc_pt_decompress(const uint8_t* in32, u64* o) { Point p; if (!curve_decompress(in32, p)) return -1; pt_to_canon(p, o); return 0; }
 // MSM over affine canonical bases and Montgomery Fr scalars (oracle of msm/mod.rs:36-40)
 void orc_msm(const u64* bases_xy, const u64* scalars_mont, size_t n, u64* out_xy) {
   std::vector<Point> b; std::vector<Fr> s;

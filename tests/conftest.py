@@ -26,6 +26,30 @@ def _build_oracle():
     return so
 
 
+def _build_oracle_bn254():
+    so = os.path.join(ROOT, "oracle", "liblasso_oracle_bn254.so")
+    srcs = [os.path.join(ROOT, "oracle", f) for f in ("oracle_capi.cpp", "kats.cpp", "lasso_oracle.hpp", "ff.hpp", "bn254.hpp", "hashes.hpp")]
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "liblasso_oracle_bn254.so"])
+    return so
+
+
+def _load_oracle(path):
+    lib = ctypes.CDLL(path)   # RTLD_LOCAL: the curve25519 and BN254 builds export the same names and must not see each other
+    lib.orc_kat_names.restype = ctypes.c_char_p
+    lib.orc_last_error.restype = ctypes.c_char_p
+    lib.orc_session_new.restype = ctypes.c_void_p
+    return lib
+
+
+@pytest.fixture(scope="session")
+def oracle_bn254():
+    """The same CPU restatement instantiated over ark-bn254's G1 / Fr (oracle/bn254.hpp)."""
+    lib = _load_oracle(_build_oracle_bn254())
+    assert lib.orc_curve_id() == 1
+    return lib
+
+
 @pytest.fixture(scope="session")
 def oracle():
     lib = ctypes.CDLL(_build_oracle())
