@@ -1,0 +1,130 @@
+// BN254 build (-DLASSO_BN254) of fe29.cuh: Fq of ark-bn254 in nine signed 29-bit limbs (mont29.cuh, Montgomery radix 2^261: a coordinate x is
+// held as x * 2^261 mod q, lazily reduced) and G1 in homogeneous projective coordinates under the complete formulas of Renes-Costello-Batina
+// 2016 (a = 0, b3 = 9) — the representation the MSM kernels keep points and tables in.  Same names as the curve25519 header so the kernels are
+// shared: pt29 keeps its four-coordinate layout (T unused), a table entry ("niels29") is the affine point (x, y), the mixed addition costs 11
+// products (7 on the Edwards curve), the full addition 12 (9), a doubling 8.  Negating a table entry negates y.
+// Bounds: "reduced" / "loose" as in mont29.cuh.  Every coordinate a function returns is reduced; products renormalise magnitudes to
+// (-X, q + X) with X < 3 q, sums of up to three such values and their small multiples (3, 8, 9) stay far below the 2^30 limb bound.
+#pragma once
+#include <stdint.h>
+#include "fq.cuh"
+#include "mont29.cuh"
+
+struct Bn254FqM {
+  static LHD int32_t p(int k) { const int32_t P[9] = {410844487, 17064118, 477274959, 47522512, 361093496, 47923392, 10936641, 240920116, 3171406}; return P[k]; }
+  static constexpr uint32_t PINV = 75916169u;
+  static constexpr int32_t QC = 1420063842;
+  static constexpr int32_t ONE_S_0 = 360500257, ONE_S_1 = 337389400, ONE_S_2 = 408039635, ONE_S_3 = 21759001, ONE_S_4 = 178483129, ONE_S_5 = 490881230, ONE_S_6 = 299191303,
+                           ONE_S_7 = 86689704, ONE_S_8 = 903222;
+  static constexpr int32_t K522_0 = 94088208, K522_1 = 219480995, K522_2 = 25171640, K522_3 = 279645352, K522_4 = 40052281, K522_5 = 46143135, K522_6 = 379321683,
+                           K522_7 = 294034764, K522_8 = 2757030;
+};
+typedef m29<Bn254FqM> fe29;
+#define FE29_MASK M29_MASK
+
+LHD fe29 fe_zero() { return m29_zero<Bn254FqM>(); }
+LHD fe29 fe_one() { fe29 r; r.v[0] = 360500257; r.v[1] = 337389400; r.v[2] = 408039635; r.v[3] = 21759001; r.v[4] = 178483129; r.v[5] = 490881230; r.v[6] = 299191303; r.v[7] = 86689704; r.v[8] = 903222; return r; }   // 2^261 mod q
+LHD fe29 fe_add(const fe29& a, const fe29& b) { return m29_add(a, b); }
+LHD fe29 fe_sub(const fe29& a, const fe29& b) { return m29_sub(a, b); }
+LHD fe29 fe_neg(const fe29& a) { return m29_neg(a); }
+LHD fe29 fe_dbl(const fe29& a) { return m29_add(a, a); }
+LHD fe29 fe_weak(const fe29& a) { return m29_weak(a); }
+LHD fe29 fe_small(const fe29& a, int32_t k) { return m29_mul_small(a, k); }   // value * k, any limbs with |.| <= 2^30 -> reduced
+LHD fe29 fe_mul(const fe29& a, const fe29& b) { return m29_mul(a, b); }       // a loose, b reduced -> reduced
+LHD fe29 fe_sqr(const fe29& a) { return m29_mul(a, a); }                       // a reduced
+// a^(q-2), a reduced
+LHD fe29 fe_inv_chain(const fe29& z) {
+  const uint32_t e[8] = {0xd87cfd45u, 0x3c208c16u, 0x6871ca8du, 0x97816a91u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};   // q - 2
+  fe29 r = fe_one();
+  for (int i = 253; i >= 0; i--) { r = fe_sqr(r); if ((e[i >> 5] >> (i & 31)) & 1u) r = fe_mul(r, z); }
+  return r;
+}
+
+// ------------------------------------------------------------------ conversions (fq_t = ark's Montgomery words x * 2^256, canonical)
+LHD fe29 fe_from_fq(const fq_t& x) { return m29_unpack_words_shl5<Bn254FqM>(x.v); }
+LHD fq_t fe_to_fq(const fe29& a) {   // any reduced / loose a
+  fe29 c256 = fe_zero(); c256.v[8] = 1 << 24;   // the integer 2^256: (x 2^261) 2^256 / 2^261 = x 2^256
+  fq_t r; m29_pack_words(m29_canonical(fe_mul(a, c256)), r.v); return r;
+}
+LHD void fe_to_plain_words(const fe29& a, uint32_t* out) {   // the canonical integer x itself
+  fe29 one = fe_zero(); one.v[0] = 1;
+  m29_pack_words(m29_canonical(fe_mul(a, one)), out);
+}
+
+// ------------------------------------------------------------------ group law
+struct pt29 { fe29 X, Y, T, Z; };                                  // (X : Y : Z); T unused (kept so that layouts match the Edwards build)
+struct alignas(16) niels29 { fe29 x, y; int32_t pad[10]; };        // affine table entry, 112 bytes: 7 x dwordx4
+
+LHD pt29 pt_identity() { pt29 p; p.X = fe_zero(); p.Y = fe_one(); p.T = fe_zero(); p.Z = fe_zero(); return p; }
+LHD fe29 fe_d2() { return fe_zero(); }   // the Edwards build passes 2d to pt_add; nothing to pass here
+LHD fe29 fe_x3(const fe29& a) { return fe_weak(fe_add(fe_add(a, a), a)); }   // reduced -> reduced
+// shared tail of the complete formulas:  X3 = t3 t1 - t4 y3,  Y3 = t1 z3 + y3 t0,  Z3 = z3 t4 + t0 t3
+//   t0 = 3 X1X2, t1 = Y1Y2 - 9 Z1Z2, z3 = Y1Y2 + 9 Z1Z2, t3 = X1Y2 + X2Y1, t4 = Y1Z2 + Y2Z1, y3 = 9 (X1Z2 + X2Z1)
+LHD pt29 pt_finish(const fe29& t0r, const fe29& t1l, const fe29& z3l, const fe29& t3l, const fe29& t4l, const fe29& y3r) {
+  const fe29 t1r = fe_weak(t1l), z3r = fe_weak(z3l), t3r = fe_weak(t3l), t4r = fe_weak(t4l);
+  pt29 r;
+  r.X = fe_weak(fe_sub(fe_mul(t3l, t1r), fe_mul(t4l, y3r)));
+  r.Y = fe_weak(fe_add(fe_mul(t1l, z3r), fe_mul(y3r, t0r)));
+  r.Z = fe_weak(fe_add(fe_mul(z3l, t4r), fe_mul(t0r, t3r)));
+  r.T = fe_zero();
+  return r;
+}
+// mixed addition p + (x, y): 11 products
+LHD pt29 pt_madd(const pt29& p, const niels29& n) {
+  const fe29 t0 = fe_mul(p.X, n.x), t1 = fe_mul(p.Y, n.y);
+  const fe29 t3 = fe_sub(fe_sub(fe_mul(fe_add(p.X, p.Y), fe_weak(fe_add(n.x, n.y))), t0), t1);
+  const fe29 t4 = fe_add(fe_mul(p.Z, n.y), p.Y);
+  const fe29 y3 = fe_add(fe_mul(p.Z, n.x), p.X);
+  const fe29 t2 = fe_small(p.Z, 9);
+  return pt_finish(fe_x3(t0), fe_sub(t1, t2), fe_add(t1, t2), t3, t4, fe_small(y3, 9));
+}
+// full addition: 12 products.  The second argument of the Edwards build (2d) is ignored.
+LHD pt29 pt_add(const pt29& p, const pt29& q, const fe29&) {
+  const fe29 t0 = fe_mul(p.X, q.X), t1 = fe_mul(p.Y, q.Y), t2 = fe_mul(p.Z, q.Z);
+  const fe29 t3 = fe_sub(fe_sub(fe_mul(fe_add(p.X, p.Y), fe_weak(fe_add(q.X, q.Y))), t0), t1);
+  const fe29 t4 = fe_sub(fe_sub(fe_mul(fe_add(p.Y, p.Z), fe_weak(fe_add(q.Y, q.Z))), t1), t2);
+  const fe29 y3 = fe_sub(fe_sub(fe_mul(fe_add(p.X, p.Z), fe_weak(fe_add(q.X, q.Z))), t0), t2);
+  const fe29 t29 = fe_small(t2, 9);
+  return pt_finish(fe_x3(t0), fe_sub(t1, t29), fe_add(t1, t29), t3, t4, fe_small(y3, 9));
+}
+LHD pt29 pt_dbl(const pt29& p) {
+  const fe29 t0 = fe_sqr(p.Y), z8 = fe_small(t0, 8), t1 = fe_mul(p.Y, p.Z), t2 = fe_small(fe_sqr(p.Z), 9);
+  const fe29 x3 = fe_mul(t2, z8), y3 = fe_weak(fe_add(t0, t2));
+  const fe29 u = fe_sub(t0, fe_x3(t2));                       // Y^2 - 27 Z^2
+  pt29 r;
+  r.Y = fe_weak(fe_add(fe_mul(u, y3), x3));
+  r.X = fe_mul(u, fe_weak(fe_dbl(fe_mul(p.X, p.Y))));
+  r.Z = fe_mul(t1, z8);
+  r.T = fe_zero();
+  return r;
+}
+LHD niels29 niels_from_xy29(const fe29& x, const fe29& y, const fe29&) {   // x, y reduced (canonicalised here so that table entries are digits)
+  niels29 n; n.x = m29_canonical(x); n.y = m29_canonical(y);
+#pragma unroll
+  for (int i = 0; i < 10; i++) n.pad[i] = 0;
+  return n;
+}
+LHD niels29 niels_from_affine(const fq_t& x, const fq_t& y) { return niels_from_xy29(fe_from_fq(x), fe_from_fq(y), fe_zero()); }
+LHD niels29 niels_cond_neg(const niels29& n, bool neg) {
+  niels29 r = n;
+#pragma unroll
+  for (int k = 0; k < 9; k++) r.y.v[k] = neg ? -n.y.v[k] : n.y.v[k];
+  return r;
+}
+LHD pt29 pt_from_ed(const ed_point& e) { pt29 p; p.X = fe_from_fq(e.X); p.Y = fe_from_fq(e.Y); p.T = fe_zero(); p.Z = fe_from_fq(e.Z); return p; }
+LHD ed_point pt_to_ed(const pt29& p) { ed_point e; e.X = fe_to_fq(p.X); e.Y = fe_to_fq(p.Y); e.T = fq_zero(); e.Z = fe_to_fq(p.Z); return e; }
+LHD ed_point pt_to_abi(const pt29& p) { return pt_to_ed(p); }   // fq_t already is ark's Montgomery form
+// ark-serialize's compressed short-Weierstrass point (ark-ec SWFlags; serialize_compressed of the normalised point, utils/transcript.rs:47-51):
+// canonical x, little endian; bit 7 of the last byte set iff y > -y as canonical integers; bit 6 = point at infinity (x = 0).
+LHD void pt_compress(const pt29& p, uint32_t* out) {
+  uint32_t zw[8]; fe_to_plain_words(p.Z, zw);
+  uint32_t any = 0; for (int i = 0; i < 8; i++) any |= zw[i];
+  if (!any) { for (int i = 0; i < 8; i++) out[i] = 0; out[7] = 0x40000000u; return; }
+  const fe29 zi = fe_inv_chain(fe_weak(p.Z));
+  const fe29 y = fe_mul(p.Y, zi);
+  uint32_t yw[8], nyw[8];
+  fe_to_plain_words(fe_mul(p.X, zi), out); fe_to_plain_words(y, yw); fe_to_plain_words(fe_neg(y), nyw);
+  bool neg = false;
+  for (int i = 7; i >= 0; i--) if (yw[i] != nyw[i]) { neg = yw[i] > nyw[i]; break; }
+  if (neg) out[7] |= 0x80000000u;
+}

@@ -9,6 +9,9 @@
 //                         "loose"    <= 2^30 + 2^16   (one add/sub of reduced values)
 // fe_mul(a, b) requires a loose, b reduced: 9 products of <= 2^59.01 stay below 2^63.
 #pragma once
+#ifdef LASSO_BN254
+#include "bn254_fe29.cuh"   // the same interface over ark-bn254's Fq and G1
+#else
 #include <stdint.h>
 #include "fq.cuh"
 
@@ -178,3 +181,15 @@ LHD void pt_compress(const pt29& p, uint32_t* out) {
   if (neg) out[7] |= 0x80000000u;
 }
 LHD ed_point pt_to_ed(const pt29& p) { ed_point e; e.X = fe_to_fq(p.X); e.Y = fe_to_fq(p.Y); e.T = fe_to_fq(p.T); e.Z = fe_to_fq(p.Z); return e; }
+
+// helpers the kernels share with the BN254 build (bn254_fe29.cuh)
+LHD niels29 niels_from_xy29(const fe29& x, const fe29& y, const fe29& d2) { niels29 e; e.ypx = fe_weak(fe_add(y, x)); e.ymx = fe_weak(fe_sub(y, x)); e.t2d = fe_mul(fe_mul(x, y), d2); e.pad = 0; return e; }
+LHD niels29 niels_cond_neg(const niels29& n, bool neg) {   // -(x, y) = (-x, y): swap y+x and y-x, negate 2dxy
+  niels29 r;
+#pragma unroll
+  for (int k = 0; k < 9; k++) { r.ypx.v[k] = neg ? n.ymx.v[k] : n.ypx.v[k]; r.ymx.v[k] = neg ? n.ypx.v[k] : n.ymx.v[k]; r.t2d.v[k] = neg ? -n.t2d.v[k] : n.t2d.v[k]; }
+  r.pad = 0;
+  return r;
+}
+LHD ed_point pt_to_abi(const pt29& p) { ed_point e = pt_to_ed(p), o; o.X = fq_to_mont(e.X); o.Y = fq_to_mont(e.Y); o.T = fq_to_mont(e.T); o.Z = fq_to_mont(e.Z); return o; }   // ark's Montgomery limbs
+#endif  // LASSO_BN254

@@ -7,6 +7,9 @@
 // Points: extended (X:Y:T:Z) = ark-ec `twisted_edwards::Projective`; bases are kept as precomputed
 // affine "Niels" triples (y+x, y-x, 2dxy) so bucket accumulation is a 7-multiplication mixed add.
 #pragma once
+#ifdef LASSO_BN254
+#include "bn254_fq.cuh"   // the same interface over ark-bn254's Fq and G1
+#else
 #include <stdint.h>
 #include "fr.cuh"
 
@@ -201,3 +204,4 @@ LHD ed_point ed_mul_limbs(const ed_point& p, const uint32_t* e, int nbits = 256)
   for (int i = nbits - 1; i >= 0; i--) { r = ed_dbl(r); if ((e[i / 32] >> (i % 32)) & 1) r = ed_add(r, p); }
   return r;
 }
+#endif  // LASSO_BN254

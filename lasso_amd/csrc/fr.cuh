@@ -8,6 +8,9 @@
 // carries and a shift (4 mads + 1 mul per reduction row instead of 8).
 // This header is __host__ __device__: the host prover uses the same arithmetic for its O(log n) tails.
 #pragma once
+#ifdef LASSO_BN254
+#include "bn254_fr.cuh"   // the same interface over ark-bn254's Fr
+#else
 #include <stdint.h>
 
 #if defined(__HIPCC__) || defined(__CUDACC__)
@@ -186,3 +189,4 @@ LHD int fr_canonical_bits(const fr_t& c) {
   for (int i = 7; i >= 0; i--) if (c.v[i]) { uint32_t x = c.v[i]; int n = 0; while (x) { n++; x >>= 1; } return 32 * i + n; }
   return 0;
 }
+#endif  // LASSO_BN254

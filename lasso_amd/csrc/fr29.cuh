@@ -16,6 +16,9 @@
 // ONE operand of each product in "s-form" (x*2^261 = the same bits shifted left by 5, free at unpack time) or corrects a whole sum
 // once at the end with a constant (FR29_K5 / FR29_K10).  mul(u, s) = u-form; mul(s, s) = s-form; mul(u, u) = u-form / 2^5.
 #pragma once
+#ifdef LASSO_BN254
+#include "bn254_fr29.cuh"   // the same interface over ark-bn254's Fr
+#else
 #include <stdint.h>
 #include "fr.cuh"
 
@@ -244,3 +247,4 @@ LHD fr29 fr29_from_columns(const int64_t* col) {
   for (int k = 0; k < 9; k++) { int64_t x = l[k] + c * ONE_S[k] + d; if (k < 8) { r.v[k] = (int32_t)x & FR29_MASK; d = x >> 29; } else r.v[8] = (int32_t)x; }
   return r;
 }
+#endif  // LASSO_BN254

@@ -7,14 +7,19 @@
 #include <cstring>
 #include <vector>
 
+#ifdef LASSO_BN254
+#define FR_TOP_SHAVE 2   // 254-bit modulus
+#else
+#define FR_TOP_SHAVE 3   // 253-bit modulus
+#endif
 static std::mt19937_64 rng(4242);
-static fr_t rand_fr() { for (;;) { uint64_t l[4]; for (int i = 0; i < 4; i++) l[i] = rng(); l[3] &= (~0ull) >> 3; fr_t t; memcpy(t.v, l, 32); if (!fr_geq_p(t.v)) return t; } }
+static fr_t rand_fr() { for (;;) { uint64_t l[4]; for (int i = 0; i < 4; i++) l[i] = rng(); l[3] &= (~0ull) >> FR_TOP_SHAVE; fr_t t; memcpy(t.v, l, 32); if (!fr_geq_p(t.v)) return t; } }
 static bool same(const fr_t& a, const fr_t& b) { return memcmp(a.v, b.v, 32) == 0; }
 #define CHECK(c) do { if (!(c)) { printf("FAIL %s line %d\n", #c, __LINE__); return 1; } } while (0)
 
 int main() {
   std::vector<fr_t> xs{fr_zero(), fr_one(), fr_neg(fr_one()), fr_from_u64(2), fr_from_u64(~0ull)};
-  { fr_t pm1; const uint32_t e[8] = {FR_P0 - 1u, FR_P1, FR_P2, FR_P3, 0, 0, 0, FR_P7}; memcpy(pm1.v, e, 32); xs.push_back(pm1); }   // memory integer p-1
+  { fr_t pm1; for (int i = 0; i < 8; i++) pm1.v[i] = fr_p_limb(i); pm1.v[0] -= 1u; xs.push_back(pm1); }   // memory integer p-1
   for (int i = 0; i < 400; i++) xs.push_back(rand_fr());
   const size_t N = xs.size();
   for (size_t i = 0; i < N; i++) {

@@ -22,3 +22,17 @@ def test_cpp_arith(name, flags):
     res = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     assert "OK" in res.stdout
+
+
+@pytest.mark.parametrize("name", ["test_bn254_host", "test_fr29_host"])
+@pytest.mark.parametrize("flags", [[], ["-DLASSO_HOST_LIMBS32"]], ids=["limbs64", "limbs32"])
+def test_cpp_arith_bn254(name, flags):
+    """The BN254 build of the same headers (-DLASSO_BN254: bn254_*.cuh over mont29.cuh) against the oracle's BN254 instantiation."""
+    src = os.path.join(ROOT, "tests", "cpp", name + ".cpp")
+    out_dir = os.path.join(ROOT, "tests", "_build")
+    os.makedirs(out_dir, exist_ok=True)
+    exe = os.path.join(out_dir, name + "_bn254" + ("_32" if flags else "_64"))
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wno-unknown-pragmas", "-DLASSO_BN254", "-DORC_BN254", *flags, "-o", exe, src])
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    assert "OK" in res.stdout
