@@ -26,6 +26,18 @@
 __global__ void k_precompute_table(const fq_t* __restrict__ aff, size_t n, niels29* __restrict__ table) {
   size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (j >= n) return;
+#ifdef LASSO_BN254
+  // BN254 build: the window multiples in the 29-bit form directly (four complete doublings, one inversion per entry)
+  niels29 e = niels_from_affine(aff[2 * j], aff[2 * j + 1]);
+  table[j] = e;
+  for (int w = 1; w < MSM_WINDOWS; w++) {
+    pt29 P = pt_madd(pt_identity(), e);
+    for (int k = 0; k < 4; k++) P = pt_dbl(P);
+    const fe29 zi = fe_inv_chain(P.Z);
+    e = niels_from_xy29(fe_mul(P.X, zi), fe_mul(P.Y, zi), fe_d2());
+    table[(size_t)w * n + j] = e;
+  }
+#else
   fq_t x = fq_from_mont(aff[2 * j]), y = fq_from_mont(aff[2 * j + 1]);
   table[j] = niels_from_affine(x, y);
   ed_point P = ed_from_affine(x, y);
@@ -34,6 +46,7 @@ __global__ void k_precompute_table(const fq_t* __restrict__ aff, size_t n, niels
     fq_t zi = fq_inv_chain(P.Z);
     table[(size_t)w * n + j] = niels_from_affine(fq_mul(P.X, zi), fq_mul(P.Y, zi));
   }
+#endif
 }
 
 // Montgomery Fr -> low 32 bits of the canonical value; flags[0] = max low word seen, flags[1] |= 1 if any value >= 2^32
@@ -204,7 +217,11 @@ __global__ void __launch_bounds__(64) k_precompute_multiples(const niels29* __re
     const fe29 zi = k ? fe_mul(inv, pre[k - 1]) : inv;
     if (k) inv = fe_mul(inv, m[k].Z);
     const fe29 x = fe_mul(m[k].X, zi), y = fe_mul(m[k].Y, zi);
+#ifdef LASSO_BN254
+    const niels29 e = niels_from_xy29(x, y, d2);
+#else
     niels29 e; e.ypx = fe_weak(fe_add(y, x)); e.ymx = fe_weak(fe_sub(y, x)); e.t2d = fe_mul(fe_mul(x, y), d2); e.pad = 0;
+#endif
     dst[(size_t)(k + 1) * n] = e;
   }
 }
@@ -224,6 +241,25 @@ __device__ __forceinline__ uint32_t msm_phys_col(const MsmColMap& m, uint32_t ro
 // C = (T1*2d)*T2 takes two, so every role issues two: the instruction stream stays uniform), stage 2: X3, Y3, T3, Z3 — through an LDS
 // exchange buffer, so a level costs three product times instead of nine.  Role selection is by data (sign / coordinate index), never by branch.
 // pts[0..live) -> pts[0].  st: exchange buffer for 64 additions.  All MSM_THREADS threads must call.
+#ifdef LASSO_BN254
+// BN254 build: the complete projective addition has twelve products in three dependent layers that do not split evenly over four lanes; the tree
+// is the plain one (one lane per addition) until a cooperative schedule for it has been measured.  Same interface.
+__device__ __forceinline__ void msm_coop_tree(pt29* pts, fe29 (*)[4], uint32_t live, const fe29& d2) {
+  const uint32_t t = threadIdx.x;
+  uint32_t p2 = 1; while (p2 < live) p2 <<= 1;
+  for (uint32_t s = p2 >> 1; s > 0; s >>= 1) {
+    for (uint32_t i0 = 0; i0 < s; i0 += MSM_THREADS) {
+      const uint32_t i = i0 + t;
+      const bool act = i < s && i + s < live;
+      pt29 sum;
+      if (act) sum = pt_add(pts[i], pts[i + s], d2);
+      __syncthreads();
+      if (act) pts[i] = sum;
+      __syncthreads();
+    }
+  }
+}
+#else
 __device__ __forceinline__ void msm_coop_tree(pt29* pts, fe29 (*st)[4], uint32_t live, const fe29& d2) {
   const uint32_t t = threadIdx.x, c = t & 3u, g = t >> 2;
   uint32_t p2 = 1; while (p2 < live) p2 <<= 1;
@@ -265,6 +301,7 @@ __device__ __forceinline__ void msm_coop_tree(pt29* pts, fe29 (*st)[4], uint32_t
     }
   }
 }
+#endif  // LASSO_BN254
 #define MSM_DIRECT_MAX_COLS 160   // columns a workgroup may touch (items_per_chunk <= 64 * (MSM_DIRECT_MAX_COLS - 1))
 // grid = (K chunks, rows).  scal: canonical little-endian scalars, 8 words each, row r at scal + r*row_words.  One item = one (column, window);
 // chunk k owns items [k*items_per_chunk, ...).  out_mont[row] (host-mapped) = the row's sum in ark's Montgomery limbs; the workgroup that
@@ -303,8 +340,12 @@ __global__ void __launch_bounds__(MSM_THREADS) k_msm_direct(const uint32_t* __re
     const niels29 nxt = mult[idx];
     if (have) B = pt_madd(B, cur);
     const bool neg = d < 0;
+#ifdef LASSO_BN254
+    cur = niels_cond_neg(nxt, neg);
+#else
 #pragma unroll
     for (int k = 0; k < 9; k++) { cur.ypx.v[k] = neg ? nxt.ymx.v[k] : nxt.ypx.v[k]; cur.ymx.v[k] = neg ? nxt.ypx.v[k] : nxt.ymx.v[k]; cur.t2d.v[k] = neg ? -nxt.t2d.v[k] : nxt.t2d.v[k]; }
+#endif
     have = valid;
   }
   if (have) B = pt_madd(B, cur);
@@ -334,7 +375,11 @@ __global__ void __launch_bounds__(MSM_THREADS) k_msm_direct(const uint32_t* __re
   }
   MSM_STAMP(4);
   if (t == 0) {
+    #ifdef LASSO_BN254
+    out_mont[row] = pt_to_abi(pts[0]);
+#else
     ed_point p = pt_to_ed(pts[0]), o; o.X = fq_to_mont(p.X); o.Y = fq_to_mont(p.Y); o.T = fq_to_mont(p.T); o.Z = fq_to_mont(p.Z); out_mont[row] = o;
+#endif
     if (flag) {
       __threadfence_system();
       const uint32_t t2 = __hip_atomic_fetch_add(&counters[16], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
@@ -362,7 +407,11 @@ __global__ void __launch_bounds__(MSM_THREADS) k_points_sum(const pt29* __restri
   MSM_STAMP(9);
   if (t == 0 && out_compressed) reinterpret_cast<pt29*>(out_compressed)[blockIdx.x] = pts[0];   // compressed mode: hand the row sum to k_points_compress (one lane per row)
   if (t == 0 && !out_compressed) {
+    #ifdef LASSO_BN254
+    out_mont[blockIdx.x] = pt_to_abi(pts[0]);
+#else
     ed_point p = pt_to_ed(pts[0]), o; o.X = fq_to_mont(p.X); o.Y = fq_to_mont(p.Y); o.T = fq_to_mont(p.T); o.Z = fq_to_mont(p.Z); out_mont[blockIdx.x] = o;
+#endif
     if (flag) {
       __threadfence_system();
       uint32_t t2 = __hip_atomic_fetch_add(counters, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);

@@ -12,16 +12,29 @@ namespace lasso {
 
 // host inversions: safegcd (modinv.hpp), ~10x faster than the Fermat chains the device code keeps (fr_inv / fq_inv remain the reference the
 // tests compare against).  Montgomery form: (aR)^-1 as an integer is a^-1 R^-1, one Montgomery product with R^3 brings it back to a^-1 R.
+#ifdef LASSO_BN254
+static const uint32_t FR_R3_WORDS[8] = {0xb4bf0040u, 0x5e94d8e1u, 0x1cfbb6b8u, 0x2a489cbeu, 0xa19fcfedu, 0x893cc664u, 0x7fcc657cu, 0x0cf8594bu};   // 2^768 mod p (BN254 Fr)
+#else
+static const uint32_t FR_R3_WORDS[8] = {0x7b83a2dbu, 0x2a9e4968u, 0xaef7f3ecu, 0x278324e6u, 0x04ec5b65u, 0x8065dc6cu, 0x3599cec7u, 0x0e530b77u};   // 2^768 mod p (curve25519 Fr)
+#endif
 inline fr_t fr_inv_host(const fr_t& a) {
-  static const uint64_t P[4] = {((uint64_t)FR_P1 << 32) | FR_P0, ((uint64_t)FR_P3 << 32) | FR_P2, 0, (uint64_t)FR_P7 << 32};
-  static const ModInv256 mi(P);
+  static const ModInv256 mi([] { static uint64_t P[4]; for (int i = 0; i < 4; i++) P[i] = ((uint64_t)fr_p_limb(2 * i + 1) << 32) | fr_p_limb(2 * i); return (const uint64_t*)P; }());
   uint64_t x[4], y[4]; memcpy(x, a.v, 32);
   if (!mi.inverse(x, y)) return fr_inv(a);
   fr_t t, r3; memcpy(t.v, y, 32);
-  const uint32_t R3[8] = {0x7b83a2dbu, 0x2a9e4968u, 0xaef7f3ecu, 0x278324e6u, 0x04ec5b65u, 0x8065dc6cu, 0x3599cec7u, 0x0e530b77u};  // 2^768 mod p
-  memcpy(r3.v, R3, 32);
+  memcpy(r3.v, FR_R3_WORDS, 32);
   return fr_mul(t, r3);
 }
+#ifdef LASSO_BN254
+inline fq_t fq_inv_host(const fq_t& a) {   // Montgomery Fq (canonical): (aR)^-1 as an integer is a^-1 R^-1; one product with R^3 gives a^-1 R
+  static const uint64_t Q[4] = {0x3c208c16d87cfd47ull, 0x97816a916871ca8dull, 0xb85045b68181585dull, 0x30644e72e131a029ull};
+  static const ModInv256 mi(Q);
+  uint64_t x[4], y[4]; memcpy(x, a.v, 32);
+  if (!mi.inverse(x, y)) return fq_inv(a);
+  fq_t t; memcpy(t.v, y, 32);
+  return fq_mul(t, fq_from_limbs(0xda1530dfu, 0xb1cd6dafu, 0xa7283db6u, 0x62f210e6u, 0x0ada0afbu, 0xef7f0b0cu, 0x2d592544u, 0x20fd6e90u));   // 2^768 mod q
+}
+#else
 inline fq_t fq_inv_host(const fq_t& a) {   // plain (non-Montgomery) Fq, lazily reduced input
   static const uint64_t Q[4] = {0xffffffffffffffedull, ~0ull, ~0ull, 0x7fffffffffffffffull};
   static const ModInv256 mi(Q);
@@ -30,6 +43,7 @@ inline fq_t fq_inv_host(const fq_t& a) {   // plain (non-Montgomery) Fq, lazily 
   if (!mi.inverse(x, y)) return fq_inv(a);
   fq_t r; memcpy(r.v, y, 32); return r;
 }
+#endif
 
 struct Sc {  // element of Fr in ark-ff's Montgomery form (bytes == lasso_fr)
   fr_t v;
@@ -54,8 +68,7 @@ struct Sc {  // element of Fr in ark-ff's Montgomery form (bytes == lasso_fr)
   // ark-ff from_le_bytes_mod_order on 64 bytes (utils/transcript.rs:61-65): (lo + hi*2^256) mod p
   static Sc from_wide_bytes(const uint8_t b[64]) {
     fr_t lo, hi; memcpy(lo.v, b, 32); memcpy(hi.v, b + 32, 32);
-    fr_t r3; const uint32_t R3[8] = {0x7b83a2dbu, 0x2a9e4968u, 0xaef7f3ecu, 0x278324e6u, 0x04ec5b65u, 0x8065dc6cu, 0x3599cec7u, 0x0e530b77u};  // 2^768 mod p
-    memcpy(r3.v, R3, 32);
+    fr_t r3; memcpy(r3.v, FR_R3_WORDS, 32);   // 2^768 mod p
     Sc s; s.v = fr_add(fr_mul(lo, fr_r2()), fr_mul(hi, r3)); return s;  // Montgomery products accept any 256-bit left operand
   }
 };
@@ -107,6 +120,18 @@ struct FixedBase {
   }
 };
 
+#ifdef LASSO_BN254
+// ark-serialize compressed short-Weierstrass point (ark-ec SWFlags): canonical x (LE); bit 7 of the last byte = "y is negative" (y > -y as
+// canonical integers); bit 6 = point at infinity.  x, y: Montgomery form.
+inline void compress_affine(const fq_t& x, const fq_t& y, uint8_t out[32]) {
+  const fq_t xc = fq_to_canonical(x), yc = fq_to_canonical(y), ny = fq_to_canonical(fq_neg(y));
+  memcpy(out, xc.v, 32);
+  bool neg = false;
+  for (int i = 7; i >= 0; i--) if (yc.v[i] != ny.v[i]) { neg = yc.v[i] > ny.v[i]; break; }
+  if (neg) out[31] |= 0x80;
+}
+inline void compress_infinity(uint8_t out[32]) { memset(out, 0, 32); out[31] = 0x40; }
+#else
 // ark-serialize compressed TE point: y (LE) with bit 7 of the last byte = "x is negative" (x > -x as canonical integers)
 inline void compress_affine(const fq_t& x, const fq_t& y, uint8_t out[32]) {
   fq_t yc = fq_canonical(y), xc = fq_canonical(x), nx = fq_canonical(fq_neg(x));
@@ -115,19 +140,36 @@ inline void compress_affine(const fq_t& x, const fq_t& y, uint8_t out[32]) {
   for (int i = 7; i >= 0; i--) if (xc.v[i] != nx.v[i]) { neg = xc.v[i] > nx.v[i]; break; }
   if (neg) out[31] |= 0x80;
 }
+#endif
 // normalize_batch + serialize_compressed for many points with ONE inversion (Montgomery's trick)
 inline void compress_batch(const std::vector<Pt>& pts, std::vector<uint8_t>& out) {
   size_t n = pts.size(); out.resize(32 * n);
   if (!n) return;
   std::vector<fq_t> pre(n);
   fq_t acc = fq_one();
+#ifdef LASSO_BN254
+  // a projective point at infinity has Z = 0 (an all-zero row of a commitment): it stays out of the product
+  for (size_t i = 0; i < n; i++) { pre[i] = acc; if (!fq_is_zero(pts[i].p.Z)) acc = fq_mul(acc, pts[i].p.Z); }
+  fq_t inv = fq_inv_host(acc);
+  for (size_t i = n; i-- > 0;) {
+    if (fq_is_zero(pts[i].p.Z)) { compress_infinity(&out[32 * i]); continue; }
+    fq_t zi = fq_mul(inv, pre[i]); inv = fq_mul(inv, pts[i].p.Z);
+    compress_affine(fq_mul(pts[i].p.X, zi), fq_mul(pts[i].p.Y, zi), &out[32 * i]);
+  }
+#else
   for (size_t i = 0; i < n; i++) { pre[i] = acc; acc = fq_mul(acc, pts[i].p.Z); }
   fq_t inv = fq_inv_host(acc);
   for (size_t i = n; i-- > 0;) {
     fq_t zi = fq_mul(inv, pre[i]); inv = fq_mul(inv, pts[i].p.Z);
     compress_affine(fq_mul(pts[i].p.X, zi), fq_mul(pts[i].p.Y, zi), &out[32 * i]);
   }
+#endif
 }
-inline void compress_one(const Pt& p, uint8_t out[32]) { fq_t zi = fq_inv_host(p.p.Z); compress_affine(fq_mul(p.p.X, zi), fq_mul(p.p.Y, zi), out); }
+inline void compress_one(const Pt& p, uint8_t out[32]) {
+#ifdef LASSO_BN254
+  if (fq_is_zero(p.p.Z)) { compress_infinity(out); return; }
+#endif
+  fq_t zi = fq_inv_host(p.p.Z); compress_affine(fq_mul(p.p.X, zi), fq_mul(p.p.Y, zi), out);
+}
 
 }  // namespace lasso

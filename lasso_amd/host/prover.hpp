@@ -179,7 +179,11 @@ class ProofTranscript {
 inline Sc fr_rand(ChaChaRng& rng) {
   for (;;) {
     uint64_t l[4]; for (int i = 0; i < 4; i++) l[i] = rng.next_u64();
+#ifdef LASSO_BN254
+    l[3] &= (~(uint64_t)0) >> 2;   // 254-bit modulus
+#else
     l[3] &= (~(uint64_t)0) >> 3;
+#endif
     fr_t t; memcpy(t.v, l, 32);
     if (!fr_geq_p(t.v)) { Sc s; s.v = t; return s; }
   }
@@ -194,6 +198,32 @@ class RandomTape {  // utils/random.rs:9-39
 };
 
 // ------------------------------------------------------------------ generators (poly/commitments.rs:22-44, dot_product.rs:139-150, dense_mlpoly.rs:34-45)
+#ifdef LASSO_BN254
+inline bool fq_sqrt(const fq_t& a, fq_t& out) {  // q = 3 (mod 4): a^((q+1)/4)
+  const uint32_t e[8] = {0xb61f3f52u, 0x4f082305u, 0x5a1c72a3u, 0x65e05aa4u, 0xa0605617u, 0x6e14116du, 0xb84c680au, 0x0c19139cu};
+  const fq_t r = fq_pow(a, e);
+  if (fq_eq(fq_sqr(r), a)) { out = r; return true; }
+  return false;
+}
+inline bool canonical_less(const fq_t& a, const fq_t& b) { fq_t x = fq_to_canonical(a), y = fq_to_canonical(b); for (int i = 7; i >= 0; i--) if (x.v[i] != y.v[i]) return x.v[i] < y.v[i]; return false; }
+// ark-ec `Projective::rand` for a short Weierstrass curve: x <- Fq::rand (limbs taken as the Montgomery representation, top 2 bits masked,
+// rejection), bool, y from x (smaller or larger root); cofactor 1
+inline Pt point_rand(ChaChaRng& rng) {
+  for (;;) {
+    uint64_t l[4]; for (int i = 0; i < 4; i++) l[i] = rng.next_u64();
+    l[3] &= (~(uint64_t)0) >> 2;
+    fq_t x; memcpy(x.v, l, 32);
+    if (fq_geq_p(x.v)) continue;
+    bool greatest = ((int32_t)rng.next_u32()) < 0;
+    fq_t y;
+    if (!fq_sqrt(fq_add(fq_mul(fq_sqr(x), x), fq_from_u64(3)), y)) continue;
+    fq_t ny = fq_neg(y), ys, yl;
+    if (canonical_less(ny, y)) { ys = ny; yl = y; } else { ys = y; yl = ny; }
+    return Pt::from_affine_plain(x, greatest ? yl : ys);
+  }
+}
+inline void compress_generator(uint8_t out[32]) { compress_affine(fq_from_u64(1), fq_from_u64(2), out); }   // G1 generator (1, 2)
+#else
 inline bool fq_sqrt(const fq_t& a, fq_t& out) {  // p = 5 (mod 8)
   const uint32_t e[8] = {0xfffffffeu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0x0fffffffu};  // (p+3)/8
   fq_t r = fq_pow(a, e);
@@ -232,6 +262,7 @@ inline void compress_generator(uint8_t out[32]) {
   fq_t gy = fq_from_limbs(0x66666658u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u);
   compress_affine(gx, gy, out);
 }
+#endif  // LASSO_BN254
 // The generator stream for one label: MultiCommitGens::new(n, label) = first n points as G, point n as h.
 struct GenStream {
   std::vector<Pt> pts;

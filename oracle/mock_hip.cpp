@@ -27,7 +27,22 @@ static int32_t fail(lasso_ctx* c, const char* m) { if (c) c->err = m; return LAS
 static inline const Fr* F(const lasso_fr* p) { return reinterpret_cast<const Fr*>(p); }
 static inline Fr* F(lasso_fr* p) { return reinterpret_cast<Fr*>(p); }
 static Strategy mk(const lasso_strategy* s) { Strategy S; S.kind = (StrategyKind)s->kind; S.C = s->c; S.M = (size_t)1 << s->log_m; S.LOG_R = s->log_r; return S; }
+#ifdef ORC_BN254
+// BN254 build: lasso_point is homogeneous projective (x : y : z), t unused; the oracle's Jacobian point goes out in affine form, the identity as (0 : 1 : 0)
+static void put_point(const Point& p, lasso_point* o) {
+  memset(o, 0, sizeof(*o));
+  if (p.is_identity()) { Fq one = Fq::one(); memcpy(o->y, one.v, 32); return; }
+  Fq x, y, one = Fq::one(); p.to_affine(x, y); memcpy(o->x, x.v, 32); memcpy(o->y, y.v, 32); memcpy(o->z, one.v, 32);
+}
+static Point get_point(const lasso_point* p) {
+  Fq X = Fq::from_raw(p->x), Y = Fq::from_raw(p->y), Z = Fq::from_raw(p->z);
+  if (Z.is_zero()) return Point::identity();
+  Fq zi = Z.inverse(); return Point::from_affine(X * zi, Y * zi);
+}
+#else
 static void put_point(const Point& p, lasso_point* o) { memcpy(o->x, p.X.v, 32); memcpy(o->y, p.Y.v, 32); memcpy(o->t, p.T.v, 32); memcpy(o->z, p.Z.v, 32); }
+static Point get_point(const lasso_point* p) { Point q; memcpy(q.X.v, p->x, 32); memcpy(q.Y.v, p->y, 32); memcpy(q.T.v, p->t, 32); memcpy(q.Z.v, p->z, 32); return q; }
+#endif
 
 extern "C" {
 int32_t lasso_ctx_create(int32_t, lasso_ctx** out) { *out = new lasso_ctx(); return 0; }
@@ -395,16 +410,22 @@ int32_t lasso_bullet_fold(lasso_ctx*, lasso_fr* a, lasso_fr* b, size_t nk, const
 }
 
 // ---- test helpers (not part of lasso_hip.h): compare projective points produced by two implementations
-void mock_point_compress(const lasso_point* p, uint8_t* out32) {
-  Point q; memcpy(q.X.v, p->x, 32); memcpy(q.Y.v, p->y, 32); memcpy(q.T.v, p->t, 32); memcpy(q.Z.v, p->z, 32); q.compress(out32);
+void mock_point_compress(const lasso_point* p, uint8_t* out32) { get_point(p).compress(out32); }
+#ifdef ORC_BN254
+int mock_point_on_curve(const lasso_point* p) {  // y^2 z = x^3 + 3 z^3 (the identity (0 : 1 : 0) included)
+  Fq X = Fq::from_raw(p->x), Y = Fq::from_raw(p->y), Z = Fq::from_raw(p->z);
+  if (X.is_zero() && Y.is_zero() && Z.is_zero()) return 0;
+  return Y.square() * Z == X.square() * X + Fq::from_u64(3) * Z.square() * Z;
 }
+#else
 int mock_point_on_curve(const lasso_point* p) {  // -x^2 + y^2 = 1 + d x^2 y^2 and T*Z = X*Y
-  Point q; memcpy(q.X.v, p->x, 32); memcpy(q.Y.v, p->y, 32); memcpy(q.T.v, p->t, 32); memcpy(q.Z.v, p->z, 32);
+  Point q = get_point(p);
   if (q.Z.is_zero()) return 0;
   Fq x, y; q.to_affine(x, y);
   bool on = (y.square() - x.square()) == (Fq::one() + EdConsts::d() * x.square() * y.square());
   return on && (q.T * q.Z == q.X * q.Y);
 }
+#endif
 // n+1 generators from the reference's derivation (commitments.rs:22-44), as lasso_affine (Montgomery limbs); last = h
 void mock_gens(const char* label, size_t n, lasso_affine* out) {
   MultiCommitGens g = MultiCommitGens::create(n, label);

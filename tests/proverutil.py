@@ -11,16 +11,19 @@ from lasso_amd import _abi
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def build_mock_prover():
+def build_mock_prover(curve="curve25519"):
+    """The host prover sources linked against the oracle's mock of the device ABI; curve = "bn254" builds both with -DLASSO_BN254 / -DORC_BN254."""
     out_dir = os.path.join(ROOT, "tests", "_build")
     os.makedirs(out_dir, exist_ok=True)
-    so = os.path.join(out_dir, "liblasso_prover_mock.so")
-    srcs = [os.path.join(ROOT, "lasso_amd", "host", f) for f in ("prover_capi.cpp", "prover.hpp", "field_host.hpp", "hashes.hpp")]
-    srcs += [os.path.join(ROOT, "lasso_amd", "csrc", f) for f in ("fr.cuh", "fq.cuh")]
-    srcs += [os.path.join(ROOT, "oracle", f) for f in ("mock_hip.cpp", "lasso_oracle.hpp", "ff.hpp", "ed25519.hpp", "hashes.hpp")]
+    bn = curve == "bn254"
+    so = os.path.join(out_dir, "liblasso_prover_mock_bn254.so" if bn else "liblasso_prover_mock.so")
+    srcs = [os.path.join(ROOT, "lasso_amd", "host", f) for f in ("prover_capi.cpp", "prover.hpp", "field_host.hpp", "hashes.hpp", "modinv.hpp")]
+    srcs += [os.path.join(ROOT, "lasso_amd", "csrc", f) for f in ("fr.cuh", "fq.cuh", "bn254_fr.cuh", "bn254_fq.cuh")]
+    srcs += [os.path.join(ROOT, "oracle", f) for f in ("mock_hip.cpp", "lasso_oracle.hpp", "ff.hpp", "ed25519.hpp", "bn254.hpp", "hashes.hpp")]
     srcs += [os.path.join(ROOT, "include", f) for f in ("lasso_hip.h", "lasso_prover.h")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-o", so,
+        flags = ["-DLASSO_BN254", "-DORC_BN254"] if bn else []
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", *flags, "-o", so,
                                os.path.join(ROOT, "lasso_amd", "host", "prover_capi.cpp"), os.path.join(ROOT, "oracle", "mock_hip.cpp")])
     return so
 
