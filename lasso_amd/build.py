@@ -20,13 +20,18 @@ def _glob(d, exts):
     return [os.path.join(d, f) for f in sorted(os.listdir(d)) if f.endswith(exts)]
 
 
-def build_device(force=False, verbose=False):
-    """liblasso_hip.so: hand-written gfx950 kernels behind include/lasso_hip.h."""
+CURVES = {"curve25519": ("", []), "bn254": ("_bn254", ["-DLASSO_BN254", "-Wl,-Bsymbolic"])}   # library suffix, extra compile flags
+
+
+def build_device(force=False, verbose=False, curve="curve25519"):
+    """liblasso_hip.so: hand-written gfx950 kernels behind include/lasso_hip.h.  curve="bn254" builds the same kernels over ark-bn254's
+    Fr / G1 (csrc/bn254_*.cuh, mont29.cuh) into liblasso_hip_bn254.so — same C ABI, same symbol names, loaded side by side (RTLD_LOCAL)."""
+    suffix, flags = CURVES[curve]
     csrc = os.path.join(HERE, "csrc")
-    target = os.path.join(HERE, "liblasso_hip.so")
+    target = os.path.join(HERE, f"liblasso_hip{suffix}.so")
     sources = _glob(csrc, (".hip", ".cuh")) + [os.path.join(ROOT, "include", "lasso_hip.h")]
     if force or _stale(target, sources):
-        cmd = [HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result",
+        cmd = [HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result", *flags,
                "-o", target, os.path.join(csrc, "lasso_hip.hip")]
         if verbose:
             print(" ".join(cmd))
@@ -34,17 +39,19 @@ def build_device(force=False, verbose=False):
     return target
 
 
-def build_host(force=False, verbose=False):
-    """liblasso_prover.so: the C++ mirror of the reference's Rust prover, linked against liblasso_hip.so."""
+def build_host(force=False, verbose=False, curve="curve25519"):
+    """liblasso_prover.so: the C++ mirror of the reference's Rust prover, linked against liblasso_hip.so (or the _bn254 pair)."""
+    suffix, flags = CURVES[curve]
     hdir = os.path.join(HERE, "host")
-    target = os.path.join(HERE, "liblasso_prover.so")
+    target = os.path.join(HERE, f"liblasso_prover{suffix}.so")
     sources = _glob(hdir, (".cpp", ".hpp")) + _glob(os.path.join(HERE, "csrc"), (".cuh",)) + [os.path.join(ROOT, "include", "lasso_hip.h"), os.path.join(ROOT, "include", "lasso_prover.h")]
     if not os.path.exists(os.path.join(hdir, "prover_capi.cpp")):
         return None
-    dev = build_device(force=False, verbose=verbose)
+    dev = build_device(force=False, verbose=verbose, curve=curve)
     if force or _stale(target, sources + [dev]):
-        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas", "-o", target,
-               os.path.join(hdir, "prover_capi.cpp"), "-L" + HERE, "-llasso_hip", "-Wl,-rpath,$ORIGIN"]
+        # -fno-gnu-unique / -Bsymbolic: the two curve builds share C++ names and may be loaded side by side; nothing may be unified across them
+        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas", "-fno-gnu-unique", "-Wl,-Bsymbolic", *flags, "-o", target,
+               os.path.join(hdir, "prover_capi.cpp"), "-L" + HERE, f"-llasso_hip{suffix}", "-Wl,-rpath,$ORIGIN"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
@@ -52,7 +59,10 @@ def build_host(force=False, verbose=False):
 
 
 def build_all(force=False, verbose=False):
-    return build_device(force, verbose), build_host(force, verbose)
+    out = []
+    for curve in CURVES:
+        out += [build_device(force, verbose, curve), build_host(force, verbose, curve)]
+    return tuple(out)
 
 
 if __name__ == "__main__":

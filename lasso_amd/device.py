@@ -14,8 +14,9 @@ class LassoError(RuntimeError):
     pass
 
 
-def load_device_library(path=None):
-    path = path or os.path.join(HERE, "liblasso_hip.so")
+def load_device_library(path=None, curve="curve25519"):
+    """curve = "bn254" loads the BN254 build of the same kernels (liblasso_hip_bn254.so: same ABI over ark-bn254's Fr / G1)."""
+    path = path or os.path.join(HERE, "liblasso_hip_bn254.so" if curve == "bn254" else "liblasso_hip.so")
     if not os.path.exists(path):
         raise LassoError(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` (no CPU fallback exists)")
     lib = C.CDLL(path)
@@ -34,8 +35,8 @@ def _vp(a):
 class Device:
     """One lasso_ctx.  `lib` may be injected (tests inject the oracle's mock ABI); the default is the HIP library."""
 
-    def __init__(self, device=0, lib=None):
-        self.lib = lib or load_device_library()
+    def __init__(self, device=0, lib=None, curve="curve25519"):
+        self.lib = lib or load_device_library(curve=curve)
         ctx = C.c_void_p()
         rc = self.lib.lasso_ctx_create(device, C.byref(ctx))
         if rc != 0:

@@ -12,8 +12,9 @@ from .device import LassoError
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def load_prover_library(path=None):
-    path = path or os.path.join(HERE, "liblasso_prover.so")
+def load_prover_library(path=None, curve="curve25519"):
+    """curve = "bn254": the BN254 pair (liblasso_prover_bn254.so over liblasso_hip_bn254.so); both pairs can live in one process."""
+    path = path or os.path.join(HERE, "liblasso_prover_bn254.so" if curve == "bn254" else "liblasso_prover.so")
     if not os.path.exists(path):
         raise LassoError(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` (no CPU fallback exists)")
     return C.CDLL(path)
@@ -44,8 +45,8 @@ def declare_prover(lib):
 class HostProver:
     """One lasso_host (device context + host prover). `lib` defaults to the product library; tests may inject the mock-backed build."""
 
-    def __init__(self, lib=None, device=0):
-        self.lib = declare_prover(lib or load_prover_library())
+    def __init__(self, lib=None, device=0, curve="curve25519"):
+        self.lib = declare_prover(lib or load_prover_library(curve=curve))
         h = C.c_void_p()
         if self.lib.lasso_host_create(device, C.byref(h)) != 0:
             raise LassoError("lasso_host_create: " + self.lib.lasso_host_last_error().decode())

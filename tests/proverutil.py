@@ -23,7 +23,7 @@ def build_mock_prover(curve="curve25519"):
     srcs += [os.path.join(ROOT, "include", f) for f in ("lasso_hip.h", "lasso_prover.h")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         flags = ["-DLASSO_BN254", "-DORC_BN254"] if bn else []
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", *flags, "-o", so,
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-fno-gnu-unique", "-Wl,-Bsymbolic", *flags, "-o", so,   # see oracle/Makefile
                                os.path.join(ROOT, "lasso_amd", "host", "prover_capi.cpp"), os.path.join(ROOT, "oracle", "mock_hip.cpp")])
     return so
 
