@@ -41,6 +41,8 @@ def parse():
     p.add_argument("--log-m", type=int, default=16)
     p.add_argument("--log-r", type=int, default=40)
     p.add_argument("--cpu-log-s", type=int, default=22, help="log2 lookups of the bounded CPU-baseline sample (2^22: ~20 s of one host core)")
+    p.add_argument("--curve", default="curve25519", choices=["curve25519", "bn254"], help="the group G: curve25519 (the reference harness's, the headline metric) or BN254 G1 "
+                                                                                          "(BASELINE.json configs[1]; the liblasso_*_bn254.so pair)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-prof", action="store_true")
     p.add_argument("--concurrent", type=int, default=4, help="extra leg at N=1: this many independent proofs proved concurrently on the one GPU (own context, stream and host "
@@ -52,11 +54,12 @@ def parse():
     return p.parse_args()
 
 
-def cpu_baseline(kind_id, c, log_m, log_r, log_s):
+def cpu_baseline(kind_id, c, log_m, log_r, log_s, curve="curve25519"):
     """Oracle ("port") prover, serial, on this box's host cores; a bounded sample of the same workload shape."""
     import subprocess
-    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "liblasso_oracle.so"])
-    orc = C.CDLL(os.path.join(ROOT, "oracle", "liblasso_oracle.so"))
+    so = "liblasso_oracle_bn254.so" if curve == "bn254" else "liblasso_oracle.so"
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), so])
+    orc = C.CDLL(os.path.join(ROOT, "oracle", so))
     td, tc, tp = C.c_double(), C.c_double(), C.c_double()
     rc = orc.orc_bench(kind_id, C.c_size_t(c), C.c_size_t(1 << log_m), C.c_size_t(log_r), C.c_size_t(1 << log_s), C.byref(td), C.byref(tc), C.byref(tp), 0)
     if rc != 0:
@@ -76,7 +79,7 @@ def pmc_traffic():
         return {}
 
 
-def concurrent_leg(HostProver, _abi, streams, steps, S, c, log_m, log_s):
+def concurrent_leg(HostProver, _abi, streams, steps, S, c, log_m, log_s, curve="curve25519"):
     """T independent proofs at a time on one GPU.  One proof is latency-bound by its ~470 sequential transcript rounds (the device idles ~25% of the time
     at 2^24 lookups); independent proofs on their own streams fill the gaps.  Serving-style throughput, reported separately from the one-proof-at-a-time metric."""
     import threading
@@ -84,7 +87,7 @@ def concurrent_leg(HostProver, _abi, streams, steps, S, c, log_m, log_s):
     alpha = 2 * c if S.kind == _abi.KINDS["lt"] else c
     workers = []
     for t in range(streams):
-        hp = HostProver()
+        hp = HostProver(curve=curve)
         idx = (hp.gen_indices(s, 1 << log_m, c) + t) % (1 << log_m)
         r = hp.gen_random_point(log_s)
         gens = hp.gens(c, s, alpha, log_m); dense = hp.densify(idx, log_m)
@@ -116,12 +119,12 @@ def main():
     from lasso_amd.parallel import Group, shard_indices
     grp = Group(backend=a.backend)     # torch.distributed (nccl = RCCL) only when WORLD_SIZE > 1
     rank, world = grp.rank, grp.world
-    hp = HostProver(device=grp.device_index)
+    hp = HostProver(device=grp.device_index, curve=a.curve)
     slab = a.shard_proof and world > 1
     if slab:
         hp.set_comm(grp)             # slab mode: every polynomial split by low index bits, RCCL all_gather of per-round sums / row commitments
     lib = hp.lib
-    dev_lib = C.CDLL(os.path.join(ROOT, "lasso_amd", "liblasso_hip.so"))
+    dev_lib = C.CDLL(os.path.join(ROOT, "lasso_amd", "liblasso_hip_bn254.so" if a.curve == "bn254" else "liblasso_hip.so"))
     _abi.declare(dev_lib)
     ctx = hp.ctx()
 
@@ -185,8 +188,8 @@ def main():
         out = {"metric": "prover lookups/sec for SparsePolynomialEvaluationProof, 2^24 AND lookups" if (a.kind, a.log_s, c) == ("and", 24, 1) else f"prover lookups/sec for SparsePolynomialEvaluationProof, 2^{a.log_s} {a.kind.upper()} lookups",
                "value": value, "unit": "lookups/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
                "higher_is_better": True, "scaling": "strong" if slab else "weak",
-               "vs_baseline": (value / PUBLISHED_LOOKUPS_PER_S) if (a.kind, a.log_s, c) == ("and", 24, 1) else None, "dtype": "u256 (Montgomery Fr / ed25519 Fq integers)", "data": "synthetic",
-               "config": {"workload": f"{a.kind.upper()} subtable, C={c}, M=2^{log_m}, s=2^{a.log_s} lookups per proof, G=curve25519 (ark_curve25519), harness inputs of src/benches/bench.rs; "
+               "vs_baseline": (value / PUBLISHED_LOOKUPS_PER_S) if (a.kind, a.log_s, c, a.curve) == ("and", 24, 1, "curve25519") else None, "dtype": "u256 (Montgomery Fr / BN254 Fq integers)" if a.curve == "bn254" else "u256 (Montgomery Fr / ed25519 Fq integers)", "data": "synthetic",
+               "config": {"workload": f"{a.kind.upper()} subtable, C={c}, M=2^{log_m}, s=2^{a.log_s} lookups per proof, G={'BN254 G1 (ark_bn254)' if a.curve == 'bn254' else 'curve25519 (ark_curve25519)'}, harness inputs of src/benches/bench.rs; "
                                       f"timed = SparsePolynomialEvaluationProof::prove with the densified representation resident in HBM",
                           "vs_baseline_reference": "2^24 AND lookups, C=1, SparsePoly.prove 35.3 s with rayon on an Apple M1 16 GB (reference's src/benches/m1_16gb_parallel_benches.log:439; BASELINE.md §1)",
                           "per_rank": ("one proof sharded over the ranks by low index bits (slab mode)" if slab else "one independent proof per rank") if world > 1 else "single proof",
@@ -216,9 +219,9 @@ def main():
                 out["roofline"] = roof(_abi.KERNEL_NAMES.index(dom["kernel"]))
             out["roofline_bind_top"] = roof(_abi.K_BIND)                                        # the kernel BASELINE.json's north_star names (bound_poly_var)
         if world == 1 and a.concurrent > 1 and a.concurrent * s * alpha * 450 < 150e9:   # ~400 bytes of HBM per lookup and memory per resident proof
-            out["concurrent_proofs"] = concurrent_leg(HostProver, _abi, a.concurrent, max(2, a.steps), S, c, log_m, a.log_s)
+            out["concurrent_proofs"] = concurrent_leg(HostProver, _abi, a.concurrent, max(2, a.steps), S, c, log_m, a.log_s, a.curve)
         if world == 1 and not a.no_cpu_baseline:
-            cb = cpu_baseline(kind_id, c, log_m, S.log_r, min(a.cpu_log_s, a.log_s))
+            cb = cpu_baseline(kind_id, c, log_m, S.log_r, min(a.cpu_log_s, a.log_s), a.curve)
             if cb:
                 out["cpu_baseline"] = cb
         print(json.dumps(out))

@@ -52,8 +52,6 @@ def oracle_bn254():
 
 @pytest.fixture(scope="session")
 def oracle():
-    lib = ctypes.CDLL(_build_oracle())
-    lib.orc_kat_names.restype = ctypes.c_char_p
-    lib.orc_last_error.restype = ctypes.c_char_p
-    lib.orc_session_new.restype = ctypes.c_void_p
-    return lib
+    if os.environ.get("LASSO_TEST_CURVE") == "bn254":   # the GPU kernel parity tests re-run on the BN254 build (tests/fieldref.py)
+        return _load_oracle(_build_oracle_bn254())
+    return _load_oracle(_build_oracle())

@@ -1,7 +1,12 @@
 """Python big-integer ground truth for the two prime fields and the Edwards curve (test helper)."""
 import random
 
-L = 2**252 + 27742317777372353535851937790883648493  # Fr: curve25519 scalar field
+import os
+
+# LASSO_TEST_CURVE=bn254 re-runs the GPU kernel parity tests (tests/test_gpu_kernels.py) on the BN254 build: Fr becomes the order of ark-bn254's G1
+CURVE = os.environ.get("LASSO_TEST_CURVE", "curve25519")
+L = (21888242871839275222246405745257275088548364400416034343698204186575808495617 if CURVE == "bn254"
+     else 2**252 + 27742317777372353535851937790883648493)  # Fr: curve25519 scalar field
 Q = 2**255 - 19                                       # Fq: curve25519 base field
 R = 2**256
 D = (-121665 * pow(121666, -1, Q)) % Q

@@ -5,17 +5,18 @@ import subprocess
 
 import numpy as np
 
-from fieldref import L as FR_P, limbs, to_mont
+from fieldref import CURVE, L as FR_P, limbs, to_mont
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def load_mock():
     from lasso_amd import _abi
-    so = os.path.join(ROOT, "oracle", "libmock_hip.so")
-    srcs = [os.path.join(ROOT, "oracle", f) for f in ("mock_hip.cpp", "lasso_oracle.hpp", "ff.hpp", "ed25519.hpp", "hashes.hpp")] + [os.path.join(ROOT, "include", "lasso_hip.h")]
+    name = "libmock_hip_bn254.so" if CURVE == "bn254" else "libmock_hip.so"
+    so = os.path.join(ROOT, "oracle", name)
+    srcs = [os.path.join(ROOT, "oracle", f) for f in ("mock_hip.cpp", "lasso_oracle.hpp", "ff.hpp", "ed25519.hpp", "bn254.hpp", "hashes.hpp")] + [os.path.join(ROOT, "include", "lasso_hip.h")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
-        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "libmock_hip.so"])
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), name])
     lib = ctypes.CDLL(so)
     _abi.declare(lib)
     lib.mock_point_compress.argtypes = [ctypes.c_void_p, ctypes.c_void_p]

@@ -15,7 +15,8 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def devs():
     from lasso_amd import Device
-    real = Device(0)                  # raises loudly if the HIP library / GPU is missing
+    from fieldref import CURVE
+    real = Device(0, curve=CURVE)     # raises loudly if the HIP library / GPU is missing (LASSO_TEST_CURVE=bn254: the BN254 build, tools/gpu_bn254.sh)
     mock = Device(0, lib=load_mock())
     yield real, mock
     real.close(); mock.close()
