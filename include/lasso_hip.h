@@ -15,6 +15,13 @@
  *  - lasso_point  = ark-ec `twisted_edwards::Projective<EdwardsConfig>` {x, y, t, z}, Montgomery form; any
  *                   valid projective representative is returned (the transcript only ever sees the
  *                   compressed affine form, src/utils/transcript.rs:47-51).
+ *  - The BN254 build of the library (liblasso_hip_bn254.so, the same source compiled with -DLASSO_BN254; BASELINE.json configs[1] names
+ *    G = BN254) exports the SAME entry points with the same layouts over ark-bn254: lasso_fr = `ark_bn254::Fr` (a*2^256 mod r, r the
+ *    254-bit order of G1), lasso_affine = `short_weierstrass::Affine<g1::Config>` {x, y} in Montgomery form (the host never passes the
+ *    point at infinity: generators are not), lasso_point = a HOMOGENEOUS projective representative {x, y, t, z} = (X : Y : Z) with t unused
+ *    (zero) and the identity (0 : 1 : 0) — ark's `Projective` for this model is Jacobian, so the binding reconstructs a `G1Projective` from
+ *    the affine point (x/z, y/z) or, as the prover does, only ever serialises it.  Compressed rows use ark-ec's SWFlags encoding.
+ *    A process may load both libraries (dlopen RTLD_LOCAL); a context belongs to the library that created it.
  *  - `d_` parameters are DEVICE pointers obtained from lasso_alloc (or any hipMalloc'd memory on the
  *    context's device, e.g. a torch tensor's data_ptr); all other pointers are HOST memory owned by the
  *    caller for the duration of the call only.
