@@ -98,6 +98,42 @@ LHD pt29 pt_dbl(const pt29& p) {
   r.T = fe_zero();
   return r;
 }
+// ---- the full addition split over SIX lanes (msm_coop_tree): its twelve products form two dependent layers of six, so lane role c of a
+// sextet computes product c of each layer and a tree level costs two product times instead of twelve.  Roles are selected by data (coordinate
+// indices, 0/1 masks, per-limb selects), never by branch: the six lanes share a wave.
+//   layer 1: m0 = X1X2, m1 = Y1Y2, m2 = Z1Z2, m3 = (X1+Y1)(X2+Y2), m4 = (Y1+Z1)(Y2+Z2), m5 = (X1+Z1)(X2+Z2)
+//   layer 2: p0 = t3 t1, p1 = t4 y3, p2 = t1 z3, p3 = y3 t0, p4 = z3 t4, p5 = t0 t3   (names as in pt_finish)
+//   output:  X3 = p0 - p1, Y3 = p2 + p3, Z3 = p4 + p5
+LHD fe29 pt_coop_layer1(const pt29& p, const pt29& q, uint32_t c) {
+  const fe29* pc = reinterpret_cast<const fe29*>(&p);   // {X, Y, T, Z} = coordinates 0, 1, 2, 3
+  const fe29* qc = reinterpret_cast<const fe29*>(&q);
+  const uint32_t i0 = c == 0 ? 0u : (c == 1 ? 1u : (c == 2 ? 3u : (c == 3 ? 0u : (c == 4 ? 1u : 0u))));
+  const uint32_t i1 = c == 3 ? 1u : 3u;                  // second summand (roles 3..5): Y, Z, Z
+  const int32_t m = c >= 3 ? 1 : 0;
+  const fe29 p0 = pc[i0], p1 = pc[i1], q0 = qc[i0], q1 = qc[i1];
+  fe29 a, b;
+#pragma unroll
+  for (int k = 0; k < 9; k++) { a.v[k] = p0.v[k] + m * p1.v[k]; b.v[k] = q0.v[k] + m * q1.v[k]; }
+  return fe_mul(a, fe_weak(b));
+}
+LHD fe29 pt_coop_layer2(const fe29* m, uint32_t c) {   // m[0..5] = the six layer-1 products
+  const fe29 t3 = fe_sub(fe_sub(m[3], m[0]), m[1]), t4 = fe_sub(fe_sub(m[4], m[1]), m[2]), y3 = fe_small(fe_sub(fe_sub(m[5], m[0]), m[2]), 9);
+  const fe29 t0 = fe_x3(m[0]), t29 = fe_small(m[2], 9), t1 = fe_sub(m[1], t29), z3 = fe_add(m[1], t29);
+  fe29 u, w;   // u loose, w weakened below
+#pragma unroll
+  for (int k = 0; k < 9; k++) {
+    u.v[k] = c == 0 ? t3.v[k] : (c == 1 ? t4.v[k] : (c == 2 ? t1.v[k] : (c == 3 ? y3.v[k] : (c == 4 ? z3.v[k] : t0.v[k]))));
+    w.v[k] = c == 0 ? t1.v[k] : (c == 1 ? y3.v[k] : (c == 2 ? z3.v[k] : (c == 3 ? t0.v[k] : (c == 4 ? t4.v[k] : t3.v[k]))));
+  }
+  return fe_mul(u, fe_weak(w));
+}
+LHD fe29 pt_coop_out(const fe29& pe, const fe29& po, uint32_t j) {   // coordinate j (0: X, 1: Y, 2: Z) from the products 2j and 2j + 1
+  fe29 r;
+  const int32_t sg = j == 0 ? -1 : 1;
+#pragma unroll
+  for (int k = 0; k < 9; k++) r.v[k] = pe.v[k] + sg * po.v[k];
+  return fe_weak(r);
+}
 LHD niels29 niels_from_xy29(const fe29& x, const fe29& y, const fe29&) {   // x, y reduced (canonicalised here so that table entries are digits)
   niels29 n; n.x = m29_canonical(x); n.y = m29_canonical(y);
 #pragma unroll

@@ -242,19 +242,33 @@ __device__ __forceinline__ uint32_t msm_phys_col(const MsmColMap& m, uint32_t ro
 // exchange buffer, so a level costs three product times instead of nine.  Role selection is by data (sign / coordinate index), never by branch.
 // pts[0..live) -> pts[0].  st: exchange buffer for 64 additions.  All MSM_THREADS threads must call.
 #ifdef LASSO_BN254
-// BN254 build: the complete projective addition has twelve products in three dependent layers that do not split evenly over four lanes; the tree
-// is the plain one (one lane per addition) until a cooperative schedule for it has been measured.  Same interface.
-__device__ __forceinline__ void msm_coop_tree(pt29* pts, fe29 (*)[4], uint32_t live, const fe29& d2) {
-  const uint32_t t = threadIdx.x;
+// BN254 build: the complete projective addition's twelve products form two dependent layers of six (bn254_fe29.cuh pt_coop_*), so SIX lanes share
+// one addition: 42 additions per pass of the workgroup, a tree level costs two product times (plus the linear step) instead of twelve.  The exchange
+// buffer is the Edwards build's (64 x 4 values >= 42 x 6), used twice per pass.  Same interface.
+__device__ __forceinline__ void msm_coop_tree(pt29* pts, fe29 (*st4)[4], uint32_t live, const fe29&) {
+  fe29* st = &st4[0][0];
+  const uint32_t t = threadIdx.x, g = t / 6u, c = t - g * 6u;
+  constexpr uint32_t GROUPS = MSM_THREADS / 6;   // 42
+  const bool lane_ok = g < GROUPS;
   uint32_t p2 = 1; while (p2 < live) p2 <<= 1;
   for (uint32_t s = p2 >> 1; s > 0; s >>= 1) {
-    for (uint32_t i0 = 0; i0 < s; i0 += MSM_THREADS) {
-      const uint32_t i = i0 + t;
-      const bool act = i < s && i + s < live;
-      pt29 sum;
-      if (act) sum = pt_add(pts[i], pts[i + s], d2);
+    for (uint32_t i0 = 0; i0 < s; i0 += GROUPS) {
+      const uint32_t i = i0 + g;
+      const bool act = lane_ok && i < s && i + s < live;
+      if (act) st[g * 6 + c] = pt_coop_layer1(pts[i], pts[i + s], c);
       __syncthreads();
-      if (act) pts[i] = sum;
+      fe29 m[6];
+      if (act) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) m[k] = st[g * 6 + k];
+      }
+      __syncthreads();
+      if (act) st[g * 6 + c] = pt_coop_layer2(m, c);
+      __syncthreads();
+      if (act && c < 3) {
+        const fe29 v = pt_coop_out(st[g * 6 + 2 * c], st[g * 6 + 2 * c + 1], c);
+        reinterpret_cast<fe29*>(&pts[i])[c == 2 ? 3 : c] = v;   // pt29 = {X, Y, T, Z}
+      }
       __syncthreads();
     }
   }

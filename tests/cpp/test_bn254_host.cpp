@@ -5,6 +5,7 @@
 #include "../../oracle/lasso_oracle.hpp"
 #include <random>
 #include <cstdio>
+#include <array>
 using namespace orc;
 
 static std::mt19937_64 rng(777);
@@ -75,6 +76,17 @@ int main() {
     CHECK(from_ed(pt_to_ed(pp)) == p);
     CHECK(from_ed(pt_to_ed(pt_add(pp, pq, dummy))) == p + q); CHECK(from_ed(pt_to_ed(pt_add(pp, pp, dummy))) == p.dbl()); CHECK(from_ed(pt_to_ed(pt_dbl(pp))) == p.dbl());
     CHECK(from_ed(pt_to_abi(pt_add(pp, pt_identity(), dummy))) == p); CHECK(from_ed(pt_to_abi(pt_add(pt_identity(), pt_identity(), dummy))).is_identity());
+    {   // the six-lane split of the full addition (msm_coop_tree), lanes emulated in a loop
+      fe29 m[6], pr[6];
+      for (uint32_t c = 0; c < 6; c++) m[c] = pt_coop_layer1(pp, pq, c);
+      for (uint32_t c = 0; c < 6; c++) pr[c] = pt_coop_layer2(m, c);
+      pt29 r; r.X = pt_coop_out(pr[0], pr[1], 0); r.Y = pt_coop_out(pr[2], pr[3], 1); r.Z = pt_coop_out(pr[4], pr[5], 2); r.T = fe_zero();
+      CHECK(from_ed(pt_to_ed(r)) == p + q);
+      for (uint32_t c = 0; c < 6; c++) m[c] = pt_coop_layer1(pp, pp, c);
+      for (uint32_t c = 0; c < 6; c++) pr[c] = pt_coop_layer2(m, c);
+      r.X = pt_coop_out(pr[0], pr[1], 0); r.Y = pt_coop_out(pr[2], pr[3], 1); r.Z = pt_coop_out(pr[4], pr[5], 2);
+      CHECK(from_ed(pt_to_ed(r)) == p.dbl());
+    }
     if (!q.is_identity()) {
       const niels29 n = to_niels(q);
       CHECK(from_ed(pt_to_ed(pt_madd(pp, n))) == p + q);
@@ -93,13 +105,38 @@ int main() {
       const int op = (int)(rng() % 4);
       if (op == 0) { acc = pt_madd(acc, to_niels(q)); ref = ref + q; }
       else if (op == 1) { acc = pt_madd(acc, niels_cond_neg(to_niels(q), true)); ref = ref - q; }
-      else if (op == 2) { acc = pt_add(acc, pt_from_ed(to_ed(q, rand_fq())), dummy); ref = ref + q; }
+      else if (op == 2 && (i & 1)) { acc = pt_add(acc, pt_from_ed(to_ed(q, rand_fq())), dummy); ref = ref + q; }
+      else if (op == 2) {
+        const pt29 pq2 = pt_from_ed(to_ed(q, rand_fq())); fe29 m[6], pr[6];
+        for (uint32_t c = 0; c < 6; c++) m[c] = pt_coop_layer1(acc, pq2, c);
+        for (uint32_t c = 0; c < 6; c++) pr[c] = pt_coop_layer2(m, c);
+        acc.X = pt_coop_out(pr[0], pr[1], 0); acc.Y = pt_coop_out(pr[2], pr[3], 1); acc.Z = pt_coop_out(pr[4], pr[5], 2); ref = ref + q;
+      }
       else { acc = pt_dbl(acc); ref = ref.dbl(); }
       for (int k = 0; k < 8; k++) { CHECK(acc.X.v[k] >= 0 && acc.X.v[k] < (1 << 29)); CHECK(acc.Z.v[k] >= 0 && acc.Z.v[k] < (1 << 29)); }
       CHECK(acc.X.v[8] > -(1 << 26) && acc.X.v[8] < (1 << 26) && acc.Y.v[8] > -(1 << 26) && acc.Y.v[8] < (1 << 26) && acc.Z.v[8] > -(1 << 26) && acc.Z.v[8] < (1 << 26));
       if (i % 50 == 49) CHECK(from_ed(pt_to_ed(acc)) == ref);
     }
     uint8_t want[32]; ref.compress(want); uint32_t got[8]; pt_compress(acc, got); CHECK(memcmp(want, got, 32) == 0);
+  }
+  // the cooperative tree's schedule (msm_kernels.cuh msm_coop_tree, BN254 build), lanes and barriers emulated: 256 threads in groups of six, 42
+  // additions per pass, one exchange buffer used twice per pass; pts[0..live) -> pts[0]
+  for (uint32_t live : {1u, 2u, 3u, 5u, 42u, 43u, 85u, 100u, 255u, 256u}) {
+    const uint32_t NT = 256, GROUPS = NT / 6;
+    std::vector<pt29> v(NT); std::vector<fe29> st(NT); Point ref = Point::identity();
+    for (uint32_t i = 0; i < NT; i++) { const Point& q = pts[rng() % pts.size()]; v[i] = pt_from_ed(to_ed(q, rand_fq())); if (i < live) ref = ref + q; }
+    uint32_t p2 = 1; while (p2 < live) p2 <<= 1;
+    for (uint32_t sft = p2 >> 1; sft > 0; sft >>= 1) {
+      for (uint32_t i0 = 0; i0 < sft; i0 += GROUPS) {
+        std::vector<std::array<fe29, 6>> regs(NT);
+        auto act = [&](uint32_t t) { const uint32_t g = t / 6, i = i0 + g; return g < GROUPS && i < sft && i + sft < live; };
+        for (uint32_t t = 0; t < NT; t++) if (act(t)) { const uint32_t g = t / 6, c = t - g * 6, i = i0 + g; st[g * 6 + c] = pt_coop_layer1(v[i], v[i + sft], c); }
+        for (uint32_t t = 0; t < NT; t++) if (act(t)) { const uint32_t g = t / 6; for (int k = 0; k < 6; k++) regs[t][k] = st[g * 6 + k]; }
+        for (uint32_t t = 0; t < NT; t++) if (act(t)) { const uint32_t g = t / 6, c = t - g * 6; st[g * 6 + c] = pt_coop_layer2(regs[t].data(), c); }
+        for (uint32_t t = 0; t < NT; t++) if (act(t)) { const uint32_t g = t / 6, c = t - g * 6, i = i0 + g; if (c < 3) reinterpret_cast<fe29*>(&v[i])[c == 2 ? 3 : c] = pt_coop_out(st[g * 6 + 2 * c], st[g * 6 + 2 * c + 1], c); }
+      }
+    }
+    CHECK(from_ed(pt_to_ed(v[0])) == ref);
   }
   printf("OK\n");
   return 0;

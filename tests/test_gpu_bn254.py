@@ -71,3 +71,17 @@ def test_gpu_bn254_baseline_config1_full_size(host, oracle_bn254):
     assert o.orc_verify_only(_abi.KINDS[kind], c, 1 << log_m, log_r, s, rr.ctypes.data_as(C.c_void_p), proof, len(proof), comm, len(comm)) == 1, o.orc_last_error()
     bad = bytearray(proof); bad[len(bad) // 2] ^= 0x04
     assert o.orc_verify_only(_abi.KINDS[kind], c, 1 << log_m, log_r, s, rr.ctypes.data_as(C.c_void_p), bytes(bad), len(bad), comm, len(comm)) != 1
+
+
+def test_gpu_bn254_kernel_parity_suite():
+    """Every entry point of the BN254 library against the BN254 mock: tests/test_gpu_kernels.py re-run in a child process with LASSO_TEST_CURVE=bn254
+    (the switch is read at import time by tests/fieldref.py, so it cannot share this process)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LASSO_TEST_CURVE="bn254")
+    res = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_kernels.py"), "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider"],
+                         cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
+    assert " passed" in res.stdout and "failed" not in res.stdout
