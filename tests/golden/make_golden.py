@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Generates tests/golden/proofs.json: commitment and proof bytes (hex SHA-256 + lengths + the first 64 proof bytes) of the ORACLE prover for fixed,
+"""Generates tests/golden/proofs.json (G = curve25519) and proofs_bn254.json (G = BN254 G1, the oracle built with -DORC_BN254): commitment and proof bytes (hex SHA-256 + lengths + the first 64 proof bytes) of the ORACLE prover for fixed,
 seeded instances.  The reference is a Rust crate that cannot be built in this image and holds no golden vector for any commitment or proof byte
 (SURVEY.md §8c), so these fixtures pin the oracle against its own drift, not against the Rust binary ("parity unpinned").
 Regenerate with:  python tests/golden/make_golden.py   (needs only the CPU oracle)."""
@@ -38,7 +38,11 @@ def instance(orc, kind, c, log_m, lookups, seed):
 def main():
     import conftest
     from proverutil import OracleSession
-    orc = C.CDLL(conftest._build_oracle())
+    for build, name in ((conftest._build_oracle, "proofs.json"), (conftest._build_oracle_bn254, "proofs_bn254.json")):   # G = curve25519, G = BN254 G1
+        make(OracleSession, C.CDLL(build()), name)
+
+
+def make(OracleSession, orc, name):
     orc.orc_last_error.restype = C.c_char_p; orc.orc_session_new.restype = C.c_void_p
     out = []
     for kind, c, log_m, log_r, lookups, seed in INSTANCES:
@@ -50,9 +54,9 @@ def main():
         out.append({"kind": kind, "c": c, "log_m": log_m, "log_r": log_r, "lookups": lookups, "seed": seed,
                     "commitment_len": len(comm), "commitment_sha256": hashlib.sha256(comm).hexdigest(),
                     "proof_len": len(proof), "proof_sha256": hashlib.sha256(proof).hexdigest(), "proof_head": proof[:64].hex()})
-    with open(os.path.join(HERE, "proofs.json"), "w") as f:
+    with open(os.path.join(HERE, name), "w") as f:
         json.dump(out, f, indent=1)
-    print(f"wrote {len(out)} instances")
+    print(f"{name}: wrote {len(out)} instances")
 
 
 if __name__ == "__main__":

@@ -66,3 +66,39 @@ def test_hip_path_reproduces_golden(oracle, g):
         _check(g, *_prove(hp, oracle, g))
     finally:
         hp.close()
+
+
+# ---- the same three-way pin for the BN254 build (tests/golden/proofs_bn254.json: oracle -DORC_BN254, host prover + mock -DLASSO_BN254, liblasso_*_bn254.so)
+with open(os.path.join(HERE, "golden", "proofs_bn254.json")) as f:
+    GOLDEN_BN254 = json.load(f)
+IDS_BN254 = [f'bn254-{g["kind"]}-C{g["c"]}-m{g["log_m"]}-n{g["lookups"]}' for g in GOLDEN_BN254]
+
+
+@pytest.mark.parametrize("g", GOLDEN_BN254, ids=IDS_BN254)
+def test_bn254_oracle_reproduces_golden(oracle_bn254, g):
+    idx, r = instance(oracle_bn254, g["kind"], g["c"], g["log_m"], g["lookups"], g["seed"])
+    o = OracleSession(oracle_bn254, KINDS[g["kind"]], g["c"], g["log_m"], g["log_r"], idx, r)
+    try:
+        _check(g, o.commit(), o.prove())
+    finally:
+        o.close()
+
+
+@pytest.mark.parametrize("g", GOLDEN_BN254, ids=IDS_BN254)
+def test_bn254_host_prover_over_mock_reproduces_golden(oracle_bn254, g):
+    hp = HostProver(C.CDLL(build_mock_prover("bn254")))
+    try:
+        _check(g, *_prove(hp, oracle_bn254, g))
+    finally:
+        hp.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("g", GOLDEN_BN254, ids=IDS_BN254)
+def test_bn254_hip_path_reproduces_golden(oracle_bn254, g):
+    from lasso_amd import HostProver as HipProver
+    hp = HipProver(curve="bn254")
+    try:
+        _check(g, *_prove(hp, oracle_bn254, g))
+    finally:
+        hp.close()
