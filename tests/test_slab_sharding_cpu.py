@@ -15,14 +15,17 @@ from proverutil import HostProver, OracleSession, build_mock_prover
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def build_slab_lib():
+def build_slab_lib(curve="curve25519"):
     out_dir = os.path.join(ROOT, "tests", "_build")
     os.makedirs(out_dir, exist_ok=True)
-    so = os.path.join(out_dir, "libslab_threads.so")
+    bn = curve == "bn254"
+    so = os.path.join(out_dir, "libslab_threads_bn254.so" if bn else "libslab_threads.so")
     srcs = [os.path.join(ROOT, "tests", "cpp", "slab_threads.cpp"), os.path.join(ROOT, "lasso_amd", "host", "prover_capi.cpp"), os.path.join(ROOT, "oracle", "mock_hip.cpp")]
     deps = srcs + [os.path.join(ROOT, "lasso_amd", "host", f) for f in ("prover.hpp", "field_host.hpp", "hashes.hpp")] + [os.path.join(ROOT, "oracle", "lasso_oracle.hpp")]
+    deps += [os.path.join(ROOT, "lasso_amd", "csrc", f) for f in ("bn254_fr.cuh", "bn254_fq.cuh")] + [os.path.join(ROOT, "oracle", "bn254.hpp")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in deps):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wno-unknown-pragmas", "-o", so] + srcs)
+        flags = ["-DLASSO_BN254", "-DORC_BN254"] if bn else []
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wno-unknown-pragmas", "-fno-gnu-unique", "-Wl,-Bsymbolic", *flags, "-o", so] + srcs)   # see oracle/Makefile
     return C.CDLL(so)
 
 
@@ -34,6 +37,18 @@ def slab():
 @pytest.fixture(scope="module")
 def host():
     hp = HostProver(C.CDLL(build_mock_prover()))
+    yield hp
+    hp.close()
+
+
+@pytest.fixture(scope="module")
+def slab_bn254():
+    return build_slab_lib("bn254")
+
+
+@pytest.fixture(scope="module")
+def host_bn254():
+    hp = HostProver(C.CDLL(build_mock_prover("bn254")))
     yield hp
     hp.close()
 
@@ -54,6 +69,17 @@ CASES = [("and", 1, 4, 0, 64), ("and", 2, 4, 0, 32), ("xor", 3, 4, 0, 50), ("or"
 @pytest.mark.parametrize("world", [2, 4, 8])
 @pytest.mark.parametrize("kind,c,log_m,log_r,lookups", CASES)
 def test_slab_proof_equals_single_rank_and_oracle(slab, host, oracle, world, kind, c, log_m, log_r, lookups):
+    _slab_case(slab, host, oracle, world, kind, c, log_m, log_r, lookups)
+
+
+@pytest.mark.parametrize("world", [2, 8])
+@pytest.mark.parametrize("kind,c,log_m,log_r,lookups", [CASES[0], CASES[2], CASES[4], CASES[6]])
+def test_slab_proof_bn254(slab_bn254, host_bn254, oracle_bn254, world, kind, c, log_m, log_r, lookups):
+    """The same over G = BN254 (partial row commitments of the ranks are added with the complete projective addition; all-zero slabs are the identity (0 : 1 : 0))."""
+    _slab_case(slab_bn254, host_bn254, oracle_bn254, world, kind, c, log_m, log_r, lookups)
+
+
+def _slab_case(slab, host, oracle, world, kind, c, log_m, log_r, lookups):
     s = 1 << (lookups - 1).bit_length()
     nv_m = (c - 1).bit_length() + log_m
     if s < 2 * world or (1 << log_m) < 2 * world or (1 << (nv_m - nv_m // 2)) < world:
