@@ -707,7 +707,10 @@ static size_t msm_chunks(size_t rows, size_t n_cols, uint32_t W) {
 static bool msm_direct_enabled() { static const bool on = [] { const char* v = getenv("LASSO_MSM_DIRECT"); return !(v && v[0] == '0'); }(); return on; }
 static size_t msm_direct_chunks(size_t rows, size_t n_cols, uint32_t* items_per_chunk) {
   const size_t total = n_cols * MSM_WINDOWS;
-  size_t K = 256 / rows; if (K < 1) K = 1;
+  // workgroups per launch: one per CU by default.  LASSO_MSM_DIRECT_WGS overrides it for tuning (more workgroups = shorter per-thread addition chains,
+  // a larger cross-workgroup tree): the BN254 build's additions cost ~2.5x the Edwards ones and its balance point has not been measured yet
+  static const size_t wgs = [] { const char* v = getenv("LASSO_MSM_DIRECT_WGS"); const long x = v ? atol(v) : 0; return (size_t)(x >= 1 && x <= 4096 ? x : 256); }();
+  size_t K = wgs / rows; if (K < 1) K = 1;
   size_t ipc = ((total + K - 1) / K + 255) / 256 * 256;
   if (ipc > 8192) ipc = 8192;
   *items_per_chunk = (uint32_t)ipc;
