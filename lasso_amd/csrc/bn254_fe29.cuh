@@ -41,7 +41,12 @@ LHD fe29 fe_inv_chain(const fe29& z) {
 }
 
 // ------------------------------------------------------------------ conversions (fq_t = ark's Montgomery words x * 2^256, canonical)
-LHD fe29 fe_from_fq(const fq_t& x) { return m29_unpack_words_shl5<Bn254FqM>(x.v); }
+// fq_t words (x 2^256, canonical) -> x 2^261 mod q with reduced MAGNITUDE: one product with 2^266 (the bare shift-by-5 form would be up to 32 q,
+// outside what m29_canonical accepts and larger than the group law's bounds assume)
+LHD fe29 fe_from_fq(const fq_t& x) {
+  const int32_t K5[9] = {322215073, 442336424, 171859116, 268585440, 314135016, 244503300, 348886451, 68918589, 360451};   // 2^266 mod q
+  return fe_mul(m29_unpack_words<Bn254FqM>(x.v), m29_const<Bn254FqM>(K5));
+}
 LHD fq_t fe_to_fq(const fe29& a) {   // any reduced / loose a
   fe29 c256 = fe_zero(); c256.v[8] = 1 << 24;   // the integer 2^256: (x 2^261) 2^256 / 2^261 = x 2^256
   fq_t r; m29_pack_words(m29_canonical(fe_mul(a, c256)), r.v); return r;

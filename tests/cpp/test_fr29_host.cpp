@@ -79,9 +79,10 @@ int main() {
   for (size_t i = 0; i < N; i++) {
     const fr_t &a = xs[i], &b = xs[(i * 7 + 3) % N], &c = xs[(i * 11 + 5) % N];
     const fr29 au = fr29_unpack_u(a), bu = fr29_unpack_u(b), cu = fr29_unpack_u(c);
+    // eight-element sums: two four-element halves, each carried once so that every limb stays below 2^31 (the contract of the reductions)
+    const fr29 h1 = fr29_weak(fr29_add(fr29_add(au, bu), fr29_add(cu, au))), h2 = fr29_weak(fr29_add(fr29_add(bu, bu), fr29_add(cu, cu)));
     const fr29 cases[6] = {au, fr29_add(au, bu), fr29_sub(au, bu), fr29_sub(fr29_sub(fr29_zero(), au), fr29_add(bu, cu)),
-                           fr29_add(fr29_add(fr29_add(au, bu), fr29_add(cu, au)), fr29_add(fr29_add(bu, bu), fr29_add(cu, cu))),
-                           fr29_sub(fr29_zero(), fr29_add(fr29_add(fr29_add(au, bu), fr29_add(cu, au)), fr29_add(fr29_add(bu, bu), fr29_add(cu, cu))))};
+                           fr29_add(h1, h2), fr29_sub(fr29_zero(), fr29_add(h1, h2))};
     for (const fr29& x : cases) {
       const fr29 sm = fr29_semi(x);
       for (int k = 0; k < 8; k++) CHECK(sm.v[k] >= 0 && sm.v[k] < (1 << 29));

@@ -36,3 +36,19 @@ def test_cpp_arith_bn254(name, flags):
     res = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     assert "OK" in res.stdout
+
+
+@pytest.mark.parametrize("name,flags", [("test_fr29_host", []), ("test_fe29_host", []), ("test_fr29_host", ["-DLASSO_BN254"]), ("test_bn254_host", ["-DLASSO_BN254", "-DORC_BN254"])],
+                         ids=["fr29", "fe29", "fr29-bn254", "curve-bn254"])
+def test_limb_bounds_hold_under_ubsan(name, flags):
+    """The 29-bit-limb forms rely on magnitudes never leaving their 32- / 64-bit containers (no carries between partial products).  The same tests
+    built with -fsanitize=undefined turn any signed overflow on the way — in a product column, a lazy sum, a quotient estimate — into a failure, for both
+    curve builds (it found the BN254 table conversion feeding a 2^259 value to a reduction that accepts 2^258)."""
+    src = os.path.join(ROOT, "tests", "cpp", name + ".cpp")
+    out_dir = os.path.join(ROOT, "tests", "_build")
+    os.makedirs(out_dir, exist_ok=True)
+    exe = os.path.join(out_dir, name + "_ubsan" + ("_bn254" if flags else ""))
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wno-unknown-pragmas", "-fsanitize=undefined", "-fno-sanitize-recover=undefined", *flags, "-o", exe, src])
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0 and "runtime error" not in res.stderr, res.stdout[-1000:] + res.stderr[-3000:]
+    assert "OK" in res.stdout
