@@ -1,5 +1,5 @@
 """Open-ended differential fuzz of the host prover over the mock against the oracle prover (test infrastructure; tests/test_fuzz_host_cpu.py is the bounded,
-seeded version).  usage: python tools/fuzz_host.py [curve25519|bn254] [seed] [seconds]"""
+seeded version).  usage: python tools/fuzz_host.py [curve25519|bn254] [seed] [seconds] [hip]"""
 import ctypes as C, sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
@@ -10,7 +10,11 @@ curve = sys.argv[1] if len(sys.argv) > 1 else "curve25519"
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 budget = float(sys.argv[3]) if len(sys.argv) > 3 else 120
 orc = conftest._load_oracle(conftest._build_oracle_bn254() if curve == "bn254" else conftest._build_oracle())
-hp = HostProver(C.CDLL(build_mock_prover(curve)))
+if "hip" in sys.argv:      # the product library on a GPU box instead of the mock: python tools/fuzz_host.py curve25519 1 60 hip
+    from lasso_amd import HostProver as HipProver
+    hp = HipProver(curve=curve)
+else:
+    hp = HostProver(C.CDLL(build_mock_prover(curve)))
 rng = np.random.default_rng(seed0)
 t0 = time.time(); n = 0
 while time.time() - t0 < budget:
