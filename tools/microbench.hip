@@ -205,6 +205,32 @@ int main(int argc, char** argv) {
     }
     CK(hipFree(z)); CK(hipFree(dst));
   }
+  // SURVEY.md 8(d)'s kernel-level sweep as written: bind_top on p polynomials of n in {2^20, 2^24, 2^26, 2^28} field elements (p = 1 and the batched
+  // alpha + 1 in {2, 5, 9, 17}), 3 warm-ups and 20 timed launches on buffers that are not bound in place repeatedly (a bind halves the live length, so every
+  // launch binds the SAME full-length arrays: the upper halves are only read, the lower halves are rewritten — the traffic of a first bind every time).
+  // Skipped when p * n * 32 bytes exceeds 160 GiB.
+  printf("\n== 4. bind_top sweep (SURVEY 8d): algorithmic bytes 48 n p; 3 warm-ups + 20 timed launches\n");
+  for (int logn : {20, 24, 26, 28}) {
+    const size_t n = (size_t)1 << logn, half = n / 2;
+    for (int p : {1, 2, 5, 9, 17}) {
+      if ((double)p * n * 32.0 > 160.0 * 1073741824.0) { printf("  n=2^%d p=%2d: skipped (%.0f GiB)\n", logn, p, p * n * 32.0 / 1073741824.0); continue; }
+      MutPtrTable T; bool ok = true;
+      for (int k = 0; k < p; k++) { fr_t* z = nullptr; if (hipMalloc(&z, n * sizeof(fr_t)) != hipSuccess) { ok = false; T.p[k] = nullptr; break; } CK(hipMemset(z, 0x11 + k, n * sizeof(fr_t))); T.p[k] = z; }
+      if (ok) {
+        const fr_t r = fr_from_u64(0x123456789abcdefull);
+        size_t g = (half + 255) / 256; if (g > (size_t)CU * 32) g = (size_t)CU * 32;
+        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        for (int w = 0; w < 3; w++) hipLaunchKernelGGL(k_bind_top, dim3((unsigned)g, (unsigned)p), dim3(256), 0, 0, T, half, r);
+        CK(hipEventRecord(e0, 0));
+        for (int it = 0; it < 20; it++) hipLaunchKernelGGL(k_bind_top, dim3((unsigned)g, (unsigned)p), dim3(256), 0, 0, T, half, r);
+        CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+        float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 20;
+        printf("  n=2^%d p=%2d: %8.3f ms per launch  %7.1f GB/s algorithmic (%.3f of 8000)\n", logn, p, ms, 48.0 * n * p / (ms * 1e-3) * 1e-9, 48.0 * n * p / (ms * 1e-3) * 1e-9 / 8000.0);
+        CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1));
+      } else printf("  n=2^%d p=%2d: allocation failed, skipped\n", logn, p);
+      for (int k = 0; k < p; k++) if (T.p[k]) CK(hipFree(T.p[k]));
+    }
+  }
   printf("\ndone\n");
   return 0;
 }
