@@ -1,7 +1,7 @@
 """CPU: seeded differential fuzz of the host prover (over the mock of the device ABI) against the oracle prover, both curve builds: random strategy,
 C in 1..4, table sizes 2^1..2^8, ragged lookup counts up to 5000, three index distributions (independent per dimension, the harness's replicated
 draw, one address hit every time).  Commitment and proof bytes must be identical and the oracle verifier must accept.  The open-ended version of this
-loop ran 1300 configurations clean (tools/fuzz_host.py); the bitwise tables need an even log_m (an address splits into two operands of log_m / 2 bits —
+loop ran 10,000 configurations clean (tools/fuzz_host.py); the bitwise tables need an even log_m (an address splits into two operands of log_m / 2 bits —
 with an odd log_m the reference's own MLE formula disagrees with its table, and its verifier rejects its own proof)."""
 import ctypes as C
 
