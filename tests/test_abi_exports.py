@@ -15,19 +15,24 @@ def header_functions(name):
     return sorted(set(re.findall(r"\b(lasso_[a-z0-9_]+)\s*\(", src)))
 
 
-def test_device_library_exports_every_symbol():
+import pytest
+
+
+@pytest.mark.parametrize("suffix", ["", "_bn254"], ids=["curve25519", "bn254"])
+def test_device_library_exports_every_symbol(suffix):
     import __graft_entry__ as g
     g.build()
-    lib = ctypes.CDLL(os.path.join(ROOT, "lasso_amd", "liblasso_hip.so"))
+    lib = ctypes.CDLL(os.path.join(ROOT, "lasso_amd", f"liblasso_hip{suffix}.so"))
     declared = _abi.declare(lib)          # AttributeError if a declared symbol is not exported
     assert declared == header_functions("lasso_hip.h")
 
 
-def test_prover_library_exports_every_symbol():
-    """include/lasso_prover.h (the host prover's C ABI): every declared function is exported by liblasso_prover.so"""
+@pytest.mark.parametrize("suffix", ["", "_bn254"], ids=["curve25519", "bn254"])
+def test_prover_library_exports_every_symbol(suffix):
+    """include/lasso_prover.h (the host prover's C ABI): every declared function is exported by liblasso_prover.so (and by the BN254 pair)"""
     import __graft_entry__ as g
     g.build()
-    lib = ctypes.CDLL(os.path.join(ROOT, "lasso_amd", "liblasso_prover.so"))
+    lib = ctypes.CDLL(os.path.join(ROOT, "lasso_amd", f"liblasso_prover{suffix}.so"))
     names = [n for n in header_functions("lasso_prover.h") if n.startswith("lasso_host_")]
     assert len(names) >= 12
     for n in names:
