@@ -9,8 +9,12 @@ is quoted on: AND table, C=1, M=2^16, s=2^24 (src/benches/bench.rs `halo2_compar
 N > 1 (torch.distributed / RCCL, one process per GPU): each rank proves an independent batch of s lookups — the path
 partitions by proof, there is no data-path collective — so value = N*s*K / max-over-ranks time and scaling is "weak".
 
-One JSON line on rank 0.  Extra objects: roofline (dominant streaming kernel, HIP events on the library's stream),
-kernels (every kernel family: launches, ms, algorithmic GB/s), cpu_baseline (oracle port timed on host cores, rank 0, N=1).
+One JSON line on rank 0.  Extra objects: roofline (dominant HBM-streaming kernel family, HIP events on the library's stream; `frac` = algorithmic
+bytes / time / peak and `frac_traffic` = counter-measured HBM bytes / time / peak), roofline_bind_top (the kernel the north star names),
+roofline_msm (the MSM families: group additions of the reference's algorithm per second against the measured mixed-addition ceiling),
+dominant_family (largest family by time over ALL families), kernels (every kernel family: launches, ms, algorithmic GB/s),
+cpu_baseline (the oracle prover on ALL host cores at the same 2^24-lookup instance, one-thread figure beside it; rank 0, N=1) and
+parity_checked (the GPU's commitment and proof compared byte for byte with the oracle's for that instance).
 """
 import argparse
 import ctypes as C
@@ -40,7 +44,8 @@ def parse():
     p.add_argument("--kind", default="and", choices=["and", "or", "xor", "lt", "range"])
     p.add_argument("--log-m", type=int, default=16)
     p.add_argument("--log-r", type=int, default=40)
-    p.add_argument("--cpu-log-s", type=int, default=22, help="log2 lookups of the bounded CPU-baseline sample (2^22: ~20 s of one host core)")
+    p.add_argument("--cpu-log-s", type=int, default=24, help="log2 lookups of the CPU-baseline instance, proved by the oracle on all host cores (2^24 = the metric's own size)")
+    p.add_argument("--cpu-1t-log-s", type=int, default=20, help="log2 lookups of the bounded ONE-thread sample reported beside the all-core figure")
     p.add_argument("--curve", default="curve25519", choices=["curve25519", "bn254"], help="the group G: curve25519 (the reference harness's, the headline metric) or BN254 G1 "
                                                                                           "(BASELINE.json configs[1]; the liblasso_*_bn254.so pair)")
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -54,29 +59,64 @@ def parse():
     return p.parse_args()
 
 
-def cpu_baseline(kind_id, c, log_m, log_r, log_s, curve="curve25519"):
-    """Oracle ("port") prover, serial, on this box's host cores; a bounded sample of the same workload shape."""
+def _oracle_run(orc, kind_id, c, log_m, log_r, log_s, threads, want_bytes):
+    orc.orc_set_threads(threads)
+    td, tc, tp = C.c_double(), C.c_double(), C.c_double()
+    cap = 1 << 23
+    pb = (C.c_uint8 * cap)() if want_bytes else None; cb = (C.c_uint8 * cap)() if want_bytes else None; pl = C.c_size_t(); cl = C.c_size_t()
+    rc = orc.orc_bench_bytes(kind_id, C.c_size_t(c), C.c_size_t(1 << log_m), C.c_size_t(log_r), C.c_size_t(1 << log_s), C.byref(td), C.byref(tc), C.byref(tp), 0,
+                             pb, C.c_size_t(cap), C.byref(pl), cb, C.c_size_t(cap), C.byref(cl))
+    if rc != 0:
+        return None
+    return {"densify_s": td.value, "commit_s": tc.value, "prove_s": tp.value, "proof": bytes(pb[: pl.value]) if want_bytes else None, "comm": bytes(cb[: cl.value]) if want_bytes else None}
+
+
+def cpu_baseline(kind_id, c, log_m, log_r, log_s, log_s_1t, curve="curve25519"):
+    """The oracle prover ("port": the C++ restatement of the reference, OpenMP over the sites the reference hands to rayon) on ALL of this box's host
+    cores at 2^log_s lookups — the harness instance itself, so its commitment and proof bytes double as the parity check of the GPU's — plus a bounded
+    one-thread sample.  Returns (json object, commitment bytes, proof bytes)."""
     import subprocess
     so = "liblasso_oracle_bn254.so" if curve == "bn254" else "liblasso_oracle.so"
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), so])
     orc = C.CDLL(os.path.join(ROOT, "oracle", so))
-    td, tc, tp = C.c_double(), C.c_double(), C.c_double()
-    rc = orc.orc_bench(kind_id, C.c_size_t(c), C.c_size_t(1 << log_m), C.c_size_t(log_r), C.c_size_t(1 << log_s), C.byref(td), C.byref(tc), C.byref(tp), 0)
-    if rc != 0:
-        return None
-    return {"value": (1 << log_s) / tp.value, "unit": "lookups/s", "cores": 1, "kind": "port",
-            "sample": f"oracle (serial C++ restatement) prove, {kind_id=} C={c} M=2^{log_m} s=2^{log_s}: {tp.value:.2f}s (densify {td.value:.3f}s, commit {tc.value:.2f}s)"}
+    cores = orc.orc_max_threads()
+    full = _oracle_run(orc, kind_id, c, log_m, log_r, log_s, cores, True)
+    if not full:
+        return None, None, None
+    one = _oracle_run(orc, kind_id, c, log_m, log_r, min(log_s_1t, log_s), 1, False) if cores > 1 else None
+    orc.orc_set_threads(cores)
+    out = {"value": (1 << log_s) / full["prove_s"], "unit": "lookups/s", "cores": cores, "kind": "port", "host_logical_cpus": os.cpu_count(),
+           "sample": f"oracle (C++ restatement of the reference prover, OpenMP = the reference's rayon sites) SparsePoly.prove, kind={kind_id} C={c} M=2^{log_m} s=2^{log_s} "
+                     f"on {cores} threads: {full['prove_s']:.2f}s (densify {full['densify_s']:.2f}s, commit {full['commit_s']:.2f}s)"}
+    if one:
+        ls1 = min(log_s_1t, log_s)
+        out["one_thread"] = {"value": (1 << ls1) / one["prove_s"], "unit": "lookups/s", "cores": 1,
+                             "sample": f"the same prover on 1 thread at s=2^{ls1}: {one['prove_s']:.2f}s (commit {one['commit_s']:.2f}s)"}
+    return out, full["comm"], full["proof"]
 
 
 def pmc_traffic():
     """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (profiles/r01_pmc/bench_traffic.json, written by
     tools/pmc_summary.py: FETCH_SIZE x2 per MI355X_MICROARCH.md's gfx950 correction + WRITE_SIZE, large launches only).  {} when absent."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc", "bench_traffic.json")
-    try:
-        with open(path) as f:
-            return json.load(f)
-    except Exception:
-        return {}
+    for d in ("r02_pmc", "r01_pmc"):     # newest committed passes first
+        try:
+            with open(os.path.join(ROOT, "profiles", d, "bench_traffic.json")) as f:
+                return json.load(f)
+        except Exception:
+            continue
+    return {}
+
+
+def madd_ceiling(curve):
+    """Measured ceiling of mixed point additions per second with every CU busy (tools/microbench section 2, the kernels' own pt_madd in 29-bit limbs),
+    committed under profiles/; None when no measurement is committed for this curve build."""
+    for name in ("r02_madd_ceiling.json",):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                return json.load(f).get(curve)
+        except Exception:
+            continue
+    return None
 
 
 def concurrent_leg(HostProver, _abi, streams, steps, S, c, log_m, log_s, curve="curve25519"):
@@ -153,9 +193,10 @@ def main():
     # in the HBM-bound regime (>= 256 MiB of algorithmic bytes, past the Infinity Cache: ~20 per proof), so the brackets cost nothing.
     # Bracketing all ~950 launches of a proof adds ~8% wall time; that full per-family table comes from one extra, untimed, profiled step.
     STREAM = [_abi.K_BIND, _abi.K_CUBIC, _abi.K_COMBINE, _abi.K_EQ, _abi.K_GP, _abi.K_FINGERPRINT, _abi.K_DOT, _abi.K_MATVEC]
+    TIMED = STREAM + [_abi.K_MSM]       # the commitment MSM (rows > 16) counts as a large launch: one per proof, bracketed in the timed region as well
     LARGE_ONLY = 0x40000000
     if not a.no_prof:
-        dev_lib.lasso_prof_reset(ctx); dev_lib.lasso_prof_enable(ctx, sum(1 << k for k in STREAM) | LARGE_ONLY)
+        dev_lib.lasso_prof_reset(ctx); dev_lib.lasso_prof_enable(ctx, sum(1 << k for k in TIMED) | LARGE_ONLY)
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -165,16 +206,20 @@ def main():
     barrier()
 
     def family(kid, large):
-        n = C.c_uint64(); ms = C.c_double(); b = C.c_double()
+        n = C.c_uint64(); ms = C.c_double(); b = C.c_double(); u = C.c_double()
         (dev_lib.lasso_prof_get_large if large else dev_lib.lasso_prof_get)(ctx, kid, C.byref(n), C.byref(ms), C.byref(b))
+        dev_lib.lasso_prof_get_units(ctx, kid, 1 if large else 0, C.byref(u))
         if not n.value:
             return None
-        return {"kernel": _abi.KERNEL_NAMES[kid], "launches": n.value, "ms": round(ms.value, 3), "alg_GB": round(b.value / 1e9, 3),
-                "alg_GBps": round(b.value / (ms.value * 1e-3) / 1e9, 1) if ms.value > 0 else None, "avg_launch_us": round(ms.value * 1e3 / n.value, 2)}
+        out = {"kernel": _abi.KERNEL_NAMES[kid], "launches": n.value, "ms": round(ms.value, 3), "alg_GB": round(b.value / 1e9, 3),
+               "alg_GBps": round(b.value / (ms.value * 1e-3) / 1e9, 1) if ms.value > 0 else None, "avg_launch_us": round(ms.value * 1e3 / n.value, 2)}
+        if u.value:
+            out["ref_group_adds"] = round(u.value); out["ref_G_adds_per_s"] = round(u.value / (ms.value * 1e-3) / 1e9, 2) if ms.value > 0 else None
+        return out
     kernels, timed_large = [], {}
     if not a.no_prof:
         dev_lib.lasso_prof_enable(ctx, 0)
-        timed_large = {k: family(k, True) for k in STREAM}
+        timed_large = {k: family(k, True) for k in TIMED}
         dev_lib.lasso_prof_reset(ctx); dev_lib.lasso_prof_enable(ctx, (1 << _abi.K_COUNT) - 1)
         hp.prove(dense, gens, S, r)                      # extra untimed step, every launch of every family bracketed
         dev_lib.lasso_prof_enable(ctx, 0)
@@ -200,30 +245,68 @@ def main():
             out["large_launches_timed"] = {v["kernel"]: {"per_step": v["launches"] // a.steps, "alg_bytes_per_launch": round(v["alg_GB"] * 1e9 / v["launches"])} for v in timed_large.values() if v}
             traffic = pmc_traffic()
             def roof(kid):
-                """HBM roofline of one kernel family from the launches bracketed inside the timed region (the HBM-bound regime)."""
+                """HBM roofline of one kernel family from the launches bracketed inside the timed region (the HBM-bound regime).  `frac` prices the ALGORITHMIC
+                bytes of SURVEY 8(d) (what the reference's loop would move); `frac_traffic` prices the bytes the kernel really moved (PMC counters of the
+                committed rocprofv3 passes of this command) over the same live-measured time — an eq-weighted or fused kernel that skips bytes gets no credit there."""
                 k = timed_large.get(kid)
                 if not k:
                     return None
                 ach = k["alg_GB"] / (k["ms"] * 1e-3)
                 allk = next((x for x in kernels if x["kernel"] == k["kernel"]), None)
                 tr = traffic.get(k["kernel"])
+                ach_tr = tr["bytes_per_launch"] * k["launches"] / (k["ms"] * 1e-3) / 1e9 if tr else None
                 return {"kernel": k["kernel"], "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                        "traffic": tr["bytes_per_launch"] if tr else None, "alg_bytes_per_launch": round(k["alg_GB"] * 1e9 / k["launches"]),
+                        "traffic": tr["bytes_per_launch"] if tr else None, "achieved_traffic": round(ach_tr, 1) if ach_tr else None,
+                        "frac_traffic": round(ach_tr / HBM_PEAK_GBS, 4) if ach_tr else None,
+                        "alg_bytes_per_launch": round(k["alg_GB"] * 1e9 / k["launches"]),
                         "launches": k["launches"], "avg_launch_us": k["avg_launch_us"],
                         "scope": "launches with >= 256 MiB algorithmic bytes, HIP events inside the timed region",
                         "traffic_source": tr["source"] if tr else None,
                         "all_launches_one_profiled_step": {"achieved": allk["alg_GBps"], "launches": allk["launches"], "avg_launch_us": allk["avg_launch_us"]} if allk else None}
-            stream = [k for k in kernels if k["kernel"] in [_abi.KERNEL_NAMES[i] for i in STREAM]]
-            dom = max(stream, key=lambda k: k["ms"]) if stream else None                      # dominant streaming kernel family by total time
+            stream_names = [_abi.KERNEL_NAMES[i] for i in STREAM]
+            stream = [k for k in kernels if k["kernel"] in stream_names]
+            dom = max(stream, key=lambda k: k["ms"]) if stream else None                      # dominant HBM-streaming kernel family by total time
             if dom:
                 out["roofline"] = roof(_abi.KERNEL_NAMES.index(dom["kernel"]))
             out["roofline_bind_top"] = roof(_abi.K_BIND)                                        # the kernel BASELINE.json's north_star names (bound_poly_var)
+            # the MSM families are bounded by integer-ALU throughput, not HBM (SURVEY 8(d)): group additions of the REFERENCE's algorithm for the same inputs
+            # per second, against the measured ceiling of the kernels' own mixed addition with every CU busy (tools/microbench; profiles/r02_madd_ceiling.json)
+            ceil_ = madd_ceiling(a.curve)
+            def roof_msm(kid, src, scope):
+                k = src.get(kid) if isinstance(src, dict) else next((x for x in src if x["kernel"] == _abi.KERNEL_NAMES[kid]), None)
+                if not k or not k.get("ref_group_adds"):
+                    return None
+                ach = k["ref_group_adds"] / (k["ms"] * 1e-3) / 1e9
+                return {"kernel": k["kernel"], "bound": "valu (integer multiply-add issue; no MFMA, no HBM stream)", "achieved": round(ach, 2), "peak": ceil_["G_madd_per_s"] if ceil_ else None,
+                        "unit": "G group-additions/s", "frac": round(ach / ceil_["G_madd_per_s"], 4) if ceil_ else None, "launches": k["launches"], "avg_launch_us": k["avg_launch_us"],
+                        "ref_group_adds_per_launch": round(k["ref_group_adds"] / k["launches"]), "scope": scope, "peak_source": ceil_["source"] if ceil_ else None,
+                        "note": "achieved = additions the reference's msm_bigint_wnaf would perform (SURVEY 8(d) formula) / measured time; the kernels run a different schedule "
+                                "(precomputed window tables, one mixed addition per non-zero 4-bit digit), so frac can exceed what the executed additions alone would give"}
+            out["roofline_msm"] = {"commit": roof_msm(_abi.K_MSM, timed_large, "row-parallel commitment MSMs (rows > 16), HIP events inside the timed region"),
+                                   "opening": roof_msm(_abi.K_MSM_DIRECT, kernels, "latency-shaped opening MSMs (2 rows of full-width scalars per bullet round), one profiled step")}
+            allfam = max(kernels, key=lambda k: k["ms"])                                        # over ALL families, streaming or not
+            msm_ms = sum(k["ms"] for k in kernels if k["kernel"].startswith("msm"))
+            out["dominant_family"] = {"by_time_one_profiled_step": allfam["kernel"], "ms": allfam["ms"], "msm_families_ms": round(msm_ms, 3),
+                                      "sum_all_families_ms": round(sum(k["ms"] for k in kernels), 3),
+                                      "covered_by": "roofline_msm" if allfam["kernel"].startswith("msm") else ("roofline" if dom and allfam["kernel"] == dom["kernel"] else "kernels_one_profiled_step")}
         if world == 1 and a.concurrent > 1 and a.concurrent * s * alpha * 450 < 150e9:   # ~400 bytes of HBM per lookup and memory per resident proof
             out["concurrent_proofs"] = concurrent_leg(HostProver, _abi, a.concurrent, max(2, a.steps), S, c, log_m, a.log_s, a.curve)
         if world == 1 and not a.no_cpu_baseline:
-            cb = cpu_baseline(kind_id, c, log_m, S.log_r, min(a.cpu_log_s, a.log_s), a.curve)
+            cls = min(a.cpu_log_s, a.log_s)
+            cb, o_comm, o_proof = cpu_baseline(kind_id, c, log_m, S.log_r, cls, a.cpu_1t_log_s, a.curve)
             if cb:
                 out["cpu_baseline"] = cb
+                # parity at the size the claim is made on: the oracle proved the harness instance of 2^cls lookups; the GPU's commitment and proof of the SAME
+                # instance (the timed one when the sizes agree, otherwise proved here) must be the same bytes
+                if cls == a.log_s:
+                    g_comm, g_proof = comm, proof
+                else:
+                    idx2 = shard_indices(hp, 1 << cls, 1 << log_m, c, 0); r2 = hp.gen_random_point(cls)
+                    gens2 = hp.gens(c, 1 << cls, alpha, log_m); dense2 = hp.densify(idx2, log_m)
+                    g_comm = hp.commit(dense2, gens2); g_proof = hp.prove(dense2, gens2, S, r2); hp.free(dense2, gens2)
+                import hashlib
+                out["parity_checked"] = {"log_s": cls, "equal": g_proof == o_proof, "commitment_equal": g_comm == o_comm, "proof_bytes": len(g_proof), "commitment_bytes": len(g_comm),
+                                         "proof_sha256": hashlib.sha256(g_proof).hexdigest(), "against": f"oracle prover on {cb['cores']} threads, same harness instance (benches/bench.rs:13-34 inputs)"}
         print(json.dumps(out))
     hp.free(dense, gens)
     hp.close()

@@ -71,11 +71,16 @@ int32_t lasso_download(lasso_ctx* ctx, void* dst, const void* d_src, size_t byte
 int32_t lasso_copy(lasso_ctx* ctx, void* d_dst, const void* d_src, size_t bytes);     /* DensePolynomial::clone / merge: src/poly/dense_mlpoly.rs:97-99,:251-261 */
 int32_t lasso_zero(lasso_ctx* ctx, void* d_dst, size_t bytes);                        /* merge's zero padding :258 */
 int32_t lasso_sync(lasso_ctx* ctx);
+/* Error recovery after a call sequence was abandoned half way (the host prover threw between lasso_sumcheck_*_tail_begin and the last
+ * lasso_sumcheck_cubic_tail_next, or left a deferred result uncollected): releases a resident kernel that is waiting for a challenge, drains the
+ * stream and resets the protocol state, so that the context is usable again.  lasso_ctx_destroy calls it when needed. */
+int32_t lasso_abort(lasso_ctx* ctx);
 void* lasso_stream(lasso_ctx* ctx);                    /* the context's hipStream_t */
 
 /* ---- per-kernel timing (HIP events on the context's stream), for bench.py's roofline ------- */
 enum lasso_kernel_id { LASSO_K_BIND = 0, LASSO_K_CUBIC = 1, LASSO_K_COMBINE = 2, LASSO_K_EQ = 3, LASSO_K_GP = 4, LASSO_K_FINGERPRINT = 5,
-                       LASSO_K_DOT = 6, LASSO_K_MATVEC = 7, LASSO_K_MSM = 8, LASSO_K_MISC = 9, LASSO_K_COUNT = 10 };
+                       LASSO_K_DOT = 6, LASSO_K_MATVEC = 7, LASSO_K_MSM = 8 /* bucket kernel: commitments, many rows */, LASSO_K_MISC = 9,
+                       LASSO_K_MSM_DIRECT = 10 /* latency-shaped kernel: the openings' few rows of full-width scalars */, LASSO_K_COUNT = 11 };
 #define LASSO_PROF_LARGE_ONLY 0x40000000   /* OR into the mask: bracket only launches of at least LASSO_PROF_LARGE_BYTES (a handful per proof: no measurable overhead) */
 int32_t lasso_prof_enable(lasso_ctx* ctx, int32_t family_mask);   /* bit k = bracket launches of lasso_kernel_id k; 0 = off */
 int32_t lasso_prof_reset(lasso_ctx* ctx);
@@ -84,6 +89,10 @@ int32_t lasso_prof_get(lasso_ctx* ctx, int32_t kernel_id, uint64_t* launches, do
 /* the same, restricted to launches with at least LASSO_PROF_LARGE_BYTES algorithmic bytes (past the 256 MiB Infinity Cache: the HBM-bound regime) */
 #define LASSO_PROF_LARGE_BYTES 268435456.0
 int32_t lasso_prof_get_large(lasso_ctx* ctx, int32_t kernel_id, uint64_t* launches, double* total_ms, double* alg_bytes);
+/* family-specific work units recorded beside the bytes.  MSM families: group additions of the REFERENCE's algorithm for the same inputs (SURVEY.md §8d:
+ * L*(R+1)*W bucket accumulation + L*W*2*2^c bucket reduction + L*(W-1)*(c+1) window combine, src/msm/mod.rs:91-164); 0 for the streaming families.
+ * large_only != 0: the launches lasso_prof_get_large counts (for LASSO_K_MSM: the row-parallel commitments, more than 16 rows). */
+int32_t lasso_prof_get_units(lasso_ctx* ctx, int32_t kernel_id, int32_t large_only, double* units);
 
 /* Host-side latency accounting: number of device->host result hand-offs (flag waits) and the host time spent spinning on them since the last reset. */
 int32_t lasso_wait_stats(lasso_ctx* ctx, uint64_t* waits, double* wait_us, int32_t reset);

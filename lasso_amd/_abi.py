@@ -13,8 +13,8 @@ class Strategy(C.Structure):
 
 
 KINDS = {"and": 0, "or": 1, "xor": 2, "lt": 3, "range": 4}
-K_BIND, K_CUBIC, K_COMBINE, K_EQ, K_GP, K_FINGERPRINT, K_DOT, K_MATVEC, K_MSM, K_MISC, K_COUNT = range(11)
-KERNEL_NAMES = ["bind_top(+fused linear round)", "sumcheck_cubic_round(+fused bind)", "sumcheck_combine", "eq_evals", "gp_build", "fingerprint", "multi_dot", "matvec_left", "msm", "misc"]
+K_BIND, K_CUBIC, K_COMBINE, K_EQ, K_GP, K_FINGERPRINT, K_DOT, K_MATVEC, K_MSM, K_MISC, K_MSM_DIRECT, K_COUNT = range(12)
+KERNEL_NAMES = ["bind_top(+fused linear round)", "sumcheck_cubic_round(+fused bind)", "sumcheck_combine", "eq_evals", "gp_build", "fingerprint", "multi_dot", "matvec_left", "msm_commit(bucket)", "misc", "msm_opening(direct)"]
 
 
 def declare(lib):
@@ -31,11 +31,13 @@ def declare(lib):
         "lasso_copy": (i32, [vp, vp, vp, sz]),
         "lasso_zero": (i32, [vp, vp, sz]),
         "lasso_sync": (i32, [vp]),
+        "lasso_abort": (i32, [vp]),
         "lasso_stream": (vp, [vp]),
         "lasso_prof_enable": (i32, [vp, i32]),
         "lasso_prof_reset": (i32, [vp]),
         "lasso_prof_get": (i32, [vp, i32, P(u64), P(C.c_double), P(C.c_double)]),
         "lasso_prof_get_large": (i32, [vp, i32, P(u64), P(C.c_double), P(C.c_double)]),
+        "lasso_prof_get_units": (i32, [vp, i32, i32, P(C.c_double)]),
         "lasso_wait_stats": (i32, [vp, P(u64), P(C.c_double), i32]),
         "lasso_fr_from_u32": (i32, [vp, vp, sz, vp]),
         "lasso_gather": (i32, [vp, vp, vp, sz, vp]),

@@ -26,8 +26,9 @@ __global__ void __launch_bounds__(256) k_densify_extract(const uint64_t* __restr
                                                           uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t* __restrict__ dim_u32, fr_t* __restrict__ dim_fr, uint32_t* __restrict__ bad) {
   const fr29 r2s = fr29_r2s();
   for (size_t k = blockIdx.x * (size_t)blockDim.x + threadIdx.x; k < s; k += (size_t)gridDim.x * blockDim.x) {
-    const uint64_t a = k < n_lookups ? idx[k * C + col] : 0;   // access_sequence.resize(s, 0)  densified.rs:38
-    if (a >= m) { atomicOr(bad, 1u); }                           // debug_assert!(memory_address < m)  :46
+    uint64_t a = k < n_lookups ? idx[k * C + col] : 0;         // access_sequence.resize(s, 0)  densified.rs:38
+    if (a >= m) { atomicOr(bad, 1u); a = 0; }                    // debug_assert!(memory_address < m)  :46 — flagged (the call returns LASSO_ERR_INVALID) and
+                                                                 // clamped, so the sort / run kernels that index 2*m words of scratch by key stay in bounds
     keys[k] = (uint32_t)a; vals[k] = (uint32_t)k;
     if (k % world == rank) { dim_u32[k / world] = (uint32_t)a; dim_fr[k / world] = fr29_store(fr29_mul(fr29_from_u64_int(a), r2s)); }
   }

@@ -27,7 +27,7 @@ __global__ void __launch_bounds__(256) k_inner_lr(const fr_t* __restrict__ a, co
 static_assert(sizeof(lasso_fr) == 32 && sizeof(fr_t) == 32, "Fr layout");
 static_assert(sizeof(lasso_affine) == 64 && sizeof(lasso_point) == 128 && sizeof(ed_point) == 128 && sizeof(niels29) == 112 && sizeof(pt29) == 144, "curve layouts");
 
-struct EventPair { hipEvent_t a, b; int kid; double bytes; };
+struct EventPair { hipEvent_t a, b; int kid; double bytes, units; bool large; };
 struct lasso_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -52,6 +52,8 @@ struct lasso_ctx {
   uint64_t prof_launches[LASSO_K_COUNT] = {0}; double prof_ms[LASSO_K_COUNT] = {0}; double prof_bytes[LASSO_K_COUNT] = {0};
   // the same, restricted to launches whose algorithmic bytes exceed LASSO_PROF_LARGE_BYTES (past the 256 MiB Infinity Cache: the HBM-bound regime)
   uint64_t big_launches[LASSO_K_COUNT] = {0}; double big_ms[LASSO_K_COUNT] = {0}; double big_bytes[LASSO_K_COUNT] = {0};
+  // family-specific work units beside the bytes (the MSM families: group additions of the reference's algorithm), all / large launches
+  double prof_units[LASSO_K_COUNT] = {0}; double big_units[LASSO_K_COUNT] = {0};
 };
 struct lasso_bases { size_t n = 0; niels29* d_table = nullptr; niels29* d_mult = nullptr; };   // d_mult: signed digit multiples for the latency-shaped MSM (k_msm_direct), optional
 
@@ -59,7 +61,11 @@ static thread_local std::string g_create_err;
 
 static int32_t fail(lasso_ctx* c, int32_t code, const std::string& msg) { if (c) c->err = msg; else g_create_err = msg; return code; }
 #define HIPCHK(c, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail((c), e_ == hipErrorOutOfMemory ? LASSO_ERR_OOM : LASSO_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
-#define REQUIRE(c, cond) do { if (!(cond)) return fail((c), LASSO_ERR_INVALID, std::string("invalid argument: ") + #cond); } while (0)
+// Every entry point runs on the context's device whatever the calling thread's current device is (two contexts on different devices driven from one
+// thread, or worker threads that default to device 0): hipGetDevice/hipSetDevice are thread-local state in the runtime, a few tens of nanoseconds.
+static inline bool bind_device(lasso_ctx* c) { if (!c) return true; int d = -1; if (hipGetDevice(&d) == hipSuccess && d == c->device) return true; return hipSetDevice(c->device) == hipSuccess; }
+#define REQUIRE(c, cond) do { if (!bind_device(c)) return fail((c), LASSO_ERR_HIP, "hipSetDevice failed for the context's device"); \
+                              if (!(cond)) return fail((c), LASSO_ERR_INVALID, std::string("invalid argument: ") + #cond); } while (0)
 
 static int32_t ensure_scratch(lasso_ctx* c, size_t bytes) {
   if (bytes <= c->scratch_cap) return 0;
@@ -91,12 +97,14 @@ static int32_t ensure_big(lasso_ctx* c, size_t count) {
 // profiling: bracket a launch with an event pair on the context's stream
 struct ProfScope {
   lasso_ctx* c; int idx = -1;
-  ProfScope(lasso_ctx* c_, int kid, double bytes) : c(c_) {
+  // `large`: the launch belongs to the throughput regime whatever its byte count (the row-parallel commitment MSMs: 64 MiB of u32 scalars, milliseconds of VALU work)
+  ProfScope(lasso_ctx* c_, int kid, double bytes, double units = 0, bool large = false) : c(c_) {
     if (!((c->prof_mask >> kid) & 1u)) return;
-    if ((c->prof_mask & 0x40000000u) && bytes < LASSO_PROF_LARGE_BYTES) return;   // LASSO_PROF_LARGE_ONLY: leave the latency-bound launches unbracketed
+    large = large || bytes >= LASSO_PROF_LARGE_BYTES;
+    if ((c->prof_mask & 0x40000000u) && !large) return;   // LASSO_PROF_LARGE_ONLY: leave the latency-bound launches unbracketed
     if (c->events_used == c->events.size()) { EventPair p; if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return; c->events.push_back(p); }
     idx = (int)c->events_used++;
-    c->events[idx].kid = kid; c->events[idx].bytes = bytes;
+    c->events[idx].kid = kid; c->events[idx].bytes = bytes; c->events[idx].units = units; c->events[idx].large = large;
     (void)hipEventRecord(c->events[idx].a, c->stream);
   }
   ~ProfScope() { if (idx >= 0) (void)hipEventRecord(c->events[idx].b, c->stream); }
@@ -106,8 +114,8 @@ static void prof_flush(lasso_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   for (size_t i = 0; i < c->events_used; i++) {
     float ms = 0; if (hipEventElapsedTime(&ms, c->events[i].a, c->events[i].b) != hipSuccess) continue;
-    int k = c->events[i].kid; c->prof_launches[k]++; c->prof_ms[k] += ms; c->prof_bytes[k] += c->events[i].bytes;
-    if (c->events[i].bytes >= LASSO_PROF_LARGE_BYTES) { c->big_launches[k]++; c->big_ms[k] += ms; c->big_bytes[k] += c->events[i].bytes; }
+    int k = c->events[i].kid; c->prof_launches[k]++; c->prof_ms[k] += ms; c->prof_bytes[k] += c->events[i].bytes; c->prof_units[k] += c->events[i].units;
+    if (c->events[i].large) { c->big_launches[k]++; c->big_ms[k] += ms; c->big_bytes[k] += c->events[i].bytes; c->big_units[k] += c->events[i].units; }
   }
   c->events_used = 0;
 }
@@ -166,9 +174,30 @@ int32_t lasso_ctx_create_background(int32_t device, int32_t background, lasso_ct
   rc = ensure_scratch(c, (size_t)1 << 22); if (rc) { g_create_err = c->err; delete c; return rc; }
   *out = c; return 0;
 }
+// Error recovery: a host that stops between *_tail_begin and the last tail_next (an exception in the prover) leaves a resident kernel waiting for a
+// challenge, tail_active / pending set, and possibly non-zero arrival tickets.  Post the poison tag (the kernels leave at their next poll instead of
+// after the 5 s bail-out), drain the stream, clear the mailbox and the protocol state, and restore the "tickets are zero between launches" invariant.
+int32_t lasso_abort(lasso_ctx* c) {
+  REQUIRE(c, c);
+  uint32_t* mail = c->h_flag + 32;
+  if (c->tail_active) {
+    const __m128i poison = _mm_set_epi32(0, 0, 0, (int)LASSO_MAIL_POISON);
+    _mm_store_si128((__m128i*)(mail + 0), poison); _mm_store_si128((__m128i*)(mail + 4), poison); _mm_store_si128((__m128i*)(mail + 8), poison);
+    __atomic_thread_fence(__ATOMIC_RELEASE);
+  }
+  (void)hipStreamSynchronize(c->stream);   // bounded: every device-side wait has the poison check and a wall-clock bail-out
+  (void)hipGetLastError();
+  const __m128i zero = _mm_setzero_si128();
+  _mm_store_si128((__m128i*)(mail + 0), zero); _mm_store_si128((__m128i*)(mail + 4), zero); _mm_store_si128((__m128i*)(mail + 8), zero);
+  c->tail_active = false; c->pending = false; c->defer_next = false; c->events_used = 0;
+  HIPCHK(c, hipMemsetAsync(c->d_counters, 0, (LASSO_MAX_PTRS + 40) * 4, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
 void lasso_ctx_destroy(lasso_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
+  if (c->tail_active || c->pending) (void)lasso_abort(c);   // never block in the synchronise below for a kernel's 5 s bail-out
   (void)hipStreamSynchronize(c->stream);
   for (auto& p : c->events) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   if (c->d_scratch) (void)hipFree(c->d_scratch);
@@ -183,13 +212,13 @@ void lasso_ctx_destroy(lasso_ctx* c) {
 }
 const char* lasso_last_error(lasso_ctx* c) { return c ? c->err.c_str() : g_create_err.c_str(); }
 void* lasso_stream(lasso_ctx* c) { return c ? (void*)c->stream : nullptr; }
-int32_t lasso_alloc(lasso_ctx* c, size_t bytes, void** d_out) { REQUIRE(c, d_out); HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipMalloc(d_out, bytes ? bytes : 1)); return 0; }
-int32_t lasso_free(lasso_ctx* c, void* p) { if (!p) return 0; HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(p)); return 0; }
+int32_t lasso_alloc(lasso_ctx* c, size_t bytes, void** d_out) { REQUIRE(c, d_out); HIPCHK(c, hipMalloc(d_out, bytes ? bytes : 1)); return 0; }
+int32_t lasso_free(lasso_ctx* c, void* p) { if (!p) return 0; REQUIRE(c, c); HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(p)); return 0; }
 int32_t lasso_upload(lasso_ctx* c, void* d, const void* s, size_t n) { REQUIRE(c, d && s); HIPCHK(c, hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); return 0; }
 int32_t lasso_download(lasso_ctx* c, void* d, const void* s, size_t n) { REQUIRE(c, d && s); HIPCHK(c, hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); return 0; }
 int32_t lasso_copy(lasso_ctx* c, void* d, const void* s, size_t n) { REQUIRE(c, d && s); ProfScope ps(c, LASSO_K_MISC, 2.0 * n); HIPCHK(c, hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, c->stream)); return 0; }
 int32_t lasso_zero(lasso_ctx* c, void* d, size_t n) { REQUIRE(c, d); HIPCHK(c, hipMemsetAsync(d, 0, n, c->stream)); return 0; }
-int32_t lasso_sync(lasso_ctx* c) { HIPCHK(c, hipStreamSynchronize(c->stream)); return 0; }
+int32_t lasso_sync(lasso_ctx* c) { REQUIRE(c, c); HIPCHK(c, hipStreamSynchronize(c->stream)); return 0; }
 
 int32_t lasso_prof_get_large(lasso_ctx* c, int32_t k, uint64_t* launches, double* ms, double* bytes) {
   REQUIRE(c, k >= 0 && k < LASSO_K_COUNT); prof_flush(c);
@@ -197,7 +226,11 @@ int32_t lasso_prof_get_large(lasso_ctx* c, int32_t k, uint64_t* launches, double
 }
 int32_t lasso_wait_stats(lasso_ctx* c, uint64_t* waits, double* wait_us, int32_t reset) { REQUIRE(c, waits && wait_us); *waits = c->stat_waits; *wait_us = c->stat_wait_us; if (reset) { c->stat_waits = 0; c->stat_wait_us = 0; } return 0; }
 int32_t lasso_prof_enable(lasso_ctx* c, int32_t mask) { prof_flush(c); c->prof_mask = (uint32_t)mask; return 0; }
-int32_t lasso_prof_reset(lasso_ctx* c) { prof_flush(c); for (int i = 0; i < LASSO_K_COUNT; i++) { c->prof_launches[i] = 0; c->prof_ms[i] = 0; c->prof_bytes[i] = 0; c->big_launches[i] = 0; c->big_ms[i] = 0; c->big_bytes[i] = 0; } return 0; }
+int32_t lasso_prof_reset(lasso_ctx* c) { prof_flush(c); for (int i = 0; i < LASSO_K_COUNT; i++) { c->prof_launches[i] = 0; c->prof_ms[i] = 0; c->prof_bytes[i] = 0; c->big_launches[i] = 0; c->big_ms[i] = 0; c->big_bytes[i] = 0; c->prof_units[i] = 0; c->big_units[i] = 0; } return 0; }
+int32_t lasso_prof_get_units(lasso_ctx* c, int32_t k, int32_t large_only, double* units) {
+  REQUIRE(c, k >= 0 && k < LASSO_K_COUNT && units); prof_flush(c);
+  *units = large_only ? c->big_units[k] : c->prof_units[k]; return 0;
+}
 int32_t lasso_prof_get(lasso_ctx* c, int32_t k, uint64_t* launches, double* ms, double* bytes) {
   REQUIRE(c, k >= 0 && k < LASSO_K_COUNT); prof_flush(c);
   if (launches) *launches = c->prof_launches[k]; if (ms) *ms = c->prof_ms[k]; if (bytes) *bytes = c->prof_bytes[k]; return 0;
@@ -693,6 +726,20 @@ void lasso_bases_destroy(lasso_ctx* c, lasso_bases* b) { if (!b) return; if (c) 
 // chunks per row.  Measured on MI355X (profiles/): the bucket kernel is VALU-issue-bound even at one wave per SIMD (the 81 independent
 // multiply-adds of a field product pipeline back to back), so extra workgroups beyond one per CU only multiply the fixed per-workgroup
 // reduction tree (2 rows x 482 chunks ran 310 us, 2 x 129 ran 180 us).  Aim for rows*K = 256 workgroups, never below 1024 pairs a chunk.
+// group additions the REFERENCE's msm_bigint_wnaf (msm/mod.rs:91-164) performs for `rows` MSMs of n terms with num_bits-bit scalars:
+// bucket accumulation n*W + bucket reduction W*2*2^c + window combine (W-1)*(c+1), c = ln_without_floats(n)+2 (:112-119,:322-325), W = ceil(num_bits/c).
+// This is the algorithmic work unit of the MSM families' roofline (bench.py roofline_msm); the kernels here execute a different schedule
+// (precomputed 4-bit window tables: one mixed addition per non-zero nibble, no per-window reduction, no doubling chain).
+#ifdef LASSO_BN254
+#define FR_MODULUS_BITS 254u
+#else
+#define FR_MODULUS_BITS 253u
+#endif
+static double msm_ref_adds(size_t rows, size_t n, uint32_t num_bits) {
+  size_t lg = n <= 1 ? 0 : 64 - (size_t)__builtin_clzll((unsigned long long)(n - 1));
+  const size_t cw = n < 32 ? 3 : lg * 69 / 100 + 2, W = (num_bits + cw - 1) / cw;
+  return (double)rows * ((double)n * W + (double)W * 2.0 * (double)((size_t)1 << cw) + (double)(W > 0 ? W - 1 : 0) * (cw + 1.0));
+}
 static size_t msm_chunks(size_t rows, size_t n_cols, uint32_t W) {
   size_t pairs = n_cols * W, K = 1;
   if (rows < 256) { K = 256 / rows; size_t kmax = (pairs + 1023) / 1024; if (kmax < 1) kmax = 1; if (K > kmax) K = kmax; }
@@ -725,7 +772,7 @@ static int32_t run_msm_direct(lasso_ctx* c, const uint8_t* d_scal, size_t row_st
   uint32_t ipc = 0; const size_t K = msm_direct_chunks(rows, n_cols, &ipc);
   const uint32_t seq = ++c->seq;
   {
-    ProfScope ps(c, LASSO_K_MSM, (double)rows * n_cols * 32);
+    ProfScope ps(c, LASSO_K_MSM_DIRECT, (double)rows * n_cols * 32, msm_ref_adds(rows, n_cols, FR_MODULUS_BITS));
     hipLaunchKernelGGL(k_msm_direct, dim3((unsigned)K, (unsigned)rows), dim3(MSM_THREADS), 0, c->stream, (const uint32_t*)d_scal, row_stride / 4, (uint32_t)n_cols, ipc, cm, (const niels29*)b->d_mult, b->n,
                        (pt29*)scratch_after, (ed_point*)c->d_small, c->d_counters + LASSO_MAX_PTRS + 8, c->d_flag, seq);
   }
@@ -742,7 +789,7 @@ static int32_t run_msm(lasso_ctx* c, const uint8_t* d_scal, uint32_t bps, uint32
   ed_point* d_final = small ? (ed_point*)c->d_small : (ed_point*)(((uintptr_t)(d_partial + rows * K) + 15) & ~(uintptr_t)15);
   const uint32_t seq = small ? ++c->seq : 0;
   {
-    ProfScope ps(c, LASSO_K_MSM, (double)rows * n_cols * bps);
+    ProfScope ps(c, LASSO_K_MSM, (double)rows * n_cols * bps, msm_ref_adds(rows, n_cols, bps == 4 ? 4 * W : FR_MODULUS_BITS), rows > MSM_SMALL_ROWS);
     hipLaunchKernelGGL(k_msm_buckets, dim3((unsigned)K, (unsigned)rows), dim3(MSM_THREADS), 0, c->stream, d_scal, bps, W, row_stride, n_cols, cols_per_chunk, (const niels29*)b->d_table, b->n, d_partial);
     hipLaunchKernelGGL(k_points_sum, dim3((unsigned)rows), dim3(MSM_THREADS), 0, c->stream, (const pt29*)d_partial, (uint32_t)K, d_final, out_compressed ? (uint32_t*)d_final : (uint32_t*)nullptr,
                        c->d_counters + LASSO_MAX_PTRS + 1, small ? c->d_flag : (uint32_t*)nullptr, seq);

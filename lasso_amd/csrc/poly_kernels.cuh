@@ -3,6 +3,7 @@
 // form of fr29.cuh (unpack on load, canonicalise + pack on store).  Streaming kernels are HBM-bound by design; the sumcheck round
 // evaluators are integer-ALU-bound.  Sums are exact field sums, so any reduction order is bit-identical to the reference's loops.
 #pragma once
+#define LASSO_MAIL_POISON 0xFFFFFFFFu   // mailbox tag written by lasso_abort: resident kernels waiting for a challenge leave at once (sequence tags never reach it)
 #include <hip/hip_runtime.h>
 #include "fr.cuh"
 #include "fr29.cuh"
@@ -428,7 +429,7 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_tail(MutPtrTable A, MutPt
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");   // nothing cached from the previous poll
         c0 = __builtin_nontemporal_load(m4); c1 = __builtin_nontemporal_load(m4 + 1); c2 = __builtin_nontemporal_load(m4 + 2);   // three 16-byte reads in flight together
         if (c0.x == seq0 + turn + 1 && c1.x == seq0 + turn + 1 && c2.x == seq0 + turn + 1) break;   // tagged with the sequence number of the publication it enables: unique per context, never reset
-        if ((++spins & 63u) == 0 && wall_clock64() > t_end) { ok = 0; break; }
+        if (c0.x == LASSO_MAIL_POISON || ((++spins & 63u) == 0 && wall_clock64() > t_end)) { ok = 0; break; }   // lasso_abort's tag, or the host stopped answering
       }
       if (ok) { chal.v[0] = c0.y; chal.v[1] = c0.z; chal.v[2] = c0.w; chal.v[3] = c1.y; chal.v[4] = c1.z; chal.v[5] = c1.w; chal.v[6] = c2.y; chal.v[7] = c2.z; }
       alive = ok;
@@ -578,7 +579,7 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_mid(MutPtrTable A, MutPtr
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
         c0 = __builtin_nontemporal_load(m4); c1 = __builtin_nontemporal_load(m4 + 1); c2 = __builtin_nontemporal_load(m4 + 2);
         if (c0.x == seq0 + turn + 1 && c1.x == seq0 + turn + 1 && c2.x == seq0 + turn + 1) break;   // tagged with the sequence number of the publication it enables: unique per context, never reset
-        if ((++spins & 63u) == 0 && wall_clock64() > t_end) { ok = 0; break; }
+        if (c0.x == LASSO_MAIL_POISON || ((++spins & 63u) == 0 && wall_clock64() > t_end)) { ok = 0; break; }   // lasso_abort's tag, or the host stopped answering
       }
       if (ok) { chal.v[0] = c0.y; chal.v[1] = c0.z; chal.v[2] = c0.w; chal.v[3] = c1.y; chal.v[4] = c1.z; chal.v[5] = c1.w; chal.v[6] = c2.y; chal.v[7] = c2.z; }
       alive = ok;
@@ -673,7 +674,7 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_linear_tail(PtrTable src, const
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
         c0 = __builtin_nontemporal_load(m4); c1 = __builtin_nontemporal_load(m4 + 1); c2 = __builtin_nontemporal_load(m4 + 2);
         if (c0.x == seq0 + turn + 1 && c1.x == seq0 + turn + 1 && c2.x == seq0 + turn + 1) break;   // tagged with the sequence number of the publication it enables: unique per context, never reset
-        if ((++spins & 63u) == 0 && wall_clock64() > t_end) { ok = 0; break; }
+        if (c0.x == LASSO_MAIL_POISON || ((++spins & 63u) == 0 && wall_clock64() > t_end)) { ok = 0; break; }   // lasso_abort's tag, or the host stopped answering
       }
       if (ok) { chal.v[0] = c0.y; chal.v[1] = c0.z; chal.v[2] = c0.w; chal.v[3] = c1.y; chal.v[4] = c1.z; chal.v[5] = c1.w; chal.v[6] = c2.y; chal.v[7] = c2.z; }
       alive = ok;

@@ -30,7 +30,7 @@ namespace lasso {
 // laid next to src/benches/*.log line by line.  Device work is asynchronous: a span closes after a stream sync only when tracing.
 struct Trace {
   static bool on() { static const bool v = [] { const char* e = getenv("LASSO_TRACE"); return e && e[0] == '1'; }(); return v; }
-  const char* name; lasso_ctx* ctx; std::chrono::steady_clock::time_point t0; static int& depth() { static int d = 0; return d; }
+  const char* name; lasso_ctx* ctx; std::chrono::steady_clock::time_point t0; static int& depth() { static thread_local int d = 0; return d; }
   uint64_t w0 = 0; double wus0 = 0;
   Trace(const char* n, lasso_ctx* c) : name(n), ctx(c) { if (on()) { t0 = std::chrono::steady_clock::now(); depth()++; if (ctx) lasso_wait_stats(ctx, &w0, &wus0, 0); } }
   ~Trace() {
@@ -46,7 +46,7 @@ struct Trace {
 // LASSO_TRACE=2: host-side time buckets (where the host spends its share of a proof), printed with the SparsePoly.prove span
 struct HostClock {
   static bool on() { static const bool v = [] { const char* e = getenv("LASSO_TRACE"); return e && e[0] == '2'; }(); return v; }
-  static std::map<std::string, double>& buckets() { static std::map<std::string, double> b; return b; }
+  static std::map<std::string, double>& buckets() { static thread_local std::map<std::string, double> b; return b; }
   const char* name; std::chrono::steady_clock::time_point t0;
   explicit HostClock(const char* n) : name(n) { if (on()) t0 = std::chrono::steady_clock::now(); }
   ~HostClock() { if (on()) buckets()[name] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
@@ -117,6 +117,8 @@ class Dev {
   void chk_side(int32_t rc, const char* what) const { if (rc != 0) throw Error(std::string(what) + " failed on the side context (" + std::to_string(rc) + "): " + lasso_last_error(side_)); }
   Dev(const Dev&) = delete; Dev& operator=(const Dev&) = delete;
   void chk(int32_t rc, const char* what) const { if (rc != 0) throw Error(std::string(what) + " failed (" + std::to_string(rc) + "): " + lasso_last_error(ctx)); }
+  // error unwinding: leave both contexts usable (a resident kernel may be waiting for a challenge, a deferred result may be uncollected)
+  void abort_all() const noexcept { if (ctx) (void)lasso_abort(ctx); if (side_) (void)lasso_abort(side_); }
   void* alloc_bytes(size_t bytes) const {
     if (!bytes) bytes = 1;
     auto it = pool_.find(bytes);
@@ -366,7 +368,9 @@ struct Strategy {
 struct UniPoly {
   ScVec coeffs;
   static const std::vector<ScVec>& inv_vandermonde(size_t n) {
-    static std::map<size_t, std::vector<ScVec>> cache;
+    // per-thread cache: slab mode drives P ranks as P threads in lockstep, which all reach the first from_evals(n) at the same moment
+    // (a shared map was a data race); a degree's matrix costs ~n^3 field operations once per thread, the returned reference stays thread-private
+    static thread_local std::map<size_t, std::vector<ScVec>> cache;
     auto it = cache.find(n); if (it != cache.end()) return it->second;
     std::vector<ScVec> a(n, ScVec(2 * n, Sc::zero()));
     for (size_t i = 0; i < n; i++) { Sc x = Sc::from_u64(i), pw = Sc::one(); for (size_t j = 0; j < n; j++) { a[i][j] = pw; pw *= x; } a[i][n + i] = Sc::one(); }

@@ -1,12 +1,29 @@
 // liblasso_prover.so — include/lasso_prover.h over lasso_amd/host/prover.hpp.  Nothing unwinds across the ABI.
 #include "prover.hpp"
+#include <atomic>
 #include "../../include/lasso_prover.h"
 
 using namespace lasso;
 
-struct lasso_host { Dev dev; explicit lasso_host(int device) : dev(device) {} };
-struct lasso_host_gens { SparsePolyCommitmentGens g; lasso_host_gens(const Dev& d, const char* label, size_t c, size_t s, size_t nm, size_t log_m) : g(d, label, c, s, nm, log_m) {} };
-struct lasso_host_dense { std::unique_ptr<DensifiedRepresentation> d; };
+// Generator and dense-representation objects hold device buffers that belong to their host's context (DBuf keeps a `const Dev*`), so the host
+// must outlive them: it is reference-counted by its children, and lasso_host_destroy only drops the caller's reference — the context goes away
+// with the last child (Python's GC may release the three in any order).
+struct lasso_host {
+  Dev dev; std::atomic<int> refs{1};
+  explicit lasso_host(int device) : dev(device) {}
+  void retain() { refs.fetch_add(1, std::memory_order_relaxed); }
+  void release() { if (refs.fetch_sub(1, std::memory_order_acq_rel) == 1) delete this; }
+};
+struct lasso_host_gens {
+  lasso_host* owner; std::unique_ptr<SparsePolyCommitmentGens> g;
+  lasso_host_gens(lasso_host* h, const char* label, size_t c, size_t s, size_t nm, size_t log_m) : owner(h) { g.reset(new SparsePolyCommitmentGens(h->dev, label, c, s, nm, log_m)); h->retain(); }
+  ~lasso_host_gens() { g.reset(); owner->release(); }
+};
+struct lasso_host_dense {
+  lasso_host* owner; std::unique_ptr<DensifiedRepresentation> d;
+  explicit lasso_host_dense(lasso_host* h) : owner(h) { h->retain(); }
+  ~lasso_host_dense() { d.reset(); owner->release(); }
+};
 
 static thread_local std::string g_err;
 #define GUARD(body) try { body } catch (const std::exception& e) { g_err = e.what(); return -1; } catch (...) { g_err = "unknown error"; return -1; }
@@ -15,21 +32,21 @@ static int32_t emit(const std::vector<uint8_t>& b, uint8_t* out, size_t cap, siz
 extern "C" {
 const char* lasso_host_last_error(void) { return g_err.c_str(); }
 int32_t lasso_host_create(int32_t device, lasso_host** out) { GUARD(*out = new lasso_host(device); return 0;) }
-void lasso_host_destroy(lasso_host* h) { delete h; }
+void lasso_host_destroy(lasso_host* h) { if (h) h->release(); }
 lasso_ctx* lasso_host_ctx(lasso_host* h) { return h ? h->dev.ctx : nullptr; }
 int32_t lasso_host_set_comm(lasso_host* h, int32_t rank, int32_t world, lasso_host_allgather_fn fn, void* user) {
   GUARD(
     if (!h || world < 1 || (world & (world - 1)) || rank < 0 || rank >= world || (world > 1 && !fn)) throw Error("lasso_host_set_comm: world must be a power of two, 0 <= rank < world, and a collective is needed when world > 1");
     h->dev.comm.rank = (size_t)rank; h->dev.comm.world = (size_t)world; h->dev.comm.fn = fn; h->dev.comm.user = user; return 0;)
 }
-int32_t lasso_host_gens_new(lasso_host* h, const char* label, size_t c, size_t s, size_t nm, size_t log_m, lasso_host_gens** out) { GUARD(*out = new lasso_host_gens(h->dev, label, c, s, nm, log_m); return 0;) }
+int32_t lasso_host_gens_new(lasso_host* h, const char* label, size_t c, size_t s, size_t nm, size_t log_m, lasso_host_gens** out) { GUARD(*out = new lasso_host_gens(h, label, c, s, nm, log_m); return 0;) }
 void lasso_host_gens_free(lasso_host_gens* g) { delete g; }
 int32_t lasso_host_densify(lasso_host* h, const uint64_t* indices, size_t n, size_t c, size_t log_m, lasso_host_dense** out) {
-  GUARD(auto* d = new lasso_host_dense(); d->d = DensifiedRepresentation::from_lookup_indices(h->dev, indices, n, c, log_m); *out = d; return 0;)
+  GUARD(std::unique_ptr<lasso_host_dense> d(new lasso_host_dense(h)); d->d = DensifiedRepresentation::from_lookup_indices(h->dev, indices, n, c, log_m); *out = d.release(); return 0;)
 }
 void lasso_host_dense_free(lasso_host_dense* d) { delete d; }
 int32_t lasso_host_commit(lasso_host_dense* d, lasso_host_gens* g, uint8_t* out, size_t cap, size_t* len) {
-  GUARD(SparsePolynomialCommitment c = d->d->commit(g->g); ProofWriter w; w.pts_vec(c.l_variate_polys_commitment.compressed); w.pts_vec(c.log_m_variate_polys_commitment.compressed); return emit(w.b, out, cap, len);)
+  GUARD(SparsePolynomialCommitment c = d->d->commit(*g->g); ProofWriter w; w.pts_vec(c.l_variate_polys_commitment.compressed); w.pts_vec(c.log_m_variate_polys_commitment.compressed); return emit(w.b, out, cap, len);)
 }
 int32_t lasso_host_prove(lasso_host* h, lasso_host_dense* d, lasso_host_gens* g, const lasso_strategy* st, const lasso_fr* r, size_t r_len, const char* tl, const char* pl,
                          uint8_t* out, size_t cap, size_t* len) {
@@ -37,8 +54,8 @@ int32_t lasso_host_prove(lasso_host* h, lasso_host_dense* d, lasso_host_gens* g,
     Strategy S(st->kind, st->c, st->log_m, st->log_r);
     ProofTranscript t(tl); RandomTape tape(pl);
     ScVec rv; for (size_t i = 0; i < r_len; i++) rv.push_back(Sc::from_abi(r[i]));
-    Prover P(h->dev, S, *d->d, g->g, t, tape);
-    P.prove(rv);
+    Prover P(h->dev, S, *d->d, *g->g, t, tape);
+    try { P.prove(rv); } catch (...) { h->dev.abort_all(); throw; }
     return emit(P.proof_bytes, out, cap, len);)
 }
 // Test support: Prover::prove_cubic_batched (sumcheck.rs:27-135 with C = EqPolynomial(rand).evals(), grand_product.rs:122-128) on caller-supplied
@@ -50,7 +67,7 @@ int32_t lasso_host_debug_cubic_batched(lasso_host* h, lasso_host_dense* dn, lass
   try {
     Strategy S(st->kind, st->c, st->log_m, st->log_r);
     ProofTranscript t(tl); RandomTape tape("unused");
-    Prover P(h->dev, S, *dn->d, g->g, t, tape);
+    Prover P(h->dev, S, *dn->d, *g->g, t, tape);
     const size_t n = (size_t)1 << ell;
     std::vector<DBuf> bufs; std::vector<lasso_fr*> pa, pb;
     for (size_t c = 0; c < 2 * k; c++) {

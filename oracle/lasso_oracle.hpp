@@ -18,6 +18,7 @@
 #include "ed25519.hpp"
 #endif
 #include "hashes.hpp"
+#include "par.hpp"
 #include <vector>
 #include <functional>
 #include <stdexcept>
@@ -184,7 +185,8 @@ inline Point msm(const std::vector<Point>& bases, const std::vector<Fr>& scalars
   std::vector<int64_t> scalar_digits; scalar_digits.reserve(size * digits_count);
   for (auto& b : bigints) { auto d = make_digits(b.data(), c, num_bits); scalar_digits.insert(scalar_digits.end(), d.begin(), d.end()); }
   std::vector<Point> window_sums(digits_count);
-  for (size_t i = 0; i < digits_count; i++) {
+  // windows are independent (ark-ec fans them out with cfg_into_iter!); sequential inside a row-parallel commit
+  par_for(digits_count, [&](size_t i) {
     std::vector<Point> buckets((size_t)1 << c, Point::identity());
     for (size_t k = 0; k < size; k++) {
       int64_t s = scalar_digits[k * digits_count + i];
@@ -194,7 +196,7 @@ inline Point msm(const std::vector<Point>& bases, const std::vector<Fr>& scalars
     Point running = Point::identity(), res = Point::identity();
     for (size_t b = buckets.size(); b-- > 0;) { running += buckets[b]; res += running; }
     window_sums[i] = res;
-  }
+  }, size >= 64 ? 2 : (size_t)-1);
   Point total = Point::identity();
   for (size_t i = digits_count; i-- > 1;) { total += window_sums[i]; for (size_t k = 0; k < c; k++) total = total.dbl(); }
   return window_sums[0] + total;
@@ -224,6 +226,11 @@ struct EqPolynomial {
     size_t size = 1;
     for (size_t j = 0; j < ell; j++) {
       size *= 2;
+      if (size >= 8192 && par_max_threads() > 1) {  // same values as the in-place reverse sweep below, read from a copy of the previous level
+        std::vector<Fr> prev(ev.begin(), ev.begin() + size / 2);
+        par_for(size / 2, [&](size_t k) { Fr hi = prev[k] * r[j]; ev[2 * k + 1] = hi; ev[2 * k] = prev[k] - hi; });
+        continue;
+      }
       for (size_t i = size; i-- > 0;) {
         if (i % 2 == 0) continue;  // (0..size).rev().step_by(2): i = size-1, size-3, ..., 1
         Fr scalar = ev[i / 2];
@@ -258,7 +265,7 @@ struct PolyCommitmentGens {
 typedef std::vector<Point> PolyCommitment;  // dense_mlpoly.rs:51-54 { C: Vec<G> }
 
 // ---------------------------------------------------------------- utils/mod.rs:64-73
-inline Fr compute_dotproduct(const Fr* a, const Fr* b, size_t n) { Fr s = Fr::zero(); for (size_t i = 0; i < n; i++) s += a[i] * b[i]; return s; }
+inline Fr compute_dotproduct(const Fr* a, const Fr* b, size_t n) { return par_sums<Fr>(n, 1, [&](size_t i, Fr* acc) { acc[0] += a[i] * b[i]; })[0]; }
 
 // ---------------------------------------------------------------- poly/dense_mlpoly.rs:28-279
 struct DensePolynomial {
@@ -284,20 +291,20 @@ struct DensePolynomial {
     auto lr = EqPolynomial::compute_factored_lens(ell);
     size_t L_size = pow2(lr.first), R_size = pow2(lr.second);
     ORC_ASSERT(L_size * R_size == n);
-    PolyCommitment C;
-    for (size_t i = 0; i < L_size; i++) C.push_back(batch_commit(&Z[R_size * i], R_size, Fr::zero(), gens.gens.gens_n));
+    PolyCommitment C(L_size);  // rows are independent MSMs over shared bases (the reference's par_iter, dense_mlpoly.rs:118-127)
+    par_for(L_size, [&](size_t i) { C[i] = batch_commit(&Z[R_size * i], R_size, Fr::zero(), gens.gens.gens_n); }, 2);
     return C;
   }
   std::vector<Fr> bound(const std::vector<Fr>& L) const {  // :184-207
     auto lr = EqPolynomial::compute_factored_lens(num_vars);
     size_t L_size = pow2(lr.first), R_size = pow2(lr.second);
     std::vector<Fr> out(R_size, Fr::zero());
-    for (size_t i = 0; i < R_size; i++) { Fr s = Fr::zero(); for (size_t j = 0; j < L_size; j++) s += L[j] * Z[j * R_size + i]; out[i] = s; }
+    par_for(R_size, [&](size_t i) { Fr s = Fr::zero(); for (size_t j = 0; j < L_size; j++) s += L[j] * Z[j * R_size + i]; out[i] = s; }, 64);
     return out;
   }
   void bound_poly_var_top(const Fr& r) {  // :209-216
     size_t n = len / 2;
-    for (size_t i = 0; i < n; i++) Z[i] = Z[i] + r * (Z[i + n] - Z[i]);
+    par_for(n, [&](size_t i) { Z[i] = Z[i] + r * (Z[i + n] - Z[i]); });
     num_vars -= 1; len = n;
   }
   void bound_poly_var_bot(const Fr& r) {  // :218-225
@@ -318,8 +325,8 @@ struct DensePolynomial {
     return DensePolynomial(std::move(Z));
   }
   static DensePolynomial from_usize(const std::vector<size_t>& v) {  // :263-269
-    std::vector<Fr> Z; Z.reserve(v.size());
-    for (size_t x : v) Z.push_back(Fr::from_u64((u64)x));
+    std::vector<Fr> Z(v.size());
+    par_for(v.size(), [&](size_t i) { Z[i] = Fr::from_u64((u64)v[i]); });
     return DensePolynomial(std::move(Z));
   }
 };
@@ -410,16 +417,15 @@ inline SumcheckInstanceProof prove_cubic_batched(const Fr& claim, size_t num_rou
     std::vector<Fr> e0(A.size()), e2(A.size()), e3(A.size());
     for (size_t c = 0; c < A.size(); c++) {
       const DensePolynomial& pa = *A[c]; const DensePolynomial& pb = *B[c];
-      Fr p0 = Fr::zero(), p2 = Fr::zero(), p3 = Fr::zero();
       size_t len = pa.len / 2;
-      for (size_t i = 0; i < len; i++) {
-        p0 += pa[i] * pb[i] * C[i];
+      auto p = par_sums<Fr>(len, 3, [&](size_t i, Fr* acc) {
+        acc[0] += pa[i] * pb[i] * C[i];
         Fr a2 = pa[len + i] + pa[len + i] - pa[i], b2 = pb[len + i] + pb[len + i] - pb[i], c2 = C[len + i] + C[len + i] - C[i];
-        p2 += a2 * b2 * c2;
+        acc[1] += a2 * b2 * c2;
         Fr a3 = a2 + pa[len + i] - pa[i], b3 = b2 + pb[len + i] - pb[i], c3 = c2 + C[len + i] - C[i];
-        p3 += a3 * b3 * c3;
-      }
-      e0[c] = p0; e2[c] = p2; e3[c] = p3;
+        acc[2] += a3 * b3 * c3;
+      });
+      e0[c] = p[0]; e2[c] = p[1]; e3[c] = p[2];
     }
     Fr c0 = Fr::zero(), c2 = Fr::zero(), c3 = Fr::zero();
     for (size_t i = 0; i < A.size(); i++) { c0 += e0[i] * coeffs[i]; c2 += e2[i] * coeffs[i]; c3 += e3[i] * coeffs[i]; }
@@ -443,19 +449,18 @@ inline SumcheckInstanceProof prove_arbitrary(size_t num_rounds, std::vector<Dens
   SumcheckInstanceProof proof;
   size_t alpha = polys.size();
   for (size_t round = 0; round < num_rounds; round++) {
-    std::vector<Fr> eval_points(combined_degree + 1, Fr::zero());
     size_t mle_half = polys[0].len / 2;
-    std::vector<Fr> lo(alpha), hi(alpha), cur(alpha);
-    for (size_t i = 0; i < mle_half; i++) {
-      for (size_t j = 0; j < alpha; j++) { lo[j] = polys[j][i]; hi[j] = polys[j][mle_half + i]; }
-      eval_points[0] += comb_func(lo.data());
-      eval_points[1] += comb_func(hi.data());
-      cur = hi;
+    ORC_ASSERT(alpha <= 64);
+    std::vector<Fr> eval_points = par_sums<Fr>(mle_half, combined_degree + 1, [&](size_t i, Fr* acc) {
+      Fr lo[64], hi[64], cur[64];
+      for (size_t j = 0; j < alpha; j++) { lo[j] = polys[j][i]; hi[j] = polys[j][mle_half + i]; cur[j] = hi[j]; }
+      acc[0] += comb_func(lo);
+      acc[1] += comb_func(hi);
       for (size_t k = 2; k <= combined_degree; k++) {
         for (size_t j = 0; j < alpha; j++) cur[j] = cur[j] + hi[j] - lo[j];
-        eval_points[k] += comb_func(cur.data());
+        acc[k] += comb_func(cur);
       }
-    }
+    });
     UniPoly up = UniPoly::from_evals(eval_points);
     up.append_to_transcript(t, "poly");
     Fr r_j = t.challenge_scalar("challenge_nextround");
@@ -493,10 +498,9 @@ struct GrandProductCircuit {
     for (size_t i = 0; i + 1 < num_layers; i++) {  // compute_layer :20-36
       const DensePolynomial& L = left_vec[i]; const DensePolynomial& R = right_vec[i];
       size_t len = L.len + R.len;
-      std::vector<Fr> ol, orr;
-      for (size_t k = 0; k < len / 4; k++) ol.push_back(L[k] * R[k]);
-      for (size_t k = len / 4; k < len / 2; k++) orr.push_back(L[k] * R[k]);
-      left_vec.push_back(DensePolynomial(ol)); right_vec.push_back(DensePolynomial(orr));
+      std::vector<Fr> ol(len / 4), orr(len / 4);
+      par_for(len / 4, [&](size_t k) { ol[k] = L[k] * R[k]; orr[k] = L[len / 4 + k] * R[len / 4 + k]; });
+      left_vec.push_back(DensePolynomial(std::move(ol))); right_vec.push_back(DensePolynomial(std::move(orr)));
     }
   }
   Fr evaluate() const {  // :60-65
@@ -566,7 +570,7 @@ inline void bgpa_verify(const BatchedGrandProductArgument& p, const std::vector<
 
 // ---------------------------------------------------------------- subprotocols/bullet.rs:23-275
 struct BulletReductionProof { std::vector<Point> L_vec, R_vec; };
-inline Fr inner_product(const Fr* a, const Fr* b, size_t n) { Fr o = Fr::zero(); for (size_t i = 0; i < n; i++) o += a[i] * b[i]; return o; }
+inline Fr inner_product(const Fr* a, const Fr* b, size_t n) { return compute_dotproduct(a, b, n); }
 struct BulletOut { BulletReductionProof proof; Point Gamma_hat; Fr a_hat, b_hat; Point g_hat; Fr blind_fin; };
 inline BulletOut bullet_prove(ProofTranscript& t, const Point& Q, const std::vector<Point>& G_vec, const Point& H, const std::vector<Fr>& a_vec,
                               const std::vector<Fr>& b_vec, const Fr& blind, const std::vector<std::pair<Fr, Fr>>& blinds_vec) {  // prove :40-154
@@ -588,11 +592,11 @@ inline BulletOut bullet_prove(ProofTranscript& t, const Point& Q, const std::vec
     Point R = msm(bs, sc);
     t.append_point("L", L); t.append_point("R", R);
     Fr u = t.challenge_scalar("u"), u_inv = u.inverse();
-    for (size_t i = 0; i < n; i++) {
+    par_for(n, [&](size_t i) {
       a[i] = a[i] * u + u_inv * a[n + i];
       b[i] = b[i] * u_inv + u * b[n + i];
       G[i] = G[i] * u_inv + G[n + i] * u;
-    }
+    }, 8);
     blind_fin = blind_fin + blind_L * u * u + blind_R * u_inv * u_inv;
     out.proof.L_vec.push_back(L); out.proof.R_vec.push_back(R);
   }
@@ -859,12 +863,13 @@ struct GrandProducts {
     auto hash_func = [&](const Fr& a, const Fr& v, const Fr& t) { return t * g2 + v * gamma + a - tau; };  // :252
     ORC_ASSERT(eval_table.size() == final_i.len);
     size_t cells = eval_table.size();
-    std::vector<Fr> vi, vf, vr, vw;
-    for (size_t i = 0; i < cells; i++) vi.push_back(hash_func(Fr::from_u64(i), eval_table[i], Fr::zero()));
-    for (size_t i = 0; i < cells; i++) vf.push_back(hash_func(Fr::from_u64(i), eval_table[i], final_i[i]));
     ORC_ASSERT(dim_i.len == read_i.len);
-    for (size_t i = 0; i < dim_i.len; i++) vr.push_back(hash_func(dim_i[i], eval_table[dim_i_usize[i]], read_i[i]));
-    for (size_t i = 0; i < dim_i.len; i++) vw.push_back(hash_func(dim_i[i], eval_table[dim_i_usize[i]], read_i[i] + Fr::one()));
+    std::vector<Fr> vi(cells), vf(cells), vr(dim_i.len), vw(dim_i.len);
+    par_for(cells, [&](size_t i) { vi[i] = hash_func(Fr::from_u64(i), eval_table[i], Fr::zero()); vf[i] = hash_func(Fr::from_u64(i), eval_table[i], final_i[i]); });
+    par_for(dim_i.len, [&](size_t i) {
+      vr[i] = hash_func(dim_i[i], eval_table[dim_i_usize[i]], read_i[i]);
+      vw[i] = hash_func(dim_i[i], eval_table[dim_i_usize[i]], read_i[i] + Fr::one());
+    });
     gi = DensePolynomial(vi); gr = DensePolynomial(vr); gw = DensePolynomial(vw); gf = DensePolynomial(vf);
   }
   GrandProducts(const DensePolynomial& gi, const DensePolynomial& gr, const DensePolynomial& gw, const DensePolynomial& gf) : init(gi), read(gr), write(gw), final_(gf) {}
@@ -877,11 +882,11 @@ struct Subtables {
     for (auto& d : nz) ORC_ASSERT(d.size() == s);
     subtable_entries = S.materialize_subtables();
     for (size_t i = 0; i < S.num_memories(); i++) {
-      std::vector<Fr> lookups; lookups.reserve(s);
+      std::vector<Fr> lookups(s);
       const auto& sub = subtable_entries[S.memory_to_subtable_index(i)];
       const auto& idx = nz[S.memory_to_dimension_index(i)];
-      for (size_t j = 0; j < s; j++) lookups.push_back(sub[idx[j]]);
-      lookup_polys.push_back(DensePolynomial(lookups));
+      par_for(s, [&](size_t j) { lookups[j] = sub[idx[j]]; });
+      lookup_polys.push_back(DensePolynomial(std::move(lookups)));
     }
     combined_poly = DensePolynomial::merge(lookup_polys);
   }
@@ -901,9 +906,9 @@ struct Subtables {
     size_t hyper = lookup_polys[0].len;
     for (auto& p : lookup_polys) ORC_ASSERT(p.len == hyper);
     auto eq_evals = eq.evals();
-    Fr claim = Fr::zero(); std::vector<Fr> ops(S.num_memories());
-    for (size_t k = 0; k < hyper; k++) { for (size_t j = 0; j < ops.size(); j++) ops[j] = lookup_polys[j][k]; claim += eq_evals[k] * S.combine_lookups(ops.data()); }
-    return claim;
+    size_t nm = S.num_memories();
+    ORC_ASSERT(nm <= 64);
+    return par_sums<Fr>(hyper, 1, [&](size_t k, Fr* acc) { Fr ops[64]; for (size_t j = 0; j < nm; j++) ops[j] = lookup_polys[j][k]; acc[0] += eq_evals[k] * S.combine_lookups(ops); })[0];
   }
 };
 inline void append_combined_table_commitment(ProofTranscript& t, const char* label, const PolyCommitment& c) {  // :382-393

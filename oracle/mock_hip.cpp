@@ -57,8 +57,10 @@ int32_t lasso_download(lasso_ctx*, void* d, const void* s, size_t n) { memcpy(d,
 int32_t lasso_copy(lasso_ctx*, void* d, const void* s, size_t n) { memmove(d, s, n); return 0; }
 int32_t lasso_zero(lasso_ctx*, void* d, size_t n) { memset(d, 0, n); return 0; }
 int32_t lasso_sync(lasso_ctx*) { return 0; }
+int32_t lasso_abort(lasso_ctx* c) { REQ(c, c); c->pending.clear(); c->defer = false; c->tail_a.clear(); c->tail_b.clear(); c->tail_e.clear(); c->mid_a.clear(); c->mid_b.clear(); return 0; }
 int32_t lasso_prof_get_large(lasso_ctx*, int32_t, uint64_t* n, double* ms, double* b) { if (n) *n = 0; if (ms) *ms = 0; if (b) *b = 0; return 0; }
 int32_t lasso_wait_stats(lasso_ctx*, uint64_t* w, double* us, int32_t) { if (w) *w = 0; if (us) *us = 0; return 0; }
+int32_t lasso_prof_get_units(lasso_ctx*, int32_t, int32_t, double* u) { if (u) *u = 0; return 0; }
 int32_t lasso_prof_enable(lasso_ctx*, int32_t) { return 0; }
 int32_t lasso_prof_reset(lasso_ctx*) { return 0; }
 int32_t lasso_prof_get(lasso_ctx*, int32_t, uint64_t* l, double* ms, double* b) { if (l) *l = 0; if (ms) *ms = 0; if (b) *b = 0; return 0; }

@@ -178,8 +178,15 @@ int orc_verify_only(int kind, size_t C, size_t M, size_t log_r, size_t s, const 
   MerlinTranscript t("example");
   return surge_verify(S, P, c, r, gens, t) ? 1 : 0; ) }
 
-// ---- timing leg for bench.py cpu_baseline ("port"): harness inputs, serial single-thread
-int orc_bench(int kind, size_t C, size_t M, size_t log_r, size_t s, double* t_densify, double* t_commit, double* t_prove, int do_verify) { GUARD(
+// ---- threads (par.hpp): the oracle's data-parallel loops run on OpenMP; bytes never depend on the count
+int orc_max_threads() { return par_max_threads(); }
+void orc_set_threads(int n) { par_set_threads(n); }
+
+// ---- timing leg for bench.py cpu_baseline ("port"): harness inputs, on the threads set by orc_set_threads / OMP_NUM_THREADS.
+// proof_out / comm_out (optional, may be null): the serialized proof and commitment (orc_session_commit's layout), so the
+// caller can compare them byte for byte with the GPU prover's output on the same instance.
+int orc_bench_bytes(int kind, size_t C, size_t M, size_t log_r, size_t s, double* t_densify, double* t_commit, double* t_prove, int do_verify,
+                    uint8_t* proof_out, size_t proof_cap, size_t* proof_len, uint8_t* comm_out, size_t comm_cap, size_t* comm_len) { GUARD(
   using clk = std::chrono::steady_clock;
   Strategy S = mk_strategy(kind, C, M, log_r);
   size_t log_m = ark_log2(M);
@@ -197,7 +204,14 @@ int orc_bench(int kind, size_t C, size_t M, size_t log_r, size_t s, double* t_de
   *t_densify = std::chrono::duration<double>(t1 - t0).count();
   *t_commit = std::chrono::duration<double>(t2 - t1).count();
   *t_prove = std::chrono::duration<double>(t3 - t2).count();
+  if (proof_out) { auto b = serialize_proof(P); *proof_len = b.size(); if (b.size() > proof_cap) return -2; memcpy(proof_out, b.data(), b.size()); }
+  if (comm_out) {
+    ByteWriter w; w.pts_vec(commitment.l_variate_polys_commitment); w.pts_vec(commitment.log_m_variate_polys_commitment);
+    *comm_len = w.b.size(); if (w.b.size() > comm_cap) return -2; memcpy(comm_out, w.b.data(), w.b.size());
+  }
   if (do_verify) { MerlinTranscript tv("example"); if (!surge_verify(S, P, commitment, r, gens, tv)) { g_err = "verify failed"; return -3; } }
   return 0; ) }
+int orc_bench(int kind, size_t C, size_t M, size_t log_r, size_t s, double* t_densify, double* t_commit, double* t_prove, int do_verify) {
+  return orc_bench_bytes(kind, C, M, log_r, s, t_densify, t_commit, t_prove, do_verify, nullptr, 0, nullptr, nullptr, 0, nullptr); }
 
 }  // extern "C"

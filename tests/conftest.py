@@ -18,20 +18,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
 
 
+def _make_oracle(name):
+    """make decides staleness (oracle/Makefile lists every header, par.hpp included)"""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), name])
+    return os.path.join(ROOT, "oracle", name)
+
+
 def _build_oracle():
-    so = os.path.join(ROOT, "oracle", "liblasso_oracle.so")
-    srcs = [os.path.join(ROOT, "oracle", f) for f in ("oracle_capi.cpp", "kats.cpp", "lasso_oracle.hpp", "ff.hpp", "ed25519.hpp", "hashes.hpp")]
-    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
-        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "liblasso_oracle.so"])
-    return so
+    return _make_oracle("liblasso_oracle.so")
 
 
 def _build_oracle_bn254():
-    so = os.path.join(ROOT, "oracle", "liblasso_oracle_bn254.so")
-    srcs = [os.path.join(ROOT, "oracle", f) for f in ("oracle_capi.cpp", "kats.cpp", "lasso_oracle.hpp", "ff.hpp", "bn254.hpp", "hashes.hpp")]
-    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
-        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "liblasso_oracle_bn254.so"])
-    return so
+    return _make_oracle("liblasso_oracle_bn254.so")
 
 
 def _load_oracle(path):

@@ -66,6 +66,22 @@ class OracleSession:
             self.o.orc_session_free(C.c_void_p(self.s)); self.s = None
 
 
+def oracle_harness_proof(oracle, kind, c, log_m, log_r, log_s, threads=0, verify=False):
+    """The oracle's densify -> commit -> prove on the reference harness's inputs (benches/bench.rs:13-34: gen_indices / gen_random_point from a fresh
+    test_rng) on `threads` OpenMP threads (0 = all host cores; bytes do not depend on it, tests/test_oracle_parallel.py).
+    Returns (commitment bytes, proof bytes, {"densify_s", "commit_s", "prove_s", "threads"})."""
+    if threads:
+        oracle.orc_set_threads(threads)
+    td, tc, tp = C.c_double(), C.c_double(), C.c_double()
+    cap = 1 << 23
+    pb = (C.c_uint8 * cap)(); cb = (C.c_uint8 * cap)(); pl = C.c_size_t(); cl = C.c_size_t()
+    rc = oracle.orc_bench_bytes(kind, C.c_size_t(c), C.c_size_t(1 << log_m), C.c_size_t(log_r), C.c_size_t(1 << log_s), C.byref(td), C.byref(tc), C.byref(tp),
+                                1 if verify else 0, pb, C.c_size_t(cap), C.byref(pl), cb, C.c_size_t(cap), C.byref(cl))
+    if rc != 0:
+        raise RuntimeError(oracle.orc_last_error().decode())
+    return bytes(cb[: cl.value]), bytes(pb[: pl.value]), {"densify_s": td.value, "commit_s": tc.value, "prove_s": tp.value, "threads": oracle.orc_max_threads()}
+
+
 def cubic_batched_case(host, oracle, k, ell, special, seed):
     """prove_cubic_batched with a scripted eq point: the host prover's eq-weighted two-sum rounds (device ABI) against the oracle's literal
     three-polynomial loop (sumcheck.rs:27-135).  `special` maps round -> 0 or 1: rand_t = 0 disables the claim-derived evaluation (three-sum

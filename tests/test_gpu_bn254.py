@@ -73,6 +73,26 @@ def test_gpu_bn254_baseline_config1_full_size(host, oracle_bn254):
     assert o.orc_verify_only(_abi.KINDS[kind], c, 1 << log_m, log_r, s, rr.ctypes.data_as(C.c_void_p), bytes(bad), len(bad), comm, len(comm)) != 1
 
 
+def test_gpu_bn254_config1_bit_exact_at_full_size(host, oracle_bn254):
+    """BASELINE.json configs[1] as written (AND, C = 4, log_M = 16, 2^20 lookups, G = BN254): commitment and proof BYTES identical to the oracle
+    prover's on the harness inputs (the oracle runs on all host cores; bytes independent of the thread count)."""
+    from proverutil import oracle_harness_proof
+    kind, c, log_m, log_r, log_s = "and", 4, 16, 0, 20
+    s = 1 << log_s
+    idx = host.gen_indices(s, 1 << log_m, c)
+    r = host.gen_random_point(log_s)
+    S = _abi.Strategy(_abi.KINDS[kind], c, log_m, log_r)
+    gens = host.gens(c, s, c, log_m)
+    dense = host.densify(idx, log_m)
+    comm = host.commit(dense, gens)
+    proof = host.prove(dense, gens, S, r)
+    host.free(dense, gens)
+    o_comm, o_proof, tm = oracle_harness_proof(oracle_bn254, _abi.KINDS[kind], c, log_m, log_r, log_s)
+    print(f"\n[oracle bn254] AND C=4 2^20: {tm['threads']} threads, commit {tm['commit_s']:.1f}s prove {tm['prove_s']:.1f}s")
+    assert comm == o_comm
+    assert proof == o_proof
+
+
 def test_gpu_bn254_kernel_parity_suite():
     """Every entry point of the BN254 library against the BN254 mock: tests/test_gpu_kernels.py re-run in a child process with LASSO_TEST_CURVE=bn254
     (the switch is read at import time by tests/fieldref.py, so it cannot share this process)."""

@@ -677,6 +677,34 @@ def test_densify_rejects_out_of_range(devs):
         d.free(p)
 
 
+def test_densify_far_out_of_range_stays_in_bounds(devs):
+    """an index far beyond M used to reach the sort / run kernels as a key and index 2*m words of scratch with it (device writes GiBs out of
+    bounds).  The key is clamped when flagged: the call must fail with the documented error AND leave the context usable — the same context then
+    densifies a valid sequence bit-exactly."""
+    d = devs[0]
+    log_m, n = 8, 1 << 12
+    m = 1 << log_m
+    rng = np.random.default_rng(5)
+    good = rng.integers(0, m, size=(n, 1), dtype=np.uint64)
+    bad = good.copy(); bad[17, 0] = (1 << 40) + 3; bad[n - 1, 0] = (1 << 63); bad[100, 0] = 0xFFFFFFFF
+    p_u32 = d.alloc(4 * n); p_dim = d.alloc(32 * n); p_read = d.alloc(32 * n); p_fin = d.alloc(32 * m)
+    p_bad = d.upload(bad)
+    with pytest.raises(Exception):
+        d.densify_dim(p_bad, n, 1, 0, n, log_m, p_u32, p_dim, p_read, p_fin)
+    p_good = d.upload(good)
+    d.densify_dim(p_good, n, 1, 0, n, log_m, p_u32, p_dim, p_read, p_fin)
+    got_read = d.download(p_read, (n, 4)); got_u32 = d.download(p_u32, (n,), dtype=np.uint32)
+    assert np.array_equal(got_u32.astype(np.uint64), good[:, 0])
+    counts = np.zeros(m, dtype=np.int64); want = np.zeros(n, dtype=np.int64)
+    for k in range(n):
+        want[k] = counts[good[k, 0]]; counts[good[k, 0]] += 1
+    Rinv = pow(1 << 256, -1, FR_P)
+    for k in (0, 1, 17, 100, n - 1):
+        assert int.from_bytes(got_read[k].tobytes(), "little") * Rinv % FR_P == want[k]
+    for p in (p_bad, p_good, p_u32, p_dim, p_read, p_fin):
+        d.free(p)
+
+
 @pytest.mark.parametrize("ls,rs", [(1, 1), (4, 8), (64, 300), (512, 1024)])
 def test_matvec_left_dev_and_to_bytes(devs, ls, rs):
     """device-resident forms of the opening's mat-vec and of CanonicalSerialize: equal to the host-result forms / to the canonical integers"""

@@ -54,3 +54,20 @@ def test_chacha20_rfc7539_block(oracle):
     a = (a + b) & 0xFFFFFFFF; d = rotl(d ^ a, 16); c = (c + d) & 0xFFFFFFFF; b = rotl(b ^ c, 12)
     a = (a + b) & 0xFFFFFFFF; d = rotl(d ^ a, 8); c = (c + d) & 0xFFFFFFFF; b = rotl(b ^ c, 7)
     assert (a, b, c, d) == (0xEA2A92F4, 0xCB1CF8CE, 0x4581472E, 0x5881C4BB)
+
+
+def test_chacha_published_vectors_8_12_20_rounds(oracle):
+    """draft-strombergson-chacha-test-vectors-01 (256-bit keys, IV = 0, first keystream block): TC1 (all-zero key) for 8, 12 and 20 rounds and
+    TC2 (key = 01 00 .. 00) for 12 rounds.  ark_std::test_rng() is rand_chacha's StdRng = ChaCha12 (ark-std 0.4 `test_rng`, rand 0.8), so the
+    12-round rows pin the oracle's `ChaChaRng(seed, 12)` block function to a PUBLISHED answer (round 1 had only the 20-round one)."""
+    tc1 = {8: "3e00ef2f895f40d67f5bb8e81f09a5a12c840ec3ce9a7f3b181be188ef711a1e984ce172b9216f419f445367456d5619314a42a3da86b001387bfdb80e0cfe42",
+           12: "9bf49a6a0755f953811fce125f2683d50429c3bb49e074147e0089a52eae155f0564f879d27ae3c02ce82834acfa8c793a629f2ca0de6919610be82f411326be",
+           20: "76b8e0ada0f13d90405d6ae55386bd28bdd219b8a08ded1aa836efcc8b770dc7da41597c5157488d7724e03fb8d84a376a43b8f41518a11cc387b669b2ee6586"}
+    for rounds, want in tc1.items():
+        out = (ctypes.c_uint32 * 16)()
+        oracle.orc_chacha_block(bytes(32), ctypes.c_uint64(0), rounds, out)
+        assert bytes(out).hex() == want
+    out = (ctypes.c_uint32 * 16)()
+    oracle.orc_chacha_block(bytes([1] + [0] * 31), ctypes.c_uint64(0), 12, out)
+    assert bytes(out).hex() == ("12056e595d56b0f6eef090f0cd25a20949248c2790525d0f930218ff0b4ddd10"
+                                "a6002239d9a454e29e107a7d06fefdfef0210feba044f9f29b1772c960dc29c0")

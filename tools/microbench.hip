@@ -7,6 +7,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <string>
+#include <cstring>
 #include "../lasso_amd/csrc/poly_kernels.cuh"
 #include "../lasso_amd/csrc/msm_kernels.cuh"
 
@@ -78,10 +80,66 @@ __global__ void k_tp_fqmul(fq_t* io, int iters) {
   fq_t r = fq_add(fq_add(a, b), fq_add(c, d));
   if (r.v[0] == 0x12345678u && r.v[1] == 0x9abcdef0u) io[blockIdx.x] = r;
 }
+#ifndef LASSO_BN254
 __global__ void k_tp_madd(ed_point* io, const ed_niels* nb, int iters) {
   ed_point p = io[threadIdx.x & 63]; ed_niels n0 = nb[threadIdx.x & 63];
   for (int i = 0; i < iters; i++) p = ed_madd(p, n0);
   if (p.X.v[0] == 0x12345678u && p.Y.v[1] == 0x9abcdef0u) io[blockIdx.x] = p;
+}
+#endif
+
+// the MSM kernels' own mixed addition (29-bit limbs: fe29.cuh, or bn254_fe29.cuh under -DLASSO_BN254): the ceiling roofline_msm is priced against
+__global__ void k_tp_ptmadd(pt29* io, const niels29* nb, int iters) {
+  pt29 p = io[threadIdx.x & 63]; const niels29 n0 = nb[threadIdx.x & 63];
+  for (int i = 0; i < iters; i++) p = pt_madd(p, n0);
+  if (p.X.v[0] == 0x12345678 && p.Y.v[1] == 0x1abcdef0) io[blockIdx.x] = p;
+}
+
+// ---- 5. streaming-ceiling exploration: cache policy (nt = non-temporal), loads in flight per lane, grid size
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+template <int LDNT, int STNT, int UNROLL>
+__global__ void __launch_bounds__(256) k_copy_v(const u32x4* __restrict__ src, u32x4* __restrict__ dst, size_t n16) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  for (; i + (UNROLL - 1) * stride < n16; i += UNROLL * stride) {
+    u32x4 v[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; u++) v[u] = LDNT ? __builtin_nontemporal_load(src + i + u * stride) : src[i + u * stride];
+#pragma unroll
+    for (int u = 0; u < UNROLL; u++) { if (STNT) __builtin_nontemporal_store(v[u], dst + i + u * stride); else dst[i + u * stride] = v[u]; }
+  }
+  for (; i < n16; i += stride) dst[i] = src[i];
+}
+template <int LDNT>
+__global__ void __launch_bounds__(256) k_read_v(const u32x4* __restrict__ src, size_t n16, uint32_t* out) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  u32x4 acc = {0, 0, 0, 0};
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n16; i += stride) { const u32x4 v = LDNT ? __builtin_nontemporal_load(src + i) : src[i]; acc ^= v; }
+  if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345679u) out[0] = 1;
+}
+template <int STNT>
+__global__ void __launch_bounds__(256) k_write_v(u32x4* __restrict__ dst, size_t n16) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const u32x4 v = {1u, 2u, 3u, (uint32_t)threadIdx.x};
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n16; i += stride) { if (STNT) __builtin_nontemporal_store(v, dst + i); else dst[i] = v; }
+}
+// k_bind_top with selectable cache policy on its two streams (in place, like the product kernel)
+template <int LDNT, int STNT>
+__global__ void __launch_bounds__(256) k_bind_pol(fr_t* __restrict__ z, size_t half, fr_t r) {
+  const fr29 rs = fr29_unpack_s(r);
+  u32x4* z4 = reinterpret_cast<u32x4*>(z);
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x) {
+    u32x4 l0, l1, h0, h1;
+    if (LDNT) { l0 = __builtin_nontemporal_load(z4 + 2 * i); l1 = __builtin_nontemporal_load(z4 + 2 * i + 1); h0 = __builtin_nontemporal_load(z4 + 2 * (i + half)); h1 = __builtin_nontemporal_load(z4 + 2 * (i + half) + 1); }
+    else { l0 = z4[2 * i]; l1 = z4[2 * i + 1]; h0 = z4[2 * (i + half)]; h1 = z4[2 * (i + half) + 1]; }
+    fr_t lo, hi;
+    lo.v[0] = l0.x; lo.v[1] = l0.y; lo.v[2] = l0.z; lo.v[3] = l0.w; lo.v[4] = l1.x; lo.v[5] = l1.y; lo.v[6] = l1.z; lo.v[7] = l1.w;
+    hi.v[0] = h0.x; hi.v[1] = h0.y; hi.v[2] = h0.z; hi.v[3] = h0.w; hi.v[4] = h1.x; hi.v[5] = h1.y; hi.v[6] = h1.z; hi.v[7] = h1.w;
+    const fr29 a = fr29_unpack_u(lo), b = fr29_unpack_u(hi);
+    const fr_t o = fr29_store(fr29_add(a, fr29_mul(fr29_sub(b, a), rs)));
+    const u32x4 o0 = {o.v[0], o.v[1], o.v[2], o.v[3]}, o1 = {o.v[4], o.v[5], o.v[6], o.v[7]};
+    if (STNT) { __builtin_nontemporal_store(o0, z4 + 2 * i); __builtin_nontemporal_store(o1, z4 + 2 * i + 1); } else { z4[2 * i] = o0; z4[2 * i + 1] = o1; }
+  }
 }
 
 // ---- 3. bandwidth kernels
@@ -126,12 +184,18 @@ __global__ void __launch_bounds__(256) k_bind_pairs(fr_t* __restrict__ z, size_t
   }
 }
 
+static bool want(int argc, char** argv, int sec) {   // microbench [sections]: e.g. `microbench 2,4,5`; no argument = 1..4 (section 5 only on request: it allocates up to 8 GiB)
+  if (argc < 2) return sec <= 4;
+  const std::string a = std::string(",") + argv[1] + ",";
+  return a.find("," + std::to_string(sec) + ",") != std::string::npos;
+}
 int main(int argc, char** argv) {
   hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
   printf("device: %s  CUs=%d  clock=%d MHz  memclk=%d MHz  L2=%d MB\n", prop.name, prop.multiProcessorCount, prop.clockRate / 1000, prop.memoryClockRate / 1000, prop.l2CacheSize >> 20);
   const int CU = prop.multiProcessorCount;
   uint32_t* d_out; CK(hipMalloc(&d_out, 4096));
 
+  if (want(argc, argv, 1)) {
   printf("\n== 1. instruction issue (wave-instructions per cycle per CU at 2.4 GHz nominal; 8 waves/SIMD resident)\n");
   struct { const char* name; void (*k)(uint32_t*, uint32_t); int per_op; } rates[] = {
       {"v_mad_u64_u32", k_rate_mad64, 1}, {"v_mul_lo_u32", k_rate_mullo, 1}, {"v_mul_hi_u32", k_rate_mulhi, 1}, {"v_mad_u32_u24", k_rate_mad24, 1},
@@ -145,6 +209,8 @@ int main(int argc, char** argv) {
     printf("  %-22s %8.3f ms  %8.2f G wave-instr/s  => %.2f cycles per wave-instr per SIMD (@2.4GHz)  lane-ops %.1f T/s\n", r.name, ms, per_s * 1e-9, (double)CU * 4 * 2.4e9 / per_s, per_s * 64e-12);
   }
 
+  }
+  if (want(argc, argv, 2)) {
   printf("\n== 2. multiplier throughput (G mult/s, whole chip)\n");
   {
     std::vector<fr_t> h(256); for (size_t i = 0; i < h.size(); i++) { h[i] = fr_from_u64(0x9e3779b97f4a7c15ull * (i + 1)); }
@@ -158,6 +224,7 @@ int main(int argc, char** argv) {
       ms = time_kernel([&] { hipLaunchKernelGGL(k_tp_fqmul, dim3(blocks), dim3(threads), 0, 0, (fq_t*)d, iters); });
       printf("  fq_mul (2^255-19 fold)          blocks/CU=%d: %8.3f ms  %7.1f G/s\n", wpb, ms, (double)blocks * threads * iters * 4 / (ms * 1e-3) * 1e-9);
     }
+#ifndef LASSO_BN254
     std::vector<ed_point> hp(64); std::vector<ed_niels> hn(64);
     for (int i = 0; i < 64; i++) { fq_t x = fq_zero(), y = fq_one(); hp[i] = ed_from_affine(x, y); fq_t a = fq_zero(); a.v[0] = 5 + i; hn[i].ypx = a; hn[i].ymx = fq_one(); hn[i].t2d = a; }
     ed_point* dp; ed_niels* dn; CK(hipMalloc(&dp, 65536 * sizeof(ed_point))); CK(hipMalloc(&dn, 64 * sizeof(ed_niels)));
@@ -165,9 +232,36 @@ int main(int argc, char** argv) {
     const int blocks = CU * 4, threads = 256, iters = 256;
     double ms = time_kernel([&] { hipLaunchKernelGGL(k_tp_madd, dim3(blocks), dim3(threads), 0, 0, dp, dn, iters); });
     printf("  ed_madd (7 fq_mul)              blocks/CU=4: %8.3f ms  %7.1f G madd/s\n", ms, (double)blocks * threads * iters / (ms * 1e-3) * 1e-9);
-    CK(hipFree(d)); CK(hipFree(dp)); CK(hipFree(dn));
+    CK(hipFree(dp)); CK(hipFree(dn));
+#endif
+    CK(hipFree(d));
+    // the kernels' own mixed addition in 29-bit limbs, at 1 / 2 / 4 workgroups of 256 threads per CU (the MSM kernels run 1 per CU: VGPR-heavy)
+    {
+      std::vector<pt29> hq(64); std::vector<niels29> hm(64);
+      const pt29 id = pt_identity();
+      for (int i = 0; i < 64; i++) { hq[i] = id; memset(&hm[i], 0, sizeof(niels29)); int32_t* w = reinterpret_cast<int32_t*>(&hm[i]); for (size_t k = 0; k < sizeof(niels29) / 4; k++) w[k] = (int32_t)((k * 2654435761u + i * 40503u) & 0x0fffffff); }
+      pt29* dq; niels29* dm; CK(hipMalloc(&dq, 65536 * sizeof(pt29))); CK(hipMalloc(&dm, 64 * sizeof(niels29)));
+      CK(hipMemcpy(dq, hq.data(), 64 * sizeof(pt29), hipMemcpyHostToDevice)); CK(hipMemcpy(dm, hm.data(), 64 * sizeof(niels29), hipMemcpyHostToDevice));
+      double best = 0; int best_w = 0;
+      for (int wpc : {1, 2, 4}) {
+        const int blocks2 = CU * wpc, iters2 = 256;
+        double ms2 = time_kernel([&] { hipLaunchKernelGGL(k_tp_ptmadd, dim3(blocks2), dim3(256), 0, 0, dq, dm, iters2); });
+        const double g = (double)blocks2 * 256 * iters2 / (ms2 * 1e-3) * 1e-9;
+        printf("  pt_madd (29-bit limbs, the MSM kernels' mixed addition) workgroups/CU=%d: %8.3f ms  %7.2f G madd/s\n", wpc, ms2, g);
+        if (g > best) { best = g; best_w = wpc; }
+      }
+#ifdef LASSO_BN254
+      const char* curve = "bn254";
+#else
+      const char* curve = "curve25519";
+#endif
+      printf("MADD_CEILING {\"curve\": \"%s\", \"G_madd_per_s\": %.2f, \"workgroups_per_cu\": %d, \"device\": \"%s\", \"CUs\": %d}\n", curve, best, best_w, prop.name, CU);
+      CK(hipFree(dq)); CK(hipFree(dm));
+    }
+  }
   }
 
+  if (want(argc, argv, 3)) {
   printf("\n== 3. bandwidth (GB/s); bind_top algorithmic bytes = 48*n (read 32n + write 16n)\n");
   for (int logn : {22, 24, 26}) {
     const size_t n = (size_t)1 << logn, half = n / 2;
@@ -209,11 +303,13 @@ int main(int argc, char** argv) {
   // alpha + 1 in {2, 5, 9, 17}), 3 warm-ups and 20 timed launches on buffers that are not bound in place repeatedly (a bind halves the live length, so every
   // launch binds the SAME full-length arrays: the upper halves are only read, the lower halves are rewritten — the traffic of a first bind every time).
   // Skipped when p * n * 32 bytes exceeds 160 GiB.
+  }
+  if (want(argc, argv, 4)) {
   printf("\n== 4. bind_top sweep (SURVEY 8d): algorithmic bytes 48 n p; 3 warm-ups + 20 timed launches\n");
   for (int logn : {20, 24, 26, 28}) {
     const size_t n = (size_t)1 << logn, half = n / 2;
     for (int p : {1, 2, 5, 9, 17}) {
-      if ((double)p * n * 32.0 > 160.0 * 1073741824.0) { printf("  n=2^%d p=%2d: skipped (%.0f GiB)\n", logn, p, p * n * 32.0 / 1073741824.0); continue; }
+      if ((double)p * n * 32.0 > 72.0 * 1073741824.0) { printf("  n=2^%d p=%2d: skipped (%.0f GiB)\n", logn, p, p * n * 32.0 / 1073741824.0); continue; }
       MutPtrTable T; bool ok = true;
       for (int k = 0; k < p; k++) { fr_t* z = nullptr; if (hipMalloc(&z, n * sizeof(fr_t)) != hipSuccess) { ok = false; T.p[k] = nullptr; break; } CK(hipMemset(z, 0x11 + k, n * sizeof(fr_t))); T.p[k] = z; }
       if (ok) {
@@ -230,6 +326,53 @@ int main(int argc, char** argv) {
       } else printf("  n=2^%d p=%2d: allocation failed, skipped\n", logn, p);
       for (int k = 0; k < p; k++) if (T.p[k]) CK(hipFree(T.p[k]));
     }
+  }
+  }
+  if (want(argc, argv, 5)) {
+  // Where is the streaming ceiling?  (copy16 tops out at 4.9-5.3 TB/s, the guide measures 6.29 TB/s for a float4 copy.)
+  printf("\n== 5. streaming ceiling: policy x loads in flight x grid x size (GB/s = bytes read + bytes written per second)\n");
+  for (size_t mib : {(size_t)128, (size_t)1024, (size_t)4096}) {
+    const size_t bytes = mib << 20, n16 = bytes / 16;
+    u32x4 *src, *dst; CK(hipMalloc(&src, bytes)); CK(hipMalloc(&dst, bytes)); CK(hipMemset(src, 0x5a, bytes)); CK(hipMemset(dst, 0, bytes));
+    for (int gm : {4, 8, 16, 32, 64}) {
+      const unsigned g = (unsigned)(CU * gm);
+      double a = time_kernel([&] { hipLaunchKernelGGL((k_copy_v<0, 0, 1>), dim3(g), dim3(256), 0, 0, (const u32x4*)src, dst, n16); });
+      double b = time_kernel([&] { hipLaunchKernelGGL((k_copy_v<1, 1, 1>), dim3(g), dim3(256), 0, 0, (const u32x4*)src, dst, n16); });
+      double c = time_kernel([&] { hipLaunchKernelGGL((k_copy_v<0, 0, 4>), dim3(g), dim3(256), 0, 0, (const u32x4*)src, dst, n16); });
+      double d = time_kernel([&] { hipLaunchKernelGGL((k_copy_v<1, 1, 4>), dim3(g), dim3(256), 0, 0, (const u32x4*)src, dst, n16); });
+      double e = time_kernel([&] { hipLaunchKernelGGL((k_copy_v<0, 1, 4>), dim3(g), dim3(256), 0, 0, (const u32x4*)src, dst, n16); });
+      double f = time_kernel([&] { hipLaunchKernelGGL((k_copy_v<1, 0, 4>), dim3(g), dim3(256), 0, 0, (const u32x4*)src, dst, n16); });
+      double h8 = time_kernel([&] { hipLaunchKernelGGL((k_copy_v<1, 1, 8>), dim3(g), dim3(256), 0, 0, (const u32x4*)src, dst, n16); });
+#define GBS(ms_) (2.0 * bytes / ((ms_) * 1e-3) * 1e-9)
+      printf("  copy %4zu MiB grid=CUx%-2d: plain u1 %6.0f | nt/nt u1 %6.0f | plain u4 %6.0f | nt/nt u4 %6.0f | ld plain st nt u4 %6.0f | ld nt st plain u4 %6.0f | nt/nt u8 %6.0f\n", mib, gm, GBS(a), GBS(b), GBS(c), GBS(d), GBS(e), GBS(f), GBS(h8));
+    }
+    for (int gm : {8, 32}) {
+      const unsigned g = (unsigned)(CU * gm);
+      double r0 = time_kernel([&] { hipLaunchKernelGGL((k_read_v<0>), dim3(g), dim3(256), 0, 0, (const u32x4*)src, n16, d_out); });
+      double r1 = time_kernel([&] { hipLaunchKernelGGL((k_read_v<1>), dim3(g), dim3(256), 0, 0, (const u32x4*)src, n16, d_out); });
+      double w0 = time_kernel([&] { hipLaunchKernelGGL((k_write_v<0>), dim3(g), dim3(256), 0, 0, dst, n16); });
+      double w1 = time_kernel([&] { hipLaunchKernelGGL((k_write_v<1>), dim3(g), dim3(256), 0, 0, dst, n16); });
+      printf("  %4zu MiB grid=CUx%-2d: read-only plain %6.0f nt %6.0f | write-only plain %6.0f nt %6.0f GB/s\n", mib, gm, bytes / (r0 * 1e-3) * 1e-9, bytes / (r1 * 1e-3) * 1e-9, bytes / (w0 * 1e-3) * 1e-9, bytes / (w1 * 1e-3) * 1e-9);
+    }
+    CK(hipFree(src)); CK(hipFree(dst));
+  }
+  for (int logn : {24, 26}) {
+    const size_t n = (size_t)1 << logn, half = n / 2;
+    fr_t* z; CK(hipMalloc(&z, n * sizeof(fr_t))); CK(hipMemset(z, 0x11, n * sizeof(fr_t)));
+    const fr_t r = fr_from_u64(0x123456789abcdefull);
+    MutPtrTable T; T.p[0] = z;
+    for (int gm : {8, 16, 32, 64}) {
+      size_t g = (half + 255) / 256; if (g > (size_t)CU * gm) g = (size_t)CU * gm;
+      double m0 = time_kernel([&] { hipLaunchKernelGGL(k_bind_top, dim3((unsigned)g, 1), dim3(256), 0, 0, T, half, r); });
+      double m1 = time_kernel([&] { hipLaunchKernelGGL((k_bind_pol<0, 0>), dim3((unsigned)g), dim3(256), 0, 0, z, half, r); });
+      double m2 = time_kernel([&] { hipLaunchKernelGGL((k_bind_pol<1, 0>), dim3((unsigned)g), dim3(256), 0, 0, z, half, r); });
+      double m3 = time_kernel([&] { hipLaunchKernelGGL((k_bind_pol<0, 1>), dim3((unsigned)g), dim3(256), 0, 0, z, half, r); });
+      double m4 = time_kernel([&] { hipLaunchKernelGGL((k_bind_pol<1, 1>), dim3((unsigned)g), dim3(256), 0, 0, z, half, r); });
+#define BGB(ms_) (48.0 * n / ((ms_) * 1e-3) * 1e-9)
+      printf("  bind n=2^%d grid=CUx%-2d: k_bind_top %6.0f | same, explicit 16B plain %6.0f | ld nt %6.0f | st nt %6.0f | ld nt + st nt %6.0f GB/s algorithmic\n", logn, gm, BGB(m0), BGB(m1), BGB(m2), BGB(m3), BGB(m4));
+    }
+    CK(hipFree(z));
+  }
   }
   printf("\ndone\n");
   return 0;
