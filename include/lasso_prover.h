@@ -51,6 +51,13 @@ int32_t lasso_host_prove(lasso_host* h, lasso_host_dense* d, lasso_host_gens* g,
  * and log2(s) field elements from a fresh test_rng() */
 void lasso_host_gen_indices(size_t sparsity, size_t memory_size, uint64_t* out);
 void lasso_host_gen_random_point(size_t bits, lasso_fr* out);
+/* SparsePolynomialEvaluationProof::verify(&commitment, &r, &gens, &mut transcript)  (src/lasso/surge.rs:214-271), over the proof's wire format
+ * (ark-serialize CanonicalSerialize, compressed — the bytes lasso_host_prove returns) and the commitment's (lasso_host_commit's layout).  The lookups
+ * are not needed: s = the (padded) number of lookups the commitment was made for.  The openings' two MSMs per proof run on the device; the rest is host
+ * arithmetic (lasso_amd/host/verifier.hpp).  Returns 0 and sets *ok to 1 (Ok(())) or 0 (Err(ProofVerifyError)); a proof that does not deserialize, or
+ * that trips one of the reference's assert!s on shapes, returns -1 with the reason in lasso_host_last_error(). */
+int32_t lasso_host_verify(lasso_host* h, lasso_host_gens* g, const lasso_strategy* strategy, size_t s, const lasso_fr* r, size_t r_len, const char* transcript_label,
+                          const uint8_t* proof, size_t proof_len, const uint8_t* commitment, size_t commitment_len, int32_t* ok);
 /* Test support (not part of the reference's surface): prove_cubic_batched (sumcheck.rs:27-135, C = EqPolynomial(rand).evals()) on caller-supplied
  * arrays with a scripted eq point, for the degenerate points (rand_t = 0 or 1) no transcript produces.  A, B: k contiguous arrays of 2^ell elements.
  * out = 3 compressed coefficients per round, the ell challenges, the k final claims of A, the k of B (32-byte canonical scalars). */

@@ -1,5 +1,6 @@
 // liblasso_prover.so — include/lasso_prover.h over lasso_amd/host/prover.hpp.  Nothing unwinds across the ABI.
 #include "prover.hpp"
+#include "verifier.hpp"
 #include <atomic>
 #include "../../include/lasso_prover.h"
 
@@ -57,6 +58,17 @@ int32_t lasso_host_prove(lasso_host* h, lasso_host_dense* d, lasso_host_gens* g,
     Prover P(h->dev, S, *d->d, *g->g, t, tape);
     try { P.prove(rv); } catch (...) { h->dev.abort_all(); throw; }
     return emit(P.proof_bytes, out, cap, len);)
+}
+int32_t lasso_host_verify(lasso_host* h, lasso_host_gens* g, const lasso_strategy* st, size_t s, const lasso_fr* r, size_t r_len, const char* tl,
+                          const uint8_t* proof, size_t proof_len, const uint8_t* commitment, size_t commitment_len, int32_t* ok) {
+  GUARD(
+    if (!h || !g || !st || !r || !proof || !commitment || !ok) throw Error("lasso_host_verify: null argument");
+    Strategy S(st->kind, st->c, st->log_m, st->log_r);
+    ProofTranscript t(tl);
+    ScVec rv; for (size_t i = 0; i < r_len; i++) rv.push_back(Sc::from_abi(r[i]));
+    Verifier V(h->dev, S, *g->g, t);
+    *ok = V.verify(proof, proof_len, commitment, commitment_len, s, st->log_m, rv) ? 1 : 0;
+    return 0;)
 }
 // Test support: Prover::prove_cubic_batched (sumcheck.rs:27-135 with C = EqPolynomial(rand).evals(), grand_product.rs:122-128) on caller-supplied
 // arrays with a SCRIPTED eq point, so that the eq points a transcript never produces (rand_t = 0: the claim-derived evaluation is unavailable;

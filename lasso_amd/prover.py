@@ -36,6 +36,7 @@ def declare_prover(lib):
     lib.lasso_host_dense_free.argtypes = [vp]
     lib.lasso_host_commit.argtypes = [vp, vp, vp, sz, C.POINTER(sz)]
     lib.lasso_host_prove.argtypes = [vp, vp, vp, C.POINTER(_abi.Strategy), vp, sz, C.c_char_p, C.c_char_p, vp, sz, C.POINTER(sz)]
+    lib.lasso_host_verify.argtypes = [vp, vp, C.POINTER(_abi.Strategy), sz, vp, sz, C.c_char_p, C.c_char_p, sz, C.c_char_p, sz, C.POINTER(i32)]
     lib.lasso_host_debug_cubic_batched.argtypes = [vp, vp, vp, C.POINTER(_abi.Strategy), sz, sz, vp, vp, vp, vp, vp, C.c_char_p, vp, sz, C.POINTER(sz)]
     lib.lasso_host_gen_indices.argtypes = [sz, sz, vp]
     lib.lasso_host_gen_random_point.argtypes = [sz, vp]
@@ -99,6 +100,14 @@ class HostProver:
     def prove(self, dense, gens, strategy, r, transcript=b"example", tape=b"proof"):
         r = np.ascontiguousarray(r, dtype=np.uint64).reshape(-1, 4)
         return self._bytes_call(self.lib.lasso_host_prove, self.h, dense, gens, C.byref(strategy), r.ctypes.data_as(C.c_void_p), r.shape[0], transcript, tape)
+
+    def verify(self, gens, strategy, s, r, proof, commitment, transcript=b"example"):
+        """SparsePolynomialEvaluationProof::verify (surge.rs:214-271) over the wire bytes: True = Ok(()), False = Err(ProofVerifyError); raises LassoError on bytes
+        that do not deserialize or on shapes the reference would assert on."""
+        r = np.ascontiguousarray(r, dtype=np.uint64).reshape(-1, 4)
+        ok = C.c_int32(-1)
+        self._chk(self.lib.lasso_host_verify(self.h, gens, C.byref(strategy), s, r.ctypes.data_as(C.c_void_p), r.shape[0], transcript, proof, len(proof), commitment, len(commitment), C.byref(ok)))
+        return ok.value == 1
 
     def debug_cubic_batched(self, dense, gens, strategy, A, B, rand, coeffs, claim, transcript=b"test"):
         """test support: prove_cubic_batched on caller arrays with a scripted eq point (lasso_host_debug_cubic_batched)"""

@@ -38,8 +38,10 @@ def test_gpu_bn254_proof_bit_exact_vs_oracle(host, oracle_bn254, kind, c, log_m,
     comm = host.commit(dense, gens)
     proof = host.prove(dense, gens, S, r)
     proof2 = host.prove(dense, gens, S, r)
+    accepted = host.verify(gens, S, s, r, proof, comm)      # product-side verifier, BN254 build
     host.free(dense, gens)
     assert proof == proof2
+    assert accepted is True
     orc = OracleSession(oracle_bn254, _abi.KINDS[kind], c, log_m, log_r, idx, r)
     try:
         assert comm == orc.commit()

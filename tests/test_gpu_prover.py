@@ -43,8 +43,15 @@ def test_gpu_proof_bit_exact_vs_oracle(host, oracle, kind, c, log_m, log_r, look
     comm = host.commit(dense, gens)
     proof = host.prove(dense, gens, S, r)
     proof2 = host.prove(dense, gens, S, r)      # prove() must not consume its inputs: a second proof is identical
+    accepted = host.verify(gens, S, s, r, proof, comm)      # the product-side verifier (surge.rs:214-271; its two MSMs per opening run on the device)
+    bad = bytearray(proof); bad[len(bad) // 3] ^= 0x20
+    try:
+        tampered = host.verify(gens, S, s, r, bytes(bad), comm)
+    except Exception:
+        tampered = False
     host.free(dense, gens)
     assert proof == proof2
+    assert accepted is True and tampered is False
     orc = OracleSession(oracle, _abi.KINDS[kind], c, log_m, log_r, idx, r)
     try:
         assert comm == orc.commit()
@@ -96,8 +103,18 @@ def test_baseline_config_full_size(host, oracle, kind, c, log_m, log_r, log_s):
     comm = host.commit(dense, gens)
     proof = host.prove(dense, gens, S, r)
     again = host.prove(dense, gens, S, r) if log_s <= 20 or c == 1 else proof
-    host.free(dense, gens)
+    host.free(dense)
+    import time
+    t0 = time.time(); accepted = host.verify(gens, S, s, r, proof, comm); tv = time.time() - t0      # product-side verifier at full size
+    badp = bytearray(proof); badp[len(badp) // 2] ^= 0x04
+    try:
+        tampered = host.verify(gens, S, s, r, bytes(badp), comm)
+    except Exception:
+        tampered = False
+    host.free(None, gens)
+    print(f"\n[verify] {kind} C={c} 2^{log_s}: product verifier {tv * 1e3:.0f} ms, proof {len(proof)} B")
     assert proof == again
+    assert accepted is True and tampered is False
     rr = np.ascontiguousarray(r, dtype=np.uint64)
     oracle.orc_verify_only.argtypes = [C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
     ok = oracle.orc_verify_only(_abi.KINDS[kind], c, 1 << log_m, log_r, s, rr.ctypes.data_as(C.c_void_p), proof, len(proof), comm, len(comm))
