@@ -79,13 +79,14 @@ def cpu_baseline(kind_id, c, log_m, log_r, log_s, log_s_1t, curve="curve25519"):
     so = "liblasso_oracle_bn254.so" if curve == "bn254" else "liblasso_oracle.so"
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), so])
     orc = C.CDLL(os.path.join(ROOT, "oracle", so))
+    orc.orc_set_threads(0)               # one thread per physical core (oracle_capi.cpp orc_set_threads)
     cores = orc.orc_max_threads()
     full = _oracle_run(orc, kind_id, c, log_m, log_r, log_s, cores, True)
     if not full:
         return None, None, None
     one = _oracle_run(orc, kind_id, c, log_m, log_r, min(log_s_1t, log_s), 1, False) if cores > 1 else None
     orc.orc_set_threads(cores)
-    out = {"value": (1 << log_s) / full["prove_s"], "unit": "lookups/s", "cores": cores, "kind": "port", "host_logical_cpus": os.cpu_count(),
+    out = {"value": (1 << log_s) / full["prove_s"], "unit": "lookups/s", "cores": cores, "kind": "port", "host_physical_cores": orc.orc_physical_cores(), "host_logical_cpus": os.cpu_count(),
            "sample": f"oracle (C++ restatement of the reference prover, OpenMP = the reference's rayon sites) SparsePoly.prove, kind={kind_id} C={c} M=2^{log_m} s=2^{log_s} "
                      f"on {cores} threads: {full['prove_s']:.2f}s (densify {full['densify_s']:.2f}s, commit {full['commit_s']:.2f}s)"}
     if one:

@@ -247,6 +247,22 @@ int32_t lasso_hyrax_commit_compressed(lasso_ctx* ctx, const lasso_fr* d_Z, size_
  * 32-byte elements to integers and its max-bit readback (msm/mod.rs:95-106 finds the same bound by scanning).  max_value >= every d_u32[i]. */
 int32_t lasso_hyrax_commit_compressed_u32(lasso_ctx* ctx, const uint32_t* d_u32, uint32_t max_value, size_t l_size, size_t r_size,
                                           const lasso_bases* bases, uint8_t* out32);
+
+/* ---- slab mode (ONE proof over the P GPUs of a node): the device-side exchange of the partial row commitments ---------------
+ * Each rank holds the columns = rank (mod P) of every Hyrax row and commits to them (lasso_hyrax_commit_rows_dev leaves the L partial row sums on the
+ * device, lasso_point_row_bytes() bytes each, in the kernels' own point form); the partials are all-gathered with RCCL on the context's stream
+ * (ncclAllGather of raw bytes over xGMI) and every rank adds the P partials of each row and compresses (lasso_points_reduce_compress).  No reference
+ * counterpart: the reference is single-process (its rows are rayon tasks, src/poly/dense_mlpoly.rs:118-127).
+ * librccl is loaded on first use (dlopen); LASSO_ERR_UNSUPPORTED when it is absent.  The unique id travels between the ranks by the caller's means
+ * (the host prover broadcasts it through its shared-memory segment). */
+int32_t lasso_rccl_unique_id(uint8_t out[128]);                                                   /* ncclGetUniqueId, rank 0 */
+int32_t lasso_rccl_init(lasso_ctx* ctx, int32_t rank, int32_t world, const uint8_t id[128]);      /* ncclCommInitRank on the context's device; collective */
+int32_t lasso_rccl_shutdown(lasso_ctx* ctx);                                                      /* ncclCommDestroy (also done by lasso_ctx_destroy) */
+int32_t lasso_rccl_ready(lasso_ctx* ctx);                                                         /* world size of the communicator, 0 = none */
+int32_t lasso_rccl_allgather(lasso_ctx* ctx, const void* d_send, void* d_recv, size_t bytes);     /* d_recv[g*bytes..) <- rank g's d_send; asynchronous on the stream */
+size_t lasso_point_row_bytes(void);
+int32_t lasso_hyrax_commit_rows_dev(lasso_ctx* ctx, const lasso_fr* d_Z, size_t l_size, size_t r_size, const lasso_bases* bases, void* d_rows);
+int32_t lasso_points_reduce_compress(lasso_ctx* ctx, const void* d_parts, uint32_t groups, size_t rows, uint8_t* out32);
 /* Subtable `sub` of the strategy as 32-bit integers, 2^log_m entries (SubtableStrategy::materialize_subtables: and.rs:16-28, or.rs, xor.rs,
  * lt.rs:17-44 (0 = LT, 1 = EQ), range_check.rs:19-51 (0 = full, 1 = remainder below 2^(LOG_R mod log_m), 2 = zeros)), written by the device. */
 int32_t lasso_materialize_subtable_u32(lasso_ctx* ctx, const lasso_strategy* strategy, uint32_t sub, uint32_t* d_out);

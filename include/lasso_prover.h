@@ -36,6 +36,10 @@ lasso_ctx* lasso_host_ctx(lasso_host* h);   /* the device context, e.g. for lass
  * produces).  world = 1 restores the single-GPU path. */
 typedef int32_t (*lasso_host_allgather_fn)(void* user, const void* send, void* recv, size_t bytes);
 int32_t lasso_host_set_comm(lasso_host* h, int32_t rank, int32_t world, lasso_host_allgather_fn allgather, void* user);
+/* The same with the library's own intra-node exchange instead of a callback: the P ranks of one node (one process per GPU) meet in the POSIX
+ * shared-memory segment `name` ("/..." — identical on every rank) and all-gather their per-round partial sums through it (lasso_amd/host/shm_comm.hpp):
+ * about a microsecond per exchange, nothing of the embedding language in the loop.  Must precede gens_new / densify, like lasso_host_set_comm. */
+int32_t lasso_host_set_comm_shm(lasso_host* h, int32_t rank, int32_t world, const char* name);
 
 int32_t lasso_host_gens_new(lasso_host* h, const char* label, size_t c, size_t s, size_t num_memories, size_t log_m, lasso_host_gens** out);
 void lasso_host_gens_free(lasso_host_gens* g);

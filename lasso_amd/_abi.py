@@ -76,6 +76,14 @@ def declare(lib):
         "lasso_hyrax_commit": (i32, [vp, vp, sz, sz, vp, vp]),
         "lasso_hyrax_commit_compressed": (i32, [vp, vp, sz, sz, vp, vp]),
         "lasso_hyrax_commit_compressed_u32": (i32, [vp, vp, u32, sz, sz, vp, vp]),
+        "lasso_rccl_unique_id": (i32, [vp]),
+        "lasso_rccl_init": (i32, [vp, i32, i32, vp]),
+        "lasso_rccl_ready": (i32, [vp]),
+        "lasso_rccl_shutdown": (i32, [vp]),
+        "lasso_rccl_allgather": (i32, [vp, vp, vp, sz]),
+        "lasso_point_row_bytes": (sz, []),
+        "lasso_hyrax_commit_rows_dev": (i32, [vp, vp, sz, sz, vp, vp]),
+        "lasso_points_reduce_compress": (i32, [vp, vp, u32, sz, vp]),
         "lasso_gather_u32": (i32, [vp, vp, vp, sz, vp]),
         "lasso_materialize_subtable_u32": (i32, [vp, P(Strategy), u32, vp]),
         "lasso_msm": (i32, [vp, vp, vp, sz, vp]),

@@ -54,6 +54,7 @@ struct lasso_ctx {
   uint64_t big_launches[LASSO_K_COUNT] = {0}; double big_ms[LASSO_K_COUNT] = {0}; double big_bytes[LASSO_K_COUNT] = {0};
   // family-specific work units beside the bytes (the MSM families: group additions of the reference's algorithm), all / large launches
   double prof_units[LASSO_K_COUNT] = {0}; double big_units[LASSO_K_COUNT] = {0};
+  void* rccl_comm = nullptr; int rccl_world = 0;   // slab mode's device-side exchange (lasso_rccl_*): an ncclComm_t bound to this context's device and stream
 };
 struct lasso_bases { size_t n = 0; niels29* d_table = nullptr; niels29* d_mult = nullptr; };   // d_mult: signed digit multiples for the latency-shaped MSM (k_msm_direct), optional
 
@@ -149,7 +150,91 @@ static int32_t fetch_small(lasso_ctx* c, size_t count, lasso_fr* out) {
   return wait_flag(c, seq, count, out);
 }
 
+// ------------------------------------------------------------------ RCCL over xGMI: the bulk exchange of slab mode (one proof over the P GPUs of a node)
+// Each rank commits to ITS columns of every Hyrax row; the L partial row sums per rank are all-gathered on the context's stream (ncclAllGather of raw
+// bytes: RCCL cannot add curve points) and every rank adds the P partials of each row itself (k_points_reduce_compress) — the north star's "RCCL reduce
+// over xGMI for partial bucket sums".  librccl is resolved with dlopen the first time a communicator is asked for, so single-GPU use never loads it.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+struct RcclApi {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+static RcclApi* rccl_api(std::string* why) {
+  static RcclApi api; static bool tried = false; static std::string err;
+  if (!tried) {
+    tried = true;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { api.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL); if (api.lib) break; }
+    if (!api.lib) err = std::string("librccl not found: ") + dlerror();
+    else {
+      api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.lib, "ncclGetUniqueId"); api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.lib, "ncclCommInitRank");
+      api.AllGather = (decltype(api.AllGather))dlsym(api.lib, "ncclAllGather"); api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.lib, "ncclCommDestroy");
+      api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.lib, "ncclGetErrorString");
+      if (!api.GetUniqueId || !api.CommInitRank || !api.AllGather || !api.CommDestroy || !api.GetErrorString) { err = "librccl lacks an expected symbol"; api.lib = nullptr; }
+    }
+  }
+  if (!api.lib) { if (why) *why = err; return nullptr; }
+  return &api;
+}
+static void rccl_release(lasso_ctx* c) { if (c->rccl_comm) { RcclApi* a = rccl_api(nullptr); if (a) (void)a->CommDestroy((ncclComm_t)c->rccl_comm); c->rccl_comm = nullptr; c->rccl_world = 0; } }
+// one thread per row: sum of the P ranks' partial row commitments, then ark-serialize's compressed form (32 bytes per row)
+__global__ void __launch_bounds__(256) k_points_reduce_compress(const pt29* __restrict__ parts, uint32_t groups, size_t rows, uint32_t* __restrict__ out32) {
+  const fe29 d2 = fe_d2();
+  for (size_t row = blockIdx.x * (size_t)blockDim.x + threadIdx.x; row < rows; row += (size_t)gridDim.x * blockDim.x) {
+    pt29 acc = parts[row];
+    for (uint32_t g = 1; g < groups; g++) acc = pt_add(acc, parts[(size_t)g * rows + row], d2);
+    pt_compress(acc, out32 + 8 * row);
+  }
+}
+
 extern "C" {
+
+// ---- slab mode's device-side exchange
+int32_t lasso_rccl_unique_id(uint8_t out[128]) {
+  std::string why; RcclApi* a = rccl_api(&why);
+  if (!a) return fail(nullptr, LASSO_ERR_UNSUPPORTED, why);
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId size");
+  ncclUniqueId id; ncclResult_t r = a->GetUniqueId(&id);
+  if (r != ncclSuccess) return fail(nullptr, LASSO_ERR_HIP, std::string("ncclGetUniqueId: ") + a->GetErrorString(r));
+  memcpy(out, &id, 128); return 0;
+}
+int32_t lasso_rccl_init(lasso_ctx* c, int32_t rank, int32_t world, const uint8_t id[128]) {
+  REQUIRE(c, id && world >= 1 && rank >= 0 && rank < world && !c->rccl_comm);
+  std::string why; RcclApi* a = rccl_api(&why);
+  if (!a) return fail(c, LASSO_ERR_UNSUPPORTED, why);
+  ncclUniqueId uid; memcpy(&uid, id, 128);
+  ncclComm_t comm = nullptr; ncclResult_t r = a->CommInitRank(&comm, world, uid, rank);
+  if (r != ncclSuccess) return fail(c, LASSO_ERR_HIP, std::string("ncclCommInitRank: ") + a->GetErrorString(r));
+  c->rccl_comm = comm; c->rccl_world = world; return 0;
+}
+int32_t lasso_rccl_ready(lasso_ctx* c) { return c && c->rccl_comm ? c->rccl_world : 0; }
+int32_t lasso_rccl_shutdown(lasso_ctx* c) { REQUIRE(c, c); (void)hipStreamSynchronize(c->stream); rccl_release(c); return 0; }
+// d_recv[g * bytes ..) <- rank g's d_send[0 .. bytes), enqueued on the context's stream (no host synchronisation)
+int32_t lasso_rccl_allgather(lasso_ctx* c, const void* d_send, void* d_recv, size_t bytes) {
+  REQUIRE(c, d_send && d_recv && c->rccl_comm);
+  RcclApi* a = rccl_api(nullptr);
+  ncclResult_t r = a->AllGather(d_send, d_recv, bytes, ncclUint8, (ncclComm_t)c->rccl_comm, c->stream);
+  if (r != ncclSuccess) return fail(c, LASSO_ERR_HIP, std::string("ncclAllGather: ") + a->GetErrorString(r));
+  return 0;
+}
+// d_parts: groups x rows points in the kernels' own form (lasso_point_row_bytes() each, rank-major, as lasso_rccl_allgather leaves them);
+// out32: rows x 32 wire bytes (host) of the per-row sums
+int32_t lasso_points_reduce_compress(lasso_ctx* c, const void* d_parts, uint32_t groups, size_t rows, uint8_t* out32) {
+  REQUIRE(c, d_parts && out32 && groups >= 1 && rows >= 1);
+  int32_t rc = ensure_scratch(c, rows * 32 + 256); if (rc) return rc;
+  {
+    ProfScope ps(c, LASSO_K_MSM, (double)groups * rows * sizeof(pt29), (double)(groups - 1) * rows);
+    hipLaunchKernelGGL(k_points_reduce_compress, dim3(grid_for(rows)), dim3(256), 0, c->stream, (const pt29*)d_parts, groups, rows, (uint32_t*)c->d_scratch);
+  }
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(out32, c->d_scratch, rows * 32, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
 
 int32_t lasso_ctx_create(int32_t device, lasso_ctx** out) { return lasso_ctx_create_background(device, 0, out); }
 // background != 0: the context's stream gets the LOWEST priority the device offers (the prover's side context: bulk work that must not delay
@@ -199,6 +284,7 @@ void lasso_ctx_destroy(lasso_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->tail_active || c->pending) (void)lasso_abort(c);   // never block in the synchronise below for a kernel's 5 s bail-out
   (void)hipStreamSynchronize(c->stream);
+  rccl_release(c);
   for (auto& p : c->events) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   if (c->d_scratch) (void)hipFree(c->d_scratch);
   if (c->h_small) (void)hipHostFree(c->h_small);
@@ -779,8 +865,11 @@ static int32_t run_msm_direct(lasso_ctx* c, const uint8_t* d_scal, size_t row_st
   HIPCHK(c, hipGetLastError());
   return wait_flag(c, seq, rows * (sizeof(ed_point) / sizeof(fr_t)), (lasso_fr*)out);
 }
+// d_rows_out (device, rows x sizeof(pt29)): leave the row sums on the device in the kernels' own point form instead of handing them to the host —
+// slab mode's partial row commitments, which go through lasso_rccl_allgather and lasso_points_reduce_compress
 static int32_t run_msm(lasso_ctx* c, const uint8_t* d_scal, uint32_t bps, uint32_t W, size_t row_stride, size_t rows, size_t n_cols, const lasso_bases* b, uint8_t* scratch_after, lasso_point* out,
-                       uint8_t* out_compressed = nullptr) {
+                       uint8_t* out_compressed = nullptr, void* d_rows_out = nullptr) {
+  if (d_rows_out) out_compressed = (uint8_t*)d_rows_out;   // same kernel path as the compressed form: k_points_sum leaves pt29 row sums in d_final
   if (bps == 32 && rows <= MSM_SMALL_ROWS && !out_compressed && b->d_mult && msm_direct_enabled()) { const MsmColMap id = {0, 0, 0, 0}; return run_msm_direct(c, d_scal, row_stride, rows, n_cols, id, b, scratch_after, out); }
   const size_t K = msm_chunks(rows, n_cols, W);
   const size_t cols_per_chunk = (n_cols + K - 1) / K;
@@ -795,6 +884,7 @@ static int32_t run_msm(lasso_ctx* c, const uint8_t* d_scal, uint32_t bps, uint32
                        c->d_counters + LASSO_MAX_PTRS + 1, small ? c->d_flag : (uint32_t*)nullptr, seq);
   }
   HIPCHK(c, hipGetLastError());
+  if (d_rows_out) { HIPCHK(c, hipMemcpyAsync(d_rows_out, d_final, rows * sizeof(pt29), hipMemcpyDeviceToDevice, c->stream)); return 0; }
   if (out_compressed) {   // d_final holds the row sums as pt29 (144 B per row: the scratch is sized for it, see hyrax_commit_impl); 32 wire bytes per row go out
     if (rows <= ((size_t)1 << 16)) {   // wire bytes straight into the host-mapped result buffer, handed over behind the sequence flag
       int32_t rc = ensure_small(c, rows); if (rc) return rc;
@@ -814,10 +904,12 @@ static int32_t run_msm(lasso_ctx* c, const uint8_t* d_scal, uint32_t bps, uint32
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return 0;
 }
-static int32_t hyrax_commit_impl(lasso_ctx* c, const lasso_fr* d_Z, size_t l_size, size_t r_size, const lasso_bases* b, lasso_point* out, uint8_t* out_compressed);
+static int32_t hyrax_commit_impl(lasso_ctx* c, const lasso_fr* d_Z, size_t l_size, size_t r_size, const lasso_bases* b, lasso_point* out, uint8_t* out_compressed, void* d_rows_out = nullptr);
+int32_t lasso_hyrax_commit_rows_dev(lasso_ctx* c, const lasso_fr* d_Z, size_t l_size, size_t r_size, const lasso_bases* b, void* d_rows) { REQUIRE(c, d_rows); return hyrax_commit_impl(c, d_Z, l_size, r_size, b, nullptr, nullptr, d_rows); }
+size_t lasso_point_row_bytes(void) { return sizeof(pt29); }
 int32_t lasso_hyrax_commit(lasso_ctx* c, const lasso_fr* d_Z, size_t l_size, size_t r_size, const lasso_bases* b, lasso_point* out) { REQUIRE(c, out); return hyrax_commit_impl(c, d_Z, l_size, r_size, b, out, nullptr); }
 int32_t lasso_hyrax_commit_compressed(lasso_ctx* c, const lasso_fr* d_Z, size_t l_size, size_t r_size, const lasso_bases* b, uint8_t* out32) { REQUIRE(c, out32); return hyrax_commit_impl(c, d_Z, l_size, r_size, b, nullptr, out32); }
-static int32_t hyrax_commit_impl(lasso_ctx* c, const lasso_fr* d_Z, size_t l_size, size_t r_size, const lasso_bases* b, lasso_point* out, uint8_t* out_compressed) {
+static int32_t hyrax_commit_impl(lasso_ctx* c, const lasso_fr* d_Z, size_t l_size, size_t r_size, const lasso_bases* b, lasso_point* out, uint8_t* out_compressed, void* d_rows_out) {
   REQUIRE(c, d_Z && b && l_size >= 1 && r_size >= 1 && r_size <= b->n && l_size < ((size_t)1 << 31));
   const size_t n = l_size * r_size;
   const size_t pts_bytes = msm_pts_bytes(l_size, r_size);   // chunk partials + row sums (pt29 or ed_point) + wire bytes
@@ -836,12 +928,12 @@ static int32_t hyrax_commit_impl(lasso_ctx* c, const lasso_fr* d_Z, size_t l_siz
   if (!flags[1]) {  // every scalar < 2^32: the reference's small-scalar regime (msm/mod.rs:95-106)
     uint32_t bits = 0; while (bits < 32 && (flags[0] >> bits)) bits++;
     uint32_t W = (bits + 3) / 4; if (W == 0) W = 1;   // 4-bit windows actually populated
-    return run_msm(c, d_scal, 4, W, r_size * 4, l_size, r_size, b, d_scal + ((n * 4 + 255) & ~(size_t)255), out, out_compressed);
+    return run_msm(c, d_scal, 4, W, r_size * 4, l_size, r_size, b, d_scal + ((n * 4 + 255) & ~(size_t)255), out, out_compressed, d_rows_out);
   }
   rc = ensure_scratch(c, n * 32 + pts_bytes); if (rc) return rc;
   d_scal = (uint8_t*)c->d_scratch;
   hipLaunchKernelGGL(k_fr_to_canonical, dim3(grid_for(n, 4096)), dim3(256), 0, c->stream, (const fr_t*)d_Z, n, (fr_t*)d_scal);
-  return run_msm(c, d_scal, 32, MSM_WINDOWS, r_size * 32, l_size, r_size, b, d_scal + n * 32, out, out_compressed);
+  return run_msm(c, d_scal, 32, MSM_WINDOWS, r_size * 32, l_size, r_size, b, d_scal + n * 32, out, out_compressed, d_rows_out);
 }
 // The commitment of a polynomial whose canonical values the caller already holds as u32 (Z[i] = F::from(d_u32[i]), e.g. E = T[dim] with a small
 // table T, or the dim / timestamp polynomials): no conversion pass over the 32-byte elements and no max-bit readback.  max_value bounds the values.

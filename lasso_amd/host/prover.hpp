@@ -432,6 +432,19 @@ inline PolyCommitment hyrax_commit(const Dev& d, const lasso_fr* d_Z, size_t num
     else d.chk(lasso_hyrax_commit_compressed(d.ctx, d_Z, l_size, r_size, gens.bases, c.compressed.data()), "lasso_hyrax_commit_compressed");
     return c;
   }
+  if (lasso_rccl_ready(d.ctx) == (int32_t)d.comm.world) {
+    // the exchange step of the path on the device: partial row commitments stay in HBM, RCCL all-gathers them over xGMI on the context's stream,
+    // and every rank adds the P partials of each row and compresses (lasso_hip.h "slab mode")
+    const size_t P = d.comm.world, rb = lasso_point_row_bytes(); LASSO_REQUIRE(gens.bases_slab && r_size >= P);
+    void* d_part = d.alloc_bytes(l_size * rb); void* d_all = d.alloc_bytes(P * l_size * rb);
+    PolyCommitment c; c.rows = l_size; c.compressed.resize(32 * l_size);
+    int32_t rc = lasso_hyrax_commit_rows_dev(d.ctx, d_Z, l_size, r_size / P, gens.bases_slab, d_part);
+    if (!rc) rc = lasso_rccl_allgather(d.ctx, d_part, d_all, l_size * rb);
+    if (!rc) rc = lasso_points_reduce_compress(d.ctx, d_all, (uint32_t)P, l_size, c.compressed.data());
+    d.free(d_part); d.free(d_all);
+    d.chk(rc, "slab commitment exchange (RCCL)");
+    return c;
+  }
   std::vector<lasso_point> rows(l_size);
   std::vector<Pt> pts(l_size);
   {

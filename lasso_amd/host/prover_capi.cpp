@@ -1,6 +1,7 @@
 // liblasso_prover.so — include/lasso_prover.h over lasso_amd/host/prover.hpp.  Nothing unwinds across the ABI.
 #include "prover.hpp"
 #include "verifier.hpp"
+#include "shm_comm.hpp"
 #include <atomic>
 #include "../../include/lasso_prover.h"
 
@@ -11,6 +12,7 @@ using namespace lasso;
 // with the last child (Python's GC may release the three in any order).
 struct lasso_host {
   Dev dev; std::atomic<int> refs{1};
+  std::unique_ptr<ShmComm> shm;   // slab mode's native intra-node exchange (lasso_host_set_comm_shm); outlives every proof of this host
   explicit lasso_host(int device) : dev(device) {}
   void retain() { refs.fetch_add(1, std::memory_order_relaxed); }
   void release() { if (refs.fetch_sub(1, std::memory_order_acq_rel) == 1) delete this; }
@@ -39,6 +41,29 @@ int32_t lasso_host_set_comm(lasso_host* h, int32_t rank, int32_t world, lasso_ho
   GUARD(
     if (!h || world < 1 || (world & (world - 1)) || rank < 0 || rank >= world || (world > 1 && !fn)) throw Error("lasso_host_set_comm: world must be a power of two, 0 <= rank < world, and a collective is needed when world > 1");
     h->dev.comm.rank = (size_t)rank; h->dev.comm.world = (size_t)world; h->dev.comm.fn = fn; h->dev.comm.user = user; return 0;)
+}
+// Slab mode with the library's own exchange: the ranks of one node meet in a POSIX shared-memory segment `name` (same on every rank, e.g. derived from
+// MASTER_PORT) and all-gather their per-round partial sums there (shm_comm.hpp) — no callback into the embedding language per round.
+int32_t lasso_host_set_comm_shm(lasso_host* h, int32_t rank, int32_t world, const char* name) {
+  GUARD(
+    if (!h || !name || world < 1 || (world & (world - 1)) || rank < 0 || rank >= world) throw Error("lasso_host_set_comm_shm: world must be a power of two and 0 <= rank < world");
+    h->shm.reset(new ShmComm(name, rank, world));
+    h->dev.comm.rank = (size_t)rank; h->dev.comm.world = (size_t)world; h->dev.comm.fn = &ShmComm::trampoline; h->dev.comm.user = h->shm.get();
+    // The bulk exchange (partial row commitments) goes over RCCL on the device stream when every rank can join one communicator: rank 0 draws the
+    // unique id and publishes it through the segment; the ranks then agree (an all-gather of one status byte) — all use RCCL or none does.
+    const char* e = getenv("LASSO_SLAB_RCCL");
+    if (world > 1 && !(e && e[0] == '0')) {
+      uint8_t blob[129] = {0};
+      if (rank == 0) blob[128] = lasso_rccl_unique_id(blob) == 0 ? 1 : 0;
+      h->shm->broadcast_blob(blob, sizeof(blob));
+      uint8_t mine = 0;
+      if (blob[128]) mine = lasso_rccl_init(h->dev.ctx, rank, world, blob) == 0 ? 1 : 0;
+      std::vector<uint8_t> all((size_t)world, 0);
+      if (h->shm->allgather(&mine, all.data(), 1) != 0) throw Error("lasso_host_set_comm_shm: ranks did not agree on the device-side exchange");
+      bool every = true; for (uint8_t v : all) every = every && v;
+      if (!every && mine) (void)lasso_rccl_shutdown(h->dev.ctx);
+    }
+    return 0;)
 }
 int32_t lasso_host_gens_new(lasso_host* h, const char* label, size_t c, size_t s, size_t nm, size_t log_m, lasso_host_gens** out) { GUARD(*out = new lasso_host_gens(h, label, c, s, nm, log_m); return 0;) }
 void lasso_host_gens_free(lasso_host_gens* g) { delete g; }

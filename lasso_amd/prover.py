@@ -30,6 +30,7 @@ def declare_prover(lib):
     lib.lasso_host_destroy.argtypes = [vp]
     lib.lasso_host_ctx.argtypes = [vp]; lib.lasso_host_ctx.restype = vp
     lib.lasso_host_set_comm.argtypes = [vp, i32, i32, ALLGATHER_FN, vp]
+    lib.lasso_host_set_comm_shm.argtypes = [vp, i32, i32, C.c_char_p]
     lib.lasso_host_gens_new.argtypes = [vp, C.c_char_p, sz, sz, sz, sz, C.POINTER(vp)]
     lib.lasso_host_gens_free.argtypes = [vp]
     lib.lasso_host_densify.argtypes = [vp, vp, sz, sz, sz, C.POINTER(vp)]
@@ -57,6 +58,10 @@ class HostProver:
         """Slab mode (one proof sharded over the ranks of `group`, lasso_amd.parallel.Group): must precede gens()/densify()."""
         self._allgather = ALLGATHER_FN(group.allgather_callback())       # keep the callback object alive
         self._chk(self.lib.lasso_host_set_comm(self.h, group.rank, group.world, self._allgather, None))
+
+    def set_comm_shm(self, rank, world, name):
+        """Slab mode over the library's own shared-memory exchange (one node): `name` = "/something", the same on every rank."""
+        self._chk(self.lib.lasso_host_set_comm_shm(self.h, rank, world, name.encode()))
 
     def _chk(self, rc):
         if rc != 0:

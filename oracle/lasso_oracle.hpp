@@ -196,7 +196,7 @@ inline Point msm(const std::vector<Point>& bases, const std::vector<Fr>& scalars
     Point running = Point::identity(), res = Point::identity();
     for (size_t b = buckets.size(); b-- > 0;) { running += buckets[b]; res += running; }
     window_sums[i] = res;
-  }, size >= 64 ? 2 : (size_t)-1);
+  }, size >= 64 ? 1 : (size_t)-1);
   Point total = Point::identity();
   for (size_t i = digits_count; i-- > 1;) { total += window_sums[i]; for (size_t k = 0; k < c; k++) total = total.dbl(); }
   return window_sums[0] + total;
@@ -226,7 +226,7 @@ struct EqPolynomial {
     size_t size = 1;
     for (size_t j = 0; j < ell; j++) {
       size *= 2;
-      if (size >= 8192 && par_max_threads() > 1) {  // same values as the in-place reverse sweep below, read from a copy of the previous level
+      if (size >= 16384 && par_max_threads() > 1) {  // same values as the in-place reverse sweep below, read from a copy of the previous level
         std::vector<Fr> prev(ev.begin(), ev.begin() + size / 2);
         par_for(size / 2, [&](size_t k) { Fr hi = prev[k] * r[j]; ev[2 * k + 1] = hi; ev[2 * k] = prev[k] - hi; });
         continue;
@@ -292,14 +292,14 @@ struct DensePolynomial {
     size_t L_size = pow2(lr.first), R_size = pow2(lr.second);
     ORC_ASSERT(L_size * R_size == n);
     PolyCommitment C(L_size);  // rows are independent MSMs over shared bases (the reference's par_iter, dense_mlpoly.rs:118-127)
-    par_for(L_size, [&](size_t i) { C[i] = batch_commit(&Z[R_size * i], R_size, Fr::zero(), gens.gens.gens_n); }, 2);
+    par_for(L_size, [&](size_t i) { C[i] = batch_commit(&Z[R_size * i], R_size, Fr::zero(), gens.gens.gens_n); }, 1);
     return C;
   }
   std::vector<Fr> bound(const std::vector<Fr>& L) const {  // :184-207
     auto lr = EqPolynomial::compute_factored_lens(num_vars);
     size_t L_size = pow2(lr.first), R_size = pow2(lr.second);
     std::vector<Fr> out(R_size, Fr::zero());
-    par_for(R_size, [&](size_t i) { Fr s = Fr::zero(); for (size_t j = 0; j < L_size; j++) s += L[j] * Z[j * R_size + i]; out[i] = s; }, 64);
+    par_for(R_size, [&](size_t i) { Fr s = Fr::zero(); for (size_t j = 0; j < L_size; j++) s += L[j] * Z[j * R_size + i]; out[i] = s; }, L_size >= 64 ? 4 : 64);
     return out;
   }
   void bound_poly_var_top(const Fr& r) {  // :209-216
@@ -596,7 +596,7 @@ inline BulletOut bullet_prove(ProofTranscript& t, const Point& Q, const std::vec
       a[i] = a[i] * u + u_inv * a[n + i];
       b[i] = b[i] * u_inv + u * b[n + i];
       G[i] = G[i] * u_inv + G[n + i] * u;
-    }, 8);
+    }, 1);
     blind_fin = blind_fin + blind_L * u * u + blind_R * u_inv * u_inv;
     out.proof.L_vec.push_back(L); out.proof.R_vec.push_back(R);
   }

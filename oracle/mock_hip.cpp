@@ -57,6 +57,15 @@ int32_t lasso_download(lasso_ctx*, void* d, const void* s, size_t n) { memcpy(d,
 int32_t lasso_copy(lasso_ctx*, void* d, const void* s, size_t n) { memmove(d, s, n); return 0; }
 int32_t lasso_zero(lasso_ctx*, void* d, size_t n) { memset(d, 0, n); return 0; }
 int32_t lasso_sync(lasso_ctx*) { return 0; }
+// the device-side exchange of slab mode has no CPU statement: the mock reports it unsupported and the host prover keeps to its host-memory exchange
+int32_t lasso_rccl_unique_id(uint8_t*) { return LASSO_ERR_UNSUPPORTED; }
+int32_t lasso_rccl_init(lasso_ctx*, int32_t, int32_t, const uint8_t*) { return LASSO_ERR_UNSUPPORTED; }
+int32_t lasso_rccl_ready(lasso_ctx*) { return 0; }
+int32_t lasso_rccl_shutdown(lasso_ctx*) { return 0; }
+int32_t lasso_rccl_allgather(lasso_ctx*, const void*, void*, size_t) { return LASSO_ERR_UNSUPPORTED; }
+size_t lasso_point_row_bytes(void) { return 144; }
+int32_t lasso_hyrax_commit_rows_dev(lasso_ctx*, const lasso_fr*, size_t, size_t, const lasso_bases*, void*) { return LASSO_ERR_UNSUPPORTED; }
+int32_t lasso_points_reduce_compress(lasso_ctx*, const void*, uint32_t, size_t, uint8_t*) { return LASSO_ERR_UNSUPPORTED; }
 int32_t lasso_abort(lasso_ctx* c) { REQ(c, c); c->pending.clear(); c->defer = false; c->tail_a.clear(); c->tail_b.clear(); c->tail_e.clear(); c->mid_a.clear(); c->mid_b.clear(); return 0; }
 int32_t lasso_prof_get_large(lasso_ctx*, int32_t, uint64_t* n, double* ms, double* b) { if (n) *n = 0; if (ms) *ms = 0; if (b) *b = 0; return 0; }
 int32_t lasso_wait_stats(lasso_ctx*, uint64_t* w, double* us, int32_t) { if (w) *w = 0; if (us) *us = 0; return 0; }

@@ -180,7 +180,23 @@ int orc_verify_only(int kind, size_t C, size_t M, size_t log_r, size_t s, const 
 
 // ---- threads (par.hpp): the oracle's data-parallel loops run on OpenMP; bytes never depend on the count
 int orc_max_threads() { return par_max_threads(); }
-void orc_set_threads(int n) { par_set_threads(n); }
+// physical cores of this host: distinct (physical id, core id) pairs of /proc/cpuinfo; 0 when that cannot be read.  The all-core runs use one thread per
+// PHYSICAL core (the reference's RAYON_NUM_THREADS convention of SURVEY 8(d)); filling the SMT siblings as well leaves no idle hardware thread for anything
+// else in the process, and a spinning OpenMP barrier then waits out whole scheduler time slices (measured: 2^24 lookups 121 s on 256 threads of a 2 x 64-core box).
+int orc_physical_cores() {
+  FILE* f = fopen("/proc/cpuinfo", "r"); if (!f) return 0;
+  std::map<std::pair<long, long>, int> seen; char line[512]; long phys = -1;
+  while (fgets(line, sizeof line, f)) {
+    long v; if (sscanf(line, "physical id : %ld", &v) == 1) phys = v; else if (sscanf(line, "core id : %ld", &v) == 1) seen[{phys, v}] = 1;
+  }
+  fclose(f); return (int)seen.size();
+}
+// n <= 0: one thread per physical core (capped by what OpenMP was given, e.g. OMP_NUM_THREADS / a cgroup limit)
+void orc_set_threads(int n) {
+  static const int initial = par_max_threads();
+  if (n <= 0) { const int pc = orc_physical_cores(); n = pc > 0 && pc < initial ? pc : initial; }
+  par_set_threads(n);
+}
 
 // ---- timing leg for bench.py cpu_baseline ("port"): harness inputs, on the threads set by orc_set_threads / OMP_NUM_THREADS.
 // proof_out / comm_out (optional, may be null): the serialized proof and commitment (orc_session_commit's layout), so the

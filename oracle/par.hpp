@@ -35,12 +35,26 @@ inline void par_set_threads(int n) {
 #endif
 }
 
-// for i in [0, n): f(i), iterations independent.  Bodies must not throw (an exception cannot leave an OpenMP region).
-template <class Fn>
-inline void par_for(size_t n, Fn&& f, size_t grain = 2048) {
+// Threads for a region of n iterations when one thread should have at least `per_thread` of them: small regions run on few threads (or inline) so that
+// their fork/join cost stays proportional to the work — a late sumcheck round of 4096 terms on 128 threads would be nothing but barrier.
+inline int par_threads_for(size_t n, size_t per_thread) {
 #ifdef _OPENMP
-  if (n >= grain && omp_get_max_threads() > 1 && !omp_in_parallel()) {
-#pragma omp parallel for schedule(static)
+  if (omp_in_parallel()) return 1;
+  const size_t mx = (size_t)omp_get_max_threads(), want = per_thread ? n / per_thread : n;
+  return (int)(want < 1 ? 1 : want > mx ? mx : want);
+#else
+  (void)n; (void)per_thread; return 1;
+#endif
+}
+
+// for i in [0, n): f(i), iterations independent.  Bodies must not throw (an exception cannot leave an OpenMP region).
+// per_thread: iterations that justify one more thread (light bodies, a few field operations: thousands; an MSM row or a scalar multiplication: 1).
+template <class Fn>
+inline void par_for(size_t n, Fn&& f, size_t per_thread = 4096) {
+#ifdef _OPENMP
+  const int nt = par_threads_for(n, per_thread);
+  if (nt > 1) {
+#pragma omp parallel for schedule(static) num_threads(nt)
     for (size_t i = 0; i < n; i++) f(i);
     return;
   }
@@ -51,11 +65,11 @@ inline void par_for(size_t n, Fn&& f, size_t grain = 2048) {
 // K running sums over i in [0, n): f(i, acc) adds its terms into acc[0..K).  T needs zero() and operator+=.
 // Per-thread accumulators joined in thread order; identical to the serial sum because the addition is exact.
 template <class T, class Fn>
-inline std::vector<T> par_sums(size_t n, size_t K, Fn&& f, size_t grain = 2048) {
+inline std::vector<T> par_sums(size_t n, size_t K, Fn&& f, size_t per_thread = 2048) {
   std::vector<T> total(K, T::zero());
 #ifdef _OPENMP
-  if (n >= grain && omp_get_max_threads() > 1 && !omp_in_parallel()) {
-    int nt = omp_get_max_threads();
+  const int nt = par_threads_for(n, per_thread);
+  if (nt > 1) {
     std::vector<std::vector<T>> part((size_t)nt, std::vector<T>(K, T::zero()));
 #pragma omp parallel num_threads(nt)
     {

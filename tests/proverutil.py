@@ -68,10 +68,9 @@ class OracleSession:
 
 def oracle_harness_proof(oracle, kind, c, log_m, log_r, log_s, threads=0, verify=False):
     """The oracle's densify -> commit -> prove on the reference harness's inputs (benches/bench.rs:13-34: gen_indices / gen_random_point from a fresh
-    test_rng) on `threads` OpenMP threads (0 = all host cores; bytes do not depend on it, tests/test_oracle_parallel.py).
+    test_rng) on `threads` OpenMP threads (0 = one per physical core; bytes do not depend on it, tests/test_oracle_parallel.py).
     Returns (commitment bytes, proof bytes, {"densify_s", "commit_s", "prove_s", "threads"})."""
-    if threads:
-        oracle.orc_set_threads(threads)
+    oracle.orc_set_threads(threads)      # 0 = one thread per physical core
     td, tc, tp = C.c_double(), C.c_double(), C.c_double()
     cap = 1 << 23
     pb = (C.c_uint8 * cap)(); cb = (C.c_uint8 * cap)(); pl = C.c_size_t(); cl = C.c_size_t()

@@ -98,3 +98,54 @@ def test_two_ranks_gloo(tmp_path, oracle):
     for rk, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, o
         assert f"rank {rk} ok" in o
+
+
+SHM_WORKER = textwrap.dedent('''
+    import ctypes as C, hashlib, os, sys
+    sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+    import numpy as np
+    from lasso_amd import _abi
+    from lasso_amd.prover import HostProver
+    from proverutil import OracleSession, build_mock_prover
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    hp = HostProver(C.CDLL(build_mock_prover()))
+    hp.set_comm_shm(rank, world, os.environ["LASSO_SHM_NAME"])      # ONE proof over all ranks; the exchange is the library's own shared-memory all-gather
+    kind, c, log_m, lookups = %(kind)r, %(c)d, %(log_m)d, %(lookups)d
+    s = 1 << (lookups - 1).bit_length()
+    alpha = 2 * c if kind == "lt" else c
+    idx = np.random.default_rng(11).integers(0, 1 << log_m, size=(lookups, c), dtype=np.uint64)     # the SAME lookups on every rank
+    r = hp.gen_random_point(s.bit_length() - 1)
+    S = _abi.Strategy(_abi.KINDS[kind], c, log_m, 0)
+    gens = hp.gens(c, s, alpha, log_m); dense = hp.densify(idx, log_m)
+    comm = hp.commit(dense, gens)
+    proof = hp.prove(dense, gens, S, r)
+    proof2 = hp.prove(dense, gens, S, r)
+    assert proof == proof2
+    orc = C.CDLL(os.path.join(%(root)r, "oracle", "liblasso_oracle.so")); orc.orc_last_error.restype = C.c_char_p; orc.orc_session_new.restype = C.c_void_p
+    o = OracleSession(orc, _abi.KINDS[kind], c, log_m, 0, idx, r)
+    assert comm == o.commit() and proof == o.prove() and o.verify(proof, comm) == 1
+    o.close(); hp.free(dense, gens); hp.close()
+    print("rank", rank, "ok", hashlib.sha256(proof).hexdigest())
+''')
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("world,kind,c,log_m,lookups", [(2, "and", 2, 6, 100), (4, "xor", 1, 8, 1 << 10), (4, "lt", 2, 6, 64), (8, "and", 1, 8, 1 << 9)])
+def test_one_proof_over_ranks_native_shm_exchange(tmp_path, oracle, world, kind, c, log_m, lookups):
+    """slab mode over lasso_host_set_comm_shm (lasso_amd/host/shm_comm.hpp): P processes, no torch, no callback — commitment and proof identical to the
+    oracle's on every rank, and identical between ranks"""
+    from proverutil import build_mock_prover
+    build_mock_prover()
+    script = tmp_path / "worker.py"
+    script.write_text(SHM_WORKER % {"root": ROOT, "kind": kind, "c": c, "log_m": log_m, "lookups": lookups})
+    env = dict(os.environ, WORLD_SIZE=str(world), LASSO_SHM_NAME=f"/lasso_test_{os.getpid()}_{world}_{kind}", OMP_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(rk)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for rk in range(world)]
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    digests = set()
+    for rk, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert f"rank {rk} ok" in o
+        digests.add(o.strip().split()[-1])
+    assert len(digests) == 1
