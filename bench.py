@@ -56,6 +56,13 @@ def parse():
                                                                               "code path be exercised on a box with fewer GPUs than ranks (ranks share devices)")
     p.add_argument("--shard-proof", action="store_true", help="N > 1: ONE proof of s lookups sharded over the N GPUs by low index bits (slab mode, strong scaling) "
                                                                 "instead of one independent proof per GPU (the default, weak scaling)")
+    p.add_argument("--slab-kind", default="range", choices=["and", "or", "xor", "lt", "range"], help="the extra slab-mode leg's workload: by default BASELINE.json configs[3], "
+                                                                                                       "RangeCheck C=4 2^26 (the configuration the north star shards over several GPUs)")
+    p.add_argument("--slab-c", type=int, default=4)
+    p.add_argument("--slab-log-s", type=int, default=26)
+    p.add_argument("--slab-steps", type=int, default=2)
+    p.add_argument("--no-slab-leg", action="store_true", help="skip the extra slab-mode leg (ONE proof over all N GPUs; at N = 1 its single-GPU reference time)")
+    p.add_argument("--slab-timeout", type=float, default=240.0)
     return p.parse_args()
 
 
@@ -154,6 +161,51 @@ def concurrent_leg(HostProver, _abi, streams, steps, S, c, log_m, log_s, curve="
             "note": "independent proofs proved concurrently on one GPU (one context, stream and host thread each); not the headline metric"}
 
 
+def slab_leg(a, HostProver, _abi, grp, shm_name):
+    """ONE proof over the N ranks (include/lasso_prover.h lasso_host_set_comm_shm): per-round partial sums through the shared-memory exchange, partial row
+    commitments through RCCL all-gather on the library's stream when every rank could join the communicator.  Returns the leg's JSON object."""
+    import threading
+    rank, world = grp.rank, grp.world
+    kind, c, log_m, log_s = a.slab_kind, a.slab_c, a.log_m, a.slab_log_s
+    alpha = 2 * c if kind == "lt" else c
+    s = 1 << log_s
+    if (2 * c + alpha) * s * 32 * 5 / world > 200e9:      # ~5x the committed polynomials resident per rank
+        return {"skipped": f"{kind} C={c} 2^{log_s} does not fit {world} GPU(s)"}
+    box = {}
+
+    def work():
+        try:
+            hp = HostProver(device=grp.device_index, curve=a.curve)
+            if world > 1:
+                hp.set_comm_shm(rank, world, shm_name + "_slab")
+            S = _abi.Strategy(_abi.KINDS[kind], c, log_m, a.log_r if kind == "range" else 0)
+            idx = hp.gen_indices(s, 1 << log_m, c)                 # the SAME lookups on every rank: one proof
+            r = hp.gen_random_point(log_s)
+            dev_lib = C.CDLL(os.path.join(ROOT, "lasso_amd", "liblasso_hip.so")); _abi.declare(dev_lib)
+            t0 = time.perf_counter(); gens = hp.gens(c, s, alpha, log_m); dense = hp.densify(idx, log_m); del idx
+            comm = hp.commit(dense, gens); t_setup = time.perf_counter() - t0
+            proof = hp.prove(dense, gens, S, r)                    # warm-up
+            t0 = time.perf_counter()
+            for _ in range(a.slab_steps):
+                proof = hp.prove(dense, gens, S, r)
+            el = (time.perf_counter() - t0) / a.slab_steps
+            rccl = dev_lib.lasso_rccl_ready(hp.ctx())
+            import hashlib
+            box.update({"workload": f"{kind.upper()} subtable, C={c}, M=2^{log_m}, s=2^{log_s} lookups, ONE proof over {world} GPU(s)" + (" (BASELINE.json configs[3])" if (kind, c, log_s) == ("range", 4, 26) else ""),
+                        "n_gpus": world, "scaling": "strong", "ms_per_proof": el * 1e3, "value": s / el, "unit": "lookups/s", "steps": a.slab_steps,
+                        "rccl_ranks": int(rccl), "exchange": ("per-round sums: shared-memory all-gather (lasso_amd/host/shm_comm.hpp); partial row commitments: " +
+                                                               ("RCCL ncclAllGather on the library's stream + device-side row sums" if rccl == world and world > 1 else "shared-memory all-gather + host row sums")) if world > 1 else "none (single GPU)",
+                        "setup_s": round(t_setup, 2), "proof_bytes": len(proof), "proof_sha256": hashlib.sha256(proof).hexdigest(), "commitment_sha256": hashlib.sha256(comm).hexdigest()})
+            hp.free(dense, gens); hp.close()
+        except Exception as e:      # the main line must survive a failing leg
+            box["error"] = repr(e)[:500]
+    th = threading.Thread(target=work, daemon=True)
+    th.start(); th.join(a.slab_timeout)
+    if th.is_alive():
+        return {"error": f"slab leg did not finish within {a.slab_timeout:.0f} s", "timed_out": True, "n_gpus": world}
+    return box
+
+
 def main():
     a = parse()
     from lasso_amd import HostProver, _abi
@@ -162,8 +214,11 @@ def main():
     rank, world = grp.rank, grp.world
     hp = HostProver(device=grp.device_index, curve=a.curve)
     slab = a.shard_proof and world > 1
+    shm_name = f"/lasso_bench_{os.environ.get('MASTER_PORT', '0')}_{os.getuid()}"
     if slab:
-        hp.set_comm(grp)             # slab mode: every polynomial split by low index bits, RCCL all_gather of per-round sums / row commitments
+        # slab mode: every polynomial split by low index bits; per-round partial sums through the library's shared-memory exchange, the partial row
+        # commitments all-gathered by RCCL over xGMI on the library's stream (lasso_host_set_comm_shm)
+        hp.set_comm_shm(rank, world, shm_name + "_main")
     lib = hp.lib
     dev_lib = C.CDLL(os.path.join(ROOT, "lasso_amd", "liblasso_hip_bn254.so" if a.curve == "bn254" else "liblasso_hip.so"))
     _abi.declare(dev_lib)
@@ -308,9 +363,21 @@ def main():
                 import hashlib
                 out["parity_checked"] = {"log_s": cls, "equal": g_proof == o_proof, "commitment_equal": g_comm == o_comm, "proof_bytes": len(g_proof), "commitment_bytes": len(g_comm),
                                          "proof_sha256": hashlib.sha256(g_proof).hexdigest(), "against": f"oracle prover on {cb['cores']} threads, same harness instance (benches/bench.rs:13-34 inputs)"}
-        print(json.dumps(out))
     hp.free(dense, gens)
     hp.close()
+    # Extra leg, beside — never instead of — `value`: ONE proof sharded over all N GPUs (slab mode, strong scaling) on the configuration the north star
+    # shards (BASELINE.json configs[3] by default).  At N = 1 the same proof on the one GPU: the base of the strong-scaling curve.  The main line's numbers
+    # are final before this leg starts; the leg runs under a watchdog so that an exchange that never completes cannot take the bench line with it.
+    hung = False
+    if not a.no_slab_leg and not slab and a.curve == "curve25519":
+        res = slab_leg(a, HostProver, _abi, grp, shm_name)
+        hung = bool(res.get("timed_out"))
+        if rank == 0:
+            out["slab_mode"] = res
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if hung:
+        os._exit(0)        # a wedged collective cannot be joined; the line is out
     grp.close()
 
 

@@ -550,6 +550,36 @@ def test_sumcheck_cubic_mid(devs, n, ncirc, bind):
     assert np.array_equal(arr_a, arr_ref)
 
 
+def test_abort_releases_a_waiting_tail_kernel(devs):
+    """a host that stops answering between tail_begin and the last tail_next used to leave the context unusable (tail_active / pending set) and a
+    kernel spinning until its 5 s bail-out.  lasso_abort posts the poison tag: the kernel leaves at its next poll, the protocol state is reset, and the very
+    same context runs a complete tail afterwards with the right answers."""
+    import time
+    d = devs[0]
+    rng = np.random.default_rng(77)
+    n, ncirc = 256, 2
+    A = [rand_fr(rng, n) for _ in range(ncirc)]; B = [rand_fr(rng, n) for _ in range(ncirc)]; E = rand_fr(rng, n // 2)
+    turns = n.bit_length() - 1
+    chal = rand_fr(rng, turns, edge=False)
+    pa = [d.upload(x) for x in A]; pb = [d.upload(x) for x in B]; pe = d.upload(E)
+    d._chk(d.lib.lasso_sumcheck_cubic_tail_begin(d.ctx, d._ptrs(pa), d._ptrs(pb), ncirc, C.c_void_p(pe), n, None))
+    out = np.empty((2 * ncirc, 4), dtype=np.uint64)
+    d._chk(d.lib.lasso_result_wait(d.ctx, out.ctypes.data_as(C.c_void_p), 2 * ncirc))      # first round's sums arrive; the kernel now waits for a challenge
+    t0 = time.perf_counter()
+    d._chk(d.lib.lasso_abort(d.ctx))
+    assert time.perf_counter() - t0 < 1.0, "abort must not wait for the kernel's 5 s bail-out"
+    want = devs[1].sumcheck_cubic_tail([devs[1].upload(x) for x in A], [devs[1].upload(x) for x in B], devs[1].upload(E), n, None, chal)
+    for p in pa + pb:
+        d.free(p)
+    pa = [d.upload(x) for x in A]; pb = [d.upload(x) for x in B]
+    got = d.sumcheck_cubic_tail(pa, pb, pe, n, None, chal)
+    assert len(got) == len(want)
+    for x, y in zip(got, want):
+        assert np.array_equal(x, y)
+    for p in pa + pb + [pe]:
+        d.free(p)
+
+
 @pytest.mark.parametrize("n,alpha,bind", [(2, 1, False), (4, 1, True), (8, 3, False), (64, 2, True), (512, 1, False), (1024, 2, True), (256, 33, True), (16, 8, False)])
 def test_sumcheck_linear_tail(devs, n, alpha, bind):
     """resident tail of the primary sumcheck (linear strategies) against the per-round eq-weighted calls: same dot products every round, same heads,

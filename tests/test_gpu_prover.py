@@ -13,7 +13,8 @@ pytestmark = pytest.mark.gpu
 CASES = [("lt", 4, 4, 0, 16), ("lt", 4, 4, 0, 128), ("and", 4, 4, 0, 16), ("range", 3, 8, 40, 16),   # e2e_test.rs:64-99
          ("and", 1, 4, 0, 2), ("xor", 3, 4, 0, 11), ("or", 2, 4, 0, 8), ("and", 1, 16, 0, 1 << 10),   # BASELINE config 1 shape
          ("and", 1, 2, 0, 3), ("or", 1, 6, 0, 7), ("lt", 1, 4, 0, 4), ("range", 2, 4, 6, 9), ("and", 3, 2, 0, 4),
-         ("and", 4, 16, 0, 1 << 12), ("xor", 8, 8, 0, 1 << 10), ("range", 4, 16, 40, 1 << 10), ("lt", 2, 8, 0, 1 << 9), ("and", 1, 16, 0, 1 << 14)]
+         ("and", 4, 16, 0, 1 << 12), ("xor", 8, 8, 0, 1 << 10), ("range", 4, 16, 40, 1 << 10), ("lt", 2, 8, 0, 1 << 9), ("and", 1, 16, 0, 1 << 14),
+         ("lt", 16, 4, 0, 64), ("lt", 16, 8, 0, 1 << 10)]   # C = 16: 32 memories, degree-17 sumcheck — the shape of BASELINE.json configs[4] with the one degree-C strategy the snapshot has
 
 
 @pytest.fixture(scope="module")
@@ -87,7 +88,7 @@ def test_gpu_proof_verifies_at_scale(host, oracle, kind, c, log_m, log_r, log_s)
 # reach these sizes in seconds, so parity rests on the size-independent property the reference itself uses as its acceptance test
 # (src/e2e_test.rs:54-59): prove -> verify, here through the oracle's verifier (a restatement of surge.rs:214-271) fed the GPU's commitment,
 # plus rejection of a tampered proof and determinism of the proof bytes.
-FULL = [("and", 4, 16, 0, 20), ("and", 1, 16, 0, 24), ("xor", 8, 16, 0, 24), ("range", 4, 16, 40, 26), ("and", 1, 16, 0, 28)]   # configs[1], the metric, configs[2], configs[3] (on one GPU: ~75 GiB), and the largest lookup count of BASELINE.json (2^28, ~75 GiB) with the AND table
+FULL = [("and", 4, 16, 0, 20), ("and", 1, 16, 0, 24), ("xor", 8, 16, 0, 24), ("range", 4, 16, 40, 26), ("and", 1, 16, 0, 28), ("lt", 16, 16, 0, 22)]   # configs[1], the metric, configs[2], configs[3] (on one GPU: ~75 GiB), the largest lookup count of BASELINE.json (2^28, ~75 GiB) with the AND table, and LT C=16 (32 memories, degree 17: configs[4]'s shape, see CASES)
 
 
 @pytest.mark.parametrize("kind,c,log_m,log_r,log_s", FULL)
@@ -97,7 +98,7 @@ def test_baseline_config_full_size(host, oracle, kind, c, log_m, log_r, log_s):
     idx = host.gen_indices(s, 1 << log_m, c)
     r = host.gen_random_point(log_s)
     S = _abi.Strategy(_abi.KINDS[kind], c, log_m, log_r)
-    gens = host.gens(c, s, c, log_m)
+    gens = host.gens(c, s, 2 * c if kind == "lt" else c, log_m)
     dense = host.densify(idx, log_m)
     del idx
     comm = host.commit(dense, gens)
