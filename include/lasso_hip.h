@@ -158,12 +158,6 @@ int32_t lasso_defer_next(lasso_ctx* ctx);
 int32_t lasso_sumcheck_cubic_tail_begin(lasso_ctx* ctx, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n,
                                         const lasso_fr* r);
 int32_t lasso_sumcheck_cubic_tail_next(lasso_ctx* ctx, const lasso_fr* r);
-/* The rounds BEFORE that tail, 256 < q <= 4096 indices per circuit, resident on 16 workgroups per circuit (each keeps the elements i = g mod 16 in LDS;
- * the slices' partial sums meet in the last workgroup to arrive): begin and challenges as for the tail, one pending result of 2*ncirc sums per round.
- * The challenge that brings the arrays down to n' = 512 elements has NO result: the kernel writes the bound arrays back (canonical, the first n'
- * elements of d_A[c] / d_B[c]) and ends; continue with lasso_sumcheck_cubic_tail_begin(ctx, d_A, d_B, ncirc, d_E, n', NULL).  ncirc <= 16. */
-int32_t lasso_sumcheck_cubic_mid_begin(lasso_ctx* ctx, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n,
-                                       const lasso_fr* r);
 /* The resident tail of the primary sumcheck for the linear strategies (the rounds lasso_sumcheck_linear_eqw_round[_fused] serve one launch at a time):
  * begin as above on the alpha polynomials d_src (only read); per round 2*alpha values out[2k] = S0_k, out[2k+1] = S1_k; challenges through
  * lasso_sumcheck_cubic_tail_next; after log2(2q) of them the pending result is the alpha heads out[k] = E_k(r_z) (surge.rs:175-176). */

@@ -53,7 +53,6 @@ def declare(lib):
         "lasso_sumcheck_cubic_tail_begin": (i32, [vp, P(vp), P(vp), u32, vp, sz, vp]),
         "lasso_sumcheck_cubic_tail_next": (i32, [vp, vp]),
         "lasso_sumcheck_linear_tail_begin": (i32, [vp, P(vp), u32, vp, sz, vp]),
-        "lasso_sumcheck_cubic_mid_begin": (i32, [vp, P(vp), P(vp), u32, vp, sz, vp]),
         "lasso_sumcheck_combine_round": (i32, [vp, P(Strategy), P(vp), vp, sz, u32, vp]),
         "lasso_sumcheck_linear_eqw_round": (i32, [vp, P(vp), u32, vp, sz, vp]),
         "lasso_sumcheck_linear_eqw_round_fused": (i32, [vp, P(vp), u32, vp, sz, vp, vp]),

@@ -491,28 +491,6 @@ int32_t lasso_sumcheck_cubic_tail_begin(lasso_ctx* c, lasso_fr* const* d_A, lass
   c->pending = true; c->pending_seq = seq0; c->pending_count = c->tail_count;
   return 0;
 }
-// The rounds before the tail (256 < q <= 4096 indices per circuit) on CUBIC_MID_G resident workgroups per circuit (k_cubic_mid): begin as
-// lasso_sumcheck_cubic_tail_begin; one pending result (2*ncirc sums) per round; challenges through lasso_sumcheck_cubic_tail_next.  The challenge
-// that brings the arrays down to 2*256 elements produces NO result: the kernel writes the bound arrays back (canonical, first n' elements of
-// d_A / d_B) and ends, and lasso_sumcheck_cubic_tail_begin(.., n', NULL) continues from there.  ncirc * 16 workgroups must be co-resident: ncirc <= 16.
-int32_t lasso_sumcheck_cubic_mid_begin(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n, const lasso_fr* r) {
-  REQUIRE(c, d_A && d_B && d_E && ncirc >= 1 && ncirc * CUBIC_MID_G <= 256 && n >= (r ? 4u : 2u) && (n & (n - 1)) == 0 && !c->pending && !c->tail_active && !c->defer_next);
-  const size_t q = r ? n / 4 : n / 2;
-  REQUIRE(c, q > CUBIC_TAIL_Q && q <= CUBIC_MID_Q);
-  MutPtrTable A, B; for (uint32_t i = 0; i < ncirc; i++) { REQUIRE(c, d_A[i] && d_B[i]); A.p[i] = (fr_t*)d_A[i]; B.p[i] = (fr_t*)d_B[i]; }
-  int32_t rc = ensure_small(c, (size_t)ncirc * 3); if (rc) return rc;
-  rc = ensure_scratch(c, (size_t)ncirc * CUBIC_MID_G * 2 * sizeof(fr_t)); if (rc) return rc;
-  uint32_t turns = 0; for (size_t qq = q; qq > CUBIC_TAIL_Q; qq /= 2) turns++;
-  const uint32_t seq0 = c->seq + 1; c->seq += turns;
-  if (r) hipLaunchKernelGGL((k_cubic_mid<true>), dim3(ncirc * CUBIC_MID_G), dim3(LASSO_BLOCK), 0, c->stream, A, B, (const fr_t*)d_E, (uint32_t)q, (uint32_t)CUBIC_TAIL_Q, to_fr(r), (const uint32_t*)(c->d_flag + 32),
-                            (fr_t*)c->d_scratch, c->d_counters, c->d_small, c->d_flag, seq0);
-  else hipLaunchKernelGGL((k_cubic_mid<false>), dim3(ncirc * CUBIC_MID_G), dim3(LASSO_BLOCK), 0, c->stream, A, B, (const fr_t*)d_E, (uint32_t)q, (uint32_t)CUBIC_TAIL_Q, fr_zero(), (const uint32_t*)(c->d_flag + 32),
-                          (fr_t*)c->d_scratch, c->d_counters, c->d_small, c->d_flag, seq0);
-  HIPCHK(c, hipGetLastError());
-  c->tail_active = true; c->tail_seq0 = seq0; c->tail_turn = 0; c->tail_turns = turns; c->tail_count = (size_t)ncirc * 2; c->tail_final = 0;
-  c->pending = true; c->pending_seq = seq0; c->pending_count = c->tail_count;
-  return 0;
-}
 // The same for the primary sumcheck of a linear strategy (k_linear_tail): per round two dot products per polynomial, out[2k] = S0_k, out[2k+1] = S1_k
 // (as lasso_sumcheck_linear_eqw_round, without the unused third slot); after the last challenge the heads out[k] = polys_k[0] (alpha values).
 // d_src is only read (r == NULL: arrays of length n = 2q; otherwise bound with r first, n = 4q).  Challenges go through lasso_sumcheck_cubic_tail_next.
@@ -544,7 +522,7 @@ int32_t lasso_sumcheck_cubic_tail_next(lasso_ctx* c, const lasso_fr* r) {
   _mm_store_si128((__m128i*)(mail + 8), _mm_set_epi32(0, (int)rr.v[7], (int)rr.v[6], (int)tn));
   __atomic_thread_fence(__ATOMIC_RELEASE);
   const size_t cnt = c->tail_turn == c->tail_turns ? c->tail_final : c->tail_count;
-  if (cnt) { c->pending = true; c->pending_seq = c->tail_seq0 + c->tail_turn; c->pending_count = cnt; }   // k_cubic_mid's last challenge has no result
+  if (cnt) { c->pending = true; c->pending_seq = c->tail_seq0 + c->tail_turn; c->pending_count = cnt; }
   if (c->tail_turn == c->tail_turns) c->tail_active = false;
   return 0;
 }

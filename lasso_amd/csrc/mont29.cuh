@@ -14,7 +14,7 @@
 #include <stdint.h>
 
 #ifndef LHD
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define LHD __host__ __device__ __forceinline__
 #else
 #define LHD inline

@@ -510,108 +510,6 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_dot_eqw_fused(PtrTable src, Mut
   fr29 e[3] = {fr29_acc_reduce(w0), fr29_acc_reduce(w1), fr29_zero()};
   cubic_epilogue(e, g, partials, counters, out, flag, seq, S, 0);
 }
-// The rounds BEFORE the tail, 256 < q <= CUBIC_MID_Q indices per circuit, resident as well but on CUBIC_MID_G workgroups per circuit: workgroup g
-// of a circuit keeps the elements i = g (mod G) of A and B in LDS — both ends of every bind pair (i, i + h) while G divides h — and runs the tail's
-// turn on its slice; the slices' two partial sums meet in the last workgroup to arrive (the same ticket as the streaming kernels' second stage).
-// Every workgroup polls the host mailbox itself.  When the arrays are down to 2 * stop_q elements the bound values go back to device memory
-// (canonical, natural order) and the kernel ends without a publication: the single-workgroup tail takes over from there.
-#define CUBIC_MID_Q 4096
-#define CUBIC_MID_G 16
-template <bool BIND>
-__global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_mid(MutPtrTable A, MutPtrTable B, const fr_t* __restrict__ E, uint32_t q, uint32_t stop_q, fr_t r0, const uint32_t* mailbox,
-                                                            fr_t* __restrict__ partials, uint32_t* counters, fr_t* __restrict__ out, uint32_t* flag, uint32_t seq0) {
-  __shared__ fr29 bound[2][2 * CUBIC_TAIL_Q];   // this workgroup's slice of A', B'
-  __shared__ fr29 ge[2 * CUBIC_TAIL_Q];
-  __shared__ int32_t rows[2 * CUBIC_TAIL_Q * 9];
-  __shared__ int64_t strips[8 * 18];
-  __shared__ int64_t cols[18];
-  __shared__ RedScratch S;
-  __shared__ fr_t chal;
-  __shared__ uint32_t alive;
-  constexpr uint32_t G = CUBIC_MID_G;
-  const uint32_t t = threadIdx.x, y = blockIdx.x / G, g = blockIdx.x % G, ncirc = gridDim.x / G;
-  const uint64_t t_end = wall_clock64() + 500000000ull;   // 5 s at 100 MHz
-  uint32_t m = 2 * q, ml = m / G;    // global and local array lengths
-  fr_t* a_glob = A.p[y]; fr_t* b_glob = B.p[y];
-  {
-    const fr29 rs = fr29_unpack_s(r0);
-    for (uint32_t item = t; item < 2 * ml; item += LASSO_BLOCK) {
-      const uint32_t p = item / ml, li = item - p * ml, gi = li * G + g;
-      const fr_t* src = p == 0 ? a_glob : b_glob;
-      const fr29 v = BIND ? bind29(src[gi], src[gi + m], rs) : fr29_unpack_u(src[gi]);
-      bound[p][li] = v;
-      if (p == 0) ge[li] = fr29_mul(v, fr29_unpack_s(E[gi < q ? gi : gi - q]));
-    }
-  }
-  __syncthreads();
-  for (uint32_t turn = 0;; turn++) {
-    const uint32_t hl = ml / 2;   // local pairs
-    for (uint32_t u = t; u < 2 * hl; u += LASSO_BLOCK) {
-      const uint32_t v = u >= hl ? 1u : 0u, i = u - v * hl;
-      const fr29 g0 = ge[i], g1 = ge[i + hl], b0 = bound[1][i], b1 = bound[1][i + hl];
-      const fr29 term = v == 0 ? fr29_mul(b0, g0) : fr29_mul(fr29_sub(g1, g0), fr29_sub(b1, b0));
-#pragma unroll
-      for (int k = 0; k < 9; k++) rows[u * 9 + k] = term.v[k];
-    }
-    __syncthreads();
-    if (t < 8 * 18) {
-      const uint32_t col = t % 18, strip = t / 18, v = col / 9, k = col - v * 9;
-      const uint32_t per = (hl + 7) / 8, i0 = strip * per < hl ? strip * per : hl, i1 = i0 + per < hl ? i0 + per : hl;
-      int64_t sum = 0;
-      for (uint32_t i = i0; i < i1; i++) sum += rows[(v * hl + i) * 9 + k];
-      strips[strip * 18 + col] = sum;
-    }
-    __syncthreads();
-    if (t < 18) { int64_t sum = 0; for (int s8 = 0; s8 < 8; s8++) sum += strips[s8 * 18 + t]; cols[t] = sum; }
-    __syncthreads();
-    if (t < 2) {
-      int64_t c[9];
-#pragma unroll
-      for (int k = 0; k < 9; k++) c[k] = cols[t * 9 + k];
-      partials[((size_t)y * G + g) * 2 + t] = fr29_pack(fr29_reduce_columns(c, 5));
-    }
-    last_block_reduce(partials, G, 2, y, ncirc, counters, out, S, flag, seq0 + turn);
-    if (t == 0) {   // the round's challenge (three self-validating 16-byte chunks, see k_cubic_tail); every workgroup polls for itself
-      typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-      const u32x4* m4 = reinterpret_cast<const u32x4*>(mailbox);
-      uint32_t ok = 1; u32x4 c0, c1, c2; uint32_t spins = 0;
-      for (;;) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-        c0 = __builtin_nontemporal_load(m4); c1 = __builtin_nontemporal_load(m4 + 1); c2 = __builtin_nontemporal_load(m4 + 2);
-        if (c0.x == seq0 + turn + 1 && c1.x == seq0 + turn + 1 && c2.x == seq0 + turn + 1) break;   // tagged with the sequence number of the publication it enables: unique per context, never reset
-        if (c0.x == LASSO_MAIL_POISON || ((++spins & 63u) == 0 && wall_clock64() > t_end)) { ok = 0; break; }   // lasso_abort's tag, or the host stopped answering
-      }
-      if (ok) { chal.v[0] = c0.y; chal.v[1] = c0.z; chal.v[2] = c0.w; chal.v[3] = c1.y; chal.v[4] = c1.z; chal.v[5] = c1.w; chal.v[6] = c2.y; chal.v[7] = c2.z; }
-      alive = ok;
-    }
-    __syncthreads();
-    if (!alive) return;
-    const fr29 rs = fr29_unpack_s(chal);
-    const uint32_t h = m / 2, qn = h / 2, hn = hl / 2;   // after this bind: global length h, global pairs qn, local pairs hn
-    const bool more = qn > stop_q;
-    fr29 nb[2], ng[2];
-#pragma unroll
-    for (int pass = 0; pass < 2; pass++) {
-      const uint32_t u = t + pass * LASSO_BLOCK;
-      if (u < 2 * hl) {
-        const uint32_t p = u >= hl ? 1u : 0u, jx = u - p * hl, gi = jx * G + g;
-        nb[pass] = fr29_canonical(fr29_add(bound[p][jx], fr29_mul(fr29_sub(bound[p][jx + hl], bound[p][jx]), rs)));
-        if (more) { if (p == 0) ng[pass] = fr29_mul(nb[pass], fr29_unpack_s(E[gi < qn ? gi : gi - qn])); }
-        else (p == 0 ? a_glob : b_glob)[gi] = fr29_pack(nb[pass]);   // hand-over to the single-workgroup tail: natural order, canonical
-      }
-    }
-    if (!more) return;
-    __syncthreads();
-#pragma unroll
-    for (int pass = 0; pass < 2; pass++) {
-      const uint32_t u = t + pass * LASSO_BLOCK;
-      if (u < 2 * hl) { const uint32_t p = u >= hl ? 1u : 0u, jx = u - p * hl; bound[p][jx] = nb[pass]; if (p == 0) ge[jx] = ng[pass]; }
-    }
-    __syncthreads();
-    m = h; ml = hl; (void)hn;
-  }
-}
-
 // The tail of the primary sumcheck for a linear strategy, resident like k_cubic_tail: from q <= CUBIC_TAIL_Q indices per polynomial on, the
 // remaining rounds' two dot products per polynomial (S0_k = sum_{i<h} z[i] E[i], S1_k = sum_{i<h} z[i+h] E[i]) and the binds run out of LDS,
 // challenges arrive through the host mailbox, and the last publication is the heads z_k[0] = E_k(r_z).  One workgroup per polynomial; src is

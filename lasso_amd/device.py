@@ -153,21 +153,6 @@ class Device:
             out = np.empty((2 * k, 4), dtype=np.uint64); self._chk(self.lib.lasso_result_wait(self.ctx, _vp(out), 2 * k)); outs.append(out)
         return outs
 
-    def sumcheck_cubic_mid(self, a_ptrs, b_ptrs, d_e, n, r, challenges):
-        """multi-workgroup resident rounds (lasso_sumcheck_cubic_mid_begin): one (2k, 4) result per round; the last challenge has no result (arrays are written back)"""
-        k = len(a_ptrs)
-        rp = None if r is None else _vp(np.ascontiguousarray(r, dtype=np.uint64))
-        outs = []
-        self._chk(self.lib.lasso_sumcheck_cubic_mid_begin(self.ctx, self._ptrs(a_ptrs), self._ptrs(b_ptrs), k, C.c_void_p(d_e), n, rp))
-        out = np.empty((2 * k, 4), dtype=np.uint64); self._chk(self.lib.lasso_result_wait(self.ctx, _vp(out), 2 * k)); outs.append(out)
-        for t, ch in enumerate(challenges):
-            ch = np.ascontiguousarray(ch, dtype=np.uint64)
-            self._chk(self.lib.lasso_sumcheck_cubic_tail_next(self.ctx, _vp(ch)))
-            if t + 1 < len(challenges):
-                out = np.empty((2 * k, 4), dtype=np.uint64); self._chk(self.lib.lasso_result_wait(self.ctx, _vp(out), 2 * k)); outs.append(out)
-        self.sync()
-        return outs
-
     def sumcheck_linear_tail(self, ptrs, d_e, n, r, challenges):
         """resident tail of the primary sumcheck (lasso_sumcheck_linear_tail_begin + lasso_sumcheck_cubic_tail_next): per-round (alpha, 2, 4) sums, then the (alpha, 4) heads"""
         k = len(ptrs)

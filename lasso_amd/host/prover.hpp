@@ -738,18 +738,7 @@ class Prover {
       for (size_t j = j0; j < rounds && plain; j++) if (rand[v0 + j].is_zero()) plain = false;
       if (plain) tail_from = j0;
     }
-    // ... and the rounds just before it (256 < q <= 4096) by the multi-workgroup resident kernel (lasso_sumcheck_cubic_mid_begin), which hands
-    // its arrays over to the tail kernel
-    static const bool mid_off = [] { const char* v = getenv("LASSO_CUBIC_MID"); return !(v && v[0] == '1'); }();   // opt-in (LASSO_CUBIC_MID=1) until it has more GPU mileage
-    size_t mid_from = tail_from;
-    if (tail_from < rounds && !mid_off && k * 16 <= 256) {
-      size_t j0 = 0, l = len;
-      while (j0 < tail_from && (j0 == 0 ? l / 2 : l / 4) > 4096) { if (j0) l /= 2; j0++; }
-      bool plain = true;
-      for (size_t j = j0; j < tail_from && plain; j++) if (rand[v0 + j].is_zero()) plain = false;
-      if (plain) mid_from = j0;
-    }
-    bool in_tail = false, in_mid = false;
+    bool in_tail = false;
     for (size_t j = 0; j < rounds; j++) {
       const lasso_fr* table = d_E; Sc scale = degenerate ? Sc::one() : inv[j];
       if (degenerate) {   // T_j = eq(rand[v0+j+1 .. v0+rounds)) built explicitly (size len / 2^(j+1) at this point), times the slab factor hidden in d_E[0] / eq-prefix
@@ -763,21 +752,13 @@ class Prover {
       const Sc f0 = base * om, f1 = base * rj, f2 = base * (rj + rj - om), f3 = base * (rj + rj + rj - om - om);
       Sc c0, c2, c3;
       static const bool three_sums = [] { const char* v = getenv("LASSO_CUBIC_THREE_SUMS"); return v && v[0] == '1'; }();   // A/B switch for measurements
-      if (j >= mid_from || (!f1.is_zero() && !three_sums)) {
+      if (j >= tail_from || (!f1.is_zero() && !three_sums)) {
         // two sums per circuit, q_c(0) and the leading coefficient; q(1) follows from the claim e = e(0) + e(1) (sumcheck.rs:99-104 derives e(1)
         // the same way) and q(2), q(3) by extrapolation.  The inversion of f(1) overlaps the kernel.
         lasso_fr rp = r_prev.abi();
-        if (j < mid_from) d.chk(lasso_sumcheck_cubic_eqw2_begin(d.ctx, A.data(), B.data(), (uint32_t)k, table, len, j == 0 ? nullptr : &rp), "lasso_sumcheck_cubic_eqw2_begin");
-        else if (j < tail_from) {
-          if (!in_mid) { d.chk(lasso_sumcheck_cubic_mid_begin(d.ctx, A.data(), B.data(), (uint32_t)k, table, len, j == 0 ? nullptr : &rp), "lasso_sumcheck_cubic_mid_begin"); in_mid = true; }
-          else d.chk(lasso_sumcheck_cubic_tail_next(d.ctx, &rp), "lasso_sumcheck_cubic_tail_next");
-        } else if (!in_tail) {
-          if (in_mid) {   // the mid kernel's last challenge: it binds, writes the 512-element arrays back and ends; the tail starts on those
-            d.chk(lasso_sumcheck_cubic_tail_next(d.ctx, &rp), "lasso_sumcheck_cubic_tail_next"); in_mid = false;
-            d.chk(lasso_sumcheck_cubic_tail_begin(d.ctx, A.data(), B.data(), (uint32_t)k, table, len / 2, nullptr), "lasso_sumcheck_cubic_tail_begin");
-          } else d.chk(lasso_sumcheck_cubic_tail_begin(d.ctx, A.data(), B.data(), (uint32_t)k, table, len, j == 0 ? nullptr : &rp), "lasso_sumcheck_cubic_tail_begin");
-          in_tail = true;
-        } else d.chk(lasso_sumcheck_cubic_tail_next(d.ctx, &rp), "lasso_sumcheck_cubic_tail_next");
+        if (j < tail_from) d.chk(lasso_sumcheck_cubic_eqw2_begin(d.ctx, A.data(), B.data(), (uint32_t)k, table, len, j == 0 ? nullptr : &rp), "lasso_sumcheck_cubic_eqw2_begin");
+        else if (!in_tail) { d.chk(lasso_sumcheck_cubic_tail_begin(d.ctx, A.data(), B.data(), (uint32_t)k, table, len, j == 0 ? nullptr : &rp), "lasso_sumcheck_cubic_tail_begin"); in_tail = true; }
+        else d.chk(lasso_sumcheck_cubic_tail_next(d.ctx, &rp), "lasso_sumcheck_cubic_tail_next");
         if (j) len /= 2;
         // f(1) = 0 inside the tail can only come from a vanished running factor s (probability 2^-252): then f = 0 identically and q is irrelevant
         const Sc f1_inv = f1.is_zero() ? Sc::zero() : f1.inverse();

@@ -18,7 +18,6 @@ struct lasso_ctx {
   std::vector<Fr> pending; bool defer = false;
   std::vector<std::vector<Fr>> tail_a, tail_b; std::vector<Fr> tail_e;   // resident tail: private copies of the arrays
   bool tail_linear = false;   // k_linear_tail: tail_a holds the alpha polynomials, tail_b is unused
-  std::vector<lasso_fr*> mid_a, mid_b;   // k_cubic_mid: where the bound arrays go back when 2*256 elements are left
 };
 struct lasso_bases { std::vector<Point> pts; };
 
@@ -66,7 +65,7 @@ int32_t lasso_rccl_allgather(lasso_ctx*, const void*, void*, size_t) { return LA
 size_t lasso_point_row_bytes(void) { return 144; }
 int32_t lasso_hyrax_commit_rows_dev(lasso_ctx*, const lasso_fr*, size_t, size_t, const lasso_bases*, void*) { return LASSO_ERR_UNSUPPORTED; }
 int32_t lasso_points_reduce_compress(lasso_ctx*, const void*, uint32_t, size_t, uint8_t*) { return LASSO_ERR_UNSUPPORTED; }
-int32_t lasso_abort(lasso_ctx* c) { REQ(c, c); c->pending.clear(); c->defer = false; c->tail_a.clear(); c->tail_b.clear(); c->tail_e.clear(); c->mid_a.clear(); c->mid_b.clear(); return 0; }
+int32_t lasso_abort(lasso_ctx* c) { REQ(c, c); c->pending.clear(); c->defer = false; c->tail_a.clear(); c->tail_b.clear(); c->tail_e.clear(); return 0; }
 int32_t lasso_prof_get_large(lasso_ctx*, int32_t, uint64_t* n, double* ms, double* b) { if (n) *n = 0; if (ms) *ms = 0; if (b) *b = 0; return 0; }
 int32_t lasso_wait_stats(lasso_ctx*, uint64_t* w, double* us, int32_t) { if (w) *w = 0; if (us) *us = 0; return 0; }
 int32_t lasso_prof_get_units(lasso_ctx*, int32_t, int32_t, double* u) { if (u) *u = 0; return 0; }
@@ -178,10 +177,6 @@ int32_t lasso_result_wait(lasso_ctx* c, lasso_fr* out, size_t count) {
 static void tail_publish(lasso_ctx* ctx) {
   auto& ta = ctx->tail_a; auto& tb = ctx->tail_b; auto& te = ctx->tail_e; auto& pend = ctx->pending;
   const size_t k = ta.size(), m = ta[0].size();
-  if (!ctx->mid_a.empty() && m <= 512) {   // k_cubic_mid hands over: write back, no result
-    for (size_t c = 0; c < k; c++) for (size_t i = 0; i < m; i++) { F(ctx->mid_a[c])[i] = ta[c][i]; F(ctx->mid_b[c])[i] = tb[c][i]; }
-    ta.clear(); tb.clear(); ctx->mid_a.clear(); ctx->mid_b.clear(); pend.clear(); return;
-  }
   if (ctx->tail_linear) {
     if (m == 1) { pend.assign(k, Fr::zero()); for (size_t c = 0; c < k; c++) pend[c] = ta[c][0]; ta.clear(); ctx->tail_linear = false; return; }
     pend.assign(2 * k, Fr::zero());
@@ -205,16 +200,6 @@ int32_t lasso_sumcheck_cubic_tail_begin(lasso_ctx* c, lasso_fr* const* A, lasso_
   REQ(c, n >= (r ? 4u : 2u) && (n & (n - 1)) == 0 && c->tail_a.empty() && c->pending.empty());
   const size_t q = r ? n / 4 : n / 2; REQ(c, q >= 1 && q <= 256);
   c->tail_a.clear(); c->tail_b.clear();
-  for (uint32_t k = 0; k < nc; k++) { c->tail_a.emplace_back(F(A[k]), F(A[k]) + n); c->tail_b.emplace_back(F(B[k]), F(B[k]) + n); }
-  c->tail_e.assign(F(E), F(E) + q);
-  if (r) tail_bind(c, *F(r));
-  tail_publish(c);
-  return 0;
-}
-int32_t lasso_sumcheck_cubic_mid_begin(lasso_ctx* c, lasso_fr* const* A, lasso_fr* const* B, uint32_t nc, const lasso_fr* E, size_t n, const lasso_fr* r) {
-  REQ(c, n >= (r ? 4u : 2u) && (n & (n - 1)) == 0 && c->tail_a.empty() && c->pending.empty() && nc * 16 <= 256);
-  const size_t q = r ? n / 4 : n / 2; REQ(c, q > 256 && q <= 4096);
-  c->tail_a.clear(); c->tail_b.clear(); c->mid_a.assign(A, A + nc); c->mid_b.assign(B, B + nc);
   for (uint32_t k = 0; k < nc; k++) { c->tail_a.emplace_back(F(A[k]), F(A[k]) + n); c->tail_b.emplace_back(F(B[k]), F(B[k]) + n); }
   c->tail_e.assign(F(E), F(E) + q);
   if (r) tail_bind(c, *F(r));

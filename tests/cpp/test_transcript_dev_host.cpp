@@ -1,7 +1,7 @@
-// CPU check of lasso_amd/csrc/transcript_dev.cuh (Keccak-f[1600] / STROBE-128 / Merlin over 25 lanes, one state word each) against the host
+// CPU check of tools/transcript_dev.cuh (Keccak-f[1600] / STROBE-128 / Merlin over 25 lanes, one state word each) against the host
 // transcript of the product (lasso_amd/host/hashes.hpp, itself pinned to merlin's published vector through the oracle tests).  The lane backend here
 // executes the same index arithmetic the device backend does; only the exchange primitive (array lookup instead of __shfl) differs.
-#include "../../lasso_amd/csrc/transcript_dev.cuh"
+#include "../../tools/transcript_dev.cuh"
 #include "../../lasso_amd/host/field_host.hpp"
 #include "../../lasso_amd/host/hashes.hpp"
 #include <array>

@@ -505,51 +505,6 @@ def test_sumcheck_cubic_tail(devs, n, ncirc, bind):
         assert np.array_equal(x, y)
 
 
-@pytest.mark.parametrize("n,ncirc,bind", [(1024, 1, False), (2048, 2, True), (8192, 2, False), (16384, 2, True), (4096, 16, True), (8192, 3, True)])
-def test_sumcheck_cubic_mid(devs, n, ncirc, bind):
-    """the multi-workgroup resident rounds (256 < q <= 4096) against the per-round two-sum calls: same sums every round, and the arrays handed over
-    to the tail (first 512 elements, canonical) are the per-round path's bound arrays"""
-    rng = np.random.default_rng(n * 19 + ncirc)
-    A = [rand_fr(rng, n) for _ in range(ncirc)]
-    B = [rand_fr(rng, n) for _ in range(ncirc)]
-    q = n // 4 if bind else n // 2
-    E = rand_fr(rng, q)
-    r0 = rand_fr(rng, 1, edge=False)[0] if bind else None
-    turns = 0
-    while (q >> turns) > 256:
-        turns += 1
-    chal = rand_fr(rng, turns, edge=False)
-
-    def run(d):
-        pa = [d.upload(x) for x in A]; pb = [d.upload(x) for x in B]; pe = d.upload(E)
-        outs = d.sumcheck_cubic_mid(pa, pb, pe, n, r0, chal)
-        arrays = np.stack([d.download(p, (512, 4)) for p in pa + pb])
-        for p in pa + pb + [pe]:
-            d.free(p)
-        return outs, arrays
-
-    def per_round(d):
-        pa = [d.upload(x) for x in A]; pb = [d.upload(x) for x in B]; pe = d.upload(E)
-        outs = [d.sumcheck_cubic_eqw2(pa, pb, pe, n, r0)]
-        length = n // 2 if bind else n
-        for t in range(turns - 1):
-            outs.append(d.sumcheck_cubic_eqw2(pa, pb, pe, length, chal[t])); length //= 2
-        d.bind_top(pa + pb, length, chal[turns - 1])
-        arrays = np.stack([d.download(p, (512, 4)) for p in pa + pb])
-        for p in pa + pb + [pe]:
-            d.free(p)
-        return outs, arrays
-    (a, arr_a), (b, arr_b) = both(devs, run)
-    assert len(a) == turns
-    for x, y in zip(a, b):
-        assert np.array_equal(x, y)
-    assert np.array_equal(arr_a, arr_b)
-    ref, arr_ref = per_round(devs[0])
-    for x, y in zip(a, ref):
-        assert np.array_equal(x, y)
-    assert np.array_equal(arr_a, arr_ref)
-
-
 def test_abort_releases_a_waiting_tail_kernel(devs):
     """a host that stops answering between tail_begin and the last tail_next used to leave the context unusable (tail_active / pending set) and a
     kernel spinning until its 5 s bail-out.  lasso_abort posts the poison tag: the kernel leaves at its next poll, the protocol state is reset, and the very

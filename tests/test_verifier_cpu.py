@@ -97,7 +97,8 @@ def test_verifier_accepts_the_oracle_provers_proof(setup):
         o.close(); hp.free(None, gens)
 
 
-@pytest.mark.parametrize("name,curve", [("artefact_and_c1_2p10", "curve25519"), ("artefact_bn254_and_c4_2p8", "bn254")])
+@pytest.mark.parametrize("name,curve", [("artefact_and_c1_2p10", "curve25519"), ("artefact_bn254_and_c4_2p8", "bn254"),
+                                        ("artefact_and_c1_2p24", "curve25519")])   # the last one: the METRIC instance (AND, C=1, 2^24 lookups), proved on the MI355X
 def test_committed_artefact_files_verify(name, curve):
     """tests/golden/<name>/ (tools/dump_proof.py --mock): the ark-serialize files an unmodified Rust `verify` would read.  File-based golden
     check: digests as recorded, accepted by the product verifier AND by the oracle's verifier, from the bytes on disk alone (no lookups, no prover)."""

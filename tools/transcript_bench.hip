@@ -1,4 +1,4 @@
-// Device-resident Fiat-Shamir microbenchmark (lasso_amd/csrc/transcript_dev.cuh): one wave runs a sumcheck-shaped transcript schedule — per round three
+// Device-resident Fiat-Shamir microbenchmark (tools/transcript_dev.cuh): one wave runs a sumcheck-shaped transcript schedule — per round three
 // 32-byte scalars appended, one 64-byte challenge drawn and reduced to Fr — and the host checks the final challenge against its own Merlin transcript
 // (lasso_amd/host/hashes.hpp) and prints the time per round.  The number to compare with: a device -> host -> device turn costs >= 12 us per round today.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -Ilasso_amd/csrc -Iinclude -o tools/transcript_bench tools/transcript_bench.hip
@@ -6,7 +6,7 @@
 #include <cstdio>
 #include <cstring>
 #include <vector>
-#include "../lasso_amd/csrc/transcript_dev.cuh"
+#include "transcript_dev.cuh"
 #include "../lasso_amd/host/hashes.hpp"
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 

@@ -1,8 +1,10 @@
-// Fiat-Shamir on the device: Keccak-f[1600], STROBE-128 and the Merlin framing (merlin ^3.0.0 — Cargo.toml:29; call sites
-// src/utils/transcript.rs:20-72) with the 200-byte state spread over 25 LANES, one 64-bit word each.  GROUNDWORK, not yet on the prover's path:
-// the proof is latency-bound by ~470 sequential transcript rounds, each a device -> host -> device turn of >= 12 us; with the
-// transcript next to the data, the last workgroup of a round can derive the next challenge itself and the following launch reads it from
-// device memory — no turn at all.  What such a round needs is here and host-checked (tests/cpp/test_transcript_dev_host.cpp) against the host
+// EXPERIMENT (tools/, not part of the product): Fiat-Shamir on the device — Keccak-f[1600], STROBE-128 and the Merlin framing (merlin ^3.0.0 —
+// Cargo.toml:29; call sites src/utils/transcript.rs:20-72) with the 200-byte state spread over 25 LANES, one 64-bit word each.
+// The idea: the proof is latency-bound by ~470 sequential transcript rounds, each a device -> host -> device turn of ~12 us; with
+// the transcript next to the data the last workgroup of a round could derive the next challenge itself.  MEASURED on MI355X and dropped
+// (profiles/r02_transcript_bench_device_fiat_shamir.txt): the lane-distributed transcript matches the host's bytes, but one sumcheck-shaped round
+// (3 appends + 1 challenge = 4-5 permutations) costs 19.3 us on one wave — each Keccak round is four dependent cross-lane exchanges — against ~2 us of host
+// Keccak inside the 12 us turn it would replace.  The host keeps the transcript.  Host-checked by tests/cpp/test_transcript_dev_host.cpp against the host
 // transcript (lasso_amd/host/hashes.hpp): the permutation, the STROBE operations Merlin uses (meta-AD, AD, PRF), append_message /
 // challenge_bytes, and the 64-byte -> Fr reduction of challenge_scalar (utils/transcript.rs:61-65).
 //
