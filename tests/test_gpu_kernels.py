@@ -237,6 +237,47 @@ def test_hyrax_commit(devs, gens_300, ls, rs, maxv):
     assert np.array_equal(wa, wb) and [bytes(x) for x in wa] == compress_points(mock_lib, b)
 
 
+@pytest.mark.parametrize("world,ls,rs,maxv", [(2, 8, 64, 300), (4, 64, 256, None), (8, 300, 256, 1 << 16), (2, 1, 2, 5)])
+def test_slab_commitment_exchange_on_device(devs, gens_300, world, ls, rs, maxv):
+    """Slab mode's device-side exchange (lasso_hip.h "slab mode"): rank g commits to the columns = g (mod P) of every row over its own generator table and
+    leaves the L partial row sums on the device (lasso_hyrax_commit_rows_dev); lasso_rccl_allgather moves them; lasso_points_reduce_compress adds the P
+    partials of each row and compresses.  One MI355X here, so the P ranks are P passes on one context and the all-gather is exercised with a one-rank
+    RCCL communicator (the collective degenerates to a copy on the library's stream — the plumbing, dlopen and stream use are the real ones); the result
+    must be the full commitment's wire bytes."""
+    d = devs[0]
+    rng = np.random.default_rng(world * 1000 + ls + rs)
+    Z = rand_fr(rng, ls * rs) if maxv is None else small_fr(rng.integers(0, maxv, size=ls * rs, dtype=np.uint64))
+    G = gens_300[:rs]
+    b_full = d.bases_create(gens_300[: rs + 1])
+    pz = d.upload(Z)
+    want = d.hyrax_commit_compressed(pz, ls, rs, b_full)
+    rb = d.lib.lasso_point_row_bytes()
+    p_all = d.alloc(world * ls * rb); p_part = d.alloc(ls * rb)
+    Zm = Z.reshape(ls, rs, 4)
+    uid = (C.c_uint8 * 128)()
+    have_rccl = d.lib.lasso_rccl_unique_id(uid) == 0 and d.lib.lasso_rccl_init(d.ctx, 0, 1, uid) == 0
+    for g in range(world):
+        bg = d.bases_create(np.ascontiguousarray(G[g::world]))
+        pg = d.upload(np.ascontiguousarray(Zm[:, g::world, :]).reshape(-1, 4))
+        d._chk(d.lib.lasso_hyrax_commit_rows_dev(d.ctx, C.c_void_p(pg), ls, rs // world, C.c_void_p(bg), C.c_void_p(p_part)))
+        if have_rccl:      # world-1 all-gather: p_part -> slot g of p_all on the library's stream
+            d._chk(d.lib.lasso_rccl_allgather(d.ctx, C.c_void_p(p_part), C.c_void_p(p_all + g * ls * rb), ls * rb))
+        else:
+            d._chk(d.lib.lasso_copy(d.ctx, C.c_void_p(p_all + g * ls * rb), C.c_void_p(p_part), ls * rb))
+        d.sync(); d.free(pg); d.bases_destroy(bg)
+    out = np.empty((ls, 32), dtype=np.uint8)
+    d._chk(d.lib.lasso_points_reduce_compress(d.ctx, C.c_void_p(p_all), world, ls, out.ctypes.data_as(C.c_void_p)))
+    if have_rccl:
+        assert d.lib.lasso_rccl_ready(d.ctx) == 1
+        d._chk(d.lib.lasso_rccl_shutdown(d.ctx))
+        assert d.lib.lasso_rccl_ready(d.ctx) == 0
+    for p in (pz, p_all, p_part):
+        d.free(p)
+    d.bases_destroy(b_full)
+    assert [bytes(x) for x in out] == [bytes(x) for x in np.asarray(want).reshape(ls, 32)]
+    assert have_rccl, "librccl could not be loaded / initialised on this box (the exchange itself was still checked through a plain copy)"
+
+
 @pytest.mark.parametrize("ls,rs,tbits", [(1, 1, 1), (4, 8, 8), (16, 256, 16), (8, 300, 24), (3, 100, 32)])
 def test_hyrax_commit_u32(devs, gens_300, ls, rs, tbits):
     """commitment from the integer values (gathered from an integer table, as for E = T[dim]) == commitment of the same polynomial as field elements"""
