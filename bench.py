@@ -271,6 +271,8 @@ def main():
                "alg_GBps": round(b.value / (ms.value * 1e-3) / 1e9, 1) if ms.value > 0 else None, "avg_launch_us": round(ms.value * 1e3 / n.value, 2)}
         if u.value:
             out["ref_group_adds"] = round(u.value); out["ref_G_adds_per_s"] = round(u.value / (ms.value * 1e-3) / 1e9, 2) if ms.value > 0 else None
+            dev_lib.lasso_prof_get_units(ctx, kid, (1 if large else 0) | 2, C.byref(u))
+            out["executed_madds_upper_bound"] = round(u.value)
         return out
     kernels, timed_large = [], {}
     if not a.no_prof:
@@ -336,8 +338,11 @@ def main():
                 return {"kernel": k["kernel"], "bound": "valu (integer multiply-add issue; no MFMA, no HBM stream)", "achieved": round(ach, 2), "peak": ceil_["G_madd_per_s"] if ceil_ else None,
                         "unit": "G group-additions/s", "frac": round(ach / ceil_["G_madd_per_s"], 4) if ceil_ else None, "launches": k["launches"], "avg_launch_us": k["avg_launch_us"],
                         "ref_group_adds_per_launch": round(k["ref_group_adds"] / k["launches"]), "scope": scope, "peak_source": ceil_["source"] if ceil_ else None,
+                        "executed": {"madds_per_launch_upper_bound": round(k["executed_madds_upper_bound"] / k["launches"]), "G_madd_per_s_upper_bound": round(k["executed_madds_upper_bound"] / (k["ms"] * 1e-3) / 1e9, 2),
+                                     "frac_upper_bound": round(k["executed_madds_upper_bound"] / (k["ms"] * 1e-3) / 1e9 / ceil_["G_madd_per_s"], 4) if ceil_ else None,
+                                     "note": "mixed additions the kernel itself issues, counted as one per scalar digit it reads (zero digits are skipped, so the true count is lower)"} if k.get("executed_madds_upper_bound") else None,
                         "note": "achieved = additions the reference's msm_bigint_wnaf would perform (SURVEY 8(d) formula) / measured time; the kernels run a different schedule "
-                                "(precomputed window tables, one mixed addition per non-zero 4-bit digit), so frac can exceed what the executed additions alone would give"}
+                                "(precomputed window / byte-multiple tables: one mixed addition per non-zero digit, no bucket reduction, no doubling chain), so frac can exceed 1; `executed` prices the kernel's own additions"}
             out["roofline_msm"] = {"commit": roof_msm(_abi.K_MSM, timed_large, "row-parallel commitment MSMs (rows > 16), HIP events inside the timed region"),
                                    "opening": roof_msm(_abi.K_MSM_DIRECT, kernels, "latency-shaped opening MSMs (2 rows of full-width scalars per bullet round), one profiled step")}
             allfam = max(kernels, key=lambda k: k["ms"])                                        # over ALL families, streaming or not

@@ -91,7 +91,8 @@ int32_t lasso_prof_get(lasso_ctx* ctx, int32_t kernel_id, uint64_t* launches, do
 int32_t lasso_prof_get_large(lasso_ctx* ctx, int32_t kernel_id, uint64_t* launches, double* total_ms, double* alg_bytes);
 /* family-specific work units recorded beside the bytes.  MSM families: group additions of the REFERENCE's algorithm for the same inputs (SURVEY.md §8d:
  * L*(R+1)*W bucket accumulation + L*W*2*2^c bucket reduction + L*(W-1)*(c+1) window combine, src/msm/mod.rs:91-164); 0 for the streaming families.
- * large_only != 0: the launches lasso_prof_get_large counts (for LASSO_K_MSM: the row-parallel commitments, more than 16 rows). */
+ * large_only bit 0: the launches lasso_prof_get_large counts (for LASSO_K_MSM: the row-parallel commitments, more than 16 rows); bit 1: the second counter
+ * instead — MSM families: the mixed additions the kernel itself issues at most (one per scalar digit it looks at; zero digits are skipped). */
 int32_t lasso_prof_get_units(lasso_ctx* ctx, int32_t kernel_id, int32_t large_only, double* units);
 
 /* Host-side latency accounting: number of device->host result hand-offs (flag waits) and the host time spent spinning on them since the last reset. */

@@ -27,7 +27,7 @@ __global__ void __launch_bounds__(256) k_inner_lr(const fr_t* __restrict__ a, co
 static_assert(sizeof(lasso_fr) == 32 && sizeof(fr_t) == 32, "Fr layout");
 static_assert(sizeof(lasso_affine) == 64 && sizeof(lasso_point) == 128 && sizeof(ed_point) == 128 && sizeof(niels29) == 112 && sizeof(pt29) == 144, "curve layouts");
 
-struct EventPair { hipEvent_t a, b; int kid; double bytes, units; bool large; };
+struct EventPair { hipEvent_t a, b; int kid; double bytes, units, units2; bool large; };
 struct lasso_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -54,9 +54,15 @@ struct lasso_ctx {
   uint64_t big_launches[LASSO_K_COUNT] = {0}; double big_ms[LASSO_K_COUNT] = {0}; double big_bytes[LASSO_K_COUNT] = {0};
   // family-specific work units beside the bytes (the MSM families: group additions of the reference's algorithm), all / large launches
   double prof_units[LASSO_K_COUNT] = {0}; double big_units[LASSO_K_COUNT] = {0};
+  double prof_units2[LASSO_K_COUNT] = {0}; double big_units2[LASSO_K_COUNT] = {0};   // MSM families: mixed additions the kernel itself issues at most (one per scalar digit it looks at)
   void* rccl_comm = nullptr; int rccl_world = 0;   // slab mode's device-side exchange (lasso_rccl_*): an ncclComm_t bound to this context's device and stream
 };
-struct lasso_bases { size_t n = 0; niels29* d_table = nullptr; niels29* d_mult = nullptr; };   // d_mult: signed digit multiples for the latency-shaped MSM (k_msm_direct), optional
+struct lasso_bases {
+  size_t n = 0; niels29* d_table = nullptr;
+  niels29* d_mult = nullptr;                 // signed digit multiples for the latency-shaped MSM (k_msm_direct), optional
+  niels29* d_tab8[2] = {nullptr, nullptr};   // byte multiples m * 256^w * G_j, m = 1..255, for the row-parallel commitments of small scalars (k_msm_rows8); built on first use
+  bool tab8_failed = false;
+};
 
 static thread_local std::string g_create_err;
 
@@ -99,13 +105,13 @@ static int32_t ensure_big(lasso_ctx* c, size_t count) {
 struct ProfScope {
   lasso_ctx* c; int idx = -1;
   // `large`: the launch belongs to the throughput regime whatever its byte count (the row-parallel commitment MSMs: 64 MiB of u32 scalars, milliseconds of VALU work)
-  ProfScope(lasso_ctx* c_, int kid, double bytes, double units = 0, bool large = false) : c(c_) {
+  ProfScope(lasso_ctx* c_, int kid, double bytes, double units = 0, bool large = false, double units2 = 0) : c(c_) {
     if (!((c->prof_mask >> kid) & 1u)) return;
     large = large || bytes >= LASSO_PROF_LARGE_BYTES;
     if ((c->prof_mask & 0x40000000u) && !large) return;   // LASSO_PROF_LARGE_ONLY: leave the latency-bound launches unbracketed
     if (c->events_used == c->events.size()) { EventPair p; if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return; c->events.push_back(p); }
     idx = (int)c->events_used++;
-    c->events[idx].kid = kid; c->events[idx].bytes = bytes; c->events[idx].units = units; c->events[idx].large = large;
+    c->events[idx].kid = kid; c->events[idx].bytes = bytes; c->events[idx].units = units; c->events[idx].units2 = units2; c->events[idx].large = large;
     (void)hipEventRecord(c->events[idx].a, c->stream);
   }
   ~ProfScope() { if (idx >= 0) (void)hipEventRecord(c->events[idx].b, c->stream); }
@@ -115,8 +121,8 @@ static void prof_flush(lasso_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   for (size_t i = 0; i < c->events_used; i++) {
     float ms = 0; if (hipEventElapsedTime(&ms, c->events[i].a, c->events[i].b) != hipSuccess) continue;
-    int k = c->events[i].kid; c->prof_launches[k]++; c->prof_ms[k] += ms; c->prof_bytes[k] += c->events[i].bytes; c->prof_units[k] += c->events[i].units;
-    if (c->events[i].large) { c->big_launches[k]++; c->big_ms[k] += ms; c->big_bytes[k] += c->events[i].bytes; c->big_units[k] += c->events[i].units; }
+    int k = c->events[i].kid; c->prof_launches[k]++; c->prof_ms[k] += ms; c->prof_bytes[k] += c->events[i].bytes; c->prof_units[k] += c->events[i].units; c->prof_units2[k] += c->events[i].units2;
+    if (c->events[i].large) { c->big_launches[k]++; c->big_ms[k] += ms; c->big_bytes[k] += c->events[i].bytes; c->big_units[k] += c->events[i].units; c->big_units2[k] += c->events[i].units2; }
   }
   c->events_used = 0;
 }
@@ -312,10 +318,11 @@ int32_t lasso_prof_get_large(lasso_ctx* c, int32_t k, uint64_t* launches, double
 }
 int32_t lasso_wait_stats(lasso_ctx* c, uint64_t* waits, double* wait_us, int32_t reset) { REQUIRE(c, waits && wait_us); *waits = c->stat_waits; *wait_us = c->stat_wait_us; if (reset) { c->stat_waits = 0; c->stat_wait_us = 0; } return 0; }
 int32_t lasso_prof_enable(lasso_ctx* c, int32_t mask) { prof_flush(c); c->prof_mask = (uint32_t)mask; return 0; }
-int32_t lasso_prof_reset(lasso_ctx* c) { prof_flush(c); for (int i = 0; i < LASSO_K_COUNT; i++) { c->prof_launches[i] = 0; c->prof_ms[i] = 0; c->prof_bytes[i] = 0; c->big_launches[i] = 0; c->big_ms[i] = 0; c->big_bytes[i] = 0; c->prof_units[i] = 0; c->big_units[i] = 0; } return 0; }
+int32_t lasso_prof_reset(lasso_ctx* c) { prof_flush(c); for (int i = 0; i < LASSO_K_COUNT; i++) { c->prof_launches[i] = 0; c->prof_ms[i] = 0; c->prof_bytes[i] = 0; c->big_launches[i] = 0; c->big_ms[i] = 0; c->big_bytes[i] = 0; c->prof_units[i] = 0; c->big_units[i] = 0; c->prof_units2[i] = 0; c->big_units2[i] = 0; } return 0; }
 int32_t lasso_prof_get_units(lasso_ctx* c, int32_t k, int32_t large_only, double* units) {
   REQUIRE(c, k >= 0 && k < LASSO_K_COUNT && units); prof_flush(c);
-  *units = large_only ? c->big_units[k] : c->prof_units[k]; return 0;
+  const bool large = large_only & 1, second = large_only & 2;   // bit 1 selects the second counter (MSM families: the kernel's own mixed additions, upper bound)
+  *units = second ? (large ? c->big_units2[k] : c->prof_units2[k]) : (large ? c->big_units[k] : c->prof_units[k]); return 0;
 }
 int32_t lasso_prof_get(lasso_ctx* c, int32_t k, uint64_t* launches, double* ms, double* bytes) {
   REQUIRE(c, k >= 0 && k < LASSO_K_COUNT); prof_flush(c);
@@ -785,7 +792,26 @@ int32_t lasso_bases_create(lasso_ctx* c, const lasso_affine* points, size_t n, l
   }
   *out = b; return 0;
 }
-void lasso_bases_destroy(lasso_ctx* c, lasso_bases* b) { if (!b) return; if (c) (void)hipStreamSynchronize(c->stream); if (b->d_table) (void)hipFree(b->d_table); if (b->d_mult) (void)hipFree(b->d_mult); delete b; }
+void lasso_bases_destroy(lasso_ctx* c, lasso_bases* b) {
+  if (!b) return; if (c) (void)hipStreamSynchronize(c->stream);
+  if (b->d_table) (void)hipFree(b->d_table); if (b->d_mult) (void)hipFree(b->d_mult);
+  for (niels29* t : b->d_tab8) if (t) (void)hipFree(t);
+  delete b;
+}
+// the byte-multiple table of window w8 (k_precompute_tab8), built the first time a commitment asks for it: 255 * n * 112 bytes (117 MB for n = 4096).
+// LASSO_MSM_ROWS8=0 switches the path off (A/B measurements); an allocation failure falls back to the bucket kernel for the life of the bases object.
+static bool msm_rows8_enabled() { static const bool on = [] { const char* v = getenv("LASSO_MSM_ROWS8"); return !(v && v[0] == '0'); }(); return on; }
+static const niels29* ensure_tab8(lasso_ctx* c, const lasso_bases* cb, uint32_t w8) {
+  lasso_bases* b = const_cast<lasso_bases*>(cb);
+  if (b->d_tab8[w8]) return b->d_tab8[w8];
+  if (b->tab8_failed) return nullptr;
+  niels29* t = nullptr;
+  if (hipMalloc((void**)&t, (size_t)MSM8_MULTS * b->n * sizeof(niels29)) != hipSuccess) { (void)hipGetLastError(); b->tab8_failed = true; return nullptr; }
+  hipLaunchKernelGGL(k_precompute_tab8, dim3((unsigned)((b->n + 63) / 64)), dim3(64), 0, c->stream, (const niels29*)b->d_table, b->n, w8, t);
+  if (hipGetLastError() != hipSuccess) { (void)hipFree(t); b->tab8_failed = true; return nullptr; }
+  b->d_tab8[w8] = t;   // stream order: every later launch on this context sees the finished table
+  return t;
+}
 
 // chunks per row.  Measured on MI355X (profiles/): the bucket kernel is VALU-issue-bound even at one wave per SIMD (the 81 independent
 // multiply-adds of a field product pipeline back to back), so extra workgroups beyond one per CU only multiply the fixed per-workgroup
@@ -836,7 +862,7 @@ static int32_t run_msm_direct(lasso_ctx* c, const uint8_t* d_scal, size_t row_st
   uint32_t ipc = 0; const size_t K = msm_direct_chunks(rows, n_cols, &ipc);
   const uint32_t seq = ++c->seq;
   {
-    ProfScope ps(c, LASSO_K_MSM_DIRECT, (double)rows * n_cols * 32, msm_ref_adds(rows, n_cols, FR_MODULUS_BITS));
+    ProfScope ps(c, LASSO_K_MSM_DIRECT, (double)rows * n_cols * 32, msm_ref_adds(rows, n_cols, FR_MODULUS_BITS), false, (double)rows * n_cols * MSM_WINDOWS);
     hipLaunchKernelGGL(k_msm_direct, dim3((unsigned)K, (unsigned)rows), dim3(MSM_THREADS), 0, c->stream, (const uint32_t*)d_scal, row_stride / 4, (uint32_t)n_cols, ipc, cm, (const niels29*)b->d_mult, b->n,
                        (pt29*)scratch_after, (ed_point*)c->d_small, c->d_counters + LASSO_MAX_PTRS + 8, c->d_flag, seq);
   }
@@ -855,9 +881,16 @@ static int32_t run_msm(lasso_ctx* c, const uint8_t* d_scal, uint32_t bps, uint32
   const bool small = rows <= MSM_SMALL_ROWS && !out_compressed;
   ed_point* d_final = small ? (ed_point*)c->d_small : (ed_point*)(((uintptr_t)(d_partial + rows * K) + 15) & ~(uintptr_t)15);
   const uint32_t seq = small ? ++c->seq : 0;
+  // many rows of small scalars (<= 16 bits): one table entry per non-zero byte (k_msm_rows8) instead of nibble buckets
+  const niels29* t8[2] = {nullptr, nullptr};
+  const uint32_t W8 = (W + 1) / 2;
+  if (bps == 4 && W <= 4 && rows >= 32 && msm_rows8_enabled()) { t8[0] = ensure_tab8(c, b, 0); t8[1] = W8 > 1 && t8[0] ? ensure_tab8(c, b, 1) : t8[0]; if (!t8[1]) t8[0] = nullptr; }
   {
-    ProfScope ps(c, LASSO_K_MSM, (double)rows * n_cols * bps, msm_ref_adds(rows, n_cols, bps == 4 ? 4 * W : FR_MODULUS_BITS), rows > MSM_SMALL_ROWS);
-    hipLaunchKernelGGL(k_msm_buckets, dim3((unsigned)K, (unsigned)rows), dim3(MSM_THREADS), 0, c->stream, d_scal, bps, W, row_stride, n_cols, cols_per_chunk, (const niels29*)b->d_table, b->n, d_partial);
+    ProfScope ps(c, LASSO_K_MSM, (double)rows * n_cols * bps, msm_ref_adds(rows, n_cols, bps == 4 ? 4 * W : FR_MODULUS_BITS), rows > MSM_SMALL_ROWS,
+                 (double)rows * n_cols * (t8[0] ? W8 : W));
+    if (t8[0]) hipLaunchKernelGGL(k_msm_rows8, dim3((unsigned)K, (unsigned)rows), dim3(MSM_THREADS), 0, c->stream, (const uint32_t*)d_scal, row_stride / 4, (uint32_t)n_cols, (uint32_t)cols_per_chunk, W8,
+                                  t8[0], t8[1], b->n, d_partial);
+    else hipLaunchKernelGGL(k_msm_buckets, dim3((unsigned)K, (unsigned)rows), dim3(MSM_THREADS), 0, c->stream, d_scal, bps, W, row_stride, n_cols, cols_per_chunk, (const niels29*)b->d_table, b->n, d_partial);
     hipLaunchKernelGGL(k_points_sum, dim3((unsigned)rows), dim3(MSM_THREADS), 0, c->stream, (const pt29*)d_partial, (uint32_t)K, d_final, out_compressed ? (uint32_t*)d_final : (uint32_t*)nullptr,
                        c->d_counters + LASSO_MAX_PTRS + 1, small ? c->d_flag : (uint32_t*)nullptr, seq);
   }

@@ -316,6 +316,65 @@ __device__ __forceinline__ void msm_coop_tree(pt29* pts, fe29 (*st)[4], uint32_t
   }
 }
 #endif  // LASSO_BN254
+// ------------------------------------------------------------------ row-parallel commitment of SMALL scalars: one mixed addition per byte
+// The commitments of the path are L rows x R columns of small integers over shared generators — E = T[dim] holds table values (< 2^8 for AND / OR / XOR over
+// 16-bit indices, bits for LT), dim / read / final hold indices and counters (<= 16 bits at the benchmark's sizes).  The bucket kernel above spends one mixed
+// addition per non-zero NIBBLE plus a fixed tail per workgroup (digit sort, segmented tree, bit planes, Horner chain: ~45% of a 4096-column row).  With every
+// byte multiple m * 256^w * G_j, m = 1..255, tabulated once per generator set (tab8: 255 x n affine Niels entries per byte window, 117 MB for n = 4096 — the
+// generators are fixed for the life of a gens object and HBM is 288 GB), a row is a plain sum of ONE table entry per non-zero byte: no sort, no buckets, no
+// bit planes, then one cooperative tree.  2^24 8-bit scalars: 2^24 mixed additions instead of ~1.9 * 2^24 + tails.
+// tab8[(m-1)*n + j] = m * B_j with B_j = table[(2*w8)*n + j] = 256^w8 * G_j.  One thread per generator; multiples by repeated mixed addition, brought to
+// affine Niels form in runs of 16 that share one inversion (Montgomery's trick).
+#define MSM8_MULTS 255
+__global__ void __launch_bounds__(64) k_precompute_tab8(const niels29* __restrict__ table, size_t n, uint32_t w8, niels29* __restrict__ tab8) {
+  const size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const niels29 b = table[(size_t)(2 * w8) * n + j];
+  const fe29 d2 = fe_d2();
+  tab8[j] = b;
+  pt29 P = pt_madd(pt_identity(), b);
+  for (uint32_t m0 = 2; m0 <= MSM8_MULTS; m0 += 16) {
+    pt29 q[16]; fe29 pre[16];
+    const uint32_t cnt = MSM8_MULTS + 1 - m0 < 16 ? MSM8_MULTS + 1 - m0 : 16;
+    for (uint32_t c = 0; c < cnt; c++) { P = pt_madd(P, b); q[c] = P; pre[c] = c ? fe_mul(pre[c - 1], P.Z) : P.Z; }
+    fe29 inv = fe_inv_chain(pre[cnt - 1]);
+    for (uint32_t c = cnt; c-- > 0;) {
+      const fe29 zi = c ? fe_mul(inv, pre[c - 1]) : inv;
+      if (c) inv = fe_mul(inv, q[c].Z);
+      tab8[(size_t)(m0 + c - 1) * n + j] = niels_from_xy29(fe_mul(q[c].X, zi), fe_mul(q[c].Y, zi), d2);
+    }
+  }
+}
+// grid = (K chunks, rows).  scal: u32 scalars, row r at scal + r*row_words; W8 = bytes per scalar that can be non-zero (1 or 2).  out[row*K + chunk] = the chunk's
+// partial sum in the kernels' point form (k_points_sum finishes the row exactly as it does for k_msm_buckets).
+__global__ void __launch_bounds__(MSM_THREADS) k_msm_rows8(const uint32_t* __restrict__ scal, size_t row_words, uint32_t n_cols, uint32_t cols_per_chunk, uint32_t W8,
+                                                            const niels29* __restrict__ tab8_0, const niels29* __restrict__ tab8_1, size_t tn, pt29* __restrict__ out) {
+  __shared__ pt29 pts[MSM_THREADS];
+  __shared__ fe29 st[MSM_THREADS / 4][4];
+  const fe29 d2 = fe_d2();
+  const uint32_t t = threadIdx.x;
+  const uint32_t* row = scal + (size_t)blockIdx.y * row_words;
+  const uint32_t c0 = blockIdx.x * cols_per_chunk;
+  uint32_t c1 = c0 + cols_per_chunk; if (c1 > n_cols) c1 = n_cols;
+  pt29 B = pt_identity();
+  niels29 cur; bool have = false;
+  for (uint32_t c = c0 + t; c < c1; c += MSM_THREADS) {
+    const uint32_t v = row[c];
+    for (uint32_t w = 0; w < W8; w++) {
+      const uint32_t d = (v >> (8 * w)) & 255u;
+      // the fetch is unconditional (entry 0 for a zero byte) so that it is issued BEFORE the mixed addition below and waited for after it
+      const niels29 nxt = (w ? tab8_1 : tab8_0)[d ? (size_t)(d - 1) * tn + c : 0];
+      if (have) B = pt_madd(B, cur);
+      cur = nxt; have = d != 0;
+    }
+  }
+  if (have) B = pt_madd(B, cur);
+  pts[t] = B;
+  __syncthreads();
+  msm_coop_tree(pts, st, MSM_THREADS, d2);
+  if (t == 0) out[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = pts[0];
+}
+
 #define MSM_DIRECT_MAX_COLS 160   // columns a workgroup may touch (items_per_chunk <= 64 * (MSM_DIRECT_MAX_COLS - 1))
 // grid = (K chunks, rows).  scal: canonical little-endian scalars, 8 words each, row r at scal + r*row_words.  One item = one (column, window);
 // chunk k owns items [k*items_per_chunk, ...).  out_mont[row] (host-mapped) = the row's sum in ark's Montgomery limbs; the workgroup that

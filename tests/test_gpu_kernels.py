@@ -213,7 +213,10 @@ def gens_300(devs):
     return gens(devs[1].lib, b"gens_sparse_poly", 300)
 
 
-@pytest.mark.parametrize("ls,rs,maxv", [(1, 1, 5), (4, 8, 256), (16, 256, 1 << 16), (8, 300, 1 << 24), (3, 100, 1 << 32), (2, 64, None)])
+@pytest.mark.parametrize("ls,rs,maxv", [(1, 1, 5), (4, 8, 256), (16, 256, 1 << 16), (8, 300, 1 << 24), (3, 100, 1 << 32), (2, 64, None),
+                                        # >= 32 rows of scalars <= 16 bits: the byte-table kernel (k_msm_rows8), one and two byte windows, ragged columns, a chunked row, and
+                                        # just past its limits (17 and 24 bits: the bucket kernel again)
+                                        (64, 256, 256), (40, 77, 2), (300, 300, 1 << 16), (33, 129, 1 << 12), (32, 5, 1 << 9), (64, 100, 1 << 17), (48, 64, 1 << 24)])
 def test_hyrax_commit(devs, gens_300, ls, rs, maxv):
     rng = np.random.default_rng(ls * 31 + rs)
     if maxv is None:
@@ -278,7 +281,7 @@ def test_slab_commitment_exchange_on_device(devs, gens_300, world, ls, rs, maxv)
     assert have_rccl, "librccl could not be loaded / initialised on this box (the exchange itself was still checked through a plain copy)"
 
 
-@pytest.mark.parametrize("ls,rs,tbits", [(1, 1, 1), (4, 8, 8), (16, 256, 16), (8, 300, 24), (3, 100, 32)])
+@pytest.mark.parametrize("ls,rs,tbits", [(1, 1, 1), (4, 8, 8), (16, 256, 16), (8, 300, 24), (3, 100, 32), (128, 128, 8), (64, 300, 16), (32, 33, 1), (40, 64, 17)])
 def test_hyrax_commit_u32(devs, gens_300, ls, rs, tbits):
     """commitment from the integer values (gathered from an integer table, as for E = T[dim]) == commitment of the same polynomial as field elements"""
     rng = np.random.default_rng(ls * 17 + rs)
