@@ -214,7 +214,7 @@ def main():
     rank, world = grp.rank, grp.world
     hp = HostProver(device=grp.device_index, curve=a.curve)
     slab = a.shard_proof and world > 1
-    shm_name = f"/lasso_bench_{os.environ.get('MASTER_PORT', '0')}_{os.getuid()}"
+    shm_name = f"/lasso_bench_{os.environ.get('MASTER_PORT', '0')}_{os.getuid()}_{grp.shared_nonce():x}"   # per-job name: a stale segment of a crashed job cannot be picked up
     if slab:
         # slab mode: every polynomial split by low index bits; per-round partial sums through the library's shared-memory exchange, the partial row
         # commitments all-gathered by RCCL over xGMI on the library's stream (lasso_host_set_comm_shm)

@@ -1,8 +1,11 @@
 """Multi-GPU plumbing (one process per GPU, torch.distributed; backend "nccl" = RCCL over xGMI on ROCm, "gloo" in CPU tests).
 
 The north-star path shards by PROOF: each rank owns an independent batch of lookups (its own DensifiedRepresentation,
-transcript and proof) — independent objects, so there is no data-path collective (DESIGN.md §multi-GPU).  torch.distributed
-is only used for the barrier / max-over-ranks timing contract of bench.py and to gather proof digests."""
+transcript and proof) — independent objects, so there is no data-path collective (DESIGN.md §5).  torch.distributed
+is only used for the barrier / max-over-ranks timing contract of bench.py, to gather proof digests and to agree on a job nonce.
+Slab mode (ONE proof over the ranks) exchanges through the library itself: HostProver.set_comm_shm (shared-memory all-gather of the per-round
+sums, RCCL all-gather of the partial row commitments on the library's stream); `allgather_callback` below is the older transport-agnostic
+hook (lasso_host_set_comm), kept for embedders and covered by the gloo test."""
 import hashlib
 import os
 
@@ -61,6 +64,17 @@ class Group:
         t = self._tensor([float(x)], self.torch.float64)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return float(t.item())
+
+    def shared_nonce(self):
+        """One random 64-bit value, the same on every rank (drawn by rank 0): makes per-job names — e.g. the shared-memory segment of slab mode — that a
+        crashed earlier job with the same MASTER_PORT cannot collide with."""
+        import secrets
+        x = secrets.randbits(62)
+        if self.dist is None:
+            return x
+        t = self._tensor([x], self.torch.int64)
+        self.dist.broadcast(t, src=0)
+        return int(t.item())
 
     def gather_digests(self, payload: bytes):
         """sha256 of each rank's proof, gathered on every rank (32 bytes per rank — the only bytes that cross ranks)."""
