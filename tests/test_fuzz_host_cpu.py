@@ -1,6 +1,7 @@
 """CPU: seeded differential fuzz of the host prover (over the mock of the device ABI) against the oracle prover, both curve builds: random strategy,
 C in 1..4, table sizes 2^1..2^8, ragged lookup counts up to 5000, three index distributions (independent per dimension, the harness's replicated
-draw, one address hit every time).  Commitment and proof bytes must be identical and the oracle verifier must accept.  The open-ended version of this
+draw, one address hit every time).  Commitment and proof bytes must be identical, the oracle verifier and the product-side verifier must accept, and the product-side
+verifier must reject the proof with one random bit flipped.  The open-ended version of this
 loop ran 10,000 configurations clean (tools/fuzz_host.py); the bitwise tables need an even log_m (an address splits into two operands of log_m / 2 bits —
 with an odd log_m the reference's own MLE formula disagrees with its table, and its verifier rejects its own proof)."""
 import ctypes as C
@@ -40,7 +41,14 @@ def run(host, oracle, seed, count):
         tag = f"{kind} C={c} log_m={log_m} log_r={log_r} lookups={lookups}"
         gens = host.gens(c, s, 2 * c if kind == "lt" else c, log_m); dense = host.densify(idx, log_m)
         comm = host.commit(dense, gens); proof = host.prove(dense, gens, S, r)
+        accepted = host.verify(gens, S, s, r, proof, comm)           # the product-side verifier on every fuzzed proof ...
+        bad = bytearray(proof); pos = int(rng.integers(len(bad))); bad[pos] ^= 1 << int(rng.integers(8))
+        try:
+            rejected = host.verify(gens, S, s, r, bytes(bad), comm) is False      # ... and on one corrupted bit of it
+        except Exception:
+            rejected = True                                                        # bytes that no longer deserialize
         host.free(dense, gens)
+        assert accepted is True and rejected, tag + f" (verifier: accepted={accepted}, corrupted byte {pos} rejected={rejected})"
         o = OracleSession(oracle, _abi.KINDS[kind], c, log_m, log_r, idx, r)
         try:
             assert comm == o.commit(), tag

@@ -37,7 +37,13 @@ while time.time() - t0 < budget:
     tag = f"{kind} C={c} log_m={log_m} log_r={log_r} lookups={lookups} mode={mode}"
     try:
         gens = hp.gens(c, s, alpha, log_m); dense = hp.densify(idx, log_m)
-        comm = hp.commit(dense, gens); proof = hp.prove(dense, gens, S, r); hp.free(dense, gens)
+        comm = hp.commit(dense, gens); proof = hp.prove(dense, gens, S, r)
+        acc = hp.verify(gens, S, s, r, proof, comm)
+        bad = bytearray(proof); bad[int(rng.integers(len(bad)))] ^= 1 << int(rng.integers(8))
+        try: rej = hp.verify(gens, S, s, r, bytes(bad), comm) is False
+        except Exception: rej = True
+        hp.free(dense, gens)
+        if acc is not True or not rej: print("VERIFIER MISMATCH", tag, acc, rej)
     except Exception as e:
         print("HOST FAIL", tag, repr(e)[:300]); continue
     try:

@@ -55,5 +55,19 @@ int main() {
     if (rep) printf("per round trip (us): launch+sync %.1f | launch+memcpyD2H+sync %.1f | launch(mapped host store)+sync %.1f | launch+host-flag spin %.1f | 2 launches+memcpy+sync %.1f\n",
                     (t1 - t0) / N, (t2 - t1) / N, (t3 - t2) / N, (t4 - t3) / N, (t5 - t4) / N);
   }
+  // host-side cost of an enqueue (the launch API call itself, nothing waited for): what every one of a proof's ~700 launches costs the host thread
+  {
+    Big big; for (int i = 0; i < 272; i++) big.p[i] = nullptr;
+    for (int rep = 0; rep < 2; rep++) {
+      CK(hipStreamSynchronize(s));
+      double a0 = now();
+      for (int i = 0; i < 400; i++) hipLaunchKernelGGL(k_small, dim3(1), dim3(64), 0, s, d, i);
+      double a1 = now(); CK(hipStreamSynchronize(s)); double a2 = now();
+      for (int i = 0; i < 400; i++) hipLaunchKernelGGL(k_flag_big, dim3(1), dim3(64), 0, s, big, dm, df, (uint32_t)i);
+      double a3 = now(); CK(hipStreamSynchronize(s)); double a4 = now();
+      if (rep) printf("enqueue only (host time per hipLaunchKernelGGL, 400 back-to-back): 16 B of arguments %.2f us (drain %.2f us per kernel) | 2176 B of arguments %.2f us (drain %.2f)\n",
+                      (a1 - a0) / 400, (a2 - a0) / 400, (a3 - a2) / 400, (a4 - a2) / 400);
+    }
+  }
   return 0;
 }
