@@ -48,12 +48,22 @@ def run(host, oracle, seed, count):
         except Exception:
             rejected = True                                                        # bytes that no longer deserialize
         host.free(dense, gens)
-        assert accepted is True and rejected, tag + f" (verifier: accepted={accepted}, corrupted byte {pos} rejected={rejected})"
+        assert accepted is True, tag
         o = OracleSession(oracle, _abi.KINDS[kind], c, log_m, log_r, idx, r)
         try:
             assert comm == o.commit(), tag
             assert proof == o.prove(), tag
             assert o.verify(proof, comm) == 1, tag
+            # One flipped bit is rejected — unless it lands on an encoding ark-serialize itself treats as equivalent (the sign bit of a point with x = 0, e.g. the
+            # identity that commits to an all-zero row: `get_point_from_y_unchecked` returns the same point for either flag value and the transcript absorbs the
+            # RE-serialised bytes); then the reference's verifier accepts too, and so must both verifiers here.  (Found by the open-ended fuzz: RangeCheck with
+            # LOG_R < log_m has all-zero memories.)
+            if not rejected:
+                try:
+                    also = o.verify(bytes(bad), comm) == 1
+                except Exception:
+                    also = False
+                assert also, tag + f": corrupted byte {pos} accepted by the product verifier but not by the oracle's"
         finally:
             o.close()
 
