@@ -31,14 +31,18 @@ lasso_ctx* lasso_host_ctx(lasso_host* h);   /* the device context, e.g. for lass
 
 /* Slab mode: ONE proof sharded over `world` GPUs (world a power of two, one lasso_host per rank, every rank given the SAME lookups and point).
  * Every polynomial is split by low index bits (rank g holds the indices = g mod world), the transcript is replicated, and `allgather` is the only
- * collective: it must gather `bytes` bytes from every rank into recv (rank order) and return 0 — RCCL/gloo all_gather in lasso_amd/parallel.py.
+ * collective: it must gather `bytes` bytes from every rank into recv (rank order) and return 0 (any transport the embedder has; the gloo test uses
+ * lasso_amd/parallel.py's).  Prefer lasso_host_set_comm_shm below on one node: no callback per round, and the partial row commitments go over RCCL.
  * Must be called before lasso_host_gens_new / lasso_host_densify.  All ranks return the same commitment and proof bytes (the bytes a single GPU
  * produces).  world = 1 restores the single-GPU path. */
 typedef int32_t (*lasso_host_allgather_fn)(void* user, const void* send, void* recv, size_t bytes);
 int32_t lasso_host_set_comm(lasso_host* h, int32_t rank, int32_t world, lasso_host_allgather_fn allgather, void* user);
 /* The same with the library's own intra-node exchange instead of a callback: the P ranks of one node (one process per GPU) meet in the POSIX
  * shared-memory segment `name` ("/..." — identical on every rank) and all-gather their per-round partial sums through it (lasso_amd/host/shm_comm.hpp):
- * about a microsecond per exchange, nothing of the embedding language in the loop.  Must precede gens_new / densify, like lasso_host_set_comm. */
+ * about a microsecond per exchange, nothing of the embedding language in the loop.  When every rank can join one RCCL communicator (one GPU per rank; rank 0's
+ * ncclUniqueId travels through the segment and the ranks agree on the outcome), the bulk exchange — the partial row commitments of the Hyrax matrices — runs as
+ * ncclAllGather on the context's stream with the per-row sums on the device (include/lasso_hip.h "slab mode"); otherwise it too goes through the segment.
+ * LASSO_SLAB_RCCL=0 keeps RCCL out.  Must precede gens_new / densify, like lasso_host_set_comm. */
 int32_t lasso_host_set_comm_shm(lasso_host* h, int32_t rank, int32_t world, const char* name);
 
 int32_t lasso_host_gens_new(lasso_host* h, const char* label, size_t c, size_t s, size_t num_memories, size_t log_m, lasso_host_gens** out);
