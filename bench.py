@@ -63,6 +63,7 @@ def parse():
     p.add_argument("--slab-steps", type=int, default=2)
     p.add_argument("--no-slab-leg", action="store_true", help="skip the extra slab-mode leg (ONE proof over all N GPUs; at N = 1 its single-GPU reference time)")
     p.add_argument("--slab-timeout", type=float, default=240.0)
+    p.add_argument("--slab-worker", default=None, help=argparse.SUPPRESS)   # internal: rank,world,device,shm_name — the slab leg's child process
     return p.parse_args()
 
 
@@ -161,53 +162,68 @@ def concurrent_leg(HostProver, _abi, streams, steps, S, c, log_m, log_s, curve="
             "note": "independent proofs proved concurrently on one GPU (one context, stream and host thread each); not the headline metric"}
 
 
-def slab_leg(a, HostProver, _abi, grp, shm_name):
-    """ONE proof over the N ranks (include/lasso_prover.h lasso_host_set_comm_shm): per-round partial sums through the shared-memory exchange, partial row
-    commitments through RCCL all-gather on the library's stream when every rank could join the communicator.  Returns the leg's JSON object."""
-    import threading
-    rank, world = grp.rank, grp.world
+def slab_worker(a):
+    """Child process of the slab leg (one per rank, `bench.py --slab-worker rank,world,device,shm_name`): ONE proof over the ranks, no torch.distributed —
+    the ranks meet in the shared-memory segment.  Prints the leg's JSON object on its last stdout line."""
+    import hashlib
+    from lasso_amd import HostProver, _abi
+    rank, world, device, shm_name = a.slab_worker.split(",", 3)
+    rank, world, device = int(rank), int(world), int(device)
     kind, c, log_m, log_s = a.slab_kind, a.slab_c, a.log_m, a.slab_log_s
     alpha = 2 * c if kind == "lt" else c
     s = 1 << log_s
-    if (2 * c + alpha) * s * 32 * 5 / world > 200e9:      # ~5x the committed polynomials resident per rank
-        return {"skipped": f"{kind} C={c} 2^{log_s} does not fit {world} GPU(s)"}
-    box = {}
+    hp = HostProver(device=device, curve=a.curve)
+    if world > 1:
+        hp.set_comm_shm(rank, world, shm_name)
+    S = _abi.Strategy(_abi.KINDS[kind], c, log_m, a.log_r if kind == "range" else 0)
+    idx = hp.gen_indices(s, 1 << log_m, c)                 # the SAME lookups on every rank: one proof
+    r = hp.gen_random_point(log_s)
+    dev_lib = C.CDLL(os.path.join(ROOT, "lasso_amd", "liblasso_hip.so")); _abi.declare(dev_lib)
+    t0 = time.perf_counter(); gens = hp.gens(c, s, alpha, log_m); dense = hp.densify(idx, log_m); del idx
+    comm = hp.commit(dense, gens); t_setup = time.perf_counter() - t0
+    proof = hp.prove(dense, gens, S, r)                    # warm-up
+    t0 = time.perf_counter()
+    for _ in range(a.slab_steps):
+        proof = hp.prove(dense, gens, S, r)
+    el = (time.perf_counter() - t0) / a.slab_steps
+    rccl = dev_lib.lasso_rccl_ready(hp.ctx())
+    out = {"workload": f"{kind.upper()} subtable, C={c}, M=2^{log_m}, s=2^{log_s} lookups, ONE proof over {world} GPU(s)" + (" (BASELINE.json configs[3])" if (kind, c, log_s) == ("range", 4, 26) else ""),
+           "n_gpus": world, "scaling": "strong", "ms_per_proof": el * 1e3, "value": s / el, "unit": "lookups/s", "steps": a.slab_steps,
+           "rccl_ranks": int(rccl), "exchange": ("per-round sums: shared-memory all-gather (lasso_amd/host/shm_comm.hpp); partial row commitments: " +
+                                                  ("RCCL ncclAllGather on the library's stream + device-side row sums" if rccl == world and world > 1 else "shared-memory all-gather + host row sums")) if world > 1 else "none (single GPU)",
+           "setup_s": round(t_setup, 2), "proof_bytes": len(proof), "proof_sha256": hashlib.sha256(proof).hexdigest(), "commitment_sha256": hashlib.sha256(comm).hexdigest()}
+    hp.free(dense, gens); hp.close()
+    print(json.dumps(out), flush=True)
 
-    def work():
-        try:
-            hp = HostProver(device=grp.device_index, curve=a.curve)
-            if world > 1:
-                hp.set_comm_shm(rank, world, shm_name + "_slab")
-            S = _abi.Strategy(_abi.KINDS[kind], c, log_m, a.log_r if kind == "range" else 0)
-            idx = hp.gen_indices(s, 1 << log_m, c)                 # the SAME lookups on every rank: one proof
-            r = hp.gen_random_point(log_s)
-            dev_lib = C.CDLL(os.path.join(ROOT, "lasso_amd", "liblasso_hip.so")); _abi.declare(dev_lib)
-            t0 = time.perf_counter(); gens = hp.gens(c, s, alpha, log_m); dense = hp.densify(idx, log_m); del idx
-            comm = hp.commit(dense, gens); t_setup = time.perf_counter() - t0
-            proof = hp.prove(dense, gens, S, r)                    # warm-up
-            t0 = time.perf_counter()
-            for _ in range(a.slab_steps):
-                proof = hp.prove(dense, gens, S, r)
-            el = (time.perf_counter() - t0) / a.slab_steps
-            rccl = dev_lib.lasso_rccl_ready(hp.ctx())
-            import hashlib
-            box.update({"workload": f"{kind.upper()} subtable, C={c}, M=2^{log_m}, s=2^{log_s} lookups, ONE proof over {world} GPU(s)" + (" (BASELINE.json configs[3])" if (kind, c, log_s) == ("range", 4, 26) else ""),
-                        "n_gpus": world, "scaling": "strong", "ms_per_proof": el * 1e3, "value": s / el, "unit": "lookups/s", "steps": a.slab_steps,
-                        "rccl_ranks": int(rccl), "exchange": ("per-round sums: shared-memory all-gather (lasso_amd/host/shm_comm.hpp); partial row commitments: " +
-                                                               ("RCCL ncclAllGather on the library's stream + device-side row sums" if rccl == world and world > 1 else "shared-memory all-gather + host row sums")) if world > 1 else "none (single GPU)",
-                        "setup_s": round(t_setup, 2), "proof_bytes": len(proof), "proof_sha256": hashlib.sha256(proof).hexdigest(), "commitment_sha256": hashlib.sha256(comm).hexdigest()})
-            hp.free(dense, gens); hp.close()
-        except Exception as e:      # the main line must survive a failing leg
-            box["error"] = repr(e)[:500]
-    th = threading.Thread(target=work, daemon=True)
-    th.start(); th.join(a.slab_timeout)
-    if th.is_alive():
+
+def slab_leg(a, grp, shm_name):
+    """ONE proof over the N ranks (include/lasso_prover.h lasso_host_set_comm_shm): per-round partial sums through the shared-memory exchange, partial row
+    commitments through RCCL all-gather on the library's stream when every rank could join the communicator.  Every rank runs the leg in a CHILD process
+    (slab_worker) under a timeout: whatever happens in there — an exchange that never completes, a fault in a code path no multi-GPU node has run yet —
+    stays in there, and the main line's numbers, final before the leg starts, are printed regardless.  Returns the leg's JSON object (rank 0's child's)."""
+    import subprocess
+    rank, world = grp.rank, grp.world
+    kind, c, log_s = a.slab_kind, a.slab_c, a.slab_log_s
+    alpha = 2 * c if kind == "lt" else c
+    if (2 * c + alpha) * (1 << log_s) * 32 * 5 / world > 200e9:      # ~5x the committed polynomials resident per rank
+        return {"skipped": f"{kind} C={c} 2^{log_s} does not fit {world} GPU(s)"}
+    cmd = [sys.executable, os.path.abspath(__file__), "--slab-worker", f"{rank},{world},{grp.device_index},{shm_name}_slab", "--slab-kind", kind, "--slab-c", str(c),
+           "--slab-log-s", str(log_s), "--slab-steps", str(a.slab_steps), "--log-m", str(a.log_m), "--log-r", str(a.log_r), "--curve", a.curve]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}   # the child is not a torch.distributed rank
+    try:
+        res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=a.slab_timeout)
+    except subprocess.TimeoutExpired:
         return {"error": f"slab leg did not finish within {a.slab_timeout:.0f} s", "timed_out": True, "n_gpus": world}
-    return box
+    lines = [ln for ln in res.stdout.strip().splitlines() if ln.startswith("{")]
+    if res.returncode != 0 or not lines:
+        return {"error": f"slab worker exited with {res.returncode}: {res.stderr.strip()[-400:]}", "n_gpus": world}
+    return json.loads(lines[-1])
 
 
 def main():
     a = parse()
+    if a.slab_worker:
+        return slab_worker(a)
     from lasso_amd import HostProver, _abi
     from lasso_amd.parallel import Group, shard_indices
     grp = Group(backend=a.backend)     # torch.distributed (nccl = RCCL) only when WORLD_SIZE > 1
@@ -372,17 +388,13 @@ def main():
     hp.close()
     # Extra leg, beside — never instead of — `value`: ONE proof sharded over all N GPUs (slab mode, strong scaling) on the configuration the north star
     # shards (BASELINE.json configs[3] by default).  At N = 1 the same proof on the one GPU: the base of the strong-scaling curve.  The main line's numbers
-    # are final before this leg starts; the leg runs under a watchdog so that an exchange that never completes cannot take the bench line with it.
-    hung = False
+    # are final before this leg starts; the leg runs in a child process per rank under a timeout, so that nothing in it can take the bench line with it.
     if not a.no_slab_leg and not slab and a.curve == "curve25519":
-        res = slab_leg(a, HostProver, _abi, grp, shm_name)
-        hung = bool(res.get("timed_out"))
+        res = slab_leg(a, grp, shm_name)
         if rank == 0:
             out["slab_mode"] = res
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if hung:
-        os._exit(0)        # a wedged collective cannot be joined; the line is out
     grp.close()
 
 
