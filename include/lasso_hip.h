@@ -195,6 +195,11 @@ int32_t lasso_gp_build(lasso_ctx* ctx, lasso_fr* d_tree, size_t n);
  * d_read_out[i]  = d_read[i]*gamma^2 + d_table[d_dim[i]]*gamma + d_dim[i] - tau,  d_write_out[i] = d_read_out[i] + gamma^2 */
 int32_t lasso_fingerprint_ops(lasso_ctx* ctx, const lasso_fr* d_table, const uint32_t* d_dim, const lasso_fr* d_read, size_t s,
                               const lasso_fr* gamma, const lasso_fr* tau, lasso_fr* d_read_out, lasso_fr* d_write_out);
+/* lasso_fingerprint_ops followed by lasso_gp_build of both trees, as ONE call: the first product layer (grand_product.rs:20-36) is taken while the leaves are still
+ * in registers, so they are written once and not read back.  d_tree_read / d_tree_write: 2s-element tree arenas (leaves, then the layers); s >= 4, a power of two.
+ * Bit-identical to the three separate calls. */
+int32_t lasso_fingerprint_ops_gp(lasso_ctx* ctx, const lasso_fr* d_table, const uint32_t* d_dim, const lasso_fr* d_read, size_t s, const lasso_fr* gamma, const lasso_fr* tau,
+                                 lasso_fr* d_tree_read, lasso_fr* d_tree_write);
 /* init/final sets (memory_checking.rs:254-273): d_init_out[i] = d_table[i]*gamma + i - tau, d_final_out[i] = d_init_out[i] + d_final[i]*gamma^2 */
 int32_t lasso_fingerprint_mem(lasso_ctx* ctx, const lasso_fr* d_table, const lasso_fr* d_final, size_t m,
                               const lasso_fr* gamma, const lasso_fr* tau, lasso_fr* d_init_out, lasso_fr* d_final_out);

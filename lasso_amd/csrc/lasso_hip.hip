@@ -642,16 +642,37 @@ int32_t lasso_read_heads(lasso_ctx* c, const lasso_fr* const* d_polys, uint32_t 
   HIPCHK(c, hipGetLastError());
   return fetch_small(c, k, out);
 }
-int32_t lasso_gp_build(lasso_ctx* c, lasso_fr* d_tree, size_t n) {
-  REQUIRE(c, d_tree && n >= 2 && (n & (n - 1)) == 0);
-  fr_t* in = (fr_t*)d_tree; size_t len = n;
-  ProfScope ps(c, LASSO_K_GP, 48.0 * n * 2.0);
+// layers above `in` (len elements, the layers laid out back to back behind it): one launch per large layer, the small ones in one workgroup
+static void gp_layers_from(lasso_ctx* c, fr_t* in, size_t len) {
   while (len > 2 * LASSO_BLOCK) {
     size_t half = len / 2;
     hipLaunchKernelGGL(k_gp_layer, dim3(grid_for(half, 4096)), dim3(LASSO_BLOCK), 0, c->stream, (const fr_t*)in, half, in + len);
     in += len; len = half;
   }
   if (len > 2) hipLaunchKernelGGL(k_gp_tail, dim3(1), dim3(LASSO_BLOCK), 0, c->stream, in, len);
+}
+int32_t lasso_gp_build(lasso_ctx* c, lasso_fr* d_tree, size_t n) {
+  REQUIRE(c, d_tree && n >= 2 && (n & (n - 1)) == 0);
+  ProfScope ps(c, LASSO_K_GP, 48.0 * n * 2.0);
+  gp_layers_from(c, (fr_t*)d_tree, n);
+  HIPCHK(c, hipGetLastError()); return 0;
+}
+// lasso_fingerprint_ops + lasso_gp_build of both trees in one call, with the first product layer taken while the leaves are still in registers
+// (k_fingerprint_ops_l1): d_tree_r / d_tree_w are 2s-element arenas, leaves first.  Same bytes as the three separate calls.
+int32_t lasso_fingerprint_ops_gp(lasso_ctx* c, const lasso_fr* d_table, const uint32_t* d_dim, const lasso_fr* d_read, size_t s, const lasso_fr* gamma, const lasso_fr* tau,
+                                 lasso_fr* d_tree_r, lasso_fr* d_tree_w) {
+  REQUIRE(c, d_table && d_dim && d_read && gamma && tau && d_tree_r && d_tree_w && s >= 4 && (s & (s - 1)) == 0);
+  fr_t g = to_fr(gamma), g2 = fr_sqr(g), t = to_fr(tau);
+  fr_t* tr = (fr_t*)d_tree_r; fr_t* tw = (fr_t*)d_tree_w;
+  {
+    ProfScope ps(c, LASSO_K_FINGERPRINT, (32.0 * 3 + 64.0) * s + 2 * 48.0 * s);   // the fingerprints + the first layer of two trees (48 n per layer)
+    hipLaunchKernelGGL(k_fingerprint_ops_l1, dim3(grid_for(s / 2, 4096)), dim3(LASSO_BLOCK), 0, c->stream, (const fr_t*)d_table, d_dim, (const fr_t*)d_read, s, g, g2, t, tr, tw, tr + s, tw + s);
+  }
+  {
+    ProfScope ps(c, LASSO_K_GP, 2 * 48.0 * s);   // the remaining layers of both trees
+    gp_layers_from(c, tr + s, s / 2);
+    gp_layers_from(c, tw + s, s / 2);
+  }
   HIPCHK(c, hipGetLastError()); return 0;
 }
 int32_t lasso_fingerprint_ops(lasso_ctx* c, const lasso_fr* d_table, const uint32_t* d_dim, const lasso_fr* d_read, size_t s, const lasso_fr* gamma, const lasso_fr* tau,

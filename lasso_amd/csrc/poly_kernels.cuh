@@ -745,6 +745,29 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_fingerprint_ops(const fr_t* __r
     out_w[i] = fr29_store(fr29_add(h, g2u));   // ts+1: (t+1)*gamma^2 = t*gamma^2 + gamma^2
   }
 }
+// The same fingerprints TOGETHER WITH the first product layer of the two trees (grand_product.rs:20-36 on the leaves just computed): thread i < s/2 makes the
+// leaves i and i + s/2 of both circuits, stores them (the bottom layer's sumcheck reads them) and multiplies the pair while it still holds them — the
+// 2 x 32 s bytes that k_gp_layer would read straight back never leave the chip.  l1_r / l1_w: s/2 elements each.  Operands go through the memory form exactly
+// as k_gp_layer reads them, so the tree is bit-identical.
+__global__ void __launch_bounds__(LASSO_BLOCK) k_fingerprint_ops_l1(const fr_t* __restrict__ table, const uint32_t* __restrict__ dim, const fr_t* __restrict__ read, size_t s,
+                                                                     fr_t gamma, fr_t gamma2, fr_t tau, fr_t* __restrict__ out_r, fr_t* __restrict__ out_w, fr_t* __restrict__ l1_r, fr_t* __restrict__ l1_w) {
+  const fr29 gs = fr29_unpack_s(gamma), g2s = fr29_unpack_s(gamma2), g2u = fr29_unpack_u(gamma2), tu = fr29_unpack_u(tau), r2s = fr29_r2s();
+  const size_t half = s / 2;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x) {
+    fr_t lr[2], lw[2];
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+      const size_t k = i + e * half;
+      const uint32_t a = dim[k];
+      fr29 h = fr29_add(fr29_mul(fr29_unpack_u(read[k]), g2s), fr29_mul(fr29_unpack_u(table[a]), gs));
+      h = fr29_canonical(fr29_sub(fr29_add(h, fr29_mul(fr29_from_u64_int(a), r2s)), tu));
+      lr[e] = fr29_pack(h); lw[e] = fr29_store(fr29_add(h, g2u));
+      out_r[k] = lr[e]; out_w[k] = lw[e];
+    }
+    l1_r[i] = fr29_store(fr29_mul(fr29_unpack_u(lr[0]), fr29_unpack_s(lr[1])));
+    l1_w[i] = fr29_store(fr29_mul(fr29_unpack_u(lw[0]), fr29_unpack_s(lw[1])));
+  }
+}
 // slab mode: local index i stands for global address a = i*world + rank; `table` is the whole subtable, `fin` and the outputs are local (m = local length)
 __global__ void __launch_bounds__(LASSO_BLOCK) k_fingerprint_mem(const fr_t* __restrict__ table, const fr_t* __restrict__ fin, size_t m, uint32_t world, uint32_t rank, fr_t gamma, fr_t gamma2, fr_t tau,
                                                                   fr_t* __restrict__ out_i, fr_t* __restrict__ out_f) {

@@ -195,6 +195,10 @@ class Device:
         g = np.ascontiguousarray(gamma, dtype=np.uint64); t = np.ascontiguousarray(tau, dtype=np.uint64)
         self._chk(self.lib.lasso_fingerprint_ops(self.ctx, C.c_void_p(d_table), C.c_void_p(d_dim), C.c_void_p(d_read), s, _vp(g), _vp(t), C.c_void_p(d_ro), C.c_void_p(d_wo)))
 
+    def fingerprint_ops_gp(self, d_table, d_dim, d_read, s, gamma, tau, d_tree_r, d_tree_w):
+        g = np.ascontiguousarray(gamma, dtype=np.uint64); t = np.ascontiguousarray(tau, dtype=np.uint64)
+        self._chk(self.lib.lasso_fingerprint_ops_gp(self.ctx, C.c_void_p(d_table), C.c_void_p(d_dim), C.c_void_p(d_read), s, _vp(g), _vp(t), C.c_void_p(d_tree_r), C.c_void_p(d_tree_w)))
+
     def fingerprint_mem(self, d_table, d_final, m, gamma, tau, d_io, d_fo):
         g = np.ascontiguousarray(gamma, dtype=np.uint64); t = np.ascontiguousarray(tau, dtype=np.uint64)
         self._chk(self.lib.lasso_fingerprint_mem(self.ctx, C.c_void_p(d_table), C.c_void_p(d_final), m, _vp(g), _vp(t), C.c_void_p(d_io), C.c_void_p(d_fo)))

@@ -1172,9 +1172,13 @@ class Prover {
       size_t j = S.memory_to_dimension_index(i); const lasso_fr* table = tables[S.memory_to_subtable_index(i)].p;
       DBuf ti(d, 2 * m_loc), tf(d, 2 * m_loc), tr(d, 2 * s_loc), tw(d, 2 * s_loc);
       d.chk(lasso_fingerprint_mem_slab(d.ctx, table, dense.final_(j), m_loc, (uint32_t)P, (uint32_t)d.comm.rank, &g, &ta, ti.p, tf.p), "lasso_fingerprint_mem");
-      d.chk(lasso_fingerprint_ops(d.ctx, table, dense.dim_u32[j].p, dense.read(j), s_loc, &g, &ta, tr.p, tw.p), "lasso_fingerprint_ops");
       d.chk(lasso_gp_build(d.ctx, ti.p, m_loc), "lasso_gp_build"); d.chk(lasso_gp_build(d.ctx, tf.p, m_loc), "lasso_gp_build");
-      d.chk(lasso_gp_build(d.ctx, tr.p, s_loc), "lasso_gp_build"); d.chk(lasso_gp_build(d.ctx, tw.p, s_loc), "lasso_gp_build");
+      if (s_loc >= 4) {   // read / write leaves and both trees in one call: the first product layer is taken while the leaves are in registers (no re-read of 2 x 32 s bytes)
+        d.chk(lasso_fingerprint_ops_gp(d.ctx, table, dense.dim_u32[j].p, dense.read(j), s_loc, &g, &ta, tr.p, tw.p), "lasso_fingerprint_ops_gp");
+      } else {
+        d.chk(lasso_fingerprint_ops(d.ctx, table, dense.dim_u32[j].p, dense.read(j), s_loc, &g, &ta, tr.p, tw.p), "lasso_fingerprint_ops");
+        d.chk(lasso_gp_build(d.ctx, tr.p, s_loc), "lasso_gp_build"); d.chk(lasso_gp_build(d.ctx, tw.p, s_loc), "lasso_gp_build");
+      }
       t_init.push_back(std::move(ti)); t_final.push_back(std::move(tf)); t_read.push_back(std::move(tr)); t_write.push_back(std::move(tw));
     }
     // ProductLayerProof::prove (memory_checking.rs:674-731)

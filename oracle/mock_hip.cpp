@@ -262,6 +262,12 @@ int32_t lasso_fingerprint_ops(lasso_ctx*, const lasso_fr* table, const uint32_t*
   }
   return 0;
 }
+int32_t lasso_fingerprint_ops_gp(lasso_ctx* c, const lasso_fr* table, const uint32_t* dim, const lasso_fr* read, size_t s, const lasso_fr* gamma, const lasso_fr* tau, lasso_fr* tr, lasso_fr* tw) {
+  REQ(c, s >= 4 && (s & (s - 1)) == 0);   // the device's fused form == the literal steps: fingerprints (memory_checking.rs:284-301), then GrandProductCircuit::new of each (grand_product.rs:38-58)
+  int32_t rc = lasso_fingerprint_ops(c, table, dim, read, s, gamma, tau, tr, tw); if (rc) return rc;
+  rc = lasso_gp_build(c, tr, s); if (rc) return rc;
+  return lasso_gp_build(c, tw, s);
+}
 int32_t lasso_fingerprint_mem(lasso_ctx*, const lasso_fr* table, const lasso_fr* fin, size_t m, const lasso_fr* gamma, const lasso_fr* tau, lasso_fr* io, lasso_fr* fo) {
   Fr g = *F(gamma), g2 = g.square(), t = *F(tau);
   for (size_t i = 0; i < m; i++) {  // memory_checking.rs:257-273

@@ -193,6 +193,32 @@ def test_fingerprints_gather_from_u32(devs, s, log_m):
         assert np.array_equal(x, y)
 
 
+@pytest.mark.parametrize("s,log_m", [(4, 2), (16, 4), (1 << 10, 8), (1 << 13, 8), (1 << 17, 16)])
+def test_fingerprint_ops_gp_fused(devs, s, log_m):
+    """lasso_fingerprint_ops_gp (leaves + first product layer in one kernel, then the remaining layers of both trees) == lasso_fingerprint_ops + two lasso_gp_build,
+    on the device AND against the mock's literal statement: every element of both 2s-element tree arenas"""
+    rng = np.random.default_rng(s + log_m)
+    m = 1 << log_m
+    table = rand_fr(rng, m); read = small_fr(rng.integers(0, 1 << 20, size=s, dtype=np.uint64))
+    dim = rng.integers(0, m, size=s, dtype=np.uint32); dim[0] = m - 1
+    gamma, tau = rand_fr(rng, 2, edge=False)
+
+    def run(d):
+        pt = d.upload(table); pd = d.upload(dim); pr = d.upload(read)
+        tr = d.alloc(64 * s); tw = d.alloc(64 * s); xr = d.alloc(64 * s); xw = d.alloc(64 * s)
+        d.fingerprint_ops_gp(pt, pd, pr, s, gamma, tau, tr, tw)
+        d.fingerprint_ops(pt, pd, pr, s, gamma, tau, xr, xw); d.gp_build(xr, s); d.gp_build(xw, s)
+        n_used = 2 * s - 2      # leaves s, then s/2, ..., 2
+        outs = [d.download(p, (2 * s, 4))[:n_used] for p in (tr, tw, xr, xw)]
+        for p in (pt, pd, pr, tr, tw, xr, xw):
+            d.free(p)
+        return outs
+    a, b = both(devs, run)
+    assert np.array_equal(a[0], a[2]) and np.array_equal(a[1], a[3])          # fused == separate calls on the device
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)                                             # device == mock (the reference's loops)
+
+
 @pytest.mark.parametrize("ls,rs", [(1, 1), (2, 4), (32, 64), (64, 300), (512, 1024)])
 def test_matvec_left(devs, ls, rs):
     rng = np.random.default_rng(ls * 1000 + rs)
