@@ -634,31 +634,44 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_combine_round_linear(StrategyDe
   }
   store_block_partials<3>(acc, 3, partials + (size_t)blockIdx.x * 3, 5, R);   // (u * s) * u: 2^5 short
 }
-// K3 for LT: degree = C + 1.  A = compile-time bound on NUM_MEMORIES = 2C, D = bound on the degree
+// K3 for LT: degree = C + 1.  A = compile-time bound on NUM_MEMORIES = 2C (dispatch only), D = bound on the degree.
+// g(x) eq(x) = sum_i LT_i(x) * prod_{j<i} EQ_j(x) * eq(x) at the points x = 0..degree (lt.rs:62-71 inside sumcheck.rs:179-218), every factor linear in x.
+// The memories are STREAMED: per point the thread keeps only the running product e(x) * prod_{j<i} EQ_j(x) and the running sum — 2 (D + 1) field elements,
+// whatever C is — and walks i = 0..C-1 loading one (LT_i, EQ_i) pair of lines at a time, stepping them from point to point by addition.  (The first version
+// held all 2C lines and their differences in registers: 4C + D + 1 elements, 738 VGPRs at C = 16 — it spilled, and the degree-17 round of LT C=16 ran at
+// 128 GB/s, 54 % of that proof.)  Starting the running product at e(x) instead of 1 weights every term by the eq polynomial for free, so the sums accumulate
+// straight across indices.  Same 2 C (D + 1) products per index as the literal loop; identical field elements.
 template <int A, int D>
 __global__ void __launch_bounds__(LASSO_BLOCK) k_combine_round_lt(StrategyDev S, PtrTable polys, const fr_t* __restrict__ eq, size_t half, uint32_t degree, fr_t* __restrict__ partials) {
   __shared__ RedScratch R;
-  fr29 acc[D + 1]; uint32_t cnt = 0;
+  fr29 sum[D + 1], run[D + 1]; uint32_t cnt = 0;
 #pragma unroll
-  for (int x = 0; x <= D; x++) acc[x] = fr29_zero();
+  for (int x = 0; x <= D; x++) sum[x] = fr29_zero();
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x) {
-    fr29 cur[A], dif[A];
+    {
+      fr29 ecur = fr29_unpack_u(eq[i]); const fr29 edif = fr29_sub(fr29_unpack_u(eq[i + half]), ecur);
 #pragma unroll
-    for (int j = 0; j < A; j++) if ((uint32_t)j < S.alpha) { cur[j] = fr29_unpack_s(polys.p[j][i]); dif[j] = fr29_sub(fr29_unpack_s(polys.p[j][i + half]), cur[j]); }
-    fr29 ecur = fr29_unpack_u(eq[i]); const fr29 edif = fr29_sub(fr29_unpack_u(eq[i + half]), ecur);
-#pragma unroll
-    for (int x = 0; x <= D; x++) if ((uint32_t)x <= degree) {
-      acc[x] = fr29_weak(fr29_add(acc[x], fr29_mul(combine_lt<A>(cur, S.c), ecur)));   // s * u = u
-#pragma unroll
-      for (int j = 0; j < A; j++) if ((uint32_t)j < S.alpha) cur[j] = fr29_weak(fr29_add(cur[j], dif[j]));
-      ecur = fr29_weak(fr29_add(ecur, edif));
+      for (int x = 0; x <= D; x++) if ((uint32_t)x <= degree) { run[x] = ecur; ecur = fr29_weak(fr29_add(ecur, edif)); }
     }
-    if ((++cnt & 63u) == 0) {
+    for (uint32_t m = 0; m < S.c; m++) {
+      const fr_t* __restrict__ pl = polys.p[2 * m]; const fr_t* __restrict__ pe = polys.p[2 * m + 1];
+      fr29 lt = fr29_unpack_s(pl[i]), eqv = fr29_unpack_s(pe[i]);   // s-form lines: products of any degree stay in the accumulator's form (s * u = u)
+      const fr29 dlt = fr29_sub(fr29_unpack_s(pl[i + half]), lt), deq = fr29_sub(fr29_unpack_s(pe[i + half]), eqv);
 #pragma unroll
-      for (int x = 0; x <= D; x++) acc[x] = fr29_mul(acc[x], fr29_one_s());
+      for (int x = 0; x <= D; x++) if ((uint32_t)x <= degree) {
+        sum[x] = fr29_weak(fr29_add(sum[x], fr29_mul(lt, run[x])));
+        run[x] = fr29_mul(eqv, run[x]);
+        lt = fr29_weak(fr29_add(lt, dlt)); eqv = fr29_weak(fr29_add(eqv, deq));
+      }
+    }
+    cnt += S.c;
+    if (cnt >= 96u) {   // at most 127 additions between folds (acc_add's bound), S.c <= 16 per index
+      cnt = 0;
+#pragma unroll
+      for (int x = 0; x <= D; x++) sum[x] = fr29_mul(sum[x], fr29_one_s());
     }
   }
-  store_block_partials<D + 1>(acc, degree + 1, partials + (size_t)blockIdx.x * (degree + 1), 0, R);
+  store_block_partials<D + 1>(sum, degree + 1, partials + (size_t)blockIdx.x * (degree + 1), 0, R);
 }
 // K10: claim = sum_k eq[k] * g(E(k))  (subtables/mod.rs:187-216)
 template <int A>
