@@ -641,38 +641,45 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_combine_round_linear(StrategyDe
 // held all 2C lines and their differences in registers: 4C + D + 1 elements, 738 VGPRs at C = 16 — it spilled, and the degree-17 round of LT C=16 ran at
 // 128 GB/s, 54 % of that proof.)  Starting the running product at e(x) instead of 1 weights every term by the eq polynomial for free, so the sums accumulate
 // straight across indices.  Same 2 C (D + 1) products per index as the literal loop; identical field elements.
+// The per-point state is spelled out as scalars (LT_REP): as arrays `fr29 sum[D + 1], run[D + 1]` the compiler left them in scratch memory even with every index
+// a constant after unrolling (1312 bytes per lane at D = 17), which is exactly the traffic this kernel exists to avoid.
+#define LT_REP(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15) M(16) M(17)
+#define LT_DECL(k) fr29 sum##k = fr29_zero(), run##k = fr29_zero();
+#define LT_INIT(k) if constexpr (k <= D) { if ((uint32_t)k <= degree) { run##k = ecur; ecur = fr29_weak(fr29_add(ecur, edif)); } }
+#define LT_STEP(k) if constexpr (k <= D) { if ((uint32_t)k <= degree) { sum##k = fr29_weak(fr29_add(sum##k, fr29_mul(lt, run##k))); run##k = fr29_mul(eqv, run##k); \
+                                                                       lt = fr29_weak(fr29_add(lt, dlt)); eqv = fr29_weak(fr29_add(eqv, deq)); } }
+#define LT_FOLD(k) if constexpr (k <= D) sum##k = fr29_mul(sum##k, fr29_one_s());
+#define LT_OUT(k) if constexpr (k <= D) res[k] = sum##k;
 template <int A, int D>
 __global__ void __launch_bounds__(LASSO_BLOCK) k_combine_round_lt(StrategyDev S, PtrTable polys, const fr_t* __restrict__ eq, size_t half, uint32_t degree, fr_t* __restrict__ partials) {
+  static_assert(D <= 17, "LT_REP lists 18 points");
   __shared__ RedScratch R;
-  fr29 sum[D + 1], run[D + 1]; uint32_t cnt = 0;
-#pragma unroll
-  for (int x = 0; x <= D; x++) sum[x] = fr29_zero();
+  LT_REP(LT_DECL)
+  uint32_t cnt = 0;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x) {
     {
       fr29 ecur = fr29_unpack_u(eq[i]); const fr29 edif = fr29_sub(fr29_unpack_u(eq[i + half]), ecur);
-#pragma unroll
-      for (int x = 0; x <= D; x++) if ((uint32_t)x <= degree) { run[x] = ecur; ecur = fr29_weak(fr29_add(ecur, edif)); }
+      LT_REP(LT_INIT)
     }
     for (uint32_t m = 0; m < S.c; m++) {
       const fr_t* __restrict__ pl = polys.p[2 * m]; const fr_t* __restrict__ pe = polys.p[2 * m + 1];
       fr29 lt = fr29_unpack_s(pl[i]), eqv = fr29_unpack_s(pe[i]);   // s-form lines: products of any degree stay in the accumulator's form (s * u = u)
       const fr29 dlt = fr29_sub(fr29_unpack_s(pl[i + half]), lt), deq = fr29_sub(fr29_unpack_s(pe[i + half]), eqv);
-#pragma unroll
-      for (int x = 0; x <= D; x++) if ((uint32_t)x <= degree) {
-        sum[x] = fr29_weak(fr29_add(sum[x], fr29_mul(lt, run[x])));
-        run[x] = fr29_mul(eqv, run[x]);
-        lt = fr29_weak(fr29_add(lt, dlt)); eqv = fr29_weak(fr29_add(eqv, deq));
-      }
+      LT_REP(LT_STEP)
     }
     cnt += S.c;
-    if (cnt >= 96u) {   // at most 127 additions between folds (acc_add's bound), S.c <= 16 per index
-      cnt = 0;
-#pragma unroll
-      for (int x = 0; x <= D; x++) sum[x] = fr29_mul(sum[x], fr29_one_s());
-    }
+    if (cnt >= 96u) { cnt = 0; LT_REP(LT_FOLD) }   // at most 127 additions between folds (acc_add's bound), S.c <= 16 per index
   }
-  store_block_partials<D + 1>(sum, degree + 1, partials + (size_t)blockIdx.x * (degree + 1), 0, R);
+  fr29 res[D + 1];
+  LT_REP(LT_OUT)
+  store_block_partials<D + 1>(res, degree + 1, partials + (size_t)blockIdx.x * (degree + 1), 0, R);
 }
+#undef LT_REP
+#undef LT_DECL
+#undef LT_INIT
+#undef LT_STEP
+#undef LT_FOLD
+#undef LT_OUT
 // K10: claim = sum_k eq[k] * g(E(k))  (subtables/mod.rs:187-216)
 template <int A>
 __global__ void __launch_bounds__(LASSO_BLOCK) k_combine_claim(StrategyDev S, PtrTable polys, const fr_t* __restrict__ eq, WeightTable W, size_t n, fr_t* __restrict__ partials) {
@@ -683,11 +690,9 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_combine_claim(StrategyDev S, Pt
   fr29 acc[1] = {fr29_zero()}; uint32_t cnt = 0;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     fr29 g;
-    if (lt) {
-      fr29 vals[A];
-#pragma unroll
-      for (int j = 0; j < A; j++) if ((uint32_t)j < S.alpha) vals[j] = fr29_unpack_s(polys.p[j][i]);
-      g = combine_lt<A>(vals, S.c);
+    if (lt) {   // lt.rs:62-71 streamed over the memories: running sum and running product, no array of values (which ended up in scratch memory at A >= 16)
+      fr29 eq_prod = fr29_one_s(); g = fr29_zero();
+      for (uint32_t m = 0; m < S.c; m++) { g = fr29_weak(fr29_add(g, fr29_mul(fr29_unpack_s(polys.p[2 * m][i]), eq_prod))); eq_prod = fr29_mul(fr29_unpack_s(polys.p[2 * m + 1][i]), eq_prod); }
     } else g = weighted_sum(polys, i, S.alpha, ws);
     acc_add(acc[0], fr29_mul(g, fr29_unpack_u(eq[i])), cnt);
   }
