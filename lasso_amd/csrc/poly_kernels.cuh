@@ -264,6 +264,9 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_eqw_lb(PtrTable A, PtrTab
 // fused with K1: bind A and B with r (length n = 4q -> 2q, in place: each element is owned by exactly one thread), then the sums of the NEXT round
 // on the bound values while they are still in registers — one launch per round, 48 bytes per element of A and B plus 32 per index of E.
 template <int NT, bool WIDE = false>
+#ifdef LASSO_FUSED_WAVES   // experiment switch: force the register budget of the fused round (waves per SIMD); default = the compiler's choice (157 VGPRs, 3 waves)
+__attribute__((amdgpu_waves_per_eu(LASSO_FUSED_WAVES, LASSO_FUSED_WAVES)))
+#endif
 __global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_eqw_fused(MutPtrTable A, MutPtrTable B, uint32_t nx, uint32_t ny, const fr_t* __restrict__ E, size_t q, fr_t r,
                                                                   fr_t* __restrict__ partials, uint32_t* counters, fr_t* __restrict__ out, uint32_t* flag, uint32_t seq) {
   __shared__ RedScratch S;
