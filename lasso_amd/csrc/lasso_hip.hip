@@ -644,6 +644,11 @@ int32_t lasso_read_heads(lasso_ctx* c, const lasso_fr* const* d_polys, uint32_t 
 }
 // layers above `in` (len elements, the layers laid out back to back behind it): one launch per large layer, the small ones in one workgroup
 static void gp_layers_from(lasso_ctx* c, fr_t* in, size_t len) {
+  while (len >= 16 * LASSO_BLOCK) {   // two layers per launch while they are large: the layer in between is written but not read back
+    const size_t q = len / 4;
+    hipLaunchKernelGGL(k_gp_layer2, dim3(grid_for(q, 4096)), dim3(LASSO_BLOCK), 0, c->stream, (const fr_t*)in, q, in + len, in + len + len / 2);
+    in += len + len / 2; len = q;
+  }
   while (len > 2 * LASSO_BLOCK) {
     size_t half = len / 2;
     hipLaunchKernelGGL(k_gp_layer, dim3(grid_for(half, 4096)), dim3(LASSO_BLOCK), 0, c->stream, (const fr_t*)in, half, in + len);

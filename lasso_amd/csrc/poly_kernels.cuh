@@ -741,6 +741,17 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_eq_outer(const fr_t* __restrict
 __global__ void __launch_bounds__(LASSO_BLOCK) k_gp_layer(const fr_t* __restrict__ in, size_t half, fr_t* __restrict__ out) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x) out[i] = fr29_store(fr29_mul(fr29_unpack_u(in[i]), fr29_unpack_s(in[i + half])));
 }
+// two layers per launch: thread i < q = len/4 holds in[i], in[i+q], in[i+2q], in[i+3q], writes the next layer's o1[i] = in[i]*in[i+2q], o1[i+q] = in[i+q]*in[i+3q]
+// (the pairs (j, j + len/2) of grand_product.rs:25-30) and the layer after it, o2[i] = o1[i]*o1[i+q], without reading o1 back: 4 reads + 3 writes instead of
+// 6 + 3 for the same two layers.  Operands go through the memory form exactly as k_gp_layer reads them.
+__global__ void __launch_bounds__(LASSO_BLOCK) k_gp_layer2(const fr_t* __restrict__ in, size_t q, fr_t* __restrict__ o1, fr_t* __restrict__ o2) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < q; i += (size_t)gridDim.x * blockDim.x) {
+    const fr_t a = fr29_store(fr29_mul(fr29_unpack_u(in[i]), fr29_unpack_s(in[i + 2 * q])));
+    const fr_t b = fr29_store(fr29_mul(fr29_unpack_u(in[i + q]), fr29_unpack_s(in[i + 3 * q])));
+    o1[i] = a; o1[i + q] = b;
+    o2[i] = fr29_store(fr29_mul(fr29_unpack_u(a), fr29_unpack_s(b)));
+  }
+}
 // the remaining small layers in one workgroup: in has `len` elements (len <= 2*blockDim.x), layers are laid out back to back
 __global__ void k_gp_tail(fr_t* __restrict__ tree, size_t len) {
   fr_t* in = tree;
