@@ -834,8 +834,9 @@ static const niels29* ensure_tab8(lasso_ctx* c, const lasso_bases* cb, uint32_t 
   niels29* t = nullptr;
   if (hipMalloc((void**)&t, (size_t)MSM8_MULTS * b->n * sizeof(niels29)) != hipSuccess) { (void)hipGetLastError(); b->tab8_failed = true; return nullptr; }
   hipLaunchKernelGGL(k_precompute_tab8, dim3((unsigned)((b->n + 63) / 64)), dim3(64), 0, c->stream, (const niels29*)b->d_table, b->n, w8, t);
-  if (hipGetLastError() != hipSuccess) { (void)hipFree(t); b->tab8_failed = true; return nullptr; }
-  b->d_tab8[w8] = t;   // stream order: every later launch on this context sees the finished table
+  // one-time build (~3 ms): waited for, so that another context sharing this bases object can never see the pointer before the table is complete
+  if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(t); b->tab8_failed = true; return nullptr; }
+  b->d_tab8[w8] = t;
   return t;
 }
 
