@@ -16,7 +16,7 @@ FAMILIES = {   # bench.py family name -> kernel-name prefixes
     "sumcheck_combine": ("k_dot_eqw_lb", "k_combine_round_linear", "k_combine_claim"),
     "multi_dot": ("k_multi_dot",),
     "matvec_left": ("k_matvec_left",),
-    "fingerprint": ("k_fingerprint_ops",),
+    "fingerprint": ("k_fingerprint_ops",),          # k_fingerprint_ops_l1 since round 2 (leaves + first product layer)
     "gp_build": ("k_gp_layer",),
 }
 # families whose bench.py "launch" (one ProfScope bracket) is a SEQUENCE of dispatches — a product tree is one k_gp_layer dispatch per layer: the traffic per
