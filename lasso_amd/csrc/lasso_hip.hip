@@ -885,17 +885,25 @@ static size_t msm_pts_bytes(size_t rows, size_t n_cols) {
   uint32_t ipc; const size_t kd = rows <= MSM_SMALL_ROWS ? msm_direct_chunks(rows, n_cols, &ipc) : 0, kb = msm_chunks(rows, n_cols, MSM_WINDOWS);
   return (rows * (kd > kb ? kd : kb) + 2 * rows + 4) * sizeof(pt29) + 512;
 }
-static int32_t run_msm_direct(lasso_ctx* c, const uint8_t* d_scal, size_t row_stride, size_t rows, size_t n_cols, const MsmColMap& cm, const lasso_bases* b, uint8_t* scratch_after, lasso_point* out) {
+// mode 0: d_scal = canonical integers; 1: field elements in memory (Montgomery) form, converted by the kernel; 2: as 1 with the first n_cols - 2 columns
+// multiplied by *scale and the last two columns = tail[0], tail[1] (k_msm_direct<MODE>)
+static int32_t run_msm_direct(lasso_ctx* c, const uint8_t* d_scal, size_t row_stride, size_t rows, size_t n_cols, const MsmColMap& cm, const lasso_bases* b, uint8_t* scratch_after, lasso_point* out,
+                              int mode = 0, const lasso_fr* scale = nullptr, const lasso_fr* tail = nullptr) {
   uint32_t ipc = 0; const size_t K = msm_direct_chunks(rows, n_cols, &ipc);
   const uint32_t seq = ++c->seq;
   {
     ProfScope ps(c, LASSO_K_MSM_DIRECT, (double)rows * n_cols * 32, msm_ref_adds(rows, n_cols, FR_MODULUS_BITS), false, (double)rows * n_cols * MSM_WINDOWS);
-    hipLaunchKernelGGL(k_msm_direct, dim3((unsigned)K, (unsigned)rows), dim3(MSM_THREADS), 0, c->stream, (const uint32_t*)d_scal, row_stride / 4, (uint32_t)n_cols, ipc, cm, (const niels29*)b->d_mult, b->n,
-                       (pt29*)scratch_after, (ed_point*)c->d_small, c->d_counters + LASSO_MAX_PTRS + 8, c->d_flag, seq);
+    const fr_t z = fr_zero();
+#define LAUNCH_DIRECT(M, SC, T0, T1) hipLaunchKernelGGL(k_msm_direct<M>, dim3((unsigned)K, (unsigned)rows), dim3(MSM_THREADS), 0, c->stream, (const uint32_t*)d_scal, row_stride / 4, (uint32_t)n_cols, ipc, cm, \
+                       (const niels29*)b->d_mult, b->n, (pt29*)scratch_after, (ed_point*)c->d_small, c->d_counters + LASSO_MAX_PTRS + 8, c->d_flag, seq, SC, T0, T1)
+    if (mode == 0) LAUNCH_DIRECT(0, z, z, z);
+    else if (mode == 1) LAUNCH_DIRECT(1, z, z, z);
+    else LAUNCH_DIRECT(2, to_fr(scale), to_fr(tail), to_fr(tail + 1));
   }
   HIPCHK(c, hipGetLastError());
   return wait_flag(c, seq, rows * (sizeof(ed_point) / sizeof(fr_t)), (lasso_fr*)out);
 }
+static bool msm_direct_fused() { static const bool on = [] { const char* v = getenv("LASSO_MSM_FUSED"); return !(v && v[0] == '0'); }(); return on; }   // A/B switch: conversions and the bullet fold inside the MSM launch
 // d_rows_out (device, rows x sizeof(pt29)): leave the row sums on the device in the kernels' own point form instead of handing them to the host —
 // slab mode's partial row commitments, which go through lasso_rccl_allgather and lasso_points_reduce_compress
 static int32_t run_msm(lasso_ctx* c, const uint8_t* d_scal, uint32_t bps, uint32_t W, size_t row_stride, size_t rows, size_t n_cols, const lasso_bases* b, uint8_t* scratch_after, lasso_point* out,
@@ -1004,6 +1012,10 @@ int32_t lasso_msm_dev(lasso_ctx* c, const lasso_bases* b, const lasso_fr* d_scal
   REQUIRE(c, b && d_scalars && out && n >= 1 && n <= b->n);
   int32_t rc = ensure_scratch(c, n * 32 + msm_pts_bytes(1, n)); if (rc) return rc;
   fr_t* d_can = (fr_t*)c->d_scratch;
+  if (b->d_mult && msm_direct_enabled() && msm_direct_fused()) {   // the latency-shaped kernel converts its own columns: one launch instead of two
+    const MsmColMap id = {0, 0, 0, 0};
+    return run_msm_direct(c, (const uint8_t*)d_scalars, n * 32, 1, n, id, b, (uint8_t*)c->d_scratch, out, 1);
+  }
   hipLaunchKernelGGL(k_fr_to_canonical, dim3(grid_for(n)), dim3(256), 0, c->stream, (const fr_t*)d_scalars, n, d_can);
   return run_msm(c, (const uint8_t*)d_can, 32, MSM_WINDOWS, n * 32, 1, n, b, (uint8_t*)(d_can + n), out);
 }
@@ -1017,6 +1029,10 @@ int32_t lasso_msm_dev_scaled(lasso_ctx* c, const lasso_bases* b, const lasso_fr*
   const size_t row = n + 2;
   int32_t rc = ensure_scratch(c, row * 32 + msm_pts_bytes(1, row)); if (rc) return rc;
   fr_t* d_can = (fr_t*)c->d_scratch;
+  if (b->d_mult && msm_direct_enabled() && msm_direct_fused()) {   // scaling and conversion inside the MSM launch (the two tail columns are kernel arguments, never read from d_scalars)
+    const MsmColMap id = {0, 0, 0, 0};
+    return run_msm_direct(c, (const uint8_t*)d_scalars, row * 32, 1, row, id, b, (uint8_t*)c->d_scratch, out, 2, scale, tail);
+  }
   hipLaunchKernelGGL(k_scale_to_integers, dim3(grid_for(n)), dim3(256), 0, c->stream, (const fr_t*)d_scalars, n, to_fr(scale), to_fr(tail), to_fr(tail + 1), d_can);
   return run_msm(c, (const uint8_t*)d_can, 32, MSM_WINDOWS, row * 32, 1, row, b, (uint8_t*)(d_can + row), out);
 }
@@ -1046,6 +1062,25 @@ int32_t lasso_bullet_round(lasso_ctx* c, const lasso_bases* b, size_t n, const l
   const bool fold = u != nullptr;
   if (fold) REQUIRE(c, u_inv && d_a_out && d_b_out && d_w_out && 2 * nk <= n && d_a_out != d_a_in && d_b_out != d_b_in && d_w_out != d_w_in);
   const bool direct = b->d_mult && msm_direct_enabled();
+  if (direct && msm_direct_fused()) {
+    // fold + scalars + both MSMs in one launch (k_bullet_msm): K chunk workgroups per row over the n/2 columns, plus one per row for a', b', the inner product and c*Q + blind*H
+    uint32_t ipc = 0; const size_t K = msm_direct_chunks(2, n / 2, &ipc);
+    int32_t rc = ensure_scratch(c, 2 * (K + 1) * sizeof(pt29) + 512); if (rc) return rc;
+    const uint32_t seq = ++c->seq;
+    {
+      const size_t row = n / 2 + 2;
+      ProfScope ps(c, LASSO_K_MSM_DIRECT, 2.0 * row * 32 + (fold ? 96.0 * 2 * nk : 64.0 * nk), msm_ref_adds(2, row, FR_MODULUS_BITS), false, 2.0 * row * MSM_WINDOWS);
+      const fr_t z = fr_zero();
+      if (fold) hipLaunchKernelGGL((k_bullet_msm<true>), dim3((unsigned)K + 1, 2), dim3(MSM_THREADS), 0, c->stream, (const fr_t*)d_a_in, (const fr_t*)d_b_in, (const fr_t*)d_w_in, (fr_t*)d_a_out, (fr_t*)d_b_out,
+                                   (fr_t*)d_w_out, (uint32_t)nk, (uint32_t)n, to_fr(u), to_fr(u_inv), to_fr(blinds), to_fr(blinds + 1), ipc, (const niels29*)b->d_mult, b->n, (pt29*)c->d_scratch,
+                                   (ed_point*)c->d_small, c->d_counters + LASSO_MAX_PTRS + 8, c->d_flag, seq);
+      else hipLaunchKernelGGL((k_bullet_msm<false>), dim3((unsigned)K + 1, 2), dim3(MSM_THREADS), 0, c->stream, (const fr_t*)d_a_in, (const fr_t*)d_b_in, (const fr_t*)d_w_in, (fr_t*)nullptr, (fr_t*)nullptr,
+                              (fr_t*)nullptr, (uint32_t)nk, (uint32_t)n, z, z, to_fr(blinds), to_fr(blinds + 1), ipc, (const niels29*)b->d_mult, b->n, (pt29*)c->d_scratch,
+                              (ed_point*)c->d_small, c->d_counters + LASSO_MAX_PTRS + 8, c->d_flag, seq);
+    }
+    HIPCHK(c, hipGetLastError());
+    return wait_flag(c, seq, 2 * (sizeof(ed_point) / sizeof(fr_t)), (lasso_fr*)out);
+  }
   const size_t row = direct ? n / 2 + 2 : n + 2;   // compact rows for k_msm_direct: only the non-zero half
   const unsigned nx = grid_for(n / 2, 64);
   int32_t rc = ensure_scratch(c, 2 * row * 32 + (size_t)nx * 2 * sizeof(fr_t) + msm_pts_bytes(2, row)); if (rc) return rc;

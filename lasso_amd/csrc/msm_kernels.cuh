@@ -376,31 +376,15 @@ __global__ void __launch_bounds__(MSM_THREADS) k_msm_rows8(const uint32_t* __res
 }
 
 #define MSM_DIRECT_MAX_COLS 160   // columns a workgroup may touch (items_per_chunk <= 64 * (MSM_DIRECT_MAX_COLS - 1))
-// grid = (K chunks, rows).  scal: canonical little-endian scalars, 8 words each, row r at scal + r*row_words.  One item = one (column, window);
-// chunk k owns items [k*items_per_chunk, ...).  out_mont[row] (host-mapped) = the row's sum in ark's Montgomery limbs; the workgroup that
-// completes the last row raises the host's sequence flag.  counters[0..rows) = per-row arrival tickets, counters[16] = finished rows.
-__global__ void __launch_bounds__(MSM_THREADS) k_msm_direct(const uint32_t* __restrict__ scal, size_t row_words, uint32_t n_cols, uint32_t items_per_chunk, MsmColMap cm,
-                                                             const niels29* __restrict__ mult, size_t tn, pt29* __restrict__ partial, ed_point* __restrict__ out_mont, uint32_t* counters,
-                                                             uint32_t* flag, uint32_t seq) {
-  __shared__ pt29 pts[MSM_THREADS];
-  __shared__ fe29 st[MSM_THREADS / 4][4];
-  __shared__ uint32_t sb[MSM_DIRECT_MAX_COLS * 8];
-  __shared__ uint32_t is_last;
-  const fe29 d2 = fe_d2();
-  const uint32_t t = threadIdx.x, row = blockIdx.y, K = gridDim.x;
-  const uint32_t total = n_cols * MSM_WINDOWS;
-  const uint32_t it0 = blockIdx.x * items_per_chunk;
-  uint32_t it1 = it0 + items_per_chunk; if (it1 > total) it1 = total;
-  const uint32_t col0 = it0 >> 6, col1 = (it1 + 63) >> 6;
-  MSM_STAMP(0);
-  for (uint32_t c = t; c < col1 - col0; c += MSM_THREADS) {   // e = s + 0x88..8
-    const uint32_t* s = scal + (size_t)row * row_words + (size_t)(col0 + c) * 8;
-    uint64_t carry = 0;
+// signed-digit recoding of one canonical scalar into LDS: e = s + 0x88..8 (nibble e_w - 8 in [-8, 7] is digit w)
+__device__ __forceinline__ void msm_recode(const uint32_t* s, uint32_t* dst) {
+  uint64_t carry = 0;
 #pragma unroll
-    for (int k = 0; k < 8; k++) { const uint64_t x = (uint64_t)s[k] + 0x88888888ull + carry; sb[c * 8 + k] = (uint32_t)x; carry = x >> 32; }
-  }
-  __syncthreads();
-  MSM_STAMP(1);
+  for (int k = 0; k < 8; k++) { const uint64_t x = (uint64_t)s[k] + 0x88888888ull + carry; dst[k] = (uint32_t)x; carry = x >> 32; }
+}
+// items [it0, it1) of a row (one item = one (column, window); sb holds the recoded scalars of columns col0..): one mixed addition per non-zero digit
+__device__ __forceinline__ pt29 msm_direct_accumulate(const uint32_t* sb, uint32_t col0, uint32_t it0, uint32_t it1, const MsmColMap& cm, uint32_t row, const niels29* __restrict__ mult, size_t tn) {
+  const uint32_t t = threadIdx.x;
   pt29 B = pt_identity();
   niels29 cur; bool have = false;
   for (uint32_t base = it0; base < it1; base += MSM_THREADS) {
@@ -422,7 +406,15 @@ __global__ void __launch_bounds__(MSM_THREADS) k_msm_direct(const uint32_t* __re
     have = valid;
   }
   if (have) B = pt_madd(B, cur);
-  MSM_STAMP(2);
+  return B;
+}
+// the workgroup's 256 partial sums -> one point (cooperative tree), then across the K workgroups of the row in the last one to arrive (ticket),
+// then the row's sum to the host-mapped result buffer in ark's Montgomery limbs; the workgroup that completes the last row raises the flag.
+// counters[0..rows) = per-row arrival tickets, counters[16] = finished rows.
+__device__ __forceinline__ void msm_direct_finish(pt29* pts, fe29 (*st)[4], uint32_t* is_last, const pt29& B, uint32_t K, uint32_t row, pt29* __restrict__ partial, ed_point* __restrict__ out_mont,
+                                                  uint32_t* counters, uint32_t* flag, uint32_t seq) {
+  const fe29 d2 = fe_d2();
+  const uint32_t t = threadIdx.x;
   pts[t] = B;
   __syncthreads();
   msm_coop_tree(pts, st, MSM_THREADS, d2);
@@ -435,10 +427,10 @@ __global__ void __launch_bounds__(MSM_THREADS) k_msm_direct(const uint32_t* __re
       const uint32_t ticket = __hip_atomic_fetch_add(&counters[row], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const uint32_t last = ticket == K - 1 ? 1u : 0u;
       if (last) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); counters[row] = 0; }
-      is_last = last;
+      *is_last = last;
     }
     __syncthreads();
-    if (!is_last) return;
+    if (!*is_last) return;
     pt29 acc = t < K ? partial[(size_t)row * K + t] : pt_identity();
     for (uint32_t k = t + MSM_THREADS; k < K; k += MSM_THREADS) acc = pt_add(acc, partial[(size_t)row * K + k], d2);
     __syncthreads();
@@ -448,7 +440,7 @@ __global__ void __launch_bounds__(MSM_THREADS) k_msm_direct(const uint32_t* __re
   }
   MSM_STAMP(4);
   if (t == 0) {
-    #ifdef LASSO_BN254
+#ifdef LASSO_BN254
     out_mont[row] = pt_to_abi(pts[0]);
 #else
     ed_point p = pt_to_ed(pts[0]), o; o.X = fq_to_mont(p.X); o.Y = fq_to_mont(p.Y); o.T = fq_to_mont(p.T); o.Z = fq_to_mont(p.Z); out_mont[row] = o;
@@ -460,6 +452,47 @@ __global__ void __launch_bounds__(MSM_THREADS) k_msm_direct(const uint32_t* __re
     }
   }
   MSM_STAMP(5);
+}
+// grid = (K chunks, rows).  scal: 8 words per scalar, row r at scal + r*row_words.  One item = one (column, window); chunk k owns items
+// [k*items_per_chunk, ...).  out_mont[row] (host-mapped) = the row's sum in ark's Montgomery limbs.
+// MODE 0: scal holds canonical little-endian integers.  MODE 1: scal holds field elements in memory (Montgomery) form, converted here — the
+// k_fr_to_canonical pass in front of the opening's Cx = <x, G> saved.  MODE 2: as 1, but columns below n_cols - 2 are multiplied by `scale` first and the
+// last two columns are the scalars tail0, tail1 (delta = d * g_hat + r_delta * h over the resident fold weights, dot_product.rs:219-224).
+template <int MODE>
+__global__ void __launch_bounds__(MSM_THREADS) k_msm_direct(const uint32_t* __restrict__ scal, size_t row_words, uint32_t n_cols, uint32_t items_per_chunk, MsmColMap cm,
+                                                             const niels29* __restrict__ mult, size_t tn, pt29* __restrict__ partial, ed_point* __restrict__ out_mont, uint32_t* counters,
+                                                             uint32_t* flag, uint32_t seq, fr_t scale, fr_t tail0, fr_t tail1) {
+  __shared__ pt29 pts[MSM_THREADS];
+  __shared__ fe29 st[MSM_THREADS / 4][4];
+  __shared__ uint32_t sb[MSM_DIRECT_MAX_COLS * 8];
+  __shared__ uint32_t is_last;
+  const uint32_t t = threadIdx.x, row = blockIdx.y, K = gridDim.x;
+  const uint32_t total = n_cols * MSM_WINDOWS;
+  const uint32_t it0 = blockIdx.x * items_per_chunk;
+  uint32_t it1 = it0 + items_per_chunk; if (it1 > total) it1 = total;
+  const uint32_t col0 = it0 >> 6, col1 = (it1 + 63) >> 6;
+  MSM_STAMP(0);
+  for (uint32_t c = t; c < col1 - col0; c += MSM_THREADS) {
+    const uint32_t* s = scal + (size_t)row * row_words + (size_t)(col0 + c) * 8;
+    if (MODE == 0) msm_recode(s, &sb[c * 8]);
+    else {
+      fr_t v;
+      if (MODE == 2 && col0 + c + 2 >= n_cols) v = fr29_to_integer(fr29_unpack_u(col0 + c + 2 == n_cols ? tail0 : tail1));
+      else {
+        fr_t x;
+#pragma unroll
+        for (int k = 0; k < 8; k++) x.v[k] = s[k];
+        fr29 k32 = fr29_zero(); k32.v[0] = 32;
+        v = MODE == 2 ? fr29_store(fr29_mul(fr29_mul(fr29_unpack_u(x), fr29_unpack_s(scale)), k32)) : fr29_to_integer(fr29_unpack_u(x));
+      }
+      msm_recode(v.v, &sb[c * 8]);
+    }
+  }
+  __syncthreads();
+  MSM_STAMP(1);
+  const pt29 B = msm_direct_accumulate(sb, col0, it0, it1, cm, row, mult, tn);
+  MSM_STAMP(2);
+  msm_direct_finish(pts, st, &is_last, B, K, row, partial, out_mont, counters, flag, seq);
 }
 
 // out[row] = sum_k partial[row*K + k], converted to ark's Montgomery limbs (out_mont) or, when out_compressed is given, to the 32-byte wire form.  One workgroup per row; thread t first adds partials
@@ -592,4 +625,78 @@ __global__ void __launch_bounds__(256) k_bullet_step(const fr_t* __restrict__ a_
     const size_t tail = compact ? n / 2 : n;
     if (threadIdx.x == 0) { SL[tail] = v; SL[tail + 1] = fr29_to_integer(fr29_unpack_u(blind_l)); } else { SR[tail] = v; SR[tail + 1] = fr29_to_integer(fr29_unpack_u(blind_r)); }
   }
+}
+
+// ------------------------------------------------------------------ one bullet round in ONE launch (bullet.rs:66-132): k_bullet_step + k_msm_direct fused
+// A round is on the proof's critical path (the host cannot draw u_{k+1} before it has L_k, R_k; 44-50 rounds per proof), and as two launches it paid
+// the fold kernel (15-22 us: a', b', w', the inner products through a last-block reduction, the scalar rows written to HBM), the gap to the next
+// launch, and the MSM kernel reading those rows back.  Here every MSM workgroup derives the scalars of ITS columns itself — column g = (i, blk) of
+// row L is w'_blk * a'_L[i] over generator blk*nk + half + i, of row R w'_blk * a'_R[i] over blk*nk + i; 3 to 5 field products per column, <= 33 columns
+// per workgroup — straight into the LDS digit buffer, and one extra workgroup per row (blockIdx.x == gridDim.x - 1) folds a and b, takes the row's inner
+// product (c_L = <a'_L, b'_R> for row 0, c_R = <a'_R, b'_L> for row 1) and contributes c * Q + blind * H as its partial sum.  The state of the next round
+// (a', b' by the two extra workgroups, w' by the row-0 workgroups that own a column with i = 0) is written on the way.
+// grid = (K + 1, 2): K chunks over the n/2 columns x 64 windows of a row, then the extra workgroup.  FOLD = false: first round, the inputs are the state.
+template <bool FOLD>
+__global__ void __launch_bounds__(MSM_THREADS) k_bullet_msm(const fr_t* __restrict__ a_in, const fr_t* __restrict__ b_in, const fr_t* __restrict__ w_in, fr_t* __restrict__ a_out,
+                                                             fr_t* __restrict__ b_out, fr_t* __restrict__ w_out, uint32_t nk, uint32_t n, fr_t u, fr_t u_inv, fr_t blind_l, fr_t blind_r,
+                                                             uint32_t items_per_chunk, const niels29* __restrict__ mult, size_t tn, pt29* __restrict__ partial, ed_point* __restrict__ out_mont,
+                                                             uint32_t* counters, uint32_t* flag, uint32_t seq) {
+  __shared__ pt29 pts[MSM_THREADS];   // the extra workgroup's reduction scratch (RedScratch, 29.6 KB) lives here before the tree needs it
+  __shared__ fe29 st[MSM_THREADS / 4][4];
+  __shared__ uint32_t sb[MSM_DIRECT_MAX_COLS * 8];
+  __shared__ uint32_t is_last;
+  static_assert(sizeof(RedScratch) <= sizeof(pt29) * MSM_THREADS, "RedScratch must fit the point buffer");
+  const uint32_t t = threadIdx.x, row = blockIdx.y, K = gridDim.x - 1;
+  const uint32_t half = nk / 2, ncols = n / 2;
+  const fr29 us = fr29_unpack_s(u), uis = fr29_unpack_s(u_inv);
+  pt29 B;
+  if (blockIdx.x < K) {
+    const uint32_t total = ncols * MSM_WINDOWS;
+    const uint32_t it0 = blockIdx.x * items_per_chunk;
+    uint32_t it1 = it0 + items_per_chunk; if (it1 > total) it1 = total;
+    const uint32_t col0 = it0 >> 6, col1 = (it1 + 63) >> 6;
+    for (uint32_t c = t; c < col1 - col0; c += MSM_THREADS) {
+      const uint32_t g = col0 + c, blk = g / half, i = g - blk * half;
+      const uint32_t ia = i + (row ? half : 0u);   // row 0 (L) takes a'_L[i], row 1 (R) a'_R[i]
+      fr29 av, wv;   // canonical u-form
+      if (FOLD) {
+        av = fr29_canonical(fr29_add(fr29_mul(fr29_unpack_u(a_in[ia]), us), fr29_mul(fr29_unpack_u(a_in[ia + nk]), uis)));
+        wv = fr29_canonical(fr29_mul(fr29_unpack_u(w_in[blk >> 1]), (blk & 1) ? us : uis));
+        if (row == 0 && i == 0) w_out[blk] = fr29_pack(wv);
+      } else { av = fr29_unpack_u(a_in[ia]); wv = fr29_unpack_u(w_in[blk]); }
+      // mul(u, u) = wv * a * 2^251; one more Montgomery step with the integer 2^10 gives the canonical integer wv * a
+      const fr_t s = fr29_store(fr29_mul(fr29_mul(wv, av), fr29_int_from_uu()));
+      msm_recode(s.v, &sb[c * 8]);
+    }
+    __syncthreads();
+    const MsmColMap cm = {nk, half, ncols, n};
+    B = msm_direct_accumulate(sb, col0, it0, it1, cm, row, mult, tn);
+  } else {
+    RedScratch& S = *reinterpret_cast<RedScratch*>(pts);
+    fr29 acc[3] = {fr29_zero(), fr29_zero(), fr29_zero()}; uint32_t cnt = 0;
+    for (uint32_t i = t; i < half; i += MSM_THREADS) {
+      const uint32_t ia = i + (row ? half : 0u), ib = i + (row ? 0u : half);   // c_L = <a_L, b_R>, c_R = <a_R, b_L>  (bullet.rs:79-80)
+      fr29 x, y;
+      if (FOLD) {
+        x = fr29_canonical(fr29_add(fr29_mul(fr29_unpack_u(a_in[ia]), us), fr29_mul(fr29_unpack_u(a_in[ia + nk]), uis)));
+        y = fr29_canonical(fr29_add(fr29_mul(fr29_unpack_u(b_in[ib]), uis), fr29_mul(fr29_unpack_u(b_in[ib + nk]), us)));
+        a_out[ia] = fr29_pack(x); b_out[ib] = fr29_pack(y);
+      } else { x = fr29_unpack_u(a_in[ia]); y = fr29_unpack_u(b_in[ib]); }
+      acc[0] = fr29_weak(fr29_add(acc[0], fr29_mul(x, y)));   // u * u products are 2^5 short: the 2^10 below covers it
+      if ((++cnt & 127u) == 0) acc[0] = fr29_mul(acc[0], fr29_one_s());
+    }
+    block_columns<3>(acc, S);
+    if (t == 0) {
+      int64_t c[9];
+#pragma unroll
+      for (int k = 0; k < 9; k++) c[k] = S.cols[k];
+      const fr_t ci = fr29_store(fr29_mul(fr29_from_columns(c), fr29_int_from_uu()));   // sum of (u*u) products -> canonical integer
+      const fr_t bi = fr29_to_integer(fr29_unpack_u(row ? blind_r : blind_l));
+      msm_recode(ci.v, &sb[0]); msm_recode(bi.v, &sb[8]);
+    }
+    __syncthreads();   // S (aliasing pts) is dead from here on
+    const MsmColMap id = {0, 0, 0, 0};
+    B = msm_direct_accumulate(sb, 0, 0, 2 * MSM_WINDOWS, id, row, mult + n, tn);   // columns n (Q) and n + 1 (H) of the table
+  }
+  msm_direct_finish(pts, st, &is_last, B, K + 1, row, partial, out_mont, counters, flag, seq);
 }
