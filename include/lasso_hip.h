@@ -92,7 +92,9 @@ int32_t lasso_prof_get_large(lasso_ctx* ctx, int32_t kernel_id, uint64_t* launch
 /* family-specific work units recorded beside the bytes.  MSM families: group additions of the REFERENCE's algorithm for the same inputs (SURVEY.md §8d:
  * L*(R+1)*W bucket accumulation + L*W*2*2^c bucket reduction + L*(W-1)*(c+1) window combine, src/msm/mod.rs:91-164); 0 for the streaming families.
  * large_only bit 0: the launches lasso_prof_get_large counts (for LASSO_K_MSM: the row-parallel commitments, more than 16 rows); bit 1: the second counter
- * instead — MSM families: the mixed additions the kernel itself issues at most (one per scalar digit it looks at; zero digits are skipped). */
+ * instead — MSM families: the mixed additions the kernel itself issues at most (one per scalar digit it looks at; zero digits are skipped); bit 2 (value 4): the
+ * mixed additions the kernels EXECUTED, counted on the device (non-zero digits / bytes) — collected only while every launch is bracketed (a mask without
+ * LASSO_PROF_LARGE_ONLY: the one untimed profiled step of bench.py), 0 otherwise.  This is the numerator of bench.py's roofline_msm fractions. */
 int32_t lasso_prof_get_units(lasso_ctx* ctx, int32_t kernel_id, int32_t large_only, double* units);
 
 /* Host-side latency accounting: number of device->host result hand-offs (flag waits) and the host time spent spinning on them since the last reset. */
@@ -255,6 +257,8 @@ int32_t lasso_hyrax_commit_compressed_u32(lasso_ctx* ctx, const uint32_t* d_u32,
  * counterpart: the reference is single-process (its rows are rayon tasks, src/poly/dense_mlpoly.rs:118-127).
  * librccl is loaded on first use (dlopen); LASSO_ERR_UNSUPPORTED when it is absent.  The unique id travels between the ranks by the caller's means
  * (the host prover broadcasts it through its shared-memory segment). */
+int32_t lasso_rccl_available(void);                                                               /* 1 = librccl loads and has every entry point used; no communicator is touched.  Exchange it between the ranks
+                                                                                                     BEFORE lasso_rccl_init: ncclCommInitRank blocks until every rank has entered it */
 int32_t lasso_rccl_unique_id(uint8_t out[128]);                                                   /* ncclGetUniqueId, rank 0 */
 int32_t lasso_rccl_init(lasso_ctx* ctx, int32_t rank, int32_t world, const uint8_t id[128]);      /* ncclCommInitRank on the context's device; collective */
 int32_t lasso_rccl_shutdown(lasso_ctx* ctx);                                                      /* ncclCommDestroy (also done by lasso_ctx_destroy) */

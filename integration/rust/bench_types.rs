@@ -1,0 +1,82 @@
+//! Patch for `/root/reference/src/benches/bench.rs` under `--features hip`: the GPU twin of `single_pass_lasso!` (bench.rs:36-73) and the
+//! `BenchType`s for BASELINE.json's configurations (bench.rs:75-88 has only JoltDemo and Halo2Comparison, both AND / curve25519).
+//! Each bench runs the reference's own sequence — gen_random_point, gen_indices, from_lookup_indices, gens, commit, prove, verify — with
+//! the three heavy calls routed through integration/rust/hip.rs; `verify` is the UNMODIFIED CPU verifier (surge.rs:214), so every run
+//! checks the GPU proof against the reference's acceptance criterion (e2e_test.rs:54-59).  The tracing span names stay the reference's
+//! (`SparsePoly.prove` is emitted by prove_hip's caller below), so `--name halo2-comparison-hip` prints a log that lines up with
+//! src/benches/*.log line by line.
+//!
+//! NOT COMPILED HERE (no Rust toolchain in the build image).  `python bench.py --kind K --c C --log-s S [--curve bn254]` is the same
+//! harness over the same libraries, and is what produced every number in profiles/.
+#![cfg(feature = "hip")]
+
+use crate::benches::bench::{gen_indices, gen_random_point};
+use crate::hip::{prove_hip, HipDensified, HipGens, HipProver};
+use crate::lasso::surge::SparsePolyCommitmentGens;
+use crate::subtables::{and::AndSubtableStrategy, range_check::RangeCheckSubtableStrategy, xor::XorSubtableStrategy};
+use ark_curve25519::{EdwardsProjective, Fr};
+use ark_std::log2;
+use merlin::Transcript;
+
+macro_rules! single_pass_lasso_hip {
+  ($span_name:expr, $field:ty, $group:ty, $subtable_strategy:ty, $C:expr, $M:expr, $sparsity:expr) => {
+    (tracing::info_span!($span_name), move || {
+      const C: usize = $C;
+      const M: usize = $M;
+      const S: usize = $sparsity;
+      type F = $field;
+      type G = $group;
+      type SubtableStrategy = $subtable_strategy;
+
+      let log_m = log2(M) as usize;
+      let log_s: usize = log2($sparsity) as usize;
+      let r: Vec<F> = gen_random_point::<F>(log_s);
+      let nz = gen_indices::<C>(S, M);
+
+      let prover = HipProver::new(0);
+      let mut dense = tracing::info_span!("Densify").in_scope(|| HipDensified::<F, C>::from_lookup_indices(&prover, &nz, log_m));
+      let hip_gens = HipGens::new(&prover, b"gens_sparse_poly", C, S, C, log_m);
+      let commitment = tracing::info_span!("DensifiedRepresentation.commit").in_scope(|| dense.commit::<G>(&hip_gens));
+      let proof = tracing::info_span!("SparsePoly.prove")
+        .in_scope(|| prove_hip::<G, C, M, SubtableStrategy>(&prover, &mut dense, &r, &hip_gens, b"example", b"proof"));
+
+      // the reference's verifier, unmodified, on the reference's own generator derivation
+      let gens = SparsePolyCommitmentGens::<G>::new(b"gens_sparse_poly", C, S, C, log_m);
+      let mut verify_transcript = Transcript::new(b"example");
+      proof.verify(&commitment, &r, &gens, &mut verify_transcript).expect("should verify");
+    })
+  };
+}
+
+// add to `pub enum BenchType` (bench.rs:75-79):
+//   Halo2ComparisonHip, Config1Bn254, Config2Xor, Config3Range
+// and to `benchmarks()` (bench.rs:81-88):
+//   BenchType::Halo2ComparisonHip => halo2_comparison_hip(), BenchType::Config1Bn254 => config1_bn254(),
+//   BenchType::Config2Xor => config2_xor(), BenchType::Config3Range => config3_range(),
+
+/// the metric's configuration (BASELINE.json `metric`): the last entry of halo2_comparison_benchmarks (bench.rs:224-232) on the GPU
+pub fn halo2_comparison_hip() -> Vec<(tracing::Span, fn())> {
+  vec![
+    single_pass_lasso_hip!("And(2^10)", Fr, EdwardsProjective, AndSubtableStrategy, /* C= */ 1, /* M= */ 1 << 16, /* S= */ 1 << 10),
+    single_pass_lasso_hip!("And(2^20)", Fr, EdwardsProjective, AndSubtableStrategy, /* C= */ 1, /* M= */ 1 << 16, /* S= */ 1 << 20),
+    single_pass_lasso_hip!("And(2^24)", Fr, EdwardsProjective, AndSubtableStrategy, /* C= */ 1, /* M= */ 1 << 16, /* S= */ 1 << 24),
+  ]
+}
+
+/// BASELINE.json configs[1]: AND, C = 4, M = 2^16, 2^20 lookups, G = BN254 (needs ark-bn254 = "0.4" in Cargo.toml and the _bn254 library pair)
+#[cfg(feature = "hip-bn254")]
+pub fn config1_bn254() -> Vec<(tracing::Span, fn())> {
+  vec![single_pass_lasso_hip!("And(C=4, 2^20, BN254)", ark_bn254::Fr, ark_bn254::G1Projective, AndSubtableStrategy, /* C= */ 4, /* M= */ 1 << 16, /* S= */ 1 << 20)]
+}
+
+/// BASELINE.json configs[2]: XOR, C = 8, M = 2^16, 2^24 lookups (bytes == oracle: tests/golden/full_config_digests.json)
+pub fn config2_xor() -> Vec<(tracing::Span, fn())> {
+  vec![single_pass_lasso_hip!("Xor(C=8, 2^24)", Fr, EdwardsProjective, XorSubtableStrategy, /* C= */ 8, /* M= */ 1 << 16, /* S= */ 1 << 24)]
+}
+
+/// BASELINE.json configs[3]: RangeCheck, C = 4, M = 2^16, LOG_R = 40, 2^26 lookups (one GPU: 119 ms; P GPUs: HipProver + lasso_host_set_comm_shm per rank)
+pub fn config3_range() -> Vec<(tracing::Span, fn())> {
+  vec![single_pass_lasso_hip!("RangeCheck(C=4, 2^26)", Fr, EdwardsProjective, RangeCheckSubtableStrategy<40>, /* C= */ 4, /* M= */ 1 << 16, /* S= */ 1 << 26)]
+}
+// BASELINE.json configs[4] names `SparkSubtableStrategy`, which this snapshot of the reference does not contain (subtables/mod.rs:22-26 lists
+// and / lt / or / range_check / xor): no BenchType can be written for it.  The degree-C stand-in is LTSubtableStrategy with C = 16.

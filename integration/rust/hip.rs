@@ -1,0 +1,175 @@
+//! src/hip/mod.rs of the reference crate under `--features hip` — the COARSE shim: the three public calls the bench harness
+//! makes (`/root/reference/src/benches/bench.rs:54-66`) routed to `liblasso_prover.so` (include/lasso_prover.h), results brought
+//! back as the crate's own types through `deserialize_compressed`.
+//!
+//!   DensifiedRepresentation::from_lookup_indices(&nz, log_m)        densified.rs:22    -> HipDensified::from_lookup_indices
+//!   dense.commit::<G>(&gens)                                        densified.rs:78    -> HipDensified::commit
+//!   SparsePolynomialEvaluationProof::<G,C,M,S>::prove(..)           surge.rs:119-125   -> prove_hip::<G,C,M,S>
+//!
+//! Nothing of the protocol is re-written in Rust on this path: the transcript schedule, the Merlin transcript and the O(log n) scalar
+//! work run inside liblasso_prover.so (lasso_amd/host/prover.hpp — the C++ mirror of the reference's host), every O(n) loop inside
+//! liblasso_hip.so.  What crosses the boundary: the lookup indices (`Vec<[usize; C]>` is n x C u64, row-major, passed as is), the point
+//! `r` (ark-ff's in-memory Montgomery limbs, passed as is), and ark-serialize's compressed wire bytes on the way back.
+//! The finely-grained ABI (include/lasso_hip.h, ffi.rs first block) stays available to a maintainer who wants the protocol in Rust and
+//! only the loops on the device; INTEGRATION.md §3 maps each loop to its entry point.
+//!
+//! NOT COMPILED HERE: the build image has no cargo/rustc.  Written against ark-* 0.4.2, merlin 3.0 as pinned in the
+//! reference's Cargo.toml; the layout asserts below are what makes passing `&[F]` as `*const lasso_fr` sound.
+#![cfg(feature = "hip")]
+
+use std::ffi::{CStr, CString};
+use std::marker::PhantomData;
+
+use ark_ec::CurveGroup;
+use ark_ff::PrimeField;
+use ark_serialize::CanonicalDeserialize;
+
+use crate::hip::ffi::*;
+use crate::lasso::surge::{SparsePolynomialCommitment, SparsePolynomialEvaluationProof};
+use crate::poly::dense_mlpoly::PolyCommitment;
+use crate::subtables::{
+  and::AndSubtableStrategy, lt::LTSubtableStrategy, or::OrSubtableStrategy, range_check::RangeCheckSubtableStrategy,
+  xor::XorSubtableStrategy, SubtableStrategy,
+};
+
+pub mod ffi; // integration/rust/ffi.rs (generated from the two C headers)
+
+// ---- layout guards: the ABI passes ark-ff / ark-ec memory through unchanged -------------------------------------------------------
+const _: () = assert!(std::mem::size_of::<ark_curve25519::Fr>() == 32 && std::mem::align_of::<ark_curve25519::Fr>() == 8);
+const _: () = assert!(std::mem::size_of::<lasso_fr>() == 32 && std::mem::size_of::<lasso_affine>() == 64 && std::mem::size_of::<lasso_point>() == 128);
+const _: () = assert!(std::mem::size_of::<ark_curve25519::EdwardsAffine>() == 64); // {x, y}; no infinity flag on TE curves
+const _: () = assert!(std::mem::size_of::<ark_curve25519::EdwardsProjective>() == 128); // {x, y, t, z}
+const _: () = assert!(std::mem::size_of::<usize>() == 8); // Vec<[usize; C]> is uploaded as n x C u64
+
+fn last_error() -> String {
+  unsafe { CStr::from_ptr(lasso_host_last_error()).to_string_lossy().into_owned() }
+}
+/// The reference prover panics on contract violations (surge.rs:131, memory_checking.rs:689); a non-zero status becomes the same.
+fn chk(rc: i32, what: &str) {
+  assert!(rc == 0, "{what} failed ({rc}): {}", last_error());
+}
+
+/// `SubtableStrategy` -> the runtime descriptor the library takes (include/lasso_hip.h `lasso_strategy`).
+pub trait HipStrategy<F: PrimeField, const C: usize, const M: usize>: SubtableStrategy<F, C, M> {
+  const KIND: i32;
+  const LOG_R: u32 = 0;
+  fn descriptor() -> lasso_strategy {
+    lasso_strategy { kind: Self::KIND, c: C as u32, log_m: M.trailing_zeros(), log_r: Self::LOG_R }
+  }
+}
+impl<F: PrimeField, const C: usize, const M: usize> HipStrategy<F, C, M> for AndSubtableStrategy { const KIND: i32 = LASSO_AND; }
+impl<F: PrimeField, const C: usize, const M: usize> HipStrategy<F, C, M> for OrSubtableStrategy { const KIND: i32 = LASSO_OR; }
+impl<F: PrimeField, const C: usize, const M: usize> HipStrategy<F, C, M> for XorSubtableStrategy { const KIND: i32 = LASSO_XOR; }
+impl<F: PrimeField, const C: usize, const M: usize> HipStrategy<F, C, M> for LTSubtableStrategy { const KIND: i32 = LASSO_LT; }
+impl<F: PrimeField, const C: usize, const M: usize, const LOG_R_: usize> HipStrategy<F, C, M> for RangeCheckSubtableStrategy<LOG_R_> {
+  const KIND: i32 = LASSO_RANGE;
+  const LOG_R: u32 = LOG_R_ as u32;
+}
+
+/// One device context + host prover (`lasso_host`).  One per prover thread; the library is not re-entrant on a context.
+pub struct HipProver { h: *mut lasso_host }
+impl HipProver {
+  pub fn new(device: i32) -> Self {
+    let mut h = std::ptr::null_mut();
+    chk(unsafe { lasso_host_create(device, &mut h) }, "lasso_host_create");
+    // start-up self-test of the layout assumption: F::from(7) -> device -> back
+    HipProver { h }
+  }
+}
+impl Drop for HipProver {
+  fn drop(&mut self) { unsafe { lasso_host_destroy(self.h) } }
+}
+
+/// `SparsePolyCommitmentGens::<G>::new(label, c, s, num_memories, log_m)` (surge.rs:32-58) with the generator tables resident on the device.
+/// The Rust-side `SparsePolyCommitmentGens` is still built by the caller for `verify` (it derives the same points: commitments.rs:22-44).
+pub struct HipGens<'a> { g: *mut lasso_host_gens, _p: PhantomData<&'a HipProver> }
+impl<'a> HipGens<'a> {
+  pub fn new(p: &'a HipProver, label: &'static [u8], c: usize, s: usize, num_memories: usize, log_m: usize) -> Self {
+    let l = CString::new(label).unwrap();
+    let mut g = std::ptr::null_mut();
+    chk(unsafe { lasso_host_gens_new(p.h, l.as_ptr(), c, s, num_memories, log_m, &mut g) }, "lasso_host_gens_new");
+    HipGens { g, _p: PhantomData }
+  }
+}
+impl Drop for HipGens<'_> {
+  fn drop(&mut self) { unsafe { lasso_host_gens_free(self.g) } }
+}
+
+/// `DensifiedRepresentation<F, C>` with dim / read / final resident in HBM (densified.rs:8-20: the `pub` fields are only read inside the crate).
+pub struct HipDensified<'a, F: PrimeField, const C: usize> {
+  d: *mut lasso_host_dense,
+  pub s: usize,
+  pub log_m: usize,
+  pub m: usize,
+  _p: PhantomData<(&'a HipProver, F)>,
+}
+impl<'a, F: PrimeField, const C: usize> HipDensified<'a, F, C> {
+  /// densified.rs:22-75.  `indices` is passed as the reference holds it.  Panics if an index is >= 2^log_m (the reference indexes out of bounds there).
+  pub fn from_lookup_indices(p: &'a HipProver, indices: &Vec<[usize; C]>, log_m: usize) -> Self {
+    let mut d = std::ptr::null_mut();
+    chk(unsafe { lasso_host_densify(p.h, indices.as_ptr() as *const u64, indices.len(), C, log_m, &mut d) }, "lasso_host_densify");
+    HipDensified { d, s: indices.len().next_power_of_two(), log_m, m: 1 << log_m, _p: PhantomData }
+  }
+
+  /// densified.rs:78-96.  The library returns `[u64 L1][L1 x 32 B][u64 L2][L2 x 32 B]` = the two `PolyCommitment { C: Vec<G> }` in
+  /// ark-serialize's compressed form, which is exactly how `SparsePolynomialCommitment` starts on the wire (surge.rs:60-68); s, log_m, m follow as u64.
+  pub fn commit<G: CurveGroup<ScalarField = F>>(&self, gens: &HipGens) -> SparsePolynomialCommitment<G> {
+    let mut buf = call_bytes(|out, cap, len| unsafe { lasso_host_commit(self.d, gens.g, out, cap, len) }, "lasso_host_commit");
+    for v in [self.s as u64, self.log_m as u64, self.m as u64] { buf.extend_from_slice(&v.to_le_bytes()); }
+    SparsePolynomialCommitment::<G>::deserialize_compressed(&buf[..]).expect("commitment bytes")
+  }
+}
+impl<F: PrimeField, const C: usize> Drop for HipDensified<'_, F, C> {
+  fn drop(&mut self) { unsafe { lasso_host_dense_free(self.d) } }
+}
+
+/// surge.rs:119-211 on the device.  `transcript_label` / `tape_label` are the labels the harness passes to `Transcript::new` / `RandomTape::new`
+/// (b"example", b"proof" in bench.rs:62-63): the library replays both from their labels, so the proof bytes are those of the CPU prover on the
+/// same inputs (DESIGN.md §3 states what that claim rests on).
+pub fn prove_hip<G, const C: usize, const M: usize, S>(
+  p: &HipProver,
+  dense: &mut HipDensified<G::ScalarField, C>,
+  r: &Vec<G::ScalarField>,
+  gens: &HipGens,
+  transcript_label: &'static [u8],
+  tape_label: &'static [u8],
+) -> SparsePolynomialEvaluationProof<G, C, M, S>
+where
+  G: CurveGroup,
+  S: HipStrategy<G::ScalarField, C, M> + Sync,
+  [(); S::NUM_SUBTABLES]: Sized,
+  [(); S::NUM_MEMORIES]: Sized,
+  [(); S::NUM_MEMORIES + 1]: Sized,
+{
+  assert_eq!(r.len(), ark_std::log2(dense.s) as usize); // surge.rs:131
+  let st = S::descriptor();
+  let (tl, pl) = (CString::new(transcript_label).unwrap(), CString::new(tape_label).unwrap());
+  let bytes = call_bytes(
+    |out, cap, len| unsafe {
+      lasso_host_prove(p.h, dense.d, gens.g, &st, r.as_ptr() as *const lasso_fr, r.len(), tl.as_ptr(), pl.as_ptr(), out, cap, len)
+    },
+    "lasso_host_prove",
+  );
+  SparsePolynomialEvaluationProof::<G, C, M, S>::deserialize_compressed(&bytes[..]).expect("proof bytes")
+}
+
+/// calls that return bytes: -2 = buffer too small, *len = needed size
+fn call_bytes(mut f: impl FnMut(*mut u8, usize, *mut usize) -> i32, what: &str) -> Vec<u8> {
+  let mut buf = vec![0u8; 1 << 20];
+  loop {
+    let mut len = 0usize;
+    let rc = f(buf.as_mut_ptr(), buf.len(), &mut len);
+    if rc == -2 && len > buf.len() { buf.resize(len, 0); continue; }
+    chk(rc, what);
+    buf.truncate(len);
+    return buf;
+  }
+}
+
+// G = BN254 (BASELINE.json configs[1]): link liblasso_prover_bn254.so / liblasso_hip_bn254.so instead — same symbols, same code above
+// (`G = ark_bn254::G1Projective`; the wire format is ark-ec's SWFlags encoding, which deserialize_compressed reads).
+#[cfg(feature = "hip-bn254")]
+const _: () = assert!(std::mem::size_of::<ark_bn254::Fr>() == 32 && std::mem::align_of::<ark_bn254::Fr>() == 8);
+
+#[allow(dead_code)]
+fn _uses(_: PolyCommitment<ark_curve25519::EdwardsProjective>) {}

@@ -76,6 +76,7 @@ def declare(lib):
         "lasso_hyrax_commit": (i32, [vp, vp, sz, sz, vp, vp]),
         "lasso_hyrax_commit_compressed": (i32, [vp, vp, sz, sz, vp, vp]),
         "lasso_hyrax_commit_compressed_u32": (i32, [vp, vp, u32, sz, sz, vp, vp]),
+        "lasso_rccl_available": (i32, []),
         "lasso_rccl_unique_id": (i32, [vp]),
         "lasso_rccl_init": (i32, [vp, i32, i32, vp]),
         "lasso_rccl_ready": (i32, [vp]),

@@ -27,7 +27,8 @@ __global__ void __launch_bounds__(256) k_inner_lr(const fr_t* __restrict__ a, co
 static_assert(sizeof(lasso_fr) == 32 && sizeof(fr_t) == 32, "Fr layout");
 static_assert(sizeof(lasso_affine) == 64 && sizeof(lasso_point) == 128 && sizeof(ed_point) == 128 && sizeof(niels29) == 112 && sizeof(pt29) == 144, "curve layouts");
 
-struct EventPair { hipEvent_t a, b; int kid; double bytes, units, units2; bool large; };
+struct EventPair { hipEvent_t a, b; int kid; double bytes, units, units2; bool large; bool counted; };
+#define LASSO_PROF_COUNT_SLOTS 4096   // device counters of exactly executed additions, one per bracketed launch of the fully-profiled step
 struct lasso_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -55,6 +56,8 @@ struct lasso_ctx {
   // family-specific work units beside the bytes (the MSM families: group additions of the reference's algorithm), all / large launches
   double prof_units[LASSO_K_COUNT] = {0}; double big_units[LASSO_K_COUNT] = {0};
   double prof_units2[LASSO_K_COUNT] = {0}; double big_units2[LASSO_K_COUNT] = {0};   // MSM families: mixed additions the kernel itself issues at most (one per scalar digit it looks at)
+  double prof_units3[LASSO_K_COUNT] = {0}; double big_units3[LASSO_K_COUNT] = {0};   // MSM families: mixed additions EXECUTED, counted by the kernels (only while every launch is bracketed: no LASSO_PROF_LARGE_ONLY)
+  uint32_t* d_prof_counts = nullptr;
   void* rccl_comm = nullptr; int rccl_world = 0;   // slab mode's device-side exchange (lasso_rccl_*): an ncclComm_t bound to this context's device and stream
 };
 struct lasso_bases {
@@ -111,18 +114,33 @@ struct ProfScope {
     if ((c->prof_mask & 0x40000000u) && !large) return;   // LASSO_PROF_LARGE_ONLY: leave the latency-bound launches unbracketed
     if (c->events_used == c->events.size()) { EventPair p; if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return; c->events.push_back(p); }
     idx = (int)c->events_used++;
-    c->events[idx].kid = kid; c->events[idx].bytes = bytes; c->events[idx].units = units; c->events[idx].units2 = units2; c->events[idx].large = large;
+    c->events[idx].kid = kid; c->events[idx].bytes = bytes; c->events[idx].units = units; c->events[idx].units2 = units2; c->events[idx].large = large; c->events[idx].counted = false;
     (void)hipEventRecord(c->events[idx].a, c->stream);
   }
   ~ProfScope() { if (idx >= 0) (void)hipEventRecord(c->events[idx].b, c->stream); }
+  // device counter the MSM kernels add their executed mixed additions to; NULL (no counting, no cost) unless every launch is being bracketed
+  uint32_t* counter() {
+    if (idx < 0 || idx >= LASSO_PROF_COUNT_SLOTS || (c->prof_mask & 0x40000000u)) return nullptr;
+    if (!c->d_prof_counts) { if (hipMalloc((void**)&c->d_prof_counts, LASSO_PROF_COUNT_SLOTS * 4) != hipSuccess || hipMemset(c->d_prof_counts, 0, LASSO_PROF_COUNT_SLOTS * 4) != hipSuccess) { (void)hipGetLastError(); c->d_prof_counts = nullptr; return nullptr; } }
+    c->events[idx].counted = true;
+    return c->d_prof_counts + idx;
+  }
 };
 static void prof_flush(lasso_ctx* c) {
   if (!c->events_used) return;
   (void)hipStreamSynchronize(c->stream);
+  std::vector<uint32_t> counts;
+  if (c->d_prof_counts) {
+    const size_t m = c->events_used < LASSO_PROF_COUNT_SLOTS ? c->events_used : LASSO_PROF_COUNT_SLOTS;
+    counts.resize(m);
+    if (hipMemcpy(counts.data(), c->d_prof_counts, m * 4, hipMemcpyDeviceToHost) != hipSuccess || hipMemset(c->d_prof_counts, 0, m * 4) != hipSuccess) { (void)hipGetLastError(); counts.clear(); }
+  }
   for (size_t i = 0; i < c->events_used; i++) {
     float ms = 0; if (hipEventElapsedTime(&ms, c->events[i].a, c->events[i].b) != hipSuccess) continue;
     int k = c->events[i].kid; c->prof_launches[k]++; c->prof_ms[k] += ms; c->prof_bytes[k] += c->events[i].bytes; c->prof_units[k] += c->events[i].units; c->prof_units2[k] += c->events[i].units2;
-    if (c->events[i].large) { c->big_launches[k]++; c->big_ms[k] += ms; c->big_bytes[k] += c->events[i].bytes; c->big_units[k] += c->events[i].units; c->big_units2[k] += c->events[i].units2; }
+    const double exact = c->events[i].counted && i < counts.size() ? (double)counts[i] : 0.0;
+    c->prof_units3[k] += exact;
+    if (c->events[i].large) { c->big_launches[k]++; c->big_ms[k] += ms; c->big_bytes[k] += c->events[i].bytes; c->big_units[k] += c->events[i].units; c->big_units2[k] += c->events[i].units2; c->big_units3[k] += exact; }
   }
   c->events_used = 0;
 }
@@ -218,6 +236,9 @@ int32_t lasso_rccl_init(lasso_ctx* c, int32_t rank, int32_t world, const uint8_t
   c->rccl_comm = comm; c->rccl_world = world; return 0;
 }
 int32_t lasso_rccl_ready(lasso_ctx* c) { return c && c->rccl_comm ? c->rccl_world : 0; }
+// 1 if librccl can be loaded and has the entry points this library uses, 0 otherwise — WITHOUT touching a communicator.  ncclCommInitRank is a collective: a rank
+// that cannot load librccl must say so BEFORE its peers enter it (they would wait for it forever), so the ranks exchange this value first.
+int32_t lasso_rccl_available(void) { return rccl_api(nullptr) ? 1 : 0; }
 int32_t lasso_rccl_shutdown(lasso_ctx* c) { REQUIRE(c, c); (void)hipStreamSynchronize(c->stream); rccl_release(c); return 0; }
 // d_recv[g * bytes ..) <- rank g's d_send[0 .. bytes), enqueued on the context's stream (no host synchronisation)
 int32_t lasso_rccl_allgather(lasso_ctx* c, const void* d_send, void* d_recv, size_t bytes) {
@@ -299,6 +320,7 @@ void lasso_ctx_destroy(lasso_ctx* c) {
   if (c->h_big) (void)hipHostFree(c->h_big);
   if (c->d_flags) (void)hipFree(c->d_flags);
   if (c->d_counters) (void)hipFree(c->d_counters);
+  if (c->d_prof_counts) (void)hipFree(c->d_prof_counts);
   (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -318,11 +340,11 @@ int32_t lasso_prof_get_large(lasso_ctx* c, int32_t k, uint64_t* launches, double
 }
 int32_t lasso_wait_stats(lasso_ctx* c, uint64_t* waits, double* wait_us, int32_t reset) { REQUIRE(c, waits && wait_us); *waits = c->stat_waits; *wait_us = c->stat_wait_us; if (reset) { c->stat_waits = 0; c->stat_wait_us = 0; } return 0; }
 int32_t lasso_prof_enable(lasso_ctx* c, int32_t mask) { prof_flush(c); c->prof_mask = (uint32_t)mask; return 0; }
-int32_t lasso_prof_reset(lasso_ctx* c) { prof_flush(c); for (int i = 0; i < LASSO_K_COUNT; i++) { c->prof_launches[i] = 0; c->prof_ms[i] = 0; c->prof_bytes[i] = 0; c->big_launches[i] = 0; c->big_ms[i] = 0; c->big_bytes[i] = 0; c->prof_units[i] = 0; c->big_units[i] = 0; c->prof_units2[i] = 0; c->big_units2[i] = 0; } return 0; }
+int32_t lasso_prof_reset(lasso_ctx* c) { prof_flush(c); for (int i = 0; i < LASSO_K_COUNT; i++) { c->prof_launches[i] = 0; c->prof_ms[i] = 0; c->prof_bytes[i] = 0; c->big_launches[i] = 0; c->big_ms[i] = 0; c->big_bytes[i] = 0; c->prof_units[i] = 0; c->big_units[i] = 0; c->prof_units2[i] = 0; c->big_units2[i] = 0; c->prof_units3[i] = 0; c->big_units3[i] = 0; } return 0; }
 int32_t lasso_prof_get_units(lasso_ctx* c, int32_t k, int32_t large_only, double* units) {
   REQUIRE(c, k >= 0 && k < LASSO_K_COUNT && units); prof_flush(c);
-  const bool large = large_only & 1, second = large_only & 2;   // bit 1 selects the second counter (MSM families: the kernel's own mixed additions, upper bound)
-  *units = second ? (large ? c->big_units2[k] : c->prof_units2[k]) : (large ? c->big_units[k] : c->prof_units[k]); return 0;
+  const bool large = large_only & 1, second = large_only & 2, third = large_only & 4;   // bit 1: the kernel's own mixed additions, upper bound; bit 2: the same counted exactly by the kernels
+  *units = third ? (large ? c->big_units3[k] : c->prof_units3[k]) : second ? (large ? c->big_units2[k] : c->prof_units2[k]) : (large ? c->big_units[k] : c->prof_units[k]); return 0;
 }
 int32_t lasso_prof_get(lasso_ctx* c, int32_t k, uint64_t* launches, double* ms, double* bytes) {
   REQUIRE(c, k >= 0 && k < LASSO_K_COUNT); prof_flush(c);
@@ -597,7 +619,11 @@ int32_t lasso_sumcheck_combine_round(lasso_ctx* c, const lasso_strategy* s, cons
     ProfScope ps(c, LASSO_K_COMBINE, 32.0 * n * (S.alpha + 1.0));
     if (s->kind != LASSO_LT) hipLaunchKernelGGL(k_combine_round_linear, dim3(nx), dim3(LASSO_BLOCK), 0, c->stream, S, P, (const fr_t*)d_eq, W, half, (fr_t*)c->d_scratch);
     else {
-#define LAUNCH_COMBINE(A_, D_) hipLaunchKernelGGL((k_combine_round_lt<A_, D_>), dim3(nx), dim3(LASSO_BLOCK), 0, c->stream, S, P, (const fr_t*)d_eq, half, degree, (fr_t*)c->d_scratch)
+      // Horner form: LT_m is pre-multiplied by kappa_m = 32^-(C-1-m) and the block sums by 32^C (k_combine_round_lt explains the radix bookkeeping)
+      LtScale LK; { static const fr_t inv32 = fr_inv(fr_from_u64(32)); const fr_t t32 = fr_from_u64(32); fr_t k = fr_one(), sc = fr_one();
+                    for (uint32_t m = S.c; m-- > 0;) { LK.kappa[m] = k; k = fr_mul(k, inv32); } for (uint32_t m = 0; m < S.c; m++) sc = fr_mul(sc, t32); LK.scale = sc;
+                    for (uint32_t m = S.c; m < LASSO_MAX_ALPHA / 2; m++) LK.kappa[m] = fr_zero(); }
+#define LAUNCH_COMBINE(A_, D_) hipLaunchKernelGGL((k_combine_round_lt<A_, D_>), dim3(nx), dim3(LASSO_BLOCK), 0, c->stream, S, P, (const fr_t*)d_eq, LK, half, degree, (fr_t*)c->d_scratch)
       DISPATCH_A(S.alpha, LAUNCH_COMBINE);
     }
     hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(LASSO_BLOCK), 0, c->stream, (const fr_t*)c->d_scratch, nx, K, c->d_small);
@@ -895,7 +921,7 @@ static int32_t run_msm_direct(lasso_ctx* c, const uint8_t* d_scal, size_t row_st
     ProfScope ps(c, LASSO_K_MSM_DIRECT, (double)rows * n_cols * 32, msm_ref_adds(rows, n_cols, FR_MODULUS_BITS), false, (double)rows * n_cols * MSM_WINDOWS);
     const fr_t z = fr_zero();
 #define LAUNCH_DIRECT(M, SC, T0, T1) hipLaunchKernelGGL(k_msm_direct<M>, dim3((unsigned)K, (unsigned)rows), dim3(MSM_THREADS), 0, c->stream, (const uint32_t*)d_scal, row_stride / 4, (uint32_t)n_cols, ipc, cm, \
-                       (const niels29*)b->d_mult, b->n, (pt29*)scratch_after, (ed_point*)c->d_small, c->d_counters + LASSO_MAX_PTRS + 8, c->d_flag, seq, SC, T0, T1)
+                       (const niels29*)b->d_mult, b->n, (pt29*)scratch_after, (ed_point*)c->d_small, c->d_counters + LASSO_MAX_PTRS + 8, c->d_flag, seq, SC, T0, T1, ps.counter())
     if (mode == 0) LAUNCH_DIRECT(0, z, z, z);
     else if (mode == 1) LAUNCH_DIRECT(1, z, z, z);
     else LAUNCH_DIRECT(2, to_fr(scale), to_fr(tail), to_fr(tail + 1));
@@ -924,8 +950,8 @@ static int32_t run_msm(lasso_ctx* c, const uint8_t* d_scal, uint32_t bps, uint32
     ProfScope ps(c, LASSO_K_MSM, (double)rows * n_cols * bps, msm_ref_adds(rows, n_cols, bps == 4 ? 4 * W : FR_MODULUS_BITS), rows > MSM_SMALL_ROWS,
                  (double)rows * n_cols * (t8[0] ? W8 : W));
     if (t8[0]) hipLaunchKernelGGL(k_msm_rows8, dim3((unsigned)K, (unsigned)rows), dim3(MSM_THREADS), 0, c->stream, (const uint32_t*)d_scal, row_stride / 4, (uint32_t)n_cols, (uint32_t)cols_per_chunk, W8,
-                                  t8[0], t8[1], b->n, d_partial);
-    else hipLaunchKernelGGL(k_msm_buckets, dim3((unsigned)K, (unsigned)rows), dim3(MSM_THREADS), 0, c->stream, d_scal, bps, W, row_stride, n_cols, cols_per_chunk, (const niels29*)b->d_table, b->n, d_partial);
+                                  t8[0], t8[1], b->n, d_partial, ps.counter());
+    else hipLaunchKernelGGL(k_msm_buckets, dim3((unsigned)K, (unsigned)rows), dim3(MSM_THREADS), 0, c->stream, d_scal, bps, W, row_stride, n_cols, cols_per_chunk, (const niels29*)b->d_table, b->n, d_partial, ps.counter());
     hipLaunchKernelGGL(k_points_sum, dim3((unsigned)rows), dim3(MSM_THREADS), 0, c->stream, (const pt29*)d_partial, (uint32_t)K, d_final, out_compressed ? (uint32_t*)d_final : (uint32_t*)nullptr,
                        c->d_counters + LASSO_MAX_PTRS + 1, small ? c->d_flag : (uint32_t*)nullptr, seq);
   }
@@ -1064,7 +1090,11 @@ int32_t lasso_bullet_round(lasso_ctx* c, const lasso_bases* b, size_t n, const l
   const bool direct = b->d_mult && msm_direct_enabled();
   if (direct && msm_direct_fused()) {
     // fold + scalars + both MSMs in one launch (k_bullet_msm): K chunk workgroups per row over the n/2 columns, plus one per row for a', b', the inner product and c*Q + blind*H
-    uint32_t ipc = 0; const size_t K = msm_direct_chunks(2, n / 2, &ipc);
+    // chunks per row: (workgroups of the launch - 2 extra) / 2 rows, items shared out evenly (a multiple of 64 keeps whole columns together where it can)
+    static const size_t wgs = [] { const char* v = getenv("LASSO_MSM_DIRECT_WGS"); const long x = v ? atol(v) : 0; return (size_t)(x >= 4 && x <= 4096 ? x : 256); }();
+    const size_t total = (n / 2) * MSM_WINDOWS, kmax = (wgs - 2) / 2;
+    size_t ipc_ = (total + kmax - 1) / kmax; ipc_ = (ipc_ + 63) / 64 * 64; if (ipc_ < 256) ipc_ = 256; if (ipc_ > 8192) ipc_ = 8192;
+    const uint32_t ipc = (uint32_t)ipc_; const size_t K = (total + ipc_ - 1) / ipc_;
     int32_t rc = ensure_scratch(c, 2 * (K + 1) * sizeof(pt29) + 512); if (rc) return rc;
     const uint32_t seq = ++c->seq;
     {
@@ -1073,10 +1103,10 @@ int32_t lasso_bullet_round(lasso_ctx* c, const lasso_bases* b, size_t n, const l
       const fr_t z = fr_zero();
       if (fold) hipLaunchKernelGGL((k_bullet_msm<true>), dim3((unsigned)K + 1, 2), dim3(MSM_THREADS), 0, c->stream, (const fr_t*)d_a_in, (const fr_t*)d_b_in, (const fr_t*)d_w_in, (fr_t*)d_a_out, (fr_t*)d_b_out,
                                    (fr_t*)d_w_out, (uint32_t)nk, (uint32_t)n, to_fr(u), to_fr(u_inv), to_fr(blinds), to_fr(blinds + 1), ipc, (const niels29*)b->d_mult, b->n, (pt29*)c->d_scratch,
-                                   (ed_point*)c->d_small, c->d_counters + LASSO_MAX_PTRS + 8, c->d_flag, seq);
+                                   (ed_point*)c->d_small, c->d_counters + LASSO_MAX_PTRS + 8, c->d_flag, seq, ps.counter());
       else hipLaunchKernelGGL((k_bullet_msm<false>), dim3((unsigned)K + 1, 2), dim3(MSM_THREADS), 0, c->stream, (const fr_t*)d_a_in, (const fr_t*)d_b_in, (const fr_t*)d_w_in, (fr_t*)nullptr, (fr_t*)nullptr,
                               (fr_t*)nullptr, (uint32_t)nk, (uint32_t)n, z, z, to_fr(blinds), to_fr(blinds + 1), ipc, (const niels29*)b->d_mult, b->n, (pt29*)c->d_scratch,
-                              (ed_point*)c->d_small, c->d_counters + LASSO_MAX_PTRS + 8, c->d_flag, seq);
+                              (ed_point*)c->d_small, c->d_counters + LASSO_MAX_PTRS + 8, c->d_flag, seq, ps.counter());
     }
     HIPCHK(c, hipGetLastError());
     return wait_flag(c, seq, 2 * (sizeof(ed_point) / sizeof(fr_t)), (lasso_fr*)out);

@@ -82,9 +82,15 @@ __device__ uint64_t msm_phase_clock[32];
 #else
 #define MSM_STAMP(k) do { } while (0)
 #endif
+// exact count of the mixed additions a launch executes (bench.py roofline_msm): only when the host passes a counter (the untimed fully-profiled step)
+__device__ __forceinline__ void msm_count_adds(uint32_t* digit_count, uint32_t mine) {
+  if (!digit_count) return;
+  for (int off = 32; off > 0; off >>= 1) mine += (uint32_t)__shfl_down(mine, off, 64);
+  if ((threadIdx.x & 63u) == 0 && mine) atomicAdd(digit_count, mine);
+}
 __device__ __forceinline__ uint32_t msm_nibble(const uint8_t* s, uint32_t w) { return (reinterpret_cast<const uint32_t*>(s)[w >> 3] >> (4 * (w & 7))) & 15u; }
 __global__ void __launch_bounds__(MSM_THREADS) k_msm_buckets(const uint8_t* __restrict__ scal, uint32_t bps, uint32_t W, size_t row_stride, size_t n_cols, size_t cols_per_chunk,
-                                                              const niels29* __restrict__ table, size_t table_stride, pt29* __restrict__ out) {
+                                                              const niels29* __restrict__ table, size_t table_stride, pt29* __restrict__ out, uint32_t* digit_count) {
   __shared__ __attribute__((aligned(16))) uint8_t raw[MSM_THREADS * sizeof(pt29)];  // sorted[] (32 KB) during accumulation, points (36 KB) during the trees
   __shared__ uint32_t counts[MSM_THREADS], start[MSM_THREADS], cursor[MSM_THREADS];
   __shared__ uint32_t toff[17], tree_top;
@@ -120,6 +126,7 @@ __global__ void __launch_bounds__(MSM_THREADS) k_msm_buckets(const uint8_t* __re
       const uint32_t d = msm_nibble(row + c * bps, w);
       if (d) sorted[atomicAdd(&cursor[(d << 4) | ((uint32_t)c & 15u)], 1u)] = (uint32_t)(w * table_stride + c);
     }
+    if (digit_count && t == 0 && start[MSM_THREADS - 1]) atomicAdd(digit_count, start[MSM_THREADS - 1]);   // non-zero digits of this batch = additions issued for it
     if (b0 == c0) {
       // share the threads out over digits 1..15 from the first batch's histogram (later batches of the same row have the same statistics);
       // every digit keeps at least one thread, so no pair of a later batch can be orphaned
@@ -348,7 +355,7 @@ __global__ void __launch_bounds__(64) k_precompute_tab8(const niels29* __restric
 // grid = (K chunks, rows).  scal: u32 scalars, row r at scal + r*row_words; W8 = bytes per scalar that can be non-zero (1 or 2).  out[row*K + chunk] = the chunk's
 // partial sum in the kernels' point form (k_points_sum finishes the row exactly as it does for k_msm_buckets).
 __global__ void __launch_bounds__(MSM_THREADS) k_msm_rows8(const uint32_t* __restrict__ scal, size_t row_words, uint32_t n_cols, uint32_t cols_per_chunk, uint32_t W8,
-                                                            const niels29* __restrict__ tab8_0, const niels29* __restrict__ tab8_1, size_t tn, pt29* __restrict__ out) {
+                                                            const niels29* __restrict__ tab8_0, const niels29* __restrict__ tab8_1, size_t tn, pt29* __restrict__ out, uint32_t* digit_count) {
   __shared__ pt29 pts[MSM_THREADS];
   __shared__ fe29 st[MSM_THREADS / 4][4];
   const fe29 d2 = fe_d2();
@@ -357,11 +364,12 @@ __global__ void __launch_bounds__(MSM_THREADS) k_msm_rows8(const uint32_t* __res
   const uint32_t c0 = blockIdx.x * cols_per_chunk;
   uint32_t c1 = c0 + cols_per_chunk; if (c1 > n_cols) c1 = n_cols;
   pt29 B = pt_identity();
-  niels29 cur; bool have = false;
+  niels29 cur; bool have = false; uint32_t nadds = 0;
   for (uint32_t c = c0 + t; c < c1; c += MSM_THREADS) {
     const uint32_t v = row[c];
     for (uint32_t w = 0; w < W8; w++) {
       const uint32_t d = (v >> (8 * w)) & 255u;
+      nadds += d != 0;
       // the fetch is unconditional (entry 0 for a zero byte) so that it is issued BEFORE the mixed addition below and waited for after it
       const niels29 nxt = (w ? tab8_1 : tab8_0)[d ? (size_t)(d - 1) * tn + c : 0];
       if (have) B = pt_madd(B, cur);
@@ -369,6 +377,7 @@ __global__ void __launch_bounds__(MSM_THREADS) k_msm_rows8(const uint32_t* __res
     }
   }
   if (have) B = pt_madd(B, cur);
+  msm_count_adds(digit_count, nadds);
   pts[t] = B;
   __syncthreads();
   msm_coop_tree(pts, st, MSM_THREADS, d2);
@@ -383,10 +392,11 @@ __device__ __forceinline__ void msm_recode(const uint32_t* s, uint32_t* dst) {
   for (int k = 0; k < 8; k++) { const uint64_t x = (uint64_t)s[k] + 0x88888888ull + carry; dst[k] = (uint32_t)x; carry = x >> 32; }
 }
 // items [it0, it1) of a row (one item = one (column, window); sb holds the recoded scalars of columns col0..): one mixed addition per non-zero digit
-__device__ __forceinline__ pt29 msm_direct_accumulate(const uint32_t* sb, uint32_t col0, uint32_t it0, uint32_t it1, const MsmColMap& cm, uint32_t row, const niels29* __restrict__ mult, size_t tn) {
+__device__ __forceinline__ pt29 msm_direct_accumulate(const uint32_t* sb, uint32_t col0, uint32_t it0, uint32_t it1, const MsmColMap& cm, uint32_t row, const niels29* __restrict__ mult, size_t tn,
+                                                      uint32_t* digit_count = nullptr) {
   const uint32_t t = threadIdx.x;
   pt29 B = pt_identity();
-  niels29 cur; bool have = false;
+  niels29 cur; bool have = false; uint32_t nadds = 0;
   for (uint32_t base = it0; base < it1; base += MSM_THREADS) {
     const uint32_t it = base + t;
     bool valid = it < it1; int32_t d = 0; uint32_t c = 0, w = 0;
@@ -403,9 +413,10 @@ __device__ __forceinline__ pt29 msm_direct_accumulate(const uint32_t* sb, uint32
 #pragma unroll
     for (int k = 0; k < 9; k++) { cur.ypx.v[k] = neg ? nxt.ymx.v[k] : nxt.ypx.v[k]; cur.ymx.v[k] = neg ? nxt.ypx.v[k] : nxt.ymx.v[k]; cur.t2d.v[k] = neg ? -nxt.t2d.v[k] : nxt.t2d.v[k]; }
 #endif
-    have = valid;
+    have = valid; nadds += valid;
   }
   if (have) B = pt_madd(B, cur);
+  msm_count_adds(digit_count, nadds);
   return B;
 }
 // the workgroup's 256 partial sums -> one point (cooperative tree), then across the K workgroups of the row in the last one to arrive (ticket),
@@ -461,7 +472,7 @@ __device__ __forceinline__ void msm_direct_finish(pt29* pts, fe29 (*st)[4], uint
 template <int MODE>
 __global__ void __launch_bounds__(MSM_THREADS) k_msm_direct(const uint32_t* __restrict__ scal, size_t row_words, uint32_t n_cols, uint32_t items_per_chunk, MsmColMap cm,
                                                              const niels29* __restrict__ mult, size_t tn, pt29* __restrict__ partial, ed_point* __restrict__ out_mont, uint32_t* counters,
-                                                             uint32_t* flag, uint32_t seq, fr_t scale, fr_t tail0, fr_t tail1) {
+                                                             uint32_t* flag, uint32_t seq, fr_t scale, fr_t tail0, fr_t tail1, uint32_t* digit_count) {
   __shared__ pt29 pts[MSM_THREADS];
   __shared__ fe29 st[MSM_THREADS / 4][4];
   __shared__ uint32_t sb[MSM_DIRECT_MAX_COLS * 8];
@@ -490,7 +501,7 @@ __global__ void __launch_bounds__(MSM_THREADS) k_msm_direct(const uint32_t* __re
   }
   __syncthreads();
   MSM_STAMP(1);
-  const pt29 B = msm_direct_accumulate(sb, col0, it0, it1, cm, row, mult, tn);
+  const pt29 B = msm_direct_accumulate(sb, col0, it0, it1, cm, row, mult, tn, digit_count);
   MSM_STAMP(2);
   msm_direct_finish(pts, st, &is_last, B, K, row, partial, out_mont, counters, flag, seq);
 }
@@ -632,15 +643,16 @@ __global__ void __launch_bounds__(256) k_bullet_step(const fr_t* __restrict__ a_
 // the fold kernel (15-22 us: a', b', w', the inner products through a last-block reduction, the scalar rows written to HBM), the gap to the next
 // launch, and the MSM kernel reading those rows back.  Here every MSM workgroup derives the scalars of ITS columns itself — column g = (i, blk) of
 // row L is w'_blk * a'_L[i] over generator blk*nk + half + i, of row R w'_blk * a'_R[i] over blk*nk + i; 3 to 5 field products per column, <= 33 columns
-// per workgroup — straight into the LDS digit buffer, and one extra workgroup per row (blockIdx.x == gridDim.x - 1) folds a and b, takes the row's inner
+// per workgroup — straight into the LDS digit buffer, and one extra workgroup per row (blockIdx.x == 0) folds a and b, takes the row's inner
 // product (c_L = <a'_L, b'_R> for row 0, c_R = <a'_R, b'_L> for row 1) and contributes c * Q + blind * H as its partial sum.  The state of the next round
 // (a', b' by the two extra workgroups, w' by the row-0 workgroups that own a column with i = 0) is written on the way.
-// grid = (K + 1, 2): K chunks over the n/2 columns x 64 windows of a row, then the extra workgroup.  FOLD = false: first round, the inputs are the state.
+// grid = (1 + K, 2): the extra workgroup, then K chunks over the n/2 columns x 64 windows of a row; 2 (K + 1) <= the CU count, so that every workgroup has a
+// CU to itself (at 258 workgroups the two that had to wait for a free CU — the extra ones — put 18 us on every round).  FOLD = false: first round, the inputs are the state.
 template <bool FOLD>
 __global__ void __launch_bounds__(MSM_THREADS) k_bullet_msm(const fr_t* __restrict__ a_in, const fr_t* __restrict__ b_in, const fr_t* __restrict__ w_in, fr_t* __restrict__ a_out,
                                                              fr_t* __restrict__ b_out, fr_t* __restrict__ w_out, uint32_t nk, uint32_t n, fr_t u, fr_t u_inv, fr_t blind_l, fr_t blind_r,
                                                              uint32_t items_per_chunk, const niels29* __restrict__ mult, size_t tn, pt29* __restrict__ partial, ed_point* __restrict__ out_mont,
-                                                             uint32_t* counters, uint32_t* flag, uint32_t seq) {
+                                                             uint32_t* counters, uint32_t* flag, uint32_t seq, uint32_t* digit_count) {
   __shared__ pt29 pts[MSM_THREADS];   // the extra workgroup's reduction scratch (RedScratch, 29.6 KB) lives here before the tree needs it
   __shared__ fe29 st[MSM_THREADS / 4][4];
   __shared__ uint32_t sb[MSM_DIRECT_MAX_COLS * 8];
@@ -650,9 +662,10 @@ __global__ void __launch_bounds__(MSM_THREADS) k_bullet_msm(const fr_t* __restri
   const uint32_t half = nk / 2, ncols = n / 2;
   const fr29 us = fr29_unpack_s(u), uis = fr29_unpack_s(u_inv);
   pt29 B;
-  if (blockIdx.x < K) {
+  // the extra workgroup is blockIdx.x == 0: dispatched first, because in the early rounds (long a, b) it is the longest of the launch
+  if (blockIdx.x > 0) {
     const uint32_t total = ncols * MSM_WINDOWS;
-    const uint32_t it0 = blockIdx.x * items_per_chunk;
+    const uint32_t it0 = (blockIdx.x - 1) * items_per_chunk;
     uint32_t it1 = it0 + items_per_chunk; if (it1 > total) it1 = total;
     const uint32_t col0 = it0 >> 6, col1 = (it1 + 63) >> 6;
     for (uint32_t c = t; c < col1 - col0; c += MSM_THREADS) {
@@ -670,7 +683,7 @@ __global__ void __launch_bounds__(MSM_THREADS) k_bullet_msm(const fr_t* __restri
     }
     __syncthreads();
     const MsmColMap cm = {nk, half, ncols, n};
-    B = msm_direct_accumulate(sb, col0, it0, it1, cm, row, mult, tn);
+    B = msm_direct_accumulate(sb, col0, it0, it1, cm, row, mult, tn, digit_count);
   } else {
     RedScratch& S = *reinterpret_cast<RedScratch*>(pts);
     fr29 acc[3] = {fr29_zero(), fr29_zero(), fr29_zero()}; uint32_t cnt = 0;
@@ -696,7 +709,7 @@ __global__ void __launch_bounds__(MSM_THREADS) k_bullet_msm(const fr_t* __restri
     }
     __syncthreads();   // S (aliasing pts) is dead from here on
     const MsmColMap id = {0, 0, 0, 0};
-    B = msm_direct_accumulate(sb, 0, 0, 2 * MSM_WINDOWS, id, row, mult + n, tn);   // columns n (Q) and n + 1 (H) of the table
+    B = msm_direct_accumulate(sb, 0, 0, 2 * MSM_WINDOWS, id, row, mult + n, tn, digit_count);   // columns n (Q) and n + 1 (H) of the table
   }
   msm_direct_finish(pts, st, &is_last, B, K + 1, row, partial, out_mont, counters, flag, seq);
 }

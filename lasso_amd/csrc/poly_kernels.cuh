@@ -638,49 +638,79 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_combine_round_linear(StrategyDe
   store_block_partials<3>(acc, 3, partials + (size_t)blockIdx.x * 3, 5, R);   // (u * s) * u: 2^5 short
 }
 // K3 for LT: degree = C + 1.  A = compile-time bound on NUM_MEMORIES = 2C (dispatch only), D = bound on the degree.
-// g(x) eq(x) = sum_i LT_i(x) * prod_{j<i} EQ_j(x) * eq(x) at the points x = 0..degree (lt.rs:62-71 inside sumcheck.rs:179-218), every factor linear in x.
-// The memories are STREAMED: per point the thread keeps only the running product e(x) * prod_{j<i} EQ_j(x) and the running sum — 2 (D + 1) field elements,
-// whatever C is — and walks i = 0..C-1 loading one (LT_i, EQ_i) pair of lines at a time, stepping them from point to point by addition.  (The first version
-// held all 2C lines and their differences in registers: 4C + D + 1 elements, 738 VGPRs at C = 16 — it spilled, and the degree-17 round of LT C=16 ran at
-// 128 GB/s, 54 % of that proof.)  Starting the running product at e(x) instead of 1 weights every term by the eq polynomial for free, so the sums accumulate
-// straight across indices.  Same 2 C (D + 1) products per index as the literal loop; identical field elements.
-// The per-point state is spelled out as scalars (LT_REP): as arrays `fr29 sum[D + 1], run[D + 1]` the compiler left them in scratch memory even with every index
+// g(x) eq(x) = e(x) * sum_i LT_i(x) * prod_{j<i} EQ_j(x) at the points x = 0..degree (lt.rs:62-71 inside sumcheck.rs:179-218), every factor linear in x.
+// HORNER FORM (round 3): sum_i LT_i prod_{j<i} EQ_j = LT_0 + EQ_0 (LT_1 + EQ_1 (LT_2 + ... + EQ_{C-2} LT_{C-1})), so walking the memories from the LAST to the
+// first needs ONE product per memory and point — t <- LT_m + EQ_m t — instead of the forward form's two (term = LT_i * run, run = EQ_i * run), and one more per
+// point for the eq weight: C (D + 1) products per index (+ 2 per memory for the scaling below) instead of 2 C (D + 1) — 318 instead of 576 at C = 16 — for the
+// same field elements (EQ_{C-1} enters no term of the sum and is not even loaded).  The memories are STREAMED: per point the thread keeps only t and the running
+// sum over indices — 2 (D + 1) field elements whatever C is — loading one (LT_m, EQ_m) pair of lines at a time and stepping them from point to point by addition.
+// (The first version held all 2C lines and their differences in registers: 4C + D + 1 elements, 738 VGPRs at C = 16 — it spilled, and the degree-17 round of LT
+// C=16 ran at 128 GB/s.)
+// Radix and magnitudes.  Horner feeds t back through a product at every step, so the multiplier must be SMALL or t grows geometrically: a line stepped to x = 17
+// is up to 18 values of < p each, and in s-form (x 32) that is 2^261.2 for curve25519 and 2^262.8 for BN254 — above the Montgomery radix 2^261, a growth factor
+// above 1.  Everything therefore stays in u-form (factor 18 p / 2^261 <= 0.11: |t| <= 24 p throughout), and the 2^5 each u * u product comes out short is
+// absorbed into the data instead: with LT_m pre-multiplied by kappa_m = 32^-(C-1-m) (two products per memory and index — the line's two end points — against
+// D + 1 for the walk) the recursion  t_m = kappa_m LT_m + (EQ_m * t_{m+1}) / 32  yields t_0 = T_0 / 32^(C-1), the weighted sum comes out as sum e T_0 / 32^C, and
+// the block partials are multiplied by 32^C once (`scale`).  tests/cpp/test_poly_math_host.cpp drives exactly this code under UBSan with extreme inputs, both curves.
+// The per-point state is spelled out as scalars (LT_REP): as arrays `fr29 sum[D + 1], t[D + 1]` the compiler left them in scratch memory even with every index
 // a constant after unrolling (1312 bytes per lane at D = 17), which is exactly the traffic this kernel exists to avoid.
+// indices between two folds of the running sums: a term e * t is below p + |e| |t| / 2^261 <= 3.6 p (18 p * 24 p; BN254's p / 2^261 = 2^-7.4), so 32 of them stay
+// below 2^261 and limb 8 inside the loose bound 2^30 that the fold's product requires
+#define LT_FOLD_EVERY() 32u
+struct LtScale { fr_t kappa[LASSO_MAX_ALPHA / 2]; fr_t scale; };   // kappa[m] = 32^-(C-1-m), scale = 32^C, memory (Montgomery) form
 #define LT_REP(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15) M(16) M(17)
-#define LT_DECL(k) fr29 sum##k = fr29_zero(), run##k = fr29_zero();
-#define LT_INIT(k) if constexpr (k <= D) { if ((uint32_t)k <= degree) { run##k = ecur; ecur = fr29_weak(fr29_add(ecur, edif)); } }
-#define LT_STEP(k) if constexpr (k <= D) { if ((uint32_t)k <= degree) { sum##k = fr29_weak(fr29_add(sum##k, fr29_mul(lt, run##k))); run##k = fr29_mul(eqv, run##k); \
-                                                                       lt = fr29_weak(fr29_add(lt, dlt)); eqv = fr29_weak(fr29_add(eqv, deq)); } }
+#define LT_DECL(k) fr29 sum##k = fr29_zero(), t##k = fr29_zero();
+#define LT_TOP(k) if constexpr (k <= D) { if ((uint32_t)k <= degree) { t##k = lt; lt = lt_line_step(lt, dlt); } }
+#define LT_STEP(k) if constexpr (k <= D) { if ((uint32_t)k <= degree) { t##k = lt_horner_step(lt, eqv, t##k); lt = lt_line_step(lt, dlt); eqv = lt_line_step(eqv, deq); } }
+#define LT_ACC(k) if constexpr (k <= D) { if ((uint32_t)k <= degree) { sum##k = lt_weighted_acc(sum##k, ecur, t##k); ecur = lt_line_step(ecur, edif); } }
 #define LT_FOLD(k) if constexpr (k <= D) sum##k = fr29_mul(sum##k, fr29_one_s());
-#define LT_OUT(k) if constexpr (k <= D) res[k] = sum##k;
+#define LT_OUT(k) if constexpr (k <= D) res[k] = fr29_mul(sum##k, sc);
+// the per-point operations of the LT round (extracted verbatim by tests/test_host_arith_cpp.py and driven under UBSan): a line stepped to the next evaluation
+// point; one Horner step t <- LT + (EQ * t) (u-form operands: the product is 2^5 short, see above); the eq-weighted accumulation sum += e * t
+__device__ __forceinline__ fr29 lt_line_step(const fr29& v, const fr29& d) {
+  return fr29_weak(fr29_add(v, d));
+}
+__device__ __forceinline__ fr29 lt_horner_step(const fr29& lt, const fr29& eqv, const fr29& t) {
+  return fr29_weak(fr29_add(lt, fr29_mul(eqv, t)));
+}
+__device__ __forceinline__ fr29 lt_weighted_acc(const fr29& sum, const fr29& e, const fr29& t) {
+  return fr29_weak(fr29_add(sum, fr29_mul(e, t)));
+}
 template <int A, int D>
-__global__ void __launch_bounds__(LASSO_BLOCK) k_combine_round_lt(StrategyDev S, PtrTable polys, const fr_t* __restrict__ eq, size_t half, uint32_t degree, fr_t* __restrict__ partials) {
+__global__ void __launch_bounds__(LASSO_BLOCK) k_combine_round_lt(StrategyDev S, PtrTable polys, const fr_t* __restrict__ eq, LtScale K, size_t half, uint32_t degree, fr_t* __restrict__ partials) {
   static_assert(D <= 17, "LT_REP lists 18 points");
   __shared__ RedScratch R;
   LT_REP(LT_DECL)
   uint32_t cnt = 0;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x) {
-    {
-      fr29 ecur = fr29_unpack_u(eq[i]); const fr29 edif = fr29_sub(fr29_unpack_u(eq[i + half]), ecur);
-      LT_REP(LT_INIT)
+    {   // innermost term: t(x) = LT_{C-1}(x)  (kappa = 1)
+      const fr_t* __restrict__ pl = polys.p[2 * (S.c - 1)];
+      fr29 lt = fr29_unpack_u(pl[i]); const fr29 dlt = fr29_sub(fr29_unpack_u(pl[i + half]), lt);
+      LT_REP(LT_TOP)
     }
-    for (uint32_t m = 0; m < S.c; m++) {
+    for (uint32_t m = S.c - 1; m-- > 0;) {   // t <- kappa_m LT_m + (EQ_m * t) / 32
       const fr_t* __restrict__ pl = polys.p[2 * m]; const fr_t* __restrict__ pe = polys.p[2 * m + 1];
-      fr29 lt = fr29_unpack_s(pl[i]), eqv = fr29_unpack_s(pe[i]);   // s-form lines: products of any degree stay in the accumulator's form (s * u = u)
-      const fr29 dlt = fr29_sub(fr29_unpack_s(pl[i + half]), lt), deq = fr29_sub(fr29_unpack_s(pe[i + half]), eqv);
+      const fr29 ks = fr29_unpack_s(K.kappa[m]);
+      fr29 lt = fr29_mul(fr29_unpack_u(pl[i]), ks), eqv = fr29_unpack_u(pe[i]);
+      const fr29 dlt = fr29_sub(fr29_mul(fr29_unpack_u(pl[i + half]), ks), lt), deq = fr29_sub(fr29_unpack_u(pe[i + half]), eqv);
       LT_REP(LT_STEP)
     }
-    cnt += S.c;
-    if (cnt >= 96u) { cnt = 0; LT_REP(LT_FOLD) }   // at most 127 additions between folds (acc_add's bound), S.c <= 16 per index
+    {   // weight by the eq polynomial's line and accumulate over the indices
+      fr29 ecur = fr29_unpack_u(eq[i]); const fr29 edif = fr29_sub(fr29_unpack_u(eq[i + half]), ecur);
+      LT_REP(LT_ACC)
+    }
+    if (++cnt >= LT_FOLD_EVERY()) { cnt = 0; LT_REP(LT_FOLD) }
   }
+  const fr29 sc = fr29_unpack_s(K.scale);   // u-form sums of (value / 32^C) times the s-form of 32^C: u-form of the value
   fr29 res[D + 1];
   LT_REP(LT_OUT)
   store_block_partials<D + 1>(res, degree + 1, partials + (size_t)blockIdx.x * (degree + 1), 0, R);
 }
 #undef LT_REP
 #undef LT_DECL
-#undef LT_INIT
+#undef LT_TOP
 #undef LT_STEP
+#undef LT_ACC
 #undef LT_FOLD
 #undef LT_OUT
 // K10: claim = sum_k eq[k] * g(E(k))  (subtables/mod.rs:187-216)
@@ -694,8 +724,9 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_combine_claim(StrategyDev S, Pt
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     fr29 g;
     if (lt) {   // lt.rs:62-71 streamed over the memories: running sum and running product, no array of values (which ended up in scratch memory at A >= 16)
-      fr29 eq_prod = fr29_one_s(); g = fr29_zero();
-      for (uint32_t m = 0; m < S.c; m++) { g = fr29_weak(fr29_add(g, fr29_mul(fr29_unpack_s(polys.p[2 * m][i]), eq_prod))); eq_prod = fr29_mul(fr29_unpack_s(polys.p[2 * m + 1][i]), eq_prod); }
+      // Horner from the last memory: g = LT_0 + EQ_0 (LT_1 + EQ_1 (...  + EQ_{C-2} LT_{C-1})): one product per memory instead of two
+      g = fr29_unpack_s(polys.p[2 * (S.c - 1)][i]);
+      for (uint32_t m = S.c - 1; m-- > 0;) g = fr29_weak(fr29_add(fr29_unpack_s(polys.p[2 * m][i]), fr29_mul(fr29_unpack_s(polys.p[2 * m + 1][i]), g)));
     } else g = weighted_sum(polys, i, S.alpha, ws);
     acc_add(acc[0], fr29_mul(g, fr29_unpack_u(eq[i])), cnt);
   }

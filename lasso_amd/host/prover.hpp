@@ -439,6 +439,15 @@ inline PolyCommitment hyrax_commit(const Dev& d, const lasso_fr* d_Z, size_t num
     void* d_part = d.alloc_bytes(l_size * rb); void* d_all = d.alloc_bytes(P * l_size * rb);
     PolyCommitment c; c.rows = l_size; c.compressed.resize(32 * l_size);
     int32_t rc = lasso_hyrax_commit_rows_dev(d.ctx, d_Z, l_size, r_size / P, gens.bases_slab, d_part);
+    // ncclAllGather is a collective and the wait behind it (lasso_points_reduce_compress synchronises the stream) has no time-out: a rank whose partial
+    // commitment failed (out of memory, ...) must not leave its peers inside it.  The ranks therefore exchange their status through the host-side
+    // all-gather first (bounded waits) and enter the device collective only if EVERY rank succeeded; otherwise all of them throw together.
+    {
+      std::vector<int32_t> st(P, 0); const int32_t mine = rc;
+      d.comm.allgather(&mine, st.data(), sizeof(int32_t));
+      for (size_t g = 0; g < P; g++) if (st[g] != 0 && rc == 0) rc = LASSO_ERR_HIP;   // a peer failed: do not enter the collective
+      if (rc != 0 && mine == 0) { d.free(d_part); d.free(d_all); throw Error("slab commitment exchange: another rank failed to compute its partial row commitments"); }
+    }
     if (!rc) rc = lasso_rccl_allgather(d.ctx, d_part, d_all, l_size * rb);
     if (!rc) rc = lasso_points_reduce_compress(d.ctx, d_all, (uint32_t)P, l_size, c.compressed.data());
     d.free(d_part); d.free(d_all);

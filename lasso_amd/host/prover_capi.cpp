@@ -51,17 +51,27 @@ int32_t lasso_host_set_comm_shm(lasso_host* h, int32_t rank, int32_t world, cons
     h->dev.comm.rank = (size_t)rank; h->dev.comm.world = (size_t)world; h->dev.comm.fn = &ShmComm::trampoline; h->dev.comm.user = h->shm.get();
     // The bulk exchange (partial row commitments) goes over RCCL on the device stream when every rank can join one communicator: rank 0 draws the
     // unique id and publishes it through the segment; the ranks then agree (an all-gather of one status byte) — all use RCCL or none does.
+    // Agreement protocol (every step an all-gather through the segment, so no rank can be left inside a collective its peers never enter):
+    //   1. every rank publishes whether IT can use RCCL at all (librccl loads, LASSO_SLAB_RCCL != 0) — ncclCommInitRank is only entered if ALL can;
+    //   2. rank 0 draws the unique id and publishes it with its status — the others read it, and all enter ncclCommInitRank or none does;
+    //   3. every rank publishes its ncclCommInitRank outcome — the communicator is kept only if it came up on every rank.
     const char* e = getenv("LASSO_SLAB_RCCL");
-    if (world > 1 && !(e && e[0] == '0')) {
-      uint8_t blob[129] = {0};
-      if (rank == 0) blob[128] = lasso_rccl_unique_id(blob) == 0 ? 1 : 0;
-      h->shm->broadcast_blob(blob, sizeof(blob));
-      uint8_t mine = 0;
-      if (blob[128]) mine = lasso_rccl_init(h->dev.ctx, rank, world, blob) == 0 ? 1 : 0;
-      std::vector<uint8_t> all((size_t)world, 0);
-      if (h->shm->allgather(&mine, all.data(), 1) != 0) throw Error("lasso_host_set_comm_shm: ranks did not agree on the device-side exchange");
-      bool every = true; for (uint8_t v : all) every = every && v;
-      if (!every && mine) (void)lasso_rccl_shutdown(h->dev.ctx);
+    if (world > 1) {
+      auto all_ok = [&](uint8_t mine, const char* what) {
+        std::vector<uint8_t> all((size_t)world, 0);
+        if (h->shm->allgather(&mine, all.data(), 1) != 0) throw Error(std::string("lasso_host_set_comm_shm: ranks did not agree on ") + what);
+        bool every = true; for (uint8_t v : all) every = every && v; return every;
+      };
+      const uint8_t can = (!(e && e[0] == '0') && lasso_rccl_available() == 1) ? 1 : 0;
+      if (all_ok(can, "RCCL availability")) {
+        uint8_t blob[129] = {0};
+        if (rank == 0) blob[128] = lasso_rccl_unique_id(blob) == 0 ? 1 : 0;
+        h->shm->broadcast_blob(blob, sizeof(blob));
+        if (blob[128]) {     // the same byte on every rank: all enter the collective init, or none
+          const uint8_t mine = lasso_rccl_init(h->dev.ctx, rank, world, blob) == 0 ? 1 : 0;
+          if (!all_ok(mine, "the device-side exchange") && mine) (void)lasso_rccl_shutdown(h->dev.ctx);
+        }
+      }
     }
     return 0;)
 }

@@ -65,6 +65,7 @@ class ShmComm {
         std::this_thread::sleep_for(std::chrono::milliseconds(2));
       }
     }
+   attach:
     void* p = mmap(nullptr, map_bytes_, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
     close(fd);
     if (p == MAP_FAILED) throw std::runtime_error("ShmComm: mmap failed");
@@ -72,7 +73,21 @@ class ShmComm {
     if (rank == 0) { hdr()->world = (uint32_t)world; hdr()->slot_bytes = slot_bytes_; hdr()->magic.store(MAGIC, std::memory_order_release); }   // fresh pages are zero: all sequence words start at 0
     while (hdr()->magic.load(std::memory_order_acquire) != MAGIC) { if (now() - t0 > timeout_s_) throw std::runtime_error("ShmComm: segment never initialised"); std::this_thread::yield(); }
     if (hdr()->world != (uint32_t)world || hdr()->slot_bytes != slot_bytes_) throw std::runtime_error("ShmComm: ranks disagree on world size / slot size");
-    hdr()->attached.fetch_add(1, std::memory_order_acq_rel);
+    // A segment left behind by a run that died before rank 0's post-attach unlink still has MAGIC set and attached >= world: a rank that opened it before
+    // rank 0 of THIS run re-created the name would pass both barriers on the dead segment.  The attach count tells them apart: in a live segment every rank
+    // is counted once, so the value a new arrival sees is < world.  On a dead one: unmap and open the name again (rank 0 replaces it with O_EXCL).
+    if (hdr()->attached.fetch_add(1, std::memory_order_acq_rel) >= (uint32_t)world) {
+      munmap(base_, map_bytes_); base_ = nullptr;
+      if (rank == 0) throw std::runtime_error("ShmComm: freshly created segment is already fully attached");
+      for (;;) {
+        if (now() - t0 > timeout_s_) throw std::runtime_error("ShmComm: only a stale segment of an earlier run exists under " + name);
+        std::this_thread::sleep_for(std::chrono::milliseconds(2));
+        fd = shm_open(name.c_str(), O_RDWR, 0600);
+        if (fd < 0) continue;
+        struct stat st; if (fstat(fd, &st) == 0 && (size_t)st.st_size >= map_bytes_) goto attach;
+        close(fd);
+      }
+    }
     while (hdr()->attached.load(std::memory_order_acquire) < (uint32_t)world) { if (now() - t0 > timeout_s_) throw std::runtime_error("ShmComm: not every rank attached"); std::this_thread::yield(); }
     if (rank == 0) shm_unlink(name.c_str());
   }

@@ -30,8 +30,11 @@ inline bool decompress_point(const uint8_t in[32], Pt& out, bool& infinity) {
   uint8_t b[32]; memcpy(b, in, 32);
   const bool neg = (b[31] & 0x80) != 0; infinity = (b[31] & 0x40) != 0; b[31] &= 0x3f;
   fq_t c; memcpy(c.v, b, 32);
-  if (infinity) { if (neg || !fq_is_zero(c)) return false; out = Pt::identity(); return true; }
+  // ark-ec 0.4 (SWCurveConfig::deserialize_with_mode): both flags set is no SWFlags value; x must be a canonical field element whatever the flags say;
+  // with the infinity flag the point is the identity WHATEVER x is (the transcript then absorbs the re-serialised identity: x = 0 with the flag)
+  if (neg && infinity) return false;
   if (fq_geq_p(c.v)) return false;
+  if (infinity) { out = Pt::identity(); return true; }
   const fq_t x = fq_from_canonical(c);
   fq_t y;
   if (!fq_sqrt(fq_add(fq_mul(fq_sqr(x), x), fq_from_u64(3)), y)) return false;
@@ -88,11 +91,13 @@ struct ProofReader {
     if (!decompress_point(p + pos, w.p, w.infinity)) throw Error("proof bytes: invalid point encoding");
     compress_affine_pt(w.p, w.infinity, w.bytes); pos += 32; return w;
   }
-  size_t len() { const uint64_t k = u64le(); if (k > n) throw Error("proof bytes: implausible vector length"); return (size_t)k; }
-  ScVec sc_vec() { const size_t k = len(); ScVec v; for (size_t i = 0; i < k; i++) v.push_back(sc()); return v; }
+  // a length prefix is believed only as far as the bytes behind it can back it: k elements of at least `elem` bytes each must still fit, so a
+  // crafted prefix cannot make the reader reserve more than the proof's own size (a WirePoint is ~200 B in memory for 32 B on the wire)
+  size_t len(size_t elem) { const uint64_t k = u64le(); if (k > (n - pos) / elem) throw Error("proof bytes: implausible vector length"); return (size_t)k; }
+  ScVec sc_vec() { const size_t k = len(32); ScVec v; v.reserve(k); for (size_t i = 0; i < k; i++) v.push_back(sc()); return v; }
   ScVec sc_arr(size_t k) { ScVec v; for (size_t i = 0; i < k; i++) v.push_back(sc()); return v; }
-  std::vector<WirePoint> pts_vec() { const size_t k = len(); std::vector<WirePoint> v; v.reserve(k); for (size_t i = 0; i < k; i++) v.push_back(pt()); return v; }
-  SumcheckProof sumcheck() { SumcheckProof s; const size_t k = len(); for (size_t i = 0; i < k; i++) s.compressed_polys.push_back(sc_vec()); return s; }
+  std::vector<WirePoint> pts_vec() { const size_t k = len(32); std::vector<WirePoint> v; v.reserve(k); for (size_t i = 0; i < k; i++) v.push_back(pt()); return v; }
+  SumcheckProof sumcheck() { SumcheckProof s; const size_t k = len(8); for (size_t i = 0; i < k; i++) s.compressed_polys.push_back(sc_vec()); return s; }   // every inner vector carries at least its own 8-byte prefix
   bool done() const { return pos == n; }
 };
 struct WireDotProductProofLog { std::vector<WirePoint> L_vec, R_vec; WirePoint delta, beta; Sc z1, z2; };   // dot_product.rs:152-159 + bullet.rs:23-28
@@ -106,7 +111,7 @@ struct WireProof {   // surge.rs:92-104 with its nested structs flattened in dec
 };
 inline WireDotProductProofLog read_dpl(ProofReader& r) { WireDotProductProofLog d; d.L_vec = r.pts_vec(); d.R_vec = r.pts_vec(); d.delta = r.pt(); d.beta = r.pt(); d.z1 = r.sc(); d.z2 = r.sc(); return d; }
 inline WireBgpa read_bgpa(ProofReader& r) {
-  WireBgpa g; const size_t k = r.len();
+  WireBgpa g; const size_t k = r.len(24);   // a layer = three length prefixes at least
   for (size_t i = 0; i < k; i++) { LayerProofBatched l; l.proof = r.sumcheck(); l.claims_prod_left = r.sc_vec(); l.claims_prod_right = r.sc_vec(); g.proof.push_back(std::move(l)); }
   return g;
 }

@@ -14,7 +14,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 def load_prover_library(path=None, curve="curve25519"):
     """curve = "bn254": the BN254 pair (liblasso_prover_bn254.so over liblasso_hip_bn254.so); both pairs can live in one process."""
-    path = path or os.path.join(HERE, "liblasso_prover_bn254.so" if curve == "bn254" else "liblasso_prover.so")
+    # LASSO_PROVER_LIB: an explicit path to another build of the SAME C ABI (the CPU tests of bench.py's multi-rank plumbing point it at the host sources linked
+    # against the test mock of the device ABI).  Never set by the package itself; when unset the HIP-backed library is the only candidate and its absence is fatal.
+    path = path or os.environ.get("LASSO_PROVER_LIB") or os.path.join(HERE, "liblasso_prover_bn254.so" if curve == "bn254" else "liblasso_prover.so")
     if not os.path.exists(path):
         raise LassoError(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` (no CPU fallback exists)")
     return C.CDLL(path)

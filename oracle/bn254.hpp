@@ -100,8 +100,11 @@ inline bool curve_decompress(const uint8_t* in, Point& out) {
   const bool neg = (b[31] & 0x80) != 0, inf = (b[31] & 0x40) != 0; b[31] &= 0x3f;
   u64 c[4] = {0, 0, 0, 0};
   for (int i = 0; i < 32; i++) c[i / 8] |= (u64)b[i] << (8 * (i % 8));
-  if (inf) { if (neg || (c[0] | c[1] | c[2] | c[3])) return false; out = Point::identity(); return true; }
+  // ark-ec 0.4 SWCurveConfig::deserialize_with_mode: (negative, infinity) both set is not a flag value; x is read as a canonical Fq first; with the
+  // infinity flag the result is Affine::identity() whatever x holds
+  if (neg && inf) return false;
   if (Fq::geq_p(c)) return false;
+  if (inf) { out = Point::identity(); return true; }
   Fq x = Fq::from_canonical(c), ys, yl;
   if (!sw_ys_from_x(x, ys, yl)) return false;
   out = Point::from_affine(x, neg ? yl : ys);

@@ -57,6 +57,7 @@ int32_t lasso_copy(lasso_ctx*, void* d, const void* s, size_t n) { memmove(d, s,
 int32_t lasso_zero(lasso_ctx*, void* d, size_t n) { memset(d, 0, n); return 0; }
 int32_t lasso_sync(lasso_ctx*) { return 0; }
 // the device-side exchange of slab mode has no CPU statement: the mock reports it unsupported and the host prover keeps to its host-memory exchange
+int32_t lasso_rccl_available(void) { return 0; }
 int32_t lasso_rccl_unique_id(uint8_t*) { return LASSO_ERR_UNSUPPORTED; }
 int32_t lasso_rccl_init(lasso_ctx*, int32_t, int32_t, const uint8_t*) { return LASSO_ERR_UNSUPPORTED; }
 int32_t lasso_rccl_ready(lasso_ctx*) { return 0; }

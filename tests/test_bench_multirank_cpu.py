@@ -1,0 +1,49 @@
+"""CPU: `python bench.py --gpus 2` outside any launcher spawns its own two ranks (torch.distributed.run on 127.0.0.1; gloo, because this box has fewer GPUs than
+ranks), prints ONE JSON line with n_gpus = 2, the per-GPU-proof (weak) value AND the slab leg (ONE proof over both ranks, strong) — VERDICT r2 "What's missing" 4.
+The product libraries need a GPU, so the harness is pointed (LASSO_PROVER_LIB / LASSO_DEVICE_LIB) at the host-prover sources linked against the test mock of the
+device ABI: what is exercised is bench.py's own multi-rank plumbing, the shared-memory exchange and the slab prover's host logic — not a kernel."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+from proverutil import OracleSession, build_mock_prover
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_gpus2_self_launch_prints_weak_and_slab(oracle):
+    so = build_mock_prover()
+    env = dict(os.environ, LASSO_PROVER_LIB=so, LASSO_DEVICE_LIB=so, OMP_NUM_THREADS="2")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--log-s", "8", "--log-m", "8", "--no-cpu-baseline", "--concurrent", "0",
+           "--slab-kind", "range", "--slab-c", "2", "--slab-log-s", "7", "--slab-steps", "1", "--log-r", "12", "--slab-timeout", "240"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]                      # rank 0 prints, once
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["steps"] == 1
+    assert out["config"]["distinct_proofs"] == 2                    # one independent proof per rank
+    assert out["config"]["launched_by"].startswith("bench.py --gpus N itself")
+    assert out["value"] > 0 and out["lib_sha"]["sources_sha256"]
+    slab = out["slab_mode"]
+    assert slab.get("n_gpus") == 2 and slab["scaling"] == "strong", slab
+    assert slab["rccl_ranks"] == 0                                   # no GPU per rank here: the rows travel through the shared-memory exchange, consistently on both ranks
+    # the sharded proof is the single-prover proof of the same instance: compare with the oracle
+    from lasso_amd import _abi
+    from lasso_amd.prover import HostProver
+    import ctypes as C
+    import hashlib
+    hp = HostProver(lib=C.CDLL(so))
+    idx = hp.gen_indices(1 << 7, 1 << 8, 2); r = hp.gen_random_point(7)
+    hp.close()
+    orc = OracleSession(oracle, _abi.KINDS["range"], 2, 8, 12, idx, r)
+    try:
+        assert hashlib.sha256(orc.prove()).hexdigest() == slab["proof_sha256"]
+        assert hashlib.sha256(orc.commit()).hexdigest() == slab["commitment_sha256"]
+    finally:
+        orc.close()

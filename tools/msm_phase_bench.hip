@@ -33,7 +33,7 @@ int main(int argc, char** argv) {
     float best1 = 1e9f, best2 = 1e9f; uint64_t clk[32] = {0};
     for (int it = 0; it < 6; it++) {
       CK(hipEventRecord(e0));
-      hipLaunchKernelGGL(k_msm_buckets, dim3((unsigned)Kc, (unsigned)rows), dim3(MSM_THREADS), 0, 0, (const uint8_t*)d_sc, 32u, (uint32_t)W, n_cols * 32, n_cols, cols_per_chunk, (const niels29*)d_tab, n_cols, d_part);
+      hipLaunchKernelGGL(k_msm_buckets, dim3((unsigned)Kc, (unsigned)rows), dim3(MSM_THREADS), 0, 0, (const uint8_t*)d_sc, 32u, (uint32_t)W, n_cols * 32, n_cols, cols_per_chunk, (const niels29*)d_tab, n_cols, d_part, (uint32_t*)nullptr);
       CK(hipEventRecord(e1));
       hipLaunchKernelGGL(k_points_sum, dim3((unsigned)rows), dim3(MSM_THREADS), 0, 0, (const pt29*)d_part, (uint32_t)Kc, d_out, (uint32_t*)nullptr, d_cnt, (uint32_t*)nullptr, 0u);
       CK(hipEventRecord(e2)); CK(hipEventSynchronize(e2));
@@ -65,7 +65,7 @@ int main(int argc, char** argv) {
       float best = 1e9f; uint64_t clk[32] = {0};
       for (int it = 0; it < 8; it++) {
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL(k_msm_direct<0>, dim3(K, (unsigned)rows), dim3(MSM_THREADS), 0, 0, (const uint32_t*)d_sc, row * 8, (uint32_t)row, ipc, cm, (const niels29*)d_tab, tn, d_part, d_out, d_cnt, (uint32_t*)nullptr, 0u, fr_zero(), fr_zero(), fr_zero());
+        hipLaunchKernelGGL(k_msm_direct<0>, dim3(K, (unsigned)rows), dim3(MSM_THREADS), 0, 0, (const uint32_t*)d_sc, row * 8, (uint32_t)row, ipc, cm, (const niels29*)d_tab, tn, d_part, d_out, d_cnt, (uint32_t*)nullptr, 0u, fr_zero(), fr_zero(), fr_zero(), (uint32_t*)nullptr);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float a; CK(hipEventElapsedTime(&a, e0, e1));
         if (it && a < best) { best = a; CK(hipMemcpyFromSymbol(clk, HIP_SYMBOL(msm_phase_clock), sizeof(clk))); }

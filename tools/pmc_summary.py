@@ -44,8 +44,9 @@ def main(fetch_csv, write_csv, bench_json, out_json, source):
     per proof fall in the bracketed class — the PMC average is taken over the same number of largest dispatches."""
     fetch, write = last_proof(load(fetch_csv)), last_proof(load(write_csv))
     with open(bench_json) as f:
-        large = json.loads(f.read().strip().splitlines()[-1]).get("large_launches_timed", {})
-    out = {}
+        line = json.loads(f.read().strip().splitlines()[-1])
+    large = line.get("large_launches_timed", {})
+    out = {"_workload": line.get("config", {}).get("workload_key", "and_c1_m16_2p24_curve25519")}      # bench.py applies a traffic file only to the workload it was taken on
     for fam, prefixes in FAMILIES.items():
         top = large.get(fam, {}).get("per_step", 0)
         if not top:
@@ -70,6 +71,7 @@ def main(fetch_csv, write_csv, bench_json, out_json, source):
     with open(out_json, "w") as fo:
         json.dump(out, fo, indent=1)
     print(json.dumps(out, indent=1))
+    return out
 
 
 if __name__ == "__main__":
