@@ -170,6 +170,14 @@ int32_t lasso_sumcheck_linear_tail_begin(lasso_ctx* ctx, const lasso_fr* const* 
  * d_polys holds alpha = NUM_MEMORIES device pointers; d_eq is the eq polynomial. */
 int32_t lasso_sumcheck_combine_round(lasso_ctx* ctx, const lasso_strategy* s, const lasso_fr* const* d_polys, const lasso_fr* d_eq,
                                      size_t n, uint32_t degree, lasso_fr* out);
+/* LT strategy, the prover's form of the degree-(C+1) round (lt.rs:62-71 inside sumcheck.rs:179-218).  In Horner form  g = LT_0 + EQ_0 (LT_1 + EQ_1 (... + EQ_{C-2} LT_{C-1}))  a round
+ * costs ONE field product per memory and evaluation point instead of two, provided the factor 2^5 that a product of two in-memory (Montgomery 2^256) operands loses against the kernels'
+ * 2^261 radix is carried by the data: lasso_lt_prescale multiplies polynomial 2m (= LT_m, length n) by 32^-(C-1-m) in place, once, before the first round — binding is linear, so the
+ * arrays stay scaled through every lasso_bind_top — and lasso_sumcheck_combine_round_lt_scaled takes such arrays and returns exactly what lasso_sumcheck_combine_round returns on the
+ * unscaled ones.  After the last bind the caller multiplies the head of polynomial 2m by 32^(C-1-m) to obtain LT_m(r); the EQ polynomials (odd indices) are never touched.
+ * (lasso_sumcheck_combine_round on an LT strategy scales private copies itself: the literal call.) */
+int32_t lasso_lt_prescale(lasso_ctx* ctx, const lasso_strategy* s, lasso_fr* const* d_polys, size_t n);
+int32_t lasso_sumcheck_combine_round_lt_scaled(lasso_ctx* ctx, const lasso_strategy* s, const lasso_fr* const* d_polys, const lasso_fr* d_eq, size_t n, uint32_t degree, lasso_fr* out);
 /* The same round in EQ-WEIGHTED form for the LINEAR strategies (AND / OR / XOR / RangeCheck: g = sum_k w_k E_k, src/subtables/and.rs:45-53) — what the
  * prover calls.  The eq polynomial is factored exactly as in lasso_sumcheck_cubic_eqw_round (prefix of the original table d_E + host scalars), and by
  * linearity of g a round needs per polynomial only  out[3k] = sum_{i<n/2} E_k[i] d_E[i]  and  out[3k+1] = sum_{i<n/2} E_k[i+n/2] d_E[i]  (out[3k+2] unused):
@@ -304,6 +312,24 @@ int32_t lasso_bullet_round(lasso_ctx* ctx, const lasso_bases* bases, size_t n, c
 /* bullet.rs:127-132: a[i] <- a_L[i]*u + u_inv*a_R[i], b[i] <- b_L[i]*u_inv + u*b_R[i] for i < nk/2 (in place), and the
  * generator fold G[i] <- G_L[i]*u_inv + G_R[i]*u recorded as weights: d_w_out[2*blk] = d_w[blk]*u_inv, d_w_out[2*blk+1] = d_w[blk]*u. */
 int32_t lasso_bullet_fold(lasso_ctx* ctx, lasso_fr* d_a, lasso_fr* d_b, size_t nk, const lasso_fr* d_w, size_t nw, lasso_fr* d_w_out, const lasso_fr* u, const lasso_fr* u_inv);
+
+
+/* ---- slab mode of the opening (ONE proof over P GPUs): the generator vector is split by residue class like every other array.
+ * `bases` = lasso_bases_create over [G_{rank}, G_{P+rank}, ..., G_{n-P+rank}, Q, H] — this rank's n/P generators, then the two extra points.  a, b and the fold weights are
+ * sqrt(N)-sized and stay replicated (every rank folds them in full, identically), but the MSMs — the dependent chain of the opening, 12-14 rounds of it — are shared:
+ * each rank adds up only its generators' terms and the host sums the P partial points of a result (the transcript sees the compressed sum: same bytes as one GPU).
+ * No reference counterpart (the reference is single-process: bullet.rs:84-132 folds G and runs its MSMs serially). */
+/* 1 if `bases` carries the digit-multiple table the two calls below need (built for generator sets up to 2^17 when memory allows); the ranks agree on it before using them */
+int32_t lasso_bases_has_direct(const lasso_bases* bases);
+/* lasso_bullet_round with out[0], out[1] = this rank's PARTIAL L and R: the terms of the generators j = rank (mod world); rank 0 alone adds c_L*Q + blinds[0]*H resp.
+ * c_R*Q + blinds[1]*H.  The state (d_a_*, d_b_*, d_w_*: whole vectors, replicated) is read and written exactly as lasso_bullet_round does. */
+int32_t lasso_bullet_round_slab(lasso_ctx* ctx, const lasso_bases* bases, size_t n, uint32_t world, uint32_t rank, const lasso_fr* d_a_in, const lasso_fr* d_b_in, const lasso_fr* d_w_in,
+                                lasso_fr* d_a_out, lasso_fr* d_b_out, lasso_fr* d_w_out, size_t nk, const lasso_fr* u, const lasso_fr* u_inv, const lasso_fr* blinds, lasso_point* out);
+/* out = sum_{jl < n/world} (scale *) d_scalars[jl*world + rank] * bases[jl]  (+ tail[0]*bases[n/world] + tail[1]*bases[n/world + 1]): this rank's share of an MSM over a whole,
+ * replicated scalar vector of length n — Cx = <x, G> (dot_product.rs:183-186) and delta = d*g_hat + r_delta*h (:219-224; rank 0 passes the tail, the others NULL).
+ * scale == NULL: 1.  Returns through the mapped result buffer (lasso_defer_next applies). */
+int32_t lasso_msm_dev_slab(lasso_ctx* ctx, const lasso_bases* bases, const lasso_fr* d_scalars, size_t n, uint32_t world, uint32_t rank, const lasso_fr* scale, const lasso_fr* tail,
+                           lasso_point* out);
 
 #ifdef __cplusplus
 }

@@ -54,6 +54,8 @@ def declare(lib):
         "lasso_sumcheck_cubic_tail_next": (i32, [vp, vp]),
         "lasso_sumcheck_linear_tail_begin": (i32, [vp, P(vp), u32, vp, sz, vp]),
         "lasso_sumcheck_combine_round": (i32, [vp, P(Strategy), P(vp), vp, sz, u32, vp]),
+        "lasso_sumcheck_combine_round_lt_scaled": (i32, [vp, P(Strategy), P(vp), vp, sz, u32, vp]),
+        "lasso_lt_prescale": (i32, [vp, P(Strategy), P(vp), sz]),
         "lasso_sumcheck_linear_eqw_round": (i32, [vp, P(vp), u32, vp, sz, vp]),
         "lasso_sumcheck_linear_eqw_round_fused": (i32, [vp, P(vp), u32, vp, sz, vp, vp]),
         "lasso_sumcheck_linear_eqw_round_fused_from": (i32, [vp, P(vp), P(vp), u32, vp, sz, vp, vp]),
@@ -76,6 +78,9 @@ def declare(lib):
         "lasso_hyrax_commit": (i32, [vp, vp, sz, sz, vp, vp]),
         "lasso_hyrax_commit_compressed": (i32, [vp, vp, sz, sz, vp, vp]),
         "lasso_hyrax_commit_compressed_u32": (i32, [vp, vp, u32, sz, sz, vp, vp]),
+        "lasso_bases_has_direct": (i32, [vp]),
+        "lasso_bullet_round_slab": (i32, [vp, vp, sz, u32, u32, vp, vp, vp, vp, vp, vp, sz, vp, vp, vp, vp]),
+        "lasso_msm_dev_slab": (i32, [vp, vp, vp, sz, u32, u32, vp, vp, vp]),
         "lasso_rccl_available": (i32, []),
         "lasso_rccl_unique_id": (i32, [vp]),
         "lasso_rccl_init": (i32, [vp, i32, i32, vp]),

@@ -28,7 +28,7 @@ static_assert(sizeof(lasso_fr) == 32 && sizeof(fr_t) == 32, "Fr layout");
 static_assert(sizeof(lasso_affine) == 64 && sizeof(lasso_point) == 128 && sizeof(ed_point) == 128 && sizeof(niels29) == 112 && sizeof(pt29) == 144, "curve layouts");
 
 struct EventPair { hipEvent_t a, b; int kid; double bytes, units, units2; bool large; bool counted; };
-#define LASSO_PROF_COUNT_SLOTS 4096   // device counters of exactly executed additions, one per bracketed launch of the fully-profiled step
+#define LASSO_PROF_COUNT_SLOTS 4096   // device counters of exactly executed additions, one group of 64 words per bracketed launch of the fully-profiled step (the waves of a launch spread their atomics over the group)
 struct lasso_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -121,9 +121,9 @@ struct ProfScope {
   // device counter the MSM kernels add their executed mixed additions to; NULL (no counting, no cost) unless every launch is being bracketed
   uint32_t* counter() {
     if (idx < 0 || idx >= LASSO_PROF_COUNT_SLOTS || (c->prof_mask & 0x40000000u)) return nullptr;
-    if (!c->d_prof_counts) { if (hipMalloc((void**)&c->d_prof_counts, LASSO_PROF_COUNT_SLOTS * 4) != hipSuccess || hipMemset(c->d_prof_counts, 0, LASSO_PROF_COUNT_SLOTS * 4) != hipSuccess) { (void)hipGetLastError(); c->d_prof_counts = nullptr; return nullptr; } }
+    if (!c->d_prof_counts) { if (hipMalloc((void**)&c->d_prof_counts, LASSO_PROF_COUNT_SLOTS * 256) != hipSuccess || hipMemset(c->d_prof_counts, 0, LASSO_PROF_COUNT_SLOTS * 256) != hipSuccess) { (void)hipGetLastError(); c->d_prof_counts = nullptr; return nullptr; } }
     c->events[idx].counted = true;
-    return c->d_prof_counts + idx;
+    return c->d_prof_counts + (size_t)idx * 64;
   }
 };
 static void prof_flush(lasso_ctx* c) {
@@ -132,8 +132,9 @@ static void prof_flush(lasso_ctx* c) {
   std::vector<uint32_t> counts;
   if (c->d_prof_counts) {
     const size_t m = c->events_used < LASSO_PROF_COUNT_SLOTS ? c->events_used : LASSO_PROF_COUNT_SLOTS;
-    counts.resize(m);
-    if (hipMemcpy(counts.data(), c->d_prof_counts, m * 4, hipMemcpyDeviceToHost) != hipSuccess || hipMemset(c->d_prof_counts, 0, m * 4) != hipSuccess) { (void)hipGetLastError(); counts.clear(); }
+    std::vector<uint32_t> raw(m * 64); counts.assign(m, 0);
+    if (hipMemcpy(raw.data(), c->d_prof_counts, m * 256, hipMemcpyDeviceToHost) != hipSuccess || hipMemset(c->d_prof_counts, 0, m * 256) != hipSuccess) { (void)hipGetLastError(); counts.clear(); }
+    else for (size_t i = 0; i < m; i++) for (size_t k = 0; k < 64; k++) counts[i] += raw[i * 64 + k];
   }
   for (size_t i = 0; i < c->events_used; i++) {
     float ms = 0; if (hipEventElapsedTime(&ms, c->events[i].a, c->events[i].b) != hipSuccess) continue;
@@ -607,29 +608,55 @@ static int32_t make_strategy(lasso_ctx* c, const lasso_strategy* s, StrategyDev&
   return 0;
 }
 #define DISPATCH_A(alpha, FN) do { if ((alpha) <= 2) { FN(2, 2); } else if ((alpha) <= 4) { FN(4, 3); } else if ((alpha) <= 8) { FN(8, 5); } else if ((alpha) <= 16) { FN(16, 9); } else { FN(32, 17); } } while (0)
-int32_t lasso_sumcheck_combine_round(lasso_ctx* c, const lasso_strategy* s, const lasso_fr* const* d_polys, const lasso_fr* d_eq, size_t n, uint32_t degree, lasso_fr* out) {
+// the LT round kernel: (bound on NUM_MEMORIES, bound on the degree, lanes per index) — at most 6 evaluation points per lane
+#define DISPATCH_LT(alpha, FN) do { if ((alpha) <= 2) { FN(2, 2, 1); } else if ((alpha) <= 4) { FN(4, 3, 1); } else if ((alpha) <= 8) { FN(8, 5, 1); } else if ((alpha) <= 16) { FN(16, 9, 2); } else { FN(32, 17, 3); } } while (0)
+static fr_t lt_pow32(uint32_t e, bool inverse) { static const fr_t inv32 = fr_inv(fr_from_u64(32)); const fr_t b = inverse ? inv32 : fr_from_u64(32); fr_t r = fr_one(); for (uint32_t i = 0; i < e; i++) r = fr_mul(r, b); return r; }
+// LT: the round kernel works on arrays whose LT memories carry the factor 32^-(C-1-m) (k_combine_round_lt).  lasso_sumcheck_combine_round keeps the literal contract (plain arrays in,
+// sumcheck.rs:165-237's evaluations out): it scales COPIES of the C LT arrays first; the prover scales its work arrays once (lasso_lt_prescale) and calls the _lt_scaled form every round.
+static int32_t combine_round_impl(lasso_ctx* c, const lasso_strategy* s, const lasso_fr* const* d_polys, const lasso_fr* d_eq, size_t n, uint32_t degree, lasso_fr* out, bool lt_scaled) {
   StrategyDev S; WeightTable W; int32_t rc = make_strategy(c, s, S, W); if (rc) return rc;
   REQUIRE(c, d_polys && d_eq && out && n >= 2 && (n & (n - 1)) == 0);
   REQUIRE(c, degree == (s->kind == LASSO_LT ? s->c + 1 : 2));   // sumcheck_poly_degree(): subtables/mod.rs:60-62
   PtrTable P; for (uint32_t i = 0; i < S.alpha; i++) { REQUIRE(c, d_polys[i]); P.p[i] = (const fr_t*)d_polys[i]; }
   const size_t half = n / 2; const unsigned nx = grid_for(half, 1024); const uint32_t K = degree + 1;
-  rc = ensure_scratch(c, (size_t)nx * K * sizeof(fr_t)); if (rc) return rc;
+  const bool lt = s->kind == LASSO_LT;
+  const size_t copy_elems = lt && !lt_scaled && S.c > 1 ? (size_t)(S.c - 1) * n : 0;
+  rc = ensure_scratch(c, ((size_t)nx * K + copy_elems) * sizeof(fr_t)); if (rc) return rc;
   rc = ensure_small(c, K); if (rc) return rc;
+  if (copy_elems) {   // literal form: scaled copies of LT_0 .. LT_{C-2} behind the partials (LT_{C-1} has kappa = 1)
+    fr_t* cp = (fr_t*)c->d_scratch + (size_t)nx * K; MutPtrTable M; LtKappa LK;
+    for (uint32_t m = 0; m + 1 < S.c; m++) { HIPCHK(c, hipMemcpyAsync(cp + (size_t)m * n, d_polys[2 * m], n * sizeof(fr_t), hipMemcpyDeviceToDevice, c->stream)); M.p[2 * m] = cp + (size_t)m * n; P.p[2 * m] = cp + (size_t)m * n; LK.k[m] = lt_pow32(S.c - 1 - m, true); }
+    hipLaunchKernelGGL(k_lt_prescale, dim3(grid_for(n, 1024), S.c - 1), dim3(LASSO_BLOCK), 0, c->stream, M, LK, n);
+  }
   {
     ProfScope ps(c, LASSO_K_COMBINE, 32.0 * n * (S.alpha + 1.0));
-    if (s->kind != LASSO_LT) hipLaunchKernelGGL(k_combine_round_linear, dim3(nx), dim3(LASSO_BLOCK), 0, c->stream, S, P, (const fr_t*)d_eq, W, half, (fr_t*)c->d_scratch);
+    if (!lt) hipLaunchKernelGGL(k_combine_round_linear, dim3(nx), dim3(LASSO_BLOCK), 0, c->stream, S, P, (const fr_t*)d_eq, W, half, (fr_t*)c->d_scratch);
     else {
-      // Horner form: LT_m is pre-multiplied by kappa_m = 32^-(C-1-m) and the block sums by 32^C (k_combine_round_lt explains the radix bookkeeping)
-      LtScale LK; { static const fr_t inv32 = fr_inv(fr_from_u64(32)); const fr_t t32 = fr_from_u64(32); fr_t k = fr_one(), sc = fr_one();
-                    for (uint32_t m = S.c; m-- > 0;) { LK.kappa[m] = k; k = fr_mul(k, inv32); } for (uint32_t m = 0; m < S.c; m++) sc = fr_mul(sc, t32); LK.scale = sc;
-                    for (uint32_t m = S.c; m < LASSO_MAX_ALPHA / 2; m++) LK.kappa[m] = fr_zero(); }
-#define LAUNCH_COMBINE(A_, D_) hipLaunchKernelGGL((k_combine_round_lt<A_, D_>), dim3(nx), dim3(LASSO_BLOCK), 0, c->stream, S, P, (const fr_t*)d_eq, LK, half, degree, (fr_t*)c->d_scratch)
-      DISPATCH_A(S.alpha, LAUNCH_COMBINE);
+      const fr_t scale = lt_pow32(S.c, false);
+#define LAUNCH_COMBINE(A_, D_, T_) hipLaunchKernelGGL((k_combine_round_lt<A_, D_, T_>), dim3(nx), dim3(LASSO_BLOCK), 0, c->stream, S, P, (const fr_t*)d_eq, scale, half, degree, (fr_t*)c->d_scratch)
+      DISPATCH_LT(S.alpha, LAUNCH_COMBINE);
     }
     hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(LASSO_BLOCK), 0, c->stream, (const fr_t*)c->d_scratch, nx, K, c->d_small);
   }
   HIPCHK(c, hipGetLastError());
   return fetch_small(c, K, out);
+}
+int32_t lasso_sumcheck_combine_round(lasso_ctx* c, const lasso_strategy* s, const lasso_fr* const* d_polys, const lasso_fr* d_eq, size_t n, uint32_t degree, lasso_fr* out) {
+  return combine_round_impl(c, s, d_polys, d_eq, n, degree, out, false);
+}
+int32_t lasso_sumcheck_combine_round_lt_scaled(lasso_ctx* c, const lasso_strategy* s, const lasso_fr* const* d_polys, const lasso_fr* d_eq, size_t n, uint32_t degree, lasso_fr* out) {
+  REQUIRE(c, s && s->kind == LASSO_LT);
+  return combine_round_impl(c, s, d_polys, d_eq, n, degree, out, true);
+}
+int32_t lasso_lt_prescale(lasso_ctx* c, const lasso_strategy* s, lasso_fr* const* d_polys, size_t n) {
+  StrategyDev S; WeightTable W; int32_t rc = make_strategy(c, s, S, W); if (rc) return rc;
+  REQUIRE(c, s->kind == LASSO_LT && d_polys && n >= 1);
+  if (S.c < 2) return 0;
+  MutPtrTable M; LtKappa LK;
+  for (uint32_t m = 0; m + 1 < S.c; m++) { REQUIRE(c, d_polys[2 * m]); M.p[2 * m] = (fr_t*)d_polys[2 * m]; LK.k[m] = lt_pow32(S.c - 1 - m, true); }
+  ProfScope ps(c, LASSO_K_MISC, 64.0 * n * (S.c - 1));
+  hipLaunchKernelGGL(k_lt_prescale, dim3(grid_for(n, 1024), S.c - 1), dim3(LASSO_BLOCK), 0, c->stream, M, LK, n);
+  HIPCHK(c, hipGetLastError()); return 0;
 }
 int32_t lasso_combine_claim(lasso_ctx* c, const lasso_strategy* s, const lasso_fr* const* d_polys, const lasso_fr* d_eq, size_t n, lasso_fr* out) {
   StrategyDev S; WeightTable W; int32_t rc = make_strategy(c, s, S, W); if (rc) return rc;
@@ -914,14 +941,14 @@ static size_t msm_pts_bytes(size_t rows, size_t n_cols) {
 // mode 0: d_scal = canonical integers; 1: field elements in memory (Montgomery) form, converted by the kernel; 2: as 1 with the first n_cols - 2 columns
 // multiplied by *scale and the last two columns = tail[0], tail[1] (k_msm_direct<MODE>)
 static int32_t run_msm_direct(lasso_ctx* c, const uint8_t* d_scal, size_t row_stride, size_t rows, size_t n_cols, const MsmColMap& cm, const lasso_bases* b, uint8_t* scratch_after, lasso_point* out,
-                              int mode = 0, const lasso_fr* scale = nullptr, const lasso_fr* tail = nullptr) {
+                              int mode = 0, const lasso_fr* scale = nullptr, const lasso_fr* tail = nullptr, uint32_t sstride = 1, uint32_t soffset = 0) {
   uint32_t ipc = 0; const size_t K = msm_direct_chunks(rows, n_cols, &ipc);
   const uint32_t seq = ++c->seq;
   {
     ProfScope ps(c, LASSO_K_MSM_DIRECT, (double)rows * n_cols * 32, msm_ref_adds(rows, n_cols, FR_MODULUS_BITS), false, (double)rows * n_cols * MSM_WINDOWS);
     const fr_t z = fr_zero();
 #define LAUNCH_DIRECT(M, SC, T0, T1) hipLaunchKernelGGL(k_msm_direct<M>, dim3((unsigned)K, (unsigned)rows), dim3(MSM_THREADS), 0, c->stream, (const uint32_t*)d_scal, row_stride / 4, (uint32_t)n_cols, ipc, cm, \
-                       (const niels29*)b->d_mult, b->n, (pt29*)scratch_after, (ed_point*)c->d_small, c->d_counters + LASSO_MAX_PTRS + 8, c->d_flag, seq, SC, T0, T1, ps.counter())
+                       (const niels29*)b->d_mult, b->n, (pt29*)scratch_after, (ed_point*)c->d_small, c->d_counters + LASSO_MAX_PTRS + 8, c->d_flag, seq, SC, T0, T1, ps.counter(), sstride, soffset)
     if (mode == 0) LAUNCH_DIRECT(0, z, z, z);
     else if (mode == 1) LAUNCH_DIRECT(1, z, z, z);
     else LAUNCH_DIRECT(2, to_fr(scale), to_fr(tail), to_fr(tail + 1));
@@ -1082,35 +1109,62 @@ int32_t lasso_bullet_lr(lasso_ctx* c, const lasso_bases* b, size_t n, const lass
   hipLaunchKernelGGL(k_bullet_expand, dim3(grid_for(n)), dim3(256), 0, c->stream, (const fr_t*)d_a, nk, (const fr_t*)d_w, n, to_fr(tail), to_fr(tail + 1), to_fr(tail + 2), to_fr(tail + 3), SL, SR);
   return run_msm(c, (const uint8_t*)SL, 32, MSM_WINDOWS, row * 32, 2, row, b, (uint8_t*)(SR + row), out);
 }
+// fold + scalars + both MSMs in one launch (k_bullet_msm): K chunk workgroups per row over the row's local columns, plus one per row for a', b', the inner product and c*Q + blind*H.
+// world / rank: slab mode (the table `b` holds the rank's n / world generators, then Q, H; the result is the rank's PARTIAL L, R).
+static int32_t bullet_round_fused(lasso_ctx* c, const lasso_bases* b, size_t n, const lasso_fr* d_a_in, const lasso_fr* d_b_in, const lasso_fr* d_w_in, lasso_fr* d_a_out, lasso_fr* d_b_out,
+                                  lasso_fr* d_w_out, size_t nk, const lasso_fr* u, const lasso_fr* u_inv, const lasso_fr* blinds, lasso_point* out, uint32_t world, uint32_t rank) {
+  const bool fold = u != nullptr;
+  // chunks per row: (workgroups of the launch - 2 extra) / 2 rows, items shared out evenly (a multiple of 64 keeps whole columns together where it can)
+  static const size_t wgs = [] { const char* v = getenv("LASSO_MSM_DIRECT_WGS"); const long x = v ? atol(v) : 0; return (size_t)(x >= 4 && x <= 4096 ? x : 256); }();
+  const size_t n_loc = n / world, cols = (nk / 2 >= world) ? n_loc / 2 : n_loc;   // the longest row's local columns
+  const size_t total = cols * MSM_WINDOWS, kmax = (wgs - 2) / 2;
+  size_t ipc_ = (total + kmax - 1) / kmax; ipc_ = (ipc_ + 63) / 64 * 64; if (ipc_ < 256) ipc_ = 256; if (ipc_ > 8192) ipc_ = 8192;
+  const uint32_t ipc = (uint32_t)ipc_; const size_t K = (total + ipc_ - 1) / ipc_;
+  int32_t rc = ensure_scratch(c, 2 * (K + 1) * sizeof(pt29) + 512); if (rc) return rc;
+  const uint32_t seq = ++c->seq;
+  {
+    const size_t row = n_loc / 2 + 2;
+    ProfScope ps(c, LASSO_K_MSM_DIRECT, 2.0 * row * 32 + (fold ? 96.0 * 2 * nk : 64.0 * nk), msm_ref_adds(2, row, FR_MODULUS_BITS), false, 2.0 * row * MSM_WINDOWS);
+    const fr_t z = fr_zero();
+    if (fold) hipLaunchKernelGGL((k_bullet_msm<true>), dim3((unsigned)K + 1, 2), dim3(MSM_THREADS), 0, c->stream, (const fr_t*)d_a_in, (const fr_t*)d_b_in, (const fr_t*)d_w_in, (fr_t*)d_a_out, (fr_t*)d_b_out,
+                                 (fr_t*)d_w_out, (uint32_t)nk, (uint32_t)n, to_fr(u), to_fr(u_inv), to_fr(blinds), to_fr(blinds + 1), ipc, (const niels29*)b->d_mult, b->n, (pt29*)c->d_scratch,
+                                 (ed_point*)c->d_small, c->d_counters + LASSO_MAX_PTRS + 8, c->d_flag, seq, ps.counter(), world, rank);
+    else hipLaunchKernelGGL((k_bullet_msm<false>), dim3((unsigned)K + 1, 2), dim3(MSM_THREADS), 0, c->stream, (const fr_t*)d_a_in, (const fr_t*)d_b_in, (const fr_t*)d_w_in, (fr_t*)nullptr, (fr_t*)nullptr,
+                            (fr_t*)nullptr, (uint32_t)nk, (uint32_t)n, z, z, to_fr(blinds), to_fr(blinds + 1), ipc, (const niels29*)b->d_mult, b->n, (pt29*)c->d_scratch,
+                            (ed_point*)c->d_small, c->d_counters + LASSO_MAX_PTRS + 8, c->d_flag, seq, ps.counter(), world, rank);
+  }
+  HIPCHK(c, hipGetLastError());
+  return wait_flag(c, seq, 2 * (sizeof(ed_point) / sizeof(fr_t)), (lasso_fr*)out);
+}
+// slab mode of the opening (include/lasso_hip.h): this rank's share of L and R over its residue class of the generators
+int32_t lasso_bullet_round_slab(lasso_ctx* c, const lasso_bases* b, size_t n, uint32_t world, uint32_t rank, const lasso_fr* d_a_in, const lasso_fr* d_b_in, const lasso_fr* d_w_in, lasso_fr* d_a_out,
+                                lasso_fr* d_b_out, lasso_fr* d_w_out, size_t nk, const lasso_fr* u, const lasso_fr* u_inv, const lasso_fr* blinds, lasso_point* out) {
+  REQUIRE(c, b && d_a_in && d_b_in && d_w_in && blinds && out && n >= 2 && (n & (n - 1)) == 0 && nk >= 2 && nk <= n && (nk & (nk - 1)) == 0);
+  REQUIRE(c, world >= 1 && (world & (world - 1)) == 0 && rank < world && world <= n && n / world + 2 <= b->n);
+  if (u) REQUIRE(c, u_inv && d_a_out && d_b_out && d_w_out && 2 * nk <= n && d_a_out != d_a_in && d_b_out != d_b_in && d_w_out != d_w_in);
+  if (!b->d_mult) return fail(c, LASSO_ERR_UNSUPPORTED, "lasso_bullet_round_slab needs the digit-multiple table of the bases (lasso_bases_has_direct)");
+  return bullet_round_fused(c, b, n, d_a_in, d_b_in, d_w_in, d_a_out, d_b_out, d_w_out, nk, u, u_inv, blinds, out, world, rank);
+}
+// out = sum_{jl < n/world} (scale *) d_scalars[jl * world + rank] * bases[jl]  (+ tail[0] * bases[n/world] + tail[1] * bases[n/world + 1]): the rank's share of an MSM over the
+// whole replicated scalar vector — Cx = <x, G> and delta = d * g_hat + r_delta * h of the opening (dot_product.rs:183-186, :219-224).  scale / tail may be NULL (1 / no extra terms).
+int32_t lasso_msm_dev_slab(lasso_ctx* c, const lasso_bases* b, const lasso_fr* d_scalars, size_t n, uint32_t world, uint32_t rank, const lasso_fr* scale, const lasso_fr* tail, lasso_point* out) {
+  REQUIRE(c, b && d_scalars && out && n >= 1 && world >= 1 && (world & (world - 1)) == 0 && rank < world && n % world == 0 && n / world + 2 <= b->n);
+  if (!b->d_mult) return fail(c, LASSO_ERR_UNSUPPORTED, "lasso_msm_dev_slab needs the digit-multiple table of the bases (lasso_bases_has_direct)");
+  const size_t nl = n / world, row = nl + 2;
+  int32_t rc = ensure_scratch(c, msm_pts_bytes(1, row) + 512); if (rc) return rc;
+  const lasso_fr one = [] { lasso_fr o; const fr_t r = fr_one(); memcpy(&o, r.v, 32); return o; }();
+  const lasso_fr zeros[2] = {{{0, 0, 0, 0}}, {{0, 0, 0, 0}}};
+  const MsmColMap id = {0, 0, 0, 0};
+  return run_msm_direct(c, (const uint8_t*)d_scalars, 0, 1, row, id, b, (uint8_t*)c->d_scratch, out, 2, scale ? scale : &one, tail ? tail : zeros, world, rank);
+}
+int32_t lasso_bases_has_direct(const lasso_bases* b) { return b && b->d_mult ? 1 : 0; }
 int32_t lasso_bullet_round(lasso_ctx* c, const lasso_bases* b, size_t n, const lasso_fr* d_a_in, const lasso_fr* d_b_in, const lasso_fr* d_w_in, lasso_fr* d_a_out, lasso_fr* d_b_out,
                            lasso_fr* d_w_out, size_t nk, const lasso_fr* u, const lasso_fr* u_inv, const lasso_fr* blinds, lasso_point* out) {
   REQUIRE(c, b && d_a_in && d_b_in && d_w_in && blinds && out && n >= 2 && (n & (n - 1)) == 0 && nk >= 2 && nk <= n && (nk & (nk - 1)) == 0 && n + 2 <= b->n);
   const bool fold = u != nullptr;
   if (fold) REQUIRE(c, u_inv && d_a_out && d_b_out && d_w_out && 2 * nk <= n && d_a_out != d_a_in && d_b_out != d_b_in && d_w_out != d_w_in);
   const bool direct = b->d_mult && msm_direct_enabled();
-  if (direct && msm_direct_fused()) {
-    // fold + scalars + both MSMs in one launch (k_bullet_msm): K chunk workgroups per row over the n/2 columns, plus one per row for a', b', the inner product and c*Q + blind*H
-    // chunks per row: (workgroups of the launch - 2 extra) / 2 rows, items shared out evenly (a multiple of 64 keeps whole columns together where it can)
-    static const size_t wgs = [] { const char* v = getenv("LASSO_MSM_DIRECT_WGS"); const long x = v ? atol(v) : 0; return (size_t)(x >= 4 && x <= 4096 ? x : 256); }();
-    const size_t total = (n / 2) * MSM_WINDOWS, kmax = (wgs - 2) / 2;
-    size_t ipc_ = (total + kmax - 1) / kmax; ipc_ = (ipc_ + 63) / 64 * 64; if (ipc_ < 256) ipc_ = 256; if (ipc_ > 8192) ipc_ = 8192;
-    const uint32_t ipc = (uint32_t)ipc_; const size_t K = (total + ipc_ - 1) / ipc_;
-    int32_t rc = ensure_scratch(c, 2 * (K + 1) * sizeof(pt29) + 512); if (rc) return rc;
-    const uint32_t seq = ++c->seq;
-    {
-      const size_t row = n / 2 + 2;
-      ProfScope ps(c, LASSO_K_MSM_DIRECT, 2.0 * row * 32 + (fold ? 96.0 * 2 * nk : 64.0 * nk), msm_ref_adds(2, row, FR_MODULUS_BITS), false, 2.0 * row * MSM_WINDOWS);
-      const fr_t z = fr_zero();
-      if (fold) hipLaunchKernelGGL((k_bullet_msm<true>), dim3((unsigned)K + 1, 2), dim3(MSM_THREADS), 0, c->stream, (const fr_t*)d_a_in, (const fr_t*)d_b_in, (const fr_t*)d_w_in, (fr_t*)d_a_out, (fr_t*)d_b_out,
-                                   (fr_t*)d_w_out, (uint32_t)nk, (uint32_t)n, to_fr(u), to_fr(u_inv), to_fr(blinds), to_fr(blinds + 1), ipc, (const niels29*)b->d_mult, b->n, (pt29*)c->d_scratch,
-                                   (ed_point*)c->d_small, c->d_counters + LASSO_MAX_PTRS + 8, c->d_flag, seq, ps.counter());
-      else hipLaunchKernelGGL((k_bullet_msm<false>), dim3((unsigned)K + 1, 2), dim3(MSM_THREADS), 0, c->stream, (const fr_t*)d_a_in, (const fr_t*)d_b_in, (const fr_t*)d_w_in, (fr_t*)nullptr, (fr_t*)nullptr,
-                              (fr_t*)nullptr, (uint32_t)nk, (uint32_t)n, z, z, to_fr(blinds), to_fr(blinds + 1), ipc, (const niels29*)b->d_mult, b->n, (pt29*)c->d_scratch,
-                              (ed_point*)c->d_small, c->d_counters + LASSO_MAX_PTRS + 8, c->d_flag, seq, ps.counter());
-    }
-    HIPCHK(c, hipGetLastError());
-    return wait_flag(c, seq, 2 * (sizeof(ed_point) / sizeof(fr_t)), (lasso_fr*)out);
-  }
+  if (direct && msm_direct_fused()) return bullet_round_fused(c, b, n, d_a_in, d_b_in, d_w_in, d_a_out, d_b_out, d_w_out, nk, u, u_inv, blinds, out, 1, 0);
   const size_t row = direct ? n / 2 + 2 : n + 2;   // compact rows for k_msm_direct: only the non-zero half
   const unsigned nx = grid_for(n / 2, 64);
   int32_t rc = ensure_scratch(c, 2 * row * 32 + (size_t)nx * 2 * sizeof(fr_t) + msm_pts_bytes(2, row)); if (rc) return rc;

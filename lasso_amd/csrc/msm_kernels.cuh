@@ -86,7 +86,8 @@ __device__ uint64_t msm_phase_clock[32];
 __device__ __forceinline__ void msm_count_adds(uint32_t* digit_count, uint32_t mine) {
   if (!digit_count) return;
   for (int off = 32; off > 0; off >>= 1) mine += (uint32_t)__shfl_down(mine, off, 64);
-  if ((threadIdx.x & 63u) == 0 && mine) atomicAdd(digit_count, mine);
+  // one atomic per wave, spread over the 64 slots of the launch's counter: a thousand waves adding to ONE address cost the opening MSM 40 us
+  if ((threadIdx.x & 63u) == 0 && mine) atomicAdd(digit_count + ((blockIdx.x * 4u + (threadIdx.x >> 6) + blockIdx.y * 17u) & 63u), mine);
 }
 __device__ __forceinline__ uint32_t msm_nibble(const uint8_t* s, uint32_t w) { return (reinterpret_cast<const uint32_t*>(s)[w >> 3] >> (4 * (w & 7))) & 15u; }
 __global__ void __launch_bounds__(MSM_THREADS) k_msm_buckets(const uint8_t* __restrict__ scal, uint32_t bps, uint32_t W, size_t row_stride, size_t n_cols, size_t cols_per_chunk,
@@ -126,7 +127,7 @@ __global__ void __launch_bounds__(MSM_THREADS) k_msm_buckets(const uint8_t* __re
       const uint32_t d = msm_nibble(row + c * bps, w);
       if (d) sorted[atomicAdd(&cursor[(d << 4) | ((uint32_t)c & 15u)], 1u)] = (uint32_t)(w * table_stride + c);
     }
-    if (digit_count && t == 0 && start[MSM_THREADS - 1]) atomicAdd(digit_count, start[MSM_THREADS - 1]);   // non-zero digits of this batch = additions issued for it
+    if (digit_count && t == 0 && start[MSM_THREADS - 1]) atomicAdd(digit_count + ((blockIdx.x + blockIdx.y * 17u) & 63u), start[MSM_THREADS - 1]);   // non-zero digits of this batch = additions issued for it
     if (b0 == c0) {
       // share the threads out over digits 1..15 from the first batch's histogram (later batches of the same row have the same statistics);
       // every digit keeps at least one thread, so no pair of a later batch can be orphaned
@@ -392,8 +393,9 @@ __device__ __forceinline__ void msm_recode(const uint32_t* s, uint32_t* dst) {
   for (int k = 0; k < 8; k++) { const uint64_t x = (uint64_t)s[k] + 0x88888888ull + carry; dst[k] = (uint32_t)x; carry = x >> 32; }
 }
 // items [it0, it1) of a row (one item = one (column, window); sb holds the recoded scalars of columns col0..): one mixed addition per non-zero digit
+// phys (optional, LDS): table index of every staged column (phys[c - col0]); otherwise the column map decides
 __device__ __forceinline__ pt29 msm_direct_accumulate(const uint32_t* sb, uint32_t col0, uint32_t it0, uint32_t it1, const MsmColMap& cm, uint32_t row, const niels29* __restrict__ mult, size_t tn,
-                                                      uint32_t* digit_count = nullptr) {
+                                                      uint32_t* digit_count = nullptr, const uint32_t* phys = nullptr) {
   const uint32_t t = threadIdx.x;
   pt29 B = pt_identity();
   niels29 cur; bool have = false; uint32_t nadds = 0;
@@ -403,7 +405,7 @@ __device__ __forceinline__ pt29 msm_direct_accumulate(const uint32_t* sb, uint32
     if (valid) { c = it >> 6; w = it & 63u; d = (int32_t)((sb[(c - col0) * 8 + (w >> 3)] >> (4 * (w & 7u))) & 15u) - 8; valid = d != 0; }
     // the fetch is unconditional (entry 0 for a skipped item) so that it is issued BEFORE the mixed add below and waited for after it
     const uint32_t m = d < 0 ? (uint32_t)(-d) : (uint32_t)d;
-    const size_t idx = valid ? ((size_t)w * MSM_MULTS + (m - 1)) * tn + msm_phys_col(cm, row, c) : 0;
+    const size_t idx = valid ? ((size_t)w * MSM_MULTS + (m - 1)) * tn + (phys ? phys[c - col0] : msm_phys_col(cm, row, c)) : 0;
     const niels29 nxt = mult[idx];
     if (have) B = pt_madd(B, cur);
     const bool neg = d < 0;
@@ -469,10 +471,11 @@ __device__ __forceinline__ void msm_direct_finish(pt29* pts, fe29 (*st)[4], uint
 // MODE 0: scal holds canonical little-endian integers.  MODE 1: scal holds field elements in memory (Montgomery) form, converted here — the
 // k_fr_to_canonical pass in front of the opening's Cx = <x, G> saved.  MODE 2: as 1, but columns below n_cols - 2 are multiplied by `scale` first and the
 // last two columns are the scalars tail0, tail1 (delta = d * g_hat + r_delta * h over the resident fold weights, dot_product.rs:219-224).
+// sstride / soffset: column j takes scalar j * sstride + soffset (1, 0 = plain; world, rank = slab mode's share of a whole vector).
 template <int MODE>
 __global__ void __launch_bounds__(MSM_THREADS) k_msm_direct(const uint32_t* __restrict__ scal, size_t row_words, uint32_t n_cols, uint32_t items_per_chunk, MsmColMap cm,
                                                              const niels29* __restrict__ mult, size_t tn, pt29* __restrict__ partial, ed_point* __restrict__ out_mont, uint32_t* counters,
-                                                             uint32_t* flag, uint32_t seq, fr_t scale, fr_t tail0, fr_t tail1, uint32_t* digit_count) {
+                                                             uint32_t* flag, uint32_t seq, fr_t scale, fr_t tail0, fr_t tail1, uint32_t* digit_count, uint32_t sstride, uint32_t soffset) {
   __shared__ pt29 pts[MSM_THREADS];
   __shared__ fe29 st[MSM_THREADS / 4][4];
   __shared__ uint32_t sb[MSM_DIRECT_MAX_COLS * 8];
@@ -484,7 +487,8 @@ __global__ void __launch_bounds__(MSM_THREADS) k_msm_direct(const uint32_t* __re
   const uint32_t col0 = it0 >> 6, col1 = (it1 + 63) >> 6;
   MSM_STAMP(0);
   for (uint32_t c = t; c < col1 - col0; c += MSM_THREADS) {
-    const uint32_t* s = scal + (size_t)row * row_words + (size_t)(col0 + c) * 8;
+    // column j reads scalar j * sstride + soffset (slab mode: this rank's generators are every P-th one, the scalar vector is the whole one)
+    const uint32_t* s = scal + (size_t)row * row_words + ((size_t)(col0 + c) * sstride + soffset) * 8;
     if (MODE == 0) msm_recode(s, &sb[c * 8]);
     else {
       fr_t v;
@@ -648,42 +652,56 @@ __global__ void __launch_bounds__(256) k_bullet_step(const fr_t* __restrict__ a_
 // (a', b' by the two extra workgroups, w' by the row-0 workgroups that own a column with i = 0) is written on the way.
 // grid = (1 + K, 2): the extra workgroup, then K chunks over the n/2 columns x 64 windows of a row; 2 (K + 1) <= the CU count, so that every workgroup has a
 // CU to itself (at 258 workgroups the two that had to wait for a free CU — the extra ones — put 18 us on every round).  FOLD = false: first round, the inputs are the state.
+// SLAB MODE (P > 1: one proof over P GPUs, the generator vector split by residue class like every other array — `mult` is the table of the generators
+// G_{jl * P + rank}, jl < n / P, then Q, H): the rank adds up only ITS generators' share of L and R (the host sums the P partial points), so the per-round MSM —
+// the openings' critical path — shrinks by P.  a, b, w are small and stay replicated: every rank folds them in full, and rank 0 alone adds c * Q + blind * H.
+// Which of a rank's generators feed which row: generator j = blk * nk + pos belongs to L if pos >= half (scalar w_blk a'_L[pos - half]), to R otherwise
+// (w_blk a'_R[pos]).  While half >= P the low bits of pos are the rank, both rows get n / (2 P) local columns and the local picture is the global one with nk / P,
+// half / P; in the last log2 P rounds (half < P) pos = rank mod nk is fixed, so ALL n / P of the rank's generators feed one row and none the other.
 template <bool FOLD>
 __global__ void __launch_bounds__(MSM_THREADS) k_bullet_msm(const fr_t* __restrict__ a_in, const fr_t* __restrict__ b_in, const fr_t* __restrict__ w_in, fr_t* __restrict__ a_out,
                                                              fr_t* __restrict__ b_out, fr_t* __restrict__ w_out, uint32_t nk, uint32_t n, fr_t u, fr_t u_inv, fr_t blind_l, fr_t blind_r,
                                                              uint32_t items_per_chunk, const niels29* __restrict__ mult, size_t tn, pt29* __restrict__ partial, ed_point* __restrict__ out_mont,
-                                                             uint32_t* counters, uint32_t* flag, uint32_t seq, uint32_t* digit_count) {
+                                                             uint32_t* counters, uint32_t* flag, uint32_t seq, uint32_t* digit_count, uint32_t P, uint32_t rank) {
   __shared__ pt29 pts[MSM_THREADS];   // the extra workgroup's reduction scratch (RedScratch, 29.6 KB) lives here before the tree needs it
   __shared__ fe29 st[MSM_THREADS / 4][4];
   __shared__ uint32_t sb[MSM_DIRECT_MAX_COLS * 8];
+  __shared__ uint32_t sphys[MSM_DIRECT_MAX_COLS];
   __shared__ uint32_t is_last;
   static_assert(sizeof(RedScratch) <= sizeof(pt29) * MSM_THREADS, "RedScratch must fit the point buffer");
   const uint32_t t = threadIdx.x, row = blockIdx.y, K = gridDim.x - 1;
-  const uint32_t half = nk / 2, ncols = n / 2;
+  const uint32_t half = nk / 2, n_loc = n / P;
   const fr29 us = fr29_unpack_s(u), uis = fr29_unpack_s(u_inv);
   pt29 B;
   // the extra workgroup is blockIdx.x == 0: dispatched first, because in the early rounds (long a, b) it is the longest of the launch
   if (blockIdx.x > 0) {
+    const bool wide = half >= P;                       // always when P == 1
+    const uint32_t hl = wide ? half / P : 1u, pos0 = rank & (nk - 1u);
+    const uint32_t ncols = wide ? n_loc / 2 : (((pos0 >= half) == (row == 0)) ? n_loc : 0u);   // this row's local columns
     const uint32_t total = ncols * MSM_WINDOWS;
-    const uint32_t it0 = (blockIdx.x - 1) * items_per_chunk;
+    uint32_t it0 = (blockIdx.x - 1) * items_per_chunk; if (it0 > total) it0 = total;
     uint32_t it1 = it0 + items_per_chunk; if (it1 > total) it1 = total;
     const uint32_t col0 = it0 >> 6, col1 = (it1 + 63) >> 6;
     for (uint32_t c = t; c < col1 - col0; c += MSM_THREADS) {
-      const uint32_t g = col0 + c, blk = g / half, i = g - blk * half;
+      const uint32_t g = col0 + c;
+      uint32_t blk, i, jl;   // fold-weight block, index into a'_L / a'_R, index into the (local) generator table
+      if (wide) { blk = g / hl; const uint32_t il = g - blk * hl; i = il * P + rank; jl = blk * (nk / P) + il + (row == 0 ? hl : 0u); }
+      else { jl = g; blk = (g * P + rank) / nk; i = row == 0 ? pos0 - half : pos0; }
       const uint32_t ia = i + (row ? half : 0u);   // row 0 (L) takes a'_L[i], row 1 (R) a'_R[i]
       fr29 av, wv;   // canonical u-form
       if (FOLD) {
         av = fr29_canonical(fr29_add(fr29_mul(fr29_unpack_u(a_in[ia]), us), fr29_mul(fr29_unpack_u(a_in[ia + nk]), uis)));
         wv = fr29_canonical(fr29_mul(fr29_unpack_u(w_in[blk >> 1]), (blk & 1) ? us : uis));
-        if (row == 0 && i == 0) w_out[blk] = fr29_pack(wv);
+        if (P == 1 && row == 0 && i == 0) w_out[blk] = fr29_pack(wv);
       } else { av = fr29_unpack_u(a_in[ia]); wv = fr29_unpack_u(w_in[blk]); }
       // mul(u, u) = wv * a * 2^251; one more Montgomery step with the integer 2^10 gives the canonical integer wv * a
       const fr_t s = fr29_store(fr29_mul(fr29_mul(wv, av), fr29_int_from_uu()));
       msm_recode(s.v, &sb[c * 8]);
+      sphys[c] = jl;
     }
     __syncthreads();
-    const MsmColMap cm = {nk, half, ncols, n};
-    B = msm_direct_accumulate(sb, col0, it0, it1, cm, row, mult, tn, digit_count);
+    const MsmColMap id = {0, 0, 0, 0};
+    B = msm_direct_accumulate(sb, col0, it0, it1, id, row, mult, tn, digit_count, sphys);
   } else {
     RedScratch& S = *reinterpret_cast<RedScratch*>(pts);
     fr29 acc[3] = {fr29_zero(), fr29_zero(), fr29_zero()}; uint32_t cnt = 0;
@@ -698,6 +716,9 @@ __global__ void __launch_bounds__(MSM_THREADS) k_bullet_msm(const fr_t* __restri
       acc[0] = fr29_weak(fr29_add(acc[0], fr29_mul(x, y)));   // u * u products are 2^5 short: the 2^10 below covers it
       if ((++cnt & 127u) == 0) acc[0] = fr29_mul(acc[0], fr29_one_s());
     }
+    if (FOLD && P > 1) {   // slab mode: no rank owns a column of every block, so the fold weights w' (n / nk of them, replicated) are written here — even blocks by row 0, odd by row 1
+      for (uint32_t blk = 2 * t + row; blk < n / nk; blk += 2 * MSM_THREADS) w_out[blk] = fr29_store(fr29_mul(fr29_unpack_u(w_in[blk >> 1]), (blk & 1) ? us : uis));
+    }
     block_columns<3>(acc, S);
     if (t == 0) {
       int64_t c[9];
@@ -709,7 +730,8 @@ __global__ void __launch_bounds__(MSM_THREADS) k_bullet_msm(const fr_t* __restri
     }
     __syncthreads();   // S (aliasing pts) is dead from here on
     const MsmColMap id = {0, 0, 0, 0};
-    B = msm_direct_accumulate(sb, 0, 0, 2 * MSM_WINDOWS, id, row, mult + n, tn, digit_count);   // columns n (Q) and n + 1 (H) of the table
+    // columns n_loc (Q) and n_loc + 1 (H) of the table; in slab mode rank 0 alone adds them
+    B = msm_direct_accumulate(sb, 0, 0, rank == 0 ? 2 * MSM_WINDOWS : 0u, id, row, mult + n_loc, tn, digit_count);
   }
   msm_direct_finish(pts, st, &is_last, B, K + 1, row, partial, out_mont, counters, flag, seq);
 }

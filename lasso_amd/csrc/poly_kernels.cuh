@@ -637,38 +637,45 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_combine_round_linear(StrategyDe
   }
   store_block_partials<3>(acc, 3, partials + (size_t)blockIdx.x * 3, 5, R);   // (u * s) * u: 2^5 short
 }
-// K3 for LT: degree = C + 1.  A = compile-time bound on NUM_MEMORIES = 2C (dispatch only), D = bound on the degree.
+// K3 for LT: degree = C + 1.  A = compile-time bound on NUM_MEMORIES = 2C (dispatch only), D = bound on the degree, T = lanes that share one index.
 // g(x) eq(x) = e(x) * sum_i LT_i(x) * prod_{j<i} EQ_j(x) at the points x = 0..degree (lt.rs:62-71 inside sumcheck.rs:179-218), every factor linear in x.
 // HORNER FORM (round 3): sum_i LT_i prod_{j<i} EQ_j = LT_0 + EQ_0 (LT_1 + EQ_1 (LT_2 + ... + EQ_{C-2} LT_{C-1})), so walking the memories from the LAST to the
 // first needs ONE product per memory and point — t <- LT_m + EQ_m t — instead of the forward form's two (term = LT_i * run, run = EQ_i * run), and one more per
-// point for the eq weight: C (D + 1) products per index (+ 2 per memory for the scaling below) instead of 2 C (D + 1) — 318 instead of 576 at C = 16 — for the
-// same field elements (EQ_{C-1} enters no term of the sum and is not even loaded).  The memories are STREAMED: per point the thread keeps only t and the running
-// sum over indices — 2 (D + 1) field elements whatever C is — loading one (LT_m, EQ_m) pair of lines at a time and stepping them from point to point by addition.
-// (The first version held all 2C lines and their differences in registers: 4C + D + 1 elements, 738 VGPRs at C = 16 — it spilled, and the degree-17 round of LT
-// C=16 ran at 128 GB/s.)
+// point for the eq weight: C (D + 1) products per index instead of 2 C (D + 1) — 288 instead of 576 at C = 16 — for the same field elements (EQ_{C-1} enters no
+// term of the sum and is not even loaded).  The memories are STREAMED: per point a lane keeps only t and the running sum over indices, loading one (LT_m, EQ_m)
+// pair of lines at a time and stepping them from point to point by addition.
 // Radix and magnitudes.  Horner feeds t back through a product at every step, so the multiplier must be SMALL or t grows geometrically: a line stepped to x = 17
 // is up to 18 values of < p each, and in s-form (x 32) that is 2^261.2 for curve25519 and 2^262.8 for BN254 — above the Montgomery radix 2^261, a growth factor
 // above 1.  Everything therefore stays in u-form (factor 18 p / 2^261 <= 0.11: |t| <= 24 p throughout), and the 2^5 each u * u product comes out short is
-// absorbed into the data instead: with LT_m pre-multiplied by kappa_m = 32^-(C-1-m) (two products per memory and index — the line's two end points — against
-// D + 1 for the walk) the recursion  t_m = kappa_m LT_m + (EQ_m * t_{m+1}) / 32  yields t_0 = T_0 / 32^(C-1), the weighted sum comes out as sum e T_0 / 32^C, and
-// the block partials are multiplied by 32^C once (`scale`).  tests/cpp/test_poly_math_host.cpp drives exactly this code under UBSan with extreme inputs, both curves.
-// The per-point state is spelled out as scalars (LT_REP): as arrays `fr29 sum[D + 1], t[D + 1]` the compiler left them in scratch memory even with every index
-// a constant after unrolling (1312 bytes per lane at D = 17), which is exactly the traffic this kernel exists to avoid.
+// carried by the DATA: the caller has multiplied LT_m by kappa_m = 32^-(C-1-m) once, before the first round (k_lt_prescale; binding is linear, so the arrays stay
+// scaled from round to round), the recursion  t_m = kappa_m LT_m + (EQ_m * t_{m+1}) / 32  then yields t_0 = T_0 / 32^(C-1), the weighted sum comes out as
+// sum e T_0 / 32^C, and the block partials are multiplied by 32^C (`scale`).  tests/cpp/test_poly_math_host.cpp drives this arithmetic under UBSan with extreme inputs.
+// Registers.  With all D + 1 points in one lane the state is 2 (D + 1) field elements = 324 VGPRs at D = 17: the compiler parked half of it in AGPRs (a copy in and out
+// around every use) and spilled the rest, and the kernel ran at 11 cycles per instruction.  So T lanes share an index (adjacent lanes: their loads of the same
+// lines coalesce into one request), each walking PPG = ceil((D + 1) / T) <= 6 consecutive points from its own start x0 = lane * PPG (lt_line_at): 12 state elements,
+// two waves per SIMD, nothing in AGPRs or scratch.
 // indices between two folds of the running sums: a term e * t is below p + |e| |t| / 2^261 <= 3.6 p (18 p * 24 p; BN254's p / 2^261 = 2^-7.4), so 32 of them stay
 // below 2^261 and limb 8 inside the loose bound 2^30 that the fold's product requires
 #define LT_FOLD_EVERY() 32u
-struct LtScale { fr_t kappa[LASSO_MAX_ALPHA / 2]; fr_t scale; };   // kappa[m] = 32^-(C-1-m), scale = 32^C, memory (Montgomery) form
-#define LT_REP(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15) M(16) M(17)
+#define LT_REP(M) M(0) M(1) M(2) M(3) M(4) M(5)
 #define LT_DECL(k) fr29 sum##k = fr29_zero(), t##k = fr29_zero();
-#define LT_TOP(k) if constexpr (k <= D) { if ((uint32_t)k <= degree) { t##k = lt; lt = lt_line_step(lt, dlt); } }
-#define LT_STEP(k) if constexpr (k <= D) { if ((uint32_t)k <= degree) { t##k = lt_horner_step(lt, eqv, t##k); lt = lt_line_step(lt, dlt); eqv = lt_line_step(eqv, deq); } }
-#define LT_ACC(k) if constexpr (k <= D) { if ((uint32_t)k <= degree) { sum##k = lt_weighted_acc(sum##k, ecur, t##k); ecur = lt_line_step(ecur, edif); } }
-#define LT_FOLD(k) if constexpr (k <= D) sum##k = fr29_mul(sum##k, fr29_one_s());
-#define LT_OUT(k) if constexpr (k <= D) res[k] = fr29_mul(sum##k, sc);
+#define LT_TOP(k) if constexpr (k < PPG) { if (x0 + k <= degree) { t##k = lt; lt = lt_line_step(lt, dlt); } }
+#define LT_STEP(k) if constexpr (k < PPG) { if (x0 + k <= degree) { t##k = lt_horner_step(lt, eqv, t##k); lt = lt_line_step(lt, dlt); eqv = lt_line_step(eqv, deq); } }
+#define LT_ACC(k) if constexpr (k < PPG) { if (x0 + k <= degree) { sum##k = lt_weighted_acc(sum##k, ecur, t##k); ecur = lt_line_step(ecur, edif); } }
+#define LT_FOLD(k) if constexpr (k < PPG) sum##k = fr29_mul(sum##k, fr29_one_s());
+#define LT_OUT(k) if constexpr (k < PPG) mine[k] = fr29_mul(sum##k, sc);
 // the per-point operations of the LT round (extracted verbatim by tests/test_host_arith_cpp.py and driven under UBSan): a line stepped to the next evaluation
-// point; one Horner step t <- LT + (EQ * t) (u-form operands: the product is 2^5 short, see above); the eq-weighted accumulation sum += e * t
+// point; a line started at point x0 (lo reduced, d a difference of reduced values, x0 <= 17); one Horner step t <- LT + (EQ * t) (u-form operands: the product is
+// 2^5 short, see above); the eq-weighted accumulation sum += e * t
 __device__ __forceinline__ fr29 lt_line_step(const fr29& v, const fr29& d) {
   return fr29_weak(fr29_add(v, d));
+}
+__device__ __forceinline__ fr29 lt_line_at(const fr29& lo, const fr29& d, uint32_t x0) {
+  fr29 r; int64_t c = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) { const int64_t x = (int64_t)lo.v[k] + (int64_t)x0 * d.v[k] + c; r.v[k] = (int32_t)(x & FR29_MASK); c = x >> 29; }
+  r.v[8] = (int32_t)((int64_t)lo.v[8] + (int64_t)x0 * d.v[8] + c);
+  return r;
 }
 __device__ __forceinline__ fr29 lt_horner_step(const fr29& lt, const fr29& eqv, const fr29& t) {
   return fr29_weak(fr29_add(lt, fr29_mul(eqv, t)));
@@ -676,35 +683,68 @@ __device__ __forceinline__ fr29 lt_horner_step(const fr29& lt, const fr29& eqv, 
 __device__ __forceinline__ fr29 lt_weighted_acc(const fr29& sum, const fr29& e, const fr29& t) {
   return fr29_weak(fr29_add(sum, fr29_mul(e, t)));
 }
-template <int A, int D>
-__global__ void __launch_bounds__(LASSO_BLOCK) k_combine_round_lt(StrategyDev S, PtrTable polys, const fr_t* __restrict__ eq, LtScale K, size_t half, uint32_t degree, fr_t* __restrict__ partials) {
-  static_assert(D <= 17, "LT_REP lists 18 points");
+// LT_m <- 32^-(C-1-m) LT_m for the memories 2m of an LT strategy (kappa in memory form, s-form at use: mul(u, s) = u-form); grid = (blocks over i, C - 1): m = C - 1 has kappa = 1
+struct LtKappa { fr_t k[LASSO_MAX_ALPHA / 2]; };
+__global__ void __launch_bounds__(LASSO_BLOCK) k_lt_prescale(MutPtrTable polys, LtKappa K, size_t n) {
+  const uint32_t m = blockIdx.y; fr_t* __restrict__ z = polys.p[2 * m];
+  const fr29 ks = fr29_unpack_s(K.k[m]);
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) z[i] = fr29_store(fr29_mul(fr29_unpack_u(z[i]), ks));
+}
+template <int A, int D, int T>
+__global__ void __launch_bounds__(LASSO_BLOCK) k_combine_round_lt(StrategyDev S, PtrTable polys, const fr_t* __restrict__ eq, fr_t scale, size_t half, uint32_t degree, fr_t* __restrict__ partials) {
+  constexpr int PPG = (D + 1 + T - 1) / T;
+  constexpr uint32_t SLOTS = LASSO_BLOCK / T;
+  static_assert(PPG <= 6, "LT_REP lists 6 points per lane");
   __shared__ RedScratch R;
+  const uint32_t slot = threadIdx.x / T, pg = threadIdx.x - slot * T, x0 = pg * PPG;
   LT_REP(LT_DECL)
   uint32_t cnt = 0;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x) {
-    {   // innermost term: t(x) = LT_{C-1}(x)  (kappa = 1)
+  if (slot < SLOTS && x0 <= degree)
+  for (size_t i = blockIdx.x * (size_t)SLOTS + slot; i < half; i += (size_t)gridDim.x * SLOTS) {
+    {   // innermost term: t(x) = LT_{C-1}(x)
       const fr_t* __restrict__ pl = polys.p[2 * (S.c - 1)];
-      fr29 lt = fr29_unpack_u(pl[i]); const fr29 dlt = fr29_sub(fr29_unpack_u(pl[i + half]), lt);
+      const fr29 lo = fr29_unpack_u(pl[i]), dlt = fr29_sub(fr29_unpack_u(pl[i + half]), lo);
+      fr29 lt = lt_line_at(lo, dlt, x0);
       LT_REP(LT_TOP)
     }
-    for (uint32_t m = S.c - 1; m-- > 0;) {   // t <- kappa_m LT_m + (EQ_m * t) / 32
+    for (uint32_t m = S.c - 1; m-- > 0;) {   // t <- LT_m + (EQ_m * t) / 32   (LT_m pre-scaled)
       const fr_t* __restrict__ pl = polys.p[2 * m]; const fr_t* __restrict__ pe = polys.p[2 * m + 1];
-      const fr29 ks = fr29_unpack_s(K.kappa[m]);
-      fr29 lt = fr29_mul(fr29_unpack_u(pl[i]), ks), eqv = fr29_unpack_u(pe[i]);
-      const fr29 dlt = fr29_sub(fr29_mul(fr29_unpack_u(pl[i + half]), ks), lt), deq = fr29_sub(fr29_unpack_u(pe[i + half]), eqv);
+      const fr29 lo = fr29_unpack_u(pl[i]), dlt = fr29_sub(fr29_unpack_u(pl[i + half]), lo);
+      const fr29 eo = fr29_unpack_u(pe[i]), deq = fr29_sub(fr29_unpack_u(pe[i + half]), eo);
+      fr29 lt = lt_line_at(lo, dlt, x0), eqv = lt_line_at(eo, deq, x0);
       LT_REP(LT_STEP)
     }
     {   // weight by the eq polynomial's line and accumulate over the indices
-      fr29 ecur = fr29_unpack_u(eq[i]); const fr29 edif = fr29_sub(fr29_unpack_u(eq[i + half]), ecur);
+      const fr29 e0 = fr29_unpack_u(eq[i]), edif = fr29_sub(fr29_unpack_u(eq[i + half]), e0);
+      fr29 ecur = lt_line_at(e0, edif, x0);
       LT_REP(LT_ACC)
     }
     if (++cnt >= LT_FOLD_EVERY()) { cnt = 0; LT_REP(LT_FOLD) }
   }
-  const fr29 sc = fr29_unpack_s(K.scale);   // u-form sums of (value / 32^C) times the s-form of 32^C: u-form of the value
-  fr29 res[D + 1];
+  const fr29 sc = fr29_unpack_s(scale);   // u-form sums of (value / 32^C) times the s-form of 32^C: u-form of the value
+  fr29 mine[6];
+#pragma unroll
+  for (int k = 0; k < 6; k++) mine[k] = fr29_zero();
   LT_REP(LT_OUT)
-  store_block_partials<D + 1>(res, degree + 1, partials + (size_t)blockIdx.x * (degree + 1), 0, R);
+  // block sums, one point group at a time: lanes of group g contribute their PPG sums, everybody else zeros (no register array is indexed by a run-time value)
+#pragma unroll
+  for (int g = 0; g < T; g++) {
+#pragma unroll
+    for (int k0 = 0; k0 < PPG; k0 += 3) {
+      fr29 grp[3];
+#pragma unroll
+      for (int v = 0; v < 3; v++) {
+        grp[v] = fr29_zero();
+        if (k0 + v < PPG) {
+#pragma unroll
+          for (int l = 0; l < 9; l++) grp[v].v[l] = pg == (uint32_t)g ? mine[k0 + v].v[l] : 0;
+        }
+      }
+      block_columns<3>(grp, R);
+      const uint32_t pt = (uint32_t)(g * PPG + k0) + threadIdx.x;
+      if (threadIdx.x < 3 && k0 + (int)threadIdx.x < PPG && pt <= degree) partials[(size_t)blockIdx.x * (degree + 1) + pt] = columns_to_fr(R, threadIdx.x, 0);
+    }
+  }
 }
 #undef LT_REP
 #undef LT_DECL

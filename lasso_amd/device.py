@@ -173,6 +173,15 @@ class Device:
         self._chk(self.lib.lasso_sumcheck_combine_round(self.ctx, C.byref(strategy), self._ptrs(ptrs), C.c_void_p(d_eq), n, degree, _vp(out)))
         return out
 
+    def lt_prescale(self, strategy, ptrs, n):
+        """LT_m <- 32^-(C-1-m) LT_m in place (the form lasso_sumcheck_combine_round_lt_scaled takes)"""
+        self._chk(self.lib.lasso_lt_prescale(self.ctx, C.byref(strategy), self._ptrs(ptrs), n))
+
+    def sumcheck_combine_round_lt_scaled(self, strategy, ptrs, d_eq, n, degree):
+        out = np.empty((degree + 1, 4), dtype=np.uint64)
+        self._chk(self.lib.lasso_sumcheck_combine_round_lt_scaled(self.ctx, C.byref(strategy), self._ptrs(ptrs), C.c_void_p(d_eq), n, degree, _vp(out)))
+        return out
+
     def combine_claim(self, strategy, ptrs, d_eq, n):
         out = np.empty((1, 4), dtype=np.uint64)
         self._chk(self.lib.lasso_combine_claim(self.ctx, C.byref(strategy), self._ptrs(ptrs), C.c_void_p(d_eq), n, _vp(out)))

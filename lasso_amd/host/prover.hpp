@@ -280,7 +280,8 @@ struct GenStream {
 // MultiCommitGens::new(n+1).split_at(n)); the device table holds [G_0..G_{n-1}, Q = G_n, h] so one MSM covers G, Q and h.
 struct PolyCommitmentGens {
   size_t n = 0; Pt Q, h; FixedBase Qmul, hmul; std::vector<lasso_affine> affine; lasso_bases* bases = nullptr; const Dev* dev = nullptr;
-  lasso_bases* bases_slab = nullptr;   // slab mode: the generators G_{j*P + rank}, j < n/P (this rank's columns of every Hyrax row)
+  lasso_bases* bases_slab = nullptr;   // slab mode: the generators G_{j*P + rank}, j < n/P (this rank's columns of every Hyrax row), then Q, h
+  bool slab_open = false;              // slab mode: every rank can run its share of the opening's MSMs (agreed at construction)
   PolyCommitmentGens() {}
   PolyCommitmentGens(const Dev& d, const GenStream& gs, size_t num_vars) : dev(&d) {
     n = (size_t)1 << (num_vars - num_vars / 2);   // right = ell - ell/2 (eq_poly.rs:40-42)
@@ -298,12 +299,20 @@ struct PolyCommitmentGens {
     d.chk(lasso_bases_create(d.ctx, affine.data(), n + 2, &bases), "lasso_bases_create");
     if (d.comm.sharded()) {
       const size_t P = d.comm.world; LASSO_REQUIRE(n >= P);
-      std::vector<lasso_affine> sub(n / P); for (size_t j = 0; j < n / P; j++) sub[j] = affine[j * P + d.comm.rank];
+      // this rank's residue class of the generators, then Q and h: the same table serves the partial row commitments (first n/P entries) and the rank's share of the
+      // opening's MSMs (lasso_bullet_round_slab / lasso_msm_dev_slab, which also need Q and h)
+      std::vector<lasso_affine> sub(n / P + 2); for (size_t j = 0; j < n / P; j++) sub[j] = affine[j * P + d.comm.rank];
+      sub[n / P] = affine[n]; sub[n / P + 1] = affine[n + 1];
       d.chk(lasso_bases_create(d.ctx, sub.data(), sub.size(), &bases_slab), "lasso_bases_create");
+      // the sharded opening is used only if EVERY rank has the table it needs (an allocation that failed on one rank must not split the ranks between two protocols)
+      static const bool off = [] { const char* e = getenv("LASSO_SLAB_OPEN"); return e && e[0] == '0'; }();
+      std::vector<uint8_t> all(P, 0); const uint8_t mine = (!off && lasso_bases_has_direct(bases_slab) == 1) ? 1 : 0;
+      d.comm.allgather(&mine, all.data(), 1);
+      slab_open = true; for (uint8_t v : all) slab_open = slab_open && v;
     }
   }
   PolyCommitmentGens(PolyCommitmentGens&& o) noexcept { *this = std::move(o); }
-  PolyCommitmentGens& operator=(PolyCommitmentGens&& o) noexcept { std::swap(n, o.n); std::swap(Q, o.Q); std::swap(h, o.h); std::swap(Qmul, o.Qmul); std::swap(hmul, o.hmul); affine.swap(o.affine); std::swap(bases, o.bases); std::swap(bases_slab, o.bases_slab); std::swap(dev, o.dev); return *this; }
+  PolyCommitmentGens& operator=(PolyCommitmentGens&& o) noexcept { std::swap(n, o.n); std::swap(Q, o.Q); std::swap(h, o.h); std::swap(Qmul, o.Qmul); std::swap(hmul, o.hmul); affine.swap(o.affine); std::swap(bases, o.bases); std::swap(bases_slab, o.bases_slab); std::swap(slab_open, o.slab_open); std::swap(dev, o.dev); return *this; }
   ~PolyCommitmentGens() { if (bases && dev) lasso_bases_destroy(dev->ctx, bases); if (bases_slab && dev) lasso_bases_destroy(dev->ctx, bases_slab); }
 };
 struct SparsePolyCommitmentGens {  // surge.rs:25-59
@@ -575,11 +584,13 @@ class Prover {
 
   // ---- SumcheckInstanceProof::prove_arbitrary (sumcheck.rs:150-260); polys[0..alpha) = E clones, polys[alpha] = eq.
   // One phase = `rounds` rounds on arrays of current length len; `reduce` = the arrays are slabs, per-round sums are all-gathered and added.
+  // LT (the one non-linear strategy): the work arrays of the LT memories carry the factor 32^-(C-1-m) (lasso_lt_prescale, applied once by prove_arbitrary — binding
+  // keeps it), which is what lets the round kernel spend one product per memory and point (Horner form, include/lasso_hip.h); the heads are scaled back in read_heads.
   void arbitrary_rounds(size_t rounds, size_t len, std::vector<lasso_fr*>& polys, size_t combined_degree, bool reduce, SumcheckProof& proof, ScVec& r_out) {
     std::vector<const lasso_fr*> cp(polys.begin(), polys.begin() + alpha);
     for (size_t round = 0; round < rounds; round++) {
       std::vector<lasso_fr> ev(combined_degree + 1);
-      d.chk(lasso_sumcheck_combine_round(d.ctx, &S.abi, cp.data(), polys[alpha], len, (uint32_t)combined_degree, ev.data()), "lasso_sumcheck_combine_round");
+      d.chk(lasso_sumcheck_combine_round_lt_scaled(d.ctx, &S.abi, cp.data(), polys[alpha], len, (uint32_t)combined_degree, ev.data()), "lasso_sumcheck_combine_round_lt_scaled");
       if (reduce) d.comm.sum(ev);
       ScVec evals; for (auto& e : ev) evals.push_back(Sc::from_abi(e));
       UniPoly up = UniPoly::from_evals(evals);
@@ -682,6 +693,10 @@ class Prover {
       std::vector<lasso_fr> h(alpha);
       d.chk(lasso_read_heads(d.ctx, (const lasso_fr* const*)arrs.data(), (uint32_t)alpha, h.data()), "lasso_read_heads");
       heads_out->clear(); for (auto& x : h) heads_out->push_back(Sc::from_abi(x));
+      if (!S.linear()) {   // undo lasso_lt_prescale on the LT memories' final values: LT_m(r) = 32^(C-1-m) * head
+        const Sc k32 = Sc::from_u64(32); Sc pw = Sc::one();
+        for (size_t m = S.C(); m-- > 0;) { (*heads_out)[2 * m] *= pw; pw *= k32; }
+      }
     };
     if (S.linear()) {
       std::vector<lasso_fr*> ep(polys.begin(), polys.begin() + alpha); Sc s_run = Sc::one();
@@ -704,6 +719,7 @@ class Prover {
       tail_bufs.clear();
       return proof;
     }
+    d.chk(lasso_lt_prescale(d.ctx, &S.abi, polys.data(), len_loc), "lasso_lt_prescale");   // the caller's clones, once (slab mode: the local arrays; the replicated tails are gathered from them)
     if (P == 1) { arbitrary_rounds(num_rounds, len_loc, polys, combined_degree, false, proof, r_out); read_heads(polys); return proof; }
     LASSO_REQUIRE(num_rounds >= lgP && ((size_t)1 << (num_rounds - lgP)) == len_loc);
     arbitrary_rounds(num_rounds - lgP, len_loc, polys, combined_degree, true, proof, r_out);
@@ -908,6 +924,16 @@ class Prover {
       dd = tape.random_scalar("d"); r_delta = tape.random_scalar("r_delta"); r_beta = tape.random_scalar("r_delta");   // sic: dot_product.rs:189
       v1 = tape.random_vector("blinds_vec_1", 2 * lg_n); v2 = tape.random_vector("blinds_vec_2", 2 * lg_n);
     }
+    // Slab mode (one proof over P GPUs): a, b and the fold weights are sqrt(N)-sized and replicated, but the MSMs — Cx, every round's L and R, delta: the dependent
+    // chain of the opening — are SHARED: each rank adds up the terms of its residue class of the generators (lasso_*_slab over gens.bases_slab) and the ranks
+    // all-gather and add the partial points (rank order everywhere: the same group element on every rank, the same compressed bytes as one GPU).
+    const bool shard = d.comm.sharded() && g.slab_open;
+    const uint32_t cw = (uint32_t)d.comm.world, cr = (uint32_t)d.comm.rank;
+    auto sum_points = [&](const lasso_point* mine, size_t count, Pt* out) {
+      std::vector<lasso_point> all(count * cw);
+      d.comm.allgather(mine, all.data(), count * sizeof(lasso_point));
+      for (size_t i = 0; i < count; i++) { Pt acc = Pt::from_abi(all[i]); for (size_t r2 = 1; r2 < cw; r2++) acc = acc + Pt::from_abi(all[r2 * count + i]); out[i] = acc; }
+    };
     DotProductProofLog P; uint8_t buf[32];
     // a, b and the generator-fold weights live on the device for the whole reduction, in ping-pong pairs: round k's fold (bullet.rs:127-132)
     // is applied by the same call that computes round k+1's c_L, c_R, L, R (lasso_bullet_round) — one host round trip per round.
@@ -916,10 +942,12 @@ class Prover {
     {   // Cx = <x, G> + 0*h (commitments.rs:84-93) on the device while the host computes Cy = y*G_1[0] + 0*h (commitments.rs:78-82)
       lasso_point cx;
       d.chk(lasso_defer_next(d.ctx), "lasso_defer_next");
-      d.chk(lasso_msm_dev(d.ctx, g.bases, d_a0.p, n, &cx), "lasso_msm_dev");
+      if (shard) d.chk(lasso_msm_dev_slab(d.ctx, g.bases_slab, d_a0.p, n, cw, cr, nullptr, nullptr, &cx), "lasso_msm_dev_slab");
+      else d.chk(lasso_msm_dev(d.ctx, g.bases, d_a0.p, n, &cx), "lasso_msm_dev");
       uint8_t cy[32]; compress_one(g.Qmul.mul(y), cy);
       d.chk(lasso_result_wait(d.ctx, (lasso_fr*)&cx, 4), "lasso_result_wait");
-      compress_one(Pt::from_abi(cx), buf); t.append_point_bytes("Cx", buf);
+      Pt cxp = Pt::from_abi(cx); if (shard) sum_points(&cx, 1, &cxp);
+      compress_one(cxp, buf); t.append_point_bytes("Cx", buf);
       t.append_point_bytes("Cy", cy);
     }
     // bullet reduction (bullet.rs:40-154), blind = blind_x + blind_y = 0
@@ -931,19 +959,23 @@ class Prover {
       lasso_fr blinds[2] = {blind_L.abi(), blind_R.abi()};
       lasso_point LR[2];
       if (have_u) {   // fold with the previous challenge (length 2nk -> nk), then this round's L, R
-        d.chk(lasso_bullet_round(d.ctx, g.bases, n, a_cur, b_cur, w_cur, a_nxt, b_nxt, w_nxt, nk, &ua, &uia, blinds, LR), "lasso_bullet_round");
+        if (shard) d.chk(lasso_bullet_round_slab(d.ctx, g.bases_slab, n, cw, cr, a_cur, b_cur, w_cur, a_nxt, b_nxt, w_nxt, nk, &ua, &uia, blinds, LR), "lasso_bullet_round_slab");
+        else d.chk(lasso_bullet_round(d.ctx, g.bases, n, a_cur, b_cur, w_cur, a_nxt, b_nxt, w_nxt, nk, &ua, &uia, blinds, LR), "lasso_bullet_round");
         std::swap(a_cur, a_nxt); std::swap(b_cur, b_nxt); std::swap(w_cur, w_nxt);
       } else {
         // round 0 needs no challenge: it runs on the device while the host absorbs the a-vector (dot_product.rs:196), the longest message of the opening
         d.chk(lasso_defer_next(d.ctx), "lasso_defer_next");
-        d.chk(lasso_bullet_round(d.ctx, g.bases, n, a_cur, b_cur, w_cur, nullptr, nullptr, nullptr, nk, nullptr, nullptr, blinds, LR), "lasso_bullet_round");
+        if (shard) d.chk(lasso_bullet_round_slab(d.ctx, g.bases_slab, n, cw, cr, a_cur, b_cur, w_cur, nullptr, nullptr, nullptr, nk, nullptr, nullptr, blinds, LR), "lasso_bullet_round_slab");
+        else d.chk(lasso_bullet_round(d.ctx, g.bases, n, a_cur, b_cur, w_cur, nullptr, nullptr, nullptr, nk, nullptr, nullptr, blinds, LR), "lasso_bullet_round");
         { HostClock hc("opening: append a_vec"); t.append_scalars_bytes("a", a_bytes); }
         d.chk(lasso_result_wait(d.ctx, (lasso_fr*)LR, 8), "lasso_result_wait");
       }
       std::vector<uint8_t> cb; Sc u, u_inv;
       {
         HostClock hc("opening: round host work");
-        std::vector<Pt> two{Pt::from_abi(LR[0]), Pt::from_abi(LR[1])}; compress_batch(two, cb);
+        std::vector<Pt> two{Pt::from_abi(LR[0]), Pt::from_abi(LR[1])};
+        if (shard) sum_points(LR, 2, two.data());
+        compress_batch(two, cb);
         t.append_point_bytes("L", &cb[0]); t.append_point_bytes("R", &cb[32]);
         u = t.challenge_scalar("u"); u_inv = u.inverse();
       }
@@ -961,10 +993,15 @@ class Prover {
     d.chk(lasso_read_heads(d.ctx, hp, 2, heads), "lasso_read_heads");
     Sc x_hat = Sc::from_abi(heads[0]), a_hat = Sc::from_abi(heads[1]), y_hat = x_hat * a_hat;
     // delta = d*g_hat + r_delta*h with g_hat = G[0] after all folds = sum_j w_j G_j: one MSM over the resident weights scaled by d, plus the h term
-    lasso_point dl; { lasso_fr sc = dd.abi(); lasso_fr tl[2] = {Sc::zero().abi(), r_delta.abi()}; d.chk(lasso_msm_dev_scaled(d.ctx, g.bases, w_cur, n, &sc, tl, &dl), "lasso_msm_dev_scaled"); }
+    lasso_point dl; Pt dlp;
+    {
+      lasso_fr sc = dd.abi(); lasso_fr tl[2] = {Sc::zero().abi(), r_delta.abi()};
+      if (shard) { d.chk(lasso_msm_dev_slab(d.ctx, g.bases_slab, w_cur, n, cw, cr, &sc, cr == 0 ? tl : nullptr, &dl), "lasso_msm_dev_slab"); sum_points(&dl, 1, &dlp); }
+      else { d.chk(lasso_msm_dev_scaled(d.ctx, g.bases, w_cur, n, &sc, tl, &dl), "lasso_msm_dev_scaled"); dlp = Pt::from_abi(dl); }
+    }
     {
       HostClock hc("opening: delta/beta scalar mults");
-      compress_one(Pt::from_abi(dl), P.delta); t.append_point_bytes("delta", P.delta);
+      compress_one(dlp, P.delta); t.append_point_bytes("delta", P.delta);
       compress_one(g.Qmul.mul(dd) + g.hmul.mul(r_beta), P.beta); t.append_point_bytes("beta", P.beta);
     }
     Sc c = t.challenge_scalar("c");

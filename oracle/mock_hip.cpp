@@ -237,6 +237,23 @@ int32_t lasso_sumcheck_combine_round(lasso_ctx* c, const lasso_strategy* s, cons
   }
   memcpy(out, ev.data(), ev.size() * 32); return 0;
 }
+// LT_m <- 32^-(C-1-m) LT_m (include/lasso_hip.h); the scaled round = the literal round on unscaled copies
+static Fr pow32(size_t e, bool inverse) { Fr b = Fr::from_u64(32); if (inverse) b = b.inverse(); Fr r = Fr::one(); for (size_t i = 0; i < e; i++) r = r * b; return r; }
+int32_t lasso_lt_prescale(lasso_ctx* c, const lasso_strategy* s, lasso_fr* const* polys, size_t n) {
+  REQ(c, s && s->kind == LASSO_LT && polys && n >= 1);
+  for (size_t m = 0; m + 1 < s->c; m++) { const Fr k = pow32(s->c - 1 - m, true); for (size_t i = 0; i < n; i++) F(polys[2 * m])[i] = F(polys[2 * m])[i] * k; }
+  return 0;
+}
+int32_t lasso_sumcheck_combine_round_lt_scaled(lasso_ctx* c, const lasso_strategy* s, const lasso_fr* const* polys, const lasso_fr* eq, size_t n, uint32_t degree, lasso_fr* out) {
+  REQ(c, s && s->kind == LASSO_LT);
+  std::vector<std::vector<lasso_fr>> tmp(s->c); std::vector<const lasso_fr*> ptrs(polys, polys + 2 * s->c);
+  for (size_t m = 0; m + 1 < s->c; m++) {
+    const Fr k = pow32(s->c - 1 - m, false); tmp[m].assign(polys[2 * m], polys[2 * m] + n);
+    for (size_t i = 0; i < n; i++) F(tmp[m].data())[i] = F(tmp[m].data())[i] * k;
+    ptrs[2 * m] = tmp[m].data();
+  }
+  return lasso_sumcheck_combine_round(c, s, ptrs.data(), eq, n, degree, out);
+}
 int32_t lasso_combine_claim(lasso_ctx* c, const lasso_strategy* s, const lasso_fr* const* polys, const lasso_fr* eq, size_t n, lasso_fr* out) {
   Strategy S = mk(s); size_t alpha = S.num_memories(); std::vector<Fr> v(alpha); Fr claim = Fr::zero();
   for (size_t k = 0; k < n; k++) { for (size_t j = 0; j < alpha; j++) v[j] = F(polys[j])[k]; claim += F(eq)[k] * S.combine_lookups(v.data()); }  // subtables/mod.rs:197-213
@@ -403,6 +420,39 @@ int32_t lasso_bullet_round(lasso_ctx* c, const lasso_bases* bs, size_t n, const 
   lasso_fr cc[2]; lasso_inner_products_lr(c, a, b, nk, cc);
   lasso_fr tail[4] = {cc[0], blinds[0], cc[1], blinds[1]};
   lasso_point lr[2]; int32_t rc = lasso_bullet_lr(c, bs, n, a, nk, w, tail, lr); if (rc) return rc;
+  return deliver_points(c, lr, 2, out);
+}
+// ---- slab mode of the opening: the rank's share of the MSMs over its residue class of the generators (include/lasso_hip.h); bases = [G_{jl*world + rank}.., Q, H]
+int32_t lasso_bases_has_direct(const lasso_bases* b) { return b ? 1 : 0; }
+int32_t lasso_msm_dev_slab(lasso_ctx* c, const lasso_bases* b, const lasso_fr* sc, size_t n, uint32_t world, uint32_t rank, const lasso_fr* scale, const lasso_fr* tail, lasso_point* out) {
+  REQ(c, b && sc && out && world >= 1 && rank < world && n % world == 0 && n / world + 2 <= b->pts.size());
+  const size_t nl = n / world; Point acc = Point::identity();
+  for (size_t jl = 0; jl < nl; jl++) { Fr v = F(sc)[jl * world + rank]; if (scale) v = v * *F(scale); acc += b->pts[jl] * v; }
+  if (tail) { acc += b->pts[nl] * F(tail)[0]; acc += b->pts[nl + 1] * F(tail)[1]; }
+  lasso_point tmp; put_point(acc, &tmp);
+  return deliver_points(c, &tmp, 1, out);
+}
+int32_t lasso_bullet_round_slab(lasso_ctx* c, const lasso_bases* bs, size_t n, uint32_t world, uint32_t rank, const lasso_fr* a_in, const lasso_fr* b_in, const lasso_fr* w_in, lasso_fr* a_out,
+                                lasso_fr* b_out, lasso_fr* w_out, size_t nk, const lasso_fr* u, const lasso_fr* u_inv, const lasso_fr* blinds, lasso_point* out) {
+  REQ(c, bs && world >= 1 && rank < world && world <= n && n / world + 2 <= bs->pts.size() && nk >= 2 && nk <= n);
+  const lasso_fr *a = a_in, *b = b_in, *w = w_in;
+  std::vector<lasso_fr> ta, tb;
+  if (u) {
+    REQ(c, u_inv && a_out && b_out && w_out && 2 * nk <= n);
+    ta.assign(a_in, a_in + 2 * nk); tb.assign(b_in, b_in + 2 * nk);
+    lasso_bullet_fold(c, ta.data(), tb.data(), 2 * nk, w_in, n / (2 * nk), w_out, u, u_inv);
+    memcpy(a_out, ta.data(), nk * sizeof(lasso_fr)); memcpy(b_out, tb.data(), nk * sizeof(lasso_fr));
+    a = a_out; b = b_out; w = w_out;
+  }
+  lasso_fr cc[2]; lasso_inner_products_lr(c, a, b, nk, cc);
+  const size_t nl = n / world, h = nk / 2;
+  Point L = Point::identity(), R = Point::identity();
+  for (size_t jl = 0; jl < nl; jl++) {   // generator j = blk*nk + pos of G^(k)_pos = sum_blk w_blk G_{blk*nk + pos}: L = <a_L, G_R>, R = <a_R, G_L>  (bullet.rs:84-118)
+    const size_t j = jl * world + rank, blk = j / nk, pos = j % nk;
+    if (pos >= h) L += bs->pts[jl] * (F(w)[blk] * F(a)[pos - h]); else R += bs->pts[jl] * (F(w)[blk] * F(a)[pos + h]);
+  }
+  if (rank == 0) { L += bs->pts[nl] * *F(&cc[0]); L += bs->pts[nl + 1] * F(blinds)[0]; R += bs->pts[nl] * *F(&cc[1]); R += bs->pts[nl + 1] * F(blinds)[1]; }
+  lasso_point lr[2]; put_point(L, &lr[0]); put_point(R, &lr[1]);
   return deliver_points(c, lr, 2, out);
 }
 int32_t lasso_bullet_fold(lasso_ctx*, lasso_fr* a, lasso_fr* b, size_t nk, const lasso_fr* w, size_t nw, lasso_fr* w_out, const lasso_fr* u, const lasso_fr* u_inv) {

@@ -117,43 +117,51 @@ int main() {
       fr29 k256 = fr29_zero(); k256.v[8] = 1 << 24;
       CHECK(same(fr29_store(fr29_mul(combine_lt<16>(vals, c), k256)), ref));
     }
-    // ---- the LT ROUND in Horner form (k_combine_round_lt, round 3): per index the memories are walked from the last to the first with u-form lines stepped
-    // from point to point by addition, LT_m pre-multiplied by kappa_m = 32^-(C-1-m), one product per memory and point, then the eq weight; sums over the indices
-    // of a "thread" (folded), times 32^C, then the block.  Reference: sum_i e(x) sum_m LT_m(x) prod_{j<m} EQ_j(x), every line evaluated at x = 0..degree by fr.cuh.
+    // ---- the LT ROUND in Horner form (k_combine_round_lt, round 3), driven as the kernel drives it: the LT arrays pre-multiplied by kappa_m = 32^-(C-1-m) (k_lt_prescale),
+    // T lanes per index each walking PPG consecutive points from x0 = lane * PPG (lt_line_at), the memories from the last to the first with u-form lines stepped by addition,
+    // one product per memory and point, then the eq weight; sums over the indices of a lane folded every LT_FOLD_EVERY, times 32^C, then the block's column sums.
+    // Reference: sum_i e(x) sum_m LT_m(x) prod_{j<m} EQ_j(x), every line evaluated at x = 0..degree by fr.cuh.
     // Trial 2 is the magnitude worst case: every line runs from 0 to p - 1 or from p - 1 to 0, so the stepped values reach 18 (p - 1) with either sign.
-    for (uint32_t c : {1u, 2u, 5u, 16u}) {
-      const uint32_t degree = c + 1; const size_t half = c == 16 ? (size_t)NTHREADS * (LT_FOLD_EVERY() + 3) : 1024;   // C = 16: every thread runs through a whole fold period
+    for (uint32_t c : {1u, 2u, 5u, 8u, 16u}) {
+      const uint32_t degree = c + 1, T = degree <= 5 ? 1 : (degree <= 9 ? 2 : 3), D = degree <= 2 ? 2 : degree <= 3 ? 3 : degree <= 5 ? 5 : degree <= 9 ? 9 : 17, PPG = (D + 1 + T - 1) / T;
+      const uint32_t SLOTS = NTHREADS / T;
+      const size_t half = c == 16 ? (size_t)SLOTS * (LT_FOLD_EVERY() + 3) : 1024;   // C = 16: every lane runs through a whole fold period
       std::vector<std::vector<fr_t>> P(2 * c, std::vector<fr_t>(2 * half)); std::vector<fr_t> E(2 * half);
       for (size_t i = 0; i < 2 * half; i++) {
         const bool hi = i >= half;
         E[i] = trial == 2 ? (((i & 1) != 0) == hi ? edge(0) : fr_zero()) : rand_fr();
         for (uint32_t m = 0; m < 2 * c; m++) P[m][i] = trial == 2 ? ((((i + m) & 1) != 0) == hi ? edge(0) : fr_zero()) : (trial == 1 && (i + m) % 3 == 0 ? edge((int)(i + m)) : rand_fr());
       }
-      const fr_t inv32 = fr_inv(fr_from_u64(32)); fr_t kappa[16], scale = fr_one(), kk = fr_one();
-      for (uint32_t m = c; m-- > 0;) { kappa[m] = kk; kk = fr_mul(kk, inv32); }
+      const fr_t inv32 = fr_inv(fr_from_u64(32)); fr_t scale = fr_one(), kk = fr_one();
+      std::vector<std::vector<fr_t>> Ps = P;     // what k_lt_prescale leaves in memory
+      for (uint32_t m = c; m-- > 0;) { const fr29 ks = fr29_unpack_s(kk); for (size_t i = 0; i < 2 * half; i++) Ps[2 * m][i] = fr29_store(fr29_mul(fr29_unpack_u(P[2 * m][i]), ks)); kk = fr_mul(kk, inv32); }
       for (uint32_t m = 0; m < c; m++) scale = fr_mul(scale, fr_from_u64(32));
       std::vector<std::vector<fr29>> acc(degree + 1, std::vector<fr29>(NTHREADS, fr29_zero()));
       for (int th = 0; th < NTHREADS; th++) {
-        fr29 sum[18], t[18]; for (auto& x : sum) x = fr29_zero();
+        const uint32_t slot = th / T, pg = th - slot * T, x0 = pg * PPG;
+        if (slot >= SLOTS || x0 > degree) continue;
+        fr29 sum[6], t[6]; for (auto& x : sum) x = fr29_zero();
         uint32_t cnt = 0;
-        for (size_t i = th; i < half; i += NTHREADS) {
+        for (size_t i = slot; i < half; i += SLOTS) {
           {
-            fr29 lt = fr29_unpack_u(P[2 * (c - 1)][i]); const fr29 dlt = fr29_sub(fr29_unpack_u(P[2 * (c - 1)][i + half]), lt);
-            for (uint32_t k = 0; k <= degree; k++) { t[k] = lt; lt = lt_line_step(lt, dlt); }
+            const fr29 lo = fr29_unpack_u(Ps[2 * (c - 1)][i]), dlt = fr29_sub(fr29_unpack_u(Ps[2 * (c - 1)][i + half]), lo);
+            fr29 lt = lt_line_at(lo, dlt, x0);
+            for (uint32_t k = 0; k < PPG; k++) if (x0 + k <= degree) { t[k] = lt; lt = lt_line_step(lt, dlt); }
           }
           for (uint32_t m = c - 1; m-- > 0;) {
-            const fr29 ks = fr29_unpack_s(kappa[m]);
-            fr29 lt = fr29_mul(fr29_unpack_u(P[2 * m][i]), ks), eqv = fr29_unpack_u(P[2 * m + 1][i]);
-            const fr29 dlt = fr29_sub(fr29_mul(fr29_unpack_u(P[2 * m][i + half]), ks), lt), deq = fr29_sub(fr29_unpack_u(P[2 * m + 1][i + half]), eqv);
-            for (uint32_t k = 0; k <= degree; k++) { t[k] = lt_horner_step(lt, eqv, t[k]); lt = lt_line_step(lt, dlt); eqv = lt_line_step(eqv, deq); }
+            const fr29 lo = fr29_unpack_u(Ps[2 * m][i]), dlt = fr29_sub(fr29_unpack_u(Ps[2 * m][i + half]), lo);
+            const fr29 eo = fr29_unpack_u(Ps[2 * m + 1][i]), deq = fr29_sub(fr29_unpack_u(Ps[2 * m + 1][i + half]), eo);
+            fr29 lt = lt_line_at(lo, dlt, x0), eqv = lt_line_at(eo, deq, x0);
+            for (uint32_t k = 0; k < PPG; k++) if (x0 + k <= degree) { t[k] = lt_horner_step(lt, eqv, t[k]); lt = lt_line_step(lt, dlt); eqv = lt_line_step(eqv, deq); }
           }
           {
-            fr29 ecur = fr29_unpack_u(E[i]); const fr29 edif = fr29_sub(fr29_unpack_u(E[i + half]), ecur);
-            for (uint32_t k = 0; k <= degree; k++) { sum[k] = lt_weighted_acc(sum[k], ecur, t[k]); ecur = lt_line_step(ecur, edif); }
+            const fr29 e0 = fr29_unpack_u(E[i]), edif = fr29_sub(fr29_unpack_u(E[i + half]), e0);
+            fr29 ecur = lt_line_at(e0, edif, x0);
+            for (uint32_t k = 0; k < PPG; k++) if (x0 + k <= degree) { sum[k] = lt_weighted_acc(sum[k], ecur, t[k]); ecur = lt_line_step(ecur, edif); }
           }
-          if (++cnt >= LT_FOLD_EVERY()) { cnt = 0; for (uint32_t k = 0; k <= degree; k++) sum[k] = fr29_mul(sum[k], fr29_one_s()); }   // the kernel's fold period
+          if (++cnt >= LT_FOLD_EVERY()) { cnt = 0; for (uint32_t k = 0; k < PPG; k++) sum[k] = fr29_mul(sum[k], fr29_one_s()); }
         }
-        for (uint32_t k = 0; k <= degree; k++) acc[k][th] = fr29_mul(sum[k], fr29_unpack_s(scale));
+        for (uint32_t k = 0; k < PPG; k++) if (x0 + k <= degree) acc[x0 + k][th] = fr29_mul(sum[k], fr29_unpack_s(scale));
       }
       auto at = [](const fr_t& lo, const fr_t& hi, uint32_t x) { fr_t d = fr_sub(hi, lo), v = lo; for (uint32_t k = 0; k < x; k++) v = fr_add(v, d); return v; };
       for (uint32_t k = 0; k <= degree; k++) {

@@ -133,6 +133,31 @@ def test_sumcheck_combine_round_and_claim(devs, kind, c, log_m, log_r, n):
     assert np.array_equal(a2, b2)
 
 
+@pytest.mark.parametrize("c", [1, 2, 3, 5, 8, 16])
+@pytest.mark.parametrize("n", [2, 8, 1 << 13])
+def test_lt_round_prescaled_horner(devs, c, n):
+    """the prover's LT round: lasso_lt_prescale once, then lasso_sumcheck_combine_round_lt_scaled (Horner form, 1 / 2 / 3 lanes per index at degree <= 5 / 9 / 17) returns
+    what the literal round returns on the unscaled arrays — on the device AND against the oracle's literal loop — and the scaled arrays are 32^-(C-1-m) LT_m"""
+    rng = np.random.default_rng(c * 1000 + n)
+    S = _abi.Strategy(_abi.KINDS["lt"], c, 4, 0)
+    polys = [rand_fr(rng, n) for _ in range(2 * c)]
+    eq = rand_fr(rng, n)
+
+    def run(d):
+        pp = [d.upload(x) for x in polys]; pe = d.upload(eq)
+        literal = d.sumcheck_combine_round(S, pp, pe, n, c + 1)
+        d.lt_prescale(S, pp, n)
+        scaled = d.sumcheck_combine_round_lt_scaled(S, pp, pe, n, c + 1)
+        arrays = [d.download(p, (n, 4)) for p in pp]
+        for p in pp + [pe]:
+            d.free(p)
+        return literal, scaled, arrays
+    (l1, s1, a1), (l2, s2, a2) = both(devs, run)
+    assert np.array_equal(l1, l2) and np.array_equal(s1, s2) and np.array_equal(l1, s1)
+    for x, y in zip(a1, a2):
+        assert np.array_equal(x, y)
+
+
 @pytest.mark.parametrize("n,k", [(1, 1), (7, 2), (1 << 12, 5), (1 << 16, 1)])
 def test_multi_dot(devs, n, k):
     rng = np.random.default_rng(n * 3 + k)
