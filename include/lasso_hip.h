@@ -149,7 +149,7 @@ int32_t lasso_result_wait(lasso_ctx* ctx, lasso_fr* out, size_t count);
  * to absorb the opening's a-vector into the transcript (dot_product.rs:196) while the first bullet round runs.  If the next call turns out not to
  * use the mapped buffer it completes synchronously and lasso_result_wait fails with LASSO_ERR_INVALID (the flag is cleared by either). */
 int32_t lasso_defer_next(lasso_ctx* ctx);
-/* The tail of prove_cubic_batched (sumcheck.rs:49-133) in one resident kernel: once a layer is down to q <= 256 indices per circuit, the remaining
+/* The tail of prove_cubic_batched (sumcheck.rs:49-133) in one resident kernel: once a layer is down to q <= lasso_sumcheck_tail_capacity() indices per circuit, the remaining
  * log2(2q) rounds and the final bind are served without a launch per round — the host posts each challenge into a host-mapped mailbox, the kernel
  * answers through the mapped result buffer (2.5 us per turn against 6.5 us for a launch, tools/pingpong_bench.hip).
  *   begin: r == NULL: first round of a layer, arrays of length n = 2q; otherwise bind r first (n = 4q, as lasso_sumcheck_cubic_eqw2_begin).
@@ -160,6 +160,8 @@ int32_t lasso_defer_next(lasso_ctx* ctx);
  * context until the heads have been collected.  A host that stops answering cannot hang the device: every wait in the kernel gives up after 5 s. */
 int32_t lasso_sumcheck_cubic_tail_begin(lasso_ctx* ctx, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n,
                                         const lasso_fr* r);
+/* largest q the two *_tail_begin calls accept (512: one workgroup per circuit holds its arrays in 147 KB of the CU's LDS) */
+uint32_t lasso_sumcheck_tail_capacity(void);
 int32_t lasso_sumcheck_cubic_tail_next(lasso_ctx* ctx, const lasso_fr* r);
 /* The resident tail of the primary sumcheck for the linear strategies (the rounds lasso_sumcheck_linear_eqw_round[_fused] serve one launch at a time):
  * begin as above on the alpha polynomials d_src (only read); per round 2*alpha values out[2k] = S0_k, out[2k+1] = S1_k; challenges through

@@ -81,6 +81,7 @@ def declare(lib):
         "lasso_bases_has_direct": (i32, [vp]),
         "lasso_bullet_round_slab": (i32, [vp, vp, sz, u32, u32, vp, vp, vp, vp, vp, vp, sz, vp, vp, vp, vp]),
         "lasso_msm_dev_slab": (i32, [vp, vp, vp, sz, u32, u32, vp, vp, vp]),
+        "lasso_sumcheck_tail_capacity": (u32, []),
         "lasso_rccl_available": (i32, []),
         "lasso_rccl_unique_id": (i32, [vp]),
         "lasso_rccl_init": (i32, [vp, i32, i32, vp]),

@@ -514,8 +514,10 @@ int32_t lasso_sumcheck_cubic_tail_begin(lasso_ctx* c, lasso_fr* const* d_A, lass
   int32_t rc = ensure_small(c, (size_t)ncirc * 3); if (rc) return rc;
   uint32_t turns = 0; while (((size_t)1 << turns) < 2 * q) turns++;   // rounds of sums; one more publication carries the heads
   const uint32_t seq0 = c->seq + 1; c->seq += turns + 1;
-  if (r) hipLaunchKernelGGL((k_cubic_tail<true>), dim3(ncirc), dim3(LASSO_BLOCK), 0, c->stream, A, B, (const fr_t*)d_E, (uint32_t)q, to_fr(r), (const uint32_t*)(c->d_flag + 32), c->d_counters, c->d_small, c->d_flag, seq0);
-  else hipLaunchKernelGGL((k_cubic_tail<false>), dim3(ncirc), dim3(LASSO_BLOCK), 0, c->stream, A, B, (const fr_t*)d_E, (uint32_t)q, fr_zero(), (const uint32_t*)(c->d_flag + 32), c->d_counters, c->d_small, c->d_flag, seq0);
+  // workgroup = capacity: 256 threads / 74 KB of LDS up to 256 indices per circuit, 512 threads / 147 KB above
+#define LAUNCH_CTAIL(B_, Q_, R_) hipLaunchKernelGGL((k_cubic_tail<B_, Q_>), dim3(ncirc), dim3(Q_), 0, c->stream, A, B, (const fr_t*)d_E, (uint32_t)q, R_, (const uint32_t*)(c->d_flag + 32), c->d_counters, c->d_small, c->d_flag, seq0)
+  if (q <= 256) { if (r) LAUNCH_CTAIL(true, 256, to_fr(r)); else LAUNCH_CTAIL(false, 256, fr_zero()); }
+  else { if (r) LAUNCH_CTAIL(true, 512, to_fr(r)); else LAUNCH_CTAIL(false, 512, fr_zero()); }
   HIPCHK(c, hipGetLastError());
   c->tail_active = true; c->tail_seq0 = seq0; c->tail_turn = 0; c->tail_turns = turns; c->tail_count = (size_t)ncirc * 2; c->tail_final = (size_t)ncirc * 2;
   c->pending = true; c->pending_seq = seq0; c->pending_count = c->tail_count;
@@ -532,8 +534,9 @@ int32_t lasso_sumcheck_linear_tail_begin(lasso_ctx* c, const lasso_fr* const* d_
   int32_t rc = ensure_small(c, (size_t)alpha * 3); if (rc) return rc;
   uint32_t turns = 0; while (((size_t)1 << turns) < 2 * q) turns++;
   const uint32_t seq0 = c->seq + 1; c->seq += turns + 1;
-  if (r) hipLaunchKernelGGL((k_linear_tail<true>), dim3(alpha), dim3(LASSO_BLOCK), 0, c->stream, Src, (const fr_t*)d_E, (uint32_t)q, to_fr(r), (const uint32_t*)(c->d_flag + 32), c->d_counters, c->d_small, c->d_flag, seq0);
-  else hipLaunchKernelGGL((k_linear_tail<false>), dim3(alpha), dim3(LASSO_BLOCK), 0, c->stream, Src, (const fr_t*)d_E, (uint32_t)q, fr_zero(), (const uint32_t*)(c->d_flag + 32), c->d_counters, c->d_small, c->d_flag, seq0);
+#define LAUNCH_LTAIL(B_, Q_, R_) hipLaunchKernelGGL((k_linear_tail<B_, Q_>), dim3(alpha), dim3(Q_), 0, c->stream, Src, (const fr_t*)d_E, (uint32_t)q, R_, (const uint32_t*)(c->d_flag + 32), c->d_counters, c->d_small, c->d_flag, seq0)
+  if (q <= 256) { if (r) LAUNCH_LTAIL(true, 256, to_fr(r)); else LAUNCH_LTAIL(false, 256, fr_zero()); }
+  else { if (r) LAUNCH_LTAIL(true, 512, to_fr(r)); else LAUNCH_LTAIL(false, 512, fr_zero()); }
   HIPCHK(c, hipGetLastError());
   c->tail_active = true; c->tail_seq0 = seq0; c->tail_turn = 0; c->tail_turns = turns; c->tail_count = (size_t)alpha * 2; c->tail_final = alpha;
   c->pending = true; c->pending_seq = seq0; c->pending_count = c->tail_count;
@@ -556,6 +559,8 @@ int32_t lasso_sumcheck_cubic_tail_next(lasso_ctx* c, const lasso_fr* r) {
   if (c->tail_turn == c->tail_turns) c->tail_active = false;
   return 0;
 }
+// largest q (indices per circuit / polynomial) lasso_sumcheck_{cubic,linear}_tail_begin accept; LASSO_TAIL_Q=256 restores round 2's capacity (A/B measurements)
+uint32_t lasso_sumcheck_tail_capacity(void) { static const uint32_t q = [] { const char* v = getenv("LASSO_TAIL_Q"); const long x = v ? atol(v) : 0; return (uint32_t)(x == 256 ? 256 : CUBIC_TAIL_Q); }(); return q; }
 int32_t lasso_defer_next(lasso_ctx* c) { REQUIRE(c, !c->pending && !c->defer_next); c->defer_next = true; return 0; }
 int32_t lasso_result_wait(lasso_ctx* c, lasso_fr* out, size_t count) {
   REQUIRE(c, out && c->pending && count == c->pending_count);
@@ -724,7 +729,9 @@ int32_t lasso_fingerprint_ops_gp(lasso_ctx* c, const lasso_fr* d_table, const ui
   fr_t* tr = (fr_t*)d_tree_r; fr_t* tw = (fr_t*)d_tree_w;
   {
     ProfScope ps(c, LASSO_K_FINGERPRINT, (32.0 * 3 + 64.0) * s + 2 * 48.0 * s);   // the fingerprints + the first layer of two trees (48 n per layer)
-    hipLaunchKernelGGL(k_fingerprint_ops_l1, dim3(grid_for(s / 2, 4096)), dim3(LASSO_BLOCK), 0, c->stream, (const fr_t*)d_table, d_dim, (const fr_t*)d_read, s, g, g2, t, tr, tw, tr + s, tw + s);
+    // LASSO_EXP_NO_LEAF_STORE=1: TIMING EXPERIMENT ONLY (the proof that follows is invalid): the kernel without its 2 x 32 s bytes of leaf stores = what "compact leaves" would leave of it
+    static const uint32_t store_leaves = [] { const char* v = getenv("LASSO_EXP_NO_LEAF_STORE"); return (v && v[0] == '1') ? 0u : 1u; }();
+    hipLaunchKernelGGL(k_fingerprint_ops_l1, dim3(grid_for(s / 2, 4096)), dim3(LASSO_BLOCK), 0, c->stream, (const fr_t*)d_table, d_dim, (const fr_t*)d_read, s, g, g2, t, tr, tw, tr + s, tw + s, store_leaves);
   }
   {
     ProfScope ps(c, LASSO_K_GP, 2 * 48.0 * s);   // the remaining layers of both trees

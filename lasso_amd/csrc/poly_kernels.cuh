@@ -359,13 +359,15 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_eqw_small(MutPtrTable A, 
 // One workgroup per circuit.  mailbox (host-mapped): three 16-byte chunks [tag, w0, w1, w2] [tag, w3, w4, w5] [tag, w6, w7, 0], w = the challenge, tag = seq0 + turn + 1;
 // turn k's results carry sequence number seq0 + k.  Every spin has a wall-clock bail-out: a host that never answers cannot hang the device.
 // out (2 * ncirc elements per turn): sums turns: out[2c], out[2c+1];  final turn: out[c] = A_c head, out[ncirc + c] = B_c head.
-#define CUBIC_TAIL_Q 256   // the resident kernel takes over at <= this many indices per circuit (arrays of <= 512 elements in LDS)
-template <bool BIND>
-__global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_tail(MutPtrTable A, MutPtrTable B, const fr_t* __restrict__ E, uint32_t q, fr_t r0, const uint32_t* mailbox, uint32_t* counters,
+// Q = capacity in indices per circuit = threads of the workgroup: 256 (74 KB of LDS) or, since round 3, 512 (147 KB of the CU's 160 KB: one streaming round fewer per layer —
+// a resident turn costs ~10 us where a launch-per-round costs ~25 us at these sizes, profiles/r03_kernel_trace_one_proof_2p24.csv)
+#define CUBIC_TAIL_Q 512   // the resident kernels take over at <= this many indices per circuit
+template <bool BIND, int Q>
+__global__ void __launch_bounds__(Q) k_cubic_tail(MutPtrTable A, MutPtrTable B, const fr_t* __restrict__ E, uint32_t q, fr_t r0, const uint32_t* mailbox, uint32_t* counters,
                                                              fr_t* __restrict__ out, uint32_t* flag, uint32_t seq0) {
-  __shared__ fr29 bound[2][2 * CUBIC_TAIL_Q];   // A', B' (m values each)
-  __shared__ fr29 ge[2 * CUBIC_TAIL_Q];         // A'[i] * E[i mod h]
-  __shared__ int32_t rows[2 * CUBIC_TAIL_Q * 9];
+  __shared__ fr29 bound[2][2 * Q];   // A', B' (m values each)
+  __shared__ fr29 ge[2 * Q];         // A'[i] * E[i mod h]
+  __shared__ int32_t rows[2 * Q * 9];
   __shared__ int64_t strips[8 * 18];
   __shared__ int64_t cols[18];
   __shared__ fr_t chal;
@@ -376,7 +378,7 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_tail(MutPtrTable A, MutPt
   {
     // every lane task (array p, index i) loads / binds its element and, for A, weights it with the eq table right away (no separate pass)
     const fr29 rs = fr29_unpack_s(r0);
-    for (uint32_t item = t; item < 2 * m; item += LASSO_BLOCK) {
+    for (uint32_t item = t; item < 2 * m; item += Q) {
       const uint32_t p = item / m, i = item - p * m;
       const fr_t* src = p == 0 ? A.p[y] : B.p[y];
       const fr29 v = BIND ? bind29(src[i], src[i + m], rs) : fr29_unpack_u(src[i]);
@@ -388,7 +390,7 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_tail(MutPtrTable A, MutPt
   for (uint32_t turn = 0;; turn++) {
     const uint32_t h = m / 2;      // pairs this round
     // 2h terms: u < h the q(0) terms, u >= h the leading-coefficient terms; row u of `rows`
-    for (uint32_t u = t; u < 2 * h; u += LASSO_BLOCK) {
+    for (uint32_t u = t; u < 2 * h; u += Q) {
       const uint32_t v = u >= h ? 1u : 0u, i = u - v * h;
       const fr29 g0 = ge[i], g1 = ge[i + h], b0 = bound[1][i], b1 = bound[1][i + h];
       const fr29 term = v == 0 ? fr29_mul(b0, g0) : fr29_mul(fr29_sub(g1, g0), fr29_sub(b1, b0));
@@ -446,7 +448,7 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_tail(MutPtrTable A, MutPt
     fr29 nb[2], ng[2];
 #pragma unroll
     for (int pass = 0; pass < 2; pass++) {
-      const uint32_t u = t + pass * LASSO_BLOCK;
+      const uint32_t u = t + pass * Q;
       if (u < 2 * h) {
         const uint32_t p = u >= h ? 1u : 0u, jx = u - p * h;
         nb[pass] = fr29_canonical(fr29_add(bound[p][jx], fr29_mul(fr29_sub(bound[p][jx + h], bound[p][jx]), rs)));
@@ -456,7 +458,7 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_tail(MutPtrTable A, MutPt
     __syncthreads();
 #pragma unroll
     for (int pass = 0; pass < 2; pass++) {
-      const uint32_t u = t + pass * LASSO_BLOCK;
+      const uint32_t u = t + pass * Q;
       if (u < 2 * h) { const uint32_t p = u >= h ? 1u : 0u, jx = u - p * h; bound[p][jx] = nb[pass]; if (p == 0 && h > 1) ge[jx] = ng[pass]; }
     }
     __syncthreads();
@@ -517,11 +519,11 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_dot_eqw_fused(PtrTable src, Mut
 // remaining rounds' two dot products per polynomial (S0_k = sum_{i<h} z[i] E[i], S1_k = sum_{i<h} z[i+h] E[i]) and the binds run out of LDS,
 // challenges arrive through the host mailbox, and the last publication is the heads z_k[0] = E_k(r_z).  One workgroup per polynomial; src is
 // only read.  out: sums turns out[2k], out[2k+1]; final turn out[k].
-template <bool BIND>
-__global__ void __launch_bounds__(LASSO_BLOCK) k_linear_tail(PtrTable src, const fr_t* __restrict__ E, uint32_t q, fr_t r0, const uint32_t* mailbox, uint32_t* counters,
+template <bool BIND, int Q>
+__global__ void __launch_bounds__(Q) k_linear_tail(PtrTable src, const fr_t* __restrict__ E, uint32_t q, fr_t r0, const uint32_t* mailbox, uint32_t* counters,
                                                               fr_t* __restrict__ out, uint32_t* flag, uint32_t seq0) {
-  __shared__ fr29 z[2 * CUBIC_TAIL_Q];
-  __shared__ int32_t rows[2 * CUBIC_TAIL_Q * 9];
+  __shared__ fr29 z[2 * Q];
+  __shared__ int32_t rows[2 * Q * 9];
   __shared__ int64_t strips[8 * 18];
   __shared__ int64_t cols[18];
   __shared__ fr_t chal;
@@ -532,12 +534,12 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_linear_tail(PtrTable src, const
   {
     const fr29 rs = fr29_unpack_s(r0);
     const fr_t* p = src.p[y];
-    for (uint32_t i = t; i < m; i += LASSO_BLOCK) z[i] = BIND ? bind29(p[i], p[i + m], rs) : fr29_unpack_u(p[i]);
+    for (uint32_t i = t; i < m; i += Q) z[i] = BIND ? bind29(p[i], p[i + m], rs) : fr29_unpack_u(p[i]);
   }
   __syncthreads();
   for (uint32_t turn = 0;; turn++) {
     const uint32_t h = m / 2;
-    for (uint32_t u = t; u < m; u += LASSO_BLOCK) {   // rows 0..h-1: S0 terms, h..2h-1: S1 terms
+    for (uint32_t u = t; u < m; u += Q) {   // rows 0..h-1: S0 terms, h..2h-1: S1 terms
       const fr29 term = fr29_mul(z[u], fr29_unpack_s(E[u < h ? u : u - h]));
 #pragma unroll
       for (int k = 0; k < 9; k++) rows[u * 9 + k] = term.v[k];
@@ -853,7 +855,8 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_fingerprint_ops(const fr_t* __r
 // 2 x 32 s bytes that k_gp_layer would read straight back never leave the chip.  l1_r / l1_w: s/2 elements each.  Operands go through the memory form exactly
 // as k_gp_layer reads them, so the tree is bit-identical.
 __global__ void __launch_bounds__(LASSO_BLOCK) k_fingerprint_ops_l1(const fr_t* __restrict__ table, const uint32_t* __restrict__ dim, const fr_t* __restrict__ read, size_t s,
-                                                                     fr_t gamma, fr_t gamma2, fr_t tau, fr_t* __restrict__ out_r, fr_t* __restrict__ out_w, fr_t* __restrict__ l1_r, fr_t* __restrict__ l1_w) {
+                                                                     fr_t gamma, fr_t gamma2, fr_t tau, fr_t* __restrict__ out_r, fr_t* __restrict__ out_w, fr_t* __restrict__ l1_r, fr_t* __restrict__ l1_w,
+                                                                     uint32_t store_leaves) {
   const fr29 gs = fr29_unpack_s(gamma), g2s = fr29_unpack_s(gamma2), g2u = fr29_unpack_u(gamma2), tu = fr29_unpack_u(tau), r2s = fr29_r2s();
   const size_t half = s / 2;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x) {
@@ -865,7 +868,7 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_fingerprint_ops_l1(const fr_t* 
       fr29 h = fr29_add(fr29_mul(fr29_unpack_u(read[k]), g2s), fr29_mul(fr29_unpack_u(table[a]), gs));
       h = fr29_canonical(fr29_sub(fr29_add(h, fr29_mul(fr29_from_u64_int(a), r2s)), tu));
       lr[e] = fr29_pack(h); lw[e] = fr29_store(fr29_add(h, g2u));
-      out_r[k] = lr[e]; out_w[k] = lw[e];
+      if (store_leaves) { out_r[k] = lr[e]; out_w[k] = lw[e]; }   // 0 only in the timing experiment LASSO_EXP_NO_LEAF_STORE (what dropping the leaf arrays would save here)
     }
     l1_r[i] = fr29_store(fr29_mul(fr29_unpack_u(lr[0]), fr29_unpack_s(lr[1])));
     l1_w[i] = fr29_store(fr29_mul(fr29_unpack_u(lw[0]), fr29_unpack_s(lw[1])));

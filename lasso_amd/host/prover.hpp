@@ -537,6 +537,7 @@ class Prover {
   const lasso_fr* E(size_t i) const { return combined_E.p + i * s_loc; }
   std::vector<DBuf> tail_bufs;       // P-element replicated arrays of the current sumcheck's tail
   std::vector<DBuf> side_keep;       // inputs of work in flight on the side context (released after lasso_sync(side))
+  static size_t tail_q() { static const size_t q = lasso_sumcheck_tail_capacity(); return q; }
   static bool side_off() { static const bool v = [] { const char* e = getenv("LASSO_SIDE_STREAM"); return e && e[0] == '0'; }(); return v; }
 
  public:
@@ -629,7 +630,7 @@ class Prover {
     size_t tail_from = rounds;
     if (tail_heads && !reduce && !degenerate && !tail_off) {
       size_t j0 = 0, l = len;
-      while (j0 < rounds && (j0 == 0 ? l / 2 : l / 4) > 256) { if (j0) l /= 2; j0++; }
+      while (j0 < rounds && (j0 == 0 ? l / 2 : l / 4) > tail_q()) { if (j0) l /= 2; j0++; }
       if (j0 < rounds) tail_from = j0;
     }
     bool in_tail = false;
@@ -758,7 +759,7 @@ class Prover {
     size_t tail_from = rounds;   // first round served by the resident kernel
     if (heads_out && !reduce && !degenerate && !tail_off) {
       size_t j0 = 0; size_t l = len;   // l = array length before round j's bind
-      while (j0 < rounds && (j0 == 0 ? l / 2 : l / 4) > 256) { if (j0) l /= 2; j0++; }   // 256 = the kernel's CUBIC_TAIL_Q
+      while (j0 < rounds && (j0 == 0 ? l / 2 : l / 4) > tail_q()) { if (j0) l /= 2; j0++; }   // the resident kernels' capacity
       bool plain = j0 < rounds;
       for (size_t j = j0; j < rounds && plain; j++) if (rand[v0 + j].is_zero()) plain = false;
       if (plain) tail_from = j0;
@@ -938,7 +939,8 @@ class Prover {
     // a, b and the generator-fold weights live on the device for the whole reduction, in ping-pong pairs: round k's fold (bullet.rs:127-132)
     // is applied by the same call that computes round k+1's c_L, c_R, L, R (lasso_bullet_round) — one host round trip per round.
     DBuf d_a1(d, n / 2 ? n / 2 : 1), d_b1(d, n / 2 ? n / 2 : 1), d_w0(d, n), d_w1(d, n);
-    { Sc one = Sc::one(); d.chk(lasso_upload(d.ctx, d_w0.p, &one, sizeof(lasso_fr)), "lasso_upload"); }
+    // the initial fold weight w = [1] = EqPolynomial([]).evals(): written by a kernel on the stream (a synchronous 32-byte upload cost every opening ~40 us of idle device)
+    d.chk(lasso_eq_evals(d.ctx, nullptr, 0, d_w0.p), "lasso_eq_evals");
     {   // Cx = <x, G> + 0*h (commitments.rs:84-93) on the device while the host computes Cy = y*G_1[0] + 0*h (commitments.rs:78-82)
       lasso_point cx;
       d.chk(lasso_defer_next(d.ctx), "lasso_defer_next");

@@ -197,9 +197,10 @@ static void tail_publish(lasso_ctx* ctx) {
 static void tail_bind(lasso_ctx* c, const Fr& r) {
   for (auto* arrs : {&c->tail_a, &c->tail_b}) for (auto& v : *arrs) { const size_t h = v.size() / 2; for (size_t i = 0; i < h; i++) v[i] = v[i] + r * (v[i + h] - v[i]); v.resize(h); }
 }
+uint32_t lasso_sumcheck_tail_capacity(void) { return 512; }
 int32_t lasso_sumcheck_cubic_tail_begin(lasso_ctx* c, lasso_fr* const* A, lasso_fr* const* B, uint32_t nc, const lasso_fr* E, size_t n, const lasso_fr* r) {
   REQ(c, n >= (r ? 4u : 2u) && (n & (n - 1)) == 0 && c->tail_a.empty() && c->pending.empty());
-  const size_t q = r ? n / 4 : n / 2; REQ(c, q >= 1 && q <= 256);
+  const size_t q = r ? n / 4 : n / 2; REQ(c, q >= 1 && q <= 512);
   c->tail_a.clear(); c->tail_b.clear();
   for (uint32_t k = 0; k < nc; k++) { c->tail_a.emplace_back(F(A[k]), F(A[k]) + n); c->tail_b.emplace_back(F(B[k]), F(B[k]) + n); }
   c->tail_e.assign(F(E), F(E) + q);
@@ -209,7 +210,7 @@ int32_t lasso_sumcheck_cubic_tail_begin(lasso_ctx* c, lasso_fr* const* A, lasso_
 }
 int32_t lasso_sumcheck_linear_tail_begin(lasso_ctx* c, const lasso_fr* const* src, uint32_t alpha, const lasso_fr* E, size_t n, const lasso_fr* r) {
   REQ(c, n >= (r ? 4u : 2u) && (n & (n - 1)) == 0 && c->tail_a.empty() && c->pending.empty());
-  const size_t q = r ? n / 4 : n / 2; REQ(c, q >= 1 && q <= 256);
+  const size_t q = r ? n / 4 : n / 2; REQ(c, q >= 1 && q <= 512);
   c->tail_a.clear(); c->tail_b.clear(); c->tail_linear = true;
   for (uint32_t k = 0; k < alpha; k++) c->tail_a.emplace_back(F(src[k]), F(src[k]) + n);
   c->tail_e.assign(F(E), F(E) + q);

@@ -559,7 +559,8 @@ def test_sumcheck_cubic_eqw2(devs, n, ncirc):
             assert (3 * t3[3 * c + 1] - 2 * t3[3 * c + 2] - q0 + 6 * qi) % FR_P == 0
 
 
-@pytest.mark.parametrize("n,ncirc,bind", [(2, 1, False), (4, 1, True), (4, 2, False), (8, 2, True), (64, 3, False), (128, 33, False), (256, 2, True), (256, 66, True), (16, 5, True), (512, 2, False), (1024, 3, True), (512, 40, True)])
+@pytest.mark.parametrize("n,ncirc,bind", [(2, 1, False), (4, 1, True), (4, 2, False), (8, 2, True), (64, 3, False), (128, 33, False), (256, 2, True), (256, 66, True), (16, 5, True), (512, 2, False), (1024, 3, True), (512, 40, True),
+                                           (1024, 2, False), (2048, 2, True), (2048, 5, True), (1024, 33, False)])   # q = 512: the 512-thread / 147 KB form (round 3)
 def test_sumcheck_cubic_tail(devs, n, ncirc, bind):
     """the resident tail kernel (all remaining rounds of a layer + the final bind in one launch, challenges through the mailbox) against the
     per-round two-sum calls: same sums every round, same heads"""
@@ -630,7 +631,7 @@ def test_abort_releases_a_waiting_tail_kernel(devs):
         d.free(p)
 
 
-@pytest.mark.parametrize("n,alpha,bind", [(2, 1, False), (4, 1, True), (8, 3, False), (64, 2, True), (512, 1, False), (1024, 2, True), (256, 33, True), (16, 8, False)])
+@pytest.mark.parametrize("n,alpha,bind", [(2, 1, False), (4, 1, True), (8, 3, False), (64, 2, True), (512, 1, False), (1024, 2, True), (256, 33, True), (16, 8, False), (1024, 1, False), (2048, 3, True)])   # the last two: q = 512
 def test_sumcheck_linear_tail(devs, n, alpha, bind):
     """resident tail of the primary sumcheck (linear strategies) against the per-round eq-weighted calls: same dot products every round, same heads,
     and the source arrays are left untouched"""
