@@ -458,8 +458,9 @@ static int32_t cubic_eqw_launch(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* co
       PtrTable Ac, Bc; for (uint32_t i = 0; i < ncirc; i++) { Ac.p[i] = A.p[i]; Bc.p[i] = B.p[i]; }
       const unsigned ny = ncirc, nx = grid_for(half, cubic_nx_cap(ny));
       rc = ensure_scratch(c, (size_t)nx * ny * 3 * sizeof(fr_t)); if (rc) return rc;
-      if (NT == 3) hipLaunchKernelGGL(k_cubic_eqw_lb<3>, dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, Ac, Bc, nx, ny, (const fr_t*)d_E, half, (fr_t*)c->d_scratch, c->d_counters, c->d_small, c->d_flag, seq);
-      else hipLaunchKernelGGL(k_cubic_eqw_lb<2>, dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, Ac, Bc, nx, ny, (const fr_t*)d_E, half, (fr_t*)c->d_scratch, c->d_counters, c->d_small, c->d_flag, seq);
+      static const uint32_t pipe = [] { const char* v = getenv("LASSO_LB_PIPELINE"); return (v && v[0] == '0') ? 0u : 1u; }();
+      if (NT == 3) hipLaunchKernelGGL(k_cubic_eqw_lb<3>, dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, Ac, Bc, nx, ny, (const fr_t*)d_E, half, (fr_t*)c->d_scratch, c->d_counters, c->d_small, c->d_flag, seq, 0u);
+      else hipLaunchKernelGGL(k_cubic_eqw_lb<2>, dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, Ac, Bc, nx, ny, (const fr_t*)d_E, half, (fr_t*)c->d_scratch, c->d_counters, c->d_small, c->d_flag, seq, pipe);
     }
   } else {
     const size_t q = n / 4;

@@ -241,21 +241,42 @@ __device__ __forceinline__ void cubic_eqw_terms2(const fr29& a0, const fr29& a1,
 // out[c*NT + ..] = the NT sums over i < half of circuit c.  1-D grid of nx*ny workgroups (cubic_grid).
 template <int NT>
 __global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_eqw_lb(PtrTable A, PtrTable B, uint32_t nx, uint32_t ny, const fr_t* __restrict__ E, size_t half, fr_t* __restrict__ partials, uint32_t* counters,
-                                                               fr_t* __restrict__ out, uint32_t* flag, uint32_t seq) {
+                                                               fr_t* __restrict__ out, uint32_t* flag, uint32_t seq, uint32_t pipeline) {
   __shared__ RedScratch S;
   const CubicGrid g = cubic_grid(nx, ny);
   const fr_t* __restrict__ a = A.p[g.by];
   const fr_t* __restrict__ b = B.p[g.by];
   fr29 e[3] = {fr29_zero(), fr29_zero(), fr29_zero()}; uint32_t cnt = 0;
   fr29_acc w0 = fr29_acc_zero(), w1 = fr29_acc_zero();
-  for (size_t i = g.bx * (size_t)blockDim.x + threadIdx.x; i < half; i += (size_t)nx * blockDim.x) {
-    fr29 t0, t2, t3;
-    if (NT == 3) { cubic_eqw_terms(fr29_unpack_u(a[i]), fr29_unpack_u(a[i + half]), fr29_unpack_u(b[i]), fr29_unpack_u(b[i + half]), fr29_unpack_s(E[i]), t0, t2, t3); CUBIC_ACCUMULATE(e, t0, t2, t3, cnt); }
-    else {
+  const size_t stride = (size_t)nx * blockDim.x;
+  size_t i = g.bx * (size_t)blockDim.x + threadIdx.x;
+  if (NT == 3) {
+    for (; i < half; i += stride) {
+      fr29 t0, t2, t3;
+      cubic_eqw_terms(fr29_unpack_u(a[i]), fr29_unpack_u(a[i + half]), fr29_unpack_u(b[i]), fr29_unpack_u(b[i + half]), fr29_unpack_s(E[i]), t0, t2, t3); CUBIC_ACCUMULATE(e, t0, t2, t3, cnt);
+    }
+  } else if (!pipeline) {   // A/B switch (LASSO_LB_PIPELINE=0): the plain loop of round 2
+    for (; i < half; i += stride) {
       const fr29 es = fr29_unpack_s(E[i]), b0 = fr29_unpack_u(b[i]), b1 = fr29_unpack_u(b[i + half]);
       const fr29 g0 = fr29_mul(fr29_unpack_u(a[i]), es), g1 = fr29_mul(fr29_unpack_u(a[i + half]), es);
       fr29_mul_acc(w0, b0, g0); fr29_mul_acc(w1, fr29_sub(g1, g0), fr29_sub(b1, b0));
       if (++cnt == 3) { fr29_acc_carry(w0); fr29_acc_carry(w1); cnt = 0; }
+    }
+  } else if (i < half) {
+    // software-pipelined: the five 32-byte loads of the NEXT index are in flight while this one's four products issue.  The round reads and never writes, its
+    // ~900 instructions per index are too few to hide a ~2 us HBM access behind two waves per SIMD, and the compiler keeps the loads at the head of the loop
+    // body: measured 3.6 TB/s of reads (1.07 GB in 316 us at the 2^24 top layer) where a read stream reaches 6.
+    fr_t a0 = a[i], a1 = a[i + half], b0m = b[i], b1m = b[i + half], em = E[i];
+    for (;;) {
+      const size_t in = i + stride; const bool more = in < half;
+      const size_t ip = more ? in : i;     // clamp: the last iteration re-reads its own (cached) lines instead of branching around the loads
+      const fr_t na0 = a[ip], na1 = a[ip + half], nb0 = b[ip], nb1 = b[ip + half], ne = E[ip];
+      const fr29 es = fr29_unpack_s(em), b0 = fr29_unpack_u(b0m), b1 = fr29_unpack_u(b1m);
+      const fr29 g0 = fr29_mul(fr29_unpack_u(a0), es), g1 = fr29_mul(fr29_unpack_u(a1), es);
+      fr29_mul_acc(w0, b0, g0); fr29_mul_acc(w1, fr29_sub(g1, g0), fr29_sub(b1, b0));
+      if (++cnt == 3) { fr29_acc_carry(w0); fr29_acc_carry(w1); cnt = 0; }
+      if (!more) break;
+      a0 = na0; a1 = na1; b0m = nb0; b1m = nb1; em = ne; i = in;
     }
   }
   if (NT == 2) { fr29_acc_carry(w0); fr29_acc_carry(w1); e[0] = fr29_acc_reduce(w0); e[1] = fr29_acc_reduce(w1); }
