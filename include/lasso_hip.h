@@ -143,6 +143,12 @@ int32_t lasso_sumcheck_cubic_eqw_round_fused(lasso_ctx* ctx, lasso_fr* const* d_
 int32_t lasso_sumcheck_cubic_eqw2_begin(lasso_ctx* ctx, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n,
                                         const lasso_fr* r);
 int32_t lasso_result_wait(lasso_ctx* ctx, lasso_fr* out, size_t count);
+/* The FIRST round of a layer (r == NULL above) with the layer's eq table built inside the same launch.  Every layer of BatchedGrandProductArgument::prove starts with
+ * poly_C = EqPolynomial(rand).evals() (grand_product.rs:122) — here  E = *scale * EqPolynomial(point[0..ell)).evals(),  2^ell = n/2 entries, scale == NULL: 1 — and as kernels of
+ * their own those tables are 40 launch-bound steps on the proof's critical path.  Afterwards d_E_out holds the table (byte-identical to lasso_eq_evals_scaled's) for the later
+ * rounds of the layer and the pending result is lasso_sumcheck_cubic_eqw2_begin's.  Tables of 2^7 .. 2^14 entries; LASSO_ERR_UNSUPPORTED otherwise (build the table, call the plain form). */
+int32_t lasso_sumcheck_cubic_eqw2_begin_eq(lasso_ctx* ctx, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, lasso_fr* d_E_out, size_t n, const lasso_fr* point, uint32_t ell,
+                                           const lasso_fr* scale);
 /* Launch/wait split for any call whose result comes back through the mapped result buffer (sumcheck rounds, MSMs of up to 16 rows,
  * lasso_bullet_round, lasso_read_heads ...): after lasso_defer_next the NEXT such call returns right after its launch, ignoring its `out`
  * argument; lasso_result_wait(ctx, out, count) then delivers the values (count in field-element units; a lasso_point is 4).  The prover uses it
@@ -160,6 +166,9 @@ int32_t lasso_defer_next(lasso_ctx* ctx);
  * context until the heads have been collected.  A host that stops answering cannot hang the device: every wait in the kernel gives up after 5 s. */
 int32_t lasso_sumcheck_cubic_tail_begin(lasso_ctx* ctx, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n,
                                         const lasso_fr* r);
+/* lasso_sumcheck_cubic_tail_begin(.., r = NULL) for a layer that fits the resident kernel from its first round on: no table at all — the kernel derives
+ * E = *scale * EqPolynomial(point[0..ell)).evals(), 2^ell = n/2 <= capacity, from the point (two factor tables of <= 32 entries in LDS, one product per use). */
+int32_t lasso_sumcheck_cubic_tail_begin_eq(lasso_ctx* ctx, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, size_t n, const lasso_fr* point, uint32_t ell, const lasso_fr* scale);
 /* largest q the two *_tail_begin calls accept (512: one workgroup per circuit holds its arrays in 147 KB of the CU's LDS) */
 uint32_t lasso_sumcheck_tail_capacity(void);
 int32_t lasso_sumcheck_cubic_tail_next(lasso_ctx* ctx, const lasso_fr* r);
@@ -174,11 +183,13 @@ int32_t lasso_sumcheck_combine_round(lasso_ctx* ctx, const lasso_strategy* s, co
                                      size_t n, uint32_t degree, lasso_fr* out);
 /* LT strategy, the prover's form of the degree-(C+1) round (lt.rs:62-71 inside sumcheck.rs:179-218).  In Horner form  g = LT_0 + EQ_0 (LT_1 + EQ_1 (... + EQ_{C-2} LT_{C-1}))  a round
  * costs ONE field product per memory and evaluation point instead of two, provided the factor 2^5 that a product of two in-memory (Montgomery 2^256) operands loses against the kernels'
- * 2^261 radix is carried by the data: lasso_lt_prescale multiplies polynomial 2m (= LT_m, length n) by 32^-(C-1-m) in place, once, before the first round — binding is linear, so the
+ * 2^261 radix is carried by the data: lasso_lt_prescale multiplies polynomial 2m (= LT_m, length n) by 32^-(C-1-m), once, before the first round — binding is linear, so the
  * arrays stay scaled through every lasso_bind_top — and lasso_sumcheck_combine_round_lt_scaled takes such arrays and returns exactly what lasso_sumcheck_combine_round returns on the
  * unscaled ones.  After the last bind the caller multiplies the head of polynomial 2m by 32^(C-1-m) to obtain LT_m(r); the EQ polynomials (odd indices) are never touched.
  * (lasso_sumcheck_combine_round on an LT strategy scales private copies itself: the literal call.) */
-int32_t lasso_lt_prescale(lasso_ctx* ctx, const lasso_strategy* s, lasso_fr* const* d_polys, size_t n);
+/* d_src == NULL: in place.  Otherwise d_polys[i] <- (scaled) d_src[i] for ALL 2C polynomials (the ones the scaling leaves alone are copied): the sumcheck's clone of the lookup
+ * polynomials (surge.rs:151) and the scaling in one pass over the data. */
+int32_t lasso_lt_prescale(lasso_ctx* ctx, const lasso_strategy* s, const lasso_fr* const* d_src, lasso_fr* const* d_polys, size_t n);
 int32_t lasso_sumcheck_combine_round_lt_scaled(lasso_ctx* ctx, const lasso_strategy* s, const lasso_fr* const* d_polys, const lasso_fr* d_eq, size_t n, uint32_t degree, lasso_fr* out);
 /* The same round in EQ-WEIGHTED form for the LINEAR strategies (AND / OR / XOR / RangeCheck: g = sum_k w_k E_k, src/subtables/and.rs:45-53) — what the
  * prover calls.  The eq polynomial is factored exactly as in lasso_sumcheck_cubic_eqw_round (prefix of the original table d_E + host scalars), and by
@@ -247,6 +258,9 @@ int32_t lasso_densify_dim_slab(lasso_ctx* ctx, const uint64_t* d_indices, size_t
 /* Upload a generator vector once (MultiCommitGens: G[0..n) then any extra points such as gens_1.G[0] and h) and
  * precompute the per-window multiples used by both MSM entry points. */
 int32_t lasso_bases_create(lasso_ctx* ctx, const lasso_affine* points, size_t n, lasso_bases** out);
+/* Device memory per bases object: the window table 64 * n * 112 B; for n <= 2^17 the digit-multiple table of the latency-shaped MSMs, 8x that (57 KB per generator); and, built by the
+ * first commitment of small scalars that uses the object (serialised by a mutex inside the object; ~3 ms, waited for), one byte-multiple table of 255 * n * 112 B per byte window
+ * (117 MB for n = 4096; at most two windows). */
 void lasso_bases_destroy(lasso_ctx* ctx, lasso_bases* b);
 /* DensePolynomial::commit / commit_inner with zero blinds (src/poly/dense_mlpoly.rs:109-181): for each of l_size rows,
  * out[row] = sum_{j < r_size} d_Z[row*r_size + j] * bases[j]   (Commitments::batch_commit, src/poly/commitments.rs:84-93) */

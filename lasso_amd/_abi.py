@@ -55,7 +55,7 @@ def declare(lib):
         "lasso_sumcheck_linear_tail_begin": (i32, [vp, P(vp), u32, vp, sz, vp]),
         "lasso_sumcheck_combine_round": (i32, [vp, P(Strategy), P(vp), vp, sz, u32, vp]),
         "lasso_sumcheck_combine_round_lt_scaled": (i32, [vp, P(Strategy), P(vp), vp, sz, u32, vp]),
-        "lasso_lt_prescale": (i32, [vp, P(Strategy), P(vp), sz]),
+        "lasso_lt_prescale": (i32, [vp, P(Strategy), P(vp), P(vp), sz]),
         "lasso_sumcheck_linear_eqw_round": (i32, [vp, P(vp), u32, vp, sz, vp]),
         "lasso_sumcheck_linear_eqw_round_fused": (i32, [vp, P(vp), u32, vp, sz, vp, vp]),
         "lasso_sumcheck_linear_eqw_round_fused_from": (i32, [vp, P(vp), P(vp), u32, vp, sz, vp, vp]),
@@ -82,6 +82,8 @@ def declare(lib):
         "lasso_bullet_round_slab": (i32, [vp, vp, sz, u32, u32, vp, vp, vp, vp, vp, vp, sz, vp, vp, vp, vp]),
         "lasso_msm_dev_slab": (i32, [vp, vp, vp, sz, u32, u32, vp, vp, vp]),
         "lasso_sumcheck_tail_capacity": (u32, []),
+        "lasso_sumcheck_cubic_eqw2_begin_eq": (i32, [vp, P(vp), P(vp), u32, vp, sz, vp, u32, vp]),
+        "lasso_sumcheck_cubic_tail_begin_eq": (i32, [vp, P(vp), P(vp), u32, sz, vp, u32, vp]),
         "lasso_rccl_available": (i32, []),
         "lasso_rccl_unique_id": (i32, [vp]),
         "lasso_rccl_init": (i32, [vp, i32, i32, vp]),

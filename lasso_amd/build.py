@@ -50,7 +50,9 @@ def build_host(force=False, verbose=False, curve="curve25519"):
     dev = build_device(force=False, verbose=verbose, curve=curve)
     if force or _stale(target, sources + [dev]):
         # -fno-gnu-unique / -Bsymbolic: the two curve builds share C++ names and may be loaded side by side; nothing may be unified across them
-        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas", "-fno-gnu-unique", "-Wl,-Bsymbolic", *flags, "-o", target,
+        # -march=x86-64-v3 (AVX2, BMI1/2: every x86 host a gfx950 ships in): the transcript's Keccak-f is 10-18 % faster with andn / rorx and three-operand forms
+        # (tools: 0.39 -> 0.32 us per permutation on the build container), and ~1.5 ms of a 19 ms proof is host Keccak
+        cmd = ["g++", "-O2", "-march=x86-64-v3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas", "-fno-gnu-unique", "-Wl,-Bsymbolic", *flags, "-o", target,
                os.path.join(hdir, "prover_capi.cpp"), "-L" + HERE, f"-llasso_hip{suffix}", "-Wl,-rpath,$ORIGIN"]
         if verbose:
             print(" ".join(cmd))

@@ -2,6 +2,7 @@
 // One context = one device + one HIP stream + scratch.  See the header for the contract of each entry point.
 #include <hip/hip_runtime.h>
 #include <emmintrin.h>
+#include <mutex>
 #include <string>
 #include <vector>
 #include <cstring>
@@ -65,6 +66,7 @@ struct lasso_bases {
   niels29* d_mult = nullptr;                 // signed digit multiples for the latency-shaped MSM (k_msm_direct), optional
   niels29* d_tab8[2] = {nullptr, nullptr};   // byte multiples m * 256^w * G_j, m = 1..255, for the row-parallel commitments of small scalars (k_msm_rows8); built on first use
   bool tab8_failed = false;
+  std::mutex tab8_mu;                        // the lazy build is serialised: two contexts (or host threads) sharing one bases object may reach first use together
 };
 
 static thread_local std::string g_create_err;
@@ -444,7 +446,8 @@ int32_t lasso_sumcheck_cubic_round(lasso_ctx* c, const lasso_fr* const* d_A, con
 // One eq-weighted cubic round, enqueued only: r == nullptr is the first round of a layer (arrays of length n, evaluation only), otherwise the
 // previous challenge is bound first (length n -> n/2) and the sums are those of the next round.  NT sums per circuit land in the mapped
 // result buffer under sequence number *seq_out.
-static int32_t cubic_eqw_launch(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n, const lasso_fr* r, int NT, uint32_t* seq_out) {
+// eqi (first round of a layer, two-sum form, streaming size only): the layer's eq table is built inside the launch and WRITTEN to d_E (k_cubic_eqw_lb<2, true>)
+static int32_t cubic_eqw_launch(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n, const lasso_fr* r, int NT, uint32_t* seq_out, const EqInline* eqi = nullptr) {
   MutPtrTable A, B; for (uint32_t i = 0; i < ncirc; i++) { REQUIRE(c, d_A[i] && d_B[i]); A.p[i] = (fr_t*)d_A[i]; B.p[i] = (fr_t*)d_B[i]; }
   int32_t rc = ensure_small(c, (size_t)ncirc * 3); if (rc) return rc;
   const uint32_t seq = ++c->seq; *seq_out = seq;
@@ -459,8 +462,9 @@ static int32_t cubic_eqw_launch(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* co
       const unsigned ny = ncirc, nx = grid_for(half, cubic_nx_cap(ny));
       rc = ensure_scratch(c, (size_t)nx * ny * 3 * sizeof(fr_t)); if (rc) return rc;
       static const uint32_t pipe = [] { const char* v = getenv("LASSO_LB_PIPELINE"); return (v && v[0] == '0') ? 0u : 1u; }();
-      if (NT == 3) hipLaunchKernelGGL(k_cubic_eqw_lb<3>, dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, Ac, Bc, nx, ny, (const fr_t*)d_E, half, (fr_t*)c->d_scratch, c->d_counters, c->d_small, c->d_flag, seq, 0u);
-      else hipLaunchKernelGGL(k_cubic_eqw_lb<2>, dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, Ac, Bc, nx, ny, (const fr_t*)d_E, half, (fr_t*)c->d_scratch, c->d_counters, c->d_small, c->d_flag, seq, pipe);
+      if (NT == 3) hipLaunchKernelGGL((k_cubic_eqw_lb<3, false>), dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, Ac, Bc, nx, ny, (const fr_t*)d_E, half, (fr_t*)c->d_scratch, c->d_counters, c->d_small, c->d_flag, seq, 0u, EqInline(), (fr_t*)nullptr);
+      else if (eqi) hipLaunchKernelGGL((k_cubic_eqw_lb<2, true>), dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, Ac, Bc, nx, ny, (const fr_t*)nullptr, half, (fr_t*)c->d_scratch, c->d_counters, c->d_small, c->d_flag, seq, 1u, *eqi, (fr_t*)d_E);
+      else hipLaunchKernelGGL((k_cubic_eqw_lb<2, false>), dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, Ac, Bc, nx, ny, (const fr_t*)d_E, half, (fr_t*)c->d_scratch, c->d_counters, c->d_small, c->d_flag, seq, pipe, EqInline(), (fr_t*)nullptr);
     }
   } else {
     const size_t q = n / 4;
@@ -507,8 +511,34 @@ int32_t lasso_sumcheck_cubic_eqw2_begin(lasso_ctx* c, lasso_fr* const* d_A, lass
 // result of the first of the log2(2q) rounds is pending afterwards (lasso_result_wait, 2*ncirc values: (q(0), q_inf) per circuit).
 // next: posts a challenge; pending: the next round's sums, or after the last round the 2*ncirc bound heads (A_0.., B_0..).
 // The arrays in device memory are NOT updated (nothing reads a layer's arrays after its sumcheck).
+static int32_t cubic_tail_begin_impl(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n, const lasso_fr* r, const EqInline* eqi);
 int32_t lasso_sumcheck_cubic_tail_begin(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n, const lasso_fr* r) {
-  REQUIRE(c, d_A && d_B && d_E && ncirc >= 1 && ncirc <= LASSO_MAX_PTRS && n >= (r ? 4u : 2u) && (n & (n - 1)) == 0 && !c->pending && !c->tail_active && !c->defer_next);
+  REQUIRE(c, d_E);
+  return cubic_tail_begin_impl(c, d_A, d_B, ncirc, d_E, n, r, nullptr);
+}
+static bool make_eq_inline(const lasso_fr* point, uint32_t ell, const lasso_fr* scale, EqInline& Q) {
+  if (ell > 14 || (ell && !point)) return false;
+  for (uint32_t j = 0; j < 14; j++) Q.r[j] = j < ell ? to_fr(point + j) : fr_zero();
+  Q.scale = scale ? to_fr(scale) : fr_one(); Q.ell = ell; return true;
+}
+// The first round of a layer with the layer's eq table  E = *scale * EqPolynomial(point[0..ell)).evals()  (2^ell = n/2 entries) built inside the launch (k_cubic_eqw_lb<2, true>):
+// the same pending result as lasso_sumcheck_cubic_eqw2_begin(.., d_E, n, NULL) after lasso_eq_evals_scaled(point, ell, scale, d_E), and d_E holds the same table afterwards.
+int32_t lasso_sumcheck_cubic_eqw2_begin_eq(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, lasso_fr* d_E_out, size_t n, const lasso_fr* point, uint32_t ell, const lasso_fr* scale) {
+  REQUIRE(c, d_A && d_B && d_E_out && ncirc >= 1 && ncirc <= LASSO_MAX_PTRS && n >= 2 && (n & (n - 1)) == 0 && !c->pending && ((size_t)1 << ell) == n / 2);
+  EqInline Q;
+  if (n / 2 <= CUBIC_SMALL_Q || !make_eq_inline(point, ell, scale, Q)) return fail(c, LASSO_ERR_UNSUPPORTED, "lasso_sumcheck_cubic_eqw2_begin_eq: tables of 2^7 .. 2^14 entries only");
+  uint32_t seq; int32_t rc = cubic_eqw_launch(c, d_A, d_B, ncirc, d_E_out, n, nullptr, 2, &seq, &Q); if (rc) return rc;
+  c->pending = true; c->pending_seq = seq; c->pending_count = (size_t)ncirc * 2;
+  return 0;
+}
+// lasso_sumcheck_cubic_tail_begin(.., r = NULL) without a table: the resident kernel derives E = *scale * EqPolynomial(point[0..ell)).evals(), 2^ell = n/2 <= capacity, itself
+int32_t lasso_sumcheck_cubic_tail_begin_eq(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, size_t n, const lasso_fr* point, uint32_t ell, const lasso_fr* scale) {
+  REQUIRE(c, n >= 2 && ((size_t)1 << ell) == n / 2 && ell <= 9);
+  EqInline Q; if (!make_eq_inline(point, ell, scale, Q)) return fail(c, LASSO_ERR_INVALID, "lasso_sumcheck_cubic_tail_begin_eq: bad point");
+  return cubic_tail_begin_impl(c, d_A, d_B, ncirc, nullptr, n, nullptr, &Q);
+}
+static int32_t cubic_tail_begin_impl(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n, const lasso_fr* r, const EqInline* eqi) {
+  REQUIRE(c, d_A && d_B && (d_E || eqi) && ncirc >= 1 && ncirc <= LASSO_MAX_PTRS && n >= (r ? 4u : 2u) && (n & (n - 1)) == 0 && !c->pending && !c->tail_active && !c->defer_next);
   const size_t q = r ? n / 4 : n / 2;
   REQUIRE(c, q >= 1 && q <= CUBIC_TAIL_Q);
   MutPtrTable A, B; for (uint32_t i = 0; i < ncirc; i++) { REQUIRE(c, d_A[i] && d_B[i]); A.p[i] = (fr_t*)d_A[i]; B.p[i] = (fr_t*)d_B[i]; }
@@ -516,9 +546,10 @@ int32_t lasso_sumcheck_cubic_tail_begin(lasso_ctx* c, lasso_fr* const* d_A, lass
   uint32_t turns = 0; while (((size_t)1 << turns) < 2 * q) turns++;   // rounds of sums; one more publication carries the heads
   const uint32_t seq0 = c->seq + 1; c->seq += turns + 1;
   // workgroup = capacity: 256 threads / 74 KB of LDS up to 256 indices per circuit, 512 threads / 147 KB above
-#define LAUNCH_CTAIL(B_, Q_, R_) hipLaunchKernelGGL((k_cubic_tail<B_, Q_>), dim3(ncirc), dim3(Q_), 0, c->stream, A, B, (const fr_t*)d_E, (uint32_t)q, R_, (const uint32_t*)(c->d_flag + 32), c->d_counters, c->d_small, c->d_flag, seq0)
-  if (q <= 256) { if (r) LAUNCH_CTAIL(true, 256, to_fr(r)); else LAUNCH_CTAIL(false, 256, fr_zero()); }
-  else { if (r) LAUNCH_CTAIL(true, 512, to_fr(r)); else LAUNCH_CTAIL(false, 512, fr_zero()); }
+#define LAUNCH_CTAIL(B_, Q_, I_, R_, EQ_) hipLaunchKernelGGL((k_cubic_tail<B_, Q_, I_>), dim3(ncirc), dim3(Q_), 0, c->stream, A, B, (const fr_t*)d_E, (uint32_t)q, R_, (const uint32_t*)(c->d_flag + 32), c->d_counters, c->d_small, c->d_flag, seq0, EQ_)
+  if (eqi) { if (q <= 256) LAUNCH_CTAIL(false, 256, true, fr_zero(), *eqi); else LAUNCH_CTAIL(false, 512, true, fr_zero(), *eqi); }
+  else if (q <= 256) { if (r) LAUNCH_CTAIL(true, 256, false, to_fr(r), EqInline()); else LAUNCH_CTAIL(false, 256, false, fr_zero(), EqInline()); }
+  else { if (r) LAUNCH_CTAIL(true, 512, false, to_fr(r), EqInline()); else LAUNCH_CTAIL(false, 512, false, fr_zero(), EqInline()); }
   HIPCHK(c, hipGetLastError());
   c->tail_active = true; c->tail_seq0 = seq0; c->tail_turn = 0; c->tail_turns = turns; c->tail_count = (size_t)ncirc * 2; c->tail_final = (size_t)ncirc * 2;
   c->pending = true; c->pending_seq = seq0; c->pending_count = c->tail_count;
@@ -630,9 +661,9 @@ static int32_t combine_round_impl(lasso_ctx* c, const lasso_strategy* s, const l
   rc = ensure_scratch(c, ((size_t)nx * K + copy_elems) * sizeof(fr_t)); if (rc) return rc;
   rc = ensure_small(c, K); if (rc) return rc;
   if (copy_elems) {   // literal form: scaled copies of LT_0 .. LT_{C-2} behind the partials (LT_{C-1} has kappa = 1)
-    fr_t* cp = (fr_t*)c->d_scratch + (size_t)nx * K; MutPtrTable M; LtKappa LK;
-    for (uint32_t m = 0; m + 1 < S.c; m++) { HIPCHK(c, hipMemcpyAsync(cp + (size_t)m * n, d_polys[2 * m], n * sizeof(fr_t), hipMemcpyDeviceToDevice, c->stream)); M.p[2 * m] = cp + (size_t)m * n; P.p[2 * m] = cp + (size_t)m * n; LK.k[m] = lt_pow32(S.c - 1 - m, true); }
-    hipLaunchKernelGGL(k_lt_prescale, dim3(grid_for(n, 1024), S.c - 1), dim3(LASSO_BLOCK), 0, c->stream, M, LK, n);
+    fr_t* cp = (fr_t*)c->d_scratch + (size_t)nx * K; MutPtrTable M; PtrTable Src; LtKappa LK;
+    for (uint32_t m = 0; m + 1 < S.c; m++) { Src.p[2 * m] = (const fr_t*)d_polys[2 * m]; M.p[2 * m] = cp + (size_t)m * n; P.p[2 * m] = cp + (size_t)m * n; LK.k[m] = lt_pow32(S.c - 1 - m, true); }
+    hipLaunchKernelGGL(k_lt_prescale, dim3(grid_for(n, 1024), S.c - 1), dim3(LASSO_BLOCK), 0, c->stream, Src, M, LK, n);
   }
   {
     ProfScope ps(c, LASSO_K_COMBINE, 32.0 * n * (S.alpha + 1.0));
@@ -654,14 +685,16 @@ int32_t lasso_sumcheck_combine_round_lt_scaled(lasso_ctx* c, const lasso_strateg
   REQUIRE(c, s && s->kind == LASSO_LT);
   return combine_round_impl(c, s, d_polys, d_eq, n, degree, out, true);
 }
-int32_t lasso_lt_prescale(lasso_ctx* c, const lasso_strategy* s, lasso_fr* const* d_polys, size_t n) {
+int32_t lasso_lt_prescale(lasso_ctx* c, const lasso_strategy* s, const lasso_fr* const* d_src, lasso_fr* const* d_polys, size_t n) {
   StrategyDev S; WeightTable W; int32_t rc = make_strategy(c, s, S, W); if (rc) return rc;
   REQUIRE(c, s->kind == LASSO_LT && d_polys && n >= 1);
-  if (S.c < 2) return 0;
-  MutPtrTable M; LtKappa LK;
-  for (uint32_t m = 0; m + 1 < S.c; m++) { REQUIRE(c, d_polys[2 * m]); M.p[2 * m] = (fr_t*)d_polys[2 * m]; LK.k[m] = lt_pow32(S.c - 1 - m, true); }
-  ProfScope ps(c, LASSO_K_MISC, 64.0 * n * (S.c - 1));
-  hipLaunchKernelGGL(k_lt_prescale, dim3(grid_for(n, 1024), S.c - 1), dim3(LASSO_BLOCK), 0, c->stream, M, LK, n);
+  MutPtrTable M; PtrTable Src; LtKappa LK;
+  for (uint32_t m = 0; m + 1 < S.c; m++) { REQUIRE(c, d_polys[2 * m] && (!d_src || d_src[2 * m])); M.p[2 * m] = (fr_t*)d_polys[2 * m]; Src.p[2 * m] = d_src ? (const fr_t*)d_src[2 * m] : (const fr_t*)d_polys[2 * m]; LK.k[m] = lt_pow32(S.c - 1 - m, true); }
+  ProfScope ps(c, LASSO_K_MISC, 64.0 * n * (S.c - 1) + (d_src ? 64.0 * n * (S.c + 1) : 0.0));
+  if (S.c >= 2) hipLaunchKernelGGL(k_lt_prescale, dim3(grid_for(n, 1024), S.c - 1), dim3(LASSO_BLOCK), 0, c->stream, Src, M, LK, n);
+  if (d_src) {   // out of place: the polynomials the scaling leaves alone (LT_{C-1} and every EQ_m) are plain copies — together the clone of sumcheck.rs / surge.rs:151
+    for (uint32_t i = 0; i < S.alpha; i++) if ((i & 1u) || i == 2 * (S.c - 1)) { REQUIRE(c, d_src[i] && d_polys[i]); HIPCHK(c, hipMemcpyAsync(d_polys[i], d_src[i], n * sizeof(fr_t), hipMemcpyDeviceToDevice, c->stream)); }
+  }
   HIPCHK(c, hipGetLastError()); return 0;
 }
 int32_t lasso_combine_claim(lasso_ctx* c, const lasso_strategy* s, const lasso_fr* const* d_polys, const lasso_fr* d_eq, size_t n, lasso_fr* out) {
@@ -890,6 +923,7 @@ void lasso_bases_destroy(lasso_ctx* c, lasso_bases* b) {
 static bool msm_rows8_enabled() { static const bool on = [] { const char* v = getenv("LASSO_MSM_ROWS8"); return !(v && v[0] == '0'); }(); return on; }
 static const niels29* ensure_tab8(lasso_ctx* c, const lasso_bases* cb, uint32_t w8) {
   lasso_bases* b = const_cast<lasso_bases*>(cb);
+  std::lock_guard<std::mutex> lock(b->tab8_mu);   // one builder at a time; the pointer is published only after the build has been waited for (below)
   if (b->d_tab8[w8]) return b->d_tab8[w8];
   if (b->tab8_failed) return nullptr;
   niels29* t = nullptr;

@@ -238,12 +238,41 @@ __device__ __forceinline__ void cubic_eqw_terms2(const fr29& a0, const fr29& a1,
     e[0] = fr29_weak(fr29_add(e[0], t0)); e[1] = fr29_weak(fr29_add(e[1], t1));                                     \
     if ((++cnt & 127u) == 0) { e[0] = fr29_mul(e[0], fr29_one_s()); e[1] = fr29_mul(e[1], fr29_one_s()); }          \
   } while (0)
+// The layer's eq table built INSIDE the first round's launch (round 3).  Every grand-product layer starts with  E = scale * EqPolynomial(point).evals()  and only then its
+// round 0; as launches of their own the table kernels sit on the proof's critical path 40 times (0.9 ms at the headline: launch-bound, profiles/r03_kernel_trace_one_proof_2p24.csv).
+// For tables of up to 2^14 entries every workgroup of the round's launch rebuilds the two FACTOR tables of eq_poly.rs:44-52's split — hi over the first ceil(ell/2)
+// coordinates (scale folded in), lo over the rest, at most 128 entries each: one lane per entry, a chain of <= 7 products, ~3 us — in LDS, and an entry of E costs one product
+// E[x] = hi[x >> lo_bits] * lo[x & mask] where it is used.  hi and lo are kept in s-form (their product is the s-form operand the round needs); lo also in u-form, so that the
+// workgroups of circuit 0 can write E[x] = hi * lo_u to memory in the canonical bytes k_eq_small / k_eq_outer produce — the later rounds of the layer read its prefix.
+struct EqInline { fr_t r[14]; fr_t scale; uint32_t ell; };
+struct EqInlineTables { fr29 hi_s[128], lo_s[128], lo_u[128]; };
+__device__ __forceinline__ void eq_inline_build(const EqInline& Q, EqInlineTables& T) {   // all threads of the workgroup; ends with a barrier
+  const uint32_t t = threadIdx.x, lb = Q.ell / 2, hb = Q.ell - lb;
+  const fr29 one_s = fr29_one_s();
+  if (t < (1u << hb)) {
+    fr29 p = fr29_unpack_s(Q.scale);
+    for (uint32_t j = 0; j < hb; j++) { const bool bit = (t >> (hb - 1 - j)) & 1u; const fr29 rs = fr29_unpack_s(Q.r[j]); p = fr29_mul(bit ? rs : fr29_sub(one_s, rs), p); }
+    T.hi_s[t] = p;
+  } else if (t >= 128 && t - 128 < (1u << lb)) {
+    const uint32_t x = t - 128;
+    fr29 p = one_s;
+    for (uint32_t j = 0; j < lb; j++) { const bool bit = (x >> (lb - 1 - j)) & 1u; const fr29 rs = fr29_unpack_s(Q.r[hb + j]); p = fr29_mul(bit ? rs : fr29_sub(one_s, rs), p); }
+    T.lo_s[x] = p;
+    T.lo_u[x] = fr29_mul(p, fr29_unpack_u(fr_one()));   // s-form times the integer 2^256: the same value in u-form
+  }
+  __syncthreads();
+}
+__device__ __forceinline__ fr29 eq_inline_s(const EqInlineTables& T, uint32_t lb, size_t x) { return fr29_mul(T.hi_s[x >> lb], T.lo_s[x & ((1u << lb) - 1u)]); }
 // out[c*NT + ..] = the NT sums over i < half of circuit c.  1-D grid of nx*ny workgroups (cubic_grid).
-template <int NT>
+// EQI: E is built on the way (eq_inline_build): E_out (half entries) is written by the workgroups of circuit 0, nothing is read from it.
+template <int NT, bool EQI = false>
 __global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_eqw_lb(PtrTable A, PtrTable B, uint32_t nx, uint32_t ny, const fr_t* __restrict__ E, size_t half, fr_t* __restrict__ partials, uint32_t* counters,
-                                                               fr_t* __restrict__ out, uint32_t* flag, uint32_t seq, uint32_t pipeline) {
+                                                               fr_t* __restrict__ out, uint32_t* flag, uint32_t seq, uint32_t pipeline, EqInline EQ = EqInline(), fr_t* __restrict__ E_out = nullptr) {
   __shared__ RedScratch S;
+  __shared__ EqInlineTables ET;
   const CubicGrid g = cubic_grid(nx, ny);
+  const uint32_t elb = EQ.ell / 2;
+  if (EQI) eq_inline_build(EQ, ET);
   const fr_t* __restrict__ a = A.p[g.by];
   const fr_t* __restrict__ b = B.p[g.by];
   fr29 e[3] = {fr29_zero(), fr29_zero(), fr29_zero()}; uint32_t cnt = 0;
@@ -266,12 +295,17 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_eqw_lb(PtrTable A, PtrTab
     // software-pipelined: the five 32-byte loads of the NEXT index are in flight while this one's four products issue.  The round reads and never writes, its
     // ~900 instructions per index are too few to hide a ~2 us HBM access behind two waves per SIMD, and the compiler keeps the loads at the head of the loop
     // body: measured 3.6 TB/s of reads (1.07 GB in 316 us at the 2^24 top layer) where a read stream reaches 6.
-    fr_t a0 = a[i], a1 = a[i + half], b0m = b[i], b1m = b[i + half], em = E[i];
+    fr_t a0 = a[i], a1 = a[i + half], b0m = b[i], b1m = b[i + half], em = EQI ? fr_zero() : E[i];
     for (;;) {
       const size_t in = i + stride; const bool more = in < half;
       const size_t ip = more ? in : i;     // clamp: the last iteration re-reads its own (cached) lines instead of branching around the loads
-      const fr_t na0 = a[ip], na1 = a[ip + half], nb0 = b[ip], nb1 = b[ip + half], ne = E[ip];
-      const fr29 es = fr29_unpack_s(em), b0 = fr29_unpack_u(b0m), b1 = fr29_unpack_u(b1m);
+      const fr_t na0 = a[ip], na1 = a[ip + half], nb0 = b[ip], nb1 = b[ip + half], ne = EQI ? fr_zero() : E[ip];
+      fr29 es;
+      if (EQI) {
+        es = eq_inline_s(ET, elb, i);
+        if (g.by == 0) E_out[i] = fr29_store(fr29_mul(ET.hi_s[i >> elb], ET.lo_u[i & ((1u << elb) - 1u)]));
+      } else es = fr29_unpack_s(em);
+      const fr29 b0 = fr29_unpack_u(b0m), b1 = fr29_unpack_u(b1m);
       const fr29 g0 = fr29_mul(fr29_unpack_u(a0), es), g1 = fr29_mul(fr29_unpack_u(a1), es);
       fr29_mul_acc(w0, b0, g0); fr29_mul_acc(w1, fr29_sub(g1, g0), fr29_sub(b1, b0));
       if (++cnt == 3) { fr29_acc_carry(w0); fr29_acc_carry(w1); cnt = 0; }
@@ -383,9 +417,20 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_eqw_small(MutPtrTable A, 
 // Q = capacity in indices per circuit = threads of the workgroup: 256 (74 KB of LDS) or, since round 3, 512 (147 KB of the CU's 160 KB: one streaming round fewer per layer —
 // a resident turn costs ~10 us where a launch-per-round costs ~25 us at these sizes, profiles/r03_kernel_trace_one_proof_2p24.csv)
 #define CUBIC_TAIL_Q 512   // the resident kernels take over at <= this many indices per circuit
-template <bool BIND, int Q>
+// EQI (first round of a layer only): the eq table is never materialised — the two factor tables are built in LDS (eq_inline_build, <= 32 entries each at q <= 512) and
+// every use of E[i] is one product.
+template <bool BIND, int Q, bool EQI = false>
 __global__ void __launch_bounds__(Q) k_cubic_tail(MutPtrTable A, MutPtrTable B, const fr_t* __restrict__ E, uint32_t q, fr_t r0, const uint32_t* mailbox, uint32_t* counters,
-                                                             fr_t* __restrict__ out, uint32_t* flag, uint32_t seq0) {
+                                                             fr_t* __restrict__ out, uint32_t* flag, uint32_t seq0, EqInline EQ = EqInline()) {
+  __shared__ fr29 eq_hi[EQI ? 32 : 1], eq_lo[EQI ? 32 : 1];
+  const uint32_t elb = EQ.ell / 2;
+  if (EQI) {   // ell = log2 q <= 9: hi over the first ceil(ell/2) coordinates (scale folded in), lo over the rest, both s-form
+    const uint32_t tt = threadIdx.x, hb = EQ.ell - elb; const fr29 one_s = fr29_one_s();
+    if (tt < (1u << hb)) { fr29 p = fr29_unpack_s(EQ.scale); for (uint32_t j = 0; j < hb; j++) { const bool bit = (tt >> (hb - 1 - j)) & 1u; const fr29 rs = fr29_unpack_s(EQ.r[j]); p = fr29_mul(bit ? rs : fr29_sub(one_s, rs), p); } eq_hi[tt] = p; }
+    else if (tt >= 64 && tt - 64 < (1u << elb)) { const uint32_t x = tt - 64; fr29 p = one_s; for (uint32_t j = 0; j < elb; j++) { const bool bit = (x >> (elb - 1 - j)) & 1u; const fr29 rs = fr29_unpack_s(EQ.r[hb + j]); p = fr29_mul(bit ? rs : fr29_sub(one_s, rs), p); } eq_lo[x] = p; }
+    __syncthreads();
+  }
+#define TAIL_EQ_S(idx) (EQI ? fr29_mul(eq_hi[(idx) >> elb], eq_lo[(idx) & ((1u << elb) - 1u)]) : fr29_unpack_s(E[(idx)]))
   __shared__ fr29 bound[2][2 * Q];   // A', B' (m values each)
   __shared__ fr29 ge[2 * Q];         // A'[i] * E[i mod h]
   __shared__ int32_t rows[2 * Q * 9];
@@ -404,7 +449,7 @@ __global__ void __launch_bounds__(Q) k_cubic_tail(MutPtrTable A, MutPtrTable B, 
       const fr_t* src = p == 0 ? A.p[y] : B.p[y];
       const fr29 v = BIND ? bind29(src[i], src[i + m], rs) : fr29_unpack_u(src[i]);
       bound[p][i] = v;
-      if (p == 0) ge[i] = fr29_mul(v, fr29_unpack_s(E[i < q ? i : i - q]));
+      if (p == 0) ge[i] = fr29_mul(v, TAIL_EQ_S(i < q ? i : i - q));
     }
   }
   __syncthreads();
@@ -473,7 +518,7 @@ __global__ void __launch_bounds__(Q) k_cubic_tail(MutPtrTable A, MutPtrTable B, 
       if (u < 2 * h) {
         const uint32_t p = u >= h ? 1u : 0u, jx = u - p * h;
         nb[pass] = fr29_canonical(fr29_add(bound[p][jx], fr29_mul(fr29_sub(bound[p][jx + h], bound[p][jx]), rs)));
-        if (p == 0 && h > 1) ng[pass] = fr29_mul(nb[pass], fr29_unpack_s(E[jx < hn ? jx : jx - hn]));
+        if (p == 0 && h > 1) ng[pass] = fr29_mul(nb[pass], TAIL_EQ_S(jx < hn ? jx : jx - hn));
       }
     }
     __syncthreads();
@@ -492,6 +537,7 @@ __global__ void __launch_bounds__(Q) k_cubic_tail(MutPtrTable A, MutPtrTable B, 
   }
 }
 
+#undef TAIL_EQ_S
 // ------------------------------------------------------------------ K3 in eq-weighted form for the linear strategies (AND / OR / XOR / RangeCheck)
 // prove_arbitrary's comb_func is g(E_1..E_alpha) * eq with g = sum_k w_k E_k LINEAR (and.rs:45-53, range_check.rs:78-86) and eq = EqPolynomial(r).evals()
 // (surge.rs:156-172).  With the eq polynomial factored as in the cubic rounds (prefix of the one table + host scalars) a round needs, per polynomial k,
@@ -708,10 +754,10 @@ __device__ __forceinline__ fr29 lt_weighted_acc(const fr29& sum, const fr29& e, 
 }
 // LT_m <- 32^-(C-1-m) LT_m for the memories 2m of an LT strategy (kappa in memory form, s-form at use: mul(u, s) = u-form); grid = (blocks over i, C - 1): m = C - 1 has kappa = 1
 struct LtKappa { fr_t k[LASSO_MAX_ALPHA / 2]; };
-__global__ void __launch_bounds__(LASSO_BLOCK) k_lt_prescale(MutPtrTable polys, LtKappa K, size_t n) {
-  const uint32_t m = blockIdx.y; fr_t* __restrict__ z = polys.p[2 * m];
+__global__ void __launch_bounds__(LASSO_BLOCK) k_lt_prescale(PtrTable src, MutPtrTable polys, LtKappa K, size_t n) {   // src[2m] may be polys[2m] (in place)
+  const uint32_t m = blockIdx.y; fr_t* z = polys.p[2 * m]; const fr_t* x = src.p[2 * m];
   const fr29 ks = fr29_unpack_s(K.k[m]);
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) z[i] = fr29_store(fr29_mul(fr29_unpack_u(z[i]), ks));
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) z[i] = fr29_store(fr29_mul(fr29_unpack_u(x[i]), ks));
 }
 template <int A, int D, int T>
 __global__ void __launch_bounds__(LASSO_BLOCK) k_combine_round_lt(StrategyDev S, PtrTable polys, const fr_t* __restrict__ eq, fr_t scale, size_t half, uint32_t degree, fr_t* __restrict__ partials) {

@@ -140,6 +140,34 @@ class Device:
         self._chk(self.lib.lasso_result_wait(self.ctx, _vp(out), 2 * len(a_ptrs)))
         return out
 
+    def sumcheck_cubic_eqw2_eq(self, a_ptrs, b_ptrs, d_e_out, n, point, scale=None):
+        """first round of a layer with the eq table (scale * eq(point), n/2 entries) built inside the launch and left in d_e_out (lasso_sumcheck_cubic_eqw2_begin_eq)"""
+        point = np.ascontiguousarray(point, dtype=np.uint64).reshape(-1, 4)
+        sp = None if scale is None else _vp(np.ascontiguousarray(scale, dtype=np.uint64))
+        out = np.empty((2 * len(a_ptrs), 4), dtype=np.uint64)
+        self._chk(self.lib.lasso_sumcheck_cubic_eqw2_begin_eq(self.ctx, self._ptrs(a_ptrs), self._ptrs(b_ptrs), len(a_ptrs), C.c_void_p(d_e_out), n, _vp(point), point.shape[0], sp))
+        self._chk(self.lib.lasso_result_wait(self.ctx, _vp(out), 2 * len(a_ptrs)))
+        return out
+
+    def sumcheck_cubic_tail_eq(self, a_ptrs, b_ptrs, n, point, scale, challenges):
+        """resident tail from a layer's first round on, eq table derived in the kernel (lasso_sumcheck_cubic_tail_begin_eq)"""
+        k = len(a_ptrs)
+        point = np.ascontiguousarray(point, dtype=np.uint64).reshape(-1, 4)
+        sp = None if scale is None else _vp(np.ascontiguousarray(scale, dtype=np.uint64))
+        outs = []
+        self._chk(self.lib.lasso_sumcheck_cubic_tail_begin_eq(self.ctx, self._ptrs(a_ptrs), self._ptrs(b_ptrs), k, n, _vp(point) if point.shape[0] else None, point.shape[0], sp))
+        out = np.empty((2 * k, 4), dtype=np.uint64); self._chk(self.lib.lasso_result_wait(self.ctx, _vp(out), 2 * k)); outs.append(out)
+        for ch in challenges:
+            ch = np.ascontiguousarray(ch, dtype=np.uint64)
+            self._chk(self.lib.lasso_sumcheck_cubic_tail_next(self.ctx, _vp(ch)))
+            out = np.empty((2 * k, 4), dtype=np.uint64); self._chk(self.lib.lasso_result_wait(self.ctx, _vp(out), 2 * k)); outs.append(out)
+        return outs
+
+    def eq_evals_scaled(self, r, scale, d_out):
+        r = np.ascontiguousarray(r, dtype=np.uint64).reshape(-1, 4)
+        sp = None if scale is None else _vp(np.ascontiguousarray(scale, dtype=np.uint64))
+        self._chk(self.lib.lasso_eq_evals_scaled(self.ctx, _vp(r) if r.shape[0] else None, r.shape[0], sp, C.c_void_p(d_out)))
+
     def sumcheck_cubic_tail(self, a_ptrs, b_ptrs, d_e, n, r, challenges):
         """resident tail kernel (lasso_sumcheck_cubic_tail_begin / _next): returns the list of per-round (2k, 4) results, the last entry being the heads"""
         k = len(a_ptrs)
@@ -173,9 +201,9 @@ class Device:
         self._chk(self.lib.lasso_sumcheck_combine_round(self.ctx, C.byref(strategy), self._ptrs(ptrs), C.c_void_p(d_eq), n, degree, _vp(out)))
         return out
 
-    def lt_prescale(self, strategy, ptrs, n):
-        """LT_m <- 32^-(C-1-m) LT_m in place (the form lasso_sumcheck_combine_round_lt_scaled takes)"""
-        self._chk(self.lib.lasso_lt_prescale(self.ctx, C.byref(strategy), self._ptrs(ptrs), n))
+    def lt_prescale(self, strategy, ptrs, n, src=None):
+        """LT_m <- 32^-(C-1-m) LT_m (the form lasso_sumcheck_combine_round_lt_scaled takes); src: read from there instead (all 2C polynomials land in ptrs)"""
+        self._chk(self.lib.lasso_lt_prescale(self.ctx, C.byref(strategy), None if src is None else self._ptrs(src), self._ptrs(ptrs), n))
 
     def sumcheck_combine_round_lt_scaled(self, strategy, ptrs, d_eq, n, degree):
         out = np.empty((degree + 1, 4), dtype=np.uint64)

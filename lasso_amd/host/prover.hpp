@@ -538,6 +538,10 @@ class Prover {
   std::vector<DBuf> tail_bufs;       // P-element replicated arrays of the current sumcheck's tail
   std::vector<DBuf> side_keep;       // inputs of work in flight on the side context (released after lasso_sync(side))
   static size_t tail_q() { static const size_t q = lasso_sumcheck_tail_capacity(); return q; }
+  // A grand-product layer's eq table, not built yet: cubic_rounds builds it INSIDE the first round's launch when the sizes allow (lasso_sumcheck_cubic_eqw2_begin_eq /
+  // lasso_sumcheck_cubic_tail_begin_eq) and with lasso_eq_evals_scaled otherwise.  Set by bgpa_prove for the layer's first phase, consumed by cubic_rounds.
+  struct LazyEq { bool on = false; std::vector<lasso_fr> rr; lasso_fr scale; lasso_fr* d_table = nullptr; } lazy_eq;
+  static bool eq_inline_off() { static const bool v = [] { const char* e = getenv("LASSO_EQ_INLINE"); return e && e[0] == '0'; }(); return v; }
   static bool side_off() { static const bool v = [] { const char* e = getenv("LASSO_SIDE_STREAM"); return e && e[0] == '0'; }(); return v; }
 
  public:
@@ -566,6 +570,15 @@ class Prover {
     Sc scale = Sc::one() - point[0]; if (P > 1) scale *= d.comm.eq_low(point);
     lasso_fr sc = scale.abi();
     d.chk(lasso_eq_evals_scaled(d.ctx, rr.data(), (uint32_t)rr.size(), &sc, d_out), "lasso_eq_evals_scaled");
+  }
+  // the same table as a specification instead of a launch (consumed by cubic_rounds, see LazyEq)
+  void eq_half_lazy(const ScVec& point, lasso_fr* d_out) {
+    LASSO_REQUIRE(point.size() >= lgP);
+    lazy_eq.on = false;
+    if (point.size() == lgP) return;
+    lazy_eq.rr.clear(); for (size_t i = 1; i + lgP < point.size(); i++) lazy_eq.rr.push_back(point[i].abi());
+    Sc scale = Sc::one() - point[0]; if (P > 1) scale *= d.comm.eq_low(point);
+    lazy_eq.scale = scale.abi(); lazy_eq.d_table = d_out; lazy_eq.on = true;
   }
   // local arrays are down to ONE element each: all-gather them into P-element replicated arrays (index = rank = the remaining low variables)
   std::vector<lasso_fr*> gather_tail(const std::vector<lasso_fr*>& polys) {
@@ -720,7 +733,8 @@ class Prover {
       tail_bufs.clear();
       return proof;
     }
-    d.chk(lasso_lt_prescale(d.ctx, &S.abi, polys.data(), len_loc), "lasso_lt_prescale");   // the caller's clones, once (slab mode: the local arrays; the replicated tails are gathered from them)
+    // the caller's work arrays, once (slab mode: the local arrays; the replicated tails are gathered from them).  With src the call also IS the clone of the lookup polynomials
+    d.chk(lasso_lt_prescale(d.ctx, &S.abi, src ? src->data() : nullptr, polys.data(), len_loc), "lasso_lt_prescale");
     if (P == 1) { arbitrary_rounds(num_rounds, len_loc, polys, combined_degree, false, proof, r_out); read_heads(polys); return proof; }
     LASSO_REQUIRE(num_rounds >= lgP && ((size_t)1 << (num_rounds - lgP)) == len_loc);
     arbitrary_rounds(num_rounds - lgP, len_loc, polys, combined_degree, true, proof, r_out);
@@ -752,6 +766,10 @@ class Prover {
     }
     DBuf tj; if (degenerate) tj = DBuf(d, len / 2);
     Sc r_prev = Sc::zero();
+    // the layer's eq table may still be a specification (eq_half_lazy): it is built inside round 0's launch where that exists, by its own kernels otherwise
+    LazyEq lz; if (lazy_eq.on && lazy_eq.d_table == d_E && v0 == 0) { lz = lazy_eq; } lazy_eq.on = false;
+    auto ensure_table = [&] { if (lz.on) { d.chk(lasso_eq_evals_scaled(d.ctx, lz.rr.data(), (uint32_t)lz.rr.size(), &lz.scale, lz.d_table), "lasso_eq_evals_scaled"); lz.on = false; } };
+    if (degenerate) lz.on = false;   // the explicit per-round tables below replace it
     // The last rounds of the phase (<= 256 indices per circuit) are served by ONE resident kernel (lasso_sumcheck_cubic_tail_*): no launch per
     // round, the bound arrays stay on chip, and the final bind + heads come back from it.  Not when a collective sits between the rounds
     // (slab-local phase), nor when one of the remaining eq coordinates is 0 or 1 (the per-round paths handle those).
@@ -782,9 +800,17 @@ class Prover {
         // two sums per circuit, q_c(0) and the leading coefficient; q(1) follows from the claim e = e(0) + e(1) (sumcheck.rs:99-104 derives e(1)
         // the same way) and q(2), q(3) by extrapolation.  The inversion of f(1) overlaps the kernel.
         lasso_fr rp = r_prev.abi();
-        if (j < tail_from) d.chk(lasso_sumcheck_cubic_eqw2_begin(d.ctx, A.data(), B.data(), (uint32_t)k, table, len, j == 0 ? nullptr : &rp), "lasso_sumcheck_cubic_eqw2_begin");
-        else if (!in_tail) { d.chk(lasso_sumcheck_cubic_tail_begin(d.ctx, A.data(), B.data(), (uint32_t)k, table, len, j == 0 ? nullptr : &rp), "lasso_sumcheck_cubic_tail_begin"); in_tail = true; }
-        else d.chk(lasso_sumcheck_cubic_tail_next(d.ctx, &rp), "lasso_sumcheck_cubic_tail_next");
+        const uint32_t ell = (uint32_t)lz.rr.size();   // table of 2^ell = len / 2 entries
+        if (j == 0 && lz.on && j < tail_from && ell <= 14 && len / 2 > 64) {   // round 0 of a streaming layer: the table is built in this launch and left in d_E for the later rounds
+          d.chk(lasso_sumcheck_cubic_eqw2_begin_eq(d.ctx, A.data(), B.data(), (uint32_t)k, lz.d_table, len, lz.rr.data(), ell, &lz.scale), "lasso_sumcheck_cubic_eqw2_begin_eq"); lz.on = false;
+        } else if (j == 0 && lz.on && j >= tail_from && ell <= 9) {            // the whole layer runs in the resident kernel: no table at all
+          d.chk(lasso_sumcheck_cubic_tail_begin_eq(d.ctx, A.data(), B.data(), (uint32_t)k, len, lz.rr.data(), ell, &lz.scale), "lasso_sumcheck_cubic_tail_begin_eq"); in_tail = true; lz.on = false;
+        } else {
+          ensure_table();
+          if (j < tail_from) d.chk(lasso_sumcheck_cubic_eqw2_begin(d.ctx, A.data(), B.data(), (uint32_t)k, table, len, j == 0 ? nullptr : &rp), "lasso_sumcheck_cubic_eqw2_begin");
+          else if (!in_tail) { d.chk(lasso_sumcheck_cubic_tail_begin(d.ctx, A.data(), B.data(), (uint32_t)k, table, len, j == 0 ? nullptr : &rp), "lasso_sumcheck_cubic_tail_begin"); in_tail = true; }
+          else d.chk(lasso_sumcheck_cubic_tail_next(d.ctx, &rp), "lasso_sumcheck_cubic_tail_next");
+        }
         if (j) len /= 2;
         // f(1) = 0 inside the tail can only come from a vanished running factor s (probability 2^-252): then f = 0 identically and q is irrelevant
         const Sc f1_inv = f1.is_zero() ? Sc::zero() : f1.inverse();
@@ -801,6 +827,7 @@ class Prover {
         poly.coeffs = {c0, f0 * ql + df * q0, f0 * qi + df * ql, df * qi};
       } else {   // rand_j = 0 (or a zero running factor): the claim says nothing about q(1); three sums from the device
         std::vector<lasso_fr> ev(3 * k);
+        ensure_table();
         if (j == 0) {
           d.chk(lasso_sumcheck_cubic_eqw_round(d.ctx, (const lasso_fr* const*)A.data(), (const lasso_fr* const*)B.data(), (uint32_t)k, table, len, ev.data()), "lasso_sumcheck_cubic_eqw_round");
         } else {
@@ -884,7 +911,7 @@ class Prover {
       if (slab || P == 1) {
         const size_t len_l = len / P, off = 2 * n_loc - 2 * len_l;
         for (auto* tr : trees) { A.push_back(tr + off); B.push_back(tr + off + len_l / 2); }
-        eq_half_local(rand, eq.p);                                                              // poly_C_par :122 (the half the rounds read)
+        if (eq_inline_off()) eq_half_local(rand, eq.p); else eq_half_lazy(rand, eq.p);        // poly_C_par :122 (the half the rounds read), built inside round 0's launch where possible
       } else {
         const size_t off = 2 * P - 2 * len;
         for (auto* tp : tops) { A.push_back(tp + off); B.push_back(tp + off + len / 2); }
@@ -1180,9 +1207,9 @@ class Prover {
       const bool no_clone = S.linear();
       const size_t wl = no_clone && s_loc >= 4 ? s_loc / 2 : s_loc;   // fewer than two local rounds: linear_rounds copies the (tiny) arrays instead
       DBuf work(d, alpha * wl);
-      if (!no_clone) d.chk(lasso_copy(d.ctx, work.p, combined_E.p, alpha * s_loc * sizeof(lasso_fr)), "lasso_copy");
+      // LT: the clone of surge.rs:151 and the scaling of the LT memories are one pass (lasso_lt_prescale with a source): E itself is only read
       std::vector<lasso_fr*> polys; for (size_t i = 0; i < alpha; i++) polys.push_back(work.p + i * wl); polys.push_back(eq.p);
-      SumcheckProof sp = prove_arbitrary(ceil_log2(s), s_loc, polys, S.sumcheck_poly_degree(), r, r_z, &sumcheck_heads, no_clone ? &Eptr : nullptr);
+      SumcheckProof sp = prove_arbitrary(ceil_log2(s), s_loc, polys, S.sumcheck_poly_degree(), r, r_z, &sumcheck_heads, &Eptr);
       sp.write(W);
     }
     W.sc(claimed_eval);

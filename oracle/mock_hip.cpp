@@ -198,6 +198,21 @@ static void tail_bind(lasso_ctx* c, const Fr& r) {
   for (auto* arrs : {&c->tail_a, &c->tail_b}) for (auto& v : *arrs) { const size_t h = v.size() / 2; for (size_t i = 0; i < h; i++) v[i] = v[i] + r * (v[i + h] - v[i]); v.resize(h); }
 }
 uint32_t lasso_sumcheck_tail_capacity(void) { return 512; }
+int32_t lasso_sumcheck_cubic_eqw2_begin(lasso_ctx* c, lasso_fr* const* A, lasso_fr* const* B, uint32_t nc, const lasso_fr* E, size_t n, const lasso_fr* r);
+int32_t lasso_sumcheck_cubic_tail_begin(lasso_ctx* c, lasso_fr* const* A, lasso_fr* const* B, uint32_t nc, const lasso_fr* E, size_t n, const lasso_fr* r);
+// the first round of a layer with the eq table built on the way: here simply the table, then the plain call
+int32_t lasso_sumcheck_cubic_eqw2_begin_eq(lasso_ctx* c, lasso_fr* const* A, lasso_fr* const* B, uint32_t nc, lasso_fr* E_out, size_t n, const lasso_fr* point, uint32_t ell, const lasso_fr* scale) {
+  REQ(c, E_out && n >= 2 && ((size_t)1 << ell) == n / 2);
+  if (ell > 14 || n / 2 <= 64) { c->err = "unsupported table size"; return LASSO_ERR_UNSUPPORTED; }
+  int32_t rc = lasso_eq_evals_scaled(c, point, ell, scale, E_out); if (rc) return rc;
+  return lasso_sumcheck_cubic_eqw2_begin(c, A, B, nc, E_out, n, nullptr);
+}
+int32_t lasso_sumcheck_cubic_tail_begin_eq(lasso_ctx* c, lasso_fr* const* A, lasso_fr* const* B, uint32_t nc, size_t n, const lasso_fr* point, uint32_t ell, const lasso_fr* scale) {
+  REQ(c, n >= 2 && ((size_t)1 << ell) == n / 2 && ell <= 9);
+  std::vector<lasso_fr> E((size_t)1 << ell);
+  int32_t rc = lasso_eq_evals_scaled(c, point, ell, scale, E.data()); if (rc) return rc;
+  return lasso_sumcheck_cubic_tail_begin(c, A, B, nc, E.data(), n, nullptr);
+}
 int32_t lasso_sumcheck_cubic_tail_begin(lasso_ctx* c, lasso_fr* const* A, lasso_fr* const* B, uint32_t nc, const lasso_fr* E, size_t n, const lasso_fr* r) {
   REQ(c, n >= (r ? 4u : 2u) && (n & (n - 1)) == 0 && c->tail_a.empty() && c->pending.empty());
   const size_t q = r ? n / 4 : n / 2; REQ(c, q >= 1 && q <= 512);
@@ -240,8 +255,9 @@ int32_t lasso_sumcheck_combine_round(lasso_ctx* c, const lasso_strategy* s, cons
 }
 // LT_m <- 32^-(C-1-m) LT_m (include/lasso_hip.h); the scaled round = the literal round on unscaled copies
 static Fr pow32(size_t e, bool inverse) { Fr b = Fr::from_u64(32); if (inverse) b = b.inverse(); Fr r = Fr::one(); for (size_t i = 0; i < e; i++) r = r * b; return r; }
-int32_t lasso_lt_prescale(lasso_ctx* c, const lasso_strategy* s, lasso_fr* const* polys, size_t n) {
+int32_t lasso_lt_prescale(lasso_ctx* c, const lasso_strategy* s, const lasso_fr* const* src, lasso_fr* const* polys, size_t n) {
   REQ(c, s && s->kind == LASSO_LT && polys && n >= 1);
+  if (src) for (size_t i = 0; i < 2 * (size_t)s->c; i++) if (src[i] != polys[i]) memcpy(polys[i], src[i], n * sizeof(lasso_fr));
   for (size_t m = 0; m + 1 < s->c; m++) { const Fr k = pow32(s->c - 1 - m, true); for (size_t i = 0; i < n; i++) F(polys[2 * m])[i] = F(polys[2 * m])[i] * k; }
   return 0;
 }

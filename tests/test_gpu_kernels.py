@@ -146,10 +146,14 @@ def test_lt_round_prescaled_horner(devs, c, n):
     def run(d):
         pp = [d.upload(x) for x in polys]; pe = d.upload(eq)
         literal = d.sumcheck_combine_round(S, pp, pe, n, c + 1)
-        d.lt_prescale(S, pp, n)
+        qq = [d.alloc(32 * n) for _ in pp]
+        d.lt_prescale(S, qq, n, src=pp)          # out of place: clone + scaling in one pass; the sources stay as they were
+        assert all(np.array_equal(d.download(p, (n, 4)), x) for p, x in zip(pp, polys))
+        d.lt_prescale(S, pp, n)                  # in place
         scaled = d.sumcheck_combine_round_lt_scaled(S, pp, pe, n, c + 1)
         arrays = [d.download(p, (n, 4)) for p in pp]
-        for p in pp + [pe]:
+        assert all(np.array_equal(d.download(q, (n, 4)), a) for q, a in zip(qq, arrays))
+        for p in pp + qq + [pe]:
             d.free(p)
         return literal, scaled, arrays
     (l1, s1, a1), (l2, s2, a2) = both(devs, run)
@@ -629,6 +633,57 @@ def test_abort_releases_a_waiting_tail_kernel(devs):
         assert np.array_equal(x, y)
     for p in pa + pb + [pe]:
         d.free(p)
+
+
+@pytest.mark.parametrize("n,ncirc,scaled", [(256, 2, False), (512, 3, True), (1 << 12, 2, False), (1 << 14, 2, True), (1 << 15, 5, False), (1 << 15, 16, True)])
+def test_sumcheck_cubic_round0_with_inline_eq_table(devs, n, ncirc, scaled):
+    """lasso_sumcheck_cubic_eqw2_begin_eq: the first round of a layer with the layer's eq table built inside the launch == lasso_eq_evals_scaled followed by the plain
+    first round — same two sums per circuit AND the same table bytes left behind for the later rounds (real library and the oracle's mock)"""
+    rng = np.random.default_rng(n + ncirc)
+    A = [rand_fr(rng, n) for _ in range(ncirc)]; B = [rand_fr(rng, n) for _ in range(ncirc)]
+    ell = (n // 2).bit_length() - 1
+    point = rand_fr(rng, max(ell, 1), edge=False)[:ell]
+    scale = rand_fr(rng, 1, edge=False)[0] if scaled else None
+
+    def run(d):
+        pa = [d.upload(x) for x in A]; pb = [d.upload(x) for x in B]
+        e1 = d.alloc(32 * (n // 2)); e2 = d.alloc(32 * (n // 2))
+        inline = d.sumcheck_cubic_eqw2_eq(pa, pb, e1, n, point, scale)
+        t1 = d.download(e1, (n // 2, 4))
+        d.eq_evals_scaled(point, scale, e2)
+        plain = d.sumcheck_cubic_eqw2(pa, pb, e2, n)
+        t2 = d.download(e2, (n // 2, 4))
+        for p in pa + pb + [e1, e2]:
+            d.free(p)
+        return inline, plain, t1, t2
+    (i1, p1, t1, u1), (i2, p2, t2, u2) = both(devs, run)
+    assert np.array_equal(i1, p1) and np.array_equal(i1, i2) and np.array_equal(p1, p2)
+    assert np.array_equal(t1, u1) and np.array_equal(t1, t2)
+
+
+@pytest.mark.parametrize("n,ncirc,scaled", [(2, 1, False), (4, 2, True), (64, 3, False), (512, 2, True), (1024, 2, False), (1024, 33, True)])
+def test_sumcheck_cubic_tail_with_inline_eq_table(devs, n, ncirc, scaled):
+    """lasso_sumcheck_cubic_tail_begin_eq (no table: the resident kernel derives the eq factors from the point) == the tail over a table built by lasso_eq_evals_scaled"""
+    rng = np.random.default_rng(n * 3 + ncirc)
+    A = [rand_fr(rng, n) for _ in range(ncirc)]; B = [rand_fr(rng, n) for _ in range(ncirc)]
+    q = n // 2; ell = q.bit_length() - 1
+    point = rand_fr(rng, max(ell, 1), edge=False)[:ell]
+    scale = rand_fr(rng, 1, edge=False)[0] if scaled else None
+    turns = (2 * q).bit_length() - 1
+    chal = rand_fr(rng, turns, edge=False)
+
+    def run(d):
+        pa = [d.upload(x) for x in A]; pb = [d.upload(x) for x in B]; pe = d.alloc(32 * q)
+        inline = d.sumcheck_cubic_tail_eq(pa, pb, n, point, scale, chal)
+        d.eq_evals_scaled(point, scale, pe)
+        plain = d.sumcheck_cubic_tail(pa, pb, pe, n, None, chal)
+        for p in pa + pb + [pe]:
+            d.free(p)
+        return inline, plain
+    (i1, p1), (i2, p2) = both(devs, run)
+    assert len(i1) == turns + 1
+    for a, b, c in zip(i1, p1, i2):
+        assert np.array_equal(a, b) and np.array_equal(a, c)
 
 
 @pytest.mark.parametrize("n,alpha,bind", [(2, 1, False), (4, 1, True), (8, 3, False), (64, 2, True), (512, 1, False), (1024, 2, True), (256, 33, True), (16, 8, False), (1024, 1, False), (2048, 3, True)])   # the last two: q = 512
