@@ -133,3 +133,49 @@ def test_committed_artefact_files_verify(name, curve):
     orc.orc_verify_only.argtypes = [C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
     rr = np.ascontiguousarray(r)
     assert orc.orc_verify_only(S.kind, S.c, 1 << log_m, S.log_r, s, rr.ctypes.data_as(C.c_void_p), files["proof.bin"], len(files["proof.bin"]), comm, len(comm)) == 1
+
+
+def test_length_prefix_cannot_outgrow_the_bytes_behind_it(setup):
+    """a vector length was bounded only by the whole input, so a crafted prefix made the reader reserve ~200 bytes per claimed 32-byte point.  Every length is
+    now bounded by (remaining bytes) / (element size) before anything is reserved: the largest prefix the old bound let through is refused as 'implausible'."""
+    hp, orc = setup
+    s, idx, r, S, gens, comm, proof = _prove(hp, "and", 1, 8, 0, 64)
+    try:
+        assert hp.verify(gens, S, s, r, proof, comm) is True
+        for claimed in (len(proof), (len(proof) - 8) // 32 + 1):      # the old bound (k <= n) let both through to reserve(k); (n - 8) / 32 + 1 is the first length the new one refuses
+            bad = claimed.to_bytes(8, "little") + proof[8:]
+            with pytest.raises(LassoError, match="implausible vector length"):
+                hp.verify(gens, S, s, r, bad, comm)
+        ok_len = ((len(proof) - 8) // 32).to_bytes(8, "little") + proof[8:]      # plausible by size: read on, and fail on content
+        with pytest.raises(LassoError):
+            hp.verify(gens, S, s, r, ok_len, comm)
+    finally:
+        hp.free(None, gens)
+
+
+def test_bn254_infinity_flag_follows_ark_ec(setup):
+    """ark-ec 0.4 (SWCurveConfig::deserialize_with_mode) reads the infinity flag BEFORE looking at x: with it set the point is the identity whatever canonical x the bytes hold,
+    and the transcript absorbs the re-serialised identity — so such an encoding of an all-zero row's commitment verifies exactly like the canonical one; both flags set is no
+    flag value at all and fails to deserialize.  The product verifier and the oracle's agree on both (they used to reject the first)."""
+    hp, orc = setup
+    if orc.orc_curve_id() != 1:
+        pytest.skip("short-Weierstrass encoding only")
+    kind, c, log_m, log_r, lookups = "range", 3, 8, 12, 16      # LOG_R < 2 log M: the third memory is all zeros, its rows commit to the identity
+    s, idx, r, S, gens, comm, proof = _prove(hp, kind, c, log_m, log_r, lookups)
+    o = OracleSession(orc, _abi.KINDS[kind], c, log_m, log_r, idx, r)
+    try:
+        ident = bytes(31) + b"\x40"
+        rows = [i for i in range(8, len(proof) - 32, 32) if proof[i:i + 32] == ident]
+        assert rows, "expected an identity row in comm_derefs"
+        at = rows[0]
+        alias = bytearray(proof); alias[at] = 1                   # x = 1 (canonical, not even on the curve) under the infinity flag
+        assert hp.verify(gens, S, s, r, bytes(alias), comm) is True
+        assert o.verify(bytes(alias), comm) == 1
+        both = bytearray(proof); both[at + 31] = 0xC0             # negative AND infinity: not an SWFlags value
+        assert _verdict(hp, gens, S, s, r, bytes(both), comm) is None
+        try:
+            assert o.verify(bytes(both), comm) != 1
+        except Exception:
+            pass
+    finally:
+        o.close(); hp.free(None, gens)
