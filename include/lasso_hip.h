@@ -202,6 +202,12 @@ int32_t lasso_sumcheck_linear_eqw_round_fused(lasso_ctx* ctx, lasso_fr* const* d
  * in-place call above.  The prover's first bind takes the lookup polynomials E_k themselves as source, so surge.rs:151's clones are never made. */
 int32_t lasso_sumcheck_linear_eqw_round_fused_from(lasso_ctx* ctx, const lasso_fr* const* d_src, lasso_fr* const* d_polys, uint32_t alpha, const lasso_fr* d_E,
                                                    size_t n, const lasso_fr* r, lasso_fr* out);
+/* The first round and the first bind of the same sumcheck from the lookup polynomials' INTEGER values: E_k[i] = F::from(d_u32[k][i]) (E_k = T[dim_k] holds subtable entries, which the
+ * prover has as 32-bit integers anyway: lasso_gather_u32).  Same results as the two calls above on the 32-byte field form — lasso_sumcheck_linear_eqw_round resp.
+ * lasso_sumcheck_linear_eqw_round_fused_from with d_src = that form — for an eighth of the bytes read per element. */
+int32_t lasso_sumcheck_linear_eqw_round_u32(lasso_ctx* ctx, const uint32_t* const* d_u32, uint32_t alpha, const lasso_fr* d_E, size_t n, lasso_fr* out);
+int32_t lasso_sumcheck_linear_eqw_round_fused_from_u32(lasso_ctx* ctx, const uint32_t* const* d_u32, lasso_fr* const* d_polys, uint32_t alpha, const lasso_fr* d_E, size_t n,
+                                                       const lasso_fr* r, lasso_fr* out);
 /* Subtables::compute_sumcheck_claim (src/subtables/mod.rs:187-216): out = sum_k eq[k] * g(E_1[k],...,E_alpha[k]) */
 int32_t lasso_combine_claim(lasso_ctx* ctx, const lasso_strategy* s, const lasso_fr* const* d_polys, const lasso_fr* d_eq, size_t n, lasso_fr* out);
 /* compute_dotproduct for k polynomials against one weight vector (src/utils/mod.rs:64-73 via DensePolynomial::evaluate

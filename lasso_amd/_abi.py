@@ -59,6 +59,8 @@ def declare(lib):
         "lasso_sumcheck_linear_eqw_round": (i32, [vp, P(vp), u32, vp, sz, vp]),
         "lasso_sumcheck_linear_eqw_round_fused": (i32, [vp, P(vp), u32, vp, sz, vp, vp]),
         "lasso_sumcheck_linear_eqw_round_fused_from": (i32, [vp, P(vp), P(vp), u32, vp, sz, vp, vp]),
+        "lasso_sumcheck_linear_eqw_round_u32": (i32, [vp, P(vp), u32, vp, sz, vp]),
+        "lasso_sumcheck_linear_eqw_round_fused_from_u32": (i32, [vp, P(vp), P(vp), u32, vp, sz, vp, vp]),
         "lasso_combine_claim": (i32, [vp, P(Strategy), P(vp), vp, sz, vp]),
         "lasso_multi_dot": (i32, [vp, P(vp), u32, vp, sz, vp]),
         "lasso_read_heads": (i32, [vp, P(vp), u32, vp]),

@@ -632,6 +632,35 @@ int32_t lasso_sumcheck_linear_eqw_round_fused_from(lasso_ctx* c, const lasso_fr*
   HIPCHK(c, hipGetLastError());
   return wait_flag(c, seq, (size_t)alpha * 3, out);
 }
+// the first round and the first bind of the primary sumcheck from the lookup polynomials' integer values (k_dot_eqw_lb_u32 / k_dot_eqw_fused_from_u32)
+int32_t lasso_sumcheck_linear_eqw_round_u32(lasso_ctx* c, const uint32_t* const* d_u32, uint32_t alpha, const lasso_fr* d_E, size_t n, lasso_fr* out) {
+  REQUIRE(c, d_u32 && d_E && out && alpha >= 1 && alpha <= LASSO_MAX_PTRS && n >= 2 && (n & (n - 1)) == 0);
+  PtrTableU32 P; for (uint32_t i = 0; i < alpha; i++) { REQUIRE(c, d_u32[i]); P.p[i] = d_u32[i]; }
+  const size_t half = n / 2; const unsigned ny = alpha, nx = grid_for(half, cubic_nx_cap(ny));
+  int32_t rc = ensure_small(c, (size_t)alpha * 3); if (rc) return rc;
+  rc = ensure_scratch(c, (size_t)nx * ny * 3 * sizeof(fr_t)); if (rc) return rc;
+  const uint32_t seq = ++c->seq;
+  {
+    ProfScope ps(c, LASSO_K_COMBINE, 32.0 * n * (alpha + 1.0));   // SURVEY 8(d)'s bytes of the reference's round; the kernel reads 4 n per polynomial + 16 n of the table
+    hipLaunchKernelGGL(k_dot_eqw_lb_u32, dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, P, nx, ny, (const fr_t*)d_E, half, (fr_t*)c->d_scratch, c->d_counters, c->d_small, c->d_flag, seq);
+  }
+  HIPCHK(c, hipGetLastError());
+  return wait_flag(c, seq, (size_t)alpha * 3, out);
+}
+int32_t lasso_sumcheck_linear_eqw_round_fused_from_u32(lasso_ctx* c, const uint32_t* const* d_u32, lasso_fr* const* d_polys, uint32_t alpha, const lasso_fr* d_E, size_t n, const lasso_fr* r, lasso_fr* out) {
+  REQUIRE(c, d_u32 && d_polys && d_E && r && out && alpha >= 1 && alpha <= LASSO_MAX_PTRS && n >= 4 && (n & (n - 1)) == 0);
+  MutPtrTable P; PtrTableU32 Src; for (uint32_t i = 0; i < alpha; i++) { REQUIRE(c, d_polys[i] && d_u32[i]); P.p[i] = (fr_t*)d_polys[i]; Src.p[i] = d_u32[i]; }
+  const size_t q = n / 4; const unsigned ny = alpha, nx = grid_for(q, cubic_nx_cap(ny));
+  int32_t rc = ensure_small(c, (size_t)alpha * 3); if (rc) return rc;
+  rc = ensure_scratch(c, (size_t)nx * ny * 3 * sizeof(fr_t)); if (rc) return rc;
+  const uint32_t seq = ++c->seq;
+  {
+    ProfScope ps(c, LASSO_K_BIND, 48.0 * n * (alpha + 1.0));
+    hipLaunchKernelGGL(k_dot_eqw_fused_from_u32, dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, Src, P, nx, ny, (const fr_t*)d_E, q, to_fr(r), (fr_t*)c->d_scratch, c->d_counters, c->d_small, c->d_flag, seq);
+  }
+  HIPCHK(c, hipGetLastError());
+  return wait_flag(c, seq, (size_t)alpha * 3, out);
+}
 static int32_t make_strategy(lasso_ctx* c, const lasso_strategy* s, StrategyDev& S, WeightTable& W) {
   REQUIRE(c, s && s->kind >= LASSO_AND && s->kind <= LASSO_RANGE && s->c >= 1);
   S.kind = s->kind; S.c = s->c; S.log_m = s->log_m; S.log_r = s->log_r;

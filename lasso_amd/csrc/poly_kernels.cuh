@@ -582,6 +582,53 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_dot_eqw_fused(PtrTable src, Mut
   fr29 e[3] = {fr29_acc_reduce(w0), fr29_acc_reduce(w1), fr29_zero()};
   cubic_epilogue(e, g, partials, counters, out, flag, seq, S, 0);
 }
+// The same two rounds from the lookup polynomials' INTEGER values (round 3).  E_k = T[dim] holds table entries — small integers the prover has as u32 anyway (the commitment
+// of E is made from them) — so the primary sumcheck's first round and first bind need not stream the 32-byte field form: 4 bytes per element instead of 32, and a product with a
+// two-limb operand is 18 multiply-adds instead of 81.  Same field elements: sum_i F(x_i) eq_i and F(lo) + r (F(hi) - F(lo)), F = Fr::from.
+struct PtrTableU32 { const uint32_t* p[LASSO_MAX_PTRS]; };
+__global__ void __launch_bounds__(LASSO_BLOCK) k_dot_eqw_lb_u32(PtrTableU32 polys, uint32_t nx, uint32_t ny, const fr_t* __restrict__ E, size_t half, fr_t* __restrict__ partials, uint32_t* counters,
+                                                                 fr_t* __restrict__ out, uint32_t* flag, uint32_t seq) {
+  __shared__ RedScratch S;
+  const CubicGrid g = cubic_grid(nx, ny);
+  const uint32_t* __restrict__ z = polys.p[g.by];
+  fr29_acc w0 = fr29_acc_zero(), w1 = fr29_acc_zero(); uint32_t cnt = 0;
+  for (size_t i = g.bx * (size_t)blockDim.x + threadIdx.x; i < half; i += (size_t)nx * blockDim.x) {
+    const fr29 es = fr29_unpack_s(E[i]);
+    fr29_mul_acc(w0, fr29_from_u64_int(z[i]), es);          // integer * s-form: after the reduction the plain residue sum x_i eq_i
+    fr29_mul_acc(w1, fr29_from_u64_int(z[i + half]), es);
+    if (++cnt == 3) { fr29_acc_carry(w0); fr29_acc_carry(w1); cnt = 0; }
+  }
+  fr29_acc_carry(w0); fr29_acc_carry(w1);
+  const fr29 r2s = fr29_r2s();   // 2^517: brings the thread's plain sum into memory (u-) form, once per thread
+  fr29 e[3] = {fr29_mul(fr29_acc_reduce(w0), r2s), fr29_mul(fr29_acc_reduce(w1), r2s), fr29_zero()};
+  cubic_epilogue(e, g, partials, counters, out, flag, seq, S, 0);
+}
+// F(lo) + r (F(hi) - F(lo)) for 32-bit integers lo, hi: two products with a two-limb operand; rx = r * 2^517 (so that integer * rx is the u-form of integer * r), canonical result
+__device__ __forceinline__ fr29 bind29_u32(uint32_t lo, uint32_t hi, const fr29& rx, const fr29& r2s) {
+  const bool neg = hi < lo; const uint32_t ad = neg ? lo - hi : hi - lo;
+  const fr29 t = fr29_mul(fr29_from_u64_int(ad), rx), l = fr29_mul(fr29_from_u64_int(lo), r2s);
+  return fr29_canonical(neg ? fr29_sub(l, t) : fr29_add(l, t));
+}
+__global__ void __launch_bounds__(LASSO_BLOCK) k_dot_eqw_fused_from_u32(PtrTableU32 src, MutPtrTable polys, uint32_t nx, uint32_t ny, const fr_t* __restrict__ E, size_t q, fr_t r, fr_t* __restrict__ partials,
+                                                                         uint32_t* counters, fr_t* __restrict__ out, uint32_t* flag, uint32_t seq) {
+  __shared__ RedScratch S;
+  const CubicGrid g = cubic_grid(nx, ny);
+  fr_t* __restrict__ zd = polys.p[g.by];
+  const uint32_t* __restrict__ z = src.p[g.by];
+  const fr29 r2s = fr29_r2s(), rx = fr29_mul(fr29_unpack_s(r), r2s);
+  fr29_acc w0 = fr29_acc_zero(), w1 = fr29_acc_zero(); uint32_t cnt = 0;
+  for (size_t i = g.bx * (size_t)blockDim.x + threadIdx.x; i < q; i += (size_t)nx * blockDim.x) {
+    const fr29 z0 = bind29_u32(z[i], z[i + 2 * q], rx, r2s), z1 = bind29_u32(z[i + q], z[i + 3 * q], rx, r2s);
+    zd[i] = fr29_pack(z0); zd[i + q] = fr29_pack(z1);
+    const fr29 es = fr29_unpack_s(E[i]);
+    fr29_mul_acc(w0, z0, es);
+    fr29_mul_acc(w1, z1, es);
+    if (++cnt == 3) { fr29_acc_carry(w0); fr29_acc_carry(w1); cnt = 0; }
+  }
+  fr29_acc_carry(w0); fr29_acc_carry(w1);
+  fr29 e[3] = {fr29_acc_reduce(w0), fr29_acc_reduce(w1), fr29_zero()};
+  cubic_epilogue(e, g, partials, counters, out, flag, seq, S, 0);
+}
 // The tail of the primary sumcheck for a linear strategy, resident like k_cubic_tail: from q <= CUBIC_TAIL_Q indices per polynomial on, the
 // remaining rounds' two dot products per polynomial (S0_k = sum_{i<h} z[i] E[i], S1_k = sum_{i<h} z[i+h] E[i]) and the binds run out of LDS,
 // challenges arrive through the host mailbox, and the last publication is the heads z_k[0] = E_k(r_z).  One workgroup per polynomial; src is

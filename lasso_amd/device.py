@@ -210,6 +210,17 @@ class Device:
         self._chk(self.lib.lasso_sumcheck_combine_round_lt_scaled(self.ctx, C.byref(strategy), self._ptrs(ptrs), C.c_void_p(d_eq), n, degree, _vp(out)))
         return out
 
+    def sumcheck_linear_eqw_round_u32(self, u32_ptrs, d_e, n):
+        out = np.empty((3 * len(u32_ptrs), 4), dtype=np.uint64)
+        self._chk(self.lib.lasso_sumcheck_linear_eqw_round_u32(self.ctx, self._ptrs(u32_ptrs), len(u32_ptrs), C.c_void_p(d_e), n, _vp(out)))
+        return out.reshape(len(u32_ptrs), 3, 4)[:, :2].copy()
+
+    def sumcheck_linear_eqw_round_fused_from_u32(self, u32_ptrs, ptrs, d_e, n, r):
+        r = np.ascontiguousarray(r, dtype=np.uint64)
+        out = np.empty((3 * len(ptrs), 4), dtype=np.uint64)
+        self._chk(self.lib.lasso_sumcheck_linear_eqw_round_fused_from_u32(self.ctx, self._ptrs(u32_ptrs), self._ptrs(ptrs), len(ptrs), C.c_void_p(d_e), n, _vp(r), _vp(out)))
+        return out.reshape(len(ptrs), 3, 4)[:, :2].copy()
+
     def combine_claim(self, strategy, ptrs, d_eq, n):
         out = np.empty((1, 4), dtype=np.uint64)
         self._chk(self.lib.lasso_combine_claim(self.ctx, C.byref(strategy), self._ptrs(ptrs), C.c_void_p(d_eq), n, _vp(out)))

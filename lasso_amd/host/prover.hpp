@@ -621,8 +621,9 @@ class Prover {
   // here.  One phase = `rounds` rounds over point[v0 .. v0+rounds) on arrays of length len; polys = the alpha E clones only.
   // src (optional): read-only arrays holding the polynomials; the bound arrays go to `polys` (half the length) — no clone of the inputs
   // tail_heads (optional): filled with the alpha final values when the phase ended in the resident tail kernel (then the arrays hold stale data)
+  // src_u32 (optional, with src): the same polynomials as 32-bit integers (E_k = T[dim_k]): the first round and the first bind read those instead of the 32-byte form
   void linear_rounds(size_t rounds, size_t len, std::vector<lasso_fr*>& polys, const lasso_fr* d_E, const ScVec& point, size_t v0, bool reduce, Sc& s_run, SumcheckProof& proof, ScVec& r_out,
-                     const std::vector<const lasso_fr*>* src = nullptr, std::vector<lasso_fr>* tail_heads = nullptr) {
+                     const std::vector<const lasso_fr*>* src = nullptr, std::vector<lasso_fr>* tail_heads = nullptr, const std::vector<const uint32_t*>* src_u32 = nullptr) {
     if (tail_heads) tail_heads->clear();
     if (!rounds) return;
     if (src && rounds < 2) {   // too short for a fused bind to move the data: a one-element copy per polynomial, then in place
@@ -667,10 +668,13 @@ class Prover {
         std::vector<lasso_fr> e2(2 * alpha);
         d.chk(lasso_result_wait(d.ctx, e2.data(), 2 * alpha), "lasso_result_wait");
         for (size_t k2 = 0; k2 < alpha; k2++) { ev[3 * k2] = e2[2 * k2]; ev[3 * k2 + 1] = e2[2 * k2 + 1]; }
-      } else if (j == 0) d.chk(lasso_sumcheck_linear_eqw_round(d.ctx, src ? src->data() : (const lasso_fr* const*)polys.data(), (uint32_t)alpha, table, len, ev.data()), "lasso_sumcheck_linear_eqw_round");
-      else {
+      } else if (j == 0) {
+        if (src && src_u32) d.chk(lasso_sumcheck_linear_eqw_round_u32(d.ctx, src_u32->data(), (uint32_t)alpha, table, len, ev.data()), "lasso_sumcheck_linear_eqw_round_u32");
+        else d.chk(lasso_sumcheck_linear_eqw_round(d.ctx, src ? src->data() : (const lasso_fr* const*)polys.data(), (uint32_t)alpha, table, len, ev.data()), "lasso_sumcheck_linear_eqw_round");
+      } else {
         lasso_fr rp = r_prev.abi();
-        if (j == 1 && src) d.chk(lasso_sumcheck_linear_eqw_round_fused_from(d.ctx, src->data(), polys.data(), (uint32_t)alpha, table, len, &rp, ev.data()), "lasso_sumcheck_linear_eqw_round_fused_from");
+        if (j == 1 && src && src_u32) d.chk(lasso_sumcheck_linear_eqw_round_fused_from_u32(d.ctx, src_u32->data(), polys.data(), (uint32_t)alpha, table, len, &rp, ev.data()), "lasso_sumcheck_linear_eqw_round_fused_from_u32");
+        else if (j == 1 && src) d.chk(lasso_sumcheck_linear_eqw_round_fused_from(d.ctx, src->data(), polys.data(), (uint32_t)alpha, table, len, &rp, ev.data()), "lasso_sumcheck_linear_eqw_round_fused_from");
         else d.chk(lasso_sumcheck_linear_eqw_round_fused(d.ctx, polys.data(), (uint32_t)alpha, table, len, &rp, ev.data()), "lasso_sumcheck_linear_eqw_round_fused");
         len /= 2;
       }
@@ -700,7 +704,7 @@ class Prover {
   // E_i.evaluate(r_z) (surge.rs:175-176) in element 0 of every array, so the prover reads them instead of evaluating E_i again
   // src (optional, linear strategies): the first alpha polynomials are read from src and never modified; polys[i < alpha] then only need len_loc / 2 elements
   SumcheckProof prove_arbitrary(size_t num_rounds, size_t len_loc, std::vector<lasso_fr*>& polys, size_t combined_degree, const ScVec& point, ScVec& r_out, ScVec* heads_out = nullptr,
-                                const std::vector<const lasso_fr*>* src = nullptr) {
+                                const std::vector<const lasso_fr*>* src = nullptr, const std::vector<const uint32_t*>* src_u32 = nullptr) {
     SumcheckProof proof;
     auto read_heads = [&](const std::vector<lasso_fr*>& arrs) {
       if (!heads_out) return;
@@ -719,7 +723,7 @@ class Prover {
         if (th.empty()) { read_heads(arrs); return; }
         if (heads_out) { heads_out->clear(); for (auto& x : th) heads_out->push_back(Sc::from_abi(x)); }
       };
-      if (P == 1) { linear_rounds(num_rounds, len_loc, ep, polys[alpha], point, 0, false, s_run, proof, r_out, src, heads_out ? &th : nullptr); finish(ep); return proof; }
+      if (P == 1) { linear_rounds(num_rounds, len_loc, ep, polys[alpha], point, 0, false, s_run, proof, r_out, src, heads_out ? &th : nullptr, src_u32); finish(ep); return proof; }
       LASSO_REQUIRE(num_rounds >= lgP && ((size_t)1 << (num_rounds - lgP)) == len_loc);
       const size_t local_rounds = num_rounds - lgP;
       if (src && local_rounds == 0) { for (size_t i = 0; i < alpha; i++) d.chk(lasso_copy(d.ctx, ep[i], (*src)[i], len_loc * sizeof(lasso_fr)), "lasso_copy"); }
@@ -1161,8 +1165,9 @@ class Prover {
     };
     ProofWriter W;
     PolyCommitment comm_derefs;
-    if (P == 1) {   // E as integers: one 4-byte gather per lookup instead of converting the 32-byte elements back
-      DBufU32 E_u32(d, n_E);
+    DBufU32 E_u32;   // E as integers (one GPU): the commitment's scalars, and what the primary sumcheck's first round and first bind read (4 bytes per element instead of 32)
+    if (P == 1) {   // one 4-byte gather per lookup instead of converting the 32-byte elements back
+      E_u32 = DBufU32(d, n_E);
       if (n_E > alpha * s) d.chk(lasso_zero(d.ctx, E_u32.p + alpha * s, (n_E - alpha * s) * sizeof(uint32_t)), "lasso_zero");
       for (size_t i = 0; i < alpha; i++)
         d.chk(lasso_gather_u32(d.ctx, tables_u32[S.memory_to_subtable_index(i)].p, dense.dim_u32[S.memory_to_dimension_index(i)].p, s, E_u32.p + i * s), "lasso_gather_u32");
@@ -1209,9 +1214,12 @@ class Prover {
       DBuf work(d, alpha * wl);
       // LT: the clone of surge.rs:151 and the scaling of the LT memories are one pass (lasso_lt_prescale with a source): E itself is only read
       std::vector<lasso_fr*> polys; for (size_t i = 0; i < alpha; i++) polys.push_back(work.p + i * wl); polys.push_back(eq.p);
-      SumcheckProof sp = prove_arbitrary(ceil_log2(s), s_loc, polys, S.sumcheck_poly_degree(), r, r_z, &sumcheck_heads, &Eptr);
+      static const bool u32_off = [] { const char* e = getenv("LASSO_SUMCHECK_U32"); return e && e[0] == '0'; }();   // A/B switch
+      std::vector<const uint32_t*> Eu32; if (P == 1 && no_clone && E_u32.p && !u32_off) for (size_t i = 0; i < alpha; i++) Eu32.push_back(E_u32.p + i * s);
+      SumcheckProof sp = prove_arbitrary(ceil_log2(s), s_loc, polys, S.sumcheck_poly_degree(), r, r_z, &sumcheck_heads, &Eptr, Eu32.empty() ? nullptr : &Eu32);
       sp.write(W);
     }
+    E_u32 = DBufU32();
     W.sc(claimed_eval);
     // eval_derefs = E_i(r_z) (surge.rs:175-176)
     sp.reset(new Trace("CombinedEval.prove", d.ctx));

@@ -123,6 +123,17 @@ int32_t lasso_sumcheck_linear_eqw_round_fused_from(lasso_ctx* c, const lasso_fr*
   for (uint32_t k = 0; k < alpha; k++) for (size_t i = 0; i < h; i++) F(polys[k])[i] = F(src[k])[i] + *F(r) * (F(src[k])[i + h] - F(src[k])[i]);
   return lasso_sumcheck_linear_eqw_round(c, polys, alpha, E, h, out);
 }
+// the same two calls from the polynomials' integer values: lift to the field, then the literal forms
+int32_t lasso_sumcheck_linear_eqw_round_u32(lasso_ctx* c, const uint32_t* const* u, uint32_t alpha, const lasso_fr* E, size_t n, lasso_fr* out) {
+  std::vector<std::vector<Fr>> z(alpha, std::vector<Fr>(n)); std::vector<const lasso_fr*> ptr(alpha);
+  for (uint32_t k = 0; k < alpha; k++) { for (size_t i = 0; i < n; i++) z[k][i] = Fr::from_u64(u[k][i]); ptr[k] = (const lasso_fr*)z[k].data(); }
+  return lasso_sumcheck_linear_eqw_round(c, ptr.data(), alpha, E, n, out);
+}
+int32_t lasso_sumcheck_linear_eqw_round_fused_from_u32(lasso_ctx* c, const uint32_t* const* u, lasso_fr* const* polys, uint32_t alpha, const lasso_fr* E, size_t n, const lasso_fr* r, lasso_fr* out) {
+  std::vector<std::vector<Fr>> z(alpha, std::vector<Fr>(n)); std::vector<const lasso_fr*> ptr(alpha);
+  for (uint32_t k = 0; k < alpha; k++) { for (size_t i = 0; i < n; i++) z[k][i] = Fr::from_u64(u[k][i]); ptr[k] = (const lasso_fr*)z[k].data(); }
+  return lasso_sumcheck_linear_eqw_round_fused_from(c, ptr.data(), polys, alpha, E, n, r, out);
+}
 int32_t lasso_sumcheck_linear_eqw_round_fused(lasso_ctx* c, lasso_fr* const* polys, uint32_t alpha, const lasso_fr* E, size_t n, const lasso_fr* r, lasso_fr* out) {
   return lasso_sumcheck_linear_eqw_round_fused_from(c, polys, polys, alpha, E, n, r, out);
 }

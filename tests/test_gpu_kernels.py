@@ -879,6 +879,39 @@ def test_msm_dev_scaled(devs, gens_300, n):
     assert compress_points(devs[1].lib, a) == compress_points(devs[1].lib, b)
 
 
+@pytest.mark.parametrize("n,alpha", [(2, 1), (4, 2), (64, 1), (1 << 12, 3), (1 << 15, 8)])
+def test_sumcheck_linear_rounds_from_u32(devs, n, alpha):
+    """the primary sumcheck's first round and first bind from the polynomials' 32-bit integer values == the same calls on the lifted 32-byte field elements: sums, bound arrays"""
+    from fieldref import L as FR_P, limbs, to_mont
+    rng = np.random.default_rng(n * 11 + alpha)
+    U = [rng.integers(0, 2**32, size=n, dtype=np.uint32) for _ in range(alpha)]
+    for u in U:
+        u[:8] = [0, 1, 2**32 - 1, 2**31, 255, 2**16, 7, 2**32 - 2][: min(8, n)]
+    if n > 16:
+        U[0][n // 2:] = 2**32 - 1; U[0][: n // 2] = 0      # every difference hi - lo at its extreme
+    Ps = [np.array([limbs(to_mont(int(x), FR_P)) for x in u], dtype=np.uint64).reshape(-1, 4) for u in U]
+    E = rand_fr(rng, n // 2); r = rand_fr(rng, 1, edge=False)[0]
+
+    def run(d):
+        pu = [d.upload(u) for u in U]; pp = [d.upload(x) for x in Ps]; pe = d.upload(E)
+        res = [d.sumcheck_linear_eqw_round_u32(pu, pe, n), d.sumcheck_linear_eqw_round(pp, pe, n)]
+        if n >= 4:
+            pd = [d.alloc(32 * (n // 2)) for _ in Ps]; pd2 = [d.alloc(32 * (n // 2)) for _ in Ps]
+            res.append(d.sumcheck_linear_eqw_round_fused_from_u32(pu, pd, pe, n, r)); res.append([d.download(p, (n // 2, 4)) for p in pd])
+            res.append(d.sumcheck_linear_eqw_round_fused_from(pp, pd2, pe, n, r)); res.append([d.download(p, (n // 2, 4)) for p in pd2])
+            for p in pd + pd2:
+                d.free(p)
+        for p in pu + pp + [pe]:
+            d.free(p)
+        return res
+    a, b = both(devs, run)
+    assert np.array_equal(a[0], a[1]) and np.array_equal(a[0], b[0])
+    if n >= 4:
+        assert np.array_equal(a[2], a[4]) and np.array_equal(a[2], b[2])
+        for x, y, z in zip(a[3], a[5], b[3]):
+            assert np.array_equal(x, y) and np.array_equal(x, z)
+
+
 @pytest.mark.parametrize("n,alpha", [(2, 1), (4, 3), (64, 8), (1 << 10, 2), (1 << 14, 16), (1 << 17, 1)])
 def test_sumcheck_linear_eqw_rounds(devs, n, alpha):
     """eq-weighted primary-sumcheck rounds for linear strategies: two dot products per polynomial against the table prefix; fused = bind_top + plain"""
