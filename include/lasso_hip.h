@@ -191,6 +191,10 @@ int32_t lasso_sumcheck_combine_round(lasso_ctx* ctx, const lasso_strategy* s, co
  * polynomials (surge.rs:151) and the scaling in one pass over the data. */
 int32_t lasso_lt_prescale(lasso_ctx* ctx, const lasso_strategy* s, const lasso_fr* const* d_src, lasso_fr* const* d_polys, size_t n);
 int32_t lasso_sumcheck_combine_round_lt_scaled(lasso_ctx* ctx, const lasso_strategy* s, const lasso_fr* const* d_polys, const lasso_fr* d_eq, size_t n, uint32_t degree, lasso_fr* out);
+/* The FIRST round of that sumcheck (before any bind) from the lookup polynomials' INTEGER values, E_k[i] = F::from(d_u32[k][i]) with EVERY ENTRY 0 OR 1 — the LT and EQ subtables
+ * hold bits (lt.rs:17-44).  All lines are then small integers at the evaluation points and the Horner walk is exact 128-bit integer arithmetic; same out[x] as
+ * lasso_sumcheck_combine_round on the lifted arrays.  Round 0 is half of the sumcheck's work. */
+int32_t lasso_sumcheck_combine_round_lt_u32(lasso_ctx* ctx, const lasso_strategy* s, const uint32_t* const* d_u32, const lasso_fr* d_eq, size_t n, uint32_t degree, lasso_fr* out);
 /* The same round in EQ-WEIGHTED form for the LINEAR strategies (AND / OR / XOR / RangeCheck: g = sum_k w_k E_k, src/subtables/and.rs:45-53) — what the
  * prover calls.  The eq polynomial is factored exactly as in lasso_sumcheck_cubic_eqw_round (prefix of the original table d_E + host scalars), and by
  * linearity of g a round needs per polynomial only  out[3k] = sum_{i<n/2} E_k[i] d_E[i]  and  out[3k+1] = sum_{i<n/2} E_k[i+n/2] d_E[i]  (out[3k+2] unused):

@@ -56,6 +56,7 @@ def declare(lib):
         "lasso_sumcheck_combine_round": (i32, [vp, P(Strategy), P(vp), vp, sz, u32, vp]),
         "lasso_sumcheck_combine_round_lt_scaled": (i32, [vp, P(Strategy), P(vp), vp, sz, u32, vp]),
         "lasso_lt_prescale": (i32, [vp, P(Strategy), P(vp), P(vp), sz]),
+        "lasso_sumcheck_combine_round_lt_u32": (i32, [vp, P(Strategy), P(vp), vp, sz, u32, vp]),
         "lasso_sumcheck_linear_eqw_round": (i32, [vp, P(vp), u32, vp, sz, vp]),
         "lasso_sumcheck_linear_eqw_round_fused": (i32, [vp, P(vp), u32, vp, sz, vp, vp]),
         "lasso_sumcheck_linear_eqw_round_fused_from": (i32, [vp, P(vp), P(vp), u32, vp, sz, vp, vp]),

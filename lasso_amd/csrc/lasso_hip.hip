@@ -714,6 +714,23 @@ int32_t lasso_sumcheck_combine_round_lt_scaled(lasso_ctx* c, const lasso_strateg
   REQUIRE(c, s && s->kind == LASSO_LT);
   return combine_round_impl(c, s, d_polys, d_eq, n, degree, out, true);
 }
+// the FIRST round of the LT sumcheck from the polynomials' integer values (entries 0 / 1: the LT and EQ subtables hold bits): exact integer Horner walk, one field product per point for the eq weight
+int32_t lasso_sumcheck_combine_round_lt_u32(lasso_ctx* c, const lasso_strategy* s, const uint32_t* const* d_u32, const lasso_fr* d_eq, size_t n, uint32_t degree, lasso_fr* out) {
+  StrategyDev S; WeightTable W; int32_t rc = make_strategy(c, s, S, W); if (rc) return rc;
+  REQUIRE(c, s->kind == LASSO_LT && d_u32 && d_eq && out && n >= 2 && (n & (n - 1)) == 0 && degree == s->c + 1);
+  PtrTableU32 P; for (uint32_t i = 0; i < S.alpha; i++) { REQUIRE(c, d_u32[i]); P.p[i] = d_u32[i]; }
+  const size_t half = n / 2; const unsigned nx = grid_for(half, 1024); const uint32_t K = degree + 1;
+  rc = ensure_scratch(c, (size_t)nx * K * sizeof(fr_t)); if (rc) return rc;
+  rc = ensure_small(c, K); if (rc) return rc;
+  {
+    ProfScope ps(c, LASSO_K_COMBINE, 32.0 * n * (S.alpha + 1.0));
+#define LAUNCH_COMBINE_U32(A_, D_, T_) hipLaunchKernelGGL((k_combine_round_lt_u32<A_, D_, T_>), dim3(nx), dim3(LASSO_BLOCK), 0, c->stream, S, P, (const fr_t*)d_eq, half, degree, (fr_t*)c->d_scratch)
+    DISPATCH_LT(S.alpha, LAUNCH_COMBINE_U32);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(LASSO_BLOCK), 0, c->stream, (const fr_t*)c->d_scratch, nx, K, c->d_small);
+  }
+  HIPCHK(c, hipGetLastError());
+  return fetch_small(c, K, out);
+}
 int32_t lasso_lt_prescale(lasso_ctx* c, const lasso_strategy* s, const lasso_fr* const* d_src, lasso_fr* const* d_polys, size_t n) {
   StrategyDev S; WeightTable W; int32_t rc = make_strategy(c, s, S, W); if (rc) return rc;
   REQUIRE(c, s->kind == LASSO_LT && d_polys && n >= 1);

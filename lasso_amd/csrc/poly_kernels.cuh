@@ -869,6 +869,83 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_combine_round_lt(StrategyDev S,
 #undef LT_ACC
 #undef LT_FOLD
 #undef LT_OUT
+// The FIRST round of the LT sumcheck from the lookup polynomials' integer values.  Before any bind E_k = T[dim_k] holds subtable entries, and the LT / EQ subtables hold
+// bits (lt.rs:17-44): every line LT_m(x), EQ_m(x) = lo + x (hi - lo) is an integer in [-16, 17] for x <= 17, and the whole Horner walk t <- LT_m + EQ_m t is exact INTEGER
+// arithmetic — |t| <= 17 (17^16 - 1) / 16 < 2^67, a 128-bit multiply-add by a small number per memory and point instead of a 256-bit field product.  Only the eq weight is
+// a field product (integer t as three signed 29-bit limbs times the eq line pre-multiplied by 2^517, so that the Montgomery product lands in memory form).  Round 0 is half of the sumcheck's
+// work; it drops from 288 field products per index at C = 16 to 18 cheap ones, reading 4 bytes per element.  Requires every entry <= 1 (the caller checks its tables).
+// a signed integer of magnitude < 2^87 as three signed 29-bit limbs (limbs 3..8 literal zeros: a product with it is 27 multiply-adds)
+__device__ __forceinline__ fr29 lt_int_limbs(__int128 t) {
+  const bool neg = t < 0; const unsigned __int128 mag = neg ? (unsigned __int128)(-t) : (unsigned __int128)t;
+  const int32_t l0 = (int32_t)((uint64_t)mag & FR29_MASK), l1 = (int32_t)((uint64_t)(mag >> 29) & FR29_MASK), l2 = (int32_t)((uint64_t)(mag >> 58) & FR29_MASK);
+  fr29 r = fr29_zero(); r.v[0] = neg ? -l0 : l0; r.v[1] = neg ? -l1 : l1; r.v[2] = neg ? -l2 : l2;
+  return r;
+}
+// the eq line's end point times 2^517: an INTEGER times it, Montgomery-reduced by 2^261, is (integer * e) 2^256 — the memory form, no correction needed
+__device__ __forceinline__ fr29 lt_eq_times_r2(const fr_t& e) {
+  return fr29_mul(fr29_unpack_s(e), fr29_r2s());
+}
+template <int A, int D, int T>
+__global__ void __launch_bounds__(LASSO_BLOCK) k_combine_round_lt_u32(StrategyDev S, PtrTableU32 polys, const fr_t* __restrict__ eq, size_t half, uint32_t degree, fr_t* __restrict__ partials) {
+  constexpr int PPG = (D + 1 + T - 1) / T;
+  constexpr uint32_t SLOTS = LASSO_BLOCK / T;
+  static_assert(PPG <= 6, "at most 6 points per lane");
+  __shared__ RedScratch R;
+  const uint32_t slot = threadIdx.x / T, pg = threadIdx.x - slot * T, x0 = pg * PPG;
+  fr29 sum[PPG];
+#pragma unroll
+  for (int k = 0; k < PPG; k++) sum[k] = fr29_zero();
+  uint32_t cnt = 0;
+  if (slot < SLOTS && x0 <= degree)
+  for (size_t i = blockIdx.x * (size_t)SLOTS + slot; i < half; i += (size_t)gridDim.x * SLOTS) {
+    __int128 t[PPG];
+    {
+      const uint32_t* __restrict__ pl = polys.p[2 * (S.c - 1)];
+      const int32_t lo = (int32_t)pl[i], d = (int32_t)pl[i + half] - lo;
+#pragma unroll
+      for (int k = 0; k < PPG; k++) t[k] = lo + (int32_t)(x0 + k) * d;
+    }
+    for (uint32_t m = S.c - 1; m-- > 0;) {
+      const uint32_t* __restrict__ pl = polys.p[2 * m]; const uint32_t* __restrict__ pe = polys.p[2 * m + 1];
+      const int32_t llo = (int32_t)pl[i], ld = (int32_t)pl[i + half] - llo, elo = (int32_t)pe[i], ed = (int32_t)pe[i + half] - elo;
+#pragma unroll
+      for (int k = 0; k < PPG; k++) { const int32_t x = (int32_t)(x0 + k); t[k] = (__int128)(llo + x * ld) + (__int128)(elo + x * ed) * t[k]; }
+    }
+    {
+      // the eq line times 2^517 (two products per index): an INTEGER t times e 2^517, Montgomery-reduced by 2^261, is t e 2^256 — the memory form of t e, no correction needed
+      const fr29 e0 = fr29_weak(lt_eq_times_r2(eq[i])), edif = fr29_sub(lt_eq_times_r2(eq[i + half]), e0);
+      fr29 ecur = lt_line_at(e0, edif, x0);
+#pragma unroll
+      for (int k = 0; k < PPG; k++) if (x0 + k <= degree) {
+        sum[k] = lt_weighted_acc(sum[k], lt_int_limbs(t[k]), ecur);
+        ecur = lt_line_step(ecur, edif);
+      }
+    }
+    if (++cnt >= LT_FOLD_EVERY()) {
+      cnt = 0;
+#pragma unroll
+      for (int k = 0; k < PPG; k++) sum[k] = fr29_mul(sum[k], fr29_one_s());
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < T; g++) {
+#pragma unroll
+    for (int k0 = 0; k0 < PPG; k0 += 3) {
+      fr29 grp[3];
+#pragma unroll
+      for (int v = 0; v < 3; v++) {
+        grp[v] = fr29_zero();
+        if (k0 + v < PPG) {
+#pragma unroll
+          for (int l = 0; l < 9; l++) grp[v].v[l] = pg == (uint32_t)g ? sum[k0 + v < PPG ? k0 + v : 0].v[l] : 0;
+        }
+      }
+      block_columns<3>(grp, R);
+      const uint32_t pt = (uint32_t)(g * PPG + k0) + threadIdx.x;
+      if (threadIdx.x < 3 && k0 + (int)threadIdx.x < PPG && pt <= degree) partials[(size_t)blockIdx.x * (degree + 1) + pt] = columns_to_fr(R, threadIdx.x, 0);
+    }
+  }
+}
 // K10: claim = sum_k eq[k] * g(E(k))  (subtables/mod.rs:187-216)
 template <int A>
 __global__ void __launch_bounds__(LASSO_BLOCK) k_combine_claim(StrategyDev S, PtrTable polys, const fr_t* __restrict__ eq, WeightTable W, size_t n, fr_t* __restrict__ partials) {

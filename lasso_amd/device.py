@@ -221,6 +221,11 @@ class Device:
         self._chk(self.lib.lasso_sumcheck_linear_eqw_round_fused_from_u32(self.ctx, self._ptrs(u32_ptrs), self._ptrs(ptrs), len(ptrs), C.c_void_p(d_e), n, _vp(r), _vp(out)))
         return out.reshape(len(ptrs), 3, 4)[:, :2].copy()
 
+    def sumcheck_combine_round_lt_u32(self, strategy, u32_ptrs, d_eq, n, degree):
+        out = np.empty((degree + 1, 4), dtype=np.uint64)
+        self._chk(self.lib.lasso_sumcheck_combine_round_lt_u32(self.ctx, C.byref(strategy), self._ptrs(u32_ptrs), C.c_void_p(d_eq), n, degree, _vp(out)))
+        return out
+
     def combine_claim(self, strategy, ptrs, d_eq, n):
         out = np.empty((1, 4), dtype=np.uint64)
         self._chk(self.lib.lasso_combine_claim(self.ctx, C.byref(strategy), self._ptrs(ptrs), C.c_void_p(d_eq), n, _vp(out)))

@@ -600,11 +600,14 @@ class Prover {
   // One phase = `rounds` rounds on arrays of current length len; `reduce` = the arrays are slabs, per-round sums are all-gathered and added.
   // LT (the one non-linear strategy): the work arrays of the LT memories carry the factor 32^-(C-1-m) (lasso_lt_prescale, applied once by prove_arbitrary — binding
   // keeps it), which is what lets the round kernel spend one product per memory and point (Horner form, include/lasso_hip.h); the heads are scaled back in read_heads.
-  void arbitrary_rounds(size_t rounds, size_t len, std::vector<lasso_fr*>& polys, size_t combined_degree, bool reduce, SumcheckProof& proof, ScVec& r_out) {
+  // first_u32 (optional): the UNBOUND polynomials as 32-bit integers with entries 0 / 1 (E_k = T[dim_k] of the LT / EQ subtables): the phase's first round is then exact integer
+  // arithmetic (lasso_sumcheck_combine_round_lt_u32) — round 0 is half of this sumcheck's work
+  void arbitrary_rounds(size_t rounds, size_t len, std::vector<lasso_fr*>& polys, size_t combined_degree, bool reduce, SumcheckProof& proof, ScVec& r_out, const std::vector<const uint32_t*>* first_u32 = nullptr) {
     std::vector<const lasso_fr*> cp(polys.begin(), polys.begin() + alpha);
     for (size_t round = 0; round < rounds; round++) {
       std::vector<lasso_fr> ev(combined_degree + 1);
-      d.chk(lasso_sumcheck_combine_round_lt_scaled(d.ctx, &S.abi, cp.data(), polys[alpha], len, (uint32_t)combined_degree, ev.data()), "lasso_sumcheck_combine_round_lt_scaled");
+      if (round == 0 && first_u32) d.chk(lasso_sumcheck_combine_round_lt_u32(d.ctx, &S.abi, first_u32->data(), polys[alpha], len, (uint32_t)combined_degree, ev.data()), "lasso_sumcheck_combine_round_lt_u32");
+      else d.chk(lasso_sumcheck_combine_round_lt_scaled(d.ctx, &S.abi, cp.data(), polys[alpha], len, (uint32_t)combined_degree, ev.data()), "lasso_sumcheck_combine_round_lt_scaled");
       if (reduce) d.comm.sum(ev);
       ScVec evals; for (auto& e : ev) evals.push_back(Sc::from_abi(e));
       UniPoly up = UniPoly::from_evals(evals);
@@ -739,7 +742,7 @@ class Prover {
     }
     // the caller's work arrays, once (slab mode: the local arrays; the replicated tails are gathered from them).  With src the call also IS the clone of the lookup polynomials
     d.chk(lasso_lt_prescale(d.ctx, &S.abi, src ? src->data() : nullptr, polys.data(), len_loc), "lasso_lt_prescale");
-    if (P == 1) { arbitrary_rounds(num_rounds, len_loc, polys, combined_degree, false, proof, r_out); read_heads(polys); return proof; }
+    if (P == 1) { arbitrary_rounds(num_rounds, len_loc, polys, combined_degree, false, proof, r_out, src_u32); read_heads(polys); return proof; }
     LASSO_REQUIRE(num_rounds >= lgP && ((size_t)1 << (num_rounds - lgP)) == len_loc);
     arbitrary_rounds(num_rounds - lgP, len_loc, polys, combined_degree, true, proof, r_out);
     std::vector<lasso_fr*> tail = gather_tail(polys);
@@ -1215,7 +1218,8 @@ class Prover {
       // LT: the clone of surge.rs:151 and the scaling of the LT memories are one pass (lasso_lt_prescale with a source): E itself is only read
       std::vector<lasso_fr*> polys; for (size_t i = 0; i < alpha; i++) polys.push_back(work.p + i * wl); polys.push_back(eq.p);
       static const bool u32_off = [] { const char* e = getenv("LASSO_SUMCHECK_U32"); return e && e[0] == '0'; }();   // A/B switch
-      std::vector<const uint32_t*> Eu32; if (P == 1 && no_clone && E_u32.p && !u32_off) for (size_t i = 0; i < alpha; i++) Eu32.push_back(E_u32.p + i * s);
+      // linear strategies: any table values; LT: only because its subtables hold bits (the integer round needs entries 0 / 1)
+      std::vector<const uint32_t*> Eu32; if (P == 1 && (no_clone || table_max <= 1) && E_u32.p && !u32_off && ceil_log2(s) > 0) for (size_t i = 0; i < alpha; i++) Eu32.push_back(E_u32.p + i * s);
       SumcheckProof sp = prove_arbitrary(ceil_log2(s), s_loc, polys, S.sumcheck_poly_degree(), r, r_z, &sumcheck_heads, &Eptr, Eu32.empty() ? nullptr : &Eu32);
       sp.write(W);
     }

@@ -282,6 +282,13 @@ int32_t lasso_sumcheck_combine_round_lt_scaled(lasso_ctx* c, const lasso_strateg
   }
   return lasso_sumcheck_combine_round(c, s, ptrs.data(), eq, n, degree, out);
 }
+int32_t lasso_sumcheck_combine_round_lt_u32(lasso_ctx* c, const lasso_strategy* s, const uint32_t* const* u, const lasso_fr* eq, size_t n, uint32_t degree, lasso_fr* out) {
+  REQ(c, s && s->kind == LASSO_LT && u);
+  const size_t alpha = 2 * (size_t)s->c;
+  std::vector<std::vector<Fr>> z(alpha, std::vector<Fr>(n)); std::vector<const lasso_fr*> ptr(alpha);
+  for (size_t k = 0; k < alpha; k++) { for (size_t i = 0; i < n; i++) { REQ(c, u[k][i] <= 1); z[k][i] = Fr::from_u64(u[k][i]); } ptr[k] = (const lasso_fr*)z[k].data(); }
+  return lasso_sumcheck_combine_round(c, s, ptr.data(), eq, n, degree, out);
+}
 int32_t lasso_combine_claim(lasso_ctx* c, const lasso_strategy* s, const lasso_fr* const* polys, const lasso_fr* eq, size_t n, lasso_fr* out) {
   Strategy S = mk(s); size_t alpha = S.num_memories(); std::vector<Fr> v(alpha); Fr claim = Fr::zero();
   for (size_t k = 0; k < n; k++) { for (size_t j = 0; j < alpha; j++) v[j] = F(polys[j])[k]; claim += F(eq)[k] * S.combine_lookups(v.data()); }  // subtables/mod.rs:197-213

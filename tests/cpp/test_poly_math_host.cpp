@@ -175,6 +175,40 @@ int main() {
       }
     }
   }
+  // ---- the FIRST LT round from bits (k_combine_round_lt_u32): exact 128-bit integer Horner walk per point, then (integer as three signed limbs) x (eq line x 2^517);
+  // reference as above on the lifted field elements.  Patterns drive |t| to its extreme 17 (17^16 - 1) / 16 at C = 16.
+  for (int pat = 0; pat < 3; pat++) for (uint32_t c : {1u, 2u, 5u, 16u}) {
+    const uint32_t degree = c + 1; const size_t half = 256;
+    std::vector<std::vector<uint32_t>> U(2 * c, std::vector<uint32_t>(2 * half)); std::vector<fr_t> E(2 * half);
+    for (size_t i = 0; i < 2 * half; i++) { const bool hi = i >= half; E[i] = pat == 2 && i % 3 == 0 ? edge((int)i) : rand_fr();
+      for (uint32_t m = 0; m < 2 * c; m++) U[m][i] = pat == 0 ? (uint32_t)(rng() & 1) : pat == 1 ? (hi ? 1u : 0u) : ((((m + 1) & 1) != 0) == !hi ? 1u : 0u); }
+    std::vector<std::vector<fr29>> acc(degree + 1, std::vector<fr29>(NTHREADS, fr29_zero()));
+    for (int th = 0; th < NTHREADS; th++) {
+      fr29 sum[18]; for (auto& x : sum) x = fr29_zero();
+      for (size_t i = th; i < half; i += NTHREADS) {
+        __int128 t[18];
+        { const int32_t lo = (int32_t)U[2 * (c - 1)][i], d = (int32_t)U[2 * (c - 1)][i + half] - lo; for (uint32_t k = 0; k <= degree; k++) t[k] = lo + (int32_t)k * d; }
+        for (uint32_t m = c - 1; m-- > 0;) {
+          const int32_t llo = (int32_t)U[2 * m][i], ld = (int32_t)U[2 * m][i + half] - llo, elo = (int32_t)U[2 * m + 1][i], ed = (int32_t)U[2 * m + 1][i + half] - elo;
+          for (uint32_t k = 0; k <= degree; k++) { const int32_t x = (int32_t)k; t[k] = (__int128)(llo + x * ld) + (__int128)(elo + x * ed) * t[k]; }
+        }
+        const fr29 e0 = fr29_weak(lt_eq_times_r2(E[i])), edif = fr29_sub(lt_eq_times_r2(E[i + half]), e0);
+        fr29 ecur = lt_line_at(e0, edif, 0);
+        for (uint32_t k = 0; k <= degree; k++) { sum[k] = lt_weighted_acc(sum[k], lt_int_limbs(t[k]), ecur); ecur = lt_line_step(ecur, edif); }
+      }
+      for (uint32_t k = 0; k <= degree; k++) acc[k][th] = sum[k];
+    }
+    auto at = [](const fr_t& lo, const fr_t& hi, uint32_t x) { fr_t d = fr_sub(hi, lo), v = lo; for (uint32_t k = 0; k < x; k++) v = fr_add(v, d); return v; };
+    for (uint32_t k = 0; k <= degree; k++) {
+      fr_t ref = fr_zero();
+      for (size_t i = 0; i < half; i++) {
+        fr_t g = fr_zero(), prod = fr_one();
+        for (uint32_t m = 0; m < c; m++) { g = fr_add(g, fr_mul(at(fr_from_u64(U[2 * m][i]), fr_from_u64(U[2 * m][i + half]), k), prod)); prod = fr_mul(prod, at(fr_from_u64(U[2 * m + 1][i]), fr_from_u64(U[2 * m + 1][i + half]), k)); }
+        ref = fr_add(ref, fr_mul(g, at(E[i], E[i + half], k)));
+      }
+      CHECK(same(block_sum(acc[k], 0), ref));
+    }
+  }
   printf("OK\n");
   return 0;
 }

@@ -134,6 +134,36 @@ def test_sumcheck_combine_round_and_claim(devs, kind, c, log_m, log_r, n):
 
 
 @pytest.mark.parametrize("c", [1, 2, 3, 5, 8, 16])
+@pytest.mark.parametrize("n", [2, 64, 1 << 13])
+@pytest.mark.parametrize("pattern", ["random", "ones", "alternating"])
+def test_lt_first_round_from_bits(devs, c, n, pattern):
+    """lasso_sumcheck_combine_round_lt_u32: the first round of the LT sumcheck from 0 / 1 integer values (exact 128-bit integer Horner walk + one field product per point) ==
+    the literal round on the lifted field elements; 'ones' / 'alternating' drive the integer magnitudes to their extremes (|t| up to 17 (17^16 - 1) / 16 at C = 16)"""
+    from fieldref import L as FR_P, limbs, to_mont
+    rng = np.random.default_rng(c * 77 + n)
+    if pattern == "random":
+        U = [rng.integers(0, 2, size=n, dtype=np.uint32) for _ in range(2 * c)]
+    elif pattern == "ones":        # lines 0 -> 1 everywhere: value x at point x
+        U = [np.concatenate([np.zeros(n // 2, dtype=np.uint32), np.ones(n // 2, dtype=np.uint32)]) for _ in range(2 * c)]
+    else:                           # lines 1 -> 0 / 0 -> 1 alternating over the memories: values 1 - x and x
+        U = [np.concatenate([np.full(n // 2, (m + 1) & 1, dtype=np.uint32), np.full(n // 2, m & 1, dtype=np.uint32)]) for m in range(2 * c)]
+    one, zero = limbs(to_mont(1, FR_P)), limbs(0)
+    Ps = [np.array([one if x else zero for x in u], dtype=np.uint64).reshape(-1, 4) for u in U]
+    eq = rand_fr(rng, n)
+    S = _abi.Strategy(_abi.KINDS["lt"], c, 4, 0)
+
+    def run(d):
+        pu = [d.upload(u) for u in U]; pp = [d.upload(x) for x in Ps]; pe = d.upload(eq)
+        a = d.sumcheck_combine_round_lt_u32(S, pu, pe, n, c + 1)
+        b = d.sumcheck_combine_round(S, pp, pe, n, c + 1)
+        for p in pu + pp + [pe]:
+            d.free(p)
+        return a, b
+    (a1, b1), (a2, b2) = both(devs, run)
+    assert np.array_equal(a1, b1) and np.array_equal(a1, a2) and np.array_equal(b1, b2)
+
+
+@pytest.mark.parametrize("c", [1, 2, 3, 5, 8, 16])
 @pytest.mark.parametrize("n", [2, 8, 1 << 13])
 def test_lt_round_prescaled_horner(devs, c, n):
     """the prover's LT round: lasso_lt_prescale once, then lasso_sumcheck_combine_round_lt_scaled (Horner form, 1 / 2 / 3 lanes per index at degree <= 5 / 9 / 17) returns
