@@ -49,6 +49,10 @@ pmc xor_c8_m16_2p24_curve25519 --kind xor --c 8
 pmc range_c4_m16_2p26_curve25519 --kind range --c 4 --log-s 26
 timeout 300 python bench.py --kind lt --c 16 --log-s 24 --steps 3 --warmup 1 --no-cpu-baseline --concurrent 0 --no-slab-leg > $OUT/bench_lt_c16_2p24.json 2> $OUT/bench_lt_c16_2p24.err; python -c "
 import json; d=json.loads(open('$OUT/bench_lt_c16_2p24.json').read().strip().splitlines()[-1]); print('lt c16 2^24', round(d['ms_per_step'],2), 'ms', [(k['kernel'][:10], k['ms']) for k in d['kernels_one_profiled_step']])"
+# the N > 1 path end to end on this 1-GPU box: bench.py starts its own two ranks (gloo: they share the device), one proof per rank + ONE proof over both (slab leg, sharded openings; RCCL declines consistently)
+timeout 600 python bench.py --gpus 2 --steps 3 --warmup 1 --no-cpu-baseline --concurrent 0 --slab-steps 1 > $OUT/bench_2ranks_one_gpu_self_launched.json 2> $OUT/bench_2ranks_one_gpu_self_launched.err; echo "2 ranks rc=$?"
+python -c "
+import json; d=json.loads(open('$OUT/bench_2ranks_one_gpu_self_launched.json').read().strip().splitlines()[-1]); print('2 ranks on one GPU: n_gpus', d['n_gpus'], 'ms_per_step', round(d['ms_per_step'],2), 'distinct', d['config']['distinct_proofs'], 'slab', {k: d['slab_mode'].get(k) for k in ('n_gpus','ms_per_proof','parity','rccl_ranks','error')})"
 for ls in 20 22 26 28; do timeout 200 python bench.py --log-s $ls --steps 3 --warmup 1 --no-cpu-baseline --concurrent 0 --no-slab-leg --no-prof > $OUT/bench_2p$ls.json 2>/dev/null; python -c "
 import json; d=json.loads(open('$OUT/bench_2p$ls.json').read().strip().splitlines()[-1]); print('2^$ls', round(d['ms_per_step'],2), 'ms', '%.3e' % d['value'])"; done
 exit 0
