@@ -42,6 +42,10 @@ struct lasso_ctx {
   fr_t* h_small = nullptr;                                // pinned, mapped, coherent
   size_t small_cap = 0;
   uint32_t* h_flag = nullptr; uint32_t* d_flag = nullptr; // sequence flag (mapped), device alias
+  // Since round 3 the round kernels of the sumchecks hand their results over as SELF-VALIDATING chunks instead (poly_kernels.cuh "results for the host": three tagged 16-byte
+  // chunks per element in h_tag, one release fence on the device, no ticket and no flag: 2.1 us per resident turn instead of 4.1, tools/handoff_bench.hip).  LASSO_TAGGED_RESULTS=0: the flag protocol.
+  uint32_t* h_tag = nullptr; uint32_t* d_tag = nullptr;    // small_cap elements of 48 bytes (mapped, zero-initialised: sequence numbers start at 1)
+  bool tagged = true, pending_tagged = false;
   uint32_t seq = 0;
   uint64_t stat_waits = 0; double stat_wait_us = 0;        // host time spent spinning on the flag (lasso_wait_stats)
   fr_t* d_big = nullptr; fr_t* h_big = nullptr; size_t big_cap = 0;   // large results (matvec rows): device buffer + pinned mirror, hipMemcpyAsync
@@ -93,6 +97,11 @@ static int32_t ensure_small(lasso_ctx* c, size_t count) {
   size_t cap = count < 4096 ? 4096 : count;
   HIPCHK(c, hipHostMalloc((void**)&c->h_small, cap * sizeof(fr_t), hipHostMallocMapped | hipHostMallocCoherent));
   HIPCHK(c, hipHostGetDevicePointer((void**)&c->d_small, c->h_small, 0));
+  if (c->h_tag) (void)hipHostFree(c->h_tag);
+  c->h_tag = nullptr; c->d_tag = nullptr;
+  HIPCHK(c, hipHostMalloc((void**)&c->h_tag, cap * 48, hipHostMallocMapped | hipHostMallocCoherent));
+  memset(c->h_tag, 0, cap * 48);
+  HIPCHK(c, hipHostGetDevicePointer((void**)&c->d_tag, c->h_tag, 0));
   c->small_cap = cap; return 0;
 }
 static int32_t ensure_big(lasso_ctx* c, size_t count) {
@@ -152,10 +161,39 @@ static inline fr_t to_fr(const lasso_fr* p) { fr_t r; memcpy(r.v, p, 32); return
 // Wait until the device has stored sequence number `seq` to the mapped flag, then copy `count` results out of the mapped buffer.
 // The producer's stores to h_small are ordered before the flag by a system-scope release on the device (k_publish / publish_flag).
 static inline double now_us() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; }
-static int32_t wait_flag(lasso_ctx* c, uint32_t seq, size_t count, lasso_fr* out) {
-  if (c->defer_next) { c->defer_next = false; c->pending = true; c->pending_seq = seq; c->pending_count = count; return 0; }   // lasso_defer_next: collected by lasso_result_wait
+// One element of the tagged result area (three 16-byte chunks, poly_kernels.cuh result_store): true once all three carry `seq` and the check word agrees.  Each chunk is read with
+// one aligned 16-byte load (the device wrote it with one aligned 16-byte store); the check word also covers a platform that would tear either.
+static inline bool tagged_element(const uint32_t* e, uint32_t seq, uint32_t* w8) {
+  uint32_t c[12];
+#if defined(__SSE2__)
+  for (int k = 0; k < 3; k++) _mm_storeu_si128((__m128i*)(c + 4 * k), _mm_load_si128((const __m128i*)(e + 4 * k)));
+#else
+  for (int k = 0; k < 12; k++) c[k] = __atomic_load_n(e + k, __ATOMIC_ACQUIRE);
+#endif
+  if (c[0] != seq || c[4] != seq || c[8] != seq) return false;
+  w8[0] = c[1]; w8[1] = c[2]; w8[2] = c[3]; w8[3] = c[5]; w8[4] = c[6]; w8[5] = c[7]; w8[6] = c[9]; w8[7] = c[10];
+  return c[11] == (w8[0] ^ w8[1] ^ w8[2] ^ w8[3] ^ w8[4] ^ w8[5] ^ w8[6] ^ w8[7]) + seq * 0x9E3779B9u;
+}
+static int32_t wait_flag(lasso_ctx* c, uint32_t seq, size_t count, lasso_fr* out, bool tagged = false) {
+  if (c->defer_next) { c->defer_next = false; c->pending = true; c->pending_seq = seq; c->pending_count = count; c->pending_tagged = tagged; return 0; }   // lasso_defer_next: collected by lasso_result_wait
   uint64_t spins = 0;
   const double t0 = now_us();
+  if (tagged) {
+    for (size_t e = 0; e < count; e++) {
+      bool last_look = false;
+      while (!tagged_element(c->h_tag + 12 * e, seq, (uint32_t*)(out + e))) {
+        if (last_look) return fail(c, LASSO_ERR_HIP, "a result was not delivered by the device");
+        if ((++spins & 0xffff) == 0) {   // a faulted or finished stream can never deliver it: look once more, then stop
+          hipError_t q = hipStreamQuery(c->stream);
+          if (q == hipSuccess) last_look = true;
+          else if (q != hipErrorNotReady) return fail(c, LASSO_ERR_HIP, std::string("stream error while waiting for a result: ") + hipGetErrorString(q));
+        }
+        __builtin_ia32_pause();
+      }
+    }
+    c->stat_waits++; c->stat_wait_us += now_us() - t0;
+    return 0;
+  }
   while (__atomic_load_n(c->h_flag, __ATOMIC_ACQUIRE) != seq) {
     if ((++spins & 0xffff) == 0) {   // a faulted or finished stream can never raise the flag: stop spinning
       hipError_t q = hipStreamQuery(c->stream);
@@ -168,6 +206,8 @@ static int32_t wait_flag(lasso_ctx* c, uint32_t seq, size_t count, lasso_fr* out
   memcpy(out, c->h_small, count * sizeof(fr_t));
   return 0;
 }
+// where a converted round kernel's results go: (out, flag) arguments of the launch
+#define RES(c) ((c)->tagged ? (fr_t*)(c)->d_tag : (c)->d_small), ((c)->tagged ? LASSO_TAGGED : (c)->d_flag)
 __global__ void k_publish(uint32_t* flag, uint32_t seq) { __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
 // results were stored to d_small (= mapped h_small) by kernels already enqueued on the stream: raise the flag behind them
 static int32_t fetch_small(lasso_ctx* c, size_t count, lasso_fr* out) {
@@ -285,6 +325,7 @@ int32_t lasso_ctx_create_background(int32_t device, int32_t background, lasso_ct
   if (hipMalloc((void**)&c->d_counters, (LASSO_MAX_PTRS + 40) * 4) != hipSuccess || hipMemset(c->d_counters, 0, (LASSO_MAX_PTRS + 40) * 4) != hipSuccess) { delete c; return fail(nullptr, LASSO_ERR_OOM, "counters alloc"); }
   if (hipHostMalloc((void**)&c->h_flag, 256, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess || hipHostGetDevicePointer((void**)&c->d_flag, c->h_flag, 0) != hipSuccess) { delete c; return fail(nullptr, LASSO_ERR_OOM, "mapped flag alloc"); }
   *c->h_flag = 0;
+  { const char* v = getenv("LASSO_TAGGED_RESULTS"); c->tagged = !(v && v[0] == '0'); }   // A/B switch: the flag protocol for every hand-off
   int32_t rc = ensure_small(c, (size_t)1 << 16); if (rc) { g_create_err = c->err; delete c; return rc; }   // 2 MiB of mapped result buffer: the largest a-vector / row-commitment hand-off without a reallocation
   rc = ensure_scratch(c, (size_t)1 << 22); if (rc) { g_create_err = c->err; delete c; return rc; }
   *out = c; return 0;
@@ -318,6 +359,7 @@ void lasso_ctx_destroy(lasso_ctx* c) {
   for (auto& p : c->events) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   if (c->d_scratch) (void)hipFree(c->d_scratch);
   if (c->h_small) (void)hipHostFree(c->h_small);
+  if (c->h_tag) (void)hipHostFree(c->h_tag);
   if (c->h_flag) (void)hipHostFree(c->h_flag);
   if (c->d_big) (void)hipFree(c->d_big);
   if (c->h_big) (void)hipHostFree(c->h_big);
@@ -436,10 +478,10 @@ int32_t lasso_sumcheck_cubic_round(lasso_ctx* c, const lasso_fr* const* d_A, con
   rc = ensure_scratch(c, (size_t)nx * ny * 3 * sizeof(fr_t)); if (rc) return rc;
   {
     ProfScope ps(c, LASSO_K_CUBIC, 32.0 * n * (2.0 * ncirc + 1.0));
-    hipLaunchKernelGGL(k_cubic_round_lb, dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, A, B, nx, ny, (const fr_t*)d_C, half, (fr_t*)c->d_scratch, c->d_counters, c->d_small, c->d_flag, seq);
+    hipLaunchKernelGGL(k_cubic_round_lb, dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, A, B, nx, ny, (const fr_t*)d_C, half, (fr_t*)c->d_scratch, c->d_counters, RES(c), seq);
   }
   HIPCHK(c, hipGetLastError());
-  return wait_flag(c, seq, (size_t)ncirc * 3, out);
+  return wait_flag(c, seq, (size_t)ncirc * 3, out, c->tagged);
 }
 // eq-weighted forms (see k_cubic_eqw_* in poly_kernels.cuh): what the prover calls.  Algorithmic bytes are SURVEY.md §8d's for the reference's round
 // (2k+1 polynomials), although the kernels read only the 2k of A and B plus n/4 .. n/2 table entries.
@@ -455,30 +497,30 @@ static int32_t cubic_eqw_launch(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* co
     const size_t half = n / 2;
     ProfScope ps(c, LASSO_K_CUBIC, 32.0 * n * (2.0 * ncirc + 1.0));
     if (half <= CUBIC_SMALL_Q) {   // arrays are read-only in this mode
-      if (NT == 3) hipLaunchKernelGGL((k_cubic_eqw_small<false, 3>), dim3(ncirc), dim3(LASSO_BLOCK), 0, c->stream, A, B, (const fr_t*)d_E, (uint32_t)half, fr_zero(), c->d_counters, c->d_small, c->d_flag, seq);
-      else hipLaunchKernelGGL((k_cubic_eqw_small<false, 2>), dim3(ncirc), dim3(LASSO_BLOCK), 0, c->stream, A, B, (const fr_t*)d_E, (uint32_t)half, fr_zero(), c->d_counters, c->d_small, c->d_flag, seq);
+      if (NT == 3) hipLaunchKernelGGL((k_cubic_eqw_small<false, 3>), dim3(ncirc), dim3(LASSO_BLOCK), 0, c->stream, A, B, (const fr_t*)d_E, (uint32_t)half, fr_zero(), c->d_counters, RES(c), seq);
+      else hipLaunchKernelGGL((k_cubic_eqw_small<false, 2>), dim3(ncirc), dim3(LASSO_BLOCK), 0, c->stream, A, B, (const fr_t*)d_E, (uint32_t)half, fr_zero(), c->d_counters, RES(c), seq);
     } else {
       PtrTable Ac, Bc; for (uint32_t i = 0; i < ncirc; i++) { Ac.p[i] = A.p[i]; Bc.p[i] = B.p[i]; }
       const unsigned ny = ncirc, nx = grid_for(half, cubic_nx_cap(ny));
       rc = ensure_scratch(c, (size_t)nx * ny * 3 * sizeof(fr_t)); if (rc) return rc;
       static const uint32_t pipe = [] { const char* v = getenv("LASSO_LB_PIPELINE"); return (v && v[0] == '0') ? 0u : 1u; }();
-      if (NT == 3) hipLaunchKernelGGL((k_cubic_eqw_lb<3, false>), dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, Ac, Bc, nx, ny, (const fr_t*)d_E, half, (fr_t*)c->d_scratch, c->d_counters, c->d_small, c->d_flag, seq, 0u, EqInline(), (fr_t*)nullptr);
-      else if (eqi) hipLaunchKernelGGL((k_cubic_eqw_lb<2, true>), dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, Ac, Bc, nx, ny, (const fr_t*)nullptr, half, (fr_t*)c->d_scratch, c->d_counters, c->d_small, c->d_flag, seq, 1u, *eqi, (fr_t*)d_E);
-      else hipLaunchKernelGGL((k_cubic_eqw_lb<2, false>), dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, Ac, Bc, nx, ny, (const fr_t*)d_E, half, (fr_t*)c->d_scratch, c->d_counters, c->d_small, c->d_flag, seq, pipe, EqInline(), (fr_t*)nullptr);
+      if (NT == 3) hipLaunchKernelGGL((k_cubic_eqw_lb<3, false>), dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, Ac, Bc, nx, ny, (const fr_t*)d_E, half, (fr_t*)c->d_scratch, c->d_counters, RES(c), seq, 0u, EqInline(), (fr_t*)nullptr);
+      else if (eqi) hipLaunchKernelGGL((k_cubic_eqw_lb<2, true>), dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, Ac, Bc, nx, ny, (const fr_t*)nullptr, half, (fr_t*)c->d_scratch, c->d_counters, RES(c), seq, 1u, *eqi, (fr_t*)d_E);
+      else hipLaunchKernelGGL((k_cubic_eqw_lb<2, false>), dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, Ac, Bc, nx, ny, (const fr_t*)d_E, half, (fr_t*)c->d_scratch, c->d_counters, RES(c), seq, pipe, EqInline(), (fr_t*)nullptr);
     }
   } else {
     const size_t q = n / 4;
     // bind: read 32n + write 16n per polynomial (SURVEY.md §8d's "fused bind+next-eval" over the reference's 2*ncirc + 1 polynomials)
     ProfScope ps(c, LASSO_K_CUBIC, 48.0 * n * (2.0 * ncirc + 1.0));
     if (q <= CUBIC_SMALL_Q) {
-      if (NT == 3) hipLaunchKernelGGL((k_cubic_eqw_small<true, 3>), dim3(ncirc), dim3(LASSO_BLOCK), 0, c->stream, A, B, (const fr_t*)d_E, (uint32_t)q, to_fr(r), c->d_counters, c->d_small, c->d_flag, seq);
-      else hipLaunchKernelGGL((k_cubic_eqw_small<true, 2>), dim3(ncirc), dim3(LASSO_BLOCK), 0, c->stream, A, B, (const fr_t*)d_E, (uint32_t)q, to_fr(r), c->d_counters, c->d_small, c->d_flag, seq);
+      if (NT == 3) hipLaunchKernelGGL((k_cubic_eqw_small<true, 3>), dim3(ncirc), dim3(LASSO_BLOCK), 0, c->stream, A, B, (const fr_t*)d_E, (uint32_t)q, to_fr(r), c->d_counters, RES(c), seq);
+      else hipLaunchKernelGGL((k_cubic_eqw_small<true, 2>), dim3(ncirc), dim3(LASSO_BLOCK), 0, c->stream, A, B, (const fr_t*)d_E, (uint32_t)q, to_fr(r), c->d_counters, RES(c), seq);
     } else {
       const unsigned ny = ncirc, nx = grid_for(q, cubic_nx_cap(ny));
       rc = ensure_scratch(c, (size_t)nx * ny * 3 * sizeof(fr_t)); if (rc) return rc;
-      if (NT == 3) hipLaunchKernelGGL(k_cubic_eqw_fused<3>, dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, A, B, nx, ny, (const fr_t*)d_E, q, to_fr(r), (fr_t*)c->d_scratch, c->d_counters, c->d_small, c->d_flag, seq);
-      else if (cubic_wide()) hipLaunchKernelGGL((k_cubic_eqw_fused<2, true>), dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, A, B, nx, ny, (const fr_t*)d_E, q, to_fr(r), (fr_t*)c->d_scratch, c->d_counters, c->d_small, c->d_flag, seq);
-      else hipLaunchKernelGGL((k_cubic_eqw_fused<2, false>), dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, A, B, nx, ny, (const fr_t*)d_E, q, to_fr(r), (fr_t*)c->d_scratch, c->d_counters, c->d_small, c->d_flag, seq);
+      if (NT == 3) hipLaunchKernelGGL(k_cubic_eqw_fused<3>, dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, A, B, nx, ny, (const fr_t*)d_E, q, to_fr(r), (fr_t*)c->d_scratch, c->d_counters, RES(c), seq);
+      else if (cubic_wide()) hipLaunchKernelGGL((k_cubic_eqw_fused<2, true>), dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, A, B, nx, ny, (const fr_t*)d_E, q, to_fr(r), (fr_t*)c->d_scratch, c->d_counters, RES(c), seq);
+      else hipLaunchKernelGGL((k_cubic_eqw_fused<2, false>), dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, A, B, nx, ny, (const fr_t*)d_E, q, to_fr(r), (fr_t*)c->d_scratch, c->d_counters, RES(c), seq);
     }
   }
   HIPCHK(c, hipGetLastError());
@@ -487,19 +529,19 @@ static int32_t cubic_eqw_launch(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* co
 int32_t lasso_sumcheck_cubic_eqw_round(lasso_ctx* c, const lasso_fr* const* d_A, const lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n, lasso_fr* out) {
   REQUIRE(c, d_A && d_B && d_E && out && ncirc >= 1 && ncirc <= LASSO_MAX_PTRS && n >= 2 && (n & (n - 1)) == 0);
   uint32_t seq; int32_t rc = cubic_eqw_launch(c, (lasso_fr* const*)d_A, (lasso_fr* const*)d_B, ncirc, d_E, n, nullptr, 3, &seq); if (rc) return rc;
-  return wait_flag(c, seq, (size_t)ncirc * 3, out);
+  return wait_flag(c, seq, (size_t)ncirc * 3, out, c->tagged);
 }
 int32_t lasso_sumcheck_cubic_eqw_round_fused(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n, const lasso_fr* r, lasso_fr* out) {
   REQUIRE(c, d_A && d_B && d_E && r && out && ncirc >= 1 && ncirc <= LASSO_MAX_PTRS && n >= 4 && (n & (n - 1)) == 0);
   uint32_t seq; int32_t rc = cubic_eqw_launch(c, d_A, d_B, ncirc, d_E, n, r, 3, &seq); if (rc) return rc;
-  return wait_flag(c, seq, (size_t)ncirc * 3, out);
+  return wait_flag(c, seq, (size_t)ncirc * 3, out, c->tagged);
 }
 // Two-sum form, split into launch and wait so that the host can prepare the round's scalars (one field inversion) while the kernel runs.
 // out (lasso_result_wait) = ncirc pairs (q(0), q_inf) — see cubic_eqw_terms2 in poly_kernels.cuh.  One result may be pending per context.
 int32_t lasso_sumcheck_cubic_eqw2_begin(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n, const lasso_fr* r) {
   REQUIRE(c, d_A && d_B && d_E && ncirc >= 1 && ncirc <= LASSO_MAX_PTRS && n >= (r ? 4u : 2u) && (n & (n - 1)) == 0 && !c->pending);
   uint32_t seq; int32_t rc = cubic_eqw_launch(c, d_A, d_B, ncirc, d_E, n, r, 2, &seq); if (rc) return rc;
-  c->pending = true; c->pending_seq = seq; c->pending_count = (size_t)ncirc * 2;
+  c->pending = true; c->pending_seq = seq; c->pending_count = (size_t)ncirc * 2; c->pending_tagged = c->tagged;
   return 0;
 }
 // The next entry point that hands its result over through the mapped buffer (the sumcheck rounds, the few-row MSMs, lasso_bullet_round ...)
@@ -528,7 +570,7 @@ int32_t lasso_sumcheck_cubic_eqw2_begin_eq(lasso_ctx* c, lasso_fr* const* d_A, l
   EqInline Q;
   if (n / 2 <= CUBIC_SMALL_Q || !make_eq_inline(point, ell, scale, Q)) return fail(c, LASSO_ERR_UNSUPPORTED, "lasso_sumcheck_cubic_eqw2_begin_eq: tables of 2^7 .. 2^14 entries only");
   uint32_t seq; int32_t rc = cubic_eqw_launch(c, d_A, d_B, ncirc, d_E_out, n, nullptr, 2, &seq, &Q); if (rc) return rc;
-  c->pending = true; c->pending_seq = seq; c->pending_count = (size_t)ncirc * 2;
+  c->pending = true; c->pending_seq = seq; c->pending_count = (size_t)ncirc * 2; c->pending_tagged = c->tagged;
   return 0;
 }
 // lasso_sumcheck_cubic_tail_begin(.., r = NULL) without a table: the resident kernel derives E = *scale * EqPolynomial(point[0..ell)).evals(), 2^ell = n/2 <= capacity, itself
@@ -546,13 +588,13 @@ static int32_t cubic_tail_begin_impl(lasso_ctx* c, lasso_fr* const* d_A, lasso_f
   uint32_t turns = 0; while (((size_t)1 << turns) < 2 * q) turns++;   // rounds of sums; one more publication carries the heads
   const uint32_t seq0 = c->seq + 1; c->seq += turns + 1;
   // workgroup = capacity: 256 threads / 74 KB of LDS up to 256 indices per circuit, 512 threads / 147 KB above
-#define LAUNCH_CTAIL(B_, Q_, I_, R_, EQ_) hipLaunchKernelGGL((k_cubic_tail<B_, Q_, I_>), dim3(ncirc), dim3(Q_), 0, c->stream, A, B, (const fr_t*)d_E, (uint32_t)q, R_, (const uint32_t*)(c->d_flag + 32), c->d_counters, c->d_small, c->d_flag, seq0, EQ_)
+#define LAUNCH_CTAIL(B_, Q_, I_, R_, EQ_) hipLaunchKernelGGL((k_cubic_tail<B_, Q_, I_>), dim3(ncirc), dim3(Q_), 0, c->stream, A, B, (const fr_t*)d_E, (uint32_t)q, R_, (const uint32_t*)(c->d_flag + 32), c->d_counters, RES(c), seq0, EQ_)
   if (eqi) { if (q <= 256) LAUNCH_CTAIL(false, 256, true, fr_zero(), *eqi); else LAUNCH_CTAIL(false, 512, true, fr_zero(), *eqi); }
   else if (q <= 256) { if (r) LAUNCH_CTAIL(true, 256, false, to_fr(r), EqInline()); else LAUNCH_CTAIL(false, 256, false, fr_zero(), EqInline()); }
   else { if (r) LAUNCH_CTAIL(true, 512, false, to_fr(r), EqInline()); else LAUNCH_CTAIL(false, 512, false, fr_zero(), EqInline()); }
   HIPCHK(c, hipGetLastError());
   c->tail_active = true; c->tail_seq0 = seq0; c->tail_turn = 0; c->tail_turns = turns; c->tail_count = (size_t)ncirc * 2; c->tail_final = (size_t)ncirc * 2;
-  c->pending = true; c->pending_seq = seq0; c->pending_count = c->tail_count;
+  c->pending = true; c->pending_seq = seq0; c->pending_count = c->tail_count; c->pending_tagged = c->tagged;
   return 0;
 }
 // The same for the primary sumcheck of a linear strategy (k_linear_tail): per round two dot products per polynomial, out[2k] = S0_k, out[2k+1] = S1_k
@@ -566,12 +608,12 @@ int32_t lasso_sumcheck_linear_tail_begin(lasso_ctx* c, const lasso_fr* const* d_
   int32_t rc = ensure_small(c, (size_t)alpha * 3); if (rc) return rc;
   uint32_t turns = 0; while (((size_t)1 << turns) < 2 * q) turns++;
   const uint32_t seq0 = c->seq + 1; c->seq += turns + 1;
-#define LAUNCH_LTAIL(B_, Q_, R_) hipLaunchKernelGGL((k_linear_tail<B_, Q_>), dim3(alpha), dim3(Q_), 0, c->stream, Src, (const fr_t*)d_E, (uint32_t)q, R_, (const uint32_t*)(c->d_flag + 32), c->d_counters, c->d_small, c->d_flag, seq0)
+#define LAUNCH_LTAIL(B_, Q_, R_) hipLaunchKernelGGL((k_linear_tail<B_, Q_>), dim3(alpha), dim3(Q_), 0, c->stream, Src, (const fr_t*)d_E, (uint32_t)q, R_, (const uint32_t*)(c->d_flag + 32), c->d_counters, RES(c), seq0)
   if (q <= 256) { if (r) LAUNCH_LTAIL(true, 256, to_fr(r)); else LAUNCH_LTAIL(false, 256, fr_zero()); }
   else { if (r) LAUNCH_LTAIL(true, 512, to_fr(r)); else LAUNCH_LTAIL(false, 512, fr_zero()); }
   HIPCHK(c, hipGetLastError());
   c->tail_active = true; c->tail_seq0 = seq0; c->tail_turn = 0; c->tail_turns = turns; c->tail_count = (size_t)alpha * 2; c->tail_final = alpha;
-  c->pending = true; c->pending_seq = seq0; c->pending_count = c->tail_count;
+  c->pending = true; c->pending_seq = seq0; c->pending_count = c->tail_count; c->pending_tagged = c->tagged;
   return 0;
 }
 int32_t lasso_sumcheck_cubic_tail_next(lasso_ctx* c, const lasso_fr* r) {
@@ -587,7 +629,7 @@ int32_t lasso_sumcheck_cubic_tail_next(lasso_ctx* c, const lasso_fr* r) {
   _mm_store_si128((__m128i*)(mail + 8), _mm_set_epi32(0, (int)rr.v[7], (int)rr.v[6], (int)tn));
   __atomic_thread_fence(__ATOMIC_RELEASE);
   const size_t cnt = c->tail_turn == c->tail_turns ? c->tail_final : c->tail_count;
-  if (cnt) { c->pending = true; c->pending_seq = c->tail_seq0 + c->tail_turn; c->pending_count = cnt; }
+  if (cnt) { c->pending = true; c->pending_seq = c->tail_seq0 + c->tail_turn; c->pending_count = cnt; c->pending_tagged = c->tagged; }
   if (c->tail_turn == c->tail_turns) c->tail_active = false;
   return 0;
 }
@@ -597,7 +639,7 @@ int32_t lasso_defer_next(lasso_ctx* c) { REQUIRE(c, !c->pending && !c->defer_nex
 int32_t lasso_result_wait(lasso_ctx* c, lasso_fr* out, size_t count) {
   REQUIRE(c, out && c->pending && count == c->pending_count);
   c->pending = false;
-  return wait_flag(c, c->pending_seq, count, out);
+  return wait_flag(c, c->pending_seq, count, out, c->pending_tagged);
 }
 // eq-weighted rounds of prove_arbitrary for the linear strategies (k_dot_eqw_* in poly_kernels.cuh)
 int32_t lasso_sumcheck_linear_eqw_round(lasso_ctx* c, const lasso_fr* const* d_polys, uint32_t alpha, const lasso_fr* d_E, size_t n, lasso_fr* out) {
@@ -609,10 +651,10 @@ int32_t lasso_sumcheck_linear_eqw_round(lasso_ctx* c, const lasso_fr* const* d_p
   const uint32_t seq = ++c->seq;
   {
     ProfScope ps(c, LASSO_K_COMBINE, 32.0 * n * (alpha + 1.0));
-    hipLaunchKernelGGL(k_dot_eqw_lb, dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, P, nx, ny, (const fr_t*)d_E, half, (fr_t*)c->d_scratch, c->d_counters, c->d_small, c->d_flag, seq);
+    hipLaunchKernelGGL(k_dot_eqw_lb, dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, P, nx, ny, (const fr_t*)d_E, half, (fr_t*)c->d_scratch, c->d_counters, RES(c), seq);
   }
   HIPCHK(c, hipGetLastError());
-  return wait_flag(c, seq, (size_t)alpha * 3, out);
+  return wait_flag(c, seq, (size_t)alpha * 3, out, c->tagged);
 }
 int32_t lasso_sumcheck_linear_eqw_round_fused(lasso_ctx* c, lasso_fr* const* d_polys, uint32_t alpha, const lasso_fr* d_E, size_t n, const lasso_fr* r, lasso_fr* out) {
   return lasso_sumcheck_linear_eqw_round_fused_from(c, (const lasso_fr* const*)d_polys, d_polys, alpha, d_E, n, r, out);
@@ -627,10 +669,10 @@ int32_t lasso_sumcheck_linear_eqw_round_fused_from(lasso_ctx* c, const lasso_fr*
   {
     // bind (48 n per polynomial, the reference's alpha + 1 of them) with the next round's sums riding on the same pass
     ProfScope ps(c, LASSO_K_BIND, 48.0 * n * (alpha + 1.0));
-    hipLaunchKernelGGL(k_dot_eqw_fused, dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, Src, P, nx, ny, (const fr_t*)d_E, q, to_fr(r), (fr_t*)c->d_scratch, c->d_counters, c->d_small, c->d_flag, seq);
+    hipLaunchKernelGGL(k_dot_eqw_fused, dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, Src, P, nx, ny, (const fr_t*)d_E, q, to_fr(r), (fr_t*)c->d_scratch, c->d_counters, RES(c), seq);
   }
   HIPCHK(c, hipGetLastError());
-  return wait_flag(c, seq, (size_t)alpha * 3, out);
+  return wait_flag(c, seq, (size_t)alpha * 3, out, c->tagged);
 }
 // the first round and the first bind of the primary sumcheck from the lookup polynomials' integer values (k_dot_eqw_lb_u32 / k_dot_eqw_fused_from_u32)
 int32_t lasso_sumcheck_linear_eqw_round_u32(lasso_ctx* c, const uint32_t* const* d_u32, uint32_t alpha, const lasso_fr* d_E, size_t n, lasso_fr* out) {
@@ -642,10 +684,10 @@ int32_t lasso_sumcheck_linear_eqw_round_u32(lasso_ctx* c, const uint32_t* const*
   const uint32_t seq = ++c->seq;
   {
     ProfScope ps(c, LASSO_K_COMBINE, 32.0 * n * (alpha + 1.0));   // SURVEY 8(d)'s bytes of the reference's round; the kernel reads 4 n per polynomial + 16 n of the table
-    hipLaunchKernelGGL(k_dot_eqw_lb_u32, dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, P, nx, ny, (const fr_t*)d_E, half, (fr_t*)c->d_scratch, c->d_counters, c->d_small, c->d_flag, seq);
+    hipLaunchKernelGGL(k_dot_eqw_lb_u32, dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, P, nx, ny, (const fr_t*)d_E, half, (fr_t*)c->d_scratch, c->d_counters, RES(c), seq);
   }
   HIPCHK(c, hipGetLastError());
-  return wait_flag(c, seq, (size_t)alpha * 3, out);
+  return wait_flag(c, seq, (size_t)alpha * 3, out, c->tagged);
 }
 int32_t lasso_sumcheck_linear_eqw_round_fused_from_u32(lasso_ctx* c, const uint32_t* const* d_u32, lasso_fr* const* d_polys, uint32_t alpha, const lasso_fr* d_E, size_t n, const lasso_fr* r, lasso_fr* out) {
   REQUIRE(c, d_u32 && d_polys && d_E && r && out && alpha >= 1 && alpha <= LASSO_MAX_PTRS && n >= 4 && (n & (n - 1)) == 0);
@@ -656,10 +698,10 @@ int32_t lasso_sumcheck_linear_eqw_round_fused_from_u32(lasso_ctx* c, const uint3
   const uint32_t seq = ++c->seq;
   {
     ProfScope ps(c, LASSO_K_BIND, 48.0 * n * (alpha + 1.0));
-    hipLaunchKernelGGL(k_dot_eqw_fused_from_u32, dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, Src, P, nx, ny, (const fr_t*)d_E, q, to_fr(r), (fr_t*)c->d_scratch, c->d_counters, c->d_small, c->d_flag, seq);
+    hipLaunchKernelGGL(k_dot_eqw_fused_from_u32, dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, Src, P, nx, ny, (const fr_t*)d_E, q, to_fr(r), (fr_t*)c->d_scratch, c->d_counters, RES(c), seq);
   }
   HIPCHK(c, hipGetLastError());
-  return wait_flag(c, seq, (size_t)alpha * 3, out);
+  return wait_flag(c, seq, (size_t)alpha * 3, out, c->tagged);
 }
 static int32_t make_strategy(lasso_ctx* c, const lasso_strategy* s, StrategyDev& S, WeightTable& W) {
   REQUIRE(c, s && s->kind >= LASSO_AND && s->kind <= LASSO_RANGE && s->c >= 1);
