@@ -439,6 +439,12 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_eqw_small(MutPtrTable A, 
 // Q = capacity in indices per circuit = threads of the workgroup: 256 (74 KB of LDS) or, since round 3, 512 (147 KB of the CU's 160 KB: one streaming round fewer per layer —
 // a resident turn costs ~10 us where a launch-per-round costs ~25 us at these sizes, profiles/r03_kernel_trace_one_proof_2p24.csv)
 #define CUBIC_TAIL_Q 512   // the resident kernels take over at <= this many indices per circuit
+#ifdef TAIL_PHASE_CLOCK   // tools/tail_phase_bench.hip: workgroup 0 stamps the 100 MHz wall clock at the phase boundaries of each of its first 16 turns
+__device__ uint64_t tail_phase_clock[16 * 8];
+#define TAIL_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x == 0 && turn < 16) tail_phase_clock[turn * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define TAIL_STAMP(k) do { } while (0)
+#endif
 // EQI (first round of a layer only): the eq table is never materialised — the two factor tables are built in LDS (eq_inline_build, <= 32 entries each at q <= 512) and
 // every use of E[i] is one product.
 template <bool BIND, int Q, bool EQI = false>
@@ -477,15 +483,22 @@ __global__ void __launch_bounds__(Q) k_cubic_tail(MutPtrTable A, MutPtrTable B, 
   __syncthreads();
   for (uint32_t turn = 0;; turn++) {
     const uint32_t h = m / 2;      // pairs this round
+    TAIL_STAMP(0);
     // 2h terms: u < h the q(0) terms, u >= h the leading-coefficient terms; row u of `rows`
     for (uint32_t u = t; u < 2 * h; u += Q) {
       const uint32_t v = u >= h ? 1u : 0u, i = u - v * h;
+      // operands selected, ONE product: at h <= 32 both kinds of term sit in the same wave, and a branch per kind would run the product twice
       const fr29 g0 = ge[i], g1 = ge[i + h], b0 = bound[1][i], b1 = bound[1][i + h];
-      const fr29 term = v == 0 ? fr29_mul(b0, g0) : fr29_mul(fr29_sub(g1, g0), fr29_sub(b1, b0));
+      const fr29 dg = fr29_sub(g1, g0), db = fr29_sub(b1, b0);
+      fr29 fa, fb;
+#pragma unroll
+      for (int k = 0; k < 9; k++) { fa.v[k] = v ? dg.v[k] : b0.v[k]; fb.v[k] = v ? db.v[k] : g0.v[k]; }
+      const fr29 term = fr29_mul(fa, fb);
 #pragma unroll
       for (int k = 0; k < 9; k++) rows[u * 9 + k] = term.v[k];
     }
     __syncthreads();
+    TAIL_STAMP(1);
     if (h > 16) {   // eight strips of rows per (sum, limb) column, then the strips
       if (t < 8 * 18) {
         const uint32_t col = t % 18, strip = t / 18, v = col / 9, k = col - v * 9;
@@ -503,6 +516,7 @@ __global__ void __launch_bounds__(Q) k_cubic_tail(MutPtrTable A, MutPtrTable B, 
       cols[t] = sum;
     }
     __syncthreads();
+    TAIL_STAMP(2);
     if (t < 2) {
       int64_t c[9];
 #pragma unroll
@@ -510,6 +524,19 @@ __global__ void __launch_bounds__(Q) k_cubic_tail(MutPtrTable A, MutPtrTable B, 
       result_store(out, (size_t)y * 2 + t, fr29_pack(fr29_reduce_columns(c, 5)), flag, seq0 + turn);
     }
     row_done(ncirc, counters, flag, seq0 + turn);
+    TAIL_STAMP(3);
+    // everything of the coming bind that does not depend on the challenge, while it travels: the pair (lo, hi - lo) of every lane task and the eq weight of the A tasks
+    const uint32_t hn = h / 2;     // pairs of the NEXT round
+    fr29 blo[2], bdf[2], bw[2];
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+      const uint32_t u = t + pass * Q;
+      if (u < 2 * h) {
+        const uint32_t p = u >= h ? 1u : 0u, jx = u - p * h;
+        blo[pass] = bound[p][jx]; bdf[pass] = fr29_sub(bound[p][jx + h], blo[pass]);
+        if (p == 0 && h > 1) bw[pass] = TAIL_EQ_S(jx < hn ? jx : jx - hn);
+      }
+    }
     // the host's answer: the round's challenge
     if (t == 0) {
       // three self-validating 16-byte chunks [turn, w, w, w]: the host writes each with one aligned 16-byte store and a PCIe read of an aligned
@@ -529,27 +556,22 @@ __global__ void __launch_bounds__(Q) k_cubic_tail(MutPtrTable A, MutPtrTable B, 
     }
     __syncthreads();
     if (!alive) return;
+    TAIL_STAMP(4);
     const fr29 rs = fr29_unpack_s(chal);
-    // bind in LDS: 2h lane tasks (array p, index j); the A tasks also produce the next round's weighted value.  Results first, stores after
-    // the barrier (task (p, j) reads j and j + h of array p)
-    const uint32_t hn = h / 2;     // pairs of the NEXT round
-    fr29 nb[2], ng[2];
+    // bind in LDS: 2h lane tasks (array p, index j); the A tasks also produce the next round's weighted value.  Every task read its operands before the
+    // barrier above, so the results can be stored at once
 #pragma unroll
     for (int pass = 0; pass < 2; pass++) {
       const uint32_t u = t + pass * Q;
       if (u < 2 * h) {
         const uint32_t p = u >= h ? 1u : 0u, jx = u - p * h;
-        nb[pass] = fr29_canonical(fr29_add(bound[p][jx], fr29_mul(fr29_sub(bound[p][jx + h], bound[p][jx]), rs)));
-        if (p == 0 && h > 1) ng[pass] = fr29_mul(nb[pass], TAIL_EQ_S(jx < hn ? jx : jx - hn));
+        const fr29 nb = fr29_canonical(fr29_add(blo[pass], fr29_mul(bdf[pass], rs)));
+        bound[p][jx] = nb;
+        if (p == 0 && h > 1) ge[jx] = fr29_mul(nb, bw[pass]);
       }
     }
     __syncthreads();
-#pragma unroll
-    for (int pass = 0; pass < 2; pass++) {
-      const uint32_t u = t + pass * Q;
-      if (u < 2 * h) { const uint32_t p = u >= h ? 1u : 0u, jx = u - p * h; bound[p][jx] = nb[pass]; if (p == 0 && h > 1) ge[jx] = ng[pass]; }
-    }
-    __syncthreads();
+    TAIL_STAMP(5);
     m = h;
     if (m == 1) {
       if (t < 2) result_store(out, (size_t)t * ncirc + y, fr29_pack(bound[t][0]), flag, seq0 + turn + 1);
