@@ -187,21 +187,30 @@ def concurrent_leg(HostProver, _abi, streams, steps, S, c, log_m, log_s, curve="
         hp.prove(dense, gens, S, r)      # warm-up
         workers.append((hp, dense, gens, r))
     bar = threading.Barrier(streams + 1)
+    errors = []
 
     def run(w):
         hp, dense, gens, r = w
-        bar.wait()
-        for _ in range(steps):
-            hp.prove(dense, gens, S, r)
-        bar.wait()
+        try:
+            bar.wait(timeout=120)
+            for _ in range(steps):
+                hp.prove(dense, gens, S, r)
+            bar.wait(timeout=120)
+        except Exception as e:   # a failed proof must not leave the others (and the bench line) waiting at the barrier
+            errors.append(repr(e)); bar.abort()
     ths = [threading.Thread(target=run, args=(w,)) for w in workers]
     for th in ths:
         th.start()
-    bar.wait(); t0 = time.perf_counter(); bar.wait(); el = time.perf_counter() - t0
+    try:
+        bar.wait(timeout=120); t0 = time.perf_counter(); bar.wait(timeout=120); el = time.perf_counter() - t0
+    except threading.BrokenBarrierError:
+        errors.append("barrier broken")
     for th in ths:
         th.join()
     for hp, dense, gens, r in workers:
         hp.free(dense, gens); hp.close()
+    if errors:
+        return {"streams": streams, "error": "; ".join(errors)[:400]}
     return {"streams": streams, "proofs": streams * steps, "value": streams * steps * s / el, "unit": "lookups/s", "ms_per_round_of_proofs": el / steps * 1e3,
             "note": "independent proofs proved concurrently on one GPU (one context, stream and host thread each); not the headline metric"}
 

@@ -46,6 +46,9 @@ struct lasso_ctx {
   // chunks per element in h_tag, one release fence on the device, no ticket and no flag: 2.1 us per resident turn instead of 4.1, tools/handoff_bench.hip).  LASSO_TAGGED_RESULTS=0: the flag protocol.
   uint32_t* h_tag = nullptr; uint32_t* d_tag = nullptr;    // small_cap elements of 48 bytes (mapped, zero-initialised: sequence numbers start at 1)
   bool tagged = true, pending_tagged = false;
+  // The resident tails' mailbox: three tagged 16-byte chunks of host-mapped memory (h_flag + 32) the kernel polls (k_cubic_tail).  Putting it in device memory the host writes through the BAR
+  // (hsa_amd_agents_allow_access) was tried in round 3: 2.5 -> 2.1 us per empty turn in tools/pingpong_bench.hip, nothing measurable in a proof, and hand-offs lost with four contexts proving at once — dropped.
+  uint32_t* mail_h = nullptr; uint32_t* mail_d = nullptr;
   uint32_t seq = 0;
   uint64_t stat_waits = 0; double stat_wait_us = 0;        // host time spent spinning on the flag (lasso_wait_stats)
   fr_t* d_big = nullptr; fr_t* h_big = nullptr; size_t big_cap = 0;   // large results (matvec rows): device buffer + pinned mirror, hipMemcpyAsync
@@ -306,6 +309,16 @@ int32_t lasso_points_reduce_compress(lasso_ctx* c, const void* d_parts, uint32_t
   return 0;
 }
 
+// three self-validating chunks [tag, w, w, w] [tag, w, w, w] [tag, w, w, check], each ONE aligned 16-byte store; the check word (result_check's formula) lets the kernel reject a chunk
+// that arrived in pieces
+static inline void post_mail(lasso_ctx* c, uint32_t tag, const uint32_t w[8]) {
+  const uint32_t chk = (w[0] ^ w[1] ^ w[2] ^ w[3] ^ w[4] ^ w[5] ^ w[6] ^ w[7]) + tag * 0x9E3779B9u;
+  uint32_t* mail = c->mail_h;
+  _mm_store_si128((__m128i*)(mail + 0), _mm_set_epi32((int)w[2], (int)w[1], (int)w[0], (int)tag));
+  _mm_store_si128((__m128i*)(mail + 4), _mm_set_epi32((int)w[5], (int)w[4], (int)w[3], (int)tag));
+  _mm_store_si128((__m128i*)(mail + 8), _mm_set_epi32((int)chk, (int)w[7], (int)w[6], (int)tag));
+  _mm_sfence();   // release: the chunks are globally visible before anything the host does next
+}
 int32_t lasso_ctx_create(int32_t device, lasso_ctx** out) { return lasso_ctx_create_background(device, 0, out); }
 // background != 0: the context's stream gets the LOWEST priority the device offers (the prover's side context: bulk work that must not delay
 // the latency-bound kernels of the main context); otherwise the highest.
@@ -326,6 +339,8 @@ int32_t lasso_ctx_create_background(int32_t device, int32_t background, lasso_ct
   if (hipHostMalloc((void**)&c->h_flag, 256, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess || hipHostGetDevicePointer((void**)&c->d_flag, c->h_flag, 0) != hipSuccess) { delete c; return fail(nullptr, LASSO_ERR_OOM, "mapped flag alloc"); }
   *c->h_flag = 0;
   { const char* v = getenv("LASSO_TAGGED_RESULTS"); c->tagged = !(v && v[0] == '0'); }   // A/B switch: the flag protocol for every hand-off
+  c->mail_h = c->h_flag + 32; c->mail_d = c->d_flag + 32;   // 128-byte offset: 16-byte aligned chunks
+  memset(c->mail_h, 0, 48);
   int32_t rc = ensure_small(c, (size_t)1 << 16); if (rc) { g_create_err = c->err; delete c; return rc; }   // 2 MiB of mapped result buffer: the largest a-vector / row-commitment hand-off without a reallocation
   rc = ensure_scratch(c, (size_t)1 << 22); if (rc) { g_create_err = c->err; delete c; return rc; }
   *out = c; return 0;
@@ -335,16 +350,11 @@ int32_t lasso_ctx_create_background(int32_t device, int32_t background, lasso_ct
 // after the 5 s bail-out), drain the stream, clear the mailbox and the protocol state, and restore the "tickets are zero between launches" invariant.
 int32_t lasso_abort(lasso_ctx* c) {
   REQUIRE(c, c);
-  uint32_t* mail = c->h_flag + 32;
-  if (c->tail_active) {
-    const __m128i poison = _mm_set_epi32(0, 0, 0, (int)LASSO_MAIL_POISON);
-    _mm_store_si128((__m128i*)(mail + 0), poison); _mm_store_si128((__m128i*)(mail + 4), poison); _mm_store_si128((__m128i*)(mail + 8), poison);
-    __atomic_thread_fence(__ATOMIC_RELEASE);
-  }
+  const uint32_t zero8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (c->tail_active) post_mail(c, LASSO_MAIL_POISON, zero8);
   (void)hipStreamSynchronize(c->stream);   // bounded: every device-side wait has the poison check and a wall-clock bail-out
   (void)hipGetLastError();
-  const __m128i zero = _mm_setzero_si128();
-  _mm_store_si128((__m128i*)(mail + 0), zero); _mm_store_si128((__m128i*)(mail + 4), zero); _mm_store_si128((__m128i*)(mail + 8), zero);
+  post_mail(c, 0, zero8);
   c->tail_active = false; c->pending = false; c->defer_next = false; c->events_used = 0;
   HIPCHK(c, hipMemsetAsync(c->d_counters, 0, (LASSO_MAX_PTRS + 40) * 4, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -588,7 +598,7 @@ static int32_t cubic_tail_begin_impl(lasso_ctx* c, lasso_fr* const* d_A, lasso_f
   uint32_t turns = 0; while (((size_t)1 << turns) < 2 * q) turns++;   // rounds of sums; one more publication carries the heads
   const uint32_t seq0 = c->seq + 1; c->seq += turns + 1;
   // workgroup = capacity: 256 threads / 74 KB of LDS up to 256 indices per circuit, 512 threads / 147 KB above
-#define LAUNCH_CTAIL(B_, Q_, I_, R_, EQ_) hipLaunchKernelGGL((k_cubic_tail<B_, Q_, I_>), dim3(ncirc), dim3(Q_), 0, c->stream, A, B, (const fr_t*)d_E, (uint32_t)q, R_, (const uint32_t*)(c->d_flag + 32), c->d_counters, RES(c), seq0, EQ_)
+#define LAUNCH_CTAIL(B_, Q_, I_, R_, EQ_) hipLaunchKernelGGL((k_cubic_tail<B_, Q_, I_>), dim3(ncirc), dim3(Q_), 0, c->stream, A, B, (const fr_t*)d_E, (uint32_t)q, R_, (const uint32_t*)c->mail_d, c->d_counters, RES(c), seq0, EQ_)
   if (eqi) { if (q <= 256) LAUNCH_CTAIL(false, 256, true, fr_zero(), *eqi); else LAUNCH_CTAIL(false, 512, true, fr_zero(), *eqi); }
   else if (q <= 256) { if (r) LAUNCH_CTAIL(true, 256, false, to_fr(r), EqInline()); else LAUNCH_CTAIL(false, 256, false, fr_zero(), EqInline()); }
   else { if (r) LAUNCH_CTAIL(true, 512, false, to_fr(r), EqInline()); else LAUNCH_CTAIL(false, 512, false, fr_zero(), EqInline()); }
@@ -608,7 +618,7 @@ int32_t lasso_sumcheck_linear_tail_begin(lasso_ctx* c, const lasso_fr* const* d_
   int32_t rc = ensure_small(c, (size_t)alpha * 3); if (rc) return rc;
   uint32_t turns = 0; while (((size_t)1 << turns) < 2 * q) turns++;
   const uint32_t seq0 = c->seq + 1; c->seq += turns + 1;
-#define LAUNCH_LTAIL(B_, Q_, R_) hipLaunchKernelGGL((k_linear_tail<B_, Q_>), dim3(alpha), dim3(Q_), 0, c->stream, Src, (const fr_t*)d_E, (uint32_t)q, R_, (const uint32_t*)(c->d_flag + 32), c->d_counters, RES(c), seq0)
+#define LAUNCH_LTAIL(B_, Q_, R_) hipLaunchKernelGGL((k_linear_tail<B_, Q_>), dim3(alpha), dim3(Q_), 0, c->stream, Src, (const fr_t*)d_E, (uint32_t)q, R_, (const uint32_t*)c->mail_d, c->d_counters, RES(c), seq0)
   if (q <= 256) { if (r) LAUNCH_LTAIL(true, 256, to_fr(r)); else LAUNCH_LTAIL(false, 256, fr_zero()); }
   else { if (r) LAUNCH_LTAIL(true, 512, to_fr(r)); else LAUNCH_LTAIL(false, 512, fr_zero()); }
   HIPCHK(c, hipGetLastError());
@@ -618,16 +628,11 @@ int32_t lasso_sumcheck_linear_tail_begin(lasso_ctx* c, const lasso_fr* const* d_
 }
 int32_t lasso_sumcheck_cubic_tail_next(lasso_ctx* c, const lasso_fr* r) {
   REQUIRE(c, r && c->tail_active && !c->pending);
-  uint32_t* mail = c->h_flag + 32;   // 128-byte offset: 16-byte aligned chunks
   const fr_t rr = to_fr(r);
   c->tail_turn++;
   const uint32_t tn = c->tail_seq0 + c->tail_turn;   // = the sequence number of the publication this challenge enables: tags are unique, the mailbox is never reset
                                                       // (a reset could erase a challenge some workgroup of a multi-workgroup kernel has not read yet)
-  // three self-validating chunks, each ONE aligned 16-byte store (atomic on every x86 with AVX), see k_cubic_tail
-  _mm_store_si128((__m128i*)(mail + 0), _mm_set_epi32((int)rr.v[2], (int)rr.v[1], (int)rr.v[0], (int)tn));
-  _mm_store_si128((__m128i*)(mail + 4), _mm_set_epi32((int)rr.v[5], (int)rr.v[4], (int)rr.v[3], (int)tn));
-  _mm_store_si128((__m128i*)(mail + 8), _mm_set_epi32(0, (int)rr.v[7], (int)rr.v[6], (int)tn));
-  __atomic_thread_fence(__ATOMIC_RELEASE);
+  post_mail(c, tn, rr.v);
   const size_t cnt = c->tail_turn == c->tail_turns ? c->tail_final : c->tail_count;
   if (cnt) { c->pending = true; c->pending_seq = c->tail_seq0 + c->tail_turn; c->pending_count = cnt; c->pending_tagged = c->tagged; }
   if (c->tail_turn == c->tail_turns) c->tail_active = false;

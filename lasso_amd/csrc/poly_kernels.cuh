@@ -433,7 +433,8 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_eqw_small(MutPtrTable A, 
 // waits for the host's next challenge in a host-mapped mailbox (tools/pingpong_bench.hip).  So: bind (or load) into LDS once, then per round
 // publish the two sums (q(0), q_inf) through the mapped result buffer + flag, spin on the mailbox, bind in LDS, ... and finally publish the
 // bound heads A[0], B[0] (sumcheck.rs:126-133) — the arrays never go back to HBM (nothing reads a layer's bound arrays after its sumcheck).
-// One workgroup per circuit.  mailbox (host-mapped): three 16-byte chunks [tag, w0, w1, w2] [tag, w3, w4, w5] [tag, w6, w7, 0], w = the challenge, tag = seq0 + turn + 1;
+// One workgroup per circuit.  mailbox (host-mapped memory, or device memory the host writes through the BAR: lasso_hip.hip device_mailbox): three 16-byte chunks
+// [tag, w0, w1, w2] [tag, w3, w4, w5] [tag, w6, w7, check], w = the challenge, tag = seq0 + turn + 1, check = result_check's formula;
 // turn k's results carry sequence number seq0 + k.  Every spin has a wall-clock bail-out: a host that never answers cannot hang the device.
 // out (2 * ncirc elements per turn): sums turns: out[2c], out[2c+1];  final turn: out[c] = A_c head, out[ncirc + c] = B_c head.
 // Q = capacity in indices per circuit = threads of the workgroup: 256 (74 KB of LDS) or, since round 3, 512 (147 KB of the CU's 160 KB: one streaming round fewer per layer —
@@ -548,7 +549,7 @@ __global__ void __launch_bounds__(Q) k_cubic_tail(MutPtrTable A, MutPtrTable B, 
       for (;;) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");   // nothing cached from the previous poll
         c0 = __builtin_nontemporal_load(m4); c1 = __builtin_nontemporal_load(m4 + 1); c2 = __builtin_nontemporal_load(m4 + 2);   // three 16-byte reads in flight together
-        if (c0.x == seq0 + turn + 1 && c1.x == seq0 + turn + 1 && c2.x == seq0 + turn + 1) break;   // tagged with the sequence number of the publication it enables: unique per context, never reset
+        if (c0.x == seq0 + turn + 1 && c1.x == seq0 + turn + 1 && c2.x == seq0 + turn + 1 && c2.w == (c0.y ^ c0.z ^ c0.w ^ c1.y ^ c1.z ^ c1.w ^ c2.y ^ c2.z) + (seq0 + turn + 1) * 0x9E3779B9u) break;   // tagged with the sequence number of the publication it enables: unique per context, never reset
         if (c0.x == LASSO_MAIL_POISON || ((++spins & 63u) == 0 && wall_clock64() > t_end)) { ok = 0; break; }   // lasso_abort's tag, or the host stopped answering
       }
       if (ok) { chal.v[0] = c0.y; chal.v[1] = c0.z; chal.v[2] = c0.w; chal.v[3] = c1.y; chal.v[4] = c1.z; chal.v[5] = c1.w; chal.v[6] = c2.y; chal.v[7] = c2.z; }
@@ -580,6 +581,7 @@ __global__ void __launch_bounds__(Q) k_cubic_tail(MutPtrTable A, MutPtrTable B, 
     }
   }
 }
+
 
 #undef TAIL_EQ_S
 // ------------------------------------------------------------------ K3 in eq-weighted form for the linear strategies (AND / OR / XOR / RangeCheck)
@@ -734,7 +736,7 @@ __global__ void __launch_bounds__(Q) k_linear_tail(PtrTable src, const fr_t* __r
       for (;;) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
         c0 = __builtin_nontemporal_load(m4); c1 = __builtin_nontemporal_load(m4 + 1); c2 = __builtin_nontemporal_load(m4 + 2);
-        if (c0.x == seq0 + turn + 1 && c1.x == seq0 + turn + 1 && c2.x == seq0 + turn + 1) break;   // tagged with the sequence number of the publication it enables: unique per context, never reset
+        if (c0.x == seq0 + turn + 1 && c1.x == seq0 + turn + 1 && c2.x == seq0 + turn + 1 && c2.w == (c0.y ^ c0.z ^ c0.w ^ c1.y ^ c1.z ^ c1.w ^ c2.y ^ c2.z) + (seq0 + turn + 1) * 0x9E3779B9u) break;   // tagged with the sequence number of the publication it enables: unique per context, never reset
         if (c0.x == LASSO_MAIL_POISON || ((++spins & 63u) == 0 && wall_clock64() > t_end)) { ok = 0; break; }   // lasso_abort's tag, or the host stopped answering
       }
       if (ok) { chal.v[0] = c0.y; chal.v[1] = c0.z; chal.v[2] = c0.w; chal.v[3] = c1.y; chal.v[4] = c1.z; chal.v[5] = c1.w; chal.v[6] = c2.y; chal.v[7] = c2.z; }

@@ -84,6 +84,43 @@ def test_gpu_proof_verifies_at_scale(host, oracle, kind, c, log_m, log_r, log_s)
         orc.close()
 
 
+def test_gpu_concurrent_proofs_identical_to_sequential():
+    """Four provers (own context, stream, mapped result area and mailbox each) proving at once on the one device, one host thread each — bench.py's concurrent leg and a serving
+    deployment: every proof must be the bytes the same prover produces alone.  Resident tail kernels of different contexts run side by side here."""
+    import threading
+    from lasso_amd import HostProver
+    kind, c, log_m, log_s, T, reps = "and", 2, 16, 16, 4, 3
+    S = _abi.Strategy(_abi.KINDS[kind], c, log_m, 0)
+    workers = []
+    for t in range(T):
+        hp = HostProver()
+        idx = (hp.gen_indices(1 << log_s, 1 << log_m, c) + 17 * t) % (1 << log_m)
+        r = hp.gen_random_point(log_s)
+        gens = hp.gens(c, 1 << log_s, c, log_m); dense = hp.densify(idx, log_m)
+        workers.append((hp, dense, gens, r, hp.prove(dense, gens, S, r)))
+    got, errors = [[] for _ in range(T)], []
+    bar = threading.Barrier(T)
+
+    def run(t):
+        hp, dense, gens, r, _ = workers[t]
+        try:
+            bar.wait(timeout=60)
+            for _ in range(reps):
+                got[t].append(hp.prove(dense, gens, S, r))
+        except Exception as e:
+            errors.append(repr(e)); bar.abort()
+    ths = [threading.Thread(target=run, args=(t,)) for t in range(T)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join(timeout=120)
+    for hp, dense, gens, r, _ in workers:
+        hp.free(dense, gens); hp.close()
+    assert not errors, errors
+    for t in range(T):
+        assert len(got[t]) == reps and all(p == workers[t][4] for p in got[t])
+
+
 # BASELINE.json's configurations at FULL size (configs[1], configs[2] and the configuration the metric is quoted on).  The oracle prover cannot
 # reach these sizes in seconds, so parity rests on the size-independent property the reference itself uses as its acceptance test
 # (src/e2e_test.rs:54-59): prove -> verify, here through the oracle's verifier (a restatement of surge.rs:214-271) fed the GPU's commitment,

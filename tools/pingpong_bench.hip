@@ -6,6 +6,10 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdint>
+#include <utility>
+#include <emmintrin.h>
+#include <hsa/hsa.h>
+#include <hsa/hsa_ext_amd.h>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 static double now() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
@@ -60,7 +64,28 @@ int main() {
       double t1 = now();
       CK(hipStreamSynchronize(s));
       printf("resident kernel, mailbox in fine-grained device memory written by the host: %.2f us per turn\n", (t1 - t0) / N);
-    } else printf("no host mapping for device memory on this platform\n");
+    } else {
+      // no host pointer through HIP: ask the HSA runtime to let the CPU agent reach the allocation (large-BAR systems map VRAM at the same address in the process)
+      hsa_agent_t cpu{}; bool have = false;
+      auto cb = [](hsa_agent_t a, void* d) -> hsa_status_t { hsa_device_type_t ty; hsa_agent_get_info(a, HSA_AGENT_INFO_DEVICE, &ty); auto* p = (std::pair<hsa_agent_t*, bool*>*)d; if (ty == HSA_DEVICE_TYPE_CPU && !*p->second) { *p->first = a; *p->second = true; } return HSA_STATUS_SUCCESS; };
+      std::pair<hsa_agent_t*, bool*> arg{&cpu, &have};
+      hsa_status_t st = hsa_init(); if (st == HSA_STATUS_SUCCESS) st = hsa_iterate_agents(cb, &arg);
+      if (st == HSA_STATUS_SUCCESS && have) st = hsa_amd_agents_allow_access(1, &cpu, nullptr, dm);
+      printf("hsa_amd_agents_allow_access(cpu, device allocation): status %d\n", (int)st);
+      if (st == HSA_STATUS_SUCCESS && have) {
+        volatile uint32_t* hp = (volatile uint32_t*)dm;
+        *h_ans = 0;
+        hipLaunchKernelGGL(k_resident, dim3(1), dim3(256), 0, s, dm, d_ans, N, 0u);
+        double t0 = now(); bool bad = false;
+        for (uint32_t i = 1; i <= N && !bad; i++) {
+          *hp = i; _mm_sfence();
+          long spins = 0; while (__atomic_load_n(h_ans, __ATOMIC_ACQUIRE) != i) { if (++spins > 2000000000L) { printf("timeout at turn %u\n", i); bad = true; break; } }
+        }
+        double t1 = now();
+        CK(hipStreamSynchronize(s));
+        if (!bad) printf("resident kernel, mailbox in DEVICE memory written by the host through the BAR: %.2f us per turn\n", (t1 - t0) / N);
+      }
+    }
   }
   return 0;
 }

@@ -10,6 +10,7 @@
 #include <vector>
 #include <emmintrin.h>
 #include "../lasso_amd/csrc/poly_kernels.cuh"
+#include "cubic_tail_ahead.cuh"
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
 static double now() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
@@ -19,7 +20,7 @@ static bool element_there(const uint32_t* e, uint32_t seq) {
   return c[0] == seq && c[4] == seq && c[8] == seq;
 }
 int main(int argc, char** argv) {
-  const uint32_t q = argc > 1 ? (uint32_t)atol(argv[1]) : 512, ncirc = 2;
+  const uint32_t q = argc > 1 ? (uint32_t)atol(argv[1]) : 512, ncirc = 2; const bool ahead = argc > 2 && atol(argv[2]) != 0;
   const uint32_t m = 2 * q;
   hipStream_t s; CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
   std::vector<fr_t> host(m); for (uint32_t i = 0; i < m; i++) { memset(&host[i], 0, sizeof(fr_t)); host[i].v[0] = 1000 + i; host[i].v[3] = 77 * i + 5; }
@@ -37,7 +38,8 @@ int main(int argc, char** argv) {
     CK(hipDeviceSynchronize());
     const uint32_t seq0 = seq + 1; seq += turns + 1;
     const double t0 = now();
-    hipLaunchKernelGGL((k_cubic_tail<false, 512, false>), dim3(ncirc), dim3(512), 0, s, A, B, (const fr_t*)E, q, fr_zero(), (const uint32_t*)d_mail, d_cnt, (fr_t*)d_tag, LASSO_TAGGED, seq0, EqInline());
+    if (ahead) hipLaunchKernelGGL((k_cubic_tail_ahead<false, 512, false>), dim3(ncirc), dim3(512), 0, s, A, B, (const fr_t*)E, q, fr_zero(), (const uint32_t*)d_mail, d_cnt, (fr_t*)d_tag, LASSO_TAGGED, seq0, EqInline());
+    else hipLaunchKernelGGL((k_cubic_tail<false, 512, false>), dim3(ncirc), dim3(512), 0, s, A, B, (const fr_t*)E, q, fr_zero(), (const uint32_t*)d_mail, d_cnt, (fr_t*)d_tag, LASSO_TAGGED, seq0, EqInline());
     double tp = t0;
     for (uint32_t turn = 0; turn <= turns; turn++) {
       const uint32_t want = seq0 + turn; const uint32_t cnt = 2 * ncirc;
@@ -45,7 +47,8 @@ int main(int argc, char** argv) {
       const double tn = now(); host_turn[turn] = tn - tp; tp = tn;
       if (turn < turns) {
         const uint32_t tag = want + 1;
-        const __m128i c0 = _mm_set_epi32(3, 2, 1, (int)tag), c1 = _mm_set_epi32(6, 5, 4, (int)tag), c2 = _mm_set_epi32(0, 8, 7, (int)tag);
+        const uint32_t chk = (1u ^ 2u ^ 3u ^ 4u ^ 5u ^ 6u ^ 7u ^ 8u) + tag * 0x9E3779B9u;
+        const __m128i c0 = _mm_set_epi32(3, 2, 1, (int)tag), c1 = _mm_set_epi32(6, 5, 4, (int)tag), c2 = _mm_set_epi32((int)chk, 8, 7, (int)tag);
         _mm_store_si128((__m128i*)(h_mail + 0), c0); _mm_store_si128((__m128i*)(h_mail + 4), c1); _mm_store_si128((__m128i*)(h_mail + 8), c2);
       }
     }
@@ -53,7 +56,7 @@ int main(int argc, char** argv) {
     CK(hipStreamSynchronize(s));
     if (rep >= 2 && total < best) { best = total; best_turn = host_turn; CK(hipMemcpyFromSymbol(clk, HIP_SYMBOL(tail_phase_clock), sizeof(clk))); }
   }
-  printf("q = %u, %u circuits: %.1f us for %u turns + heads (%.2f us per hand-off, launch included)\n", q, ncirc, best, turns, best / (turns + 1));
+  printf("%s: q = %u, %u circuits: %.1f us for %u turns + heads (%.2f us per hand-off, launch included)\n", ahead ? "k_cubic_tail_ahead (phases: - | G + terms | column sums + coefficients | wait | evaluate + publish | bind)" : "k_cubic_tail", q, ncirc, best, turns, best / (turns + 1));
   printf("turn  pairs | terms  reduce  pack+publish  wait-for-host  bind | device turn   host-side turn (us)\n");
   for (uint32_t turn = 0; turn < turns && turn < 16; turn++) {
     const uint64_t* c = clk + turn * 8; auto us = [&](int a, int b) { return (double)(c[b] - c[a]) * 0.01; };
