@@ -10,7 +10,7 @@
 #include <vector>
 #include <emmintrin.h>
 #include "../lasso_amd/csrc/poly_kernels.cuh"
-#include "cubic_tail_ahead.cuh"
+#include "experiments/cubic_tail_ahead.cuh"
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
 static double now() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
