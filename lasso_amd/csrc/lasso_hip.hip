@@ -46,6 +46,8 @@ struct lasso_ctx {
   // chunks per element in h_tag, one release fence on the device, no ticket and no flag: 2.1 us per resident turn instead of 4.1, tools/handoff_bench.hip).  LASSO_TAGGED_RESULTS=0: the flag protocol.
   uint32_t* h_tag = nullptr; uint32_t* d_tag = nullptr;    // small_cap elements of 48 bytes (mapped, zero-initialised: sequence numbers start at 1)
   bool tagged = true, pending_tagged = false;
+  uint32_t pending_groups = 1, pending_K = 0;   // a launch whose workgroups each published their own block sums (LASSO_TAGGED_DIRECT): groups per row, values per row
+  std::vector<lasso_fr> group_tmp;
   // The resident tails' mailbox: three tagged 16-byte chunks of host-mapped memory (h_flag + 32) the kernel polls (k_cubic_tail).  Putting it in device memory the host writes through the BAR
   // (hsa_amd_agents_allow_access) was tried in round 3: 2.5 -> 2.1 us per empty turn in tools/pingpong_bench.hip, nothing measurable in a proof, and hand-offs lost with four contexts proving at once — dropped.
   uint32_t* mail_h = nullptr; uint32_t* mail_d = nullptr;
@@ -177,8 +179,19 @@ static inline bool tagged_element(const uint32_t* e, uint32_t seq, uint32_t* w8)
   w8[0] = c[1]; w8[1] = c[2]; w8[2] = c[3]; w8[3] = c[5]; w8[4] = c[6]; w8[5] = c[7]; w8[6] = c[9]; w8[7] = c[10];
   return c[11] == (w8[0] ^ w8[1] ^ w8[2] ^ w8[3] ^ w8[4] ^ w8[5] ^ w8[6] ^ w8[7]) + seq * 0x9E3779B9u;
 }
-static int32_t wait_flag(lasso_ctx* c, uint32_t seq, size_t count, lasso_fr* out, bool tagged = false) {
-  if (c->defer_next) { c->defer_next = false; c->pending = true; c->pending_seq = seq; c->pending_count = count; c->pending_tagged = tagged; return 0; }   // lasso_defer_next: collected by lasso_result_wait
+static int32_t wait_flag(lasso_ctx* c, uint32_t seq, size_t count, lasso_fr* out, bool tagged = false, uint32_t groups = 1, uint32_t K = 0) {
+  if (c->defer_next) { c->defer_next = false; c->pending = true; c->pending_seq = seq; c->pending_count = count; c->pending_tagged = tagged; c->pending_groups = groups; c->pending_K = K; return 0; }
+  if (groups > 1) {   // every workgroup of a row published its block sums, slot (row * groups + bx) * K + k: the row's K values are the sums over bx
+    c->group_tmp.resize(count * groups);
+    int32_t rc = wait_flag(c, seq, count * groups, c->group_tmp.data(), tagged); if (rc) return rc;
+    const size_t rows = count / K;
+    for (size_t y = 0; y < rows; y++) for (uint32_t k = 0; k < K; k++) {
+      fr_t acc = to_fr(&c->group_tmp[(y * groups) * K + k]);
+      for (uint32_t bx = 1; bx < groups; bx++) acc = fr_add(acc, to_fr(&c->group_tmp[(y * groups + bx) * K + k]));
+      memcpy(out + y * K + k, acc.v, 32);
+    }
+    return 0;
+  }   // lasso_defer_next: collected by lasso_result_wait
   uint64_t spins = 0;
   const double t0 = now_us();
   if (tagged) {
@@ -355,7 +368,7 @@ int32_t lasso_abort(lasso_ctx* c) {
   (void)hipStreamSynchronize(c->stream);   // bounded: every device-side wait has the poison check and a wall-clock bail-out
   (void)hipGetLastError();
   post_mail(c, 0, zero8);
-  c->tail_active = false; c->pending = false; c->defer_next = false; c->events_used = 0;
+  c->tail_active = false; c->pending = false; c->defer_next = false; c->events_used = 0; c->pending_groups = 1; c->pending_K = 0;
   HIPCHK(c, hipMemsetAsync(c->d_counters, 0, (LASSO_MAX_PTRS + 40) * 4, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return 0;
@@ -499,7 +512,14 @@ int32_t lasso_sumcheck_cubic_round(lasso_ctx* c, const lasso_fr* const* d_A, con
 // previous challenge is bound first (length n -> n/2) and the sums are those of the next round.  NT sums per circuit land in the mapped
 // result buffer under sequence number *seq_out.
 // eqi (first round of a layer, two-sum form, streaming size only): the layer's eq table is built inside the launch and WRITTEN to d_E (k_cubic_eqw_lb<2, true>)
-static int32_t cubic_eqw_launch(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n, const lasso_fr* r, int NT, uint32_t* seq_out, const EqInline* eqi = nullptr) {
+// a launch of a few workgroups per circuit hands over EVERY workgroup's block sums (LASSO_TAGGED_DIRECT; the host adds them in wait_flag) instead of running the in-launch second stage
+static unsigned direct_nx_max() { static const unsigned v = [] { const char* e = getenv("LASSO_DIRECT_NX"); const long x = e ? atol(e) : 16; return (unsigned)(x < 0 ? 0 : x > 64 ? 64 : x); }(); return v; }
+#define CUBIC_RESULT_ARGS(nx_) \
+  const bool direct = groups_out && c->tagged && (nx_) > 1 && (nx_) <= direct_nx_max(); \
+  if (direct) { *groups_out = (nx_); rc = ensure_small(c, (size_t)ncirc * 3 * (nx_)); if (rc) return rc; } \
+  fr_t* const r_out = c->tagged ? (fr_t*)c->d_tag : c->d_small; uint32_t* const r_flag = direct ? LASSO_TAGGED_DIRECT : c->tagged ? LASSO_TAGGED : c->d_flag
+static int32_t cubic_eqw_launch(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n, const lasso_fr* r, int NT, uint32_t* seq_out, const EqInline* eqi = nullptr, uint32_t* groups_out = nullptr) {
+  if (groups_out) *groups_out = 1;
   MutPtrTable A, B; for (uint32_t i = 0; i < ncirc; i++) { REQUIRE(c, d_A[i] && d_B[i]); A.p[i] = (fr_t*)d_A[i]; B.p[i] = (fr_t*)d_B[i]; }
   int32_t rc = ensure_small(c, (size_t)ncirc * 3); if (rc) return rc;
   const uint32_t seq = ++c->seq; *seq_out = seq;
@@ -513,10 +533,11 @@ static int32_t cubic_eqw_launch(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* co
       PtrTable Ac, Bc; for (uint32_t i = 0; i < ncirc; i++) { Ac.p[i] = A.p[i]; Bc.p[i] = B.p[i]; }
       const unsigned ny = ncirc, nx = grid_for(half, cubic_nx_cap(ny));
       rc = ensure_scratch(c, (size_t)nx * ny * 3 * sizeof(fr_t)); if (rc) return rc;
+      CUBIC_RESULT_ARGS(nx);
       static const uint32_t pipe = [] { const char* v = getenv("LASSO_LB_PIPELINE"); return (v && v[0] == '0') ? 0u : 1u; }();
-      if (NT == 3) hipLaunchKernelGGL((k_cubic_eqw_lb<3, false>), dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, Ac, Bc, nx, ny, (const fr_t*)d_E, half, (fr_t*)c->d_scratch, c->d_counters, RES(c), seq, 0u, EqInline(), (fr_t*)nullptr);
-      else if (eqi) hipLaunchKernelGGL((k_cubic_eqw_lb<2, true>), dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, Ac, Bc, nx, ny, (const fr_t*)nullptr, half, (fr_t*)c->d_scratch, c->d_counters, RES(c), seq, 1u, *eqi, (fr_t*)d_E);
-      else hipLaunchKernelGGL((k_cubic_eqw_lb<2, false>), dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, Ac, Bc, nx, ny, (const fr_t*)d_E, half, (fr_t*)c->d_scratch, c->d_counters, RES(c), seq, pipe, EqInline(), (fr_t*)nullptr);
+      if (NT == 3) hipLaunchKernelGGL((k_cubic_eqw_lb<3, false>), dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, Ac, Bc, nx, ny, (const fr_t*)d_E, half, (fr_t*)c->d_scratch, c->d_counters, r_out, r_flag, seq, 0u, EqInline(), (fr_t*)nullptr);
+      else if (eqi) hipLaunchKernelGGL((k_cubic_eqw_lb<2, true>), dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, Ac, Bc, nx, ny, (const fr_t*)nullptr, half, (fr_t*)c->d_scratch, c->d_counters, r_out, r_flag, seq, 1u, *eqi, (fr_t*)d_E);
+      else hipLaunchKernelGGL((k_cubic_eqw_lb<2, false>), dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, Ac, Bc, nx, ny, (const fr_t*)d_E, half, (fr_t*)c->d_scratch, c->d_counters, r_out, r_flag, seq, pipe, EqInline(), (fr_t*)nullptr);
     }
   } else {
     const size_t q = n / 4;
@@ -528,9 +549,10 @@ static int32_t cubic_eqw_launch(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* co
     } else {
       const unsigned ny = ncirc, nx = grid_for(q, cubic_nx_cap(ny));
       rc = ensure_scratch(c, (size_t)nx * ny * 3 * sizeof(fr_t)); if (rc) return rc;
-      if (NT == 3) hipLaunchKernelGGL(k_cubic_eqw_fused<3>, dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, A, B, nx, ny, (const fr_t*)d_E, q, to_fr(r), (fr_t*)c->d_scratch, c->d_counters, RES(c), seq);
-      else if (cubic_wide()) hipLaunchKernelGGL((k_cubic_eqw_fused<2, true>), dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, A, B, nx, ny, (const fr_t*)d_E, q, to_fr(r), (fr_t*)c->d_scratch, c->d_counters, RES(c), seq);
-      else hipLaunchKernelGGL((k_cubic_eqw_fused<2, false>), dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, A, B, nx, ny, (const fr_t*)d_E, q, to_fr(r), (fr_t*)c->d_scratch, c->d_counters, RES(c), seq);
+      CUBIC_RESULT_ARGS(nx);
+      if (NT == 3) hipLaunchKernelGGL(k_cubic_eqw_fused<3>, dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, A, B, nx, ny, (const fr_t*)d_E, q, to_fr(r), (fr_t*)c->d_scratch, c->d_counters, r_out, r_flag, seq);
+      else if (cubic_wide()) hipLaunchKernelGGL((k_cubic_eqw_fused<2, true>), dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, A, B, nx, ny, (const fr_t*)d_E, q, to_fr(r), (fr_t*)c->d_scratch, c->d_counters, r_out, r_flag, seq);
+      else hipLaunchKernelGGL((k_cubic_eqw_fused<2, false>), dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, A, B, nx, ny, (const fr_t*)d_E, q, to_fr(r), (fr_t*)c->d_scratch, c->d_counters, r_out, r_flag, seq);
     }
   }
   HIPCHK(c, hipGetLastError());
@@ -538,20 +560,20 @@ static int32_t cubic_eqw_launch(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* co
 }
 int32_t lasso_sumcheck_cubic_eqw_round(lasso_ctx* c, const lasso_fr* const* d_A, const lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n, lasso_fr* out) {
   REQUIRE(c, d_A && d_B && d_E && out && ncirc >= 1 && ncirc <= LASSO_MAX_PTRS && n >= 2 && (n & (n - 1)) == 0);
-  uint32_t seq; int32_t rc = cubic_eqw_launch(c, (lasso_fr* const*)d_A, (lasso_fr* const*)d_B, ncirc, d_E, n, nullptr, 3, &seq); if (rc) return rc;
-  return wait_flag(c, seq, (size_t)ncirc * 3, out, c->tagged);
+  uint32_t seq, groups; int32_t rc = cubic_eqw_launch(c, (lasso_fr* const*)d_A, (lasso_fr* const*)d_B, ncirc, d_E, n, nullptr, 3, &seq, nullptr, &groups); if (rc) return rc;
+  return wait_flag(c, seq, (size_t)ncirc * 3, out, c->tagged, groups, 3);
 }
 int32_t lasso_sumcheck_cubic_eqw_round_fused(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n, const lasso_fr* r, lasso_fr* out) {
   REQUIRE(c, d_A && d_B && d_E && r && out && ncirc >= 1 && ncirc <= LASSO_MAX_PTRS && n >= 4 && (n & (n - 1)) == 0);
-  uint32_t seq; int32_t rc = cubic_eqw_launch(c, d_A, d_B, ncirc, d_E, n, r, 3, &seq); if (rc) return rc;
-  return wait_flag(c, seq, (size_t)ncirc * 3, out, c->tagged);
+  uint32_t seq, groups; int32_t rc = cubic_eqw_launch(c, d_A, d_B, ncirc, d_E, n, r, 3, &seq, nullptr, &groups); if (rc) return rc;
+  return wait_flag(c, seq, (size_t)ncirc * 3, out, c->tagged, groups, 3);
 }
 // Two-sum form, split into launch and wait so that the host can prepare the round's scalars (one field inversion) while the kernel runs.
 // out (lasso_result_wait) = ncirc pairs (q(0), q_inf) — see cubic_eqw_terms2 in poly_kernels.cuh.  One result may be pending per context.
 int32_t lasso_sumcheck_cubic_eqw2_begin(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n, const lasso_fr* r) {
   REQUIRE(c, d_A && d_B && d_E && ncirc >= 1 && ncirc <= LASSO_MAX_PTRS && n >= (r ? 4u : 2u) && (n & (n - 1)) == 0 && !c->pending);
-  uint32_t seq; int32_t rc = cubic_eqw_launch(c, d_A, d_B, ncirc, d_E, n, r, 2, &seq); if (rc) return rc;
-  c->pending = true; c->pending_seq = seq; c->pending_count = (size_t)ncirc * 2; c->pending_tagged = c->tagged;
+  uint32_t seq, groups; int32_t rc = cubic_eqw_launch(c, d_A, d_B, ncirc, d_E, n, r, 2, &seq, nullptr, &groups); if (rc) return rc;
+  c->pending = true; c->pending_seq = seq; c->pending_count = (size_t)ncirc * 2; c->pending_tagged = c->tagged; c->pending_groups = groups; c->pending_K = 2;
   return 0;
 }
 // The next entry point that hands its result over through the mapped buffer (the sumcheck rounds, the few-row MSMs, lasso_bullet_round ...)
@@ -579,8 +601,8 @@ int32_t lasso_sumcheck_cubic_eqw2_begin_eq(lasso_ctx* c, lasso_fr* const* d_A, l
   REQUIRE(c, d_A && d_B && d_E_out && ncirc >= 1 && ncirc <= LASSO_MAX_PTRS && n >= 2 && (n & (n - 1)) == 0 && !c->pending && ((size_t)1 << ell) == n / 2);
   EqInline Q;
   if (n / 2 <= CUBIC_SMALL_Q || !make_eq_inline(point, ell, scale, Q)) return fail(c, LASSO_ERR_UNSUPPORTED, "lasso_sumcheck_cubic_eqw2_begin_eq: tables of 2^7 .. 2^14 entries only");
-  uint32_t seq; int32_t rc = cubic_eqw_launch(c, d_A, d_B, ncirc, d_E_out, n, nullptr, 2, &seq, &Q); if (rc) return rc;
-  c->pending = true; c->pending_seq = seq; c->pending_count = (size_t)ncirc * 2; c->pending_tagged = c->tagged;
+  uint32_t seq, groups; int32_t rc = cubic_eqw_launch(c, d_A, d_B, ncirc, d_E_out, n, nullptr, 2, &seq, &Q, &groups); if (rc) return rc;
+  c->pending = true; c->pending_seq = seq; c->pending_count = (size_t)ncirc * 2; c->pending_tagged = c->tagged; c->pending_groups = groups; c->pending_K = 2;
   return 0;
 }
 // lasso_sumcheck_cubic_tail_begin(.., r = NULL) without a table: the resident kernel derives E = *scale * EqPolynomial(point[0..ell)).evals(), 2^ell = n/2 <= capacity, itself
@@ -644,7 +666,7 @@ int32_t lasso_defer_next(lasso_ctx* c) { REQUIRE(c, !c->pending && !c->defer_nex
 int32_t lasso_result_wait(lasso_ctx* c, lasso_fr* out, size_t count) {
   REQUIRE(c, out && c->pending && count == c->pending_count);
   c->pending = false;
-  return wait_flag(c, c->pending_seq, count, out, c->pending_tagged);
+  { const uint32_t g = c->pending_groups, K = c->pending_K; c->pending_groups = 1; c->pending_K = 0; return wait_flag(c, c->pending_seq, count, out, c->pending_tagged, g, K); }
 }
 // eq-weighted rounds of prove_arbitrary for the linear strategies (k_dot_eqw_* in poly_kernels.cuh)
 int32_t lasso_sumcheck_linear_eqw_round(lasso_ctx* c, const lasso_fr* const* d_polys, uint32_t alpha, const lasso_fr* d_E, size_t n, lasso_fr* out) {

@@ -73,10 +73,13 @@ __device__ __forceinline__ void acc_add(fr29& acc, const fr29& t, uint32_t& coun
 //    cross-row ordering.  The host accepts an element once its three chunks carry the hand-off's sequence number (unique for the life of the context) and the
 //    check word matches.  2.1-2.3 us for the same turn.
 #define LASSO_TAGGED (reinterpret_cast<uint32_t*>(uintptr_t(16)))
+// the same area, and EVERY workgroup of a row publishes its own block sums under slot (row * nx + bx) * K + k: the host adds the nx of them (lasso_hip.hip wait_flag) — for launches
+// of a few workgroups per row, where the in-launch second stage (agent-scope release, ticket, acquire, re-read, second block reduction) is a third of the kernel's time
+#define LASSO_TAGGED_DIRECT (reinterpret_cast<uint32_t*>(uintptr_t(32)))
 typedef uint32_t lasso_u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint32_t result_check(const fr_t& v, uint32_t seq) { return (v.v[0] ^ v.v[1] ^ v.v[2] ^ v.v[3] ^ v.v[4] ^ v.v[5] ^ v.v[6] ^ v.v[7]) + seq * 0x9E3779B9u; }
 __device__ __forceinline__ void result_store(fr_t* __restrict__ out, size_t slot, const fr_t& v, uint32_t* flag, uint32_t seq) {
-  if (flag == LASSO_TAGGED) {
+  if (flag == LASSO_TAGGED || flag == LASSO_TAGGED_DIRECT) {
     lasso_u32x4* o = reinterpret_cast<lasso_u32x4*>(out) + 3 * slot;
     const lasso_u32x4 c0 = {seq, v.v[0], v.v[1], v.v[2]}, c1 = {seq, v.v[3], v.v[4], v.v[5]}, c2 = {seq, v.v[6], v.v[7], result_check(v, seq)};
     o[0] = c0; o[1] = c1; o[2] = c2;
@@ -177,7 +180,7 @@ __device__ __forceinline__ CubicGrid cubic_grid(uint32_t nx, uint32_t ny) {
 }
 // raise the host flag once every grid row has stored its results: called by the workgroup that finished row y, stores issued by wave 0
 __device__ __forceinline__ void row_done(uint32_t nrows, uint32_t* counters, uint32_t* flag, uint32_t seq) {
-  if (flag == LASSO_TAGGED) { if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, ""); return; }   // this row's chunks leave the device; nothing to agree on with the other rows
+  if (flag == LASSO_TAGGED || flag == LASSO_TAGGED_DIRECT) { if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, ""); return; }   // this row's chunks leave the device; nothing to agree on with the other rows
   if (threadIdx.x == 0 && flag) {
     __threadfence_system();
     uint32_t t2 = __hip_atomic_fetch_add(&counters[LASSO_MAX_PTRS], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
@@ -189,6 +192,11 @@ __device__ __forceinline__ void cubic_epilogue(const fr29* e, const CubicGrid& g
                                                int shift, uint32_t K = 3) {   // K <= 3 results per row
   if (g.nx == 1) {
     store_block_partials<3>(e, K, out, shift, S, flag, seq, (size_t)g.by * K);
+    row_done(g.ny, counters, flag, seq);
+    return;
+  }
+  if (flag == LASSO_TAGGED_DIRECT) {
+    store_block_partials<3>(e, K, out, shift, S, flag, seq, ((size_t)g.by * g.nx + g.bx) * K);
     row_done(g.ny, counters, flag, seq);
     return;
   }
