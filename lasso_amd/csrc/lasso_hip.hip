@@ -518,45 +518,51 @@ static unsigned direct_nx_max() { static const unsigned v = [] { const char* e =
   const bool direct = groups_out && c->tagged && (nx_) > 1 && (nx_) <= direct_nx_max(); \
   if (direct) { *groups_out = (nx_); rc = ensure_small(c, (size_t)ncirc * 3 * (nx_)); if (rc) return rc; } \
   fr_t* const r_out = c->tagged ? (fr_t*)c->d_tag : c->d_small; uint32_t* const r_flag = direct ? LASSO_TAGGED_DIRECT : c->tagged ? LASSO_TAGGED : c->d_flag
-static int32_t cubic_eqw_launch(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n, const lasso_fr* r, int NT, uint32_t* seq_out, const EqInline* eqi = nullptr, uint32_t* groups_out = nullptr) {
+extern "C++" {
+template <class TM, class TP>   // pointer tables sized for the number of circuits (MutPtrTable8 / PtrTable8 up to 8: 64 bytes of kernel arguments each instead of 1088)
+static int32_t cubic_eqw_launch_t(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n, const lasso_fr* r, int NT, uint32_t* seq_out, const EqInline* eqi, uint32_t* groups_out) {
   if (groups_out) *groups_out = 1;
-  MutPtrTable A, B; for (uint32_t i = 0; i < ncirc; i++) { REQUIRE(c, d_A[i] && d_B[i]); A.p[i] = (fr_t*)d_A[i]; B.p[i] = (fr_t*)d_B[i]; }
+  TM A, B; for (uint32_t i = 0; i < ncirc; i++) { REQUIRE(c, d_A[i] && d_B[i]); A.p[i] = (fr_t*)d_A[i]; B.p[i] = (fr_t*)d_B[i]; }
   int32_t rc = ensure_small(c, (size_t)ncirc * 3); if (rc) return rc;
   const uint32_t seq = ++c->seq; *seq_out = seq;
   if (!r) {
     const size_t half = n / 2;
     ProfScope ps(c, LASSO_K_CUBIC, 32.0 * n * (2.0 * ncirc + 1.0));
     if (half <= CUBIC_SMALL_Q) {   // arrays are read-only in this mode
-      if (NT == 3) hipLaunchKernelGGL((k_cubic_eqw_small<false, 3>), dim3(ncirc), dim3(LASSO_BLOCK), 0, c->stream, A, B, (const fr_t*)d_E, (uint32_t)half, fr_zero(), c->d_counters, RES(c), seq);
-      else hipLaunchKernelGGL((k_cubic_eqw_small<false, 2>), dim3(ncirc), dim3(LASSO_BLOCK), 0, c->stream, A, B, (const fr_t*)d_E, (uint32_t)half, fr_zero(), c->d_counters, RES(c), seq);
+      if (NT == 3) hipLaunchKernelGGL((k_cubic_eqw_small<false, 3, TM>), dim3(ncirc), dim3(LASSO_BLOCK), 0, c->stream, A, B, (const fr_t*)d_E, (uint32_t)half, fr_zero(), c->d_counters, RES(c), seq);
+      else hipLaunchKernelGGL((k_cubic_eqw_small<false, 2, TM>), dim3(ncirc), dim3(LASSO_BLOCK), 0, c->stream, A, B, (const fr_t*)d_E, (uint32_t)half, fr_zero(), c->d_counters, RES(c), seq);
     } else {
-      PtrTable Ac, Bc; for (uint32_t i = 0; i < ncirc; i++) { Ac.p[i] = A.p[i]; Bc.p[i] = B.p[i]; }
+      TP Ac, Bc; for (uint32_t i = 0; i < ncirc; i++) { Ac.p[i] = A.p[i]; Bc.p[i] = B.p[i]; }
       const unsigned ny = ncirc, nx = grid_for(half, cubic_nx_cap(ny));
       rc = ensure_scratch(c, (size_t)nx * ny * 3 * sizeof(fr_t)); if (rc) return rc;
       CUBIC_RESULT_ARGS(nx);
       static const uint32_t pipe = [] { const char* v = getenv("LASSO_LB_PIPELINE"); return (v && v[0] == '0') ? 0u : 1u; }();
-      if (NT == 3) hipLaunchKernelGGL((k_cubic_eqw_lb<3, false>), dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, Ac, Bc, nx, ny, (const fr_t*)d_E, half, (fr_t*)c->d_scratch, c->d_counters, r_out, r_flag, seq, 0u, EqInline(), (fr_t*)nullptr);
-      else if (eqi) hipLaunchKernelGGL((k_cubic_eqw_lb<2, true>), dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, Ac, Bc, nx, ny, (const fr_t*)nullptr, half, (fr_t*)c->d_scratch, c->d_counters, r_out, r_flag, seq, 1u, *eqi, (fr_t*)d_E);
-      else hipLaunchKernelGGL((k_cubic_eqw_lb<2, false>), dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, Ac, Bc, nx, ny, (const fr_t*)d_E, half, (fr_t*)c->d_scratch, c->d_counters, r_out, r_flag, seq, pipe, EqInline(), (fr_t*)nullptr);
+      if (NT == 3) hipLaunchKernelGGL((k_cubic_eqw_lb<3, false, TP, EqNone>), dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, Ac, Bc, nx, ny, (const fr_t*)d_E, half, (fr_t*)c->d_scratch, c->d_counters, r_out, r_flag, seq, 0u, EqNone(), (fr_t*)nullptr);
+      else if (eqi) hipLaunchKernelGGL((k_cubic_eqw_lb<2, true, TP, EqInline>), dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, Ac, Bc, nx, ny, (const fr_t*)nullptr, half, (fr_t*)c->d_scratch, c->d_counters, r_out, r_flag, seq, 1u, *eqi, (fr_t*)d_E);
+      else hipLaunchKernelGGL((k_cubic_eqw_lb<2, false, TP, EqNone>), dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, Ac, Bc, nx, ny, (const fr_t*)d_E, half, (fr_t*)c->d_scratch, c->d_counters, r_out, r_flag, seq, pipe, EqNone(), (fr_t*)nullptr);
     }
   } else {
     const size_t q = n / 4;
     // bind: read 32n + write 16n per polynomial (SURVEY.md §8d's "fused bind+next-eval" over the reference's 2*ncirc + 1 polynomials)
     ProfScope ps(c, LASSO_K_CUBIC, 48.0 * n * (2.0 * ncirc + 1.0));
     if (q <= CUBIC_SMALL_Q) {
-      if (NT == 3) hipLaunchKernelGGL((k_cubic_eqw_small<true, 3>), dim3(ncirc), dim3(LASSO_BLOCK), 0, c->stream, A, B, (const fr_t*)d_E, (uint32_t)q, to_fr(r), c->d_counters, RES(c), seq);
-      else hipLaunchKernelGGL((k_cubic_eqw_small<true, 2>), dim3(ncirc), dim3(LASSO_BLOCK), 0, c->stream, A, B, (const fr_t*)d_E, (uint32_t)q, to_fr(r), c->d_counters, RES(c), seq);
+      if (NT == 3) hipLaunchKernelGGL((k_cubic_eqw_small<true, 3, TM>), dim3(ncirc), dim3(LASSO_BLOCK), 0, c->stream, A, B, (const fr_t*)d_E, (uint32_t)q, to_fr(r), c->d_counters, RES(c), seq);
+      else hipLaunchKernelGGL((k_cubic_eqw_small<true, 2, TM>), dim3(ncirc), dim3(LASSO_BLOCK), 0, c->stream, A, B, (const fr_t*)d_E, (uint32_t)q, to_fr(r), c->d_counters, RES(c), seq);
     } else {
       const unsigned ny = ncirc, nx = grid_for(q, cubic_nx_cap(ny));
       rc = ensure_scratch(c, (size_t)nx * ny * 3 * sizeof(fr_t)); if (rc) return rc;
       CUBIC_RESULT_ARGS(nx);
-      if (NT == 3) hipLaunchKernelGGL(k_cubic_eqw_fused<3>, dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, A, B, nx, ny, (const fr_t*)d_E, q, to_fr(r), (fr_t*)c->d_scratch, c->d_counters, r_out, r_flag, seq);
-      else if (cubic_wide()) hipLaunchKernelGGL((k_cubic_eqw_fused<2, true>), dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, A, B, nx, ny, (const fr_t*)d_E, q, to_fr(r), (fr_t*)c->d_scratch, c->d_counters, r_out, r_flag, seq);
-      else hipLaunchKernelGGL((k_cubic_eqw_fused<2, false>), dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, A, B, nx, ny, (const fr_t*)d_E, q, to_fr(r), (fr_t*)c->d_scratch, c->d_counters, r_out, r_flag, seq);
+      if (NT == 3) hipLaunchKernelGGL((k_cubic_eqw_fused<3, false, TM>), dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, A, B, nx, ny, (const fr_t*)d_E, q, to_fr(r), (fr_t*)c->d_scratch, c->d_counters, r_out, r_flag, seq);
+      else if (cubic_wide()) hipLaunchKernelGGL((k_cubic_eqw_fused<2, true, TM>), dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, A, B, nx, ny, (const fr_t*)d_E, q, to_fr(r), (fr_t*)c->d_scratch, c->d_counters, r_out, r_flag, seq);
+      else hipLaunchKernelGGL((k_cubic_eqw_fused<2, false, TM>), dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, A, B, nx, ny, (const fr_t*)d_E, q, to_fr(r), (fr_t*)c->d_scratch, c->d_counters, r_out, r_flag, seq);
     }
   }
   HIPCHK(c, hipGetLastError());
   return 0;
+}
+}   // extern "C++"
+static int32_t cubic_eqw_launch(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n, const lasso_fr* r, int NT, uint32_t* seq_out, const EqInline* eqi = nullptr, uint32_t* groups_out = nullptr) {
+  return ncirc <= 8 ? cubic_eqw_launch_t<MutPtrTable8, PtrTable8>(c, d_A, d_B, ncirc, d_E, n, r, NT, seq_out, eqi, groups_out) : cubic_eqw_launch_t<MutPtrTable, PtrTable>(c, d_A, d_B, ncirc, d_E, n, r, NT, seq_out, eqi, groups_out);
 }
 int32_t lasso_sumcheck_cubic_eqw_round(lasso_ctx* c, const lasso_fr* const* d_A, const lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n, lasso_fr* out) {
   REQUIRE(c, d_A && d_B && d_E && out && ncirc >= 1 && ncirc <= LASSO_MAX_PTRS && n >= 2 && (n & (n - 1)) == 0);
@@ -611,23 +617,29 @@ int32_t lasso_sumcheck_cubic_tail_begin_eq(lasso_ctx* c, lasso_fr* const* d_A, l
   EqInline Q; if (!make_eq_inline(point, ell, scale, Q)) return fail(c, LASSO_ERR_INVALID, "lasso_sumcheck_cubic_tail_begin_eq: bad point");
   return cubic_tail_begin_impl(c, d_A, d_B, ncirc, nullptr, n, nullptr, &Q);
 }
-static int32_t cubic_tail_begin_impl(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n, const lasso_fr* r, const EqInline* eqi) {
+extern "C++" {
+template <class TM>
+static int32_t cubic_tail_begin_t(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n, const lasso_fr* r, const EqInline* eqi) {
   REQUIRE(c, d_A && d_B && (d_E || eqi) && ncirc >= 1 && ncirc <= LASSO_MAX_PTRS && n >= (r ? 4u : 2u) && (n & (n - 1)) == 0 && !c->pending && !c->tail_active && !c->defer_next);
   const size_t q = r ? n / 4 : n / 2;
   REQUIRE(c, q >= 1 && q <= CUBIC_TAIL_Q);
-  MutPtrTable A, B; for (uint32_t i = 0; i < ncirc; i++) { REQUIRE(c, d_A[i] && d_B[i]); A.p[i] = (fr_t*)d_A[i]; B.p[i] = (fr_t*)d_B[i]; }
+  TM A, B; for (uint32_t i = 0; i < ncirc; i++) { REQUIRE(c, d_A[i] && d_B[i]); A.p[i] = (fr_t*)d_A[i]; B.p[i] = (fr_t*)d_B[i]; }
   int32_t rc = ensure_small(c, (size_t)ncirc * 3); if (rc) return rc;
   uint32_t turns = 0; while (((size_t)1 << turns) < 2 * q) turns++;   // rounds of sums; one more publication carries the heads
   const uint32_t seq0 = c->seq + 1; c->seq += turns + 1;
   // workgroup = capacity: 256 threads / 74 KB of LDS up to 256 indices per circuit, 512 threads / 147 KB above
-#define LAUNCH_CTAIL(B_, Q_, I_, R_, EQ_) hipLaunchKernelGGL((k_cubic_tail<B_, Q_, I_>), dim3(ncirc), dim3(Q_), 0, c->stream, A, B, (const fr_t*)d_E, (uint32_t)q, R_, (const uint32_t*)c->mail_d, c->d_counters, RES(c), seq0, EQ_)
-  if (eqi) { if (q <= 256) LAUNCH_CTAIL(false, 256, true, fr_zero(), *eqi); else LAUNCH_CTAIL(false, 512, true, fr_zero(), *eqi); }
-  else if (q <= 256) { if (r) LAUNCH_CTAIL(true, 256, false, to_fr(r), EqInline()); else LAUNCH_CTAIL(false, 256, false, fr_zero(), EqInline()); }
-  else { if (r) LAUNCH_CTAIL(true, 512, false, to_fr(r), EqInline()); else LAUNCH_CTAIL(false, 512, false, fr_zero(), EqInline()); }
+#define LAUNCH_CTAIL(B_, Q_, I_, TE_, R_, EQ_) hipLaunchKernelGGL((k_cubic_tail<B_, Q_, I_, TM, TE_>), dim3(ncirc), dim3(Q_), 0, c->stream, A, B, (const fr_t*)d_E, (uint32_t)q, R_, (const uint32_t*)c->mail_d, c->d_counters, RES(c), seq0, EQ_)
+  if (eqi) { if (q <= 256) LAUNCH_CTAIL(false, 256, true, EqInline, fr_zero(), *eqi); else LAUNCH_CTAIL(false, 512, true, EqInline, fr_zero(), *eqi); }
+  else if (q <= 256) { if (r) LAUNCH_CTAIL(true, 256, false, EqNone, to_fr(r), EqNone()); else LAUNCH_CTAIL(false, 256, false, EqNone, fr_zero(), EqNone()); }
+  else { if (r) LAUNCH_CTAIL(true, 512, false, EqNone, to_fr(r), EqNone()); else LAUNCH_CTAIL(false, 512, false, EqNone, fr_zero(), EqNone()); }
   HIPCHK(c, hipGetLastError());
   c->tail_active = true; c->tail_seq0 = seq0; c->tail_turn = 0; c->tail_turns = turns; c->tail_count = (size_t)ncirc * 2; c->tail_final = (size_t)ncirc * 2;
   c->pending = true; c->pending_seq = seq0; c->pending_count = c->tail_count; c->pending_tagged = c->tagged;
   return 0;
+}
+}   // extern "C++"
+static int32_t cubic_tail_begin_impl(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n, const lasso_fr* r, const EqInline* eqi) {
+  return ncirc <= 8 ? cubic_tail_begin_t<MutPtrTable8>(c, d_A, d_B, ncirc, d_E, n, r, eqi) : cubic_tail_begin_t<MutPtrTable>(c, d_A, d_B, ncirc, d_E, n, r, eqi);
 }
 // The same for the primary sumcheck of a linear strategy (k_linear_tail): per round two dot products per polynomial, out[2k] = S0_k, out[2k+1] = S1_k
 // (as lasso_sumcheck_linear_eqw_round, without the unused third slot); after the last challenge the heads out[k] = polys_k[0] (alpha values).

@@ -8,12 +8,18 @@
 #include "fr.cuh"
 #include "fr29.cuh"
 
+#ifndef LASSO_MAX_PTRS
 #define LASSO_MAX_PTRS 136   // 2 * (2 * 33 memories) + slack; pointer tables travel by value in the kernarg segment
+#endif
 #define LASSO_BLOCK 256
 #define LASSO_MAX_ALPHA 32
 
 struct PtrTable { const fr_t* p[LASSO_MAX_PTRS]; };
 struct MutPtrTable { fr_t* p[LASSO_MAX_PTRS]; };
+// the same for <= 8 arrays: 64 bytes of kernel arguments instead of 1088.  The cubic round kernels are templated on the table type — a launch's arguments are written through the
+// BAR before the dispatch, and two full tables plus an unused EqInline were 2.7 KB per launch (18.54 -> 18.34 ms per proof with 16-entry tables, profiles/r03_ab_kernarg_tables.txt)
+struct PtrTable8 { const fr_t* p[8]; };
+struct MutPtrTable8 { fr_t* p[8]; };
 struct StrategyDev { int kind; uint32_t c, log_m, log_r, alpha; };
 struct WeightTable { fr_t w[LASSO_MAX_ALPHA]; };
 
@@ -275,6 +281,7 @@ __device__ __forceinline__ void cubic_eqw_terms2(const fr29& a0, const fr29& a1,
 // E[x] = hi[x >> lo_bits] * lo[x & mask] where it is used.  hi and lo are kept in s-form (their product is the s-form operand the round needs); lo also in u-form, so that the
 // workgroups of circuit 0 can write E[x] = hi * lo_u to memory in the canonical bytes k_eq_small / k_eq_outer produce — the later rounds of the layer read its prefix.
 struct EqInline { fr_t r[14]; fr_t scale; uint32_t ell; };
+struct EqNone { uint32_t ell = 0; };   // stands in for EqInline in the launches that carry no point (4 bytes of kernel arguments instead of 484)
 struct EqInlineTables { fr29 hi_s[128], lo_s[128], lo_u[128]; };
 __device__ __forceinline__ void eq_inline_build(const EqInline& Q, EqInlineTables& T) {   // all threads of the workgroup; ends with a barrier
   const uint32_t t = threadIdx.x, lb = Q.ell / 2, hb = Q.ell - lb;
@@ -295,14 +302,14 @@ __device__ __forceinline__ void eq_inline_build(const EqInline& Q, EqInlineTable
 __device__ __forceinline__ fr29 eq_inline_s(const EqInlineTables& T, uint32_t lb, size_t x) { return fr29_mul(T.hi_s[x >> lb], T.lo_s[x & ((1u << lb) - 1u)]); }
 // out[c*NT + ..] = the NT sums over i < half of circuit c.  1-D grid of nx*ny workgroups (cubic_grid).
 // EQI: E is built on the way (eq_inline_build): E_out (half entries) is written by the workgroups of circuit 0, nothing is read from it.
-template <int NT, bool EQI = false>
-__global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_eqw_lb(PtrTable A, PtrTable B, uint32_t nx, uint32_t ny, const fr_t* __restrict__ E, size_t half, fr_t* __restrict__ partials, uint32_t* counters,
-                                                               fr_t* __restrict__ out, uint32_t* flag, uint32_t seq, uint32_t pipeline, EqInline EQ = EqInline(), fr_t* __restrict__ E_out = nullptr) {
+template <int NT, bool EQI = false, class TP = PtrTable, class TE = EqInline>
+__global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_eqw_lb(TP A, TP B, uint32_t nx, uint32_t ny, const fr_t* __restrict__ E, size_t half, fr_t* __restrict__ partials, uint32_t* counters,
+                                                               fr_t* __restrict__ out, uint32_t* flag, uint32_t seq, uint32_t pipeline, TE EQ = TE(), fr_t* __restrict__ E_out = nullptr) {
   __shared__ RedScratch S;
   __shared__ EqInlineTables ET;
   const CubicGrid g = cubic_grid(nx, ny);
   const uint32_t elb = EQ.ell / 2;
-  if (EQI) eq_inline_build(EQ, ET);
+  if constexpr (EQI) eq_inline_build(EQ, ET);
   const fr_t* __restrict__ a = A.p[g.by];
   const fr_t* __restrict__ b = B.p[g.by];
   fr29 e[3] = {fr29_zero(), fr29_zero(), fr29_zero()}; uint32_t cnt = 0;
@@ -348,11 +355,11 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_eqw_lb(PtrTable A, PtrTab
 }
 // fused with K1: bind A and B with r (length n = 4q -> 2q, in place: each element is owned by exactly one thread), then the sums of the NEXT round
 // on the bound values while they are still in registers — one launch per round, 48 bytes per element of A and B plus 32 per index of E.
-template <int NT, bool WIDE = false>
+template <int NT, bool WIDE = false, class TM = MutPtrTable>
 #ifdef LASSO_FUSED_WAVES   // experiment switch: force the register budget of the fused round (waves per SIMD); default = the compiler's choice (157 VGPRs, 3 waves)
 __attribute__((amdgpu_waves_per_eu(LASSO_FUSED_WAVES, LASSO_FUSED_WAVES)))
 #endif
-__global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_eqw_fused(MutPtrTable A, MutPtrTable B, uint32_t nx, uint32_t ny, const fr_t* __restrict__ E, size_t q, fr_t r,
+__global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_eqw_fused(TM A, TM B, uint32_t nx, uint32_t ny, const fr_t* __restrict__ E, size_t q, fr_t r,
                                                                   fr_t* __restrict__ partials, uint32_t* counters, fr_t* __restrict__ out, uint32_t* flag, uint32_t seq) {
   __shared__ RedScratch S;
   const CubicGrid g = cubic_grid(nx, ny);
@@ -384,8 +391,8 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_eqw_fused(MutPtrTable A, 
 // phase 1 gives every bind its own lane (4q products side by side instead of 4 in a row per thread), phase 2 every weighted value a'[i] E[i mod q],
 // phase 3 every (index, evaluation point), one wave per point; the three sums are 64-row column sums.  BIND = false is the first round of a
 // layer (no challenge yet): phase 1 only unpacks.  Lengths: A, B hold 4q elements when BIND, 2q otherwise.
-template <bool BIND, int NT>
-__global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_eqw_small(MutPtrTable A, MutPtrTable B, const fr_t* __restrict__ E, uint32_t q, fr_t r, uint32_t* counters, fr_t* __restrict__ out,
+template <bool BIND, int NT, class TM = MutPtrTable>
+__global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_eqw_small(TM A, TM B, const fr_t* __restrict__ E, uint32_t q, fr_t r, uint32_t* counters, fr_t* __restrict__ out,
                                                                   uint32_t* flag, uint32_t seq) {
   __shared__ fr29 bound[2][128];   // A', B' (2q values each)
   __shared__ fr29 ge[128];         // A'[i] * E[i mod q]
@@ -456,12 +463,12 @@ __device__ uint64_t tail_phase_clock[16 * 8];
 #endif
 // EQI (first round of a layer only): the eq table is never materialised — the two factor tables are built in LDS (eq_inline_build, <= 32 entries each at q <= 512) and
 // every use of E[i] is one product.
-template <bool BIND, int Q, bool EQI = false>
-__global__ void __launch_bounds__(Q) k_cubic_tail(MutPtrTable A, MutPtrTable B, const fr_t* __restrict__ E, uint32_t q, fr_t r0, const uint32_t* mailbox, uint32_t* counters,
-                                                             fr_t* __restrict__ out, uint32_t* flag, uint32_t seq0, EqInline EQ = EqInline()) {
+template <bool BIND, int Q, bool EQI = false, class TM = MutPtrTable, class TE = EqInline>
+__global__ void __launch_bounds__(Q) k_cubic_tail(TM A, TM B, const fr_t* __restrict__ E, uint32_t q, fr_t r0, const uint32_t* mailbox, uint32_t* counters,
+                                                             fr_t* __restrict__ out, uint32_t* flag, uint32_t seq0, TE EQ = TE()) {
   __shared__ fr29 eq_hi[EQI ? 32 : 1], eq_lo[EQI ? 32 : 1];
   const uint32_t elb = EQ.ell / 2;
-  if (EQI) {   // ell = log2 q <= 9: hi over the first ceil(ell/2) coordinates (scale folded in), lo over the rest, both s-form
+  if constexpr (EQI) {   // ell = log2 q <= 9: hi over the first ceil(ell/2) coordinates (scale folded in), lo over the rest, both s-form
     const uint32_t tt = threadIdx.x, hb = EQ.ell - elb; const fr29 one_s = fr29_one_s();
     if (tt < (1u << hb)) { fr29 p = fr29_unpack_s(EQ.scale); for (uint32_t j = 0; j < hb; j++) { const bool bit = (tt >> (hb - 1 - j)) & 1u; const fr29 rs = fr29_unpack_s(EQ.r[j]); p = fr29_mul(bit ? rs : fr29_sub(one_s, rs), p); } eq_hi[tt] = p; }
     else if (tt >= 64 && tt - 64 < (1u << elb)) { const uint32_t x = tt - 64; fr29 p = one_s; for (uint32_t j = 0; j < elb; j++) { const bool bit = (x >> (elb - 1 - j)) & 1u; const fr29 rs = fr29_unpack_s(EQ.r[hb + j]); p = fr29_mul(bit ? rs : fr29_sub(one_s, rs), p); } eq_lo[x] = p; }
