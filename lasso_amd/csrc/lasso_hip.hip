@@ -469,9 +469,15 @@ int32_t lasso_eq_evals_scaled(lasso_ctx* c, const lasso_fr* r, uint32_t ell, con
     const uint32_t lo_bits = ell / 2, hi_bits = ell - lo_bits;
     int32_t rc = ensure_scratch(c, (((size_t)1 << hi_bits) + ((size_t)1 << lo_bits)) * sizeof(fr_t)); if (rc) return rc;
     fr_t* hi = (fr_t*)c->d_scratch; fr_t* lo = hi + ((size_t)1 << hi_bits);
-    RTable Rh, Rl; for (uint32_t j = 0; j < hi_bits; j++) Rh.r[j] = to_fr(r + j); for (uint32_t j = 0; j < lo_bits; j++) Rl.r[j] = to_fr(r + hi_bits + j);
-    hipLaunchKernelGGL(k_eq_small, dim3(grid_for((size_t)1 << hi_bits)), dim3(LASSO_BLOCK), 0, c->stream, Rh, hi_bits, sc, hi);
-    hipLaunchKernelGGL(k_eq_small, dim3(grid_for((size_t)1 << lo_bits)), dim3(LASSO_BLOCK), 0, c->stream, Rl, lo_bits, fr_one(), lo);
+    if (hi_bits <= 16) {   // both factor tables in one launch
+      RTable16 Rh, Rl; for (uint32_t j = 0; j < 16; j++) { Rh.r[j] = j < hi_bits ? to_fr(r + j) : fr_zero(); Rl.r[j] = j < lo_bits ? to_fr(r + hi_bits + j) : fr_zero(); }
+      const unsigned hb = grid_for((size_t)1 << hi_bits), lb = grid_for((size_t)1 << lo_bits);
+      hipLaunchKernelGGL(k_eq_small2, dim3(hb + lb), dim3(LASSO_BLOCK), 0, c->stream, Rh, hi_bits, sc, hi, hb, Rl, lo_bits, lo);
+    } else {
+      RTable Rh, Rl; for (uint32_t j = 0; j < hi_bits; j++) Rh.r[j] = to_fr(r + j); for (uint32_t j = 0; j < lo_bits; j++) Rl.r[j] = to_fr(r + hi_bits + j);
+      hipLaunchKernelGGL(k_eq_small, dim3(grid_for((size_t)1 << hi_bits)), dim3(LASSO_BLOCK), 0, c->stream, Rh, hi_bits, sc, hi);
+      hipLaunchKernelGGL(k_eq_small, dim3(grid_for((size_t)1 << lo_bits)), dim3(LASSO_BLOCK), 0, c->stream, Rl, lo_bits, fr_one(), lo);
+    }
     hipLaunchKernelGGL(k_eq_outer, dim3(grid_for(n, 4096)), dim3(LASSO_BLOCK), 0, c->stream, (const fr_t*)hi, (const fr_t*)lo, lo_bits, n, (fr_t*)d_out);
   }
   HIPCHK(c, hipGetLastError()); return 0;

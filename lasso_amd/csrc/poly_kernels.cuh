@@ -1056,6 +1056,19 @@ __global__ void k_eq_small(RTable R, uint32_t ell, fr_t scale, fr_t* __restrict_
   for (uint32_t j = 0; j < ell; j++) { const bool bit = (x >> (ell - 1 - j)) & 1; const fr29 rs = fr29_unpack_s(R.r[j]); p = fr29_mul(bit ? rs : fr29_sub(one_s, rs), p); }
   out[x] = fr29_store(p);
 }
+// both factor tables of a large eq table in ONE launch (the first hi_blocks workgroups build hi, scale folded in; the rest lo): a launch of a few hundred threads costs 8-15 us
+// whatever it computes, and every streaming layer of the grand-product argument paid two of them in front of k_eq_outer
+struct RTable16 { fr_t r[16]; };
+__global__ void k_eq_small2(RTable16 Rh, uint32_t hi_bits, fr_t scale, fr_t* __restrict__ hi, uint32_t hi_blocks, RTable16 Rl, uint32_t lo_bits, fr_t* __restrict__ lo) {
+  const bool is_lo = blockIdx.x >= hi_blocks;
+  const uint32_t ell = is_lo ? lo_bits : hi_bits;
+  const size_t x = (blockIdx.x - (is_lo ? hi_blocks : 0u)) * (size_t)blockDim.x + threadIdx.x;
+  if (x >= ((size_t)1 << ell)) return;
+  fr29 p = is_lo ? fr29_unpack_u(fr_one()) : fr29_unpack_u(scale);
+  const fr29 one_s = fr29_one_s();
+  for (uint32_t j = 0; j < ell; j++) { const bool bit = (x >> (ell - 1 - j)) & 1; const fr29 rs = fr29_unpack_s(is_lo ? Rl.r[j] : Rh.r[j]); p = fr29_mul(bit ? rs : fr29_sub(one_s, rs), p); }
+  (is_lo ? lo : hi)[x] = fr29_store(p);
+}
 // out[x] = hi[x >> lo_bits] * lo[x & mask]
 __global__ void __launch_bounds__(LASSO_BLOCK) k_eq_outer(const fr_t* __restrict__ hi, const fr_t* __restrict__ lo, uint32_t lo_bits, size_t n, fr_t* __restrict__ out) {
   const size_t mask = ((size_t)1 << lo_bits) - 1;
