@@ -121,6 +121,41 @@ def test_gpu_concurrent_proofs_identical_to_sequential():
         assert len(got[t]) == reps and all(p == workers[t][4] for p in got[t])
 
 
+_SWITCH_SCRIPT = """
+import hashlib, sys
+import numpy as np
+from lasso_amd import HostProver, _abi
+hp = HostProver()
+kind, c, log_m, log_s = "and", 2, 16, 14
+S = _abi.Strategy(_abi.KINDS[kind], c, log_m, 0)
+idx = hp.gen_indices(1 << log_s, 1 << log_m, c); r = hp.gen_random_point(log_s)
+gens = hp.gens(c, 1 << log_s, c, log_m); dense = hp.densify(idx, log_m)
+comm = hp.commit(dense, gens); proof = hp.prove(dense, gens, S, r)
+print("DIGEST", hashlib.sha256(comm + proof).hexdigest())
+"""
+
+
+@pytest.mark.parametrize("env", [{"LASSO_TAGGED_RESULTS": "0"}, {"LASSO_DIRECT_NX": "0"}, {"LASSO_TAGGED_RESULTS": "0", "LASSO_CUBIC_TAIL": "0", "LASSO_LINEAR_TAIL": "0"},
+                                 {"LASSO_EQ_INLINE": "0", "LASSO_SUMCHECK_U32": "0", "LASSO_MSM_FUSED": "0"}, {"LASSO_TAIL_Q": "256", "LASSO_LB_PIPELINE": "0"}])
+def test_gpu_ab_switches_do_not_change_the_bytes(host, env):
+    """The A/B switches the measurements in DESIGN.md rest on (flag protocol instead of tagged results, in-launch second stage, launch per round instead of the resident tails, ...)
+    select other kernels / protocols for the same arithmetic: commitment and proof must be the bytes of the default configuration.  Each setting runs in its own process
+    (the switches are read once per process)."""
+    import hashlib, os, subprocess, sys
+    kind, c, log_m, log_s = "and", 2, 16, 14
+    S = _abi.Strategy(_abi.KINDS[kind], c, log_m, 0)
+    idx = host.gen_indices(1 << log_s, 1 << log_m, c); r = host.gen_random_point(log_s)
+    gens = host.gens(c, 1 << log_s, c, log_m); dense = host.densify(idx, log_m)
+    want = hashlib.sha256(host.commit(dense, gens) + host.prove(dense, gens, S, r)).hexdigest()
+    host.free(dense, gens)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ); e.update(env); e["PYTHONPATH"] = root + os.pathsep + e.get("PYTHONPATH", "")
+    out = subprocess.run([sys.executable, "-c", _SWITCH_SCRIPT], env=e, cwd=root, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    got = [l.split()[1] for l in out.stdout.splitlines() if l.startswith("DIGEST")]
+    assert got == [want], (env, got, want)
+
+
 # BASELINE.json's configurations at FULL size (configs[1], configs[2] and the configuration the metric is quoted on).  The oracle prover cannot
 # reach these sizes in seconds, so parity rests on the size-independent property the reference itself uses as its acceptance test
 # (src/e2e_test.rs:54-59): prove -> verify, here through the oracle's verifier (a restatement of surge.rs:214-271) fed the GPU's commitment,
