@@ -253,13 +253,24 @@ __device__ __forceinline__ uint32_t msm_phys_col(const MsmColMap& m, uint32_t ro
 // BN254 build: the complete projective addition's twelve products form two dependent layers of six (bn254_fe29.cuh pt_coop_*), so SIX lanes share
 // one addition: 42 additions per pass of the workgroup, a tree level costs two product times (plus the linear step) instead of twelve.  The exchange
 // buffer is the Edwards build's (64 x 4 values >= 42 x 6), used twice per pass.  Same interface.
-__device__ __forceinline__ void msm_coop_tree(pt29* pts, fe29 (*st4)[4], uint32_t live, const fe29&) {
+#ifndef MSM_COOP_PLAIN_FROM
+#define MSM_COOP_PLAIN_FROM 64u   // tree levels with at least this many additions run one addition per lane (-DMSM_COOP_PLAIN_FROM=1024: the six-lane form at every level, as in round 2)
+#endif
+__device__ __forceinline__ void msm_coop_tree(pt29* pts, fe29 (*st4)[4], uint32_t live, const fe29& d2_unused) {
   fe29* st = &st4[0][0];
   const uint32_t t = threadIdx.x, g = t / 6u, c = t - g * 6u;
   constexpr uint32_t GROUPS = MSM_THREADS / 6;   // 42
   const bool lane_ok = g < GROUPS;
   uint32_t p2 = 1; while (p2 < live) p2 <<= 1;
   for (uint32_t s = p2 >> 1; s > 0; s >>= 1) {
+    if (s >= MSM_COOP_PLAIN_FROM) {
+      // the two widest levels: one whole addition per lane.  42 six-lane groups need 4 passes (19 us) for 128 additions and 2 (9.6 us) for 64; 128 / 64 lanes each running the
+      // 12 products of an addition on their own take ~7 us (tools/msm_phase_bench.hip: the six-lane tree was 58 of 141 us per opening MSM).  Same group elements, other projective
+      // representatives: the wire bytes do not change
+      if (t < s && t + s < live) pts[t] = pt_add(pts[t], pts[t + s], d2_unused);
+      __syncthreads();
+      continue;
+    }
     for (uint32_t i0 = 0; i0 < s; i0 += GROUPS) {
       const uint32_t i = i0 + g;
       const bool act = lane_ok && i < s && i + s < live;
