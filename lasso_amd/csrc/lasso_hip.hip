@@ -324,12 +324,14 @@ int32_t lasso_points_reduce_compress(lasso_ctx* c, const void* d_parts, uint32_t
 
 // three self-validating chunks [tag, w, w, w] [tag, w, w, w] [tag, w, w, check], each ONE aligned 16-byte store; the check word (result_check's formula) lets the kernel reject a chunk
 // that arrived in pieces
-static inline void post_mail(lasso_ctx* c, uint32_t tag, const uint32_t w[8]) {
+static inline void mail_chunks(uint32_t* mail, uint32_t tag, const uint32_t w[8]) {
   const uint32_t chk = (w[0] ^ w[1] ^ w[2] ^ w[3] ^ w[4] ^ w[5] ^ w[6] ^ w[7]) + tag * 0x9E3779B9u;
-  uint32_t* mail = c->mail_h;
   _mm_store_si128((__m128i*)(mail + 0), _mm_set_epi32((int)w[2], (int)w[1], (int)w[0], (int)tag));
   _mm_store_si128((__m128i*)(mail + 4), _mm_set_epi32((int)w[5], (int)w[4], (int)w[3], (int)tag));
   _mm_store_si128((__m128i*)(mail + 8), _mm_set_epi32((int)chk, (int)w[7], (int)w[6], (int)tag));
+}
+static inline void post_mail(lasso_ctx* c, uint32_t tag, const uint32_t w[8]) {
+  mail_chunks(c->mail_h, tag, w);
   _mm_sfence();   // release: the chunks are globally visible before anything the host does next
 }
 int32_t lasso_ctx_create(int32_t device, lasso_ctx** out) { return lasso_ctx_create_background(device, 0, out); }

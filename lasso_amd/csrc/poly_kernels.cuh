@@ -91,6 +91,10 @@ __device__ __forceinline__ void result_store(fr_t* __restrict__ out, size_t slot
     o[0] = c0; o[1] = c1; o[2] = c2;
   } else out[slot] = v;
 }
+// the host -> device direction of a resident kernel (lasso_hip.hip post_mail): the three mailbox chunks carry this tag and the check word of their eight challenge words
+__device__ __forceinline__ bool mail_valid(const lasso_u32x4& c0, const lasso_u32x4& c1, const lasso_u32x4& c2, uint32_t tag) {
+  return c0.x == tag && c1.x == tag && c2.x == tag && c2.w == (c0.y ^ c0.z ^ c0.w ^ c1.y ^ c1.z ^ c1.w ^ c2.y ^ c2.z) + tag * 0x9E3779B9u;
+}
 // block partials of up to KMAX accumulators (groups of 3) -> dst[k], k < K; `shift` also corrects the radix of the accumulated products.
 // With `flag` the destination is the launch's result area (result_store at slot0 + k).
 template <int KMAX>
@@ -564,7 +568,7 @@ __global__ void __launch_bounds__(Q) k_cubic_tail(TM A, TM B, const fr_t* __rest
       for (;;) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");   // nothing cached from the previous poll
         c0 = __builtin_nontemporal_load(m4); c1 = __builtin_nontemporal_load(m4 + 1); c2 = __builtin_nontemporal_load(m4 + 2);   // three 16-byte reads in flight together
-        if (c0.x == seq0 + turn + 1 && c1.x == seq0 + turn + 1 && c2.x == seq0 + turn + 1 && c2.w == (c0.y ^ c0.z ^ c0.w ^ c1.y ^ c1.z ^ c1.w ^ c2.y ^ c2.z) + (seq0 + turn + 1) * 0x9E3779B9u) break;   // tagged with the sequence number of the publication it enables: unique per context, never reset
+        if (mail_valid(c0, c1, c2, seq0 + turn + 1)) break;   // tagged with the sequence number of the publication it enables: unique per context, never reset
         if (c0.x == LASSO_MAIL_POISON || ((++spins & 63u) == 0 && wall_clock64() > t_end)) { ok = 0; break; }   // lasso_abort's tag, or the host stopped answering
       }
       if (ok) { chal.v[0] = c0.y; chal.v[1] = c0.z; chal.v[2] = c0.w; chal.v[3] = c1.y; chal.v[4] = c1.z; chal.v[5] = c1.w; chal.v[6] = c2.y; chal.v[7] = c2.z; }
@@ -751,7 +755,7 @@ __global__ void __launch_bounds__(Q) k_linear_tail(PtrTable src, const fr_t* __r
       for (;;) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
         c0 = __builtin_nontemporal_load(m4); c1 = __builtin_nontemporal_load(m4 + 1); c2 = __builtin_nontemporal_load(m4 + 2);
-        if (c0.x == seq0 + turn + 1 && c1.x == seq0 + turn + 1 && c2.x == seq0 + turn + 1 && c2.w == (c0.y ^ c0.z ^ c0.w ^ c1.y ^ c1.z ^ c1.w ^ c2.y ^ c2.z) + (seq0 + turn + 1) * 0x9E3779B9u) break;   // tagged with the sequence number of the publication it enables: unique per context, never reset
+        if (mail_valid(c0, c1, c2, seq0 + turn + 1)) break;   // tagged with the sequence number of the publication it enables: unique per context, never reset
         if (c0.x == LASSO_MAIL_POISON || ((++spins & 63u) == 0 && wall_clock64() > t_end)) { ok = 0; break; }   // lasso_abort's tag, or the host stopped answering
       }
       if (ok) { chal.v[0] = c0.y; chal.v[1] = c0.z; chal.v[2] = c0.w; chal.v[3] = c1.y; chal.v[4] = c1.z; chal.v[5] = c1.w; chal.v[6] = c2.y; chal.v[7] = c2.z; }
