@@ -47,3 +47,37 @@ def test_bench_gpus2_self_launch_prints_weak_and_slab(oracle):
         assert hashlib.sha256(orc.commit()).hexdigest() == slab["commitment_sha256"]
     finally:
         orc.close()
+
+
+def test_concurrent_leg_reports_a_failed_proof_instead_of_hanging():
+    """bench.py's concurrent-proofs leg with a prover that fails in one of its threads: the leg must come back with an `error` entry (round 3: a lost hand-off in an
+    experiment left the main thread waiting at the barrier until the outer time-out, and with it the whole bench line)."""
+    import importlib.util
+    import threading
+    import time
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    from lasso_amd import _abi
+    made = []
+
+    class FakeProver:
+        def __init__(self, curve="curve25519"):
+            self.calls = 0; self.id = len(made); made.append(self)
+        def gen_indices(self, s, m, c): return np.zeros((s, c), dtype=np.uint64)
+        def gen_random_point(self, n): return np.zeros((n, 4), dtype=np.uint64)
+        def gens(self, c, s, alpha, log_m): return object()
+        def densify(self, idx, log_m): return object()
+        def prove(self, dense, gens, S, r):
+            self.calls += 1
+            if self.id == 1 and self.calls == 2:   # the second prover's first timed proof (call 1 is the warm-up)
+                raise RuntimeError("a result was not delivered by the device")
+            time.sleep(0.01); return b"proof"
+        def free(self, *a): pass
+        def close(self): pass
+    S = _abi.Strategy(_abi.KINDS["and"], 1, 8, 0)
+    box = {}
+    th = threading.Thread(target=lambda: box.update(out=bench.concurrent_leg(FakeProver, _abi, 3, 2, S, 1, 8, 6)), daemon=True)
+    th.start(); th.join(timeout=60)
+    assert not th.is_alive(), "the leg hung"
+    assert "error" in box["out"] and "not delivered" in box["out"]["error"]
+
