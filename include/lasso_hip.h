@@ -66,6 +66,11 @@ void lasso_ctx_destroy(lasso_ctx* ctx);
 const char* lasso_last_error(lasso_ctx* ctx);          /* ctx may be NULL: last error of a failed create */
 int32_t lasso_alloc(lasso_ctx* ctx, size_t bytes, void** d_out);
 int32_t lasso_free(lasso_ctx* ctx, void* d_ptr);
+/* Device memory held through this context: bytes currently allocated — lasso_alloc'd buffers, the context's own scratch and result buffers, and the generator
+ * tables of every lasso_bases object created with it (window, digit-multiple and byte-multiple tables) — and the high-water mark of that figure since the
+ * context was created or since the last call with reset_peak != 0.  What one rank of slab mode needs of its GPU's 288 GB (bench.py `peak_bytes_per_rank`);
+ * the reference's counterpart is the resident set of its Vec<F>s (src/poly/dense_mlpoly.rs:28-32, src/subprotocols/grand_product.rs:19-58). */
+int32_t lasso_mem_stats(lasso_ctx* ctx, uint64_t* live_bytes, uint64_t* peak_bytes, int32_t reset_peak);
 int32_t lasso_upload(lasso_ctx* ctx, void* d_dst, const void* src, size_t bytes);     /* synchronous */
 int32_t lasso_download(lasso_ctx* ctx, void* dst, const void* d_src, size_t bytes);   /* synchronous */
 int32_t lasso_copy(lasso_ctx* ctx, void* d_dst, const void* d_src, size_t bytes);     /* DensePolynomial::clone / merge: src/poly/dense_mlpoly.rs:97-99,:251-261 */

@@ -28,6 +28,14 @@ const char* lasso_host_last_error(void);
 int32_t lasso_host_create(int32_t device, lasso_host** out);
 void lasso_host_destroy(lasso_host* h);
 lasso_ctx* lasso_host_ctx(lasso_host* h);   /* the device context, e.g. for lasso_prof_* */
+/* Device memory of this host (its main and side contexts, include/lasso_hip.h lasso_mem_stats): bytes held now, their high-water mark, and the high-water mark of
+ * what the prover itself had in use (buffers parked in the host's recycling pool excluded) since creation / the last call with reset != 0.  Any pointer may be NULL. */
+int32_t lasso_host_mem_stats(lasso_host* h, uint64_t* live_bytes, uint64_t* peak_bytes, uint64_t* prover_peak_bytes, int32_t reset);
+/* Capacity mode (slab mode's purpose: proofs whose polynomials do not fit one GPU — the reference keeps every DensePolynomial and every product-tree layer as a
+ * Vec<F>, src/subprotocols/grand_product.rs:38-58): large device buffers go back to the driver when the prover releases them instead of into the recycling pool,
+ * and the prover drops what it no longer needs as early as the protocol allows, so the per-rank high-water mark is the live peak.  Same bytes, more driver calls.
+ * Off by default (LASSO_CAPACITY=1 turns it on for every host). */
+int32_t lasso_host_set_capacity(lasso_host* h, int32_t on);
 
 /* Slab mode: ONE proof sharded over `world` GPUs (world a power of two, one lasso_host per rank, every rank given the SAME lookups and point).
  * Every polynomial is split by low index bits (rank g holds the indices = g mod world), the transcript is replicated, and `allgather` is the only

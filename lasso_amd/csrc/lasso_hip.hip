@@ -4,6 +4,7 @@
 #include <emmintrin.h>
 #include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 #include <cstring>
 #include <cstdio>
@@ -69,9 +70,12 @@ struct lasso_ctx {
   double prof_units3[LASSO_K_COUNT] = {0}; double big_units3[LASSO_K_COUNT] = {0};   // MSM families: mixed additions EXECUTED, counted by the kernels (only while every launch is bracketed: no LASSO_PROF_LARGE_ONLY)
   uint32_t* d_prof_counts = nullptr;
   void* rccl_comm = nullptr; int rccl_world = 0;   // slab mode's device-side exchange (lasso_rccl_*): an ncclComm_t bound to this context's device and stream
+  // device memory held through this context (lasso_mem_stats): lasso_alloc'd buffers, the context's scratch / result buffers and the generator tables built with it
+  std::unordered_map<void*, size_t> mem_sizes; uint64_t mem_live = 0, mem_peak = 0; std::mutex mem_mu;   // bases tables may be built from another host thread (ensure_tab8)
 };
 struct lasso_bases {
   size_t n = 0; niels29* d_table = nullptr;
+  lasso_ctx* owner = nullptr;                // the context its tables' bytes are accounted to (lasso_mem_stats)
   niels29* d_mult = nullptr;                 // signed digit multiples for the latency-shaped MSM (k_msm_direct), optional
   niels29* d_tab8[2] = {nullptr, nullptr};   // byte multiples m * 256^w * G_j, m = 1..255, for the row-parallel commitments of small scalars (k_msm_rows8); built on first use
   bool tab8_failed = false;
@@ -88,11 +92,22 @@ static inline bool bind_device(lasso_ctx* c) { if (!c) return true; int d = -1; 
 #define REQUIRE(c, cond) do { if (!bind_device(c)) return fail((c), LASSO_ERR_HIP, "hipSetDevice failed for the context's device"); \
                               if (!(cond)) return fail((c), LASSO_ERR_INVALID, std::string("invalid argument: ") + #cond); } while (0)
 
+// hipMalloc / hipFree with the context's byte accounting (lasso_mem_stats)
+static hipError_t dmalloc(lasso_ctx* c, void** p, size_t bytes) {
+  hipError_t e = hipMalloc(p, bytes);
+  if (e == hipSuccess && c) { std::lock_guard<std::mutex> g(c->mem_mu); c->mem_sizes[*p] = bytes; c->mem_live += bytes; if (c->mem_live > c->mem_peak) c->mem_peak = c->mem_live; }
+  return e;
+}
+static hipError_t dfree(lasso_ctx* c, void* p) {
+  if (c && p) { std::lock_guard<std::mutex> g(c->mem_mu); auto it = c->mem_sizes.find(p); if (it != c->mem_sizes.end()) { c->mem_live -= it->second; c->mem_sizes.erase(it); } }
+  return hipFree(p);
+}
+
 static int32_t ensure_scratch(lasso_ctx* c, size_t bytes) {
   if (bytes <= c->scratch_cap) return 0;
-  if (c->d_scratch) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(c->d_scratch)); c->d_scratch = nullptr; c->scratch_cap = 0; }
+  if (c->d_scratch) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, dfree(c, c->d_scratch)); c->d_scratch = nullptr; c->scratch_cap = 0; }
   size_t cap = bytes < ((size_t)1 << 22) ? ((size_t)1 << 22) : bytes;
-  HIPCHK(c, hipMalloc(&c->d_scratch, cap)); c->scratch_cap = cap; return 0;
+  HIPCHK(c, dmalloc(c, &c->d_scratch, cap)); c->scratch_cap = cap; return 0;
 }
 static int32_t ensure_small(lasso_ctx* c, size_t count) {
   if (count <= c->small_cap) return 0;
@@ -112,11 +127,11 @@ static int32_t ensure_small(lasso_ctx* c, size_t count) {
 static int32_t ensure_big(lasso_ctx* c, size_t count) {
   if (count <= c->big_cap) return 0;
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  if (c->d_big) (void)hipFree(c->d_big);
+  if (c->d_big) (void)dfree(c, c->d_big);
   if (c->h_big) (void)hipHostFree(c->h_big);
   c->d_big = nullptr; c->h_big = nullptr; c->big_cap = 0;
   size_t cap = count < 8192 ? 8192 : count;
-  HIPCHK(c, hipMalloc((void**)&c->d_big, cap * sizeof(fr_t)));
+  HIPCHK(c, dmalloc(c, (void**)&c->d_big, cap * sizeof(fr_t)));
   HIPCHK(c, hipHostMalloc((void**)&c->h_big, cap * sizeof(fr_t), hipHostMallocDefault));
   c->big_cap = cap; return 0;
 }
@@ -222,12 +237,26 @@ static int32_t wait_flag(lasso_ctx* c, uint32_t seq, size_t count, lasso_fr* out
   memcpy(out, c->h_small, count * sizeof(fr_t));
   return 0;
 }
+// Sequence numbers tag every hand-off (result chunks, the tails' mailbox) and must be unique among everything the tagged areas can still hold.  They are 32 bits: at ~1e5
+// hand-offs per second a long-lived context would wrap after about 12 hours, reach LASSO_MAIL_POISON (0xFFFFFFFF) and then meet 0 (= "never written") and its own old tags
+// (ADVICE r3).  next_seq hands out `span` consecutive numbers and, long before the top of the range, starts a new epoch instead: drain the stream (nothing in flight can
+// still publish), zero the tagged result area and the mailbox, and restart at 1.  Costs one stream synchronisation per ~4e9 hand-offs.
+static uint32_t next_seq(lasso_ctx* c, uint32_t span = 1) {
+  if (c->seq > 0xFFF00000u - span) {
+    (void)hipStreamSynchronize(c->stream);
+    if (c->h_tag) memset(c->h_tag, 0, c->small_cap * 48);
+    if (c->mail_h) memset(c->mail_h, 0, 48);
+    if (c->h_flag) *c->h_flag = 0;
+    c->seq = 0;
+  }
+  const uint32_t first = c->seq + 1; c->seq += span; return first;
+}
 // where a converted round kernel's results go: (out, flag) arguments of the launch
 #define RES(c) ((c)->tagged ? (fr_t*)(c)->d_tag : (c)->d_small), ((c)->tagged ? LASSO_TAGGED : (c)->d_flag)
 __global__ void k_publish(uint32_t* flag, uint32_t seq) { __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
 // results were stored to d_small (= mapped h_small) by kernels already enqueued on the stream: raise the flag behind them
 static int32_t fetch_small(lasso_ctx* c, size_t count, lasso_fr* out) {
-  const uint32_t seq = ++c->seq;
+  const uint32_t seq = next_seq(c);
   hipLaunchKernelGGL(k_publish, dim3(1), dim3(1), 0, c->stream, c->d_flag, seq);
   HIPCHK(c, hipGetLastError());
   return wait_flag(c, seq, count, out);
@@ -354,6 +383,7 @@ int32_t lasso_ctx_create_background(int32_t device, int32_t background, lasso_ct
   if (hipHostMalloc((void**)&c->h_flag, 256, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess || hipHostGetDevicePointer((void**)&c->d_flag, c->h_flag, 0) != hipSuccess) { delete c; return fail(nullptr, LASSO_ERR_OOM, "mapped flag alloc"); }
   *c->h_flag = 0;
   { const char* v = getenv("LASSO_TAGGED_RESULTS"); c->tagged = !(v && v[0] == '0'); }   // A/B switch: the flag protocol for every hand-off
+  { const char* v = getenv("LASSO_SEQ_START"); if (v) c->seq = (uint32_t)strtoul(v, nullptr, 0); }   // tests: start close to the end of a sequence epoch (next_seq)
   c->mail_h = c->h_flag + 32; c->mail_d = c->d_flag + 32;   // 128-byte offset: 16-byte aligned chunks
   memset(c->mail_h, 0, 48);
   int32_t rc = ensure_small(c, (size_t)1 << 16); if (rc) { g_create_err = c->err; delete c; return rc; }   // 2 MiB of mapped result buffer: the largest a-vector / row-commitment hand-off without a reallocation
@@ -396,8 +426,12 @@ void lasso_ctx_destroy(lasso_ctx* c) {
 }
 const char* lasso_last_error(lasso_ctx* c) { return c ? c->err.c_str() : g_create_err.c_str(); }
 void* lasso_stream(lasso_ctx* c) { return c ? (void*)c->stream : nullptr; }
-int32_t lasso_alloc(lasso_ctx* c, size_t bytes, void** d_out) { REQUIRE(c, d_out); HIPCHK(c, hipMalloc(d_out, bytes ? bytes : 1)); return 0; }
-int32_t lasso_free(lasso_ctx* c, void* p) { if (!p) return 0; REQUIRE(c, c); HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(p)); return 0; }
+int32_t lasso_alloc(lasso_ctx* c, size_t bytes, void** d_out) { REQUIRE(c, d_out); HIPCHK(c, dmalloc(c, d_out, bytes ? bytes : 1)); return 0; }
+int32_t lasso_free(lasso_ctx* c, void* p) { if (!p) return 0; REQUIRE(c, c); HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, dfree(c, p)); return 0; }
+int32_t lasso_mem_stats(lasso_ctx* c, uint64_t* live_bytes, uint64_t* peak_bytes, int32_t reset_peak) {
+  REQUIRE(c, c); std::lock_guard<std::mutex> g(c->mem_mu);
+  if (live_bytes) *live_bytes = c->mem_live; if (peak_bytes) *peak_bytes = c->mem_peak; if (reset_peak) c->mem_peak = c->mem_live; return 0;
+}
 int32_t lasso_upload(lasso_ctx* c, void* d, const void* s, size_t n) { REQUIRE(c, d && s); HIPCHK(c, hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); return 0; }
 int32_t lasso_download(lasso_ctx* c, void* d, const void* s, size_t n) { REQUIRE(c, d && s); HIPCHK(c, hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); return 0; }
 int32_t lasso_copy(lasso_ctx* c, void* d, const void* s, size_t n) { REQUIRE(c, d && s); ProfScope ps(c, LASSO_K_MISC, 2.0 * n); HIPCHK(c, hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, c->stream)); return 0; }
@@ -503,7 +537,7 @@ int32_t lasso_sumcheck_cubic_round(lasso_ctx* c, const lasso_fr* const* d_A, con
   REQUIRE(c, d_A && d_B && d_C && out && ncirc >= 1 && ncirc <= LASSO_MAX_PTRS && n >= 2 && (n & (n - 1)) == 0);
   const size_t half = n / 2;
   int32_t rc = ensure_small(c, (size_t)ncirc * 3); if (rc) return rc;
-  const uint32_t seq = ++c->seq;
+  const uint32_t seq = next_seq(c);
   PtrTable A, B; for (uint32_t i = 0; i < ncirc; i++) { REQUIRE(c, d_A[i] && d_B[i]); A.p[i] = (const fr_t*)d_A[i]; B.p[i] = (const fr_t*)d_B[i]; }
   const unsigned ny = ncirc, nx = grid_for(half, cubic_nx_cap(ny));
   rc = ensure_scratch(c, (size_t)nx * ny * 3 * sizeof(fr_t)); if (rc) return rc;
@@ -532,7 +566,7 @@ static int32_t cubic_eqw_launch_t(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* 
   if (groups_out) *groups_out = 1;
   TM A, B; for (uint32_t i = 0; i < ncirc; i++) { REQUIRE(c, d_A[i] && d_B[i]); A.p[i] = (fr_t*)d_A[i]; B.p[i] = (fr_t*)d_B[i]; }
   int32_t rc = ensure_small(c, (size_t)ncirc * 3); if (rc) return rc;
-  const uint32_t seq = ++c->seq; *seq_out = seq;
+  const uint32_t seq = next_seq(c); *seq_out = seq;
   if (!r) {
     const size_t half = n / 2;
     ProfScope ps(c, LASSO_K_CUBIC, 32.0 * n * (2.0 * ncirc + 1.0));
@@ -634,7 +668,7 @@ static int32_t cubic_tail_begin_t(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* 
   TM A, B; for (uint32_t i = 0; i < ncirc; i++) { REQUIRE(c, d_A[i] && d_B[i]); A.p[i] = (fr_t*)d_A[i]; B.p[i] = (fr_t*)d_B[i]; }
   int32_t rc = ensure_small(c, (size_t)ncirc * 3); if (rc) return rc;
   uint32_t turns = 0; while (((size_t)1 << turns) < 2 * q) turns++;   // rounds of sums; one more publication carries the heads
-  const uint32_t seq0 = c->seq + 1; c->seq += turns + 1;
+  const uint32_t seq0 = next_seq(c, turns + 1);
   // workgroup = capacity: 256 threads / 74 KB of LDS up to 256 indices per circuit, 512 threads / 147 KB above
 #define LAUNCH_CTAIL(B_, Q_, I_, TE_, R_, EQ_) hipLaunchKernelGGL((k_cubic_tail<B_, Q_, I_, TM, TE_>), dim3(ncirc), dim3(Q_), 0, c->stream, A, B, (const fr_t*)d_E, (uint32_t)q, R_, (const uint32_t*)c->mail_d, c->d_counters, RES(c), seq0, EQ_)
   if (eqi) { if (q <= 256) LAUNCH_CTAIL(false, 256, true, EqInline, fr_zero(), *eqi); else LAUNCH_CTAIL(false, 512, true, EqInline, fr_zero(), *eqi); }
@@ -659,7 +693,7 @@ int32_t lasso_sumcheck_linear_tail_begin(lasso_ctx* c, const lasso_fr* const* d_
   PtrTable Src; for (uint32_t i = 0; i < alpha; i++) { REQUIRE(c, d_src[i]); Src.p[i] = (const fr_t*)d_src[i]; }
   int32_t rc = ensure_small(c, (size_t)alpha * 3); if (rc) return rc;
   uint32_t turns = 0; while (((size_t)1 << turns) < 2 * q) turns++;
-  const uint32_t seq0 = c->seq + 1; c->seq += turns + 1;
+  const uint32_t seq0 = next_seq(c, turns + 1);
 #define LAUNCH_LTAIL(B_, Q_, R_) hipLaunchKernelGGL((k_linear_tail<B_, Q_>), dim3(alpha), dim3(Q_), 0, c->stream, Src, (const fr_t*)d_E, (uint32_t)q, R_, (const uint32_t*)c->mail_d, c->d_counters, RES(c), seq0)
   if (q <= 256) { if (r) LAUNCH_LTAIL(true, 256, to_fr(r)); else LAUNCH_LTAIL(false, 256, fr_zero()); }
   else { if (r) LAUNCH_LTAIL(true, 512, to_fr(r)); else LAUNCH_LTAIL(false, 512, fr_zero()); }
@@ -695,7 +729,7 @@ int32_t lasso_sumcheck_linear_eqw_round(lasso_ctx* c, const lasso_fr* const* d_p
   const size_t half = n / 2; const unsigned ny = alpha, nx = grid_for(half, cubic_nx_cap(ny));
   int32_t rc = ensure_small(c, (size_t)alpha * 3); if (rc) return rc;
   rc = ensure_scratch(c, (size_t)nx * ny * 3 * sizeof(fr_t)); if (rc) return rc;
-  const uint32_t seq = ++c->seq;
+  const uint32_t seq = next_seq(c);
   {
     ProfScope ps(c, LASSO_K_COMBINE, 32.0 * n * (alpha + 1.0));
     hipLaunchKernelGGL(k_dot_eqw_lb, dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, P, nx, ny, (const fr_t*)d_E, half, (fr_t*)c->d_scratch, c->d_counters, RES(c), seq);
@@ -712,7 +746,7 @@ int32_t lasso_sumcheck_linear_eqw_round_fused_from(lasso_ctx* c, const lasso_fr*
   const size_t q = n / 4; const unsigned ny = alpha, nx = grid_for(q, cubic_nx_cap(ny));
   int32_t rc = ensure_small(c, (size_t)alpha * 3); if (rc) return rc;
   rc = ensure_scratch(c, (size_t)nx * ny * 3 * sizeof(fr_t)); if (rc) return rc;
-  const uint32_t seq = ++c->seq;
+  const uint32_t seq = next_seq(c);
   {
     // bind (48 n per polynomial, the reference's alpha + 1 of them) with the next round's sums riding on the same pass
     ProfScope ps(c, LASSO_K_BIND, 48.0 * n * (alpha + 1.0));
@@ -728,7 +762,7 @@ int32_t lasso_sumcheck_linear_eqw_round_u32(lasso_ctx* c, const uint32_t* const*
   const size_t half = n / 2; const unsigned ny = alpha, nx = grid_for(half, cubic_nx_cap(ny));
   int32_t rc = ensure_small(c, (size_t)alpha * 3); if (rc) return rc;
   rc = ensure_scratch(c, (size_t)nx * ny * 3 * sizeof(fr_t)); if (rc) return rc;
-  const uint32_t seq = ++c->seq;
+  const uint32_t seq = next_seq(c);
   {
     ProfScope ps(c, LASSO_K_COMBINE, 32.0 * n * (alpha + 1.0));   // SURVEY 8(d)'s bytes of the reference's round; the kernel reads 4 n per polynomial + 16 n of the table
     hipLaunchKernelGGL(k_dot_eqw_lb_u32, dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, P, nx, ny, (const fr_t*)d_E, half, (fr_t*)c->d_scratch, c->d_counters, RES(c), seq);
@@ -742,7 +776,7 @@ int32_t lasso_sumcheck_linear_eqw_round_fused_from_u32(lasso_ctx* c, const uint3
   const size_t q = n / 4; const unsigned ny = alpha, nx = grid_for(q, cubic_nx_cap(ny));
   int32_t rc = ensure_small(c, (size_t)alpha * 3); if (rc) return rc;
   rc = ensure_scratch(c, (size_t)nx * ny * 3 * sizeof(fr_t)); if (rc) return rc;
-  const uint32_t seq = ++c->seq;
+  const uint32_t seq = next_seq(c);
   {
     ProfScope ps(c, LASSO_K_BIND, 48.0 * n * (alpha + 1.0));
     hipLaunchKernelGGL(k_dot_eqw_fused_from_u32, dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, Src, P, nx, ny, (const fr_t*)d_E, q, to_fr(r), (fr_t*)c->d_scratch, c->d_counters, RES(c), seq);
@@ -1025,32 +1059,33 @@ int32_t lasso_densify_dim_slab(lasso_ctx* c, const uint64_t* d_indices, size_t n
 // ------------------------------------------------------------------ curve entry points
 int32_t lasso_bases_create(lasso_ctx* c, const lasso_affine* points, size_t n, lasso_bases** out) {
   REQUIRE(c, points && out && n >= 1 && n * MSM_WINDOWS < ((size_t)1 << 32));
-  lasso_bases* b = new lasso_bases(); b->n = n;
+  lasso_bases* b = new lasso_bases(); b->n = n; b->owner = c;
   void* d_aff = nullptr;
-  if (hipMalloc(&d_aff, n * sizeof(lasso_affine)) != hipSuccess || hipMalloc((void**)&b->d_table, n * MSM_WINDOWS * sizeof(niels29)) != hipSuccess) {
-    if (d_aff) (void)hipFree(d_aff); delete b; return fail(c, LASSO_ERR_OOM, "bases alloc");
+  if (dmalloc(c, &d_aff, n * sizeof(lasso_affine)) != hipSuccess || dmalloc(c, (void**)&b->d_table, n * MSM_WINDOWS * sizeof(niels29)) != hipSuccess) {
+    if (d_aff) (void)dfree(c, d_aff); delete b; return fail(c, LASSO_ERR_OOM, "bases alloc");
   }
   hipError_t e = hipMemcpyAsync(d_aff, points, n * sizeof(lasso_affine), hipMemcpyHostToDevice, c->stream);
   if (e == hipSuccess) { hipLaunchKernelGGL(k_precompute_table, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream, (const fq_t*)d_aff, n, b->d_table); e = hipGetLastError(); }
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-  (void)hipFree(d_aff);
-  if (e != hipSuccess) { (void)hipFree(b->d_table); delete b; return fail(c, LASSO_ERR_HIP, hipGetErrorString(e)); }
+  (void)dfree(c, d_aff);
+  if (e != hipSuccess) { (void)dfree(c, b->d_table); delete b; return fail(c, LASSO_ERR_HIP, hipGetErrorString(e)); }
   // digit multiples for the few-row full-width MSMs of the opening tail: 8 x the window table (57 KB per generator).  Optional: if the
   // allocation fails or the generator set is larger than LASSO_MSM_DIRECT_MAX_N the bucket kernel serves those MSMs too.
   static const size_t direct_max = [] { const char* v = getenv("LASSO_MSM_DIRECT_MAX_N"); return v ? (size_t)atoll(v) : (((size_t)1 << 17) + 64); }();
   if (n <= direct_max) {
-    if (hipMalloc((void**)&b->d_mult, n * MSM_WINDOWS * MSM_MULTS * sizeof(niels29)) == hipSuccess) {
+    if (dmalloc(c, (void**)&b->d_mult, n * MSM_WINDOWS * MSM_MULTS * sizeof(niels29)) == hipSuccess) {
       hipLaunchKernelGGL(k_precompute_multiples, dim3((unsigned)((n * MSM_WINDOWS + 63) / 64)), dim3(64), 0, c->stream, (const niels29*)b->d_table, n, b->d_mult);
       e = hipGetLastError(); if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-      if (e != hipSuccess) { (void)hipFree(b->d_mult); (void)hipFree(b->d_table); delete b; return fail(c, LASSO_ERR_HIP, hipGetErrorString(e)); }
+      if (e != hipSuccess) { (void)dfree(c, b->d_mult); (void)dfree(c, b->d_table); delete b; return fail(c, LASSO_ERR_HIP, hipGetErrorString(e)); }
     } else { (void)hipGetLastError(); b->d_mult = nullptr; }
   }
   *out = b; return 0;
 }
 void lasso_bases_destroy(lasso_ctx* c, lasso_bases* b) {
   if (!b) return; if (c) (void)hipStreamSynchronize(c->stream);
-  if (b->d_table) (void)hipFree(b->d_table); if (b->d_mult) (void)hipFree(b->d_mult);
-  for (niels29* t : b->d_tab8) if (t) (void)hipFree(t);
+  lasso_ctx* o = c == b->owner ? c : nullptr;   // the tables' bytes are accounted to the context that built them; a caller that passes another context (or NULL) only loses the bookkeeping
+  if (b->d_table) (void)dfree(o, b->d_table); if (b->d_mult) (void)dfree(o, b->d_mult);
+  for (niels29* t : b->d_tab8) if (t) (void)dfree(o, t);
   delete b;
 }
 // the byte-multiple table of window w8 (k_precompute_tab8), built the first time a commitment asks for it: 255 * n * 112 bytes (117 MB for n = 4096).
@@ -1062,10 +1097,10 @@ static const niels29* ensure_tab8(lasso_ctx* c, const lasso_bases* cb, uint32_t 
   if (b->d_tab8[w8]) return b->d_tab8[w8];
   if (b->tab8_failed) return nullptr;
   niels29* t = nullptr;
-  if (hipMalloc((void**)&t, (size_t)MSM8_MULTS * b->n * sizeof(niels29)) != hipSuccess) { (void)hipGetLastError(); b->tab8_failed = true; return nullptr; }
+  if (dmalloc(b->owner, (void**)&t, (size_t)MSM8_MULTS * b->n * sizeof(niels29)) != hipSuccess) { (void)hipGetLastError(); b->tab8_failed = true; return nullptr; }
   hipLaunchKernelGGL(k_precompute_tab8, dim3((unsigned)((b->n + 63) / 64)), dim3(64), 0, c->stream, (const niels29*)b->d_table, b->n, w8, t);
   // one-time build (~3 ms): waited for, so that another context sharing this bases object can never see the pointer before the table is complete
-  if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(t); b->tab8_failed = true; return nullptr; }
+  if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { (void)hipGetLastError(); (void)dfree(b->owner, t); b->tab8_failed = true; return nullptr; }
   b->d_tab8[w8] = t;
   return t;
 }
@@ -1120,7 +1155,7 @@ static size_t msm_pts_bytes(size_t rows, size_t n_cols) {
 static int32_t run_msm_direct(lasso_ctx* c, const uint8_t* d_scal, size_t row_stride, size_t rows, size_t n_cols, const MsmColMap& cm, const lasso_bases* b, uint8_t* scratch_after, lasso_point* out,
                               int mode = 0, const lasso_fr* scale = nullptr, const lasso_fr* tail = nullptr, uint32_t sstride = 1, uint32_t soffset = 0) {
   uint32_t ipc = 0; const size_t K = msm_direct_chunks(rows, n_cols, &ipc);
-  const uint32_t seq = ++c->seq;
+  const uint32_t seq = next_seq(c);
   {
     ProfScope ps(c, LASSO_K_MSM_DIRECT, (double)rows * n_cols * 32, msm_ref_adds(rows, n_cols, FR_MODULUS_BITS), false, (double)rows * n_cols * MSM_WINDOWS);
     const fr_t z = fr_zero();
@@ -1145,7 +1180,7 @@ static int32_t run_msm(lasso_ctx* c, const uint8_t* d_scal, uint32_t bps, uint32
   pt29* d_partial = (pt29*)scratch_after;
   const bool small = rows <= MSM_SMALL_ROWS && !out_compressed;
   ed_point* d_final = small ? (ed_point*)c->d_small : (ed_point*)(((uintptr_t)(d_partial + rows * K) + 15) & ~(uintptr_t)15);
-  const uint32_t seq = small ? ++c->seq : 0;
+  const uint32_t seq = small ? next_seq(c) : 0;
   // many rows of small scalars (<= 16 bits): one table entry per non-zero byte (k_msm_rows8) instead of nibble buckets
   const niels29* t8[2] = {nullptr, nullptr};
   const uint32_t W8 = (W + 1) / 2;
@@ -1298,7 +1333,7 @@ static int32_t bullet_round_fused(lasso_ctx* c, const lasso_bases* b, size_t n, 
   size_t ipc_ = (total + kmax - 1) / kmax; ipc_ = (ipc_ + 63) / 64 * 64; if (ipc_ < 256) ipc_ = 256; if (ipc_ > 8192) ipc_ = 8192;
   const uint32_t ipc = (uint32_t)ipc_; const size_t K = (total + ipc_ - 1) / ipc_;
   int32_t rc = ensure_scratch(c, 2 * (K + 1) * sizeof(pt29) + 512); if (rc) return rc;
-  const uint32_t seq = ++c->seq;
+  const uint32_t seq = next_seq(c);
   {
     const size_t row = n_loc / 2 + 2;
     ProfScope ps(c, LASSO_K_MSM_DIRECT, 2.0 * row * 32 + (fold ? 96.0 * 2 * nk : 64.0 * nk), msm_ref_adds(2, row, FR_MODULUS_BITS), false, 2.0 * row * MSM_WINDOWS);

@@ -98,12 +98,19 @@ struct Comm {
 class Dev {
   mutable std::multimap<size_t, void*> pool_;
   mutable std::map<void*, size_t> live_;
+  mutable size_t in_use_ = 0, in_use_peak_ = 0;   // bytes the prover holds (live_), and their high-water mark: what a pool-free allocator would need
   int device_ = 0;
   mutable lasso_ctx* side_ = nullptr;
 
  public:
   lasso_ctx* ctx = nullptr;
   Comm comm;
+  // Capacity mode (slab mode's purpose): a released buffer of at least kCapacityMin bytes goes back to the driver at once instead of into the
+  // size-keyed pool, so the device high-water mark is the prover's LIVE peak, not the sum of every size it ever used.  Costs a hipFree (a device
+  // synchronisation) and a hipMalloc per large buffer and proof — time, which is not what this mode is for.  LASSO_CAPACITY=1/0 forces it on / off;
+  // lasso_host_set_capacity sets it per host; default: off.
+  bool capacity = [] { const char* e = getenv("LASSO_CAPACITY"); return e && e[0] == '1'; }();
+  static constexpr size_t kCapacityMin = (size_t)1 << 24;
   explicit Dev(int device) : device_(device) {
     if (lasso_ctx_create(device, &ctx) != 0) throw Error(std::string("lasso_ctx_create: ") + lasso_last_error(nullptr));
     const char* e = getenv("LASSO_SIDE_STREAM");
@@ -124,13 +131,33 @@ class Dev {
     auto it = pool_.find(bytes);
     void* p = nullptr;
     if (it != pool_.end()) { p = it->second; pool_.erase(it); }
-    else chk(lasso_alloc(ctx, bytes, &p), "lasso_alloc");
-    live_[p] = bytes; return p;
+    else {
+      int32_t rc = lasso_alloc(ctx, bytes, &p);
+      if (rc == LASSO_ERR_OOM && !pool_.empty()) { trim(); rc = lasso_alloc(ctx, bytes, &p); }   // the pool holds memory nobody uses: give it back before giving up
+      chk(rc, "lasso_alloc");
+    }
+    live_[p] = bytes; in_use_ += bytes; if (in_use_ > in_use_peak_) in_use_peak_ = in_use_;
+    return p;
   }
   lasso_fr* alloc_fr(size_t n) const { return (lasso_fr*)alloc_bytes(n * sizeof(lasso_fr)); }
   uint32_t* alloc_u32(size_t n) const { return (uint32_t*)alloc_bytes(n * 4); }
   // stream-ordered reuse: every kernel of this context runs on one stream, so a recycled buffer cannot be overtaken
-  void free(void* p) const { if (!p) return; auto it = live_.find(p); if (it == live_.end()) return; pool_.emplace(it->second, p); live_.erase(it); }
+  void free(void* p) const {
+    if (!p) return; auto it = live_.find(p); if (it == live_.end()) return;
+    const size_t bytes = it->second; live_.erase(it); in_use_ -= bytes;
+    if (capacity && bytes >= kCapacityMin) { (void)lasso_free(ctx, p); return; }   // lasso_free synchronises the stream first: nothing in flight reads it
+    pool_.emplace(bytes, p);
+  }
+  // hand every pooled buffer back to the driver
+  void trim() const { for (auto& kv : pool_) (void)lasso_free(ctx, kv.second); pool_.clear(); }
+  // device bytes held through this host's contexts now / at most (lasso_mem_stats of the main and the side context), and what the prover itself held at most
+  void mem_stats(uint64_t* live, uint64_t* peak, uint64_t* in_use_peak, bool reset) const {
+    uint64_t l = 0, p = 0, l2 = 0, p2 = 0;
+    chk(lasso_mem_stats(ctx, &l, &p, reset ? 1 : 0), "lasso_mem_stats");
+    if (side_) chk_side(lasso_mem_stats(side_, &l2, &p2, reset ? 1 : 0), "lasso_mem_stats");
+    if (live) *live = l + l2; if (peak) *peak = p + p2; if (in_use_peak) *in_use_peak = in_use_peak_;
+    if (reset) in_use_peak_ = in_use_;
+  }
 };
 // owning device buffer of field elements
 struct DBuf {

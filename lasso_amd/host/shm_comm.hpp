@@ -21,6 +21,8 @@
 #include <string>
 #include <stdexcept>
 #include <thread>
+#include <cerrno>
+#include <csignal>
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -29,7 +31,7 @@
 namespace lasso {
 
 class ShmComm {
-  struct alignas(64) Header { std::atomic<uint32_t> magic; uint32_t world; uint64_t slot_bytes; std::atomic<uint32_t> attached; std::atomic<uint32_t> blob_ready; uint8_t blob[256]; };
+  struct alignas(64) Header { std::atomic<uint32_t> magic; uint32_t world; uint64_t slot_bytes; std::atomic<uint32_t> attached; std::atomic<uint32_t> blob_ready; uint32_t creator_pid; uint8_t blob[256]; };
   struct alignas(64) SeqLine { std::atomic<uint64_t> seq; uint8_t pad[56]; };
   static constexpr uint32_t MAGIC = 0x4c53484du;   // "LSHM"
   uint8_t* base_ = nullptr; size_t map_bytes_ = 0; std::string name_;
@@ -48,44 +50,44 @@ class ShmComm {
   int world() const { return world_; }
   // Every rank calls this with the same name / world / slot_bytes.  Rank 0 creates and sizes the segment; the others attach (retrying until it exists);
   // once all have attached rank 0 unlinks the name, so nothing is left behind in /dev/shm whatever happens later.
+  // A segment under the same name that an EARLIER run left behind (it died before rank 0's post-attach unlink) must never be joined.  A peer recognises one by
+  // any of: a world / slot size other than this run's, a creator process that no longer exists (rank 0 records its pid; the ranks of one node share a pid
+  // namespace), or an attach count that is already full.  It then drops the mapping and opens the name again until rank 0 of THIS run has replaced it (rank 0
+  // unlinks and re-creates with O_EXCL) or the time-out expires.
   ShmComm(const std::string& name, int rank, int world, size_t slot_bytes = (size_t)1 << 20) : name_(name), rank_(rank), world_(world), slot_bytes_((slot_bytes + 63) & ~(size_t)63) {
     if (world < 1 || rank < 0 || rank >= world || name.empty() || name[0] != '/') throw std::runtime_error("ShmComm: bad arguments");
     map_bytes_ = 4096 + (size_t)world * rank_stride();
     const double t0 = now();
-    int fd = -1;
+    auto map_fd = [&](int fd) { void* p = mmap(nullptr, map_bytes_, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0); close(fd); if (p == MAP_FAILED) throw std::runtime_error("ShmComm: mmap failed"); base_ = (uint8_t*)p; };
     if (rank == 0) {
       shm_unlink(name.c_str());   // a stale segment of a crashed run
-      fd = shm_open(name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+      int fd = shm_open(name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
       if (fd < 0 || ftruncate(fd, (off_t)map_bytes_) != 0) { if (fd >= 0) close(fd); throw std::runtime_error("ShmComm: cannot create " + name); }
+      map_fd(fd);
+      hdr()->world = (uint32_t)world; hdr()->slot_bytes = slot_bytes_; hdr()->creator_pid = (uint32_t)getpid();
+      hdr()->magic.store(MAGIC, std::memory_order_release);   // fresh pages are zero: all sequence words start at 0
+      if (hdr()->attached.fetch_add(1, std::memory_order_acq_rel) != 0) throw std::runtime_error("ShmComm: freshly created segment is already attached");
     } else {
+      const char* why = "rank 0 never created the segment";
       for (;;) {
-        fd = shm_open(name.c_str(), O_RDWR, 0600);
-        if (fd >= 0) { struct stat st; if (fstat(fd, &st) == 0 && (size_t)st.st_size >= map_bytes_) break; close(fd); fd = -1; }
-        if (now() - t0 > timeout_s_) throw std::runtime_error("ShmComm: timed out waiting for rank 0 to create " + name);
+        if (now() - t0 > timeout_s_) throw std::runtime_error("ShmComm: timed out attaching to " + name + " (" + why + ")");
+        int fd = shm_open(name.c_str(), O_RDWR, 0600);
+        struct stat st;
+        if (fd < 0 || fstat(fd, &st) != 0 || (size_t)st.st_size < sizeof(Header)) { if (fd >= 0) close(fd); std::this_thread::sleep_for(std::chrono::milliseconds(2)); continue; }
+        if ((size_t)st.st_size != map_bytes_) { close(fd); why = "only a segment of another size (an earlier run's) exists"; std::this_thread::sleep_for(std::chrono::milliseconds(2)); continue; }
+        map_fd(fd);
+        bool stale = false;
+        const double t1 = now();
+        while (hdr()->magic.load(std::memory_order_acquire) != MAGIC) {   // rank 0 sets it right after sizing the segment; a creator that died in between never will
+          if (now() - t1 > 2.0) { stale = true; why = "segment never initialised"; break; }
+          std::this_thread::yield();
+        }
+        if (!stale && (hdr()->world != (uint32_t)world || hdr()->slot_bytes != slot_bytes_)) { stale = true; why = "only a segment of another world / slot size (an earlier run's) exists"; }
+        if (!stale && (kill((pid_t)hdr()->creator_pid, 0) != 0 && errno == ESRCH)) { stale = true; why = "only a segment whose creator no longer exists (an earlier run's) exists"; }
+        if (!stale && hdr()->attached.fetch_add(1, std::memory_order_acq_rel) >= (uint32_t)world) { stale = true; why = "only a fully attached segment (an earlier run's) exists"; }
+        if (!stale) break;
+        munmap(base_, map_bytes_); base_ = nullptr;
         std::this_thread::sleep_for(std::chrono::milliseconds(2));
-      }
-    }
-   attach:
-    void* p = mmap(nullptr, map_bytes_, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-    close(fd);
-    if (p == MAP_FAILED) throw std::runtime_error("ShmComm: mmap failed");
-    base_ = (uint8_t*)p;
-    if (rank == 0) { hdr()->world = (uint32_t)world; hdr()->slot_bytes = slot_bytes_; hdr()->magic.store(MAGIC, std::memory_order_release); }   // fresh pages are zero: all sequence words start at 0
-    while (hdr()->magic.load(std::memory_order_acquire) != MAGIC) { if (now() - t0 > timeout_s_) throw std::runtime_error("ShmComm: segment never initialised"); std::this_thread::yield(); }
-    if (hdr()->world != (uint32_t)world || hdr()->slot_bytes != slot_bytes_) throw std::runtime_error("ShmComm: ranks disagree on world size / slot size");
-    // A segment left behind by a run that died before rank 0's post-attach unlink still has MAGIC set and attached >= world: a rank that opened it before
-    // rank 0 of THIS run re-created the name would pass both barriers on the dead segment.  The attach count tells them apart: in a live segment every rank
-    // is counted once, so the value a new arrival sees is < world.  On a dead one: unmap and open the name again (rank 0 replaces it with O_EXCL).
-    if (hdr()->attached.fetch_add(1, std::memory_order_acq_rel) >= (uint32_t)world) {
-      munmap(base_, map_bytes_); base_ = nullptr;
-      if (rank == 0) throw std::runtime_error("ShmComm: freshly created segment is already fully attached");
-      for (;;) {
-        if (now() - t0 > timeout_s_) throw std::runtime_error("ShmComm: only a stale segment of an earlier run exists under " + name);
-        std::this_thread::sleep_for(std::chrono::milliseconds(2));
-        fd = shm_open(name.c_str(), O_RDWR, 0600);
-        if (fd < 0) continue;
-        struct stat st; if (fstat(fd, &st) == 0 && (size_t)st.st_size >= map_bytes_) goto attach;
-        close(fd);
       }
     }
     while (hdr()->attached.load(std::memory_order_acquire) < (uint32_t)world) { if (now() - t0 > timeout_s_) throw std::runtime_error("ShmComm: not every rank attached"); std::this_thread::yield(); }

@@ -31,6 +31,9 @@ def declare_prover(lib):
     lib.lasso_host_create.argtypes = [i32, C.POINTER(vp)]
     lib.lasso_host_destroy.argtypes = [vp]
     lib.lasso_host_ctx.argtypes = [vp]; lib.lasso_host_ctx.restype = vp
+    u64p = C.POINTER(C.c_uint64)
+    lib.lasso_host_mem_stats.argtypes = [vp, u64p, u64p, u64p, i32]
+    lib.lasso_host_set_capacity.argtypes = [vp, i32]
     lib.lasso_host_set_comm.argtypes = [vp, i32, i32, ALLGATHER_FN, vp]
     lib.lasso_host_set_comm_shm.argtypes = [vp, i32, i32, C.c_char_p]
     lib.lasso_host_gens_new.argtypes = [vp, C.c_char_p, sz, sz, sz, sz, C.POINTER(vp)]
@@ -137,7 +140,15 @@ class HostProver:
             self.lib.lasso_host_destroy(self.h)
             self.h = None
 
-
-
     def ctx(self):
         return self.lib.lasso_host_ctx(self.h)
+
+    def mem_stats(self, reset=False):
+        """device bytes held by this host now / at most, and the most the prover itself had in use (lasso_host_mem_stats)"""
+        live, peak, used = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self._chk(self.lib.lasso_host_mem_stats(self.h, C.byref(live), C.byref(peak), C.byref(used), 1 if reset else 0))
+        return {"live_bytes": live.value, "peak_bytes": peak.value, "prover_peak_bytes": used.value}
+
+    def set_capacity(self, on=True):
+        """capacity mode (lasso_host_set_capacity): large buffers go back to the driver on release; the per-rank high-water mark is the live peak"""
+        self._chk(self.lib.lasso_host_set_capacity(self.h, 1 if on else 0))

@@ -81,3 +81,35 @@ def test_concurrent_leg_reports_a_failed_proof_instead_of_hanging():
     assert not th.is_alive(), "the leg hung"
     assert "error" in box["out"] and "not delivered" in box["out"]["error"]
 
+
+
+def test_concurrent_sweep_checks_every_proof_against_its_sequential_bytes():
+    """bench.py's throughput sweep: streams in {2, 4, 8}, every proof of every stream compared with the bytes the same prover produced alone; a stream whose
+    concurrent proof differs is reported, and the best round is the headline of the leg."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_under_test2", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    from lasso_amd import _abi
+    made = []
+
+    class FakeProver:
+        flaky = False
+        def __init__(self, curve="curve25519"):
+            self.calls = 0; self.id = len(made); made.append(self)
+        def gen_indices(self, s, m, c): return np.zeros((s, c), dtype=np.uint64)
+        def gen_random_point(self, n): return np.zeros((n, 4), dtype=np.uint64)
+        def gens(self, c, s, alpha, log_m): return object()
+        def densify(self, idx, log_m): return object()
+        def prove(self, dense, gens, S, r):
+            self.calls += 1
+            import time as _t; _t.sleep(0.002)
+            return b"other" if (FakeProver.flaky and self.id == 3 and self.calls == 3) else b"proof%d" % self.id
+        def free(self, *a): pass
+        def close(self): pass
+    S = _abi.Strategy(_abi.KINDS["and"], 1, 8, 0)
+    out = bench.concurrent_leg(FakeProver, _abi, 8, 2, S, 1, 8, 6, kernel_ms_per_proof=1.0)
+    assert [x["streams"] for x in out["sweep"]] == [2, 4, 8] and out["all_proofs_identical_to_sequential"] is True
+    assert out["value"] == max(x["value"] for x in out["sweep"]) and out["device_serial_bound"]["lookups_per_s_if_kernels_never_overlap"] == 64 / 1e-3
+    made.clear(); FakeProver.flaky = True
+    out = bench.concurrent_leg(FakeProver, _abi, 4, 2, S, 1, 8, 6)
+    assert out["all_proofs_identical_to_sequential"] is False and sum(x["proofs_differing_from_sequential"] for x in out["sweep"]) == 1

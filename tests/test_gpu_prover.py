@@ -136,7 +136,9 @@ print("DIGEST", hashlib.sha256(comm + proof).hexdigest())
 
 
 @pytest.mark.parametrize("env", [{"LASSO_TAGGED_RESULTS": "0"}, {"LASSO_DIRECT_NX": "0"}, {"LASSO_TAGGED_RESULTS": "0", "LASSO_CUBIC_TAIL": "0", "LASSO_LINEAR_TAIL": "0"},
-                                 {"LASSO_EQ_INLINE": "0", "LASSO_SUMCHECK_U32": "0", "LASSO_MSM_FUSED": "0"}, {"LASSO_TAIL_Q": "256", "LASSO_LB_PIPELINE": "0"}])
+                                 {"LASSO_EQ_INLINE": "0", "LASSO_SUMCHECK_U32": "0", "LASSO_MSM_FUSED": "0"}, {"LASSO_TAIL_Q": "256", "LASSO_LB_PIPELINE": "0"},
+                                 {"LASSO_SEQ_START": "0xffefff9c"},     # the context's hand-off sequence numbers start 100 short of the end of an epoch: the proof crosses next_seq's restart
+                                 {"LASSO_CAPACITY": "1"}])
 def test_gpu_ab_switches_do_not_change_the_bytes(host, env):
     """The A/B switches the measurements in DESIGN.md rest on (flag protocol instead of tagged results, in-launch second stage, launch per round instead of the resident tails, ...)
     select other kernels / protocols for the same arithmetic: commitment and proof must be the bytes of the default configuration.  Each setting runs in its own process
@@ -274,6 +276,58 @@ def test_gpu_slab_proof_bit_exact(host, oracle, world, kind, c, log_m, log_r, lo
         assert orc.verify(proof_p, comm_p) == 1
     finally:
         orc.close()
+
+
+def run_slab_threads(lib, world, S, alpha, idx, r, shm_name=None, capacity=False, steps=1):
+    """ONE proof over `world` contexts of the one device (tests/cpp/slab_threads.cpp): (commitment, proof, info)"""
+    import ctypes as C
+    idx = np.ascontiguousarray(idx, dtype=np.uint64); r = np.ascontiguousarray(r, dtype=np.uint64)
+    comm = (C.c_uint8 * (1 << 23))(); proof = (C.c_uint8 * (1 << 23))(); cl = C.c_size_t(); pl = C.c_size_t(); nc = C.c_size_t(); nb = C.c_size_t(); err = C.create_string_buffer(512)
+    peak = (C.c_uint64 * world)(); used = (C.c_uint64 * world)(); ms = C.c_double()
+    rc = lib.slab_prove_threads_ex(world, C.byref(S), C.c_size_t(alpha), idx.ctypes.data_as(C.c_void_p), C.c_size_t(idx.shape[0]), r.ctypes.data_as(C.c_void_p), C.c_size_t(r.shape[0]),
+                                   shm_name.encode() if shm_name else None, 1 if capacity else 0, steps, comm, C.c_size_t(len(comm)), C.byref(cl), proof, C.c_size_t(len(proof)), C.byref(pl),
+                                   C.byref(nc), C.byref(nb), peak, used, C.byref(ms), err, C.c_size_t(512))
+    assert rc == 0, err.value.decode()
+    return bytes(comm[: cl.value]), bytes(proof[: pl.value]), {"peak_bytes_per_rank": list(peak), "prover_peak_bytes_per_rank": list(used), "ms_per_proof": ms.value}
+
+
+# BASELINE.json configs[3] (RangeCheck, C=4, 2^26 lookups — the configuration the north star shards over 4 GPUs) as ONE proof over P = 4 and P = 8 ranks, at FULL size, through the
+# transport an N-GPU run uses (lasso_host_set_comm_shm: the library's shared-memory exchange; RCCL declines when ranks share a device, so the partial row commitments take the
+# same route).  The box has one MI355X: the P ranks are P contexts on it (own stream, buffers, generator tables; ~75 GiB in total), each rank holding 1/P of every polynomial.
+# Commitment and proof must be the bytes the ORACLE produced for this instance (tests/golden/full_config_digests.json, re-derived by test_oracle_rederives_config3_digest).
+@pytest.mark.parametrize("world,capacity", [(4, False), (8, True)])
+def test_gpu_slab_config3_full_size_one_proof_over_P_ranks(host, world, capacity):
+    import hashlib, json, os
+    kind, c, log_m, log_r, log_s = "range", 4, 16, 40, 26
+    lib = _build_slab_hip()
+    s = 1 << log_s
+    idx = host.gen_indices(s, 1 << log_m, c); r = host.gen_random_point(log_s)
+    S = _abi.Strategy(_abi.KINDS[kind], c, log_m, log_r)
+    comm, proof, info = run_slab_threads(lib, world, S, c, idx, r, shm_name=f"/lasso_test_cfg3_{os.getpid()}_{world}", capacity=capacity, steps=2)
+    del idx
+    print(f"\n[slab] configs[3] over {world} ranks on one device (capacity mode {capacity}): {info['ms_per_proof']:.1f} ms per proof, peak bytes per rank {max(info['peak_bytes_per_rank']) / 2**30:.2f} GiB "
+          f"(prover in use at most {max(info['prover_peak_bytes_per_rank']) / 2**30:.2f} GiB)")
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "full_config_digests.json")) as f:
+        gold = json.load(f)[f"{kind},{c},{log_m},{log_r},{log_s}"]["oracle"]
+    assert hashlib.sha256(comm).hexdigest() == gold["commitment_sha256"]
+    assert hashlib.sha256(proof).hexdigest() == gold["proof_sha256"]
+
+
+def test_oracle_rederives_config3_digest(oracle):
+    """The committed digests of configs[3] (tests/golden/full_config_digests.json) are the ORACLE's: re-derive them in-tree — the oracle prover at RangeCheck C=4 2^26 on one thread
+    per physical core (~150 s on the GPU box's 128 cores) — so that the constant the GPU is held to at 2^26 cannot drift from the oracle (src/e2e_test.rs:17-62 is the reference's
+    own acceptance shape).  Marked gpu because only the GPU box has the cores and the memory; it makes no device call."""
+    import hashlib, json, os
+    from proverutil import oracle_harness_proof
+    kind, c, log_m, log_r, log_s = "range", 4, 16, 40, 26
+    if (os.cpu_count() or 1) < 32:
+        pytest.skip("needs the GPU box's host cores (the oracle proves 2^26 lookups)")
+    o_comm, o_proof, tm = oracle_harness_proof(oracle, _abi.KINDS[kind], c, log_m, log_r, log_s)
+    print(f"\n[oracle] configs[3]: {tm['threads']} threads, densify {tm['densify_s']:.1f}s commit {tm['commit_s']:.1f}s prove {tm['prove_s']:.1f}s")
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "full_config_digests.json")) as f:
+        gold = json.load(f)[f"{kind},{c},{log_m},{log_r},{log_s}"]["oracle"]
+    assert hashlib.sha256(o_comm).hexdigest() == gold["commitment_sha256"]
+    assert hashlib.sha256(o_proof).hexdigest() == gold["proof_sha256"]
 
 
 @pytest.mark.parametrize("k,ell,special", [(1, 1, {}), (2, 3, {}), (3, 5, {0: 0}), (2, 5, {2: 0}), (2, 5, {1: 1}), (1, 6, {0: 0, 1: 1, 2: 0, 5: 1}), (2, 8, {7: 0}), (33, 2, {1: 0}),

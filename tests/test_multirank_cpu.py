@@ -151,11 +151,13 @@ def test_one_proof_over_ranks_native_shm_exchange(tmp_path, oracle, world, kind,
     assert len(digests) == 1
 
 
-def test_shm_exchange_survives_a_stale_segment(tmp_path):
-    """a segment left behind by a crashed run (magic set, fully attached) must not capture a rank of the next run: tests/cpp/test_shm_stale.cpp starts rank 1 against
-    the stale segment and rank 0 150 ms later; both must end up in the fresh segment and complete an all-gather."""
+@pytest.mark.parametrize("mode", ["full", "partial", "world", "size"])
+def test_shm_exchange_survives_a_stale_segment(tmp_path, mode):
+    """a segment left behind by a crashed run must not capture a rank of the next run — whether it is fully attached, was abandoned before every rank attached
+    (its creator's pid is gone), or belongs to a run of another world / slot size: tests/cpp/test_shm_stale.cpp starts rank 1 against the stale segment and rank 0 150 ms later;
+    both must end up in the fresh segment and complete an all-gather."""
     import subprocess
     exe = str(tmp_path / "test_shm_stale")
     subprocess.check_call(["g++", "-O1", "-std=c++17", "-pthread", "-o", exe, os.path.join(ROOT, "tests", "cpp", "test_shm_stale.cpp"), "-lrt"])
-    res = subprocess.run([exe, f"/lasso_test_stale_{os.getpid()}"], capture_output=True, text=True, timeout=60)
+    res = subprocess.run([exe, f"/lasso_test_stale_{os.getpid()}_{mode}", mode], capture_output=True, text=True, timeout=60)
     assert res.returncode == 0 and "OK" in res.stdout, res.stdout + res.stderr

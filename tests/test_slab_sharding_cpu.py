@@ -99,3 +99,26 @@ def _slab_case(slab, host, oracle, world, kind, c, log_m, log_r, lookups):
         assert comm_p == orc.commit() and proof_p == orc.prove() and orc.verify(proof_p, comm_p) == 1
     finally:
         orc.close()
+
+
+@pytest.mark.parametrize("world,capacity", [(2, False), (4, True)])
+def test_slab_threads_over_the_shm_exchange_and_capacity_mode(slab, host, world, capacity):
+    """The harness the full-size GPU test uses (slab_prove_threads_ex: lasso_host_set_comm_shm between the ranks of one process, lasso_host_set_capacity, repeated proofs): the same
+    bytes as the single-rank prover, every repeat identical."""
+    kind, c, log_m, log_r, lookups = "xor", 2, 6, 0, 100
+    s = 1 << (lookups - 1).bit_length()
+    idx = np.ascontiguousarray(np.random.default_rng(world).integers(0, 1 << log_m, size=(lookups, c), dtype=np.uint64))
+    r = np.ascontiguousarray(host.gen_random_point(s.bit_length() - 1), dtype=np.uint64)
+    S = _abi.Strategy(_abi.KINDS[kind], c, log_m, log_r)
+    comm = (C.c_uint8 * (1 << 20))(); proof = (C.c_uint8 * (1 << 22))(); cl = C.c_size_t(); pl = C.c_size_t(); nc = C.c_size_t(); nb = C.c_size_t(); err = C.create_string_buffer(512)
+    peak = (C.c_uint64 * world)(); used = (C.c_uint64 * world)(); ms = C.c_double()
+    rc = slab.slab_prove_threads_ex(world, C.byref(S), C.c_size_t(c), idx.ctypes.data_as(C.c_void_p), C.c_size_t(lookups), r.ctypes.data_as(C.c_void_p), C.c_size_t(r.shape[0]),
+                                    f"/lasso_test_slab_ex_{os.getpid()}_{world}".encode(), 1 if capacity else 0, 3, comm, C.c_size_t(len(comm)), C.byref(cl), proof, C.c_size_t(len(proof)), C.byref(pl),
+                                    C.byref(nc), C.byref(nb), peak, used, C.byref(ms), err, C.c_size_t(512))
+    assert rc == 0, err.value.decode()
+    gens = host.gens(c, s, c, log_m); dense = host.densify(idx, log_m)
+    try:
+        assert bytes(comm[: cl.value]) == host.commit(dense, gens) and bytes(proof[: pl.value]) == host.prove(dense, gens, S, r)
+    finally:
+        host.free(dense, gens)
+    assert all(u > 0 for u in used)     # the prover's own accounting (the mock does not track device bytes)
