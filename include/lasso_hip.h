@@ -198,7 +198,9 @@ int32_t lasso_lt_prescale(lasso_ctx* ctx, const lasso_strategy* s, const lasso_f
 int32_t lasso_sumcheck_combine_round_lt_scaled(lasso_ctx* ctx, const lasso_strategy* s, const lasso_fr* const* d_polys, const lasso_fr* d_eq, size_t n, uint32_t degree, lasso_fr* out);
 /* The FIRST round of that sumcheck (before any bind) from the lookup polynomials' INTEGER values, E_k[i] = F::from(d_u32[k][i]) with EVERY ENTRY 0 OR 1 — the LT and EQ subtables
  * hold bits (lt.rs:17-44).  All lines are then small integers at the evaluation points and the Horner walk is exact 128-bit integer arithmetic; same out[x] as
- * lasso_sumcheck_combine_round on the lifted arrays.  Round 0 is half of the sumcheck's work. */
+ * lasso_sumcheck_combine_round on the lifted arrays.  Round 0 is half of the sumcheck's work.
+ * Enforced, not assumed: the kernel checks every entry it reads and the call returns LASSO_ERR_INVALID when one exceeds 1 (out is then meaningless); C <= 16 (with bits the
+ * walk's intermediate values stay below 17 (17^16 - 1) / 16 < 2^67, inside the three 29-bit limbs the eq weighting multiplies by; a larger C is refused). */
 int32_t lasso_sumcheck_combine_round_lt_u32(lasso_ctx* ctx, const lasso_strategy* s, const uint32_t* const* d_u32, const lasso_fr* d_eq, size_t n, uint32_t degree, lasso_fr* out);
 /* The same round in EQ-WEIGHTED form for the LINEAR strategies (AND / OR / XOR / RangeCheck: g = sum_k w_k E_k, src/subtables/and.rs:45-53) — what the
  * prover calls.  The eq polynomial is factored exactly as in lasso_sumcheck_cubic_eqw_round (prefix of the original table d_E + host scalars), and by

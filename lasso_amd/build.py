@@ -39,6 +39,22 @@ def build_device(force=False, verbose=False, curve="curve25519"):
     return target
 
 
+def host_march_flags():
+    """-march=x86-64-v3 (AVX2, BMI1/2: what every x86 host a gfx950 ships in has) makes the transcript's Keccak-f 10-18 % faster — but a library built with it dies with SIGILL,
+    and no diagnostic, on a host or VM without those extensions.  The flag is therefore used only when the build host's CPU reports them (LASSO_HOST_MARCH overrides:
+    a -march value, or "none"), the library records the choice (-DLASSO_HOST_V3), and lasso_host_create checks the CPU it is LOADED on before anything else runs."""
+    ov = os.environ.get("LASSO_HOST_MARCH")
+    if ov:
+        return [] if ov == "none" else [f"-march={ov}"] + (["-DLASSO_HOST_V3"] if ov == "x86-64-v3" else [])
+    try:
+        flags = set(next(l for l in open("/proc/cpuinfo") if l.startswith("flags")).split())
+    except Exception:
+        flags = set()
+    if {"avx2", "bmi1", "bmi2", "fma", "movbe"} <= flags:
+        return ["-march=x86-64-v3", "-DLASSO_HOST_V3"]
+    return []
+
+
 def build_host(force=False, verbose=False, curve="curve25519"):
     """liblasso_prover.so: the C++ mirror of the reference's Rust prover, linked against liblasso_hip.so (or the _bn254 pair)."""
     suffix, flags = CURVES[curve]
@@ -52,7 +68,7 @@ def build_host(force=False, verbose=False, curve="curve25519"):
         # -fno-gnu-unique / -Bsymbolic: the two curve builds share C++ names and may be loaded side by side; nothing may be unified across them
         # -march=x86-64-v3 (AVX2, BMI1/2: every x86 host a gfx950 ships in): the transcript's Keccak-f is 10-18 % faster with andn / rorx and three-operand forms
         # (tools: 0.39 -> 0.32 us per permutation on the build container), and ~1.5 ms of a 19 ms proof is host Keccak
-        cmd = ["g++", "-O2", "-march=x86-64-v3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas", "-fno-gnu-unique", "-Wl,-Bsymbolic", *flags, "-o", target,
+        cmd = ["g++", "-O2", *host_march_flags(), "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas", "-fno-gnu-unique", "-Wl,-Bsymbolic", *flags, "-o", target,
                os.path.join(hdir, "prover_capi.cpp"), "-L" + HERE, f"-llasso_hip{suffix}", "-Wl,-rpath,$ORIGIN"]
         if verbose:
             print(" ".join(cmd))

@@ -1,7 +1,9 @@
 // liblasso_hip.so — implementation of include/lasso_hip.h for MI355X (gfx950).
 // One context = one device + one HIP stream + scratch.  See the header for the contract of each entry point.
 #include <hip/hip_runtime.h>
-#include <emmintrin.h>
+#if defined(__SSE2__)
+#include <emmintrin.h>   // 16-byte single-copy stores / loads of the hand-off chunks; other hosts take the per-word fallbacks (the check word covers tearing)
+#endif
 #include <mutex>
 #include <string>
 #include <unordered_map>
@@ -355,13 +357,23 @@ int32_t lasso_points_reduce_compress(lasso_ctx* c, const void* d_parts, uint32_t
 // that arrived in pieces
 static inline void mail_chunks(uint32_t* mail, uint32_t tag, const uint32_t w[8]) {
   const uint32_t chk = (w[0] ^ w[1] ^ w[2] ^ w[3] ^ w[4] ^ w[5] ^ w[6] ^ w[7]) + tag * 0x9E3779B9u;
+#if defined(__SSE2__)
   _mm_store_si128((__m128i*)(mail + 0), _mm_set_epi32((int)w[2], (int)w[1], (int)w[0], (int)tag));
   _mm_store_si128((__m128i*)(mail + 4), _mm_set_epi32((int)w[5], (int)w[4], (int)w[3], (int)tag));
   _mm_store_si128((__m128i*)(mail + 8), _mm_set_epi32((int)chk, (int)w[7], (int)w[6], (int)tag));
+#else   // no 16-byte store: data words first, the tags last (a reader that sees all three tags with a matching check word has the whole message)
+  const uint32_t m[12] = {tag, w[0], w[1], w[2], tag, w[3], w[4], w[5], tag, w[6], w[7], chk};
+  for (int k : {1, 2, 3, 5, 6, 7, 9, 10, 11}) __atomic_store_n(mail + k, m[k], __ATOMIC_RELAXED);
+  for (int k : {0, 4, 8}) __atomic_store_n(mail + k, m[k], __ATOMIC_RELEASE);
+#endif
 }
 static inline void post_mail(lasso_ctx* c, uint32_t tag, const uint32_t w[8]) {
   mail_chunks(c->mail_h, tag, w);
+#if defined(__SSE2__)
   _mm_sfence();   // release: the chunks are globally visible before anything the host does next
+#else
+  __atomic_thread_fence(__ATOMIC_SEQ_CST);
+#endif
 }
 int32_t lasso_ctx_create(int32_t device, lasso_ctx** out) { return lasso_ctx_create_background(device, 0, out); }
 // background != 0: the context's stream gets the LOWEST priority the device offers (the prover's side context: bulk work that must not delay
@@ -840,19 +852,22 @@ int32_t lasso_sumcheck_combine_round_lt_scaled(lasso_ctx* c, const lasso_strateg
 // the FIRST round of the LT sumcheck from the polynomials' integer values (entries 0 / 1: the LT and EQ subtables hold bits): exact integer Horner walk, one field product per point for the eq weight
 int32_t lasso_sumcheck_combine_round_lt_u32(lasso_ctx* c, const lasso_strategy* s, const uint32_t* const* d_u32, const lasso_fr* d_eq, size_t n, uint32_t degree, lasso_fr* out) {
   StrategyDev S; WeightTable W; int32_t rc = make_strategy(c, s, S, W); if (rc) return rc;
-  REQUIRE(c, s->kind == LASSO_LT && d_u32 && d_eq && out && n >= 2 && (n & (n - 1)) == 0 && degree == s->c + 1);
+  REQUIRE(c, s->kind == LASSO_LT && d_u32 && d_eq && out && n >= 2 && (n & (n - 1)) == 0 && degree == s->c + 1 && s->c <= 16 && !c->defer_next);   // C <= 16: |t| < 2^67 fits the three-limb form (header)
   PtrTableU32 P; for (uint32_t i = 0; i < S.alpha; i++) { REQUIRE(c, d_u32[i]); P.p[i] = d_u32[i]; }
   const size_t half = n / 2; const unsigned nx = grid_for(half, 1024); const uint32_t K = degree + 1;
   rc = ensure_scratch(c, (size_t)nx * K * sizeof(fr_t)); if (rc) return rc;
   rc = ensure_small(c, K); if (rc) return rc;
   {
     ProfScope ps(c, LASSO_K_COMBINE, 32.0 * n * (S.alpha + 1.0));
-#define LAUNCH_COMBINE_U32(A_, D_, T_) hipLaunchKernelGGL((k_combine_round_lt_u32<A_, D_, T_>), dim3(nx), dim3(LASSO_BLOCK), 0, c->stream, S, P, (const fr_t*)d_eq, half, degree, (fr_t*)c->d_scratch)
+#define LAUNCH_COMBINE_U32(A_, D_, T_) hipLaunchKernelGGL((k_combine_round_lt_u32<A_, D_, T_>), dim3(nx), dim3(LASSO_BLOCK), 0, c->stream, S, P, (const fr_t*)d_eq, half, degree, (fr_t*)c->d_scratch, c->d_flag + 16)
+    __atomic_store_n(c->h_flag + 16, 0u, __ATOMIC_RELEASE);   // "an entry was not 0 / 1": a host-mapped word the kernel sets, read behind the result's flag
     DISPATCH_LT(S.alpha, LAUNCH_COMBINE_U32);
     hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(LASSO_BLOCK), 0, c->stream, (const fr_t*)c->d_scratch, nx, K, c->d_small);
   }
   HIPCHK(c, hipGetLastError());
-  return fetch_small(c, K, out);
+  rc = fetch_small(c, K, out); if (rc) return rc;
+  if (__atomic_load_n(c->h_flag + 16, __ATOMIC_ACQUIRE) != 0) return fail(c, LASSO_ERR_INVALID, "lasso_sumcheck_combine_round_lt_u32: an entry is neither 0 nor 1 (the integer round is exact only for the LT / EQ subtables' bits)");
+  return 0;
 }
 int32_t lasso_lt_prescale(lasso_ctx* c, const lasso_strategy* s, const lasso_fr* const* d_src, lasso_fr* const* d_polys, size_t n) {
   StrategyDev S; WeightTable W; int32_t rc = make_strategy(c, s, S, W); if (rc) return rc;

@@ -951,8 +951,10 @@ __device__ __forceinline__ fr29 lt_eq_times_r2(const fr_t& e) {
   return fr29_mul(fr29_unpack_s(e), fr29_r2s());
 }
 template <int A, int D, int T>
-__global__ void __launch_bounds__(LASSO_BLOCK) k_combine_round_lt_u32(StrategyDev S, PtrTableU32 polys, const fr_t* __restrict__ eq, size_t half, uint32_t degree, fr_t* __restrict__ partials) {
+__global__ void __launch_bounds__(LASSO_BLOCK) k_combine_round_lt_u32(StrategyDev S, PtrTableU32 polys, const fr_t* __restrict__ eq, size_t half, uint32_t degree, fr_t* __restrict__ partials,
+                                                                      uint32_t* __restrict__ bad) {
   constexpr int PPG = (D + 1 + T - 1) / T;
+  uint32_t seen = 0;   // OR of every entry read: the integer walk is only exact (and only fits its containers) for entries 0 / 1 — anything else is reported, not computed
   constexpr uint32_t SLOTS = LASSO_BLOCK / T;
   static_assert(PPG <= 6, "at most 6 points per lane");
   __shared__ RedScratch R;
@@ -966,13 +968,15 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_combine_round_lt_u32(StrategyDe
     __int128 t[PPG];
     {
       const uint32_t* __restrict__ pl = polys.p[2 * (S.c - 1)];
-      const int32_t lo = (int32_t)pl[i], d = (int32_t)pl[i + half] - lo;
+      const uint32_t u0 = pl[i], u1 = pl[i + half]; seen |= u0 | u1 | polys.p[2 * (S.c - 1) + 1][i] | polys.p[2 * (S.c - 1) + 1][i + half];   // the last EQ memory never enters the walk: checked all the same
+      const int32_t lo = (int32_t)u0, d = (int32_t)u1 - lo;
 #pragma unroll
       for (int k = 0; k < PPG; k++) t[k] = lo + (int32_t)(x0 + k) * d;
     }
     for (uint32_t m = S.c - 1; m-- > 0;) {
       const uint32_t* __restrict__ pl = polys.p[2 * m]; const uint32_t* __restrict__ pe = polys.p[2 * m + 1];
-      const int32_t llo = (int32_t)pl[i], ld = (int32_t)pl[i + half] - llo, elo = (int32_t)pe[i], ed = (int32_t)pe[i + half] - elo;
+      const uint32_t a0 = pl[i], a1 = pl[i + half], b0 = pe[i], b1 = pe[i + half]; seen |= a0 | a1 | b0 | b1;
+      const int32_t llo = (int32_t)a0, ld = (int32_t)a1 - llo, elo = (int32_t)b0, ed = (int32_t)b1 - elo;
 #pragma unroll
       for (int k = 0; k < PPG; k++) { const int32_t x = (int32_t)(x0 + k); t[k] = (__int128)(llo + x * ld) + (__int128)(elo + x * ed) * t[k]; }
     }
@@ -992,6 +996,7 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_combine_round_lt_u32(StrategyDe
       for (int k = 0; k < PPG; k++) sum[k] = fr29_mul(sum[k], fr29_one_s());
     }
   }
+  if (seen > 1u) *bad = 1u;   // host-mapped word, read by the host behind the result's flag (lasso_sumcheck_combine_round_lt_u32)
 #pragma unroll
   for (int g = 0; g < T; g++) {
 #pragma unroll

@@ -143,7 +143,8 @@ class Dev {
   uint32_t* alloc_u32(size_t n) const { return (uint32_t*)alloc_bytes(n * 4); }
   // stream-ordered reuse: every kernel of this context runs on one stream, so a recycled buffer cannot be overtaken
   void free(void* p) const {
-    if (!p) return; auto it = live_.find(p); if (it == live_.end()) return;
+    if (!p) return;
+    auto it = live_.find(p); if (it == live_.end()) return;
     const size_t bytes = it->second; live_.erase(it); in_use_ -= bytes;
     if (capacity && bytes >= kCapacityMin) { (void)lasso_free(ctx, p); return; }   // lasso_free synchronises the stream first: nothing in flight reads it
     pool_.emplace(bytes, p);
@@ -155,7 +156,9 @@ class Dev {
     uint64_t l = 0, p = 0, l2 = 0, p2 = 0;
     chk(lasso_mem_stats(ctx, &l, &p, reset ? 1 : 0), "lasso_mem_stats");
     if (side_) chk_side(lasso_mem_stats(side_, &l2, &p2, reset ? 1 : 0), "lasso_mem_stats");
-    if (live) *live = l + l2; if (peak) *peak = p + p2; if (in_use_peak) *in_use_peak = in_use_peak_;
+    if (live) *live = l + l2;
+    if (peak) *peak = p + p2;
+    if (in_use_peak) *in_use_peak = in_use_peak_;
     if (reset) in_use_peak_ = in_use_;
   }
 };

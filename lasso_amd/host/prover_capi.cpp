@@ -34,7 +34,17 @@ static int32_t emit(const std::vector<uint8_t>& b, uint8_t* out, size_t cap, siz
 
 extern "C" {
 const char* lasso_host_last_error(void) { return g_err.c_str(); }
-int32_t lasso_host_create(int32_t device, lasso_host** out) { GUARD(*out = new lasso_host(device); return 0;) }
+// The library may have been built with -march=x86-64-v3 (lasso_amd/build.py host_march_flags): refuse, with a message, to run on a CPU without those extensions — the alternative
+// is a SIGILL somewhere inside the first Keccak permutation.  This function itself must not need them: it is compiled for the baseline ISA.
+#if defined(LASSO_HOST_V3) && defined(__x86_64__)
+__attribute__((target("arch=x86-64"))) static bool host_cpu_ok() { __builtin_cpu_init(); return __builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi2") && __builtin_cpu_supports("fma"); }
+#else
+static bool host_cpu_ok() { return true; }
+#endif
+int32_t lasso_host_create(int32_t device, lasso_host** out) {
+  if (!host_cpu_ok()) { g_err = "liblasso_prover was built with -march=x86-64-v3 (AVX2 / BMI2 / FMA) and this CPU lacks them: rebuild with LASSO_HOST_MARCH=none"; return -1; }
+  GUARD(*out = new lasso_host(device); return 0;)
+}
 void lasso_host_destroy(lasso_host* h) { if (h) h->release(); }
 lasso_ctx* lasso_host_ctx(lasso_host* h) { return h ? h->dev.ctx : nullptr; }
 int32_t lasso_host_mem_stats(lasso_host* h, uint64_t* live_bytes, uint64_t* peak_bytes, uint64_t* prover_peak_bytes, int32_t reset) {

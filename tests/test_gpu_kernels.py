@@ -163,6 +163,40 @@ def test_lt_first_round_from_bits(devs, c, n, pattern):
     assert np.array_equal(a1, b1) and np.array_equal(a1, a2) and np.array_equal(b1, b2)
 
 
+@pytest.mark.parametrize("c,bad_mem,bad_at", [(1, 0, 0), (3, 5, 17), (16, 31, 63), (16, 0, 32), (2, 2, 1)])
+def test_lt_first_round_refuses_entries_that_are_not_bits(devs, c, bad_mem, bad_at):
+    """lasso_sumcheck_combine_round_lt_u32 is only exact for entries 0 / 1 and nothing used to enforce it at the ABI — a caller passing other integers got a silently
+    wrong round polynomial.  Now the kernel checks what it reads (every memory, the last EQ memory included, which never enters the walk) and the call fails; same on the mock."""
+    from lasso_amd import LassoError
+    n = 64
+    rng = np.random.default_rng(c + bad_mem)
+    U = [rng.integers(0, 2, size=n, dtype=np.uint32) for _ in range(2 * c)]
+    U[bad_mem][bad_at] = 2
+    eq = rand_fr(rng, n)
+    S = _abi.Strategy(_abi.KINDS["lt"], c, 4, 0)
+
+    def run(d):
+        pu = [d.upload(u) for u in U]; pe = d.upload(eq)
+        try:
+            d.sumcheck_combine_round_lt_u32(S, pu, pe, n, c + 1)
+            return "accepted"
+        except LassoError as e:
+            return "refused"
+        finally:
+            for p in pu + [pe]:
+                d.free(p)
+    assert both(devs, run) == ("refused", "refused")
+    U[bad_mem][bad_at] = 1      # and the same call is fine again afterwards (the flag does not stick)
+    def run2(d):
+        pu = [d.upload(u) for u in U]; pe = d.upload(eq)
+        a = d.sumcheck_combine_round_lt_u32(S, pu, pe, n, c + 1)
+        for p in pu + [pe]:
+            d.free(p)
+        return a
+    a, b = both(devs, run2)
+    assert np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("c", [1, 2, 3, 5, 8, 16])
 @pytest.mark.parametrize("n", [2, 8, 1 << 13])
 def test_lt_round_prescaled_horner(devs, c, n):

@@ -1,0 +1,78 @@
+#!/bin/bash
+# ONE parameterised script for everything that runs on the MI355X box (replaces the 62 one-off tools/gpu_r*.sh of rounds 1-3; tools/README.md maps every file under profiles/ to
+# the recipe and arguments that produced it).  Usage on the box (through gpurun):   bash tools/gpu.sh <recipe> [args...]   — several recipes: separate with `--`.
+# Every recipe writes under gpurun_out/<tag>/ (scratch, merged back); what is to be judged is copied into profiles/ by hand.  Every command runs under its own `timeout`.
+set -u
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+cd "$ROOT"; export TMPDIR=/tmp
+say() { echo "=== $*"; }
+
+r_tests() {        # tests [pytest -k expression] [tag]: the -m gpu suite (or a selection), summary line + failures
+  local k="${1:-}" tag="${2:-tests}"; mkdir -p gpurun_out/$tag
+  if [ -n "$k" ]; then timeout 1500 python -m pytest tests -m gpu -q -x -k "$k" -s > gpurun_out/$tag/pytest.log 2>&1; else timeout 1500 python -m pytest tests -m gpu -q -x > gpurun_out/$tag/pytest.log 2>&1; fi
+  grep -E "passed|failed|error" gpurun_out/$tag/pytest.log | tail -2; grep -E "^FAILED|^ERROR|Error" gpurun_out/$tag/pytest.log | head -5; grep -E "^\[(slab|oracle|verify)\]" gpurun_out/$tag/pytest.log
+}
+r_tests_bn254() {  # tests_bn254 [k] [tag]: the entry-point cases on the BN254 library pair
+  local k="${1:-}" tag="${2:-tests_bn254}"; mkdir -p gpurun_out/$tag
+  LASSO_TEST_CURVE=bn254 timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_bn254.py -m gpu -q -x ${k:+-k "$k"} > gpurun_out/$tag/pytest.log 2>&1; grep -E "passed|failed|error" gpurun_out/$tag/pytest.log | tail -2
+}
+r_bench() {        # bench <tag> [bench.py args...]: one bench.py run, JSON line kept, headline printed
+  local tag="$1"; shift; mkdir -p gpurun_out/$tag
+  timeout 900 python bench.py "$@" > gpurun_out/$tag/bench.json 2> gpurun_out/$tag/bench.err
+  python - "$tag" <<'PY'
+import json, sys
+tag = sys.argv[1]
+try:
+    d = json.loads(open(f"gpurun_out/{tag}/bench.json").read().strip().splitlines()[-1])
+except Exception as e:
+    print("no bench line:", e); print(open(f"gpurun_out/{tag}/bench.err").read()[-1500:]); sys.exit(0)
+rf = d.get("roofline") or {}; rm = d.get("roofline_msm") or {}
+print(f"{tag}: {d.get('ms_per_step', 0):.3f} ms/step  value {d.get('value', 0):.4g}  roofline frac {rf.get('frac')} traffic {rf.get('frac_traffic')}  parity {(d.get('parity_checked') or {}).get('equal')}")
+for k in ("commit", "opening"):
+    if rm.get(k): print(f"  msm {k}: frac {rm[k].get('frac')} achieved {rm[k].get('achieved')} launches {rm[k].get('launches')} avg {rm[k].get('avg_launch_us')} us")
+for k in d.get("kernels_one_profiled_step", []): print(f"  {k['kernel']:38s} {k['launches']:4d} launches {k['ms']:8.3f} ms  {k.get('alg_GBps')} GB/s")
+cp = d.get("concurrent_proofs")
+if cp: print("  concurrent:", [(x["streams"], round(x["value"] / 1e9, 3), x["proofs_differing_from_sequential"]) for x in cp.get("sweep", [])], cp.get("error"))
+bs = d.get("bind_top_sweep")
+if bs: print("  bind_top_sweep:", [(x["log_n"], x["polys"], x.get("alg_GBps"), x.get("frac"), x.get("error")) for x in bs["rows"]])
+sm = d.get("slab_mode")
+if sm: print("  slab:", {k: sm.get(k) for k in ("ms_per_proof", "parity", "peak_bytes_per_rank", "model_bytes_per_rank", "error", "skipped")})
+PY
+}
+r_prof() {         # prof <tag> [bench.py args...]: rocprofv3 --kernel-trace --stats of a short bench run; csv files kept
+  local tag="$1"; shift; mkdir -p gpurun_out/$tag
+  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -o bench -- python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --concurrent 0 --no-slab-leg --no-bind-sweep "$@" > $ROOT/gpurun_out/$tag/bench_under_rocprof.json 2> $ROOT/gpurun_out/$tag/rocprof.err)
+  find /tmp/prof_$tag -name '*stats.csv' -exec cp {} gpurun_out/$tag/ \; ; ls gpurun_out/$tag | head
+}
+r_pmc() {          # pmc <tag> [bench.py args...]: the two separate PMC passes (FETCH_SIZE, WRITE_SIZE; only --kernel-trace beside --pmc) + tools/pmc_summary.py
+  local tag="$1"; shift; mkdir -p gpurun_out/$tag
+  for CTR in FETCH_SIZE WRITE_SIZE; do
+    (cd /tmp && timeout 900 rocprofv3 --pmc $CTR --kernel-trace --output-format csv -d /tmp/pmc_${tag}_$CTR -o bench -- python $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --concurrent 0 --no-slab-leg --no-bind-sweep "$@" > $ROOT/gpurun_out/$tag/bench_$CTR.json 2> $ROOT/gpurun_out/$tag/rocprof_$CTR.err)
+    f=$(find /tmp/pmc_${tag}_$CTR -name '*counter_collection.csv' | head -1); [ -n "$f" ] && cp $f gpurun_out/$tag/bench_${CTR}_counter_collection.csv
+  done
+  python tools/pmc_summary.py gpurun_out/$tag/bench_FETCH_SIZE_counter_collection.csv gpurun_out/$tag/bench_WRITE_SIZE_counter_collection.csv gpurun_out/$tag/bench_FETCH_SIZE.json gpurun_out/$tag/bench_traffic.json "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of bench.py $* (tools/gpu.sh pmc)" | tail -30
+}
+r_pmc_bind() {     # pmc_bind <tag>: PMC passes + kernel stats of the kernel-level bind_top sweep (bench.py --only-bind-sweep)
+  local tag="$1"; mkdir -p gpurun_out/$tag
+  for CTR in FETCH_SIZE WRITE_SIZE; do
+    (cd /tmp && timeout 600 rocprofv3 --pmc $CTR --kernel-trace --output-format csv -d /tmp/pmcb_${tag}_$CTR -o bench -- python $ROOT/bench.py --only-bind-sweep > $ROOT/gpurun_out/$tag/sweep_$CTR.json 2> $ROOT/gpurun_out/$tag/rocprof_$CTR.err)
+    f=$(find /tmp/pmcb_${tag}_$CTR -name '*counter_collection.csv' | head -1); [ -n "$f" ] && cp $f gpurun_out/$tag/sweep_${CTR}_counter_collection.csv
+  done
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/statb_$tag -o bench -- python $ROOT/bench.py --only-bind-sweep > $ROOT/gpurun_out/$tag/sweep_stats_run.json 2> $ROOT/gpurun_out/$tag/rocprof_stats.err)
+  find /tmp/statb_$tag -name '*kernel_stats.csv' -exec cp {} gpurun_out/$tag/ \;
+  python tools/pmc_bind_summary.py gpurun_out/$tag | tail -20
+}
+r_memtable() {     # memtable <tag> [tools/slab_mem_table.py args...]
+  local tag="$1"; shift; mkdir -p gpurun_out/$tag
+  timeout 1200 python tools/slab_mem_table.py --out gpurun_out/$tag/slab_peak_bytes.json "$@" > gpurun_out/$tag/memtable.log 2> gpurun_out/$tag/memtable.err; grep '"world"' gpurun_out/$tag/memtable.log | cut -c1-400; tail -3 gpurun_out/$tag/memtable.err
+}
+r_sh() { "$@"; }   # sh <command...>: anything else, verbatim
+
+while [ $# -gt 0 ]; do
+  recipe="$1"; shift; args=()
+  while [ $# -gt 0 ] && [ "$1" != "--" ]; do args+=("$1"); shift; done
+  [ $# -gt 0 ] && shift
+  say "$recipe ${args[*]:-}"
+  "r_$recipe" "${args[@]}"
+done
+exit 0
