@@ -346,7 +346,14 @@ def slab_units(kind, c):
 
 
 def slab_bytes_per_rank(kind, c, log_s, world, log_m=16):
-    fixed = 3e9 + 6 * (2 * c) * (1 << log_m) * 32      # generator tables (window + digit-multiple + byte-multiple tables), scratch, the M-sized side
+    """slab_units x (s / P) x 32 bytes + the constant term: the generator tables (per generator 64 window entries + 512 digit multiples of 112 bytes; the rank's residue class
+    again as its slab table; 2 x 255 byte multiples for the commitments' table, of the rank's class only when P > 1) over the three Hyrax widths, and ~1.5 GB of scratch.
+    Checked against lasso_mem_stats at configs[3], P = 1, 2, 4, 8 (profiles/r04_slab_peak_bytes.json)."""
+    alpha = 2 * c if kind == "lt" else c
+    p2 = lambda x: 1 << (x - 1).bit_length()
+    width = lambda n_elems: 1 << ((n_elems.bit_length() - 1) - (n_elems.bit_length() - 1) // 2)      # R = 2^(nv - nv / 2), eq_poly.rs:40-42
+    r_l, r_e, r_m = width(p2(2 * c) << log_s), width(p2(alpha) << log_s), width(p2(c) << log_m)
+    fixed = 576 * 112 * (r_l + r_e + r_m) * (1 + (1.0 / world if world > 1 else 0)) + 2 * 255 * 112 * (r_l + r_e) / world + 1.5e9
     return slab_units(kind, c) * ((1 << log_s) / world) * 32 + fixed
 
 

@@ -32,8 +32,8 @@ lasso_ctx* lasso_host_ctx(lasso_host* h);   /* the device context, e.g. for lass
  * what the prover itself had in use (buffers parked in the host's recycling pool excluded) since creation / the last call with reset != 0.  Any pointer may be NULL. */
 int32_t lasso_host_mem_stats(lasso_host* h, uint64_t* live_bytes, uint64_t* peak_bytes, uint64_t* prover_peak_bytes, int32_t reset);
 /* Capacity mode (slab mode's purpose: proofs whose polynomials do not fit one GPU — the reference keeps every DensePolynomial and every product-tree layer as a
- * Vec<F>, src/subprotocols/grand_product.rs:38-58): large device buffers go back to the driver when the prover releases them instead of into the recycling pool,
- * and the prover drops what it no longer needs as early as the protocol allows, so the per-rank high-water mark is the live peak.  Same bytes, more driver calls.
+ * Vec<F>, src/subprotocols/grand_product.rs:38-58): the prover keeps the read / write product trees without their leaf layers (half of each tree) and recomputes the
+ * fingerprints strip by strip for the two streaming rounds of the bottom layer that read them.  Same proof bytes, less resident memory, more time.
  * Off by default (LASSO_CAPACITY=1 turns it on for every host). */
 int32_t lasso_host_set_capacity(lasso_host* h, int32_t on);
 

@@ -105,12 +105,12 @@ class Dev {
  public:
   lasso_ctx* ctx = nullptr;
   Comm comm;
-  // Capacity mode (slab mode's purpose): a released buffer of at least kCapacityMin bytes goes back to the driver at once instead of into the
-  // size-keyed pool, so the device high-water mark is the prover's LIVE peak, not the sum of every size it ever used.  Costs a hipFree (a device
-  // synchronisation) and a hipMalloc per large buffer and proof — time, which is not what this mode is for.  LASSO_CAPACITY=1/0 forces it on / off;
-  // lasso_host_set_capacity sets it per host; default: off.
+  // Capacity mode (slab mode's purpose): the prover trades time for resident bytes — the read / write product trees are kept WITHOUT their leaf layers
+  // (half of every tree: the fingerprints are recomputed strip by strip when the bottom layer's two streaming rounds need them, Prover::leaf_rounds).
+  // Round 4 first tried the obvious thing, handing every released buffer straight back to the driver: measured on configs[3] it bought nothing at P <= 4 (the
+  // high-water mark is the live set at the tree phase, not the pool) and cost 10x the proof time in hipFree / hipMalloc (profiles/r04_slab_peak_bytes_first_cut.json).
+  // LASSO_CAPACITY=1 turns it on for every host; lasso_host_set_capacity sets it per host; default: off.
   bool capacity = [] { const char* e = getenv("LASSO_CAPACITY"); return e && e[0] == '1'; }();
-  static constexpr size_t kCapacityMin = (size_t)1 << 24;
   explicit Dev(int device) : device_(device) {
     if (lasso_ctx_create(device, &ctx) != 0) throw Error(std::string("lasso_ctx_create: ") + lasso_last_error(nullptr));
     const char* e = getenv("LASSO_SIDE_STREAM");
@@ -146,9 +146,10 @@ class Dev {
     if (!p) return;
     auto it = live_.find(p); if (it == live_.end()) return;
     const size_t bytes = it->second; live_.erase(it); in_use_ -= bytes;
-    if (capacity && bytes >= kCapacityMin) { (void)lasso_free(ctx, p); return; }   // lasso_free synchronises the stream first: nothing in flight reads it
     pool_.emplace(bytes, p);
   }
+  // a one-off buffer (the uploaded index array of densify: 8 C s bytes that nothing of that size will ever want again) goes back to the driver, not into the pool
+  void release(void* p) const { if (!p) return; auto it = live_.find(p); if (it == live_.end()) return; in_use_ -= it->second; live_.erase(it); (void)lasso_free(ctx, p); }
   // hand every pooled buffer back to the driver
   void trim() const { for (auto& kv : pool_) (void)lasso_free(ctx, kv.second); pool_.clear(); }
   // device bytes held through this host's contexts now / at most (lasso_mem_stats of the main and the side context), and what the prover itself held at most
@@ -177,7 +178,7 @@ struct DBufU64 {   // read-only upload of a host u64 array
   const Dev* dev = nullptr; uint64_t* p = nullptr; size_t n = 0;
   DBufU64(const Dev& d, const uint64_t* h, size_t n_) : dev(&d), p((uint64_t*)d.alloc_bytes((n_ ? n_ : 1) * 8)), n(n_) { if (n) d.chk(lasso_upload(d.ctx, p, h, n * 8), "lasso_upload"); }
   DBufU64(const DBufU64&) = delete; DBufU64& operator=(const DBufU64&) = delete;
-  ~DBufU64() { try { if (p && dev) dev->free(p); } catch (...) {} }
+  ~DBufU64() { try { if (p && dev) dev->release(p); } catch (...) {} }   // only densify's index upload uses this type: not worth keeping
 };
 struct DBufU32 {
   const Dev* dev = nullptr; uint32_t* p = nullptr; size_t n = 0;
