@@ -63,6 +63,38 @@ int32_t lasso_host_commit(lasso_host_dense* d, lasso_host_gens* g, uint8_t* out,
 int32_t lasso_host_prove(lasso_host* h, lasso_host_dense* d, lasso_host_gens* g, const lasso_strategy* strategy, const lasso_fr* r, size_t r_len,
                          const char* transcript_label, const char* tape_label, uint8_t* out, size_t cap, size_t* len);
 
+/* ---- the caller's LIVE transcript and random tape --------------------------------------------------------------------------------------------------
+ * SparsePolynomialEvaluationProof::prove takes `&mut merlin::Transcript` and `&mut RandomTape<G>` (src/lasso/surge.rs:119-125): a caller whose transcript already holds
+ * state — anything but the bench harness, whose transcripts are fresh — needs the proof bound to THAT state.  Everything src/utils/transcript.rs:20-72 does to a
+ * merlin::Transcript is one of two operations, so the transcript crosses the ABI as two callbacks; `user` is the caller's object (the Rust shim passes the
+ * `&mut Transcript` itself, integration/rust/hip.rs).  RandomTape<G> is a merlin::Transcript too (src/utils/random.rs:9-39: `tape`), initialised by the caller's
+ * RandomTape::new; it crosses the same way.  Labels are NOT NUL-terminated (pointer + length) and live as long as the library is loaded (string literals: the Rust
+ * side may treat them as &'static [u8], which merlin's signatures ask for).  Callbacks are called from the thread that called lasso_host_prove_cb, never concurrently. */
+typedef struct {
+  /* merlin::Transcript::append_message(label, message); append_u64(label, x) arrives as its 8 little-endian bytes (what merlin absorbs) */
+  void (*append_message)(void* user, const uint8_t* label, size_t label_len, const uint8_t* message, size_t message_len);
+  /* merlin::Transcript::challenge_bytes(label, dest) */
+  void (*challenge_bytes)(void* user, const uint8_t* label, size_t label_len, uint8_t* dest, size_t dest_len);
+} lasso_transcript_vtbl;
+/* lasso_host_prove with the caller's live transcript and tape.  lasso_host_prove(.., "example", "proof", ..) is this call with the library's own Merlin objects
+ * (below) behind the callbacks: same bytes (tests/test_transcript_callbacks_cpu.py). */
+int32_t lasso_host_prove_cb(lasso_host* h, lasso_host_dense* d, lasso_host_gens* g, const lasso_strategy* strategy, const lasso_fr* r, size_t r_len,
+                            const lasso_transcript_vtbl* transcript, void* transcript_user, const lasso_transcript_vtbl* tape, void* tape_user,
+                            uint8_t* out, size_t cap, size_t* len);
+/* lasso_host_verify (below) against the caller's live transcript (surge.rs:214-220 takes `&mut Transcript` as well) */
+int32_t lasso_host_verify_cb(lasso_host* h, lasso_host_gens* g, const lasso_strategy* strategy, size_t s, const lasso_fr* r, size_t r_len,
+                             const lasso_transcript_vtbl* transcript, void* transcript_user,
+                             const uint8_t* proof, size_t proof_len, const uint8_t* commitment, size_t commitment_len, int32_t* ok);
+/* The library's own Merlin (STROBE-128 / Keccak-f[1600], merlin 3.0's framing) as one implementation of that interface — for callers without a merlin of their own
+ * (C, Python) that need a transcript living across several calls.  lasso_host_merlin_new(label) = Transcript::new(label);
+ * lasso_host_random_tape_new(name) = RandomTape::new(name) (init_randomness = F::rand(&mut test_rng()) absorbed, src/utils/random.rs:15-31).
+ * Pass the object as `user` with lasso_host_merlin_vtbl(). */
+typedef struct lasso_merlin lasso_merlin;
+lasso_merlin* lasso_host_merlin_new(const char* label);
+lasso_merlin* lasso_host_random_tape_new(const char* name);
+void lasso_host_merlin_free(lasso_merlin* m);
+const lasso_transcript_vtbl* lasso_host_merlin_vtbl(void);
+
 /* the bench harness's inputs (src/benches/bench.rs:13-34): one `next_u64() % memory_size` per lookup from ark_std::test_rng(),
  * and log2(s) field elements from a fresh test_rng() */
 void lasso_host_gen_indices(size_t sparsity, size_t memory_size, uint64_t* out);

@@ -16,6 +16,7 @@ use crate::lasso::surge::SparsePolyCommitmentGens;
 use crate::subtables::{and::AndSubtableStrategy, range_check::RangeCheckSubtableStrategy, xor::XorSubtableStrategy};
 use ark_curve25519::{EdwardsProjective, Fr};
 use ark_std::log2;
+use crate::utils::random::RandomTape;
 use merlin::Transcript;
 
 macro_rules! single_pass_lasso_hip {
@@ -37,8 +38,11 @@ macro_rules! single_pass_lasso_hip {
       let mut dense = tracing::info_span!("Densify").in_scope(|| HipDensified::<F, C>::from_lookup_indices(&prover, &nz, log_m));
       let hip_gens = HipGens::new(&prover, b"gens_sparse_poly", C, S, C, log_m);
       let commitment = tracing::info_span!("DensifiedRepresentation.commit").in_scope(|| dense.commit::<G>(&hip_gens));
+      // exactly bench.rs:59-66: the harness's own fresh transcript and tape, passed as the live objects they are
+      let mut random_tape = RandomTape::new(b"proof");
+      let mut prover_transcript = Transcript::new(b"example");
       let proof = tracing::info_span!("SparsePoly.prove")
-        .in_scope(|| prove_hip::<G, C, M, SubtableStrategy>(&prover, &mut dense, &r, &hip_gens, b"example", b"proof"));
+        .in_scope(|| prove_hip::<G, C, M, SubtableStrategy>(&prover, &mut dense, &r, &hip_gens, &mut prover_transcript, &mut random_tape));
 
       // the reference's verifier, unmodified, on the reference's own generator derivation
       let gens = SparsePolyCommitmentGens::<G>::new(b"gens_sparse_poly", C, S, C, log_m);

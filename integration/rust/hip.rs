@@ -6,9 +6,11 @@
 //!   dense.commit::<G>(&gens)                                        densified.rs:78    -> HipDensified::commit
 //!   SparsePolynomialEvaluationProof::<G,C,M,S>::prove(..)           surge.rs:119-125   -> prove_hip::<G,C,M,S>
 //!
-//! Nothing of the protocol is re-written in Rust on this path: the transcript schedule, the Merlin transcript and the O(log n) scalar
-//! work run inside liblasso_prover.so (lasso_amd/host/prover.hpp — the C++ mirror of the reference's host), every O(n) loop inside
-//! liblasso_hip.so.  What crosses the boundary: the lookup indices (`Vec<[usize; C]>` is n x C u64, row-major, passed as is), the point
+//! Nothing of the protocol is re-written in Rust on this path: the transcript schedule and the O(log n) scalar work run inside
+//! liblasso_prover.so (lasso_amd/host/prover.hpp — the C++ mirror of the reference's host), every O(n) loop inside liblasso_hip.so.
+//! The Merlin transcript and the random tape are the CALLER'S: `prove_hip` takes `&mut Transcript` and `&mut RandomTape<G>` exactly as
+//! surge.rs:119-125 does and hands them to the library as two callbacks each (lasso_transcript_vtbl), so a transcript that already holds
+//! state binds the proof to that state — byte for byte what the CPU prover produces from the same transcript.  What crosses the boundary: the lookup indices (`Vec<[usize; C]>` is n x C u64, row-major, passed as is), the point
 //! `r` (ark-ff's in-memory Montgomery limbs, passed as is), and ark-serialize's compressed wire bytes on the way back.
 //! The finely-grained ABI (include/lasso_hip.h, ffi.rs first block) stays available to a maintainer who wants the protocol in Rust and
 //! only the loops on the device; INTEGRATION.md §3 maps each loop to its entry point.
@@ -19,6 +21,9 @@
 
 use std::ffi::{CStr, CString};
 use std::marker::PhantomData;
+use std::os::raw::c_void;
+
+use merlin::Transcript;
 
 use ark_ec::CurveGroup;
 use ark_ff::PrimeField;
@@ -27,6 +32,7 @@ use ark_serialize::CanonicalDeserialize;
 use crate::hip::ffi::*;
 use crate::lasso::surge::{SparsePolynomialCommitment, SparsePolynomialEvaluationProof};
 use crate::poly::dense_mlpoly::PolyCommitment;
+use crate::utils::random::RandomTape;
 use crate::subtables::{
   and::AndSubtableStrategy, lt::LTSubtableStrategy, or::OrSubtableStrategy, range_check::RangeCheckSubtableStrategy,
   xor::XorSubtableStrategy, SubtableStrategy,
@@ -72,10 +78,56 @@ impl HipProver {
   pub fn new(device: i32) -> Self {
     let mut h = std::ptr::null_mut();
     chk(unsafe { lasso_host_create(device, &mut h) }, "lasso_host_create");
-    // start-up self-test of the layout assumption: F::from(7) -> device -> back
-    HipProver { h }
+    let p = HipProver { h };
+    p.self_test();
+    p
+  }
+
+  /// Start-up self-test of the layout assumption the whole boundary rests on: ark-ff's in-memory `Fr` IS the library's `lasso_fr`.
+  /// `F::from(7)` and `F::from(6)` go to the device as raw bytes, the device lifts the integers 7 and 6 itself (`lasso_fr_from_u32`), and both pairs must come
+  /// back as the same 32 bytes — which also read back as 7 and 6 through ark-ff.  A build of ark-ff with another limb order, radix or Montgomery constant fails here,
+  /// at start-up, instead of producing proofs nobody can verify.
+  fn self_test(&self) {
+    use ark_ff::PrimeField as _;
+    type F = ark_curve25519::Fr;
+    let ctx = unsafe { lasso_host_ctx(self.h) };
+    let host_side = [F::from(7u64), F::from(6u64)];
+    let ints: [u32; 2] = [7, 6];
+    let (mut d_ints, mut d_fr) = (std::ptr::null_mut::<c_void>(), std::ptr::null_mut::<c_void>());
+    unsafe {
+      chk(lasso_alloc(ctx, 8, &mut d_ints), "lasso_alloc");
+      chk(lasso_alloc(ctx, 64, &mut d_fr), "lasso_alloc");
+      chk(lasso_upload(ctx, d_ints, ints.as_ptr() as *const c_void, 8), "lasso_upload");
+      chk(lasso_fr_from_u32(ctx, d_ints as *const u32, 2, d_fr as *mut lasso_fr), "lasso_fr_from_u32");
+      let mut back = [F::from(0u64); 2];
+      chk(lasso_download(ctx, back.as_mut_ptr() as *mut c_void, d_fr, 64), "lasso_download");
+      assert!(back == host_side, "ark_curve25519::Fr's memory form is not the library's field-element layout: 4 x u64 LE, Montgomery R = 2^256");
+      assert!(back[0].into_bigint().0 == [7, 0, 0, 0]);
+      // and the other direction: the host's bytes, through the device and back, unchanged
+      chk(lasso_upload(ctx, d_fr, host_side.as_ptr() as *const c_void, 64), "lasso_upload");
+      chk(lasso_download(ctx, back.as_mut_ptr() as *mut c_void, d_fr, 64), "lasso_download");
+      assert!(back == host_side);
+      chk(lasso_free(ctx, d_ints), "lasso_free");
+      chk(lasso_free(ctx, d_fr), "lasso_free");
+    }
   }
 }
+
+// ---- merlin::Transcript behind include/lasso_prover.h's two callbacks ------------------------------------------------------------
+// `user` is the caller's `&mut Transcript`.  merlin's signatures ask for `&'static [u8]` labels: the library's labels are string literals of the loaded
+// shared object (include/lasso_prover.h states the lifetime), so extending the slice's lifetime is sound for as long as the library stays loaded.
+unsafe extern "C" fn merlin_append(user: *mut c_void, label: *const u8, label_len: usize, msg: *const u8, msg_len: usize) {
+  let t = &mut *(user as *mut Transcript);
+  let label: &'static [u8] = std::slice::from_raw_parts(label, label_len);
+  t.append_message(label, std::slice::from_raw_parts(msg, msg_len));
+}
+unsafe extern "C" fn merlin_challenge(user: *mut c_void, label: *const u8, label_len: usize, dest: *mut u8, dest_len: usize) {
+  let t = &mut *(user as *mut Transcript);
+  let label: &'static [u8] = std::slice::from_raw_parts(label, label_len);
+  t.challenge_bytes(label, std::slice::from_raw_parts_mut(dest, dest_len));
+}
+const MERLIN_VTBL: lasso_transcript_vtbl = lasso_transcript_vtbl { append_message: Some(merlin_append), challenge_bytes: Some(merlin_challenge) };
+// RandomTape<G> { tape: Transcript, .. } (utils/random.rs:9-12): the shim lives inside the crate, `tape` gets `pub(crate)`.
 impl Drop for HipProver {
   fn drop(&mut self) { unsafe { lasso_host_destroy(self.h) } }
 }
@@ -123,16 +175,17 @@ impl<F: PrimeField, const C: usize> Drop for HipDensified<'_, F, C> {
   fn drop(&mut self) { unsafe { lasso_host_dense_free(self.d) } }
 }
 
-/// surge.rs:119-211 on the device.  `transcript_label` / `tape_label` are the labels the harness passes to `Transcript::new` / `RandomTape::new`
-/// (b"example", b"proof" in bench.rs:62-63): the library replays both from their labels, so the proof bytes are those of the CPU prover on the
-/// same inputs (DESIGN.md §3 states what that claim rests on).
+/// surge.rs:119-211 on the device, with the reference's own signature: the caller's live `&mut Transcript` and `&mut RandomTape<G>` (whatever they already
+/// hold) are what the proof is bound to — the library appends to and draws from THEM through `lasso_host_prove_cb`, in the schedule of surge.rs:127-199,
+/// so the proof bytes are those of the CPU prover given the same two objects (DESIGN.md §3 states what that claim rests on;
+/// tests/test_transcript_callbacks_cpu.py holds the library to the oracle on pre-seeded transcripts).
 pub fn prove_hip<G, const C: usize, const M: usize, S>(
   p: &HipProver,
   dense: &mut HipDensified<G::ScalarField, C>,
   r: &Vec<G::ScalarField>,
   gens: &HipGens,
-  transcript_label: &'static [u8],
-  tape_label: &'static [u8],
+  transcript: &mut Transcript,
+  random_tape: &mut RandomTape<G>,
 ) -> SparsePolynomialEvaluationProof<G, C, M, S>
 where
   G: CurveGroup,
@@ -143,19 +196,22 @@ where
 {
   assert_eq!(r.len(), ark_std::log2(dense.s) as usize); // surge.rs:131
   let st = S::descriptor();
-  let (tl, pl) = (CString::new(transcript_label).unwrap(), CString::new(tape_label).unwrap());
+  let (t_user, tape_user) = (transcript as *mut Transcript as *mut c_void, &mut random_tape.tape as *mut Transcript as *mut c_void);
+  let mut first = true;
   let bytes = call_bytes(
     |out, cap, len| unsafe {
-      lasso_host_prove(p.h, dense.d, gens.g, &st, r.as_ptr() as *const lasso_fr, r.len(), tl.as_ptr(), pl.as_ptr(), out, cap, len)
+      // a retry with a larger buffer would replay the protocol into transcripts that have already advanced: the first buffer is sized so that it cannot happen
+      assert!(first, "proof larger than the buffer sized for it"); first = false;
+      lasso_host_prove_cb(p.h, dense.d, gens.g, &st, r.as_ptr() as *const lasso_fr, r.len(), &MERLIN_VTBL, t_user, &MERLIN_VTBL, tape_user, out, cap, len)
     },
-    "lasso_host_prove",
+    "lasso_host_prove_cb",
   );
   SparsePolynomialEvaluationProof::<G, C, M, S>::deserialize_compressed(&bytes[..]).expect("proof bytes")
 }
 
 /// calls that return bytes: -2 = buffer too small, *len = needed size
 fn call_bytes(mut f: impl FnMut(*mut u8, usize, *mut usize) -> i32, what: &str) -> Vec<u8> {
-  let mut buf = vec![0u8; 1 << 20];
+  let mut buf = vec![0u8; 1 << 24]; // 16 MiB: a proof is O(log^2 s + sqrt(s)) elements (600 KB at 2^26 lookups, C = 4); commitments 0.5 MB
   loop {
     let mut len = 0usize;
     let rc = f(buf.as_mut_ptr(), buf.len(), &mut len);

@@ -106,15 +106,18 @@ class Merlin {
 
  public:
   explicit Merlin(const char* label) : s("Merlin v1.0") { append_message("dom-sep", label, strlen(label)); }
-  void append_message(const char* label, const void* msg, size_t n) {
+  void append_message(const char* label, const void* msg, size_t n) { append_message_l(label, strlen(label), msg, n); }
+  // the same with the label as (pointer, length): labels that arrive through the C ABI are not NUL-terminated (include/lasso_prover.h lasso_transcript_vtbl)
+  void append_message_l(const void* label, size_t label_len, const void* msg, size_t n) {
     uint8_t len[4]; le32((uint32_t)n, len);
-    s.meta_ad(label, strlen(label), false); s.meta_ad(len, 4, true); s.ad(msg, n, false);
+    s.meta_ad(label, label_len, false); s.meta_ad(len, 4, true); s.ad(msg, n, false);
   }
   void append_str(const char* label, const char* msg) { append_message(label, msg, strlen(msg)); }
   void append_u64(const char* label, uint64_t x) { uint8_t b[8]; for (int i = 0; i < 8; i++) b[i] = (uint8_t)(x >> (8 * i)); append_message(label, b, 8); }
-  void challenge_bytes(const char* label, uint8_t* out, size_t n) {
+  void challenge_bytes(const char* label, uint8_t* out, size_t n) { challenge_bytes_l(label, strlen(label), out, n); }
+  void challenge_bytes_l(const void* label, size_t label_len, uint8_t* out, size_t n) {
     uint8_t len[4]; le32((uint32_t)n, len);
-    s.meta_ad(label, strlen(label), false); s.meta_ad(len, 4, true); s.prf(out, n, false);
+    s.meta_ad(label, label_len, false); s.meta_ad(len, 4, true); s.prf(out, n, false);
   }
 };
 

@@ -19,6 +19,7 @@
 #include <vector>
 #include "field_host.hpp"
 #include "hashes.hpp"
+#include "../../include/lasso_prover.h"
 
 #include <chrono>
 #include <cstdio>
@@ -192,20 +193,30 @@ struct DBufU32 {
 };
 
 // ------------------------------------------------------------------ transcript (utils/transcript.rs:6-72)
+// Everything the reference does to a merlin::Transcript is one of two calls: append_message (append_u64 = its 8 little-endian bytes, the scalar / point / vector forms
+// = messages built from ark-serialize's bytes, :20-62) and challenge_bytes (:64-72).  The transcript is therefore either the library's own Merlin (built from a label: the
+// harness's `Transcript::new(b"example")`) or a caller's LIVE transcript behind those two callbacks (include/lasso_prover.h lasso_transcript_vtbl: surge.rs:119-125 takes
+// `&mut Transcript`, whatever state it already holds) — the protocol code below cannot tell the difference.
 class ProofTranscript {
-  Merlin m;
+  Merlin m; const lasso_transcript_vtbl* vt = nullptr; void* user = nullptr;
+  void app(const char* label, const void* msg, size_t n) { if (vt) vt->append_message(user, (const uint8_t*)label, strlen(label), (const uint8_t*)msg, n); else m.append_message(label, msg, n); }
 
  public:
   explicit ProofTranscript(const char* label) : m(label) {}
-  void append_message(const char* label, const char* msg) { m.append_str(label, msg); }
-  void append_protocol_name(const char* name) { m.append_str("protocol-name", name); }
-  void append_u64(const char* label, uint64_t x) { m.append_u64(label, x); }
-  void append_scalar(const char* label, const Sc& s) { uint8_t b[32]; s.to_bytes(b); m.append_message(label, b, 32); }
+  ProofTranscript(const lasso_transcript_vtbl* v, void* u) : m("(external transcript)"), vt(v), user(u) { if (!v || !v->append_message || !v->challenge_bytes) throw std::runtime_error("lasso prover: transcript callbacks missing"); }
+  void append_message(const char* label, const char* msg) { app(label, msg, strlen(msg)); }
+  void append_protocol_name(const char* name) { app("protocol-name", name, strlen(name)); }
+  void append_u64(const char* label, uint64_t x) { uint8_t b[8]; for (int i = 0; i < 8; i++) b[i] = (uint8_t)(x >> (8 * i)); app(label, b, 8); }   // merlin::Transcript::append_u64 = encode_u64 little-endian
+  void append_scalar(const char* label, const Sc& s) { uint8_t b[32]; s.to_bytes(b); app(label, b, 32); }
   // the same with the scalars already serialised (32 canonical bytes each, e.g. by lasso_fr_to_bytes)
-  void append_scalars_bytes(const char* label, const std::vector<uint8_t>& b) { m.append_str(label, "begin_append_vector"); for (size_t i = 0; i + 32 <= b.size(); i += 32) m.append_message(label, &b[i], 32); m.append_str(label, "end_append_vector"); }
-  void append_scalars(const char* label, const ScVec& v) { m.append_str(label, "begin_append_vector"); for (auto& s : v) append_scalar(label, s); m.append_str(label, "end_append_vector"); }
-  void append_point_bytes(const char* label, const uint8_t b[32]) { m.append_message(label, b, 32); }
-  Sc challenge_scalar(const char* label) { uint8_t b[64]; m.challenge_bytes(label, b, 64); return Sc::from_wide_bytes(b); }
+  void append_scalars_bytes(const char* label, const std::vector<uint8_t>& b) { append_message(label, "begin_append_vector"); for (size_t i = 0; i + 32 <= b.size(); i += 32) app(label, &b[i], 32); append_message(label, "end_append_vector"); }
+  void append_scalars(const char* label, const ScVec& v) { append_message(label, "begin_append_vector"); for (auto& s : v) append_scalar(label, s); append_message(label, "end_append_vector"); }
+  void append_point_bytes(const char* label, const uint8_t b[32]) { app(label, b, 32); }
+  Sc challenge_scalar(const char* label) {
+    uint8_t b[64];
+    if (vt) vt->challenge_bytes(user, (const uint8_t*)label, strlen(label), b, 64); else m.challenge_bytes(label, b, 64);
+    return Sc::from_wide_bytes(b);
+  }
   ScVec challenge_vector(const char* label, size_t n) { ScVec v; for (size_t i = 0; i < n; i++) v.push_back(challenge_scalar(label)); return v; }
 };
 // ark-ff Fp::rand on the test RNG (first draw): limbs taken as the Montgomery representation, top 3 bits masked, rejection
@@ -226,6 +237,8 @@ class RandomTape {  // utils/random.rs:9-39
 
  public:
   explicit RandomTape(const char* name) : tape(name) { ChaChaRng prng = ChaChaRng::test_rng(); tape.append_scalar("init_randomness", fr_rand(prng)); }
+  // a caller's live RandomTape: its inner transcript (already initialised by RandomTape::new on the caller's side, possibly already drawn from) behind the two callbacks
+  RandomTape(const lasso_transcript_vtbl* v, void* u) : tape(v, u) {}
   Sc random_scalar(const char* label) { return tape.challenge_scalar(label); }
   ScVec random_vector(const char* label, size_t n) { return tape.challenge_vector(label, n); }
 };

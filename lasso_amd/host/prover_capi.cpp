@@ -108,6 +108,45 @@ int32_t lasso_host_prove(lasso_host* h, lasso_host_dense* d, lasso_host_gens* g,
     try { P.prove(rv); } catch (...) { h->dev.abort_all(); throw; }
     return emit(P.proof_bytes, out, cap, len);)
 }
+// ---- live transcripts (include/lasso_prover.h lasso_transcript_vtbl)
+struct lasso_merlin { Merlin m; explicit lasso_merlin(const char* label) : m(label) {} };
+static void merlin_append(void* u, const uint8_t* label, size_t ll, const uint8_t* msg, size_t n) { ((lasso_merlin*)u)->m.append_message_l(label, ll, msg, n); }
+static void merlin_challenge(void* u, const uint8_t* label, size_t ll, uint8_t* dest, size_t n) { ((lasso_merlin*)u)->m.challenge_bytes_l(label, ll, dest, n); }
+static const lasso_transcript_vtbl g_merlin_vtbl = {merlin_append, merlin_challenge};
+const lasso_transcript_vtbl* lasso_host_merlin_vtbl(void) { return &g_merlin_vtbl; }
+lasso_merlin* lasso_host_merlin_new(const char* label) { try { return label ? new lasso_merlin(label) : nullptr; } catch (...) { return nullptr; } }
+lasso_merlin* lasso_host_random_tape_new(const char* name) {
+  try {
+    if (!name) return nullptr;
+    lasso_merlin* t = new lasso_merlin(name);
+    ChaChaRng prng = ChaChaRng::test_rng(); uint8_t b[32]; fr_rand(prng).to_bytes(b);
+    t->m.append_message("init_randomness", b, 32);   // RandomTape::new (utils/random.rs:15-31)
+    return t;
+  } catch (...) { return nullptr; }
+}
+void lasso_host_merlin_free(lasso_merlin* m) { delete m; }
+int32_t lasso_host_prove_cb(lasso_host* h, lasso_host_dense* d, lasso_host_gens* g, const lasso_strategy* st, const lasso_fr* r, size_t r_len,
+                            const lasso_transcript_vtbl* tv, void* tu, const lasso_transcript_vtbl* pv, void* pu, uint8_t* out, size_t cap, size_t* len) {
+  GUARD(
+    if (!h || !d || !g || !st || !r || !tv || !pv) throw Error("lasso_host_prove_cb: null argument");
+    Strategy S(st->kind, st->c, st->log_m, st->log_r);
+    ProofTranscript t(tv, tu); RandomTape tape(pv, pu);
+    ScVec rv; for (size_t i = 0; i < r_len; i++) rv.push_back(Sc::from_abi(r[i]));
+    Prover P(h->dev, S, *d->d, *g->g, t, tape);
+    try { P.prove(rv); } catch (...) { h->dev.abort_all(); throw; }
+    return emit(P.proof_bytes, out, cap, len);)
+}
+int32_t lasso_host_verify_cb(lasso_host* h, lasso_host_gens* g, const lasso_strategy* st, size_t s, const lasso_fr* r, size_t r_len, const lasso_transcript_vtbl* tv, void* tu,
+                             const uint8_t* proof, size_t proof_len, const uint8_t* commitment, size_t commitment_len, int32_t* ok) {
+  GUARD(
+    if (!h || !g || !st || !r || !proof || !commitment || !ok || !tv) throw Error("lasso_host_verify_cb: null argument");
+    Strategy S(st->kind, st->c, st->log_m, st->log_r);
+    ProofTranscript t(tv, tu);
+    ScVec rv; for (size_t i = 0; i < r_len; i++) rv.push_back(Sc::from_abi(r[i]));
+    Verifier V(h->dev, S, *g->g, t);
+    *ok = V.verify(proof, proof_len, commitment, commitment_len, s, st->log_m, rv) ? 1 : 0;
+    return 0;)
+}
 int32_t lasso_host_verify(lasso_host* h, lasso_host_gens* g, const lasso_strategy* st, size_t s, const lasso_fr* r, size_t r_len, const char* tl,
                           const uint8_t* proof, size_t proof_len, const uint8_t* commitment, size_t commitment_len, int32_t* ok) {
   GUARD(

@@ -23,6 +23,13 @@ def load_prover_library(path=None, curve="curve25519"):
 
 
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)   # (user, send, recv, bytes per rank) -> 0
+# include/lasso_prover.h lasso_transcript_vtbl: merlin::Transcript as append_message / challenge_bytes callbacks (labels are pointer + length)
+APPEND_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t, C.POINTER(C.c_uint8), C.c_size_t)
+CHALLENGE_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t, C.POINTER(C.c_uint8), C.c_size_t)
+
+
+class TranscriptVtbl(C.Structure):
+    _fields_ = [("append_message", APPEND_FN), ("challenge_bytes", CHALLENGE_FN)]
 
 
 def declare_prover(lib):
@@ -44,6 +51,13 @@ def declare_prover(lib):
     lib.lasso_host_prove.argtypes = [vp, vp, vp, C.POINTER(_abi.Strategy), vp, sz, C.c_char_p, C.c_char_p, vp, sz, C.POINTER(sz)]
     lib.lasso_host_verify.argtypes = [vp, vp, C.POINTER(_abi.Strategy), sz, vp, sz, C.c_char_p, C.c_char_p, sz, C.c_char_p, sz, C.POINTER(i32)]
     lib.lasso_host_debug_cubic_batched.argtypes = [vp, vp, vp, C.POINTER(_abi.Strategy), sz, sz, vp, vp, vp, vp, vp, C.c_char_p, vp, sz, C.POINTER(sz)]
+    vt = C.POINTER(TranscriptVtbl)
+    lib.lasso_host_prove_cb.argtypes = [vp, vp, vp, C.POINTER(_abi.Strategy), vp, sz, vt, vp, vt, vp, vp, sz, C.POINTER(sz)]
+    lib.lasso_host_verify_cb.argtypes = [vp, vp, C.POINTER(_abi.Strategy), sz, vp, sz, vt, vp, C.c_char_p, sz, C.c_char_p, sz, C.POINTER(i32)]
+    lib.lasso_host_merlin_new.argtypes = [C.c_char_p]; lib.lasso_host_merlin_new.restype = vp
+    lib.lasso_host_random_tape_new.argtypes = [C.c_char_p]; lib.lasso_host_random_tape_new.restype = vp
+    lib.lasso_host_merlin_free.argtypes = [vp]
+    lib.lasso_host_merlin_vtbl.argtypes = []; lib.lasso_host_merlin_vtbl.restype = vt
     lib.lasso_host_gen_indices.argtypes = [sz, sz, vp]
     lib.lasso_host_gen_random_point.argtypes = [sz, vp]
     return lib
@@ -111,6 +125,18 @@ class HostProver:
         r = np.ascontiguousarray(r, dtype=np.uint64).reshape(-1, 4)
         return self._bytes_call(self.lib.lasso_host_prove, self.h, dense, gens, C.byref(strategy), r.ctypes.data_as(C.c_void_p), r.shape[0], transcript, tape)
 
+    def prove_with(self, dense, gens, strategy, r, transcript, tape):
+        """SparsePolynomialEvaluationProof::prove against LIVE transcripts (surge.rs:119-125 `&mut Transcript`, `&mut RandomTape`): `transcript` / `tape` are
+        (vtbl pointer, user pointer) pairs — lasso_host_prove_cb; see Transcript below for the library's own Merlin behind that interface"""
+        r = np.ascontiguousarray(r, dtype=np.uint64).reshape(-1, 4)
+        return self._bytes_call(lambda *a: self.lib.lasso_host_prove_cb(self.h, dense, gens, C.byref(strategy), r.ctypes.data_as(C.c_void_p), r.shape[0], transcript[0], transcript[1], tape[0], tape[1], *a))
+
+    def verify_with(self, gens, strategy, s, r, proof, commitment, transcript):
+        r = np.ascontiguousarray(r, dtype=np.uint64).reshape(-1, 4)
+        ok = C.c_int32(-1)
+        self._chk(self.lib.lasso_host_verify_cb(self.h, gens, C.byref(strategy), s, r.ctypes.data_as(C.c_void_p), r.shape[0], transcript[0], transcript[1], proof, len(proof), commitment, len(commitment), C.byref(ok)))
+        return ok.value == 1
+
     def verify(self, gens, strategy, s, r, proof, commitment, transcript=b"example"):
         """SparsePolynomialEvaluationProof::verify (surge.rs:214-271) over the wire bytes: True = Ok(()), False = Err(ProofVerifyError); raises LassoError on bytes
         that do not deserialize or on shapes the reference would assert on."""
@@ -152,3 +178,31 @@ class HostProver:
     def set_capacity(self, on=True):
         """capacity mode (lasso_host_set_capacity): large buffers go back to the driver on release; the per-rank high-water mark is the live peak"""
         self._chk(self.lib.lasso_host_set_capacity(self.h, 1 if on else 0))
+
+
+class Transcript:
+    """The library's own Merlin transcript as an object that lives across calls (lasso_host_merlin_new / lasso_host_random_tape_new): `pair()` is what
+    HostProver.prove_with / verify_with take.  tape=True builds RandomTape::new(label) (utils/random.rs:15-31) instead of Transcript::new(label)."""
+
+    def __init__(self, lib, label, tape=False):
+        self.lib = lib
+        self.m = (lib.lasso_host_random_tape_new if tape else lib.lasso_host_merlin_new)(label)
+        if not self.m:
+            raise LassoError("lasso_host_merlin_new failed")
+        self.vt = lib.lasso_host_merlin_vtbl()
+
+    def append_message(self, label, msg):
+        lb = (C.c_uint8 * len(label)).from_buffer_copy(label); mb = (C.c_uint8 * max(len(msg), 1)).from_buffer_copy(msg or b"\0")
+        self.vt.contents.append_message(self.m, lb, len(label), mb, len(msg))
+
+    def challenge_bytes(self, label, n):
+        lb = (C.c_uint8 * len(label)).from_buffer_copy(label); out = (C.c_uint8 * n)()
+        self.vt.contents.challenge_bytes(self.m, lb, len(label), out, n)
+        return bytes(out)
+
+    def pair(self):
+        return (self.vt, C.c_void_p(self.m))
+
+    def close(self):
+        if self.m:
+            self.lib.lasso_host_merlin_free(self.m); self.m = None

@@ -122,6 +122,26 @@ int orc_session_prove(void* sv, uint8_t* out, size_t cap, size_t* len) { GUARD(
   auto P = surge_prove(se->S, se->dense, se->r, se->gens, t, tape);
   auto b = serialize_proof(P);
   *len = b.size(); if (b.size() > cap) return -2; memcpy(out, b.data(), b.size()); return 0; ) }
+// The same with LIVE transcripts, as surge.rs:119-125 takes them (&mut Transcript, &mut RandomTape): `pre_*` is a message the caller's protocol absorbed into the transcript
+// (label "example") before calling prove, `tape_pre_*` likewise into the random tape's transcript (label "proof", after init_randomness); NULL labels = nothing absorbed.
+// The checker for lasso_host_prove_cb's claim that a caller's pre-seeded transcript changes the proof exactly as it changes the reference's.
+int orc_session_prove_seeded(void* sv, const char* pre_label, const uint8_t* pre_msg, size_t pre_len, const char* tape_pre_label, const uint8_t* tape_pre_msg, size_t tape_pre_len,
+                             uint8_t* out, size_t cap, size_t* len) { GUARD(
+  Session* se = (Session*)sv;
+  RandomTape tape("proof"); MerlinTranscript t("example");
+  if (pre_label) t.append_message(pre_label, pre_msg, pre_len);
+  if (tape_pre_label) tape.tape.append_message(tape_pre_label, tape_pre_msg, tape_pre_len);
+  auto P = surge_prove(se->S, se->dense, se->r, se->gens, t, tape);
+  auto b = serialize_proof(P);
+  *len = b.size(); if (b.size() > cap) return -2; memcpy(out, b.data(), b.size()); return 0; ) }
+int orc_session_verify_seeded(void* sv, const char* pre_label, const uint8_t* pre_msg, size_t pre_len, const uint8_t* proof, size_t n) { GUARD(
+  Session* se = (Session*)sv;
+  if (!se->committed) { se->commitment = se->dense.commit(se->gens); se->committed = true; }
+  SparsePolynomialEvaluationProof P;
+  if (!deserialize_proof(se->S, proof, n, P)) { g_err = "deserialize failed"; return 0; }
+  MerlinTranscript t("example");
+  if (pre_label) t.append_message(pre_label, pre_msg, pre_len);
+  return surge_verify(se->S, P, se->commitment, se->r, se->gens, t) ? 1 : 0; ) }
 // prove_cubic_batched (sumcheck.rs:27-135) on caller-supplied arrays with C = EqPolynomial(rand).evals() (grand_product.rs:122-128) and a scripted
 // eq point: the literal three-polynomial loop.  A, B: k contiguous arrays of 2^ell Montgomery elements.  out = the honest claim, then (same
 // layout as lasso_host_debug_cubic_batched) 3 compressed coefficients per round, the challenges, the final claims of A and of B.

@@ -336,3 +336,34 @@ def test_gpu_cubic_batched_scripted_eq_points(host, oracle, k, ell, special):
     """the two-sum rounds, the three-sum fallback (rand_t = 0) and the explicit-table path (rand_t = 1) on the device kernels, all sizes
     (latency-shaped and streaming kernels), against the oracle's literal loop"""
     cubic_batched_case(host, oracle, k, ell, special, seed=k * 100 + ell)
+
+
+@pytest.mark.parametrize("kind,c,log_m,log_r,log_s", [("and", 2, 16, 0, 14), ("lt", 2, 8, 0, 10)])
+def test_gpu_live_transcript_and_tape_through_the_callbacks(host, oracle, kind, c, log_m, log_r, log_s):
+    """lasso_host_prove_cb on the device (surge.rs:119-125's `&mut Transcript`, `&mut RandomTape`): fresh Merlin objects behind the callbacks give the label path's bytes, and a
+    transcript the caller has already written to gives the ORACLE's proof for the same pre-seeded transcript (tests/test_transcript_callbacks_cpu.py holds the host logic to
+    more cases over the mock)."""
+    import ctypes as C
+    from lasso_amd.prover import Transcript
+    s = 1 << log_s
+    alpha = 2 * c if kind == "lt" else c
+    idx = host.gen_indices(s, 1 << log_m, c); r = host.gen_random_point(log_s)
+    S = _abi.Strategy(_abi.KINDS[kind], c, log_m, log_r)
+    gens = host.gens(c, s, alpha, log_m); dense = host.densify(idx, log_m)
+    t = Transcript(host.lib, b"example"); tape = Transcript(host.lib, b"proof", tape=True)
+    t2 = Transcript(host.lib, b"example"); tape2 = Transcript(host.lib, b"proof", tape=True)
+    pre_label, pre_msg = b"outer protocol", b"absorbed before prove"
+    t2.append_message(pre_label, pre_msg)
+    orc = OracleSession(oracle, _abi.KINDS[kind], c, log_m, log_r, idx, r)
+    try:
+        assert host.prove_with(dense, gens, S, r, t.pair(), tape.pair()) == host.prove(dense, gens, S, r)
+        seeded = host.prove_with(dense, gens, S, r, t2.pair(), tape2.pair())
+        oracle.orc_session_prove_seeded.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        buf = (C.c_uint8 * (1 << 22))(); n = C.c_size_t()
+        assert oracle.orc_session_prove_seeded(C.c_void_p(orc.s), pre_label, pre_msg, len(pre_msg), None, None, 0, buf, len(buf), C.byref(n)) == 0, oracle.orc_last_error()
+        assert seeded == bytes(buf[: n.value])
+    finally:
+        orc.close()
+        for x in (t, tape, t2, tape2):
+            x.close()
+        host.free(dense, gens)
