@@ -240,6 +240,19 @@ int32_t lasso_fingerprint_ops(lasso_ctx* ctx, const lasso_fr* d_table, const uin
  * Bit-identical to the three separate calls. */
 int32_t lasso_fingerprint_ops_gp(lasso_ctx* ctx, const lasso_fr* d_table, const uint32_t* d_dim, const lasso_fr* d_read, size_t s, const lasso_fr* gamma, const lasso_fr* tau,
                                  lasso_fr* d_tree_read, lasso_fr* d_tree_write);
+/* Capacity mode (one proof larger than the reference's "every layer a Vec<F>" layout allows, grand_product.rs:38-58): the same two trees WITHOUT their leaf layers —
+ * d_upper_read / d_upper_write receive the layers of s/2, s/4, .., 2 elements back to back (s - 2 elements; what lasso_fingerprint_ops_gp leaves at d_tree + s); the
+ * fingerprints exist only inside the launch.  Half the resident bytes of the read / write trees. */
+int32_t lasso_fingerprint_ops_gp_upper(lasso_ctx* ctx, const lasso_fr* d_table, const uint32_t* d_dim, const lasso_fr* d_read, size_t s, const lasso_fr* gamma, const lasso_fr* tau,
+                                       lasso_fr* d_upper_read, lasso_fr* d_upper_write);
+/* ... and the leaves recomputed for ONE strip set of the bottom layer, where its two streaming sumcheck rounds need them.  The layer's arrays are A = leaves[0 .. s/2),
+ * B = leaves[s/2 .. s).  A round on the index range [i0, i0 + cs) reads `nstrips` strips of each array, stride = s / 2 / nstrips apart (nstrips = 2: the layer's first round;
+ * 4: the second round, which binds); d_out_read / d_out_write (2 * nstrips * cs elements each) receive [A strips.., B strips..]:
+ *   out[(arr * nstrips + t) * cs + i] = leaf[arr * s/2 + t * stride + i0 + i],   arr in {0 (A), 1 (B)}, t < nstrips, i < cs,
+ * i.e. the arrays lasso_sumcheck_cubic_eqw2_begin takes as (A = out, B = out + nstrips * cs, n = nstrips * cs) with the eq table offset by i0.  Same bytes as
+ * lasso_fingerprint_ops at those positions.  i0 + cs <= stride. */
+int32_t lasso_fingerprint_ops_strips(lasso_ctx* ctx, const lasso_fr* d_table, const uint32_t* d_dim, const lasso_fr* d_read, size_t s, const lasso_fr* gamma, const lasso_fr* tau,
+                                     uint32_t nstrips, size_t i0, size_t cs, lasso_fr* d_out_read, lasso_fr* d_out_write);
 /* init/final sets (memory_checking.rs:254-273): d_init_out[i] = d_table[i]*gamma + i - tau, d_final_out[i] = d_init_out[i] + d_final[i]*gamma^2 */
 int32_t lasso_fingerprint_mem(lasso_ctx* ctx, const lasso_fr* d_table, const lasso_fr* d_final, size_t m,
                               const lasso_fr* gamma, const lasso_fr* tau, lasso_fr* d_init_out, lasso_fr* d_final_out);

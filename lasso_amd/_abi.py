@@ -69,6 +69,8 @@ def declare(lib):
         "lasso_gp_build": (i32, [vp, vp, sz]),
         "lasso_fingerprint_ops": (i32, [vp, vp, vp, vp, sz, vp, vp, vp, vp]),
         "lasso_fingerprint_ops_gp": (i32, [vp, vp, vp, vp, sz, vp, vp, vp, vp]),
+        "lasso_fingerprint_ops_gp_upper": (i32, [vp, vp, vp, vp, sz, vp, vp, vp, vp]),
+        "lasso_fingerprint_ops_strips": (i32, [vp, vp, vp, vp, sz, vp, vp, u32, sz, sz, vp, vp]),
         "lasso_fingerprint_mem": (i32, [vp, vp, vp, sz, vp, vp, vp, vp]),
         "lasso_fingerprint_mem_slab": (i32, [vp, vp, vp, sz, u32, u32, vp, vp, vp, vp]),
         "lasso_densify_dim_slab": (i32, [vp, vp, sz, sz, sz, sz, u32, u32, u32, vp, vp, vp, vp]),

@@ -958,6 +958,37 @@ int32_t lasso_fingerprint_ops_gp(lasso_ctx* c, const lasso_fr* d_table, const ui
   }
   HIPCHK(c, hipGetLastError()); return 0;
 }
+// Capacity mode: the two trees WITHOUT their leaf layers.  d_upper_r / d_upper_w: s - 2 (allocate s) elements each = the layers of s/2, s/4, .., 2 elements back to back, i.e.
+// what lasso_fingerprint_ops_gp leaves at d_tree + s.  The leaves exist only inside the launch (k_fingerprint_ops_l1 without its leaf stores).
+int32_t lasso_fingerprint_ops_gp_upper(lasso_ctx* c, const lasso_fr* d_table, const uint32_t* d_dim, const lasso_fr* d_read, size_t s, const lasso_fr* gamma, const lasso_fr* tau,
+                                       lasso_fr* d_upper_r, lasso_fr* d_upper_w) {
+  REQUIRE(c, d_table && d_dim && d_read && gamma && tau && d_upper_r && d_upper_w && s >= 4 && (s & (s - 1)) == 0);
+  fr_t g = to_fr(gamma), g2 = fr_sqr(g), t = to_fr(tau);
+  fr_t* ur = (fr_t*)d_upper_r; fr_t* uw = (fr_t*)d_upper_w;
+  {
+    ProfScope ps(c, LASSO_K_FINGERPRINT, (32.0 * 3 + 64.0) * s + 2 * 48.0 * s);   // the reference's bytes for the same step; the leaf stores are not made
+    hipLaunchKernelGGL(k_fingerprint_ops_l1, dim3(grid_for(s / 2, 4096)), dim3(LASSO_BLOCK), 0, c->stream, (const fr_t*)d_table, d_dim, (const fr_t*)d_read, s, g, g2, t, (fr_t*)nullptr, (fr_t*)nullptr, ur, uw, 0u);
+  }
+  {
+    ProfScope ps(c, LASSO_K_GP, 2 * 48.0 * s);
+    gp_layers_from(c, ur, s / 2);
+    gp_layers_from(c, uw, s / 2);
+  }
+  HIPCHK(c, hipGetLastError()); return 0;
+}
+// ... and the leaves of one strip set of the bottom layer, recomputed for a round on the index range [i0, i0 + cs) (k_fingerprint_ops_strips states the layout)
+int32_t lasso_fingerprint_ops_strips(lasso_ctx* c, const lasso_fr* d_table, const uint32_t* d_dim, const lasso_fr* d_read, size_t s, const lasso_fr* gamma, const lasso_fr* tau,
+                                     uint32_t nstrips, size_t i0, size_t cs, lasso_fr* d_out_r, lasso_fr* d_out_w) {
+  REQUIRE(c, d_table && d_dim && d_read && gamma && tau && d_out_r && d_out_w && s >= 4 && (s & (s - 1)) == 0 && (nstrips == 2 || nstrips == 4) && cs >= 1);
+  const size_t stride = s / 2 / nstrips;
+  REQUIRE(c, stride >= 1 && i0 + cs <= stride);
+  fr_t g = to_fr(gamma), g2 = fr_sqr(g), t = to_fr(tau);
+  const size_t total = 2 * (size_t)nstrips * cs;
+  ProfScope ps(c, LASSO_K_FINGERPRINT, (32.0 * 3 + 64.0) * total);
+  hipLaunchKernelGGL(k_fingerprint_ops_strips, dim3(grid_for(total, 4096)), dim3(LASSO_BLOCK), 0, c->stream, (const fr_t*)d_table, d_dim, (const fr_t*)d_read, s, g, g2, t, nstrips, stride, i0, cs,
+                     (fr_t*)d_out_r, (fr_t*)d_out_w);
+  HIPCHK(c, hipGetLastError()); return 0;
+}
 int32_t lasso_fingerprint_ops(lasso_ctx* c, const lasso_fr* d_table, const uint32_t* d_dim, const lasso_fr* d_read, size_t s, const lasso_fr* gamma, const lasso_fr* tau,
                               lasso_fr* d_read_out, lasso_fr* d_write_out) {
   REQUIRE(c, d_table && d_dim && d_read && gamma && tau && d_read_out && d_write_out); if (!s) return 0;

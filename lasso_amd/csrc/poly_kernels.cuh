@@ -1142,10 +1142,30 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_fingerprint_ops_l1(const fr_t* 
       fr29 h = fr29_add(fr29_mul(fr29_unpack_u(read[k]), g2s), fr29_mul(fr29_unpack_u(table[a]), gs));
       h = fr29_canonical(fr29_sub(fr29_add(h, fr29_mul(fr29_from_u64_int(a), r2s)), tu));
       lr[e] = fr29_pack(h); lw[e] = fr29_store(fr29_add(h, g2u));
-      if (store_leaves) { out_r[k] = lr[e]; out_w[k] = lw[e]; }   // 0 only in the timing experiment LASSO_EXP_NO_LEAF_STORE (what dropping the leaf arrays would save here)
+      if (store_leaves) { out_r[k] = lr[e]; out_w[k] = lw[e]; }   // 0: capacity mode's leafless trees (lasso_fingerprint_ops_gp_upper; out_r / out_w are then NULL), and the timing experiment LASSO_EXP_NO_LEAF_STORE
     }
     l1_r[i] = fr29_store(fr29_mul(fr29_unpack_u(lr[0]), fr29_unpack_s(lr[1])));
     l1_w[i] = fr29_store(fr29_mul(fr29_unpack_u(lw[0]), fr29_unpack_s(lw[1])));
+  }
+}
+// Capacity mode (trees kept without their leaf layer): the fingerprints of ONE strip set of the bottom layer, recomputed where the bottom layer's two streaming rounds need them.
+// The layer's A = leaves[0 .. s/2), B = leaves[s/2 .. s); a round on an index range [i0, i0 + cs) reads, of each array, `nstrips` strips `stride` apart (2 strips s/4 apart for
+// the first round, 4 strips s/8 apart for the bind-fused second round).  out_r / out_w (2 * nstrips * cs elements each) receive the mini-layer [A strips..., B strips...]:
+// element (arr * nstrips + t) * cs + i = leaf[arr * s/2 + t * stride + i0 + i] — exactly the arrays lasso_sumcheck_cubic_eqw2_begin takes with n = nstrips * cs.
+// Same arithmetic, same canonical bytes as k_fingerprint_ops.
+__global__ void __launch_bounds__(LASSO_BLOCK) k_fingerprint_ops_strips(const fr_t* __restrict__ table, const uint32_t* __restrict__ dim, const fr_t* __restrict__ read, size_t s,
+                                                                         fr_t gamma, fr_t gamma2, fr_t tau, uint32_t nstrips, size_t stride, size_t i0, size_t cs,
+                                                                         fr_t* __restrict__ out_r, fr_t* __restrict__ out_w) {
+  const fr29 gs = fr29_unpack_s(gamma), g2s = fr29_unpack_s(gamma2), g2u = fr29_unpack_u(gamma2), tu = fr29_unpack_u(tau), r2s = fr29_r2s();
+  const size_t total = 2 * (size_t)nstrips * cs;
+  for (size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x; j < total; j += (size_t)gridDim.x * blockDim.x) {
+    const size_t strip = j / cs, i = j - strip * cs, arr = strip / nstrips, t = strip - arr * nstrips;
+    const size_t k = arr * (s / 2) + t * stride + i0 + i;
+    const uint32_t a = dim[k];
+    fr29 h = fr29_add(fr29_mul(fr29_unpack_u(read[k]), g2s), fr29_mul(fr29_unpack_u(table[a]), gs));
+    h = fr29_canonical(fr29_sub(fr29_add(h, fr29_mul(fr29_from_u64_int(a), r2s)), tu));
+    out_r[j] = fr29_pack(h);
+    out_w[j] = fr29_store(fr29_add(h, g2u));
   }
 }
 // slab mode: local index i stands for global address a = i*world + rank; `table` is the whole subtable, `fin` and the outputs are local (m = local length)

@@ -252,6 +252,16 @@ class Device:
         g = np.ascontiguousarray(gamma, dtype=np.uint64); t = np.ascontiguousarray(tau, dtype=np.uint64)
         self._chk(self.lib.lasso_fingerprint_ops_gp(self.ctx, C.c_void_p(d_table), C.c_void_p(d_dim), C.c_void_p(d_read), s, _vp(g), _vp(t), C.c_void_p(d_tree_r), C.c_void_p(d_tree_w)))
 
+    def fingerprint_ops_gp_upper(self, d_table, d_dim, d_read, s, gamma, tau, d_upper_r, d_upper_w):
+        """capacity mode: both trees without their leaf layers (s - 2 elements each)"""
+        g = np.ascontiguousarray(gamma, dtype=np.uint64); t = np.ascontiguousarray(tau, dtype=np.uint64)
+        self._chk(self.lib.lasso_fingerprint_ops_gp_upper(self.ctx, C.c_void_p(d_table), C.c_void_p(d_dim), C.c_void_p(d_read), s, _vp(g), _vp(t), C.c_void_p(d_upper_r), C.c_void_p(d_upper_w)))
+
+    def fingerprint_ops_strips(self, d_table, d_dim, d_read, s, gamma, tau, nstrips, i0, cs, d_out_r, d_out_w):
+        """capacity mode: the leaves of one strip set of the bottom layer (2 * nstrips * cs elements per circuit)"""
+        g = np.ascontiguousarray(gamma, dtype=np.uint64); t = np.ascontiguousarray(tau, dtype=np.uint64)
+        self._chk(self.lib.lasso_fingerprint_ops_strips(self.ctx, C.c_void_p(d_table), C.c_void_p(d_dim), C.c_void_p(d_read), s, _vp(g), _vp(t), nstrips, i0, cs, C.c_void_p(d_out_r), C.c_void_p(d_out_w)))
+
     def fingerprint_mem(self, d_table, d_final, m, gamma, tau, d_io, d_fo):
         g = np.ascontiguousarray(gamma, dtype=np.uint64); t = np.ascontiguousarray(tau, dtype=np.uint64)
         self._chk(self.lib.lasso_fingerprint_mem(self.ctx, C.c_void_p(d_table), C.c_void_p(d_final), m, _vp(g), _vp(t), C.c_void_p(d_io), C.c_void_p(d_fo)))

@@ -795,6 +795,55 @@ class Prover {
     tail_bufs.clear();
     return proof;
   }
+  // ---- capacity mode: the bottom layer of the read / write trees without stored leaves.
+  // The trees of the operations (read, write) are kept from their layer of n/2 elements upwards (lasso_fingerprint_ops_gp_upper): half their bytes.  Only the bottom layer's
+  // sumcheck reads leaves, and only in its two streaming rounds — round 0 (sums over A, B) and round 1 (bind by the first challenge + sums); from round 2 on it works on the
+  // bound arrays, which go into the storage of the layer above (dead by then: the argument descends).  Those two rounds run chunk by chunk: the fingerprints of one index range
+  // are recomputed into a small mini-layer (lasso_fingerprint_ops_strips), the ordinary round kernel runs on it with the eq table offset to the range, and the host adds the
+  // chunks' sums (exact field additions: the same round polynomial).  Costs two extra fingerprint passes and 2 x kLeafChunks hand-offs; saves 7/8 of the leaf bytes.
+  struct LeafLayer {
+    struct Mem { const lasso_fr* table; const uint32_t* dim; const lasso_fr* read; };
+    std::vector<Mem> mems; lasso_fr gamma, tau; size_t n_loc = 0;    // circuits 2m (read) and 2m + 1 (write) of memory m, n_loc leaves each
+    std::vector<lasso_fr*> work_a, work_b;                          // the arrays bound by the first challenge (n_loc / 8 elements each)
+  };
+  static constexpr size_t kLeafChunks = 8;
+  // below this many leaves per circuit the trees are small and kept whole (LASSO_LEAFLESS_MIN: tests drive the chunked rounds at toy sizes; at least 64 so that a chunk holds an index)
+  static size_t leafless_min() { static const size_t v = [] { const char* e = getenv("LASSO_LEAFLESS_MIN"); const size_t x = e ? (size_t)atoll(e) : ((size_t)1 << 16); return x < 64 ? (size_t)64 : x; }(); return v; }
+  // round j in {0, 1} of the bottom layer from recomputed leaves; len = length of A and B (n_loc / 2); ev receives the 2k sums (q(0), q_inf per circuit)
+  void leaf_round(const LeafLayer& L, size_t j, size_t len, const lasso_fr* table, const lasso_fr* rp, std::vector<lasso_fr>& ev) {
+    HostClock hc("capacity: chunked leaf rounds");
+    const size_t k = 2 * L.mems.size(), nstrips = j == 0 ? 2 : 4, idx = len / nstrips, cs = idx / kLeafChunks;
+    LASSO_REQUIRE(len == L.n_loc / 2 && cs >= 1 && cs * kLeafChunks == idx && (j == 0) == (rp == nullptr));
+    const size_t per = 2 * nstrips * cs;     // mini-layer of one circuit: [A strips.., B strips..]
+    DBuf tmp(d, k * per);
+    std::vector<lasso_fr*> am(k), bm(k); for (size_t c = 0; c < k; c++) { am[c] = tmp.p + c * per; bm[c] = am[c] + nstrips * cs; }
+    std::vector<Sc> acc(2 * k, Sc::zero()); std::vector<lasso_fr> part(2 * k);
+    for (size_t ch = 0; ch < kLeafChunks; ch++) {
+      const size_t i0 = ch * cs;
+      for (size_t m = 0; m < L.mems.size(); m++)
+        d.chk(lasso_fingerprint_ops_strips(d.ctx, L.mems[m].table, L.mems[m].dim, L.mems[m].read, L.n_loc, &L.gamma, &L.tau, (uint32_t)nstrips, i0, cs, am[2 * m], am[2 * m + 1]), "lasso_fingerprint_ops_strips");
+      d.chk(lasso_sumcheck_cubic_eqw2_begin(d.ctx, am.data(), bm.data(), (uint32_t)k, table + i0, nstrips * cs, rp), "lasso_sumcheck_cubic_eqw2_begin");
+      d.chk(lasso_result_wait(d.ctx, part.data(), 2 * k), "lasso_result_wait");
+      for (size_t i = 0; i < 2 * k; i++) acc[i] += Sc::from_abi(part[i]);
+      if (j == 1) for (size_t c = 0; c < k; c++) {   // the bound halves go to their places in the (2 * idx)-element arrays the later rounds work on
+        d.chk(lasso_copy(d.ctx, L.work_a[c] + i0, am[c], cs * sizeof(lasso_fr)), "lasso_copy"); d.chk(lasso_copy(d.ctx, L.work_a[c] + idx + i0, am[c] + cs, cs * sizeof(lasso_fr)), "lasso_copy");
+        d.chk(lasso_copy(d.ctx, L.work_b[c] + i0, bm[c], cs * sizeof(lasso_fr)), "lasso_copy"); d.chk(lasso_copy(d.ctx, L.work_b[c] + idx + i0, bm[c] + cs, cs * sizeof(lasso_fr)), "lasso_copy");
+      }
+    }
+    ev.resize(2 * k); for (size_t i = 0; i < 2 * k; i++) ev[i] = acc[i].abi();
+  }
+  // the same layer's leaves in full (the rare paths of cubic_rounds — an eq coordinate of 0 or 1 among the first two — take the ordinary kernels): arrays of n_loc elements per circuit
+  std::vector<DBuf> leaf_materialise(const LeafLayer& L, std::vector<lasso_fr*>& A, std::vector<lasso_fr*>& B) {
+    HostClock hc("capacity: leaves materialised after all");
+    std::vector<DBuf> out; A.clear(); B.clear();
+    for (auto& m : L.mems) {
+      DBuf lr(d, L.n_loc), lw(d, L.n_loc);
+      d.chk(lasso_fingerprint_ops(d.ctx, m.table, m.dim, m.read, L.n_loc, &L.gamma, &L.tau, lr.p, lw.p), "lasso_fingerprint_ops");
+      A.push_back(lr.p); B.push_back(lr.p + L.n_loc / 2); A.push_back(lw.p); B.push_back(lw.p + L.n_loc / 2);
+      out.push_back(std::move(lr)); out.push_back(std::move(lw));
+    }
+    return out;
+  }
   // ---- SumcheckInstanceProof::prove_cubic_batched (sumcheck.rs:27-135), comb = A*B*C with C = EqPolynomial(rand).evals() (grand_product.rs:122-128).
   // Round j's bind (sumcheck.rs:116-120) is executed by the same kernel that evaluates round j+1, so a round is ONE launch.  The eq polynomial is
   // never bound or stored: after j binds it is  s_j * eq1(rand_j, x_top) * T_j  with T_j a scalar multiple of the PREFIX of the layer's table
@@ -803,9 +852,11 @@ class Prover {
   // One phase = `rounds` rounds on arrays of length len (>= 2 when rounds > 0) over the variables rand[v0 .. v0+rounds), ending with A and B bound by
   // the last challenge.  d_E: table whose first len/2^(j+1) entries are prod_{t<=j}(1 - rand[v0+t]) * T_j (the phase's eq table); s = running
   // prod eq1(rand_t, rho_t) over all rounds so far (all phases).
+  // leaf (capacity mode, bottom layer of the operations' trees): A and B do not exist — rounds 0 and 1 recompute them chunk by chunk (leaf_round) and the later rounds
+  // run on leaf->work_a / work_b
   void cubic_rounds(size_t rounds, size_t len, std::vector<lasso_fr*>& A, std::vector<lasso_fr*>& B, const lasso_fr* d_E, const ScVec& rand, size_t v0, const ScVec& coeffs, bool reduce, Sc& s_run,
-                    Sc& e, SumcheckProof& proof, ScVec& r_out, std::vector<lasso_fr>* heads_out = nullptr) {
-    const size_t k = A.size();
+                    Sc& e, SumcheckProof& proof, ScVec& r_out, std::vector<lasso_fr>* heads_out = nullptr, const LeafLayer* leaf = nullptr) {
+    const size_t k = leaf ? 2 * leaf->mems.size() : A.size();
     if (heads_out) heads_out->clear();
     if (!rounds) return;
     // 1 / prod_{t<=j}(1 - rand[v0+t]) for every round of the phase with one inversion; a zero factor (rand_t = 1) takes the explicit-table path
@@ -834,6 +885,12 @@ class Prover {
       if (plain) tail_from = j0;
     }
     bool in_tail = false;
+    std::vector<DBuf> leaf_full;   // the leaves after all, for the rare shapes the chunked rounds do not cover
+    if (leaf) {
+      static const bool three = [] { const char* v = getenv("LASSO_CUBIC_THREE_SUMS"); return v && v[0] == '1'; }();
+      const bool plain = v0 == 0 && !degenerate && !three && rounds >= 3 && tail_from >= 2 && !rand[0].is_zero() && !rand[1].is_zero() && !s_run.is_zero();
+      if (!plain) { leaf_full = leaf_materialise(*leaf, A, B); leaf = nullptr; }
+    }
     for (size_t j = 0; j < rounds; j++) {
       const lasso_fr* table = d_E; Sc scale = degenerate ? Sc::one() : inv[j];
       if (degenerate) {   // T_j = eq(rand[v0+j+1 .. v0+rounds)) built explicitly (size len / 2^(j+1) at this point), times the slab factor hidden in d_E[0] / eq-prefix
@@ -852,6 +909,12 @@ class Prover {
         // the same way) and q(2), q(3) by extrapolation.  The inversion of f(1) overlaps the kernel.
         lasso_fr rp = r_prev.abi();
         const uint32_t ell = (uint32_t)lz.rr.size();   // table of 2^ell = len / 2 entries
+        std::vector<lasso_fr> ev(2 * k); bool have_ev = false;
+        if (leaf && j < 2) {   // capacity mode: this round's A and B are recomputed chunk by chunk; after round 1 the bound arrays are the working arrays
+          ensure_table();
+          leaf_round(*leaf, j, len, table, j ? &rp : nullptr, ev); have_ev = true;
+          if (j == 1) { A = leaf->work_a; B = leaf->work_b; }
+        } else
         if (j == 0 && lz.on && j < tail_from && ell <= 14 && len / 2 > 64) {   // round 0 of a streaming layer: the table is built in this launch and left in d_E for the later rounds
           d.chk(lasso_sumcheck_cubic_eqw2_begin_eq(d.ctx, A.data(), B.data(), (uint32_t)k, lz.d_table, len, lz.rr.data(), ell, &lz.scale), "lasso_sumcheck_cubic_eqw2_begin_eq"); lz.on = false;
         } else if (j == 0 && lz.on && j >= tail_from && ell <= 9) {            // the whole layer runs in the resident kernel: no table at all
@@ -865,8 +928,7 @@ class Prover {
         if (j) len /= 2;
         // f(1) = 0 inside the tail can only come from a vanished running factor s (probability 2^-252): then f = 0 identically and q is irrelevant
         const Sc f1_inv = f1.is_zero() ? Sc::zero() : f1.inverse();
-        std::vector<lasso_fr> ev(2 * k);
-        d.chk(lasso_result_wait(d.ctx, ev.data(), 2 * k), "lasso_result_wait");
+        if (!have_ev) d.chk(lasso_result_wait(d.ctx, ev.data(), 2 * k), "lasso_result_wait");
         if (reduce) d.comm.sum(ev);
         HostClock hc("cubic round host work");
         Sc q0 = Sc::zero(), qi = Sc::zero();
@@ -914,17 +976,17 @@ class Prover {
   }
   // A, B: local arrays of length 2^num_rounds / P (slab mode) or the whole arrays; d_E = the layer's eq table over `rand` (local share in slab mode)
   SumcheckProof prove_cubic_batched(const Sc& claim, size_t num_rounds, bool slab, std::vector<lasso_fr*>& A, std::vector<lasso_fr*>& B, const lasso_fr* d_E, const ScVec& rand, const ScVec& coeffs,
-                                    ScVec& r_out, ScVec& claims_a, ScVec& claims_b) {
-    SumcheckProof proof; Sc e = claim, s_run = Sc::one(); const size_t k = A.size();
+                                    ScVec& r_out, ScVec& claims_a, ScVec& claims_b, const LeafLayer* leaf = nullptr) {
+    SumcheckProof proof; Sc e = claim, s_run = Sc::one(); const size_t k = leaf ? 2 * leaf->mems.size() : A.size();
     LASSO_REQUIRE(rand.size() == num_rounds);
     std::vector<lasso_fr*> fa(A), fb(B);   // where the final values end up
     std::vector<lasso_fr> heads;            // ... unless the resident tail kernel hands them back directly
     if (!slab) {
-      cubic_rounds(num_rounds, (size_t)1 << num_rounds, fa, fb, d_E, rand, 0, coeffs, false, s_run, e, proof, r_out, &heads);
+      cubic_rounds(num_rounds, (size_t)1 << num_rounds, fa, fb, d_E, rand, 0, coeffs, false, s_run, e, proof, r_out, &heads, leaf);
     } else {
       LASSO_REQUIRE(num_rounds >= lgP);
       const size_t local_rounds = num_rounds - lgP;
-      cubic_rounds(local_rounds, (size_t)1 << local_rounds, fa, fb, d_E, rand, 0, coeffs, true, s_run, e, proof, r_out);
+      cubic_rounds(local_rounds, (size_t)1 << local_rounds, fa, fb, d_E, rand, 0, coeffs, true, s_run, e, proof, r_out, nullptr, leaf);
       std::vector<lasso_fr*> local_heads(fa); local_heads.insert(local_heads.end(), fb.begin(), fb.end());
       std::vector<lasso_fr*> tail = gather_tail(local_heads);
       fa.assign(tail.begin(), tail.begin() + k); fb.assign(tail.begin() + k, tail.begin() + 2 * k);
@@ -948,7 +1010,9 @@ class Prover {
   // trees[c]: product tree of n_loc leaves (2*n_loc - 2 elements: layer k at offset n_loc*(2 - 2^(1-k))); in slab mode n_loc = n / P and the tree is the
   // rank's residue class of the global tree down to the global layer of 2P elements; the global layers of P, P/2, .., 2 elements are replicated in tops[c]
   // (P elements = the ranks' local roots, then their product tree).
-  BatchedGrandProductArgument bgpa_prove(std::vector<lasso_fr*>& trees, std::vector<lasso_fr*>& tops, size_t n, const ScVec& roots, ScVec& rand_out) {
+  // leaf (capacity mode): trees[c] holds the layers ABOVE the leaves only (n_loc - 2 elements: layer k >= 1 at offset n_loc * (1 - 2^(1-k))); the bottom layer's
+  // arrays are recomputed by cubic_rounds from *leaf, whose work_a / work_b this function points at the (by then dead) storage of layer 1
+  BatchedGrandProductArgument bgpa_prove(std::vector<lasso_fr*>& trees, std::vector<lasso_fr*>& tops, size_t n, const ScVec& roots, ScVec& rand_out, LeafLayer* leaf = nullptr) {
     Trace tr("BatchedGrandProductArgument.prove", d.ctx);
     BatchedGrandProductArgument out; const size_t k = trees.size(), num_layers = ceil_log2(n), n_loc = n / P;
     ScVec claims_to_verify = roots, rand;
@@ -959,8 +1023,14 @@ class Prover {
       const size_t num_rounds_prod = ceil_log2(len / 2);
       const bool slab = P > 1 && len >= 2 * P;              // this layer lives in the local trees; smaller ones in the replicated tops
       std::vector<lasso_fr*> A, B;
-      if (slab || P == 1) {
-        const size_t len_l = len / P, off = 2 * n_loc - 2 * len_l;
+      const bool bottom_leafless = leaf && layer_id == 0;
+      if (bottom_leafless) {
+        // layer 1's storage (n_loc / 2 elements, at the start of the leafless arena) is dead: layer 1's sumcheck is over.  It receives the bound arrays A', B' (n_loc / 4 each).
+        leaf->work_a.clear(); leaf->work_b.clear();
+        for (auto* tr : trees) { leaf->work_a.push_back(tr); leaf->work_b.push_back(tr + n_loc / 4); }
+        if (eq_inline_off()) eq_half_local(rand, eq.p); else eq_half_lazy(rand, eq.p);
+      } else if (slab || P == 1) {
+        const size_t len_l = len / P, off = 2 * n_loc - 2 * len_l - (leaf ? n_loc : 0);
         for (auto* tr : trees) { A.push_back(tr + off); B.push_back(tr + off + len_l / 2); }
         if (eq_inline_off()) eq_half_local(rand, eq.p); else eq_half_lazy(rand, eq.p);        // poly_C_par :122 (the half the rounds read), built inside round 0's launch where possible
       } else {
@@ -972,7 +1042,7 @@ class Prover {
       ScVec coeff_vec = t.challenge_vector("rand_coeffs_next_layer", claims_to_verify.size());
       Sc claim = Sc::zero(); for (size_t i = 0; i < claims_to_verify.size(); i++) claim += claims_to_verify[i] * coeff_vec[i];
       LayerProofBatched lp; ScVec rand_prod;
-      lp.proof = prove_cubic_batched(claim, num_rounds_prod, slab, A, B, eq.p, rand, coeff_vec, rand_prod, lp.claims_prod_left, lp.claims_prod_right);
+      lp.proof = prove_cubic_batched(claim, num_rounds_prod, slab, A, B, eq.p, rand, coeff_vec, rand_prod, lp.claims_prod_left, lp.claims_prod_right, bottom_leafless ? leaf : nullptr);
       for (size_t i = 0; i < k; i++) { t.append_scalar("claim_prod_left", lp.claims_prod_left[i]); t.append_scalar("claim_prod_right", lp.claims_prod_right[i]); }
       Sc r_layer = t.challenge_scalar("challenge_r_layer");
       claims_to_verify.clear();
@@ -1299,12 +1369,18 @@ class Prover {
     lasso_fr g = gamma.abi(), ta = tau.abi();
     std::unique_ptr<Trace> sp(new Trace("Subtables.to_grand_products", d.ctx));
     std::vector<DBuf> t_init, t_read, t_write, t_final;
+    // capacity mode: the read / write trees without their leaf layers (half of each tree); the bottom layer's sumcheck recomputes the fingerprints (LeafLayer above)
+    const bool leafless = d.capacity && s_loc >= leafless_min();
+    LeafLayer leaf; leaf.gamma = g; leaf.tau = ta; leaf.n_loc = s_loc;
     for (size_t i = 0; i < alpha; i++) {
       size_t j = S.memory_to_dimension_index(i); const lasso_fr* table = tables[S.memory_to_subtable_index(i)].p;
-      DBuf ti(d, 2 * m_loc), tf(d, 2 * m_loc), tr(d, 2 * s_loc), tw(d, 2 * s_loc);
+      DBuf ti(d, 2 * m_loc), tf(d, 2 * m_loc), tr(d, leafless ? s_loc : 2 * s_loc), tw(d, leafless ? s_loc : 2 * s_loc);
       d.chk(lasso_fingerprint_mem_slab(d.ctx, table, dense.final_(j), m_loc, (uint32_t)P, (uint32_t)d.comm.rank, &g, &ta, ti.p, tf.p), "lasso_fingerprint_mem");
       d.chk(lasso_gp_build(d.ctx, ti.p, m_loc), "lasso_gp_build"); d.chk(lasso_gp_build(d.ctx, tf.p, m_loc), "lasso_gp_build");
-      if (s_loc >= 4) {   // read / write leaves and both trees in one call: the first product layer is taken while the leaves are in registers (no re-read of 2 x 32 s bytes)
+      if (leafless) {
+        d.chk(lasso_fingerprint_ops_gp_upper(d.ctx, table, dense.dim_u32[j].p, dense.read(j), s_loc, &g, &ta, tr.p, tw.p), "lasso_fingerprint_ops_gp_upper");
+        leaf.mems.push_back({table, dense.dim_u32[j].p, dense.read(j)});
+      } else if (s_loc >= 4) {   // read / write leaves and both trees in one call: the first product layer is taken while the leaves are in registers (no re-read of 2 x 32 s bytes)
         d.chk(lasso_fingerprint_ops_gp(d.ctx, table, dense.dim_u32[j].p, dense.read(j), s_loc, &g, &ta, tr.p, tw.p), "lasso_fingerprint_ops_gp");
       } else {
         d.chk(lasso_fingerprint_ops(d.ctx, table, dense.dim_u32[j].p, dense.read(j), s_loc, &g, &ta, tr.p, tw.p), "lasso_fingerprint_ops");
@@ -1318,8 +1394,8 @@ class Prover {
     // GrandProductCircuit::evaluate = product of the last layer's two elements; in slab mode that is the rank's LOCAL root, i.e. element `rank` of the
     // global layer of P elements: the roots are all-gathered, the global layers P, P/2, .., 2 are built from them (replicated) and the hash is the top product
     std::vector<DBuf> tops_store;
-    auto root_and_top = [&](const DBuf& tree, size_t n_loc, lasso_fr*& top_out) {
-      lasso_fr two[2]; const lasso_fr* last[2] = {tree.p + (2 * n_loc - 4), tree.p + (2 * n_loc - 3)};
+    auto root_and_top = [&](const DBuf& tree, size_t n_loc, lasso_fr*& top_out, size_t missing = 0) {   // missing: elements the arena lacks in front (a leafless tree: n_loc)
+      lasso_fr two[2]; const lasso_fr* last[2] = {tree.p + (2 * n_loc - 4 - missing), tree.p + (2 * n_loc - 3 - missing)};
       d.chk(lasso_read_heads(d.ctx, last, 2, two), "lasso_read_heads");   // through the mapped result buffer: no memcpy, no stream synchronisation
       Sc local = Sc::from_abi(two[0]) * Sc::from_abi(two[1]);
       top_out = nullptr;
@@ -1337,7 +1413,8 @@ class Prover {
     std::vector<lasso_fr*> rw, inf, rw_top, inf_top;
     for (size_t i = 0; i < alpha; i++) {
       lasso_fr *ti_top, *tr_top, *tw_top, *tf_top;
-      Sc hi = root_and_top(t_init[i], m_loc, ti_top), hr = root_and_top(t_read[i], s_loc, tr_top), hw = root_and_top(t_write[i], s_loc, tw_top), hf = root_and_top(t_final[i], m_loc, tf_top);
+      const size_t lm = leafless ? s_loc : 0;
+      Sc hi = root_and_top(t_init[i], m_loc, ti_top), hr = root_and_top(t_read[i], s_loc, tr_top, lm), hw = root_and_top(t_write[i], s_loc, tw_top, lm), hf = root_and_top(t_final[i], m_loc, tf_top);
       if (!(hi * hw == hr * hf)) throw Error("memory checking: hash_init * hash_write != hash_read * hash_final (memory_checking.rs:689)");
       t.append_scalar("claim_hash_init", hi); t.append_scalar("claim_hash_read", hr); t.append_scalar("claim_hash_write", hw); t.append_scalar("claim_hash_final", hf);
       W.sc(hi); W.sc(hr); W.sc(hw); W.sc(hf);
@@ -1346,7 +1423,7 @@ class Prover {
       rw_top.push_back(tr_top); rw_top.push_back(tw_top); inf_top.push_back(ti_top); inf_top.push_back(tf_top);
     }
     ScVec rand_ops, rand_mem;
-    BatchedGrandProductArgument proof_ops = bgpa_prove(rw, rw_top, s, roots_rw, rand_ops);
+    BatchedGrandProductArgument proof_ops = bgpa_prove(rw, rw_top, s, roots_rw, rand_ops, leafless ? &leaf : nullptr);
     t_read.clear(); t_write.clear();
     // Everything HashLayerProof needs at rand_ops that does not depend on the transcript — the evaluations of E / dim / read (one pass over all of
     // them) and the big mat-vecs of the two openings at rand_ops — starts now on the side context and runs under the second grand-product

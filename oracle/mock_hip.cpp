@@ -322,6 +322,25 @@ int32_t lasso_fingerprint_ops_gp(lasso_ctx* c, const lasso_fr* table, const uint
   rc = lasso_gp_build(c, tr, s); if (rc) return rc;
   return lasso_gp_build(c, tw, s);
 }
+// capacity mode: the literal steps into temporaries, then the layers above the leaves / the requested strips
+int32_t lasso_fingerprint_ops_gp_upper(lasso_ctx* c, const lasso_fr* table, const uint32_t* dim, const lasso_fr* read, size_t s, const lasso_fr* gamma, const lasso_fr* tau, lasso_fr* ur, lasso_fr* uw) {
+  REQ(c, s >= 4 && (s & (s - 1)) == 0);
+  std::vector<lasso_fr> tr(2 * s), tw(2 * s);
+  int32_t rc = lasso_fingerprint_ops_gp(c, table, dim, read, s, gamma, tau, tr.data(), tw.data()); if (rc) return rc;
+  memcpy(ur, tr.data() + s, (s - 2) * 32); memcpy(uw, tw.data() + s, (s - 2) * 32); return 0;
+}
+int32_t lasso_fingerprint_ops_strips(lasso_ctx* c, const lasso_fr* table, const uint32_t* dim, const lasso_fr* read, size_t s, const lasso_fr* gamma, const lasso_fr* tau,
+                                     uint32_t nstrips, size_t i0, size_t cs, lasso_fr* out_r, lasso_fr* out_w) {
+  REQ(c, s >= 4 && (s & (s - 1)) == 0 && (nstrips == 2 || nstrips == 4) && cs >= 1 && i0 + cs <= s / 2 / nstrips);
+  std::vector<lasso_fr> lr(s), lw(s);
+  int32_t rc = lasso_fingerprint_ops(c, table, dim, read, s, gamma, tau, lr.data(), lw.data()); if (rc) return rc;
+  const size_t stride = s / 2 / nstrips;
+  for (size_t arr = 0; arr < 2; arr++) for (size_t t = 0; t < nstrips; t++) for (size_t i = 0; i < cs; i++) {
+    const size_t k = arr * (s / 2) + t * stride + i0 + i, j = (arr * nstrips + t) * cs + i;
+    out_r[j] = lr[k]; out_w[j] = lw[k];
+  }
+  return 0;
+}
 int32_t lasso_fingerprint_mem(lasso_ctx*, const lasso_fr* table, const lasso_fr* fin, size_t m, const lasso_fr* gamma, const lasso_fr* tau, lasso_fr* io, lasso_fr* fo) {
   Fr g = *F(gamma), g2 = g.square(), t = *F(tau);
   for (size_t i = 0; i < m; i++) {  // memory_checking.rs:257-273

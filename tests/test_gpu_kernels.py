@@ -312,6 +312,53 @@ def test_fingerprint_ops_gp_fused(devs, s, log_m):
         assert np.array_equal(x, y)                                             # device == mock (the reference's loops)
 
 
+@pytest.mark.parametrize("s,log_m", [(4, 2), (64, 4), (1 << 12, 8), (1 << 16, 16)])
+def test_fingerprint_leafless_trees_and_strips(devs, s, log_m):
+    """capacity mode's two entry points: lasso_fingerprint_ops_gp_upper == the layers above the leaves of lasso_fingerprint_ops_gp's trees, and lasso_fingerprint_ops_strips
+    == the leaves at the positions a chunked round reads (2 strips s/4 apart for the first round, 4 strips s/8 apart for the second), on the device and against the mock"""
+    rng = np.random.default_rng(s * 3 + log_m)
+    m = 1 << log_m
+    table = rand_fr(rng, m); read = small_fr(rng.integers(0, 1 << 20, size=s, dtype=np.uint64))
+    dim = rng.integers(0, m, size=s, dtype=np.uint32); dim[-1] = m - 1
+    gamma, tau = rand_fr(rng, 2, edge=False)
+    picks = []      # (nstrips, i0, cs)
+    for nstrips in (2, 4):
+        stride = s // 2 // nstrips
+        if stride >= 1:
+            picks.append((nstrips, 0, stride))
+            if stride >= 8:
+                picks += [(nstrips, stride // 8 * 3, stride // 8), (nstrips, stride - 1, 1)]
+
+    def run(d):
+        pt = d.upload(table); pd = d.upload(dim); pr = d.upload(read)
+        tr = d.alloc(64 * s); tw = d.alloc(64 * s); ur = d.alloc(32 * s); uw = d.alloc(32 * s)
+        d.fingerprint_ops_gp(pt, pd, pr, s, gamma, tau, tr, tw)
+        d.fingerprint_ops_gp_upper(pt, pd, pr, s, gamma, tau, ur, uw)
+        full = [d.download(p, (2 * s, 4))[: 2 * s - 2] for p in (tr, tw)]
+        upper = [d.download(p, (s, 4))[: s - 2] for p in (ur, uw)]
+        strips = []
+        for nstrips, i0, cs in picks:
+            n = 2 * nstrips * cs
+            o_r = d.alloc(32 * n); o_w = d.alloc(32 * n)
+            d.fingerprint_ops_strips(pt, pd, pr, s, gamma, tau, nstrips, i0, cs, o_r, o_w)
+            strips.append((d.download(o_r, (n, 4)), d.download(o_w, (n, 4))))
+            d.free(o_r); d.free(o_w)
+        for p in (pt, pd, pr, tr, tw, ur, uw):
+            d.free(p)
+        return full, upper, strips
+    (full, upper, strips), (mfull, mupper, mstrips) = both(devs, run)
+    for c in range(2):
+        assert np.array_equal(upper[c], full[c][s:]) and np.array_equal(upper[c], mupper[c])
+    for (nstrips, i0, cs), got, want in zip(picks, strips, mstrips):
+        stride = s // 2 // nstrips
+        for c in range(2):
+            assert np.array_equal(got[c], want[c])
+            for arr in range(2):
+                for t in range(nstrips):
+                    k0 = arr * (s // 2) + t * stride + i0
+                    assert np.array_equal(got[c][(arr * nstrips + t) * cs:(arr * nstrips + t + 1) * cs], full[c][k0:k0 + cs])
+
+
 @pytest.mark.parametrize("ls,rs", [(1, 1), (2, 4), (32, 64), (64, 300), (512, 1024)])
 def test_matvec_left(devs, ls, rs):
     rng = np.random.default_rng(ls * 1000 + rs)
