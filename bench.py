@@ -332,20 +332,21 @@ def bind_top_sweep(dev_lib, ctx, _abi, curve, iterations=20, warmup=3):
     return out
 
 
-def slab_units(kind, c):
+def slab_units(kind, c, capacity=False):
     """Per-rank device footprint of ONE proof in slab mode, in units of (s / P) field elements of 32 bytes, from the prover's allocation schedule (lasso_amd/host/prover.hpp;
     DESIGN 5 holds the measured table this is checked against): the two merged committed polynomials dim|read (2C, padded to a power of two) and E (alpha, padded), dim as u32
     (C / 8), the eq table of r and the chi table (2), the primary sumcheck's work arrays (alpha / 2; alpha for LT's clones), and — the peak — the read / write product trees
-    (2 per tree, 4 alpha) with the layer's eq table (1/4).  The M-sized polynomials, generator tables and scratch are the constant term."""
+    (2 per tree, 4 alpha) with the layer's eq table (1/4).  Capacity mode (lasso_host_set_capacity) keeps those trees without their leaf layers: 2 alpha, plus the mini-layers
+    of the chunked leaf rounds (2 alpha / 8).  The M-sized polynomials, generator tables and scratch are the constant term (slab_bytes_per_rank)."""
     alpha = 2 * c if kind == "lt" else c
     p2 = lambda x: 1 << (x - 1).bit_length()
     committed = p2(2 * c) + p2(alpha) + c / 8.0
     sumcheck_peak = committed + 2 + (alpha if kind == "lt" else alpha / 2.0)
-    trees_peak = committed + 2 + 4 * alpha + 0.25
+    trees_peak = committed + 2 + (2 * alpha + alpha / 4.0 if capacity else 4 * alpha) + 0.25
     return max(sumcheck_peak, trees_peak)
 
 
-def slab_bytes_per_rank(kind, c, log_s, world, log_m=16):
+def slab_bytes_per_rank(kind, c, log_s, world, log_m=16, capacity=False):
     """slab_units x (s / P) x 32 bytes + the constant term: the generator tables (per generator 64 window entries + 512 digit multiples of 112 bytes; the rank's residue class
     again as its slab table; 2 x 255 byte multiples for the commitments' table, of the rank's class only when P > 1) over the three Hyrax widths, and ~1.5 GB of scratch.
     Checked against lasso_mem_stats at configs[3], P = 1, 2, 4, 8 (profiles/r04_slab_peak_bytes.json)."""
@@ -354,7 +355,7 @@ def slab_bytes_per_rank(kind, c, log_s, world, log_m=16):
     width = lambda n_elems: 1 << ((n_elems.bit_length() - 1) - (n_elems.bit_length() - 1) // 2)      # R = 2^(nv - nv / 2), eq_poly.rs:40-42
     r_l, r_e, r_m = width(p2(2 * c) << log_s), width(p2(alpha) << log_s), width(p2(c) << log_m)
     fixed = 576 * 112 * (r_l + r_e + r_m) * (1 + (1.0 / world if world > 1 else 0)) + 2 * 255 * 112 * (r_l + r_e) / world + 1.5e9
-    return slab_units(kind, c) * ((1 << log_s) / world) * 32 + fixed
+    return slab_units(kind, c, capacity) * ((1 << log_s) / world) * 32 + fixed
 
 
 def slab_worker(a):
@@ -389,7 +390,7 @@ def slab_worker(a):
            "n_gpus": world, "scaling": "strong", "ms_per_proof": el * 1e3, "value": s / el, "unit": "lookups/s", "steps": a.slab_steps,
            "rccl_ranks": int(rccl), "exchange": ("per-round sums: shared-memory all-gather (lasso_amd/host/shm_comm.hpp); partial row commitments: " +
                                                   ("RCCL ncclAllGather on the library's stream + device-side row sums" if rccl == world and world > 1 else "shared-memory all-gather + host row sums")) if world > 1 else "none (single GPU)",
-           "peak_bytes_per_rank": mem["peak_bytes"], "prover_peak_bytes_per_rank": mem["prover_peak_bytes"], "model_bytes_per_rank": int(slab_bytes_per_rank(kind, c, log_s, world, log_m)),
+           "peak_bytes_per_rank": mem["peak_bytes"], "prover_peak_bytes_per_rank": mem["prover_peak_bytes"], "model_bytes_per_rank": int(slab_bytes_per_rank(kind, c, log_s, world, log_m, bool(a.slab_capacity))),
            "capacity_mode": bool(a.slab_capacity),
            "setup_s": round(t_setup, 2), "proof_bytes": len(proof), "proof_sha256": hashlib.sha256(proof).hexdigest(), "commitment_sha256": hashlib.sha256(comm).hexdigest()}
     gold = golden_digest(kind, c, log_m, S.log_r, log_s)
@@ -411,9 +412,13 @@ def slab_leg(a, grp, shm_name):
     rank, world = grp.rank, grp.world
     kind, c, log_s = a.slab_kind, a.slab_c, a.slab_log_s
     alpha = 2 * c if kind == "lt" else c
-    need = slab_bytes_per_rank(kind, c, log_s, world, a.log_m)
-    if need > 250e9:      # 288 GB of HBM3E per GPU; the model is the prover's allocation schedule (slab_units), checked against lasso_mem_stats in DESIGN 5
-        return {"skipped": f"{kind} C={c} 2^{log_s} needs ~{need / 1e9:.0f} GB per rank on {world} GPU(s)", "model_bytes_per_rank": int(need)}
+    # 288 GB of HBM3E per GPU, 200 GB budgeted per rank; the model is the prover's allocation schedule (slab_units), checked against lasso_mem_stats at configs[3] for
+    # P = 1, 2, 4, 8 (profiles/r04_slab_peak_bytes.json).  A shape that only fits without the trees' leaf layers runs in capacity mode.
+    need = slab_bytes_per_rank(kind, c, log_s, world, a.log_m, a.slab_capacity)
+    if need > 200e9 and not a.slab_capacity and slab_bytes_per_rank(kind, c, log_s, world, a.log_m, True) <= 200e9:
+        a.slab_capacity = True; need = slab_bytes_per_rank(kind, c, log_s, world, a.log_m, True)
+    if need > 200e9:
+        return {"skipped": f"{kind} C={c} 2^{log_s} needs ~{need / 1e9:.0f} GB per rank on {world} GPU(s) even in capacity mode", "model_bytes_per_rank": int(need)}
     cmd = [sys.executable, os.path.abspath(__file__), "--slab-worker", f"{rank},{world},{grp.device_index},{shm_name}_slab", "--slab-kind", kind, "--slab-c", str(c),
            "--slab-log-s", str(log_s), "--slab-steps", str(a.slab_steps), "--log-m", str(a.log_m), "--log-r", str(a.log_r), "--curve", a.curve] + (["--slab-capacity"] if a.slab_capacity else [])
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}   # the child is not a torch.distributed rank

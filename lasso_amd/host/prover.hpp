@@ -1371,6 +1371,7 @@ class Prover {
     std::vector<DBuf> t_init, t_read, t_write, t_final;
     // capacity mode: the read / write trees without their leaf layers (half of each tree); the bottom layer's sumcheck recomputes the fingerprints (LeafLayer above)
     const bool leafless = d.capacity && s_loc >= leafless_min();
+    if (d.capacity) d.trim();   // what the earlier phases parked in the recycling pool (the primary sumcheck's work arrays: no later buffer has their size) goes back before the peak
     LeafLayer leaf; leaf.gamma = g; leaf.tau = ta; leaf.n_loc = s_loc;
     for (size_t i = 0; i < alpha; i++) {
       size_t j = S.memory_to_dimension_index(i); const lasso_fr* table = tables[S.memory_to_subtable_index(i)].p;

@@ -41,14 +41,15 @@ def main():
                 rows.append({"world": w, "mode": mode, "error": str(e)[:300]}); continue
             row = {"world": w, "mode": mode, "peak_bytes_per_rank": max(info["peak_bytes_per_rank"]), "prover_peak_bytes_per_rank": max(info["prover_peak_bytes_per_rank"]),
                    "sum_over_ranks_GiB": round(sum(info["peak_bytes_per_rank"]) / 2**30, 2), "ms_per_proof": round(info["ms_per_proof"], 2),
-                   "model_bytes_per_rank": int(bench.slab_bytes_per_rank(a.kind, a.c, a.log_s, w, a.log_m)), "proof_sha256": hashlib.sha256(proof).hexdigest()}
+                   "model_bytes_per_rank": int(bench.slab_bytes_per_rank(a.kind, a.c, a.log_s, w, a.log_m, mode == "capacity")), "proof_sha256": hashlib.sha256(proof).hexdigest()}
             row["peak_GiB_per_rank"] = round(row["peak_bytes_per_rank"] / 2**30, 2); row["model_over_measured"] = round(row["model_bytes_per_rank"] / row["peak_bytes_per_rank"], 3)
             if gold:
                 row["parity"] = row["proof_sha256"] == gold["proof_sha256"] and hashlib.sha256(comm).hexdigest() == gold["commitment_sha256"]
             rows.append(row)
             print(json.dumps(row), flush=True)
     out = {"workload": f"{a.kind.upper()} C={a.c} M=2^{a.log_m} s=2^{a.log_s}, ONE proof over P contexts of one MI355X (slab mode, lasso_host_set_comm_shm)", "rows": rows,
-           "extrapolation_C16_2p28_world8": {k: {"bytes_per_rank": int(bench.slab_bytes_per_rank(k, 16, 28, 8)), "units_of_s_over_P": bench.slab_units(k, 16)} for k in ("and", "lt")}}
+           "extrapolation_C16_2p28_world8": {f"{k}{'_capacity' if cap else ''}": {"bytes_per_rank": int(bench.slab_bytes_per_rank(k, 16, 28, 8, 16, cap)), "units_of_s_over_P": bench.slab_units(k, 16, cap)}
+                                             for k in ("and", "lt") for cap in (False, True)}}
     print(json.dumps(out))
     if a.out:
         with open(a.out, "w") as f:
