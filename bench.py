@@ -41,7 +41,7 @@ def parse():
     p.add_argument("--warmup", type=int, default=1)
     p.add_argument("--log-s", type=int, default=24, help="log2 of lookups per proof (default 24 = the headline metric)")
     p.add_argument("--c", type=int, default=1)
-    p.add_argument("--kind", default="and", choices=["and", "or", "xor", "lt", "range"])
+    p.add_argument("--kind", default="and", choices=["and", "or", "xor", "lt", "range", "spark"], help="\"spark\" = LASSO_SPARK_UNCONFIRMED: BASELINE.json configs[4]'s strategy as SURVEY 8(f3) describes it (not in the reference snapshot)")
     p.add_argument("--log-m", type=int, default=16)
     p.add_argument("--log-r", type=int, default=40)
     p.add_argument("--cpu-log-s", type=int, default=24, help="log2 lookups of the CPU-baseline instance, proved by the oracle on all host cores (2^24 = the metric's own size)")
@@ -56,7 +56,7 @@ def parse():
                                                                               "code path be exercised on a box with fewer GPUs than ranks (ranks share devices)")
     p.add_argument("--shard-proof", action="store_true", help="N > 1: ONE proof of s lookups sharded over the N GPUs by low index bits (slab mode, strong scaling) "
                                                                 "instead of one independent proof per GPU (the default, weak scaling)")
-    p.add_argument("--slab-kind", default="range", choices=["and", "or", "xor", "lt", "range"], help="the extra slab-mode leg's workload: by default BASELINE.json configs[3], "
+    p.add_argument("--slab-kind", default="range", choices=["and", "or", "xor", "lt", "range", "spark"], help="the extra slab-mode leg's workload: by default BASELINE.json configs[3], "
                                                                                                        "RangeCheck C=4 2^26 (the configuration the north star shards over several GPUs)")
     p.add_argument("--slab-c", type=int, default=4)
     p.add_argument("--slab-log-s", type=int, default=26)
@@ -341,7 +341,7 @@ def slab_units(kind, c, capacity=False):
     alpha = 2 * c if kind == "lt" else c
     p2 = lambda x: 1 << (x - 1).bit_length()
     committed = p2(2 * c) + p2(alpha) + c / 8.0
-    sumcheck_peak = committed + 2 + (alpha if kind == "lt" else alpha / 2.0)
+    sumcheck_peak = committed + 2 + (alpha if kind in ("lt", "spark") else alpha / 2.0)     # LT and Spark bind clones of all their polynomials
     trees_peak = committed + 2 + (2 * alpha + alpha / 4.0 if capacity else 4 * alpha) + 0.25
     return max(sumcheck_peak, trees_peak)
 

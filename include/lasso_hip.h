@@ -49,7 +49,12 @@ typedef struct { uint64_t x[4], y[4], t[4], z[4]; } lasso_point;
 enum lasso_status { LASSO_OK = 0, LASSO_ERR_INVALID = -1, LASSO_ERR_OOM = -2, LASSO_ERR_HIP = -3, LASSO_ERR_UNSUPPORTED = -4 };
 
 /* src/subtables/{and,or,xor,lt,range_check}.rs — the table plug-in (`SubtableStrategy`) as a runtime descriptor */
-enum lasso_strategy_kind { LASSO_AND = 0, LASSO_OR = 1, LASSO_XOR = 2, LASSO_LT = 3, LASSO_RANGE = 4 };
+enum lasso_strategy_kind { LASSO_AND = 0, LASSO_OR = 1, LASSO_XOR = 2, LASSO_LT = 3, LASSO_RANGE = 4,
+  /* NOT in the reference snapshot (src/subtables/mod.rs:22-26): BASELINE.json configs[4] names a "SparkSubtableStrategy"; upstream Lasso's history had one — subtable i =
+   * EqPolynomial(tau_i).evals(), combine_lookups = the product of the C values, sumcheck degree C (to be confirmed against upstream).  Restated from that
+   * description so that configs[4]'s shape runs under its own name; tau = C * log2(M) draws of F::rand from a fresh ark_std::test_rng() (the snapshot's trait has no
+   * per-proof table parameter).  The tables hold field elements, so the integer shortcuts (lasso_materialize_subtable_u32, the *_u32 entry points) do not apply. */
+  LASSO_SPARK_UNCONFIRMED = 5 };
 typedef struct {
   int32_t kind;      /* lasso_strategy_kind */
   uint32_t c;        /* const generic C */

@@ -12,7 +12,7 @@ class Strategy(C.Structure):
     _fields_ = [("kind", i32), ("c", u32), ("log_m", u32), ("log_r", u32)]
 
 
-KINDS = {"and": 0, "or": 1, "xor": 2, "lt": 3, "range": 4}
+KINDS = {"and": 0, "or": 1, "xor": 2, "lt": 3, "range": 4, "spark": 5}   # "spark" = LASSO_SPARK_UNCONFIRMED (include/lasso_hip.h): not in the reference snapshot
 K_BIND, K_CUBIC, K_COMBINE, K_EQ, K_GP, K_FINGERPRINT, K_DOT, K_MATVEC, K_MSM, K_MISC, K_MSM_DIRECT, K_COUNT = range(12)
 KERNEL_NAMES = ["bind_top(+fused linear round)", "sumcheck_cubic_round(+fused bind)", "sumcheck_combine", "eq_evals", "gp_build", "fingerprint", "multi_dot", "matvec_left", "msm_commit(bucket)", "misc", "msm_opening(direct)"]
 

@@ -797,12 +797,12 @@ int32_t lasso_sumcheck_linear_eqw_round_fused_from_u32(lasso_ctx* c, const uint3
   return wait_flag(c, seq, (size_t)alpha * 3, out, c->tagged);
 }
 static int32_t make_strategy(lasso_ctx* c, const lasso_strategy* s, StrategyDev& S, WeightTable& W) {
-  REQUIRE(c, s && s->kind >= LASSO_AND && s->kind <= LASSO_RANGE && s->c >= 1);
+  REQUIRE(c, s && s->kind >= LASSO_AND && s->kind <= LASSO_SPARK_UNCONFIRMED && s->c >= 1);
   S.kind = s->kind; S.c = s->c; S.log_m = s->log_m; S.log_r = s->log_r;
   S.alpha = s->kind == LASSO_LT ? 2 * s->c : s->c;
   REQUIRE(c, S.alpha <= LASSO_MAX_ALPHA);
   for (uint32_t i = 0; i < LASSO_MAX_ALPHA; i++) W.w[i] = fr_zero();
-  if (s->kind != LASSO_LT) {
+  if (s->kind != LASSO_LT && s->kind != LASSO_SPARK_UNCONFIRMED) {
     const uint32_t inc = s->kind == LASSO_RANGE ? s->log_m : s->log_m / 2;  // and.rs:46 / range_check.rs:79
     for (uint32_t i = 0; i < S.alpha; i++) { REQUIRE(c, i * inc < 64); W.w[i] = fr_from_u64((uint64_t)1 << (i * inc)); }  // `1u64 << ...` in the reference overflows beyond 63
   }
@@ -817,7 +817,8 @@ static fr_t lt_pow32(uint32_t e, bool inverse) { static const fr_t inv32 = fr_in
 static int32_t combine_round_impl(lasso_ctx* c, const lasso_strategy* s, const lasso_fr* const* d_polys, const lasso_fr* d_eq, size_t n, uint32_t degree, lasso_fr* out, bool lt_scaled) {
   StrategyDev S; WeightTable W; int32_t rc = make_strategy(c, s, S, W); if (rc) return rc;
   REQUIRE(c, d_polys && d_eq && out && n >= 2 && (n & (n - 1)) == 0);
-  REQUIRE(c, degree == (s->kind == LASSO_LT ? s->c + 1 : 2));   // sumcheck_poly_degree(): subtables/mod.rs:60-62
+  const bool spark = s->kind == LASSO_SPARK_UNCONFIRMED;
+  REQUIRE(c, degree == ((s->kind == LASSO_LT || spark) ? s->c + 1 : 2));   // sumcheck_poly_degree(): subtables/mod.rs:60-62
   PtrTable P; for (uint32_t i = 0; i < S.alpha; i++) { REQUIRE(c, d_polys[i]); P.p[i] = (const fr_t*)d_polys[i]; }
   const size_t half = n / 2; const unsigned nx = grid_for(half, 1024); const uint32_t K = degree + 1;
   const bool lt = s->kind == LASSO_LT;
@@ -831,7 +832,11 @@ static int32_t combine_round_impl(lasso_ctx* c, const lasso_strategy* s, const l
   }
   {
     ProfScope ps(c, LASSO_K_COMBINE, 32.0 * n * (S.alpha + 1.0));
-    if (!lt) hipLaunchKernelGGL(k_combine_round_linear, dim3(nx), dim3(LASSO_BLOCK), 0, c->stream, S, P, (const fr_t*)d_eq, W, half, (fr_t*)c->d_scratch);
+    if (spark) {   // g = prod_m E_m: the LT walk without its LT terms (k_combine_round_lt<.., PROD>), same 32^C correction of the block sums
+      const fr_t scale = lt_pow32(S.c, false);
+#define LAUNCH_COMBINE_PROD(A_, D_, T_) hipLaunchKernelGGL((k_combine_round_lt<A_, D_, T_, true>), dim3(nx), dim3(LASSO_BLOCK), 0, c->stream, S, P, (const fr_t*)d_eq, scale, half, degree, (fr_t*)c->d_scratch)
+      DISPATCH_LT(2 * S.c, LAUNCH_COMBINE_PROD);   // the dispatch table is keyed by LT's memory count 2C: same degree bounds
+    } else if (!lt) hipLaunchKernelGGL(k_combine_round_linear, dim3(nx), dim3(LASSO_BLOCK), 0, c->stream, S, P, (const fr_t*)d_eq, W, half, (fr_t*)c->d_scratch);
     else {
       const fr_t scale = lt_pow32(S.c, false);
 #define LAUNCH_COMBINE(A_, D_, T_) hipLaunchKernelGGL((k_combine_round_lt<A_, D_, T_>), dim3(nx), dim3(LASSO_BLOCK), 0, c->stream, S, P, (const fr_t*)d_eq, scale, half, degree, (fr_t*)c->d_scratch)

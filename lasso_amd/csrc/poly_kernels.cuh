@@ -842,6 +842,7 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_combine_round_linear(StrategyDe
 #define LT_DECL(k) fr29 sum##k = fr29_zero(), t##k = fr29_zero();
 #define LT_TOP(k) if constexpr (k < PPG) { if (x0 + k <= degree) { t##k = lt; lt = lt_line_step(lt, dlt); } }
 #define LT_STEP(k) if constexpr (k < PPG) { if (x0 + k <= degree) { t##k = lt_horner_step(lt, eqv, t##k); lt = lt_line_step(lt, dlt); eqv = lt_line_step(eqv, deq); } }
+#define LT_STEP_PROD(k) if constexpr (k < PPG) { if (x0 + k <= degree) { t##k = fr29_weak(fr29_mul(eqv, t##k)); eqv = lt_line_step(eqv, deq); } }
 #define LT_ACC(k) if constexpr (k < PPG) { if (x0 + k <= degree) { sum##k = lt_weighted_acc(sum##k, ecur, t##k); ecur = lt_line_step(ecur, edif); } }
 #define LT_FOLD(k) if constexpr (k < PPG) sum##k = fr29_mul(sum##k, fr29_one_s());
 #define LT_OUT(k) if constexpr (k < PPG) mine[k] = fr29_mul(sum##k, sc);
@@ -871,7 +872,9 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_lt_prescale(PtrTable src, MutPt
   const fr29 ks = fr29_unpack_s(K.k[m]);
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) z[i] = fr29_store(fr29_mul(fr29_unpack_u(x[i]), ks));
 }
-template <int A, int D, int T>
+// PROD (the unconfirmed Spark strategy: g = prod_m E_m, degree C): the same walk without the LT terms — t starts as the last memory's line and every other memory multiplies it
+// once, t <- (E_m * t) / 32; memory m is polys[m] (no LT / EQ pairs), nothing is pre-scaled, and the block sums come out as sum e prod_m E_m / 32^C like LT's (same `scale`).
+template <int A, int D, int T, bool PROD = false>
 __global__ void __launch_bounds__(LASSO_BLOCK) k_combine_round_lt(StrategyDev S, PtrTable polys, const fr_t* __restrict__ eq, fr_t scale, size_t half, uint32_t degree, fr_t* __restrict__ partials) {
   constexpr int PPG = (D + 1 + T - 1) / T;
   constexpr uint32_t SLOTS = LASSO_BLOCK / T;
@@ -882,12 +885,20 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_combine_round_lt(StrategyDev S,
   uint32_t cnt = 0;
   if (slot < SLOTS && x0 <= degree)
   for (size_t i = blockIdx.x * (size_t)SLOTS + slot; i < half; i += (size_t)gridDim.x * SLOTS) {
-    {   // innermost term: t(x) = LT_{C-1}(x)
-      const fr_t* __restrict__ pl = polys.p[2 * (S.c - 1)];
+    {   // innermost term: t(x) = LT_{C-1}(x)   (PROD: the last memory's line)
+      const fr_t* __restrict__ pl = polys.p[PROD ? S.c - 1 : 2 * (S.c - 1)];
       const fr29 lo = fr29_unpack_u(pl[i]), dlt = fr29_sub(fr29_unpack_u(pl[i + half]), lo);
       fr29 lt = lt_line_at(lo, dlt, x0);
       LT_REP(LT_TOP)
     }
+    if constexpr (PROD) {
+      for (uint32_t m = S.c - 1; m-- > 0;) {   // t <- (E_m * t) / 32
+        const fr_t* __restrict__ pe = polys.p[m];
+        const fr29 eo = fr29_unpack_u(pe[i]), deq = fr29_sub(fr29_unpack_u(pe[i + half]), eo);
+        fr29 eqv = lt_line_at(eo, deq, x0);
+        LT_REP(LT_STEP_PROD)
+      }
+    } else
     for (uint32_t m = S.c - 1; m-- > 0;) {   // t <- LT_m + (EQ_m * t) / 32   (LT_m pre-scaled)
       const fr_t* __restrict__ pl = polys.p[2 * m]; const fr_t* __restrict__ pe = polys.p[2 * m + 1];
       const fr29 lo = fr29_unpack_u(pl[i]), dlt = fr29_sub(fr29_unpack_u(pl[i + half]), lo);
@@ -931,6 +942,7 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_combine_round_lt(StrategyDev S,
 #undef LT_DECL
 #undef LT_TOP
 #undef LT_STEP
+#undef LT_STEP_PROD
 #undef LT_ACC
 #undef LT_FOLD
 #undef LT_OUT
@@ -1022,18 +1034,21 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_combine_claim(StrategyDev S, Pt
   __shared__ RedScratch R;
   __shared__ fr29 ws[LASSO_MAX_ALPHA];
   load_weights(S, W, ws);
-  const bool lt = S.kind == 3;
+  const bool lt = S.kind == 3, prod = S.kind == 5;   // LASSO_LT, LASSO_SPARK_UNCONFIRMED
   fr29 acc[1] = {fr29_zero()}; uint32_t cnt = 0;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     fr29 g;
-    if (lt) {   // lt.rs:62-71 streamed over the memories: running sum and running product, no array of values (which ended up in scratch memory at A >= 16)
+    if (prod) {   // g = prod_m E_m: s-form values, so the running product stays in s-form whatever the degree
+      g = fr29_unpack_s(polys.p[S.c - 1][i]);
+      for (uint32_t m = S.c - 1; m-- > 0;) g = fr29_mul(fr29_unpack_s(polys.p[m][i]), g);
+    } else if (lt) {   // lt.rs:62-71 streamed over the memories: running sum and running product, no array of values (which ended up in scratch memory at A >= 16)
       // Horner from the last memory: g = LT_0 + EQ_0 (LT_1 + EQ_1 (...  + EQ_{C-2} LT_{C-1})): one product per memory instead of two
       g = fr29_unpack_s(polys.p[2 * (S.c - 1)][i]);
       for (uint32_t m = S.c - 1; m-- > 0;) g = fr29_weak(fr29_add(fr29_unpack_s(polys.p[2 * m][i]), fr29_mul(fr29_unpack_s(polys.p[2 * m + 1][i]), g)));
     } else g = weighted_sum(polys, i, S.alpha, ws);
     acc_add(acc[0], fr29_mul(g, fr29_unpack_u(eq[i])), cnt);
   }
-  store_block_partials<1>(acc, 1, partials + blockIdx.x, lt ? 0 : 5, R);
+  store_block_partials<1>(acc, 1, partials + blockIdx.x, (lt || prod) ? 0 : 5, R);
 }
 
 // K12: out[p] = sum_i polys[p][i] * w[i]; 1-D grid of nx*ny workgroups in cubic_grid order (the workgroups of one index range and different polynomials

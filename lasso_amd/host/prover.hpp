@@ -377,16 +377,21 @@ struct Strategy {
   Strategy(int kind, uint32_t c, uint32_t log_m, uint32_t log_r) { abi.kind = kind; abi.c = c; abi.log_m = log_m; abi.log_r = log_r; }
   size_t C() const { return abi.c; }
   size_t M() const { return (size_t)1 << abi.log_m; }
-  size_t num_subtables() const { return abi.kind == LASSO_LT ? 2 : abi.kind == LASSO_RANGE ? 3 : 1; }
+  bool spark() const { return abi.kind == LASSO_SPARK_UNCONFIRMED; }   // NOT in the reference snapshot: see include/lasso_hip.h lasso_strategy_kind
+  size_t num_subtables() const { return abi.kind == LASSO_LT ? 2 : abi.kind == LASSO_RANGE ? 3 : spark() ? C() : 1; }
   size_t num_memories() const { return abi.kind == LASSO_LT ? 2 * C() : C(); }
-  bool linear() const { return abi.kind != LASSO_LT; }   // g = sum_k 2^(k*inc) E_k: and.rs:45-53, range_check.rs:78-86
+  bool linear() const { return abi.kind != LASSO_LT && !spark(); }   // g = sum_k 2^(k*inc) E_k: and.rs:45-53, range_check.rs:78-86
+  bool integer_tables() const { return !spark(); }                  // every subtable of the snapshot holds small integers (u32 on the device); Spark's hold field elements
   ScVec weights() const { ScVec w; size_t inc = abi.kind == LASSO_RANGE ? abi.log_m : abi.log_m / 2; for (size_t i = 0; i < num_memories(); i++) { LASSO_REQUIRE(i * inc < 64); w.push_back(Sc::from_u64((uint64_t)1 << (i * inc))); } return w; }
-  size_t sumcheck_poly_degree() const { return (abi.kind == LASSO_LT ? C() : 1) + 1; }
+  size_t sumcheck_poly_degree() const { return (abi.kind == LASSO_LT || spark() ? C() : 1) + 1; }
   size_t memory_to_subtable_index(size_t i) const {
     if (abi.kind == LASSO_RANGE) { size_t lm = abi.log_m; if (i * lm > abi.log_r) return 2; return ((i + 1) * lm > abi.log_r) ? 1 : 0; }  // range_check.rs:62-69
-    return i % num_subtables();                                                                                                        // subtables/mod.rs:64-68
+    return i % num_subtables();                                                                                                        // subtables/mod.rs:64-68 (Spark: i)
   }
-  size_t memory_to_dimension_index(size_t i) const { return abi.kind == LASSO_RANGE ? i : i / num_subtables(); }                       // mod.rs:70-74, range_check.rs:71-73
+  size_t memory_to_dimension_index(size_t i) const { return abi.kind == LASSO_RANGE || spark() ? i : i / num_subtables(); }             // mod.rs:70-74, range_check.rs:71-73
+  // Spark (unconfirmed): subtable i = EqPolynomial(tau_i).evals(); the snapshot's trait has no per-proof table parameter, so tau is fixed by the strategy:
+  // C * log2(M) draws of F::rand from a fresh ark_std::test_rng(), tau_i = draws [i log M, (i + 1) log M)
+  std::vector<ScVec> spark_point() const;
   // materialize_subtables: every table of the reference holds small integers, so the host builds u32 and the device lifts to Fr
   // largest entry of any subtable (bounds the scalars of E's commitment): l op r < 2^(log_m / 2); LT / EQ are bits; range tables hold indices
   uint32_t max_table_value() const {
@@ -414,6 +419,12 @@ struct Strategy {
     return out;
   }
 };
+
+inline std::vector<ScVec> Strategy::spark_point() const {
+  ChaChaRng rng = ChaChaRng::test_rng(); std::vector<ScVec> tau(C());
+  for (size_t i = 0; i < C(); i++) for (size_t b = 0; b < abi.log_m; b++) tau[i].push_back(fr_rand(rng));
+  return tau;
+}
 
 // ------------------------------------------------------------------ UniPoly (poly/unipoly.rs:13-120)
 // from_evals solves the same Vandermonde system as the reference's Gaussian elimination; the solution is unique and the
@@ -650,7 +661,8 @@ class Prover {
     std::vector<const lasso_fr*> cp(polys.begin(), polys.begin() + alpha);
     for (size_t round = 0; round < rounds; round++) {
       std::vector<lasso_fr> ev(combined_degree + 1);
-      if (round == 0 && first_u32) d.chk(lasso_sumcheck_combine_round_lt_u32(d.ctx, &S.abi, first_u32->data(), polys[alpha], len, (uint32_t)combined_degree, ev.data()), "lasso_sumcheck_combine_round_lt_u32");
+      if (S.spark()) d.chk(lasso_sumcheck_combine_round(d.ctx, &S.abi, cp.data(), polys[alpha], len, (uint32_t)combined_degree, ev.data()), "lasso_sumcheck_combine_round");   // g = prod E_m: nothing is pre-scaled
+      else if (round == 0 && first_u32) d.chk(lasso_sumcheck_combine_round_lt_u32(d.ctx, &S.abi, first_u32->data(), polys[alpha], len, (uint32_t)combined_degree, ev.data()), "lasso_sumcheck_combine_round_lt_u32");
       else d.chk(lasso_sumcheck_combine_round_lt_scaled(d.ctx, &S.abi, cp.data(), polys[alpha], len, (uint32_t)combined_degree, ev.data()), "lasso_sumcheck_combine_round_lt_scaled");
       if (reduce) d.comm.sum(ev);
       ScVec evals; for (auto& e : ev) evals.push_back(Sc::from_abi(e));
@@ -758,7 +770,7 @@ class Prover {
       std::vector<lasso_fr> h(alpha);
       d.chk(lasso_read_heads(d.ctx, (const lasso_fr* const*)arrs.data(), (uint32_t)alpha, h.data()), "lasso_read_heads");
       heads_out->clear(); for (auto& x : h) heads_out->push_back(Sc::from_abi(x));
-      if (!S.linear()) {   // undo lasso_lt_prescale on the LT memories' final values: LT_m(r) = 32^(C-1-m) * head
+      if (S.abi.kind == LASSO_LT) {   // undo lasso_lt_prescale on the LT memories' final values: LT_m(r) = 32^(C-1-m) * head
         const Sc k32 = Sc::from_u64(32); Sc pw = Sc::one();
         for (size_t m = S.C(); m-- > 0;) { (*heads_out)[2 * m] *= pw; pw *= k32; }
       }
@@ -785,7 +797,8 @@ class Prover {
       return proof;
     }
     // the caller's work arrays, once (slab mode: the local arrays; the replicated tails are gathered from them).  With src the call also IS the clone of the lookup polynomials
-    d.chk(lasso_lt_prescale(d.ctx, &S.abi, src ? src->data() : nullptr, polys.data(), len_loc), "lasso_lt_prescale");
+    if (S.spark()) { if (src) for (size_t i = 0; i < alpha; i++) d.chk(lasso_copy(d.ctx, polys[i], (*src)[i], len_loc * sizeof(lasso_fr)), "lasso_copy"); }   // the clone of surge.rs:151
+    else d.chk(lasso_lt_prescale(d.ctx, &S.abi, src ? src->data() : nullptr, polys.data(), len_loc), "lasso_lt_prescale");
     if (P == 1) { arbitrary_rounds(num_rounds, len_loc, polys, combined_degree, false, proof, r_out, src_u32); read_heads(polys); return proof; }
     LASSO_REQUIRE(num_rounds >= lgP && ((size_t)1 << (num_rounds - lgP)) == len_loc);
     arbitrary_rounds(num_rounds - lgP, len_loc, polys, combined_degree, true, proof, r_out);
@@ -1259,10 +1272,17 @@ class Prover {
     std::unique_ptr<Trace> sp(new Trace("Subtables.new", d.ctx));
     // the subtables as integers, written by the device (64 K entries each: nothing to compute on the host and upload); they stay until E is
     // committed (the commitment's scalars are T[dim] as integers)
-    std::vector<DBufU32> tables_u32; const uint32_t table_max = S.max_table_value();
-    for (size_t i = 0; i < S.num_subtables(); i++) {
+    std::vector<DBufU32> tables_u32; const bool ints = S.integer_tables(); const uint32_t table_max = ints ? S.max_table_value() : 0;
+    if (ints) for (size_t i = 0; i < S.num_subtables(); i++) {
       tables_u32.emplace_back(d, m); tables.emplace_back(d, m);
       d.chk(lasso_materialize_subtable_u32(d.ctx, &S.abi, (uint32_t)i, tables_u32.back().p), "lasso_materialize_subtable_u32");
+    } else {   // Spark (unconfirmed): subtable i = EqPolynomial(tau_i).evals(), field elements from the start
+      const std::vector<ScVec> tau = S.spark_point();
+      for (size_t i = 0; i < S.num_subtables(); i++) {
+        tables.emplace_back(d, m);
+        std::vector<lasso_fr> tv; for (auto& x : tau[i]) tv.push_back(x.abi());
+        d.chk(lasso_eq_evals(d.ctx, tv.data(), (uint32_t)tv.size(), tables.back().p), "lasso_eq_evals");
+      }
     }
     if (side_off() || P != 1) {} else d.chk(lasso_sync(d.ctx), "lasso_sync");   // the side context reads them
     size_t n_E = next_pow2(alpha * s); nv_derefs = ceil_log2(n_E);
@@ -1271,11 +1291,11 @@ class Prover {
     // The commitment of E needs only E's INTEGER values (a 4-byte gather per lookup), so on one GPU the field-element side of Subtables::new — the
     // tables lifted to Fr, E = T[dim] as 32-byte elements — and the eq table of r run on the side context UNDER the commitment's MSM (VALU-bound;
     // these are HBM-bound) instead of in front of it.
-    const bool side_new = P == 1 && !side_off();
+    const bool side_new = P == 1 && !side_off() && ints;
     lasso_ctx* fc = side_new ? d.side() : d.ctx;
     auto fchk = [&](int32_t rc, const char* what) { if (side_new) d.chk_side(rc, what); else d.chk(rc, what); };
     auto field_side = [&] {
-      for (size_t i = 0; i < tables.size(); i++) fchk(lasso_fr_from_u32(fc, tables_u32[i].p, m, tables[i].p), "lasso_fr_from_u32");
+      if (ints) for (size_t i = 0; i < tables.size(); i++) fchk(lasso_fr_from_u32(fc, tables_u32[i].p, m, tables[i].p), "lasso_fr_from_u32");
       if (n_E > alpha * s) fchk(lasso_zero(fc, combined_E.p + alpha * s_loc, (n_E - alpha * s) / P * sizeof(lasso_fr)), "lasso_zero");
       for (size_t i = 0; i < alpha; i++)
         fchk(lasso_gather(fc, tables[S.memory_to_subtable_index(i)].p, dense.dim_u32[S.memory_to_dimension_index(i)].p, s_loc, combined_E.p + i * s_loc), "lasso_gather");
@@ -1283,7 +1303,7 @@ class Prover {
     ProofWriter W;
     PolyCommitment comm_derefs;
     DBufU32 E_u32;   // E as integers (one GPU): the commitment's scalars, and what the primary sumcheck's first round and first bind read (4 bytes per element instead of 32)
-    if (P == 1) {   // one 4-byte gather per lookup instead of converting the 32-byte elements back
+    if (P == 1 && ints) {   // one 4-byte gather per lookup instead of converting the 32-byte elements back
       E_u32 = DBufU32(d, n_E);
       if (n_E > alpha * s) d.chk(lasso_zero(d.ctx, E_u32.p + alpha * s, (n_E - alpha * s) * sizeof(uint32_t)), "lasso_zero");
       for (size_t i = 0; i < alpha; i++)

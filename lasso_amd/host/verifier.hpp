@@ -131,6 +131,12 @@ inline WireProof read_proof(const Strategy& S, const uint8_t* bytes, size_t n) {
 // ------------------------------------------------------------------ host side of SubtableStrategy the verifier needs (subtables/*.rs)
 inline Sc evaluate_subtable_mle(const Strategy& S, size_t k, const ScVec& point) {
   const int kind = S.abi.kind; const size_t n = point.size();
+  if (kind == LASSO_SPARK_UNCONFIRMED) {   // the MLE of eq(tau_k, .) at a point is eq(tau_k, point) (eq_poly.rs:14-20)
+    const std::vector<ScVec> tau = S.spark_point(); LASSO_REQUIRE(k < tau.size() && n == tau[k].size());
+    Sc res = Sc::one();
+    for (size_t b = 0; b < n; b++) res *= tau[k][b] * point[b] + (Sc::one() - tau[k][b]) * (Sc::one() - point[b]);
+    return res;
+  }
   if (kind == LASSO_RANGE) {   // range_check.rs:42-66
     if (k == 2) return Sc::zero();
     const size_t cutoff = S.abi.log_r % S.abi.log_m; Sc res = Sc::zero();
@@ -156,6 +162,7 @@ inline Sc evaluate_subtable_mle(const Strategy& S, size_t k, const ScVec& point)
   return res;
 }
 inline Sc combine_lookups(const Strategy& S, const ScVec& vals) {
+  if (S.spark()) { Sc prod = Sc::one(); for (size_t i = 0; i < S.C(); i++) prod *= vals[i]; return prod; }
   if (S.abi.kind == LASSO_LT) {   // lt.rs:62-71
     Sc sum = Sc::zero(), eq = Sc::one();
     for (size_t i = 0; i < S.C(); i++) { sum += vals[2 * i] * eq; eq *= vals[2 * i + 1]; }

@@ -699,12 +699,22 @@ inline std::pair<size_t, size_t> split_bits(size_t item, size_t num_bits) {  // 
   size_t max_value = ((size_t)1 << num_bits) - 1;
   return {(item >> num_bits) & max_value, item & max_value};
 }
-enum StrategyKind { STRAT_AND = 0, STRAT_OR = 1, STRAT_XOR = 2, STRAT_LT = 3, STRAT_RANGE = 4 };
+// STRAT_SPARK_UNCONFIRMED: NOT in the reference snapshot (src/subtables/mod.rs:22-26 lists and / lt / or / range_check / xor).  BASELINE.json configs[4] names a
+// "SparkSubtableStrategy"; upstream Lasso's history had one — subtables = the eq polynomials of a point, combine_lookups = the product of the C values, degree C
+// ("must be confirmed against upstream before use").  Restated here from that description so that configs[4]'s SHAPE (C memories, a degree-C
+// combine, field-element tables) runs under its own name; nothing pins it to upstream bytes, hence the name.  The snapshot's trait has no per-proof table
+// parameter, so the point is fixed by the strategy itself: tau = C * log2(M) draws of F::rand from a fresh ark_std::test_rng(), tau_i = draws [i log M, (i+1) log M).
+enum StrategyKind { STRAT_AND = 0, STRAT_OR = 1, STRAT_XOR = 2, STRAT_LT = 3, STRAT_RANGE = 4, STRAT_SPARK_UNCONFIRMED = 5 };
+inline std::vector<std::vector<Fr>> spark_point(size_t C, size_t log_m) {
+  ChaChaRng rng = test_rng(); std::vector<std::vector<Fr>> tau(C);
+  for (size_t i = 0; i < C; i++) for (size_t b = 0; b < log_m; b++) tau[i].push_back(fr_rand(rng));
+  return tau;
+}
 struct Strategy {  // trait SubtableStrategy<F, C, M> subtables/mod.rs:31-93, made runtime-parametric
   StrategyKind kind; size_t C, M, LOG_R;
-  size_t num_subtables() const { return kind == STRAT_LT ? 2 : kind == STRAT_RANGE ? 3 : 1; }
+  size_t num_subtables() const { return kind == STRAT_LT ? 2 : kind == STRAT_RANGE ? 3 : kind == STRAT_SPARK_UNCONFIRMED ? C : 1; }
   size_t num_memories() const { return kind == STRAT_LT ? 2 * C : C; }
-  size_t g_poly_degree() const { return kind == STRAT_LT ? C : 1; }
+  size_t g_poly_degree() const { return kind == STRAT_LT || kind == STRAT_SPARK_UNCONFIRMED ? C : 1; }
   size_t sumcheck_poly_degree() const { return g_poly_degree() + 1; }  // mod.rs:60-62
   size_t memory_to_subtable_index(size_t i) const {
     if (kind == STRAT_RANGE) {  // range_check.rs:62-69
@@ -712,11 +722,12 @@ struct Strategy {  // trait SubtableStrategy<F, C, M> subtables/mod.rs:31-93, ma
       if (i * log_m > LOG_R) return 2;
       return ((i + 1) * log_m > LOG_R) ? 1 : 0;
     }
+    if (kind == STRAT_SPARK_UNCONFIRMED) { ORC_ASSERT(i < C); return i; }   // memory i reads subtable i = eq(tau_i, .) along dimension i
     ORC_ASSERT(num_subtables() * C == num_memories() && i < num_memories());  // mod.rs:64-68
     return i % num_subtables();
   }
   size_t memory_to_dimension_index(size_t i) const {
-    if (kind == STRAT_RANGE) return i;  // range_check.rs:71-73
+    if (kind == STRAT_RANGE || kind == STRAT_SPARK_UNCONFIRMED) return i;  // range_check.rs:71-73
     ORC_ASSERT(i < num_memories());
     return i / num_subtables();  // mod.rs:70-74
   }
@@ -744,6 +755,11 @@ struct Strategy {  // trait SubtableStrategy<F, C, M> subtables/mod.rs:31-93, ma
         size_t cutoff = (size_t)1 << (LOG_R % ark_log2(M));
         for (size_t i = 0; i < M; i++) { full.push_back(Fr::from_u64(i)); rem.push_back(i < cutoff ? Fr::from_u64(i) : Fr::zero()); }
         out.push_back(full); out.push_back(rem); out.push_back(zeros); break;
+      }
+      case STRAT_SPARK_UNCONFIRMED: {  // subtable i = EqPolynomial(tau_i).evals() (eq_poly.rs:22-38)
+        ORC_ASSERT(is_pow2(M));
+        for (auto& t : spark_point(C, ark_log2(M))) out.push_back(EqPolynomial(t).evals());
+        break;
       }
     }
     return out;
@@ -783,6 +799,12 @@ struct Strategy {  // trait SubtableStrategy<F, C, M> subtables/mod.rs:31-93, ma
         }
         ORC_ASSERT(subtable_index == 2); return Fr::zero();
       }
+      case STRAT_SPARK_UNCONFIRMED: {  // the MLE of eq(tau_i, .) is eq(tau_i, point) (eq_poly.rs:14-20 evaluate)
+        ORC_ASSERT(subtable_index < C && point.size() == ark_log2(M));
+        const auto tau = spark_point(C, ark_log2(M)); Fr r = one;
+        for (size_t b = 0; b < point.size(); b++) r *= tau[subtable_index][b] * point[b] + (one - tau[subtable_index][b]) * (one - point[b]);
+        return r;
+      }
     }
     return Fr::zero();
   }
@@ -803,6 +825,7 @@ struct Strategy {  // trait SubtableStrategy<F, C, M> subtables/mod.rs:31-93, ma
         for (size_t i = 0; i < C; i++) sum += Fr::from_u64((u64)1 << (i * log_m)) * vals[i];
         return sum;
       }
+      case STRAT_SPARK_UNCONFIRMED: { Fr prod = Fr::one(); for (size_t i = 0; i < C; i++) prod *= vals[i]; return prod; }
     }
     return Fr::zero();
   }

@@ -47,7 +47,8 @@ assert proof == orc.prove(), "proof differs from the oracle's"
 print("OK", hashlib.sha256(proof).hexdigest())
 """
 
-CASES = [("and", 1, 8, 0, 1 << 9, 1), ("xor", 2, 6, 0, 300, 1), ("lt", 2, 6, 0, 1 << 8, 1), ("range", 3, 8, 40, 1 << 8, 1), ("and", 2, 8, 0, 1 << 10, 2), ("range", 2, 8, 12, 1 << 10, 4)]
+CASES = [("and", 1, 8, 0, 1 << 9, 1), ("xor", 2, 6, 0, 300, 1), ("lt", 2, 6, 0, 1 << 8, 1), ("range", 3, 8, 40, 1 << 8, 1), ("and", 2, 8, 0, 1 << 10, 2), ("range", 2, 8, 12, 1 << 10, 4),
+         ("spark", 2, 6, 0, 1 << 8, 1)]
 
 
 @pytest.mark.parametrize("tails", ["streaming bottom layer (chunked leaf rounds)", "resident tail (leaves materialised after all)"])

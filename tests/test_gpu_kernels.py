@@ -1,6 +1,7 @@
 """-m gpu: every entry point of liblasso_hip.so (include/lasso_hip.h) against the oracle's CPU statement of the same
 call (oracle/mock_hip.cpp), bit-exact, on seeded inputs incl. the edge sizes the reference exercises (n = 2, ragged grids)."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -108,7 +109,8 @@ def test_sumcheck_cubic_round(devs, n, ncirc):
     assert np.array_equal(a, b)
 
 
-CONFIGS = [("and", 1, 16, 0), ("and", 4, 16, 0), ("xor", 8, 16, 0), ("or", 2, 4, 0), ("lt", 1, 4, 0), ("lt", 2, 4, 0), ("lt", 4, 4, 0), ("range", 3, 8, 40), ("range", 4, 16, 40)]
+CONFIGS = [("and", 1, 16, 0), ("and", 4, 16, 0), ("xor", 8, 16, 0), ("or", 2, 4, 0), ("lt", 1, 4, 0), ("lt", 2, 4, 0), ("lt", 4, 4, 0), ("range", 3, 8, 40), ("range", 4, 16, 40),
+           ("spark", 1, 4, 0), ("spark", 2, 4, 0), ("spark", 3, 4, 0), ("spark", 5, 4, 0), ("spark", 8, 4, 0), ("spark", 16, 4, 0)]   # LASSO_SPARK_UNCONFIRMED: g = prod E_m, degree C
 
 
 @pytest.mark.parametrize("kind,c,log_m,log_r", CONFIGS)
@@ -117,7 +119,7 @@ def test_sumcheck_combine_round_and_claim(devs, kind, c, log_m, log_r, n):
     rng = np.random.default_rng(abs(hash((kind, c, n))) % 2**32)
     S = _abi.Strategy(_abi.KINDS[kind], c, log_m, log_r)
     alpha = 2 * c if kind == "lt" else c
-    degree = c + 1 if kind == "lt" else 2
+    degree = c + 1 if kind in ("lt", "spark") else 2
     polys = [rand_fr(rng, n) for _ in range(alpha)]
     eq = rand_fr(rng, n)
 
@@ -445,6 +447,60 @@ def test_slab_commitment_exchange_on_device(devs, gens_300, world, ls, rs, maxv)
     d.bases_destroy(b_full)
     assert [bytes(x) for x in out] == [bytes(x) for x in np.asarray(want).reshape(ls, 32)]
     assert have_rccl, "librccl could not be loaded / initialised on this box (the exchange itself was still checked through a plain copy)"
+
+
+def test_rccl_two_ranks_on_one_device(devs):
+    """drive ncclAllGather with world > 1 if the box allows two communicators on one device.  Two contexts of the one MI355X join one communicator
+    (lasso_rccl_init rank 0 / 1, one host thread each, as two ranks of a node would).  Either RCCL accepts — then a real 2-rank ncclAllGather runs on the two library streams and
+    both ranks must hold [rank 0's bytes, rank 1's bytes] — or it refuses duplicate devices, consistently on BOTH ranks (which is what lets lasso_host_set_comm_shm's agreement
+    protocol fall back to the shared-memory exchange without splitting the ranks).  The outcome is printed; a hang or a split decision fails."""
+    import threading
+    from lasso_amd import Device
+    if devs[0].lib.lasso_rccl_available() != 1:
+        pytest.skip("librccl cannot be loaded on this box")
+    curve = "bn254" if os.environ.get("LASSO_TEST_CURVE") == "bn254" else "curve25519"
+    ds = [Device(curve=curve), Device(curve=curve)]
+    uid = (C.c_uint8 * 128)()
+    assert ds[0].lib.lasso_rccl_unique_id(uid) == 0
+    rc, msg = [None, None], [b"", b""]
+
+    def init(k):
+        rc[k] = ds[k].lib.lasso_rccl_init(ds[k].ctx, k, 2, uid)
+        if rc[k] != 0:
+            msg[k] = ds[k].lib.lasso_last_error(ds[k].ctx)
+    ths = [threading.Thread(target=init, args=(k,), daemon=True) for k in range(2)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(timeout=90)
+    assert not any(t.is_alive() for t in ths), "ncclCommInitRank hung with two ranks on one device"
+    assert (rc[0] == 0) == (rc[1] == 0), f"the ranks disagree: {rc} {msg}"
+    if rc[0] != 0:
+        print(f"\n[rccl] two ranks on one device: refused on both ranks ({msg[0].decode()[:160]}) — a world > 1 ncclAllGather cannot run on this one-GPU box")
+        for d in ds:
+            d.close()
+        return
+    n = 1 << 16
+    send = [np.full(n, 17 + k, dtype=np.uint8) for k in range(2)]
+    ps = [d.upload(x) for d, x in zip(ds, send)]; pr = [d.alloc(2 * n) for d in ds]
+    arc = [None, None]
+
+    def gather(k):
+        arc[k] = ds[k].lib.lasso_rccl_allgather(ds[k].ctx, C.c_void_p(ps[k]), C.c_void_p(pr[k]), n)
+        ds[k].sync()
+    ths = [threading.Thread(target=gather, args=(k,), daemon=True) for k in range(2)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(timeout=90)
+    assert not any(t.is_alive() for t in ths), "ncclAllGather hung"
+    assert arc == [0, 0]
+    for k in range(2):
+        got = ds[k].download(pr[k], (2 * n,), dtype=np.uint8)
+        assert np.array_equal(got[:n], send[0]) and np.array_equal(got[n:], send[1])
+    print("\n[rccl] two ranks on one device: accepted; a 2-rank ncclAllGather of 64 KiB per rank ran on the two library streams")
+    for d in ds:
+        d._chk(d.lib.lasso_rccl_shutdown(d.ctx)); d.close()
 
 
 @pytest.mark.parametrize("ls,rs,tbits", [(1, 1, 1), (4, 8, 8), (16, 256, 16), (8, 300, 24), (3, 100, 32), (128, 128, 8), (64, 300, 16), (32, 33, 1), (40, 64, 17)])

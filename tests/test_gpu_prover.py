@@ -14,7 +14,9 @@ CASES = [("lt", 4, 4, 0, 16), ("lt", 4, 4, 0, 128), ("and", 4, 4, 0, 16), ("rang
          ("and", 1, 4, 0, 2), ("xor", 3, 4, 0, 11), ("or", 2, 4, 0, 8), ("and", 1, 16, 0, 1 << 10),   # BASELINE config 1 shape
          ("and", 1, 2, 0, 3), ("or", 1, 6, 0, 7), ("lt", 1, 4, 0, 4), ("range", 2, 4, 6, 9), ("and", 3, 2, 0, 4),
          ("and", 4, 16, 0, 1 << 12), ("xor", 8, 8, 0, 1 << 10), ("range", 4, 16, 40, 1 << 10), ("lt", 2, 8, 0, 1 << 9), ("and", 1, 16, 0, 1 << 14),
-         ("lt", 16, 4, 0, 64), ("lt", 16, 8, 0, 1 << 10)]   # C = 16: 32 memories, degree-17 sumcheck — the shape of BASELINE.json configs[4] with the one degree-C strategy the snapshot has
+         ("lt", 16, 4, 0, 64), ("lt", 16, 8, 0, 1 << 10),   # C = 16: 32 memories, degree-17 sumcheck — the shape of BASELINE.json configs[4] with the one degree-C strategy the snapshot has
+         ("spark", 1, 4, 0, 16), ("spark", 2, 8, 0, 300), ("spark", 3, 6, 0, 1 << 10), ("spark", 4, 16, 0, 1 << 12), ("spark", 8, 8, 0, 1 << 11), ("spark", 16, 4, 0, 64),
+         ("spark", 16, 16, 0, 1 << 12)]   # configs[4] under its own name: SparkSubtableStrategy as SURVEY 8(f3) describes it (LASSO_SPARK_UNCONFIRMED: eq tables, product combine, degree C)
 
 
 @pytest.fixture(scope="module")
@@ -163,7 +165,7 @@ def test_gpu_ab_switches_do_not_change_the_bytes(host, env):
 # reach these sizes in seconds, so parity rests on the size-independent property the reference itself uses as its acceptance test
 # (src/e2e_test.rs:54-59): prove -> verify, here through the oracle's verifier (a restatement of surge.rs:214-271) fed the GPU's commitment,
 # plus rejection of a tampered proof and determinism of the proof bytes.
-FULL = [("and", 4, 16, 0, 20), ("and", 1, 16, 0, 24), ("xor", 8, 16, 0, 24), ("range", 4, 16, 40, 26), ("and", 1, 16, 0, 28), ("lt", 16, 16, 0, 22)]   # configs[1], the metric, configs[2], configs[3] (on one GPU: ~75 GiB), the largest lookup count of BASELINE.json (2^28, ~75 GiB) with the AND table, and LT C=16 (32 memories, degree 17: configs[4]'s shape, see CASES)
+FULL = [("and", 4, 16, 0, 20), ("and", 1, 16, 0, 24), ("xor", 8, 16, 0, 24), ("range", 4, 16, 40, 26), ("and", 1, 16, 0, 28), ("lt", 16, 16, 0, 22), ("spark", 16, 16, 0, 20)]   # configs[1], the metric, configs[2], configs[3] (on one GPU: ~75 GiB), the largest lookup count of BASELINE.json (2^28, ~75 GiB) with the AND table, and LT C=16 (32 memories, degree 17: configs[4]'s shape, see CASES)
 
 
 @pytest.mark.parametrize("kind,c,log_m,log_r,log_s", FULL)
@@ -256,7 +258,8 @@ def _build_slab_hip():
 
 
 @pytest.mark.parametrize("world", [2, 4, 8])
-@pytest.mark.parametrize("kind,c,log_m,log_r,lookups", [("and", 1, 8, 0, 1 << 10), ("xor", 3, 6, 0, 500), ("lt", 2, 6, 0, 64), ("range", 3, 8, 40, 100), ("and", 2, 16, 0, 1 << 13)])
+@pytest.mark.parametrize("kind,c,log_m,log_r,lookups", [("and", 1, 8, 0, 1 << 10), ("xor", 3, 6, 0, 500), ("lt", 2, 6, 0, 64), ("range", 3, 8, 40, 100), ("and", 2, 16, 0, 1 << 13),
+                                                          ("spark", 4, 8, 0, 1 << 10)])
 def test_gpu_slab_proof_bit_exact(host, oracle, world, kind, c, log_m, log_r, lookups):
     import ctypes as C
     lib = _build_slab_hip()

@@ -12,7 +12,8 @@ from proverutil import HostProver, OracleSession, build_mock_prover, cubic_batch
 # (kind, C, log_m, log_r, lookups) — the reference's e2e_test.rs configurations first
 CASES = [("lt", 4, 4, 0, 16), ("lt", 4, 4, 0, 128), ("and", 4, 4, 0, 16), ("range", 3, 8, 40, 16),
          ("and", 1, 4, 0, 64), ("xor", 2, 4, 0, 32), ("or", 2, 4, 0, 8), ("and", 1, 16, 0, 1 << 10), ("and", 1, 4, 0, 2), ("xor", 3, 4, 0, 11),
-         ("and", 1, 2, 0, 3), ("or", 1, 6, 0, 7), ("lt", 1, 4, 0, 4), ("range", 2, 4, 6, 9), ("and", 3, 2, 0, 4)]   # smallest tables / ragged counts / C not a power of two
+         ("and", 1, 2, 0, 3), ("or", 1, 6, 0, 7), ("lt", 1, 4, 0, 4), ("range", 2, 4, 6, 9), ("and", 3, 2, 0, 4),   # smallest tables / ragged counts / C not a power of two
+         ("spark", 1, 4, 0, 16), ("spark", 2, 4, 0, 32), ("spark", 3, 6, 0, 50), ("spark", 4, 4, 0, 256), ("spark", 8, 4, 0, 64), ("spark", 16, 2, 0, 32)]   # "spark" = LASSO_SPARK_UNCONFIRMED: the strategy BASELINE.json configs[4] names, restated (not in the reference snapshot)
 
 
 @pytest.fixture(scope="module")

@@ -63,7 +63,8 @@ def slab_prove(lib, world, S, num_memories, idx, r):
 
 
 # (kind, C, log_m, log_r, lookups): every strategy; ragged lookups; sizes where late layers are smaller than the world (replicated tops)
-CASES = [("and", 1, 4, 0, 64), ("and", 2, 4, 0, 32), ("xor", 3, 4, 0, 50), ("or", 2, 6, 0, 16), ("lt", 2, 6, 0, 32), ("range", 3, 8, 40, 16), ("and", 1, 8, 0, 1 << 9), ("xor", 4, 6, 0, 100)]
+CASES = [("and", 1, 4, 0, 64), ("and", 2, 4, 0, 32), ("xor", 3, 4, 0, 50), ("or", 2, 6, 0, 16), ("lt", 2, 6, 0, 32), ("range", 3, 8, 40, 16), ("and", 1, 8, 0, 1 << 9), ("xor", 4, 6, 0, 100),
+         ("spark", 2, 4, 0, 64), ("spark", 3, 6, 0, 100)]   # "spark" = LASSO_SPARK_UNCONFIRMED: the strategy BASELINE.json configs[4] names, restated (not in the reference snapshot)
 
 
 @pytest.mark.parametrize("world", [2, 4, 8])

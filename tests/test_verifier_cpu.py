@@ -12,7 +12,8 @@ from lasso_amd.device import LassoError
 from proverutil import HostProver, OracleSession, build_mock_prover
 
 CASES = [("lt", 4, 4, 0, 16), ("and", 4, 4, 0, 16), ("range", 3, 8, 40, 16), ("lt", 4, 4, 0, 128),          # e2e_test.rs:64-99
-         ("and", 1, 16, 0, 1 << 10), ("xor", 3, 4, 0, 11), ("or", 2, 6, 0, 40), ("range", 2, 8, 12, 100), ("and", 1, 2, 0, 2), ("lt", 1, 4, 0, 3)]
+         ("and", 1, 16, 0, 1 << 10), ("xor", 3, 4, 0, 11), ("or", 2, 6, 0, 40), ("range", 2, 8, 12, 100), ("and", 1, 2, 0, 2), ("lt", 1, 4, 0, 3),
+         ("spark", 2, 4, 0, 32), ("spark", 5, 4, 0, 20)]   # "spark" = LASSO_SPARK_UNCONFIRMED: the strategy BASELINE.json configs[4] names, restated (not in the reference snapshot)
 
 
 @pytest.fixture(scope="module", params=["curve25519", "bn254"])

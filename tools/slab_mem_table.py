@@ -49,7 +49,7 @@ def main():
             print(json.dumps(row), flush=True)
     out = {"workload": f"{a.kind.upper()} C={a.c} M=2^{a.log_m} s=2^{a.log_s}, ONE proof over P contexts of one MI355X (slab mode, lasso_host_set_comm_shm)", "rows": rows,
            "extrapolation_C16_2p28_world8": {f"{k}{'_capacity' if cap else ''}": {"bytes_per_rank": int(bench.slab_bytes_per_rank(k, 16, 28, 8, 16, cap)), "units_of_s_over_P": bench.slab_units(k, 16, cap)}
-                                             for k in ("and", "lt") for cap in (False, True)}}
+                                             for k in ("and", "spark", "lt") for cap in (False, True)}}
     print(json.dumps(out))
     if a.out:
         with open(a.out, "w") as f:
