@@ -68,6 +68,16 @@ LHD fe29 fe_mul(const fe29& a, const fe29& b) {
   return r;
 }
 LHD fe29 fe_sqr(const fe29& a) { return fe_mul(a, a); }   // a must be reduced
+// a reduced, 0 < k < 2^18 -> reduced: nine multiply-adds and one carry pass (a third of a product)
+LHD fe29 fe_mul_small(const fe29& a, int32_t k) {
+  fe29 r; int64_t c = 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++) { const int64_t x = (int64_t)a.v[i] * k + c; c = x >> 29; r.v[i] = (int32_t)x & FE29_MASK; }
+  const int64_t x0 = (int64_t)r.v[0] + c * 1216;   // the carry out of limb 8 (< 2^19) has weight 2^261 = 1216
+  r.v[0] = (int32_t)x0 & FE29_MASK;
+  r.v[1] += (int32_t)(x0 >> 29);
+  return r;
+}
 
 // a^(p-2) by the curve25519 addition chain (254 squarings + 11 multiplications); a reduced
 LHD fe29 fe_inv_chain(const fe29& z) {
@@ -159,6 +169,36 @@ LHD pt29 pt_add(const pt29& p, const pt29& q, const fe29& d2) {
   fe29 D = fe_dbl(fe_mul(p.Z, q.Z));
   fe29 E = fe_sub(B, A), F = fe_weak(fe_sub(D, C)), G = fe_weak(fe_add(D, C)), H = fe_weak(fe_add(B, A));
   pt29 r; r.X = fe_mul(E, F); r.Y = fe_mul(H, G); r.T = fe_mul(E, H); r.Z = fe_mul(F, G); return r;
+}
+// The curve constant is d = -121665 / 121666 (RFC 7748 / 8032: edwards25519; ark-curve25519's COEFF_D).  Scaling all four of A, B, C = 2d T1 T2, D = 2 Z1 Z2 by
+// lambda = 121666 scales E, F, G, H by lambda and hence X3 = E F, Y3 = G H, T3 = E H, Z3 = F G all by lambda^2: the same point, a consistent extended representation.  And
+//   lambda A = 121666 A,   lambda B = 121666 B,   lambda C = -243330 T1 T2,   lambda D = 243332 Z1 Z2
+// are products with SMALL constants (fe_mul_small: a third of a product) — no full-width multiplication by 2d is left.  For one lane that is no gain (four small products
+// for one large), but in the four-lane tree (msm_coop_tree) every role has exactly one of them: a level is two product times deep instead of three.
+#define ED_K_AB 121666  // lambda
+#define ED_K_C 243330   // 2 * 121665:  Cs = ED_K_C T1 T2 = -lambda C
+#define ED_K_D 243332   // 2 * 121666:  Ds = ED_K_D Z1 Z2 =  lambda D
+// The addition shared by four lanes (msm_coop_tree): lane role c computes one of lambda A, lambda B, Cs, Ds (stage 1: ONE product + the small constant, selected by data so
+// that the instruction stream is uniform), the four exchange them, and role c computes coordinate c of the sum (stage 2: one product).
+LHD fe29 pt_coop4_stage1(const pt29& p, const pt29& q, uint32_t c) {
+  const fe29* pc = reinterpret_cast<const fe29*>(&p); const fe29* qc = reinterpret_cast<const fe29*>(&q);   // {X, Y, T, Z}
+  const uint32_t ci = c < 2 ? 1u : c;                               // roles 0 / 1 use Y -/+ X, role 2 T, role 3 Z
+  const int32_t sg = c == 0 ? -1 : (c == 1 ? 1 : 0);
+  fe29 a, b;
+#pragma unroll
+  for (int k = 0; k < 9; k++) { a.v[k] = pc[ci].v[k] + sg * pc[0].v[k]; b.v[k] = qc[ci].v[k] + sg * qc[0].v[k]; }
+  return fe_mul_small(fe_mul(a, fe_weak(b)), c == 2 ? ED_K_C : (c == 3 ? ED_K_D : ED_K_AB));
+}
+LHD fe29 pt_coop4_stage2(const fe29& A, const fe29& Bv, const fe29& Cs, const fe29& Ds, uint32_t c) {
+  // role 0: E*F, role 1: H*G, role 2: E*H, role 3: F*G   with (all times lambda) E = B - A, F = D - C = Ds + Cs, G = D + C = Ds - Cs, H = B + A
+  fe29 u, w;
+#pragma unroll
+  for (int k = 0; k < 9; k++) {
+    const int32_t E = Bv.v[k] - A.v[k], F = Ds.v[k] + Cs.v[k], G = Ds.v[k] - Cs.v[k], H = Bv.v[k] + A.v[k];
+    u.v[k] = c == 0 ? E : (c == 1 ? H : (c == 2 ? E : F));
+    w.v[k] = c == 0 ? F : (c == 1 ? G : (c == 2 ? H : G));
+  }
+  return fe_mul(fe_weak(u), fe_weak(w));
 }
 LHD pt29 pt_dbl(const pt29& p) {
   fe29 A = fe_sqr(p.X), B = fe_sqr(p.Y), C = fe_dbl(fe_sqr(p.Z));

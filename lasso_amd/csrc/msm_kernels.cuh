@@ -294,42 +294,16 @@ __device__ __forceinline__ void msm_coop_tree(pt29* pts, fe29 (*st4)[4], uint32_
 }
 #else
 __device__ __forceinline__ void msm_coop_tree(pt29* pts, fe29 (*st)[4], uint32_t live, const fe29& d2) {
+  (void)d2;   // the curve constant enters as two small multipliers (fe29.cuh pt_coop4_stage1)
   const uint32_t t = threadIdx.x, c = t & 3u, g = t >> 2;
   uint32_t p2 = 1; while (p2 < live) p2 <<= 1;
-  // roles 0/1 use (Y -/+ X), role 2 T, role 3 Z:  first = coordinate index {1,1,2,3} (X,Y,T,Z = 0..3), second = X with sign {-1,+1,0,0}
-  const uint32_t ci = c < 2 ? 1u : c;
-  const int32_t sg = c == 0 ? -1 : (c == 1 ? 1 : 0);
-  fe29 k1 = fe_one();   // first-stage constant: 2d for role 2, 1 otherwise
-#pragma unroll
-  for (int k = 0; k < 9; k++) k1.v[k] = c == 2 ? d2.v[k] : k1.v[k];
   for (uint32_t s = p2 >> 1; s > 0; s >>= 1) {
     for (uint32_t i0 = 0; i0 < s; i0 += MSM_THREADS / 4) {
       const uint32_t i = i0 + g;
       const bool act = i < s && i + s < live;
-      if (act) {
-        const fe29* pc = reinterpret_cast<const fe29*>(&pts[i]);
-        const fe29* qc = reinterpret_cast<const fe29*>(&pts[i + s]);
-        const fe29 p1 = pc[ci], px = pc[0], q1 = qc[ci], qx = qc[0];
-        fe29 a, b;
-#pragma unroll
-        for (int k = 0; k < 9; k++) { a.v[k] = p1.v[k] + sg * px.v[k]; b.v[k] = q1.v[k] + sg * qx.v[k]; }
-        fe29 v = fe_mul(fe_mul(a, k1), fe_weak(b));
-        if (c == 3) v = fe_dbl(v);
-        st[g][c] = v;
-      }
+      if (act) st[g][c] = pt_coop4_stage1(pts[i], pts[i + s], c);
       __syncthreads();
-      if (act) {
-        const fe29 A = st[g][0], Bv = st[g][1], C = st[g][2], D = st[g][3];
-        // role 0: E*F, role 1: H*G, role 2: E*H, role 3: F*G   with E = B-A, F = D-C, G = D+C, H = B+A
-        fe29 u, w;
-#pragma unroll
-        for (int k = 0; k < 9; k++) {
-          const int32_t E = Bv.v[k] - A.v[k], F = D.v[k] - C.v[k], G = D.v[k] + C.v[k], H = Bv.v[k] + A.v[k];
-          u.v[k] = c == 0 ? E : (c == 1 ? H : (c == 2 ? E : F));
-          w.v[k] = c == 0 ? F : (c == 1 ? G : (c == 2 ? H : G));
-        }
-        reinterpret_cast<fe29*>(&pts[i])[c] = fe_mul(fe_weak(u), fe_weak(w));   // pt29 = {X, Y, T, Z}: role c owns coordinate c
-      }
+      if (act) reinterpret_cast<fe29*>(&pts[i])[c] = pt_coop4_stage2(st[g][0], st[g][1], st[g][2], st[g][3], c);   // pt29 = {X, Y, T, Z}: role c owns coordinate c
       __syncthreads();
     }
   }

@@ -49,6 +49,28 @@ int main() {
     const Point &p = pts[i], &q = pts[(i * 5 + 2) % pts.size()];
     CHECK(same_pt(pt_add(to29(p), to29(q), d2), p + q));
     CHECK(same_pt(pt_add(to29(p), to29(p), d2), p.dbl()));
+    {   // the addition split over four lanes (msm_coop_tree): stage 1 = A, B, Cs, Ds (one product + the small curve constants), stage 2 = the four coordinates; lanes emulated
+      for (int rep = 0; rep < 3; rep++) {
+        const pt29 pa = to29(p), pb = rep == 0 ? to29(q) : (rep == 1 ? to29(p) : pt_identity());
+        fe29 st[4]; for (uint32_t c = 0; c < 4; c++) st[c] = pt_coop4_stage1(pa, pb, c);
+        pt29 r; for (uint32_t c = 0; c < 4; c++) reinterpret_cast<fe29*>(&r)[c] = pt_coop4_stage2(st[0], st[1], st[2], st[3], c);
+        CHECK(same_pt(r, rep == 0 ? p + q : (rep == 1 ? p.dbl() : p)));
+      }
+    }
+    {   // small-constant multiplication on reduced and on product-output operands
+      const fe29 x = fe_from_fq(fq32(p.X)), y = fe_mul(x, fe_from_fq(fq32(q.Y)));
+      for (int32_t k : {1, 2, 243330, 243332, (1 << 18) - 1}) { CHECK(reduced(fe_mul_small(x, k))); CHECK(same29(fe_mul_small(x, k), p.X * Fq::from_u64((uint64_t)k))); CHECK(same29(fe_mul_small(y, k), p.X * q.Y * Fq::from_u64((uint64_t)k))); }
+    }
+    {   // a chain of 300 cooperative additions stays reduced and correct (the tree's levels feed each other)
+      pt29 acc = to29(p); Point ref = p;
+      for (int k2 = 0; k2 < 300; k2++) {
+        const pt29 other = (k2 & 1) ? to29(q) : acc;
+        fe29 st[4]; for (uint32_t c = 0; c < 4; c++) st[c] = pt_coop4_stage1(acc, other, c);
+        pt29 r; for (uint32_t c = 0; c < 4; c++) reinterpret_cast<fe29*>(&r)[c] = pt_coop4_stage2(st[0], st[1], st[2], st[3], c);
+        ref = (k2 & 1) ? ref + q : ref.dbl(); acc = r;
+      }
+      CHECK(same_pt(acc, ref));
+    }
     CHECK(same_pt(pt_dbl(to29(p)), p.dbl()));
     Fq qx, qy; q.to_affine(qx, qy);
     niels29 n = niels_from_affine(fq32(qx), fq32(qy));
