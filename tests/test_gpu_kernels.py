@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 def devs():
     from lasso_amd import Device
     from fieldref import CURVE
-    real = Device(0, curve=CURVE)     # raises loudly if the HIP library / GPU is missing (LASSO_TEST_CURVE=bn254: the BN254 build, tools/gpu_bn254.sh)
+    real = Device(0, curve=CURVE)     # raises loudly if the HIP library / GPU is missing (LASSO_TEST_CURVE=bn254: the BN254 build, tools/gpu.sh tests_bn254)
     mock = Device(0, lib=load_mock())
     yield real, mock
     real.close(); mock.close()
