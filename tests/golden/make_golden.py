@@ -15,10 +15,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-KINDS = {"and": 0, "or": 1, "xor": 2, "lt": 3, "range": 4}
+KINDS = {"and": 0, "or": 1, "xor": 2, "lt": 3, "range": 4, "spark": 5}   # spark = LASSO_SPARK_UNCONFIRMED (round 4): pins the restated strategy against its own drift, like the rest
 # (kind, C, log_m, log_r, lookups, seed): seed None = the bench harness's inputs (benches/bench.rs:13-34), else numpy default_rng(seed) indices
 INSTANCES = [("and", 1, 16, 0, 1 << 10, None), ("and", 4, 4, 0, 16, None), ("lt", 4, 4, 0, 128, None), ("range", 3, 8, 40, 16, None),
-             ("xor", 3, 4, 0, 11, 7), ("or", 2, 6, 0, 50, 3), ("and", 1, 8, 0, 300, 11)]
+             ("xor", 3, 4, 0, 11, 7), ("or", 2, 6, 0, 50, 3), ("and", 1, 8, 0, 300, 11), ("spark", 3, 6, 0, 100, 5), ("spark", 16, 4, 0, 64, None)]
 
 
 def instance(orc, kind, c, log_m, lookups, seed):
