@@ -10,7 +10,8 @@ from lasso_amd import _abi
 from proverutil import HostProver, OracleSession, build_mock_prover
 
 CASES = [("lt", 4, 4, 0, 16), ("and", 4, 4, 0, 16), ("range", 3, 8, 40, 16), ("and", 1, 4, 0, 64), ("xor", 2, 4, 0, 32), ("or", 2, 4, 0, 8),
-         ("and", 1, 16, 0, 1 << 10), ("and", 1, 4, 0, 2), ("xor", 3, 4, 0, 11), ("and", 4, 8, 0, 1 << 8)]
+         ("and", 1, 16, 0, 1 << 10), ("and", 1, 4, 0, 2), ("xor", 3, 4, 0, 11), ("and", 4, 8, 0, 1 << 8),
+         ("spark", 2, 4, 0, 32), ("spark", 5, 4, 0, 40), ("spark", 16, 2, 0, 32)]   # LASSO_SPARK_UNCONFIRMED over BN254
 
 
 @pytest.fixture(scope="module")

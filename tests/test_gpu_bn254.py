@@ -13,7 +13,8 @@ from proverutil import OracleSession
 pytestmark = pytest.mark.gpu
 
 CASES = [("lt", 4, 4, 0, 16), ("and", 4, 4, 0, 16), ("range", 3, 8, 40, 16), ("and", 1, 4, 0, 2), ("xor", 3, 4, 0, 11), ("or", 2, 4, 0, 8),
-         ("and", 1, 16, 0, 1 << 10), ("and", 4, 16, 0, 1 << 12), ("xor", 8, 8, 0, 1 << 10), ("and", 1, 16, 0, 1 << 14)]
+         ("and", 1, 16, 0, 1 << 10), ("and", 4, 16, 0, 1 << 12), ("xor", 8, 8, 0, 1 << 10), ("and", 1, 16, 0, 1 << 14),
+         ("spark", 2, 8, 0, 300), ("spark", 4, 16, 0, 1 << 12), ("spark", 16, 4, 0, 64)]   # LASSO_SPARK_UNCONFIRMED over BN254
 
 
 @pytest.fixture(scope="module")
