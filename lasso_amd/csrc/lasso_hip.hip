@@ -244,7 +244,8 @@ static int32_t wait_flag(lasso_ctx* c, uint32_t seq, size_t count, lasso_fr* out
 // (ADVICE r3).  next_seq hands out `span` consecutive numbers and, long before the top of the range, starts a new epoch instead: drain the stream (nothing in flight can
 // still publish), zero the tagged result area and the mailbox, and restart at 1.  Costs one stream synchronisation per ~4e9 hand-offs.
 static uint32_t next_seq(lasso_ctx* c, uint32_t span = 1) {
-  if (c->seq > 0xFFF00000u - span) {
+  // not while a result is still uncollected (lasso_defer_next) or a resident tail holds a block of numbers: the 2^20 numbers of slack cover any such stretch
+  if (c->seq > 0xFFF00000u - span && ((!c->pending && !c->tail_active) || c->seq > 0xFFFFFF00u - span)) {
     (void)hipStreamSynchronize(c->stream);
     if (c->h_tag) memset(c->h_tag, 0, c->small_cap * 48);
     if (c->mail_h) memset(c->mail_h, 0, 48);
