@@ -399,6 +399,18 @@ def slab_worker(a):
         out["parity_against"] = f"oracle prover digests of this instance (tests/golden/full_config_digests.json; oracle on {gold['threads']} threads, tools/parity_full_configs.py)"
     else:
         out["parity"] = None
+    if not a.slab_capacity:
+        # the same proof once more in capacity mode (lasso_host_set_capacity: product trees without their leaf layers): what a rank holds at most, and what it costs
+        try:
+            hp.set_capacity(True); hp.mem_stats(reset=True)
+            p2 = hp.prove(dense, gens, S, r)      # warm-up of the capacity path
+            t0 = time.perf_counter(); p2 = hp.prove(dense, gens, S, r); el2 = time.perf_counter() - t0
+            m2 = hp.mem_stats()
+            out["capacity_mode"] = {"ms_per_proof": el2 * 1e3, "peak_bytes_per_rank": m2["peak_bytes"], "prover_peak_bytes_per_rank": m2["prover_peak_bytes"],
+                                    "model_bytes_per_rank": int(slab_bytes_per_rank(kind, c, log_s, world, log_m, True)), "same_bytes_as_pooled": p2 == proof,
+                                    "note": "peak = the resident committed polynomials and generator tables + this mode's proof (the high-water mark was reset after the pooled proofs)"}
+        except Exception as e:
+            out["capacity_mode"] = {"error": repr(e)[:300]}
     hp.free(dense, gens); hp.close()
     print(json.dumps(out), flush=True)
 

@@ -32,6 +32,7 @@ def test_bench_gpus2_self_launch_prints_weak_and_slab(oracle):
     assert out["value"] > 0 and out["lib_sha"]["sources_sha256"]
     slab = out["slab_mode"]
     assert slab.get("n_gpus") == 2 and slab["scaling"] == "strong", slab
+    assert slab["capacity_mode"]["same_bytes_as_pooled"] is True      # the leg's second pass (lasso_host_set_capacity) proves the same bytes
     assert slab["rccl_ranks"] == 0                                   # no GPU per rank here: the rows travel through the shared-memory exchange, consistently on both ranks
     # the sharded proof is the single-prover proof of the same instance: compare with the oracle
     from lasso_amd import _abi

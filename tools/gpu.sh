@@ -36,7 +36,7 @@ if cp: print("  concurrent:", [(x["streams"], round(x["value"] / 1e9, 3), x["pro
 bs = d.get("bind_top_sweep")
 if bs: print("  bind_top_sweep:", [(x["log_n"], x["polys"], x.get("alg_GBps"), x.get("frac"), x.get("error")) for x in bs["rows"]])
 sm = d.get("slab_mode")
-if sm: print("  slab:", {k: sm.get(k) for k in ("ms_per_proof", "parity", "peak_bytes_per_rank", "model_bytes_per_rank", "error", "skipped")})
+if sm: print("  slab:", {k: sm.get(k) for k in ("ms_per_proof", "parity", "peak_bytes_per_rank", "model_bytes_per_rank", "error", "skipped")}, "capacity:", sm.get("capacity_mode"))
 PY
 }
 r_prof() {         # prof <tag> [bench.py args...]: rocprofv3 --kernel-trace --stats of a short bench run; csv files kept
