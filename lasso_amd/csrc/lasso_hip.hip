@@ -162,7 +162,7 @@ struct ProfScope {
 static void prof_flush(lasso_ctx* c) {
   if (!c->events_used) return;
   (void)hipStreamSynchronize(c->stream);
-  std::vector<uint32_t> counts;
+  std::vector<uint64_t> counts;   // 64-bit: a full-width commitment of 2^28 scalars executes 1.6e10 additions in ONE launch (the 32-bit sum wrapped: Spark C=16 2^24 read 0.12 for 0.67)
   if (c->d_prof_counts) {
     const size_t m = c->events_used < LASSO_PROF_COUNT_SLOTS ? c->events_used : LASSO_PROF_COUNT_SLOTS;
     std::vector<uint32_t> raw(m * 64); counts.assign(m, 0);
