@@ -594,7 +594,11 @@ static int32_t cubic_eqw_launch_t(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* 
       static const uint32_t pipe = [] { const char* v = getenv("LASSO_LB_PIPELINE"); return (v && v[0] == '0') ? 0u : 1u; }();
       if (NT == 3) hipLaunchKernelGGL((k_cubic_eqw_lb<3, false, TP, EqNone>), dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, Ac, Bc, nx, ny, (const fr_t*)d_E, half, (fr_t*)c->d_scratch, c->d_counters, r_out, r_flag, seq, 0u, EqNone(), (fr_t*)nullptr);
       else if (eqi) hipLaunchKernelGGL((k_cubic_eqw_lb<2, true, TP, EqInline>), dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, Ac, Bc, nx, ny, (const fr_t*)nullptr, half, (fr_t*)c->d_scratch, c->d_counters, r_out, r_flag, seq, 1u, *eqi, (fr_t*)d_E);
-      else hipLaunchKernelGGL((k_cubic_eqw_lb<2, false, TP, EqNone>), dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, Ac, Bc, nx, ny, (const fr_t*)d_E, half, (fr_t*)c->d_scratch, c->d_counters, r_out, r_flag, seq, pipe, EqNone(), (fr_t*)nullptr);
+      else {
+        static const bool lb_nt = [] { const char* v = getenv("LASSO_LB_NT"); return v && v[0] == '1'; }();   // A/B switch: non-temporal loads of A and B in the evaluation-only round
+        if (lb_nt && pipe) hipLaunchKernelGGL((k_cubic_eqw_lb<2, false, TP, EqNone, true>), dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, Ac, Bc, nx, ny, (const fr_t*)d_E, half, (fr_t*)c->d_scratch, c->d_counters, r_out, r_flag, seq, pipe, EqNone(), (fr_t*)nullptr);
+        else hipLaunchKernelGGL((k_cubic_eqw_lb<2, false, TP, EqNone>), dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, Ac, Bc, nx, ny, (const fr_t*)d_E, half, (fr_t*)c->d_scratch, c->d_counters, r_out, r_flag, seq, pipe, EqNone(), (fr_t*)nullptr);
+      }
     }
   } else {
     const size_t q = n / 4;

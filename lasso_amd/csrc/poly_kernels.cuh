@@ -306,7 +306,13 @@ __device__ __forceinline__ void eq_inline_build(const EqInline& Q, EqInlineTable
 __device__ __forceinline__ fr29 eq_inline_s(const EqInlineTables& T, uint32_t lb, size_t x) { return fr29_mul(T.hi_s[x >> lb], T.lo_s[x & ((1u << lb) - 1u)]); }
 // out[c*NT + ..] = the NT sums over i < half of circuit c.  1-D grid of nx*ny workgroups (cubic_grid).
 // EQI: E is built on the way (eq_inline_build): E_out (half entries) is written by the workgroups of circuit 0, nothing is read from it.
-template <int NT, bool EQI = false, class TP = PtrTable, class TE = EqInline>
+// one 32-byte element with the non-temporal hint (two dwordx4): data that is read exactly once per launch (the layer's A and B in a round that only evaluates)
+__device__ __forceinline__ fr_t fr_load_nt(const fr_t* p) {
+  const lasso_u32x4* q = reinterpret_cast<const lasso_u32x4*>(p);
+  const lasso_u32x4 x = __builtin_nontemporal_load(q), y = __builtin_nontemporal_load(q + 1);
+  fr_t r; r.v[0] = x.x; r.v[1] = x.y; r.v[2] = x.z; r.v[3] = x.w; r.v[4] = y.x; r.v[5] = y.y; r.v[6] = y.z; r.v[7] = y.w; return r;
+}
+template <int NT, bool EQI = false, class TP = PtrTable, class TE = EqInline, bool NTL = false>
 __global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_eqw_lb(TP A, TP B, uint32_t nx, uint32_t ny, const fr_t* __restrict__ E, size_t half, fr_t* __restrict__ partials, uint32_t* counters,
                                                                fr_t* __restrict__ out, uint32_t* flag, uint32_t seq, uint32_t pipeline, TE EQ = TE(), fr_t* __restrict__ E_out = nullptr) {
   __shared__ RedScratch S;
@@ -336,11 +342,15 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_eqw_lb(TP A, TP B, uint32
     // software-pipelined: the five 32-byte loads of the NEXT index are in flight while this one's four products issue.  The round reads and never writes, its
     // ~900 instructions per index are too few to hide a ~2 us HBM access behind two waves per SIMD, and the compiler keeps the loads at the head of the loop
     // body: measured 3.6 TB/s of reads (1.07 GB in 316 us at the 2^24 top layer) where a read stream reaches 6.
-    fr_t a0 = a[i], a1 = a[i + half], b0m = b[i], b1m = b[i + half], em = EQI ? fr_zero() : E[i];
+    // NTL (LASSO_LB_NT=1): A and B with the non-temporal hint — they are read once, and a read-only stream reaches 6.7-7.0 TB/s that way against 6.0-6.3 plain
+    // (DESIGN_HISTORY 6.1); E is shared by the circuits' workgroups on one XCD and stays cached
+#define LB_LD(ptr) (NTL ? fr_load_nt(ptr) : *(ptr))
+    fr_t a0 = LB_LD(a + i), a1 = LB_LD(a + i + half), b0m = LB_LD(b + i), b1m = LB_LD(b + i + half), em = EQI ? fr_zero() : E[i];
     for (;;) {
       const size_t in = i + stride; const bool more = in < half;
       const size_t ip = more ? in : i;     // clamp: the last iteration re-reads its own (cached) lines instead of branching around the loads
-      const fr_t na0 = a[ip], na1 = a[ip + half], nb0 = b[ip], nb1 = b[ip + half], ne = EQI ? fr_zero() : E[ip];
+      const fr_t na0 = LB_LD(a + ip), na1 = LB_LD(a + ip + half), nb0 = LB_LD(b + ip), nb1 = LB_LD(b + ip + half), ne = EQI ? fr_zero() : E[ip];
+#undef LB_LD
       fr29 es;
       if (EQI) {
         es = eq_inline_s(ET, elb, i);

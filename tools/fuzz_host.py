@@ -10,17 +10,18 @@ curve = sys.argv[1] if len(sys.argv) > 1 else "curve25519"
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 budget = float(sys.argv[3]) if len(sys.argv) > 3 else 120
 orc = conftest._load_oracle(conftest._build_oracle_bn254() if curve == "bn254" else conftest._build_oracle())
-if "hip" in sys.argv:      # the product library on a GPU box instead of the mock: python tools/fuzz_host.py curve25519 1 60 hip
+if "hip" in sys.argv:      # the product library on a GPU box instead of the mock: python tools/fuzz_host.py curve25519 1 60 hip [capacity]
     from lasso_amd import HostProver as HipProver
     hp = HipProver(curve=curve)
+    if "capacity" in sys.argv: hp.set_capacity(True)      # with LASSO_LEAFLESS_MIN=64 in the environment: the chunked leaf rounds on every instance large enough
 else:
     hp = HostProver(C.CDLL(build_mock_prover(curve)))
 rng = np.random.default_rng(seed0)
 t0 = time.time(); n = 0
 while time.time() - t0 < budget:
-    kind = ["and", "or", "xor", "lt", "range"][rng.integers(5)]
+    kind = ["and", "or", "xor", "lt", "range", "spark"][rng.integers(6)]      # spark = LASSO_SPARK_UNCONFIRMED (round 4)
     c = int(rng.integers(1, 5)); log_m = int(rng.integers(1, 9));
-    if kind != "range" and log_m % 2: log_m += 1   # the bitwise tables split an address into two operands of log_m / 2 bits
+    if kind not in ("range", "spark") and log_m % 2: log_m += 1   # the bitwise tables split an address into two operands of log_m / 2 bits
     lookups = int(rng.integers(2, 700)) if rng.integers(4) else int(rng.integers(2, 5000))   # one lookup (s = 1) is outside the reference's domain: GrandProductCircuit::new needs two leaves
     log_r = int(rng.integers(1, c * log_m + 1)) if kind == "range" else 0
     if kind == "range" and c * log_m > 63: continue
