@@ -293,6 +293,17 @@ __device__ __forceinline__ void msm_coop_tree(pt29* pts, fe29 (*st4)[4], uint32_
   }
 }
 #else
+// Barriers: a quad is four adjacent lanes of ONE wave, so the exchange between its two stages only needs the wave's own LDS operations kept in order (tree_wave_sync), not a
+// workgroup barrier; and from the level of 16 additions down every active quad AND every point it reads (written one level up by quads 0..31 -> for s <= 16 by quads 0..15)
+// belongs to wave 0, so those levels need no workgroup barrier either.  What stays: one workgroup barrier after each level of more than 16 additions.  LASSO_TREE_BARRIERS=1
+// at compile time restores the two workgroup barriers per pass (A/B).
+__device__ __forceinline__ void tree_wave_sync() {
+#ifdef LASSO_TREE_BARRIERS
+  __syncthreads();
+#else
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+}
 __device__ __forceinline__ void msm_coop_tree(pt29* pts, fe29 (*st)[4], uint32_t live, const fe29& d2) {
   (void)d2;   // the curve constant enters as two small multipliers (fe29.cuh pt_coop4_stage1)
   const uint32_t t = threadIdx.x, c = t & 3u, g = t >> 2;
@@ -302,9 +313,13 @@ __device__ __forceinline__ void msm_coop_tree(pt29* pts, fe29 (*st)[4], uint32_t
       const uint32_t i = i0 + g;
       const bool act = i < s && i + s < live;
       if (act) st[g][c] = pt_coop4_stage1(pts[i], pts[i + s], c);
-      __syncthreads();
+      tree_wave_sync();
       if (act) reinterpret_cast<fe29*>(&pts[i])[c] = pt_coop4_stage2(st[g][0], st[g][1], st[g][2], st[g][3], c);   // pt29 = {X, Y, T, Z}: role c owns coordinate c
+#ifdef LASSO_TREE_BARRIERS
       __syncthreads();
+#else
+      if (s > 16) __syncthreads(); else tree_wave_sync();   // s is uniform over the workgroup: every thread takes the same path
+#endif
     }
   }
 }
