@@ -114,3 +114,22 @@ def test_concurrent_sweep_checks_every_proof_against_its_sequential_bytes():
     made.clear(); FakeProver.flaky = True
     out = bench.concurrent_leg(FakeProver, _abi, 4, 2, S, 1, 8, 6)
     assert out["all_proofs_identical_to_sequential"] is False and sum(x["proofs_differing_from_sequential"] for x in out["sweep"]) == 1
+
+
+def test_bench_gpus2_shard_proof_is_one_proof_over_both_ranks(oracle):
+    """`bench.py --gpus 2 --shard-proof`: the timed proof itself is ONE proof over the two ranks (slab mode as `value`, "scaling": "strong") — both ranks must hold the same
+    bytes, and they are the oracle's for that instance."""
+    import hashlib
+    so = build_mock_prover()
+    env = dict(os.environ, LASSO_PROVER_LIB=so, LASSO_DEVICE_LIB=so, OMP_NUM_THREADS="2")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--shard-proof", "--steps", "1", "--warmup", "0", "--kind", "xor", "--c", "2", "--log-s", "8", "--log-m", "6",
+           "--no-cpu-baseline", "--concurrent", "0", "--no-slab-leg", "--no-prof"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["config"]["distinct_proofs"] == 1 and out["value"] > 0
+    assert out["config"]["per_rank"].startswith("one proof sharded")
