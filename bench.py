@@ -399,6 +399,7 @@ def slab_worker(a):
         out["parity_against"] = f"oracle prover digests of this instance (tests/golden/full_config_digests.json; oracle on {gold['threads']} threads, tools/parity_full_configs.py)"
     else:
         out["parity"] = None
+    print(json.dumps(out), flush=True)      # the leg's result so far: whatever happens in the capacity pass below, the parent still has this line (it takes the LAST one it can parse)
     if not a.slab_capacity:
         # the same proof once more in capacity mode (lasso_host_set_capacity: product trees without their leaf layers): what a rank holds at most, and what it costs
         try:
@@ -434,14 +435,26 @@ def slab_leg(a, grp, shm_name):
     cmd = [sys.executable, os.path.abspath(__file__), "--slab-worker", f"{rank},{world},{grp.device_index},{shm_name}_slab", "--slab-kind", kind, "--slab-c", str(c),
            "--slab-log-s", str(log_s), "--slab-steps", str(a.slab_steps), "--log-m", str(a.log_m), "--log-r", str(a.log_r), "--curve", a.curve] + (["--slab-capacity"] if a.slab_capacity else [])
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}   # the child is not a torch.distributed rank
+    def last_line(text):
+        for ln in reversed([x for x in (text or "").strip().splitlines() if x.startswith("{")]):
+            try:
+                return json.loads(ln)
+            except Exception:
+                continue
+        return None
     try:
         res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=a.slab_timeout)
-    except subprocess.TimeoutExpired:
+    except subprocess.TimeoutExpired as e:
+        got = last_line(e.stdout.decode() if isinstance(e.stdout, bytes) else e.stdout)
+        if got:     # the pooled pass finished and printed; only the capacity pass behind it did not
+            got["capacity_mode"] = {"error": f"did not finish within {a.slab_timeout:.0f} s"}; return got
         return {"error": f"slab leg did not finish within {a.slab_timeout:.0f} s", "timed_out": True, "n_gpus": world}
-    lines = [ln for ln in res.stdout.strip().splitlines() if ln.startswith("{")]
-    if res.returncode != 0 or not lines:
+    got = last_line(res.stdout)
+    if got is None:
         return {"error": f"slab worker exited with {res.returncode}: {res.stderr.strip()[-400:]}", "n_gpus": world}
-    return json.loads(lines[-1])
+    if res.returncode != 0:
+        got.setdefault("capacity_mode", {"error": f"worker exited with {res.returncode}: {res.stderr.strip()[-300:]}"})
+    return got
 
 
 def self_launch(a):
