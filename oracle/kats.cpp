@@ -186,6 +186,20 @@ KAT(range_table)
   // memory_to_subtable_index (range_check.rs:62-69) at LOG_R=40, log_m=16: memories 0,1 full; 2 remainder; 3 zeros
   CHECK(S.memory_to_subtable_index(0) == 0 && S.memory_to_subtable_index(1) == 0 && S.memory_to_subtable_index(2) == 1 && S.memory_to_subtable_index(3) == 2, 6);
 KAT_END
+// STRAT_SPARK_UNCONFIRMED (not in the reference snapshot; lasso_oracle.hpp states what it restates): no reference KAT exists, so the self-consistency properties the reference's
+// own macro checks for every strategy (subtables/test.rs:15-40): each subtable's MLE agrees with the materialised table on the hypercube; plus the shape of the strategy
+KAT(spark_unconfirmed)
+  for (size_t C : {(size_t)1, (size_t)3, (size_t)16}) {
+    Strategy S = strat(STRAT_SPARK_UNCONFIRMED, C, 16);
+    CHECK(S.num_subtables() == C && S.num_memories() == C && S.g_poly_degree() == C && S.sumcheck_poly_degree() == C + 1, 1);
+    for (size_t i = 0; i < C; i++) CHECK(S.memory_to_subtable_index(i) == i && S.memory_to_dimension_index(i) == i, 2);
+    CHECK(mle_parity(S) == 0, 3);
+    auto t = S.materialize_subtables();
+    for (size_t k = 0; k < C; k++) { Fr sum = Fr::zero(); for (auto& x : t[k]) sum += x; CHECK(sum == Fr::one(), 4); }   // an eq table sums to 1
+  }
+  Fr vals[3] = {F(3), F(5), F(7)};
+  CHECK(strat(STRAT_SPARK_UNCONFIRMED, 3, 16).combine_lookups(vals) == F(105), 5);
+KAT_END
 // poly/dense_mlpoly.rs:585-625 check_polynomial_commit: commit -> open -> verify
 KAT(poly_commit_open_verify)
   DensePolynomial p({F(1), F(2), F(1), F(4)});
@@ -250,10 +264,11 @@ KAT(e2e_prove_3d_range) return e2e(STRAT_RANGE, 3, 256, 40, 16); KAT_END
 KAT(e2e_prove_1d_and_s64) return e2e(STRAT_AND, 1, 16, 0, 64); KAT_END
 KAT(e2e_prove_2d_xor) return e2e(STRAT_XOR, 2, 16, 0, 32); KAT_END
 KAT(e2e_prove_2d_or) return e2e(STRAT_OR, 2, 16, 0, 8); KAT_END
+KAT(e2e_prove_spark_unconfirmed) return e2e(STRAT_SPARK_UNCONFIRMED, 3, 16, 0, 16); KAT_END   // the same acceptance criterion for the restated strategy (not a reference test)
 
 extern "C" const char* orc_kat_names() {
   return "poly_evaluation_28,poly_evaluation_const8,eq_evals_vs_naive,unipoly_quad,unipoly_cubic,gauss,split_bits,grand_product_24,"
          "sumcheck_scripted_313,memory_checking_multiset,and_table,and_merged_poly,or_table,xor_table,lt_table,range_table,"
          "poly_commit_open_verify,dot_product_log,e2e_prove_4d_lt,e2e_prove_4d_lt_big_s,e2e_prove_4d_and,e2e_prove_3d_range,"
-         "e2e_prove_1d_and_s64,e2e_prove_2d_xor,e2e_prove_2d_or";
+         "e2e_prove_1d_and_s64,e2e_prove_2d_xor,e2e_prove_2d_or,spark_unconfirmed,e2e_prove_spark_unconfirmed";
 }

@@ -449,6 +449,36 @@ def test_slab_commitment_exchange_on_device(devs, gens_300, world, ls, rs, maxv)
     assert have_rccl, "librccl could not be loaded / initialised on this box (the exchange itself was still checked through a plain copy)"
 
 
+def test_mem_stats_accounts_allocations_tables_and_peak():
+    """lasso_mem_stats: bytes held through a context (buffers, generator tables), the high-water mark and its reset — what bench.py's peak_bytes_per_rank rests on"""
+    from lasso_amd import Device
+    d = Device(curve="bn254" if os.environ.get("LASSO_TEST_CURVE") == "bn254" else "curve25519")
+    u64 = C.c_uint64
+
+    def stats(reset=0):
+        live, peak = u64(), u64()
+        assert d.lib.lasso_mem_stats(d.ctx, C.byref(live), C.byref(peak), reset) == 0
+        return live.value, peak.value
+    l0, p0 = stats()
+    assert p0 >= l0 > 0                      # the context's own scratch
+    a = d.alloc(1 << 26); b = d.alloc(3 << 20)
+    l1, p1 = stats()
+    assert l1 == l0 + (1 << 26) + (3 << 20) and p1 >= l1
+    d.free(a)
+    l2, p2 = stats()
+    assert l2 == l0 + (3 << 20) and p2 == p1  # the peak stays
+    l3, p3 = stats(reset=1); l4, p4 = stats()
+    assert p4 == l4 == l2                     # reset: the peak restarts at what is live
+    G = gens(40)
+    bases = d.bases_create(G)
+    l5, _ = stats()
+    assert l5 > l4 + 40 * 64 * 100            # window table (+ digit multiples) of 40 generators
+    d.bases_destroy(bases); d.free(b)
+    l6, _ = stats()
+    assert l6 == l0
+    d.close()
+
+
 def test_rccl_two_ranks_on_one_device(devs):
     """drive ncclAllGather with world > 1 if the box allows two communicators on one device.  Two contexts of the one MI355X join one communicator
     (lasso_rccl_init rank 0 / 1, one host thread each, as two ranks of a node would).  Either RCCL accepts — then a real 2-rank ncclAllGather runs on the two library streams and
