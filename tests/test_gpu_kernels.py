@@ -449,7 +449,7 @@ def test_slab_commitment_exchange_on_device(devs, gens_300, world, ls, rs, maxv)
     assert have_rccl, "librccl could not be loaded / initialised on this box (the exchange itself was still checked through a plain copy)"
 
 
-def test_mem_stats_accounts_allocations_tables_and_peak():
+def test_mem_stats_accounts_allocations_tables_and_peak(gens_300):
     """lasso_mem_stats: bytes held through a context (buffers, generator tables), the high-water mark and its reset — what bench.py's peak_bytes_per_rank rests on"""
     from lasso_amd import Device
     d = Device(curve="bn254" if os.environ.get("LASSO_TEST_CURVE") == "bn254" else "curve25519")
@@ -469,8 +469,7 @@ def test_mem_stats_accounts_allocations_tables_and_peak():
     assert l2 == l0 + (3 << 20) and p2 == p1  # the peak stays
     l3, p3 = stats(reset=1); l4, p4 = stats()
     assert p4 == l4 == l2                     # reset: the peak restarts at what is live
-    G = gens(40)
-    bases = d.bases_create(G)
+    bases = d.bases_create(np.ascontiguousarray(gens_300[:40]))
     l5, _ = stats()
     assert l5 > l4 + 40 * 64 * 100            # window table (+ digit multiples) of 40 generators
     d.bases_destroy(bases); d.free(b)
