@@ -371,3 +371,16 @@ def test_gpu_live_transcript_and_tape_through_the_callbacks(host, oracle, kind, 
         for x in (t, tape, t2, tape2):
             x.close()
         host.free(dense, gens)
+
+
+def test_gpu_c99_program_through_the_c_abi(tmp_path):
+    """examples/prove_c_abi.c linked against the PRODUCT libraries (liblasso_prover.so -> liblasso_hip.so): the boundary driven from plain C on the device — densify, commit,
+    prove (labels and callbacks: identical bytes), verify."""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib_dir = os.path.join(root, "lasso_amd"); exe = str(tmp_path / "prove_c_abi")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "prove_c_abi.c"), "-o", exe,
+                           "-L" + lib_dir, "-llasso_prover", "-Wl,-rpath," + lib_dir])
+    res = subprocess.run([exe, "14"], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "verified 1" in res.stdout and "callback path identical 1" in res.stdout
