@@ -31,7 +31,7 @@
 namespace lasso {
 
 class ShmComm {
-  struct alignas(64) Header { std::atomic<uint32_t> magic; uint32_t world; uint64_t slot_bytes; std::atomic<uint32_t> attached; std::atomic<uint32_t> blob_ready; uint32_t creator_pid; uint8_t blob[256]; };
+  struct alignas(64) Header { std::atomic<uint32_t> magic; uint32_t world; uint64_t slot_bytes; std::atomic<uint32_t> attached; std::atomic<uint32_t> blob_ready; uint32_t creator_pid; uint64_t creator_pidns; uint8_t blob[256]; };
   struct alignas(64) SeqLine { std::atomic<uint64_t> seq; uint8_t pad[56]; };
   static constexpr uint32_t MAGIC = 0x4c53484du;   // "LSHM"
   uint8_t* base_ = nullptr; size_t map_bytes_ = 0; std::string name_;
@@ -43,6 +43,8 @@ class ShmComm {
   size_t rank_stride() const { return 2 * sizeof(SeqLine) + 2 * slot_bytes_; }
   SeqLine* seq(int g, int bank) const { return reinterpret_cast<SeqLine*>(base_ + 4096 + (size_t)g * rank_stride()) + bank; }
   uint8_t* data(int g, int bank) const { return base_ + 4096 + (size_t)g * rank_stride() + 2 * sizeof(SeqLine) + (size_t)bank * slot_bytes_; }
+  // the pid namespace this process lives in (inode of /proc/self/ns/pid; 0 if unknown): a recorded creator pid only means something to a peer in the SAME namespace
+  static uint64_t pid_namespace() { struct stat st; return stat("/proc/self/ns/pid", &st) == 0 ? (uint64_t)st.st_ino : 0; }
   static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
  public:
@@ -52,7 +54,7 @@ class ShmComm {
   // once all have attached rank 0 unlinks the name, so nothing is left behind in /dev/shm whatever happens later.
   // A segment under the same name that an EARLIER run left behind (it died before rank 0's post-attach unlink) must never be joined.  A peer recognises one by
   // any of: a world / slot size other than this run's, a creator process that no longer exists (rank 0 records its pid; the ranks of one node share a pid
-  // namespace), or an attach count that is already full.  It then drops the mapping and opens the name again until rank 0 of THIS run has replaced it (rank 0
+  // namespace — the check is skipped when the recorded namespace is not the peer's own), or an attach count that is already full.  It then drops the mapping and opens the name again until rank 0 of THIS run has replaced it (rank 0
   // unlinks and re-creates with O_EXCL) or the time-out expires.
   ShmComm(const std::string& name, int rank, int world, size_t slot_bytes = (size_t)1 << 20) : name_(name), rank_(rank), world_(world), slot_bytes_((slot_bytes + 63) & ~(size_t)63) {
     if (world < 1 || rank < 0 || rank >= world || name.empty() || name[0] != '/') throw std::runtime_error("ShmComm: bad arguments");
@@ -64,7 +66,7 @@ class ShmComm {
       int fd = shm_open(name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
       if (fd < 0 || ftruncate(fd, (off_t)map_bytes_) != 0) { if (fd >= 0) close(fd); throw std::runtime_error("ShmComm: cannot create " + name); }
       map_fd(fd);
-      hdr()->world = (uint32_t)world; hdr()->slot_bytes = slot_bytes_; hdr()->creator_pid = (uint32_t)getpid();
+      hdr()->world = (uint32_t)world; hdr()->slot_bytes = slot_bytes_; hdr()->creator_pid = (uint32_t)getpid(); hdr()->creator_pidns = pid_namespace();
       hdr()->magic.store(MAGIC, std::memory_order_release);   // fresh pages are zero: all sequence words start at 0
       if (hdr()->attached.fetch_add(1, std::memory_order_acq_rel) != 0) throw std::runtime_error("ShmComm: freshly created segment is already attached");
     } else {
@@ -83,7 +85,7 @@ class ShmComm {
           std::this_thread::yield();
         }
         if (!stale && (hdr()->world != (uint32_t)world || hdr()->slot_bytes != slot_bytes_)) { stale = true; why = "only a segment of another world / slot size (an earlier run's) exists"; }
-        if (!stale && (kill((pid_t)hdr()->creator_pid, 0) != 0 && errno == ESRCH)) { stale = true; why = "only a segment whose creator no longer exists (an earlier run's) exists"; }
+        if (!stale && hdr()->creator_pidns != 0 && hdr()->creator_pidns == pid_namespace() && (kill((pid_t)hdr()->creator_pid, 0) != 0 && errno == ESRCH)) { stale = true; why = "only a segment whose creator no longer exists (an earlier run's) exists"; }
         if (!stale && hdr()->attached.fetch_add(1, std::memory_order_acq_rel) >= (uint32_t)world) { stale = true; why = "only a fully attached segment (an earlier run's) exists"; }
         if (!stale) break;
         munmap(base_, map_bytes_); base_ = nullptr;

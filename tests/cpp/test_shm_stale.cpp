@@ -21,7 +21,9 @@ int main(int argc, char** argv) {
     if (fd < 0 || ftruncate(fd, (off_t)bytes) != 0) { printf("FAIL cannot create the stale segment\n"); return 1; }
     uint8_t* p = (uint8_t*)mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0); close(fd);
     *(uint32_t*)(p + 4) = (uint32_t)(mode == "world" ? 2 * world : world); *(uint64_t*)(p + 8) = mode == "world" ? slot / 2 : slot;
-    *(uint32_t*)(p + 16) = (uint32_t)(mode == "partial" ? 1 : world); *(uint32_t*)(p + 24) = mode == "partial" ? dead_pid : (uint32_t)getpid(); *(uint32_t*)(p + 0) = 0x4c53484du;
+    *(uint32_t*)(p + 16) = (uint32_t)(mode == "partial" ? 1 : world); *(uint32_t*)(p + 24) = mode == "partial" ? dead_pid : (uint32_t)getpid();
+    { struct stat ns; *(uint64_t*)(p + 32) = stat("/proc/self/ns/pid", &ns) == 0 ? (uint64_t)ns.st_ino : 0; }   // creator_pidns: this test's own namespace
+    *(uint32_t*)(p + 0) = 0x4c53484du;
     munmap(p, bytes);
   }
   int ok[2] = {0, 0}; uint32_t got[2][2] = {{0, 0}, {0, 0}};
