@@ -384,3 +384,21 @@ def test_gpu_c99_program_through_the_c_abi(tmp_path):
     res = subprocess.run([exe, "14"], capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stdout + res.stderr
     assert "verified 1" in res.stdout and "callback path identical 1" in res.stdout
+
+
+def test_gpu_slab_spark_c16_one_proof_over_8_ranks(host):
+    """BASELINE.json configs[4]'s shape — the (restated, unconfirmed) Spark strategy, C = 16 — as ONE proof over 8 ranks in capacity mode, at the largest size that is quick on
+    one device (2^22 lookups: 2^26 field-element table reads, a degree-17 sumcheck over 16 memories, 32 product trees): the 8 ranks (contexts of the one MI355X, the library's
+    shared-memory exchange) must produce the bytes the single-GPU prover produces, which test_gpu_proof_bit_exact_vs_oracle holds to the oracle at the sizes the oracle reaches."""
+    import os
+    kind, c, log_m, log_s = "spark", 16, 16, 22
+    lib = _build_slab_hip()
+    s = 1 << log_s
+    idx = host.gen_indices(s, 1 << log_m, c); r = host.gen_random_point(log_s)
+    S = _abi.Strategy(_abi.KINDS[kind], c, log_m, 0)
+    gens = host.gens(c, s, c, log_m); dense = host.densify(idx, log_m)
+    comm1 = host.commit(dense, gens); proof1 = host.prove(dense, gens, S, r)
+    host.free(dense, gens)
+    comm, proof, info = run_slab_threads(lib, 8, S, c, idx, r, shm_name=f"/lasso_test_spark16_{os.getpid()}", capacity=True, steps=1)
+    print(f"\n[slab] spark C=16 2^{log_s} over 8 ranks on one device (capacity mode): peak bytes per rank {max(info['peak_bytes_per_rank']) / 2**30:.2f} GiB")
+    assert comm == comm1 and proof == proof1
