@@ -385,6 +385,44 @@ __global__ void __launch_bounds__(MSM_THREADS) k_msm_rows8(const uint32_t* __res
   if (t == 0) out[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = pts[0];
 }
 
+// The same commitment with ONE WAVE PER ROW (four rows per workgroup), for launches of many rows (>= 1024).  k_msm_rows8 gives a row 256 threads: at the headline's E (4096
+// columns of 8-bit values) that is 16 mixed additions per thread followed by a 256-point tree of nine passes — a quarter of the workgroup's time is the tree.  With 64 lanes
+// per row a lane runs 64 additions and the row's partial sums are 64: six plain addition levels inside the wave, no workgroup barrier anywhere, the tree a tenth of the chain.
+// Same table entries, same group element per row (other projective representative: the wire bytes do not change).  out[row] = the row's sum (K = 1 layout of k_points_sum).
+__global__ void __launch_bounds__(MSM_THREADS) k_msm_rows8w(const uint32_t* __restrict__ scal, size_t row_words, uint32_t n_cols, uint32_t W8, const niels29* __restrict__ tab8_0,
+                                                             const niels29* __restrict__ tab8_1, size_t tn, pt29* __restrict__ out, uint32_t rows, uint32_t* digit_count) {
+  __shared__ pt29 pts[MSM_THREADS];
+  const fe29 d2 = fe_d2();
+  const uint32_t t = threadIdx.x, wave = t >> 6, lane = t & 63u;
+  const uint32_t r = blockIdx.x * (MSM_THREADS / 64) + wave;
+  pt29 B = pt_identity();
+  uint32_t nadds = 0;
+  if (r < rows) {
+    const uint32_t* row = scal + (size_t)r * row_words;
+    niels29 cur; bool have = false;
+    for (uint32_t c = lane; c < n_cols; c += 64) {
+      const uint32_t v = row[c];
+      for (uint32_t w = 0; w < W8; w++) {
+        const uint32_t d = (v >> (8 * w)) & 255u;
+        nadds += d != 0;
+        const niels29 nxt = (w ? tab8_1 : tab8_0)[d ? (size_t)(d - 1) * tn + c : 0];   // issued before the addition below, waited for after it
+        if (have) B = pt_madd(B, cur);
+        cur = nxt; have = d != 0;
+      }
+    }
+    if (have) B = pt_madd(B, cur);
+  }
+  msm_count_adds(digit_count, nadds);
+  pt29* mine = pts + 64 * wave;
+  mine[lane] = B;
+  // the wave's 64 partial sums -> one: plain additions, 32 + 16 + .. + 1; only this wave touches `mine`, so its own LDS operations kept in order are all the synchronisation there is
+  for (uint32_t s2 = 32; s2 > 0; s2 >>= 1) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane < s2) { const pt29 x = pt_add(mine[lane], mine[lane + s2], d2); mine[lane] = x; }
+  }
+  if (lane == 0 && r < rows) out[r] = mine[0];
+}
+
 #define MSM_DIRECT_MAX_COLS 160   // columns a workgroup may touch (items_per_chunk <= 64 * (MSM_DIRECT_MAX_COLS - 1))
 // signed-digit recoding of one canonical scalar into LDS: e = s + 0x88..8 (nibble e_w - 8 in [-8, 7] is digit w)
 __device__ __forceinline__ void msm_recode(const uint32_t* s, uint32_t* dst) {

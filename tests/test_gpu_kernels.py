@@ -384,7 +384,9 @@ def gens_300(devs):
 @pytest.mark.parametrize("ls,rs,maxv", [(1, 1, 5), (4, 8, 256), (16, 256, 1 << 16), (8, 300, 1 << 24), (3, 100, 1 << 32), (2, 64, None),
                                         # >= 32 rows of scalars <= 16 bits: the byte-table kernel (k_msm_rows8), one and two byte windows, ragged columns, a chunked row, and
                                         # just past its limits (17 and 24 bits: the bucket kernel again)
-                                        (64, 256, 256), (40, 77, 2), (300, 300, 1 << 16), (33, 129, 1 << 12), (32, 5, 1 << 9), (64, 100, 1 << 17), (48, 64, 1 << 24)])
+                                        (64, 256, 256), (40, 77, 2), (300, 300, 1 << 16), (33, 129, 1 << 12), (32, 5, 1 << 9), (64, 100, 1 << 17), (48, 64, 1 << 24),
+                                        # >= 1024 rows: one wave per row (k_msm_rows8w), one and two byte windows, fewer columns than lanes, ragged rows (not a multiple of 4), all-zero values
+                                        (1024, 64, 256), (1500, 100, 1 << 16), (2049, 33, 2), (1027, 300, 1 << 12), (1024, 8, 1)])
 def test_hyrax_commit(devs, gens_300, ls, rs, maxv):
     rng = np.random.default_rng(ls * 31 + rs)
     if maxv is None:
