@@ -1244,9 +1244,11 @@ static int32_t run_msm(lasso_ctx* c, const uint8_t* d_scal, uint32_t bps, uint32
   {
     ProfScope ps(c, LASSO_K_MSM, (double)rows * n_cols * bps, msm_ref_adds(rows, n_cols, bps == 4 ? 4 * W : FR_MODULUS_BITS), rows > MSM_SMALL_ROWS,
                  (double)rows * n_cols * (t8[0] ? W8 : W));
-    // many rows: one wave per row (k_msm_rows8w: 64 additions per lane and a 6-level tree inside the wave instead of 16 per thread and a 256-point tree).  LASSO_MSM_ROWS8W=0: A/B switch
+    // many SHORT rows: one wave per row (k_msm_rows8w: 64 additions per lane and a 6-level tree inside the wave instead of 16 per thread and a 256-point tree).  Measured
+    // (profiles/r04_ab_rows8w.txt): -9 % on the headline's E (4096 one-byte columns), -8 % on BN254 configs[1], +2 % on configs[2]'s 16384-column rows, where a thread of the
+    // 256-lane kernel already runs 64 additions — hence the column bound.  LASSO_MSM_ROWS8W=0: A/B switch
     static const bool rows8w = [] { const char* v = getenv("LASSO_MSM_ROWS8W"); return !(v && v[0] == '0'); }();
-    if (t8[0] && rows8w && K == 1 && rows >= 1024) hipLaunchKernelGGL(k_msm_rows8w, dim3((unsigned)((rows + MSM_THREADS / 64 - 1) / (MSM_THREADS / 64))), dim3(MSM_THREADS), 0, c->stream, (const uint32_t*)d_scal, row_stride / 4,
+    if (t8[0] && rows8w && K == 1 && rows >= 1024 && n_cols * W8 <= 8192) hipLaunchKernelGGL(k_msm_rows8w, dim3((unsigned)((rows + MSM_THREADS / 64 - 1) / (MSM_THREADS / 64))), dim3(MSM_THREADS), 0, c->stream, (const uint32_t*)d_scal, row_stride / 4,
                                                                       (uint32_t)n_cols, W8, t8[0], t8[1], b->n, d_partial, (uint32_t)rows, ps.counter());
     else if (t8[0]) hipLaunchKernelGGL(k_msm_rows8, dim3((unsigned)K, (unsigned)rows), dim3(MSM_THREADS), 0, c->stream, (const uint32_t*)d_scal, row_stride / 4, (uint32_t)n_cols, (uint32_t)cols_per_chunk, W8,
                                   t8[0], t8[1], b->n, d_partial, ps.counter());
