@@ -270,6 +270,10 @@ def bind_top_sweep(dev_lib, ctx, _abi, curve, iterations=20, warmup=3):
     stream.  Returns the `bind_top_sweep` object of the bench line."""
     rows = []
     vp = C.c_void_p
+
+    def chk(rc, what):      # a device call that fails ends this row of the sweep, not the bench line
+        if rc != 0:
+            raise RuntimeError(f"{what} failed ({rc})")
     r = np.array([0x123456789abcdef1, 0x0fedcba987654321, 0x1111111122222222, 0x0123456701234567], dtype=np.uint64)   # any field element < p in ark-ff's in-memory form
     for log_n in (24, 26, 28):
         for polys in (1, 9):
@@ -280,10 +284,10 @@ def bind_top_sweep(dev_lib, ctx, _abi, curve, iterations=20, warmup=3):
                 rows.append({"log_n": log_n, "polys": polys, "skipped": "does not fit beside the resident proof"}); continue
             bufs = []
             try:
-                src = vp(); assert dev_lib.lasso_alloc(ctx, n * 4, C.byref(src)) == 0
+                src = vp(); chk(dev_lib.lasso_alloc(ctx, n * 4, C.byref(src)), "lasso_alloc")
                 # fill: seeded random 32-bit integers lifted to Fr — v * 2^256 mod p in memory, i.e. full-width field elements (8(d): "uniformly random canonical field elements")
                 h_src = np.random.default_rng(1).integers(0, 1 << 32, size=n, dtype=np.uint32)
-                assert dev_lib.lasso_upload(ctx, src, h_src.ctypes.data_as(vp), n * 4) == 0
+                chk(dev_lib.lasso_upload(ctx, src, h_src.ctypes.data_as(vp), n * 4), "lasso_upload")
                 del h_src
                 for _ in range(sets):
                     b = vp()
@@ -291,17 +295,17 @@ def bind_top_sweep(dev_lib, ctx, _abi, curve, iterations=20, warmup=3):
                         raise MemoryError("lasso_alloc")
                     bufs.append(b)
                     for k in range(polys):
-                        assert dev_lib.lasso_fr_from_u32(ctx, src, n, vp(b.value + k * n * 32)) == 0
+                        chk(dev_lib.lasso_fr_from_u32(ctx, src, n, vp(b.value + k * n * 32)), "lasso_fr_from_u32")
                 dev_lib.lasso_sync(ctx)
                 tabs = []
                 for b in bufs:
                     tabs.append((vp * polys)(*[vp(b.value + k * n * 32) for k in range(polys)]))
                 for i in range(warmup):
-                    assert dev_lib.lasso_bind_top(ctx, tabs[i % sets], polys, n, r.ctypes.data_as(vp)) == 0
+                    chk(dev_lib.lasso_bind_top(ctx, tabs[i % sets], polys, n, r.ctypes.data_as(vp)), "lasso_bind_top")
                 dev_lib.lasso_sync(ctx)
                 dev_lib.lasso_prof_reset(ctx); dev_lib.lasso_prof_enable(ctx, 1 << _abi.K_BIND)
                 for i in range(iterations):
-                    assert dev_lib.lasso_bind_top(ctx, tabs[(warmup + i) % sets], polys, n, r.ctypes.data_as(vp)) == 0
+                    chk(dev_lib.lasso_bind_top(ctx, tabs[(warmup + i) % sets], polys, n, r.ctypes.data_as(vp)), "lasso_bind_top")
                 dev_lib.lasso_sync(ctx)
                 cnt = C.c_uint64(); ms = C.c_double(); by = C.c_double()
                 dev_lib.lasso_prof_get(ctx, _abi.K_BIND, C.byref(cnt), C.byref(ms), C.byref(by)); dev_lib.lasso_prof_enable(ctx, 0)
@@ -309,7 +313,7 @@ def bind_top_sweep(dev_lib, ctx, _abi, curve, iterations=20, warmup=3):
                 gbps = alg * cnt.value / (ms.value * 1e-3) / 1e9
                 rows.append({"log_n": log_n, "polys": polys, "launches": cnt.value, "us_per_launch": round(ms.value * 1e3 / cnt.value, 2), "alg_bytes_per_launch": int(alg),
                              "alg_GBps": round(gbps, 1), "frac": round(gbps / HBM_PEAK_GBS, 4), "buffer_sets_rotated": sets})
-            except (MemoryError, AssertionError) as e:
+            except (MemoryError, RuntimeError) as e:
                 rows.append({"log_n": log_n, "polys": polys, "error": repr(e)})
             finally:
                 dev_lib.lasso_sync(ctx)
