@@ -341,10 +341,11 @@ def slab_units(kind, c, capacity=False):
     DESIGN 5 holds the measured table this is checked against): the two merged committed polynomials dim|read (2C, padded to a power of two) and E (alpha, padded), dim as u32
     (C / 8), the eq table of r and the chi table (2), the primary sumcheck's work arrays (alpha / 2; alpha for LT's clones), and — the peak — the read / write product trees
     (2 per tree, 4 alpha) with the layer's eq table (1/4).  Capacity mode (lasso_host_set_capacity) keeps those trees without their leaf layers: 2 alpha, plus the mini-layers
-    of the chunked leaf rounds (2 alpha / 8).  The M-sized polynomials, generator tables and scratch are the constant term (slab_bytes_per_rank)."""
+    of the chunked leaf rounds (2 alpha / 8), and holds dim | read as 4-byte integers only (2C / 8; no field-element copy of that merged polynomial).  The M-sized polynomials,
+    generator tables and scratch are the constant term (slab_bytes_per_rank)."""
     alpha = 2 * c if kind == "lt" else c
     p2 = lambda x: 1 << (x - 1).bit_length()
-    committed = p2(2 * c) + p2(alpha) + c / 8.0
+    committed = (2 * c / 8.0 if capacity else p2(2 * c) + c / 8.0) + p2(alpha)
     sumcheck_peak = committed + 2 + (alpha if kind in ("lt", "spark") else alpha / 2.0)     # LT and Spark bind clones of all their polynomials
     trees_peak = committed + 2 + (2 * alpha + alpha / 4.0 if capacity else 4 * alpha) + 0.25
     return max(sumcheck_peak, trees_peak)

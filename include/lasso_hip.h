@@ -113,6 +113,9 @@ int32_t lasso_wait_stats(lasso_ctx* ctx, uint64_t* waits, double* wait_us, int32
 /* ---- polynomial kernels -------------------------------------------------------------------- */
 /* DensePolynomial::from_usize (src/poly/dense_mlpoly.rs:263-269): d_dst[i] = Fr::from(d_src[i]) */
 int32_t lasso_fr_from_u32(lasso_ctx* ctx, const uint32_t* d_src, size_t n, lasso_fr* d_dst);
+/* ... and its inverse for the values that are integers (capacity mode keeps dim / read_ts as 4-byte integers between the phases that need them as field elements):
+ * d_dst[i] = d_src[i] as an integer; LASSO_ERR_INVALID if some value is >= 2^32; *max_out (may be NULL) = the largest value. */
+int32_t lasso_fr_to_u32(lasso_ctx* ctx, const lasso_fr* d_src, size_t n, uint32_t* d_dst, uint32_t* max_out);
 /* SubtableStrategy::to_lookup_polys (src/subtables/mod.rs:78-92): d_out[j] = d_table[d_idx[j]] */
 int32_t lasso_gather(lasso_ctx* ctx, const lasso_fr* d_table, const uint32_t* d_idx, size_t n, lasso_fr* d_out);
 /* EqPolynomial::evals (src/poly/eq_poly.rs:22-38): d_out[x] = prod_j (x_j ? r_j : 1-r_j), r[0] <-> top bit */
@@ -250,6 +253,9 @@ int32_t lasso_fingerprint_ops_gp(lasso_ctx* ctx, const lasso_fr* d_table, const 
  * fingerprints exist only inside the launch.  Half the resident bytes of the read / write trees. */
 int32_t lasso_fingerprint_ops_gp_upper(lasso_ctx* ctx, const lasso_fr* d_table, const uint32_t* d_dim, const lasso_fr* d_read, size_t s, const lasso_fr* gamma, const lasso_fr* tau,
                                        lasso_fr* d_upper_read, lasso_fr* d_upper_write);
+/* the same, the read timestamps given as 32-bit integers (identical bytes out) */
+int32_t lasso_fingerprint_ops_gp_upper_u32(lasso_ctx* ctx, const lasso_fr* d_table, const uint32_t* d_dim, const uint32_t* d_read_u32, size_t s, const lasso_fr* gamma, const lasso_fr* tau,
+                                           lasso_fr* d_upper_read, lasso_fr* d_upper_write);
 /* ... and the leaves recomputed for ONE strip set of the bottom layer, where its two streaming sumcheck rounds need them.  The layer's arrays are A = leaves[0 .. s/2),
  * B = leaves[s/2 .. s).  A round on the index range [i0, i0 + cs) reads `nstrips` strips of each array, stride = s / 2 / nstrips apart (nstrips = 2: the layer's first round;
  * 4: the second round, which binds); d_out_read / d_out_write (2 * nstrips * cs elements each) receive [A strips.., B strips..]:
@@ -258,6 +264,8 @@ int32_t lasso_fingerprint_ops_gp_upper(lasso_ctx* ctx, const lasso_fr* d_table, 
  * lasso_fingerprint_ops at those positions.  i0 + cs <= stride. */
 int32_t lasso_fingerprint_ops_strips(lasso_ctx* ctx, const lasso_fr* d_table, const uint32_t* d_dim, const lasso_fr* d_read, size_t s, const lasso_fr* gamma, const lasso_fr* tau,
                                      uint32_t nstrips, size_t i0, size_t cs, lasso_fr* d_out_read, lasso_fr* d_out_write);
+int32_t lasso_fingerprint_ops_strips_u32(lasso_ctx* ctx, const lasso_fr* d_table, const uint32_t* d_dim, const uint32_t* d_read_u32, size_t s, const lasso_fr* gamma, const lasso_fr* tau,
+                                         uint32_t nstrips, size_t i0, size_t cs, lasso_fr* d_out_read, lasso_fr* d_out_write);
 /* init/final sets (memory_checking.rs:254-273): d_init_out[i] = d_table[i]*gamma + i - tau, d_final_out[i] = d_init_out[i] + d_final[i]*gamma^2 */
 int32_t lasso_fingerprint_mem(lasso_ctx* ctx, const lasso_fr* d_table, const lasso_fr* d_final, size_t m,
                               const lasso_fr* gamma, const lasso_fr* tau, lasso_fr* d_init_out, lasso_fr* d_final_out);

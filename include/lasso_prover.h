@@ -33,9 +33,13 @@ lasso_ctx* lasso_host_ctx(lasso_host* h);   /* the device context, e.g. for lass
 int32_t lasso_host_mem_stats(lasso_host* h, uint64_t* live_bytes, uint64_t* peak_bytes, uint64_t* prover_peak_bytes, int32_t reset);
 /* Capacity mode (slab mode's purpose: proofs whose polynomials do not fit one GPU — the reference keeps every DensePolynomial and every product-tree layer as a
  * Vec<F>, src/subprotocols/grand_product.rs:38-58): the prover keeps the read / write product trees without their leaf layers (half of each tree) and recomputes the
- * fingerprints strip by strip for the two streaming rounds of the bottom layer that read them.  Same proof bytes, less resident memory, more time.
+ * fingerprints strip by strip for the two streaming rounds of the bottom layer that read them; and a representation densified while the mode is on keeps dim_i / read_i
+ * (integers: addresses and access counts, densified.rs:32-57) as 4-byte integers instead of field elements — whoever needs them as field elements (a row block's
+ * commitment in slab mode, their evaluation, the opening's L*Z) lifts one polynomial at a time into a scratch array.  Same proof bytes, less resident memory, more time.
  * Off by default (LASSO_CAPACITY=1 turns it on for every host). */
 int32_t lasso_host_set_capacity(lasso_host* h, int32_t on);
+/* what a densified representation holds on the device: bytes, and whether dim / read are in the compact form */
+int32_t lasso_host_dense_info(lasso_host_dense* d, uint64_t* device_bytes, int32_t* compact);
 
 /* Slab mode: ONE proof sharded over `world` GPUs (world a power of two, one lasso_host per rank, every rank given the SAME lookups and point).
  * Every polynomial is split by low index bits (rank g holds the indices = g mod world), the transcript is replicated, and `allgather` is the only

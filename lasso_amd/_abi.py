@@ -41,6 +41,7 @@ def declare(lib):
         "lasso_wait_stats": (i32, [vp, P(u64), P(C.c_double), i32]),
         "lasso_mem_stats": (i32, [vp, P(u64), P(u64), i32]),
         "lasso_fr_from_u32": (i32, [vp, vp, sz, vp]),
+        "lasso_fr_to_u32": (i32, [vp, vp, sz, vp, vp]),
         "lasso_gather": (i32, [vp, vp, vp, sz, vp]),
         "lasso_eq_evals": (i32, [vp, vp, u32, vp]),
         "lasso_eq_evals_scaled": (i32, [vp, vp, u32, vp, vp]),
@@ -71,6 +72,8 @@ def declare(lib):
         "lasso_fingerprint_ops_gp": (i32, [vp, vp, vp, vp, sz, vp, vp, vp, vp]),
         "lasso_fingerprint_ops_gp_upper": (i32, [vp, vp, vp, vp, sz, vp, vp, vp, vp]),
         "lasso_fingerprint_ops_strips": (i32, [vp, vp, vp, vp, sz, vp, vp, u32, sz, sz, vp, vp]),
+        "lasso_fingerprint_ops_gp_upper_u32": (i32, [vp, vp, vp, vp, sz, vp, vp, vp, vp]),
+        "lasso_fingerprint_ops_strips_u32": (i32, [vp, vp, vp, vp, sz, vp, vp, u32, sz, sz, vp, vp]),
         "lasso_fingerprint_mem": (i32, [vp, vp, vp, sz, vp, vp, vp, vp]),
         "lasso_fingerprint_mem_slab": (i32, [vp, vp, vp, sz, u32, u32, vp, vp, vp, vp]),
         "lasso_densify_dim_slab": (i32, [vp, vp, sz, sz, sz, sz, u32, u32, u32, vp, vp, vp, vp]),

@@ -959,7 +959,7 @@ int32_t lasso_fingerprint_ops_gp(lasso_ctx* c, const lasso_fr* d_table, const ui
     ProfScope ps(c, LASSO_K_FINGERPRINT, (32.0 * 3 + 64.0) * s + 2 * 48.0 * s);   // the fingerprints + the first layer of two trees (48 n per layer)
     // LASSO_EXP_NO_LEAF_STORE=1: TIMING EXPERIMENT ONLY (the proof that follows is invalid): the kernel without its 2 x 32 s bytes of leaf stores = what "compact leaves" would leave of it
     static const uint32_t store_leaves = [] { const char* v = getenv("LASSO_EXP_NO_LEAF_STORE"); return (v && v[0] == '1') ? 0u : 1u; }();
-    hipLaunchKernelGGL(k_fingerprint_ops_l1, dim3(grid_for(s / 2, 4096)), dim3(LASSO_BLOCK), 0, c->stream, (const fr_t*)d_table, d_dim, (const fr_t*)d_read, s, g, g2, t, tr, tw, tr + s, tw + s, store_leaves);
+    hipLaunchKernelGGL(k_fingerprint_ops_l1<false>, dim3(grid_for(s / 2, 4096)), dim3(LASSO_BLOCK), 0, c->stream, (const fr_t*)d_table, d_dim, (const void*)d_read, s, g, g2, t, tr, tw, tr + s, tw + s, store_leaves);
   }
   {
     ProfScope ps(c, LASSO_K_GP, 2 * 48.0 * s);   // the remaining layers of both trees
@@ -970,14 +970,15 @@ int32_t lasso_fingerprint_ops_gp(lasso_ctx* c, const lasso_fr* d_table, const ui
 }
 // Capacity mode: the two trees WITHOUT their leaf layers.  d_upper_r / d_upper_w: s - 2 (allocate s) elements each = the layers of s/2, s/4, .., 2 elements back to back, i.e.
 // what lasso_fingerprint_ops_gp leaves at d_tree + s.  The leaves exist only inside the launch (k_fingerprint_ops_l1 without its leaf stores).
-int32_t lasso_fingerprint_ops_gp_upper(lasso_ctx* c, const lasso_fr* d_table, const uint32_t* d_dim, const lasso_fr* d_read, size_t s, const lasso_fr* gamma, const lasso_fr* tau,
-                                       lasso_fr* d_upper_r, lasso_fr* d_upper_w) {
+static int32_t fingerprint_gp_upper_impl(lasso_ctx* c, const lasso_fr* d_table, const uint32_t* d_dim, const void* d_read, bool read_u32, size_t s, const lasso_fr* gamma, const lasso_fr* tau,
+                                         lasso_fr* d_upper_r, lasso_fr* d_upper_w) {
   REQUIRE(c, d_table && d_dim && d_read && gamma && tau && d_upper_r && d_upper_w && s >= 4 && (s & (s - 1)) == 0);
   fr_t g = to_fr(gamma), g2 = fr_sqr(g), t = to_fr(tau);
   fr_t* ur = (fr_t*)d_upper_r; fr_t* uw = (fr_t*)d_upper_w;
   {
     ProfScope ps(c, LASSO_K_FINGERPRINT, (32.0 * 3 + 64.0) * s + 2 * 48.0 * s);   // the reference's bytes for the same step; the leaf stores are not made
-    hipLaunchKernelGGL(k_fingerprint_ops_l1, dim3(grid_for(s / 2, 4096)), dim3(LASSO_BLOCK), 0, c->stream, (const fr_t*)d_table, d_dim, (const fr_t*)d_read, s, g, g2, t, (fr_t*)nullptr, (fr_t*)nullptr, ur, uw, 0u);
+    if (read_u32) hipLaunchKernelGGL(k_fingerprint_ops_l1<true>, dim3(grid_for(s / 2, 4096)), dim3(LASSO_BLOCK), 0, c->stream, (const fr_t*)d_table, d_dim, d_read, s, g, g2, t, (fr_t*)nullptr, (fr_t*)nullptr, ur, uw, 0u);
+    else hipLaunchKernelGGL(k_fingerprint_ops_l1<false>, dim3(grid_for(s / 2, 4096)), dim3(LASSO_BLOCK), 0, c->stream, (const fr_t*)d_table, d_dim, d_read, s, g, g2, t, (fr_t*)nullptr, (fr_t*)nullptr, ur, uw, 0u);
   }
   {
     ProfScope ps(c, LASSO_K_GP, 2 * 48.0 * s);
@@ -986,19 +987,30 @@ int32_t lasso_fingerprint_ops_gp_upper(lasso_ctx* c, const lasso_fr* d_table, co
   }
   HIPCHK(c, hipGetLastError()); return 0;
 }
-// ... and the leaves of one strip set of the bottom layer, recomputed for a round on the index range [i0, i0 + cs) (k_fingerprint_ops_strips states the layout)
-int32_t lasso_fingerprint_ops_strips(lasso_ctx* c, const lasso_fr* d_table, const uint32_t* d_dim, const lasso_fr* d_read, size_t s, const lasso_fr* gamma, const lasso_fr* tau,
-                                     uint32_t nstrips, size_t i0, size_t cs, lasso_fr* d_out_r, lasso_fr* d_out_w) {
+// Capacity mode: the two trees WITHOUT their leaf layers.  d_upper_r / d_upper_w: s - 2 (allocate s) elements each = the layers of s/2, s/4, .., 2 elements back to back, i.e.
+// what lasso_fingerprint_ops_gp leaves at d_tree + s.  The leaves exist only inside the launch (k_fingerprint_ops_l1 without its leaf stores).
+int32_t lasso_fingerprint_ops_gp_upper(lasso_ctx* c, const lasso_fr* d_table, const uint32_t* d_dim, const lasso_fr* d_read, size_t s, const lasso_fr* gamma, const lasso_fr* tau,
+                                       lasso_fr* d_upper_r, lasso_fr* d_upper_w) { return fingerprint_gp_upper_impl(c, d_table, d_dim, d_read, false, s, gamma, tau, d_upper_r, d_upper_w); }
+// the same with the read timestamps as 32-bit integers (capacity mode keeps dim / read compact: 4 bytes per entry instead of 32)
+int32_t lasso_fingerprint_ops_gp_upper_u32(lasso_ctx* c, const lasso_fr* d_table, const uint32_t* d_dim, const uint32_t* d_read_u32, size_t s, const lasso_fr* gamma, const lasso_fr* tau,
+                                           lasso_fr* d_upper_r, lasso_fr* d_upper_w) { return fingerprint_gp_upper_impl(c, d_table, d_dim, d_read_u32, true, s, gamma, tau, d_upper_r, d_upper_w); }
+static int32_t fingerprint_strips_impl(lasso_ctx* c, const lasso_fr* d_table, const uint32_t* d_dim, const void* d_read, bool read_u32, size_t s, const lasso_fr* gamma, const lasso_fr* tau,
+                                       uint32_t nstrips, size_t i0, size_t cs, lasso_fr* d_out_r, lasso_fr* d_out_w) {
   REQUIRE(c, d_table && d_dim && d_read && gamma && tau && d_out_r && d_out_w && s >= 4 && (s & (s - 1)) == 0 && (nstrips == 2 || nstrips == 4) && cs >= 1);
   const size_t stride = s / 2 / nstrips;
   REQUIRE(c, stride >= 1 && i0 + cs <= stride);
   fr_t g = to_fr(gamma), g2 = fr_sqr(g), t = to_fr(tau);
   const size_t total = 2 * (size_t)nstrips * cs;
   ProfScope ps(c, LASSO_K_FINGERPRINT, (32.0 * 3 + 64.0) * total);
-  hipLaunchKernelGGL(k_fingerprint_ops_strips, dim3(grid_for(total, 4096)), dim3(LASSO_BLOCK), 0, c->stream, (const fr_t*)d_table, d_dim, (const fr_t*)d_read, s, g, g2, t, nstrips, stride, i0, cs,
-                     (fr_t*)d_out_r, (fr_t*)d_out_w);
+  if (read_u32) hipLaunchKernelGGL(k_fingerprint_ops_strips<true>, dim3(grid_for(total, 4096)), dim3(LASSO_BLOCK), 0, c->stream, (const fr_t*)d_table, d_dim, d_read, s, g, g2, t, nstrips, stride, i0, cs, (fr_t*)d_out_r, (fr_t*)d_out_w);
+  else hipLaunchKernelGGL(k_fingerprint_ops_strips<false>, dim3(grid_for(total, 4096)), dim3(LASSO_BLOCK), 0, c->stream, (const fr_t*)d_table, d_dim, d_read, s, g, g2, t, nstrips, stride, i0, cs, (fr_t*)d_out_r, (fr_t*)d_out_w);
   HIPCHK(c, hipGetLastError()); return 0;
 }
+// ... and the leaves of one strip set of the bottom layer, recomputed for a round on the index range [i0, i0 + cs) (k_fingerprint_ops_strips states the layout)
+int32_t lasso_fingerprint_ops_strips(lasso_ctx* c, const lasso_fr* d_table, const uint32_t* d_dim, const lasso_fr* d_read, size_t s, const lasso_fr* gamma, const lasso_fr* tau,
+                                     uint32_t nstrips, size_t i0, size_t cs, lasso_fr* d_out_r, lasso_fr* d_out_w) { return fingerprint_strips_impl(c, d_table, d_dim, d_read, false, s, gamma, tau, nstrips, i0, cs, d_out_r, d_out_w); }
+int32_t lasso_fingerprint_ops_strips_u32(lasso_ctx* c, const lasso_fr* d_table, const uint32_t* d_dim, const uint32_t* d_read_u32, size_t s, const lasso_fr* gamma, const lasso_fr* tau,
+                                         uint32_t nstrips, size_t i0, size_t cs, lasso_fr* d_out_r, lasso_fr* d_out_w) { return fingerprint_strips_impl(c, d_table, d_dim, d_read_u32, true, s, gamma, tau, nstrips, i0, cs, d_out_r, d_out_w); }
 int32_t lasso_fingerprint_ops(lasso_ctx* c, const lasso_fr* d_table, const uint32_t* d_dim, const lasso_fr* d_read, size_t s, const lasso_fr* gamma, const lasso_fr* tau,
                               lasso_fr* d_read_out, lasso_fr* d_write_out) {
   REQUIRE(c, d_table && d_dim && d_read && gamma && tau && d_read_out && d_write_out); if (!s) return 0;
@@ -1054,6 +1066,20 @@ int32_t lasso_matvec_left_dev(lasso_ctx* c, const lasso_fr* d_Z, const lasso_fr*
   HIPCHK(c, hipGetLastError()); return 0;
 }
 // ark-serialize of n field elements (canonical integers, 32 little-endian bytes each) — what append_scalar feeds the transcript (utils/transcript.rs:33-45)
+// d_dst[i] = the canonical value of d_src[i] as a 32-bit integer; LASSO_ERR_INVALID if some value does not fit; *max_out (optional) = the largest one.  How capacity mode
+// turns the timestamps densify wrote as field elements into its compact form (DensePolynomial::from_usize's inverse, dense_mlpoly.rs:263-269).
+int32_t lasso_fr_to_u32(lasso_ctx* c, const lasso_fr* d_src, size_t n, uint32_t* d_dst, uint32_t* max_out) {
+  REQUIRE(c, d_src && d_dst && n >= 1);
+  HIPCHK(c, hipMemsetAsync(c->d_flags, 0, 8, c->stream));
+  hipLaunchKernelGGL(k_fr_to_u32, dim3(grid_for(n, 4096)), dim3(256), 0, c->stream, (const fr_t*)d_src, n, d_dst, c->d_flags);
+  HIPCHK(c, hipGetLastError());
+  uint32_t flags[2];
+  HIPCHK(c, hipMemcpyAsync(flags, c->d_flags, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (flags[1]) return fail(c, LASSO_ERR_INVALID, "lasso_fr_to_u32: a value does not fit 32 bits");
+  if (max_out) *max_out = flags[0];
+  return 0;
+}
 int32_t lasso_fr_to_bytes(lasso_ctx* c, const lasso_fr* d_src, size_t n, uint8_t* out) {
   REQUIRE(c, d_src && out && n >= 1);
   // up to 2^16 elements (the a-vector of an opening: 128-256 KiB) go straight into the host-mapped result buffer and come back behind the

@@ -1153,10 +1153,14 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_fingerprint_ops(const fr_t* __r
 // leaves i and i + s/2 of both circuits, stores them (the bottom layer's sumcheck reads them) and multiplies the pair while it still holds them — the
 // 2 x 32 s bytes that k_gp_layer would read straight back never leave the chip.  l1_r / l1_w: s/2 elements each.  Operands go through the memory form exactly
 // as k_gp_layer reads them, so the tree is bit-identical.
-__global__ void __launch_bounds__(LASSO_BLOCK) k_fingerprint_ops_l1(const fr_t* __restrict__ table, const uint32_t* __restrict__ dim, const fr_t* __restrict__ read, size_t s,
+// RU32: the read timestamps as 32-bit integers (capacity mode keeps dim / read compact): t * gamma^2 = mul(integer t, gamma^2 * 2^517) lands in the same u-form — same canonical leaf
+template <bool RU32>
+__global__ void __launch_bounds__(LASSO_BLOCK) k_fingerprint_ops_l1(const fr_t* __restrict__ table, const uint32_t* __restrict__ dim, const void* __restrict__ read_any, size_t s,
                                                                      fr_t gamma, fr_t gamma2, fr_t tau, fr_t* __restrict__ out_r, fr_t* __restrict__ out_w, fr_t* __restrict__ l1_r, fr_t* __restrict__ l1_w,
                                                                      uint32_t store_leaves) {
   const fr29 gs = fr29_unpack_s(gamma), g2s = fr29_unpack_s(gamma2), g2u = fr29_unpack_u(gamma2), tu = fr29_unpack_u(tau), r2s = fr29_r2s();
+  const fr29 g2r = fr29_mul(g2s, r2s);   // gamma^2 * 2^517: an INTEGER times it is (integer * gamma^2) in u-form
+  const fr_t* __restrict__ read = reinterpret_cast<const fr_t*>(read_any); const uint32_t* __restrict__ read32 = reinterpret_cast<const uint32_t*>(read_any);
   const size_t half = s / 2;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x) {
     fr_t lr[2], lw[2];
@@ -1164,7 +1168,7 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_fingerprint_ops_l1(const fr_t* 
     for (int e = 0; e < 2; e++) {
       const size_t k = i + e * half;
       const uint32_t a = dim[k];
-      fr29 h = fr29_add(fr29_mul(fr29_unpack_u(read[k]), g2s), fr29_mul(fr29_unpack_u(table[a]), gs));
+      fr29 h = fr29_add(RU32 ? fr29_mul(fr29_from_u64_int(read32[k]), g2r) : fr29_mul(fr29_unpack_u(read[k]), g2s), fr29_mul(fr29_unpack_u(table[a]), gs));
       h = fr29_canonical(fr29_sub(fr29_add(h, fr29_mul(fr29_from_u64_int(a), r2s)), tu));
       lr[e] = fr29_pack(h); lw[e] = fr29_store(fr29_add(h, g2u));
       if (store_leaves) { out_r[k] = lr[e]; out_w[k] = lw[e]; }   // 0: capacity mode's leafless trees (lasso_fingerprint_ops_gp_upper; out_r / out_w are then NULL), and the timing experiment LASSO_EXP_NO_LEAF_STORE
@@ -1178,16 +1182,19 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_fingerprint_ops_l1(const fr_t* 
 // the first round, 4 strips s/8 apart for the bind-fused second round).  out_r / out_w (2 * nstrips * cs elements each) receive the mini-layer [A strips..., B strips...]:
 // element (arr * nstrips + t) * cs + i = leaf[arr * s/2 + t * stride + i0 + i] — exactly the arrays lasso_sumcheck_cubic_eqw2_begin takes with n = nstrips * cs.
 // Same arithmetic, same canonical bytes as k_fingerprint_ops.
-__global__ void __launch_bounds__(LASSO_BLOCK) k_fingerprint_ops_strips(const fr_t* __restrict__ table, const uint32_t* __restrict__ dim, const fr_t* __restrict__ read, size_t s,
+template <bool RU32>
+__global__ void __launch_bounds__(LASSO_BLOCK) k_fingerprint_ops_strips(const fr_t* __restrict__ table, const uint32_t* __restrict__ dim, const void* __restrict__ read_any, size_t s,
                                                                          fr_t gamma, fr_t gamma2, fr_t tau, uint32_t nstrips, size_t stride, size_t i0, size_t cs,
                                                                          fr_t* __restrict__ out_r, fr_t* __restrict__ out_w) {
   const fr29 gs = fr29_unpack_s(gamma), g2s = fr29_unpack_s(gamma2), g2u = fr29_unpack_u(gamma2), tu = fr29_unpack_u(tau), r2s = fr29_r2s();
+  const fr29 g2r = fr29_mul(g2s, r2s);
+  const fr_t* __restrict__ read = reinterpret_cast<const fr_t*>(read_any); const uint32_t* __restrict__ read32 = reinterpret_cast<const uint32_t*>(read_any);
   const size_t total = 2 * (size_t)nstrips * cs;
   for (size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x; j < total; j += (size_t)gridDim.x * blockDim.x) {
     const size_t strip = j / cs, i = j - strip * cs, arr = strip / nstrips, t = strip - arr * nstrips;
     const size_t k = arr * (s / 2) + t * stride + i0 + i;
     const uint32_t a = dim[k];
-    fr29 h = fr29_add(fr29_mul(fr29_unpack_u(read[k]), g2s), fr29_mul(fr29_unpack_u(table[a]), gs));
+    fr29 h = fr29_add(RU32 ? fr29_mul(fr29_from_u64_int(read32[k]), g2r) : fr29_mul(fr29_unpack_u(read[k]), g2s), fr29_mul(fr29_unpack_u(table[a]), gs));
     h = fr29_canonical(fr29_sub(fr29_add(h, fr29_mul(fr29_from_u64_int(a), r2s)), tu));
     out_r[j] = fr29_pack(h);
     out_w[j] = fr29_store(fr29_add(h, g2u));

@@ -88,6 +88,12 @@ class Device:
     def fr_from_u32(self, d_src, n, d_dst):
         self._chk(self.lib.lasso_fr_from_u32(self.ctx, C.c_void_p(d_src), n, C.c_void_p(d_dst)))
 
+    def fr_to_u32(self, d_src, n, d_dst):
+        """the integers behind n field elements; raises if one does not fit 32 bits; returns the largest"""
+        mx = C.c_uint32(0)
+        self._chk(self.lib.lasso_fr_to_u32(self.ctx, C.c_void_p(d_src), n, C.c_void_p(d_dst), C.byref(mx)))
+        return mx.value
+
     def gather(self, d_table, d_idx, n, d_out):
         self._chk(self.lib.lasso_gather(self.ctx, C.c_void_p(d_table), C.c_void_p(d_idx), n, C.c_void_p(d_out)))
 
@@ -252,15 +258,17 @@ class Device:
         g = np.ascontiguousarray(gamma, dtype=np.uint64); t = np.ascontiguousarray(tau, dtype=np.uint64)
         self._chk(self.lib.lasso_fingerprint_ops_gp(self.ctx, C.c_void_p(d_table), C.c_void_p(d_dim), C.c_void_p(d_read), s, _vp(g), _vp(t), C.c_void_p(d_tree_r), C.c_void_p(d_tree_w)))
 
-    def fingerprint_ops_gp_upper(self, d_table, d_dim, d_read, s, gamma, tau, d_upper_r, d_upper_w):
-        """capacity mode: both trees without their leaf layers (s - 2 elements each)"""
+    def fingerprint_ops_gp_upper(self, d_table, d_dim, d_read, s, gamma, tau, d_upper_r, d_upper_w, read_u32=False):
+        """capacity mode: both trees without their leaf layers (s - 2 elements each); read_u32: d_read holds 32-bit integers"""
         g = np.ascontiguousarray(gamma, dtype=np.uint64); t = np.ascontiguousarray(tau, dtype=np.uint64)
-        self._chk(self.lib.lasso_fingerprint_ops_gp_upper(self.ctx, C.c_void_p(d_table), C.c_void_p(d_dim), C.c_void_p(d_read), s, _vp(g), _vp(t), C.c_void_p(d_upper_r), C.c_void_p(d_upper_w)))
+        fn = self.lib.lasso_fingerprint_ops_gp_upper_u32 if read_u32 else self.lib.lasso_fingerprint_ops_gp_upper
+        self._chk(fn(self.ctx, C.c_void_p(d_table), C.c_void_p(d_dim), C.c_void_p(d_read), s, _vp(g), _vp(t), C.c_void_p(d_upper_r), C.c_void_p(d_upper_w)))
 
-    def fingerprint_ops_strips(self, d_table, d_dim, d_read, s, gamma, tau, nstrips, i0, cs, d_out_r, d_out_w):
+    def fingerprint_ops_strips(self, d_table, d_dim, d_read, s, gamma, tau, nstrips, i0, cs, d_out_r, d_out_w, read_u32=False):
         """capacity mode: the leaves of one strip set of the bottom layer (2 * nstrips * cs elements per circuit)"""
         g = np.ascontiguousarray(gamma, dtype=np.uint64); t = np.ascontiguousarray(tau, dtype=np.uint64)
-        self._chk(self.lib.lasso_fingerprint_ops_strips(self.ctx, C.c_void_p(d_table), C.c_void_p(d_dim), C.c_void_p(d_read), s, _vp(g), _vp(t), nstrips, i0, cs, C.c_void_p(d_out_r), C.c_void_p(d_out_w)))
+        fn = self.lib.lasso_fingerprint_ops_strips_u32 if read_u32 else self.lib.lasso_fingerprint_ops_strips
+        self._chk(fn(self.ctx, C.c_void_p(d_table), C.c_void_p(d_dim), C.c_void_p(d_read), s, _vp(g), _vp(t), nstrips, i0, cs, C.c_void_p(d_out_r), C.c_void_p(d_out_w)))
 
     def fingerprint_mem(self, d_table, d_final, m, gamma, tau, d_io, d_fo):
         g = np.ascontiguousarray(gamma, dtype=np.uint64); t = np.ascontiguousarray(tau, dtype=np.uint64)

@@ -173,6 +173,7 @@ struct DBuf {
   DBuf& operator=(DBuf&& o) noexcept { if (this != &o) { reset(); dev = o.dev; p = o.p; n = o.n; o.p = nullptr; } return *this; }
   DBuf(const DBuf&) = delete; DBuf& operator=(const DBuf&) = delete;
   void reset() { if (p && dev) dev->free(p); p = nullptr; n = 0; }
+  void release() { if (p && dev) dev->release(p); p = nullptr; n = 0; }   // straight back to the driver (Dev::release)
   ~DBuf() { try { reset(); } catch (...) {} }
 };
 struct DBufU64 {   // read-only upload of a host u64 array
@@ -487,9 +488,9 @@ struct BatchedGrandProductArgument { std::vector<LayerProofBatched> proof; void 
 struct PolyCommitment { std::vector<uint8_t> compressed; size_t rows = 0; };   // C: Vec<G>, kept in wire form
 // d_Z: the whole polynomial, or in slab mode the rank's local array (row-major L x R/P: its columns of every row)
 // d_u32 (optional): the polynomial's canonical values as 32-bit integers, all <= max_u32, when the caller has them anyway
-inline PolyCommitment hyrax_commit(const Dev& d, const lasso_fr* d_Z, size_t num_vars, const PolyCommitmentGens& gens, const uint32_t* d_u32 = nullptr, uint32_t max_u32 = 0) {
-  size_t l_size = (size_t)1 << (num_vars / 2), r_size = (size_t)1 << (num_vars - num_vars / 2);
-  LASSO_REQUIRE(r_size == gens.n);
+// hyrax_commit_rows: any run of l_size whole rows of the matrix (capacity mode commits its compact polynomials block by block)
+inline PolyCommitment hyrax_commit_rows(const Dev& d, const lasso_fr* d_Z, size_t l_size, size_t r_size, const PolyCommitmentGens& gens, const uint32_t* d_u32 = nullptr, uint32_t max_u32 = 0) {
+  LASSO_REQUIRE(r_size == gens.n && l_size >= 1);
   if (!d.comm.sharded()) {   // rows come back in wire form: the normalisation (one inversion per row) runs on the device
     PolyCommitment c; c.rows = l_size; c.compressed.resize(32 * l_size);
     if (d_u32) d.chk(lasso_hyrax_commit_compressed_u32(d.ctx, d_u32, max_u32, l_size, r_size, gens.bases, c.compressed.data()), "lasso_hyrax_commit_compressed_u32");
@@ -530,6 +531,9 @@ inline PolyCommitment hyrax_commit(const Dev& d, const lasso_fr* d_Z, size_t num
   }
   PolyCommitment c; c.rows = l_size; compress_batch(pts, c.compressed); return c;
 }
+inline PolyCommitment hyrax_commit(const Dev& d, const lasso_fr* d_Z, size_t num_vars, const PolyCommitmentGens& gens, const uint32_t* d_u32 = nullptr, uint32_t max_u32 = 0) {
+  return hyrax_commit_rows(d, d_Z, (size_t)1 << (num_vars / 2), (size_t)1 << (num_vars - num_vars / 2), gens, d_u32, max_u32);
+}
 inline void append_poly_commitment(ProofTranscript& t, const char* label, const PolyCommitment& c) {  // dense_mlpoly.rs:281-289
   t.append_message(label, "poly_commitment_begin");
   for (size_t i = 0; i < c.rows; i++) t.append_point_bytes("poly_commitment_share", &c.compressed[32 * i]);
@@ -538,14 +542,26 @@ inline void append_poly_commitment(ProofTranscript& t, const char* label, const 
 
 // ------------------------------------------------------------------ DensifiedRepresentation (densified.rs:8-97)
 struct SparsePolynomialCommitment { PolyCommitment l_variate_polys_commitment, log_m_variate_polys_commitment; size_t s, log_m, m; };
+// capacity mode: local lookup count from which the operations' trees are kept without leaves and dim / read are kept compact
+inline size_t capacity_leafless_min() { static const size_t v = [] { const char* e = getenv("LASSO_LEAFLESS_MIN"); const size_t x = e ? (size_t)atoll(e) : ((size_t)1 << 16); return x < 64 ? (size_t)64 : x; }(); return v; }
+inline bool capacity_compact_off() { static const bool v = [] { const char* e = getenv("LASSO_CAPACITY_COMPACT"); return e && e[0] == '0'; }(); return v; }
 struct DensifiedRepresentation {
   const Dev* dev; size_t C, s, log_m, m;               // global sizes
   size_t s_loc, m_loc;                                  // this rank's share (== s, m when not sharded)
   std::vector<DBufU32> dim_u32;                       // dim_usize, on device (local)
   DBuf combined_l_variate_polys, combined_log_m_variate_polys;   // [dim_1..dim_C, read_1..read_C | 0...], [final_1..final_C | 0...] (local slabs)
   size_t nv_l, nv_m;                                    // global numbers of variables of the two merged polynomials
-  const lasso_fr* dim(size_t i) const { return combined_l_variate_polys.p + i * s_loc; }
-  const lasso_fr* read(size_t i) const { return combined_l_variate_polys.p + (C + i) * s_loc; }
+  // Capacity mode, compact form: dim_i and read_i are integers below 2^32 (addresses, access counts), so the merged polynomial [dim.. read.. | 0..] is held as
+  // dim_u32 + read_u32 (4 bytes per entry instead of 32) and NO field-element copy exists; whoever needs field elements (commitment of a row block, evaluation,
+  // the opening's L*Z) lifts one polynomial at a time into a scratch array.  Same proof bytes.
+  bool compact = false;
+  std::vector<DBufU32> read_u32; std::vector<uint32_t> read_max;
+  const lasso_fr* dim(size_t i) const { LASSO_REQUIRE(!compact); return combined_l_variate_polys.p + i * s_loc; }
+  const lasso_fr* read(size_t i) const { LASSO_REQUIRE(!compact); return combined_l_variate_polys.p + (C + i) * s_loc; }
+  // compact form: polynomial b of the merged buffer (b < C: dim_b, b < 2C: read_{b-C}) as integers, and lifted into d_tmp (s_loc elements)
+  const uint32_t* block_u32(size_t b) const { return b < C ? dim_u32[b].p : read_u32[b - C].p; }
+  uint32_t block_max(size_t b) const { return b < C ? (uint32_t)(m - 1) : read_max[b - C]; }
+  void lift_block(size_t b, lasso_fr* d_tmp) const { dev->chk(lasso_fr_from_u32(dev->ctx, block_u32(b), s_loc, d_tmp), "lasso_fr_from_u32"); }
   const lasso_fr* final_(size_t i) const { return combined_log_m_variate_polys.p + i * m_loc; }
 
   // indices: n_lookups x C, row-major (the reference's Vec<[usize; C]>)
@@ -558,25 +574,55 @@ struct DensifiedRepresentation {
     size_t n_l = next_pow2(2 * C * s), n_m = next_pow2(C) * m;
     D->nv_l = ceil_log2(n_l); D->nv_m = ceil_log2(n_m);
     if (d.comm.sharded() && (((size_t)1 << (D->nv_m - D->nv_m / 2)) < P || ((size_t)1 << (D->nv_l - D->nv_l / 2)) < P)) throw Error("slab sharding needs every Hyrax matrix to have at least one column per rank");
-    D->combined_l_variate_polys = DBuf(d, n_l / P); D->combined_log_m_variate_polys = DBuf(d, n_m / P);
+    // compact form needs a polynomial to be whole rows of the Hyrax matrix (s >= its row length: true from s = 2 * next_pow2(2C) on)
+    D->compact = d.capacity && !capacity_compact_off() && D->s_loc >= capacity_leafless_min() && s >= ((size_t)1 << (D->nv_l - D->nv_l / 2));
+    D->combined_log_m_variate_polys = DBuf(d, n_m / P);
+    if (!D->compact) D->combined_l_variate_polys = DBuf(d, n_l / P);
     // DensePolynomial::merge pads with zeros up to the next power of two (dense_mlpoly.rs:251-261)
-    if (n_l > 2 * C * s) d.chk(lasso_zero(d.ctx, D->combined_l_variate_polys.p + 2 * C * D->s_loc, (n_l - 2 * C * s) / P * sizeof(lasso_fr)), "lasso_zero");
+    if (!D->compact && n_l > 2 * C * s) d.chk(lasso_zero(d.ctx, D->combined_l_variate_polys.p + 2 * C * D->s_loc, (n_l - 2 * C * s) / P * sizeof(lasso_fr)), "lasso_zero");
     if (n_m > C * m) d.chk(lasso_zero(d.ctx, D->combined_log_m_variate_polys.p + C * D->m_loc, (n_m - C * m) / P * sizeof(lasso_fr)), "lasso_zero");
     // densified.rs:32-57 on the device: the index array is uploaded once as the reference holds it (Vec<[usize; C]>), each dimension is one
     // lasso_densify_dim call (stable radix sort by address -> read/final timestamps), the polynomials are written straight into the merged buffers.
     // Slab mode: every rank sorts the whole sequence (timestamps are a property of the whole sequence) and keeps its residue class.
     DBufU64 d_idx(d, indices, n_lookups * C);
+    DBuf tmp_dim, tmp_read; if (D->compact) { tmp_dim = DBuf(d, D->s_loc); tmp_read = DBuf(d, D->s_loc); }
     for (size_t i = 0; i < C; i++) {
       DBufU32 d_access(d, D->s_loc);
-      d.chk(lasso_densify_dim_slab(d.ctx, d_idx.p, n_lookups, C, i, s, (uint32_t)log_m, (uint32_t)P, (uint32_t)d.comm.rank, d_access.p, D->combined_l_variate_polys.p + i * D->s_loc,
-                                   D->combined_l_variate_polys.p + (C + i) * D->s_loc, D->combined_log_m_variate_polys.p + i * D->m_loc), "lasso_densify_dim");
+      lasso_fr* dim_out = D->compact ? tmp_dim.p : D->combined_l_variate_polys.p + i * D->s_loc;
+      lasso_fr* read_out = D->compact ? tmp_read.p : D->combined_l_variate_polys.p + (C + i) * D->s_loc;
+      d.chk(lasso_densify_dim_slab(d.ctx, d_idx.p, n_lookups, C, i, s, (uint32_t)log_m, (uint32_t)P, (uint32_t)d.comm.rank, d_access.p, dim_out, read_out, D->combined_log_m_variate_polys.p + i * D->m_loc), "lasso_densify_dim");
       D->dim_u32.push_back(std::move(d_access));
+      if (D->compact) {
+        DBufU32 r32(d, D->s_loc); uint32_t mx = 0;
+        d.chk(lasso_fr_to_u32(d.ctx, tmp_read.p, D->s_loc, r32.p, &mx), "lasso_fr_to_u32");
+        D->read_u32.push_back(std::move(r32)); D->read_max.push_back(mx);
+      }
     }
+    if (D->compact) { tmp_dim.release(); tmp_read.release(); }
     return D;
   }
   SparsePolynomialCommitment commit(const SparsePolyCommitmentGens& gens) const {  // densified.rs:78-96
     SparsePolynomialCommitment c;
-    c.l_variate_polys_commitment = hyrax_commit(*dev, combined_l_variate_polys.p, nv_l, gens.gens_combined_l_variate);
+    if (!compact) c.l_variate_polys_commitment = hyrax_commit(*dev, combined_l_variate_polys.p, nv_l, gens.gens_combined_l_variate);
+    else {
+      // one polynomial = rows_per whole rows: committed block by block (straight from the integers on one GPU — the commitment has that form anyway —, lifted into a
+      // scratch array in slab mode); the zero padding's rows commit to the identity
+      const size_t L = (size_t)1 << (nv_l / 2), R = (size_t)1 << (nv_l - nv_l / 2), rows_per = s / R;
+      PolyCommitment& pc = c.l_variate_polys_commitment; pc.rows = L; pc.compressed.reserve(32 * L);
+      DBuf tmp(*dev, s_loc);
+      for (size_t b = 0; b < 2 * C; b++) {
+        PolyCommitment part;
+        if (!dev->comm.sharded()) part = hyrax_commit_rows(*dev, nullptr, rows_per, R, gens.gens_combined_l_variate, block_u32(b), block_max(b));
+        else { lift_block(b, tmp.p); part = hyrax_commit_rows(*dev, tmp.p, rows_per, R, gens.gens_combined_l_variate); }
+        pc.compressed.insert(pc.compressed.end(), part.compressed.begin(), part.compressed.end());
+      }
+      if (2 * C * rows_per < L) {
+        dev->chk(lasso_zero(dev->ctx, tmp.p, (R / dev->comm.world) * sizeof(lasso_fr)), "lasso_zero");
+        PolyCommitment zero_row = hyrax_commit_rows(*dev, tmp.p, 1, R, gens.gens_combined_l_variate);
+        for (size_t r = 2 * C * rows_per; r < L; r++) pc.compressed.insert(pc.compressed.end(), zero_row.compressed.begin(), zero_row.compressed.end());
+      }
+      tmp.release();
+    }
     c.log_m_variate_polys_commitment = hyrax_commit(*dev, combined_log_m_variate_polys.p, nv_m, gens.gens_combined_log_m_variate);
     c.s = s; c.log_m = log_m; c.m = m; return c;
   }
@@ -815,13 +861,13 @@ class Prover {
   // are recomputed into a small mini-layer (lasso_fingerprint_ops_strips), the ordinary round kernel runs on it with the eq table offset to the range, and the host adds the
   // chunks' sums (exact field additions: the same round polynomial).  Costs two extra fingerprint passes and 2 x kLeafChunks hand-offs; saves 7/8 of the leaf bytes.
   struct LeafLayer {
-    struct Mem { const lasso_fr* table; const uint32_t* dim; const lasso_fr* read; };
+    struct Mem { const lasso_fr* table; const uint32_t* dim; const lasso_fr* read; const uint32_t* read32 = nullptr; };   // read32: compact form (read == nullptr)
     std::vector<Mem> mems; lasso_fr gamma, tau; size_t n_loc = 0;    // circuits 2m (read) and 2m + 1 (write) of memory m, n_loc leaves each
     std::vector<lasso_fr*> work_a, work_b;                          // the arrays bound by the first challenge (n_loc / 8 elements each)
   };
   static constexpr size_t kLeafChunks = 8;
   // below this many leaves per circuit the trees are small and kept whole (LASSO_LEAFLESS_MIN: tests drive the chunked rounds at toy sizes; at least 64 so that a chunk holds an index)
-  static size_t leafless_min() { static const size_t v = [] { const char* e = getenv("LASSO_LEAFLESS_MIN"); const size_t x = e ? (size_t)atoll(e) : ((size_t)1 << 16); return x < 64 ? (size_t)64 : x; }(); return v; }
+  static size_t leafless_min() { return capacity_leafless_min(); }
   // round j in {0, 1} of the bottom layer from recomputed leaves; len = length of A and B (n_loc / 2); ev receives the 2k sums (q(0), q_inf per circuit)
   void leaf_round(const LeafLayer& L, size_t j, size_t len, const lasso_fr* table, const lasso_fr* rp, std::vector<lasso_fr>& ev) {
     HostClock hc("capacity: chunked leaf rounds");
@@ -833,8 +879,10 @@ class Prover {
     std::vector<Sc> acc(2 * k, Sc::zero()); std::vector<lasso_fr> part(2 * k);
     for (size_t ch = 0; ch < kLeafChunks; ch++) {
       const size_t i0 = ch * cs;
-      for (size_t m = 0; m < L.mems.size(); m++)
-        d.chk(lasso_fingerprint_ops_strips(d.ctx, L.mems[m].table, L.mems[m].dim, L.mems[m].read, L.n_loc, &L.gamma, &L.tau, (uint32_t)nstrips, i0, cs, am[2 * m], am[2 * m + 1]), "lasso_fingerprint_ops_strips");
+      for (size_t m = 0; m < L.mems.size(); m++) {
+        if (L.mems[m].read32) d.chk(lasso_fingerprint_ops_strips_u32(d.ctx, L.mems[m].table, L.mems[m].dim, L.mems[m].read32, L.n_loc, &L.gamma, &L.tau, (uint32_t)nstrips, i0, cs, am[2 * m], am[2 * m + 1]), "lasso_fingerprint_ops_strips_u32");
+        else d.chk(lasso_fingerprint_ops_strips(d.ctx, L.mems[m].table, L.mems[m].dim, L.mems[m].read, L.n_loc, &L.gamma, &L.tau, (uint32_t)nstrips, i0, cs, am[2 * m], am[2 * m + 1]), "lasso_fingerprint_ops_strips");
+      }
       d.chk(lasso_sumcheck_cubic_eqw2_begin(d.ctx, am.data(), bm.data(), (uint32_t)k, table + i0, nstrips * cs, rp), "lasso_sumcheck_cubic_eqw2_begin");
       d.chk(lasso_result_wait(d.ctx, part.data(), 2 * k), "lasso_result_wait");
       for (size_t i = 0; i < 2 * k; i++) acc[i] += Sc::from_abi(part[i]);
@@ -850,8 +898,9 @@ class Prover {
     HostClock hc("capacity: leaves materialised after all");
     std::vector<DBuf> out; A.clear(); B.clear();
     for (auto& m : L.mems) {
-      DBuf lr(d, L.n_loc), lw(d, L.n_loc);
-      d.chk(lasso_fingerprint_ops(d.ctx, m.table, m.dim, m.read, L.n_loc, &L.gamma, &L.tau, lr.p, lw.p), "lasso_fingerprint_ops");
+      DBuf lr(d, L.n_loc), lw(d, L.n_loc), lifted;
+      if (m.read32) { lifted = DBuf(d, L.n_loc); d.chk(lasso_fr_from_u32(d.ctx, m.read32, L.n_loc, lifted.p), "lasso_fr_from_u32"); }
+      d.chk(lasso_fingerprint_ops(d.ctx, m.table, m.dim, m.read32 ? lifted.p : m.read, L.n_loc, &L.gamma, &L.tau, lr.p, lw.p), "lasso_fingerprint_ops");
       A.push_back(lr.p); B.push_back(lr.p + L.n_loc / 2); A.push_back(lw.p); B.push_back(lw.p + L.n_loc / 2);
       out.push_back(std::move(lr)); out.push_back(std::move(lw));
     }
@@ -1182,7 +1231,21 @@ class Prover {
     DBuf d_LZ(d, Rn), d_R(d, Rn);
     std::vector<uint8_t> a_bytes(32 * Rn);
     std::vector<lasso_fr> rl, rr; for (size_t i = 0; i < left; i++) rl.push_back(r[i].abi()); for (size_t i = left; i < num_vars; i++) rr.push_back(r[i].abi());
-    if (this->P == 1) {
+    // d_poly == nullptr: the compact merged polynomial of the operations (capacity mode).  L*Z is a sum over row blocks — one polynomial each, lifted into a
+    // scratch array in turn: L*Z = sum_b L[b * rows_per ..) * Z_b; the zero padding contributes nothing
+    const bool blocks = d_poly == nullptr;
+    const size_t rows_per = blocks ? dense.s / Rn : 0, nb = blocks ? 2 * dense.C : 0;
+    if (blocks) LASSO_REQUIRE(dense.compact && num_vars == dense.nv_l && rows_per >= 1 && nb * rows_per <= Ln);
+    if (this->P == 1 && blocks) {
+      DBuf d_L(d, Ln), Mb(d, nb * Rn), ones(d, nb), tmp(d, s_loc);
+      d.chk(lasso_eq_evals(d.ctx, rl.data(), (uint32_t)left, d_L.p), "lasso_eq_evals");
+      d.chk(lasso_eq_evals(d.ctx, rr.data(), (uint32_t)right, d_R.p), "lasso_eq_evals");
+      for (size_t b = 0; b < nb; b++) { dense.lift_block(b, tmp.p); d.chk(lasso_matvec_left_dev(d.ctx, tmp.p, d_L.p + b * rows_per, rows_per, Rn, Mb.p + b * Rn), "lasso_matvec_left_dev"); }
+      std::vector<lasso_fr> one_h(nb, Sc::one().abi());
+      d.chk(lasso_upload(d.ctx, ones.p, one_h.data(), nb * sizeof(lasso_fr)), "lasso_upload");
+      d.chk(lasso_matvec_left_dev(d.ctx, Mb.p, ones.p, nb, Rn, d_LZ.p), "lasso_matvec_left_dev");
+      d.chk(lasso_fr_to_bytes(d.ctx, d_R.p, Rn, a_bytes.data()), "lasso_fr_to_bytes");
+    } else if (this->P == 1) {
       // everything stays on the device: the two halves of the eq table (eq_poly.rs:44-52), L*Z (dense_mlpoly.rs:184-207); only serialize(R) comes back
       DBuf d_L(d, Ln);
       d.chk(lasso_eq_evals(d.ctx, rl.data(), (uint32_t)left, d_L.p), "lasso_eq_evals");
@@ -1196,6 +1259,15 @@ class Prover {
       std::vector<lasso_fr> Lh(Ln), LZh(Rn); for (size_t i = 0; i < Ln; i++) Lh[i] = L[i].abi();
       const size_t Pw = this->P, r_loc = Rn / Pw; LASSO_REQUIRE(Rn >= Pw);
       std::vector<lasso_fr> mine(r_loc), all(Rn);
+      if (blocks) {
+        DBuf tmp(d, s_loc); std::vector<lasso_fr> part(r_loc); ScVec acc(r_loc, Sc::zero());
+        for (size_t b = 0; b < nb; b++) {
+          dense.lift_block(b, tmp.p);
+          d.chk(lasso_matvec_left(d.ctx, tmp.p, Lh.data() + b * rows_per, rows_per, r_loc, part.data()), "lasso_matvec_left");
+          for (size_t j = 0; j < r_loc; j++) acc[j] += Sc::from_abi(part[j]);
+        }
+        for (size_t j = 0; j < r_loc; j++) mine[j] = acc[j].abi();
+      } else
       d.chk(lasso_matvec_left(d.ctx, d_poly, Lh.data(), Ln, r_loc, mine.data()), "lasso_matvec_left");
       d.comm.allgather(mine.data(), all.data(), r_loc * sizeof(lasso_fr));
       for (size_t g2 = 0; g2 < Pw; g2++) for (size_t j = 0; j < r_loc; j++) LZh[j * Pw + g2] = all[g2 * r_loc + j];
@@ -1390,7 +1462,7 @@ class Prover {
     std::unique_ptr<Trace> sp(new Trace("Subtables.to_grand_products", d.ctx));
     std::vector<DBuf> t_init, t_read, t_write, t_final;
     // capacity mode: the read / write trees without their leaf layers (half of each tree); the bottom layer's sumcheck recomputes the fingerprints (LeafLayer above)
-    const bool leafless = d.capacity && s_loc >= leafless_min();
+    const bool leafless = (d.capacity || dense.compact) && s_loc >= leafless_min();   // a compact representation implies the leafless trees (same size condition)
     if (d.capacity) d.trim();   // what the earlier phases parked in the recycling pool (the primary sumcheck's work arrays: no later buffer has their size) goes back before the peak
     LeafLayer leaf; leaf.gamma = g; leaf.tau = ta; leaf.n_loc = s_loc;
     for (size_t i = 0; i < alpha; i++) {
@@ -1398,7 +1470,10 @@ class Prover {
       DBuf ti(d, 2 * m_loc), tf(d, 2 * m_loc), tr(d, leafless ? s_loc : 2 * s_loc), tw(d, leafless ? s_loc : 2 * s_loc);
       d.chk(lasso_fingerprint_mem_slab(d.ctx, table, dense.final_(j), m_loc, (uint32_t)P, (uint32_t)d.comm.rank, &g, &ta, ti.p, tf.p), "lasso_fingerprint_mem");
       d.chk(lasso_gp_build(d.ctx, ti.p, m_loc), "lasso_gp_build"); d.chk(lasso_gp_build(d.ctx, tf.p, m_loc), "lasso_gp_build");
-      if (leafless) {
+      if (leafless && dense.compact) {
+        d.chk(lasso_fingerprint_ops_gp_upper_u32(d.ctx, table, dense.dim_u32[j].p, dense.read_u32[j].p, s_loc, &g, &ta, tr.p, tw.p), "lasso_fingerprint_ops_gp_upper_u32");
+        leaf.mems.push_back({table, dense.dim_u32[j].p, nullptr, dense.read_u32[j].p});
+      } else if (leafless) {
         d.chk(lasso_fingerprint_ops_gp_upper(d.ctx, table, dense.dim_u32[j].p, dense.read(j), s_loc, &g, &ta, tr.p, tw.p), "lasso_fingerprint_ops_gp_upper");
         leaf.mems.push_back({table, dense.dim_u32[j].p, dense.read(j)});
       } else if (s_loc >= 4) {   // read / write leaves and both trees in one call: the first product layer is taken while the leaves are in registers (no re-read of 2 x 32 s bytes)
@@ -1451,9 +1526,10 @@ class Prover {
     // argument, which is latency-bound (two 2^16-leaf circuits per memory) and leaves the device mostly idle.
     const size_t C = S.C();
     const size_t k_derefs = ceil_log2(next_pow2(alpha)), k_ops = ceil_log2(next_pow2(2 * C)), k_mem = ceil_log2(next_pow2(C));
-    std::vector<const lasso_fr*> at_ops(Eptr); for (size_t i = 0; i < C; i++) at_ops.push_back(dense.dim(i)); for (size_t i = 0; i < C; i++) at_ops.push_back(dense.read(i));
+    std::vector<const lasso_fr*> at_ops(Eptr);
+    if (!dense.compact) { for (size_t i = 0; i < C; i++) at_ops.push_back(dense.dim(i)); for (size_t i = 0; i < C; i++) at_ops.push_back(dense.read(i)); }
     OpenPrep prep_derefs, prep_ops, prep_mem;
-    const bool side = P == 1 && !side_off();
+    const bool side = P == 1 && !side_off() && !dense.compact;   // compact form: dim / read exist as field elements one at a time, on the main context
     if (side) {
       lasso_ctx* sc = d.side();
       std::vector<lasso_fr> rr; for (auto& x : rand_ops) rr.push_back(x.abi());
@@ -1487,6 +1563,11 @@ class Prover {
       } else {
         eq_evals_local(rand_ops, chis.p);
         d.chk(lasso_multi_dot(d.ctx, at_ops.data(), (uint32_t)at_ops.size(), chis.p, s_loc, out.data()), "lasso_multi_dot");
+        if (dense.compact) {   // dim_i, read_i: lifted into one scratch array and evaluated one after the other
+          DBuf tmp(d, s_loc); const lasso_fr* one[1] = {tmp.p};
+          out.resize(alpha + 2 * C);
+          for (size_t b = 0; b < 2 * C; b++) { dense.lift_block(b, tmp.p); d.chk(lasso_multi_dot(d.ctx, one, 1, chis.p, s_loc, &out[alpha + b]), "lasso_multi_dot"); }
+        }
         d.comm.sum(out);
       }
       for (auto& o : out) ev_ops.push_back(Sc::from_abi(o));
@@ -1506,7 +1587,7 @@ class Prover {
       for (auto& o : out) eval_final.push_back(Sc::from_abi(o));
     }
     ScVec evals_ops = eval_dim; evals_ops.insert(evals_ops.end(), eval_read.begin(), eval_read.end());
-    DotProductProofLog proof_ops_open = joint_open("claim_evals_ops", "challenge_combine_n_to_one", "joint_claim_eval_ops", evals_ops, true, dense.combined_l_variate_polys.p, dense.nv_l, rand_ops, gens.gens_combined_l_variate, &prep_ops);
+    DotProductProofLog proof_ops_open = joint_open("claim_evals_ops", "challenge_combine_n_to_one", "joint_claim_eval_ops", evals_ops, true, dense.compact ? nullptr : dense.combined_l_variate_polys.p, dense.nv_l, rand_ops, gens.gens_combined_l_variate, &prep_ops);
     DotProductProofLog proof_mem_open = joint_open("claim_evals_mem", "challenge_combine_two_to_one", "joint_claim_eval_mem", eval_final, false, dense.combined_log_m_variate_polys.p, dense.nv_m, rand_mem, gens.gens_combined_log_m_variate, &prep_mem);
     if (side) side_sync();
     W.sc_arr(eval_dim); W.sc_arr(eval_read); W.sc_arr(eval_final); W.sc_arr(eval_derefs);     // HashLayerProof field order (:314-329)

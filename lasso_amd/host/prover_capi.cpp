@@ -95,6 +95,16 @@ int32_t lasso_host_densify(lasso_host* h, const uint64_t* indices, size_t n, siz
   GUARD(std::unique_ptr<lasso_host_dense> d(new lasso_host_dense(h)); d->d = DensifiedRepresentation::from_lookup_indices(h->dev, indices, n, c, log_m); *out = d.release(); return 0;)
 }
 void lasso_host_dense_free(lasso_host_dense* d) { delete d; }
+int32_t lasso_host_dense_info(lasso_host_dense* d, uint64_t* device_bytes, int32_t* compact) {
+  if (!d || !d->d) return LASSO_ERR_INVALID;
+  const DensifiedRepresentation& D = *d->d;
+  uint64_t b = (uint64_t)(D.combined_l_variate_polys.n + D.combined_log_m_variate_polys.n) * sizeof(lasso_fr);
+  for (auto& x : D.dim_u32) b += 4 * (uint64_t)x.n;
+  for (auto& x : D.read_u32) b += 4 * (uint64_t)x.n;
+  if (device_bytes) *device_bytes = b;
+  if (compact) *compact = D.compact ? 1 : 0;
+  return 0;
+}
 int32_t lasso_host_commit(lasso_host_dense* d, lasso_host_gens* g, uint8_t* out, size_t cap, size_t* len) {
   GUARD(SparsePolynomialCommitment c = d->d->commit(*g->g); ProofWriter w; w.pts_vec(c.l_variate_polys_commitment.compressed); w.pts_vec(c.log_m_variate_polys_commitment.compressed); return emit(w.b, out, cap, len);)
 }

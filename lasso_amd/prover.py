@@ -47,6 +47,7 @@ def declare_prover(lib):
     lib.lasso_host_gens_free.argtypes = [vp]
     lib.lasso_host_densify.argtypes = [vp, vp, sz, sz, sz, C.POINTER(vp)]
     lib.lasso_host_dense_free.argtypes = [vp]
+    lib.lasso_host_dense_info.argtypes = [vp, u64p, C.POINTER(C.c_int32)]
     lib.lasso_host_commit.argtypes = [vp, vp, vp, sz, C.POINTER(sz)]
     lib.lasso_host_prove.argtypes = [vp, vp, vp, C.POINTER(_abi.Strategy), vp, sz, C.c_char_p, C.c_char_p, vp, sz, C.POINTER(sz)]
     lib.lasso_host_verify.argtypes = [vp, vp, C.POINTER(_abi.Strategy), sz, vp, sz, C.c_char_p, C.c_char_p, sz, C.c_char_p, sz, C.POINTER(i32)]
@@ -106,6 +107,12 @@ class HostProver:
         d = C.c_void_p()
         self._chk(self.lib.lasso_host_densify(self.h, indices.ctypes.data_as(C.c_void_p), indices.shape[0], indices.shape[1], log_m, C.byref(d)))
         return d
+
+    def dense_info(self, dense):
+        """device bytes a densified representation holds, and whether dim / read are in capacity mode's compact form"""
+        b, c = C.c_uint64(), C.c_int32()
+        self._chk(self.lib.lasso_host_dense_info(dense, C.byref(b), C.byref(c)))
+        return {"device_bytes": b.value, "compact": bool(c.value)}
 
     def _bytes_call(self, fn, *args, cap=1 << 20):
         while True:

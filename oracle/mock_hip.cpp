@@ -76,6 +76,16 @@ int32_t lasso_prof_reset(lasso_ctx*) { return 0; }
 int32_t lasso_prof_get(lasso_ctx*, int32_t, uint64_t* l, double* ms, double* b) { if (l) *l = 0; if (ms) *ms = 0; if (b) *b = 0; return 0; }
 
 int32_t lasso_fr_from_u32(lasso_ctx*, const uint32_t* s, size_t n, lasso_fr* d) { for (size_t i = 0; i < n; i++) F(d)[i] = Fr::from_u64(s[i]); return 0; }
+int32_t lasso_fr_to_u32(lasso_ctx* c, const lasso_fr* s, size_t n, uint32_t* d, uint32_t* max_out) {
+  uint32_t mx = 0;
+  for (size_t i = 0; i < n; i++) {
+    uint8_t b[32]; F(s)[i].to_bytes_le(b);
+    for (int k = 4; k < 32; k++) REQ(c, b[k] == 0);
+    d[i] = (uint32_t)b[0] | (uint32_t)b[1] << 8 | (uint32_t)b[2] << 16 | (uint32_t)b[3] << 24; if (d[i] > mx) mx = d[i];
+  }
+  if (max_out) *max_out = mx;
+  return 0;
+}
 int32_t lasso_gather(lasso_ctx*, const lasso_fr* t, const uint32_t* idx, size_t n, lasso_fr* o) { for (size_t i = 0; i < n; i++) o[i] = t[idx[i]]; return 0; }
 int32_t lasso_eq_evals(lasso_ctx*, const lasso_fr* r, uint32_t ell, lasso_fr* o) {
   std::vector<Fr> rr(F(r), F(r) + ell); auto ev = EqPolynomial(rr).evals(); memcpy(o, ev.data(), ev.size() * 32); return 0;
@@ -340,6 +350,15 @@ int32_t lasso_fingerprint_ops_strips(lasso_ctx* c, const lasso_fr* table, const 
     out_r[j] = lr[k]; out_w[j] = lw[k];
   }
   return 0;
+}
+int32_t lasso_fingerprint_ops_gp_upper_u32(lasso_ctx* c, const lasso_fr* table, const uint32_t* dim, const uint32_t* read32, size_t s, const lasso_fr* gamma, const lasso_fr* tau, lasso_fr* ur, lasso_fr* uw) {
+  std::vector<lasso_fr> read(s); lasso_fr_from_u32(c, read32, s, read.data());
+  return lasso_fingerprint_ops_gp_upper(c, table, dim, read.data(), s, gamma, tau, ur, uw);
+}
+int32_t lasso_fingerprint_ops_strips_u32(lasso_ctx* c, const lasso_fr* table, const uint32_t* dim, const uint32_t* read32, size_t s, const lasso_fr* gamma, const lasso_fr* tau,
+                                         uint32_t nstrips, size_t i0, size_t cs, lasso_fr* out_r, lasso_fr* out_w) {
+  std::vector<lasso_fr> read(s); lasso_fr_from_u32(c, read32, s, read.data());
+  return lasso_fingerprint_ops_strips(c, table, dim, read.data(), s, gamma, tau, nstrips, i0, cs, out_r, out_w);
 }
 int32_t lasso_fingerprint_mem(lasso_ctx*, const lasso_fr* table, const lasso_fr* fin, size_t m, const lasso_fr* gamma, const lasso_fr* tau, lasso_fr* io, lasso_fr* fo) {
   Fr g = *F(gamma), g2 = g.square(), t = *F(tau);

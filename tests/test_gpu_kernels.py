@@ -320,7 +320,8 @@ def test_fingerprint_leafless_trees_and_strips(devs, s, log_m):
     == the leaves at the positions a chunked round reads (2 strips s/4 apart for the first round, 4 strips s/8 apart for the second), on the device and against the mock"""
     rng = np.random.default_rng(s * 3 + log_m)
     m = 1 << log_m
-    table = rand_fr(rng, m); read = small_fr(rng.integers(0, 1 << 20, size=s, dtype=np.uint64))
+    read_int = rng.integers(0, 1 << 20, size=s, dtype=np.uint64); read_int[0] = 0; read_int[-1] = (1 << 32) - 1
+    table = rand_fr(rng, m); read = small_fr(read_int)
     dim = rng.integers(0, m, size=s, dtype=np.uint32); dim[-1] = m - 1
     gamma, tau = rand_fr(rng, 2, edge=False)
     picks = []      # (nstrips, i0, cs)
@@ -338,19 +339,31 @@ def test_fingerprint_leafless_trees_and_strips(devs, s, log_m):
         d.fingerprint_ops_gp_upper(pt, pd, pr, s, gamma, tau, ur, uw)
         full = [d.download(p, (2 * s, 4))[: 2 * s - 2] for p in (tr, tw)]
         upper = [d.download(p, (s, 4))[: s - 2] for p in (ur, uw)]
+        # the compact form: the timestamps back as 32-bit integers (lasso_fr_to_u32), and the same two entry points reading those
+        p32 = d.alloc(4 * s)
+        assert d.fr_to_u32(pr, s, p32) == int(read_int.max())
+        assert np.array_equal(d.download(p32, (s,), dtype=np.uint32), read_int.astype(np.uint32))
+        d.fingerprint_ops_gp_upper(pt, pd, p32, s, gamma, tau, ur, uw, read_u32=True)
+        upper32 = [d.download(p, (s, 4))[: s - 2] for p in (ur, uw)]
         strips = []
         for nstrips, i0, cs in picks:
             n = 2 * nstrips * cs
             o_r = d.alloc(32 * n); o_w = d.alloc(32 * n)
             d.fingerprint_ops_strips(pt, pd, pr, s, gamma, tau, nstrips, i0, cs, o_r, o_w)
             strips.append((d.download(o_r, (n, 4)), d.download(o_w, (n, 4))))
+            d.fingerprint_ops_strips(pt, pd, p32, s, gamma, tau, nstrips, i0, cs, o_r, o_w, read_u32=True)
+            assert np.array_equal(strips[-1][0], d.download(o_r, (n, 4))) and np.array_equal(strips[-1][1], d.download(o_w, (n, 4)))
             d.free(o_r); d.free(o_w)
-        for p in (pt, pd, pr, tr, tw, ur, uw):
+        pbig = d.upload(small_fr(np.array([5, 1 << 32, 7], dtype=np.uint64)))
+        with pytest.raises(Exception):          # a value that does not fit 32 bits is refused
+            d.fr_to_u32(pbig, 3, p32)
+        for p in (pt, pd, pr, tr, tw, ur, uw, p32, pbig):
             d.free(p)
-        return full, upper, strips
-    (full, upper, strips), (mfull, mupper, mstrips) = both(devs, run)
+        return full, upper, strips, upper32
+    (full, upper, strips, upper32), (mfull, mupper, mstrips, mupper32) = both(devs, run)
     for c in range(2):
         assert np.array_equal(upper[c], full[c][s:]) and np.array_equal(upper[c], mupper[c])
+        assert np.array_equal(upper32[c], upper[c]) and np.array_equal(mupper32[c], upper[c])
     for (nstrips, i0, cs), got, want in zip(picks, strips, mstrips):
         stride = s // 2 // nstrips
         for c in range(2):
