@@ -347,7 +347,7 @@ def slab_units(kind, c, capacity=False):
     p2 = lambda x: 1 << (x - 1).bit_length()
     committed = (2 * c / 8.0 if capacity else p2(2 * c) + c / 8.0) + p2(alpha)
     sumcheck_peak = committed + 2 + (alpha if kind in ("lt", "spark") else alpha / 2.0)     # LT and Spark bind clones of all their polynomials
-    trees_peak = committed + 2 + (2 * alpha + alpha / 4.0 if capacity else 4 * alpha) + 0.25
+    trees_peak = committed + (2 * alpha + alpha / 4.0 if capacity else 2 + 4 * alpha) + 0.25            # capacity mode also lets go of the eq / chi tables for the duration of the trees
     return max(sumcheck_peak, trees_peak)
 
 

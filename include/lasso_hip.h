@@ -76,6 +76,9 @@ int32_t lasso_free(lasso_ctx* ctx, void* d_ptr);
  * context was created or since the last call with reset_peak != 0.  What one rank of slab mode needs of its GPU's 288 GB (bench.py `peak_bytes_per_rank`);
  * the reference's counterpart is the resident set of its Vec<F>s (src/poly/dense_mlpoly.rs:28-32, src/subprotocols/grand_product.rs:19-58). */
 int32_t lasso_mem_stats(lasso_ctx* ctx, uint64_t* live_bytes, uint64_t* peak_bytes, int32_t reset_peak);
+/* The context's scratch buffer grows to the largest request it has served (densify's sort buffers, a commitment's digit arrays: 16 bytes per lookup and more) and is
+ * kept; lasso_trim drains the stream and shrinks it back to its initial 4 MiB.  Not while a deferred result or a resident tail is outstanding (LASSO_ERR_INVALID). */
+int32_t lasso_trim(lasso_ctx* ctx);
 int32_t lasso_upload(lasso_ctx* ctx, void* d_dst, const void* src, size_t bytes);     /* synchronous */
 int32_t lasso_download(lasso_ctx* ctx, void* dst, const void* d_src, size_t bytes);   /* synchronous */
 int32_t lasso_copy(lasso_ctx* ctx, void* d_dst, const void* d_src, size_t bytes);     /* DensePolynomial::clone / merge: src/poly/dense_mlpoly.rs:97-99,:251-261 */

@@ -40,6 +40,7 @@ def declare(lib):
         "lasso_prof_get_units": (i32, [vp, i32, i32, P(C.c_double)]),
         "lasso_wait_stats": (i32, [vp, P(u64), P(C.c_double), i32]),
         "lasso_mem_stats": (i32, [vp, P(u64), P(u64), i32]),
+        "lasso_trim": (i32, [vp]),
         "lasso_fr_from_u32": (i32, [vp, vp, sz, vp]),
         "lasso_fr_to_u32": (i32, [vp, vp, sz, vp, vp]),
         "lasso_gather": (i32, [vp, vp, vp, sz, vp]),

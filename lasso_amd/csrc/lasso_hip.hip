@@ -445,6 +445,13 @@ int32_t lasso_mem_stats(lasso_ctx* c, uint64_t* live_bytes, uint64_t* peak_bytes
   REQUIRE(c, c); std::lock_guard<std::mutex> g(c->mem_mu);
   if (live_bytes) *live_bytes = c->mem_live; if (peak_bytes) *peak_bytes = c->mem_peak; if (reset_peak) c->mem_peak = c->mem_live; return 0;
 }
+int32_t lasso_trim(lasso_ctx* c) {
+  REQUIRE(c, c && !c->pending && !c->tail_active);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->scratch_cap <= ((size_t)1 << 22)) return 0;
+  HIPCHK(c, dfree(c, c->d_scratch)); c->d_scratch = nullptr; c->scratch_cap = 0;
+  return ensure_scratch(c, (size_t)1 << 22);
+}
 int32_t lasso_upload(lasso_ctx* c, void* d, const void* s, size_t n) { REQUIRE(c, d && s); HIPCHK(c, hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); return 0; }
 int32_t lasso_download(lasso_ctx* c, void* d, const void* s, size_t n) { REQUIRE(c, d && s); HIPCHK(c, hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); return 0; }
 int32_t lasso_copy(lasso_ctx* c, void* d, const void* s, size_t n) { REQUIRE(c, d && s); ProfScope ps(c, LASSO_K_MISC, 2.0 * n); HIPCHK(c, hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, c->stream)); return 0; }

@@ -31,10 +31,19 @@ namespace lasso {
 // laid next to src/benches/*.log line by line.  Device work is asynchronous: a span closes after a stream sync only when tracing.
 struct Trace {
   static bool on() { static const bool v = [] { const char* e = getenv("LASSO_TRACE"); return e && e[0] == '1'; }(); return v; }
+  // LASSO_TRACE=3: device bytes per span instead (live at entry, the span's own high-water mark; lasso_mem_stats with reset, so an enclosing span reports what followed its last child)
+  static bool mem() { static const bool v = [] { const char* e = getenv("LASSO_TRACE"); return e && e[0] == '3'; }(); return v; }
   const char* name; lasso_ctx* ctx; std::chrono::steady_clock::time_point t0; static int& depth() { static thread_local int d = 0; return d; }
-  uint64_t w0 = 0; double wus0 = 0;
-  Trace(const char* n, lasso_ctx* c) : name(n), ctx(c) { if (on()) { t0 = std::chrono::steady_clock::now(); depth()++; if (ctx) lasso_wait_stats(ctx, &w0, &wus0, 0); } }
+  uint64_t w0 = 0; double wus0 = 0; uint64_t live0 = 0;
+  Trace(const char* n, lasso_ctx* c) : name(n), ctx(c) {
+    if (on()) { t0 = std::chrono::steady_clock::now(); depth()++; if (ctx) lasso_wait_stats(ctx, &w0, &wus0, 0); }
+    if (mem() && ctx) { uint64_t pk = 0; lasso_mem_stats(ctx, &live0, &pk, 1); depth()++; }
+  }
   ~Trace() {
+    if (mem() && ctx) {
+      uint64_t live = 0, pk = 0; lasso_mem_stats(ctx, &live, &pk, 1); depth()--;
+      fprintf(stderr, "[mem] %*s%s: live at entry %.2f GB, peak inside %.2f GB, live at exit %.2f GB\n", 2 * depth(), "", name, live0 / 1e9, pk / 1e9, live / 1e9);
+    }
     if (!on()) return;
     if (ctx) lasso_sync(ctx);
     depth()--;
@@ -151,8 +160,16 @@ class Dev {
   }
   // a one-off buffer (the uploaded index array of densify: 8 C s bytes that nothing of that size will ever want again) goes back to the driver, not into the pool
   void release(void* p) const { if (!p) return; auto it = live_.find(p); if (it == live_.end()) return; in_use_ -= it->second; live_.erase(it); (void)lasso_free(ctx, p); }
+  // LASSO_TRACE=3: what the prover holds right now, by size
+  void dump_live(const char* tag) const {
+    std::map<size_t, size_t> by; for (auto& kv : live_) by[kv.second]++;
+    size_t pooled = 0; for (auto& kv : pool_) pooled += kv.first;
+    fprintf(stderr, "[mem] %s: in use %.2f GB, parked in the pool %.2f GB;", tag, in_use_ / 1e9, pooled / 1e9);
+    for (auto it = by.rbegin(); it != by.rend() && it->first >= ((size_t)1 << 20); ++it) fprintf(stderr, " %zu x %.3f GB", it->second, it->first / 1e9);
+    fprintf(stderr, "\n");
+  }
   // hand every pooled buffer back to the driver
-  void trim() const { for (auto& kv : pool_) (void)lasso_free(ctx, kv.second); pool_.clear(); }
+  void trim() const { for (auto& kv : pool_) (void)lasso_free(ctx, kv.second); pool_.clear(); (void)lasso_trim(ctx); }   // ... and the context's grown scratch buffer
   // device bytes held through this host's contexts now / at most (lasso_mem_stats of the main and the side context), and what the prover itself held at most
   void mem_stats(uint64_t* live, uint64_t* peak, uint64_t* in_use_peak, bool reset) const {
     uint64_t l = 0, p = 0, l2 = 0, p2 = 0;
@@ -566,6 +583,7 @@ struct DensifiedRepresentation {
 
   // indices: n_lookups x C, row-major (the reference's Vec<[usize; C]>)
   static std::unique_ptr<DensifiedRepresentation> from_lookup_indices(const Dev& d, const uint64_t* indices, size_t n_lookups, size_t C, size_t log_m) {
+    Trace tr_all("DensifiedRepresentation.from_lookup_indices", d.ctx);
     auto D = std::make_unique<DensifiedRepresentation>();
     D->dev = &d; D->C = C; D->s = next_pow2(n_lookups); D->log_m = log_m; D->m = (size_t)1 << log_m;
     const size_t s = D->s, m = D->m, P = d.comm.world;
@@ -602,6 +620,7 @@ struct DensifiedRepresentation {
     return D;
   }
   SparsePolynomialCommitment commit(const SparsePolyCommitmentGens& gens) const {  // densified.rs:78-96
+    Trace tr_all("DensifiedRepresentation.commit", dev->ctx);
     SparsePolynomialCommitment c;
     if (!compact) c.l_variate_polys_commitment = hyrax_commit(*dev, combined_l_variate_polys.p, nv_l, gens.gens_combined_l_variate);
     else {
@@ -1385,12 +1404,12 @@ class Prover {
         std::vector<lasso_fr> rr; for (auto& x : r) rr.push_back(x.abi());
         d.chk_side(lasso_eq_evals(fc, rr.data(), (uint32_t)rr.size(), eq.p), "lasso_eq_evals");
       } else field_side();
-      sp.reset(new Trace("Subtables.commit", d.ctx));
+      sp.reset(), sp.reset(new Trace("Subtables.commit", d.ctx));
       comm_derefs = hyrax_commit(d, combined_E.p, nv_derefs, gens.gens_derefs, E_u32.p, table_max);
       if (side_new) side_sync();
     } else {
       field_side();
-      sp.reset(new Trace("Subtables.commit", d.ctx));
+      sp.reset(), sp.reset(new Trace("Subtables.commit", d.ctx));
       comm_derefs = hyrax_commit(d, combined_E.p, nv_derefs, gens.gens_derefs);
     }
     tables_u32.clear();
@@ -1406,14 +1425,14 @@ class Prover {
     t.append_message("subtable_evals_commitment", "end_subtable_evals_commitment");
     W.pts_vec(comm_derefs.compressed);
     // claim
-    sp.reset(new Trace("Subtables.compute_sumcheck_claim", d.ctx));
+    sp.reset(), sp.reset(new Trace("Subtables.compute_sumcheck_claim", d.ctx));
     d.chk(lasso_result_wait(d.ctx, claim_abi.data(), 1), "lasso_result_wait");
     d.comm.sum(claim_abi);
     Sc claimed_eval = Sc::from_abi(claim_abi[0]);
     t.append_scalar("claim_eval_scalar_product", claimed_eval);
     // primary sumcheck on clones of E_i and the eq polynomial (surge.rs:151-172)
     ScVec r_z;
-    sp.reset(new Trace("Sumcheck.prove", d.ctx));
+    sp.reset(), sp.reset(new Trace("Sumcheck.prove", d.ctx));
     ScVec sumcheck_heads;
     {
       // the sumcheck binds its polynomials; E itself must survive (the openings read it).  Linear strategies: the first bind reads E and writes the
@@ -1430,9 +1449,10 @@ class Prover {
       sp.write(W);
     }
     E_u32 = DBufU32();
+    if (d.capacity) eq.release();   // bound down to one element by the sumcheck: nothing reads it again
     W.sc(claimed_eval);
     // eval_derefs = E_i(r_z) (surge.rs:175-176)
-    sp.reset(new Trace("CombinedEval.prove", d.ctx));
+    sp.reset(), sp.reset(new Trace("CombinedEval.prove", d.ctx));
     DBuf chis(d, s_loc);
     auto evaluate_at = [&](const std::vector<const lasso_fr*>& polys, const ScVec& point, size_t n_loc, DBuf& chi) {
       eq_evals_local(point, chi.p);
@@ -1447,7 +1467,7 @@ class Prover {
     t.append_protocol_name("Lasso CombinedTableEvalProof");
     joint_open("evals_ops_val", "challenge_combine_n_to_one", "joint_claim_eval", eval_derefs, true, combined_E.p, nv_derefs, r_z, gens.gens_derefs).write(W);
     // memory checking (surge.rs:186-199)
-    sp.reset(new Trace("MemoryChecking.prove", d.ctx));
+    sp.reset(), sp.reset(new Trace("MemoryChecking.prove", d.ctx));
     ScVec r_hash = t.challenge_vector("challenge_r_hash", 2);
     memory_checking_prove(r_hash[0], r_hash[1], Eptr, chis, W);
     sp.reset();
@@ -1463,7 +1483,8 @@ class Prover {
     std::vector<DBuf> t_init, t_read, t_write, t_final;
     // capacity mode: the read / write trees without their leaf layers (half of each tree); the bottom layer's sumcheck recomputes the fingerprints (LeafLayer above)
     const bool leafless = (d.capacity || dense.compact) && s_loc >= leafless_min();   // a compact representation implies the leafless trees (same size condition)
-    if (d.capacity) d.trim();   // what the earlier phases parked in the recycling pool (the primary sumcheck's work arrays: no later buffer has their size) goes back before the peak
+    if (d.capacity) { chis.release(); d.trim(); }   // the chi table is next needed after the operations' argument (re-allocated there); and what the earlier phases parked in the
+                                                    // recycling pool (the primary sumcheck's work arrays: no later buffer has their size) goes back before the peak
     LeafLayer leaf; leaf.gamma = g; leaf.tau = ta; leaf.n_loc = s_loc;
     for (size_t i = 0; i < alpha; i++) {
       size_t j = S.memory_to_dimension_index(i); const lasso_fr* table = tables[S.memory_to_subtable_index(i)].p;
@@ -1484,8 +1505,9 @@ class Prover {
       }
       t_init.push_back(std::move(ti)); t_final.push_back(std::move(tf)); t_read.push_back(std::move(tr)); t_write.push_back(std::move(tw));
     }
+    if (Trace::mem()) d.dump_live("trees built");
     // ProductLayerProof::prove (memory_checking.rs:674-731)
-    sp.reset(new Trace("ProductLayer.prove", d.ctx));
+    sp.reset(), sp.reset(new Trace("ProductLayer.prove", d.ctx));
     t.append_protocol_name("Lasso ProductLayerProof");
     // GrandProductCircuit::evaluate = product of the last layer's two elements; in slab mode that is the rank's LOCAL root, i.e. element `rank` of the
     // global layer of P elements: the roots are all-gathered, the global layers P, P/2, .., 2 are built from them (replicated) and the hash is the top product
@@ -1521,6 +1543,7 @@ class Prover {
     ScVec rand_ops, rand_mem;
     BatchedGrandProductArgument proof_ops = bgpa_prove(rw, rw_top, s, roots_rw, rand_ops, leafless ? &leaf : nullptr);
     t_read.clear(); t_write.clear();
+    if (!chis.p) chis = DBuf(d, s_loc);
     // Everything HashLayerProof needs at rand_ops that does not depend on the transcript — the evaluations of E / dim / read (one pass over all of
     // them) and the big mat-vecs of the two openings at rand_ops — starts now on the side context and runs under the second grand-product
     // argument, which is latency-bound (two 2^16-leaf circuits per memory) and leaves the device mostly idle.
@@ -1544,7 +1567,7 @@ class Prover {
     t_init.clear(); t_final.clear(); tops_store.clear();
     proof_mem.write(W); proof_ops.write(W);    // field order of ProductLayerProof: grand_product_evals, proof_mem, proof_ops (:656-660)
     // HashLayerProof::prove (memory_checking.rs:338-460)
-    sp.reset(new Trace("HashLayer.prove", d.ctx));
+    sp.reset(), sp.reset(new Trace("HashLayer.prove", d.ctx));
     t.append_protocol_name("Lasso HashLayerProof");
     ScVec ev_ops;
     DBuf chim(d, m_loc);

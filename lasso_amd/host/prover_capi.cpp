@@ -108,15 +108,25 @@ int32_t lasso_host_dense_info(lasso_host_dense* d, uint64_t* device_bytes, int32
 int32_t lasso_host_commit(lasso_host_dense* d, lasso_host_gens* g, uint8_t* out, size_t cap, size_t* len) {
   GUARD(SparsePolynomialCommitment c = d->d->commit(*g->g); ProofWriter w; w.pts_vec(c.l_variate_polys_commitment.compressed); w.pts_vec(c.log_m_variate_polys_commitment.compressed); return emit(w.b, out, cap, len);)
 }
+// one proof; capacity mode: nothing of a finished proof stays parked in the host's recycling pool (the next proof's first allocations would otherwise sit on top of it)
+static std::vector<uint8_t> run_prover(lasso_host* h, const Strategy& S, DensifiedRepresentation& D, const SparsePolyCommitmentGens& G, ProofTranscript& t, RandomTape& tape, const ScVec& rv) {
+  std::vector<uint8_t> bytes;
+  {
+    Prover P(h->dev, S, D, G, t, tape);
+    try { P.prove(rv); } catch (...) { h->dev.abort_all(); throw; }
+    bytes.swap(P.proof_bytes);
+  }
+  if (h->dev.capacity) h->dev.trim();
+  return bytes;
+}
 int32_t lasso_host_prove(lasso_host* h, lasso_host_dense* d, lasso_host_gens* g, const lasso_strategy* st, const lasso_fr* r, size_t r_len, const char* tl, const char* pl,
                          uint8_t* out, size_t cap, size_t* len) {
   GUARD(
     Strategy S(st->kind, st->c, st->log_m, st->log_r);
     ProofTranscript t(tl); RandomTape tape(pl);
     ScVec rv; for (size_t i = 0; i < r_len; i++) rv.push_back(Sc::from_abi(r[i]));
-    Prover P(h->dev, S, *d->d, *g->g, t, tape);
-    try { P.prove(rv); } catch (...) { h->dev.abort_all(); throw; }
-    return emit(P.proof_bytes, out, cap, len);)
+    std::vector<uint8_t> bytes = run_prover(h, S, *d->d, *g->g, t, tape, rv);
+    return emit(bytes, out, cap, len);)
 }
 // ---- live transcripts (include/lasso_prover.h lasso_transcript_vtbl)
 struct lasso_merlin { Merlin m; explicit lasso_merlin(const char* label) : m(label) {} };
@@ -142,9 +152,8 @@ int32_t lasso_host_prove_cb(lasso_host* h, lasso_host_dense* d, lasso_host_gens*
     Strategy S(st->kind, st->c, st->log_m, st->log_r);
     ProofTranscript t(tv, tu); RandomTape tape(pv, pu);
     ScVec rv; for (size_t i = 0; i < r_len; i++) rv.push_back(Sc::from_abi(r[i]));
-    Prover P(h->dev, S, *d->d, *g->g, t, tape);
-    try { P.prove(rv); } catch (...) { h->dev.abort_all(); throw; }
-    return emit(P.proof_bytes, out, cap, len);)
+    std::vector<uint8_t> bytes = run_prover(h, S, *d->d, *g->g, t, tape, rv);
+    return emit(bytes, out, cap, len);)
 }
 int32_t lasso_host_verify_cb(lasso_host* h, lasso_host_gens* g, const lasso_strategy* st, size_t s, const lasso_fr* r, size_t r_len, const lasso_transcript_vtbl* tv, void* tu,
                              const uint8_t* proof, size_t proof_len, const uint8_t* commitment, size_t commitment_len, int32_t* ok) {

@@ -51,6 +51,7 @@ const char* lasso_last_error(lasso_ctx* c) { return c ? c->err.c_str() : ""; }
 void* lasso_stream(lasso_ctx*) { return nullptr; }
 int32_t lasso_alloc(lasso_ctx* c, size_t bytes, void** d) { REQ(c, d); *d = malloc(bytes ? bytes : 1); return *d ? 0 : LASSO_ERR_OOM; }
 int32_t lasso_free(lasso_ctx*, void* p) { free(p); return 0; }
+int32_t lasso_trim(lasso_ctx*) { return 0; }
 int32_t lasso_mem_stats(lasso_ctx*, uint64_t* live, uint64_t* peak, int32_t) { if (live) *live = 0; if (peak) *peak = 0; return 0; }   // host memory: not tracked
 int32_t lasso_upload(lasso_ctx*, void* d, const void* s, size_t n) { memcpy(d, s, n); return 0; }
 int32_t lasso_download(lasso_ctx*, void* d, const void* s, size_t n) { memcpy(d, s, n); return 0; }

@@ -23,8 +23,10 @@ def build_mock_prover(curve="curve25519"):
     srcs += [os.path.join(ROOT, "include", f) for f in ("lasso_hip.h", "lasso_prover.h")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         flags = ["-DLASSO_BN254", "-DORC_BN254"] if bn else []
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-fno-gnu-unique", "-Wl,-Bsymbolic", *flags, "-o", so,   # see oracle/Makefile
+        tmp = f"{so}.{os.getpid()}.tmp"    # several test processes (pytest -n) may find the library stale at once: each links its own file, the rename is atomic
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-fno-gnu-unique", "-Wl,-Bsymbolic", *flags, "-o", tmp,   # see oracle/Makefile
                                os.path.join(ROOT, "lasso_amd", "host", "prover_capi.cpp"), os.path.join(ROOT, "oracle", "mock_hip.cpp")])
+        os.replace(tmp, so)
     return so
 
 

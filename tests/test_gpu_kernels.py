@@ -490,6 +490,16 @@ def test_mem_stats_accounts_allocations_tables_and_peak(gens_300):
     d.bases_destroy(bases); d.free(b)
     l6, _ = stats()
     assert l6 == l0
+    # the scratch buffer grows with the largest request served and stays; lasso_trim shrinks it back
+    n = 1 << 16
+    polys = [d.upload(np.zeros((n, 4), dtype=np.uint64)) for _ in range(40)]; w = d.upload(np.zeros((n, 4), dtype=np.uint64))
+    d.multi_dot(polys, w, n)
+    for p in polys + [w]:
+        d.free(p)
+    l7, _ = stats()
+    assert d.lib.lasso_trim(d.ctx) == 0
+    l8, _ = stats()
+    assert l8 == l0 and l7 >= l8
     d.close()
 
 
