@@ -142,6 +142,13 @@ class Dev {
     void* p = nullptr;
     if (it != pool_.end()) { p = it->second; pool_.erase(it); }
     else {
+      // capacity mode: a buffer the pool cannot serve must not land ON TOP of what is parked there — parked buffers go back to the driver first, largest first, until
+      // they make up the request (live + parked bytes then do not grow past the larger of the two proofs' own needs)
+      if (capacity && bytes >= ((size_t)1 << 20)) {
+        auto fit = pool_.lower_bound(bytes);      // the smallest parked buffer that covers the request, else the largest ones until they add up
+        if (fit != pool_.end()) { (void)lasso_free(ctx, fit->second); pool_.erase(fit); }
+        else { size_t freed = 0; while (freed < bytes && !pool_.empty()) { auto big = std::prev(pool_.end()); freed += big->first; (void)lasso_free(ctx, big->second); pool_.erase(big); } }
+      }
       int32_t rc = lasso_alloc(ctx, bytes, &p);
       if (rc == LASSO_ERR_OOM && !pool_.empty()) { trim(); rc = lasso_alloc(ctx, bytes, &p); }   // the pool holds memory nobody uses: give it back before giving up
       chk(rc, "lasso_alloc");
@@ -170,6 +177,14 @@ class Dev {
   }
   // hand every pooled buffer back to the driver
   void trim() const { for (auto& kv : pool_) (void)lasso_free(ctx, kv.second); pool_.clear(); (void)lasso_trim(ctx); }   // ... and the context's grown scratch buffer
+  // the same, except up to `count` parked buffers of exactly `bytes` (what the caller is about to allocate)
+  void trim_keep(size_t bytes, size_t count) const {
+    for (auto it = pool_.begin(); it != pool_.end();) {
+      if (it->first == bytes && count) { count--; ++it; continue; }
+      (void)lasso_free(ctx, it->second); it = pool_.erase(it);
+    }
+    (void)lasso_trim(ctx);
+  }
   // device bytes held through this host's contexts now / at most (lasso_mem_stats of the main and the side context), and what the prover itself held at most
   void mem_stats(uint64_t* live, uint64_t* peak, uint64_t* in_use_peak, bool reset) const {
     uint64_t l = 0, p = 0, l2 = 0, p2 = 0;
@@ -1449,7 +1464,7 @@ class Prover {
       sp.write(W);
     }
     E_u32 = DBufU32();
-    if (d.capacity) eq.release();   // bound down to one element by the sumcheck: nothing reads it again
+    if (d.capacity) eq.reset();   // bound down to one element by the sumcheck: nothing reads it again (parked: a tree of the operations takes its place)
     W.sc(claimed_eval);
     // eval_derefs = E_i(r_z) (surge.rs:175-176)
     sp.reset(), sp.reset(new Trace("CombinedEval.prove", d.ctx));
@@ -1483,8 +1498,9 @@ class Prover {
     std::vector<DBuf> t_init, t_read, t_write, t_final;
     // capacity mode: the read / write trees without their leaf layers (half of each tree); the bottom layer's sumcheck recomputes the fingerprints (LeafLayer above)
     const bool leafless = (d.capacity || dense.compact) && s_loc >= leafless_min();   // a compact representation implies the leafless trees (same size condition)
-    if (d.capacity) { chis.release(); d.trim(); }   // the chi table is next needed after the operations' argument (re-allocated there); and what the earlier phases parked in the
-                                                    // recycling pool (the primary sumcheck's work arrays: no later buffer has their size) goes back before the peak
+    // the chi table is next needed after the operations' argument (re-allocated there); and what the earlier phases parked in the recycling pool goes back to the driver
+    // before the peak (the primary sumcheck's work arrays: no later buffer has their size) — except buffers of a tree's size, which the loop below takes
+    if (d.capacity) { chis.reset(); d.trim_keep((leafless ? s_loc : 2 * s_loc) * sizeof(lasso_fr), 2 * alpha); }
     LeafLayer leaf; leaf.gamma = g; leaf.tau = ta; leaf.n_loc = s_loc;
     for (size_t i = 0; i < alpha; i++) {
       size_t j = S.memory_to_dimension_index(i); const lasso_fr* table = tables[S.memory_to_subtable_index(i)].p;
