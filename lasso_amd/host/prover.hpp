@@ -178,12 +178,12 @@ class Dev {
   // hand every pooled buffer back to the driver
   void trim() const { for (auto& kv : pool_) (void)lasso_free(ctx, kv.second); pool_.clear(); (void)lasso_trim(ctx); }   // ... and the context's grown scratch buffer
   // the same, except up to `count` parked buffers of exactly `bytes` (what the caller is about to allocate)
+  // ... and smaller ones (they add up to little; hipFree / hipMalloc of gigabytes per proof cost more than the proof: measured 600 ms at configs[3])
   void trim_keep(size_t bytes, size_t count) const {
     for (auto it = pool_.begin(); it != pool_.end();) {
-      if (it->first == bytes && count) { count--; ++it; continue; }
+      if (it->first < bytes || (it->first == bytes && count)) { if (it->first == bytes) count--; ++it; continue; }
       (void)lasso_free(ctx, it->second); it = pool_.erase(it);
     }
-    (void)lasso_trim(ctx);
   }
   // device bytes held through this host's contexts now / at most (lasso_mem_stats of the main and the side context), and what the prover itself held at most
   void mem_stats(uint64_t* live, uint64_t* peak, uint64_t* in_use_peak, bool reset) const {
@@ -632,6 +632,7 @@ struct DensifiedRepresentation {
       }
     }
     if (D->compact) { tmp_dim.release(); tmp_read.release(); }
+    if (d.capacity) (void)lasso_trim(d.ctx);   // the sort's buffers (16 bytes per lookup of scratch) are not needed again
     return D;
   }
   SparsePolynomialCommitment commit(const SparsePolyCommitmentGens& gens) const {  // densified.rs:78-96
@@ -1454,9 +1455,11 @@ class Prover {
       // half-length work arrays (no clone, surge.rs:151); LT (every polynomial enters the combine kernel and is bound in place): a clone
       const bool no_clone = S.linear();
       const size_t wl = no_clone && s_loc >= 4 ? s_loc / 2 : s_loc;   // fewer than two local rounds: linear_rounds copies the (tiny) arrays instead
-      DBuf work(d, alpha * wl);
+      // capacity mode: in pieces of s_loc elements — the size of an operations' tree, which takes their place afterwards (no buffer of another size to return to the driver)
+      const size_t per_piece = d.capacity ? s_loc / wl : alpha, n_pieces = (alpha + per_piece - 1) / per_piece;
+      std::vector<DBuf> work; for (size_t i = 0; i < n_pieces; i++) work.emplace_back(d, d.capacity ? s_loc : alpha * wl);
       // LT: the clone of surge.rs:151 and the scaling of the LT memories are one pass (lasso_lt_prescale with a source): E itself is only read
-      std::vector<lasso_fr*> polys; for (size_t i = 0; i < alpha; i++) polys.push_back(work.p + i * wl); polys.push_back(eq.p);
+      std::vector<lasso_fr*> polys; for (size_t i = 0; i < alpha; i++) polys.push_back(work[i / per_piece].p + (i % per_piece) * wl); polys.push_back(eq.p);
       static const bool u32_off = [] { const char* e = getenv("LASSO_SUMCHECK_U32"); return e && e[0] == '0'; }();   // A/B switch
       // linear strategies: any table values; LT: only because its subtables hold bits (the integer round needs entries 0 / 1)
       std::vector<const uint32_t*> Eu32; if (P == 1 && (no_clone || table_max <= 1) && E_u32.p && !u32_off && ceil_log2(s) > 0) for (size_t i = 0; i < alpha; i++) Eu32.push_back(E_u32.p + i * s);
