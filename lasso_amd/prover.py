@@ -114,13 +114,16 @@ class HostProver:
         self._chk(self.lib.lasso_host_dense_info(dense, C.byref(b), C.byref(c)))
         return {"device_bytes": b.value, "compact": bool(c.value)}
 
-    def _bytes_call(self, fn, *args, cap=1 << 20):
+    _cap = 1 << 22      # output buffer of the byte-returning calls: a proof is 0.15 MB (C = 1) to 1.3 MB (C = 16); grows, and stays grown, if a call reports more
+
+    def _bytes_call(self, fn, *args):
         while True:
+            cap = self._cap
             buf = (C.c_uint8 * cap)()
             n = C.c_size_t()
             rc = fn(*args, buf, cap, C.byref(n))
-            if rc == -2 and n.value > cap:
-                cap = n.value
+            if rc == -2 and n.value > cap:      # the call ran to the end before it knew (a proof is proved to be measured): never pay that twice for one shape
+                self._cap = 2 * n.value
                 continue
             self._chk(rc)
             return bytes(buf[: n.value])
