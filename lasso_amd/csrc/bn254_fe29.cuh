@@ -68,9 +68,15 @@ LHD fe29 fe_x3(const fe29& a) { return fe_weak(fe_add(fe_add(a, a), a)); }   // 
 LHD pt29 pt_finish(const fe29& t0r, const fe29& t1l, const fe29& z3l, const fe29& t3l, const fe29& t4l, const fe29& y3r) {
   const fe29 t1r = fe_weak(t1l), z3r = fe_weak(z3l), t3r = fe_weak(t3l), t4r = fe_weak(t4l);
   pt29 r;
+#ifdef LASSO_BN254_SPLIT_FINISH   // round 3's form (A/B): six products, six reductions
   r.X = fe_weak(fe_sub(fe_mul(t3l, t1r), fe_mul(t4l, y3r)));
   r.Y = fe_weak(fe_add(fe_mul(t1l, z3r), fe_mul(y3r, t0r)));
   r.Z = fe_weak(fe_add(fe_mul(z3l, t4r), fe_mul(t0r, t3r)));
+#else                             // each coordinate is a sum of two products: accumulated in the 64-bit columns, ONE Montgomery reduction per coordinate (3 x 81 multiply-adds fewer)
+  r.X = m29_mul2(t3r, t1r, t4r, y3r, -1);
+  r.Y = m29_mul2(t1r, z3r, y3r, t0r, 1);
+  r.Z = m29_mul2(z3r, t4r, t0r, t3r, 1);
+#endif
   r.T = fe_zero();
   return r;
 }
@@ -131,6 +137,32 @@ LHD fe29 pt_coop_layer2(const fe29* m, uint32_t c) {   // m[0..5] = the six laye
     w.v[k] = c == 0 ? t1.v[k] : (c == 1 ? y3.v[k] : (c == 2 ? z3.v[k] : (c == 3 ? t0.v[k] : (c == 4 ? t4.v[k] : t3.v[k]))));
   }
   return fe_mul(u, fe_weak(w));
+}
+// Round 4: the linear step between the layers as its OWN lane step.  pt_coop_layer2 above has every lane form all six combinations (two 9-limb multiplications by 9, a
+// tripling, six subtractions) and pick two of them through 90 per-limb selects; here lane role c forms ONE combination f_c from at most three of the products — read at
+// role-dependent addresses, so nothing is selected per limb — and the second layer's product reads its two operands the same way:
+//   f0 = t0 = 3 m0,  f1 = t1 = m1 - 9 m2,  f2 = z3 = m1 + 9 m2,  f3 = t3 = m3 - m0 - m1,  f4 = t4 = m4 - m1 - m2,  f5 = y3 = 9 (m5 - m0 - m2)
+//   p0 = f3 f1, p1 = f4 f5, p2 = f1 f2, p3 = f5 f0, p4 = f2 f4, p5 = f0 f3      (the same integers as pt_coop_layer2 / pt_finish: same limbs out)
+// m: the six layer-1 products of the group (reduced).  Result reduced (limbs 0..7 in [0, 2^29), limb 8 small and signed), |value| < 27 (q + X).
+LHD fe29 pt_coop_form(const fe29* m, uint32_t c) {
+  // (ix, iy, iz) and the coefficients (a, b, cz) of f_c = a m[ix] + b m[iy] + cz m[iz]
+  const uint32_t ix = c == 0 ? 0u : (c <= 2 ? 1u : c);
+  const uint32_t iy = c == 0 ? 0u : (c <= 2 ? 2u : (c == 3 ? 0u : (c == 4 ? 1u : 0u)));
+  const uint32_t iz = c <= 2 ? 0u : (c == 3 ? 1u : 2u);
+  const int32_t a = c == 0 ? 3 : (c == 5 ? 9 : 1);
+  const int32_t b = c == 0 ? 0 : (c == 1 ? -9 : (c == 2 ? 9 : (c == 5 ? -9 : -1)));
+  const int32_t cz = c <= 2 ? 0 : (c == 5 ? -9 : -1);
+  const fe29 X = m[ix], Y = m[iy], Z = m[iz];
+  fe29 r; int64_t carry = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) { const int64_t x = (int64_t)a * X.v[k] + (int64_t)b * Y.v[k] + (int64_t)cz * Z.v[k] + carry; r.v[k] = (int32_t)x & FE29_MASK; carry = x >> 29; }
+  r.v[8] = (int32_t)((int64_t)a * X.v[8] + (int64_t)b * Y.v[8] + (int64_t)cz * Z.v[8] + carry);
+  return r;
+}
+LHD fe29 pt_coop_prod2(const fe29* f, uint32_t c) {   // f[0..5] = the six forms; product c of the second layer
+  const uint32_t iu = c == 0 ? 3u : (c == 1 ? 4u : (c == 2 ? 1u : (c == 3 ? 5u : (c == 4 ? 2u : 0u))));
+  const uint32_t iw = c == 0 ? 1u : (c == 1 ? 5u : (c == 2 ? 2u : (c == 3 ? 0u : (c == 4 ? 4u : 3u))));
+  return fe_mul(f[iu], f[iw]);
 }
 LHD fe29 pt_coop_out(const fe29& pe, const fe29& po, uint32_t j) {   // coordinate j (0: X, 1: Y, 2: Z) from the products 2j and 2j + 1
   fe29 r;

@@ -250,12 +250,20 @@ __device__ __forceinline__ uint32_t msm_phys_col(const MsmColMap& m, uint32_t ro
 // exchange buffer, so a level costs three product times instead of nine.  Role selection is by data (sign / coordinate index), never by branch.
 // pts[0..live) -> pts[0].  st: exchange buffer for 64 additions.  All MSM_THREADS threads must call.
 #ifdef LASSO_BN254
+#define MSM_ST_ROWS (MSM_THREADS / 2)   // two exchange buffers (products, linear forms)
+#else
+#define MSM_ST_ROWS (MSM_THREADS / 4)
+#endif
+#ifdef LASSO_BN254
 // BN254 build: the complete projective addition's twelve products form two dependent layers of six (bn254_fe29.cuh pt_coop_*), so SIX lanes share
 // one addition: 42 additions per pass of the workgroup, a tree level costs two product times (plus the linear step) instead of twelve.  The exchange
 // buffer is the Edwards build's (64 x 4 values >= 42 x 6), used twice per pass.  Same interface.
 #ifndef MSM_COOP_PLAIN_FROM
-#define MSM_COOP_PLAIN_FROM 64u   // tree levels with at least this many additions run one addition per lane (-DMSM_COOP_PLAIN_FROM=1024: the six-lane form at every level, as in round 2)
+#define MSM_COOP_PLAIN_FROM 128u   // tree levels with at least this many additions run one addition per lane (-DMSM_COOP_PLAIN_FROM=1024: the six-lane form at every level, as in round 2)
 #endif
+__device__ __forceinline__ void tree_wave_sync() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+#ifdef MSM_COOP6_V1
+// round 3's pass: 42 sextets over the workgroup, every lane forms all six linear combinations, four workgroup barriers (kept for A/B: -DMSM_COOP6_V1)
 __device__ __forceinline__ void msm_coop_tree(pt29* pts, fe29 (*st4)[4], uint32_t live, const fe29& d2_unused) {
   fe29* st = &st4[0][0];
   const uint32_t t = threadIdx.x, g = t / 6u, c = t - g * 6u;
@@ -264,9 +272,6 @@ __device__ __forceinline__ void msm_coop_tree(pt29* pts, fe29 (*st4)[4], uint32_
   uint32_t p2 = 1; while (p2 < live) p2 <<= 1;
   for (uint32_t s = p2 >> 1; s > 0; s >>= 1) {
     if (s >= MSM_COOP_PLAIN_FROM) {
-      // the two widest levels: one whole addition per lane.  42 six-lane groups need 4 passes (19 us) for 128 additions and 2 (9.6 us) for 64; 128 / 64 lanes each running the
-      // 12 products of an addition on their own take ~7 us (tools/msm_phase_bench.hip: the six-lane tree was 58 of 141 us per opening MSM).  Same group elements, other projective
-      // representatives: the wire bytes do not change
       if (t < s && t + s < live) pts[t] = pt_add(pts[t], pts[t + s], d2_unused);
       __syncthreads();
       continue;
@@ -292,6 +297,43 @@ __device__ __forceinline__ void msm_coop_tree(pt29* pts, fe29 (*st4)[4], uint32_
     }
   }
 }
+#else
+// Round 4's pass.  A sextet is six adjacent lanes of ONE wave (ten sextets per wave, lanes 60..63 idle: 40 additions per pass), so the exchanges inside a pass need the wave's
+// own LDS operations kept in order, not a workgroup barrier; the linear step between the two product layers is a lane step of its own (pt_coop_form: one combination per lane
+// instead of all six in every lane) through a second exchange buffer.  Measured (tools/msm_phase_bench.hip, BN254 build): a pass 4.8 -> see DESIGN 6.11.  Workgroup barriers
+// remain after the levels whose results the next level reads from another wave (more than 10 additions) and after the plain levels.
+__device__ __forceinline__ void msm_coop_tree(pt29* pts, fe29 (*st4)[4], uint32_t live, const fe29& d2_unused) {
+  fe29* st = &st4[0][0]; fe29* sf = st + MSM_THREADS;   // the exchange buffer is two buffers of MSM_THREADS values in this build (MSM_ST_ROWS)
+  const uint32_t t = threadIdx.x, wv = t >> 6, ln = t & 63u, q = ln / 6u, c = ln - q * 6u, g = wv * 10u + q;
+  constexpr uint32_t GROUPS = (MSM_THREADS / 64) * 10;   // 40
+  const bool lane_ok = q < 10u;
+  uint32_t p2 = 1; while (p2 < live) p2 <<= 1;
+  for (uint32_t s = p2 >> 1; s > 0; s >>= 1) {
+    if (s >= MSM_COOP_PLAIN_FROM) {
+      // the widest levels: one whole addition per lane (128 lanes running the 12 products of an addition on their own take ~7 us; four passes of sextets more).  Same group
+      // elements, other projective representatives than the sextets' only in the order of the field operations: the wire bytes do not change
+      if (t < s && t + s < live) pts[t] = pt_add(pts[t], pts[t + s], d2_unused);
+      __syncthreads();
+      continue;
+    }
+    for (uint32_t i0 = 0; i0 < s; i0 += GROUPS) {
+      const uint32_t i = i0 + g;
+      const bool act = lane_ok && i < s && i + s < live;
+      if (act) st[g * 6 + c] = pt_coop_layer1(pts[i], pts[i + s], c);
+      tree_wave_sync();
+      if (act) sf[g * 6 + c] = pt_coop_form(&st[g * 6], c);
+      tree_wave_sync();
+      if (act) st[g * 6 + c] = pt_coop_prod2(&sf[g * 6], c);
+      tree_wave_sync();
+      if (act && c < 3) {
+        const fe29 v = pt_coop_out(st[g * 6 + 2 * c], st[g * 6 + 2 * c + 1], c);
+        reinterpret_cast<fe29*>(&pts[i])[c == 2 ? 3 : c] = v;   // pt29 = {X, Y, T, Z}
+      }
+      if (s > 10u || i0 + GROUPS < s) __syncthreads(); else tree_wave_sync();   // uniform over the workgroup
+    }
+  }
+}
+#endif  // MSM_COOP6_V1
 #else
 // Barriers: a quad is four adjacent lanes of ONE wave, so the exchange between its two stages only needs the wave's own LDS operations kept in order (tree_wave_sync), not a
 // workgroup barrier; and from the level of 16 additions down every active quad AND every point it reads (written one level up by quads 0..31 -> for s <= 16 by quads 0..15)
@@ -358,7 +400,7 @@ __global__ void __launch_bounds__(64) k_precompute_tab8(const niels29* __restric
 __global__ void __launch_bounds__(MSM_THREADS) k_msm_rows8(const uint32_t* __restrict__ scal, size_t row_words, uint32_t n_cols, uint32_t cols_per_chunk, uint32_t W8,
                                                             const niels29* __restrict__ tab8_0, const niels29* __restrict__ tab8_1, size_t tn, pt29* __restrict__ out, uint32_t* digit_count) {
   __shared__ pt29 pts[MSM_THREADS];
-  __shared__ fe29 st[MSM_THREADS / 4][4];
+  __shared__ fe29 st[MSM_ST_ROWS][4];
   const fe29 d2 = fe_d2();
   const uint32_t t = threadIdx.x;
   const uint32_t* row = scal + (size_t)blockIdx.y * row_words;
@@ -515,7 +557,7 @@ __global__ void __launch_bounds__(MSM_THREADS) k_msm_direct(const uint32_t* __re
                                                              const niels29* __restrict__ mult, size_t tn, pt29* __restrict__ partial, ed_point* __restrict__ out_mont, uint32_t* counters,
                                                              uint32_t* flag, uint32_t seq, fr_t scale, fr_t tail0, fr_t tail1, uint32_t* digit_count, uint32_t sstride, uint32_t soffset) {
   __shared__ pt29 pts[MSM_THREADS];
-  __shared__ fe29 st[MSM_THREADS / 4][4];
+  __shared__ fe29 st[MSM_ST_ROWS][4];
   __shared__ uint32_t sb[MSM_DIRECT_MAX_COLS * 8];
   __shared__ uint32_t is_last;
   const uint32_t t = threadIdx.x, row = blockIdx.y, K = gridDim.x;
@@ -702,7 +744,7 @@ __global__ void __launch_bounds__(MSM_THREADS) k_bullet_msm(const fr_t* __restri
                                                              uint32_t items_per_chunk, const niels29* __restrict__ mult, size_t tn, pt29* __restrict__ partial, ed_point* __restrict__ out_mont,
                                                              uint32_t* counters, uint32_t* flag, uint32_t seq, uint32_t* digit_count, uint32_t P, uint32_t rank) {
   __shared__ pt29 pts[MSM_THREADS];   // the extra workgroup's reduction scratch (RedScratch, 29.6 KB) lives here before the tree needs it
-  __shared__ fe29 st[MSM_THREADS / 4][4];
+  __shared__ fe29 st[MSM_ST_ROWS][4];
   __shared__ uint32_t sb[MSM_DIRECT_MAX_COLS * 8];
   __shared__ uint32_t sphys[MSM_DIRECT_MAX_COLS];
   __shared__ uint32_t is_last;

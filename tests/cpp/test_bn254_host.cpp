@@ -86,6 +86,16 @@ int main() {
       for (uint32_t c = 0; c < 6; c++) pr[c] = pt_coop_layer2(m, c);
       r.X = pt_coop_out(pr[0], pr[1], 0); r.Y = pt_coop_out(pr[2], pr[3], 1); r.Z = pt_coop_out(pr[4], pr[5], 2);
       CHECK(from_ed(pt_to_ed(r)) == p.dbl());
+      // round 4's pass: the linear step as a lane step of its own (pt_coop_form), operands of the second layer read by index (pt_coop_prod2) — the same limbs as above
+      fe29 f[6], pr2[6];
+      for (uint32_t c = 0; c < 6; c++) m[c] = pt_coop_layer1(pp, pq, c);
+      for (uint32_t c = 0; c < 6; c++) pr[c] = pt_coop_layer2(m, c);
+      for (uint32_t c = 0; c < 6; c++) f[c] = pt_coop_form(m, c);
+      for (uint32_t c = 0; c < 6; c++) { for (int k = 0; k < 8; k++) CHECK(f[c].v[k] >= 0 && f[c].v[k] < (1 << 29)); CHECK(f[c].v[8] > -(1 << 28) && f[c].v[8] < (1 << 28)); }
+      for (uint32_t c = 0; c < 6; c++) pr2[c] = pt_coop_prod2(f, c);
+      for (uint32_t c = 0; c < 6; c++) CHECK(memcmp(&pr[c], &pr2[c], sizeof(fe29)) == 0);
+      pt29 r2; r2.X = pt_coop_out(pr2[0], pr2[1], 0); r2.Y = pt_coop_out(pr2[2], pr2[3], 1); r2.Z = pt_coop_out(pr2[4], pr2[5], 2); r2.T = fe_zero();
+      CHECK(from_ed(pt_to_ed(r2)) == p + q);
     }
     if (!q.is_identity()) {
       const niels29 n = to_niels(q);
@@ -108,8 +118,10 @@ int main() {
       else if (op == 2 && (i & 1)) { acc = pt_add(acc, pt_from_ed(to_ed(q, rand_fq())), dummy); ref = ref + q; }
       else if (op == 2) {
         const pt29 pq2 = pt_from_ed(to_ed(q, rand_fq())); fe29 m[6], pr[6];
+        fe29 f[6];
         for (uint32_t c = 0; c < 6; c++) m[c] = pt_coop_layer1(acc, pq2, c);
-        for (uint32_t c = 0; c < 6; c++) pr[c] = pt_coop_layer2(m, c);
+        for (uint32_t c = 0; c < 6; c++) f[c] = pt_coop_form(m, c);
+        for (uint32_t c = 0; c < 6; c++) pr[c] = pt_coop_prod2(f, c);
         acc.X = pt_coop_out(pr[0], pr[1], 0); acc.Y = pt_coop_out(pr[2], pr[3], 1); acc.Z = pt_coop_out(pr[4], pr[5], 2); ref = ref + q;
       }
       else { acc = pt_dbl(acc); ref = ref.dbl(); }
