@@ -79,6 +79,7 @@ struct lasso_bases {
   size_t n = 0; niels29* d_table = nullptr;
   lasso_ctx* owner = nullptr;                // the context its tables' bytes are accounted to (lasso_mem_stats)
   niels29* d_mult = nullptr;                 // signed digit multiples for the latency-shaped MSM (k_msm_direct), optional
+  niels29* d_mult8 = nullptr;                // signed BYTE multiples m * 256^w * G, m = 1..128 (32 windows): half the additions of the same MSMs; generator sets up to LASSO_MSM_DIRECT8_MAX_N
   niels29* d_tab8[2] = {nullptr, nullptr};   // byte multiples m * 256^w * G_j, m = 1..255, for the row-parallel commitments of small scalars (k_msm_rows8); built on first use
   bool tab8_failed = false;
   std::mutex tab8_mu;                        // the lazy build is serialised: two contexts (or host threads) sharing one bases object may reach first use together
@@ -1168,12 +1169,24 @@ int32_t lasso_bases_create(lasso_ctx* c, const lasso_affine* points, size_t n, l
       if (e != hipSuccess) { (void)dfree(c, b->d_mult); (void)dfree(c, b->d_table); delete b; return fail(c, LASSO_ERR_HIP, hipGetErrorString(e)); }
     } else { (void)hipGetLastError(); b->d_mult = nullptr; }
   }
+  // ... and their byte multiples (8x the bytes of d_mult: 459 KB per generator, 3.8 GB for the 8194 generators of the headline's widest opening; HBM is 288 GB and the
+  // generators are fixed for the life of the object).  LASSO_MSM_DIRECT8=0 turns them off, LASSO_MSM_DIRECT8_MAX_N moves the size limit; a failed allocation is not an error.
+  static const size_t direct8_max = [] { const char* off = getenv("LASSO_MSM_DIRECT8"); if (off && off[0] == '0') return (size_t)0; const char* v = getenv("LASSO_MSM_DIRECT8_MAX_N"); return v ? (size_t)atoll(v) : (((size_t)1 << 14) + 64); }();
+  if (b->d_mult && n <= direct8_max) {
+    typedef MsmD<8> D8;
+    if (dmalloc(c, (void**)&b->d_mult8, n * D8::WINDOWS * D8::MULTS * sizeof(niels29)) == hipSuccess) {
+      for (uint32_t w = 0; w < D8::WINDOWS; w++)
+        hipLaunchKernelGGL(k_precompute_tab8, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream, (const niels29*)b->d_table, n, w, b->d_mult8 + (size_t)w * D8::MULTS * n, D8::MULTS);
+      e = hipGetLastError(); if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+      if (e != hipSuccess) { (void)dfree(c, b->d_mult8); (void)dfree(c, b->d_mult); (void)dfree(c, b->d_table); delete b; return fail(c, LASSO_ERR_HIP, hipGetErrorString(e)); }
+    } else { (void)hipGetLastError(); b->d_mult8 = nullptr; }
+  }
   *out = b; return 0;
 }
 void lasso_bases_destroy(lasso_ctx* c, lasso_bases* b) {
   if (!b) return; if (c) (void)hipStreamSynchronize(c->stream);
   lasso_ctx* o = c == b->owner ? c : nullptr;   // the tables' bytes are accounted to the context that built them; a caller that passes another context (or NULL) only loses the bookkeeping
-  if (b->d_table) (void)dfree(o, b->d_table); if (b->d_mult) (void)dfree(o, b->d_mult);
+  if (b->d_table) (void)dfree(o, b->d_table); if (b->d_mult) (void)dfree(o, b->d_mult); if (b->d_mult8) (void)dfree(o, b->d_mult8);
   for (niels29* t : b->d_tab8) if (t) (void)dfree(o, t);
   delete b;
 }
@@ -1223,14 +1236,15 @@ static size_t msm_chunks(size_t rows, size_t n_cols, uint32_t W) {
 // Chunking: one workgroup per CU over all rows, whole multiples of 256 items per workgroup (every thread the same number of mixed adds),
 // at most 8192 items (128 columns of LDS-staged scalars).  Scratch after the scalars: rows * K partial points.
 static bool msm_direct_enabled() { static const bool on = [] { const char* v = getenv("LASSO_MSM_DIRECT"); return !(v && v[0] == '0'); }(); return on; }
-static size_t msm_direct_chunks(size_t rows, size_t n_cols, uint32_t* items_per_chunk) {
-  const size_t total = n_cols * MSM_WINDOWS;
+static size_t msm_direct_chunks(size_t rows, size_t n_cols, uint32_t* items_per_chunk, size_t windows = MSM_WINDOWS) {
+  const size_t total = n_cols * windows;
   // workgroups per launch: one per CU by default.  LASSO_MSM_DIRECT_WGS overrides it for tuning (more workgroups = shorter per-thread addition chains,
   // a larger cross-workgroup tree): the BN254 build's additions cost ~2.5x the Edwards ones and its balance point has not been measured yet
   static const size_t wgs = [] { const char* v = getenv("LASSO_MSM_DIRECT_WGS"); const long x = v ? atol(v) : 0; return (size_t)(x >= 1 && x <= 4096 ? x : 256); }();
   size_t K = wgs / rows; if (K < 1) K = 1;
   size_t ipc = ((total + K - 1) / K + 255) / 256 * 256;
-  if (ipc > 8192) ipc = 8192;
+  const size_t ipc_max = windows * 128;   // 128 columns of LDS-staged scalars
+  if (ipc > ipc_max) ipc = ipc_max;
   *items_per_chunk = (uint32_t)ipc;
   return (total + ipc - 1) / ipc;
 }
@@ -1243,16 +1257,23 @@ static size_t msm_pts_bytes(size_t rows, size_t n_cols) {
 // multiplied by *scale and the last two columns = tail[0], tail[1] (k_msm_direct<MODE>)
 static int32_t run_msm_direct(lasso_ctx* c, const uint8_t* d_scal, size_t row_stride, size_t rows, size_t n_cols, const MsmColMap& cm, const lasso_bases* b, uint8_t* scratch_after, lasso_point* out,
                               int mode = 0, const lasso_fr* scale = nullptr, const lasso_fr* tail = nullptr, uint32_t sstride = 1, uint32_t soffset = 0) {
-  uint32_t ipc = 0; const size_t K = msm_direct_chunks(rows, n_cols, &ipc);
+  const bool w8 = b->d_mult8 != nullptr; const size_t windows = w8 ? MsmD<8>::WINDOWS : MsmD<4>::WINDOWS;
+  uint32_t ipc = 0; const size_t K = msm_direct_chunks(rows, n_cols, &ipc, windows);
   const uint32_t seq = next_seq(c);
   {
-    ProfScope ps(c, LASSO_K_MSM_DIRECT, (double)rows * n_cols * 32, msm_ref_adds(rows, n_cols, FR_MODULUS_BITS), false, (double)rows * n_cols * MSM_WINDOWS);
+    ProfScope ps(c, LASSO_K_MSM_DIRECT, (double)rows * n_cols * 32, msm_ref_adds(rows, n_cols, FR_MODULUS_BITS), false, (double)rows * n_cols * windows);
     const fr_t z = fr_zero();
-#define LAUNCH_DIRECT(M, SC, T0, T1) hipLaunchKernelGGL(k_msm_direct<M>, dim3((unsigned)K, (unsigned)rows), dim3(MSM_THREADS), 0, c->stream, (const uint32_t*)d_scal, row_stride / 4, (uint32_t)n_cols, ipc, cm, \
-                       (const niels29*)b->d_mult, b->n, (pt29*)scratch_after, (ed_point*)c->d_small, c->d_counters + LASSO_MAX_PTRS + 8, c->d_flag, seq, SC, T0, T1, ps.counter(), sstride, soffset)
-    if (mode == 0) LAUNCH_DIRECT(0, z, z, z);
-    else if (mode == 1) LAUNCH_DIRECT(1, z, z, z);
-    else LAUNCH_DIRECT(2, to_fr(scale), to_fr(tail), to_fr(tail + 1));
+#define LAUNCH_DIRECT(M, WB_, TAB_, SC, T0, T1) hipLaunchKernelGGL((k_msm_direct<M, WB_>), dim3((unsigned)K, (unsigned)rows), dim3(MSM_THREADS), 0, c->stream, (const uint32_t*)d_scal, row_stride / 4, (uint32_t)n_cols, ipc, cm, \
+                       (const niels29*)TAB_, b->n, (pt29*)scratch_after, (ed_point*)c->d_small, c->d_counters + LASSO_MAX_PTRS + 8, c->d_flag, seq, SC, T0, T1, ps.counter(), sstride, soffset)
+    if (w8) {
+      if (mode == 0) LAUNCH_DIRECT(0, 8, b->d_mult8, z, z, z);
+      else if (mode == 1) LAUNCH_DIRECT(1, 8, b->d_mult8, z, z, z);
+      else LAUNCH_DIRECT(2, 8, b->d_mult8, to_fr(scale), to_fr(tail), to_fr(tail + 1));
+    } else {
+      if (mode == 0) LAUNCH_DIRECT(0, 4, b->d_mult, z, z, z);
+      else if (mode == 1) LAUNCH_DIRECT(1, 4, b->d_mult, z, z, z);
+      else LAUNCH_DIRECT(2, 4, b->d_mult, to_fr(scale), to_fr(tail), to_fr(tail + 1));
+    }
   }
   HIPCHK(c, hipGetLastError());
   return wait_flag(c, seq, rows * (sizeof(ed_point) / sizeof(fr_t)), (lasso_fr*)out);
@@ -1424,21 +1445,21 @@ static int32_t bullet_round_fused(lasso_ctx* c, const lasso_bases* b, size_t n, 
   // chunks per row: (workgroups of the launch - 2 extra) / 2 rows, items shared out evenly (a multiple of 64 keeps whole columns together where it can)
   static const size_t wgs = [] { const char* v = getenv("LASSO_MSM_DIRECT_WGS"); const long x = v ? atol(v) : 0; return (size_t)(x >= 4 && x <= 4096 ? x : 256); }();
   const size_t n_loc = n / world, cols = (nk / 2 >= world) ? n_loc / 2 : n_loc;   // the longest row's local columns
-  const size_t total = cols * MSM_WINDOWS, kmax = (wgs - 2) / 2;
-  size_t ipc_ = (total + kmax - 1) / kmax; ipc_ = (ipc_ + 63) / 64 * 64; if (ipc_ < 256) ipc_ = 256; if (ipc_ > 8192) ipc_ = 8192;
+  const bool w8 = b->d_mult8 != nullptr; const size_t windows = w8 ? MsmD<8>::WINDOWS : MsmD<4>::WINDOWS;
+  const size_t total = cols * windows, kmax = (wgs - 2) / 2;
+  size_t ipc_ = (total + kmax - 1) / kmax; ipc_ = (ipc_ + windows - 1) / windows * windows; if (ipc_ < 256) ipc_ = 256; if (ipc_ > windows * 128) ipc_ = windows * 128;
   const uint32_t ipc = (uint32_t)ipc_; const size_t K = (total + ipc_ - 1) / ipc_;
   int32_t rc = ensure_scratch(c, 2 * (K + 1) * sizeof(pt29) + 512); if (rc) return rc;
   const uint32_t seq = next_seq(c);
   {
     const size_t row = n_loc / 2 + 2;
-    ProfScope ps(c, LASSO_K_MSM_DIRECT, 2.0 * row * 32 + (fold ? 96.0 * 2 * nk : 64.0 * nk), msm_ref_adds(2, row, FR_MODULUS_BITS), false, 2.0 * row * MSM_WINDOWS);
+    ProfScope ps(c, LASSO_K_MSM_DIRECT, 2.0 * row * 32 + (fold ? 96.0 * 2 * nk : 64.0 * nk), msm_ref_adds(2, row, FR_MODULUS_BITS), false, 2.0 * row * windows);
     const fr_t z = fr_zero();
-    if (fold) hipLaunchKernelGGL((k_bullet_msm<true>), dim3((unsigned)K + 1, 2), dim3(MSM_THREADS), 0, c->stream, (const fr_t*)d_a_in, (const fr_t*)d_b_in, (const fr_t*)d_w_in, (fr_t*)d_a_out, (fr_t*)d_b_out,
-                                 (fr_t*)d_w_out, (uint32_t)nk, (uint32_t)n, to_fr(u), to_fr(u_inv), to_fr(blinds), to_fr(blinds + 1), ipc, (const niels29*)b->d_mult, b->n, (pt29*)c->d_scratch,
-                                 (ed_point*)c->d_small, c->d_counters + LASSO_MAX_PTRS + 8, c->d_flag, seq, ps.counter(), world, rank);
-    else hipLaunchKernelGGL((k_bullet_msm<false>), dim3((unsigned)K + 1, 2), dim3(MSM_THREADS), 0, c->stream, (const fr_t*)d_a_in, (const fr_t*)d_b_in, (const fr_t*)d_w_in, (fr_t*)nullptr, (fr_t*)nullptr,
-                            (fr_t*)nullptr, (uint32_t)nk, (uint32_t)n, z, z, to_fr(blinds), to_fr(blinds + 1), ipc, (const niels29*)b->d_mult, b->n, (pt29*)c->d_scratch,
-                            (ed_point*)c->d_small, c->d_counters + LASSO_MAX_PTRS + 8, c->d_flag, seq, ps.counter(), world, rank);
+#define LAUNCH_BULLET(FOLD_, WB_, TAB_, AO, BO, WO, U, UI) hipLaunchKernelGGL((k_bullet_msm<FOLD_, WB_>), dim3((unsigned)K + 1, 2), dim3(MSM_THREADS), 0, c->stream, (const fr_t*)d_a_in, (const fr_t*)d_b_in, (const fr_t*)d_w_in, \
+                                 (fr_t*)AO, (fr_t*)BO, (fr_t*)WO, (uint32_t)nk, (uint32_t)n, U, UI, to_fr(blinds), to_fr(blinds + 1), ipc, (const niels29*)TAB_, b->n, (pt29*)c->d_scratch, \
+                                 (ed_point*)c->d_small, c->d_counters + LASSO_MAX_PTRS + 8, c->d_flag, seq, ps.counter(), world, rank)
+    if (fold) { if (w8) LAUNCH_BULLET(true, 8, b->d_mult8, d_a_out, d_b_out, d_w_out, to_fr(u), to_fr(u_inv)); else LAUNCH_BULLET(true, 4, b->d_mult, d_a_out, d_b_out, d_w_out, to_fr(u), to_fr(u_inv)); }
+    else { if (w8) LAUNCH_BULLET(false, 8, b->d_mult8, nullptr, nullptr, nullptr, z, z); else LAUNCH_BULLET(false, 4, b->d_mult, nullptr, nullptr, nullptr, z, z); }
   }
   HIPCHK(c, hipGetLastError());
   return wait_flag(c, seq, 2 * (sizeof(ed_point) / sizeof(fr_t)), (lasso_fr*)out);

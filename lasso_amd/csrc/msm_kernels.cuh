@@ -376,16 +376,17 @@ __device__ __forceinline__ void msm_coop_tree(pt29* pts, fe29 (*st)[4], uint32_t
 // tab8[(m-1)*n + j] = m * B_j with B_j = table[(2*w8)*n + j] = 256^w8 * G_j.  One thread per generator; multiples by repeated mixed addition, brought to
 // affine Niels form in runs of 16 that share one inversion (Montgomery's trick).
 #define MSM8_MULTS 255
-__global__ void __launch_bounds__(64) k_precompute_tab8(const niels29* __restrict__ table, size_t n, uint32_t w8, niels29* __restrict__ tab8) {
+// nm: multiples per generator (255 for the commitments' unsigned bytes; 128 for the signed bytes of the latency-shaped MSMs, mult8)
+__global__ void __launch_bounds__(64) k_precompute_tab8(const niels29* __restrict__ table, size_t n, uint32_t w8, niels29* __restrict__ tab8, uint32_t nm = MSM8_MULTS) {
   const size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (j >= n) return;
   const niels29 b = table[(size_t)(2 * w8) * n + j];
   const fe29 d2 = fe_d2();
   tab8[j] = b;
   pt29 P = pt_madd(pt_identity(), b);
-  for (uint32_t m0 = 2; m0 <= MSM8_MULTS; m0 += 16) {
+  for (uint32_t m0 = 2; m0 <= nm; m0 += 16) {
     pt29 q[16]; fe29 pre[16];
-    const uint32_t cnt = MSM8_MULTS + 1 - m0 < 16 ? MSM8_MULTS + 1 - m0 : 16;
+    const uint32_t cnt = nm + 1 - m0 < 16 ? nm + 1 - m0 : 16;
     for (uint32_t c = 0; c < cnt; c++) { P = pt_madd(P, b); q[c] = P; pre[c] = c ? fe_mul(pre[c - 1], P.Z) : P.Z; }
     fe29 inv = fe_inv_chain(pre[cnt - 1]);
     for (uint32_t c = cnt; c-- > 0;) {
@@ -466,26 +467,35 @@ __global__ void __launch_bounds__(MSM_THREADS) k_msm_rows8w(const uint32_t* __re
 }
 
 #define MSM_DIRECT_MAX_COLS 160   // columns a workgroup may touch (items_per_chunk <= 64 * (MSM_DIRECT_MAX_COLS - 1))
-// signed-digit recoding of one canonical scalar into LDS: e = s + 0x88..8 (nibble e_w - 8 in [-8, 7] is digit w)
+// Window width of the digit-multiple table a latency-shaped launch reads: WB = 4 (mult: m * 16^w * G, m = 1..8, 64 windows — every generator set has it) or WB = 8
+// (mult8: m * 256^w * G, m = 1..128, 32 windows — 8x the bytes, half the mixed additions per scalar; generator sets up to LASSO_MSM_DIRECT8_MAX_N).
+template <int WB> struct MsmD {
+  static constexpr uint32_t WINDOWS = 256u / WB, LOGW = WB == 4 ? 6u : 5u, MULTS = 1u << (WB - 1), DMASK = (1u << WB) - 1u, PER_WORD = 32u / WB;
+  static constexpr uint32_t BIAS = WB == 4 ? 0x88888888u : 0x80808080u;
+};
+// signed-digit recoding of one canonical scalar into LDS: e = s + 0x88..8 (0x8080..80): digit w = (field w of e) - 2^(WB-1), in [-2^(WB-1), 2^(WB-1) - 1]; s < 2^254, so the top field cannot overflow
+template <int WB>
 __device__ __forceinline__ void msm_recode(const uint32_t* s, uint32_t* dst) {
   uint64_t carry = 0;
 #pragma unroll
-  for (int k = 0; k < 8; k++) { const uint64_t x = (uint64_t)s[k] + 0x88888888ull + carry; dst[k] = (uint32_t)x; carry = x >> 32; }
+  for (int k = 0; k < 8; k++) { const uint64_t x = (uint64_t)s[k] + MsmD<WB>::BIAS + carry; dst[k] = (uint32_t)x; carry = x >> 32; }
 }
 // items [it0, it1) of a row (one item = one (column, window); sb holds the recoded scalars of columns col0..): one mixed addition per non-zero digit
 // phys (optional, LDS): table index of every staged column (phys[c - col0]); otherwise the column map decides
+template <int WB>
 __device__ __forceinline__ pt29 msm_direct_accumulate(const uint32_t* sb, uint32_t col0, uint32_t it0, uint32_t it1, const MsmColMap& cm, uint32_t row, const niels29* __restrict__ mult, size_t tn,
                                                       uint32_t* digit_count = nullptr, const uint32_t* phys = nullptr) {
+  typedef MsmD<WB> D;
   const uint32_t t = threadIdx.x;
   pt29 B = pt_identity();
   niels29 cur; bool have = false; uint32_t nadds = 0;
   for (uint32_t base = it0; base < it1; base += MSM_THREADS) {
     const uint32_t it = base + t;
     bool valid = it < it1; int32_t d = 0; uint32_t c = 0, w = 0;
-    if (valid) { c = it >> 6; w = it & 63u; d = (int32_t)((sb[(c - col0) * 8 + (w >> 3)] >> (4 * (w & 7u))) & 15u) - 8; valid = d != 0; }
+    if (valid) { c = it >> D::LOGW; w = it & (D::WINDOWS - 1u); d = (int32_t)((sb[(c - col0) * 8 + w / D::PER_WORD] >> (WB * (w % D::PER_WORD))) & D::DMASK) - (int32_t)D::MULTS; valid = d != 0; }
     // the fetch is unconditional (entry 0 for a skipped item) so that it is issued BEFORE the mixed add below and waited for after it
     const uint32_t m = d < 0 ? (uint32_t)(-d) : (uint32_t)d;
-    const size_t idx = valid ? ((size_t)w * MSM_MULTS + (m - 1)) * tn + (phys ? phys[c - col0] : msm_phys_col(cm, row, c)) : 0;
+    const size_t idx = valid ? ((size_t)w * D::MULTS + (m - 1)) * tn + (phys ? phys[c - col0] : msm_phys_col(cm, row, c)) : 0;
     const niels29 nxt = mult[idx];
     if (have) B = pt_madd(B, cur);
     const bool neg = d < 0;
@@ -552,7 +562,7 @@ __device__ __forceinline__ void msm_direct_finish(pt29* pts, fe29 (*st)[4], uint
 // k_fr_to_canonical pass in front of the opening's Cx = <x, G> saved.  MODE 2: as 1, but columns below n_cols - 2 are multiplied by `scale` first and the
 // last two columns are the scalars tail0, tail1 (delta = d * g_hat + r_delta * h over the resident fold weights, dot_product.rs:219-224).
 // sstride / soffset: column j takes scalar j * sstride + soffset (1, 0 = plain; world, rank = slab mode's share of a whole vector).
-template <int MODE>
+template <int MODE, int WB>
 __global__ void __launch_bounds__(MSM_THREADS) k_msm_direct(const uint32_t* __restrict__ scal, size_t row_words, uint32_t n_cols, uint32_t items_per_chunk, MsmColMap cm,
                                                              const niels29* __restrict__ mult, size_t tn, pt29* __restrict__ partial, ed_point* __restrict__ out_mont, uint32_t* counters,
                                                              uint32_t* flag, uint32_t seq, fr_t scale, fr_t tail0, fr_t tail1, uint32_t* digit_count, uint32_t sstride, uint32_t soffset) {
@@ -561,15 +571,15 @@ __global__ void __launch_bounds__(MSM_THREADS) k_msm_direct(const uint32_t* __re
   __shared__ uint32_t sb[MSM_DIRECT_MAX_COLS * 8];
   __shared__ uint32_t is_last;
   const uint32_t t = threadIdx.x, row = blockIdx.y, K = gridDim.x;
-  const uint32_t total = n_cols * MSM_WINDOWS;
+  const uint32_t total = n_cols * MsmD<WB>::WINDOWS;
   const uint32_t it0 = blockIdx.x * items_per_chunk;
   uint32_t it1 = it0 + items_per_chunk; if (it1 > total) it1 = total;
-  const uint32_t col0 = it0 >> 6, col1 = (it1 + 63) >> 6;
+  const uint32_t col0 = it0 >> MsmD<WB>::LOGW, col1 = (it1 + MsmD<WB>::WINDOWS - 1u) >> MsmD<WB>::LOGW;
   MSM_STAMP(0);
   for (uint32_t c = t; c < col1 - col0; c += MSM_THREADS) {
     // column j reads scalar j * sstride + soffset (slab mode: this rank's generators are every P-th one, the scalar vector is the whole one)
     const uint32_t* s = scal + (size_t)row * row_words + ((size_t)(col0 + c) * sstride + soffset) * 8;
-    if (MODE == 0) msm_recode(s, &sb[c * 8]);
+    if (MODE == 0) msm_recode<WB>(s, &sb[c * 8]);
     else {
       fr_t v;
       if (MODE == 2 && col0 + c + 2 >= n_cols) v = fr29_to_integer(fr29_unpack_u(col0 + c + 2 == n_cols ? tail0 : tail1));
@@ -580,12 +590,12 @@ __global__ void __launch_bounds__(MSM_THREADS) k_msm_direct(const uint32_t* __re
         fr29 k32 = fr29_zero(); k32.v[0] = 32;
         v = MODE == 2 ? fr29_store(fr29_mul(fr29_mul(fr29_unpack_u(x), fr29_unpack_s(scale)), k32)) : fr29_to_integer(fr29_unpack_u(x));
       }
-      msm_recode(v.v, &sb[c * 8]);
+      msm_recode<WB>(v.v, &sb[c * 8]);
     }
   }
   __syncthreads();
   MSM_STAMP(1);
-  const pt29 B = msm_direct_accumulate(sb, col0, it0, it1, cm, row, mult, tn, digit_count);
+  const pt29 B = msm_direct_accumulate<WB>(sb, col0, it0, it1, cm, row, mult, tn, digit_count);
   MSM_STAMP(2);
   msm_direct_finish(pts, st, &is_last, B, K, row, partial, out_mont, counters, flag, seq);
 }
@@ -738,7 +748,7 @@ __global__ void __launch_bounds__(256) k_bullet_step(const fr_t* __restrict__ a_
 // Which of a rank's generators feed which row: generator j = blk * nk + pos belongs to L if pos >= half (scalar w_blk a'_L[pos - half]), to R otherwise
 // (w_blk a'_R[pos]).  While half >= P the low bits of pos are the rank, both rows get n / (2 P) local columns and the local picture is the global one with nk / P,
 // half / P; in the last log2 P rounds (half < P) pos = rank mod nk is fixed, so ALL n / P of the rank's generators feed one row and none the other.
-template <bool FOLD>
+template <bool FOLD, int WB>
 __global__ void __launch_bounds__(MSM_THREADS) k_bullet_msm(const fr_t* __restrict__ a_in, const fr_t* __restrict__ b_in, const fr_t* __restrict__ w_in, fr_t* __restrict__ a_out,
                                                              fr_t* __restrict__ b_out, fr_t* __restrict__ w_out, uint32_t nk, uint32_t n, fr_t u, fr_t u_inv, fr_t blind_l, fr_t blind_r,
                                                              uint32_t items_per_chunk, const niels29* __restrict__ mult, size_t tn, pt29* __restrict__ partial, ed_point* __restrict__ out_mont,
@@ -758,10 +768,10 @@ __global__ void __launch_bounds__(MSM_THREADS) k_bullet_msm(const fr_t* __restri
     const bool wide = half >= P;                       // always when P == 1
     const uint32_t hl = wide ? half / P : 1u, pos0 = rank & (nk - 1u);
     const uint32_t ncols = wide ? n_loc / 2 : (((pos0 >= half) == (row == 0)) ? n_loc : 0u);   // this row's local columns
-    const uint32_t total = ncols * MSM_WINDOWS;
+    const uint32_t total = ncols * MsmD<WB>::WINDOWS;
     uint32_t it0 = (blockIdx.x - 1) * items_per_chunk; if (it0 > total) it0 = total;
     uint32_t it1 = it0 + items_per_chunk; if (it1 > total) it1 = total;
-    const uint32_t col0 = it0 >> 6, col1 = (it1 + 63) >> 6;
+    const uint32_t col0 = it0 >> MsmD<WB>::LOGW, col1 = (it1 + MsmD<WB>::WINDOWS - 1u) >> MsmD<WB>::LOGW;
     for (uint32_t c = t; c < col1 - col0; c += MSM_THREADS) {
       const uint32_t g = col0 + c;
       uint32_t blk, i, jl;   // fold-weight block, index into a'_L / a'_R, index into the (local) generator table
@@ -776,12 +786,12 @@ __global__ void __launch_bounds__(MSM_THREADS) k_bullet_msm(const fr_t* __restri
       } else { av = fr29_unpack_u(a_in[ia]); wv = fr29_unpack_u(w_in[blk]); }
       // mul(u, u) = wv * a * 2^251; one more Montgomery step with the integer 2^10 gives the canonical integer wv * a
       const fr_t s = fr29_store(fr29_mul(fr29_mul(wv, av), fr29_int_from_uu()));
-      msm_recode(s.v, &sb[c * 8]);
+      msm_recode<WB>(s.v, &sb[c * 8]);
       sphys[c] = jl;
     }
     __syncthreads();
     const MsmColMap id = {0, 0, 0, 0};
-    B = msm_direct_accumulate(sb, col0, it0, it1, id, row, mult, tn, digit_count, sphys);
+    B = msm_direct_accumulate<WB>(sb, col0, it0, it1, id, row, mult, tn, digit_count, sphys);
   } else {
     RedScratch& S = *reinterpret_cast<RedScratch*>(pts);
     fr29 acc[3] = {fr29_zero(), fr29_zero(), fr29_zero()}; uint32_t cnt = 0;
@@ -806,12 +816,12 @@ __global__ void __launch_bounds__(MSM_THREADS) k_bullet_msm(const fr_t* __restri
       for (int k = 0; k < 9; k++) c[k] = S.cols[k];
       const fr_t ci = fr29_store(fr29_mul(fr29_from_columns(c), fr29_int_from_uu()));   // sum of (u*u) products -> canonical integer
       const fr_t bi = fr29_to_integer(fr29_unpack_u(row ? blind_r : blind_l));
-      msm_recode(ci.v, &sb[0]); msm_recode(bi.v, &sb[8]);
+      msm_recode<WB>(ci.v, &sb[0]); msm_recode<WB>(bi.v, &sb[8]);
     }
     __syncthreads();   // S (aliasing pts) is dead from here on
     const MsmColMap id = {0, 0, 0, 0};
     // columns n_loc (Q) and n_loc + 1 (H) of the table; in slab mode rank 0 alone adds them
-    B = msm_direct_accumulate(sb, 0, 0, rank == 0 ? 2 * MSM_WINDOWS : 0u, id, row, mult + n_loc, tn, digit_count);
+    B = msm_direct_accumulate<WB>(sb, 0, 0, rank == 0 ? 2 * MsmD<WB>::WINDOWS : 0u, id, row, mult + n_loc, tn, digit_count);
   }
   msm_direct_finish(pts, st, &is_last, B, K + 1, row, partial, out_mont, counters, flag, seq);
 }

@@ -140,6 +140,8 @@ print("DIGEST", hashlib.sha256(comm + proof).hexdigest())
 @pytest.mark.parametrize("env", [{"LASSO_TAGGED_RESULTS": "0"}, {"LASSO_DIRECT_NX": "0"}, {"LASSO_TAGGED_RESULTS": "0", "LASSO_CUBIC_TAIL": "0", "LASSO_LINEAR_TAIL": "0"},
                                  {"LASSO_EQ_INLINE": "0", "LASSO_SUMCHECK_U32": "0", "LASSO_MSM_FUSED": "0"}, {"LASSO_TAIL_Q": "256", "LASSO_LB_PIPELINE": "0"},
                                  {"LASSO_SEQ_START": "0xffefff9c"},     # the context's hand-off sequence numbers start 100 short of the end of an epoch: the proof crosses next_seq's restart
+                                 {"LASSO_MSM_DIRECT8": "0"},                 # the openings' MSMs over the 4-bit digit-multiple tables instead of the byte-multiple ones
+                                 {"LASSO_MSM_DIRECT8": "0", "LASSO_MSM_FUSED": "0"},
                                  {"LASSO_CAPACITY": "1", "LASSO_LEAFLESS_MIN": "1024"},      # capacity mode: leafless trees, the bottom layer's two streaming rounds from recomputed leaves (8 chunks)
                                  {"LASSO_CAPACITY": "1", "LASSO_LEAFLESS_MIN": "1024", "LASSO_CUBIC_TAIL": "0", "LASSO_EQ_INLINE": "0"}])
 def test_gpu_ab_switches_do_not_change_the_bytes(host, env):

@@ -3,6 +3,9 @@
 // (the L / R rows of bullet.rs:98-121 over the original generators).  Arithmetic is data-independent, so the table holds arbitrary limbs.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/msm_phase_bench tools/msm_phase_bench.hip
 #define MSM_PHASE_CLOCK 1
+#ifndef MSM_BENCH_WB
+#define MSM_BENCH_WB 4   // -DMSM_BENCH_WB=8: the byte-multiple table (32 windows x 128 multiples)
+#endif
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -52,20 +55,20 @@ int main(int argc, char** argv) {
     const size_t row = n / 2 + 2, tn = n + 2;
     std::vector<uint64_t> sc(rows * row * 4);
     for (size_t i = 0; i < sc.size(); i += 4) { for (int k = 0; k < 4; k++) sc[i + k] = splitmix(); sc[i + 3] &= 0x0fffffffffffffffull; }
-    std::vector<uint32_t> tab(tn * W * MSM_MULTS * sizeof(niels29) / 4);
+    std::vector<uint32_t> tab(tn * (size_t)MsmD<MSM_BENCH_WB>::WINDOWS * MsmD<MSM_BENCH_WB>::MULTS * sizeof(niels29) / 4);
     for (auto& x : tab) x = (uint32_t)splitmix() & 0x0fffffff;
     uint32_t* d_sc; niels29* d_tab; pt29* d_part; ed_point* d_out; uint32_t* d_cnt;
     CK(hipMalloc(&d_sc, sc.size() * 8)); CK(hipMalloc(&d_tab, tab.size() * 4)); CK(hipMalloc(&d_part, rows * 4096 * sizeof(pt29))); CK(hipMalloc(&d_out, rows * sizeof(ed_point))); CK(hipMalloc(&d_cnt, 256)); CK(hipMemset(d_cnt, 0, 256));
     CK(hipMemcpy(d_sc, sc.data(), sc.size() * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(d_tab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
     const MsmColMap cm = {(uint32_t)n, (uint32_t)(n / 2), (uint32_t)(n / 2), (uint32_t)n};
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    const uint32_t total = (uint32_t)(row * W);
+    const uint32_t total = (uint32_t)(row * MsmD<MSM_BENCH_WB>::WINDOWS);
     for (uint32_t ipc : {256u, 512u, 768u, 1024u, 1280u, 2048u}) {
       const uint32_t K = (total + ipc - 1) / ipc;
       float best = 1e9f; uint64_t clk[32] = {0};
       for (int it = 0; it < 8; it++) {
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL(k_msm_direct<0>, dim3(K, (unsigned)rows), dim3(MSM_THREADS), 0, 0, (const uint32_t*)d_sc, row * 8, (uint32_t)row, ipc, cm, (const niels29*)d_tab, tn, d_part, d_out, d_cnt, (uint32_t*)nullptr, 0u, fr_zero(), fr_zero(), fr_zero(), (uint32_t*)nullptr, 1u, 0u);
+        hipLaunchKernelGGL((k_msm_direct<0, MSM_BENCH_WB>), dim3(K, (unsigned)rows), dim3(MSM_THREADS), 0, 0, (const uint32_t*)d_sc, row * 8, (uint32_t)row, ipc, cm, (const niels29*)d_tab, tn, d_part, d_out, d_cnt, (uint32_t*)nullptr, 0u, fr_zero(), fr_zero(), fr_zero(), (uint32_t*)nullptr, 1u, 0u);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float a; CK(hipEventElapsedTime(&a, e0, e1));
         if (it && a < best) { best = a; CK(hipMemcpyFromSymbol(clk, HIP_SYMBOL(msm_phase_clock), sizeof(clk))); }
