@@ -352,14 +352,17 @@ def slab_units(kind, c, capacity=False):
 
 
 def slab_bytes_per_rank(kind, c, log_s, world, log_m=16, capacity=False):
-    """slab_units x (s / P) x 32 bytes + the constant term: the generator tables (per generator 64 window entries + 512 digit multiples of 112 bytes; the rank's residue class
+    """slab_units x (s / P) x 32 bytes + the constant term: the generator tables (per generator 64 window entries + 512 digit multiples of 112 bytes, + 4096 byte multiples for sets of at most 2^14 generators; the rank's residue class
     again as its slab table; 2 x 255 byte multiples for the commitments' table, of the rank's class only when P > 1) over the three Hyrax widths, and ~1.5 GB of scratch.
     Checked against lasso_mem_stats at configs[3], P = 1, 2, 4, 8 (profiles/r04_slab_peak_bytes.json)."""
     alpha = 2 * c if kind == "lt" else c
     p2 = lambda x: 1 << (x - 1).bit_length()
     width = lambda n_elems: 1 << ((n_elems.bit_length() - 1) - (n_elems.bit_length() - 1) // 2)      # R = 2^(nv - nv / 2), eq_poly.rs:40-42
     r_l, r_e, r_m = width(p2(2 * c) << log_s), width(p2(alpha) << log_s), width(p2(c) << log_m)
-    fixed = 576 * 112 * (r_l + r_e + r_m) * (1 + (1.0 / world if world > 1 else 0)) + 2 * 255 * 112 * (r_l + r_e) / world + 1.5e9
+    # per generator: 64 window entries + 512 digit multiples, and 4096 byte multiples for sets of up to 2^14 generators (the openings' MSMs, lasso_bases_create_opt) — for the
+    # set the openings read (the full one on one GPU, the rank's residue class in slab mode), not in capacity mode
+    ent = lambda n_gens, bytes_too: (576 + (4096 if bytes_too and not capacity and n_gens <= (1 << 14) + 64 else 0)) * n_gens
+    fixed = 112 * sum(ent(rr + 2, world == 1) + (ent(rr // world + 2, True) if world > 1 else 0) for rr in (r_l, r_e, r_m)) + 2 * 255 * 112 * (r_l + r_e) / world + 1.5e9
     return slab_units(kind, c, capacity) * ((1 << log_s) / world) * 32 + fixed
 
 
@@ -409,8 +412,9 @@ def slab_worker(a):
         # the same proof once more in capacity mode (lasso_host_set_capacity: product trees without their leaf layers): what a rank holds at most, and what it costs
         try:
             # the representation is densified again under the mode (dim / read then stay 4-byte integers: DensifiedRepresentation::compact)
-            hp.free(dense=dense); dense = None
+            hp.free(dense, gens); dense = gens = None     # the generator sets too: under the mode they come without the openings' byte-multiple tables
             hp.set_capacity(True); hp.mem_stats(reset=True)
+            gens = hp.gens(c, s, alpha, log_m)
             idx = hp.gen_indices(s, 1 << log_m, c); dense = hp.densify(idx, log_m); del idx
             comm2 = hp.commit(dense, gens)
             p2 = hp.prove(dense, gens, S, r)      # warm-up of the capacity path
@@ -419,7 +423,7 @@ def slab_worker(a):
             out["capacity_mode"] = {"ms_per_proof": el2 * 1e3, "peak_bytes_per_rank": m2["peak_bytes"], "prover_peak_bytes_per_rank": m2["prover_peak_bytes"],
                                     "model_bytes_per_rank": int(slab_bytes_per_rank(kind, c, log_s, world, log_m, True)), "same_bytes_as_pooled": p2 == proof and comm2 == comm,
                                     "compact_dim_read": hp.dense_info(dense)["compact"],
-                                    "note": "densify + commit + two proofs under lasso_host_set_capacity (the high-water mark was reset after the pooled proofs; the generator tables stay)"}
+                                    "note": "generator sets + densify + commit + two proofs under lasso_host_set_capacity (the high-water mark was reset after the pooled proofs)"}
         except Exception as e:
             out["capacity_mode"] = {"error": repr(e)[:300]}
     hp.free(dense, gens); hp.close()

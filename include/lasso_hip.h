@@ -304,6 +304,12 @@ int32_t lasso_densify_dim_slab(lasso_ctx* ctx, const uint64_t* d_indices, size_t
 /* Upload a generator vector once (MultiCommitGens: G[0..n) then any extra points such as gens_1.G[0] and h) and
  * precompute the per-window multiples used by both MSM entry points. */
 int32_t lasso_bases_create(lasso_ctx* ctx, const lasso_affine* points, size_t n, lasso_bases** out);
+/* Tables a generator set holds (bytes per generator): the window table 16^w G (64 x 112 = 7 KB: the commitments' bucket MSM), the signed digit multiples m 16^w G, m = 1..8
+ * (57 KB: the openings' latency-shaped MSMs), byte multiples of the low windows on demand (the commitments of small scalars), and — for sets of at most 2^14 + 64 generators —
+ * the signed BYTE multiples m 256^w G, m = 1..128 (459 KB: the same openings with half the additions per scalar).  byte_multiples = 0 leaves the last ones out (a caller
+ * that wants the bytes more than the time: slab mode's unused full-width set, capacity mode); lasso_bases_create = byte_multiples 1.  LASSO_MSM_DIRECT8=0 in the
+ * environment leaves them out everywhere. */
+int32_t lasso_bases_create_opt(lasso_ctx* ctx, const lasso_affine* points, size_t n, int32_t byte_multiples, lasso_bases** out);
 /* Device memory per bases object: the window table 64 * n * 112 B; for n <= 2^17 the digit-multiple table of the latency-shaped MSMs, 8x that (57 KB per generator); and, built by the
  * first commitment of small scalars that uses the object (serialised by a mutex inside the object; ~3 ms, waited for), one byte-multiple table of 255 * n * 112 B per byte window
  * (117 MB for n = 4096; at most two windows). */

@@ -84,6 +84,7 @@ def declare(lib):
         "lasso_densify_dim": (i32, [vp, vp, sz, sz, sz, sz, u32, vp, vp, vp, vp]),
         "lasso_matvec_left": (i32, [vp, vp, vp, sz, sz, vp]),
         "lasso_bases_create": (i32, [vp, vp, sz, P(vp)]),
+        "lasso_bases_create_opt": (i32, [vp, vp, sz, i32, P(vp)]),
         "lasso_bases_destroy": (None, [vp, vp]),
         "lasso_hyrax_commit": (i32, [vp, vp, sz, sz, vp, vp]),
         "lasso_hyrax_commit_compressed": (i32, [vp, vp, sz, sz, vp, vp]),

@@ -1147,7 +1147,8 @@ int32_t lasso_densify_dim_slab(lasso_ctx* c, const uint64_t* d_indices, size_t n
 }
 
 // ------------------------------------------------------------------ curve entry points
-int32_t lasso_bases_create(lasso_ctx* c, const lasso_affine* points, size_t n, lasso_bases** out) {
+int32_t lasso_bases_create(lasso_ctx* c, const lasso_affine* points, size_t n, lasso_bases** out) { return lasso_bases_create_opt(c, points, n, 1, out); }
+int32_t lasso_bases_create_opt(lasso_ctx* c, const lasso_affine* points, size_t n, int32_t byte_multiples, lasso_bases** out) {
   REQUIRE(c, points && out && n >= 1 && n * MSM_WINDOWS < ((size_t)1 << 32));
   lasso_bases* b = new lasso_bases(); b->n = n; b->owner = c;
   void* d_aff = nullptr;
@@ -1172,7 +1173,7 @@ int32_t lasso_bases_create(lasso_ctx* c, const lasso_affine* points, size_t n, l
   // ... and their byte multiples (8x the bytes of d_mult: 459 KB per generator, 3.8 GB for the 8194 generators of the headline's widest opening; HBM is 288 GB and the
   // generators are fixed for the life of the object).  LASSO_MSM_DIRECT8=0 turns them off, LASSO_MSM_DIRECT8_MAX_N moves the size limit; a failed allocation is not an error.
   static const size_t direct8_max = [] { const char* off = getenv("LASSO_MSM_DIRECT8"); if (off && off[0] == '0') return (size_t)0; const char* v = getenv("LASSO_MSM_DIRECT8_MAX_N"); return v ? (size_t)atoll(v) : (((size_t)1 << 14) + 64); }();
-  if (b->d_mult && n <= direct8_max) {
+  if (b->d_mult && byte_multiples && n <= direct8_max) {
     typedef MsmD<8> D8;
     if (dmalloc(c, (void**)&b->d_mult8, n * D8::WINDOWS * D8::MULTS * sizeof(niels29)) == hipSuccess) {
       for (uint32_t w = 0; w < D8::WINDOWS; w++)

@@ -373,14 +373,16 @@ struct PolyCommitmentGens {
       fq_t x = fq_to_mont(fq_mul(gs.pts[i].p.X, zi)), y = fq_to_mont(fq_mul(gs.pts[i].p.Y, zi));
       memcpy(affine[i].x, x.v, 32); memcpy(affine[i].y, y.v, 32);
     }
-    d.chk(lasso_bases_create(d.ctx, affine.data(), n + 2, &bases), "lasso_bases_create");
+    // the byte-multiple tables (459 KB per generator, the openings' MSMs at half the additions) only where they are read: not for the full-width set in slab mode (the rank's
+    // residue class serves the openings), not at all in capacity mode
+    d.chk(lasso_bases_create_opt(d.ctx, affine.data(), n + 2, (!d.comm.sharded() && !d.capacity) ? 1 : 0, &bases), "lasso_bases_create");
     if (d.comm.sharded()) {
       const size_t P = d.comm.world; LASSO_REQUIRE(n >= P);
       // this rank's residue class of the generators, then Q and h: the same table serves the partial row commitments (first n/P entries) and the rank's share of the
       // opening's MSMs (lasso_bullet_round_slab / lasso_msm_dev_slab, which also need Q and h)
       std::vector<lasso_affine> sub(n / P + 2); for (size_t j = 0; j < n / P; j++) sub[j] = affine[j * P + d.comm.rank];
       sub[n / P] = affine[n]; sub[n / P + 1] = affine[n + 1];
-      d.chk(lasso_bases_create(d.ctx, sub.data(), sub.size(), &bases_slab), "lasso_bases_create");
+      d.chk(lasso_bases_create_opt(d.ctx, sub.data(), sub.size(), d.capacity ? 0 : 1, &bases_slab), "lasso_bases_create");
       // the sharded opening is used only if EVERY rank has the table it needs (an allocation that failed on one rank must not split the ranks between two protocols)
       static const bool off = [] { const char* e = getenv("LASSO_SLAB_OPEN"); return e && e[0] == '0'; }();
       std::vector<uint8_t> all(P, 0); const uint8_t mine = (!off && lasso_bases_has_direct(bases_slab) == 1) ? 1 : 0;

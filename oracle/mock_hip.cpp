@@ -405,6 +405,8 @@ int32_t lasso_densify_dim_slab(lasso_ctx* c, const uint64_t* idx, size_t n_looku
   for (size_t a = rank; a < m; a += world) d_final[a / world] = ff[a];
   return 0;
 }
+int32_t lasso_bases_create(lasso_ctx*, const lasso_affine* pts, size_t n, lasso_bases** out);
+int32_t lasso_bases_create_opt(lasso_ctx* c, const lasso_affine* pts, size_t n, int32_t, lasso_bases** out) { return lasso_bases_create(c, pts, n, out); }
 int32_t lasso_bases_create(lasso_ctx*, const lasso_affine* pts, size_t n, lasso_bases** out) {
   auto* b = new lasso_bases();
   for (size_t i = 0; i < n; i++) b->pts.push_back(Point::from_affine(Fq::from_raw(pts[i].x), Fq::from_raw(pts[i].y)));
