@@ -300,7 +300,7 @@ __device__ __forceinline__ void msm_coop_tree(pt29* pts, fe29 (*st4)[4], uint32_
 #else
 // Round 4's pass.  A sextet is six adjacent lanes of ONE wave (ten sextets per wave, lanes 60..63 idle: 40 additions per pass), so the exchanges inside a pass need the wave's
 // own LDS operations kept in order, not a workgroup barrier; the linear step between the two product layers is a lane step of its own (pt_coop_form: one combination per lane
-// instead of all six in every lane) through a second exchange buffer.  Measured (tools/msm_phase_bench.hip, BN254 build): a pass 4.8 -> see DESIGN 6.11.  Workgroup barriers
+// instead of all six in every lane) through a second exchange buffer.  Measured (tools/msm_phase_bench.hip, BN254 build): a pass 4.8 -> 2.5 us, DESIGN 6.11.  Workgroup barriers
 // remain after the levels whose results the next level reads from another wave (more than 10 additions) and after the plain levels.
 __device__ __forceinline__ void msm_coop_tree(pt29* pts, fe29 (*st4)[4], uint32_t live, const fe29& d2_unused) {
   fe29* st = &st4[0][0]; fe29* sf = st + MSM_THREADS;   // the exchange buffer is two buffers of MSM_THREADS values in this build (MSM_ST_ROWS)
