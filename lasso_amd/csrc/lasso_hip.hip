@@ -1176,8 +1176,7 @@ int32_t lasso_bases_create_opt(lasso_ctx* c, const lasso_affine* points, size_t 
   if (b->d_mult && byte_multiples && n <= direct8_max) {
     typedef MsmD<8> D8;
     if (dmalloc(c, (void**)&b->d_mult8, n * D8::WINDOWS * D8::MULTS * sizeof(niels29)) == hipSuccess) {
-      for (uint32_t w = 0; w < D8::WINDOWS; w++)
-        hipLaunchKernelGGL(k_precompute_tab8, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream, (const niels29*)b->d_table, n, w, b->d_mult8 + (size_t)w * D8::MULTS * n, D8::MULTS);
+      hipLaunchKernelGGL(k_precompute_tab8, dim3((unsigned)((n + 63) / 64), D8::WINDOWS), dim3(64), 0, c->stream, (const niels29*)b->d_table, n, 0u, b->d_mult8, D8::MULTS);   // all 32 windows in one launch
       e = hipGetLastError(); if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
       if (e != hipSuccess) { (void)dfree(c, b->d_mult8); (void)dfree(c, b->d_mult); (void)dfree(c, b->d_table); delete b; return fail(c, LASSO_ERR_HIP, hipGetErrorString(e)); }
     } else { (void)hipGetLastError(); b->d_mult8 = nullptr; }

@@ -377,9 +377,11 @@ __device__ __forceinline__ void msm_coop_tree(pt29* pts, fe29 (*st)[4], uint32_t
 // affine Niels form in runs of 16 that share one inversion (Montgomery's trick).
 #define MSM8_MULTS 255
 // nm: multiples per generator (255 for the commitments' unsigned bytes; 128 for the signed bytes of the latency-shaped MSMs, mult8)
+// grid.y > 1: one launch for gridDim.y consecutive byte windows w8 + blockIdx.y, each window's nm * n entries after the previous one's (mult8)
 __global__ void __launch_bounds__(64) k_precompute_tab8(const niels29* __restrict__ table, size_t n, uint32_t w8, niels29* __restrict__ tab8, uint32_t nm = MSM8_MULTS) {
   const size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (j >= n) return;
+  w8 += blockIdx.y; tab8 += (size_t)blockIdx.y * nm * n;
   const niels29 b = table[(size_t)(2 * w8) * n + j];
   const fe29 d2 = fe_d2();
   tab8[j] = b;
