@@ -94,6 +94,24 @@ class Strobe {
     memcpy(k.bytes, head, 18); k.permute();
     meta_ad(proto, strlen(proto), false);
   }
+  // meta_ad(label, false); meta_ad(len4, true); ad(msg, false) — merlin's append_message — in ONE pass over the rate block when the framed record (2 + label + 4 + 2 + msg
+  // bytes) ends before the block does; false = a block boundary falls inside it and the caller takes the three calls.  The openings append their 16 640 a-vector scalars one
+  // by one (dot_product.rs:196): three out of four of those records take this path.
+  bool append_framed(const void* label, size_t ll, const uint8_t len4[4], const void* msg, size_t n) {
+    const size_t total = 2 + ll + 4 + 2 + n;
+    if ((size_t)pos + total >= RATE) return false;
+    uint8_t* d = k.bytes + pos;
+    d[0] ^= pos_begin; d[1] ^= (uint8_t)(M | A);                       // begin(M | A): header = [previous pos_begin, flags], pos_begin = pos + 1
+    const uint8_t* l = (const uint8_t*)label; for (size_t i = 0; i < ll; i++) d[2 + i] ^= l[i];
+    uint8_t* e = d + 2 + ll;
+    e[0] ^= len4[0]; e[1] ^= len4[1]; e[2] ^= len4[2]; e[3] ^= len4[3];
+    e[4] ^= (uint8_t)(pos + 1); e[5] ^= (uint8_t)A;                    // begin(A): header = [pos_begin of the meta op, flags]
+    const uint8_t* m = (const uint8_t*)msg; uint8_t* f = e + 6; size_t i = 0;
+    for (; i + 8 <= n; i += 8) { uint64_t a, b; memcpy(&a, f + i, 8); memcpy(&b, m + i, 8); a ^= b; memcpy(f + i, &a, 8); }
+    for (; i < n; i++) f[i] ^= m[i];
+    pos_begin = (uint8_t)(pos + 2 + ll + 4 + 1); cur = A; pos = (uint8_t)(pos + total);
+    return true;
+  }
   void meta_ad(const void* d, size_t n, bool more) { begin(M | A, more); absorb((const uint8_t*)d, n); }
   void ad(const void* d, size_t n, bool more) { begin(A, more); absorb((const uint8_t*)d, n); }
   void prf(uint8_t* d, size_t n, bool more) { begin(I | A | C, more); squeeze(d, n); }
@@ -110,6 +128,7 @@ class Merlin {
   // the same with the label as (pointer, length): labels that arrive through the C ABI are not NUL-terminated (include/lasso_prover.h lasso_transcript_vtbl)
   void append_message_l(const void* label, size_t label_len, const void* msg, size_t n) {
     uint8_t len[4]; le32((uint32_t)n, len);
+    if (s.append_framed(label, label_len, len, msg, n)) return;
     s.meta_ad(label, label_len, false); s.meta_ad(len, 4, true); s.ad(msg, n, false);
   }
   void append_str(const char* label, const char* msg) { append_message(label, msg, strlen(msg)); }

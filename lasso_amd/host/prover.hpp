@@ -1245,14 +1245,20 @@ class Prover {
     lasso_point dl; Pt dlp;
     {
       lasso_fr sc = dd.abi(); lasso_fr tl[2] = {Sc::zero().abi(), r_delta.abi()};
-      if (shard) { d.chk(lasso_msm_dev_slab(d.ctx, g.bases_slab, w_cur, n, cw, cr, &sc, cr == 0 ? tl : nullptr, &dl), "lasso_msm_dev_slab"); sum_points(&dl, 1, &dlp); }
-      else { d.chk(lasso_msm_dev_scaled(d.ctx, g.bases, w_cur, n, &sc, tl, &dl), "lasso_msm_dev_scaled"); dlp = Pt::from_abi(dl); }
+      if (shard) {
+        d.chk(lasso_msm_dev_slab(d.ctx, g.bases_slab, w_cur, n, cw, cr, &sc, cr == 0 ? tl : nullptr, &dl), "lasso_msm_dev_slab"); sum_points(&dl, 1, &dlp);
+        HostClock hc("opening: delta/beta scalar mults");
+        compress_one(dlp, P.delta); compress_one(g.Qmul.mul(dd) + g.hmul.mul(r_beta), P.beta);
+      } else {
+        // beta = d * Q + r_beta * h (two fixed-base scalar multiplications, ~60 us of host time) while the device computes delta — as Cx / Cy above
+        d.chk(lasso_defer_next(d.ctx), "lasso_defer_next");
+        d.chk(lasso_msm_dev_scaled(d.ctx, g.bases, w_cur, n, &sc, tl, &dl), "lasso_msm_dev_scaled");
+        { HostClock hc("opening: delta/beta scalar mults"); compress_one(g.Qmul.mul(dd) + g.hmul.mul(r_beta), P.beta); }
+        d.chk(lasso_result_wait(d.ctx, (lasso_fr*)&dl, 4), "lasso_result_wait");
+        dlp = Pt::from_abi(dl); compress_one(dlp, P.delta);
+      }
     }
-    {
-      HostClock hc("opening: delta/beta scalar mults");
-      compress_one(dlp, P.delta); t.append_point_bytes("delta", P.delta);
-      compress_one(g.Qmul.mul(dd) + g.hmul.mul(r_beta), P.beta); t.append_point_bytes("beta", P.beta);
-    }
+    t.append_point_bytes("delta", P.delta); t.append_point_bytes("beta", P.beta);
     Sc c = t.challenge_scalar("c");
     P.z1 = dd + c * y_hat;
     P.z2 = a_hat * (c * blind_fin + r_beta) + r_delta;

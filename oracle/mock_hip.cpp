@@ -461,7 +461,7 @@ int32_t lasso_msm_dev_scaled(lasso_ctx* c, const lasso_bases* b, const lasso_fr*
   std::vector<Point> bases(b->pts.begin(), b->pts.begin() + n + 2); std::vector<Fr> s;
   for (size_t i = 0; i < n; i++) s.push_back(F(sc)[i] * *F(scale));
   s.push_back(F(tail)[0]); s.push_back(F(tail)[1]);
-  put_point(msm(bases, s), out); return 0;
+  lasso_point tmp; put_point(msm(bases, s), &tmp); return deliver_points(c, &tmp, 1, out);
 }
 int32_t lasso_inner_products_lr(lasso_ctx*, const lasso_fr* a, const lasso_fr* b, size_t nk, lasso_fr* out) {
   size_t h = nk / 2; F(out)[0] = inner_product(F(a), F(b) + h, h); F(out)[1] = inner_product(F(a) + h, F(b), h); return 0;   // bullet.rs:79-80

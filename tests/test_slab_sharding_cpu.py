@@ -25,7 +25,9 @@ def build_slab_lib(curve="curve25519"):
     deps += [os.path.join(ROOT, "lasso_amd", "csrc", f) for f in ("bn254_fr.cuh", "bn254_fq.cuh")] + [os.path.join(ROOT, "oracle", "bn254.hpp")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in deps):
         flags = ["-DLASSO_BN254", "-DORC_BN254"] if bn else []
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wno-unknown-pragmas", "-fno-gnu-unique", "-Wl,-Bsymbolic", *flags, "-o", so] + srcs)   # see oracle/Makefile
+        tmp = f"{so}.{os.getpid()}.tmp"      # atomic replace: other test processes (pytest -n, the capacity-mode children) may be building or loading the same library
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wno-unknown-pragmas", "-fno-gnu-unique", "-Wl,-Bsymbolic", *flags, "-o", tmp] + srcs)   # see oracle/Makefile
+        os.replace(tmp, so)
     return C.CDLL(so)
 
 
