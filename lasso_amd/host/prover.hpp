@@ -144,7 +144,7 @@ class Dev {
     else {
       // capacity mode: a buffer the pool cannot serve must not land ON TOP of what is parked there — parked buffers go back to the driver first, largest first, until
       // they make up the request (live + parked bytes then do not grow past the larger of the two proofs' own needs)
-      if (capacity && bytes >= ((size_t)1 << 20)) {
+      if (capacity && bytes >= ((size_t)64 << 20)) {   // small requests never evict (a 2 MB miss that returned a parked gigabyte started a miss / evict cycle that repeated every proof)
         auto fit = pool_.lower_bound(bytes);      // the smallest parked buffer that covers the request, else the largest ones until they add up
         if (fit != pool_.end()) { (void)lasso_free(ctx, fit->second); pool_.erase(fit); }
         else { size_t freed = 0; while (freed < bytes && !pool_.empty()) { auto big = std::prev(pool_.end()); freed += big->first; (void)lasso_free(ctx, big->second); pool_.erase(big); } }
