@@ -377,6 +377,19 @@ int32_t lasso_bullet_lr(lasso_ctx* ctx, const lasso_bases* bases, size_t n, cons
  * with G the virtually folded generators as in lasso_bullet_lr. */
 int32_t lasso_bullet_round(lasso_ctx* ctx, const lasso_bases* bases, size_t n, const lasso_fr* d_a_in, const lasso_fr* d_b_in, const lasso_fr* d_w_in,
                            lasso_fr* d_a_out, lasso_fr* d_b_out, lasso_fr* d_w_out, size_t nk, const lasso_fr* u, const lasso_fr* u_inv, const lasso_fr* blinds, lasso_point* out);
+/* The same folding round LAUNCHED AHEAD of its challenge.  A bullet round is on the proof's critical path and the host turn between two rounds is ~4 us of work inside ~31 us of
+ * launch and completion latency; so the host enqueues round k+1 behind round k BEFORE it has round k's L and R — the kernel starts the moment round k ends and waits for the
+ * challenge in a host-mapped mailbox (the resident sumcheck tails' protocol) — and posts u, u^-1 when it has drawn them:
+ *   lasso_bullet_round_ahead(..., nk, blinds)   enqueue (arguments as lasso_bullet_round's folding form, without u / u_inv / out); returns at once
+ *   lasso_bullet_post(ctx, u, u_inv)            release it: from here on it is a deferred result
+ *   lasso_result_wait(ctx, (lasso_fr*)LR, 8)    L and R
+ * Between the first and the second call no other launch of this context may be made except... none: only host work and lasso_result_wait of the PREVIOUS round.
+ * lasso_abort releases a round that never got its challenge (the kernel also leaves by itself after 5 s).  lasso_bullet_ahead_ok: 1 if the form is available for this generator
+ * set now (its digit-multiple table exists, the fused launch is not switched off, LASSO_BULLET_AHEAD != 0, the opening MSMs are not being profiled launch by launch). */
+int32_t lasso_bullet_ahead_ok(lasso_ctx* ctx, const lasso_bases* bases);
+int32_t lasso_bullet_round_ahead(lasso_ctx* ctx, const lasso_bases* bases, size_t n, const lasso_fr* d_a_in, const lasso_fr* d_b_in, const lasso_fr* d_w_in,
+                                 lasso_fr* d_a_out, lasso_fr* d_b_out, lasso_fr* d_w_out, size_t nk, const lasso_fr* blinds);
+int32_t lasso_bullet_post(lasso_ctx* ctx, const lasso_fr* u, const lasso_fr* u_inv);
 /* bullet.rs:127-132: a[i] <- a_L[i]*u + u_inv*a_R[i], b[i] <- b_L[i]*u_inv + u*b_R[i] for i < nk/2 (in place), and the
  * generator fold G[i] <- G_L[i]*u_inv + G_R[i]*u recorded as weights: d_w_out[2*blk] = d_w[blk]*u_inv, d_w_out[2*blk+1] = d_w[blk]*u. */
 int32_t lasso_bullet_fold(lasso_ctx* ctx, lasso_fr* d_a, lasso_fr* d_b, size_t nk, const lasso_fr* d_w, size_t nw, lasso_fr* d_w_out, const lasso_fr* u, const lasso_fr* u_inv);

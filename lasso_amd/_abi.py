@@ -111,6 +111,9 @@ def declare(lib):
         "lasso_inner_products_lr": (i32, [vp, vp, vp, sz, vp]),
         "lasso_bullet_lr": (i32, [vp, vp, sz, vp, sz, vp, vp, vp]),
         "lasso_bullet_round": (i32, [vp, vp, sz, vp, vp, vp, vp, vp, vp, sz, vp, vp, vp, vp]),
+        "lasso_bullet_ahead_ok": (i32, [vp, vp]),
+        "lasso_bullet_round_ahead": (i32, [vp, vp, sz, vp, vp, vp, vp, vp, vp, sz, vp]),
+        "lasso_bullet_post": (i32, [vp, vp, vp]),
         "lasso_bullet_fold": (i32, [vp, vp, vp, sz, vp, sz, vp, vp, vp]),
     }
     for name, (res, args) in sig.items():

@@ -60,6 +60,9 @@ struct lasso_ctx {
   uint32_t* d_flags = nullptr;
   uint32_t* d_counters = nullptr;                         // arrival tickets of the in-launch reductions (zero between launches)
   bool pending = false, defer_next = false; uint32_t pending_seq = 0; size_t pending_count = 0;   // a deferred result not yet collected by lasso_result_wait
+  // a bullet round launched ahead of its challenge (k_bullet_msm with a mailbox): enqueued by lasso_bullet_round_ahead, released by lasso_bullet_post (u, u^-1 in the two
+  // mailboxes mail_h, mail_h + 12), after which it is an ordinary pending result.  d_gmail: 18 words of device memory, workgroup (0, 0)'s republication of the two scalars
+  bool ahead_active = false; uint32_t ahead_seq = 0; uint32_t* d_gmail = nullptr;
   bool tail_active = false; uint32_t tail_seq0 = 0, tail_turn = 0, tail_turns = 0; size_t tail_count = 0, tail_final = 0;   // resident sumcheck-tail kernel (k_cubic_tail); its mailbox = h_flag + 32 (bytes 128..163)
   uint32_t prof_mask = 0;   // bit k set = kernel family k is bracketed with events
   std::vector<EventPair> events; size_t events_used = 0;
@@ -246,10 +249,10 @@ static int32_t wait_flag(lasso_ctx* c, uint32_t seq, size_t count, lasso_fr* out
 // still publish), zero the tagged result area and the mailbox, and restart at 1.  Costs one stream synchronisation per ~4e9 hand-offs.
 static uint32_t next_seq(lasso_ctx* c, uint32_t span = 1) {
   // not while a result is still uncollected (lasso_defer_next) or a resident tail holds a block of numbers: the 2^20 numbers of slack cover any such stretch
-  if (c->seq > 0xFFF00000u - span && ((!c->pending && !c->tail_active) || c->seq > 0xFFFFFF00u - span)) {
+  if (c->seq > 0xFFF00000u - span && ((!c->pending && !c->tail_active && !c->ahead_active) || c->seq > 0xFFFFFF00u - span)) {
     (void)hipStreamSynchronize(c->stream);
     if (c->h_tag) memset(c->h_tag, 0, c->small_cap * 48);
-    if (c->mail_h) memset(c->mail_h, 0, 48);
+    if (c->mail_h) memset(c->mail_h, 0, 96);   // both mailboxes
     if (c->h_flag) *c->h_flag = 0;
     c->seq = 0;
   }
@@ -402,6 +405,7 @@ int32_t lasso_ctx_create_background(int32_t device, int32_t background, lasso_ct
   memset(c->mail_h, 0, 48);
   int32_t rc = ensure_small(c, (size_t)1 << 16); if (rc) { g_create_err = c->err; delete c; return rc; }   // 2 MiB of mapped result buffer: the largest a-vector / row-commitment hand-off without a reallocation
   rc = ensure_scratch(c, (size_t)1 << 22); if (rc) { g_create_err = c->err; delete c; return rc; }
+  if (dmalloc(c, (void**)&c->d_gmail, 128) != hipSuccess || hipMemset(c->d_gmail, 0, 128) != hipSuccess) { g_create_err = "gmail alloc"; delete c; return LASSO_ERR_OOM; }
   *out = c; return 0;
 }
 // Error recovery: a host that stops between *_tail_begin and the last tail_next (an exception in the prover) leaves a resident kernel waiting for a
@@ -410,10 +414,11 @@ int32_t lasso_ctx_create_background(int32_t device, int32_t background, lasso_ct
 int32_t lasso_abort(lasso_ctx* c) {
   REQUIRE(c, c);
   const uint32_t zero8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (c->tail_active) post_mail(c, LASSO_MAIL_POISON, zero8);
+  if (c->tail_active || c->ahead_active) { mail_chunks(c->mail_h + 12, LASSO_MAIL_POISON, zero8); post_mail(c, LASSO_MAIL_POISON, zero8); }
   (void)hipStreamSynchronize(c->stream);   // bounded: every device-side wait has the poison check and a wall-clock bail-out
   (void)hipGetLastError();
-  post_mail(c, 0, zero8);
+  mail_chunks(c->mail_h + 12, 0, zero8); post_mail(c, 0, zero8);
+  c->ahead_active = false;
   c->tail_active = false; c->pending = false; c->defer_next = false; c->events_used = 0; c->pending_groups = 1; c->pending_K = 0;
   HIPCHK(c, hipMemsetAsync(c->d_counters, 0, (LASSO_MAX_PTRS + 40) * 4, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -422,11 +427,12 @@ int32_t lasso_abort(lasso_ctx* c) {
 void lasso_ctx_destroy(lasso_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  if (c->tail_active || c->pending) (void)lasso_abort(c);   // never block in the synchronise below for a kernel's 5 s bail-out
+  if (c->tail_active || c->pending || c->ahead_active) (void)lasso_abort(c);   // never block in the synchronise below for a kernel's 5 s bail-out
   (void)hipStreamSynchronize(c->stream);
   rccl_release(c);
   for (auto& p : c->events) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   if (c->d_scratch) (void)hipFree(c->d_scratch);
+  if (c->d_gmail) (void)hipFree(c->d_gmail);
   if (c->h_small) (void)hipHostFree(c->h_small);
   if (c->h_tag) (void)hipHostFree(c->h_tag);
   if (c->h_flag) (void)hipHostFree(c->h_flag);
@@ -1440,8 +1446,8 @@ int32_t lasso_bullet_lr(lasso_ctx* c, const lasso_bases* b, size_t n, const lass
 // fold + scalars + both MSMs in one launch (k_bullet_msm): K chunk workgroups per row over the row's local columns, plus one per row for a', b', the inner product and c*Q + blind*H.
 // world / rank: slab mode (the table `b` holds the rank's n / world generators, then Q, H; the result is the rank's PARTIAL L, R).
 static int32_t bullet_round_fused(lasso_ctx* c, const lasso_bases* b, size_t n, const lasso_fr* d_a_in, const lasso_fr* d_b_in, const lasso_fr* d_w_in, lasso_fr* d_a_out, lasso_fr* d_b_out,
-                                  lasso_fr* d_w_out, size_t nk, const lasso_fr* u, const lasso_fr* u_inv, const lasso_fr* blinds, lasso_point* out, uint32_t world, uint32_t rank) {
-  const bool fold = u != nullptr;
+                                  lasso_fr* d_w_out, size_t nk, const lasso_fr* u, const lasso_fr* u_inv, const lasso_fr* blinds, lasso_point* out, uint32_t world, uint32_t rank, bool ahead = false) {
+  const bool fold = u != nullptr || ahead;   // ahead: a folding round enqueued before its challenge exists (the kernel waits for lasso_bullet_post)
   // chunks per row: (workgroups of the launch - 2 extra) / 2 rows, items shared out evenly (a multiple of 64 keeps whole columns together where it can)
   static const size_t wgs = [] { const char* v = getenv("LASSO_MSM_DIRECT_WGS"); const long x = v ? atol(v) : 0; return (size_t)(x >= 4 && x <= 4096 ? x : 256); }();
   const size_t n_loc = n / world, cols = (nk / 2 >= world) ? n_loc / 2 : n_loc;   // the longest row's local columns
@@ -1457,11 +1463,12 @@ static int32_t bullet_round_fused(lasso_ctx* c, const lasso_bases* b, size_t n, 
     const fr_t z = fr_zero();
 #define LAUNCH_BULLET(FOLD_, WB_, TAB_, AO, BO, WO, U, UI) hipLaunchKernelGGL((k_bullet_msm<FOLD_, WB_>), dim3((unsigned)K + 1, 2), dim3(MSM_THREADS), 0, c->stream, (const fr_t*)d_a_in, (const fr_t*)d_b_in, (const fr_t*)d_w_in, \
                                  (fr_t*)AO, (fr_t*)BO, (fr_t*)WO, (uint32_t)nk, (uint32_t)n, U, UI, to_fr(blinds), to_fr(blinds + 1), ipc, (const niels29*)TAB_, b->n, (pt29*)c->d_scratch, \
-                                 (ed_point*)c->d_small, c->d_counters + LASSO_MAX_PTRS + 8, c->d_flag, seq, ps.counter(), world, rank)
-    if (fold) { if (w8) LAUNCH_BULLET(true, 8, b->d_mult8, d_a_out, d_b_out, d_w_out, to_fr(u), to_fr(u_inv)); else LAUNCH_BULLET(true, 4, b->d_mult, d_a_out, d_b_out, d_w_out, to_fr(u), to_fr(u_inv)); }
+                                 (ed_point*)c->d_small, c->d_counters + LASSO_MAX_PTRS + 8, c->d_flag, seq, ps.counter(), world, rank, (const uint32_t*)(ahead ? c->mail_d : nullptr), c->d_gmail)
+    if (fold) { const fr_t uu = ahead ? z : to_fr(u), ui = ahead ? z : to_fr(u_inv); if (w8) LAUNCH_BULLET(true, 8, b->d_mult8, d_a_out, d_b_out, d_w_out, uu, ui); else LAUNCH_BULLET(true, 4, b->d_mult, d_a_out, d_b_out, d_w_out, uu, ui); }
     else { if (w8) LAUNCH_BULLET(false, 8, b->d_mult8, nullptr, nullptr, nullptr, z, z); else LAUNCH_BULLET(false, 4, b->d_mult, nullptr, nullptr, nullptr, z, z); }
   }
   HIPCHK(c, hipGetLastError());
+  if (ahead) { c->ahead_active = true; c->ahead_seq = seq; return 0; }
   return wait_flag(c, seq, 2 * (sizeof(ed_point) / sizeof(fr_t)), (lasso_fr*)out);
 }
 // slab mode of the opening (include/lasso_hip.h): this rank's share of L and R over its residue class of the generators
@@ -1508,6 +1515,28 @@ int32_t lasso_bullet_round(lasso_ctx* c, const lasso_bases* b, size_t n, const l
   HIPCHK(c, hipGetLastError());
   if (direct) { const MsmColMap cm = {(uint32_t)nk, (uint32_t)(nk / 2), (uint32_t)(n / 2), (uint32_t)n}; return run_msm_direct(c, (const uint8_t*)SL, row * 32, 2, row, cm, b, (uint8_t*)(partials + (size_t)nx * 2), out); }
   return run_msm(c, (const uint8_t*)SL, 32, MSM_WINDOWS, row * 32, 2, row, b, (uint8_t*)(partials + (size_t)nx * 2), out);
+}
+// ---- a folding round LAUNCHED AHEAD of its challenge (include/lasso_hip.h): enqueue, later post u / u^-1, then collect like any deferred result
+static bool bullet_ahead_possible(lasso_ctx* c, const lasso_bases* b) {
+  static const bool off = [] { const char* v = getenv("LASSO_BULLET_AHEAD"); return v && v[0] == '0'; }();
+  const bool bracketed = ((c->prof_mask >> LASSO_K_MSM_DIRECT) & 1u) && !(c->prof_mask & 0x40000000u);   // a launch between profiling events would count the wait for the host as kernel time
+  return !off && !bracketed && b && b->d_mult && msm_direct_enabled() && msm_direct_fused();
+}
+int32_t lasso_bullet_ahead_ok(lasso_ctx* c, const lasso_bases* b) { return c && bullet_ahead_possible(c, b) ? 1 : 0; }
+int32_t lasso_bullet_round_ahead(lasso_ctx* c, const lasso_bases* b, size_t n, const lasso_fr* d_a_in, const lasso_fr* d_b_in, const lasso_fr* d_w_in, lasso_fr* d_a_out, lasso_fr* d_b_out,
+                                 lasso_fr* d_w_out, size_t nk, const lasso_fr* blinds) {
+  REQUIRE(c, b && d_a_in && d_b_in && d_w_in && d_a_out && d_b_out && d_w_out && blinds && n >= 2 && (n & (n - 1)) == 0 && nk >= 2 && 2 * nk <= n && (nk & (nk - 1)) == 0 && n + 2 <= b->n &&
+             d_a_out != d_a_in && d_b_out != d_b_in && d_w_out != d_w_in && !c->ahead_active && !c->tail_active && !c->defer_next);
+  if (!bullet_ahead_possible(c, b)) return fail(c, LASSO_ERR_UNSUPPORTED, "lasso_bullet_round_ahead: not available for this generator set / configuration (lasso_bullet_ahead_ok)");
+  return bullet_round_fused(c, b, n, d_a_in, d_b_in, d_w_in, d_a_out, d_b_out, d_w_out, nk, nullptr, nullptr, blinds, nullptr, 1, 0, true);
+}
+int32_t lasso_bullet_post(lasso_ctx* c, const lasso_fr* u, const lasso_fr* u_inv) {
+  REQUIRE(c, u && u_inv && c->ahead_active && !c->pending);
+  mail_chunks(c->mail_h + 12, c->ahead_seq, (const uint32_t*)u_inv);
+  post_mail(c, c->ahead_seq, (const uint32_t*)u);
+  c->ahead_active = false;
+  c->pending = true; c->pending_seq = c->ahead_seq; c->pending_count = 2 * (sizeof(ed_point) / sizeof(fr_t)); c->pending_tagged = false; c->pending_groups = 1; c->pending_K = 0;
+  return 0;
 }
 int32_t lasso_bullet_fold(lasso_ctx* c, lasso_fr* d_a, lasso_fr* d_b, size_t nk, const lasso_fr* d_w, size_t nw, lasso_fr* d_w_out, const lasso_fr* u, const lasso_fr* u_inv) {
   REQUIRE(c, d_a && d_b && d_w && d_w_out && u && u_inv && nk >= 2 && (nk & (nk - 1)) == 0 && nw >= 1 && d_w != d_w_out);

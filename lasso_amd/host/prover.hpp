@@ -1203,11 +1203,27 @@ class Prover {
     lasso_fr *a_cur = d_a0.p, *a_nxt = d_a1.p, *b_cur = d_b0.p, *b_nxt = d_b1.p, *w_cur = d_w0.p, *w_nxt = d_w1.p;
     Sc blind_fin = Sc::zero(); size_t nk = n, nw = 1, round = 0;
     bool have_u = false; lasso_fr ua, uia;
+    // Rounds launched AHEAD (one GPU): the kernel of round k+1 is enqueued behind round k before round k's L, R are back; it waits on the device for the challenge the host posts
+    // (lasso_bullet_post) — the host turn between two rounds is ~4 us of work, the launch and its dispatch were 27 us more (include/lasso_hip.h).  `queued`: this round's kernel is
+    // already in the stream, its ping-pong buffers already swapped.
+    const bool ahead = !shard && lasso_bullet_ahead_ok(d.ctx, g.bases) == 1;
+    bool queued = false;
+    auto enqueue_next = [&](size_t nk_next) {   // the round after the one in flight: folds (a_cur, b_cur, w_cur) — being written by the launch in flight, stream order — to length nk_next
+      lasso_fr bl[2] = {v1[round + 1].abi(), v2[round + 1].abi()};
+      d.chk(lasso_bullet_round_ahead(d.ctx, g.bases, n, a_cur, b_cur, w_cur, a_nxt, b_nxt, w_nxt, nk_next, bl), "lasso_bullet_round_ahead");
+      std::swap(a_cur, a_nxt); std::swap(b_cur, b_nxt); std::swap(w_cur, w_nxt);
+      queued = true;
+    };
     while (nk != 1) {
       const Sc& blind_L = v1[round]; const Sc& blind_R = v2[round];
       lasso_fr blinds[2] = {blind_L.abi(), blind_R.abi()};
       lasso_point LR[2];
-      if (have_u) {   // fold with the previous challenge (length 2nk -> nk), then this round's L, R
+      if (have_u && queued) {   // this round's kernel is waiting for the challenge drawn at the end of the previous iteration
+        d.chk(lasso_bullet_post(d.ctx, &ua, &uia), "lasso_bullet_post");
+        queued = false;
+        if (nk / 2 != 1) enqueue_next(nk / 2);
+        d.chk(lasso_result_wait(d.ctx, (lasso_fr*)LR, 8), "lasso_result_wait");
+      } else if (have_u) {   // fold with the previous challenge (length 2nk -> nk), then this round's L, R
         if (shard) d.chk(lasso_bullet_round_slab(d.ctx, g.bases_slab, n, cw, cr, a_cur, b_cur, w_cur, a_nxt, b_nxt, w_nxt, nk, &ua, &uia, blinds, LR), "lasso_bullet_round_slab");
         else d.chk(lasso_bullet_round(d.ctx, g.bases, n, a_cur, b_cur, w_cur, a_nxt, b_nxt, w_nxt, nk, &ua, &uia, blinds, LR), "lasso_bullet_round");
         std::swap(a_cur, a_nxt); std::swap(b_cur, b_nxt); std::swap(w_cur, w_nxt);
@@ -1216,6 +1232,7 @@ class Prover {
         d.chk(lasso_defer_next(d.ctx), "lasso_defer_next");
         if (shard) d.chk(lasso_bullet_round_slab(d.ctx, g.bases_slab, n, cw, cr, a_cur, b_cur, w_cur, nullptr, nullptr, nullptr, nk, nullptr, nullptr, blinds, LR), "lasso_bullet_round_slab");
         else d.chk(lasso_bullet_round(d.ctx, g.bases, n, a_cur, b_cur, w_cur, nullptr, nullptr, nullptr, nk, nullptr, nullptr, blinds, LR), "lasso_bullet_round");
+        if (ahead && nk / 2 != 1) enqueue_next(nk / 2);
         { HostClock hc("opening: append a_vec"); t.append_scalars_bytes("a", a_bytes); }
         d.chk(lasso_result_wait(d.ctx, (lasso_fr*)LR, 8), "lasso_result_wait");
       }

@@ -18,6 +18,8 @@ struct lasso_ctx {
   std::vector<Fr> pending; bool defer = false;
   std::vector<std::vector<Fr>> tail_a, tail_b; std::vector<Fr> tail_e;   // resident tail: private copies of the arrays
   bool tail_linear = false;   // k_linear_tail: tail_a holds the alpha polynomials, tail_b is unused
+  // a bullet round launched ahead of its challenge: the arguments wait here for lasso_bullet_post
+  struct Ahead { bool on = false; const lasso_bases* bs; size_t n, nk; const lasso_fr *a_in, *b_in, *w_in; lasso_fr *a_out, *b_out, *w_out; lasso_fr blinds[2]; } ahead;
 };
 struct lasso_bases { std::vector<Point> pts; };
 
@@ -498,6 +500,22 @@ int32_t lasso_bullet_round(lasso_ctx* c, const lasso_bases* bs, size_t n, const 
   lasso_fr tail[4] = {cc[0], blinds[0], cc[1], blinds[1]};
   lasso_point lr[2]; int32_t rc = lasso_bullet_lr(c, bs, n, a, nk, w, tail, lr); if (rc) return rc;
   return deliver_points(c, lr, 2, out);
+}
+// a folding round launched ahead of its challenge: nothing can be computed before the challenge exists, so the mock records the launch and runs it when the challenge is posted —
+// the device's order of effects (round k reads what round k-1 wrote; the result is collected by lasso_result_wait)
+int32_t lasso_bullet_ahead_ok(lasso_ctx* c, const lasso_bases* b) { const char* v = getenv("LASSO_BULLET_AHEAD"); return c && b && !(v && v[0] == '0') ? 1 : 0; }
+int32_t lasso_bullet_round_ahead(lasso_ctx* c, const lasso_bases* bs, size_t n, const lasso_fr* a_in, const lasso_fr* b_in, const lasso_fr* w_in, lasso_fr* a_out, lasso_fr* b_out, lasso_fr* w_out, size_t nk,
+                                 const lasso_fr* blinds) {
+  REQ(c, bs && a_in && b_in && w_in && a_out && b_out && w_out && blinds && nk >= 2 && 2 * nk <= n && !c->ahead.on && !c->defer);
+  c->ahead.on = true; c->ahead.bs = bs; c->ahead.n = n; c->ahead.nk = nk; c->ahead.a_in = a_in; c->ahead.b_in = b_in; c->ahead.w_in = w_in; c->ahead.a_out = a_out; c->ahead.b_out = b_out; c->ahead.w_out = w_out;
+  c->ahead.blinds[0] = blinds[0]; c->ahead.blinds[1] = blinds[1];
+  return 0;
+}
+int32_t lasso_bullet_post(lasso_ctx* c, const lasso_fr* u, const lasso_fr* u_inv) {
+  REQ(c, u && u_inv && c->ahead.on && c->pending.empty() && !c->defer);
+  c->ahead.on = false; c->defer = true;   // the result is parked for lasso_result_wait, as after lasso_defer_next
+  lasso_point unused[2];
+  return lasso_bullet_round(c, c->ahead.bs, c->ahead.n, c->ahead.a_in, c->ahead.b_in, c->ahead.w_in, c->ahead.a_out, c->ahead.b_out, c->ahead.w_out, c->ahead.nk, u, u_inv, c->ahead.blinds, unused);
 }
 // ---- slab mode of the opening: the rank's share of the MSMs over its residue class of the generators (include/lasso_hip.h); bases = [G_{jl*world + rank}.., Q, H]
 int32_t lasso_bases_has_direct(const lasso_bases* b) { return b ? 1 : 0; }

@@ -142,6 +142,7 @@ print("DIGEST", hashlib.sha256(comm + proof).hexdigest())
                                  {"LASSO_SEQ_START": "0xffefff9c"},     # the context's hand-off sequence numbers start 100 short of the end of an epoch: the proof crosses next_seq's restart
                                  {"LASSO_MSM_DIRECT8": "0"},                 # the openings' MSMs over the 4-bit digit-multiple tables instead of the byte-multiple ones
                                  {"LASSO_MSM_DIRECT8": "0", "LASSO_MSM_FUSED": "0"},
+                                 {"LASSO_BULLET_AHEAD": "0"},                # every bullet round launched after its challenge is known (round 3's schedule)
                                  {"LASSO_MSM_DIRECT": "0"},                  # the bucket kernel serves the openings' MSMs too (incl. the deferred delta MSM)
                                  {"LASSO_CAPACITY": "1", "LASSO_LEAFLESS_MIN": "1024"},      # capacity mode: leafless trees, the bottom layer's two streaming rounds from recomputed leaves (8 chunks)
                                  {"LASSO_CAPACITY": "1", "LASSO_LEAFLESS_MIN": "1024", "LASSO_CUBIC_TAIL": "0", "LASSO_EQ_INLINE": "0"}])
