@@ -234,7 +234,12 @@ static int32_t wait_flag(lasso_ctx* c, uint32_t seq, size_t count, lasso_fr* out
   while (__atomic_load_n(c->h_flag, __ATOMIC_ACQUIRE) != seq) {
     if ((++spins & 0xffff) == 0) {   // a faulted or finished stream can never raise the flag: stop spinning
       hipError_t q = hipStreamQuery(c->stream);
-      if (q == hipSuccess) { if (__atomic_load_n(c->h_flag, __ATOMIC_ACQUIRE) == seq) break; return fail(c, LASSO_ERR_HIP, "result flag was not raised by the device"); }
+      if (q == hipSuccess) {
+        if (__atomic_load_n(c->h_flag, __ATOMIC_ACQUIRE) == seq) break;
+        uint32_t gm[18] = {0}; if (c->d_gmail) (void)hipMemcpy(gm, c->d_gmail, sizeof(gm), hipMemcpyDeviceToHost);
+        return fail(c, LASSO_ERR_HIP, "result flag was not raised by the device (flag " + std::to_string(*c->h_flag) + ", waiting for " + std::to_string(seq) + ", last sequence number " + std::to_string(c->seq) +
+                                      ", launched-ahead tags " + std::to_string(gm[16]) + " / " + std::to_string(gm[17]) + ", mailbox tags " + std::to_string(c->mail_h[0]) + " / " + std::to_string(c->mail_h[12]) + ")");
+      }
       if (q != hipErrorNotReady) return fail(c, LASSO_ERR_HIP, std::string("stream error while waiting for a result: ") + hipGetErrorString(q));
     }
     __builtin_ia32_pause();

@@ -755,7 +755,7 @@ __global__ void __launch_bounds__(MSM_THREADS) k_bullet_msm(const fr_t* __restri
                                                              fr_t* __restrict__ b_out, fr_t* __restrict__ w_out, uint32_t nk, uint32_t n, fr_t u, fr_t u_inv, fr_t blind_l, fr_t blind_r,
                                                              uint32_t items_per_chunk, const niels29* __restrict__ mult, size_t tn, pt29* __restrict__ partial, ed_point* __restrict__ out_mont,
                                                              uint32_t* counters, uint32_t* flag, uint32_t seq, uint32_t* digit_count, uint32_t P, uint32_t rank,
-                                                             const uint32_t* __restrict__ mail, uint32_t* __restrict__ gmail) {
+                                                             const uint32_t* mail, uint32_t* gmail) {   // no __restrict__: the host writes the mailbox while the kernel polls it (with it the compiler may keep the first read)
   __shared__ pt29 pts[MSM_THREADS];   // the extra workgroup's reduction scratch (RedScratch, 29.6 KB) lives here before the tree needs it
   __shared__ fe29 st[MSM_ST_ROWS][4];
   __shared__ uint32_t sb[MSM_DIRECT_MAX_COLS * 8];
