@@ -207,6 +207,7 @@ def concurrent_leg(HostProver, _abi, max_streams, steps, S, c, log_m, log_s, cur
     workers = []
     for t in range(max(sweep)):
         hp = HostProver(curve=curve)
+        hp.set_throughput_mode(True)      # one of several hosts on this GPU: no kernel waits on the device for its host thread (include/lasso_prover.h)
         idx = (hp.gen_indices(s, 1 << log_m, c) + t) % (1 << log_m)
         r = hp.gen_random_point(log_s)
         gens = hp.gens(c, s, alpha, log_m); dense = hp.densify(idx, log_m); del idx

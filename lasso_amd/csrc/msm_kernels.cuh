@@ -793,7 +793,7 @@ __global__ void __launch_bounds__(MSM_THREADS) k_bullet_msm(const fr_t* __restri
       for (spins = 0;;) {
         if (__hip_atomic_load(gmail + 16, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == seq) break;
         if (__hip_atomic_load(gmail + 17, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == seq || ((++spins & 63u) == 0 && wall_clock64() > t_end + 100000000ull)) { ok = 0; break; }
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(20);   // ~0.5 us between looks: 253 waiting workgroups polling at the atomics' rate took 5 % off the throughput of 16 concurrent proofs
       }
       if (ok) {
 #pragma unroll

@@ -121,6 +121,7 @@ class Dev {
   // high-water mark is the live set at the tree phase, not the pool) and cost 10x the proof time in hipFree / hipMalloc (profiles/r04_slab_peak_bytes_first_cut.json).
   // LASSO_CAPACITY=1 turns it on for every host; lasso_host_set_capacity sets it per host; default: off.
   bool capacity = [] { const char* e = getenv("LASSO_CAPACITY"); return e && e[0] == '1'; }();
+  bool throughput = false;   // lasso_host_set_throughput_mode: several hosts prove concurrently on this GPU — no kernel of this host waits on the device for its host thread
   explicit Dev(int device) : device_(device) {
     if (lasso_ctx_create(device, &ctx) != 0) throw Error(std::string("lasso_ctx_create: ") + lasso_last_error(nullptr));
     const char* e = getenv("LASSO_SIDE_STREAM");
@@ -1206,7 +1207,7 @@ class Prover {
     // Rounds launched AHEAD (one GPU): the kernel of round k+1 is enqueued behind round k before round k's L, R are back; it waits on the device for the challenge the host posts
     // (lasso_bullet_post) — the host turn between two rounds is ~4 us of work, the launch and its dispatch were 27 us more (include/lasso_hip.h).  `queued`: this round's kernel is
     // already in the stream, its ping-pong buffers already swapped.
-    const bool ahead = !shard && lasso_bullet_ahead_ok(d.ctx, g.bases) == 1;
+    const bool ahead = !shard && !d.throughput && lasso_bullet_ahead_ok(d.ctx, g.bases) == 1;
     bool queued = false;
     auto enqueue_next = [&](size_t nk_next) {   // the round after the one in flight: folds (a_cur, b_cur, w_cur) — being written by the launch in flight, stream order — to length nk_next
       lasso_fr bl[2] = {v1[round + 1].abi(), v2[round + 1].abi()};

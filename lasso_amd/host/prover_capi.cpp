@@ -51,6 +51,7 @@ int32_t lasso_host_mem_stats(lasso_host* h, uint64_t* live_bytes, uint64_t* peak
   GUARD(if (!h) throw Error("lasso_host_mem_stats: null host"); h->dev.mem_stats(live_bytes, peak_bytes, prover_peak_bytes, reset != 0); return 0;)
 }
 int32_t lasso_host_set_capacity(lasso_host* h, int32_t on) { GUARD(if (!h) throw Error("lasso_host_set_capacity: null host"); h->dev.capacity = on != 0; if (on) h->dev.trim(); return 0;) }
+int32_t lasso_host_set_throughput_mode(lasso_host* h, int32_t on) { GUARD(if (!h) throw Error("lasso_host_set_throughput_mode: null host"); h->dev.throughput = on != 0; return 0;) }
 int32_t lasso_host_set_comm(lasso_host* h, int32_t rank, int32_t world, lasso_host_allgather_fn fn, void* user) {
   GUARD(
     if (!h || world < 1 || (world & (world - 1)) || rank < 0 || rank >= world || (world > 1 && !fn)) throw Error("lasso_host_set_comm: world must be a power of two, 0 <= rank < world, and a collective is needed when world > 1");

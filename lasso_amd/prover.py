@@ -41,6 +41,7 @@ def declare_prover(lib):
     u64p = C.POINTER(C.c_uint64)
     lib.lasso_host_mem_stats.argtypes = [vp, u64p, u64p, u64p, i32]
     lib.lasso_host_set_capacity.argtypes = [vp, i32]
+    lib.lasso_host_set_throughput_mode.argtypes = [vp, i32]
     lib.lasso_host_set_comm.argtypes = [vp, i32, i32, ALLGATHER_FN, vp]
     lib.lasso_host_set_comm_shm.argtypes = [vp, i32, i32, C.c_char_p]
     lib.lasso_host_gens_new.argtypes = [vp, C.c_char_p, sz, sz, sz, sz, C.POINTER(vp)]
@@ -184,6 +185,10 @@ class HostProver:
         live, peak, used = C.c_uint64(), C.c_uint64(), C.c_uint64()
         self._chk(self.lib.lasso_host_mem_stats(self.h, C.byref(live), C.byref(peak), C.byref(used), 1 if reset else 0))
         return {"live_bytes": live.value, "peak_bytes": peak.value, "prover_peak_bytes": used.value}
+
+    def set_throughput_mode(self, on=True):
+        """this host is one of several proving concurrently on the GPU: no kernel of it waits on the device for its host thread (lasso_host_set_throughput_mode)"""
+        self._chk(self.lib.lasso_host_set_throughput_mode(self.h, 1 if on else 0))
 
     def set_capacity(self, on=True):
         """capacity mode (lasso_host_set_capacity): large buffers go back to the driver on release; the per-rank high-water mark is the live peak"""

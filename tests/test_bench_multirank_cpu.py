@@ -64,6 +64,7 @@ def test_concurrent_leg_reports_a_failed_proof_instead_of_hanging():
     class FakeProver:
         def __init__(self, curve="curve25519"):
             self.calls = 0; self.id = len(made); made.append(self)
+        def set_throughput_mode(self, on=True): self.throughput = on
         def gen_indices(self, s, m, c): return np.zeros((s, c), dtype=np.uint64)
         def gen_random_point(self, n): return np.zeros((n, 4), dtype=np.uint64)
         def gens(self, c, s, alpha, log_m): return object()
@@ -97,6 +98,7 @@ def test_concurrent_sweep_checks_every_proof_against_its_sequential_bytes():
         flaky = False
         def __init__(self, curve="curve25519"):
             self.calls = 0; self.id = len(made); made.append(self)
+        def set_throughput_mode(self, on=True): self.throughput = on
         def gen_indices(self, s, m, c): return np.zeros((s, c), dtype=np.uint64)
         def gen_random_point(self, n): return np.zeros((n, 4), dtype=np.uint64)
         def gens(self, c, s, alpha, log_m): return object()
