@@ -258,6 +258,7 @@ static uint32_t next_seq(lasso_ctx* c, uint32_t span = 1) {
     (void)hipStreamSynchronize(c->stream);
     if (c->h_tag) memset(c->h_tag, 0, c->small_cap * 48);
     if (c->mail_h) memset(c->mail_h, 0, 96);   // both mailboxes
+    if (c->d_gmail) (void)hipMemset(c->d_gmail, 0, 128);   // ... and the launched-ahead rounds' republication tags
     if (c->h_flag) *c->h_flag = 0;
     c->seq = 0;
   }
