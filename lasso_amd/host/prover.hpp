@@ -1529,7 +1529,8 @@ class Prover {
     const bool leafless = (d.capacity || dense.compact) && s_loc >= leafless_min();   // a compact representation implies the leafless trees (same size condition)
     // the chi table is next needed after the operations' argument (re-allocated there); and what the earlier phases parked in the recycling pool goes back to the driver
     // before the peak (the primary sumcheck's work arrays: no later buffer has their size) — except buffers of a tree's size, which the loop below takes
-    if (d.capacity) { chis.reset(); d.trim_keep((leafless ? s_loc : 2 * s_loc) * sizeof(lasso_fr), 2 * alpha); }
+    // (+ 1 when the chunked leaf rounds' mini-layers, alpha * s_loc / 4 elements, happen to be of a tree's size — alpha = 4 — or they are allocated anew every proof: tests/test_buffer_policy_cpu.py)
+    if (d.capacity) { chis.reset(); d.trim_keep((leafless ? s_loc : 2 * s_loc) * sizeof(lasso_fr), 2 * alpha + (leafless && alpha == 4 ? 1 : 0)); }
     LeafLayer leaf; leaf.gamma = g; leaf.tau = ta; leaf.n_loc = s_loc;
     for (size_t i = 0; i < alpha; i++) {
       size_t j = S.memory_to_dimension_index(i); const lasso_fr* table = tables[S.memory_to_subtable_index(i)].p;

@@ -9,6 +9,8 @@
 #include "lasso_oracle.hpp"
 #include "../include/lasso_hip.h"
 #include <cstdlib>
+#include <map>
+#include <mutex>
 
 using namespace orc;
 
@@ -19,6 +21,7 @@ struct lasso_ctx {
   std::vector<std::vector<Fr>> tail_a, tail_b; std::vector<Fr> tail_e;   // resident tail: private copies of the arrays
   bool tail_linear = false;   // k_linear_tail: tail_a holds the alpha polynomials, tail_b is unused
   // a bullet round launched ahead of its challenge: the arguments wait here for lasso_bullet_post
+  std::mutex mem_mu; std::map<void*, size_t> mem_sizes; uint64_t mem_live = 0, mem_peak = 0, alloc_calls = 0;   // lasso_mem_stats of the mock
   struct Ahead { bool on = false; const lasso_bases* bs; size_t n, nk; const lasso_fr *a_in, *b_in, *w_in; lasso_fr *a_out, *b_out, *w_out; lasso_fr blinds[2]; } ahead;
 };
 struct lasso_bases { std::vector<Point> pts; };
@@ -51,10 +54,23 @@ int32_t lasso_ctx_create_background(int32_t, int32_t, lasso_ctx** out) { *out = 
 void lasso_ctx_destroy(lasso_ctx* c) { delete c; }
 const char* lasso_last_error(lasso_ctx* c) { return c ? c->err.c_str() : ""; }
 void* lasso_stream(lasso_ctx*) { return nullptr; }
-int32_t lasso_alloc(lasso_ctx* c, size_t bytes, void** d) { REQ(c, d); *d = malloc(bytes ? bytes : 1); return *d ? 0 : LASSO_ERR_OOM; }
-int32_t lasso_free(lasso_ctx*, void* p) { free(p); return 0; }
+// lasso_alloc / lasso_free with the device's byte accounting (lasso_mem_stats), so that the host prover's buffer policy — recycling pool, capacity mode's evictions and trims —
+// can be checked on the CPU: per context live / peak bytes, and the number of lasso_alloc calls (mock_alloc_calls: a steady state of repeated proofs must make none)
+int32_t lasso_alloc(lasso_ctx* c, size_t bytes, void** d) {
+  REQ(c, d); *d = malloc(bytes ? bytes : 1); if (!*d) return LASSO_ERR_OOM;
+  std::lock_guard<std::mutex> g(c->mem_mu); c->mem_sizes[*d] = bytes ? bytes : 1; c->mem_live += bytes ? bytes : 1; if (c->mem_live > c->mem_peak) c->mem_peak = c->mem_live; c->alloc_calls++;
+  return 0;
+}
+int32_t lasso_free(lasso_ctx* c, void* p) {
+  if (c && p) { std::lock_guard<std::mutex> g(c->mem_mu); auto it = c->mem_sizes.find(p); if (it != c->mem_sizes.end()) { c->mem_live -= it->second; c->mem_sizes.erase(it); } }
+  free(p); return 0;
+}
 int32_t lasso_trim(lasso_ctx*) { return 0; }
-int32_t lasso_mem_stats(lasso_ctx*, uint64_t* live, uint64_t* peak, int32_t) { if (live) *live = 0; if (peak) *peak = 0; return 0; }   // host memory: not tracked
+int32_t lasso_mem_stats(lasso_ctx* c, uint64_t* live, uint64_t* peak, int32_t reset) {
+  REQ(c, c); std::lock_guard<std::mutex> g(c->mem_mu);
+  if (live) *live = c->mem_live; if (peak) *peak = c->mem_peak; if (reset) c->mem_peak = c->mem_live; return 0;
+}
+extern "C" uint64_t mock_alloc_calls(lasso_ctx* c) { return c ? c->alloc_calls : 0; }
 int32_t lasso_upload(lasso_ctx*, void* d, const void* s, size_t n) { memcpy(d, s, n); return 0; }
 int32_t lasso_download(lasso_ctx*, void* d, const void* s, size_t n) { memcpy(d, s, n); return 0; }
 int32_t lasso_copy(lasso_ctx*, void* d, const void* s, size_t n) { memmove(d, s, n); return 0; }
