@@ -46,7 +46,7 @@ print("OK", out["pooled"][1][3], out["capacity"][1][3], round(ratio, 3), out["po
 """
 
 
-@pytest.mark.parametrize("kind,c", [("and", 2), ("lt", 2), ("range", 3)])
+@pytest.mark.parametrize("kind,c", [("and", 2), ("lt", 2), ("range", 3), ("range", 4), ("xor", 1), ("spark", 2), ("spark", 4)])
 def test_steady_state_allocates_nothing_and_capacity_mode_holds_less(oracle, kind, c):
     env = dict(os.environ, LASSO_LEAFLESS_MIN="64", LASSO_CUBIC_TAIL="0", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), OMP_NUM_THREADS="2")
     env.pop("LASSO_CAPACITY", None)
