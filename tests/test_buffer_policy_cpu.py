@@ -52,3 +52,36 @@ def test_steady_state_allocates_nothing_and_capacity_mode_holds_less(oracle, kin
     env.pop("LASSO_CAPACITY", None)
     res = subprocess.run([sys.executable, "-c", SCRIPT % {"root": ROOT, "kind": kind, "c": c}], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0 and "OK" in res.stdout, res.stdout[-1500:] + res.stderr[-3000:]
+
+
+LEAK_SCRIPT = r"""
+import ctypes as C, os, sys
+import numpy as np
+sys.path.insert(0, os.path.join(%(root)r, "tests"))
+from lasso_amd import _abi
+from proverutil import HostProver, build_mock_prover
+lib = C.CDLL(build_mock_prover())
+hp = HostProver(lib)
+for kind, c in (("and", 2), ("lt", 1), ("spark", 2)):
+    S = _abi.Strategy(_abi.KINDS[kind], c, 8, 0)
+    idx = np.ascontiguousarray(np.random.default_rng(9).integers(0, 256, size=(1 << 10, c), dtype=np.uint64))
+    r = np.ascontiguousarray(hp.gen_random_point(10), dtype=np.uint64)
+    for cap in (False, True):
+        hp.set_capacity(cap)
+        gens = hp.gens(c, 1 << 10, 2 * c if kind == "lt" else c, 8); dense = hp.densify(idx, 8)
+        comm = hp.commit(dense, gens); proof = hp.prove(dense, gens, S, r)
+        assert hp.verify(gens, S, 1 << 10, r, proof, comm)
+        hp.free(dense, gens)
+        hp.set_capacity(True)          # trims the recycling pool
+        live = hp.mem_stats()["live_bytes"]
+        assert live == 0, (kind, c, cap, live)      # every buffer the representation, the prover and the verifier took went back
+print("OK")
+"""
+
+
+def test_nothing_is_left_allocated_after_a_proof(oracle):
+    """densify + commit + prove + verify + free, pooled and capacity: once the pool is trimmed the mock device holds no byte of this host"""
+    env = dict(os.environ, LASSO_LEAFLESS_MIN="64", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), OMP_NUM_THREADS="2")
+    env.pop("LASSO_CAPACITY", None)
+    res = subprocess.run([sys.executable, "-c", LEAK_SCRIPT % {"root": ROOT}], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and "OK" in res.stdout, res.stdout[-1500:] + res.stderr[-3000:]
