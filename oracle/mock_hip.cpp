@@ -86,7 +86,7 @@ int32_t lasso_rccl_allgather(lasso_ctx*, const void*, void*, size_t) { return LA
 size_t lasso_point_row_bytes(void) { return 144; }
 int32_t lasso_hyrax_commit_rows_dev(lasso_ctx*, const lasso_fr*, size_t, size_t, const lasso_bases*, void*) { return LASSO_ERR_UNSUPPORTED; }
 int32_t lasso_points_reduce_compress(lasso_ctx*, const void*, uint32_t, size_t, uint8_t*) { return LASSO_ERR_UNSUPPORTED; }
-int32_t lasso_abort(lasso_ctx* c) { REQ(c, c); c->pending.clear(); c->defer = false; c->tail_a.clear(); c->tail_b.clear(); c->tail_e.clear(); return 0; }
+int32_t lasso_abort(lasso_ctx* c) { REQ(c, c); c->pending.clear(); c->defer = false; c->ahead.on = false; c->tail_a.clear(); c->tail_b.clear(); c->tail_e.clear(); return 0; }
 int32_t lasso_prof_get_large(lasso_ctx*, int32_t, uint64_t* n, double* ms, double* b) { if (n) *n = 0; if (ms) *ms = 0; if (b) *b = 0; return 0; }
 int32_t lasso_wait_stats(lasso_ctx*, uint64_t* w, double* us, int32_t) { if (w) *w = 0; if (us) *us = 0; return 0; }
 int32_t lasso_prof_get_units(lasso_ctx*, int32_t, int32_t, double* u) { if (u) *u = 0; return 0; }

@@ -702,6 +702,52 @@ def test_bullet_round_fused(devs, n, nk, fold):
         assert np.array_equal(x, y)
 
 
+@pytest.mark.parametrize("n,nk", [(8, 2), (64, 16), (1024, 512), (4096, 256)])
+def test_bullet_round_launched_ahead(devs, n, nk):
+    """lasso_bullet_round_ahead + lasso_bullet_post + lasso_result_wait == lasso_bullet_round with the same challenge (L, R and the folded state), on the device and in the mock;
+    and a round that never gets its challenge is released by lasso_abort at once (not by its 5 s bail-out), after which the context runs the same round normally."""
+    import time
+    rng = np.random.default_rng(n * 77 + nk)
+    mock_lib = devs[1].lib
+    g = gens(mock_lib, b"gens_sparse_poly", n + 1)
+    nw_in = n // (2 * nk)
+    a = rand_fr(rng, 2 * nk, edge=False); b = rand_fr(rng, 2 * nk, edge=False); w = rand_fr(rng, nw_in, edge=False)
+    blinds = rand_fr(rng, 2, edge=False)
+    u, ui = rand_fr(rng, 2, edge=False)
+    vp = lambda x: np.ascontiguousarray(x, dtype=np.uint64).ctypes.data_as(C.c_void_p)
+
+    def run(d):
+        bases = d.bases_create(g)
+        assert d.lib.lasso_bullet_ahead_ok(d.ctx, bases) == 1
+        pa = d.upload(a); pb = d.upload(b); pw = d.upload(w)
+        pa2 = d.alloc(32 * nk); pb2 = d.alloc(32 * nk); pw2 = d.alloc(32 * 2 * nw_in)
+        want = d.bullet_round(bases, n, pa, pb, pw, pa2, pb2, pw2, nk, u, ui, blinds)
+        want_state = (d.download(pa2, (nk, 4)), d.download(pb2, (nk, 4)), d.download(pw2, (2 * nw_in, 4)))
+        # a round that is enqueued and then abandoned
+        d._chk(d.lib.lasso_bullet_round_ahead(d.ctx, bases, n, C.c_void_p(pa), C.c_void_p(pb), C.c_void_p(pw), C.c_void_p(pa2), C.c_void_p(pb2), C.c_void_p(pw2), nk, vp(blinds)))
+        t0 = time.perf_counter()
+        d._chk(d.lib.lasso_abort(d.ctx))
+        assert time.perf_counter() - t0 < 1.0, "abort must not wait for the kernel's 5 s bail-out"
+        # ... and the real thing on the same context
+        for p in (pa2, pb2, pw2):
+            d._chk(d.lib.lasso_zero(d.ctx, C.c_void_p(p), 32))
+        d._chk(d.lib.lasso_bullet_round_ahead(d.ctx, bases, n, C.c_void_p(pa), C.c_void_p(pb), C.c_void_p(pw), C.c_void_p(pa2), C.c_void_p(pb2), C.c_void_p(pw2), nk, vp(blinds)))
+        time.sleep(0.002)                                   # the kernel is waiting on the device for these two scalars
+        d._chk(d.lib.lasso_bullet_post(d.ctx, vp(u), vp(ui)))
+        got = np.empty((2, 16), dtype=np.uint64)
+        d._chk(d.lib.lasso_result_wait(d.ctx, got.ctypes.data_as(C.c_void_p), 8))
+        got_state = (d.download(pa2, (nk, 4)), d.download(pb2, (nk, 4)), d.download(pw2, (2 * nw_in, 4)))
+        for p in (pa, pb, pw, pa2, pb2, pw2):
+            d.free(p)
+        d.bases_destroy(bases)
+        return want, want_state, got, got_state
+    (wa, wsa, ga, gsa), (wb, wsb, gb, gsb) = both(devs, run)
+    for want, got in ((wa, ga), (wb, gb), (wa, gb)):
+        assert compress_points(mock_lib, np.asarray(want).reshape(2, -1)) == compress_points(mock_lib, np.asarray(got).reshape(2, -1))
+    for x, y, z in zip(wsa, gsa, gsb):
+        assert np.array_equal(x, y) and np.array_equal(x, z)
+
+
 @pytest.mark.parametrize("n,ncirc", [(2, 1), (4, 2), (16, 33), (128, 5), (256, 2), (1 << 9, 2), (1 << 13, 8), (1 << 16, 3)])   # n <= 128: latency-shaped kernel
 def test_sumcheck_cubic_eqw_round(devs, n, ncirc):
     """eq-weighted round sums: sum_i A(x)[i] B(x)[i] E[i] at x = 0, 2, 3, vs the oracle's loop"""
