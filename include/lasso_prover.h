@@ -3,7 +3,8 @@
  * In the reference the host is Rust and these are methods (src/lasso/densified.rs, src/lasso/surge.rs); with no Rust
  * toolchain in this image the same surface is offered to Python (tests/, bench.py) through this header:
  *   lasso_host_densify  = DensifiedRepresentation::<F,C>::from_lookup_indices(&indices, log_m)      densified.rs:22
- *   lasso_host_gens_new = SparsePolyCommitmentGens::<G>::new(label, c, s, num_memories, log_m)      surge.rs:32
+ *   lasso_host_gens_from_points = the `gens: &SparsePolyCommitmentGens<G>` argument of commit / prove    surge.rs:119-125 (the caller's points)
+ *   lasso_host_gens_new = SparsePolyCommitmentGens::<G>::new(label, c, s, num_memories, log_m)      surge.rs:32 (convenience)
  *   lasso_host_commit   = DensifiedRepresentation::commit(&gens)                                     densified.rs:78
  *   lasso_host_prove    = SparsePolynomialEvaluationProof::<G,C,M,S>::prove(&mut dense, &r, &gens,
  *                             &mut Transcript::new(transcript_label), &mut RandomTape::new(tape_label))   surge.rs:119
@@ -61,7 +62,26 @@ int32_t lasso_host_set_comm(lasso_host* h, int32_t rank, int32_t world, lasso_ho
  * LASSO_SLAB_RCCL=0 keeps RCCL out.  Must precede gens_new / densify, like lasso_host_set_comm. */
 int32_t lasso_host_set_comm_shm(lasso_host* h, int32_t rank, int32_t world, const char* name);
 
+/* The CALLER's generators: SparsePolynomialEvaluationProof::prove and DensifiedRepresentation::commit take `gens: &SparsePolyCommitmentGens<G>` (src/lasso/surge.rs:119-125,
+ * src/lasso/densified.rs:78-81) — points the caller already holds, however it came by them.  This is that argument: nothing is derived inside the library.
+ * Each of the three sets is one PolyCommitmentGens (src/poly/dense_mlpoly.rs:34-45 -> DotProductProofGens, src/subprotocols/dot_product.rs:139-150 -> two MultiCommitGens,
+ * src/poly/commitments.rs:15-19) passed as n + 2 affine points in the order
+ *     gens.gens_n.G[0], ..., gens.gens_n.G[n-1],   gens.gens_1.G[0],   gens.gens_n.h          (gens_1.h is the same point by construction: split_at, commitments.rs:54-71)
+ * with n = 2^(num_vars - num_vars/2) for the set's polynomial size (surge.rs:39-47: l_variate = log2(next_pow2(2 c s)), log_m_variate = log2(next_pow2(c)) + log_m,
+ * derefs = log2(next_pow2(num_memories s))); a count other than n + 2 is refused (num_memories = 0: the strategy is not known yet — `commit` reads only the first two sets —
+ * and the derefs set is only required to be a power of two + 2; a wrong size then fails at use, as batch_commit's assert does, commitments.rs:85).  Coordinates are ark-ff's in-memory form (4 x u64 Montgomery limbs of x then y: what
+ * CurveGroup::normalize_batch yields, commitments.rs:87); points must be finite and on the curve (as the reference, the library does not check).  The points are copied:
+ * the caller's buffers are not retained.  The Rust shim fills the three arrays from the caller's `&SparsePolyCommitmentGens<G>` (integration/rust/hip.rs HipGens::from_gens). */
+int32_t lasso_host_gens_from_points(lasso_host* h, size_t c, size_t s, size_t num_memories, size_t log_m,
+                                    const lasso_affine* l_variate, size_t n_l_variate, const lasso_affine* log_m_variate, size_t n_log_m_variate,
+                                    const lasso_affine* derefs, size_t n_derefs, lasso_host_gens** out);
+/* SparsePolyCommitmentGens::new(label, c, s, num_memories, log_m) (surge.rs:32-58) as a CONVENIENCE for callers with no generators of their own (C, Python, bench.py):
+ * the library's restatement of MultiCommitGens::new (SHAKE256(label || compressed generator) -> ChaCha20Rng -> G::rand, commitments.rs:22-44).  A Rust caller should not
+ * rely on it reproducing arkworks' stream: it passes its own points through lasso_host_gens_from_points. */
 int32_t lasso_host_gens_new(lasso_host* h, const char* label, size_t c, size_t s, size_t num_memories, size_t log_m, lasso_host_gens** out);
+/* the points of set `which` (0 = gens_combined_l_variate, 1 = gens_combined_log_m_variate, 2 = gens_derefs) in lasso_host_gens_from_points' layout; *count = n + 2
+ * (returns -2 with *count set when cap is smaller) */
+int32_t lasso_host_gens_points(lasso_host_gens* g, int32_t which, lasso_affine* out, size_t cap, size_t* count);
 void lasso_host_gens_free(lasso_host_gens* g);
 /* indices: n_lookups x c, row-major (Vec<[usize; C]>) */
 int32_t lasso_host_densify(lasso_host* h, const uint64_t* indices, size_t n_lookups, size_t c, size_t log_m, lasso_host_dense** out);

@@ -19,7 +19,8 @@
 //! reference's Cargo.toml; the layout asserts below are what makes passing `&[F]` as `*const lasso_fr` sound.
 #![cfg(feature = "hip")]
 
-use std::ffi::{CStr, CString};
+use std::cell::RefCell;
+use std::ffi::CStr;
 use std::marker::PhantomData;
 use std::os::raw::c_void;
 
@@ -30,7 +31,8 @@ use ark_ff::PrimeField;
 use ark_serialize::CanonicalDeserialize;
 
 use crate::hip::ffi::*;
-use crate::lasso::surge::{SparsePolynomialCommitment, SparsePolynomialEvaluationProof};
+use crate::lasso::surge::{SparsePolyCommitmentGens, SparsePolynomialCommitment, SparsePolynomialEvaluationProof};
+use crate::poly::dense_mlpoly::PolyCommitmentGens;
 use crate::poly::dense_mlpoly::PolyCommitment;
 use crate::utils::random::RandomTape;
 use crate::subtables::{
@@ -73,12 +75,16 @@ impl<F: PrimeField, const C: usize, const M: usize, const LOG_R_: usize> HipStra
 }
 
 /// One device context + host prover (`lasso_host`).  One per prover thread; the library is not re-entrant on a context.
-pub struct HipProver { h: *mut lasso_host }
+pub struct HipProver {
+  h: *mut lasso_host,
+  /// device-resident generator tables, one entry per distinct `SparsePolyCommitmentGens` the caller has passed (see `gens_on_device`)
+  gens_cache: RefCell<Vec<(GensKey, *mut lasso_host_gens)>>,
+}
 impl HipProver {
   pub fn new(device: i32) -> Self {
     let mut h = std::ptr::null_mut();
     chk(unsafe { lasso_host_create(device, &mut h) }, "lasso_host_create");
-    let p = HipProver { h };
+    let p = HipProver { h, gens_cache: RefCell::new(Vec::new()) };
     p.self_test();
     p
   }
@@ -88,8 +94,12 @@ impl HipProver {
   /// back as the same 32 bytes — which also read back as 7 and 6 through ark-ff.  A build of ark-ff with another limb order, radix or Montgomery constant fails here,
   /// at start-up, instead of producing proofs nobody can verify.
   fn self_test(&self) {
-    use ark_ff::PrimeField as _;
+    // the scalar field of the library pair this binary is linked against (the BN254 pair must be checked against ark_bn254::Fr, not curve25519's)
+    #[cfg(feature = "hip-bn254")]
+    type F = ark_bn254::Fr;
+    #[cfg(not(feature = "hip-bn254"))]
     type F = ark_curve25519::Fr;
+    use ark_ff::PrimeField as _;
     let ctx = unsafe { lasso_host_ctx(self.h) };
     let host_side = [F::from(7u64), F::from(6u64)];
     let ints: [u32; 2] = [7, 6];
@@ -101,7 +111,7 @@ impl HipProver {
       chk(lasso_fr_from_u32(ctx, d_ints as *const u32, 2, d_fr as *mut lasso_fr), "lasso_fr_from_u32");
       let mut back = [F::from(0u64); 2];
       chk(lasso_download(ctx, back.as_mut_ptr() as *mut c_void, d_fr, 64), "lasso_download");
-      assert!(back == host_side, "ark_curve25519::Fr's memory form is not the library's field-element layout: 4 x u64 LE, Montgomery R = 2^256");
+      assert!(back == host_side, "ark-ff's Fr memory form is not the loaded library's field-element layout (4 x u64 LE, Montgomery R = 2^256) — or the library pair is the other curve's");
       assert!(back[0].into_bigint().0 == [7, 0, 0, 0]);
       // and the other direction: the host's bytes, through the device and back, unchanged
       chk(lasso_upload(ctx, d_fr, host_side.as_ptr() as *const c_void, 64), "lasso_upload");
@@ -128,23 +138,60 @@ unsafe extern "C" fn merlin_challenge(user: *mut c_void, label: *const u8, label
 }
 const MERLIN_VTBL: lasso_transcript_vtbl = lasso_transcript_vtbl { append_message: Some(merlin_append), challenge_bytes: Some(merlin_challenge) };
 // RandomTape<G> { tape: Transcript, .. } (utils/random.rs:9-12): the shim lives inside the crate, `tape` gets `pub(crate)`.
-impl Drop for HipProver {
-  fn drop(&mut self) { unsafe { lasso_host_destroy(self.h) } }
+// ---- the caller's generators --------------------------------------------------------------------------------------------------------
+// `commit` and `prove` take `gens: &SparsePolyCommitmentGens<G>` (densified.rs:78-81, surge.rs:119-125) and so do the shims below: the POINTS the caller holds are
+// uploaded (lasso_host_gens_from_points) — the library derives nothing, so no restatement of arkworks' SHAKE256 -> ChaCha20Rng -> G::rand stream is in the
+// prover's trust base.  Building the device tables costs tens of milliseconds, so they are cached per HipProver under a key taken from the points themselves.
+#[derive(PartialEq, Eq, Clone)]
+struct GensKey { sizes: [usize; 3], probe: Vec<u8> }
+
+/// [gens_n.G[0..n), gens_1.G[0], gens_n.h] as affine points in ark-ec's memory form (= lasso_affine: x then y, Montgomery limbs), one batch inversion
+/// (CurveGroup::normalize_batch, as commitments.rs:87 does before every MSM)
+fn flatten<G: CurveGroup>(g: &PolyCommitmentGens<G>) -> Vec<G::Affine> {
+  let d = &g.gens; // DotProductProofGens { gens_n, gens_1 } (dot_product.rs:139-150)
+  assert!(d.gens_1.G.len() == 1 && d.gens_1.h == d.gens_n.h, "gens_1 / gens_n must share h (split_at, commitments.rs:54-71)");
+  let mut pts: Vec<G> = d.gens_n.G.clone();
+  pts.push(d.gens_1.G[0]);
+  pts.push(d.gens_n.h);
+  G::normalize_batch(&pts)
 }
 
-/// `SparsePolyCommitmentGens::<G>::new(label, c, s, num_memories, log_m)` (surge.rs:32-58) with the generator tables resident on the device.
-/// The Rust-side `SparsePolyCommitmentGens` is still built by the caller for `verify` (it derives the same points: commitments.rs:22-44).
-pub struct HipGens<'a> { g: *mut lasso_host_gens, _p: PhantomData<&'a HipProver> }
-impl<'a> HipGens<'a> {
-  pub fn new(p: &'a HipProver, label: &'static [u8], c: usize, s: usize, num_memories: usize, log_m: usize) -> Self {
-    let l = CString::new(label).unwrap();
+impl HipProver {
+  /// the device-side twin of `gens`, built on first sight.  c, s, log_m: the shape (surge.rs:39-47); num_memories = 0 where the strategy is not known (commit).
+  fn gens_on_device<G: CurveGroup>(&self, gens: &SparsePolyCommitmentGens<G>, c: usize, s: usize, num_memories: usize, log_m: usize) -> *mut lasso_host_gens {
+    // the layout assert that makes passing `&[G::Affine]` as `*const lasso_affine` sound for this G (TE: {x, y}; SW: {x, y, infinity} is 72 bytes and is repacked below)
+    let sets = [flatten(&gens.gens_combined_l_variate), flatten(&gens.gens_combined_log_m_variate), flatten(&gens.gens_derefs)];
+    let raw: Vec<Vec<lasso_affine>> = sets.iter().map(|v| v.iter().map(affine_to_abi::<G>).collect()).collect();
+    // key: the three sizes and the bytes of the first, middle and last two points of every set — generators are random points; two different sets agreeing on all of them do not occur
+    let mut probe = Vec::new();
+    for r in &raw { for &i in &[0, r.len() / 2, r.len() - 2, r.len() - 1] { probe.extend_from_slice(unsafe { std::slice::from_raw_parts(&r[i] as *const lasso_affine as *const u8, 64) }); } }
+    let key = GensKey { sizes: [raw[0].len(), raw[1].len(), raw[2].len()], probe };
+    if let Some((_, g)) = self.gens_cache.borrow().iter().find(|(k, _)| *k == key) { return *g; }
     let mut g = std::ptr::null_mut();
-    chk(unsafe { lasso_host_gens_new(p.h, l.as_ptr(), c, s, num_memories, log_m, &mut g) }, "lasso_host_gens_new");
-    HipGens { g, _p: PhantomData }
+    chk(unsafe { lasso_host_gens_from_points(self.h, c, s, num_memories, log_m, raw[0].as_ptr(), raw[0].len(), raw[1].as_ptr(), raw[1].len(), raw[2].as_ptr(), raw[2].len(), &mut g) },
+        "lasso_host_gens_from_points");
+    self.gens_cache.borrow_mut().push((key, g));
+    g
   }
 }
-impl Drop for HipGens<'_> {
-  fn drop(&mut self) { unsafe { lasso_host_gens_free(self.g) } }
+/// ark-ec affine point -> lasso_affine (x, y as ark-ff's Montgomery limbs); generators are never the point at infinity
+fn affine_to_abi<G: CurveGroup>(p: &G::Affine) -> lasso_affine {
+  use ark_ec::AffineRepr;
+  let (x, y) = p.xy().expect("a generator at infinity");
+  let mut out = lasso_affine { x: [0; 4], y: [0; 4] };
+  // BaseField = Fp256<MontBackend<_, 4>>: `.0` is the BigInt of Montgomery limbs — copied as they lie in memory
+  assert!(std::mem::size_of_val(x) == 32 && std::mem::size_of_val(y) == 32);
+  unsafe {
+    std::ptr::copy_nonoverlapping(x as *const _ as *const u64, out.x.as_mut_ptr(), 4);
+    std::ptr::copy_nonoverlapping(y as *const _ as *const u64, out.y.as_mut_ptr(), 4);
+  }
+  out
+}
+impl Drop for HipProver {
+  fn drop(&mut self) {
+    for (_, g) in self.gens_cache.borrow_mut().drain(..) { unsafe { lasso_host_gens_free(g) } }
+    unsafe { lasso_host_destroy(self.h) }
+  }
 }
 
 /// `DensifiedRepresentation<F, C>` with dim / read / final resident in HBM (densified.rs:8-20: the `pub` fields are only read inside the crate).
@@ -153,20 +200,23 @@ pub struct HipDensified<'a, F: PrimeField, const C: usize> {
   pub s: usize,
   pub log_m: usize,
   pub m: usize,
-  _p: PhantomData<(&'a HipProver, F)>,
+  p: &'a HipProver,
+  _p: PhantomData<F>,
 }
 impl<'a, F: PrimeField, const C: usize> HipDensified<'a, F, C> {
   /// densified.rs:22-75.  `indices` is passed as the reference holds it.  Panics if an index is >= 2^log_m (the reference indexes out of bounds there).
   pub fn from_lookup_indices(p: &'a HipProver, indices: &Vec<[usize; C]>, log_m: usize) -> Self {
     let mut d = std::ptr::null_mut();
     chk(unsafe { lasso_host_densify(p.h, indices.as_ptr() as *const u64, indices.len(), C, log_m, &mut d) }, "lasso_host_densify");
-    HipDensified { d, s: indices.len().next_power_of_two(), log_m, m: 1 << log_m, _p: PhantomData }
+    HipDensified { d, s: indices.len().next_power_of_two(), log_m, m: 1 << log_m, p, _p: PhantomData }
   }
 
   /// densified.rs:78-96.  The library returns `[u64 L1][L1 x 32 B][u64 L2][L2 x 32 B]` = the two `PolyCommitment { C: Vec<G> }` in
   /// ark-serialize's compressed form, which is exactly how `SparsePolynomialCommitment` starts on the wire (surge.rs:60-68); s, log_m, m follow as u64.
-  pub fn commit<G: CurveGroup<ScalarField = F>>(&self, gens: &HipGens) -> SparsePolynomialCommitment<G> {
-    let mut buf = call_bytes(|out, cap, len| unsafe { lasso_host_commit(self.d, gens.g, out, cap, len) }, "lasso_host_commit");
+  /// `gens` is the reference's own argument (densified.rs:78-81): the caller's points, uploaded on first sight (HipProver::gens_on_device)
+  pub fn commit<G: CurveGroup<ScalarField = F>>(&self, gens: &SparsePolyCommitmentGens<G>) -> SparsePolynomialCommitment<G> {
+    let g = self.p.gens_on_device(gens, C, self.s, 0, self.log_m);
+    let mut buf = call_bytes(|out, cap, len| unsafe { lasso_host_commit(self.d, g, out, cap, len) }, "lasso_host_commit");
     for v in [self.s as u64, self.log_m as u64, self.m as u64] { buf.extend_from_slice(&v.to_le_bytes()); }
     SparsePolynomialCommitment::<G>::deserialize_compressed(&buf[..]).expect("commitment bytes")
   }
@@ -183,7 +233,7 @@ pub fn prove_hip<G, const C: usize, const M: usize, S>(
   p: &HipProver,
   dense: &mut HipDensified<G::ScalarField, C>,
   r: &Vec<G::ScalarField>,
-  gens: &HipGens,
+  gens: &SparsePolyCommitmentGens<G>,
   transcript: &mut Transcript,
   random_tape: &mut RandomTape<G>,
 ) -> SparsePolynomialEvaluationProof<G, C, M, S>
@@ -196,13 +246,18 @@ where
 {
   assert_eq!(r.len(), ark_std::log2(dense.s) as usize); // surge.rs:131
   let st = S::descriptor();
+  let g = p.gens_on_device(gens, C, dense.s, S::NUM_MEMORIES, dense.log_m); // the argument list of surge.rs:119-125, one to one: the caller's generators
   let (t_user, tape_user) = (transcript as *mut Transcript as *mut c_void, &mut random_tape.tape as *mut Transcript as *mut c_void);
+  // A retry with a larger buffer would replay the protocol into transcripts that have already advanced, so the buffer is sized from the shape BEFORE the call
+  // (ADVICE r4): a proof holds sqrt-sized point vectors for C + NUM_MEMORIES + 2C... commitments and openings plus O(log^2 s) scalars — bounded by
+  // 32 bytes x (4 sqrt(next_pow2(2 C s)) + 4 sqrt(NUM_MEMORIES s)) + 64 KiB x (C + NUM_MEMORIES) with a wide margin (measured: 0.18 MB at C = 1, s = 2^24; 1.3 MB at C = 16, 2^24).
+  let need = 32 * 8 * (((2 * C * dense.s) as f64).sqrt() as usize + ((S::NUM_MEMORIES * dense.s) as f64).sqrt() as usize + 2) + (1 << 16) * (C + S::NUM_MEMORIES + 2);
   let mut first = true;
-  let bytes = call_bytes(
+  let bytes = call_bytes_sized(
+    need.max(1 << 20),
     |out, cap, len| unsafe {
-      // a retry with a larger buffer would replay the protocol into transcripts that have already advanced: the first buffer is sized so that it cannot happen
-      assert!(first, "proof larger than the buffer sized for it"); first = false;
-      lasso_host_prove_cb(p.h, dense.d, gens.g, &st, r.as_ptr() as *const lasso_fr, r.len(), &MERLIN_VTBL, t_user, &MERLIN_VTBL, tape_user, out, cap, len)
+      assert!(first, "proof larger than the bound computed from its shape: a bug in that bound, not a condition to retry"); first = false;
+      lasso_host_prove_cb(p.h, dense.d, g, &st, r.as_ptr() as *const lasso_fr, r.len(), &MERLIN_VTBL, t_user, &MERLIN_VTBL, tape_user, out, cap, len)
     },
     "lasso_host_prove_cb",
   );
@@ -210,8 +265,9 @@ where
 }
 
 /// calls that return bytes: -2 = buffer too small, *len = needed size
-fn call_bytes(mut f: impl FnMut(*mut u8, usize, *mut usize) -> i32, what: &str) -> Vec<u8> {
-  let mut buf = vec![0u8; 1 << 24]; // 16 MiB: a proof is O(log^2 s + sqrt(s)) elements (600 KB at 2^26 lookups, C = 4); commitments 0.5 MB
+fn call_bytes(f: impl FnMut(*mut u8, usize, *mut usize) -> i32, what: &str) -> Vec<u8> { call_bytes_sized(1 << 24, f, what) }
+fn call_bytes_sized(cap0: usize, mut f: impl FnMut(*mut u8, usize, *mut usize) -> i32, what: &str) -> Vec<u8> {
+  let mut buf = vec![0u8; cap0]; // commitments: 32 bytes per row, 0.5 MB at 2^28 entries
   loop {
     let mut len = 0usize;
     let rc = f(buf.as_mut_ptr(), buf.len(), &mut len);

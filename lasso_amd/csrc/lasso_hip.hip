@@ -89,6 +89,9 @@ struct lasso_bases {
 };
 
 static thread_local std::string g_create_err;
+// contexts alive in this process: a lasso_bases keeps a raw pointer to the context its tables are accounted to, and may outlive it
+static std::mutex g_ctx_mu; static std::vector<lasso_ctx*> g_ctx_live;
+static lasso_ctx* live_or_null(lasso_ctx* c) { std::lock_guard<std::mutex> g(g_ctx_mu); for (lasso_ctx* x : g_ctx_live) if (x == c) return c; return nullptr; }
 
 static int32_t fail(lasso_ctx* c, int32_t code, const std::string& msg) { if (c) c->err = msg; else g_create_err = msg; return code; }
 #define HIPCHK(c, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail((c), e_ == hipErrorOutOfMemory ? LASSO_ERR_OOM : LASSO_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
@@ -111,12 +114,14 @@ static hipError_t dfree(lasso_ctx* c, void* p) {
 
 static int32_t ensure_scratch(lasso_ctx* c, size_t bytes) {
   if (bytes <= c->scratch_cap) return 0;
+  if (c->ahead_active) return fail(c, LASSO_ERR_INVALID, "a launch is waiting on the device for its challenge: only lasso_result_wait and the post of that challenge are legal until then");   // growing would synchronise the stream for the kernel's whole 5 s bail-out and lose the round
   if (c->d_scratch) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, dfree(c, c->d_scratch)); c->d_scratch = nullptr; c->scratch_cap = 0; }
   size_t cap = bytes < ((size_t)1 << 22) ? ((size_t)1 << 22) : bytes;
   HIPCHK(c, dmalloc(c, &c->d_scratch, cap)); c->scratch_cap = cap; return 0;
 }
 static int32_t ensure_small(lasso_ctx* c, size_t count) {
   if (count <= c->small_cap) return 0;
+  if (c->ahead_active) return fail(c, LASSO_ERR_INVALID, "a launch is waiting on the device for its challenge: only lasso_result_wait and the post of that challenge are legal until then");   // growing would synchronise the stream for the kernel's whole 5 s bail-out and lose the round
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (c->h_small) (void)hipHostFree(c->h_small);
   c->h_small = nullptr; c->d_small = nullptr; c->small_cap = 0;
@@ -132,6 +137,7 @@ static int32_t ensure_small(lasso_ctx* c, size_t count) {
 }
 static int32_t ensure_big(lasso_ctx* c, size_t count) {
   if (count <= c->big_cap) return 0;
+  if (c->ahead_active) return fail(c, LASSO_ERR_INVALID, "a launch is waiting on the device for its challenge: only lasso_result_wait and the post of that challenge are legal until then");   // growing would synchronise the stream for the kernel's whole 5 s bail-out and lose the round
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (c->d_big) (void)dfree(c, c->d_big);
   if (c->h_big) (void)hipHostFree(c->h_big);
@@ -408,10 +414,11 @@ int32_t lasso_ctx_create_background(int32_t device, int32_t background, lasso_ct
   { const char* v = getenv("LASSO_TAGGED_RESULTS"); c->tagged = !(v && v[0] == '0'); }   // A/B switch: the flag protocol for every hand-off
   { const char* v = getenv("LASSO_SEQ_START"); if (v) c->seq = (uint32_t)strtoul(v, nullptr, 0); }   // tests: start close to the end of a sequence epoch (next_seq)
   c->mail_h = c->h_flag + 32; c->mail_d = c->d_flag + 32;   // 128-byte offset: 16-byte aligned chunks
-  memset(c->mail_h, 0, 48);
+  memset(c->h_flag, 0, 256);   // the flag word, the LT round's "not a bit" word and BOTH mailboxes (hipHostMalloc does not promise zeroed memory: a stale poison tag in the second mailbox ended the first launched-ahead round)
   int32_t rc = ensure_small(c, (size_t)1 << 16); if (rc) { g_create_err = c->err; delete c; return rc; }   // 2 MiB of mapped result buffer: the largest a-vector / row-commitment hand-off without a reallocation
   rc = ensure_scratch(c, (size_t)1 << 22); if (rc) { g_create_err = c->err; delete c; return rc; }
   if (dmalloc(c, (void**)&c->d_gmail, 128) != hipSuccess || hipMemset(c->d_gmail, 0, 128) != hipSuccess) { g_create_err = "gmail alloc"; delete c; return LASSO_ERR_OOM; }
+  { std::lock_guard<std::mutex> g(g_ctx_mu); g_ctx_live.push_back(c); }
   *out = c; return 0;
 }
 // Error recovery: a host that stops between *_tail_begin and the last tail_next (an exception in the prover) leaves a resident kernel waiting for a
@@ -432,6 +439,7 @@ int32_t lasso_abort(lasso_ctx* c) {
 }
 void lasso_ctx_destroy(lasso_ctx* c) {
   if (!c) return;
+  { std::lock_guard<std::mutex> g(g_ctx_mu); for (size_t i = 0; i < g_ctx_live.size(); i++) if (g_ctx_live[i] == c) { g_ctx_live.erase(g_ctx_live.begin() + i); break; } }
   (void)hipSetDevice(c->device);
   if (c->tail_active || c->pending || c->ahead_active) (void)lasso_abort(c);   // never block in the synchronise below for a kernel's 5 s bail-out
   (void)hipStreamSynchronize(c->stream);
@@ -453,23 +461,23 @@ void lasso_ctx_destroy(lasso_ctx* c) {
 const char* lasso_last_error(lasso_ctx* c) { return c ? c->err.c_str() : g_create_err.c_str(); }
 void* lasso_stream(lasso_ctx* c) { return c ? (void*)c->stream : nullptr; }
 int32_t lasso_alloc(lasso_ctx* c, size_t bytes, void** d_out) { REQUIRE(c, d_out); HIPCHK(c, dmalloc(c, d_out, bytes ? bytes : 1)); return 0; }
-int32_t lasso_free(lasso_ctx* c, void* p) { if (!p) return 0; REQUIRE(c, c); HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, dfree(c, p)); return 0; }
+int32_t lasso_free(lasso_ctx* c, void* p) { if (!p) return 0; REQUIRE(c, c && !c->ahead_active); HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, dfree(c, p)); return 0; }
 int32_t lasso_mem_stats(lasso_ctx* c, uint64_t* live_bytes, uint64_t* peak_bytes, int32_t reset_peak) {
   REQUIRE(c, c); std::lock_guard<std::mutex> g(c->mem_mu);
   if (live_bytes) *live_bytes = c->mem_live; if (peak_bytes) *peak_bytes = c->mem_peak; if (reset_peak) c->mem_peak = c->mem_live; return 0;
 }
 int32_t lasso_trim(lasso_ctx* c) {
-  REQUIRE(c, c && !c->pending && !c->tail_active);
+  REQUIRE(c, c && !c->pending && !c->tail_active && !c->ahead_active);
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (c->scratch_cap <= ((size_t)1 << 22)) return 0;
   HIPCHK(c, dfree(c, c->d_scratch)); c->d_scratch = nullptr; c->scratch_cap = 0;
   return ensure_scratch(c, (size_t)1 << 22);
 }
-int32_t lasso_upload(lasso_ctx* c, void* d, const void* s, size_t n) { REQUIRE(c, d && s); HIPCHK(c, hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); return 0; }
-int32_t lasso_download(lasso_ctx* c, void* d, const void* s, size_t n) { REQUIRE(c, d && s); HIPCHK(c, hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); return 0; }
+int32_t lasso_upload(lasso_ctx* c, void* d, const void* s, size_t n) { REQUIRE(c, d && s && !c->ahead_active); HIPCHK(c, hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); return 0; }
+int32_t lasso_download(lasso_ctx* c, void* d, const void* s, size_t n) { REQUIRE(c, d && s && !c->ahead_active); HIPCHK(c, hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); return 0; }
 int32_t lasso_copy(lasso_ctx* c, void* d, const void* s, size_t n) { REQUIRE(c, d && s); ProfScope ps(c, LASSO_K_MISC, 2.0 * n); HIPCHK(c, hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, c->stream)); return 0; }
 int32_t lasso_zero(lasso_ctx* c, void* d, size_t n) { REQUIRE(c, d); HIPCHK(c, hipMemsetAsync(d, 0, n, c->stream)); return 0; }
-int32_t lasso_sync(lasso_ctx* c) { REQUIRE(c, c); HIPCHK(c, hipStreamSynchronize(c->stream)); return 0; }
+int32_t lasso_sync(lasso_ctx* c) { REQUIRE(c, c && !c->ahead_active); HIPCHK(c, hipStreamSynchronize(c->stream)); return 0; }
 
 int32_t lasso_prof_get_large(lasso_ctx* c, int32_t k, uint64_t* launches, double* ms, double* bytes) {
   REQUIRE(c, k >= 0 && k < LASSO_K_COUNT); prof_flush(c);
@@ -1197,7 +1205,7 @@ int32_t lasso_bases_create_opt(lasso_ctx* c, const lasso_affine* points, size_t 
 }
 void lasso_bases_destroy(lasso_ctx* c, lasso_bases* b) {
   if (!b) return; if (c) (void)hipStreamSynchronize(c->stream);
-  lasso_ctx* o = c == b->owner ? c : nullptr;   // the tables' bytes are accounted to the context that built them; a caller that passes another context (or NULL) only loses the bookkeeping
+  lasso_ctx* o = live_or_null(b->owner);   // the tables' bytes are accounted to the context that built them; a caller that passes another context (or NULL) only loses the bookkeeping
   if (b->d_table) (void)dfree(o, b->d_table); if (b->d_mult) (void)dfree(o, b->d_mult); if (b->d_mult8) (void)dfree(o, b->d_mult8);
   for (niels29* t : b->d_tab8) if (t) (void)dfree(o, t);
   delete b;
@@ -1211,10 +1219,11 @@ static const niels29* ensure_tab8(lasso_ctx* c, const lasso_bases* cb, uint32_t 
   if (b->d_tab8[w8]) return b->d_tab8[w8];
   if (b->tab8_failed) return nullptr;
   niels29* t = nullptr;
-  if (dmalloc(b->owner, (void**)&t, (size_t)MSM8_MULTS * b->n * sizeof(niels29)) != hipSuccess) { (void)hipGetLastError(); b->tab8_failed = true; return nullptr; }
+  lasso_ctx* const owner = live_or_null(b->owner);   // accounted to the creating context while it lives, to nobody afterwards
+  if (dmalloc(owner, (void**)&t, (size_t)MSM8_MULTS * b->n * sizeof(niels29)) != hipSuccess) { (void)hipGetLastError(); b->tab8_failed = true; return nullptr; }
   hipLaunchKernelGGL(k_precompute_tab8, dim3((unsigned)((b->n + 63) / 64)), dim3(64), 0, c->stream, (const niels29*)b->d_table, b->n, w8, t);
   // one-time build (~3 ms): waited for, so that another context sharing this bases object can never see the pointer before the table is complete
-  if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { (void)hipGetLastError(); (void)dfree(b->owner, t); b->tab8_failed = true; return nullptr; }
+  if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { (void)hipGetLastError(); (void)dfree(owner, t); b->tab8_failed = true; return nullptr; }
   b->d_tab8[w8] = t;
   return t;
 }

@@ -361,19 +361,36 @@ struct PolyCommitmentGens {
   lasso_bases* bases_slab = nullptr;   // slab mode: the generators G_{j*P + rank}, j < n/P (this rank's columns of every Hyrax row), then Q, h
   bool slab_open = false;              // slab mode: every rank can run its share of the opening's MSMs (agreed at construction)
   PolyCommitmentGens() {}
-  PolyCommitmentGens(const Dev& d, const GenStream& gs, size_t num_vars) : dev(&d) {
-    n = (size_t)1 << (num_vars - num_vars / 2);   // right = ell - ell/2 (eq_poly.rs:40-42)
-    LASSO_REQUIRE(gs.pts.size() >= n + 2);
-    Q = gs.pts[n]; h = gs.pts[n + 1]; Qmul = FixedBase(Q); hmul = FixedBase(h);
+  // From the generator stream of a label (PolyCommitmentGens::new, dense_mlpoly.rs:38-45): the first n + 2 points, normalised with one batch inversion
+  PolyCommitmentGens(const Dev& d, const GenStream& gs, size_t num_vars) {
+    const size_t nn = (size_t)1 << (num_vars - num_vars / 2);   // right = ell - ell/2 (eq_poly.rs:40-42)
+    LASSO_REQUIRE(gs.pts.size() >= nn + 2);
     // affine Montgomery limbs for the ABI, one batch inversion
-    std::vector<fq_t> pre(n + 2); fq_t acc = fq_one();
-    for (size_t i = 0; i < n + 2; i++) { pre[i] = acc; acc = fq_mul(acc, gs.pts[i].p.Z); }
-    fq_t inv = fq_inv(acc); affine.resize(n + 2);
-    for (size_t i = n + 2; i-- > 0;) {
+    std::vector<fq_t> pre(nn + 2); fq_t acc = fq_one();
+    for (size_t i = 0; i < nn + 2; i++) { pre[i] = acc; acc = fq_mul(acc, gs.pts[i].p.Z); }
+    fq_t inv = fq_inv(acc); std::vector<lasso_affine> aff(nn + 2);
+    for (size_t i = nn + 2; i-- > 0;) {
       fq_t zi = fq_mul(inv, pre[i]); inv = fq_mul(inv, gs.pts[i].p.Z);
       fq_t x = fq_to_mont(fq_mul(gs.pts[i].p.X, zi)), y = fq_to_mont(fq_mul(gs.pts[i].p.Y, zi));
-      memcpy(affine[i].x, x.v, 32); memcpy(affine[i].y, y.v, 32);
+      memcpy(aff[i].x, x.v, 32); memcpy(aff[i].y, y.v, 32);
     }
+    init(d, std::move(aff), nn);
+  }
+  // From the CALLER's points — what SparsePolynomialEvaluationProof::prove is handed (surge.rs:119-125 `gens: &SparsePolyCommitmentGens<G>`): the n + 2 points
+  // [gens.gens_n.G[0..n), gens.gens_1.G[0], gens.gens_n.h] of one PolyCommitmentGens (dense_mlpoly.rs:34-45, dot_product.rs:139-150, commitments.rs:15-19), affine, ark-ff's
+  // Montgomery limbs as CurveGroup::normalize_batch yields them (commitments.rs:87).  Nothing is derived: whatever valid points the caller holds are the generators.
+  // num_vars == 0: any power of two (the shim building the object for `commit`, which does not know the strategy's NUM_MEMORIES yet; a wrong size then fails where the reference's
+  // does: at use, batch_commit's assert_eq!(gens_n.n, inputs.len()), commitments.rs:85)
+  PolyCommitmentGens(const Dev& d, const lasso_affine* pts, size_t count, size_t num_vars) {
+    const size_t nn = num_vars ? (size_t)1 << (num_vars - num_vars / 2) : (count >= 3 ? count - 2 : 0);
+    if (!pts || count != nn + 2 || !is_pow2(nn)) throw Error("generators: a polynomial of " + std::to_string(num_vars) + " variables needs " + std::to_string(nn + 2) + " points (G[0.." + std::to_string(nn) + "), gens_1.G[0], h), got " + std::to_string(count));
+    init(d, std::vector<lasso_affine>(pts, pts + count), nn);
+  }
+ private:
+  void init(const Dev& d, std::vector<lasso_affine>&& aff, size_t nn) {
+    dev = &d; n = nn; affine = std::move(aff);
+    auto from_aff = [](const lasso_affine& a) { fq_t x, y; memcpy(x.v, a.x, 32); memcpy(y.v, a.y, 32); return Pt::from_affine_plain(fq_from_mont(x), fq_from_mont(y)); };
+    Q = from_aff(affine[n]); h = from_aff(affine[n + 1]); Qmul = FixedBase(Q); hmul = FixedBase(h);
     // the byte-multiple tables (459 KB per generator, the openings' MSMs at half the additions) only where they are read: not for the full-width set in slab mode (the rank's
     // residue class serves the openings), not at all in capacity mode
     d.chk(lasso_bases_create_opt(d.ctx, affine.data(), n + 2, (!d.comm.sharded() && !d.capacity) ? 1 : 0, &bases), "lasso_bases_create");
@@ -391,20 +408,35 @@ struct PolyCommitmentGens {
       slab_open = true; for (uint8_t v : all) slab_open = slab_open && v;
     }
   }
+ public:
   PolyCommitmentGens(PolyCommitmentGens&& o) noexcept { *this = std::move(o); }
   PolyCommitmentGens& operator=(PolyCommitmentGens&& o) noexcept { std::swap(n, o.n); std::swap(Q, o.Q); std::swap(h, o.h); std::swap(Qmul, o.Qmul); std::swap(hmul, o.hmul); affine.swap(o.affine); std::swap(bases, o.bases); std::swap(bases_slab, o.bases_slab); std::swap(slab_open, o.slab_open); std::swap(dev, o.dev); return *this; }
   ~PolyCommitmentGens() { if (bases && dev) lasso_bases_destroy(dev->ctx, bases); if (bases_slab && dev) lasso_bases_destroy(dev->ctx, bases_slab); }
 };
 struct SparsePolyCommitmentGens {  // surge.rs:25-59
   PolyCommitmentGens gens_combined_l_variate, gens_combined_log_m_variate, gens_derefs;
+  static void num_vars(size_t c, size_t s, size_t num_memories, size_t log_m, size_t& nv_l, size_t& nv_m, size_t& nv_d) {   // surge.rs:39-47
+    nv_l = ceil_log2(next_pow2(2 * c * s)); nv_m = ceil_log2(next_pow2(c)) + log_m; nv_d = ceil_log2(next_pow2(num_memories * s));
+  }
+  // SparsePolyCommitmentGens::new(label, c, s, num_memories, log_m) (surge.rs:32-58): a convenience for callers without generators of their own (C, Python, the bench)
   SparsePolyCommitmentGens(const Dev& d, const char* label, size_t c, size_t s, size_t num_memories, size_t log_m) {
-    size_t nv_l = ceil_log2(next_pow2(2 * c * s)), nv_m = ceil_log2(next_pow2(c)) + log_m, nv_d = ceil_log2(next_pow2(num_memories * s));
+    size_t nv_l, nv_m, nv_d; num_vars(c, s, num_memories, log_m, nv_l, nv_m, nv_d);
     size_t mx = std::max(nv_l, std::max(nv_m, nv_d));
     GenStream gs(label, ((size_t)1 << (mx - mx / 2)) + 2);   // the three sets share one label => one stream, three prefixes
     gens_combined_l_variate = PolyCommitmentGens(d, gs, nv_l);
     gens_combined_log_m_variate = PolyCommitmentGens(d, gs, nv_m);
     gens_derefs = PolyCommitmentGens(d, gs, nv_d);
   }
+  // the caller's generators, set by set (lasso_host_gens_from_points): what `prove` receives in the reference (surge.rs:119-125)
+  SparsePolyCommitmentGens(const Dev& d, size_t c, size_t s, size_t num_memories, size_t log_m, const lasso_affine* l_variate, size_t n_l, const lasso_affine* log_m_variate, size_t n_m,
+                           const lasso_affine* derefs, size_t n_d) {
+    size_t nv_l, nv_m, nv_d; num_vars(c, s, num_memories ? num_memories : 1, log_m, nv_l, nv_m, nv_d);
+    if (!num_memories) nv_d = 0;   // strategy not known yet: the derefs set only has to be a power of two (+ 2)
+    gens_combined_l_variate = PolyCommitmentGens(d, l_variate, n_l, nv_l);
+    gens_combined_log_m_variate = PolyCommitmentGens(d, log_m_variate, n_m, nv_m);
+    gens_derefs = PolyCommitmentGens(d, derefs, n_d, nv_d);
+  }
+  const PolyCommitmentGens& set(int which) const { if (which == 0) return gens_combined_l_variate; if (which == 1) return gens_combined_log_m_variate; if (which == 2) return gens_derefs; throw Error("generator set index must be 0 (l-variate), 1 (log_m-variate) or 2 (derefs)"); }
 };
 
 // ------------------------------------------------------------------ strategies (host side of subtables/*.rs)

@@ -20,6 +20,9 @@ struct lasso_host {
 struct lasso_host_gens {
   lasso_host* owner; std::unique_ptr<SparsePolyCommitmentGens> g;
   lasso_host_gens(lasso_host* h, const char* label, size_t c, size_t s, size_t nm, size_t log_m) : owner(h) { g.reset(new SparsePolyCommitmentGens(h->dev, label, c, s, nm, log_m)); h->retain(); }
+  lasso_host_gens(lasso_host* h, size_t c, size_t s, size_t nm, size_t log_m, const lasso_affine* p1, size_t n1, const lasso_affine* p2, size_t n2, const lasso_affine* p3, size_t n3) : owner(h) {
+    g.reset(new SparsePolyCommitmentGens(h->dev, c, s, nm, log_m, p1, n1, p2, n2, p3, n3)); h->retain();
+  }
   ~lasso_host_gens() { g.reset(); owner->release(); }
 };
 struct lasso_host_dense {
@@ -91,6 +94,18 @@ int32_t lasso_host_set_comm_shm(lasso_host* h, int32_t rank, int32_t world, cons
     return 0;)
 }
 int32_t lasso_host_gens_new(lasso_host* h, const char* label, size_t c, size_t s, size_t nm, size_t log_m, lasso_host_gens** out) { GUARD(*out = new lasso_host_gens(h, label, c, s, nm, log_m); return 0;) }
+int32_t lasso_host_gens_from_points(lasso_host* h, size_t c, size_t s, size_t nm, size_t log_m, const lasso_affine* l_variate, size_t n_l, const lasso_affine* log_m_variate, size_t n_m,
+                                    const lasso_affine* derefs, size_t n_d, lasso_host_gens** out) {
+  GUARD(if (!h || !out) throw Error("lasso_host_gens_from_points: null argument"); *out = new lasso_host_gens(h, c, s, nm, log_m, l_variate, n_l, log_m_variate, n_m, derefs, n_d); return 0;)
+}
+int32_t lasso_host_gens_points(lasso_host_gens* g, int32_t which, lasso_affine* out, size_t cap, size_t* count) {
+  GUARD(
+    if (!g || !count) throw Error("lasso_host_gens_points: null argument");
+    const PolyCommitmentGens& pg = g->g->set(which);
+    *count = pg.affine.size();
+    if (!out || cap < pg.affine.size()) { g_err = "output buffer too small"; return -2; }
+    memcpy(out, pg.affine.data(), pg.affine.size() * sizeof(lasso_affine)); return 0;)
+}
 void lasso_host_gens_free(lasso_host_gens* g) { delete g; }
 int32_t lasso_host_densify(lasso_host* h, const uint64_t* indices, size_t n, size_t c, size_t log_m, lasso_host_dense** out) {
   GUARD(std::unique_ptr<lasso_host_dense> d(new lasso_host_dense(h)); d->d = DensifiedRepresentation::from_lookup_indices(h->dev, indices, n, c, log_m); *out = d.release(); return 0;)

@@ -45,6 +45,8 @@ def declare_prover(lib):
     lib.lasso_host_set_comm.argtypes = [vp, i32, i32, ALLGATHER_FN, vp]
     lib.lasso_host_set_comm_shm.argtypes = [vp, i32, i32, C.c_char_p]
     lib.lasso_host_gens_new.argtypes = [vp, C.c_char_p, sz, sz, sz, sz, C.POINTER(vp)]
+    lib.lasso_host_gens_from_points.argtypes = [vp, sz, sz, sz, sz, vp, sz, vp, sz, vp, sz, C.POINTER(vp)]
+    lib.lasso_host_gens_points.argtypes = [vp, i32, vp, sz, C.POINTER(sz)]
     lib.lasso_host_gens_free.argtypes = [vp]
     lib.lasso_host_densify.argtypes = [vp, vp, sz, sz, sz, C.POINTER(vp)]
     lib.lasso_host_dense_free.argtypes = [vp]
@@ -102,6 +104,25 @@ class HostProver:
         g = C.c_void_p()
         self._chk(self.lib.lasso_host_gens_new(self.h, label, c, s, num_memories, log_m, C.byref(g)))
         return g
+
+    def gens_from_points(self, c, s, num_memories, log_m, l_variate, log_m_variate, derefs):
+        """The caller's generators (surge.rs:119-125 `gens: &SparsePolyCommitmentGens<G>`): three arrays of shape (n + 2, 8) uint64 — affine (x, y) Montgomery limbs in the
+        order G[0..n), gens_1.G[0], h (lasso_host_gens_from_points)."""
+        sets = [np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 8) for a in (l_variate, log_m_variate, derefs)]
+        g = C.c_void_p()
+        args = []
+        for a in sets:
+            args += [a.ctypes.data_as(C.c_void_p), a.shape[0]]
+        self._chk(self.lib.lasso_host_gens_from_points(self.h, c, s, num_memories, log_m, *args, C.byref(g)))
+        return g
+
+    def gens_points(self, gens, which):
+        """the points of generator set `which` (0 l-variate, 1 log_m-variate, 2 derefs) as an (n + 2, 8) uint64 array (lasso_host_gens_points)"""
+        n = C.c_size_t()
+        self.lib.lasso_host_gens_points(gens, which, None, 0, C.byref(n))
+        out = np.empty((n.value, 8), dtype=np.uint64)
+        self._chk(self.lib.lasso_host_gens_points(gens, which, out.ctypes.data_as(C.c_void_p), n.value, C.byref(n)))
+        return out
 
     def densify(self, indices, log_m):
         indices = np.ascontiguousarray(indices, dtype=np.uint64)

@@ -266,9 +266,28 @@ KAT(e2e_prove_2d_xor) return e2e(STRAT_XOR, 2, 16, 0, 32); KAT_END
 KAT(e2e_prove_2d_or) return e2e(STRAT_OR, 2, 16, 0, 8); KAT_END
 KAT(e2e_prove_spark_unconfirmed) return e2e(STRAT_SPARK_UNCONFIRMED, 3, 16, 0, 16); KAT_END   // the same acceptance criterion for the restated strategy (not a reference test)
 
+// rand 0.8 `StdRng` value stability (rand/src/rngs/std.rs test_stdrng_construction) — the seed is ark_std::test_rng()'s (ark-std 0.4 rand_helper.rs), the source of the
+// harness's indices and points (benches/bench.rs:13-34) and of RandomTape's init scalar (utils/random.rs:17): first next_u64 and, through SeedableRng::from_rng
+// (fill_bytes of 32 = the next eight words), the second generator's first next_u64.  Published by the rand crate, not derived here.
+KAT(rand_stdrng_value_stability)
+  ChaChaRng r0 = test_rng();
+  CHECK(r0.next_u64() == 10719222850664546238ull, 1);
+  uint8_t seed[32]; for (int i = 0; i < 8; i++) { const uint32_t w = r0.next_u32(); for (int k = 0; k < 4; k++) seed[4 * i + k] = (uint8_t)(w >> (8 * k)); }
+  ChaChaRng r1(seed, 12);
+  CHECK(r1.next_u64() == 14064965282130556830ull, 2);
+KAT_END
+// rand_chacha 0.3 test_chacha_true_values_a (src/chacha.rs): ChaCha20Rng::from_seed([0; 32]) — the generator stream's RNG (commitments.rs:31) — first two blocks
+KAT(rand_chacha20_true_values_a)
+  const uint32_t e1[16] = {0xade0b876, 0x903df1a0, 0xe56a5d40, 0x28bd8653, 0xb819d2bd, 0x1aed8da0, 0xccef36a8, 0xc70d778b, 0x7c5941da, 0x8d485751, 0x3fe02477, 0x374ad8b8, 0xf4b8436a, 0x1ca11815, 0x69b687c3, 0x8665eeb2};
+  const uint32_t e2[16] = {0xbee7079f, 0x7a385155, 0x7c97ba98, 0x0d082d73, 0xa0290fcb, 0x6965e348, 0x3e53c612, 0xed7aee32, 0x7621b729, 0x434ee69c, 0xb03371d5, 0xd539d874, 0x281fed31, 0x45fb0a51, 0x1f0ae1ac, 0x6f4d794b};
+  const uint8_t z[32] = {0}; ChaChaRng r(z, 20);
+  for (int i = 0; i < 16; i++) CHECK(r.next_u32() == e1[i], 1);
+  for (int i = 0; i < 16; i++) CHECK(r.next_u32() == e2[i], 2);
+KAT_END
+
 extern "C" const char* orc_kat_names() {
   return "poly_evaluation_28,poly_evaluation_const8,eq_evals_vs_naive,unipoly_quad,unipoly_cubic,gauss,split_bits,grand_product_24,"
          "sumcheck_scripted_313,memory_checking_multiset,and_table,and_merged_poly,or_table,xor_table,lt_table,range_table,"
          "poly_commit_open_verify,dot_product_log,e2e_prove_4d_lt,e2e_prove_4d_lt_big_s,e2e_prove_4d_and,e2e_prove_3d_range,"
-         "e2e_prove_1d_and_s64,e2e_prove_2d_xor,e2e_prove_2d_or,spark_unconfirmed,e2e_prove_spark_unconfirmed";
+         "e2e_prove_1d_and_s64,e2e_prove_2d_xor,e2e_prove_2d_or,spark_unconfirmed,e2e_prove_spark_unconfirmed,rand_stdrng_value_stability,rand_chacha20_true_values_a";
 }

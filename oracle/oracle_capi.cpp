@@ -110,6 +110,22 @@ void* orc_session_new(int kind, size_t C, size_t M, size_t log_r, const uint64_t
   } catch (const std::exception& e) { g_err = e.what(); return nullptr; }
 }
 void orc_session_free(void* s) { delete (Session*)s; }
+// Replace the session's generators by CALLER-SUPPLIED points — `prove` and `commit` take `gens: &SparsePolyCommitmentGens<G>` (surge.rs:119-125, densified.rs:78-81), whatever
+// points the caller holds.  Each set = n + 2 affine points, canonical (x, y) as 8 u64: gens_n.G[0..n), gens_1.G[0], h  (dense_mlpoly.rs:34-45, dot_product.rs:139-150,
+// commitments.rs:15-19 / :54-71: both MultiCommitGens of a DotProductProofGens share h).  Sizes are checked against surge.rs:39-47.  The checker for lasso_host_gens_from_points.
+int orc_session_set_gens(void* sv, const u64* l_xy, size_t n_l, const u64* m_xy, size_t n_m, const u64* d_xy, size_t n_d) { GUARD(
+  Session* se = (Session*)sv;
+  auto mk = [](const PolyCommitmentGens& like, const u64* xy, size_t cnt) {
+    const size_t n = like.gens.n; if (cnt != n + 2) throw std::runtime_error("orc_session_set_gens: a set needs n + 2 points");
+    PolyCommitmentGens g; g.gens.n = n; g.gens.gens_n.n = n; g.gens.gens_1.n = 1;
+    for (size_t i = 0; i < n; i++) g.gens.gens_n.G.push_back(pt_from_canon(xy + 8 * i));
+    g.gens.gens_1.G.push_back(pt_from_canon(xy + 8 * n));
+    g.gens.gens_n.h = pt_from_canon(xy + 8 * (n + 1)); g.gens.gens_1.h = g.gens.gens_n.h; return g; };
+  SparsePolyCommitmentGens ng;
+  ng.gens_combined_l_variate = mk(se->gens.gens_combined_l_variate, l_xy, n_l);
+  ng.gens_combined_log_m_variate = mk(se->gens.gens_combined_log_m_variate, m_xy, n_m);
+  ng.gens_derefs = mk(se->gens.gens_derefs, d_xy, n_d);
+  se->gens = ng; se->committed = false; return 0; ) }
 // commitment bytes: [u64 n1][n1 x 32B compressed][u64 n2][n2 x 32B]
 int orc_session_commit(void* sv, uint8_t* out, size_t cap, size_t* len) { GUARD(
   Session* se = (Session*)sv;
