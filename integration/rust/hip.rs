@@ -174,7 +174,7 @@ impl HipProver {
     g
   }
 }
-/// ark-ec affine point -> lasso_affine (x, y as ark-ff's Montgomery limbs); generators are never the point at infinity
+/// ark-ec affine point -> `lasso_affine`: x, y as ark-ff's Montgomery limbs; generators are never the point at infinity
 fn affine_to_abi<G: CurveGroup>(p: &G::Affine) -> lasso_affine {
   use ark_ec::AffineRepr;
   let (x, y) = p.xy().expect("a generator at infinity");
