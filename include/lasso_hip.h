@@ -186,6 +186,25 @@ int32_t lasso_sumcheck_cubic_tail_begin(lasso_ctx* ctx, lasso_fr* const* d_A, la
  * E = *scale * EqPolynomial(point[0..ell)).evals(), 2^ell = n/2 <= capacity, from the point (two factor tables of <= 32 entries in LDS, one product per use). */
 int32_t lasso_sumcheck_cubic_tail_begin_eq(lasso_ctx* ctx, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, size_t n, const lasso_fr* point, uint32_t ell, const lasso_fr* scale);
 /* largest q the two *_tail_begin calls accept (512: one workgroup per circuit holds its arrays in 147 KB of the CU's LDS) */
+/* The resident tail stops EARLY and hands its arrays to the host (round 5): the next lasso_sumcheck_cubic_tail_begin* ends when the arrays are down to m_stop elements each
+ * (a power of two, 2 <= m_stop <= 128, smaller than the arrays at the tail's first round) and its LAST pending result is the arrays instead of the heads:
+ * 2 * ncirc * m_stop values, A_0[0..m_stop), A_1[..], .., B_0[..], ..  A resident turn costs ~7 us of round trip whatever the size; the last log2(m_stop) rounds of a layer are a
+ * few dozen field products, which the host does in less (prover.hpp cubic_rounds: sumcheck.rs:49-124 on the handed-over arrays — the same field elements).  m_stop <= 1: the heads. */
+int32_t lasso_tail_handover_next(lasso_ctx* ctx, uint32_t m_stop);
+/* Sumcheck rounds LAUNCHED AHEAD of their challenge (round 5; lasso_bullet_round_ahead is the same device for the openings).  Between two launched rounds the host turn was ~12 us of
+ * which ~1.5 us Fiat-Shamir: the rest is the launch and its dispatch.  So round j + 1 is enqueued behind round j BEFORE round j's sums are back:
+ *     lasso_sumcheck_cubic_eqw2_begin_ahead(A, B, ncirc, d_E, n)   — the round lasso_sumcheck_cubic_eqw2_begin(.., r) would run, minus r; legal while a result is pending
+ *     lasso_result_wait(..)                                          — round j's sums; transcript; challenge r_j
+ *     lasso_challenge_post(&r_j)                                     — the waiting kernel proceeds; its sums are now the pending result
+ * The kernel (k_cubic_eqw_fused<.., AHEAD>) waits on the device: workgroup 0 polls the host-mapped mailbox, republishes the scalar in device memory, all workgroups go on.  It ends
+ * WITHOUT a result on lasso_abort's poison tag or after 5 s without a post (then lasso_result_wait fails: nothing hangs).  Between begin_ahead and the post ONLY lasso_result_wait
+ * is legal on the context: entry points that would synchronise the stream (lasso_free / upload / download / sync / trim, buffer growth) return LASSO_ERR_INVALID instead of blocking
+ * behind the waiting kernel.  Streaming two-sum rounds only (n / 4 > 64); LASSO_ERR_UNSUPPORTED otherwise.  lasso_rounds_ahead_ok: 1 unless LASSO_ROUNDS_AHEAD=0.
+ * lasso_sumcheck_cubic_tail_begin_ahead: the resident tail enqueued ahead of the challenge it binds first (n = 4q); the first lasso_sumcheck_cubic_tail_next posts it. */
+int32_t lasso_rounds_ahead_ok(lasso_ctx* ctx);
+int32_t lasso_sumcheck_cubic_eqw2_begin_ahead(lasso_ctx* ctx, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n);
+int32_t lasso_challenge_post(lasso_ctx* ctx, const lasso_fr* r);
+int32_t lasso_sumcheck_cubic_tail_begin_ahead(lasso_ctx* ctx, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n);
 uint32_t lasso_sumcheck_tail_capacity(void);
 int32_t lasso_sumcheck_cubic_tail_next(lasso_ctx* ctx, const lasso_fr* r);
 /* The resident tail of the primary sumcheck for the linear strategies (the rounds lasso_sumcheck_linear_eqw_round[_fused] serve one launch at a time):
@@ -238,6 +257,9 @@ int32_t lasso_multi_dot(lasso_ctx* ctx, const lasso_fr* const* d_polys, uint32_t
 /* out[p] = d_polys[p][0] for k polynomials — the final claims a sumcheck hands back after the last bind
  * (src/subprotocols/sumcheck.rs:126-132 `poly_A_vec_par[i][0]`, :257 `poly[0]`) in one transfer. */
 int32_t lasso_read_heads(lasso_ctx* ctx, const lasso_fr* const* d_polys, uint32_t k, lasso_fr* out);
+/* out[i * count + j] = d_polys[i][j], j < count: short runs of k arrays (k * count <= 16384) through the mapped result buffer — the tops of the product trees, whose
+ * layers of up to 32 elements the host proves without the device (lasso_amd/host/prover.hpp host_layers) */
+int32_t lasso_read_runs(lasso_ctx* ctx, const lasso_fr* const* d_polys, uint32_t k, uint32_t count, lasso_fr* out);
 /* GrandProductCircuit::new (src/subprotocols/grand_product.rs:38-58).  d_tree holds 2n-2 elements: layer 0 (the n
  * inputs, left half | right half) at [0,n) must be filled by the caller; layer k (n/2^k elements) follows layer k-1
  * and is computed here as layer_k[i] = left_{k-1}[i] * right_{k-1}[i]. */

@@ -68,6 +68,12 @@ def declare(lib):
         "lasso_combine_claim": (i32, [vp, P(Strategy), P(vp), vp, sz, vp]),
         "lasso_multi_dot": (i32, [vp, P(vp), u32, vp, sz, vp]),
         "lasso_read_heads": (i32, [vp, P(vp), u32, vp]),
+        "lasso_read_runs": (i32, [vp, P(vp), u32, u32, vp]),
+        "lasso_tail_handover_next": (i32, [vp, u32]),
+        "lasso_rounds_ahead_ok": (i32, [vp]),
+        "lasso_sumcheck_cubic_eqw2_begin_ahead": (i32, [vp, P(vp), P(vp), u32, vp, sz]),
+        "lasso_challenge_post": (i32, [vp, vp]),
+        "lasso_sumcheck_cubic_tail_begin_ahead": (i32, [vp, P(vp), P(vp), u32, vp, sz]),
         "lasso_gp_build": (i32, [vp, vp, sz]),
         "lasso_fingerprint_ops": (i32, [vp, vp, vp, vp, sz, vp, vp, vp, vp]),
         "lasso_fingerprint_ops_gp": (i32, [vp, vp, vp, vp, sz, vp, vp, vp, vp]),

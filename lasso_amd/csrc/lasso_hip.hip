@@ -64,6 +64,10 @@ struct lasso_ctx {
   // mailboxes mail_h, mail_h + 12), after which it is an ordinary pending result.  d_gmail: 18 words of device memory, workgroup (0, 0)'s republication of the two scalars
   bool ahead_active = false; uint32_t ahead_seq = 0; uint32_t* d_gmail = nullptr;
   bool tail_active = false; uint32_t tail_seq0 = 0, tail_turn = 0, tail_turns = 0; size_t tail_count = 0, tail_final = 0;   // resident sumcheck-tail kernel (k_cubic_tail); its mailbox = h_flag + 32 (bytes 128..163)
+  bool tail_unstarted = false;    // the resident tail was launched AHEAD of its first challenge (lasso_sumcheck_cubic_tail_begin_ahead): the first lasso_sumcheck_cubic_tail_next starts it
+  uint32_t handover_next = 0;     // lasso_tail_handover_next: the next cubic tail stops at this many elements per array and hands the arrays over
+  // a sumcheck round launched ahead (lasso_sumcheck_cubic_eqw2_begin_ahead): what lasso_challenge_post turns into the pending result
+  size_t ahead_count = 0; bool ahead_tagged = false; uint32_t ahead_groups = 1, ahead_K = 0; bool ahead_bullet = false;
   uint32_t prof_mask = 0;   // bit k set = kernel family k is bracketed with events
   std::vector<EventPair> events; size_t events_used = 0;
   uint64_t prof_launches[LASSO_K_COUNT] = {0}; double prof_ms[LASSO_K_COUNT] = {0}; double prof_bytes[LASSO_K_COUNT] = {0};
@@ -431,7 +435,7 @@ int32_t lasso_abort(lasso_ctx* c) {
   (void)hipStreamSynchronize(c->stream);   // bounded: every device-side wait has the poison check and a wall-clock bail-out
   (void)hipGetLastError();
   mail_chunks(c->mail_h + 12, 0, zero8); post_mail(c, 0, zero8);
-  c->ahead_active = false;
+  c->ahead_active = false; c->ahead_bullet = false; c->tail_unstarted = false; c->handover_next = 0;
   c->tail_active = false; c->pending = false; c->defer_next = false; c->events_used = 0; c->pending_groups = 1; c->pending_K = 0;
   HIPCHK(c, hipMemsetAsync(c->d_counters, 0, (LASSO_MAX_PTRS + 40) * 4, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -603,8 +607,9 @@ static unsigned direct_nx_max() { static const unsigned v = [] { const char* e =
   fr_t* const r_out = c->tagged ? (fr_t*)c->d_tag : c->d_small; uint32_t* const r_flag = direct ? LASSO_TAGGED_DIRECT : c->tagged ? LASSO_TAGGED : c->d_flag
 extern "C++" {
 template <class TM, class TP>   // pointer tables sized for the number of circuits (MutPtrTable8 / PtrTable8 up to 8: 64 bytes of kernel arguments each instead of 1088)
-static int32_t cubic_eqw_launch_t(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n, const lasso_fr* r, int NT, uint32_t* seq_out, const EqInline* eqi, uint32_t* groups_out) {
+static int32_t cubic_eqw_launch_t(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n, const lasso_fr* r, int NT, uint32_t* seq_out, const EqInline* eqi, uint32_t* groups_out, bool ahead = false) {
   if (groups_out) *groups_out = 1;
+  if (ahead && (NT != 2 || n / 4 <= CUBIC_SMALL_Q)) return fail(c, LASSO_ERR_UNSUPPORTED, "a round launched ahead of its challenge: two-sum streaming rounds only (more than 64 index quadruples per circuit)");
   TM A, B; for (uint32_t i = 0; i < ncirc; i++) { REQUIRE(c, d_A[i] && d_B[i]); A.p[i] = (fr_t*)d_A[i]; B.p[i] = (fr_t*)d_B[i]; }
   int32_t rc = ensure_small(c, (size_t)ncirc * 3); if (rc) return rc;
   const uint32_t seq = next_seq(c); *seq_out = seq;
@@ -628,6 +633,14 @@ static int32_t cubic_eqw_launch_t(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* 
         else hipLaunchKernelGGL((k_cubic_eqw_lb<2, false, TP, EqNone>), dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, Ac, Bc, nx, ny, (const fr_t*)d_E, half, (fr_t*)c->d_scratch, c->d_counters, r_out, r_flag, seq, pipe, EqNone(), (fr_t*)nullptr);
       }
     }
+  } else if (ahead) {
+    const size_t q = n / 4;
+    ProfScope ps(c, LASSO_K_CUBIC, 48.0 * n * (2.0 * ncirc + 1.0));
+    const unsigned ny = ncirc, nx = grid_for(q, cubic_nx_cap(ny));
+    rc = ensure_scratch(c, (size_t)nx * ny * 3 * sizeof(fr_t)); if (rc) return rc;
+    CUBIC_RESULT_ARGS(nx);
+    if (cubic_wide()) hipLaunchKernelGGL((k_cubic_eqw_fused<2, true, TM, true>), dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, A, B, nx, ny, (const fr_t*)d_E, q, fr_zero(), (fr_t*)c->d_scratch, c->d_counters, r_out, r_flag, seq, (const uint32_t*)c->mail_d, c->d_gmail);
+    else hipLaunchKernelGGL((k_cubic_eqw_fused<2, false, TM, true>), dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, A, B, nx, ny, (const fr_t*)d_E, q, fr_zero(), (fr_t*)c->d_scratch, c->d_counters, r_out, r_flag, seq, (const uint32_t*)c->mail_d, c->d_gmail);
   } else {
     const size_t q = n / 4;
     // bind: read 32n + write 16n per polynomial (SURVEY.md §8d's "fused bind+next-eval" over the reference's 2*ncirc + 1 polynomials)
@@ -648,8 +661,8 @@ static int32_t cubic_eqw_launch_t(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* 
   return 0;
 }
 }   // extern "C++"
-static int32_t cubic_eqw_launch(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n, const lasso_fr* r, int NT, uint32_t* seq_out, const EqInline* eqi = nullptr, uint32_t* groups_out = nullptr) {
-  return ncirc <= 8 ? cubic_eqw_launch_t<MutPtrTable8, PtrTable8>(c, d_A, d_B, ncirc, d_E, n, r, NT, seq_out, eqi, groups_out) : cubic_eqw_launch_t<MutPtrTable, PtrTable>(c, d_A, d_B, ncirc, d_E, n, r, NT, seq_out, eqi, groups_out);
+static int32_t cubic_eqw_launch(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n, const lasso_fr* r, int NT, uint32_t* seq_out, const EqInline* eqi = nullptr, uint32_t* groups_out = nullptr, bool ahead = false) {
+  return ncirc <= 8 ? cubic_eqw_launch_t<MutPtrTable8, PtrTable8>(c, d_A, d_B, ncirc, d_E, n, r, NT, seq_out, eqi, groups_out, ahead) : cubic_eqw_launch_t<MutPtrTable, PtrTable>(c, d_A, d_B, ncirc, d_E, n, r, NT, seq_out, eqi, groups_out, ahead);
 }
 int32_t lasso_sumcheck_cubic_eqw_round(lasso_ctx* c, const lasso_fr* const* d_A, const lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n, lasso_fr* out) {
   REQUIRE(c, d_A && d_B && d_E && out && ncirc >= 1 && ncirc <= LASSO_MAX_PTRS && n >= 2 && (n & (n - 1)) == 0);
@@ -669,6 +682,28 @@ int32_t lasso_sumcheck_cubic_eqw2_begin(lasso_ctx* c, lasso_fr* const* d_A, lass
   c->pending = true; c->pending_seq = seq; c->pending_count = (size_t)ncirc * 2; c->pending_tagged = c->tagged; c->pending_groups = groups; c->pending_K = 2;
   return 0;
 }
+// The same round enqueued AHEAD of its challenge (k_cubic_eqw_fused<.., AHEAD>): legal while the previous round's result is still pending; the kernel waits on the device for
+// lasso_challenge_post, which turns the launch into the context's pending result.  Only streaming two-sum rounds (n / 4 > 64); LASSO_ERR_UNSUPPORTED otherwise (the caller launches
+// the ordinary round once it has the challenge).
+int32_t lasso_sumcheck_cubic_eqw2_begin_ahead(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n) {
+  REQUIRE(c, d_A && d_B && d_E && ncirc >= 1 && ncirc <= LASSO_MAX_PTRS && n >= 4 && (n & (n - 1)) == 0 && !c->ahead_active && !c->tail_active && !c->defer_next);
+  if (n / 4 <= CUBIC_SMALL_Q) return fail(c, LASSO_ERR_UNSUPPORTED, "lasso_sumcheck_cubic_eqw2_begin_ahead: streaming rounds only");
+  // everything that could synchronise the stream happens here, BEFORE the launch that waits
+  { const unsigned nx = grid_for(n / 4, cubic_nx_cap(ncirc)); int32_t rc0 = ensure_small(c, (size_t)ncirc * 3 * (nx <= direct_nx_max() ? nx : 1)); if (rc0) return rc0; rc0 = ensure_scratch(c, (size_t)nx * ncirc * 3 * sizeof(fr_t)); if (rc0) return rc0; }
+  uint32_t seq, groups; int32_t rc = cubic_eqw_launch(c, d_A, d_B, ncirc, d_E, n, nullptr, 2, &seq, nullptr, &groups, true); if (rc) return rc;
+  c->ahead_active = true; c->ahead_bullet = false; c->ahead_seq = seq; c->ahead_count = (size_t)ncirc * 2; c->ahead_tagged = c->tagged; c->ahead_groups = groups; c->ahead_K = 2;
+  return 0;
+}
+// the challenge of the round launched ahead: after this call its sums are the context's pending result (lasso_result_wait)
+int32_t lasso_challenge_post(lasso_ctx* c, const lasso_fr* r) {
+  REQUIRE(c, r && c->ahead_active && !c->ahead_bullet && !c->pending);
+  post_mail(c, c->ahead_seq, (const uint32_t*)r);
+  c->ahead_active = false;
+  c->pending = true; c->pending_seq = c->ahead_seq; c->pending_count = c->ahead_count; c->pending_tagged = c->ahead_tagged; c->pending_groups = c->ahead_groups; c->pending_K = c->ahead_K;
+  return 0;
+}
+// 1 when rounds may be launched ahead on this context (LASSO_ROUNDS_AHEAD=0: A/B switch)
+int32_t lasso_rounds_ahead_ok(lasso_ctx* c) { static const bool off = [] { const char* v = getenv("LASSO_ROUNDS_AHEAD"); return v && v[0] == '0'; }(); return c && !off && c->mail_d && c->d_gmail ? 1 : 0; }
 // The next entry point that hands its result over through the mapped buffer (the sumcheck rounds, the few-row MSMs, lasso_bullet_round ...)
 // returns right after its launch; its `out` argument is ignored and lasso_result_wait(ctx, out, count) delivers the same values
 // (count in field-element units: a point is 4).  Lets the host absorb transcript data or do scalar work while the device computes.
@@ -678,10 +713,10 @@ int32_t lasso_sumcheck_cubic_eqw2_begin(lasso_ctx* c, lasso_fr* const* d_A, lass
 // result of the first of the log2(2q) rounds is pending afterwards (lasso_result_wait, 2*ncirc values: (q(0), q_inf) per circuit).
 // next: posts a challenge; pending: the next round's sums, or after the last round the 2*ncirc bound heads (A_0.., B_0..).
 // The arrays in device memory are NOT updated (nothing reads a layer's arrays after its sumcheck).
-static int32_t cubic_tail_begin_impl(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n, const lasso_fr* r, const EqInline* eqi);
+static int32_t cubic_tail_begin_impl(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n, const lasso_fr* r, const EqInline* eqi, bool ahead);
 int32_t lasso_sumcheck_cubic_tail_begin(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n, const lasso_fr* r) {
   REQUIRE(c, d_E);
-  return cubic_tail_begin_impl(c, d_A, d_B, ncirc, d_E, n, r, nullptr);
+  return cubic_tail_begin_impl(c, d_A, d_B, ncirc, d_E, n, r, nullptr, false);
 }
 static bool make_eq_inline(const lasso_fr* point, uint32_t ell, const lasso_fr* scale, EqInline& Q) {
   if (ell > 14 || (ell && !point)) return false;
@@ -702,37 +737,51 @@ int32_t lasso_sumcheck_cubic_eqw2_begin_eq(lasso_ctx* c, lasso_fr* const* d_A, l
 int32_t lasso_sumcheck_cubic_tail_begin_eq(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, size_t n, const lasso_fr* point, uint32_t ell, const lasso_fr* scale) {
   REQUIRE(c, n >= 2 && ((size_t)1 << ell) == n / 2 && ell <= 9);
   EqInline Q; if (!make_eq_inline(point, ell, scale, Q)) return fail(c, LASSO_ERR_INVALID, "lasso_sumcheck_cubic_tail_begin_eq: bad point");
-  return cubic_tail_begin_impl(c, d_A, d_B, ncirc, nullptr, n, nullptr, &Q);
+  return cubic_tail_begin_impl(c, d_A, d_B, ncirc, nullptr, n, nullptr, &Q, false);
 }
 extern "C++" {
 template <class TM>
-static int32_t cubic_tail_begin_t(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n, const lasso_fr* r, const EqInline* eqi) {
-  REQUIRE(c, d_A && d_B && (d_E || eqi) && ncirc >= 1 && ncirc <= LASSO_MAX_PTRS && n >= (r ? 4u : 2u) && (n & (n - 1)) == 0 && !c->pending && !c->tail_active && !c->defer_next);
-  const size_t q = r ? n / 4 : n / 2;
-  REQUIRE(c, q >= 1 && q <= CUBIC_TAIL_Q);
+static int32_t cubic_tail_begin_t(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n, const lasso_fr* r, const EqInline* eqi, bool ahead) {
+  const uint32_t m_stop = c->handover_next ? c->handover_next : 1u; c->handover_next = 0;   // consumed by this call, whatever its outcome
+  REQUIRE(c, d_A && d_B && (d_E || eqi) && ncirc >= 1 && ncirc <= LASSO_MAX_PTRS && n >= ((r || ahead) ? 4u : 2u) && (n & (n - 1)) == 0 && (ahead || !c->pending) && !c->tail_active && !c->defer_next && !c->ahead_active);
+  const size_t q = (r || ahead) ? n / 4 : n / 2;
+  REQUIRE(c, q >= 1 && q <= CUBIC_TAIL_Q && (m_stop & (m_stop - 1)) == 0 && m_stop <= 128 && 2 * q > m_stop);   // at least one round of sums before the arrays are handed over
   TM A, B; for (uint32_t i = 0; i < ncirc; i++) { REQUIRE(c, d_A[i] && d_B[i]); A.p[i] = (fr_t*)d_A[i]; B.p[i] = (fr_t*)d_B[i]; }
-  int32_t rc = ensure_small(c, (size_t)ncirc * 3); if (rc) return rc;
-  uint32_t turns = 0; while (((size_t)1 << turns) < 2 * q) turns++;   // rounds of sums; one more publication carries the heads
+  int32_t rc = ensure_small(c, (size_t)ncirc * 2 * (m_stop > 2 ? m_stop : 2)); if (rc) return rc;
+  uint32_t turns = 0; while (((size_t)m_stop << turns) < 2 * q) turns++;   // rounds of sums; one more publication carries the heads (or the arrays of m_stop elements)
   const uint32_t seq0 = next_seq(c, turns + 1);
   // workgroup = capacity: 256 threads / 74 KB of LDS up to 256 indices per circuit, 512 threads / 147 KB above
-#define LAUNCH_CTAIL(B_, Q_, I_, TE_, R_, EQ_) hipLaunchKernelGGL((k_cubic_tail<B_, Q_, I_, TM, TE_>), dim3(ncirc), dim3(Q_), 0, c->stream, A, B, (const fr_t*)d_E, (uint32_t)q, R_, (const uint32_t*)c->mail_d, c->d_counters, RES(c), seq0, EQ_)
+#define LAUNCH_CTAIL(B_, Q_, I_, TE_, R_, EQ_) hipLaunchKernelGGL((k_cubic_tail<B_, Q_, I_, TM, TE_>), dim3(ncirc), dim3(Q_), 0, c->stream, A, B, (const fr_t*)d_E, (uint32_t)q, R_, (const uint32_t*)c->mail_d, c->d_counters, RES(c), seq0, EQ_, m_stop, ahead ? 1u : 0u)
   if (eqi) { if (q <= 256) LAUNCH_CTAIL(false, 256, true, EqInline, fr_zero(), *eqi); else LAUNCH_CTAIL(false, 512, true, EqInline, fr_zero(), *eqi); }
-  else if (q <= 256) { if (r) LAUNCH_CTAIL(true, 256, false, EqNone, to_fr(r), EqNone()); else LAUNCH_CTAIL(false, 256, false, EqNone, fr_zero(), EqNone()); }
-  else { if (r) LAUNCH_CTAIL(true, 512, false, EqNone, to_fr(r), EqNone()); else LAUNCH_CTAIL(false, 512, false, EqNone, fr_zero(), EqNone()); }
+  else if (q <= 256) { if (r || ahead) LAUNCH_CTAIL(true, 256, false, EqNone, r ? to_fr(r) : fr_zero(), EqNone()); else LAUNCH_CTAIL(false, 256, false, EqNone, fr_zero(), EqNone()); }
+  else { if (r || ahead) LAUNCH_CTAIL(true, 512, false, EqNone, r ? to_fr(r) : fr_zero(), EqNone()); else LAUNCH_CTAIL(false, 512, false, EqNone, fr_zero(), EqNone()); }
   HIPCHK(c, hipGetLastError());
-  c->tail_active = true; c->tail_seq0 = seq0; c->tail_turn = 0; c->tail_turns = turns; c->tail_count = (size_t)ncirc * 2; c->tail_final = (size_t)ncirc * 2;
+  c->tail_active = true; c->tail_seq0 = seq0; c->tail_turn = 0; c->tail_turns = turns; c->tail_count = (size_t)ncirc * 2; c->tail_final = (size_t)ncirc * 2 * m_stop;
+  if (ahead) { c->tail_unstarted = true; return 0; }   // nothing is pending until the first challenge has been posted (lasso_sumcheck_cubic_tail_next)
   c->pending = true; c->pending_seq = seq0; c->pending_count = c->tail_count; c->pending_tagged = c->tagged;
   return 0;
 }
 }   // extern "C++"
-static int32_t cubic_tail_begin_impl(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n, const lasso_fr* r, const EqInline* eqi) {
-  return ncirc <= 8 ? cubic_tail_begin_t<MutPtrTable8>(c, d_A, d_B, ncirc, d_E, n, r, eqi) : cubic_tail_begin_t<MutPtrTable>(c, d_A, d_B, ncirc, d_E, n, r, eqi);
+static int32_t cubic_tail_begin_impl(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n, const lasso_fr* r, const EqInline* eqi, bool ahead) {
+  return ncirc <= 8 ? cubic_tail_begin_t<MutPtrTable8>(c, d_A, d_B, ncirc, d_E, n, r, eqi, ahead) : cubic_tail_begin_t<MutPtrTable>(c, d_A, d_B, ncirc, d_E, n, r, eqi, ahead);
+}
+// The resident tail enqueued AHEAD of the challenge it binds first (n = 4q): legal while the previous round's result is pending; the first lasso_sumcheck_cubic_tail_next
+// posts that challenge and makes the first round's sums the pending result.
+int32_t lasso_sumcheck_cubic_tail_begin_ahead(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n) {
+  REQUIRE(c, d_E);
+  return cubic_tail_begin_impl(c, d_A, d_B, ncirc, d_E, n, nullptr, nullptr, true);
+}
+// The next lasso_sumcheck_cubic_tail_begin* stops when its arrays are down to m_stop elements each (a power of two, 2 <= m_stop <= 128, below the arrays' length at the first
+// round) and its LAST publication is the arrays instead of the heads: 2 * ncirc * m_stop values, A_0[0..m_stop), A_1[..], .., B_0[..], ...  m_stop = 1 or 0: the heads.
+int32_t lasso_tail_handover_next(lasso_ctx* c, uint32_t m_stop) {
+  REQUIRE(c, c && !c->tail_active && (m_stop & (m_stop - 1)) == 0 && m_stop <= 128);
+  c->handover_next = m_stop <= 1 ? 0 : m_stop; return 0;
 }
 // The same for the primary sumcheck of a linear strategy (k_linear_tail): per round two dot products per polynomial, out[2k] = S0_k, out[2k+1] = S1_k
 // (as lasso_sumcheck_linear_eqw_round, without the unused third slot); after the last challenge the heads out[k] = polys_k[0] (alpha values).
 // d_src is only read (r == NULL: arrays of length n = 2q; otherwise bound with r first, n = 4q).  Challenges go through lasso_sumcheck_cubic_tail_next.
 int32_t lasso_sumcheck_linear_tail_begin(lasso_ctx* c, const lasso_fr* const* d_src, uint32_t alpha, const lasso_fr* d_E, size_t n, const lasso_fr* r) {
-  REQUIRE(c, d_src && d_E && alpha >= 1 && alpha <= LASSO_MAX_PTRS && n >= (r ? 4u : 2u) && (n & (n - 1)) == 0 && !c->pending && !c->tail_active && !c->defer_next);
+  REQUIRE(c, d_src && d_E && alpha >= 1 && alpha <= LASSO_MAX_PTRS && n >= (r ? 4u : 2u) && (n & (n - 1)) == 0 && !c->pending && !c->tail_active && !c->defer_next && !c->handover_next && !c->ahead_active);
   const size_t q = r ? n / 4 : n / 2;
   REQUIRE(c, q >= 1 && q <= CUBIC_TAIL_Q);
   PtrTable Src; for (uint32_t i = 0; i < alpha; i++) { REQUIRE(c, d_src[i]); Src.p[i] = (const fr_t*)d_src[i]; }
@@ -750,6 +799,12 @@ int32_t lasso_sumcheck_linear_tail_begin(lasso_ctx* c, const lasso_fr* const* d_
 int32_t lasso_sumcheck_cubic_tail_next(lasso_ctx* c, const lasso_fr* r) {
   REQUIRE(c, r && c->tail_active && !c->pending);
   const fr_t rr = to_fr(r);
+  if (c->tail_unstarted) {   // launched ahead: this is the challenge the kernel binds first; it enables publication tail_seq0 (the first round's sums)
+    c->tail_unstarted = false;
+    post_mail(c, c->tail_seq0, rr.v);
+    c->pending = true; c->pending_seq = c->tail_seq0; c->pending_count = c->tail_count; c->pending_tagged = c->tagged;
+    return 0;
+  }
   c->tail_turn++;
   const uint32_t tn = c->tail_seq0 + c->tail_turn;   // = the sequence number of the publication this challenge enables: tags are unique, the mailbox is never reset
                                                       // (a reset could erase a challenge some workgroup of a multi-workgroup kernel has not read yet)
@@ -955,6 +1010,15 @@ int32_t lasso_read_heads(lasso_ctx* c, const lasso_fr* const* d_polys, uint32_t 
   hipLaunchKernelGGL(k_read_heads, dim3(1), dim3(LASSO_BLOCK), 0, c->stream, P, k, c->d_small);
   HIPCHK(c, hipGetLastError());
   return fetch_small(c, k, out);
+}
+// out[i * count + j] = d_polys[i][j], j < count (k * count <= 16384 elements), through the mapped result buffer: no memcpy, no stream synchronisation
+int32_t lasso_read_runs(lasso_ctx* c, const lasso_fr* const* d_polys, uint32_t k, uint32_t count, lasso_fr* out) {
+  REQUIRE(c, d_polys && out && k >= 1 && k <= LASSO_MAX_PTRS && count >= 1 && (size_t)k * count <= 16384);
+  PtrTable P; for (uint32_t i = 0; i < k; i++) { REQUIRE(c, d_polys[i]); P.p[i] = (const fr_t*)d_polys[i]; }
+  int32_t rc = ensure_small(c, (size_t)k * count); if (rc) return rc;
+  hipLaunchKernelGGL(k_read_runs, dim3((k * count + LASSO_BLOCK - 1) / LASSO_BLOCK), dim3(LASSO_BLOCK), 0, c->stream, P, k, count, c->d_small);
+  HIPCHK(c, hipGetLastError());
+  return fetch_small(c, (size_t)k * count, out);
 }
 // layers above `in` (len elements, the layers laid out back to back behind it): one launch per large layer, the small ones in one workgroup
 static void gp_layers_from(lasso_ctx* c, fr_t* in, size_t len) {
@@ -1483,7 +1547,7 @@ static int32_t bullet_round_fused(lasso_ctx* c, const lasso_bases* b, size_t n, 
     else { if (w8) LAUNCH_BULLET(false, 8, b->d_mult8, nullptr, nullptr, nullptr, z, z); else LAUNCH_BULLET(false, 4, b->d_mult, nullptr, nullptr, nullptr, z, z); }
   }
   HIPCHK(c, hipGetLastError());
-  if (ahead) { c->ahead_active = true; c->ahead_seq = seq; return 0; }
+  if (ahead) { c->ahead_active = true; c->ahead_bullet = true; c->ahead_seq = seq; return 0; }
   return wait_flag(c, seq, 2 * (sizeof(ed_point) / sizeof(fr_t)), (lasso_fr*)out);
 }
 // slab mode of the opening (include/lasso_hip.h): this rank's share of L and R over its residue class of the generators
@@ -1546,7 +1610,7 @@ int32_t lasso_bullet_round_ahead(lasso_ctx* c, const lasso_bases* b, size_t n, c
   return bullet_round_fused(c, b, n, d_a_in, d_b_in, d_w_in, d_a_out, d_b_out, d_w_out, nk, nullptr, nullptr, blinds, nullptr, 1, 0, true);
 }
 int32_t lasso_bullet_post(lasso_ctx* c, const lasso_fr* u, const lasso_fr* u_inv) {
-  REQUIRE(c, u && u_inv && c->ahead_active && !c->pending);
+  REQUIRE(c, u && u_inv && c->ahead_active && c->ahead_bullet && !c->pending);
   mail_chunks(c->mail_h + 12, c->ahead_seq, (const uint32_t*)u_inv);
   post_mail(c, c->ahead_seq, (const uint32_t*)u);
   c->ahead_active = false;

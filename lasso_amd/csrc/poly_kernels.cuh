@@ -95,6 +95,57 @@ __device__ __forceinline__ void result_store(fr_t* __restrict__ out, size_t slot
 __device__ __forceinline__ bool mail_valid(const lasso_u32x4& c0, const lasso_u32x4& c1, const lasso_u32x4& c2, uint32_t tag) {
   return c0.x == tag && c1.x == tag && c2.x == tag && c2.w == (c0.y ^ c0.z ^ c0.w ^ c1.y ^ c1.z ^ c1.w ^ c2.y ^ c2.z) + tag * 0x9E3779B9u;
 }
+// ------------------------------------------------------------------ challenges that arrive while the kernel is already running
+// One poll loop of the host-mapped mailbox (lasso_hip.hip post_mail: three self-validating 16-byte chunks [tag, w, w, w] [tag, w, w, w] [tag, w, w, check]; the host writes each with one
+// aligned 16-byte store and a PCIe read of an aligned 16 bytes is one transaction, so when all three carry the expected tag and the check word agrees the eight words are that message's).
+// Returns false on lasso_abort's poison tag or when the wall clock passes t_end (a host that never answers cannot hang the device).  ONE lane calls it.
+__device__ __forceinline__ bool mail_wait(const uint32_t* mailbox, uint32_t tag, uint64_t t_end, fr_t& chal) {   // no __restrict__ on the mailbox: the host writes it while the kernel polls
+  const lasso_u32x4* m4 = reinterpret_cast<const lasso_u32x4*>(mailbox);
+  lasso_u32x4 c0, c1, c2; uint32_t spins = 0;
+  for (;;) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");   // nothing cached from the previous poll
+    c0 = __builtin_nontemporal_load(m4); c1 = __builtin_nontemporal_load(m4 + 1); c2 = __builtin_nontemporal_load(m4 + 2);   // three 16-byte reads in flight together
+    if (mail_valid(c0, c1, c2, tag)) break;
+    if (c0.x == LASSO_MAIL_POISON || ((++spins & 63u) == 0 && wall_clock64() > t_end)) return false;
+  }
+  chal.v[0] = c0.y; chal.v[1] = c0.z; chal.v[2] = c0.w; chal.v[3] = c1.y; chal.v[4] = c1.z; chal.v[5] = c1.w; chal.v[6] = c2.y; chal.v[7] = c2.z;
+  return true;
+}
+// A round LAUNCHED AHEAD of its challenge (round 5; the openings' folding rounds have had this form since round 4, msm_kernels.cuh k_bullet_msm): the host enqueues round j + 1
+// behind round j BEFORE it has round j's sums, so that neither the launch nor its dispatch sits between two rounds (12 us of host turn per launched round, of which ~1.5 us are
+// the Fiat-Shamir step), and posts the challenge into the mailbox under the launch's own sequence number when it has it.  Workgroup 0 — dispatched first — is the one PCIe poller;
+// it republishes the scalar in device memory (gmail[0..8), then the tag in gmail[16], release at agent scope) and every workgroup waits on that tag.  gmail[17] = tag means
+// "this launch gets no challenge" (poison / 5 s bail-out): everybody leaves without a result.  All threads of the workgroup call it; s_mail = 9 words of LDS.
+__device__ __forceinline__ bool ahead_challenge(const uint32_t* mail, uint32_t* gmail, uint32_t seq, fr_t& r, uint32_t* s_mail) {
+  if (threadIdx.x == 0) {
+    const uint64_t t_end = wall_clock64() + 500000000ull;   // 5 s at 100 MHz
+    uint32_t ok = 1, spins = 0;
+    if (blockIdx.x == 0) {
+      fr_t c;
+      if (mail_wait(mail, seq, t_end, c)) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) gmail[k] = c.v[k];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __hip_atomic_store(gmail + 16, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      } else __hip_atomic_store(gmail + 17, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    for (;;) {
+      if (__hip_atomic_load(gmail + 16, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == seq) break;
+      if (__hip_atomic_load(gmail + 17, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == seq || ((++spins & 63u) == 0 && wall_clock64() > t_end + 100000000ull)) { ok = 0; break; }
+      __builtin_amdgcn_s_sleep(8);   // ~0.2 us between looks (the waiting workgroups must not crowd the poller's L2 traffic)
+    }
+    if (ok) {
+#pragma unroll
+      for (int k = 0; k < 8; k++) s_mail[k] = __hip_atomic_load(gmail + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    s_mail[8] = ok;
+  }
+  __syncthreads();
+  if (!s_mail[8]) return false;
+#pragma unroll
+  for (int k = 0; k < 8; k++) r.v[k] = s_mail[k];
+  return true;
+}
 // block partials of up to KMAX accumulators (groups of 3) -> dst[k], k < K; `shift` also corrects the radix of the accumulated products.
 // With `flag` the destination is the launch's result area (result_store at slot0 + k).
 template <int KMAX>
@@ -369,16 +420,29 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_eqw_lb(TP A, TP B, uint32
 }
 // fused with K1: bind A and B with r (length n = 4q -> 2q, in place: each element is owned by exactly one thread), then the sums of the NEXT round
 // on the bound values while they are still in registers — one launch per round, 48 bytes per element of A and B plus 32 per index of E.
-template <int NT, bool WIDE = false, class TM = MutPtrTable>
+// AHEAD: the challenge is not an argument — the launch was enqueued before the host had it and waits for it on the device (ahead_challenge above).  What the wait hides: the
+// launch, the dispatch, and the first index's eight loads, which are issued before the wait (`pre`): they do not depend on the challenge.
+template <int NT, bool WIDE = false, class TM = MutPtrTable, bool AHEAD = false>
 #ifdef LASSO_FUSED_WAVES   // experiment switch: force the register budget of the fused round (waves per SIMD); default = the compiler's choice (157 VGPRs, 3 waves)
 __attribute__((amdgpu_waves_per_eu(LASSO_FUSED_WAVES, LASSO_FUSED_WAVES)))
 #endif
 __global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_eqw_fused(TM A, TM B, uint32_t nx, uint32_t ny, const fr_t* __restrict__ E, size_t q, fr_t r,
-                                                                  fr_t* __restrict__ partials, uint32_t* counters, fr_t* __restrict__ out, uint32_t* flag, uint32_t seq) {
+                                                                  fr_t* __restrict__ partials, uint32_t* counters, fr_t* __restrict__ out, uint32_t* flag, uint32_t seq,
+                                                                  const uint32_t* mail = nullptr, uint32_t* gmail = nullptr) {
   __shared__ RedScratch S;
   const CubicGrid g = cubic_grid(nx, ny);
   fr_t* __restrict__ a = A.p[g.by];
   fr_t* __restrict__ b = B.p[g.by];
+  if constexpr (AHEAD) {
+    __shared__ uint32_t s_mail[9];
+    // warm the first index's lines while the challenge travels (the loop below re-reads them from the cache; keeping them in registers across the wait cost 64 VGPRs and a wave of occupancy)
+    const size_t i0 = g.bx * (size_t)blockDim.x + threadIdx.x;
+    if (i0 < q) {   // one word of each of the eight lines (gfx950 has no prefetch instruction): in flight during the first poll, consumed by an empty asm so that they are not dropped
+      const uint32_t warm = a[i0].v[0] ^ a[i0 + q].v[0] ^ a[i0 + 2 * q].v[0] ^ a[i0 + 3 * q].v[0] ^ b[i0].v[0] ^ b[i0 + q].v[0] ^ b[i0 + 2 * q].v[0] ^ b[i0 + 3 * q].v[0] ^ E[i0].v[0];
+      asm volatile("" ::"v"(warm));
+    }
+    if (!ahead_challenge(mail, gmail, seq, r, s_mail)) return;
+  }
   const fr29 rs = fr29_unpack_s(r);
   fr29 e[3] = {fr29_zero(), fr29_zero(), fr29_zero()}; uint32_t cnt = 0;
   fr29_acc w0 = fr29_acc_zero(), w1 = fr29_acc_zero();
@@ -477,9 +541,12 @@ __device__ uint64_t tail_phase_clock[16 * 8];
 #endif
 // EQI (first round of a layer only): the eq table is never materialised — the two factor tables are built in LDS (eq_inline_build, <= 32 entries each at q <= 512) and
 // every use of E[i] is one product.
+// m_stop (round 5): the kernel stops when the arrays are down to m_stop elements each and its LAST publication carries the arrays — out[(p * ncirc + c) * m_stop + i] = (p ? B : A)_c[i] —
+// instead of the heads (m_stop = 1: the heads, as before): the host finishes the last log2(m_stop) rounds itself (a few dozen field products against ~7 us per resident turn).
+// wait_r0 (BIND only): the launch was enqueued AHEAD of its first challenge; r0 arrives through the mailbox under tag seq0 (the publication it enables) while the loads are in flight.
 template <bool BIND, int Q, bool EQI = false, class TM = MutPtrTable, class TE = EqInline>
 __global__ void __launch_bounds__(Q) k_cubic_tail(TM A, TM B, const fr_t* __restrict__ E, uint32_t q, fr_t r0, const uint32_t* mailbox, uint32_t* counters,
-                                                             fr_t* __restrict__ out, uint32_t* flag, uint32_t seq0, TE EQ = TE()) {
+                                                             fr_t* __restrict__ out, uint32_t* flag, uint32_t seq0, TE EQ = TE(), uint32_t m_stop = 1, uint32_t wait_r0 = 0) {
   __shared__ fr29 eq_hi[EQI ? 32 : 1], eq_lo[EQI ? 32 : 1];
   const uint32_t elb = EQ.ell / 2;
   if constexpr (EQI) {   // ell = log2 q <= 9: hi over the first ceil(ell/2) coordinates (scale folded in), lo over the rest, both s-form
@@ -500,14 +567,35 @@ __global__ void __launch_bounds__(Q) k_cubic_tail(TM A, TM B, const fr_t* __rest
   const uint64_t t_end = wall_clock64() + 500000000ull;   // 5 s at 100 MHz
   uint32_t m = 2 * q;
   {
-    // every lane task (array p, index i) loads / binds its element and, for A, weights it with the eq table right away (no separate pass)
+    // every lane task (array p, index i) loads / binds its element and, for A, weights it with the eq table right away (no separate pass).  2 m <= 4 Q lane tasks: all of a
+    // thread's loads are issued first (and, launched ahead, travel while the first challenge does)
+    fr_t lo[4], hi[4];
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+      const uint32_t item = t + it * Q;
+      if (item < 2 * m) {
+        const uint32_t p = item / m, i = item - p * m;
+        const fr_t* src = p == 0 ? A.p[y] : B.p[y];
+        lo[it] = src[i]; if (BIND) hi[it] = src[i + m];
+      }
+    }
+    if (BIND && wait_r0) {
+      if (t == 0) alive = mail_wait(mailbox, seq0, t_end, chal) ? 1u : 0u;
+      __syncthreads();
+      if (!alive) return;
+      r0 = chal;
+      __syncthreads();   // chal / alive are written again at the first turn's poll
+    }
     const fr29 rs = fr29_unpack_s(r0);
-    for (uint32_t item = t; item < 2 * m; item += Q) {
-      const uint32_t p = item / m, i = item - p * m;
-      const fr_t* src = p == 0 ? A.p[y] : B.p[y];
-      const fr29 v = BIND ? bind29(src[i], src[i + m], rs) : fr29_unpack_u(src[i]);
-      bound[p][i] = v;
-      if (p == 0) ge[i] = fr29_mul(v, TAIL_EQ_S(i < q ? i : i - q));
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+      const uint32_t item = t + it * Q;
+      if (item < 2 * m) {
+        const uint32_t p = item / m, i = item - p * m;
+        const fr29 v = BIND ? bind29(lo[it], hi[it], rs) : fr29_unpack_u(lo[it]);
+        bound[p][i] = v;
+        if (p == 0) ge[i] = fr29_mul(v, TAIL_EQ_S(i < q ? i : i - q));
+      }
     }
   }
   __syncthreads();
@@ -603,8 +691,9 @@ __global__ void __launch_bounds__(Q) k_cubic_tail(TM A, TM B, const fr_t* __rest
     __syncthreads();
     TAIL_STAMP(5);
     m = h;
-    if (m == 1) {
-      if (t < 2) result_store(out, (size_t)t * ncirc + y, fr29_pack(bound[t][0]), flag, seq0 + turn + 1);
+    if (m <= m_stop) {   // m_stop = 1: the heads A_c[0], B_c[0]; otherwise the bound arrays, for the host to finish the layer
+      for (uint32_t u = t; u < 2 * m; u += Q) { const uint32_t p = u / m, i = u - p * m; result_store(out, ((size_t)p * ncirc + y) * m + i, fr29_pack(bound[p][i]), flag, seq0 + turn + 1); }
+      if (2 * m > 64) { if (t < 2 * m) __builtin_amdgcn_fence(__ATOMIC_RELEASE, ""); __syncthreads(); }   // more than one wave stored: each releases its own stores before wave 0 signs off in row_done
       row_done(ncirc, counters, flag, seq0 + turn + 1);
       return;
     }
@@ -1223,6 +1312,11 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_gather(const fr_t* __restrict__
 __global__ void k_read_heads(PtrTable polys, uint32_t k, fr_t* __restrict__ out) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < k) out[i] = polys.p[i][0];
+}
+// out[i * count + j] = polys_i[j], j < count: short runs of several arrays for the host (the tops of the product trees)
+__global__ void k_read_runs(PtrTable polys, uint32_t k, uint32_t count, fr_t* __restrict__ out) {
+  const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < k * count) out[e] = polys.p[e / count][e % count];
 }
 // Montgomery memory form -> the canonical integer (ark-ff into_bigint): x*2^256 * 2^5 / 2^261 = x
 __device__ __forceinline__ fr_t fr29_to_integer(const fr29& u) { fr29 k32 = fr29_zero(); k32.v[0] = 32; return fr29_store(fr29_mul(u, k32)); }

@@ -65,6 +65,7 @@ struct HostClock {
 struct Error : std::runtime_error { using std::runtime_error::runtime_error; };
 #define LASSO_REQUIRE(c) do { if (!(c)) throw Error(std::string("lasso prover: requirement failed: ") + #c); } while (0)
 
+#define LASSO_HOST_TOPS_MAX_PTRS 128   // lasso_read_runs takes up to LASSO_MAX_PTRS (136) arrays per call
 inline size_t next_pow2(size_t n) { size_t p = 1; while (p < n) p <<= 1; return p; }
 inline bool is_pow2(size_t n) { return n && !(n & (n - 1)); }
 inline size_t ceil_log2(size_t n) { size_t k = 0; while (((size_t)1 << k) < n) k++; return k; }  // == Math::log_2 (utils/math.rs:27-35) and ark_std::log2
@@ -976,6 +977,54 @@ class Prover {
     }
     return out;
   }
+  // ---- rounds the HOST finishes (round 5).  A hand-off to the device costs ~7 us per resident turn (5.6 us of device turn + the host's step) and ~25 us per launched round
+  // whatever the size; once a layer's arrays are down to a few elements per circuit the round's arithmetic itself is a few dozen field products.  So (one GPU):
+  //  * the resident tail hands its ARRAYS over when they are down to m_stop elements each (lasso_tail_handover_next) and the last log2(m_stop) rounds run here;
+  //  * the layers of the product trees with at most 2 * m_stop elements — the top of every tree — are proved here entirely, from the tops read once per argument
+  //    (lasso_read_runs in memory_checking_prove): no launch, no hand-off.
+  // What runs is sumcheck.rs:49-124 literally on (A_c, B_c, C) with C = the bound eq polynomial s * EqPolynomial(rand[first..]).evals(): evaluations at 0, 2, 3 by
+  // `prev + hi - lo`, e(1) from the claim (:99-104), UniPoly::from_evals, bind (:116-120) — the same field elements as the device's eq-weighted form, any eq coordinate.
+  // The device remains the only place where an O(n) loop runs; this is the O(1) end of the O(log n) host share.
+  // budget = elements per array x circuits the host takes over (LASSO_HOST_TAIL, default 32; 0 switches the host rounds off: A/B measurements, byte-identical)
+  static size_t host_tail_budget() { static const size_t v = [] { const char* e = getenv("LASSO_HOST_TAIL"); const long x = e ? atol(e) : 32; return (size_t)(x < 0 ? 0 : x > 1024 ? 1024 : x); }(); return v; }
+  size_t host_m_stop(size_t k) const {   // elements per array at which the host takes a layer over: a power of two, 1 = never
+    if (P != 1 || !host_tail_budget() || !k) return 1;
+    size_t m0 = 1; while (2 * m0 * k <= host_tail_budget() && 2 * m0 <= 64) m0 *= 2;
+    return m0;
+  }
+  // a, b: k arrays of m = 2^rounds_left elements; rand[first ..first + rounds_left) the eq coordinates still unbound; s = the running factor prod eq1(rand_t, rho_t) so far
+  void host_cubic_rounds(std::vector<ScVec>& a, std::vector<ScVec>& b, size_t rounds_left, const ScVec& rand, size_t first, const ScVec& coeffs, const Sc& s_run, Sc& e, SumcheckProof& proof,
+                         ScVec& r_out, std::vector<lasso_fr>& heads) {
+    HostClock hc("host rounds (handed-over tails, tree tops)");
+    const size_t k = a.size(); size_t m = (size_t)1 << rounds_left;
+    LASSO_REQUIRE(k == b.size() && first + rounds_left <= rand.size());
+    for (size_t c = 0; c < k; c++) LASSO_REQUIRE(a[c].size() == m && b[c].size() == m);
+    ScVec C = eq_evals_host(rand.data() + first, rounds_left); for (auto& x : C) x *= s_run;
+    for (size_t j = 0; j < rounds_left; j++) {
+      const size_t h = m / 2;
+      Sc e0 = Sc::zero(), e2 = Sc::zero(), e3 = Sc::zero();
+      for (size_t i = 0; i < h; i++) {
+        Sc t0 = Sc::zero(), t2 = Sc::zero(), t3 = Sc::zero();   // sum_c coeffs_c A_c(x) B_c(x) at x = 0, 2, 3 (:95-97 applies the coefficients to the sums: the same by linearity)
+        for (size_t c = 0; c < k; c++) {
+          const Sc &a0 = a[c][i], &a1 = a[c][i + h], &b0 = b[c][i], &b1 = b[c][i + h];
+          const Sc da = a1 - a0, db = b1 - b0, a2 = a1 + da, b2 = b1 + db, a3 = a2 + da, b3 = b2 + db;
+          t0 += coeffs[c] * (a0 * b0); t2 += coeffs[c] * (a2 * b2); t3 += coeffs[c] * (a3 * b3);
+        }
+        const Sc dc = C[i + h] - C[i], c2 = C[i + h] + dc, c3 = c2 + dc;
+        e0 += t0 * C[i]; e2 += t2 * c2; e3 += t3 * c3;
+      }
+      UniPoly poly = UniPoly::from_evals({e0, e - e0, e2, e3});
+      poly.append_to_transcript(t, "poly");
+      const Sc r_j = t.challenge_scalar("challenge_nextround"); r_out.push_back(r_j);
+      e = poly.evaluate(r_j);
+      proof.compressed_polys.push_back(poly.compress());
+      for (size_t c = 0; c < k; c++) for (size_t i = 0; i < h; i++) { a[c][i] += r_j * (a[c][i + h] - a[c][i]); b[c][i] += r_j * (b[c][i + h] - b[c][i]); }
+      for (size_t i = 0; i < h; i++) C[i] += r_j * (C[i + h] - C[i]);
+      m = h;
+    }
+    heads.resize(2 * k);
+    for (size_t c = 0; c < k; c++) { heads[c] = a[c][0].abi(); heads[k + c] = b[c][0].abi(); }
+  }
   // ---- SumcheckInstanceProof::prove_cubic_batched (sumcheck.rs:27-135), comb = A*B*C with C = EqPolynomial(rand).evals() (grand_product.rs:122-128).
   // Round j's bind (sumcheck.rs:116-120) is executed by the same kernel that evaluates round j+1, so a round is ONE launch.  The eq polynomial is
   // never bound or stored: after j binds it is  s_j * eq1(rand_j, x_top) * T_j  with T_j a scalar multiple of the PREFIX of the layer's table
@@ -1017,13 +1066,24 @@ class Prover {
       if (plain) tail_from = j0;
     }
     bool in_tail = false;
+    // the host takes the layer over when its arrays are down to m_stop elements each: the resident tail runs the rounds [tail_from, j_host) and hands the arrays over
+    size_t m_stop = 1, j_host = rounds;
+    if (tail_from < rounds && len == ((size_t)1 << rounds)) {
+      const size_t m0 = host_m_stop(k), lt = len >> tail_from;   // lt = array length at the tail's first round
+      if (m0 >= 2 && m0 < lt) { m_stop = m0; j_host = rounds - ceil_log2(m0); }
+    }
+    // Rounds LAUNCHED AHEAD of their challenge (include/lasso_hip.h lasso_sumcheck_cubic_eqw2_begin_ahead): while round j runs, round j + 1 — a streaming round, or the resident
+    // tail — is already in the stream and waits on the device for the challenge this loop posts.  One GPU, plain rounds only (no collective between rounds, no per-round table).
+    static const bool ahead_env_off = [] { const char* v = getenv("LASSO_ROUNDS_AHEAD"); return v && v[0] == '0'; }();
+    const bool ahead_ok = !ahead_env_off && !reduce && !degenerate && P == 1 && !d.throughput && heads_out && lasso_rounds_ahead_ok(d.ctx) == 1;
+    bool queued = false, queued_tail = false;   // this round's kernel is already enqueued (a streaming round / the resident tail) and waits for r_prev
     std::vector<DBuf> leaf_full;   // the leaves after all, for the rare shapes the chunked rounds do not cover
     if (leaf) {
       static const bool three = [] { const char* v = getenv("LASSO_CUBIC_THREE_SUMS"); return v && v[0] == '1'; }();
       const bool plain = v0 == 0 && !degenerate && !three && rounds >= 3 && tail_from >= 2 && !rand[0].is_zero() && !rand[1].is_zero() && !s_run.is_zero();
       if (!plain) { leaf_full = leaf_materialise(*leaf, A, B); leaf = nullptr; }
     }
-    for (size_t j = 0; j < rounds; j++) {
+    for (size_t j = 0; j < j_host; j++) {
       const lasso_fr* table = d_E; Sc scale = degenerate ? Sc::one() : inv[j];
       if (degenerate) {   // T_j = eq(rand[v0+j+1 .. v0+rounds)) built explicitly (size len / 2^(j+1) at this point), times the slab factor hidden in d_E[0] / eq-prefix
         std::vector<lasso_fr> rr; for (size_t t2 = v0 + j + 1; t2 < v0 + rounds; t2++) rr.push_back(rand[t2].abi());
@@ -1036,12 +1096,17 @@ class Prover {
       const Sc f0 = base * om, f1 = base * rj;   // f is linear: f(x) = f0 + (f1 - f0) x
       UniPoly poly;
       static const bool three_sums = [] { const char* v = getenv("LASSO_CUBIC_THREE_SUMS"); return v && v[0] == '1'; }();   // A/B switch for measurements
-      if (j >= tail_from || (!f1.is_zero() && !three_sums)) {
+      if (j >= tail_from || queued || (!f1.is_zero() && !three_sums)) {
         // two sums per circuit, q_c(0) and the leading coefficient; q(1) follows from the claim e = e(0) + e(1) (sumcheck.rs:99-104 derives e(1)
         // the same way) and q(2), q(3) by extrapolation.  The inversion of f(1) overlaps the kernel.
         lasso_fr rp = r_prev.abi();
         const uint32_t ell = (uint32_t)lz.rr.size();   // table of 2^ell = len / 2 entries
         std::vector<lasso_fr> ev(2 * k); bool have_ev = false;
+        if (queued) {          // enqueued while the previous round ran: it only needs its challenge
+          d.chk(lasso_challenge_post(d.ctx, &rp), "lasso_challenge_post"); queued = false;
+        } else if (queued_tail) {
+          d.chk(lasso_sumcheck_cubic_tail_next(d.ctx, &rp), "lasso_sumcheck_cubic_tail_next"); queued_tail = false; in_tail = true;
+        } else
         if (leaf && j < 2) {   // capacity mode: this round's A and B are recomputed chunk by chunk; after round 1 the bound arrays are the working arrays
           ensure_table();
           leaf_round(*leaf, j, len, table, j ? &rp : nullptr, ev); have_ev = true;
@@ -1050,14 +1115,28 @@ class Prover {
         if (j == 0 && lz.on && j < tail_from && ell <= 14 && len / 2 > 64) {   // round 0 of a streaming layer: the table is built in this launch and left in d_E for the later rounds
           d.chk(lasso_sumcheck_cubic_eqw2_begin_eq(d.ctx, A.data(), B.data(), (uint32_t)k, lz.d_table, len, lz.rr.data(), ell, &lz.scale), "lasso_sumcheck_cubic_eqw2_begin_eq"); lz.on = false;
         } else if (j == 0 && lz.on && j >= tail_from && ell <= 9) {            // the whole layer runs in the resident kernel: no table at all
+          if (m_stop > 1) d.chk(lasso_tail_handover_next(d.ctx, (uint32_t)m_stop), "lasso_tail_handover_next");
           d.chk(lasso_sumcheck_cubic_tail_begin_eq(d.ctx, A.data(), B.data(), (uint32_t)k, len, lz.rr.data(), ell, &lz.scale), "lasso_sumcheck_cubic_tail_begin_eq"); in_tail = true; lz.on = false;
         } else {
           ensure_table();
           if (j < tail_from) d.chk(lasso_sumcheck_cubic_eqw2_begin(d.ctx, A.data(), B.data(), (uint32_t)k, table, len, j == 0 ? nullptr : &rp), "lasso_sumcheck_cubic_eqw2_begin");
-          else if (!in_tail) { d.chk(lasso_sumcheck_cubic_tail_begin(d.ctx, A.data(), B.data(), (uint32_t)k, table, len, j == 0 ? nullptr : &rp), "lasso_sumcheck_cubic_tail_begin"); in_tail = true; }
+          else if (!in_tail) {
+            if (m_stop > 1) d.chk(lasso_tail_handover_next(d.ctx, (uint32_t)m_stop), "lasso_tail_handover_next");
+            d.chk(lasso_sumcheck_cubic_tail_begin(d.ctx, A.data(), B.data(), (uint32_t)k, table, len, j == 0 ? nullptr : &rp), "lasso_sumcheck_cubic_tail_begin"); in_tail = true;
+          }
           else d.chk(lasso_sumcheck_cubic_tail_next(d.ctx, &rp), "lasso_sumcheck_cubic_tail_next");
         }
         if (j) len /= 2;
+        // round j + 1 into the stream behind round j, before round j's sums are waited for: a streaming round (bind of the challenge to come + its sums), or the resident tail
+        if (ahead_ok && !in_tail && !lz.on && j + 1 < j_host && !(leaf && j + 1 < 3) && !rand[v0 + j + 1].is_zero()) {
+          if (j + 1 < tail_from) {
+            const int32_t rc = lasso_sumcheck_cubic_eqw2_begin_ahead(d.ctx, A.data(), B.data(), (uint32_t)k, table, len);
+            if (rc == 0) queued = true; else if (rc != LASSO_ERR_UNSUPPORTED) d.chk(rc, "lasso_sumcheck_cubic_eqw2_begin_ahead");
+          } else if (j + 1 == tail_from) {
+            if (m_stop > 1) d.chk(lasso_tail_handover_next(d.ctx, (uint32_t)m_stop), "lasso_tail_handover_next");
+            d.chk(lasso_sumcheck_cubic_tail_begin_ahead(d.ctx, A.data(), B.data(), (uint32_t)k, table, len), "lasso_sumcheck_cubic_tail_begin_ahead"); queued_tail = true;
+          }
+        }
         // f(1) = 0 inside the tail can only come from a vanished running factor s (probability 2^-252): then f = 0 identically and q is irrelevant
         const Sc f1_inv = f1.is_zero() ? Sc::zero() : f1.inverse();
         if (!have_ev) d.chk(lasso_result_wait(d.ctx, ev.data(), 2 * k), "lasso_result_wait");
@@ -1096,12 +1175,18 @@ class Prover {
       proof.compressed_polys.push_back(poly.compress());
     }
     lasso_fr rp = r_prev.abi();
-    if (in_tail) {   // the resident kernel binds the last challenge itself and hands back the heads A_c[0], B_c[0]
+    if (in_tail) {   // the resident kernel binds the last challenge itself and hands back the heads A_c[0], B_c[0] — or, stopped early, the arrays of m_stop elements
       d.chk(lasso_sumcheck_cubic_tail_next(d.ctx, &rp), "lasso_sumcheck_cubic_tail_next");
-      heads_out->resize(2 * k);
-      d.chk(lasso_result_wait(d.ctx, heads_out->data(), 2 * k), "lasso_result_wait");
+      heads_out->resize(2 * k * m_stop);
+      d.chk(lasso_result_wait(d.ctx, heads_out->data(), 2 * k * m_stop), "lasso_result_wait");
+      if (m_stop > 1) {   // the host finishes the layer: rounds [j_host, rounds) on the handed-over arrays
+        std::vector<ScVec> ha(k, ScVec(m_stop)), hb(k, ScVec(m_stop));
+        for (size_t c = 0; c < k; c++) for (size_t i = 0; i < m_stop; i++) { ha[c][i] = Sc::from_abi((*heads_out)[c * m_stop + i]); hb[c][i] = Sc::from_abi((*heads_out)[(k + c) * m_stop + i]); }
+        host_cubic_rounds(ha, hb, rounds - j_host, rand, v0 + j_host, coeffs, s_run, e, proof, r_out, *heads_out);
+      }
       return;
     }
+    LASSO_REQUIRE(j_host == rounds && !queued && !queued_tail);
     // the last challenge of the phase still has to be bound (len == 2 here)
     std::vector<lasso_fr*> ab(A); ab.insert(ab.end(), B.begin(), B.end());
     d.chk(lasso_bind_top(d.ctx, ab.data(), (uint32_t)ab.size(), len, &rp), "lasso_bind_top");
@@ -1144,7 +1229,10 @@ class Prover {
   // (P elements = the ranks' local roots, then their product tree).
   // leaf (capacity mode): trees[c] holds the layers ABOVE the leaves only (n_loc - 2 elements: layer k >= 1 at offset n_loc * (1 - 2^(1-k))); the bottom layer's
   // arrays are recomputed by cubic_rounds from *leaf, whose work_a / work_b this function points at the (by then dead) storage of layer 1
-  BatchedGrandProductArgument bgpa_prove(std::vector<lasso_fr*>& trees, std::vector<lasso_fr*>& tops, size_t n, const ScVec& roots, ScVec& rand_out, LeafLayer* leaf = nullptr) {
+  // host_tops (one GPU, optional): the top of every tree on the host — tree c's layers of at most host_tops->len elements, back to back as they lie in the arena (the layer of
+  // `len` elements first, the two-element layer last): those layers are proved without the device (host_cubic_rounds)
+  struct HostTops { size_t len = 0; std::vector<ScVec> run; };   // run[c]: 2 * len - 2 elements
+  BatchedGrandProductArgument bgpa_prove(std::vector<lasso_fr*>& trees, std::vector<lasso_fr*>& tops, size_t n, const ScVec& roots, ScVec& rand_out, LeafLayer* leaf = nullptr, const HostTops* host_tops = nullptr) {
     Trace tr("BatchedGrandProductArgument.prove", d.ctx);
     BatchedGrandProductArgument out; const size_t k = trees.size(), num_layers = ceil_log2(n), n_loc = n / P;
     ScVec claims_to_verify = roots, rand;
@@ -1153,6 +1241,24 @@ class Prover {
       const size_t len = n >> layer_id;                     // global layer `layer_id` has n/2^layer_id elements
       LASSO_REQUIRE(((size_t)1 << rand.size()) == len / 2);
       const size_t num_rounds_prod = ceil_log2(len / 2);
+      if (host_tops && len <= host_tops->len && !(leaf && layer_id == 0)) {   // a layer of O(1) elements: the whole layer proof on the host (grand_product.rs:113-190, same transcript schedule)
+        LASSO_REQUIRE(P == 1 && host_tops->run.size() == k);
+        const size_t off = 2 * host_tops->len - 2 * len;    // within the run, as in the arena: the layer of `len` elements starts 2 * len elements before the end (+ 2)
+        std::vector<ScVec> ha(k), hb(k);
+        for (size_t c = 0; c < k; c++) { const ScVec& r = host_tops->run[c]; ha[c].assign(r.begin() + off, r.begin() + off + len / 2); hb[c].assign(r.begin() + off + len / 2, r.begin() + off + len); }
+        ScVec coeff_vec = t.challenge_vector("rand_coeffs_next_layer", claims_to_verify.size());
+        Sc claim = Sc::zero(); for (size_t i = 0; i < claims_to_verify.size(); i++) claim += claims_to_verify[i] * coeff_vec[i];
+        LayerProofBatched lp; ScVec rand_prod; std::vector<lasso_fr> heads;
+        host_cubic_rounds(ha, hb, num_rounds_prod, rand, 0, coeff_vec, Sc::one(), claim, lp.proof, rand_prod, heads);
+        for (size_t i = 0; i < k; i++) { lp.claims_prod_left.push_back(Sc::from_abi(heads[i])); lp.claims_prod_right.push_back(Sc::from_abi(heads[k + i])); }
+        for (size_t i = 0; i < k; i++) { t.append_scalar("claim_prod_left", lp.claims_prod_left[i]); t.append_scalar("claim_prod_right", lp.claims_prod_right[i]); }
+        Sc r_layer = t.challenge_scalar("challenge_r_layer");
+        claims_to_verify.clear();
+        for (size_t i = 0; i < k; i++) claims_to_verify.push_back(lp.claims_prod_left[i] + r_layer * (lp.claims_prod_right[i] - lp.claims_prod_left[i]));
+        ScVec ext{r_layer}; ext.insert(ext.end(), rand_prod.begin(), rand_prod.end()); rand = ext;
+        out.proof.push_back(std::move(lp));
+        continue;
+      }
       const bool slab = P > 1 && len >= 2 * P;              // this layer lives in the local trees; smaller ones in the replicated tops
       std::vector<lasso_fr*> A, B;
       const bool bottom_leafless = leaf && layer_id == 0;
@@ -1607,10 +1713,31 @@ class Prover {
     };
     ScVec roots_rw, roots_if;
     std::vector<lasso_fr*> rw, inf, rw_top, inf_top;
+    // One GPU: the TOP of every tree — its layers of at most 2 * m_stop elements — comes to the host in one read per argument (lasso_read_runs through the mapped buffer:
+    // was 4 alpha two-element reads for the roots alone); the roots are the products of the two-element layers, and bgpa_prove proves those layers without the device.
+    HostTops tops_rw, tops_if;
+    auto read_tops = [&](const std::vector<DBuf>& ta, const std::vector<DBuf>& tb, size_t n_leaves, size_t missing, HostTops& out) {   // trees interleaved (ta[0], tb[0], ta[1], ..): bgpa's circuit order
+      const size_t kk = 2 * ta.size(), m0 = host_m_stop(kk);
+      if (P != 1 || !host_tail_budget() || kk > LASSO_HOST_TOPS_MAX_PTRS) return;   // LASSO_HOST_TAIL=0: everything through the device, as before round 5
+      size_t hl = 2 * m0; if (hl > n_leaves) hl = n_leaves;                     // a tree of fewer leaves is all top
+      if (missing && hl >= n_leaves) return;                                       // leafless trees: the leaf layer is not there to be read
+      if (hl < 2) return;
+      const size_t count = 2 * hl - 2, start = 2 * n_leaves - 2 * hl - missing;   // the layers of hl, hl / 2, .., 2 elements: the last 2 hl - 2 elements of the arena
+      std::vector<const lasso_fr*> ptr; for (size_t i = 0; i < ta.size(); i++) { ptr.push_back(ta[i].p + start); ptr.push_back(tb[i].p + start); }
+      std::vector<lasso_fr> flat(kk * count);
+      d.chk(lasso_read_runs(d.ctx, ptr.data(), (uint32_t)kk, (uint32_t)count, flat.data()), "lasso_read_runs");
+      out.len = hl; out.run.assign(kk, ScVec(count));
+      for (size_t c = 0; c < kk; c++) for (size_t i = 0; i < count; i++) out.run[c][i] = Sc::from_abi(flat[c * count + i]);
+    };
+    read_tops(t_read, t_write, s_loc, leafless ? s_loc : 0, tops_rw);
+    read_tops(t_init, t_final, m_loc, 0, tops_if);
+    auto root_of = [](const HostTops& T, size_t c) { const ScVec& r = T.run[c]; return r[r.size() - 2] * r[r.size() - 1]; };   // GrandProductCircuit::evaluate: the last layer's two elements
     for (size_t i = 0; i < alpha; i++) {
-      lasso_fr *ti_top, *tr_top, *tw_top, *tf_top;
+      lasso_fr *ti_top = nullptr, *tr_top = nullptr, *tw_top = nullptr, *tf_top = nullptr;
       const size_t lm = leafless ? s_loc : 0;
-      Sc hi = root_and_top(t_init[i], m_loc, ti_top), hr = root_and_top(t_read[i], s_loc, tr_top, lm), hw = root_and_top(t_write[i], s_loc, tw_top, lm), hf = root_and_top(t_final[i], m_loc, tf_top);
+      Sc hi, hr, hw, hf;
+      if (tops_if.len) { hi = root_of(tops_if, 2 * i); hf = root_of(tops_if, 2 * i + 1); } else { hi = root_and_top(t_init[i], m_loc, ti_top); hf = root_and_top(t_final[i], m_loc, tf_top); }
+      if (tops_rw.len) { hr = root_of(tops_rw, 2 * i); hw = root_of(tops_rw, 2 * i + 1); } else { hr = root_and_top(t_read[i], s_loc, tr_top, lm); hw = root_and_top(t_write[i], s_loc, tw_top, lm); }
       if (!(hi * hw == hr * hf)) throw Error("memory checking: hash_init * hash_write != hash_read * hash_final (memory_checking.rs:689)");
       t.append_scalar("claim_hash_init", hi); t.append_scalar("claim_hash_read", hr); t.append_scalar("claim_hash_write", hw); t.append_scalar("claim_hash_final", hf);
       W.sc(hi); W.sc(hr); W.sc(hw); W.sc(hf);
@@ -1619,7 +1746,7 @@ class Prover {
       rw_top.push_back(tr_top); rw_top.push_back(tw_top); inf_top.push_back(ti_top); inf_top.push_back(tf_top);
     }
     ScVec rand_ops, rand_mem;
-    BatchedGrandProductArgument proof_ops = bgpa_prove(rw, rw_top, s, roots_rw, rand_ops, leafless ? &leaf : nullptr);
+    BatchedGrandProductArgument proof_ops = bgpa_prove(rw, rw_top, s, roots_rw, rand_ops, leafless ? &leaf : nullptr, tops_rw.len ? &tops_rw : nullptr);
     t_read.clear(); t_write.clear();
     if (!chis.p) chis = DBuf(d, s_loc);
     // Everything HashLayerProof needs at rand_ops that does not depend on the transcript — the evaluations of E / dim / read (one pass over all of
@@ -1641,7 +1768,7 @@ class Prover {
       prep_derefs = prep_open(combined_E.p, k_derefs, rand_ops);
       prep_ops = prep_open(dense.combined_l_variate_polys.p, k_ops, rand_ops);
     }
-    BatchedGrandProductArgument proof_mem = bgpa_prove(inf, inf_top, m, roots_if, rand_mem);
+    BatchedGrandProductArgument proof_mem = bgpa_prove(inf, inf_top, m, roots_if, rand_mem, nullptr, tops_if.len ? &tops_if : nullptr);
     t_init.clear(); t_final.clear(); tops_store.clear();
     proof_mem.write(W); proof_ops.write(W);    // field order of ProductLayerProof: grand_product_evals, proof_mem, proof_ops (:656-660)
     // HashLayerProof::prove (memory_checking.rs:338-460)

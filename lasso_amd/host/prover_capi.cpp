@@ -211,6 +211,17 @@ int32_t lasso_host_debug_cubic_batched(lasso_host* h, lasso_host_dense* dn, lass
       (c < k ? pa : pb).push_back(bufs.back().p);
     }
     ScVec rv, cv; for (size_t i = 0; i < ell; i++) rv.push_back(Sc::from_abi(rand[i])); for (size_t i = 0; i < k; i++) cv.push_back(Sc::from_abi(coeffs[i]));
+    { const char* e = getenv("LASSO_DEBUG_CUBIC_HOST");   // read per call: the tests drive the HOST rounds (Prover::host_cubic_rounds: the tree tops' layers) through the same scripted points
+      if (e && e[0] == '1') {
+        std::vector<ScVec> ha(k, ScVec(n)), hb(k, ScVec(n));
+        for (size_t c = 0; c < k; c++) for (size_t i = 0; i < n; i++) { ha[c][i] = Sc::from_abi(A[c * n + i]); hb[c][i] = Sc::from_abi(B[c * n + i]); }
+        SumcheckProof sp; ScVec r_out; std::vector<lasso_fr> heads; Sc e0 = Sc::from_abi(*claim);
+        P.host_cubic_rounds(ha, hb, ell, rv, 0, cv, Sc::one(), e0, sp, r_out, heads);
+        ProofWriter w;
+        for (auto& c : sp.compressed_polys) w.sc_arr(c);
+        w.sc_arr(r_out); for (auto& x : heads) w.sc(Sc::from_abi(x));
+        return emit(w.b, out, cap, len);
+      } }
     DBuf eq(h->dev, n / 2 ? n / 2 : 1);
     P.eq_half_local(rv, eq.p);
     ScVec r_out, ca, cb;

@@ -20,6 +20,10 @@ struct lasso_ctx {
   std::vector<Fr> pending; bool defer = false;
   std::vector<std::vector<Fr>> tail_a, tail_b; std::vector<Fr> tail_e;   // resident tail: private copies of the arrays
   bool tail_linear = false;   // k_linear_tail: tail_a holds the alpha polynomials, tail_b is unused
+  size_t tail_stop = 1;       // lasso_tail_handover_next: the tail in progress hands its arrays over at this length; handover_next: the value for the next begin
+  uint32_t handover_next = 0;
+  // sumcheck rounds / the resident tail launched ahead of their challenge: the arguments wait here for lasso_challenge_post / the first lasso_sumcheck_cubic_tail_next
+  struct RoundAhead { bool on = false, tail = false; std::vector<lasso_fr*> A, B; const lasso_fr* E; size_t n; } rahead;
   // a bullet round launched ahead of its challenge: the arguments wait here for lasso_bullet_post
   std::mutex mem_mu; std::map<void*, size_t> mem_sizes; uint64_t mem_live = 0, mem_peak = 0, alloc_calls = 0;   // lasso_mem_stats of the mock
   struct Ahead { bool on = false; const lasso_bases* bs; size_t n, nk; const lasso_fr *a_in, *b_in, *w_in; lasso_fr *a_out, *b_out, *w_out; lasso_fr blinds[2]; } ahead;
@@ -86,7 +90,7 @@ int32_t lasso_rccl_allgather(lasso_ctx*, const void*, void*, size_t) { return LA
 size_t lasso_point_row_bytes(void) { return 144; }
 int32_t lasso_hyrax_commit_rows_dev(lasso_ctx*, const lasso_fr*, size_t, size_t, const lasso_bases*, void*) { return LASSO_ERR_UNSUPPORTED; }
 int32_t lasso_points_reduce_compress(lasso_ctx*, const void*, uint32_t, size_t, uint8_t*) { return LASSO_ERR_UNSUPPORTED; }
-int32_t lasso_abort(lasso_ctx* c) { REQ(c, c); c->pending.clear(); c->defer = false; c->ahead.on = false; c->tail_a.clear(); c->tail_b.clear(); c->tail_e.clear(); return 0; }
+int32_t lasso_abort(lasso_ctx* c) { REQ(c, c); c->pending.clear(); c->defer = false; c->ahead.on = false; c->rahead.on = false; c->handover_next = 0; c->tail_stop = 1; c->tail_a.clear(); c->tail_b.clear(); c->tail_e.clear(); return 0; }
 int32_t lasso_prof_get_large(lasso_ctx*, int32_t, uint64_t* n, double* ms, double* b) { if (n) *n = 0; if (ms) *ms = 0; if (b) *b = 0; return 0; }
 int32_t lasso_wait_stats(lasso_ctx*, uint64_t* w, double* us, int32_t) { if (w) *w = 0; if (us) *us = 0; return 0; }
 int32_t lasso_prof_get_units(lasso_ctx*, int32_t, int32_t, double* u) { if (u) *u = 0; return 0; }
@@ -227,7 +231,11 @@ static void tail_publish(lasso_ctx* ctx) {
     return;
   }
   pend.assign(2 * k, Fr::zero());
-  if (m == 1) { for (size_t c = 0; c < k; c++) { pend[c] = ta[c][0]; pend[k + c] = tb[c][0]; } ta.clear(); tb.clear(); return; }
+  if (m <= ctx->tail_stop) {   // the heads (tail_stop = 1) or the arrays for the host to finish: A_0[0..m), A_1.., B_0..
+    pend.assign(2 * k * m, Fr::zero());
+    for (size_t c = 0; c < k; c++) for (size_t i = 0; i < m; i++) { pend[c * m + i] = ta[c][i]; pend[(k + c) * m + i] = tb[c][i]; }
+    ta.clear(); tb.clear(); ctx->tail_stop = 1; return;
+  }
   const size_t h = m / 2;
   for (size_t c = 0; c < k; c++) {
     Fr q0 = Fr::zero(), qi = Fr::zero();
@@ -254,9 +262,12 @@ int32_t lasso_sumcheck_cubic_tail_begin_eq(lasso_ctx* c, lasso_fr* const* A, las
   int32_t rc = lasso_eq_evals_scaled(c, point, ell, scale, E.data()); if (rc) return rc;
   return lasso_sumcheck_cubic_tail_begin(c, A, B, nc, E.data(), n, nullptr);
 }
+int32_t lasso_tail_handover_next(lasso_ctx* c, uint32_t m_stop) { REQ(c, c && c->tail_a.empty() && (m_stop & (m_stop - 1)) == 0 && m_stop <= 128); c->handover_next = m_stop <= 1 ? 0 : m_stop; return 0; }
 int32_t lasso_sumcheck_cubic_tail_begin(lasso_ctx* c, lasso_fr* const* A, lasso_fr* const* B, uint32_t nc, const lasso_fr* E, size_t n, const lasso_fr* r) {
-  REQ(c, n >= (r ? 4u : 2u) && (n & (n - 1)) == 0 && c->tail_a.empty() && c->pending.empty());
-  const size_t q = r ? n / 4 : n / 2; REQ(c, q >= 1 && q <= 512);
+  const size_t m_stop = c->handover_next ? c->handover_next : 1; c->handover_next = 0;
+  REQ(c, n >= (r ? 4u : 2u) && (n & (n - 1)) == 0 && c->tail_a.empty() && c->pending.empty() && !c->rahead.on);
+  const size_t q = r ? n / 4 : n / 2; REQ(c, q >= 1 && q <= 512 && 2 * q > m_stop);
+  c->tail_stop = m_stop;
   c->tail_a.clear(); c->tail_b.clear();
   for (uint32_t k = 0; k < nc; k++) { c->tail_a.emplace_back(F(A[k]), F(A[k]) + n); c->tail_b.emplace_back(F(B[k]), F(B[k]) + n); }
   c->tail_e.assign(F(E), F(E) + q);
@@ -265,7 +276,7 @@ int32_t lasso_sumcheck_cubic_tail_begin(lasso_ctx* c, lasso_fr* const* A, lasso_
   return 0;
 }
 int32_t lasso_sumcheck_linear_tail_begin(lasso_ctx* c, const lasso_fr* const* src, uint32_t alpha, const lasso_fr* E, size_t n, const lasso_fr* r) {
-  REQ(c, n >= (r ? 4u : 2u) && (n & (n - 1)) == 0 && c->tail_a.empty() && c->pending.empty());
+  REQ(c, n >= (r ? 4u : 2u) && (n & (n - 1)) == 0 && c->tail_a.empty() && c->pending.empty() && !c->handover_next && !c->rahead.on);
   const size_t q = r ? n / 4 : n / 2; REQ(c, q >= 1 && q <= 512);
   c->tail_a.clear(); c->tail_b.clear(); c->tail_linear = true;
   for (uint32_t k = 0; k < alpha; k++) c->tail_a.emplace_back(F(src[k]), F(src[k]) + n);
@@ -274,7 +285,29 @@ int32_t lasso_sumcheck_linear_tail_begin(lasso_ctx* c, const lasso_fr* const* sr
   tail_publish(c);
   return 0;
 }
+// launched ahead: the arguments are parked; lasso_challenge_post / the first lasso_sumcheck_cubic_tail_next run the ordinary call with the challenge
+int32_t lasso_rounds_ahead_ok(lasso_ctx* c) { const char* v = getenv("LASSO_ROUNDS_AHEAD"); return c && !(v && v[0] == '0') ? 1 : 0; }
+int32_t lasso_sumcheck_cubic_eqw2_begin_ahead(lasso_ctx* c, lasso_fr* const* A, lasso_fr* const* B, uint32_t nc, const lasso_fr* E, size_t n) {
+  REQ(c, A && B && E && nc >= 1 && n >= 4 && (n & (n - 1)) == 0 && !c->rahead.on && !c->ahead.on && c->tail_a.empty() && !c->defer);
+  if (n / 4 <= 64) { c->err = "streaming rounds only"; return LASSO_ERR_UNSUPPORTED; }
+  c->rahead.on = true; c->rahead.tail = false; c->rahead.A.assign(A, A + nc); c->rahead.B.assign(B, B + nc); c->rahead.E = E; c->rahead.n = n; return 0;
+}
+int32_t lasso_challenge_post(lasso_ctx* c, const lasso_fr* r) {
+  REQ(c, r && c->rahead.on && !c->rahead.tail && c->pending.empty());
+  c->rahead.on = false;
+  return lasso_sumcheck_cubic_eqw2_begin(c, c->rahead.A.data(), c->rahead.B.data(), (uint32_t)c->rahead.A.size(), c->rahead.E, c->rahead.n, r);
+}
+int32_t lasso_sumcheck_cubic_tail_begin_ahead(lasso_ctx* c, lasso_fr* const* A, lasso_fr* const* B, uint32_t nc, const lasso_fr* E, size_t n) {
+  REQ(c, A && B && E && nc >= 1 && n >= 4 && (n & (n - 1)) == 0 && n / 4 <= 512 && !c->rahead.on && !c->ahead.on && c->tail_a.empty() && !c->defer);
+  REQ(c, n / 2 > (c->handover_next ? c->handover_next : 1u));
+  c->rahead.on = true; c->rahead.tail = true; c->rahead.A.assign(A, A + nc); c->rahead.B.assign(B, B + nc); c->rahead.E = E; c->rahead.n = n; return 0;
+}
 int32_t lasso_sumcheck_cubic_tail_next(lasso_ctx* c, const lasso_fr* r) {
+  if (c && c->rahead.on && c->rahead.tail) {   // the first challenge of a tail launched ahead
+    REQ(c, r && c->pending.empty());
+    c->rahead.on = false;
+    return lasso_sumcheck_cubic_tail_begin(c, c->rahead.A.data(), c->rahead.B.data(), (uint32_t)c->rahead.A.size(), c->rahead.E, c->rahead.n, r);
+  }
   REQ(c, r && !c->tail_a.empty() && c->pending.empty());
   tail_bind(c, *F(r));
   tail_publish(c);
@@ -330,6 +363,7 @@ int32_t lasso_multi_dot(lasso_ctx* c, const lasso_fr* const* polys, uint32_t k, 
   for (uint32_t p = 0; p < k; p++) F(out)[p] = compute_dotproduct(F(polys[p]), F(w), n); return 0;
 }
 int32_t lasso_read_heads(lasso_ctx*, const lasso_fr* const* polys, uint32_t k, lasso_fr* out) { for (uint32_t p = 0; p < k; p++) out[p] = polys[p][0]; return 0; }
+int32_t lasso_read_runs(lasso_ctx* c, const lasso_fr* const* polys, uint32_t k, uint32_t count, lasso_fr* out) { REQ(c, polys && out && k >= 1 && count >= 1 && (size_t)k * count <= 16384); for (uint32_t p = 0; p < k; p++) for (uint32_t j = 0; j < count; j++) out[p * count + j] = polys[p][j]; return 0; }
 int32_t lasso_gp_build(lasso_ctx* c, lasso_fr* tree, size_t n) {
   REQ(c, n >= 2 && (n & (n - 1)) == 0);
   Fr* in = F(tree); size_t len = n;

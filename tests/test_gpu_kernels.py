@@ -1215,3 +1215,178 @@ def test_sumcheck_linear_eqw_rounds(devs, n, alpha):
             assert np.array_equal(x, y) and np.array_equal(z, y)
         for x, y in zip(a[6], Ps):
             assert np.array_equal(x, y)
+
+
+# ---- round 5: tails that hand their arrays to the host, rounds launched ahead of their challenge, the trees' tops in one read
+@pytest.mark.parametrize("k,count", [(1, 1), (2, 62), (8, 30), (33, 6), (128, 2), (4, 4094)])
+def test_read_runs(devs, k, count):
+    rng = np.random.default_rng(k * 31 + count)
+    arrs = [rand_fr(rng, count + 5) for _ in range(k)]
+
+    def run(d):
+        ptrs = [d.upload(a) for a in arrs]
+        shifted = [p + 32 * 3 for p in ptrs]          # runs need not start at an allocation's first element (the tops sit at the end of a tree's arena)
+        out = np.empty((k * count, 4), dtype=np.uint64)
+        d._chk(d.lib.lasso_read_runs(d.ctx, d._ptrs(shifted), k, count, out.ctypes.data_as(C.c_void_p)))
+        for p in ptrs:
+            d.free(p)
+        return out
+    a, b = both(devs, run)
+    assert np.array_equal(a, b)
+    assert np.array_equal(a, np.concatenate([x[3:3 + count] for x in arrs]))
+
+
+@pytest.mark.parametrize("n,ncirc,bind,m_stop", [(64, 2, False, 16), (256, 2, True, 16), (1024, 2, False, 2), (2048, 2, True, 16), (2048, 4, True, 8), (1024, 16, False, 2), (512, 3, True, 64),
+                                                  (1024, 2, False, 128), (2048, 33, True, 4), (8, 1, False, 2), (16, 2, True, 2), (2048, 2, True, 128)])
+def test_cubic_tail_hands_its_arrays_over(devs, n, ncirc, bind, m_stop):
+    """lasso_tail_handover_next: the resident tail stops at m_stop elements per array; every round's sums equal the ordinary tail's, and the LAST publication is the arrays
+    A_c[0..m_stop), B_c[0..m_stop) — which, bound with the remaining challenges, give the ordinary tail's heads.  Device == mock, and both == the per-round kernels."""
+    rng = np.random.default_rng(n * 17 + ncirc * 3 + m_stop)
+    A = [rand_fr(rng, n) for _ in range(ncirc)]; B = [rand_fr(rng, n) for _ in range(ncirc)]
+    q = n // 4 if bind else n // 2
+    E = rand_fr(rng, q)
+    r0 = rand_fr(rng, 1, edge=False)[0] if bind else None
+    turns_full = (2 * q).bit_length() - 1
+    turns = turns_full - (m_stop.bit_length() - 1)            # rounds of sums before the hand-over
+    assert turns >= 1
+    chal = rand_fr(rng, turns_full, edge=False)
+    vp = lambda x: np.ascontiguousarray(x, dtype=np.uint64).ctypes.data_as(C.c_void_p)
+
+    def run(d):
+        pa = [d.upload(x) for x in A]; pb = [d.upload(x) for x in B]; pe = d.upload(E)
+        d._chk(d.lib.lasso_tail_handover_next(d.ctx, m_stop))
+        d._chk(d.lib.lasso_sumcheck_cubic_tail_begin(d.ctx, d._ptrs(pa), d._ptrs(pb), ncirc, C.c_void_p(pe), n, None if r0 is None else vp(r0)))
+        outs = []
+        for t in range(turns):
+            out = np.empty((2 * ncirc, 4), dtype=np.uint64); d._chk(d.lib.lasso_result_wait(d.ctx, vp(out), 2 * ncirc)); outs.append(out)
+            d._chk(d.lib.lasso_sumcheck_cubic_tail_next(d.ctx, vp(chal[t])))
+        arrs = np.empty((2 * ncirc * m_stop, 4), dtype=np.uint64); d._chk(d.lib.lasso_result_wait(d.ctx, vp(arrs), 2 * ncirc * m_stop))
+        # the context is free again: the next tail is an ordinary one (the setting applies to ONE begin)
+        full = d.sumcheck_cubic_tail(pa, pb, pe, n, r0, chal)
+        for p in pa + pb + [pe]:
+            d.free(p)
+        return outs, arrs, full
+    (oa, aa, fa), (ob, ab, fb) = both(devs, run)
+    for x, y in zip(oa, ob):
+        assert np.array_equal(x, y)
+    assert np.array_equal(aa, ab)
+    for x, y in zip(fa, fb):
+        assert np.array_equal(x, y)
+    for t in range(turns):
+        assert np.array_equal(oa[t], fa[t])                   # same sums as the tail that runs to the heads
+    # binding the handed-over arrays with the remaining challenges (python big ints) reproduces the heads
+    def to_int(row): return (int(row[0]) | int(row[1]) << 64 | int(row[2]) << 128 | int(row[3]) << 192) % FR_P
+    RINV = pow(1 << 256, -1, FR_P)
+    vals = [[to_int(aa[c * m_stop + i]) * RINV % FR_P for i in range(m_stop)] for c in range(2 * ncirc)]
+    for t in range(turns, turns_full):
+        r = to_int(chal[t]) * RINV % FR_P
+        vals = [[(v[i] + r * (v[i + len(v) // 2] - v[i])) % FR_P for i in range(len(v) // 2)] for v in vals]
+    heads = [to_int(row) * RINV % FR_P for row in fa[-1]]
+    assert [v[0] for v in vals] == heads
+
+
+@pytest.mark.parametrize("n,ncirc", [(512, 2), (1 << 12, 2), (1 << 12, 8), (1 << 16, 2), (1 << 18, 3), (1 << 20, 2), (1 << 13, 16)])
+def test_cubic_round_launched_ahead(devs, n, ncirc):
+    """lasso_sumcheck_cubic_eqw2_begin_ahead + lasso_challenge_post == lasso_sumcheck_cubic_eqw2_begin with the same challenge — sums and the bound arrays — when the round is
+    enqueued while the previous round's result is still pending (the prover's schedule), device and mock; a round that never gets its challenge is released by lasso_abort at once;
+    and while a launch waits, the stream-synchronising entry points refuse instead of blocking."""
+    import time
+    rng = np.random.default_rng(n * 3 + ncirc)
+    A = [rand_fr(rng, n) for _ in range(ncirc)]; B = [rand_fr(rng, n) for _ in range(ncirc)]
+    E = rand_fr(rng, n // 2)
+    r1, r2 = rand_fr(rng, 2, edge=False)
+    vp = lambda x: np.ascontiguousarray(x, dtype=np.uint64).ctypes.data_as(C.c_void_p)
+
+    def plain(d):
+        pa = [d.upload(x) for x in A]; pb = [d.upload(x) for x in B]; pe = d.upload(E)
+        outs = [d.sumcheck_cubic_eqw2(pa, pb, pe, n, None), d.sumcheck_cubic_eqw2(pa, pb, pe, n, r1), d.sumcheck_cubic_eqw2(pa, pb, pe, n // 2, r2)]
+        state = [d.download(p, (n // 4, 4)) for p in pa + pb]
+        for p in pa + pb + [pe]:
+            d.free(p)
+        return outs, state
+
+    def ahead(d):
+        assert d.lib.lasso_rounds_ahead_ok(d.ctx) == 1
+        pa = [d.upload(x) for x in A]; pb = [d.upload(x) for x in B]; pe = d.upload(E)
+        out0 = np.empty((2 * ncirc, 4), dtype=np.uint64); out1 = np.empty_like(out0); out2 = np.empty_like(out0)
+        d._chk(d.lib.lasso_sumcheck_cubic_eqw2_begin(d.ctx, d._ptrs(pa), d._ptrs(pb), ncirc, C.c_void_p(pe), n, None))          # round 0 in flight
+        d._chk(d.lib.lasso_sumcheck_cubic_eqw2_begin_ahead(d.ctx, d._ptrs(pa), d._ptrs(pb), ncirc, C.c_void_p(pe), n))           # round 1 behind it, no challenge yet
+        assert d.lib.lasso_sync(d.ctx) != 0 and d.lib.lasso_trim(d.ctx) != 0                                                       # would block behind the waiting kernel: refused
+        d._chk(d.lib.lasso_result_wait(d.ctx, vp(out0), 2 * ncirc))
+        time.sleep(0.001)
+        d._chk(d.lib.lasso_challenge_post(d.ctx, vp(r1)))
+        d._chk(d.lib.lasso_sumcheck_cubic_eqw2_begin_ahead(d.ctx, d._ptrs(pa), d._ptrs(pb), ncirc, C.c_void_p(pe), n // 2))      # round 2 behind round 1
+        d._chk(d.lib.lasso_result_wait(d.ctx, vp(out1), 2 * ncirc))
+        d._chk(d.lib.lasso_challenge_post(d.ctx, vp(r2)))
+        d._chk(d.lib.lasso_result_wait(d.ctx, vp(out2), 2 * ncirc))
+        state = [d.download(p, (n // 4, 4)) for p in pa + pb]
+        # a round that is enqueued and abandoned: abort returns at once and the context works afterwards
+        d._chk(d.lib.lasso_sumcheck_cubic_eqw2_begin_ahead(d.ctx, d._ptrs(pa), d._ptrs(pb), ncirc, C.c_void_p(pe), n // 4))
+        t0 = time.perf_counter()
+        d._chk(d.lib.lasso_abort(d.ctx))
+        assert time.perf_counter() - t0 < 1.0, "abort must not wait for the kernel's 5 s bail-out"
+        again = d.sumcheck_cubic_eqw2(pa, pb, pe, n // 4, None)
+        for p in pa + pb + [pe]:
+            d.free(p)
+        return [out0, out1, out2], state, again
+    if n // 8 <= 64:      # too short for the streaming kernel: the entry point says so and the caller launches the ordinary round
+        d = devs[0]
+        pa = [d.upload(x) for x in A]; pb = [d.upload(x) for x in B]; pe = d.upload(E)
+        assert d.lib.lasso_sumcheck_cubic_eqw2_begin_ahead(d.ctx, d._ptrs(pa), d._ptrs(pb), ncirc, C.c_void_p(pe), 256) == -4      # LASSO_ERR_UNSUPPORTED
+        out = d.sumcheck_cubic_eqw2(pa, pb, pe, 256, None)       # ... and nothing is left behind on the context
+        assert out.shape == (2 * ncirc, 4)
+        for p in pa + pb + [pe]:
+            d.free(p)
+        return
+    (pa_o, pa_s), (pb_o, pb_s) = both(devs, plain)
+    (aa_o, aa_s, aa_again), (ab_o, ab_s, ab_again) = both(devs, ahead)
+    for x, y, z, w in zip(pa_o, pb_o, aa_o, ab_o):
+        assert np.array_equal(x, y) and np.array_equal(x, z) and np.array_equal(x, w)
+    for x, y, z in zip(pa_s, aa_s, ab_s):
+        assert np.array_equal(canon(x), canon(y)) and np.array_equal(canon(x), canon(z))      # bound arrays: lazily reduced on the device (fr29_semi), canonical in the mock
+    assert np.array_equal(aa_again, ab_again)
+
+
+@pytest.mark.parametrize("n,ncirc,m_stop", [(2048, 2, 1), (2048, 2, 16), (1024, 8, 4), (256, 3, 1), (2048, 33, 2)])
+def test_cubic_tail_launched_ahead(devs, n, ncirc, m_stop):
+    """lasso_sumcheck_cubic_tail_begin_ahead (the resident tail enqueued before the challenge it binds first; the first lasso_sumcheck_cubic_tail_next posts it) == the ordinary
+    tail begun with that challenge, with and without the hand-over of its arrays; enqueued while a round's result is pending, as the prover does."""
+    rng = np.random.default_rng(n * 5 + ncirc + m_stop)
+    A = [rand_fr(rng, 2 * n) for _ in range(ncirc)]; B = [rand_fr(rng, 2 * n) for _ in range(ncirc)]      # the round before the tail works on arrays of 2n
+    E = rand_fr(rng, n)
+    r_prev, r0 = rand_fr(rng, 2, edge=False)
+    q = n // 4
+    turns = (2 * q).bit_length() - 1 - (m_stop.bit_length() - 1)
+    chal = rand_fr(rng, turns, edge=False)
+    vp = lambda x: np.ascontiguousarray(x, dtype=np.uint64).ctypes.data_as(C.c_void_p)
+
+    def run(d, ahead):
+        pa = [d.upload(x) for x in A]; pb = [d.upload(x) for x in B]; pe = d.upload(E)
+        out_prev = np.empty((2 * ncirc, 4), dtype=np.uint64)
+        d._chk(d.lib.lasso_sumcheck_cubic_eqw2_begin(d.ctx, d._ptrs(pa), d._ptrs(pb), ncirc, C.c_void_p(pe), 2 * n, vp(r_prev)))     # the round before: binds 2n -> n, result pending
+        if m_stop > 1:
+            d._chk(d.lib.lasso_tail_handover_next(d.ctx, m_stop))
+        if ahead:
+            d._chk(d.lib.lasso_sumcheck_cubic_tail_begin_ahead(d.ctx, d._ptrs(pa), d._ptrs(pb), ncirc, C.c_void_p(pe), n))
+            d._chk(d.lib.lasso_result_wait(d.ctx, vp(out_prev), 2 * ncirc))
+            d._chk(d.lib.lasso_sumcheck_cubic_tail_next(d.ctx, vp(r0)))
+        else:
+            d._chk(d.lib.lasso_result_wait(d.ctx, vp(out_prev), 2 * ncirc))
+            d._chk(d.lib.lasso_sumcheck_cubic_tail_begin(d.ctx, d._ptrs(pa), d._ptrs(pb), ncirc, C.c_void_p(pe), n, vp(r0)))
+        outs = [out_prev]
+        for t in range(turns):
+            out = np.empty((2 * ncirc, 4), dtype=np.uint64); d._chk(d.lib.lasso_result_wait(d.ctx, vp(out), 2 * ncirc)); outs.append(out)
+            d._chk(d.lib.lasso_sumcheck_cubic_tail_next(d.ctx, vp(chal[t])))
+        fin = np.empty((2 * ncirc * m_stop, 4), dtype=np.uint64); d._chk(d.lib.lasso_result_wait(d.ctx, vp(fin), 2 * ncirc * m_stop)); outs.append(fin)
+        for p in pa + pb + [pe]:
+            d.free(p)
+        return outs
+    ref = run(devs[1], False)
+    for d in devs:
+        for ahead in (False, True):
+            if d is devs[1] and not ahead:
+                continue
+            got = run(d, ahead)
+            assert len(got) == len(ref)
+            for x, y in zip(got, ref):
+                assert np.array_equal(x, y)

@@ -145,7 +145,14 @@ print("DIGEST", hashlib.sha256(comm + proof).hexdigest())
                                  {"LASSO_BULLET_AHEAD": "0"},                # every bullet round launched after its challenge is known (round 3's schedule)
                                  {"LASSO_MSM_DIRECT": "0"},                  # the bucket kernel serves the openings' MSMs too (incl. the deferred delta MSM)
                                  {"LASSO_CAPACITY": "1", "LASSO_LEAFLESS_MIN": "1024"},      # capacity mode: leafless trees, the bottom layer's two streaming rounds from recomputed leaves (8 chunks)
-                                 {"LASSO_CAPACITY": "1", "LASSO_LEAFLESS_MIN": "1024", "LASSO_CUBIC_TAIL": "0", "LASSO_EQ_INLINE": "0"}])
+                                 {"LASSO_CAPACITY": "1", "LASSO_LEAFLESS_MIN": "1024", "LASSO_CUBIC_TAIL": "0", "LASSO_EQ_INLINE": "0"},
+                                 {"LASSO_ROUNDS_AHEAD": "0"},                # round 5: no sumcheck round / resident tail is enqueued before its challenge is known
+                                 {"LASSO_HOST_TAIL": "0"},                   # round 5: the host finishes no tail and proves no tree-top layer (every round through the device, as in round 4)
+                                 {"LASSO_HOST_TAIL": "0", "LASSO_ROUNDS_AHEAD": "0", "LASSO_BULLET_AHEAD": "0"},
+                                 {"LASSO_HOST_TAIL": "128"},                 # ... and takes over four times earlier than the default (arrays of 32 elements at two circuits... here of 32 / 16)
+                                 {"LASSO_HOST_TAIL": "8", "LASSO_TAGGED_RESULTS": "0"},      # hand-over through the flag protocol
+                                 {"LASSO_ROUNDS_AHEAD": "1", "LASSO_CUBIC_TAIL": "0"},      # every round of a layer launched ahead (no resident tail to end in)
+                                 {"LASSO_CAPACITY": "1", "LASSO_LEAFLESS_MIN": "1024", "LASSO_HOST_TAIL": "0"}])
 def test_gpu_ab_switches_do_not_change_the_bytes(host, env):
     """The A/B switches the measurements in DESIGN.md rest on (flag protocol instead of tagged results, in-launch second stage, launch per round instead of the resident tails, ...)
     select other kernels / protocols for the same arithmetic: commitment and proof must be the bytes of the default configuration.  Each setting runs in its own process

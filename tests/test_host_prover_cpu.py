@@ -67,3 +67,47 @@ def test_proof_bytes_equal_oracle_and_verify(host, oracle, kind, c, log_m, log_r
                                           (33, 2, {1: 0}), (2, 9, {}), (2, 9, {0: 1, 8: 0}), (2, 12, {}), (3, 12, {2: 0}), (2, 13, {1: 1, 5: 0})])   # ell >= 11: streaming rounds before the resident tail
 def test_cubic_batched_scripted_eq_points(host, oracle, k, ell, special):
     cubic_batched_case(host, oracle, k, ell, special, seed=k * 100 + ell)
+
+
+_SWITCH_SCRIPT_CPU = """
+import ctypes as C, hashlib, sys
+sys.path.insert(0, "tests")
+from lasso_amd import _abi
+from proverutil import HostProver, build_mock_prover
+hp = HostProver(C.CDLL(build_mock_prover()))
+for kind, c, log_m, log_s in (("and", 2, 12, 12), ("xor", 1, 16, 11), ("lt", 2, 4, 9)):
+    S = _abi.Strategy(_abi.KINDS[kind], c, log_m, 0)
+    idx = hp.gen_indices(1 << log_s, 1 << log_m, c); r = hp.gen_random_point(log_s)
+    gens = hp.gens(c, 1 << log_s, 2 * c if kind == "lt" else c, log_m); dense = hp.densify(idx, log_m)
+    print("DIGEST", hashlib.sha256(hp.commit(dense, gens) + hp.prove(dense, gens, S, r)).hexdigest())
+"""
+
+
+@pytest.mark.parametrize("env", [{"LASSO_HOST_TAIL": "0"}, {"LASSO_ROUNDS_AHEAD": "0"}, {"LASSO_HOST_TAIL": "0", "LASSO_ROUNDS_AHEAD": "0", "LASSO_BULLET_AHEAD": "0"},
+                                 {"LASSO_HOST_TAIL": "128"}, {"LASSO_HOST_TAIL": "4"}, {"LASSO_CUBIC_TAIL": "0"}, {"LASSO_CUBIC_TAIL": "0", "LASSO_HOST_TAIL": "0"},
+                                 {"LASSO_CAPACITY": "1", "LASSO_LEAFLESS_MIN": "64"}, {"LASSO_CAPACITY": "1", "LASSO_LEAFLESS_MIN": "64", "LASSO_HOST_TAIL": "0", "LASSO_ROUNDS_AHEAD": "0"}])
+def test_host_schedule_switches_do_not_change_the_bytes(env):
+    """Round 5's host-side schedule — rounds launched ahead of their challenge, resident tails that hand their arrays to the host, tree-top layers proved on the host — selects
+    WHERE and WHEN the same field arithmetic runs: with every combination of the switches the commitment and proof bytes are those of the default (each setting in its own process:
+    the switches are read once).  CPU twin (mock device ABI) of tests/test_gpu_prover.py::test_gpu_ab_switches_do_not_change_the_bytes."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(extra):
+        e = dict(os.environ); e.pop("LASSO_HOST_TAIL", None); e.pop("LASSO_ROUNDS_AHEAD", None); e.update(extra); e["PYTHONPATH"] = root + os.pathsep + e.get("PYTHONPATH", "")
+        out = subprocess.run([sys.executable, "-c", _SWITCH_SCRIPT_CPU], env=e, cwd=root, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return [l.split()[1] for l in out.stdout.splitlines() if l.startswith("DIGEST")]
+    want = run({})
+    assert len(want) == 3
+    assert run(env) == want
+
+
+@pytest.mark.parametrize("k,ell,special", [(1, 0, {}), (2, 1, {}), (2, 3, {}), (3, 4, {0: 0}), (2, 4, {2: 0}), (2, 4, {3: 1}), (1, 5, {0: 0, 1: 1, 2: 0, 4: 1}), (16, 2, {1: 0}), (2, 5, {0: 1, 4: 0})])
+def test_host_rounds_scripted_eq_points(host, oracle, k, ell, special, monkeypatch):
+    """Prover::host_cubic_rounds (the rounds the host finishes / the tree tops' layers, prover.hpp) against the oracle's literal prove_cubic_batched at the eq points no transcript
+    produces (coordinates 0 and 1), through the same debug entry as the device rounds above (LASSO_DEBUG_CUBIC_HOST=1 routes it to the host rounds)."""
+    monkeypatch.setenv("LASSO_DEBUG_CUBIC_HOST", "1")
+    if ell == 0:
+        pytest.skip("the debug entry needs at least one round")
+    cubic_batched_case(host, oracle, k, ell, special, seed=7000 + k * 100 + ell)
