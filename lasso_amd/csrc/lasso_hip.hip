@@ -613,7 +613,7 @@ static int32_t cubic_eqw_launch_t(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* 
   TM A, B; for (uint32_t i = 0; i < ncirc; i++) { REQUIRE(c, d_A[i] && d_B[i]); A.p[i] = (fr_t*)d_A[i]; B.p[i] = (fr_t*)d_B[i]; }
   int32_t rc = ensure_small(c, (size_t)ncirc * 3); if (rc) return rc;
   const uint32_t seq = next_seq(c); *seq_out = seq;
-  if (!r) {
+  if (!r && !ahead) {
     const size_t half = n / 2;
     ProfScope ps(c, LASSO_K_CUBIC, 32.0 * n * (2.0 * ncirc + 1.0));
     if (half <= CUBIC_SMALL_Q) {   // arrays are read-only in this mode

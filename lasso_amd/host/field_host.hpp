@@ -45,6 +45,88 @@ inline fq_t fq_inv_host(const fq_t& a) {   // plain (non-Montgomery) Fq, lazily 
 }
 #endif
 
+// Host additions / subtractions over four 64-bit limbs (the shared fr_add / fr_sub walk eight 32-bit limbs — the form the device executes — at 17 ns each on x86-64; these take
+// 3-4 ns).  The rounds the host finishes (prover.hpp host_cubic_rounds) are as many additions as products.  Operands canonical (< p), as for fr_add / fr_sub; same results
+// (tests/cpp/test_arith_host.cpp compares them).
+#if defined(__x86_64__) && !defined(LASSO_HOST_LIMBS32)
+}  // namespace lasso
+#include <x86intrin.h>
+namespace lasso {
+struct FrModulus64 { unsigned long long p[4]; FrModulus64() { for (int i = 0; i < 4; i++) p[i] = ((unsigned long long)fr_p_limb(2 * i + 1) << 32) | fr_p_limb(2 * i); } };
+static const FrModulus64 g_fr_p64;
+inline fr_t fr_add_host(const fr_t& a, const fr_t& b) {   // adc / sbb chains (the 128-bit-integer form of the same loops compiled to 25 ns)
+  unsigned long long x[4], y[4], s[4], d[4]; memcpy(x, a.v, 32); memcpy(y, b.v, 32);
+  unsigned char c = 0;
+  c = _addcarry_u64(c, x[0], y[0], &s[0]); c = _addcarry_u64(c, x[1], y[1], &s[1]); c = _addcarry_u64(c, x[2], y[2], &s[2]); c = _addcarry_u64(c, x[3], y[3], &s[3]);   // a, b < p < 2^254: no carry out
+  unsigned char bw = 0;
+  bw = _subborrow_u64(bw, s[0], g_fr_p64.p[0], &d[0]); bw = _subborrow_u64(bw, s[1], g_fr_p64.p[1], &d[1]); bw = _subborrow_u64(bw, s[2], g_fr_p64.p[2], &d[2]); bw = _subborrow_u64(bw, s[3], g_fr_p64.p[3], &d[3]);
+  for (int i = 0; i < 4; i++) s[i] = bw ? s[i] : d[i];   // borrow: the sum is below p
+  fr_t r; memcpy(r.v, s, 32); return r;
+}
+inline fr_t fr_sub_host(const fr_t& a, const fr_t& b) {
+  unsigned long long x[4], y[4], d[4], r4[4]; memcpy(x, a.v, 32); memcpy(y, b.v, 32);
+  unsigned char bw = 0;
+  bw = _subborrow_u64(bw, x[0], y[0], &d[0]); bw = _subborrow_u64(bw, x[1], y[1], &d[1]); bw = _subborrow_u64(bw, x[2], y[2], &d[2]); bw = _subborrow_u64(bw, x[3], y[3], &d[3]);
+  const unsigned long long m = 0ull - (unsigned long long)bw;   // borrowed: add p back
+  unsigned char c = 0;
+  c = _addcarry_u64(c, d[0], g_fr_p64.p[0] & m, &r4[0]); c = _addcarry_u64(c, d[1], g_fr_p64.p[1] & m, &r4[1]); c = _addcarry_u64(c, d[2], g_fr_p64.p[2] & m, &r4[2]); c = _addcarry_u64(c, d[3], g_fr_p64.p[3] & m, &r4[3]);
+  fr_t r; memcpy(r.v, r4, 32); return r;
+}
+// The same field as plain 4 x u64 values that STAY in that form across operations (H4): going through fr_t (eight 32-bit words, 16-byte aligned) between two operations costs a
+// store-forwarding stall each time — 13 ns per addition where the adc chain itself takes 3.  For the rounds the host finishes (prover.hpp host_cubic_rounds).
+struct H4 { unsigned long long l[4]; };
+struct FrMont64 { unsigned long long inv; FrMont64() { unsigned long long x = 1; for (int i = 0; i < 7; i++) x *= 2 - g_fr_p64.p[0] * x; inv = 0ull - x; } };   // -p^-1 mod 2^64 (Newton)
+static const FrMont64 g_fr_mont64;
+inline H4 h4_add(const H4& a, const H4& b) {
+  H4 s, d; unsigned char c = 0, bw = 0;
+  c = _addcarry_u64(c, a.l[0], b.l[0], &s.l[0]); c = _addcarry_u64(c, a.l[1], b.l[1], &s.l[1]); c = _addcarry_u64(c, a.l[2], b.l[2], &s.l[2]); c = _addcarry_u64(c, a.l[3], b.l[3], &s.l[3]);
+  bw = _subborrow_u64(bw, s.l[0], g_fr_p64.p[0], &d.l[0]); bw = _subborrow_u64(bw, s.l[1], g_fr_p64.p[1], &d.l[1]); bw = _subborrow_u64(bw, s.l[2], g_fr_p64.p[2], &d.l[2]); bw = _subborrow_u64(bw, s.l[3], g_fr_p64.p[3], &d.l[3]);
+  for (int i = 0; i < 4; i++) s.l[i] = bw ? s.l[i] : d.l[i];
+  return s;
+}
+inline H4 h4_sub(const H4& a, const H4& b) {
+  H4 d, r; unsigned char bw = 0, c = 0;
+  bw = _subborrow_u64(bw, a.l[0], b.l[0], &d.l[0]); bw = _subborrow_u64(bw, a.l[1], b.l[1], &d.l[1]); bw = _subborrow_u64(bw, a.l[2], b.l[2], &d.l[2]); bw = _subborrow_u64(bw, a.l[3], b.l[3], &d.l[3]);
+  const unsigned long long m = 0ull - (unsigned long long)bw;
+  c = _addcarry_u64(c, d.l[0], g_fr_p64.p[0] & m, &r.l[0]); c = _addcarry_u64(c, d.l[1], g_fr_p64.p[1] & m, &r.l[1]); c = _addcarry_u64(c, d.l[2], g_fr_p64.p[2] & m, &r.l[2]); c = _addcarry_u64(c, d.l[3], g_fr_p64.p[3] & m, &r.l[3]);
+  return r;
+}
+inline H4 h4_mul(const H4& a, const H4& b) {   // Montgomery product (CIOS, R = 2^256): the function fr_mul computes, operands and result canonical
+  typedef unsigned __int128 u128;
+  const unsigned long long* P = g_fr_p64.p; const unsigned long long INV = g_fr_mont64.inv;
+  unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+  for (int i = 0; i < 4; i++) {
+    const unsigned long long y = b.l[i];
+    u128 c = (u128)a.l[0] * y + t0; t0 = (unsigned long long)c; c >>= 64;
+    c += (u128)a.l[1] * y + t1; t1 = (unsigned long long)c; c >>= 64;
+    c += (u128)a.l[2] * y + t2; t2 = (unsigned long long)c; c >>= 64;
+    c += (u128)a.l[3] * y + t3; t3 = (unsigned long long)c; c >>= 64;
+    c += t4; t4 = (unsigned long long)c; const unsigned long long t5 = (unsigned long long)(c >> 64);
+    const unsigned long long m = t0 * INV;
+    c = (u128)m * P[0] + t0; c >>= 64;
+    c += (u128)m * P[1] + t1; t0 = (unsigned long long)c; c >>= 64;
+    c += (u128)m * P[2] + t2; t1 = (unsigned long long)c; c >>= 64;
+    c += (u128)m * P[3] + t3; t2 = (unsigned long long)c; c >>= 64;
+    c += t4; t3 = (unsigned long long)c; t4 = t5 + (unsigned long long)(c >> 64);
+  }
+  H4 s = {{t0, t1, t2, t3}}, d; unsigned char bw = 0;   // < 2p < 2^255: t4 == 0
+  bw = _subborrow_u64(bw, s.l[0], P[0], &d.l[0]); bw = _subborrow_u64(bw, s.l[1], P[1], &d.l[1]); bw = _subborrow_u64(bw, s.l[2], P[2], &d.l[2]); bw = _subborrow_u64(bw, s.l[3], P[3], &d.l[3]);
+  for (int i = 0; i < 4; i++) s.l[i] = bw ? s.l[i] : d.l[i];
+  return s;
+}
+#define LASSO_HAVE_H4 1
+#else
+inline fr_t fr_add_host(const fr_t& a, const fr_t& b) { return fr_add(a, b); }
+inline fr_t fr_sub_host(const fr_t& a, const fr_t& b) { return fr_sub(a, b); }
+struct H4 { fr_t v; };   // portable form: the shared arithmetic
+inline H4 h4_add(const H4& a, const H4& b) { H4 r; r.v = fr_add(a.v, b.v); return r; }
+inline H4 h4_sub(const H4& a, const H4& b) { H4 r; r.v = fr_sub(a.v, b.v); return r; }
+inline H4 h4_mul(const H4& a, const H4& b) { H4 r; r.v = fr_mul(a.v, b.v); return r; }
+#endif
+inline H4 h4_from(const fr_t& a) { H4 r; memcpy(&r, a.v, 32); return r; }
+inline fr_t h4_to(const H4& a) { fr_t r; memcpy(r.v, &a, 32); return r; }
+inline H4 h4_zero() { H4 r; memset(&r, 0, sizeof(r)); return r; }
+
 struct Sc {  // element of Fr in ark-ff's Montgomery form (bytes == lasso_fr)
   fr_t v;
   static Sc zero() { Sc s; s.v = fr_zero(); return s; }
@@ -52,12 +134,12 @@ struct Sc {  // element of Fr in ark-ff's Montgomery form (bytes == lasso_fr)
   static Sc from_u64(uint64_t x) { Sc s; s.v = fr_from_u64(x); return s; }
   static Sc from_abi(const lasso_fr& f) { Sc s; memcpy(s.v.v, f.l, 32); return s; }
   lasso_fr abi() const { lasso_fr f; memcpy(f.l, v.v, 32); return f; }
-  Sc operator+(const Sc& o) const { Sc s; s.v = fr_add(v, o.v); return s; }
-  Sc operator-(const Sc& o) const { Sc s; s.v = fr_sub(v, o.v); return s; }
+  Sc operator+(const Sc& o) const { Sc s; s.v = fr_add_host(v, o.v); return s; }
+  Sc operator-(const Sc& o) const { Sc s; s.v = fr_sub_host(v, o.v); return s; }
   Sc operator*(const Sc& o) const { Sc s; s.v = fr_mul(v, o.v); return s; }
   Sc operator-() const { Sc s; s.v = fr_neg(v); return s; }
-  Sc& operator+=(const Sc& o) { v = fr_add(v, o.v); return *this; }
-  Sc& operator-=(const Sc& o) { v = fr_sub(v, o.v); return *this; }
+  Sc& operator+=(const Sc& o) { v = fr_add_host(v, o.v); return *this; }
+  Sc& operator-=(const Sc& o) { v = fr_sub_host(v, o.v); return *this; }
   Sc& operator*=(const Sc& o) { v = fr_mul(v, o.v); return *this; }
   bool operator==(const Sc& o) const { return fr_eq(v, o.v); }
   bool is_zero() const { return fr_is_zero(v); }

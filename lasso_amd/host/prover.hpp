@@ -999,31 +999,39 @@ class Prover {
     const size_t k = a.size(); size_t m = (size_t)1 << rounds_left;
     LASSO_REQUIRE(k == b.size() && first + rounds_left <= rand.size());
     for (size_t c = 0; c < k; c++) LASSO_REQUIRE(a[c].size() == m && b[c].size() == m);
-    ScVec C = eq_evals_host(rand.data() + first, rounds_left); for (auto& x : C) x *= s_run;
+    // plain 4 x u64 values for the inner loops (field_host.hpp H4).  Per circuit: A, B and A' = coeffs_c * A — the batching coefficient rides on A' (sumcheck.rs:95-97 applies it to
+    // the circuit's sums: the same by linearity), so a term is ONE product per evaluation point; A itself is bound alongside because its final value is a claim (:126-133)
+    std::vector<H4> A(k * m), B(k * m), Aw(k * m), C(m);
+    for (size_t c = 0; c < k; c++) { const H4 w = h4_from(coeffs[c].v); for (size_t i = 0; i < m; i++) { A[c * m + i] = h4_from(a[c][i].v); B[c * m + i] = h4_from(b[c][i].v); Aw[c * m + i] = h4_mul(A[c * m + i], w); } }
+    { ScVec Ce = eq_evals_host(rand.data() + first, rounds_left); const H4 sr = h4_from(s_run.v); for (size_t i = 0; i < m; i++) C[i] = h4_mul(h4_from(Ce[i].v), sr); }
+    auto to_sc = [](const H4& x) { Sc r; r.v = h4_to(x); return r; };
+    size_t stride = m;   // arrays keep their stride; the live prefix halves
     for (size_t j = 0; j < rounds_left; j++) {
       const size_t h = m / 2;
-      Sc e0 = Sc::zero(), e2 = Sc::zero(), e3 = Sc::zero();
+      H4 e0 = h4_zero(), e2 = h4_zero(), e3 = h4_zero();
       for (size_t i = 0; i < h; i++) {
-        Sc t0 = Sc::zero(), t2 = Sc::zero(), t3 = Sc::zero();   // sum_c coeffs_c A_c(x) B_c(x) at x = 0, 2, 3 (:95-97 applies the coefficients to the sums: the same by linearity)
+        H4 t0 = h4_zero(), t2 = h4_zero(), t3 = h4_zero();   // sum_c coeffs_c A_c(x) B_c(x) at x = 0, 2, 3 (`prev + hi - lo`, :68-89)
         for (size_t c = 0; c < k; c++) {
-          const Sc &a0 = a[c][i], &a1 = a[c][i + h], &b0 = b[c][i], &b1 = b[c][i + h];
-          const Sc da = a1 - a0, db = b1 - b0, a2 = a1 + da, b2 = b1 + db, a3 = a2 + da, b3 = b2 + db;
-          t0 += coeffs[c] * (a0 * b0); t2 += coeffs[c] * (a2 * b2); t3 += coeffs[c] * (a3 * b3);
+          const H4 *pa = &Aw[c * stride], *pb = &B[c * stride];
+          const H4 da = h4_sub(pa[i + h], pa[i]), db = h4_sub(pb[i + h], pb[i]), a2 = h4_add(pa[i + h], da), b2 = h4_add(pb[i + h], db), a3 = h4_add(a2, da), b3 = h4_add(b2, db);
+          t0 = h4_add(t0, h4_mul(pa[i], pb[i])); t2 = h4_add(t2, h4_mul(a2, b2)); t3 = h4_add(t3, h4_mul(a3, b3));
         }
-        const Sc dc = C[i + h] - C[i], c2 = C[i + h] + dc, c3 = c2 + dc;
-        e0 += t0 * C[i]; e2 += t2 * c2; e3 += t3 * c3;
+        const H4 dc = h4_sub(C[i + h], C[i]), c2 = h4_add(C[i + h], dc), c3 = h4_add(c2, dc);
+        e0 = h4_add(e0, h4_mul(t0, C[i])); e2 = h4_add(e2, h4_mul(t2, c2)); e3 = h4_add(e3, h4_mul(t3, c3));
       }
-      UniPoly poly = UniPoly::from_evals({e0, e - e0, e2, e3});
+      const Sc E0 = to_sc(e0);
+      UniPoly poly = UniPoly::from_evals({E0, e - E0, to_sc(e2), to_sc(e3)});   // e(1) = claim - e(0) (:99-104)
       poly.append_to_transcript(t, "poly");
       const Sc r_j = t.challenge_scalar("challenge_nextround"); r_out.push_back(r_j);
       e = poly.evaluate(r_j);
       proof.compressed_polys.push_back(poly.compress());
-      for (size_t c = 0; c < k; c++) for (size_t i = 0; i < h; i++) { a[c][i] += r_j * (a[c][i + h] - a[c][i]); b[c][i] += r_j * (b[c][i + h] - b[c][i]); }
-      for (size_t i = 0; i < h; i++) C[i] += r_j * (C[i + h] - C[i]);
+      const H4 rj = h4_from(r_j.v);
+      for (size_t c = 0; c < k; c++) for (H4* arr : {&A[c * stride], &B[c * stride], &Aw[c * stride]}) for (size_t i = 0; i < h; i++) arr[i] = h4_add(arr[i], h4_mul(rj, h4_sub(arr[i + h], arr[i])));   // :116-120
+      for (size_t i = 0; i < h; i++) C[i] = h4_add(C[i], h4_mul(rj, h4_sub(C[i + h], C[i])));
       m = h;
     }
     heads.resize(2 * k);
-    for (size_t c = 0; c < k; c++) { heads[c] = a[c][0].abi(); heads[k + c] = b[c][0].abi(); }
+    for (size_t c = 0; c < k; c++) { heads[c] = to_sc(A[c * stride]).abi(); heads[k + c] = to_sc(B[c * stride]).abi(); }
   }
   // ---- SumcheckInstanceProof::prove_cubic_batched (sumcheck.rs:27-135), comb = A*B*C with C = EqPolynomial(rand).evals() (grand_product.rs:122-128).
   // Round j's bind (sumcheck.rs:116-120) is executed by the same kernel that evaluates round j+1, so a round is ONE launch.  The eq polynomial is

@@ -66,6 +66,39 @@ r_memtable() {     # memtable <tag> [tools/slab_mem_table.py args...]
   local tag="$1"; shift; mkdir -p gpurun_out/$tag
   timeout 1200 python tools/slab_mem_table.py --out gpurun_out/$tag/slab_peak_bytes.json "$@" > gpurun_out/$tag/memtable.log 2> gpurun_out/$tag/memtable.err; grep '"world"' gpurun_out/$tag/memtable.log | cut -c1-400; tail -3 gpurun_out/$tag/memtable.err
 }
+r_benv() {         # benv <tag> "<VAR=val VAR=val ...>" [bench.py args...]: r_bench under environment switches (A/B runs); the quick form of the bench (no CPU baseline / sweeps)
+  local tag="$1" envs="$2"; shift 2; mkdir -p gpurun_out/$tag
+  env $envs timeout 600 python bench.py --no-cpu-baseline --concurrent 0 --no-slab-leg --no-bind-sweep "$@" > gpurun_out/$tag/bench.json 2> gpurun_out/$tag/bench.err
+  python - "$tag" "$envs" <<'PY'
+import json, sys
+tag, envs = sys.argv[1], sys.argv[2]
+try:
+    d = json.loads(open(f"gpurun_out/{tag}/bench.json").read().strip().splitlines()[-1])
+    print(f"{tag} [{envs}]: {d.get('ms_per_step', 0):.3f} ms/step  parity {(d.get('parity_checked') or {}).get('equal')}  roofline {((d.get('roofline') or {}).get('frac'))}")
+except Exception as e:
+    print(f"{tag} [{envs}]: no bench line: {e}"); print(open(f"gpurun_out/{tag}/bench.err").read()[-1200:])
+PY
+}
+r_trace() {        # trace <tag> [bench.py args...]: per-launch kernel trace of ONE proof (timeline csv: start, duration, gap before) + LASSO_TRACE=1 spans + LASSO_TRACE=2 host buckets
+  local tag="$1"; shift; mkdir -p gpurun_out/$tag
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/kt_$tag -o bench -- python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --concurrent 0 --no-slab-leg --no-bind-sweep --no-prof "$@" > $ROOT/gpurun_out/$tag/bench_under_trace.json 2> $ROOT/gpurun_out/$tag/trace.err)
+  f=$(find /tmp/kt_$tag -name '*kernel_trace.csv' | head -1)
+  python - "$f" > gpurun_out/$tag/kernel_trace_one_proof.csv <<'PY'
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1]))); rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+idx = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("k_gather_u32")]
+rows = rows[idx[-1]:] if idx else rows
+t0 = int(rows[0]["Start_Timestamp"]); prev = t0
+print("start_us,dur_us,gap_us,grid,wg,kernel")
+for r in rows:
+    s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+    print("%.2f,%.2f,%.2f,%s,%s,%s" % ((s - t0) / 1e3, (e - s) / 1e3, (s - prev) / 1e3, r.get("Grid_Size_X", r.get("Grid_Size", "")), r.get("Workgroup_Size_X", r.get("Workgroup_Size", "")), r["Kernel_Name"].split("(")[0].replace(",", ";")[:60]))
+    prev = max(prev, e)
+PY
+  wc -l gpurun_out/$tag/kernel_trace_one_proof.csv; tail -1 gpurun_out/$tag/kernel_trace_one_proof.csv
+  LASSO_TRACE=1 timeout 200 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --concurrent 0 --no-slab-leg --no-bind-sweep --no-prof "$@" > /dev/null 2> gpurun_out/$tag/trace_spans.txt; grep "\[trace\]" gpurun_out/$tag/trace_spans.txt | tail -22
+  LASSO_TRACE=2 timeout 200 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --concurrent 0 --no-slab-leg --no-bind-sweep --no-prof "$@" > /dev/null 2> gpurun_out/$tag/host_buckets.txt; grep "\[host\]" gpurun_out/$tag/host_buckets.txt | tail -14
+}
 r_sh() { "$@"; }   # sh <command...>: anything else, verbatim
 
 while [ $# -gt 0 ]; do
