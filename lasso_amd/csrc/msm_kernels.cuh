@@ -765,44 +765,12 @@ __global__ void __launch_bounds__(MSM_THREADS) k_bullet_msm(const fr_t* __restri
   const uint32_t t = threadIdx.x, row = blockIdx.y, K = gridDim.x - 1;
   const uint32_t half = nk / 2, n_loc = n / P;
   // LAUNCHED AHEAD (mail != nullptr): the host enqueued this round behind the previous one, before it knew the challenge — so that neither the launch nor the dispatch sits between
-  // two rounds (27 of the 31 us between two bullet launches were launch and completion latency, 4 us host work) — and posts u, u^-1 into two tagged host-mapped mailboxes
-  // (lasso_hip.hip post_mail, the resident tails' protocol) when it has them.  Workgroup (0, 0) — dispatched first — polls the mailboxes (one PCIe poller, not 254) and republishes
-  // the two scalars in device memory behind a tag; every workgroup spins on that tag.  lasso_abort's poison tag or 5 s without an answer end the launch without a result.
+  // two rounds (27 of the 31 us between two bullet launches were launch and completion latency, 4 us host work).  Since round 5 the wait is a GATE KERNEL in front of this one
+  // (poly_kernels.cuh k_gate: one wave polls the two host-mapped mailboxes and leaves u, u^-1 in gmail[0..16) behind a tag); this kernel starts when the gate ends and reads them
+  // there.  Round 4's form — workgroup (0, 0) polling inside this kernel, the other ~170 spinning on the tag — cost 40 ns per waiting workgroup on the one cache line they shared.
   if (FOLD && mail != nullptr) {
     __shared__ uint32_t s_mail[17];
-    if (t == 0) {
-      const uint64_t t_end = wall_clock64() + 500000000ull;   // 5 s at 100 MHz
-      uint32_t ok = 1, spins = 0;
-      if (blockIdx.x == 0 && blockIdx.y == 0) {
-        const lasso_u32x4* m4 = reinterpret_cast<const lasso_u32x4*>(mail);
-        lasso_u32x4 c[6];
-        for (;;) {
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-#pragma unroll
-          for (int k = 0; k < 6; k++) c[k] = __builtin_nontemporal_load(m4 + k);
-          if (mail_valid(c[0], c[1], c[2], seq) && mail_valid(c[3], c[4], c[5], seq)) break;
-          if (c[0].x == LASSO_MAIL_POISON || c[3].x == LASSO_MAIL_POISON || ((++spins & 63u) == 0 && wall_clock64() > t_end)) { ok = 0; break; }
-        }
-        if (ok) {
-          gmail[0] = c[0].y; gmail[1] = c[0].z; gmail[2] = c[0].w; gmail[3] = c[1].y; gmail[4] = c[1].z; gmail[5] = c[1].w; gmail[6] = c[2].y; gmail[7] = c[2].z;
-          gmail[8] = c[3].y; gmail[9] = c[3].z; gmail[10] = c[3].w; gmail[11] = c[4].y; gmail[12] = c[4].z; gmail[13] = c[4].w; gmail[14] = c[5].y; gmail[15] = c[5].z;
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-          __hip_atomic_store(gmail + 16, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        } else __hip_atomic_store(gmail + 17, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // "this launch has no challenge": everybody leaves
-      }
-      for (spins = 0;;) {
-        if (__hip_atomic_load(gmail + 16, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == seq) break;
-        if (__hip_atomic_load(gmail + 17, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == seq || ((++spins & 63u) == 0 && wall_clock64() > t_end + 100000000ull)) { ok = 0; break; }
-        __builtin_amdgcn_s_sleep(20);   // ~0.5 us between looks: 253 waiting workgroups polling at the atomics' rate took 5 % off the throughput of 16 concurrent proofs
-      }
-      if (ok) {
-#pragma unroll
-        for (int k = 0; k < 16; k++) s_mail[k] = __hip_atomic_load(gmail + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      s_mail[16] = ok;
-    }
-    __syncthreads();
-    if (!s_mail[16]) return;
+    if (!gated_challenge(gmail, seq, 16, s_mail)) return;
 #pragma unroll
     for (int k = 0; k < 8; k++) { u.v[k] = s_mail[k]; u_inv.v[k] = s_mail[8 + k]; }
   }

@@ -111,40 +111,34 @@ __device__ __forceinline__ bool mail_wait(const uint32_t* mailbox, uint32_t tag,
   chal.v[0] = c0.y; chal.v[1] = c0.z; chal.v[2] = c0.w; chal.v[3] = c1.y; chal.v[4] = c1.z; chal.v[5] = c1.w; chal.v[6] = c2.y; chal.v[7] = c2.z;
   return true;
 }
-// A round LAUNCHED AHEAD of its challenge (round 5; the openings' folding rounds have had this form since round 4, msm_kernels.cuh k_bullet_msm): the host enqueues round j + 1
-// behind round j BEFORE it has round j's sums, so that neither the launch nor its dispatch sits between two rounds (12 us of host turn per launched round, of which ~1.5 us are
-// the Fiat-Shamir step), and posts the challenge into the mailbox under the launch's own sequence number when it has it.  Workgroup 0 — dispatched first — is the one PCIe poller;
-// it republishes the scalar in device memory (gmail[0..8), then the tag in gmail[16], release at agent scope) and every workgroup waits on that tag.  gmail[17] = tag means
-// "this launch gets no challenge" (poison / 5 s bail-out): everybody leaves without a result.  All threads of the workgroup call it; s_mail = 9 words of LDS.
-__device__ __forceinline__ bool ahead_challenge(const uint32_t* mail, uint32_t* gmail, uint32_t seq, fr_t& r, uint32_t* s_mail) {
-  if (threadIdx.x == 0) {
-    const uint64_t t_end = wall_clock64() + 500000000ull;   // 5 s at 100 MHz
-    uint32_t ok = 1, spins = 0;
-    if (blockIdx.x == 0) {
-      fr_t c;
-      if (mail_wait(mail, seq, t_end, c)) {
+// A round LAUNCHED AHEAD of its challenge (round 5): the host enqueues round j + 1 behind round j BEFORE it has round j's sums, so that neither the launch nor its dispatch sits
+// between two rounds (12 us of host turn per launched round, of which ~1.5 us are the Fiat-Shamir step), and posts the challenge into the host-mapped mailbox under the launch's own
+// sequence number when it has it.  The wait is a GATE: a one-wave kernel (k_gate) enqueued in front of the round polls the mailbox and leaves the scalar(s) in device memory —
+// gmail[0..8) (and [8..16) for the openings' pair u, u^-1), then gmail[16] = seq; gmail[17] = seq instead means "no challenge" (lasso_abort's poison tag / 5 s without a post) —
+// and the round's kernel, which the stream starts when the gate ends, reads them there (gated_challenge).  Measured on the way (profiles/r05_ahead_wait_forms.txt): with the wait
+// INSIDE the round's kernel (workgroup 0 polling, the others spinning on gmail[16]) a launch lost 40 ns per waiting workgroup — 22 us at 512 workgroups, more than the launch it saved —
+// to 512 lanes hammering one cache line; queued kernels follow each other without a measurable gap, so the gate costs nothing of the kind and occupies one wave, not the chip.
+__global__ void __launch_bounds__(64) k_gate(const uint32_t* mail, uint32_t* gmail, uint32_t seq, uint32_t pair) {   // no __restrict__: the host writes the mailbox while this polls
+  if (threadIdx.x != 0) return;
+  const uint64_t t_end = wall_clock64() + 500000000ull;   // 5 s at 100 MHz
+  fr_t c0, c1;
+  bool ok = mail_wait(mail, seq, t_end, c0);
+  if (ok && pair) ok = mail_wait(mail + 12, seq, t_end, c1);
+  if (ok) {
 #pragma unroll
-        for (int k = 0; k < 8; k++) gmail[k] = c.v[k];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        __hip_atomic_store(gmail + 16, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-      } else __hip_atomic_store(gmail + 17, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    for (;;) {
-      if (__hip_atomic_load(gmail + 16, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == seq) break;
-      if (__hip_atomic_load(gmail + 17, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == seq || ((++spins & 63u) == 0 && wall_clock64() > t_end + 100000000ull)) { ok = 0; break; }
-      __builtin_amdgcn_s_sleep(8);   // ~0.2 us between looks (the waiting workgroups must not crowd the poller's L2 traffic)
-    }
-    if (ok) {
-#pragma unroll
-      for (int k = 0; k < 8; k++) s_mail[k] = __hip_atomic_load(gmail + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    s_mail[8] = ok;
+    for (int k = 0; k < 8; k++) { gmail[k] = c0.v[k]; if (pair) gmail[8 + k] = c1.v[k]; }
+    gmail[16] = seq;
+  } else gmail[17] = seq;
+}
+// every workgroup of the gated launch: the scalar the gate left (false: this launch gets no challenge and must end without a result).  s_mail = 17 words of LDS.
+__device__ __forceinline__ bool gated_challenge(const uint32_t* gmail, uint32_t seq, uint32_t words, uint32_t* s_mail) {
+  if (threadIdx.x < 17) {
+    const uint32_t t = threadIdx.x;
+    if (t < words) s_mail[t] = gmail[t];
+    if (t == 16) s_mail[16] = (gmail[16] == seq && gmail[17] != seq) ? 1u : 0u;
   }
   __syncthreads();
-  if (!s_mail[8]) return false;
-#pragma unroll
-  for (int k = 0; k < 8; k++) r.v[k] = s_mail[k];
-  return true;
+  return s_mail[16] != 0;
 }
 // block partials of up to KMAX accumulators (groups of 3) -> dst[k], k < K; `shift` also corrects the radix of the accumulated products.
 // With `flag` the destination is the launch's result area (result_store at slot0 + k).
@@ -420,28 +414,23 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_eqw_lb(TP A, TP B, uint32
 }
 // fused with K1: bind A and B with r (length n = 4q -> 2q, in place: each element is owned by exactly one thread), then the sums of the NEXT round
 // on the bound values while they are still in registers — one launch per round, 48 bytes per element of A and B plus 32 per index of E.
-// AHEAD: the challenge is not an argument — the launch was enqueued before the host had it and waits for it on the device (ahead_challenge above).  What the wait hides: the
-// launch, the dispatch, and the first index's eight loads, which are issued before the wait (`pre`): they do not depend on the challenge.
+// AHEAD: the challenge is not an argument — the launch was enqueued before the host had it, behind a gate kernel that waits for it (k_gate above) and leaves it in gmail.
 template <int NT, bool WIDE = false, class TM = MutPtrTable, bool AHEAD = false>
 #ifdef LASSO_FUSED_WAVES   // experiment switch: force the register budget of the fused round (waves per SIMD); default = the compiler's choice (157 VGPRs, 3 waves)
 __attribute__((amdgpu_waves_per_eu(LASSO_FUSED_WAVES, LASSO_FUSED_WAVES)))
 #endif
 __global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_eqw_fused(TM A, TM B, uint32_t nx, uint32_t ny, const fr_t* __restrict__ E, size_t q, fr_t r,
                                                                   fr_t* __restrict__ partials, uint32_t* counters, fr_t* __restrict__ out, uint32_t* flag, uint32_t seq,
-                                                                  const uint32_t* mail = nullptr, uint32_t* gmail = nullptr) {
+                                                                  const uint32_t* gmail = nullptr) {
   __shared__ RedScratch S;
   const CubicGrid g = cubic_grid(nx, ny);
   fr_t* __restrict__ a = A.p[g.by];
   fr_t* __restrict__ b = B.p[g.by];
   if constexpr (AHEAD) {
-    __shared__ uint32_t s_mail[9];
-    // warm the first index's lines while the challenge travels (the loop below re-reads them from the cache; keeping them in registers across the wait cost 64 VGPRs and a wave of occupancy)
-    const size_t i0 = g.bx * (size_t)blockDim.x + threadIdx.x;
-    if (i0 < q) {   // one word of each of the eight lines (gfx950 has no prefetch instruction): in flight during the first poll, consumed by an empty asm so that they are not dropped
-      const uint32_t warm = a[i0].v[0] ^ a[i0 + q].v[0] ^ a[i0 + 2 * q].v[0] ^ a[i0 + 3 * q].v[0] ^ b[i0].v[0] ^ b[i0 + q].v[0] ^ b[i0 + 2 * q].v[0] ^ b[i0 + 3 * q].v[0] ^ E[i0].v[0];
-      asm volatile("" ::"v"(warm));
-    }
-    if (!ahead_challenge(mail, gmail, seq, r, s_mail)) return;
+    __shared__ uint32_t s_mail[17];
+    if (!gated_challenge(gmail, seq, 8, s_mail)) return;
+#pragma unroll
+    for (int k = 0; k < 8; k++) r.v[k] = s_mail[k];
   }
   const fr29 rs = fr29_unpack_s(r);
   fr29 e[3] = {fr29_zero(), fr29_zero(), fr29_zero()}; uint32_t cnt = 0;
