@@ -204,6 +204,8 @@ int32_t lasso_tail_handover_next(lasso_ctx* ctx, uint32_t m_stop);
 int32_t lasso_rounds_ahead_ok(lasso_ctx* ctx);
 int32_t lasso_sumcheck_cubic_eqw2_begin_ahead(lasso_ctx* ctx, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n);
 int32_t lasso_challenge_post(lasso_ctx* ctx, const lasso_fr* r);
+/* lasso_sumcheck_linear_eqw_round_fused (in place) enqueued ahead of its challenge: lasso_challenge_post, then lasso_result_wait delivers its 3 * alpha values */
+int32_t lasso_sumcheck_linear_eqw_round_fused_ahead(lasso_ctx* ctx, lasso_fr* const* d_polys, uint32_t alpha, const lasso_fr* d_E, size_t n);
 int32_t lasso_sumcheck_cubic_tail_begin_ahead(lasso_ctx* ctx, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n);
 uint32_t lasso_sumcheck_tail_capacity(void);
 int32_t lasso_sumcheck_cubic_tail_next(lasso_ctx* ctx, const lasso_fr* r);

@@ -73,6 +73,7 @@ def declare(lib):
         "lasso_rounds_ahead_ok": (i32, [vp]),
         "lasso_sumcheck_cubic_eqw2_begin_ahead": (i32, [vp, P(vp), P(vp), u32, vp, sz]),
         "lasso_challenge_post": (i32, [vp, vp]),
+        "lasso_sumcheck_linear_eqw_round_fused_ahead": (i32, [vp, P(vp), u32, vp, sz]),
         "lasso_sumcheck_cubic_tail_begin_ahead": (i32, [vp, P(vp), P(vp), u32, vp, sz]),
         "lasso_gp_build": (i32, [vp, vp, sz]),
         "lasso_fingerprint_ops": (i32, [vp, vp, vp, vp, sz, vp, vp, vp, vp]),

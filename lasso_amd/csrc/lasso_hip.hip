@@ -851,10 +851,28 @@ int32_t lasso_sumcheck_linear_eqw_round_fused_from(lasso_ctx* c, const lasso_fr*
   {
     // bind (48 n per polynomial, the reference's alpha + 1 of them) with the next round's sums riding on the same pass
     ProfScope ps(c, LASSO_K_BIND, 48.0 * n * (alpha + 1.0));
-    hipLaunchKernelGGL(k_dot_eqw_fused, dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, Src, P, nx, ny, (const fr_t*)d_E, q, to_fr(r), (fr_t*)c->d_scratch, c->d_counters, RES(c), seq);
+    hipLaunchKernelGGL(k_dot_eqw_fused<false>, dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, Src, P, nx, ny, (const fr_t*)d_E, q, to_fr(r), (fr_t*)c->d_scratch, c->d_counters, RES(c), seq);
   }
   HIPCHK(c, hipGetLastError());
   return wait_flag(c, seq, (size_t)alpha * 3, out, c->tagged);
+}
+// lasso_sumcheck_linear_eqw_round_fused(.., r, out) enqueued AHEAD of r (in place; gate kernel + k_dot_eqw_fused<AHEAD>): lasso_challenge_post releases it, lasso_result_wait
+// delivers the 3 * alpha values.  Same rules as lasso_sumcheck_cubic_eqw2_begin_ahead.
+int32_t lasso_sumcheck_linear_eqw_round_fused_ahead(lasso_ctx* c, lasso_fr* const* d_polys, uint32_t alpha, const lasso_fr* d_E, size_t n) {
+  REQUIRE(c, d_polys && d_E && alpha >= 1 && alpha <= LASSO_MAX_PTRS && n >= 4 && (n & (n - 1)) == 0 && !c->ahead_active && !c->tail_active && !c->defer_next);
+  MutPtrTable P; PtrTable Src; for (uint32_t i = 0; i < alpha; i++) { REQUIRE(c, d_polys[i]); P.p[i] = (fr_t*)d_polys[i]; Src.p[i] = (const fr_t*)d_polys[i]; }
+  const size_t q = n / 4; const unsigned ny = alpha, nx = grid_for(q, cubic_nx_cap(ny));
+  int32_t rc = ensure_small(c, (size_t)alpha * 3); if (rc) return rc;
+  rc = ensure_scratch(c, (size_t)nx * ny * 3 * sizeof(fr_t)); if (rc) return rc;
+  const uint32_t seq = next_seq(c);
+  {
+    ProfScope ps(c, LASSO_K_BIND, 48.0 * n * (alpha + 1.0));
+    hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, c->stream, (const uint32_t*)c->mail_d, c->d_gmail, seq, 0u);
+    hipLaunchKernelGGL(k_dot_eqw_fused<true>, dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, Src, P, nx, ny, (const fr_t*)d_E, q, fr_zero(), (fr_t*)c->d_scratch, c->d_counters, RES(c), seq, (const uint32_t*)c->d_gmail);
+  }
+  HIPCHK(c, hipGetLastError());
+  c->ahead_active = true; c->ahead_bullet = false; c->ahead_seq = seq; c->ahead_count = (size_t)alpha * 3; c->ahead_tagged = c->tagged; c->ahead_groups = 1; c->ahead_K = 0;
+  return 0;
 }
 // the first round and the first bind of the primary sumcheck from the lookup polynomials' integer values (k_dot_eqw_lb_u32 / k_dot_eqw_fused_from_u32)
 int32_t lasso_sumcheck_linear_eqw_round_u32(lasso_ctx* c, const uint32_t* const* d_u32, uint32_t alpha, const lasso_fr* d_E, size_t n, lasso_fr* out) {

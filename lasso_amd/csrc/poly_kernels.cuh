@@ -715,12 +715,20 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_dot_eqw_lb(PtrTable polys, uint
 }
 // src != polys: the bind reads src (length 4q) and writes the bound halves to polys — the first bind of the primary sumcheck takes E itself as
 // src, so surge.rs:151's clone of the lookup polynomials never happens (the sumcheck must not modify E, which the later openings read)
+// AHEAD: launched before the host had the challenge, behind a gate kernel (k_gate) that leaves it in gmail
+template <bool AHEAD = false>
 __global__ void __launch_bounds__(LASSO_BLOCK) k_dot_eqw_fused(PtrTable src, MutPtrTable polys, uint32_t nx, uint32_t ny, const fr_t* __restrict__ E, size_t q, fr_t r, fr_t* __restrict__ partials, uint32_t* counters,
-                                                                fr_t* __restrict__ out, uint32_t* flag, uint32_t seq) {
+                                                                fr_t* __restrict__ out, uint32_t* flag, uint32_t seq, const uint32_t* gmail = nullptr) {
   __shared__ RedScratch S;
   const CubicGrid g = cubic_grid(nx, ny);
   fr_t* zd = polys.p[g.by];          // may alias z (in-place call): every thread reads its four elements before it writes its two
   const fr_t* z = src.p[g.by];
+  if constexpr (AHEAD) {
+    __shared__ uint32_t s_mail[17];
+    if (!gated_challenge(gmail, seq, 8, s_mail)) return;
+#pragma unroll
+    for (int k = 0; k < 8; k++) r.v[k] = s_mail[k];
+  }
   const fr29 rs = fr29_unpack_s(r);
   fr29_acc w0 = fr29_acc_zero(), w1 = fr29_acc_zero(); uint32_t cnt = 0;
   for (size_t i = g.bx * (size_t)blockDim.x + threadIdx.x; i < q; i += (size_t)nx * blockDim.x) {

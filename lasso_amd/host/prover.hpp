@@ -122,7 +122,8 @@ class Dev {
   // high-water mark is the live set at the tree phase, not the pool) and cost 10x the proof time in hipFree / hipMalloc (profiles/r04_slab_peak_bytes_first_cut.json).
   // LASSO_CAPACITY=1 turns it on for every host; lasso_host_set_capacity sets it per host; default: off.
   bool capacity = [] { const char* e = getenv("LASSO_CAPACITY"); return e && e[0] == '1'; }();
-  bool throughput = false;   // lasso_host_set_throughput_mode: several hosts prove concurrently on this GPU — no kernel of this host waits on the device for its host thread
+  bool throughput = false;   // lasso_host_set_throughput_mode: several hosts prove concurrently on this GPU — nothing of this host is launched ahead of its challenge (LASSO_THROUGHPUT_AHEAD=1: launched ahead all the same — since round 5 the wait is one gate wave, not a kernel's worth of compute units; A/B switch)
+  bool no_ahead() const { static const bool keep = [] { const char* e = getenv("LASSO_THROUGHPUT_AHEAD"); return e && e[0] == '1'; }(); return throughput && !keep; }
   explicit Dev(int device) : device_(device) {
     if (lasso_ctx_create(device, &ctx) != 0) throw Error(std::string("lasso_ctx_create: ") + lasso_last_error(nullptr));
     const char* e = getenv("LASSO_SIDE_STREAM");
@@ -824,6 +825,14 @@ class Prover {
       if (j0 < rounds) tail_from = j0;
     }
     bool in_tail = false;
+    // streaming rounds launched ahead of their challenge, as in cubic_rounds (in-place rounds only: from round 2 on)
+    static const bool ahead_env_off = [] { const char* v = getenv("LASSO_ROUNDS_AHEAD"); return v && v[0] == '0'; }();
+    const bool ahead_ok = !ahead_env_off && !reduce && !degenerate && P == 1 && !d.no_ahead() && lasso_rounds_ahead_ok(d.ctx) == 1;
+    bool queued = false;
+    auto enqueue_next = [&](size_t jn, size_t len_now) {   // round jn (>= 2) on arrays of len_now elements, behind the round in flight
+      if (!ahead_ok || jn < 2 || jn >= rounds || jn >= tail_from) return;
+      d.chk(lasso_sumcheck_linear_eqw_round_fused_ahead(d.ctx, polys.data(), (uint32_t)alpha, d_E, len_now), "lasso_sumcheck_linear_eqw_round_fused_ahead"); queued = true;
+    };
     for (size_t j = 0; j < rounds; j++) {
       const lasso_fr* table = d_E; Sc scale = degenerate ? Sc::one() : inv[j];
       if (degenerate) {
@@ -833,6 +842,13 @@ class Prover {
         table = tj.p;
       }
       std::vector<lasso_fr> ev(3 * alpha);
+      if (queued) {   // this round's kernel is in the stream already: its challenge, the next round behind it, then its sums
+        lasso_fr rp = r_prev.abi();
+        d.chk(lasso_challenge_post(d.ctx, &rp), "lasso_challenge_post"); queued = false;
+        len /= 2;
+        enqueue_next(j + 1, len);
+        d.chk(lasso_result_wait(d.ctx, ev.data(), 3 * alpha), "lasso_result_wait");
+      } else
       if (j >= tail_from) {
         lasso_fr rp = r_prev.abi();
         if (!in_tail) {   // the data is still in src if no bind has moved it yet
@@ -853,6 +869,7 @@ class Prover {
         else if (j == 1 && src) d.chk(lasso_sumcheck_linear_eqw_round_fused_from(d.ctx, src->data(), polys.data(), (uint32_t)alpha, table, len, &rp, ev.data()), "lasso_sumcheck_linear_eqw_round_fused_from");
         else d.chk(lasso_sumcheck_linear_eqw_round_fused(d.ctx, polys.data(), (uint32_t)alpha, table, len, &rp, ev.data()), "lasso_sumcheck_linear_eqw_round_fused");
         len /= 2;
+        enqueue_next(j + 1, len);   // the chain of launched-ahead rounds starts here: round j + 1 goes into the stream before this round's Fiat-Shamir step
       }
       if (reduce) d.comm.sum(ev);
       Sc G0 = Sc::zero(), G1 = Sc::zero();
@@ -1083,7 +1100,7 @@ class Prover {
     // Rounds LAUNCHED AHEAD of their challenge (include/lasso_hip.h lasso_sumcheck_cubic_eqw2_begin_ahead): while round j runs, round j + 1 — a streaming round, or the resident
     // tail — is already in the stream and waits on the device for the challenge this loop posts.  One GPU, plain rounds only (no collective between rounds, no per-round table).
     static const bool ahead_env_off = [] { const char* v = getenv("LASSO_ROUNDS_AHEAD"); return v && v[0] == '0'; }();
-    const bool ahead_ok = !ahead_env_off && !reduce && !degenerate && P == 1 && !d.throughput && heads_out && lasso_rounds_ahead_ok(d.ctx) == 1;
+    const bool ahead_ok = !ahead_env_off && !reduce && !degenerate && P == 1 && !d.no_ahead() && heads_out && lasso_rounds_ahead_ok(d.ctx) == 1;
     bool queued = false, queued_tail = false;   // this round's kernel is already enqueued (a streaming round / the resident tail) and waits for r_prev
     std::vector<DBuf> leaf_full;   // the leaves after all, for the rare shapes the chunked rounds do not cover
     if (leaf) {
@@ -1353,7 +1370,7 @@ class Prover {
     // Rounds launched AHEAD (one GPU): the kernel of round k+1 is enqueued behind round k before round k's L, R are back; it waits on the device for the challenge the host posts
     // (lasso_bullet_post) — the host turn between two rounds is ~4 us of work, the launch and its dispatch were 27 us more (include/lasso_hip.h).  `queued`: this round's kernel is
     // already in the stream, its ping-pong buffers already swapped.
-    const bool ahead = !shard && !d.throughput && lasso_bullet_ahead_ok(d.ctx, g.bases) == 1;
+    const bool ahead = !shard && !d.no_ahead() && lasso_bullet_ahead_ok(d.ctx, g.bases) == 1;
     bool queued = false;
     auto enqueue_next = [&](size_t nk_next) {   // the round after the one in flight: folds (a_cur, b_cur, w_cur) — being written by the launch in flight, stream order — to length nk_next
       lasso_fr bl[2] = {v1[round + 1].abi(), v2[round + 1].abi()};

@@ -23,7 +23,7 @@ struct lasso_ctx {
   size_t tail_stop = 1;       // lasso_tail_handover_next: the tail in progress hands its arrays over at this length; handover_next: the value for the next begin
   uint32_t handover_next = 0;
   // sumcheck rounds / the resident tail launched ahead of their challenge: the arguments wait here for lasso_challenge_post / the first lasso_sumcheck_cubic_tail_next
-  struct RoundAhead { bool on = false, tail = false; std::vector<lasso_fr*> A, B; const lasso_fr* E; size_t n; } rahead;
+  struct RoundAhead { bool on = false, tail = false, linear = false; std::vector<lasso_fr*> A, B; const lasso_fr* E; size_t n; } rahead;
   // a bullet round launched ahead of its challenge: the arguments wait here for lasso_bullet_post
   std::mutex mem_mu; std::map<void*, size_t> mem_sizes; uint64_t mem_live = 0, mem_peak = 0, alloc_calls = 0;   // lasso_mem_stats of the mock
   struct Ahead { bool on = false; const lasso_bases* bs; size_t n, nk; const lasso_fr *a_in, *b_in, *w_in; lasso_fr *a_out, *b_out, *w_out; lasso_fr blinds[2]; } ahead;
@@ -292,9 +292,20 @@ int32_t lasso_sumcheck_cubic_eqw2_begin_ahead(lasso_ctx* c, lasso_fr* const* A, 
   if (n / 4 <= 64) { c->err = "streaming rounds only"; return LASSO_ERR_UNSUPPORTED; }
   c->rahead.on = true; c->rahead.tail = false; c->rahead.A.assign(A, A + nc); c->rahead.B.assign(B, B + nc); c->rahead.E = E; c->rahead.n = n; return 0;
 }
+int32_t lasso_sumcheck_linear_eqw_round_fused(lasso_ctx* c, lasso_fr* const* polys, uint32_t alpha, const lasso_fr* E, size_t n, const lasso_fr* r, lasso_fr* out);
+int32_t lasso_sumcheck_linear_eqw_round_fused_ahead(lasso_ctx* c, lasso_fr* const* polys, uint32_t alpha, const lasso_fr* E, size_t n) {
+  REQ(c, polys && E && alpha >= 1 && n >= 4 && (n & (n - 1)) == 0 && !c->rahead.on && !c->ahead.on && c->tail_a.empty() && !c->defer);
+  c->rahead.on = true; c->rahead.tail = false; c->rahead.linear = true; c->rahead.A.assign(polys, polys + alpha); c->rahead.B.clear(); c->rahead.E = E; c->rahead.n = n; return 0;
+}
 int32_t lasso_challenge_post(lasso_ctx* c, const lasso_fr* r) {
   REQ(c, r && c->rahead.on && !c->rahead.tail && c->pending.empty());
   c->rahead.on = false;
+  if (c->rahead.linear) {   // parked for lasso_result_wait, as after lasso_defer_next
+    c->rahead.linear = false;
+    std::vector<lasso_fr> out(3 * c->rahead.A.size());
+    int32_t rc = lasso_sumcheck_linear_eqw_round_fused(c, c->rahead.A.data(), (uint32_t)c->rahead.A.size(), c->rahead.E, c->rahead.n, r, out.data()); if (rc) return rc;
+    c->pending.assign(F(out.data()), F(out.data()) + out.size()); return 0;
+  }
   return lasso_sumcheck_cubic_eqw2_begin(c, c->rahead.A.data(), c->rahead.B.data(), (uint32_t)c->rahead.A.size(), c->rahead.E, c->rahead.n, r);
 }
 int32_t lasso_sumcheck_cubic_tail_begin_ahead(lasso_ctx* c, lasso_fr* const* A, lasso_fr* const* B, uint32_t nc, const lasso_fr* E, size_t n) {
