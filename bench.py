@@ -121,7 +121,7 @@ def pmc_traffic(key):
     """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command ON THIS WORKLOAD (profiles/r0N_pmc/<workload key>/bench_traffic.json, written by
     tools/pmc_summary.py: FETCH_SIZE x2 per MI355X_MICROARCH.md's gfx950 correction + WRITE_SIZE, large launches only).  {} when no pass of this workload is
     committed — `traffic` / `frac_traffic` are then null rather than borrowed from another configuration (VERDICT r2 "What's weak" 4)."""
-    for d in ("r03_pmc", "r02_pmc", "r01_pmc"):     # newest committed passes first
+    for d in ("r05_pmc", "r03_pmc", "r02_pmc", "r01_pmc"):     # newest committed passes first
         for sub in (key, ""):
             try:
                 with open(os.path.join(ROOT, "profiles", d, sub, "bench_traffic.json")) as f:
@@ -130,6 +130,7 @@ def pmc_traffic(key):
                 continue
             wk = t.pop("_workload", "and_c1_m16_2p24_curve25519")      # files of rounds 1-2 carry no key: they are passes of the default command
             if wk == key:
+                t["_pass"] = {"dir": f"profiles/{d}/{sub}".rstrip("/"), "device_sources_sha256": t.pop("_device_sources_sha256", None)}
                 return t
     return {}
 
@@ -337,13 +338,19 @@ def bind_top_sweep(dev_lib, ctx, _abi, curve, iterations=20, warmup=3):
            "iterations": iterations, "warmup": warmup, "algorithmic_bytes": "48 * n * polys per launch (read 32 n + write 16 n per polynomial, SURVEY 8(d))",
            "timing": "HIP events on the library's stream around each launch (lasso_prof_*), buffer sets rotated so that no launch re-reads what the previous one touched",
            "rows": rows, "frac_min": min((x["frac"] for x in ok), default=None), "frac_max": max((x["frac"] for x in ok), default=None)}
-    try:     # counter-measured HBM bytes of the same sweep (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --only-bind-sweep`, tools/pmc_summary.py)
-        with open(os.path.join(ROOT, "profiles", "r04_pmc", "bind_top_sweep", "bench_traffic.json")) as f:
-            t = json.load(f)
+    out["traffic"] = None
+    for d in ("r05_pmc", "r04_pmc"):     # counter-measured HBM bytes of the same sweep (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --only-bind-sweep`, tools/pmc_bind_summary.py)
+        try:
+            with open(os.path.join(ROOT, "profiles", d, "bind_top_sweep", "bench_traffic.json")) as f:
+                t = json.load(f)
+        except Exception:
+            continue
         if t.get("_curve", "curve25519") == curve:
+            sha = t.get("_device_sources_sha256"); now = lib_sha(curve).get("device_sources_sha256")
+            t["fresh"] = bool(sha) and sha == now
+            t["note"] = "PMC pass taken on these device sources" if t["fresh"] else f"STALE: pass under profiles/{d}/bind_top_sweep taken on other device sources (digest {str(sha)[:12]}, this run {now[:12]})"
             out["traffic"] = t
-    except Exception:
-        out["traffic"] = None
+            break
     return out
 
 
@@ -593,6 +600,8 @@ def main():
         kernels = [f for f in (family(k, False) for k in range(_abi.K_COUNT)) if f]
     elapsed = grp.max_over_ranks(elapsed)
     digests = grp.gather_digests(proof)
+    mem_now = hp.mem_stats()
+    peaks = grp.gather_floats(mem_now["peak_bytes"]); rccl_all = grp.gather_floats(dev_lib.lasso_rccl_ready(ctx))
 
     if rank == 0:
         ms_per_step = elapsed / a.steps * 1e3
@@ -605,10 +614,20 @@ def main():
                                       f"timed = SparsePolynomialEvaluationProof::prove with the densified representation resident in HBM",
                           "vs_baseline_reference": "2^24 AND lookups, C=1, SparsePoly.prove 35.3 s with rayon on an Apple M1 16 GB (reference's src/benches/m1_16gb_parallel_benches.log:439; BASELINE.md §1)",
                           "per_rank": ("one proof sharded over the ranks by low index bits (slab mode)" if slab else "one independent proof per rank") if world > 1 else "single proof",
-                          "proof_bytes": len(proof), "distinct_proofs": len(set(digests)), "densify_s": round(t_densify, 3), "commit_s": round(t_commit, 3), "commit_warm_s": round(t_commit_warm, 3), "gens_setup_s": round(t_setup, 3),
+                          "proof_bytes": len(proof), "proof_sha256": __import__("hashlib").sha256(proof).hexdigest(), "distinct_proofs": len(set(digests)), "densify_s": round(t_densify, 3), "commit_s": round(t_commit, 3), "commit_warm_s": round(t_commit_warm, 3), "gens_setup_s": round(t_setup, 3),
                           "whole_bench_lookups_per_s": s / (t_densify + t_commit + ms_per_step / 1e3)}}
         out["lib_sha"] = lib_sha(a.curve)
         out["config"]["workload_key"] = workload_key(a.kind, c, log_m, a.log_s, a.curve)
+        if a.kind == "spark":    # not a parity claim against upstream
+            out["config"]["unverified_against_reference"] = ("kind=spark is LASSO_SPARK_UNCONFIRMED: BASELINE.json configs[4] names a SparkSubtableStrategy the reference snapshot does not contain "
+                                                             "(src/subtables/mod.rs:22-26); tables, degree and combine function are restated from SURVEY 8(f3)'s one-line description — GPU == this repo's own oracle, nothing more")
+        # self-describing multi-GPU line: what ran on how many ranks, which exchange, and what each rank held at most
+        out["multi_gpu"] = {"ranks": world, "mode": ("one proof sharded over the ranks by low index bits (slab mode)" if slab else "one independent proof per rank, no data-path collective") if world > 1 else "single GPU",
+                            "rccl_ranks": int(min(rccl_all)) if rccl_all else 0,
+                            "exchange": ("per-round partial sums: shared-memory all-gather (lasso_amd/host/shm_comm.hpp); partial row commitments: " +
+                                         ("RCCL ncclAllGather on the library's stream + device-side row sums" if world > 1 and int(min(rccl_all)) == world else "shared-memory all-gather + host row sums"))
+                                        if slab else ("none on the data path; torch.distributed (" + str(a.backend or ("nccl" if world > 1 else "-")) + ") for the timing barrier and the 32-byte proof digests" if world > 1 else "none"),
+                            "peak_bytes_per_rank": [int(x) for x in peaks]}
         if os.environ.get("LASSO_BENCH_SELF_LAUNCHED"):
             out["config"]["launched_by"] = "bench.py --gpus N itself (torch.distributed.run, 127.0.0.1)"
         if kernels:
@@ -626,9 +645,17 @@ def main():
                 allk = next((x for x in kernels if x["kernel"] == k["kernel"]), None)
                 tr = traffic.get(k["kernel"])
                 ach_tr = tr["bytes_per_launch"] * k["launches"] / (k["ms"] * 1e-3) / 1e9 if tr else None
+                # The counters are a committed rocprofv3 pass, not part of this run: they describe THIS run's kernels only if the device sources are the ones the pass was
+                # taken on.  The pass records their digest (tools/pmc_summary.py); anything else is labelled stale instead of passing as measured at HEAD (VERDICT r4 "weak" 6).
+                pas = traffic.get("_pass") or {}
+                fresh = bool(pas.get("device_sources_sha256")) and pas["device_sources_sha256"] == out["lib_sha"].get("device_sources_sha256")
                 return {"kernel": k["kernel"], "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                         "traffic": tr["bytes_per_launch"] if tr else None, "achieved_traffic": round(ach_tr, 1) if ach_tr else None,
                         "frac_traffic": round(ach_tr / HBM_PEAK_GBS, 4) if ach_tr else None,
+                        "traffic_fresh": fresh if tr else None,
+                        "traffic_note": None if not tr else ("PMC pass taken on these device sources" if fresh else
+                                                             f"STALE: the PMC pass under {pas.get('dir')} was taken on other device sources (its digest {str(pas.get('device_sources_sha256'))[:12]}, this run's "
+                                                             f"{out['lib_sha'].get('device_sources_sha256', '')[:12]}): bytes per launch of an older build of the kernel"),
                         "alg_bytes_per_launch": round(k["alg_GB"] * 1e9 / k["launches"]),
                         "launches": k["launches"], "avg_launch_us": k["avg_launch_us"],
                         "scope": "launches with >= 256 MiB algorithmic bytes, HIP events inside the timed region",
@@ -667,6 +694,9 @@ def main():
                 peak = ceil_["G_madd_per_s"] if ceil_ else None
                 return {"kernel": k["kernel"], "bound": "valu (integer multiply-add issue; no MFMA, no HBM stream)", "achieved": round(ach, 2) if ach else None, "peak": peak,
                         "unit": "G mixed additions/s", "frac": round(ach / peak, 4) if ach and peak else None,
+                        # the same rate against what a tight loop of NOTHING BUT mixed additions sustains on this part (tools/microbench.hip: 64-bit multiply-adds issue every ~5.25 cycles,
+                        # not 4) — the practical ceiling; `frac` against the ISA-derived one understates a kernel that is close to it (VERDICT r4 "weak" 7)
+                        "frac_microbench": round(ach / ceil_["microbenchmark_G_madd_per_s"], 4) if ach and ceil_ and ceil_.get("microbenchmark_G_madd_per_s") else None,
                         "counted": "on the device (non-zero digits / bytes), profiled step" if exact_per_launch else "upper bound (one per digit read; zero digits are skipped)",
                         "executed_madds_per_launch": round(per_launch) if per_launch else None, "launches": k["launches"], "avg_launch_us": k["avg_launch_us"], "scope": scope,
                         "peak_source": ceil_["source"] if ceil_ else None, "valu_instructions_per_madd": ceil_.get("valu_instructions_per_madd") if ceil_ else None,
@@ -679,6 +709,21 @@ def main():
             for fam, rm in out["roofline_msm"].items():     # a fraction above 1 is a broken denominator, not a result: say so instead of printing it
                 if rm and rm.get("frac") is not None and rm["frac"] > 1.0:
                     rm["error"] = f"frac {rm['frac']} > 1: the ceiling is not a ceiling"; rm["frac"] = None
+            if a.kind in ("lt", "spark"):
+                # The degree-C strategies' round kernel (prove_arbitrary with a product form, sumcheck.rs:165-255) is VALU-bound, not HBM-bound: per index it evaluates
+                # comb_func at d + 1 points, ~alpha field products each (g = prod E_m for Spark; the LT / EQ chain of lt.rs:60-83) — 17 x 16 products per index at C = 16
+                # against 32 (alpha + 1) bytes.  Its ceiling is the part's field-product rate (tools/microbench.hip: 180 G reduced 29-bit-limb products/s sustained;
+                # 256 CUs x 64 lanes x 2.4 GHz / 210 VALU instructions per fr29_mul = 187 G/s from the ISA), not 8 TB/s (VERDICT r4 "weak" 3).
+                kc = next((x for x in kernels if x["kernel"] == _abi.KERNEL_NAMES[_abi.K_COMBINE]), None)
+                if kc and kc["ms"] > 0:
+                    deg1 = (c + 1) + 1                                                        # sumcheck_poly_degree() + 1 evaluation points
+                    n_total = kc["alg_GB"] * 1e9 / (32.0 * (alpha + 1))                        # sum over the launches of the arrays' length (the family's algorithmic bytes are 32 (alpha + 1) n)
+                    products = n_total / 2 * deg1 * alpha
+                    ach = products / (kc["ms"] * 1e-3) / 1e9
+                    out["roofline_combine"] = {"kernel": kc["kernel"], "bound": "valu (field products; the HBM figure of this family is not its roofline for degree-C strategies)",
+                                               "achieved": round(ach, 1), "peak": 180.0, "peak_isa": 187.2, "unit": "G field products/s", "frac": round(ach / 180.0, 4),
+                                               "products_counted": "reference loop: (n / 2) indices x (d + 1) points x alpha products, summed over the family's launches of one profiled step",
+                                               "launches": kc["launches"], "ms": kc["ms"], "peak_source": "tools/microbench.hip (profiles/r02_microbench_sweep_and_ceiling.txt): 180 G fr29 products/s sustained; ISA: 210 VALU instructions per product"}
             allfam = max(kernels, key=lambda k: k["ms"])                                        # over ALL families, streaming or not
             msm_ms = sum(k["ms"] for k in kernels if k["kernel"].startswith("msm"))
             out["dominant_family"] = {"by_time_one_profiled_step": allfam["kernel"], "ms": allfam["ms"], "msm_families_ms": round(msm_ms, 3),

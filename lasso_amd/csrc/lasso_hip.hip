@@ -635,11 +635,11 @@ static int32_t cubic_eqw_launch_t(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* 
     }
   } else if (ahead) {
     const size_t q = n / 4;
-    ProfScope ps(c, LASSO_K_CUBIC, 48.0 * n * (2.0 * ncirc + 1.0));
     const unsigned ny = ncirc, nx = grid_for(q, cubic_nx_cap(ny));
     rc = ensure_scratch(c, (size_t)nx * ny * 3 * sizeof(fr_t)); if (rc) return rc;
     CUBIC_RESULT_ARGS(nx);
     hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, c->stream, (const uint32_t*)c->mail_d, c->d_gmail, seq, 0u);   // the wait: one wave; the round starts when it ends
+    ProfScope ps(c, LASSO_K_CUBIC, 48.0 * n * (2.0 * ncirc + 1.0));   // the events bracket the round's kernel, not the gate's wait for the host
     if (cubic_wide()) hipLaunchKernelGGL((k_cubic_eqw_fused<2, true, TM, true>), dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, A, B, nx, ny, (const fr_t*)d_E, q, fr_zero(), (fr_t*)c->d_scratch, c->d_counters, r_out, r_flag, seq, (const uint32_t*)c->d_gmail);
     else hipLaunchKernelGGL((k_cubic_eqw_fused<2, false, TM, true>), dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, A, B, nx, ny, (const fr_t*)d_E, q, fr_zero(), (fr_t*)c->d_scratch, c->d_counters, r_out, r_flag, seq, (const uint32_t*)c->d_gmail);
   } else {
@@ -865,9 +865,9 @@ int32_t lasso_sumcheck_linear_eqw_round_fused_ahead(lasso_ctx* c, lasso_fr* cons
   int32_t rc = ensure_small(c, (size_t)alpha * 3); if (rc) return rc;
   rc = ensure_scratch(c, (size_t)nx * ny * 3 * sizeof(fr_t)); if (rc) return rc;
   const uint32_t seq = next_seq(c);
+  hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, c->stream, (const uint32_t*)c->mail_d, c->d_gmail, seq, 0u);
   {
     ProfScope ps(c, LASSO_K_BIND, 48.0 * n * (alpha + 1.0));
-    hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, c->stream, (const uint32_t*)c->mail_d, c->d_gmail, seq, 0u);
     hipLaunchKernelGGL(k_dot_eqw_fused<true>, dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, Src, P, nx, ny, (const fr_t*)d_E, q, fr_zero(), (fr_t*)c->d_scratch, c->d_counters, RES(c), seq, (const uint32_t*)c->d_gmail);
   }
   HIPCHK(c, hipGetLastError());
@@ -1555,6 +1555,7 @@ static int32_t bullet_round_fused(lasso_ctx* c, const lasso_bases* b, size_t n, 
   const uint32_t ipc = (uint32_t)ipc_; const size_t K = (total + ipc_ - 1) / ipc_;
   int32_t rc = ensure_scratch(c, 2 * (K + 1) * sizeof(pt29) + 512); if (rc) return rc;
   const uint32_t seq = next_seq(c);
+  if (ahead) hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, c->stream, (const uint32_t*)c->mail_d, c->d_gmail, seq, 1u);   // waits for lasso_bullet_post's two scalars; the round starts when it ends
   {
     const size_t row = n_loc / 2 + 2;
     ProfScope ps(c, LASSO_K_MSM_DIRECT, 2.0 * row * 32 + (fold ? 96.0 * 2 * nk : 64.0 * nk), msm_ref_adds(2, row, FR_MODULUS_BITS), false, 2.0 * row * windows);
@@ -1562,7 +1563,6 @@ static int32_t bullet_round_fused(lasso_ctx* c, const lasso_bases* b, size_t n, 
 #define LAUNCH_BULLET(FOLD_, WB_, TAB_, AO, BO, WO, U, UI) hipLaunchKernelGGL((k_bullet_msm<FOLD_, WB_>), dim3((unsigned)K + 1, 2), dim3(MSM_THREADS), 0, c->stream, (const fr_t*)d_a_in, (const fr_t*)d_b_in, (const fr_t*)d_w_in, \
                                  (fr_t*)AO, (fr_t*)BO, (fr_t*)WO, (uint32_t)nk, (uint32_t)n, U, UI, to_fr(blinds), to_fr(blinds + 1), ipc, (const niels29*)TAB_, b->n, (pt29*)c->d_scratch, \
                                  (ed_point*)c->d_small, c->d_counters + LASSO_MAX_PTRS + 8, c->d_flag, seq, ps.counter(), world, rank, (const uint32_t*)(ahead ? c->mail_d : nullptr), c->d_gmail)
-    if (ahead) hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, c->stream, (const uint32_t*)c->mail_d, c->d_gmail, seq, 1u);   // waits for lasso_bullet_post's two scalars; the round starts when it ends
     if (fold) { const fr_t uu = ahead ? z : to_fr(u), ui = ahead ? z : to_fr(u_inv); if (w8) LAUNCH_BULLET(true, 8, b->d_mult8, d_a_out, d_b_out, d_w_out, uu, ui); else LAUNCH_BULLET(true, 4, b->d_mult, d_a_out, d_b_out, d_w_out, uu, ui); }
     else { if (w8) LAUNCH_BULLET(false, 8, b->d_mult8, nullptr, nullptr, nullptr, z, z); else LAUNCH_BULLET(false, 4, b->d_mult, nullptr, nullptr, nullptr, z, z); }
   }

@@ -65,6 +65,15 @@ class Group:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return float(t.item())
 
+    def gather_floats(self, x):
+        """one number per rank, gathered on every rank (rank order): per-rank measurements (peak bytes, ...) for the bench line"""
+        if self.dist is None:
+            return [float(x)]
+        t = self._tensor([float(x)], self.torch.float64)
+        out = [self.torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(out, t)
+        return [float(o.item()) for o in out]
+
     def shared_nonce(self):
         """One random 64-bit value, the same on every rank (drawn by rank 0): makes per-job names — e.g. the shared-memory segment of slab mode — that a
         crashed earlier job with the same MASTER_PORT cannot collide with."""

@@ -135,3 +135,64 @@ def test_bench_gpus2_shard_proof_is_one_proof_over_both_ranks(oracle):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["config"]["distinct_proofs"] == 1 and out["value"] > 0
     assert out["config"]["per_rank"].startswith("one proof sharded")
+    mg = out["multi_gpu"]
+    assert mg["ranks"] == 2 and mg["mode"].startswith("one proof sharded") and mg["rccl_ranks"] == 0 and len(mg["peak_bytes_per_rank"]) == 2 and "shared-memory" in mg["exchange"]
+
+
+def _oracle_digest(oracle, so, kind, c, log_m, log_r, log_s):
+    import ctypes as C
+    import hashlib
+    from lasso_amd import _abi
+    from lasso_amd.prover import HostProver
+    hp = HostProver(lib=C.CDLL(so))
+    idx = hp.gen_indices(1 << log_s, 1 << log_m, c); r = hp.gen_random_point(log_s)
+    hp.close()
+    orc = OracleSession(oracle, _abi.KINDS[kind], c, log_m, log_r, idx, r)
+    try:
+        return hashlib.sha256(orc.prove()).hexdigest()
+    finally:
+        orc.close()
+
+
+def test_bench_world8_shard_proof_pooled_and_capacity(oracle):
+    """The first real 8-GPU run will be `bench.py --gpus 8 [--shard-proof]`: the same command at world = 8 here — eight gloo ranks, ONE proof sharded over
+    them — in the pooled mode and in capacity mode (LASSO_CAPACITY=1, leafless trees from 64 lookups per rank on), both byte-identical on all eight ranks, and the line
+    describes itself: ranks, exchange, per-rank peak bytes.  The slab leg of the default (independent-proof) line at world = 8 is covered by its world = 2 twin above; this is
+    the strong-scaling form."""
+    import hashlib
+    so = build_mock_prover()
+    digests = []
+    for cap in (False, True):
+        env = dict(os.environ, LASSO_PROVER_LIB=so, LASSO_DEVICE_LIB=so, OMP_NUM_THREADS="1")
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
+        if cap:
+            env.update(LASSO_CAPACITY="1", LASSO_LEAFLESS_MIN="64")
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--shard-proof", "--steps", "1", "--warmup", "0", "--kind", "range", "--c", "2", "--log-s", "10", "--log-m", "8",
+               "--log-r", "12", "--no-cpu-baseline", "--concurrent", "0", "--no-slab-leg", "--no-prof"]
+        res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        assert res.returncode == 0, res.stderr[-3000:]
+        lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, res.stdout[-2000:]
+        out = json.loads(lines[0])
+        assert out["n_gpus"] == 8 and out["scaling"] == "strong" and out["config"]["distinct_proofs"] == 1 and out["value"] > 0
+        mg = out["multi_gpu"]
+        assert mg["ranks"] == 8 and len(mg["peak_bytes_per_rank"]) == 8 and all(b > 0 for b in mg["peak_bytes_per_rank"]) and mg["rccl_ranks"] == 0
+        digests.append(out["config"].get("proof_sha256"))
+    want = _oracle_digest(oracle, so, "range", 2, 8, 12, 10)
+    assert digests[0] == digests[1] == want, (digests, want)
+
+
+def test_bench_world8_independent_proofs_line_is_self_describing():
+    """`bench.py --gpus 8` (the driver's scaling command): eight independent proofs, weak scaling, and the multi_gpu object of the line"""
+    so = build_mock_prover()
+    env = dict(os.environ, LASSO_PROVER_LIB=so, LASSO_DEVICE_LIB=so, OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0", "--log-s", "7", "--log-m", "6", "--no-cpu-baseline", "--concurrent", "0", "--no-slab-leg", "--no-prof"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 8 and out["scaling"] == "weak" and out["config"]["distinct_proofs"] == 8
+    mg = out["multi_gpu"]
+    assert mg["ranks"] == 8 and mg["mode"].startswith("one independent proof per rank") and mg["exchange"].startswith("none on the data path") and len(mg["peak_bytes_per_rank"]) == 8

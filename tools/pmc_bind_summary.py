@@ -2,7 +2,7 @@
 """HBM traffic of the kernel-level bind_top sweep from the two rocprofv3 PMC passes of `bench.py --only-bind-sweep` (tools/gpu.sh pmc_bind): per (n, polys) row the average
 over that row's k_bind_top dispatches of 2 x FETCH_SIZE (gfx950 counts a wide coalesced stream at half its bytes, MI355X_MICROARCH.md) + WRITE_SIZE, both in KB, against the
 algorithmic 48 n p bytes.  The sweep launches rows in a fixed order with a fixed number of launches per row (warmup + iterations), which is how dispatches map to rows.
-Writes <dir>/bench_traffic.json (bench.py attaches it to `bind_top_sweep.traffic` when it is committed under profiles/r04_pmc/bind_top_sweep/)."""
+Writes <dir>/bench_traffic.json (bench.py attaches it to `bind_top_sweep.traffic` when it is committed under profiles/r0N_pmc/bind_top_sweep/, and labels it stale when the device sources have changed since)."""
 import csv
 import json
 import os
@@ -21,11 +21,12 @@ def load(path):
 
 
 def main(d):
-    line = json.loads(open(os.path.join(d, "sweep_FETCH_SIZE.json")).read().strip().splitlines()[-1])["bind_top_sweep"]
+    whole = json.loads(open(os.path.join(d, "sweep_FETCH_SIZE.json")).read().strip().splitlines()[-1])
+    line = whole["bind_top_sweep"]
     per_row = line["iterations"] + line["warmup"]
     fetch, write = load(os.path.join(d, "sweep_FETCH_SIZE_counter_collection.csv")), load(os.path.join(d, "sweep_WRITE_SIZE_counter_collection.csv"))
     rows = [x for x in line["rows"] if "launches" in x]
-    out = {"_curve": "curve25519", "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `bench.py --only-bind-sweep` (tools/gpu.sh pmc_bind, tools/pmc_bind_summary.py)", "rows": []}
+    out = {"_curve": "curve25519", "_device_sources_sha256": whole.get("lib_sha", {}).get("device_sources_sha256"), "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `bench.py --only-bind-sweep` (tools/gpu.sh pmc_bind, tools/pmc_bind_summary.py)", "rows": []}
     ok = len(fetch) == per_row * len(rows) == len(write)
     out["dispatches_match_the_sweep"] = ok
     for i, x in enumerate(rows if ok else []):

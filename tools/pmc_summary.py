@@ -46,7 +46,9 @@ def main(fetch_csv, write_csv, bench_json, out_json, source):
     with open(bench_json) as f:
         line = json.loads(f.read().strip().splitlines()[-1])
     large = line.get("large_launches_timed", {})
-    out = {"_workload": line.get("config", {}).get("workload_key", "and_c1_m16_2p24_curve25519")}      # bench.py applies a traffic file only to the workload it was taken on
+    out = {"_workload": line.get("config", {}).get("workload_key", "and_c1_m16_2p24_curve25519"),      # bench.py applies a traffic file only to the workload it was taken on
+           # ... and calls it measured only for the device sources it was taken on (bench.py roof(): anything else is labelled STALE)
+           "_device_sources_sha256": line.get("lib_sha", {}).get("device_sources_sha256")}
     for fam, prefixes in FAMILIES.items():
         top = large.get(fam, {}).get("per_step", 0)
         if not top:
