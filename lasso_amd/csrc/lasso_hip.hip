@@ -638,10 +638,15 @@ static int32_t cubic_eqw_launch_t(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* 
     const unsigned ny = ncirc, nx = grid_for(q, cubic_nx_cap(ny));
     rc = ensure_scratch(c, (size_t)nx * ny * 3 * sizeof(fr_t)); if (rc) return rc;
     CUBIC_RESULT_ARGS(nx);
-    hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, c->stream, (const uint32_t*)c->mail_d, c->d_gmail, seq, 0u);   // the wait: one wave; the round starts when it ends
+    // where the wait lives: in a one-wave gate kernel in front of the round (many workgroups), or in the round's own kernel (few: the gate's second launch costs the host more
+    // than a handful of spinning workgroups cost the device — profiles/r05_ahead_wait_forms.txt).  LASSO_AHEAD_INKERNEL_WGS: the bound (default 32; 0 = always the gate)
+    static const unsigned inkernel_max = [] { const char* v = getenv("LASSO_AHEAD_INKERNEL_WGS"); const long x = v ? atol(v) : 32; return (unsigned)(x < 0 ? 0 : x > 4096 ? 4096 : x); }();
+    const bool inkernel = nx * ny <= inkernel_max;
+    const uint32_t* wait_mail = inkernel ? (const uint32_t*)c->mail_d : (const uint32_t*)nullptr;
+    if (!inkernel) hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, c->stream, (const uint32_t*)c->mail_d, c->d_gmail, seq, 0u);   // the wait: one wave; the round starts when it ends
     ProfScope ps(c, LASSO_K_CUBIC, 48.0 * n * (2.0 * ncirc + 1.0));   // the events bracket the round's kernel, not the gate's wait for the host
-    if (cubic_wide()) hipLaunchKernelGGL((k_cubic_eqw_fused<2, true, TM, true>), dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, A, B, nx, ny, (const fr_t*)d_E, q, fr_zero(), (fr_t*)c->d_scratch, c->d_counters, r_out, r_flag, seq, (const uint32_t*)c->d_gmail);
-    else hipLaunchKernelGGL((k_cubic_eqw_fused<2, false, TM, true>), dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, A, B, nx, ny, (const fr_t*)d_E, q, fr_zero(), (fr_t*)c->d_scratch, c->d_counters, r_out, r_flag, seq, (const uint32_t*)c->d_gmail);
+    if (cubic_wide()) hipLaunchKernelGGL((k_cubic_eqw_fused<2, true, TM, true>), dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, A, B, nx, ny, (const fr_t*)d_E, q, fr_zero(), (fr_t*)c->d_scratch, c->d_counters, r_out, r_flag, seq, (const uint32_t*)c->d_gmail, wait_mail);
+    else hipLaunchKernelGGL((k_cubic_eqw_fused<2, false, TM, true>), dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, A, B, nx, ny, (const fr_t*)d_E, q, fr_zero(), (fr_t*)c->d_scratch, c->d_counters, r_out, r_flag, seq, (const uint32_t*)c->d_gmail, wait_mail);
   } else {
     const size_t q = n / 4;
     // bind: read 32n + write 16n per polynomial (SURVEY.md §8d's "fused bind+next-eval" over the reference's 2*ncirc + 1 polynomials)

@@ -130,6 +130,39 @@ __global__ void __launch_bounds__(64) k_gate(const uint32_t* mail, uint32_t* gma
     gmail[16] = seq;
   } else gmail[17] = seq;
 }
+// The same wait INSIDE the round's kernel, for launches of a few workgroups (<= 32: profiles/r05_ahead_wait_forms.txt — there the spinning costs less than the gate's second launch
+// costs the host, 14.8 against 18.2 us per round at 8 workgroups; from 64 workgroups on the gate wins): workgroup 0 — dispatched first — polls the host-mapped mailbox and
+// republishes the scalar in gmail[0..8) behind the tag gmail[16]; the others wait on that tag.  gmail[17] = tag: no challenge (poison / 5 s), everybody leaves.  s_mail = 9 words.
+__device__ __forceinline__ bool ahead_challenge(const uint32_t* mail, uint32_t* gmail, uint32_t seq, fr_t& r, uint32_t* s_mail) {
+  if (threadIdx.x == 0) {
+    const uint64_t t_end = wall_clock64() + 500000000ull;   // 5 s at 100 MHz
+    uint32_t ok = 1, spins = 0;
+    if (blockIdx.x == 0) {
+      fr_t c;
+      if (mail_wait(mail, seq, t_end, c)) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) gmail[k] = c.v[k];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __hip_atomic_store(gmail + 16, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      } else __hip_atomic_store(gmail + 17, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    for (;;) {
+      if (__hip_atomic_load(gmail + 16, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == seq) break;
+      if (__hip_atomic_load(gmail + 17, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == seq || ((++spins & 63u) == 0 && wall_clock64() > t_end + 100000000ull)) { ok = 0; break; }
+      __builtin_amdgcn_s_sleep(8);   // ~0.2 us between looks (the waiting workgroups must not crowd the poller's L2 traffic)
+    }
+    if (ok) {
+#pragma unroll
+      for (int k = 0; k < 8; k++) s_mail[k] = __hip_atomic_load(gmail + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    s_mail[8] = ok;
+  }
+  __syncthreads();
+  if (!s_mail[8]) return false;
+#pragma unroll
+  for (int k = 0; k < 8; k++) r.v[k] = s_mail[k];
+  return true;
+}
 // every workgroup of the gated launch: the scalar the gate left (false: this launch gets no challenge and must end without a result).  s_mail = 17 words of LDS.
 __device__ __forceinline__ bool gated_challenge(const uint32_t* gmail, uint32_t seq, uint32_t words, uint32_t* s_mail) {
   if (threadIdx.x < 17) {
@@ -421,16 +454,20 @@ __attribute__((amdgpu_waves_per_eu(LASSO_FUSED_WAVES, LASSO_FUSED_WAVES)))
 #endif
 __global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_eqw_fused(TM A, TM B, uint32_t nx, uint32_t ny, const fr_t* __restrict__ E, size_t q, fr_t r,
                                                                   fr_t* __restrict__ partials, uint32_t* counters, fr_t* __restrict__ out, uint32_t* flag, uint32_t seq,
-                                                                  const uint32_t* gmail = nullptr) {
+                                                                  const uint32_t* gmail = nullptr, const uint32_t* mail = nullptr) {
   __shared__ RedScratch S;
   const CubicGrid g = cubic_grid(nx, ny);
   fr_t* __restrict__ a = A.p[g.by];
   fr_t* __restrict__ b = B.p[g.by];
   if constexpr (AHEAD) {
     __shared__ uint32_t s_mail[17];
-    if (!gated_challenge(gmail, seq, 8, s_mail)) return;
+    if (mail) {   // few workgroups: they wait themselves (gmail is written by workgroup 0 of this launch)
+      if (!ahead_challenge(mail, const_cast<uint32_t*>(gmail), seq, r, s_mail)) return;
+    } else {      // many: a gate kernel in front of this launch did the waiting
+      if (!gated_challenge(gmail, seq, 8, s_mail)) return;
 #pragma unroll
-    for (int k = 0; k < 8; k++) r.v[k] = s_mail[k];
+      for (int k = 0; k < 8; k++) r.v[k] = s_mail[k];
+    }
   }
   const fr29 rs = fr29_unpack_s(r);
   fr29 e[3] = {fr29_zero(), fr29_zero(), fr29_zero()}; uint32_t cnt = 0;
