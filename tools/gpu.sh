@@ -79,6 +79,24 @@ except Exception as e:
     print(f"{tag} [{envs}]: no bench line: {e}"); print(open(f"gpurun_out/{tag}/bench.err").read()[-1200:])
 PY
 }
+r_ab() {           # ab <tag> <reps> "<env A>" "<env B>" ...: alternating runs of the quick bench under each environment (one process per run: the switches are read once); median / min / all
+  local tag="$1" reps="$2"; shift 2; mkdir -p gpurun_out/$tag; : > gpurun_out/$tag/ab.txt
+  for rep in $(seq 1 $reps); do
+    for envs in "$@"; do
+      ms=$(env $envs timeout 300 python bench.py --no-cpu-baseline --concurrent 0 --no-slab-leg --no-bind-sweep --steps ${AB_STEPS:-30} --warmup 5 2>/dev/null | python -c "import json,sys; print(json.loads(sys.stdin.read().strip().splitlines()[-1])['ms_per_step'])" 2>/dev/null)
+      echo "$envs|$ms" >> gpurun_out/$tag/ab.txt
+    done
+  done
+  python - gpurun_out/$tag/ab.txt <<'PY'
+import sys, collections, statistics
+runs = collections.OrderedDict()
+for l in open(sys.argv[1]):
+    k, v = l.rstrip("\n").split("|")
+    if v: runs.setdefault(k, []).append(float(v))
+for k, v in runs.items():
+    print(f"{k:60s} median {statistics.median(v):7.3f}  min {min(v):7.3f}  " + " ".join(f"{x:.2f}" for x in v))
+PY
+}
 r_trace() {        # trace <tag> [bench.py args...]: per-launch kernel trace of ONE proof (timeline csv: start, duration, gap before) + LASSO_TRACE=1 spans + LASSO_TRACE=2 host buckets
   local tag="$1"; shift; mkdir -p gpurun_out/$tag
   (cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/kt_$tag -o bench -- python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --concurrent 0 --no-slab-leg --no-bind-sweep --no-prof "$@" > $ROOT/gpurun_out/$tag/bench_under_trace.json 2> $ROOT/gpurun_out/$tag/trace.err)
