@@ -1036,8 +1036,12 @@ class Prover {
         const H4 dc = h4_sub(C[i + h], C[i]), c2 = h4_add(C[i + h], dc), c3 = h4_add(c2, dc);
         e0 = h4_add(e0, h4_mul(t0, C[i])); e2 = h4_add(e2, h4_mul(t2, c2)); e3 = h4_add(e3, h4_mul(t3, c3));
       }
-      const Sc E0 = to_sc(e0);
-      UniPoly poly = UniPoly::from_evals({E0, e - E0, to_sc(e2), to_sc(e3)});   // e(1) = claim - e(0) (:99-104)
+      // UniPoly::from_evals on (e(0), e(1) = claim - e(0) (:99-104), e(2), e(3)): the unique cubic through four points, in closed form (third and second finite differences) —
+      // the same four coefficients the Vandermonde solve of unipoly.rs:30-66 returns, for 2 products instead of 16
+      static const Sc inv2 = Sc::from_u64(2).inverse(), inv6 = Sc::from_u64(6).inverse();
+      const Sc E0 = to_sc(e0), E1 = e - E0, E2 = to_sc(e2), E3 = to_sc(e3);
+      const Sc c3 = (E3 - E2 - E2 - E2 + E1 + E1 + E1 - E0) * inv6, c2 = (E2 - E1 - E1 + E0) * inv2 - c3 - c3 - c3, c1 = E1 - E0 - c2 - c3;
+      UniPoly poly; poly.coeffs = {E0, c1, c2, c3};
       poly.append_to_transcript(t, "poly");
       const Sc r_j = t.challenge_scalar("challenge_nextround"); r_out.push_back(r_j);
       e = poly.evaluate(r_j);
