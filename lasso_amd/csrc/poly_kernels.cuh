@@ -595,16 +595,11 @@ __global__ void __launch_bounds__(Q) k_cubic_tail(TM A, TM B, const fr_t* __rest
   {
     // every lane task (array p, index i) loads / binds its element and, for A, weights it with the eq table right away (no separate pass).  2 m <= 4 Q lane tasks: all of a
     // thread's loads are issued first (and, launched ahead, travel while the first challenge does)
-    fr_t lo[4], hi[4];
-#pragma unroll
-    for (int it = 0; it < 4; it++) {
-      const uint32_t item = t + it * Q;
-      if (item < 2 * m) {
-        const uint32_t p = item / m, i = item - p * m;
-        const fr_t* src = p == 0 ? A.p[y] : B.p[y];
-        lo[it] = src[i]; if (BIND) hi[it] = src[i + m];
-      }
-    }
+    // (four named pairs, not arrays: the compiler does not unroll the second loop and would index arrays in scratch — 272 bytes per lane and a round trip through memory)
+    fr_t lo0, lo1, lo2, lo3, hi0, hi1, hi2, hi3;
+#define TAIL_LD(LO, HI, IT) do { const uint32_t item = t + (IT) * Q; if (item < 2 * m) { const uint32_t p = item / m, i = item - p * m; const fr_t* src = p == 0 ? A.p[y] : B.p[y]; LO = src[i]; if (BIND) HI = src[i + m]; } } while (0)
+    TAIL_LD(lo0, hi0, 0); TAIL_LD(lo1, hi1, 1); TAIL_LD(lo2, hi2, 2); TAIL_LD(lo3, hi3, 3);
+#undef TAIL_LD
     if (BIND && wait_r0) {
       if (t == 0) alive = mail_wait(mailbox, seq0, t_end, chal) ? 1u : 0u;
       __syncthreads();
@@ -613,16 +608,10 @@ __global__ void __launch_bounds__(Q) k_cubic_tail(TM A, TM B, const fr_t* __rest
       __syncthreads();   // chal / alive are written again at the first turn's poll
     }
     const fr29 rs = fr29_unpack_s(r0);
-#pragma unroll
-    for (int it = 0; it < 4; it++) {
-      const uint32_t item = t + it * Q;
-      if (item < 2 * m) {
-        const uint32_t p = item / m, i = item - p * m;
-        const fr29 v = BIND ? bind29(lo[it], hi[it], rs) : fr29_unpack_u(lo[it]);
-        bound[p][i] = v;
-        if (p == 0) ge[i] = fr29_mul(v, TAIL_EQ_S(i < q ? i : i - q));
-      }
-    }
+#define TAIL_BIND(LO, HI, IT) do { const uint32_t item = t + (IT) * Q; if (item < 2 * m) { const uint32_t p = item / m, i = item - p * m; \
+      const fr29 v = BIND ? bind29(LO, HI, rs) : fr29_unpack_u(LO); bound[p][i] = v; if (p == 0) ge[i] = fr29_mul(v, TAIL_EQ_S(i < q ? i : i - q)); } } while (0)
+    TAIL_BIND(lo0, hi0, 0); TAIL_BIND(lo1, hi1, 1); TAIL_BIND(lo2, hi2, 2); TAIL_BIND(lo3, hi3, 3);
+#undef TAIL_BIND
   }
   __syncthreads();
   for (uint32_t turn = 0;; turn++) {
@@ -1223,8 +1212,11 @@ __global__ void k_eq_small2(RTable16 Rh, uint32_t hi_bits, fr_t scale, fr_t* __r
   if (x >= ((size_t)1 << ell)) return;
   fr29 p = is_lo ? fr29_unpack_u(fr_one()) : fr29_unpack_u(scale);
   const fr29 one_s = fr29_one_s();
-  for (uint32_t j = 0; j < ell; j++) { const bool bit = (x >> (ell - 1 - j)) & 1; const fr29 rs = fr29_unpack_s(is_lo ? Rl.r[j] : Rh.r[j]); p = fr29_mul(bit ? rs : fr29_sub(one_s, rs), p); }
-  (is_lo ? lo : hi)[x] = fr29_store(p);
+  // one loop per table: `is_lo ? Rl.r[j] : Rh.r[j]` made the compiler copy a 512-byte argument struct into scratch (1040 bytes per lane) and index it there — ~2.5 us per step of
+  // the chain, 18-34 us for a kernel that computes two tables of <= 2^11 entries in front of round 0 of every large layer (profiles/r05_kernel_trace_one_proof_2p24.csv); with
+  // the block-uniform branch outside, r[j] is a scalar load from the argument segment
+  if (is_lo) { for (uint32_t j = 0; j < ell; j++) { const bool bit = (x >> (ell - 1 - j)) & 1; const fr29 rs = fr29_unpack_s(Rl.r[j]); p = fr29_mul(bit ? rs : fr29_sub(one_s, rs), p); } lo[x] = fr29_store(p); }
+  else { for (uint32_t j = 0; j < ell; j++) { const bool bit = (x >> (ell - 1 - j)) & 1; const fr29 rs = fr29_unpack_s(Rh.r[j]); p = fr29_mul(bit ? rs : fr29_sub(one_s, rs), p); } hi[x] = fr29_store(p); }
 }
 // out[x] = hi[x >> lo_bits] * lo[x & mask]
 __global__ void __launch_bounds__(LASSO_BLOCK) k_eq_outer(const fr_t* __restrict__ hi, const fr_t* __restrict__ lo, uint32_t lo_bits, size_t n, fr_t* __restrict__ out) {
