@@ -606,8 +606,9 @@ static unsigned direct_nx_max() { static const unsigned v = [] { const char* e =
   if (direct) { *groups_out = (nx_); rc = ensure_small(c, (size_t)ncirc * 3 * (nx_)); if (rc) return rc; } \
   fr_t* const r_out = c->tagged ? (fr_t*)c->d_tag : c->d_small; uint32_t* const r_flag = direct ? LASSO_TAGGED_DIRECT : c->tagged ? LASSO_TAGGED : c->d_flag
 extern "C++" {
+struct EqPointArg { const lasso_fr* point; uint32_t ell; fr_t scale; };   // a table too large for the in-LDS build: factor tables by k_eq_small2 into the scratch, the product inside round 0 (EqGlobal)
 template <class TM, class TP>   // pointer tables sized for the number of circuits (MutPtrTable8 / PtrTable8 up to 8: 64 bytes of kernel arguments each instead of 1088)
-static int32_t cubic_eqw_launch_t(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n, const lasso_fr* r, int NT, uint32_t* seq_out, const EqInline* eqi, uint32_t* groups_out, bool ahead = false) {
+static int32_t cubic_eqw_launch_t(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n, const lasso_fr* r, int NT, uint32_t* seq_out, const EqInline* eqi, uint32_t* groups_out, bool ahead = false, const EqPointArg* eqg = nullptr) {
   if (groups_out) *groups_out = 1;
   if (ahead && (NT != 2 || n / 4 <= CUBIC_SMALL_Q)) return fail(c, LASSO_ERR_UNSUPPORTED, "a round launched ahead of its challenge: two-sum streaming rounds only (more than 64 index quadruples per circuit)");
   TM A, B; for (uint32_t i = 0; i < ncirc; i++) { REQUIRE(c, d_A[i] && d_B[i]); A.p[i] = (fr_t*)d_A[i]; B.p[i] = (fr_t*)d_B[i]; }
@@ -622,9 +623,19 @@ static int32_t cubic_eqw_launch_t(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* 
     } else {
       TP Ac, Bc; for (uint32_t i = 0; i < ncirc; i++) { Ac.p[i] = A.p[i]; Bc.p[i] = B.p[i]; }
       const unsigned ny = ncirc, nx = grid_for(half, cubic_nx_cap(ny));
-      rc = ensure_scratch(c, (size_t)nx * ny * 3 * sizeof(fr_t)); if (rc) return rc;
+      const uint32_t g_lo = eqg ? eqg->ell / 2 : 0, g_hi = eqg ? eqg->ell - g_lo : 0;
+      const size_t part_elems = (size_t)nx * ny * 3;
+      rc = ensure_scratch(c, (part_elems + (eqg ? ((size_t)1 << g_hi) + ((size_t)1 << g_lo) : 0)) * sizeof(fr_t)); if (rc) return rc;
       CUBIC_RESULT_ARGS(nx);
       static const uint32_t pipe = [] { const char* v = getenv("LASSO_LB_PIPELINE"); return (v && v[0] == '0') ? 0u : 1u; }();
+      if (eqg && NT == 2) {   // factor tables behind the partials in the scratch, then round 0 with the product inside (the table goes to d_E on the way)
+        fr_t* hi = (fr_t*)c->d_scratch + part_elems; fr_t* lo = hi + ((size_t)1 << g_hi);
+        RTable16 Rh, Rl; for (uint32_t j = 0; j < 16; j++) { Rh.r[j] = j < g_hi ? to_fr(eqg->point + j) : fr_zero(); Rl.r[j] = j < g_lo ? to_fr(eqg->point + g_hi + j) : fr_zero(); }
+        const unsigned hb = grid_for((size_t)1 << g_hi), lb2 = grid_for((size_t)1 << g_lo);
+        hipLaunchKernelGGL(k_eq_small2, dim3(hb + lb2), dim3(LASSO_BLOCK), 0, c->stream, Rh, g_hi, eqg->scale, hi, hb, Rl, g_lo, lo);
+        EqGlobal G; G.hi = hi; G.lo = lo; G.lo_bits = g_lo; G.ell = eqg->ell;
+        hipLaunchKernelGGL((k_cubic_eqw_lb<2, true, TP, EqGlobal>), dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, Ac, Bc, nx, ny, (const fr_t*)nullptr, half, (fr_t*)c->d_scratch, c->d_counters, r_out, r_flag, seq, 1u, G, (fr_t*)d_E);
+      } else
       if (NT == 3) hipLaunchKernelGGL((k_cubic_eqw_lb<3, false, TP, EqNone>), dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, Ac, Bc, nx, ny, (const fr_t*)d_E, half, (fr_t*)c->d_scratch, c->d_counters, r_out, r_flag, seq, 0u, EqNone(), (fr_t*)nullptr);
       else if (eqi) hipLaunchKernelGGL((k_cubic_eqw_lb<2, true, TP, EqInline>), dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, Ac, Bc, nx, ny, (const fr_t*)nullptr, half, (fr_t*)c->d_scratch, c->d_counters, r_out, r_flag, seq, 1u, *eqi, (fr_t*)d_E);
       else {
@@ -667,8 +678,8 @@ static int32_t cubic_eqw_launch_t(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* 
   return 0;
 }
 }   // extern "C++"
-static int32_t cubic_eqw_launch(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n, const lasso_fr* r, int NT, uint32_t* seq_out, const EqInline* eqi = nullptr, uint32_t* groups_out = nullptr, bool ahead = false) {
-  return ncirc <= 8 ? cubic_eqw_launch_t<MutPtrTable8, PtrTable8>(c, d_A, d_B, ncirc, d_E, n, r, NT, seq_out, eqi, groups_out, ahead) : cubic_eqw_launch_t<MutPtrTable, PtrTable>(c, d_A, d_B, ncirc, d_E, n, r, NT, seq_out, eqi, groups_out, ahead);
+static int32_t cubic_eqw_launch(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n, const lasso_fr* r, int NT, uint32_t* seq_out, const EqInline* eqi = nullptr, uint32_t* groups_out = nullptr, bool ahead = false, const EqPointArg* eqg = nullptr) {
+  return ncirc <= 8 ? cubic_eqw_launch_t<MutPtrTable8, PtrTable8>(c, d_A, d_B, ncirc, d_E, n, r, NT, seq_out, eqi, groups_out, ahead, eqg) : cubic_eqw_launch_t<MutPtrTable, PtrTable>(c, d_A, d_B, ncirc, d_E, n, r, NT, seq_out, eqi, groups_out, ahead, eqg);
 }
 int32_t lasso_sumcheck_cubic_eqw_round(lasso_ctx* c, const lasso_fr* const* d_A, const lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n, lasso_fr* out) {
   REQUIRE(c, d_A && d_B && d_E && out && ncirc >= 1 && ncirc <= LASSO_MAX_PTRS && n >= 2 && (n & (n - 1)) == 0);
@@ -734,8 +745,11 @@ static bool make_eq_inline(const lasso_fr* point, uint32_t ell, const lasso_fr* 
 int32_t lasso_sumcheck_cubic_eqw2_begin_eq(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, lasso_fr* d_E_out, size_t n, const lasso_fr* point, uint32_t ell, const lasso_fr* scale) {
   REQUIRE(c, d_A && d_B && d_E_out && ncirc >= 1 && ncirc <= LASSO_MAX_PTRS && n >= 2 && (n & (n - 1)) == 0 && !c->pending && ((size_t)1 << ell) == n / 2);
   EqInline Q;
-  if (n / 2 <= CUBIC_SMALL_Q || !make_eq_inline(point, ell, scale, Q)) return fail(c, LASSO_ERR_UNSUPPORTED, "lasso_sumcheck_cubic_eqw2_begin_eq: tables of 2^7 .. 2^14 entries only");
-  uint32_t seq, groups; int32_t rc = cubic_eqw_launch(c, d_A, d_B, ncirc, d_E_out, n, nullptr, 2, &seq, &Q, &groups); if (rc) return rc;
+  if (n / 2 <= CUBIC_SMALL_Q || (ell && !point) || ell > 32) return fail(c, LASSO_ERR_UNSUPPORTED, "lasso_sumcheck_cubic_eqw2_begin_eq: tables of 2^7 .. 2^32 entries only");
+  uint32_t seq, groups; int32_t rc;
+  if (make_eq_inline(point, ell, scale, Q)) rc = cubic_eqw_launch(c, d_A, d_B, ncirc, d_E_out, n, nullptr, 2, &seq, &Q, &groups);     // <= 2^14 entries: factor tables in LDS
+  else { EqPointArg G; G.point = point; G.ell = ell; G.scale = scale ? to_fr(scale) : fr_one(); rc = cubic_eqw_launch(c, d_A, d_B, ncirc, d_E_out, n, nullptr, 2, &seq, nullptr, &groups, false, &G); }   // larger: factor tables in memory
+  if (rc) return rc;
   c->pending = true; c->pending_seq = seq; c->pending_count = (size_t)ncirc * 2; c->pending_tagged = c->tagged; c->pending_groups = groups; c->pending_K = 2;
   return 0;
 }

@@ -382,6 +382,24 @@ __device__ __forceinline__ void eq_inline_build(const EqInline& Q, EqInlineTable
   __syncthreads();
 }
 __device__ __forceinline__ fr29 eq_inline_s(const EqInlineTables& T, uint32_t lb, size_t x) { return fr29_mul(T.hi_s[x >> lb], T.lo_s[x & ((1u << lb) - 1u)]); }
+// Tables of MORE than 2^14 entries (round 5): the two factor tables (<= 2^11 entries each) do not fit LDS, so they stay where k_eq_small2 wrote them — global memory, memory form,
+// L2-resident — and round 0 forms  E[x] = hi[x >> lo_bits] * lo[x & mask]  where it uses it: k_eq_outer's product, bit for bit, written to E_out by circuit 0's workgroups for the
+// later rounds and never read back in this launch.  Takes k_eq_outer (a 32-byte write per entry, then the same bytes read again by round 0: 5-200 us in front of round 0 of the
+// nine largest layers of a 2^24 proof) off the critical path for one product per index in a launch that is HBM-bound.
+struct EqGlobal { const fr_t* hi; const fr_t* lo; uint32_t lo_bits; uint32_t ell; };
+__device__ __forceinline__ void eq_inline_build(const EqGlobal&, EqInlineTables&) {}
+__device__ __forceinline__ void eq_inline_build(const EqNone&, EqInlineTables&) {}
+// the eq weight of index i as the s-form operand of the round, and (write) the table entry in memory form
+__device__ __forceinline__ fr29 eq_inline_value(const EqInline&, const EqInlineTables& T, uint32_t lb, size_t i, bool write, fr_t* __restrict__ E_out) {
+  if (write) E_out[i] = fr29_store(fr29_mul(T.hi_s[i >> lb], T.lo_u[i & ((1u << lb) - 1u)]));
+  return eq_inline_s(T, lb, i);
+}
+__device__ __forceinline__ fr29 eq_inline_value(const EqGlobal& Q, const EqInlineTables&, uint32_t, size_t i, bool write, fr_t* __restrict__ E_out) {
+  const fr_t mem = fr29_store(fr29_mul(fr29_unpack_u(Q.hi[i >> Q.lo_bits]), fr29_unpack_s(Q.lo[i & (((size_t)1 << Q.lo_bits) - 1)])));
+  if (write) E_out[i] = mem;
+  return fr29_unpack_s(mem);
+}
+__device__ __forceinline__ fr29 eq_inline_value(const EqNone&, const EqInlineTables&, uint32_t, size_t, bool, fr_t* __restrict__) { return fr29_zero(); }
 // out[c*NT + ..] = the NT sums over i < half of circuit c.  1-D grid of nx*ny workgroups (cubic_grid).
 // EQI: E is built on the way (eq_inline_build): E_out (half entries) is written by the workgroups of circuit 0, nothing is read from it.
 // one 32-byte element with the non-temporal hint (two dwordx4): data that is read exactly once per launch (the layer's A and B in a round that only evaluates)
@@ -430,10 +448,8 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_eqw_lb(TP A, TP B, uint32
       const fr_t na0 = LB_LD(a + ip), na1 = LB_LD(a + ip + half), nb0 = LB_LD(b + ip), nb1 = LB_LD(b + ip + half), ne = EQI ? fr_zero() : E[ip];
 #undef LB_LD
       fr29 es;
-      if (EQI) {
-        es = eq_inline_s(ET, elb, i);
-        if (g.by == 0) E_out[i] = fr29_store(fr29_mul(ET.hi_s[i >> elb], ET.lo_u[i & ((1u << elb) - 1u)]));
-      } else es = fr29_unpack_s(em);
+      if (EQI) es = eq_inline_value(EQ, ET, elb, i, g.by == 0, E_out);
+      else es = fr29_unpack_s(em);
       const fr29 b0 = fr29_unpack_u(b0m), b1 = fr29_unpack_u(b1m);
       const fr29 g0 = fr29_mul(fr29_unpack_u(a0), es), g1 = fr29_mul(fr29_unpack_u(a1), es);
       fr29_mul_acc(w0, b0, g0); fr29_mul_acc(w1, fr29_sub(g1, g0), fr29_sub(b1, b0));

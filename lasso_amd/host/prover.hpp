@@ -1003,6 +1003,8 @@ class Prover {
   // `prev + hi - lo`, e(1) from the claim (:99-104), UniPoly::from_evals, bind (:116-120) — the same field elements as the device's eq-weighted form, any eq coordinate.
   // The device remains the only place where an O(n) loop runs; this is the O(1) end of the O(log n) host share.
   // budget = elements per array x circuits the host takes over (LASSO_HOST_TAIL, default 32; 0 switches the host rounds off: A/B measurements, byte-identical)
+  // A/B switch: eq tables above 2^14 entries built by their own kernels (k_eq_small2 + k_eq_outer) in front of round 0, as before round 5, instead of inside round 0
+  static bool eq_inline_big_off() { static const bool off = [] { const char* v = getenv("LASSO_EQ_INLINE_BIG"); return v && v[0] == '0'; }(); return off; }
   static size_t host_tail_budget() { static const size_t v = [] { const char* e = getenv("LASSO_HOST_TAIL"); const long x = e ? atol(e) : 32; return (size_t)(x < 0 ? 0 : x > 1024 ? 1024 : x); }(); return v; }
   size_t host_m_stop(size_t k) const {   // elements per array at which the host takes a layer over: a power of two, 1 = never
     if (P != 1 || !host_tail_budget() || !k) return 1;
@@ -1141,7 +1143,7 @@ class Prover {
           leaf_round(*leaf, j, len, table, j ? &rp : nullptr, ev); have_ev = true;
           if (j == 1) { A = leaf->work_a; B = leaf->work_b; }
         } else
-        if (j == 0 && lz.on && j < tail_from && ell <= 14 && len / 2 > 64) {   // round 0 of a streaming layer: the table is built in this launch and left in d_E for the later rounds
+        if (j == 0 && lz.on && j < tail_from && (ell <= 14 || (!eq_inline_big_off() && ell <= 32)) && len / 2 > 64) {   // round 0 of a streaming layer: the table is built in this launch and left in d_E for the later rounds
           d.chk(lasso_sumcheck_cubic_eqw2_begin_eq(d.ctx, A.data(), B.data(), (uint32_t)k, lz.d_table, len, lz.rr.data(), ell, &lz.scale), "lasso_sumcheck_cubic_eqw2_begin_eq"); lz.on = false;
         } else if (j == 0 && lz.on && j >= tail_from && ell <= 9) {            // the whole layer runs in the resident kernel: no table at all
           if (m_stop > 1) d.chk(lasso_tail_handover_next(d.ctx, (uint32_t)m_stop), "lasso_tail_handover_next");

@@ -252,7 +252,7 @@ int32_t lasso_sumcheck_cubic_tail_begin(lasso_ctx* c, lasso_fr* const* A, lasso_
 // the first round of a layer with the eq table built on the way: here simply the table, then the plain call
 int32_t lasso_sumcheck_cubic_eqw2_begin_eq(lasso_ctx* c, lasso_fr* const* A, lasso_fr* const* B, uint32_t nc, lasso_fr* E_out, size_t n, const lasso_fr* point, uint32_t ell, const lasso_fr* scale) {
   REQ(c, E_out && n >= 2 && ((size_t)1 << ell) == n / 2);
-  if (ell > 14 || n / 2 <= 64) { c->err = "unsupported table size"; return LASSO_ERR_UNSUPPORTED; }
+  if (ell > 32 || n / 2 <= 64) { c->err = "unsupported table size"; return LASSO_ERR_UNSUPPORTED; }
   int32_t rc = lasso_eq_evals_scaled(c, point, ell, scale, E_out); if (rc) return rc;
   return lasso_sumcheck_cubic_eqw2_begin(c, A, B, nc, E_out, n, nullptr);
 }

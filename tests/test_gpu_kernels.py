@@ -902,7 +902,8 @@ def test_abort_releases_a_waiting_tail_kernel(devs):
         d.free(p)
 
 
-@pytest.mark.parametrize("n,ncirc,scaled", [(256, 2, False), (512, 3, True), (1 << 12, 2, False), (1 << 14, 2, True), (1 << 15, 5, False), (1 << 15, 16, True)])
+@pytest.mark.parametrize("n,ncirc,scaled", [(256, 2, False), (512, 3, True), (1 << 12, 2, False), (1 << 14, 2, True), (1 << 15, 5, False), (1 << 15, 16, True),
+                                             (1 << 16, 2, True), (1 << 18, 3, False), (1 << 20, 1, True), (1 << 17, 9, False)])   # above 2^14 entries: factor tables in memory (EqGlobal)
 def test_sumcheck_cubic_round0_with_inline_eq_table(devs, n, ncirc, scaled):
     """lasso_sumcheck_cubic_eqw2_begin_eq: the first round of a layer with the layer's eq table built inside the launch == lasso_eq_evals_scaled followed by the plain
     first round — same two sums per circuit AND the same table bytes left behind for the later rounds (real library and the oracle's mock)"""
