@@ -207,6 +207,22 @@ int32_t lasso_challenge_post(lasso_ctx* ctx, const lasso_fr* r);
 /* lasso_sumcheck_linear_eqw_round_fused (in place) enqueued ahead of its challenge: lasso_challenge_post, then lasso_result_wait delivers its 3 * alpha values */
 int32_t lasso_sumcheck_linear_eqw_round_fused_ahead(lasso_ctx* ctx, lasso_fr* const* d_polys, uint32_t alpha, const lasso_fr* d_E, size_t n);
 int32_t lasso_sumcheck_cubic_tail_begin_ahead(lasso_ctx* ctx, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n);
+/* A grand-product LAYER enqueued ahead of its eq point (round 5).  Between two layers the device idled for the host's last rounds, the layer's closing Fiat-Shamir step AND the
+ * launch + dispatch of the next layer's first kernel(s).  The next layer's first launch — lasso_sumcheck_cubic_eqw2_begin_eq's round 0, or lasso_sumcheck_cubic_tail_begin_eq's
+ * resident kernel (after lasso_tail_handover_next, as there) — may be enqueued while the CURRENT layer's resident tail is still active and a result is pending:
+ *     lasso_sumcheck_cubic_eqw2_begin_eq_ahead(A, B, ncirc, d_E_out, n, ell)  /  lasso_sumcheck_cubic_tail_begin_eq_ahead(A, B, ncirc, n, ell)
+ *     ... the current layer's remaining lasso_sumcheck_cubic_tail_next / lasso_result_wait turns, the host's rounds, the layer's closing transcript step ...
+ *     lasso_point_post(point, ell, scale)    — the context is now where the plain entry point would have left it (first sums pending; the tail active)
+ *  or lasso_point_cancel()                   — the enqueued kernels end without a result and without touching anything
+ * A one-wave gate kernel (k_gate_point) in front of the launch waits for the post (host-mapped area, one self-validating three-chunk entry per field element, all under the launch's
+ * sequence number) and leaves the point in device memory for the kernels behind it; lasso_abort's poison tag and a 5 s wall-clock bound end the wait as everywhere else.  Nothing may
+ * grow while a resident kernel is active: LASSO_ERR_UNSUPPORTED when a buffer would have to, or when LASSO_LAYER_AHEAD=0 (lasso_layer_ahead_ok: 0) — the caller then starts the layer
+ * the plain way.  Until the post / cancel, entry points that synchronise the stream return LASSO_ERR_INVALID (as for rounds launched ahead). */
+int32_t lasso_layer_ahead_ok(lasso_ctx* ctx);
+int32_t lasso_sumcheck_cubic_eqw2_begin_eq_ahead(lasso_ctx* ctx, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, lasso_fr* d_E_out, size_t n, uint32_t ell);
+int32_t lasso_sumcheck_cubic_tail_begin_eq_ahead(lasso_ctx* ctx, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, size_t n, uint32_t ell);
+int32_t lasso_point_post(lasso_ctx* ctx, const lasso_fr* point, uint32_t ell, const lasso_fr* scale);
+int32_t lasso_point_cancel(lasso_ctx* ctx);
 uint32_t lasso_sumcheck_tail_capacity(void);
 int32_t lasso_sumcheck_cubic_tail_next(lasso_ctx* ctx, const lasso_fr* r);
 /* The resident tail of the primary sumcheck for the linear strategies (the rounds lasso_sumcheck_linear_eqw_round[_fused] serve one launch at a time):

@@ -71,6 +71,11 @@ def declare(lib):
         "lasso_read_runs": (i32, [vp, P(vp), u32, u32, vp]),
         "lasso_tail_handover_next": (i32, [vp, u32]),
         "lasso_rounds_ahead_ok": (i32, [vp]),
+        "lasso_layer_ahead_ok": (i32, [vp]),
+        "lasso_sumcheck_cubic_eqw2_begin_eq_ahead": (i32, [vp, P(vp), P(vp), u32, vp, sz, u32]),
+        "lasso_sumcheck_cubic_tail_begin_eq_ahead": (i32, [vp, P(vp), P(vp), u32, sz, u32]),
+        "lasso_point_post": (i32, [vp, vp, u32, vp]),
+        "lasso_point_cancel": (i32, [vp]),
         "lasso_sumcheck_cubic_eqw2_begin_ahead": (i32, [vp, P(vp), P(vp), u32, vp, sz]),
         "lasso_challenge_post": (i32, [vp, vp]),
         "lasso_sumcheck_linear_eqw_round_fused_ahead": (i32, [vp, P(vp), u32, vp, sz]),

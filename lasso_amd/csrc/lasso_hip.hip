@@ -68,6 +68,11 @@ struct lasso_ctx {
   uint32_t handover_next = 0;     // lasso_tail_handover_next: the next cubic tail stops at this many elements per array and hands the arrays over
   // a sumcheck round launched ahead (lasso_sumcheck_cubic_eqw2_begin_ahead): what lasso_challenge_post turns into the pending result
   size_t ahead_count = 0; bool ahead_tagged = false; uint32_t ahead_groups = 1, ahead_K = 0; bool ahead_bullet = false;
+  // a LAYER's first launch enqueued ahead of the layer's eq point (lasso_sumcheck_cubic_eqw2_begin_eq_ahead / lasso_sumcheck_cubic_tail_begin_eq_ahead): legal while the previous
+  // layer's tail is still active; lasso_point_post delivers the point through pmail (host-mapped, one mailbox entry per field element) and turns the launch into the pending
+  // result / the active tail; lasso_point_cancel ends it without a result.  d_gpoint: where the gate (k_gate_point) leaves the point for the kernels behind it.
+  uint32_t* pmail_h = nullptr; uint32_t* pmail_d = nullptr; uint32_t* d_gpoint = nullptr;
+  bool lay_active = false, lay_tail = false, lay_tagged = false, no_grow = false; uint32_t lay_seq = 0, lay_ell = 0, lay_groups = 1, lay_K = 0, lay_turns = 0; size_t lay_count = 0, lay_final = 0;
   uint32_t prof_mask = 0;   // bit k set = kernel family k is bracketed with events
   std::vector<EventPair> events; size_t events_used = 0;
   uint64_t prof_launches[LASSO_K_COUNT] = {0}; double prof_ms[LASSO_K_COUNT] = {0}; double prof_bytes[LASSO_K_COUNT] = {0};
@@ -118,14 +123,16 @@ static hipError_t dfree(lasso_ctx* c, void* p) {
 
 static int32_t ensure_scratch(lasso_ctx* c, size_t bytes) {
   if (bytes <= c->scratch_cap) return 0;
-  if (c->ahead_active) return fail(c, LASSO_ERR_INVALID, "a launch is waiting on the device for its challenge: only lasso_result_wait and the post of that challenge are legal until then");   // growing would synchronise the stream for the kernel's whole 5 s bail-out and lose the round
+  if (c->no_grow) return LASSO_ERR_UNSUPPORTED;   // a launch enqueued behind a resident kernel: the caller takes the ordinary path instead
+  if (c->ahead_active || c->lay_active) return fail(c, LASSO_ERR_INVALID, "a launch is waiting on the device for its challenge: only lasso_result_wait and the post of that challenge are legal until then");   // growing would synchronise the stream for the kernel's whole 5 s bail-out and lose the round
   if (c->d_scratch) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, dfree(c, c->d_scratch)); c->d_scratch = nullptr; c->scratch_cap = 0; }
   size_t cap = bytes < ((size_t)1 << 22) ? ((size_t)1 << 22) : bytes;
   HIPCHK(c, dmalloc(c, &c->d_scratch, cap)); c->scratch_cap = cap; return 0;
 }
 static int32_t ensure_small(lasso_ctx* c, size_t count) {
   if (count <= c->small_cap) return 0;
-  if (c->ahead_active) return fail(c, LASSO_ERR_INVALID, "a launch is waiting on the device for its challenge: only lasso_result_wait and the post of that challenge are legal until then");   // growing would synchronise the stream for the kernel's whole 5 s bail-out and lose the round
+  if (c->no_grow) return LASSO_ERR_UNSUPPORTED;   // a launch enqueued behind a resident kernel: the caller takes the ordinary path instead
+  if (c->ahead_active || c->lay_active) return fail(c, LASSO_ERR_INVALID, "a launch is waiting on the device for its challenge: only lasso_result_wait and the post of that challenge are legal until then");   // growing would synchronise the stream for the kernel's whole 5 s bail-out and lose the round
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (c->h_small) (void)hipHostFree(c->h_small);
   c->h_small = nullptr; c->d_small = nullptr; c->small_cap = 0;
@@ -141,7 +148,8 @@ static int32_t ensure_small(lasso_ctx* c, size_t count) {
 }
 static int32_t ensure_big(lasso_ctx* c, size_t count) {
   if (count <= c->big_cap) return 0;
-  if (c->ahead_active) return fail(c, LASSO_ERR_INVALID, "a launch is waiting on the device for its challenge: only lasso_result_wait and the post of that challenge are legal until then");   // growing would synchronise the stream for the kernel's whole 5 s bail-out and lose the round
+  if (c->no_grow) return LASSO_ERR_UNSUPPORTED;   // a launch enqueued behind a resident kernel: the caller takes the ordinary path instead
+  if (c->ahead_active || c->lay_active) return fail(c, LASSO_ERR_INVALID, "a launch is waiting on the device for its challenge: only lasso_result_wait and the post of that challenge are legal until then");   // growing would synchronise the stream for the kernel's whole 5 s bail-out and lose the round
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (c->d_big) (void)dfree(c, c->d_big);
   if (c->h_big) (void)hipHostFree(c->h_big);
@@ -264,8 +272,10 @@ static int32_t wait_flag(lasso_ctx* c, uint32_t seq, size_t count, lasso_fr* out
 // still publish), zero the tagged result area and the mailbox, and restart at 1.  Costs one stream synchronisation per ~4e9 hand-offs.
 static uint32_t next_seq(lasso_ctx* c, uint32_t span = 1) {
   // not while a result is still uncollected (lasso_defer_next) or a resident tail holds a block of numbers: the 2^20 numbers of slack cover any such stretch
-  if (c->seq > 0xFFF00000u - span && ((!c->pending && !c->tail_active && !c->ahead_active) || c->seq > 0xFFFFFF00u - span)) {
+  if (c->seq > 0xFFF00000u - span && ((!c->pending && !c->tail_active && !c->ahead_active && !c->lay_active) || c->seq > 0xFFFFFF00u - span)) {
     (void)hipStreamSynchronize(c->stream);
+    if (c->pmail_h) memset(c->pmail_h, 0, LASSO_PMAIL_BYTES);
+    if (c->d_gpoint) (void)hipMemset(c->d_gpoint, 0, LASSO_GPOINT_BYTES);
     if (c->h_tag) memset(c->h_tag, 0, c->small_cap * 48);
     if (c->mail_h) memset(c->mail_h, 0, 96);   // both mailboxes
     if (c->d_gmail) (void)hipMemset(c->d_gmail, 0, 128);   // ... and the launched-ahead rounds' republication tags
@@ -422,6 +432,9 @@ int32_t lasso_ctx_create_background(int32_t device, int32_t background, lasso_ct
   int32_t rc = ensure_small(c, (size_t)1 << 16); if (rc) { g_create_err = c->err; delete c; return rc; }   // 2 MiB of mapped result buffer: the largest a-vector / row-commitment hand-off without a reallocation
   rc = ensure_scratch(c, (size_t)1 << 22); if (rc) { g_create_err = c->err; delete c; return rc; }
   if (dmalloc(c, (void**)&c->d_gmail, 128) != hipSuccess || hipMemset(c->d_gmail, 0, 128) != hipSuccess) { g_create_err = "gmail alloc"; delete c; return LASSO_ERR_OOM; }
+  if (hipHostMalloc((void**)&c->pmail_h, LASSO_PMAIL_BYTES, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess || hipHostGetDevicePointer((void**)&c->pmail_d, c->pmail_h, 0) != hipSuccess) { g_create_err = "point mailbox alloc"; delete c; return LASSO_ERR_OOM; }
+  memset(c->pmail_h, 0, LASSO_PMAIL_BYTES);
+  if (dmalloc(c, (void**)&c->d_gpoint, LASSO_GPOINT_BYTES) != hipSuccess || hipMemset(c->d_gpoint, 0, LASSO_GPOINT_BYTES) != hipSuccess) { g_create_err = "gpoint alloc"; delete c; return LASSO_ERR_OOM; }
   { std::lock_guard<std::mutex> g(g_ctx_mu); g_ctx_live.push_back(c); }
   *out = c; return 0;
 }
@@ -431,10 +444,13 @@ int32_t lasso_ctx_create_background(int32_t device, int32_t background, lasso_ct
 int32_t lasso_abort(lasso_ctx* c) {
   REQUIRE(c, c);
   const uint32_t zero8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (c->tail_active || c->ahead_active) { mail_chunks(c->mail_h + 12, LASSO_MAIL_POISON, zero8); post_mail(c, LASSO_MAIL_POISON, zero8); }
+  if (c->lay_active && c->pmail_h) for (uint32_t j = 0; j < LASSO_POINT_MAX + 2; j++) mail_chunks(c->pmail_h + 12 * j, LASSO_MAIL_POISON, zero8);
+  if (c->tail_active || c->ahead_active || c->lay_active) { mail_chunks(c->mail_h + 12, LASSO_MAIL_POISON, zero8); post_mail(c, LASSO_MAIL_POISON, zero8); }
   (void)hipStreamSynchronize(c->stream);   // bounded: every device-side wait has the poison check and a wall-clock bail-out
   (void)hipGetLastError();
+  if (c->lay_active && c->pmail_h) memset(c->pmail_h, 0, LASSO_PMAIL_BYTES);
   mail_chunks(c->mail_h + 12, 0, zero8); post_mail(c, 0, zero8);
+  c->lay_active = false; c->lay_tail = false; c->no_grow = false;
   c->ahead_active = false; c->ahead_bullet = false; c->tail_unstarted = false; c->handover_next = 0;
   c->tail_active = false; c->pending = false; c->defer_next = false; c->events_used = 0; c->pending_groups = 1; c->pending_K = 0;
   HIPCHK(c, hipMemsetAsync(c->d_counters, 0, (LASSO_MAX_PTRS + 40) * 4, c->stream));
@@ -445,12 +461,14 @@ void lasso_ctx_destroy(lasso_ctx* c) {
   if (!c) return;
   { std::lock_guard<std::mutex> g(g_ctx_mu); for (size_t i = 0; i < g_ctx_live.size(); i++) if (g_ctx_live[i] == c) { g_ctx_live.erase(g_ctx_live.begin() + i); break; } }
   (void)hipSetDevice(c->device);
-  if (c->tail_active || c->pending || c->ahead_active) (void)lasso_abort(c);   // never block in the synchronise below for a kernel's 5 s bail-out
+  if (c->tail_active || c->pending || c->ahead_active || c->lay_active) (void)lasso_abort(c);   // never block in the synchronise below for a kernel's 5 s bail-out
   (void)hipStreamSynchronize(c->stream);
   rccl_release(c);
   for (auto& p : c->events) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   if (c->d_scratch) (void)hipFree(c->d_scratch);
   if (c->d_gmail) (void)hipFree(c->d_gmail);
+  if (c->d_gpoint) (void)hipFree(c->d_gpoint);
+  if (c->pmail_h) (void)hipHostFree(c->pmail_h);
   if (c->h_small) (void)hipHostFree(c->h_small);
   if (c->h_tag) (void)hipHostFree(c->h_tag);
   if (c->h_flag) (void)hipHostFree(c->h_flag);
@@ -465,23 +483,23 @@ void lasso_ctx_destroy(lasso_ctx* c) {
 const char* lasso_last_error(lasso_ctx* c) { return c ? c->err.c_str() : g_create_err.c_str(); }
 void* lasso_stream(lasso_ctx* c) { return c ? (void*)c->stream : nullptr; }
 int32_t lasso_alloc(lasso_ctx* c, size_t bytes, void** d_out) { REQUIRE(c, d_out); HIPCHK(c, dmalloc(c, d_out, bytes ? bytes : 1)); return 0; }
-int32_t lasso_free(lasso_ctx* c, void* p) { if (!p) return 0; REQUIRE(c, c && !c->ahead_active); HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, dfree(c, p)); return 0; }
+int32_t lasso_free(lasso_ctx* c, void* p) { if (!p) return 0; REQUIRE(c, c && !c->ahead_active && !c->lay_active); HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, dfree(c, p)); return 0; }
 int32_t lasso_mem_stats(lasso_ctx* c, uint64_t* live_bytes, uint64_t* peak_bytes, int32_t reset_peak) {
   REQUIRE(c, c); std::lock_guard<std::mutex> g(c->mem_mu);
   if (live_bytes) *live_bytes = c->mem_live; if (peak_bytes) *peak_bytes = c->mem_peak; if (reset_peak) c->mem_peak = c->mem_live; return 0;
 }
 int32_t lasso_trim(lasso_ctx* c) {
-  REQUIRE(c, c && !c->pending && !c->tail_active && !c->ahead_active);
+  REQUIRE(c, c && !c->pending && !c->tail_active && !c->ahead_active && !c->lay_active);
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (c->scratch_cap <= ((size_t)1 << 22)) return 0;
   HIPCHK(c, dfree(c, c->d_scratch)); c->d_scratch = nullptr; c->scratch_cap = 0;
   return ensure_scratch(c, (size_t)1 << 22);
 }
-int32_t lasso_upload(lasso_ctx* c, void* d, const void* s, size_t n) { REQUIRE(c, d && s && !c->ahead_active); HIPCHK(c, hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); return 0; }
-int32_t lasso_download(lasso_ctx* c, void* d, const void* s, size_t n) { REQUIRE(c, d && s && !c->ahead_active); HIPCHK(c, hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); return 0; }
+int32_t lasso_upload(lasso_ctx* c, void* d, const void* s, size_t n) { REQUIRE(c, d && s && !c->ahead_active && !c->lay_active); HIPCHK(c, hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); return 0; }
+int32_t lasso_download(lasso_ctx* c, void* d, const void* s, size_t n) { REQUIRE(c, d && s && !c->ahead_active && !c->lay_active); HIPCHK(c, hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); return 0; }
 int32_t lasso_copy(lasso_ctx* c, void* d, const void* s, size_t n) { REQUIRE(c, d && s); ProfScope ps(c, LASSO_K_MISC, 2.0 * n); HIPCHK(c, hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, c->stream)); return 0; }
 int32_t lasso_zero(lasso_ctx* c, void* d, size_t n) { REQUIRE(c, d); HIPCHK(c, hipMemsetAsync(d, 0, n, c->stream)); return 0; }
-int32_t lasso_sync(lasso_ctx* c) { REQUIRE(c, c && !c->ahead_active); HIPCHK(c, hipStreamSynchronize(c->stream)); return 0; }
+int32_t lasso_sync(lasso_ctx* c) { REQUIRE(c, c && !c->ahead_active && !c->lay_active); HIPCHK(c, hipStreamSynchronize(c->stream)); return 0; }
 
 int32_t lasso_prof_get_large(lasso_ctx* c, int32_t k, uint64_t* launches, double* ms, double* bytes) {
   REQUIRE(c, k >= 0 && k < LASSO_K_COUNT); prof_flush(c);
@@ -608,7 +626,7 @@ static unsigned direct_nx_max() { static const unsigned v = [] { const char* e =
 extern "C++" {
 struct EqPointArg { const lasso_fr* point; uint32_t ell; fr_t scale; };   // a table too large for the in-LDS build: factor tables by k_eq_small2 into the scratch, the product inside round 0 (EqGlobal)
 template <class TM, class TP>   // pointer tables sized for the number of circuits (MutPtrTable8 / PtrTable8 up to 8: 64 bytes of kernel arguments each instead of 1088)
-static int32_t cubic_eqw_launch_t(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n, const lasso_fr* r, int NT, uint32_t* seq_out, const EqInline* eqi, uint32_t* groups_out, bool ahead = false, const EqPointArg* eqg = nullptr) {
+static int32_t cubic_eqw_launch_t(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n, const lasso_fr* r, int NT, uint32_t* seq_out, const EqInline* eqi, uint32_t* groups_out, bool ahead = false, const EqPointArg* eqg = nullptr, int gate_ell = -1) {
   if (groups_out) *groups_out = 1;
   if (ahead && (NT != 2 || n / 4 <= CUBIC_SMALL_Q)) return fail(c, LASSO_ERR_UNSUPPORTED, "a round launched ahead of its challenge: two-sum streaming rounds only (more than 64 index quadruples per circuit)");
   TM A, B; for (uint32_t i = 0; i < ncirc; i++) { REQUIRE(c, d_A[i] && d_B[i]); A.p[i] = (fr_t*)d_A[i]; B.p[i] = (fr_t*)d_B[i]; }
@@ -616,24 +634,45 @@ static int32_t cubic_eqw_launch_t(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* 
   const uint32_t seq = next_seq(c); *seq_out = seq;
   if (!r && !ahead) {
     const size_t half = n / 2;
-    ProfScope ps(c, LASSO_K_CUBIC, 32.0 * n * (2.0 * ncirc + 1.0));
     if (half <= CUBIC_SMALL_Q) {   // arrays are read-only in this mode
+      ProfScope ps(c, LASSO_K_CUBIC, 32.0 * n * (2.0 * ncirc + 1.0));
       if (NT == 3) hipLaunchKernelGGL((k_cubic_eqw_small<false, 3, TM>), dim3(ncirc), dim3(LASSO_BLOCK), 0, c->stream, A, B, (const fr_t*)d_E, (uint32_t)half, fr_zero(), c->d_counters, RES(c), seq);
       else hipLaunchKernelGGL((k_cubic_eqw_small<false, 2, TM>), dim3(ncirc), dim3(LASSO_BLOCK), 0, c->stream, A, B, (const fr_t*)d_E, (uint32_t)half, fr_zero(), c->d_counters, RES(c), seq);
     } else {
       TP Ac, Bc; for (uint32_t i = 0; i < ncirc; i++) { Ac.p[i] = A.p[i]; Bc.p[i] = B.p[i]; }
       const unsigned ny = ncirc, nx = grid_for(half, cubic_nx_cap(ny));
-      const uint32_t g_lo = eqg ? eqg->ell / 2 : 0, g_hi = eqg ? eqg->ell - g_lo : 0;
+      const bool gated = gate_ell >= 0, gbig = gated && gate_ell > 14;   // the point comes through the gate (the layer is enqueued ahead of it); above 2^14 entries with factor tables in memory
+      const uint32_t g_ell = gbig ? (uint32_t)gate_ell : eqg ? eqg->ell : 0, g_lo = g_ell / 2, g_hi = g_ell - g_lo;
       const size_t part_elems = (size_t)nx * ny * 3;
-      rc = ensure_scratch(c, (part_elems + (eqg ? ((size_t)1 << g_hi) + ((size_t)1 << g_lo) : 0)) * sizeof(fr_t)); if (rc) return rc;
+      rc = ensure_scratch(c, (part_elems + ((eqg || gbig) ? ((size_t)1 << g_hi) + ((size_t)1 << g_lo) : 0)) * sizeof(fr_t)); if (rc) return rc;
       CUBIC_RESULT_ARGS(nx);
       static const uint32_t pipe = [] { const char* v = getenv("LASSO_LB_PIPELINE"); return (v && v[0] == '0') ? 0u : 1u; }();
-      if (eqg && NT == 2) {   // factor tables behind the partials in the scratch, then round 0 with the product inside (the table goes to d_E on the way)
-        fr_t* hi = (fr_t*)c->d_scratch + part_elems; fr_t* lo = hi + ((size_t)1 << g_hi);
-        RTable16 Rh, Rl; for (uint32_t j = 0; j < 16; j++) { Rh.r[j] = j < g_hi ? to_fr(eqg->point + j) : fr_zero(); Rl.r[j] = j < g_lo ? to_fr(eqg->point + g_hi + j) : fr_zero(); }
+      // what runs in front of the round is outside the round's profiling bracket: the wait for the point (one wave), the two factor tables (their own bracket)
+      fr_t* const f_hi = (fr_t*)c->d_scratch + part_elems; fr_t* const f_lo = f_hi + ((size_t)1 << g_hi);
+      if (gated && NT == 2) hipLaunchKernelGGL(k_gate_point, dim3(1), dim3(64), 0, c->stream, (const uint32_t*)c->pmail_d, c->d_gpoint, seq, (uint32_t)gate_ell + 2u);
+      if ((gbig || eqg) && NT == 2) {
+        ProfScope pe(c, LASSO_K_EQ, 32.0 * (((size_t)1 << g_hi) + ((size_t)1 << g_lo)));
         const unsigned hb = grid_for((size_t)1 << g_hi), lb2 = grid_for((size_t)1 << g_lo);
-        hipLaunchKernelGGL(k_eq_small2, dim3(hb + lb2), dim3(LASSO_BLOCK), 0, c->stream, Rh, g_hi, eqg->scale, hi, hb, Rl, g_lo, lo);
-        EqGlobal G; G.hi = hi; G.lo = lo; G.lo_bits = g_lo; G.ell = eqg->ell;
+        if (gbig) hipLaunchKernelGGL(k_eq_small2_mem, dim3(hb + lb2), dim3(LASSO_BLOCK), 0, c->stream, (const uint32_t*)c->d_gpoint, seq, g_hi, f_hi, hb, g_lo, f_lo);
+        else {
+          RTable16 Rh, Rl; for (uint32_t j = 0; j < 16; j++) { Rh.r[j] = j < g_hi ? to_fr(eqg->point + j) : fr_zero(); Rl.r[j] = j < g_lo ? to_fr(eqg->point + g_hi + j) : fr_zero(); }
+          hipLaunchKernelGGL(k_eq_small2, dim3(hb + lb2), dim3(LASSO_BLOCK), 0, c->stream, Rh, g_hi, eqg->scale, f_hi, hb, Rl, g_lo, f_lo);
+        }
+      }
+      ProfScope ps(c, LASSO_K_CUBIC, 32.0 * n * (2.0 * ncirc + 1.0));
+      if (gated && NT == 2) {
+        if (gbig) {
+          fr_t* hi = f_hi; fr_t* lo = f_lo;
+          EqGlobal G; G.hi = hi; G.lo = lo; G.lo_bits = g_lo; G.ell = g_ell; G.gp = c->d_gpoint; G.seq = seq;
+          hipLaunchKernelGGL((k_cubic_eqw_lb<2, true, TP, EqGlobal>), dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, Ac, Bc, nx, ny, (const fr_t*)nullptr, half, (fr_t*)c->d_scratch, c->d_counters, r_out, r_flag, seq, 1u, G, (fr_t*)d_E);
+        } else {
+          EqInlineMem M; M.gp = c->d_gpoint; M.seq = seq; M.ell = (uint32_t)gate_ell;
+          hipLaunchKernelGGL((k_cubic_eqw_lb<2, true, TP, EqInlineMem>), dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, Ac, Bc, nx, ny, (const fr_t*)nullptr, half, (fr_t*)c->d_scratch, c->d_counters, r_out, r_flag, seq, 1u, M, (fr_t*)d_E);
+        }
+      } else
+      if (eqg && NT == 2) {   // factor tables behind the partials in the scratch (above), then round 0 with the product inside (the table goes to d_E on the way)
+        fr_t* hi = f_hi; fr_t* lo = f_lo;
+        EqGlobal G; G.hi = hi; G.lo = lo; G.lo_bits = g_lo; G.ell = eqg->ell; G.gp = nullptr; G.seq = 0;
         hipLaunchKernelGGL((k_cubic_eqw_lb<2, true, TP, EqGlobal>), dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, Ac, Bc, nx, ny, (const fr_t*)nullptr, half, (fr_t*)c->d_scratch, c->d_counters, r_out, r_flag, seq, 1u, G, (fr_t*)d_E);
       } else
       if (NT == 3) hipLaunchKernelGGL((k_cubic_eqw_lb<3, false, TP, EqNone>), dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, Ac, Bc, nx, ny, (const fr_t*)d_E, half, (fr_t*)c->d_scratch, c->d_counters, r_out, r_flag, seq, 0u, EqNone(), (fr_t*)nullptr);
@@ -678,8 +717,8 @@ static int32_t cubic_eqw_launch_t(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* 
   return 0;
 }
 }   // extern "C++"
-static int32_t cubic_eqw_launch(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n, const lasso_fr* r, int NT, uint32_t* seq_out, const EqInline* eqi = nullptr, uint32_t* groups_out = nullptr, bool ahead = false, const EqPointArg* eqg = nullptr) {
-  return ncirc <= 8 ? cubic_eqw_launch_t<MutPtrTable8, PtrTable8>(c, d_A, d_B, ncirc, d_E, n, r, NT, seq_out, eqi, groups_out, ahead, eqg) : cubic_eqw_launch_t<MutPtrTable, PtrTable>(c, d_A, d_B, ncirc, d_E, n, r, NT, seq_out, eqi, groups_out, ahead, eqg);
+static int32_t cubic_eqw_launch(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n, const lasso_fr* r, int NT, uint32_t* seq_out, const EqInline* eqi = nullptr, uint32_t* groups_out = nullptr, bool ahead = false, const EqPointArg* eqg = nullptr, int gate_ell = -1) {
+  return ncirc <= 8 ? cubic_eqw_launch_t<MutPtrTable8, PtrTable8>(c, d_A, d_B, ncirc, d_E, n, r, NT, seq_out, eqi, groups_out, ahead, eqg, gate_ell) : cubic_eqw_launch_t<MutPtrTable, PtrTable>(c, d_A, d_B, ncirc, d_E, n, r, NT, seq_out, eqi, groups_out, ahead, eqg, gate_ell);
 }
 int32_t lasso_sumcheck_cubic_eqw_round(lasso_ctx* c, const lasso_fr* const* d_A, const lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n, lasso_fr* out) {
   REQUIRE(c, d_A && d_B && d_E && out && ncirc >= 1 && ncirc <= LASSO_MAX_PTRS && n >= 2 && (n & (n - 1)) == 0);
@@ -730,7 +769,7 @@ int32_t lasso_rounds_ahead_ok(lasso_ctx* c) { static const bool off = [] { const
 // result of the first of the log2(2q) rounds is pending afterwards (lasso_result_wait, 2*ncirc values: (q(0), q_inf) per circuit).
 // next: posts a challenge; pending: the next round's sums, or after the last round the 2*ncirc bound heads (A_0.., B_0..).
 // The arrays in device memory are NOT updated (nothing reads a layer's arrays after its sumcheck).
-static int32_t cubic_tail_begin_impl(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n, const lasso_fr* r, const EqInline* eqi, bool ahead);
+static int32_t cubic_tail_begin_impl(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n, const lasso_fr* r, const EqInline* eqi, bool ahead, int gate_ell = -1);
 int32_t lasso_sumcheck_cubic_tail_begin(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n, const lasso_fr* r) {
   REQUIRE(c, d_E);
   return cubic_tail_begin_impl(c, d_A, d_B, ncirc, d_E, n, r, nullptr, false);
@@ -761,9 +800,10 @@ int32_t lasso_sumcheck_cubic_tail_begin_eq(lasso_ctx* c, lasso_fr* const* d_A, l
 }
 extern "C++" {
 template <class TM>
-static int32_t cubic_tail_begin_t(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n, const lasso_fr* r, const EqInline* eqi, bool ahead) {
+static int32_t cubic_tail_begin_t(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n, const lasso_fr* r, const EqInline* eqi, bool ahead, int gate_ell) {
   const uint32_t m_stop = c->handover_next ? c->handover_next : 1u; c->handover_next = 0;   // consumed by this call, whatever its outcome
-  REQUIRE(c, d_A && d_B && (d_E || eqi) && ncirc >= 1 && ncirc <= LASSO_MAX_PTRS && n >= ((r || ahead) ? 4u : 2u) && (n & (n - 1)) == 0 && (ahead || !c->pending) && !c->tail_active && !c->defer_next && !c->ahead_active);
+  const bool gated = gate_ell >= 0;   // the whole layer enqueued ahead of its eq point, possibly behind the previous layer's (still active) tail: the point comes through k_gate_point
+  REQUIRE(c, d_A && d_B && (d_E || eqi || gated) && ncirc >= 1 && ncirc <= LASSO_MAX_PTRS && n >= ((r || ahead) ? 4u : 2u) && (n & (n - 1)) == 0 && (ahead || gated || !c->pending) && (gated || !c->tail_active) && !c->defer_next && !c->ahead_active && !c->lay_active);
   const size_t q = (r || ahead) ? n / 4 : n / 2;
   REQUIRE(c, q >= 1 && q <= CUBIC_TAIL_Q && (m_stop & (m_stop - 1)) == 0 && m_stop <= 128 && 2 * q > m_stop);   // at least one round of sums before the arrays are handed over
   TM A, B; for (uint32_t i = 0; i < ncirc; i++) { REQUIRE(c, d_A[i] && d_B[i]); A.p[i] = (fr_t*)d_A[i]; B.p[i] = (fr_t*)d_B[i]; }
@@ -772,6 +812,14 @@ static int32_t cubic_tail_begin_t(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* 
   const uint32_t seq0 = next_seq(c, turns + 1);
   // workgroup = capacity: 256 threads / 74 KB of LDS up to 256 indices per circuit, 512 threads / 147 KB above
 #define LAUNCH_CTAIL(B_, Q_, I_, TE_, R_, EQ_) hipLaunchKernelGGL((k_cubic_tail<B_, Q_, I_, TM, TE_>), dim3(ncirc), dim3(Q_), 0, c->stream, A, B, (const fr_t*)d_E, (uint32_t)q, R_, (const uint32_t*)c->mail_d, c->d_counters, RES(c), seq0, EQ_, m_stop, ahead ? 1u : 0u)
+  if (gated) {
+    hipLaunchKernelGGL(k_gate_point, dim3(1), dim3(64), 0, c->stream, (const uint32_t*)c->pmail_d, c->d_gpoint, seq0, (uint32_t)gate_ell + 2u);
+    EqInlineMem M; M.gp = c->d_gpoint; M.seq = seq0; M.ell = (uint32_t)gate_ell;
+    if (q <= 256) LAUNCH_CTAIL(false, 256, true, EqInlineMem, fr_zero(), M); else LAUNCH_CTAIL(false, 512, true, EqInlineMem, fr_zero(), M);
+    HIPCHK(c, hipGetLastError());
+    c->lay_active = true; c->lay_tail = true; c->lay_seq = seq0; c->lay_ell = (uint32_t)gate_ell; c->lay_turns = turns; c->lay_count = (size_t)ncirc * 2; c->lay_final = (size_t)ncirc * 2 * m_stop; c->lay_tagged = c->tagged;
+    return 0;   // the tail state of the context still belongs to the previous layer: lasso_point_post installs this one
+  }
   if (eqi) { if (q <= 256) LAUNCH_CTAIL(false, 256, true, EqInline, fr_zero(), *eqi); else LAUNCH_CTAIL(false, 512, true, EqInline, fr_zero(), *eqi); }
   else if (q <= 256) { if (r || ahead) LAUNCH_CTAIL(true, 256, false, EqNone, r ? to_fr(r) : fr_zero(), EqNone()); else LAUNCH_CTAIL(false, 256, false, EqNone, fr_zero(), EqNone()); }
   else { if (r || ahead) LAUNCH_CTAIL(true, 512, false, EqNone, r ? to_fr(r) : fr_zero(), EqNone()); else LAUNCH_CTAIL(false, 512, false, EqNone, fr_zero(), EqNone()); }
@@ -782,8 +830,72 @@ static int32_t cubic_tail_begin_t(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* 
   return 0;
 }
 }   // extern "C++"
-static int32_t cubic_tail_begin_impl(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n, const lasso_fr* r, const EqInline* eqi, bool ahead) {
-  return ncirc <= 8 ? cubic_tail_begin_t<MutPtrTable8>(c, d_A, d_B, ncirc, d_E, n, r, eqi, ahead) : cubic_tail_begin_t<MutPtrTable>(c, d_A, d_B, ncirc, d_E, n, r, eqi, ahead);
+static int32_t cubic_tail_begin_impl(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n, const lasso_fr* r, const EqInline* eqi, bool ahead, int gate_ell) {
+  return ncirc <= 8 ? cubic_tail_begin_t<MutPtrTable8>(c, d_A, d_B, ncirc, d_E, n, r, eqi, ahead, gate_ell) : cubic_tail_begin_t<MutPtrTable>(c, d_A, d_B, ncirc, d_E, n, r, eqi, ahead, gate_ell);
+}
+// ---- A LAYER enqueued ahead of its eq point (round 5).  Between two layers of a grand-product argument the device used to idle for the host's last rounds, the layer's closing
+// Fiat-Shamir step AND the launch + dispatch of the next layer's first kernel(s) (20-40 us per transition, ~30 transitions per proof).  With these entry points the next layer's
+// first launch — round 0 with its eq table built inside (lasso_sumcheck_cubic_eqw2_begin_eq), or the resident tail that serves a small layer whole
+// (lasso_sumcheck_cubic_tail_begin_eq) — is enqueued while the CURRENT layer's resident tail is still answering (legal with a tail active and a result pending), behind a one-wave
+// gate that waits for the point; lasso_point_post delivers point and scale and turns the launch into the context's pending result (and active tail), exactly as if the plain entry
+// point had been called then; lasso_point_cancel ends the enqueued kernels without a result (a layer whose shape turned out different).  Nothing may grow while a tail is resident:
+// LASSO_ERR_UNSUPPORTED when a buffer would have to (the caller takes the plain path after the layer).
+int32_t lasso_layer_ahead_ok(lasso_ctx* c) { static const bool off = [] { const char* v = getenv("LASSO_LAYER_AHEAD"); return v && v[0] == '0'; }(); return c && !off && c->pmail_d && c->d_gpoint ? 1 : 0; }
+int32_t lasso_sumcheck_cubic_eqw2_begin_eq_ahead(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, lasso_fr* d_E_out, size_t n, uint32_t ell) {
+  REQUIRE(c, d_A && d_B && d_E_out && ncirc >= 1 && ncirc <= LASSO_MAX_PTRS && n >= 2 && (n & (n - 1)) == 0 && ell < 48 && ((size_t)1 << ell) == n / 2 && !c->lay_active && !c->ahead_active && !c->defer_next);
+  if (!lasso_layer_ahead_ok(c) || n / 2 <= CUBIC_SMALL_Q || ell > 32 || ell > LASSO_POINT_MAX) return fail(c, LASSO_ERR_UNSUPPORTED, "lasso_sumcheck_cubic_eqw2_begin_eq_ahead: tables of 2^7 .. 2^32 entries only");
+  uint32_t seq, groups;
+  c->no_grow = true;
+  const int32_t rc = cubic_eqw_launch(c, d_A, d_B, ncirc, d_E_out, n, nullptr, 2, &seq, nullptr, &groups, false, nullptr, (int)ell);
+  c->no_grow = false;
+  if (rc == LASSO_ERR_UNSUPPORTED) return fail(c, rc, "lasso_sumcheck_cubic_eqw2_begin_eq_ahead: a buffer would have to grow while kernels are in flight");
+  if (rc) return rc;
+  HIPCHK(c, hipGetLastError());
+  c->lay_active = true; c->lay_tail = false; c->lay_seq = seq; c->lay_ell = ell; c->lay_count = (size_t)ncirc * 2; c->lay_tagged = c->tagged; c->lay_groups = groups; c->lay_K = 2;
+  return 0;
+}
+int32_t lasso_sumcheck_cubic_tail_begin_eq_ahead(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, size_t n, uint32_t ell) {
+  REQUIRE(c, n >= 2 && ell <= 9 && ((size_t)1 << ell) == n / 2);
+  if (!lasso_layer_ahead_ok(c)) { c->handover_next = 0; return fail(c, LASSO_ERR_UNSUPPORTED, "lasso_sumcheck_cubic_tail_begin_eq_ahead: switched off"); }
+  c->no_grow = true;
+  const int32_t rc = cubic_tail_begin_impl(c, d_A, d_B, ncirc, nullptr, n, nullptr, nullptr, false, (int)ell);
+  c->no_grow = false;
+  if (rc == LASSO_ERR_UNSUPPORTED) return fail(c, rc, "lasso_sumcheck_cubic_tail_begin_eq_ahead: a buffer would have to grow while kernels are in flight");
+  return rc;
+}
+static void point_mail(lasso_ctx* c, uint32_t ell, const lasso_fr* point, const lasso_fr* scale, uint32_t ctrl) {
+  const uint32_t zero8[8] = {0, 0, 0, 0, 0, 0, 0, 0}; const fr_t one = fr_one();
+  for (uint32_t j = 0; j < ell; j++) mail_chunks(c->pmail_h + 12 * j, c->lay_seq, point ? (const uint32_t*)(point + j) : zero8);
+  mail_chunks(c->pmail_h + 12 * ell, c->lay_seq, scale ? (const uint32_t*)scale : one.v);
+  const uint32_t ctl[8] = {ctrl, 0, 0, 0, 0, 0, 0, 0};
+  mail_chunks(c->pmail_h + 12 * (ell + 1), c->lay_seq, ctl);
+#if defined(__SSE2__)
+  _mm_sfence();
+#else
+  __atomic_thread_fence(__ATOMIC_SEQ_CST);
+#endif
+}
+// point[0..ell) and *scale (NULL = 1) of the layer enqueued ahead: afterwards the context is where the plain entry point would have left it (first round's sums pending;
+// the resident tail active).  Legal once the previous layer's tail has ended and its last result has been collected.
+int32_t lasso_point_post(lasso_ctx* c, const lasso_fr* point, uint32_t ell, const lasso_fr* scale) {
+  REQUIRE(c, c && c->lay_active && ell == c->lay_ell && (point || !ell) && !c->pending && !c->tail_active && !c->ahead_active);
+  point_mail(c, ell, point, scale, 0u);
+  c->lay_active = false;
+  if (c->lay_tail) {
+    c->tail_active = true; c->tail_seq0 = c->lay_seq; c->tail_turn = 0; c->tail_turns = c->lay_turns; c->tail_count = c->lay_count; c->tail_final = c->lay_final; c->tail_unstarted = false;
+    c->pending = true; c->pending_seq = c->lay_seq; c->pending_count = c->lay_count; c->pending_tagged = c->lay_tagged; c->pending_groups = 1; c->pending_K = 0;
+  } else {
+    c->pending = true; c->pending_seq = c->lay_seq; c->pending_count = c->lay_count; c->pending_tagged = c->lay_tagged; c->pending_groups = c->lay_groups; c->pending_K = c->lay_K;
+  }
+  c->lay_tail = false;
+  return 0;
+}
+// the layer enqueued ahead is not wanted after all: its kernels end without touching anything (stream order: whatever is enqueued next runs after them)
+int32_t lasso_point_cancel(lasso_ctx* c) {
+  REQUIRE(c, c && c->lay_active);
+  point_mail(c, c->lay_ell, nullptr, nullptr, 1u);
+  c->lay_active = false; c->lay_tail = false;
+  return 0;
 }
 // The resident tail enqueued AHEAD of the challenge it binds first (n = 4q): legal while the previous round's result is pending; the first lasso_sumcheck_cubic_tail_next
 // posts that challenge and makes the first round's sums the pending result.
@@ -794,7 +906,7 @@ int32_t lasso_sumcheck_cubic_tail_begin_ahead(lasso_ctx* c, lasso_fr* const* d_A
 // The next lasso_sumcheck_cubic_tail_begin* stops when its arrays are down to m_stop elements each (a power of two, 2 <= m_stop <= 128, below the arrays' length at the first
 // round) and its LAST publication is the arrays instead of the heads: 2 * ncirc * m_stop values, A_0[0..m_stop), A_1[..], .., B_0[..], ...  m_stop = 1 or 0: the heads.
 int32_t lasso_tail_handover_next(lasso_ctx* c, uint32_t m_stop) {
-  REQUIRE(c, c && !c->tail_active && (m_stop & (m_stop - 1)) == 0 && m_stop <= 128);
+  REQUIRE(c, c && (m_stop & (m_stop - 1)) == 0 && m_stop <= 128);   // (legal with a tail active: the next begin may be a layer enqueued ahead, lasso_sumcheck_cubic_tail_begin_eq_ahead)
   c->handover_next = m_stop <= 1 ? 0 : m_stop; return 0;
 }
 // The same for the primary sumcheck of a linear strategy (k_linear_tail): per round two dot products per polynomial, out[2k] = S0_k, out[2k+1] = S1_k

@@ -173,6 +173,38 @@ __device__ __forceinline__ bool gated_challenge(const uint32_t* gmail, uint32_t 
   __syncthreads();
   return s_mail[16] != 0;
 }
+// A LAYER's first launch enqueued ahead of the layer's eq point (round 5): the host enqueues the next grand-product layer's round 0 (or its resident tail) while the current layer's
+// last kernel is still running, and posts the point — the current layer's challenges and 1 - r_layer, known only after the layer's last Fiat-Shamir step — when it has it.  The
+// message is ell + 2 field elements (point[0..ell), scale, control: word 0 != 0 cancels) in a host-mapped area of one three-chunk mailbox entry each (mail_wait's format), all
+// under the launch's sequence number; ONE wave waits for it, lane j for entry j, and leaves the elements in device memory: gpoint[8 j ..), then gpoint[LASSO_GP_TAG] = seq —
+// or gpoint[LASSO_GP_TAG + 1] = seq: cancelled, poisoned (lasso_abort) or 5 s without a post, and the kernels behind the gate end without a result.
+#define LASSO_POINT_MAX 40
+#define LASSO_GP_TAG (8 * (LASSO_POINT_MAX + 2))
+#define LASSO_PMAIL_BYTES 2048    // (LASSO_POINT_MAX + 2) entries of 48 bytes
+#define LASSO_GPOINT_BYTES 2048   // (LASSO_GP_TAG + 2) words
+__global__ void __launch_bounds__(64) k_gate_point(const uint32_t* pmail, uint32_t* gpoint, uint32_t seq, uint32_t nfr) {   // no __restrict__: the host writes pmail while this polls
+  const uint32_t t = threadIdx.x;
+  const uint64_t t_end = wall_clock64() + 500000000ull;   // 5 s at 100 MHz
+  bool ok = true; fr_t v = fr_zero();
+  if (t < nfr) {
+    ok = mail_wait(pmail + 12 * t, seq, t_end, v);
+    if (ok) {
+#pragma unroll
+      for (int k = 0; k < 8; k++) gpoint[8 * t + k] = v.v[k];
+      if (t == nfr - 1 && v.v[0] != 0) ok = false;   // the control entry: cancelled by the host
+    }
+  }
+  const bool all_ok = __ballot(!ok) == 0;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  if (t == 0) gpoint[LASSO_GP_TAG + (all_ok ? 0 : 1)] = seq;
+}
+__device__ __forceinline__ bool gate_point_ok(const uint32_t* __restrict__ gp, uint32_t seq) { return gp[LASSO_GP_TAG] == seq && gp[LASSO_GP_TAG + 1] != seq; }
+__device__ __forceinline__ fr_t gate_point_fr(const uint32_t* __restrict__ gp, uint32_t j) {
+  fr_t r;
+#pragma unroll
+  for (int k = 0; k < 8; k++) r.v[k] = gp[8 * j + k];
+  return r;
+}
 // block partials of up to KMAX accumulators (groups of 3) -> dst[k], k < K; `shift` also corrects the radix of the accumulated products.
 // With `flag` the destination is the launch's result area (result_store at slot0 + k).
 template <int KMAX>
@@ -365,32 +397,50 @@ __device__ __forceinline__ void cubic_eqw_terms2(const fr29& a0, const fr29& a1,
 struct EqInline { fr_t r[14]; fr_t scale; uint32_t ell; };
 struct EqNone { uint32_t ell = 0; };   // stands in for EqInline in the launches that carry no point (4 bytes of kernel arguments instead of 484)
 struct EqInlineTables { fr29 hi_s[128], lo_s[128], lo_u[128]; };
-__device__ __forceinline__ void eq_inline_build(const EqInline& Q, EqInlineTables& T) {   // all threads of the workgroup; ends with a barrier
+// the same point, not an argument: left in device memory by the gate in front of the launch (k_gate_point), for a layer enqueued before its point was known
+struct EqInlineMem { const uint32_t* gp; uint32_t seq; uint32_t ell; };
+__device__ __forceinline__ fr_t eq_point_r(const EqInline& Q, uint32_t j) { return Q.r[j]; }
+__device__ __forceinline__ fr_t eq_point_scale(const EqInline& Q) { return Q.scale; }
+__device__ __forceinline__ bool eq_point_ok(const EqInline&) { return true; }
+__device__ __forceinline__ fr_t eq_point_r(const EqInlineMem& Q, uint32_t j) { return gate_point_fr(Q.gp, j); }
+__device__ __forceinline__ fr_t eq_point_scale(const EqInlineMem& Q) { return gate_point_fr(Q.gp, Q.ell); }
+__device__ __forceinline__ bool eq_point_ok(const EqInlineMem& Q) { return gate_point_ok(Q.gp, Q.seq); }
+// all threads of the workgroup; ends with a barrier.  false (block-uniform): the point never came, the launch ends without a result
+template <class QT>
+__device__ __forceinline__ bool eq_inline_build_t(const QT& Q, EqInlineTables& T) {
+  if (!eq_point_ok(Q)) return false;
   const uint32_t t = threadIdx.x, lb = Q.ell / 2, hb = Q.ell - lb;
   const fr29 one_s = fr29_one_s();
   if (t < (1u << hb)) {
-    fr29 p = fr29_unpack_s(Q.scale);
-    for (uint32_t j = 0; j < hb; j++) { const bool bit = (t >> (hb - 1 - j)) & 1u; const fr29 rs = fr29_unpack_s(Q.r[j]); p = fr29_mul(bit ? rs : fr29_sub(one_s, rs), p); }
+    fr29 p = fr29_unpack_s(eq_point_scale(Q));
+    for (uint32_t j = 0; j < hb; j++) { const bool bit = (t >> (hb - 1 - j)) & 1u; const fr29 rs = fr29_unpack_s(eq_point_r(Q, j)); p = fr29_mul(bit ? rs : fr29_sub(one_s, rs), p); }
     T.hi_s[t] = p;
   } else if (t >= 128 && t - 128 < (1u << lb)) {
     const uint32_t x = t - 128;
     fr29 p = one_s;
-    for (uint32_t j = 0; j < lb; j++) { const bool bit = (x >> (lb - 1 - j)) & 1u; const fr29 rs = fr29_unpack_s(Q.r[hb + j]); p = fr29_mul(bit ? rs : fr29_sub(one_s, rs), p); }
+    for (uint32_t j = 0; j < lb; j++) { const bool bit = (x >> (lb - 1 - j)) & 1u; const fr29 rs = fr29_unpack_s(eq_point_r(Q, hb + j)); p = fr29_mul(bit ? rs : fr29_sub(one_s, rs), p); }
     T.lo_s[x] = p;
     T.lo_u[x] = fr29_mul(p, fr29_unpack_u(fr_one()));   // s-form times the integer 2^256: the same value in u-form
   }
   __syncthreads();
+  return true;
 }
+__device__ __forceinline__ bool eq_inline_build(const EqInline& Q, EqInlineTables& T) { return eq_inline_build_t(Q, T); }
+__device__ __forceinline__ bool eq_inline_build(const EqInlineMem& Q, EqInlineTables& T) { return eq_inline_build_t(Q, T); }
 __device__ __forceinline__ fr29 eq_inline_s(const EqInlineTables& T, uint32_t lb, size_t x) { return fr29_mul(T.hi_s[x >> lb], T.lo_s[x & ((1u << lb) - 1u)]); }
 // Tables of MORE than 2^14 entries (round 5): the two factor tables (<= 2^11 entries each) do not fit LDS, so they stay where k_eq_small2 wrote them — global memory, memory form,
 // L2-resident — and round 0 forms  E[x] = hi[x >> lo_bits] * lo[x & mask]  where it uses it: k_eq_outer's product, bit for bit, written to E_out by circuit 0's workgroups for the
 // later rounds and never read back in this launch.  Takes k_eq_outer (a 32-byte write per entry, then the same bytes read again by round 0: 5-200 us in front of round 0 of the
 // nine largest layers of a 2^24 proof) off the critical path for one product per index in a launch that is HBM-bound.
-struct EqGlobal { const fr_t* hi; const fr_t* lo; uint32_t lo_bits; uint32_t ell; };
-__device__ __forceinline__ void eq_inline_build(const EqGlobal&, EqInlineTables&) {}
-__device__ __forceinline__ void eq_inline_build(const EqNone&, EqInlineTables&) {}
+struct EqGlobal { const fr_t* hi; const fr_t* lo; uint32_t lo_bits; uint32_t ell; const uint32_t* gp; uint32_t seq; };   // gp != nullptr: the factor tables were built behind a point gate (k_eq_small2_mem), which may have failed
+__device__ __forceinline__ bool eq_inline_build(const EqGlobal& Q, EqInlineTables&) { return Q.gp == nullptr || gate_point_ok(Q.gp, Q.seq); }
+__device__ __forceinline__ bool eq_inline_build(const EqNone&, EqInlineTables&) { return true; }
 // the eq weight of index i as the s-form operand of the round, and (write) the table entry in memory form
 __device__ __forceinline__ fr29 eq_inline_value(const EqInline&, const EqInlineTables& T, uint32_t lb, size_t i, bool write, fr_t* __restrict__ E_out) {
+  if (write) E_out[i] = fr29_store(fr29_mul(T.hi_s[i >> lb], T.lo_u[i & ((1u << lb) - 1u)]));
+  return eq_inline_s(T, lb, i);
+}
+__device__ __forceinline__ fr29 eq_inline_value(const EqInlineMem&, const EqInlineTables& T, uint32_t lb, size_t i, bool write, fr_t* __restrict__ E_out) {
   if (write) E_out[i] = fr29_store(fr29_mul(T.hi_s[i >> lb], T.lo_u[i & ((1u << lb) - 1u)]));
   return eq_inline_s(T, lb, i);
 }
@@ -415,7 +465,7 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_eqw_lb(TP A, TP B, uint32
   __shared__ EqInlineTables ET;
   const CubicGrid g = cubic_grid(nx, ny);
   const uint32_t elb = EQ.ell / 2;
-  if constexpr (EQI) eq_inline_build(EQ, ET);
+  if constexpr (EQI) { if (!eq_inline_build(EQ, ET)) return; }
   const fr_t* __restrict__ a = A.p[g.by];
   const fr_t* __restrict__ b = B.p[g.by];
   fr29 e[3] = {fr29_zero(), fr29_zero(), fr29_zero()}; uint32_t cnt = 0;
@@ -592,9 +642,10 @@ __global__ void __launch_bounds__(Q) k_cubic_tail(TM A, TM B, const fr_t* __rest
   __shared__ fr29 eq_hi[EQI ? 32 : 1], eq_lo[EQI ? 32 : 1];
   const uint32_t elb = EQ.ell / 2;
   if constexpr (EQI) {   // ell = log2 q <= 9: hi over the first ceil(ell/2) coordinates (scale folded in), lo over the rest, both s-form
+    if (!eq_point_ok(EQ)) return;   // (EqInlineMem: the layer was enqueued ahead of its point and the point never came)
     const uint32_t tt = threadIdx.x, hb = EQ.ell - elb; const fr29 one_s = fr29_one_s();
-    if (tt < (1u << hb)) { fr29 p = fr29_unpack_s(EQ.scale); for (uint32_t j = 0; j < hb; j++) { const bool bit = (tt >> (hb - 1 - j)) & 1u; const fr29 rs = fr29_unpack_s(EQ.r[j]); p = fr29_mul(bit ? rs : fr29_sub(one_s, rs), p); } eq_hi[tt] = p; }
-    else if (tt >= 64 && tt - 64 < (1u << elb)) { const uint32_t x = tt - 64; fr29 p = one_s; for (uint32_t j = 0; j < elb; j++) { const bool bit = (x >> (elb - 1 - j)) & 1u; const fr29 rs = fr29_unpack_s(EQ.r[hb + j]); p = fr29_mul(bit ? rs : fr29_sub(one_s, rs), p); } eq_lo[x] = p; }
+    if (tt < (1u << hb)) { fr29 p = fr29_unpack_s(eq_point_scale(EQ)); for (uint32_t j = 0; j < hb; j++) { const bool bit = (tt >> (hb - 1 - j)) & 1u; const fr29 rs = fr29_unpack_s(eq_point_r(EQ, j)); p = fr29_mul(bit ? rs : fr29_sub(one_s, rs), p); } eq_hi[tt] = p; }
+    else if (tt >= 64 && tt - 64 < (1u << elb)) { const uint32_t x = tt - 64; fr29 p = one_s; for (uint32_t j = 0; j < elb; j++) { const bool bit = (x >> (elb - 1 - j)) & 1u; const fr29 rs = fr29_unpack_s(eq_point_r(EQ, hb + j)); p = fr29_mul(bit ? rs : fr29_sub(one_s, rs), p); } eq_lo[x] = p; }
     __syncthreads();
   }
 #define TAIL_EQ_S(idx) (EQI ? fr29_mul(eq_hi[(idx) >> elb], eq_lo[(idx) & ((1u << elb) - 1u)]) : fr29_unpack_s(E[(idx)]))
@@ -1233,6 +1284,18 @@ __global__ void k_eq_small2(RTable16 Rh, uint32_t hi_bits, fr_t scale, fr_t* __r
   // the block-uniform branch outside, r[j] is a scalar load from the argument segment
   if (is_lo) { for (uint32_t j = 0; j < ell; j++) { const bool bit = (x >> (ell - 1 - j)) & 1; const fr29 rs = fr29_unpack_s(Rl.r[j]); p = fr29_mul(bit ? rs : fr29_sub(one_s, rs), p); } lo[x] = fr29_store(p); }
   else { for (uint32_t j = 0; j < ell; j++) { const bool bit = (x >> (ell - 1 - j)) & 1; const fr29 rs = fr29_unpack_s(Rh.r[j]); p = fr29_mul(bit ? rs : fr29_sub(one_s, rs), p); } hi[x] = fr29_store(p); }
+}
+// the same two tables from a point the gate left in device memory (k_gate_point): r_j = gp[8 j ..), scale = entry hi_bits + lo_bits
+__global__ void k_eq_small2_mem(const uint32_t* __restrict__ gp, uint32_t seq, uint32_t hi_bits, fr_t* __restrict__ hi, uint32_t hi_blocks, uint32_t lo_bits, fr_t* __restrict__ lo) {
+  if (!gate_point_ok(gp, seq)) return;
+  const bool is_lo = blockIdx.x >= hi_blocks;
+  const uint32_t ell = is_lo ? lo_bits : hi_bits, j0 = is_lo ? hi_bits : 0u;
+  const size_t x = (blockIdx.x - (is_lo ? hi_blocks : 0u)) * (size_t)blockDim.x + threadIdx.x;
+  if (x >= ((size_t)1 << ell)) return;
+  fr29 p = is_lo ? fr29_unpack_u(fr_one()) : fr29_unpack_u(gate_point_fr(gp, hi_bits + lo_bits));
+  const fr29 one_s = fr29_one_s();
+  for (uint32_t j = 0; j < ell; j++) { const bool bit = (x >> (ell - 1 - j)) & 1; const fr29 rs = fr29_unpack_s(gate_point_fr(gp, j0 + j)); p = fr29_mul(bit ? rs : fr29_sub(one_s, rs), p); }
+  (is_lo ? lo : hi)[x] = fr29_store(p);
 }
 // out[x] = hi[x >> lo_bits] * lo[x & mask]
 __global__ void __launch_bounds__(LASSO_BLOCK) k_eq_outer(const fr_t* __restrict__ hi, const fr_t* __restrict__ lo, uint32_t lo_bits, size_t n, fr_t* __restrict__ out) {

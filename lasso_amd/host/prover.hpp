@@ -13,6 +13,7 @@
 // There is no CPU fallback: a failing device call throws (the reference panics).
 #pragma once
 #include <array>
+#include <functional>
 #include <map>
 #include <memory>
 #include <string>
@@ -714,6 +715,33 @@ class Prover {
   // A grand-product layer's eq table, not built yet: cubic_rounds builds it INSIDE the first round's launch when the sizes allow (lasso_sumcheck_cubic_eqw2_begin_eq /
   // lasso_sumcheck_cubic_tail_begin_eq) and with lasso_eq_evals_scaled otherwise.  Set by bgpa_prove for the layer's first phase, consumed by cubic_rounds.
   struct LazyEq { bool on = false; std::vector<lasso_fr> rr; lasso_fr scale; lasso_fr* d_table = nullptr; } lazy_eq;
+  // The NEXT layer's first launch enqueued while the current layer's resident tail is still answering (include/lasso_hip.h lasso_sumcheck_cubic_*_begin_eq_ahead): bgpa_prove
+  // sets next_layer_hook before a layer's sumcheck, cubic_rounds calls it once its own last launch (the tail) is in the stream, and the next layer's cubic_rounds posts the eq
+  // point (lasso_point_post) instead of launching — or cancels when the layer turns out to have another shape (a zero coordinate: probability 2^-252, scripted tests).
+  struct LayerAhead { bool on = false, tail = false; std::vector<lasso_fr*> A, B; lasso_fr* d_table = nullptr; size_t len = 0, m_stop = 1; uint32_t ell = 0; } layer_ahead;
+  std::function<void()> next_layer_hook;
+  static bool tail_switched_off() { static const bool off = [] { const char* v = getenv("LASSO_CUBIC_TAIL"); return v && v[0] == '0'; }(); return off; }
+  bool layer_ahead_ok() { return P == 1 && !d.no_ahead() && !eq_inline_off() && !tail_switched_off() && lasso_layer_ahead_ok(d.ctx) == 1; }
+  // what cubic_rounds would launch first for a whole plain layer of k circuits and `len` elements per circuit, enqueued now (mirrors its choices: tail_from, m_stop, the table sizes)
+  void enqueue_layer_ahead(const std::vector<lasso_fr*>& A, const std::vector<lasso_fr*>& B, size_t len, lasso_fr* d_table) {
+    layer_ahead.on = false;
+    if (!layer_ahead_ok() || len < 4) return;
+    const size_t k = A.size(); const uint32_t ell = (uint32_t)ceil_log2(len / 2);
+    LayerAhead la; la.A = A; la.B = B; la.d_table = d_table; la.len = len; la.ell = ell;
+    int32_t rc;
+    if (len / 2 <= tail_q()) {   // the whole layer in the resident kernel (tail_from = 0)
+      if (ell > 9) return;
+      const size_t m0 = host_m_stop(k); la.m_stop = (m0 >= 2 && m0 < len) ? m0 : 1; la.tail = true;
+      if (la.m_stop > 1) d.chk(lasso_tail_handover_next(d.ctx, (uint32_t)la.m_stop), "lasso_tail_handover_next");
+      rc = lasso_sumcheck_cubic_tail_begin_eq_ahead(d.ctx, la.A.data(), la.B.data(), (uint32_t)k, len, ell);
+    } else {
+      if (!(ell <= 14 || (!eq_inline_big_off() && ell <= 32)) || len / 2 <= 64) return;
+      rc = lasso_sumcheck_cubic_eqw2_begin_eq_ahead(d.ctx, la.A.data(), la.B.data(), (uint32_t)k, d_table, len, ell);
+    }
+    if (rc == LASSO_ERR_UNSUPPORTED) return;   // a buffer would have had to grow: the layer starts the plain way
+    d.chk(rc, "lasso_sumcheck_cubic_*_begin_eq_ahead");
+    la.on = true; layer_ahead = std::move(la);
+  }
   static bool eq_inline_off() { static const bool v = [] { const char* e = getenv("LASSO_EQ_INLINE"); return e && e[0] == '0'; }(); return v; }
   static bool side_off() { static const bool v = [] { const char* e = getenv("LASSO_SIDE_STREAM"); return e && e[0] == '0'; }(); return v; }
 
@@ -1070,7 +1098,9 @@ class Prover {
                     Sc& e, SumcheckProof& proof, ScVec& r_out, std::vector<lasso_fr>* heads_out = nullptr, const LeafLayer* leaf = nullptr) {
     const size_t k = leaf ? 2 * leaf->mems.size() : A.size();
     if (heads_out) heads_out->clear();
-    if (!rounds) return;
+    LayerAhead pre = std::move(layer_ahead); layer_ahead.on = false;                 // this layer's first launch, enqueued during the previous layer (or not)
+    std::function<void()> hook = std::move(next_layer_hook); next_layer_hook = nullptr;   // the next layer's, to be enqueued once this layer's last launch is in the stream
+    if (!rounds) { if (pre.on) d.chk(lasso_point_cancel(d.ctx), "lasso_point_cancel"); return; }
     // 1 / prod_{t<=j}(1 - rand[v0+t]) for every round of the phase with one inversion; a zero factor (rand_t = 1) takes the explicit-table path
     ScVec inv(rounds); bool degenerate = false;
     {
@@ -1105,6 +1135,15 @@ class Prover {
     }
     // Rounds LAUNCHED AHEAD of their challenge (include/lasso_hip.h lasso_sumcheck_cubic_eqw2_begin_ahead): while round j runs, round j + 1 — a streaming round, or the resident
     // tail — is already in the stream and waits on the device for the challenge this loop posts.  One GPU, plain rounds only (no collective between rounds, no per-round table).
+    // the launch enqueued during the previous layer is this layer's first launch only if the layer has the shape that was assumed then
+    bool use_pre = false;
+    if (pre.on) {
+      static const bool three = [] { const char* v = getenv("LASSO_CUBIC_THREE_SUMS"); return v && v[0] == '1'; }();
+      use_pre = lz.on && !degenerate && !leaf && v0 == 0 && heads_out && !reduce && pre.len == len && pre.A == A && pre.B == B && pre.d_table == lz.d_table && pre.ell == lz.rr.size() &&
+                (pre.tail ? (tail_from == 0 && m_stop == pre.m_stop) : (tail_from > 0 && !three && !rand[0].is_zero() && !s_run.is_zero()));
+      if (!use_pre && getenv("LASSO_DEBUG_LAYER_AHEAD")) fprintf(stderr, "[layer ahead] cancelled: lz %d degen %d leaf %d v0 %zu heads %d reduce %d len %zu/%zu A %d B %d tab %d ell %u/%zu tail %d tail_from %zu m_stop %zu/%zu\n", (int)lz.on, (int)degenerate, leaf != nullptr, v0, heads_out != nullptr, (int)reduce, pre.len, len, pre.A == A, pre.B == B, pre.d_table == lz.d_table, pre.ell, lz.rr.size(), (int)pre.tail, tail_from, pre.m_stop, m_stop);
+      if (!use_pre) d.chk(lasso_point_cancel(d.ctx), "lasso_point_cancel");
+    }
     static const bool ahead_env_off = [] { const char* v = getenv("LASSO_ROUNDS_AHEAD"); return v && v[0] == '0'; }();
     const bool ahead_ok = !ahead_env_off && !reduce && !degenerate && P == 1 && !d.no_ahead() && heads_out && lasso_rounds_ahead_ok(d.ctx) == 1;
     bool queued = false, queued_tail = false;   // this round's kernel is already enqueued (a streaming round / the resident tail) and waits for r_prev
@@ -1138,6 +1177,10 @@ class Prover {
         } else if (queued_tail) {
           d.chk(lasso_sumcheck_cubic_tail_next(d.ctx, &rp), "lasso_sumcheck_cubic_tail_next"); queued_tail = false; in_tail = true;
         } else
+        if (j == 0 && use_pre) {   // enqueued during the previous layer, waiting on the device for this point
+          d.chk(lasso_point_post(d.ctx, lz.rr.data(), ell, &lz.scale), "lasso_point_post"); lz.on = false;
+          if (pre.tail) { in_tail = true; if (hook) { hook(); hook = nullptr; } }
+        } else
         if (leaf && j < 2) {   // capacity mode: this round's A and B are recomputed chunk by chunk; after round 1 the bound arrays are the working arrays
           ensure_table();
           leaf_round(*leaf, j, len, table, j ? &rp : nullptr, ev); have_ev = true;
@@ -1148,12 +1191,14 @@ class Prover {
         } else if (j == 0 && lz.on && j >= tail_from && ell <= 9) {            // the whole layer runs in the resident kernel: no table at all
           if (m_stop > 1) d.chk(lasso_tail_handover_next(d.ctx, (uint32_t)m_stop), "lasso_tail_handover_next");
           d.chk(lasso_sumcheck_cubic_tail_begin_eq(d.ctx, A.data(), B.data(), (uint32_t)k, len, lz.rr.data(), ell, &lz.scale), "lasso_sumcheck_cubic_tail_begin_eq"); in_tail = true; lz.on = false;
+          if (hook) { hook(); hook = nullptr; }   // this layer's last launch is in the stream: the next layer's first goes in behind it
         } else {
           ensure_table();
           if (j < tail_from) d.chk(lasso_sumcheck_cubic_eqw2_begin(d.ctx, A.data(), B.data(), (uint32_t)k, table, len, j == 0 ? nullptr : &rp), "lasso_sumcheck_cubic_eqw2_begin");
           else if (!in_tail) {
             if (m_stop > 1) d.chk(lasso_tail_handover_next(d.ctx, (uint32_t)m_stop), "lasso_tail_handover_next");
             d.chk(lasso_sumcheck_cubic_tail_begin(d.ctx, A.data(), B.data(), (uint32_t)k, table, len, j == 0 ? nullptr : &rp), "lasso_sumcheck_cubic_tail_begin"); in_tail = true;
+            if (hook) { hook(); hook = nullptr; }
           }
           else d.chk(lasso_sumcheck_cubic_tail_next(d.ctx, &rp), "lasso_sumcheck_cubic_tail_next");
         }
@@ -1166,6 +1211,7 @@ class Prover {
           } else if (j + 1 == tail_from) {
             if (m_stop > 1) d.chk(lasso_tail_handover_next(d.ctx, (uint32_t)m_stop), "lasso_tail_handover_next");
             d.chk(lasso_sumcheck_cubic_tail_begin_ahead(d.ctx, A.data(), B.data(), (uint32_t)k, table, len), "lasso_sumcheck_cubic_tail_begin_ahead"); queued_tail = true;
+            if (hook) { hook(); hook = nullptr; }
           }
         }
         // f(1) = 0 inside the tail can only come from a vanished running factor s (probability 2^-252): then f = 0 identically and q is irrelevant
@@ -1263,6 +1309,12 @@ class Prover {
   // host_tops (one GPU, optional): the top of every tree on the host — tree c's layers of at most host_tops->len elements, back to back as they lie in the arena (the layer of
   // `len` elements first, the two-element layer last): those layers are proved without the device (host_cubic_rounds)
   struct HostTops { size_t len = 0; std::vector<ScVec> run; };   // run[c]: 2 * len - 2 elements
+  // layer `layer_id` of whole trees on one GPU (P == 1, no capacity mode): the arrays bgpa_prove will pass to its sumcheck, enqueued ahead
+  void enqueue_next_layer(const std::vector<lasso_fr*>& trees, size_t n, size_t layer_id, lasso_fr* d_table) {
+    const size_t len = n >> layer_id, off = 2 * n - 2 * len;
+    std::vector<lasso_fr*> A, B; for (auto* tr : trees) { A.push_back(tr + off); B.push_back(tr + off + len / 2); }
+    enqueue_layer_ahead(A, B, len / 2, d_table);   // A = the layer's first half, B its second: arrays of len / 2
+  }
   BatchedGrandProductArgument bgpa_prove(std::vector<lasso_fr*>& trees, std::vector<lasso_fr*>& tops, size_t n, const ScVec& roots, ScVec& rand_out, LeafLayer* leaf = nullptr, const HostTops* host_tops = nullptr) {
     Trace tr("BatchedGrandProductArgument.prove", d.ctx);
     BatchedGrandProductArgument out; const size_t k = trees.size(), num_layers = ceil_log2(n), n_loc = n / P;
@@ -1277,6 +1329,7 @@ class Prover {
         const size_t off = 2 * host_tops->len - 2 * len;    // within the run, as in the arena: the layer of `len` elements starts 2 * len elements before the end (+ 2)
         std::vector<ScVec> ha(k), hb(k);
         for (size_t c = 0; c < k; c++) { const ScVec& r = host_tops->run[c]; ha[c].assign(r.begin() + off, r.begin() + off + len / 2); hb[c].assign(r.begin() + off + len / 2, r.begin() + off + len); }
+        if (layer_id > 0 && 2 * len > host_tops->len && !leaf) enqueue_next_layer(trees, n, layer_id - 1, eq.p);   // the first layer the device proves: its first launch waits for its point from here on
         ScVec coeff_vec = t.challenge_vector("rand_coeffs_next_layer", claims_to_verify.size());
         Sc claim = Sc::zero(); for (size_t i = 0; i < claims_to_verify.size(); i++) claim += claims_to_verify[i] * coeff_vec[i];
         LayerProofBatched lp; ScVec rand_prod; std::vector<lasso_fr> heads;
@@ -1311,7 +1364,10 @@ class Prover {
       ScVec coeff_vec = t.challenge_vector("rand_coeffs_next_layer", claims_to_verify.size());
       Sc claim = Sc::zero(); for (size_t i = 0; i < claims_to_verify.size(); i++) claim += claims_to_verify[i] * coeff_vec[i];
       LayerProofBatched lp; ScVec rand_prod;
+      next_layer_hook = nullptr;
+      if (P == 1 && !leaf && layer_id > 0) next_layer_hook = [this, &trees, n, layer_id, &eq] { enqueue_next_layer(trees, n, layer_id - 1, eq.p); };
       lp.proof = prove_cubic_batched(claim, num_rounds_prod, slab, A, B, eq.p, rand, coeff_vec, rand_prod, lp.claims_prod_left, lp.claims_prod_right, bottom_leafless ? leaf : nullptr);
+      next_layer_hook = nullptr;
       for (size_t i = 0; i < k; i++) { t.append_scalar("claim_prod_left", lp.claims_prod_left[i]); t.append_scalar("claim_prod_right", lp.claims_prod_right[i]); }
       Sc r_layer = t.challenge_scalar("challenge_r_layer");
       claims_to_verify.clear();

@@ -23,7 +23,9 @@ struct lasso_ctx {
   size_t tail_stop = 1;       // lasso_tail_handover_next: the tail in progress hands its arrays over at this length; handover_next: the value for the next begin
   uint32_t handover_next = 0;
   // sumcheck rounds / the resident tail launched ahead of their challenge: the arguments wait here for lasso_challenge_post / the first lasso_sumcheck_cubic_tail_next
-  struct RoundAhead { bool on = false, tail = false, linear = false; std::vector<lasso_fr*> A, B; const lasso_fr* E; size_t n; } rahead;
+  // a layer enqueued ahead of its eq point (lasso_sumcheck_cubic_*_begin_eq_ahead): parked until lasso_point_post runs the plain entry point / lasso_point_cancel drops it
+  struct LayerAhead { bool on = false, tail = false; std::vector<lasso_fr*> A, B; lasso_fr* E_out = nullptr; size_t n = 0; uint32_t ell = 0, m_stop = 0; } lahead;
+  struct RoundAhead { bool on = false, tail = false, linear = false; std::vector<lasso_fr*> A, B; const lasso_fr* E; size_t n; uint32_t m_stop = 0; } rahead;
   // a bullet round launched ahead of its challenge: the arguments wait here for lasso_bullet_post
   std::mutex mem_mu; std::map<void*, size_t> mem_sizes; uint64_t mem_live = 0, mem_peak = 0, alloc_calls = 0;   // lasso_mem_stats of the mock
   struct Ahead { bool on = false; const lasso_bases* bs; size_t n, nk; const lasso_fr *a_in, *b_in, *w_in; lasso_fr *a_out, *b_out, *w_out; lasso_fr blinds[2]; } ahead;
@@ -90,7 +92,7 @@ int32_t lasso_rccl_allgather(lasso_ctx*, const void*, void*, size_t) { return LA
 size_t lasso_point_row_bytes(void) { return 144; }
 int32_t lasso_hyrax_commit_rows_dev(lasso_ctx*, const lasso_fr*, size_t, size_t, const lasso_bases*, void*) { return LASSO_ERR_UNSUPPORTED; }
 int32_t lasso_points_reduce_compress(lasso_ctx*, const void*, uint32_t, size_t, uint8_t*) { return LASSO_ERR_UNSUPPORTED; }
-int32_t lasso_abort(lasso_ctx* c) { REQ(c, c); c->pending.clear(); c->defer = false; c->ahead.on = false; c->rahead.on = false; c->handover_next = 0; c->tail_stop = 1; c->tail_a.clear(); c->tail_b.clear(); c->tail_e.clear(); return 0; }
+int32_t lasso_abort(lasso_ctx* c) { REQ(c, c); c->pending.clear(); c->defer = false; c->ahead.on = false; c->rahead.on = false; c->lahead.on = false; c->handover_next = 0; c->tail_stop = 1; c->tail_a.clear(); c->tail_b.clear(); c->tail_e.clear(); return 0; }
 int32_t lasso_prof_get_large(lasso_ctx*, int32_t, uint64_t* n, double* ms, double* b) { if (n) *n = 0; if (ms) *ms = 0; if (b) *b = 0; return 0; }
 int32_t lasso_wait_stats(lasso_ctx*, uint64_t* w, double* us, int32_t) { if (w) *w = 0; if (us) *us = 0; return 0; }
 int32_t lasso_prof_get_units(lasso_ctx*, int32_t, int32_t, double* u) { if (u) *u = 0; return 0; }
@@ -262,7 +264,29 @@ int32_t lasso_sumcheck_cubic_tail_begin_eq(lasso_ctx* c, lasso_fr* const* A, las
   int32_t rc = lasso_eq_evals_scaled(c, point, ell, scale, E.data()); if (rc) return rc;
   return lasso_sumcheck_cubic_tail_begin(c, A, B, nc, E.data(), n, nullptr);
 }
-int32_t lasso_tail_handover_next(lasso_ctx* c, uint32_t m_stop) { REQ(c, c && c->tail_a.empty() && (m_stop & (m_stop - 1)) == 0 && m_stop <= 128); c->handover_next = m_stop <= 1 ? 0 : m_stop; return 0; }
+int32_t lasso_tail_handover_next(lasso_ctx* c, uint32_t m_stop) { REQ(c, c && (m_stop & (m_stop - 1)) == 0 && m_stop <= 128); c->handover_next = m_stop <= 1 ? 0 : m_stop; return 0; }
+int32_t lasso_layer_ahead_ok(lasso_ctx* c) { const char* v = getenv("LASSO_LAYER_AHEAD"); return c && !(v && v[0] == '0') ? 1 : 0; }
+int32_t lasso_sumcheck_cubic_eqw2_begin_eq_ahead(lasso_ctx* c, lasso_fr* const* A, lasso_fr* const* B, uint32_t nc, lasso_fr* E_out, size_t n, uint32_t ell) {
+  REQ(c, A && B && E_out && nc >= 1 && n >= 2 && (n & (n - 1)) == 0 && ell < 48 && ((size_t)1 << ell) == n / 2 && !c->lahead.on && !(c->rahead.on && !c->rahead.tail) && !c->ahead.on && !c->defer);
+  if (!lasso_layer_ahead_ok(c) || ell > 32 || n / 2 <= 64) { c->err = "unsupported table size"; return LASSO_ERR_UNSUPPORTED; }
+  c->lahead.on = true; c->lahead.tail = false; c->lahead.A.assign(A, A + nc); c->lahead.B.assign(B, B + nc); c->lahead.E_out = E_out; c->lahead.n = n; c->lahead.ell = ell; return 0;
+}
+int32_t lasso_sumcheck_cubic_tail_begin_eq_ahead(lasso_ctx* c, lasso_fr* const* A, lasso_fr* const* B, uint32_t nc, size_t n, uint32_t ell) {
+  const uint32_t m_stop = c ? c->handover_next : 0; if (c) c->handover_next = 0;
+  REQ(c, A && B && nc >= 1 && n >= 2 && ((size_t)1 << ell) == n / 2 && ell <= 9 && n > (m_stop ? m_stop : 1u) && !c->lahead.on && !(c->rahead.on && !c->rahead.tail) && !c->ahead.on && !c->defer);
+  if (!lasso_layer_ahead_ok(c)) { c->err = "switched off"; return LASSO_ERR_UNSUPPORTED; }
+  c->lahead.on = true; c->lahead.tail = true; c->lahead.A.assign(A, A + nc); c->lahead.B.assign(B, B + nc); c->lahead.n = n; c->lahead.ell = ell; c->lahead.m_stop = m_stop; return 0;
+}
+int32_t lasso_point_post(lasso_ctx* c, const lasso_fr* point, uint32_t ell, const lasso_fr* scale) {
+  REQ(c, c && c->lahead.on && ell == c->lahead.ell && (point || !ell) && c->pending.empty() && c->tail_a.empty() && !c->rahead.on);
+  c->lahead.on = false;
+  if (c->lahead.tail) {
+    c->handover_next = c->lahead.m_stop;
+    return lasso_sumcheck_cubic_tail_begin_eq(c, c->lahead.A.data(), c->lahead.B.data(), (uint32_t)c->lahead.A.size(), c->lahead.n, point, ell, scale);
+  }
+  return lasso_sumcheck_cubic_eqw2_begin_eq(c, c->lahead.A.data(), c->lahead.B.data(), (uint32_t)c->lahead.A.size(), c->lahead.E_out, c->lahead.n, point, ell, scale);
+}
+int32_t lasso_point_cancel(lasso_ctx* c) { REQ(c, c && c->lahead.on); c->lahead.on = false; return 0; }
 int32_t lasso_sumcheck_cubic_tail_begin(lasso_ctx* c, lasso_fr* const* A, lasso_fr* const* B, uint32_t nc, const lasso_fr* E, size_t n, const lasso_fr* r) {
   const size_t m_stop = c->handover_next ? c->handover_next : 1; c->handover_next = 0;
   REQ(c, n >= (r ? 4u : 2u) && (n & (n - 1)) == 0 && c->tail_a.empty() && c->pending.empty() && !c->rahead.on);
@@ -311,12 +335,15 @@ int32_t lasso_challenge_post(lasso_ctx* c, const lasso_fr* r) {
 int32_t lasso_sumcheck_cubic_tail_begin_ahead(lasso_ctx* c, lasso_fr* const* A, lasso_fr* const* B, uint32_t nc, const lasso_fr* E, size_t n) {
   REQ(c, A && B && E && nc >= 1 && n >= 4 && (n & (n - 1)) == 0 && n / 4 <= 512 && !c->rahead.on && !c->ahead.on && c->tail_a.empty() && !c->defer);
   REQ(c, n / 2 > (c->handover_next ? c->handover_next : 1u));
-  c->rahead.on = true; c->rahead.tail = true; c->rahead.A.assign(A, A + nc); c->rahead.B.assign(B, B + nc); c->rahead.E = E; c->rahead.n = n; return 0;
+  c->rahead.on = true; c->rahead.tail = true; c->rahead.A.assign(A, A + nc); c->rahead.B.assign(B, B + nc); c->rahead.E = E; c->rahead.n = n;
+  c->rahead.m_stop = c->handover_next; c->handover_next = 0;   // consumed by THIS begin, as on the device (another begin may be enqueued before this tail starts)
+  return 0;
 }
 int32_t lasso_sumcheck_cubic_tail_next(lasso_ctx* c, const lasso_fr* r) {
   if (c && c->rahead.on && c->rahead.tail) {   // the first challenge of a tail launched ahead
     REQ(c, r && c->pending.empty());
     c->rahead.on = false;
+    { const uint32_t later = c->handover_next; c->handover_next = c->rahead.m_stop; const int32_t rc = lasso_sumcheck_cubic_tail_begin(c, c->rahead.A.data(), c->rahead.B.data(), (uint32_t)c->rahead.A.size(), c->rahead.E, c->rahead.n, r); c->handover_next = later; return rc; }
     return lasso_sumcheck_cubic_tail_begin(c, c->rahead.A.data(), c->rahead.B.data(), (uint32_t)c->rahead.A.size(), c->rahead.E, c->rahead.n, r);
   }
   REQ(c, r && !c->tail_a.empty() && c->pending.empty());

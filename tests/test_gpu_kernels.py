@@ -1392,3 +1392,78 @@ def test_cubic_tail_launched_ahead(devs, n, ncirc, m_stop):
             assert len(got) == len(ref)
             for x, y in zip(got, ref):
                 assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("n2,ncirc2,m_stop2,mode", [(1 << 12, 2, 1, "post"), (1 << 15, 3, 1, "post"), (1 << 17, 2, 1, "post"), (1 << 18, 9, 1, "post"), (512, 2, 4, "post"), (1024, 2, 1, "post"),
+                                                    (64, 9, 2, "post"), (1 << 13, 2, 1, "cancel"), (1 << 17, 2, 1, "cancel"), (512, 2, 8, "cancel")])
+def test_layer_enqueued_ahead_of_its_point(devs, n2, ncirc2, m_stop2, mode):
+    """lasso_sumcheck_cubic_eqw2_begin_eq_ahead / lasso_sumcheck_cubic_tail_begin_eq_ahead + lasso_point_post: the NEXT layer's first launch enqueued while the current layer's
+    resident tail is still answering, its eq point delivered afterwards == the plain entry points called after the layer (sums, the table left behind, every turn of a resident
+    layer, the handed-over arrays); lasso_point_cancel: nothing happens and the plain call that follows gives the same."""
+    rng = np.random.default_rng(n2 + ncirc2 * 3 + m_stop2)
+    n1, k1 = 256, 2                                                        # the current layer: a resident tail over arrays of 256, handing over at 4
+    A1 = [rand_fr(rng, n1) for _ in range(k1)]; B1 = [rand_fr(rng, n1) for _ in range(k1)]
+    ell1 = (n1 // 2).bit_length() - 1; pt1 = rand_fr(rng, ell1, edge=False); sc1 = rand_fr(rng, 1, edge=False)[0]; ms1 = 4
+    turns1 = ell1 + 1 - (ms1.bit_length() - 1); chal1 = rand_fr(rng, turns1, edge=False)
+    A2 = [rand_fr(rng, n2) for _ in range(ncirc2)]; B2 = [rand_fr(rng, n2) for _ in range(ncirc2)]
+    ell2 = (n2 // 2).bit_length() - 1; pt2 = rand_fr(rng, max(ell2, 1), edge=False)[:ell2]; sc2 = rand_fr(rng, 1, edge=False)[0]
+    tail2 = ell2 <= 9
+    turns2 = ell2 + 1 - (m_stop2.bit_length() - 1); chal2 = rand_fr(rng, max(turns2, 1), edge=False)
+    vp = lambda x: np.ascontiguousarray(x, dtype=np.uint64).ctypes.data_as(C.c_void_p)
+
+    def layer2_rest(d, outs):          # after the first sums of layer 2 are pending
+        out = np.empty((2 * ncirc2, 4), dtype=np.uint64); d._chk(d.lib.lasso_result_wait(d.ctx, vp(out), 2 * ncirc2)); outs.append(out)
+        if tail2:
+            for t in range(turns2):
+                d._chk(d.lib.lasso_sumcheck_cubic_tail_next(d.ctx, vp(chal2[t])))
+                cnt = 2 * ncirc2 * (m_stop2 if t == turns2 - 1 else 1)
+                out = np.empty((cnt, 4), dtype=np.uint64); d._chk(d.lib.lasso_result_wait(d.ctx, vp(out), cnt)); outs.append(out)
+
+    def run(d, ahead):
+        pa1 = [d.upload(x) for x in A1]; pb1 = [d.upload(x) for x in B1]
+        pa2 = [d.upload(x) for x in A2]; pb2 = [d.upload(x) for x in B2]
+        e2 = d.alloc(32 * max(n2 // 2, 1))
+        outs = []
+        d._chk(d.lib.lasso_tail_handover_next(d.ctx, ms1))
+        d._chk(d.lib.lasso_sumcheck_cubic_tail_begin_eq(d.ctx, d._ptrs(pa1), d._ptrs(pb1), k1, n1, vp(pt1), ell1, vp(sc1)))
+        for t in range(turns1 + 1):
+            if ahead and t == 1:       # in the middle of the current layer: a tail is active and a result is pending
+                if tail2:
+                    if m_stop2 > 1:
+                        d._chk(d.lib.lasso_tail_handover_next(d.ctx, m_stop2))
+                    d._chk(d.lib.lasso_sumcheck_cubic_tail_begin_eq_ahead(d.ctx, d._ptrs(pa2), d._ptrs(pb2), ncirc2, n2, ell2))
+                else:
+                    d._chk(d.lib.lasso_sumcheck_cubic_eqw2_begin_eq_ahead(d.ctx, d._ptrs(pa2), d._ptrs(pb2), ncirc2, C.c_void_p(e2), n2, ell2))
+                if d is devs[0] and not getattr(d, "_dry_run_mock", False):       # the real library: nothing that synchronises the stream is legal now
+                    assert d.lib.lasso_sync(d.ctx) != 0
+            cnt = 2 * k1 * (ms1 if t == turns1 else 1)
+            out = np.empty((cnt, 4), dtype=np.uint64); d._chk(d.lib.lasso_result_wait(d.ctx, vp(out), cnt)); outs.append(out)
+            if t < turns1:
+                d._chk(d.lib.lasso_sumcheck_cubic_tail_next(d.ctx, vp(chal1[t])))
+        if ahead and mode == "post":
+            d._chk(d.lib.lasso_point_post(d.ctx, vp(pt2) if ell2 else None, ell2, vp(sc2)))
+        else:
+            if ahead:
+                d._chk(d.lib.lasso_point_cancel(d.ctx))
+                assert d.lib.lasso_sync(d.ctx) == 0
+            if tail2:
+                if m_stop2 > 1:
+                    d._chk(d.lib.lasso_tail_handover_next(d.ctx, m_stop2))
+                d._chk(d.lib.lasso_sumcheck_cubic_tail_begin_eq(d.ctx, d._ptrs(pa2), d._ptrs(pb2), ncirc2, n2, vp(pt2) if ell2 else None, ell2, vp(sc2)))
+            else:
+                d._chk(d.lib.lasso_sumcheck_cubic_eqw2_begin_eq(d.ctx, d._ptrs(pa2), d._ptrs(pb2), ncirc2, C.c_void_p(e2), n2, vp(pt2), ell2, vp(sc2)))
+        layer2_rest(d, outs)
+        if not tail2:
+            outs.append(d.download(e2, (n2 // 2, 4)))
+        for p in pa1 + pb1 + pa2 + pb2 + [e2]:
+            d.free(p)
+        return outs
+    ref = run(devs[1], False)
+    for d in devs:
+        got = run(d, True)
+        assert len(got) == len(ref)
+        for x, y in zip(got, ref):
+            assert np.array_equal(x, y)
+    got = run(devs[0], False)
+    for x, y in zip(got, ref):
+        assert np.array_equal(x, y)

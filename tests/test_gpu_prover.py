@@ -152,6 +152,10 @@ print("DIGEST", hashlib.sha256(comm + proof).hexdigest())
                                  {"LASSO_HOST_TAIL": "128"},                 # ... and takes over four times earlier than the default (arrays of 32 elements at two circuits... here of 32 / 16)
                                  {"LASSO_HOST_TAIL": "8", "LASSO_TAGGED_RESULTS": "0"},      # hand-over through the flag protocol
                                  {"LASSO_ROUNDS_AHEAD": "1", "LASSO_CUBIC_TAIL": "0"},      # every round of a layer launched ahead (no resident tail to end in)
+                                 {"LASSO_LAYER_AHEAD": "0"},                 # round 5: no layer's first launch is enqueued during the previous layer
+                                 {"LASSO_LAYER_AHEAD": "0", "LASSO_EQ_INLINE_BIG": "0"},      # ... and the tables above 2^14 entries by their own kernels
+                                 {"LASSO_HOST_TAIL": "0", "LASSO_LAYER_AHEAD": "1"},          # layers enqueued ahead behind tails that run to the heads
+                                 {"LASSO_ROUNDS_AHEAD": "0", "LASSO_LAYER_AHEAD": "1", "LASSO_TAGGED_RESULTS": "0"},
                                  {"LASSO_CAPACITY": "1", "LASSO_LEAFLESS_MIN": "1024", "LASSO_HOST_TAIL": "0"}])
 def test_gpu_ab_switches_do_not_change_the_bytes(host, env):
     """The A/B switches the measurements in DESIGN.md rest on (flag protocol instead of tagged results, in-launch second stage, launch per round instead of the resident tails, ...)
