@@ -19,6 +19,7 @@
 #include <string>
 #include <vector>
 #include "field_host.hpp"
+#include "field52.hpp"
 #include "hashes.hpp"
 #include "../../include/lasso_prover.h"
 
@@ -1033,7 +1034,16 @@ class Prover {
   // budget = elements per array x circuits the host takes over (LASSO_HOST_TAIL, default 32; 0 switches the host rounds off: A/B measurements, byte-identical)
   // A/B switch: eq tables above 2^14 entries built by their own kernels (k_eq_small2 + k_eq_outer) in front of round 0, as before round 5, instead of inside round 0
   static bool eq_inline_big_off() { static const bool off = [] { const char* v = getenv("LASSO_EQ_INLINE_BIG"); return v && v[0] == '0'; }(); return off; }
-  static size_t host_tail_budget() { static const size_t v = [] { const char* e = getenv("LASSO_HOST_TAIL"); const long x = e ? atol(e) : 32; return (size_t)(x < 0 ? 0 : x > 1024 ? 1024 : x); }(); return v; }
+  // default: 32 with the scalar loop; 128 where the rounds run eight elements at a time (field52.hpp, AVX-512 IFMA: a layer of 2 x 2 x 32 elements costs the host less than the two
+  // device turns it replaces — profiles/r05_ab_host_ifma.txt)
+  static bool host_ifma() {
+#ifdef LASSO_HOST_IFMA
+    return field52_ok();
+#else
+    return false;
+#endif
+  }
+  static size_t host_tail_budget() { static const size_t v = [] { const char* e = getenv("LASSO_HOST_TAIL"); const long x = e ? atol(e) : (host_ifma() ? 128 : 32); return (size_t)(x < 0 ? 0 : x > 1024 ? 1024 : x); }(); return v; }
   size_t host_m_stop(size_t k) const {   // elements per array at which the host takes a layer over: a power of two, 1 = never
     if (P != 1 || !host_tail_budget() || !k) return 1;
     size_t m0 = 1; while (2 * m0 * k <= host_tail_budget() && 2 * m0 <= 64) m0 *= 2;
@@ -1046,16 +1056,38 @@ class Prover {
     const size_t k = a.size(); size_t m = (size_t)1 << rounds_left;
     LASSO_REQUIRE(k == b.size() && first + rounds_left <= rand.size());
     for (size_t c = 0; c < k; c++) LASSO_REQUIRE(a[c].size() == m && b[c].size() == m);
-    // plain 4 x u64 values for the inner loops (field_host.hpp H4).  Per circuit: A, B and A' = coeffs_c * A — the batching coefficient rides on A' (sumcheck.rs:95-97 applies it to
-    // the circuit's sums: the same by linearity), so a term is ONE product per evaluation point; A itself is bound alongside because its final value is a claim (:126-133)
-    std::vector<H4> A(k * m), B(k * m), Aw(k * m), C(m);
-    for (size_t c = 0; c < k; c++) { const H4 w = h4_from(coeffs[c].v); for (size_t i = 0; i < m; i++) { A[c * m + i] = h4_from(a[c][i].v); B[c * m + i] = h4_from(b[c][i].v); Aw[c * m + i] = h4_mul(A[c * m + i], w); } }
-    { ScVec Ce = eq_evals_host(rand.data() + first, rounds_left); const H4 sr = h4_from(s_run.v); for (size_t i = 0; i < m; i++) C[i] = h4_mul(h4_from(Ce[i].v), sr); }
     auto to_sc = [](const H4& x) { Sc r; r.v = h4_to(x); return r; };
+    // the eq weights of the remaining coordinates with the running factor folded in
+    std::vector<H4> C(m);
+    { ScVec Ce = eq_evals_host(rand.data() + first, rounds_left); const H4 sr = h4_from(s_run.v); for (size_t i = 0; i < m; i++) C[i] = h4_mul(h4_from(Ce[i].v), sr); }
+    // Two forms of the same loops: eight elements at a time in 52-bit limbs on AVX-512 IFMA (field52.hpp HostRounds52) where the CPU has it, plain 4 x u64 values (field_host.hpp H4)
+    // otherwise.  Per circuit: A, B and A' = coeffs_c * A — the batching coefficient rides on A' (sumcheck.rs:95-97 applies it to the circuit's sums: the same by linearity), so a
+    // term is ONE product per evaluation point; A itself is bound alongside because its final value is a claim (:126-133).  Both forms work on canonical values: same field
+    // elements, same bytes.
+#ifdef LASSO_HOST_IFMA
+    std::unique_ptr<HostRounds52> v52;
+    bool w_nonzero = true; for (size_t c = 0; c < k; c++) if (coeffs[c].is_zero()) w_nonzero = false;   // (the vector form recovers A_c's final value as A'_c / coeffs_c)
+    if (field52_ok() && HostRounds52::fits(k, m) && w_nonzero) {
+      std::vector<std::vector<H4>> ha(k, std::vector<H4>(m)), hb(k, std::vector<H4>(m)); std::vector<H4> w(k);
+      for (size_t c = 0; c < k; c++) { w[c] = h4_from(coeffs[c].v); for (size_t i = 0; i < m; i++) { ha[c][i] = h4_from(a[c][i].v); hb[c][i] = h4_from(b[c][i].v); } }
+      v52.reset(new HostRounds52(ha, hb, w, C));
+    }
+    const bool vec = v52 != nullptr;
+#else
+    const bool vec = false;
+#endif
+    std::vector<H4> A, B, Aw;
+    if (!vec) {
+      A.resize(k * m); B.resize(k * m); Aw.resize(k * m);
+      for (size_t c = 0; c < k; c++) { const H4 w = h4_from(coeffs[c].v); for (size_t i = 0; i < m; i++) { A[c * m + i] = h4_from(a[c][i].v); B[c * m + i] = h4_from(b[c][i].v); Aw[c * m + i] = h4_mul(A[c * m + i], w); } }
+    }
     size_t stride = m;   // arrays keep their stride; the live prefix halves
     for (size_t j = 0; j < rounds_left; j++) {
       const size_t h = m / 2;
       H4 e0 = h4_zero(), e2 = h4_zero(), e3 = h4_zero();
+#ifdef LASSO_HOST_IFMA
+      if (vec) v52->sums(h, e0, e2, e3); else
+#endif
       for (size_t i = 0; i < h; i++) {
         H4 t0 = h4_zero(), t2 = h4_zero(), t3 = h4_zero();   // sum_c coeffs_c A_c(x) B_c(x) at x = 0, 2, 3 (`prev + hi - lo`, :68-89)
         for (size_t c = 0; c < k; c++) {
@@ -1077,11 +1109,19 @@ class Prover {
       e = poly.evaluate(r_j);
       proof.compressed_polys.push_back(poly.compress());
       const H4 rj = h4_from(r_j.v);
-      for (size_t c = 0; c < k; c++) for (H4* arr : {&A[c * stride], &B[c * stride], &Aw[c * stride]}) for (size_t i = 0; i < h; i++) arr[i] = h4_add(arr[i], h4_mul(rj, h4_sub(arr[i + h], arr[i])));   // :116-120
-      for (size_t i = 0; i < h; i++) C[i] = h4_add(C[i], h4_mul(rj, h4_sub(C[i + h], C[i])));
+#ifdef LASSO_HOST_IFMA
+      if (vec) v52->bind(h, rj); else
+#endif
+      {
+        for (size_t c = 0; c < k; c++) for (H4* arr : {&A[c * stride], &B[c * stride], &Aw[c * stride]}) for (size_t i = 0; i < h; i++) arr[i] = h4_add(arr[i], h4_mul(rj, h4_sub(arr[i + h], arr[i])));   // :116-120
+        for (size_t i = 0; i < h; i++) C[i] = h4_add(C[i], h4_mul(rj, h4_sub(C[i + h], C[i])));
+      }
       m = h;
     }
     heads.resize(2 * k);
+#ifdef LASSO_HOST_IFMA
+    if (vec) { std::vector<H4> hh; v52->heads(hh); for (size_t c = 0; c < 2 * k; c++) heads[c] = to_sc(hh[c]).abi(); return; }
+#endif
     for (size_t c = 0; c < k; c++) { heads[c] = to_sc(A[c * stride]).abi(); heads[k + c] = to_sc(B[c * stride]).abi(); }
   }
   // ---- SumcheckInstanceProof::prove_cubic_batched (sumcheck.rs:27-135), comb = A*B*C with C = EqPolynomial(rand).evals() (grand_product.rs:122-128).
@@ -1098,6 +1138,7 @@ class Prover {
                     Sc& e, SumcheckProof& proof, ScVec& r_out, std::vector<lasso_fr>* heads_out = nullptr, const LeafLayer* leaf = nullptr) {
     const size_t k = leaf ? 2 * leaf->mems.size() : A.size();
     if (heads_out) heads_out->clear();
+    std::unique_ptr<HostClock> hpro(new HostClock("layer transition: sumcheck prologue"));
     LayerAhead pre = std::move(layer_ahead); layer_ahead.on = false;                 // this layer's first launch, enqueued during the previous layer (or not)
     std::function<void()> hook = std::move(next_layer_hook); next_layer_hook = nullptr;   // the next layer's, to be enqueued once this layer's last launch is in the stream
     if (!rounds) { if (pre.on) d.chk(lasso_point_cancel(d.ctx), "lasso_point_cancel"); return; }
@@ -1141,7 +1182,6 @@ class Prover {
       static const bool three = [] { const char* v = getenv("LASSO_CUBIC_THREE_SUMS"); return v && v[0] == '1'; }();
       use_pre = lz.on && !degenerate && !leaf && v0 == 0 && heads_out && !reduce && pre.len == len && pre.A == A && pre.B == B && pre.d_table == lz.d_table && pre.ell == lz.rr.size() &&
                 (pre.tail ? (tail_from == 0 && m_stop == pre.m_stop) : (tail_from > 0 && !three && !rand[0].is_zero() && !s_run.is_zero()));
-      if (!use_pre && getenv("LASSO_DEBUG_LAYER_AHEAD")) fprintf(stderr, "[layer ahead] cancelled: lz %d degen %d leaf %d v0 %zu heads %d reduce %d len %zu/%zu A %d B %d tab %d ell %u/%zu tail %d tail_from %zu m_stop %zu/%zu\n", (int)lz.on, (int)degenerate, leaf != nullptr, v0, heads_out != nullptr, (int)reduce, pre.len, len, pre.A == A, pre.B == B, pre.d_table == lz.d_table, pre.ell, lz.rr.size(), (int)pre.tail, tail_from, pre.m_stop, m_stop);
       if (!use_pre) d.chk(lasso_point_cancel(d.ctx), "lasso_point_cancel");
     }
     static const bool ahead_env_off = [] { const char* v = getenv("LASSO_ROUNDS_AHEAD"); return v && v[0] == '0'; }();
@@ -1153,6 +1193,7 @@ class Prover {
       const bool plain = v0 == 0 && !degenerate && !three && rounds >= 3 && tail_from >= 2 && !rand[0].is_zero() && !rand[1].is_zero() && !s_run.is_zero();
       if (!plain) { leaf_full = leaf_materialise(*leaf, A, B); leaf = nullptr; }
     }
+    hpro.reset();
     for (size_t j = 0; j < j_host; j++) {
       const lasso_fr* table = d_E; Sc scale = degenerate ? Sc::one() : inv[j];
       if (degenerate) {   // T_j = eq(rand[v0+j+1 .. v0+rounds)) built explicitly (size len / 2^(j+1) at this point), times the slab factor hidden in d_E[0] / eq-prefix
@@ -1178,7 +1219,7 @@ class Prover {
           d.chk(lasso_sumcheck_cubic_tail_next(d.ctx, &rp), "lasso_sumcheck_cubic_tail_next"); queued_tail = false; in_tail = true;
         } else
         if (j == 0 && use_pre) {   // enqueued during the previous layer, waiting on the device for this point
-          d.chk(lasso_point_post(d.ctx, lz.rr.data(), ell, &lz.scale), "lasso_point_post"); lz.on = false;
+          { HostClock hp("layer transition: point post"); d.chk(lasso_point_post(d.ctx, lz.rr.data(), ell, &lz.scale), "lasso_point_post"); } lz.on = false;
           if (pre.tail) { in_tail = true; if (hook) { hook(); hook = nullptr; } }
         } else
         if (leaf && j < 2) {   // capacity mode: this round's A and B are recomputed chunk by chunk; after round 1 the bound arrays are the working arrays
@@ -1344,6 +1385,7 @@ class Prover {
         continue;
       }
       const bool slab = P > 1 && len >= 2 * P;              // this layer lives in the local trees; smaller ones in the replicated tops
+      std::unique_ptr<HostClock> hco(new HostClock("layer transition: opening (arrays, coefficients, claim)"));
       std::vector<lasso_fr*> A, B;
       const bool bottom_leafless = leaf && layer_id == 0;
       if (bottom_leafless) {
@@ -1364,10 +1406,12 @@ class Prover {
       ScVec coeff_vec = t.challenge_vector("rand_coeffs_next_layer", claims_to_verify.size());
       Sc claim = Sc::zero(); for (size_t i = 0; i < claims_to_verify.size(); i++) claim += claims_to_verify[i] * coeff_vec[i];
       LayerProofBatched lp; ScVec rand_prod;
+      hco.reset();
       next_layer_hook = nullptr;
       if (P == 1 && !leaf && layer_id > 0) next_layer_hook = [this, &trees, n, layer_id, &eq] { enqueue_next_layer(trees, n, layer_id - 1, eq.p); };
       lp.proof = prove_cubic_batched(claim, num_rounds_prod, slab, A, B, eq.p, rand, coeff_vec, rand_prod, lp.claims_prod_left, lp.claims_prod_right, bottom_leafless ? leaf : nullptr);
       next_layer_hook = nullptr;
+      HostClock hcl("layer transition: closing claims + r_layer");
       for (size_t i = 0; i < k; i++) { t.append_scalar("claim_prod_left", lp.claims_prod_left[i]); t.append_scalar("claim_prod_right", lp.claims_prod_right[i]); }
       Sc r_layer = t.challenge_scalar("challenge_r_layer");
       claims_to_verify.clear();
