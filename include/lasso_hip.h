@@ -162,7 +162,7 @@ int32_t lasso_result_wait(lasso_ctx* ctx, lasso_fr* out, size_t count);
 /* The FIRST round of a layer (r == NULL above) with the layer's eq table built inside the same launch.  Every layer of BatchedGrandProductArgument::prove starts with
  * poly_C = EqPolynomial(rand).evals() (grand_product.rs:122) — here  E = *scale * EqPolynomial(point[0..ell)).evals(),  2^ell = n/2 entries, scale == NULL: 1 — and as kernels of
  * their own those tables are 40 launch-bound steps on the proof's critical path.  Afterwards d_E_out holds the table (byte-identical to lasso_eq_evals_scaled's) for the later
- * rounds of the layer and the pending result is lasso_sumcheck_cubic_eqw2_begin's.  Tables of 2^7 .. 2^32 entries (up to 2^14 the two factor tables are built in LDS by every workgroup; above, k_eq_small2 leaves them in the scratch and the round multiplies them per index: no k_eq_outer pass, round 5); LASSO_ERR_UNSUPPORTED otherwise (build the table, call the plain form). */
+ * rounds of the layer and the pending result is lasso_sumcheck_cubic_eqw2_begin's.  Tables of 2^7 .. 2^32 entries (up to 2^14 the two factor tables are built in LDS by every workgroup and the table is written on the way; above, the call enqueues what lasso_eq_evals_scaled enqueues — k_eq_small2, k_eq_outer — in front of the round, or with LASSO_EQ_INLINE_BIG=1 forms the entries inside the round from the factor tables: measured, not the default); LASSO_ERR_UNSUPPORTED otherwise (build the table, call the plain form). */
 int32_t lasso_sumcheck_cubic_eqw2_begin_eq(lasso_ctx* ctx, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, lasso_fr* d_E_out, size_t n, const lasso_fr* point, uint32_t ell,
                                            const lasso_fr* scale);
 /* Launch/wait split for any call whose result comes back through the mapped result buffer (sumcheck rounds, MSMs of up to 16 rows,

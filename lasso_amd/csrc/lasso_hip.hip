@@ -641,6 +641,7 @@ static int32_t cubic_eqw_launch_t(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* 
     } else {
       TP Ac, Bc; for (uint32_t i = 0; i < ncirc; i++) { Ac.p[i] = A.p[i]; Bc.p[i] = B.p[i]; }
       const unsigned ny = ncirc, nx = grid_for(half, cubic_nx_cap(ny));
+      static const bool big_inline = [] { const char* v = getenv("LASSO_EQ_INLINE_BIG"); return v && v[0] == '1'; }();   // A/B switch: tables above 2^14 entries formed inside round 0 (EqGlobal) instead of by k_eq_outer in front of it
       const bool gated = gate_ell >= 0, gbig = gated && gate_ell > 14;   // the point comes through the gate (the layer is enqueued ahead of it); above 2^14 entries with factor tables in memory
       const uint32_t g_ell = gbig ? (uint32_t)gate_ell : eqg ? eqg->ell : 0, g_lo = g_ell / 2, g_hi = g_ell - g_lo;
       const size_t part_elems = (size_t)nx * ny * 3;
@@ -650,16 +651,22 @@ static int32_t cubic_eqw_launch_t(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* 
       // what runs in front of the round is outside the round's profiling bracket: the wait for the point (one wave), the two factor tables (their own bracket)
       fr_t* const f_hi = (fr_t*)c->d_scratch + part_elems; fr_t* const f_lo = f_hi + ((size_t)1 << g_hi);
       if (gated && NT == 2) hipLaunchKernelGGL(k_gate_point, dim3(1), dim3(64), 0, c->stream, (const uint32_t*)c->pmail_d, c->d_gpoint, seq, (uint32_t)gate_ell + 2u);
+      const uint32_t* const gate_gp = gated ? (const uint32_t*)c->d_gpoint : (const uint32_t*)nullptr;
       if ((gbig || eqg) && NT == 2) {
-        ProfScope pe(c, LASSO_K_EQ, 32.0 * (((size_t)1 << g_hi) + ((size_t)1 << g_lo)));
+        ProfScope pe(c, LASSO_K_EQ, big_inline ? 32.0 * (((size_t)1 << g_hi) + ((size_t)1 << g_lo)) : 32.0 * half);
         const unsigned hb = grid_for((size_t)1 << g_hi), lb2 = grid_for((size_t)1 << g_lo);
         if (gbig) hipLaunchKernelGGL(k_eq_small2_mem, dim3(hb + lb2), dim3(LASSO_BLOCK), 0, c->stream, (const uint32_t*)c->d_gpoint, seq, g_hi, f_hi, hb, g_lo, f_lo);
         else {
           RTable16 Rh, Rl; for (uint32_t j = 0; j < 16; j++) { Rh.r[j] = j < g_hi ? to_fr(eqg->point + j) : fr_zero(); Rl.r[j] = j < g_lo ? to_fr(eqg->point + g_hi + j) : fr_zero(); }
           hipLaunchKernelGGL(k_eq_small2, dim3(hb + lb2), dim3(LASSO_BLOCK), 0, c->stream, Rh, g_hi, eqg->scale, f_hi, hb, Rl, g_lo, f_lo);
         }
+        if (!big_inline) hipLaunchKernelGGL(k_eq_outer, dim3(grid_for(half, 4096)), dim3(LASSO_BLOCK), 0, c->stream, (const fr_t*)f_hi, (const fr_t*)f_lo, g_lo, half, (fr_t*)d_E, gate_gp, seq);   // the table itself, as lasso_eq_evals_scaled writes it
       }
       ProfScope ps(c, LASSO_K_CUBIC, 32.0 * n * (2.0 * ncirc + 1.0));
+      if ((gbig || eqg) && NT == 2 && !big_inline) {   // round 0 reads the table the kernels above left in d_E
+        EqNone EN; EN.ell = 0; EN.gp = gate_gp; EN.seq = seq;
+        hipLaunchKernelGGL((k_cubic_eqw_lb<2, false, TP, EqNone>), dim3(nx * ny), dim3(LASSO_BLOCK), 0, c->stream, Ac, Bc, nx, ny, (const fr_t*)d_E, half, (fr_t*)c->d_scratch, c->d_counters, r_out, r_flag, seq, pipe, EN, (fr_t*)nullptr);
+      } else
       if (gated && NT == 2) {
         if (gbig) {
           fr_t* hi = f_hi; fr_t* lo = f_lo;

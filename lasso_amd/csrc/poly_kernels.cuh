@@ -395,7 +395,7 @@ __device__ __forceinline__ void cubic_eqw_terms2(const fr29& a0, const fr29& a1,
 // E[x] = hi[x >> lo_bits] * lo[x & mask] where it is used.  hi and lo are kept in s-form (their product is the s-form operand the round needs); lo also in u-form, so that the
 // workgroups of circuit 0 can write E[x] = hi * lo_u to memory in the canonical bytes k_eq_small / k_eq_outer produce — the later rounds of the layer read its prefix.
 struct EqInline { fr_t r[14]; fr_t scale; uint32_t ell; };
-struct EqNone { uint32_t ell = 0; };   // stands in for EqInline in the launches that carry no point (4 bytes of kernel arguments instead of 484)
+struct EqNone { uint32_t ell = 0; const uint32_t* gp = nullptr; uint32_t seq = 0; };   // stands in for EqInline in the launches that carry no point (16 bytes of kernel arguments instead of 484); gp: the launch sits behind a point gate that may have failed
 struct EqInlineTables { fr29 hi_s[128], lo_s[128], lo_u[128]; };
 // the same point, not an argument: left in device memory by the gate in front of the launch (k_gate_point), for a layer enqueued before its point was known
 struct EqInlineMem { const uint32_t* gp; uint32_t seq; uint32_t ell; };
@@ -428,13 +428,18 @@ __device__ __forceinline__ bool eq_inline_build_t(const QT& Q, EqInlineTables& T
 __device__ __forceinline__ bool eq_inline_build(const EqInline& Q, EqInlineTables& T) { return eq_inline_build_t(Q, T); }
 __device__ __forceinline__ bool eq_inline_build(const EqInlineMem& Q, EqInlineTables& T) { return eq_inline_build_t(Q, T); }
 __device__ __forceinline__ fr29 eq_inline_s(const EqInlineTables& T, uint32_t lb, size_t x) { return fr29_mul(T.hi_s[x >> lb], T.lo_s[x & ((1u << lb) - 1u)]); }
-// Tables of MORE than 2^14 entries (round 5): the two factor tables (<= 2^11 entries each) do not fit LDS, so they stay where k_eq_small2 wrote them — global memory, memory form,
+// Tables of MORE than 2^14 entries, optional form (LASSO_EQ_INLINE_BIG=1; round 5 — measured and NOT the default: it takes k_eq_outer's 63 us per proof out of the stream but costs
+// round 0 of the eight largest layers 120 us, +18 %, in a kernel that is already VALU co-limited, and those launches are a third of the roofline set:
+// profiles/r05_ab_layer_ahead_eq_global.txt; with the layers enqueued ahead of their point the separate kernels cost no launch gap any more): the two factor tables (<= 2^11 entries each) do not fit LDS, so they stay where k_eq_small2 wrote them — global memory, memory form,
 // L2-resident — and round 0 forms  E[x] = hi[x >> lo_bits] * lo[x & mask]  where it uses it: k_eq_outer's product, bit for bit, written to E_out by circuit 0's workgroups for the
 // later rounds and never read back in this launch.  Takes k_eq_outer (a 32-byte write per entry, then the same bytes read again by round 0: 5-200 us in front of round 0 of the
 // nine largest layers of a 2^24 proof) off the critical path for one product per index in a launch that is HBM-bound.
 struct EqGlobal { const fr_t* hi; const fr_t* lo; uint32_t lo_bits; uint32_t ell; const uint32_t* gp; uint32_t seq; };   // gp != nullptr: the factor tables were built behind a point gate (k_eq_small2_mem), which may have failed
 __device__ __forceinline__ bool eq_inline_build(const EqGlobal& Q, EqInlineTables&) { return Q.gp == nullptr || gate_point_ok(Q.gp, Q.seq); }
 __device__ __forceinline__ bool eq_inline_build(const EqNone&, EqInlineTables&) { return true; }
+// launches that READ their table (EQI = false) behind a point gate: the table was built from the gated point by the kernels in front (k_eq_small2_mem, k_eq_outer)
+template <class TE> __device__ __forceinline__ bool eq_gate_ok(const TE&) { return true; }
+template <> __device__ __forceinline__ bool eq_gate_ok<EqNone>(const EqNone& Q) { return Q.gp == nullptr || gate_point_ok(Q.gp, Q.seq); }
 // the eq weight of index i as the s-form operand of the round, and (write) the table entry in memory form
 __device__ __forceinline__ fr29 eq_inline_value(const EqInline&, const EqInlineTables& T, uint32_t lb, size_t i, bool write, fr_t* __restrict__ E_out) {
   if (write) E_out[i] = fr29_store(fr29_mul(T.hi_s[i >> lb], T.lo_u[i & ((1u << lb) - 1u)]));
@@ -465,7 +470,7 @@ __global__ void __launch_bounds__(LASSO_BLOCK) k_cubic_eqw_lb(TP A, TP B, uint32
   __shared__ EqInlineTables ET;
   const CubicGrid g = cubic_grid(nx, ny);
   const uint32_t elb = EQ.ell / 2;
-  if constexpr (EQI) { if (!eq_inline_build(EQ, ET)) return; }
+  if constexpr (EQI) { if (!eq_inline_build(EQ, ET)) return; } else { if (!eq_gate_ok(EQ)) return; }
   const fr_t* __restrict__ a = A.p[g.by];
   const fr_t* __restrict__ b = B.p[g.by];
   fr29 e[3] = {fr29_zero(), fr29_zero(), fr29_zero()}; uint32_t cnt = 0;
@@ -1298,7 +1303,8 @@ __global__ void k_eq_small2_mem(const uint32_t* __restrict__ gp, uint32_t seq, u
   (is_lo ? lo : hi)[x] = fr29_store(p);
 }
 // out[x] = hi[x >> lo_bits] * lo[x & mask]
-__global__ void __launch_bounds__(LASSO_BLOCK) k_eq_outer(const fr_t* __restrict__ hi, const fr_t* __restrict__ lo, uint32_t lo_bits, size_t n, fr_t* __restrict__ out) {
+__global__ void __launch_bounds__(LASSO_BLOCK) k_eq_outer(const fr_t* __restrict__ hi, const fr_t* __restrict__ lo, uint32_t lo_bits, size_t n, fr_t* __restrict__ out, const uint32_t* __restrict__ gp = nullptr, uint32_t seq = 0) {
+  if (gp != nullptr && !gate_point_ok(gp, seq)) return;   // behind a point gate that failed: nothing is touched
   const size_t mask = ((size_t)1 << lo_bits) - 1;
   for (size_t x = blockIdx.x * (size_t)blockDim.x + threadIdx.x; x < n; x += (size_t)gridDim.x * blockDim.x) out[x] = fr29_store(fr29_mul(fr29_unpack_u(hi[x >> lo_bits]), fr29_unpack_s(lo[x & mask])));
 }

@@ -736,7 +736,7 @@ class Prover {
       if (la.m_stop > 1) d.chk(lasso_tail_handover_next(d.ctx, (uint32_t)la.m_stop), "lasso_tail_handover_next");
       rc = lasso_sumcheck_cubic_tail_begin_eq_ahead(d.ctx, la.A.data(), la.B.data(), (uint32_t)k, len, ell);
     } else {
-      if (!(ell <= 14 || (!eq_inline_big_off() && ell <= 32)) || len / 2 <= 64) return;
+      if (!ell <= 32 || len / 2 <= 64) return;
       rc = lasso_sumcheck_cubic_eqw2_begin_eq_ahead(d.ctx, la.A.data(), la.B.data(), (uint32_t)k, d_table, len, ell);
     }
     if (rc == LASSO_ERR_UNSUPPORTED) return;   // a buffer would have had to grow: the layer starts the plain way
@@ -1032,8 +1032,6 @@ class Prover {
   // `prev + hi - lo`, e(1) from the claim (:99-104), UniPoly::from_evals, bind (:116-120) — the same field elements as the device's eq-weighted form, any eq coordinate.
   // The device remains the only place where an O(n) loop runs; this is the O(1) end of the O(log n) host share.
   // budget = elements per array x circuits the host takes over (LASSO_HOST_TAIL, default 32; 0 switches the host rounds off: A/B measurements, byte-identical)
-  // A/B switch: eq tables above 2^14 entries built by their own kernels (k_eq_small2 + k_eq_outer) in front of round 0, as before round 5, instead of inside round 0
-  static bool eq_inline_big_off() { static const bool off = [] { const char* v = getenv("LASSO_EQ_INLINE_BIG"); return v && v[0] == '0'; }(); return off; }
   // default: 32 with the scalar loop; 128 where the rounds run eight elements at a time (field52.hpp, AVX-512 IFMA: a layer of 2 x 2 x 32 elements costs the host less than the two
   // device turns it replaces — profiles/r05_ab_host_ifma.txt)
   static bool host_ifma() {
@@ -1227,7 +1225,7 @@ class Prover {
           leaf_round(*leaf, j, len, table, j ? &rp : nullptr, ev); have_ev = true;
           if (j == 1) { A = leaf->work_a; B = leaf->work_b; }
         } else
-        if (j == 0 && lz.on && j < tail_from && (ell <= 14 || (!eq_inline_big_off() && ell <= 32)) && len / 2 > 64) {   // round 0 of a streaming layer: the table is built in this launch and left in d_E for the later rounds
+        if (j == 0 && lz.on && j < tail_from && ell <= 32 && len / 2 > 64) {   // round 0 of a streaming layer: the table is built in this launch and left in d_E for the later rounds
           d.chk(lasso_sumcheck_cubic_eqw2_begin_eq(d.ctx, A.data(), B.data(), (uint32_t)k, lz.d_table, len, lz.rr.data(), ell, &lz.scale), "lasso_sumcheck_cubic_eqw2_begin_eq"); lz.on = false;
         } else if (j == 0 && lz.on && j >= tail_from && ell <= 9) {            // the whole layer runs in the resident kernel: no table at all
           if (m_stop > 1) d.chk(lasso_tail_handover_next(d.ctx, (uint32_t)m_stop), "lasso_tail_handover_next");

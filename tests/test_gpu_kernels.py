@@ -1467,3 +1467,14 @@ def test_layer_enqueued_ahead_of_its_point(devs, n2, ncirc2, m_stop2, mode):
     got = run(devs[0], False)
     for x, y in zip(got, ref):
         assert np.array_equal(x, y)
+
+
+def test_big_eq_tables_formed_inside_round0_in_their_own_process():
+    """LASSO_EQ_INLINE_BIG=1 (read once per process): tables above 2^14 entries formed inside round 0 from factor tables in memory (EqGlobal; measured, not the default) —
+    the round-0 and layer-enqueued-ahead cases of this file once more under that switch."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ, LASSO_EQ_INLINE_BIG="1")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_kernels.py"), "-m", "gpu", "-q", "-x", "-k", "round0_with_inline_eq_table or layer_enqueued_ahead"],
+                         env=e, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and " passed" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]

@@ -155,7 +155,7 @@ print("DIGEST", hashlib.sha256(comm + proof).hexdigest())
                                  {"LASSO_HOST_IFMA": "0"},                   # round 5: the host's rounds by the scalar loop (and its smaller take-over size)
                                  {"LASSO_HOST_IFMA": "0", "LASSO_HOST_TAIL": "128"}, {"LASSO_HOST_IFMA": "1", "LASSO_HOST_TAIL": "512"},
                                  {"LASSO_LAYER_AHEAD": "0"},                 # round 5: no layer's first launch is enqueued during the previous layer
-                                 {"LASSO_LAYER_AHEAD": "0", "LASSO_EQ_INLINE_BIG": "0"},      # ... and the tables above 2^14 entries by their own kernels
+                                 {"LASSO_LAYER_AHEAD": "0", "LASSO_EQ_INLINE_BIG": "1"}, {"LASSO_EQ_INLINE_BIG": "1"},      # the tables above 2^14 entries formed inside round 0 (measured, not the default)
                                  {"LASSO_HOST_TAIL": "0", "LASSO_LAYER_AHEAD": "1"},          # layers enqueued ahead behind tails that run to the heads
                                  {"LASSO_ROUNDS_AHEAD": "0", "LASSO_LAYER_AHEAD": "1", "LASSO_TAGGED_RESULTS": "0"},
                                  {"LASSO_CAPACITY": "1", "LASSO_LEAFLESS_MIN": "1024", "LASSO_HOST_TAIL": "0"}])
