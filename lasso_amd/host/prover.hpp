@@ -736,7 +736,7 @@ class Prover {
       if (la.m_stop > 1) d.chk(lasso_tail_handover_next(d.ctx, (uint32_t)la.m_stop), "lasso_tail_handover_next");
       rc = lasso_sumcheck_cubic_tail_begin_eq_ahead(d.ctx, la.A.data(), la.B.data(), (uint32_t)k, len, ell);
     } else {
-      if (!ell <= 32 || len / 2 <= 64) return;
+      if (ell > 32 || len / 2 <= 64) return;
       rc = lasso_sumcheck_cubic_eqw2_begin_eq_ahead(d.ctx, la.A.data(), la.B.data(), (uint32_t)k, d_table, len, ell);
     }
     if (rc == LASSO_ERR_UNSUPPORTED) return;   // a buffer would have had to grow: the layer starts the plain way
