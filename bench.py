@@ -140,6 +140,25 @@ def prover_library_path(curve):
     return os.environ.get("LASSO_PROVER_LIB") or os.path.join(ROOT, "lasso_amd", "liblasso_prover_bn254.so" if curve == "bn254" else "liblasso_prover.so")
 
 
+def host_info():
+    """CPU model and what the prover's host share runs on: lasso_amd/host/field52.hpp (AVX-512 IFMA, eight field elements per register, take-over budget 128) where the CPU has
+    it and LASSO_HOST_IFMA != 0, the scalar loop (budget 32) otherwise; LASSO_HOST_TAIL overrides the budget (lasso_amd/host/prover.hpp host_tail_budget)"""
+    info = {"cpu_model": None, "avx512ifma": None}
+    try:
+        txt = open("/proc/cpuinfo").read()
+        for line in txt.splitlines():
+            if line.startswith("model name") and info["cpu_model"] is None:
+                info["cpu_model"] = line.split(":", 1)[1].strip()
+            if line.startswith("flags") and info["avx512ifma"] is None:
+                fl = line.split(":", 1)[1].split(); info["avx512ifma"] = "avx512ifma" in fl and "avx512f" in fl
+    except OSError:
+        pass
+    ifma = bool(info["avx512ifma"]) and os.environ.get("LASSO_HOST_IFMA", "1")[:1] != "0"
+    info["host_rounds"] = "avx512-ifma (lasso_amd/host/field52.hpp)" if ifma else "scalar 4 x u64 (lasso_amd/host/field_host.hpp H4)"
+    info["host_tail_budget"] = int(os.environ["LASSO_HOST_TAIL"]) if os.environ.get("LASSO_HOST_TAIL", "").lstrip("-").isdigit() else (128 if ifma else 32)
+    return info
+
+
 def lib_sha(curve):
     """sha256 over the sources the two libraries are built from, and whether the .so files THIS RUN LOADED are at least as new as every one of them: a stale prebuilt
     binary cannot be timed silently (VERDICT r2 "What's weak" 10).  The paths are the ones actually opened — LASSO_DEVICE_LIB / LASSO_PROVER_LIB included (a line
@@ -617,6 +636,7 @@ def main():
                           "proof_bytes": len(proof), "proof_sha256": __import__("hashlib").sha256(proof).hexdigest(), "distinct_proofs": len(set(digests)), "densify_s": round(t_densify, 3), "commit_s": round(t_commit, 3), "commit_warm_s": round(t_commit_warm, 3), "gens_setup_s": round(t_setup, 3),
                           "whole_bench_lookups_per_s": s / (t_densify + t_commit + ms_per_step / 1e3)}}
         out["lib_sha"] = lib_sha(a.curve)
+        out["host"] = host_info()   # the metric depends on the host's share of the Fiat-Shamir chain: say what the host was
         out["config"]["workload_key"] = workload_key(a.kind, c, log_m, a.log_s, a.curve)
         if a.kind == "spark":    # not a parity claim against upstream
             out["config"]["unverified_against_reference"] = ("kind=spark is LASSO_SPARK_UNCONFIRMED: BASELINE.json configs[4] names a SparkSubtableStrategy the reference snapshot does not contain "
