@@ -87,7 +87,9 @@ for kind, c, log_m, log_s in (("and", 2, 12, 12), ("xor", 1, 16, 11), ("lt", 2, 
                                  {"LASSO_HOST_TAIL": "128"}, {"LASSO_HOST_TAIL": "4"}, {"LASSO_CUBIC_TAIL": "0"}, {"LASSO_CUBIC_TAIL": "0", "LASSO_HOST_TAIL": "0"},
                                  {"LASSO_CAPACITY": "1", "LASSO_LEAFLESS_MIN": "64"}, {"LASSO_CAPACITY": "1", "LASSO_LEAFLESS_MIN": "64", "LASSO_HOST_TAIL": "0", "LASSO_ROUNDS_AHEAD": "0"},
                                  {"LASSO_LAYER_AHEAD": "0"}, {"LASSO_LAYER_AHEAD": "1", "LASSO_HOST_TAIL": "0"}, {"LASSO_LAYER_AHEAD": "1", "LASSO_ROUNDS_AHEAD": "0"},
-                                 {"LASSO_HOST_IFMA": "0"}, {"LASSO_HOST_IFMA": "0", "LASSO_HOST_TAIL": "128"}, {"LASSO_HOST_IFMA": "1", "LASSO_HOST_TAIL": "512"}, {"LASSO_HOST_IFMA": "1", "LASSO_HOST_TAIL": "8"}])
+                                 {"LASSO_HOST_IFMA": "0"}, {"LASSO_HOST_IFMA": "0", "LASSO_HOST_TAIL": "128"}, {"LASSO_HOST_IFMA": "1", "LASSO_HOST_TAIL": "512"}, {"LASSO_HOST_IFMA": "1", "LASSO_HOST_TAIL": "8"},
+                                 {"LASSO_CUBIC_THREE_SUMS": "1"},      # every streaming layer enqueued ahead turns out to have "another shape": lasso_point_cancel, then the plain path
+                                 {"LASSO_CUBIC_THREE_SUMS": "1", "LASSO_LAYER_AHEAD": "0"}])
 def test_host_schedule_switches_do_not_change_the_bytes(env):
     """Round 5's host-side schedule — rounds launched ahead of their challenge, resident tails that hand their arrays to the host, tree-top layers proved on the host — selects
     WHERE and WHEN the same field arithmetic runs: with every combination of the switches the commitment and proof bytes are those of the default (each setting in its own process:
@@ -96,7 +98,7 @@ def test_host_schedule_switches_do_not_change_the_bytes(env):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
     def run(extra):
-        e = dict(os.environ); e.pop("LASSO_HOST_TAIL", None); e.pop("LASSO_ROUNDS_AHEAD", None); e.pop("LASSO_LAYER_AHEAD", None); e.pop("LASSO_HOST_IFMA", None); e.update(extra); e["PYTHONPATH"] = root + os.pathsep + e.get("PYTHONPATH", "")
+        e = dict(os.environ); e.pop("LASSO_HOST_TAIL", None); e.pop("LASSO_ROUNDS_AHEAD", None); e.pop("LASSO_LAYER_AHEAD", None); e.pop("LASSO_HOST_IFMA", None); e.pop("LASSO_CUBIC_THREE_SUMS", None); e.update(extra); e["PYTHONPATH"] = root + os.pathsep + e.get("PYTHONPATH", "")
         out = subprocess.run([sys.executable, "-c", _SWITCH_SCRIPT_CPU], env=e, cwd=root, capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, out.stderr[-2000:]
         return [l.split()[1] for l in out.stdout.splitlines() if l.startswith("DIGEST")]
