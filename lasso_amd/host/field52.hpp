@@ -126,12 +126,19 @@ class HostRounds52 {
     for (size_t c = 0; c < k; c++) for (size_t i = 0; i < m; i++) { put(off_aw(c) + i, a[c][i]); put(off_b(c) + i, b[c][i]); }
     for (size_t i = 0; i < m; i++) put(off_c() + i, cw[i]);
     const F52Consts& K = f52_consts(); const F52 P = f52_bcast(K.p), cin = f52_bcast(K.c_in); const __m512i pinv = _mm512_set1_epi64((long long)K.pinv);
-    // B, C into the 2^260 domain (x 2^264 / 2^260); A' = A * (w * 2^264) / 2^260 = A w 2^260 directly
-    for (size_t at = off_b(0); at < off_c() + stride; at += 8) store(at, f52_mul(load(at), cin, P, pinv));
-    for (size_t c = 0; c < k; c++) {
-      uint64_t wl[5]; F52Consts::split(w[c].l, wl);
-      const F52 wx = f52_mul(f52_mul(f52_bcast(wl), cin, P, pinv), cin, P, pinv);   // w 2^264
-      for (size_t i = 0; i < stride; i += 8) store(off_aw(c) + i, f52_mul(load(off_aw(c) + i), wx, P, pinv));
+    // B, C into the 2^260 domain (x 2^264 / 2^260); A' = A * (w * 2^264) / 2^260 = A w 2^260 directly.  Work items (chunk, factor), three products side by side
+    std::vector<F52> wx(k);
+    for (size_t c = 0; c < k; c++) { uint64_t wl[5]; F52Consts::split(w[c].l, wl); wx[c] = f52_mul(f52_mul(f52_bcast(wl), cin, P, pinv), cin, P, pinv); }   // w 2^264
+    const size_t per = stride / 8, items = narr * per;
+    for (size_t it = 0; it < items; it += 3) {
+      F52 x[3], f[3], q[3]; size_t at[3];
+      for (int u = 0; u < 3; u++) {
+        const size_t id = it + u < items ? it + u : items - 1, arr = id / per;   // (the last group repeats its last item)
+        at[u] = arr * stride + (id % per) * 8; x[u] = load(at[u]); f[u] = arr < k ? wx[arr] : cin;
+      }
+      f52_mul_lazy<3>(q, x, f, P, pinv);
+      for (int u = 0; u < 3; u++) q[u] = f52_condsub(q[u], P);
+      for (int u = 0; u < 3; u++) store(at[u], q[u]);
     }
   }
   // e(0), e(2), e(3) of the round over the live prefix of length 2h (sumcheck.rs:68-97), ark form

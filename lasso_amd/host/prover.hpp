@@ -524,7 +524,12 @@ struct UniPoly {
     for (size_t i = 0; i < evals.size(); i++) for (size_t j = 0; j < evals.size(); j++) p.coeffs[i] += V[i][j] * evals[j];
     return p;
   }
-  Sc evaluate(const Sc& r) const { Sc e = coeffs[0], pw = r; for (size_t i = 1; i < coeffs.size(); i++) { e += pw * coeffs[i]; pw *= r; } return e; }
+  Sc evaluate(const Sc& r) const {   // Horner on plain 4 x u64 values: degree products instead of 2 * degree (once per sumcheck round, between the round's sums and its challenge's use)
+    if (coeffs.empty()) return Sc::zero();
+    const H4 x = h4_from(r.v); H4 e = h4_from(coeffs.back().v);
+    for (size_t i = coeffs.size() - 1; i-- > 0;) e = h4_add(h4_mul(e, x), h4_from(coeffs[i].v));
+    Sc out; out.v = h4_to(e); return out;
+  }
   ScVec compress() const { ScVec c; c.push_back(coeffs[0]); c.insert(c.end(), coeffs.begin() + 2, coeffs.end()); return c; }   // drops the linear term :82-88
   void append_to_transcript(ProofTranscript& t, const char* label) const {   // :112-120
     t.append_message(label, "UniPoly_begin"); for (auto& c : coeffs) t.append_scalar("coeff", c); t.append_message(label, "UniPoly_end");
@@ -534,6 +539,13 @@ struct UniPoly {
 inline ScVec eq_evals_host(const Sc* r, size_t ell) {
   ScVec ev((size_t)1 << ell, Sc::one()); size_t size = 1;
   for (size_t j = 0; j < ell; j++) { size *= 2; for (size_t i = size; i-- > 0;) { if (!(i & 1)) continue; Sc sc = ev[i / 2]; ev[i] = sc * r[j]; ev[i - 1] = sc - ev[i]; } }
+  return ev;
+}
+
+// init * EqPolynomial(r[0..ell)).evals() as plain 4 x u64 values: the running factor rides on the root instead of costing a product per entry afterwards
+inline std::vector<H4> eq_evals_host_scaled(const Sc* r, size_t ell, const Sc& init) {
+  std::vector<H4> ev((size_t)1 << ell); ev[0] = h4_from(init.v); size_t size = 1;
+  for (size_t j = 0; j < ell; j++) { const H4 rj = h4_from(r[j].v); size *= 2; for (size_t i = size; i-- > 0;) { if (!(i & 1)) continue; const H4 sc = ev[i / 2]; ev[i] = h4_mul(sc, rj); ev[i - 1] = h4_sub(sc, ev[i]); } }
   return ev;
 }
 
@@ -1056,8 +1068,7 @@ class Prover {
     for (size_t c = 0; c < k; c++) LASSO_REQUIRE(a[c].size() == m && b[c].size() == m);
     auto to_sc = [](const H4& x) { Sc r; r.v = h4_to(x); return r; };
     // the eq weights of the remaining coordinates with the running factor folded in
-    std::vector<H4> C(m);
-    { ScVec Ce = eq_evals_host(rand.data() + first, rounds_left); const H4 sr = h4_from(s_run.v); for (size_t i = 0; i < m; i++) C[i] = h4_mul(h4_from(Ce[i].v), sr); }
+    std::vector<H4> C = eq_evals_host_scaled(rand.data() + first, rounds_left, s_run);
     // Two forms of the same loops: eight elements at a time in 52-bit limbs on AVX-512 IFMA (field52.hpp HostRounds52) where the CPU has it, plain 4 x u64 values (field_host.hpp H4)
     // otherwise.  Per circuit: A, B and A' = coeffs_c * A — the batching coefficient rides on A' (sumcheck.rs:95-97 applies it to the circuit's sums: the same by linearity), so a
     // term is ONE product per evaluation point; A itself is bound alongside because its final value is a claim (:126-133).  Both forms work on canonical values: same field
@@ -1098,10 +1109,13 @@ class Prover {
       }
       // UniPoly::from_evals on (e(0), e(1) = claim - e(0) (:99-104), e(2), e(3)): the unique cubic through four points, in closed form (third and second finite differences) —
       // the same four coefficients the Vandermonde solve of unipoly.rs:30-66 returns, for 2 products instead of 16
-      static const Sc inv2 = Sc::from_u64(2).inverse(), inv6 = Sc::from_u64(6).inverse();
-      const Sc E0 = to_sc(e0), E1 = e - E0, E2 = to_sc(e2), E3 = to_sc(e3);
-      const Sc c3 = (E3 - E2 - E2 - E2 + E1 + E1 + E1 - E0) * inv6, c2 = (E2 - E1 - E1 + E0) * inv2 - c3 - c3 - c3, c1 = E1 - E0 - c2 - c3;
-      UniPoly poly; poly.coeffs = {E0, c1, c2, c3};
+      static const H4 inv2 = h4_from(Sc::from_u64(2).inverse().v), inv6 = h4_from(Sc::from_u64(6).inverse().v);
+      const H4 e1 = h4_sub(h4_from(e.v), e0);
+      const H4 t32 = h4_sub(e3, h4_add(h4_add(e2, e2), e2)), t11 = h4_add(h4_add(e1, e1), e1);                       // e3 - 3 e2, 3 e1
+      const H4 k3 = h4_mul(h4_sub(h4_add(t32, t11), e0), inv6);                                                          // (e3 - 3 e2 + 3 e1 - e0) / 6
+      const H4 k2 = h4_sub(h4_mul(h4_add(h4_sub(e2, h4_add(e1, e1)), e0), inv2), h4_add(h4_add(k3, k3), k3));          // (e2 - 2 e1 + e0) / 2 - 3 c3
+      const H4 k1 = h4_sub(h4_sub(h4_sub(e1, e0), k2), k3);
+      UniPoly poly; poly.coeffs = {to_sc(e0), to_sc(k1), to_sc(k2), to_sc(k3)};
       poly.append_to_transcript(t, "poly");
       const Sc r_j = t.challenge_scalar("challenge_nextround"); r_out.push_back(r_j);
       e = poly.evaluate(r_j);
