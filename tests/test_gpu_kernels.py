@@ -1478,3 +1478,38 @@ def test_big_eq_tables_formed_inside_round0_in_their_own_process():
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_kernels.py"), "-m", "gpu", "-q", "-x", "-k", "round0_with_inline_eq_table or layer_enqueued_ahead"],
                          env=e, cwd=root, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and " passed" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+
+
+@pytest.mark.parametrize("n", [1 << 12, 1 << 17, 512])
+def test_layer_enqueued_ahead_and_never_posted_is_aborted_quickly(devs, n):
+    """A layer enqueued ahead of its point whose host never posts (an exception in the prover): lasso_abort poisons the point mailbox, the gate and the kernels behind it leave at
+    once (not after the gate's 5 s bound), and the context goes on working — the plain call gives what the mock gives."""
+    import time
+    d = devs[0]
+    rng = np.random.default_rng(77)
+    ncirc = 2
+    A = [rand_fr(rng, n) for _ in range(ncirc)]; B = [rand_fr(rng, n) for _ in range(ncirc)]
+    ell = (n // 2).bit_length() - 1; pt = rand_fr(rng, ell, edge=False); sc = rand_fr(rng, 1, edge=False)[0]
+    pa = [d.upload(x) for x in A]; pb = [d.upload(x) for x in B]; e = d.alloc(32 * (n // 2))
+    if ell <= 9:      # the resident-tail form (a small layer served whole)
+        d._chk(d.lib.lasso_sumcheck_cubic_tail_begin_eq_ahead(d.ctx, d._ptrs(pa), d._ptrs(pb), ncirc, n, ell))
+    else:
+        d._chk(d.lib.lasso_sumcheck_cubic_eqw2_begin_eq_ahead(d.ctx, d._ptrs(pa), d._ptrs(pb), ncirc, C.c_void_p(e), n, ell))
+    assert d.lib.lasso_sync(d.ctx) != 0           # waiting on the device: nothing that synchronises is legal
+    t0 = time.time()
+    assert d.lib.lasso_abort(d.ctx) == 0
+    assert time.time() - t0 < 2.0                 # the poison tag, not the 5 s bail-out
+    assert d.lib.lasso_sync(d.ctx) == 0
+    m = devs[1]
+    ma = [m.upload(x) for x in A]; mb = [m.upload(x) for x in B]; me = m.alloc(32 * (n // 2))
+    if ell <= 9:
+        chal = rand_fr(rng, ell + 1, edge=False)
+        got = d.sumcheck_cubic_tail_eq(pa, pb, n, pt, sc, chal); want = m.sumcheck_cubic_tail_eq(ma, mb, n, pt, sc, chal)
+        assert len(got) == len(want) and all(np.array_equal(x, y) for x, y in zip(got, want))
+    else:
+        got = d.sumcheck_cubic_eqw2_eq(pa, pb, e, n, pt, sc); want = m.sumcheck_cubic_eqw2_eq(ma, mb, me, n, pt, sc)
+        assert np.array_equal(got, want)
+    for p in pa + pb + [e]:
+        d.free(p)
+    for p in ma + mb + [me]:
+        m.free(p)
