@@ -152,6 +152,7 @@ print("DIGEST", hashlib.sha256(comm + proof).hexdigest())
                                  {"LASSO_HOST_TAIL": "128"},                 # ... and takes over four times earlier than the default (arrays of 32 elements at two circuits... here of 32 / 16)
                                  {"LASSO_HOST_TAIL": "8", "LASSO_TAGGED_RESULTS": "0"},      # hand-over through the flag protocol
                                  {"LASSO_ROUNDS_AHEAD": "1", "LASSO_CUBIC_TAIL": "0"},      # every round of a layer launched ahead (no resident tail to end in)
+                                 {"LASSO_CUBIC_THREE_SUMS": "1"},            # three sums per round from the device — and every streaming layer enqueued ahead is cancelled (lasso_point_cancel), then started the plain way
                                  {"LASSO_HOST_IFMA": "0"},                   # round 5: the host's rounds by the scalar loop (and its smaller take-over size)
                                  {"LASSO_HOST_IFMA": "0", "LASSO_HOST_TAIL": "128"}, {"LASSO_HOST_IFMA": "1", "LASSO_HOST_TAIL": "512"},
                                  {"LASSO_LAYER_AHEAD": "0"},                 # round 5: no layer's first launch is enqueued during the previous layer
