@@ -354,6 +354,10 @@ int32_t lasso_bases_create_opt(lasso_ctx* ctx, const lasso_affine* points, size_
  * first commitment of small scalars that uses the object (serialised by a mutex inside the object; ~3 ms, waited for), one byte-multiple table of 255 * n * 112 B per byte window
  * (117 MB for n = 4096; at most two windows). */
 void lasso_bases_destroy(lasso_ctx* ctx, lasso_bases* b);
+/* Build the byte-multiple tables of byte windows 0 .. byte_windows-1 (1 or 2) NOW instead of inside the first commitment of small scalars that uses the object, so that a caller
+ * timing DensifiedRepresentation::commit (src/benches/bench.rs:54-66) does not time a one-off table build (3 x 10 ms at n = 4096).  A failed allocation is not an error: that
+ * commitment then takes the bucket kernel.  Not while a launch of this context waits for the host. */
+int32_t lasso_bases_prepare(lasso_ctx* ctx, const lasso_bases* bases, uint32_t byte_windows);
 /* DensePolynomial::commit / commit_inner with zero blinds (src/poly/dense_mlpoly.rs:109-181): for each of l_size rows,
  * out[row] = sum_{j < r_size} d_Z[row*r_size + j] * bases[j]   (Commitments::batch_commit, src/poly/commitments.rs:84-93) */
 int32_t lasso_hyrax_commit(lasso_ctx* ctx, const lasso_fr* d_Z, size_t l_size, size_t r_size, const lasso_bases* bases, lasso_point* out);
@@ -379,6 +383,8 @@ int32_t lasso_rccl_unique_id(uint8_t out[128]);                                 
 int32_t lasso_rccl_init(lasso_ctx* ctx, int32_t rank, int32_t world, const uint8_t id[128]);      /* ncclCommInitRank on the context's device; collective */
 int32_t lasso_rccl_shutdown(lasso_ctx* ctx);                                                      /* ncclCommDestroy (also done by lasso_ctx_destroy) */
 int32_t lasso_rccl_ready(lasso_ctx* ctx);                                                         /* world size of the communicator, 0 = none */
+int32_t lasso_rccl_selftest(lasso_ctx* ctx);                                                      /* collective: all-gather 1 KB of a rank-dependent pattern and check every slot; bounded wait (20 s), the
+                                                                                                     communicator is aborted and dropped on a time-out — the caller then falls back to its host exchange */
 int32_t lasso_rccl_allgather(lasso_ctx* ctx, const void* d_send, void* d_recv, size_t bytes);     /* d_recv[g*bytes..) <- rank g's d_send; asynchronous on the stream */
 size_t lasso_point_row_bytes(void);
 int32_t lasso_hyrax_commit_rows_dev(lasso_ctx* ctx, const lasso_fr* d_Z, size_t l_size, size_t r_size, const lasso_bases* bases, void* d_rows);

@@ -82,12 +82,23 @@ int32_t lasso_host_gens_new(lasso_host* h, const char* label, size_t c, size_t s
 /* the points of set `which` (0 = gens_combined_l_variate, 1 = gens_combined_log_m_variate, 2 = gens_derefs) in lasso_host_gens_from_points' layout; *count = n + 2
  * (returns -2 with *count set when cap is smaller) */
 int32_t lasso_host_gens_points(lasso_host_gens* g, int32_t which, lasso_affine* out, size_t cap, size_t* count);
+/* Build every device table a proof over these generators reads NOW (lasso_bases_prepare on the three sets): the byte-multiple tables of the small-scalar commitments are
+ * otherwise built by the first lasso_host_commit / lasso_host_prove that meets the object — inside whatever span the caller times.  The Rust harness calls it before its
+ * `DensifiedRepresentation.commit` span (integration/rust/bench_types.rs, src/benches/bench.rs:54-66); bench.py reports its time as `gens_tables_s`. */
+int32_t lasso_host_gens_prepare(lasso_host_gens* g);
 void lasso_host_gens_free(lasso_host_gens* g);
 /* indices: n_lookups x c, row-major (Vec<[usize; C]>) */
 int32_t lasso_host_densify(lasso_host* h, const uint64_t* indices, size_t n_lookups, size_t c, size_t log_m, lasso_host_dense** out);
 void lasso_host_dense_free(lasso_host_dense* d);
 /* out = [u64 L1][L1 x 32 B][u64 L2][L2 x 32 B]: l_variate_polys_commitment.C then log_m_variate_polys_commitment.C */
 int32_t lasso_host_commit(lasso_host_dense* d, lasso_host_gens* g, uint8_t* out, size_t cap, size_t* len);
+/* LIVENESS.  While a proof runs, kernels of this context wait ON THE DEVICE for the calling thread's next Fiat-Shamir challenge (resident tails, gate kernels
+ * in front of rounds / layers / bullet rounds launched ahead, include/lasso_hip.h).  Every such wait ends by itself after 5 s of wall clock (or at once on lasso_abort's poison
+ * tag), so a host that stops answering can never hang the GPU — but the bound cuts both ways: if the thread inside lasso_host_prove* is descheduled or stopped (debugger,
+ * SIGSTOP, a starved container) for more than 5 s in the middle of a proof, the waiting kernel leaves WITHOUT a result, the next lasso_result_wait fails ("flag not raised"),
+ * and lasso_host_prove* returns an error after restoring the context (lasso_abort: both contexts usable again, nothing leaked).  The proof is NOT retried inside the library: with
+ * the caller's live transcript (lasso_host_prove_cb) a replay would absorb into a transcript that has already advanced.  A caller that owns fresh transcripts (this entry
+ * point, the bench harness) simply calls again; the proof bytes are deterministic.  The prover thread should not share its core with work that can starve it for seconds. */
 int32_t lasso_host_prove(lasso_host* h, lasso_host_dense* d, lasso_host_gens* g, const lasso_strategy* strategy, const lasso_fr* r, size_t r_len,
                          const char* transcript_label, const char* tape_label, uint8_t* out, size_t cap, size_t* len);
 

@@ -35,10 +35,13 @@ macro_rules! single_pass_lasso_hip {
       let nz = gen_indices::<C>(S, M);
 
       let prover = HipProver::new(0);
-      let mut dense = tracing::info_span!("Densify").in_scope(|| HipDensified::<F, C>::from_lookup_indices(&prover, &nz, log_m));
       // bench.rs:56: ONE generator object, built by the reference's own code, handed to commit, prove AND verify — the library receives its points
-      // (lasso_host_gens_from_points) and derives nothing
+      // (lasso_host_gens_from_points) and derives nothing.  Built BEFORE the `Densify` span here (the reference builds it between the spans, outside both), and its device
+      // tables with it (prepare_gens: upload, window / digit-multiple / byte-multiple tables), so that the spans below time what bench.py's `densify_s`, `commit_warm_s` and
+      // `ms_per_step` time and not a one-off table build (bench.py reports that as `gens_derive_s` + `gens_tables_s`)
       let gens = SparsePolyCommitmentGens::<G>::new(b"gens_sparse_poly", C, S, C, log_m);
+      prover.prepare_gens::<G>(&gens, C, S, <SubtableStrategy as crate::subtables::SubtableStrategy<F, C, M>>::NUM_MEMORIES, log_m);
+      let mut dense = tracing::info_span!("Densify").in_scope(|| HipDensified::<F, C>::from_lookup_indices(&prover, &nz, log_m));
       let commitment = tracing::info_span!("DensifiedRepresentation.commit").in_scope(|| dense.commit::<G>(&gens));
       // exactly bench.rs:59-66: the harness's own fresh transcript and tape, passed as the live objects they are
       let mut random_tape = RandomTape::new(b"proof");

@@ -142,11 +142,31 @@ const MERLIN_VTBL: lasso_transcript_vtbl = lasso_transcript_vtbl { append_messag
 // `commit` and `prove` take `gens: &SparsePolyCommitmentGens<G>` (densified.rs:78-81, surge.rs:119-125) and so do the shims below: the POINTS the caller holds are
 // uploaded (lasso_host_gens_from_points) — the library derives nothing, so no restatement of arkworks' SHAKE256 -> ChaCha20Rng -> G::rand stream is in the
 // prover's trust base.  Building the device tables costs tens of milliseconds, so they are cached per HipProver under a key taken from the points themselves.
+/// Cache key (the first form normalised and copied every point of all three sets on EVERY commit / prove call just to form the key — tens of thousands of
+/// points at 2^24, inside the timed `SparsePoly.prove` span): what identifies a generator object cheaply is where its three `G` vectors live and how long they are, the raw
+/// bytes of a few PROJECTIVE points of each set (first, middle, last, and `h`: no normalisation, 4 x 128 bytes per set), and the shape the tables were built for.
+/// Two different generator sets that agree on all of it do not occur; a `Vec` that was dropped and re-allocated at the same address with other points differs in the probe.
 #[derive(PartialEq, Eq, Clone)]
-struct GensKey { sizes: [usize; 3], probe: Vec<u8> }
+struct GensKey { addrs: [usize; 3], sizes: [usize; 3], shape: [usize; 4], probe: Vec<u8> }
+
+fn key_of<G: CurveGroup>(gens: &SparsePolyCommitmentGens<G>, shape: [usize; 4]) -> GensKey {
+  let sets = [&gens.gens_combined_l_variate, &gens.gens_combined_log_m_variate, &gens.gens_derefs];
+  let mut probe = Vec::with_capacity(3 * 4 * std::mem::size_of::<G>());
+  let raw = |p: &G| unsafe { std::slice::from_raw_parts(p as *const G as *const u8, std::mem::size_of::<G>()) }.to_vec();
+  for s in sets.iter() {
+    let v = &s.gens.gens_n.G;
+    for &i in &[0, v.len() / 2, v.len() - 1] { probe.extend_from_slice(&raw(&v[i])); }
+    probe.extend_from_slice(&raw(&s.gens.gens_n.h));
+  }
+  GensKey {
+    addrs: [sets[0].gens.gens_n.G.as_ptr() as usize, sets[1].gens.gens_n.G.as_ptr() as usize, sets[2].gens.gens_n.G.as_ptr() as usize],
+    sizes: [sets[0].gens.gens_n.G.len(), sets[1].gens.gens_n.G.len(), sets[2].gens.gens_n.G.len()],
+    shape, probe,
+  }
+}
 
 /// [gens_n.G[0..n), gens_1.G[0], gens_n.h] as affine points in ark-ec's memory form (= lasso_affine: x then y, Montgomery limbs), one batch inversion
-/// (CurveGroup::normalize_batch, as commitments.rs:87 does before every MSM)
+/// (CurveGroup::normalize_batch, as commitments.rs:87 does before every MSM).  Only on a cache miss.
 fn flatten<G: CurveGroup>(g: &PolyCommitmentGens<G>) -> Vec<G::Affine> {
   let d = &g.gens; // DotProductProofGens { gens_n, gens_1 } (dot_product.rs:139-150)
   assert!(d.gens_1.G.len() == 1 && d.gens_1.h == d.gens_n.h, "gens_1 / gens_n must share h (split_at, commitments.rs:54-71)");
@@ -156,22 +176,45 @@ fn flatten<G: CurveGroup>(g: &PolyCommitmentGens<G>) -> Vec<G::Affine> {
   G::normalize_batch(&pts)
 }
 
+/// at most this many generator objects stay resident per HipProver (each holds its tables in HBM: ~0.5 MB per generator with the byte multiples); the least recently
+/// used one is freed when a new one arrives.  `HipProver::drop_gens` frees one explicitly.
+const GENS_CACHE_MAX: usize = 4;
+
 impl HipProver {
   /// the device-side twin of `gens`, built on first sight.  c, s, log_m: the shape (surge.rs:39-47); num_memories = 0 where the strategy is not known (commit).
   fn gens_on_device<G: CurveGroup>(&self, gens: &SparsePolyCommitmentGens<G>, c: usize, s: usize, num_memories: usize, log_m: usize) -> *mut lasso_host_gens {
-    // the layout assert that makes passing `&[G::Affine]` as `*const lasso_affine` sound for this G (TE: {x, y}; SW: {x, y, infinity} is 72 bytes and is repacked below)
+    // `commit` (num_memories = 0: the strategy is not known there) is served by any object built for the same c, s, log_m — prepare_gens / prove build it with the real count
+    let key = key_of(gens, [c, s, num_memories, log_m]);
+    {
+      let mut cache = self.gens_cache.borrow_mut();
+      let hit = cache.iter().position(|(k, _)| *k == key || (num_memories == 0 && k.addrs == key.addrs && k.sizes == key.sizes && k.probe == key.probe && k.shape[0] == c && k.shape[1] == s && k.shape[3] == log_m));
+      if let Some(i) = hit { let e = cache.remove(i); let g = e.1; cache.push(e); return g; }   // most recently used last
+    }
+    // miss: normalise, repack (TE: {x, y}; SW: {x, y, infinity} is 72 bytes and is repacked by affine_to_abi), upload, build the tables
     let sets = [flatten(&gens.gens_combined_l_variate), flatten(&gens.gens_combined_log_m_variate), flatten(&gens.gens_derefs)];
     let raw: Vec<Vec<lasso_affine>> = sets.iter().map(|v| v.iter().map(affine_to_abi::<G>).collect()).collect();
-    // key: the three sizes and the bytes of the first, middle and last two points of every set — generators are random points; two different sets agreeing on all of them do not occur
-    let mut probe = Vec::new();
-    for r in &raw { for &i in &[0, r.len() / 2, r.len() - 2, r.len() - 1] { probe.extend_from_slice(unsafe { std::slice::from_raw_parts(&r[i] as *const lasso_affine as *const u8, 64) }); } }
-    let key = GensKey { sizes: [raw[0].len(), raw[1].len(), raw[2].len()], probe };
-    if let Some((_, g)) = self.gens_cache.borrow().iter().find(|(k, _)| *k == key) { return *g; }
     let mut g = std::ptr::null_mut();
     chk(unsafe { lasso_host_gens_from_points(self.h, c, s, num_memories, log_m, raw[0].as_ptr(), raw[0].len(), raw[1].as_ptr(), raw[1].len(), raw[2].as_ptr(), raw[2].len(), &mut g) },
         "lasso_host_gens_from_points");
-    self.gens_cache.borrow_mut().push((key, g));
+    let mut cache = self.gens_cache.borrow_mut();
+    if cache.len() >= GENS_CACHE_MAX { let (_, old) = cache.remove(0); unsafe { lasso_host_gens_free(old) } }
+    cache.push((key, g));
     g
+  }
+
+  /// Upload `gens` and build EVERY device table a proof over it reads — window, digit-multiple and byte-multiple tables (lasso_host_gens_prepare) — now, outside any timed span.
+  /// The reference builds its generators outside the spans it times (bench.rs:56 sits between `Densify` and `DensifiedRepresentation.commit`); without this call the first
+  /// `commit` pays normalize_batch + upload + k_precompute_table / _multiples / _tab8 (tens of ms) inside its span, and bench.py's `commit_warm_s` / `ms_per_step` would not line up
+  /// with the Rust harness's spans (INTEGRATION.md §2 "which span pays what").
+  pub fn prepare_gens<G: CurveGroup>(&self, gens: &SparsePolyCommitmentGens<G>, c: usize, s: usize, num_memories: usize, log_m: usize) {
+    let g = self.gens_on_device(gens, c, s, num_memories, log_m);
+    chk(unsafe { lasso_host_gens_prepare(g) }, "lasso_host_gens_prepare");
+  }
+
+  /// free the device tables held for `gens` (any shape); they are rebuilt on next sight
+  pub fn drop_gens<G: CurveGroup>(&self, gens: &SparsePolyCommitmentGens<G>) {
+    let probe = key_of(gens, [0; 4]);
+    self.gens_cache.borrow_mut().retain(|(k, g)| { let same = k.addrs == probe.addrs && k.sizes == probe.sizes && k.probe == probe.probe; if same { unsafe { lasso_host_gens_free(*g) } } !same });
   }
 }
 /// ark-ec affine point -> `lasso_affine`: x, y as ark-ff's Montgomery limbs; generators are never the point at infinity

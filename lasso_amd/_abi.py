@@ -112,6 +112,8 @@ def declare(lib):
         "lasso_rccl_init": (i32, [vp, i32, i32, vp]),
         "lasso_rccl_ready": (i32, [vp]),
         "lasso_rccl_shutdown": (i32, [vp]),
+        "lasso_rccl_selftest": (i32, [vp]),
+        "lasso_bases_prepare": (i32, [vp, vp, u32]),
         "lasso_rccl_allgather": (i32, [vp, vp, vp, sz]),
         "lasso_point_row_bytes": (sz, []),
         "lasso_hyrax_commit_rows_dev": (i32, [vp, vp, sz, sz, vp, vp]),

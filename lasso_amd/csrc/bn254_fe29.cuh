@@ -186,7 +186,8 @@ LHD niels29 niels_cond_neg(const niels29& n, bool neg) {
 }
 LHD pt29 pt_from_ed(const ed_point& e) { pt29 p; p.X = fe_from_fq(e.X); p.Y = fe_from_fq(e.Y); p.T = fe_zero(); p.Z = fe_from_fq(e.Z); return p; }
 LHD ed_point pt_to_ed(const pt29& p) { ed_point e; e.X = fe_to_fq(p.X); e.Y = fe_to_fq(p.Y); e.T = fq_zero(); e.Z = fe_to_fq(p.Z); return e; }
-LHD ed_point pt_to_abi(const pt29& p) { return pt_to_ed(p); }   // fq_t already is ark's Montgomery form
+LHD ed_point pt_to_abi(const pt29& p) { return pt_to_ed(p); }
+LHD fq_t pt_coord_abi(const pt29& p, uint32_t c) { return c == 2u ? fq_zero() : fe_to_fq(reinterpret_cast<const fe29*>(&p)[c]); }   // coordinate c of pt_to_abi(p): {X, Y, 0, Z}   // fq_t already is ark's Montgomery form
 // ark-serialize's compressed short-Weierstrass point (ark-ec SWFlags; serialize_compressed of the normalised point, utils/transcript.rs:47-51):
 // canonical x, little endian; bit 7 of the last byte set iff y > -y as canonical integers; bit 6 = point at infinity (x = 0).
 LHD void pt_compress(const pt29& p, uint32_t* out) {

@@ -180,6 +180,9 @@ LHD pt29 pt_add(const pt29& p, const pt29& q, const fe29& d2) {
 #define ED_K_D 243332   // 2 * 121666:  Ds = ED_K_D Z1 Z2 =  lambda D
 // The addition shared by four lanes (msm_coop_tree): lane role c computes one of lambda A, lambda B, Cs, Ds (stage 1: ONE product + the small constant, selected by data so
 // that the instruction stream is uniform), the four exchange them, and role c computes coordinate c of the sum (stage 2: one product).
+// Round 6 (profiles/r06_bullet_phase_curve25519_before.txt: a tree level cost 1.28-1.36 us = 551 VALU instructions, of which the two products are 284): the small constant now rides
+// on the SECOND operand before the product — fe_mul_small(b, k) is the carry pass fe_weak(b) was, with a multiply-add per limb in it — so the separate pass after the
+// product is gone (-30 instructions), and stage 2 below neither selects per limb nor weakens (-114).  Same integers mod p as before; other representatives, same points.
 LHD fe29 pt_coop4_stage1(const pt29& p, const pt29& q, uint32_t c) {
   const fe29* pc = reinterpret_cast<const fe29*>(&p); const fe29* qc = reinterpret_cast<const fe29*>(&q);   // {X, Y, T, Z}
   const uint32_t ci = c < 2 ? 1u : c;                               // roles 0 / 1 use Y -/+ X, role 2 T, role 3 Z
@@ -187,7 +190,20 @@ LHD fe29 pt_coop4_stage1(const pt29& p, const pt29& q, uint32_t c) {
   fe29 a, b;
 #pragma unroll
   for (int k = 0; k < 9; k++) { a.v[k] = pc[ci].v[k] + sg * pc[0].v[k]; b.v[k] = qc[ci].v[k] + sg * qc[0].v[k]; }
-  return fe_mul_small(fe_mul(a, fe_weak(b)), c == 2 ? ED_K_C : (c == 3 ? ED_K_D : ED_K_AB));
+  // a: a sum or difference of two reduced values = loose.  b: likewise (|limb| < 2^30 + 2^17), times k < 2^18 stays far inside 64 bits; fe_mul_small's carry pass leaves it reduced.
+  return fe_mul(a, fe_mul_small(b, c == 2 ? ED_K_C : (c == 3 ? ED_K_D : ED_K_AB)));
+}
+// Stage 2 by ADDRESS instead of by select: P = {lambda A, lambda B, Cs, Ds} as the quad left them (reduced: outputs of fe_mul).  Every coordinate of the sum is (a sum) x (a difference):
+//   X3 = E F = (B - A)(Ds + Cs),  Y3 = G H = (Ds - Cs)(B + A),  T3 = E H = (B - A)(B + A),  Z3 = F G = (Ds + Cs)(Ds - Cs)
+// so role c reads the pair its sum is made of and the pair its difference is made of — sum of two reduced values = loose (fe_mul's first operand), difference of two
+// reduced values = reduced in magnitude (its second) — and multiplies: 18 additions and one product, no per-limb selects, no carry pass.
+LHD fe29 pt_coop4_stage2p(const fe29* P, uint32_t c) {
+  const uint32_t sl = (c == 0u || c == 3u) ? 2u : 0u, sr = (c == 1u || c == 3u) ? 2u : 0u;   // the sum is F (from Cs, Ds) for X3 and Z3, H (from A, B) otherwise; the difference is G for Y3 and Z3, E otherwise
+  const fe29 l0 = P[sl], l1 = P[sl + 1], r0 = P[sr], r1 = P[sr + 1];
+  fe29 u, w;
+#pragma unroll
+  for (int k = 0; k < 9; k++) { u.v[k] = l1.v[k] + l0.v[k]; w.v[k] = r1.v[k] - r0.v[k]; }
+  return fe_mul(u, w);
 }
 LHD fe29 pt_coop4_stage2(const fe29& A, const fe29& Bv, const fe29& Cs, const fe29& Ds, uint32_t c) {
   // role 0: E*F, role 1: H*G, role 2: E*H, role 3: F*G   with (all times lambda) E = B - A, F = D - C = Ds + Cs, G = D + C = Ds - Cs, H = B + A
@@ -199,6 +215,20 @@ LHD fe29 pt_coop4_stage2(const fe29& A, const fe29& Bv, const fe29& Cs, const fe
     w.v[k] = c == 0 ? F : (c == 1 ? G : (c == 2 ? H : G));
   }
   return fe_mul(fe_weak(u), fe_weak(w));
+}
+// The MIXED addition shared by four lanes (round 6: the last, partly filled pass of a latency-shaped MSM's accumulation — msm_coop_leftover — costs a tree level's time
+// instead of a lone lane's seven products in a row): role c computes P[c] of {A, B, -C, D} = {(Y - X) ymx, (Y + X) ypx, T (-t2d), Z 2} — one product each, D's by the constant
+// 2 so that the instruction stream stays uniform and every P is a reduced product output — and pt_coop4_stage2p finishes: E = B - A, F = D - C = P3 + P2, G = D + C = P3 - P2,
+// H = B + A, exactly pt_madd's X3 = E F, Y3 = H G, T3 = E H, Z3 = F G.  n: {ypx, ymx, t2d} as three reduced values (a table entry, sign applied).
+LHD fe29 pt_coop4_madd_stage1(const pt29& p, const fe29* n, uint32_t c) {
+  const fe29* pc = reinterpret_cast<const fe29*>(&p);   // {X, Y, T, Z}
+  const uint32_t ci = c < 2 ? 1u : c;
+  const int32_t sg = c == 0 ? -1 : (c == 1 ? 1 : 0), sb = c == 2 ? -1 : 1;
+  const fe29 nb = n[c == 0 ? 1u : (c == 1 ? 0u : 2u)];   // role 0: ymx, role 1: ypx, role 2: t2d (negated below); role 3 reads t2d too and replaces it by the constant
+  fe29 a, b;
+#pragma unroll
+  for (int k = 0; k < 9; k++) { a.v[k] = pc[ci].v[k] + sg * pc[0].v[k]; b.v[k] = c == 3 ? (k == 0 ? 2 : 0) : sb * nb.v[k]; }
+  return fe_mul(a, b);
 }
 LHD pt29 pt_dbl(const pt29& p) {
   fe29 A = fe_sqr(p.X), B = fe_sqr(p.Y), C = fe_dbl(fe_sqr(p.Z));
@@ -231,5 +261,7 @@ LHD niels29 niels_cond_neg(const niels29& n, bool neg) {   // -(x, y) = (-x, y):
   r.pad = 0;
   return r;
 }
+// coordinate c (0 X, 1 Y, 2 T, 3 Z) of pt_to_abi(p): four lanes convert one point side by side (msm_direct_finish's tagged hand-over)
+LHD fq_t pt_coord_abi(const pt29& p, uint32_t c) { return fq_to_mont(fe_to_fq(reinterpret_cast<const fe29*>(&p)[c])); }
 LHD ed_point pt_to_abi(const pt29& p) { ed_point e = pt_to_ed(p), o; o.X = fq_to_mont(e.X); o.Y = fq_to_mont(e.Y); o.T = fq_to_mont(e.T); o.Z = fq_to_mont(e.Z); return o; }   // ark's Montgomery limbs
 #endif  // LASSO_BN254

@@ -72,6 +72,7 @@ struct lasso_ctx {
   // layer's tail is still active; lasso_point_post delivers the point through pmail (host-mapped, one mailbox entry per field element) and turns the launch into the pending
   // result / the active tail; lasso_point_cancel ends it without a result.  d_gpoint: where the gate (k_gate_point) leaves the point for the kernels behind it.
   uint32_t* pmail_h = nullptr; uint32_t* pmail_d = nullptr; uint32_t* d_gpoint = nullptr;
+  uint32_t gate_sent = 0;         // sequence number of the last point gate launched: the mailbox area is its until pmail_h[LASSO_PMAIL_ACK_WORD] shows it (gate_free)
   bool lay_active = false, lay_tail = false, lay_tagged = false, no_grow = false; uint32_t lay_seq = 0, lay_ell = 0, lay_groups = 1, lay_K = 0, lay_turns = 0; size_t lay_count = 0, lay_final = 0;
   uint32_t prof_mask = 0;   // bit k set = kernel family k is bracketed with events
   std::vector<EventPair> events; size_t events_used = 0;
@@ -83,7 +84,7 @@ struct lasso_ctx {
   double prof_units2[LASSO_K_COUNT] = {0}; double big_units2[LASSO_K_COUNT] = {0};   // MSM families: mixed additions the kernel itself issues at most (one per scalar digit it looks at)
   double prof_units3[LASSO_K_COUNT] = {0}; double big_units3[LASSO_K_COUNT] = {0};   // MSM families: mixed additions EXECUTED, counted by the kernels (only while every launch is bracketed: no LASSO_PROF_LARGE_ONLY)
   uint32_t* d_prof_counts = nullptr;
-  void* rccl_comm = nullptr; int rccl_world = 0;   // slab mode's device-side exchange (lasso_rccl_*): an ncclComm_t bound to this context's device and stream
+  void* rccl_comm = nullptr; int rccl_world = 0; int rccl_rank = -1;   // slab mode's device-side exchange (lasso_rccl_*): an ncclComm_t bound to this context's device and stream
   // device memory held through this context (lasso_mem_stats): lasso_alloc'd buffers, the context's scratch / result buffers and the generator tables built with it
   std::unordered_map<void*, size_t> mem_sizes; uint64_t mem_live = 0, mem_peak = 0; std::mutex mem_mu;   // bases tables may be built from another host thread (ensure_tab8)
 };
@@ -274,7 +275,7 @@ static uint32_t next_seq(lasso_ctx* c, uint32_t span = 1) {
   // not while a result is still uncollected (lasso_defer_next) or a resident tail holds a block of numbers: the 2^20 numbers of slack cover any such stretch
   if (c->seq > 0xFFF00000u - span && ((!c->pending && !c->tail_active && !c->ahead_active && !c->lay_active) || c->seq > 0xFFFFFF00u - span)) {
     (void)hipStreamSynchronize(c->stream);
-    if (c->pmail_h) memset(c->pmail_h, 0, LASSO_PMAIL_BYTES);
+    if (c->pmail_h) { memset(c->pmail_h, 0, LASSO_PMAIL_BYTES); c->gate_sent = 0; }
     if (c->d_gpoint) (void)hipMemset(c->d_gpoint, 0, LASSO_GPOINT_BYTES);
     if (c->h_tag) memset(c->h_tag, 0, c->small_cap * 48);
     if (c->mail_h) memset(c->mail_h, 0, 96);   // both mailboxes
@@ -300,6 +301,8 @@ static int32_t fetch_small(lasso_ctx* c, size_t count, lasso_fr* out) {
 // bytes: RCCL cannot add curve points) and every rank adds the P partials of each row itself (k_points_reduce_compress) — the north star's "RCCL reduce
 // over xGMI for partial bucket sums".  librccl is resolved with dlopen the first time a communicator is asked for, so single-GPU use never loads it.
 #include <dlfcn.h>
+#include <chrono>
+#include <thread>
 #include <rccl/rccl.h>
 struct RcclApi {
   void* lib = nullptr;
@@ -307,6 +310,7 @@ struct RcclApi {
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;   // optional: only the self-test's time-out path uses it
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 static RcclApi* rccl_api(std::string* why) {
@@ -318,7 +322,7 @@ static RcclApi* rccl_api(std::string* why) {
     else {
       api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.lib, "ncclGetUniqueId"); api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.lib, "ncclCommInitRank");
       api.AllGather = (decltype(api.AllGather))dlsym(api.lib, "ncclAllGather"); api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.lib, "ncclCommDestroy");
-      api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.lib, "ncclGetErrorString");
+      api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.lib, "ncclGetErrorString"); api.CommAbort = (decltype(api.CommAbort))dlsym(api.lib, "ncclCommAbort");
       if (!api.GetUniqueId || !api.CommInitRank || !api.AllGather || !api.CommDestroy || !api.GetErrorString) { err = "librccl lacks an expected symbol"; api.lib = nullptr; }
     }
   }
@@ -354,13 +358,53 @@ int32_t lasso_rccl_init(lasso_ctx* c, int32_t rank, int32_t world, const uint8_t
   ncclUniqueId uid; memcpy(&uid, id, 128);
   ncclComm_t comm = nullptr; ncclResult_t r = a->CommInitRank(&comm, world, uid, rank);
   if (r != ncclSuccess) return fail(c, LASSO_ERR_HIP, std::string("ncclCommInitRank: ") + a->GetErrorString(r));
-  c->rccl_comm = comm; c->rccl_world = world; return 0;
+  c->rccl_comm = comm; c->rccl_world = world; c->rccl_rank = rank; return 0;
 }
 int32_t lasso_rccl_ready(lasso_ctx* c) { return c && c->rccl_comm ? c->rccl_world : 0; }
 // 1 if librccl can be loaded and has the entry points this library uses, 0 otherwise — WITHOUT touching a communicator.  ncclCommInitRank is a collective: a rank
 // that cannot load librccl must say so BEFORE its peers enter it (they would wait for it forever), so the ranks exchange this value first.
 int32_t lasso_rccl_available(void) { return rccl_api(nullptr) ? 1 : 0; }
 int32_t lasso_rccl_shutdown(lasso_ctx* c) { REQUIRE(c, c); (void)hipStreamSynchronize(c->stream); rccl_release(c); return 0; }
+// First contact with a communicator (ncclAllGather with world > 1 had never executed anywhere when this was written): all-gather 1 KB of a rank-dependent
+// pattern on the context's stream and check every byte.  Collective — every rank of the communicator calls it.  The wait is BOUNDED (20 s of polling, not a stream
+// synchronisation): on a time-out the communicator is aborted (ncclCommAbort, when the library has it) and dropped, so the caller falls back instead of hanging.
+int32_t lasso_rccl_selftest(lasso_ctx* c) {
+  REQUIRE(c, c && c->rccl_comm && !c->ahead_active && !c->lay_active && !c->tail_active);
+  RcclApi* a = rccl_api(nullptr);
+  const int world = c->rccl_world;
+  const size_t bytes = 1024;
+  uint8_t* d = nullptr;
+  if (hipMalloc((void**)&d, bytes * (size_t)(world + 1)) != hipSuccess) { (void)hipGetLastError(); return fail(c, LASSO_ERR_OOM, "lasso_rccl_selftest: alloc"); }
+  // the pattern is built from what the receiver can recompute: byte i of rank g = (g * 131 + i * 7 + 1) mod 251; this rank's g comes back in the gathered buffer itself
+  // (slot g must hold g's pattern for EVERY g, which also proves the slots are in rank order)
+  std::vector<uint8_t> mine(bytes), all(bytes * (size_t)world);
+  int32_t rc = 0; std::string msg;
+  const int my_rank = c->rccl_rank;
+  for (size_t i = 0; i < bytes; i++) mine[i] = (uint8_t)(((size_t)my_rank * 131 + i * 7 + 1) % 251);
+  hipEvent_t ev = nullptr;
+  if (hipMemcpyAsync(d, mine.data(), bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess || hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { rc = LASSO_ERR_HIP; msg = "lasso_rccl_selftest: upload"; }
+  if (!rc) {
+    const ncclResult_t r = a->AllGather(d, d + bytes, bytes, ncclUint8, (ncclComm_t)c->rccl_comm, c->stream);
+    if (r != ncclSuccess) { rc = LASSO_ERR_HIP; msg = std::string("lasso_rccl_selftest: ncclAllGather: ") + a->GetErrorString(r); }
+  }
+  if (!rc) {
+    (void)hipEventRecord(ev, c->stream);
+    const auto t0 = std::chrono::steady_clock::now(); bool done = false;
+    while (std::chrono::steady_clock::now() - t0 < std::chrono::seconds(20)) { const hipError_t q = hipEventQuery(ev); if (q == hipSuccess) { done = true; break; } if (q != hipErrorNotReady) break; std::this_thread::sleep_for(std::chrono::microseconds(200)); }
+    if (!done) {
+      rc = LASSO_ERR_HIP; msg = "lasso_rccl_selftest: the 1 KB all-gather did not complete within 20 s (a peer never entered it, or the fabric is down)";
+      if (a->CommAbort) (void)a->CommAbort((ncclComm_t)c->rccl_comm); c->rccl_comm = nullptr; c->rccl_world = 0;   // never destroy a communicator with a collective stuck in it
+    }
+  }
+  if (!rc) {
+    if (hipMemcpy(all.data(), d + bytes, bytes * (size_t)world, hipMemcpyDeviceToHost) != hipSuccess) { rc = LASSO_ERR_HIP; msg = "lasso_rccl_selftest: download"; }
+    else for (int g = 0; g < world && !rc; g++) for (size_t i = 0; i < bytes; i++) if (all[(size_t)g * bytes + i] != (uint8_t)(((size_t)g * 131 + i * 7 + 1) % 251)) { rc = LASSO_ERR_HIP; msg = "lasso_rccl_selftest: slot " + std::to_string(g) + " does not hold rank " + std::to_string(g) + "'s bytes"; break; }
+  }
+  if (ev) (void)hipEventDestroy(ev);
+  if (c->rccl_comm || rc == 0) (void)hipFree(d);   // (after an abort the buffer is left to the driver: a stuck collective may still reference it)
+  (void)hipGetLastError();
+  return rc ? fail(c, rc, msg) : 0;
+}
 // d_recv[g * bytes ..) <- rank g's d_send[0 .. bytes), enqueued on the context's stream (no host synchronisation)
 int32_t lasso_rccl_allgather(lasso_ctx* c, const void* d_send, void* d_recv, size_t bytes) {
   REQUIRE(c, d_send && d_recv && c->rccl_comm);
@@ -448,7 +492,7 @@ int32_t lasso_abort(lasso_ctx* c) {
   if (c->tail_active || c->ahead_active || c->lay_active) { mail_chunks(c->mail_h + 12, LASSO_MAIL_POISON, zero8); post_mail(c, LASSO_MAIL_POISON, zero8); }
   (void)hipStreamSynchronize(c->stream);   // bounded: every device-side wait has the poison check and a wall-clock bail-out
   (void)hipGetLastError();
-  if (c->lay_active && c->pmail_h) memset(c->pmail_h, 0, LASSO_PMAIL_BYTES);
+  if (c->pmail_h) { memset(c->pmail_h, 0, LASSO_PMAIL_BYTES); c->gate_sent = 0; }   // the stream is drained: no gate is left to read or acknowledge anything
   mail_chunks(c->mail_h + 12, 0, zero8); post_mail(c, 0, zero8);
   c->lay_active = false; c->lay_tail = false; c->no_grow = false;
   c->ahead_active = false; c->ahead_bullet = false; c->tail_unstarted = false; c->handover_next = 0;
@@ -650,7 +694,7 @@ static int32_t cubic_eqw_launch_t(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* 
       static const uint32_t pipe = [] { const char* v = getenv("LASSO_LB_PIPELINE"); return (v && v[0] == '0') ? 0u : 1u; }();
       // what runs in front of the round is outside the round's profiling bracket: the wait for the point (one wave), the two factor tables (their own bracket)
       fr_t* const f_hi = (fr_t*)c->d_scratch + part_elems; fr_t* const f_lo = f_hi + ((size_t)1 << g_hi);
-      if (gated && NT == 2) hipLaunchKernelGGL(k_gate_point, dim3(1), dim3(64), 0, c->stream, (const uint32_t*)c->pmail_d, c->d_gpoint, seq, (uint32_t)gate_ell + 2u);
+      if (gated && NT == 2) hipLaunchKernelGGL(k_gate_point, dim3(1), dim3(64), 0, c->stream, (const uint32_t*)c->pmail_d, c->d_gpoint, seq, (uint32_t)gate_ell + 2u, c->pmail_d + LASSO_PMAIL_ACK_WORD); if (gated && NT == 2) c->gate_sent = seq;
       const uint32_t* const gate_gp = gated ? (const uint32_t*)c->d_gpoint : (const uint32_t*)nullptr;
       if ((gbig || eqg) && NT == 2) {
         ProfScope pe(c, LASSO_K_EQ, big_inline ? 32.0 * (((size_t)1 << g_hi) + ((size_t)1 << g_lo)) : 32.0 * half);
@@ -698,7 +742,8 @@ static int32_t cubic_eqw_launch_t(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* 
     // where the wait lives: in a one-wave gate kernel in front of the round (many workgroups), or in the round's own kernel (few: the gate's second launch costs the host more
     // than a handful of spinning workgroups cost the device — profiles/r05_ahead_wait_forms.txt).  LASSO_AHEAD_INKERNEL_WGS: the bound (default 32; 0 = always the gate)
     static const unsigned inkernel_max = [] { const char* v = getenv("LASSO_AHEAD_INKERNEL_WGS"); const long x = v ? atol(v) : 32; return (unsigned)(x < 0 ? 0 : x > 4096 ? 4096 : x); }();
-    const bool inkernel = nx * ny <= inkernel_max;
+    const bool bracketed = ((c->prof_mask >> LASSO_K_CUBIC) & 1u) && !(c->prof_mask & 0x40000000u);   // every launch of the family is between profiling events: the wait must not be inside them -> always the gate
+    const bool inkernel = nx * ny <= inkernel_max && !bracketed;
     const uint32_t* wait_mail = inkernel ? (const uint32_t*)c->mail_d : (const uint32_t*)nullptr;
     if (!inkernel) hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, c->stream, (const uint32_t*)c->mail_d, c->d_gmail, seq, 0u);   // the wait: one wave; the round starts when it ends
     ProfScope ps(c, LASSO_K_CUBIC, 48.0 * n * (2.0 * ncirc + 1.0));   // the events bracket the round's kernel, not the gate's wait for the host
@@ -776,10 +821,14 @@ int32_t lasso_rounds_ahead_ok(lasso_ctx* c) { static const bool off = [] { const
 // result of the first of the log2(2q) rounds is pending afterwards (lasso_result_wait, 2*ncirc values: (q(0), q_inf) per circuit).
 // next: posts a challenge; pending: the next round's sums, or after the last round the 2*ncirc bound heads (A_0.., B_0..).
 // The arrays in device memory are NOT updated (nothing reads a layer's arrays after its sumcheck).
-static int32_t cubic_tail_begin_impl(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n, const lasso_fr* r, const EqInline* eqi, bool ahead, int gate_ell = -1);
+static int32_t cubic_tail_begin_impl(lasso_ctx* c, uint32_t m_stop, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n, const lasso_fr* r, const EqInline* eqi, bool ahead, int gate_ell = -1);
+// lasso_tail_handover_next's one-shot setting is consumed by the NEXT tail entry point whatever its outcome: every public wrapper takes it first thing, before any argument check can
+// return (a REQUIRE in a wrapper used to leave it armed for the next, unrelated tail)
+static uint32_t take_handover(lasso_ctx* c) { if (!c) return 0; const uint32_t m = c->handover_next; c->handover_next = 0; return m; }
 int32_t lasso_sumcheck_cubic_tail_begin(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n, const lasso_fr* r) {
+  const uint32_t ho = take_handover(c);
   REQUIRE(c, d_E);
-  return cubic_tail_begin_impl(c, d_A, d_B, ncirc, d_E, n, r, nullptr, false);
+  return cubic_tail_begin_impl(c, ho, d_A, d_B, ncirc, d_E, n, r, nullptr, false);
 }
 static bool make_eq_inline(const lasso_fr* point, uint32_t ell, const lasso_fr* scale, EqInline& Q) {
   if (ell > 14 || (ell && !point)) return false;
@@ -801,14 +850,15 @@ int32_t lasso_sumcheck_cubic_eqw2_begin_eq(lasso_ctx* c, lasso_fr* const* d_A, l
 }
 // lasso_sumcheck_cubic_tail_begin(.., r = NULL) without a table: the resident kernel derives E = *scale * EqPolynomial(point[0..ell)).evals(), 2^ell = n/2 <= capacity, itself
 int32_t lasso_sumcheck_cubic_tail_begin_eq(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, size_t n, const lasso_fr* point, uint32_t ell, const lasso_fr* scale) {
+  const uint32_t ho = take_handover(c);
   REQUIRE(c, n >= 2 && ((size_t)1 << ell) == n / 2 && ell <= 9);
   EqInline Q; if (!make_eq_inline(point, ell, scale, Q)) return fail(c, LASSO_ERR_INVALID, "lasso_sumcheck_cubic_tail_begin_eq: bad point");
-  return cubic_tail_begin_impl(c, d_A, d_B, ncirc, nullptr, n, nullptr, &Q, false);
+  return cubic_tail_begin_impl(c, ho, d_A, d_B, ncirc, nullptr, n, nullptr, &Q, false);
 }
 extern "C++" {
 template <class TM>
-static int32_t cubic_tail_begin_t(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n, const lasso_fr* r, const EqInline* eqi, bool ahead, int gate_ell) {
-  const uint32_t m_stop = c->handover_next ? c->handover_next : 1u; c->handover_next = 0;   // consumed by this call, whatever its outcome
+static int32_t cubic_tail_begin_t(lasso_ctx* c, uint32_t m_stop_arg, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n, const lasso_fr* r, const EqInline* eqi, bool ahead, int gate_ell) {
+  const uint32_t m_stop = m_stop_arg ? m_stop_arg : 1u;   // the caller's take_handover(): explicit, not sticky context state
   const bool gated = gate_ell >= 0;   // the whole layer enqueued ahead of its eq point, possibly behind the previous layer's (still active) tail: the point comes through k_gate_point
   REQUIRE(c, d_A && d_B && (d_E || eqi || gated) && ncirc >= 1 && ncirc <= LASSO_MAX_PTRS && n >= ((r || ahead) ? 4u : 2u) && (n & (n - 1)) == 0 && (ahead || gated || !c->pending) && (gated || !c->tail_active) && !c->defer_next && !c->ahead_active && !c->lay_active);
   const size_t q = (r || ahead) ? n / 4 : n / 2;
@@ -820,7 +870,7 @@ static int32_t cubic_tail_begin_t(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* 
   // workgroup = capacity: 256 threads / 74 KB of LDS up to 256 indices per circuit, 512 threads / 147 KB above
 #define LAUNCH_CTAIL(B_, Q_, I_, TE_, R_, EQ_) hipLaunchKernelGGL((k_cubic_tail<B_, Q_, I_, TM, TE_>), dim3(ncirc), dim3(Q_), 0, c->stream, A, B, (const fr_t*)d_E, (uint32_t)q, R_, (const uint32_t*)c->mail_d, c->d_counters, RES(c), seq0, EQ_, m_stop, ahead ? 1u : 0u)
   if (gated) {
-    hipLaunchKernelGGL(k_gate_point, dim3(1), dim3(64), 0, c->stream, (const uint32_t*)c->pmail_d, c->d_gpoint, seq0, (uint32_t)gate_ell + 2u);
+    hipLaunchKernelGGL(k_gate_point, dim3(1), dim3(64), 0, c->stream, (const uint32_t*)c->pmail_d, c->d_gpoint, seq0, (uint32_t)gate_ell + 2u, c->pmail_d + LASSO_PMAIL_ACK_WORD); c->gate_sent = seq0;
     EqInlineMem M; M.gp = c->d_gpoint; M.seq = seq0; M.ell = (uint32_t)gate_ell;
     if (q <= 256) LAUNCH_CTAIL(false, 256, true, EqInlineMem, fr_zero(), M); else LAUNCH_CTAIL(false, 512, true, EqInlineMem, fr_zero(), M);
     HIPCHK(c, hipGetLastError());
@@ -837,8 +887,8 @@ static int32_t cubic_tail_begin_t(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* 
   return 0;
 }
 }   // extern "C++"
-static int32_t cubic_tail_begin_impl(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n, const lasso_fr* r, const EqInline* eqi, bool ahead, int gate_ell) {
-  return ncirc <= 8 ? cubic_tail_begin_t<MutPtrTable8>(c, d_A, d_B, ncirc, d_E, n, r, eqi, ahead, gate_ell) : cubic_tail_begin_t<MutPtrTable>(c, d_A, d_B, ncirc, d_E, n, r, eqi, ahead, gate_ell);
+static int32_t cubic_tail_begin_impl(lasso_ctx* c, uint32_t m_stop, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n, const lasso_fr* r, const EqInline* eqi, bool ahead, int gate_ell) {
+  return ncirc <= 8 ? cubic_tail_begin_t<MutPtrTable8>(c, m_stop, d_A, d_B, ncirc, d_E, n, r, eqi, ahead, gate_ell) : cubic_tail_begin_t<MutPtrTable>(c, m_stop, d_A, d_B, ncirc, d_E, n, r, eqi, ahead, gate_ell);
 }
 // ---- A LAYER enqueued ahead of its eq point (round 5).  Between two layers of a grand-product argument the device used to idle for the host's last rounds, the layer's closing
 // Fiat-Shamir step AND the launch + dispatch of the next layer's first kernel(s) (20-40 us per transition, ~30 transitions per proof).  With these entry points the next layer's
@@ -847,10 +897,15 @@ static int32_t cubic_tail_begin_impl(lasso_ctx* c, lasso_fr* const* d_A, lasso_f
 // gate that waits for the point; lasso_point_post delivers point and scale and turns the launch into the context's pending result (and active tail), exactly as if the plain entry
 // point had been called then; lasso_point_cancel ends the enqueued kernels without a result (a layer whose shape turned out different).  Nothing may grow while a tail is resident:
 // LASSO_ERR_UNSUPPORTED when a buffer would have to (the caller takes the plain path after the layer).
+// the ONE mailbox area is free when the last gate launched has ended (it acknowledges with its sequence number); until then a new layer may not be enqueued ahead — its
+// post / cancel would overwrite a message that gate has not read yet, and the gate would spin to its 5 s bail-out.  prover.hpp never gets here with a gate in
+// flight (a layer's first result is collected before the next one is enqueued); the entry points enforce it for every other caller: LASSO_ERR_UNSUPPORTED = take the plain path.
+static bool gate_free(lasso_ctx* c) { return !c->gate_sent || __atomic_load_n(c->pmail_h + LASSO_PMAIL_ACK_WORD, __ATOMIC_ACQUIRE) == c->gate_sent; }
 int32_t lasso_layer_ahead_ok(lasso_ctx* c) { static const bool off = [] { const char* v = getenv("LASSO_LAYER_AHEAD"); return v && v[0] == '0'; }(); return c && !off && c->pmail_d && c->d_gpoint ? 1 : 0; }
 int32_t lasso_sumcheck_cubic_eqw2_begin_eq_ahead(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, lasso_fr* d_E_out, size_t n, uint32_t ell) {
   REQUIRE(c, d_A && d_B && d_E_out && ncirc >= 1 && ncirc <= LASSO_MAX_PTRS && n >= 2 && (n & (n - 1)) == 0 && ell < 48 && ((size_t)1 << ell) == n / 2 && !c->lay_active && !c->ahead_active && !c->defer_next);
   if (!lasso_layer_ahead_ok(c) || n / 2 <= CUBIC_SMALL_Q || ell > 32 || ell > LASSO_POINT_MAX) return fail(c, LASSO_ERR_UNSUPPORTED, "lasso_sumcheck_cubic_eqw2_begin_eq_ahead: tables of 2^7 .. 2^32 entries only");
+  if (!gate_free(c)) return fail(c, LASSO_ERR_UNSUPPORTED, "lasso_sumcheck_cubic_eqw2_begin_eq_ahead: the previous point gate has not consumed its message yet");
   uint32_t seq, groups;
   c->no_grow = true;
   const int32_t rc = cubic_eqw_launch(c, d_A, d_B, ncirc, d_E_out, n, nullptr, 2, &seq, nullptr, &groups, false, nullptr, (int)ell);
@@ -862,10 +917,12 @@ int32_t lasso_sumcheck_cubic_eqw2_begin_eq_ahead(lasso_ctx* c, lasso_fr* const* 
   return 0;
 }
 int32_t lasso_sumcheck_cubic_tail_begin_eq_ahead(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, size_t n, uint32_t ell) {
+  const uint32_t ho = take_handover(c);
   REQUIRE(c, n >= 2 && ell <= 9 && ((size_t)1 << ell) == n / 2);
-  if (!lasso_layer_ahead_ok(c)) { c->handover_next = 0; return fail(c, LASSO_ERR_UNSUPPORTED, "lasso_sumcheck_cubic_tail_begin_eq_ahead: switched off"); }
+  if (!lasso_layer_ahead_ok(c)) return fail(c, LASSO_ERR_UNSUPPORTED, "lasso_sumcheck_cubic_tail_begin_eq_ahead: switched off");
+  if (!gate_free(c)) return fail(c, LASSO_ERR_UNSUPPORTED, "lasso_sumcheck_cubic_tail_begin_eq_ahead: the previous point gate has not consumed its message yet");
   c->no_grow = true;
-  const int32_t rc = cubic_tail_begin_impl(c, d_A, d_B, ncirc, nullptr, n, nullptr, nullptr, false, (int)ell);
+  const int32_t rc = cubic_tail_begin_impl(c, ho, d_A, d_B, ncirc, nullptr, n, nullptr, nullptr, false, (int)ell);
   c->no_grow = false;
   if (rc == LASSO_ERR_UNSUPPORTED) return fail(c, rc, "lasso_sumcheck_cubic_tail_begin_eq_ahead: a buffer would have to grow while kernels are in flight");
   return rc;
@@ -907,8 +964,9 @@ int32_t lasso_point_cancel(lasso_ctx* c) {
 // The resident tail enqueued AHEAD of the challenge it binds first (n = 4q): legal while the previous round's result is pending; the first lasso_sumcheck_cubic_tail_next
 // posts that challenge and makes the first round's sums the pending result.
 int32_t lasso_sumcheck_cubic_tail_begin_ahead(lasso_ctx* c, lasso_fr* const* d_A, lasso_fr* const* d_B, uint32_t ncirc, const lasso_fr* d_E, size_t n) {
+  const uint32_t ho = take_handover(c);
   REQUIRE(c, d_E);
-  return cubic_tail_begin_impl(c, d_A, d_B, ncirc, d_E, n, nullptr, nullptr, true);
+  return cubic_tail_begin_impl(c, ho, d_A, d_B, ncirc, d_E, n, nullptr, nullptr, true);
 }
 // The next lasso_sumcheck_cubic_tail_begin* stops when its arrays are down to m_stop elements each (a power of two, 2 <= m_stop <= 128, below the arrays' length at the first
 // round) and its LAST publication is the arrays instead of the heads: 2 * ncirc * m_stop values, A_0[0..m_stop), A_1[..], .., B_0[..], ...  m_stop = 1 or 0: the heads.
@@ -920,7 +978,8 @@ int32_t lasso_tail_handover_next(lasso_ctx* c, uint32_t m_stop) {
 // (as lasso_sumcheck_linear_eqw_round, without the unused third slot); after the last challenge the heads out[k] = polys_k[0] (alpha values).
 // d_src is only read (r == NULL: arrays of length n = 2q; otherwise bound with r first, n = 4q).  Challenges go through lasso_sumcheck_cubic_tail_next.
 int32_t lasso_sumcheck_linear_tail_begin(lasso_ctx* c, const lasso_fr* const* d_src, uint32_t alpha, const lasso_fr* d_E, size_t n, const lasso_fr* r) {
-  REQUIRE(c, d_src && d_E && alpha >= 1 && alpha <= LASSO_MAX_PTRS && n >= (r ? 4u : 2u) && (n & (n - 1)) == 0 && !c->pending && !c->tail_active && !c->defer_next && !c->handover_next && !c->ahead_active);
+  const uint32_t ho = take_handover(c);   // the linear tail has no hand-over form: refused, and the one-shot setting does not survive the refusal
+  REQUIRE(c, d_src && d_E && alpha >= 1 && alpha <= LASSO_MAX_PTRS && n >= (r ? 4u : 2u) && (n & (n - 1)) == 0 && !c->pending && !c->tail_active && !c->defer_next && !ho && !c->ahead_active);
   const size_t q = r ? n / 4 : n / 2;
   REQUIRE(c, q >= 1 && q <= CUBIC_TAIL_Q);
   PtrTable Src; for (uint32_t i = 0; i < alpha; i++) { REQUIRE(c, d_src[i]); Src.p[i] = (const fr_t*)d_src[i]; }
@@ -1448,6 +1507,14 @@ static const niels29* ensure_tab8(lasso_ctx* c, const lasso_bases* cb, uint32_t 
   b->d_tab8[w8] = t;
   return t;
 }
+// the byte-multiple tables the commitments of small scalars read (k_msm_rows8 / k_msm_rows8w), built NOW instead of inside the first commitment that uses them: a caller that times
+// `commit` (benches/bench.rs:54-66) prepares its generators first.  byte_windows = 1 (values < 2^8) or 2 (< 2^16).  A table that cannot be allocated is not an error (the bucket kernel serves).
+int32_t lasso_bases_prepare(lasso_ctx* c, const lasso_bases* b, uint32_t byte_windows) {
+  REQUIRE(c, b && byte_windows >= 1 && byte_windows <= 2 && !c->ahead_active && !c->lay_active && !c->tail_active);
+  if (!msm_rows8_enabled()) return 0;
+  for (uint32_t w = 0; w < byte_windows; w++) if (!ensure_tab8(c, b, w)) break;
+  return 0;
+}
 
 // chunks per row.  Measured on MI355X (profiles/): the bucket kernel is VALU-issue-bound even at one wave per SIMD (the 81 independent
 // multiply-adds of a field product pipeline back to back), so extra workgroups beyond one per CU only multiply the fixed per-workgroup
@@ -1495,6 +1562,9 @@ static size_t msm_pts_bytes(size_t rows, size_t n_cols) {
   uint32_t ipc; const size_t kd = rows <= MSM_SMALL_ROWS ? msm_direct_chunks(rows, n_cols, &ipc) : 0, kb = msm_chunks(rows, n_cols, MSM_WINDOWS);
   return (rows * (kd > kb ? kd : kb) + 2 * rows + 4) * sizeof(pt29) + 512;
 }
+// round 6: the few-row MSMs hand their points over as tagged elements (msm_direct_finish) when the context is in tagged mode; LASSO_MSM_TAGGED=0: the flag protocol (A/B switch)
+static bool msm_tagged(lasso_ctx* c) { static const bool off = [] { const char* v = getenv("LASSO_MSM_TAGGED"); return v && v[0] == '0'; }(); return c->tagged && !off; }
+#define MSM_RES(c) (msm_tagged(c) ? (ed_point*)(c)->d_tag : (ed_point*)(c)->d_small), (c)->d_counters + LASSO_MAX_PTRS + 8, (msm_tagged(c) ? LASSO_TAGGED : (c)->d_flag)
 // mode 0: d_scal = canonical integers; 1: field elements in memory (Montgomery) form, converted by the kernel; 2: as 1 with the first n_cols - 2 columns
 // multiplied by *scale and the last two columns = tail[0], tail[1] (k_msm_direct<MODE>)
 static int32_t run_msm_direct(lasso_ctx* c, const uint8_t* d_scal, size_t row_stride, size_t rows, size_t n_cols, const MsmColMap& cm, const lasso_bases* b, uint8_t* scratch_after, lasso_point* out,
@@ -1506,7 +1576,7 @@ static int32_t run_msm_direct(lasso_ctx* c, const uint8_t* d_scal, size_t row_st
     ProfScope ps(c, LASSO_K_MSM_DIRECT, (double)rows * n_cols * 32, msm_ref_adds(rows, n_cols, FR_MODULUS_BITS), false, (double)rows * n_cols * windows);
     const fr_t z = fr_zero();
 #define LAUNCH_DIRECT(M, WB_, TAB_, SC, T0, T1) hipLaunchKernelGGL((k_msm_direct<M, WB_>), dim3((unsigned)K, (unsigned)rows), dim3(MSM_THREADS), 0, c->stream, (const uint32_t*)d_scal, row_stride / 4, (uint32_t)n_cols, ipc, cm, \
-                       (const niels29*)TAB_, b->n, (pt29*)scratch_after, (ed_point*)c->d_small, c->d_counters + LASSO_MAX_PTRS + 8, c->d_flag, seq, SC, T0, T1, ps.counter(), sstride, soffset)
+                       (const niels29*)TAB_, b->n, (pt29*)scratch_after, MSM_RES(c), seq, SC, T0, T1, ps.counter(), sstride, soffset)
     if (w8) {
       if (mode == 0) LAUNCH_DIRECT(0, 8, b->d_mult8, z, z, z);
       else if (mode == 1) LAUNCH_DIRECT(1, 8, b->d_mult8, z, z, z);
@@ -1518,7 +1588,7 @@ static int32_t run_msm_direct(lasso_ctx* c, const uint8_t* d_scal, size_t row_st
     }
   }
   HIPCHK(c, hipGetLastError());
-  return wait_flag(c, seq, rows * (sizeof(ed_point) / sizeof(fr_t)), (lasso_fr*)out);
+  return wait_flag(c, seq, rows * (sizeof(ed_point) / sizeof(fr_t)), (lasso_fr*)out, msm_tagged(c));
 }
 static bool msm_direct_fused() { static const bool on = [] { const char* v = getenv("LASSO_MSM_FUSED"); return !(v && v[0] == '0'); }(); return on; }   // A/B switch: conversions and the bullet fold inside the MSM launch
 // d_rows_out (device, rows x sizeof(pt29)): leave the row sums on the device in the kernels' own point form instead of handing them to the host —
@@ -1700,13 +1770,13 @@ static int32_t bullet_round_fused(lasso_ctx* c, const lasso_bases* b, size_t n, 
     const fr_t z = fr_zero();
 #define LAUNCH_BULLET(FOLD_, WB_, TAB_, AO, BO, WO, U, UI) hipLaunchKernelGGL((k_bullet_msm<FOLD_, WB_>), dim3((unsigned)K + 1, 2), dim3(MSM_THREADS), 0, c->stream, (const fr_t*)d_a_in, (const fr_t*)d_b_in, (const fr_t*)d_w_in, \
                                  (fr_t*)AO, (fr_t*)BO, (fr_t*)WO, (uint32_t)nk, (uint32_t)n, U, UI, to_fr(blinds), to_fr(blinds + 1), ipc, (const niels29*)TAB_, b->n, (pt29*)c->d_scratch, \
-                                 (ed_point*)c->d_small, c->d_counters + LASSO_MAX_PTRS + 8, c->d_flag, seq, ps.counter(), world, rank, (const uint32_t*)(ahead ? c->mail_d : nullptr), c->d_gmail)
+                                 MSM_RES(c), seq, ps.counter(), world, rank, (const uint32_t*)(ahead ? c->mail_d : nullptr), c->d_gmail)
     if (fold) { const fr_t uu = ahead ? z : to_fr(u), ui = ahead ? z : to_fr(u_inv); if (w8) LAUNCH_BULLET(true, 8, b->d_mult8, d_a_out, d_b_out, d_w_out, uu, ui); else LAUNCH_BULLET(true, 4, b->d_mult, d_a_out, d_b_out, d_w_out, uu, ui); }
     else { if (w8) LAUNCH_BULLET(false, 8, b->d_mult8, nullptr, nullptr, nullptr, z, z); else LAUNCH_BULLET(false, 4, b->d_mult, nullptr, nullptr, nullptr, z, z); }
   }
   HIPCHK(c, hipGetLastError());
-  if (ahead) { c->ahead_active = true; c->ahead_bullet = true; c->ahead_seq = seq; return 0; }
-  return wait_flag(c, seq, 2 * (sizeof(ed_point) / sizeof(fr_t)), (lasso_fr*)out);
+  if (ahead) { c->ahead_active = true; c->ahead_bullet = true; c->ahead_seq = seq; c->ahead_tagged = msm_tagged(c); return 0; }
+  return wait_flag(c, seq, 2 * (sizeof(ed_point) / sizeof(fr_t)), (lasso_fr*)out, msm_tagged(c));
 }
 // slab mode of the opening (include/lasso_hip.h): this rank's share of L and R over its residue class of the generators
 int32_t lasso_bullet_round_slab(lasso_ctx* c, const lasso_bases* b, size_t n, uint32_t world, uint32_t rank, const lasso_fr* d_a_in, const lasso_fr* d_b_in, const lasso_fr* d_w_in, lasso_fr* d_a_out,
@@ -1772,7 +1842,7 @@ int32_t lasso_bullet_post(lasso_ctx* c, const lasso_fr* u, const lasso_fr* u_inv
   mail_chunks(c->mail_h + 12, c->ahead_seq, (const uint32_t*)u_inv);
   post_mail(c, c->ahead_seq, (const uint32_t*)u);
   c->ahead_active = false;
-  c->pending = true; c->pending_seq = c->ahead_seq; c->pending_count = 2 * (sizeof(ed_point) / sizeof(fr_t)); c->pending_tagged = false; c->pending_groups = 1; c->pending_K = 0;
+  c->pending = true; c->pending_seq = c->ahead_seq; c->pending_count = 2 * (sizeof(ed_point) / sizeof(fr_t)); c->pending_tagged = c->ahead_tagged; c->pending_groups = 1; c->pending_K = 0;
   return 0;
 }
 int32_t lasso_bullet_fold(lasso_ctx* c, lasso_fr* d_a, lasso_fr* d_b, size_t nk, const lasso_fr* d_w, size_t nw, lasso_fr* d_w_out, const lasso_fr* u, const lasso_fr* u_inv) {

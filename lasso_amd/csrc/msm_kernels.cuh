@@ -76,11 +76,20 @@ __global__ void __launch_bounds__(256) k_fr_to_canonical(const fr_t* __restrict_
 // fetched while the current one is added), a segmented LDS tree joins the threads of each digit, and sum_d d*B_d is taken through the four
 // bit planes S_b = sum_{d: bit b} B_d (three tree levels on 32 lanes) and one Horner chain 2(2(2 S_3 + S_2) + S_1) + S_0.
 // phase timing for tools/msm_phase_bench.hip only (compiled out of the library): workgroup (0,0) stamps the 100 MHz wall clock at phase boundaries
-#ifdef MSM_PHASE_CLOCK
+// MSM_PHASE_LOG (tools/bullet_phase_bench.hip): EVERY workgroup stamps, 32 slots each, so that the launch's critical path — which runs through whichever workgroup arrives last —
+// can be read off afterwards; slots 16.. / 24.. are the levels of the workgroup tree / the cross-workgroup tree (MSM_TREE_STAMP).
+#if defined(MSM_PHASE_LOG)
+#define MSM_PHASE_LOG_WGS 1024
+__device__ uint64_t msm_phase_log[MSM_PHASE_LOG_WGS * 32];
+#define MSM_STAMP(k) do { if (threadIdx.x == 0) msm_phase_log[((blockIdx.y * gridDim.x + blockIdx.x) & (MSM_PHASE_LOG_WGS - 1)) * 32 + (k)] = wall_clock64(); } while (0)
+#define MSM_TREE_STAMP(base, lvl) do { if ((base) >= 0 && (lvl) < 8) MSM_STAMP((base) + (lvl)); } while (0)
+#elif defined(MSM_PHASE_CLOCK)
 __device__ uint64_t msm_phase_clock[32];
 #define MSM_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) msm_phase_clock[k] = wall_clock64(); } while (0)
+#define MSM_TREE_STAMP(base, lvl) do { } while (0)
 #else
 #define MSM_STAMP(k) do { } while (0)
+#define MSM_TREE_STAMP(base, lvl) do { } while (0)
 #endif
 // exact count of the mixed additions a launch executes (bench.py roofline_msm): only when the host passes a counter (the untimed fully-profiled step)
 __device__ __forceinline__ void msm_count_adds(uint32_t* digit_count, uint32_t mine) {
@@ -264,7 +273,7 @@ __device__ __forceinline__ uint32_t msm_phys_col(const MsmColMap& m, uint32_t ro
 __device__ __forceinline__ void tree_wave_sync() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
 #ifdef MSM_COOP6_V1
 // round 3's pass: 42 sextets over the workgroup, every lane forms all six linear combinations, four workgroup barriers (kept for A/B: -DMSM_COOP6_V1)
-__device__ __forceinline__ void msm_coop_tree(pt29* pts, fe29 (*st4)[4], uint32_t live, const fe29& d2_unused) {
+__device__ __forceinline__ void msm_coop_tree(pt29* pts, fe29 (*st4)[4], uint32_t live, const fe29& d2_unused, int stamp_base = -1) {
   fe29* st = &st4[0][0];
   const uint32_t t = threadIdx.x, g = t / 6u, c = t - g * 6u;
   constexpr uint32_t GROUPS = MSM_THREADS / 6;   // 42
@@ -302,7 +311,7 @@ __device__ __forceinline__ void msm_coop_tree(pt29* pts, fe29 (*st4)[4], uint32_
 // own LDS operations kept in order, not a workgroup barrier; the linear step between the two product layers is a lane step of its own (pt_coop_form: one combination per lane
 // instead of all six in every lane) through a second exchange buffer.  Measured (tools/msm_phase_bench.hip, BN254 build): a pass 4.8 -> 2.5 us, DESIGN 6.11.  Workgroup barriers
 // remain after the levels whose results the next level reads from another wave (more than 10 additions) and after the plain levels.
-__device__ __forceinline__ void msm_coop_tree(pt29* pts, fe29 (*st4)[4], uint32_t live, const fe29& d2_unused) {
+__device__ __forceinline__ void msm_coop_tree(pt29* pts, fe29 (*st4)[4], uint32_t live, const fe29& d2_unused, int stamp_base = -1) {
   fe29* st = &st4[0][0]; fe29* sf = st + MSM_THREADS;   // the exchange buffer is two buffers of MSM_THREADS values in this build (MSM_ST_ROWS)
   const uint32_t t = threadIdx.x, wv = t >> 6, ln = t & 63u, q = ln / 6u, c = ln - q * 6u, g = wv * 10u + q;
   constexpr uint32_t GROUPS = (MSM_THREADS / 64) * 10;   // 40
@@ -314,6 +323,7 @@ __device__ __forceinline__ void msm_coop_tree(pt29* pts, fe29 (*st4)[4], uint32_
       // elements, other projective representatives than the sextets' only in the order of the field operations: the wire bytes do not change
       if (t < s && t + s < live) pts[t] = pt_add(pts[t], pts[t + s], d2_unused);
       __syncthreads();
+      MSM_TREE_STAMP(stamp_base, 31 - __clz(s));
       continue;
     }
     for (uint32_t i0 = 0; i0 < s; i0 += GROUPS) {
@@ -331,6 +341,7 @@ __device__ __forceinline__ void msm_coop_tree(pt29* pts, fe29 (*st4)[4], uint32_
       }
       if (s > 10u || i0 + GROUPS < s) __syncthreads(); else tree_wave_sync();   // uniform over the workgroup
     }
+    MSM_TREE_STAMP(stamp_base, 31 - __clz(s));
   }
 }
 #endif  // MSM_COOP6_V1
@@ -346,8 +357,8 @@ __device__ __forceinline__ void tree_wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #endif
 }
-__device__ __forceinline__ void msm_coop_tree(pt29* pts, fe29 (*st)[4], uint32_t live, const fe29& d2) {
-  (void)d2;   // the curve constant enters as two small multipliers (fe29.cuh pt_coop4_stage1)
+__device__ __forceinline__ void msm_coop_tree(pt29* pts, fe29 (*st)[4], uint32_t live, const fe29& d2, int stamp_base = -1) {
+  (void)d2; (void)stamp_base;   // the curve constant enters as two small multipliers (fe29.cuh pt_coop4_stage1)
   const uint32_t t = threadIdx.x, c = t & 3u, g = t >> 2;
   uint32_t p2 = 1; while (p2 < live) p2 <<= 1;
   for (uint32_t s = p2 >> 1; s > 0; s >>= 1) {
@@ -356,13 +367,14 @@ __device__ __forceinline__ void msm_coop_tree(pt29* pts, fe29 (*st)[4], uint32_t
       const bool act = i < s && i + s < live;
       if (act) st[g][c] = pt_coop4_stage1(pts[i], pts[i + s], c);
       tree_wave_sync();
-      if (act) reinterpret_cast<fe29*>(&pts[i])[c] = pt_coop4_stage2(st[g][0], st[g][1], st[g][2], st[g][3], c);   // pt29 = {X, Y, T, Z}: role c owns coordinate c
+      if (act) reinterpret_cast<fe29*>(&pts[i])[c] = pt_coop4_stage2p(&st[g][0], c);   // pt29 = {X, Y, T, Z}: role c owns coordinate c
 #ifdef LASSO_TREE_BARRIERS
       __syncthreads();
 #else
       if (s > 16) __syncthreads(); else tree_wave_sync();   // s is uniform over the workgroup: every thread takes the same path
 #endif
     }
+    MSM_TREE_STAMP(stamp_base, 31 - __clz(s));   // slot = log2 of the level's addition count
   }
 }
 #endif  // LASSO_BN254
@@ -484,13 +496,47 @@ __device__ __forceinline__ void msm_recode(const uint32_t* s, uint32_t* dst) {
 }
 // items [it0, it1) of a row (one item = one (column, window); sb holds the recoded scalars of columns col0..): one mixed addition per non-zero digit
 // phys (optional, LDS): table index of every staged column (phys[c - col0]); otherwise the column map decides
+// The last, partly filled pass of a chunk (round 6).  A chunk of 544 items is two full passes of the workgroup and 32 items more; as a third pass of the loop below those 32
+// items cost wave 0 a third mixed addition in a row — 2.65 us on the launch's critical path for an eighth of a wave's worth of work (profiles/r06_bullet_phase_curve25519_before.txt:
+// accumulate 12.4 us).  With `left` the loop stops at the last full pass; the <= 64 entries that remain are fetched FIRST (their latency hides under the full passes) and handed
+// back, and msm_coop_leftover adds entry j to the partial sum of lane j with FOUR lanes per addition after the sums are in LDS: one tree level's time (1.2 us).  Edwards build only.
+struct MsmLeft { niels29 e; uint32_t valid = 0, rem = 0; };
+#ifndef LASSO_BN254
+#define MSM_LEFT_MAX 64u
+__device__ __forceinline__ void msm_coop_leftover(pt29* pts, fe29 (*st)[4], fe29 (*ln)[3], uint32_t* lval, const MsmLeft& L) {   // all threads; pts[t] already holds the lanes' sums (barrier passed)
+  if (!L.rem) return;   // block-uniform
+  const uint32_t t = threadIdx.x, c = t & 3u, g = t >> 2;
+  if (t < L.rem) { ln[t][0] = L.e.ypx; ln[t][1] = L.e.ymx; ln[t][2] = L.e.t2d; lval[t] = L.valid; }
+  __syncthreads();
+  const bool act = g < L.rem && lval[g] != 0;
+  if (act) st[g][c] = pt_coop4_madd_stage1(pts[g], &ln[g][0], c);
+  tree_wave_sync();
+  if (act) reinterpret_cast<fe29*>(&pts[g])[c] = pt_coop4_stage2p(&st[g][0], c);
+  __syncthreads();
+}
+#endif
 template <int WB>
 __device__ __forceinline__ pt29 msm_direct_accumulate(const uint32_t* sb, uint32_t col0, uint32_t it0, uint32_t it1, const MsmColMap& cm, uint32_t row, const niels29* __restrict__ mult, size_t tn,
-                                                      uint32_t* digit_count = nullptr, const uint32_t* phys = nullptr) {
+                                                      uint32_t* digit_count = nullptr, const uint32_t* phys = nullptr, MsmLeft* left = nullptr) {
   typedef MsmD<WB> D;
   const uint32_t t = threadIdx.x;
   pt29 B = pt_identity();
   niels29 cur; bool have = false; uint32_t nadds = 0;
+#ifndef LASSO_BN254
+  if (left) {
+    const uint32_t span = it1 - it0, rem = span % MSM_THREADS;
+    if (rem != 0 && rem <= MSM_LEFT_MAX && span > MSM_THREADS) {   // block-uniform
+      left->rem = rem; it1 -= rem;
+      const uint32_t it = it1 + t;
+      bool valid = t < rem; int32_t d = 0; uint32_t c = 0, w = 0;
+      if (valid) { c = it >> D::LOGW; w = it & (D::WINDOWS - 1u); d = (int32_t)((sb[(c - col0) * 8 + w / D::PER_WORD] >> (WB * (w % D::PER_WORD))) & D::DMASK) - (int32_t)D::MULTS; valid = d != 0; }
+      const uint32_t m = d < 0 ? (uint32_t)(-d) : (uint32_t)d;
+      const size_t idx = valid ? ((size_t)w * D::MULTS + (m - 1)) * tn + (phys ? phys[c - col0] : msm_phys_col(cm, row, c)) : 0;
+      if (t < rem) left->e = niels_cond_neg(mult[idx], d < 0);   // only the first rem lanes fetch (<= one wave's worth): in flight while the full passes run
+      left->valid = valid ? 1u : 0u; nadds += valid;
+    }
+  }
+#endif
   for (uint32_t base = it0; base < it1; base += MSM_THREADS) {
     const uint32_t it = base + t;
     bool valid = it < it1; int32_t d = 0; uint32_t c = 0, w = 0;
@@ -517,23 +563,42 @@ __device__ __forceinline__ pt29 msm_direct_accumulate(const uint32_t* sb, uint32
 // then the row's sum to the host-mapped result buffer in ark's Montgomery limbs; the workgroup that completes the last row raises the flag.
 // counters[0..rows) = per-row arrival tickets, counters[16] = finished rows.
 __device__ __forceinline__ void msm_direct_finish(pt29* pts, fe29 (*st)[4], uint32_t* is_last, const pt29& B, uint32_t K, uint32_t row, pt29* __restrict__ partial, ed_point* __restrict__ out_mont,
-                                                  uint32_t* counters, uint32_t* flag, uint32_t seq) {
+                                                  uint32_t* counters, uint32_t* flag, uint32_t seq, const MsmLeft* left = nullptr, fe29 (*ln)[3] = nullptr, uint32_t* lval = nullptr) {
   const fe29 d2 = fe_d2();
   const uint32_t t = threadIdx.x;
   pts[t] = B;
   __syncthreads();
-  msm_coop_tree(pts, st, MSM_THREADS, d2);
+#ifndef LASSO_BN254
+  if (left) msm_coop_leftover(pts, st, ln, lval, *left);
+#endif
+  MSM_STAMP(13);
+  msm_coop_tree(pts, st, MSM_THREADS, d2, 16);
   MSM_STAMP(3);
   if (K > 1) {
+    // round 6: the partial leaves as 18 write-through (sc1) 8-byte stores by 18 lanes of wave 0 — one store instruction instead of 36 by one lane — and what orders it before the
+    // ticket is the wave's own `s_waitcnt vmcnt(0)`, not an L2 write-back (cdna_hip_programming.md §6 G16, the sc1 form: 0.3-1.0 us cheaper per episode than release + plain stores;
+    // the reader keeps its agent-scope acquire + plain loads).  LASSO_MSM_PLAIN_PARTIALS (compile time): the round-5 form.
+#ifndef LASSO_MSM_PLAIN_PARTIALS
+    static_assert(sizeof(pt29) == 144, "pt29 = 18 x 8 bytes");
+    if (t < 18) {
+      const uint32_t* src = reinterpret_cast<const uint32_t*>(&pts[0]);
+      const uint64_t v = (uint64_t)src[2 * t] | ((uint64_t)src[2 * t + 1] << 32);
+      __hip_atomic_store(reinterpret_cast<uint64_t*>(&partial[(size_t)row * K + blockIdx.x]) + t, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // all 18 lanes are wave 0's: its stores have been acknowledged before lane 0 takes the ticket
+#endif
     if (t == 0) {
+#ifdef LASSO_MSM_PLAIN_PARTIALS
       partial[(size_t)row * K + blockIdx.x] = pts[0];
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
       const uint32_t ticket = __hip_atomic_fetch_add(&counters[row], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const uint32_t last = ticket == K - 1 ? 1u : 0u;
       if (last) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); counters[row] = 0; }
       *is_last = last;
     }
+    MSM_STAMP(11);
     __syncthreads();
     if (!*is_last) return;
     pt29 acc = t < K ? partial[(size_t)row * K + t] : pt_identity();
@@ -541,9 +606,25 @@ __device__ __forceinline__ void msm_direct_finish(pt29* pts, fe29 (*st)[4], uint
     __syncthreads();
     pts[t] = acc;
     __syncthreads();
-    msm_coop_tree(pts, st, K < MSM_THREADS ? K : MSM_THREADS, d2);
+    MSM_STAMP(12);
+    msm_coop_tree(pts, st, K < MSM_THREADS ? K : MSM_THREADS, d2, 24);
   }
   MSM_STAMP(4);
+  if (flag == LASSO_TAGGED) {
+    // round 6 (profiles/r06_bullet_phase_*_before.txt: conversion by ONE lane + system fence + ticket + flag = 2.5-3.4 us at the very end of every launch's critical path): the row's
+    // point leaves as four self-validating elements (poly_kernels.cuh result_store: three 16-byte chunks each, tagged with the launch's sequence number), one coordinate per lane —
+    // no ticket between the rows, no flag; the host reads the 2 x 4 elements of the launch like any tagged result.  out_mont = the context's tagged area.
+    if (t < 4) {
+      const fq_t q = pt_coord_abi(pts[0], t);
+      fr_t v;
+#pragma unroll
+      for (int k = 0; k < 8; k++) v.v[k] = q.v[k];
+      result_store(reinterpret_cast<fr_t*>(out_mont), (size_t)row * 4 + t, v, flag, seq);
+    }
+    if (t == 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");   // the wave's stores leave the device (row_done's form)
+    MSM_STAMP(5);
+    return;
+  }
   if (t == 0) {
 #ifdef LASSO_BN254
     out_mont[row] = pt_to_abi(pts[0]);
@@ -572,6 +653,12 @@ __global__ void __launch_bounds__(MSM_THREADS) k_msm_direct(const uint32_t* __re
   __shared__ fe29 st[MSM_ST_ROWS][4];
   __shared__ uint32_t sb[MSM_DIRECT_MAX_COLS * 8];
   __shared__ uint32_t is_last;
+#ifndef LASSO_BN254
+  __shared__ fe29 ln[MSM_LEFT_MAX][3];
+  __shared__ uint32_t lval[MSM_LEFT_MAX];
+#else
+  fe29 (*ln)[3] = nullptr; uint32_t* lval = nullptr;
+#endif
   const uint32_t t = threadIdx.x, row = blockIdx.y, K = gridDim.x;
   const uint32_t total = n_cols * MsmD<WB>::WINDOWS;
   const uint32_t it0 = blockIdx.x * items_per_chunk;
@@ -597,9 +684,10 @@ __global__ void __launch_bounds__(MSM_THREADS) k_msm_direct(const uint32_t* __re
   }
   __syncthreads();
   MSM_STAMP(1);
-  const pt29 B = msm_direct_accumulate<WB>(sb, col0, it0, it1, cm, row, mult, tn, digit_count);
+  MsmLeft left;
+  const pt29 B = msm_direct_accumulate<WB>(sb, col0, it0, it1, cm, row, mult, tn, digit_count, nullptr, &left);
   MSM_STAMP(2);
-  msm_direct_finish(pts, st, &is_last, B, K, row, partial, out_mont, counters, flag, seq);
+  msm_direct_finish(pts, st, &is_last, B, K, row, partial, out_mont, counters, flag, seq, &left, ln, lval);
 }
 
 // out[row] = sum_k partial[row*K + k], converted to ark's Montgomery limbs (out_mont) or, when out_compressed is given, to the 32-byte wire form.  One workgroup per row; thread t first adds partials
@@ -761,6 +849,13 @@ __global__ void __launch_bounds__(MSM_THREADS) k_bullet_msm(const fr_t* __restri
   __shared__ uint32_t sb[MSM_DIRECT_MAX_COLS * 8];
   __shared__ uint32_t sphys[MSM_DIRECT_MAX_COLS];
   __shared__ uint32_t is_last;
+#ifndef LASSO_BN254
+  __shared__ fe29 ln[MSM_LEFT_MAX][3];
+  __shared__ uint32_t lval[MSM_LEFT_MAX];
+#else
+  fe29 (*ln)[3] = nullptr; uint32_t* lval = nullptr;
+#endif
+  MsmLeft left;
   static_assert(sizeof(RedScratch) <= sizeof(pt29) * MSM_THREADS, "RedScratch must fit the point buffer");
   const uint32_t t = threadIdx.x, row = blockIdx.y, K = gridDim.x - 1;
   const uint32_t half = nk / 2, n_loc = n / P;
@@ -776,6 +871,7 @@ __global__ void __launch_bounds__(MSM_THREADS) k_bullet_msm(const fr_t* __restri
   }
   const fr29 us = fr29_unpack_s(u), uis = fr29_unpack_s(u_inv);
   pt29 B;
+  MSM_STAMP(0);
   // the extra workgroup is blockIdx.x == 0: dispatched first, because in the early rounds (long a, b) it is the longest of the launch
   if (blockIdx.x > 0) {
     const bool wide = half >= P;                       // always when P == 1
@@ -803,8 +899,9 @@ __global__ void __launch_bounds__(MSM_THREADS) k_bullet_msm(const fr_t* __restri
       sphys[c] = jl;
     }
     __syncthreads();
+    MSM_STAMP(1);
     const MsmColMap id = {0, 0, 0, 0};
-    B = msm_direct_accumulate<WB>(sb, col0, it0, it1, id, row, mult, tn, digit_count, sphys);
+    B = msm_direct_accumulate<WB>(sb, col0, it0, it1, id, row, mult, tn, digit_count, sphys, &left);
   } else {
     RedScratch& S = *reinterpret_cast<RedScratch*>(pts);
     fr29 acc[3] = {fr29_zero(), fr29_zero(), fr29_zero()}; uint32_t cnt = 0;
@@ -832,9 +929,11 @@ __global__ void __launch_bounds__(MSM_THREADS) k_bullet_msm(const fr_t* __restri
       msm_recode<WB>(ci.v, &sb[0]); msm_recode<WB>(bi.v, &sb[8]);
     }
     __syncthreads();   // S (aliasing pts) is dead from here on
+    MSM_STAMP(1);
     const MsmColMap id = {0, 0, 0, 0};
     // columns n_loc (Q) and n_loc + 1 (H) of the table; in slab mode rank 0 alone adds them
     B = msm_direct_accumulate<WB>(sb, 0, 0, rank == 0 ? 2 * MsmD<WB>::WINDOWS : 0u, id, row, mult + n_loc, tn, digit_count);
   }
-  msm_direct_finish(pts, st, &is_last, B, K + 1, row, partial, out_mont, counters, flag, seq);
+  MSM_STAMP(2);
+  msm_direct_finish(pts, st, &is_last, B, K + 1, row, partial, out_mont, counters, flag, seq, &left, ln, lval);
 }

@@ -182,7 +182,9 @@ __device__ __forceinline__ bool gated_challenge(const uint32_t* gmail, uint32_t 
 #define LASSO_GP_TAG (8 * (LASSO_POINT_MAX + 2))
 #define LASSO_PMAIL_BYTES 2048    // (LASSO_POINT_MAX + 2) entries of 48 bytes
 #define LASSO_GPOINT_BYTES 2048   // (LASSO_GP_TAG + 2) words
-__global__ void __launch_bounds__(64) k_gate_point(const uint32_t* pmail, uint32_t* gpoint, uint32_t seq, uint32_t nfr) {   // no __restrict__: the host writes pmail while this polls
+#define LASSO_PMAIL_ACK_WORD 504   // the first spare word behind the 42 entries: the gate leaves its sequence number there when it ENDS (message consumed, cancelled or timed out), so the
+                                  // host knows the one mailbox area is free for the next gate's message (cancel -> begin -> post could overwrite a message no gate had read yet)
+__global__ void __launch_bounds__(64) k_gate_point(const uint32_t* pmail, uint32_t* gpoint, uint32_t seq, uint32_t nfr, uint32_t* ack) {   // no __restrict__: the host writes pmail while this polls
   const uint32_t t = threadIdx.x;
   const uint64_t t_end = wall_clock64() + 500000000ull;   // 5 s at 100 MHz
   bool ok = true; fr_t v = fr_zero();
@@ -196,7 +198,7 @@ __global__ void __launch_bounds__(64) k_gate_point(const uint32_t* pmail, uint32
   }
   const bool all_ok = __ballot(!ok) == 0;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-  if (t == 0) gpoint[LASSO_GP_TAG + (all_ok ? 0 : 1)] = seq;
+  if (t == 0) { gpoint[LASSO_GP_TAG + (all_ok ? 0 : 1)] = seq; if (ack) __hip_atomic_store(ack, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
 }
 __device__ __forceinline__ bool gate_point_ok(const uint32_t* __restrict__ gp, uint32_t seq) { return gp[LASSO_GP_TAG] == seq && gp[LASSO_GP_TAG + 1] != seq; }
 __device__ __forceinline__ fr_t gate_point_fr(const uint32_t* __restrict__ gp, uint32_t j) {

@@ -151,8 +151,9 @@ class Dev {
       // they make up the request (live + parked bytes then do not grow past the larger of the two proofs' own needs)
       if (capacity && bytes >= ((size_t)64 << 20)) {   // small requests never evict (a 2 MB miss that returned a parked gigabyte started a miss / evict cycle that repeated every proof)
         auto fit = pool_.lower_bound(bytes);      // the smallest parked buffer that covers the request, else the largest ones until they add up
-        if (fit != pool_.end()) { (void)lasso_free(ctx, fit->second); pool_.erase(fit); }
-        else { size_t freed = 0; while (freed < bytes && !pool_.empty()) { auto big = std::prev(pool_.end()); freed += big->first; (void)lasso_free(ctx, big->second); pool_.erase(big); } }
+        // (a buffer the driver refuses to take back — lasso_free returns LASSO_ERR_INVALID while a launch waits for its challenge — stays parked: ADVICE r5)
+        if (fit != pool_.end()) { if (lasso_free(ctx, fit->second) == 0) pool_.erase(fit); }
+        else { size_t freed = 0; while (freed < bytes && !pool_.empty()) { auto big = std::prev(pool_.end()); if (lasso_free(ctx, big->second) != 0) break; freed += big->first; pool_.erase(big); } }
       }
       int32_t rc = lasso_alloc(ctx, bytes, &p);
       if (rc == LASSO_ERR_OOM && !pool_.empty()) { trim(); rc = lasso_alloc(ctx, bytes, &p); }   // the pool holds memory nobody uses: give it back before giving up
@@ -171,7 +172,11 @@ class Dev {
     pool_.emplace(bytes, p);
   }
   // a one-off buffer (the uploaded index array of densify: 8 C s bytes that nothing of that size will ever want again) goes back to the driver, not into the pool
-  void release(void* p) const { if (!p) return; auto it = live_.find(p); if (it == live_.end()) return; in_use_ -= it->second; live_.erase(it); (void)lasso_free(ctx, p); }
+  void release(void* p) const {
+    if (!p) return; auto it = live_.find(p); if (it == live_.end()) return;
+    const size_t bytes = it->second; in_use_ -= bytes; live_.erase(it);
+    if (lasso_free(ctx, p) != 0) pool_.emplace(bytes, p);   // refused inside a launched-ahead window: parked instead of dropped (the pointer must not be lost; the next trim returns it)
+  }
   // LASSO_TRACE=3: what the prover holds right now, by size
   void dump_live(const char* tag) const {
     std::map<size_t, size_t> by; for (auto& kv : live_) by[kv.second]++;
@@ -181,13 +186,13 @@ class Dev {
     fprintf(stderr, "\n");
   }
   // hand every pooled buffer back to the driver
-  void trim() const { for (auto& kv : pool_) (void)lasso_free(ctx, kv.second); pool_.clear(); (void)lasso_trim(ctx); }   // ... and the context's grown scratch buffer
+  void trim() const { for (auto it = pool_.begin(); it != pool_.end();) { if (lasso_free(ctx, it->second) == 0) it = pool_.erase(it); else ++it; } (void)lasso_trim(ctx); }   // ... and the context's grown scratch buffer; what the driver refuses stays parked
   // the same, except up to `count` parked buffers of exactly `bytes` (what the caller is about to allocate)
   // ... and smaller ones (they add up to little; hipFree / hipMalloc of gigabytes per proof cost more than the proof: measured 600 ms at configs[3])
   void trim_keep(size_t bytes, size_t count) const {
     for (auto it = pool_.begin(); it != pool_.end();) {
       if (it->first < bytes || (it->first == bytes && count)) { if (it->first == bytes) count--; ++it; continue; }
-      (void)lasso_free(ctx, it->second); it = pool_.erase(it);
+      if (lasso_free(ctx, it->second) == 0) it = pool_.erase(it); else ++it;
     }
   }
   // device bytes held through this host's contexts now / at most (lasso_mem_stats of the main and the side context), and what the prover itself held at most

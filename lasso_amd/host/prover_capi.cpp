@@ -87,7 +87,14 @@ int32_t lasso_host_set_comm_shm(lasso_host* h, int32_t rank, int32_t world, cons
         h->shm->broadcast_blob(blob, sizeof(blob));
         if (blob[128]) {     // the same byte on every rank: all enter the collective init, or none
           const uint8_t mine = lasso_rccl_init(h->dev.ctx, rank, world, blob) == 0 ? 1 : 0;
-          if (!all_ok(mine, "the device-side exchange") && mine) (void)lasso_rccl_shutdown(h->dev.ctx);
+          if (!all_ok(mine, "the device-side exchange")) { if (mine) (void)lasso_rccl_shutdown(h->dev.ctx); }
+          else {
+            //   4. first contact: every rank all-gathers 1 KB through the new communicator and checks every slot (lasso_rccl_selftest, bounded wait); the communicator is kept only
+            //      if that worked on EVERY rank — otherwise the fall-back is announced on stderr, not silent (a node where xGMI / RCCL is half-configured must say so once)
+            const uint8_t st = lasso_rccl_selftest(h->dev.ctx) == 0 ? 1 : 0;
+            if (!st) fprintf(stderr, "[lasso] rank %d: RCCL self-test failed (%s) — slab mode falls back to the shared-memory exchange of partial row commitments\n", rank, lasso_last_error(h->dev.ctx));
+            if (!all_ok(st, "the RCCL self-test")) { if (lasso_rccl_ready(h->dev.ctx)) (void)lasso_rccl_shutdown(h->dev.ctx); if (st) fprintf(stderr, "[lasso] rank %d: a peer's RCCL self-test failed — shared-memory exchange on every rank\n", rank); }
+          }
         }
       }
     }
@@ -105,6 +112,18 @@ int32_t lasso_host_gens_points(lasso_host_gens* g, int32_t which, lasso_affine* 
     *count = pg.affine.size();
     if (!out || cap < pg.affine.size()) { g_err = "output buffer too small"; return -2; }
     memcpy(out, pg.affine.data(), pg.affine.size() * sizeof(lasso_affine)); return 0;)
+}
+// every table a proof over these generators reads, built now: the byte-multiple tables of the small-scalar commitments (dim / read / final: two byte windows; E: one) are otherwise
+// built by the first lasso_host_commit / lasso_host_prove that meets the object — inside whatever span the caller times
+int32_t lasso_host_gens_prepare(lasso_host_gens* g) {
+  GUARD(
+    if (!g) throw Error("lasso_host_gens_prepare: null argument");
+    for (int which = 0; which < 3; which++) {
+      const PolyCommitmentGens& pg = g->g->set(which);
+      if (pg.bases) pg.dev->chk(lasso_bases_prepare(pg.dev->ctx, pg.bases, 2), "lasso_bases_prepare");
+      if (pg.bases_slab) pg.dev->chk(lasso_bases_prepare(pg.dev->ctx, pg.bases_slab, 2), "lasso_bases_prepare");
+    }
+    return 0;)
 }
 void lasso_host_gens_free(lasso_host_gens* g) { delete g; }
 int32_t lasso_host_densify(lasso_host* h, const uint64_t* indices, size_t n, size_t c, size_t log_m, lasso_host_dense** out) {

@@ -46,6 +46,7 @@ def declare_prover(lib):
     lib.lasso_host_set_comm_shm.argtypes = [vp, i32, i32, C.c_char_p]
     lib.lasso_host_gens_new.argtypes = [vp, C.c_char_p, sz, sz, sz, sz, C.POINTER(vp)]
     lib.lasso_host_gens_from_points.argtypes = [vp, sz, sz, sz, sz, vp, sz, vp, sz, vp, sz, C.POINTER(vp)]
+    lib.lasso_host_gens_prepare.argtypes = [vp]
     lib.lasso_host_gens_points.argtypes = [vp, i32, vp, sz, C.POINTER(sz)]
     lib.lasso_host_gens_free.argtypes = [vp]
     lib.lasso_host_densify.argtypes = [vp, vp, sz, sz, sz, C.POINTER(vp)]
@@ -104,6 +105,10 @@ class HostProver:
         g = C.c_void_p()
         self._chk(self.lib.lasso_host_gens_new(self.h, label, c, s, num_memories, log_m, C.byref(g)))
         return g
+
+    def gens_prepare(self, gens):
+        """build every device table a proof over `gens` reads now instead of inside the first commit / prove (lasso_host_gens_prepare)"""
+        self._chk(self.lib.lasso_host_gens_prepare(gens))
 
     def gens_from_points(self, c, s, num_memories, log_m, l_variate, log_m_variate, derefs):
         """The caller's generators (surge.rs:119-125 `gens: &SparsePolyCommitmentGens<G>`): three arrays of shape (n + 2, 8) uint64 — affine (x, y) Montgomery limbs in the

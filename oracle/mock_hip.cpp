@@ -88,6 +88,7 @@ int32_t lasso_rccl_unique_id(uint8_t*) { return LASSO_ERR_UNSUPPORTED; }
 int32_t lasso_rccl_init(lasso_ctx*, int32_t, int32_t, const uint8_t*) { return LASSO_ERR_UNSUPPORTED; }
 int32_t lasso_rccl_ready(lasso_ctx*) { return 0; }
 int32_t lasso_rccl_shutdown(lasso_ctx*) { return 0; }
+int32_t lasso_rccl_selftest(lasso_ctx*) { return LASSO_ERR_UNSUPPORTED; }
 int32_t lasso_rccl_allgather(lasso_ctx*, const void*, void*, size_t) { return LASSO_ERR_UNSUPPORTED; }
 size_t lasso_point_row_bytes(void) { return 144; }
 int32_t lasso_hyrax_commit_rows_dev(lasso_ctx*, const lasso_fr*, size_t, size_t, const lasso_bases*, void*) { return LASSO_ERR_UNSUPPORTED; }
@@ -503,6 +504,7 @@ int32_t lasso_bases_create(lasso_ctx*, const lasso_affine* pts, size_t n, lasso_
   *out = b; return 0;
 }
 void lasso_bases_destroy(lasso_ctx*, lasso_bases* b) { delete b; }
+int32_t lasso_bases_prepare(lasso_ctx* c, const lasso_bases* b, uint32_t byte_windows) { (void)c; return (b && byte_windows >= 1 && byte_windows <= 2) ? 0 : LASSO_ERR_INVALID; }   // the mock holds no tables
 int32_t lasso_hyrax_commit(lasso_ctx* c, const lasso_fr* Z, size_t ls, size_t rs, const lasso_bases* b, lasso_point* out) {
   REQ(c, rs <= b->pts.size());
   std::vector<Point> bases(b->pts.begin(), b->pts.begin() + rs);

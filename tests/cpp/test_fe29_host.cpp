@@ -30,11 +30,15 @@ int main() {
     CHECK(same29(fe_mul(fe_mul(m1, m2), m), (a - c) * b * (a + c) * b * a * b));   // chains of reduced outputs
   }
   // worst-case magnitudes: all limbs at the loose / reduced bounds, both signs
-  for (int sa = -1; sa <= 1; sa += 2) for (int sb = -1; sb <= 1; sb += 2) {
-    fe29 x, y; for (int i = 0; i < 9; i++) { x.v[i] = sa * ((1 << 30) + (1 << 16)); y.v[i] = sb * ((1 << 29) + (1 << 15)); }
+  // (second pair of magnitudes: what the four-lane tree feeds fe_mul since round 6 — sums / differences of two product outputs whose limb 1 may carry 2^16 extra)
+  for (int mag = 0; mag < 2; mag++) for (int sa = -1; sa <= 1; sa += 2) for (int sb = -1; sb <= 1; sb += 2) {
+    const uint64_t ml = (1ull << 30) + (mag ? (1ull << 17) : (1ull << 16)), mr = (1ull << 29) + (mag ? (1ull << 16) : (1ull << 15));
+    fe29 x, y; for (int i = 0; i < 9; i++) { x.v[i] = sa > 0 ? (int32_t)ml : -(int32_t)ml; y.v[i] = sb > 0 ? (int32_t)mr : -(int32_t)mr; }
     Fq X = Fq::zero(), Y = Fq::zero(), pw = Fq::one(), two29 = Fq::from_u64(1ull << 29);
-    for (int i = 0; i < 9; i++) { Fq lx = Fq::from_u64((1ull << 30) + (1 << 16)), ly = Fq::from_u64((1ull << 29) + (1 << 15)); X += (sa > 0 ? lx : -lx) * pw; Y += (sb > 0 ? ly : -ly) * pw; pw *= two29; }
+    for (int i = 0; i < 9; i++) { Fq lx = Fq::from_u64(ml), ly = Fq::from_u64(mr); X += (sa > 0 ? lx : -lx) * pw; Y += (sb > 0 ? ly : -ly) * pw; pw *= two29; }
     fe29 m = fe_mul(x, y); CHECK(reduced(m)); CHECK(same29(m, X * Y)); CHECK(same29(x, X)); CHECK(same29(y, Y));
+    // the small constant applied to a LOOSE signed operand (stage 1 of the tree): reduced, and the right value
+    for (int32_t k : {121666, 243330, 243332, (1 << 18) - 1}) { const fe29 s = fe_mul_small(x, k); CHECK(reduced(s)); CHECK(same29(s, X * Fq::from_u64((uint64_t)k))); const fe29 m2 = fe_mul(x, fe_mul_small(x, k)); CHECK(reduced(m2)); CHECK(same29(m2, X * X * Fq::from_u64((uint64_t)k))); }
   }
   // group law vs oracle
   Point G = Point::generator();
@@ -55,6 +59,9 @@ int main() {
         fe29 st[4]; for (uint32_t c = 0; c < 4; c++) st[c] = pt_coop4_stage1(pa, pb, c);
         pt29 r; for (uint32_t c = 0; c < 4; c++) reinterpret_cast<fe29*>(&r)[c] = pt_coop4_stage2(st[0], st[1], st[2], st[3], c);
         CHECK(same_pt(r, rep == 0 ? p + q : (rep == 1 ? p.dbl() : p)));
+        // round 6: stage 2 by address (what msm_coop_tree runs): the same point, every coordinate reduced, and stage 1's outputs reduced (fe_mul's second operand must be)
+        pt29 r2; for (uint32_t c = 0; c < 4; c++) { CHECK(reduced(st[c])); reinterpret_cast<fe29*>(&r2)[c] = pt_coop4_stage2p(st, c); CHECK(reduced(reinterpret_cast<fe29*>(&r2)[c])); }
+        CHECK(same_pt(r2, rep == 0 ? p + q : (rep == 1 ? p.dbl() : p)));
       }
     }
     {   // small-constant multiplication on reduced and on product-output operands
@@ -66,7 +73,7 @@ int main() {
       for (int k2 = 0; k2 < 300; k2++) {
         const pt29 other = (k2 & 1) ? to29(q) : acc;
         fe29 st[4]; for (uint32_t c = 0; c < 4; c++) st[c] = pt_coop4_stage1(acc, other, c);
-        pt29 r; for (uint32_t c = 0; c < 4; c++) reinterpret_cast<fe29*>(&r)[c] = pt_coop4_stage2(st[0], st[1], st[2], st[3], c);
+        pt29 r; for (uint32_t c = 0; c < 4; c++) reinterpret_cast<fe29*>(&r)[c] = pt_coop4_stage2p(st, c);
         ref = (k2 & 1) ? ref + q : ref.dbl(); acc = r;
       }
       CHECK(same_pt(acc, ref));
@@ -75,6 +82,19 @@ int main() {
     Fq qx, qy; q.to_affine(qx, qy);
     niels29 n = niels_from_affine(fq32(qx), fq32(qy));
     CHECK(same_pt(pt_madd(to29(p), n), p + q));
+    {   // round 6: the mixed addition shared by four lanes (msm_coop_leftover), both signs of the table entry, and on an accumulator that is itself a cooperative sum
+      for (int neg = 0; neg < 2; neg++) {
+        const niels29 e = niels_cond_neg(n, neg != 0);
+        const fe29 nf[3] = {e.ypx, e.ymx, e.t2d};
+        pt29 acc = to29(p); Point ref = p;
+        for (int rep = 0; rep < 3; rep++) {
+          fe29 st[4]; for (uint32_t c = 0; c < 4; c++) { st[c] = pt_coop4_madd_stage1(acc, nf, c); CHECK(reduced(st[c])); }
+          pt29 r; for (uint32_t c = 0; c < 4; c++) reinterpret_cast<fe29*>(&r)[c] = pt_coop4_stage2p(st, c);
+          ref = neg ? ref - q : ref + q; acc = r;
+          CHECK(same_pt(acc, ref));
+        }
+      }
+    }
     // long chain: 200 mixed adds then doublings stay reduced and correct
     pt29 acc = to29(p); Point ref = p;
     for (int k = 0; k < 200; k++) { acc = pt_madd(acc, n); ref = ref + q; }

@@ -552,7 +552,19 @@ def test_rccl_two_ranks_on_one_device(devs):
     for k in range(2):
         got = ds[k].download(pr[k], (2 * n,), dtype=np.uint8)
         assert np.array_equal(got[:n], send[0]) and np.array_equal(got[n:], send[1])
-    print("\n[rccl] two ranks on one device: accepted; a 2-rank ncclAllGather of 64 KiB per rank ran on the two library streams")
+    # round 6: the first-contact self-test lasso_host_set_comm_shm runs on a fresh communicator (1 KB all-gather, every slot checked, bounded wait)
+    src = [None, None]
+
+    def selftest(k):
+        src[k] = ds[k].lib.lasso_rccl_selftest(ds[k].ctx)
+    ths = [threading.Thread(target=selftest, args=(k,), daemon=True) for k in range(2)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(timeout=90)
+    assert not any(t.is_alive() for t in ths), "lasso_rccl_selftest hung"
+    assert src == [0, 0], [d.lib.lasso_last_error(d.ctx) for d in ds]
+    print("\n[rccl] two ranks on one device: accepted; a 2-rank ncclAllGather of 64 KiB per rank ran on the two library streams; lasso_rccl_selftest ok on both")
     for d in ds:
         d._chk(d.lib.lasso_rccl_shutdown(d.ctx)); d.close()
 

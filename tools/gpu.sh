@@ -117,6 +117,55 @@ PY
   LASSO_TRACE=1 timeout 200 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --concurrent 0 --no-slab-leg --no-bind-sweep --no-prof "$@" > /dev/null 2> gpurun_out/$tag/trace_spans.txt; grep "\[trace\]" gpurun_out/$tag/trace_spans.txt | tail -22
   LASSO_TRACE=2 timeout 200 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --concurrent 0 --no-slab-leg --no-bind-sweep --no-prof "$@" > /dev/null 2> gpurun_out/$tag/host_buckets.txt; grep "\[host\]" gpurun_out/$tag/host_buckets.txt | tail -14
 }
+r_micro() {        # micro <tag> [n ...]: round 6's microbenchmarks — phase-stamped timeline of one k_bullet_msm launch per curve (tools/bullet_phase_bench*) and the mixed addition's ceiling (tools/madd_bench*)
+  local tag="$1"; shift; mkdir -p gpurun_out/$tag
+  for n in "${@:-4096}"; do
+    timeout 120 tools/bullet_phase_bench $n > gpurun_out/$tag/bullet_phase_curve25519_n$n.txt 2>&1; timeout 120 tools/bullet_phase_bench_bn254 $n > gpurun_out/$tag/bullet_phase_bn254_n$n.txt 2>&1
+  done
+  timeout 200 tools/madd_bench > gpurun_out/$tag/madd_bench_curve25519.txt 2>&1; timeout 200 tools/madd_bench_bn254 > gpurun_out/$tag/madd_bench_bn254.txt 2>&1
+  grep -h "####\|MADD_CEILING\|k_msm_rows8w" gpurun_out/$tag/*.txt | cut -c1-260
+}
+r_scale() {        # scale <tag> [bench.py args...]: FIRST CONTACT WITH AN 8-GPU NODE.  bench.py --gpus N for N = 1, 2, 4, 8 (those the node has) in both modes —
+                   # independent proofs (weak scaling: the driver's SCALE line) and ONE proof sharded over the N GPUs (--shard-proof, slab mode, configs[3] by default) — then one table:
+                   # N, mode, lookups/s, ms per step, x vs N = 1, ranks that joined the RCCL communicator, the exchange used, per-rank peak bytes, parity.  Every leg under its own timeout.
+  local tag="$1"; shift; mkdir -p gpurun_out/$tag
+  local ngpu; ngpu=$(python -c "import torch; print(torch.cuda.device_count())" 2>/dev/null || echo 1)
+  say "visible GPUs: $ngpu"
+  for N in 1 2 4 8; do
+    [ "$N" -gt "$ngpu" ] && { echo "N=$N: skipped (the node shows $ngpu GPUs)"; continue; }
+    local port=$((29500 + N))
+    if [ "$N" -eq 1 ]; then
+      timeout 900 python bench.py --gpus 1 --steps 10 --warmup 3 --no-cpu-baseline --concurrent 0 --no-slab-leg --no-bind-sweep "$@" > gpurun_out/$tag/indep_$N.json 2> gpurun_out/$tag/indep_$N.err
+      timeout 900 python bench.py --gpus 1 --steps 3 --warmup 1 --kind range --c 4 --log-s 26 --no-cpu-baseline --concurrent 0 --no-slab-leg --no-bind-sweep > gpurun_out/$tag/slab_$N.json 2> gpurun_out/$tag/slab_$N.err
+    else
+      HSA_ENABLE_IPC_MODE_LEGACY=0 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port $port bench.py --gpus $N --steps 10 --warmup 3 --no-cpu-baseline --concurrent 0 --no-slab-leg --no-bind-sweep "$@" > gpurun_out/$tag/indep_$N.json 2> gpurun_out/$tag/indep_$N.err
+      HSA_ENABLE_IPC_MODE_LEGACY=0 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port $((port + 20)) bench.py --gpus $N --shard-proof --steps 3 --warmup 1 --kind range --c 4 --log-s 26 --no-cpu-baseline --concurrent 0 --no-slab-leg --no-bind-sweep > gpurun_out/$tag/slab_$N.json 2> gpurun_out/$tag/slab_$N.err
+    fi
+  done
+  python - "$tag" <<'PY'
+import json, os, sys
+tag = sys.argv[1]
+def line(path):
+    try:
+        return json.loads([l for l in open(path).read().strip().splitlines() if l.startswith("{")][-1])
+    except Exception as e:
+        return None
+print(f"{'N':>2} {'mode':<11} {'lookups/s':>12} {'ms/step':>9} {'x vs N=1':>9} {'rccl':>5}  {'peak GB/rank':>12}  parity  exchange")
+base = {}
+for mode in ("indep", "slab"):
+    for N in (1, 2, 4, 8):
+        d = line(f"gpurun_out/{tag}/{mode}_{N}.json")
+        if d is None:
+            err = f"gpurun_out/{tag}/{mode}_{N}.err"
+            if os.path.exists(err): print(f"{N:>2} {mode:<11} no bench line — {open(err).read()[-300:].strip()!r}")
+            continue
+        mg = d.get("multi_gpu") or {}
+        if N == 1: base[mode] = d["value"]
+        peaks = mg.get("peak_bytes_per_rank") or []
+        par = (d.get("parity_checked") or {}).get("equal", (d.get("slab_mode") or {}).get("parity"))
+        print(f"{N:>2} {mode:<11} {d['value']:12.4g} {d['ms_per_step']:9.2f} {d['value'] / base.get(mode, d['value']):9.2f} {mg.get('rccl_ranks', 0):>5}  {max(peaks) / 1e9 if peaks else 0:12.2f}  {str(par):<6}  {str(mg.get('exchange'))[:110]}")
+PY
+}
 r_sh() { "$@"; }   # sh <command...>: anything else, verbatim
 
 while [ $# -gt 0 ]; do
