@@ -390,7 +390,7 @@ def slab_units(kind, c, capacity=False):
 
 
 def slab_bytes_per_rank(kind, c, log_s, world, log_m=16, capacity=False):
-    """slab_units x (s / P) x 32 bytes + the constant term: the generator tables (per generator 64 window entries + 512 digit multiples of 112 bytes, + 4096 byte multiples for sets of at most 2^14 generators; the rank's residue class
+    """slab_units x (s / P) x 32 bytes + the constant term: the generator tables (per generator 64 window entries + 512 digit multiples of 128 bytes (one cache line per table entry since round 6), + 4096 byte multiples for sets of at most 2^14 generators; the rank's residue class
     again as its slab table; 2 x 255 byte multiples for the commitments' table, of the rank's class only when P > 1) over the three Hyrax widths, and ~1.5 GB of scratch.
     Checked against lasso_mem_stats at configs[3], P = 1, 2, 4, 8 (profiles/r04_slab_peak_bytes.json)."""
     alpha = 2 * c if kind == "lt" else c
@@ -400,7 +400,7 @@ def slab_bytes_per_rank(kind, c, log_s, world, log_m=16, capacity=False):
     # per generator: 64 window entries + 512 digit multiples, and 4096 byte multiples for sets of up to 2^14 generators (the openings' MSMs, lasso_bases_create_opt) — for the
     # set the openings read (the full one on one GPU, the rank's residue class in slab mode), not in capacity mode
     ent = lambda n_gens, bytes_too: (576 + (4096 if bytes_too and not capacity and n_gens <= (1 << 14) + 64 else 0)) * n_gens
-    fixed = 112 * sum(ent(rr + 2, world == 1) + (ent(rr // world + 2, True) if world > 1 else 0) for rr in (r_l, r_e, r_m)) + 2 * 255 * 112 * (r_l + r_e) / world + 1.5e9
+    fixed = 128 * sum(ent(rr + 2, world == 1) + (ent(rr // world + 2, True) if world > 1 else 0) for rr in (r_l, r_e, r_m)) + 2 * 255 * 128 * (r_l + r_e) / world + 1.5e9
     return slab_units(kind, c, capacity) * ((1 << log_s) / world) * 32 + fixed
 
 

@@ -58,7 +58,10 @@ LHD void fe_to_plain_words(const fe29& a, uint32_t* out) {   // the canonical in
 
 // ------------------------------------------------------------------ group law
 struct pt29 { fe29 X, Y, T, Z; };                                  // (X : Y : Z); T unused (kept so that layouts match the Edwards build)
-struct alignas(16) niels29 { fe29 x, y; int32_t pad[10]; };        // affine table entry, 112 bytes: 7 x dwordx4
+#ifndef MSM_NIELS_ALIGN
+#define MSM_NIELS_ALIGN 128   // one table entry = one cache line (fe29.cuh says why)
+#endif
+struct alignas(MSM_NIELS_ALIGN) niels29 { fe29 x, y; int32_t pad[10]; };        // affine table entry: 72 bytes of payload in a 128-byte line
 
 LHD pt29 pt_identity() { pt29 p; p.X = fe_zero(); p.Y = fe_one(); p.T = fe_zero(); p.Z = fe_zero(); return p; }
 LHD fe29 fe_d2() { return fe_zero(); }   // the Edwards build passes 2d to pt_add; nothing to pass here

@@ -146,7 +146,13 @@ LHD fq_t fe_to_fq(const fe29& a) {   // loose input ok; returns a lazy fq_t cong
 
 // ------------------------------------------------------------------ group law on fe29 coordinates
 struct pt29 { fe29 X, Y, T, Z; };            // extended coordinates, all reduced
-struct alignas(16) niels29 { fe29 ypx, ymx, t2d; int32_t pad; };   // 112 bytes: 7 x dwordx4
+// One table entry = ONE 128-byte cache line (round 6).  The payload is 108 bytes (7 x dwordx4 loads); at the 112-byte stride of rounds 1-5 seven entries in eight straddled two
+// lines, so every mixed addition pulled 256 bytes through the fabric: the row-parallel commitment ran at 18 G additions/s x 256 B = 4.6 TB/s — at the memory system's rate, not
+// the VALUs' (tools/madd_bench.hip section C against section A's 31 G/s).  -DMSM_NIELS_ALIGN=16 restores the packed layout (A/B).
+#ifndef MSM_NIELS_ALIGN
+#define MSM_NIELS_ALIGN 128
+#endif
+struct alignas(MSM_NIELS_ALIGN) niels29 { fe29 ypx, ymx, t2d; int32_t pad; };   // 108 bytes of payload: 7 x dwordx4
 
 LHD pt29 pt_identity() { pt29 p; p.X = fe_zero(); p.Y = fe_one(); p.T = fe_zero(); p.Z = fe_one(); return p; }
 LHD fe29 fe_d2() {   // 2d mod p

@@ -29,7 +29,7 @@ __global__ void __launch_bounds__(256) k_inner_lr(const fr_t* __restrict__ a, co
 }
 
 static_assert(sizeof(lasso_fr) == 32 && sizeof(fr_t) == 32, "Fr layout");
-static_assert(sizeof(lasso_affine) == 64 && sizeof(lasso_point) == 128 && sizeof(ed_point) == 128 && sizeof(niels29) == 112 && sizeof(pt29) == 144, "curve layouts");
+static_assert(sizeof(lasso_affine) == 64 && sizeof(lasso_point) == 128 && sizeof(ed_point) == 128 && sizeof(niels29) == (MSM_NIELS_ALIGN > 16 ? 128 : 112) && sizeof(pt29) == 144, "curve layouts");
 
 struct EventPair { hipEvent_t a, b; int kid; double bytes, units, units2; bool large; bool counted; };
 #define LASSO_PROF_COUNT_SLOTS 4096   // device counters of exactly executed additions, one group of 64 words per bracketed launch of the fully-profiled step (the waves of a launch spread their atomics over the group)
@@ -1614,8 +1614,13 @@ static int32_t run_msm(lasso_ctx* c, const uint8_t* d_scal, uint32_t bps, uint32
     // (profiles/r04_ab_rows8w.txt): -9 % on the headline's E (4096 one-byte columns), -8 % on BN254 configs[1], +2 % on configs[2]'s 16384-column rows, where a thread of the
     // 256-lane kernel already runs 64 additions — hence the column bound.  LASSO_MSM_ROWS8W=0: A/B switch
     static const bool rows8w = [] { const char* v = getenv("LASSO_MSM_ROWS8W"); return !(v && v[0] == '0'); }();
-    if (t8[0] && rows8w && K == 1 && rows >= 1024 && n_cols * W8 <= 8192) hipLaunchKernelGGL(k_msm_rows8w, dim3((unsigned)((rows + MSM_THREADS / 64 - 1) / (MSM_THREADS / 64))), dim3(MSM_THREADS), 0, c->stream, (const uint32_t*)d_scal, row_stride / 4,
-                                                                      (uint32_t)n_cols, W8, t8[0], t8[1], b->n, d_partial, (uint32_t)rows, ps.counter());
+    // rows per wave (round 6 experiment, NOT the default: LASSO_MSM_ROWS8W_WAVES=2048 caps a launch at two waves per SIMD, all resident at once — measured 0.966 ms against
+    // 0.896 ms at one row per wave on the headline's E, profiles/r06_madd_bench_curve25519.txt section C: two waves per SIMD hide less than three, the tail of the
+    // three-wave schedule costs less than that)
+    static const size_t w_max = [] { const char* v = getenv("LASSO_MSM_ROWS8W_WAVES"); const long x = v ? atol(v) : 0; return (size_t)(x < 0 ? 0 : x); }();
+    const size_t rpw = w_max ? (rows + w_max - 1) / w_max : 1, waves = (rows + rpw - 1) / rpw;
+    if (t8[0] && rows8w && K == 1 && rows >= 1024 && n_cols * W8 <= 8192) hipLaunchKernelGGL(k_msm_rows8w, dim3((unsigned)((waves + MSM_THREADS / 64 - 1) / (MSM_THREADS / 64))), dim3(MSM_THREADS), 0, c->stream, (const uint32_t*)d_scal, row_stride / 4,
+                                                                      (uint32_t)n_cols, W8, t8[0], t8[1], b->n, d_partial, (uint32_t)rows, ps.counter(), (uint32_t)rpw);
     else if (t8[0]) hipLaunchKernelGGL(k_msm_rows8, dim3((unsigned)K, (unsigned)rows), dim3(MSM_THREADS), 0, c->stream, (const uint32_t*)d_scal, row_stride / 4, (uint32_t)n_cols, (uint32_t)cols_per_chunk, W8,
                                   t8[0], t8[1], b->n, d_partial, ps.counter());
     else hipLaunchKernelGGL(k_msm_buckets, dim3((unsigned)K, (unsigned)rows), dim3(MSM_THREADS), 0, c->stream, d_scal, bps, W, row_stride, n_cols, cols_per_chunk, (const niels29*)b->d_table, b->n, d_partial, ps.counter());

@@ -20,6 +20,16 @@
 #define MSM_THREADS 256
 #define MSM_BATCH 8192   // (bin, index) pairs sorted per pass: 32 KB of the 36 KB LDS buffer the reduction tree reuses
 #define MSM_WINDOWS 64   // 4-bit windows over 256-bit scalars
+// Layout of the digit- / byte-multiple tables: entry (window w, multiple m1 = m - 1, generator j) of a table with NW windows of NM multiples over tn generators.
+//   window-major (rounds 2-5):  ((w NM + m1) tn + j)   — a wave's 64 lanes (consecutive items = consecutive windows of a column, or consecutive columns with random bytes) touch 64 pages
+//   column-major (MSM_TABLE_COLMAJOR): ((j NW + w) NM + m1) — everything a column can ever ask for is one contiguous block (28 KB per byte window), a wave's lanes stay inside 1-2 MB
+#ifdef MSM_TABLE_COLMAJOR
+#define MSM_IDX(w, m1, j, tn, NW, NM) ((((size_t)(j)) * (NW) + (w)) * (NM) + (m1))
+#define MSM_COL_BASE(tab, j0, NW, NM) ((tab) + (size_t)(j0) * (NW) * (NM))
+#else
+#define MSM_IDX(w, m1, j, tn, NW, NM) ((((size_t)(w)) * (NM) + (m1)) * (tn) + (j))
+#define MSM_COL_BASE(tab, j0, NW, NM) ((tab) + (j0))
+#endif
 
 // table[w*n + j] = Niels(2^(4w) * G_j) in 29-bit-limb form (fe29.cuh).  One thread per generator; built once per gens object
 // with the 8x32 arithmetic (needs an inversion per entry), then converted.  `aff` = ark Affine {x,y} Montgomery limbs.
@@ -228,8 +238,7 @@ __global__ void __launch_bounds__(64) k_precompute_multiples(const niels29* __re
   fe29 pre[7]; pre[0] = m[0].Z;
   for (int k = 1; k < 7; k++) pre[k] = fe_mul(pre[k - 1], m[k].Z);
   fe29 inv = fe_inv_chain(pre[6]);
-  niels29* dst = mult + (w * MSM_MULTS) * n + j;
-  dst[0] = b;
+  mult[MSM_IDX(w, 0, j, n, MSM_WINDOWS, MSM_MULTS)] = b;
   for (int k = 6; k >= 0; k--) {
     const fe29 zi = k ? fe_mul(inv, pre[k - 1]) : inv;
     if (k) inv = fe_mul(inv, m[k].Z);
@@ -239,7 +248,7 @@ __global__ void __launch_bounds__(64) k_precompute_multiples(const niels29* __re
 #else
     niels29 e; e.ypx = fe_weak(fe_add(y, x)); e.ymx = fe_weak(fe_sub(y, x)); e.t2d = fe_mul(fe_mul(x, y), d2); e.pad = 0;
 #endif
-    dst[(size_t)(k + 1) * n] = e;
+    mult[MSM_IDX(w, k + 1, j, n, MSM_WINDOWS, MSM_MULTS)] = e;
   }
 }
 // Logical column j of row `row` -> generator index.  nk = 0: identity.  Bullet rows (nk > 0) are stored compactly: the n/2 non-zero scalars
@@ -393,10 +402,11 @@ __device__ __forceinline__ void msm_coop_tree(pt29* pts, fe29 (*st)[4], uint32_t
 __global__ void __launch_bounds__(64) k_precompute_tab8(const niels29* __restrict__ table, size_t n, uint32_t w8, niels29* __restrict__ tab8, uint32_t nm = MSM8_MULTS) {
   const size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (j >= n) return;
-  w8 += blockIdx.y; tab8 += (size_t)blockIdx.y * nm * n;
+  w8 += blockIdx.y;
+  const uint32_t wy = blockIdx.y, nwin = gridDim.y;
   const niels29 b = table[(size_t)(2 * w8) * n + j];
   const fe29 d2 = fe_d2();
-  tab8[j] = b;
+  tab8[MSM_IDX(wy, 0, j, n, nwin, nm)] = b;
   pt29 P = pt_madd(pt_identity(), b);
   for (uint32_t m0 = 2; m0 <= nm; m0 += 16) {
     pt29 q[16]; fe29 pre[16];
@@ -406,7 +416,7 @@ __global__ void __launch_bounds__(64) k_precompute_tab8(const niels29* __restric
     for (uint32_t c = cnt; c-- > 0;) {
       const fe29 zi = c ? fe_mul(inv, pre[c - 1]) : inv;
       if (c) inv = fe_mul(inv, q[c].Z);
-      tab8[(size_t)(m0 + c - 1) * n + j] = niels_from_xy29(fe_mul(q[c].X, zi), fe_mul(q[c].Y, zi), d2);
+      tab8[MSM_IDX(wy, m0 + c - 1, j, n, nwin, nm)] = niels_from_xy29(fe_mul(q[c].X, zi), fe_mul(q[c].Y, zi), d2);
     }
   }
 }
@@ -429,7 +439,7 @@ __global__ void __launch_bounds__(MSM_THREADS) k_msm_rows8(const uint32_t* __res
       const uint32_t d = (v >> (8 * w)) & 255u;
       nadds += d != 0;
       // the fetch is unconditional (entry 0 for a zero byte) so that it is issued BEFORE the mixed addition below and waited for after it
-      const niels29 nxt = (w ? tab8_1 : tab8_0)[d ? (size_t)(d - 1) * tn + c : 0];
+      const niels29 nxt = (w ? tab8_1 : tab8_0)[d ? MSM_IDX(0, d - 1, c, tn, 1, MSM8_MULTS) : 0];
       if (have) B = pt_madd(B, cur);
       cur = nxt; have = d != 0;
     }
@@ -447,37 +457,45 @@ __global__ void __launch_bounds__(MSM_THREADS) k_msm_rows8(const uint32_t* __res
 // per row a lane runs 64 additions and the row's partial sums are 64: six plain addition levels inside the wave, no workgroup barrier anywhere, the tree a tenth of the chain.
 // Same table entries, same group element per row (other projective representative: the wire bytes do not change).  out[row] = the row's sum (K = 1 layout of k_points_sum).
 __global__ void __launch_bounds__(MSM_THREADS) k_msm_rows8w(const uint32_t* __restrict__ scal, size_t row_words, uint32_t n_cols, uint32_t W8, const niels29* __restrict__ tab8_0,
-                                                             const niels29* __restrict__ tab8_1, size_t tn, pt29* __restrict__ out, uint32_t rows, uint32_t* digit_count) {
+                                                             const niels29* __restrict__ tab8_1, size_t tn, pt29* __restrict__ out, uint32_t rows, uint32_t* digit_count, uint32_t rpw) {
+  // Round 6 (profiles/r06_madd_bench_curve25519.txt: this kernel runs at 18.3 G additions/s where a chain of additions sustains 31).  Tried: (i) `rpw` rows per wave so that a
+  // launch is two waves per SIMD, all resident at once, instead of 4096 waves on 3072 slots (a round of three per SIMD, then a round of one) — SLOWER (0.966 against 0.896 ms: two
+  // waves hide less latency than three), kept as a parameter, default 1; (ii) the row's scalar for the next column loaded one iteration ahead, like the table entry (the compiler's
+  // vmcnt(0) at the top of the loop body waited for a load issued two instructions earlier) — kept, worth 1-2 %.
   __shared__ pt29 pts[MSM_THREADS];
   const fe29 d2 = fe_d2();
   const uint32_t t = threadIdx.x, wave = t >> 6, lane = t & 63u;
-  const uint32_t r = blockIdx.x * (MSM_THREADS / 64) + wave;
-  pt29 B = pt_identity();
+  pt29* mine = pts + 64 * wave;
   uint32_t nadds = 0;
-  if (r < rows) {
+  for (uint32_t k = 0; k < rpw; k++) {
+    const uint32_t r = (blockIdx.x * (MSM_THREADS / 64) + wave) * rpw + k;   // wave-uniform
+    if (r >= rows) break;
+    pt29 B = pt_identity();
     const uint32_t* row = scal + (size_t)r * row_words;
     niels29 cur; bool have = false;
+    uint32_t v_next = lane < n_cols ? row[lane] : 0u;
     for (uint32_t c = lane; c < n_cols; c += 64) {
-      const uint32_t v = row[c];
+      const uint32_t v = v_next;
+      v_next = c + 64 < n_cols ? row[c + 64] : 0u;   // in flight during this column's additions
       for (uint32_t w = 0; w < W8; w++) {
         const uint32_t d = (v >> (8 * w)) & 255u;
         nadds += d != 0;
-        const niels29 nxt = (w ? tab8_1 : tab8_0)[d ? (size_t)(d - 1) * tn + c : 0];   // issued before the addition below, waited for after it
+        const niels29 nxt = (w ? tab8_1 : tab8_0)[d ? MSM_IDX(0, d - 1, c, tn, 1, MSM8_MULTS) : 0];   // issued before the addition below, waited for after it
         if (have) B = pt_madd(B, cur);
         cur = nxt; have = d != 0;
       }
     }
     if (have) B = pt_madd(B, cur);
+    mine[lane] = B;
+    // the wave's 64 partial sums -> one: plain additions, 32 + 16 + .. + 1; only this wave touches `mine`, so its own LDS operations kept in order are all the synchronisation there is
+    for (uint32_t s2 = 32; s2 > 0; s2 >>= 1) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (lane < s2) { const pt29 x = pt_add(mine[lane], mine[lane + s2], d2); mine[lane] = x; }
+    }
+    if (lane == 0) out[r] = mine[0];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // lane 0's read of mine[0] before the next row overwrites it
   }
   msm_count_adds(digit_count, nadds);
-  pt29* mine = pts + 64 * wave;
-  mine[lane] = B;
-  // the wave's 64 partial sums -> one: plain additions, 32 + 16 + .. + 1; only this wave touches `mine`, so its own LDS operations kept in order are all the synchronisation there is
-  for (uint32_t s2 = 32; s2 > 0; s2 >>= 1) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (lane < s2) { const pt29 x = pt_add(mine[lane], mine[lane + s2], d2); mine[lane] = x; }
-  }
-  if (lane == 0 && r < rows) out[r] = mine[0];
 }
 
 #define MSM_DIRECT_MAX_COLS 160   // columns a workgroup may touch (items_per_chunk <= 64 * (MSM_DIRECT_MAX_COLS - 1))
@@ -531,7 +549,7 @@ __device__ __forceinline__ pt29 msm_direct_accumulate(const uint32_t* sb, uint32
       bool valid = t < rem; int32_t d = 0; uint32_t c = 0, w = 0;
       if (valid) { c = it >> D::LOGW; w = it & (D::WINDOWS - 1u); d = (int32_t)((sb[(c - col0) * 8 + w / D::PER_WORD] >> (WB * (w % D::PER_WORD))) & D::DMASK) - (int32_t)D::MULTS; valid = d != 0; }
       const uint32_t m = d < 0 ? (uint32_t)(-d) : (uint32_t)d;
-      const size_t idx = valid ? ((size_t)w * D::MULTS + (m - 1)) * tn + (phys ? phys[c - col0] : msm_phys_col(cm, row, c)) : 0;
+      const size_t idx = valid ? MSM_IDX(w, m - 1, (phys ? phys[c - col0] : msm_phys_col(cm, row, c)), tn, D::WINDOWS, D::MULTS) : 0;
       if (t < rem) left->e = niels_cond_neg(mult[idx], d < 0);   // only the first rem lanes fetch (<= one wave's worth): in flight while the full passes run
       left->valid = valid ? 1u : 0u; nadds += valid;
     }
@@ -543,7 +561,7 @@ __device__ __forceinline__ pt29 msm_direct_accumulate(const uint32_t* sb, uint32
     if (valid) { c = it >> D::LOGW; w = it & (D::WINDOWS - 1u); d = (int32_t)((sb[(c - col0) * 8 + w / D::PER_WORD] >> (WB * (w % D::PER_WORD))) & D::DMASK) - (int32_t)D::MULTS; valid = d != 0; }
     // the fetch is unconditional (entry 0 for a skipped item) so that it is issued BEFORE the mixed add below and waited for after it
     const uint32_t m = d < 0 ? (uint32_t)(-d) : (uint32_t)d;
-    const size_t idx = valid ? ((size_t)w * D::MULTS + (m - 1)) * tn + (phys ? phys[c - col0] : msm_phys_col(cm, row, c)) : 0;
+    const size_t idx = valid ? MSM_IDX(w, m - 1, (phys ? phys[c - col0] : msm_phys_col(cm, row, c)), tn, D::WINDOWS, D::MULTS) : 0;
     const niels29 nxt = mult[idx];
     if (have) B = pt_madd(B, cur);
     const bool neg = d < 0;
@@ -932,7 +950,7 @@ __global__ void __launch_bounds__(MSM_THREADS) k_bullet_msm(const fr_t* __restri
     MSM_STAMP(1);
     const MsmColMap id = {0, 0, 0, 0};
     // columns n_loc (Q) and n_loc + 1 (H) of the table; in slab mode rank 0 alone adds them
-    B = msm_direct_accumulate<WB>(sb, 0, 0, rank == 0 ? 2 * MsmD<WB>::WINDOWS : 0u, id, row, mult + n_loc, tn, digit_count);
+    B = msm_direct_accumulate<WB>(sb, 0, 0, rank == 0 ? 2 * MsmD<WB>::WINDOWS : 0u, id, row, MSM_COL_BASE(mult, n_loc, MsmD<WB>::WINDOWS, MsmD<WB>::MULTS), tn, digit_count);
   }
   MSM_STAMP(2);
   msm_direct_finish(pts, st, &is_last, B, K + 1, row, partial, out_mont, counters, flag, seq, &left, ln, lval);
