@@ -31,7 +31,8 @@ def build_device(force=False, verbose=False, curve="curve25519"):
     target = os.path.join(HERE, f"liblasso_hip{suffix}.so")
     sources = _glob(csrc, (".hip", ".cuh")) + [os.path.join(ROOT, "include", "lasso_hip.h")]
     if force or _stale(target, sources):
-        cmd = [HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result", *flags,
+        extra = os.environ.get("LASSO_EXTRA_HIPCC_FLAGS", "").split()   # A/B builds of compile-time switches (e.g. -DLASSO_PLAIN_PARTIALS), on the GPU box
+        cmd = [HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result", *flags, *extra,
                "-o", target, os.path.join(csrc, "lasso_hip.hip")]
         if verbose:
             print(" ".join(cmd))

@@ -89,7 +89,21 @@ __device__ __forceinline__ void result_store(fr_t* __restrict__ out, size_t slot
     lasso_u32x4* o = reinterpret_cast<lasso_u32x4*>(out) + 3 * slot;
     const lasso_u32x4 c0 = {seq, v.v[0], v.v[1], v.v[2]}, c1 = {seq, v.v[3], v.v[4], v.v[5]}, c2 = {seq, v.v[6], v.v[7], result_check(v, seq)};
     o[0] = c0; o[1] = c1; o[2] = c2;
-  } else out[slot] = v;
+  } else {
+    // A value another workgroup of THIS launch will read (block partials on their way to last_block_reduce): write-through (sc1) 8-byte stores, so that what publishes them
+    // is the storing wave's `s_waitcnt vmcnt(0)` and not an L2 write-back (round 6; cdna_hip_programming.md §6 G16, the sc1 form).  The release fence this replaces wrote back
+    // EVERY dirty line of the XCD's L2 — and every workgroup of a fused round has just dirtied 32 KB of bound values there: 512 such fences per launch.
+    // (flag != nullptr: the flag protocol's result area in host-mapped memory, LASSO_TAGGED_RESULTS=0 — plain stores, published by row_done's system-scope fence as before)
+#ifndef LASSO_PLAIN_PARTIALS
+    if (flag == nullptr) {
+      uint64_t* o = reinterpret_cast<uint64_t*>(out + slot);
+#pragma unroll
+      for (int k = 0; k < 4; k++) __hip_atomic_store(o + k, (uint64_t)v.v[2 * k] | ((uint64_t)v.v[2 * k + 1] << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+#endif
+    out[slot] = v;
+  }
 }
 // the host -> device direction of a resident kernel (lasso_hip.hip post_mail): the three mailbox chunks carry this tag and the check word of their eight challenge words
 __device__ __forceinline__ bool mail_valid(const lasso_u32x4& c0, const lasso_u32x4& c1, const lasso_u32x4& c2, uint32_t tag) {
@@ -251,8 +265,10 @@ __device__ __forceinline__ void row_done(uint32_t nrows, uint32_t* counters, uin
 __device__ __forceinline__ void last_block_reduce(const fr_t* partials, uint32_t nx, uint32_t K, uint32_t y, uint32_t nrows, uint32_t* counters, fr_t* __restrict__ out, RedScratch& S,
                                                   uint32_t* flag, uint32_t seq, uint32_t Kv = 0xffffffffu) {
   __shared__ uint32_t is_last;
-  if (threadIdx.x == 0) {   // wave 0 holds the partial stores; fence and vmcnt are wave-wide
+  if (threadIdx.x == 0) {   // wave 0 holds the partial stores (sc1: result_store); vmcnt is wave-wide
+#ifdef LASSO_PLAIN_PARTIALS
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     uint32_t ticket = __hip_atomic_fetch_add(&counters[y], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     uint32_t last = (ticket == nx - 1) ? 1u : 0u;
