@@ -67,6 +67,10 @@ int32_t lasso_ctx_create(int32_t device, lasso_ctx** out);
 /* The same with a stream priority: background != 0 gives the context's stream the lowest priority of the device (bulk work issued beside a
  * latency-bound context, see lasso_amd/host/prover.hpp Dev::side), 0 the highest (what lasso_ctx_create does). */
 int32_t lasso_ctx_create_background(int32_t device, int32_t background, lasso_ctx** out);
+/* 16 bytes that identify the PHYSICAL device behind the context (hipDeviceGetUuid).  Slab mode uses it to learn whether two ranks of one proof share a GPU (P contexts of one
+ * device: the one-box tests): launches that wait ON THE DEVICE for a challenge that depends on another rank's result must then not be used — streams of one device share its few
+ * hardware queues, and a waiting gate would sit in front of the very kernel it waits for. */
+int32_t lasso_ctx_device_uuid(lasso_ctx* ctx, uint8_t out[16]);
 void lasso_ctx_destroy(lasso_ctx* ctx);
 const char* lasso_last_error(lasso_ctx* ctx);          /* ctx may be NULL: last error of a failed create */
 int32_t lasso_alloc(lasso_ctx* ctx, size_t bytes, void** d_out);

@@ -113,6 +113,7 @@ def declare(lib):
         "lasso_rccl_ready": (i32, [vp]),
         "lasso_rccl_shutdown": (i32, [vp]),
         "lasso_rccl_selftest": (i32, [vp]),
+        "lasso_ctx_device_uuid": (i32, [vp, vp]),
         "lasso_bases_prepare": (i32, [vp, vp, u32]),
         "lasso_rccl_allgather": (i32, [vp, vp, vp, sz]),
         "lasso_point_row_bytes": (sz, []),

@@ -451,6 +451,13 @@ static inline void post_mail(lasso_ctx* c, uint32_t tag, const uint32_t w[8]) {
 #endif
 }
 int32_t lasso_ctx_create(int32_t device, lasso_ctx** out) { return lasso_ctx_create_background(device, 0, out); }
+int32_t lasso_ctx_device_uuid(lasso_ctx* c, uint8_t out[16]) {
+  REQUIRE(c, c && out);
+  hipUUID u; memset(&u, 0, sizeof(u));
+  HIPCHK(c, hipDeviceGetUuid(&u, c->device));
+  static_assert(sizeof(u.bytes) == 16, "hipUUID");
+  memcpy(out, u.bytes, 16); return 0;
+}
 // background != 0: the context's stream gets the LOWEST priority the device offers (the prover's side context: bulk work that must not delay
 // the latency-bound kernels of the main context); otherwise the highest.
 int32_t lasso_ctx_create_background(int32_t device, int32_t background, lasso_ctx** out) {

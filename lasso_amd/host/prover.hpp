@@ -84,6 +84,7 @@ inline size_t ceil_log2(size_t n) { size_t k = 0; while (((size_t)1 << k) < n) k
 typedef int32_t (*lasso_allgather_fn)(void* user, const void* send, void* recv, size_t bytes);
 struct Comm {
   size_t rank = 0, world = 1; lasso_allgather_fn fn = nullptr; void* user = nullptr;
+  bool shared_device = false;   // another rank of this proof runs on the SAME physical device (found out once, Dev::note_shared_devices): nothing may then wait on the device for a peer's result
   bool sharded() const { return world > 1; }
   size_t log_world() const { size_t k = 0; while (((size_t)1 << k) < world) k++; return k; }
   void allgather(const void* send, void* recv, size_t bytes) const {
@@ -137,6 +138,21 @@ class Dev {
   // the pool's stream-ordered reuse argument below holds per context, so lasso_sync(side()) precedes their release.
   lasso_ctx* side() const { if (!side_ && lasso_ctx_create_background(device_, 1, &side_) != 0) throw Error(std::string("lasso_ctx_create (side): ") + lasso_last_error(nullptr)); return side_; }
   void chk_side(int32_t rc, const char* what) const { if (rc != 0) throw Error(std::string(what) + " failed on the side context (" + std::to_string(rc) + "): " + lasso_last_error(side_)); }
+  // slab mode: do two ranks of the proof share a physical device?  One all-gather of the 16-byte device identifiers, the first time the question is asked after the
+  // communicator was set (collective: every rank asks at the same point — the first proof's first slab sumcheck).
+  bool ranks_share_a_device() const {
+    if (!comm.sharded()) return false;
+    if (!shared_known_) {
+      std::vector<uint8_t> mine(16, 0), all(16 * comm.world, 0);
+      chk(lasso_ctx_device_uuid(ctx, mine.data()), "lasso_ctx_device_uuid");
+      comm.allgather(mine.data(), all.data(), 16);
+      bool shared = false;
+      for (size_t a = 0; a < comm.world; a++) for (size_t b = a + 1; b < comm.world; b++) if (memcmp(&all[16 * a], &all[16 * b], 16) == 0) shared = true;
+      const_cast<Comm&>(comm).shared_device = shared; shared_known_ = true;
+    }
+    return comm.shared_device;
+  }
+  mutable bool shared_known_ = false;
   Dev(const Dev&) = delete; Dev& operator=(const Dev&) = delete;
   void chk(int32_t rc, const char* what) const { if (rc != 0) throw Error(std::string(what) + " failed (" + std::to_string(rc) + "): " + lasso_last_error(ctx)); }
   // error unwinding: leave both contexts usable (a resident kernel may be waiting for a challenge, a deferred result may be uncollected)
@@ -873,7 +889,8 @@ class Prover {
     bool in_tail = false;
     // streaming rounds launched ahead of their challenge, as in cubic_rounds (in-place rounds only: from round 2 on)
     static const bool ahead_env_off = [] { const char* v = getenv("LASSO_ROUNDS_AHEAD"); return v && v[0] == '0'; }();
-    const bool ahead_ok = !ahead_env_off && !reduce && !degenerate && P == 1 && !d.no_ahead() && lasso_rounds_ahead_ok(d.ctx) == 1;
+    static const bool slab_ahead_off = [] { const char* v = getenv("LASSO_SLAB_AHEAD"); return v && v[0] == '0'; }();
+    const bool ahead_ok = !ahead_env_off && !degenerate && (reduce ? (!slab_ahead_off && !d.ranks_share_a_device()) : P == 1) && !d.no_ahead() && lasso_rounds_ahead_ok(d.ctx) == 1;   // with a collective between the rounds too (cubic_rounds says why)
     bool queued = false;
     auto enqueue_next = [&](size_t jn, size_t len_now) {   // round jn (>= 2) on arrays of len_now elements, behind the round in flight
       if (!ahead_ok || jn < 2 || jn >= rounds || jn >= tail_from) return;
@@ -1202,7 +1219,10 @@ class Prover {
       if (!use_pre) d.chk(lasso_point_cancel(d.ctx), "lasso_point_cancel");
     }
     static const bool ahead_env_off = [] { const char* v = getenv("LASSO_ROUNDS_AHEAD"); return v && v[0] == '0'; }();
-    const bool ahead_ok = !ahead_env_off && !reduce && !degenerate && P == 1 && !d.no_ahead() && heads_out && lasso_rounds_ahead_ok(d.ctx) == 1;
+    // Slab mode (reduce, round 6): the ranks' partial sums meet on the host (d.comm.sum below) BEFORE the challenge exists, so posting it is the same step one exchange later —
+    // every rank keeps its own next round in its own stream behind its own gate.  (The resident tail is not used with a collective between the rounds: tail_from == rounds.)
+    static const bool slab_ahead_off = [] { const char* v = getenv("LASSO_SLAB_AHEAD"); return v && v[0] == '0'; }();   // A/B switch: round 5's schedule for P > 1
+    const bool ahead_ok = !ahead_env_off && !degenerate && (reduce ? (!slab_ahead_off && !d.ranks_share_a_device()) : (P == 1 && heads_out != nullptr)) && !d.no_ahead() && lasso_rounds_ahead_ok(d.ctx) == 1;
     bool queued = false, queued_tail = false;   // this round's kernel is already enqueued (a streaming round / the resident tail) and waits for r_prev
     std::vector<DBuf> leaf_full;   // the leaves after all, for the rare shapes the chunked rounds do not cover
     if (leaf) {
@@ -1340,6 +1360,21 @@ class Prover {
       const size_t local_rounds = num_rounds - lgP;
       cubic_rounds(local_rounds, (size_t)1 << local_rounds, fa, fb, d_E, rand, 0, coeffs, true, s_run, e, proof, r_out, nullptr, leaf);
       std::vector<lasso_fr*> local_heads(fa); local_heads.insert(local_heads.end(), fb.begin(), fb.end());
+      static const bool slab_host_tail_off = [] { const char* v = getenv("LASSO_SLAB_HOST_TAIL"); return v && v[0] == '0'; }();   // A/B switch: round 5's device phase
+      if (!slab_host_tail_off) {
+        // Round 6: the remaining log2 P variables live in P-element arrays that every rank holds whole after one all-gather of the local heads — 2 k P field elements.  Round 5
+        // uploaded them (2k hipMemcpy), built a P-entry eq table and ran a resident kernel for log2 P rounds: ~100 us of launches and hand-offs per layer for a few dozen field
+        // products.  They are the host's: host_cubic_rounds is sumcheck.rs:49-124 literally on (A_c, B_c, eq), every rank computes the same bytes, nothing touches the device.
+        std::vector<lasso_fr> mine(2 * k), all(2 * k * P);
+        d.chk(lasso_read_heads(d.ctx, (const lasso_fr* const*)local_heads.data(), (uint32_t)(2 * k), mine.data()), "lasso_read_heads");
+        d.comm.allgather(mine.data(), all.data(), 2 * k * sizeof(lasso_fr));
+        std::vector<ScVec> ha(k, ScVec(P)), hb(k, ScVec(P));   // element g = rank g's head: the rank index IS the remaining low variables (gather_tail's layout)
+        for (size_t g = 0; g < P; g++) for (size_t c = 0; c < k; c++) { ha[c][g] = Sc::from_abi(all[g * 2 * k + c]); hb[c][g] = Sc::from_abi(all[g * 2 * k + k + c]); }
+        host_cubic_rounds(ha, hb, lgP, rand, local_rounds, coeffs, s_run, e, proof, r_out, heads);
+        claims_a.clear(); claims_b.clear();
+        for (size_t i = 0; i < k; i++) { claims_a.push_back(Sc::from_abi(heads[i])); claims_b.push_back(Sc::from_abi(heads[k + i])); }
+        return proof;
+      }
       std::vector<lasso_fr*> tail = gather_tail(local_heads);
       fa.assign(tail.begin(), tail.begin() + k); fb.assign(tail.begin() + k, tail.begin() + 2 * k);
       // the remaining log2 P variables: replicated P-element arrays and the (whole) eq table over rand[local_rounds..]

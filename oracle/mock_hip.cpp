@@ -57,6 +57,9 @@ static Point get_point(const lasso_point* p) { Point q; memcpy(q.X.v, p->x, 32);
 extern "C" {
 int32_t lasso_ctx_create(int32_t, lasso_ctx** out) { *out = new lasso_ctx(); return 0; }
 int32_t lasso_ctx_create_background(int32_t, int32_t, lasso_ctx** out) { *out = new lasso_ctx(); return 0; }
+// every mock context is its own "device" (nothing is shared between two of them: no queues, no gates that could wait behind each other), so slab mode's launched-ahead schedule is
+// exercised by the CPU tests; the real library reports the physical device
+int32_t lasso_ctx_device_uuid(lasso_ctx* c, uint8_t out[16]) { if (!c || !out) return LASSO_ERR_INVALID; memset(out, 0, 16); const uintptr_t p = (uintptr_t)c; memcpy(out, &p, sizeof(p)); out[15] = 0x4d; return 0; }
 void lasso_ctx_destroy(lasso_ctx* c) { delete c; }
 const char* lasso_last_error(lasso_ctx* c) { return c ? c->err.c_str() : ""; }
 void* lasso_stream(lasso_ctx*) { return nullptr; }

@@ -125,3 +125,44 @@ def test_slab_threads_over_the_shm_exchange_and_capacity_mode(slab, host, world,
     finally:
         host.free(dense, gens)
     assert all(u > 0 for u in used)     # the prover's own accounting (the mock does not track device bytes)
+
+
+_SLAB_SWITCH_SCRIPT = r"""
+import ctypes as C, hashlib, sys
+sys.path.insert(0, "tests")
+import numpy as np
+from lasso_amd import _abi
+import test_slab_sharding_cpu as T
+from proverutil import HostProver, build_mock_prover
+lib = T.build_slab_lib()
+hp = HostProver(C.CDLL(build_mock_prover()))
+for world, (kind, c, log_m, log_r, lookups) in [(2, T.CASES[0]), (4, T.CASES[2]), (8, T.CASES[6]), (2, T.CASES[4])]:
+    S = _abi.Strategy(_abi.KINDS[kind], c, log_m, log_r)
+    alpha = 2 * c if kind == "lt" else c
+    s = 1 << (lookups - 1).bit_length()
+    idx = np.random.default_rng(world * 1000 + lookups + c).integers(0, 1 << log_m, size=(lookups, c), dtype=np.uint64)
+    r = hp.gen_random_point(s.bit_length() - 1)
+    comm, proof, _, _ = T.slab_prove(lib, world, S, alpha, idx, r)
+    print("DIGEST", hashlib.sha256(comm + proof).hexdigest())
+"""
+
+
+@pytest.mark.parametrize("env", [{"LASSO_SLAB_AHEAD": "0"}, {"LASSO_SLAB_HOST_TAIL": "0"}, {"LASSO_SLAB_AHEAD": "0", "LASSO_SLAB_HOST_TAIL": "0"}, {"LASSO_ROUNDS_AHEAD": "0"}])
+def test_slab_schedule_switches_do_not_change_the_bytes(env):
+    """Round 6 brought round 5's schedule to slab mode: rounds launched ahead of their challenge with the cross-rank exchange in between (LASSO_SLAB_AHEAD), and the last log2 P
+    rounds of every layer on the host from one all-gather of the local heads instead of uploads + a device phase (LASSO_SLAB_HOST_TAIL).  Both only move WHERE and WHEN the same
+    field arithmetic runs: with either switched off (round 5's schedule) commitment and proof bytes are the default's (each setting in its own process: the switches are read once).
+    The defaults themselves are held to the oracle by test_slab_proof_equals_single_rank_and_oracle above."""
+    import sys
+
+    def run(extra):
+        e = dict(os.environ)
+        for k in ("LASSO_SLAB_AHEAD", "LASSO_SLAB_HOST_TAIL", "LASSO_ROUNDS_AHEAD"):
+            e.pop(k, None)
+        e.update(extra); e["PYTHONPATH"] = ROOT + os.pathsep + e.get("PYTHONPATH", "")
+        out = subprocess.run([sys.executable, "-c", _SLAB_SWITCH_SCRIPT], env=e, cwd=ROOT, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return [l.split()[1] for l in out.stdout.splitlines() if l.startswith("DIGEST")]
+    want = run({})
+    assert len(want) == 4
+    assert run(env) == want
