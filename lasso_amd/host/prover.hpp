@@ -1418,11 +1418,11 @@ class Prover {
       LASSO_REQUIRE(((size_t)1 << rand.size()) == len / 2);
       const size_t num_rounds_prod = ceil_log2(len / 2);
       if (host_tops && len <= host_tops->len && !(leaf && layer_id == 0)) {   // a layer of O(1) elements: the whole layer proof on the host (grand_product.rs:113-190, same transcript schedule)
-        LASSO_REQUIRE(P == 1 && host_tops->run.size() == k);
+        LASSO_REQUIRE(host_tops->run.size() == k && (P == 1 || host_tops->len == P));   // P > 1 (round 6): the replicated top layers P, P/2, .., 2 — every rank holds them whole
         const size_t off = 2 * host_tops->len - 2 * len;    // within the run, as in the arena: the layer of `len` elements starts 2 * len elements before the end (+ 2)
         std::vector<ScVec> ha(k), hb(k);
         for (size_t c = 0; c < k; c++) { const ScVec& r = host_tops->run[c]; ha[c].assign(r.begin() + off, r.begin() + off + len / 2); hb[c].assign(r.begin() + off + len / 2, r.begin() + off + len); }
-        if (layer_id > 0 && 2 * len > host_tops->len && !leaf) enqueue_next_layer(trees, n, layer_id - 1, eq.p);   // the first layer the device proves: its first launch waits for its point from here on
+        if (P == 1 && layer_id > 0 && 2 * len > host_tops->len && !leaf) enqueue_next_layer(trees, n, layer_id - 1, eq.p);   // the first layer the device proves: its first launch waits for its point from here on
         ScVec coeff_vec = t.challenge_vector("rand_coeffs_next_layer", claims_to_verify.size());
         Sc claim = Sc::zero(); for (size_t i = 0; i < claims_to_verify.size(); i++) claim += claims_to_verify[i] * coeff_vec[i];
         LayerProofBatched lp; ScVec rand_prod; std::vector<lasso_fr> heads;
@@ -1894,6 +1894,23 @@ class Prover {
       Sc prod = Sc::one(); for (auto& x : all) prod *= Sc::from_abi(x);
       return prod;
     };
+    // Slab mode (round 6): the global layers of P, P/2, .., 2 elements are built from the all-gathered local roots — which arrive ON THE HOST.  Round 5 uploaded them, built the
+    // layers on the device and proved them with device rounds (log2 P layers per argument, each a launch or a resident kernel's worth of hand-offs for <= P field products);
+    // now the layers are P - 1 host products and bgpa_prove proves them through host_cubic_rounds, as it does a single GPU's tree tops.  LASSO_SLAB_HOST_TOPS=0: round 5's form.
+    static const bool slab_host_tops_off = [] { const char* v = getenv("LASSO_SLAB_HOST_TOPS"); return v && v[0] == '0'; }();
+    const bool slab_host_tops = P > 1 && !slab_host_tops_off;
+    auto root_and_host_top = [&](const DBuf& tree, size_t n_loc, size_t missing, HostTops& T, size_t c, size_t kk) {
+      lasso_fr two[2]; const lasso_fr* last[2] = {tree.p + (2 * n_loc - 4 - missing), tree.p + (2 * n_loc - 3 - missing)};
+      d.chk(lasso_read_heads(d.ctx, last, 2, two), "lasso_read_heads");
+      const Sc local = Sc::from_abi(two[0]) * Sc::from_abi(two[1]);
+      std::vector<lasso_fr> mine{local.abi()}, all(P);
+      d.comm.allgather(mine.data(), all.data(), sizeof(lasso_fr));
+      if (T.run.empty()) { T.len = P; T.run.assign(kk, ScVec()); }
+      ScVec& run = T.run[c]; run.clear(); run.reserve(2 * P - 2);
+      for (auto& x : all) run.push_back(Sc::from_abi(x));                                  // the layer of P elements: element g = rank g's local root
+      for (size_t len = P, off = 0; len > 2; off += len, len /= 2) for (size_t i = 0; i < len / 2; i++) run.push_back(run[off + i] * run[off + i + len / 2]);   // grand_product.rs:25-30's pairs (i, i + len/2)
+      return run[run.size() - 2] * run[run.size() - 1];
+    };
     ScVec roots_rw, roots_if;
     std::vector<lasso_fr*> rw, inf, rw_top, inf_top;
     // One GPU: the TOP of every tree — its layers of at most 2 * m_stop elements — comes to the host in one read per argument (lasso_read_runs through the mapped buffer:
@@ -1919,8 +1936,13 @@ class Prover {
       lasso_fr *ti_top = nullptr, *tr_top = nullptr, *tw_top = nullptr, *tf_top = nullptr;
       const size_t lm = leafless ? s_loc : 0;
       Sc hi, hr, hw, hf;
+      if (slab_host_tops) {   // (the four all-gathers in the same order on every rank)
+        hi = root_and_host_top(t_init[i], m_loc, 0, tops_if, 2 * i, 2 * alpha); hf = root_and_host_top(t_final[i], m_loc, 0, tops_if, 2 * i + 1, 2 * alpha);
+        hr = root_and_host_top(t_read[i], s_loc, lm, tops_rw, 2 * i, 2 * alpha); hw = root_and_host_top(t_write[i], s_loc, lm, tops_rw, 2 * i + 1, 2 * alpha);
+      } else {
       if (tops_if.len) { hi = root_of(tops_if, 2 * i); hf = root_of(tops_if, 2 * i + 1); } else { hi = root_and_top(t_init[i], m_loc, ti_top); hf = root_and_top(t_final[i], m_loc, tf_top); }
       if (tops_rw.len) { hr = root_of(tops_rw, 2 * i); hw = root_of(tops_rw, 2 * i + 1); } else { hr = root_and_top(t_read[i], s_loc, tr_top, lm); hw = root_and_top(t_write[i], s_loc, tw_top, lm); }
+      }
       if (!(hi * hw == hr * hf)) throw Error("memory checking: hash_init * hash_write != hash_read * hash_final (memory_checking.rs:689)");
       t.append_scalar("claim_hash_init", hi); t.append_scalar("claim_hash_read", hr); t.append_scalar("claim_hash_write", hw); t.append_scalar("claim_hash_final", hf);
       W.sc(hi); W.sc(hr); W.sc(hw); W.sc(hf);

@@ -147,17 +147,19 @@ for world, (kind, c, log_m, log_r, lookups) in [(2, T.CASES[0]), (4, T.CASES[2])
 """
 
 
-@pytest.mark.parametrize("env", [{"LASSO_SLAB_AHEAD": "0"}, {"LASSO_SLAB_HOST_TAIL": "0"}, {"LASSO_SLAB_AHEAD": "0", "LASSO_SLAB_HOST_TAIL": "0"}, {"LASSO_ROUNDS_AHEAD": "0"}])
+@pytest.mark.parametrize("env", [{"LASSO_SLAB_AHEAD": "0"}, {"LASSO_SLAB_HOST_TAIL": "0"}, {"LASSO_SLAB_HOST_TOPS": "0"}, {"LASSO_SLAB_AHEAD": "0", "LASSO_SLAB_HOST_TAIL": "0", "LASSO_SLAB_HOST_TOPS": "0"},
+                                 {"LASSO_ROUNDS_AHEAD": "0"}])
 def test_slab_schedule_switches_do_not_change_the_bytes(env):
     """Round 6 brought round 5's schedule to slab mode: rounds launched ahead of their challenge with the cross-rank exchange in between (LASSO_SLAB_AHEAD), and the last log2 P
-    rounds of every layer on the host from one all-gather of the local heads instead of uploads + a device phase (LASSO_SLAB_HOST_TAIL).  Both only move WHERE and WHEN the same
+    rounds of every layer on the host from one all-gather of the local heads instead of uploads + a device phase (LASSO_SLAB_HOST_TAIL), and the replicated top layers P .. 2 of
+    every tree built and proved on the host from the all-gathered local roots (LASSO_SLAB_HOST_TOPS).  All of it only moves WHERE and WHEN the same
     field arithmetic runs: with either switched off (round 5's schedule) commitment and proof bytes are the default's (each setting in its own process: the switches are read once).
     The defaults themselves are held to the oracle by test_slab_proof_equals_single_rank_and_oracle above."""
     import sys
 
     def run(extra):
         e = dict(os.environ)
-        for k in ("LASSO_SLAB_AHEAD", "LASSO_SLAB_HOST_TAIL", "LASSO_ROUNDS_AHEAD"):
+        for k in ("LASSO_SLAB_AHEAD", "LASSO_SLAB_HOST_TAIL", "LASSO_SLAB_HOST_TOPS", "LASSO_ROUNDS_AHEAD"):
             e.pop(k, None)
         e.update(extra); e["PYTHONPATH"] = ROOT + os.pathsep + e.get("PYTHONPATH", "")
         out = subprocess.run([sys.executable, "-c", _SLAB_SWITCH_SCRIPT], env=e, cwd=ROOT, capture_output=True, text=True, timeout=900)
