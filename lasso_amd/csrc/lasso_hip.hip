@@ -1614,9 +1614,15 @@ static int32_t run_msm(lasso_ctx* c, const uint8_t* d_scal, uint32_t bps, uint32
   const niels29* t8[2] = {nullptr, nullptr};
   const uint32_t W8 = (W + 1) / 2;
   if (bps == 4 && W <= 4 && rows >= 32 && msm_rows8_enabled()) { t8[0] = ensure_tab8(c, b, 0); t8[1] = W8 > 1 && t8[0] ? ensure_tab8(c, b, 1) : t8[0]; if (!t8[1]) t8[0] = nullptr; }
+  // full-width scalars over the signed byte-multiple table (k_msm_rows_full: 32 additions per scalar, no buckets) — MEASURED AND NOT THE DEFAULT (round 6, LASSO_MSM_FULL8=1 turns
+  // it on): Spark C=16 2^22's E commitment 198 ms against the bucket kernel's 182 ms.  Half the additions, but every one of them reads its own 128-byte line of a 4.3 GB table
+  // (8194 generators x 32 windows x 128 multiples): 2.1e9 random line reads = 1.38 TB/s, the rate HBM serves random lines at; the bucket kernel's 64-window table is 67 MB and
+  // stays in the Infinity Cache.  profiles/r06_full_width_commit_ab.txt
+  static const bool full8_on = [] { const char* v = getenv("LASSO_MSM_FULL8"); return v && v[0] == '1'; }();
+  const bool full8 = bps == 32 && b->d_mult8 != nullptr && full8_on && !t8[0];
   {
     ProfScope ps(c, LASSO_K_MSM, (double)rows * n_cols * bps, msm_ref_adds(rows, n_cols, bps == 4 ? 4 * W : FR_MODULUS_BITS), rows > MSM_SMALL_ROWS,
-                 (double)rows * n_cols * (t8[0] ? W8 : W));
+                 (double)rows * n_cols * (t8[0] ? W8 : full8 ? 32 : W));
     // many SHORT rows: one wave per row (k_msm_rows8w: 64 additions per lane and a 6-level tree inside the wave instead of 16 per thread and a 256-point tree).  Measured
     // (profiles/r04_ab_rows8w.txt): -9 % on the headline's E (4096 one-byte columns), -8 % on BN254 configs[1], +2 % on configs[2]'s 16384-column rows, where a thread of the
     // 256-lane kernel already runs 64 additions — hence the column bound.  LASSO_MSM_ROWS8W=0: A/B switch
@@ -1630,6 +1636,8 @@ static int32_t run_msm(lasso_ctx* c, const uint8_t* d_scal, uint32_t bps, uint32
                                                                       (uint32_t)n_cols, W8, t8[0], t8[1], b->n, d_partial, (uint32_t)rows, ps.counter(), (uint32_t)rpw);
     else if (t8[0]) hipLaunchKernelGGL(k_msm_rows8, dim3((unsigned)K, (unsigned)rows), dim3(MSM_THREADS), 0, c->stream, (const uint32_t*)d_scal, row_stride / 4, (uint32_t)n_cols, (uint32_t)cols_per_chunk, W8,
                                   t8[0], t8[1], b->n, d_partial, ps.counter());
+    else if (full8) hipLaunchKernelGGL((k_msm_rows_full<8>), dim3((unsigned)K, (unsigned)rows), dim3(MSM_THREADS), 0, c->stream, (const uint32_t*)d_scal, row_stride / 4, (uint32_t)n_cols, (uint32_t)cols_per_chunk,
+                                       (const niels29*)b->d_mult8, b->n, d_partial, ps.counter());
     else hipLaunchKernelGGL(k_msm_buckets, dim3((unsigned)K, (unsigned)rows), dim3(MSM_THREADS), 0, c->stream, d_scal, bps, W, row_stride, n_cols, cols_per_chunk, (const niels29*)b->d_table, b->n, d_partial, ps.counter());
     hipLaunchKernelGGL(k_points_sum, dim3((unsigned)rows), dim3(MSM_THREADS), 0, c->stream, (const pt29*)d_partial, (uint32_t)K, d_final, out_compressed ? (uint32_t*)d_final : (uint32_t*)nullptr,
                        c->d_counters + LASSO_MAX_PTRS + 1, small ? c->d_flag : (uint32_t*)nullptr, seq);

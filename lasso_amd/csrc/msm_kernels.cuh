@@ -708,6 +708,52 @@ __global__ void __launch_bounds__(MSM_THREADS) k_msm_direct(const uint32_t* __re
   msm_direct_finish(pts, st, &is_last, B, K, row, partial, out_mont, counters, flag, seq, &left, ln, lval);
 }
 
+// ------------------------------------------------------------------ row-parallel commitment of FULL-WIDTH scalars over the signed byte-multiple table (round 6)
+// MEASURED, NOT THE DEFAULT (lasso_hip.hip run_msm says why: half the additions, but random line reads of a multi-GB table at HBM's random-access rate).
+// The bucket kernel spends, per full-width scalar, one mixed addition per non-zero NIBBLE (~60) plus per workgroup a digit sort, a segmented tree, bit planes and a Horner chain.
+// Generator sets of up to 2^14 points already hold mult8 — every signed byte multiple m 256^w G_j, m = 1..128, built for the openings' latency-shaped MSMs — and with it a scalar is
+// a plain sum of ONE table entry per non-zero byte: 32 additions, no sort, no buckets, no doublings.  This is k_msm_rows8's schedule with k_msm_direct's signed recoding: a
+// workgroup owns (a chunk of) a row, stages 128 columns' recoded scalars in LDS at a time, every thread runs its share of the (column, window) items with the next entry in
+// flight, one cooperative tree at the end.  scal: canonical little-endian scalars, 8 words each, row r at scal + r * row_words.  out[row * K + chunk] (k_points_sum finishes).
+#define MSM_FULL8_COLS 128u
+template <int WB>
+__global__ void __launch_bounds__(MSM_THREADS) k_msm_rows_full(const uint32_t* __restrict__ scal, size_t row_words, uint32_t n_cols, uint32_t cols_per_chunk, const niels29* __restrict__ mult, size_t tn,
+                                                                pt29* __restrict__ out, uint32_t* digit_count) {
+  typedef MsmD<WB> D;
+  __shared__ pt29 pts[MSM_THREADS];
+  __shared__ fe29 st[MSM_ST_ROWS][4];
+  __shared__ uint32_t sb[MSM_FULL8_COLS * 8];
+  const fe29 d2 = fe_d2();
+  const uint32_t t = threadIdx.x;
+  const uint32_t* row = scal + (size_t)blockIdx.y * row_words;
+  const uint32_t c0 = blockIdx.x * cols_per_chunk;
+  uint32_t c1 = c0 + cols_per_chunk; if (c1 > n_cols) c1 = n_cols;
+  pt29 B = pt_identity();
+  niels29 cur; bool have = false; uint32_t nadds = 0;
+  for (uint32_t b0 = c0; b0 < c1; b0 += MSM_FULL8_COLS) {
+    const uint32_t nb = c1 - b0 < MSM_FULL8_COLS ? c1 - b0 : MSM_FULL8_COLS;
+    __syncthreads();   // the previous batch's digits have been read
+    for (uint32_t c = t; c < nb; c += MSM_THREADS) msm_recode<WB>(row + (size_t)(b0 + c) * 8, &sb[c * 8]);
+    __syncthreads();
+    const uint32_t items = nb * D::WINDOWS;
+    for (uint32_t it = t; it < items; it += MSM_THREADS) {
+      const uint32_t c = it >> D::LOGW, w = it & (D::WINDOWS - 1u);
+      const int32_t d = (int32_t)((sb[c * 8 + w / D::PER_WORD] >> (WB * (w % D::PER_WORD))) & D::DMASK) - (int32_t)D::MULTS;
+      const bool valid = d != 0;
+      const uint32_t m = d < 0 ? (uint32_t)(-d) : (uint32_t)d;
+      const niels29 nxt = mult[valid ? MSM_IDX(w, m - 1, b0 + c, tn, D::WINDOWS, D::MULTS) : 0];   // issued before the addition below, waited for after it
+      if (have) B = pt_madd(B, cur);
+      cur = niels_cond_neg(nxt, d < 0); have = valid; nadds += valid;
+    }
+  }
+  if (have) B = pt_madd(B, cur);
+  msm_count_adds(digit_count, nadds);
+  pts[t] = B;
+  __syncthreads();
+  msm_coop_tree(pts, st, MSM_THREADS, d2);
+  if (t == 0) out[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = pts[0];
+}
+
 // out[row] = sum_k partial[row*K + k], converted to ark's Montgomery limbs (out_mont) or, when out_compressed is given, to the 32-byte wire form.  One workgroup per row; thread t first adds partials
 // t, t+256, ... serially, then an LDS tree.  `out_mont` may be host-mapped memory: when `flag` is set, the row that finishes last
 // raises the host's sequence flag (same hand-off as last_block_reduce in poly_kernels.cuh).
