@@ -117,7 +117,11 @@ __device__ __forceinline__ bool mail_wait(const uint32_t* mailbox, uint32_t tag,
   const lasso_u32x4* m4 = reinterpret_cast<const lasso_u32x4*>(mailbox);
   lasso_u32x4 c0, c1, c2; uint32_t spins = 0;
   for (;;) {
+#ifndef LASSO_NO_POLL_FENCE
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");   // nothing cached from the previous poll
+#else
+    asm volatile("" ::: "memory");
+#endif
     c0 = __builtin_nontemporal_load(m4); c1 = __builtin_nontemporal_load(m4 + 1); c2 = __builtin_nontemporal_load(m4 + 2);   // three 16-byte reads in flight together
     if (mail_valid(c0, c1, c2, tag)) break;
     if (c0.x == LASSO_MAIL_POISON || ((++spins & 63u) == 0 && wall_clock64() > t_end)) return false;
@@ -318,7 +322,14 @@ __device__ __forceinline__ CubicGrid cubic_grid(uint32_t nx, uint32_t ny) {
 }
 // raise the host flag once every grid row has stored its results: called by the workgroup that finished row y, stores issued by wave 0
 __device__ __forceinline__ void row_done(uint32_t nrows, uint32_t* counters, uint32_t* flag, uint32_t seq) {
-  if (flag == LASSO_TAGGED || flag == LASSO_TAGGED_DIRECT) { if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, ""); return; }   // this row's chunks leave the device; nothing to agree on with the other rows
+  if (flag == LASSO_TAGGED || flag == LASSO_TAGGED_DIRECT) {   // this row's chunks leave the device; nothing to agree on with the other rows
+    // (the fence is REQUIRED: the mapped result area is cached in the device's L2 — without it the host never sees the chunks of a kernel that stays resident.  Round 6 tried:
+    // tools/tail_phase_bench built with -DLASSO_NO_PUBLISH_FENCE stops at turn 0, with -DLASSO_NO_POLL_FENCE (no acquire in the mailbox poll) at turn 1 on a stale line.)
+#ifndef LASSO_NO_PUBLISH_FENCE
+    if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+#endif
+    return;
+  }
   if (threadIdx.x == 0 && flag) {
     __threadfence_system();
     uint32_t t2 = __hip_atomic_fetch_add(&counters[LASSO_MAX_PTRS], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
@@ -769,7 +780,11 @@ __global__ void __launch_bounds__(Q) k_cubic_tail(TM A, TM B, const fr_t* __rest
       const u32x4* m4 = reinterpret_cast<const u32x4*>(mailbox);
       uint32_t ok = 1; u32x4 c0, c1, c2; uint32_t spins = 0;
       for (;;) {
+#ifndef LASSO_NO_POLL_FENCE
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");   // nothing cached from the previous poll
+#else
+        asm volatile("" ::: "memory");
+#endif
         c0 = __builtin_nontemporal_load(m4); c1 = __builtin_nontemporal_load(m4 + 1); c2 = __builtin_nontemporal_load(m4 + 2);   // three 16-byte reads in flight together
         if (mail_valid(c0, c1, c2, seq0 + turn + 1)) break;   // tagged with the sequence number of the publication it enables: unique per context, never reset
         if (c0.x == LASSO_MAIL_POISON || ((++spins & 63u) == 0 && wall_clock64() > t_end)) { ok = 0; break; }   // lasso_abort's tag, or the host stopped answering
