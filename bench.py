@@ -121,7 +121,7 @@ def pmc_traffic(key):
     """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command ON THIS WORKLOAD (profiles/r0N_pmc/<workload key>/bench_traffic.json, written by
     tools/pmc_summary.py: FETCH_SIZE x2 per MI355X_MICROARCH.md's gfx950 correction + WRITE_SIZE, large launches only).  {} when no pass of this workload is
     committed — `traffic` / `frac_traffic` are then null rather than borrowed from another configuration (VERDICT r2 "What's weak" 4)."""
-    for d in ("r05_pmc", "r03_pmc", "r02_pmc", "r01_pmc"):     # newest committed passes first
+    for d in ("r06_pmc", "r05_pmc", "r03_pmc", "r02_pmc", "r01_pmc"):     # newest committed passes first
         for sub in (key, ""):
             try:
                 with open(os.path.join(ROOT, "profiles", d, sub, "bench_traffic.json")) as f:
@@ -359,7 +359,7 @@ def bind_top_sweep(dev_lib, ctx, _abi, curve, iterations=20, warmup=3):
            "timing": "HIP events on the library's stream around each launch (lasso_prof_*), buffer sets rotated so that no launch re-reads what the previous one touched",
            "rows": rows, "frac_min": min((x["frac"] for x in ok), default=None), "frac_max": max((x["frac"] for x in ok), default=None)}
     out["traffic"] = None
-    for d in ("r05_pmc", "r04_pmc"):     # counter-measured HBM bytes of the same sweep (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --only-bind-sweep`, tools/pmc_bind_summary.py)
+    for d in ("r06_pmc", "r05_pmc", "r04_pmc"):     # counter-measured HBM bytes of the same sweep (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --only-bind-sweep`, tools/pmc_bind_summary.py)
         try:
             with open(os.path.join(ROOT, "profiles", d, "bind_top_sweep", "bench_traffic.json")) as f:
                 t = json.load(f)
