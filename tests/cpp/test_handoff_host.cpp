@@ -12,6 +12,9 @@
 #define __forceinline__ inline
 #define __restrict__
 typedef uint32_t lasso_u32x4 __attribute__((ext_vector_type(4)));
+// round 6: result_store's partials path (flag == nullptr) uses write-through 8-byte stores on the device; on the host they are plain stores of the same bytes
+#define __HIP_MEMORY_SCOPE_AGENT 0
+#define __hip_atomic_store(ptr, val, order, scope) (*(ptr) = (val))
 #include "handoff_extract.hpp"
 #define CHECK(c) do { if (!(c)) { printf("FAIL %s line %d\n", #c, __LINE__); return 1; } } while (0)
 int main() {
@@ -23,6 +26,9 @@ int main() {
     if (trial % 7 == 0) memset(v.v, 0, 32);
     if (trial % 11 == 0) memset(v.v, 0xff, 32);
     memset(area, 0, sizeof(area));
+    // device -> device, block partials (flag == nullptr): the element's 32 bytes as they are, at 32 * slot
+    result_store(plain, slot, v, (uint32_t*)nullptr, seq);
+    CHECK(memcmp(plain[slot].v, v.v, 32) == 0);
     // device -> host, tagged: three chunks at 48 * slot, accepted with exactly the stored words
     result_store(reinterpret_cast<fr_t*>(area), slot, v, LASSO_TAGGED, seq);
     uint32_t w[8];
