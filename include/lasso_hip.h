@@ -440,6 +440,18 @@ int32_t lasso_bullet_ahead_ok(lasso_ctx* ctx, const lasso_bases* bases);
 int32_t lasso_bullet_round_ahead(lasso_ctx* ctx, const lasso_bases* bases, size_t n, const lasso_fr* d_a_in, const lasso_fr* d_b_in, const lasso_fr* d_w_in,
                                  lasso_fr* d_a_out, lasso_fr* d_b_out, lasso_fr* d_w_out, size_t nk, const lasso_fr* blinds);
 int32_t lasso_bullet_post(lasso_ctx* ctx, const lasso_fr* u, const lasso_fr* u_inv);
+/* The END of an opening enqueued ahead of its last challenge (round 6): what dot_product.rs:198-231 does after the last folding round — the last fold of a, b (two elements each)
+ * and of the generators' weights (bullet.rs:127-132), x_hat = a[0], a_hat = b[0], and delta = d * g_hat + r_delta * h (dot_product.rs:219-224: one MSM over the folded weights) —
+ * as ONE chain in the stream: gate, fold, MSM (which also publishes the two heads).  Enqueue it right after lasso_bullet_post of the last round (its result may still be pending),
+ * collect that round's L, R, draw u, then
+ *   lasso_bullet_post(ctx, u, u_inv)               release the chain
+ *   lasso_result_wait(ctx, out, 6)                 out[0..4) = delta as a lasso_point, out[4] = d_a[0], out[5] = d_b[0]
+ * d_a, d_b: the two-element state after the last round (folded in place); d_w: n / 2 weights, d_w_out: n; scale = d; tail = {0, r_delta} (the Q and h terms).
+ * Same group element and field elements as lasso_bullet_fold + lasso_read_heads + lasso_msm_dev_scaled.  lasso_bullet_tail_ahead_ok: lasso_bullet_ahead_ok, tagged results on,
+ * LASSO_BULLET_TAIL_AHEAD != 0.  LASSO_ERR_UNSUPPORTED when a buffer would have to grow (first proof of a context: the plain calls size them). */
+int32_t lasso_bullet_tail_ahead_ok(lasso_ctx* ctx, const lasso_bases* bases);
+int32_t lasso_bullet_tail_ahead(lasso_ctx* ctx, const lasso_bases* bases, size_t n, lasso_fr* d_a, lasso_fr* d_b, const lasso_fr* d_w, size_t nw, lasso_fr* d_w_out,
+                                const lasso_fr* scale, const lasso_fr* tail);
 /* bullet.rs:127-132: a[i] <- a_L[i]*u + u_inv*a_R[i], b[i] <- b_L[i]*u_inv + u*b_R[i] for i < nk/2 (in place), and the
  * generator fold G[i] <- G_L[i]*u_inv + G_R[i]*u recorded as weights: d_w_out[2*blk] = d_w[blk]*u_inv, d_w_out[2*blk+1] = d_w[blk]*u. */
 int32_t lasso_bullet_fold(lasso_ctx* ctx, lasso_fr* d_a, lasso_fr* d_b, size_t nk, const lasso_fr* d_w, size_t nw, lasso_fr* d_w_out, const lasso_fr* u, const lasso_fr* u_inv);

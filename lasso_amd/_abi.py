@@ -114,6 +114,8 @@ def declare(lib):
         "lasso_rccl_shutdown": (i32, [vp]),
         "lasso_rccl_selftest": (i32, [vp]),
         "lasso_ctx_device_uuid": (i32, [vp, vp]),
+        "lasso_bullet_tail_ahead_ok": (i32, [vp, vp]),
+        "lasso_bullet_tail_ahead": (i32, [vp, vp, sz, vp, vp, vp, sz, vp, vp, vp]),
         "lasso_bases_prepare": (i32, [vp, vp, u32]),
         "lasso_rccl_allgather": (i32, [vp, vp, vp, sz]),
         "lasso_point_row_bytes": (sz, []),

@@ -1574,16 +1574,21 @@ static bool msm_tagged(lasso_ctx* c) { static const bool off = [] { const char* 
 #define MSM_RES(c) (msm_tagged(c) ? (ed_point*)(c)->d_tag : (ed_point*)(c)->d_small), (c)->d_counters + LASSO_MAX_PTRS + 8, (msm_tagged(c) ? LASSO_TAGGED : (c)->d_flag)
 // mode 0: d_scal = canonical integers; 1: field elements in memory (Montgomery) form, converted by the kernel; 2: as 1 with the first n_cols - 2 columns
 // multiplied by *scale and the last two columns = tail[0], tail[1] (k_msm_direct<MODE>)
+// heads / gate_seq (the opening's tail chain): the launch also publishes heads[0][0], heads[1][0] behind the point, sits behind the gate of sequence number *gate_seq (whose tag it
+// checks and whose number its result carries) and is NOT waited for here
 static int32_t run_msm_direct(lasso_ctx* c, const uint8_t* d_scal, size_t row_stride, size_t rows, size_t n_cols, const MsmColMap& cm, const lasso_bases* b, uint8_t* scratch_after, lasso_point* out,
-                              int mode = 0, const lasso_fr* scale = nullptr, const lasso_fr* tail = nullptr, uint32_t sstride = 1, uint32_t soffset = 0) {
+                              int mode = 0, const lasso_fr* scale = nullptr, const lasso_fr* tail = nullptr, uint32_t sstride = 1, uint32_t soffset = 0,
+                              const lasso_fr* const* heads = nullptr, const uint32_t* gate_seq = nullptr) {
   const bool w8 = b->d_mult8 != nullptr; const size_t windows = w8 ? MsmD<8>::WINDOWS : MsmD<4>::WINDOWS;
   uint32_t ipc = 0; const size_t K = msm_direct_chunks(rows, n_cols, &ipc, windows);
-  const uint32_t seq = next_seq(c);
+  const uint32_t seq = gate_seq ? *gate_seq : next_seq(c);
+  const fr_t* const h0 = heads ? (const fr_t*)heads[0] : nullptr; const fr_t* const h1 = heads ? (const fr_t*)heads[1] : nullptr;
+  const uint32_t* const ggm = gate_seq ? (const uint32_t*)c->d_gmail : nullptr;
   {
     ProfScope ps(c, LASSO_K_MSM_DIRECT, (double)rows * n_cols * 32, msm_ref_adds(rows, n_cols, FR_MODULUS_BITS), false, (double)rows * n_cols * windows);
     const fr_t z = fr_zero();
 #define LAUNCH_DIRECT(M, WB_, TAB_, SC, T0, T1) hipLaunchKernelGGL((k_msm_direct<M, WB_>), dim3((unsigned)K, (unsigned)rows), dim3(MSM_THREADS), 0, c->stream, (const uint32_t*)d_scal, row_stride / 4, (uint32_t)n_cols, ipc, cm, \
-                       (const niels29*)TAB_, b->n, (pt29*)scratch_after, MSM_RES(c), seq, SC, T0, T1, ps.counter(), sstride, soffset)
+                       (const niels29*)TAB_, b->n, (pt29*)scratch_after, MSM_RES(c), seq, SC, T0, T1, ps.counter(), sstride, soffset, h0, h1, ggm)
     if (w8) {
       if (mode == 0) LAUNCH_DIRECT(0, 8, b->d_mult8, z, z, z);
       else if (mode == 1) LAUNCH_DIRECT(1, 8, b->d_mult8, z, z, z);
@@ -1595,6 +1600,7 @@ static int32_t run_msm_direct(lasso_ctx* c, const uint8_t* d_scal, size_t row_st
     }
   }
   HIPCHK(c, hipGetLastError());
+  if (gate_seq) return 0;   // released by lasso_bullet_post, collected by lasso_result_wait
   return wait_flag(c, seq, rows * (sizeof(ed_point) / sizeof(fr_t)), (lasso_fr*)out, msm_tagged(c));
 }
 static bool msm_direct_fused() { static const bool on = [] { const char* v = getenv("LASSO_MSM_FUSED"); return !(v && v[0] == '0'); }(); return on; }   // A/B switch: conversions and the bullet fold inside the MSM launch
@@ -1795,7 +1801,7 @@ static int32_t bullet_round_fused(lasso_ctx* c, const lasso_bases* b, size_t n, 
     else { if (w8) LAUNCH_BULLET(false, 8, b->d_mult8, nullptr, nullptr, nullptr, z, z); else LAUNCH_BULLET(false, 4, b->d_mult, nullptr, nullptr, nullptr, z, z); }
   }
   HIPCHK(c, hipGetLastError());
-  if (ahead) { c->ahead_active = true; c->ahead_bullet = true; c->ahead_seq = seq; c->ahead_tagged = msm_tagged(c); return 0; }
+  if (ahead) { c->ahead_active = true; c->ahead_bullet = true; c->ahead_seq = seq; c->ahead_tagged = msm_tagged(c); c->ahead_count = 2 * (sizeof(ed_point) / sizeof(fr_t)); return 0; }
   return wait_flag(c, seq, 2 * (sizeof(ed_point) / sizeof(fr_t)), (lasso_fr*)out, msm_tagged(c));
 }
 // slab mode of the opening (include/lasso_hip.h): this rank's share of L and R over its residue class of the generators
@@ -1857,12 +1863,40 @@ int32_t lasso_bullet_round_ahead(lasso_ctx* c, const lasso_bases* b, size_t n, c
   if (!bullet_ahead_possible(c, b)) return fail(c, LASSO_ERR_UNSUPPORTED, "lasso_bullet_round_ahead: not available for this generator set / configuration (lasso_bullet_ahead_ok)");
   return bullet_round_fused(c, b, n, d_a_in, d_b_in, d_w_in, d_a_out, d_b_out, d_w_out, nk, nullptr, nullptr, blinds, nullptr, 1, 0, true);
 }
+// ---- THE END OF AN OPENING enqueued ahead of its last challenge (round 6).  After the last folding round the host used to: draw u, launch the fold of the two-element
+// a, b and of the weights, launch lasso_read_heads and wait for it, launch the delta MSM over the folded weights, wait.  Three launches and two hand-offs behind one host turn.  Here
+// the whole chain — gate, k_bullet_fold (u, u^-1 from the gate), k_msm_direct<2> over d_w_out scaled by *scale with the two tail terms, which also publishes a[0] and b[0] — is in
+// the stream before the host has the last round's L and R; lasso_bullet_post releases it and lasso_result_wait(ctx, out, 6) delivers the point (4 values) and the two heads.
+//   = lasso_bullet_fold(d_a, d_b, 2, d_w, nw, d_w_out, u, u_inv); lasso_read_heads({d_a, d_b}); lasso_msm_dev_scaled(bases, d_w_out, n, scale, tail)     with n = 2 nw
+int32_t lasso_bullet_tail_ahead_ok(lasso_ctx* c, const lasso_bases* b) {
+  static const bool off = [] { const char* v = getenv("LASSO_BULLET_TAIL_AHEAD"); return v && v[0] == '0'; }();
+  return c && !off && bullet_ahead_possible(c, b) && msm_tagged(c) ? 1 : 0;
+}
+int32_t lasso_bullet_tail_ahead(lasso_ctx* c, const lasso_bases* b, size_t n, lasso_fr* d_a, lasso_fr* d_b, const lasso_fr* d_w, size_t nw, lasso_fr* d_w_out, const lasso_fr* scale, const lasso_fr* tail) {
+  REQUIRE(c, b && d_a && d_b && d_w && d_w_out && scale && tail && n >= 2 && (n & (n - 1)) == 0 && 2 * nw == n && n + 2 <= b->n && d_w != d_w_out && !c->ahead_active && !c->tail_active && !c->defer_next && !c->lay_active);
+  if (!lasso_bullet_tail_ahead_ok(c, b)) return fail(c, LASSO_ERR_UNSUPPORTED, "lasso_bullet_tail_ahead: not available for this generator set / configuration (lasso_bullet_tail_ahead_ok)");
+  const size_t row = n + 2;
+  c->no_grow = true;   // nothing may synchronise the stream here: the previous round's kernel may still be running, its result uncollected
+  int32_t rc = ensure_scratch(c, msm_pts_bytes(1, row) + 512); if (!rc) rc = ensure_small(c, 8);
+  c->no_grow = false;
+  if (rc) return rc == LASSO_ERR_UNSUPPORTED ? fail(c, rc, "lasso_bullet_tail_ahead: a buffer would have to grow while kernels are in flight") : rc;
+  const uint32_t seq = next_seq(c);
+  hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, c->stream, (const uint32_t*)c->mail_d, c->d_gmail, seq, 1u);
+  const fr_t z = fr_zero();
+  hipLaunchKernelGGL(k_bullet_fold, dim3(grid_for(nw)), dim3(256), 0, c->stream, (fr_t*)d_a, (fr_t*)d_b, (size_t)1, (const fr_t*)d_w, nw, (fr_t*)d_w_out, z, z, (const uint32_t*)c->d_gmail, seq);
+  HIPCHK(c, hipGetLastError());
+  const MsmColMap id = {0, 0, 0, 0};
+  const lasso_fr* heads[2] = {d_a, d_b};
+  rc = run_msm_direct(c, (const uint8_t*)d_w_out, row * 32, 1, row, id, b, (uint8_t*)c->d_scratch, nullptr, 2, scale, tail, 1, 0, heads, &seq); if (rc) return rc;
+  c->ahead_active = true; c->ahead_bullet = true; c->ahead_seq = seq; c->ahead_tagged = true; c->ahead_count = sizeof(ed_point) / sizeof(fr_t) + 2;
+  return 0;
+}
 int32_t lasso_bullet_post(lasso_ctx* c, const lasso_fr* u, const lasso_fr* u_inv) {
   REQUIRE(c, u && u_inv && c->ahead_active && c->ahead_bullet && !c->pending);
   mail_chunks(c->mail_h + 12, c->ahead_seq, (const uint32_t*)u_inv);
   post_mail(c, c->ahead_seq, (const uint32_t*)u);
   c->ahead_active = false;
-  c->pending = true; c->pending_seq = c->ahead_seq; c->pending_count = 2 * (sizeof(ed_point) / sizeof(fr_t)); c->pending_tagged = c->ahead_tagged; c->pending_groups = 1; c->pending_K = 0;
+  c->pending = true; c->pending_seq = c->ahead_seq; c->pending_count = c->ahead_count; c->pending_tagged = c->ahead_tagged; c->pending_groups = 1; c->pending_K = 0;
   return 0;
 }
 int32_t lasso_bullet_fold(lasso_ctx* c, lasso_fr* d_a, lasso_fr* d_b, size_t nk, const lasso_fr* d_w, size_t nw, lasso_fr* d_w_out, const lasso_fr* u, const lasso_fr* u_inv) {

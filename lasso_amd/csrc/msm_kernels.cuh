@@ -581,7 +581,8 @@ __device__ __forceinline__ pt29 msm_direct_accumulate(const uint32_t* sb, uint32
 // then the row's sum to the host-mapped result buffer in ark's Montgomery limbs; the workgroup that completes the last row raises the flag.
 // counters[0..rows) = per-row arrival tickets, counters[16] = finished rows.
 __device__ __forceinline__ void msm_direct_finish(pt29* pts, fe29 (*st)[4], uint32_t* is_last, const pt29& B, uint32_t K, uint32_t row, pt29* __restrict__ partial, ed_point* __restrict__ out_mont,
-                                                  uint32_t* counters, uint32_t* flag, uint32_t seq, const MsmLeft* left = nullptr, fe29 (*ln)[3] = nullptr, uint32_t* lval = nullptr) {
+                                                  uint32_t* counters, uint32_t* flag, uint32_t seq, const MsmLeft* left = nullptr, fe29 (*ln)[3] = nullptr, uint32_t* lval = nullptr,
+                                                  const fr_t* head0 = nullptr, const fr_t* head1 = nullptr) {
   const fe29 d2 = fe_d2();
   const uint32_t t = threadIdx.x;
   pts[t] = B;
@@ -639,6 +640,9 @@ __device__ __forceinline__ void msm_direct_finish(pt29* pts, fe29 (*st)[4], uint
       for (int k = 0; k < 8; k++) v.v[k] = q.v[k];
       result_store(reinterpret_cast<fr_t*>(out_mont), (size_t)row * 4 + t, v, flag, seq);
     }
+    // the opening's tail chain: the two heads a[0], b[0] the fold in front of this launch left ride behind the point(s) — elements 4 * rows and 4 * rows + 1 — instead of a
+    // launch and a hand-off of their own (lasso_read_heads)
+    if (head0 != nullptr && row == 0 && t >= 4 && t < 6) result_store(reinterpret_cast<fr_t*>(out_mont), (size_t)gridDim.y * 4 + (t - 4), (t == 4 ? head0 : head1)[0], flag, seq);
     if (t == 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");   // the wave's stores leave the device (row_done's form)
     MSM_STAMP(5);
     return;
@@ -666,7 +670,10 @@ __device__ __forceinline__ void msm_direct_finish(pt29* pts, fe29 (*st)[4], uint
 template <int MODE, int WB>
 __global__ void __launch_bounds__(MSM_THREADS) k_msm_direct(const uint32_t* __restrict__ scal, size_t row_words, uint32_t n_cols, uint32_t items_per_chunk, MsmColMap cm,
                                                              const niels29* __restrict__ mult, size_t tn, pt29* __restrict__ partial, ed_point* __restrict__ out_mont, uint32_t* counters,
-                                                             uint32_t* flag, uint32_t seq, fr_t scale, fr_t tail0, fr_t tail1, uint32_t* digit_count, uint32_t sstride, uint32_t soffset) {
+                                                             uint32_t* flag, uint32_t seq, fr_t scale, fr_t tail0, fr_t tail1, uint32_t* digit_count, uint32_t sstride, uint32_t soffset,
+                                                             const fr_t* head0 = nullptr, const fr_t* head1 = nullptr, const uint32_t* gate_gmail = nullptr) {
+  // behind a gate that may have ended without a challenge (lasso_bullet_tail_ahead): then the fold in front did nothing and this launch must publish nothing
+  if (gate_gmail != nullptr && __hip_atomic_load(gate_gmail + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != seq) return;
   __shared__ pt29 pts[MSM_THREADS];
   __shared__ fe29 st[MSM_ST_ROWS][4];
   __shared__ uint32_t sb[MSM_DIRECT_MAX_COLS * 8];
@@ -705,7 +712,7 @@ __global__ void __launch_bounds__(MSM_THREADS) k_msm_direct(const uint32_t* __re
   MsmLeft left;
   const pt29 B = msm_direct_accumulate<WB>(sb, col0, it0, it1, cm, row, mult, tn, digit_count, nullptr, &left);
   MSM_STAMP(2);
-  msm_direct_finish(pts, st, &is_last, B, K, row, partial, out_mont, counters, flag, seq, &left, ln, lval);
+  msm_direct_finish(pts, st, &is_last, B, K, row, partial, out_mont, counters, flag, seq, &left, ln, lval, head0, head1);
 }
 
 // ------------------------------------------------------------------ row-parallel commitment of FULL-WIDTH scalars over the signed byte-multiple table (round 6)
@@ -809,7 +816,15 @@ __global__ void __launch_bounds__(256) k_bullet_expand(const fr_t* __restrict__ 
     SL[n] = fr29_to_integer(fr29_unpack_u(cL)); SL[n + 1] = fr29_to_integer(fr29_unpack_u(bL)); SR[n] = fr29_to_integer(fr29_unpack_u(cR)); SR[n + 1] = fr29_to_integer(fr29_unpack_u(bR));
   }
 }
-__global__ void __launch_bounds__(256) k_bullet_fold(fr_t* __restrict__ a, fr_t* __restrict__ b, size_t half, const fr_t* __restrict__ w, size_t nw, fr_t* __restrict__ w_out, fr_t u, fr_t u_inv) {
+// gmail != nullptr (the opening's tail chain, lasso_bullet_tail_ahead): enqueued before the host had the last challenge, behind k_gate — u, u^-1 are read where the gate left them
+__global__ void __launch_bounds__(256) k_bullet_fold(fr_t* __restrict__ a, fr_t* __restrict__ b, size_t half, const fr_t* __restrict__ w, size_t nw, fr_t* __restrict__ w_out, fr_t u, fr_t u_inv,
+                                                      const uint32_t* gmail = nullptr, uint32_t seq = 0) {
+  if (gmail != nullptr) {
+    __shared__ uint32_t s_mail[17];
+    if (!gated_challenge(gmail, seq, 16, s_mail)) return;
+#pragma unroll
+    for (int k = 0; k < 8; k++) { u.v[k] = s_mail[k]; u_inv.v[k] = s_mail[8 + k]; }
+  }
   const size_t tid = blockIdx.x * (size_t)blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
   const fr29 us = fr29_unpack_s(u), uis = fr29_unpack_s(u_inv);
   for (size_t i = tid; i < half; i += stride) {

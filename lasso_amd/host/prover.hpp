@@ -1530,6 +1530,15 @@ class Prover {
     // already in the stream, its ping-pong buffers already swapped.
     const bool ahead = !shard && !d.no_ahead() && lasso_bullet_ahead_ok(d.ctx, g.bases) == 1;
     bool queued = false;
+    // The END of the opening enqueued ahead too (round 6, lasso_bullet_tail_ahead): when the round in flight is the last one, the chain fold -> heads -> delta MSM goes into the
+    // stream behind it, waiting for the challenge this loop draws last; three launches and two hand-offs leave the critical path.  tail_queued: posted after the loop.
+    const bool tail_ahead = ahead && lasso_bullet_tail_ahead_ok(d.ctx, g.bases) == 1;
+    bool tail_queued = false;
+    auto enqueue_tail = [&](size_t nw_now) {   // a_cur, b_cur: the two-element state the round in flight is writing; w_cur: its nw_now = n / 2 weights
+      lasso_fr sc = dd.abi(); lasso_fr tl[2] = {Sc::zero().abi(), r_delta.abi()};
+      const int32_t rc = lasso_bullet_tail_ahead(d.ctx, g.bases, n, a_cur, b_cur, w_cur, nw_now, w_nxt, &sc, tl);
+      if (rc == 0) { std::swap(w_cur, w_nxt); tail_queued = true; } else if (rc != LASSO_ERR_UNSUPPORTED) d.chk(rc, "lasso_bullet_tail_ahead");
+    };
     auto enqueue_next = [&](size_t nk_next) {   // the round after the one in flight: folds (a_cur, b_cur, w_cur) — being written by the launch in flight, stream order — to length nk_next
       lasso_fr bl[2] = {v1[round + 1].abi(), v2[round + 1].abi()};
       d.chk(lasso_bullet_round_ahead(d.ctx, g.bases, n, a_cur, b_cur, w_cur, a_nxt, b_nxt, w_nxt, nk_next, bl), "lasso_bullet_round_ahead");
@@ -1543,7 +1552,7 @@ class Prover {
       if (have_u && queued) {   // this round's kernel is waiting for the challenge drawn at the end of the previous iteration
         d.chk(lasso_bullet_post(d.ctx, &ua, &uia), "lasso_bullet_post");
         queued = false;
-        if (nk / 2 != 1) enqueue_next(nk / 2);
+        if (nk / 2 != 1) enqueue_next(nk / 2); else if (tail_ahead) enqueue_tail(nw);   // (nk == 2: this round writes w of n / nk = nw entries)
         d.chk(lasso_result_wait(d.ctx, (lasso_fr*)LR, 8), "lasso_result_wait");
       } else if (have_u) {   // fold with the previous challenge (length 2nk -> nk), then this round's L, R
         if (shard) d.chk(lasso_bullet_round_slab(d.ctx, g.bases_slab, n, cw, cr, a_cur, b_cur, w_cur, a_nxt, b_nxt, w_nxt, nk, &ua, &uia, blinds, LR), "lasso_bullet_round_slab");
@@ -1573,6 +1582,20 @@ class Prover {
       nk /= 2; nw *= 2; round++;
     }
     if (!have_u) { HostClock hc("opening: append a_vec"); t.append_scalars_bytes("a", a_bytes); }   // n = 1: no round absorbed it
+    if (tail_queued) {   // fold, heads and the delta MSM are in the stream: release them, compute beta under them, collect the point and the two heads in one hand-off
+      d.chk(lasso_bullet_post(d.ctx, &ua, &uia), "lasso_bullet_post");
+      { HostClock hc("opening: delta/beta scalar mults"); compress_one(g.Qmul.mul(dd) + g.hmul.mul(r_beta), P.beta); }
+      lasso_fr six[6];
+      d.chk(lasso_result_wait(d.ctx, six, 6), "lasso_result_wait");
+      lasso_point dl; memcpy(&dl, six, sizeof(dl));
+      compress_one(Pt::from_abi(dl), P.delta);
+      const Sc x_hat = Sc::from_abi(six[4]), a_hat = Sc::from_abi(six[5]), y_hat = x_hat * a_hat;
+      t.append_point_bytes("delta", P.delta); t.append_point_bytes("beta", P.beta);
+      Sc c = t.challenge_scalar("c");
+      P.z1 = dd + c * y_hat;
+      P.z2 = a_hat * (c * blind_fin + r_beta) + r_delta;
+      return P;
+    }
     if (have_u) {   // the last challenge still folds a, b (length 2 -> 1) and the weights
       d.chk(lasso_bullet_fold(d.ctx, a_cur, b_cur, 2, w_cur, nw / 2, w_nxt, &ua, &uia), "lasso_bullet_fold");
       std::swap(w_cur, w_nxt);

@@ -28,7 +28,7 @@ struct lasso_ctx {
   struct RoundAhead { bool on = false, tail = false, linear = false; std::vector<lasso_fr*> A, B; const lasso_fr* E; size_t n; uint32_t m_stop = 0; } rahead;
   // a bullet round launched ahead of its challenge: the arguments wait here for lasso_bullet_post
   std::mutex mem_mu; std::map<void*, size_t> mem_sizes; uint64_t mem_live = 0, mem_peak = 0, alloc_calls = 0;   // lasso_mem_stats of the mock
-  struct Ahead { bool on = false; const lasso_bases* bs; size_t n, nk; const lasso_fr *a_in, *b_in, *w_in; lasso_fr *a_out, *b_out, *w_out; lasso_fr blinds[2]; } ahead;
+  struct Ahead { bool on = false, tail = false; const lasso_bases* bs; size_t n, nk; const lasso_fr *a_in, *b_in, *w_in; lasso_fr *a_out, *b_out, *w_out; lasso_fr blinds[2]; lasso_fr scale, tl[2]; } ahead;   // tail: lasso_bullet_tail_ahead (a_out / b_out = the two-element state, nk = nw)
 };
 struct lasso_bases { std::vector<Point> pts; };
 
@@ -604,8 +604,24 @@ int32_t lasso_bullet_round_ahead(lasso_ctx* c, const lasso_bases* bs, size_t n, 
   c->ahead.blinds[0] = blinds[0]; c->ahead.blinds[1] = blinds[1];
   return 0;
 }
+int32_t lasso_bullet_tail_ahead_ok(lasso_ctx* c, const lasso_bases* b) { const char* v = getenv("LASSO_BULLET_TAIL_AHEAD"); return lasso_bullet_ahead_ok(c, b) && !(v && v[0] == '0') ? 1 : 0; }
+int32_t lasso_bullet_tail_ahead(lasso_ctx* c, const lasso_bases* bs, size_t n, lasso_fr* a, lasso_fr* b, const lasso_fr* w, size_t nw, lasso_fr* w_out, const lasso_fr* scale, const lasso_fr* tail) {
+  REQ(c, bs && a && b && w && w_out && scale && tail && n >= 2 && 2 * nw == n && !c->ahead.on && !c->defer);
+  c->ahead.on = true; c->ahead.tail = true; c->ahead.bs = bs; c->ahead.n = n; c->ahead.nk = nw; c->ahead.a_out = a; c->ahead.b_out = b; c->ahead.w_in = w; c->ahead.w_out = w_out;
+  c->ahead.scale = *scale; c->ahead.tl[0] = tail[0]; c->ahead.tl[1] = tail[1];
+  return 0;
+}
+int32_t lasso_msm_dev_scaled(lasso_ctx* c, const lasso_bases* b, const lasso_fr* sc, size_t n, const lasso_fr* scale, const lasso_fr* tail, lasso_point* out);
 int32_t lasso_bullet_post(lasso_ctx* c, const lasso_fr* u, const lasso_fr* u_inv) {
   REQ(c, u && u_inv && c->ahead.on && c->pending.empty() && !c->defer);
+  if (c->ahead.tail) {   // the opening's tail chain: fold, heads, delta MSM — the result is the point (4 values) and the two heads
+    c->ahead.on = false; c->ahead.tail = false;
+    lasso_bullet_fold(c, c->ahead.a_out, c->ahead.b_out, 2, c->ahead.w_in, c->ahead.nk, c->ahead.w_out, u, u_inv);
+    lasso_point dl; const int32_t rc = lasso_msm_dev_scaled(c, c->ahead.bs, c->ahead.w_out, c->ahead.n, &c->ahead.scale, c->ahead.tl, &dl); if (rc) return rc;
+    c->pending.resize(6); memcpy((void*)c->pending.data(), &dl, sizeof(lasso_point));
+    c->pending[4] = F(c->ahead.a_out)[0]; c->pending[5] = F(c->ahead.b_out)[0];
+    return 0;
+  }
   c->ahead.on = false; c->defer = true;   // the result is parked for lasso_result_wait, as after lasso_defer_next
   lasso_point unused[2];
   return lasso_bullet_round(c, c->ahead.bs, c->ahead.n, c->ahead.a_in, c->ahead.b_in, c->ahead.w_in, c->ahead.a_out, c->ahead.b_out, c->ahead.w_out, c->ahead.nk, u, u_inv, c->ahead.blinds, unused);

@@ -161,6 +161,8 @@ print("DIGEST", hashlib.sha256(comm + proof).hexdigest())
                                  {"LASSO_ROUNDS_AHEAD": "0", "LASSO_LAYER_AHEAD": "1", "LASSO_TAGGED_RESULTS": "0"},
                                  {"LASSO_CAPACITY": "1", "LASSO_LEAFLESS_MIN": "1024", "LASSO_HOST_TAIL": "0"},
                                  {"LASSO_MSM_TAGGED": "0"},                  # round 6: the few-row MSMs' points through the flag protocol (one lane converts, system fence, ticket, flag)
+                                 {"LASSO_BULLET_TAIL_AHEAD": "0"},           # round 6: the openings' last fold, heads and delta MSM as separate calls instead of one chain enqueued ahead
+                                 {"LASSO_BULLET_TAIL_AHEAD": "0", "LASSO_MSM_TAGGED": "0"},
                                  {"LASSO_MSM_FULL8": "1"},                   # round 6: full-width commitments over the signed byte-multiple table instead of the bucket kernel (measured, not the default)
                                  {"LASSO_MSM_ROWS8W_WAVES": "2048"}, {"LASSO_MSM_ROWS8W": "0"}])   # round 6: several rows per wave in the one-wave-per-row commitment (measured, not the default); the 256-lane form
 def test_gpu_ab_switches_do_not_change_the_bytes(host, env):

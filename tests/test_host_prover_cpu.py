@@ -89,7 +89,8 @@ for kind, c, log_m, log_s in (("and", 2, 12, 12), ("xor", 1, 16, 11), ("lt", 2, 
                                  {"LASSO_LAYER_AHEAD": "0"}, {"LASSO_LAYER_AHEAD": "1", "LASSO_HOST_TAIL": "0"}, {"LASSO_LAYER_AHEAD": "1", "LASSO_ROUNDS_AHEAD": "0"},
                                  {"LASSO_HOST_IFMA": "0"}, {"LASSO_HOST_IFMA": "0", "LASSO_HOST_TAIL": "128"}, {"LASSO_HOST_IFMA": "1", "LASSO_HOST_TAIL": "512"}, {"LASSO_HOST_IFMA": "1", "LASSO_HOST_TAIL": "8"},
                                  {"LASSO_CUBIC_THREE_SUMS": "1"},      # every streaming layer enqueued ahead turns out to have "another shape": lasso_point_cancel, then the plain path
-                                 {"LASSO_CUBIC_THREE_SUMS": "1", "LASSO_LAYER_AHEAD": "0"}])
+                                 {"LASSO_CUBIC_THREE_SUMS": "1", "LASSO_LAYER_AHEAD": "0"},
+                                 {"LASSO_BULLET_TAIL_AHEAD": "0"}])    # round 6: the openings' last fold, heads and delta MSM as separate calls after the last challenge
 def test_host_schedule_switches_do_not_change_the_bytes(env):
     """Round 5's host-side schedule — rounds launched ahead of their challenge, resident tails that hand their arrays to the host, tree-top layers proved on the host — selects
     WHERE and WHEN the same field arithmetic runs: with every combination of the switches the commitment and proof bytes are those of the default (each setting in its own process:
