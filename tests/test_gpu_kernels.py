@@ -92,6 +92,59 @@ def test_eq_evals(devs, ell):
     assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("n", [2, 8, 256, 4096])
+def test_bullet_tail_chain_launched_ahead(devs, n):
+    """lasso_bullet_tail_ahead + lasso_bullet_post + ONE lasso_result_wait of six values == lasso_bullet_fold (2 -> 1) + lasso_read_heads + lasso_msm_dev_scaled with the same
+    challenge: the delta point, the two heads and the folded weights, on the device and in the mock; a chain that never gets its challenge is released by lasso_abort at once."""
+    import time
+    rng = np.random.default_rng(n * 91 + 5)
+    mock_lib = devs[1].lib
+    g = gens(mock_lib, b"gens_sparse_poly", n + 1)       # n + 2 points: G_0..G_{n-1}, Q, H
+    nw = n // 2
+    a = rand_fr(rng, 2, edge=False); b = rand_fr(rng, 2, edge=False); w = rand_fr(rng, max(nw, 1), edge=False)
+    scale = rand_fr(rng, 1, edge=False); tail = rand_fr(rng, 2, edge=False)
+    u, ui = rand_fr(rng, 2, edge=False)
+    vp = lambda x: np.ascontiguousarray(x, dtype=np.uint64).ctypes.data_as(C.c_void_p)
+
+    def run(d):
+        bases = d.bases_create(g)
+        if d.lib.lasso_bullet_tail_ahead_ok(d.ctx, bases) != 1:
+            pytest.skip("lasso_bullet_tail_ahead not available in this configuration")
+        pa = d.upload(a); pb = d.upload(b); pw = d.upload(w); pw2 = d.alloc(32 * n)
+        # the three separate calls (they also size the context's buffers: the chain itself must not grow anything)
+        d.bullet_fold(pa, pb, 2, pw, nw, pw2, u, ui)
+        want_heads = d.read_heads([pa, pb]); want_w = d.download(pw2, (n, 4))
+        want_pt = d.msm_dev_scaled(bases, pw2, n, scale, tail)
+        for p, x in ((pa, a), (pb, b)):
+            d.free(p)
+        pa = d.upload(a); pb = d.upload(b)
+        d._chk(d.lib.lasso_zero(d.ctx, C.c_void_p(pw2), 32 * n))
+        # enqueued and abandoned
+        d._chk(d.lib.lasso_bullet_tail_ahead(d.ctx, bases, n, C.c_void_p(pa), C.c_void_p(pb), C.c_void_p(pw), nw, C.c_void_p(pw2), vp(scale), vp(tail)))
+        t0 = time.perf_counter()
+        d._chk(d.lib.lasso_abort(d.ctx))
+        assert time.perf_counter() - t0 < 1.0, "abort must not wait for a 5 s bail-out"
+        d.free(pa); d.free(pb)
+        pa = d.upload(a); pb = d.upload(b)
+        d._chk(d.lib.lasso_zero(d.ctx, C.c_void_p(pw2), 32 * n))
+        # the real thing on the same context
+        d._chk(d.lib.lasso_bullet_tail_ahead(d.ctx, bases, n, C.c_void_p(pa), C.c_void_p(pb), C.c_void_p(pw), nw, C.c_void_p(pw2), vp(scale), vp(tail)))
+        time.sleep(0.002)                                   # the chain is waiting on the device for these two scalars
+        d._chk(d.lib.lasso_bullet_post(d.ctx, vp(u), vp(ui)))
+        got = np.empty((6, 4), dtype=np.uint64)
+        d._chk(d.lib.lasso_result_wait(d.ctx, got.ctypes.data_as(C.c_void_p), 6))
+        got_w = d.download(pw2, (n, 4))
+        for p in (pa, pb, pw, pw2):
+            d.free(p)
+        d.bases_destroy(bases)
+        return want_pt, want_heads, want_w, got, got_w
+    (pa_, ha, wa, ga, gwa), (pb_, hb, wb, gb, gwb) = both(devs, run)
+    for want, got in ((pa_, ga), (pb_, gb), (pa_, gb)):
+        assert compress_points(mock_lib, np.asarray(want).reshape(1, -1)) == compress_points(mock_lib, np.asarray(got[:4]).reshape(1, -1))
+    assert np.array_equal(ha, ga[4:6]) and np.array_equal(hb, gb[4:6]) and np.array_equal(ha, hb)
+    assert np.array_equal(wa, gwa) and np.array_equal(wb, gwb) and np.array_equal(wa, wb)
+
+
 @pytest.mark.parametrize("n,ncirc", [(2, 1), (4, 2), (16, 33), (128, 5), (256, 2), (1 << 9, 2), (1 << 13, 8), (1 << 16, 3)])   # n <= 128: latency-shaped kernel
 def test_sumcheck_cubic_round(devs, n, ncirc):
     rng = np.random.default_rng(n + ncirc)

@@ -123,6 +123,33 @@ def test_gpu_concurrent_proofs_identical_to_sequential():
         assert len(got[t]) == reps and all(p == workers[t][4] for p in got[t])
 
 
+def test_gpu_soak_alternating_shapes_on_one_prover(host):
+    """Soak: 240 proofs on ONE prover, alternating four instances of different shapes and sizes (so every proof finds the buffer pool, the scratch areas, the generator tables' caches,
+    the hand-off sequence numbers and the launched-ahead windows as ANOTHER shape left them).  Every proof must be the bytes its instance produced the first time; every 40th is
+    also put through the product-side verifier.  The launched-ahead protocols (rounds, layers, bullet rounds, the opening's tail chain) are all on this path."""
+    shapes = [("and", 1, 16, 0, 1 << 14), ("xor", 4, 8, 0, 1 << 12), ("lt", 2, 8, 0, 1 << 10), ("range", 2, 16, 40, 3000)]
+    inst = []
+    for kind, c, log_m, log_r, lookups in shapes:
+        alpha = 2 * c if kind == "lt" else c
+        s_, idx, r = _instance(host, kind, c, log_m, lookups, seed=1000 + lookups)
+        S = _abi.Strategy(_abi.KINDS[kind], c, log_m, log_r)
+        gens = host.gens(c, s_, alpha, log_m); dense = host.densify(idx, log_m)
+        comm = host.commit(dense, gens)
+        inst.append((S, s_, r, gens, dense, comm, host.prove(dense, gens, S, r)))
+    try:
+        for it in range(240):
+            S, s_, r, gens, dense, comm, first = inst[(it * 7 + it // 4) % len(inst)]
+            if it % 3 == 0:
+                assert host.commit(dense, gens) == comm, f"commitment {it} differs"
+            proof = host.prove(dense, gens, S, r)
+            assert proof == first, f"proof {it} differs from its instance's first proof"
+            if it % 40 == 0:
+                assert host.verify(gens, S, s_, r, proof, comm) is True
+    finally:
+        for S, s_, r, gens, dense, comm, first in inst:
+            host.free(dense, gens)
+
+
 _SWITCH_SCRIPT = """
 import hashlib, sys
 import numpy as np
