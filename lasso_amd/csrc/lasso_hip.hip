@@ -38,6 +38,7 @@ struct lasso_ctx {
   hipStream_t stream = nullptr;
   std::string err;
   void* d_scratch = nullptr; size_t scratch_cap = 0;      // reduction partials / converted scalars
+  void* d_pip = nullptr; size_t pip_cap = 0;              // k_msm_pip_*: a group of rows' sorted pairs, bucket offsets, size ranks and bucket sums (run_msm)
   // Small results (round polynomials, claims) return through HOST-MAPPED pinned memory: the producing kernel stores straight into
   // h_small (d_small is the device alias of the same pages), then a sequence number is stored to h_flag and the host spins on it.
   // No hipMemcpy, no stream synchronisation: 6.7 us per round trip instead of 13.6 us (tools/latency_bench.hip on MI355X).
@@ -129,6 +130,13 @@ static int32_t ensure_scratch(lasso_ctx* c, size_t bytes) {
   if (c->d_scratch) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, dfree(c, c->d_scratch)); c->d_scratch = nullptr; c->scratch_cap = 0; }
   size_t cap = bytes < ((size_t)1 << 22) ? ((size_t)1 << 22) : bytes;
   HIPCHK(c, dmalloc(c, &c->d_scratch, cap)); c->scratch_cap = cap; return 0;
+}
+static int32_t ensure_pip(lasso_ctx* c, size_t bytes) {
+  if (bytes <= c->pip_cap) return 0;
+  if (c->no_grow || c->ahead_active || c->lay_active) return LASSO_ERR_UNSUPPORTED;   // the caller takes the bucket kernel instead
+  if (c->d_pip) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, dfree(c, c->d_pip)); c->d_pip = nullptr; c->pip_cap = 0; }
+  if (dmalloc(c, &c->d_pip, bytes) != hipSuccess) { (void)hipGetLastError(); c->d_pip = nullptr; return LASSO_ERR_UNSUPPORTED; }   // no room: not an error, the bucket kernel serves the commitment
+  c->pip_cap = bytes; return 0;
 }
 static int32_t ensure_small(lasso_ctx* c, size_t count) {
   if (count <= c->small_cap) return 0;
@@ -517,6 +525,7 @@ void lasso_ctx_destroy(lasso_ctx* c) {
   rccl_release(c);
   for (auto& p : c->events) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   if (c->d_scratch) (void)hipFree(c->d_scratch);
+  if (c->d_pip) (void)hipFree(c->d_pip);
   if (c->d_gmail) (void)hipFree(c->d_gmail);
   if (c->d_gpoint) (void)hipFree(c->d_gpoint);
   if (c->pmail_h) (void)hipHostFree(c->pmail_h);
@@ -542,6 +551,7 @@ int32_t lasso_mem_stats(lasso_ctx* c, uint64_t* live_bytes, uint64_t* peak_bytes
 int32_t lasso_trim(lasso_ctx* c) {
   REQUIRE(c, c && !c->pending && !c->tail_active && !c->ahead_active && !c->lay_active);
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->d_pip) { HIPCHK(c, dfree(c, c->d_pip)); c->d_pip = nullptr; c->pip_cap = 0; }
   if (c->scratch_cap <= ((size_t)1 << 22)) return 0;
   HIPCHK(c, dfree(c, c->d_scratch)); c->d_scratch = nullptr; c->scratch_cap = 0;
   return ensure_scratch(c, (size_t)1 << 22);
@@ -1626,9 +1636,22 @@ static int32_t run_msm(lasso_ctx* c, const uint8_t* d_scal, uint32_t bps, uint32
   // stays in the Infinity Cache.  profiles/r06_full_width_commit_ab.txt
   static const bool full8_on = [] { const char* v = getenv("LASSO_MSM_FULL8"); return v && v[0] == '1'; }();
   const bool full8 = bps == 32 && b->d_mult8 != nullptr && full8_on && !t8[0];
+  // many long rows of full-width scalars: 12-bit signed windows over the SAME nibble-window table, 2048 buckets per row, 22 additions per scalar instead of 60
+  // (msm_kernels.cuh k_msm_pip_*; round 6).  Rows go through in groups that keep the scratch (sorted pairs 88 B per column, bucket sums 288 KB per row) near 1.2 GB.
+  // LASSO_MSM_PIP=0: the bucket kernel (A/B switch).  A refused allocation falls back to it as well.
+  // (both switches are read per call — a commitment of this size is milliseconds — so that one test process can run both forms)
+  const bool pip_on = [] { const char* v = getenv("LASSO_MSM_PIP"); return !(v && v[0] == '0'); }();
+  const size_t pip_min_cols = [] { const char* v = getenv("LASSO_MSM_PIP_MIN_COLS"); const long x = v ? atol(v) : 2048; return (size_t)(x < 1 ? 1 : x); }();
+  size_t pip_group = 0, pip_row_bytes = 0, pip_items = 0;
+  if (bps == 32 && pip_on && !full8 && K == 1 && rows >= 256 && n_cols >= pip_min_cols && n_cols < ((size_t)1 << 26) && b->n * MSM_WINDOWS < ((size_t)1 << 31)) {
+    pip_items = n_cols * MSM_PIP_WINDOWS;
+    pip_row_bytes = ((pip_items * 4 + (MSM_PIP_BUCKETS + 1) * 4 + MSM_PIP_BUCKETS * 2 + MSM_PIP_BUCKETS * sizeof(pt29) + n_cols) + 255) & ~(size_t)255;
+    pip_group = ((size_t)1200 << 20) / pip_row_bytes; if (pip_group < 64) pip_group = 64; if (pip_group > rows) pip_group = rows;
+    if (ensure_pip(c, pip_group * pip_row_bytes + 256) != 0) pip_group = 0;
+  }
   {
     ProfScope ps(c, LASSO_K_MSM, (double)rows * n_cols * bps, msm_ref_adds(rows, n_cols, bps == 4 ? 4 * W : FR_MODULUS_BITS), rows > MSM_SMALL_ROWS,
-                 (double)rows * n_cols * (t8[0] ? W8 : full8 ? 32 : W));
+                 (double)rows * n_cols * (t8[0] ? W8 : full8 ? 32 : pip_group ? MSM_PIP_WINDOWS : W));
     // many SHORT rows: one wave per row (k_msm_rows8w: 64 additions per lane and a 6-level tree inside the wave instead of 16 per thread and a 256-point tree).  Measured
     // (profiles/r04_ab_rows8w.txt): -9 % on the headline's E (4096 one-byte columns), -8 % on BN254 configs[1], +2 % on configs[2]'s 16384-column rows, where a thread of the
     // 256-lane kernel already runs 64 additions — hence the column bound.  LASSO_MSM_ROWS8W=0: A/B switch
@@ -1642,6 +1665,18 @@ static int32_t run_msm(lasso_ctx* c, const uint8_t* d_scal, uint32_t bps, uint32
                                                                       (uint32_t)n_cols, W8, t8[0], t8[1], b->n, d_partial, (uint32_t)rows, ps.counter(), (uint32_t)rpw);
     else if (t8[0]) hipLaunchKernelGGL(k_msm_rows8, dim3((unsigned)K, (unsigned)rows), dim3(MSM_THREADS), 0, c->stream, (const uint32_t*)d_scal, row_stride / 4, (uint32_t)n_cols, (uint32_t)cols_per_chunk, W8,
                                   t8[0], t8[1], b->n, d_partial, ps.counter());
+    else if (pip_group) {
+      uint8_t* base = (uint8_t*)c->d_pip;
+      uint32_t* d_sorted = (uint32_t*)base; uint32_t* d_offs = d_sorted + pip_group * pip_items; uint16_t* d_perm = (uint16_t*)(d_offs + pip_group * (MSM_PIP_BUCKETS + 1));
+      uint8_t* d_vtop = (uint8_t*)(d_perm + pip_group * MSM_PIP_BUCKETS);
+      pt29* d_bk = (pt29*)((((uintptr_t)(d_vtop + pip_group * n_cols)) + 15) & ~(uintptr_t)15);
+      for (size_t r0 = 0; r0 < rows; r0 += pip_group) {
+        const unsigned g = (unsigned)(rows - r0 < pip_group ? rows - r0 : pip_group);
+        hipLaunchKernelGGL(k_msm_pip_sort, dim3(g), dim3(MSM_THREADS), 0, c->stream, d_scal + r0 * row_stride, row_stride, (uint32_t)n_cols, (uint32_t)b->n, d_sorted, pip_items, d_offs, d_perm, d_vtop, ps.counter());
+        hipLaunchKernelGGL(k_msm_pip_accumulate, dim3(g, MSM_PIP_PER_THREAD), dim3(MSM_THREADS), 0, c->stream, (const uint32_t*)d_sorted, pip_items, (const uint32_t*)d_offs, (const uint16_t*)d_perm, (const niels29*)b->d_table, d_bk);
+        hipLaunchKernelGGL(k_msm_pip_reduce, dim3(g), dim3(MSM_THREADS), 0, c->stream, (const pt29*)d_bk, (const uint8_t*)d_vtop, (uint32_t)n_cols, (const niels29*)b->d_table + (size_t)(MSM_WINDOWS - 1) * b->n, d_partial + r0);
+      }
+    }
     else if (full8) hipLaunchKernelGGL((k_msm_rows_full<8>), dim3((unsigned)K, (unsigned)rows), dim3(MSM_THREADS), 0, c->stream, (const uint32_t*)d_scal, row_stride / 4, (uint32_t)n_cols, (uint32_t)cols_per_chunk,
                                        (const niels29*)b->d_mult8, b->n, d_partial, ps.counter());
     else hipLaunchKernelGGL(k_msm_buckets, dim3((unsigned)K, (unsigned)rows), dim3(MSM_THREADS), 0, c->stream, d_scal, bps, W, row_stride, n_cols, cols_per_chunk, (const niels29*)b->d_table, b->n, d_partial, ps.counter());

@@ -387,6 +387,164 @@ __device__ __forceinline__ void msm_coop_tree(pt29* pts, fe29 (*st)[4], uint32_t
   }
 }
 #endif  // LASSO_BN254
+// ------------------------------------------------------------------ many LONG rows of FULL-WIDTH scalars: 12-bit signed windows, 2048 buckets per row (round 6)
+// k_msm_buckets spends one mixed addition per non-zero NIBBLE: 60 per full-width scalar.  The nibble-window table it reads already holds 2^(4w) G_j for every w, so a
+// 12-bit window w12 finds 2^(12 w12) G_j at nibble window 3 w12 — no new table — and a scalar costs 22 additions instead of 60 if the row's (scalar, window) pairs
+// are first sorted by the magnitude of their signed digit: sum_j s_j G_j = sum_{d=1..2048} d * B_d, B_d = sum of +-(table entries) whose digit is +-d
+// (msm/mod.rs:91-164's bucket method with the window sums folded into ONE bucket set per row, because the table carries the window's power of two).  Three launches:
+//   k_msm_pip_sort        one workgroup per row: signed digits (carry into the next window), histogram and offsets of the 2048 buckets in LDS, the row's pairs scattered
+//                         into bucket order (global scratch), and the buckets RANKED BY SIZE (bitonic sort of 2048 keys in LDS);
+//   k_msm_pip_accumulate  eight workgroups per row: in workgroup k lane t sums the bucket of rank 256 k + t — the lanes of a wave run buckets of (nearly) equal
+//                         length, so the lockstep loop wastes no lane (by bucket NUMBER the lengths scatter ~ +-25 % around 84 at the Spark shape: a fifth of the
+//                         issue slots); next pair and next table entry in flight during the current addition;
+//   k_msm_pip_reduce      one workgroup per row: thread t owns buckets 8t .. 8t+7: running sums give T_t = sum_k (k+1) B_{8t+k} and S_t = sum_k B_{8t+k};
+//                         the row is sum_t T_t + 8 sum_t t S_t, the second sum through a suffix scan of the S_t in LDS (sum_t t S_t = sum_{j>=1} sum_{t>=j} S_t).
+// Same group element per row as k_msm_buckets (another projective representative; the order of additions inside a bucket depends on the scatter's atomics: wire bytes do
+// not change).  Additions per 8192-column row: 172 K + 4 K (the values above bit 252) + 8 K (bucket sums) instead of 491 K.
+#define MSM_PIP_WINDOWS 21            // bucket windows: bits 0 .. 251; what is left above them (bits 252 .. 255 plus the last carry: 0 .. 4 for a canonical scalar) is NOT a bucket digit:
+                                      // half the scalars of a row have 1 there (the carry), and a bucket of 4096 pairs in a row of 88-pair buckets is one lane working alone for 35 ms (measured)
+#define MSM_PIP_BUCKETS 2048
+#define MSM_PIP_PER_THREAD (MSM_PIP_BUCKETS / MSM_THREADS)
+__device__ __forceinline__ uint32_t msm_pip_bits(const uint32_t* s, uint32_t w) {   // bits [12 w, 12 w + 12) of a 256-bit little-endian integer held in eight words
+  const uint32_t bit = 12u * w, word = bit >> 5, sh = bit & 31u;
+  uint64_t v = s[word]; if (word < 7u) v |= (uint64_t)s[word + 1] << 32;
+  return (uint32_t)(v >> sh) & 4095u;
+}
+// signed digit of window w given the carry of the windows below: returns the magnitude (0 .. 2048), sets neg and the carry out
+__device__ __forceinline__ uint32_t msm_pip_digit(const uint32_t* s, uint32_t w, uint32_t& carry, bool& neg) {
+  const uint32_t raw = msm_pip_bits(s, w) + carry;
+  carry = raw > 2048u; neg = carry != 0;
+  return carry ? 4096u - raw : raw;
+}
+// grid = rows.  scal: canonical 32-byte scalars, row r at scal + r * row_stride.  sorted + r * items_stride: the row's pairs ((3 w) * table_stride + column) | sign << 31 in
+// bucket order; offs + r * 2049: exclusive offsets of the buckets (+ the total); perm + r * 2048: bucket numbers by ascending size.
+__global__ void __launch_bounds__(MSM_THREADS) k_msm_pip_sort(const uint8_t* __restrict__ scal, size_t row_stride, uint32_t n_cols, uint32_t table_stride, uint32_t* __restrict__ sorted,
+                                                               size_t items_stride, uint32_t* __restrict__ offs, uint16_t* __restrict__ perm, uint8_t* __restrict__ vtop, uint32_t* digit_count) {
+  __shared__ uint32_t cnt[MSM_PIP_BUCKETS], key[MSM_PIP_BUCKETS], tsum[MSM_THREADS], topsum;
+  const uint32_t t = threadIdx.x; const size_t r = blockIdx.x;
+  const uint32_t* row = reinterpret_cast<const uint32_t*>(scal + r * row_stride);
+  for (uint32_t i = t; i < MSM_PIP_BUCKETS; i += MSM_THREADS) cnt[i] = 0;
+  if (t == 0) topsum = 0;
+  __syncthreads();
+  uint32_t my_top = 0;
+  for (uint32_t c = t; c < n_cols; c += MSM_THREADS) {
+    uint32_t s[8]; const lasso_u32x4 lo = reinterpret_cast<const lasso_u32x4*>(row + 8 * (size_t)c)[0], hi = reinterpret_cast<const lasso_u32x4*>(row + 8 * (size_t)c)[1];
+    s[0] = lo.x; s[1] = lo.y; s[2] = lo.z; s[3] = lo.w; s[4] = hi.x; s[5] = hi.y; s[6] = hi.z; s[7] = hi.w;
+    uint32_t carry = 0; bool neg;
+#pragma unroll
+    for (uint32_t w = 0; w < MSM_PIP_WINDOWS; w++) { const uint32_t d = msm_pip_digit(s, w, carry, neg); if (d) atomicAdd(&cnt[d - 1], 1u); }
+    const uint32_t v = (s[7] >> 28) + carry;          // the value above the bucket windows: times 2^252 G_c, added by k_msm_pip_reduce
+    vtop[r * n_cols + c] = (uint8_t)v; my_top += v;
+  }
+  if (my_top) atomicAdd(&topsum, my_top);
+  __syncthreads();
+  // exclusive offsets: eight consecutive buckets per thread, a scan over the threads' sums
+  uint32_t mine[MSM_PIP_PER_THREAD], sum = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < MSM_PIP_PER_THREAD; k++) { mine[k] = cnt[MSM_PIP_PER_THREAD * t + k]; sum += mine[k]; }
+  tsum[t] = sum;
+  __syncthreads();
+  for (uint32_t off = 1; off < MSM_THREADS; off <<= 1) { const uint32_t v = t >= off ? tsum[t - off] : 0; __syncthreads(); tsum[t] += v; __syncthreads(); }
+  uint32_t run = tsum[t] - sum;
+  uint32_t* of = offs + r * (MSM_PIP_BUCKETS + 1);
+#pragma unroll
+  for (uint32_t k = 0; k < MSM_PIP_PER_THREAD; k++) {
+    const uint32_t b = MSM_PIP_PER_THREAD * t + k;
+    of[b] = run; cnt[b] = run;                                               // cnt: now the scatter's cursors
+    key[b] = ((mine[k] < (1u << 21) ? mine[k] : (1u << 21) - 1u) << 11) | b;   // size (clipped: it only orders the work) above the bucket number
+    run += mine[k];
+  }
+  if (t == MSM_THREADS - 1) { of[MSM_PIP_BUCKETS] = run; if (digit_count && run + topsum) atomicAdd(digit_count + (blockIdx.x & 63u), run + topsum); }
+  __syncthreads();
+  // buckets by ascending size (bitonic, 2048 keys, eight per thread and stage)
+  for (uint32_t k = 2; k <= MSM_PIP_BUCKETS; k <<= 1)
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      for (uint32_t i = t; i < MSM_PIP_BUCKETS; i += MSM_THREADS) {
+        const uint32_t x = i ^ j;
+        if (x > i) { const uint32_t a = key[i], b = key[x]; if ((a > b) == ((i & k) == 0)) { key[i] = b; key[x] = a; } }
+      }
+      __syncthreads();
+    }
+  for (uint32_t i = t; i < MSM_PIP_BUCKETS; i += MSM_THREADS) perm[r * MSM_PIP_BUCKETS + i] = (uint16_t)(key[i] & (MSM_PIP_BUCKETS - 1u));
+  // the scatter
+  uint32_t* so = sorted + r * items_stride;
+  for (uint32_t c = t; c < n_cols; c += MSM_THREADS) {
+    uint32_t s[8]; const lasso_u32x4 lo = reinterpret_cast<const lasso_u32x4*>(row + 8 * (size_t)c)[0], hi = reinterpret_cast<const lasso_u32x4*>(row + 8 * (size_t)c)[1];
+    s[0] = lo.x; s[1] = lo.y; s[2] = lo.z; s[3] = lo.w; s[4] = hi.x; s[5] = hi.y; s[6] = hi.z; s[7] = hi.w;
+    uint32_t carry = 0; bool neg;
+#pragma unroll
+    for (uint32_t w = 0; w < MSM_PIP_WINDOWS; w++) {
+      const uint32_t d = msm_pip_digit(s, w, carry, neg);
+      if (d) so[atomicAdd(&cnt[d - 1], 1u)] = (3u * w * table_stride + c) | (neg ? 0x80000000u : 0u);
+    }
+  }
+}
+// grid = (rows, 8 steps): workgroup (r, k) sums the 256 buckets of ranks 256 k .. 256 k + 255 of row r, one per lane.  bk + (r * 2048 + b): the sum of bucket b of row r.
+// (Rows in x: with the steps in x every step-k workgroup lands on XCD k, and the step of the largest buckets becomes one XCD's work.)  Measured on the way here
+// (profiles/r06_full_width_commit_ab.txt): the loop is VALU time — folding the table into 1024 entries and dropping the pair loads altogether changed nothing — so the pairs
+// are read one at a time, two ahead of the addition that uses them; fetching them eight at a time (32 bytes per lane) bought 0.5 %.
+__global__ void __launch_bounds__(MSM_THREADS) k_msm_pip_accumulate(const uint32_t* __restrict__ sorted, size_t items_stride, const uint32_t* __restrict__ offs, const uint16_t* __restrict__ perm,
+                                                                     const niels29* __restrict__ table, pt29* __restrict__ bk) {
+  const uint32_t t = threadIdx.x, k = blockIdx.y; const size_t r = blockIdx.x;
+  const uint32_t* so = sorted + r * items_stride; const uint32_t* of = offs + r * (MSM_PIP_BUCKETS + 1);
+  const uint32_t b = perm[r * MSM_PIP_BUCKETS + k * MSM_THREADS + t];
+  const uint32_t lo = of[b], hi = of[b + 1];
+  pt29 B = pt_identity();
+  if (lo < hi) {
+    uint32_t p_cur = so[lo], p_nxt = lo + 1 < hi ? so[lo + 1] : 0u;
+    niels29 cur = table[p_cur & 0x7fffffffu];
+    for (uint32_t pos = lo; pos < hi; pos++) {
+      const uint32_t p_nn = pos + 2 < hi ? so[pos + 2] : 0u;          // two pairs ahead: its table address must exist one addition before its entry is needed
+      const niels29 nxt = table[p_nxt & 0x7fffffffu];                  // in flight during the addition below (entry 0 when the bucket ends)
+      B = pt_madd(B, niels_cond_neg(cur, (p_cur >> 31) != 0));
+      cur = nxt; p_cur = p_nxt; p_nxt = p_nn;
+    }
+  }
+  bk[r * MSM_PIP_BUCKETS + b] = B;
+}
+// grid = rows.  out[r] = sum_b (b + 1) * bk[r][b]  (K = 1 layout of k_points_sum)
+__global__ void __launch_bounds__(MSM_THREADS) k_msm_pip_reduce(const pt29* __restrict__ bk, const uint8_t* __restrict__ vtop, uint32_t n_cols, const niels29* __restrict__ top_table,
+                                                                 pt29* __restrict__ out) {
+  __shared__ pt29 pts[MSM_THREADS];
+  __shared__ fe29 st[MSM_ST_ROWS][4];
+  const fe29 d2 = fe_d2();
+  const uint32_t t = threadIdx.x; const size_t r = blockIdx.x;
+  const pt29* B = bk + r * MSM_PIP_BUCKETS + MSM_PIP_PER_THREAD * (size_t)t;
+  pt29 R = pt_identity(), T = pt_identity();
+  for (uint32_t k = MSM_PIP_PER_THREAD; k-- > 0;) { R = pt_add(R, B[k], d2); T = pt_add(T, R, d2); }   // R = S_t, T = sum_k (k + 1) B_{8t+k}
+  pts[t] = R;
+  __syncthreads();
+  for (uint32_t off = 1; off < MSM_THREADS; off <<= 1) {   // inclusive suffix sums of the S_t
+    pt29 v; const bool a = t + off < MSM_THREADS;
+    if (a) v = pts[t + off];
+    __syncthreads();
+    if (a) pts[t] = pt_add(pts[t], v, d2);
+    __syncthreads();
+  }
+  if (t == 0) pts[0] = pt_identity();                      // sum_t t S_t = sum_{j >= 1} suffix_j
+  __syncthreads();
+  msm_coop_tree(pts, st, MSM_THREADS, d2);
+  pt29 W = pt_identity();
+  if (t == 0) W = pts[0];
+  __syncthreads();
+  pts[t] = T;
+  __syncthreads();
+  msm_coop_tree(pts, st, MSM_THREADS, d2);
+  pt29 V = pt_identity();
+  if (t == 0) V = pt_add(pts[0], pt_dbl(pt_dbl(pt_dbl(W))), d2);
+  __syncthreads();
+  // the values above the bucket windows: sum_c vtop[c] * (2^252 G_c), vtop <= 4 for canonical scalars (any value up to 16 is handled: the entry is added that many times)
+  pt29 top = pt_identity();
+  for (uint32_t c = t; c < n_cols; c += MSM_THREADS) {
+    const uint32_t v = vtop[r * n_cols + c];
+    if (v) { const niels29 e = top_table[c]; for (uint32_t i = 0; i < v; i++) top = pt_madd(top, e); }
+  }
+  pts[t] = top;
+  __syncthreads();
+  msm_coop_tree(pts, st, MSM_THREADS, d2);
+  if (t == 0) out[r] = pt_add(V, pts[0], d2);
+}
+
 // ------------------------------------------------------------------ row-parallel commitment of SMALL scalars: one mixed addition per byte
 // The commitments of the path are L rows x R columns of small integers over shared generators — E = T[dim] holds table values (< 2^8 for AND / OR / XOR over
 // 16-bit indices, bits for LT), dim / read / final hold indices and counters (<= 16 bits at the benchmark's sizes).  The bucket kernel above spends one mixed

@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from fieldref import L as FR_P, limbs
+from fieldref import L as FR_P, limbs, to_mont
 from gpuutil import compress_points, gens, load_mock, rand_fr, small_fr
 from lasso_amd import _abi
 
@@ -474,6 +474,43 @@ def test_hyrax_commit(devs, gens_300, ls, rs, maxv):
     assert compress_points(mock_lib, a) == compress_points(mock_lib, b)
     # rows normalised + serialised on the device == the oracle's serialize_compressed of the same rows
     assert np.array_equal(wa, wb) and [bytes(x) for x in wa] == compress_points(mock_lib, b)
+
+
+@pytest.mark.parametrize("ls,rs,shape", [(256, 300, "random"), (300, 257, "edges"), (256, 64, "equal"), (512, 300, "sparse")])
+def test_hyrax_commit_full_width_wide_windows(devs, gens_300, ls, rs, shape, monkeypatch):
+    """>= 256 rows of FULL-WIDTH scalars: the 12-bit signed-window bucket form (k_msm_pip_sort / _accumulate / _reduce; by default from 2048 columns on, here forced down to
+    the fixture's 300 generators) against the oracle's row commitments and against the nibble-bucket kernel (LASSO_MSM_PIP=0) on the same device.  Shapes: random scalars;
+    canonical values built from the digit edge cases (digit 2048 stays positive, 2049 turns negative and carries, all-0xFFF carry chains, 0, 1, p - 1, 2^252 - 1); rows of
+    EQUAL scalars (every pair of a row in 22 buckets: the size ranking's worst case); mostly-zero rows (empty buckets everywhere)."""
+    rng = np.random.default_rng(ls * 131 + rs)
+    if shape == "random":
+        Z = rand_fr(rng, ls * rs)
+    elif shape == "edges":
+        pats = [0, 1, 2048, 2049, 4095, 4096, FR_P - 1, FR_P - 2, 2**252 - 1, 2**252, sum(0x800 << (12 * w) for w in range(21)), sum(0x801 << (12 * w) for w in range(21)),
+                sum(0xFFF << (12 * w) for w in range(21)), sum(0x7FF << (12 * w) for w in range(21)), (0x801 << 240) + 0x800, 2**251 + 2**11]
+        vals = [pats[int(i)] % FR_P for i in rng.integers(0, len(pats), size=ls * rs)]
+        Z = np.array([limbs(to_mont(v, FR_P)) for v in vals], dtype=np.uint64).reshape(-1, 4)
+    elif shape == "equal":
+        rows = rand_fr(rng, ls, edge=False)
+        Z = np.repeat(rows, rs, axis=0)
+    else:
+        Z = rand_fr(rng, ls * rs, edge=False)
+        Z[rng.random(ls * rs) < 0.97] = 0
+    real, mock = devs
+    monkeypatch.setenv("LASSO_MSM_PIP_MIN_COLS", "32")
+
+    def run(d, pip):
+        monkeypatch.setenv("LASSO_MSM_PIP", "1" if pip else "0")
+        b = d.bases_create(gens_300)
+        p = d.upload(Z)
+        out = d.hyrax_commit(p, ls, rs, b)
+        wire = d.hyrax_commit_compressed(p, ls, rs, b)
+        d.free(p); d.bases_destroy(b)
+        return out, wire
+    (a, wa), (a0, wa0), (b, wb) = run(real, True), run(real, False), run(mock, True)
+    want = compress_points(mock.lib, b)
+    assert compress_points(mock.lib, a) == want and compress_points(mock.lib, a0) == want
+    assert np.array_equal(wa, wb) and np.array_equal(wa0, wb) and [bytes(x) for x in wa] == want
 
 
 @pytest.mark.parametrize("world,ls,rs,maxv", [(2, 8, 64, 300), (4, 64, 256, None), (8, 300, 256, 1 << 16), (2, 1, 2, 5)])

@@ -264,7 +264,8 @@ def test_baseline_config_full_size(host, oracle, kind, c, log_m, log_r, log_s):
 # proof must be identical.  ("and", 1, 16, 0, 24) is the configuration BASELINE.json's metric is quoted on.
 # ("xor", 8, 16, 0, 24) = BASELINE.json configs[2] at full size (oracle: ~85 s on the GPU box's 128 cores).  configs[3] (RangeCheck C=4 2^26, oracle ~150 s) is
 # held to the digests tools/parity_full_configs.py recorded from the oracle at that size (tests/golden/full_config_digests.json) in test_baseline_config_full_size.
-AT_SIZE = [("and", 1, 16, 0, 24), ("xor", 2, 16, 0, 22), ("range", 2, 16, 40, 21), ("lt", 1, 16, 0, 20), ("xor", 8, 16, 0, 24)]
+# ("spark", 4, 16, 0, 20): E is 2048 rows x 2048 columns of FULL-WIDTH scalars — the shape from which the commitment runs the 12-bit-window bucket kernels (k_msm_pip_*, round 6).
+AT_SIZE = [("and", 1, 16, 0, 24), ("xor", 2, 16, 0, 22), ("range", 2, 16, 40, 21), ("lt", 1, 16, 0, 20), ("xor", 8, 16, 0, 24), ("spark", 4, 16, 0, 20)]
 
 
 @pytest.mark.parametrize("kind,c,log_m,log_r,log_s", AT_SIZE)
