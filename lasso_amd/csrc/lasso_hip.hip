@@ -1637,16 +1637,18 @@ static int32_t run_msm(lasso_ctx* c, const uint8_t* d_scal, uint32_t bps, uint32
   static const bool full8_on = [] { const char* v = getenv("LASSO_MSM_FULL8"); return v && v[0] == '1'; }();
   const bool full8 = bps == 32 && b->d_mult8 != nullptr && full8_on && !t8[0];
   // many long rows of full-width scalars: 12-bit signed windows over the SAME nibble-window table, 2048 buckets per row, 22 additions per scalar instead of 60
-  // (msm_kernels.cuh k_msm_pip_*; round 6).  Rows go through in groups that keep the scratch (sorted pairs 88 B per column, bucket sums 288 KB per row) near 1.2 GB.
-  // LASSO_MSM_PIP=0: the bucket kernel (A/B switch).  A refused allocation falls back to it as well.
+  // (msm_kernels.cuh k_msm_pip_*; round 6).  Rows go through in groups that keep the scratch (sorted pairs 84 B per column, bucket sums 288 KB per row) near 1.2 GB
+  // (LASSO_MSM_PIP_SCRATCH_MB).  From 256 rows of 512 columns on (measured, profiles/r06_full_width_commit_ab.txt: 512 x 512 0.69 against 1.12 ms, 1024 x 1024 1.86 against 3.70,
+  // 4096 x 4096 23.5 against 47.9).  LASSO_MSM_PIP=0: the bucket kernel (A/B switch).  A refused allocation falls back to it as well.
   // (both switches are read per call — a commitment of this size is milliseconds — so that one test process can run both forms)
   const bool pip_on = [] { const char* v = getenv("LASSO_MSM_PIP"); return !(v && v[0] == '0'); }();
-  const size_t pip_min_cols = [] { const char* v = getenv("LASSO_MSM_PIP_MIN_COLS"); const long x = v ? atol(v) : 2048; return (size_t)(x < 1 ? 1 : x); }();
+  const size_t pip_min_cols = [] { const char* v = getenv("LASSO_MSM_PIP_MIN_COLS"); const long x = v ? atol(v) : 512; return (size_t)(x < 1 ? 1 : x); }();
   size_t pip_group = 0, pip_row_bytes = 0, pip_items = 0;
   if (bps == 32 && pip_on && !full8 && K == 1 && rows >= 256 && n_cols >= pip_min_cols && n_cols < ((size_t)1 << 26) && b->n * MSM_WINDOWS < ((size_t)1 << 31)) {
     pip_items = n_cols * MSM_PIP_WINDOWS;
     pip_row_bytes = ((pip_items * 4 + (MSM_PIP_BUCKETS + 1) * 4 + MSM_PIP_BUCKETS * 2 + MSM_PIP_BUCKETS * sizeof(pt29) + n_cols) + 255) & ~(size_t)255;
-    pip_group = ((size_t)1200 << 20) / pip_row_bytes; if (pip_group < 64) pip_group = 64; if (pip_group > rows) pip_group = rows;
+    const size_t pip_mb = [] { const char* v = getenv("LASSO_MSM_PIP_SCRATCH_MB"); const long x = v ? atol(v) : 1200; return (size_t)(x < 16 ? 16 : x); }();
+    pip_group = (pip_mb << 20) / pip_row_bytes; if (pip_group < 64) pip_group = 64; if (pip_group > rows) pip_group = rows;
     if (ensure_pip(c, pip_group * pip_row_bytes + 256) != 0) pip_group = 0;
   }
   {

@@ -387,7 +387,7 @@ __device__ __forceinline__ void msm_coop_tree(pt29* pts, fe29 (*st)[4], uint32_t
   }
 }
 #endif  // LASSO_BN254
-// ------------------------------------------------------------------ many LONG rows of FULL-WIDTH scalars: 12-bit signed windows, 2048 buckets per row (round 6)
+// ------------------------------------------------------------------ many rows of FULL-WIDTH scalars: 12-bit signed windows, 2048 buckets per row (round 6)
 // k_msm_buckets spends one mixed addition per non-zero NIBBLE: 60 per full-width scalar.  The nibble-window table it reads already holds 2^(4w) G_j for every w, so a
 // 12-bit window w12 finds 2^(12 w12) G_j at nibble window 3 w12 — no new table — and a scalar costs 22 additions instead of 60 if the row's (scalar, window) pairs
 // are first sorted by the magnitude of their signed digit: sum_j s_j G_j = sum_{d=1..2048} d * B_d, B_d = sum of +-(table entries) whose digit is +-d
