@@ -117,6 +117,19 @@ PY
   LASSO_TRACE=1 timeout 200 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --concurrent 0 --no-slab-leg --no-bind-sweep --no-prof "$@" > /dev/null 2> gpurun_out/$tag/trace_spans.txt; grep "\[trace\]" gpurun_out/$tag/trace_spans.txt | tail -22
   LASSO_TRACE=2 timeout 200 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --concurrent 0 --no-slab-leg --no-bind-sweep --no-prof "$@" > /dev/null 2> gpurun_out/$tag/host_buckets.txt; grep "\[host\]" gpurun_out/$tag/host_buckets.txt | tail -14
 }
+r_numa() {         # numa <tag> [reps]: where the GPU hangs (NUMA node of its PCIe function) and what the quick bench takes with the process confined to each node's CPUs (taskset) and unconfined
+  local tag="$1" reps="${2:-2}"; mkdir -p gpurun_out/$tag; local out=gpurun_out/$tag/numa.txt; : > $out
+  { lscpu | grep -iE "^CPU\(s\)|socket|thread|numa|model name"; for f in /sys/class/drm/card*/device/numa_node; do echo "$f: $(cat $f 2>/dev/null)"; done; } >> $out 2>&1
+  local nodes; nodes=$(ls -d /sys/devices/system/node/node* 2>/dev/null | sed 's/.*node//' | sort -n)
+  for rep in $(seq 1 $reps); do
+    for n in $nodes free; do
+      local pre=""; [ "$n" != free ] && pre="taskset -c $(cat /sys/devices/system/node/node$n/cpulist)"
+      ms=$($pre timeout 300 python bench.py --no-cpu-baseline --concurrent 0 --no-slab-leg --no-bind-sweep --steps 30 --warmup 5 2>/dev/null | python -c "import json,sys; print(json.loads(sys.stdin.read().strip().splitlines()[-1])['ms_per_step'])" 2>/dev/null)
+      echo "node $n: $ms ms per proof" >> $out
+    done
+  done
+  cat $out
+}
 r_micro() {        # micro <tag> [n ...]: round 6's microbenchmarks — phase-stamped timeline of one k_bullet_msm launch per curve (tools/bullet_phase_bench*) and the mixed addition's ceiling (tools/madd_bench*)
   local tag="$1"; shift; mkdir -p gpurun_out/$tag
   for n in "${@:-4096}"; do
