@@ -476,15 +476,17 @@ def test_hyrax_commit(devs, gens_300, ls, rs, maxv):
     assert np.array_equal(wa, wb) and [bytes(x) for x in wa] == compress_points(mock_lib, b)
 
 
-@pytest.mark.parametrize("ls,rs,shape", [(256, 300, "random"), (300, 257, "edges"), (256, 64, "equal"), (512, 300, "sparse")])
+@pytest.mark.parametrize("ls,rs,shape", [(256, 300, "random"), (300, 257, "edges"), (256, 64, "equal"), (512, 300, "sparse"), (333, 300, "groups")])
 def test_hyrax_commit_full_width_wide_windows(devs, gens_300, ls, rs, shape, monkeypatch):
     """>= 256 rows of FULL-WIDTH scalars: the 12-bit signed-window bucket form (k_msm_pip_sort / _accumulate / _reduce; by default from 2048 columns on, here forced down to
     the fixture's 300 generators) against the oracle's row commitments and against the nibble-bucket kernel (LASSO_MSM_PIP=0) on the same device.  Shapes: random scalars;
     canonical values built from the digit edge cases (digit 2048 stays positive, 2049 turns negative and carries, all-0xFFF carry chains, 0, 1, p - 1, 2^252 - 1); rows of
-    EQUAL scalars (every pair of a row in 22 buckets: the size ranking's worst case); mostly-zero rows (empty buckets everywhere)."""
+    EQUAL scalars (every pair of a row in 21 buckets: the size ranking's worst case); mostly-zero rows (empty buckets everywhere); rows in several groups (small scratch)."""
     rng = np.random.default_rng(ls * 131 + rs)
-    if shape == "random":
+    if shape in ("random", "groups"):
         Z = rand_fr(rng, ls * rs)
+        if shape == "groups":   # a 16 MB scratch: the rows go through in groups of 64 (the floor), the last one partly filled
+            monkeypatch.setenv("LASSO_MSM_PIP_SCRATCH_MB", "16")
     elif shape == "edges":
         pats = [0, 1, 2048, 2049, 4095, 4096, FR_P - 1, FR_P - 2, 2**252 - 1, 2**252, sum(0x800 << (12 * w) for w in range(21)), sum(0x801 << (12 * w) for w in range(21)),
                 sum(0xFFF << (12 * w) for w in range(21)), sum(0x7FF << (12 * w) for w in range(21)), (0x801 << 240) + 0x800, 2**251 + 2**11]
