@@ -63,7 +63,21 @@ struct pt29 { fe29 X, Y, T, Z; };                                  // (X : Y : Z
 #endif
 struct alignas(MSM_NIELS_ALIGN) niels29 { fe29 x, y; int32_t pad[10]; };        // affine table entry: 72 bytes of payload in a 128-byte line
 
-LHD pt29 pt_identity() { pt29 p; p.X = fe_zero(); p.Y = fe_one(); p.T = fe_zero(); p.Z = fe_zero(); return p; }
+// The identity as a starting value of an accumulation loop.  On the device its limbs are made OPAQUE to the optimizer (an empty asm per limb): with the constants visible,
+// hipcc (ROCm 7.2) derives value ranges for the loop-carried limbs of `B = pt_identity(); for (..) B = pt_madd(B, entry)` under which the 32 x 32 -> 64 products of
+// fe_mul no longer match v_mad_i64_i32 and are expanded into 64 x 32 multiplies: 782 multiply-adds and 365 moves per mixed addition instead of 638 and 45 (1700 instructions
+// instead of 1220; round 6, measured with hipcc -S on a four-line loop: tools/README.md "pt_identity").  Every commitment / opening kernel starts its sums this way.
+LHD pt29 pt_identity() {
+  pt29 p; p.X = fe_zero(); p.Y = fe_one(); p.T = fe_zero(); p.Z = fe_zero();
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(LASSO_VISIBLE_IDENTITY)
+  fe29* c = reinterpret_cast<fe29*>(&p);
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int k = 0; k < 9; k++) asm volatile("" : "+v"(c[i].v[k]));
+#endif
+  return p;
+}
 LHD fe29 fe_d2() { return fe_zero(); }   // the Edwards build passes 2d to pt_add; nothing to pass here
 LHD fe29 fe_x3(const fe29& a) { return fe_weak(fe_add(fe_add(a, a), a)); }   // reduced -> reduced
 // shared tail of the complete formulas:  X3 = t3 t1 - t4 y3,  Y3 = t1 z3 + y3 t0,  Z3 = z3 t4 + t0 t3

@@ -154,7 +154,21 @@ struct pt29 { fe29 X, Y, T, Z; };            // extended coordinates, all reduce
 #endif
 struct alignas(MSM_NIELS_ALIGN) niels29 { fe29 ypx, ymx, t2d; int32_t pad; };   // 108 bytes of payload: 7 x dwordx4
 
-LHD pt29 pt_identity() { pt29 p; p.X = fe_zero(); p.Y = fe_one(); p.T = fe_zero(); p.Z = fe_one(); return p; }
+// The identity as a starting value of an accumulation loop.  On the device its limbs are made OPAQUE to the optimizer (an empty asm per limb): with the constants visible,
+// hipcc (ROCm 7.2) derives value ranges for the loop-carried limbs of `B = pt_identity(); for (..) B = pt_madd(B, entry)` under which the 32 x 32 -> 64 products of
+// fe_mul no longer match v_mad_i64_i32 and are expanded into 64 x 32 multiplies: 782 multiply-adds and 365 moves per mixed addition instead of 638 and 45 (1700 instructions
+// instead of 1220; round 6, measured with hipcc -S on a four-line loop: tools/README.md "pt_identity").  Every commitment / opening kernel starts its sums this way.
+LHD pt29 pt_identity() {
+  pt29 p; p.X = fe_zero(); p.Y = fe_one(); p.T = fe_zero(); p.Z = fe_one();
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(LASSO_VISIBLE_IDENTITY)
+  fe29* c = reinterpret_cast<fe29*>(&p);
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int k = 0; k < 9; k++) asm volatile("" : "+v"(c[i].v[k]));
+#endif
+  return p;
+}
 LHD fe29 fe_d2() {   // 2d mod p
   fe29 r; r.v[0] = 112390489; r.v[1] = 515169441; r.v[2] = 15488442; r.v[3] = 2700549; r.v[4] = 487784462; r.v[5] = 7960441; r.v[6] = 329016890; r.v[7] = 462085119; r.v[8] = 2361049; return r;
 }

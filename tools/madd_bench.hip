@@ -3,6 +3,7 @@
 // Section A: a chain of pt_madd with the table entry in registers, compiled for 1 / 2 / 3 / 4 waves per SIMD (VGPR budgets 512 / 256 / 168 / 128), run at that occupancy and below.
 // Section B: field products alone (fe_mul chains) at the same occupancies — the issue rate of the product's instruction mix.
 // Section C: the commitment kernels themselves (k_msm_rows8w / k_msm_rows8) on random one-byte scalars at the headline's E shape (4096 x 4096) and at configs[2]'s.
+// Section D: the one-wave-per-row commitment with the table fetches made cheap (does the Infinity Cache bound it, or the instruction stream?).
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DLASSO_BN254] -o tools/madd_bench tools/madd_bench.hip     Run: tools/madd_bench [sections, e.g. A,B,C]
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -18,6 +19,13 @@ template <int MINW>
 __global__ void __launch_bounds__(256, MINW) k_chain_madd(pt29* io, const niels29* nb, int iters) {
   pt29 p = io[threadIdx.x & 63]; const niels29 n0 = nb[threadIdx.x & 63];
   for (int i = 0; i < iters; i++) p = pt_madd(p, n0);
+  if (p.X.v[0] == 0x12345678 && p.Y.v[1] == 0x1abcdef0) io[blockIdx.x] = p;
+}
+// the same chain with a FRESH table entry per addition (64 entries, L1-resident, next entry in flight during the addition): what a commitment kernel's loop looks like to the compiler
+template <int MINW>
+__global__ void __launch_bounds__(256, MINW) k_chain_madd_var(pt29* io, const niels29* nb, int iters) {
+  pt29 p = io[threadIdx.x & 63]; niels29 cur = nb[threadIdx.x & 63];
+  for (int i = 0; i < iters; i++) { const niels29 nxt = nb[(threadIdx.x + 7 * i + 7) & 63]; p = pt_madd(p, cur); cur = nxt; }
   if (p.X.v[0] == 0x12345678 && p.Y.v[1] == 0x1abcdef0) io[blockIdx.x] = p;
 }
 template <int MINW>
@@ -71,6 +79,11 @@ int main(int argc, char** argv) {
       printf("  compiled for %d waves/SIMD, run at %d: %8.3f ms  %7.2f G madd/s   (%.2f us per wave-addition per SIMD)\n", MINW, wpc, ms, g, ms * 1e3 / iters / wpc); \
       if (g > best_madd) { best_madd = g; best_cfg[0] = MINW; best_cfg[1] = wpc; } }
     RUN_A(1) RUN_A(2) RUN_A(3) RUN_A(4)
+    printf("   -- the same with a fresh (L1-resident) table entry per addition:\n");
+#define RUN_AV(MINW) for (int wpc = 1; wpc <= MINW; wpc++) { const int blocks = CU * wpc; \
+      const double ms = time_kernel([&] { hipLaunchKernelGGL((k_chain_madd_var<MINW>), dim3(blocks), dim3(256), 0, 0, (pt29*)d, (const niels29*)d2, iters); }); \
+      printf("  fresh entry, compiled for %d waves/SIMD, run at %d: %8.3f ms  %7.2f G madd/s\n", MINW, wpc, ms, (double)blocks * 256 * iters / (ms * 1e-3) * 1e-9); }
+    RUN_AV(1) RUN_AV(2) RUN_AV(3)
     printf("MADD_CEILING {\"curve\": \"%s\", \"G_madd_per_s\": %.2f, \"compiled_for_waves_per_simd\": %d, \"run_at_waves_per_simd\": %d, \"device\": \"%s\", \"CUs\": %d}\n", curve, best_madd, best_cfg[0], best_cfg[1], prop.name, CU);
   }
   if (want(argc, argv, 'B')) {
@@ -106,6 +119,22 @@ int main(int argc, char** argv) {
       printf("  %-44s %5zu x %5zu: k_msm_rows8w %8.3f ms %6.2f G/s (one row per wave %8.3f ms %6.2f G/s) | k_msm_rows8 %8.3f ms %6.2f G/s\n", sh.what, sh.rows, sh.cols, msw, msw > 0 ? nz / (msw * 1e-3) * 1e-9 : 0.0,
              msw1, msw1 > 0 ? nz / (msw1 * 1e-3) * 1e-9 : 0.0, ms8, nz / (ms8 * 1e-3) * 1e-9);
       CK(hipFree(d_tab)); CK(hipFree(d_sc)); CK(hipFree(d_out));
+    }
+  }
+  if (want(argc, argv, 'D')) {
+    printf("\n== D. k_msm_rows8w at the headline's E shape with the table fetches made cheap: every scalar the SAME byte (one 512 KB run of the table, L2-resident) against random bytes (134 MB, Infinity Cache)\n");
+    const size_t rows = 4096, cols = 4096, n = cols;
+    std::vector<uint32_t> tab((size_t)MSM8_MULTS * n * (sizeof(niels29) / 4));
+    for (auto& x : tab) x = (uint32_t)splitmix() & 0x0fffffff;
+    niels29* d_tab; CK(hipMalloc(&d_tab, tab.size() * 4)); CK(hipMemcpy(d_tab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+    uint32_t* d_sc; CK(hipMalloc(&d_sc, rows * cols * 4));
+    pt29* d_out; CK(hipMalloc(&d_out, rows * sizeof(pt29)));
+    for (int mode = 0; mode < 3; mode++) {
+      std::vector<uint32_t> sc(rows * cols);
+      for (auto& x : sc) x = mode == 0 ? ((uint32_t)splitmix() % 255u) + 1u : (mode == 1 ? 7u : ((uint32_t)splitmix() % 8u) + 1u);
+      CK(hipMemcpy(d_sc, sc.data(), sc.size() * 4, hipMemcpyHostToDevice));
+      const double ms = time_kernel([&] { hipLaunchKernelGGL(k_msm_rows8w, dim3((unsigned)(rows / 4)), dim3(MSM_THREADS), 0, 0, (const uint32_t*)d_sc, cols, (uint32_t)cols, 1u, (const niels29*)d_tab, (const niels29*)d_tab, n, d_out, (uint32_t)rows, (uint32_t*)nullptr, 1u); }, 5);
+      printf("  %-62s %8.3f ms  %6.2f G additions/s\n", mode == 0 ? "random non-zero bytes (255 x 4096 entries = 134 MB)" : (mode == 1 ? "every byte = 7 (4096 entries = 512 KB)" : "bytes 1..8 (8 x 4096 entries = 4 MB)"), ms, (double)rows * cols / (ms * 1e-3) * 1e-9);
     }
   }
   return 0;
