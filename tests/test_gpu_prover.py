@@ -137,7 +137,8 @@ def test_gpu_soak_alternating_shapes_on_one_prover(host):
         comm = host.commit(dense, gens)
         inst.append((S, s_, r, gens, dense, comm, host.prove(dense, gens, S, r)))
     try:
-        for it in range(240):
+        import os
+        for it in range(int(os.environ.get("LASSO_SOAK_ITERS", "240"))):   # LASSO_SOAK_ITERS=20000: the long form (profiles/r06_soak.txt)
             S, s_, r, gens, dense, comm, first = inst[(it * 7 + it // 4) % len(inst)]
             if it % 3 == 0:
                 assert host.commit(dense, gens) == comm, f"commitment {it} differs"
